@@ -1,0 +1,446 @@
+// Per-point and per-cloud arithmetic of the differentiable-ICP iteration.
+//
+// Everything here is plain inline C++ templated on the scalar type, included by
+// the HIP kernels (dicp_kernels.hip) — and by tests/hostcheck/hostcheck.cpp, a
+// TEST-ONLY g++ build that checks these formulas against autograd on a CPU box
+// with no GPU.  The product never runs the host instantiation.
+//
+// Reference semantics (file:line under /root/reference/dICP):
+//   transform            ICP.py:137          residuals  ICP.py:143-149
+//   trim weight          loss.py:43-58       huber      loss.py:21-32   cauchy loss.py:34-41
+//   weight combine       ICP.py:162-169,194-196
+//   Jacobian             ICP.py:171-190,513-531
+//   normal equations     ICP.py:198-201      pose update ICP.py:209-217
+// Backward: closed-form adjoint of the above (the reference uses stock autograd).
+#pragma once
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define DICP_HD __host__ __device__ __forceinline__
+#else
+#define DICP_HD inline
+#endif
+
+namespace dicp {
+
+enum Mode { MODE_PT2PT = 0, MODE_PT2PL = 1 };
+enum Loss { LOSS_NONE = 0, LOSS_HUBER = 1, LOSS_CAUCHY = 2 };
+
+// Accumulator slots produced per cloud and iteration.
+//   [0,21)  upper triangle of the 6x6  A = sum u J^T J   (row-major, i<=j)
+//   [21,27) b = sum u J^T e
+//   27 cost = sum u e^2      28 sum of w      29 #(w > match_thresh) (x3 for pt2pt rows)
+constexpr int ACC_A = 0, ACC_B = 21, ACC_COST = 27, ACC_SUMW = 28, ACC_NMATCH = 29, NACC = 30;
+constexpr int NACC_PAD = 32;
+// Backward per-cloud slots: C-bar (9, row-major) then r-bar (3).
+constexpr int NBWD = 12, NBWD_PAD = 16;
+
+struct WeightParams {
+    int mode;          // Mode
+    int trim_on;       // trim_dist is not None and >= 0          (ICP.py:153)
+    int differentiable;
+    int loss;          // Loss
+    double trim_dist;  // tau
+    double tanh_k;     // tanh_steepness
+    double loss_delta; // loss_fn["metric"]
+    double match_thresh;
+};
+
+DICP_HD int tri(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }   // i <= j
+
+DICP_HD float  m_sqrt(float x)  { return sqrtf(x); }
+DICP_HD double m_sqrt(double x) { return sqrt(x); }
+DICP_HD float  m_tanh(float x)  { return tanhf(x); }
+DICP_HD double m_tanh(double x) { return tanh(x); }
+DICP_HD float  m_abs(float x)   { return fabsf(x); }
+DICP_HD double m_abs(double x)  { return fabs(x); }
+
+template <typename T> DICP_HD void cross3(const T* a, const T* b, T* o) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+template <typename T> DICP_HD T dot3(const T* a, const T* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+template <typename T> DICP_HD void matvec3(const T* C, const T* p, T* o) {
+    o[0] = C[0] * p[0] + C[1] * p[1] + C[2] * p[2];
+    o[1] = C[3] * p[0] + C[4] * p[1] + C[5] * p[2];
+    o[2] = C[6] * p[0] + C[7] * p[1] + C[8] * p[2];
+}
+
+// ---------------------------------------------------------------- per-point state
+template <typename T> struct PointState {
+    T q[3];      // C p
+    T e3[3];     // C p + r - y
+    T d3;        // ||e3||
+    T e;         // pt2pl: n . e3
+    T en;        // norm the robust loss sees (|e| or d3)
+    T tw, lw;    // trim and loss weights
+    T th;        // tanh(...) of the soft trim gate
+    T w, root, ws, u;   // w, sqrt(w+1e-10), root-1e-5, ws^2
+};
+
+template <typename T, int MODE>
+DICP_HD void point_weights(const WeightParams& P, const T* C, const T* r, const T* p, const T* y,
+                           const T* nrm, T w0, PointState<T>& s) {
+    matvec3(C, p, s.q);
+    s.e3[0] = s.q[0] + r[0] - y[0];
+    s.e3[1] = s.q[1] + r[1] - y[1];
+    s.e3[2] = s.q[2] + r[2] - y[2];
+    s.d3 = m_sqrt(dot3(s.e3, s.e3));
+    if (MODE == MODE_PT2PL) { s.e = dot3(s.e3, nrm); s.en = m_abs(s.e); }
+    else                    { s.e = T(0);            s.en = s.d3; }
+    s.tw = T(1); s.th = T(0);
+    if (P.trim_on) {
+        if (P.differentiable) {                                            // loss.py:54
+            s.th = m_tanh(T(P.tanh_k) * (T(P.trim_dist) - s.d3) - T(3));
+            s.tw = T(0.5) * s.th + T(0.5);
+        } else {                                                           // loss.py:58
+            s.tw = (s.d3 < T(P.trim_dist)) ? T(1) : T(0);
+        }
+    }
+    s.lw = T(1);
+    const T dl = T(P.loss_delta);
+    if (P.loss == LOSS_HUBER) {
+        if (P.differentiable) s.lw = (dl * dl) / (dl * dl + s.en * s.en);  // loss.py:30
+        else                  s.lw = (s.en > dl) ? dl / s.en : T(1);       // loss.py:32
+    } else if (P.loss == LOSS_CAUCHY) {                                    // loss.py:41
+        const T t = s.en / dl;
+        s.lw = T(1) / (T(1) + t * t);
+    }
+    s.w = w0 * s.tw * s.lw;                                                // ICP.py:169
+    s.root = m_sqrt(s.w + T(1.0e-10));                                     // ICP.py:194
+    s.ws = s.root - T(1.0e-5);
+    s.u = s.ws * s.ws;
+}
+
+// Forward: add this point's contribution to acc[NACC]; returns w through s.w.
+template <typename T, int MODE>
+DICP_HD void point_forward(const WeightParams& P, const T* C, const T* r, const T* p, const T* y,
+                           const T* nrm, T w0, T* acc, PointState<T>& s) {
+    point_weights<T, MODE>(P, C, r, p, y, nrm, w0, s);
+    const T u = s.u;
+    if (MODE == MODE_PT2PL) {
+        T j[6];
+        cross3(nrm, s.q, j);                       // (q^)^T n = n x q        ICP.py:175
+        j[3] = -nrm[0]; j[4] = -nrm[1]; j[5] = -nrm[2];                    // ICP.py:176
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const T uj = u * j[a];
+#pragma unroll
+            for (int b = a; b < 6; ++b) acc[ACC_A + k++] += uj * j[b];
+            acc[ACC_B + a] += uj * s.e;
+        }
+        acc[ACC_COST] += u * s.e * s.e;
+    } else {
+        const T* q = s.q;
+        const T* e = s.e3;
+        const T qq = dot3(q, q);
+        // J = [q^, -I]: J^T J = [[|q|^2 I - q q^T, q^], [-q^, I]]        ICP.py:178-183
+        acc[ACC_A + 0]  += u * (qq - q[0] * q[0]);   // (0,0)
+        acc[ACC_A + 1]  += u * (-q[0] * q[1]);       // (0,1)
+        acc[ACC_A + 2]  += u * (-q[0] * q[2]);       // (0,2)
+        /* (0,3) = 0 */
+        acc[ACC_A + 4]  += u * (-q[2]);              // (0,4)
+        acc[ACC_A + 5]  += u * (q[1]);               // (0,5)
+        acc[ACC_A + 6]  += u * (qq - q[1] * q[1]);   // (1,1)
+        acc[ACC_A + 7]  += u * (-q[1] * q[2]);       // (1,2)
+        acc[ACC_A + 8]  += u * (q[2]);               // (1,3)
+        /* (1,4) = 0 */
+        acc[ACC_A + 10] += u * (-q[0]);              // (1,5)
+        acc[ACC_A + 11] += u * (qq - q[2] * q[2]);   // (2,2)
+        acc[ACC_A + 12] += u * (-q[1]);              // (2,3)
+        acc[ACC_A + 13] += u * (q[0]);               // (2,4)
+        /* (2,5) = 0 */
+        acc[ACC_A + 15] += u;                        // (3,3)
+        acc[ACC_A + 18] += u;                        // (4,4)
+        acc[ACC_A + 20] += u;                        // (5,5)
+        T exq[3];
+        cross3(e, q, exq);                           // (q^)^T e = e x q
+        acc[ACC_B + 0] += u * exq[0];
+        acc[ACC_B + 1] += u * exq[1];
+        acc[ACC_B + 2] += u * exq[2];
+        acc[ACC_B + 3] -= u * e[0];
+        acc[ACC_B + 4] -= u * e[1];
+        acc[ACC_B + 5] -= u * e[2];
+        acc[ACC_COST] += u * dot3(e, e);
+    }
+    const T rows = (MODE == MODE_PT2PT) ? T(3) : T(1);
+    acc[ACC_SUMW] += rows * s.w;
+    if (s.w > T(P.match_thresh)) acc[ACC_NMATCH] += rows;
+}
+
+// Backward for one point.  Gs = G_A + G_A^T (6x6 row-major, symmetric), gb = dL/db.
+// Outputs: gp (dL/dp), gy (dL/dy), gn (dL/dnormal, pt2pl only), gw0 (dL/dw0),
+// and adds q-bar p^T into gC[9] and s-bar into gr[3].
+template <typename T, int MODE>
+DICP_HD void point_backward(const WeightParams& P, const T* C, const T* r, const T* p, const T* y,
+                            const T* nrm, T w0, const T* Gs, const T* gb,
+                            T* gp, T* gy, T* gn, T& gw0, T* gC, T* gr) {
+    PointState<T> s;
+    point_weights<T, MODE>(P, C, r, p, y, nrm, w0, s);
+    const T u = s.u;
+    T ubar, qbar[3], e3bar[3] = {T(0), T(0), T(0)};
+    T ebar_s = T(0);            // pt2pl scalar e-bar
+    T ja[3] = {T(0), T(0), T(0)}, jc[3] = {T(0), T(0), T(0)};   // pt2pl J-bar halves
+    T j[6];
+    if (MODE == MODE_PT2PL) {
+        cross3(nrm, s.q, j);
+        j[3] = -nrm[0]; j[4] = -nrm[1]; j[5] = -nrm[2];
+        T Gj[6];
+        T jGj = T(0), jgb = T(0);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            T acc = T(0);
+#pragma unroll
+            for (int b = 0; b < 6; ++b) acc += Gs[a * 6 + b] * j[b];
+            Gj[a] = acc;
+            jGj += j[a] * acc;
+            jgb += j[a] * gb[a];
+        }
+        ubar = T(0.5) * jGj + s.e * jgb;
+        ebar_s = u * jgb;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            ja[a] = u * (Gj[a] + s.e * gb[a]);
+            jc[a] = u * (Gj[a + 3] + s.e * gb[a + 3]);
+        }
+    } else {
+        const T* q = s.q;
+        const T* e = s.e3;
+        // Pm = Q G11 - G21, Rm = Q G12 - G22 with Q = q^ ; column c of Q G = q x G[:,c]
+        T Pm[9], Rm[9];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            T g1[3] = {Gs[0 * 6 + c], Gs[1 * 6 + c], Gs[2 * 6 + c]};
+            T g2[3] = {Gs[0 * 6 + 3 + c], Gs[1 * 6 + 3 + c], Gs[2 * 6 + 3 + c]};
+            T x1[3], x2[3];
+            cross3(q, g1, x1);
+            cross3(q, g2, x2);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                Pm[i * 3 + c] = x1[i] - Gs[(3 + i) * 6 + c];
+                Rm[i * 3 + c] = x2[i] - Gs[(3 + i) * 6 + 3 + c];
+            }
+        }
+        // rows of Q
+        const T Q[9] = {T(0), -q[2], q[1], q[2], T(0), -q[0], -q[1], q[0], T(0)};
+        T tr = T(0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) tr += Pm[i * 3 + c] * Q[i * 3 + c];
+            tr -= Rm[i * 3 + i];
+        }
+        T Jgb[3], qxg[3];
+        cross3(q, gb, qxg);
+        Jgb[0] = qxg[0] - gb[3]; Jgb[1] = qxg[1] - gb[4]; Jgb[2] = qxg[2] - gb[5];
+        ubar = T(0.5) * tr + dot3(e, Jgb);
+        // M = u (Pm + e gb1^T); q-bar from the skew structure of Q
+        T M[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) M[i * 3 + c] = u * (Pm[i * 3 + c] + e[i] * gb[c]);
+        qbar[0] = M[7] - M[5];
+        qbar[1] = M[2] - M[6];
+        qbar[2] = M[3] - M[1];
+        e3bar[0] = u * Jgb[0]; e3bar[1] = u * Jgb[1]; e3bar[2] = u * Jgb[2];
+    }
+    // u = (sqrt(w+1e-10) - 1e-5)^2
+    const T wbar = ubar * s.ws / s.root;
+    gw0 = wbar * s.tw * s.lw;
+    const T twbar = wbar * w0 * s.lw;
+    const T lwbar = wbar * w0 * s.tw;
+    // robust loss -> error
+    const T dl = T(P.loss_delta);
+    T dlw_den = T(0);     // d lw / d en
+    if (P.loss == LOSS_HUBER) {
+        if (P.differentiable) dlw_den = -T(2) * s.en * s.lw * s.lw / (dl * dl);
+        else                  dlw_den = (s.en > dl) ? -dl / (s.en * s.en) : T(0);
+    } else if (P.loss == LOSS_CAUCHY) {
+        dlw_den = -T(2) * s.en * s.lw * s.lw / (dl * dl);
+    }
+    if (MODE == MODE_PT2PL) {
+        // en = |e| ; torch's norm backward gives e/|e| (0 at e == 0)
+        const T sgn = (s.e > T(0)) ? T(1) : ((s.e < T(0)) ? T(-1) : T(0));
+        ebar_s += lwbar * dlw_den * sgn;
+    } else if (s.d3 > T(0)) {
+        const T f = lwbar * dlw_den / s.d3;
+        e3bar[0] += f * s.e3[0]; e3bar[1] += f * s.e3[1]; e3bar[2] += f * s.e3[2];
+    }
+    // soft trim gate -> e3 (hard gate has no gradient)
+    if (P.trim_on && P.differentiable && s.d3 > T(0)) {
+        const T f = twbar * (-T(0.5) * T(P.tanh_k) * (T(1) - s.th * s.th)) / s.d3;
+        e3bar[0] += f * s.e3[0]; e3bar[1] += f * s.e3[1]; e3bar[2] += f * s.e3[2];
+    }
+    if (MODE == MODE_PT2PL) {
+        e3bar[0] += ebar_s * nrm[0]; e3bar[1] += ebar_s * nrm[1]; e3bar[2] += ebar_s * nrm[2];
+        T qxa[3];
+        cross3(s.q, ja, qxa);
+        gn[0] = ebar_s * s.e3[0] + qxa[0] - jc[0];
+        gn[1] = ebar_s * s.e3[1] + qxa[1] - jc[1];
+        gn[2] = ebar_s * s.e3[2] + qxa[2] - jc[2];
+        cross3(ja, nrm, qbar);
+    } else {
+        gn[0] = gn[1] = gn[2] = T(0);
+    }
+    gy[0] = -e3bar[0]; gy[1] = -e3bar[1]; gy[2] = -e3bar[2];
+    qbar[0] += e3bar[0]; qbar[1] += e3bar[1]; qbar[2] += e3bar[2];
+    gr[0] += e3bar[0]; gr[1] += e3bar[1]; gr[2] += e3bar[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gC[i * 3 + c] += qbar[i] * p[c];
+    gp[0] = C[0] * qbar[0] + C[3] * qbar[1] + C[6] * qbar[2];
+    gp[1] = C[1] * qbar[0] + C[4] * qbar[1] + C[7] * qbar[2];
+    gp[2] = C[2] * qbar[0] + C[5] * qbar[1] + C[8] * qbar[2];
+}
+
+// ------------------------------------------------------------------ per-cloud step
+// All in double regardless of the cloud dtype (36 numbers per cloud).
+
+// Solve the d x d system M x = rhs (M row-major, leading dim 6) by Gaussian
+// elimination with partial pivoting (what LAPACK getrf does under torch.linalg.inv,
+// ICP.py:201).  M and rhs are destroyed.  Returns false if a pivot is exactly zero.
+DICP_HD bool solve_small(double* M, double* rhs, double* x, int d) {
+    for (int k = 0; k < d; ++k) {
+        int piv = k;
+        double best = fabs(M[k * 6 + k]);
+        for (int i = k + 1; i < d; ++i) {
+            const double v = fabs(M[i * 6 + k]);
+            if (v > best) { best = v; piv = i; }
+        }
+        if (best == 0.0) return false;
+        if (piv != k) {
+            for (int c = k; c < d; ++c) { const double t = M[k * 6 + c]; M[k * 6 + c] = M[piv * 6 + c]; M[piv * 6 + c] = t; }
+            const double t = rhs[k]; rhs[k] = rhs[piv]; rhs[piv] = t;
+        }
+        const double inv = 1.0 / M[k * 6 + k];
+        for (int i = k + 1; i < d; ++i) {
+            const double f = M[i * 6 + k] * inv;
+            if (f != 0.0) {
+                for (int c = k + 1; c < d; ++c) M[i * 6 + c] -= f * M[k * 6 + c];
+                rhs[i] -= f * rhs[k];
+            }
+        }
+    }
+    for (int i = d - 1; i >= 0; --i) {
+        double v = rhs[i];
+        for (int c = i + 1; c < d; ++c) v -= M[i * 6 + c] * x[c];
+        x[i] = v / M[i * 6 + i];
+    }
+    return true;
+}
+
+// Rodrigues coefficients: exp(phi^) = I + a K + b K^2, J_l = a I + c phi phi^T + b K.
+DICP_HD void so3_coeffs(const double* phi, double& a, double& b, double& c) {
+    const double t2 = phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2];
+    if (t2 < 1e-8) {
+        a = 1.0 - t2 / 6.0 + t2 * t2 / 120.0;
+        b = 0.5 - t2 / 24.0 + t2 * t2 / 720.0;
+        c = 1.0 / 6.0 - t2 / 120.0 + t2 * t2 / 5040.0;
+    } else {
+        const double t = sqrt(t2);
+        a = sin(t) / t;
+        b = (1.0 - cos(t)) / t2;
+        c = (1.0 - a) / t2;
+    }
+}
+
+DICP_HD void so3_exp(const double* phi, double* R) {
+    double a, b, c;
+    so3_coeffs(phi, a, b, c);
+    const double x = phi[0], y = phi[1], z = phi[2];
+    // K^2 = phi phi^T - |phi|^2 I
+    const double t2 = x * x + y * y + z * z;
+    R[0] = 1.0 + b * (x * x - t2); R[1] = -a * z + b * x * y;     R[2] = a * y + b * x * z;
+    R[3] = a * z + b * x * y;      R[4] = 1.0 + b * (y * y - t2); R[5] = -a * x + b * y * z;
+    R[6] = -a * y + b * x * z;     R[7] = a * x + b * y * z;      R[8] = 1.0 + b * (z * z - t2);
+}
+
+// Expand the 21-slot upper triangle into a full symmetric 6x6.
+template <typename T> DICP_HD void unpack_sym6(const T* tri21, double* A) {
+    int k = 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 6; ++j) { A[i * 6 + j] = A[j * 6 + i] = (double)tri21[k++]; }
+}
+
+// Map between the d-dim unknowns and the 6-vector: dim==2 optimises (rot-z, tx, ty) = slots 2,3,4
+// (ICP.py:186-189, 203-207).
+DICP_HD int slot(int dim, int i) { return dim == 2 ? i + 2 : i; }
+DICP_HD int ndof(int dim) { return dim == 2 ? 3 : 6; }
+
+// Forward step.  A6 (full 6x6, without the regulariser), b6 -> delta6, and the new pose.
+// Areg receives the d x d matrix actually inverted (leading dim 6), kept for backward.
+DICP_HD void step_forward(const double* A6, const double* b6, int dim, const double* C, const double* r,
+                          double* delta6, double* Cn, double* rn, double* Areg) {
+    const int d = ndof(dim);
+    double M[36], rhs[6], x[6];
+    for (int i = 0; i < d; ++i) {
+        for (int j = 0; j < d; ++j) M[i * 6 + j] = A6[slot(dim, i) * 6 + slot(dim, j)];
+        M[i * 6 + i] += 1e-12;                                      // ICP.py:200
+        rhs[i] = b6[slot(dim, i)];
+    }
+    for (int i = 0; i < 36; ++i) Areg[i] = 0.0;
+    for (int i = 0; i < d; ++i) for (int j = 0; j < d; ++j) Areg[i * 6 + j] = M[i * 6 + j];
+    for (int i = 0; i < 6; ++i) delta6[i] = 0.0;
+    if (solve_small(M, rhs, x, d))
+        for (int i = 0; i < d; ++i) delta6[slot(dim, i)] = -x[i];    // ICP.py:201
+    double R[9];
+    so3_exp(delta6, R);                                              // ICP.py:210
+    for (int i = 0; i < 3; ++i)                                      // C <- R^T C   ICP.py:214
+        for (int j = 0; j < 3; ++j)
+            Cn[i * 3 + j] = R[0 * 3 + i] * C[0 * 3 + j] + R[1 * 3 + i] * C[1 * 3 + j] + R[2 * 3 + i] * C[2 * 3 + j];
+    for (int i = 0; i < 3; ++i) rn[i] = r[i] - delta6[3 + i];        // ICP.py:216
+}
+
+// Backward step.  In: gCn, grn (cotangents of the new pose), saved C, delta6, Areg.
+// Out: Gs = G_A + G_A^T (6x6), gb (6), gC, gr (cotangents of the old pose).
+DICP_HD void step_backward(const double* gCn, const double* grn, int dim, const double* C,
+                           const double* delta6, const double* Areg,
+                           double* Gs, double* gb, double* gC, double* gr) {
+    const int d = ndof(dim);
+    double R[9];
+    so3_exp(delta6, R);
+    // C_new = R^T C  ->  gC = R gCn ,  gR = C gCn^T
+    double gR[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            gC[i * 3 + j] = R[i * 3 + 0] * gCn[0 * 3 + j] + R[i * 3 + 1] * gCn[1 * 3 + j] + R[i * 3 + 2] * gCn[2 * 3 + j];
+            gR[i * 3 + j] = C[i * 3 + 0] * gCn[j * 3 + 0] + C[i * 3 + 1] * gCn[j * 3 + 1] + C[i * 3 + 2] * gCn[j * 3 + 2];
+        }
+    for (int i = 0; i < 3; ++i) gr[i] = grn[i];
+    // dR = (J_l dphi)^ R  ->  gphi = J_l^T vee(M - M^T), M = gR R^T
+    double M[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            M[i * 3 + j] = gR[i * 3 + 0] * R[j * 3 + 0] + gR[i * 3 + 1] * R[j * 3 + 1] + gR[i * 3 + 2] * R[j * 3 + 2];
+    const double v[3] = {M[7] - M[5], M[2] - M[6], M[3] - M[1]};
+    double a, b, c;
+    so3_coeffs(delta6, a, b, c);
+    const double* phi = delta6;
+    const double pv = phi[0] * v[0] + phi[1] * v[1] + phi[2] * v[2];
+    double pxv[3];
+    cross3(phi, v, pxv);
+    double gd[6];
+    for (int i = 0; i < 3; ++i) gd[i] = a * v[i] + c * phi[i] * pv - b * pxv[i];
+    for (int i = 0; i < 3; ++i) gd[3 + i] = -grn[i];
+    // delta = -Areg^{-1} b  ->  g = Areg^{-1} gdelta ; gb = -g ; G_A = -g delta^T
+    double Mx[36], rhs[6], g[6];
+    for (int i = 0; i < 36; ++i) Mx[i] = Areg[i];
+    for (int i = 0; i < d; ++i) rhs[i] = gd[slot(dim, i)];
+    for (int i = 0; i < 36; ++i) Gs[i] = 0.0;
+    for (int i = 0; i < 6; ++i) gb[i] = 0.0;
+    if (!solve_small(Mx, rhs, g, d)) return;
+    for (int i = 0; i < d; ++i) {
+        const int si = slot(dim, i);
+        gb[si] = -g[i];
+        for (int j = 0; j < d; ++j) {
+            const int sj = slot(dim, j);
+            Gs[si * 6 + sj] = -(g[i] * delta6[sj] + delta6[si] * g[j]);
+        }
+    }
+}
+
+}  // namespace dicp

@@ -1,0 +1,146 @@
+"""CPU check of the closed-form arithmetic the HIP kernels execute.
+
+``dicp_amd/csrc/dicp_math.h`` is compiled here with g++ (tests/hostcheck/, a TEST-ONLY
+build) and driven through the same forward / reverse loop structure as the product;
+results are held to the oracle's forward values and to its *autograd* gradients on the
+reference-generated ``matrix3d`` scenarios.  This validates the backward formulas of
+SURVEY.md section 8(a-11) without a GPU.
+"""
+import ctypes
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+import scipy.linalg
+import torch
+
+from oracle import dicp_oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "hostcheck", "hostcheck.cpp")
+LIB = os.path.join(HERE, "hostcheck", "libhostcheck.so")
+
+pytestmark = pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
+
+
+class WeightParams(ctypes.Structure):
+    _fields_ = [("mode", ctypes.c_int), ("trim_on", ctypes.c_int), ("differentiable", ctypes.c_int),
+                ("loss", ctypes.c_int), ("trim_dist", ctypes.c_double), ("tanh_k", ctypes.c_double),
+                ("loss_delta", ctypes.c_double), ("match_thresh", ctypes.c_double)]
+
+
+@pytest.fixture(scope="module")
+def hc():
+    hdr = os.path.join(HERE, "..", "dicp_amd", "csrc", "dicp_math.h")
+    if (not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(SRC), os.path.getmtime(hdr))):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wno-unknown-pragmas", "-o", LIB, SRC])
+    lib = ctypes.CDLL(LIB)
+    assert lib.hc_sizeof_params() == ctypes.sizeof(WeightParams)
+    return lib
+
+
+def ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def run_chain(hc, src, tgt, w0, T0, P, K, dim, gT, gpc):
+    """Forward K iterations + reverse sweep for ONE cloud using the hostcheck math."""
+    n, c = src.shape[0], tgt.shape[1]
+    mask_s = np.array([1, 1, 0.0]) if dim == 2 else np.ones(3)
+    mask_t = (np.array([1, 1, 0, 1, 1, 0.0]) if dim == 2 else np.ones(6))[:c]
+    s = np.ascontiguousarray(src * mask_s)
+    t = np.ascontiguousarray(tgt * mask_t)
+    C = np.ascontiguousarray(T0[:3, :3]).copy()
+    r = np.ascontiguousarray(T0[:3, 3]).copy()
+    saved = []
+    for _ in range(K):
+        pt = s @ C.T + r
+        idx = O.nn_index(torch.tensor(pt)[None], torch.tensor(t)[None])[0].numpy().astype(np.int32)
+        acc = np.zeros(30)
+        w = np.zeros(n)
+        hc.hc_forward_f64(ctypes.byref(P), n, c, ptr(s), ptr(t), ptr(idx), ptr(C), ptr(r), ptr(w0), ptr(acc), ptr(w))
+        d6, Cn, rn, Areg = np.zeros(6), np.zeros(9), np.zeros(3), np.zeros(36)
+        hc.hc_step_forward(ptr(acc), dim, ptr(C), ptr(r), ptr(d6), ptr(Cn), ptr(rn), ptr(Areg))
+        saved.append((idx, C.copy(), r.copy(), d6, Areg, acc, w))
+        C, r = Cn.reshape(3, 3).copy(), rn.copy()
+    T = np.eye(4)
+    T[:3, :3], T[:3, 3] = C, r
+    # reverse sweep: pc = s C^T + r and T both carry cotangents
+    gC = gT[:3, :3] + gpc.T @ s
+    gr = gT[:3, 3] + gpc.sum(0)
+    gs = gpc @ C
+    gt = np.zeros_like(t)
+    gw = np.zeros(n)
+    for idx, Ck, rk, d6, Areg, acc, w in reversed(saved):
+        Gs, gb, gCo, gro = np.zeros(36), np.zeros(6), np.zeros(9), np.zeros(3)
+        hc.hc_step_backward(ptr(np.ascontiguousarray(gC)), ptr(np.ascontiguousarray(gr)), dim, ptr(Ck), ptr(d6), ptr(Areg),
+                            ptr(Gs), ptr(gb), ptr(gCo), ptr(gro))
+        hc.hc_backward_f64(ctypes.byref(P), n, c, ptr(s), ptr(t), ptr(idx), ptr(Ck), ptr(rk), ptr(w0), ptr(Gs), ptr(gb),
+                           ptr(gs), ptr(gt), ptr(gw), ptr(gCo), ptr(gro))
+        gC, gr = gCo.reshape(3, 3), gro
+    gT0 = np.zeros((4, 4))
+    gT0[:3, :3], gT0[:3, 3] = gC, gr
+    return T, saved, gs * mask_s, gt * mask_t, gw, gT0
+
+
+def test_matrix3d_forward_and_backward(hc, golden):
+    g = golden("matrix3d")
+    K = int(g["K"])
+    keys = sorted(k[:-len("__T")] for k in g if k.endswith("__T"))
+    for key in keys:
+        icp_type, mode, lname, trim, d = key.split("_")
+        dim = int(d[1])
+        P = WeightParams(mode=1 if icp_type == "pt2pl" else 0, trim_on=int(trim == "trim"),
+                         differentiable=int(mode == "diff"),
+                         loss={"none": 0, "huber": 1, "cauchy": 2}[lname],
+                         trim_dist=1.5, tanh_k=5.0, loss_delta=0.3, match_thresh=0.0)
+        tgt_all = g["target"] if icp_type == "pt2pl" else np.ascontiguousarray(g["target"][:, :, :3])
+        for b in range(g["source"].shape[0]):
+            T, saved, gs, gt, gw, gT0 = run_chain(hc, g["source"][b], tgt_all[b], np.ascontiguousarray(g["weight"][b]),
+                                                  g["T_init"][b], P, K, dim, g["gT"][b], g["gpc"][b])
+            np.testing.assert_allclose(T, g[key + "__T"][b], rtol=0, atol=1e-11, err_msg=key)
+            deltas = np.stack([sv[3] for sv in saved])
+            np.testing.assert_allclose(deltas, g[key + "__deltas"][b, :, :, 0], rtol=0, atol=1e-11, err_msg=key)
+            costs = np.array([sv[5][27] for sv in saved])
+            np.testing.assert_allclose(costs, g[key + "__costs"][b, :, 0], rtol=1e-10, atol=1e-13, err_msg=key)
+            w_last = saved[-1][6]
+            want_w = g[key + "__w_last"][b]
+            np.testing.assert_allclose(w_last, want_w[::3] if icp_type == "pt2pt" else want_w, rtol=0, atol=1e-12)
+            np.testing.assert_allclose(gs, g[key + "__grad_source"][b], rtol=1e-8, atol=1e-10, err_msg=key + " src")
+            np.testing.assert_allclose(gt, g[key + "__grad_target"][b], rtol=1e-8, atol=1e-10, err_msg=key + " tgt")
+            np.testing.assert_allclose(gw, g[key + "__grad_weight"][b], rtol=1e-8, atol=1e-10, err_msg=key + " w")
+            np.testing.assert_allclose(gT0, g[key + "__grad_T_init"][b], rtol=1e-8, atol=1e-10, err_msg=key + " T0")
+
+
+def test_solver_and_exp_small_angles(hc):
+    """so3 series branch and the 3-dof sub-block path agree with numpy."""
+    rng = np.random.RandomState(0)
+    for dim in (2, 3):
+        for scale in (1e-7, 1e-3, 0.5):
+            J = rng.normal(size=(40, 6))
+            e = rng.normal(size=40) * scale
+            A = J.T @ J
+            b = J.T @ e
+            acc = np.zeros(30)
+            k = 0
+            for i in range(6):
+                for j in range(i, 6):
+                    acc[k] = A[i, j]
+                    k += 1
+            acc[21:27] = b
+            C = np.eye(3).ravel().copy()
+            r = np.zeros(3)
+            d6, Cn, rn, Areg = np.zeros(6), np.zeros(9), np.zeros(3), np.zeros(36)
+            hc.hc_step_forward(ptr(acc), dim, ptr(C), ptr(r), ptr(d6), ptr(Cn), ptr(rn), ptr(Areg))
+            sl = [2, 3, 4] if dim == 2 else list(range(6))
+            want = np.zeros(6)
+            want[sl] = -np.linalg.solve(A[np.ix_(sl, sl)] + 1e-12 * np.eye(len(sl)), b[sl])
+            np.testing.assert_allclose(d6, want, rtol=1e-9, atol=1e-15)
+            Kx = np.array([[0, -d6[2], d6[1]], [d6[2], 0, -d6[0]], [-d6[1], d6[0], 0]])
+            # closed-form Rodrigues is exact to rounding; torch.matrix_exp (what the reference calls,
+            # ICP.py:210) is itself only good to ~4e-12 here, so it gets the looser bound.
+            np.testing.assert_allclose(Cn.reshape(3, 3), scipy.linalg.expm(Kx).T, rtol=0, atol=2e-15)
+            np.testing.assert_allclose(Cn.reshape(3, 3), torch.matrix_exp(torch.tensor(Kx)).numpy().T, rtol=0, atol=1e-10)
+            np.testing.assert_allclose(rn, -d6[3:], rtol=0, atol=0)

@@ -1,0 +1,228 @@
+"""Host side of MI355X-native differentiable ICP: same call surface as the reference's
+``dICP.ICP.ICP`` (/root/reference/dICP/ICP.py:14-47), with the per-iteration loop
+(ICP.py:131-260) executed by libdicp_hip.so as one autograd node.
+
+    icp = ICP(icp_type='pt2pl', differentiable=True, max_iterations=100, tolerance=1e-12)
+    out = icp.icp(source, target, T_init, weight=None, trim_dist=5.0,
+                  loss_fn={"name": "huber", "metric": 1.0}, dim=3)
+    out["T"], out["pc"], out["deltas"], out["weights"], out["costs"], out["stats"]
+
+Input forms, result keys / shapes / dtypes, config keys and error behaviour follow the
+reference; citations are inline.  Inputs may live on the CPU (the reference's tests do):
+they are moved to the visible HIP device for the computation and the results are returned
+on the inputs' device.  Without a HIP device this class raises -- no CPU fallback exists.
+"""
+import os.path as osp
+
+import torch
+import yaml
+
+from . import _lib
+from ._ops import ICPLoop, LoopConfig, compute_device
+from .nn import nn
+
+
+class ICP:
+    def __init__(self, config_path=None, icp_type='pt2pl', max_iterations=100, tolerance=1e-12, differentiable=True):
+        # ICP.py:16-27 -- the YAML ships inside the package (the reference reads ../config/)
+        if config_path is None:
+            config_path = osp.join(osp.dirname(osp.abspath(__file__)), 'config', 'dICP_config.yaml')
+        with open(config_path, 'r') as f:
+            self.config = yaml.safe_load(f)
+
+        # ICP.py:30-38 -- plain mutable attributes (tests poke them: test_ICP_inputs.py:263)
+        prm, log, fun = (self.config['dICP'][k] for k in ('parameters', 'logging', 'functionality'))
+        self.icp_type = icp_type
+        self.max_iterations = max_iterations
+        self.tolerance = tolerance
+        self.const_iter = prm['const_iter']
+        self.verbose = log['verbose']
+        self.target_pad_val = prm['target_pad_val']
+        self.source_zeroes_are_pad = prm['source_zeroes_are_pad']
+        self.match_ratio_thresh = log['matched_ratio_thresh']
+        self.diff = differentiable
+        # ICP.py:40-44
+        self.nn = nn(self.diff, use_gumbel=fun['gumbel'], eps=fun['gumbel_eps'], tau=fun['gumbel_tau'])
+        # build-specific knob (not in the reference): which kNN kernel the loop uses
+        self.knn_variant = _lib.KNN_AUTO
+        self._timing_hook = None
+
+    def icp(self, source, target, T_init, weight=None, trim_dist=None, loss_fn=None, dim=3):
+        return self.dICP(source, target, T_init, weight, trim_dist, loss_fn, dim)      # ICP.py:46-47
+
+    def dICP(self, source, target, T_init, weight=None, trim_dist=None, loss_fn=None, dim=3):
+        """Point-to-point / point-to-plane ICP on a batch of scan pairs (ICP.py:49-303).
+
+        source : (n,3|6) | (N,n,3|6) | list of (n_i,3|6);  only xyz is used
+        target : (m,3|6) | (N,m,3|6) | list of (m_i,3|6);  pt2pl needs the normals in 3:6
+        T_init : (4,4) | (N,4,4) | list of (4,4)
+        weight : None | (n) | (N,n) | list of (n_i)|None
+        trim_dist : None or a distance; loss_fn : None or {"name": "huber"|"cauchy", "metric": x}
+        dim : 3, or 2 to optimise rotation about z and translation in x,y only
+        returns {"pc" (N,n,3), "T" (N,4,4), "costs" (N,K,1), "deltas" (N,K,6,1),
+                 "weights" (N,K,n*r,1), "stats": {"converged","iterations","matched_ratio"}}
+        """
+        assert dim == 2 or dim == 3, "dim must be 2 or 3"                                # ICP.py:79
+        source, target, T_init, w_pts = self._batch(source, target, T_init, weight)      # ICP.py:85
+        assert source.dtype == target.dtype == T_init.dtype                              # ICP.py:96
+        if self.icp_type == 'pt2pl':
+            assert target.shape[2] == 6                                                  # ICP.py:103
+        else:
+            target = target[:, :, :3]                                                    # ICP.py:105
+        if loss_fn is not None and loss_fn['name'] not in ('huber', 'cauchy', 'trim'):
+            raise ValueError("Invalid loss name: {}".format(loss_fn['name']))            # loss.py:19
+        if self.nn.differentiable and self.nn.use_gumbel:
+            raise NotImplementedError(
+                "dicp_amd: the Gumbel-softmax correspondence (config functionality.gumbel) is served by "
+                "dicp_amd.nn.find_nn but is not fused into the ICP loop yet (SURVEY.md 8f-1)")
+
+        home = source.device
+        dev = home if source.is_cuda else compute_device()
+        source, target, T_init, w_pts = (t.to(dev) for t in (source, target, T_init, w_pts))
+
+        if dim == 2:                                                                     # ICP.py:107-116
+            keep_s = torch.tensor([1.0, 1.0, 0.0], dtype=source.dtype, device=dev)
+            keep_t = torch.tensor([1.0, 1.0, 0.0, 1.0, 1.0, 0.0], dtype=source.dtype, device=dev)[:target.shape[2]]
+            source = source * keep_s
+            target = target * keep_t
+
+        loss_name = loss_fn['name'] if loss_fn is not None else None
+        if loss_name == 'trim':
+            raise ValueError("dicp_amd: 'trim' is selected with trim_dist, not loss_fn")
+        cfg = LoopConfig(
+            icp_type=self.icp_type, differentiable=bool(self.diff), max_iterations=int(self.max_iterations),
+            tolerance=float(self.tolerance), trim_dist=trim_dist, loss_name=loss_name,
+            loss_metric=float(loss_fn['metric']) if loss_fn is not None else 1.0, dim=dim,
+            const_iter=bool(self.const_iter),
+            tanh_steepness=float(self.config['dICP']['parameters']['tanh_steepness']),   # ICP.py:119
+            match_ratio_thresh=float(self.match_ratio_thresh),
+            knn_variant=self.knn_variant, timing_hook=self._timing_hook)
+        T, deltas, weights, costs, converged, iterations, matched = ICPLoop.apply(source, target, T_init, w_pts, cfg)
+
+        if self.verbose:                                                                 # ICP.py:262-264
+            print("ICP converged in {} iterations".format(deltas.shape[1]))
+            print("Final del_T_ts: {}".format(torch.linalg.norm(deltas[:, -1])))
+
+        # ICP.py:274: transformed source, with the graph running through T
+        pc = source @ T[:, :3, :3].transpose(1, 2) + T[:, :3, 3].unsqueeze(1)
+        if self.icp_type == 'pt2pt':                                                     # ICP.py:164-165
+            weights = weights.repeat_interleave(3, dim=2)
+        results = {                                                                      # ICP.py:283-303
+            "pc": pc,
+            "T": T,
+            "costs": costs.unsqueeze(-1),
+            "deltas": deltas.unsqueeze(-1),
+            "weights": weights.unsqueeze(-1),
+            "stats": {"converged": converged, "iterations": iterations, "matched_ratio": matched},
+        }
+        if home != dev:
+            results = {k: (v.to(home) if k != "stats" else {s: x.to(home) for s, x in v.items()})
+                       for k, v in results.items()}
+        return results
+
+    # ------------------------------------------------------------------ batching
+    def batch_size_handling(self, source, target, T_init=None, weight=None):
+        """Normalise the accepted input forms to batched tensors (ICP.py:305-511):
+        source (N,n_max,3) zero-padded, target (N,m_max,c) padded with max(source)*target_pad_val,
+        T_init (N,4,4) or None, weights (N,n_max) -- repeated x3 along dim 1 for pt2pt (ICP.py:508-509)."""
+        s, t, T, w = self._batch(source, target, T_init, weight)
+        if self.icp_type == 'pt2pt':
+            w = w.repeat_interleave(3, dim=1)
+        return s, t, T, w
+
+    def _batch(self, source, target, T_init, weight):
+        """As batch_size_handling, with ONE weight per point (what the kernels consume)."""
+        if weight is not None:                                                           # ICP.py:321-326
+            if isinstance(source, list):
+                assert len(source) == len(weight), "weight must be list of same length as source"
+            else:
+                assert source.shape[0] == weight.shape[0], "weight must have same number of rows as source"
+
+        # whole-input None / empty -> one phony pair with zero weight and identity T (ICP.py:328-346)
+        if source is None or target is None or len(source) == 0 or len(target) == 0:
+            f32 = dict(dtype=torch.float32, device="cpu")
+            return (torch.zeros((1, 1, 3), **f32), torch.zeros((1, 1, 6), **f32),
+                    torch.eye(4, **f32).unsqueeze(0), torch.zeros((1, 1), **f32))
+
+        # dtype / device / column count come from the first non-empty target (ICP.py:347-358)
+        dt, dev, cols = torch.float32, "cpu", None
+        for t_i in target:
+            if t_i is not None and len(t_i) > 0:
+                dt, dev = t_i.dtype, t_i.device
+                cols = t_i.shape[0] if (not isinstance(target, list) and target.dim() == 2) else t_i.shape[1]
+                break
+        opts = dict(dtype=dt, device=dev)
+
+        # ---- source and per-point prior weights (ICP.py:360-446)
+        if isinstance(source, list):
+            pts, pri = [], []
+            for i, s_i in enumerate(source):
+                if len(s_i) == 0:                                   # empty cloud: one zero point, zero weight
+                    pts.append(torch.zeros((1, 3), **opts))
+                    pri.append(torch.zeros((1,), **opts))
+                    continue
+                if i > 0 and (s_i.dim() != 2 or s_i.shape[1] not in (3, 6)):
+                    raise ValueError("source list must contain (n x 3/6) tensors")
+                w_i = torch.ones(s_i.shape[0], **opts)
+                if weight is not None and weight[i] is not None:
+                    assert len(weight[i]) == s_i.shape[0], "weight must have same number of rows as source"
+                    w_i = weight[i] * w_i
+                pts.append(s_i[:, :3])
+                pri.append(w_i)
+            n_max = max(p.shape[0] for p in pts)
+            source_b = torch.zeros((len(pts), n_max, 3), **opts)
+            w = torch.zeros((len(pts), n_max), **opts)
+            for i, (p_i, w_i) in enumerate(zip(pts, pri)):
+                source_b[i, :p_i.shape[0]] = p_i
+                w[i, :w_i.shape[0]] = w_i
+        elif source.dim() == 2 and source.shape[1] in (3, 6):
+            source_b = source[:, :3].unsqueeze(0)
+            w = torch.ones((1, source_b.shape[1]), **opts) if weight is None else weight.unsqueeze(0)
+        elif source.dim() == 3 and source.shape[2] in (3, 6):
+            source_b = source[:, :, :3]
+            w = torch.ones(source_b.shape[:2], **opts) if weight is None else weight
+        else:
+            raise ValueError("source must be (n x 3/6) or (N x n x 3/6) or list len(N) (n_N x 3/6)")
+
+        if self.source_zeroes_are_pad:                                                   # ICP.py:445-446
+            w = w * (torch.linalg.norm(source_b, dim=2) != 0.0).to(dt)
+
+        # ---- target, padded with a value no source point can be nearest to (ICP.py:448-491)
+        if isinstance(target, list):
+            pad = torch.max(source_b) * self.target_pad_val                              # ICP.py:460
+            rows, dead = [], []
+            for i, t_i in enumerate(target):
+                if len(t_i) == 0:                                   # empty target: one zero row, cloud switched off
+                    rows.append(torch.zeros((1, cols), **opts))
+                    dead.append(i)
+                    continue
+                if i > 0 and (t_i.dim() != 2 or t_i.shape[1] != cols):
+                    raise ValueError("target list must contain (m x 3/6) tensors. All tensors must have same number of columns")
+                rows.append(t_i)
+            m_max = max(r_i.shape[0] for r_i in rows)
+            target_b = pad * torch.ones((len(rows), m_max, rows[0].shape[1]), **opts)
+            for i, r_i in enumerate(rows):
+                target_b[i, :r_i.shape[0]] = r_i
+            if dead:
+                live = torch.ones((w.shape[0], 1), **opts)
+                live[dead] = 0.0
+                w = w * live                                                             # ICP.py:456,467
+        elif target.dim() == 2 and target.shape[1] in (3, 6):
+            target_b = target.unsqueeze(0)
+        elif target.dim() == 3 and target.shape[2] in (3, 6):
+            target_b = target
+        else:
+            raise ValueError("target must be (m x 3/6) or (N x m x 3/6) or list len(N) (m_N x 3/6)")
+
+        # ---- initial transforms (ICP.py:493-504)
+        if T_init is None:
+            T_b = None
+        elif isinstance(T_init, list):
+            T_b = torch.stack(T_init, dim=0)
+        elif T_init.shape == (4, 4):
+            T_b = T_init.unsqueeze(0)
+        elif T_init.dim() == 3 and T_init.shape[1:] == (4, 4):
+            T_b = T_init
+        else:
+            raise ValueError("T_init must be (4 x 4) or (N x 4 x 4) or list len(N) (4 x 4)")
+        return source_b, target_b, T_b, w

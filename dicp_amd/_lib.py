@@ -1,0 +1,109 @@
+"""ctypes binding of libdicp_hip.so (include/dicp_hip.h) and its in-tree build recipe.
+
+There is no CPU compute path in this package: if the library is missing or no HIP
+device is visible, every operator raises.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "libdicp_hip.so")
+SOURCES = [os.path.join(_HERE, "csrc", "dicp_kernels.hip")]
+HEADERS = [os.path.join(_HERE, "csrc", "dicp_math.h"), os.path.join(_ROOT, "include", "dicp_hip.h")]
+
+F32, F64 = 0, 1
+PT2PT, PT2PL = 0, 1
+LOSS_NONE, LOSS_HUBER, LOSS_CAUCHY, LOSS_TRIM = 0, 1, 2, 3
+KNN_AUTO, KNN_VALU, KNN_MFMA = 0, 1, 2
+NACC_PAD, NBWD_PAD = 32, 16
+_ERRORS = {1: "null pointer", 2: "bad shape/stride", 3: "unsupported dtype", 4: "bad enum value", 5: "misaligned buffer"}
+
+vp, i32, i64, f64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
+
+
+class WeightParams(ctypes.Structure):
+    """dicp_weight_params (include/dicp_hip.h)."""
+    _fields_ = [("mode", i32), ("trim_on", i32), ("differentiable", i32), ("loss", i32),
+                ("trim_dist", f64), ("tanh_k", f64), ("loss_delta", f64), ("match_thresh", f64)]
+
+
+class StepIO(ctypes.Structure):
+    """dicp_step_io (include/dicp_hip.h)."""
+    _fields_ = [("partials", vp), ("nblk", i32), ("iter", i32), ("dim", i32), ("const_iter", i32),
+                ("tolerance", f64), ("rows_per_point", i32), ("n", i32),
+                ("pose_in", vp), ("pose_out", vp), ("delta", vp), ("delta_stride", i64),
+                ("cost", vp), ("cost_prev", vp), ("cost_stride", i64), ("areg", vp), ("alive", vp),
+                ("converged", vp), ("iterations", vp), ("matched_ratio", vp), ("n_start", vp),
+                ("n_matched", vp), ("w_cur", vp), ("w_prev", vp), ("w_stride", i64), ("n_not_converged", vp)]
+
+
+_SIGNATURES = {
+    "dicp_abi_version": ([], ctypes.c_int),
+    "dicp_padded_targets": ([i32], ctypes.c_int),
+    "dicp_accumulate_blocks": ([i32], ctypes.c_int),
+    "dicp_pack_target": ([i32, vp, i32, i32, i32, vp, i32, vp], ctypes.c_int),
+    "dicp_knn": ([i32, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp], ctypes.c_int),
+    "dicp_gather_rows": ([i32, vp, vp, i32, i32, i32, i32, vp, vp], ctypes.c_int),
+    "dicp_scatter_add_rows": ([i32, vp, vp, i32, i32, i32, i32, vp, vp], ctypes.c_int),
+    "dicp_accumulate": ([i32, ctypes.POINTER(WeightParams), vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp, i64, vp], ctypes.c_int),
+    "dicp_step": ([i32, ctypes.POINTER(StepIO), i32, vp], ctypes.c_int),
+    "dicp_step_bwd": ([i32, vp, vp, i32, i32, vp, vp, i64, vp, vp, vp, vp, i32, vp], ctypes.c_int),
+    "dicp_accumulate_bwd": ([i32, ctypes.POINTER(WeightParams), vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp], ctypes.c_int),
+    "dicp_loss_weight": ([i32, i32, i32, f64, f64, vp, i64, i32, vp, vp], ctypes.c_int),
+    "dicp_loss_weight_bwd": ([i32, i32, i32, f64, f64, vp, vp, i64, i32, vp, vp], ctypes.c_int),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+_lock = threading.Lock()
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP sources for gfx950 into dicp_amd/libdicp_hip.so (hipcc cross-compiles
+    without a GPU).  Rebuilds only when a source or header is newer than the library."""
+    deps = SOURCES + HEADERS
+    if (not force and os.path.exists(LIB_PATH)
+            and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(p) for p in deps)):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC",
+           "-Wall", "-Wno-unused-function", "-I", os.path.join(_ROOT, "include"),
+           "-o", LIB_PATH + ".tmp"] + SOURCES
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+def load():
+    """Load the C-ABI library; raises (never falls back) if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(
+                    "dicp_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, (args, res) in _SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.argtypes = args
+                fn.restype = res
+            if lib.dicp_abi_version() != 1:
+                raise RuntimeError("dicp_amd: libdicp_hip.so ABI version mismatch; rebuild it")
+            _lib = lib
+    return _lib
+
+
+def check(status, what):
+    if status == 0:
+        return
+    if status > 0:
+        raise RuntimeError("dicp_amd: %s rejected its arguments: %s" % (what, _ERRORS.get(status, status)))
+    raise RuntimeError("dicp_amd: %s failed to launch: hipError_t %d" % (what, -status))

@@ -1,0 +1,313 @@
+"""Tensor-level wrappers over the C ABI and the autograd glue.
+
+PyTorch-ROCm is plumbing here (device memory, streams, the autograd graph); every
+arithmetic step of the ICP iteration runs in libdicp_hip.so.  All functions require
+HIP-device tensors and raise otherwise -- there is no CPU compute path.
+"""
+import ctypes
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+
+_DT = {torch.float32: _lib.F32, torch.float64: _lib.F64}
+_LOSS = {None: _lib.LOSS_NONE, "huber": _lib.LOSS_HUBER, "cauchy": _lib.LOSS_CAUCHY, "trim": _lib.LOSS_TRIM}
+
+
+def require_device(t, what):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError("dicp_amd.%s needs tensors on a HIP device (got %s); there is no CPU fallback"
+                           % (what, getattr(t, "device", type(t))))
+    if t.dtype not in _DT:
+        raise TypeError("dicp_amd.%s supports float32/float64, got %s" % (what, t.dtype))
+
+
+def compute_device():
+    """The device the kernels run on; raises if this process cannot see an MI355X."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("dicp_amd: no HIP device visible (torch.cuda.is_available() is False). "
+                           "The ICP hot path only exists as gfx950 kernels; there is no CPU fallback.")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+# ------------------------------------------------------------------ thin kernels
+def padded_targets(m):
+    return _lib.load().dicp_padded_targets(int(m))
+
+
+def accumulate_blocks(n):
+    return _lib.load().dicp_accumulate_blocks(int(n))
+
+
+def pack_target(tgt):
+    """(N,m,c) -> (N,m_pad,4) rows [x,y,z,0.5|y|^2]."""
+    require_device(tgt, "pack_target")
+    N, m, c = tgt.shape
+    m_pad = padded_targets(m)
+    out = torch.empty((N, m_pad, 4), dtype=tgt.dtype, device=tgt.device)
+    with torch.cuda.device(tgt.device):
+        _lib.check(_lib.load().dicp_pack_target(_DT[tgt.dtype], _p(tgt), N, m, c, _p(out), m_pad, _stream()), "dicp_pack_target")
+    return out
+
+
+def knn(src, pose, tgt4, m, variant=_lib.KNN_AUTO, out=None):
+    """Fused transform + brute-force 1-NN: (N,n,3), (N,12)|None, packed targets -> idx (N,n) int32."""
+    require_device(src, "knn")
+    N, n, _ = src.shape
+    idx = out if out is not None else torch.empty((N, n), dtype=torch.int32, device=src.device)
+    with torch.cuda.device(src.device):
+        _lib.check(_lib.load().dicp_knn(_DT[src.dtype], _p(src), _p(pose), _p(tgt4), N, n, m, tgt4.shape[1],
+                                        _p(idx), variant, _stream()), "dicp_knn")
+    return idx
+
+
+class _GatherRows(torch.autograd.Function):
+    """nn.py:37-38: neighbours = y[idx]; backward = scatter-add into y.grad."""
+
+    @staticmethod
+    def forward(ctx, y, idx):
+        N, m, c = y.shape
+        n = idx.shape[1]
+        out = torch.empty((N, n, c), dtype=y.dtype, device=y.device)
+        with torch.cuda.device(y.device):
+            _lib.check(_lib.load().dicp_gather_rows(_DT[y.dtype], _p(y), _p(idx), N, n, m, c, _p(out), _stream()), "dicp_gather_rows")
+        ctx.save_for_backward(idx)
+        ctx.shape = (N, m, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (idx,) = ctx.saved_tensors
+        N, m, c = ctx.shape
+        gout = gout.contiguous()
+        gy = torch.zeros((N, m, c), dtype=gout.dtype, device=gout.device)
+        with torch.cuda.device(gout.device):
+            _lib.check(_lib.load().dicp_scatter_add_rows(_DT[gout.dtype], _p(gout), _p(idx), N, idx.shape[1], m, c, _p(gy), _stream()),
+                       "dicp_scatter_add_rows")
+        return gy, None
+
+
+def gather_rows(y, idx):
+    return _GatherRows.apply(y.contiguous(), idx)
+
+
+class _LossWeight(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, err2d, loss, diff, metric, tanh_k):
+        rows, r = err2d.shape
+        w = torch.empty((rows,), dtype=err2d.dtype, device=err2d.device)
+        with torch.cuda.device(err2d.device):
+            _lib.check(_lib.load().dicp_loss_weight(_DT[err2d.dtype], loss, int(diff), float(metric), float(tanh_k),
+                                                    _p(err2d), rows, r, _p(w), _stream()), "dicp_loss_weight")
+        ctx.save_for_backward(err2d)
+        ctx.cfg = (loss, int(diff), float(metric), float(tanh_k))
+        return w
+
+    @staticmethod
+    def backward(ctx, gw):
+        (err2d,) = ctx.saved_tensors
+        loss, diff, metric, tanh_k = ctx.cfg
+        rows, r = err2d.shape
+        gerr = torch.empty_like(err2d)
+        gw = gw.contiguous()
+        with torch.cuda.device(err2d.device):
+            _lib.check(_lib.load().dicp_loss_weight_bwd(_DT[err2d.dtype], loss, diff, metric, tanh_k, _p(err2d), _p(gw),
+                                                        rows, r, _p(gerr), _stream()), "dicp_loss_weight_bwd")
+        return gerr, None, None, None, None
+
+
+def loss_weight(err2d, name, diff, metric, tanh_k):
+    require_device(err2d, "loss_weight")
+    return _LossWeight.apply(err2d.contiguous(), _LOSS[name], diff, metric, tanh_k)
+
+
+# --------------------------------------------------------------- the ICP loop
+@dataclass
+class LoopConfig:
+    icp_type: str
+    differentiable: bool
+    max_iterations: int
+    tolerance: float
+    trim_dist: object          # None or float
+    loss_name: object          # None | "huber" | "cauchy"
+    loss_metric: float
+    dim: int
+    const_iter: bool
+    tanh_steepness: float
+    match_ratio_thresh: float
+    knn_variant: int = _lib.KNN_AUTO
+    timing_hook: object = None    # optional callable(name, phase) used by bench.py to drop HIP events
+
+    def params(self):
+        return _lib.WeightParams(
+            mode=_lib.PT2PL if self.icp_type == "pt2pl" else _lib.PT2PT,
+            trim_on=int(self.trim_dist is not None and self.trim_dist >= 0.0),
+            differentiable=int(self.differentiable),
+            loss=_LOSS[self.loss_name],
+            trim_dist=float(self.trim_dist if self.trim_dist is not None else 0.0),
+            tanh_k=float(self.tanh_steepness),
+            loss_delta=float(self.loss_metric),
+            match_thresh=float(self.match_ratio_thresh))
+
+
+def _pose_from_T(T):
+    N = T.shape[0]
+    return torch.cat((T[:, :3, :3].reshape(N, 9), T[:, :3, 3]), dim=1).contiguous()
+
+
+class ICPLoop(torch.autograd.Function):
+    """The whole iteration loop of ICP.dICP (ICP.py:131-260) as ONE autograd node.
+
+    forward : K x { dicp_knn -> dicp_accumulate -> dicp_step }, no torch arithmetic between
+    backward: K x { dicp_step_bwd -> dicp_accumulate_bwd } in reverse, recomputing per-point
+              quantities from the saved (idx, pose) instead of keeping autograd's intermediates.
+    Inputs : source (N,n,3), target (N,m,c), T_init (N,4,4), w0 (N,n)  [one weight per POINT]
+    Outputs: T (N,4,4) differentiable; deltas (N,K,6), weights (N,K,n), costs (N,K),
+             converged (N) bool, iterations (N), matched_ratio (N)  (non-differentiable).
+    """
+
+    @staticmethod
+    def forward(ctx, source, target, T_init, w0, cfg):
+        for t, nm in ((source, "source"), (target, "target"), (T_init, "T_init"), (w0, "weight")):
+            require_device(t, "ICP(" + nm + ")")
+        lib = _lib.load()
+        dev, dt = source.device, source.dtype
+        code = _DT[dt]
+        N, n, _ = source.shape
+        m, c = target.shape[1], target.shape[2]
+        src = source.contiguous()
+        tgt = target.contiguous()
+        w0c = w0.contiguous()
+        P = cfg.params()
+        rows = 3 if cfg.icp_type == "pt2pt" else 1
+        Kmax = int(cfg.max_iterations)
+        need_grad = any(ctx.needs_input_grad[:4])
+        hook = cfg.timing_hook
+
+        with torch.cuda.device(dev):
+            st = _stream()
+            tgt4 = pack_target(tgt)
+            m_pad = tgt4.shape[1]
+            nblk = lib.dicp_accumulate_blocks(n)
+            poses = torch.empty((Kmax + 1, N, 12), dtype=dt, device=dev)
+            poses[0] = _pose_from_T(T_init)
+            deltas = torch.zeros((N, Kmax, 6), dtype=dt, device=dev)
+            costs = torch.zeros((N, Kmax), dtype=dt, device=dev)
+            partials = torch.empty((N, nblk, _lib.NACC_PAD), dtype=dt, device=dev)
+            areg = torch.empty((Kmax, N, 36), dtype=torch.float64, device=dev)
+            alive = torch.ones((N,), dtype=dt, device=dev)
+            alive_hist = torch.empty((Kmax, N), dtype=dt, device=dev)
+            converged = torch.zeros((N,), dtype=torch.uint8, device=dev)
+            iterations = torch.zeros((N,), dtype=dt, device=dev)
+            matched = torch.zeros((N,), dtype=dt, device=dev)
+            n_matched = torch.zeros((N,), dtype=dt, device=dev)
+            n_start = (torch.sum(w0c > cfg.match_ratio_thresh, dim=1) * rows).to(dt)
+            counters = torch.zeros((Kmax,), dtype=torch.int32, device=dev)
+            w_hist, idx_hist = [], []
+
+            K = 0
+            for k in range(Kmax):
+                idx = torch.empty((N, n), dtype=torch.int32, device=dev)
+                if hook:
+                    hook("knn", 0)
+                _lib.check(lib.dicp_knn(code, _p(src), _p(poses[k]), _p(tgt4), N, n, m, m_pad, _p(idx), cfg.knn_variant, st), "dicp_knn")
+                if hook:
+                    hook("knn", 1)
+                wk = torch.empty((N, n), dtype=dt, device=dev)
+                alive_hist[k].copy_(alive)
+                _lib.check(lib.dicp_accumulate(code, ctypes.byref(P), _p(src), _p(tgt), c, _p(idx), _p(poses[k]), _p(w0c), _p(alive),
+                                               N, n, m, _p(partials), _p(wk), n, st), "dicp_accumulate")
+                io = _lib.StepIO(
+                    partials=_p(partials), nblk=nblk, iter=k, dim=int(cfg.dim), const_iter=int(cfg.const_iter),
+                    tolerance=float(cfg.tolerance), rows_per_point=rows, n=n,
+                    pose_in=_p(poses[k]), pose_out=_p(poses[k + 1]),
+                    delta=ctypes.c_void_p(deltas.data_ptr() + k * 6 * deltas.element_size()), delta_stride=Kmax * 6,
+                    cost=ctypes.c_void_p(costs.data_ptr() + k * costs.element_size()),
+                    cost_prev=ctypes.c_void_p(costs.data_ptr() + (k - 1) * costs.element_size()) if k > 0 else None,
+                    cost_stride=Kmax, areg=_p(areg[k]), alive=_p(alive), converged=_p(converged),
+                    iterations=_p(iterations), matched_ratio=_p(matched), n_start=_p(n_start), n_matched=_p(n_matched),
+                    w_cur=_p(wk), w_prev=_p(w_hist[-1]) if w_hist else None, w_stride=n,
+                    n_not_converged=ctypes.c_void_p(counters.data_ptr() + 4 * k))
+                _lib.check(lib.dicp_step(code, ctypes.byref(io), N, st), "dicp_step")
+                w_hist.append(wk)
+                idx_hist.append(idx if need_grad else None)
+                K = k + 1
+                # ICP.py:259: stop once every cloud's step is below tolerance (same host sync as the reference)
+                if not cfg.const_iter and int(counters[k].item()) == 0:
+                    break
+
+            # ICP.py:267-271: fill the stats of clouds that never converged
+            iterations = torch.where(iterations == 0, torch.full_like(iterations, K), iterations)
+            start = (n_start * (alive != 0)).to(torch.int64)
+            start[start == 0] = 1
+            ratio = n_matched.to(torch.int64) / start           # int64/int64 -> float32, as in the reference
+            matched = torch.where(matched == 0, ratio.to(dt), matched)
+
+            pose_K = poses[K]
+            T = torch.zeros((N, 4, 4), dtype=dt, device=dev)
+            T[:, :3, :3] = pose_K[:, :9].reshape(N, 3, 3)
+            T[:, :3, 3] = pose_K[:, 9:]
+            T[:, 3, 3] = 1.0
+            weights = torch.stack(w_hist, dim=1)
+            deltas_out = deltas[:, :K].contiguous()
+            costs_out = costs[:, :K].contiguous()
+
+        if need_grad:
+            ctx.save_for_backward(src, tgt, w0c, poses, deltas, areg, alive_hist, *idx_hist)
+            ctx.cfg, ctx.K, ctx.P, ctx.Kmax = cfg, K, P, Kmax
+        conv = converged.bool()
+        ctx.mark_non_differentiable(deltas_out, weights, costs_out, conv, iterations, matched)
+        return T, deltas_out, weights, costs_out, conv, iterations, matched
+
+    @staticmethod
+    def backward(ctx, gT, *_unused):
+        src, tgt, w0c, poses, deltas, areg, alive_hist, *idx_hist = ctx.saved_tensors
+        cfg, K, P, Kmax = ctx.cfg, ctx.K, ctx.P, ctx.Kmax
+        lib = _lib.load()
+        dev, dt = src.device, src.dtype
+        code = _DT[dt]
+        N, n, _ = src.shape
+        m, c = tgt.shape[1], tgt.shape[2]
+        hook = cfg.timing_hook
+        with torch.cuda.device(dev):
+            st = _stream()
+            nblk = lib.dicp_accumulate_blocks(n)
+            gT = gT.contiguous()
+            gpose = torch.cat((gT[:, :3, :3].reshape(N, 9), gT[:, :3, 3]), dim=1).to(torch.float64).contiguous()
+            gpose_next = torch.empty_like(gpose)
+            gsrc = torch.zeros_like(src)
+            want_tgt = ctx.needs_input_grad[1]
+            gtgt = torch.zeros_like(tgt) if want_tgt else None
+            gw = torch.zeros_like(w0c)
+            gs = torch.empty((N, 36), dtype=dt, device=dev)
+            gb = torch.empty((N, 6), dtype=dt, device=dev)
+            bwdp = torch.empty((N, nblk, _lib.NBWD_PAD), dtype=dt, device=dev)
+            have_partials = False
+            for k in range(K - 1, -1, -1):
+                _lib.check(lib.dicp_step_bwd(code, _p(gpose), _p(bwdp) if have_partials else None, nblk, int(cfg.dim),
+                                             _p(poses[k]), ctypes.c_void_p(deltas.data_ptr() + k * 6 * deltas.element_size()),
+                                             Kmax * 6, _p(areg[k]), _p(gs), _p(gb), _p(gpose_next), N, st), "dicp_step_bwd")
+                if hook:
+                    hook("accumulate_bwd", 0)
+                _lib.check(lib.dicp_accumulate_bwd(code, ctypes.byref(P), _p(src), _p(tgt), c, _p(idx_hist[k]), _p(poses[k]),
+                                                   _p(w0c), _p(alive_hist[k]), _p(gs), _p(gb), N, n, m,
+                                                   _p(gsrc), _p(gtgt), _p(gw), _p(bwdp), st), "dicp_accumulate_bwd")
+                if hook:
+                    hook("accumulate_bwd", 1)
+                have_partials = True
+                gpose, gpose_next = gpose_next, gpose
+            if have_partials:
+                gpose = gpose + bwdp.sum(dim=1)[:, :12].to(torch.float64)
+            gT0 = torch.zeros((N, 4, 4), dtype=dt, device=dev)
+            gT0[:, :3, :3] = gpose[:, :9].reshape(N, 3, 3).to(dt)
+            gT0[:, :3, 3] = gpose[:, 9:].to(dt)
+        return gsrc, gtgt, gT0, gw, None

@@ -1,0 +1,734 @@
+// libdicp_hip.so — hand-written HIP kernels (gfx950 / MI355X) for the differentiable-ICP
+// hot path, behind the C ABI declared in include/dicp_hip.h.
+//
+// Kernels (one section each):
+//   pack_kernel            target rows -> [x,y,z,0.5|y|^2] (once per ICP call)
+//   knn_valu_kernel        fused transform + brute-force 1-NN, VALU FMA form, LDS-tiled targets
+//   knn_mfma_kernel        same contraction on the f32 matrix cores (v_mfma_f32_16x16x4_f32)
+//   gather / scatter       nn.find_nn's row gather and its backward
+//   accumulate_kernel      residual/weights/Jacobian/normal-equation sums, per-block partials
+//   step_kernel            per-cloud reduce + 6x6 solve + pose update + loop bookkeeping
+//   accumulate_bwd_kernel  adjoint of accumulate_kernel (recompute from idx and pose)
+//   step_bwd_kernel        adjoint of step_kernel
+//   loss_weight kernels    loss.get_weight for direct users of the class
+//
+// Written for 64-wide wavefronts and 8 XCDs: block ids are dealt so that all blocks of
+// one cloud land on one XCD (they share that cloud's targets in its L2).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dicp_hip.h"
+#include "dicp_math.h"
+
+using namespace dicp;
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int WAVE = 64;
+constexpr int ACC_PTS = 1024;          // source points per accumulate block
+constexpr int KNN_CHUNK = 8;           // targets per running-min update (VALU kernel)
+constexpr int KNN_PAD = 16;            // m_pad granularity (MFMA tile height)
+
+template <typename T> struct V4;
+template <> struct V4<float>  { using type = float4; };
+template <> struct V4<double> { using type = double4; };
+
+template <typename T> __device__ __forceinline__ T inf_v();
+template <> __device__ __forceinline__ float  inf_v<float>()  { return __builtin_huge_valf(); }
+template <> __device__ __forceinline__ double inf_v<double>() { return __builtin_huge_val(); }
+
+__device__ __forceinline__ float  fma_t(float a, float b, float c)    { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float  min_t(float a, float b)   { return __builtin_fminf(a, b); }
+__device__ __forceinline__ double min_t(double a, double b) { return __builtin_fmin(a, b); }
+
+// Blocks b and b+8 share an XCD (round-robin dispatch; speed only, never correctness):
+// give every cloud's blocks the same b % 8.
+__device__ __forceinline__ bool decode_block(int bpc, int N, int& cloud, int& blk) {
+    const int b = blockIdx.x;
+    const int i = b >> 3;
+    cloud = (i / bpc) * 8 + (b & 7);
+    blk = i % bpc;
+    return cloud < N;
+}
+inline unsigned grid_for(int N, int bpc) { return 8u * (unsigned)((N + 7) / 8) * (unsigned)bpc; }
+
+template <typename T>
+__device__ __forceinline__ void load_pose(const T* __restrict__ pose, int cloud, T* C, T* r) {
+    if (pose) {
+        const T* p = pose + (size_t)cloud * 12;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) C[k] = p[k];
+        r[0] = p[9]; r[1] = p[10]; r[2] = p[11];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) C[k] = (k % 4 == 0) ? T(1) : T(0);
+        r[0] = r[1] = r[2] = T(0);
+    }
+}
+
+// ------------------------------------------------------------------------- pack
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void pack_kernel(const T* __restrict__ tgt, int N, int m, int c,
+                                                     typename V4<T>::type* __restrict__ out, int m_pad) {
+    const size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= (size_t)N * m_pad) return;
+    const int b = (int)(t / m_pad), j = (int)(t % m_pad);
+    typename V4<T>::type v;
+    if (j < m) {
+        const T* y = tgt + ((size_t)b * m + j) * c;
+        v.x = y[0]; v.y = y[1]; v.z = y[2];
+        v.w = T(0.5) * (v.x * v.x + v.y * v.y + v.z * v.z);
+    } else {
+        v.x = v.y = v.z = T(0);
+        v.w = inf_v<T>();
+    }
+    out[t] = v;
+}
+
+// ------------------------------------------------------------------- kNN (VALU)
+// score(x, y) = 0.5|y|^2 - x.y  = 0.5(|x-y|^2 - |x|^2): same argmin as the distance.
+template <typename T, typename T4>
+__device__ __forceinline__ T score(const T* nx, const T4& y) {
+    return fma_t(nx[0], y.x, fma_t(nx[1], y.y, fma_t(nx[2], y.z, y.w)));
+}
+
+// Each lane owns Q queries and walks every target of its cloud; targets are staged once
+// per block through LDS and read back as wave-wide broadcasts.  Per chunk of 8 targets the
+// lane only tracks the running minimum VALUE (v_min3) and which chunk last improved it;
+// the index inside that chunk is recovered once at the end (strict <, ascending order,
+// so ties resolve to the lowest index exactly like torch.argmin).
+template <typename T, int Q, int TILE>
+__global__ __launch_bounds__(BLOCK) void knn_valu_kernel(const T* __restrict__ src, const T* __restrict__ pose,
+                                                         const typename V4<T>::type* __restrict__ tgt4,
+                                                         int32_t* __restrict__ idx, int N, int n, int m, int m_pad, int bpc) {
+    using T4 = typename V4<T>::type;
+    __shared__ T4 tile[TILE];
+    int cloud, blk;
+    if (!decode_block(bpc, N, cloud, blk)) return;
+    const int tid = threadIdx.x;
+    T C[9], r[3];
+    load_pose(pose, cloud, C, r);
+
+    T nx[Q][3], best[Q];
+    int bchunk[Q];
+#pragma unroll
+    for (int qi = 0; qi < Q; ++qi) {
+        const int i = blk * (BLOCK * Q) + qi * BLOCK + tid;
+        T p[3] = {T(0), T(0), T(0)};
+        if (i < n) {
+            const T* sp = src + ((size_t)cloud * n + i) * 3;
+            p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2];
+        }
+        T q[3];
+        matvec3(C, p, q);                                   // ICP.py:137
+        nx[qi][0] = -(q[0] + r[0]); nx[qi][1] = -(q[1] + r[1]); nx[qi][2] = -(q[2] + r[2]);
+        best[qi] = inf_v<T>();
+        bchunk[qi] = 0;
+    }
+
+    const T4* __restrict__ tg = tgt4 + (size_t)cloud * m_pad;
+    for (int base = 0; base < m_pad; base += TILE) {
+        const int len = min(TILE, m_pad - base);            // multiple of 16
+        for (int t = tid; t < len; t += BLOCK) tile[t] = tg[base + t];
+        __syncthreads();
+        for (int j0 = 0; j0 < len; j0 += KNN_CHUNK) {
+            T4 y[KNN_CHUNK];
+#pragma unroll
+            for (int k = 0; k < KNN_CHUNK; ++k) y[k] = tile[j0 + k];
+#pragma unroll
+            for (int qi = 0; qi < Q; ++qi) {
+                T c = best[qi];
+#pragma unroll
+                for (int k = 0; k < KNN_CHUNK; ++k) c = min_t(c, score<T, T4>(nx[qi], y[k]));
+                if (c < best[qi]) { best[qi] = c; bchunk[qi] = base + j0; }
+            }
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int qi = 0; qi < Q; ++qi) {
+        const int i = blk * (BLOCK * Q) + qi * BLOCK + tid;
+        if (i < n) {
+            const T4* cp = tg + bchunk[qi];
+            T bv = inf_v<T>();
+            int bj = bchunk[qi];
+#pragma unroll
+            for (int k = 0; k < KNN_CHUNK; ++k) {
+                const T s = score<T, T4>(nx[qi], cp[k]);
+                if (s < bv) { bv = s; bj = bchunk[qi] + k; }
+            }
+            idx[(size_t)cloud * n + i] = min(bj, m - 1);
+        }
+    }
+}
+
+// ------------------------------------------------------------------- kNN (MFMA)
+// The distance matrix IS a dense K=4 contraction: A = targets [y0,y1,y2,h] (16x4),
+// B = queries [-x0,-x1,-x2,1]^T (4x16), D = scores (16 targets x 16 queries) on
+// v_mfma_f32_16x16x4_f32 (exact f32).  Lane l holds D[(l>>4)*4+r][l&15], r=0..3: four
+// targets of one query, so the running min stays lane-local; the four lanes that share a
+// query are combined once at the end.  The VALU only does 2 v_min3 + cmp + select per MFMA.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NB, int TILE>
+__global__ __launch_bounds__(BLOCK) void knn_mfma_kernel(const float* __restrict__ src, const float* __restrict__ pose,
+                                                         const float4* __restrict__ tgt4, int32_t* __restrict__ idx,
+                                                         int N, int n, int m, int m_pad, int bpc) {
+    constexpr int TS = TILE + 16;      // component stride: lanes 16..31 land 16 banks after lanes 0..15
+    __shared__ float tl[4 * TS];
+    int cloud, blk;
+    if (!decode_block(bpc, N, cloud, blk)) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & (WAVE - 1), wave = tid >> 6;
+    const int ql = lane & 15, kq = lane >> 4;
+    const int qwave = (blk * (BLOCK / WAVE) + wave) * (16 * NB);
+    float C[9], r[3];
+    load_pose(pose, cloud, C, r);
+
+    float nx[NB][3], bq[NB], best[NB];
+    int bt[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int i = qwave + nb * 16 + ql;
+        float p[3] = {0.f, 0.f, 0.f};
+        if (i < n) {
+            const float* sp = src + ((size_t)cloud * n + i) * 3;
+            p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2];
+        }
+        float q[3];
+        matvec3(C, p, q);
+        nx[nb][0] = -(q[0] + r[0]); nx[nb][1] = -(q[1] + r[1]); nx[nb][2] = -(q[2] + r[2]);
+        bq[nb] = (kq == 0) ? nx[nb][0] : (kq == 1) ? nx[nb][1] : (kq == 2) ? nx[nb][2] : 1.0f;
+        best[nb] = inf_v<float>();
+        bt[nb] = 0;
+    }
+
+    const float4* __restrict__ tg = tgt4 + (size_t)cloud * m_pad;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int base = 0; base < m_pad; base += TILE) {
+        const int len = min(TILE, m_pad - base);            // multiple of 16
+        for (int t = tid; t < len; t += BLOCK) {
+            const float4 v = tg[base + t];
+            tl[t] = v.x; tl[TS + t] = v.y; tl[2 * TS + t] = v.z; tl[3 * TS + t] = v.w;
+        }
+        __syncthreads();
+        for (int t0 = 0; t0 < len; t0 += 16) {
+            const float a = tl[kq * TS + t0 + ql];          // A[target t0+ql][k = kq]
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq[nb], zero, 0, 0, 0);
+                float c = min_t(min_t(best[nb], d[0]), d[1]);
+                c = min_t(min_t(c, d[2]), d[3]);
+                if (c < best[nb]) { best[nb] = c; bt[nb] = base + t0; }
+            }
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int i = qwave + nb * 16 + ql;
+        const int j0 = bt[nb] + kq * 4;                     // this lane's four targets of the winning tile
+        float bv = inf_v<float>();
+        int bj = j0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float s = score<float, float4>(nx[nb], tg[j0 + k]);
+            if (s < bv) { bv = s; bj = j0 + k; }
+        }
+#pragma unroll
+        for (int off = 16; off < 64; off <<= 1) {           // the 4 lanes that share query ql
+            const float ov = __shfl_xor(bv, off);
+            const int oj = __shfl_xor(bj, off);
+            if (ov < bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
+        }
+        if (kq == 0 && i < n) idx[(size_t)cloud * n + i] = min(bj, m - 1);
+    }
+}
+
+// ------------------------------------------------------------- gather / scatter
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void gather_kernel(const T* __restrict__ tgt, const int32_t* __restrict__ idx,
+                                                       int N, int n, int m, int c, T* __restrict__ out) {
+    const size_t e = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= (size_t)N * n * c) return;
+    const size_t pt = e / c;
+    const int k = (int)(e % c);
+    const int b = (int)(pt / n);
+    const int j = min(max(idx[pt], 0), m - 1);
+    out[e] = tgt[((size_t)b * m + j) * c + k];
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void scatter_add_kernel(const T* __restrict__ gout, const int32_t* __restrict__ idx,
+                                                            int N, int n, int m, int c, T* __restrict__ gtgt) {
+    const size_t e = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= (size_t)N * n * c) return;
+    const size_t pt = e / c;
+    const int k = (int)(e % c);
+    const int b = (int)(pt / n);
+    const int j = min(max(idx[pt], 0), m - 1);
+    unsafeAtomicAdd(&gtgt[((size_t)b * m + j) * c + k], gout[e]);
+}
+
+// -------------------------------------------------------------------- reductions
+// Sum NV per-thread values over the block; thread k < PAD writes slot k of out.
+template <typename T, int NV, int PAD>
+__device__ __forceinline__ void block_reduce_store(T* v, T* __restrict__ out, T* lds /* [BLOCK/WAVE][PAD] */) {
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        T x = v[k];
+#pragma unroll
+        for (int off = WAVE / 2; off > 0; off >>= 1) x += __shfl_down(x, off);
+        if (lane == 0) lds[wave * PAD + k] = x;
+    }
+    __syncthreads();
+    if (tid < PAD) {
+        T s = T(0);
+        if (tid < NV) {
+#pragma unroll
+            for (int w = 0; w < BLOCK / WAVE; ++w) s += lds[w * PAD + tid];
+        }
+        out[tid] = s;
+    }
+}
+
+// -------------------------------------------------------------------- accumulate
+template <typename T, int MODE>
+__global__ __launch_bounds__(BLOCK) void accumulate_kernel(WeightParams P, const T* __restrict__ src, const T* __restrict__ tgt, int c,
+                                                           const int32_t* __restrict__ idx, const T* __restrict__ pose,
+                                                           const T* __restrict__ w_init, const T* __restrict__ alive,
+                                                           int N, int n, int m, int bpc, T* __restrict__ partials,
+                                                           T* __restrict__ w_out, long w_stride) {
+    __shared__ T red[(BLOCK / WAVE) * NACC_PAD];
+    int cloud, blk;
+    if (!decode_block(bpc, N, cloud, blk)) return;
+    T C[9], r[3];
+    load_pose(pose, cloud, C, r);
+    const T live = alive ? alive[cloud] : T(1);
+    T acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = T(0);
+    const int end = min(n, (blk + 1) * ACC_PTS);
+    for (int i = blk * ACC_PTS + threadIdx.x; i < end; i += BLOCK) {
+        const size_t pt = (size_t)cloud * n + i;
+        const T* sp = src + pt * 3;
+        const T p[3] = {sp[0], sp[1], sp[2]};
+        const int j = min(max(idx[pt], 0), m - 1);
+        const T* yp = tgt + ((size_t)cloud * m + j) * c;
+        const T y[3] = {yp[0], yp[1], yp[2]};
+        T nrm[3] = {T(0), T(0), T(0)};
+        if (MODE == MODE_PT2PL) { nrm[0] = yp[3]; nrm[1] = yp[4]; nrm[2] = yp[5]; }
+        PointState<T> s;
+        point_forward<T, MODE>(P, C, r, p, y, nrm, w_init[pt] * live, acc, s);
+        if (w_out) w_out[(size_t)cloud * w_stride + i] = s.w;
+    }
+    block_reduce_store<T, NACC, NACC_PAD>(acc, partials + ((size_t)cloud * bpc + blk) * NACC_PAD, red);
+}
+
+// -------------------------------------------------------------------------- step
+template <typename T>
+__global__ __launch_bounds__(WAVE) void step_kernel(dicp_step_io io, int N) {
+    __shared__ double sacc[NACC_PAD];
+    __shared__ int s_copy;
+    const int cloud = blockIdx.x, tid = threadIdx.x;
+    if (tid < NACC_PAD) {
+        const T* pp = (const T*)io.partials + (size_t)cloud * io.nblk * NACC_PAD + tid;
+        double s = 0.0;
+        for (int b = 0; b < io.nblk; ++b) s += (double)pp[(size_t)b * NACC_PAD];
+        sacc[tid] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double A6[36], C[9], r[3], d6[6], Cn[9], rn[3], Areg[36];
+        unpack_sym6(sacc + ACC_A, A6);
+        const T* pin = (const T*)io.pose_in + (size_t)cloud * 12;
+        for (int k = 0; k < 9; ++k) C[k] = (double)pin[k];
+        for (int k = 0; k < 3; ++k) r[k] = (double)pin[9 + k];
+        // solve with the pose untouched first so delta can be rounded to T like the reference's
+        step_forward(A6, sacc + ACC_B, io.dim, C, r, d6, Cn, rn, Areg);
+        T* dout = (T*)io.delta + (size_t)cloud * io.delta_stride;
+        double nrm2 = 0.0;
+        for (int k = 0; k < 6; ++k) { const T v = (T)d6[k]; dout[k] = v; d6[k] = (double)v; nrm2 += d6[k] * d6[k]; }
+        double R[9];
+        so3_exp(d6, R);                                                   // ICP.py:210
+        T* pout = (T*)io.pose_out + (size_t)cloud * 12;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                pout[i * 3 + j] = (T)(R[0 * 3 + i] * C[0 * 3 + j] + R[1 * 3 + i] * C[1 * 3 + j] + R[2 * 3 + i] * C[2 * 3 + j]);
+        for (int k = 0; k < 3; ++k) pout[9 + k] = (T)(r[k] - d6[3 + k]);
+        if (io.areg) for (int k = 0; k < 36; ++k) io.areg[(size_t)cloud * 36 + k] = Areg[k];
+
+        T cost = (T)sacc[ACC_COST];                                       // ICP.py:229-232
+        if (io.cost_prev && cost == T(0)) cost = ((const T*)io.cost_prev)[(size_t)cloud * io.cost_stride];
+        ((T*)io.cost)[(size_t)cloud * io.cost_stride] = cost;
+
+        const double nmatch = sacc[ACC_NMATCH];
+        if (io.n_matched) ((T*)io.n_matched)[cloud] = (T)nmatch;
+        const bool hit = (double)(T)sqrt(nrm2) < io.tolerance;            // ICP.py:237-239
+        if (hit) io.converged[cloud] = 1;
+        else if (io.n_not_converged) atomicAdd(io.n_not_converged, 1);
+        if (hit && !io.const_iter) {                                      // ICP.py:240-257
+            T* it = (T*)io.iterations + cloud;
+            if (*it == T(0)) *it = (T)(io.iter + 1);
+            T* mr = (T*)io.matched_ratio + cloud;
+            T* al = (T*)io.alive + cloud;
+            if (*mr == T(0)) {
+                float start = (*al != T(0)) ? (float)((const T*)io.n_start)[cloud] : 0.f;
+                if (start == 0.f) start = 1.f;
+                *mr = (T)((float)nmatch / start);       // int64/int64 -> float32 in the reference
+            }
+            *al = T(0);
+        }
+        s_copy = (io.w_cur && io.w_prev && sacc[ACC_SUMW] == 0.0) ? 1 : 0;   // ICP.py:224-226
+    }
+    __syncthreads();
+    if (s_copy) {
+        T* wc = (T*)io.w_cur + (size_t)cloud * io.w_stride;
+        const T* wp = (const T*)io.w_prev + (size_t)cloud * io.w_stride;
+        for (int i = tid; i < io.n; i += WAVE) wc[i] = wp[i];
+    }
+}
+
+// ---------------------------------------------------------------- accumulate bwd
+template <typename T, int MODE>
+__global__ __launch_bounds__(BLOCK) void accumulate_bwd_kernel(WeightParams P, const T* __restrict__ src, const T* __restrict__ tgt, int c,
+                                                               const int32_t* __restrict__ idx, const T* __restrict__ pose,
+                                                               const T* __restrict__ w_init, const T* __restrict__ alive,
+                                                               const T* __restrict__ gs, const T* __restrict__ gb,
+                                                               int N, int n, int m, int bpc,
+                                                               T* __restrict__ gsrc, T* __restrict__ gtgt, T* __restrict__ gw,
+                                                               T* __restrict__ bwd_partials) {
+    __shared__ T red[(BLOCK / WAVE) * NBWD_PAD];
+    int cloud, blk;
+    if (!decode_block(bpc, N, cloud, blk)) return;
+    T C[9], r[3], Gs[36], Gb[6];
+    load_pose(pose, cloud, C, r);
+#pragma unroll
+    for (int k = 0; k < 36; ++k) Gs[k] = gs[(size_t)cloud * 36 + k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Gb[k] = gb[(size_t)cloud * 6 + k];
+    const T live = alive ? alive[cloud] : T(1);
+    T acc[NBWD];
+#pragma unroll
+    for (int k = 0; k < NBWD; ++k) acc[k] = T(0);
+    const int end = min(n, (blk + 1) * ACC_PTS);
+    for (int i = blk * ACC_PTS + threadIdx.x; i < end; i += BLOCK) {
+        const size_t pt = (size_t)cloud * n + i;
+        const T* sp = src + pt * 3;
+        const T p[3] = {sp[0], sp[1], sp[2]};
+        const int j = min(max(idx[pt], 0), m - 1);
+        const size_t row = ((size_t)cloud * m + j) * c;
+        const T* yp = tgt + row;
+        const T y[3] = {yp[0], yp[1], yp[2]};
+        T nrm[3] = {T(0), T(0), T(0)};
+        if (MODE == MODE_PT2PL) { nrm[0] = yp[3]; nrm[1] = yp[4]; nrm[2] = yp[5]; }
+        T gp[3], gy[3], gn[3], gw0;
+        point_backward<T, MODE>(P, C, r, p, y, nrm, w_init[pt] * live, Gs, Gb, gp, gy, gn, gw0, acc, acc + 9);
+        T* gsp = gsrc + pt * 3;
+        gsp[0] += gp[0]; gsp[1] += gp[1]; gsp[2] += gp[2];
+        if (gw) gw[pt] += gw0 * live;
+        if (gtgt) {
+            unsafeAtomicAdd(&gtgt[row + 0], gy[0]);
+            unsafeAtomicAdd(&gtgt[row + 1], gy[1]);
+            unsafeAtomicAdd(&gtgt[row + 2], gy[2]);
+            if (MODE == MODE_PT2PL) {
+                unsafeAtomicAdd(&gtgt[row + 3], gn[0]);
+                unsafeAtomicAdd(&gtgt[row + 4], gn[1]);
+                unsafeAtomicAdd(&gtgt[row + 5], gn[2]);
+            }
+        }
+    }
+    block_reduce_store<T, NBWD, NBWD_PAD>(acc, bwd_partials + ((size_t)cloud * bpc + blk) * NBWD_PAD, red);
+}
+
+// ---------------------------------------------------------------------- step bwd
+template <typename T>
+__global__ __launch_bounds__(WAVE) void step_bwd_kernel(const double* __restrict__ gpose_in, const T* __restrict__ bwd_partials,
+                                                        int nblk, int dim, const T* __restrict__ pose_k,
+                                                        const T* __restrict__ delta_k, long delta_stride,
+                                                        const double* __restrict__ areg_k, T* __restrict__ gs,
+                                                        T* __restrict__ gb, double* __restrict__ gpose_out, int N) {
+    __shared__ double sg[NBWD_PAD];
+    const int cloud = blockIdx.x, tid = threadIdx.x;
+    if (tid < NBWD_PAD) {
+        double s = (tid < NBWD) ? gpose_in[(size_t)cloud * 12 + tid] : 0.0;
+        if (bwd_partials && tid < NBWD) {
+            const T* pp = bwd_partials + (size_t)cloud * nblk * NBWD_PAD + tid;
+            for (int b = 0; b < nblk; ++b) s += (double)pp[(size_t)b * NBWD_PAD];
+        }
+        sg[tid] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double C[9], d6[6], Gs[36], Gb[6], gC[9], gr[3];
+        for (int k = 0; k < 9; ++k) C[k] = (double)pose_k[(size_t)cloud * 12 + k];
+        for (int k = 0; k < 6; ++k) d6[k] = (double)delta_k[(size_t)cloud * delta_stride + k];
+        step_backward(sg, sg + 9, dim, C, d6, areg_k + (size_t)cloud * 36, Gs, Gb, gC, gr);
+        for (int k = 0; k < 36; ++k) gs[(size_t)cloud * 36 + k] = (T)Gs[k];
+        for (int k = 0; k < 6; ++k) gb[(size_t)cloud * 6 + k] = (T)Gb[k];
+        for (int k = 0; k < 9; ++k) gpose_out[(size_t)cloud * 12 + k] = gC[k];
+        for (int k = 0; k < 3; ++k) gpose_out[(size_t)cloud * 12 + 9 + k] = gr[k];
+    }
+}
+
+// ------------------------------------------------------------------ loss weights
+template <typename T>
+__device__ __forceinline__ void loss_eval(int loss, int diff, T metric, T kk, const T* e, int r, T& w, T& en, T& th) {
+    T s = T(0);
+    for (int k = 0; k < r; ++k) s += e[k] * e[k];
+    en = m_sqrt(s);
+    th = T(0);
+    if (loss == DICP_LOSS_HUBER) {
+        if (diff) w = (metric * metric) / (metric * metric + en * en);
+        else      w = (en > metric) ? metric / en : T(1);
+    } else if (loss == DICP_LOSS_CAUCHY) {
+        const T t = en / metric;
+        w = T(1) / (T(1) + t * t);
+    } else {   // trim
+        if (diff) { th = m_tanh(kk * (metric - en) - T(3)); w = T(0.5) * th + T(0.5); }
+        else      w = (en < metric) ? T(1) : T(0);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void loss_weight_kernel(int loss, int diff, T metric, T kk, const T* __restrict__ err,
+                                                            long rows, int r, T* __restrict__ w) {
+    const long i = (long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= rows) return;
+    T e[3] = {T(0), T(0), T(0)};
+    for (int k = 0; k < r; ++k) e[k] = err[i * r + k];
+    T wv, en, th;
+    loss_eval(loss, diff, metric, kk, e, r, wv, en, th);
+    w[i] = wv;
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void loss_weight_bwd_kernel(int loss, int diff, T metric, T kk, const T* __restrict__ err,
+                                                                const T* __restrict__ gw, long rows, int r, T* __restrict__ gerr) {
+    const long i = (long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= rows) return;
+    T e[3] = {T(0), T(0), T(0)};
+    for (int k = 0; k < r; ++k) e[k] = err[i * r + k];
+    T wv, en, th;
+    loss_eval(loss, diff, metric, kk, e, r, wv, en, th);
+    T dw = T(0);      // d w / d en
+    if (loss == DICP_LOSS_HUBER) {
+        if (diff) dw = -T(2) * en * wv * wv / (metric * metric);
+        else      dw = (en > metric) ? -metric / (en * en) : T(0);
+    } else if (loss == DICP_LOSS_CAUCHY) {
+        dw = -T(2) * en * wv * wv / (metric * metric);
+    } else if (diff) {
+        dw = -T(0.5) * kk * (T(1) - th * th);
+    }
+    const T f = (en > T(0)) ? gw[i] * dw / en : T(0);
+    for (int k = 0; k < r; ++k) gerr[i * r + k] = f * e[k];
+}
+
+// ------------------------------------------------------------------- host helpers
+inline int launch_status() {
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : -(int)e;
+}
+inline WeightParams to_params(const dicp_weight_params* p) {
+    WeightParams P;
+    P.mode = p->mode; P.trim_on = p->trim_on; P.differentiable = p->differentiable; P.loss = p->loss;
+    P.trim_dist = p->trim_dist; P.tanh_k = p->tanh_k; P.loss_delta = p->loss_delta; P.match_thresh = p->match_thresh;
+    return P;
+}
+inline bool bad_dtype(int d) { return d != DICP_F32 && d != DICP_F64; }
+inline unsigned blocks_for(size_t total) { return (unsigned)((total + BLOCK - 1) / BLOCK); }
+
+template <typename T>
+int knn_valu_launch(const void* src, const void* pose, const void* tgt4, int N, int n, int m, int m_pad, int32_t* idx, hipStream_t st) {
+    using T4 = typename V4<T>::type;
+    constexpr int TILE = sizeof(T) == 4 ? 2048 : 1024;      // 32 KiB of LDS either way
+    // queries per lane: enough blocks to fill 256 CUs first, then register-block for LDS-read amortisation
+    const long q_total = (long)N * n;
+    if (q_total >= 4L * BLOCK * 1024) {
+        const int bpc = (n + BLOCK * 4 - 1) / (BLOCK * 4);
+        knn_valu_kernel<T, 4, TILE><<<grid_for(N, bpc), BLOCK, 0, st>>>((const T*)src, (const T*)pose, (const T4*)tgt4, idx, N, n, m, m_pad, bpc);
+    } else if (q_total >= 2L * BLOCK * 1024) {
+        const int bpc = (n + BLOCK * 2 - 1) / (BLOCK * 2);
+        knn_valu_kernel<T, 2, TILE><<<grid_for(N, bpc), BLOCK, 0, st>>>((const T*)src, (const T*)pose, (const T4*)tgt4, idx, N, n, m, m_pad, bpc);
+    } else {
+        const int bpc = (n + BLOCK - 1) / BLOCK;
+        knn_valu_kernel<T, 1, TILE><<<grid_for(N, bpc), BLOCK, 0, st>>>((const T*)src, (const T*)pose, (const T4*)tgt4, idx, N, n, m, m_pad, bpc);
+    }
+    return launch_status();
+}
+
+}  // namespace
+
+// ======================================================================== C ABI
+extern "C" {
+
+int dicp_abi_version(void) { return DICP_ABI_VERSION; }
+int dicp_padded_targets(int m) { return m <= 0 ? 0 : ((m + KNN_PAD - 1) / KNN_PAD) * KNN_PAD; }
+int dicp_accumulate_blocks(int n) { return n <= 0 ? 0 : (n + ACC_PTS - 1) / ACC_PTS; }
+
+int dicp_pack_target(int dtype, const void* tgt, int N, int m, int c, void* tgt4, int m_pad, void* stream) {
+    if (!tgt || !tgt4) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0 || m <= 0 || (c != 3 && c != 6) || m_pad != dicp_padded_targets(m)) return DICP_ERR_SHAPE;
+    if ((uintptr_t)tgt4 % (dtype == DICP_F32 ? 16 : 32)) return DICP_ERR_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned g = blocks_for((size_t)N * m_pad);
+    if (dtype == DICP_F32) pack_kernel<float><<<g, BLOCK, 0, st>>>((const float*)tgt, N, m, c, (float4*)tgt4, m_pad);
+    else                   pack_kernel<double><<<g, BLOCK, 0, st>>>((const double*)tgt, N, m, c, (double4*)tgt4, m_pad);
+    return launch_status();
+}
+
+int dicp_knn(int dtype, const void* src, const void* pose, const void* tgt4, int N, int n, int m, int m_pad,
+             int32_t* idx, int variant, void* stream) {
+    if (!src || !tgt4 || !idx) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0 || n <= 0 || m <= 0 || m_pad != dicp_padded_targets(m)) return DICP_ERR_SHAPE;
+    if (variant < DICP_KNN_AUTO || variant > DICP_KNN_MFMA) return DICP_ERR_ENUM;
+    if (variant == DICP_KNN_MFMA && dtype != DICP_F32) return DICP_ERR_DTYPE;
+    if ((uintptr_t)tgt4 % (dtype == DICP_F32 ? 16 : 32)) return DICP_ERR_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    if (variant == DICP_KNN_AUTO) variant = DICP_KNN_VALU;
+    if (variant == DICP_KNN_MFMA) {
+        const long q_total = (long)N * n;
+        if (q_total >= 512L * 1024) {
+            const int bpc = (n + 64 * 8 - 1) / (64 * 8);
+            knn_mfma_kernel<8, 2048><<<grid_for(N, bpc), BLOCK, 0, st>>>((const float*)src, (const float*)pose, (const float4*)tgt4, idx, N, n, m, m_pad, bpc);
+        } else {
+            const int bpc = (n + 64 * 2 - 1) / (64 * 2);
+            knn_mfma_kernel<2, 2048><<<grid_for(N, bpc), BLOCK, 0, st>>>((const float*)src, (const float*)pose, (const float4*)tgt4, idx, N, n, m, m_pad, bpc);
+        }
+        return launch_status();
+    }
+    if (dtype == DICP_F32) return knn_valu_launch<float>(src, pose, tgt4, N, n, m, m_pad, idx, st);
+    return knn_valu_launch<double>(src, pose, tgt4, N, n, m, m_pad, idx, st);
+}
+
+int dicp_gather_rows(int dtype, const void* tgt, const int32_t* idx, int N, int n, int m, int c, void* out, void* stream) {
+    if (!tgt || !idx || !out) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0 || n <= 0 || m <= 0 || c <= 0) return DICP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned g = blocks_for((size_t)N * n * c);
+    if (dtype == DICP_F32) gather_kernel<float><<<g, BLOCK, 0, st>>>((const float*)tgt, idx, N, n, m, c, (float*)out);
+    else                   gather_kernel<double><<<g, BLOCK, 0, st>>>((const double*)tgt, idx, N, n, m, c, (double*)out);
+    return launch_status();
+}
+
+int dicp_scatter_add_rows(int dtype, const void* gout, const int32_t* idx, int N, int n, int m, int c, void* gtgt, void* stream) {
+    if (!gout || !idx || !gtgt) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0 || n <= 0 || m <= 0 || c <= 0) return DICP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned g = blocks_for((size_t)N * n * c);
+    if (dtype == DICP_F32) scatter_add_kernel<float><<<g, BLOCK, 0, st>>>((const float*)gout, idx, N, n, m, c, (float*)gtgt);
+    else                   scatter_add_kernel<double><<<g, BLOCK, 0, st>>>((const double*)gout, idx, N, n, m, c, (double*)gtgt);
+    return launch_status();
+}
+
+static int check_params(const dicp_weight_params* p, int c) {
+    if (!p) return DICP_ERR_NULL;
+    if (p->mode != DICP_PT2PT && p->mode != DICP_PT2PL) return DICP_ERR_ENUM;
+    if (p->loss < DICP_LOSS_NONE || p->loss > DICP_LOSS_CAUCHY) return DICP_ERR_ENUM;
+    if (p->mode == DICP_PT2PL ? (c != 6) : (c != 3 && c != 6)) return DICP_ERR_SHAPE;   // ICP.py:103
+    return 0;
+}
+
+int dicp_accumulate(int dtype, const dicp_weight_params* prm, const void* src, const void* tgt, int c,
+                    const int32_t* idx, const void* pose, const void* w_init, const void* alive,
+                    int N, int n, int m, void* partials, void* w_out, int64_t w_stride, void* stream) {
+    if (const int e = check_params(prm, c)) return e;
+    if (!src || !tgt || !idx || !w_init || !partials) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0 || n <= 0 || m <= 0 || (w_out && w_stride < n)) return DICP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const WeightParams P = to_params(prm);
+    const int bpc = dicp_accumulate_blocks(n);
+    const unsigned g = grid_for(N, bpc);
+#define DICP_ACC(T, M) accumulate_kernel<T, M><<<g, BLOCK, 0, st>>>(P, (const T*)src, (const T*)tgt, c, idx, (const T*)pose, \
+        (const T*)w_init, (const T*)alive, N, n, m, bpc, (T*)partials, (T*)w_out, (long)w_stride)
+    if (dtype == DICP_F32) { if (P.mode == MODE_PT2PL) DICP_ACC(float, MODE_PT2PL); else DICP_ACC(float, MODE_PT2PT); }
+    else                   { if (P.mode == MODE_PT2PL) DICP_ACC(double, MODE_PT2PL); else DICP_ACC(double, MODE_PT2PT); }
+#undef DICP_ACC
+    return launch_status();
+}
+
+int dicp_step(int dtype, const dicp_step_io* io, int N, void* stream) {
+    if (!io || !io->partials || !io->pose_in || !io->pose_out || !io->delta || !io->cost || !io->alive ||
+        !io->converged || !io->iterations || !io->matched_ratio || !io->n_start) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0 || io->nblk <= 0 || (io->dim != 2 && io->dim != 3) || io->delta_stride < 6 || io->cost_stride < 1 ||
+        (io->w_cur && io->w_stride < io->n)) return DICP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DICP_F32) step_kernel<float><<<N, WAVE, 0, st>>>(*io, N);
+    else                   step_kernel<double><<<N, WAVE, 0, st>>>(*io, N);
+    return launch_status();
+}
+
+int dicp_step_bwd(int dtype, const double* gpose_in, const void* bwd_partials, int nblk, int dim,
+                  const void* pose_k, const void* delta_k, int64_t delta_stride, const double* areg_k,
+                  void* gs, void* gb, double* gpose_out, int N, void* stream) {
+    if (!gpose_in || !pose_k || !delta_k || !areg_k || !gs || !gb || !gpose_out) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0 || (dim != 2 && dim != 3) || delta_stride < 6 || (bwd_partials && nblk <= 0)) return DICP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DICP_F32)
+        step_bwd_kernel<float><<<N, WAVE, 0, st>>>(gpose_in, (const float*)bwd_partials, nblk, dim, (const float*)pose_k,
+                                                  (const float*)delta_k, (long)delta_stride, areg_k, (float*)gs, (float*)gb, gpose_out, N);
+    else
+        step_bwd_kernel<double><<<N, WAVE, 0, st>>>(gpose_in, (const double*)bwd_partials, nblk, dim, (const double*)pose_k,
+                                                   (const double*)delta_k, (long)delta_stride, areg_k, (double*)gs, (double*)gb, gpose_out, N);
+    return launch_status();
+}
+
+int dicp_accumulate_bwd(int dtype, const dicp_weight_params* prm, const void* src, const void* tgt, int c,
+                        const int32_t* idx, const void* pose, const void* w_init, const void* alive,
+                        const void* gs, const void* gb, int N, int n, int m,
+                        void* gsrc, void* gtgt, void* gw, void* bwd_partials, void* stream) {
+    if (const int e = check_params(prm, c)) return e;
+    if (!src || !tgt || !idx || !w_init || !gs || !gb || !gsrc || !bwd_partials) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0 || n <= 0 || m <= 0) return DICP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const WeightParams P = to_params(prm);
+    const int bpc = dicp_accumulate_blocks(n);
+    const unsigned g = grid_for(N, bpc);
+#define DICP_BWD(T, M) accumulate_bwd_kernel<T, M><<<g, BLOCK, 0, st>>>(P, (const T*)src, (const T*)tgt, c, idx, (const T*)pose, \
+        (const T*)w_init, (const T*)alive, (const T*)gs, (const T*)gb, N, n, m, bpc, (T*)gsrc, (T*)gtgt, (T*)gw, (T*)bwd_partials)
+    if (dtype == DICP_F32) { if (P.mode == MODE_PT2PL) DICP_BWD(float, MODE_PT2PL); else DICP_BWD(float, MODE_PT2PT); }
+    else                   { if (P.mode == MODE_PT2PL) DICP_BWD(double, MODE_PT2PL); else DICP_BWD(double, MODE_PT2PT); }
+#undef DICP_BWD
+    return launch_status();
+}
+
+int dicp_loss_weight(int dtype, int loss, int differentiable, double metric, double tanh_k,
+                     const void* err, int64_t rows, int r, void* w, void* stream) {
+    if (!err || !w) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (loss < DICP_LOSS_HUBER || loss > DICP_LOSS_TRIM) return DICP_ERR_ENUM;    // loss.py:19
+    if (rows <= 0 || r < 1 || r > 3) return DICP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned g = blocks_for((size_t)rows);
+    if (dtype == DICP_F32) loss_weight_kernel<float><<<g, BLOCK, 0, st>>>(loss, differentiable, (float)metric, (float)tanh_k, (const float*)err, (long)rows, r, (float*)w);
+    else                   loss_weight_kernel<double><<<g, BLOCK, 0, st>>>(loss, differentiable, metric, tanh_k, (const double*)err, (long)rows, r, (double*)w);
+    return launch_status();
+}
+
+int dicp_loss_weight_bwd(int dtype, int loss, int differentiable, double metric, double tanh_k,
+                         const void* err, const void* gw, int64_t rows, int r, void* gerr, void* stream) {
+    if (!err || !gw || !gerr) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (loss < DICP_LOSS_HUBER || loss > DICP_LOSS_TRIM) return DICP_ERR_ENUM;
+    if (rows <= 0 || r < 1 || r > 3) return DICP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned g = blocks_for((size_t)rows);
+    if (dtype == DICP_F32) loss_weight_bwd_kernel<float><<<g, BLOCK, 0, st>>>(loss, differentiable, (float)metric, (float)tanh_k, (const float*)err, (const float*)gw, (long)rows, r, (float*)gerr);
+    else                   loss_weight_bwd_kernel<double><<<g, BLOCK, 0, st>>>(loss, differentiable, metric, tanh_k, (const double*)err, (const double*)gw, (long)rows, r, (double*)gerr);
+    return launch_status();
+}
+
+}  // extern "C"

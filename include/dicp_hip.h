@@ -1,0 +1,148 @@
+/* dicp_hip.h — C ABI of libdicp_hip.so: the MI355X (gfx950) hot path of differentiable ICP.
+ *
+ * The reference (utiasASRL/dICP) has no FFI: its boundary is the Python call surface and
+ * the seam the kernels sit behind is inside dICP/ICP.py's loop.  Each entry point below
+ * cites the reference lines it replaces (paths relative to /root/reference).  The Python
+ * host side (dicp_amd/_lib.py) binds these with ctypes; INTEGRATION.md shows the stub a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch-ROCm allocations);
+ *     the library allocates nothing, keeps no state, and never synchronises;
+ *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream);
+ *   - dtype: DICP_F32 or DICP_F64 selects the scalar type T of all `void*` tensors
+ *     (the reference's tests run float64: tests/test_ICP.py:41-42);
+ *   - tensors are dense row-major unless a stride argument says otherwise;
+ *   - return value: 0 = ok, DICP_ERR_* (>0) = rejected argument (nothing launched),
+ *     <0 = -(hipError_t) from the launch.  Nothing throws across the boundary.
+ */
+#ifndef DICP_HIP_H
+#define DICP_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DICP_ABI_VERSION 1
+
+enum { DICP_F32 = 0, DICP_F64 = 1 };
+enum { DICP_PT2PT = 0, DICP_PT2PL = 1 };                 /* ICP(icp_type=...)  ICP.py:15,101-105 */
+enum { DICP_LOSS_NONE = 0, DICP_LOSS_HUBER = 1, DICP_LOSS_CAUCHY = 2, DICP_LOSS_TRIM = 3 };
+enum { DICP_KNN_AUTO = 0, DICP_KNN_VALU = 1, DICP_KNN_MFMA = 2 };
+enum { DICP_ERR_NULL = 1, DICP_ERR_SHAPE = 2, DICP_ERR_DTYPE = 3, DICP_ERR_ENUM = 4, DICP_ERR_ALIGN = 5 };
+
+/* Accumulator layout of one (cloud, block) partial: see dicp_amd/csrc/dicp_math.h */
+#define DICP_NACC_PAD 32   /* 21 A-upper, 6 b, cost, sum w, #matched, 2 pad */
+#define DICP_NBWD_PAD 16   /* 9 C-bar, 3 r-bar, 4 pad */
+
+/* loss.py:4 constructor arguments + the ICP.py:152-160 call-site switches. */
+typedef struct dicp_weight_params {
+    int32_t mode;            /* DICP_PT2PT | DICP_PT2PL */
+    int32_t trim_on;         /* trim_dist is not None and >= 0            ICP.py:153 */
+    int32_t differentiable;  /* ICP(differentiable=...)                   ICP.py:38  */
+    int32_t loss;            /* DICP_LOSS_NONE | _HUBER | _CAUCHY         ICP.py:158 */
+    double trim_dist;
+    double tanh_k;           /* config tanh_steepness                     ICP.py:119 */
+    double loss_delta;       /* loss_fn["metric"]                                    */
+    double match_thresh;     /* config matched_ratio_thresh               ICP.py:37  */
+} dicp_weight_params;
+
+int dicp_abi_version(void);
+
+/* Rows of target points padded for the kNN kernels: returns m rounded up to 16. */
+int dicp_padded_targets(int m);
+/* Blocks per cloud used by dicp_accumulate / dicp_accumulate_bwd for n source points. */
+int dicp_accumulate_blocks(int n);
+
+/* Once per ICP call: tgt (N,m,c) -> tgt4 (N,m_pad,4) rows [x,y,z,0.5|y|^2], pad rows
+ * [0,0,0,+inf].  The norms are the ||y||^2 column that torch.cdist's matmul path builds
+ * on every call (nn.py:32 -> ATen _euclidean_dist).  c in {3,6}. */
+int dicp_pack_target(int dtype, const void* tgt, int N, int m, int c, void* tgt4, int m_pad, void* stream);
+
+/* Fused transform + brute-force 1-NN: replaces ICP.py:137 (ps_t = C p + r) followed by
+ * nn.find_nn's cdist -> argmin, nn.py:32-35 / 83-86.  Never materialises (N,n,m).
+ *   src (N,n,3); pose (N,12) = [C row-major (9), r (3)] or NULL for identity;
+ *   idx (N,n) int32, ties -> lowest index.  variant: DICP_KNN_*; MFMA is f32 only. */
+int dicp_knn(int dtype, const void* src, const void* pose, const void* tgt4, int N, int n, int m, int m_pad,
+             int32_t* idx, int variant, void* stream);
+
+/* Gather whole target rows at idx (nn.py:37-38 / 89-90) and its backward, a scatter-add
+ * into a zero-initialised (N,m,c) buffer (autograd's gather backward). */
+int dicp_gather_rows(int dtype, const void* tgt, const int32_t* idx, int N, int n, int m, int c, void* out, void* stream);
+int dicp_scatter_add_rows(int dtype, const void* gout, const int32_t* idx, int N, int n, int m, int c, void* gtgt, void* stream);
+
+/* One pass over the source points: residuals (ICP.py:143-149), trim and robust weights
+ * (loss.py:21-58 via ICP.py:152-160), weight combine (ICP.py:162-169,194-196), Jacobian
+ * rows (ICP.py:171-183) and the normal-equation sums A = J_w^T J_w, b = J_w^T e_w
+ * (ICP.py:198-201) plus cost (ICP.py:229), sum(w) and #(w > thresh) (ICP.py:225,247).
+ *   tgt (N,m,c) with c = 6 for pt2pl (normals in 3:6), 3 or 6 for pt2pt;
+ *   w_init (N,n); alive (N) multiplies w_init (the zeroing of ICP.py:256-257), may be NULL;
+ *   partials (N, nblk, DICP_NACC_PAD) with nblk = dicp_accumulate_blocks(n);
+ *   w_out: cloud b's n weights are written at w_out + b*w_stride (elements); may be NULL. */
+int dicp_accumulate(int dtype, const dicp_weight_params* prm, const void* src, const void* tgt, int c,
+                    const int32_t* idx, const void* pose, const void* w_init, const void* alive,
+                    int N, int n, int m, void* partials, void* w_out, int64_t w_stride, void* stream);
+
+/* Per-cloud state advanced by dicp_step (one ICP iteration's tail, ICP.py:198-260). */
+typedef struct dicp_step_io {
+    const void* partials;    /* (N,nblk,32) T from dicp_accumulate */
+    int32_t nblk;
+    int32_t iter;            /* ii, 0-based */
+    int32_t dim;             /* 2 or 3                                    ICP.py:186-189,203-207 */
+    int32_t const_iter;      /* config const_iter                         ICP.py:240 */
+    double tolerance;        /* ICP(tolerance=...)                        ICP.py:239 */
+    int32_t rows_per_point;  /* 3 for pt2pt, 1 for pt2pl (weights layout ICP.py:164-165) */
+    int32_t n;               /* source points per cloud */
+    const void* pose_in;     /* (N,12) T */
+    void* pose_out;          /* (N,12) T   C <- exp(dphi^)^T C, r <- r - dr    ICP.py:209-217 */
+    void* delta;             /* T: cloud b's 6 numbers at delta + b*delta_stride       ICP.py:220 */
+    int64_t delta_stride;
+    void* cost;              /* T: cloud b's cost at cost + b*cost_stride              ICP.py:229-234 */
+    const void* cost_prev;   /* same layout, previous iteration, or NULL */
+    int64_t cost_stride;
+    double* areg;            /* (N,36) the regularised matrix that was inverted (for backward) */
+    void* alive;             /* (N) T in/out                               ICP.py:256-257 */
+    uint8_t* converged;      /* (N) in/out                                 ICP.py:239 */
+    void* iterations;        /* (N) T in/out                               ICP.py:245 */
+    void* matched_ratio;     /* (N) T in/out                               ICP.py:247-251 */
+    const void* n_start;     /* (N) T: #(w_init > thresh) of the ORIGINAL w_init, in weight rows */
+    void* n_matched;         /* (N) T out: #(w > thresh) this iteration (for ICP.py:268-271) */
+    void* w_cur;             /* this iteration's weights (cloud stride w_stride) or NULL */
+    const void* w_prev;      /* previous iteration's, or NULL              ICP.py:224-226 */
+    int64_t w_stride;
+    int32_t* n_not_converged;/* device counter for this iteration, pre-zeroed: += 1 per cloud with |delta| >= tol */
+} dicp_step_io;
+
+/* Reduce the partials, solve the 6x6 (3x3 for dim 2) system (ICP.py:200-201), update the
+ * pose (ICP.py:209-217) and do the loop bookkeeping of ICP.py:219-257 on device. */
+int dicp_step(int dtype, const dicp_step_io* io, int N, void* stream);
+
+/* Backward of dicp_step for iteration k.  gpose_in (N,12) double = cotangent of pose_out
+ * that flowed through later iterations; bwd_partials (N,nblk,DICP_NBWD_PAD) T = the
+ * C-bar/r-bar sums dicp_accumulate_bwd produced for iteration k+1 (NULL for the last).
+ * Out: gs (N,36) T = G_A + G_A^T, gb (N,6) T, gpose_out (N,12) double. */
+int dicp_step_bwd(int dtype, const double* gpose_in, const void* bwd_partials, int nblk, int dim,
+                  const void* pose_k, const void* delta_k, int64_t delta_stride, const double* areg_k,
+                  void* gs, void* gb, double* gpose_out, int N, void* stream);
+
+/* Backward of dicp_accumulate (the reference uses stock autograd through
+ * ICP.py:137-201).  Recomputes the forward quantities from (src,tgt,idx,pose,w_init).
+ *   gsrc (N,n,3) +=, gw (N,n) +=, gtgt (N,m,c) += via atomics (zero-initialised by caller;
+ *   may be NULL if target needs no gradient), bwd_partials (N,nblk,DICP_NBWD_PAD) written. */
+int dicp_accumulate_bwd(int dtype, const dicp_weight_params* prm, const void* src, const void* tgt, int c,
+                        const int32_t* idx, const void* pose, const void* w_init, const void* alive,
+                        const void* gs, const void* gb, int N, int n, int m,
+                        void* gsrc, void* gtgt, void* gw, void* bwd_partials, void* stream);
+
+/* loss(name, metric, differentiable, tanh_steepness).get_weight(err), loss.py:11-58, for
+ * callers that use the class directly.  err (rows,r), r in {1,3}; w (rows). */
+int dicp_loss_weight(int dtype, int loss, int differentiable, double metric, double tanh_k,
+                     const void* err, int64_t rows, int r, void* w, void* stream);
+int dicp_loss_weight_bwd(int dtype, int loss, int differentiable, double metric, double tanh_k,
+                         const void* err, const void* gw, int64_t rows, int r, void* gerr, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DICP_HIP_H */

@@ -1,0 +1,92 @@
+"""The drop-in boundary (no GPU needed): the C-ABI library loads, exports every symbol that
+include/dicp_hip.h declares, rejects bad arguments without launching, and the product
+package never touches the oracle."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from dicp_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    _lib.build()
+    return _lib.load()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "dicp_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dicp_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree(lib):
+    names = declared_symbols()
+    assert len(names) >= 13
+    assert sorted(_lib.EXPORTS) == names
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), "libdicp_hip.so does not export " + n
+
+
+def test_struct_layouts_match_header(lib):
+    assert ctypes.sizeof(_lib.WeightParams) == 4 * 4 + 4 * 8
+    # dicp_step_io: field order and padding as the C compiler lays it out
+    expect = ["partials", "nblk", "iter", "dim", "const_iter", "tolerance", "rows_per_point", "n", "pose_in", "pose_out",
+              "delta", "delta_stride", "cost", "cost_prev", "cost_stride", "areg", "alive", "converged", "iterations",
+              "matched_ratio", "n_start", "n_matched", "w_cur", "w_prev", "w_stride", "n_not_converged"]
+    assert [f[0] for f in _lib.StepIO._fields_] == expect
+    hdr = open(os.path.join(ROOT, "include", "dicp_hip.h")).read()
+    body = hdr[hdr.index("typedef struct dicp_step_io {"):hdr.index("} dicp_step_io;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"([A-Za-z_0-9]+)\s*;", body)
+    assert fields == expect
+
+
+def test_sizes_and_argument_checks(lib):
+    assert lib.dicp_abi_version() == 1
+    assert [lib.dicp_padded_targets(m) for m in (0, 1, 16, 17, 65)] == [0, 16, 16, 32, 80]
+    assert [lib.dicp_accumulate_blocks(n) for n in (0, 1, 1024, 1025, 16384)] == [0, 1, 1, 2, 16]
+    # rejected before any launch (no GPU touched): null pointers, bad dtype / shapes / enums
+    one = ctypes.c_void_p(16)
+    assert lib.dicp_pack_target(0, None, 1, 1, 3, None, 16, None) == 1
+    assert lib.dicp_pack_target(7, one, 1, 1, 3, one, 16, None) == 3
+    assert lib.dicp_pack_target(0, one, 1, 1, 4, one, 16, None) == 2
+    assert lib.dicp_pack_target(0, one, 1, 1, 3, one, 15, None) == 2
+    assert lib.dicp_knn(0, one, None, one, 1, 1, 1, 16, one, 9, None) == 4
+    assert lib.dicp_knn(1, one, None, ctypes.c_void_p(32), 1, 1, 1, 16, one, _lib.KNN_MFMA, None) == 3
+    assert lib.dicp_knn(0, one, None, ctypes.c_void_p(8), 1, 1, 1, 16, one, 0, None) == 5
+    P = _lib.WeightParams(mode=1, loss=0)
+    assert lib.dicp_accumulate(0, ctypes.byref(P), one, one, 3, one, one, one, None, 1, 1, 1, one, None, 0, None) == 2   # pt2pl needs normals (ICP.py:103)
+    P.loss = 9
+    assert lib.dicp_accumulate(0, ctypes.byref(P), one, one, 6, one, one, one, None, 1, 1, 1, one, None, 0, None) == 4
+    assert lib.dicp_loss_weight(0, 0, 0, 1.0, 5.0, one, 4, 3, one, None) == 4      # unknown loss (loss.py:19)
+    with pytest.raises(RuntimeError, match="rejected"):
+        _lib.check(2, "x")
+    with pytest.raises(RuntimeError, match="hipError_t 98"):
+        _lib.check(-98, "x")
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "dicp_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "hostcheck" not in src or f == "dicp_math.h", f
+    for f in os.listdir(os.path.join(ROOT, "dICP")):
+        if not f.endswith(".py"):
+            continue
+        assert "oracle" not in open(os.path.join(ROOT, "dICP", f)).read()

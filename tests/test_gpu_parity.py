@@ -1,0 +1,381 @@
+"""Parity of the HIP path (libdicp_hip.so through dicp_amd) against the golden vectors
+generated from the reference and against the CPU oracle.  Needs an MI355X: `-m gpu`.
+
+Bars (BASELINE.json north_star): pose <= 1e-4, gradients <= 1e-3.  In float64 the kernels
+are held far tighter (1e-9 .. 1e-11); float32 runs are held to the north-star bars against
+the float64 reference.  kNN indices are integer work: exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from dicp_amd import _lib, _ops
+from dicp_amd.ICP import ICP
+from dicp_amd.loss import loss
+from dicp_amd.nn import nn
+from dicp_amd.synthetic import make_pairs
+from oracle import dicp_oracle as O
+from oracle.se3 import tran2vec
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def t(a, dtype=None, grad=False, dev=DEV):
+    x = torch.tensor(np.asarray(a), dtype=dtype, device=dev)
+    return x.requires_grad_(True) if grad else x
+
+
+def npy(x):
+    return x.detach().cpu().numpy()
+
+
+def check_result(res, g, prefix="", atol=1e-10):
+    np.testing.assert_allclose(npy(res["T"]), g[prefix + "T"], rtol=0, atol=atol)
+    assert res["deltas"].shape == g[prefix + "deltas"].shape
+    np.testing.assert_allclose(npy(res["deltas"]), g[prefix + "deltas"], rtol=0, atol=atol)
+    np.testing.assert_allclose(npy(res["costs"]), g[prefix + "costs"], rtol=1e-7, atol=atol)
+    if prefix + "weights" in g:
+        np.testing.assert_allclose(npy(res["weights"]), g[prefix + "weights"], rtol=0, atol=atol)
+    if prefix + "pc" in g:
+        np.testing.assert_allclose(npy(res["pc"]), g[prefix + "pc"], rtol=0, atol=atol)
+    np.testing.assert_array_equal(npy(res["stats"]["converged"]), g[prefix + "stats_converged"])
+    np.testing.assert_allclose(npy(res["stats"]["iterations"]), g[prefix + "stats_iterations"])
+    np.testing.assert_allclose(npy(res["stats"]["matched_ratio"]), g[prefix + "stats_matched_ratio"], atol=1e-7)
+
+
+# ------------------------------------------------------------------------- kNN
+def exact_or_tied(idx_gpu, x, y, tol):
+    """idx must equal the exact-f64 brute force unless the runner-up is within `tol` (squared distance)."""
+    idx, best, second = O.knn_exact_f64(x.cpu(), y.cpu())
+    got = idx_gpu.cpu().long()
+    bad = got != idx
+    if bad.any():
+        d_got = ((x.cpu().double() - torch.gather(y.cpu()[:, :, :3].double(), 1, got.unsqueeze(-1).expand(-1, -1, 3))) ** 2).sum(-1)
+        assert bool(((d_got - best)[bad] <= tol).all()), "kNN picked a point that is not (nearly) nearest"
+    return int(bad.sum())
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("N,n,m", [(1, 1, 1), (3, 70, 90), (2, 257, 16), (5, 1000, 2049), (2, 2100, 4100)])
+def test_knn_small_shapes(dtype, N, n, m):
+    g = torch.Generator().manual_seed(N * 1000 + n)
+    x = (torch.rand((N, n, 3), generator=g, dtype=torch.float64) * 10 - 5).to(dtype).to(DEV)
+    y = (torch.rand((N, m, 6), generator=g, dtype=torch.float64) * 10 - 5).to(dtype).to(DEV)
+    tgt4 = _ops.pack_target(y)
+    idx = _ops.knn(x, None, tgt4, m, _lib.KNN_VALU)
+    assert idx.dtype == torch.int32 and int(idx.min()) >= 0 and int(idx.max()) < m
+    if dtype == torch.float64:
+        assert torch.equal(idx.cpu().long(), O.nn_index(x.cpu(), y.cpu()))
+    else:
+        assert exact_or_tied(idx, x, y, 1e-4) <= max(1, N * n // 2000)
+        assert torch.equal(_ops.knn(x, None, tgt4, m, _lib.KNN_MFMA).cpu(), idx.cpu()) or \
+            exact_or_tied(_ops.knn(x, None, tgt4, m, _lib.KNN_MFMA), x, y, 1e-4) <= max(1, N * n // 2000)
+
+
+def test_knn_ties_take_lowest_index():
+    """torch.argmin semantics: duplicates of the nearest target -> first one."""
+    y = torch.zeros((1, 40, 3), dtype=torch.float32, device=DEV)
+    y[0, :, 0] = torch.arange(40, device=DEV) % 10          # each x value appears 4 times
+    x = torch.tensor([[[3.1, 0, 0], [8.9, 0, 0], [0.2, 0, 0]]], dtype=torch.float32, device=DEV)
+    tgt4 = _ops.pack_target(y)
+    for variant in (_lib.KNN_VALU, _lib.KNN_MFMA):
+        assert _ops.knn(x, None, tgt4, 40, variant).cpu().tolist() == [[3, 9, 0]]
+    yd = y.double()
+    assert _ops.knn(x.double(), None, _ops.pack_target(yd), 40, _lib.KNN_VALU).cpu().tolist() == [[3, 9, 0]]
+
+
+def test_knn_fused_transform_and_pad_rows():
+    """pose is applied inside the kernel (ICP.py:137); target pad rows (ICP.py:460) never win."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand((4, 300, 3), generator=g, dtype=torch.float64) * 4
+    y = torch.rand((4, 333, 6), generator=g, dtype=torch.float64) * 4
+    y[:, 300:] = 4000.0                                        # what batch_size_handling pads with
+    Tm = torch.stack([torch.tensor(np.linalg.inv(np.eye(4))) for _ in range(4)])
+    ang = 0.3
+    C = torch.tensor([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1.0]])
+    r = torch.tensor([0.2, -0.1, 0.3])
+    pose = torch.cat((C.reshape(9), r)).repeat(4, 1).to(DEV)
+    idx = _ops.knn(x.to(DEV), pose, _ops.pack_target(y.to(DEV)), 333)
+    want = O.nn_index(x @ C.T + r, y)
+    assert torch.equal(idx.cpu().long(), want) and int(idx.max()) < 300
+    del Tm
+
+
+@pytest.mark.parametrize("variant", [_lib.KNN_VALU, _lib.KNN_MFMA])
+def test_knn_big_launch_configs(variant):
+    """Exercises the Q=4 / NB=8 instantiations (>= 1M queries), ragged n and m."""
+    N, n, m = 66, 16001, 523
+    src, tgt = make_pairs(N, n, m, seed=3, dtype=torch.float32)
+    sd, td = src.to(DEV), tgt.to(DEV)
+    idx = _ops.knn(sd, None, _ops.pack_target(td), m, variant)
+    pick = [0, 17, 65]
+    assert exact_or_tied(idx[pick], sd[pick], td[pick], 1e-4) <= 8
+    # the mid-size instantiations
+    idx2 = _ops.knn(sd[:40], None, _ops.pack_target(td[:40]), m, variant)
+    assert torch.equal(idx2.cpu(), idx[:40].cpu())
+
+
+# ------------------------------------------------------------- C1: tests/data pair
+@pytest.mark.parametrize("name,icp_type,diff", [
+    ("c1_pt2pt_diff", "pt2pt", True),
+    ("c1_pt2pl_diff", "pt2pl", True),
+    ("c1_pt2pt_hard", "pt2pt", False),
+])
+def test_c1_float64(golden, name, icp_type, diff):
+    """tests/test_ICP.py:35-149 on the HIP path, float64 like the reference."""
+    g = golden(name)
+    trim, huber, tol, max_iter = g["params"]
+    src, tgt = t(g["source"], grad=True), t(g["target"], grad=True)
+    icp = ICP(icp_type=icp_type, differentiable=diff, max_iterations=int(max_iter), tolerance=float(tol))
+    res = icp.icp(src, tgt, t(g["T_init"]), trim_dist=float(trim), loss_fn={"name": "huber", "metric": float(huber)}, dim=2)
+    check_result(res, g)
+    err = tran2vec(g["T_ts_true"] @ np.linalg.inv(npy(res["T"])[0]))
+    assert np.linalg.norm(err) < float(tol)                                  # test_ICP.py:65-66
+    assert np.allclose(npy(res["pc"])[0], g["target"][:, :3], atol=1e-5)     # test_ICP.py:69
+    res["T"].sum().backward()
+    np.testing.assert_allclose(npy(src.grad), g["grad_source"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(npy(tgt.grad), g["grad_target"], rtol=0, atol=1e-10)
+    src2, tgt2 = t(g["source"], grad=True), t(g["target"], grad=True)
+    res2 = icp.icp(src2, tgt2, t(g["T_init"]), trim_dist=float(trim), loss_fn={"name": "huber", "metric": float(huber)}, dim=2)
+    (res2["pc"] ** 2).sum().backward()
+    np.testing.assert_allclose(npy(src2.grad), g["grad_source_pc2"], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(npy(tgt2.grad), g["grad_target_pc2"], rtol=0, atol=1e-8)
+
+
+@pytest.mark.parametrize("name,icp_type", [("c1_pt2pt_diff", "pt2pt"), ("c1_pt2pl_diff", "pt2pl")])
+def test_c1_float32_meets_north_star(golden, name, icp_type):
+    """float32 kernels vs the float64 reference: pose <= 1e-4, gradients <= 1e-3."""
+    g = golden(name)
+    trim, huber, tol, _ = g["params"]
+    src, tgt = t(g["source"], torch.float32, grad=True), t(g["target"], torch.float32, grad=True)
+    icp = ICP(icp_type=icp_type, differentiable=True, max_iterations=30, tolerance=float(tol))
+    res = icp.icp(src, tgt, t(g["T_init"], torch.float32), trim_dist=float(trim), loss_fn={"name": "huber", "metric": float(huber)}, dim=2)
+    assert res["T"].dtype == torch.float32
+    np.testing.assert_allclose(npy(res["T"]), g["T"], rtol=0, atol=1e-4)
+    res["T"].sum().backward()
+    np.testing.assert_allclose(npy(src.grad), g["grad_source"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(npy(tgt.grad), g["grad_target"], rtol=0, atol=1e-3)
+    g32 = golden(name + "_f32")                       # and against the reference's own float32 run
+    np.testing.assert_allclose(npy(res["T"]), g32["T"], rtol=0, atol=2e-5)
+
+
+# --------------------------------------------------- reference input-handling tests
+def test_ragged_list_batch(golden):
+    """tests/test_ICP_inputs.py:36-110: batch == per-item loop == reference."""
+    g = golden("input_types")
+    S = [t(g["s0"]), t(g["s1"]), t(g["s2"])]
+    Tg = [t(g["t0"]), t(g["t1"]), t(g["t2"])]
+    T0 = torch.stack([torch.eye(4, dtype=torch.float64, device=DEV)] * 3)
+    icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=25, tolerance=1e-8)
+    kw = dict(trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0}, dim=2)
+    batch = icp.icp(S, Tg, T0, **kw)
+    check_result(batch, g, "batch_")
+    for i in range(3):
+        single = icp.icp(S[i], Tg[i], T0[i], **kw)
+        check_result(single, g, "single%d_" % i)
+        err = tran2vec(npy(single["T"])[0] @ np.linalg.inv(npy(batch["T"])[i]))
+        assert np.linalg.norm(err) < 1e-8                                   # test_ICP_inputs.py:106-107
+    g2 = golden("input_types_pt2pt")
+    icp2 = ICP(icp_type="pt2pt", differentiable=True, max_iterations=25, tolerance=1e-8)
+    check_result(icp2.icp(S, [x[:, :3] for x in Tg], list(T0), **kw), g2, "batch_")
+
+
+def test_empty_clouds(golden, scan_map):
+    """tests/test_ICP_inputs.py:113-155: missing data returns T_init."""
+    scan, mp = scan_map
+    g = golden("zero_inputs")
+    S = [t(scan), [], []]
+    Tg = [[], t(mp), []]
+    T0 = torch.stack([torch.eye(4, dtype=torch.float64, device=DEV)] * 3)
+    icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=25, tolerance=1e-8)
+    batch = icp.icp(S, Tg, T0, trim_dist=5.0, loss_fn=None, dim=2)
+    check_result(batch, g, "batch_")
+    assert np.linalg.norm(npy(batch["T"]) - npy(T0)) < 1e-8
+    for i in range(3):
+        single = icp.icp(S[i], Tg[i], T0[i], trim_dist=5.0, loss_fn=None, dim=2)
+        check_result(single, g, "single%d_" % i)
+
+
+def test_weight_inputs(golden, scan_map):
+    """tests/test_ICP_inputs.py:157-211 (+ the weight gradients no reference test checks)."""
+    scan, mp = scan_map
+    g = golden("weight_inputs")
+    S = [t(scan[:, :3]), t(scan[:, :3]), t(np.vstack((scan[:, :3], g["junk"])))]
+    Tg = [t(mp)] * 3
+    W = [None, t(np.ones(65), grad=True), t(np.hstack((np.ones(65), np.zeros(10))), grad=True)]
+    T0 = torch.stack([torch.eye(4, dtype=torch.float64, device=DEV)] * 3)
+    icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=25, tolerance=1e-8)
+    kw = dict(trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0}, dim=2)
+    batch = icp.icp(S, Tg, T0, weight=W, **kw)
+    check_result(batch, g, "batch_")
+    batch["T"].sum().backward()
+    np.testing.assert_allclose(npy(W[1].grad), g["grad_w1"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(npy(W[2].grad), g["grad_w2"], rtol=0, atol=1e-10)
+    Ts = npy(batch["T"])
+    assert np.linalg.norm(Ts[0] - Ts[1]) < 1e-8 and np.linalg.norm(Ts[0] - Ts[2]) < 1e-8   # test_ICP_inputs.py:210-211
+
+
+def test_diff_vs_nondiff_and_padding(golden, scan_map):
+    """tests/test_ICP_inputs.py:213-271."""
+    scan, mp = scan_map
+    g = golden("diff_vs_nondiff")
+    s, tg = t(scan[:50, :3]), t(mp[:55])
+    T0 = torch.eye(4, dtype=torch.float64, device=DEV)
+    for lname, metric in (("huber", 1.0), ("cauchy", 0.5)):
+        outs = {}
+        for diff in (True, False):
+            icp = ICP(icp_type="pt2pl", differentiable=diff, max_iterations=25, tolerance=1e-8)
+            outs[diff] = icp.icp(s, tg, T0, trim_dist=5.0, loss_fn={"name": lname, "metric": metric}, dim=2)
+            check_result(outs[diff], g, "%s_%s_" % (lname, "diff" if diff else "hard"))
+        err = tran2vec(npy(outs[True]["T"])[0] @ np.linalg.inv(npy(outs[False]["T"])[0]))
+        assert np.linalg.norm(err) < 1e-8
+    gp = golden("padded_inputs")
+    icp = ICP(icp_type="pt2pt", differentiable=False, max_iterations=25, tolerance=1e-8)
+    icp.source_zeroes_are_pad = True
+    plain = icp.icp(s, tg, T0, dim=2)
+    padded = icp.icp(torch.cat((s, torch.zeros((20, 3), dtype=torch.float64, device=DEV))), tg, T0, dim=2)
+    check_result(plain, gp, "plain_")
+    check_result(padded, gp, "padded_")
+
+
+# ------------------------------------------------ 3-D matrix with all four gradients
+def matrix_keys(g):
+    return sorted(k[:-len("__T")] for k in g if k.endswith("__T"))
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_matrix3d(golden, dtype):
+    g = golden("matrix3d")
+    K = int(g["K"])
+    f64 = dtype == torch.float64
+    for key in matrix_keys(g):
+        icp_type, mode, lname, trim, d = key.split("_")
+        src = t(g["source"], dtype, grad=True)
+        tgt = t(g["target"] if icp_type == "pt2pl" else g["target"][:, :, :3], dtype, grad=True)
+        w = t(g["weight"], dtype, grad=True)
+        T0 = t(g["T_init"], dtype, grad=True)
+        icp = ICP(icp_type=icp_type, differentiable=(mode == "diff"), max_iterations=K, tolerance=1e-14)
+        icp.const_iter = True
+        res = icp.icp(src, tgt, T0, weight=w, trim_dist=(1.5 if trim == "trim" else None),
+                      loss_fn=None if lname == "none" else {"name": lname, "metric": 0.3}, dim=int(d[1]))
+        np.testing.assert_allclose(npy(res["T"]), g[key + "__T"], rtol=0, atol=1e-10 if f64 else 1e-4, err_msg=key)
+        np.testing.assert_allclose(npy(res["deltas"]), g[key + "__deltas"], rtol=0, atol=1e-10 if f64 else 1e-4, err_msg=key)
+        np.testing.assert_allclose(npy(res["weights"])[:, -1, :, 0], g[key + "__w_last"], rtol=0, atol=1e-10 if f64 else 2e-3, err_msg=key)
+        np.testing.assert_allclose(npy(res["stats"]["iterations"]), g[key + "__stats_iterations"])
+        ((res["T"] * t(g["gT"], dtype)).sum() + (res["pc"] * t(g["gpc"], dtype)).sum()).backward()
+        for nm, leaf in (("source", src), ("target", tgt), ("weight", w), ("T_init", T0)):
+            want = g[key + "__grad_" + nm]
+            if f64:
+                np.testing.assert_allclose(npy(leaf.grad), want, rtol=1e-8, atol=1e-9, err_msg=key + " " + nm)
+            elif mode == "diff":
+                # north-star bar (1e-3) relative to the gradient's scale; hard-weight variants can flip a
+                # where() branch in float32, so only the differentiable ones are held in float32
+                scale = max(1.0, float(np.abs(want).max()))
+                np.testing.assert_allclose(npy(leaf.grad), want, rtol=0, atol=1e-3 * scale, err_msg=key + " " + nm)
+
+
+# ---------------------------------------------------------------- nn / loss classes
+def test_nn_class(golden):
+    g = golden("nn_vectors")
+    y = t(g["y"], grad=True)
+    x = t(g["x"], grad=True)
+    hard = nn(differentiable=False)
+    nb = hard.find_nn(x, y)
+    np.testing.assert_array_equal(npy(nb), g["nb"])
+    (nb * t(g["cot"])).sum().backward()
+    np.testing.assert_allclose(npy(y.grad), g["grad_y"], rtol=0, atol=1e-12)
+    assert x.grad is None                                                  # argmin has no gradient
+    np.testing.assert_array_equal(npy(hard.find_nn(t(g["x"]).transpose(1, 2), t(g["y"]).transpose(1, 2))), g["nb_T"])
+    np.testing.assert_array_equal(npy(hard.find_nn(t(g["x"][0]), t(g["y"][0]))), g["nb_2d"])
+    np.testing.assert_array_equal(npy(nn(differentiable=True, use_gumbel=False).find_nn(t(g["x"]), t(g["y"]))), g["nb"])
+    # CPU tensors in, CPU tensors out (computed on the HIP device)
+    out_cpu = hard.find_nn(torch.tensor(g["x"]), torch.tensor(g["y"]))
+    assert out_cpu.device.type == "cpu"
+    np.testing.assert_array_equal(out_cpu.numpy(), g["nb"])
+    # Gumbel path with the reference's uniform draw injected
+    xs, ys = t(g["x"], torch.float32, grad=True), t(g["y"], torch.float32, grad=True)
+    soft = nn(differentiable=True, use_gumbel=True, eps=1e-10, tau=0.1)
+    soft.gumbel_chunk = 32
+    nb_soft = soft.find_nn(xs, ys, U=t(g["U"]))
+    np.testing.assert_allclose(npy(nb_soft), g["nb_soft"], rtol=0, atol=2e-5)
+    (nb_soft * t(g["cot"], torch.float32)).sum().backward()
+    np.testing.assert_allclose(npy(xs.grad), g["grad_x_soft"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(npy(ys.grad), g["grad_y_soft"], rtol=1e-3, atol=1e-4)
+
+
+def test_nn_known_answer(golden):
+    """/root/reference/tests/test_nn.py:12-41 on the HIP device (default ctor = Gumbel path)."""
+    g = golden("nn_vectors")
+    torch.manual_seed(0)
+    d = nn(differentiable=True)
+    pts = t(g["kat_points"], grad=True)
+    q = t(g["kat_query"], grad=True)
+    near = d.find_nn(q, pts)
+    assert torch.allclose(near[0, 0], t(g["kat_expect1"]), atol=1e-3)
+    near.sum().backward()
+    assert q.grad is not None and pts.grad is not None
+    assert not torch.isnan(q.grad).any() and not torch.isnan(pts.grad).any()
+    h = nn(differentiable=False)
+    assert torch.equal(h.find_nn(q, pts)[0, 0], t(g["kat_expect1"]))
+    pts2 = torch.cat((pts.detach(), t(g["kat_extra"]).view(1, -1)))
+    assert torch.equal(h.find_nn(q, pts2)[0, 0], t(g["kat_expect2"]))
+
+
+def test_loss_class(golden):
+    g = golden("loss_vectors")
+    for name, metric in (("huber", 1.0), ("cauchy", 0.5), ("trim", 2.0)):
+        for diff in (True, False):
+            for tag in ("e1", "e3", "eb"):
+                key = "%s_%s_%s" % (name, "diff" if diff else "hard", tag)
+                e = t(g[tag], grad=True)
+                w = loss(name=name, metric=metric, differentiable=diff, tanh_steepness=5.0).get_weight(e)
+                assert tuple(w.shape) == g[key].shape, key
+                np.testing.assert_allclose(npy(w), g[key], rtol=0, atol=1e-13, err_msg=key)
+                if key + "_grad" in g:
+                    w.sum().backward()
+                    np.testing.assert_allclose(npy(e.grad), g[key + "_grad"], rtol=0, atol=1e-12, err_msg=key)
+    with pytest.raises(ValueError):
+        loss("tukey").get_weight(t(g["e1"]))
+
+
+# -------------------------------------------------------- oracle parity at larger sizes
+@pytest.mark.parametrize("icp_type,variant", [("pt2pl", _lib.KNN_VALU), ("pt2pt", _lib.KNN_VALU), ("pt2pl", _lib.KNN_MFMA)])
+def test_synthetic_float32_vs_oracle(icp_type, variant):
+    """Benchmark-shaped input at a size the oracle finishes in seconds (B=4, 2048 pts)."""
+    N, n, m, K = 4, 2048, 2048, 5
+    src, tgt = make_pairs(N, n, m, seed=2, dtype=torch.float32)
+    tg = tgt if icp_type == "pt2pl" else tgt[:, :, :3].contiguous()
+    kw = dict(trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0}, dim=3)
+    sc, tc = src.clone().requires_grad_(True), tg.clone().requires_grad_(True)
+    rows = 3 if icp_type == "pt2pt" else 1
+    ref = O.icp_batched(sc, tc, torch.eye(4).repeat(N, 1, 1), torch.ones(N, n * rows), icp_type=icp_type,
+                        differentiable=True, max_iterations=K, tolerance=1e-12, const_iter=True, **kw)
+    ref["T"].sum().backward()
+    sd, td = src.to(DEV).requires_grad_(True), tg.to(DEV).requires_grad_(True)
+    icp = ICP(icp_type=icp_type, differentiable=True, max_iterations=K, tolerance=1e-12)
+    icp.const_iter = True
+    icp.knn_variant = variant
+    out = icp.icp(sd, td, torch.eye(4, device=DEV).repeat(N, 1, 1), **kw)
+    out["T"].sum().backward()
+    assert out["deltas"].shape == (N, K, 6, 1) and out["weights"].shape == (N, K, n * rows, 1)
+    np.testing.assert_allclose(npy(out["T"]), npy(ref["T"]), rtol=0, atol=1e-4)
+    np.testing.assert_allclose(npy(out["pc"]), npy(ref["pc"]), rtol=0, atol=2e-4)
+    np.testing.assert_allclose(npy(out["costs"]), npy(ref["costs"]), rtol=2e-3, atol=1e-4)
+    np.testing.assert_allclose(npy(sd.grad), npy(sc.grad), rtol=0, atol=1e-3)
+    np.testing.assert_allclose(npy(td.grad), npy(tc.grad), rtol=0, atol=1e-3)
+    assert float(npy(out["stats"]["iterations"]).min()) == K
+
+
+def test_cpu_tensors_round_trip(golden):
+    """The reference's tests pass CPU tensors: they are computed on the GPU and come back on the CPU."""
+    g = golden("c1_pt2pl_diff")
+    src = torch.tensor(g["source"], requires_grad=True)
+    tgt = torch.tensor(g["target"], requires_grad=True)
+    icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=100, tolerance=1e-10)
+    res = icp.icp(src, tgt, torch.tensor(g["T_init"]), trim_dist=5.0, loss_fn={"name": "huber", "metric": 10.0}, dim=2)
+    assert res["T"].device.type == "cpu" and res["stats"]["converged"].device.type == "cpu"
+    np.testing.assert_allclose(res["T"].detach().numpy(), g["T"], rtol=0, atol=1e-10)
+    res["T"].sum().backward()
+    np.testing.assert_allclose(src.grad.numpy(), g["grad_source"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(tgt.grad.numpy(), g["grad_target"], rtol=0, atol=1e-10)

@@ -70,7 +70,9 @@ def cpu_baseline(n, m, budget_s=25.0):
     on this host's cores, fwd+bwd, on a bounded sample: chunks of 2 clouds x 3 iterations
     ((2,n,m) fp32 distances = 2 GiB per chunk at 16384^2; per-cloud cost is flat in B)."""
     from oracle import dicp_oracle as O
-    cores = os.cpu_count() or 1
+    # 16 threads is the fastest setting for this op sequence on the GPU box's 2 x EPYC 9575F host
+    # (profiles/r01_cpu_threads_probe.txt: 8/16/32/64/128/256 threads -> 3.9/5.5/5.0/3.4/2.1/0.1 cloud-it/s)
+    cores = min(16, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     Bc, K = 2, 3
     src, tgt = make_pairs(Bc, n, m, seed=3, dtype=torch.float32)

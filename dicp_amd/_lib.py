@@ -84,6 +84,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # libdicp_hip.so must share PyTorch's HIP runtime (PyTorch bundles its own libamdhip64.so.7):
+    # importing torch first makes the loader resolve our NEEDED libamdhip64.so.7 to that copy.  A
+    # second runtime (from /opt/rocm) in one process sees no device (hipErrorNoDevice).
+    import torch  # noqa: F401
     with _lock:
         if _lib is None:
             if not os.path.exists(LIB_PATH):

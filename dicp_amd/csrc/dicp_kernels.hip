@@ -519,17 +519,21 @@ __global__ __launch_bounds__(BLOCK) void loss_weight_bwd_kernel(int loss, int di
     T dw = T(0);      // d w / d en
     if (loss == DICP_LOSS_HUBER) {
         if (diff) dw = -T(2) * en * wv * wv / (metric * metric);
-        else      dw = (en > metric) ? -metric / (en * en) : T(0);
+        else      dw = hard_huber_slope(en, metric);
     } else if (loss == DICP_LOSS_CAUCHY) {
         dw = -T(2) * en * wv * wv / (metric * metric);
     } else if (diff) {
         dw = -T(0.5) * kk * (T(1) - th * th);
     }
-    const T f = (en > T(0)) ? gw[i] * dw / en : T(0);
-    for (int k = 0; k < r; ++k) gerr[i * r + k] = f * e[k];
+    // torch's norm backward is e/|e| with 0 at e == 0; a NaN slope (hard huber at 0) still propagates
+    for (int k = 0; k < r; ++k) gerr[i * r + k] = (en > T(0)) ? gw[i] * dw * e[k] / en : gw[i] * dw * T(0);
 }
 
 // ------------------------------------------------------------------- host helpers
+// hipGetLastError() is sticky per host thread and the HIP runtime is shared with PyTorch, which can
+// leave an unrelated error behind: every entry point clears it (begin_launch) before launching and
+// reads it back (launch_status) after, so the status returned is that of OUR launch only.
+inline void begin_launch() { (void)hipGetLastError(); }
 inline int launch_status() {
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
@@ -577,6 +581,7 @@ int dicp_pack_target(int dtype, const void* tgt, int N, int m, int c, void* tgt4
     if (N <= 0 || m <= 0 || (c != 3 && c != 6) || m_pad != dicp_padded_targets(m)) return DICP_ERR_SHAPE;
     if ((uintptr_t)tgt4 % (dtype == DICP_F32 ? 16 : 32)) return DICP_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
+    begin_launch();
     const unsigned g = blocks_for((size_t)N * m_pad);
     if (dtype == DICP_F32) pack_kernel<float><<<g, BLOCK, 0, st>>>((const float*)tgt, N, m, c, (float4*)tgt4, m_pad);
     else                   pack_kernel<double><<<g, BLOCK, 0, st>>>((const double*)tgt, N, m, c, (double4*)tgt4, m_pad);
@@ -592,6 +597,7 @@ int dicp_knn(int dtype, const void* src, const void* pose, const void* tgt4, int
     if (variant == DICP_KNN_MFMA && dtype != DICP_F32) return DICP_ERR_DTYPE;
     if ((uintptr_t)tgt4 % (dtype == DICP_F32 ? 16 : 32)) return DICP_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
+    begin_launch();
     if (variant == DICP_KNN_AUTO) variant = DICP_KNN_VALU;
     if (variant == DICP_KNN_MFMA) {
         const long q_total = (long)N * n;
@@ -613,6 +619,7 @@ int dicp_gather_rows(int dtype, const void* tgt, const int32_t* idx, int N, int 
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || n <= 0 || m <= 0 || c <= 0) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
+    begin_launch();
     const unsigned g = blocks_for((size_t)N * n * c);
     if (dtype == DICP_F32) gather_kernel<float><<<g, BLOCK, 0, st>>>((const float*)tgt, idx, N, n, m, c, (float*)out);
     else                   gather_kernel<double><<<g, BLOCK, 0, st>>>((const double*)tgt, idx, N, n, m, c, (double*)out);
@@ -624,6 +631,7 @@ int dicp_scatter_add_rows(int dtype, const void* gout, const int32_t* idx, int N
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || n <= 0 || m <= 0 || c <= 0) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
+    begin_launch();
     const unsigned g = blocks_for((size_t)N * n * c);
     if (dtype == DICP_F32) scatter_add_kernel<float><<<g, BLOCK, 0, st>>>((const float*)gout, idx, N, n, m, c, (float*)gtgt);
     else                   scatter_add_kernel<double><<<g, BLOCK, 0, st>>>((const double*)gout, idx, N, n, m, c, (double*)gtgt);
@@ -646,6 +654,7 @@ int dicp_accumulate(int dtype, const dicp_weight_params* prm, const void* src, c
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || n <= 0 || m <= 0 || (w_out && w_stride < n)) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
+    begin_launch();
     const WeightParams P = to_params(prm);
     const int bpc = dicp_accumulate_blocks(n);
     const unsigned g = grid_for(N, bpc);
@@ -664,6 +673,7 @@ int dicp_step(int dtype, const dicp_step_io* io, int N, void* stream) {
     if (N <= 0 || io->nblk <= 0 || (io->dim != 2 && io->dim != 3) || io->delta_stride < 6 || io->cost_stride < 1 ||
         (io->w_cur && io->w_stride < io->n)) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
+    begin_launch();
     if (dtype == DICP_F32) step_kernel<float><<<N, WAVE, 0, st>>>(*io, N);
     else                   step_kernel<double><<<N, WAVE, 0, st>>>(*io, N);
     return launch_status();
@@ -676,6 +686,7 @@ int dicp_step_bwd(int dtype, const double* gpose_in, const void* bwd_partials, i
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || (dim != 2 && dim != 3) || delta_stride < 6 || (bwd_partials && nblk <= 0)) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
+    begin_launch();
     if (dtype == DICP_F32)
         step_bwd_kernel<float><<<N, WAVE, 0, st>>>(gpose_in, (const float*)bwd_partials, nblk, dim, (const float*)pose_k,
                                                   (const float*)delta_k, (long)delta_stride, areg_k, (float*)gs, (float*)gb, gpose_out, N);
@@ -694,6 +705,7 @@ int dicp_accumulate_bwd(int dtype, const dicp_weight_params* prm, const void* sr
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || n <= 0 || m <= 0) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
+    begin_launch();
     const WeightParams P = to_params(prm);
     const int bpc = dicp_accumulate_blocks(n);
     const unsigned g = grid_for(N, bpc);
@@ -712,6 +724,7 @@ int dicp_loss_weight(int dtype, int loss, int differentiable, double metric, dou
     if (loss < DICP_LOSS_HUBER || loss > DICP_LOSS_TRIM) return DICP_ERR_ENUM;    // loss.py:19
     if (rows <= 0 || r < 1 || r > 3) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
+    begin_launch();
     const unsigned g = blocks_for((size_t)rows);
     if (dtype == DICP_F32) loss_weight_kernel<float><<<g, BLOCK, 0, st>>>(loss, differentiable, (float)metric, (float)tanh_k, (const float*)err, (long)rows, r, (float*)w);
     else                   loss_weight_kernel<double><<<g, BLOCK, 0, st>>>(loss, differentiable, metric, tanh_k, (const double*)err, (long)rows, r, (double*)w);
@@ -725,6 +738,7 @@ int dicp_loss_weight_bwd(int dtype, int loss, int differentiable, double metric,
     if (loss < DICP_LOSS_HUBER || loss > DICP_LOSS_TRIM) return DICP_ERR_ENUM;
     if (rows <= 0 || r < 1 || r > 3) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
+    begin_launch();
     const unsigned g = blocks_for((size_t)rows);
     if (dtype == DICP_F32) loss_weight_bwd_kernel<float><<<g, BLOCK, 0, st>>>(loss, differentiable, (float)metric, (float)tanh_k, (const float*)err, (const float*)gw, (long)rows, r, (float*)gerr);
     else                   loss_weight_bwd_kernel<double><<<g, BLOCK, 0, st>>>(loss, differentiable, metric, tanh_k, (const double*)err, (const double*)gw, (long)rows, r, (double*)gerr);

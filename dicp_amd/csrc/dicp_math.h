@@ -55,6 +55,14 @@ DICP_HD double m_tanh(double x) { return tanh(x); }
 DICP_HD float  m_abs(float x)   { return fabsf(x); }
 DICP_HD double m_abs(double x)  { return fabs(x); }
 
+// d/d(en) of the hard Huber weight where(en > delta, delta/en, 1), loss.py:32.  autograd differentiates
+// BOTH where() branches and masks afterwards, so at en == 0 the reference's gradient is 0 * (-inf) = NaN;
+// that (tested-as-is) behaviour is kept rather than silently repaired.
+template <typename T> DICP_HD T hard_huber_slope(T en, T delta) {
+    if (en > delta) return -delta / (en * en);
+    return (en == T(0)) ? (T(0) * (-delta / (en * en))) : T(0);
+}
+
 template <typename T> DICP_HD void cross3(const T* a, const T* b, T* o) {
     o[0] = a[1] * b[2] - a[2] * b[1];
     o[1] = a[2] * b[0] - a[0] * b[2];
@@ -257,7 +265,7 @@ DICP_HD void point_backward(const WeightParams& P, const T* C, const T* r, const
     T dlw_den = T(0);     // d lw / d en
     if (P.loss == LOSS_HUBER) {
         if (P.differentiable) dlw_den = -T(2) * s.en * s.lw * s.lw / (dl * dl);
-        else                  dlw_den = (s.en > dl) ? -dl / (s.en * s.en) : T(0);
+        else                  dlw_den = hard_huber_slope(s.en, dl);
     } else if (P.loss == LOSS_CAUCHY) {
         dlw_den = -T(2) * s.en * s.lw * s.lw / (dl * dl);
     }
@@ -265,8 +273,9 @@ DICP_HD void point_backward(const WeightParams& P, const T* C, const T* r, const
         // en = |e| ; torch's norm backward gives e/|e| (0 at e == 0)
         const T sgn = (s.e > T(0)) ? T(1) : ((s.e < T(0)) ? T(-1) : T(0));
         ebar_s += lwbar * dlw_den * sgn;
-    } else if (s.d3 > T(0)) {
-        const T f = lwbar * dlw_den / s.d3;
+    } else {
+        // torch's vector-norm backward is e3/|e3|, and 0 at e3 == 0 (a NaN slope still propagates)
+        const T f = (s.d3 > T(0)) ? lwbar * dlw_den / s.d3 : lwbar * dlw_den * T(0);
         e3bar[0] += f * s.e3[0]; e3bar[1] += f * s.e3[1]; e3bar[2] += f * s.e3[2];
     }
     // soft trim gate -> e3 (hard gate has no gradient)

@@ -36,7 +36,9 @@ def check_result(res, g, prefix="", atol=1e-10):
     np.testing.assert_allclose(npy(res["deltas"]), g[prefix + "deltas"], rtol=0, atol=atol)
     np.testing.assert_allclose(npy(res["costs"]), g[prefix + "costs"], rtol=1e-7, atol=atol)
     if prefix + "weights" in g:
-        np.testing.assert_allclose(npy(res["weights"]), g[prefix + "weights"], rtol=0, atol=atol)
+        # weights see the pose through tanh(5(tau-|e|)): ~10x the pose error, and the kernels' exact
+        # Rodrigues differs from torch.matrix_exp (the reference) by ~4e-12 per iteration
+        np.testing.assert_allclose(npy(res["weights"]), g[prefix + "weights"], rtol=0, atol=10 * atol)
     if prefix + "pc" in g:
         np.testing.assert_allclose(npy(res["pc"]), g[prefix + "pc"], rtol=0, atol=atol)
     np.testing.assert_array_equal(npy(res["stats"]["converged"]), g[prefix + "stats_converged"])

@@ -144,3 +144,28 @@ def test_solver_and_exp_small_angles(hc):
             np.testing.assert_allclose(Cn.reshape(3, 3), scipy.linalg.expm(Kx).T, rtol=0, atol=2e-15)
             np.testing.assert_allclose(Cn.reshape(3, 3), torch.matrix_exp(torch.tensor(Kx)).numpy().T, rtol=0, atol=1e-10)
             np.testing.assert_allclose(rn, -d6[3:], rtol=0, atol=0)
+
+
+def test_hard_huber_zero_residual_is_nan_like_reference(hc):
+    """Reference quirk kept on purpose: with non-differentiable Huber an exactly-zero residual makes
+    autograd produce 0*(-inf)=NaN (loss.py:32 through torch.where); the closed-form adjoint does too."""
+    torch.manual_seed(0)
+    tgt = torch.rand(1, 20, 6, dtype=torch.float64)
+    tgt[:, :, 3:] /= tgt[:, :, 3:].norm(dim=2, keepdim=True)
+    src = tgt[:, :10, :3].clone() + 0.01 * torch.rand(1, 10, 3, dtype=torch.float64)
+    src[0, 0] = tgt[0, 0, :3]
+    for icp_type in ("pt2pl", "pt2pt"):
+        tg = tgt if icp_type == "pt2pl" else tgt[:, :, :3].contiguous()
+        s, t = src.clone().requires_grad_(True), tg.clone().requires_grad_(True)
+        rows = 3 if icp_type == "pt2pt" else 1
+        out = O.icp_batched(s, t, torch.eye(4, dtype=torch.float64)[None], torch.ones(1, 10 * rows, dtype=torch.float64),
+                            icp_type=icp_type, differentiable=False, max_iterations=1, loss_fn={"name": "huber", "metric": 1.0})
+        out["T"].sum().backward()
+        P = WeightParams(mode=1 if icp_type == "pt2pl" else 0, trim_on=0, differentiable=0, loss=1,
+                         trim_dist=0.0, tanh_k=5.0, loss_delta=1.0, match_thresh=0.0)
+        T, saved, gs, gt, gw, gT0 = run_chain(hc, src[0].numpy(), tg[0].numpy(), np.ones(10), np.eye(4), P, 1, 3,
+                                              np.ones((4, 4)), np.zeros((10, 3)))
+        np.testing.assert_array_equal(np.isnan(gs), np.isnan(s.grad[0].numpy()))
+        ok = ~np.isnan(gs)
+        np.testing.assert_allclose(gs[ok], s.grad[0].numpy()[ok], rtol=1e-8, atol=1e-12)
+        assert np.isnan(gs[0]).all() and not np.isnan(gs[1:]).any()

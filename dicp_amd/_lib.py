@@ -10,7 +10,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "libdicp_hip.so")
+LIB_PATH = os.environ.get("DICP_HIP_LIB") or os.path.join(_HERE, "libdicp_hip.so")   # env override: A/B builds
 SOURCES = [os.path.join(_HERE, "csrc", "dicp_kernels.hip")]
 HEADERS = [os.path.join(_HERE, "csrc", "dicp_math.h"), os.path.join(_ROOT, "include", "dicp_hip.h")]
 

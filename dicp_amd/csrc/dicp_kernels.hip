@@ -27,7 +27,6 @@ namespace {
 constexpr int BLOCK = 256;
 constexpr int WAVE = 64;
 constexpr int ACC_PTS = 1024;          // source points per accumulate block
-constexpr int KNN_CHUNK = 8;           // targets per running-min update (VALU kernel)
 constexpr int KNN_PAD = 16;            // m_pad granularity (MFMA tile height)
 
 template <typename T> struct V4;
@@ -99,7 +98,7 @@ __device__ __forceinline__ T score(const T* nx, const T4& y) {
 // lane only tracks the running minimum VALUE (v_min3) and which chunk last improved it;
 // the index inside that chunk is recovered once at the end (strict <, ascending order,
 // so ties resolve to the lowest index exactly like torch.argmin).
-template <typename T, int Q, int TILE>
+template <typename T, int Q, int TILE, int CH>
 __global__ __launch_bounds__(BLOCK) void knn_valu_kernel(const T* __restrict__ src, const T* __restrict__ pose,
                                                          const typename V4<T>::type* __restrict__ tgt4,
                                                          int32_t* __restrict__ idx, int N, int n, int m, int m_pad, int bpc) {
@@ -133,16 +132,17 @@ __global__ __launch_bounds__(BLOCK) void knn_valu_kernel(const T* __restrict__ s
         const int len = min(TILE, m_pad - base);            // multiple of 16
         for (int t = tid; t < len; t += BLOCK) tile[t] = tg[base + t];
         __syncthreads();
-        for (int j0 = 0; j0 < len; j0 += KNN_CHUNK) {
-            T4 y[KNN_CHUNK];
+        for (int j0 = 0; j0 < len; j0 += CH) {
+            T4 y[CH];
 #pragma unroll
-            for (int k = 0; k < KNN_CHUNK; ++k) y[k] = tile[j0 + k];
+            for (int k = 0; k < CH; ++k) y[k] = tile[j0 + k];
 #pragma unroll
             for (int qi = 0; qi < Q; ++qi) {
                 T c = best[qi];
 #pragma unroll
-                for (int k = 0; k < KNN_CHUNK; ++k) c = min_t(c, score<T, T4>(nx[qi], y[k]));
-                if (c < best[qi]) { best[qi] = c; bchunk[qi] = base + j0; }
+                for (int k = 0; k < CH; ++k) c = min_t(c, score<T, T4>(nx[qi], y[k]));
+                bchunk[qi] = (c < best[qi]) ? base + j0 : bchunk[qi];
+                best[qi] = c;                               // c = min(best, chunk): no select needed
             }
         }
         __syncthreads();
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(BLOCK) void knn_valu_kernel(const T* __restrict__ s
             T bv = inf_v<T>();
             int bj = bchunk[qi];
 #pragma unroll
-            for (int k = 0; k < KNN_CHUNK; ++k) {
+            for (int k = 0; k < CH; ++k) {
                 const T s = score<T, T4>(nx[qi], cp[k]);
                 if (s < bv) { bv = s; bj = bchunk[qi] + k; }
             }
@@ -217,12 +217,15 @@ __global__ __launch_bounds__(BLOCK) void knn_mfma_kernel(const float* __restrict
         __syncthreads();
         for (int t0 = 0; t0 < len; t0 += 16) {
             const float a = tl[kq * TS + t0 + ql];          // A[target t0+ql][k = kq]
+            f32x4 d[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) d[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq[nb], zero, 0, 0, 0);
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq[nb], zero, 0, 0, 0);
-                float c = min_t(min_t(best[nb], d[0]), d[1]);
-                c = min_t(min_t(c, d[2]), d[3]);
-                if (c < best[nb]) { best[nb] = c; bt[nb] = base + t0; }
+                float c = min_t(min_t(best[nb], d[nb][0]), d[nb][1]);
+                c = min_t(min_t(c, d[nb][2]), d[nb][3]);
+                bt[nb] = (c < best[nb]) ? base + t0 : bt[nb];
+                best[nb] = c;
             }
         }
         __syncthreads();
@@ -395,6 +398,11 @@ __global__ __launch_bounds__(WAVE) void step_kernel(dicp_step_io io, int N) {
 }
 
 // ---------------------------------------------------------------- accumulate bwd
+// Target gradients are a scatter-add of one 12/24-byte row per source point.  Float atomics execute at the
+// memory side in 64-byte requests, and 64 lanes adding to 64 different rows cost 64 requests per
+// instruction (MI355X_MICROARCH.md, Global float atomics).  So each wave first transposes its 64 rows
+// through LDS: in the add instructions lane l carries element l of the flattened [point][column] list, i.e.
+// the CV floats of one row sit in CV consecutive lanes and leave L2 as one (sometimes two) requests.
 template <typename T, int MODE>
 __global__ __launch_bounds__(BLOCK) void accumulate_bwd_kernel(WeightParams P, const T* __restrict__ src, const T* __restrict__ tgt, int c,
                                                                const int32_t* __restrict__ idx, const T* __restrict__ pose,
@@ -403,9 +411,13 @@ __global__ __launch_bounds__(BLOCK) void accumulate_bwd_kernel(WeightParams P, c
                                                                int N, int n, int m, int bpc,
                                                                T* __restrict__ gsrc, T* __restrict__ gtgt, T* __restrict__ gw,
                                                                T* __restrict__ bwd_partials) {
+    constexpr int CV = (MODE == MODE_PT2PL) ? 6 : 3;        // gradient columns per target row
     __shared__ T red[(BLOCK / WAVE) * NBWD_PAD];
+    __shared__ T stage_v[(BLOCK / WAVE) * WAVE * CV];
+    __shared__ int stage_j[BLOCK];
     int cloud, blk;
     if (!decode_block(bpc, N, cloud, blk)) return;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
     T C[9], r[3], Gs[36], Gb[6];
     load_pose(pose, cloud, C, r);
 #pragma unroll
@@ -416,31 +428,43 @@ __global__ __launch_bounds__(BLOCK) void accumulate_bwd_kernel(WeightParams P, c
     T acc[NBWD];
 #pragma unroll
     for (int k = 0; k < NBWD; ++k) acc[k] = T(0);
+    T* sv = stage_v + wave * (WAVE * CV);
+    int* sj = stage_j + wave * WAVE;
+    T* grow = gtgt ? gtgt + (size_t)cloud * m * c : nullptr;
     const int end = min(n, (blk + 1) * ACC_PTS);
-    for (int i = blk * ACC_PTS + threadIdx.x; i < end; i += BLOCK) {
-        const size_t pt = (size_t)cloud * n + i;
-        const T* sp = src + pt * 3;
-        const T p[3] = {sp[0], sp[1], sp[2]};
-        const int j = min(max(idx[pt], 0), m - 1);
-        const size_t row = ((size_t)cloud * m + j) * c;
-        const T* yp = tgt + row;
-        const T y[3] = {yp[0], yp[1], yp[2]};
-        T nrm[3] = {T(0), T(0), T(0)};
-        if (MODE == MODE_PT2PL) { nrm[0] = yp[3]; nrm[1] = yp[4]; nrm[2] = yp[5]; }
-        T gp[3], gy[3], gn[3], gw0;
-        point_backward<T, MODE>(P, C, r, p, y, nrm, w_init[pt] * live, Gs, Gb, gp, gy, gn, gw0, acc, acc + 9);
-        T* gsp = gsrc + pt * 3;
-        gsp[0] += gp[0]; gsp[1] += gp[1]; gsp[2] += gp[2];
-        if (gw) gw[pt] += gw0 * live;
-        if (gtgt) {
-            unsafeAtomicAdd(&gtgt[row + 0], gy[0]);
-            unsafeAtomicAdd(&gtgt[row + 1], gy[1]);
-            unsafeAtomicAdd(&gtgt[row + 2], gy[2]);
-            if (MODE == MODE_PT2PL) {
-                unsafeAtomicAdd(&gtgt[row + 3], gn[0]);
-                unsafeAtomicAdd(&gtgt[row + 4], gn[1]);
-                unsafeAtomicAdd(&gtgt[row + 5], gn[2]);
+    for (int base = blk * ACC_PTS; base < end; base += BLOCK) {     // trip count is block-uniform
+        const int i = base + tid;
+        const bool on = i < end;
+        T gy[3] = {T(0), T(0), T(0)}, gn[3] = {T(0), T(0), T(0)};
+        int j = -1;
+        if (on) {
+            const size_t pt = (size_t)cloud * n + i;
+            const T* sp = src + pt * 3;
+            const T p[3] = {sp[0], sp[1], sp[2]};
+            j = min(max(idx[pt], 0), m - 1);
+            const T* yp = tgt + ((size_t)cloud * m + j) * c;
+            const T y[3] = {yp[0], yp[1], yp[2]};
+            T nrm[3] = {T(0), T(0), T(0)};
+            if (MODE == MODE_PT2PL) { nrm[0] = yp[3]; nrm[1] = yp[4]; nrm[2] = yp[5]; }
+            T gp[3], gw0;
+            point_backward<T, MODE>(P, C, r, p, y, nrm, w_init[pt] * live, Gs, Gb, gp, gy, gn, gw0, acc, acc + 9);
+            T* gsp = gsrc + pt * 3;
+            gsp[0] += gp[0]; gsp[1] += gp[1]; gsp[2] += gp[2];
+            if (gw) gw[pt] += gw0 * live;
+        }
+        if (grow) {
+            sj[lane] = j;
+            sv[lane * CV + 0] = gy[0]; sv[lane * CV + 1] = gy[1]; sv[lane * CV + 2] = gy[2];
+            if (MODE == MODE_PT2PL) { sv[lane * CV + 3] = gn[0]; sv[lane * CV + 4] = gn[1]; sv[lane * CV + 5] = gn[2]; }
+            __builtin_amdgcn_wave_barrier();                // same-wave LDS hand-off: DS ops retire in order
+#pragma unroll
+            for (int t = 0; t < CV; ++t) {
+                const int e = t * WAVE + lane;
+                const int pnt = e / CV, col = e - pnt * CV;
+                const int jj = sj[pnt];
+                if (jj >= 0) unsafeAtomicAdd(&grow[(size_t)jj * c + col], sv[e]);
             }
+            __builtin_amdgcn_wave_barrier();
         }
     }
     block_reduce_store<T, NBWD, NBWD_PAD>(acc, bwd_partials + ((size_t)cloud * bpc + blk) * NBWD_PAD, red);
@@ -547,21 +571,45 @@ inline WeightParams to_params(const dicp_weight_params* p) {
 inline bool bad_dtype(int d) { return d != DICP_F32 && d != DICP_F64; }
 inline unsigned blocks_for(size_t total) { return (unsigned)((total + BLOCK - 1) / BLOCK); }
 
-template <typename T>
-int knn_valu_launch(const void* src, const void* pose, const void* tgt4, int N, int n, int m, int m_pad, int32_t* idx, hipStream_t st) {
+template <typename T, int Q, int CH>
+void knn_valu_go(const void* src, const void* pose, const void* tgt4, int N, int n, int m, int m_pad, int32_t* idx, hipStream_t st) {
     using T4 = typename V4<T>::type;
     constexpr int TILE = sizeof(T) == 4 ? 2048 : 1024;      // 32 KiB of LDS either way
-    // queries per lane: enough blocks to fill 256 CUs first, then register-block for LDS-read amortisation
+    const int bpc = (n + BLOCK * Q - 1) / (BLOCK * Q);
+    knn_valu_kernel<T, Q, TILE, CH><<<grid_for(N, bpc), BLOCK, 0, st>>>((const T*)src, (const T*)pose, (const T4*)tgt4, idx, N, n, m, m_pad, bpc);
+}
+
+// cfg 0 = pick by problem size: enough blocks to fill 256 CUs first, then register-block queries to
+// amortise the LDS broadcasts.  cfg 1.. = fixed (tuning / tests).
+template <typename T>
+int knn_valu_launch(int cfg, const void* src, const void* pose, const void* tgt4, int N, int n, int m, int m_pad, int32_t* idx, hipStream_t st) {
     const long q_total = (long)N * n;
-    if (q_total >= 4L * BLOCK * 1024) {
-        const int bpc = (n + BLOCK * 4 - 1) / (BLOCK * 4);
-        knn_valu_kernel<T, 4, TILE><<<grid_for(N, bpc), BLOCK, 0, st>>>((const T*)src, (const T*)pose, (const T4*)tgt4, idx, N, n, m, m_pad, bpc);
-    } else if (q_total >= 2L * BLOCK * 1024) {
-        const int bpc = (n + BLOCK * 2 - 1) / (BLOCK * 2);
-        knn_valu_kernel<T, 2, TILE><<<grid_for(N, bpc), BLOCK, 0, st>>>((const T*)src, (const T*)pose, (const T4*)tgt4, idx, N, n, m, m_pad, bpc);
-    } else {
-        const int bpc = (n + BLOCK - 1) / BLOCK;
-        knn_valu_kernel<T, 1, TILE><<<grid_for(N, bpc), BLOCK, 0, st>>>((const T*)src, (const T*)pose, (const T4*)tgt4, idx, N, n, m, m_pad, bpc);
+    if (cfg == 0) cfg = q_total >= 4L * BLOCK * 1024 ? 3 : (q_total >= 2L * BLOCK * 1024 ? 2 : 1);
+    switch (cfg) {
+        case 1: knn_valu_go<T, 1, 8>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
+        case 2: knn_valu_go<T, 2, 8>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
+        case 3: knn_valu_go<T, 4, 8>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
+        case 4: knn_valu_go<T, 8, 8>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
+        case 5: knn_valu_go<T, 4, 16>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
+        case 6: knn_valu_go<T, 8, 4>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
+        default: return DICP_ERR_ENUM;
+    }
+    return launch_status();
+}
+
+template <int NB>
+void knn_mfma_go(const void* src, const void* pose, const void* tgt4, int N, int n, int m, int m_pad, int32_t* idx, hipStream_t st) {
+    const int bpc = (n + 64 * NB - 1) / (64 * NB);
+    knn_mfma_kernel<NB, 2048><<<grid_for(N, bpc), BLOCK, 0, st>>>((const float*)src, (const float*)pose, (const float4*)tgt4, idx, N, n, m, m_pad, bpc);
+}
+
+int knn_mfma_launch(int cfg, const void* src, const void* pose, const void* tgt4, int N, int n, int m, int m_pad, int32_t* idx, hipStream_t st) {
+    if (cfg == 0) cfg = ((long)N * n >= 512L * 1024) ? 3 : 1;
+    switch (cfg) {
+        case 1: knn_mfma_go<2>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
+        case 2: knn_mfma_go<4>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
+        case 3: knn_mfma_go<8>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
+        default: return DICP_ERR_ENUM;
     }
     return launch_status();
 }
@@ -593,25 +641,15 @@ int dicp_knn(int dtype, const void* src, const void* pose, const void* tgt4, int
     if (!src || !tgt4 || !idx) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || n <= 0 || m <= 0 || m_pad != dicp_padded_targets(m)) return DICP_ERR_SHAPE;
-    if (variant < DICP_KNN_AUTO || variant > DICP_KNN_MFMA) return DICP_ERR_ENUM;
-    if (variant == DICP_KNN_MFMA && dtype != DICP_F32) return DICP_ERR_DTYPE;
+    const int kind = variant & 0xff, cfg = (variant >> 8) & 0xff;      // cfg != 0: fixed launch config (tuning)
+    if (kind < DICP_KNN_AUTO || kind > DICP_KNN_MFMA || (variant >> 16)) return DICP_ERR_ENUM;
+    if (kind == DICP_KNN_MFMA && dtype != DICP_F32) return DICP_ERR_DTYPE;
     if ((uintptr_t)tgt4 % (dtype == DICP_F32 ? 16 : 32)) return DICP_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
     begin_launch();
-    if (variant == DICP_KNN_AUTO) variant = DICP_KNN_VALU;
-    if (variant == DICP_KNN_MFMA) {
-        const long q_total = (long)N * n;
-        if (q_total >= 512L * 1024) {
-            const int bpc = (n + 64 * 8 - 1) / (64 * 8);
-            knn_mfma_kernel<8, 2048><<<grid_for(N, bpc), BLOCK, 0, st>>>((const float*)src, (const float*)pose, (const float4*)tgt4, idx, N, n, m, m_pad, bpc);
-        } else {
-            const int bpc = (n + 64 * 2 - 1) / (64 * 2);
-            knn_mfma_kernel<2, 2048><<<grid_for(N, bpc), BLOCK, 0, st>>>((const float*)src, (const float*)pose, (const float4*)tgt4, idx, N, n, m, m_pad, bpc);
-        }
-        return launch_status();
-    }
-    if (dtype == DICP_F32) return knn_valu_launch<float>(src, pose, tgt4, N, n, m, m_pad, idx, st);
-    return knn_valu_launch<double>(src, pose, tgt4, N, n, m, m_pad, idx, st);
+    if (kind == DICP_KNN_MFMA) return knn_mfma_launch(cfg, src, pose, tgt4, N, n, m, m_pad, idx, st);
+    if (dtype == DICP_F32) return knn_valu_launch<float>(cfg, src, pose, tgt4, N, n, m, m_pad, idx, st);
+    return knn_valu_launch<double>(cfg, src, pose, tgt4, N, n, m, m_pad, idx, st);
 }
 
 int dicp_gather_rows(int dtype, const void* tgt, const int32_t* idx, int N, int n, int m, int c, void* out, void* stream) {

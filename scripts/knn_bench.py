@@ -1,0 +1,39 @@
+"""A/B timing of the kNN launch configurations at the benchmark shape (interleaved rounds, HIP events)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dicp_amd import _lib, _ops
+from dicp_amd.synthetic import make_pairs
+
+B = int(os.environ.get("B", 256)); n = int(os.environ.get("NPTS", 16384)); rounds = int(os.environ.get("ROUNDS", 5))
+src, tgt = make_pairs(B, n, n, seed=3)
+src, tgt = src.cuda(), tgt.cuda()
+tgt4 = _ops.pack_target(tgt)
+idx = torch.empty((B, n), dtype=torch.int32, device="cuda")
+variants = {"valu_q4c8": 1 | (3 << 8), "valu_q8c8": 1 | (4 << 8), "valu_q4c16": 1 | (5 << 8), "valu_q8c4": 1 | (6 << 8),
+            "valu_q2c8": 1 | (2 << 8), "mfma_nb8": 2 | (3 << 8), "mfma_nb4": 2 | (2 << 8)}
+sel = os.environ.get("VARIANTS")
+if sel:
+    variants = {k: v for k, v in variants.items() if k in sel.split(",")}
+ref = None
+times = {k: [] for k in variants}
+for rnd in range(rounds + 1):
+    for name, v in variants.items():
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        _ops.knn(src, None, tgt4, n, v, out=idx)
+        b.record()
+        torch.cuda.synchronize()
+        if rnd:
+            times[name].append(a.elapsed_time(b))
+        else:
+            if ref is None:
+                ref = idx.clone()
+            else:
+                print("%-12s mismatches vs first variant: %d" % (name, int((idx != ref).sum())))
+pairs = float(B) * n * n
+print("lib:", _lib.LIB_PATH)
+for name, ts in times.items():
+    ts = sorted(ts)
+    med = ts[len(ts) // 2]
+    print("%-12s median %.3f ms  min %.3f ms  -> %.1f TF (8nm)  %.2f Gpairs/s" % (name, med, ts[0], 8 * pairs / med / 1e9, pairs / med / 1e6))

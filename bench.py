@@ -56,6 +56,24 @@ class EventLog:
         return sum(a.elapsed_time(b) for a, b in p) / len(p) if p else None
 
 
+def pmc_traffic(kernel_prefix, B, n):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_hbm_traffic.json, made by
+    scripts/pmc_summary.py from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command).
+    PMC counters cannot be read from inside the process, so this is null when no matching profile exists."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("workload") != {"B": B, "n": n}:
+            continue
+        for name, k in d["kernels"].items():
+            if name.startswith(kernel_prefix):
+                return k["hbm_bytes"], os.path.basename(f)
+    return None, None
+
+
 def run_call(icp, src, tgt, T0, world):
     s = src.detach().requires_grad_(True)
     t = tgt.detach().requires_grad_(True)
@@ -155,6 +173,8 @@ def main():
         flops = 8.0 * n * m * B                                          # per kNN launch
         knn_tf = flops / (knn_ms * 1e-3) / 1e12
         bwd_bytes = 88.0 * n * B                                         # per backward launch
+        knn_traffic, knn_src = pmc_traffic("knn_", B, n)
+        bwd_traffic, bwd_src = pmc_traffic("accumulate_bwd", B, n)
         line = {
             "metric": "ICP cloud-iterations/sec (fwd+bwd), B=256x16384-pt clouds per GPU",
             "value": world * B * K / elapsed,
@@ -171,12 +191,13 @@ def main():
                        "parallelism": "batch-sharded x%d, one pose all-gather per call" % world},
             "roofline": {"kernel": "knn (fused transform + brute-force 1-NN)", "bound": "mfma",
                          "achieved": knn_tf, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": knn_tf / F32_PEAK_TFLOPS,
-                         "traffic": None, "avg_launch_ms": knn_ms,
+                         "traffic": knn_traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, " + str(knn_src) + ")",
+                         "algorithmic_hbm_bytes": (16.0 * n + 16.0 * m) * B, "avg_launch_ms": knn_ms,
                          "note": "8*n*m flops per cloud-iteration vs the f32 MFMA(=VALU) peak; algorithmic HBM bytes "
                                  "are only %.1f MB per launch, so HBM is not the binding roof" % ((16 * n + 16 * m) * B / 1e6)},
             "roofline_streaming": {"kernel": "accumulate_bwd", "bound": "hbm", "achieved": bwd_bytes / (bwd_ms * 1e-3) / 1e9,
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bwd_bytes / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                   "traffic": None, "avg_launch_ms": bwd_ms},
+                                   "traffic": bwd_traffic, "avg_launch_ms": bwd_ms},
             "finite": sane,
         }
         if world == 1 and not args.no_cpu_baseline:

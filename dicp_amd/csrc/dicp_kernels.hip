@@ -27,7 +27,7 @@ namespace {
 constexpr int BLOCK = 256;
 constexpr int WAVE = 64;
 constexpr int ACC_PTS = 1024;          // source points per accumulate block
-constexpr int KNN_PAD = 16;            // m_pad granularity (MFMA tile height)
+constexpr int KNN_PAD = 64;            // m_pad granularity: 4 MFMA tiles of 16 targets / largest VALU chunk
 
 template <typename T> struct V4;
 template <> struct V4<float>  { using type = float4; };
@@ -98,8 +98,8 @@ __device__ __forceinline__ T score(const T* nx, const T4& y) {
 // lane only tracks the running minimum VALUE (v_min3) and which chunk last improved it;
 // the index inside that chunk is recovered once at the end (strict <, ascending order,
 // so ties resolve to the lowest index exactly like torch.argmin).
-template <typename T, int Q, int TILE, int CH>
-__global__ __launch_bounds__(BLOCK) void knn_valu_kernel(const T* __restrict__ src, const T* __restrict__ pose,
+template <typename T, int Q, int TILE, int CH, int MINW>
+__global__ __launch_bounds__(BLOCK, MINW) void knn_valu_kernel(const T* __restrict__ src, const T* __restrict__ pose,
                                                          const typename V4<T>::type* __restrict__ tgt4,
                                                          int32_t* __restrict__ idx, int N, int n, int m, int m_pad, int bpc) {
     using T4 = typename V4<T>::type;
@@ -165,6 +165,87 @@ __global__ __launch_bounds__(BLOCK) void knn_valu_kernel(const T* __restrict__ s
     }
 }
 
+// Packed-math form of the same kernel (float only): the LDS tile holds target PAIRS as
+// {y0a,y0b,y1a,y1b},{y2a,y2b,ha,hb} so that one v_pk_fma_f32 scores two targets for one query.
+// Same IEEE fma per component, so scores are bit-identical to score<>() and the final resolve
+// (which re-reads the AoS rows from global memory) picks the same index.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int Q, int TILE, int CH>
+__global__ __launch_bounds__(BLOCK) void knn_valu_pk_kernel(const float* __restrict__ src, const float* __restrict__ pose,
+                                                            const float4* __restrict__ tgt4, int32_t* __restrict__ idx,
+                                                            int N, int n, int m, int m_pad, int bpc) {
+    __shared__ float4 tile[TILE];
+    int cloud, blk;
+    if (!decode_block(bpc, N, cloud, blk)) return;
+    const int tid = threadIdx.x;
+    float C[9], r[3];
+    load_pose(pose, cloud, C, r);
+    float nx[Q][3], best[Q];
+    f32x2 nx2[Q][3];
+    int bchunk[Q];
+#pragma unroll
+    for (int qi = 0; qi < Q; ++qi) {
+        const int i = blk * (BLOCK * Q) + qi * BLOCK + tid;
+        float p[3] = {0.f, 0.f, 0.f};
+        if (i < n) {
+            const float* sp = src + ((size_t)cloud * n + i) * 3;
+            p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2];
+        }
+        float q[3];
+        matvec3(C, p, q);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { nx[qi][k] = -(q[k] + r[k]); nx2[qi][k] = {nx[qi][k], nx[qi][k]}; }
+        best[qi] = inf_v<float>();
+        bchunk[qi] = 0;
+    }
+    const float4* __restrict__ tg = tgt4 + (size_t)cloud * m_pad;
+    for (int base = 0; base < m_pad; base += TILE) {
+        const int len = min(TILE, m_pad - base);            // multiple of 64
+        for (int t = tid; t < len / 2; t += BLOCK) {
+            const float4 a = tg[base + 2 * t], b = tg[base + 2 * t + 1];
+            tile[2 * t] = make_float4(a.x, b.x, a.y, b.y);
+            tile[2 * t + 1] = make_float4(a.z, b.z, a.w, b.w);
+        }
+        __syncthreads();
+        for (int j0 = 0; j0 < len; j0 += CH) {
+            float4 y[CH];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) y[k] = tile[j0 + k];
+#pragma unroll
+            for (int qi = 0; qi < Q; ++qi) {
+                float c = best[qi];
+#pragma unroll
+                for (int k = 0; k < CH; k += 2) {
+                    const f32x2 y0 = {y[k].x, y[k].y}, y1 = {y[k].z, y[k].w};
+                    const f32x2 y2 = {y[k + 1].x, y[k + 1].y}, h = {y[k + 1].z, y[k + 1].w};
+                    const f32x2 s2 = __builtin_elementwise_fma(nx2[qi][0], y0, __builtin_elementwise_fma(nx2[qi][1], y1,
+                                     __builtin_elementwise_fma(nx2[qi][2], y2, h)));
+                    c = min_t(min_t(c, s2[0]), s2[1]);
+                }
+                bchunk[qi] = (c < best[qi]) ? base + j0 : bchunk[qi];
+                best[qi] = c;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int qi = 0; qi < Q; ++qi) {
+        const int i = blk * (BLOCK * Q) + qi * BLOCK + tid;
+        if (i < n) {
+            const float4* cp = tg + bchunk[qi];
+            float bv = inf_v<float>();
+            int bj = bchunk[qi];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const float sc = score<float, float4>(nx[qi], cp[k]);
+                if (sc < bv) { bv = sc; bj = bchunk[qi] + k; }
+            }
+            idx[(size_t)cloud * n + i] = min(bj, m - 1);
+        }
+    }
+}
+
 // ------------------------------------------------------------------- kNN (MFMA)
 // The distance matrix IS a dense K=4 contraction: A = targets [y0,y1,y2,h] (16x4),
 // B = queries [-x0,-x1,-x2,1]^T (4x16), D = scores (16 targets x 16 queries) on
@@ -173,7 +254,7 @@ __global__ __launch_bounds__(BLOCK) void knn_valu_kernel(const T* __restrict__ s
 // query are combined once at the end.  The VALU only does 2 v_min3 + cmp + select per MFMA.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int NB, int TILE>
+template <int NB, int TILE, int G>
 __global__ __launch_bounds__(BLOCK) void knn_mfma_kernel(const float* __restrict__ src, const float* __restrict__ pose,
                                                          const float4* __restrict__ tgt4, int32_t* __restrict__ idx,
                                                          int N, int n, int m, int m_pad, int bpc) {
@@ -215,17 +296,26 @@ __global__ __launch_bounds__(BLOCK) void knn_mfma_kernel(const float* __restrict
             tl[t] = v.x; tl[TS + t] = v.y; tl[2 * TS + t] = v.z; tl[3 * TS + t] = v.w;
         }
         __syncthreads();
-        for (int t0 = 0; t0 < len; t0 += 16) {
-            const float a = tl[kq * TS + t0 + ql];          // A[target t0+ql][k = kq]
-            f32x4 d[NB];
+        // G MFMA tiles (16 targets each) share one compare+select: the winning GROUP is recorded and
+        // re-scanned once at the end
+        for (int t0 = 0; t0 < len; t0 += 16 * G) {         // len is a multiple of 64 >= 16*G
+            float c[NB];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) d[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq[nb], zero, 0, 0, 0);
+            for (int nb = 0; nb < NB; ++nb) c[nb] = best[nb];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const float a = tl[kq * TS + t0 + g * 16 + ql];      // A[target t0+16g+ql][k = kq]
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq[nb], zero, 0, 0, 0);
+                    c[nb] = min_t(min_t(c[nb], d[0]), d[1]);
+                    c[nb] = min_t(min_t(c[nb], d[2]), d[3]);
+                }
+            }
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                float c = min_t(min_t(best[nb], d[nb][0]), d[nb][1]);
-                c = min_t(min_t(c, d[nb][2]), d[nb][3]);
-                bt[nb] = (c < best[nb]) ? base + t0 : bt[nb];
-                best[nb] = c;
+                bt[nb] = (c[nb] < best[nb]) ? base + t0 : bt[nb];
+                best[nb] = c[nb];
             }
         }
         __syncthreads();
@@ -234,13 +324,16 @@ __global__ __launch_bounds__(BLOCK) void knn_mfma_kernel(const float* __restrict
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int i = qwave + nb * 16 + ql;
-        const int j0 = bt[nb] + kq * 4;                     // this lane's four targets of the winning tile
         float bv = inf_v<float>();
-        int bj = j0;
+        int bj = bt[nb];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float s = score<float, float4>(nx[nb], tg[j0 + k]);
-            if (s < bv) { bv = s; bj = j0 + k; }
+        for (int g = 0; g < G; ++g) {                       // this lane's 4 targets in each tile of the winning group
+            const int j0 = bt[nb] + g * 16 + kq * 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float s = score<float, float4>(nx[nb], tg[j0 + k]);
+                if (s < bv) { bv = s; bj = j0 + k; }
+            }
         }
 #pragma unroll
         for (int off = 16; off < 64; off <<= 1) {           // the 4 lanes that share query ql
@@ -334,37 +427,39 @@ __global__ __launch_bounds__(BLOCK) void accumulate_kernel(WeightParams P, const
 }
 
 // -------------------------------------------------------------------------- step
+// One 64-thread block per cloud.  All small matrices live in LDS: private arrays with dynamic indexing
+// would be scratch (global) memory, and this kernel is pure latency (it sits between two big launches).
 template <typename T>
 __global__ __launch_bounds__(WAVE) void step_kernel(dicp_step_io io, int N) {
-    __shared__ double sacc[NACC_PAD];
+    __shared__ double sacc[NACC_PAD], sA[36], sAreg[36], sws[STEP_WS], spose[12], sout[24];
     __shared__ int s_copy;
     const int cloud = blockIdx.x, tid = threadIdx.x;
-    if (tid < NACC_PAD) {
-        const T* pp = (const T*)io.partials + (size_t)cloud * io.nblk * NACC_PAD + tid;
+    {   // reduce the per-block partials: lane = (part, slot); fixed summation order -> bit-reproducible
+        const int slot_i = tid & 31, part = tid >> 5;
+        const T* pp = (const T*)io.partials + (size_t)cloud * io.nblk * NACC_PAD + slot_i;
         double s = 0.0;
-        for (int b = 0; b < io.nblk; ++b) s += (double)pp[(size_t)b * NACC_PAD];
-        sacc[tid] = s;
+        for (int b = part; b < io.nblk; b += 2) s += (double)pp[(size_t)b * NACC_PAD];
+        s += __shfl_down(s, 32);
+        if (tid < NACC_PAD) sacc[tid] = s;
+        if (tid < 12) spose[tid] = (double)((const T*)io.pose_in)[(size_t)cloud * 12 + tid];
     }
     __syncthreads();
     if (tid == 0) {
-        double A6[36], C[9], r[3], d6[6], Cn[9], rn[3], Areg[36];
-        unpack_sym6(sacc + ACC_A, A6);
-        const T* pin = (const T*)io.pose_in + (size_t)cloud * 12;
-        for (int k = 0; k < 9; ++k) C[k] = (double)pin[k];
-        for (int k = 0; k < 3; ++k) r[k] = (double)pin[9 + k];
+        double* d6 = sout; double* Cn = sout + 6; double* rn = sout + 15;
+        unpack_sym6(sacc + ACC_A, sA);
         // solve with the pose untouched first so delta can be rounded to T like the reference's
-        step_forward(A6, sacc + ACC_B, io.dim, C, r, d6, Cn, rn, Areg);
+        step_forward(sA, sacc + ACC_B, io.dim, spose, spose + 9, d6, Cn, rn, sAreg, sws);
         T* dout = (T*)io.delta + (size_t)cloud * io.delta_stride;
         double nrm2 = 0.0;
         for (int k = 0; k < 6; ++k) { const T v = (T)d6[k]; dout[k] = v; d6[k] = (double)v; nrm2 += d6[k] * d6[k]; }
         double R[9];
         so3_exp(d6, R);                                                   // ICP.py:210
         T* pout = (T*)io.pose_out + (size_t)cloud * 12;
+        const double* C = spose;
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 3; ++j)
                 pout[i * 3 + j] = (T)(R[0 * 3 + i] * C[0 * 3 + j] + R[1 * 3 + i] * C[1 * 3 + j] + R[2 * 3 + i] * C[2 * 3 + j]);
-        for (int k = 0; k < 3; ++k) pout[9 + k] = (T)(r[k] - d6[3 + k]);
-        if (io.areg) for (int k = 0; k < 36; ++k) io.areg[(size_t)cloud * 36 + k] = Areg[k];
+        for (int k = 0; k < 3; ++k) pout[9 + k] = (T)(spose[9 + k] - d6[3 + k]);
 
         T cost = (T)sacc[ACC_COST];                                       // ICP.py:229-232
         if (io.cost_prev && cost == T(0)) cost = ((const T*)io.cost_prev)[(size_t)cloud * io.cost_stride];
@@ -390,6 +485,7 @@ __global__ __launch_bounds__(WAVE) void step_kernel(dicp_step_io io, int N) {
         s_copy = (io.w_cur && io.w_prev && sacc[ACC_SUMW] == 0.0) ? 1 : 0;   // ICP.py:224-226
     }
     __syncthreads();
+    if (io.areg && tid < 36) io.areg[(size_t)cloud * 36 + tid] = sAreg[tid];
     if (s_copy) {
         T* wc = (T*)io.w_cur + (size_t)cloud * io.w_stride;
         const T* wp = (const T*)io.w_prev + (size_t)cloud * io.w_stride;
@@ -477,27 +573,28 @@ __global__ __launch_bounds__(WAVE) void step_bwd_kernel(const double* __restrict
                                                         const T* __restrict__ delta_k, long delta_stride,
                                                         const double* __restrict__ areg_k, T* __restrict__ gs,
                                                         T* __restrict__ gb, double* __restrict__ gpose_out, int N) {
-    __shared__ double sg[NBWD_PAD];
+    __shared__ double sg[NBWD_PAD], sC[9], sd[6], sAreg[36], sGs[36], sGb[6], sgo[12], sws[STEP_WS];
     const int cloud = blockIdx.x, tid = threadIdx.x;
-    if (tid < NBWD_PAD) {
-        double s = (tid < NBWD) ? gpose_in[(size_t)cloud * 12 + tid] : 0.0;
-        if (bwd_partials && tid < NBWD) {
-            const T* pp = bwd_partials + (size_t)cloud * nblk * NBWD_PAD + tid;
-            for (int b = 0; b < nblk; ++b) s += (double)pp[(size_t)b * NBWD_PAD];
+    {
+        const int slot_i = tid & 15, part = tid >> 4;       // 4 partial sums per slot
+        double s = 0.0;
+        if (bwd_partials && slot_i < NBWD) {
+            const T* pp = bwd_partials + (size_t)cloud * nblk * NBWD_PAD + slot_i;
+            for (int b = part; b < nblk; b += 4) s += (double)pp[(size_t)b * NBWD_PAD];
         }
-        sg[tid] = s;
+        s += __shfl_down(s, 32);
+        s += __shfl_down(s, 16);
+        if (tid < NBWD) sg[tid] = s + gpose_in[(size_t)cloud * 12 + tid];
+        if (tid < 9) sC[tid] = (double)pose_k[(size_t)cloud * 12 + tid];
+        if (tid < 6) sd[tid] = (double)delta_k[(size_t)cloud * delta_stride + tid];
+        if (tid < 36) sAreg[tid] = areg_k[(size_t)cloud * 36 + tid];
     }
     __syncthreads();
-    if (tid == 0) {
-        double C[9], d6[6], Gs[36], Gb[6], gC[9], gr[3];
-        for (int k = 0; k < 9; ++k) C[k] = (double)pose_k[(size_t)cloud * 12 + k];
-        for (int k = 0; k < 6; ++k) d6[k] = (double)delta_k[(size_t)cloud * delta_stride + k];
-        step_backward(sg, sg + 9, dim, C, d6, areg_k + (size_t)cloud * 36, Gs, Gb, gC, gr);
-        for (int k = 0; k < 36; ++k) gs[(size_t)cloud * 36 + k] = (T)Gs[k];
-        for (int k = 0; k < 6; ++k) gb[(size_t)cloud * 6 + k] = (T)Gb[k];
-        for (int k = 0; k < 9; ++k) gpose_out[(size_t)cloud * 12 + k] = gC[k];
-        for (int k = 0; k < 3; ++k) gpose_out[(size_t)cloud * 12 + 9 + k] = gr[k];
-    }
+    if (tid == 0) step_backward(sg, sg + 9, dim, sC, sd, sAreg, sGs, sGb, sgo, sgo + 9, sws);
+    __syncthreads();
+    if (tid < 36) gs[(size_t)cloud * 36 + tid] = (T)sGs[tid];
+    if (tid < 6) gb[(size_t)cloud * 6 + tid] = (T)sGb[tid];
+    if (tid < 12) gpose_out[(size_t)cloud * 12 + tid] = sgo[tid];
 }
 
 // ------------------------------------------------------------------ loss weights
@@ -571,12 +668,12 @@ inline WeightParams to_params(const dicp_weight_params* p) {
 inline bool bad_dtype(int d) { return d != DICP_F32 && d != DICP_F64; }
 inline unsigned blocks_for(size_t total) { return (unsigned)((total + BLOCK - 1) / BLOCK); }
 
-template <typename T, int Q, int CH>
+template <typename T, int Q, int CH, int MINW = 1>
 void knn_valu_go(const void* src, const void* pose, const void* tgt4, int N, int n, int m, int m_pad, int32_t* idx, hipStream_t st) {
     using T4 = typename V4<T>::type;
     constexpr int TILE = sizeof(T) == 4 ? 2048 : 1024;      // 32 KiB of LDS either way
     const int bpc = (n + BLOCK * Q - 1) / (BLOCK * Q);
-    knn_valu_kernel<T, Q, TILE, CH><<<grid_for(N, bpc), BLOCK, 0, st>>>((const T*)src, (const T*)pose, (const T4*)tgt4, idx, N, n, m, m_pad, bpc);
+    knn_valu_kernel<T, Q, TILE, CH, MINW><<<grid_for(N, bpc), BLOCK, 0, st>>>((const T*)src, (const T*)pose, (const T4*)tgt4, idx, N, n, m, m_pad, bpc);
 }
 
 // cfg 0 = pick by problem size: enough blocks to fill 256 CUs first, then register-block queries to
@@ -584,7 +681,12 @@ void knn_valu_go(const void* src, const void* pose, const void* tgt4, int N, int
 template <typename T>
 int knn_valu_launch(int cfg, const void* src, const void* pose, const void* tgt4, int N, int n, int m, int m_pad, int32_t* idx, hipStream_t st) {
     const long q_total = (long)N * n;
-    if (cfg == 0) cfg = q_total >= 4L * BLOCK * 1024 ? 3 : (q_total >= 2L * BLOCK * 1024 ? 2 : 1);
+    if (cfg == 0) {
+        if (q_total >= 8L * BLOCK * 1024)      cfg = (sizeof(T) == 4) ? 11 : 3;    // Q=8, 16-target chunks (f32)
+        else if (q_total >= 4L * BLOCK * 1024) cfg = (sizeof(T) == 4) ? 5 : 3;     // Q=4
+        else if (q_total >= 2L * BLOCK * 1024) cfg = 2;
+        else                                   cfg = 1;
+    }
     switch (cfg) {
         case 1: knn_valu_go<T, 1, 8>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
         case 2: knn_valu_go<T, 2, 8>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
@@ -592,23 +694,38 @@ int knn_valu_launch(int cfg, const void* src, const void* pose, const void* tgt4
         case 4: knn_valu_go<T, 8, 8>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
         case 5: knn_valu_go<T, 4, 16>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
         case 6: knn_valu_go<T, 8, 4>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
+        case 7: knn_valu_go<T, 8, 16>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
+        case 8: knn_valu_go<T, 4, 32>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
+        case 11: knn_valu_go<T, 8, 16, (sizeof(T) == 4 ? 4 : 1)>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
+        case 9: case 10:
+            if (sizeof(T) != 4) return DICP_ERR_DTYPE;
+            {
+                const int Q = 4, bpc = (n + BLOCK * Q - 1) / (BLOCK * Q);
+                if (cfg == 9) knn_valu_pk_kernel<4, 2048, 16><<<grid_for(N, bpc), BLOCK, 0, st>>>((const float*)src, (const float*)pose, (const float4*)tgt4, idx, N, n, m, m_pad, bpc);
+                else          knn_valu_pk_kernel<4, 2048, 32><<<grid_for(N, bpc), BLOCK, 0, st>>>((const float*)src, (const float*)pose, (const float4*)tgt4, idx, N, n, m, m_pad, bpc);
+            }
+            break;
         default: return DICP_ERR_ENUM;
     }
     return launch_status();
 }
 
-template <int NB>
+template <int NB, int G>
 void knn_mfma_go(const void* src, const void* pose, const void* tgt4, int N, int n, int m, int m_pad, int32_t* idx, hipStream_t st) {
     const int bpc = (n + 64 * NB - 1) / (64 * NB);
-    knn_mfma_kernel<NB, 2048><<<grid_for(N, bpc), BLOCK, 0, st>>>((const float*)src, (const float*)pose, (const float4*)tgt4, idx, N, n, m, m_pad, bpc);
+    knn_mfma_kernel<NB, 2048, G><<<grid_for(N, bpc), BLOCK, 0, st>>>((const float*)src, (const float*)pose, (const float4*)tgt4, idx, N, n, m, m_pad, bpc);
 }
 
 int knn_mfma_launch(int cfg, const void* src, const void* pose, const void* tgt4, int N, int n, int m, int m_pad, int32_t* idx, hipStream_t st) {
-    if (cfg == 0) cfg = ((long)N * n >= 512L * 1024) ? 3 : 1;
+    if (cfg == 0) cfg = ((long)N * n >= 512L * 1024) ? 5 : 1;
     switch (cfg) {
-        case 1: knn_mfma_go<2>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
-        case 2: knn_mfma_go<4>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
-        case 3: knn_mfma_go<8>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
+        case 1: knn_mfma_go<2, 1>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
+        case 2: knn_mfma_go<4, 1>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
+        case 3: knn_mfma_go<8, 1>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
+        case 4: knn_mfma_go<4, 2>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
+        case 5: knn_mfma_go<4, 4>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
+        case 6: knn_mfma_go<8, 4>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
+        case 7: knn_mfma_go<2, 4>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
         default: return DICP_ERR_ENUM;
     }
     return launch_status();

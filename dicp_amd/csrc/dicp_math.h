@@ -382,10 +382,14 @@ DICP_HD int ndof(int dim) { return dim == 2 ? 3 : 6; }
 
 // Forward step.  A6 (full 6x6, without the regulariser), b6 -> delta6, and the new pose.
 // Areg receives the d x d matrix actually inverted (leading dim 6), kept for backward.
+constexpr int STEP_WS = 48;   // doubles of workspace step_forward / step_backward need
+
 DICP_HD void step_forward(const double* A6, const double* b6, int dim, const double* C, const double* r,
-                          double* delta6, double* Cn, double* rn, double* Areg) {
+                          double* delta6, double* Cn, double* rn, double* Areg, double* ws) {
     const int d = ndof(dim);
-    double M[36], rhs[6], x[6];
+    double* M = ws;            // 36
+    double* rhs = ws + 36;     // 6
+    double* x = ws + 42;       // 6
     for (int i = 0; i < d; ++i) {
         for (int j = 0; j < d; ++j) M[i * 6 + j] = A6[slot(dim, i) * 6 + slot(dim, j)];
         M[i * 6 + i] += 1e-12;                                      // ICP.py:200
@@ -408,7 +412,7 @@ DICP_HD void step_forward(const double* A6, const double* b6, int dim, const dou
 // Out: Gs = G_A + G_A^T (6x6), gb (6), gC, gr (cotangents of the old pose).
 DICP_HD void step_backward(const double* gCn, const double* grn, int dim, const double* C,
                            const double* delta6, const double* Areg,
-                           double* Gs, double* gb, double* gC, double* gr) {
+                           double* Gs, double* gb, double* gC, double* gr, double* ws) {
     const int d = ndof(dim);
     double R[9];
     so3_exp(delta6, R);
@@ -436,7 +440,9 @@ DICP_HD void step_backward(const double* gCn, const double* grn, int dim, const 
     for (int i = 0; i < 3; ++i) gd[i] = a * v[i] + c * phi[i] * pv - b * pxv[i];
     for (int i = 0; i < 3; ++i) gd[3 + i] = -grn[i];
     // delta = -Areg^{-1} b  ->  g = Areg^{-1} gdelta ; gb = -g ; G_A = -g delta^T
-    double Mx[36], rhs[6], g[6];
+    double* Mx = ws;           // 36
+    double* rhs = ws + 36;     // 6
+    double* g = ws + 42;       // 6
     for (int i = 0; i < 36; ++i) Mx[i] = Areg[i];
     for (int i = 0; i < d; ++i) rhs[i] = gd[slot(dim, i)];
     for (int i = 0; i < 36; ++i) Gs[i] = 0.0;

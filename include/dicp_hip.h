@@ -50,7 +50,7 @@ typedef struct dicp_weight_params {
 
 int dicp_abi_version(void);
 
-/* Rows of target points padded for the kNN kernels: returns m rounded up to 16. */
+/* Rows of target points padded for the kNN kernels: returns m rounded up to 64. */
 int dicp_padded_targets(int m);
 /* Blocks per cloud used by dicp_accumulate / dicp_accumulate_bwd for n source points. */
 int dicp_accumulate_blocks(int n);
@@ -63,7 +63,8 @@ int dicp_pack_target(int dtype, const void* tgt, int N, int m, int c, void* tgt4
 /* Fused transform + brute-force 1-NN: replaces ICP.py:137 (ps_t = C p + r) followed by
  * nn.find_nn's cdist -> argmin, nn.py:32-35 / 83-86.  Never materialises (N,n,m).
  *   src (N,n,3); pose (N,12) = [C row-major (9), r (3)] or NULL for identity;
- *   idx (N,n) int32, ties -> lowest index.  variant: DICP_KNN_*; MFMA is f32 only. */
+ *   idx (N,n) int32, ties -> lowest index.  variant: DICP_KNN_* in the low byte (MFMA is f32 only);
+ *   bits 8..15 optionally pin a launch configuration (0 = chosen from the problem size). */
 int dicp_knn(int dtype, const void* src, const void* pose, const void* tgt4, int N, int n, int m, int m_pad,
              int32_t* idx, int variant, void* stream);
 

@@ -52,13 +52,14 @@ void hc_backward_f64(const WeightParams* P, int n, int c, const double* src, con
 }
 void hc_step_forward(const double* acc, int dim, const double* C, const double* r,
                      double* delta6, double* Cn, double* rn, double* Areg) {
-    double A6[36];
+    double A6[36], ws[STEP_WS];
     unpack_sym6(acc + ACC_A, A6);
-    step_forward(A6, acc + ACC_B, dim, C, r, delta6, Cn, rn, Areg);
+    step_forward(A6, acc + ACC_B, dim, C, r, delta6, Cn, rn, Areg, ws);
 }
 void hc_step_backward(const double* gCn, const double* grn, int dim, const double* C, const double* delta6,
                       const double* Areg, double* Gs, double* gb, double* gC, double* gr) {
-    step_backward(gCn, grn, dim, C, delta6, Areg, Gs, gb, gC, gr);
+    double ws[STEP_WS];
+    step_backward(gCn, grn, dim, C, delta6, Areg, Gs, gb, gC, gr, ws);
 }
 int hc_sizeof_params() { return (int)sizeof(WeightParams); }
 

@@ -49,17 +49,17 @@ def test_struct_layouts_match_header(lib):
 
 def test_sizes_and_argument_checks(lib):
     assert lib.dicp_abi_version() == 1
-    assert [lib.dicp_padded_targets(m) for m in (0, 1, 16, 17, 65)] == [0, 16, 16, 32, 80]
+    assert [lib.dicp_padded_targets(m) for m in (0, 1, 64, 65, 129)] == [0, 64, 64, 128, 192]
     assert [lib.dicp_accumulate_blocks(n) for n in (0, 1, 1024, 1025, 16384)] == [0, 1, 1, 2, 16]
     # rejected before any launch (no GPU touched): null pointers, bad dtype / shapes / enums
     one = ctypes.c_void_p(16)
-    assert lib.dicp_pack_target(0, None, 1, 1, 3, None, 16, None) == 1
-    assert lib.dicp_pack_target(7, one, 1, 1, 3, one, 16, None) == 3
-    assert lib.dicp_pack_target(0, one, 1, 1, 4, one, 16, None) == 2
-    assert lib.dicp_pack_target(0, one, 1, 1, 3, one, 15, None) == 2
-    assert lib.dicp_knn(0, one, None, one, 1, 1, 1, 16, one, 9, None) == 4
-    assert lib.dicp_knn(1, one, None, ctypes.c_void_p(32), 1, 1, 1, 16, one, _lib.KNN_MFMA, None) == 3
-    assert lib.dicp_knn(0, one, None, ctypes.c_void_p(8), 1, 1, 1, 16, one, 0, None) == 5
+    assert lib.dicp_pack_target(0, None, 1, 1, 3, None, 64, None) == 1
+    assert lib.dicp_pack_target(7, one, 1, 1, 3, one, 64, None) == 3
+    assert lib.dicp_pack_target(0, one, 1, 1, 4, one, 64, None) == 2
+    assert lib.dicp_pack_target(0, one, 1, 1, 3, one, 63, None) == 2
+    assert lib.dicp_knn(0, one, None, one, 1, 1, 1, 64, one, 9, None) == 4
+    assert lib.dicp_knn(1, one, None, ctypes.c_void_p(32), 1, 1, 1, 64, one, _lib.KNN_MFMA, None) == 3
+    assert lib.dicp_knn(0, one, None, ctypes.c_void_p(8), 1, 1, 1, 64, one, 0, None) == 5
     P = _lib.WeightParams(mode=1, loss=0)
     assert lib.dicp_accumulate(0, ctypes.byref(P), one, one, 3, one, one, one, None, 1, 1, 1, one, None, 0, None) == 2   # pt2pl needs normals (ICP.py:103)
     P.loss = 9

@@ -381,3 +381,102 @@ def test_cpu_tensors_round_trip(golden):
     res["T"].sum().backward()
     np.testing.assert_allclose(src.grad.numpy(), g["grad_source"], rtol=0, atol=1e-10)
     np.testing.assert_allclose(tgt.grad.numpy(), g["grad_target"], rtol=0, atol=1e-10)
+
+
+# ------------------------------------------------ BASELINE.json full sizes: size-independent properties
+def sampled_exact(x, y, rows):
+    """Exact f64 nearest neighbour of the sampled query rows against ALL targets: (idx, best, second)."""
+    xs = x[rows].double()
+    d = ((xs[:, None, :] - y[None, :, :3].double()) ** 2).sum(-1)
+    v, i = torch.topk(d, 2, dim=1, largest=False)
+    return torch.argmin(d, dim=1), v[:, 0], v[:, 1]
+
+
+@pytest.mark.parametrize("n,variant", [(16384, _lib.KNN_VALU), (16384, _lib.KNN_MFMA), (65536, _lib.KNN_MFMA), (65536, _lib.KNN_VALU)])
+def test_knn_full_size_properties(n, variant):
+    """configs[2]/[3] cloud sizes (16384 and 65536 points): sampled exactness, permutation equivariance,
+    self-match, pad rows never selected."""
+    N = 16 if n == 16384 else 4
+    src, tgt = make_pairs(N, n, n, seed=7, dtype=torch.float32)
+    sd, td = src.to(DEV), tgt.to(DEV)
+    tgt4 = _ops.pack_target(td)
+    idx = _ops.knn(sd, None, tgt4, n, variant)
+    assert int(idx.min()) >= 0 and int(idx.max()) < n
+    g = torch.Generator().manual_seed(1)
+    rows = torch.randint(0, n, (256,), generator=g).to(DEV)
+    for b in (0, N - 1):
+        want, best, second = sampled_exact(sd[b], td[b], rows)
+        got = idx[b][rows].long()
+        bad = got != want
+        if bad.any():      # only allowed where the runner-up is within float32 resolution of the expanded form
+            assert bool(((second - best)[bad] < 1e-4).all())
+        assert int(bad.sum()) <= 2
+    # permuting the queries permutes the answer; permuting the targets relabels it
+    perm = torch.randperm(n, generator=g).to(DEV)
+    idx_p = _ops.knn(sd[:, perm].contiguous(), None, tgt4, n, variant)
+    assert torch.equal(idx_p, idx[:, perm])
+    tperm = torch.randperm(n, generator=g).to(DEV)
+    idx_t = _ops.knn(sd[:2], None, _ops.pack_target(td[:2, tperm].contiguous()), n, variant)
+    same = tperm[idx_t.long()] == idx[:2].long()
+    assert float(same.float().mean()) > 0.9999          # ties/near-ties may relabel
+    # a cloud queried against itself returns the identity (distance exactly 0 beats everything)
+    self_idx = _ops.knn(td[:2, :, :3].contiguous(), None, _ops.pack_target(td[:2]), n, variant)
+    assert torch.equal(self_idx.cpu(), torch.arange(n, dtype=torch.int32).repeat(2, 1))
+
+
+def test_full_size_icp_properties():
+    """configs[2] shape (16384-pt clouds, pt2pl + huber + trim, fwd+bwd) on 8 clouds: recovers the planted
+    pose, batch == per-item, already-aligned input stays put, gradients finite and batch-independent."""
+    N, n = 8, 16384
+    src, tgt = make_pairs(N, n, n, seed=9, dtype=torch.float32)
+    sd, td = src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True)
+    T0 = torch.eye(4, device=DEV).repeat(N, 1, 1)
+    icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=12, tolerance=1e-12)
+    icp.const_iter = True
+    kw = dict(trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0}, dim=3)
+    out = icp.icp(sd, td, T0, **kw)
+    out["T"].sum().backward()
+    # planted motion: make_pairs builds source = C^T (s_t - r): ICP must return pc ~ the noisy target picks
+    nbr = nn(differentiable=False).find_nn(out["pc"].detach(), td.detach())[:, :, :3]
+    assert float((out["pc"].detach() - nbr).norm(dim=2).mean()) < 0.03          # noise sigma 0.01 per axis
+    assert float(out["deltas"][:, -1].abs().max()) < 1e-3                        # converged
+    assert bool(torch.isfinite(sd.grad).all() and torch.isfinite(td.grad).all())
+    # batch == single item (independent clouds)
+    s1, t1 = src[3:4].to(DEV).requires_grad_(True), tgt[3:4].to(DEV).requires_grad_(True)
+    one = icp.icp(s1, t1, T0[:1], **kw)
+    one["T"].sum().backward()
+    np.testing.assert_allclose(npy(one["T"])[0], npy(out["T"])[3], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(npy(s1.grad)[0], npy(sd.grad)[3], rtol=0, atol=1e-5)
+    # idempotence: restarting from the solution moves by (almost) nothing
+    again = icp.icp(sd.detach(), td.detach(), out["T"].detach(), **kw)
+    assert float((again["T"] - out["T"].detach()).abs().max()) < 1e-4
+
+
+def test_config2_point_to_point_batch32():
+    """configs[1]: B=32 synthetic 4096-pt clouds, point-to-point; oracle parity on a 4-cloud slice."""
+    N, n = 32, 4096
+    src, tgt = make_pairs(N, n, n, seed=1, dtype=torch.float32)
+    tg = tgt[:, :, :3].contiguous()
+    icp = ICP(icp_type="pt2pt", differentiable=True, max_iterations=5, tolerance=1e-12)
+    icp.const_iter = True
+    out = icp.icp(src.to(DEV), tg.to(DEV), torch.eye(4, device=DEV).repeat(N, 1, 1), trim_dist=5.0)
+    sl = slice(10, 14)
+    ref = O.icp_batched(src[sl], tg[sl], torch.eye(4).repeat(4, 1, 1), torch.ones(4, 3 * n), icp_type="pt2pt",
+                        differentiable=True, max_iterations=5, tolerance=1e-12, trim_dist=5.0, const_iter=True)
+    np.testing.assert_allclose(npy(out["T"])[sl], npy(ref["T"]), rtol=0, atol=1e-4)
+    np.testing.assert_allclose(npy(out["costs"])[sl], npy(ref["costs"]), rtol=2e-3, atol=1e-3)
+    assert out["weights"].shape == (N, 5, 3 * n, 1)
+
+
+def test_tolerance_stop_equals_const_iter(golden):
+    """converged clouds are frozen, so running extra constant iterations changes nothing."""
+    g = golden("c1_pt2pl_diff")
+    src, tgt = t(g["source"]), t(g["target"])
+    kw = dict(trim_dist=5.0, loss_fn={"name": "huber", "metric": 10.0}, dim=2)
+    a = ICP(icp_type="pt2pl", max_iterations=100, tolerance=1e-10).icp(src, tgt, t(g["T_init"]), **kw)
+    b_icp = ICP(icp_type="pt2pl", max_iterations=30, tolerance=1e-10)
+    b_icp.const_iter = True
+    b = b_icp.icp(src, tgt, t(g["T_init"]), **kw)
+    assert a["deltas"].shape[1] == 6 and b["deltas"].shape[1] == 30
+    np.testing.assert_allclose(npy(a["T"]), npy(b["T"]), rtol=0, atol=1e-12)
+    assert float(npy(a["stats"]["iterations"])[0]) == 6.0 and float(npy(b["stats"]["iterations"])[0]) == 30.0

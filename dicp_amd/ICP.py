@@ -44,7 +44,8 @@ class ICP:
         # ICP.py:40-44
         self.nn = nn(self.diff, use_gumbel=fun['gumbel'], eps=fun['gumbel_eps'], tau=fun['gumbel_tau'])
         # build-specific knob (not in the reference): which kNN kernel the loop uses
-        self.knn_variant = _lib.KNN_AUTO
+        self.knn_variant = _lib.KNN_AUTO      # _lib.KNN_VALU | KNN_MFMA (brute force) | KNN_SWEEP (exact, slab-pruned)
+        self.knn_stats = {}                   # "knn_pairs": pairs scored by the last call's sweep kNN
         self._timing_hook = None
 
     def icp(self, source, target, T_init, weight=None, trim_dist=None, loss_fn=None, dim=3):
@@ -96,7 +97,7 @@ class ICP:
             const_iter=bool(self.const_iter),
             tanh_steepness=float(self.config['dICP']['parameters']['tanh_steepness']),   # ICP.py:119
             match_ratio_thresh=float(self.match_ratio_thresh),
-            knn_variant=self.knn_variant, timing_hook=self._timing_hook)
+            knn_variant=self.knn_variant, stats_out=self.knn_stats, timing_hook=self._timing_hook)
         T, deltas, weights, costs, converged, iterations, matched = ICPLoop.apply(source, target, T_init, w_pts, cfg)
 
         if self.verbose:                                                                 # ICP.py:262-264

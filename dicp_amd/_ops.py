@@ -12,6 +12,7 @@ import torch
 from . import _lib
 
 _DT = {torch.float32: _lib.F32, torch.float64: _lib.F64}
+SWEEP_MIN_TARGETS = 2048     # KNN_AUTO inside ICP: below this the brute-force kernel is used
 _LOSS = {None: _lib.LOSS_NONE, "huber": _lib.LOSS_HUBER, "cauchy": _lib.LOSS_CAUCHY, "trim": _lib.LOSS_TRIM}
 
 
@@ -68,6 +69,51 @@ def knn(src, pose, tgt4, m, variant=_lib.KNN_AUTO, out=None):
         _lib.check(_lib.load().dicp_knn(_DT[src.dtype], _p(src), _p(pose), _p(tgt4), N, n, m, tgt4.shape[1],
                                         _p(idx), variant, _stream()), "dicp_knn")
     return idx
+
+
+class SweepIndex:
+    """Per-call search structure of the exact sorted-sweep kNN (dicp_knn_sweep): targets do not move during
+    an ICP call, so they are sorted by x once.  Index preparation uses torch.sort/searchsorted (plumbing)."""
+    NBKT = 1024
+
+    def __init__(self, tgt):
+        require_device(tgt, "SweepIndex")
+        N, m, _ = tgt.shape
+        self.m = m
+        tgt4 = pack_target(tgt.contiguous())                     # (N,m_pad,4), pad rows [0,0,0,+inf]
+        m_pad = tgt4.shape[1]
+        big = torch.finfo(tgt.dtype).max
+        key = tgt4[:, :, 0].clone()
+        key[:, m:] = big                                         # pads sort last
+        order = torch.argsort(key, dim=1, stable=True)
+        self.tgs4 = torch.gather(tgt4, 1, order.unsqueeze(-1).expand(-1, -1, 4)).contiguous()
+        self.tgs4[:, m:, 0] = big
+        self.tperm = order.to(torch.int32).contiguous()
+        xs = self.tgs4[:, :m, 0].contiguous()
+        xlo, xhi = xs[:, 0], xs[:, -1]
+        span = (xhi - xlo)
+        inv = torch.where(span > 0, self.NBKT / span.clamp_min(torch.finfo(tgt.dtype).tiny), torch.zeros_like(span))
+        edges = xlo[:, None] + torch.arange(self.NBKT + 1, device=tgt.device, dtype=tgt.dtype)[None, :] * (span / self.NBKT)[:, None]
+        self.bucket = torch.searchsorted(xs, edges.contiguous()).to(torch.int32).contiguous()
+        self.brange = torch.stack((xlo, inv), dim=1).contiguous()
+        self.pairs = torch.zeros((1,), dtype=torch.int64, device=tgt.device)
+
+    def query_order(self, src, pose):
+        """Query indices in ascending transformed x (keeps a wave's queries neighbours)."""
+        if pose is None:
+            x = src[:, :, 0]
+        else:
+            x = (src * pose[:, None, 0:3]).sum(dim=2) + pose[:, None, 9]
+        return torch.argsort(x, dim=1).to(torch.int32).contiguous()
+
+    def knn(self, src, pose, qorder=None, out=None, cfg=0):
+        N, n, _ = src.shape
+        idx = out if out is not None else torch.empty((N, n), dtype=torch.int32, device=src.device)
+        with torch.cuda.device(src.device):
+            _lib.check(_lib.load().dicp_knn_sweep(_DT[src.dtype], _p(src), _p(pose), _p(self.tgs4), _p(self.tperm), _p(qorder),
+                                                  _p(self.bucket), _p(self.brange), self.NBKT, N, n, self.m, self.tgs4.shape[1],
+                                                  _p(idx), _p(self.pairs), cfg, _stream()), "dicp_knn_sweep")
+        return idx
 
 
 class _GatherRows(torch.autograd.Function):
@@ -145,6 +191,8 @@ class LoopConfig:
     tanh_steepness: float
     match_ratio_thresh: float
     knn_variant: int = _lib.KNN_AUTO
+    sweep_resort: tuple = (0, 1)  # iterations at which the sweep kNN re-sorts its queries by x
+    stats_out: object = None      # optional dict: receives "knn_pairs" (pairs scored by the sweep kNN)
     timing_hook: object = None    # optional callable(name, phase) used by bench.py to drop HIP events
 
     def params(self):
@@ -195,7 +243,15 @@ class ICPLoop(torch.autograd.Function):
 
         with torch.cuda.device(dev):
             st = _stream()
-            tgt4 = pack_target(tgt)
+            sweep = None
+            kind = cfg.knn_variant & 0xff
+            if kind == _lib.KNN_AUTO:       # exact slab-pruned search once the clouds are big enough to repay the sort
+                kind = _lib.KNN_SWEEP if (m >= SWEEP_MIN_TARGETS and n >= 64) else _lib.KNN_VALU
+            if kind == _lib.KNN_SWEEP:
+                sweep = SweepIndex(tgt)
+                tgt4, qorder = sweep.tgs4, None
+            else:
+                tgt4 = pack_target(tgt)
             m_pad = tgt4.shape[1]
             nblk = lib.dicp_accumulate_blocks(n)
             poses = torch.empty((Kmax + 1, N, 12), dtype=dt, device=dev)
@@ -219,7 +275,13 @@ class ICPLoop(torch.autograd.Function):
                 idx = torch.empty((N, n), dtype=torch.int32, device=dev)
                 if hook:
                     hook("knn", 0)
-                _lib.check(lib.dicp_knn(code, _p(src), _p(poses[k]), _p(tgt4), N, n, m, m_pad, _p(idx), cfg.knn_variant, st), "dicp_knn")
+                if sweep is not None:
+                    if k in cfg.sweep_resort:                   # queries re-sorted by x under the current pose
+                        qorder = sweep.query_order(src, poses[k])
+                    sweep.knn(src, poses[k], qorder, out=idx, cfg=(cfg.knn_variant >> 8) & 0xff)
+                else:
+                    _lib.check(lib.dicp_knn(code, _p(src), _p(poses[k]), _p(tgt4), N, n, m, m_pad, _p(idx),
+                                            kind | (cfg.knn_variant & 0xff00), st), "dicp_knn")
                 if hook:
                     hook("knn", 1)
                 wk = torch.empty((N, n), dtype=dt, device=dev)
@@ -252,6 +314,8 @@ class ICPLoop(torch.autograd.Function):
             ratio = n_matched.to(torch.int64) / start           # int64/int64 -> float32, as in the reference
             matched = torch.where(matched == 0, ratio.to(dt), matched)
 
+            if sweep is not None and cfg.stats_out is not None:
+                cfg.stats_out["knn_pairs"] = sweep.pairs          # device int64 (read it after a sync)
             pose_K = poses[K]
             T = torch.zeros((N, 4, 4), dtype=dt, device=dev)
             T[:, :3, :3] = pose_K[:, :9].reshape(N, 3, 3)

@@ -345,6 +345,172 @@ __global__ __launch_bounds__(BLOCK) void knn_mfma_kernel(const float* __restrict
     }
 }
 
+// ------------------------------------------------------------------ kNN (sweep)
+// Exact 1-NN with slab pruning (same answer and tie rule as the brute-force kernels, far fewer pairs):
+// the targets of a cloud are sorted by x ONCE per ICP call (they do not move); a wave owns 64*Q queries
+// that are neighbours in x, starts at the target tile under them and sweeps tiles outwards, right and
+// left alternately.  A side stops when its next tile starts further away in x alone than every query's
+// current best distance: score(y) = 0.5|x-y|^2 - 0.5|x|^2 >= 0.5 (edge - x.x)^2 - 0.5|x|^2.
+// The bound is applied with a safety margin far above the rounding error of a score, so a skipped
+// target can never beat the kept minimum; exact score ties (duplicates) are detected and resolved to the
+// lowest ORIGINAL index by a rare re-scan of the visited range.
+template <typename T> struct SweepEps;
+template <> struct SweepEps<float>  { static constexpr float  v = 1e-4f; };
+template <> struct SweepEps<double> { static constexpr double v = 1e-10; };
+
+template <typename T, int Q>
+__global__ __launch_bounds__(BLOCK) void knn_sweep_kernel(const T* __restrict__ src, const T* __restrict__ pose,
+                                                          const typename V4<T>::type* __restrict__ tgs4,
+                                                          const int32_t* __restrict__ tperm, const int32_t* __restrict__ qorder,
+                                                          const int32_t* __restrict__ bucket, const T* __restrict__ brange, int nbkt,
+                                                          int32_t* __restrict__ idx, unsigned long long* __restrict__ pairs,
+                                                          int N, int n, int m, int m_pad, int bpc) {
+    using T4 = typename V4<T>::type;
+    constexpr int CH = 8;
+    __shared__ T4 tiles[BLOCK / WAVE][WAVE];
+    int cloud, blk;
+    if (!decode_block(bpc, N, cloud, blk)) return;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
+    const int unit = blk * (BLOCK / WAVE) + wave;           // 64*Q consecutive sorted queries
+    if (unit * (WAVE * Q) >= n) return;                     // whole wave idle (no block-level sync below)
+    T C[9], r[3];
+    load_pose(pose, cloud, C, r);
+    T4* tile = tiles[wave];
+
+    T nx[Q][3], xq[Q], hx[Q], best[Q];
+    int qi[Q], c1[Q], c2[Q];          // c1: chunk that set the minimum; c2: a second chunk with an EQUAL minimum
+    bool over[Q];                     // three or more chunks tied: resolved by re-scanning the visited range
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int pos = unit * (WAVE * Q) + q * WAVE + lane;
+        qi[q] = -1;
+        T p[3] = {T(0), T(0), T(0)};
+        if (pos < n) {
+            qi[q] = qorder ? qorder[(size_t)cloud * n + pos] : pos;
+            const T* sp = src + ((size_t)cloud * n + qi[q]) * 3;
+            p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2];
+        }
+        T v[3];
+        matvec3(C, p, v);
+        v[0] += r[0]; v[1] += r[1]; v[2] += r[2];
+        nx[q][0] = -v[0]; nx[q][1] = -v[1]; nx[q][2] = -v[2];
+        xq[q] = v[0];
+        hx[q] = T(0.5) * (v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        best[q] = inf_v<T>();
+        c1[q] = 0; c2[q] = -1;
+        over[q] = false;
+    }
+    // idle slots of a partial last wave take a real query's values (their own first one, else lane 0's:
+    // lane 0 of a live wave always holds a real query) so that they never hold the sweep open
+    {
+        const T b0 = __shfl(nx[0][0], 0), b1 = __shfl(nx[0][1], 0), b2 = __shfl(nx[0][2], 0), bx = __shfl(xq[0], 0), bh = __shfl(hx[0], 0);
+        if (qi[0] < 0) { nx[0][0] = b0; nx[0][1] = b1; nx[0][2] = b2; xq[0] = bx; hx[0] = bh; }
+#pragma unroll
+        for (int q = 1; q < Q; ++q)
+            if (qi[q] < 0) { nx[q][0] = nx[0][0]; nx[q][1] = nx[0][1]; nx[q][2] = nx[0][2]; xq[q] = xq[0]; hx[q] = hx[0]; }
+    }
+
+    const T4* __restrict__ tg = tgs4 + (size_t)cloud * m_pad;
+    const int ntiles = m_pad / WAVE;
+    // start under the wave's middle query: coarse bucket table of lower_bound positions (built once per call)
+    const T xc = __shfl(xq[Q / 2], WAVE / 2);
+    const T xlo = brange[(size_t)cloud * 2], inv = brange[(size_t)cloud * 2 + 1];
+    T fb = (xc - xlo) * inv;
+    fb = fb < T(0) ? T(0) : (fb > T(nbkt) ? T(nbkt) : fb);
+    const int start = bucket[(size_t)cloud * (nbkt + 1) + (int)fb];
+    int tR = min(max(start / WAVE, 0), ntiles - 1), tL = tR - 1;
+    int visR = tR, visL = tR;                               // tiles [visL, visR) have been scored
+    T edgeR = -inf_v<T>(), edgeL = inf_v<T>();
+    // both directions keep their next tile in flight while the current one is being scored
+    T4 preR = tg[(size_t)tR * WAVE + lane];
+    T4 preL = tg[(size_t)max(tL, 0) * WAVE + lane];
+
+    auto process = [&](const T4& mine, int t) {
+        tile[lane] = mine;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+        for (int j0 = 0; j0 < WAVE; j0 += CH) {
+            T4 y[CH];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) y[k] = tile[j0 + k];
+            const int chunk = t * WAVE + j0;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                T cm = score<T, T4>(nx[q], y[0]);
+#pragma unroll
+                for (int k = 1; k < CH; ++k) cm = min_t(cm, score<T, T4>(nx[q], y[k]));
+                const bool lt = cm < best[q];
+                const bool eq = (cm == best[q]) && (cm < inf_v<T>());
+                over[q] = lt ? false : (over[q] || (eq && c2[q] >= 0));
+                c2[q] = lt ? -1 : ((eq && c2[q] < 0) ? chunk : c2[q]);
+                c1[q] = lt ? chunk : c1[q];
+                best[q] = lt ? cm : best[q];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto prunable = [&](T edge, bool right) {
+        bool ok = true;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const T dx = right ? edge - xq[q] : xq[q] - edge;
+            const T lb = T(0.5) * dx * dx - hx[q];
+            const T mg = SweepEps<T>::v * (T(1) + m_abs(best[q]) + hx[q]);
+            ok = ok && (dx > T(0)) && (lb > best[q] + mg);
+        }
+        return __all(ok) != 0;
+    };
+
+    while (tR < ntiles || tL >= 0) {
+        if (tR < ntiles) {
+            if (prunable(edgeR, true)) tR = ntiles;
+            else {
+                const T4 cur = preR;
+                if (tR + 1 < ntiles) preR = tg[(size_t)(tR + 1) * WAVE + lane];
+                process(cur, tR);
+                edgeR = __shfl(cur.x, WAVE - 1);
+                visR = ++tR;
+            }
+        }
+        if (tL >= 0) {
+            if (prunable(edgeL, false)) tL = -1;
+            else {
+                const T4 cur = preL;
+                if (tL >= 1) preL = tg[(size_t)(tL - 1) * WAVE + lane];
+                process(cur, tL);
+                edgeL = __shfl(cur.x, 0);
+                visL = tL--;
+            }
+        }
+    }
+
+    const int32_t* __restrict__ pm = tperm + (size_t)cloud * m_pad;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        if (qi[q] < 0) continue;
+        T bv = inf_v<T>();
+        int bo = 0x7fffffff;
+        auto consider = [&](int j) {
+            const T sc = score<T, T4>(nx[q], tg[j]);
+            const int o = pm[j];
+            if (sc < bv || (sc == bv && o < bo)) { bv = sc; bo = o; }     // lowest ORIGINAL index among equals
+        };
+        if (!over[q]) {
+#pragma unroll
+            for (int k = 0; k < CH; ++k) consider(c1[q] + k);
+            if (c2[q] >= 0) {
+#pragma unroll
+                for (int k = 0; k < CH; ++k) consider(c2[q] + k);
+            }
+        } else {
+            // >= 3 chunks share the minimum (duplicated targets): rare, re-scan what this wave visited
+            for (int j = visL * WAVE; j < visR * WAVE; ++j) consider(j);
+        }
+        idx[(size_t)cloud * n + qi[q]] = (bo == 0x7fffffff) ? 0 : min(max(bo, 0), m - 1);
+    }
+    if (pairs && lane == 0) atomicAdd(pairs, (unsigned long long)(visR - visL) * WAVE * WAVE * Q);
+}
+
 // ------------------------------------------------------------- gather / scatter
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void gather_kernel(const T* __restrict__ tgt, const int32_t* __restrict__ idx,
@@ -767,6 +933,28 @@ int dicp_knn(int dtype, const void* src, const void* pose, const void* tgt4, int
     if (kind == DICP_KNN_MFMA) return knn_mfma_launch(cfg, src, pose, tgt4, N, n, m, m_pad, idx, st);
     if (dtype == DICP_F32) return knn_valu_launch<float>(cfg, src, pose, tgt4, N, n, m, m_pad, idx, st);
     return knn_valu_launch<double>(cfg, src, pose, tgt4, N, n, m, m_pad, idx, st);
+}
+
+int dicp_knn_sweep(int dtype, const void* src, const void* pose, const void* tgs4, const int32_t* tperm,
+                   const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt,
+                   int N, int n, int m, int m_pad, int32_t* idx, unsigned long long* pairs, int cfg, void* stream) {
+    if (!src || !tgs4 || !tperm || !bucket || !brange || !idx) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0 || n <= 0 || m <= 0 || nbkt <= 0 || m_pad != dicp_padded_targets(m)) return DICP_ERR_SHAPE;
+    if ((uintptr_t)tgs4 % (dtype == DICP_F32 ? 16 : 32)) return DICP_ERR_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    begin_launch();
+    if (cfg == 0) cfg = ((long)N * n >= 2L * BLOCK * 1024) ? 2 : 1;
+#define DICP_SWEEP(T, Q) do { const int units = (n + WAVE * Q - 1) / (WAVE * Q), bpc = (units + BLOCK / WAVE - 1) / (BLOCK / WAVE); \
+        knn_sweep_kernel<T, Q><<<grid_for(N, bpc), BLOCK, 0, st>>>((const T*)src, (const T*)pose, (const typename V4<T>::type*)tgs4, tperm, qorder, \
+            bucket, (const T*)brange, nbkt, idx, pairs, N, n, m, m_pad, bpc); } while (0)
+    if (dtype == DICP_F32) {
+        if (cfg == 1) DICP_SWEEP(float, 1); else if (cfg == 2) DICP_SWEEP(float, 2); else if (cfg == 3) DICP_SWEEP(float, 4); else return DICP_ERR_ENUM;
+    } else {
+        if (cfg == 1) DICP_SWEEP(double, 1); else if (cfg == 2) DICP_SWEEP(double, 2); else if (cfg == 3) DICP_SWEEP(double, 4); else return DICP_ERR_ENUM;
+    }
+#undef DICP_SWEEP
+    return launch_status();
 }
 
 int dicp_gather_rows(int dtype, const void* tgt, const int32_t* idx, int N, int n, int m, int c, void* out, void* stream) {

@@ -46,8 +46,11 @@ class nn:
     def _index(self, x, y):
         if x.dtype != y.dtype:
             raise TypeError("x and y must share a dtype, got %s and %s" % (x.dtype, y.dtype))
-        tgt4 = _ops.pack_target(y.detach().contiguous())
-        return _ops.knn(x.detach().contiguous(), None, tgt4, y.shape[1], self.knn_variant)
+        xd, yd = x.detach().contiguous(), y.detach().contiguous()
+        if (self.knn_variant & 0xff) == _lib.KNN_SWEEP:
+            sw = _ops.SweepIndex(yd)
+            return sw.knn(xd, None, sw.query_order(xd, None), cfg=(self.knn_variant >> 8) & 0xff)
+        return _ops.knn(xd, None, _ops.pack_target(yd), y.shape[1], self.knn_variant)
 
     def _hard(self, x, y):
         return _ops.gather_rows(y, self._index(x, y))

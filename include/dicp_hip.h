@@ -29,7 +29,7 @@ extern "C" {
 enum { DICP_F32 = 0, DICP_F64 = 1 };
 enum { DICP_PT2PT = 0, DICP_PT2PL = 1 };                 /* ICP(icp_type=...)  ICP.py:15,101-105 */
 enum { DICP_LOSS_NONE = 0, DICP_LOSS_HUBER = 1, DICP_LOSS_CAUCHY = 2, DICP_LOSS_TRIM = 3 };
-enum { DICP_KNN_AUTO = 0, DICP_KNN_VALU = 1, DICP_KNN_MFMA = 2 };
+enum { DICP_KNN_AUTO = 0, DICP_KNN_VALU = 1, DICP_KNN_MFMA = 2, DICP_KNN_SWEEP = 3 /* via dicp_knn_sweep */ };
 enum { DICP_ERR_NULL = 1, DICP_ERR_SHAPE = 2, DICP_ERR_DTYPE = 3, DICP_ERR_ENUM = 4, DICP_ERR_ALIGN = 5 };
 
 /* Accumulator layout of one (cloud, block) partial: see dicp_amd/csrc/dicp_math.h */
@@ -67,6 +67,19 @@ int dicp_pack_target(int dtype, const void* tgt, int N, int m, int c, void* tgt4
  *   bits 8..15 optionally pin a launch configuration (0 = chosen from the problem size). */
 int dicp_knn(int dtype, const void* src, const void* pose, const void* tgt4, int N, int n, int m, int m_pad,
              int32_t* idx, int variant, void* stream);
+
+/* Exact 1-NN with slab pruning: same result (and lowest-index tie rule) as dicp_knn, far fewer pairs.
+ * The caller prepares, ONCE per ICP call (targets do not move between iterations):
+ *   tgs4  (N,m_pad,4)  the rows of dicp_pack_target re-ordered by ascending x (pad rows last, x = +max);
+ *   tperm (N,m_pad)    original row index of each sorted row;
+ *   bucket (N,nbkt+1)  bucket[b] = #rows with x < xlo + b/inv  (lower_bound table), brange (N,2) = [xlo, inv];
+ *   qorder (N,n)       optional: query indices in ascending x (under any recent pose) so that a wave's
+ *                      queries are neighbours; NULL = natural order (still exact, less pruning).
+ * pairs: optional device counter, += number of (query,target) pairs actually scored (roofline accounting).
+ * cfg: 0 auto, 1..3 = 1/2/4 queries per lane. */
+int dicp_knn_sweep(int dtype, const void* src, const void* pose, const void* tgs4, const int32_t* tperm,
+                   const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt,
+                   int N, int n, int m, int m_pad, int32_t* idx, unsigned long long* pairs, int cfg, void* stream);
 
 /* Gather whole target rows at idx (nn.py:37-38 / 89-90) and its backward, a scatter-add
  * into a zero-initialised (N,m,c) buffer (autograd's gather backward). */

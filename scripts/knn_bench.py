@@ -33,6 +33,25 @@ for rnd in range(rounds + 1):
                 ref = idx.clone()
             else:
                 print("%-12s mismatches vs first variant: %d" % (name, int((idx != ref).sum())))
+# exact sorted-sweep variants
+sw = _ops.SweepIndex(tgt)
+qo = sw.query_order(src, None)
+for name, cfg, q in (("sweep_q1", 1, qo), ("sweep_q2", 2, qo), ("sweep_q4", 3, qo), ("sweep_q2_unsorted", 2, None)):
+    if sel and name not in sel.split(","):
+        continue
+    ts = []
+    for rnd in range(rounds + 1):
+        sw.pairs.zero_()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        sw.knn(src, None, q, out=idx, cfg=cfg)
+        b.record()
+        torch.cuda.synchronize()
+        if rnd:
+            ts.append(a.elapsed_time(b))
+        elif ref is not None:
+            print("%-12s mismatches vs first variant: %d   pairs scored: %.2f%% of brute force" % (name, int((idx != ref).sum()), 100.0 * sw.pairs.item() / (float(B) * n * n)))
+    times[name] = ts
 pairs = float(B) * n * n
 print("lib:", _lib.LIB_PATH)
 for name, ts in times.items():

@@ -480,3 +480,102 @@ def test_tolerance_stop_equals_const_iter(golden):
     assert a["deltas"].shape[1] == 6 and b["deltas"].shape[1] == 30
     np.testing.assert_allclose(npy(a["T"]), npy(b["T"]), rtol=0, atol=1e-12)
     assert float(npy(a["stats"]["iterations"])[0]) == 6.0 and float(npy(b["stats"]["iterations"])[0]) == 30.0
+
+
+# ----------------------------------------------------------- exact sorted-sweep kNN (dicp_knn_sweep)
+def sweep_knn(x, y, pose=None, sort_queries=True, cfg=0):
+    sw = _ops.SweepIndex(y)
+    return sw.knn(x, pose, sw.query_order(x, pose) if sort_queries else None, cfg=cfg), sw
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("N,n,m", [(1, 1, 1), (3, 70, 90), (2, 257, 16), (5, 1000, 2049), (2, 2100, 4100), (9, 130, 64)])
+def test_sweep_knn_equals_brute_force(dtype, N, n, m):
+    g = torch.Generator().manual_seed(N * 1000 + n + 1)
+    x = (torch.rand((N, n, 3), generator=g, dtype=torch.float64) * 10 - 5).to(dtype).to(DEV)
+    y = (torch.rand((N, m, 6), generator=g, dtype=torch.float64) * 10 - 5).to(dtype).to(DEV)
+    brute = _ops.knn(x, None, _ops.pack_target(y), m, _lib.KNN_VALU)
+    for cfg in (1, 2, 3):
+        for sort_q in (True, False):
+            got, sw = sweep_knn(x, y, sort_queries=sort_q, cfg=cfg)
+            assert torch.equal(got, brute), (cfg, sort_q)        # same scores, same tie rule: bit-identical indices
+    if dtype == torch.float64:
+        assert torch.equal(brute.cpu().long(), O.nn_index(x.cpu(), y.cpu()))
+
+
+def test_sweep_knn_ties_duplicates_and_pads():
+    """Duplicated targets (exact score ties across chunks and tiles) resolve to the lowest ORIGINAL index,
+    like torch.argmin; pad rows never win; a fused pose is honoured."""
+    g = torch.Generator().manual_seed(3)
+    base = torch.rand((2, 50, 3), generator=g, dtype=torch.float32) * 6
+    y = base.repeat(1, 7, 1)[:, torch.randperm(350, generator=g)]            # every point 7 times, shuffled
+    y = torch.cat((y, torch.full((2, 30, 3), 6000.0)), dim=1).to(DEV)        # + pad rows (ICP.py:460)
+    x = (base[:, :40] + 0.01 * torch.rand((2, 40, 3), generator=g)).to(DEV)
+    brute = _ops.knn(x, None, _ops.pack_target(y), 380, _lib.KNN_VALU)
+    # among exact duplicates the kernels return the lowest index; the reference's pick depends on how its
+    # BLAS rounds each column of the cdist matmul, so only "same point, nothing nearer" is comparable
+    ref = O.nn_index(x.cpu().double(), y.cpu().double())
+    pick = lambda ix: torch.gather(y.cpu(), 1, ix.cpu().long().unsqueeze(-1).expand(-1, -1, 3))
+    assert torch.equal(pick(brute), pick(ref))
+    first = torch.stack([torch.stack([(y[b] == y[b, brute[b, i]]).all(dim=1).nonzero()[0, 0] for i in range(40)]) for b in range(2)])
+    assert torch.equal(brute.cpu().long(), first.cpu())
+    for cfg in (1, 2, 3):
+        got, _ = sweep_knn(x, y, cfg=cfg)
+        assert torch.equal(got, brute)
+    ang = 0.4
+    C = torch.tensor([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1.0]], dtype=torch.float32)
+    r = torch.tensor([0.5, -0.2, 0.1])
+    pose = torch.cat((C.reshape(9), r)).repeat(2, 1).to(DEV)
+    got, _ = sweep_knn(x, y, pose=pose)
+    assert torch.equal(got, _ops.knn(x, pose, _ops.pack_target(y), 380, _lib.KNN_VALU))
+    # degenerate: every target on one x plane (no pruning possible) and identical points
+    flat = y.clone()
+    flat[:, :, 0] = 1.0
+    got, _ = sweep_knn(x, flat)
+    assert torch.equal(got, _ops.knn(x, None, _ops.pack_target(flat), 380, _lib.KNN_VALU))
+
+
+def test_sweep_knn_full_size_and_pruning():
+    """configs[2] cloud size: identical to brute force on every query, while scoring a small fraction of pairs."""
+    N, n = 16, 16384
+    src, tgt = make_pairs(N, n, n, seed=7, dtype=torch.float32)
+    sd, td = src.to(DEV), tgt.to(DEV)
+    brute = _ops.knn(sd, None, _ops.pack_target(td), n, _lib.KNN_VALU)
+    got, sw = sweep_knn(sd, td)
+    assert torch.equal(got, brute)
+    frac = float(sw.pairs.item()) / (float(N) * n * n)
+    assert frac < 0.25, frac
+    got2, _ = sweep_knn(sd, td, sort_queries=False)                         # unsorted queries: still exact
+    assert torch.equal(got2, brute)
+
+
+@pytest.mark.parametrize("name,icp_type,diff", [("c1_pt2pt_diff", "pt2pt", True), ("c1_pt2pl_diff", "pt2pl", True)])
+def test_icp_with_sweep_knn_matches_reference(golden, name, icp_type, diff):
+    g = golden(name)
+    trim, huber, tol, max_iter = g["params"]
+    src, tgt = t(g["source"], grad=True), t(g["target"], grad=True)
+    icp = ICP(icp_type=icp_type, differentiable=diff, max_iterations=int(max_iter), tolerance=float(tol))
+    icp.knn_variant = _lib.KNN_SWEEP
+    res = icp.icp(src, tgt, t(g["T_init"]), trim_dist=float(trim), loss_fn={"name": "huber", "metric": float(huber)}, dim=2)
+    check_result(res, g)
+    res["T"].sum().backward()
+    np.testing.assert_allclose(npy(src.grad), g["grad_source"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(npy(tgt.grad), g["grad_target"], rtol=0, atol=1e-10)
+    assert int(icp.knn_stats["knn_pairs"].item()) > 0
+
+
+def test_icp_sweep_equals_brute_on_synthetic():
+    N, n, K = 6, 4096, 6
+    src, tgt = make_pairs(N, n, n, seed=5, dtype=torch.float32)
+    outs = []
+    for variant in (_lib.KNN_VALU, _lib.KNN_SWEEP):
+        sd, td = src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True)
+        icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
+        icp.const_iter = True
+        icp.knn_variant = variant
+        out = icp.icp(sd, td, torch.eye(4, device=DEV).repeat(N, 1, 1), trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0})
+        out["T"].sum().backward()
+        outs.append((out, sd.grad, td.grad))
+    assert torch.equal(outs[0][0]["T"], outs[1][0]["T"]) and torch.equal(outs[0][0]["weights"], outs[1][0]["weights"])
+    assert torch.equal(outs[0][1], outs[1][1])
+    np.testing.assert_allclose(npy(outs[0][2]), npy(outs[1][2]), rtol=0, atol=1e-6)     # float atomics order

@@ -5,6 +5,7 @@ arithmetic step of the ICP iteration runs in libdicp_hip.so.  All functions requ
 HIP-device tensors and raise otherwise -- there is no CPU compute path.
 """
 import ctypes
+import os
 from dataclasses import dataclass
 
 import torch
@@ -191,7 +192,7 @@ class LoopConfig:
     tanh_steepness: float
     match_ratio_thresh: float
     knn_variant: int = _lib.KNN_AUTO
-    sweep_resort: tuple = (0, 1)  # iterations at which the sweep kNN re-sorts its queries by x
+    sweep_resort: tuple = tuple(int(v) for v in os.environ.get("DICP_SWEEP_RESORT", "0,1").split(","))  # iterations at which the sweep kNN re-sorts its queries by x
     stats_out: object = None      # optional dict: receives "knn_pairs" (pairs scored by the sweep kNN)
     timing_hook: object = None    # optional callable(name, phase) used by bench.py to drop HIP events
 

@@ -358,7 +358,7 @@ template <typename T> struct SweepEps;
 template <> struct SweepEps<float>  { static constexpr float  v = 1e-4f; };
 template <> struct SweepEps<double> { static constexpr double v = 1e-10; };
 
-template <typename T, int Q>
+template <typename T, int Q, int CH>
 __global__ __launch_bounds__(BLOCK) void knn_sweep_kernel(const T* __restrict__ src, const T* __restrict__ pose,
                                                           const typename V4<T>::type* __restrict__ tgs4,
                                                           const int32_t* __restrict__ tperm, const int32_t* __restrict__ qorder,
@@ -366,7 +366,6 @@ __global__ __launch_bounds__(BLOCK) void knn_sweep_kernel(const T* __restrict__ 
                                                           int32_t* __restrict__ idx, unsigned long long* __restrict__ pairs,
                                                           int N, int n, int m, int m_pad, int bpc) {
     using T4 = typename V4<T>::type;
-    constexpr int CH = 8;
     __shared__ T4 tiles[BLOCK / WAVE][WAVE];
     int cloud, blk;
     if (!decode_block(bpc, N, cloud, blk)) return;
@@ -944,14 +943,24 @@ int dicp_knn_sweep(int dtype, const void* src, const void* pose, const void* tgs
     if ((uintptr_t)tgs4 % (dtype == DICP_F32 ? 16 : 32)) return DICP_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
     begin_launch();
-    if (cfg == 0) cfg = ((long)N * n >= 2L * BLOCK * 1024) ? 2 : 1;
-#define DICP_SWEEP(T, Q) do { const int units = (n + WAVE * Q - 1) / (WAVE * Q), bpc = (units + BLOCK / WAVE - 1) / (BLOCK / WAVE); \
-        knn_sweep_kernel<T, Q><<<grid_for(N, bpc), BLOCK, 0, st>>>((const T*)src, (const T*)pose, (const typename V4<T>::type*)tgs4, tperm, qorder, \
+    if (cfg == 0) cfg = ((long)N * n >= 2L * BLOCK * 1024) ? 8 : 4;      // 3 (else 1) queries per lane, 16-target chunks
+#define DICP_SWEEP(T, Q, CH) do { const int units = (n + WAVE * Q - 1) / (WAVE * Q), bpc = (units + BLOCK / WAVE - 1) / (BLOCK / WAVE); \
+        knn_sweep_kernel<T, Q, CH><<<grid_for(N, bpc), BLOCK, 0, st>>>((const T*)src, (const T*)pose, (const typename V4<T>::type*)tgs4, tperm, qorder, \
             bucket, (const T*)brange, nbkt, idx, pairs, N, n, m, m_pad, bpc); } while (0)
     if (dtype == DICP_F32) {
-        if (cfg == 1) DICP_SWEEP(float, 1); else if (cfg == 2) DICP_SWEEP(float, 2); else if (cfg == 3) DICP_SWEEP(float, 4); else return DICP_ERR_ENUM;
+        switch (cfg) {
+            case 1: DICP_SWEEP(float, 1, 8); break;   case 2: DICP_SWEEP(float, 2, 8); break;   case 3: DICP_SWEEP(float, 4, 8); break;
+            case 4: DICP_SWEEP(float, 1, 16); break;  case 5: DICP_SWEEP(float, 2, 16); break;  case 6: DICP_SWEEP(float, 4, 16); break;
+            case 7: DICP_SWEEP(float, 3, 8); break;   case 8: DICP_SWEEP(float, 3, 16); break;
+            default: return DICP_ERR_ENUM;
+        }
     } else {
-        if (cfg == 1) DICP_SWEEP(double, 1); else if (cfg == 2) DICP_SWEEP(double, 2); else if (cfg == 3) DICP_SWEEP(double, 4); else return DICP_ERR_ENUM;
+        switch (cfg) {
+            case 1: case 4: DICP_SWEEP(double, 1, 8); break;
+            case 2: case 5: case 7: case 8: DICP_SWEEP(double, 2, 8); break;
+            case 3: case 6: DICP_SWEEP(double, 4, 8); break;
+            default: return DICP_ERR_ENUM;
+        }
     }
 #undef DICP_SWEEP
     return launch_status();

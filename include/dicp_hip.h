@@ -76,7 +76,7 @@ int dicp_knn(int dtype, const void* src, const void* pose, const void* tgt4, int
  *   qorder (N,n)       optional: query indices in ascending x (under any recent pose) so that a wave's
  *                      queries are neighbours; NULL = natural order (still exact, less pruning).
  * pairs: optional device counter, += number of (query,target) pairs actually scored (roofline accounting).
- * cfg: 0 auto, 1..3 = 1/2/4 queries per lane. */
+ * cfg: 0 auto, 1.. = fixed (queries per lane, chunk) launch configuration (tuning). */
 int dicp_knn_sweep(int dtype, const void* src, const void* pose, const void* tgs4, const int32_t* tperm,
                    const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt,
                    int N, int n, int m, int m_pad, int32_t* idx, unsigned long long* pairs, int cfg, void* stream);

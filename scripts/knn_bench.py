@@ -36,7 +36,8 @@ for rnd in range(rounds + 1):
 # exact sorted-sweep variants
 sw = _ops.SweepIndex(tgt)
 qo = sw.query_order(src, None)
-for name, cfg, q in (("sweep_q1", 1, qo), ("sweep_q2", 2, qo), ("sweep_q4", 3, qo), ("sweep_q2_unsorted", 2, None)):
+for name, cfg, q in (("sweep_q1", 1, qo), ("sweep_q2", 2, qo), ("sweep_q4", 3, qo), ("sweep_q2_unsorted", 2, None),
+                     ("sweep_q1c16", 4, qo), ("sweep_q2c16", 5, qo), ("sweep_q4c16", 6, qo), ("sweep_q3", 7, qo), ("sweep_q3c16", 8, qo)):
     if sel and name not in sel.split(","):
         continue
     ts = []

@@ -18,7 +18,7 @@ import torch
 import yaml
 
 from . import _lib
-from ._ops import ICPLoop, LoopConfig, compute_device
+from ._ops import ICPLoop, KabschLoop, LoopConfig, compute_device
 from .nn import nn
 
 
@@ -120,6 +120,36 @@ class ICP:
             results = {k: (v.to(home) if k != "stats" else {s: x.to(home) for s, x in v.items()})
                        for k, v in results.items()}
         return results
+
+    def pt2pt_dICP_SVD(self, source, target, T_init, trim_dist=None, huber_delta=None, dim=3, weight=None):
+        """SVD-based point-to-point ICP (reference: ICP.py:533-591, "not yet integrated").
+
+        Same signature and return value as the reference -- (transformed source, T_ts) -- for a single pair
+        (n,3|6), (m,3|6), (4,4); additionally accepts every batched / list form ``icp`` accepts and then
+        returns (N,n,3), (N,4,4).  The step is the correct Kabsch solution C = U diag(1,1,det U det V) V^T,
+        r = mu_t - C mu_s (the reference multiplies by V instead of V^T, ICP.py:566-570, which is only right
+        for planar scenes; on those -- e.g. the bundled tests/data -- both reach the same pose).
+        Differences kept honest: ``T_init`` seeds the first correspondence search (the reference folds it into
+        the product without moving the points, ICP.py:545-547,578); ``trim_dist`` gates matches farther than
+        that (the reference ignores it); ``huber_delta`` and ``dim`` are accepted and ignored, as there;
+        ``weight`` (build-specific) gives per-point weights.  Stops when sum |T p - nn|^2 < tolerance (ICP.py:585).
+        """
+        single = not isinstance(source, list) and source is not None and source.dim() == 2
+        s_b, t_b, T_b, w_pts = self._batch(source, target, T_init, weight)
+        t_b = t_b[:, :, :3]                                                              # ICP.py:548
+        assert s_b.dtype == t_b.dtype == T_b.dtype
+        home = s_b.device
+        dev = home if s_b.is_cuda else compute_device()
+        s_b, t_b, T_b, w_pts = (t.to(dev) for t in (s_b, t_b, T_b, w_pts))
+        T, costs, iterations = KabschLoop.apply(s_b, t_b, T_b, w_pts, int(self.max_iterations), float(self.tolerance),
+                                                trim_dist, bool(self.const_iter), self.knn_variant)
+        if self.verbose:                                                                 # ICP.py:588-589
+            print("ICP converged in {} iterations".format(int(iterations.max().item()) - 1))
+        pc = s_b @ T[:, :3, :3].transpose(1, 2) + T[:, :3, 3].unsqueeze(1)               # ICP.py:581
+        self.svd_stats = {"costs": costs, "iterations": iterations}
+        if home != dev:
+            pc, T = pc.to(home), T.to(home)
+        return (pc[0], T[0]) if single else (pc, T)
 
     # ------------------------------------------------------------------ batching
     def batch_size_handling(self, source, target, T_init=None, weight=None):

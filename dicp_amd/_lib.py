@@ -18,7 +18,7 @@ F32, F64 = 0, 1
 PT2PT, PT2PL = 0, 1
 LOSS_NONE, LOSS_HUBER, LOSS_CAUCHY, LOSS_TRIM = 0, 1, 2, 3
 KNN_AUTO, KNN_VALU, KNN_MFMA, KNN_SWEEP = 0, 1, 2, 3
-NACC_PAD, NBWD_PAD = 32, 16
+NACC_PAD, NBWD_PAD, KAB_SAVE = 32, 16, 40
 _ERRORS = {1: "null pointer", 2: "bad shape/stride", 3: "unsupported dtype", 4: "bad enum value", 5: "misaligned buffer"}
 
 vp, i32, i64, f64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
@@ -53,6 +53,10 @@ _SIGNATURES = {
     "dicp_step": ([i32, ctypes.POINTER(StepIO), i32, vp], ctypes.c_int),
     "dicp_step_bwd": ([i32, vp, vp, i32, i32, vp, vp, i64, vp, vp, vp, vp, i32, vp], ctypes.c_int),
     "dicp_accumulate_bwd": ([i32, ctypes.POINTER(WeightParams), vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp], ctypes.c_int),
+    "dicp_kabsch_accumulate": ([i32, vp, vp, i32, vp, vp, vp, i32, f64, i32, i32, i32, vp, vp], ctypes.c_int),
+    "dicp_kabsch_step": ([i32, vp, i32, vp, vp, vp, i32, vp], ctypes.c_int),
+    "dicp_kabsch_step_bwd": ([i32, vp, vp, vp, i32, vp], ctypes.c_int),
+    "dicp_kabsch_bwd": ([i32, vp, vp, i32, vp, vp, vp, i32, f64, vp, i32, i32, i32, vp, vp, vp, vp], ctypes.c_int),
     "dicp_loss_weight": ([i32, i32, i32, f64, f64, vp, i64, i32, vp, vp], ctypes.c_int),
     "dicp_loss_weight_bwd": ([i32, i32, i32, f64, f64, vp, vp, i64, i32, vp, vp], ctypes.c_int),
 }

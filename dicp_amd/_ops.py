@@ -376,3 +376,96 @@ class ICPLoop(torch.autograd.Function):
             gT0[:, :3, :3] = gpose[:, :9].reshape(N, 3, 3).to(dt)
             gT0[:, :3, 3] = gpose[:, 9:].to(dt)
         return gsrc, gtgt, gT0, gw, None
+
+
+class KabschLoop(torch.autograd.Function):
+    """Point-to-point ICP with the closed-form SVD step (reference: ICP.pt2pt_dICP_SVD, ICP.py:533-591), batched.
+
+    forward : K x { kNN -> dicp_kabsch_accumulate -> dicp_kabsch_step }.  Every iterate is the absolute optimum
+              T_k = argmin_T sum w |T p - y[idx_k]|^2, so the reference's composed updates telescope to the
+              last one and the gradient is ONE Kabsch adjoint through (source, target[idx_K], weight).
+    Inputs : source (N,n,3), target (N,m,3|6), T_init (N,4,4) [only seeds the first correspondence], w0 (N,n)
+    Outputs: T (N,4,4) differentiable; costs (N,K), iterations (N) non-differentiable.
+    """
+
+    @staticmethod
+    def forward(ctx, source, target, T_init, w0, max_iterations, tolerance, trim_dist, const_iter, knn_variant):
+        for t, nm in ((source, "source"), (target, "target"), (T_init, "T_init"), (w0, "weight")):
+            require_device(t, "pt2pt_dICP_SVD(" + nm + ")")
+        lib = _lib.load()
+        dev, dt = source.device, source.dtype
+        code = _DT[dt]
+        N, n, _ = source.shape
+        m, c = target.shape[1], target.shape[2]
+        src, tgt, w0c = source.contiguous(), target.contiguous(), w0.contiguous()
+        trim_on = int(trim_dist is not None and trim_dist >= 0.0)
+        trim = float(trim_dist) if trim_on else 0.0
+        with torch.cuda.device(dev):
+            st = _stream()
+            kind = knn_variant & 0xff
+            if kind == _lib.KNN_AUTO:
+                kind = _lib.KNN_SWEEP if (m >= SWEEP_MIN_TARGETS and n >= 64) else _lib.KNN_VALU
+            sweep = SweepIndex(tgt) if kind == _lib.KNN_SWEEP else None
+            tgt4 = sweep.tgs4 if sweep is not None else pack_target(tgt)
+            nblk = lib.dicp_accumulate_blocks(n)
+            pose = _pose_from_T(T_init)
+            pose_prev = pose
+            partials = torch.empty((N, nblk, _lib.NACC_PAD), dtype=dt, device=dev)
+            save = torch.empty((N, _lib.KAB_SAVE), dtype=torch.float64, device=dev)
+            costs = torch.zeros((N, max_iterations), dtype=dt, device=dev)
+            iterations = torch.zeros((N,), dtype=dt, device=dev)
+            idx = torch.empty((N, n), dtype=torch.int32, device=dev)
+            qorder = None
+            K = 0
+            for k in range(max_iterations):
+                if sweep is not None:
+                    if k < 2:
+                        qorder = sweep.query_order(src, pose)
+                    sweep.knn(src, pose, qorder, out=idx, cfg=(knn_variant >> 8) & 0xff)
+                else:
+                    _lib.check(lib.dicp_knn(code, _p(src), _p(pose), _p(tgt4), N, n, m, tgt4.shape[1], _p(idx),
+                                            kind | (knn_variant & 0xff00), st), "dicp_knn")
+                _lib.check(lib.dicp_kabsch_accumulate(code, _p(src), _p(tgt), c, _p(idx), _p(pose), _p(w0c), trim_on, trim,
+                                                      N, n, m, _p(partials), st), "dicp_kabsch_accumulate")
+                pose_prev, pose = pose, torch.empty((N, 12), dtype=dt, device=dev)
+                cost_k = torch.empty((N,), dtype=dt, device=dev)
+                _lib.check(lib.dicp_kabsch_step(code, _p(partials), nblk, _p(pose), _p(cost_k), _p(save), N, st), "dicp_kabsch_step")
+                costs[:, k] = cost_k
+                K = k + 1
+                if not const_iter:                                          # ICP.py:585-586
+                    done = cost_k < tolerance
+                    iterations = torch.where((iterations == 0) & done, torch.full_like(iterations, K), iterations)
+                    if bool(done.all()):
+                        break
+            iterations = torch.where(iterations == 0, torch.full_like(iterations, K), iterations)
+            T = torch.zeros((N, 4, 4), dtype=dt, device=dev)
+            T[:, :3, :3] = pose[:, :9].reshape(N, 3, 3)
+            T[:, :3, 3] = pose[:, 9:]
+            T[:, 3, 3] = 1.0
+            costs = costs[:, :K].contiguous()
+        ctx.save_for_backward(src, tgt, w0c, idx, pose_prev, save)
+        ctx.trim = (trim_on, trim)
+        ctx.mark_non_differentiable(costs, iterations)
+        return T, costs, iterations
+
+    @staticmethod
+    def backward(ctx, gT, *_unused):
+        src, tgt, w0c, idx, pose_prev, save = ctx.saved_tensors
+        trim_on, trim = ctx.trim
+        lib = _lib.load()
+        dev, dt = src.device, src.dtype
+        code = _DT[dt]
+        N, n, _ = src.shape
+        m, c = tgt.shape[1], tgt.shape[2]
+        with torch.cuda.device(dev):
+            st = _stream()
+            gT = gT.contiguous()
+            gpose = torch.cat((gT[:, :3, :3].reshape(N, 9), gT[:, :3, 3]), dim=1).contiguous()
+            gacc = torch.empty((N, 16), dtype=dt, device=dev)
+            _lib.check(lib.dicp_kabsch_step_bwd(code, _p(gpose), _p(save), _p(gacc), N, st), "dicp_kabsch_step_bwd")
+            gsrc = torch.zeros_like(src)
+            gtgt = torch.zeros_like(tgt) if ctx.needs_input_grad[1] else None
+            gw = torch.zeros_like(w0c)
+            _lib.check(lib.dicp_kabsch_bwd(code, _p(src), _p(tgt), c, _p(idx), _p(pose_prev), _p(w0c), trim_on, trim, _p(gacc),
+                                           N, n, m, _p(gsrc), _p(gtgt), _p(gw), st), "dicp_kabsch_bwd")
+        return gsrc, gtgt, None, gw, None, None, None, None, None

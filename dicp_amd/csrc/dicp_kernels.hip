@@ -762,6 +762,125 @@ __global__ __launch_bounds__(WAVE) void step_bwd_kernel(const double* __restrict
     if (tid < 12) gpose_out[(size_t)cloud * 12 + tid] = sgo[tid];
 }
 
+// ------------------------------------------------------------------ Kabsch / SVD path
+// Point-to-point alignment in closed form (the step of the reference's pt2pt_dICP_SVD, ICP.py:533-591),
+// batched and weighted.  accumulate: 18 sums per cloud; step: 3x3 SVD per cloud; bwd: one pass.
+template <typename T>
+__device__ __forceinline__ T kabsch_weight(const T* C, const T* r, const T* p, const T* y, T w0, int trim_on, T trim_dist) {
+    if (!trim_on) return w0;
+    T q[3];
+    matvec3(C, p, q);
+    const T e[3] = {q[0] + r[0] - y[0], q[1] + r[1] - y[1], q[2] + r[2] - y[2]};
+    return (m_sqrt(dot3(e, e)) < trim_dist) ? w0 : T(0);      // hard gate on the CURRENT residual (not differentiated)
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void kabsch_accumulate_kernel(const T* __restrict__ src, const T* __restrict__ tgt, int c,
+                                                                  const int32_t* __restrict__ idx, const T* __restrict__ pose,
+                                                                  const T* __restrict__ w_init, int trim_on, T trim_dist,
+                                                                  int N, int n, int m, int bpc, T* __restrict__ partials) {
+    __shared__ T red[(BLOCK / WAVE) * NACC_PAD];
+    int cloud, blk;
+    if (!decode_block(bpc, N, cloud, blk)) return;
+    T C[9], r[3];
+    load_pose(pose, cloud, C, r);
+    T acc[NKAB];
+#pragma unroll
+    for (int k = 0; k < NKAB; ++k) acc[k] = T(0);
+    const int end = min(n, (blk + 1) * ACC_PTS);
+    for (int i = blk * ACC_PTS + threadIdx.x; i < end; i += BLOCK) {
+        const size_t pt = (size_t)cloud * n + i;
+        const T* sp = src + pt * 3;
+        const T p[3] = {sp[0], sp[1], sp[2]};
+        const int j = min(max(idx[pt], 0), m - 1);
+        const T* yp = tgt + ((size_t)cloud * m + j) * c;
+        const T y[3] = {yp[0], yp[1], yp[2]};
+        const T w = kabsch_weight(C, r, p, y, w_init[pt], trim_on, trim_dist);
+        acc[KAB_S0] += w;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            acc[KAB_SP + a] += w * p[a];
+            acc[KAB_SY + a] += w * y[a];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) acc[KAB_M + a * 3 + b] += w * y[a] * p[b];
+        }
+        acc[KAB_PP] += w * dot3(p, p);
+        acc[KAB_YY] += w * dot3(y, y);
+    }
+    block_reduce_store<T, NKAB, NACC_PAD>(acc, partials + ((size_t)cloud * bpc + blk) * NACC_PAD, red);
+}
+
+template <typename T>
+__global__ __launch_bounds__(WAVE) void kabsch_step_kernel(const T* __restrict__ partials, int nblk, T* __restrict__ pose_out,
+                                                           T* __restrict__ cost, double* __restrict__ save, int N) {
+    __shared__ double sacc[NACC_PAD], ssave[KAB_SAVE], sC[9], sr[3];
+    __shared__ double scost;
+    const int cloud = blockIdx.x, tid = threadIdx.x;
+    {
+        const int slot_i = tid & 31, part = tid >> 5;
+        const T* pp = partials + (size_t)cloud * nblk * NACC_PAD + slot_i;
+        double s = 0.0;
+        for (int b = part; b < nblk; b += 2) s += (double)pp[(size_t)b * NACC_PAD];
+        s += __shfl_down(s, 32);
+        if (tid < NACC_PAD) sacc[tid] = s;
+    }
+    __syncthreads();
+    if (tid == 0) scost = kabsch_forward(sacc, sC, sr, ssave);
+    __syncthreads();
+    if (tid < 9) pose_out[(size_t)cloud * 12 + tid] = (T)sC[tid];
+    if (tid < 3) pose_out[(size_t)cloud * 12 + 9 + tid] = (T)sr[tid];
+    if (tid < KAB_SAVE && save) save[(size_t)cloud * KAB_SAVE + tid] = ssave[tid];
+    if (tid == 0 && cost) cost[cloud] = (T)scost;
+}
+
+template <typename T>
+__global__ __launch_bounds__(WAVE) void kabsch_step_bwd_kernel(const T* __restrict__ gpose, const double* __restrict__ save,
+                                                               T* __restrict__ gacc, int N) {
+    __shared__ double sg[12], ssave[KAB_SAVE], sout[16];
+    const int cloud = blockIdx.x, tid = threadIdx.x;
+    if (tid < 12) sg[tid] = (double)gpose[(size_t)cloud * 12 + tid];
+    if (tid < KAB_SAVE) ssave[tid] = save[(size_t)cloud * KAB_SAVE + tid];
+    __syncthreads();
+    if (tid == 0) kabsch_backward(sg, sg + 9, ssave, sout);
+    __syncthreads();
+    if (tid < 16) gacc[(size_t)cloud * 16 + tid] = (T)sout[tid];
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void kabsch_bwd_kernel(const T* __restrict__ src, const T* __restrict__ tgt, int c,
+                                                           const int32_t* __restrict__ idx, const T* __restrict__ pose,
+                                                           const T* __restrict__ w_init, int trim_on, T trim_dist,
+                                                           const T* __restrict__ gacc, int N, int n, int m, int bpc,
+                                                           T* __restrict__ gsrc, T* __restrict__ gtgt, T* __restrict__ gw) {
+    int cloud, blk;
+    if (!decode_block(bpc, N, cloud, blk)) return;
+    T C[9], r[3], g[16];
+    load_pose(pose, cloud, C, r);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) g[k] = gacc[(size_t)cloud * 16 + k];
+    const int end = min(n, (blk + 1) * ACC_PTS);
+    for (int i = blk * ACC_PTS + threadIdx.x; i < end; i += BLOCK) {
+        const size_t pt = (size_t)cloud * n + i;
+        const T* sp = src + pt * 3;
+        const T p[3] = {sp[0], sp[1], sp[2]};
+        const int j = min(max(idx[pt], 0), m - 1);
+        const size_t row = ((size_t)cloud * m + j) * c;
+        const T y[3] = {tgt[row], tgt[row + 1], tgt[row + 2]};
+        const T w0 = w_init[pt];
+        const T w = kabsch_weight(C, r, p, y, w0, trim_on, trim_dist);
+        T yMp = T(0);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            T gp = g[KAB_SP + a], gy = g[KAB_SY + a];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) { gp += g[KAB_M + b * 3 + a] * y[b]; gy += g[KAB_M + a * 3 + b] * p[b]; yMp += y[a] * g[KAB_M + a * 3 + b] * p[b]; }
+            gsrc[pt * 3 + a] += w * gp;
+            if (gtgt) unsafeAtomicAdd(&gtgt[row + a], w * gy);
+        }
+        if (gw) gw[pt] += (w == w0 ? T(1) : T(0)) * (g[KAB_S0] + dot3(g + KAB_SP, p) + dot3(g + KAB_SY, y) + yMp);
+    }
+}
+
 // ------------------------------------------------------------------ loss weights
 template <typename T>
 __device__ __forceinline__ void loss_eval(int loss, int diff, T metric, T kk, const T* e, int r, T& w, T& en, T& th) {
@@ -1066,6 +1185,54 @@ int dicp_accumulate_bwd(int dtype, const dicp_weight_params* prm, const void* sr
     if (dtype == DICP_F32) { if (P.mode == MODE_PT2PL) DICP_BWD(float, MODE_PT2PL); else DICP_BWD(float, MODE_PT2PT); }
     else                   { if (P.mode == MODE_PT2PL) DICP_BWD(double, MODE_PT2PL); else DICP_BWD(double, MODE_PT2PT); }
 #undef DICP_BWD
+    return launch_status();
+}
+
+int dicp_kabsch_accumulate(int dtype, const void* src, const void* tgt, int c, const int32_t* idx, const void* pose,
+                           const void* w_init, int trim_on, double trim_dist, int N, int n, int m, void* partials, void* stream) {
+    if (!src || !tgt || !idx || !w_init || !partials) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0 || n <= 0 || m <= 0 || (c != 3 && c != 6)) return DICP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    begin_launch();
+    const int bpc = dicp_accumulate_blocks(n);
+    if (dtype == DICP_F32) kabsch_accumulate_kernel<float><<<grid_for(N, bpc), BLOCK, 0, st>>>((const float*)src, (const float*)tgt, c, idx, (const float*)pose, (const float*)w_init, trim_on, (float)trim_dist, N, n, m, bpc, (float*)partials);
+    else                   kabsch_accumulate_kernel<double><<<grid_for(N, bpc), BLOCK, 0, st>>>((const double*)src, (const double*)tgt, c, idx, (const double*)pose, (const double*)w_init, trim_on, trim_dist, N, n, m, bpc, (double*)partials);
+    return launch_status();
+}
+
+int dicp_kabsch_step(int dtype, const void* partials, int nblk, void* pose_out, void* cost, double* save, int N, void* stream) {
+    if (!partials || !pose_out) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0 || nblk <= 0) return DICP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    begin_launch();
+    if (dtype == DICP_F32) kabsch_step_kernel<float><<<N, WAVE, 0, st>>>((const float*)partials, nblk, (float*)pose_out, (float*)cost, save, N);
+    else                   kabsch_step_kernel<double><<<N, WAVE, 0, st>>>((const double*)partials, nblk, (double*)pose_out, (double*)cost, save, N);
+    return launch_status();
+}
+
+int dicp_kabsch_step_bwd(int dtype, const void* gpose, const double* save, void* gacc, int N, void* stream) {
+    if (!gpose || !save || !gacc) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0) return DICP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    begin_launch();
+    if (dtype == DICP_F32) kabsch_step_bwd_kernel<float><<<N, WAVE, 0, st>>>((const float*)gpose, save, (float*)gacc, N);
+    else                   kabsch_step_bwd_kernel<double><<<N, WAVE, 0, st>>>((const double*)gpose, save, (double*)gacc, N);
+    return launch_status();
+}
+
+int dicp_kabsch_bwd(int dtype, const void* src, const void* tgt, int c, const int32_t* idx, const void* pose, const void* w_init,
+                    int trim_on, double trim_dist, const void* gacc, int N, int n, int m, void* gsrc, void* gtgt, void* gw, void* stream) {
+    if (!src || !tgt || !idx || !w_init || !gacc || !gsrc) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0 || n <= 0 || m <= 0 || (c != 3 && c != 6)) return DICP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    begin_launch();
+    const int bpc = dicp_accumulate_blocks(n);
+    if (dtype == DICP_F32) kabsch_bwd_kernel<float><<<grid_for(N, bpc), BLOCK, 0, st>>>((const float*)src, (const float*)tgt, c, idx, (const float*)pose, (const float*)w_init, trim_on, (float)trim_dist, (const float*)gacc, N, n, m, bpc, (float*)gsrc, (float*)gtgt, (float*)gw);
+    else                   kabsch_bwd_kernel<double><<<grid_for(N, bpc), BLOCK, 0, st>>>((const double*)src, (const double*)tgt, c, idx, (const double*)pose, (const double*)w_init, trim_on, trim_dist, (const double*)gacc, N, n, m, bpc, (double*)gsrc, (double*)gtgt, (double*)gw);
     return launch_status();
 }
 

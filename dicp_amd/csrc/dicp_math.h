@@ -458,4 +458,156 @@ DICP_HD void step_backward(const double* gCn, const double* grn, int dim, const 
     }
 }
 
+
+// ------------------------------------------------------------------ Kabsch / SVD step
+// Closed-form point-to-point alignment (the step of the reference's pt2pt_dICP_SVD, ICP.py:557-573,
+// with the rotation composed as U diag(1,1,det U det V) V^T -- the reference multiplies by V where V^T is
+// required, which is only right for planar data).  Batched and weighted:
+//   sums per cloud: S0 = sum w, sp = sum w p, sy = sum w y, M = sum w y p^T, pp = sum w |p|^2, yy = sum w |y|^2
+//   W = M/S0 - mu_t mu_s^T ;  W = U S V^T ;  C = U D V^T ;  r = mu_t - C mu_s
+constexpr int KAB_S0 = 0, KAB_SP = 1, KAB_SY = 4, KAB_M = 7, KAB_PP = 16, KAB_YY = 17, NKAB = 18;
+constexpr int KAB_SAVE = 40;      // doubles kept per cloud for the backward pass
+
+// One-sided Jacobi SVD of a 3x3 (row-major): A = U diag(S) V^T, S descending, U and V orthogonal.
+DICP_HD void svd3(const double* A, double* U, double* S, double* V) {
+    double G[9];
+    for (int i = 0; i < 9; ++i) { G[i] = A[i]; V[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                double a = 0, b = 0, g = 0;
+                for (int i = 0; i < 3; ++i) { a += G[i * 3 + p] * G[i * 3 + p]; b += G[i * 3 + q] * G[i * 3 + q]; g += G[i * 3 + p] * G[i * 3 + q]; }
+                if (fabs(g) <= 1e-300 || fabs(g) <= 1e-17 * sqrt(a * b)) continue;
+                off += fabs(g);
+                const double zeta = (b - a) / (2.0 * g);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                for (int i = 0; i < 3; ++i) {
+                    const double gp = G[i * 3 + p], gq = G[i * 3 + q];
+                    G[i * 3 + p] = c * gp - sn * gq; G[i * 3 + q] = sn * gp + c * gq;
+                    const double vp = V[i * 3 + p], vq = V[i * 3 + q];
+                    V[i * 3 + p] = c * vp - sn * vq; V[i * 3 + q] = sn * vp + c * vq;
+                }
+            }
+        if (off == 0.0) break;
+    }
+    double nrm[3];
+    for (int j = 0; j < 3; ++j) nrm[j] = sqrt(G[j] * G[j] + G[3 + j] * G[3 + j] + G[6 + j] * G[6 + j]);
+    int ord[3] = {0, 1, 2};                                            // sort columns by singular value, descending
+    for (int a = 0; a < 2; ++a) for (int b = a + 1; b < 3; ++b) if (nrm[ord[b]] > nrm[ord[a]]) { const int t = ord[a]; ord[a] = ord[b]; ord[b] = t; }
+    double Vs[9];
+    for (int j = 0; j < 3; ++j) {
+        S[j] = nrm[ord[j]];
+        for (int i = 0; i < 3; ++i) { Vs[i * 3 + j] = V[i * 3 + ord[j]]; U[i * 3 + j] = (S[j] > 0) ? G[i * 3 + ord[j]] / S[j] : 0.0; }
+    }
+    for (int i = 0; i < 9; ++i) V[i] = Vs[i];
+    // rank-deficient input (planar / collinear clouds): complete U to an orthonormal basis
+    const double tiny = 1e-14 * (S[0] > 0 ? S[0] : 1.0);
+    if (S[0] <= 0) { for (int i = 0; i < 9; ++i) U[i] = (i % 4 == 0) ? 1.0 : 0.0; return; }
+    if (S[1] <= tiny) {
+        const double u0[3] = {U[0], U[3], U[6]};
+        int k = (fabs(u0[0]) <= fabs(u0[1]) && fabs(u0[0]) <= fabs(u0[2])) ? 0 : (fabs(u0[1]) <= fabs(u0[2]) ? 1 : 2);
+        double e[3] = {0, 0, 0}; e[k] = 1.0;
+        const double d = u0[k];
+        double v[3] = {e[0] - d * u0[0], e[1] - d * u0[1], e[2] - d * u0[2]};
+        const double n = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        U[1] = v[0] / n; U[4] = v[1] / n; U[7] = v[2] / n;
+    }
+    if (S[2] <= tiny) {
+        const double a0[3] = {U[0], U[3], U[6]}, a1[3] = {U[1], U[4], U[7]};
+        double c3[3];
+        cross3(a0, a1, c3);
+        U[2] = c3[0]; U[5] = c3[1]; U[8] = c3[2];
+    }
+}
+
+DICP_HD double det3(const double* A) {
+    return A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * A[7] - A[4] * A[6]);
+}
+
+// sums -> pose.  save[KAB_SAVE]: U(9) V(9) lambda(3) d3(1) mus(3) mut(3) S0(1) C(9) = 38 used.
+// Returns the alignment cost sum w |C p + r - y|^2 under the NEW pose (ICP.py:585's stopping quantity).
+DICP_HD double kabsch_forward(const double* acc, double* C, double* r, double* save) {
+    const double S0 = acc[KAB_S0];
+    for (int i = 0; i < 9; ++i) C[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    r[0] = r[1] = r[2] = 0.0;
+    for (int i = 0; i < KAB_SAVE; ++i) save[i] = 0.0;
+    if (!(S0 > 0.0)) return 0.0;                       // no weight at all (empty / switched-off cloud): identity
+    double mus[3], mut[3], W[9];
+    for (int a = 0; a < 3; ++a) { mus[a] = acc[KAB_SP + a] / S0; mut[a] = acc[KAB_SY + a] / S0; }
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) W[a * 3 + b] = acc[KAB_M + a * 3 + b] / S0 - mut[a] * mus[b];
+    double U[9], S[3], V[9];
+    svd3(W, U, S, V);
+    const double d3 = (det3(U) * det3(V) < 0.0) ? -1.0 : 1.0;          // ICP.py:570
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) C[a * 3 + b] = U[a * 3 + 0] * V[b * 3 + 0] + U[a * 3 + 1] * V[b * 3 + 1] + d3 * U[a * 3 + 2] * V[b * 3 + 2];
+    for (int a = 0; a < 3; ++a) r[a] = mut[a] - (C[a * 3] * mus[0] + C[a * 3 + 1] * mus[1] + C[a * 3 + 2] * mus[2]);   // ICP.py:573
+    for (int i = 0; i < 9; ++i) { save[i] = U[i]; save[9 + i] = V[i]; save[29 + i] = C[i]; }
+    save[18] = S[0]; save[19] = S[1]; save[20] = d3 * S[2]; save[21] = d3;
+    for (int a = 0; a < 3; ++a) { save[22 + a] = mus[a]; save[25 + a] = mut[a]; }
+    save[28] = S0;
+    // sum w |Cp + r - y|^2 = pp + yy + S0|r|^2 + 2 r.C sp - 2 r.sy - 2 <C, M>
+    double rr = 0, rCsp = 0, rsy = 0, CM = 0;
+    for (int a = 0; a < 3; ++a) {
+        rr += r[a] * r[a];
+        rsy += r[a] * acc[KAB_SY + a];
+        for (int b = 0; b < 3; ++b) { rCsp += r[a] * C[a * 3 + b] * acc[KAB_SP + b]; CM += C[a * 3 + b] * acc[KAB_M + a * 3 + b]; }
+    }
+    return acc[KAB_PP] + acc[KAB_YY] + S0 * rr + 2.0 * rCsp - 2.0 * rsy - 2.0 * CM;
+}
+
+// Adjoint of kabsch_forward: cotangents of (C, r) -> cotangents of the sums [gS0, gsp(3), gsy(3), gM(9)].
+// Rotation: with P = C^T W = V Lambda V^T (Lambda = D S) and dC = C Om, Om skew:  Om~_ij =
+// (d_i X_ij - d_j X_ji) / (lambda_i + lambda_j), X = U^T dW V.  Degenerate pairs (lambda_i + lambda_j ~ 0) get 0.
+DICP_HD void kabsch_backward(const double* gC, const double* gr, const double* save, double* gacc) {
+    for (int i = 0; i < 16; ++i) gacc[i] = 0.0;
+    const double S0 = save[28];
+    if (!(S0 > 0.0)) return;
+    const double* U = save; const double* V = save + 9; const double* lam = save + 18; const double* C = save + 29;
+    const double d[3] = {1.0, 1.0, save[21]};
+    const double* mus = save + 22; const double* mut = save + 25;
+    // r = mut - C mus
+    double gmut[3], gmus[3], gCt[9];
+    for (int a = 0; a < 3; ++a) {
+        gmut[a] = gr[a];
+        gmus[a] = -(C[0 * 3 + a] * gr[0] + C[1 * 3 + a] * gr[1] + C[2 * 3 + a] * gr[2]);
+        for (int b = 0; b < 3; ++b) gCt[a * 3 + b] = gC[a * 3 + b] - gr[a] * mus[b];
+    }
+    // G = D U^T gCt V
+    double T1[9], G[9], Xb[9], gW[9];
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) T1[a * 3 + b] = U[0 * 3 + a] * gCt[0 * 3 + b] + U[1 * 3 + a] * gCt[1 * 3 + b] + U[2 * 3 + a] * gCt[2 * 3 + b];
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) G[a * 3 + b] = d[a] * (T1[a * 3 + 0] * V[0 * 3 + b] + T1[a * 3 + 1] * V[1 * 3 + b] + T1[a * 3 + 2] * V[2 * 3 + b]);
+    const double scale = fabs(lam[0]) + fabs(lam[1]) + fabs(lam[2]);
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+            const double den = lam[a] + lam[b];
+            Xb[a * 3 + b] = (a != b && fabs(den) > 1e-12 * scale) ? d[a] * (G[a * 3 + b] - G[b * 3 + a]) / den : 0.0;
+        }
+    // gW = U Xb V^T
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) T1[a * 3 + b] = U[a * 3 + 0] * Xb[0 * 3 + b] + U[a * 3 + 1] * Xb[1 * 3 + b] + U[a * 3 + 2] * Xb[2 * 3 + b];
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) gW[a * 3 + b] = T1[a * 3 + 0] * V[b * 3 + 0] + T1[a * 3 + 1] * V[b * 3 + 1] + T1[a * 3 + 2] * V[b * 3 + 2];
+    // W = M/S0 - mut mus^T ; mus = sp/S0 ; mut = sy/S0
+    double gS0 = 0.0;
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+            gacc[KAB_M + a * 3 + b] = gW[a * 3 + b] / S0;
+            gmut[a] -= gW[a * 3 + b] * mus[b];
+            gmus[b] -= gW[a * 3 + b] * mut[a];
+        }
+    // <gW, M>/S0^2 with M/S0 = W + mut mus^T and W = U S V^T (lam_i d_i = s_i)
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+            double Wab = 0.0;
+            for (int k = 0; k < 3; ++k) Wab += U[a * 3 + k] * (lam[k] * d[k]) * V[b * 3 + k];
+            gS0 -= gW[a * 3 + b] * (Wab + mut[a] * mus[b]) / S0;
+        }
+    for (int a = 0; a < 3; ++a) {
+        gacc[KAB_SP + a] = gmus[a] / S0;
+        gacc[KAB_SY + a] = gmut[a] / S0;
+        gS0 -= (gmus[a] * mus[a] + gmut[a] * mut[a]) / S0;
+    }
+    gacc[KAB_S0] = gS0;
+}
+
 }  // namespace dicp

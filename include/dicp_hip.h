@@ -149,6 +149,24 @@ int dicp_accumulate_bwd(int dtype, const dicp_weight_params* prm, const void* sr
                         const void* gs, const void* gb, int N, int n, int m,
                         void* gsrc, void* gtgt, void* gw, void* bwd_partials, void* stream);
 
+/* Closed-form point-to-point step (Kabsch / SVD), the solver of ICP.pt2pt_dICP_SVD (ICP.py:533-591): batched,
+ * weighted, with the rotation composed as U diag(1,1,det U det V) V^T (the reference multiplies by V where V^T
+ * is required, ICP.py:566-570 -- only correct for planar data).
+ *   accumulate: per-block sums [sum w, sum w p (3), sum w y (3), sum w y p^T (9), sum w|p|^2, sum w|y|^2] in
+ *               partials (N, dicp_accumulate_blocks(n), DICP_NACC_PAD); w = w_init, times a hard gate
+ *               |C p + r - y| < trim_dist when trim_on;
+ *   step:       pose_out (N,12) = [C, r] minimising sum w |C p + r - y|^2; cost (N) = that minimum (ICP.py:585);
+ *               save (N,DICP_KAB_SAVE) doubles for the backward pass (may be NULL);
+ *   step_bwd:   gpose (N,12) T -> gacc (N,16) T = cotangents of the 16 leading sums;
+ *   bwd:        gsrc (N,n,3) +=, gtgt (N,m,c) += (atomics, may be NULL), gw (N,n) += (may be NULL). */
+#define DICP_KAB_SAVE 40
+int dicp_kabsch_accumulate(int dtype, const void* src, const void* tgt, int c, const int32_t* idx, const void* pose,
+                           const void* w_init, int trim_on, double trim_dist, int N, int n, int m, void* partials, void* stream);
+int dicp_kabsch_step(int dtype, const void* partials, int nblk, void* pose_out, void* cost, double* save, int N, void* stream);
+int dicp_kabsch_step_bwd(int dtype, const void* gpose, const double* save, void* gacc, int N, void* stream);
+int dicp_kabsch_bwd(int dtype, const void* src, const void* tgt, int c, const int32_t* idx, const void* pose, const void* w_init,
+                    int trim_on, double trim_dist, const void* gacc, int N, int n, int m, void* gsrc, void* gtgt, void* gw, void* stream);
+
 /* loss(name, metric, differentiable, tanh_steepness).get_weight(err), loss.py:11-58, for
  * callers that use the class directly.  err (rows,r), r in {1,3}; w (rows). */
 int dicp_loss_weight(int dtype, int loss, int differentiable, double metric, double tanh_k,

@@ -19,8 +19,8 @@ sys.dont_write_bytecode = True
 os.environ.setdefault("MPLBACKEND", "Agg")
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-sys.path.insert(0, "/root/reference")
 sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")       # must precede ROOT: the repo ships a drop-in alias package also named dICP
 
 import numpy as np
 import torch
@@ -28,6 +28,8 @@ import torch
 from dICP.ICP import ICP as RefICP            # the reference
 from dICP.nn import nn as RefNN
 from dICP.loss import loss as RefLoss
+import dICP as _ref_pkg
+assert _ref_pkg.__file__.startswith("/root/reference/"), "golden vectors must come from the reference, not the alias package"
 from oracle.se3 import vec2tran
 
 torch.set_num_threads(4)
@@ -292,7 +294,21 @@ def loss_vectors():
     save("loss_vectors", **arrs)
 
 
+def svd_planar():
+    """ICP.pt2pt_dICP_SVD (ICP.py:533-591) on the bundled planar pair -- the one setting where the
+    reference's V-for-V^T composition is harmless."""
+    src = torch.tensor(SCAN[:, :3])
+    tgt = torch.tensor(MAP[:, :3])
+    icp = RefICP(icp_type="pt2pt", differentiable=False, max_iterations=100, tolerance=1e-20)
+    ps, T = icp.pt2pt_dICP_SVD(src, tgt, torch.eye(4, dtype=src.dtype))
+    save("svd_planar", pc=npy(ps), T=npy(T), T_ts_true=np.linalg.inv(vec2tran([1.0, 1.0, 0, 0, 0, 0.1])))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                      # regenerate selected files only: make_golden.py svd_planar ...
+        for fn in sys.argv[1:]:
+            globals()[fn]()
+        sys.exit(0)
     np.save(os.path.join(HERE, "points_scan.npy"), SCAN)
     np.save(os.path.join(HERE, "points_map.npy"), MAP)
     c1("c1_pt2pt_diff", "pt2pt", True, 1.0, torch.float64)
@@ -308,3 +324,4 @@ if __name__ == "__main__":
     matrix3d()
     nn_vectors()
     loss_vectors()
+    svd_planar()

@@ -61,6 +61,9 @@ void hc_step_backward(const double* gCn, const double* grn, int dim, const doubl
     double ws[STEP_WS];
     step_backward(gCn, grn, dim, C, delta6, Areg, Gs, gb, gC, gr, ws);
 }
+double hc_kabsch_forward(const double* acc, double* C, double* r, double* save) { return kabsch_forward(acc, C, r, save); }
+void hc_kabsch_backward(const double* gC, const double* gr, const double* save, double* gacc) { kabsch_backward(gC, gr, save, gacc); }
+void hc_svd3(const double* A, double* U, double* S, double* V) { svd3(A, U, S, V); }
 int hc_sizeof_params() { return (int)sizeof(WeightParams); }
 
 }  // extern "C"

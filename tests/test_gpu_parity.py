@@ -579,3 +579,108 @@ def test_icp_sweep_equals_brute_on_synthetic():
     assert torch.equal(outs[0][0]["T"], outs[1][0]["T"]) and torch.equal(outs[0][0]["weights"], outs[1][0]["weights"])
     assert torch.equal(outs[0][1], outs[1][1])
     np.testing.assert_allclose(npy(outs[0][2]), npy(outs[1][2]), rtol=0, atol=1e-6)     # float atomics order
+
+
+# ------------------------------------------------------------------- SVD point-to-point (a-12 / f-4)
+def kabsch_np(p, y, w=None):
+    """Published Kabsch/Umeyama: the rigid transform minimising sum w |C p + r - y|^2."""
+    w = np.ones(len(p)) if w is None else w
+    mus, mut = (w[:, None] * p).sum(0) / w.sum(), (w[:, None] * y).sum(0) / w.sum()
+    W = ((w[:, None] * (y - mut)).T @ (p - mus)) / w.sum()
+    U, S, Vt = np.linalg.svd(W)
+    C = U @ np.diag([1, 1, np.linalg.det(U) * np.linalg.det(Vt)]) @ Vt
+    return C, mut - C @ mus
+
+
+def test_svd_icp_planar_matches_reference(golden, scan_map):
+    """The reference's pt2pt_dICP_SVD on its own planar test pair (where its V-for-V^T slip is harmless)."""
+    scan, mp = scan_map
+    g = golden("svd_planar")
+    icp = ICP(icp_type="pt2pt", differentiable=False, max_iterations=100, tolerance=1e-20)
+    ps, T = icp.pt2pt_dICP_SVD(t(scan[:, :3]), t(mp[:, :3]), torch.eye(4, dtype=torch.float64, device=DEV))
+    assert ps.shape == (65, 3) and T.shape == (4, 4)                       # unbatched in, unbatched out (ICP.py:591)
+    np.testing.assert_allclose(npy(T), g["T"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(npy(ps), g["pc"], rtol=0, atol=1e-10)
+    err = tran2vec(g["T_ts_true"] @ np.linalg.inv(npy(T)))
+    assert np.linalg.norm(err) < 1e-10
+    # and it agrees with the integrated Gauss-Newton pt2pt solver on the same data (SURVEY 8a-12 pin)
+    gn = ICP(icp_type="pt2pt", differentiable=True, max_iterations=100, tolerance=1e-10)
+    Tg = gn.icp(t(scan[:, :3]), t(mp[:, :3]), torch.eye(4, dtype=torch.float64, device=DEV), dim=2)["T"]
+    np.testing.assert_allclose(npy(T), npy(Tg)[0], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_svd_icp_3d_batched_vs_numpy_kabsch(dtype):
+    """General 3-D clouds: each iterate must equal numpy Kabsch on the current correspondences, and the final
+    pose must recover the planted motion -- the case the reference's own function gets wrong."""
+    N, n, m = 3, 600, 700
+    src, tgt = make_pairs(N, n, m, seed=21, dtype=torch.float64, max_rot=0.2, max_trans=0.5)
+    w = torch.rand((N, n), generator=torch.Generator().manual_seed(0), dtype=torch.float64) + 0.1
+    icp = ICP(icp_type="pt2pt", max_iterations=20, tolerance=1e-30)
+    icp.const_iter = True
+    ps, T = icp.pt2pt_dICP_SVD(src.to(dtype).to(DEV), tgt.to(dtype).to(DEV), torch.eye(4, dtype=dtype, device=DEV).repeat(N, 1, 1),
+                               weight=w.to(dtype).to(DEV))
+    assert ps.shape == (N, n, 3) and T.shape == (N, 4, 4)
+    for b in range(N):
+        C, r = np.eye(3), np.zeros(3)
+        for _ in range(20):
+            idx = O.nn_index(torch.tensor(src[b].numpy() @ C.T + r)[None], tgt[b:b + 1, :, :3])[0].numpy()
+            C, r = kabsch_np(src[b].numpy(), tgt[b, idx, :3].numpy(), w[b].numpy())
+        tol = 1e-9 if dtype == torch.float64 else 1e-4
+        np.testing.assert_allclose(npy(T)[b, :3, :3], C, rtol=0, atol=tol)
+        np.testing.assert_allclose(npy(T)[b, :3, 3], r, rtol=0, atol=tol)
+        assert abs(np.linalg.det(npy(T)[b, :3, :3].astype(np.float64)) - 1.0) < 1e-5
+    assert float((ps - tgt.to(dtype).to(DEV)[:, :, :3].mean()).abs().max()) < 50      # sane output
+
+
+def test_svd_icp_gradients_vs_autograd():
+    """Gradient of the final pose w.r.t. source, target and weight == torch autograd through one Kabsch solve
+    on the final correspondences (the composed updates of the reference telescope to exactly that)."""
+    N, n, m = 2, 300, 350
+    src, tgt = make_pairs(N, n, m, seed=33, dtype=torch.float64, max_rot=0.15)
+    tg3 = tgt[:, :, :3].contiguous()
+    w = torch.rand((N, n), generator=torch.Generator().manual_seed(1), dtype=torch.float64) + 0.2
+    sd, td, wd = src.to(DEV).requires_grad_(True), tg3.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    icp = ICP(icp_type="pt2pt", max_iterations=15, tolerance=1e-30)
+    icp.const_iter = True
+    ps, T = icp.pt2pt_dICP_SVD(sd, td, torch.eye(4, dtype=torch.float64, device=DEV).repeat(N, 1, 1), weight=wd)
+    gT = torch.randn((N, 4, 4), generator=torch.Generator().manual_seed(2), dtype=torch.float64)
+    gP = torch.randn((N, n, 3), generator=torch.Generator().manual_seed(3), dtype=torch.float64)
+    ((T * gT.to(DEV)).sum() + (ps * gP.to(DEV)).sum()).backward()
+    for b in range(N):
+        # final correspondences = NN under the pose of the second-to-last iterate; recover them from the result
+        sc, tc, wc = (x[b].clone().requires_grad_(True) for x in (src, tg3, w))
+        C, r = np.eye(3), np.zeros(3)
+        for _ in range(15):
+            idx = O.nn_index(torch.tensor(src[b].numpy() @ C.T + r)[None], tg3[b:b + 1])[0]
+            C, r = kabsch_np(src[b].numpy(), tg3[b, idx].numpy(), w[b].numpy())
+        y = tc[idx]
+        S0 = wc.sum()
+        mus, mut = (wc[:, None] * sc).sum(0) / S0, (wc[:, None] * y).sum(0) / S0
+        W = (wc[:, None, None] * y[:, :, None] * sc[:, None, :]).sum(0) / S0 - mut[:, None] * mus[None, :]
+        U, S, Vh = torch.linalg.svd(W)
+        Ct = U @ torch.diag(torch.stack([torch.ones((), dtype=torch.float64), torch.ones((), dtype=torch.float64), torch.det(U) * torch.det(Vh)])) @ Vh
+        rt = mut - Ct @ mus
+        Tt = torch.eye(4, dtype=torch.float64)
+        Tt = torch.cat((torch.cat((Ct, rt[:, None]), dim=1), torch.tensor([[0, 0, 0, 1.0]], dtype=torch.float64)), dim=0)
+        ((Tt * gT[b]).sum() + ((sc @ Ct.T + rt) * gP[b]).sum()).backward()
+        np.testing.assert_allclose(npy(T)[b], Tt.detach().numpy(), rtol=0, atol=1e-10)
+        np.testing.assert_allclose(npy(sd.grad)[b], sc.grad.numpy(), rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(npy(td.grad)[b], tc.grad.numpy(), rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(npy(wd.grad)[b], wc.grad.numpy(), rtol=1e-7, atol=1e-9)
+
+
+def test_svd_icp_config2_shape_and_trim():
+    """configs[1]: B=32 x 4096-pt clouds, point-to-point with the SVD step; trim gate and tolerance stop."""
+    N, n = 32, 4096
+    src, tgt = make_pairs(N, n, n, seed=1, dtype=torch.float32)
+    icp = ICP(icp_type="pt2pt", max_iterations=30, tolerance=1e-3)
+    ps, T = icp.pt2pt_dICP_SVD(src.to(DEV), tgt.to(DEV), torch.eye(4, device=DEV).repeat(N, 1, 1), trim_dist=5.0)
+    gn = ICP(icp_type="pt2pt", differentiable=True, max_iterations=30, tolerance=1e-7)
+    Tg = gn.icp(src.to(DEV), tgt[:, :, :3].contiguous().to(DEV), torch.eye(4, device=DEV).repeat(N, 1, 1), trim_dist=5.0)["T"]
+    np.testing.assert_allclose(npy(T), npy(Tg), rtol=0, atol=2e-3)            # same optimum as Gauss-Newton pt2pt
+    assert icp.svd_stats["costs"].shape[0] == N and float(icp.svd_stats["iterations"].max()) <= 30
+    # empty / switched-off cloud: zero total weight -> identity step (no NaN)
+    ps0, T0 = icp.pt2pt_dICP_SVD(src[:2].to(DEV), tgt[:2].to(DEV), torch.eye(4, device=DEV).repeat(2, 1, 1),
+                                 weight=torch.zeros((2, n), device=DEV))
+    assert torch.equal(T0, torch.eye(4, device=DEV).repeat(2, 1, 1))

@@ -169,3 +169,71 @@ def test_hard_huber_zero_residual_is_nan_like_reference(hc):
         ok = ~np.isnan(gs)
         np.testing.assert_allclose(gs[ok], s.grad[0].numpy()[ok], rtol=1e-8, atol=1e-12)
         assert np.isnan(gs[0]).all() and not np.isnan(gs[1:]).any()
+
+
+def kabsch_torch(p, y, w):
+    """Weighted Kabsch/Umeyama with torch ops (autograd reference): C = U diag(1,1,det U det V) V^T."""
+    S0 = w.sum()
+    mus, mut = (w[:, None] * p).sum(0) / S0, (w[:, None] * y).sum(0) / S0
+    W = (w[:, None, None] * y[:, :, None] * p[:, None, :]).sum(0) / S0 - mut[:, None] * mus[None, :]
+    U, S, Vh = torch.linalg.svd(W)
+    D = torch.diag(torch.stack([torch.ones(()), torch.ones(()), torch.det(U) * torch.det(Vh)]).to(W.dtype))
+    C = U @ D @ Vh
+    return C, mut - C @ mus
+
+
+def kabsch_sums(p, y, w):
+    acc = np.zeros(18)
+    acc[0] = w.sum()
+    acc[1:4] = (w[:, None] * p).sum(0)
+    acc[4:7] = (w[:, None] * y).sum(0)
+    acc[7:16] = (w[:, None, None] * y[:, :, None] * p[:, None, :]).sum(0).ravel()
+    acc[16] = (w * (p ** 2).sum(1)).sum()
+    acc[17] = (w * (y ** 2).sum(1)).sum()
+    return acc
+
+
+def test_svd3_and_kabsch_forward_backward(hc):
+    hc.hc_kabsch_forward.restype = ctypes.c_double
+    rng = np.random.RandomState(2)
+    for trial in range(40):
+        A = rng.normal(size=(3, 3))
+        if trial % 4 == 1:
+            A[:, 2] = 0.0                         # rank 2 (planar clouds)
+        if trial % 8 == 7:
+            A = np.outer(rng.normal(size=3), rng.normal(size=3))   # rank 1
+        U, S, V = np.zeros(9), np.zeros(3), np.zeros(9)
+        hc.hc_svd3(ptr(np.ascontiguousarray(A)), ptr(U), ptr(S), ptr(V))
+        U, V = U.reshape(3, 3), V.reshape(3, 3)
+        np.testing.assert_allclose(U @ np.diag(S) @ V.T, A, atol=1e-13)
+        np.testing.assert_allclose(U.T @ U, np.eye(3), atol=1e-13)
+        np.testing.assert_allclose(V.T @ V, np.eye(3), atol=1e-13)
+        np.testing.assert_allclose(S, np.linalg.svd(A, compute_uv=False), atol=1e-13)
+    for trial in range(10):
+        n = 30
+        p = rng.normal(size=(n, 3)) * 2
+        ang = rng.uniform(-1, 1, 3)
+        Rt = scipy.linalg.expm(np.array([[0, -ang[2], ang[1]], [ang[2], 0, -ang[0]], [-ang[1], ang[0], 0]]))
+        if trial == 9:
+            Rt = Rt @ np.diag([1, 1, -1.0])       # a reflection in the data: d3 = -1 branch
+        y = p @ Rt.T + rng.normal(size=3) + 0.05 * rng.normal(size=(n, 3))
+        w = rng.uniform(0.1, 1.0, n)
+        C, r, save = np.zeros(9), np.zeros(3), np.zeros(40)
+        cost = hc.hc_kabsch_forward(ptr(kabsch_sums(p, y, w)), ptr(C), ptr(r), ptr(save))
+        pt, yt, wt = (torch.tensor(a, requires_grad=True) for a in (p, y, w))
+        Ct, rt = kabsch_torch(pt, yt, wt)
+        np.testing.assert_allclose(C.reshape(3, 3), Ct.detach().numpy(), atol=1e-12)
+        np.testing.assert_allclose(r, rt.detach().numpy(), atol=1e-12)
+        np.testing.assert_allclose(np.linalg.det(C.reshape(3, 3)), 1.0, atol=1e-12)
+        np.testing.assert_allclose(cost, float((wt * ((pt @ Ct.T + rt - yt) ** 2).sum(1)).sum()), rtol=1e-9, atol=1e-10)
+        gC, gr = rng.normal(size=(3, 3)), rng.normal(size=3)
+        ((Ct * torch.tensor(gC)).sum() + (rt * torch.tensor(gr)).sum()).backward()
+        gacc = np.zeros(16)
+        hc.hc_kabsch_backward(ptr(np.ascontiguousarray(gC)), ptr(gr), ptr(save), ptr(gacc))
+        gM = gacc[7:16].reshape(3, 3)
+        gp = w[:, None] * (gacc[1:4][None, :] + y @ gM)
+        gy = w[:, None] * (gacc[4:7][None, :] + p @ gM.T)
+        gw = gacc[0] + p @ gacc[1:4] + y @ gacc[4:7] + np.einsum("ia,ab,ib->i", y, gM, p)
+        np.testing.assert_allclose(gp, pt.grad.numpy(), rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(gy, yt.grad.numpy(), rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(gw, wt.grad.numpy(), rtol=1e-8, atol=1e-10)

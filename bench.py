@@ -148,6 +148,9 @@ def main():
     if W > 0:
         run_call(icp, src, tgt, T0, world)                               # W untimed warm-up steps
     icp.max_iterations = K
+    # still untimed: one call at the timed call's own shapes, so that the caching allocator already owns the
+    # K-sized history / saved-index buffers (the first use of a new size is a synchronous hipMalloc)
+    run_call(icp, src, tgt, T0, world)
     log = EventLog()
     icp._timing_hook = log
 
@@ -201,6 +204,7 @@ def main():
             "value": world * B * K / elapsed,
             "unit": "cloud-iterations/s",
             "n_gpus": world, "steps": K, "warmup": W,
+            "warmup_note": "W-iteration call, then one untimed K-iteration call (allocator warm-up at the timed shapes)",
             "ms_per_step": elapsed * 1e3 / K,
             "batch_iterations_per_s": K / elapsed,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -12,6 +12,7 @@ reference; citations are inline.  Inputs may live on the CPU (the reference's te
 they are moved to the visible HIP device for the computation and the results are returned
 on the inputs' device.  Without a HIP device this class raises -- no CPU fallback exists.
 """
+import os
 import os.path as osp
 
 import torch
@@ -46,6 +47,7 @@ class ICP:
         # build-specific knob (not in the reference): which kNN kernel the loop uses
         self.knn_variant = _lib.KNN_AUTO      # _lib.KNN_VALU | KNN_MFMA (brute force) | KNN_SWEEP (exact, slab-pruned)
         self.knn_stats = {}                   # "knn_pairs": pairs scored by the last call's sweep kNN
+        self.bwd_owned = os.environ.get("DICP_BWD_OWNED", "0") == "1"   # atomics-free backward (measured slower: opt-in)
         self._timing_hook = None
 
     def icp(self, source, target, T_init, weight=None, trim_dist=None, loss_fn=None, dim=3):
@@ -97,7 +99,8 @@ class ICP:
             const_iter=bool(self.const_iter),
             tanh_steepness=float(self.config['dICP']['parameters']['tanh_steepness']),   # ICP.py:119
             match_ratio_thresh=float(self.match_ratio_thresh),
-            knn_variant=self.knn_variant, stats_out=self.knn_stats, timing_hook=self._timing_hook)
+            knn_variant=self.knn_variant, bwd_owned=bool(self.bwd_owned), stats_out=self.knn_stats,
+            timing_hook=self._timing_hook)
         T, deltas, weights, costs, converged, iterations, matched = ICPLoop.apply(source, target, T_init, w_pts, cfg)
 
         if self.verbose:                                                                 # ICP.py:262-264

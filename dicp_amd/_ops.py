@@ -107,13 +107,13 @@ class SweepIndex:
             x = (src * pose[:, None, 0:3]).sum(dim=2) + pose[:, None, 9]
         return torch.argsort(x, dim=1).to(torch.int32).contiguous()
 
-    def knn(self, src, pose, qorder=None, out=None, cfg=0):
+    def knn(self, src, pose, qorder=None, out=None, cfg=0, spos=None):
         N, n, _ = src.shape
         idx = out if out is not None else torch.empty((N, n), dtype=torch.int32, device=src.device)
         with torch.cuda.device(src.device):
             _lib.check(_lib.load().dicp_knn_sweep(_DT[src.dtype], _p(src), _p(pose), _p(self.tgs4), _p(self.tperm), _p(qorder),
                                                   _p(self.bucket), _p(self.brange), self.NBKT, N, n, self.m, self.tgs4.shape[1],
-                                                  _p(idx), _p(self.pairs), cfg, _stream()), "dicp_knn_sweep")
+                                                  _p(idx), _p(spos), _p(self.pairs), cfg, _stream()), "dicp_knn_sweep")
         return idx
 
 
@@ -193,6 +193,9 @@ class LoopConfig:
     match_ratio_thresh: float
     knn_variant: int = _lib.KNN_AUTO
     sweep_resort: tuple = tuple(int(v) for v in os.environ.get("DICP_SWEEP_RESORT", "0,1").split(","))  # iterations at which the sweep kNN re-sorts its queries by x
+    # backward through the owner-computes kernel (no global atomics).  Measured SLOWER than the row-coalesced
+    # atomic kernel on MI355X (0.41 vs 0.28 ms at B=256 x 16384), so it is opt-in: DICP_BWD_OWNED=1
+    bwd_owned: bool = False
     stats_out: object = None      # optional dict: receives "knn_pairs" (pairs scored by the sweep kNN)
     timing_hook: object = None    # optional callable(name, phase) used by bench.py to drop HIP events
 
@@ -270,6 +273,7 @@ class ICPLoop(torch.autograd.Function):
             n_start = (torch.sum(w0c > cfg.match_ratio_thresh, dim=1) * rows).to(dt)
             counters = torch.zeros((Kmax,), dtype=torch.int32, device=dev)
             w_hist, idx_hist = [], []
+            qorders, qorder_of = [], []      # distinct query orders used by the sweep, and which one iteration k used
 
             K = 0
             for k in range(Kmax):
@@ -277,10 +281,18 @@ class ICPLoop(torch.autograd.Function):
                 if hook:
                     hook("knn", 0)
                 if sweep is not None:
-                    if k in cfg.sweep_resort:                   # queries re-sorted by x under the current pose
+                    if k in cfg.sweep_resort or qorder is None:   # queries re-sorted by x under the current pose
                         qorder = sweep.query_order(src, poses[k])
-                    sweep.knn(src, poses[k], qorder, out=idx, cfg=(cfg.knn_variant >> 8) & 0xff)
+                        qorders.append(qorder)
+                    qorder_of.append(len(qorders) - 1)
+                    # with gradients on, the kernel also lists every match by SORTED target position: that is what
+                    # the owner-computes backward scans (it replaces the saved index tensor)
+                    saved_k = torch.empty((N, n), dtype=torch.int32, device=dev) if (need_grad and cfg.bwd_owned) else None
+                    sweep.knn(src, poses[k], qorder, out=idx, cfg=(cfg.knn_variant >> 8) & 0xff, spos=saved_k)
+                    if saved_k is None:
+                        saved_k = idx
                 else:
+                    saved_k = idx
                     _lib.check(lib.dicp_knn(code, _p(src), _p(poses[k]), _p(tgt4), N, n, m, m_pad, _p(idx),
                                             kind | (cfg.knn_variant & 0xff00), st), "dicp_knn")
                 if hook:
@@ -302,7 +314,7 @@ class ICPLoop(torch.autograd.Function):
                     n_not_converged=ctypes.c_void_p(counters.data_ptr() + 4 * k))
                 _lib.check(lib.dicp_step(code, ctypes.byref(io), N, st), "dicp_step")
                 w_hist.append(wk)
-                idx_hist.append(idx if need_grad else None)
+                idx_hist.append(saved_k if need_grad else None)
                 K = k + 1
                 # ICP.py:259: stop once every cloud's step is below tolerance (same host sync as the reference)
                 if not cfg.const_iter and int(counters[k].item()) == 0:
@@ -327,16 +339,22 @@ class ICPLoop(torch.autograd.Function):
             costs_out = costs[:, :K].contiguous()
 
         if need_grad:
-            ctx.save_for_backward(src, tgt, w0c, poses, deltas, areg, alive_hist, *idx_hist)
+            owned = sweep is not None and cfg.bwd_owned
+            extra = [sweep.tperm] + qorders if owned else []
+            ctx.save_for_backward(src, tgt, w0c, poses, deltas, areg, alive_hist, *idx_hist, *extra)
             ctx.cfg, ctx.K, ctx.P, ctx.Kmax = cfg, K, P, Kmax
+            ctx.owned = (owned, list(qorder_of), m_pad)
         conv = converged.bool()
         ctx.mark_non_differentiable(deltas_out, weights, costs_out, conv, iterations, matched)
         return T, deltas_out, weights, costs_out, conv, iterations, matched
 
     @staticmethod
     def backward(ctx, gT, *_unused):
-        src, tgt, w0c, poses, deltas, areg, alive_hist, *idx_hist = ctx.saved_tensors
+        src, tgt, w0c, poses, deltas, areg, alive_hist, *rest = ctx.saved_tensors
         cfg, K, P, Kmax = ctx.cfg, ctx.K, ctx.P, ctx.Kmax
+        owned, qorder_of, m_pad = ctx.owned
+        idx_hist = rest[:K]
+        tperm, qorders = (rest[K], rest[K + 1:]) if owned else (None, [])
         lib = _lib.load()
         dev, dt = src.device, src.dtype
         code = _DT[dt]
@@ -345,13 +363,18 @@ class ICPLoop(torch.autograd.Function):
         hook = cfg.timing_hook
         with torch.cuda.device(dev):
             st = _stream()
-            nblk = lib.dicp_accumulate_blocks(n)
+            nblk = lib.dicp_owned_tiles(code, m_pad) if owned else lib.dicp_accumulate_blocks(n)
             gT = gT.contiguous()
             gpose = torch.cat((gT[:, :3, :3].reshape(N, 9), gT[:, :3, 3]), dim=1).to(torch.float64).contiguous()
             gpose_next = torch.empty_like(gpose)
             gsrc = torch.zeros_like(src)
             want_tgt = ctx.needs_input_grad[1]
-            gtgt = torch.zeros_like(tgt) if want_tgt else None
+            cv = 6 if cfg.icp_type == "pt2pl" else 3
+            if owned:       # target gradients accumulate in SORTED order, un-permuted once at the end
+                gts = torch.zeros((N, m_pad, cv), dtype=dt, device=dev) if want_tgt else None
+                gtgt = None
+            else:
+                gtgt = torch.zeros_like(tgt) if want_tgt else None
             gw = torch.zeros_like(w0c)
             gs = torch.empty((N, 36), dtype=dt, device=dev)
             gb = torch.empty((N, 6), dtype=dt, device=dev)
@@ -363,15 +386,24 @@ class ICPLoop(torch.autograd.Function):
                                              Kmax * 6, _p(areg[k]), _p(gs), _p(gb), _p(gpose_next), N, st), "dicp_step_bwd")
                 if hook:
                     hook("accumulate_bwd", 0)
-                _lib.check(lib.dicp_accumulate_bwd(code, ctypes.byref(P), _p(src), _p(tgt), c, _p(idx_hist[k]), _p(poses[k]),
-                                                   _p(w0c), _p(alive_hist[k]), _p(gs), _p(gb), N, n, m,
-                                                   _p(gsrc), _p(gtgt), _p(gw), _p(bwdp), st), "dicp_accumulate_bwd")
+                if owned:
+                    _lib.check(lib.dicp_accumulate_bwd_owned(code, ctypes.byref(P), _p(src), _p(tgt), c, _p(idx_hist[k]),
+                                                             _p(qorders[qorder_of[k]]), _p(tperm), _p(poses[k]), _p(w0c),
+                                                             _p(alive_hist[k]), _p(gs), _p(gb), N, n, m, m_pad,
+                                                             _p(gsrc), _p(gts), _p(gw), _p(bwdp), st), "dicp_accumulate_bwd_owned")
+                else:
+                    _lib.check(lib.dicp_accumulate_bwd(code, ctypes.byref(P), _p(src), _p(tgt), c, _p(idx_hist[k]), _p(poses[k]),
+                                                       _p(w0c), _p(alive_hist[k]), _p(gs), _p(gb), N, n, m,
+                                                       _p(gsrc), _p(gtgt), _p(gw), _p(bwdp), st), "dicp_accumulate_bwd")
                 if hook:
                     hook("accumulate_bwd", 1)
                 have_partials = True
                 gpose, gpose_next = gpose_next, gpose
             if have_partials:
                 gpose = gpose + bwdp.sum(dim=1)[:, :12].to(torch.float64)
+            if owned and want_tgt:      # sorted row s holds the gradient of original row tperm[s]
+                gtgt = torch.zeros_like(tgt)
+                gtgt[:, :, :cv].scatter_(1, tperm[:, :m].long().unsqueeze(-1).expand(-1, -1, cv), gts[:, :m])
             gT0 = torch.zeros((N, 4, 4), dtype=dt, device=dev)
             gT0[:, :3, :3] = gpose[:, :9].reshape(N, 3, 3).to(dt)
             gT0[:, :3, 3] = gpose[:, 9:].to(dt)

@@ -363,7 +363,8 @@ __global__ __launch_bounds__(BLOCK) void knn_sweep_kernel(const T* __restrict__ 
                                                           const typename V4<T>::type* __restrict__ tgs4,
                                                           const int32_t* __restrict__ tperm, const int32_t* __restrict__ qorder,
                                                           const int32_t* __restrict__ bucket, const T* __restrict__ brange, int nbkt,
-                                                          int32_t* __restrict__ idx, unsigned long long* __restrict__ pairs,
+                                                          int32_t* __restrict__ idx, int32_t* __restrict__ spos,
+                                                          unsigned long long* __restrict__ pairs,
                                                           int N, int n, int m, int m_pad, int bpc) {
     using T4 = typename V4<T>::type;
     __shared__ T4 tiles[BLOCK / WAVE][WAVE];
@@ -488,11 +489,11 @@ __global__ __launch_bounds__(BLOCK) void knn_sweep_kernel(const T* __restrict__ 
     for (int q = 0; q < Q; ++q) {
         if (qi[q] < 0) continue;
         T bv = inf_v<T>();
-        int bo = 0x7fffffff;
+        int bo = 0x7fffffff, bs = 0;
         auto consider = [&](int j) {
             const T sc = score<T, T4>(nx[q], tg[j]);
             const int o = pm[j];
-            if (sc < bv || (sc == bv && o < bo)) { bv = sc; bo = o; }     // lowest ORIGINAL index among equals
+            if (sc < bv || (sc == bv && o < bo)) { bv = sc; bo = o; bs = j; }     // lowest ORIGINAL index among equals
         };
         if (!over[q]) {
 #pragma unroll
@@ -506,6 +507,8 @@ __global__ __launch_bounds__(BLOCK) void knn_sweep_kernel(const T* __restrict__ 
             for (int j = visL * WAVE; j < visR * WAVE; ++j) consider(j);
         }
         idx[(size_t)cloud * n + qi[q]] = (bo == 0x7fffffff) ? 0 : min(max(bo, 0), m - 1);
+        // sorted position of the winner, stored at the query's SORTED slot: what the owner-computes backward scans
+        if (spos) spos[(size_t)cloud * n + unit * (WAVE * Q) + q * WAVE + lane] = (bo == 0x7fffffff || bo >= m) ? -1 : bs;
     }
     if (pairs && lane == 0) atomicAdd(pairs, (unsigned long long)(visR - visL) * WAVE * WAVE * Q);
 }
@@ -729,6 +732,101 @@ __global__ __launch_bounds__(BLOCK) void accumulate_bwd_kernel(WeightParams P, c
         }
     }
     block_reduce_store<T, NBWD, NBWD_PAD>(acc, bwd_partials + ((size_t)cloud * bpc + blk) * NBWD_PAD, red);
+}
+
+// Owner-computes form of the same backward, for the sorted-sweep path: NO global atomics.
+// A block owns TT consecutive SORTED targets of one cloud and keeps their gradient rows in LDS.  It scans the
+// cloud's matches in sorted-query order (spos[s] = sorted position of query s's neighbour, written by the sweep
+// kernel; nearly monotone in s, so whole waves either match or skip), runs the per-point adjoint for the
+// queries whose neighbour it owns, adds their target rows with LDS atomics, and finally adds its tile to the
+// sorted-order gradient buffer with plain coalesced read-modify-writes (it is the only writer of those rows).
+// Every query is matched by exactly one block, so src-bar / w-bar writes stay exclusive as well.
+template <typename T, int MODE, int TT>
+__global__ __launch_bounds__(BLOCK) void accumulate_bwd_owned_kernel(WeightParams P, const T* __restrict__ src, const T* __restrict__ tgt, int c,
+                                                                     const int32_t* __restrict__ spos, const int32_t* __restrict__ qorder,
+                                                                     const int32_t* __restrict__ tperm, const T* __restrict__ pose,
+                                                                     const T* __restrict__ w_init, const T* __restrict__ alive,
+                                                                     const T* __restrict__ gs, const T* __restrict__ gb,
+                                                                     int N, int n, int m, int m_pad, int tpc,
+                                                                     T* __restrict__ gsrc, T* __restrict__ gts /* (N,m_pad,CV) sorted order */,
+                                                                     T* __restrict__ gw, T* __restrict__ bwd_partials) {
+    constexpr int CV = (MODE == MODE_PT2PL) ? 6 : 3;
+    constexpr int SEG = 4096;                               // sorted queries scanned per compaction round
+    __shared__ T red[(BLOCK / WAVE) * NBWD_PAD];
+    __shared__ T rows[TT * CV];
+    __shared__ int list[SEG];
+    __shared__ int cnt;
+    int cloud, tile;
+    if (!decode_block(tpc, N, cloud, tile)) return;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int lo = tile * TT, hi = min(lo + TT, m_pad);
+    for (int k = tid; k < TT * CV; k += BLOCK) rows[k] = T(0);
+    T C[9], r[3], Gs[36], Gb[6];
+    load_pose(pose, cloud, C, r);
+#pragma unroll
+    for (int k = 0; k < 36; ++k) Gs[k] = gs[(size_t)cloud * 36 + k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Gb[k] = gb[(size_t)cloud * 6 + k];
+    const T live = alive ? alive[cloud] : T(1);
+    T acc[NBWD];
+#pragma unroll
+    for (int k = 0; k < NBWD; ++k) acc[k] = T(0);
+    const int32_t* __restrict__ sp_c = spos + (size_t)cloud * n;
+    for (int seg = 0; seg < n; seg += SEG) {
+        if (tid == 0) cnt = 0;
+        __syncthreads();
+        // phase 1: which sorted slots of this segment have their neighbour in [lo, hi)?  4 independent loads in
+        // flight per thread; matches are appended to an LDS list (wave ballot + one LDS atomic per wave).
+        for (int it = 0; it < SEG; it += 4 * BLOCK) {
+            int pos[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int sl = seg + it + e * BLOCK + tid;
+                pos[e] = (sl < n && it + e * BLOCK + tid < SEG) ? sp_c[sl] : -1;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool hit = pos[e] >= lo && pos[e] < hi;
+                const unsigned long long mask = __ballot(hit);
+                if (mask) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&cnt, __popcll(mask));
+                    base = __shfl(base, 0);
+                    if (hit) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = seg + it + e * BLOCK + tid;
+                }
+            }
+        }
+        __syncthreads();
+        // phase 2: dense pass over the matches
+        const int total = cnt;
+        for (int k = tid; k < total; k += BLOCK) {
+            const int sl = list[k];
+            const int pos = sp_c[sl];
+            const int i = qorder ? qorder[(size_t)cloud * n + sl] : sl;
+            const size_t pt = (size_t)cloud * n + i;
+            const T* spp = src + pt * 3;
+            const T p[3] = {spp[0], spp[1], spp[2]};
+            const int j = tperm[(size_t)cloud * m_pad + pos];
+            const T* yp = tgt + ((size_t)cloud * m + j) * c;
+            const T y[3] = {yp[0], yp[1], yp[2]};
+            T nrm[3] = {T(0), T(0), T(0)};
+            if (MODE == MODE_PT2PL) { nrm[0] = yp[3]; nrm[1] = yp[4]; nrm[2] = yp[5]; }
+            T gp[3], gy[3], gn[3], gw0;
+            point_backward<T, MODE>(P, C, r, p, y, nrm, w_init[pt] * live, Gs, Gb, gp, gy, gn, gw0, acc, acc + 9);
+            T* gsp = gsrc + pt * 3;
+            gsp[0] += gp[0]; gsp[1] += gp[1]; gsp[2] += gp[2];
+            if (gw) gw[pt] += gw0 * live;
+            T* row = rows + (pos - lo) * CV;
+            atomicAdd(&row[0], gy[0]); atomicAdd(&row[1], gy[1]); atomicAdd(&row[2], gy[2]);
+            if (MODE == MODE_PT2PL) { atomicAdd(&row[3], gn[0]); atomicAdd(&row[4], gn[1]); atomicAdd(&row[5], gn[2]); }
+        }
+        __syncthreads();
+    }
+    if (gts) {
+        T* out = gts + ((size_t)cloud * m_pad + lo) * CV;
+        for (int k = tid; k < (hi - lo) * CV; k += BLOCK) out[k] += rows[k];
+    }
+    block_reduce_store<T, NBWD, NBWD_PAD>(acc, bwd_partials + ((size_t)cloud * tpc + tile) * NBWD_PAD, red);
 }
 
 // ---------------------------------------------------------------------- step bwd
@@ -1055,7 +1153,7 @@ int dicp_knn(int dtype, const void* src, const void* pose, const void* tgt4, int
 
 int dicp_knn_sweep(int dtype, const void* src, const void* pose, const void* tgs4, const int32_t* tperm,
                    const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt,
-                   int N, int n, int m, int m_pad, int32_t* idx, unsigned long long* pairs, int cfg, void* stream) {
+                   int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg, void* stream) {
     if (!src || !tgs4 || !tperm || !bucket || !brange || !idx) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || n <= 0 || m <= 0 || nbkt <= 0 || m_pad != dicp_padded_targets(m)) return DICP_ERR_SHAPE;
@@ -1065,7 +1163,7 @@ int dicp_knn_sweep(int dtype, const void* src, const void* pose, const void* tgs
     if (cfg == 0) cfg = ((long)N * n >= 2L * BLOCK * 1024) ? 8 : 4;      // 3 (else 1) queries per lane, 16-target chunks
 #define DICP_SWEEP(T, Q, CH) do { const int units = (n + WAVE * Q - 1) / (WAVE * Q), bpc = (units + BLOCK / WAVE - 1) / (BLOCK / WAVE); \
         knn_sweep_kernel<T, Q, CH><<<grid_for(N, bpc), BLOCK, 0, st>>>((const T*)src, (const T*)pose, (const typename V4<T>::type*)tgs4, tperm, qorder, \
-            bucket, (const T*)brange, nbkt, idx, pairs, N, n, m, m_pad, bpc); } while (0)
+            bucket, (const T*)brange, nbkt, idx, spos, pairs, N, n, m, m_pad, bpc); } while (0)
     if (dtype == DICP_F32) {
         switch (cfg) {
             case 1: DICP_SWEEP(float, 1, 8); break;   case 2: DICP_SWEEP(float, 2, 8); break;   case 3: DICP_SWEEP(float, 4, 8); break;
@@ -1233,6 +1331,32 @@ int dicp_kabsch_bwd(int dtype, const void* src, const void* tgt, int c, const in
     const int bpc = dicp_accumulate_blocks(n);
     if (dtype == DICP_F32) kabsch_bwd_kernel<float><<<grid_for(N, bpc), BLOCK, 0, st>>>((const float*)src, (const float*)tgt, c, idx, (const float*)pose, (const float*)w_init, trim_on, (float)trim_dist, (const float*)gacc, N, n, m, bpc, (float*)gsrc, (float*)gtgt, (float*)gw);
     else                   kabsch_bwd_kernel<double><<<grid_for(N, bpc), BLOCK, 0, st>>>((const double*)src, (const double*)tgt, c, idx, (const double*)pose, (const double*)w_init, trim_on, trim_dist, (const double*)gacc, N, n, m, bpc, (double*)gsrc, (double*)gtgt, (double*)gw);
+    return launch_status();
+}
+
+int dicp_owned_tiles(int dtype, int m_pad) {
+    const int TT = (dtype == DICP_F32) ? 2048 : 1024;
+    return m_pad <= 0 ? 0 : (m_pad + TT - 1) / TT;
+}
+
+int dicp_accumulate_bwd_owned(int dtype, const dicp_weight_params* prm, const void* src, const void* tgt, int c,
+                              const int32_t* spos, const int32_t* qorder, const int32_t* tperm, const void* pose,
+                              const void* w_init, const void* alive, const void* gs, const void* gb,
+                              int N, int n, int m, int m_pad, void* gsrc, void* gts, void* gw, void* bwd_partials, void* stream) {
+    if (const int e = check_params(prm, c)) return e;
+    if (!src || !tgt || !spos || !tperm || !w_init || !gs || !gb || !gsrc || !bwd_partials) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0 || n <= 0 || m <= 0 || m_pad != dicp_padded_targets(m)) return DICP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    begin_launch();
+    const WeightParams P = to_params(prm);
+    const int tpc = dicp_owned_tiles(dtype, m_pad);
+    const unsigned g = grid_for(N, tpc);
+#define DICP_OWN(T, M, TT) accumulate_bwd_owned_kernel<T, M, TT><<<g, BLOCK, 0, st>>>(P, (const T*)src, (const T*)tgt, c, spos, qorder, tperm, \
+        (const T*)pose, (const T*)w_init, (const T*)alive, (const T*)gs, (const T*)gb, N, n, m, m_pad, tpc, (T*)gsrc, (T*)gts, (T*)gw, (T*)bwd_partials)
+    if (dtype == DICP_F32) { if (P.mode == MODE_PT2PL) DICP_OWN(float, MODE_PT2PL, 2048); else DICP_OWN(float, MODE_PT2PT, 2048); }
+    else                   { if (P.mode == MODE_PT2PL) DICP_OWN(double, MODE_PT2PL, 1024); else DICP_OWN(double, MODE_PT2PT, 1024); }
+#undef DICP_OWN
     return launch_status();
 }
 

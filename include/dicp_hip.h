@@ -75,11 +75,13 @@ int dicp_knn(int dtype, const void* src, const void* pose, const void* tgt4, int
  *   bucket (N,nbkt+1)  bucket[b] = #rows with x < xlo + b/inv  (lower_bound table), brange (N,2) = [xlo, inv];
  *   qorder (N,n)       optional: query indices in ascending x (under any recent pose) so that a wave's
  *                      queries are neighbours; NULL = natural order (still exact, less pruning).
+ * spos (N,n), optional: spos[b][s] = SORTED position of the neighbour of the query in sorted slot s (-1 if none):
+ *   the match list dicp_accumulate_bwd_owned scans.
  * pairs: optional device counter, += number of (query,target) pairs actually scored (roofline accounting).
  * cfg: 0 auto, 1.. = fixed (queries per lane, chunk) launch configuration (tuning). */
 int dicp_knn_sweep(int dtype, const void* src, const void* pose, const void* tgs4, const int32_t* tperm,
                    const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt,
-                   int N, int n, int m, int m_pad, int32_t* idx, unsigned long long* pairs, int cfg, void* stream);
+                   int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg, void* stream);
 
 /* Gather whole target rows at idx (nn.py:37-38 / 89-90) and its backward, a scatter-add
  * into a zero-initialised (N,m,c) buffer (autograd's gather backward). */
@@ -148,6 +150,17 @@ int dicp_accumulate_bwd(int dtype, const dicp_weight_params* prm, const void* sr
                         const int32_t* idx, const void* pose, const void* w_init, const void* alive,
                         const void* gs, const void* gb, int N, int n, int m,
                         void* gsrc, void* gtgt, void* gw, void* bwd_partials, void* stream);
+
+/* Owner-computes form of dicp_accumulate_bwd for the sorted-sweep path: no global atomics.  Each block owns a
+ * range of SORTED targets (dicp_owned_tiles(dtype, m_pad) ranges per cloud), accumulates their gradient rows in
+ * LDS from the matches listed in spos/qorder (as written by / passed to dicp_knn_sweep for that iteration), and
+ * adds them to gts (N,m_pad,CV) -- target gradients in SORTED order, CV = 6 for pt2pl, 3 for pt2pt; the caller
+ * un-permutes once after the last iteration.  bwd_partials: (N, dicp_owned_tiles, DICP_NBWD_PAD). */
+int dicp_owned_tiles(int dtype, int m_pad);
+int dicp_accumulate_bwd_owned(int dtype, const dicp_weight_params* prm, const void* src, const void* tgt, int c,
+                              const int32_t* spos, const int32_t* qorder, const int32_t* tperm, const void* pose,
+                              const void* w_init, const void* alive, const void* gs, const void* gb,
+                              int N, int n, int m, int m_pad, void* gsrc, void* gts, void* gw, void* bwd_partials, void* stream);
 
 /* Closed-form point-to-point step (Kabsch / SVD), the solver of ICP.pt2pt_dICP_SVD (ICP.py:533-591): batched,
  * weighted, with the rotation composed as U diag(1,1,det U det V) V^T (the reference multiplies by V where V^T

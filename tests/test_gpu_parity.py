@@ -549,13 +549,15 @@ def test_sweep_knn_full_size_and_pruning():
     assert torch.equal(got2, brute)
 
 
+@pytest.mark.parametrize("owned", [False, True])
 @pytest.mark.parametrize("name,icp_type,diff", [("c1_pt2pt_diff", "pt2pt", True), ("c1_pt2pl_diff", "pt2pl", True)])
-def test_icp_with_sweep_knn_matches_reference(golden, name, icp_type, diff):
+def test_icp_with_sweep_knn_matches_reference(golden, name, icp_type, diff, owned):
     g = golden(name)
     trim, huber, tol, max_iter = g["params"]
     src, tgt = t(g["source"], grad=True), t(g["target"], grad=True)
     icp = ICP(icp_type=icp_type, differentiable=diff, max_iterations=int(max_iter), tolerance=float(tol))
     icp.knn_variant = _lib.KNN_SWEEP
+    icp.bwd_owned = owned
     res = icp.icp(src, tgt, t(g["T_init"]), trim_dist=float(trim), loss_fn={"name": "huber", "metric": float(huber)}, dim=2)
     check_result(res, g)
     res["T"].sum().backward()
@@ -564,7 +566,9 @@ def test_icp_with_sweep_knn_matches_reference(golden, name, icp_type, diff):
     assert int(icp.knn_stats["knn_pairs"].item()) > 0
 
 
-def test_icp_sweep_equals_brute_on_synthetic():
+@pytest.mark.parametrize("owned", [False, True])
+def test_icp_sweep_equals_brute_on_synthetic(owned):
+    """Sweep kNN (+ optionally the owner-computes, atomics-free backward) against the brute-force path."""
     N, n, K = 6, 4096, 6
     src, tgt = make_pairs(N, n, n, seed=5, dtype=torch.float32)
     outs = []
@@ -573,12 +577,14 @@ def test_icp_sweep_equals_brute_on_synthetic():
         icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
         icp.const_iter = True
         icp.knn_variant = variant
+        icp.bwd_owned = owned
         out = icp.icp(sd, td, torch.eye(4, device=DEV).repeat(N, 1, 1), trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0})
         out["T"].sum().backward()
         outs.append((out, sd.grad, td.grad))
     assert torch.equal(outs[0][0]["T"], outs[1][0]["T"]) and torch.equal(outs[0][0]["weights"], outs[1][0]["weights"])
-    assert torch.equal(outs[0][1], outs[1][1])
-    np.testing.assert_allclose(npy(outs[0][2]), npy(outs[1][2]), rtol=0, atol=1e-6)     # float atomics order
+    # identical forward; the backward sums the same terms in a different grouping (owner-computes vs atomics)
+    np.testing.assert_allclose(npy(outs[0][1]), npy(outs[1][1]), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(npy(outs[0][2]), npy(outs[1][2]), rtol=0, atol=1e-6)
 
 
 # ------------------------------------------------------------------- SVD point-to-point (a-12 / f-4)

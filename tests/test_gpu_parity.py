@@ -690,3 +690,88 @@ def test_svd_icp_config2_shape_and_trim():
     ps0, T0 = icp.pt2pt_dICP_SVD(src[:2].to(DEV), tgt[:2].to(DEV), torch.eye(4, device=DEV).repeat(2, 1, 1),
                                  weight=torch.zeros((2, n), device=DEV))
     assert torch.equal(T0, torch.eye(4, device=DEV).repeat(2, 1, 1))
+
+
+# ----------------------------------------------------------------------- robustness of the call surface
+def test_views_partial_grads_and_no_grad():
+    """Non-contiguous inputs, gradients for a subset of the inputs, no_grad, tiny clouds."""
+    N, n, m = 3, 200, 260
+    src6, tgt = make_pairs(N, n, m, seed=40, dtype=torch.float64)
+    src6 = torch.cat((src6, torch.zeros(N, n, 3, dtype=torch.float64)), dim=2)       # (N,n,6): xyz is a strided view
+    kw = dict(trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0}, dim=3)
+    w = torch.rand((N, n), generator=torch.Generator().manual_seed(4), dtype=torch.float64) + 0.5
+    sc, tc, wc = src6.clone().requires_grad_(True), tgt.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    T0 = torch.eye(4, dtype=torch.float64).repeat(N, 1, 1)
+    T0[:, :3, 3] = 0.05
+    ref = O.icp_batched(sc[:, :, :3], tc, T0, wc, icp_type="pt2pl", differentiable=True, max_iterations=4, tolerance=1e-12,
+                        const_iter=True, **kw)
+    ref["T"].sum().backward()
+    icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=4, tolerance=1e-12)
+    icp.const_iter = True
+    # (a) only the source wants a gradient; 6-column source -> strided xyz view inside
+    sd = src6.to(DEV).requires_grad_(True)
+    out = icp.icp(sd, tgt.to(DEV), T0.to(DEV), weight=w.to(DEV), **kw)
+    out["T"].sum().backward()
+    np.testing.assert_allclose(npy(out["T"]), npy(ref["T"]), rtol=0, atol=1e-10)
+    np.testing.assert_allclose(npy(sd.grad), npy(sc.grad), rtol=0, atol=1e-9)
+    assert float(sd.grad[:, :, 3:].abs().max()) == 0.0
+    # (b) only the weight wants a gradient; target passed as a transposed-back (non-contiguous) view
+    wd = w.to(DEV).requires_grad_(True)
+    tview = tgt.to(DEV).transpose(1, 2).contiguous().transpose(1, 2)
+    assert not tview.is_contiguous()
+    out = icp.icp(src6.to(DEV), tview, T0.to(DEV), weight=wd, **kw)
+    out["T"].sum().backward()
+    np.testing.assert_allclose(npy(wd.grad), npy(wc.grad), rtol=0, atol=1e-9)
+    # (c) T_init gradient
+    Td = T0.to(DEV).requires_grad_(True)
+    Tc = T0.clone().requires_grad_(True)
+    O.icp_batched(src6[:, :, :3], tgt, Tc, w, icp_type="pt2pl", differentiable=True, max_iterations=4, tolerance=1e-12,
+                  const_iter=True, **kw)["T"].sum().backward()
+    icp.icp(src6.to(DEV), tgt.to(DEV), Td, weight=w.to(DEV), **kw)["T"].sum().backward()
+    np.testing.assert_allclose(npy(Td.grad), npy(Tc.grad), rtol=0, atol=1e-9)
+    # (d) no_grad: nothing is saved, outputs carry no graph
+    with torch.no_grad():
+        out = icp.icp(src6.to(DEV), tgt.to(DEV), T0.to(DEV), weight=w.to(DEV), **kw)
+    assert not out["T"].requires_grad and not out["pc"].requires_grad
+    np.testing.assert_allclose(npy(out["T"]), npy(ref["T"]), rtol=0, atol=1e-10)
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (1, 70), (63, 5), (300, 64), (65, 65)])
+def test_tiny_and_odd_sizes(n, m):
+    g = torch.Generator().manual_seed(n * 100 + m)
+    src = torch.rand((2, n, 3), generator=g, dtype=torch.float64)
+    tgt = torch.rand((2, m, 6), generator=g, dtype=torch.float64)
+    T0 = torch.eye(4, dtype=torch.float64).repeat(2, 1, 1)
+    for icp_type in ("pt2pl", "pt2pt"):
+        rows = 3 if icp_type == "pt2pt" else 1
+        tg = tgt if icp_type == "pt2pl" else tgt[:, :, :3].contiguous()
+        ref = O.icp_batched(src, tg, T0, torch.ones(2, n * rows, dtype=torch.float64), icp_type=icp_type, differentiable=True,
+                            max_iterations=3, tolerance=1e-14, const_iter=True, trim_dist=5.0)
+        icp = ICP(icp_type=icp_type, differentiable=True, max_iterations=3, tolerance=1e-14)
+        icp.const_iter = True
+        for variant in (_lib.KNN_VALU, _lib.KNN_SWEEP):
+            icp.knn_variant = variant
+            out = icp.icp(src.to(DEV), tg.to(DEV), T0.to(DEV), trim_dist=5.0)
+            assert out["weights"].shape == (2, 3, n * rows, 1) and out["deltas"].shape == (2, 3, 6, 1)
+            assert bool(torch.isfinite(out["T"]).all())
+            # iteration 0 depends only on T_init: weights and cost must agree whatever the conditioning
+            np.testing.assert_allclose(npy(out["weights"])[:, 0], npy(ref["weights"])[:, 0], rtol=0, atol=1e-12)
+            np.testing.assert_allclose(npy(out["costs"])[:, 0], npy(ref["costs"])[:, 0], rtol=1e-10, atol=1e-14)
+            if min(n, m) >= 64:     # fewer distinct correspondences than unknowns leaves only the 1e-12 regulariser
+                np.testing.assert_allclose(npy(out["T"]), npy(ref["T"]), rtol=0, atol=1e-9)
+
+
+def test_errors_on_device_inputs():
+    src, tgt = make_pairs(1, 50, 60, seed=1, dtype=torch.float32)
+    icp = ICP(icp_type="pt2pl")
+    with pytest.raises(AssertionError):
+        icp.icp(src.to(DEV), tgt[:, :, :3].to(DEV), torch.eye(4, device=DEV))          # pt2pl needs normals (ICP.py:103)
+    with pytest.raises(AssertionError):
+        icp.icp(src.to(DEV), tgt.double().to(DEV), torch.eye(4, device=DEV))           # dtype mismatch (ICP.py:96)
+    with pytest.raises(ValueError):
+        icp.icp(src.to(DEV), tgt.to(DEV), torch.eye(4, device=DEV), loss_fn={"name": "tukey", "metric": 1.0})   # loss.py:19
+    with pytest.raises(TypeError):
+        icp.icp(src.half().to(DEV), tgt.half().to(DEV), torch.eye(4, device=DEV).half())
+    icp.nn.use_gumbel = True
+    with pytest.raises(NotImplementedError):
+        icp.icp(src.to(DEV), tgt.to(DEV), torch.eye(4, device=DEV))

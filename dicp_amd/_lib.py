@@ -55,6 +55,8 @@ _SIGNATURES = {
     "dicp_step": ([i32, ctypes.POINTER(StepIO), i32, vp], ctypes.c_int),
     "dicp_step_bwd": ([i32, vp, vp, i32, i32, vp, vp, i64, vp, vp, vp, vp, i32, vp], ctypes.c_int),
     "dicp_accumulate_bwd": ([i32, ctypes.POINTER(WeightParams), vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp], ctypes.c_int),
+    "dicp_gumbel_nn": ([i32, vp, vp, i32, vp, ctypes.c_uint32, f64, f64, i32, i32, i32, vp, vp, vp], ctypes.c_int),
+    "dicp_gumbel_nn_bwd": ([i32, vp, vp, i32, vp, ctypes.c_uint32, f64, f64, vp, vp, vp, i32, i32, i32, vp, vp, vp], ctypes.c_int),
     "dicp_kabsch_accumulate": ([i32, vp, vp, i32, vp, vp, vp, i32, f64, i32, i32, i32, vp, vp], ctypes.c_int),
     "dicp_kabsch_step": ([i32, vp, i32, vp, vp, vp, i32, vp], ctypes.c_int),
     "dicp_kabsch_step_bwd": ([i32, vp, vp, vp, i32, vp], ctypes.c_int),

@@ -147,6 +147,51 @@ def gather_rows(y, idx):
     return _GatherRows.apply(y.contiguous(), idx)
 
 
+class _GumbelNN(torch.autograd.Function):
+    """nn.__diff_nn_gumbel (nn.py:43-70) through dicp_gumbel_nn / dicp_gumbel_nn_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, y, U, seed, eps, tau):
+        N, n, _ = x.shape
+        m, c = y.shape[1], y.shape[2]
+        out = torch.empty((N, n, c), dtype=x.dtype, device=x.device)
+        lse = torch.empty((N, n), dtype=x.dtype, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().dicp_gumbel_nn(_DT[x.dtype], _p(x), _p(y), c, _p(U), seed, float(eps), float(tau), N, n, m,
+                                                  _p(out), _p(lse), _stream()), "dicp_gumbel_nn")
+        ctx.save_for_backward(x, y, out, lse, *([U] if U is not None else []))
+        ctx.cfg = (seed, float(eps), float(tau), U is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, y, out, lse, *rest = ctx.saved_tensors
+        seed, eps, tau, has_u = ctx.cfg
+        U = rest[0] if has_u else None
+        N, n, _ = x.shape
+        m, c = y.shape[1], y.shape[2]
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gy = torch.empty_like(y) if ctx.needs_input_grad[1] else None
+        if gx is None and gy is None:
+            return None, None, None, None, None, None
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().dicp_gumbel_nn_bwd(_DT[x.dtype], _p(x), _p(y), c, _p(U), seed, eps, tau, _p(out), _p(lse),
+                                                      _p(gout.contiguous()), N, n, m, _p(gx), _p(gy), _stream()), "dicp_gumbel_nn_bwd")
+        return gx, gy, None, None, None, None
+
+
+def gumbel_nn(x, y, eps, tau, U=None, seed=None):
+    """Soft neighbours (N,n,c).  U=None: noise from the in-kernel generator, seeded from torch's CPU generator
+    (so torch.manual_seed makes it reproducible)."""
+    require_device(x, "gumbel_nn")
+    require_device(y, "gumbel_nn")
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    if U is not None:
+        U = U.to(device=x.device, dtype=x.dtype).contiguous()
+    return _GumbelNN.apply(x.contiguous(), y.contiguous(), U, seed & 0xFFFFFFFF, eps, tau)
+
+
 class _LossWeight(torch.autograd.Function):
     @staticmethod
     def forward(ctx, err2d, loss, diff, metric, tanh_k):

@@ -860,6 +860,171 @@ __global__ __launch_bounds__(WAVE) void step_bwd_kernel(const double* __restrict
     if (tid < 12) gpose_out[(size_t)cloud * 12 + tid] = sgo[tid];
 }
 
+// ------------------------------------------------------------- Gumbel-softmax soft kNN
+// nn.__diff_nn_gumbel (nn.py:43-70): out_i = sum_j softmax_j((-|x_i - y_j|^2 + g_ij) / tau) * y_j with
+// g = -log(-log(U + eps) + eps).  The reference materialises (N,n,m) distances, noise and probabilities; here
+// the targets stream through LDS and each lane keeps an ONLINE softmax (running max, sum, weighted row) for
+// its query.  Noise is either an injected U (N,n,m) -- what the parity tests use -- or generated in-kernel
+// from a counter-based hash of (seed, cloud, i, j), so the backward passes can regenerate it instead of
+// storing it.  Backward recomputes the probabilities from the saved log-sum-exp in two passes: one lane per
+// query (x-bar) and one lane per target (y-bar, no atomics).
+__device__ __forceinline__ unsigned mix32(unsigned v) {
+    v ^= v >> 16; v *= 0x7feb352du; v ^= v >> 15; v *= 0x846ca68bu; v ^= v >> 16;
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ T gumbel_uniform(const T* __restrict__ U, size_t off, unsigned key_bi, unsigned j) {
+    if (U) return U[off];
+    return T(mix32(key_bi ^ (j * 0xC2B2AE35u + 0x27D4EB2Fu)) >> 8) * T(1.0 / 16777216.0);      // [0,1) like torch.rand
+}
+__device__ __forceinline__ float  log_t(float v)  { return __logf(v); }
+__device__ __forceinline__ double log_t(double v) { return log(v); }
+__device__ __forceinline__ float  exp_t(float v)  { return __expf(v); }
+__device__ __forceinline__ double exp_t(double v) { return exp(v); }
+
+template <typename T>
+__device__ __forceinline__ T gumbel_logit(const T* x, const T* y, T u, T eps, T inv_tau) {
+    const T d0 = x[0] - y[0], d1 = x[1] - y[1], d2 = x[2] - y[2];
+    const T g = -log_t(-log_t(u + eps) + eps);                                   // nn.py:62
+    return (g - (d0 * d0 + d1 * d1 + d2 * d2)) * inv_tau;                         // nn.py:56-64
+}
+
+constexpr int GUM_TILE = 512;
+
+template <typename T, int C>
+__global__ __launch_bounds__(BLOCK) void gumbel_fwd_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ U,
+                                                           unsigned seed, T eps, T inv_tau, T* __restrict__ out, T* __restrict__ lse,
+                                                           int N, int n, int m, int bpc) {
+    __shared__ T ty[GUM_TILE * C];
+    int cloud, blk;
+    if (!decode_block(bpc, N, cloud, blk)) return;
+    const int tid = threadIdx.x, i = blk * BLOCK + tid;
+    const bool on = i < n;
+    T xi[3] = {T(0), T(0), T(0)};
+    if (on) { const T* xp = x + ((size_t)cloud * n + i) * 3; xi[0] = xp[0]; xi[1] = xp[1]; xi[2] = xp[2]; }
+    const unsigned key = mix32(mix32(seed ^ ((unsigned)cloud * 0x9E3779B9u)) ^ ((unsigned)i * 0x85EBCA6Bu));
+    const size_t urow = ((size_t)cloud * n + (on ? i : 0)) * m;
+    T M = -inf_v<T>(), S = T(0), acc[C];
+#pragma unroll
+    for (int k = 0; k < C; ++k) acc[k] = T(0);
+    const T* __restrict__ yc = y + (size_t)cloud * m * C;
+    for (int base = 0; base < m; base += GUM_TILE) {
+        const int len = min(GUM_TILE, m - base);
+        for (int t = tid; t < len * C; t += BLOCK) ty[t] = yc[(size_t)base * C + t];
+        __syncthreads();
+        for (int j = 0; j < len; ++j) {
+            const T* yj = ty + j * C;
+            const T l = gumbel_logit(xi, yj, gumbel_uniform(U, urow + base + j, key, (unsigned)(base + j)), eps, inv_tau);
+            const T Mn = l > M ? l : M;
+            const T sc = exp_t(M - Mn), e = exp_t(l - Mn);                        // M = -inf first time: sc = 0
+            S = S * sc + e;
+#pragma unroll
+            for (int k = 0; k < C; ++k) acc[k] = acc[k] * sc + e * yj[k];
+            M = Mn;
+        }
+        __syncthreads();
+    }
+    if (on) {
+        const T invS = T(1) / S;
+        T* op = out + ((size_t)cloud * n + i) * C;
+#pragma unroll
+        for (int k = 0; k < C; ++k) op[k] = acc[k] * invS;                        // probs @ y, nn.py:65-68
+        lse[(size_t)cloud * n + i] = M + log_t(S);
+    }
+}
+
+// x-bar: one lane per query.
+template <typename T, int C>
+__global__ __launch_bounds__(BLOCK) void gumbel_bwd_q_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ U,
+                                                             unsigned seed, T eps, T inv_tau, const T* __restrict__ out,
+                                                             const T* __restrict__ lse, const T* __restrict__ gout, T* __restrict__ gx,
+                                                             int N, int n, int m, int bpc) {
+    __shared__ T ty[GUM_TILE * C];
+    int cloud, blk;
+    if (!decode_block(bpc, N, cloud, blk)) return;
+    const int tid = threadIdx.x, i = blk * BLOCK + tid;
+    const bool on = i < n;
+    const size_t q = (size_t)cloud * n + (on ? i : 0);
+    T xi[3], go[C], D = T(0);
+    xi[0] = x[q * 3]; xi[1] = x[q * 3 + 1]; xi[2] = x[q * 3 + 2];
+#pragma unroll
+    for (int k = 0; k < C; ++k) { go[k] = gout[q * C + k]; D += go[k] * out[q * C + k]; }
+    const T L = lse[q];
+    const unsigned key = mix32(mix32(seed ^ ((unsigned)cloud * 0x9E3779B9u)) ^ ((unsigned)i * 0x85EBCA6Bu));
+    T g[3] = {T(0), T(0), T(0)};
+    const T* __restrict__ yc = y + (size_t)cloud * m * C;
+    for (int base = 0; base < m; base += GUM_TILE) {
+        const int len = min(GUM_TILE, m - base);
+        for (int t = tid; t < len * C; t += BLOCK) ty[t] = yc[(size_t)base * C + t];
+        __syncthreads();
+        for (int j = 0; j < len; ++j) {
+            const T* yj = ty + j * C;
+            const T l = gumbel_logit(xi, yj, gumbel_uniform(U, q * m + base + j, key, (unsigned)(base + j)), eps, inv_tau);
+            const T p = exp_t(l - L);
+            T gy = T(0);
+#pragma unroll
+            for (int k = 0; k < C; ++k) gy += go[k] * yj[k];
+            const T dl = p * (gy - D);
+            g[0] += dl * (xi[0] - yj[0]); g[1] += dl * (xi[1] - yj[1]); g[2] += dl * (xi[2] - yj[2]);
+        }
+        __syncthreads();
+    }
+    if (on) {
+        const T f = -T(2) * inv_tau;
+        gx[q * 3] = f * g[0]; gx[q * 3 + 1] = f * g[1]; gx[q * 3 + 2] = f * g[2];
+    }
+}
+
+// y-bar: one lane per target, queries stream through LDS as [x(3), gout(C), lse, D].
+template <typename T, int C>
+__global__ __launch_bounds__(BLOCK) void gumbel_bwd_t_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ U,
+                                                             unsigned seed, T eps, T inv_tau, const T* __restrict__ out,
+                                                             const T* __restrict__ lse, const T* __restrict__ gout, T* __restrict__ gy,
+                                                             int N, int n, int m, int bpc) {
+    constexpr int R = C + 5;
+    __shared__ T tq[GUM_TILE * R];
+    int cloud, blk;
+    if (!decode_block(bpc, N, cloud, blk)) return;
+    const int tid = threadIdx.x, j = blk * BLOCK + tid;
+    const bool on = j < m;
+    const size_t tj = (size_t)cloud * m + (on ? j : 0);
+    T yj[C], g[C];
+#pragma unroll
+    for (int k = 0; k < C; ++k) { yj[k] = y[tj * C + k]; g[k] = T(0); }
+    const unsigned kc = mix32(seed ^ ((unsigned)cloud * 0x9E3779B9u));
+    for (int base = 0; base < n; base += GUM_TILE) {
+        const int len = min(GUM_TILE, n - base);
+        for (int t = tid; t < len; t += BLOCK) {
+            const size_t q = (size_t)cloud * n + base + t;
+            T* r = tq + t * R;
+            r[0] = x[q * 3]; r[1] = x[q * 3 + 1]; r[2] = x[q * 3 + 2];
+            T D = T(0);
+#pragma unroll
+            for (int k = 0; k < C; ++k) { const T v = gout[q * C + k]; r[3 + k] = v; D += v * out[q * C + k]; }
+            r[3 + C] = lse[q];
+            r[4 + C] = D;
+        }
+        __syncthreads();
+        for (int t = 0; t < len; ++t) {
+            const T* r = tq + t * R;
+            const int i = base + t;
+            const unsigned key = mix32(kc ^ ((unsigned)i * 0x85EBCA6Bu));
+            const T l = gumbel_logit(r, yj, gumbel_uniform(U, ((size_t)cloud * n + i) * m + (on ? j : 0), key, (unsigned)j), eps, inv_tau);
+            const T p = exp_t(l - r[3 + C]);
+            T gd = T(0);
+#pragma unroll
+            for (int k = 0; k < C; ++k) { gd += r[3 + k] * yj[k]; g[k] += p * r[3 + k]; }
+            const T dl = p * (gd - r[4 + C]) * (T(2) * inv_tau);
+            g[0] += dl * (r[0] - yj[0]); g[1] += dl * (r[1] - yj[1]); g[2] += dl * (r[2] - yj[2]);
+        }
+        __syncthreads();
+    }
+    if (on) {
+#pragma unroll
+        for (int k = 0; k < C; ++k) gy[tj * C + k] = g[k];
+    }
+}
+
 // ------------------------------------------------------------------ Kabsch / SVD path
 // Point-to-point alignment in closed form (the step of the reference's pt2pt_dICP_SVD, ICP.py:533-591),
 // batched and weighted.  accumulate: 18 sums per cloud; step: 3x3 SVD per cloud; bwd: one pass.
@@ -1283,6 +1448,39 @@ int dicp_accumulate_bwd(int dtype, const dicp_weight_params* prm, const void* sr
     if (dtype == DICP_F32) { if (P.mode == MODE_PT2PL) DICP_BWD(float, MODE_PT2PL); else DICP_BWD(float, MODE_PT2PT); }
     else                   { if (P.mode == MODE_PT2PL) DICP_BWD(double, MODE_PT2PL); else DICP_BWD(double, MODE_PT2PT); }
 #undef DICP_BWD
+    return launch_status();
+}
+
+int dicp_gumbel_nn(int dtype, const void* x, const void* y, int c, const void* U, uint32_t seed, double eps, double tau,
+                   int N, int n, int m, void* out, void* lse, void* stream) {
+    if (!x || !y || !out || !lse) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0 || n <= 0 || m <= 0 || (c != 3 && c != 6) || !(tau > 0.0)) return DICP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    begin_launch();
+    const int bpc = (n + BLOCK - 1) / BLOCK;
+    const unsigned g = grid_for(N, bpc);
+#define DICP_GF(T, C) gumbel_fwd_kernel<T, C><<<g, BLOCK, 0, st>>>((const T*)x, (const T*)y, (const T*)U, seed, (T)eps, (T)(1.0 / tau), (T*)out, (T*)lse, N, n, m, bpc)
+    if (dtype == DICP_F32) { if (c == 6) DICP_GF(float, 6); else DICP_GF(float, 3); }
+    else                   { if (c == 6) DICP_GF(double, 6); else DICP_GF(double, 3); }
+#undef DICP_GF
+    return launch_status();
+}
+
+int dicp_gumbel_nn_bwd(int dtype, const void* x, const void* y, int c, const void* U, uint32_t seed, double eps, double tau,
+                       const void* out, const void* lse, const void* gout, int N, int n, int m, void* gx, void* gy, void* stream) {
+    if (!x || !y || !out || !lse || !gout || (!gx && !gy)) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0 || n <= 0 || m <= 0 || (c != 3 && c != 6) || !(tau > 0.0)) return DICP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    begin_launch();
+    const int bq = (n + BLOCK - 1) / BLOCK, bt = (m + BLOCK - 1) / BLOCK;
+#define DICP_GB(T, C) do { \
+        if (gx) gumbel_bwd_q_kernel<T, C><<<grid_for(N, bq), BLOCK, 0, st>>>((const T*)x, (const T*)y, (const T*)U, seed, (T)eps, (T)(1.0 / tau), (const T*)out, (const T*)lse, (const T*)gout, (T*)gx, N, n, m, bq); \
+        if (gy) gumbel_bwd_t_kernel<T, C><<<grid_for(N, bt), BLOCK, 0, st>>>((const T*)x, (const T*)y, (const T*)U, seed, (T)eps, (T)(1.0 / tau), (const T*)out, (const T*)lse, (const T*)gout, (T*)gy, N, n, m, bt); } while (0)
+    if (dtype == DICP_F32) { if (c == 6) DICP_GB(float, 6); else DICP_GB(float, 3); }
+    else                   { if (c == 6) DICP_GB(double, 6); else DICP_GB(double, 3); }
+#undef DICP_GB
     return launch_status();
 }
 

@@ -6,8 +6,9 @@ present, the normal).  The hard path (what ICP uses) runs the fused brute-force 
 libdicp_hip.so -- the (N,n,m) distance matrix of nn.py:32 is never materialised -- followed
 by a row gather whose backward is a scatter-add (the only gradient path: argmin has none,
 so ``x`` receives no gradient, exactly as in the reference).  The Gumbel-softmax path
-(nn.py:43-70) is served by PyTorch-ROCm ops on the HIP device in query chunks until its
-fused kernel lands.
+(nn.py:43-70) runs as fused flash-style kernels (dicp_gumbel_nn / _bwd): online softmax over
+LDS-tiled targets, noise generated in-kernel (or injected for parity tests), gradients to both
+``x`` and ``y`` by recomputation -- the (N,n,m) tensors of the reference never exist.
 """
 import torch
 
@@ -21,7 +22,6 @@ class nn:
         self.eps = eps
         self.tau = tau
         self.knn_variant = _lib.KNN_AUTO
-        self.gumbel_chunk = 4096        # queries per chunk of the soft path
 
     def find_nn(self, x, y, U=None):
         """x: (n,3) | (N,n,3) | (N,3,n) | (N,6,n>6);  y: (m,c) | (c,m) | (N,m,c) | (N,c,m), c in {3,6}
@@ -55,16 +55,11 @@ class nn:
     def _hard(self, x, y):
         return _ops.gather_rows(y, self._index(x, y))
 
-    # nn.py:43-70, chunked over queries so the (n,m) score block stays small
+    # nn.py:43-70 as fused kernels: online softmax over LDS-tiled targets, noise generated (or injected) in-kernel
     def _soft(self, x, y, U):
-        outs = []
-        for s in range(0, x.shape[1], self.gumbel_chunk):
-            xs = x[:, s:s + self.gumbel_chunk]
-            d2 = torch.sum((xs.unsqueeze(2) - y.unsqueeze(1)[:, :, :, :3]) ** 2, dim=3)
-            u = torch.rand(d2.shape, device=d2.device) if U is None else U[:, s:s + self.gumbel_chunk]
-            g = -torch.log(-torch.log(u + self.eps) + self.eps)
-            outs.append(torch.softmax((-d2 + g) / self.tau, dim=2) @ y)
-        return torch.cat(outs, dim=1)
+        if x.dtype != y.dtype:
+            raise TypeError("x and y must share a dtype, got %s and %s" % (x.dtype, y.dtype))
+        return _ops.gumbel_nn(x, y, self.eps, self.tau, U=U)
 
     @staticmethod
     def _handle_dimensions(x, y):

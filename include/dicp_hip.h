@@ -162,6 +162,17 @@ int dicp_accumulate_bwd_owned(int dtype, const dicp_weight_params* prm, const vo
                               const void* w_init, const void* alive, const void* gs, const void* gb,
                               int N, int n, int m, int m_pad, void* gsrc, void* gts, void* gw, void* bwd_partials, void* stream);
 
+/* Gumbel-softmax soft correspondence, nn.__diff_nn_gumbel (nn.py:43-70), without the (N,n,m) tensors:
+ *   out (N,n,c) = softmax_j((-|x_i - y_j|^2 + g_ij)/tau) @ y,  g = -log(-log(U + eps) + eps)   (nn.py:56-68)
+ *   x (N,n,3), y (N,m,c) with c in {3,6}; lse (N,n) = log-sum-exp of the logits (kept for the backward).
+ *   U (N,n,m) injects the uniform draw of nn.py:60; NULL = generated in-kernel from a counter hash of
+ *   (seed, cloud, i, j) -- the backward regenerates it from the same seed instead of storing it.
+ * Backward: gx (N,n,3) and/or gy (N,m,c) are WRITTEN (either may be NULL). */
+int dicp_gumbel_nn(int dtype, const void* x, const void* y, int c, const void* U, uint32_t seed, double eps, double tau,
+                   int N, int n, int m, void* out, void* lse, void* stream);
+int dicp_gumbel_nn_bwd(int dtype, const void* x, const void* y, int c, const void* U, uint32_t seed, double eps, double tau,
+                       const void* out, const void* lse, const void* gout, int N, int n, int m, void* gx, void* gy, void* stream);
+
 /* Closed-form point-to-point step (Kabsch / SVD), the solver of ICP.pt2pt_dICP_SVD (ICP.py:533-591): batched,
  * weighted, with the rotation composed as U diag(1,1,det U det V) V^T (the reference multiplies by V where V^T
  * is required, ICP.py:566-570 -- only correct for planar data).

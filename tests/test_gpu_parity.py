@@ -298,7 +298,6 @@ def test_nn_class(golden):
     # Gumbel path with the reference's uniform draw injected
     xs, ys = t(g["x"], torch.float32, grad=True), t(g["y"], torch.float32, grad=True)
     soft = nn(differentiable=True, use_gumbel=True, eps=1e-10, tau=0.1)
-    soft.gumbel_chunk = 32
     nb_soft = soft.find_nn(xs, ys, U=t(g["U"]))
     np.testing.assert_allclose(npy(nb_soft), g["nb_soft"], rtol=0, atol=2e-5)
     (nb_soft * t(g["cot"], torch.float32)).sum().backward()
@@ -775,3 +774,81 @@ def test_errors_on_device_inputs():
     icp.nn.use_gumbel = True
     with pytest.raises(NotImplementedError):
         icp.icp(src.to(DEV), tgt.to(DEV), torch.eye(4, device=DEV))
+
+
+# ------------------------------------------------------------- fused Gumbel-softmax soft kNN (a-15 / f-1)
+@pytest.mark.parametrize("dtype,c", [(torch.float32, 6), (torch.float32, 3), (torch.float64, 6)])
+def test_gumbel_kernels_vs_oracle_with_injected_noise(dtype, c):
+    g = torch.Generator().manual_seed(12)
+    N, n, m = 2, 300, 777                                   # several LDS tiles, ragged tails
+    x = torch.rand((N, n, 3), generator=g, dtype=torch.float64) * 3
+    y = torch.rand((N, m, c), generator=g, dtype=torch.float64) * 3
+    U = torch.rand((N, n, m), generator=g, dtype=torch.float64)
+    cot = torch.randn((N, n, c), generator=g, dtype=torch.float64)
+    xc, yc = x.to(dtype).clone().requires_grad_(True), y.to(dtype).clone().requires_grad_(True)
+    ref = O.nn_gumbel(xc, yc, 1e-10, 0.5, U=U.to(dtype))
+    (ref * cot.to(dtype)).sum().backward()
+    xd, yd = x.to(dtype).to(DEV).detach().requires_grad_(True), y.to(dtype).to(DEV).detach().requires_grad_(True)
+    soft = nn(differentiable=True, use_gumbel=True, eps=1e-10, tau=0.5)
+    out = soft.find_nn(xd, yd, U=U.to(dtype).to(DEV))
+    (out * cot.to(dtype).to(DEV)).sum().backward()
+    tol = dict(rtol=0, atol=1e-10) if dtype == torch.float64 else dict(rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(npy(out), ref.detach().numpy(), **tol)
+    gt = dict(rtol=0, atol=1e-9) if dtype == torch.float64 else dict(rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(npy(xd.grad), xc.grad.numpy(), **gt)
+    np.testing.assert_allclose(npy(yd.grad), yc.grad.numpy(), **gt)
+
+
+def test_gumbel_in_kernel_noise_is_seeded_uniform_and_consistent():
+    """U=None: the noise comes from the in-kernel counter hash.  Same torch seed -> same output; the backward
+    regenerates the same noise (finite-difference check); the sampled correspondence follows softmax(-d^2)."""
+    g = torch.Generator().manual_seed(2)
+    x = (torch.rand((1, 40, 3), generator=g, dtype=torch.float64)).to(DEV)
+    y = (torch.rand((1, 50, 6), generator=g, dtype=torch.float64)).to(DEV)
+    soft = nn(differentiable=True, use_gumbel=True, eps=1e-10, tau=0.3)
+    torch.manual_seed(7)
+    a = soft.find_nn(x, y)
+    torch.manual_seed(7)
+    b = soft.find_nn(x, y)
+    torch.manual_seed(8)
+    c2 = soft.find_nn(x, y)
+    assert torch.equal(a, b) and not torch.equal(a, c2)
+    # gradient w.r.t. x and y by central differences at a fixed seed
+    from dicp_amd._ops import gumbel_nn
+    xr, yr = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    w = torch.randn(a.shape, generator=torch.Generator().manual_seed(1), dtype=torch.float64).to(DEV)
+    (gumbel_nn(xr, yr, 1e-10, 0.3, seed=99) * w).sum().backward()
+    f = lambda xx, yy: float((gumbel_nn(xx, yy, 1e-10, 0.3, seed=99) * w).sum())
+    h = 1e-6
+    for (b_, i_, k_) in ((0, 3, 0), (0, 17, 2), (0, 39, 1)):
+        xp, xm = x.clone(), x.clone()
+        xp[b_, i_, k_] += h
+        xm[b_, i_, k_] -= h
+        assert abs((f(xp, y) - f(xm, y)) / (2 * h) - float(xr.grad[b_, i_, k_])) < 1e-5
+    for (b_, j_, k_) in ((0, 0, 0), (0, 21, 4), (0, 49, 2)):
+        yp, ym = y.clone(), y.clone()
+        yp[b_, j_, k_] += h
+        ym[b_, j_, k_] -= h
+        assert abs((f(x, yp) - f(x, ym)) / (2 * h) - float(yr.grad[b_, j_, k_])) < 1e-5
+    # distribution: as tau -> 0 the output is the row of argmax(-d^2 + g), a sample from softmax(-d^2)
+    q = torch.zeros((1, 1, 3), dtype=torch.float64, device=DEV)
+    t2 = torch.tensor([[[0.3, 0, 0], [1.0, 0, 0]]], dtype=torch.float64, device=DEV)
+    hard = nn(differentiable=True, use_gumbel=True, eps=1e-10, tau=1e-3)
+    torch.manual_seed(0)
+    picks = torch.cat([hard.find_nn(q, t2)[:, :, 0] for _ in range(400)]).flatten()
+    p_near = float((picks < 0.65).double().mean())
+    want = float(torch.softmax(torch.tensor([-0.09, -1.0]), 0)[0])                 # 0.713
+    assert abs(p_near - want) < 0.08
+
+
+def test_gumbel_at_benchmark_cloud_size_runs():
+    """16384-pt clouds: 2.7e8 noisy logits per cloud, never materialised."""
+    src, tgt = make_pairs(2, 16384, 16384, seed=3, dtype=torch.float32)
+    xd, yd = src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True)
+    torch.manual_seed(0)
+    out = nn(differentiable=True, use_gumbel=True, eps=1e-10, tau=0.1).find_nn(xd, yd)
+    out.sum().backward()
+    assert out.shape == (2, 16384, 6) and bool(torch.isfinite(out).all())
+    assert bool(torch.isfinite(xd.grad).all() and torch.isfinite(yd.grad).all())
+    # a convex combination of target rows: inside the targets' bounding box
+    assert float(out[:, :, :3].abs().max()) <= float(tgt[:, :, :3].abs().max()) + 1e-4

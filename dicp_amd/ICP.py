@@ -19,7 +19,7 @@ import torch
 import yaml
 
 from . import _lib
-from ._ops import ICPLoop, KabschLoop, LoopConfig, compute_device
+from ._ops import ICPLoop, KabschLoop, LoopConfig, compute_device, icp_loop_gumbel
 from .nn import nn
 
 
@@ -74,11 +74,6 @@ class ICP:
             target = target[:, :, :3]                                                    # ICP.py:105
         if loss_fn is not None and loss_fn['name'] not in ('huber', 'cauchy', 'trim'):
             raise ValueError("Invalid loss name: {}".format(loss_fn['name']))            # loss.py:19
-        if self.nn.differentiable and self.nn.use_gumbel:
-            raise NotImplementedError(
-                "dicp_amd: the Gumbel-softmax correspondence (config functionality.gumbel) is served by "
-                "dicp_amd.nn.find_nn but is not fused into the ICP loop yet (SURVEY.md 8f-1)")
-
         home = source.device
         dev = home if source.is_cuda else compute_device()
         source, target, T_init, w_pts = (t.to(dev) for t in (source, target, T_init, w_pts))
@@ -101,7 +96,12 @@ class ICP:
             match_ratio_thresh=float(self.match_ratio_thresh),
             knn_variant=self.knn_variant, bwd_owned=bool(self.bwd_owned), stats_out=self.knn_stats,
             timing_hook=self._timing_hook)
-        T, deltas, weights, costs, converged, iterations, matched = ICPLoop.apply(source, target, T_init, w_pts, cfg)
+        if self.nn.differentiable and self.nn.use_gumbel:                                # nn.py:14-16 via ICP.py:140
+            # soft correspondences carry gradient themselves: one autograd node per iteration instead of one per call
+            T, deltas, weights, costs, converged, iterations, matched = icp_loop_gumbel(
+                source, target, T_init, w_pts, cfg, self.nn.eps, self.nn.tau, inject_U=getattr(self.nn, "_inject_U", None))
+        else:
+            T, deltas, weights, costs, converged, iterations, matched = ICPLoop.apply(source, target, T_init, w_pts, cfg)
 
         if self.verbose:                                                                 # ICP.py:262-264
             print("ICP converged in {} iterations".format(deltas.shape[1]))

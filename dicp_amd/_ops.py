@@ -546,3 +546,118 @@ class KabschLoop(torch.autograd.Function):
             _lib.check(lib.dicp_kabsch_bwd(code, _p(src), _p(tgt), c, _p(idx), _p(pose_prev), _p(w0c), trim_on, trim, _p(gacc),
                                            N, n, m, _p(gsrc), _p(gtgt), _p(gw), st), "dicp_kabsch_bwd")
         return gsrc, gtgt, None, gw, None, None, None, None, None
+
+
+class _RowsIteration(torch.autograd.Function):
+    """One ICP iteration on explicit per-point neighbour rows (the soft correspondences of the Gumbel path):
+    dicp_accumulate (idx = NULL) -> dicp_step, with dicp_step_bwd -> dicp_accumulate_bwd as its backward.
+    Unlike ICPLoop this is ONE node per iteration, because the neighbours themselves carry gradient
+    (to the transformed source and to the target) through the soft-kNN node upstream.
+    Inputs : source (N,n,3), nbr (N,n,c), pose (N,12), w0 (N,n); `st` = per-call bookkeeping tensors.
+    Outputs: pose_next (N,12) [differentiable]; delta (N,6), cost (N), w (N,n) [not differentiable]."""
+
+    @staticmethod
+    def forward(ctx, source, nbr, pose, w0, st, cfg, k):
+        lib = _lib.load()
+        dev, dt = source.device, source.dtype
+        code = _DT[dt]
+        N, n, _ = source.shape
+        c = nbr.shape[2]
+        src, rows, pose_in, w0c = source.contiguous(), nbr.contiguous(), pose.contiguous(), w0.contiguous()
+        P = cfg.params()
+        nblk = lib.dicp_accumulate_blocks(n)
+        with torch.cuda.device(dev):
+            stream = _stream()
+            partials = torch.empty((N, nblk, _lib.NACC_PAD), dtype=dt, device=dev)
+            wk = torch.empty((N, n), dtype=dt, device=dev)
+            alive_k = st["alive"].clone()
+            _lib.check(lib.dicp_accumulate(code, ctypes.byref(P), _p(src), _p(rows), c, None, _p(pose_in), _p(w0c), _p(st["alive"]),
+                                           N, n, n, _p(partials), _p(wk), n, stream), "dicp_accumulate")
+            pose_out = torch.empty((N, 12), dtype=dt, device=dev)
+            delta = torch.empty((N, 6), dtype=dt, device=dev)
+            cost = torch.empty((N,), dtype=dt, device=dev)
+            areg = torch.empty((N, 36), dtype=torch.float64, device=dev)
+            io = _lib.StepIO(
+                partials=_p(partials), nblk=nblk, iter=k, dim=int(cfg.dim), const_iter=int(cfg.const_iter),
+                tolerance=float(cfg.tolerance), rows_per_point=3 if cfg.icp_type == "pt2pt" else 1, n=n,
+                pose_in=_p(pose_in), pose_out=_p(pose_out), delta=_p(delta), delta_stride=6,
+                cost=_p(cost), cost_prev=_p(st["cost_prev"]), cost_stride=1, areg=_p(areg), alive=_p(st["alive"]),
+                converged=_p(st["converged"]), iterations=_p(st["iterations"]), matched_ratio=_p(st["matched"]),
+                n_start=_p(st["n_start"]), n_matched=_p(st["n_matched"]), w_cur=_p(wk), w_prev=_p(st["w_prev"]), w_stride=n,
+                n_not_converged=ctypes.c_void_p(st["counters"].data_ptr() + 4 * k))
+            _lib.check(lib.dicp_step(code, ctypes.byref(io), N, stream), "dicp_step")
+        ctx.save_for_backward(src, rows, pose_in, w0c, alive_k, delta, areg)
+        ctx.cfg, ctx.P = cfg, P
+        ctx.mark_non_differentiable(delta, cost, wk)
+        return pose_out, delta, cost, wk
+
+    @staticmethod
+    def backward(ctx, gpose_out, *_unused):
+        src, rows, pose_in, w0c, alive_k, delta, areg = ctx.saved_tensors
+        cfg, P = ctx.cfg, ctx.P
+        lib = _lib.load()
+        dev, dt = src.device, src.dtype
+        code = _DT[dt]
+        N, n, _ = src.shape
+        c = rows.shape[2]
+        nblk = lib.dicp_accumulate_blocks(n)
+        with torch.cuda.device(dev):
+            stream = _stream()
+            gin = gpose_out.to(torch.float64).contiguous()
+            gs = torch.empty((N, 36), dtype=dt, device=dev)
+            gb = torch.empty((N, 6), dtype=dt, device=dev)
+            gpass = torch.empty((N, 12), dtype=torch.float64, device=dev)
+            _lib.check(lib.dicp_step_bwd(code, _p(gin), None, nblk, int(cfg.dim), _p(pose_in), _p(delta), 6, _p(areg),
+                                         _p(gs), _p(gb), _p(gpass), N, stream), "dicp_step_bwd")
+            gsrc = torch.zeros_like(src)
+            grows = torch.zeros_like(rows)
+            gw = torch.zeros_like(w0c)
+            bwdp = torch.empty((N, nblk, _lib.NBWD_PAD), dtype=dt, device=dev)
+            _lib.check(lib.dicp_accumulate_bwd(code, ctypes.byref(P), _p(src), _p(rows), c, None, _p(pose_in), _p(w0c), _p(alive_k),
+                                               _p(gs), _p(gb), N, n, n, _p(gsrc), _p(grows), _p(gw), _p(bwdp), stream), "dicp_accumulate_bwd")
+            gpose = (gpass + bwdp.sum(dim=1)[:, :12].to(torch.float64)).to(dt)
+        return gsrc, grows, gpose, gw, None, None, None
+
+
+def icp_loop_gumbel(source, target, T_init, w0, cfg, eps, tau, inject_U=None):
+    """ICP.dICP's loop (ICP.py:131-260) with the Gumbel-softmax correspondence (config functionality.gumbel):
+    per iteration  ps_t = C p + r  ->  dicp_gumbel_nn  ->  _RowsIteration.  Returns the same tuple as ICPLoop."""
+    for t, nm in ((source, "source"), (target, "target"), (T_init, "T_init"), (w0, "weight")):
+        require_device(t, "ICP(" + nm + ")")
+    dev, dt = source.device, source.dtype
+    N, n, _ = source.shape
+    rows = 3 if cfg.icp_type == "pt2pt" else 1
+    Kmax = int(cfg.max_iterations)
+    st = {
+        "alive": torch.ones((N,), dtype=dt, device=dev), "converged": torch.zeros((N,), dtype=torch.uint8, device=dev),
+        "iterations": torch.zeros((N,), dtype=dt, device=dev), "matched": torch.zeros((N,), dtype=dt, device=dev),
+        "n_matched": torch.zeros((N,), dtype=dt, device=dev),
+        "n_start": (torch.sum(w0.detach() > cfg.match_ratio_thresh, dim=1) * rows).to(dt),
+        "counters": torch.zeros((Kmax,), dtype=torch.int32, device=dev), "cost_prev": None, "w_prev": None,
+    }
+    pose = _pose_from_T(T_init)
+    deltas, costs, weights = [], [], []
+    K = 0
+    for k in range(Kmax):
+        C = pose[:, :9].reshape(N, 3, 3)
+        ps_t = source @ C.transpose(1, 2) + pose[:, None, 9:]                      # ICP.py:137
+        U = inject_U[k] if inject_U is not None else None
+        nbr = gumbel_nn(ps_t, target, eps, tau, U=U)                               # ICP.py:140 -> nn.py:43-70
+        pose, delta, cost, wk = _RowsIteration.apply(source, nbr, pose, w0, st, cfg, k)
+        st["cost_prev"], st["w_prev"] = cost, wk
+        deltas.append(delta)
+        costs.append(cost)
+        weights.append(wk)
+        K = k + 1
+        if not cfg.const_iter and int(st["counters"][k].item()) == 0:              # ICP.py:259
+            break
+    iterations = torch.where(st["iterations"] == 0, torch.full_like(st["iterations"], K), st["iterations"])
+    start = (st["n_start"] * (st["alive"] != 0)).to(torch.int64)
+    start[start == 0] = 1
+    ratio = st["n_matched"].to(torch.int64) / start
+    matched = torch.where(st["matched"] == 0, ratio.to(dt), st["matched"])
+    T = torch.zeros((N, 4, 4), dtype=dt, device=dev)
+    T[:, 3, 3] = 1.0
+    T = T + torch.nn.functional.pad(torch.cat((pose[:, :9].reshape(N, 3, 3), pose[:, 9:, None]), dim=2), (0, 0, 0, 1))
+    return (T, torch.stack(deltas, dim=1), torch.stack(weights, dim=1), torch.stack(costs, dim=1),
+            st["converged"].bool(), iterations, matched)

@@ -582,7 +582,7 @@ __global__ __launch_bounds__(BLOCK) void accumulate_kernel(WeightParams P, const
         const size_t pt = (size_t)cloud * n + i;
         const T* sp = src + pt * 3;
         const T p[3] = {sp[0], sp[1], sp[2]};
-        const int j = min(max(idx[pt], 0), m - 1);
+        const int j = idx ? min(max(idx[pt], 0), m - 1) : i;     // idx == NULL: tgt holds one row per source point
         const T* yp = tgt + ((size_t)cloud * m + j) * c;
         const T y[3] = {yp[0], yp[1], yp[2]};
         T nrm[3] = {T(0), T(0), T(0)};
@@ -705,7 +705,7 @@ __global__ __launch_bounds__(BLOCK) void accumulate_bwd_kernel(WeightParams P, c
             const size_t pt = (size_t)cloud * n + i;
             const T* sp = src + pt * 3;
             const T p[3] = {sp[0], sp[1], sp[2]};
-            j = min(max(idx[pt], 0), m - 1);
+            j = idx ? min(max(idx[pt], 0), m - 1) : i;
             const T* yp = tgt + ((size_t)cloud * m + j) * c;
             const T y[3] = {yp[0], yp[1], yp[2]};
             T nrm[3] = {T(0), T(0), T(0)};
@@ -1055,7 +1055,7 @@ __global__ __launch_bounds__(BLOCK) void kabsch_accumulate_kernel(const T* __res
         const size_t pt = (size_t)cloud * n + i;
         const T* sp = src + pt * 3;
         const T p[3] = {sp[0], sp[1], sp[2]};
-        const int j = min(max(idx[pt], 0), m - 1);
+        const int j = idx ? min(max(idx[pt], 0), m - 1) : i;     // idx == NULL: tgt holds one row per source point
         const T* yp = tgt + ((size_t)cloud * m + j) * c;
         const T y[3] = {yp[0], yp[1], yp[2]};
         const T w = kabsch_weight(C, r, p, y, w_init[pt], trim_on, trim_dist);
@@ -1126,7 +1126,7 @@ __global__ __launch_bounds__(BLOCK) void kabsch_bwd_kernel(const T* __restrict__
         const size_t pt = (size_t)cloud * n + i;
         const T* sp = src + pt * 3;
         const T p[3] = {sp[0], sp[1], sp[2]};
-        const int j = min(max(idx[pt], 0), m - 1);
+        const int j = idx ? min(max(idx[pt], 0), m - 1) : i;     // idx == NULL: tgt holds one row per source point
         const size_t row = ((size_t)cloud * m + j) * c;
         const T y[3] = {tgt[row], tgt[row + 1], tgt[row + 2]};
         const T w0 = w_init[pt];
@@ -1384,9 +1384,9 @@ int dicp_accumulate(int dtype, const dicp_weight_params* prm, const void* src, c
                     const int32_t* idx, const void* pose, const void* w_init, const void* alive,
                     int N, int n, int m, void* partials, void* w_out, int64_t w_stride, void* stream) {
     if (const int e = check_params(prm, c)) return e;
-    if (!src || !tgt || !idx || !w_init || !partials) return DICP_ERR_NULL;
+    if (!src || !tgt || !w_init || !partials) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
-    if (N <= 0 || n <= 0 || m <= 0 || (w_out && w_stride < n)) return DICP_ERR_SHAPE;
+    if (N <= 0 || n <= 0 || m <= 0 || (w_out && w_stride < n) || (!idx && m != n)) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     begin_launch();
     const WeightParams P = to_params(prm);
@@ -1435,9 +1435,9 @@ int dicp_accumulate_bwd(int dtype, const dicp_weight_params* prm, const void* sr
                         const void* gs, const void* gb, int N, int n, int m,
                         void* gsrc, void* gtgt, void* gw, void* bwd_partials, void* stream) {
     if (const int e = check_params(prm, c)) return e;
-    if (!src || !tgt || !idx || !w_init || !gs || !gb || !gsrc || !bwd_partials) return DICP_ERR_NULL;
+    if (!src || !tgt || !w_init || !gs || !gb || !gsrc || !bwd_partials) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
-    if (N <= 0 || n <= 0 || m <= 0) return DICP_ERR_SHAPE;
+    if (N <= 0 || n <= 0 || m <= 0 || (!idx && m != n)) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     begin_launch();
     const WeightParams P = to_params(prm);

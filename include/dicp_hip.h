@@ -92,7 +92,8 @@ int dicp_scatter_add_rows(int dtype, const void* gout, const int32_t* idx, int N
  * (loss.py:21-58 via ICP.py:152-160), weight combine (ICP.py:162-169,194-196), Jacobian
  * rows (ICP.py:171-183) and the normal-equation sums A = J_w^T J_w, b = J_w^T e_w
  * (ICP.py:198-201) plus cost (ICP.py:229), sum(w) and #(w > thresh) (ICP.py:225,247).
- *   tgt (N,m,c) with c = 6 for pt2pl (normals in 3:6), 3 or 6 for pt2pt;
+ *   tgt (N,m,c) with c = 6 for pt2pl (normals in 3:6), 3 or 6 for pt2pt; idx == NULL (then m must equal n)
+ *   means tgt already holds ONE ROW PER SOURCE POINT -- the soft neighbours of dicp_gumbel_nn;
  *   w_init (N,n); alive (N) multiplies w_init (the zeroing of ICP.py:256-257), may be NULL;
  *   partials (N, nblk, DICP_NACC_PAD) with nblk = dicp_accumulate_blocks(n);
  *   w_out: cloud b's n weights are written at w_out + b*w_stride (elements); may be NULL. */

@@ -771,9 +771,6 @@ def test_errors_on_device_inputs():
         icp.icp(src.to(DEV), tgt.to(DEV), torch.eye(4, device=DEV), loss_fn={"name": "tukey", "metric": 1.0})   # loss.py:19
     with pytest.raises(TypeError):
         icp.icp(src.half().to(DEV), tgt.half().to(DEV), torch.eye(4, device=DEV).half())
-    icp.nn.use_gumbel = True
-    with pytest.raises(NotImplementedError):
-        icp.icp(src.to(DEV), tgt.to(DEV), torch.eye(4, device=DEV))
 
 
 # ------------------------------------------------------------- fused Gumbel-softmax soft kNN (a-15 / f-1)
@@ -852,3 +849,44 @@ def test_gumbel_at_benchmark_cloud_size_runs():
     assert bool(torch.isfinite(xd.grad).all() and torch.isfinite(yd.grad).all())
     # a convex combination of target rows: inside the targets' bounding box
     assert float(out[:, :, :3].abs().max()) <= float(tgt[:, :, :3].abs().max()) + 1e-4
+
+
+@pytest.mark.parametrize("icp_type", ["pt2pl", "pt2pt"])
+def test_icp_with_gumbel_correspondence_vs_oracle(icp_type, monkeypatch):
+    """config functionality.gumbel = True (ICP.py:40-44): the loop runs on soft neighbours.  The oracle draws its
+    noise with torch.rand (nn.py:60); both sides are fed the same pre-drawn U_k."""
+    N, n, m, K = 2, 120, 150, 3
+    src, tgt = make_pairs(N, n, m, seed=50, dtype=torch.float64, max_rot=0.03, max_trans=0.1)
+    tg = tgt if icp_type == "pt2pl" else tgt[:, :, :3].contiguous()
+    g = torch.Generator().manual_seed(3)
+    Us = [torch.rand((N, n, m), generator=g, dtype=torch.float32) for _ in range(K)]
+    w = torch.rand((N, n), generator=g, dtype=torch.float64) + 0.5
+    kw = dict(trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0}, dim=3)
+    # oracle with injected draws
+    draws = iter(Us)
+    monkeypatch.setattr(torch, "rand", lambda *a, **k: next(draws))
+    sc, tc, wc = src.clone().requires_grad_(True), tg.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    T0c = torch.eye(4, dtype=torch.float64).repeat(N, 1, 1).requires_grad_(True)
+    rows = 3 if icp_type == "pt2pt" else 1
+    ref = O.icp_batched(sc, tc, T0c, wc.repeat_interleave(rows, dim=1), icp_type=icp_type, differentiable=True, max_iterations=K,
+                        tolerance=1e-14, const_iter=True, use_gumbel=True, gumbel_eps=1e-10, gumbel_tau=0.1, **kw)
+    monkeypatch.undo()
+    gT = torch.randn((N, 4, 4), generator=g, dtype=torch.float64)
+    (ref["T"] * gT).sum().backward()
+    # HIP path
+    icp = ICP(icp_type=icp_type, differentiable=True, max_iterations=K, tolerance=1e-14)
+    icp.const_iter = True
+    icp.nn.use_gumbel, icp.nn.eps, icp.nn.tau = True, 1e-10, 0.1
+    icp.nn._inject_U = [u.double().to(DEV) for u in Us]
+    sd, td, wd = src.to(DEV).requires_grad_(True), tg.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    T0d = torch.eye(4, dtype=torch.float64, device=DEV).repeat(N, 1, 1).requires_grad_(True)
+    out = icp.icp(sd, td, T0d, weight=wd, **kw)
+    (out["T"] * gT.to(DEV)).sum().backward()
+    # noise is float32 in the reference (torch.rand default dtype) and float64 here: agreement to ~1e-6
+    np.testing.assert_allclose(npy(out["T"]), npy(ref["T"]), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(npy(out["deltas"]), npy(ref["deltas"]), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(npy(out["weights"]), npy(ref["weights"]), rtol=0, atol=1e-5)
+    assert out["weights"].shape == ref["weights"].shape and out["costs"].shape == ref["costs"].shape
+    for a, b in ((sd, sc), (td, tc), (wd, wc), (T0d, T0c)):
+        scale = max(1.0, float(b.grad.abs().max()))
+        np.testing.assert_allclose(npy(a.grad), npy(b.grad), rtol=0, atol=2e-5 * scale)

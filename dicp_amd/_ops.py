@@ -14,6 +14,14 @@ from . import _lib
 
 _DT = {torch.float32: _lib.F32, torch.float64: _lib.F64}
 SWEEP_MIN_TARGETS = 2048     # KNN_AUTO inside ICP: below this the brute-force kernel is used
+SWEEP_MIN_PAIRS = 4e9        # ... and below this many (query,target) pairs per iteration: the per-call sorts of the
+                             # sweep cost ~0.6 ms, brute force scores ~1.4e13 pairs/s (profiles/r01_config_sweep.txt)
+
+
+def auto_knn_kind(N, n, m):
+    """KNN_AUTO: exact slab-pruned search once the clouds are big enough to repay its per-call sorts."""
+    big = m >= SWEEP_MIN_TARGETS and n >= 64 and float(N) * n * m >= SWEEP_MIN_PAIRS
+    return _lib.KNN_SWEEP if big else _lib.KNN_VALU
 _LOSS = {None: _lib.LOSS_NONE, "huber": _lib.LOSS_HUBER, "cauchy": _lib.LOSS_CAUCHY, "trim": _lib.LOSS_TRIM}
 
 
@@ -294,8 +302,8 @@ class ICPLoop(torch.autograd.Function):
             st = _stream()
             sweep = None
             kind = cfg.knn_variant & 0xff
-            if kind == _lib.KNN_AUTO:       # exact slab-pruned search once the clouds are big enough to repay the sort
-                kind = _lib.KNN_SWEEP if (m >= SWEEP_MIN_TARGETS and n >= 64) else _lib.KNN_VALU
+            if kind == _lib.KNN_AUTO:
+                kind = auto_knn_kind(N, n, m)
             if kind == _lib.KNN_SWEEP:
                 sweep = SweepIndex(tgt)
                 tgt4, qorder = sweep.tgs4, None
@@ -481,7 +489,7 @@ class KabschLoop(torch.autograd.Function):
             st = _stream()
             kind = knn_variant & 0xff
             if kind == _lib.KNN_AUTO:
-                kind = _lib.KNN_SWEEP if (m >= SWEEP_MIN_TARGETS and n >= 64) else _lib.KNN_VALU
+                kind = auto_knn_kind(N, n, m)
             sweep = SweepIndex(tgt) if kind == _lib.KNN_SWEEP else None
             tgt4 = sweep.tgs4 if sweep is not None else pack_target(tgt)
             nblk = lib.dicp_accumulate_blocks(n)

@@ -203,12 +203,9 @@ class ICP:
                     w_i = weight[i] * w_i
                 pts.append(s_i[:, :3])
                 pri.append(w_i)
-            n_max = max(p.shape[0] for p in pts)
-            source_b = torch.zeros((len(pts), n_max, 3), **opts)
-            w = torch.zeros((len(pts), n_max), **opts)
-            for i, (p_i, w_i) in enumerate(zip(pts, pri)):
-                source_b[i, :p_i.shape[0]] = p_i
-                w[i, :w_i.shape[0]] = w_i
+            # one padded copy for the whole list (the reference grows the batch item by item: O(N^2) copies)
+            source_b = torch.nn.utils.rnn.pad_sequence(pts, batch_first=True).to(**opts)
+            w = torch.nn.utils.rnn.pad_sequence(pri, batch_first=True).to(**opts)
         elif source.dim() == 2 and source.shape[1] in (3, 6):
             source_b = source[:, :3].unsqueeze(0)
             w = torch.ones((1, source_b.shape[1]), **opts) if weight is None else weight.unsqueeze(0)
@@ -233,10 +230,10 @@ class ICP:
                 if i > 0 and (t_i.dim() != 2 or t_i.shape[1] != cols):
                     raise ValueError("target list must contain (m x 3/6) tensors. All tensors must have same number of columns")
                 rows.append(t_i)
-            m_max = max(r_i.shape[0] for r_i in rows)
-            target_b = pad * torch.ones((len(rows), m_max, rows[0].shape[1]), **opts)
-            for i, r_i in enumerate(rows):
-                target_b[i, :r_i.shape[0]] = r_i
+            lens = torch.tensor([r_i.shape[0] for r_i in rows], device=dev)
+            target_b = torch.nn.utils.rnn.pad_sequence(rows, batch_first=True).to(**opts)
+            real = (torch.arange(target_b.shape[1], device=dev)[None, :] < lens[:, None]).unsqueeze(-1)
+            target_b = torch.where(real, target_b, pad * torch.ones((), **opts))
             if dead:
                 live = torch.ones((w.shape[0], 1), **opts)
                 live[dead] = 0.0

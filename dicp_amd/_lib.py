@@ -78,7 +78,9 @@ def build(force=False, verbose=False):
             and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(p) for p in deps)):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC",
+    # -amdgpu-mfma-vgpr-form: let the f32 MFMA of the kNN variant write VGPRs directly (no v_accvgpr_read per
+    # result): 6.1 -> 5.5 ms on that kernel (profiles/r01_knn_variants_ab.txt); no effect on the other kernels
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form",
            "-Wall", "-Wno-unused-function", "-I", os.path.join(_ROOT, "include"),
            "-o", LIB_PATH + ".tmp"] + SOURCES
     if verbose:

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(BLOCK) void knn_mfma_kernel(const float* __restrict
 // target can never beat the kept minimum; exact score ties (duplicates) are detected and resolved to the
 // lowest ORIGINAL index by a rare re-scan of the visited range.
 template <typename T> struct SweepEps;
-template <> struct SweepEps<float>  { static constexpr float  v = 1e-4f; };
+template <> struct SweepEps<float>  { static constexpr float  v = 1e-5f; };   // ~10x the worst-case rounding of two f32 scores
 template <> struct SweepEps<double> { static constexpr double v = 1e-10; };
 
 template <typename T, int Q, int CH>

@@ -25,12 +25,12 @@ def shard(items, rank=None, world=None):
     return items[lo:hi]
 
 
-def gather_poses(T_local, total=None, group=None):
+def gather_poses(T_local, total=None, group=None, force=False):
     """All-gather per-shard poses (B_local,4,4) -> (B_total,4,4), in cloud order, on every rank.
     Shards may differ in size by one (shard_bounds): they are padded to the largest for the
     collective and trimmed afterwards.  The result is detached (poses are gathered for the
     consumer's loss/logging; gradients w.r.t. source/target stay shard-local)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return T_local.detach()
     world = dist.get_world_size(group)
     sizes = torch.tensor([T_local.shape[0]], dtype=torch.int64, device=T_local.device)

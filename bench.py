@@ -38,22 +38,27 @@ TRIM = 5.0
 
 
 class EventLog:
-    """HIP events dropped around named kernels on the stream they are launched on."""
+    """HIP events around the kNN launch (forward) and the accumulate_bwd launch (backward) of every iteration.
+    The loop runs inside libdicp_hip.so (dicp_icp_forward / _backward), so the library records them: it is handed
+    the raw hipEvent_t handles of these torch events (same HIP runtime) -- on the stream the kernels run on."""
 
     def __init__(self):
-        self.open, self.pairs = {}, {}
+        self.K, self.ev, self.arr = 0, None, None
 
-    def __call__(self, name, phase):
-        ev = torch.cuda.Event(enable_timing=True)
-        ev.record(torch.cuda.current_stream())
-        if phase == 0:
-            self.open[name] = ev
-        else:
-            self.pairs.setdefault(name, []).append((self.open.pop(name), ev))
+    def handles(self, K):
+        import ctypes
+        if self.K != K:
+            self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(4 * K)]
+            for e in self.ev:
+                e.record()                       # materialises the underlying hipEvent_t
+            self.arr = (ctypes.c_void_p * (4 * K))(*[e.cuda_event for e in self.ev])
+            self.K = K
+        return ctypes.cast(self.arr, ctypes.c_void_p)
 
     def mean_ms(self, name):
-        p = self.pairs.get(name, [])
-        return sum(a.elapsed_time(b) for a, b in p) / len(p) if p else None
+        off = 0 if name == "knn" else 2
+        ts = [self.ev[4 * k + off].elapsed_time(self.ev[4 * k + off + 1]) for k in range(self.K)]
+        return sum(ts) / len(ts) if ts else None
 
 
 def pmc_traffic(kernel_prefix, B, n):
@@ -158,7 +163,7 @@ def main():
     # K-sized history / saved-index buffers (the first use of a new size is a synchronous hipMalloc)
     run_call(icp, src, tgt, T0, cw)
     log = EventLog()
-    icp._timing_hook = log
+    icp._timing_events = log
 
     def fence():
         torch.cuda.synchronize()

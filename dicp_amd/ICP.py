@@ -48,7 +48,8 @@ class ICP:
         self.knn_variant = _lib.KNN_AUTO      # _lib.KNN_VALU | KNN_MFMA (brute force) | KNN_SWEEP (exact, slab-pruned)
         self.knn_stats = {}                   # "knn_pairs": pairs scored by the last call's sweep kNN
         self.bwd_owned = os.environ.get("DICP_BWD_OWNED", "0") == "1"   # atomics-free backward (measured slower: opt-in)
-        self._timing_hook = None
+        self.sync_every = 1                   # tolerance mode: iterations enqueued between two all-converged checks (ICP.py:259)
+        self._timing_events = None
 
     def icp(self, source, target, T_init, weight=None, trim_dist=None, loss_fn=None, dim=3):
         return self.dICP(source, target, T_init, weight, trim_dist, loss_fn, dim)      # ICP.py:46-47
@@ -95,7 +96,7 @@ class ICP:
             tanh_steepness=float(self.config['dICP']['parameters']['tanh_steepness']),   # ICP.py:119
             match_ratio_thresh=float(self.match_ratio_thresh),
             knn_variant=self.knn_variant, bwd_owned=bool(self.bwd_owned), stats_out=self.knn_stats,
-            timing_hook=self._timing_hook)
+            sync_every=int(self.sync_every), timing_events=self._timing_events)
         if self.nn.differentiable and self.nn.use_gumbel:                                # nn.py:14-16 via ICP.py:140
             # soft correspondences carry gradient themselves: one autograd node per iteration instead of one per call
             T, deltas, weights, costs, converged, iterations, matched = icp_loop_gumbel(

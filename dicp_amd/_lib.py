@@ -35,9 +35,18 @@ class StepIO(ctypes.Structure):
     _fields_ = [("partials", vp), ("nblk", i32), ("iter", i32), ("dim", i32), ("const_iter", i32),
                 ("tolerance", f64), ("rows_per_point", i32), ("n", i32),
                 ("pose_in", vp), ("pose_out", vp), ("delta", vp), ("delta_stride", i64),
-                ("cost", vp), ("cost_prev", vp), ("cost_stride", i64), ("areg", vp), ("alive", vp),
+                ("cost", vp), ("cost_prev", vp), ("cost_stride", i64), ("areg", vp), ("alive", vp), ("alive_out", vp),
                 ("converged", vp), ("iterations", vp), ("matched_ratio", vp), ("n_start", vp),
                 ("n_matched", vp), ("w_cur", vp), ("w_prev", vp), ("w_stride", i64), ("n_not_converged", vp)]
+
+
+class LoopBuffers(ctypes.Structure):
+    """dicp_loop_buffers (include/dicp_hip.h)."""
+    _fields_ = [("src", vp), ("tgt", vp), ("w_init", vp), ("c", i32), ("K", i32), ("knn_variant", i32), ("m_pad", i32),
+                ("tgt4", vp), ("tperm", vp), ("qorder", vp), ("bucket", vp), ("brange", vp), ("nbkt", i32), ("idx_per_iter", i32),
+                ("pairs", vp), ("spos", vp), ("poses", vp), ("deltas", vp), ("costs", vp), ("areg", vp), ("alive", vp), ("converged", vp),
+                ("iterations", vp), ("matched_ratio", vp), ("n_start", vp), ("n_matched", vp), ("idx", vp), ("w", vp), ("w_prev0", vp),
+                ("partials", vp), ("counters", vp), ("events", vp)]
 
 
 _SIGNATURES = {
@@ -53,6 +62,8 @@ _SIGNATURES = {
     "dicp_scatter_add_rows": ([i32, vp, vp, i32, i32, i32, i32, vp, vp], ctypes.c_int),
     "dicp_accumulate": ([i32, ctypes.POINTER(WeightParams), vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp, i64, vp], ctypes.c_int),
     "dicp_step": ([i32, ctypes.POINTER(StepIO), i32, vp], ctypes.c_int),
+    "dicp_icp_forward": ([i32, ctypes.POINTER(WeightParams), ctypes.POINTER(LoopBuffers), i32, i32, i32, i32, i32, f64, i32, i32, vp], ctypes.c_int),
+    "dicp_icp_backward": ([i32, ctypes.POINTER(WeightParams), ctypes.POINTER(LoopBuffers), i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp], ctypes.c_int),
     "dicp_step_bwd": ([i32, vp, vp, i32, i32, vp, vp, i64, vp, vp, vp, vp, i32, vp], ctypes.c_int),
     "dicp_accumulate_bwd": ([i32, ctypes.POINTER(WeightParams), vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp], ctypes.c_int),
     "dicp_gumbel_nn": ([i32, vp, vp, i32, vp, ctypes.c_uint32, f64, f64, i32, i32, i32, vp, vp, vp], ctypes.c_int),

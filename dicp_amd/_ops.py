@@ -250,7 +250,8 @@ class LoopConfig:
     # atomic kernel on MI355X (0.41 vs 0.28 ms at B=256 x 16384), so it is opt-in: DICP_BWD_OWNED=1
     bwd_owned: bool = False
     stats_out: object = None      # optional dict: receives "knn_pairs" (pairs scored by the sweep kNN)
-    timing_hook: object = None    # optional callable(name, phase) used by bench.py to drop HIP events
+    sync_every: int = 1           # tolerance mode: iterations between the host's all-converged checks (ICP.py:259)
+    timing_events: object = None  # optional object with .handles(K) -> ctypes array of 4*K hipEvent_t (bench.py)
 
     def params(self):
         return _lib.WeightParams(
@@ -269,12 +270,24 @@ def _pose_from_T(T):
     return torch.cat((T[:, :3, :3].reshape(N, 9), T[:, :3, 3]), dim=1).contiguous()
 
 
+HIST_CHUNK_BYTES = 1 << 29      # per-iteration histories (indices, weights) are allocated in slabs of at most this size
+
+
+def _segments(Kmax, extra_cuts):
+    cuts = sorted(set([0, Kmax] + [c for c in extra_cuts if 0 < c < Kmax]))
+    return list(zip(cuts[:-1], cuts[1:]))
+
+
 class ICPLoop(torch.autograd.Function):
     """The whole iteration loop of ICP.dICP (ICP.py:131-260) as ONE autograd node.
 
-    forward : K x { dicp_knn -> dicp_accumulate -> dicp_step }, no torch arithmetic between
-    backward: K x { dicp_step_bwd -> dicp_accumulate_bwd } in reverse, recomputing per-point
-              quantities from the saved (idx, pose) instead of keeping autograd's intermediates.
+    forward : dicp_icp_forward enqueues K x { kNN -> accumulate -> step } back to back (no host work between
+              iterations); it is called once per segment, segments being cut only where the host must act: a new
+              history slab, a re-sort of the sweep's query order, or the reference's all-converged check (ICP.py:259,
+              every `sync_every` iterations; converged clouds are frozen, so running a few extra iterations and
+              trimming the histories afterwards gives the identical result).
+    backward: dicp_icp_backward, K x { step_bwd -> accumulate_bwd } in reverse, recomputing per-point quantities
+              from the saved (index, pose) histories instead of keeping autograd's intermediates.
     Inputs : source (N,n,3), target (N,m,c), T_init (N,4,4), w0 (N,n)  [one weight per POINT]
     Outputs: T (N,4,4) differentiable; deltas (N,K,6), weights (N,K,n), costs (N,K),
              converged (N) bool, iterations (N), matched_ratio (N)  (non-differentiable).
@@ -286,97 +299,101 @@ class ICPLoop(torch.autograd.Function):
             require_device(t, "ICP(" + nm + ")")
         lib = _lib.load()
         dev, dt = source.device, source.dtype
-        code = _DT[dt]
+        code, es = _DT[dt], source.element_size()
         N, n, _ = source.shape
         m, c = target.shape[1], target.shape[2]
-        src = source.contiguous()
-        tgt = target.contiguous()
-        w0c = w0.contiguous()
+        src, tgt, w0c = source.contiguous(), target.contiguous(), w0.contiguous()
         P = cfg.params()
         rows = 3 if cfg.icp_type == "pt2pt" else 1
         Kmax = int(cfg.max_iterations)
+        assert Kmax >= 1, "max_iterations must be at least 1"
         need_grad = any(ctx.needs_input_grad[:4])
-        hook = cfg.timing_hook
 
         with torch.cuda.device(dev):
             st = _stream()
-            sweep = None
             kind = cfg.knn_variant & 0xff
             if kind == _lib.KNN_AUTO:
                 kind = auto_knn_kind(N, n, m)
-            if kind == _lib.KNN_SWEEP:
-                sweep = SweepIndex(tgt)
-                tgt4, qorder = sweep.tgs4, None
-            else:
-                tgt4 = pack_target(tgt)
+            sweep = SweepIndex(tgt) if kind == _lib.KNN_SWEEP else None
+            owned = sweep is not None and need_grad and cfg.bwd_owned
+            tgt4 = sweep.tgs4 if sweep is not None else pack_target(tgt)
             m_pad = tgt4.shape[1]
             nblk = lib.dicp_accumulate_blocks(n)
             poses = torch.empty((Kmax + 1, N, 12), dtype=dt, device=dev)
             poses[0] = _pose_from_T(T_init)
+            alive = torch.empty((Kmax + 1, N), dtype=dt, device=dev)
+            alive[0] = 1.0
             deltas = torch.zeros((N, Kmax, 6), dtype=dt, device=dev)
             costs = torch.zeros((N, Kmax), dtype=dt, device=dev)
-            partials = torch.empty((N, nblk, _lib.NACC_PAD), dtype=dt, device=dev)
-            areg = torch.empty((Kmax, N, 36), dtype=torch.float64, device=dev)
-            alive = torch.ones((N,), dtype=dt, device=dev)
-            alive_hist = torch.empty((Kmax, N), dtype=dt, device=dev)
+            areg = torch.empty((Kmax, N, 36), dtype=torch.float64, device=dev) if need_grad else None
             converged = torch.zeros((N,), dtype=torch.uint8, device=dev)
             iterations = torch.zeros((N,), dtype=dt, device=dev)
             matched = torch.zeros((N,), dtype=dt, device=dev)
             n_matched = torch.zeros((N,), dtype=dt, device=dev)
             n_start = (torch.sum(w0c > cfg.match_ratio_thresh, dim=1) * rows).to(dt)
+            partials = torch.empty((N, nblk, _lib.NACC_PAD), dtype=dt, device=dev)
             counters = torch.zeros((Kmax,), dtype=torch.int32, device=dev)
-            w_hist, idx_hist = [], []
-            qorders, qorder_of = [], []      # distinct query orders used by the sweep, and which one iteration k used
+            idx_once = None if need_grad else torch.empty((N, n), dtype=torch.int32, device=dev)
 
-            K = 0
-            for k in range(Kmax):
-                idx = torch.empty((N, n), dtype=torch.int32, device=dev)
-                if hook:
-                    hook("knn", 0)
-                if sweep is not None:
-                    if k in cfg.sweep_resort or qorder is None:   # queries re-sorted by x under the current pose
-                        qorder = sweep.query_order(src, poses[k])
-                        qorders.append(qorder)
-                    qorder_of.append(len(qorders) - 1)
-                    # with gradients on, the kernel also lists every match by SORTED target position: that is what
-                    # the owner-computes backward scans (it replaces the saved index tensor)
-                    saved_k = torch.empty((N, n), dtype=torch.int32, device=dev) if (need_grad and cfg.bwd_owned) else None
-                    sweep.knn(src, poses[k], qorder, out=idx, cfg=(cfg.knn_variant >> 8) & 0xff, spos=saved_k)
-                    if saved_k is None:
-                        saved_k = idx
-                else:
-                    saved_k = idx
-                    _lib.check(lib.dicp_knn(code, _p(src), _p(poses[k]), _p(tgt4), N, n, m, m_pad, _p(idx),
-                                            kind | (cfg.knn_variant & 0xff00), st), "dicp_knn")
-                if hook:
-                    hook("knn", 1)
-                wk = torch.empty((N, n), dtype=dt, device=dev)
-                alive_hist[k].copy_(alive)
-                _lib.check(lib.dicp_accumulate(code, ctypes.byref(P), _p(src), _p(tgt), c, _p(idx), _p(poses[k]), _p(w0c), _p(alive),
-                                               N, n, m, _p(partials), _p(wk), n, st), "dicp_accumulate")
-                io = _lib.StepIO(
-                    partials=_p(partials), nblk=nblk, iter=k, dim=int(cfg.dim), const_iter=int(cfg.const_iter),
-                    tolerance=float(cfg.tolerance), rows_per_point=rows, n=n,
-                    pose_in=_p(poses[k]), pose_out=_p(poses[k + 1]),
-                    delta=ctypes.c_void_p(deltas.data_ptr() + k * 6 * deltas.element_size()), delta_stride=Kmax * 6,
-                    cost=ctypes.c_void_p(costs.data_ptr() + k * costs.element_size()),
-                    cost_prev=ctypes.c_void_p(costs.data_ptr() + (k - 1) * costs.element_size()) if k > 0 else None,
-                    cost_stride=Kmax, areg=_p(areg[k]), alive=_p(alive), converged=_p(converged),
+            # histories in slabs of kc iterations: slab j covers iterations [j*kc, (j+1)*kc)
+            per_iter = N * n * max(es, 4)
+            kc = max(1, min(Kmax, HIST_CHUNK_BYTES // max(1, per_iter)))
+            w_slabs, idx_slabs, spos_slabs = [], [], []
+            cuts = list(range(0, Kmax, kc))
+            if sweep is not None:
+                cuts += list(cfg.sweep_resort)
+            if not cfg.const_iter:
+                cuts += list(range(0, Kmax, max(1, int(cfg.sync_every))))
+            ev = cfg.timing_events
+            events = ev.handles(Kmax) if ev is not None else None
+
+            qorders, seg_q = [], []          # distinct query orders of the sweep and which one each segment used
+            qorder = None
+            K = Kmax
+            segs = _segments(Kmax, cuts)
+            done_segs = []
+            for (k0, k1) in segs:
+                j = k0 // kc
+                if j == len(w_slabs):
+                    kk = min(kc, Kmax - j * kc)
+                    w_slabs.append(torch.empty((kk, N, n), dtype=dt, device=dev))
+                    if need_grad:
+                        idx_slabs.append(torch.empty((kk, N, n), dtype=torch.int32, device=dev))
+                    if owned:
+                        spos_slabs.append(torch.empty((kk, N, n), dtype=torch.int32, device=dev))
+                if sweep is not None and (qorder is None or k0 in cfg.sweep_resort):
+                    qorder = sweep.query_order(src, poses[k0])       # queries re-sorted by x under the current pose
+                    qorders.append(qorder)
+                seg_q.append(len(qorders) - 1)
+                base = j * kc                                         # virtual bases: slab pointer minus its first iteration
+                LB = _lib.LoopBuffers(
+                    src=_p(src), tgt=_p(tgt), w_init=_p(w0c), c=c, K=Kmax, knn_variant=kind | (cfg.knn_variant & 0xff00), m_pad=m_pad,
+                    tgt4=_p(tgt4), tperm=_p(sweep.tperm) if sweep else None, qorder=_p(qorder),
+                    bucket=_p(sweep.bucket) if sweep else None, brange=_p(sweep.brange) if sweep else None,
+                    nbkt=SweepIndex.NBKT, idx_per_iter=int(need_grad), pairs=_p(sweep.pairs) if sweep else None,
+                    spos=ctypes.c_void_p(spos_slabs[j].data_ptr() - base * N * n * 4) if owned else None,
+                    poses=_p(poses), deltas=_p(deltas), costs=_p(costs), areg=_p(areg), alive=_p(alive), converged=_p(converged),
                     iterations=_p(iterations), matched_ratio=_p(matched), n_start=_p(n_start), n_matched=_p(n_matched),
-                    w_cur=_p(wk), w_prev=_p(w_hist[-1]) if w_hist else None, w_stride=n,
-                    n_not_converged=ctypes.c_void_p(counters.data_ptr() + 4 * k))
-                _lib.check(lib.dicp_step(code, ctypes.byref(io), N, st), "dicp_step")
-                w_hist.append(wk)
-                idx_hist.append(saved_k if need_grad else None)
-                K = k + 1
-                # ICP.py:259: stop once every cloud's step is below tolerance (same host sync as the reference)
-                if not cfg.const_iter and int(counters[k].item()) == 0:
-                    break
+                    idx=ctypes.c_void_p(idx_slabs[j].data_ptr() - base * N * n * 4) if need_grad else _p(idx_once),
+                    w=ctypes.c_void_p(w_slabs[j].data_ptr() - base * N * n * es),
+                    w_prev0=_p(w_slabs[(k0 - 1) // kc][(k0 - 1) % kc]) if k0 > 0 else None,
+                    partials=_p(partials), counters=_p(counters), events=events)
+                _lib.check(lib.dicp_icp_forward(code, ctypes.byref(P), ctypes.byref(LB), N, n, m, int(cfg.dim), int(cfg.const_iter),
+                                                float(cfg.tolerance), k0, k1, st), "dicp_icp_forward")
+                done_segs.append((k0, k1))
+                if not cfg.const_iter:
+                    # ICP.py:259: stop at the first iteration whose steps are ALL below tolerance (host sync, like the reference)
+                    zero = (counters[k0:k1] == 0).nonzero()
+                    if zero.numel():
+                        K = k0 + int(zero[0, 0].item()) + 1
+                        break
 
             # ICP.py:267-271: fill the stats of clouds that never converged
             iterations = torch.where(iterations == 0, torch.full_like(iterations, K), iterations)
-            start = (n_start * (alive != 0)).to(torch.int64)
+            start = (n_start * (alive[K] != 0)).to(torch.int64)
             start[start == 0] = 1
+            # clouds that never converged report the matches of the LAST executed iteration; with sync_every > 1 a few
+            # frozen no-op iterations may have run past K, which leaves n_matched of such clouds unchanged or zero-weighted
             ratio = n_matched.to(torch.int64) / start           # int64/int64 -> float32, as in the reference
             matched = torch.where(matched == 0, ratio.to(dt), matched)
 
@@ -387,76 +404,75 @@ class ICPLoop(torch.autograd.Function):
             T[:, :3, :3] = pose_K[:, :9].reshape(N, 3, 3)
             T[:, :3, 3] = pose_K[:, 9:]
             T[:, 3, 3] = 1.0
-            weights = torch.stack(w_hist, dim=1)
+            weights = torch.cat(w_slabs, dim=0)[:K].transpose(0, 1).contiguous()
             deltas_out = deltas[:, :K].contiguous()
             costs_out = costs[:, :K].contiguous()
 
         if need_grad:
-            owned = sweep is not None and cfg.bwd_owned
-            extra = [sweep.tperm] + qorders if owned else []
-            ctx.save_for_backward(src, tgt, w0c, poses, deltas, areg, alive_hist, *idx_hist, *extra)
+            saved = [src, tgt, w0c, poses, deltas, areg, alive] + idx_slabs + spos_slabs + qorders + ([sweep.tperm] if owned else [])
+            ctx.save_for_backward(*saved)
             ctx.cfg, ctx.K, ctx.P, ctx.Kmax = cfg, K, P, Kmax
-            ctx.owned = (owned, list(qorder_of), m_pad)
+            ctx.layout = (len(idx_slabs), len(spos_slabs), len(qorders), kc, owned, m_pad, kind,
+                          [(a, min(b, K), q) for (a, b), q in zip(done_segs, seg_q) if a < K])
         conv = converged.bool()
         ctx.mark_non_differentiable(deltas_out, weights, costs_out, conv, iterations, matched)
         return T, deltas_out, weights, costs_out, conv, iterations, matched
 
     @staticmethod
     def backward(ctx, gT, *_unused):
-        src, tgt, w0c, poses, deltas, areg, alive_hist, *rest = ctx.saved_tensors
+        src, tgt, w0c, poses, deltas, areg, alive, *rest = ctx.saved_tensors
         cfg, K, P, Kmax = ctx.cfg, ctx.K, ctx.P, ctx.Kmax
-        owned, qorder_of, m_pad = ctx.owned
-        idx_hist = rest[:K]
-        tperm, qorders = (rest[K], rest[K + 1:]) if owned else (None, [])
+        n_idx, n_spos, n_q, kc, owned, m_pad, kind, segs = ctx.layout
+        idx_slabs, spos_slabs = rest[:n_idx], rest[n_idx:n_idx + n_spos]
+        qorders = rest[n_idx + n_spos:n_idx + n_spos + n_q]
+        tperm = rest[-1] if owned else None
         lib = _lib.load()
         dev, dt = src.device, src.dtype
-        code = _DT[dt]
+        code, es = _DT[dt], src.element_size()
         N, n, _ = src.shape
         m, c = tgt.shape[1], tgt.shape[2]
-        hook = cfg.timing_hook
         with torch.cuda.device(dev):
             st = _stream()
             nblk = lib.dicp_owned_tiles(code, m_pad) if owned else lib.dicp_accumulate_blocks(n)
             gT = gT.contiguous()
             gpose = torch.cat((gT[:, :3, :3].reshape(N, 9), gT[:, :3, 3]), dim=1).to(torch.float64).contiguous()
-            gpose_next = torch.empty_like(gpose)
+            gtmp = torch.empty_like(gpose)
             gsrc = torch.zeros_like(src)
             want_tgt = ctx.needs_input_grad[1]
             cv = 6 if cfg.icp_type == "pt2pl" else 3
             if owned:       # target gradients accumulate in SORTED order, un-permuted once at the end
                 gts = torch.zeros((N, m_pad, cv), dtype=dt, device=dev) if want_tgt else None
-                gtgt = None
+                gacc = gts
             else:
-                gtgt = torch.zeros_like(tgt) if want_tgt else None
+                gacc = torch.zeros_like(tgt) if want_tgt else None
             gw = torch.zeros_like(w0c)
             gs = torch.empty((N, 36), dtype=dt, device=dev)
             gb = torch.empty((N, 6), dtype=dt, device=dev)
             bwdp = torch.empty((N, nblk, _lib.NBWD_PAD), dtype=dt, device=dev)
-            have_partials = False
-            for k in range(K - 1, -1, -1):
-                _lib.check(lib.dicp_step_bwd(code, _p(gpose), _p(bwdp) if have_partials else None, nblk, int(cfg.dim),
-                                             _p(poses[k]), ctypes.c_void_p(deltas.data_ptr() + k * 6 * deltas.element_size()),
-                                             Kmax * 6, _p(areg[k]), _p(gs), _p(gb), _p(gpose_next), N, st), "dicp_step_bwd")
-                if hook:
-                    hook("accumulate_bwd", 0)
-                if owned:
-                    _lib.check(lib.dicp_accumulate_bwd_owned(code, ctypes.byref(P), _p(src), _p(tgt), c, _p(idx_hist[k]),
-                                                             _p(qorders[qorder_of[k]]), _p(tperm), _p(poses[k]), _p(w0c),
-                                                             _p(alive_hist[k]), _p(gs), _p(gb), N, n, m, m_pad,
-                                                             _p(gsrc), _p(gts), _p(gw), _p(bwdp), st), "dicp_accumulate_bwd_owned")
-                else:
-                    _lib.check(lib.dicp_accumulate_bwd(code, ctypes.byref(P), _p(src), _p(tgt), c, _p(idx_hist[k]), _p(poses[k]),
-                                                       _p(w0c), _p(alive_hist[k]), _p(gs), _p(gb), N, n, m,
-                                                       _p(gsrc), _p(gtgt), _p(gw), _p(bwdp), st), "dicp_accumulate_bwd")
-                if hook:
-                    hook("accumulate_bwd", 1)
-                have_partials = True
-                gpose, gpose_next = gpose_next, gpose
-            if have_partials:
+            ev = cfg.timing_events
+            events = ev.handles(Kmax) if ev is not None else None
+            have = 0
+            for (k0, k1, q) in reversed(segs):
+                j = k0 // kc
+                base = j * kc
+                LB = _lib.LoopBuffers(
+                    src=_p(src), tgt=_p(tgt), w_init=_p(w0c), c=c, K=Kmax, knn_variant=kind, m_pad=m_pad,
+                    tperm=_p(tperm), qorder=_p(qorders[q]) if owned else None, idx_per_iter=1,
+                    spos=ctypes.c_void_p(spos_slabs[j].data_ptr() - base * N * n * 4) if owned else None,
+                    poses=_p(poses), deltas=_p(deltas), areg=_p(areg), alive=_p(alive),
+                    idx=ctypes.c_void_p(idx_slabs[j].data_ptr() - base * N * n * 4), events=events)
+                _lib.check(lib.dicp_icp_backward(code, ctypes.byref(P), ctypes.byref(LB), N, n, m, int(cfg.dim), _p(gpose), _p(gtmp), have,
+                                                 _p(gs), _p(gb), _p(gsrc), _p(gacc), _p(gw), _p(bwdp), k0, k1, st), "dicp_icp_backward")
+                have = 1
+            if have:
                 gpose = gpose + bwdp.sum(dim=1)[:, :12].to(torch.float64)
-            if owned and want_tgt:      # sorted row s holds the gradient of original row tperm[s]
-                gtgt = torch.zeros_like(tgt)
-                gtgt[:, :, :cv].scatter_(1, tperm[:, :m].long().unsqueeze(-1).expand(-1, -1, cv), gts[:, :m])
+            gtgt = None
+            if want_tgt:
+                if owned:   # sorted row s holds the gradient of original row tperm[s]
+                    gtgt = torch.zeros_like(tgt)
+                    gtgt[:, :, :cv].scatter_(1, tperm[:, :m].long().unsqueeze(-1).expand(-1, -1, cv), gts[:, :m])
+                else:
+                    gtgt = gacc
             gT0 = torch.zeros((N, 4, 4), dtype=dt, device=dev)
             gT0[:, :3, :3] = gpose[:, :9].reshape(N, 3, 3).to(dt)
             gT0[:, :3, 3] = gpose[:, 9:].to(dt)
@@ -589,7 +605,7 @@ class _RowsIteration(torch.autograd.Function):
                 partials=_p(partials), nblk=nblk, iter=k, dim=int(cfg.dim), const_iter=int(cfg.const_iter),
                 tolerance=float(cfg.tolerance), rows_per_point=3 if cfg.icp_type == "pt2pt" else 1, n=n,
                 pose_in=_p(pose_in), pose_out=_p(pose_out), delta=_p(delta), delta_stride=6,
-                cost=_p(cost), cost_prev=_p(st["cost_prev"]), cost_stride=1, areg=_p(areg), alive=_p(st["alive"]),
+                cost=_p(cost), cost_prev=_p(st["cost_prev"]), cost_stride=1, areg=_p(areg), alive=_p(st["alive"]), alive_out=_p(st["alive"]),
                 converged=_p(st["converged"]), iterations=_p(st["iterations"]), matched_ratio=_p(st["matched"]),
                 n_start=_p(st["n_start"]), n_matched=_p(st["n_matched"]), w_cur=_p(wk), w_prev=_p(st["w_prev"]), w_stride=n,
                 n_not_converged=ctypes.c_void_p(st["counters"].data_ptr() + 4 * k))

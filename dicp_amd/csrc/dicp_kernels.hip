@@ -635,6 +635,8 @@ __global__ __launch_bounds__(WAVE) void step_kernel(dicp_step_io io, int N) {
 
         const double nmatch = sacc[ACC_NMATCH];
         if (io.n_matched) ((T*)io.n_matched)[cloud] = (T)nmatch;
+        const T alive_in = ((const T*)io.alive)[cloud];
+        T alive_next = alive_in;
         const bool hit = (double)(T)sqrt(nrm2) < io.tolerance;            // ICP.py:237-239
         if (hit) io.converged[cloud] = 1;
         else if (io.n_not_converged) atomicAdd(io.n_not_converged, 1);
@@ -642,14 +644,14 @@ __global__ __launch_bounds__(WAVE) void step_kernel(dicp_step_io io, int N) {
             T* it = (T*)io.iterations + cloud;
             if (*it == T(0)) *it = (T)(io.iter + 1);
             T* mr = (T*)io.matched_ratio + cloud;
-            T* al = (T*)io.alive + cloud;
             if (*mr == T(0)) {
-                float start = (*al != T(0)) ? (float)((const T*)io.n_start)[cloud] : 0.f;
+                float start = (alive_in != T(0)) ? (float)((const T*)io.n_start)[cloud] : 0.f;
                 if (start == 0.f) start = 1.f;
                 *mr = (T)((float)nmatch / start);       // int64/int64 -> float32 in the reference
             }
-            *al = T(0);
+            alive_next = T(0);
         }
+        ((T*)io.alive_out)[cloud] = alive_next;
         s_copy = (io.w_cur && io.w_prev && sacc[ACC_SUMW] == 0.0) ? 1 : 0;   // ICP.py:224-226
     }
     __syncthreads();
@@ -1401,7 +1403,7 @@ int dicp_accumulate(int dtype, const dicp_weight_params* prm, const void* src, c
 }
 
 int dicp_step(int dtype, const dicp_step_io* io, int N, void* stream) {
-    if (!io || !io->partials || !io->pose_in || !io->pose_out || !io->delta || !io->cost || !io->alive ||
+    if (!io || !io->partials || !io->pose_in || !io->pose_out || !io->delta || !io->cost || !io->alive || !io->alive_out ||
         !io->converged || !io->iterations || !io->matched_ratio || !io->n_start) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || io->nblk <= 0 || (io->dim != 2 && io->dim != 3) || io->delta_stride < 6 || io->cost_stride < 1 ||
@@ -1556,6 +1558,98 @@ int dicp_accumulate_bwd_owned(int dtype, const dicp_weight_params* prm, const vo
     else                   { if (P.mode == MODE_PT2PL) DICP_OWN(double, MODE_PT2PL, 1024); else DICP_OWN(double, MODE_PT2PT, 1024); }
 #undef DICP_OWN
     return launch_status();
+}
+
+// ------------------------------------------------------------------ whole-loop entry points
+// The iteration loop of ICP.dICP (ICP.py:131-260) behind ONE call: K x { kNN -> accumulate -> step } are
+// enqueued back to back on the stream with every piece of per-iteration state in caller-allocated buffers
+// (pose / alive / index / weight histories indexed by iteration), so the host does no per-iteration work.
+// The reference's per-iteration host check `all(converged)` (ICP.py:259) is the caller's business: it runs
+// [k0,k1) chunks and reads counters[] between them (converged clouds are frozen, extra iterations are no-ops).
+int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_buffers* B, int N, int n, int m,
+                     int dim, int const_iter, double tolerance, int k0, int k1, void* stream) {
+    if (!prm || !B || !B->src || !B->tgt || !B->w_init || !B->poses || !B->deltas || !B->costs || !B->alive ||
+        !B->converged || !B->iterations || !B->matched_ratio || !B->n_start || !B->n_matched || !B->idx || !B->w ||
+        !B->partials || !B->counters) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (k0 < 0 || k1 > B->K || k0 > k1 || N <= 0 || n <= 0 || m <= 0) return DICP_ERR_SHAPE;
+    const size_t es = dtype == DICP_F32 ? 4 : 8;
+    const int kind = B->knn_variant & 0xff;
+    if (kind == DICP_KNN_SWEEP ? (!B->tperm || !B->bucket || !B->brange) : !B->tgt4) return DICP_ERR_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = dicp_accumulate_blocks(n);
+    for (int k = k0; k < k1; ++k) {
+        const char* pose_k = (const char*)B->poses + (size_t)k * N * 12 * es;
+        int32_t* idx_k = B->idx + (B->idx_per_iter ? (size_t)k * N * n : 0);
+        char* w_k = (char*)B->w + (size_t)k * N * n * es;
+        const char* alive_k = (const char*)B->alive + (size_t)k * N * es;
+        if (B->events) { if (hipEventRecord((hipEvent_t)B->events[4 * k + 0], st) != hipSuccess) return -(int)hipGetLastError(); }
+        int rc;
+        if (kind == DICP_KNN_SWEEP)
+            rc = dicp_knn_sweep(dtype, B->src, pose_k, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, N, n, m, B->m_pad,
+                                idx_k, B->spos ? B->spos + (size_t)k * N * n : nullptr, B->pairs, (B->knn_variant >> 8) & 0xff, stream);
+        else
+            rc = dicp_knn(dtype, B->src, pose_k, B->tgt4, N, n, m, B->m_pad, idx_k, B->knn_variant, stream);
+        if (rc) return rc;
+        if (B->events) { if (hipEventRecord((hipEvent_t)B->events[4 * k + 1], st) != hipSuccess) return -(int)hipGetLastError(); }
+        rc = dicp_accumulate(dtype, prm, B->src, B->tgt, B->c, idx_k, pose_k, B->w_init, alive_k, N, n, m, B->partials, w_k, n, stream);
+        if (rc) return rc;
+        dicp_step_io io;
+        io.partials = B->partials; io.nblk = nblk; io.iter = k; io.dim = dim; io.const_iter = const_iter; io.tolerance = tolerance;
+        io.rows_per_point = prm->mode == DICP_PT2PT ? 3 : 1; io.n = n;
+        io.pose_in = pose_k; io.pose_out = (char*)B->poses + (size_t)(k + 1) * N * 12 * es;
+        io.delta = (char*)B->deltas + (size_t)k * 6 * es; io.delta_stride = (int64_t)B->K * 6;
+        io.cost = (char*)B->costs + (size_t)k * es; io.cost_prev = k > 0 ? (const char*)B->costs + (size_t)(k - 1) * es : nullptr;
+        io.cost_stride = B->K;
+        io.areg = B->areg ? B->areg + (size_t)k * N * 36 : nullptr;
+        io.alive = alive_k; io.alive_out = (char*)B->alive + (size_t)(k + 1) * N * es;
+        io.converged = B->converged; io.iterations = B->iterations; io.matched_ratio = B->matched_ratio;
+        io.n_start = B->n_start; io.n_matched = B->n_matched;
+        io.w_cur = w_k; io.w_prev = k > k0 ? (const char*)B->w + (size_t)(k - 1) * N * n * es : (const char*)B->w_prev0; io.w_stride = n;
+        io.n_not_converged = B->counters + k;
+        rc = dicp_step(dtype, &io, N, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// Reverse sweep for iterations k1-1 .. k0: K x { step_bwd -> accumulate_bwd }.  gpose (N,12) double holds the
+// cotangent of pose_{k1} on entry and of pose_{k0} (without the last accumulate_bwd partials, which stay in
+// bwd_partials for the caller or the next chunk) on exit; gpose_tmp is scratch of the same size.
+int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_buffers* B, int N, int n, int m, int dim,
+                      double* gpose, double* gpose_tmp, int have_partials, void* gs, void* gb, void* gsrc, void* gtgt, void* gw,
+                      void* bwd_partials, int k0, int k1, void* stream) {
+    if (!prm || !B || !B->src || !B->tgt || !B->w_init || !B->poses || !B->deltas || !B->areg || !B->alive || !B->idx ||
+        !gpose || !gpose_tmp || !gs || !gb || !gsrc || !bwd_partials) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (k0 < 0 || k1 > B->K || k0 > k1 || !B->idx_per_iter) return DICP_ERR_SHAPE;
+    const size_t es = dtype == DICP_F32 ? 4 : 8;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = B->spos ? dicp_owned_tiles(dtype, B->m_pad) : dicp_accumulate_blocks(n);
+    double* gin = gpose;
+    double* gout = gpose_tmp;
+    for (int k = k1 - 1; k >= k0; --k) {
+        const char* pose_k = (const char*)B->poses + (size_t)k * N * 12 * es;
+        int rc = dicp_step_bwd(dtype, gin, have_partials ? bwd_partials : nullptr, nblk, dim, pose_k,
+                               (const char*)B->deltas + (size_t)k * 6 * es, (int64_t)B->K * 6, B->areg + (size_t)k * N * 36,
+                               gs, gb, gout, N, stream);
+        if (rc) return rc;
+        if (B->events) { if (hipEventRecord((hipEvent_t)B->events[4 * k + 2], st) != hipSuccess) return -(int)hipGetLastError(); }
+        if (B->spos)    // owner-computes form: gtgt is the SORTED-order (N,m_pad,CV) buffer
+            rc = dicp_accumulate_bwd_owned(dtype, prm, B->src, B->tgt, B->c, B->spos + (size_t)k * N * n, B->qorder, B->tperm, pose_k,
+                                           B->w_init, (const char*)B->alive + (size_t)k * N * es, gs, gb, N, n, m, B->m_pad,
+                                           gsrc, gtgt, gw, bwd_partials, stream);
+        else
+            rc = dicp_accumulate_bwd(dtype, prm, B->src, B->tgt, B->c, B->idx + (size_t)k * N * n, pose_k, B->w_init,
+                                     (const char*)B->alive + (size_t)k * N * es, gs, gb, N, n, m, gsrc, gtgt, gw, bwd_partials, stream);
+        if (rc) return rc;
+        if (B->events) { if (hipEventRecord((hipEvent_t)B->events[4 * k + 3], st) != hipSuccess) return -(int)hipGetLastError(); }
+        have_partials = 1;
+        double* t = gin; gin = gout; gout = t;
+    }
+    if (gin != gpose && k1 > k0)      // odd number of iterations: result sits in the scratch buffer
+        if (hipMemcpyAsync(gpose, gin, (size_t)N * 12 * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) return -(int)hipGetLastError();
+    return 0;
 }
 
 int dicp_loss_weight(int dtype, int loss, int differentiable, double metric, double tanh_k,

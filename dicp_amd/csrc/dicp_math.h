@@ -382,24 +382,78 @@ DICP_HD int ndof(int dim) { return dim == 2 ? 3 : 6; }
 
 // Forward step.  A6 (full 6x6, without the regulariser), b6 -> delta6, and the new pose.
 // Areg receives the d x d matrix actually inverted (leading dim 6), kept for backward.
-constexpr int STEP_WS = 48;   // doubles of workspace step_forward / step_backward need
+constexpr int STEP_WS = 48;   // doubles of workspace (kept in the signatures; the fixed-size solver below lives in registers)
 
-DICP_HD void step_forward(const double* A6, const double* b6, int dim, const double* C, const double* r,
-                          double* delta6, double* Cn, double* rn, double* Areg, double* ws) {
-    const int d = ndof(dim);
-    double* M = ws;            // 36
-    double* rhs = ws + 36;     // 6
-    double* x = ws + 42;       // 6
-    for (int i = 0; i < d; ++i) {
-        for (int j = 0; j < d; ++j) M[i * 6 + j] = A6[slot(dim, i) * 6 + slot(dim, j)];
-        M[i * 6 + i] += 1e-12;                                      // ICP.py:200
-        rhs[i] = b6[slot(dim, i)];
+// D x D solve with partial pivoting, fully unrolled with compile-time indices so that the matrix stays in
+// REGISTERS on the GPU (a runtime-indexed private array would live in scratch memory, and an LDS copy makes the
+// serial elimination LDS-latency-bound: the per-cloud step kernels sit between the big launches, so their
+// latency is what small problems see).  Same pivot rule and arithmetic as solve_small.
+template <int D>
+DICP_HD bool solve_fixed(double (&M)[D * D], double (&rhs)[D], double (&x)[D]) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        int piv = k;
+        double best = fabs(M[k * D + k]);
+#pragma unroll
+        for (int i = k + 1; i < D; ++i) {
+            const double v = fabs(M[i * D + k]);
+            if (v > best) { best = v; piv = i; }
+        }
+        if (best == 0.0) return false;
+#pragma unroll
+        for (int i = k + 1; i < D; ++i) {               // branch-free row swap k <-> piv
+            const bool sw = (piv == i);
+#pragma unroll
+            for (int c = k; c < D; ++c) {
+                const double a = M[k * D + c], b = M[i * D + c];
+                M[k * D + c] = sw ? b : a;
+                M[i * D + c] = sw ? a : b;
+            }
+            const double a = rhs[k], b = rhs[i];
+            rhs[k] = sw ? b : a;
+            rhs[i] = sw ? a : b;
+        }
+        const double inv = 1.0 / M[k * D + k];
+#pragma unroll
+        for (int i = k + 1; i < D; ++i) {
+            const double f = M[i * D + k] * inv;
+#pragma unroll
+            for (int c = k + 1; c < D; ++c) M[i * D + c] -= f * M[k * D + c];
+            rhs[i] -= f * rhs[k];
+        }
+    }
+#pragma unroll
+    for (int i = D - 1; i >= 0; --i) {
+        double v = rhs[i];
+#pragma unroll
+        for (int c = i + 1; c < D; ++c) v -= M[i * D + c] * x[c];
+        x[i] = v / M[i * D + i];
+    }
+    return true;
+}
+
+template <int D>
+DICP_HD void step_forward_fixed(const double* A6, const double* b6, const double* C, const double* r,
+                                double* delta6, double* Cn, double* rn, double* Areg) {
+    constexpr int OFF = (D == 3) ? 2 : 0;              // dim == 2 optimises slots 2,3,4 (ICP.py:186-189)
+    double M[D * D], rhs[D], x[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) M[i * D + j] = A6[(i + OFF) * 6 + (j + OFF)];
+        M[i * D + i] += 1e-12;                                      // ICP.py:200
+        rhs[i] = b6[i + OFF];
     }
     for (int i = 0; i < 36; ++i) Areg[i] = 0.0;
-    for (int i = 0; i < d; ++i) for (int j = 0; j < d; ++j) Areg[i * 6 + j] = M[i * 6 + j];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) Areg[i * 6 + j] = M[i * D + j];
     for (int i = 0; i < 6; ++i) delta6[i] = 0.0;
-    if (solve_small(M, rhs, x, d))
-        for (int i = 0; i < d; ++i) delta6[slot(dim, i)] = -x[i];    // ICP.py:201
+    if (solve_fixed<D>(M, rhs, x)) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) delta6[i + OFF] = -x[i];         // ICP.py:201
+    }
     double R[9];
     so3_exp(delta6, R);                                              // ICP.py:210
     for (int i = 0; i < 3; ++i)                                      // C <- R^T C   ICP.py:214
@@ -408,12 +462,19 @@ DICP_HD void step_forward(const double* A6, const double* b6, int dim, const dou
     for (int i = 0; i < 3; ++i) rn[i] = r[i] - delta6[3 + i];        // ICP.py:216
 }
 
+DICP_HD void step_forward(const double* A6, const double* b6, int dim, const double* C, const double* r,
+                          double* delta6, double* Cn, double* rn, double* Areg, double* /*ws*/) {
+    if (dim == 2) step_forward_fixed<3>(A6, b6, C, r, delta6, Cn, rn, Areg);
+    else          step_forward_fixed<6>(A6, b6, C, r, delta6, Cn, rn, Areg);
+}
+
 // Backward step.  In: gCn, grn (cotangents of the new pose), saved C, delta6, Areg.
 // Out: Gs = G_A + G_A^T (6x6), gb (6), gC, gr (cotangents of the old pose).
-DICP_HD void step_backward(const double* gCn, const double* grn, int dim, const double* C,
-                           const double* delta6, const double* Areg,
-                           double* Gs, double* gb, double* gC, double* gr, double* ws) {
-    const int d = ndof(dim);
+template <int D>
+DICP_HD void step_backward_fixed(const double* gCn, const double* grn, const double* C,
+                                 const double* delta6, const double* Areg,
+                                 double* Gs, double* gb, double* gC, double* gr) {
+    constexpr int OFF = (D == 3) ? 2 : 0;
     double R[9];
     so3_exp(delta6, R);
     // C_new = R^T C  ->  gC = R gCn ,  gR = C gCn^T
@@ -425,11 +486,11 @@ DICP_HD void step_backward(const double* gCn, const double* grn, int dim, const 
         }
     for (int i = 0; i < 3; ++i) gr[i] = grn[i];
     // dR = (J_l dphi)^ R  ->  gphi = J_l^T vee(M - M^T), M = gR R^T
-    double M[9];
+    double Mm[9];
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j)
-            M[i * 3 + j] = gR[i * 3 + 0] * R[j * 3 + 0] + gR[i * 3 + 1] * R[j * 3 + 1] + gR[i * 3 + 2] * R[j * 3 + 2];
-    const double v[3] = {M[7] - M[5], M[2] - M[6], M[3] - M[1]};
+            Mm[i * 3 + j] = gR[i * 3 + 0] * R[j * 3 + 0] + gR[i * 3 + 1] * R[j * 3 + 1] + gR[i * 3 + 2] * R[j * 3 + 2];
+    const double v[3] = {Mm[7] - Mm[5], Mm[2] - Mm[6], Mm[3] - Mm[1]};
     double a, b, c;
     so3_coeffs(delta6, a, b, c);
     const double* phi = delta6;
@@ -440,24 +501,30 @@ DICP_HD void step_backward(const double* gCn, const double* grn, int dim, const 
     for (int i = 0; i < 3; ++i) gd[i] = a * v[i] + c * phi[i] * pv - b * pxv[i];
     for (int i = 0; i < 3; ++i) gd[3 + i] = -grn[i];
     // delta = -Areg^{-1} b  ->  g = Areg^{-1} gdelta ; gb = -g ; G_A = -g delta^T
-    double* Mx = ws;           // 36
-    double* rhs = ws + 36;     // 6
-    double* g = ws + 42;       // 6
-    for (int i = 0; i < 36; ++i) Mx[i] = Areg[i];
-    for (int i = 0; i < d; ++i) rhs[i] = gd[slot(dim, i)];
+    double Mx[D * D], rhs[D], g[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) Mx[i * D + j] = Areg[i * 6 + j];
+        rhs[i] = gd[i + OFF];
+    }
     for (int i = 0; i < 36; ++i) Gs[i] = 0.0;
     for (int i = 0; i < 6; ++i) gb[i] = 0.0;
-    if (!solve_small(Mx, rhs, g, d)) return;
-    for (int i = 0; i < d; ++i) {
-        const int si = slot(dim, i);
-        gb[si] = -g[i];
-        for (int j = 0; j < d; ++j) {
-            const int sj = slot(dim, j);
-            Gs[si * 6 + sj] = -(g[i] * delta6[sj] + delta6[si] * g[j]);
-        }
+    if (!solve_fixed<D>(Mx, rhs, g)) return;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        gb[i + OFF] = -g[i];
+#pragma unroll
+        for (int j = 0; j < D; ++j) Gs[(i + OFF) * 6 + (j + OFF)] = -(g[i] * delta6[j + OFF] + delta6[i + OFF] * g[j]);
     }
 }
 
+DICP_HD void step_backward(const double* gCn, const double* grn, int dim, const double* C,
+                           const double* delta6, const double* Areg,
+                           double* Gs, double* gb, double* gC, double* gr, double* /*ws*/) {
+    if (dim == 2) step_backward_fixed<3>(gCn, grn, C, delta6, Areg, Gs, gb, gC, gr);
+    else          step_backward_fixed<6>(gCn, grn, C, delta6, Areg, Gs, gb, gC, gr);
+}
 
 // ------------------------------------------------------------------ Kabsch / SVD step
 // Closed-form point-to-point alignment (the step of the reference's pt2pt_dICP_SVD, ICP.py:557-573,

@@ -119,7 +119,8 @@ typedef struct dicp_step_io {
     const void* cost_prev;   /* same layout, previous iteration, or NULL */
     int64_t cost_stride;
     double* areg;            /* (N,36) the regularised matrix that was inverted (for backward) */
-    void* alive;             /* (N) T in/out                               ICP.py:256-257 */
+    const void* alive;       /* (N) T in:  w_init multiplier of THIS iteration        ICP.py:256-257 */
+    void* alive_out;         /* (N) T out: multiplier of the next one (0 once converged; may alias alive) */
     uint8_t* converged;      /* (N) in/out                                 ICP.py:239 */
     void* iterations;        /* (N) T in/out                               ICP.py:245 */
     void* matched_ratio;     /* (N) T in/out                               ICP.py:247-251 */
@@ -134,6 +135,54 @@ typedef struct dicp_step_io {
 /* Reduce the partials, solve the 6x6 (3x3 for dim 2) system (ICP.py:200-201), update the
  * pose (ICP.py:209-217) and do the loop bookkeeping of ICP.py:219-257 on device. */
 int dicp_step(int dtype, const dicp_step_io* io, int N, void* stream);
+
+/* Caller-allocated state of one whole ICP call, indexed by iteration k = 0..K-1 (T = dtype's scalar). */
+typedef struct dicp_loop_buffers {
+    const void* src;         /* (N,n,3) */
+    const void* tgt;         /* (N,m,c) */
+    const void* w_init;      /* (N,n) */
+    int32_t c;
+    int32_t K;               /* capacity of the histories (= max_iterations) */
+    int32_t knn_variant;     /* DICP_KNN_VALU | _MFMA (uses tgt4) or DICP_KNN_SWEEP (uses tgt4 = tgs4 + the arrays below) */
+    int32_t m_pad;
+    const void* tgt4;        /* dicp_pack_target output, or its x-sorted form for the sweep */
+    const int32_t* tperm;    /* sweep only */
+    const int32_t* qorder;   /* sweep only, may be NULL */
+    const int32_t* bucket;   /* sweep only */
+    const void* brange;      /* sweep only */
+    int32_t nbkt;
+    int32_t idx_per_iter;    /* 1: idx is (K,N,n) and every iteration keeps its own (needed for backward); 0: (N,n) reused */
+    unsigned long long* pairs;   /* sweep only, optional */
+    int32_t* spos;           /* sweep only, optional (K,N,n): per-iteration match lists -> backward uses dicp_accumulate_bwd_owned,
+                                whose gtgt is the sorted-order (N,m_pad,CV) buffer and bwd_partials has dicp_owned_tiles blocks */
+    void* poses;             /* (K+1,N,12): poses[0] = initial pose, poses[k+1] written by iteration k */
+    void* deltas;            /* (N,K,6) */
+    void* costs;             /* (N,K) */
+    double* areg;            /* (K,N,36) or NULL when no backward is needed */
+    void* alive;             /* (K+1,N): alive[0] = 1, alive[k+1] written by iteration k */
+    uint8_t* converged;      /* (N) zero-initialised */
+    void* iterations;        /* (N) zero-initialised */
+    void* matched_ratio;     /* (N) zero-initialised */
+    const void* n_start;     /* (N) */
+    void* n_matched;         /* (N) */
+    int32_t* idx;            /* (K,N,n) or (N,n) */
+    void* w;                 /* (K,N,n): weights of every iteration (may be a per-slab virtual base: only [k0,k1) is touched) */
+    const void* w_prev0;     /* (N,n) weights of iteration k0-1, or NULL when k0 == 0            ICP.py:224-226 */
+    void* partials;          /* (N, dicp_accumulate_blocks(n), DICP_NACC_PAD) scratch */
+    int32_t* counters;       /* (K) zero-initialised: #clouds with |delta| >= tol at iteration k */
+    void** events;           /* optional 4*K hipEvent_t: [4k] before / [4k+1] after the kNN of iteration k (forward),
+                                [4k+2] before / [4k+3] after its accumulate_bwd (backward); NULL = none */
+} dicp_loop_buffers;
+
+/* Iterations [k0,k1) of the loop (ICP.py:131-260), enqueued back to back: no host work between iterations. */
+int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_buffers* buf, int N, int n, int m,
+                     int dim, int const_iter, double tolerance, int k0, int k1, void* stream);
+/* Reverse sweep over iterations k1-1..k0.  gpose/gpose_tmp (N,12) double; gs (N,36), gb (N,6) scratch T;
+ * gsrc/gtgt/gw accumulate like dicp_accumulate_bwd; bwd_partials (N,nblk,DICP_NBWD_PAD) carries the last
+ * accumulate_bwd's C-bar/r-bar sums across chunks (have_partials: it holds valid sums on entry). */
+int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_buffers* buf, int N, int n, int m, int dim,
+                      double* gpose, double* gpose_tmp, int have_partials, void* gs, void* gb, void* gsrc, void* gtgt, void* gw,
+                      void* bwd_partials, int k0, int k1, void* stream);
 
 /* Backward of dicp_step for iteration k.  gpose_in (N,12) double = cotangent of pose_out
  * that flowed through later iterations; bwd_partials (N,nblk,DICP_NBWD_PAD) T = the

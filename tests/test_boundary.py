@@ -37,7 +37,7 @@ def test_struct_layouts_match_header(lib):
     assert ctypes.sizeof(_lib.WeightParams) == 4 * 4 + 4 * 8
     # dicp_step_io: field order and padding as the C compiler lays it out
     expect = ["partials", "nblk", "iter", "dim", "const_iter", "tolerance", "rows_per_point", "n", "pose_in", "pose_out",
-              "delta", "delta_stride", "cost", "cost_prev", "cost_stride", "areg", "alive", "converged", "iterations",
+              "delta", "delta_stride", "cost", "cost_prev", "cost_stride", "areg", "alive", "alive_out", "converged", "iterations",
               "matched_ratio", "n_start", "n_matched", "w_cur", "w_prev", "w_stride", "n_not_converged"]
     assert [f[0] for f in _lib.StepIO._fields_] == expect
     hdr = open(os.path.join(ROOT, "include", "dicp_hip.h")).read()

@@ -890,3 +890,26 @@ def test_icp_with_gumbel_correspondence_vs_oracle(icp_type, monkeypatch):
     for a, b in ((sd, sc), (td, tc), (wd, wc), (T0d, T0c)):
         scale = max(1.0, float(b.grad.abs().max()))
         np.testing.assert_allclose(npy(a.grad), npy(b.grad), rtol=0, atol=2e-5 * scale)
+
+
+def test_sync_every_and_history_slabs_do_not_change_results(golden, monkeypatch):
+    """f-3: the loop is enqueued in segments; checking convergence only every few iterations (converged clouds
+    are frozen) and splitting the histories into several slabs must give the reference's result exactly."""
+    g = golden("input_types")
+    S = [t(g["s0"]), t(g["s1"]), t(g["s2"])]
+    Tg = [t(g["t0"]), t(g["t1"]), t(g["t2"])]
+    T0 = torch.stack([torch.eye(4, dtype=torch.float64, device=DEV)] * 3)
+    kw = dict(trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0}, dim=2)
+    for sync_every, slab in ((1, 1 << 29), (4, 1 << 29), (7, 1), (25, 1 << 29)):
+        monkeypatch.setattr(_ops, "HIST_CHUNK_BYTES", slab)          # slab = 1 byte -> one iteration per slab
+        icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=25, tolerance=1e-8)
+        icp.sync_every = sync_every
+        src = [x.clone().requires_grad_(True) for x in S]
+        out = icp.icp(src, Tg, T0, **kw)
+        check_result(out, g, "batch_")
+        out["T"].sum().backward()
+        if sync_every == 1:
+            ref_grads = [x.grad.clone() for x in src]
+        else:
+            for a, b in zip(src, ref_grads):
+                np.testing.assert_allclose(npy(a.grad), npy(b), rtol=0, atol=1e-12)

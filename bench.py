@@ -139,6 +139,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # synthetic inputs are generated on the CPU: keep N ranks from oversubscribing the host's cores
+    torch.set_num_threads(max(1, min(16, (os.cpu_count() or 1) // max(1, world))))
     # DICP_BENCH_FORCE_DIST=1 runs the distributed code path (RCCL init, barrier, pose all-gather, max-reduce)
     # even with one rank: how the N>1 path is smoke-tested on a 1-GPU box
     force_dist = os.environ.get("DICP_BENCH_FORCE_DIST", "0") == "1" and "RANK" in os.environ

@@ -19,7 +19,7 @@ import torch
 import yaml
 
 from . import _lib
-from ._ops import ICPLoop, KabschLoop, LoopConfig, compute_device, icp_loop_gumbel
+from ._ops import ICPLoop, KabschLoop, LoopConfig, compute_device, icp_loop_gumbel, transform_points
 from .nn import nn
 
 
@@ -109,7 +109,7 @@ class ICP:
             print("Final del_T_ts: {}".format(torch.linalg.norm(deltas[:, -1])))
 
         # ICP.py:274: transformed source, with the graph running through T
-        pc = source @ T[:, :3, :3].transpose(1, 2) + T[:, :3, 3].unsqueeze(1)
+        pc = transform_points(source, T)
         if self.icp_type == 'pt2pt':                                                     # ICP.py:164-165
             weights = weights.repeat_interleave(3, dim=2)
         results = {                                                                      # ICP.py:283-303
@@ -149,7 +149,7 @@ class ICP:
                                                 trim_dist, bool(self.const_iter), self.knn_variant)
         if self.verbose:                                                                 # ICP.py:588-589
             print("ICP converged in {} iterations".format(int(iterations.max().item()) - 1))
-        pc = s_b @ T[:, :3, :3].transpose(1, 2) + T[:, :3, 3].unsqueeze(1)               # ICP.py:581
+        pc = transform_points(s_b, T)                                                    # ICP.py:581
         self.svd_stats = {"costs": costs, "iterations": iterations}
         if home != dev:
             pc, T = pc.to(home), T.to(home)

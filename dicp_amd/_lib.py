@@ -72,6 +72,8 @@ _SIGNATURES = {
     "dicp_kabsch_step": ([i32, vp, i32, vp, vp, vp, i32, vp], ctypes.c_int),
     "dicp_kabsch_step_bwd": ([i32, vp, vp, vp, i32, vp], ctypes.c_int),
     "dicp_kabsch_bwd": ([i32, vp, vp, i32, vp, vp, vp, i32, f64, vp, i32, i32, i32, vp, vp, vp, vp], ctypes.c_int),
+    "dicp_transform_points": ([i32, vp, vp, vp, i32, i32, vp], ctypes.c_int),
+    "dicp_transform_points_bwd": ([i32, vp, vp, vp, vp, vp, i32, i32, vp], ctypes.c_int),
     "dicp_loss_weight": ([i32, i32, i32, f64, f64, vp, i64, i32, vp, vp], ctypes.c_int),
     "dicp_loss_weight_bwd": ([i32, i32, i32, f64, f64, vp, vp, i64, i32, vp, vp], ctypes.c_int),
 }

@@ -200,6 +200,44 @@ def gumbel_nn(x, y, eps, tau, U=None, seed=None):
     return _GumbelNN.apply(x.contiguous(), y.contiguous(), U, seed & 0xFFFFFFFF, eps, tau)
 
 
+class _TransformPoints(torch.autograd.Function):
+    """pc = C p + r for every point (ICP.py:274), differentiable w.r.t. the points and the pose T (N,4,4)."""
+
+    @staticmethod
+    def forward(ctx, source, T):
+        N, n, _ = source.shape
+        src = source.contiguous()
+        pose = _pose_from_T(T)
+        out = torch.empty_like(src)
+        with torch.cuda.device(src.device):
+            _lib.check(_lib.load().dicp_transform_points(_DT[src.dtype], _p(src), _p(pose), _p(out), N, n, _stream()), "dicp_transform_points")
+        ctx.save_for_backward(src, pose)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        src, pose = ctx.saved_tensors
+        N, n, _ = src.shape
+        lib = _lib.load()
+        gsrc = torch.empty_like(src) if ctx.needs_input_grad[0] else None
+        partials = torch.empty((N, lib.dicp_accumulate_blocks(n), _lib.NBWD_PAD), dtype=src.dtype, device=src.device)
+        with torch.cuda.device(src.device):
+            _lib.check(lib.dicp_transform_points_bwd(_DT[src.dtype], _p(src), _p(pose), _p(gout.contiguous()), _p(gsrc), _p(partials),
+                                                     N, n, _stream()), "dicp_transform_points_bwd")
+        gT = None
+        if ctx.needs_input_grad[1]:
+            g = partials.sum(dim=1)
+            gT = torch.zeros((N, 4, 4), dtype=src.dtype, device=src.device)
+            gT[:, :3, :3] = g[:, :9].reshape(N, 3, 3)
+            gT[:, :3, 3] = g[:, 9:12]
+        return gsrc, gT
+
+
+def transform_points(source, T):
+    require_device(source, "transform_points")
+    return _TransformPoints.apply(source, T)
+
+
 class _LossWeight(torch.autograd.Function):
     @staticmethod
     def forward(ctx, err2d, loss, diff, metric, tanh_k):

@@ -241,6 +241,12 @@ int dicp_kabsch_step_bwd(int dtype, const void* gpose, const double* save, void*
 int dicp_kabsch_bwd(int dtype, const void* src, const void* tgt, int c, const int32_t* idx, const void* pose, const void* w_init,
                     int trim_on, double trim_dist, const void* gacc, int N, int n, int m, void* gsrc, void* gtgt, void* gw, void* stream);
 
+/* The returned cloud pc = C p + r (ICP.py:274) and its adjoint: gsrc (N,n,3) = C^T gout (may be NULL);
+ * partials (N, dicp_accumulate_blocks(n), DICP_NBWD_PAD) = per-block [sum gout p^T (9), sum gout (3)] for the pose. */
+int dicp_transform_points(int dtype, const void* src, const void* pose, void* out, int N, int n, void* stream);
+int dicp_transform_points_bwd(int dtype, const void* src, const void* pose, const void* gout, void* gsrc, void* partials,
+                              int N, int n, void* stream);
+
 /* loss(name, metric, differentiable, tanh_steepness).get_weight(err), loss.py:11-58, for
  * callers that use the class directly.  err (rows,r), r in {1,3}; w (rows). */
 int dicp_loss_weight(int dtype, int loss, int differentiable, double metric, double tanh_k,

@@ -48,7 +48,10 @@ class ICP:
         self.knn_variant = _lib.KNN_AUTO      # _lib.KNN_VALU | KNN_MFMA (brute force) | KNN_SWEEP (exact, slab-pruned)
         self.knn_stats = {}                   # "knn_pairs": pairs scored by the last call's sweep kNN
         self.bwd_owned = os.environ.get("DICP_BWD_OWNED", "0") == "1"   # atomics-free backward (measured slower: opt-in)
-        self.sync_every = 1                   # tolerance mode: iterations enqueued between two all-converged checks (ICP.py:259)
+        # tolerance mode: iterations enqueued between two host checks of "all converged" (ICP.py:259).  None = auto:
+        # every iteration for big batches (an iteration costs far more than a sync), every 4th for small ones
+        # (converged clouds are frozen, so the extra iterations change nothing and the histories are trimmed)
+        self.sync_every = None
         self._timing_events = None
 
     def icp(self, source, target, T_init, weight=None, trim_dist=None, loss_fn=None, dim=3):
@@ -96,7 +99,7 @@ class ICP:
             tanh_steepness=float(self.config['dICP']['parameters']['tanh_steepness']),   # ICP.py:119
             match_ratio_thresh=float(self.match_ratio_thresh),
             knn_variant=self.knn_variant, bwd_owned=bool(self.bwd_owned), stats_out=self.knn_stats,
-            sync_every=int(self.sync_every), timing_events=self._timing_events)
+            sync_every=self.sync_every, timing_events=self._timing_events)
         if self.nn.differentiable and self.nn.use_gumbel:                                # nn.py:14-16 via ICP.py:140
             # soft correspondences carry gradient themselves: one autograd node per iteration instead of one per call
             T, deltas, weights, costs, converged, iterations, matched = icp_loop_gumbel(

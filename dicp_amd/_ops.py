@@ -288,7 +288,7 @@ class LoopConfig:
     # atomic kernel on MI355X (0.41 vs 0.28 ms at B=256 x 16384), so it is opt-in: DICP_BWD_OWNED=1
     bwd_owned: bool = False
     stats_out: object = None      # optional dict: receives "knn_pairs" (pairs scored by the sweep kNN)
-    sync_every: int = 1           # tolerance mode: iterations between the host's all-converged checks (ICP.py:259)
+    sync_every: object = None     # tolerance mode: iterations between the host's all-converged checks (None = auto)
     timing_events: object = None  # optional object with .handles(K) -> ctypes array of 4*K hipEvent_t (bench.py)
 
     def params(self):
@@ -381,7 +381,10 @@ class ICPLoop(torch.autograd.Function):
             if sweep is not None:
                 cuts += list(cfg.sweep_resort)
             if not cfg.const_iter:
-                cuts += list(range(0, Kmax, max(1, int(cfg.sync_every))))
+                every = cfg.sync_every
+                if every is None:
+                    every = 1 if float(N) * n * m >= SWEEP_MIN_PAIRS else 4
+                cuts += list(range(0, Kmax, max(1, int(every))))
             ev = cfg.timing_events
             events = ev.handles(Kmax) if ev is not None else None
 

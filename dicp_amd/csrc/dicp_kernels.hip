@@ -599,7 +599,7 @@ __global__ __launch_bounds__(BLOCK) void accumulate_kernel(WeightParams P, const
 // would be scratch (global) memory, and this kernel is pure latency (it sits between two big launches).
 template <typename T>
 __global__ __launch_bounds__(WAVE) void step_kernel(dicp_step_io io, int N) {
-    __shared__ double sacc[NACC_PAD], sA[36], sAreg[36], sws[STEP_WS], spose[12], sout[24];
+    __shared__ double sacc[NACC_PAD], sA[36], sAreg[36], spose[12], sout[24];
     __shared__ int s_copy;
     const int cloud = blockIdx.x, tid = threadIdx.x;
     {   // reduce the per-block partials: lane = (part, slot); fixed summation order -> bit-reproducible
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(WAVE) void step_kernel(dicp_step_io io, int N) {
         double* d6 = sout; double* Cn = sout + 6; double* rn = sout + 15;
         unpack_sym6(sacc + ACC_A, sA);
         // solve with the pose untouched first so delta can be rounded to T like the reference's
-        step_forward(sA, sacc + ACC_B, io.dim, spose, spose + 9, d6, Cn, rn, sAreg, sws);
+        step_forward(sA, sacc + ACC_B, io.dim, spose, spose + 9, d6, Cn, rn, sAreg);
         T* dout = (T*)io.delta + (size_t)cloud * io.delta_stride;
         double nrm2 = 0.0;
         for (int k = 0; k < 6; ++k) { const T v = (T)d6[k]; dout[k] = v; d6[k] = (double)v; nrm2 += d6[k] * d6[k]; }
@@ -838,7 +838,7 @@ __global__ __launch_bounds__(WAVE) void step_bwd_kernel(const double* __restrict
                                                         const T* __restrict__ delta_k, long delta_stride,
                                                         const double* __restrict__ areg_k, T* __restrict__ gs,
                                                         T* __restrict__ gb, double* __restrict__ gpose_out, int N) {
-    __shared__ double sg[NBWD_PAD], sC[9], sd[6], sAreg[36], sGs[36], sGb[6], sgo[12], sws[STEP_WS];
+    __shared__ double sg[NBWD_PAD], sC[9], sd[6], sAreg[36], sGs[36], sGb[6], sgo[12];
     const int cloud = blockIdx.x, tid = threadIdx.x;
     {
         const int slot_i = tid & 15, part = tid >> 4;       // 4 partial sums per slot
@@ -855,7 +855,7 @@ __global__ __launch_bounds__(WAVE) void step_bwd_kernel(const double* __restrict
         if (tid < 36) sAreg[tid] = areg_k[(size_t)cloud * 36 + tid];
     }
     __syncthreads();
-    if (tid == 0) step_backward(sg, sg + 9, dim, sC, sd, sAreg, sGs, sGb, sgo, sgo + 9, sws);
+    if (tid == 0) step_backward(sg, sg + 9, dim, sC, sd, sAreg, sGs, sGb, sgo, sgo + 9);
     __syncthreads();
     if (tid < 36) gs[(size_t)cloud * 36 + tid] = (T)sGs[tid];
     if (tid < 6) gb[(size_t)cloud * 6 + tid] = (T)sGb[tid];

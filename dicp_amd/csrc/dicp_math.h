@@ -309,39 +309,6 @@ DICP_HD void point_backward(const WeightParams& P, const T* C, const T* r, const
 // ------------------------------------------------------------------ per-cloud step
 // All in double regardless of the cloud dtype (36 numbers per cloud).
 
-// Solve the d x d system M x = rhs (M row-major, leading dim 6) by Gaussian
-// elimination with partial pivoting (what LAPACK getrf does under torch.linalg.inv,
-// ICP.py:201).  M and rhs are destroyed.  Returns false if a pivot is exactly zero.
-DICP_HD bool solve_small(double* M, double* rhs, double* x, int d) {
-    for (int k = 0; k < d; ++k) {
-        int piv = k;
-        double best = fabs(M[k * 6 + k]);
-        for (int i = k + 1; i < d; ++i) {
-            const double v = fabs(M[i * 6 + k]);
-            if (v > best) { best = v; piv = i; }
-        }
-        if (best == 0.0) return false;
-        if (piv != k) {
-            for (int c = k; c < d; ++c) { const double t = M[k * 6 + c]; M[k * 6 + c] = M[piv * 6 + c]; M[piv * 6 + c] = t; }
-            const double t = rhs[k]; rhs[k] = rhs[piv]; rhs[piv] = t;
-        }
-        const double inv = 1.0 / M[k * 6 + k];
-        for (int i = k + 1; i < d; ++i) {
-            const double f = M[i * 6 + k] * inv;
-            if (f != 0.0) {
-                for (int c = k + 1; c < d; ++c) M[i * 6 + c] -= f * M[k * 6 + c];
-                rhs[i] -= f * rhs[k];
-            }
-        }
-    }
-    for (int i = d - 1; i >= 0; --i) {
-        double v = rhs[i];
-        for (int c = i + 1; c < d; ++c) v -= M[i * 6 + c] * x[c];
-        x[i] = v / M[i * 6 + i];
-    }
-    return true;
-}
-
 // Rodrigues coefficients: exp(phi^) = I + a K + b K^2, J_l = a I + c phi phi^T + b K.
 DICP_HD void so3_coeffs(const double* phi, double& a, double& b, double& c) {
     const double t2 = phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2];
@@ -382,12 +349,10 @@ DICP_HD int ndof(int dim) { return dim == 2 ? 3 : 6; }
 
 // Forward step.  A6 (full 6x6, without the regulariser), b6 -> delta6, and the new pose.
 // Areg receives the d x d matrix actually inverted (leading dim 6), kept for backward.
-constexpr int STEP_WS = 48;   // doubles of workspace (kept in the signatures; the fixed-size solver below lives in registers)
-
-// D x D solve with partial pivoting, fully unrolled with compile-time indices so that the matrix stays in
+// D x D solve with partial pivoting (what LAPACK getrf does under torch.linalg.inv, ICP.py:201), fully unrolled with compile-time indices so that the matrix stays in
 // REGISTERS on the GPU (a runtime-indexed private array would live in scratch memory, and an LDS copy makes the
 // serial elimination LDS-latency-bound: the per-cloud step kernels sit between the big launches, so their
-// latency is what small problems see).  Same pivot rule and arithmetic as solve_small.
+// latency is what small problems see).  Returns false if a pivot is exactly zero.
 template <int D>
 DICP_HD bool solve_fixed(double (&M)[D * D], double (&rhs)[D], double (&x)[D]) {
 #pragma unroll
@@ -463,7 +428,7 @@ DICP_HD void step_forward_fixed(const double* A6, const double* b6, const double
 }
 
 DICP_HD void step_forward(const double* A6, const double* b6, int dim, const double* C, const double* r,
-                          double* delta6, double* Cn, double* rn, double* Areg, double* /*ws*/) {
+                          double* delta6, double* Cn, double* rn, double* Areg) {
     if (dim == 2) step_forward_fixed<3>(A6, b6, C, r, delta6, Cn, rn, Areg);
     else          step_forward_fixed<6>(A6, b6, C, r, delta6, Cn, rn, Areg);
 }
@@ -521,7 +486,7 @@ DICP_HD void step_backward_fixed(const double* gCn, const double* grn, const dou
 
 DICP_HD void step_backward(const double* gCn, const double* grn, int dim, const double* C,
                            const double* delta6, const double* Areg,
-                           double* Gs, double* gb, double* gC, double* gr, double* /*ws*/) {
+                           double* Gs, double* gb, double* gC, double* gr) {
     if (dim == 2) step_backward_fixed<3>(gCn, grn, C, delta6, Areg, Gs, gb, gC, gr);
     else          step_backward_fixed<6>(gCn, grn, C, delta6, Areg, Gs, gb, gC, gr);
 }

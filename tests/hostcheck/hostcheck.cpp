@@ -52,14 +52,13 @@ void hc_backward_f64(const WeightParams* P, int n, int c, const double* src, con
 }
 void hc_step_forward(const double* acc, int dim, const double* C, const double* r,
                      double* delta6, double* Cn, double* rn, double* Areg) {
-    double A6[36], ws[STEP_WS];
+    double A6[36];
     unpack_sym6(acc + ACC_A, A6);
-    step_forward(A6, acc + ACC_B, dim, C, r, delta6, Cn, rn, Areg, ws);
+    step_forward(A6, acc + ACC_B, dim, C, r, delta6, Cn, rn, Areg);
 }
 void hc_step_backward(const double* gCn, const double* grn, int dim, const double* C, const double* delta6,
                       const double* Areg, double* Gs, double* gb, double* gC, double* gr) {
-    double ws[STEP_WS];
-    step_backward(gCn, grn, dim, C, delta6, Areg, Gs, gb, gC, gr, ws);
+    step_backward(gCn, grn, dim, C, delta6, Areg, Gs, gb, gC, gr);
 }
 double hc_kabsch_forward(const double* acc, double* C, double* r, double* save) { return kabsch_forward(acc, C, r, save); }
 void hc_kabsch_backward(const double* gC, const double* gr, const double* save, double* gacc) { kabsch_backward(gC, gr, save, gacc); }

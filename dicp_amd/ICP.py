@@ -47,7 +47,7 @@ class ICP:
         # build-specific knob (not in the reference): which kNN kernel the loop uses
         self.knn_variant = _lib.KNN_AUTO      # _lib.KNN_VALU | KNN_MFMA (brute force) | KNN_SWEEP (exact, slab-pruned)
         self.knn_stats = {}                   # "knn_pairs": pairs scored by the last call's sweep kNN
-        self.bwd_owned = os.environ.get("DICP_BWD_OWNED", "0") == "1"   # atomics-free backward (measured slower: opt-in)
+        self.bwd_window = os.environ.get("DICP_BWD_WINDOW", "1") == "1"   # sweep path: sorted-space backward (LDS window)
         # tolerance mode: iterations enqueued between two host checks of "all converged" (ICP.py:259).  None = auto:
         # every iteration for big batches (an iteration costs far more than a sync), every 4th for small ones
         # (converged clouds are frozen, so the extra iterations change nothing and the histories are trimmed)
@@ -98,7 +98,7 @@ class ICP:
             const_iter=bool(self.const_iter),
             tanh_steepness=float(self.config['dICP']['parameters']['tanh_steepness']),   # ICP.py:119
             match_ratio_thresh=float(self.match_ratio_thresh),
-            knn_variant=self.knn_variant, bwd_owned=bool(self.bwd_owned), stats_out=self.knn_stats,
+            knn_variant=self.knn_variant, bwd_window=bool(self.bwd_window), stats_out=self.knn_stats,
             sync_every=self.sync_every, timing_events=self._timing_events)
         if self.nn.differentiable and self.nn.use_gumbel:                                # nn.py:14-16 via ICP.py:140
             # soft correspondences carry gradient themselves: one autograd node per iteration instead of one per call

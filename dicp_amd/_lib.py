@@ -44,7 +44,7 @@ class LoopBuffers(ctypes.Structure):
     """dicp_loop_buffers (include/dicp_hip.h)."""
     _fields_ = [("src", vp), ("tgt", vp), ("w_init", vp), ("c", i32), ("K", i32), ("knn_variant", i32), ("m_pad", i32),
                 ("tgt4", vp), ("tperm", vp), ("qorder", vp), ("bucket", vp), ("brange", vp), ("nbkt", i32), ("idx_per_iter", i32),
-                ("pairs", vp), ("spos", vp), ("poses", vp), ("deltas", vp), ("costs", vp), ("areg", vp), ("alive", vp), ("converged", vp),
+                ("pairs", vp), ("spos", vp), ("spos_ref", vp), ("gts_far", vp), ("poses", vp), ("deltas", vp), ("costs", vp), ("areg", vp), ("alive", vp), ("converged", vp),
                 ("iterations", vp), ("matched_ratio", vp), ("n_start", vp), ("n_matched", vp), ("idx", vp), ("w", vp), ("w_prev0", vp),
                 ("partials", vp), ("counters", vp), ("events", vp)]
 
@@ -56,8 +56,11 @@ _SIGNATURES = {
     "dicp_pack_target": ([i32, vp, i32, i32, i32, vp, i32, vp], ctypes.c_int),
     "dicp_knn": ([i32, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp], ctypes.c_int),
     "dicp_knn_sweep": ([i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp], ctypes.c_int),
-    "dicp_owned_tiles": ([i32, i32], ctypes.c_int),
-    "dicp_accumulate_bwd_owned": ([i32, ctypes.POINTER(WeightParams), vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp], ctypes.c_int),
+    "dicp_window_blocks": ([i32, i32, i32], ctypes.c_int),
+    "dicp_window_rows": ([i32], ctypes.c_int),
+    "dicp_accumulate_bwd_window": ([i32, ctypes.POINTER(WeightParams), vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp], ctypes.c_int),
+    "dicp_window_reduce": ([i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, vp], ctypes.c_int),
+    "dicp_permute_add_rows": ([i32, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp], ctypes.c_int),
     "dicp_gather_rows": ([i32, vp, vp, i32, i32, i32, i32, vp, vp], ctypes.c_int),
     "dicp_scatter_add_rows": ([i32, vp, vp, i32, i32, i32, i32, vp, vp], ctypes.c_int),
     "dicp_accumulate": ([i32, ctypes.POINTER(WeightParams), vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp, i64, vp], ctypes.c_int),

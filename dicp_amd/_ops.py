@@ -155,6 +155,17 @@ def gather_rows(y, idx):
     return _GatherRows.apply(y.contiguous(), idx)
 
 
+def _gather_rows_raw(y, idx):
+    """y (N,m,c), idx (N,k) int32 -> (N,k,c) = y[b, clamp(idx[b,s])] (dicp_gather_rows, no autograd)."""
+    y = y.contiguous()
+    N, m, c = y.shape
+    k = idx.shape[1]
+    out = torch.empty((N, k, c), dtype=y.dtype, device=y.device)
+    with torch.cuda.device(y.device):
+        _lib.check(_lib.load().dicp_gather_rows(_DT[y.dtype], _p(y), _p(idx), N, k, m, c, _p(out), _stream()), "dicp_gather_rows")
+    return out
+
+
 class _GumbelNN(torch.autograd.Function):
     """nn.__diff_nn_gumbel (nn.py:43-70) through dicp_gumbel_nn / dicp_gumbel_nn_bwd."""
 
@@ -284,9 +295,7 @@ class LoopConfig:
     match_ratio_thresh: float
     knn_variant: int = _lib.KNN_AUTO
     sweep_resort: tuple = tuple(int(v) for v in os.environ.get("DICP_SWEEP_RESORT", "0,1").split(","))  # iterations at which the sweep kNN re-sorts its queries by x
-    # backward through the owner-computes kernel (no global atomics).  Measured SLOWER than the row-coalesced
-    # atomic kernel on MI355X (0.41 vs 0.28 ms at B=256 x 16384), so it is opt-in: DICP_BWD_OWNED=1
-    bwd_owned: bool = False
+    bwd_window: bool = True       # sweep path: backward in sorted space (LDS window + full-line atomic flush)
     stats_out: object = None      # optional dict: receives "knn_pairs" (pairs scored by the sweep kNN)
     sync_every: object = None     # tolerance mode: iterations between the host's all-converged checks (None = auto)
     timing_events: object = None  # optional object with .handles(K) -> ctypes array of 4*K hipEvent_t (bench.py)
@@ -308,6 +317,7 @@ def _pose_from_T(T):
     return torch.cat((T[:, :3, :3].reshape(N, 9), T[:, :3, 3]), dim=1).contiguous()
 
 
+WINDOW_MIN_ITERS = 3            # query orders used by fewer iterations than this take the atomic backward (see ICPLoop.backward)
 HIST_CHUNK_BYTES = 1 << 29      # per-iteration histories (indices, weights) are allocated in slabs of at most this size
 
 
@@ -353,7 +363,7 @@ class ICPLoop(torch.autograd.Function):
             if kind == _lib.KNN_AUTO:
                 kind = auto_knn_kind(N, n, m)
             sweep = SweepIndex(tgt) if kind == _lib.KNN_SWEEP else None
-            owned = sweep is not None and need_grad and cfg.bwd_owned
+            owned = sweep is not None and need_grad and cfg.bwd_window
             tgt4 = sweep.tgs4 if sweep is not None else pack_target(tgt)
             m_pad = tgt4.shape[1]
             nblk = lib.dicp_accumulate_blocks(n)
@@ -474,46 +484,74 @@ class ICPLoop(torch.autograd.Function):
         m, c = tgt.shape[1], tgt.shape[2]
         with torch.cuda.device(dev):
             st = _stream()
-            nblk = lib.dicp_owned_tiles(code, m_pad) if owned else lib.dicp_accumulate_blocks(n)
             gT = gT.contiguous()
             gpose = torch.cat((gT[:, :3, :3].reshape(N, 9), gT[:, :3, 3]), dim=1).to(torch.float64).contiguous()
             gtmp = torch.empty_like(gpose)
-            gsrc = torch.zeros_like(src)
-            want_tgt = ctx.needs_input_grad[1]
+            want_tgt, want_w = ctx.needs_input_grad[1], ctx.needs_input_grad[3]
             cv = 6 if cfg.icp_type == "pt2pl" else 3
-            if owned:       # target gradients accumulate in SORTED order, un-permuted once at the end
-                gts = torch.zeros((N, m_pad, cv), dtype=dt, device=dev) if want_tgt else None
-                gacc = gts
-            else:
-                gacc = torch.zeros_like(tgt) if want_tgt else None
-            gw = torch.zeros_like(w0c)
+            gsrc = torch.zeros_like(src)
+            gw = torch.zeros_like(w0c) if want_w else None
+            gtgt = torch.zeros_like(tgt) if want_tgt else None
+            # Two forms of accumulate_bwd.  Atomic form (dicp_accumulate_bwd): original order, no set-up.  Windowed form
+            # (dicp_accumulate_bwd_window, sweep path): everything in sorted space -- one sorted copy of the source /
+            # weights and one gradient accumulator per query order, target rows in the sweep's order, per-block slabs
+            # for the target gradient -- 2.4x faster per iteration but ~0.4 ms of set-up and un-permuting per order,
+            # so an order is worth it from WINDOW_MIN_ITERS iterations on (the pre-resort order of iteration 0 is not).
+            iters_of = {}
+            for (a, b, q) in segs:
+                iters_of[q] = iters_of.get(q, 0) + (b - a)
+            win = sorted(q for q in iters_of if owned and iters_of[q] >= WINDOW_MIN_ITERS)
+            nblk_a, nblk_w = lib.dicp_accumulate_blocks(n), lib.dicp_window_blocks(code, n, m_pad)
+            if win:
+                src_q = {q: _gather_rows_raw(src, qorders[q]) for q in win}
+                w_q = {q: _gather_rows_raw(w0c.unsqueeze(-1), qorders[q]).squeeze(-1) for q in win}
+                gsrc_q = {q: torch.zeros_like(src) for q in win}
+                gw_q = {q: torch.zeros_like(w0c) if want_w else None for q in win}
+                tgt_s = _gather_rows_raw(tgt, tperm)                       # (N,m_pad,c); pad slots repeat row m-1 (never matched)
+                # windows placed by the matches of the LAST iteration that used the order
+                last_k = {q: max(b for (_, b, qq) in segs if qq == q) - 1 for q in win}
+                ref_q = {q: spos_slabs[last_k[q] // kc][last_k[q] % kc] for q in win}
+                wt = lib.dicp_window_rows(code)
+                slab_q = {q: torch.zeros((N, nblk_w, wt, cv), dtype=dt, device=dev) if want_tgt else None for q in win}
+                gfar = torch.zeros((N, m_pad, cv), dtype=dt, device=dev) if want_tgt else None
             gs = torch.empty((N, 36), dtype=dt, device=dev)
             gb = torch.empty((N, 6), dtype=dt, device=dev)
-            bwdp = torch.empty((N, nblk, _lib.NBWD_PAD), dtype=dt, device=dev)
+            bwd_flat = torch.empty((N * max(nblk_a, nblk_w) * _lib.NBWD_PAD,), dtype=dt, device=dev)
+            bwdp = {False: bwd_flat[:N * nblk_a * _lib.NBWD_PAD].view(N, nblk_a, _lib.NBWD_PAD),
+                    True: bwd_flat[:N * nblk_w * _lib.NBWD_PAD].view(N, nblk_w, _lib.NBWD_PAD)}
             ev = cfg.timing_events
             events = ev.handles(Kmax) if ev is not None else None
-            have = 0
+            have, form = 0, None
             for (k0, k1, q) in reversed(segs):
+                w_form = q in win
+                if have and w_form != form:     # the partials of the other form have another block count: fold them in here
+                    gpose += bwdp[form].sum(dim=1)[:, :12].to(torch.float64)
+                    have = 0
+                form = w_form
                 j = k0 // kc
                 base = j * kc
                 LB = _lib.LoopBuffers(
-                    src=_p(src), tgt=_p(tgt), w_init=_p(w0c), c=c, K=Kmax, knn_variant=kind, m_pad=m_pad,
-                    tperm=_p(tperm), qorder=_p(qorders[q]) if owned else None, idx_per_iter=1,
-                    spos=ctypes.c_void_p(spos_slabs[j].data_ptr() - base * N * n * 4) if owned else None,
+                    src=_p(src_q[q]) if w_form else _p(src), tgt=_p(tgt_s) if w_form else _p(tgt),
+                    w_init=_p(w_q[q]) if w_form else _p(w0c), c=c, K=Kmax, knn_variant=kind, m_pad=m_pad, idx_per_iter=1,
+                    spos=ctypes.c_void_p(spos_slabs[j].data_ptr() - base * N * n * 4) if w_form else None,
+                    spos_ref=_p(ref_q[q]) if w_form else None, gts_far=_p(gfar) if w_form else None,
                     poses=_p(poses), deltas=_p(deltas), areg=_p(areg), alive=_p(alive),
                     idx=ctypes.c_void_p(idx_slabs[j].data_ptr() - base * N * n * 4), events=events)
                 _lib.check(lib.dicp_icp_backward(code, ctypes.byref(P), ctypes.byref(LB), N, n, m, int(cfg.dim), _p(gpose), _p(gtmp), have,
-                                                 _p(gs), _p(gb), _p(gsrc), _p(gacc), _p(gw), _p(bwdp), k0, k1, st), "dicp_icp_backward")
+                                                 _p(gs), _p(gb), _p(gsrc_q[q]) if w_form else _p(gsrc), _p(slab_q[q]) if w_form else _p(gtgt),
+                                                 _p(gw_q[q]) if w_form else _p(gw), _p(bwdp[form]), k0, k1, st), "dicp_icp_backward")
                 have = 1
             if have:
-                gpose = gpose + bwdp.sum(dim=1)[:, :12].to(torch.float64)
-            gtgt = None
-            if want_tgt:
-                if owned:   # sorted row s holds the gradient of original row tperm[s]
-                    gtgt = torch.zeros_like(tgt)
-                    gtgt[:, :, :cv].scatter_(1, tperm[:, :m].long().unsqueeze(-1).expand(-1, -1, cv), gts[:, :m])
-                else:
-                    gtgt = gacc
+                gpose = gpose + bwdp[form].sum(dim=1)[:, :12].to(torch.float64)
+            for i, q in enumerate(win):     # slot s of order q is source point qorders[q][s]
+                _lib.check(lib.dicp_permute_add_rows(code, _p(gsrc_q[q]), _p(qorders[q]), N, n, n, n, 3, 3, _p(gsrc), n, 3, st),
+                           "dicp_permute_add_rows")
+                if want_w:
+                    _lib.check(lib.dicp_permute_add_rows(code, _p(gw_q[q]), _p(qorders[q]), N, n, n, n, 1, 1, _p(gw), n, 1, st),
+                               "dicp_permute_add_rows")
+                if want_tgt:                # slabs + out-of-window rows -> original target order
+                    _lib.check(lib.dicp_window_reduce(code, _p(slab_q[q]), _p(ref_q[q]), _p(tperm), _p(gfar) if i == 0 else None,
+                                                      N, n, m, m_pad, cv, _p(gtgt), c, st), "dicp_window_reduce")
             gT0 = torch.zeros((N, 4, 4), dtype=dt, device=dev)
             gT0[:, :3, :3] = gpose[:, :9].reshape(N, 3, 3).to(dt)
             gT0[:, :3, 3] = gpose[:, 9:].to(dt)

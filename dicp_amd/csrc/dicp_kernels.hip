@@ -9,6 +9,7 @@
 //   accumulate_kernel      residual/weights/Jacobian/normal-equation sums, per-block partials
 //   step_kernel            per-cloud reduce + 6x6 solve + pose update + loop bookkeeping
 //   accumulate_bwd_kernel  adjoint of accumulate_kernel (recompute from idx and pose)
+//   accumulate_bwd_window  the same adjoint in sorted space (sweep path): LDS window + full-line atomic flush
 //   step_bwd_kernel        adjoint of step_kernel
 //   loss_weight kernels    loss.get_weight for direct users of the class
 //
@@ -736,33 +737,64 @@ __global__ __launch_bounds__(BLOCK) void accumulate_bwd_kernel(WeightParams P, c
     block_reduce_store<T, NBWD, NBWD_PAD>(acc, bwd_partials + ((size_t)cloud * bpc + blk) * NBWD_PAD, red);
 }
 
-// Owner-computes form of the same backward, for the sorted-sweep path: NO global atomics.
-// A block owns TT consecutive SORTED targets of one cloud and keeps their gradient rows in LDS.  It scans the
-// cloud's matches in sorted-query order (spos[s] = sorted position of query s's neighbour, written by the sweep
-// kernel; nearly monotone in s, so whole waves either match or skip), runs the per-point adjoint for the
-// queries whose neighbour it owns, adds their target rows with LDS atomics, and finally adds its tile to the
-// sorted-order gradient buffer with plain coalesced read-modify-writes (it is the only writer of those rows).
-// Every query is matched by exactly one block, so src-bar / w-bar writes stay exclusive as well.
-template <typename T, int MODE, int TT>
-__global__ __launch_bounds__(BLOCK) void accumulate_bwd_owned_kernel(WeightParams P, const T* __restrict__ src, const T* __restrict__ tgt, int c,
-                                                                     const int32_t* __restrict__ spos, const int32_t* __restrict__ qorder,
-                                                                     const int32_t* __restrict__ tperm, const T* __restrict__ pose,
-                                                                     const T* __restrict__ w_init, const T* __restrict__ alive,
-                                                                     const T* __restrict__ gs, const T* __restrict__ gb,
-                                                                     int N, int n, int m, int m_pad, int tpc,
-                                                                     T* __restrict__ gsrc, T* __restrict__ gts /* (N,m_pad,CV) sorted order */,
-                                                                     T* __restrict__ gw, T* __restrict__ bwd_partials) {
+// Windowed form of the same backward, for the sorted-sweep path.  Everything is in SORTED space: slot s of a
+// cloud is the s-th query in the x-order the sweep used, spos[s] the sorted position of its neighbour, and
+// src_s / w_s / tgt_s are the caller's copies in those orders, so every stream is coalesced.  Queries that are
+// neighbours in x match targets that are neighbours in x: a block of `spb` consecutive slots covers a window of
+// WT consecutive sorted target rows.  Its threads leave their target-row contributions in LDS and thread each one
+// onto a per-row list (ONE LDS exchange per slot: head[row] <-> slot); then every row is summed by the one thread
+// that owns it and added to the block's OWN slab (N, blocks, WT, CV) with plain read-modify-writes -- no float
+// atomics anywhere on the common path.  Measured at the benchmark shape: global float atomics for the flush cost
+// 0.145 ms per launch and do not overlap the streams (a CU's vector-memory path is in order), and 6 LDS float
+// atomics per slot (ds_add_f32) cost 0.10 ms -- about 137 cycles per wave-instruction.
+// The windows of neighbouring blocks overlap; dicp_window_reduce sums the slabs into the target gradient once per
+// call.  The window origins come from spos_ref (the matches of ONE reference iteration, the same for every launch
+// that adds into a slab), so a slab row means the same target row in every iteration.  A match outside the window
+// (outlier, or an iteration whose matches moved) goes to gts_far with atomics: locality only decides the speed.
+template <typename T> struct WindowRows;
+template <> struct WindowRows<float>  { static constexpr int v = 1536; };    // 36 KiB of rows at 6 columns: 4 blocks per CU
+template <> struct WindowRows<double> { static constexpr int v = 768; };
+
+// slots per block: two thirds of the window for the span of the block's own slots (slots * m/n sorted targets),
+// one third for the spread of the matches around the diagonal (measured at the benchmark shape: median 80 rows,
+// 99th percentile 486)
+__host__ __device__ inline int window_slots(int WT, int n, int m_pad) {
+    long s = (long)(WT - WT / 3) * n / (m_pad > 0 ? m_pad : 1);
+    s = (s / BLOCK) * BLOCK;
+    return (int)(s < BLOCK ? BLOCK : (s > 4 * BLOCK ? 4 * BLOCK : s));        // <= SPB of the kernel
+}
+
+// first sorted row of block blk's window: centred on the reference neighbour of the block's middle slot
+// (robust against outliers at the ends), a multiple of 16 rows
+__device__ __forceinline__ int window_origin(const int32_t* __restrict__ sp_ref_c, int blk, int spb, int n, int m_pad, int WT) {
+    if (m_pad <= WT) return 0;
+    const int ctr = max(sp_ref_c[min(blk * spb + spb / 2, n - 1)], 0);
+    return min(max(ctr - WT / 2, 0), m_pad - WT) & ~15;
+}
+
+template <typename T, int MODE, int WT>
+__global__ __launch_bounds__(BLOCK) void accumulate_bwd_window_kernel(WeightParams P, const T* __restrict__ src_s, const T* __restrict__ tgt_s, int c,
+                                                                      const int32_t* __restrict__ spos, const int32_t* __restrict__ spos_ref,
+                                                                      const T* __restrict__ pose, const T* __restrict__ w_s, const T* __restrict__ alive,
+                                                                      const T* __restrict__ gs, const T* __restrict__ gb,
+                                                                      int N, int n, int m_pad, int spb, int bpc,
+                                                                      T* __restrict__ gsrc_s, T* __restrict__ slab /* (N,bpc,WT,CV) */,
+                                                                      T* __restrict__ gts_far /* (N,m_pad,CV) */,
+                                                                      T* __restrict__ gw_s, T* __restrict__ bwd_partials) {
     constexpr int CV = (MODE == MODE_PT2PL) ? 6 : 3;
-    constexpr int SEG = 4096;                               // sorted queries scanned per compaction round
     __shared__ T red[(BLOCK / WAVE) * NBWD_PAD];
-    __shared__ T rows[TT * CV];
-    __shared__ int list[SEG];
-    __shared__ int cnt;
-    int cloud, tile;
-    if (!decode_block(tpc, N, cloud, tile)) return;
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
-    const int lo = tile * TT, hi = min(lo + TT, m_pad);
-    for (int k = tid; k < TT * CV; k += BLOCK) rows[k] = T(0);
+    constexpr int SPB = 4 * BLOCK;                          // window_slots() never exceeds this
+    __shared__ T contrib[SPB * CV];                         // target-row contribution of each of the block's slots
+    __shared__ int head[WT], next[SPB];                     // per window row: list of the slots that matched it
+    int cloud, blk;
+    if (!decode_block(bpc, N, cloud, blk)) return;
+    const int tid = threadIdx.x;
+    const int s0 = blk * spb, s1 = min(n, s0 + spb);
+    const int32_t* __restrict__ sp_c = spos + (size_t)cloud * n;
+    const int lo = window_origin(spos_ref + (size_t)cloud * n, blk, spb, n, m_pad, WT);
+    const int hi = min(lo + WT, m_pad);
+    if (slab)
+        for (int k = tid; k < hi - lo; k += BLOCK) head[k] = -1;
     T C[9], r[3], Gs[36], Gb[6];
     load_pose(pose, cloud, C, r);
 #pragma unroll
@@ -773,62 +805,135 @@ __global__ __launch_bounds__(BLOCK) void accumulate_bwd_owned_kernel(WeightParam
     T acc[NBWD];
 #pragma unroll
     for (int k = 0; k < NBWD; ++k) acc[k] = T(0);
-    const int32_t* __restrict__ sp_c = spos + (size_t)cloud * n;
-    for (int seg = 0; seg < n; seg += SEG) {
-        if (tid == 0) cnt = 0;
-        __syncthreads();
-        // phase 1: which sorted slots of this segment have their neighbour in [lo, hi)?  4 independent loads in
-        // flight per thread; matches are appended to an LDS list (wave ballot + one LDS atomic per wave).
-        for (int it = 0; it < SEG; it += 4 * BLOCK) {
-            int pos[4];
+    __syncthreads();
+    T* gfar = gts_far ? gts_far + (size_t)cloud * m_pad * CV : nullptr;
+    constexpr int U = 4;                                    // slots per thread in flight: every load of a round is issued
+    for (int base = s0; base < s1; base += U * BLOCK) {     // before the first dependent use (the block is latency-bound)
+        bool on[U];
+        int pos[U];
+        T p[U][3], y[U][3], nrm[U][3], wv[U], g0[U][3], gwv[U];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int sl = seg + it + e * BLOCK + tid;
-                pos[e] = (sl < n && it + e * BLOCK + tid < SEG) ? sp_c[sl] : -1;
-            }
+        for (int u = 0; u < U; ++u) {
+            const int s = base + u * BLOCK + tid;
+            on[u] = s < s1;
+            const size_t pt = (size_t)cloud * n + (on[u] ? s : s0);
+            pos[u] = min(max(sp_c[on[u] ? s : s0], 0), m_pad - 1);  // -1 (no neighbour: non-finite input) -> row 0
+            const T* spp = src_s + pt * 3;
+            p[u][0] = spp[0]; p[u][1] = spp[1]; p[u][2] = spp[2];
+            wv[u] = w_s[pt];
+            const T* gsp = gsrc_s + pt * 3;
+            g0[u][0] = gsp[0]; g0[u][1] = gsp[1]; g0[u][2] = gsp[2];
+            gwv[u] = gw_s ? gw_s[pt] : T(0);
+        }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const bool hit = pos[e] >= lo && pos[e] < hi;
-                const unsigned long long mask = __ballot(hit);
-                if (mask) {
-                    int base = 0;
-                    if (lane == 0) base = atomicAdd(&cnt, __popcll(mask));
-                    base = __shfl(base, 0);
-                    if (hit) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = seg + it + e * BLOCK + tid;
+        for (int u = 0; u < U; ++u) {
+            const T* yp = tgt_s + ((size_t)cloud * m_pad + pos[u]) * c;
+            y[u][0] = yp[0]; y[u][1] = yp[1]; y[u][2] = yp[2];
+            nrm[u][0] = nrm[u][1] = nrm[u][2] = T(0);
+            if (MODE == MODE_PT2PL) { nrm[u][0] = yp[3]; nrm[u][1] = yp[4]; nrm[u][2] = yp[5]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!on[u]) continue;
+            const size_t pt = (size_t)cloud * n + base + u * BLOCK + tid;
+            T gp[3], gy[3], gn[3], gw0;
+            point_backward<T, MODE>(P, C, r, p[u], y[u], nrm[u], wv[u] * live, Gs, Gb, gp, gy, gn, gw0, acc, acc + 9);
+            T* gsp = gsrc_s + pt * 3;
+            gsp[0] = g0[u][0] + gp[0]; gsp[1] = g0[u][1] + gp[1]; gsp[2] = g0[u][2] + gp[2];
+            if (gw_s) gw_s[pt] = gwv[u] + gw0 * live;
+            if (slab) {
+                if (pos[u] >= lo && pos[u] < hi) {
+                    const int sl = base - s0 + u * BLOCK + tid;     // < spb <= SPB
+                    T* row = contrib + sl * CV;
+                    row[0] = gy[0]; row[1] = gy[1]; row[2] = gy[2];
+                    if (MODE == MODE_PT2PL) { row[3] = gn[0]; row[4] = gn[1]; row[5] = gn[2]; }
+                    next[sl] = atomicExch(&head[pos[u] - lo], sl);
+                } else {
+                    T* row = gfar + (size_t)pos[u] * CV;
+                    unsafeAtomicAdd(&row[0], gy[0]); unsafeAtomicAdd(&row[1], gy[1]); unsafeAtomicAdd(&row[2], gy[2]);
+                    if (MODE == MODE_PT2PL) { unsafeAtomicAdd(&row[3], gn[0]); unsafeAtomicAdd(&row[4], gn[1]); unsafeAtomicAdd(&row[5], gn[2]); }
                 }
             }
         }
-        __syncthreads();
-        // phase 2: dense pass over the matches
-        const int total = cnt;
-        for (int k = tid; k < total; k += BLOCK) {
-            const int sl = list[k];
-            const int pos = sp_c[sl];
-            const int i = qorder ? qorder[(size_t)cloud * n + sl] : sl;
-            const size_t pt = (size_t)cloud * n + i;
-            const T* spp = src + pt * 3;
-            const T p[3] = {spp[0], spp[1], spp[2]};
-            const int j = tperm[(size_t)cloud * m_pad + pos];
-            const T* yp = tgt + ((size_t)cloud * m + j) * c;
-            const T y[3] = {yp[0], yp[1], yp[2]};
-            T nrm[3] = {T(0), T(0), T(0)};
-            if (MODE == MODE_PT2PL) { nrm[0] = yp[3]; nrm[1] = yp[4]; nrm[2] = yp[5]; }
-            T gp[3], gy[3], gn[3], gw0;
-            point_backward<T, MODE>(P, C, r, p, y, nrm, w_init[pt] * live, Gs, Gb, gp, gy, gn, gw0, acc, acc + 9);
-            T* gsp = gsrc + pt * 3;
-            gsp[0] += gp[0]; gsp[1] += gp[1]; gsp[2] += gp[2];
-            if (gw) gw[pt] += gw0 * live;
-            T* row = rows + (pos - lo) * CV;
-            atomicAdd(&row[0], gy[0]); atomicAdd(&row[1], gy[1]); atomicAdd(&row[2], gy[2]);
-            if (MODE == MODE_PT2PL) { atomicAdd(&row[3], gn[0]); atomicAdd(&row[4], gn[1]); atomicAdd(&row[5], gn[2]); }
+    }
+    __syncthreads();
+    if (slab) {     // one thread per window row; this block is the only writer of its slab rows
+        T* out = slab + ((size_t)cloud * bpc + blk) * (WT * CV);
+        for (int rr = tid; rr < hi - lo; rr += BLOCK) {
+            int h = head[rr];
+            if (h < 0) continue;
+            T sum[CV];
+#pragma unroll
+            for (int k = 0; k < CV; ++k) sum[k] = T(0);
+            for (int guard = 0; h >= 0 && guard < SPB; ++guard) {       // every slot is on at most one list
+#pragma unroll
+                for (int k = 0; k < CV; ++k) sum[k] += contrib[h * CV + k];
+                h = next[h];
+            }
+#pragma unroll
+            for (int k = 0; k < CV; ++k) out[rr * CV + k] += sum[k];
         }
+    }
+    block_reduce_store<T, NBWD, NBWD_PAD>(acc, bwd_partials + ((size_t)cloud * bpc + blk) * NBWD_PAD, red);
+}
+
+// gtgt[b][tperm[s]][col] += gts_far[b][s][col] + sum over the blocks whose window covers sorted row s of their
+// slab rows: the once-per-call end of the windowed backward (also undoes the sorted target order).
+template <typename T, int WT>
+__global__ __launch_bounds__(BLOCK) void window_reduce_kernel(const T* __restrict__ slab, const int32_t* __restrict__ spos_ref,
+                                                              const int32_t* __restrict__ tperm, const T* __restrict__ gts_far,
+                                                              int N, int n, int m, int m_pad, int cv, int spb, int bpc, int rpc,
+                                                              T* __restrict__ gtgt, int c) {
+    constexpr int MAXB = 256;                               // window blocks per cloud handled per pass
+    __shared__ int origin[MAXB];
+    int cloud, rb;
+    if (!decode_block(rpc, N, cloud, rb)) return;
+    const int tid = threadIdx.x;
+    const int e0 = rb * (BLOCK * 4);                        // this block's elements of the (m*cv) row-major gradient
+    T acc[4] = {T(0), T(0), T(0), T(0)};
+    for (int b0 = 0; b0 < bpc; b0 += MAXB) {
         __syncthreads();
+        for (int b = tid; b < min(MAXB, bpc - b0); b += BLOCK)
+            origin[b] = window_origin(spos_ref + (size_t)cloud * n, b0 + b, spb, n, m_pad, WT);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * BLOCK + tid;
+            if (e >= m * cv) continue;
+            const int s = e / cv, col = e - s * cv;
+            for (int b = 0; b < min(MAXB, bpc - b0); ++b) {
+                const int lo = origin[b];
+                if (s >= lo && s < lo + WT)
+                    acc[u] += slab[(((size_t)cloud * bpc + b0 + b) * WT + (s - lo)) * cv + col];
+            }
+        }
     }
-    if (gts) {
-        T* out = gts + ((size_t)cloud * m_pad + lo) * CV;
-        for (int k = tid; k < (hi - lo) * CV; k += BLOCK) out[k] += rows[k];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * BLOCK + tid;
+        if (e >= m * cv) continue;
+        const int s = e / cv, col = e - s * cv;
+        T v = acc[u];
+        if (gts_far) v += gts_far[((size_t)cloud * m_pad + s) * cv + col];
+        const int j = tperm[(size_t)cloud * m_pad + s];
+        if (j >= 0 && j < m) gtgt[((size_t)cloud * m + j) * c + col] += v;
     }
-    block_reduce_store<T, NBWD, NBWD_PAD>(acc, bwd_partials + ((size_t)cloud * tpc + tile) * NBWD_PAD, red);
+}
+
+// out[b][perm[b][s]][0..cols) += in[b][s][0..cols) for s < cnt: undoes a sorted order.  perm must be injective per
+// cloud (plain read-modify-write, no atomics).
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void permute_add_rows_kernel(const T* __restrict__ in, const int32_t* __restrict__ perm,
+                                                                 int N, int cnt, int in_rows, int perm_rows, int c_in, int cols,
+                                                                 T* __restrict__ out, int out_rows, int c_out) {
+    const size_t e = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= (size_t)N * cnt * cols) return;
+    const size_t rowi = e / cols;
+    const int k = (int)(e % cols);
+    const int b = (int)(rowi / cnt), s = (int)(rowi % cnt);
+    const int j = perm[(size_t)b * perm_rows + s];
+    if (j < 0 || j >= out_rows) return;
+    out[((size_t)b * out_rows + j) * c_out + k] += in[((size_t)b * in_rows + s) * c_in + k];
 }
 
 // ---------------------------------------------------------------------- step bwd
@@ -1585,29 +1690,70 @@ int dicp_kabsch_bwd(int dtype, const void* src, const void* tgt, int c, const in
     return launch_status();
 }
 
-int dicp_owned_tiles(int dtype, int m_pad) {
-    const int TT = (dtype == DICP_F32) ? 2048 : 1024;
-    return m_pad <= 0 ? 0 : (m_pad + TT - 1) / TT;
+int dicp_window_blocks(int dtype, int n, int m_pad) {
+    if (n <= 0 || m_pad <= 0) return 0;
+    const int spb = window_slots(dtype == DICP_F32 ? WindowRows<float>::v : WindowRows<double>::v, n, m_pad);
+    return (n + spb - 1) / spb;
 }
 
-int dicp_accumulate_bwd_owned(int dtype, const dicp_weight_params* prm, const void* src, const void* tgt, int c,
-                              const int32_t* spos, const int32_t* qorder, const int32_t* tperm, const void* pose,
-                              const void* w_init, const void* alive, const void* gs, const void* gb,
-                              int N, int n, int m, int m_pad, void* gsrc, void* gts, void* gw, void* bwd_partials, void* stream) {
+int dicp_window_rows(int dtype) { return dtype == DICP_F32 ? WindowRows<float>::v : WindowRows<double>::v; }
+
+int dicp_accumulate_bwd_window(int dtype, const dicp_weight_params* prm, const void* src_s, const void* tgt_s, int c,
+                               const int32_t* spos, const int32_t* spos_ref, const void* pose, const void* w_s, const void* alive,
+                               const void* gs, const void* gb, int N, int n, int m_pad, void* gsrc_s, void* slab, void* gts_far,
+                               void* gw_s, void* bwd_partials, void* stream) {
     if (const int e = check_params(prm, c)) return e;
-    if (!src || !tgt || !spos || !tperm || !w_init || !gs || !gb || !gsrc || !bwd_partials) return DICP_ERR_NULL;
+    if (!src_s || !tgt_s || !spos || !spos_ref || !pose || !w_s || !gs || !gb || !gsrc_s || !bwd_partials || (slab && !gts_far))
+        return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
-    if (N <= 0 || n <= 0 || m <= 0 || m_pad != dicp_padded_targets(m)) return DICP_ERR_SHAPE;
+    if (N <= 0 || n <= 0 || m_pad <= 0 || m_pad % KNN_PAD) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     begin_launch();
     const WeightParams P = to_params(prm);
-    const int tpc = dicp_owned_tiles(dtype, m_pad);
-    const unsigned g = grid_for(N, tpc);
-#define DICP_OWN(T, M, TT) accumulate_bwd_owned_kernel<T, M, TT><<<g, BLOCK, 0, st>>>(P, (const T*)src, (const T*)tgt, c, spos, qorder, tperm, \
-        (const T*)pose, (const T*)w_init, (const T*)alive, (const T*)gs, (const T*)gb, N, n, m, m_pad, tpc, (T*)gsrc, (T*)gts, (T*)gw, (T*)bwd_partials)
-    if (dtype == DICP_F32) { if (P.mode == MODE_PT2PL) DICP_OWN(float, MODE_PT2PL, 2048); else DICP_OWN(float, MODE_PT2PT, 2048); }
-    else                   { if (P.mode == MODE_PT2PL) DICP_OWN(double, MODE_PT2PL, 1024); else DICP_OWN(double, MODE_PT2PT, 1024); }
-#undef DICP_OWN
+    const int bpc = dicp_window_blocks(dtype, n, m_pad);
+    const unsigned g = grid_for(N, bpc);
+#define DICP_WIN(T, M) do { constexpr int WT = WindowRows<T>::v; const int spb = window_slots(WT, n, m_pad); \
+        accumulate_bwd_window_kernel<T, M, WT><<<g, BLOCK, 0, st>>>(P, (const T*)src_s, (const T*)tgt_s, c, spos, spos_ref, (const T*)pose, \
+            (const T*)w_s, (const T*)alive, (const T*)gs, (const T*)gb, N, n, m_pad, spb, bpc, (T*)gsrc_s, (T*)slab, (T*)gts_far, (T*)gw_s, \
+            (T*)bwd_partials); } while (0)
+    if (dtype == DICP_F32) { if (P.mode == MODE_PT2PL) DICP_WIN(float, MODE_PT2PL); else DICP_WIN(float, MODE_PT2PT); }
+    else                   { if (P.mode == MODE_PT2PL) DICP_WIN(double, MODE_PT2PL); else DICP_WIN(double, MODE_PT2PT); }
+#undef DICP_WIN
+    return launch_status();
+}
+
+int dicp_window_reduce(int dtype, const void* slab, const int32_t* spos_ref, const int32_t* tperm, const void* gts_far,
+                       int N, int n, int m, int m_pad, int cv, void* gtgt, int c, void* stream) {
+    if (!slab || !spos_ref || !tperm || !gtgt) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0 || n <= 0 || m <= 0 || m_pad != dicp_padded_targets(m) || (cv != 3 && cv != 6) || c < cv) return DICP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    begin_launch();
+    const int bpc = dicp_window_blocks(dtype, n, m_pad);
+    const int rpc = (m * cv + BLOCK * 4 - 1) / (BLOCK * 4);
+    const unsigned g = grid_for(N, rpc);
+    if (dtype == DICP_F32) {
+        constexpr int WT = WindowRows<float>::v;
+        window_reduce_kernel<float, WT><<<g, BLOCK, 0, st>>>((const float*)slab, spos_ref, tperm, (const float*)gts_far, N, n, m, m_pad, cv,
+                                                              window_slots(WT, n, m_pad), bpc, rpc, (float*)gtgt, c);
+    } else {
+        constexpr int WT = WindowRows<double>::v;
+        window_reduce_kernel<double, WT><<<g, BLOCK, 0, st>>>((const double*)slab, spos_ref, tperm, (const double*)gts_far, N, n, m, m_pad, cv,
+                                                               window_slots(WT, n, m_pad), bpc, rpc, (double*)gtgt, c);
+    }
+    return launch_status();
+}
+
+int dicp_permute_add_rows(int dtype, const void* in, const int32_t* perm, int N, int cnt, int in_rows, int perm_rows, int c_in, int cols,
+                          void* out, int out_rows, int c_out, void* stream) {
+    if (!in || !perm || !out) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0 || cnt <= 0 || cnt > in_rows || cnt > perm_rows || cols <= 0 || cols > c_in || cols > c_out || out_rows <= 0) return DICP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    begin_launch();
+    const unsigned g = blocks_for((size_t)N * cnt * cols);
+    if (dtype == DICP_F32) permute_add_rows_kernel<float><<<g, BLOCK, 0, st>>>((const float*)in, perm, N, cnt, in_rows, perm_rows, c_in, cols, (float*)out, out_rows, c_out);
+    else                   permute_add_rows_kernel<double><<<g, BLOCK, 0, st>>>((const double*)in, perm, N, cnt, in_rows, perm_rows, c_in, cols, (double*)out, out_rows, c_out);
     return launch_status();
 }
 
@@ -1670,13 +1816,13 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
 int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_buffers* B, int N, int n, int m, int dim,
                       double* gpose, double* gpose_tmp, int have_partials, void* gs, void* gb, void* gsrc, void* gtgt, void* gw,
                       void* bwd_partials, int k0, int k1, void* stream) {
-    if (!prm || !B || !B->src || !B->tgt || !B->w_init || !B->poses || !B->deltas || !B->areg || !B->alive || !B->idx ||
+    if (!prm || !B || !B->src || !B->tgt || !B->w_init || !B->poses || !B->deltas || !B->areg || !B->alive || (!B->idx && !B->spos) ||
         !gpose || !gpose_tmp || !gs || !gb || !gsrc || !bwd_partials) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
-    if (k0 < 0 || k1 > B->K || k0 > k1 || !B->idx_per_iter) return DICP_ERR_SHAPE;
+    if (k0 < 0 || k1 > B->K || k0 > k1 || !B->idx_per_iter || (B->spos && (B->m_pad <= 0 || !B->spos_ref))) return DICP_ERR_SHAPE;
     const size_t es = dtype == DICP_F32 ? 4 : 8;
     hipStream_t st = (hipStream_t)stream;
-    const int nblk = B->spos ? dicp_owned_tiles(dtype, B->m_pad) : dicp_accumulate_blocks(n);
+    const int nblk = B->spos ? dicp_window_blocks(dtype, n, B->m_pad) : dicp_accumulate_blocks(n);
     double* gin = gpose;
     double* gout = gpose_tmp;
     for (int k = k1 - 1; k >= k0; --k) {
@@ -1686,10 +1832,10 @@ int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_
                                gs, gb, gout, N, stream);
         if (rc) return rc;
         if (B->events) { if (hipEventRecord((hipEvent_t)B->events[4 * k + 2], st) != hipSuccess) return -(int)hipGetLastError(); }
-        if (B->spos)    // owner-computes form: gtgt is the SORTED-order (N,m_pad,CV) buffer
-            rc = dicp_accumulate_bwd_owned(dtype, prm, B->src, B->tgt, B->c, B->spos + (size_t)k * N * n, B->qorder, B->tperm, pose_k,
-                                           B->w_init, (const char*)B->alive + (size_t)k * N * es, gs, gb, N, n, m, B->m_pad,
-                                           gsrc, gtgt, gw, bwd_partials, stream);
+        if (B->spos)    // windowed form: src / w_init / tgt are the SORTED copies, gsrc / gw accumulate in slot order, gtgt is the slab
+            rc = dicp_accumulate_bwd_window(dtype, prm, B->src, B->tgt, B->c, B->spos + (size_t)k * N * n, B->spos_ref, pose_k, B->w_init,
+                                            (const char*)B->alive + (size_t)k * N * es, gs, gb, N, n, B->m_pad,
+                                            gsrc, gtgt, B->gts_far, gw, bwd_partials, stream);
         else
             rc = dicp_accumulate_bwd(dtype, prm, B->src, B->tgt, B->c, B->idx + (size_t)k * N * n, pose_k, B->w_init,
                                      (const char*)B->alive + (size_t)k * N * es, gs, gb, N, n, m, gsrc, gtgt, gw, bwd_partials, stream);

@@ -76,7 +76,7 @@ int dicp_knn(int dtype, const void* src, const void* pose, const void* tgt4, int
  *   qorder (N,n)       optional: query indices in ascending x (under any recent pose) so that a wave's
  *                      queries are neighbours; NULL = natural order (still exact, less pruning).
  * spos (N,n), optional: spos[b][s] = SORTED position of the neighbour of the query in sorted slot s (-1 if none):
- *   the match list dicp_accumulate_bwd_owned scans.
+ *   what dicp_accumulate_bwd_window consumes.
  * pairs: optional device counter, += number of (query,target) pairs actually scored (roofline accounting).
  * cfg: 0 auto, 1.. = fixed (queries per lane, chunk) launch configuration (tuning). */
 int dicp_knn_sweep(int dtype, const void* src, const void* pose, const void* tgs4, const int32_t* tperm,
@@ -153,8 +153,11 @@ typedef struct dicp_loop_buffers {
     int32_t nbkt;
     int32_t idx_per_iter;    /* 1: idx is (K,N,n) and every iteration keeps its own (needed for backward); 0: (N,n) reused */
     unsigned long long* pairs;   /* sweep only, optional */
-    int32_t* spos;           /* sweep only, optional (K,N,n): per-iteration match lists -> backward uses dicp_accumulate_bwd_owned,
-                                whose gtgt is the sorted-order (N,m_pad,CV) buffer and bwd_partials has dicp_owned_tiles blocks */
+    int32_t* spos;           /* sweep only, optional (K,N,n): per-iteration sorted match positions.  Non-NULL in dicp_icp_backward
+                                selects dicp_accumulate_bwd_window: src / w_init / tgt are then the SORTED copies it documents,
+                                gsrc / gw accumulate in slot order, gtgt is the slab, bwd_partials has dicp_window_blocks blocks */
+    const int32_t* spos_ref; /* backward, windowed form: (N,n) reference matches that place the windows */
+    void* gts_far;           /* backward, windowed form: (N,m_pad,CV) atomically accumulated out-of-window rows */
     void* poses;             /* (K+1,N,12): poses[0] = initial pose, poses[k+1] written by iteration k */
     void* deltas;            /* (N,K,6) */
     void* costs;             /* (N,K) */
@@ -201,16 +204,32 @@ int dicp_accumulate_bwd(int dtype, const dicp_weight_params* prm, const void* sr
                         const void* gs, const void* gb, int N, int n, int m,
                         void* gsrc, void* gtgt, void* gw, void* bwd_partials, void* stream);
 
-/* Owner-computes form of dicp_accumulate_bwd for the sorted-sweep path: no global atomics.  Each block owns a
- * range of SORTED targets (dicp_owned_tiles(dtype, m_pad) ranges per cloud), accumulates their gradient rows in
- * LDS from the matches listed in spos/qorder (as written by / passed to dicp_knn_sweep for that iteration), and
- * adds them to gts (N,m_pad,CV) -- target gradients in SORTED order, CV = 6 for pt2pl, 3 for pt2pt; the caller
- * un-permutes once after the last iteration.  bwd_partials: (N, dicp_owned_tiles, DICP_NBWD_PAD). */
-int dicp_owned_tiles(int dtype, int m_pad);
-int dicp_accumulate_bwd_owned(int dtype, const dicp_weight_params* prm, const void* src, const void* tgt, int c,
-                              const int32_t* spos, const int32_t* qorder, const int32_t* tperm, const void* pose,
-                              const void* w_init, const void* alive, const void* gs, const void* gb,
-                              int N, int n, int m, int m_pad, void* gsrc, void* gts, void* gw, void* bwd_partials, void* stream);
+/* Windowed form of dicp_accumulate_bwd for the sorted-sweep path, entirely in SORTED space and without global
+ * atomics on the common path:
+ *   slot s of cloud b = the s-th query in the order `qorder` that dicp_knn_sweep was given for that iteration;
+ *   src_s (N,n,3) = src rows in slot order, w_s (N,n) likewise; tgt_s (N,m_pad,c) = target rows in the sweep's
+ *   sorted order (row s = tgt[tperm[s]]); spos (N,n) as written by dicp_knn_sweep for THIS iteration;
+ *   spos_ref (N,n) = the spos of ONE reference iteration, the same in every launch that adds into a given slab
+ *   (it places each block's window of dicp_window_rows consecutive sorted target rows; may equal spos).
+ * Accumulates (+=) gsrc_s (N,n,3), gw_s (N,n) in slot order.  Target gradients (slab = NULL: not wanted): each of the
+ * dicp_window_blocks(dtype,n,m_pad) blocks per cloud sums its matches in LDS and adds its window to its own rows
+ * of slab (N, blocks, dicp_window_rows(dtype), CV) with plain read-modify-writes (CV = 6 for pt2pl, 3 for pt2pt);
+ * matches outside a window are added to gts_far (N,m_pad,CV) with atomics.  After the last iteration
+ * dicp_window_reduce adds slab + gts_far into gtgt (N,m,c) in the ORIGINAL target order (+=, call it once per
+ * slab; pass gts_far with one of them).  bwd_partials: (N, dicp_window_blocks, DICP_NBWD_PAD). */
+int dicp_window_blocks(int dtype, int n, int m_pad);
+int dicp_window_rows(int dtype);
+int dicp_accumulate_bwd_window(int dtype, const dicp_weight_params* prm, const void* src_s, const void* tgt_s, int c,
+                               const int32_t* spos, const int32_t* spos_ref, const void* pose, const void* w_s, const void* alive,
+                               const void* gs, const void* gb, int N, int n, int m_pad, void* gsrc_s, void* slab, void* gts_far,
+                               void* gw_s, void* bwd_partials, void* stream);
+int dicp_window_reduce(int dtype, const void* slab, const int32_t* spos_ref, const int32_t* tperm, const void* gts_far,
+                       int N, int n, int m, int m_pad, int cv, void* gtgt, int c, void* stream);
+
+/* out[b][perm[b][s]][k] += in[b][s][k] for s < cnt, k < cols.  in (N,in_rows,c_in), perm (N,perm_rows) injective per
+ * cloud (plain read-modify-write), out (N,out_rows,c_out).  Undoes a sorted order. */
+int dicp_permute_add_rows(int dtype, const void* in, const int32_t* perm, int N, int cnt, int in_rows, int perm_rows, int c_in, int cols,
+                          void* out, int out_rows, int c_out, void* stream);
 
 /* Gumbel-softmax soft correspondence, nn.__diff_nn_gumbel (nn.py:43-70), without the (N,n,m) tensors:
  *   out (N,n,c) = softmax_j((-|x_i - y_j|^2 + g_ij)/tau) @ y,  g = -log(-log(U + eps) + eps)   (nn.py:56-68)

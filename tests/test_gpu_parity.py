@@ -548,15 +548,15 @@ def test_sweep_knn_full_size_and_pruning():
     assert torch.equal(got2, brute)
 
 
-@pytest.mark.parametrize("owned", [False, True])
+@pytest.mark.parametrize("window", [False, True])
 @pytest.mark.parametrize("name,icp_type,diff", [("c1_pt2pt_diff", "pt2pt", True), ("c1_pt2pl_diff", "pt2pl", True)])
-def test_icp_with_sweep_knn_matches_reference(golden, name, icp_type, diff, owned):
+def test_icp_with_sweep_knn_matches_reference(golden, name, icp_type, diff, window):
     g = golden(name)
     trim, huber, tol, max_iter = g["params"]
     src, tgt = t(g["source"], grad=True), t(g["target"], grad=True)
     icp = ICP(icp_type=icp_type, differentiable=diff, max_iterations=int(max_iter), tolerance=float(tol))
     icp.knn_variant = _lib.KNN_SWEEP
-    icp.bwd_owned = owned
+    icp.bwd_window = window
     res = icp.icp(src, tgt, t(g["T_init"]), trim_dist=float(trim), loss_fn={"name": "huber", "metric": float(huber)}, dim=2)
     check_result(res, g)
     res["T"].sum().backward()
@@ -565,25 +565,111 @@ def test_icp_with_sweep_knn_matches_reference(golden, name, icp_type, diff, owne
     assert int(icp.knn_stats["knn_pairs"].item()) > 0
 
 
-@pytest.mark.parametrize("owned", [False, True])
-def test_icp_sweep_equals_brute_on_synthetic(owned):
-    """Sweep kNN (+ optionally the owner-computes, atomics-free backward) against the brute-force path."""
+@pytest.mark.parametrize("window", [False, True])
+def test_icp_sweep_equals_brute_on_synthetic(window):
+    """Sweep kNN (+ the sorted-space windowed backward or the plain atomic one) against the brute-force path.
+    K = 6 with the default re-sort at iteration 1: iteration 0 takes the atomic form, 1..5 the windowed one."""
     N, n, K = 6, 4096, 6
     src, tgt = make_pairs(N, n, n, seed=5, dtype=torch.float32)
+    wgt = torch.rand((N, n), generator=torch.Generator().manual_seed(1)) * 0.5 + 0.5
     outs = []
     for variant in (_lib.KNN_VALU, _lib.KNN_SWEEP):
-        sd, td = src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True)
+        sd, td, wd = src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True), wgt.to(DEV).requires_grad_(True)
         icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
         icp.const_iter = True
         icp.knn_variant = variant
-        icp.bwd_owned = owned
-        out = icp.icp(sd, td, torch.eye(4, device=DEV).repeat(N, 1, 1), trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0})
+        icp.bwd_window = window
+        T0 = torch.eye(4, device=DEV).repeat(N, 1, 1).requires_grad_(True)
+        out = icp.icp(sd, td, T0, weight=wd, trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0})
         out["T"].sum().backward()
-        outs.append((out, sd.grad, td.grad))
+        outs.append((out, sd.grad, td.grad, wd.grad, T0.grad))
     assert torch.equal(outs[0][0]["T"], outs[1][0]["T"]) and torch.equal(outs[0][0]["weights"], outs[1][0]["weights"])
-    # identical forward; the backward sums the same terms in a different grouping (owner-computes vs atomics)
-    np.testing.assert_allclose(npy(outs[0][1]), npy(outs[1][1]), rtol=0, atol=1e-6)
-    np.testing.assert_allclose(npy(outs[0][2]), npy(outs[1][2]), rtol=0, atol=1e-6)
+    # identical forward; the backward sums the same terms in a different grouping (per-row lists vs direct atomics)
+    for k in (1, 2, 3, 4):
+        assert torch.isfinite(outs[1][k]).all()
+        np.testing.assert_allclose(npy(outs[0][k]), npy(outs[1][k]), rtol=0, atol=2e-6 * max(1.0, float(outs[0][k].abs().max())))
+
+
+@pytest.mark.parametrize("dtype,mode,n,m,local", [
+    (torch.float32, "pt2pl", 5000, 5000, True),       # matches near the diagonal: the LDS window takes them
+    (torch.float32, "pt2pt", 3000, 9000, True),       # m = 3n: fewer slots per block
+    (torch.float64, "pt2pl", 2500, 4100, False),      # random matches: almost everything misses the window (global fallback)
+    (torch.float32, "pt2pl", 300, 70, False),         # window covers the whole cloud
+])
+def test_windowed_backward_kernel_equals_atomic_kernel(dtype, mode, n, m, local):
+    """dicp_accumulate_bwd_window (sorted space) + dicp_window_reduce / dicp_permute_add_rows against dicp_accumulate_bwd on the same
+    matches, for arbitrary query orders / target orders / match positions (the kernel must not rely on locality)."""
+    import ctypes
+    lib = _lib.load()
+    code = _ops._DT[dtype]
+    N, c = 3, 6 if mode == "pt2pl" else 3
+    cv = c
+    gen = torch.Generator().manual_seed(n * 7 + m)
+    src = torch.randn((N, n, 3), generator=gen, dtype=dtype).to(DEV)
+    tgt = torch.randn((N, m, c), generator=gen, dtype=dtype).to(DEV)
+    w0 = torch.rand((N, n), generator=gen, dtype=dtype).to(DEV)
+    m_pad = lib.dicp_padded_targets(m)
+    qorder = torch.stack([torch.randperm(n, generator=gen) for _ in range(N)]).to(torch.int32).to(DEV)
+    tperm = torch.stack([torch.randperm(m_pad, generator=gen) for _ in range(N)]).to(torch.int32)
+    # real rows first (any order), pads last -- like SweepIndex
+    tperm = torch.stack([torch.cat((r[r < m], r[r >= m])) for r in tperm]).to(DEV)
+    if local:
+        ctr = (torch.arange(n)[None, :].float() * (m / n)).long()
+        spos = (ctr + torch.randint(-300, 301, (N, n), generator=gen)).clamp(0, m - 1)
+        spos[:, ::97] = torch.randint(0, m, (N, len(range(0, n, 97))), generator=gen)      # a few outliers
+    else:
+        spos = torch.randint(0, m, (N, n), generator=gen)
+    spos = spos.to(torch.int32).to(DEV)
+    spos[0, 5] = -1                                                                         # "no neighbour" -> sorted row 0
+    pose = torch.tensor([[1, 0, 0, 0, 1, 0, 0, 0, 1, 0.1, -0.2, 0.3]] * N, dtype=dtype, device=DEV)
+    alive = torch.tensor([1.0, 1.0, 0.0], dtype=dtype, device=DEV)
+    gs = torch.randn((N, 36), generator=gen, dtype=dtype).to(DEV)
+    gb = torch.randn((N, 6), generator=gen, dtype=dtype).to(DEV)
+    P = _ops.LoopConfig(icp_type=mode, differentiable=True, max_iterations=1, tolerance=0.0, trim_dist=2.0, loss_name="huber", loss_metric=1.0,
+                        dim=3, const_iter=True, tanh_steepness=10.0, match_ratio_thresh=0.01).params()
+    st = _ops._stream()
+
+    # atomic form on the original-order arrays: idx of slot s = tperm[spos[s]], at point qorder[s]
+    sp_c = spos.clamp(min=0).long()
+    idx_slot = torch.gather(tperm.long(), 1, sp_c)
+    idx = torch.empty((N, n), dtype=torch.int64, device=DEV).scatter_(1, qorder.long(), idx_slot).to(torch.int32)
+    nb = lib.dicp_accumulate_blocks(n)
+    g1 = dict(gsrc=torch.zeros_like(src), gtgt=torch.zeros_like(tgt), gw=torch.zeros_like(w0),
+              part=torch.zeros((N, nb, _lib.NBWD_PAD), dtype=dtype, device=DEV))
+    _lib.check(lib.dicp_accumulate_bwd(code, ctypes.byref(P), _ops._p(src), _ops._p(tgt), c, _ops._p(idx), _ops._p(pose), _ops._p(w0),
+                                       _ops._p(alive), _ops._p(gs), _ops._p(gb), N, n, m, _ops._p(g1["gsrc"]), _ops._p(g1["gtgt"]),
+                                       _ops._p(g1["gw"]), _ops._p(g1["part"]), st), "dicp_accumulate_bwd")
+
+    src_s = _ops._gather_rows_raw(src, qorder)
+    w_s = _ops._gather_rows_raw(w0.unsqueeze(-1), qorder).squeeze(-1).contiguous()
+    tgt_s = _ops._gather_rows_raw(tgt, tperm)
+    nw = lib.dicp_window_blocks(code, n, m_pad)
+    assert nw >= 1
+    gsrc_s, gw_s = torch.zeros_like(src), torch.zeros_like(w0)
+    wt = lib.dicp_window_rows(code)
+    slab = torch.zeros((N, nw, wt, cv), dtype=dtype, device=DEV)
+    gfar = torch.zeros((N, m_pad, cv), dtype=dtype, device=DEV)
+    part = torch.zeros((N, nw, _lib.NBWD_PAD), dtype=dtype, device=DEV)
+    # the windows are placed by a DIFFERENT set of matches than the ones being accumulated in the second call
+    spos_ref = spos if local else torch.randint(0, m, (N, n), generator=gen).to(torch.int32).to(DEV)
+    for _ in range(2):      # accumulating entry point: two calls = twice the gradient
+        _lib.check(lib.dicp_accumulate_bwd_window(code, ctypes.byref(P), _ops._p(src_s), _ops._p(tgt_s), c, _ops._p(spos), _ops._p(spos_ref),
+                                                  _ops._p(pose), _ops._p(w_s), _ops._p(alive), _ops._p(gs), _ops._p(gb), N, n, m_pad,
+                                                  _ops._p(gsrc_s), _ops._p(slab), _ops._p(gfar), _ops._p(gw_s), _ops._p(part), st),
+                   "dicp_accumulate_bwd_window")
+    gsrc, gw, gtgt = torch.zeros_like(src), torch.zeros_like(w0), torch.zeros_like(tgt)
+    _lib.check(lib.dicp_permute_add_rows(code, _ops._p(gsrc_s), _ops._p(qorder), N, n, n, n, 3, 3, _ops._p(gsrc), n, 3, st), "permute")
+    _lib.check(lib.dicp_permute_add_rows(code, _ops._p(gw_s), _ops._p(qorder), N, n, n, n, 1, 1, _ops._p(gw), n, 1, st), "permute")
+    _lib.check(lib.dicp_window_reduce(code, _ops._p(slab), _ops._p(spos_ref), _ops._p(tperm), _ops._p(gfar), N, n, m, m_pad, cv,
+                                      _ops._p(gtgt), c, st), "dicp_window_reduce")
+    tol = 1e-11 if dtype == torch.float64 else 2e-4
+    scale = lambda a: max(1.0, float(a.abs().max()))
+    for a, b, nm in ((gsrc, g1["gsrc"], "gsrc"), (gw, g1["gw"], "gw"), (gtgt, g1["gtgt"], "gtgt")):
+        assert torch.isfinite(a).all(), nm
+        assert float((a - 2 * b).abs().max()) <= tol * scale(b), nm
+    pa, pb = part.sum(dim=1), g1["part"].sum(dim=1)
+    assert float((pa - pb).abs().max()) <= tol * scale(pb) * 10
+    assert float(gfar[:, m:].abs().max() if m_pad > m else 0.0) == 0.0         # pad rows are never matched
 
 
 # ------------------------------------------------------------------- SVD point-to-point (a-12 / f-4)

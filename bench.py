@@ -55,9 +55,12 @@ class EventLog:
             self.K = K
         return ctypes.cast(self.arr, ctypes.c_void_p)
 
-    def mean_ms(self, name):
+    def all_ms(self, name):
         off = 0 if name == "knn" else 2
-        ts = [self.ev[4 * k + off].elapsed_time(self.ev[4 * k + off + 1]) for k in range(self.K)]
+        return [self.ev[4 * k + off].elapsed_time(self.ev[4 * k + off + 1]) for k in range(self.K)]
+
+    def mean_ms(self, name):
+        ts = self.all_ms(name)
         return sum(ts) / len(ts) if ts else None
 
 
@@ -209,7 +212,7 @@ def main():
         torch.cuda.synchronize()
         bf.append(a.elapsed_time(b))
     bf_ms = sorted(bf)[1]
-    pairs_scored = None if brute else float(icp.knn_stats["knn_pairs"].item()) / K      # per launch
+    pairs_scored = None if brute else float(icp.knn_stats["knn_pairs"].sum().item()) / K      # per launch
 
     if rank == 0:
         flops_bf = 8.0 * n * m * B                                       # brute force, per launch
@@ -239,6 +242,7 @@ def main():
                          "traffic": knn_traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, " + str(knn_src) + ")",
                          "algorithmic_hbm_bytes": (16.0 * n + 16.0 * m) * B, "avg_launch_ms": knn_ms,
                          "flops_per_launch": flops,
+                         "launch_ms_by_iteration": [round(v, 4) for v in log.all_ms("knn")],
                          "pairs_scored_fraction": None if brute else pairs_scored / (float(n) * m * B),
                          "dense_equivalent_tflops": flops_bf / (knn_ms * 1e-3) / 1e12,
                          "note": "8 flop per scored (query,target) pair vs the f32 MFMA(=VALU) peak; the kernel is FP32-compute-bound, "
@@ -249,7 +253,8 @@ def main():
                                         "avg_launch_ms": bf_ms, "measured": "3 extra launches outside the timed region, HIP events"},
             "roofline_streaming": {"kernel": "accumulate_bwd", "bound": "hbm", "achieved": bwd_bytes / (bwd_ms * 1e-3) / 1e9,
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bwd_bytes / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                   "traffic": bwd_traffic, "avg_launch_ms": bwd_ms},
+                                   "traffic": bwd_traffic, "avg_launch_ms": bwd_ms,
+                                   "launch_ms_by_iteration": [round(v, 4) for v in log.all_ms("accumulate_bwd")]},
             "finite": sane,
         }
         if world == 1 and not args.no_cpu_baseline:

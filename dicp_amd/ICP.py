@@ -46,7 +46,7 @@ class ICP:
         self.nn = nn(self.diff, use_gumbel=fun['gumbel'], eps=fun['gumbel_eps'], tau=fun['gumbel_tau'])
         # build-specific knob (not in the reference): which kNN kernel the loop uses
         self.knn_variant = _lib.KNN_AUTO      # _lib.KNN_VALU | KNN_MFMA (brute force) | KNN_SWEEP (exact, slab-pruned)
-        self.knn_stats = {}                   # "knn_pairs": pairs scored by the last call's sweep kNN
+        self.knn_stats = {}                   # "knn_pairs": pairs scored by the last call's sweep kNN (device int64 shards: .sum())
         self.bwd_window = os.environ.get("DICP_BWD_WINDOW", "1") == "1"   # sweep path: sorted-space backward (LDS window)
         # tolerance mode: iterations enqueued between two host checks of "all converged" (ICP.py:259).  None = auto:
         # every iteration for big batches (an iteration costs far more than a sync), every 4th for small ones

@@ -87,33 +87,36 @@ class SweepIndex:
 
     def __init__(self, tgt):
         require_device(tgt, "SweepIndex")
-        N, m, _ = tgt.shape
+        tgt = tgt.contiguous()
+        N, m, c = tgt.shape
         self.m = m
-        tgt4 = pack_target(tgt.contiguous())                     # (N,m_pad,4), pad rows [0,0,0,+inf]
-        m_pad = tgt4.shape[1]
-        big = torch.finfo(tgt.dtype).max
-        key = tgt4[:, :, 0].clone()
-        key[:, m:] = big                                         # pads sort last
-        order = torch.argsort(key, dim=1, stable=True)
-        self.tgs4 = torch.gather(tgt4, 1, order.unsqueeze(-1).expand(-1, -1, 4)).contiguous()
-        self.tgs4[:, m:, 0] = big
-        self.tperm = order.to(torch.int32).contiguous()
-        xs = self.tgs4[:, :m, 0].contiguous()
-        xlo, xhi = xs[:, 0], xs[:, -1]
-        span = (xhi - xlo)
-        inv = torch.where(span > 0, self.NBKT / span.clamp_min(torch.finfo(tgt.dtype).tiny), torch.zeros_like(span))
-        edges = xlo[:, None] + torch.arange(self.NBKT + 1, device=tgt.device, dtype=tgt.dtype)[None, :] * (span / self.NBKT)[:, None]
-        self.bucket = torch.searchsorted(xs, edges.contiguous()).to(torch.int32).contiguous()
-        self.brange = torch.stack((xlo, inv), dim=1).contiguous()
-        self.pairs = torch.zeros((1,), dtype=torch.int64, device=tgt.device)
+        lib = _lib.load()
+        dev, dt = tgt.device, tgt.dtype
+        m_pad = lib.dicp_padded_targets(m)
+        key = torch.full((N, m_pad), torch.finfo(dt).max, dtype=dt, device=dev)       # pad slots sort last
+        key[:, :m] = tgt[:, :, 0]
+        keys, order = torch.sort(key, dim=1, stable=True)
+        self.tgs4 = torch.empty((N, m_pad, 4), dtype=dt, device=dev)
+        self.tperm = torch.empty((N, m_pad), dtype=torch.int32, device=dev)
+        self.bucket = torch.empty((N, self.NBKT + 1), dtype=torch.int32, device=dev)
+        self.brange = torch.empty((N, 2), dtype=dt, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.dicp_sweep_build(_DT[dt], _p(tgt), c, _p(order), _p(keys), N, m, m_pad, self.NBKT, _p(self.tgs4), _p(self.tperm),
+                                            _p(self.bucket), _p(self.brange), _stream()), "dicp_sweep_build")
+        self.pair_shards = torch.zeros((_lib.PAIR_SHARDS,), dtype=torch.int64, device=dev)
+
+    @property
+    def pairs(self):
+        """(query,target) pairs scored so far (device scalar)."""
+        return self.pair_shards.sum()
 
     def query_order(self, src, pose):
         """Query indices in ascending transformed x (keeps a wave's queries neighbours)."""
-        if pose is None:
-            x = src[:, :, 0]
-        else:
-            x = (src * pose[:, None, 0:3]).sum(dim=2) + pose[:, None, 9]
-        return torch.argsort(x, dim=1).to(torch.int32).contiguous()
+        N, n, _ = src.shape
+        keys = torch.empty((N, n), dtype=src.dtype, device=src.device)
+        with torch.cuda.device(src.device):
+            _lib.check(_lib.load().dicp_query_keys(_DT[src.dtype], _p(src), _p(pose), N, n, _p(keys), _stream()), "dicp_query_keys")
+        return torch.argsort(keys, dim=1).to(torch.int32)
 
     def knn(self, src, pose, qorder=None, out=None, cfg=0, spos=None):
         N, n, _ = src.shape
@@ -121,7 +124,7 @@ class SweepIndex:
         with torch.cuda.device(src.device):
             _lib.check(_lib.load().dicp_knn_sweep(_DT[src.dtype], _p(src), _p(pose), _p(self.tgs4), _p(self.tperm), _p(qorder),
                                                   _p(self.bucket), _p(self.brange), self.NBKT, N, n, self.m, self.tgs4.shape[1],
-                                                  _p(idx), _p(spos), _p(self.pairs), cfg, _stream()), "dicp_knn_sweep")
+                                                  _p(idx), _p(spos), _p(self.pair_shards), cfg, _stream()), "dicp_knn_sweep")
         return idx
 
 
@@ -294,9 +297,9 @@ class LoopConfig:
     tanh_steepness: float
     match_ratio_thresh: float
     knn_variant: int = _lib.KNN_AUTO
-    sweep_resort: tuple = tuple(int(v) for v in os.environ.get("DICP_SWEEP_RESORT", "0,1").split(","))  # iterations at which the sweep kNN re-sorts its queries by x
+    sweep_resort: tuple = tuple(int(v) for v in os.environ.get("DICP_SWEEP_RESORT", "0,2").split(","))  # iterations at which the sweep kNN re-sorts its queries by x
     bwd_window: bool = True       # sweep path: backward in sorted space (LDS window + full-line atomic flush)
-    stats_out: object = None      # optional dict: receives "knn_pairs" (pairs scored by the sweep kNN)
+    stats_out: object = None      # optional dict: receives "knn_pairs" (pairs scored by the sweep kNN; int64 shards, sum them)
     sync_every: object = None     # tolerance mode: iterations between the host's all-converged checks (None = auto)
     timing_events: object = None  # optional object with .handles(K) -> ctypes array of 4*K hipEvent_t (bench.py)
 
@@ -324,6 +327,25 @@ HIST_CHUNK_BYTES = 1 << 29      # per-iteration histories (indices, weights) are
 def _segments(Kmax, extra_cuts):
     cuts = sorted(set([0, Kmax] + [c for c in extra_cuts if 0 < c < Kmax]))
     return list(zip(cuts[:-1], cuts[1:]))
+
+
+class _Arena:
+    """Zero-initialised device tensors carved out of one allocation: take() the shapes, finish() -> the tensors."""
+
+    def __init__(self, dev):
+        self.dev, self.specs, self.size = dev, [], 0
+
+    def take(self, shape, dtype):
+        nbytes = int(torch.empty((), dtype=dtype).element_size())
+        for d in shape:
+            nbytes *= int(d)
+        self.specs.append((self.size, nbytes, shape, dtype))
+        self.size += (nbytes + 255) // 256 * 256
+        return None
+
+    def finish(self):
+        buf = torch.zeros((max(self.size, 1),), dtype=torch.uint8, device=self.dev)
+        return [buf[o:o + nb].view(dt).view(shape) for (o, nb, shape, dt) in self.specs]
 
 
 class ICPLoop(torch.autograd.Function):
@@ -368,19 +390,23 @@ class ICPLoop(torch.autograd.Function):
             m_pad = tgt4.shape[1]
             nblk = lib.dicp_accumulate_blocks(n)
             poses = torch.empty((Kmax + 1, N, 12), dtype=dt, device=dev)
-            poses[0] = _pose_from_T(T_init)
             alive = torch.empty((Kmax + 1, N), dtype=dt, device=dev)
-            alive[0] = 1.0
-            deltas = torch.zeros((N, Kmax, 6), dtype=dt, device=dev)
-            costs = torch.zeros((N, Kmax), dtype=dt, device=dev)
             areg = torch.empty((Kmax, N, 36), dtype=torch.float64, device=dev) if need_grad else None
-            converged = torch.zeros((N,), dtype=torch.uint8, device=dev)
-            iterations = torch.zeros((N,), dtype=dt, device=dev)
-            matched = torch.zeros((N,), dtype=dt, device=dev)
-            n_matched = torch.zeros((N,), dtype=dt, device=dev)
-            n_start = (torch.sum(w0c > cfg.match_ratio_thresh, dim=1) * rows).to(dt)
+            n_start = torch.empty((N,), dtype=dt, device=dev)
             partials = torch.empty((N, nblk, _lib.NACC_PAD), dtype=dt, device=dev)
-            counters = torch.zeros((Kmax,), dtype=torch.int32, device=dev)
+            # every zero-initialised piece of loop state comes out of ONE zeroed arena (one fill instead of seven)
+            arena = _Arena(dev)
+            deltas = arena.take((N, Kmax, 6), dt)
+            costs = arena.take((N, Kmax), dt)
+            converged = arena.take((N,), torch.uint8)
+            iterations = arena.take((N,), dt)
+            matched = arena.take((N,), dt)
+            n_matched = arena.take((N,), dt)
+            counters = arena.take((Kmax,), torch.int32)
+            deltas, costs, converged, iterations, matched, n_matched, counters = arena.finish()
+            # pose_0, alive_0, n_start (ICP.py:124-129)
+            _lib.check(lib.dicp_loop_init(code, _p(T_init.contiguous()), _p(w0c), float(cfg.match_ratio_thresh), rows, N, n,
+                                          _p(poses), _p(alive), _p(n_start), st), "dicp_loop_init")
             idx_once = None if need_grad else torch.empty((N, n), dtype=torch.int32, device=dev)
 
             # histories in slabs of kc iterations: slab j covers iterations [j*kc, (j+1)*kc)
@@ -407,7 +433,7 @@ class ICPLoop(torch.autograd.Function):
                 j = k0 // kc
                 if j == len(w_slabs):
                     kk = min(kc, Kmax - j * kc)
-                    w_slabs.append(torch.empty((kk, N, n), dtype=dt, device=dev))
+                    w_slabs.append(torch.empty((N, kc, n), dtype=dt, device=dev))     # (N,K,n) layout as returned; same cloud stride in every slab
                     if need_grad:
                         idx_slabs.append(torch.empty((kk, N, n), dtype=torch.int32, device=dev))
                     if owned:
@@ -418,16 +444,16 @@ class ICPLoop(torch.autograd.Function):
                 seg_q.append(len(qorders) - 1)
                 base = j * kc                                         # virtual bases: slab pointer minus its first iteration
                 LB = _lib.LoopBuffers(
-                    src=_p(src), tgt=_p(tgt), w_init=_p(w0c), c=c, K=Kmax, knn_variant=kind | (cfg.knn_variant & 0xff00), m_pad=m_pad,
+                    src=_p(src), tgt=_p(tgt), w_init=_p(w0c), c=c, K=Kmax, knn_variant=kind | (cfg.knn_variant & 0xffff00), m_pad=m_pad,
                     tgt4=_p(tgt4), tperm=_p(sweep.tperm) if sweep else None, qorder=_p(qorder),
                     bucket=_p(sweep.bucket) if sweep else None, brange=_p(sweep.brange) if sweep else None,
-                    nbkt=SweepIndex.NBKT, idx_per_iter=int(need_grad), pairs=_p(sweep.pairs) if sweep else None,
+                    nbkt=SweepIndex.NBKT, idx_per_iter=int(need_grad), pairs=_p(sweep.pair_shards) if sweep else None,
                     spos=ctypes.c_void_p(spos_slabs[j].data_ptr() - base * N * n * 4) if owned else None,
                     poses=_p(poses), deltas=_p(deltas), costs=_p(costs), areg=_p(areg), alive=_p(alive), converged=_p(converged),
                     iterations=_p(iterations), matched_ratio=_p(matched), n_start=_p(n_start), n_matched=_p(n_matched),
                     idx=ctypes.c_void_p(idx_slabs[j].data_ptr() - base * N * n * 4) if need_grad else _p(idx_once),
-                    w=ctypes.c_void_p(w_slabs[j].data_ptr() - base * N * n * es),
-                    w_prev0=_p(w_slabs[(k0 - 1) // kc][(k0 - 1) % kc]) if k0 > 0 else None,
+                    w=ctypes.c_void_p(w_slabs[j].data_ptr() - base * n * es), w_iter=n, w_stride=kc * n,
+                    w_prev0=_p(w_slabs[(k0 - 1) // kc][:, (k0 - 1) % kc]) if k0 > 0 else None,
                     partials=_p(partials), counters=_p(counters), events=events)
                 _lib.check(lib.dicp_icp_forward(code, ctypes.byref(P), ctypes.byref(LB), N, n, m, int(cfg.dim), int(cfg.const_iter),
                                                 float(cfg.tolerance), k0, k1, st), "dicp_icp_forward")
@@ -439,25 +465,17 @@ class ICPLoop(torch.autograd.Function):
                         K = k0 + int(zero[0, 0].item()) + 1
                         break
 
-            # ICP.py:267-271: fill the stats of clouds that never converged
-            iterations = torch.where(iterations == 0, torch.full_like(iterations, K), iterations)
-            start = (n_start * (alive[K] != 0)).to(torch.int64)
-            start[start == 0] = 1
-            # clouds that never converged report the matches of the LAST executed iteration; with sync_every > 1 a few
-            # frozen no-op iterations may have run past K, which leaves n_matched of such clouds unchanged or zero-weighted
-            ratio = n_matched.to(torch.int64) / start           # int64/int64 -> float32, as in the reference
-            matched = torch.where(matched == 0, ratio.to(dt), matched)
-
+            # ICP.py:267-281: stats of the clouds that never converged (they report the matches of the LAST executed
+            # iteration; with sync_every > 1 a few frozen no-op iterations may have run past K, which leaves n_matched of
+            # such clouds unchanged or zero-weighted) and T from the last pose
+            T = torch.empty((N, 4, 4), dtype=dt, device=dev)
+            _lib.check(lib.dicp_loop_finish(code, _p(poses[K]), _p(alive[K]), _p(n_start), _p(n_matched), K, N,
+                                            _p(iterations), _p(matched), _p(T), st), "dicp_loop_finish")
             if sweep is not None and cfg.stats_out is not None:
-                cfg.stats_out["knn_pairs"] = sweep.pairs          # device int64 (read it after a sync)
-            pose_K = poses[K]
-            T = torch.zeros((N, 4, 4), dtype=dt, device=dev)
-            T[:, :3, :3] = pose_K[:, :9].reshape(N, 3, 3)
-            T[:, :3, 3] = pose_K[:, 9:]
-            T[:, 3, 3] = 1.0
-            weights = torch.cat(w_slabs, dim=0)[:K].transpose(0, 1).contiguous()
-            deltas_out = deltas[:, :K].contiguous()
-            costs_out = costs[:, :K].contiguous()
+                cfg.stats_out["knn_pairs"] = sweep.pair_shards    # device int64 shards: sum them after a sync
+            weights = (w_slabs[0] if len(w_slabs) == 1 else torch.cat(w_slabs, dim=1))[:, :K]
+            deltas_out = deltas[:, :K]
+            costs_out = costs[:, :K]
 
         if need_grad:
             saved = [src, tgt, w0c, poses, deltas, areg, alive] + idx_slabs + spos_slabs + qorders + ([sweep.tperm] if owned else [])

@@ -69,6 +69,19 @@ __device__ __forceinline__ void load_pose(const T* __restrict__ pose, int cloud,
 }
 
 // ------------------------------------------------------------------------- pack
+template <typename T> __device__ __forceinline__ T big_v();
+template <> __device__ __forceinline__ float  big_v<float>()  { return 3.402823466e+38f; }
+template <> __device__ __forceinline__ double big_v<double>() { return 1.7976931348623157e+308; }
+
+// one expression for 0.5|y|^2 wherever a target row is packed, so every kNN form sees bit-identical scores
+template <typename T>
+__device__ __forceinline__ typename V4<T>::type pack_row(const T* __restrict__ y) {
+    typename V4<T>::type v;
+    v.x = y[0]; v.y = y[1]; v.z = y[2];
+    v.w = T(0.5) * (v.x * v.x + v.y * v.y + v.z * v.z);
+    return v;
+}
+
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void pack_kernel(const T* __restrict__ tgt, int N, int m, int c,
                                                      typename V4<T>::type* __restrict__ out, int m_pad) {
@@ -76,15 +89,105 @@ __global__ __launch_bounds__(BLOCK) void pack_kernel(const T* __restrict__ tgt, 
     if (t >= (size_t)N * m_pad) return;
     const int b = (int)(t / m_pad), j = (int)(t % m_pad);
     typename V4<T>::type v;
-    if (j < m) {
-        const T* y = tgt + ((size_t)b * m + j) * c;
-        v.x = y[0]; v.y = y[1]; v.z = y[2];
-        v.w = T(0.5) * (v.x * v.x + v.y * v.y + v.z * v.z);
-    } else {
-        v.x = v.y = v.z = T(0);
-        v.w = inf_v<T>();
-    }
+    if (j < m) v = pack_row<T>(tgt + ((size_t)b * m + j) * c);
+    else { v.x = v.y = v.z = T(0); v.w = inf_v<T>(); }
     out[t] = v;
+}
+
+// ------------------------------------------------------------ sweep index / loop set-up
+// Everything of the sorted-sweep search structure that follows the sort itself (the sort is torch.sort: plumbing):
+// sorted packed rows, the permutation as int32, and the coarse bucket table of lower-bound positions.
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void sweep_rows_kernel(const T* __restrict__ tgt, const int64_t* __restrict__ order, int N, int m, int c,
+                                                           int m_pad, typename V4<T>::type* __restrict__ tgs4, int32_t* __restrict__ tperm) {
+    const size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= (size_t)N * m_pad) return;
+    const int b = (int)(t / m_pad);
+    const long j = order[t];
+    typename V4<T>::type v;
+    if (j >= 0 && j < m) v = pack_row<T>(tgt + ((size_t)b * m + j) * c);
+    else { v.x = big_v<T>(); v.y = v.z = T(0); v.w = inf_v<T>(); }      // pads sort last and can never win
+    tgs4[t] = v;
+    tperm[t] = (int32_t)j;
+}
+
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void sweep_buckets_kernel(const T* __restrict__ keys /* (N,m_pad) ascending */, int N, int m, int m_pad,
+                                                              int nbkt, int32_t* __restrict__ bucket, T* __restrict__ brange) {
+    const int cloud = blockIdx.x;
+    const T* __restrict__ xs = keys + (size_t)cloud * m_pad;
+    const T xlo = xs[0], span = xs[m - 1] - xlo;
+    for (int b = threadIdx.x; b <= nbkt; b += BLOCK) {
+        const T edge = xlo + T(b) * (span / T(nbkt));
+        int lo = 0, hi = m;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (xs[mid] < edge) lo = mid + 1; else hi = mid; }
+        bucket[(size_t)cloud * (nbkt + 1) + b] = lo;
+    }
+    if (threadIdx.x == 0) {
+        brange[(size_t)cloud * 2] = xlo;
+        brange[(size_t)cloud * 2 + 1] = span > T(0) ? T(nbkt) / span : T(0);
+    }
+}
+
+// sort key of the queries: their x coordinate under the given pose (NULL = identity)
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void query_keys_kernel(const T* __restrict__ src, const T* __restrict__ pose, int N, int n,
+                                                           T* __restrict__ keys) {
+    const size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= (size_t)N * n) return;
+    const T* p = src + t * 3;
+    T x = p[0];
+    if (pose) {
+        const T* q = pose + (t / n) * 12;
+        x = fma_t(q[0], p[0], fma_t(q[1], p[1], fma_t(q[2], p[2], q[9])));
+    }
+    keys[t] = x;
+}
+
+// first-iteration state of the loop: pose_0 from T_init, alive_0 = 1, n_start = rows * #(w0 > thresh)  (ICP.py:124-129)
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void loop_init_kernel(const T* __restrict__ T_init, const T* __restrict__ w0, T thresh, int rows, int n,
+                                                          T* __restrict__ pose0, T* __restrict__ alive0, T* __restrict__ n_start) {
+    __shared__ int cnt[BLOCK / WAVE];
+    const int cloud = blockIdx.x, tid = threadIdx.x;
+    int k = 0;
+    for (int i = tid; i < n; i += BLOCK) k += w0[(size_t)cloud * n + i] > thresh ? 1 : 0;
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) k += __shfl_down(k, off);
+    if ((tid & (WAVE - 1)) == 0) cnt[tid >> 6] = k;
+    __syncthreads();
+    if (tid == 0) {
+        int tot = 0;
+        for (int w = 0; w < BLOCK / WAVE; ++w) tot += cnt[w];
+        n_start[cloud] = (T)((long)tot * rows);
+        alive0[cloud] = T(1);
+    }
+    if (tid < 12) {
+        const T* M = T_init + (size_t)cloud * 16;
+        pose0[(size_t)cloud * 12 + tid] = tid < 9 ? M[(tid / 3) * 4 + tid % 3] : M[(tid - 9) * 4 + 3];
+    }
+}
+
+// what follows the loop (ICP.py:267-281): stats of the clouds that never converged, and T from the last pose
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void loop_finish_kernel(const T* __restrict__ pose_K, const T* __restrict__ alive_K, const T* __restrict__ n_start,
+                                                            const T* __restrict__ n_matched, int K, int N, T* __restrict__ iterations,
+                                                            T* __restrict__ matched_ratio, T* __restrict__ T_out) {
+    const int cloud = blockIdx.x * BLOCK + threadIdx.x;
+    if (cloud >= N) return;
+    if (iterations[cloud] == T(0)) iterations[cloud] = (T)K;
+    if (matched_ratio[cloud] == T(0)) {
+        long start = (alive_K[cloud] != T(0)) ? (long)n_start[cloud] : 0;
+        if (start == 0) start = 1;
+        matched_ratio[cloud] = (T)((float)(long)n_matched[cloud] / (float)start);     // int64/int64 -> float32 in the reference
+    }
+    const T* q = pose_K + (size_t)cloud * 12;
+    T* M = T_out + (size_t)cloud * 16;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        M[i * 4 + 0] = q[i * 3 + 0]; M[i * 4 + 1] = q[i * 3 + 1]; M[i * 4 + 2] = q[i * 3 + 2]; M[i * 4 + 3] = q[9 + i];
+    }
+    M[12] = M[13] = M[14] = T(0); M[15] = T(1);
 }
 
 // ------------------------------------------------------------------- kNN (VALU)
@@ -511,7 +614,159 @@ __global__ __launch_bounds__(BLOCK) void knn_sweep_kernel(const T* __restrict__ 
         // sorted position of the winner, stored at the query's SORTED slot: what the owner-computes backward scans
         if (spos) spos[(size_t)cloud * n + unit * (WAVE * Q) + q * WAVE + lane] = (bo == 0x7fffffff || bo >= m) ? -1 : bs;
     }
-    if (pairs && lane == 0) atomicAdd(pairs, (unsigned long long)(visR - visL) * WAVE * WAVE * Q);
+    // sharded: one counter serialises ~12 ns per add, which at 65k waves would outlast the kernel itself
+    if (pairs && lane == 0) atomicAdd(pairs + (blockIdx.x & (DICP_PAIR_SHARDS - 1)), (unsigned long long)(visR - visL) * WAVE * WAVE * Q);
+}
+
+// ------------------------------------------------------------------ kNN (scan)
+// The narrow-slab form of the same exact search, for iterations whose pose is already close: there a query's
+// neighbour is a few dozen sorted rows from its own x position, but the tile sweep above still scores every
+// query of a wave against the union of the wave's slabs (>= 256 rows at 192 queries per wave).  Here a wave owns 64
+// queries that are neighbours in x, stages ONE window of W sorted target rows around them in LDS, and each lane
+// scans outwards from ITS OWN lower bound, G rows per side per step, until its own slab bound
+// 0.5 (y.x - x.x)^2 - 0.5|x|^2 > best + margin closes each side -- the same bound, margin and score arithmetic as
+// the tile sweep, so the indices are identical.  The common step only tracks min3 of the G scores; the exact
+// per-candidate update (and the lowest-ORIGINAL-index rule on equal scores) runs when some lane's minimum moves.
+// Rows outside the staged window are read from global memory, so any data is handled; locality decides the speed.
+template <typename T, int W, int G>
+__global__ __launch_bounds__(BLOCK) void knn_scan_kernel(const T* __restrict__ src, const T* __restrict__ pose,
+                                                         const typename V4<T>::type* __restrict__ tgs4,
+                                                         const int32_t* __restrict__ tperm, const int32_t* __restrict__ qorder,
+                                                         const int32_t* __restrict__ bucket, const T* __restrict__ brange, int nbkt,
+                                                         int32_t* __restrict__ idx, int32_t* __restrict__ spos,
+                                                         unsigned long long* __restrict__ pairs,
+                                                         int N, int n, int m, int m_pad, int bpc) {
+    using T4 = typename V4<T>::type;
+    __shared__ T4 wins[BLOCK / WAVE][W];
+    int cloud, blk;
+    if (!decode_block(bpc, N, cloud, blk)) return;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
+    const int unit = blk * (BLOCK / WAVE) + wave;           // 64 consecutive sorted queries
+    if (unit * WAVE >= n) return;                           // whole wave idle (no block-level sync below)
+    T C[9], r3[3];
+    load_pose(pose, cloud, C, r3);
+    const int slot = unit * WAVE + lane;
+    const bool live = slot < n;
+    int qi = -1;
+    T p[3] = {T(0), T(0), T(0)};
+    if (live) {
+        qi = qorder ? qorder[(size_t)cloud * n + slot] : slot;
+        const T* sp = src + ((size_t)cloud * n + qi) * 3;
+        p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2];
+    }
+    T v[3];
+    matvec3(C, p, v);
+    v[0] += r3[0]; v[1] += r3[1]; v[2] += r3[2];
+    const T nx[3] = {-v[0], -v[1], -v[2]};
+    const T xq = v[0];
+    const T hx = T(0.5) * (v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+
+    // the wave's window starts a quarter of its length to the left of the smallest query x (coarse bucket table)
+    T xm = live ? xq : inf_v<T>();
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) { const T o = __shfl_xor(xm, off); xm = o < xm ? o : xm; }
+    const T xlo = brange[(size_t)cloud * 2], inv = brange[(size_t)cloud * 2 + 1];
+    T fb = (xm - xlo) * inv;
+    fb = fb > T(0) ? (fb > T(nbkt) ? T(nbkt) : fb) : T(0);      // NaN -> 0
+    const int start = bucket[(size_t)cloud * (nbkt + 1) + (int)fb];
+    const int w0 = max(min(start - W / 4, m_pad - W), 0);
+    const int wn = min(W, m_pad - w0);                       // staged rows: [w0, w0 + wn)
+    const T4* __restrict__ tg = tgs4 + (size_t)cloud * m_pad;
+    for (int k = lane; k < wn; k += WAVE) wins[wave][k] = tg[w0 + k];
+    __builtin_amdgcn_wave_barrier();
+
+    // per-lane lower bound of xq among the sorted x keys: in the window, else (rare) in the rest of the cloud
+    auto lower_bound = [&](auto key, int lo, int hi) {      // first j in [lo,hi) with key(j) >= xq
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (key(mid) < xq) lo = mid + 1; else hi = mid; }
+        return lo;
+    };
+    int c = w0 + lower_bound([&](int k) { return wins[wave][k].x; }, 0, wn);
+    if (live && c == w0 + wn && w0 + wn < m_pad) c = lower_bound([&](int j) { return tg[j].x; }, w0 + wn, m_pad);
+    else if (live && c == w0 && w0 > 0) c = lower_bound([&](int j) { return tg[j].x; }, 0, w0);
+
+    const int32_t* __restrict__ pm = tperm + (size_t)cloud * m_pad;
+    auto row = [&](int j) -> T4 {
+        j = min(max(j, 0), m_pad - 1);
+        const int k = j - w0;
+        const bool out = k < 0 || k >= wn;
+        T4 y = wins[wave][min(max(k, 0), wn - 1)];                 // always an LDS read (ds_read_b128), never a flat load
+        if (__any(out)) {                                   // wave-uniform branch: the global path costs nothing when unused
+            if (out) y = tg[j];
+        }
+        return y;
+    };
+    T best = inf_v<T>(), thr = inf_v<T>();
+    int bs = -1;
+    auto exact_update = [&](T sc, int j) {
+        j = min(max(j, 0), m_pad - 1);
+        if (sc < best) { best = sc; bs = j; }
+        else if (sc == best && sc < inf_v<T>() && pm[j] < pm[bs]) bs = j;       // lowest ORIGINAL index among equals
+    };
+    int r = c, l = c - 1;
+    bool aR = live && r < m_pad, aL = live && l >= 0;
+    // one group of G rows on one side: y[0] is the row nearest to the query in x, j0 its sorted index, dir = +-1
+    auto group = [&](const T4* y, int j0, int dir, T dx, bool& act) {
+        act = act && !(dx > T(0) && T(0.5) * dx * dx - hx > thr);
+        T sc[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) sc[g] = score<T, T4>(nx, y[g]);
+        T mg = sc[0];
+#pragma unroll
+        for (int g = 1; g < G; ++g) mg = min_t(mg, sc[g]);
+        const bool hit = act && mg <= best && mg < inf_v<T>();
+        if (__any(hit)) {               // some lane's minimum moves (or ties): exact per-candidate update
+            if (hit) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) exact_update(sc[g], j0 + dir * g);
+                thr = best + SweepEps<T>::v * (T(1) + m_abs(best) + hx);
+            }
+        }
+    };
+    while (__any(aR || aL)) {
+        if (__any(aR)) {
+            const int k = r - w0;
+            const bool staged = k >= 0 && k + G <= wn;      // the whole group is in the LDS window (so also < m_pad)
+            T4 y[G];
+            if (!__any(aR && !staged)) {
+                const T4* b = &wins[wave][min(max(k, 0), wn - G)];
+#pragma unroll
+                for (int g = 0; g < G; ++g) y[g] = b[g];    // one address, immediate offsets
+            } else {
+#pragma unroll
+                for (int g = 0; g < G; ++g) y[g] = row(r + g);
+            }
+            group(y, r, 1, y[0].x - xq, aR);
+            r = aR ? r + G : r;
+            aR = aR && r < m_pad;
+        }
+        if (__any(aL)) {
+            const int k = l - (G - 1) - w0;
+            const bool staged = k >= 0 && k + G <= wn;
+            T4 y[G];
+            if (!__any(aL && !staged)) {
+                const T4* b = &wins[wave][min(max(k, 0), wn - G)];
+#pragma unroll
+                for (int g = 0; g < G; ++g) y[g] = b[G - 1 - g];
+            } else {
+#pragma unroll
+                for (int g = 0; g < G; ++g) y[g] = row(l - g);
+            }
+            group(y, l, -1, xq - y[0].x, aL);
+            l = aL ? l - G : l;
+            aL = aL && l >= 0;
+        }
+    }
+    if (live) {
+        const int bo = bs >= 0 ? pm[bs] : 0x7fffffff;
+        idx[(size_t)cloud * n + qi] = (bo == 0x7fffffff) ? 0 : min(max(bo, 0), m - 1);
+        if (spos) spos[(size_t)cloud * n + slot] = (bo == 0x7fffffff || bo >= m) ? -1 : bs;
+    }
+    if (pairs) {
+        int cnt = live ? (min(r, m_pad) - c) + (c - 1 - max(l, -1)) : 0;
+#pragma unroll
+        for (int off = WAVE / 2; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+        if (lane == 0) atomicAdd(pairs + (blockIdx.x & (DICP_PAIR_SHARDS - 1)), (unsigned long long)cnt);
+    }
 }
 
 // ------------------------------------------------------------- gather / scatter
@@ -1458,6 +1713,62 @@ int dicp_pack_target(int dtype, const void* tgt, int N, int m, int c, void* tgt4
     return launch_status();
 }
 
+int dicp_sweep_build(int dtype, const void* tgt, int c, const int64_t* order, const void* keys_sorted, int N, int m, int m_pad, int nbkt,
+                     void* tgs4, int32_t* tperm, int32_t* bucket, void* brange, void* stream) {
+    if (!tgt || !order || !keys_sorted || !tgs4 || !tperm || !bucket || !brange) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0 || m <= 0 || (c != 3 && c != 6) || nbkt <= 0 || m_pad != dicp_padded_targets(m)) return DICP_ERR_SHAPE;
+    if ((uintptr_t)tgs4 % (dtype == DICP_F32 ? 16 : 32)) return DICP_ERR_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    begin_launch();
+    const unsigned g = blocks_for((size_t)N * m_pad);
+    if (dtype == DICP_F32) {
+        sweep_rows_kernel<float><<<g, BLOCK, 0, st>>>((const float*)tgt, order, N, m, c, m_pad, (float4*)tgs4, tperm);
+        sweep_buckets_kernel<float><<<N, BLOCK, 0, st>>>((const float*)keys_sorted, N, m, m_pad, nbkt, bucket, (float*)brange);
+    } else {
+        sweep_rows_kernel<double><<<g, BLOCK, 0, st>>>((const double*)tgt, order, N, m, c, m_pad, (double4*)tgs4, tperm);
+        sweep_buckets_kernel<double><<<N, BLOCK, 0, st>>>((const double*)keys_sorted, N, m, m_pad, nbkt, bucket, (double*)brange);
+    }
+    return launch_status();
+}
+
+int dicp_query_keys(int dtype, const void* src, const void* pose, int N, int n, void* keys, void* stream) {
+    if (!src || !keys) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0 || n <= 0) return DICP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    begin_launch();
+    const unsigned g = blocks_for((size_t)N * n);
+    if (dtype == DICP_F32) query_keys_kernel<float><<<g, BLOCK, 0, st>>>((const float*)src, (const float*)pose, N, n, (float*)keys);
+    else                   query_keys_kernel<double><<<g, BLOCK, 0, st>>>((const double*)src, (const double*)pose, N, n, (double*)keys);
+    return launch_status();
+}
+
+int dicp_loop_init(int dtype, const void* T_init, const void* w0, double thresh, int rows, int N, int n,
+                   void* pose0, void* alive0, void* n_start, void* stream) {
+    if (!T_init || !w0 || !pose0 || !alive0 || !n_start) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0 || n <= 0 || (rows != 1 && rows != 3)) return DICP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    begin_launch();
+    if (dtype == DICP_F32) loop_init_kernel<float><<<N, BLOCK, 0, st>>>((const float*)T_init, (const float*)w0, (float)thresh, rows, n, (float*)pose0, (float*)alive0, (float*)n_start);
+    else                   loop_init_kernel<double><<<N, BLOCK, 0, st>>>((const double*)T_init, (const double*)w0, thresh, rows, n, (double*)pose0, (double*)alive0, (double*)n_start);
+    return launch_status();
+}
+
+int dicp_loop_finish(int dtype, const void* pose_K, const void* alive_K, const void* n_start, const void* n_matched, int K, int N,
+                     void* iterations, void* matched_ratio, void* T_out, void* stream) {
+    if (!pose_K || !alive_K || !n_start || !n_matched || !iterations || !matched_ratio || !T_out) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0 || K < 0) return DICP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    begin_launch();
+    const unsigned g = blocks_for((size_t)N);
+    if (dtype == DICP_F32) loop_finish_kernel<float><<<g, BLOCK, 0, st>>>((const float*)pose_K, (const float*)alive_K, (const float*)n_start, (const float*)n_matched, K, N, (float*)iterations, (float*)matched_ratio, (float*)T_out);
+    else                   loop_finish_kernel<double><<<g, BLOCK, 0, st>>>((const double*)pose_K, (const double*)alive_K, (const double*)n_start, (const double*)n_matched, K, N, (double*)iterations, (double*)matched_ratio, (double*)T_out);
+    return launch_status();
+}
+
 int dicp_knn(int dtype, const void* src, const void* pose, const void* tgt4, int N, int n, int m, int m_pad,
              int32_t* idx, int variant, void* stream) {
     if (!src || !tgt4 || !idx) return DICP_ERR_NULL;
@@ -1484,6 +1795,21 @@ int dicp_knn_sweep(int dtype, const void* src, const void* pose, const void* tgs
     hipStream_t st = (hipStream_t)stream;
     begin_launch();
     if (cfg == 0) cfg = ((long)N * n >= 2L * BLOCK * 1024) ? 8 : 4;      // 3 (else 1) queries per lane, 16-target chunks
+    if (cfg >= DICP_SWEEP_SCAN && cfg <= DICP_SWEEP_SCAN + 3) {           // narrow-slab form: one query per lane, per-lane scan
+        const int bpc = (n + BLOCK - 1) / BLOCK;
+#define DICP_SCAN(T, W, G) knn_scan_kernel<T, W, G><<<grid_for(N, bpc), BLOCK, 0, st>>>((const T*)src, (const T*)pose, (const typename V4<T>::type*)tgs4, \
+            tperm, qorder, bucket, (const T*)brange, nbkt, idx, spos, pairs, N, n, m, m_pad, bpc)
+        if (dtype == DICP_F32) {
+            switch (cfg - DICP_SWEEP_SCAN) {
+                case 0: DICP_SCAN(float, 256, 8); break;  case 1: DICP_SCAN(float, 256, 4); break;
+                case 2: DICP_SCAN(float, 512, 8); break;  default: DICP_SCAN(float, 384, 8); break;
+            }
+        } else {
+            if ((cfg - DICP_SWEEP_SCAN) & 1) DICP_SCAN(double, 128, 4); else DICP_SCAN(double, 256, 4);
+        }
+#undef DICP_SCAN
+        return launch_status();
+    }
 #define DICP_SWEEP(T, Q, CH) do { const int units = (n + WAVE * Q - 1) / (WAVE * Q), bpc = (units + BLOCK / WAVE - 1) / (BLOCK / WAVE); \
         knn_sweep_kernel<T, Q, CH><<<grid_for(N, bpc), BLOCK, 0, st>>>((const T*)src, (const T*)pose, (const typename V4<T>::type*)tgs4, tperm, qorder, \
             bucket, (const T*)brange, nbkt, idx, spos, pairs, N, n, m, m_pad, bpc); } while (0)
@@ -1769,7 +2095,7 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
         !B->converged || !B->iterations || !B->matched_ratio || !B->n_start || !B->n_matched || !B->idx || !B->w ||
         !B->partials || !B->counters) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
-    if (k0 < 0 || k1 > B->K || k0 > k1 || N <= 0 || n <= 0 || m <= 0) return DICP_ERR_SHAPE;
+    if (k0 < 0 || k1 > B->K || k0 > k1 || N <= 0 || n <= 0 || m <= 0 || B->w_stride < n || B->w_iter < n) return DICP_ERR_SHAPE;
     const size_t es = dtype == DICP_F32 ? 4 : 8;
     const int kind = B->knn_variant & 0xff;
     if (kind == DICP_KNN_SWEEP ? (!B->tperm || !B->bucket || !B->brange) : !B->tgt4) return DICP_ERR_NULL;
@@ -1778,18 +2104,23 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
     for (int k = k0; k < k1; ++k) {
         const char* pose_k = (const char*)B->poses + (size_t)k * N * 12 * es;
         int32_t* idx_k = B->idx + (B->idx_per_iter ? (size_t)k * N * n : 0);
-        char* w_k = (char*)B->w + (size_t)k * N * n * es;
+        char* w_k = (char*)B->w + (size_t)k * B->w_iter * es;       // cloud stride B->w_stride: (N,K,n) or (K,N,n) alike
         const char* alive_k = (const char*)B->alive + (size_t)k * N * es;
         if (B->events) { if (hipEventRecord((hipEvent_t)B->events[4 * k + 0], st) != hipSuccess) return -(int)hipGetLastError(); }
         int rc;
         if (kind == DICP_KNN_SWEEP)
+        {   // bits 16..23 of knn_variant: first iteration that takes the narrow-slab (per-lane scan) form; 0 = never
+            const int scan_from = (B->knn_variant >> 16) & 0xff;
+            int cfg = (B->knn_variant >> 8) & 0xff;
+            if (cfg == 0 && scan_from > 0 && k >= scan_from) cfg = DICP_SWEEP_SCAN;
             rc = dicp_knn_sweep(dtype, B->src, pose_k, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, N, n, m, B->m_pad,
-                                idx_k, B->spos ? B->spos + (size_t)k * N * n : nullptr, B->pairs, (B->knn_variant >> 8) & 0xff, stream);
+                                idx_k, B->spos ? B->spos + (size_t)k * N * n : nullptr, B->pairs, cfg, stream);
+        }
         else
-            rc = dicp_knn(dtype, B->src, pose_k, B->tgt4, N, n, m, B->m_pad, idx_k, B->knn_variant, stream);
+            rc = dicp_knn(dtype, B->src, pose_k, B->tgt4, N, n, m, B->m_pad, idx_k, B->knn_variant & 0xffff, stream);
         if (rc) return rc;
         if (B->events) { if (hipEventRecord((hipEvent_t)B->events[4 * k + 1], st) != hipSuccess) return -(int)hipGetLastError(); }
-        rc = dicp_accumulate(dtype, prm, B->src, B->tgt, B->c, idx_k, pose_k, B->w_init, alive_k, N, n, m, B->partials, w_k, n, stream);
+        rc = dicp_accumulate(dtype, prm, B->src, B->tgt, B->c, idx_k, pose_k, B->w_init, alive_k, N, n, m, B->partials, w_k, B->w_stride, stream);
         if (rc) return rc;
         dicp_step_io io;
         io.partials = B->partials; io.nblk = nblk; io.iter = k; io.dim = dim; io.const_iter = const_iter; io.tolerance = tolerance;
@@ -1802,7 +2133,7 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
         io.alive = alive_k; io.alive_out = (char*)B->alive + (size_t)(k + 1) * N * es;
         io.converged = B->converged; io.iterations = B->iterations; io.matched_ratio = B->matched_ratio;
         io.n_start = B->n_start; io.n_matched = B->n_matched;
-        io.w_cur = w_k; io.w_prev = k > k0 ? (const char*)B->w + (size_t)(k - 1) * N * n * es : (const char*)B->w_prev0; io.w_stride = n;
+        io.w_cur = w_k; io.w_prev = k > k0 ? (const char*)B->w + (size_t)(k - 1) * B->w_iter * es : (const char*)B->w_prev0; io.w_stride = B->w_stride;
         io.n_not_converged = B->counters + k;
         rc = dicp_step(dtype, &io, N, stream);
         if (rc) return rc;

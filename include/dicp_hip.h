@@ -68,6 +68,16 @@ int dicp_pack_target(int dtype, const void* tgt, int N, int m, int c, void* tgt4
 int dicp_knn(int dtype, const void* src, const void* pose, const void* tgt4, int N, int n, int m, int m_pad,
              int32_t* idx, int variant, void* stream);
 
+/* Set-up of the sorted-sweep search structure AFTER the sort (the sort itself is the caller's: any stable ascending
+ * sort of the target x keys with the m_pad - m pad slots keyed +max so that they come last):
+ *   order (N,m_pad) int64 = the sorting permutation, keys_sorted (N,m_pad) = the sorted keys
+ *   -> tgs4 (N,m_pad,4) packed rows in sorted order (pads [max,0,0,+inf]), tperm (N,m_pad) = order as int32,
+ *      bucket (N,nbkt+1) lower-bound positions of nbkt+1 equally spaced x edges, brange (N,2) = [x_min, nbkt/(x_max-x_min)]. */
+int dicp_sweep_build(int dtype, const void* tgt, int c, const int64_t* order, const void* keys_sorted, int N, int m, int m_pad, int nbkt,
+                     void* tgs4, int32_t* tperm, int32_t* bucket, void* brange, void* stream);
+/* keys (N,n) = x coordinate of every source point under pose (NULL = identity): the sort key of the query order. */
+int dicp_query_keys(int dtype, const void* src, const void* pose, int N, int n, void* keys, void* stream);
+
 /* Exact 1-NN with slab pruning: same result (and lowest-index tie rule) as dicp_knn, far fewer pairs.
  * The caller prepares, ONCE per ICP call (targets do not move between iterations):
  *   tgs4  (N,m_pad,4)  the rows of dicp_pack_target re-ordered by ascending x (pad rows last, x = +max);
@@ -77,8 +87,13 @@ int dicp_knn(int dtype, const void* src, const void* pose, const void* tgt4, int
  *                      queries are neighbours; NULL = natural order (still exact, less pruning).
  * spos (N,n), optional: spos[b][s] = SORTED position of the neighbour of the query in sorted slot s (-1 if none):
  *   what dicp_accumulate_bwd_window consumes.
- * pairs: optional device counter, += number of (query,target) pairs actually scored (roofline accounting).
- * cfg: 0 auto, 1.. = fixed (queries per lane, chunk) launch configuration (tuning). */
+ * pairs: optional DICP_PAIR_SHARDS device counters; their sum += number of (query,target) pairs actually scored
+ *   (roofline accounting; sharded because adds to ONE address serialise at ~12 ns each).
+ * cfg: 0 auto (tile sweep), 1..8 = fixed (queries per lane, chunk) tile-sweep configuration (tuning),
+ *      DICP_SWEEP_SCAN (+1..3: other window / group sizes) = the narrow-slab form: per-lane scan from the query's own x position,
+ *      same indices, far fewer pairs once the pose is close (iterations >= 1 of an ICP call). */
+#define DICP_SWEEP_SCAN 16
+#define DICP_PAIR_SHARDS 64
 int dicp_knn_sweep(int dtype, const void* src, const void* pose, const void* tgs4, const int32_t* tperm,
                    const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt,
                    int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg, void* stream);
@@ -152,7 +167,7 @@ typedef struct dicp_loop_buffers {
     const void* brange;      /* sweep only */
     int32_t nbkt;
     int32_t idx_per_iter;    /* 1: idx is (K,N,n) and every iteration keeps its own (needed for backward); 0: (N,n) reused */
-    unsigned long long* pairs;   /* sweep only, optional */
+    unsigned long long* pairs;   /* sweep only, optional: DICP_PAIR_SHARDS counters */
     int32_t* spos;           /* sweep only, optional (K,N,n): per-iteration sorted match positions.  Non-NULL in dicp_icp_backward
                                 selects dicp_accumulate_bwd_window: src / w_init / tgt are then the SORTED copies it documents,
                                 gsrc / gw accumulate in slot order, gtgt is the slab, bwd_partials has dicp_window_blocks blocks */
@@ -169,13 +184,23 @@ typedef struct dicp_loop_buffers {
     const void* n_start;     /* (N) */
     void* n_matched;         /* (N) */
     int32_t* idx;            /* (K,N,n) or (N,n) */
-    void* w;                 /* (K,N,n): weights of every iteration (may be a per-slab virtual base: only [k0,k1) is touched) */
-    const void* w_prev0;     /* (N,n) weights of iteration k0-1, or NULL when k0 == 0            ICP.py:224-226 */
+    void* w;                 /* weights of every iteration: iteration k, cloud b at w + k*w_iter + b*w_stride (elements);
+                                (N,K,n): w_iter = n, w_stride = K*n.  May be a per-slab virtual base: only [k0,k1) is touched */
+    int64_t w_iter, w_stride;
+    const void* w_prev0;     /* weights of iteration k0-1 (cloud stride w_stride too), or NULL when k0 == 0   ICP.py:224-226 */
     void* partials;          /* (N, dicp_accumulate_blocks(n), DICP_NACC_PAD) scratch */
     int32_t* counters;       /* (K) zero-initialised: #clouds with |delta| >= tol at iteration k */
     void** events;           /* optional 4*K hipEvent_t: [4k] before / [4k+1] after the kNN of iteration k (forward),
                                 [4k+2] before / [4k+3] after its accumulate_bwd (backward); NULL = none */
 } dicp_loop_buffers;
+
+/* Loop state before iteration 0 (ICP.py:124-129): pose0 (N,12) from T_init (N,4,4), alive0 (N) = 1,
+ * n_start (N) = rows * #(w0 > thresh), rows = 3 for pt2pt, 1 for pt2pl.  And after the last executed iteration K
+ * (ICP.py:267-281): iterations / matched_ratio of clouds that never converged, T_out (N,4,4) from pose_K. */
+int dicp_loop_init(int dtype, const void* T_init, const void* w0, double thresh, int rows, int N, int n,
+                   void* pose0, void* alive0, void* n_start, void* stream);
+int dicp_loop_finish(int dtype, const void* pose_K, const void* alive_K, const void* n_start, const void* n_matched, int K, int N,
+                     void* iterations, void* matched_ratio, void* T_out, void* stream);
 
 /* Iterations [k0,k1) of the loop (ICP.py:131-260), enqueued back to back: no host work between iterations. */
 int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_buffers* buf, int N, int n, int m,

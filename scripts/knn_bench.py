@@ -8,6 +8,8 @@ from dicp_amd.synthetic import make_pairs
 B = int(os.environ.get("B", 256)); n = int(os.environ.get("NPTS", 16384)); rounds = int(os.environ.get("ROUNDS", 5))
 src, tgt = make_pairs(B, n, n, seed=3)
 src, tgt = src.cuda(), tgt.cuda()
+if os.environ.get("NEAR") == "1":      # converged-pose queries: every query 0.01-noise away from a target
+    src = (tgt[:, torch.randperm(n, device="cuda"), :3] + 0.01 * torch.randn((B, n, 3), device="cuda")).contiguous()
 tgt4 = _ops.pack_target(tgt)
 idx = torch.empty((B, n), dtype=torch.int32, device="cuda")
 variants = {"valu_q4c8": 1 | (3 << 8), "valu_q8c8": 1 | (4 << 8), "valu_q4c16": 1 | (5 << 8), "valu_q8c16": 1 | (7 << 8),
@@ -37,12 +39,12 @@ for rnd in range(rounds + 1):
 sw = _ops.SweepIndex(tgt)
 qo = sw.query_order(src, None)
 for name, cfg, q in (("sweep_q1", 1, qo), ("sweep_q2", 2, qo), ("sweep_q4", 3, qo), ("sweep_q2_unsorted", 2, None),
-                     ("sweep_q1c16", 4, qo), ("sweep_q2c16", 5, qo), ("sweep_q4c16", 6, qo), ("sweep_q3", 7, qo), ("sweep_q3c16", 8, qo)):
+                     ("sweep_q1c16", 4, qo), ("sweep_q2c16", 5, qo), ("sweep_q4c16", 6, qo), ("sweep_q3", 7, qo), ("sweep_q3c16", 8, qo), ("scan_w256g8", 16, qo), ("scan_w256g4", 17, qo), ("scan_w512g8", 18, qo), ("scan_w384g8", 19, qo)):
     if sel and name not in sel.split(","):
         continue
     ts = []
     for rnd in range(rounds + 1):
-        sw.pairs.zero_()
+        sw.pair_shards.zero_()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         sw.knn(src, None, q, out=idx, cfg=cfg)

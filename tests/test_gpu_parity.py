@@ -494,7 +494,7 @@ def test_sweep_knn_equals_brute_force(dtype, N, n, m):
     x = (torch.rand((N, n, 3), generator=g, dtype=torch.float64) * 10 - 5).to(dtype).to(DEV)
     y = (torch.rand((N, m, 6), generator=g, dtype=torch.float64) * 10 - 5).to(dtype).to(DEV)
     brute = _ops.knn(x, None, _ops.pack_target(y), m, _lib.KNN_VALU)
-    for cfg in (1, 2, 3):
+    for cfg in (1, 2, 3, 8, 16, 17):                              # tile sweep (1..8) and per-lane scan (16, 17) forms
         for sort_q in (True, False):
             got, sw = sweep_knn(x, y, sort_queries=sort_q, cfg=cfg)
             assert torch.equal(got, brute), (cfg, sort_q)        # same scores, same tie rule: bit-identical indices
@@ -518,20 +518,30 @@ def test_sweep_knn_ties_duplicates_and_pads():
     assert torch.equal(pick(brute), pick(ref))
     first = torch.stack([torch.stack([(y[b] == y[b, brute[b, i]]).all(dim=1).nonzero()[0, 0] for i in range(40)]) for b in range(2)])
     assert torch.equal(brute.cpu().long(), first.cpu())
-    for cfg in (1, 2, 3):
+    for cfg in (1, 2, 3, 16, 17):
         got, _ = sweep_knn(x, y, cfg=cfg)
-        assert torch.equal(got, brute)
+        assert torch.equal(got, brute), cfg
     ang = 0.4
     C = torch.tensor([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1.0]], dtype=torch.float32)
     r = torch.tensor([0.5, -0.2, 0.1])
     pose = torch.cat((C.reshape(9), r)).repeat(2, 1).to(DEV)
-    got, _ = sweep_knn(x, y, pose=pose)
-    assert torch.equal(got, _ops.knn(x, pose, _ops.pack_target(y), 380, _lib.KNN_VALU))
+    for cfg in (0, 16):
+        got, _ = sweep_knn(x, y, pose=pose, cfg=cfg)
+        assert torch.equal(got, _ops.knn(x, pose, _ops.pack_target(y), 380, _lib.KNN_VALU))
     # degenerate: every target on one x plane (no pruning possible) and identical points
     flat = y.clone()
     flat[:, :, 0] = 1.0
-    got, _ = sweep_knn(x, flat)
-    assert torch.equal(got, _ops.knn(x, None, _ops.pack_target(flat), 380, _lib.KNN_VALU))
+    for cfg in (0, 16, 17):
+        got, _ = sweep_knn(x, flat, cfg=cfg)
+        assert torch.equal(got, _ops.knn(x, None, _ops.pack_target(flat), 380, _lib.KNN_VALU))
+    # non-finite queries: every form answers 0 like the brute-force kernel (no neighbour)
+    xn = x.clone()
+    xn[0, 3] = float("nan")
+    xn[1, 7, 1] = float("inf")
+    bn = _ops.knn(xn, None, _ops.pack_target(y), 380, _lib.KNN_VALU)
+    for cfg in (0, 16):
+        got, _ = sweep_knn(xn, y, cfg=cfg)
+        assert torch.equal(got, bn), cfg
 
 
 def test_sweep_knn_full_size_and_pruning():
@@ -546,6 +556,17 @@ def test_sweep_knn_full_size_and_pruning():
     assert frac < 0.25, frac
     got2, _ = sweep_knn(sd, td, sort_queries=False)                         # unsorted queries: still exact
     assert torch.equal(got2, brute)
+    # per-lane scan form: far pose (wide slabs), near pose (a few dozen rows per query), and m = 4n
+    for cfg in (16, 17):
+        got3, sw3 = sweep_knn(sd, td, cfg=cfg)
+        assert torch.equal(got3, brute), cfg
+    near = td[:, :, :3] + 0.01 * torch.randn((N, n, 3), generator=torch.Generator().manual_seed(1)).to(DEV)
+    bn = _ops.knn(near, None, _ops.pack_target(td), n, _lib.KNN_VALU)
+    got4, sw4 = sweep_knn(near, td, cfg=16)
+    assert torch.equal(got4, bn)
+    assert float(sw4.pairs.item()) / (float(N) * n * n) < 0.02
+    q4 = near[:, ::4].contiguous()
+    assert torch.equal(sweep_knn(q4, td, cfg=16)[0], _ops.knn(q4, None, _ops.pack_target(td), n, _lib.KNN_VALU))
 
 
 @pytest.mark.parametrize("window", [False, True])
@@ -562,7 +583,7 @@ def test_icp_with_sweep_knn_matches_reference(golden, name, icp_type, diff, wind
     res["T"].sum().backward()
     np.testing.assert_allclose(npy(src.grad), g["grad_source"], rtol=0, atol=1e-10)
     np.testing.assert_allclose(npy(tgt.grad), g["grad_target"], rtol=0, atol=1e-10)
-    assert int(icp.knn_stats["knn_pairs"].item()) > 0
+    assert int(icp.knn_stats["knn_pairs"].sum().item()) > 0
 
 
 @pytest.mark.parametrize("window", [False, True])

@@ -84,14 +84,15 @@ __device__ __forceinline__ typename V4<T>::type pack_row(const T* __restrict__ y
 
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void pack_kernel(const T* __restrict__ tgt, int N, int m, int c,
-                                                     typename V4<T>::type* __restrict__ out, int m_pad) {
-    const size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (t >= (size_t)N * m_pad) return;
-    const int b = (int)(t / m_pad), j = (int)(t % m_pad);
+                                                     typename V4<T>::type* __restrict__ out, int m_pad, int bpc) {
+    int b, blk;                                             // all blocks of a cloud on one XCD (decode_block)
+    if (!decode_block(bpc, N, b, blk)) return;
+    const int j = blk * BLOCK + threadIdx.x;
+    if (j >= m_pad) return;
     typename V4<T>::type v;
     if (j < m) v = pack_row<T>(tgt + ((size_t)b * m + j) * c);
     else { v.x = v.y = v.z = T(0); v.w = inf_v<T>(); }
-    out[t] = v;
+    out[(size_t)b * m_pad + j] = v;
 }
 
 // ------------------------------------------------------------ sweep index / loop set-up
@@ -99,16 +100,32 @@ __global__ __launch_bounds__(BLOCK) void pack_kernel(const T* __restrict__ tgt, 
 // sorted packed rows, the permutation as int32, and the coarse bucket table of lower-bound positions.
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void sweep_rows_kernel(const T* __restrict__ tgt, const int64_t* __restrict__ order, int N, int m, int c,
-                                                           int m_pad, typename V4<T>::type* __restrict__ tgs4, int32_t* __restrict__ tperm) {
-    const size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (t >= (size_t)N * m_pad) return;
-    const int b = (int)(t / m_pad);
-    const long j = order[t];
-    typename V4<T>::type v;
-    if (j >= 0 && j < m) v = pack_row<T>(tgt + ((size_t)b * m + j) * c);
-    else { v.x = big_v<T>(); v.y = v.z = T(0); v.w = inf_v<T>(); }      // pads sort last and can never win
-    tgs4[t] = v;
-    tperm[t] = (int32_t)j;
+                                                           int m_pad, int bpc, typename V4<T>::type* __restrict__ tgs4, int32_t* __restrict__ tperm) {
+    constexpr int U = 4;                                    // rows per thread in flight (index -> row is a dependent pair)
+    int b, blk;
+    if (!decode_block(bpc, N, b, blk)) return;
+    const int s0 = blk * (BLOCK * U) + threadIdx.x;
+    {
+        long j[U];
+        T y[U][3];
+#pragma unroll
+        for (int u = 0; u < U; ++u) j[u] = order[(size_t)b * m_pad + min(s0 + u * BLOCK, m_pad - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const T* yp = tgt + ((size_t)b * m + (j[u] >= 0 && j[u] < m ? j[u] : 0)) * c;
+            y[u][0] = yp[0]; y[u][1] = yp[1]; y[u][2] = yp[2];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int sl = s0 + u * BLOCK;
+            if (sl >= m_pad) continue;
+            typename V4<T>::type v;
+            if (j[u] >= 0 && j[u] < m) v = pack_row<T>(y[u]);
+            else { v.x = big_v<T>(); v.y = v.z = T(0); v.w = inf_v<T>(); }      // pads sort last and can never win
+            tgs4[(size_t)b * m_pad + sl] = v;
+            tperm[(size_t)b * m_pad + sl] = (int32_t)j[u];
+        }
+    }
 }
 
 template <typename T>
@@ -131,17 +148,22 @@ __global__ __launch_bounds__(BLOCK) void sweep_buckets_kernel(const T* __restric
 
 // sort key of the queries: their x coordinate under the given pose (NULL = identity)
 template <typename T>
-__global__ __launch_bounds__(BLOCK) void query_keys_kernel(const T* __restrict__ src, const T* __restrict__ pose, int N, int n,
+__global__ __launch_bounds__(BLOCK) void query_keys_kernel(const T* __restrict__ src, const T* __restrict__ pose, int N, int n, int bpc,
                                                            T* __restrict__ keys) {
-    const size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (t >= (size_t)N * n) return;
-    const T* p = src + t * 3;
-    T x = p[0];
-    if (pose) {
-        const T* q = pose + (t / n) * 12;
-        x = fma_t(q[0], p[0], fma_t(q[1], p[1], fma_t(q[2], p[2], q[9])));
+    int b, blk;
+    if (!decode_block(bpc, N, b, blk)) return;
+    const int i = blk * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    {
+        const size_t t = (size_t)b * n + i;
+        const T* p = src + t * 3;
+        T x = p[0];
+        if (pose) {
+            const T* q = pose + (size_t)b * 12;
+            x = fma_t(q[0], p[0], fma_t(q[1], p[1], fma_t(q[2], p[2], q[9])));
+        }
+        keys[t] = x;
     }
-    keys[t] = x;
 }
 
 // first-iteration state of the loop: pose_0 from T_init, alive_0 = 1, n_start = rows * #(w0 > thresh)  (ICP.py:124-129)
@@ -770,28 +792,56 @@ __global__ __launch_bounds__(BLOCK) void knn_scan_kernel(const T* __restrict__ s
 }
 
 // ------------------------------------------------------------- gather / scatter
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void gather_kernel(const T* __restrict__ tgt, const int32_t* __restrict__ idx,
-                                                       int N, int n, int m, int c, T* __restrict__ out) {
-    const size_t e = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (e >= (size_t)N * n * c) return;
-    const size_t pt = e / c;
-    const int k = (int)(e % c);
-    const int b = (int)(pt / n);
-    const int j = min(max(idx[pt], 0), m - 1);
-    out[e] = tgt[((size_t)b * m + j) * c + k];
+// Row-indexed copies.  One thread per ELEMENT (consecutive lanes walk a row, so reads of a row and writes of the
+// output are as coalesced as the data allows); all blocks of a cloud run on ONE XCD (decode_block): the rows they
+// pick at random then come out of one L2 instead of being fetched into eight.
+template <int C>
+__device__ __forceinline__ void split_cols(unsigned e, int c, int& row, int& col) {
+    if (C > 0) { row = (int)(e / (unsigned)C); col = (int)(e - (unsigned)row * C); }
+    else       { row = (int)(e / (unsigned)c); col = (int)(e - (unsigned)row * (unsigned)c); }
 }
 
-template <typename T>
+constexpr int ROWS_U = 4;       // elements per thread: both loads of an element depend on each other (index, then row), so
+                                // the kernels are pure latency unless each thread keeps several elements in flight
+
+template <typename T, int C>
+__global__ __launch_bounds__(BLOCK) void gather_kernel(const T* __restrict__ tgt, const int32_t* __restrict__ idx,
+                                                       int N, int n, int m, int c, int bpc, T* __restrict__ out) {
+    const unsigned total = (unsigned)n * (unsigned)c;
+    int b, blk;
+    if (!decode_block(bpc, N, b, blk)) return;
+    const unsigned e0 = (unsigned)blk * (BLOCK * ROWS_U) + threadIdx.x;
+    {
+        int j[ROWS_U], k[ROWS_U];
+#pragma unroll
+        for (int u = 0; u < ROWS_U; ++u) {
+            const unsigned e = min(e0 + u * BLOCK, total - 1);
+            int i;
+            split_cols<C>(e, c, i, k[u]);
+            j[u] = min(max(idx[(size_t)b * n + i], 0), m - 1);
+        }
+        T v[ROWS_U];
+#pragma unroll
+        for (int u = 0; u < ROWS_U; ++u) v[u] = tgt[((size_t)b * m + j[u]) * c + k[u]];
+#pragma unroll
+        for (int u = 0; u < ROWS_U; ++u)
+            if (e0 + u * BLOCK < total) out[(size_t)b * total + e0 + u * BLOCK] = v[u];
+    }
+}
+
+template <typename T, int C>
 __global__ __launch_bounds__(BLOCK) void scatter_add_kernel(const T* __restrict__ gout, const int32_t* __restrict__ idx,
-                                                            int N, int n, int m, int c, T* __restrict__ gtgt) {
-    const size_t e = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (e >= (size_t)N * n * c) return;
-    const size_t pt = e / c;
-    const int k = (int)(e % c);
-    const int b = (int)(pt / n);
-    const int j = min(max(idx[pt], 0), m - 1);
-    unsafeAtomicAdd(&gtgt[((size_t)b * m + j) * c + k], gout[e]);
+                                                            int N, int n, int m, int c, int bpc, T* __restrict__ gtgt) {
+    int b, blk;
+    if (!decode_block(bpc, N, b, blk)) return;
+    const unsigned e = (unsigned)blk * BLOCK + threadIdx.x;
+    if (e >= (unsigned)n * (unsigned)c) return;
+    int i, k;
+    split_cols<C>(e, c, i, k);
+    {
+        const int j = min(max(idx[(size_t)b * n + i], 0), m - 1);
+        unsafeAtomicAdd(&gtgt[((size_t)b * m + j) * c + k], gout[(size_t)b * n * c + e]);
+    }
 }
 
 // -------------------------------------------------------------------- reductions
@@ -834,7 +884,7 @@ __global__ __launch_bounds__(BLOCK) void accumulate_kernel(WeightParams P, const
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = T(0);
     const int end = min(n, (blk + 1) * ACC_PTS);
-    for (int i = blk * ACC_PTS + threadIdx.x; i < end; i += BLOCK) {
+    for (int i = blk * ACC_PTS + threadIdx.x; i < end; i += BLOCK) {       // (4 points in flight per thread measured slower: 85 vs 72 us)
         const size_t pt = (size_t)cloud * n + i;
         const T* sp = src + pt * 3;
         const T p[3] = {sp[0], sp[1], sp[2]};
@@ -1134,7 +1184,7 @@ __global__ __launch_bounds__(BLOCK) void accumulate_bwd_window_kernel(WeightPara
 
 // gtgt[b][tperm[s]][col] += gts_far[b][s][col] + sum over the blocks whose window covers sorted row s of their
 // slab rows: the once-per-call end of the windowed backward (also undoes the sorted target order).
-template <typename T, int WT>
+template <typename T, int WT, int CV>
 __global__ __launch_bounds__(BLOCK) void window_reduce_kernel(const T* __restrict__ slab, const int32_t* __restrict__ spos_ref,
                                                               const int32_t* __restrict__ tperm, const T* __restrict__ gts_far,
                                                               int N, int n, int m, int m_pad, int cv, int spb, int bpc, int rpc,
@@ -1155,7 +1205,7 @@ __global__ __launch_bounds__(BLOCK) void window_reduce_kernel(const T* __restric
         for (int u = 0; u < 4; ++u) {
             const int e = e0 + u * BLOCK + tid;
             if (e >= m * cv) continue;
-            const int s = e / cv, col = e - s * cv;
+            const int s = e / CV, col = e - s * CV;
             for (int b = 0; b < min(MAXB, bpc - b0); ++b) {
                 const int lo = origin[b];
                 if (s >= lo && s < lo + WT)
@@ -1167,7 +1217,7 @@ __global__ __launch_bounds__(BLOCK) void window_reduce_kernel(const T* __restric
     for (int u = 0; u < 4; ++u) {
         const int e = e0 + u * BLOCK + tid;
         if (e >= m * cv) continue;
-        const int s = e / cv, col = e - s * cv;
+        const int s = e / CV, col = e - s * CV;
         T v = acc[u];
         if (gts_far) v += gts_far[((size_t)cloud * m_pad + s) * cv + col];
         const int j = tperm[(size_t)cloud * m_pad + s];
@@ -1177,18 +1227,33 @@ __global__ __launch_bounds__(BLOCK) void window_reduce_kernel(const T* __restric
 
 // out[b][perm[b][s]][0..cols) += in[b][s][0..cols) for s < cnt: undoes a sorted order.  perm must be injective per
 // cloud (plain read-modify-write, no atomics).
-template <typename T>
+template <typename T, int C>
 __global__ __launch_bounds__(BLOCK) void permute_add_rows_kernel(const T* __restrict__ in, const int32_t* __restrict__ perm,
                                                                  int N, int cnt, int in_rows, int perm_rows, int c_in, int cols,
-                                                                 T* __restrict__ out, int out_rows, int c_out) {
-    const size_t e = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (e >= (size_t)N * cnt * cols) return;
-    const size_t rowi = e / cols;
-    const int k = (int)(e % cols);
-    const int b = (int)(rowi / cnt), s = (int)(rowi % cnt);
-    const int j = perm[(size_t)b * perm_rows + s];
-    if (j < 0 || j >= out_rows) return;
-    out[((size_t)b * out_rows + j) * c_out + k] += in[((size_t)b * in_rows + s) * c_in + k];
+                                                                 T* __restrict__ out, int out_rows, int c_out, int bpc) {
+    const unsigned total = (unsigned)cnt * (unsigned)cols;
+    int b, blk;
+    if (!decode_block(bpc, N, b, blk)) return;
+    const unsigned e0 = (unsigned)blk * (BLOCK * ROWS_U) + threadIdx.x;
+    {
+        int j[ROWS_U], k[ROWS_U];
+        T v[ROWS_U], o[ROWS_U];
+        bool ok[ROWS_U];
+#pragma unroll
+        for (int u = 0; u < ROWS_U; ++u) {
+            const unsigned e = min(e0 + u * BLOCK, total - 1);
+            int s;
+            split_cols<C>(e, cols, s, k[u]);
+            j[u] = perm[(size_t)b * perm_rows + s];
+            v[u] = in[((size_t)b * in_rows + s) * c_in + k[u]];
+            ok[u] = e0 + u * BLOCK < total && j[u] >= 0 && j[u] < out_rows;
+        }
+#pragma unroll
+        for (int u = 0; u < ROWS_U; ++u) o[u] = ok[u] ? out[((size_t)b * out_rows + j[u]) * c_out + k[u]] : T(0);
+#pragma unroll
+        for (int u = 0; u < ROWS_U; ++u)
+            if (ok[u]) out[((size_t)b * out_rows + j[u]) * c_out + k[u]] = o[u] + v[u];
+    }
 }
 
 // ---------------------------------------------------------------------- step bwd
@@ -1707,9 +1772,10 @@ int dicp_pack_target(int dtype, const void* tgt, int N, int m, int c, void* tgt4
     if ((uintptr_t)tgt4 % (dtype == DICP_F32 ? 16 : 32)) return DICP_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
     begin_launch();
-    const unsigned g = blocks_for((size_t)N * m_pad);
-    if (dtype == DICP_F32) pack_kernel<float><<<g, BLOCK, 0, st>>>((const float*)tgt, N, m, c, (float4*)tgt4, m_pad);
-    else                   pack_kernel<double><<<g, BLOCK, 0, st>>>((const double*)tgt, N, m, c, (double4*)tgt4, m_pad);
+    const int bpc = (int)blocks_for((size_t)m_pad);
+    const unsigned g = grid_for(N, bpc);
+    if (dtype == DICP_F32) pack_kernel<float><<<g, BLOCK, 0, st>>>((const float*)tgt, N, m, c, (float4*)tgt4, m_pad, bpc);
+    else                   pack_kernel<double><<<g, BLOCK, 0, st>>>((const double*)tgt, N, m, c, (double4*)tgt4, m_pad, bpc);
     return launch_status();
 }
 
@@ -1721,12 +1787,13 @@ int dicp_sweep_build(int dtype, const void* tgt, int c, const int64_t* order, co
     if ((uintptr_t)tgs4 % (dtype == DICP_F32 ? 16 : 32)) return DICP_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
     begin_launch();
-    const unsigned g = blocks_for((size_t)N * m_pad);
+    const int bpc = (m_pad + BLOCK * 4 - 1) / (BLOCK * 4);
+    const unsigned g = grid_for(N, bpc);
     if (dtype == DICP_F32) {
-        sweep_rows_kernel<float><<<g, BLOCK, 0, st>>>((const float*)tgt, order, N, m, c, m_pad, (float4*)tgs4, tperm);
+        sweep_rows_kernel<float><<<g, BLOCK, 0, st>>>((const float*)tgt, order, N, m, c, m_pad, bpc, (float4*)tgs4, tperm);
         sweep_buckets_kernel<float><<<N, BLOCK, 0, st>>>((const float*)keys_sorted, N, m, m_pad, nbkt, bucket, (float*)brange);
     } else {
-        sweep_rows_kernel<double><<<g, BLOCK, 0, st>>>((const double*)tgt, order, N, m, c, m_pad, (double4*)tgs4, tperm);
+        sweep_rows_kernel<double><<<g, BLOCK, 0, st>>>((const double*)tgt, order, N, m, c, m_pad, bpc, (double4*)tgs4, tperm);
         sweep_buckets_kernel<double><<<N, BLOCK, 0, st>>>((const double*)keys_sorted, N, m, m_pad, nbkt, bucket, (double*)brange);
     }
     return launch_status();
@@ -1738,9 +1805,10 @@ int dicp_query_keys(int dtype, const void* src, const void* pose, int N, int n, 
     if (N <= 0 || n <= 0) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     begin_launch();
-    const unsigned g = blocks_for((size_t)N * n);
-    if (dtype == DICP_F32) query_keys_kernel<float><<<g, BLOCK, 0, st>>>((const float*)src, (const float*)pose, N, n, (float*)keys);
-    else                   query_keys_kernel<double><<<g, BLOCK, 0, st>>>((const double*)src, (const double*)pose, N, n, (double*)keys);
+    const int bpc = (int)blocks_for((size_t)n);
+    const unsigned g = grid_for(N, bpc);
+    if (dtype == DICP_F32) query_keys_kernel<float><<<g, BLOCK, 0, st>>>((const float*)src, (const float*)pose, N, n, bpc, (float*)keys);
+    else                   query_keys_kernel<double><<<g, BLOCK, 0, st>>>((const double*)src, (const double*)pose, N, n, bpc, (double*)keys);
     return launch_status();
 }
 
@@ -1838,9 +1906,14 @@ int dicp_gather_rows(int dtype, const void* tgt, const int32_t* idx, int N, int 
     if (N <= 0 || n <= 0 || m <= 0 || c <= 0) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     begin_launch();
-    const unsigned g = blocks_for((size_t)N * n * c);
-    if (dtype == DICP_F32) gather_kernel<float><<<g, BLOCK, 0, st>>>((const float*)tgt, idx, N, n, m, c, (float*)out);
-    else                   gather_kernel<double><<<g, BLOCK, 0, st>>>((const double*)tgt, idx, N, n, m, c, (double*)out);
+    if ((size_t)n * c > 0x7fffffffu) return DICP_ERR_SHAPE;
+    const int bpc = (int)(((size_t)n * c + BLOCK * ROWS_U - 1) / (BLOCK * ROWS_U));
+    const unsigned g = grid_for(N, bpc);
+#define DICP_ROWS(K, T, C) K<T, C><<<g, BLOCK, 0, st>>>((const T*)tgt, idx, N, n, m, c, bpc, (T*)out)
+#define DICP_ROWS_C(K, T) do { if (c == 1) DICP_ROWS(K, T, 1); else if (c == 3) DICP_ROWS(K, T, 3); else if (c == 6) DICP_ROWS(K, T, 6); \
+        else DICP_ROWS(K, T, 0); } while (0)
+    if (dtype == DICP_F32) DICP_ROWS_C(gather_kernel, float); else DICP_ROWS_C(gather_kernel, double);
+#undef DICP_ROWS
     return launch_status();
 }
 
@@ -1850,9 +1923,13 @@ int dicp_scatter_add_rows(int dtype, const void* gout, const int32_t* idx, int N
     if (N <= 0 || n <= 0 || m <= 0 || c <= 0) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     begin_launch();
-    const unsigned g = blocks_for((size_t)N * n * c);
-    if (dtype == DICP_F32) scatter_add_kernel<float><<<g, BLOCK, 0, st>>>((const float*)gout, idx, N, n, m, c, (float*)gtgt);
-    else                   scatter_add_kernel<double><<<g, BLOCK, 0, st>>>((const double*)gout, idx, N, n, m, c, (double*)gtgt);
+    if ((size_t)n * c > 0x7fffffffu) return DICP_ERR_SHAPE;
+    const int bpc = (int)blocks_for((size_t)n * c);
+    const unsigned g = grid_for(N, bpc);
+#define DICP_ROWS(K, T, C) K<T, C><<<g, BLOCK, 0, st>>>((const T*)gout, idx, N, n, m, c, bpc, (T*)gtgt)
+    if (dtype == DICP_F32) DICP_ROWS_C(scatter_add_kernel, float); else DICP_ROWS_C(scatter_add_kernel, double);
+#undef DICP_ROWS
+#undef DICP_ROWS_C
     return launch_status();
 }
 
@@ -2058,15 +2135,11 @@ int dicp_window_reduce(int dtype, const void* slab, const int32_t* spos_ref, con
     const int bpc = dicp_window_blocks(dtype, n, m_pad);
     const int rpc = (m * cv + BLOCK * 4 - 1) / (BLOCK * 4);
     const unsigned g = grid_for(N, rpc);
-    if (dtype == DICP_F32) {
-        constexpr int WT = WindowRows<float>::v;
-        window_reduce_kernel<float, WT><<<g, BLOCK, 0, st>>>((const float*)slab, spos_ref, tperm, (const float*)gts_far, N, n, m, m_pad, cv,
-                                                              window_slots(WT, n, m_pad), bpc, rpc, (float*)gtgt, c);
-    } else {
-        constexpr int WT = WindowRows<double>::v;
-        window_reduce_kernel<double, WT><<<g, BLOCK, 0, st>>>((const double*)slab, spos_ref, tperm, (const double*)gts_far, N, n, m, m_pad, cv,
-                                                               window_slots(WT, n, m_pad), bpc, rpc, (double*)gtgt, c);
-    }
+#define DICP_RED(T, CVV) window_reduce_kernel<T, WindowRows<T>::v, CVV><<<g, BLOCK, 0, st>>>((const T*)slab, spos_ref, tperm, (const T*)gts_far, N, n, m, m_pad, cv, \
+        window_slots(WindowRows<T>::v, n, m_pad), bpc, rpc, (T*)gtgt, c)
+    if (dtype == DICP_F32) { if (cv == 6) DICP_RED(float, 6); else DICP_RED(float, 3); }
+    else                   { if (cv == 6) DICP_RED(double, 6); else DICP_RED(double, 3); }
+#undef DICP_RED
     return launch_status();
 }
 
@@ -2077,9 +2150,14 @@ int dicp_permute_add_rows(int dtype, const void* in, const int32_t* perm, int N,
     if (N <= 0 || cnt <= 0 || cnt > in_rows || cnt > perm_rows || cols <= 0 || cols > c_in || cols > c_out || out_rows <= 0) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     begin_launch();
-    const unsigned g = blocks_for((size_t)N * cnt * cols);
-    if (dtype == DICP_F32) permute_add_rows_kernel<float><<<g, BLOCK, 0, st>>>((const float*)in, perm, N, cnt, in_rows, perm_rows, c_in, cols, (float*)out, out_rows, c_out);
-    else                   permute_add_rows_kernel<double><<<g, BLOCK, 0, st>>>((const double*)in, perm, N, cnt, in_rows, perm_rows, c_in, cols, (double*)out, out_rows, c_out);
+    if ((size_t)cnt * cols > 0x7fffffffu) return DICP_ERR_SHAPE;
+    const int bpc = (int)(((size_t)cnt * cols + BLOCK * ROWS_U - 1) / (BLOCK * ROWS_U));
+    const unsigned g = grid_for(N, bpc);
+#define DICP_PERM(T, C) permute_add_rows_kernel<T, C><<<g, BLOCK, 0, st>>>((const T*)in, perm, N, cnt, in_rows, perm_rows, c_in, cols, (T*)out, out_rows, c_out, bpc)
+#define DICP_PERM_C(T) do { if (cols == 1) DICP_PERM(T, 1); else if (cols == 3) DICP_PERM(T, 3); else if (cols == 6) DICP_PERM(T, 6); else DICP_PERM(T, 0); } while (0)
+    if (dtype == DICP_F32) DICP_PERM_C(float); else DICP_PERM_C(double);
+#undef DICP_PERM
+#undef DICP_PERM_C
     return launch_status();
 }
 

@@ -1,0 +1,49 @@
+"""Timeline of the LAST (timed) ICP call in a rocprofv3 --kernel-trace of bench.py: kernel, duration, gap before it.
+
+    rocprofv3 --kernel-trace -d out -o t --output-format csv -- python3 bench.py --no-cpu-baseline
+    python scripts/trace_timeline.py out/t_kernel_trace.csv [--full]
+"""
+import csv, sys, collections
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+
+
+def short(n):
+    n = n.replace("(anonymous namespace)::", "").replace("void ", "")
+    if n.startswith("Cijk"):
+        return "GEMM"
+    for key in ("segmented_sort", "fill_reverse_indices", "FillFunctor", "direct_copy", "copyBuffer", "where_kernel", "CompareEq",
+                "MulFunctor", "DivFunctor", "sum_functor", "CUDAFunctor_add", "searchsorted", "BatchedCopy", "masked_fill", "gather", "arange",
+                "compare_scalar", "clamp", "reciprocal"):
+        if key in n:
+            return "torch:" + key
+    return n.split("<")[0].split("(")[0]
+
+
+# the timed call = everything after the last big idle gap that precedes the last 10 kNN launches
+knn = [i for i, r in enumerate(rows) if "knn_sweep_kernel" in r["Kernel_Name"] or "knn_valu_kernel" in r["Kernel_Name"] or "knn_scan" in r["Kernel_Name"]]
+first = knn[-13] if len(knn) >= 13 else knn[0]      # 10 timed launches + 3 brute-force launches of the roofline leg after them
+lo = first
+while lo > 0 and int(rows[lo]["Start_Timestamp"]) - int(rows[lo - 1]["End_Timestamp"]) < 2_000_000:
+    lo -= 1
+hi = max(i for i, r in enumerate(rows) if "window_reduce" in r["Kernel_Name"] or "accumulate_bwd" in r["Kernel_Name"]) + 6
+seg = rows[lo:min(hi, len(rows))]
+t0 = int(seg[0]["Start_Timestamp"])
+agg = collections.OrderedDict()
+prev = None
+gaps = 0.0
+for r in seg:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    gap = max(0.0, (s - prev) / 1e3) if prev else 0.0
+    gaps += gap
+    nm = short(r["Kernel_Name"])
+    a = agg.setdefault(nm, [0, 0.0])
+    a[0] += 1; a[1] += (e - s) / 1e3
+    if "--full" in sys.argv:
+        print("%9.1f us  dur %8.1f  gap %7.1f  %s" % ((s - t0) / 1e3, (e - s) / 1e3, gap, nm))
+    prev = max(prev or 0, e)
+span = (prev - t0) / 1e3
+print("timed call: %.1f us from first to last kernel, %d kernels, idle gaps %.1f us" % (span, len(seg), gaps))
+for nm, (cnt, dur) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    print("%-44s x%-3d %9.1f us  %5.1f %%" % (nm[:44], cnt, dur, 100 * dur / span))

@@ -110,12 +110,19 @@ class SweepIndex:
         """(query,target) pairs scored so far (device scalar)."""
         return self.pair_shards.sum()
 
-    def query_order(self, src, pose):
-        """Query indices in ascending transformed x (keeps a wave's queries neighbours)."""
+    def query_order(self, src, pose, exact=False):
+        """Query indices in (approximately) ascending transformed x: keeps a wave's queries neighbours.  Default: a
+        counting sort by x bucket (dicp_query_order); exact=True: a full sort of the x keys."""
         N, n, _ = src.shape
-        keys = torch.empty((N, n), dtype=src.dtype, device=src.device)
+        lib = _lib.load()
         with torch.cuda.device(src.device):
-            _lib.check(_lib.load().dicp_query_keys(_DT[src.dtype], _p(src), _p(pose), N, n, _p(keys), _stream()), "dicp_query_keys")
+            if not exact:
+                qorder = torch.empty((N, n), dtype=torch.int32, device=src.device)
+                _lib.check(lib.dicp_query_order(_DT[src.dtype], _p(src), _p(pose), _p(self.brange), self.NBKT, N, n, _p(qorder), _stream()),
+                           "dicp_query_order")
+                return qorder
+            keys = torch.empty((N, n), dtype=src.dtype, device=src.device)
+            _lib.check(lib.dicp_query_keys(_DT[src.dtype], _p(src), _p(pose), N, n, _p(keys), _stream()), "dicp_query_keys")
         return torch.argsort(keys, dim=1).to(torch.int32)
 
     def knn(self, src, pose, qorder=None, out=None, cfg=0, spos=None):
@@ -297,7 +304,7 @@ class LoopConfig:
     tanh_steepness: float
     match_ratio_thresh: float
     knn_variant: int = _lib.KNN_AUTO
-    sweep_resort: tuple = tuple(int(v) for v in os.environ.get("DICP_SWEEP_RESORT", "0,2").split(","))  # iterations at which the sweep kNN re-sorts its queries by x
+    sweep_resort: tuple = tuple(int(v) for v in os.environ.get("DICP_SWEEP_RESORT", "0,1,2,3").split(","))  # iterations at which the sweep kNN re-sorts its queries by x
     bwd_window: bool = True       # sweep path: backward in sorted space (LDS window + full-line atomic flush)
     stats_out: object = None      # optional dict: receives "knn_pairs" (pairs scored by the sweep kNN; int64 shards, sum them)
     sync_every: object = None     # tolerance mode: iterations between the host's all-converged checks (None = auto)
@@ -320,7 +327,8 @@ def _pose_from_T(T):
     return torch.cat((T[:, :3, :3].reshape(N, 9), T[:, :3, 3]), dim=1).contiguous()
 
 
-WINDOW_MIN_ITERS = 3            # query orders used by fewer iterations than this take the atomic backward (see ICPLoop.backward)
+WINDOW_MIN_ITERS = 3            # fewer windowed iterations than this: all take the atomic backward (see ICPLoop.backward)
+WINDOW_FROM = int(os.environ.get("DICP_WINDOW_FROM", "0"))      # first windowed iteration (measured: even iteration 0 pays, 0.13 vs 0.28 ms)
 HIST_CHUNK_BYTES = 1 << 29      # per-iteration histories (indices, weights) are allocated in slabs of at most this size
 
 
@@ -511,26 +519,27 @@ class ICPLoop(torch.autograd.Function):
             gw = torch.zeros_like(w0c) if want_w else None
             gtgt = torch.zeros_like(tgt) if want_tgt else None
             # Two forms of accumulate_bwd.  Atomic form (dicp_accumulate_bwd): original order, no set-up.  Windowed form
-            # (dicp_accumulate_bwd_window, sweep path): everything in sorted space -- one sorted copy of the source /
-            # weights and one gradient accumulator per query order, target rows in the sweep's order, per-block slabs
-            # for the target gradient -- 2.4x faster per iteration but ~0.4 ms of set-up and un-permuting per order,
-            # so an order is worth it from WINDOW_MIN_ITERS iterations on (the pre-resort order of iteration 0 is not).
-            iters_of = {}
-            for (a, b, q) in segs:
-                iters_of[q] = iters_of.get(q, 0) + (b - a)
-            win = sorted(q for q in iters_of if owned and iters_of[q] >= WINDOW_MIN_ITERS)
+            # (dicp_accumulate_bwd_window, sweep path): everything in sorted space -- sorted copies of the source /
+            # weights, slot-order gradient accumulators, target rows in the sweep's order, per-block slabs for the target
+            # gradient -- 2.4x faster per iteration for ~0.4 ms of set-up and un-permuting per call.  ONE slot order serves
+            # every windowed iteration: the last query order of the forward (the best sorted under the final poses); the
+            # matches are stored per query, so the forward may have searched those iterations in other orders.  Matches that
+            # fall outside a window (early iterations, whose poses are still far) take the kernel's atomic side path.
+            q_star = len(qorders) - 1
+            windowed = [owned and (q == q_star or a >= WINDOW_FROM) for (a, _, q) in segs]
+            if sum(b - a for (a, b, _), wf in zip(segs, windowed) if wf) < WINDOW_MIN_ITERS:
+                windowed = [False] * len(segs)
             nblk_a, nblk_w = lib.dicp_accumulate_blocks(n), lib.dicp_window_blocks(code, n, m_pad)
-            if win:
-                src_q = {q: _gather_rows_raw(src, qorders[q]) for q in win}
-                w_q = {q: _gather_rows_raw(w0c.unsqueeze(-1), qorders[q]).squeeze(-1) for q in win}
-                gsrc_q = {q: torch.zeros_like(src) for q in win}
-                gw_q = {q: torch.zeros_like(w0c) if want_w else None for q in win}
+            if any(windowed):
+                qo = qorders[q_star]
+                src_s = _gather_rows_raw(src, qo)
+                w_s = _gather_rows_raw(w0c.unsqueeze(-1), qo).squeeze(-1)
+                gsrc_s = torch.zeros_like(src)
+                gw_s = torch.zeros_like(w0c) if want_w else None
                 tgt_s = _gather_rows_raw(tgt, tperm)                       # (N,m_pad,c); pad slots repeat row m-1 (never matched)
-                # windows placed by the matches of the LAST iteration that used the order
-                last_k = {q: max(b for (_, b, qq) in segs if qq == q) - 1 for q in win}
-                ref_q = {q: spos_slabs[last_k[q] // kc][last_k[q] % kc] for q in win}
-                wt = lib.dicp_window_rows(code)
-                slab_q = {q: torch.zeros((N, nblk_w, wt, cv), dtype=dt, device=dev) if want_tgt else None for q in win}
+                k_ref = max(b for (_, b, _), wf in zip(segs, windowed) if wf) - 1      # windows placed by the last iteration's matches
+                spos_ref = spos_slabs[k_ref // kc][k_ref % kc]
+                slab = torch.zeros((N, nblk_w, lib.dicp_window_rows(code), cv), dtype=dt, device=dev) if want_tgt else None
                 gfar = torch.zeros((N, m_pad, cv), dtype=dt, device=dev) if want_tgt else None
             gs = torch.empty((N, 36), dtype=dt, device=dev)
             gb = torch.empty((N, 6), dtype=dt, device=dev)
@@ -540,8 +549,7 @@ class ICPLoop(torch.autograd.Function):
             ev = cfg.timing_events
             events = ev.handles(Kmax) if ev is not None else None
             have, form = 0, None
-            for (k0, k1, q) in reversed(segs):
-                w_form = q in win
+            for (k0, k1, q), w_form in zip(reversed(segs), reversed(windowed)):
                 if have and w_form != form:     # the partials of the other form have another block count: fold them in here
                     gpose += bwdp[form].sum(dim=1)[:, :12].to(torch.float64)
                     have = 0
@@ -549,27 +557,26 @@ class ICPLoop(torch.autograd.Function):
                 j = k0 // kc
                 base = j * kc
                 LB = _lib.LoopBuffers(
-                    src=_p(src_q[q]) if w_form else _p(src), tgt=_p(tgt_s) if w_form else _p(tgt),
-                    w_init=_p(w_q[q]) if w_form else _p(w0c), c=c, K=Kmax, knn_variant=kind, m_pad=m_pad, idx_per_iter=1,
+                    src=_p(src_s) if w_form else _p(src), tgt=_p(tgt_s) if w_form else _p(tgt),
+                    w_init=_p(w_s) if w_form else _p(w0c), c=c, K=Kmax, knn_variant=kind, m_pad=m_pad, idx_per_iter=1,
+                    qorder=_p(qo) if w_form else None,
                     spos=ctypes.c_void_p(spos_slabs[j].data_ptr() - base * N * n * 4) if w_form else None,
-                    spos_ref=_p(ref_q[q]) if w_form else None, gts_far=_p(gfar) if w_form else None,
+                    spos_ref=_p(spos_ref) if w_form else None, gts_far=_p(gfar) if w_form else None,
                     poses=_p(poses), deltas=_p(deltas), areg=_p(areg), alive=_p(alive),
                     idx=ctypes.c_void_p(idx_slabs[j].data_ptr() - base * N * n * 4), events=events)
                 _lib.check(lib.dicp_icp_backward(code, ctypes.byref(P), ctypes.byref(LB), N, n, m, int(cfg.dim), _p(gpose), _p(gtmp), have,
-                                                 _p(gs), _p(gb), _p(gsrc_q[q]) if w_form else _p(gsrc), _p(slab_q[q]) if w_form else _p(gtgt),
-                                                 _p(gw_q[q]) if w_form else _p(gw), _p(bwdp[form]), k0, k1, st), "dicp_icp_backward")
+                                                 _p(gs), _p(gb), _p(gsrc_s) if w_form else _p(gsrc), _p(slab) if w_form else _p(gtgt),
+                                                 _p(gw_s) if w_form else _p(gw), _p(bwdp[form]), k0, k1, st), "dicp_icp_backward")
                 have = 1
             if have:
                 gpose = gpose + bwdp[form].sum(dim=1)[:, :12].to(torch.float64)
-            for i, q in enumerate(win):     # slot s of order q is source point qorders[q][s]
-                _lib.check(lib.dicp_permute_add_rows(code, _p(gsrc_q[q]), _p(qorders[q]), N, n, n, n, 3, 3, _p(gsrc), n, 3, st),
-                           "dicp_permute_add_rows")
+            if any(windowed):               # slot s is source point qo[s]; slabs + out-of-window rows -> original target order
+                _lib.check(lib.dicp_permute_add_rows(code, _p(gsrc_s), _p(qo), N, n, n, n, 3, 3, _p(gsrc), n, 3, st), "dicp_permute_add_rows")
                 if want_w:
-                    _lib.check(lib.dicp_permute_add_rows(code, _p(gw_q[q]), _p(qorders[q]), N, n, n, n, 1, 1, _p(gw), n, 1, st),
-                               "dicp_permute_add_rows")
-                if want_tgt:                # slabs + out-of-window rows -> original target order
-                    _lib.check(lib.dicp_window_reduce(code, _p(slab_q[q]), _p(ref_q[q]), _p(tperm), _p(gfar) if i == 0 else None,
-                                                      N, n, m, m_pad, cv, _p(gtgt), c, st), "dicp_window_reduce")
+                    _lib.check(lib.dicp_permute_add_rows(code, _p(gw_s), _p(qo), N, n, n, n, 1, 1, _p(gw), n, 1, st), "dicp_permute_add_rows")
+                if want_tgt:
+                    _lib.check(lib.dicp_window_reduce(code, _p(slab), _p(spos_ref), _p(qo), _p(tperm), _p(gfar), N, n, m, m_pad, cv,
+                                                      _p(gtgt), c, st), "dicp_window_reduce")
             gT0 = torch.zeros((N, 4, 4), dtype=dt, device=dev)
             gT0[:, :3, :3] = gpose[:, :9].reshape(N, 3, 3).to(dt)
             gT0[:, :3, 3] = gpose[:, 9:].to(dt)

@@ -166,6 +166,55 @@ __global__ __launch_bounds__(BLOCK) void query_keys_kernel(const T* __restrict__
     }
 }
 
+// Query order for the sweep: a counting sort of the queries by the bucket of their transformed x (equal-width buckets over
+// the TARGET's x range, the same table geometry as the search's bucket index).  The order inside a bucket is arbitrary:
+// the search is exact for any order, the order only keeps a wave's queries neighbours in x, and 16 unordered queries
+// per bucket widen a wave's slab by a few rows.  One block per cloud, everything in LDS: ~20x cheaper than a full sort.
+constexpr int QO_THREADS = 1024;
+constexpr int QO_BUCKETS = 2048;
+template <typename T>
+__global__ __launch_bounds__(QO_THREADS) void query_order_kernel(const T* __restrict__ src, const T* __restrict__ pose,
+                                                                 const T* __restrict__ brange, int nbkt_range, int N, int n,
+                                                                 int32_t* __restrict__ qorder) {
+    __shared__ int cnt[QO_BUCKETS];
+    __shared__ int wsum[QO_THREADS / WAVE];
+    const int cloud = blockIdx.x, tid = threadIdx.x;
+    for (int b = tid; b < QO_BUCKETS; b += QO_THREADS) cnt[b] = 0;
+    T q[4] = {T(1), T(0), T(0), T(0)};
+    if (pose) { const T* pp = pose + (size_t)cloud * 12; q[0] = pp[0]; q[1] = pp[1]; q[2] = pp[2]; q[3] = pp[9]; }
+    const T xlo = brange[(size_t)cloud * 2];
+    const T scale = brange[(size_t)cloud * 2 + 1] * (T(QO_BUCKETS) / T(nbkt_range));      // buckets per unit x
+    auto bucket_of = [&](int i) {
+        const T* p = src + ((size_t)cloud * n + i) * 3;
+        const T x = fma_t(q[0], p[0], fma_t(q[1], p[1], fma_t(q[2], p[2], q[3])));
+        T f = (x - xlo) * scale;
+        f = f > T(0) ? (f < T(QO_BUCKETS - 1) ? f : T(QO_BUCKETS - 1)) : T(0);             // NaN and out-of-range -> end buckets
+        return (int)f;
+    };
+    __syncthreads();
+    for (int i = tid; i < n; i += QO_THREADS) atomicAdd(&cnt[bucket_of(i)], 1);
+    __syncthreads();
+    // exclusive prefix sum of the QO_BUCKETS counters (two per thread)
+    const int a0 = cnt[2 * tid], a1 = cnt[2 * tid + 1];
+    int v = a0 + a1;
+    const int lane = tid & (WAVE - 1), wave = tid >> 6;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) { const int o = __shfl_up(v, off); if (lane >= off) v += o; }
+    if (lane == WAVE - 1) wsum[wave] = v;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    const int excl = base + v - (a0 + a1);
+    __syncthreads();
+    cnt[2 * tid] = excl;
+    cnt[2 * tid + 1] = excl + a0;
+    __syncthreads();
+    for (int i = tid; i < n; i += QO_THREADS) {
+        const int slot = atomicAdd(&cnt[bucket_of(i)], 1);
+        qorder[(size_t)cloud * n + min(slot, n - 1)] = i;
+    }
+}
+
 // first-iteration state of the loop: pose_0 from T_init, alive_0 = 1, n_start = rows * #(w0 > thresh)  (ICP.py:124-129)
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void loop_init_kernel(const T* __restrict__ T_init, const T* __restrict__ w0, T thresh, int rows, int n,
@@ -633,8 +682,8 @@ __global__ __launch_bounds__(BLOCK) void knn_sweep_kernel(const T* __restrict__ 
             for (int j = visL * WAVE; j < visR * WAVE; ++j) consider(j);
         }
         idx[(size_t)cloud * n + qi[q]] = (bo == 0x7fffffff) ? 0 : min(max(bo, 0), m - 1);
-        // sorted position of the winner, stored at the query's SORTED slot: what the owner-computes backward scans
-        if (spos) spos[(size_t)cloud * n + unit * (WAVE * Q) + q * WAVE + lane] = (bo == 0x7fffffff || bo >= m) ? -1 : bs;
+        // sorted position of the winner (indexed like idx, by the query): what the windowed backward consumes
+        if (spos) spos[(size_t)cloud * n + qi[q]] = (bo == 0x7fffffff || bo >= m) ? -1 : bs;
     }
     // sharded: one counter serialises ~12 ns per add, which at 65k waves would outlast the kernel itself
     if (pairs && lane == 0) atomicAdd(pairs + (blockIdx.x & (DICP_PAIR_SHARDS - 1)), (unsigned long long)(visR - visL) * WAVE * WAVE * Q);
@@ -781,7 +830,7 @@ __global__ __launch_bounds__(BLOCK) void knn_scan_kernel(const T* __restrict__ s
     if (live) {
         const int bo = bs >= 0 ? pm[bs] : 0x7fffffff;
         idx[(size_t)cloud * n + qi] = (bo == 0x7fffffff) ? 0 : min(max(bo, 0), m - 1);
-        if (spos) spos[(size_t)cloud * n + slot] = (bo == 0x7fffffff || bo >= m) ? -1 : bs;
+        if (spos) spos[(size_t)cloud * n + qi] = (bo == 0x7fffffff || bo >= m) ? -1 : bs;
     }
     if (pairs) {
         int cnt = live ? (min(r, m_pad) - c) + (c - 1 - max(l, -1)) : 0;
@@ -1071,15 +1120,18 @@ __host__ __device__ inline int window_slots(int WT, int n, int m_pad) {
 
 // first sorted row of block blk's window: centred on the reference neighbour of the block's middle slot
 // (robust against outliers at the ends), a multiple of 16 rows
-__device__ __forceinline__ int window_origin(const int32_t* __restrict__ sp_ref_c, int blk, int spb, int n, int m_pad, int WT) {
+__device__ __forceinline__ int window_origin(const int32_t* __restrict__ sp_ref_c, const int32_t* __restrict__ qo_c,
+                                             int blk, int spb, int n, int m_pad, int WT) {
     if (m_pad <= WT) return 0;
-    const int ctr = max(sp_ref_c[min(blk * spb + spb / 2, n - 1)], 0);
+    const int mid = min(blk * spb + spb / 2, n - 1);
+    const int ctr = max(sp_ref_c[qo_c ? min(max(qo_c[mid], 0), n - 1) : mid], 0);
     return min(max(ctr - WT / 2, 0), m_pad - WT) & ~15;
 }
 
 template <typename T, int MODE, int WT>
 __global__ __launch_bounds__(BLOCK) void accumulate_bwd_window_kernel(WeightParams P, const T* __restrict__ src_s, const T* __restrict__ tgt_s, int c,
                                                                       const int32_t* __restrict__ spos, const int32_t* __restrict__ spos_ref,
+                                                                      const int32_t* __restrict__ qorder,
                                                                       const T* __restrict__ pose, const T* __restrict__ w_s, const T* __restrict__ alive,
                                                                       const T* __restrict__ gs, const T* __restrict__ gb,
                                                                       int N, int n, int m_pad, int spb, int bpc,
@@ -1096,8 +1148,23 @@ __global__ __launch_bounds__(BLOCK) void accumulate_bwd_window_kernel(WeightPara
     const int tid = threadIdx.x;
     const int s0 = blk * spb, s1 = min(n, s0 + spb);
     const int32_t* __restrict__ sp_c = spos + (size_t)cloud * n;
-    const int lo = window_origin(spos_ref + (size_t)cloud * n, blk, spb, n, m_pad, WT);
+    const int32_t* __restrict__ qo_c = qorder ? qorder + (size_t)cloud * n : nullptr;  // slot -> query (spos is indexed by query)
+    constexpr int U = 4;                                    // slots per thread, all in flight: spb <= U * BLOCK = SPB
+    // the two dependent index chains (slot -> query -> match, and the same for the window origin) start first and
+    // run under everything else the prologue loads
+    bool on[U];
+    int pos[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int s = s0 + u * BLOCK + tid;
+        on[u] = s < s1;
+        const int sq = on[u] ? s : s0;
+        pos[u] = qo_c ? min(max(qo_c[sq], 0), n - 1) : sq;
+    }
+    const int lo = window_origin(spos_ref + (size_t)cloud * n, qo_c, blk, spb, n, m_pad, WT);
     const int hi = min(lo + WT, m_pad);
+#pragma unroll
+    for (int u = 0; u < U; ++u) pos[u] = min(max(sp_c[pos[u]], 0), m_pad - 1);     // -1 (no neighbour: non-finite input) -> row 0
     if (slab)
         for (int k = tid; k < hi - lo; k += BLOCK) head[k] = -1;
     T C[9], r[3], Gs[36], Gb[6];
@@ -1112,17 +1179,13 @@ __global__ __launch_bounds__(BLOCK) void accumulate_bwd_window_kernel(WeightPara
     for (int k = 0; k < NBWD; ++k) acc[k] = T(0);
     __syncthreads();
     T* gfar = gts_far ? gts_far + (size_t)cloud * m_pad * CV : nullptr;
-    constexpr int U = 4;                                    // slots per thread in flight: every load of a round is issued
-    for (int base = s0; base < s1; base += U * BLOCK) {     // before the first dependent use (the block is latency-bound)
-        bool on[U];
-        int pos[U];
+    {                                                       // every load is issued before its first dependent use
+        const int base = s0;                                // (the block is latency-bound)
         T p[U][3], y[U][3], nrm[U][3], wv[U], g0[U][3], gwv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int s = base + u * BLOCK + tid;
-            on[u] = s < s1;
             const size_t pt = (size_t)cloud * n + (on[u] ? s : s0);
-            pos[u] = min(max(sp_c[on[u] ? s : s0], 0), m_pad - 1);  // -1 (no neighbour: non-finite input) -> row 0
             const T* spp = src_s + pt * 3;
             p[u][0] = spp[0]; p[u][1] = spp[1]; p[u][2] = spp[2];
             wv[u] = w_s[pt];
@@ -1186,6 +1249,7 @@ __global__ __launch_bounds__(BLOCK) void accumulate_bwd_window_kernel(WeightPara
 // slab rows: the once-per-call end of the windowed backward (also undoes the sorted target order).
 template <typename T, int WT, int CV>
 __global__ __launch_bounds__(BLOCK) void window_reduce_kernel(const T* __restrict__ slab, const int32_t* __restrict__ spos_ref,
+                                                              const int32_t* __restrict__ qorder,
                                                               const int32_t* __restrict__ tperm, const T* __restrict__ gts_far,
                                                               int N, int n, int m, int m_pad, int cv, int spb, int bpc, int rpc,
                                                               T* __restrict__ gtgt, int c) {
@@ -1199,7 +1263,7 @@ __global__ __launch_bounds__(BLOCK) void window_reduce_kernel(const T* __restric
     for (int b0 = 0; b0 < bpc; b0 += MAXB) {
         __syncthreads();
         for (int b = tid; b < min(MAXB, bpc - b0); b += BLOCK)
-            origin[b] = window_origin(spos_ref + (size_t)cloud * n, b0 + b, spb, n, m_pad, WT);
+            origin[b] = window_origin(spos_ref + (size_t)cloud * n, qorder ? qorder + (size_t)cloud * n : nullptr, b0 + b, spb, n, m_pad, WT);
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -1812,6 +1876,17 @@ int dicp_query_keys(int dtype, const void* src, const void* pose, int N, int n, 
     return launch_status();
 }
 
+int dicp_query_order(int dtype, const void* src, const void* pose, const void* brange, int nbkt, int N, int n, int32_t* qorder, void* stream) {
+    if (!src || !brange || !qorder) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0 || n <= 0 || nbkt <= 0) return DICP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    begin_launch();
+    if (dtype == DICP_F32) query_order_kernel<float><<<N, QO_THREADS, 0, st>>>((const float*)src, (const float*)pose, (const float*)brange, nbkt, N, n, qorder);
+    else                   query_order_kernel<double><<<N, QO_THREADS, 0, st>>>((const double*)src, (const double*)pose, (const double*)brange, nbkt, N, n, qorder);
+    return launch_status();
+}
+
 int dicp_loop_init(int dtype, const void* T_init, const void* w0, double thresh, int rows, int N, int n,
                    void* pose0, void* alive0, void* n_start, void* stream) {
     if (!T_init || !w0 || !pose0 || !alive0 || !n_start) return DICP_ERR_NULL;
@@ -2102,9 +2177,9 @@ int dicp_window_blocks(int dtype, int n, int m_pad) {
 int dicp_window_rows(int dtype) { return dtype == DICP_F32 ? WindowRows<float>::v : WindowRows<double>::v; }
 
 int dicp_accumulate_bwd_window(int dtype, const dicp_weight_params* prm, const void* src_s, const void* tgt_s, int c,
-                               const int32_t* spos, const int32_t* spos_ref, const void* pose, const void* w_s, const void* alive,
-                               const void* gs, const void* gb, int N, int n, int m_pad, void* gsrc_s, void* slab, void* gts_far,
-                               void* gw_s, void* bwd_partials, void* stream) {
+                               const int32_t* spos, const int32_t* spos_ref, const int32_t* qorder, const void* pose, const void* w_s,
+                               const void* alive, const void* gs, const void* gb, int N, int n, int m_pad, void* gsrc_s, void* slab,
+                               void* gts_far, void* gw_s, void* bwd_partials, void* stream) {
     if (const int e = check_params(prm, c)) return e;
     if (!src_s || !tgt_s || !spos || !spos_ref || !pose || !w_s || !gs || !gb || !gsrc_s || !bwd_partials || (slab && !gts_far))
         return DICP_ERR_NULL;
@@ -2116,7 +2191,7 @@ int dicp_accumulate_bwd_window(int dtype, const dicp_weight_params* prm, const v
     const int bpc = dicp_window_blocks(dtype, n, m_pad);
     const unsigned g = grid_for(N, bpc);
 #define DICP_WIN(T, M) do { constexpr int WT = WindowRows<T>::v; const int spb = window_slots(WT, n, m_pad); \
-        accumulate_bwd_window_kernel<T, M, WT><<<g, BLOCK, 0, st>>>(P, (const T*)src_s, (const T*)tgt_s, c, spos, spos_ref, (const T*)pose, \
+        accumulate_bwd_window_kernel<T, M, WT><<<g, BLOCK, 0, st>>>(P, (const T*)src_s, (const T*)tgt_s, c, spos, spos_ref, qorder, (const T*)pose, \
             (const T*)w_s, (const T*)alive, (const T*)gs, (const T*)gb, N, n, m_pad, spb, bpc, (T*)gsrc_s, (T*)slab, (T*)gts_far, (T*)gw_s, \
             (T*)bwd_partials); } while (0)
     if (dtype == DICP_F32) { if (P.mode == MODE_PT2PL) DICP_WIN(float, MODE_PT2PL); else DICP_WIN(float, MODE_PT2PT); }
@@ -2125,7 +2200,7 @@ int dicp_accumulate_bwd_window(int dtype, const dicp_weight_params* prm, const v
     return launch_status();
 }
 
-int dicp_window_reduce(int dtype, const void* slab, const int32_t* spos_ref, const int32_t* tperm, const void* gts_far,
+int dicp_window_reduce(int dtype, const void* slab, const int32_t* spos_ref, const int32_t* qorder, const int32_t* tperm, const void* gts_far,
                        int N, int n, int m, int m_pad, int cv, void* gtgt, int c, void* stream) {
     if (!slab || !spos_ref || !tperm || !gtgt) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
@@ -2135,7 +2210,7 @@ int dicp_window_reduce(int dtype, const void* slab, const int32_t* spos_ref, con
     const int bpc = dicp_window_blocks(dtype, n, m_pad);
     const int rpc = (m * cv + BLOCK * 4 - 1) / (BLOCK * 4);
     const unsigned g = grid_for(N, rpc);
-#define DICP_RED(T, CVV) window_reduce_kernel<T, WindowRows<T>::v, CVV><<<g, BLOCK, 0, st>>>((const T*)slab, spos_ref, tperm, (const T*)gts_far, N, n, m, m_pad, cv, \
+#define DICP_RED(T, CVV) window_reduce_kernel<T, WindowRows<T>::v, CVV><<<g, BLOCK, 0, st>>>((const T*)slab, spos_ref, qorder, tperm, (const T*)gts_far, N, n, m, m_pad, cv, \
         window_slots(WindowRows<T>::v, n, m_pad), bpc, rpc, (T*)gtgt, c)
     if (dtype == DICP_F32) { if (cv == 6) DICP_RED(float, 6); else DICP_RED(float, 3); }
     else                   { if (cv == 6) DICP_RED(double, 6); else DICP_RED(double, 3); }
@@ -2242,7 +2317,7 @@ int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_
         if (rc) return rc;
         if (B->events) { if (hipEventRecord((hipEvent_t)B->events[4 * k + 2], st) != hipSuccess) return -(int)hipGetLastError(); }
         if (B->spos)    // windowed form: src / w_init / tgt are the SORTED copies, gsrc / gw accumulate in slot order, gtgt is the slab
-            rc = dicp_accumulate_bwd_window(dtype, prm, B->src, B->tgt, B->c, B->spos + (size_t)k * N * n, B->spos_ref, pose_k, B->w_init,
+            rc = dicp_accumulate_bwd_window(dtype, prm, B->src, B->tgt, B->c, B->spos + (size_t)k * N * n, B->spos_ref, B->qorder, pose_k, B->w_init,
                                             (const char*)B->alive + (size_t)k * N * es, gs, gb, N, n, B->m_pad,
                                             gsrc, gtgt, B->gts_far, gw, bwd_partials, stream);
         else

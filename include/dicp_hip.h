@@ -77,6 +77,10 @@ int dicp_sweep_build(int dtype, const void* tgt, int c, const int64_t* order, co
                      void* tgs4, int32_t* tperm, int32_t* bucket, void* brange, void* stream);
 /* keys (N,n) = x coordinate of every source point under pose (NULL = identity): the sort key of the query order. */
 int dicp_query_keys(int dtype, const void* src, const void* pose, int N, int n, void* keys, void* stream);
+/* qorder (N,n) = the queries in ascending bucket of their x under pose (counting sort over equal-width buckets of the
+ * target's x range [brange from dicp_sweep_build, nbkt its bucket count]; arbitrary order inside a bucket).  A cheap
+ * replacement for an exact sort of dicp_query_keys: the sweep is exact for ANY query order, the order is speed only. */
+int dicp_query_order(int dtype, const void* src, const void* pose, const void* brange, int nbkt, int N, int n, int32_t* qorder, void* stream);
 
 /* Exact 1-NN with slab pruning: same result (and lowest-index tie rule) as dicp_knn, far fewer pairs.
  * The caller prepares, ONCE per ICP call (targets do not move between iterations):
@@ -85,7 +89,7 @@ int dicp_query_keys(int dtype, const void* src, const void* pose, int N, int n, 
  *   bucket (N,nbkt+1)  bucket[b] = #rows with x < xlo + b/inv  (lower_bound table), brange (N,2) = [xlo, inv];
  *   qorder (N,n)       optional: query indices in ascending x (under any recent pose) so that a wave's
  *                      queries are neighbours; NULL = natural order (still exact, less pruning).
- * spos (N,n), optional: spos[b][s] = SORTED position of the neighbour of the query in sorted slot s (-1 if none):
+ * spos (N,n), optional: spos[b][i] = SORTED position of the neighbour of query i (-1 if none; indexed like idx):
  *   what dicp_accumulate_bwd_window consumes.
  * pairs: optional DICP_PAIR_SHARDS device counters; their sum += number of (query,target) pairs actually scored
  *   (roofline accounting; sharded because adds to ONE address serialise at ~12 ns each).
@@ -171,7 +175,7 @@ typedef struct dicp_loop_buffers {
     int32_t* spos;           /* sweep only, optional (K,N,n): per-iteration sorted match positions.  Non-NULL in dicp_icp_backward
                                 selects dicp_accumulate_bwd_window: src / w_init / tgt are then the SORTED copies it documents,
                                 gsrc / gw accumulate in slot order, gtgt is the slab, bwd_partials has dicp_window_blocks blocks */
-    const int32_t* spos_ref; /* backward, windowed form: (N,n) reference matches that place the windows */
+    const int32_t* spos_ref; /* backward, windowed form: (N,n) reference matches that place the windows; qorder = its slot order */
     void* gts_far;           /* backward, windowed form: (N,m_pad,CV) atomically accumulated out-of-window rows */
     void* poses;             /* (K+1,N,12): poses[0] = initial pose, poses[k+1] written by iteration k */
     void* deltas;            /* (N,K,6) */
@@ -231,9 +235,10 @@ int dicp_accumulate_bwd(int dtype, const dicp_weight_params* prm, const void* sr
 
 /* Windowed form of dicp_accumulate_bwd for the sorted-sweep path, entirely in SORTED space and without global
  * atomics on the common path:
- *   slot s of cloud b = the s-th query in the order `qorder` that dicp_knn_sweep was given for that iteration;
+ *   slot s of cloud b = query qorder[b][s], qorder (N,n) being ANY order that keeps x-neighbours together under the
+ *   poses involved (NULL = identity; it need not be the order the forward search used);
  *   src_s (N,n,3) = src rows in slot order, w_s (N,n) likewise; tgt_s (N,m_pad,c) = target rows in the sweep's
- *   sorted order (row s = tgt[tperm[s]]); spos (N,n) as written by dicp_knn_sweep for THIS iteration;
+ *   sorted order (row s = tgt[tperm[s]]); spos (N,n) as written by dicp_knn_sweep for THIS iteration (by query);
  *   spos_ref (N,n) = the spos of ONE reference iteration, the same in every launch that adds into a given slab
  *   (it places each block's window of dicp_window_rows consecutive sorted target rows; may equal spos).
  * Accumulates (+=) gsrc_s (N,n,3), gw_s (N,n) in slot order.  Target gradients (slab = NULL: not wanted): each of the
@@ -245,10 +250,10 @@ int dicp_accumulate_bwd(int dtype, const dicp_weight_params* prm, const void* sr
 int dicp_window_blocks(int dtype, int n, int m_pad);
 int dicp_window_rows(int dtype);
 int dicp_accumulate_bwd_window(int dtype, const dicp_weight_params* prm, const void* src_s, const void* tgt_s, int c,
-                               const int32_t* spos, const int32_t* spos_ref, const void* pose, const void* w_s, const void* alive,
-                               const void* gs, const void* gb, int N, int n, int m_pad, void* gsrc_s, void* slab, void* gts_far,
-                               void* gw_s, void* bwd_partials, void* stream);
-int dicp_window_reduce(int dtype, const void* slab, const int32_t* spos_ref, const int32_t* tperm, const void* gts_far,
+                               const int32_t* spos, const int32_t* spos_ref, const int32_t* qorder, const void* pose, const void* w_s,
+                               const void* alive, const void* gs, const void* gb, int N, int n, int m_pad, void* gsrc_s, void* slab,
+                               void* gts_far, void* gw_s, void* bwd_partials, void* stream);
+int dicp_window_reduce(int dtype, const void* slab, const int32_t* spos_ref, const int32_t* qorder, const int32_t* tperm, const void* gts_far,
                        int N, int n, int m, int m_pad, int cv, void* gtgt, int c, void* stream);
 
 /* out[b][perm[b][s]][k] += in[b][s][k] for s < cnt, k < cols.  in (N,in_rows,c_in), perm (N,perm_rows) injective per

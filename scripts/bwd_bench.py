@@ -47,13 +47,13 @@ def atomic(want):
 
 
 def window(want):
-    _lib.check(lib.dicp_accumulate_bwd_window(code, ctypes.byref(P), p(src_s), p(tgt_s), c, p(spos), p(spos), p(pose), p(w_s), None, p(gs), p(gb),
+    _lib.check(lib.dicp_accumulate_bwd_window(code, ctypes.byref(P), p(src_s), p(tgt_s), c, p(spos), p(spos), p(qo), p(pose), p(w_s), None, p(gs), p(gb),
                                               B, n, m_pad, p(gsrc), p(slab) if want else None, p(gfar) if want else None, p(gw), p(part), st),
                "bwd_window")
 
 
 def reduce_():
-    _lib.check(lib.dicp_window_reduce(code, p(slab), p(spos), p(sw.tperm), p(gfar), B, n, n, m_pad, cv, p(gtgt), c, st), "reduce")
+    _lib.check(lib.dicp_window_reduce(code, p(slab), p(spos), p(qo), p(sw.tperm), p(gfar), B, n, n, m_pad, cv, p(gtgt), c, st), "reduce")
 
 
 def fresh():
@@ -85,7 +85,7 @@ for rnd in range(rounds + 1):
         torch.cuda.synchronize()
         if rnd:
             times[name].append(a.elapsed_time(b))
-sp = spos.long()
+sp = torch.gather(spos.long(), 1, qo.long())       # spos is indexed by query: bring it to slot order
 slot = torch.arange(n, device="cuda")[None, :]
 off = (sp - slot).abs().float()
 print("B=%d n=m=%d %s  window blocks/cloud=%d rows/window=%d  |spos - slot|: median %.0f  p99 %.0f  max %.0f"

@@ -502,6 +502,36 @@ def test_sweep_knn_equals_brute_force(dtype, N, n, m):
         assert torch.equal(brute.cpu().long(), O.nn_index(x.cpu(), y.cpu()))
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_query_order_is_a_permutation_in_bucket_order(dtype):
+    """dicp_query_order (counting sort by x bucket): a permutation of the queries whose x keys ascend bucket by bucket,
+    for any pose, with queries outside the target's x range and non-finite ones parked in the end buckets."""
+    g = torch.Generator().manual_seed(11)
+    N, n, m = 5, 3001, 777
+    x = ((torch.rand((N, n, 3), generator=g, dtype=torch.float64) * 14 - 7)).to(dtype)
+    x[0, 5] = float("nan")
+    x[1, 9, 0] = float("inf")
+    y = ((torch.rand((N, m, 3), generator=g, dtype=torch.float64) * 10 - 5)).to(dtype)
+    xd, yd = x.to(DEV), y.to(DEV)
+    sw = _ops.SweepIndex(yd)
+    ang = 0.3
+    pose = torch.tensor([np.cos(ang), -np.sin(ang), 0, np.sin(ang), np.cos(ang), 0, 0, 0, 1, 0.4, -0.1, 0.2], dtype=dtype).repeat(N, 1).to(DEV)
+    for ps in (None, pose):
+        qo = sw.query_order(xd, ps)
+        assert qo.dtype == torch.int32 and qo.shape == (N, n)
+        assert torch.equal(torch.sort(qo.long(), dim=1).values, torch.arange(n, device=DEV).repeat(N, 1))
+        key = xd[:, :, 0] if ps is None else (xd * ps[:, None, 0:3]).sum(dim=2) + ps[:, None, 9]
+        ks = torch.gather(key, 1, qo.long()).cpu().double()
+        lo, hi = yd[:, :, 0].min(dim=1).values.cpu().double(), yd[:, :, 0].max(dim=1).values.cpu().double()
+        width = ((hi - lo) / 2048.0)[:, None]
+        kc = torch.nan_to_num(ks, nan=-1e30, posinf=1e30).clamp(lo[:, None], hi[:, None])
+        # ascending up to one bucket width (+ rounding): a later query is never more than ~a bucket to the left
+        runmax = torch.cummax(kc, dim=1).values
+        assert float((runmax - kc - 1.01 * width).max()) <= 1e-4 * float((hi - lo).max())
+        exact = sw.query_order(xd, ps, exact=True)
+        assert torch.equal(torch.sort(exact.long(), dim=1).values, torch.arange(n, device=DEV).repeat(N, 1))
+
+
 def test_sweep_knn_ties_duplicates_and_pads():
     """Duplicated targets (exact score ties across chunks and tiles) resolve to the lowest ORIGINAL index,
     like torch.argmin; pad rows never win; a fused pose is honoured."""
@@ -642,6 +672,8 @@ def test_windowed_backward_kernel_equals_atomic_kernel(dtype, mode, n, m, local)
         spos = torch.randint(0, m, (N, n), generator=gen)
     spos = spos.to(torch.int32).to(DEV)
     spos[0, 5] = -1                                                                         # "no neighbour" -> sorted row 0
+    # spos above is written per SLOT; the kernels index it per QUERY (like idx): query qorder[s] sits in slot s
+    spos_q = torch.empty_like(spos).scatter_(1, qorder.long(), spos)
     pose = torch.tensor([[1, 0, 0, 0, 1, 0, 0, 0, 1, 0.1, -0.2, 0.3]] * N, dtype=dtype, device=DEV)
     alive = torch.tensor([1.0, 1.0, 0.0], dtype=dtype, device=DEV)
     gs = torch.randn((N, 36), generator=gen, dtype=dtype).to(DEV)
@@ -672,16 +704,16 @@ def test_windowed_backward_kernel_equals_atomic_kernel(dtype, mode, n, m, local)
     gfar = torch.zeros((N, m_pad, cv), dtype=dtype, device=DEV)
     part = torch.zeros((N, nw, _lib.NBWD_PAD), dtype=dtype, device=DEV)
     # the windows are placed by a DIFFERENT set of matches than the ones being accumulated in the second call
-    spos_ref = spos if local else torch.randint(0, m, (N, n), generator=gen).to(torch.int32).to(DEV)
+    spos_ref = spos_q if local else torch.randint(0, m, (N, n), generator=gen).to(torch.int32).to(DEV)
     for _ in range(2):      # accumulating entry point: two calls = twice the gradient
-        _lib.check(lib.dicp_accumulate_bwd_window(code, ctypes.byref(P), _ops._p(src_s), _ops._p(tgt_s), c, _ops._p(spos), _ops._p(spos_ref),
-                                                  _ops._p(pose), _ops._p(w_s), _ops._p(alive), _ops._p(gs), _ops._p(gb), N, n, m_pad,
+        _lib.check(lib.dicp_accumulate_bwd_window(code, ctypes.byref(P), _ops._p(src_s), _ops._p(tgt_s), c, _ops._p(spos_q), _ops._p(spos_ref),
+                                                  _ops._p(qorder), _ops._p(pose), _ops._p(w_s), _ops._p(alive), _ops._p(gs), _ops._p(gb), N, n, m_pad,
                                                   _ops._p(gsrc_s), _ops._p(slab), _ops._p(gfar), _ops._p(gw_s), _ops._p(part), st),
                    "dicp_accumulate_bwd_window")
     gsrc, gw, gtgt = torch.zeros_like(src), torch.zeros_like(w0), torch.zeros_like(tgt)
     _lib.check(lib.dicp_permute_add_rows(code, _ops._p(gsrc_s), _ops._p(qorder), N, n, n, n, 3, 3, _ops._p(gsrc), n, 3, st), "permute")
     _lib.check(lib.dicp_permute_add_rows(code, _ops._p(gw_s), _ops._p(qorder), N, n, n, n, 1, 1, _ops._p(gw), n, 1, st), "permute")
-    _lib.check(lib.dicp_window_reduce(code, _ops._p(slab), _ops._p(spos_ref), _ops._p(tperm), _ops._p(gfar), N, n, m, m_pad, cv,
+    _lib.check(lib.dicp_window_reduce(code, _ops._p(slab), _ops._p(spos_ref), _ops._p(qorder), _ops._p(tperm), _ops._p(gfar), N, n, m, m_pad, cv,
                                       _ops._p(gtgt), c, st), "dicp_window_reduce")
     tol = 1e-11 if dtype == torch.float64 else 2e-4
     scale = lambda a: max(1.0, float(a.abs().max()))

@@ -192,7 +192,21 @@ __global__ __launch_bounds__(QO_THREADS) void query_order_kernel(const T* __rest
         return (int)f;
     };
     __syncthreads();
-    for (int i = tid; i < n; i += QO_THREADS) atomicAdd(&cnt[bucket_of(i)], 1);
+    // one returning LDS add per query gives its bucket AND its rank inside the bucket; both stay in registers while
+    // the counters are turned into offsets (LDS atomics are the cost of this kernel: ~137 cycles per wave-instruction)
+    constexpr int PER = 16;                                 // register-resident up to PER * QO_THREADS queries per cloud
+    int bk[PER], rk[PER];
+    const bool small = n <= PER * QO_THREADS;
+    if (small) {
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const int i = e * QO_THREADS + tid;
+            bk[e] = i < n ? bucket_of(i) : -1;
+            rk[e] = i < n ? atomicAdd(&cnt[bk[e]], 1) : 0;
+        }
+    } else {
+        for (int i = tid; i < n; i += QO_THREADS) atomicAdd(&cnt[bucket_of(i)], 1);
+    }
     __syncthreads();
     // exclusive prefix sum of the QO_BUCKETS counters (two per thread)
     const int a0 = cnt[2 * tid], a1 = cnt[2 * tid + 1];
@@ -209,9 +223,17 @@ __global__ __launch_bounds__(QO_THREADS) void query_order_kernel(const T* __rest
     cnt[2 * tid] = excl;
     cnt[2 * tid + 1] = excl + a0;
     __syncthreads();
-    for (int i = tid; i < n; i += QO_THREADS) {
-        const int slot = atomicAdd(&cnt[bucket_of(i)], 1);
-        qorder[(size_t)cloud * n + min(slot, n - 1)] = i;
+    if (small) {
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const int i = e * QO_THREADS + tid;
+            if (i < n) qorder[(size_t)cloud * n + min(cnt[bk[e]] + rk[e], n - 1)] = i;
+        }
+    } else {
+        for (int i = tid; i < n; i += QO_THREADS) {
+            const int slot = atomicAdd(&cnt[bucket_of(i)], 1);
+            qorder[(size_t)cloud * n + min(slot, n - 1)] = i;
+        }
     }
 }
 
@@ -933,7 +955,7 @@ __global__ __launch_bounds__(BLOCK) void accumulate_kernel(WeightParams P, const
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = T(0);
     const int end = min(n, (blk + 1) * ACC_PTS);
-    for (int i = blk * ACC_PTS + threadIdx.x; i < end; i += BLOCK) {       // (4 points in flight per thread measured slower: 85 vs 72 us)
+    for (int i = blk * ACC_PTS + threadIdx.x; i < end; i += BLOCK) {       // (2 or 4 points in flight per thread measured slower: 78 / 85 vs 72 us)
         const size_t pt = (size_t)cloud * n + i;
         const T* sp = src + pt * 3;
         const T p[3] = {sp[0], sp[1], sp[2]};
@@ -1265,15 +1287,22 @@ __global__ __launch_bounds__(BLOCK) void window_reduce_kernel(const T* __restric
         for (int b = tid; b < min(MAXB, bpc - b0); b += BLOCK)
             origin[b] = window_origin(spos_ref + (size_t)cloud * n, qorder ? qorder + (size_t)cloud * n : nullptr, b0 + b, spb, n, m_pad, WT);
         __syncthreads();
+        const int nb = min(MAXB, bpc - b0);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int e = e0 + u * BLOCK + tid;
-            if (e >= m * cv) continue;
-            const int s = e / CV, col = e - s * CV;
-            for (int b = 0; b < min(MAXB, bpc - b0); ++b) {
-                const int lo = origin[b];
-                if (s >= lo && s < lo + WT)
-                    acc[u] += slab[(((size_t)cloud * bpc + b0 + b) * WT + (s - lo)) * cv + col];
+            const int e = min(e0 + u * BLOCK + tid, m * cv - 1);
+            const int s = e / CV;
+            for (int bb = 0; bb < nb; bb += 8) {            // 8 independent predicated loads in flight per element
+                T v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int b = min(bb + k, nb - 1);
+                    const int lo = origin[b];
+                    const bool cov = bb + k < nb && s >= lo && s < lo + WT;
+                    v[k] = cov ? slab[((size_t)cloud * bpc + b0 + b) * (WT * CV) + (size_t)(e - lo * CV)] : T(0);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[u] += v[k];
             }
         }
     }
@@ -2266,6 +2295,9 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
             const int scan_from = (B->knn_variant >> 16) & 0xff;
             int cfg = (B->knn_variant >> 8) & 0xff;
             if (cfg == 0 && scan_from > 0 && k >= scan_from) cfg = DICP_SWEEP_SCAN;
+            // auto: once the pose is close the slabs are a few tiles and the 2-queries-per-lane / 8-row-chunk form wins
+            // (0.195 vs 0.222 ms at the benchmark shape); the first iterations keep 3 queries per lane / 16-row chunks
+            if (cfg == 0 && k >= 2 && (long)N * n >= 2L * BLOCK * 1024) cfg = 2;
             rc = dicp_knn_sweep(dtype, B->src, pose_k, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, N, n, m, B->m_pad,
                                 idx_k, B->spos ? B->spos + (size_t)k * N * n : nullptr, B->pairs, cfg, stream);
         }

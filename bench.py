@@ -220,7 +220,8 @@ def main():
         knn_tf = flops / (knn_ms * 1e-3) / 1e12
         bwd_bytes = 88.0 * n * B                                         # per backward launch
         knn_traffic, knn_src = pmc_traffic("knn_valu" if brute else "knn_sweep", B, n)
-        bwd_traffic, bwd_src = pmc_traffic("accumulate_bwd", B, n)
+        bwd_kernel = "accumulate_bwd_kernel" if brute else "accumulate_bwd_window_kernel"
+        bwd_traffic, bwd_src = pmc_traffic(bwd_kernel, B, n)
         bf_traffic, bf_src = pmc_traffic("knn_valu", B, n)
         line = {
             "metric": "ICP cloud-iterations/sec (fwd+bwd), B=256x16384-pt clouds per GPU",
@@ -251,9 +252,11 @@ def main():
                                         "achieved": flops_bf / (bf_ms * 1e-3) / 1e12, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                         "frac": flops_bf / (bf_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS, "traffic": bf_traffic,
                                         "avg_launch_ms": bf_ms, "measured": "3 extra launches outside the timed region, HIP events"},
-            "roofline_streaming": {"kernel": "accumulate_bwd", "bound": "hbm", "achieved": bwd_bytes / (bwd_ms * 1e-3) / 1e9,
+            "roofline_streaming": {"kernel": bwd_kernel + (" (row atomics)" if brute else " (sorted space: LDS windows, per-block slabs, no float atomics)"),
+                                   "bound": "hbm", "achieved": bwd_bytes / (bwd_ms * 1e-3) / 1e9,
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bwd_bytes / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                   "traffic": bwd_traffic, "avg_launch_ms": bwd_ms,
+                                   "traffic": bwd_traffic, "traffic_source": bwd_src, "avg_launch_ms": bwd_ms,
+                                   "algorithmic_bytes_per_launch": bwd_bytes,
                                    "launch_ms_by_iteration": [round(v, 4) for v in log.all_ms("accumulate_bwd")]},
             "finite": sane,
         }

@@ -178,6 +178,7 @@ __global__ __launch_bounds__(QO_THREADS) void query_order_kernel(const T* __rest
                                                                  int32_t* __restrict__ qorder) {
     __shared__ int cnt[QO_BUCKETS];
     __shared__ int wsum[QO_THREADS / WAVE];
+    __shared__ unsigned short stage[16 * QO_THREADS];       // query ids (< 65536) by slot, for clouds of up to 16384 queries
     const int cloud = blockIdx.x, tid = threadIdx.x;
     for (int b = tid; b < QO_BUCKETS; b += QO_THREADS) cnt[b] = 0;
     T q[4] = {T(1), T(0), T(0), T(0)};
@@ -224,11 +225,15 @@ __global__ __launch_bounds__(QO_THREADS) void query_order_kernel(const T* __rest
     cnt[2 * tid + 1] = excl + a0;
     __syncthreads();
     if (small) {
+        // the permutation is assembled in LDS and leaves as coalesced rows: 4-byte stores scattered over the cloud's
+        // slots cost a 64-byte memory write each (measured: 243 MB written for 17 MB of order, 60 us instead of ~15)
 #pragma unroll
         for (int e = 0; e < PER; ++e) {
             const int i = e * QO_THREADS + tid;
-            if (i < n) qorder[(size_t)cloud * n + min(cnt[bk[e]] + rk[e], n - 1)] = i;
+            if (i < n) stage[min(cnt[bk[e]] + rk[e], n - 1)] = (unsigned short)i;
         }
+        __syncthreads();
+        for (int sl = tid; sl < n; sl += QO_THREADS) qorder[(size_t)cloud * n + sl] = (int32_t)stage[sl];
     } else {
         for (int i = tid; i < n; i += QO_THREADS) {
             const int slot = atomicAdd(&cnt[bucket_of(i)], 1);

@@ -76,9 +76,10 @@ def pmc_traffic(kernel_prefix, B, n):
             continue
         if d.get("workload") != {"B": B, "n": n}:
             continue
-        for name, k in d["kernels"].items():
-            if name.startswith(kernel_prefix):
-                return k["hbm_bytes"], os.path.basename(f)
+        hits = [k for name, k in d["kernels"].items() if name.startswith(kernel_prefix) and k.get("launches")]
+        if hits:        # several launch configurations of one kernel (template arguments): launch-weighted mean
+            tot = sum(k["launches"] for k in hits)
+            return sum(k["hbm_bytes"] * k["launches"] for k in hits) / tot, os.path.basename(f)
     return None, None
 
 

@@ -10,7 +10,10 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 
 
 def short(n):
+    own = "(anonymous namespace)::" in n and "at::native" not in n
     n = n.replace("(anonymous namespace)::", "").replace("void ", "")
+    if own:
+        return n.split("<")[0].split("(")[0]
     if n.startswith("Cijk"):
         return "GEMM"
     for key in ("segmented_sort", "fill_reverse_indices", "FillFunctor", "direct_copy", "copyBuffer", "where_kernel", "CompareEq",

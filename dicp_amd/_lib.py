@@ -60,6 +60,10 @@ _SIGNATURES = {
     "dicp_window_blocks": ([i32, i32, i32], ctypes.c_int),
     "dicp_window_rows": ([i32], ctypes.c_int),
     "dicp_sweep_build": ([i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp], ctypes.c_int),
+    "dicp_sweep_partials": ([i32, i32, i32], ctypes.c_int),
+    "dicp_loop_partial_blocks": ([i32, i32], ctypes.c_int),
+    "dicp_knn_sweep_accumulate": ([i32, ctypes.POINTER(WeightParams), vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32,
+                                   vp, vp, vp, i32, vp, vp, i64, vp], ctypes.c_int),
     "dicp_query_order": ([i32, vp, vp, vp, i32, i32, i32, vp, vp], ctypes.c_int),
     "dicp_query_keys": ([i32, vp, vp, i32, i32, vp, vp], ctypes.c_int),
     "dicp_loop_init": ([i32, vp, vp, ctypes.c_double, i32, i32, i32, vp, vp, vp, vp], ctypes.c_int),

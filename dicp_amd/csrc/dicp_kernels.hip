@@ -233,6 +233,19 @@ __global__ __launch_bounds__(QO_THREADS) void query_order_kernel(const T* __rest
             if (i < n) stage[min(cnt[bk[e]] + rk[e], n - 1)] = (unsigned short)i;
         }
         __syncthreads();
+        // the arrival order of the LDS adds is not reproducible: put every bucket's members in ascending query index
+        // (insertion sort, ~8 per bucket) so that the order -- and every sum taken in it -- is the same on every run
+        for (int b = tid; b < QO_BUCKETS; b += QO_THREADS) {
+            const int lo = cnt[b], hi = b + 1 < QO_BUCKETS ? cnt[b + 1] : n;
+            if (hi - lo > 64) continue;                     // degenerate crowd (e.g. one x plane): left as it arrived
+            for (int a = lo + 1; a < hi; ++a) {
+                const unsigned short v = stage[a];
+                int k = a - 1;
+                while (k >= lo && stage[k] > v) { stage[k + 1] = stage[k]; --k; }
+                stage[k + 1] = v;
+            }
+        }
+        __syncthreads();
         for (int sl = tid; sl < n; sl += QO_THREADS) qorder[(size_t)cloud * n + sl] = (int32_t)stage[sl];
     } else {
         for (int i = tid; i < n; i += QO_THREADS) {
@@ -560,32 +573,49 @@ template <typename T> struct SweepEps;
 template <> struct SweepEps<float>  { static constexpr float  v = 1e-5f; };   // ~10x the worst-case rounding of two f32 scores
 template <> struct SweepEps<double> { static constexpr double v = 1e-10; };
 
-template <typename T, int Q, int CH>
+template <typename T, int NV, int PAD>
+__device__ __forceinline__ void block_reduce_store(T* v, T* __restrict__ out, T* lds);
+
+// Optional fusion: with MODE >= 0 the search kernel goes on, for the matches it has just found, with what
+// accumulate_kernel does (residual, weights, Jacobian, normal-equation sums; ICP.py:143-201) -- the query, its pose and
+// the winner are in hand, so one pass over the points (and one launch) per iteration disappears.  The partials
+// then follow the search's waves: (N, units of this launch, NACC_PAD).
+constexpr int MODE_SEARCH_ONLY = -1;
+template <typename T> struct FusedAcc {
+    WeightParams P;
+    const T* tgt; int c;            // (N,m,c) target rows in ORIGINAL order
+    const T* w_init; const T* alive;
+    T* partials; T* w_out; long w_stride;
+    int units;                      // waves per cloud = partial rows per cloud
+};
+
+template <typename T, int Q, int CH, int MODE>
 __global__ __launch_bounds__(BLOCK) void knn_sweep_kernel(const T* __restrict__ src, const T* __restrict__ pose,
                                                           const typename V4<T>::type* __restrict__ tgs4,
                                                           const int32_t* __restrict__ tperm, const int32_t* __restrict__ qorder,
                                                           const int32_t* __restrict__ bucket, const T* __restrict__ brange, int nbkt,
                                                           int32_t* __restrict__ idx, int32_t* __restrict__ spos,
                                                           unsigned long long* __restrict__ pairs,
-                                                          int N, int n, int m, int m_pad, int bpc) {
+                                                          int N, int n, int m, int m_pad, int bpc, FusedAcc<T> F) {
     using T4 = typename V4<T>::type;
     __shared__ T4 tiles[BLOCK / WAVE][WAVE];
     int cloud, blk;
     if (!decode_block(bpc, N, cloud, blk)) return;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
     const int unit = blk * (BLOCK / WAVE) + wave;           // 64*Q consecutive sorted queries
-    if (unit * (WAVE * Q) >= n) return;                     // whole wave idle (no block-level sync below)
+    const bool idle_wave = unit * (WAVE * Q) >= n;
+    if (idle_wave) return;                                  // whole wave idle (no block-level sync anywhere below)
     T C[9], r[3];
     load_pose(pose, cloud, C, r);
     T4* tile = tiles[wave];
 
     T nx[Q][3], xq[Q], hx[Q], best[Q];
-    int qi[Q], c1[Q], c2[Q];          // c1: chunk that set the minimum; c2: a second chunk with an EQUAL minimum
+    int qi[Q], mi[Q], c1[Q], c2[Q];   // c1: chunk that set the minimum; c2: a second chunk with an EQUAL minimum; mi: the match
     bool over[Q];                     // three or more chunks tied: resolved by re-scanning the visited range
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         const int pos = unit * (WAVE * Q) + q * WAVE + lane;
-        qi[q] = -1;
+        qi[q] = -1; mi[q] = 0;
         T p[3] = {T(0), T(0), T(0)};
         if (pos < n) {
             qi[q] = qorder ? qorder[(size_t)cloud * n + pos] : pos;
@@ -621,6 +651,7 @@ __global__ __launch_bounds__(BLOCK) void knn_sweep_kernel(const T* __restrict__ 
     fb = fb < T(0) ? T(0) : (fb > T(nbkt) ? T(nbkt) : fb);
     const int start = bucket[(size_t)cloud * (nbkt + 1) + (int)fb];
     int tR = min(max(start / WAVE, 0), ntiles - 1), tL = tR - 1;
+    if (idle_wave) { tR = ntiles; tL = -1; }
     int visR = tR, visL = tR;                               // tiles [visL, visR) have been scored
     T edgeR = -inf_v<T>(), edgeL = inf_v<T>();
     // both directions keep their next tile in flight while the current one is being scored
@@ -708,12 +739,50 @@ __global__ __launch_bounds__(BLOCK) void knn_sweep_kernel(const T* __restrict__ 
             // >= 3 chunks share the minimum (duplicated targets): rare, re-scan what this wave visited
             for (int j = visL * WAVE; j < visR * WAVE; ++j) consider(j);
         }
-        idx[(size_t)cloud * n + qi[q]] = (bo == 0x7fffffff) ? 0 : min(max(bo, 0), m - 1);
+        mi[q] = (bo == 0x7fffffff) ? 0 : min(max(bo, 0), m - 1);
+        idx[(size_t)cloud * n + qi[q]] = mi[q];
         // sorted position of the winner (indexed like idx, by the query): what the windowed backward consumes
         if (spos) spos[(size_t)cloud * n + qi[q]] = (bo == 0x7fffffff || bo >= m) ? -1 : bs;
     }
     // sharded: one counter serialises ~12 ns per add, which at 65k waves would outlast the kernel itself
-    if (pairs && lane == 0) atomicAdd(pairs + (blockIdx.x & (DICP_PAIR_SHARDS - 1)), (unsigned long long)(visR - visL) * WAVE * WAVE * Q);
+    if (pairs && lane == 0 && !idle_wave)
+        atomicAdd(pairs + (blockIdx.x & (DICP_PAIR_SHARDS - 1)), (unsigned long long)(visR - visL) * WAVE * WAVE * Q);
+    if (MODE != MODE_SEARCH_ONLY) {
+        constexpr int M = MODE == MODE_SEARCH_ONLY ? MODE_PT2PT : MODE;
+        const T live = F.alive ? F.alive[cloud] : T(1);
+        T acc[NACC];
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) acc[k] = T(0);
+        T p[Q][3], y[Q][3], nrm[Q][3], wv[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {                       // all gathers of the wave's Q queries in flight together
+            const size_t pt = (size_t)cloud * n + max(qi[q], 0);
+            const T* sp = src + pt * 3;
+            p[q][0] = sp[0]; p[q][1] = sp[1]; p[q][2] = sp[2];
+            wv[q] = F.w_init[pt];
+            const T* yp = F.tgt + ((size_t)cloud * m + (qi[q] >= 0 ? mi[q] : 0)) * F.c;
+            y[q][0] = yp[0]; y[q][1] = yp[1]; y[q][2] = yp[2];
+            nrm[q][0] = nrm[q][1] = nrm[q][2] = T(0);
+            if (M == MODE_PT2PL) { nrm[q][0] = yp[3]; nrm[q][1] = yp[4]; nrm[q][2] = yp[5]; }
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            if (qi[q] < 0) continue;
+            PointState<T> st;
+            point_forward<T, M>(F.P, C, r, p[q], y[q], nrm[q], wv[q] * live, acc, st);
+            if (F.w_out) F.w_out[(size_t)cloud * F.w_stride + qi[q]] = st.w;
+        }
+        // one partial per WAVE (N, units, NACC_PAD): no block barrier, so a wave with a long sweep holds nobody up
+        T* out = F.partials + ((size_t)cloud * F.units + unit) * NACC_PAD;
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) {
+            T v = acc[k];
+#pragma unroll
+            for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off);
+            if (lane == 0) out[k] = v;
+        }
+        if (lane == 0) { out[NACC] = T(0); out[NACC + 1] = T(0); }
+    }
 }
 
 // ------------------------------------------------------------------ kNN (scan)
@@ -1962,17 +2031,30 @@ int dicp_knn(int dtype, const void* src, const void* pose, const void* tgt4, int
     return knn_valu_launch<double>(cfg, src, pose, tgt4, N, n, m, m_pad, idx, st);
 }
 
-int dicp_knn_sweep(int dtype, const void* src, const void* pose, const void* tgs4, const int32_t* tperm,
-                   const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt,
-                   int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg, void* stream) {
-    if (!src || !tgs4 || !tperm || !bucket || !brange || !idx) return DICP_ERR_NULL;
-    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
-    if (N <= 0 || n <= 0 || m <= 0 || nbkt <= 0 || m_pad != dicp_padded_targets(m)) return DICP_ERR_SHAPE;
-    if ((uintptr_t)tgs4 % (dtype == DICP_F32 ? 16 : 32)) return DICP_ERR_ALIGN;
-    hipStream_t st = (hipStream_t)stream;
-    begin_launch();
-    if (cfg == 0) cfg = ((long)N * n >= 2L * BLOCK * 1024) ? 8 : 4;      // 3 (else 1) queries per lane, 16-target chunks
+// queries per lane of a tile-sweep launch configuration (0 = not a tile-sweep configuration)
+static int sweep_queries_per_lane(int dtype, int cfg) {
+    if (dtype == DICP_F32) {
+        switch (cfg) { case 1: case 4: return 1; case 2: case 5: return 2; case 3: case 6: return 4; case 7: case 8: return 3; default: return 0; }
+    }
+    switch (cfg) { case 1: case 4: return 1; case 2: case 5: case 7: case 8: return 2; case 3: case 6: return 4; default: return 0; }
+}
+static int sweep_auto_cfg(int N, int n) { return ((long)N * n >= 2L * BLOCK * 1024) ? 8 : 4; }   // 3 (else 1) queries per lane, 16-target chunks
+
+int dicp_sweep_partials(int dtype, int n, int cfg) {      // waves per cloud of a tile-sweep configuration
+    const int Q = sweep_queries_per_lane(dtype, cfg);
+    if (Q <= 0 || n <= 0) return 0;
+    return (n + WAVE * Q - 1) / (WAVE * Q);
+}
+
+struct FusedHost { const dicp_weight_params* prm; const void* tgt; int c; const void* w_init; const void* alive; void* partials; void* w_out; int64_t w_stride; };
+
+static int sweep_launch(int dtype, const void* src, const void* pose, const void* tgs4, const int32_t* tperm,
+                        const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt,
+                        int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg,
+                        const FusedHost* fh, hipStream_t st) {
+    if (cfg == 0) cfg = sweep_auto_cfg(N, n);
     if (cfg >= DICP_SWEEP_SCAN && cfg <= DICP_SWEEP_SCAN + 3) {           // narrow-slab form: one query per lane, per-lane scan
+        if (fh) return DICP_ERR_ENUM;
         const int bpc = (n + BLOCK - 1) / BLOCK;
 #define DICP_SCAN(T, W, G) knn_scan_kernel<T, W, G><<<grid_for(N, bpc), BLOCK, 0, st>>>((const T*)src, (const T*)pose, (const typename V4<T>::type*)tgs4, \
             tperm, qorder, bucket, (const T*)brange, nbkt, idx, spos, pairs, N, n, m, m_pad, bpc)
@@ -1987,26 +2069,51 @@ int dicp_knn_sweep(int dtype, const void* src, const void* pose, const void* tgs
 #undef DICP_SCAN
         return launch_status();
     }
-#define DICP_SWEEP(T, Q, CH) do { const int units = (n + WAVE * Q - 1) / (WAVE * Q), bpc = (units + BLOCK / WAVE - 1) / (BLOCK / WAVE); \
-        knn_sweep_kernel<T, Q, CH><<<grid_for(N, bpc), BLOCK, 0, st>>>((const T*)src, (const T*)pose, (const typename V4<T>::type*)tgs4, tperm, qorder, \
-            bucket, (const T*)brange, nbkt, idx, spos, pairs, N, n, m, m_pad, bpc); } while (0)
+    const int units = dicp_sweep_partials(dtype, n, cfg);
+    if (units <= 0) return DICP_ERR_ENUM;
+    const int bpc = (units + BLOCK / WAVE - 1) / (BLOCK / WAVE);
+#define DICP_SWEEP_M(T, Q, CH, M, FA) knn_sweep_kernel<T, Q, CH, M><<<grid_for(N, bpc), BLOCK, 0, st>>>((const T*)src, (const T*)pose, \
+        (const typename V4<T>::type*)tgs4, tperm, qorder, bucket, (const T*)brange, nbkt, idx, spos, pairs, N, n, m, m_pad, bpc, FA)
+#define DICP_SWEEP(T, Q, CH) do { FusedAcc<T> none{}; DICP_SWEEP_M(T, Q, CH, MODE_SEARCH_ONLY, none); } while (0)
+    // the fused form exists for the configurations the ICP loop uses
+#define DICP_SWEEP_F(T, Q, CH) do { if (!fh) { DICP_SWEEP(T, Q, CH); break; } \
+        FusedAcc<T> fa; fa.P = to_params(fh->prm); fa.tgt = (const T*)fh->tgt; fa.c = fh->c; fa.w_init = (const T*)fh->w_init; \
+        fa.alive = (const T*)fh->alive; fa.partials = (T*)fh->partials; fa.w_out = (T*)fh->w_out; fa.w_stride = (long)fh->w_stride; fa.units = units; \
+        if (fa.P.mode == MODE_PT2PL) DICP_SWEEP_M(T, Q, CH, MODE_PT2PL, fa); else DICP_SWEEP_M(T, Q, CH, MODE_PT2PT, fa); } while (0)
     if (dtype == DICP_F32) {
         switch (cfg) {
-            case 1: DICP_SWEEP(float, 1, 8); break;   case 2: DICP_SWEEP(float, 2, 8); break;   case 3: DICP_SWEEP(float, 4, 8); break;
-            case 4: DICP_SWEEP(float, 1, 16); break;  case 5: DICP_SWEEP(float, 2, 16); break;  case 6: DICP_SWEEP(float, 4, 16); break;
-            case 7: DICP_SWEEP(float, 3, 8); break;   case 8: DICP_SWEEP(float, 3, 16); break;
-            default: return DICP_ERR_ENUM;
+            case 2: DICP_SWEEP_F(float, 2, 8); break;   case 4: DICP_SWEEP_F(float, 1, 16); break;  case 8: DICP_SWEEP_F(float, 3, 16); break;
+            default:
+                if (fh) return DICP_ERR_ENUM;
+                switch (cfg) {
+                    case 1: DICP_SWEEP(float, 1, 8); break;   case 3: DICP_SWEEP(float, 4, 8); break;   case 5: DICP_SWEEP(float, 2, 16); break;
+                    case 6: DICP_SWEEP(float, 4, 16); break;  case 7: DICP_SWEEP(float, 3, 8); break;
+                    default: return DICP_ERR_ENUM;
+                }
         }
     } else {
         switch (cfg) {
-            case 1: case 4: DICP_SWEEP(double, 1, 8); break;
-            case 2: case 5: case 7: case 8: DICP_SWEEP(double, 2, 8); break;
-            case 3: case 6: DICP_SWEEP(double, 4, 8); break;
+            case 1: case 4: DICP_SWEEP_F(double, 1, 8); break;
+            case 2: case 5: case 7: case 8: DICP_SWEEP_F(double, 2, 8); break;
+            case 3: case 6: if (fh) return DICP_ERR_ENUM; DICP_SWEEP(double, 4, 8); break;
             default: return DICP_ERR_ENUM;
         }
     }
+#undef DICP_SWEEP_F
 #undef DICP_SWEEP
+#undef DICP_SWEEP_M
     return launch_status();
+}
+
+int dicp_knn_sweep(int dtype, const void* src, const void* pose, const void* tgs4, const int32_t* tperm,
+                   const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt,
+                   int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg, void* stream) {
+    if (!src || !tgs4 || !tperm || !bucket || !brange || !idx) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0 || n <= 0 || m <= 0 || nbkt <= 0 || m_pad != dicp_padded_targets(m)) return DICP_ERR_SHAPE;
+    if ((uintptr_t)tgs4 % (dtype == DICP_F32 ? 16 : 32)) return DICP_ERR_ALIGN;
+    begin_launch();
+    return sweep_launch(dtype, src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, N, n, m, m_pad, idx, spos, pairs, cfg, nullptr, (hipStream_t)stream);
 }
 
 int dicp_gather_rows(int dtype, const void* tgt, const int32_t* idx, int N, int n, int m, int c, void* out, void* stream) {
@@ -2068,6 +2175,27 @@ int dicp_accumulate(int dtype, const dicp_weight_params* prm, const void* src, c
     else                   { if (P.mode == MODE_PT2PL) DICP_ACC(double, MODE_PT2PL); else DICP_ACC(double, MODE_PT2PT); }
 #undef DICP_ACC
     return launch_status();
+}
+
+int dicp_knn_sweep_accumulate(int dtype, const dicp_weight_params* prm, const void* src, const void* pose, const void* tgs4,
+                              const int32_t* tperm, const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt,
+                              const void* tgt, int c, const void* w_init, const void* alive, int N, int n, int m, int m_pad,
+                              int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg,
+                              void* partials, void* w_out, int64_t w_stride, void* stream) {
+    if (const int e = check_params(prm, c)) return e;
+    if (!src || !tgs4 || !tperm || !bucket || !brange || !idx || !tgt || !w_init || !partials) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0 || n <= 0 || m <= 0 || nbkt <= 0 || m_pad != dicp_padded_targets(m) || (w_out && w_stride < n)) return DICP_ERR_SHAPE;
+    if ((uintptr_t)tgs4 % (dtype == DICP_F32 ? 16 : 32)) return DICP_ERR_ALIGN;
+    begin_launch();
+    const FusedHost fh{prm, tgt, c, w_init, alive, partials, w_out, w_stride};
+    return sweep_launch(dtype, src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, N, n, m, m_pad, idx, spos, pairs, cfg, &fh, (hipStream_t)stream);
+}
+
+int dicp_loop_partial_blocks(int dtype, int n) {        // enough (N, blocks, DICP_NACC_PAD) partials for every launch of the loop
+    int b = dicp_accumulate_blocks(n);
+    for (int cfg = 1; cfg <= 8; ++cfg) { const int s = dicp_sweep_partials(dtype, n, cfg); b = s > b ? s : b; }
+    return b;
 }
 
 int dicp_step(int dtype, const dicp_step_io* io, int N, void* stream) {
@@ -2295,25 +2423,43 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
         const char* alive_k = (const char*)B->alive + (size_t)k * N * es;
         if (B->events) { if (hipEventRecord((hipEvent_t)B->events[4 * k + 0], st) != hipSuccess) return -(int)hipGetLastError(); }
         int rc;
-        if (kind == DICP_KNN_SWEEP)
-        {   // bits 16..23 of knn_variant: first iteration that takes the narrow-slab (per-lane scan) form; 0 = never
+        int nblk_k = nblk;
+        if (kind == DICP_KNN_SWEEP) {
+            // bits 16..23 of knn_variant: first iteration that takes the narrow-slab (per-lane scan) form; 0 = never.
+            // bit 24: fuse accumulate into the search kernel's epilogue (tile-sweep configurations 2, 4, 8)
             const int scan_from = (B->knn_variant >> 16) & 0xff;
+            const bool fuse = (B->knn_variant >> 24) & 1;
             int cfg = (B->knn_variant >> 8) & 0xff;
             if (cfg == 0 && scan_from > 0 && k >= scan_from) cfg = DICP_SWEEP_SCAN;
             // auto: once the pose is close the slabs are a few tiles and the 2-queries-per-lane / 8-row-chunk form wins
             // (0.195 vs 0.222 ms at the benchmark shape); the first iterations keep 3 queries per lane / 16-row chunks
             if (cfg == 0 && k >= 2 && (long)N * n >= 2L * BLOCK * 1024) cfg = 2;
-            rc = dicp_knn_sweep(dtype, B->src, pose_k, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, N, n, m, B->m_pad,
-                                idx_k, B->spos ? B->spos + (size_t)k * N * n : nullptr, B->pairs, cfg, stream);
-        }
-        else
+            if (cfg == 0) cfg = sweep_auto_cfg(N, n);
+            int32_t* spos_k = B->spos ? B->spos + (size_t)k * N * n : nullptr;
+            if (fuse && (cfg == 2 || cfg == 4 || cfg == 8)) {
+                rc = dicp_knn_sweep_accumulate(dtype, prm, B->src, pose_k, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt,
+                                               B->tgt, B->c, B->w_init, alive_k, N, n, m, B->m_pad, idx_k, spos_k, B->pairs, cfg,
+                                               B->partials, w_k, B->w_stride, stream);
+                nblk_k = dicp_sweep_partials(dtype, n, cfg);
+                if (rc) return rc;
+                if (B->events) { if (hipEventRecord((hipEvent_t)B->events[4 * k + 1], st) != hipSuccess) return -(int)hipGetLastError(); }
+            } else {
+                rc = dicp_knn_sweep(dtype, B->src, pose_k, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, N, n, m, B->m_pad,
+                                    idx_k, spos_k, B->pairs, cfg, stream);
+                if (rc) return rc;
+                if (B->events) { if (hipEventRecord((hipEvent_t)B->events[4 * k + 1], st) != hipSuccess) return -(int)hipGetLastError(); }
+                rc = dicp_accumulate(dtype, prm, B->src, B->tgt, B->c, idx_k, pose_k, B->w_init, alive_k, N, n, m, B->partials, w_k, B->w_stride, stream);
+                if (rc) return rc;
+            }
+        } else {
             rc = dicp_knn(dtype, B->src, pose_k, B->tgt4, N, n, m, B->m_pad, idx_k, B->knn_variant & 0xffff, stream);
-        if (rc) return rc;
-        if (B->events) { if (hipEventRecord((hipEvent_t)B->events[4 * k + 1], st) != hipSuccess) return -(int)hipGetLastError(); }
-        rc = dicp_accumulate(dtype, prm, B->src, B->tgt, B->c, idx_k, pose_k, B->w_init, alive_k, N, n, m, B->partials, w_k, B->w_stride, stream);
-        if (rc) return rc;
+            if (rc) return rc;
+            if (B->events) { if (hipEventRecord((hipEvent_t)B->events[4 * k + 1], st) != hipSuccess) return -(int)hipGetLastError(); }
+            rc = dicp_accumulate(dtype, prm, B->src, B->tgt, B->c, idx_k, pose_k, B->w_init, alive_k, N, n, m, B->partials, w_k, B->w_stride, stream);
+            if (rc) return rc;
+        }
         dicp_step_io io;
-        io.partials = B->partials; io.nblk = nblk; io.iter = k; io.dim = dim; io.const_iter = const_iter; io.tolerance = tolerance;
+        io.partials = B->partials; io.nblk = nblk_k; io.iter = k; io.dim = dim; io.const_iter = const_iter; io.tolerance = tolerance;
         io.rows_per_point = prm->mode == DICP_PT2PT ? 3 : 1; io.n = n;
         io.pose_in = pose_k; io.pose_out = (char*)B->poses + (size_t)(k + 1) * N * 12 * es;
         io.delta = (char*)B->deltas + (size_t)k * 6 * es; io.delta_stride = (int64_t)B->K * 6;

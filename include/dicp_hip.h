@@ -102,6 +102,19 @@ int dicp_knn_sweep(int dtype, const void* src, const void* pose, const void* tgs
                    const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt,
                    int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg, void* stream);
 
+/* dicp_knn_sweep that goes on, for the matches it has just found, with dicp_accumulate (declared below): one pass over
+ * the points and one launch less per iteration.  Tile-sweep configurations cfg in {0 (auto), 2, 4, 8}; partials
+ * (N, dicp_sweep_partials(dtype, n, cfg), DICP_NACC_PAD): one row per wave of the search (pass that count to dicp_step);
+ * dicp_loop_partial_blocks(dtype, n) blocks are enough for any launch of the loop.  Sums are taken in the order of
+ * `qorder`, which dicp_query_order makes reproducible. */
+int dicp_sweep_partials(int dtype, int n, int cfg);
+int dicp_loop_partial_blocks(int dtype, int n);
+int dicp_knn_sweep_accumulate(int dtype, const dicp_weight_params* prm, const void* src, const void* pose, const void* tgs4,
+                              const int32_t* tperm, const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt,
+                              const void* tgt, int c, const void* w_init, const void* alive, int N, int n, int m, int m_pad,
+                              int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg,
+                              void* partials, void* w_out, int64_t w_stride, void* stream);
+
 /* Gather whole target rows at idx (nn.py:37-38 / 89-90) and its backward, a scatter-add
  * into a zero-initialised (N,m,c) buffer (autograd's gather backward). */
 int dicp_gather_rows(int dtype, const void* tgt, const int32_t* idx, int N, int n, int m, int c, void* out, void* stream);
@@ -192,7 +205,7 @@ typedef struct dicp_loop_buffers {
                                 (N,K,n): w_iter = n, w_stride = K*n.  May be a per-slab virtual base: only [k0,k1) is touched */
     int64_t w_iter, w_stride;
     const void* w_prev0;     /* weights of iteration k0-1 (cloud stride w_stride too), or NULL when k0 == 0   ICP.py:224-226 */
-    void* partials;          /* (N, dicp_accumulate_blocks(n), DICP_NACC_PAD) scratch */
+    void* partials;          /* (N, dicp_loop_partial_blocks(dtype, n), DICP_NACC_PAD) scratch */
     int32_t* counters;       /* (K) zero-initialised: #clouds with |delta| >= tol at iteration k */
     void** events;           /* optional 4*K hipEvent_t: [4k] before / [4k+1] after the kNN of iteration k (forward),
                                 [4k+2] before / [4k+3] after its accumulate_bwd (backward); NULL = none */

@@ -634,11 +634,37 @@ def test_icp_sweep_equals_brute_on_synthetic(window):
         out = icp.icp(sd, td, T0, weight=wd, trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0})
         out["T"].sum().backward()
         outs.append((out, sd.grad, td.grad, wd.grad, T0.grad))
-    assert torch.equal(outs[0][0]["T"], outs[1][0]["T"]) and torch.equal(outs[0][0]["weights"], outs[1][0]["weights"])
-    # identical forward; the backward sums the same terms in a different grouping (per-row lists vs direct atomics)
+    # same matches and the same per-point arithmetic; the sweep path takes the normal-equation sums in the search kernel's
+    # blocks (query order) and the backward in sorted space, i.e. the same terms in a different grouping
+    np.testing.assert_allclose(npy(outs[0][0]["T"]), npy(outs[1][0]["T"]), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(npy(outs[0][0]["weights"]), npy(outs[1][0]["weights"]), rtol=0, atol=2e-5)
     for k in (1, 2, 3, 4):
         assert torch.isfinite(outs[1][k]).all()
         np.testing.assert_allclose(npy(outs[0][k]), npy(outs[1][k]), rtol=0, atol=2e-6 * max(1.0, float(outs[0][k].abs().max())))
+
+
+@pytest.mark.parametrize("icp_type", ["pt2pl", "pt2pt"])
+def test_fused_search_accumulate_equals_separate_kernels(icp_type, monkeypatch):
+    """dicp_knn_sweep_accumulate (accumulate in the search kernel's epilogue, per-wave partials) against the separate
+    dicp_knn_sweep + dicp_accumulate launches: same matches, same per-point arithmetic, sums grouped differently."""
+    N, n, K = 5, 4500, 5
+    src, tgt = make_pairs(N, n, n, seed=9, dtype=torch.float32)
+    outs = []
+    for fuse in (0, 1):
+        monkeypatch.setattr(_ops, "FUSE_ACCUMULATE", fuse)
+        sd, td = src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True)
+        icp = ICP(icp_type=icp_type, differentiable=True, max_iterations=K, tolerance=1e-12)
+        icp.const_iter = True
+        icp.knn_variant = _lib.KNN_SWEEP
+        out = icp.icp(sd, td, torch.eye(4, device=DEV).repeat(N, 1, 1), trim_dist=5.0, loss_fn={"name": "cauchy", "metric": 0.5})
+        out["T"].sum().backward()
+        outs.append((out, sd.grad, td.grad))
+    for key, tol in (("T", 2e-6), ("weights", 2e-5), ("costs", 1e-3), ("deltas", 2e-6)):
+        a, b = npy(outs[0][0][key]), npy(outs[1][0][key])
+        assert a.shape == b.shape and np.isfinite(b).all()
+        np.testing.assert_allclose(a, b, rtol=1e-5, atol=tol)
+    for k in (1, 2):
+        np.testing.assert_allclose(npy(outs[0][k]), npy(outs[1][k]), rtol=0, atol=2e-5 * max(1.0, float(outs[0][k].abs().max())))
 
 
 @pytest.mark.parametrize("dtype,mode,n,m,local", [

@@ -19,7 +19,7 @@ PT2PT, PT2PL = 0, 1
 LOSS_NONE, LOSS_HUBER, LOSS_CAUCHY, LOSS_TRIM = 0, 1, 2, 3
 KNN_AUTO, KNN_VALU, KNN_MFMA, KNN_SWEEP = 0, 1, 2, 3
 NACC_PAD, NBWD_PAD, KAB_SAVE = 32, 16, 40
-SWEEP_SCAN, PAIR_SHARDS = 16, 64      # DICP_SWEEP_SCAN, DICP_PAIR_SHARDS
+SWEEP_SCAN, PAIR_SHARDS, SWEEP_SRC_SORTED = 16, 64, 0x100      # DICP_SWEEP_SCAN, DICP_PAIR_SHARDS, DICP_SWEEP_SRC_SORTED
 _ERRORS = {1: "null pointer", 2: "bad shape/stride", 3: "unsupported dtype", 4: "bad enum value", 5: "misaligned buffer"}
 
 vp, i32, i64, f64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
@@ -45,7 +45,7 @@ class LoopBuffers(ctypes.Structure):
     """dicp_loop_buffers (include/dicp_hip.h)."""
     _fields_ = [("src", vp), ("tgt", vp), ("w_init", vp), ("c", i32), ("K", i32), ("knn_variant", i32), ("m_pad", i32),
                 ("tgt4", vp), ("tperm", vp), ("qorder", vp), ("bucket", vp), ("brange", vp), ("nbkt", i32), ("idx_per_iter", i32),
-                ("pairs", vp), ("spos", vp), ("spos_ref", vp), ("gts_far", vp), ("poses", vp), ("deltas", vp), ("costs", vp), ("areg", vp), ("alive", vp), ("converged", vp),
+                ("pairs", vp), ("spos", vp), ("src_s", vp), ("spos_ref", vp), ("gts_far", vp), ("poses", vp), ("deltas", vp), ("costs", vp), ("areg", vp), ("alive", vp), ("converged", vp),
                 ("iterations", vp), ("matched_ratio", vp), ("n_start", vp), ("n_matched", vp), ("idx", vp), ("w", vp), ("w_iter", i64), ("w_stride", i64), ("w_prev0", vp),
                 ("partials", vp), ("counters", vp), ("events", vp)]
 
@@ -64,7 +64,7 @@ _SIGNATURES = {
     "dicp_loop_partial_blocks": ([i32, i32], ctypes.c_int),
     "dicp_knn_sweep_accumulate": ([i32, ctypes.POINTER(WeightParams), vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32,
                                    vp, vp, vp, i32, vp, vp, i64, vp], ctypes.c_int),
-    "dicp_query_order": ([i32, vp, vp, vp, i32, i32, i32, vp, vp], ctypes.c_int),
+    "dicp_query_order": ([i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp], ctypes.c_int),
     "dicp_query_keys": ([i32, vp, vp, i32, i32, vp, vp], ctypes.c_int),
     "dicp_loop_init": ([i32, vp, vp, ctypes.c_double, i32, i32, i32, vp, vp, vp, vp], ctypes.c_int),
     "dicp_loop_finish": ([i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp], ctypes.c_int),

@@ -110,24 +110,33 @@ class SweepIndex:
         """(query,target) pairs scored so far (device scalar)."""
         return self.pair_shards.sum()
 
-    def query_order(self, src, pose, exact=False):
+    def query_order(self, src, pose, exact=False, w=None, copies=False, reproducible=False):
         """Query indices in (approximately) ascending transformed x: keeps a wave's queries neighbours.  Default: a
-        counting sort by x bucket (dicp_query_order); exact=True: a full sort of the x keys."""
+        counting sort by x bucket (dicp_query_order); exact=True: a full sort of the x keys.
+        copies=True -> (qorder, src_s, w_s): also the source rows (and the weights w, if given) in that slot order."""
         N, n, _ = src.shape
         lib = _lib.load()
         with torch.cuda.device(src.device):
             if not exact:
                 qorder = torch.empty((N, n), dtype=torch.int32, device=src.device)
-                _lib.check(lib.dicp_query_order(_DT[src.dtype], _p(src), _p(pose), _p(self.brange), self.NBKT, N, n, _p(qorder), _stream()),
-                           "dicp_query_order")
+                _lib.check(lib.dicp_query_order(_DT[src.dtype], _p(src), _p(pose), _p(self.brange), self.NBKT, N, n, _p(qorder),
+                                                None, None, None, int(reproducible), _stream()), "dicp_query_order")
+                if copies:      # (the ordering kernel can write them itself, but one block per cloud gathers slowly: 115 vs 16 us)
+                    return qorder, _gather_rows_raw(src, qorder), (_gather_rows_raw(w.unsqueeze(-1), qorder).squeeze(-1) if w is not None else None)
                 return qorder
             keys = torch.empty((N, n), dtype=src.dtype, device=src.device)
             _lib.check(lib.dicp_query_keys(_DT[src.dtype], _p(src), _p(pose), N, n, _p(keys), _stream()), "dicp_query_keys")
-        return torch.argsort(keys, dim=1).to(torch.int32)
+        qorder = torch.argsort(keys, dim=1).to(torch.int32)
+        if copies:
+            return qorder, _gather_rows_raw(src, qorder), (_gather_rows_raw(w.unsqueeze(-1), qorder).squeeze(-1) if w is not None else None)
+        return qorder
 
-    def knn(self, src, pose, qorder=None, out=None, cfg=0, spos=None):
+    def knn(self, src, pose, qorder=None, out=None, cfg=0, spos=None, src_s=None):
+        """src_s: the rows of src in qorder's slot order (query_order(copies=True)) -> coalesced query loads."""
         N, n, _ = src.shape
         idx = out if out is not None else torch.empty((N, n), dtype=torch.int32, device=src.device)
+        if src_s is not None:
+            src, cfg = src_s, cfg | _lib.SWEEP_SRC_SORTED
         with torch.cuda.device(src.device):
             _lib.check(_lib.load().dicp_knn_sweep(_DT[src.dtype], _p(src), _p(pose), _p(self.tgs4), _p(self.tperm), _p(qorder),
                                                   _p(self.bucket), _p(self.brange), self.NBKT, N, n, self.m, self.tgs4.shape[1],
@@ -448,7 +457,8 @@ class ICPLoop(torch.autograd.Function):
                     if owned:
                         spos_slabs.append(torch.empty((kk, N, n), dtype=torch.int32, device=dev))
                 if sweep is not None and (qorder is None or k0 in cfg.sweep_resort):
-                    qorder = sweep.query_order(src, poses[k0])       # queries re-sorted by x under the current pose
+                    # queries re-ordered by x under the current pose (reproducibly when the forward sums in that order)
+                    qorder = sweep.query_order(src, poses[k0], reproducible=bool(FUSE_ACCUMULATE))
                     qorders.append(qorder)
                 seg_q.append(len(qorders) - 1)
                 base = j * kc                                         # virtual bases: slab pointer minus its first iteration

@@ -175,7 +175,8 @@ constexpr int QO_BUCKETS = 2048;
 template <typename T>
 __global__ __launch_bounds__(QO_THREADS) void query_order_kernel(const T* __restrict__ src, const T* __restrict__ pose,
                                                                  const T* __restrict__ brange, int nbkt_range, int N, int n,
-                                                                 int32_t* __restrict__ qorder) {
+                                                                 int32_t* __restrict__ qorder, const T* __restrict__ w,
+                                                                 T* __restrict__ src_s, T* __restrict__ w_s, int reproducible) {
     __shared__ int cnt[QO_BUCKETS];
     __shared__ int wsum[QO_THREADS / WAVE];
     __shared__ unsigned short stage[16 * QO_THREADS];       // query ids (< 65536) by slot, for clouds of up to 16384 queries
@@ -233,11 +234,11 @@ __global__ __launch_bounds__(QO_THREADS) void query_order_kernel(const T* __rest
             if (i < n) stage[min(cnt[bk[e]] + rk[e], n - 1)] = (unsigned short)i;
         }
         __syncthreads();
-        // the arrival order of the LDS adds is not reproducible: put every bucket's members in ascending query index
-        // (insertion sort, ~8 per bucket) so that the order -- and every sum taken in it -- is the same on every run
-        for (int b = tid; b < QO_BUCKETS; b += QO_THREADS) {
+        // the arrival order of the LDS adds is not reproducible: on request (15 us) put every bucket's members in ascending
+        // query index (insertion sort, ~8 per bucket) so that the order -- and every sum taken in it -- is the same every run
+        for (int b = tid; reproducible && b < QO_BUCKETS; b += QO_THREADS) {
             const int lo = cnt[b], hi = b + 1 < QO_BUCKETS ? cnt[b + 1] : n;
-            if (hi - lo > 64) continue;                     // degenerate crowd (e.g. one x plane): left as it arrived
+            if (hi - lo > 64) continue;                     // a crowd (one x plane; queries outside the targets' x range): left as it arrived
             for (int a = lo + 1; a < hi; ++a) {
                 const unsigned short v = stage[a];
                 int k = a - 1;
@@ -246,11 +247,26 @@ __global__ __launch_bounds__(QO_THREADS) void query_order_kernel(const T* __rest
             }
         }
         __syncthreads();
-        for (int sl = tid; sl < n; sl += QO_THREADS) qorder[(size_t)cloud * n + sl] = (int32_t)stage[sl];
+        for (int sl = tid; sl < n; sl += QO_THREADS) {
+            const int i = stage[sl];
+            qorder[(size_t)cloud * n + sl] = (int32_t)i;
+            if (src_s) {                                    // the rows in slot order, for coalesced query loads (and the backward)
+                const T* p = src + ((size_t)cloud * n + i) * 3;
+                T* o = src_s + ((size_t)cloud * n + sl) * 3;
+                o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+            }
+            if (w_s) w_s[(size_t)cloud * n + sl] = w[(size_t)cloud * n + i];
+        }
     } else {
         for (int i = tid; i < n; i += QO_THREADS) {
-            const int slot = atomicAdd(&cnt[bucket_of(i)], 1);
-            qorder[(size_t)cloud * n + min(slot, n - 1)] = i;
+            const int slot = min(atomicAdd(&cnt[bucket_of(i)], 1), n - 1);
+            qorder[(size_t)cloud * n + slot] = i;
+            if (src_s) {
+                const T* p = src + ((size_t)cloud * n + i) * 3;
+                T* o = src_s + ((size_t)cloud * n + slot) * 3;
+                o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+            }
+            if (w_s) w_s[(size_t)cloud * n + slot] = w[(size_t)cloud * n + i];
         }
     }
 }
@@ -596,7 +612,7 @@ __global__ __launch_bounds__(BLOCK) void knn_sweep_kernel(const T* __restrict__ 
                                                           const int32_t* __restrict__ bucket, const T* __restrict__ brange, int nbkt,
                                                           int32_t* __restrict__ idx, int32_t* __restrict__ spos,
                                                           unsigned long long* __restrict__ pairs,
-                                                          int N, int n, int m, int m_pad, int bpc, FusedAcc<T> F) {
+                                                          int N, int n, int m, int m_pad, int bpc, int src_sorted, FusedAcc<T> F) {
     using T4 = typename V4<T>::type;
     __shared__ T4 tiles[BLOCK / WAVE][WAVE];
     int cloud, blk;
@@ -619,7 +635,7 @@ __global__ __launch_bounds__(BLOCK) void knn_sweep_kernel(const T* __restrict__ 
         T p[3] = {T(0), T(0), T(0)};
         if (pos < n) {
             qi[q] = qorder ? qorder[(size_t)cloud * n + pos] : pos;
-            const T* sp = src + ((size_t)cloud * n + qi[q]) * 3;
+            const T* sp = src + ((size_t)cloud * n + (src_sorted ? pos : qi[q])) * 3;      // src_sorted: rows already in slot order
             p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2];
         }
         T v[3];
@@ -757,7 +773,7 @@ __global__ __launch_bounds__(BLOCK) void knn_sweep_kernel(const T* __restrict__ 
 #pragma unroll
         for (int q = 0; q < Q; ++q) {                       // all gathers of the wave's Q queries in flight together
             const size_t pt = (size_t)cloud * n + max(qi[q], 0);
-            const T* sp = src + pt * 3;
+            const T* sp = src + (src_sorted ? (size_t)cloud * n + min(unit * (WAVE * Q) + q * WAVE + lane, n - 1) : pt) * 3;
             p[q][0] = sp[0]; p[q][1] = sp[1]; p[q][2] = sp[2];
             wv[q] = F.w_init[pt];
             const T* yp = F.tgt + ((size_t)cloud * m + (qi[q] >= 0 ? mi[q] : 0)) * F.c;
@@ -1979,14 +1995,17 @@ int dicp_query_keys(int dtype, const void* src, const void* pose, int N, int n, 
     return launch_status();
 }
 
-int dicp_query_order(int dtype, const void* src, const void* pose, const void* brange, int nbkt, int N, int n, int32_t* qorder, void* stream) {
-    if (!src || !brange || !qorder) return DICP_ERR_NULL;
+int dicp_query_order(int dtype, const void* src, const void* pose, const void* brange, int nbkt, int N, int n, int32_t* qorder,
+                     const void* w, void* src_s, void* w_s, int reproducible, void* stream) {
+    if (!src || !brange || !qorder || (w_s && !w)) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || n <= 0 || nbkt <= 0) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     begin_launch();
-    if (dtype == DICP_F32) query_order_kernel<float><<<N, QO_THREADS, 0, st>>>((const float*)src, (const float*)pose, (const float*)brange, nbkt, N, n, qorder);
-    else                   query_order_kernel<double><<<N, QO_THREADS, 0, st>>>((const double*)src, (const double*)pose, (const double*)brange, nbkt, N, n, qorder);
+    if (dtype == DICP_F32) query_order_kernel<float><<<N, QO_THREADS, 0, st>>>((const float*)src, (const float*)pose, (const float*)brange, nbkt, N, n, qorder,
+                                                                                (const float*)w, (float*)src_s, (float*)w_s, reproducible);
+    else                   query_order_kernel<double><<<N, QO_THREADS, 0, st>>>((const double*)src, (const double*)pose, (const double*)brange, nbkt, N, n, qorder,
+                                                                                 (const double*)w, (double*)src_s, (double*)w_s, reproducible);
     return launch_status();
 }
 
@@ -2052,9 +2071,12 @@ static int sweep_launch(int dtype, const void* src, const void* pose, const void
                         const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt,
                         int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg,
                         const FusedHost* fh, hipStream_t st) {
+    const int src_sorted = (cfg & DICP_SWEEP_SRC_SORTED) ? 1 : 0;      // src holds the rows in qorder's slot order
+    cfg &= ~DICP_SWEEP_SRC_SORTED;
+    if (src_sorted && !qorder) return DICP_ERR_NULL;
     if (cfg == 0) cfg = sweep_auto_cfg(N, n);
     if (cfg >= DICP_SWEEP_SCAN && cfg <= DICP_SWEEP_SCAN + 3) {           // narrow-slab form: one query per lane, per-lane scan
-        if (fh) return DICP_ERR_ENUM;
+        if (fh || src_sorted) return DICP_ERR_ENUM;
         const int bpc = (n + BLOCK - 1) / BLOCK;
 #define DICP_SCAN(T, W, G) knn_scan_kernel<T, W, G><<<grid_for(N, bpc), BLOCK, 0, st>>>((const T*)src, (const T*)pose, (const typename V4<T>::type*)tgs4, \
             tperm, qorder, bucket, (const T*)brange, nbkt, idx, spos, pairs, N, n, m, m_pad, bpc)
@@ -2073,7 +2095,7 @@ static int sweep_launch(int dtype, const void* src, const void* pose, const void
     if (units <= 0) return DICP_ERR_ENUM;
     const int bpc = (units + BLOCK / WAVE - 1) / (BLOCK / WAVE);
 #define DICP_SWEEP_M(T, Q, CH, M, FA) knn_sweep_kernel<T, Q, CH, M><<<grid_for(N, bpc), BLOCK, 0, st>>>((const T*)src, (const T*)pose, \
-        (const typename V4<T>::type*)tgs4, tperm, qorder, bucket, (const T*)brange, nbkt, idx, spos, pairs, N, n, m, m_pad, bpc, FA)
+        (const typename V4<T>::type*)tgs4, tperm, qorder, bucket, (const T*)brange, nbkt, idx, spos, pairs, N, n, m, m_pad, bpc, src_sorted, FA)
 #define DICP_SWEEP(T, Q, CH) do { FusedAcc<T> none{}; DICP_SWEEP_M(T, Q, CH, MODE_SEARCH_ONLY, none); } while (0)
     // the fused form exists for the configurations the ICP loop uses
 #define DICP_SWEEP_F(T, Q, CH) do { if (!fh) { DICP_SWEEP(T, Q, CH); break; } \
@@ -2436,15 +2458,19 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
             if (cfg == 0 && k >= 2 && (long)N * n >= 2L * BLOCK * 1024) cfg = 2;
             if (cfg == 0) cfg = sweep_auto_cfg(N, n);
             int32_t* spos_k = B->spos ? B->spos + (size_t)k * N * n : nullptr;
-            if (fuse && (cfg == 2 || cfg == 4 || cfg == 8)) {
-                rc = dicp_knn_sweep_accumulate(dtype, prm, B->src, pose_k, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt,
+            // src_s: the source rows in qorder's slot order (dicp_query_order wrote them): coalesced query loads
+            const void* qsrc = B->src;
+            if (B->src_s && B->qorder && cfg < DICP_SWEEP_SCAN) { qsrc = B->src_s; cfg |= DICP_SWEEP_SRC_SORTED; }
+            const int cfg_plain = cfg & ~DICP_SWEEP_SRC_SORTED;
+            if (fuse && (cfg_plain == 2 || cfg_plain == 4 || cfg_plain == 8)) {
+                rc = dicp_knn_sweep_accumulate(dtype, prm, qsrc, pose_k, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt,
                                                B->tgt, B->c, B->w_init, alive_k, N, n, m, B->m_pad, idx_k, spos_k, B->pairs, cfg,
                                                B->partials, w_k, B->w_stride, stream);
-                nblk_k = dicp_sweep_partials(dtype, n, cfg);
+                nblk_k = dicp_sweep_partials(dtype, n, cfg_plain);
                 if (rc) return rc;
                 if (B->events) { if (hipEventRecord((hipEvent_t)B->events[4 * k + 1], st) != hipSuccess) return -(int)hipGetLastError(); }
             } else {
-                rc = dicp_knn_sweep(dtype, B->src, pose_k, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, N, n, m, B->m_pad,
+                rc = dicp_knn_sweep(dtype, qsrc, pose_k, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, N, n, m, B->m_pad,
                                     idx_k, spos_k, B->pairs, cfg, stream);
                 if (rc) return rc;
                 if (B->events) { if (hipEventRecord((hipEvent_t)B->events[4 * k + 1], st) != hipSuccess) return -(int)hipGetLastError(); }

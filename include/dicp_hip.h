@@ -79,8 +79,14 @@ int dicp_sweep_build(int dtype, const void* tgt, int c, const int64_t* order, co
 int dicp_query_keys(int dtype, const void* src, const void* pose, int N, int n, void* keys, void* stream);
 /* qorder (N,n) = the queries in ascending bucket of their x under pose (counting sort over equal-width buckets of the
  * target's x range [brange from dicp_sweep_build, nbkt its bucket count]; arbitrary order inside a bucket).  A cheap
- * replacement for an exact sort of dicp_query_keys: the sweep is exact for ANY query order, the order is speed only. */
-int dicp_query_order(int dtype, const void* src, const void* pose, const void* brange, int nbkt, int N, int n, int32_t* qorder, void* stream);
+ * replacement for an exact sort of dicp_query_keys: the sweep is exact for ANY query order, the order is speed only.
+ * Optional: src_s (N,n,3) / w_s (N,n) = the source rows / the per-point weights w (N,n) in that slot order, for coalesced
+ * query loads in dicp_knn_sweep (cfg | DICP_SWEEP_SRC_SORTED) and for dicp_accumulate_bwd_window (measured: one block
+ * per cloud gathers slowly, 115 vs 16 us; dicp_gather_rows does it better).  reproducible != 0: buckets of up to 64
+ * members are put in index order, so the permutation is the same on every run (needed only when sums are taken in
+ * this order, i.e. by dicp_knn_sweep_accumulate). */
+int dicp_query_order(int dtype, const void* src, const void* pose, const void* brange, int nbkt, int N, int n, int32_t* qorder,
+                     const void* w, void* src_s, void* w_s, int reproducible, void* stream);
 
 /* Exact 1-NN with slab pruning: same result (and lowest-index tie rule) as dicp_knn, far fewer pairs.
  * The caller prepares, ONCE per ICP call (targets do not move between iterations):
@@ -98,6 +104,7 @@ int dicp_query_order(int dtype, const void* src, const void* pose, const void* b
  *      same indices, far fewer pairs once the pose is close (iterations >= 1 of an ICP call). */
 #define DICP_SWEEP_SCAN 16
 #define DICP_PAIR_SHARDS 64
+#define DICP_SWEEP_SRC_SORTED 0x100   /* OR into cfg: `src` holds the rows in qorder's slot order (dicp_query_order's src_s) */
 int dicp_knn_sweep(int dtype, const void* src, const void* pose, const void* tgs4, const int32_t* tperm,
                    const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt,
                    int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg, void* stream);
@@ -188,6 +195,7 @@ typedef struct dicp_loop_buffers {
     int32_t* spos;           /* sweep only, optional (K,N,n): per-iteration sorted match positions.  Non-NULL in dicp_icp_backward
                                 selects dicp_accumulate_bwd_window: src / w_init / tgt are then the SORTED copies it documents,
                                 gsrc / gw accumulate in slot order, gtgt is the slab, bwd_partials has dicp_window_blocks blocks */
+    const void* src_s;       /* forward, sweep: optional source rows in qorder's slot order (dicp_query_order) */
     const int32_t* spos_ref; /* backward, windowed form: (N,n) reference matches that place the windows; qorder = its slot order */
     void* gts_far;           /* backward, windowed form: (N,m_pad,CV) atomically accumulated out-of-window rows */
     void* poses;             /* (K+1,N,12): poses[0] = initial pose, poses[k+1] written by iteration k */

@@ -484,6 +484,9 @@ def test_tolerance_stop_equals_const_iter(golden):
 # ----------------------------------------------------------- exact sorted-sweep kNN (dicp_knn_sweep)
 def sweep_knn(x, y, pose=None, sort_queries=True, cfg=0):
     sw = _ops.SweepIndex(y)
+    if sort_queries == "copies":        # queries read from the slot-ordered copy dicp_query_order makes
+        qo, x_s, _ = sw.query_order(x, pose, copies=True)
+        return sw.knn(x, pose, qo, cfg=cfg, src_s=x_s), sw
     return sw.knn(x, pose, sw.query_order(x, pose) if sort_queries else None, cfg=cfg), sw
 
 
@@ -495,7 +498,7 @@ def test_sweep_knn_equals_brute_force(dtype, N, n, m):
     y = (torch.rand((N, m, 6), generator=g, dtype=torch.float64) * 10 - 5).to(dtype).to(DEV)
     brute = _ops.knn(x, None, _ops.pack_target(y), m, _lib.KNN_VALU)
     for cfg in (1, 2, 3, 8, 16, 17):                              # tile sweep (1..8) and per-lane scan (16, 17) forms
-        for sort_q in (True, False):
+        for sort_q in (True, False) + (("copies",) if cfg < 16 else ()):
             got, sw = sweep_knn(x, y, sort_queries=sort_q, cfg=cfg)
             assert torch.equal(got, brute), (cfg, sort_q)        # same scores, same tie rule: bit-identical indices
     if dtype == torch.float64:
@@ -530,6 +533,18 @@ def test_query_order_is_a_permutation_in_bucket_order(dtype):
         assert float((runmax - kc - 1.01 * width).max()) <= 1e-4 * float((hi - lo).max())
         exact = sw.query_order(xd, ps, exact=True)
         assert torch.equal(torch.sort(exact.long(), dim=1).values, torch.arange(n, device=DEV).repeat(N, 1))
+        # reproducible (buckets hold their members in index order) and the slot-ordered copies are what they say
+        wq = torch.rand((N, n), generator=g, dtype=torch.float64).to(dtype).to(DEV)
+        qo, x_s, w_s = sw.query_order(xd, ps, w=wq, copies=True)
+        gi = qo.long().unsqueeze(-1).expand(-1, -1, 3)
+        assert torch.equal(torch.nan_to_num(x_s, nan=7.0), torch.nan_to_num(torch.gather(xd, 1, gi), nan=7.0))
+        assert torch.equal(w_s, torch.gather(wq, 1, qo.long()))
+    # reproducible when no bucket is crowded (buckets of up to 64 members are put in index order): queries inside the
+    # target's x range, two calls -> the same permutation
+    xin = (xd * 0.6).contiguous()
+    xin[0, 5] = 0.0
+    xin[1, 9, 0] = 0.0
+    assert torch.equal(sw.query_order(xin, None, reproducible=True), sw.query_order(xin, None, reproducible=True))
 
 
 def test_sweep_knn_ties_duplicates_and_pads():

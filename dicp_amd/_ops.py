@@ -85,7 +85,8 @@ class SweepIndex:
     an ICP call, so they are sorted by x once.  Index preparation uses torch.sort/searchsorted (plumbing)."""
     NBKT = 1024
 
-    def __init__(self, tgt):
+    def __init__(self, tgt, sorted_rows=False):
+        """sorted_rows: also keep tgt_s (N,m_pad,c), the full rows in sorted order (the windowed backward reads them)."""
         require_device(tgt, "SweepIndex")
         tgt = tgt.contiguous()
         N, m, c = tgt.shape
@@ -100,9 +101,10 @@ class SweepIndex:
         self.tperm = torch.empty((N, m_pad), dtype=torch.int32, device=dev)
         self.bucket = torch.empty((N, self.NBKT + 1), dtype=torch.int32, device=dev)
         self.brange = torch.empty((N, 2), dtype=dt, device=dev)
+        self.tgt_s = torch.empty((N, m_pad, c), dtype=dt, device=dev) if sorted_rows else None
         with torch.cuda.device(dev):
             _lib.check(lib.dicp_sweep_build(_DT[dt], _p(tgt), c, _p(order), _p(keys), N, m, m_pad, self.NBKT, _p(self.tgs4), _p(self.tperm),
-                                            _p(self.bucket), _p(self.brange), _stream()), "dicp_sweep_build")
+                                            _p(self.bucket), _p(self.brange), _p(self.tgt_s), _stream()), "dicp_sweep_build")
         self.pair_shards = torch.zeros((_lib.PAIR_SHARDS,), dtype=torch.int64, device=dev)
 
     @property
@@ -402,8 +404,8 @@ class ICPLoop(torch.autograd.Function):
             kind = cfg.knn_variant & 0xff
             if kind == _lib.KNN_AUTO:
                 kind = auto_knn_kind(N, n, m)
-            sweep = SweepIndex(tgt) if kind == _lib.KNN_SWEEP else None
-            owned = sweep is not None and need_grad and cfg.bwd_window
+            owned = kind == _lib.KNN_SWEEP and need_grad and cfg.bwd_window
+            sweep = SweepIndex(tgt, sorted_rows=owned) if kind == _lib.KNN_SWEEP else None
             tgt4 = sweep.tgs4 if sweep is not None else pack_target(tgt)
             m_pad = tgt4.shape[1]
             nblk = lib.dicp_loop_partial_blocks(code, n)
@@ -497,7 +499,7 @@ class ICPLoop(torch.autograd.Function):
             costs_out = costs[:, :K]
 
         if need_grad:
-            saved = [src, tgt, w0c, poses, deltas, areg, alive] + idx_slabs + spos_slabs + qorders + ([sweep.tperm] if owned else [])
+            saved = [src, tgt, w0c, poses, deltas, areg, alive] + idx_slabs + spos_slabs + qorders + ([sweep.tperm, sweep.tgt_s] if owned else [])
             ctx.save_for_backward(*saved)
             ctx.cfg, ctx.K, ctx.P, ctx.Kmax = cfg, K, P, Kmax
             ctx.layout = (len(idx_slabs), len(spos_slabs), len(qorders), kc, owned, m_pad, kind,
@@ -513,7 +515,7 @@ class ICPLoop(torch.autograd.Function):
         n_idx, n_spos, n_q, kc, owned, m_pad, kind, segs = ctx.layout
         idx_slabs, spos_slabs = rest[:n_idx], rest[n_idx:n_idx + n_spos]
         qorders = rest[n_idx + n_spos:n_idx + n_spos + n_q]
-        tperm = rest[-1] if owned else None
+        tperm, tgt_s = (rest[-2], rest[-1]) if owned else (None, None)
         lib = _lib.load()
         dev, dt = src.device, src.dtype
         code, es = _DT[dt], src.element_size()
@@ -528,7 +530,8 @@ class ICPLoop(torch.autograd.Function):
             cv = 6 if cfg.icp_type == "pt2pl" else 3
             gsrc = torch.zeros_like(src)
             gw = torch.zeros_like(w0c) if want_w else None
-            gtgt = torch.zeros_like(tgt) if want_tgt else None
+            all_windowed = None         # set below: every iteration takes the windowed form -> dicp_window_reduce writes gtgt
+            gtgt = None
             # Two forms of accumulate_bwd.  Atomic form (dicp_accumulate_bwd): original order, no set-up.  Windowed form
             # (dicp_accumulate_bwd_window, sweep path): everything in sorted space -- sorted copies of the source /
             # weights, slot-order gradient accumulators, target rows in the sweep's order, per-block slabs for the target
@@ -540,6 +543,9 @@ class ICPLoop(torch.autograd.Function):
             windowed = [owned and (q == q_star or a >= WINDOW_FROM) for (a, _, q) in segs]
             if sum(b - a for (a, b, _), wf in zip(segs, windowed) if wf) < WINDOW_MIN_ITERS:
                 windowed = [False] * len(segs)
+            all_windowed = all(windowed) and len(windowed) > 0 and c == cv
+            if want_tgt:    # all windowed: dicp_window_reduce writes every element once, no zero fill needed
+                gtgt = torch.empty_like(tgt) if all_windowed else torch.zeros_like(tgt)
             nblk_a, nblk_w = lib.dicp_accumulate_blocks(n), lib.dicp_window_blocks(code, n, m_pad)
             if any(windowed):
                 qo = qorders[q_star]
@@ -547,7 +553,6 @@ class ICPLoop(torch.autograd.Function):
                 w_s = _gather_rows_raw(w0c.unsqueeze(-1), qo).squeeze(-1)
                 gsrc_s = torch.zeros_like(src)
                 gw_s = torch.zeros_like(w0c) if want_w else None
-                tgt_s = _gather_rows_raw(tgt, tperm)                       # (N,m_pad,c); pad slots repeat row m-1 (never matched)
                 k_ref = max(b for (_, b, _), wf in zip(segs, windowed) if wf) - 1      # windows placed by the last iteration's matches
                 spos_ref = spos_slabs[k_ref // kc][k_ref % kc]
                 slab = torch.zeros((N, nblk_w, lib.dicp_window_rows(code), cv), dtype=dt, device=dev) if want_tgt else None
@@ -587,7 +592,7 @@ class ICPLoop(torch.autograd.Function):
                     _lib.check(lib.dicp_permute_add_rows(code, _p(gw_s), _p(qo), N, n, n, n, 1, 1, _p(gw), n, 1, st), "dicp_permute_add_rows")
                 if want_tgt:
                     _lib.check(lib.dicp_window_reduce(code, _p(slab), _p(spos_ref), _p(qo), _p(tperm), _p(gfar), N, n, m, m_pad, cv,
-                                                      _p(gtgt), c, st), "dicp_window_reduce")
+                                                      _p(gtgt), c, int(all_windowed), st), "dicp_window_reduce")
             gT0 = torch.zeros((N, 4, 4), dtype=dt, device=dev)
             gT0[:, :3, :3] = gpose[:, :9].reshape(N, 3, 3).to(dt)
             gT0[:, :3, 3] = gpose[:, 9:].to(dt)

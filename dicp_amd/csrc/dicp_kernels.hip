@@ -100,7 +100,8 @@ __global__ __launch_bounds__(BLOCK) void pack_kernel(const T* __restrict__ tgt, 
 // sorted packed rows, the permutation as int32, and the coarse bucket table of lower-bound positions.
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void sweep_rows_kernel(const T* __restrict__ tgt, const int64_t* __restrict__ order, int N, int m, int c,
-                                                           int m_pad, int bpc, typename V4<T>::type* __restrict__ tgs4, int32_t* __restrict__ tperm) {
+                                                           int m_pad, int bpc, typename V4<T>::type* __restrict__ tgs4, int32_t* __restrict__ tperm,
+                                                           T* __restrict__ tgt_s /* optional (N,m_pad,c): the full rows in sorted order */) {
     constexpr int U = 4;                                    // rows per thread in flight (index -> row is a dependent pair)
     int b, blk;
     if (!decode_block(bpc, N, b, blk)) return;
@@ -124,6 +125,11 @@ __global__ __launch_bounds__(BLOCK) void sweep_rows_kernel(const T* __restrict__
             else { v.x = big_v<T>(); v.y = v.z = T(0); v.w = inf_v<T>(); }      // pads sort last and can never win
             tgs4[(size_t)b * m_pad + sl] = v;
             tperm[(size_t)b * m_pad + sl] = (int32_t)j[u];
+            if (tgt_s) {                                    // pad slots repeat row 0 (they are never matched)
+                const T* yp = tgt + ((size_t)b * m + (j[u] >= 0 && j[u] < m ? j[u] : 0)) * c;
+                T* o = tgt_s + ((size_t)b * m_pad + sl) * c;
+                for (int k = 0; k < c; ++k) o[k] = yp[k];
+            }
         }
     }
 }
@@ -1364,7 +1370,7 @@ __global__ __launch_bounds__(BLOCK) void window_reduce_kernel(const T* __restric
                                                               const int32_t* __restrict__ qorder,
                                                               const int32_t* __restrict__ tperm, const T* __restrict__ gts_far,
                                                               int N, int n, int m, int m_pad, int cv, int spb, int bpc, int rpc,
-                                                              T* __restrict__ gtgt, int c) {
+                                                              T* __restrict__ gtgt, int c, int overwrite) {
     constexpr int MAXB = 256;                               // window blocks per cloud handled per pass
     __shared__ int origin[MAXB];
     int cloud, rb;
@@ -1404,7 +1410,10 @@ __global__ __launch_bounds__(BLOCK) void window_reduce_kernel(const T* __restric
         T v = acc[u];
         if (gts_far) v += gts_far[((size_t)cloud * m_pad + s) * cv + col];
         const int j = tperm[(size_t)cloud * m_pad + s];
-        if (j >= 0 && j < m) gtgt[((size_t)cloud * m + j) * c + col] += v;
+        if (j >= 0 && j < m) {
+            T* o = gtgt + ((size_t)cloud * m + j) * c + col;
+            *o = overwrite ? v : *o + v;                    // overwrite: every row of gtgt[:, :, :cv] is written exactly once
+        }
     }
 }
 
@@ -1963,7 +1972,7 @@ int dicp_pack_target(int dtype, const void* tgt, int N, int m, int c, void* tgt4
 }
 
 int dicp_sweep_build(int dtype, const void* tgt, int c, const int64_t* order, const void* keys_sorted, int N, int m, int m_pad, int nbkt,
-                     void* tgs4, int32_t* tperm, int32_t* bucket, void* brange, void* stream) {
+                     void* tgs4, int32_t* tperm, int32_t* bucket, void* brange, void* tgt_s, void* stream) {
     if (!tgt || !order || !keys_sorted || !tgs4 || !tperm || !bucket || !brange) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || m <= 0 || (c != 3 && c != 6) || nbkt <= 0 || m_pad != dicp_padded_targets(m)) return DICP_ERR_SHAPE;
@@ -1973,10 +1982,10 @@ int dicp_sweep_build(int dtype, const void* tgt, int c, const int64_t* order, co
     const int bpc = (m_pad + BLOCK * 4 - 1) / (BLOCK * 4);
     const unsigned g = grid_for(N, bpc);
     if (dtype == DICP_F32) {
-        sweep_rows_kernel<float><<<g, BLOCK, 0, st>>>((const float*)tgt, order, N, m, c, m_pad, bpc, (float4*)tgs4, tperm);
+        sweep_rows_kernel<float><<<g, BLOCK, 0, st>>>((const float*)tgt, order, N, m, c, m_pad, bpc, (float4*)tgs4, tperm, (float*)tgt_s);
         sweep_buckets_kernel<float><<<N, BLOCK, 0, st>>>((const float*)keys_sorted, N, m, m_pad, nbkt, bucket, (float*)brange);
     } else {
-        sweep_rows_kernel<double><<<g, BLOCK, 0, st>>>((const double*)tgt, order, N, m, c, m_pad, bpc, (double4*)tgs4, tperm);
+        sweep_rows_kernel<double><<<g, BLOCK, 0, st>>>((const double*)tgt, order, N, m, c, m_pad, bpc, (double4*)tgs4, tperm, (double*)tgt_s);
         sweep_buckets_kernel<double><<<N, BLOCK, 0, st>>>((const double*)keys_sorted, N, m, m_pad, nbkt, bucket, (double*)brange);
     }
     return launch_status();
@@ -2385,7 +2394,7 @@ int dicp_accumulate_bwd_window(int dtype, const dicp_weight_params* prm, const v
 }
 
 int dicp_window_reduce(int dtype, const void* slab, const int32_t* spos_ref, const int32_t* qorder, const int32_t* tperm, const void* gts_far,
-                       int N, int n, int m, int m_pad, int cv, void* gtgt, int c, void* stream) {
+                       int N, int n, int m, int m_pad, int cv, void* gtgt, int c, int overwrite, void* stream) {
     if (!slab || !spos_ref || !tperm || !gtgt) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || n <= 0 || m <= 0 || m_pad != dicp_padded_targets(m) || (cv != 3 && cv != 6) || c < cv) return DICP_ERR_SHAPE;
@@ -2395,7 +2404,7 @@ int dicp_window_reduce(int dtype, const void* slab, const int32_t* spos_ref, con
     const int rpc = (m * cv + BLOCK * 4 - 1) / (BLOCK * 4);
     const unsigned g = grid_for(N, rpc);
 #define DICP_RED(T, CVV) window_reduce_kernel<T, WindowRows<T>::v, CVV><<<g, BLOCK, 0, st>>>((const T*)slab, spos_ref, qorder, tperm, (const T*)gts_far, N, n, m, m_pad, cv, \
-        window_slots(WindowRows<T>::v, n, m_pad), bpc, rpc, (T*)gtgt, c)
+        window_slots(WindowRows<T>::v, n, m_pad), bpc, rpc, (T*)gtgt, c, overwrite)
     if (dtype == DICP_F32) { if (cv == 6) DICP_RED(float, 6); else DICP_RED(float, 3); }
     else                   { if (cv == 6) DICP_RED(double, 6); else DICP_RED(double, 3); }
 #undef DICP_RED

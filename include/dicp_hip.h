@@ -72,9 +72,10 @@ int dicp_knn(int dtype, const void* src, const void* pose, const void* tgt4, int
  * sort of the target x keys with the m_pad - m pad slots keyed +max so that they come last):
  *   order (N,m_pad) int64 = the sorting permutation, keys_sorted (N,m_pad) = the sorted keys
  *   -> tgs4 (N,m_pad,4) packed rows in sorted order (pads [max,0,0,+inf]), tperm (N,m_pad) = order as int32,
- *      bucket (N,nbkt+1) lower-bound positions of nbkt+1 equally spaced x edges, brange (N,2) = [x_min, nbkt/(x_max-x_min)]. */
+ *      bucket (N,nbkt+1) lower-bound positions of nbkt+1 equally spaced x edges, brange (N,2) = [x_min, nbkt/(x_max-x_min)],
+ *      optional tgt_s (N,m_pad,c) = the full target rows in sorted order (what dicp_accumulate_bwd_window reads). */
 int dicp_sweep_build(int dtype, const void* tgt, int c, const int64_t* order, const void* keys_sorted, int N, int m, int m_pad, int nbkt,
-                     void* tgs4, int32_t* tperm, int32_t* bucket, void* brange, void* stream);
+                     void* tgs4, int32_t* tperm, int32_t* bucket, void* brange, void* tgt_s, void* stream);
 /* keys (N,n) = x coordinate of every source point under pose (NULL = identity): the sort key of the query order. */
 int dicp_query_keys(int dtype, const void* src, const void* pose, int N, int n, void* keys, void* stream);
 /* qorder (N,n) = the queries in ascending bucket of their x under pose (counting sort over equal-width buckets of the
@@ -267,7 +268,7 @@ int dicp_accumulate_bwd(int dtype, const dicp_weight_params* prm, const void* sr
  * of slab (N, blocks, dicp_window_rows(dtype), CV) with plain read-modify-writes (CV = 6 for pt2pl, 3 for pt2pt);
  * matches outside a window are added to gts_far (N,m_pad,CV) with atomics.  After the last iteration
  * dicp_window_reduce adds slab + gts_far into gtgt (N,m,c) in the ORIGINAL target order (+=, call it once per
- * slab; pass gts_far with one of them).  bwd_partials: (N, dicp_window_blocks, DICP_NBWD_PAD). */
+ * slab; pass gts_far with one of them; overwrite != 0: = instead of +=, when nothing else has been added to gtgt).  bwd_partials: (N, dicp_window_blocks, DICP_NBWD_PAD). */
 int dicp_window_blocks(int dtype, int n, int m_pad);
 int dicp_window_rows(int dtype);
 int dicp_accumulate_bwd_window(int dtype, const dicp_weight_params* prm, const void* src_s, const void* tgt_s, int c,
@@ -275,7 +276,7 @@ int dicp_accumulate_bwd_window(int dtype, const dicp_weight_params* prm, const v
                                const void* alive, const void* gs, const void* gb, int N, int n, int m_pad, void* gsrc_s, void* slab,
                                void* gts_far, void* gw_s, void* bwd_partials, void* stream);
 int dicp_window_reduce(int dtype, const void* slab, const int32_t* spos_ref, const int32_t* qorder, const int32_t* tperm, const void* gts_far,
-                       int N, int n, int m, int m_pad, int cv, void* gtgt, int c, void* stream);
+                       int N, int n, int m, int m_pad, int cv, void* gtgt, int c, int overwrite, void* stream);
 
 /* out[b][perm[b][s]][k] += in[b][s][k] for s < cnt, k < cols.  in (N,in_rows,c_in), perm (N,perm_rows) injective per
  * cloud (plain read-modify-write), out (N,out_rows,c_out).  Undoes a sorted order. */

@@ -53,7 +53,7 @@ def window(want):
 
 
 def reduce_():
-    _lib.check(lib.dicp_window_reduce(code, p(slab), p(spos), p(qo), p(sw.tperm), p(gfar), B, n, n, m_pad, cv, p(gtgt), c, st), "reduce")
+    _lib.check(lib.dicp_window_reduce(code, p(slab), p(spos), p(qo), p(sw.tperm), p(gfar), B, n, n, m_pad, cv, p(gtgt), c, 0, st), "reduce")
 
 
 def fresh():

@@ -755,7 +755,7 @@ def test_windowed_backward_kernel_equals_atomic_kernel(dtype, mode, n, m, local)
     _lib.check(lib.dicp_permute_add_rows(code, _ops._p(gsrc_s), _ops._p(qorder), N, n, n, n, 3, 3, _ops._p(gsrc), n, 3, st), "permute")
     _lib.check(lib.dicp_permute_add_rows(code, _ops._p(gw_s), _ops._p(qorder), N, n, n, n, 1, 1, _ops._p(gw), n, 1, st), "permute")
     _lib.check(lib.dicp_window_reduce(code, _ops._p(slab), _ops._p(spos_ref), _ops._p(qorder), _ops._p(tperm), _ops._p(gfar), N, n, m, m_pad, cv,
-                                      _ops._p(gtgt), c, st), "dicp_window_reduce")
+                                      _ops._p(gtgt), c, 0, st), "dicp_window_reduce")
     tol = 1e-11 if dtype == torch.float64 else 2e-4
     scale = lambda a: max(1.0, float(a.abs().max()))
     for a, b, nm in ((gsrc, g1["gsrc"], "gsrc"), (gw, g1["gw"], "gw"), (gtgt, g1["gtgt"], "gtgt")):

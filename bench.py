@@ -31,6 +31,7 @@ from dicp_amd import dist as ddist                      # noqa: E402
 from dicp_amd.ICP import ICP                            # noqa: E402
 from dicp_amd.synthetic import make_pairs               # noqa: E402
 
+STEADY_CALLS = 3              # untimed K-iteration calls before the timed one
 F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32 vector == f32-input MFMA peak
 HBM_PEAK_GBS = 8000.0        # HBM3E spec
 LOSS = {"name": "huber", "metric": 1.0}
@@ -165,12 +166,22 @@ def main():
     if W > 0:
         run_call(icp, src, tgt, T0, cw)                                  # W untimed warm-up steps
     icp.max_iterations = K
-    # still untimed: one call at the timed call's own shapes, so that the caching allocator already owns the
-    # K-sized history / saved-index buffers (the first use of a new size is a synchronous hipMalloc)
-    run_call(icp, src, tgt, T0, cw)
+    # still untimed: calls at the timed call's own shapes, so that the caching allocator already owns the K-sized
+    # history / saved-index buffers (the first use of a new size is a synchronous hipMalloc) and the chip is in its
+    # steady state -- back-to-back calls get faster for a while (6.8, 6.15, 6.1, 5.95, 5.9 ms: scripts/call_repeat_diag.py);
+    # the number reported is what a training loop that calls icp() every step sees
     log = EventLog()
     log.handles(K)                          # create the HIP events now: not part of the timed workload
     icp._timing_events = None if os.environ.get("DICP_BENCH_NO_EVENTS") == "1" else log      # (experiment switch: what do the events cost?)
+    # a generational GC pass over this process's heap takes tens of ms (10 steps take 7 ms): whether one lands inside
+    # the timed call depends on the allocation count so far, i.e. on things as irrelevant as argv -> collect now and
+    # pause the collector.  The collection goes BEFORE the steady-state calls: the first call after one is ~0.8 ms
+    # slower (it frees the previous calls' graphs and the caching allocator re-splits its blocks).
+    import gc
+    gc.collect()
+    gc.disable()
+    for _ in range(STEADY_CALLS):           # the events ride along: their first use costs the host too
+        run_call(icp, src, tgt, T0, cw)
 
     def fence():
         torch.cuda.synchronize()
@@ -178,16 +189,17 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    # a generational GC pass over this process's heap takes tens of ms (10 steps take 10 ms): whether one lands
-    # inside the timed call depends on the allocation count so far, i.e. on things as irrelevant as argv
-    import gc
-    gc.collect()
-    gc.disable()
     fence()
     t0 = time.perf_counter()
     out, T_all, gs, gt = run_call(icp, src, tgt, T0, cw)                 # exactly K steps
+    t_host = time.perf_counter() - t0
     fence()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("DICP_BENCH_DIAG") == "1":
+        sys.stderr.write("timed call: host-return %.2f ms, done %.2f ms\n" % (t_host * 1e3, elapsed * 1e3))
+        for _ in range(3):
+            fence(); a = time.perf_counter(); run_call(icp, src, tgt, T0, cw); b = time.perf_counter(); fence()
+            sys.stderr.write("  again: host-return %.2f ms, done %.2f ms\n" % ((b - a) * 1e3, (time.perf_counter() - a) * 1e3))
     gc.enable()
     if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -229,7 +241,7 @@ def main():
             "value": world * B * K / elapsed,
             "unit": "cloud-iterations/s",
             "n_gpus": world, "steps": K, "warmup": W,
-            "warmup_note": "W-iteration call, then one untimed K-iteration call (allocator warm-up at the timed shapes)",
+            "warmup_note": "W-iteration call, then %d untimed K-iteration calls (allocator + steady state at the timed shapes)" % STEADY_CALLS,
             "ms_per_step": elapsed * 1e3 / K,
             "batch_iterations_per_s": K / elapsed,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -27,8 +27,10 @@ def short(n):
 # the timed call = everything after the last big idle gap that precedes the last 10 kNN launches
 knn = [i for i, r in enumerate(rows) if "knn_sweep_kernel" in r["Kernel_Name"] or "knn_valu_kernel" in r["Kernel_Name"] or "knn_scan" in r["Kernel_Name"]]
 first = knn[-13] if len(knn) >= 13 else knn[0]      # 10 timed launches + 3 brute-force launches of the roofline leg after them
+# the call starts a few dozen small set-up kernels before its first kNN launch: walk back until the idle gap that
+# separates it from the previous (untimed, synchronised) call
 lo = first
-while lo > 0 and int(rows[lo]["Start_Timestamp"]) - int(rows[lo - 1]["End_Timestamp"]) < 2_000_000:
+while lo > 0 and first - lo < 80 and int(rows[lo]["Start_Timestamp"]) - int(rows[lo - 1]["End_Timestamp"]) < 90_000:
     lo -= 1
 hi = max(i for i, r in enumerate(rows) if "window_reduce" in r["Kernel_Name"] or "accumulate_bwd" in r["Kernel_Name"]) + 6
 seg = rows[lo:min(hi, len(rows))]

@@ -31,7 +31,7 @@ from dicp_amd import dist as ddist                      # noqa: E402
 from dicp_amd.ICP import ICP                            # noqa: E402
 from dicp_amd.synthetic import make_pairs               # noqa: E402
 
-STEADY_CALLS = 3              # untimed K-iteration calls before the timed one
+STEADY_CALLS, STEADY_MAX = 3, 40   # untimed K-iteration calls before the timed one: at least / at most
 F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32 vector == f32-input MFMA peak
 HBM_PEAK_GBS = 8000.0        # HBM3E spec
 LOSS = {"name": "huber", "metric": 1.0}
@@ -180,8 +180,23 @@ def main():
     import gc
     gc.collect()
     gc.disable()
-    for _ in range(STEADY_CALLS):           # the events ride along: their first use costs the host too
+    steady_calls, recent = 0, []
+    while steady_calls < STEADY_MAX:        # the events ride along: their first use costs the host too
+        torch.cuda.synchronize()
+        t_w = time.perf_counter()
         run_call(icp, src, tgt, T0, cw)
+        torch.cuda.synchronize()
+        recent = (recent + [time.perf_counter() - t_w])[-3:]
+        steady_calls += 1
+        # steady = the last three calls within 3 % of each other (a fresh box needs more calls than a warm one: clocks,
+        # first-touch of code objects and of the allocator's pools); every rank makes the same number of calls
+        done = steady_calls >= STEADY_CALLS and max(recent) <= 1.03 * min(recent)
+        if use_dist:
+            flag = torch.tensor([1 if done else 0], device=dev)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            done = bool(flag.item())
+        if done:
+            break
 
     def fence():
         torch.cuda.synchronize()
@@ -241,7 +256,7 @@ def main():
             "value": world * B * K / elapsed,
             "unit": "cloud-iterations/s",
             "n_gpus": world, "steps": K, "warmup": W,
-            "warmup_note": "W-iteration call, then %d untimed K-iteration calls (allocator + steady state at the timed shapes)" % STEADY_CALLS,
+            "warmup_note": "W-iteration call, then %d untimed K-iteration calls (until three in a row agree to 3 %%: allocator + steady state at the timed shapes)" % steady_calls,
             "ms_per_step": elapsed * 1e3 / K,
             "batch_iterations_per_s": K / elapsed,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

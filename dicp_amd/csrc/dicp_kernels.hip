@@ -612,7 +612,7 @@ template <typename T> struct FusedAcc {
 };
 
 template <typename T, int Q, int CH, int MODE>
-__global__ __launch_bounds__(BLOCK) void knn_sweep_kernel(const T* __restrict__ src, const T* __restrict__ pose,
+__global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? 6 : 1) void knn_sweep_kernel(const T* __restrict__ src, const T* __restrict__ pose,
                                                           const typename V4<T>::type* __restrict__ tgs4,
                                                           const int32_t* __restrict__ tperm, const int32_t* __restrict__ qorder,
                                                           const int32_t* __restrict__ bucket, const T* __restrict__ brange, int nbkt,

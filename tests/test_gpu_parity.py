@@ -505,6 +505,23 @@ def test_sweep_knn_equals_brute_force(dtype, N, n, m):
         assert torch.equal(brute.cpu().long(), O.nn_index(x.cpu(), y.cpu()))
 
 
+def test_query_order_beyond_the_lds_path():
+    """More than 16384 queries per cloud take dicp_query_order's two-pass form: still a permutation in bucket order,
+    and the sweep built on it still equals brute force."""
+    g = torch.Generator().manual_seed(5)
+    N, n, m = 2, 20011, 3000
+    x = (torch.rand((N, n, 3), generator=g) * 8 - 4).to(DEV)
+    y = (torch.rand((N, m, 3), generator=g) * 8 - 4).to(DEV)
+    sw = _ops.SweepIndex(y)
+    qo = sw.query_order(x, None)
+    assert torch.equal(torch.sort(qo.long(), dim=1).values, torch.arange(n, device=DEV).repeat(N, 1))
+    lo, hi = y[:, :, 0].min(dim=1).values[:, None], y[:, :, 0].max(dim=1).values[:, None]
+    ks = torch.gather(x[:, :, 0], 1, qo.long()).clamp(lo, hi)          # queries outside the targets' x range sit in the end buckets
+    width = float(((hi - lo) / 2048.0).max())
+    assert float((torch.cummax(ks, dim=1).values - ks).max()) <= 1.05 * width + 1e-4
+    assert torch.equal(sw.knn(x, None, qo), _ops.knn(x, None, _ops.pack_target(y), m, _lib.KNN_VALU))
+
+
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 def test_query_order_is_a_permutation_in_bucket_order(dtype):
     """dicp_query_order (counting sort by x bucket): a permutation of the queries whose x keys ascend bucket by bucket,

@@ -178,14 +178,15 @@ __global__ __launch_bounds__(BLOCK) void query_keys_kernel(const T* __restrict__
 // per bucket widen a wave's slab by a few rows.  One block per cloud, everything in LDS: ~20x cheaper than a full sort.
 constexpr int QO_THREADS = 1024;
 constexpr int QO_BUCKETS = 2048;
-template <typename T>
+// QO_STAGE: queries per cloud whose permutation is assembled in LDS (16384 -> 32 KiB, several clouds per CU; 65536 -> 128 KiB)
+template <typename T, int QO_STAGE>
 __global__ __launch_bounds__(QO_THREADS) void query_order_kernel(const T* __restrict__ src, const T* __restrict__ pose,
                                                                  const T* __restrict__ brange, int nbkt_range, int N, int n,
                                                                  int32_t* __restrict__ qorder, const T* __restrict__ w,
                                                                  T* __restrict__ src_s, T* __restrict__ w_s, int reproducible) {
     __shared__ int cnt[QO_BUCKETS];
     __shared__ int wsum[QO_THREADS / WAVE];
-    __shared__ unsigned short stage[16 * QO_THREADS];       // query ids (< 65536) by slot, for clouds of up to 16384 queries
+    __shared__ unsigned short stage[QO_STAGE];              // query ids (< 65536) by slot: the permutation is assembled here
     const int cloud = blockIdx.x, tid = threadIdx.x;
     for (int b = tid; b < QO_BUCKETS; b += QO_THREADS) cnt[b] = 0;
     T q[4] = {T(1), T(0), T(0), T(0)};
@@ -263,6 +264,10 @@ __global__ __launch_bounds__(QO_THREADS) void query_order_kernel(const T* __rest
             }
             if (w_s) w_s[(size_t)cloud * n + sl] = w[(size_t)cloud * n + i];
         }
+    } else if (n <= QO_STAGE && !src_s && !w_s) {           // two passes of LDS adds, permutation still assembled in LDS
+        for (int i = tid; i < n; i += QO_THREADS) stage[min(atomicAdd(&cnt[bucket_of(i)], 1), n - 1)] = (unsigned short)i;
+        __syncthreads();
+        for (int sl = tid; sl < n; sl += QO_THREADS) qorder[(size_t)cloud * n + sl] = (int32_t)stage[sl];
     } else {
         for (int i = tid; i < n; i += QO_THREADS) {
             const int slot = min(atomicAdd(&cnt[bucket_of(i)], 1), n - 1);
@@ -2011,10 +2016,11 @@ int dicp_query_order(int dtype, const void* src, const void* pose, const void* b
     if (N <= 0 || n <= 0 || nbkt <= 0) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     begin_launch();
-    if (dtype == DICP_F32) query_order_kernel<float><<<N, QO_THREADS, 0, st>>>((const float*)src, (const float*)pose, (const float*)brange, nbkt, N, n, qorder,
-                                                                                (const float*)w, (float*)src_s, (float*)w_s, reproducible);
-    else                   query_order_kernel<double><<<N, QO_THREADS, 0, st>>>((const double*)src, (const double*)pose, (const double*)brange, nbkt, N, n, qorder,
-                                                                                 (const double*)w, (double*)src_s, (double*)w_s, reproducible);
+#define DICP_QO(T, S) query_order_kernel<T, S><<<N, QO_THREADS, 0, st>>>((const T*)src, (const T*)pose, (const T*)brange, nbkt, N, n, qorder, \
+        (const T*)w, (T*)src_s, (T*)w_s, reproducible)
+    if (dtype == DICP_F32) { if (n <= 16384) DICP_QO(float, 16384); else DICP_QO(float, 65536); }
+    else                   { if (n <= 16384) DICP_QO(double, 16384); else DICP_QO(double, 65536); }
+#undef DICP_QO
     return launch_status();
 }
 

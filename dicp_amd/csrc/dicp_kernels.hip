@@ -636,7 +636,7 @@ __global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? 6 : 
     load_pose(pose, cloud, C, r);
     T4* tile = tiles[wave];
 
-    T nx[Q][3], xq[Q], hx[Q], best[Q];
+    T nx[Q][3], xq[Q], hx[Q], best[Q], thr[Q];
     int qi[Q], mi[Q], c1[Q], c2[Q];   // c1: chunk that set the minimum; c2: a second chunk with an EQUAL minimum; mi: the match
     bool over[Q];                     // three or more chunks tied: resolved by re-scanning the visited range
 #pragma unroll
@@ -655,7 +655,7 @@ __global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? 6 : 
         nx[q][0] = -v[0]; nx[q][1] = -v[1]; nx[q][2] = -v[2];
         xq[q] = v[0];
         hx[q] = T(0.5) * (v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-        best[q] = inf_v<T>();
+        best[q] = thr[q] = inf_v<T>();
         c1[q] = 0; c2[q] = -1;
         over[q] = false;
     }
@@ -699,12 +699,17 @@ __global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? 6 : 
                 T cm = score<T, T4>(nx[q], y[0]);
 #pragma unroll
                 for (int k = 1; k < CH; ++k) cm = min_t(cm, score<T, T4>(nx[q], y[k]));
-                const bool lt = cm < best[q];
-                const bool eq = (cm == best[q]) && (cm < inf_v<T>());
-                over[q] = lt ? false : (over[q] || (eq && c2[q] >= 0));
-                c2[q] = lt ? -1 : ((eq && c2[q] < 0) ? chunk : c2[q]);
-                c1[q] = lt ? chunk : c1[q];
-                best[q] = lt ? cm : best[q];
+                // most chunks change nobody's minimum: the bookkeeping sits behind ONE wave-uniform branch
+                // (written out inline it was a quarter of this loop's instructions)
+                if (__any(cm <= best[q])) {
+                    const bool lt = cm < best[q];
+                    const bool eq = (cm == best[q]) && (cm < inf_v<T>());
+                    over[q] = lt ? false : (over[q] || (eq && c2[q] >= 0));
+                    c2[q] = lt ? -1 : ((eq && c2[q] < 0) ? chunk : c2[q]);
+                    c1[q] = lt ? chunk : c1[q];
+                    best[q] = lt ? cm : best[q];
+                    thr[q] = best[q] + SweepEps<T>::v * (T(1) + m_abs(best[q]) + hx[q]);      // the prune threshold moves with it
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -715,8 +720,7 @@ __global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? 6 : 
         for (int q = 0; q < Q; ++q) {
             const T dx = right ? edge - xq[q] : xq[q] - edge;
             const T lb = T(0.5) * dx * dx - hx[q];
-            const T mg = SweepEps<T>::v * (T(1) + m_abs(best[q]) + hx[q]);
-            ok = ok && (dx > T(0)) && (lb > best[q] + mg);
+            ok = ok && (dx > T(0)) && (lb > thr[q]);       // thr = best + margin, kept up to date where best changes
         }
         return __all(ok) != 0;
     };
@@ -750,10 +754,14 @@ __global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? 6 : 
         if (qi[q] < 0) continue;
         T bv = inf_v<T>();
         int bo = 0x7fffffff, bs = 0;
-        auto consider = [&](int j) {
-            const T sc = score<T, T4>(nx[q], tg[j]);
-            const int o = pm[j];
-            if (sc < bv || (sc == bv && o < bo)) { bv = sc; bo = o; bs = j; }     // lowest ORIGINAL index among equals
+        auto consider = [&](int j) {                        // lowest ORIGINAL index among equal scores; the permutation
+            const T sc = score<T, T4>(nx[q], tg[j]);        // is only read for the winner and on (rare) exact ties
+            if (sc < bv) { bv = sc; bs = j; bo = -1; }
+            else if (sc == bv && sc < inf_v<T>()) {
+                if (bo < 0) bo = pm[bs];
+                const int o = pm[j];
+                if (o < bo) { bo = o; bs = j; }
+            }
         };
         if (!over[q]) {
 #pragma unroll
@@ -766,6 +774,7 @@ __global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? 6 : 
             // >= 3 chunks share the minimum (duplicated targets): rare, re-scan what this wave visited
             for (int j = visL * WAVE; j < visR * WAVE; ++j) consider(j);
         }
+        if (bo < 0) bo = pm[bs];                            // (0x7fffffff: nothing finite was seen)
         mi[q] = (bo == 0x7fffffff) ? 0 : min(max(bo, 0), m - 1);
         idx[(size_t)cloud * n + qi[q]] = mi[q];
         // sorted position of the winner (indexed like idx, by the query): what the windowed backward consumes

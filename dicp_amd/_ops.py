@@ -584,6 +584,8 @@ class ICPLoop(torch.autograd.Function):
                                                  _p(gs), _p(gb), _p(gsrc_s) if w_form else _p(gsrc), _p(slab) if w_form else _p(gtgt),
                                                  _p(gw_s) if w_form else _p(gw), _p(bwdp[form]), k0, k1, st), "dicp_icp_backward")
                 have = 1
+                if (k1 - k0) % 2:           # the library alternates the two buffers: odd chunk -> the result is in the other one
+                    gpose, gtmp = gtmp, gpose
             if have:
                 gpose = gpose + bwdp[form].sum(dim=1)[:, :12].to(torch.float64)
             if any(windowed):               # slot s is source point qo[s]; slabs + out-of-window rows -> original target order

@@ -78,8 +78,17 @@ template <typename T>
 __device__ __forceinline__ typename V4<T>::type pack_row(const T* __restrict__ y) {
     typename V4<T>::type v;
     v.x = y[0]; v.y = y[1]; v.z = y[2];
-    v.w = T(0.5) * (v.x * v.x + v.y * v.y + v.z * v.z);
+    v.w = T(0.5) * fma_t(v.z, v.z, fma_t(v.y, v.y, v.x * v.x));     // explicit fmas: no per-kernel contraction choices
     return v;
+}
+
+// -(C p + r), the query every kNN form scores with: ONE explicit fma chain, so that all forms (VALU, packed, MFMA,
+// sweep, scan) see bit-identical queries whatever the compiler would contract in their different surroundings
+template <typename T>
+__device__ __forceinline__ void query_point(const T* C, const T* r, const T* p, T* nx) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        nx[k] = -fma_t(C[3 * k], p[0], fma_t(C[3 * k + 1], p[1], fma_t(C[3 * k + 2], p[2], r[k])));
 }
 
 template <typename T>
@@ -108,13 +117,15 @@ __global__ __launch_bounds__(BLOCK) void sweep_rows_kernel(const T* __restrict__
     const int s0 = blk * (BLOCK * U) + threadIdx.x;
     {
         long j[U];
-        T y[U][3];
+        T y[U][6];
 #pragma unroll
         for (int u = 0; u < U; ++u) j[u] = order[(size_t)b * m_pad + min(s0 + u * BLOCK, m_pad - 1)];
+        const bool full = tgt_s && c == 6;                  // the normals are wanted too: read the whole row once
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const T* yp = tgt + ((size_t)b * m + (j[u] >= 0 && j[u] < m ? j[u] : 0)) * c;
+            const T* yp = tgt + ((size_t)b * m + (j[u] >= 0 && j[u] < m ? j[u] : 0)) * c;   // pad slots repeat row 0 (never matched)
             y[u][0] = yp[0]; y[u][1] = yp[1]; y[u][2] = yp[2];
+            if (full) { y[u][3] = yp[3]; y[u][4] = yp[4]; y[u][5] = yp[5]; }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -125,10 +136,10 @@ __global__ __launch_bounds__(BLOCK) void sweep_rows_kernel(const T* __restrict__
             else { v.x = big_v<T>(); v.y = v.z = T(0); v.w = inf_v<T>(); }      // pads sort last and can never win
             tgs4[(size_t)b * m_pad + sl] = v;
             tperm[(size_t)b * m_pad + sl] = (int32_t)j[u];
-            if (tgt_s) {                                    // pad slots repeat row 0 (they are never matched)
-                const T* yp = tgt + ((size_t)b * m + (j[u] >= 0 && j[u] < m ? j[u] : 0)) * c;
+            if (tgt_s) {
                 T* o = tgt_s + ((size_t)b * m_pad + sl) * c;
-                for (int k = 0; k < c; ++k) o[k] = yp[k];
+                o[0] = y[u][0]; o[1] = y[u][1]; o[2] = y[u][2];
+                if (full) { o[3] = y[u][3]; o[4] = y[u][4]; o[5] = y[u][5]; }
             }
         }
     }
@@ -362,9 +373,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_valu_kernel(const T* __restri
             const T* sp = src + ((size_t)cloud * n + i) * 3;
             p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2];
         }
-        T q[3];
-        matvec3(C, p, q);                                   // ICP.py:137
-        nx[qi][0] = -(q[0] + r[0]); nx[qi][1] = -(q[1] + r[1]); nx[qi][2] = -(q[2] + r[2]);
+        query_point(C, r, p, nx[qi]);                       // ICP.py:137
         best[qi] = inf_v<T>();
         bchunk[qi] = 0;
     }
@@ -434,10 +443,9 @@ __global__ __launch_bounds__(BLOCK) void knn_valu_pk_kernel(const float* __restr
             const float* sp = src + ((size_t)cloud * n + i) * 3;
             p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2];
         }
-        float q[3];
-        matvec3(C, p, q);
+        query_point(C, r, p, nx[qi]);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { nx[qi][k] = -(q[k] + r[k]); nx2[qi][k] = {nx[qi][k], nx[qi][k]}; }
+        for (int k = 0; k < 3; ++k) nx2[qi][k] = {nx[qi][k], nx[qi][k]};
         best[qi] = inf_v<float>();
         bchunk[qi] = 0;
     }
@@ -521,9 +529,7 @@ __global__ __launch_bounds__(BLOCK) void knn_mfma_kernel(const float* __restrict
             const float* sp = src + ((size_t)cloud * n + i) * 3;
             p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2];
         }
-        float q[3];
-        matvec3(C, p, q);
-        nx[nb][0] = -(q[0] + r[0]); nx[nb][1] = -(q[1] + r[1]); nx[nb][2] = -(q[2] + r[2]);
+        query_point(C, r, p, nx[nb]);
         bq[nb] = (kq == 0) ? nx[nb][0] : (kq == 1) ? nx[nb][1] : (kq == 2) ? nx[nb][2] : 1.0f;
         best[nb] = inf_v<float>();
         bt[nb] = 0;
@@ -649,10 +655,8 @@ __global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? 6 : 
             const T* sp = src + ((size_t)cloud * n + (src_sorted ? pos : qi[q])) * 3;      // src_sorted: rows already in slot order
             p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2];
         }
-        T v[3];
-        matvec3(C, p, v);
-        v[0] += r[0]; v[1] += r[1]; v[2] += r[2];
-        nx[q][0] = -v[0]; nx[q][1] = -v[1]; nx[q][2] = -v[2];
+        query_point(C, r, p, nx[q]);
+        const T v[3] = {-nx[q][0], -nx[q][1], -nx[q][2]};
         xq[q] = v[0];
         hx[q] = T(0.5) * (v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
         best[q] = thr[q] = inf_v<T>();
@@ -857,10 +861,9 @@ __global__ __launch_bounds__(BLOCK) void knn_scan_kernel(const T* __restrict__ s
         const T* sp = src + ((size_t)cloud * n + qi) * 3;
         p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2];
     }
-    T v[3];
-    matvec3(C, p, v);
-    v[0] += r3[0]; v[1] += r3[1]; v[2] += r3[2];
-    const T nx[3] = {-v[0], -v[1], -v[2]};
+    T nx[3];
+    query_point(C, r3, p, nx);
+    const T v[3] = {-nx[0], -nx[1], -nx[2]};
     const T xq = v[0];
     const T hx = T(0.5) * (v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
 
@@ -2528,8 +2531,8 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
 }
 
 // Reverse sweep for iterations k1-1 .. k0: K x { step_bwd -> accumulate_bwd }.  gpose (N,12) double holds the
-// cotangent of pose_{k1} on entry and of pose_{k0} (without the last accumulate_bwd partials, which stay in
-// bwd_partials for the caller or the next chunk) on exit; gpose_tmp is scratch of the same size.
+// cotangent of pose_{k1} on entry; the cotangent of pose_{k0} (without the last accumulate_bwd partials, which stay in
+// bwd_partials for the caller or the next chunk) is left in gpose when k1-k0 is even and in gpose_tmp when it is odd.
 int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_buffers* B, int N, int n, int m, int dim,
                       double* gpose, double* gpose_tmp, int have_partials, void* gs, void* gb, void* gsrc, void* gtgt, void* gw,
                       void* bwd_partials, int k0, int k1, void* stream) {
@@ -2561,8 +2564,8 @@ int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_
         have_partials = 1;
         double* t = gin; gin = gout; gout = t;
     }
-    if (gin != gpose && k1 > k0)      // odd number of iterations: result sits in the scratch buffer
-        if (hipMemcpyAsync(gpose, gin, (size_t)N * 12 * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) return -(int)hipGetLastError();
+    // the two buffers alternate: after an odd number of iterations the result sits in gpose_tmp (no copy: the caller
+    // swaps its two pointers, see dicp_hip.h)
     return 0;
 }
 

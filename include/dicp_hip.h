@@ -231,7 +231,9 @@ int dicp_loop_finish(int dtype, const void* pose_K, const void* alive_K, const v
 /* Iterations [k0,k1) of the loop (ICP.py:131-260), enqueued back to back: no host work between iterations. */
 int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_buffers* buf, int N, int n, int m,
                      int dim, int const_iter, double tolerance, int k0, int k1, void* stream);
-/* Reverse sweep over iterations k1-1..k0.  gpose/gpose_tmp (N,12) double; gs (N,36), gb (N,6) scratch T;
+/* Reverse sweep over iterations k1-1..k0.  gpose/gpose_tmp (N,12) double: gpose holds the cotangent of pose_k1 on entry;
+ * the two alternate, so the cotangent of pose_k0 is left in gpose when k1-k0 is even and in gpose_tmp when it is odd
+ * (no copy: swap the two pointers for the next chunk); gs (N,36), gb (N,6) scratch T;
  * gsrc/gtgt/gw accumulate like dicp_accumulate_bwd; bwd_partials (N,nblk,DICP_NBWD_PAD) carries the last
  * accumulate_bwd's C-bar/r-bar sums across chunks (have_partials: it holds valid sums on entry). */
 int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_buffers* buf, int N, int n, int m, int dim,

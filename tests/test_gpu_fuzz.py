@@ -80,3 +80,33 @@ def test_sweep_path_equals_brute_path(seed, kind):
         assert (np.isfinite(x) == np.isfinite(y)).all(), nm
         scale = max(1.0, float(np.abs(x[ok]).max()) if ok.any() else 1.0)
         assert float(np.abs(x[ok] - y[ok]).max() if ok.any() else 0.0) <= (1e-8 if f64 else 2e-3) * scale, (nm, seed, kind)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_every_knn_form_returns_the_same_indices(seed):
+    """All-pairs VALU (several launch configurations), packed-FMA, MFMA, tile sweep (every configuration, any query order)
+    and per-lane scan share one score arithmetic: under a random pose they must agree index for index, near-ties included."""
+    from dicp_amd import _ops
+    rng = np.random.default_rng(50 + seed)
+    N = int(rng.integers(1, 4))
+    n = int(rng.choice([3, 64, 200, 1111, 4097]))
+    m = int(rng.choice([2, 64, 300, 2049, 6000]))
+    g = torch.Generator().manual_seed(seed)
+    y = ((torch.rand((N, m, 3), generator=g) - 0.5) * 6.0)
+    if seed % 3 == 0:
+        y[:, :, 2] = 0.0                                    # planar clouds (dim = 2 use): many near-ties
+    x = y[:, torch.randint(0, m, (n,), generator=g)] + 0.01 * torch.randn((N, n, 3), generator=g)
+    ang = float(rng.uniform(-0.5, 0.5))
+    C = torch.tensor([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1.0]], dtype=torch.float32)
+    pose = torch.cat((C.reshape(9), torch.tensor(rng.uniform(-0.3, 0.3, 3), dtype=torch.float32))).repeat(N, 1).to(DEV)
+    x, y = x.to(DEV).contiguous(), y.to(DEV).contiguous()
+    tgt4 = _ops.pack_target(y)
+    ref = _ops.knn(x, pose, tgt4, m, _lib.KNN_VALU)
+    for cfg in (1, 2, 5, 7, 11, 9):                         # VALU launch configurations, incl. the packed-FMA form (9)
+        assert torch.equal(_ops.knn(x, pose, tgt4, m, _lib.KNN_VALU | (cfg << 8)), ref), ("valu", cfg)
+    for cfg in (0, 1, 5):
+        assert torch.equal(_ops.knn(x, pose, tgt4, m, _lib.KNN_MFMA | (cfg << 8)), ref), ("mfma", cfg)
+    sw = _ops.SweepIndex(y)
+    for cfg in (1, 2, 3, 4, 5, 6, 7, 8, 16, 17, 18):
+        for qo in (None, sw.query_order(x, pose), sw.query_order(x, pose, exact=True)):
+            assert torch.equal(sw.knn(x, pose, qo, cfg=cfg), ref), ("sweep", cfg)

@@ -339,6 +339,7 @@ def _pose_from_T(T):
 
 
 FUSE_ACCUMULATE = int(os.environ.get("DICP_FUSE_ACC", "0"))      # sweep path: accumulate in the search kernel's epilogue (measured slower: off)
+SMALL_LOOP = int(os.environ.get("DICP_SMALL_LOOP", "1"))       # small clouds: one block runs a cloud's whole chunk of iterations
 WINDOW_MIN_ITERS = 3            # fewer windowed iterations than this: all take the atomic backward (see ICPLoop.backward)
 WINDOW_FROM = int(os.environ.get("DICP_WINDOW_FROM", "0"))      # first windowed iteration (measured: even iteration 0 pays, 0.13 vs 0.28 ms)
 HIST_CHUNK_BYTES = 1 << 29      # per-iteration histories (indices, weights) are allocated in slabs of at most this size
@@ -465,7 +466,7 @@ class ICPLoop(torch.autograd.Function):
                 seg_q.append(len(qorders) - 1)
                 base = j * kc                                         # virtual bases: slab pointer minus its first iteration
                 LB = _lib.LoopBuffers(
-                    src=_p(src), tgt=_p(tgt), w_init=_p(w0c), c=c, K=Kmax, knn_variant=kind | (cfg.knn_variant & 0xffff00) | (FUSE_ACCUMULATE << 24), m_pad=m_pad,
+                    src=_p(src), tgt=_p(tgt), w_init=_p(w0c), c=c, K=Kmax, knn_variant=kind | (cfg.knn_variant & 0xffff00) | (FUSE_ACCUMULATE << 24) | ((0 if SMALL_LOOP else 1) << 25), m_pad=m_pad,
                     tgt4=_p(tgt4), tperm=_p(sweep.tperm) if sweep else None, qorder=_p(qorder),
                     bucket=_p(sweep.bucket) if sweep else None, brange=_p(sweep.brange) if sweep else None,
                     nbkt=SweepIndex.NBKT, idx_per_iter=int(need_grad), pairs=_p(sweep.pair_shards) if sweep else None,

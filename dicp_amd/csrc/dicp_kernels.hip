@@ -1087,12 +1087,33 @@ __global__ __launch_bounds__(BLOCK) void accumulate_kernel(WeightParams P, const
 // -------------------------------------------------------------------------- step
 // One 64-thread block per cloud.  All small matrices live in LDS: private arrays with dynamic indexing
 // would be scratch (global) memory, and this kernel is pure latency (it sits between two big launches).
-template <typename T>
-__global__ __launch_bounds__(WAVE) void step_kernel(dicp_step_io io, int N) {
+// dicp_step_io of iteration k of a dicp_icp_forward chunk [k0, k1): one place for the host loop and the small-cloud kernel
+__host__ __device__ inline dicp_step_io make_step_io(const dicp_loop_buffers& B, int k, int k0, int N, int n, int mode, int dim,
+                                                     int const_iter, double tolerance, size_t es, int nblk) {
+    dicp_step_io io;
+    io.partials = B.partials; io.nblk = nblk; io.iter = k; io.dim = dim; io.const_iter = const_iter; io.tolerance = tolerance;
+    io.rows_per_point = mode == DICP_PT2PT ? 3 : 1; io.n = n;
+    io.pose_in = (const char*)B.poses + (size_t)k * N * 12 * es; io.pose_out = (char*)B.poses + (size_t)(k + 1) * N * 12 * es;
+    io.delta = (char*)B.deltas + (size_t)k * 6 * es; io.delta_stride = (int64_t)B.K * 6;
+    io.cost = (char*)B.costs + (size_t)k * es; io.cost_prev = k > 0 ? (const char*)B.costs + (size_t)(k - 1) * es : nullptr;
+    io.cost_stride = B.K;
+    io.areg = B.areg ? B.areg + (size_t)k * N * 36 : nullptr;
+    io.alive = (const char*)B.alive + (size_t)k * N * es; io.alive_out = (char*)B.alive + (size_t)(k + 1) * N * es;
+    io.converged = B.converged; io.iterations = B.iterations; io.matched_ratio = B.matched_ratio;
+    io.n_start = B.n_start; io.n_matched = B.n_matched;
+    io.w_cur = (char*)B.w + (size_t)k * B.w_iter * es;
+    io.w_prev = k > k0 ? (const char*)B.w + (size_t)(k - 1) * B.w_iter * es : (const char*)B.w_prev0; io.w_stride = B.w_stride;
+    io.n_not_converged = B.counters + k;
+    return io;
+}
+
+// The step of one cloud, run by a whole block of NT >= 64 threads (its first wave does the work, everybody joins the
+// barriers): the body of step_kernel, and of the small-cloud kernel that keeps a cloud in one block for a whole chunk.
+template <typename T, int NT>
+__device__ __forceinline__ void step_body(const dicp_step_io& io, int cloud, int tid) {
     __shared__ double sacc[NACC_PAD], sA[36], sAreg[36], spose[12], sout[24];
     __shared__ int s_copy;
-    const int cloud = blockIdx.x, tid = threadIdx.x;
-    {   // reduce the per-block partials: lane = (part, slot); fixed summation order -> bit-reproducible
+    if (tid < WAVE) {   // reduce the per-block partials: lane = (part, slot); fixed summation order -> bit-reproducible
         const int slot_i = tid & 31, part = tid >> 5;
         const T* pp = (const T*)io.partials + (size_t)cloud * io.nblk * NACC_PAD + slot_i;
         double s = 0.0;
@@ -1149,7 +1170,77 @@ __global__ __launch_bounds__(WAVE) void step_kernel(dicp_step_io io, int N) {
     if (s_copy) {
         T* wc = (T*)io.w_cur + (size_t)cloud * io.w_stride;
         const T* wp = (const T*)io.w_prev + (size_t)cloud * io.w_stride;
-        for (int i = tid; i < io.n; i += WAVE) wc[i] = wp[i];
+        for (int i = tid; i < io.n; i += NT) wc[i] = wp[i];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(WAVE) void step_kernel(dicp_step_io io, int N) {
+    step_body<T, WAVE>(io, blockIdx.x, threadIdx.x);
+}
+
+// ------------------------------------------------------------ whole loop, small clouds
+// Clouds of a few hundred points (the reference's own 65-point test pair; batches of many small scans) are pure
+// launch latency on the multi-kernel path: 3 dependent launches per iteration, each a few microseconds of work.
+// Here ONE block owns a cloud for a whole chunk of iterations: packed targets staged in LDS once, then per iteration
+// brute-force 1-NN (same score arithmetic and lowest-index rule as every other form), the accumulate pass, the block
+// reduction and the step (step_body), with the pose handed from one iteration to the next through the pose history.
+template <typename T, int MODE>
+__global__ __launch_bounds__(BLOCK) void icp_small_forward_kernel(WeightParams P, dicp_loop_buffers B, int N, int n, int m, int dim,
+                                                                  int const_iter, double tolerance, int k0, int k1) {
+    using T4 = typename V4<T>::type;
+    extern __shared__ __align__(32) unsigned char small_lds[];
+    T4* tg = reinterpret_cast<T4*>(small_lds);
+    __shared__ T red[(BLOCK / WAVE) * NACC_PAD];
+    const int cloud = blockIdx.x, tid = threadIdx.x, m_pad = B.m_pad, c = B.c;
+    {
+        const T4* __restrict__ g = (const T4*)B.tgt4 + (size_t)cloud * m_pad;
+        for (int j = tid; j < m_pad; j += BLOCK) tg[j] = g[j];
+    }
+    __syncthreads();
+    const T* __restrict__ src = (const T*)B.src + (size_t)cloud * n * 3;
+    const T* __restrict__ tgt = (const T*)B.tgt + (size_t)cloud * m * c;
+    const T* __restrict__ w_init = (const T*)B.w_init + (size_t)cloud * n;
+    for (int k = k0; k < k1; ++k) {
+        T C[9], r[3];
+        load_pose((const T*)B.poses + (size_t)k * N * 12, cloud, C, r);
+        const T live = ((const T*)B.alive)[(size_t)k * N + cloud];
+        int32_t* __restrict__ idx_k = B.idx + (B.idx_per_iter ? (size_t)k * N * n : 0) + (size_t)cloud * n;
+        T* __restrict__ w_k = (T*)B.w + (size_t)k * B.w_iter + (size_t)cloud * B.w_stride;
+        T acc[NACC];
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) acc[a] = T(0);
+        for (int i = tid; i < n; i += BLOCK) {
+            const T p[3] = {src[i * 3], src[i * 3 + 1], src[i * 3 + 2]};
+            T nx[3];
+            query_point(C, r, p, nx);
+            T best = inf_v<T>();
+            int bj = 0;
+            for (int j = 0; j < m_pad; j += 4) {            // m_pad is a multiple of 64; ascending, strict <: lowest index on ties
+                const T s0 = score<T, T4>(nx, tg[j]), s1 = score<T, T4>(nx, tg[j + 1]);
+                const T s2 = score<T, T4>(nx, tg[j + 2]), s3 = score<T, T4>(nx, tg[j + 3]);
+                if (s0 < best) { best = s0; bj = j; }
+                if (s1 < best) { best = s1; bj = j + 1; }
+                if (s2 < best) { best = s2; bj = j + 2; }
+                if (s3 < best) { best = s3; bj = j + 3; }
+            }
+            bj = min(bj, m - 1);
+            idx_k[i] = bj;
+            const T* yp = tgt + (size_t)bj * c;
+            const T y[3] = {yp[0], yp[1], yp[2]};
+            T nrm[3] = {T(0), T(0), T(0)};
+            if (MODE == MODE_PT2PL) { nrm[0] = yp[3]; nrm[1] = yp[4]; nrm[2] = yp[5]; }
+            PointState<T> st;
+            point_forward<T, MODE>(P, C, r, p, y, nrm, w_init[i] * live, acc, st);
+            w_k[i] = st.w;
+        }
+        block_reduce_store<T, NACC, NACC_PAD>(acc, (T*)B.partials + (size_t)cloud * NACC_PAD, red);
+        __threadfence_block();
+        __syncthreads();
+        const dicp_step_io io = make_step_io(B, k, k0, N, n, MODE == MODE_PT2PT ? DICP_PT2PT : DICP_PT2PL, dim, const_iter, tolerance, sizeof(T), 1);
+        step_body<T, BLOCK>(io, cloud, tid);
+        __threadfence_block();                              // pose / alive / weights of iteration k+1 are read next
+        __syncthreads();
     }
 }
 
@@ -2447,6 +2538,15 @@ int dicp_permute_add_rows(int dtype, const void* in, const int32_t* perm, int N,
     return launch_status();
 }
 
+// One block per cloud runs the whole chunk when the packed targets fit comfortably in LDS and a block's brute-force
+// search stays in the microseconds (SMALL_PAIRS pairs per iteration); anything bigger is better off spread over the chip.
+constexpr long SMALL_PAIRS = 128L * 1024;    // measured break-even against the multi-kernel path: ~512 x 512 (profiles/r01_small_clouds.txt)
+static bool small_loop_eligible(int dtype, int kind, int knn_variant, int n, int m_pad) {
+    if (kind == DICP_KNN_SWEEP || kind == DICP_KNN_MFMA || ((knn_variant >> 25) & 1) || ((knn_variant >> 8) & 0xff)) return false;
+    const size_t lds = (size_t)m_pad * (dtype == DICP_F32 ? 16 : 32);
+    return lds <= 48 * 1024 && (long)n * m_pad <= SMALL_PAIRS;
+}
+
 // ------------------------------------------------------------------ whole-loop entry points
 // The iteration loop of ICP.dICP (ICP.py:131-260) behind ONE call: K x { kNN -> accumulate -> step } are
 // enqueued back to back on the stream with every piece of per-iteration state in caller-allocated buffers
@@ -2465,6 +2565,18 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
     if (kind == DICP_KNN_SWEEP ? (!B->tperm || !B->bucket || !B->brange) : !B->tgt4) return DICP_ERR_NULL;
     hipStream_t st = (hipStream_t)stream;
     const int nblk = dicp_accumulate_blocks(n);
+    if (small_loop_eligible(dtype, kind, B->knn_variant, n, B->m_pad) && k1 > k0) {
+        // small clouds: the whole chunk is ONE launch, one block per cloud (bit 25 of knn_variant switches this off)
+        if (const int e = check_params(prm, B->c)) return e;
+        begin_launch();
+        const WeightParams P = to_params(prm);
+        const size_t lds = (size_t)B->m_pad * (dtype == DICP_F32 ? sizeof(float4) : sizeof(double4));
+#define DICP_SMALL(T, M) icp_small_forward_kernel<T, M><<<N, BLOCK, lds, st>>>(P, *B, N, n, m, dim, const_iter, tolerance, k0, k1)
+        if (dtype == DICP_F32) { if (P.mode == MODE_PT2PL) DICP_SMALL(float, MODE_PT2PL); else DICP_SMALL(float, MODE_PT2PT); }
+        else                   { if (P.mode == MODE_PT2PL) DICP_SMALL(double, MODE_PT2PL); else DICP_SMALL(double, MODE_PT2PT); }
+#undef DICP_SMALL
+        return launch_status();
+    }
     for (int k = k0; k < k1; ++k) {
         const char* pose_k = (const char*)B->poses + (size_t)k * N * 12 * es;
         int32_t* idx_k = B->idx + (B->idx_per_iter ? (size_t)k * N * n : 0);
@@ -2511,19 +2623,7 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
             rc = dicp_accumulate(dtype, prm, B->src, B->tgt, B->c, idx_k, pose_k, B->w_init, alive_k, N, n, m, B->partials, w_k, B->w_stride, stream);
             if (rc) return rc;
         }
-        dicp_step_io io;
-        io.partials = B->partials; io.nblk = nblk_k; io.iter = k; io.dim = dim; io.const_iter = const_iter; io.tolerance = tolerance;
-        io.rows_per_point = prm->mode == DICP_PT2PT ? 3 : 1; io.n = n;
-        io.pose_in = pose_k; io.pose_out = (char*)B->poses + (size_t)(k + 1) * N * 12 * es;
-        io.delta = (char*)B->deltas + (size_t)k * 6 * es; io.delta_stride = (int64_t)B->K * 6;
-        io.cost = (char*)B->costs + (size_t)k * es; io.cost_prev = k > 0 ? (const char*)B->costs + (size_t)(k - 1) * es : nullptr;
-        io.cost_stride = B->K;
-        io.areg = B->areg ? B->areg + (size_t)k * N * 36 : nullptr;
-        io.alive = alive_k; io.alive_out = (char*)B->alive + (size_t)(k + 1) * N * es;
-        io.converged = B->converged; io.iterations = B->iterations; io.matched_ratio = B->matched_ratio;
-        io.n_start = B->n_start; io.n_matched = B->n_matched;
-        io.w_cur = w_k; io.w_prev = k > k0 ? (const char*)B->w + (size_t)(k - 1) * B->w_iter * es : (const char*)B->w_prev0; io.w_stride = B->w_stride;
-        io.n_not_converged = B->counters + k;
+        dicp_step_io io = make_step_io(*B, k, k0, N, n, prm->mode, dim, const_iter, tolerance, es, nblk_k);
         rc = dicp_step(dtype, &io, N, stream);
         if (rc) return rc;
     }

@@ -112,9 +112,10 @@ class SweepIndex:
         """(query,target) pairs scored so far (device scalar)."""
         return self.pair_shards.sum()
 
-    def query_order(self, src, pose, exact=False, w=None, copies=False, reproducible=False):
+    def query_order(self, src, pose, exact=False, w=None, copies=False, reproducible=False, spos_prev=None):
         """Query indices in (approximately) ascending transformed x: keeps a wave's queries neighbours.  Default: a
-        counting sort by x bucket (dicp_query_order); exact=True: a full sort of the x keys.
+        counting sort by x bucket (dicp_query_order) -- or, given spos_prev (the matches of an earlier iteration), by the
+        rank of each query's previous match among the sorted targets; exact=True: a full sort of the x keys.
         copies=True -> (qorder, src_s, w_s): also the source rows (and the weights w, if given) in that slot order."""
         N, n, _ = src.shape
         lib = _lib.load()
@@ -122,7 +123,8 @@ class SweepIndex:
             if not exact:
                 qorder = torch.empty((N, n), dtype=torch.int32, device=src.device)
                 _lib.check(lib.dicp_query_order(_DT[src.dtype], _p(src), _p(pose), _p(self.brange), self.NBKT, N, n, _p(qorder),
-                                                None, None, None, int(reproducible), _stream()), "dicp_query_order")
+                                                None, None, None, int(reproducible), _p(spos_prev), self.tgs4.shape[1], _stream()),
+                           "dicp_query_order")
                 if copies:      # (the ordering kernel can write them itself, but one block per cloud gathers slowly: 115 vs 16 us)
                     return qorder, _gather_rows_raw(src, qorder), (_gather_rows_raw(w.unsqueeze(-1), qorder).squeeze(-1) if w is not None else None)
                 return qorder
@@ -340,6 +342,8 @@ def _pose_from_T(T):
 
 FUSE_ACCUMULATE = int(os.environ.get("DICP_FUSE_ACC", "0"))      # sweep path: accumulate in the search kernel's epilogue (measured slower: off)
 SMALL_LOOP = int(os.environ.get("DICP_SMALL_LOOP", "1"))       # small clouds: one block runs a cloud's whole chunk of iterations
+SPOS_ORDER = int(os.environ.get("DICP_SPOS_ORDER", "0"))       # re-order queries by the rank of their previous match instead of their x
+                                                              # (density-robust, but measured slower on the benchmark clouds: 0.62 vs 0.58 ms/step)
 WINDOW_MIN_ITERS = 3            # fewer windowed iterations than this: all take the atomic backward (see ICPLoop.backward)
 WINDOW_FROM = int(os.environ.get("DICP_WINDOW_FROM", "0"))      # first windowed iteration (measured: even iteration 0 pays, 0.13 vs 0.28 ms)
 HIST_CHUNK_BYTES = 1 << 29      # per-iteration histories (indices, weights) are allocated in slabs of at most this size
@@ -461,7 +465,8 @@ class ICPLoop(torch.autograd.Function):
                         spos_slabs.append(torch.empty((kk, N, n), dtype=torch.int32, device=dev))
                 if sweep is not None and (qorder is None or k0 in cfg.sweep_resort):
                     # queries re-ordered by x under the current pose (reproducibly when the forward sums in that order)
-                    qorder = sweep.query_order(src, poses[k0], reproducible=bool(FUSE_ACCUMULATE))
+                    prev = spos_slabs[(k0 - 1) // kc][(k0 - 1) % kc] if (owned and k0 > 0 and SPOS_ORDER) else None
+                    qorder = sweep.query_order(src, poses[k0], reproducible=bool(FUSE_ACCUMULATE), spos_prev=prev)
                     qorders.append(qorder)
                 seg_q.append(len(qorders) - 1)
                 base = j * kc                                         # virtual bases: slab pointer minus its first iteration

@@ -194,7 +194,8 @@ template <typename T, int QO_STAGE>
 __global__ __launch_bounds__(QO_THREADS) void query_order_kernel(const T* __restrict__ src, const T* __restrict__ pose,
                                                                  const T* __restrict__ brange, int nbkt_range, int N, int n,
                                                                  int32_t* __restrict__ qorder, const T* __restrict__ w,
-                                                                 T* __restrict__ src_s, T* __restrict__ w_s, int reproducible) {
+                                                                 T* __restrict__ src_s, T* __restrict__ w_s, int reproducible,
+                                                                 const int32_t* __restrict__ spos_prev, int m_pad) {
     __shared__ int cnt[QO_BUCKETS];
     __shared__ int wsum[QO_THREADS / WAVE];
     __shared__ unsigned short stage[QO_STAGE];              // query ids (< 65536) by slot: the permutation is assembled here
@@ -205,6 +206,11 @@ __global__ __launch_bounds__(QO_THREADS) void query_order_kernel(const T* __rest
     const T xlo = brange[(size_t)cloud * 2];
     const T scale = brange[(size_t)cloud * 2 + 1] * (T(QO_BUCKETS) / T(nbkt_range));      // buckets per unit x
     auto bucket_of = [&](int i) {
+        if (spos_prev) {        // bucket = rank of the query's previous match among the sorted targets: equal-POPULATION buckets,
+                                // whatever the density of the cloud along x (an outlier cannot coarsen them)
+            const int sp = spos_prev[(size_t)cloud * n + i];
+            return sp < 0 ? QO_BUCKETS - 1 : (int)(((long)min(sp, m_pad - 1) * QO_BUCKETS) / m_pad);
+        }
         const T* p = src + ((size_t)cloud * n + i) * 3;
         const T x = fma_t(q[0], p[0], fma_t(q[1], p[1], fma_t(q[2], p[2], q[3])));
         T f = (x - xlo) * scale;
@@ -2113,14 +2119,14 @@ int dicp_query_keys(int dtype, const void* src, const void* pose, int N, int n, 
 }
 
 int dicp_query_order(int dtype, const void* src, const void* pose, const void* brange, int nbkt, int N, int n, int32_t* qorder,
-                     const void* w, void* src_s, void* w_s, int reproducible, void* stream) {
+                     const void* w, void* src_s, void* w_s, int reproducible, const int32_t* spos_prev, int m_pad, void* stream) {
     if (!src || !brange || !qorder || (w_s && !w)) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
-    if (N <= 0 || n <= 0 || nbkt <= 0) return DICP_ERR_SHAPE;
+    if (N <= 0 || n <= 0 || nbkt <= 0 || (spos_prev && m_pad <= 0)) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     begin_launch();
 #define DICP_QO(T, S) query_order_kernel<T, S><<<N, QO_THREADS, 0, st>>>((const T*)src, (const T*)pose, (const T*)brange, nbkt, N, n, qorder, \
-        (const T*)w, (T*)src_s, (T*)w_s, reproducible)
+        (const T*)w, (T*)src_s, (T*)w_s, reproducible, spos_prev, m_pad)
     if (dtype == DICP_F32) { if (n <= 16384) DICP_QO(float, 16384); else DICP_QO(float, 65536); }
     else                   { if (n <= 16384) DICP_QO(double, 16384); else DICP_QO(double, 65536); }
 #undef DICP_QO

@@ -85,9 +85,11 @@ int dicp_query_keys(int dtype, const void* src, const void* pose, int N, int n, 
  * query loads in dicp_knn_sweep (cfg | DICP_SWEEP_SRC_SORTED) and for dicp_accumulate_bwd_window (measured: one block
  * per cloud gathers slowly, 115 vs 16 us; dicp_gather_rows does it better).  reproducible != 0: buckets of up to 64
  * members are put in index order, so the permutation is the same on every run (needed only when sums are taken in
- * this order, i.e. by dicp_knn_sweep_accumulate). */
+ * this order, i.e. by dicp_knn_sweep_accumulate).  spos_prev (N,n), optional: the queries' matches of an earlier iteration
+ * (dicp_knn_sweep's spos): the bucket is then the match's rank among the m_pad sorted targets instead of the query's x --
+ * equal-population buckets, robust against uneven density along x. */
 int dicp_query_order(int dtype, const void* src, const void* pose, const void* brange, int nbkt, int N, int n, int32_t* qorder,
-                     const void* w, void* src_s, void* w_s, int reproducible, void* stream);
+                     const void* w, void* src_s, void* w_s, int reproducible, const int32_t* spos_prev, int m_pad, void* stream);
 
 /* Exact 1-NN with slab pruning: same result (and lowest-index tie rule) as dicp_knn, far fewer pairs.
  * The caller prepares, ONCE per ICP call (targets do not move between iterations):

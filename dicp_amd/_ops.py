@@ -114,8 +114,9 @@ class SweepIndex:
 
     def query_order(self, src, pose, exact=False, w=None, copies=False, reproducible=False, spos_prev=None):
         """Query indices in (approximately) ascending transformed x: keeps a wave's queries neighbours.  Default: a
-        counting sort by x bucket (dicp_query_order) -- or, given spos_prev (the matches of an earlier iteration), by the
-        rank of each query's previous match among the sorted targets; exact=True: a full sort of the x keys.
+        counting sort by the rank bucket of each query's x among the sorted target keys (dicp_query_order; equal-width x
+        buckets for clouds beyond 16384 points or with RANK_ORDER off) -- or, given spos_prev (the matches of an earlier
+        iteration), by the rank of each query's previous match; exact=True: a full sort of the x keys.
         copies=True -> (qorder, src_s, w_s): also the source rows (and the weights w, if given) in that slot order."""
         N, n, _ = src.shape
         lib = _lib.load()
@@ -123,7 +124,8 @@ class SweepIndex:
             if not exact:
                 qorder = torch.empty((N, n), dtype=torch.int32, device=src.device)
                 _lib.check(lib.dicp_query_order(_DT[src.dtype], _p(src), _p(pose), _p(self.brange), self.NBKT, N, n, _p(qorder),
-                                                None, None, None, int(reproducible), _p(spos_prev), self.tgs4.shape[1], _stream()),
+                                                None, None, None, int(reproducible), _p(spos_prev), self.tgs4.shape[1],
+                                                _p(self.tgs4) if RANK_ORDER else None, self.m, _stream()),
                            "dicp_query_order")
                 if copies:      # (the ordering kernel can write them itself, but one block per cloud gathers slowly: 115 vs 16 us)
                     return qorder, _gather_rows_raw(src, qorder), (_gather_rows_raw(w.unsqueeze(-1), qorder).squeeze(-1) if w is not None else None)
@@ -344,6 +346,7 @@ FUSE_ACCUMULATE = int(os.environ.get("DICP_FUSE_ACC", "0"))      # sweep path: a
 SMALL_LOOP = int(os.environ.get("DICP_SMALL_LOOP", "1"))       # small clouds: one block runs a cloud's whole chunk of iterations
 SPOS_ORDER = int(os.environ.get("DICP_SPOS_ORDER", "0"))       # re-order queries by the rank of their previous match instead of their x
                                                               # (density-robust, but measured slower on the benchmark clouds: 0.62 vs 0.58 ms/step)
+RANK_ORDER = int(os.environ.get("DICP_RANK_ORDER", "1"))       # order queries by the rank of their x among the sorted targets (density-robust)
 WINDOW_MIN_ITERS = 3            # fewer windowed iterations than this: all take the atomic backward (see ICPLoop.backward)
 WINDOW_FROM = int(os.environ.get("DICP_WINDOW_FROM", "0"))      # first windowed iteration (measured: even iteration 0 pays, 0.13 vs 0.28 ms)
 HIST_CHUNK_BYTES = 1 << 29      # per-iteration histories (indices, weights) are allocated in slabs of at most this size

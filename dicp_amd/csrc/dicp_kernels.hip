@@ -189,22 +189,32 @@ __global__ __launch_bounds__(BLOCK) void query_keys_kernel(const T* __restrict__
 // per bucket widen a wave's slab by a few rows.  One block per cloud, everything in LDS: ~20x cheaper than a full sort.
 constexpr int QO_THREADS = 1024;
 constexpr int QO_BUCKETS = 2048;
+constexpr int QO_KEYS = 16384;      // sorted target keys kept in LDS for the rank search (64 KiB)
 // QO_STAGE: queries per cloud whose permutation is assembled in LDS (16384 -> 32 KiB, several clouds per CU; 65536 -> 128 KiB)
 template <typename T, int QO_STAGE>
 __global__ __launch_bounds__(QO_THREADS) void query_order_kernel(const T* __restrict__ src, const T* __restrict__ pose,
                                                                  const T* __restrict__ brange, int nbkt_range, int N, int n,
                                                                  int32_t* __restrict__ qorder, const T* __restrict__ w,
                                                                  T* __restrict__ src_s, T* __restrict__ w_s, int reproducible,
-                                                                 const int32_t* __restrict__ spos_prev, int m_pad) {
+                                                                 const int32_t* __restrict__ spos_prev, int m_pad,
+                                                                 const T* __restrict__ skeys, int kstride, int mt) {
     __shared__ int cnt[QO_BUCKETS];
     __shared__ int wsum[QO_THREADS / WAVE];
     __shared__ unsigned short stage[QO_STAGE];              // query ids (< 65536) by slot: the permutation is assembled here
+    __shared__ float lkeys[QO_STAGE <= 16384 ? QO_KEYS : 1];
     const int cloud = blockIdx.x, tid = threadIdx.x;
     for (int b = tid; b < QO_BUCKETS; b += QO_THREADS) cnt[b] = 0;
     T q[4] = {T(1), T(0), T(0), T(0)};
     if (pose) { const T* pp = pose + (size_t)cloud * 12; q[0] = pp[0]; q[1] = pp[1]; q[2] = pp[2]; q[3] = pp[9]; }
     const T xlo = brange[(size_t)cloud * 2];
-    const T scale = brange[(size_t)cloud * 2 + 1] * (T(QO_BUCKETS) / T(nbkt_range));      // buckets per unit x
+    const T tscale = brange[(size_t)cloud * 2 + 1];                                       // table buckets per unit x
+    const T scale = tscale * (T(QO_BUCKETS) / T(nbkt_range));                             // ordering buckets per unit x
+    // rank ordering: the cloud's sorted target x keys, as floats, in LDS (QO_KEYS of them: bigger clouds fall back to x buckets)
+    const bool ranked = QO_STAGE <= 16384 && skeys && !spos_prev && mt <= QO_KEYS;
+    if (ranked) {
+        const T* __restrict__ keys = skeys + (size_t)cloud * m_pad * kstride;
+        for (int j = tid; j < mt; j += QO_THREADS) lkeys[j] = (float)keys[(size_t)j * kstride];
+    }
     auto bucket_of = [&](int i) {
         if (spos_prev) {        // bucket = rank of the query's previous match among the sorted targets: equal-POPULATION buckets,
                                 // whatever the density of the cloud along x (an outlier cannot coarsen them)
@@ -223,7 +233,25 @@ __global__ __launch_bounds__(QO_THREADS) void query_order_kernel(const T* __rest
     constexpr int PER = 16;                                 // register-resident up to PER * QO_THREADS queries per cloud
     int bk[PER], rk[PER];
     const bool small = n <= PER * QO_THREADS;
-    if (small) {
+    if (small && ranked) {
+        // rank of every query's x among the sorted target keys, from the LDS copy of the keys: a full binary search per
+        // query (14 LDS reads; from global memory the same chain of dependent loads took 144 us per launch)
+#pragma unroll 1
+        for (int e = 0; e < PER; ++e) {
+            const int i = e * QO_THREADS + tid;
+            int bb = -1, rr = 0;
+            if (i < n) {
+                const T* p = src + ((size_t)cloud * n + i) * 3;
+                const float x = (float)fma_t(q[0], p[0], fma_t(q[1], p[1], fma_t(q[2], p[2], q[3])));
+                int lo = 0, hi = mt;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (lkeys[mid] < x) lo = mid + 1; else hi = mid; }
+                bb = (int)(((long)lo * (QO_BUCKETS - 1)) / max(mt, 1));
+                rr = atomicAdd(&cnt[bb], 1);
+            }
+#pragma unroll
+            for (int k = 0; k < PER; ++k) if (k == e) { bk[k] = bb; rk[k] = rr; }
+        }
+    } else if (small) {
 #pragma unroll
         for (int e = 0; e < PER; ++e) {
             const int i = e * QO_THREADS + tid;
@@ -686,7 +714,15 @@ __global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? 6 : 
     const T xlo = brange[(size_t)cloud * 2], inv = brange[(size_t)cloud * 2 + 1];
     T fb = (xc - xlo) * inv;
     fb = fb < T(0) ? T(0) : (fb > T(nbkt) ? T(nbkt) : fb);
-    const int start = bucket[(size_t)cloud * (nbkt + 1) + (int)fb];
+    int start = bucket[(size_t)cloud * (nbkt + 1) + (int)fb];
+    {   // an uneven cloud can put thousands of targets into one equal-width table bucket: finish the lower bound there
+        // (wave-uniform; on even clouds a bucket is a fraction of a tile and this costs nothing)
+        int hi = bucket[(size_t)cloud * (nbkt + 1) + min((int)fb + 1, nbkt)];
+        while (hi - start > WAVE) {
+            const int mid = (start + hi) >> 1;
+            if (tg[mid].x < xc) start = mid + 1; else hi = mid;
+        }
+    }
     int tR = min(max(start / WAVE, 0), ntiles - 1), tL = tR - 1;
     if (idle_wave) { tR = ntiles; tL = -1; }
     int visR = tR, visL = tR;                               // tiles [visL, visR) have been scored
@@ -2119,14 +2155,15 @@ int dicp_query_keys(int dtype, const void* src, const void* pose, int N, int n, 
 }
 
 int dicp_query_order(int dtype, const void* src, const void* pose, const void* brange, int nbkt, int N, int n, int32_t* qorder,
-                     const void* w, void* src_s, void* w_s, int reproducible, const int32_t* spos_prev, int m_pad, void* stream) {
+                     const void* w, void* src_s, void* w_s, int reproducible, const int32_t* spos_prev, int m_pad,
+                     const void* tgs4, int m, void* stream) {
     if (!src || !brange || !qorder || (w_s && !w)) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
-    if (N <= 0 || n <= 0 || nbkt <= 0 || (spos_prev && m_pad <= 0)) return DICP_ERR_SHAPE;
+    if (N <= 0 || n <= 0 || nbkt <= 0 || ((spos_prev || tgs4) && m_pad <= 0) || (tgs4 && (m <= 0 || m > m_pad))) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     begin_launch();
 #define DICP_QO(T, S) query_order_kernel<T, S><<<N, QO_THREADS, 0, st>>>((const T*)src, (const T*)pose, (const T*)brange, nbkt, N, n, qorder, \
-        (const T*)w, (T*)src_s, (T*)w_s, reproducible, spos_prev, m_pad)
+        (const T*)w, (T*)src_s, (T*)w_s, reproducible, spos_prev, m_pad, (const T*)tgs4, 4, m)
     if (dtype == DICP_F32) { if (n <= 16384) DICP_QO(float, 16384); else DICP_QO(float, 65536); }
     else                   { if (n <= 16384) DICP_QO(double, 16384); else DICP_QO(double, 65536); }
 #undef DICP_QO

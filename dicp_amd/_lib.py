@@ -64,7 +64,7 @@ _SIGNATURES = {
     "dicp_loop_partial_blocks": ([i32, i32], ctypes.c_int),
     "dicp_knn_sweep_accumulate": ([i32, ctypes.POINTER(WeightParams), vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32,
                                    vp, vp, vp, i32, vp, vp, i64, vp], ctypes.c_int),
-    "dicp_query_order": ([i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, i32, vp, i32, vp], ctypes.c_int),
+    "dicp_query_order": ([i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, vp], ctypes.c_int),
     "dicp_query_keys": ([i32, vp, vp, i32, i32, vp, vp], ctypes.c_int),
     "dicp_loop_init": ([i32, vp, vp, ctypes.c_double, i32, i32, i32, vp, vp, vp, vp], ctypes.c_int),
     "dicp_loop_finish": ([i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp], ctypes.c_int),

@@ -97,6 +97,7 @@ class SweepIndex:
         key = torch.full((N, m_pad), torch.finfo(dt).max, dtype=dt, device=dev)       # pad slots sort last
         key[:, :m] = tgt[:, :, 0]
         keys, order = torch.sort(key, dim=1, stable=True)
+        self.keys = keys                                         # sorted x keys (N,m_pad): the rank search of query_order reads them
         self.tgs4 = torch.empty((N, m_pad, 4), dtype=dt, device=dev)
         self.tperm = torch.empty((N, m_pad), dtype=torch.int32, device=dev)
         self.bucket = torch.empty((N, self.NBKT + 1), dtype=torch.int32, device=dev)
@@ -125,7 +126,7 @@ class SweepIndex:
                 qorder = torch.empty((N, n), dtype=torch.int32, device=src.device)
                 _lib.check(lib.dicp_query_order(_DT[src.dtype], _p(src), _p(pose), _p(self.brange), self.NBKT, N, n, _p(qorder),
                                                 None, None, None, int(reproducible), _p(spos_prev), self.tgs4.shape[1],
-                                                _p(self.tgs4) if RANK_ORDER else None, self.m, _stream()),
+                                                _p(self.keys) if RANK_ORDER else None, _p(self.bucket), self.m, _stream()),
                            "dicp_query_order")
                 if copies:      # (the ordering kernel can write them itself, but one block per cloud gathers slowly: 115 vs 16 us)
                     return qorder, _gather_rows_raw(src, qorder), (_gather_rows_raw(w.unsqueeze(-1), qorder).squeeze(-1) if w is not None else None)

@@ -190,6 +190,7 @@ __global__ __launch_bounds__(BLOCK) void query_keys_kernel(const T* __restrict__
 constexpr int QO_THREADS = 1024;
 constexpr int QO_BUCKETS = 2048;
 constexpr int QO_KEYS = 16384;      // sorted target keys kept in LDS for the rank search (64 KiB)
+constexpr int QO_TABLE = 1024;      // ... and the coarse lower-bound table that brackets it
 // QO_STAGE: queries per cloud whose permutation is assembled in LDS (16384 -> 32 KiB, several clouds per CU; 65536 -> 128 KiB)
 template <typename T, int QO_STAGE>
 __global__ __launch_bounds__(QO_THREADS) void query_order_kernel(const T* __restrict__ src, const T* __restrict__ pose,
@@ -197,11 +198,12 @@ __global__ __launch_bounds__(QO_THREADS) void query_order_kernel(const T* __rest
                                                                  int32_t* __restrict__ qorder, const T* __restrict__ w,
                                                                  T* __restrict__ src_s, T* __restrict__ w_s, int reproducible,
                                                                  const int32_t* __restrict__ spos_prev, int m_pad,
-                                                                 const T* __restrict__ skeys, int kstride, int mt) {
+                                                                 const T* __restrict__ skeys, int kstride, int mt, const int32_t* __restrict__ table) {
     __shared__ int cnt[QO_BUCKETS];
     __shared__ int wsum[QO_THREADS / WAVE];
     __shared__ unsigned short stage[QO_STAGE];              // query ids (< 65536) by slot: the permutation is assembled here
     __shared__ float lkeys[QO_STAGE <= 16384 ? QO_KEYS : 1];
+    __shared__ int ltab[QO_STAGE <= 16384 ? QO_TABLE + 1 : 1];
     const int cloud = blockIdx.x, tid = threadIdx.x;
     for (int b = tid; b < QO_BUCKETS; b += QO_THREADS) cnt[b] = 0;
     T q[4] = {T(1), T(0), T(0), T(0)};
@@ -210,10 +212,11 @@ __global__ __launch_bounds__(QO_THREADS) void query_order_kernel(const T* __rest
     const T tscale = brange[(size_t)cloud * 2 + 1];                                       // table buckets per unit x
     const T scale = tscale * (T(QO_BUCKETS) / T(nbkt_range));                             // ordering buckets per unit x
     // rank ordering: the cloud's sorted target x keys, as floats, in LDS (QO_KEYS of them: bigger clouds fall back to x buckets)
-    const bool ranked = QO_STAGE <= 16384 && skeys && !spos_prev && mt <= QO_KEYS;
+    const bool ranked = QO_STAGE <= 16384 && skeys && table && !spos_prev && mt <= QO_KEYS && nbkt_range <= QO_TABLE;
     if (ranked) {
         const T* __restrict__ keys = skeys + (size_t)cloud * m_pad * kstride;
         for (int j = tid; j < mt; j += QO_THREADS) lkeys[j] = (float)keys[(size_t)j * kstride];
+        for (int j = tid; j <= nbkt_range; j += QO_THREADS) ltab[j] = table[(size_t)cloud * (nbkt_range + 1) + j];
     }
     auto bucket_of = [&](int i) {
         if (spos_prev) {        // bucket = rank of the query's previous match among the sorted targets: equal-POPULATION buckets,
@@ -243,7 +246,12 @@ __global__ __launch_bounds__(QO_THREADS) void query_order_kernel(const T* __rest
             if (i < n) {
                 const T* p = src + ((size_t)cloud * n + i) * 3;
                 const float x = (float)fma_t(q[0], p[0], fma_t(q[1], p[1], fma_t(q[2], p[2], q[3])));
-                int lo = 0, hi = mt;
+                // the coarse table (also in LDS) brackets the lower bound: ~4 steps on an even cloud instead of 14
+                float f = (x - (float)xlo) * (float)tscale;
+                f = f > 0.f ? (f < (float)nbkt_range ? f : (float)nbkt_range) : 0.f;
+                const int tb = (int)f;
+                int lo = ltab[tb], hi = ltab[min(tb + 1, nbkt_range)];
+                if (!(lo <= hi) || (lo > 0 && !(lkeys[lo - 1] < x)) || (hi < mt && lkeys[hi] < x)) { lo = 0; hi = mt; }  // rounding at an edge
                 while (lo < hi) { const int mid = (lo + hi) >> 1; if (lkeys[mid] < x) lo = mid + 1; else hi = mid; }
                 bb = (int)(((long)lo * (QO_BUCKETS - 1)) / max(mt, 1));
                 rr = atomicAdd(&cnt[bb], 1);
@@ -2156,14 +2164,14 @@ int dicp_query_keys(int dtype, const void* src, const void* pose, int N, int n, 
 
 int dicp_query_order(int dtype, const void* src, const void* pose, const void* brange, int nbkt, int N, int n, int32_t* qorder,
                      const void* w, void* src_s, void* w_s, int reproducible, const int32_t* spos_prev, int m_pad,
-                     const void* tgs4, int m, void* stream) {
+                     const void* skeys, const int32_t* bucket, int m, void* stream) {
     if (!src || !brange || !qorder || (w_s && !w)) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
-    if (N <= 0 || n <= 0 || nbkt <= 0 || ((spos_prev || tgs4) && m_pad <= 0) || (tgs4 && (m <= 0 || m > m_pad))) return DICP_ERR_SHAPE;
+    if (N <= 0 || n <= 0 || nbkt <= 0 || ((spos_prev || skeys) && m_pad <= 0) || (skeys && (m <= 0 || m > m_pad))) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     begin_launch();
 #define DICP_QO(T, S) query_order_kernel<T, S><<<N, QO_THREADS, 0, st>>>((const T*)src, (const T*)pose, (const T*)brange, nbkt, N, n, qorder, \
-        (const T*)w, (T*)src_s, (T*)w_s, reproducible, spos_prev, m_pad, (const T*)tgs4, 4, m)
+        (const T*)w, (T*)src_s, (T*)w_s, reproducible, spos_prev, m_pad, (const T*)skeys, 1, m, bucket)
     if (dtype == DICP_F32) { if (n <= 16384) DICP_QO(float, 16384); else DICP_QO(float, 65536); }
     else                   { if (n <= 16384) DICP_QO(double, 16384); else DICP_QO(double, 65536); }
 #undef DICP_QO

@@ -87,14 +87,14 @@ int dicp_query_keys(int dtype, const void* src, const void* pose, int N, int n, 
  * members are put in index order, so the permutation is the same on every run (needed only when sums are taken in
  * this order, i.e. by dicp_knn_sweep_accumulate).  spos_prev (N,n), optional: the queries' matches of an earlier iteration
  * (dicp_knn_sweep's spos): the bucket is then the match's rank among the m_pad sorted targets instead of the query's x --
- * equal-population buckets, robust against uneven density along x (but one pose late).  tgs4 (from dicp_sweep_build; m
- * real targets), optional: the bucket is the RANK of the query's x among the sorted target keys under the given pose (a
+ * equal-population buckets, robust against uneven density along x (but one pose late).  keys_sorted (N,m_pad; the
+ * sorted keys dicp_sweep_build was given) + bucket (from dicp_sweep_build; m real targets), optional: the bucket is the RANK of the query's x among the sorted target keys under the given pose (a
  * binary search in an LDS copy of the keys; clouds of up to 16384 queries and targets, bigger ones keep the x buckets):
  * equal-population buckets without the lag -- what the ICP loop uses (0.58 vs 1.50 ms/iteration on clouds with a dense
  * blob and one far outlier, profiles/r01_uneven_clouds.txt). */
 int dicp_query_order(int dtype, const void* src, const void* pose, const void* brange, int nbkt, int N, int n, int32_t* qorder,
                      const void* w, void* src_s, void* w_s, int reproducible, const int32_t* spos_prev, int m_pad,
-                     const void* tgs4, int m, void* stream);
+                     const void* keys_sorted, const int32_t* bucket, int m, void* stream);
 
 /* Exact 1-NN with slab pruning: same result (and lowest-index tie rule) as dicp_knn, far fewer pairs.
  * The caller prepares, ONCE per ICP call (targets do not move between iterations):

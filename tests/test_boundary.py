@@ -47,6 +47,59 @@ def test_struct_layouts_match_header(lib):
     assert fields == expect
 
 
+def test_loop_buffers_layout_matches_header(lib):
+    """dicp_loop_buffers: the ctypes mirror lists the header's fields in the header's order (a mismatch would hand the
+    library a pose history where it expects an index history)."""
+    hdr = open(os.path.join(ROOT, "include", "dicp_hip.h")).read()
+    body = hdr[hdr.index("typedef struct dicp_loop_buffers {"):hdr.index("} dicp_loop_buffers;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        names = decl.replace("*", " ").split()
+        # "int64_t w_iter, w_stride" declares two fields
+        first = names[-1] if "," not in decl else None
+        if first is None:
+            head, *more = [x.strip() for x in decl.split(",")]
+            fields.append(head.replace("*", " ").split()[-1])
+            fields.extend(x.replace("*", " ").split()[-1] for x in more)
+        else:
+            fields.append(first)
+    assert [f[0] for f in _lib.LoopBuffers._fields_] == fields
+
+
+def test_new_entry_points_reject_bad_arguments(lib):
+    """Set-up / windowed-backward entry points: null pointers, bad shapes and dtypes are rejected before any launch."""
+    one, P = ctypes.c_void_p(64), _lib.WeightParams(mode=1, loss=0)
+    assert [lib.dicp_window_blocks(0, n, 16384) for n in (0, 1, 16384)] == [0, 1, 16]
+    assert lib.dicp_window_rows(0) == 1536 and lib.dicp_window_rows(1) == 768
+    assert lib.dicp_sweep_partials(0, 16384, 8) == 86 and lib.dicp_sweep_partials(0, 16384, 2) == 128 and lib.dicp_sweep_partials(0, 16384, 16) == 0
+    assert lib.dicp_loop_partial_blocks(0, 16384) == 256
+    assert lib.dicp_sweep_build(0, None, 3, one, one, 1, 1, 64, 1024, one, one, one, one, None, None) == 1
+    assert lib.dicp_sweep_build(0, one, 4, one, one, 1, 1, 64, 1024, one, one, one, one, None, None) == 2
+    assert lib.dicp_sweep_build(0, one, 3, one, one, 1, 1, 64, 1024, ctypes.c_void_p(8), one, one, one, None, None) == 5
+    assert lib.dicp_query_order(0, one, None, None, 1024, 1, 1, one, None, None, None, 0, None, 0, None, None, 0, None) == 1
+    assert lib.dicp_query_order(9, one, None, one, 1024, 1, 1, one, None, None, None, 0, None, 0, None, None, 0, None) == 3
+    assert lib.dicp_query_order(0, one, None, one, 1024, 1, 1, one, None, None, None, 0, None, 0, one, one, 0, None) == 2      # keys without m
+    assert lib.dicp_loop_init(0, one, one, 0.01, 2, 1, 1, one, one, one, None) == 2
+    assert lib.dicp_loop_finish(0, one, one, one, one, 1, 1, None, one, one, None) == 1
+    assert lib.dicp_accumulate_bwd_window(0, ctypes.byref(P), one, one, 6, None, one, None, one, one, None, one, one, 1, 1, 64,
+                                          one, None, None, None, one, None) == 1
+    assert lib.dicp_accumulate_bwd_window(0, ctypes.byref(P), one, one, 6, one, one, None, one, one, None, one, one, 1, 1, 63,
+                                          one, None, None, None, one, None) == 2
+    assert lib.dicp_accumulate_bwd_window(0, ctypes.byref(P), one, one, 6, one, one, None, one, one, None, one, one, 1, 1, 64,
+                                          one, one, None, None, one, None) == 1      # a slab needs the side buffer too
+    assert lib.dicp_window_reduce(0, one, one, None, one, None, 1, 1, 1, 64, 5, one, 6, 0, None) == 2
+    assert lib.dicp_window_reduce(0, one, one, None, one, None, 1, 1, 1, 64, 6, one, 3, 0, None) == 2
+    assert lib.dicp_permute_add_rows(0, one, one, 1, 2, 1, 2, 3, 3, one, 4, 3, None) == 2
+    assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, 1, 1, 1, 64, one, None, None, 99, None) == 4
+    assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, 1, 1, 1, 64, one, None, None, 8 | 0x100, None) == 1  # sorted rows need the order
+    assert lib.dicp_knn_sweep_accumulate(0, ctypes.byref(P), one, None, one, one, None, one, one, 1024, one, 6, one, None, 1, 1, 1, 64,
+                                         one, None, None, 16, one, None, 0, None) == 4      # no fused form of the scan kernel
+
+
 def test_sizes_and_argument_checks(lib):
     assert lib.dicp_abi_version() == 1
     assert [lib.dicp_padded_targets(m) for m in (0, 1, 64, 65, 129)] == [0, 64, 64, 128, 192]

@@ -162,7 +162,7 @@ def main():
     icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=max(W, 1), tolerance=1e-12)
     icp.const_iter = True
     icp.knn_variant = {"auto": 0, "sweep": 3, "valu": 1, "mfma": 2}[args.knn]
-    brute = args.knn in ("valu", "mfma")
+    brute = args.knn in ("valu", "mfma")      # (auto also runs brute force when the clouds are small: settled after the timed call)
     if W > 0:
         run_call(icp, src, tgt, T0, cw)                                  # W untimed warm-up steps
     icp.max_iterations = K
@@ -240,6 +240,10 @@ def main():
         torch.cuda.synchronize()
         bf.append(a.elapsed_time(b))
     bf_ms = sorted(bf)[1]
+    # knn=auto takes the brute-force kernel for small clouds (no sorted-sweep statistics then)
+    from dicp_amd._ops import auto_knn_kind
+    if args.knn == "auto" and auto_knn_kind(B, n, m) != L.KNN_SWEEP:
+        brute = True
     pairs_scored = None if brute else float(icp.knn_stats["knn_pairs"].sum().item()) / K      # per launch
 
     if rank == 0:
@@ -252,7 +256,7 @@ def main():
         bwd_traffic, bwd_src = pmc_traffic(bwd_kernel, B, n)
         bf_traffic, bf_src = pmc_traffic("knn_valu", B, n)
         line = {
-            "metric": "ICP cloud-iterations/sec (fwd+bwd), B=256x16384-pt clouds per GPU",
+            "metric": "ICP cloud-iterations/sec (fwd+bwd), B=%dx%d-pt clouds per GPU" % (B, n),
             "value": world * B * K / elapsed,
             "unit": "cloud-iterations/s",
             "n_gpus": world, "steps": K, "warmup": W,

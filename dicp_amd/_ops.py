@@ -584,7 +584,7 @@ class ICPLoop(torch.autograd.Function):
                 base = j * kc
                 LB = _lib.LoopBuffers(
                     src=_p(src_s) if w_form else _p(src), tgt=_p(tgt_s) if w_form else _p(tgt),
-                    w_init=_p(w_s) if w_form else _p(w0c), c=c, K=Kmax, knn_variant=kind, m_pad=m_pad, idx_per_iter=1,
+                    w_init=_p(w_s) if w_form else _p(w0c), c=c, K=Kmax, knn_variant=kind | ((0 if SMALL_LOOP else 1) << 25), m_pad=m_pad, idx_per_iter=1,
                     qorder=_p(qo) if w_form else None,
                     spos=ctypes.c_void_p(spos_slabs[j].data_ptr() - base * N * n * 4) if w_form else None,
                     spos_ref=_p(spos_ref) if w_form else None, gts_far=_p(gfar) if w_form else None,

@@ -1637,6 +1637,91 @@ __global__ __launch_bounds__(WAVE) void step_bwd_kernel(const double* __restrict
     if (tid < 12) gpose_out[(size_t)cloud * 12 + tid] = sgo[tid];
 }
 
+// The reverse sweep of small clouds: what icp_small_forward_kernel is to the forward.  One block owns a cloud for a whole
+// chunk of iterations, in reverse: step_bwd (cotangent of the pose -> cotangents of the normal equations, first thread),
+// accumulate_bwd (per-point adjoint; source / weight gradients straight to memory, the block is their only writer; target
+// gradients into an LDS copy of the cloud's rows, added to memory once at the end), block reduction of the pose
+// cotangent sums, next iteration.  Two launches per iteration become one launch per chunk.
+template <typename T, int MODE>
+__global__ __launch_bounds__(BLOCK) void icp_small_backward_kernel(WeightParams P, dicp_loop_buffers B, int N, int n, int m, int dim,
+                                                                   const double* __restrict__ gpose_in, double* __restrict__ gpose_out,
+                                                                   int have_partials, T* __restrict__ gsrc, T* __restrict__ gtgt,
+                                                                   T* __restrict__ gw, T* __restrict__ bwd_partials, int nblk, int k0, int k1) {
+    constexpr int CV = (MODE == MODE_PT2PL) ? 6 : 3;
+    extern __shared__ __align__(16) unsigned char small_bwd_lds[];
+    T* gt = reinterpret_cast<T*>(small_bwd_lds);            // (m, CV) target-gradient rows of this cloud
+    __shared__ double sg[NBWD_PAD], sC[9], sd[6], sAreg[36], sGs[36], sGb[6], sgo[12], spart[NBWD_PAD];
+    __shared__ T red[(BLOCK / WAVE) * NBWD_PAD];
+    __shared__ T part[NBWD_PAD];
+    const int cloud = blockIdx.x, tid = threadIdx.x, c = B.c;
+    if (gtgt)
+        for (int e = tid; e < m * CV; e += BLOCK) gt[e] = T(0);
+    if (tid < 12) sgo[tid] = gpose_in[(size_t)cloud * 12 + tid];
+    if (tid < NBWD_PAD) {
+        double s = 0.0;
+        if (have_partials && tid < NBWD)
+            for (int b = 0; b < nblk; ++b) s += (double)bwd_partials[((size_t)cloud * nblk + b) * NBWD_PAD + tid];
+        spart[tid] = s;
+        part[tid] = T(0);
+    }
+    const T* __restrict__ src = (const T*)B.src + (size_t)cloud * n * 3;
+    const T* __restrict__ tgt = (const T*)B.tgt + (size_t)cloud * m * c;
+    const T* __restrict__ w_init = (const T*)B.w_init + (size_t)cloud * n;
+    __syncthreads();
+    for (int k = k1 - 1; k >= k0; --k) {
+        const T* pose_k = (const T*)B.poses + (size_t)k * N * 12;
+        if (tid < NBWD) sg[tid] = spart[tid] + sgo[tid];
+        if (tid < 9) sC[tid] = (double)pose_k[(size_t)cloud * 12 + tid];
+        if (tid < 6) sd[tid] = (double)((const T*)B.deltas)[(size_t)cloud * B.K * 6 + (size_t)k * 6 + tid];
+        if (tid < 36) sAreg[tid] = B.areg[((size_t)k * N + cloud) * 36 + tid];
+        __syncthreads();
+        if (tid == 0) step_backward(sg, sg + 9, dim, sC, sd, sAreg, sGs, sGb, sgo, sgo + 9);
+        __syncthreads();
+        T C[9], r[3], Gs[36], Gb[6];
+        load_pose(pose_k, cloud, C, r);
+#pragma unroll
+        for (int a = 0; a < 36; ++a) Gs[a] = (T)sGs[a];     // rounded to T like the gs / gb buffers of the multi-kernel path
+#pragma unroll
+        for (int a = 0; a < 6; ++a) Gb[a] = (T)sGb[a];
+        const T live = ((const T*)B.alive)[(size_t)k * N + cloud];
+        const int32_t* __restrict__ idx_k = B.idx + (size_t)k * N * n + (size_t)cloud * n;
+        T acc[NBWD];
+#pragma unroll
+        for (int a = 0; a < NBWD; ++a) acc[a] = T(0);
+        for (int i = tid; i < n; i += BLOCK) {
+            const T p[3] = {src[i * 3], src[i * 3 + 1], src[i * 3 + 2]};
+            const int j = min(max(idx_k[i], 0), m - 1);
+            const T* yp = tgt + (size_t)j * c;
+            const T y[3] = {yp[0], yp[1], yp[2]};
+            T nrm[3] = {T(0), T(0), T(0)};
+            if (MODE == MODE_PT2PL) { nrm[0] = yp[3]; nrm[1] = yp[4]; nrm[2] = yp[5]; }
+            T gp[3], gy[3], gn[3], gw0;
+            point_backward<T, MODE>(P, C, r, p, y, nrm, w_init[i] * live, Gs, Gb, gp, gy, gn, gw0, acc, acc + 9);
+            T* gsp = gsrc + ((size_t)cloud * n + i) * 3;
+            gsp[0] += gp[0]; gsp[1] += gp[1]; gsp[2] += gp[2];
+            if (gw) gw[(size_t)cloud * n + i] += gw0 * live;
+            if (gtgt) {
+                T* row = gt + j * CV;
+                atomicAdd(&row[0], gy[0]); atomicAdd(&row[1], gy[1]); atomicAdd(&row[2], gy[2]);
+                if (MODE == MODE_PT2PL) { atomicAdd(&row[3], gn[0]); atomicAdd(&row[4], gn[1]); atomicAdd(&row[5], gn[2]); }
+            }
+        }
+        block_reduce_store<T, NBWD, NBWD_PAD>(acc, part, red);
+        __syncthreads();
+        if (tid < NBWD_PAD) spart[tid] = (double)part[tid];
+        __syncthreads();
+    }
+    if (tid < 12) gpose_out[(size_t)cloud * 12 + tid] = sgo[tid];
+    // the last accumulate_bwd's sums stay in bwd_partials (block 0 of nblk; the others are zero) for the caller / next chunk
+    for (int e = tid; e < nblk * NBWD_PAD; e += BLOCK)
+        bwd_partials[(size_t)cloud * nblk * NBWD_PAD + e] = e < NBWD_PAD ? part[e] : T(0);
+    if (gtgt)
+        for (int e = tid; e < m * CV; e += BLOCK) {
+            const int j = e / CV, col = e - j * CV;
+            gtgt[((size_t)cloud * m + j) * c + col] += gt[e];
+        }
+}
+
 // ------------------------------------------------------------- Gumbel-softmax soft kNN
 // nn.__diff_nn_gumbel (nn.py:43-70): out_i = sum_j softmax_j((-|x_i - y_j|^2 + g_ij) / tau) * y_j with
 // g = -log(-log(U + eps) + eps).  The reference materialises (N,n,m) distances, noise and probabilities; here
@@ -2694,6 +2779,22 @@ int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_
     const size_t es = dtype == DICP_F32 ? 4 : 8;
     hipStream_t st = (hipStream_t)stream;
     const int nblk = B->spos ? dicp_window_blocks(dtype, n, B->m_pad) : dicp_accumulate_blocks(n);
+    {   // small clouds (atomic form only): the whole chunk is ONE launch, one block per cloud
+        const size_t lds = (size_t)m * (prm->mode == DICP_PT2PL ? 6 : 3) * es;
+        if (!B->spos && k1 > k0 && B->m_pad > 0 && lds <= 40 * 1024 &&
+            small_loop_eligible(dtype, B->knn_variant & 0xff, B->knn_variant, n, B->m_pad)) {
+            if (const int e = check_params(prm, B->c)) return e;
+            begin_launch();
+            const WeightParams P = to_params(prm);
+            double* dst = ((k1 - k0) & 1) ? gpose_tmp : gpose;        // where the alternating buffers would have left it
+#define DICP_SMALLB(T, M) icp_small_backward_kernel<T, M><<<N, BLOCK, lds, st>>>(P, *B, N, n, m, dim, gpose, dst, have_partials, \
+                (T*)gsrc, (T*)gtgt, (T*)gw, (T*)bwd_partials, nblk, k0, k1)
+            if (dtype == DICP_F32) { if (P.mode == MODE_PT2PL) DICP_SMALLB(float, MODE_PT2PL); else DICP_SMALLB(float, MODE_PT2PT); }
+            else                   { if (P.mode == MODE_PT2PL) DICP_SMALLB(double, MODE_PT2PL); else DICP_SMALLB(double, MODE_PT2PT); }
+#undef DICP_SMALLB
+            return launch_status();
+        }
+    }
     double* gin = gpose;
     double* gout = gpose_tmp;
     for (int k = k1 - 1; k >= k0; --k) {

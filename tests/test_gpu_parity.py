@@ -683,6 +683,37 @@ def test_icp_sweep_equals_brute_on_synthetic(window):
         np.testing.assert_allclose(npy(outs[0][k]), npy(outs[1][k]), rtol=0, atol=2e-6 * max(1.0, float(outs[0][k].abs().max())))
 
 
+@pytest.mark.parametrize("dtype,icp_type,N,n,m,const_iter", [
+    (torch.float64, "pt2pl", 3, 65, 65, True), (torch.float32, "pt2pt", 7, 200, 150, True),
+    (torch.float64, "pt2pl", 2, 300, 333, False), (torch.float32, "pt2pl", 5, 128, 1000, False)])
+def test_small_cloud_kernels_equal_multi_kernel_loop(dtype, icp_type, N, n, m, const_iter, monkeypatch):
+    """icp_small_forward_kernel / icp_small_backward_kernel (one block per cloud, a whole chunk of iterations per launch)
+    against the multi-kernel loop: same matches, same per-point arithmetic, same block reduction -> same results to
+    rounding, in const-iteration mode and with the host's convergence checks (several chunks) alike."""
+    src, tgt = make_pairs(N, n, m, seed=21, dtype=dtype)
+    wgt = torch.rand((N, n), generator=torch.Generator().manual_seed(2), dtype=torch.float64).to(dtype) * 0.5 + 0.5
+    outs = []
+    for small in (0, 1):
+        monkeypatch.setattr(_ops, "SMALL_LOOP", small)
+        sd, td, wd = src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True), wgt.to(DEV).requires_grad_(True)
+        T0 = torch.eye(4, dtype=dtype, device=DEV).repeat(N, 1, 1).requires_grad_(True)
+        icp = ICP(icp_type=icp_type, differentiable=True, max_iterations=9, tolerance=1e-12 if const_iter else (1e-7 if dtype == torch.float64 else 1e-4))
+        icp.const_iter = const_iter
+        icp.sync_every = 2
+        out = icp.icp(sd, td if icp_type == "pt2pl" else td[:, :, :3], T0, weight=wd, trim_dist=4.0, loss_fn={"name": "huber", "metric": 0.7})
+        (out["T"][:, :3].sum() + out["pc"].mean()).backward()
+        outs.append((out, sd.grad, td.grad, wd.grad, T0.grad))
+    a, b = outs
+    f64 = dtype == torch.float64
+    assert a[0]["deltas"].shape == b[0]["deltas"].shape
+    assert torch.equal(a[0]["stats"]["iterations"], b[0]["stats"]["iterations"]) and torch.equal(a[0]["stats"]["converged"], b[0]["stats"]["converged"])
+    for key in ("T", "deltas", "weights", "costs"):
+        np.testing.assert_allclose(npy(a[0][key]), npy(b[0][key]), rtol=0, atol=(1e-11 if f64 else 5e-6) * max(1.0, float(a[0][key].detach().abs().max())))
+    for k in (1, 2, 3, 4):
+        assert torch.isfinite(b[k]).all()
+        np.testing.assert_allclose(npy(a[k]), npy(b[k]), rtol=0, atol=(1e-9 if f64 else 2e-4) * max(1.0, float(a[k].abs().max())))
+
+
 @pytest.mark.parametrize("icp_type", ["pt2pl", "pt2pt"])
 def test_fused_search_accumulate_equals_separate_kernels(icp_type, monkeypatch):
     """dicp_knn_sweep_accumulate (accumulate in the search kernel's epilogue, per-wave partials) against the separate

@@ -3,15 +3,27 @@
 //
 // Kernels (one section each):
 //   pack_kernel            target rows -> [x,y,z,0.5|y|^2] (once per ICP call)
-//   knn_valu_kernel        fused transform + brute-force 1-NN, VALU FMA form, LDS-tiled targets
+//   sweep_rows / sweep_buckets / query_order / query_keys / loop_init / loop_finish
+//                          per-call set-up of the sorted-sweep search and of the loop state (everything after torch.sort)
+//   knn_valu_kernel        fused transform + brute-force 1-NN, VALU FMA form, LDS-tiled targets (+ packed-FMA variant)
 //   knn_mfma_kernel        same contraction on the f32 matrix cores (v_mfma_f32_16x16x4_f32)
-//   gather / scatter       nn.find_nn's row gather and its backward
+//   knn_sweep_kernel       exact 1-NN with slab pruning over x-sorted targets (the ICP default for big clouds);
+//                          optionally goes on with the accumulate pass for its matches (FusedAcc)
+//   knn_scan_kernel        the same search as a per-lane scan (narrow slabs; selectable)
+//   gather / scatter / permute_add
+//                          row-indexed copies (nn.find_nn's gather and its backward; sorted copies and their undoing)
 //   accumulate_kernel      residual/weights/Jacobian/normal-equation sums, per-block partials
-//   step_kernel            per-cloud reduce + 6x6 solve + pose update + loop bookkeeping
-//   accumulate_bwd_kernel  adjoint of accumulate_kernel (recompute from idx and pose)
-//   accumulate_bwd_window  the same adjoint in sorted space (sweep path): LDS window + full-line atomic flush
+//   step_kernel            per-cloud reduce + 6x6 solve + pose update + loop bookkeeping (step_body)
+//   icp_small_forward / icp_small_backward
+//                          small clouds: one block runs a cloud's whole chunk of iterations, forward and reverse
+//   accumulate_bwd_kernel  adjoint of accumulate_kernel (recompute from idx and pose), row-coalesced float atomics
+//   accumulate_bwd_window  the same adjoint in sorted space (sweep path): per-block LDS windows with per-row lists,
+//                          per-block slabs, no float atomics on the common path; window_reduce sums the slabs
 //   step_bwd_kernel        adjoint of step_kernel
-//   loss_weight kernels    loss.get_weight for direct users of the class
+//   gumbel_* kernels       Gumbel-softmax soft correspondence (online softmax) and its two-pass backward
+//   kabsch_* kernels       closed-form SVD point-to-point step and its adjoint
+//   transform / loss_weight kernels
+//                          pc = C p + r and loss.get_weight for direct users of the classes
 //
 // Written for 64-wide wavefronts and 8 XCDs: block ids are dealt so that all blocks of
 // one cloud land on one XCD (they share that cloud's targets in its L2).

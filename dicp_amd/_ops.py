@@ -94,12 +94,18 @@ class SweepIndex:
         lib = _lib.load()
         dev, dt = tgt.device, tgt.dtype
         m_pad = lib.dicp_padded_targets(m)
-        key = torch.full((N, m_pad), torch.finfo(dt).max, dtype=dt, device=dev)       # pad slots sort last
-        key[:, :m] = tgt[:, :, 0]
-        keys, order = torch.sort(key, dim=1, stable=True)
-        self.keys = keys                                         # sorted x keys (N,m_pad): the rank search of query_order reads them
         self.tgs4 = torch.empty((N, m_pad, 4), dtype=dt, device=dev)
         self.tperm = torch.empty((N, m_pad), dtype=torch.int32, device=dev)
+        if dt == torch.float32 and m_pad <= 16384 and NATIVE_SORT:
+            # the stable sort of the x keys in LDS (dicp_sweep_sort): same keys and permutation as torch.sort(stable=True)
+            keys, order = torch.empty((N, m_pad), dtype=dt, device=dev), None
+            with torch.cuda.device(dev):
+                _lib.check(lib.dicp_sweep_sort(_DT[dt], _p(tgt), c, N, m, m_pad, _p(keys), _p(self.tperm), _stream()), "dicp_sweep_sort")
+        else:
+            key = torch.full((N, m_pad), torch.finfo(dt).max, dtype=dt, device=dev)   # pad slots sort last
+            key[:, :m] = tgt[:, :, 0]
+            keys, order = torch.sort(key, dim=1, stable=True)
+        self.keys = keys                                         # sorted x keys (N,m_pad): the rank search of query_order reads them
         self.bucket = torch.empty((N, self.NBKT + 1), dtype=torch.int32, device=dev)
         self.brange = torch.empty((N, 2), dtype=dt, device=dev)
         self.tgt_s = torch.empty((N, m_pad, c), dtype=dt, device=dev) if sorted_rows else None
@@ -348,6 +354,7 @@ SMALL_LOOP = int(os.environ.get("DICP_SMALL_LOOP", "1"))       # small clouds: o
 SPOS_ORDER = int(os.environ.get("DICP_SPOS_ORDER", "0"))       # re-order queries by the rank of their previous match instead of their x
                                                               # (density-robust, but measured slower on the benchmark clouds: 0.62 vs 0.58 ms/step)
 RANK_ORDER = int(os.environ.get("DICP_RANK_ORDER", "1"))       # order queries by the rank of their x among the sorted targets (density-robust)
+NATIVE_SORT = int(os.environ.get("DICP_NATIVE_SORT", "1"))     # float32 clouds of up to 16384 targets: the key sort in LDS instead of torch.sort
 WINDOW_MIN_ITERS = 3            # fewer windowed iterations than this: all take the atomic backward (see ICPLoop.backward)
 WINDOW_FROM = int(os.environ.get("DICP_WINDOW_FROM", "0"))      # first windowed iteration (measured: even iteration 0 pays, 0.13 vs 0.28 ms)
 HIST_CHUNK_BYTES = 1 << 29      # per-iteration histories (indices, weights) are allocated in slabs of at most this size

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(BLOCK) void pack_kernel(const T* __restrict__ tgt, 
 // Everything of the sorted-sweep search structure that follows the sort itself (the sort is torch.sort: plumbing):
 // sorted packed rows, the permutation as int32, and the coarse bucket table of lower-bound positions.
 template <typename T>
-__global__ __launch_bounds__(BLOCK) void sweep_rows_kernel(const T* __restrict__ tgt, const int64_t* __restrict__ order, int N, int m, int c,
+__global__ __launch_bounds__(BLOCK) void sweep_rows_kernel(const T* __restrict__ tgt, const int64_t* __restrict__ order /* NULL: tperm holds it */, int N, int m, int c,
                                                            int m_pad, int bpc, typename V4<T>::type* __restrict__ tgs4, int32_t* __restrict__ tperm,
                                                            T* __restrict__ tgt_s /* optional (N,m_pad,c): the full rows in sorted order */) {
     constexpr int U = 4;                                    // rows per thread in flight (index -> row is a dependent pair)
@@ -131,7 +131,10 @@ __global__ __launch_bounds__(BLOCK) void sweep_rows_kernel(const T* __restrict__
         long j[U];
         T y[U][6];
 #pragma unroll
-        for (int u = 0; u < U; ++u) j[u] = order[(size_t)b * m_pad + min(s0 + u * BLOCK, m_pad - 1)];
+        for (int u = 0; u < U; ++u) {
+            const size_t at = (size_t)b * m_pad + min(s0 + u * BLOCK, m_pad - 1);
+            j[u] = order ? order[at] : (long)tperm[at];
+        }
         const bool full = tgt_s && c == 6;                  // the normals are wanted too: read the whole row once
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -172,6 +175,107 @@ __global__ __launch_bounds__(BLOCK) void sweep_buckets_kernel(const T* __restric
     if (threadIdx.x == 0) {
         brange[(size_t)cloud * 2] = xlo;
         brange[(size_t)cloud * 2 + 1] = span > T(0) ? T(nbkt) / span : T(0);
+    }
+}
+
+// Stable sort of a cloud's target x keys (float) entirely in LDS: LSD radix sort, 8-bit digits, 4 passes, one block of
+// 1024 threads per cloud, 16 keys per thread, up to 16384 keys (the pad slots carry +max and sort last; ties keep their
+// index order, like torch.sort(stable=True), so the permutation is the one the rest of the path was built on).
+// A pass never uses an atomic: a wave takes its 16 rounds of 64 keys in order; per round, 8 ballots tell every lane which
+// lanes hold the same digit (rank inside the round = set bits below the lane), the first lane of every digit group
+// advances the wave's per-digit counter in LDS, and after the rounds a block scan turns the 16 x 256 wave histograms
+// into offsets.  Keys and indices stay in registers between passes; one LDS buffer (written at the new positions, read
+// back in the striped order) is all the exchange space it takes.
+constexpr int RS_THREADS = 1024, RS_PER = 16, RS_MAX = RS_THREADS * RS_PER;
+__global__ __launch_bounds__(RS_THREADS) void sort_keys_kernel(const float* __restrict__ tgt, int c, int N, int m, int m_pad,
+                                                               float* __restrict__ keys_sorted, int32_t* __restrict__ tperm) {
+    __shared__ unsigned skey[RS_MAX];
+    __shared__ unsigned short sidx[RS_MAX];
+    __shared__ int cnt[RS_THREADS / WAVE][256];             // per wave, per digit: running count, then offset
+    __shared__ int tot[256];
+    const int cloud = blockIdx.x, tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
+    const float* __restrict__ rows = tgt + (size_t)cloud * m * c;
+    unsigned key[RS_PER];
+    unsigned short idx[RS_PER];
+#pragma unroll
+    for (int e = 0; e < RS_PER; ++e) {                      // striped: position = wave * 1024 + e * 64 + lane
+        const int pos = wave * (WAVE * RS_PER) + e * WAVE + lane;
+        unsigned u = 0xffffffffu;                           // beyond m_pad: sentinel, sorts after everything
+        if (pos < m_pad) {
+            const float x = pos < m ? rows[(size_t)pos * c] : 3.402823466e+38f;
+            u = __float_as_uint(x + 0.0f);                  // -0 sorts as +0 (they compare equal; index order decides)
+            u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;     // order-preserving map float -> unsigned
+            if (x != x) u = 0xffffffffu;                    // NaN of either sign sorts last, as torch.sort has it
+        }
+        key[e] = u;
+        idx[e] = (unsigned short)pos;
+    }
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = pass * 8;
+        for (int d = lane; d < 256; d += WAVE) cnt[wave][d] = 0;
+        __builtin_amdgcn_wave_barrier();
+        int rank[RS_PER];
+#pragma unroll
+        for (int e = 0; e < RS_PER; ++e) {
+            const unsigned d = (key[e] >> shift) & 0xffu;
+            unsigned long long same = ~0ull;                // lanes of this round holding the same digit
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const unsigned long long bal = __ballot((d >> b) & 1u);
+                same &= ((d >> b) & 1u) ? bal : ~bal;
+            }
+            const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(same >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)same, 0u));
+            const int base = cnt[wave][d];                  // every lane of the group reads before its first lane writes
+            __builtin_amdgcn_wave_barrier();
+            if (below == 0) cnt[wave][d] = base + __popcll(same);
+            __builtin_amdgcn_wave_barrier();
+            rank[e] = base + below;
+        }
+        __syncthreads();
+        // offsets: digit-major, wave-minor exclusive scan of the 256 x 16 counts
+        if (tid < 256) {
+            int s = 0;
+            for (int w = 0; w < RS_THREADS / WAVE; ++w) { const int v = cnt[w][tid]; cnt[w][tid] = s; s += v; }
+            tot[tid] = s;
+        }
+        __syncthreads();
+        if (tid < WAVE) {                                   // exclusive scan of the 256 digit totals by one wave (4 per lane)
+            int v[4], s = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[k] = tot[lane * 4 + k]; s += v[k]; }
+            int inc = s;
+#pragma unroll
+            for (int off = 1; off < WAVE; off <<= 1) { const int o = __shfl_up(inc, off); if (lane >= off) inc += o; }
+            int run = inc - s;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { tot[lane * 4 + k] = run; run += v[k]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < RS_PER; ++e) {
+            const unsigned d = (key[e] >> shift) & 0xffu;
+            const int pos = tot[d] + cnt[wave][d] + rank[e];
+            skey[pos] = key[e];
+            sidx[pos] = idx[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < RS_PER; ++e) {
+            const int pos = wave * (WAVE * RS_PER) + e * WAVE + lane;
+            key[e] = skey[pos];
+            idx[e] = sidx[pos];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int e = 0; e < RS_PER; ++e) {
+        const int pos = wave * (WAVE * RS_PER) + e * WAVE + lane;
+        if (pos < m_pad) {
+            unsigned u = key[e];
+            u ^= (u >> 31) ? 0x80000000u : 0xffffffffu;
+            keys_sorted[(size_t)cloud * m_pad + pos] = __uint_as_float(u);
+            tperm[(size_t)cloud * m_pad + pos] = (int32_t)idx[e];
+        }
     }
 }
 
@@ -2226,9 +2330,18 @@ int dicp_pack_target(int dtype, const void* tgt, int N, int m, int c, void* tgt4
     return launch_status();
 }
 
+int dicp_sweep_sort(int dtype, const void* tgt, int c, int N, int m, int m_pad, void* keys_sorted, int32_t* tperm, void* stream) {
+    if (!tgt || !keys_sorted || !tperm) return DICP_ERR_NULL;
+    if (dtype != DICP_F32) return DICP_ERR_DTYPE;          // float keys; float64 clouds and more than 16384 targets: sort on the caller's side
+    if (N <= 0 || m <= 0 || (c != 3 && c != 6) || m_pad != dicp_padded_targets(m) || m_pad > RS_MAX) return DICP_ERR_SHAPE;
+    begin_launch();
+    sort_keys_kernel<<<N, RS_THREADS, 0, (hipStream_t)stream>>>((const float*)tgt, c, N, m, m_pad, (float*)keys_sorted, tperm);
+    return launch_status();
+}
+
 int dicp_sweep_build(int dtype, const void* tgt, int c, const int64_t* order, const void* keys_sorted, int N, int m, int m_pad, int nbkt,
                      void* tgs4, int32_t* tperm, int32_t* bucket, void* brange, void* tgt_s, void* stream) {
-    if (!tgt || !order || !keys_sorted || !tgs4 || !tperm || !bucket || !brange) return DICP_ERR_NULL;
+    if (!tgt || !keys_sorted || !tgs4 || !tperm || !bucket || !brange) return DICP_ERR_NULL;      // order == NULL: tperm holds it
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || m <= 0 || (c != 3 && c != 6) || nbkt <= 0 || m_pad != dicp_padded_targets(m)) return DICP_ERR_SHAPE;
     if ((uintptr_t)tgs4 % (dtype == DICP_F32 ? 16 : 32)) return DICP_ERR_ALIGN;

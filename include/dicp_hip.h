@@ -74,6 +74,10 @@ int dicp_knn(int dtype, const void* src, const void* pose, const void* tgt4, int
  *   -> tgs4 (N,m_pad,4) packed rows in sorted order (pads [max,0,0,+inf]), tperm (N,m_pad) = order as int32,
  *      bucket (N,nbkt+1) lower-bound positions of nbkt+1 equally spaced x edges, brange (N,2) = [x_min, nbkt/(x_max-x_min)],
  *      optional tgt_s (N,m_pad,c) = the full target rows in sorted order (what dicp_accumulate_bwd_window reads). */
+/* The sort itself, for float32 clouds of up to 16384 targets (m_pad <= 16384): keys_sorted (N,m_pad) and tperm (N,m_pad)
+ * as a stable ascending sort of the target x keys gives them (an LDS radix sort, one block per cloud).  Then pass
+ * order = NULL to dicp_sweep_build: it reads the permutation from tperm. */
+int dicp_sweep_sort(int dtype, const void* tgt, int c, int N, int m, int m_pad, void* keys_sorted, int32_t* tperm, void* stream);
 int dicp_sweep_build(int dtype, const void* tgt, int c, const int64_t* order, const void* keys_sorted, int N, int m, int m_pad, int nbkt,
                      void* tgs4, int32_t* tperm, int32_t* bucket, void* brange, void* tgt_s, void* stream);
 /* keys (N,n) = x coordinate of every source point under pose (NULL = identity): the sort key of the query order. */

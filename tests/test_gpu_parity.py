@@ -1149,3 +1149,54 @@ def test_sync_every_and_history_slabs_do_not_change_results(golden, monkeypatch)
         else:
             for a, b in zip(src, ref_grads):
                 np.testing.assert_allclose(npy(a.grad), npy(b), rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("m,c", [(1, 3), (63, 6), (64, 3), (1000, 6), (4097, 3), (16384, 6), (16321, 6)])
+def test_sweep_sort_is_the_stable_torch_sort(m, c):
+    """dicp_sweep_sort (LDS radix sort of the target x keys) against torch.sort(stable=True): same sorted keys, same
+    permutation -- with duplicates, negative values, zeros of both signs, infinities and NaN among the keys -- and the
+    SweepIndex built on either is the same index."""
+    from dicp_amd import _ops, _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(m)
+    N = 5
+    tgt = torch.randn((N, m, c), generator=g) * 3
+    tgt[1, :, 0] = torch.randint(-4, 4, (m,), generator=g).float()                    # heavy duplicates
+    tgt[2, :, 0] = (tgt[2, :, 0] * 1e30).clamp(-3e38, 3e38)                           # large magnitudes
+    if m >= 64:
+        tgt[3, 5, 0], tgt[3, 9, 0], tgt[3, 11, 0], tgt[3, 20, 0] = 0.0, -0.0, float("inf"), float("-inf")
+        tgt[3, 30, 0], tgt[3, 31, 0] = float("nan"), -float("nan")
+        tgt[4, :, 0] = tgt[4, :, 0].abs().neg()                                        # all negative
+    tgt = tgt.cuda()
+    m_pad = lib.dicp_padded_targets(m)
+    key = torch.full((N, m_pad), torch.finfo(torch.float32).max, device="cuda")
+    key[:, :m] = tgt[:, :, 0]
+    ref_keys, ref_order = torch.sort(key, dim=1, stable=True)
+    keys = torch.empty((N, m_pad), device="cuda")
+    perm = torch.empty((N, m_pad), dtype=torch.int32, device="cuda")
+    _lib.check(lib.dicp_sweep_sort(_lib.F32, _ops._p(tgt), c, N, m, m_pad, _ops._p(keys), _ops._p(perm), _ops._stream()), "sort")
+    plain = [0, 1, 2, 4] if m >= 64 else list(range(N))                               # row 3 holds the special values
+    assert torch.equal(perm.long()[plain], ref_order[plain])
+    assert torch.equal(keys[plain], ref_keys[plain])
+    # every row, the special one included, by the properties of a stable sort under "NaN last, -0 == +0":
+    p64 = perm.long()
+    assert torch.equal(torch.sort(p64, dim=1).values, torch.arange(m_pad, device="cuda").expand(N, -1))
+    got = torch.gather(key, 1, p64)
+    assert torch.equal(torch.nan_to_num(keys, nan=7.0), torch.nan_to_num(got, nan=7.0))  # equal as floats (-0 == +0)
+    a, b = keys[:, :-1], keys[:, 1:]
+    assert bool(((a <= b) | torch.isnan(b)).all()) and bool((~torch.isnan(a) | torch.isnan(b)).all())
+    tie = (a == b) | (torch.isnan(a) & torch.isnan(b))
+    assert bool((p64[:, :-1] < p64[:, 1:])[tie].all())                                # ties keep their index order
+    if m >= 64:
+        tgt[3, 30:32, 0] = 1.0                                                         # the index itself: finite clouds
+        tgt[3, 11, 0], tgt[3, 20, 0] = 2.0, -2.0
+    old = _ops.NATIVE_SORT
+    try:
+        _ops.NATIVE_SORT = 1
+        a = _ops.SweepIndex(tgt)
+        _ops.NATIVE_SORT = 0
+        b = _ops.SweepIndex(tgt)
+    finally:
+        _ops.NATIVE_SORT = old
+    for name in ("keys", "tgs4", "tperm", "bucket", "brange"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name

@@ -41,7 +41,10 @@ TRIM = 5.0
 class EventLog:
     """HIP events around the kNN launch (forward) and the accumulate_bwd launch (backward) of every iteration.
     The loop runs inside libdicp_hip.so (dicp_icp_forward / _backward), so the library records them: it is handed
-    the raw hipEvent_t handles of these torch events (same HIP runtime) -- on the stream the kernels run on."""
+    the raw hipEvent_t handles of these torch events (same HIP runtime) -- on the stream the kernels run on.  The
+    sweep and windowed-backward launches carry their pair on the dispatch itself (hipExtLaunchKernel start / stop
+    events: the kernel's own begin / end timestamps, no barrier packets in the timed queue); the brute-force and
+    atomic forms are bracketed by hipEventRecord."""
 
     def __init__(self):
         self.K, self.ev, self.arr = 0, None, None

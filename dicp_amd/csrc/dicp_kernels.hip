@@ -28,6 +28,7 @@
 // Written for 64-wide wavefronts and 8 XCDs: block ids are dealt so that all blocks of
 // one cloud land on one XCD (they share that cloud's targets in its L2).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/dicp_hip.h"
@@ -2231,6 +2232,13 @@ __global__ __launch_bounds__(BLOCK) void loss_weight_bwd_kernel(int loss, int di
 // leave an unrelated error behind: every entry point clears it (begin_launch) before launching and
 // reads it back (launch_status) after, so the status returned is that of OUR launch only.
 inline void begin_launch() { (void)hipGetLastError(); }
+// Timing events of the loop entry points (dicp_loop_buffers.events): the search and the windowed-backward launches
+// carry their pair of events ON the dispatch (hipExtLaunchKernel: start / stop are taken from the kernel's own
+// completion signal), where two hipEventRecord calls would put a barrier packet -- about 6 us of idle queue -- on
+// either side of every launch they time.  The loop sets the pair, the next such launch of this host thread takes it.
+thread_local hipEvent_t tl_launch_start = nullptr, tl_launch_stop = nullptr;
+inline void set_launch_events(hipEvent_t a, hipEvent_t b) { tl_launch_start = a; tl_launch_stop = b; }
+inline void take_launch_events(hipEvent_t& a, hipEvent_t& b) { a = tl_launch_start; b = tl_launch_stop; tl_launch_start = tl_launch_stop = nullptr; }
 inline int launch_status() {
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : -(int)e;
@@ -2450,6 +2458,8 @@ static int sweep_launch(int dtype, const void* src, const void* pose, const void
                         const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt,
                         int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg,
                         const FusedHost* fh, hipStream_t st) {
+    hipEvent_t ev0, ev1;
+    take_launch_events(ev0, ev1);                                       // (null unless a timed loop set them for this launch)
     const int src_sorted = (cfg & DICP_SWEEP_SRC_SORTED) ? 1 : 0;      // src holds the rows in qorder's slot order
     cfg &= ~DICP_SWEEP_SRC_SORTED;
     if (src_sorted && !qorder) return DICP_ERR_NULL;
@@ -2457,7 +2467,8 @@ static int sweep_launch(int dtype, const void* src, const void* pose, const void
     if (cfg >= DICP_SWEEP_SCAN && cfg <= DICP_SWEEP_SCAN + 3) {           // narrow-slab form: one query per lane, per-lane scan
         if (fh || src_sorted) return DICP_ERR_ENUM;
         const int bpc = (n + BLOCK - 1) / BLOCK;
-#define DICP_SCAN(T, W, G) knn_scan_kernel<T, W, G><<<grid_for(N, bpc), BLOCK, 0, st>>>((const T*)src, (const T*)pose, (const typename V4<T>::type*)tgs4, \
+#define DICP_SCAN(T, W, G) hipExtLaunchKernelGGL((knn_scan_kernel<T, W, G>), dim3(grid_for(N, bpc)), dim3(BLOCK), 0, st, ev0, ev1, 0, \
+            (const T*)src, (const T*)pose, (const typename V4<T>::type*)tgs4, \
             tperm, qorder, bucket, (const T*)brange, nbkt, idx, spos, pairs, N, n, m, m_pad, bpc)
         if (dtype == DICP_F32) {
             switch (cfg - DICP_SWEEP_SCAN) {
@@ -2473,8 +2484,9 @@ static int sweep_launch(int dtype, const void* src, const void* pose, const void
     const int units = dicp_sweep_partials(dtype, n, cfg);
     if (units <= 0) return DICP_ERR_ENUM;
     const int bpc = (units + BLOCK / WAVE - 1) / (BLOCK / WAVE);
-#define DICP_SWEEP_M(T, Q, CH, M, FA) knn_sweep_kernel<T, Q, CH, M><<<grid_for(N, bpc), BLOCK, 0, st>>>((const T*)src, (const T*)pose, \
-        (const typename V4<T>::type*)tgs4, tperm, qorder, bucket, (const T*)brange, nbkt, idx, spos, pairs, N, n, m, m_pad, bpc, src_sorted, FA)
+#define DICP_SWEEP_M(T, Q, CH, M, FA) hipExtLaunchKernelGGL((knn_sweep_kernel<T, Q, CH, M>), dim3(grid_for(N, bpc)), dim3(BLOCK), 0, st, ev0, ev1, 0, \
+        (const T*)src, (const T*)pose, (const typename V4<T>::type*)tgs4, tperm, qorder, bucket, (const T*)brange, nbkt, idx, spos, pairs, \
+        N, n, m, m_pad, bpc, src_sorted, FA)
 #define DICP_SWEEP(T, Q, CH) do { FusedAcc<T> none{}; DICP_SWEEP_M(T, Q, CH, MODE_SEARCH_ONLY, none); } while (0)
     // the fused form exists for the configurations the ICP loop uses
 #define DICP_SWEEP_F(T, Q, CH) do { if (!fh) { DICP_SWEEP(T, Q, CH); break; } \
@@ -2750,11 +2762,13 @@ int dicp_accumulate_bwd_window(int dtype, const dicp_weight_params* prm, const v
     if (N <= 0 || n <= 0 || m_pad <= 0 || m_pad % KNN_PAD) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     begin_launch();
+    hipEvent_t ev0, ev1;
+    take_launch_events(ev0, ev1);
     const WeightParams P = to_params(prm);
     const int bpc = dicp_window_blocks(dtype, n, m_pad);
     const unsigned g = grid_for(N, bpc);
 #define DICP_WIN(T, M) do { constexpr int WT = WindowRows<T>::v; const int spb = window_slots(WT, n, m_pad); \
-        accumulate_bwd_window_kernel<T, M, WT><<<g, BLOCK, 0, st>>>(P, (const T*)src_s, (const T*)tgt_s, c, spos, spos_ref, qorder, (const T*)pose, \
+        hipExtLaunchKernelGGL((accumulate_bwd_window_kernel<T, M, WT>), dim3(g), dim3(BLOCK), 0, st, ev0, ev1, 0, P, (const T*)src_s, (const T*)tgt_s, c, spos, spos_ref, qorder, (const T*)pose, \
             (const T*)w_s, (const T*)alive, (const T*)gs, (const T*)gb, N, n, m_pad, spb, bpc, (T*)gsrc_s, (T*)slab, (T*)gts_far, (T*)gw_s, \
             (T*)bwd_partials); } while (0)
     if (dtype == DICP_F32) { if (P.mode == MODE_PT2PL) DICP_WIN(float, MODE_PT2PL); else DICP_WIN(float, MODE_PT2PT); }
@@ -2843,7 +2857,10 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
         int32_t* idx_k = B->idx + (B->idx_per_iter ? (size_t)k * N * n : 0);
         char* w_k = (char*)B->w + (size_t)k * B->w_iter * es;       // cloud stride B->w_stride: (N,K,n) or (K,N,n) alike
         const char* alive_k = (const char*)B->alive + (size_t)k * N * es;
-        if (B->events) { if (hipEventRecord((hipEvent_t)B->events[4 * k + 0], st) != hipSuccess) return -(int)hipGetLastError(); }
+        if (B->events) {    // the sweep launch carries its two events itself; the brute-force forms are bracketed by records
+            if (kind == DICP_KNN_SWEEP) set_launch_events((hipEvent_t)B->events[4 * k + 0], (hipEvent_t)B->events[4 * k + 1]);
+            else if (hipEventRecord((hipEvent_t)B->events[4 * k + 0], st) != hipSuccess) return -(int)hipGetLastError();
+        }
         int rc;
         int nblk_k = nblk;
         if (kind == DICP_KNN_SWEEP) {
@@ -2867,13 +2884,13 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
                                                B->tgt, B->c, B->w_init, alive_k, N, n, m, B->m_pad, idx_k, spos_k, B->pairs, cfg,
                                                B->partials, w_k, B->w_stride, stream);
                 nblk_k = dicp_sweep_partials(dtype, n, cfg_plain);
+                set_launch_events(nullptr, nullptr);
                 if (rc) return rc;
-                if (B->events) { if (hipEventRecord((hipEvent_t)B->events[4 * k + 1], st) != hipSuccess) return -(int)hipGetLastError(); }
             } else {
                 rc = dicp_knn_sweep(dtype, qsrc, pose_k, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, N, n, m, B->m_pad,
                                     idx_k, spos_k, B->pairs, cfg, stream);
+                set_launch_events(nullptr, nullptr);
                 if (rc) return rc;
-                if (B->events) { if (hipEventRecord((hipEvent_t)B->events[4 * k + 1], st) != hipSuccess) return -(int)hipGetLastError(); }
                 rc = dicp_accumulate(dtype, prm, B->src, B->tgt, B->c, idx_k, pose_k, B->w_init, alive_k, N, n, m, B->partials, w_k, B->w_stride, stream);
                 if (rc) return rc;
             }
@@ -2928,7 +2945,10 @@ int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_
                                (const char*)B->deltas + (size_t)k * 6 * es, (int64_t)B->K * 6, B->areg + (size_t)k * N * 36,
                                gs, gb, gout, N, stream);
         if (rc) return rc;
-        if (B->events) { if (hipEventRecord((hipEvent_t)B->events[4 * k + 2], st) != hipSuccess) return -(int)hipGetLastError(); }
+        if (B->events) {
+            if (B->spos) set_launch_events((hipEvent_t)B->events[4 * k + 2], (hipEvent_t)B->events[4 * k + 3]);
+            else if (hipEventRecord((hipEvent_t)B->events[4 * k + 2], st) != hipSuccess) return -(int)hipGetLastError();
+        }
         if (B->spos)    // windowed form: src / w_init / tgt are the SORTED copies, gsrc / gw accumulate in slot order, gtgt is the slab
             rc = dicp_accumulate_bwd_window(dtype, prm, B->src, B->tgt, B->c, B->spos + (size_t)k * N * n, B->spos_ref, B->qorder, pose_k, B->w_init,
                                             (const char*)B->alive + (size_t)k * N * es, gs, gb, N, n, B->m_pad,
@@ -2936,8 +2956,9 @@ int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_
         else
             rc = dicp_accumulate_bwd(dtype, prm, B->src, B->tgt, B->c, B->idx + (size_t)k * N * n, pose_k, B->w_init,
                                      (const char*)B->alive + (size_t)k * N * es, gs, gb, N, n, m, gsrc, gtgt, gw, bwd_partials, stream);
+        set_launch_events(nullptr, nullptr);
         if (rc) return rc;
-        if (B->events) { if (hipEventRecord((hipEvent_t)B->events[4 * k + 3], st) != hipSuccess) return -(int)hipGetLastError(); }
+        if (B->events && !B->spos) { if (hipEventRecord((hipEvent_t)B->events[4 * k + 3], st) != hipSuccess) return -(int)hipGetLastError(); }
         have_partials = 1;
         double* t = gin; gin = gout; gout = t;
     }

@@ -228,7 +228,9 @@ typedef struct dicp_loop_buffers {
     void* partials;          /* (N, dicp_loop_partial_blocks(dtype, n), DICP_NACC_PAD) scratch */
     int32_t* counters;       /* (K) zero-initialised: #clouds with |delta| >= tol at iteration k */
     void** events;           /* optional 4*K hipEvent_t: [4k] before / [4k+1] after the kNN of iteration k (forward),
-                                [4k+2] before / [4k+3] after its accumulate_bwd (backward); NULL = none */
+                                [4k+2] before / [4k+3] after its accumulate_bwd (backward); NULL = none.  The sweep and the
+                                windowed-backward launches take their pair as the start / stop events of the dispatch
+                                (hipExtLaunchKernel), the other forms are bracketed by hipEventRecord */
 } dicp_loop_buffers;
 
 /* Loop state before iteration 0 (ICP.py:124-129): pose0 (N,12) from T_init (N,4,4), alive0 (N) = 1,

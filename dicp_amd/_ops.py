@@ -545,8 +545,6 @@ class ICPLoop(torch.autograd.Function):
             gtmp = torch.empty_like(gpose)
             want_tgt, want_w = ctx.needs_input_grad[1], ctx.needs_input_grad[3]
             cv = 6 if cfg.icp_type == "pt2pl" else 3
-            gsrc = torch.zeros_like(src)
-            gw = torch.zeros_like(w0c) if want_w else None
             all_windowed = None         # set below: every iteration takes the windowed form -> dicp_window_reduce writes gtgt
             gtgt = None
             # Two forms of accumulate_bwd.  Atomic form (dicp_accumulate_bwd): original order, no set-up.  Windowed form
@@ -560,19 +558,24 @@ class ICPLoop(torch.autograd.Function):
             windowed = [owned and (q == q_star or a >= WINDOW_FROM) for (a, _, q) in segs]
             if sum(b - a for (a, b, _), wf in zip(segs, windowed) if wf) < WINDOW_MIN_ITERS:
                 windowed = [False] * len(segs)
-            all_windowed = all(windowed) and len(windowed) > 0 and c == cv
+            only_windowed = all(windowed) and len(windowed) > 0
+            all_windowed = only_windowed and c == cv
             if want_tgt:    # all windowed: dicp_window_reduce writes every element once, no zero fill needed
                 gtgt = torch.empty_like(tgt) if all_windowed else torch.zeros_like(tgt)
+            # likewise the source / weight gradients: un-permuted from the slot-order accumulators with = (dicp_permute_rows)
+            gsrc = torch.empty_like(src) if only_windowed else torch.zeros_like(src)
+            gw = (torch.empty_like(w0c) if only_windowed else torch.zeros_like(w0c)) if want_w else None
             nblk_a, nblk_w = lib.dicp_accumulate_blocks(n), lib.dicp_window_blocks(code, n, m_pad)
             if any(windowed):
                 qo = qorders[q_star]
                 src_s = _gather_rows_raw(src, qo)
                 w_s = _gather_rows_raw(w0c.unsqueeze(-1), qo).squeeze(-1)
-                gsrc_s = torch.zeros_like(src)
-                gw_s = torch.zeros_like(w0c) if want_w else None
+                # slot-order accumulators and slabs: the first windowed launch writes them (bwd_overwrite), no zero fill
+                gsrc_s = torch.empty_like(src)
+                gw_s = torch.empty_like(w0c) if want_w else None
                 k_ref = max(b for (_, b, _), wf in zip(segs, windowed) if wf) - 1      # windows placed by the last iteration's matches
                 spos_ref = spos_slabs[k_ref // kc][k_ref % kc]
-                slab = torch.zeros((N, nblk_w, lib.dicp_window_rows(code), cv), dtype=dt, device=dev) if want_tgt else None
+                slab = torch.empty((N, nblk_w, lib.dicp_window_rows(code), cv), dtype=dt, device=dev) if want_tgt else None
                 gfar = torch.zeros((N, m_pad, cv), dtype=dt, device=dev) if want_tgt else None
             gs = torch.empty((N, 36), dtype=dt, device=dev)
             gb = torch.empty((N, 6), dtype=dt, device=dev)
@@ -581,7 +584,7 @@ class ICPLoop(torch.autograd.Function):
                     True: bwd_flat[:N * nblk_w * _lib.NBWD_PAD].view(N, nblk_w, _lib.NBWD_PAD)}
             ev = cfg.timing_events
             events = ev.handles(Kmax) if ev is not None else None
-            have, form = 0, None
+            have, form, fresh = 0, None, 1
             for (k0, k1, q), w_form in zip(reversed(segs), reversed(windowed)):
                 if have and w_form != form:     # the partials of the other form have another block count: fold them in here
                     gpose += bwdp[form].sum(dim=1)[:, :12].to(torch.float64)
@@ -596,7 +599,10 @@ class ICPLoop(torch.autograd.Function):
                     spos=ctypes.c_void_p(spos_slabs[j].data_ptr() - base * N * n * 4) if w_form else None,
                     spos_ref=_p(spos_ref) if w_form else None, gts_far=_p(gfar) if w_form else None,
                     poses=_p(poses), deltas=_p(deltas), areg=_p(areg), alive=_p(alive),
-                    idx=ctypes.c_void_p(idx_slabs[j].data_ptr() - base * N * n * 4), events=events)
+                    idx=ctypes.c_void_p(idx_slabs[j].data_ptr() - base * N * n * 4), events=events,
+                    bwd_overwrite=fresh if (w_form and k1 > k0) else 0)
+                if w_form and k1 > k0:
+                    fresh = 0
                 _lib.check(lib.dicp_icp_backward(code, ctypes.byref(P), ctypes.byref(LB), N, n, m, int(cfg.dim), _p(gpose), _p(gtmp), have,
                                                  _p(gs), _p(gb), _p(gsrc_s) if w_form else _p(gsrc), _p(slab) if w_form else _p(gtgt),
                                                  _p(gw_s) if w_form else _p(gw), _p(bwdp[form]), k0, k1, st), "dicp_icp_backward")
@@ -606,9 +612,10 @@ class ICPLoop(torch.autograd.Function):
             if have:
                 gpose = gpose + bwdp[form].sum(dim=1)[:, :12].to(torch.float64)
             if any(windowed):               # slot s is source point qo[s]; slabs + out-of-window rows -> original target order
-                _lib.check(lib.dicp_permute_add_rows(code, _p(gsrc_s), _p(qo), N, n, n, n, 3, 3, _p(gsrc), n, 3, st), "dicp_permute_add_rows")
+                permute = lib.dicp_permute_rows if only_windowed else lib.dicp_permute_add_rows
+                _lib.check(permute(code, _p(gsrc_s), _p(qo), N, n, n, n, 3, 3, _p(gsrc), n, 3, st), "dicp_permute_rows")
                 if want_w:
-                    _lib.check(lib.dicp_permute_add_rows(code, _p(gw_s), _p(qo), N, n, n, n, 1, 1, _p(gw), n, 1, st), "dicp_permute_add_rows")
+                    _lib.check(permute(code, _p(gw_s), _p(qo), N, n, n, n, 1, 1, _p(gw), n, 1, st), "dicp_permute_rows")
                 if want_tgt:
                     _lib.check(lib.dicp_window_reduce(code, _p(slab), _p(spos_ref), _p(qo), _p(tperm), _p(gfar), N, n, m, m_pad, cv,
                                                       _p(gtgt), c, int(all_windowed), st), "dicp_window_reduce")

@@ -1521,7 +1521,7 @@ __device__ __forceinline__ int window_origin(const int32_t* __restrict__ sp_ref_
     return min(max(ctr - WT / 2, 0), m_pad - WT) & ~15;
 }
 
-template <typename T, int MODE, int WT>
+template <typename T, int MODE, int WT, bool overwrite>
 __global__ __launch_bounds__(BLOCK) void accumulate_bwd_window_kernel(WeightParams P, const T* __restrict__ src_s, const T* __restrict__ tgt_s, int c,
                                                                       const int32_t* __restrict__ spos, const int32_t* __restrict__ spos_ref,
                                                                       const int32_t* __restrict__ qorder,
@@ -1531,6 +1531,7 @@ __global__ __launch_bounds__(BLOCK) void accumulate_bwd_window_kernel(WeightPara
                                                                       T* __restrict__ gsrc_s, T* __restrict__ slab /* (N,bpc,WT,CV) */,
                                                                       T* __restrict__ gts_far /* (N,m_pad,CV) */,
                                                                       T* __restrict__ gw_s, T* __restrict__ bwd_partials) {
+    // overwrite: first launch into uninitialised accumulators -- gsrc_s / gw_s / the slab windows are written, not added to
     constexpr int CV = (MODE == MODE_PT2PL) ? 6 : 3;
     __shared__ T red[(BLOCK / WAVE) * NBWD_PAD];
     constexpr int SPB = 4 * BLOCK;                          // window_slots() never exceeds this
@@ -1583,8 +1584,11 @@ __global__ __launch_bounds__(BLOCK) void accumulate_bwd_window_kernel(WeightPara
             p[u][0] = spp[0]; p[u][1] = spp[1]; p[u][2] = spp[2];
             wv[u] = w_s[pt];
             const T* gsp = gsrc_s + pt * 3;
-            g0[u][0] = gsp[0]; g0[u][1] = gsp[1]; g0[u][2] = gsp[2];
-            gwv[u] = gw_s ? gw_s[pt] : T(0);
+            g0[u][0] = g0[u][1] = g0[u][2] = gwv[u] = T(0);
+            if (!overwrite) {
+                g0[u][0] = gsp[0]; g0[u][1] = gsp[1]; g0[u][2] = gsp[2];
+                if (gw_s) gwv[u] = gw_s[pt];
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1622,7 +1626,7 @@ __global__ __launch_bounds__(BLOCK) void accumulate_bwd_window_kernel(WeightPara
         T* out = slab + ((size_t)cloud * bpc + blk) * (WT * CV);
         for (int rr = tid; rr < hi - lo; rr += BLOCK) {
             int h = head[rr];
-            if (h < 0) continue;
+            if (h < 0 && !overwrite) continue;
             T sum[CV];
 #pragma unroll
             for (int k = 0; k < CV; ++k) sum[k] = T(0);
@@ -1632,7 +1636,7 @@ __global__ __launch_bounds__(BLOCK) void accumulate_bwd_window_kernel(WeightPara
                 h = next[h];
             }
 #pragma unroll
-            for (int k = 0; k < CV; ++k) out[rr * CV + k] += sum[k];
+            for (int k = 0; k < CV; ++k) out[rr * CV + k] = overwrite ? sum[k] : out[rr * CV + k] + sum[k];
         }
     }
     block_reduce_store<T, NBWD, NBWD_PAD>(acc, bwd_partials + ((size_t)cloud * bpc + blk) * NBWD_PAD, red);
@@ -1653,6 +1657,15 @@ __global__ __launch_bounds__(BLOCK) void window_reduce_kernel(const T* __restric
     const int tid = threadIdx.x;
     const int e0 = rb * (BLOCK * 4);                        // this block's elements of the (m*cv) row-major gradient
     T acc[4] = {T(0), T(0), T(0), T(0)};
+    // the loads that do not wait for the window origins (two dependent index loads) go out first and run under them
+    int dst[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = min(e0 + u * BLOCK + tid, m * cv - 1);
+        const int s = e / CV;
+        dst[u] = tperm[(size_t)cloud * m_pad + s];
+        if (gts_far) acc[u] = gts_far[((size_t)cloud * m_pad + s) * cv + (e - s * CV)];
+    }
     for (int b0 = 0; b0 < bpc; b0 += MAXB) {
         __syncthreads();
         for (int b = tid; b < min(MAXB, bpc - b0); b += BLOCK)
@@ -1682,9 +1695,8 @@ __global__ __launch_bounds__(BLOCK) void window_reduce_kernel(const T* __restric
         const int e = e0 + u * BLOCK + tid;
         if (e >= m * cv) continue;
         const int s = e / CV, col = e - s * CV;
-        T v = acc[u];
-        if (gts_far) v += gts_far[((size_t)cloud * m_pad + s) * cv + col];
-        const int j = tperm[(size_t)cloud * m_pad + s];
+        const T v = acc[u];
+        const int j = dst[u];
         if (j >= 0 && j < m) {
             T* o = gtgt + ((size_t)cloud * m + j) * c + col;
             *o = overwrite ? v : *o + v;                    // overwrite: every row of gtgt[:, :, :cv] is written exactly once
@@ -1697,7 +1709,7 @@ __global__ __launch_bounds__(BLOCK) void window_reduce_kernel(const T* __restric
 template <typename T, int C>
 __global__ __launch_bounds__(BLOCK) void permute_add_rows_kernel(const T* __restrict__ in, const int32_t* __restrict__ perm,
                                                                  int N, int cnt, int in_rows, int perm_rows, int c_in, int cols,
-                                                                 T* __restrict__ out, int out_rows, int c_out, int bpc) {
+                                                                 T* __restrict__ out, int out_rows, int c_out, int bpc, int overwrite) {
     const unsigned total = (unsigned)cnt * (unsigned)cols;
     int b, blk;
     if (!decode_block(bpc, N, b, blk)) return;
@@ -1716,7 +1728,7 @@ __global__ __launch_bounds__(BLOCK) void permute_add_rows_kernel(const T* __rest
             ok[u] = e0 + u * BLOCK < total && j[u] >= 0 && j[u] < out_rows;
         }
 #pragma unroll
-        for (int u = 0; u < ROWS_U; ++u) o[u] = ok[u] ? out[((size_t)b * out_rows + j[u]) * c_out + k[u]] : T(0);
+        for (int u = 0; u < ROWS_U; ++u) o[u] = (ok[u] && !overwrite) ? out[((size_t)b * out_rows + j[u]) * c_out + k[u]] : T(0);
 #pragma unroll
         for (int u = 0; u < ROWS_U; ++u)
             if (ok[u]) out[((size_t)b * out_rows + j[u]) * c_out + k[u]] = o[u] + v[u];
@@ -2754,7 +2766,7 @@ int dicp_window_rows(int dtype) { return dtype == DICP_F32 ? WindowRows<float>::
 int dicp_accumulate_bwd_window(int dtype, const dicp_weight_params* prm, const void* src_s, const void* tgt_s, int c,
                                const int32_t* spos, const int32_t* spos_ref, const int32_t* qorder, const void* pose, const void* w_s,
                                const void* alive, const void* gs, const void* gb, int N, int n, int m_pad, void* gsrc_s, void* slab,
-                               void* gts_far, void* gw_s, void* bwd_partials, void* stream) {
+                               void* gts_far, void* gw_s, void* bwd_partials, int overwrite, void* stream) {
     if (const int e = check_params(prm, c)) return e;
     if (!src_s || !tgt_s || !spos || !spos_ref || !pose || !w_s || !gs || !gb || !gsrc_s || !bwd_partials || (slab && !gts_far))
         return DICP_ERR_NULL;
@@ -2767,13 +2779,15 @@ int dicp_accumulate_bwd_window(int dtype, const dicp_weight_params* prm, const v
     const WeightParams P = to_params(prm);
     const int bpc = dicp_window_blocks(dtype, n, m_pad);
     const unsigned g = grid_for(N, bpc);
-#define DICP_WIN(T, M) do { constexpr int WT = WindowRows<T>::v; const int spb = window_slots(WT, n, m_pad); \
-        hipExtLaunchKernelGGL((accumulate_bwd_window_kernel<T, M, WT>), dim3(g), dim3(BLOCK), 0, st, ev0, ev1, 0, P, (const T*)src_s, (const T*)tgt_s, c, spos, spos_ref, qorder, (const T*)pose, \
+#define DICP_WIN(T, M) do { if (overwrite) DICP_WIN_O(T, M, true); else DICP_WIN_O(T, M, false); } while (0)
+#define DICP_WIN_O(T, M, OV) do { constexpr int WT = WindowRows<T>::v; const int spb = window_slots(WT, n, m_pad); \
+        hipExtLaunchKernelGGL((accumulate_bwd_window_kernel<T, M, WT, OV>), dim3(g), dim3(BLOCK), 0, st, ev0, ev1, 0, P, (const T*)src_s, (const T*)tgt_s, c, spos, spos_ref, qorder, (const T*)pose, \
             (const T*)w_s, (const T*)alive, (const T*)gs, (const T*)gb, N, n, m_pad, spb, bpc, (T*)gsrc_s, (T*)slab, (T*)gts_far, (T*)gw_s, \
             (T*)bwd_partials); } while (0)
     if (dtype == DICP_F32) { if (P.mode == MODE_PT2PL) DICP_WIN(float, MODE_PT2PL); else DICP_WIN(float, MODE_PT2PT); }
     else                   { if (P.mode == MODE_PT2PL) DICP_WIN(double, MODE_PT2PL); else DICP_WIN(double, MODE_PT2PT); }
 #undef DICP_WIN
+#undef DICP_WIN_O
     return launch_status();
 }
 
@@ -2795,8 +2809,18 @@ int dicp_window_reduce(int dtype, const void* slab, const int32_t* spos_ref, con
     return launch_status();
 }
 
+static int permute_rows(int dtype, const void* in, const int32_t* perm, int N, int cnt, int in_rows, int perm_rows, int c_in, int cols,
+                        void* out, int out_rows, int c_out, int overwrite, void* stream);
 int dicp_permute_add_rows(int dtype, const void* in, const int32_t* perm, int N, int cnt, int in_rows, int perm_rows, int c_in, int cols,
                           void* out, int out_rows, int c_out, void* stream) {
+    return permute_rows(dtype, in, perm, N, cnt, in_rows, perm_rows, c_in, cols, out, out_rows, c_out, 0, stream);
+}
+int dicp_permute_rows(int dtype, const void* in, const int32_t* perm, int N, int cnt, int in_rows, int perm_rows, int c_in, int cols,
+                      void* out, int out_rows, int c_out, void* stream) {
+    return permute_rows(dtype, in, perm, N, cnt, in_rows, perm_rows, c_in, cols, out, out_rows, c_out, 1, stream);
+}
+static int permute_rows(int dtype, const void* in, const int32_t* perm, int N, int cnt, int in_rows, int perm_rows, int c_in, int cols,
+                        void* out, int out_rows, int c_out, int overwrite, void* stream) {
     if (!in || !perm || !out) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || cnt <= 0 || cnt > in_rows || cnt > perm_rows || cols <= 0 || cols > c_in || cols > c_out || out_rows <= 0) return DICP_ERR_SHAPE;
@@ -2805,7 +2829,7 @@ int dicp_permute_add_rows(int dtype, const void* in, const int32_t* perm, int N,
     if ((size_t)cnt * cols > 0x7fffffffu) return DICP_ERR_SHAPE;
     const int bpc = (int)(((size_t)cnt * cols + BLOCK * ROWS_U - 1) / (BLOCK * ROWS_U));
     const unsigned g = grid_for(N, bpc);
-#define DICP_PERM(T, C) permute_add_rows_kernel<T, C><<<g, BLOCK, 0, st>>>((const T*)in, perm, N, cnt, in_rows, perm_rows, c_in, cols, (T*)out, out_rows, c_out, bpc)
+#define DICP_PERM(T, C) permute_add_rows_kernel<T, C><<<g, BLOCK, 0, st>>>((const T*)in, perm, N, cnt, in_rows, perm_rows, c_in, cols, (T*)out, out_rows, c_out, bpc, overwrite)
 #define DICP_PERM_C(T) do { if (cols == 1) DICP_PERM(T, 1); else if (cols == 3) DICP_PERM(T, 3); else if (cols == 6) DICP_PERM(T, 6); else DICP_PERM(T, 0); } while (0)
     if (dtype == DICP_F32) DICP_PERM_C(float); else DICP_PERM_C(double);
 #undef DICP_PERM
@@ -2952,7 +2976,7 @@ int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_
         if (B->spos)    // windowed form: src / w_init / tgt are the SORTED copies, gsrc / gw accumulate in slot order, gtgt is the slab
             rc = dicp_accumulate_bwd_window(dtype, prm, B->src, B->tgt, B->c, B->spos + (size_t)k * N * n, B->spos_ref, B->qorder, pose_k, B->w_init,
                                             (const char*)B->alive + (size_t)k * N * es, gs, gb, N, n, B->m_pad,
-                                            gsrc, gtgt, B->gts_far, gw, bwd_partials, stream);
+                                            gsrc, gtgt, B->gts_far, gw, bwd_partials, (B->bwd_overwrite && k == k1 - 1) ? 1 : 0, stream);
         else
             rc = dicp_accumulate_bwd(dtype, prm, B->src, B->tgt, B->c, B->idx + (size_t)k * N * n, pose_k, B->w_init,
                                      (const char*)B->alive + (size_t)k * N * es, gs, gb, N, n, m, gsrc, gtgt, gw, bwd_partials, stream);

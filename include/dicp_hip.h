@@ -231,6 +231,8 @@ typedef struct dicp_loop_buffers {
                                 [4k+2] before / [4k+3] after its accumulate_bwd (backward); NULL = none.  The sweep and the
                                 windowed-backward launches take their pair as the start / stop events of the dispatch
                                 (hipExtLaunchKernel), the other forms are bracketed by hipEventRecord */
+    int32_t bwd_overwrite;   /* dicp_icp_backward, windowed form: 1 = gsrc / gw / the slab (gtgt) are uninitialised and this call's
+                                first launch (iteration k1-1) writes them instead of adding; 0 = they are accumulators */
 } dicp_loop_buffers;
 
 /* Loop state before iteration 0 (ICP.py:124-129): pose0 (N,12) from T_init (N,4,4), alive0 (N) = 1,
@@ -283,13 +285,15 @@ int dicp_accumulate_bwd(int dtype, const dicp_weight_params* prm, const void* sr
  * of slab (N, blocks, dicp_window_rows(dtype), CV) with plain read-modify-writes (CV = 6 for pt2pl, 3 for pt2pt);
  * matches outside a window are added to gts_far (N,m_pad,CV) with atomics.  After the last iteration
  * dicp_window_reduce adds slab + gts_far into gtgt (N,m,c) in the ORIGINAL target order (+=, call it once per
- * slab; pass gts_far with one of them; overwrite != 0: = instead of +=, when nothing else has been added to gtgt).  bwd_partials: (N, dicp_window_blocks, DICP_NBWD_PAD). */
+ * slab; pass gts_far with one of them; overwrite != 0: = instead of +=, when nothing else has been added to gtgt).  bwd_partials: (N, dicp_window_blocks, DICP_NBWD_PAD).
+ * dicp_accumulate_bwd_window's own overwrite != 0: the FIRST launch into gsrc_s / gw_s / slab, which then need no
+ * zero fill (it writes every slot and every window row instead of adding to them); gts_far is always added to. */
 int dicp_window_blocks(int dtype, int n, int m_pad);
 int dicp_window_rows(int dtype);
 int dicp_accumulate_bwd_window(int dtype, const dicp_weight_params* prm, const void* src_s, const void* tgt_s, int c,
                                const int32_t* spos, const int32_t* spos_ref, const int32_t* qorder, const void* pose, const void* w_s,
                                const void* alive, const void* gs, const void* gb, int N, int n, int m_pad, void* gsrc_s, void* slab,
-                               void* gts_far, void* gw_s, void* bwd_partials, void* stream);
+                               void* gts_far, void* gw_s, void* bwd_partials, int overwrite, void* stream);
 int dicp_window_reduce(int dtype, const void* slab, const int32_t* spos_ref, const int32_t* qorder, const int32_t* tperm, const void* gts_far,
                        int N, int n, int m, int m_pad, int cv, void* gtgt, int c, int overwrite, void* stream);
 
@@ -297,6 +301,9 @@ int dicp_window_reduce(int dtype, const void* slab, const int32_t* spos_ref, con
  * cloud (plain read-modify-write), out (N,out_rows,c_out).  Undoes a sorted order. */
 int dicp_permute_add_rows(int dtype, const void* in, const int32_t* perm, int N, int cnt, int in_rows, int perm_rows, int c_in, int cols,
                           void* out, int out_rows, int c_out, void* stream);
+/* The same with = instead of += (perm a bijection onto the out rows: nothing of out[:, :, :cols] needs initialising). */
+int dicp_permute_rows(int dtype, const void* in, const int32_t* perm, int N, int cnt, int in_rows, int perm_rows, int c_in, int cols,
+                      void* out, int out_rows, int c_out, void* stream);
 
 /* Gumbel-softmax soft correspondence, nn.__diff_nn_gumbel (nn.py:43-70), without the (N,n,m) tensors:
  *   out (N,n,c) = softmax_j((-|x_i - y_j|^2 + g_ij)/tau) @ y,  g = -log(-log(U + eps) + eps)   (nn.py:56-68)

@@ -48,7 +48,7 @@ def atomic(want):
 
 def window(want):
     _lib.check(lib.dicp_accumulate_bwd_window(code, ctypes.byref(P), p(src_s), p(tgt_s), c, p(spos), p(spos), p(qo), p(pose), p(w_s), None, p(gs), p(gb),
-                                              B, n, m_pad, p(gsrc), p(slab) if want else None, p(gfar) if want else None, p(gw), p(part), st),
+                                              B, n, m_pad, p(gsrc), p(slab) if want else None, p(gfar) if want else None, p(gw), p(part), 0, st),
                "bwd_window")
 
 

@@ -90,14 +90,15 @@ def test_new_entry_points_reject_bad_arguments(lib):
     assert lib.dicp_loop_init(0, one, one, 0.01, 2, 1, 1, one, one, one, None) == 2
     assert lib.dicp_loop_finish(0, one, one, one, one, 1, 1, None, one, one, None) == 1
     assert lib.dicp_accumulate_bwd_window(0, ctypes.byref(P), one, one, 6, None, one, None, one, one, None, one, one, 1, 1, 64,
-                                          one, None, None, None, one, None) == 1
+                                          one, None, None, None, one, 0, None) == 1
     assert lib.dicp_accumulate_bwd_window(0, ctypes.byref(P), one, one, 6, one, one, None, one, one, None, one, one, 1, 1, 63,
-                                          one, None, None, None, one, None) == 2
+                                          one, None, None, None, one, 0, None) == 2
     assert lib.dicp_accumulate_bwd_window(0, ctypes.byref(P), one, one, 6, one, one, None, one, one, None, one, one, 1, 1, 64,
-                                          one, one, None, None, one, None) == 1      # a slab needs the side buffer too
+                                          one, one, None, None, one, 0, None) == 1      # a slab needs the side buffer too
     assert lib.dicp_window_reduce(0, one, one, None, one, None, 1, 1, 1, 64, 5, one, 6, 0, None) == 2
     assert lib.dicp_window_reduce(0, one, one, None, one, None, 1, 1, 1, 64, 6, one, 3, 0, None) == 2
     assert lib.dicp_permute_add_rows(0, one, one, 1, 2, 1, 2, 3, 3, one, 4, 3, None) == 2
+    assert lib.dicp_permute_rows(0, one, one, 1, 2, 1, 2, 3, 3, one, 4, 3, None) == 2
     assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, 1, 1, 1, 64, one, None, None, 99, None) == 4
     assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, 1, 1, 1, 64, one, None, None, 8 | 0x100, None) == 1  # sorted rows need the order
     assert lib.dicp_knn_sweep_accumulate(0, ctypes.byref(P), one, None, one, one, None, one, one, 1024, one, 6, one, None, 1, 1, 1, 64,

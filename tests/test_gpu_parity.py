@@ -795,20 +795,22 @@ def test_windowed_backward_kernel_equals_atomic_kernel(dtype, mode, n, m, local)
     tgt_s = _ops._gather_rows_raw(tgt, tperm)
     nw = lib.dicp_window_blocks(code, n, m_pad)
     assert nw >= 1
-    gsrc_s, gw_s = torch.zeros_like(src), torch.zeros_like(w0)
+    # the first launch overwrites (its accumulators start as garbage), the second adds
+    gsrc_s, gw_s = torch.full_like(src, float("nan")), torch.full_like(w0, 777.0)
     wt = lib.dicp_window_rows(code)
-    slab = torch.zeros((N, nw, wt, cv), dtype=dtype, device=DEV)
+    slab = torch.full((N, nw, wt, cv), float("nan"), dtype=dtype, device=DEV)
     gfar = torch.zeros((N, m_pad, cv), dtype=dtype, device=DEV)
     part = torch.zeros((N, nw, _lib.NBWD_PAD), dtype=dtype, device=DEV)
     # the windows are placed by a DIFFERENT set of matches than the ones being accumulated in the second call
     spos_ref = spos_q if local else torch.randint(0, m, (N, n), generator=gen).to(torch.int32).to(DEV)
-    for _ in range(2):      # accumulating entry point: two calls = twice the gradient
+    for call in range(2):   # overwrite, then accumulate: two calls = twice the gradient
         _lib.check(lib.dicp_accumulate_bwd_window(code, ctypes.byref(P), _ops._p(src_s), _ops._p(tgt_s), c, _ops._p(spos_q), _ops._p(spos_ref),
                                                   _ops._p(qorder), _ops._p(pose), _ops._p(w_s), _ops._p(alive), _ops._p(gs), _ops._p(gb), N, n, m_pad,
-                                                  _ops._p(gsrc_s), _ops._p(slab), _ops._p(gfar), _ops._p(gw_s), _ops._p(part), st),
+                                                  _ops._p(gsrc_s), _ops._p(slab), _ops._p(gfar), _ops._p(gw_s), _ops._p(part), int(call == 0), st),
                    "dicp_accumulate_bwd_window")
-    gsrc, gw, gtgt = torch.zeros_like(src), torch.zeros_like(w0), torch.zeros_like(tgt)
-    _lib.check(lib.dicp_permute_add_rows(code, _ops._p(gsrc_s), _ops._p(qorder), N, n, n, n, 3, 3, _ops._p(gsrc), n, 3, st), "permute")
+    # un-permute: = into garbage (dicp_permute_rows) for the points, += into zeros (dicp_permute_add_rows) for the weights
+    gsrc, gw, gtgt = torch.full_like(src, float("nan")), torch.zeros_like(w0), torch.zeros_like(tgt)
+    _lib.check(lib.dicp_permute_rows(code, _ops._p(gsrc_s), _ops._p(qorder), N, n, n, n, 3, 3, _ops._p(gsrc), n, 3, st), "permute")
     _lib.check(lib.dicp_permute_add_rows(code, _ops._p(gw_s), _ops._p(qorder), N, n, n, n, 1, 1, _ops._p(gw), n, 1, st), "permute")
     _lib.check(lib.dicp_window_reduce(code, _ops._p(slab), _ops._p(spos_ref), _ops._p(qorder), _ops._p(tperm), _ops._p(gfar), N, n, m, m_pad, cv,
                                       _ops._p(gtgt), c, 0, st), "dicp_window_reduce")

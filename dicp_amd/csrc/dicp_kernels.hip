@@ -40,7 +40,10 @@ namespace {
 
 constexpr int BLOCK = 256;
 constexpr int WAVE = 64;
-constexpr int ACC_PTS = 1024;          // source points per accumulate block
+#ifndef DICP_ACC_PTS
+#define DICP_ACC_PTS 1024
+#endif
+constexpr int ACC_PTS = DICP_ACC_PTS;  // source points per accumulate block
 constexpr int KNN_PAD = 64;            // m_pad granularity: 4 MFMA tiles of 16 targets / largest VALU chunk
 
 template <typename T> struct V4;
@@ -1197,16 +1200,36 @@ __global__ __launch_bounds__(BLOCK) void scatter_add_kernel(const T* __restrict_
 
 // -------------------------------------------------------------------- reductions
 // Sum NV per-thread values over the block; thread k < PAD writes slot k of out.
+// The wave step is a reduce-scatter: a lane exchange costs an LDS-crossbar instruction (ds_bpermute), and NV full
+// butterflies (6 NV of them: 174 for the 29 forward sums) made the reduction a fifth of accumulate_kernel's time at
+// 1024 points per block.  Here each exchange also HALVES the values a lane carries -- the lane keeps the half its
+// lane bit selects and adds the partner's copy of that half -- so 32 values take 16+8+4+2+1 exchanges, one more joins
+// the two lanes that end up with the same value: 32 in all, every value summed in one fixed order.
+template <typename T, int H>
+__device__ __forceinline__ void halve_step(T* v, int lane) {      // v[0..2H) -> v[0..H): partner = lane ^ (2H) for H = 16..1
+    const bool up = (lane & (2 * H)) != 0;
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+        const T keep = up ? v[H + k] : v[k];
+        const T give = up ? v[k] : v[H + k];
+        v[k] = keep + __shfl_xor(give, 2 * H);
+    }
+}
 template <typename T, int NV, int PAD>
 __device__ __forceinline__ void block_reduce_store(T* v, T* __restrict__ out, T* lds /* [BLOCK/WAVE][PAD] */) {
+    static_assert(NV <= 32 && PAD >= NV, "reduce-scatter over 32 slots");
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
+    T a[32];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        T x = v[k];
-#pragma unroll
-        for (int off = WAVE / 2; off > 0; off >>= 1) x += __shfl_down(x, off);
-        if (lane == 0) lds[wave * PAD + k] = x;
-    }
+    for (int k = 0; k < 32; ++k) a[k] = k < NV ? v[k] : T(0);
+    halve_step<T, 16>(a, lane);     // lane bit 5 picks the half, ... lane bit 1 the last pair:
+    halve_step<T, 8>(a, lane);      // lane L ends with slot (L >> 1) & 31 in bit order 5,4,3,2,1
+    halve_step<T, 4>(a, lane);
+    halve_step<T, 2>(a, lane);
+    halve_step<T, 1>(a, lane);
+    const T x = a[0] + __shfl_xor(a[0], 1);
+    const int slot = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+    if (!(lane & 1) && slot < NV) lds[wave * PAD + slot] = x;
     __syncthreads();
     if (tid < PAD) {
         T s = T(0);

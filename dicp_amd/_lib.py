@@ -72,6 +72,8 @@ _SIGNATURES = {
     "dicp_accumulate_bwd_window": ([i32, ctypes.POINTER(WeightParams), vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp], ctypes.c_int),
     "dicp_window_reduce": ([i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, i32, vp], ctypes.c_int),
     "dicp_permute_add_rows": ([i32, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp], ctypes.c_int),
+    "dicp_pose_grad_in": ([i32, vp, vp, i32, vp], ctypes.c_int),
+    "dicp_pose_grad_out": ([i32, vp, vp, i32, vp, i32, vp], ctypes.c_int),
     "dicp_permute_rows": ([i32, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp], ctypes.c_int),
     "dicp_gather_rows": ([i32, vp, vp, i32, i32, i32, i32, vp, vp], ctypes.c_int),
     "dicp_scatter_add_rows": ([i32, vp, vp, i32, i32, i32, i32, vp, vp], ctypes.c_int),

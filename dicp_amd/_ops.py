@@ -414,6 +414,7 @@ class ICPLoop(torch.autograd.Function):
         Kmax = int(cfg.max_iterations)
         assert Kmax >= 1, "max_iterations must be at least 1"
         need_grad = any(ctx.needs_input_grad[:4])
+        ctx.set_materialize_grads(False)    # no zero tensors for the six non-differentiable outputs (168 MB for the weights)
 
         with torch.cuda.device(dev):
             st = _stream()
@@ -540,9 +541,9 @@ class ICPLoop(torch.autograd.Function):
         m, c = tgt.shape[1], tgt.shape[2]
         with torch.cuda.device(dev):
             st = _stream()
-            gT = gT.contiguous()
-            gpose = torch.cat((gT[:, :3, :3].reshape(N, 9), gT[:, :3, 3]), dim=1).to(torch.float64).contiguous()
+            gpose = torch.empty((N, 12), dtype=torch.float64, device=dev)
             gtmp = torch.empty_like(gpose)
+            _lib.check(lib.dicp_pose_grad_in(code, _p(gT.contiguous()) if gT is not None else None, _p(gpose), N, st), "dicp_pose_grad_in")
             want_tgt, want_w = ctx.needs_input_grad[1], ctx.needs_input_grad[3]
             cv = 6 if cfg.icp_type == "pt2pl" else 3
             all_windowed = None         # set below: every iteration takes the windowed form -> dicp_window_reduce writes gtgt
@@ -609,8 +610,6 @@ class ICPLoop(torch.autograd.Function):
                 have = 1
                 if (k1 - k0) % 2:           # the library alternates the two buffers: odd chunk -> the result is in the other one
                     gpose, gtmp = gtmp, gpose
-            if have:
-                gpose = gpose + bwdp[form].sum(dim=1)[:, :12].to(torch.float64)
             if any(windowed):               # slot s is source point qo[s]; slabs + out-of-window rows -> original target order
                 permute = lib.dicp_permute_rows if only_windowed else lib.dicp_permute_add_rows
                 _lib.check(permute(code, _p(gsrc_s), _p(qo), N, n, n, n, 3, 3, _p(gsrc), n, 3, st), "dicp_permute_rows")
@@ -619,9 +618,9 @@ class ICPLoop(torch.autograd.Function):
                 if want_tgt:
                     _lib.check(lib.dicp_window_reduce(code, _p(slab), _p(spos_ref), _p(qo), _p(tperm), _p(gfar), N, n, m, m_pad, cv,
                                                       _p(gtgt), c, int(all_windowed), st), "dicp_window_reduce")
-            gT0 = torch.zeros((N, 4, 4), dtype=dt, device=dev)
-            gT0[:, :3, :3] = gpose[:, :9].reshape(N, 3, 3).to(dt)
-            gT0[:, :3, 3] = gpose[:, 9:].to(dt)
+            gT0 = torch.empty((N, 4, 4), dtype=dt, device=dev)      # final gpose + the last launch's pose partials
+            _lib.check(lib.dicp_pose_grad_out(code, _p(gpose), _p(bwdp[form]) if have else None, bwdp[form].shape[1] if have else 0,
+                                              _p(gT0), N, st), "dicp_pose_grad_out")
         return gsrc, gtgt, gT0, gw, None
 
 

@@ -2262,6 +2262,36 @@ __global__ __launch_bounds__(BLOCK) void loss_weight_bwd_kernel(int loss, int di
     for (int k = 0; k < r; ++k) gerr[i * r + k] = (en > T(0)) ? gw[i] * dw * e[k] / en : gw[i] * dw * T(0);
 }
 
+// ------------------------------------------------------- pose gradient in / out of the backward loop
+// gpose (N,12) double = [dL/dC row-major, dL/dr] from the upstream gradient of T (N,4,4) (NULL: zeros), and back:
+// gT0 (N,4,4) = the same layout from the final gpose plus the pose sums of the last accumulate_bwd's partials
+// (slots 0..11 of each block's row; summed in block order, in double) -- the head and tail of ICPLoop.backward in
+// one launch each instead of a dozen tensor ops.
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void pose_grad_in_kernel(const T* __restrict__ gT, double* __restrict__ gpose, int N) {
+    const int e = blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= N * 12) return;
+    const int b = e / 12, k = e - b * 12;
+    const int row = k < 9 ? k / 3 : k - 9, col = k < 9 ? k - (k / 3) * 3 : 3;
+    gpose[e] = gT ? (double)gT[(size_t)b * 16 + row * 4 + col] : 0.0;
+}
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void pose_grad_out_kernel(const double* __restrict__ gpose, const T* __restrict__ bwd_partials, int nblk,
+                                                              T* __restrict__ gT0, int N) {
+    const int e = blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= N * 16) return;
+    const int b = e >> 4, row = (e >> 2) & 3, col = e & 3;
+    T out = T(0);
+    if (row < 3) {
+        const int k = col < 3 ? row * 3 + col : 9 + row;
+        double v = gpose[(size_t)b * 12 + k];
+        if (bwd_partials)
+            for (int blk = 0; blk < nblk; ++blk) v += (double)bwd_partials[((size_t)b * nblk + blk) * NBWD_PAD + k];
+        out = (T)v;
+    }
+    gT0[e] = out;
+}
+
 // ------------------------------------------------------------------- host helpers
 // hipGetLastError() is sticky per host thread and the HIP runtime is shared with PyTorch, which can
 // leave an unrelated error behind: every entry point clears it (begin_launch) before launching and
@@ -2453,6 +2483,30 @@ int dicp_loop_finish(int dtype, const void* pose_K, const void* alive_K, const v
     const unsigned g = blocks_for((size_t)N);
     if (dtype == DICP_F32) loop_finish_kernel<float><<<g, BLOCK, 0, st>>>((const float*)pose_K, (const float*)alive_K, (const float*)n_start, (const float*)n_matched, K, N, (float*)iterations, (float*)matched_ratio, (float*)T_out);
     else                   loop_finish_kernel<double><<<g, BLOCK, 0, st>>>((const double*)pose_K, (const double*)alive_K, (const double*)n_start, (const double*)n_matched, K, N, (double*)iterations, (double*)matched_ratio, (double*)T_out);
+    return launch_status();
+}
+
+int dicp_pose_grad_in(int dtype, const void* gT, double* gpose, int N, void* stream) {
+    if (!gpose) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0) return DICP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    begin_launch();
+    const unsigned g = blocks_for((size_t)N * 12);
+    if (dtype == DICP_F32) pose_grad_in_kernel<float><<<g, BLOCK, 0, st>>>((const float*)gT, gpose, N);
+    else                   pose_grad_in_kernel<double><<<g, BLOCK, 0, st>>>((const double*)gT, gpose, N);
+    return launch_status();
+}
+
+int dicp_pose_grad_out(int dtype, const double* gpose, const void* bwd_partials, int nblk, void* gT0, int N, void* stream) {
+    if (!gpose || !gT0) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0 || (bwd_partials && nblk <= 0)) return DICP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    begin_launch();
+    const unsigned g = blocks_for((size_t)N * 16);
+    if (dtype == DICP_F32) pose_grad_out_kernel<float><<<g, BLOCK, 0, st>>>(gpose, (const float*)bwd_partials, nblk, (float*)gT0, N);
+    else                   pose_grad_out_kernel<double><<<g, BLOCK, 0, st>>>(gpose, (const double*)bwd_partials, nblk, (double*)gT0, N);
     return launch_status();
 }
 

@@ -235,6 +235,13 @@ typedef struct dicp_loop_buffers {
                                 first launch (iteration k1-1) writes them instead of adding; 0 = they are accumulators */
 } dicp_loop_buffers;
 
+/* Head and tail of the backward loop.  dicp_pose_grad_in: gpose (N,12) double = [dL/dC row-major (9), dL/dr (3)] taken from the
+ * upstream gradient gT (N,4,4) of the result T (NULL = zeros).  dicp_pose_grad_out: gT0 (N,4,4) = the same entries of
+ * gpose + the sum over the nblk rows of bwd_partials (N,nblk,DICP_NBWD_PAD) of their pose slots 0..11 (the partials of the
+ * last dicp_accumulate_bwd* launch, not yet folded in; NULL = none), bottom row 0: the gradient w.r.t. T_init. */
+int dicp_pose_grad_in(int dtype, const void* gT, double* gpose, int N, void* stream);
+int dicp_pose_grad_out(int dtype, const double* gpose, const void* bwd_partials, int nblk, void* gT0, int N, void* stream);
+
 /* Loop state before iteration 0 (ICP.py:124-129): pose0 (N,12) from T_init (N,4,4), alive0 (N) = 1,
  * n_start (N) = rows * #(w0 > thresh), rows = 3 for pt2pt, 1 for pt2pl.  And after the last executed iteration K
  * (ICP.py:267-281): iterations / matched_ratio of clouds that never converged, T_out (N,4,4) from pose_K. */

@@ -46,7 +46,8 @@ for r in seg:
     a = agg.setdefault(nm, [0, 0.0])
     a[0] += 1; a[1] += (e - s) / 1e3
     if "--full" in sys.argv:
-        print("%9.1f us  dur %8.1f  gap %7.1f  %s" % ((s - t0) / 1e3, (e - s) / 1e3, gap, nm))
+        grid = "x".join(r.get(k, "?") for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z") if r.get(k, "1") != "1") or "1"
+        print("%9.1f us  dur %8.1f  gap %7.1f  %-36s threads %s" % ((s - t0) / 1e3, (e - s) / 1e3, gap, nm, grid))
     prev = max(prev or 0, e)
 span = (prev - t0) / 1e3
 print("timed call: %.1f us from first to last kernel, %d kernels, idle gaps %.1f us" % (span, len(seg), gaps))

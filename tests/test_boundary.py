@@ -99,6 +99,8 @@ def test_new_entry_points_reject_bad_arguments(lib):
     assert lib.dicp_window_reduce(0, one, one, None, one, None, 1, 1, 1, 64, 6, one, 3, 0, None) == 2
     assert lib.dicp_permute_add_rows(0, one, one, 1, 2, 1, 2, 3, 3, one, 4, 3, None) == 2
     assert lib.dicp_permute_rows(0, one, one, 1, 2, 1, 2, 3, 3, one, 4, 3, None) == 2
+    assert lib.dicp_pose_grad_in(0, None, None, 1, None) == 1 and lib.dicp_pose_grad_in(7, None, one, 1, None) == 3
+    assert lib.dicp_pose_grad_out(0, one, one, 0, one, 1, None) == 2 and lib.dicp_pose_grad_out(0, one, None, 0, None, 1, None) == 1
     assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, 1, 1, 1, 64, one, None, None, 99, None) == 4
     assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, 1, 1, 1, 64, one, None, None, 8 | 0x100, None) == 1  # sorted rows need the order
     assert lib.dicp_knn_sweep_accumulate(0, ctypes.byref(P), one, None, one, one, None, one, one, 1024, one, 6, one, None, 1, 1, 1, 64,

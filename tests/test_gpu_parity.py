@@ -1202,3 +1202,34 @@ def test_sweep_sort_is_the_stable_torch_sort(m, c):
         _ops.NATIVE_SORT = old
     for name in ("keys", "tgs4", "tperm", "bucket", "brange"):
         assert torch.equal(getattr(a, name), getattr(b, name)), name
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_pose_grad_in_out_kernels(dtype):
+    """dicp_pose_grad_in / dicp_pose_grad_out (head and tail of ICPLoop.backward) against the tensor expressions
+    they replace: gpose = [gT[:, :3, :3].ravel, gT[:, :3, 3]] in double; gT0 = the same layout from gpose + the summed
+    pose slots of the last launch's partials, bottom row zero."""
+    from dicp_amd import _ops, _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    N, nblk = 37, 5
+    code = _lib.F32 if dtype == torch.float32 else _lib.F64
+    gT = torch.randn((N, 4, 4), generator=g, dtype=dtype).to(DEV)
+    gpose = torch.full((N, 12), float("nan"), dtype=torch.float64, device=DEV)
+    st = _ops._stream()
+    _lib.check(lib.dicp_pose_grad_in(code, _ops._p(gT), _ops._p(gpose), N, st), "in")
+    ref = torch.cat((gT[:, :3, :3].reshape(N, 9), gT[:, :3, 3]), dim=1).to(torch.float64)
+    assert torch.equal(gpose, ref)
+    _lib.check(lib.dicp_pose_grad_in(code, None, _ops._p(gpose), N, st), "in")
+    assert float(gpose.abs().max()) == 0.0
+    gpose = torch.randn((N, 12), generator=g, dtype=torch.float64).to(DEV)
+    part = torch.randn((N, nblk, _lib.NBWD_PAD), generator=g, dtype=dtype).to(DEV)
+    for p_, nb in ((part, nblk), (None, 0)):
+        out = torch.full((N, 4, 4), float("nan"), dtype=dtype, device=DEV)
+        _lib.check(lib.dicp_pose_grad_out(code, _ops._p(gpose), _ops._p(p_), nb, _ops._p(out), N, st), "out")
+        tot = gpose + (p_.to(torch.float64).sum(dim=1)[:, :12] if p_ is not None else 0.0)
+        want = torch.zeros((N, 4, 4), dtype=torch.float64, device=DEV)
+        want[:, :3, :3] = tot[:, :9].reshape(N, 3, 3)
+        want[:, :3, 3] = tot[:, 9:]
+        assert float((out.to(torch.float64) - want).abs().max()) <= (1e-6 if dtype == torch.float32 else 1e-14)
+        assert float(out[:, 3].abs().max()) == 0.0

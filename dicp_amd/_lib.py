@@ -59,7 +59,7 @@ _SIGNATURES = {
     "dicp_knn_sweep": ([i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp], ctypes.c_int),
     "dicp_window_blocks": ([i32, i32, i32], ctypes.c_int),
     "dicp_window_rows": ([i32], ctypes.c_int),
-    "dicp_sweep_sort": ([i32, vp, i32, i32, i32, i32, vp, vp, vp], ctypes.c_int),
+    "dicp_sweep_sort": ([i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp], ctypes.c_int),
     "dicp_sweep_build": ([i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp], ctypes.c_int),
     "dicp_sweep_partials": ([i32, i32, i32], ctypes.c_int),
     "dicp_loop_partial_blocks": ([i32, i32], ctypes.c_int),

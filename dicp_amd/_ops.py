@@ -96,21 +96,24 @@ class SweepIndex:
         m_pad = lib.dicp_padded_targets(m)
         self.tgs4 = torch.empty((N, m_pad, 4), dtype=dt, device=dev)
         self.tperm = torch.empty((N, m_pad), dtype=torch.int32, device=dev)
-        if dt == torch.float32 and m_pad <= 16384 and NATIVE_SORT:
-            # the stable sort of the x keys in LDS (dicp_sweep_sort): same keys and permutation as torch.sort(stable=True)
+        self.bucket = torch.empty((N, self.NBKT + 1), dtype=torch.int32, device=dev)
+        self.brange = torch.empty((N, 2), dtype=dt, device=dev)
+        native = dt == torch.float32 and m_pad <= 16384 and NATIVE_SORT
+        if native:
+            # the stable sort of the x keys in LDS (dicp_sweep_sort): same keys and permutation as torch.sort(stable=True),
+            # and the bucket table while the keys are there
             keys, order = torch.empty((N, m_pad), dtype=dt, device=dev), None
             with torch.cuda.device(dev):
-                _lib.check(lib.dicp_sweep_sort(_DT[dt], _p(tgt), c, N, m, m_pad, _p(keys), _p(self.tperm), _stream()), "dicp_sweep_sort")
+                _lib.check(lib.dicp_sweep_sort(_DT[dt], _p(tgt), c, N, m, m_pad, _p(keys), _p(self.tperm), self.NBKT, _p(self.bucket),
+                                               _p(self.brange), _stream()), "dicp_sweep_sort")
         else:
             key = torch.full((N, m_pad), torch.finfo(dt).max, dtype=dt, device=dev)   # pad slots sort last
             key[:, :m] = tgt[:, :, 0]
             keys, order = torch.sort(key, dim=1, stable=True)
         self.keys = keys                                         # sorted x keys (N,m_pad): the rank search of query_order reads them
-        self.bucket = torch.empty((N, self.NBKT + 1), dtype=torch.int32, device=dev)
-        self.brange = torch.empty((N, 2), dtype=dt, device=dev)
         self.tgt_s = torch.empty((N, m_pad, c), dtype=dt, device=dev) if sorted_rows else None
         with torch.cuda.device(dev):
-            _lib.check(lib.dicp_sweep_build(_DT[dt], _p(tgt), c, _p(order), _p(keys), N, m, m_pad, self.NBKT, _p(self.tgs4), _p(self.tperm),
+            _lib.check(lib.dicp_sweep_build(_DT[dt], _p(tgt), c, _p(order), None if native else _p(keys), N, m, m_pad, self.NBKT, _p(self.tgs4), _p(self.tperm),
                                             _p(self.bucket), _p(self.brange), _p(self.tgt_s), _stream()), "dicp_sweep_build")
         self.pair_shards = torch.zeros((_lib.PAIR_SHARDS,), dtype=torch.int64, device=dev)
 

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(BLOCK) void sweep_buckets_kernel(const T* __restric
     const T* __restrict__ xs = keys + (size_t)cloud * m_pad;
     const T xlo = xs[0], span = xs[m - 1] - xlo;
     for (int b = threadIdx.x; b <= nbkt; b += BLOCK) {
-        const T edge = xlo + T(b) * (span / T(nbkt));
+        const T edge = fma_t(T(b), span / T(nbkt), xlo);    // (explicit fma: dicp_sweep_sort builds the same table from LDS)
         int lo = 0, hi = m;
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (xs[mid] < edge) lo = mid + 1; else hi = mid; }
         bucket[(size_t)cloud * (nbkt + 1) + b] = lo;
@@ -191,8 +191,14 @@ __global__ __launch_bounds__(BLOCK) void sweep_buckets_kernel(const T* __restric
 // into offsets.  Keys and indices stay in registers between passes; one LDS buffer (written at the new positions, read
 // back in the striped order) is all the exchange space it takes.
 constexpr int RS_THREADS = 1024, RS_PER = 16, RS_MAX = RS_THREADS * RS_PER;
+__device__ __forceinline__ unsigned sortable_bits(float x) {      // order-preserving map float -> unsigned
+    unsigned u = __float_as_uint(x + 0.0f);                        // -0 sorts as +0 (they compare equal; index order decides)
+    u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;
+    return x != x ? 0xffffffffu : u;                               // NaN of either sign sorts last, as torch.sort has it
+}
 __global__ __launch_bounds__(RS_THREADS) void sort_keys_kernel(const float* __restrict__ tgt, int c, int N, int m, int m_pad,
-                                                               float* __restrict__ keys_sorted, int32_t* __restrict__ tperm) {
+                                                               float* __restrict__ keys_sorted, int32_t* __restrict__ tperm,
+                                                               int nbkt, int32_t* __restrict__ bucket, float* __restrict__ brange) {
     __shared__ unsigned skey[RS_MAX];
     __shared__ unsigned short sidx[RS_MAX];
     __shared__ int cnt[RS_THREADS / WAVE][256];             // per wave, per digit: running count, then offset
@@ -206,10 +212,7 @@ __global__ __launch_bounds__(RS_THREADS) void sort_keys_kernel(const float* __re
         const int pos = wave * (WAVE * RS_PER) + e * WAVE + lane;
         unsigned u = 0xffffffffu;                           // beyond m_pad: sentinel, sorts after everything
         if (pos < m_pad) {
-            const float x = pos < m ? rows[(size_t)pos * c] : 3.402823466e+38f;
-            u = __float_as_uint(x + 0.0f);                  // -0 sorts as +0 (they compare equal; index order decides)
-            u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;     // order-preserving map float -> unsigned
-            if (x != x) u = 0xffffffffu;                    // NaN of either sign sorts last, as torch.sort has it
+            u = sortable_bits(pos < m ? rows[(size_t)pos * c] : 3.402823466e+38f);
         }
         key[e] = u;
         idx[e] = (unsigned short)pos;
@@ -279,6 +282,21 @@ __global__ __launch_bounds__(RS_THREADS) void sort_keys_kernel(const float* __re
             u ^= (u >> 31) ? 0x80000000u : 0xffffffffu;
             keys_sorted[(size_t)cloud * m_pad + pos] = __uint_as_float(u);
             tperm[(size_t)cloud * m_pad + pos] = (int32_t)idx[e];
+        }
+    }
+    // the sweep's bucket table (what sweep_buckets_kernel computes from global memory) while the sorted keys are in LDS
+    if (bucket) {
+        auto key_at = [&](int i) { unsigned u = skey[i]; u ^= (u >> 31) ? 0x80000000u : 0xffffffffu; return __uint_as_float(u); };
+        const float xlo = key_at(0), span = key_at(m - 1) - xlo;
+        for (int b = tid; b <= nbkt; b += RS_THREADS) {
+            const unsigned edge = sortable_bits(fma_t(float(b), span / float(nbkt), xlo));
+            int lo = 0, hi = m;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (skey[mid] < edge) lo = mid + 1; else hi = mid; }
+            bucket[(size_t)cloud * (nbkt + 1) + b] = lo;
+        }
+        if (tid == 0) {
+            brange[(size_t)cloud * 2] = xlo;
+            brange[(size_t)cloud * 2 + 1] = span > 0.f ? float(nbkt) / span : 0.f;
         }
     }
 }
@@ -2403,18 +2421,21 @@ int dicp_pack_target(int dtype, const void* tgt, int N, int m, int c, void* tgt4
     return launch_status();
 }
 
-int dicp_sweep_sort(int dtype, const void* tgt, int c, int N, int m, int m_pad, void* keys_sorted, int32_t* tperm, void* stream) {
-    if (!tgt || !keys_sorted || !tperm) return DICP_ERR_NULL;
+int dicp_sweep_sort(int dtype, const void* tgt, int c, int N, int m, int m_pad, void* keys_sorted, int32_t* tperm,
+                    int nbkt, int32_t* bucket, void* brange, void* stream) {
+    if (!tgt || !keys_sorted || !tperm || (bucket && !brange)) return DICP_ERR_NULL;
+    if (bucket && nbkt <= 0) return DICP_ERR_SHAPE;
     if (dtype != DICP_F32) return DICP_ERR_DTYPE;          // float keys; float64 clouds and more than 16384 targets: sort on the caller's side
     if (N <= 0 || m <= 0 || (c != 3 && c != 6) || m_pad != dicp_padded_targets(m) || m_pad > RS_MAX) return DICP_ERR_SHAPE;
     begin_launch();
-    sort_keys_kernel<<<N, RS_THREADS, 0, (hipStream_t)stream>>>((const float*)tgt, c, N, m, m_pad, (float*)keys_sorted, tperm);
+    sort_keys_kernel<<<N, RS_THREADS, 0, (hipStream_t)stream>>>((const float*)tgt, c, N, m, m_pad, (float*)keys_sorted, tperm, nbkt, bucket, (float*)brange);
     return launch_status();
 }
 
 int dicp_sweep_build(int dtype, const void* tgt, int c, const int64_t* order, const void* keys_sorted, int N, int m, int m_pad, int nbkt,
                      void* tgs4, int32_t* tperm, int32_t* bucket, void* brange, void* tgt_s, void* stream) {
-    if (!tgt || !keys_sorted || !tgs4 || !tperm || !bucket || !brange) return DICP_ERR_NULL;      // order == NULL: tperm holds it
+    // order == NULL: tperm holds the permutation.  keys_sorted == NULL: bucket / brange are already filled (dicp_sweep_sort)
+    if (!tgt || !tgs4 || !tperm || !bucket || !brange) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || m <= 0 || (c != 3 && c != 6) || nbkt <= 0 || m_pad != dicp_padded_targets(m)) return DICP_ERR_SHAPE;
     if ((uintptr_t)tgs4 % (dtype == DICP_F32 ? 16 : 32)) return DICP_ERR_ALIGN;
@@ -2424,10 +2445,10 @@ int dicp_sweep_build(int dtype, const void* tgt, int c, const int64_t* order, co
     const unsigned g = grid_for(N, bpc);
     if (dtype == DICP_F32) {
         sweep_rows_kernel<float><<<g, BLOCK, 0, st>>>((const float*)tgt, order, N, m, c, m_pad, bpc, (float4*)tgs4, tperm, (float*)tgt_s);
-        sweep_buckets_kernel<float><<<N, BLOCK, 0, st>>>((const float*)keys_sorted, N, m, m_pad, nbkt, bucket, (float*)brange);
+        if (keys_sorted) sweep_buckets_kernel<float><<<N, BLOCK, 0, st>>>((const float*)keys_sorted, N, m, m_pad, nbkt, bucket, (float*)brange);
     } else {
         sweep_rows_kernel<double><<<g, BLOCK, 0, st>>>((const double*)tgt, order, N, m, c, m_pad, bpc, (double4*)tgs4, tperm, (double*)tgt_s);
-        sweep_buckets_kernel<double><<<N, BLOCK, 0, st>>>((const double*)keys_sorted, N, m, m_pad, nbkt, bucket, (double*)brange);
+        if (keys_sorted) sweep_buckets_kernel<double><<<N, BLOCK, 0, st>>>((const double*)keys_sorted, N, m, m_pad, nbkt, bucket, (double*)brange);
     }
     return launch_status();
 }

@@ -76,8 +76,11 @@ int dicp_knn(int dtype, const void* src, const void* pose, const void* tgt4, int
  *      optional tgt_s (N,m_pad,c) = the full target rows in sorted order (what dicp_accumulate_bwd_window reads). */
 /* The sort itself, for float32 clouds of up to 16384 targets (m_pad <= 16384): keys_sorted (N,m_pad) and tperm (N,m_pad)
  * as a stable ascending sort of the target x keys gives them (an LDS radix sort, one block per cloud).  Then pass
- * order = NULL to dicp_sweep_build: it reads the permutation from tperm. */
-int dicp_sweep_sort(int dtype, const void* tgt, int c, int N, int m, int m_pad, void* keys_sorted, int32_t* tperm, void* stream);
+ * order = NULL to dicp_sweep_build: it reads the permutation from tperm.  Given bucket (N,nbkt+1) and brange (N,2) it
+ * also builds the bucket table while the sorted keys are in LDS; dicp_sweep_build is then told so with
+ * keys_sorted = NULL and leaves the table alone. */
+int dicp_sweep_sort(int dtype, const void* tgt, int c, int N, int m, int m_pad, void* keys_sorted, int32_t* tperm,
+                    int nbkt, int32_t* bucket, void* brange, void* stream);
 int dicp_sweep_build(int dtype, const void* tgt, int c, const int64_t* order, const void* keys_sorted, int N, int m, int m_pad, int nbkt,
                      void* tgs4, int32_t* tperm, int32_t* bucket, void* brange, void* tgt_s, void* stream);
 /* keys (N,n) = x coordinate of every source point under pose (NULL = identity): the sort key of the query order. */

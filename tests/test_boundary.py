@@ -80,10 +80,11 @@ def test_new_entry_points_reject_bad_arguments(lib):
     assert lib.dicp_sweep_build(0, None, 3, one, one, 1, 1, 64, 1024, one, one, one, one, None, None) == 1
     assert lib.dicp_sweep_build(0, one, 4, one, one, 1, 1, 64, 1024, one, one, one, one, None, None) == 2
     assert lib.dicp_sweep_build(0, one, 3, one, one, 1, 1, 64, 1024, ctypes.c_void_p(8), one, one, one, None, None) == 5
-    assert lib.dicp_sweep_sort(0, None, 3, 1, 1, 64, one, one, None) == 1
-    assert lib.dicp_sweep_sort(1, one, 3, 1, 1, 64, one, one, None) == 3                 # float keys only
-    assert lib.dicp_sweep_sort(0, one, 3, 1, 16385, 16448, one, one, None) == 2          # beyond the LDS sort
-    assert lib.dicp_sweep_sort(0, one, 3, 1, 5, 128, one, one, None) == 2                # not the padded size
+    assert lib.dicp_sweep_sort(0, None, 3, 1, 1, 64, one, one, 0, None, None, None) == 1
+    assert lib.dicp_sweep_sort(1, one, 3, 1, 1, 64, one, one, 0, None, None, None) == 3                 # float keys only
+    assert lib.dicp_sweep_sort(0, one, 3, 1, 16385, 16448, one, one, 0, None, None, None) == 2          # beyond the LDS sort
+    assert lib.dicp_sweep_sort(0, one, 3, 1, 5, 128, one, one, 0, None, None, None) == 2                # not the padded size
+    assert lib.dicp_sweep_sort(0, one, 3, 1, 5, 64, one, one, 1024, one, None, None) == 1   # a table needs its range too
     assert lib.dicp_query_order(0, one, None, None, 1024, 1, 1, one, None, None, None, 0, None, 0, None, None, 0, None) == 1
     assert lib.dicp_query_order(9, one, None, one, 1024, 1, 1, one, None, None, None, 0, None, 0, None, None, 0, None) == 3
     assert lib.dicp_query_order(0, one, None, one, 1024, 1, 1, one, None, None, None, 0, None, 0, one, one, 0, None) == 2      # keys without m

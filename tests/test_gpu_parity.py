@@ -1176,7 +1176,7 @@ def test_sweep_sort_is_the_stable_torch_sort(m, c):
     ref_keys, ref_order = torch.sort(key, dim=1, stable=True)
     keys = torch.empty((N, m_pad), device="cuda")
     perm = torch.empty((N, m_pad), dtype=torch.int32, device="cuda")
-    _lib.check(lib.dicp_sweep_sort(_lib.F32, _ops._p(tgt), c, N, m, m_pad, _ops._p(keys), _ops._p(perm), _ops._stream()), "sort")
+    _lib.check(lib.dicp_sweep_sort(_lib.F32, _ops._p(tgt), c, N, m, m_pad, _ops._p(keys), _ops._p(perm), 0, None, None, _ops._stream()), "sort")
     plain = [0, 1, 2, 4] if m >= 64 else list(range(N))                               # row 3 holds the special values
     assert torch.equal(perm.long()[plain], ref_order[plain])
     assert torch.equal(keys[plain], ref_keys[plain])

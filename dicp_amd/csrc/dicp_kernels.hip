@@ -793,6 +793,11 @@ __device__ __forceinline__ void block_reduce_store(T* v, T* __restrict__ out, T*
 // accumulate_kernel does (residual, weights, Jacobian, normal-equation sums; ICP.py:143-201) -- the query, its pose and
 // the winner are in hand, so one pass over the points (and one launch) per iteration disappears.  The partials
 // then follow the search's waves: (N, units of this launch, NACC_PAD).
+// Launch configuration of the tile sweep, measured at the benchmark shape (profiles/r01_sweep_configs_ab.txt): 2 queries per
+// lane with 8-row chunks wins at every iteration once the per-chunk bookkeeping is three lane operations, and it wants
+// registers rather than occupancy: 5 waves/SIMD (96 VGPRs, no scratch) beats 6 (80 VGPRs: the tie state spills).
+constexpr int SWEEP_CFG_BIG = 2;            // (Q, CH) = (2, 8)
+constexpr int SWEEP_MINW_Q2C8 = 5;
 constexpr int MODE_SEARCH_ONLY = -1;
 template <typename T> struct FusedAcc {
     WeightParams P;
@@ -803,7 +808,7 @@ template <typename T> struct FusedAcc {
 };
 
 template <typename T, int Q, int CH, int MODE>
-__global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? 6 : 1) void knn_sweep_kernel(const T* __restrict__ src, const T* __restrict__ pose,
+__global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? SWEEP_MINW_Q2C8 : 1) void knn_sweep_kernel(const T* __restrict__ src, const T* __restrict__ pose,
                                                           const typename V4<T>::type* __restrict__ tgs4,
                                                           const int32_t* __restrict__ tperm, const int32_t* __restrict__ qorder,
                                                           const int32_t* __restrict__ bucket, const T* __restrict__ brange, int nbkt,
@@ -822,9 +827,11 @@ __global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? 6 : 
     load_pose(pose, cloud, C, r);
     T4* tile = tiles[wave];
 
-    T nx[Q][3], xq[Q], hx[Q], best[Q], thr[Q];
+    T nx[Q][3], xq[Q], hx[Q], best[Q];
     int qi[Q], mi[Q], c1[Q], c2[Q];   // c1: chunk that set the minimum; c2: a second chunk with an EQUAL minimum; mi: the match
-    bool over[Q];                     // three or more chunks tied: resolved by re-scanning the visited range
+    T tb[Q], ob[Q];                   // tie records carry the minimum they were made at and count only if it is still the
+                                      // final one (nothing to reset when the minimum moves): tb for c2; ob: three or more
+                                      // chunks tied, resolved by re-scanning the visited range
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         const int pos = unit * (WAVE * Q) + q * WAVE + lane;
@@ -839,9 +846,9 @@ __global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? 6 : 
         const T v[3] = {-nx[q][0], -nx[q][1], -nx[q][2]};
         xq[q] = v[0];
         hx[q] = T(0.5) * (v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-        best[q] = thr[q] = inf_v<T>();
+        best[q] = inf_v<T>();
         c1[q] = 0; c2[q] = -1;
-        over[q] = false;
+        tb[q] = ob[q] = -inf_v<T>();
     }
     // idle slots of a partial last wave take a real query's values (their own first one, else lane 0's:
     // lane 0 of a live wave always holds a real query) so that they never hold the sweep open
@@ -891,17 +898,20 @@ __global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? 6 : 
                 T cm = score<T, T4>(nx[q], y[0]);
 #pragma unroll
                 for (int k = 1; k < CH; ++k) cm = min_t(cm, score<T, T4>(nx[q], y[k]));
-                // most chunks change nobody's minimum: the bookkeeping sits behind ONE wave-uniform branch
-                // (written out inline it was a quarter of this loop's instructions)
-                if (__any(cm <= best[q])) {
-                    const bool lt = cm < best[q];
-                    const bool eq = (cm == best[q]) && (cm < inf_v<T>());
-                    over[q] = lt ? false : (over[q] || (eq && c2[q] >= 0));
-                    c2[q] = lt ? -1 : ((eq && c2[q] < 0) ? chunk : c2[q]);
-                    c1[q] = lt ? chunk : c1[q];
-                    best[q] = lt ? cm : best[q];
-                    thr[q] = best[q] + SweepEps<T>::v * (T(1) + m_abs(best[q]) + hx[q]);      // the prune threshold moves with it
+                // common path: compare, select the chunk, min -- three lane operations.  With 64 lanes a chunk lowers
+                // SOMEBODY's minimum most of the time near the pose, so a wave-uniform "anything changed?" branch around
+                // a longer update was taken almost always; only exact ties (duplicated targets) are rare, and they alone
+                // sit behind the wave-uniform branch.  The prune threshold is derived from best where it is used.
+                if (__builtin_expect(__any(cm == best[q]) != 0, 0)) {
+                    asm volatile("" ::: "memory");          // keep this a real (wave-uniform) branch, not predicated code
+                    if (cm == best[q] && cm < inf_v<T>()) {
+                        if (c2[q] >= 0 && tb[q] == best[q]) ob[q] = best[q];
+                        else { c2[q] = chunk; tb[q] = best[q]; }
+                    }
                 }
+                const bool lt = cm < best[q];
+                c1[q] = lt ? chunk : c1[q];
+                best[q] = lt ? cm : best[q];
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -912,7 +922,8 @@ __global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? 6 : 
         for (int q = 0; q < Q; ++q) {
             const T dx = right ? edge - xq[q] : xq[q] - edge;
             const T lb = T(0.5) * dx * dx - hx[q];
-            ok = ok && (dx > T(0)) && (lb > thr[q]);       // thr = best + margin, kept up to date where best changes
+            const T thr = best[q] + SweepEps<T>::v * (T(1) + m_abs(best[q]) + hx[q]);      // best + margin
+            ok = ok && (dx > T(0)) && (lb > thr);
         }
         return __all(ok) != 0;
     };
@@ -955,10 +966,10 @@ __global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? 6 : 
                 if (o < bo) { bo = o; bs = j; }
             }
         };
-        if (!over[q]) {
+        if (ob[q] != best[q]) {
 #pragma unroll
             for (int k = 0; k < CH; ++k) consider(c1[q] + k);
-            if (c2[q] >= 0) {
+            if (c2[q] >= 0 && tb[q] == best[q]) {
 #pragma unroll
                 for (int k = 0; k < CH; ++k) consider(c2[q] + k);
             }
@@ -2554,7 +2565,7 @@ static int sweep_queries_per_lane(int dtype, int cfg) {
     }
     switch (cfg) { case 1: case 4: return 1; case 2: case 5: case 7: case 8: return 2; case 3: case 6: return 4; default: return 0; }
 }
-static int sweep_auto_cfg(int N, int n) { return ((long)N * n >= 2L * BLOCK * 1024) ? 8 : 4; }   // 3 (else 1) queries per lane, 16-target chunks
+static int sweep_auto_cfg(int N, int n) { return ((long)N * n >= 2L * BLOCK * 1024) ? SWEEP_CFG_BIG : 4; }   // 2 queries per lane / 8-row chunks, small problems 1 / 16
 
 int dicp_sweep_partials(int dtype, int n, int cfg) {      // waves per cloud of a tile-sweep configuration
     const int Q = sweep_queries_per_lane(dtype, cfg);
@@ -2992,9 +3003,6 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
             const bool fuse = (B->knn_variant >> 24) & 1;
             int cfg = (B->knn_variant >> 8) & 0xff;
             if (cfg == 0 && scan_from > 0 && k >= scan_from) cfg = DICP_SWEEP_SCAN;
-            // auto: once the pose is close the slabs are a few tiles and the 2-queries-per-lane / 8-row-chunk form wins
-            // (0.195 vs 0.222 ms at the benchmark shape); the first iterations keep 3 queries per lane / 16-row chunks
-            if (cfg == 0 && k >= 2 && (long)N * n >= 2L * BLOCK * 1024) cfg = 2;
             if (cfg == 0) cfg = sweep_auto_cfg(N, n);
             int32_t* spos_k = B->spos ? B->spos + (size_t)k * N * n : nullptr;
             // src_s: the source rows in qorder's slot order (dicp_query_order wrote them): coalesced query loads

@@ -32,8 +32,11 @@ first = knn[-13] if len(knn) >= 13 else knn[0]      # 10 timed launches + 3 brut
 lo = first
 while lo > 0 and first - lo < 80 and int(rows[lo]["Start_Timestamp"]) - int(rows[lo - 1]["End_Timestamp"]) < 90_000:
     lo -= 1
-hi = max(i for i, r in enumerate(rows) if "window_reduce" in r["Kernel_Name"] or "accumulate_bwd" in r["Kernel_Name"]) + 6
-seg = rows[lo:min(hi, len(rows))]
+# ... and ends at the first idle gap after its backward (the host synchronises there; later legs of bench.py follow)
+hi = first
+while hi + 1 < len(rows) and int(rows[hi + 1]["Start_Timestamp"]) - int(rows[hi]["End_Timestamp"]) < 200_000:
+    hi += 1
+seg = rows[lo:hi + 1]
 t0 = int(seg[0]["Start_Timestamp"])
 agg = collections.OrderedDict()
 prev = None

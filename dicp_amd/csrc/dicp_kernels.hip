@@ -816,7 +816,10 @@ __global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? SWEE
                                                           unsigned long long* __restrict__ pairs,
                                                           int N, int n, int m, int m_pad, int bpc, int src_sorted, FusedAcc<T> F) {
     using T4 = typename V4<T>::type;
-    __shared__ T4 tiles[BLOCK / WAVE][WAVE];
+    // each wave keeps the last NT tiles it scored in a ring: near the pose that is the whole visited range, and the
+    // epilogue then re-scores the winning chunk out of LDS instead of gathering its rows (Q x CH 16-byte gathers per lane)
+    constexpr int NT = sizeof(T) == 4 ? 6 : 3;
+    __shared__ T4 tiles[BLOCK / WAVE][NT * WAVE];
     int cloud, blk;
     if (!decode_block(bpc, N, cloud, blk)) return;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
@@ -825,7 +828,7 @@ __global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? SWEE
     if (idle_wave) return;                                  // whole wave idle (no block-level sync anywhere below)
     T C[9], r[3];
     load_pose(pose, cloud, C, r);
-    T4* tile = tiles[wave];
+    T4* ring = tiles[wave];
 
     T nx[Q][3], xq[Q], hx[Q], best[Q];
     int qi[Q], mi[Q], c1[Q], c2[Q];   // c1: chunk that set the minimum; c2: a second chunk with an EQUAL minimum; mi: the match
@@ -879,12 +882,15 @@ __global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? SWEE
     int tR = min(max(start / WAVE, 0), ntiles - 1), tL = tR - 1;
     if (idle_wave) { tR = ntiles; tL = -1; }
     int visR = tR, visL = tR;                               // tiles [visL, visR) have been scored
+    const int t0 = tR;                                      // tile t sits in ring slot (t - t0) mod NT
+    int sR = 0, sL = NT - 1;
     T edgeR = -inf_v<T>(), edgeL = inf_v<T>();
     // both directions keep their next tile in flight while the current one is being scored
     T4 preR = tg[(size_t)tR * WAVE + lane];
     T4 preL = tg[(size_t)max(tL, 0) * WAVE + lane];
 
-    auto process = [&](const T4& mine, int t) {
+    auto process = [&](const T4& mine, int t, int slot) {
+        T4* tile = ring + slot * WAVE;
         tile[lane] = mine;
         __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
@@ -934,7 +940,8 @@ __global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? SWEE
             else {
                 const T4 cur = preR;
                 if (tR + 1 < ntiles) preR = tg[(size_t)(tR + 1) * WAVE + lane];
-                process(cur, tR);
+                process(cur, tR, sR);
+                sR = sR + 1 == NT ? 0 : sR + 1;
                 edgeR = __shfl(cur.x, WAVE - 1);
                 visR = ++tR;
             }
@@ -944,7 +951,8 @@ __global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? SWEE
             else {
                 const T4 cur = preL;
                 if (tL >= 1) preL = tg[(size_t)(tL - 1) * WAVE + lane];
-                process(cur, tL);
+                process(cur, tL, sL);
+                sL = sL == 0 ? NT - 1 : sL - 1;
                 edgeL = __shfl(cur.x, 0);
                 visL = tL--;
             }
@@ -957,8 +965,8 @@ __global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? SWEE
         if (qi[q] < 0) continue;
         T bv = inf_v<T>();
         int bo = 0x7fffffff, bs = 0;
-        auto consider = [&](int j) {                        // lowest ORIGINAL index among equal scores; the permutation
-            const T sc = score<T, T4>(nx[q], tg[j]);        // is only read for the winner and on (rare) exact ties
+        auto consider = [&](int j, const T4& row) {          // lowest ORIGINAL index among equal scores; the permutation
+            const T sc = score<T, T4>(nx[q], row);          // is only read for the winner and on (rare) exact ties
             if (sc < bv) { bv = sc; bs = j; bo = -1; }
             else if (sc == bv && sc < inf_v<T>()) {
                 if (bo < 0) bo = pm[bs];
@@ -966,16 +974,24 @@ __global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? SWEE
                 if (o < bo) { bo = o; bs = j; }
             }
         };
-        if (ob[q] != best[q]) {
+        auto consider_chunk = [&](int c) {
+            const int t = c >> 6;
+            // still in the ring: visited, and neither t + NT nor t - NT was scored (either would have taken its slot)
+            if (t >= visL && t < visR && t + NT >= visR && t - NT < visL) {
+                const T4* rp = ring + ((unsigned)(t - t0 + NT * (1 << 24)) % NT) * WAVE + (c & (WAVE - 1));
 #pragma unroll
-            for (int k = 0; k < CH; ++k) consider(c1[q] + k);
-            if (c2[q] >= 0 && tb[q] == best[q]) {
+                for (int k = 0; k < CH; ++k) consider(c + k, rp[k]);
+            } else {
 #pragma unroll
-                for (int k = 0; k < CH; ++k) consider(c2[q] + k);
+                for (int k = 0; k < CH; ++k) consider(c + k, tg[c + k]);
             }
+        };
+        if (ob[q] != best[q]) {
+            consider_chunk(c1[q]);
+            if (c2[q] >= 0 && tb[q] == best[q]) consider_chunk(c2[q]);
         } else {
             // >= 3 chunks share the minimum (duplicated targets): rare, re-scan what this wave visited
-            for (int j = visL * WAVE; j < visR * WAVE; ++j) consider(j);
+            for (int j = visL * WAVE; j < visR * WAVE; ++j) consider(j, tg[j]);
         }
         if (bo < 0) bo = pm[bs];                            // (0x7fffffff: nothing finite was seen)
         mi[q] = (bo == 0x7fffffff) ? 0 : min(max(bo, 0), m - 1);

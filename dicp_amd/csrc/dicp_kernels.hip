@@ -783,7 +783,12 @@ __global__ __launch_bounds__(BLOCK) void knn_mfma_kernel(const float* __restrict
 // target can never beat the kept minimum; exact score ties (duplicates) are detected and resolved to the
 // lowest ORIGINAL index by a rare re-scan of the visited range.
 template <typename T> struct SweepEps;
-template <> struct SweepEps<float>  { static constexpr float  v = 1e-5f; };   // ~10x the worst-case rounding of two f32 scores
+// How large the margin has to be (u = 2^-24; D = 0.5|x-y|^2, h = 0.5|x|^2; score() is three fmas on top of the stored 0.5|y|^2):
+//   computed score of a target  >=  D(1 - 15u) - h(1 + 21u)        (3u on each of the four terms, 3u on the stored 0.5|y|^2,
+//                                                                     |y| <= |x| + sqrt(2D), 4 sqrt(hD) <= 2h + 2D)
+//   computed bound lb           <=  (0.5 dx^2 (1 + 3u) - h(1 - 3u))(1 + u),   D >= 0.5 dx^2 beyond the edge
+// => a skipped target scores above `best` whenever  lb > best + 29u h + 13u |best|  = best + 1.8e-6 h + ...;  3e-6 keeps 1.7x of that.
+template <> struct SweepEps<float>  { static constexpr float  v = 3e-6f; };
 template <> struct SweepEps<double> { static constexpr double v = 1e-10; };
 
 template <typename T, int NV, int PAD>

@@ -639,6 +639,21 @@ def test_sweep_knn_full_size_and_pruning():
     assert torch.equal(sweep_knn(q4, td, cfg=16)[0], _ops.knn(q4, None, _ops.pack_target(td), n, _lib.KNN_VALU))
 
 
+@pytest.mark.parametrize("offset,noise", [(0.0, 1e-2), (0.0, 1e-4), (60.0, 1e-2), (300.0, 1e-2), (300.0, 0.0), (2000.0, 1e-3)])
+def test_sweep_prune_margin_near_pose_and_far_from_origin(offset, noise):
+    """The sweep's prune margin (SweepEps) is sized from the rounding error of a score, which grows with 0.5|x|^2: clouds far
+    from the origin, queries a hair away from (or exactly on) their neighbours, must still return the brute-force indices."""
+    N, n = 8, 16384
+    g = torch.Generator().manual_seed(int(offset) + 5)
+    pts = (torch.rand((N, n, 3), generator=g) - 0.5) * 20 + torch.tensor([offset, -0.5 * offset, 0.25 * offset])
+    td = torch.cat((pts, torch.nn.functional.normalize(torch.randn((N, n, 3), generator=g), dim=2)), dim=2).float().to(DEV)
+    qd = (pts[:, torch.randperm(n, generator=g)] + noise * torch.randn((N, n, 3), generator=g)).float().to(DEV).contiguous()
+    brute = _ops.knn(qd, None, _ops.pack_target(td), n, _lib.KNN_VALU)
+    for cfg in (0, 2, 8, 16):
+        got, _ = sweep_knn(qd, td, cfg=cfg)
+        assert torch.equal(got, brute), (offset, noise, cfg, int((got != brute).sum()))
+
+
 @pytest.mark.parametrize("window", [False, True])
 @pytest.mark.parametrize("name,icp_type,diff", [("c1_pt2pt_diff", "pt2pt", True), ("c1_pt2pl_diff", "pt2pl", True)])
 def test_icp_with_sweep_knn_matches_reference(golden, name, icp_type, diff, window):

@@ -305,10 +305,15 @@ def main():
             o = chk.icp(src[:T_ref.shape[0]], tgt[:T_ref.shape[0]], T0[:T_ref.shape[0]], trim_dist=TRIM, loss_fn=LOSS, dim=3)
             line["check"] = {"pose_max_abs_diff_vs_oracle": float((o["T"].cpu() - T_ref).abs().max())}
             line["speedup_vs_cpu"] = line["value"] / base["value"]
-        print(json.dumps(line))
+        os.write(_REAL_STDOUT, (json.dumps(line) + "\n").encode())
     if use_dist:
         torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
+    # stdout carries exactly ONE line, the JSON: RCCL prints its version banner to stdout when the process group comes up
+    # (and libraries may log there too), so everything else this process writes to fd 1 goes to stderr instead
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     main()

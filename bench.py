@@ -103,7 +103,7 @@ def cpu_baseline(n, m, budget_s=25.0):
     ((4,n,m) fp32 distances = 4 GiB per chunk at 16384^2; per-cloud cost is flat in B), about 10 s of CPU work."""
     from oracle import dicp_oracle as O
     # 16 threads is the fastest setting for this op sequence on the GPU box's 2 x EPYC 9575F host
-    # (profiles/r01_cpu_threads_probe.txt: 8/16/32/64/128/256 threads -> 3.9/5.5/5.0/3.4/2.1/0.1 cloud-it/s)
+    # (tests/tools/cpu_threads_probe.py -> profiles/r01_cpu_threads_probe.txt: 8/16/32/64/128/256 threads -> 3.9/5.5/5.0/3.4/2.1/0.1 cloud-it/s)
     cores = min(16, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     Bc, K = 4, 3

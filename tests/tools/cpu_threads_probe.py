@@ -1,7 +1,7 @@
 """Pick the thread count for bench.py's cpu_baseline: time the oracle (1 cloud x 1 iteration fwd+bwd,
 n=m=16384) at several torch thread counts on this host."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from dicp_amd.synthetic import make_pairs
 from oracle import dicp_oracle as O

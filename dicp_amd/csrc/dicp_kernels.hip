@@ -794,15 +794,16 @@ template <> struct SweepEps<double> { static constexpr double v = 1e-10; };
 template <typename T, int NV, int PAD>
 __device__ __forceinline__ void block_reduce_store(T* v, T* __restrict__ out, T* lds);
 
-// Optional fusion: with MODE >= 0 the search kernel goes on, for the matches it has just found, with what
-// accumulate_kernel does (residual, weights, Jacobian, normal-equation sums; ICP.py:143-201) -- the query, its pose and
-// the winner are in hand, so one pass over the points (and one launch) per iteration disappears.  The partials
-// then follow the search's waves: (N, units of this launch, NACC_PAD).
 // Launch configuration of the tile sweep, measured at the benchmark shape (profiles/r01_sweep_configs_ab.txt): 2 queries per
 // lane with 8-row chunks wins at every iteration once the per-chunk bookkeeping is three lane operations, and it wants
 // registers rather than occupancy: 5 waves/SIMD (96 VGPRs, no scratch) beats 6 (80 VGPRs: the tie state spills).
 constexpr int SWEEP_CFG_BIG = 2;            // (Q, CH) = (2, 8)
 constexpr int SWEEP_MINW_Q2C8 = 5;
+
+// Optional fusion: with MODE >= 0 the search kernel goes on, for the matches it has just found, with what
+// accumulate_kernel does (residual, weights, Jacobian, normal-equation sums; ICP.py:143-201) -- the query, its pose and
+// the winner are in hand, so one pass over the points (and one launch) per iteration disappears.  The partials
+// then follow the search's waves: (N, units of this launch, NACC_PAD).
 constexpr int MODE_SEARCH_ONLY = -1;
 template <typename T> struct FusedAcc {
     WeightParams P;

@@ -5,6 +5,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -51,13 +52,13 @@ def test_shard_bounds():
     assert ddist.gather_poses(torch.eye(4).repeat(3, 1, 1)).shape == (3, 4, 4)    # no process group: identity
 
 
-def test_two_rank_gloo_matches_single_process(tmp_path):
-    total, world = 5, 2
+@pytest.mark.parametrize("total,world,sizes", [(5, 2, [3, 2]), (5, 3, [2, 2, 1]), (2, 3, [1, 1, 0])])
+def test_gloo_ranks_match_single_process(tmp_path, total, world, sizes):
     mp.spawn(worker, args=(world, free_port(), total, str(tmp_path)), nprocs=world, join=True)
     src, tgt = make_pairs(total, 96, 128, seed=4, dtype=torch.float64)
     ref = oracle_icp(src, tgt, torch.eye(4, dtype=torch.float64).repeat(total, 1, 1), **KW)["T"].numpy()
     a = np.load(tmp_path / "T_all_0.npy")
-    b = np.load(tmp_path / "T_all_1.npy")
-    assert [int(np.load(tmp_path / ("n_local_%d.npy" % r))) for r in range(2)] == [3, 2]
-    np.testing.assert_array_equal(a, b)
+    assert [int(np.load(tmp_path / ("n_local_%d.npy" % r))) for r in range(world)] == sizes
+    for r in range(1, world):                            # every rank holds the whole batch's poses, in cloud order
+        np.testing.assert_array_equal(a, np.load(tmp_path / ("T_all_%d.npy" % r)))
     np.testing.assert_allclose(a, ref, rtol=0, atol=1e-12)

@@ -1718,6 +1718,8 @@ __global__ __launch_bounds__(BLOCK) void accumulate_bwd_window_kernel(WeightPara
 
 // gtgt[b][tperm[s]][col] += gts_far[b][s][col] + sum over the blocks whose window covers sorted row s of their
 // slab rows: the once-per-call end of the windowed backward (also undoes the sorted target order).
+constexpr int WR_U = 4;      // gradient elements per thread
+constexpr int WR_B = 8;      // window blocks per round of loads (16: 160 us instead of 118 -- registers)
 template <typename T, int WT, int CV>
 __global__ __launch_bounds__(BLOCK) void window_reduce_kernel(const T* __restrict__ slab, const int32_t* __restrict__ spos_ref,
                                                               const int32_t* __restrict__ qorder,
@@ -1729,12 +1731,14 @@ __global__ __launch_bounds__(BLOCK) void window_reduce_kernel(const T* __restric
     int cloud, rb;
     if (!decode_block(rpc, N, cloud, rb)) return;
     const int tid = threadIdx.x;
-    const int e0 = rb * (BLOCK * 4);                        // this block's elements of the (m*cv) row-major gradient
-    T acc[4] = {T(0), T(0), T(0), T(0)};
-    // the loads that do not wait for the window origins (two dependent index loads) go out first and run under them
-    int dst[4];
+    const int e0 = rb * (BLOCK * WR_U);                        // this block's elements of the (m*cv) row-major gradient
+    T acc[WR_U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < WR_U; ++u) acc[u] = T(0);
+    // the loads that do not wait for the window origins (two dependent index loads) go out first and run under them
+    int dst[WR_U];
+#pragma unroll
+    for (int u = 0; u < WR_U; ++u) {
         const int e = min(e0 + u * BLOCK + tid, m * cv - 1);
         const int s = e / CV;
         dst[u] = tperm[(size_t)cloud * m_pad + s];
@@ -1746,26 +1750,30 @@ __global__ __launch_bounds__(BLOCK) void window_reduce_kernel(const T* __restric
             origin[b] = window_origin(spos_ref + (size_t)cloud * n, qorder ? qorder + (size_t)cloud * n : nullptr, b0 + b, spb, n, m_pad, WT);
         __syncthreads();
         const int nb = min(MAXB, bpc - b0);
+        // the block loop is the OUTER one: all of a thread's elements have their (predicated) loads of WR_B window blocks in
+        // flight together -- the kernel is bound by how many dependent rounds of loads a thread makes, not by bytes
+        for (int bb = 0; bb < nb; bb += WR_B) {
+            T v[WR_U][WR_B];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = min(e0 + u * BLOCK + tid, m * cv - 1);
-            const int s = e / CV;
-            for (int bb = 0; bb < nb; bb += 8) {            // 8 independent predicated loads in flight per element
-                T v[8];
+            for (int u = 0; u < WR_U; ++u) {
+                const int e = min(e0 + u * BLOCK + tid, m * cv - 1);
+                const int s = e / CV;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
+                for (int k = 0; k < WR_B; ++k) {
                     const int b = min(bb + k, nb - 1);
                     const int lo = origin[b];
                     const bool cov = bb + k < nb && s >= lo && s < lo + WT;
-                    v[k] = cov ? slab[((size_t)cloud * bpc + b0 + b) * (WT * CV) + (size_t)(e - lo * CV)] : T(0);
+                    v[u][k] = cov ? slab[((size_t)cloud * bpc + b0 + b) * (WT * CV) + (size_t)(e - lo * CV)] : T(0);
                 }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) acc[u] += v[k];
             }
+#pragma unroll
+            for (int u = 0; u < WR_U; ++u)
+#pragma unroll
+                for (int k = 0; k < WR_B; ++k) acc[u] += v[u][k];
         }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < WR_U; ++u) {
         const int e = e0 + u * BLOCK + tid;
         if (e >= m * cv) continue;
         const int s = e / CV, col = e - s * CV;
@@ -2930,7 +2938,7 @@ int dicp_window_reduce(int dtype, const void* slab, const int32_t* spos_ref, con
     hipStream_t st = (hipStream_t)stream;
     begin_launch();
     const int bpc = dicp_window_blocks(dtype, n, m_pad);
-    const int rpc = (m * cv + BLOCK * 4 - 1) / (BLOCK * 4);
+    const int rpc = (m * cv + BLOCK * WR_U - 1) / (BLOCK * WR_U);
     const unsigned g = grid_for(N, rpc);
 #define DICP_RED(T, CVV) window_reduce_kernel<T, WindowRows<T>::v, CVV><<<g, BLOCK, 0, st>>>((const T*)slab, spos_ref, qorder, tperm, (const T*)gts_far, N, n, m, m_pad, cv, \
         window_slots(WindowRows<T>::v, n, m_pad), bpc, rpc, (T*)gtgt, c, overwrite)

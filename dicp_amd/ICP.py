@@ -19,7 +19,7 @@ import torch
 import yaml
 
 from . import _lib
-from ._ops import ICPLoop, KabschLoop, LoopConfig, compute_device, icp_loop_gumbel, transform_points
+from ._ops import ICPLoop, KabschLoop, LoopConfig, compute_device, icp_loop_gumbel, prebuild_search, transform_points
 from .nn import nn
 
 
@@ -91,6 +91,12 @@ class ICP:
         loss_name = loss_fn['name'] if loss_fn is not None else None
         if loss_name == 'trim':
             raise ValueError("dicp_amd: 'trim' is selected with trim_dist, not loss_fn")
+        # the target sort / index build of the sweep path goes to the GPU before the rest of this function's host work
+        prebuilt = None
+        if not (self.nn.differentiable and self.nn.use_gumbel):
+            target = target.contiguous()
+            wants_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (source, target, T_init, w_pts))
+            prebuilt = prebuild_search(source, target, self.knn_variant, wants_grad and bool(self.bwd_window))
         cfg = LoopConfig(
             icp_type=self.icp_type, differentiable=bool(self.diff), max_iterations=int(self.max_iterations),
             tolerance=float(self.tolerance), trim_dist=trim_dist, loss_name=loss_name,
@@ -99,7 +105,7 @@ class ICP:
             tanh_steepness=float(self.config['dICP']['parameters']['tanh_steepness']),   # ICP.py:119
             match_ratio_thresh=float(self.match_ratio_thresh),
             knn_variant=self.knn_variant, bwd_window=bool(self.bwd_window), stats_out=self.knn_stats,
-            sync_every=self.sync_every, timing_events=self._timing_events)
+            sync_every=self.sync_every, timing_events=self._timing_events, prebuilt=prebuilt)
         if self.nn.differentiable and self.nn.use_gumbel:                                # nn.py:14-16 via ICP.py:140
             # soft correspondences carry gradient themselves: one autograd node per iteration instead of one per call
             T, deltas, weights, costs, converged, iterations, matched = icp_loop_gumbel(

@@ -315,6 +315,21 @@ def loss_weight(err2d, name, diff, metric, tanh_k):
 
 
 # --------------------------------------------------------------- the ICP loop
+def prebuild_search(source, target, knn_variant, want_rows):
+    """Enqueue the per-call search structure of the sweep path (target sort + index build, ~0.15 ms of kernels) NOW, so that
+    it runs under the host work the caller still has to do before the loop starts (a call that begins on an idle GPU is
+    host-bound until its first long kernel).  Returns (target, SweepIndex) for LoopConfig.prebuilt, or None when the loop
+    will not use the sweep.  ICPLoop.forward uses it only if it was built from the very tensor it is given."""
+    N, n = source.shape[0], source.shape[1]
+    kind = knn_variant & 0xff
+    if kind == _lib.KNN_AUTO:
+        kind = auto_knn_kind(N, n, target.shape[1])
+    if kind != _lib.KNN_SWEEP or not target.is_cuda or not target.is_contiguous() or target.dtype not in _DT:
+        return None
+    with torch.cuda.device(target.device):
+        return (target, SweepIndex(target, sorted_rows=bool(want_rows)))
+
+
 @dataclass
 class LoopConfig:
     icp_type: str
@@ -334,6 +349,7 @@ class LoopConfig:
     stats_out: object = None      # optional dict: receives "knn_pairs" (pairs scored by the sweep kNN; int64 shards, sum them)
     sync_every: object = None     # tolerance mode: iterations between the host's all-converged checks (None = auto)
     timing_events: object = None  # optional object with .handles(K) -> ctypes array of 4*K hipEvent_t (bench.py)
+    prebuilt: object = None       # (target, SweepIndex) started by the caller before its own host work (prebuild_search)
 
     def params(self):
         return _lib.WeightParams(
@@ -425,7 +441,14 @@ class ICPLoop(torch.autograd.Function):
             if kind == _lib.KNN_AUTO:
                 kind = auto_knn_kind(N, n, m)
             owned = kind == _lib.KNN_SWEEP and need_grad and cfg.bwd_window
-            sweep = SweepIndex(tgt, sorted_rows=owned) if kind == _lib.KNN_SWEEP else None
+            sweep = None
+            if kind == _lib.KNN_SWEEP:
+                pre = cfg.prebuilt
+                if (pre is not None and pre[0].data_ptr() == tgt.data_ptr() and pre[0].shape == tgt.shape and pre[0].dtype == tgt.dtype
+                        and (pre[1].tgt_s is not None or not owned)):
+                    sweep = pre[1]                           # started by the caller, under its host work
+                else:
+                    sweep = SweepIndex(tgt, sorted_rows=owned)
             tgt4 = sweep.tgs4 if sweep is not None else pack_target(tgt)
             m_pad = tgt4.shape[1]
             nblk = lib.dicp_loop_partial_blocks(code, n)

@@ -190,11 +190,16 @@ class ICP:
 
         # dtype / device / column count come from the first non-empty target (ICP.py:347-358)
         dt, dev, cols = torch.float32, "cpu", None
-        for t_i in target:
-            if t_i is not None and len(t_i) > 0:
-                dt, dev = t_i.dtype, t_i.device
-                cols = t_i.shape[0] if (not isinstance(target, list) and target.dim() == 2) else t_i.shape[1]
-                break
+        if isinstance(target, torch.Tensor) and target.dim() in (2, 3) and target.shape[1] > 0:
+            # a batched tensor answers for itself (iterating over it would build one view per cloud: ~70 us of host time at 256)
+            dt, dev = target.dtype, target.device
+            cols = target.shape[1] if target.dim() == 2 else target.shape[2]
+        else:
+            for t_i in target:
+                if t_i is not None and len(t_i) > 0:
+                    dt, dev = t_i.dtype, t_i.device
+                    cols = t_i.shape[0] if (not isinstance(target, list) and target.dim() == 2) else t_i.shape[1]
+                    break
         opts = dict(dtype=dt, device=dev)
 
         # ---- source and per-point prior weights (ICP.py:360-446)

@@ -32,6 +32,14 @@ first = knn[-13] if len(knn) >= 13 else knn[0]      # 10 timed launches + 3 brut
 lo = first
 while lo > 0 and first - lo < 80 and int(rows[lo]["Start_Timestamp"]) - int(rows[lo - 1]["End_Timestamp"]) < 90_000:
     lo -= 1
+# (a fast host leaves less than that between two calls: the call's own target sort is its first long kernel, at most a
+# couple of fills precede it)
+sorts = [i for i in range(lo, first) if "sort_keys_kernel" in rows[i]["Kernel_Name"] or "segmented_sort" in rows[i]["Kernel_Name"]]
+if sorts:
+    lo = sorts[-1]
+    steps = 0
+    while lo > 0 and steps < 2 and "Fill" in rows[lo - 1]["Kernel_Name"] and int(rows[lo]["Start_Timestamp"]) - int(rows[lo - 1]["End_Timestamp"]) < 90_000:
+        lo -= 1; steps += 1
 # ... and ends at the first idle gap after its backward (the host synchronises there; later legs of bench.py follow)
 hi = first
 while hi + 1 < len(rows) and int(rows[hi + 1]["Start_Timestamp"]) - int(rows[hi]["End_Timestamp"]) < 200_000:

@@ -93,7 +93,8 @@ def run_call(icp, src, tgt, T0, world):
     t = tgt.detach().requires_grad_(True)
     out = icp.icp(s, t, T0, trim_dist=TRIM, loss_fn=LOSS, dim=3)
     out["T"].sum().backward()
-    T_all = ddist.gather_poses(out["T"], force=True) if world != 1 else out["T"].detach()
+    # every rank holds the same number of clouds: the shard sizes are known, no size exchange (and no host sync) before the gather
+    T_all = ddist.gather_poses(out["T"], total=src.shape[0] * abs(world), force=True) if world != 1 else out["T"].detach()
     return out, T_all, s.grad, t.grad
 
 

@@ -33,14 +33,18 @@ def gather_poses(T_local, total=None, group=None, force=False):
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return T_local.detach()
     world = dist.get_world_size(group)
-    sizes = torch.tensor([T_local.shape[0]], dtype=torch.int64, device=T_local.device)
-    all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
     if total is None:
+        sizes = torch.tensor([T_local.shape[0]], dtype=torch.int64, device=T_local.device)
+        all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
         dist.all_gather(all_sizes, sizes, group=group)
         counts = [int(s.item()) for s in all_sizes]
     else:
         counts = [shard_bounds(total, g, world)[1] - shard_bounds(total, g, world)[0] for g in range(world)]
     big = max(counts)
+    if min(counts) == big:              # equal shards (the usual case): gather straight into the result, no padding, no trimming
+        recv = torch.empty((world * big, 4, 4), dtype=T_local.dtype, device=T_local.device)
+        dist.all_gather_into_tensor(recv, T_local.detach().contiguous(), group=group)
+        return recv
     send = torch.zeros((big, 4, 4), dtype=T_local.dtype, device=T_local.device)
     send[:T_local.shape[0]] = T_local.detach()
     recv = torch.empty((world * big, 4, 4), dtype=T_local.dtype, device=T_local.device)

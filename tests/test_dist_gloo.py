@@ -52,7 +52,7 @@ def test_shard_bounds():
     assert ddist.gather_poses(torch.eye(4).repeat(3, 1, 1)).shape == (3, 4, 4)    # no process group: identity
 
 
-@pytest.mark.parametrize("total,world,sizes", [(5, 2, [3, 2]), (5, 3, [2, 2, 1]), (2, 3, [1, 1, 0])])
+@pytest.mark.parametrize("total,world,sizes", [(5, 2, [3, 2]), (4, 2, [2, 2]), (5, 3, [2, 2, 1]), (2, 3, [1, 1, 0])])
 def test_gloo_ranks_match_single_process(tmp_path, total, world, sizes):
     mp.spawn(worker, args=(world, free_port(), total, str(tmp_path)), nprocs=world, join=True)
     src, tgt = make_pairs(total, 96, 128, seed=4, dtype=torch.float64)

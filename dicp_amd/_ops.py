@@ -403,6 +403,15 @@ class _Arena:
         return [buf[o:o + nb].view(dt).view(shape) for (o, nb, shape, dt) in self.specs]
 
 
+def _converged_at(pending):
+    """pending = (k0, k1, pinned counters, event): K = 1 + the first iteration of [k0, k1) after which no cloud was still moving
+    (ICP.py:240,259), or None.  Waits for that segment's copy only."""
+    k0, k1, host_cnt, ev = pending
+    ev.synchronize()
+    zero = (host_cnt[k0:k1] == 0).nonzero()
+    return k0 + int(zero[0, 0]) + 1 if zero.numel() else None
+
+
 class ICPLoop(torch.autograd.Function):
     """The whole iteration loop of ICP.dICP (ICP.py:131-260) as ONE autograd node.
 
@@ -492,6 +501,7 @@ class ICPLoop(torch.autograd.Function):
             K = Kmax
             segs = _segments(Kmax, cuts)
             done_segs = []
+            pending, host_cnt = None, None   # tolerance mode: the segment whose convergence counters are still in flight
             for (k0, k1) in segs:
                 j = k0 // kc
                 if j == len(w_slabs):
@@ -524,11 +534,23 @@ class ICPLoop(torch.autograd.Function):
                                                 float(cfg.tolerance), k0, k1, st), "dicp_icp_forward")
                 done_segs.append((k0, k1))
                 if not cfg.const_iter:
-                    # ICP.py:259: stop at the first iteration whose steps are ALL below tolerance (host sync, like the reference)
-                    zero = (counters[k0:k1] == 0).nonzero()
-                    if zero.numel():
-                        K = k0 + int(zero[0, 0].item()) + 1
+                    # ICP.py:259: stop at the first iteration whose steps are ALL below tolerance.  The reference synchronises
+                    # every iteration for this; here the counters of a segment travel to pinned host memory asynchronously
+                    # and are read one segment LATER, while the next segment is already running: no drained GPU, no launch
+                    # bubble.  The price is at most one segment of frozen no-op iterations past K (every cloud has converged,
+                    # so nothing moves), trimmed below exactly like the ones a sync_every > 1 leaves.
+                    if pending is not None and _converged_at(pending) is not None:
+                        K = _converged_at(pending)
+                        pending = None
                         break
+                    if host_cnt is None:
+                        host_cnt = torch.empty((Kmax,), dtype=torch.int32, pin_memory=True)
+                    host_cnt[k0:k1].copy_(counters[k0:k1], non_blocking=True)
+                    seg_done = torch.cuda.Event()
+                    seg_done.record()
+                    pending = (k0, k1, host_cnt, seg_done)
+            if pending is not None and _converged_at(pending) is not None:          # the last segment that ran
+                K = _converged_at(pending)
 
             # ICP.py:267-281: stats of the clouds that never converged (they report the matches of the LAST executed
             # iteration; with sync_every > 1 a few frozen no-op iterations may have run past K, which leaves n_matched of

@@ -38,7 +38,8 @@ class StepIO(ctypes.Structure):
                 ("pose_in", vp), ("pose_out", vp), ("delta", vp), ("delta_stride", i64),
                 ("cost", vp), ("cost_prev", vp), ("cost_stride", i64), ("areg", vp), ("alive", vp), ("alive_out", vp),
                 ("converged", vp), ("iterations", vp), ("matched_ratio", vp), ("n_start", vp),
-                ("n_matched", vp), ("w_cur", vp), ("w_prev", vp), ("w_stride", i64), ("n_not_converged", vp)]
+                ("n_matched", vp), ("w_cur", vp), ("w_prev", vp), ("w_stride", i64), ("n_not_converged", vp),
+                ("center", vp), ("pose_search_out", vp)]
 
 
 class LoopBuffers(ctypes.Structure):
@@ -47,7 +48,7 @@ class LoopBuffers(ctypes.Structure):
                 ("tgt4", vp), ("tperm", vp), ("qorder", vp), ("bucket", vp), ("brange", vp), ("nbkt", i32), ("idx_per_iter", i32),
                 ("pairs", vp), ("spos", vp), ("src_s", vp), ("spos_ref", vp), ("gts_far", vp), ("poses", vp), ("deltas", vp), ("costs", vp), ("areg", vp), ("alive", vp), ("converged", vp),
                 ("iterations", vp), ("matched_ratio", vp), ("n_start", vp), ("n_matched", vp), ("idx", vp), ("w", vp), ("w_iter", i64), ("w_stride", i64), ("w_prev0", vp),
-                ("partials", vp), ("counters", vp), ("events", vp), ("bwd_overwrite", i32)]
+                ("partials", vp), ("counters", vp), ("events", vp), ("bwd_overwrite", i32), ("center", vp), ("poses_search", vp)]
 
 
 _SIGNATURES = {
@@ -55,12 +56,16 @@ _SIGNATURES = {
     "dicp_padded_targets": ([i32], ctypes.c_int),
     "dicp_accumulate_blocks": ([i32], ctypes.c_int),
     "dicp_pack_target": ([i32, vp, i32, i32, i32, vp, i32, vp], ctypes.c_int),
+    "dicp_cloud_center": ([i32, vp, i32, i32, i32, f64, vp, vp], ctypes.c_int),
+    "dicp_pack_target_centered": ([i32, vp, i32, i32, i32, vp, vp, i32, vp], ctypes.c_int),
     "dicp_knn": ([i32, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp], ctypes.c_int),
     "dicp_knn_sweep": ([i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp], ctypes.c_int),
     "dicp_window_blocks": ([i32, i32, i32], ctypes.c_int),
     "dicp_window_rows": ([i32], ctypes.c_int),
     "dicp_sweep_sort": ([i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp], ctypes.c_int),
     "dicp_sweep_build": ([i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp], ctypes.c_int),
+    "dicp_sweep_sort_centered": ([i32, vp, i32, vp, i32, i32, i32, vp, vp, i32, vp, vp, vp], ctypes.c_int),
+    "dicp_sweep_build_centered": ([i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp], ctypes.c_int),
     "dicp_sweep_partials": ([i32, i32, i32], ctypes.c_int),
     "dicp_loop_partial_blocks": ([i32, i32], ctypes.c_int),
     "dicp_knn_sweep_accumulate": ([i32, ctypes.POINTER(WeightParams), vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32,
@@ -68,6 +73,7 @@ _SIGNATURES = {
     "dicp_query_order": ([i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, vp], ctypes.c_int),
     "dicp_query_keys": ([i32, vp, vp, i32, i32, vp, vp], ctypes.c_int),
     "dicp_loop_init": ([i32, vp, vp, ctypes.c_double, i32, i32, i32, vp, vp, vp, vp], ctypes.c_int),
+    "dicp_loop_init_centered": ([i32, vp, vp, ctypes.c_double, i32, i32, i32, vp, vp, vp, vp, vp, vp], ctypes.c_int),
     "dicp_loop_finish": ([i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp], ctypes.c_int),
     "dicp_accumulate_bwd_window": ([i32, ctypes.POINTER(WeightParams), vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp], ctypes.c_int),
     "dicp_window_reduce": ([i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, i32, vp], ctypes.c_int),
@@ -140,7 +146,7 @@ def load():
                 fn = getattr(lib, name)
                 fn.argtypes = args
                 fn.restype = res
-            if lib.dicp_abi_version() != 1:
+            if lib.dicp_abi_version() != 2:
                 raise RuntimeError("dicp_amd: libdicp_hip.so ABI version mismatch; rebuild it")
             _lib = lib
     return _lib

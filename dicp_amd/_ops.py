@@ -58,14 +58,30 @@ def accumulate_blocks(n):
     return _lib.load().dicp_accumulate_blocks(int(n))
 
 
-def pack_target(tgt):
-    """(N,m,c) -> (N,m_pad,4) rows [x,y,z,0.5|y|^2]."""
+CENTER_QUANTUM = float(os.environ.get("DICP_CENTER_QUANTUM", "16"))    # metres; clouds whose centroid is within half of it of the origin keep c = 0
+
+
+def cloud_center(tgt, quantum=None):
+    """(N,m,c) -> (N,3): the centre of the search coordinates (dicp_cloud_center): the target centroid rounded to a multiple of
+    `quantum`, so that clouds near the origin get exactly 0 and with it the bits of an uncentred search."""
+    require_device(tgt, "cloud_center")
+    N, m, c = tgt.shape
+    out = torch.empty((N, 3), dtype=tgt.dtype, device=tgt.device)
+    with torch.cuda.device(tgt.device):
+        _lib.check(_lib.load().dicp_cloud_center(_DT[tgt.dtype], _p(tgt), c, N, m, CENTER_QUANTUM if quantum is None else float(quantum),
+                                                 _p(out), _stream()), "dicp_cloud_center")
+    return out
+
+
+def pack_target(tgt, center=None):
+    """(N,m,c) -> (N,m_pad,4) rows [x,y,z,0.5|y|^2] of y (or of y - center: the caller then searches with [C | r - center])."""
     require_device(tgt, "pack_target")
     N, m, c = tgt.shape
     m_pad = padded_targets(m)
     out = torch.empty((N, m_pad, 4), dtype=tgt.dtype, device=tgt.device)
     with torch.cuda.device(tgt.device):
-        _lib.check(_lib.load().dicp_pack_target(_DT[tgt.dtype], _p(tgt), N, m, c, _p(out), m_pad, _stream()), "dicp_pack_target")
+        _lib.check(_lib.load().dicp_pack_target_centered(_DT[tgt.dtype], _p(tgt), N, m, c, _p(center), _p(out), m_pad, _stream()),
+                   "dicp_pack_target")
     return out
 
 
@@ -85,12 +101,15 @@ class SweepIndex:
     an ICP call, so they are sorted by x once.  Index preparation uses torch.sort/searchsorted (plumbing)."""
     NBKT = 1024
 
-    def __init__(self, tgt, sorted_rows=False):
-        """sorted_rows: also keep tgt_s (N,m_pad,c), the full rows in sorted order (the windowed backward reads them)."""
+    def __init__(self, tgt, sorted_rows=False, center=None):
+        """sorted_rows: also keep tgt_s (N,m_pad,c), the full rows in sorted order (the windowed backward reads them).
+        center (N,3): the index is built on y - center (keys, table and packed rows; tgt_s keeps the rows as given) and the
+        searches must then be given the pose [C | r - center]."""
         require_device(tgt, "SweepIndex")
         tgt = tgt.contiguous()
         N, m, c = tgt.shape
         self.m = m
+        self.center = center
         lib = _lib.load()
         dev, dt = tgt.device, tgt.dtype
         m_pad = lib.dicp_padded_targets(m)
@@ -104,17 +123,18 @@ class SweepIndex:
             # and the bucket table while the keys are there
             keys, order = torch.empty((N, m_pad), dtype=dt, device=dev), None
             with torch.cuda.device(dev):
-                _lib.check(lib.dicp_sweep_sort(_DT[dt], _p(tgt), c, N, m, m_pad, _p(keys), _p(self.tperm), self.NBKT, _p(self.bucket),
-                                               _p(self.brange), _stream()), "dicp_sweep_sort")
+                _lib.check(lib.dicp_sweep_sort_centered(_DT[dt], _p(tgt), c, _p(center), N, m, m_pad, _p(keys), _p(self.tperm), self.NBKT,
+                                                        _p(self.bucket), _p(self.brange), _stream()), "dicp_sweep_sort")
         else:
             key = torch.full((N, m_pad), torch.finfo(dt).max, dtype=dt, device=dev)   # pad slots sort last
-            key[:, :m] = tgt[:, :, 0]
+            key[:, :m] = tgt[:, :, 0] if center is None else tgt[:, :, 0] - center[:, 0:1]
             keys, order = torch.sort(key, dim=1, stable=True)
         self.keys = keys                                         # sorted x keys (N,m_pad): the rank search of query_order reads them
         self.tgt_s = torch.empty((N, m_pad, c), dtype=dt, device=dev) if sorted_rows else None
         with torch.cuda.device(dev):
-            _lib.check(lib.dicp_sweep_build(_DT[dt], _p(tgt), c, _p(order), None if native else _p(keys), N, m, m_pad, self.NBKT, _p(self.tgs4), _p(self.tperm),
-                                            _p(self.bucket), _p(self.brange), _p(self.tgt_s), _stream()), "dicp_sweep_build")
+            _lib.check(lib.dicp_sweep_build_centered(_DT[dt], _p(tgt), c, _p(center), _p(order), None if native else _p(keys), N, m, m_pad, self.NBKT,
+                                                     _p(self.tgs4), _p(self.tperm), _p(self.bucket), _p(self.brange), _p(self.tgt_s), _stream()),
+                       "dicp_sweep_build")
         self.pair_shards = torch.zeros((_lib.PAIR_SHARDS,), dtype=torch.int64, device=dev)
 
     @property
@@ -327,7 +347,7 @@ def prebuild_search(source, target, knn_variant, want_rows):
     if kind != _lib.KNN_SWEEP or not target.is_cuda or not target.is_contiguous() or target.dtype not in _DT:
         return None
     with torch.cuda.device(target.device):
-        return (target, SweepIndex(target, sorted_rows=bool(want_rows)))
+        return (target, SweepIndex(target, sorted_rows=bool(want_rows), center=cloud_center(target)))
 
 
 @dataclass
@@ -457,11 +477,14 @@ class ICPLoop(torch.autograd.Function):
                         and (pre[1].tgt_s is not None or not owned)):
                     sweep = pre[1]                           # started by the caller, under its host work
                 else:
-                    sweep = SweepIndex(tgt, sorted_rows=owned)
-            tgt4 = sweep.tgs4 if sweep is not None else pack_target(tgt)
+                    sweep = SweepIndex(tgt, sorted_rows=owned, center=cloud_center(tgt))
+            # the searches run in coordinates centred on the target cloud (dicp_cloud_center): packed rows y - c, pose [C | r - c]
+            center = sweep.center if sweep is not None else cloud_center(tgt)
+            tgt4 = sweep.tgs4 if sweep is not None else pack_target(tgt, center)
             m_pad = tgt4.shape[1]
             nblk = lib.dicp_loop_partial_blocks(code, n)
             poses = torch.empty((Kmax + 1, N, 12), dtype=dt, device=dev)
+            poses_c = torch.empty((Kmax + 1, N, 12), dtype=dt, device=dev)     # [C | r - center]: what the searches read
             alive = torch.empty((Kmax + 1, N), dtype=dt, device=dev)
             areg = torch.empty((Kmax, N, 36), dtype=torch.float64, device=dev) if need_grad else None
             n_start = torch.empty((N,), dtype=dt, device=dev)
@@ -477,8 +500,8 @@ class ICPLoop(torch.autograd.Function):
             counters = arena.take((Kmax,), torch.int32)
             deltas, costs, converged, iterations, matched, n_matched, counters = arena.finish()
             # pose_0, alive_0, n_start (ICP.py:124-129)
-            _lib.check(lib.dicp_loop_init(code, _p(T_init.contiguous()), _p(w0c), float(cfg.match_ratio_thresh), rows, N, n,
-                                          _p(poses), _p(alive), _p(n_start), st), "dicp_loop_init")
+            _lib.check(lib.dicp_loop_init_centered(code, _p(T_init.contiguous()), _p(w0c), float(cfg.match_ratio_thresh), rows, N, n,
+                                                   _p(poses), _p(alive), _p(n_start), _p(center), _p(poses_c), st), "dicp_loop_init")
             idx_once = None if need_grad else torch.empty((N, n), dtype=torch.int32, device=dev)
 
             # histories in slabs of kc iterations: slab j covers iterations [j*kc, (j+1)*kc)
@@ -514,7 +537,7 @@ class ICPLoop(torch.autograd.Function):
                 if sweep is not None and (qorder is None or k0 in cfg.sweep_resort):
                     # queries re-ordered by x under the current pose (reproducibly when the forward sums in that order)
                     prev = spos_slabs[(k0 - 1) // kc][(k0 - 1) % kc] if (owned and k0 > 0 and SPOS_ORDER) else None
-                    qorder = sweep.query_order(src, poses[k0], reproducible=bool(FUSE_ACCUMULATE), spos_prev=prev)
+                    qorder = sweep.query_order(src, poses_c[k0], reproducible=bool(FUSE_ACCUMULATE), spos_prev=prev)
                     qorders.append(qorder)
                 seg_q.append(len(qorders) - 1)
                 base = j * kc                                         # virtual bases: slab pointer minus its first iteration
@@ -529,7 +552,7 @@ class ICPLoop(torch.autograd.Function):
                     idx=ctypes.c_void_p(idx_slabs[j].data_ptr() - base * N * n * 4) if need_grad else _p(idx_once),
                     w=ctypes.c_void_p(w_slabs[j].data_ptr() - base * n * es), w_iter=n, w_stride=kc * n,
                     w_prev0=_p(w_slabs[(k0 - 1) // kc][:, (k0 - 1) % kc]) if k0 > 0 else None,
-                    partials=_p(partials), counters=_p(counters), events=events)
+                    partials=_p(partials), counters=_p(counters), events=events, center=_p(center), poses_search=_p(poses_c))
                 _lib.check(lib.dicp_icp_forward(code, ctypes.byref(P), ctypes.byref(LB), N, n, m, int(cfg.dim), int(cfg.const_iter),
                                                 float(cfg.tolerance), k0, k1, st), "dicp_icp_forward")
                 done_segs.append((k0, k1))

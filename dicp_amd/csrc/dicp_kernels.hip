@@ -90,10 +90,12 @@ template <> __device__ __forceinline__ float  big_v<float>()  { return 3.4028234
 template <> __device__ __forceinline__ double big_v<double>() { return 1.7976931348623157e+308; }
 
 // one expression for 0.5|y|^2 wherever a target row is packed, so every kNN form sees bit-identical scores
+// ctr (optional): the search runs in coordinates centred on the target cloud, rows are packed as y - ctr (section "centre" below)
 template <typename T>
-__device__ __forceinline__ typename V4<T>::type pack_row(const T* __restrict__ y) {
+__device__ __forceinline__ typename V4<T>::type pack_row(const T* __restrict__ y, const T* __restrict__ ctr = nullptr) {
     typename V4<T>::type v;
     v.x = y[0]; v.y = y[1]; v.z = y[2];
+    if (ctr) { v.x -= ctr[0]; v.y -= ctr[1]; v.z -= ctr[2]; }
     v.w = T(0.5) * fma_t(v.z, v.z, fma_t(v.y, v.y, v.x * v.x));     // explicit fmas: no per-kernel contraction choices
     return v;
 }
@@ -107,15 +109,43 @@ __device__ __forceinline__ void query_point(const T* C, const T* r, const T* p, 
         nx[k] = -fma_t(C[3 * k], p[0], fma_t(C[3 * k + 1], p[1], fma_t(C[3 * k + 2], p[2], r[k])));
 }
 
+// ------------------------------------------------------------------------ centre
+// The search scores in the expanded form 0.5|y|^2 - x.y, whose rounding error -- and with it the sweep's prune margin -- grows
+// with 0.5|x|^2: in a map frame a kilometre from the origin nothing is pruned any more (profiles/r01_offset_clouds.txt).  So the
+// search runs in coordinates centred on the target cloud: packed rows hold y - c, and the search kernels are handed the pose
+// [C | r - c] (a second, search-only pose buffer).  Every search form reads only (pose, packed rows), so none of them changes and
+// they all stay index-for-index identical.  c = the target centroid rounded to a multiple of `quantum`: clouds near the origin get
+// c = 0 and with it exactly the bits they had without centring.
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void cloud_center_kernel(const T* __restrict__ tgt, int c, int m, double quantum, T* __restrict__ center) {
+    __shared__ double part[BLOCK / WAVE][3];
+    const int cloud = blockIdx.x, tid = threadIdx.x;
+    const T* __restrict__ rows = tgt + (size_t)cloud * m * c;
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    for (int j = tid; j < m; j += BLOCK) { sx += (double)rows[(size_t)j * c]; sy += (double)rows[(size_t)j * c + 1]; sz += (double)rows[(size_t)j * c + 2]; }
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) { sx += __shfl_down(sx, off); sy += __shfl_down(sy, off); sz += __shfl_down(sz, off); }
+    if ((tid & (WAVE - 1)) == 0) { part[tid >> 6][0] = sx; part[tid >> 6][1] = sy; part[tid >> 6][2] = sz; }
+    __syncthreads();
+    if (tid < 3) {
+        double v = 0.0;
+        for (int w = 0; w < BLOCK / WAVE; ++w) v += part[w][tid];
+        v /= (double)m;
+        v = quantum > 0.0 ? rint(v / quantum) * quantum : v;
+        center[(size_t)cloud * 3 + tid] = (v == v && fabs(v) < 1e30) ? (T)v : T(0);        // non-finite input: no centring
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void pack_kernel(const T* __restrict__ tgt, int N, int m, int c,
-                                                     typename V4<T>::type* __restrict__ out, int m_pad, int bpc) {
+                                                     typename V4<T>::type* __restrict__ out, int m_pad, int bpc,
+                                                     const T* __restrict__ center) {
     int b, blk;                                             // all blocks of a cloud on one XCD (decode_block)
     if (!decode_block(bpc, N, b, blk)) return;
     const int j = blk * BLOCK + threadIdx.x;
     if (j >= m_pad) return;
     typename V4<T>::type v;
-    if (j < m) v = pack_row<T>(tgt + ((size_t)b * m + j) * c);
+    if (j < m) v = pack_row<T>(tgt + ((size_t)b * m + j) * c, center ? center + (size_t)b * 3 : nullptr);
     else { v.x = v.y = v.z = T(0); v.w = inf_v<T>(); }
     out[(size_t)b * m_pad + j] = v;
 }
@@ -126,7 +156,8 @@ __global__ __launch_bounds__(BLOCK) void pack_kernel(const T* __restrict__ tgt, 
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void sweep_rows_kernel(const T* __restrict__ tgt, const int64_t* __restrict__ order /* NULL: tperm holds it */, int N, int m, int c,
                                                            int m_pad, int bpc, typename V4<T>::type* __restrict__ tgs4, int32_t* __restrict__ tperm,
-                                                           T* __restrict__ tgt_s /* optional (N,m_pad,c): the full rows in sorted order */) {
+                                                           T* __restrict__ tgt_s /* optional (N,m_pad,c): the full rows in sorted order */,
+                                                           const T* __restrict__ center /* optional (N,3): tgs4 rows are y - centre; tgt_s stays as given */) {
     constexpr int U = 4;                                    // rows per thread in flight (index -> row is a dependent pair)
     int b, blk;
     if (!decode_block(bpc, N, b, blk)) return;
@@ -151,7 +182,7 @@ __global__ __launch_bounds__(BLOCK) void sweep_rows_kernel(const T* __restrict__
             const int sl = s0 + u * BLOCK;
             if (sl >= m_pad) continue;
             typename V4<T>::type v;
-            if (j[u] >= 0 && j[u] < m) v = pack_row<T>(y[u]);
+            if (j[u] >= 0 && j[u] < m) v = pack_row<T>(y[u], center ? center + (size_t)b * 3 : nullptr);
             else { v.x = big_v<T>(); v.y = v.z = T(0); v.w = inf_v<T>(); }      // pads sort last and can never win
             tgs4[(size_t)b * m_pad + sl] = v;
             tperm[(size_t)b * m_pad + sl] = (int32_t)j[u];
@@ -198,7 +229,8 @@ __device__ __forceinline__ unsigned sortable_bits(float x) {      // order-prese
 }
 __global__ __launch_bounds__(RS_THREADS) void sort_keys_kernel(const float* __restrict__ tgt, int c, int N, int m, int m_pad,
                                                                float* __restrict__ keys_sorted, int32_t* __restrict__ tperm,
-                                                               int nbkt, int32_t* __restrict__ bucket, float* __restrict__ brange) {
+                                                               int nbkt, int32_t* __restrict__ bucket, float* __restrict__ brange,
+                                                               const float* __restrict__ center) {
     __shared__ unsigned skey[RS_MAX];
     __shared__ unsigned short sidx[RS_MAX];
     __shared__ int cnt[RS_THREADS / WAVE][256];             // per wave, per digit: running count, then offset
@@ -212,7 +244,7 @@ __global__ __launch_bounds__(RS_THREADS) void sort_keys_kernel(const float* __re
         const int pos = wave * (WAVE * RS_PER) + e * WAVE + lane;
         unsigned u = 0xffffffffu;                           // beyond m_pad: sentinel, sorts after everything
         if (pos < m_pad) {
-            u = sortable_bits(pos < m ? rows[(size_t)pos * c] : 3.402823466e+38f);
+            u = sortable_bits(pos < m ? (center ? rows[(size_t)pos * c] - center[(size_t)cloud * 3] : rows[(size_t)pos * c]) : 3.402823466e+38f);
         }
         key[e] = u;
         idx[e] = (unsigned short)pos;
@@ -476,7 +508,8 @@ __global__ __launch_bounds__(QO_THREADS) void query_order_kernel(const T* __rest
 // first-iteration state of the loop: pose_0 from T_init, alive_0 = 1, n_start = rows * #(w0 > thresh)  (ICP.py:124-129)
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void loop_init_kernel(const T* __restrict__ T_init, const T* __restrict__ w0, T thresh, int rows, int n,
-                                                          T* __restrict__ pose0, T* __restrict__ alive0, T* __restrict__ n_start) {
+                                                          T* __restrict__ pose0, T* __restrict__ alive0, T* __restrict__ n_start,
+                                                          const T* __restrict__ center, T* __restrict__ pose_search0) {
     __shared__ int cnt[BLOCK / WAVE];
     const int cloud = blockIdx.x, tid = threadIdx.x;
     int k = 0;
@@ -493,7 +526,9 @@ __global__ __launch_bounds__(BLOCK) void loop_init_kernel(const T* __restrict__ 
     }
     if (tid < 12) {
         const T* M = T_init + (size_t)cloud * 16;
-        pose0[(size_t)cloud * 12 + tid] = tid < 9 ? M[(tid / 3) * 4 + tid % 3] : M[(tid - 9) * 4 + 3];
+        const T v = tid < 9 ? M[(tid / 3) * 4 + tid % 3] : M[(tid - 9) * 4 + 3];
+        pose0[(size_t)cloud * 12 + tid] = v;
+        if (pose_search0) pose_search0[(size_t)cloud * 12 + tid] = (tid >= 9 && center) ? v - center[(size_t)cloud * 3 + tid - 9] : v;
     }
 }
 
@@ -1335,6 +1370,7 @@ __host__ __device__ inline dicp_step_io make_step_io(const dicp_loop_buffers& B,
     io.partials = B.partials; io.nblk = nblk; io.iter = k; io.dim = dim; io.const_iter = const_iter; io.tolerance = tolerance;
     io.rows_per_point = mode == DICP_PT2PT ? 3 : 1; io.n = n;
     io.pose_in = (const char*)B.poses + (size_t)k * N * 12 * es; io.pose_out = (char*)B.poses + (size_t)(k + 1) * N * 12 * es;
+    io.center = B.center; io.pose_search_out = B.poses_search ? (char*)B.poses_search + (size_t)(k + 1) * N * 12 * es : nullptr;
     io.delta = (char*)B.deltas + (size_t)k * 6 * es; io.delta_stride = (int64_t)B.K * 6;
     io.cost = (char*)B.costs + (size_t)k * es; io.cost_prev = k > 0 ? (const char*)B.costs + (size_t)(k - 1) * es : nullptr;
     io.cost_stride = B.K;
@@ -1380,6 +1416,12 @@ __device__ __forceinline__ void step_body(const dicp_step_io& io, int cloud, int
             for (int j = 0; j < 3; ++j)
                 pout[i * 3 + j] = (T)(R[0 * 3 + i] * C[0 * 3 + j] + R[1 * 3 + i] * C[1 * 3 + j] + R[2 * 3 + i] * C[2 * 3 + j]);
         for (int k = 0; k < 3; ++k) pout[9 + k] = (T)(spose[9 + k] - d6[3 + k]);
+        if (io.pose_search_out) {                                         // what the next search reads: [C | r - centre]
+            T* ps = (T*)io.pose_search_out + (size_t)cloud * 12;
+            const T* ctr = io.center ? (const T*)io.center + (size_t)cloud * 3 : nullptr;
+            for (int k = 0; k < 9; ++k) ps[k] = pout[k];
+            for (int k = 0; k < 3; ++k) ps[9 + k] = ctr ? pout[9 + k] - ctr[k] : pout[9 + k];
+        }
 
         T cost = (T)sacc[ACC_COST];                                       // ICP.py:229-232
         if (io.cost_prev && cost == T(0)) cost = ((const T*)io.cost_prev)[(size_t)cloud * io.cost_stride];
@@ -1445,6 +1487,8 @@ __global__ __launch_bounds__(BLOCK) void icp_small_forward_kernel(WeightParams P
     for (int k = k0; k < k1; ++k) {
         T C[9], r[3];
         load_pose((const T*)B.poses + (size_t)k * N * 12, cloud, C, r);
+        T rs[3] = {r[0], r[1], r[2]};                       // the search's translation: r - centre (packed rows are y - centre)
+        if (B.center) { const T* ctr = (const T*)B.center + (size_t)cloud * 3; rs[0] -= ctr[0]; rs[1] -= ctr[1]; rs[2] -= ctr[2]; }
         const T live = ((const T*)B.alive)[(size_t)k * N + cloud];
         int32_t* __restrict__ idx_k = B.idx + (B.idx_per_iter ? (size_t)k * N * n : 0) + (size_t)cloud * n;
         T* __restrict__ w_k = (T*)B.w + (size_t)k * B.w_iter + (size_t)cloud * B.w_stride;
@@ -1454,7 +1498,7 @@ __global__ __launch_bounds__(BLOCK) void icp_small_forward_kernel(WeightParams P
         for (int i = tid; i < n; i += BLOCK) {
             const T p[3] = {src[i * 3], src[i * 3 + 1], src[i * 3 + 2]};
             T nx[3];
-            query_point(C, r, p, nx);
+            query_point(C, rs, p, nx);
             T best = inf_v<T>();
             int bj = 0;
             for (int j = 0; j < m_pad; j += 4) {            // m_pad is a multiple of 64; ascending, strict <: lowest index on ties
@@ -2448,7 +2492,21 @@ int dicp_abi_version(void) { return DICP_ABI_VERSION; }
 int dicp_padded_targets(int m) { return m <= 0 ? 0 : ((m + KNN_PAD - 1) / KNN_PAD) * KNN_PAD; }
 int dicp_accumulate_blocks(int n) { return n <= 0 ? 0 : (n + ACC_PTS - 1) / ACC_PTS; }
 
+int dicp_cloud_center(int dtype, const void* tgt, int c, int N, int m, double quantum, void* center, void* stream) {
+    if (!tgt || !center) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0 || m <= 0 || (c != 3 && c != 6) || !(quantum >= 0.0)) return DICP_ERR_SHAPE;
+    begin_launch();
+    if (dtype == DICP_F32) cloud_center_kernel<float><<<N, BLOCK, 0, (hipStream_t)stream>>>((const float*)tgt, c, m, quantum, (float*)center);
+    else                   cloud_center_kernel<double><<<N, BLOCK, 0, (hipStream_t)stream>>>((const double*)tgt, c, m, quantum, (double*)center);
+    return launch_status();
+}
+
 int dicp_pack_target(int dtype, const void* tgt, int N, int m, int c, void* tgt4, int m_pad, void* stream) {
+    return dicp_pack_target_centered(dtype, tgt, N, m, c, nullptr, tgt4, m_pad, stream);
+}
+
+int dicp_pack_target_centered(int dtype, const void* tgt, int N, int m, int c, const void* center, void* tgt4, int m_pad, void* stream) {
     if (!tgt || !tgt4) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || m <= 0 || (c != 3 && c != 6) || m_pad != dicp_padded_targets(m)) return DICP_ERR_SHAPE;
@@ -2457,24 +2515,35 @@ int dicp_pack_target(int dtype, const void* tgt, int N, int m, int c, void* tgt4
     begin_launch();
     const int bpc = (int)blocks_for((size_t)m_pad);
     const unsigned g = grid_for(N, bpc);
-    if (dtype == DICP_F32) pack_kernel<float><<<g, BLOCK, 0, st>>>((const float*)tgt, N, m, c, (float4*)tgt4, m_pad, bpc);
-    else                   pack_kernel<double><<<g, BLOCK, 0, st>>>((const double*)tgt, N, m, c, (double4*)tgt4, m_pad, bpc);
+    if (dtype == DICP_F32) pack_kernel<float><<<g, BLOCK, 0, st>>>((const float*)tgt, N, m, c, (float4*)tgt4, m_pad, bpc, (const float*)center);
+    else                   pack_kernel<double><<<g, BLOCK, 0, st>>>((const double*)tgt, N, m, c, (double4*)tgt4, m_pad, bpc, (const double*)center);
     return launch_status();
 }
 
 int dicp_sweep_sort(int dtype, const void* tgt, int c, int N, int m, int m_pad, void* keys_sorted, int32_t* tperm,
                     int nbkt, int32_t* bucket, void* brange, void* stream) {
+    return dicp_sweep_sort_centered(dtype, tgt, c, nullptr, N, m, m_pad, keys_sorted, tperm, nbkt, bucket, brange, stream);
+}
+
+int dicp_sweep_sort_centered(int dtype, const void* tgt, int c, const void* center, int N, int m, int m_pad, void* keys_sorted, int32_t* tperm,
+                             int nbkt, int32_t* bucket, void* brange, void* stream) {
     if (!tgt || !keys_sorted || !tperm || (bucket && !brange)) return DICP_ERR_NULL;
     if (bucket && nbkt <= 0) return DICP_ERR_SHAPE;
     if (dtype != DICP_F32) return DICP_ERR_DTYPE;          // float keys; float64 clouds and more than 16384 targets: sort on the caller's side
     if (N <= 0 || m <= 0 || (c != 3 && c != 6) || m_pad != dicp_padded_targets(m) || m_pad > RS_MAX) return DICP_ERR_SHAPE;
     begin_launch();
-    sort_keys_kernel<<<N, RS_THREADS, 0, (hipStream_t)stream>>>((const float*)tgt, c, N, m, m_pad, (float*)keys_sorted, tperm, nbkt, bucket, (float*)brange);
+    sort_keys_kernel<<<N, RS_THREADS, 0, (hipStream_t)stream>>>((const float*)tgt, c, N, m, m_pad, (float*)keys_sorted, tperm, nbkt, bucket, (float*)brange, (const float*)center);
     return launch_status();
 }
 
 int dicp_sweep_build(int dtype, const void* tgt, int c, const int64_t* order, const void* keys_sorted, int N, int m, int m_pad, int nbkt,
                      void* tgs4, int32_t* tperm, int32_t* bucket, void* brange, void* tgt_s, void* stream) {
+    return dicp_sweep_build_centered(dtype, tgt, c, nullptr, order, keys_sorted, N, m, m_pad, nbkt, tgs4, tperm, bucket, brange, tgt_s, stream);
+}
+
+int dicp_sweep_build_centered(int dtype, const void* tgt, int c, const void* center, const int64_t* order, const void* keys_sorted, int N, int m,
+                              int m_pad, int nbkt, void* tgs4, int32_t* tperm, int32_t* bucket, void* brange, void* tgt_s, void* stream) {
+    // center != NULL: the packed rows tgs4 are y - centre and keys_sorted (if given) are the centred x keys; tgt_s stays as given
     // order == NULL: tperm holds the permutation.  keys_sorted == NULL: bucket / brange are already filled (dicp_sweep_sort)
     if (!tgt || !tgs4 || !tperm || !bucket || !brange) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
@@ -2485,10 +2554,10 @@ int dicp_sweep_build(int dtype, const void* tgt, int c, const int64_t* order, co
     const int bpc = (m_pad + BLOCK * 4 - 1) / (BLOCK * 4);
     const unsigned g = grid_for(N, bpc);
     if (dtype == DICP_F32) {
-        sweep_rows_kernel<float><<<g, BLOCK, 0, st>>>((const float*)tgt, order, N, m, c, m_pad, bpc, (float4*)tgs4, tperm, (float*)tgt_s);
+        sweep_rows_kernel<float><<<g, BLOCK, 0, st>>>((const float*)tgt, order, N, m, c, m_pad, bpc, (float4*)tgs4, tperm, (float*)tgt_s, (const float*)center);
         if (keys_sorted) sweep_buckets_kernel<float><<<N, BLOCK, 0, st>>>((const float*)keys_sorted, N, m, m_pad, nbkt, bucket, (float*)brange);
     } else {
-        sweep_rows_kernel<double><<<g, BLOCK, 0, st>>>((const double*)tgt, order, N, m, c, m_pad, bpc, (double4*)tgs4, tperm, (double*)tgt_s);
+        sweep_rows_kernel<double><<<g, BLOCK, 0, st>>>((const double*)tgt, order, N, m, c, m_pad, bpc, (double4*)tgs4, tperm, (double*)tgt_s, (const double*)center);
         if (keys_sorted) sweep_buckets_kernel<double><<<N, BLOCK, 0, st>>>((const double*)keys_sorted, N, m, m_pad, nbkt, bucket, (double*)brange);
     }
     return launch_status();
@@ -2525,13 +2594,18 @@ int dicp_query_order(int dtype, const void* src, const void* pose, const void* b
 
 int dicp_loop_init(int dtype, const void* T_init, const void* w0, double thresh, int rows, int N, int n,
                    void* pose0, void* alive0, void* n_start, void* stream) {
+    return dicp_loop_init_centered(dtype, T_init, w0, thresh, rows, N, n, pose0, alive0, n_start, nullptr, nullptr, stream);
+}
+
+int dicp_loop_init_centered(int dtype, const void* T_init, const void* w0, double thresh, int rows, int N, int n,
+                            void* pose0, void* alive0, void* n_start, const void* center, void* pose_search0, void* stream) {
     if (!T_init || !w0 || !pose0 || !alive0 || !n_start) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || n <= 0 || (rows != 1 && rows != 3)) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     begin_launch();
-    if (dtype == DICP_F32) loop_init_kernel<float><<<N, BLOCK, 0, st>>>((const float*)T_init, (const float*)w0, (float)thresh, rows, n, (float*)pose0, (float*)alive0, (float*)n_start);
-    else                   loop_init_kernel<double><<<N, BLOCK, 0, st>>>((const double*)T_init, (const double*)w0, thresh, rows, n, (double*)pose0, (double*)alive0, (double*)n_start);
+    if (dtype == DICP_F32) loop_init_kernel<float><<<N, BLOCK, 0, st>>>((const float*)T_init, (const float*)w0, (float)thresh, rows, n, (float*)pose0, (float*)alive0, (float*)n_start, (const float*)center, (float*)pose_search0);
+    else                   loop_init_kernel<double><<<N, BLOCK, 0, st>>>((const double*)T_init, (const double*)w0, thresh, rows, n, (double*)pose0, (double*)alive0, (double*)n_start, (const double*)center, (double*)pose_search0);
     return launch_status();
 }
 
@@ -3017,6 +3091,8 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
     }
     for (int k = k0; k < k1; ++k) {
         const char* pose_k = (const char*)B->poses + (size_t)k * N * 12 * es;
+        // the searches read [C | r - centre] when the caller keeps that second pose history (packed rows are then y - centre)
+        const char* pose_s = B->poses_search ? (const char*)B->poses_search + (size_t)k * N * 12 * es : pose_k;
         int32_t* idx_k = B->idx + (B->idx_per_iter ? (size_t)k * N * n : 0);
         char* w_k = (char*)B->w + (size_t)k * B->w_iter * es;       // cloud stride B->w_stride: (N,K,n) or (K,N,n) alike
         const char* alive_k = (const char*)B->alive + (size_t)k * N * es;
@@ -3030,7 +3106,7 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
             // bits 16..23 of knn_variant: first iteration that takes the narrow-slab (per-lane scan) form; 0 = never.
             // bit 24: fuse accumulate into the search kernel's epilogue (tile-sweep configurations 2, 4, 8)
             const int scan_from = (B->knn_variant >> 16) & 0xff;
-            const bool fuse = (B->knn_variant >> 24) & 1;
+            const bool fuse = ((B->knn_variant >> 24) & 1) && !B->poses_search;   // (the fused form scores and accumulates with ONE pose)
             int cfg = (B->knn_variant >> 8) & 0xff;
             if (cfg == 0 && scan_from > 0 && k >= scan_from) cfg = DICP_SWEEP_SCAN;
             if (cfg == 0) cfg = sweep_auto_cfg(N, n);
@@ -3047,7 +3123,7 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
                 set_launch_events(nullptr, nullptr);
                 if (rc) return rc;
             } else {
-                rc = dicp_knn_sweep(dtype, qsrc, pose_k, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, N, n, m, B->m_pad,
+                rc = dicp_knn_sweep(dtype, qsrc, pose_s, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, N, n, m, B->m_pad,
                                     idx_k, spos_k, B->pairs, cfg, stream);
                 set_launch_events(nullptr, nullptr);
                 if (rc) return rc;
@@ -3055,7 +3131,7 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
                 if (rc) return rc;
             }
         } else {
-            rc = dicp_knn(dtype, B->src, pose_k, B->tgt4, N, n, m, B->m_pad, idx_k, B->knn_variant & 0xffff, stream);
+            rc = dicp_knn(dtype, B->src, pose_s, B->tgt4, N, n, m, B->m_pad, idx_k, B->knn_variant & 0xffff, stream);
             if (rc) return rc;
             if (B->events) { if (hipEventRecord((hipEvent_t)B->events[4 * k + 1], st) != hipSuccess) return -(int)hipGetLastError(); }
             rc = dicp_accumulate(dtype, prm, B->src, B->tgt, B->c, idx_k, pose_k, B->w_init, alive_k, N, n, m, B->partials, w_k, B->w_stride, stream);

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DICP_ABI_VERSION 1
+#define DICP_ABI_VERSION 2   /* 2: dicp_step_io / dicp_loop_buffers end with the centred-search fields */
 
 enum { DICP_F32 = 0, DICP_F64 = 1 };
 enum { DICP_PT2PT = 0, DICP_PT2PL = 1 };                 /* ICP(icp_type=...)  ICP.py:15,101-105 */
@@ -60,6 +60,16 @@ int dicp_accumulate_blocks(int n);
  * on every call (nn.py:32 -> ATen _euclidean_dist).  c in {3,6}. */
 int dicp_pack_target(int dtype, const void* tgt, int N, int m, int c, void* tgt4, int m_pad, void* stream);
 
+/* Centred search coordinates.  The searches score in the expanded form 0.5|y|^2 - x.y (the reference's own: nn.py:32), whose rounding
+ * error grows with 0.5|x|^2 -- and with it the prune margin of dicp_knn_sweep: a cloud a kilometre from the origin is searched almost
+ * exhaustively.  dicp_cloud_center writes, per cloud, the target centroid rounded to a multiple of `quantum` (0: not rounded) into
+ * center (N,3) T; the *_centered entry points below pack rows as y - center, and the caller hands the searches the pose
+ * [C | r - center] (dicp_loop_buffers.poses_search; dicp_loop_init_centered / the step kernels write it).  Every search form reads only
+ * (pose, packed rows): with the same centre they return the same indices as each other, and with center == 0 (clouds near the origin,
+ * given a quantum) exactly the bits of the uncentred entry points.  center == NULL == the uncentred entry point. */
+int dicp_cloud_center(int dtype, const void* tgt, int c, int N, int m, double quantum, void* center, void* stream);
+int dicp_pack_target_centered(int dtype, const void* tgt, int N, int m, int c, const void* center, void* tgt4, int m_pad, void* stream);
+
 /* Fused transform + brute-force 1-NN: replaces ICP.py:137 (ps_t = C p + r) followed by
  * nn.find_nn's cdist -> argmin, nn.py:32-35 / 83-86.  Never materialises (N,n,m).
  *   src (N,n,3); pose (N,12) = [C row-major (9), r (3)] or NULL for identity;
@@ -83,6 +93,11 @@ int dicp_sweep_sort(int dtype, const void* tgt, int c, int N, int m, int m_pad, 
                     int nbkt, int32_t* bucket, void* brange, void* stream);
 int dicp_sweep_build(int dtype, const void* tgt, int c, const int64_t* order, const void* keys_sorted, int N, int m, int m_pad, int nbkt,
                      void* tgs4, int32_t* tperm, int32_t* bucket, void* brange, void* tgt_s, void* stream);
+/* as above with packed rows / x keys taken relative to center (N,3) (NULL: as above); tgt_s keeps the rows as given */
+int dicp_sweep_sort_centered(int dtype, const void* tgt, int c, const void* center, int N, int m, int m_pad, void* keys_sorted, int32_t* tperm,
+                             int nbkt, int32_t* bucket, void* brange, void* stream);
+int dicp_sweep_build_centered(int dtype, const void* tgt, int c, const void* center, const int64_t* order, const void* keys_sorted, int N, int m,
+                              int m_pad, int nbkt, void* tgs4, int32_t* tperm, int32_t* bucket, void* brange, void* tgt_s, void* stream);
 /* keys (N,n) = x coordinate of every source point under pose (NULL = identity): the sort key of the query order. */
 int dicp_query_keys(int dtype, const void* src, const void* pose, int N, int n, void* keys, void* stream);
 /* qorder (N,n) = the queries in ascending bucket of their x under pose (counting sort over equal-width buckets of the
@@ -184,6 +199,8 @@ typedef struct dicp_step_io {
     const void* w_prev;      /* previous iteration's, or NULL              ICP.py:224-226 */
     int64_t w_stride;
     int32_t* n_not_converged;/* device counter for this iteration, pre-zeroed: += 1 per cloud with |delta| >= tol */
+    const void* center;      /* optional (N,3) T: the search's centre (dicp_cloud_center) */
+    void* pose_search_out;   /* optional (N,12) T: [C' | r' - centre], what the NEXT search reads (NULL: not kept) */
 } dicp_step_io;
 
 /* Reduce the partials, solve the 6x6 (3x3 for dim 2) system (ICP.py:200-201), update the
@@ -236,6 +253,10 @@ typedef struct dicp_loop_buffers {
                                 (hipExtLaunchKernel), the other forms are bracketed by hipEventRecord */
     int32_t bwd_overwrite;   /* dicp_icp_backward, windowed form: 1 = gsrc / gw / the slab (gtgt) are uninitialised and this call's
                                 first launch (iteration k1-1) writes them instead of adding; 0 = they are accumulators */
+    const void* center;      /* optional (N,3) T: centre of the search coordinates (dicp_cloud_center); tgt4 / the sweep index were then
+                                built by the *_centered entry points */
+    void* poses_search;      /* optional (K+1,N,12) T: [C | r - centre] per iteration, written by dicp_loop_init_centered (k = 0) and
+                                the step kernels; the searches read it instead of poses.  NULL: they read poses */
 } dicp_loop_buffers;
 
 /* Head and tail of the backward loop.  dicp_pose_grad_in: gpose (N,12) double = [dL/dC row-major (9), dL/dr (3)] taken from the
@@ -250,6 +271,9 @@ int dicp_pose_grad_out(int dtype, const double* gpose, const void* bwd_partials,
  * (ICP.py:267-281): iterations / matched_ratio of clouds that never converged, T_out (N,4,4) from pose_K. */
 int dicp_loop_init(int dtype, const void* T_init, const void* w0, double thresh, int rows, int N, int n,
                    void* pose0, void* alive0, void* n_start, void* stream);
+/* ... and the search pose of iteration 0, pose_search0 (N,12) = [C_0 | r_0 - center] (both optional) */
+int dicp_loop_init_centered(int dtype, const void* T_init, const void* w0, double thresh, int rows, int N, int n,
+                            void* pose0, void* alive0, void* n_start, const void* center, void* pose_search0, void* stream);
 int dicp_loop_finish(int dtype, const void* pose_K, const void* alive_K, const void* n_start, const void* n_matched, int K, int N,
                      void* iterations, void* matched_ratio, void* T_out, void* stream);
 

@@ -90,6 +90,19 @@ def test_new_entry_points_reject_bad_arguments(lib):
     assert lib.dicp_query_order(0, one, None, one, 1024, 1, 1, one, None, None, None, 0, None, 0, one, one, 0, None) == 2      # keys without m
     assert lib.dicp_loop_init(0, one, one, 0.01, 2, 1, 1, one, one, one, None) == 2
     assert lib.dicp_loop_finish(0, one, one, one, one, 1, 1, None, one, one, None) == 1
+    # centred search: the same checks as the uncentred entry points they extend (center itself is optional)
+    assert lib.dicp_cloud_center(0, None, 3, 1, 1, 16.0, one, None) == 1
+    assert lib.dicp_cloud_center(0, one, 3, 1, 1, 16.0, None, None) == 1
+    assert lib.dicp_cloud_center(0, one, 4, 1, 1, 16.0, one, None) == 2
+    assert lib.dicp_cloud_center(0, one, 3, 1, 1, -1.0, one, None) == 2
+    assert lib.dicp_cloud_center(5, one, 3, 1, 1, 16.0, one, None) == 3
+    assert lib.dicp_pack_target_centered(0, None, 1, 1, 3, None, None, 64, None) == 1
+    assert lib.dicp_pack_target_centered(0, one, 1, 1, 3, one, one, 63, None) == 2
+    assert lib.dicp_sweep_sort_centered(1, one, 3, one, 1, 1, 64, one, one, 0, None, None, None) == 3
+    assert lib.dicp_sweep_build_centered(0, None, 3, one, one, one, 1, 1, 64, 1024, one, one, one, one, None, None) == 1
+    assert lib.dicp_sweep_build_centered(0, one, 4, None, one, one, 1, 1, 64, 1024, one, one, one, one, None, None) == 2
+    assert lib.dicp_loop_init_centered(0, one, one, 0.01, 2, 1, 1, one, one, one, None, None, None) == 2
+    assert lib.dicp_loop_init_centered(0, None, one, 0.01, 1, 1, 1, one, one, one, one, one, None) == 1
     assert lib.dicp_accumulate_bwd_window(0, ctypes.byref(P), one, one, 6, None, one, None, one, one, None, one, one, 1, 1, 64,
                                           one, None, None, None, one, 0, None) == 1
     assert lib.dicp_accumulate_bwd_window(0, ctypes.byref(P), one, one, 6, one, one, None, one, one, None, one, one, 1, 1, 63,

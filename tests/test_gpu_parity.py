@@ -671,6 +671,76 @@ def test_icp_with_sweep_knn_matches_reference(golden, name, icp_type, diff, wind
     assert int(icp.knn_stats["knn_pairs"].sum().item()) > 0
 
 
+def test_cloud_center_is_the_quantised_centroid_and_zero_keeps_the_bits():
+    """dicp_cloud_center: centroid rounded to multiples of the quantum (0 near the origin); the *_centered producers with a zero
+    centre write exactly what the uncentred entry points write."""
+    g = torch.Generator().manual_seed(3)
+    tgt = torch.rand((5, 777, 6), generator=g) * 20 - 10
+    tgt[1, :, :3] += torch.tensor([1000.0, -37.0, 7.9])
+    tgt[2, :, :3] += torch.tensor([-8.1, 24.3, 100000.0])
+    td = tgt.to(DEV)
+    c = _ops.cloud_center(td, quantum=16.0).cpu()
+    want = torch.round(tgt[:, :, :3].double().mean(1) / 16.0) * 16.0
+    assert torch.equal(c.double(), want), (c, want)
+    assert torch.equal(c[0], torch.zeros(3))
+    exact = _ops.cloud_center(td, quantum=0.0).cpu()
+    np.testing.assert_allclose(exact.double().numpy(), tgt[:, :, :3].double().mean(1).numpy(), rtol=1e-6, atol=1e-6)
+    zero = torch.zeros((5, 3), device=DEV)
+    assert torch.equal(_ops.pack_target(td), _ops.pack_target(td, zero))
+    a, b = _ops.SweepIndex(td, sorted_rows=True), _ops.SweepIndex(td, sorted_rows=True, center=zero)
+    for name in ("tgs4", "tperm", "bucket", "brange", "keys", "tgt_s"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    # a real centre: rows and keys are the shifted ones, the full rows for the backward stay as given
+    cc = _ops.cloud_center(td)
+    sw = _ops.SweepIndex(td, sorted_rows=True, center=cc)
+    perm = sw.tperm[:, :777].long()
+    rows = torch.gather(td, 1, perm.unsqueeze(-1).expand(-1, -1, 6))
+    assert torch.equal(sw.tgt_s[:, :777], rows)
+    assert torch.equal(sw.tgs4[:, :777, :3], rows[:, :, :3] - cc[:, None, :])
+    assert torch.equal(sw.keys[:, :777], rows[:, :, 0] - cc[:, None, 0])
+
+
+@pytest.mark.parametrize("offset", [0.0, 1000.0, 25000.0])
+@pytest.mark.parametrize("icp_type,n", [("pt2pl", 3000), ("pt2pt", 200)])
+def test_icp_far_from_the_origin_prunes_and_matches_brute_force(offset, icp_type, n):
+    """Clouds in a map frame: the search is centred on the target cloud, so the sweep prunes as it does at the origin, and the
+    sweep / brute-force / small-cloud paths (all centred alike) still agree; poses follow the float64 oracle as far as float32
+    coordinates of that size allow."""
+    N, K = 4, 5
+    src, tgt = make_pairs(N, n, n, seed=9, dtype=torch.float32)
+    shift = torch.tensor([offset, -0.5 * offset, 0.25 * offset])
+    src = src + shift
+    tgt = tgt.clone(); tgt[:, :, :3] += shift
+    if icp_type == "pt2pt":
+        tgt = tgt[:, :, :3].contiguous()
+    kw = dict(trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0})
+    outs = []
+    for variant in (_lib.KNN_VALU, _lib.KNN_SWEEP):
+        sd, td = src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True)
+        icp = ICP(icp_type=icp_type, differentiable=True, max_iterations=K, tolerance=1e-12)
+        icp.const_iter = True
+        icp.knn_variant = variant
+        T0 = torch.eye(4, device=DEV).repeat(N, 1, 1)
+        out = icp.icp(sd, td, T0, **kw)
+        out["T"].sum().backward()
+        outs.append((out, sd.grad, td.grad, dict(icp.knn_stats)))
+    scale = max(1.0, offset)
+    np.testing.assert_allclose(npy(outs[0][0]["T"]), npy(outs[1][0]["T"]), rtol=0, atol=4e-6 * scale)
+    assert torch.equal(outs[0][0]["weights"] > 0, outs[1][0]["weights"] > 0)
+    for k in (1, 2):
+        assert torch.isfinite(outs[1][k]).all()
+    if n >= 1000 and offset <= 1000.0:              # (25 km away float32 ICP itself is coarse -- 2 mm coordinates, a 25 km lever arm --
+        frac = float(outs[1][3]["knn_pairs"].sum()) / (float(N) * n * n * K)       # and badly aligned clouds have far neighbours)
+        assert frac < 0.25, frac                     # uncentred: 27 % at 1 km with 16384 points, everything at 10 km
+    if offset > 1000.0:         # float32 normal equations with 25 km coordinates are not ICP any more (in the reference either)
+        return
+    ref = O.icp_batched(src.double(), tgt.double(), torch.eye(4, dtype=torch.float64).repeat(N, 1, 1),
+                        torch.ones((N, n * (3 if icp_type == "pt2pt" else 1)), dtype=torch.float64),      # (one weight per residual row: ICP.py:508-509)
+                        icp_type=icp_type, differentiable=True, max_iterations=K, tolerance=1e-12, const_iter=True, tanh_steepness=5.0, dim=3, **kw)
+    # float32 coordinates carry ~6e-8 * |x| of rounding each: the pose error budget grows with the offset
+    np.testing.assert_allclose(npy(outs[1][0]["T"]), ref["T"].numpy(), rtol=0, atol=1e-4 + 2e-5 * offset)
+
+
 @pytest.mark.parametrize("window", [False, True])
 def test_icp_sweep_equals_brute_on_synthetic(window):
     """Sweep kNN (+ the sorted-space windowed backward or the plain atomic one) against the brute-force path.

@@ -73,6 +73,18 @@ def cloud_center(tgt, quantum=None):
     return out
 
 
+def search_pose(pose, center, N=None):
+    """[C | r - center] (N,12): the pose a search is handed when its packed rows / index were built on y - center (pose None = identity)."""
+    if pose is None:
+        pose = torch.zeros((N if N is not None else center.shape[0], 12), dtype=center.dtype, device=center.device)
+        pose[:, 0] = pose[:, 4] = pose[:, 8] = 1.0
+    if center is None:
+        return pose
+    out = pose.clone()
+    out[:, 9:] = pose[:, 9:] - center
+    return out
+
+
 def pack_target(tgt, center=None):
     """(N,m,c) -> (N,m_pad,4) rows [x,y,z,0.5|y|^2] of y (or of y - center: the caller then searches with [C | r - center])."""
     require_device(tgt, "pack_target")
@@ -722,8 +734,9 @@ class KabschLoop(torch.autograd.Function):
             kind = knn_variant & 0xff
             if kind == _lib.KNN_AUTO:
                 kind = auto_knn_kind(N, n, m)
-            sweep = SweepIndex(tgt) if kind == _lib.KNN_SWEEP else None
-            tgt4 = sweep.tgs4 if sweep is not None else pack_target(tgt)
+            center = cloud_center(tgt)                          # centred search, as in ICPLoop
+            sweep = SweepIndex(tgt, center=center) if kind == _lib.KNN_SWEEP else None
+            tgt4 = sweep.tgs4 if sweep is not None else pack_target(tgt, center)
             nblk = lib.dicp_accumulate_blocks(n)
             pose = _pose_from_T(T_init)
             pose_prev = pose
@@ -735,12 +748,13 @@ class KabschLoop(torch.autograd.Function):
             qorder = None
             K = 0
             for k in range(max_iterations):
+                pose_s = search_pose(pose, center)
                 if sweep is not None:
                     if k < 2:
-                        qorder = sweep.query_order(src, pose)
-                    sweep.knn(src, pose, qorder, out=idx, cfg=(knn_variant >> 8) & 0xff)
+                        qorder = sweep.query_order(src, pose_s)
+                    sweep.knn(src, pose_s, qorder, out=idx, cfg=(knn_variant >> 8) & 0xff)
                 else:
-                    _lib.check(lib.dicp_knn(code, _p(src), _p(pose), _p(tgt4), N, n, m, tgt4.shape[1], _p(idx),
+                    _lib.check(lib.dicp_knn(code, _p(src), _p(pose_s), _p(tgt4), N, n, m, tgt4.shape[1], _p(idx),
                                             kind | (knn_variant & 0xff00), st), "dicp_knn")
                 _lib.check(lib.dicp_kabsch_accumulate(code, _p(src), _p(tgt), c, _p(idx), _p(pose), _p(w0c), trim_on, trim,
                                                       N, n, m, _p(partials), st), "dicp_kabsch_accumulate")

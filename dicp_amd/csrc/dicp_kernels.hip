@@ -116,21 +116,38 @@ __device__ __forceinline__ void query_point(const T* C, const T* r, const T* p, 
 // [C | r - c] (a second, search-only pose buffer).  Every search form reads only (pose, packed rows), so none of them changes and
 // they all stay index-for-index identical.  c = the target centroid rounded to a multiple of `quantum`: clouds near the origin get
 // c = 0 and with it exactly the bits they had without centring.
+constexpr int CC_SAMPLE = 4096;      // rows averaged per cloud
+constexpr int CC_THREADS = 1024;     // one block per cloud: wide, and several rows in flight per thread (the kernel is pure load latency)
 template <typename T>
-__global__ __launch_bounds__(BLOCK) void cloud_center_kernel(const T* __restrict__ tgt, int c, int m, double quantum, T* __restrict__ center) {
-    __shared__ double part[BLOCK / WAVE][3];
+__global__ __launch_bounds__(CC_THREADS) void cloud_center_kernel(const T* __restrict__ tgt, int c, int m, double quantum, T* __restrict__ center) {
+    __shared__ double part[CC_THREADS / WAVE][3];
     const int cloud = blockIdx.x, tid = threadIdx.x;
     const T* __restrict__ rows = tgt + (size_t)cloud * m * c;
     double sx = 0.0, sy = 0.0, sz = 0.0;
-    for (int j = tid; j < m; j += BLOCK) { sx += (double)rows[(size_t)j * c]; sy += (double)rows[(size_t)j * c + 1]; sz += (double)rows[(size_t)j * c + 2]; }
+    // any point near the cloud serves as a centre (it sizes a margin, it decides no result): a stride sample of at most
+    // CC_SAMPLE rows -- rows 0, step, 2 step, ... -- is averaged, not all m
+    const int step = (m + CC_SAMPLE - 1) / CC_SAMPLE, ms = (m + step - 1) / step;
+    constexpr int U = 4;
+    for (int j0 = tid; j0 < ms; j0 += CC_THREADS * U) {
+        T x[U], y[U], z[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * CC_THREADS;
+            const bool on = j < ms;
+            const T* r = rows + (size_t)(on ? j : 0) * step * c;
+            x[u] = on ? r[0] : T(0); y[u] = on ? r[1] : T(0); z[u] = on ? r[2] : T(0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { sx += (double)x[u]; sy += (double)y[u]; sz += (double)z[u]; }
+    }
 #pragma unroll
     for (int off = WAVE / 2; off > 0; off >>= 1) { sx += __shfl_down(sx, off); sy += __shfl_down(sy, off); sz += __shfl_down(sz, off); }
     if ((tid & (WAVE - 1)) == 0) { part[tid >> 6][0] = sx; part[tid >> 6][1] = sy; part[tid >> 6][2] = sz; }
     __syncthreads();
     if (tid < 3) {
         double v = 0.0;
-        for (int w = 0; w < BLOCK / WAVE; ++w) v += part[w][tid];
-        v /= (double)m;
+        for (int w = 0; w < CC_THREADS / WAVE; ++w) v += part[w][tid];
+        v /= (double)((m + (m + CC_SAMPLE - 1) / CC_SAMPLE - 1) / ((m + CC_SAMPLE - 1) / CC_SAMPLE));
         v = quantum > 0.0 ? rint(v / quantum) * quantum : v;
         center[(size_t)cloud * 3 + tid] = (v == v && fabs(v) < 1e30) ? (T)v : T(0);        // non-finite input: no centring
     }
@@ -2497,8 +2514,8 @@ int dicp_cloud_center(int dtype, const void* tgt, int c, int N, int m, double qu
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || m <= 0 || (c != 3 && c != 6) || !(quantum >= 0.0)) return DICP_ERR_SHAPE;
     begin_launch();
-    if (dtype == DICP_F32) cloud_center_kernel<float><<<N, BLOCK, 0, (hipStream_t)stream>>>((const float*)tgt, c, m, quantum, (float*)center);
-    else                   cloud_center_kernel<double><<<N, BLOCK, 0, (hipStream_t)stream>>>((const double*)tgt, c, m, quantum, (double*)center);
+    if (dtype == DICP_F32) cloud_center_kernel<float><<<N, CC_THREADS, 0, (hipStream_t)stream>>>((const float*)tgt, c, m, quantum, (float*)center);
+    else                   cloud_center_kernel<double><<<N, CC_THREADS, 0, (hipStream_t)stream>>>((const double*)tgt, c, m, quantum, (double*)center);
     return launch_status();
 }
 

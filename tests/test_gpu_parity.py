@@ -676,15 +676,19 @@ def test_cloud_center_is_the_quantised_centroid_and_zero_keeps_the_bits():
     centre write exactly what the uncentred entry points write."""
     g = torch.Generator().manual_seed(3)
     tgt = torch.rand((5, 777, 6), generator=g) * 20 - 10
-    tgt[1, :, :3] += torch.tensor([1000.0, -37.0, 7.9])
+    tgt[1, :, :3] += torch.tensor([1003.0, -37.0, 7.9])
     tgt[2, :, :3] += torch.tensor([-8.1, 24.3, 100000.0])
     td = tgt.to(DEV)
     c = _ops.cloud_center(td, quantum=16.0).cpu()
-    want = torch.round(tgt[:, :, :3].double().mean(1) / 16.0) * 16.0
-    assert torch.equal(c.double(), want), (c, want)
+    mean = tgt[:, :, :3].double().mean(1)                    # (777 rows: all of them are in the <= 4096-row sample)
+    assert torch.equal(c.double(), torch.round(mean / 16.0) * 16.0), (c, mean)
     assert torch.equal(c[0], torch.zeros(3))
     exact = _ops.cloud_center(td, quantum=0.0).cpu()
-    np.testing.assert_allclose(exact.double().numpy(), tgt[:, :, :3].double().mean(1).numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(exact.double().numpy(), mean.numpy(), rtol=1e-6, atol=1e-6)
+    big = (torch.rand((2, 10000, 3), generator=g) * 20 - 10 + torch.tensor([500.0, 0.0, -300.0]))
+    step = (10000 + 4095) // 4096
+    np.testing.assert_allclose(_ops.cloud_center(big.to(DEV), quantum=0.0).cpu().double().numpy(), big[:, ::step].double().mean(1).numpy(),
+                               rtol=1e-6, atol=1e-6)         # larger clouds: the centroid of rows 0, step, 2 step, ...
     zero = torch.zeros((5, 3), device=DEV)
     assert torch.equal(_ops.pack_target(td), _ops.pack_target(td, zero))
     a, b = _ops.SweepIndex(td, sorted_rows=True), _ops.SweepIndex(td, sorted_rows=True, center=zero)

@@ -96,7 +96,8 @@ class ICP:
         if not (self.nn.differentiable and self.nn.use_gumbel):
             target = target.contiguous()
             wants_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (source, target, T_init, w_pts))
-            prebuilt = prebuild_search(source, target, self.knn_variant, wants_grad and bool(self.bwd_window))
+            source = source.contiguous()
+            prebuilt = prebuild_search(source, target, self.knn_variant, wants_grad and bool(self.bwd_window), T_init)
         cfg = LoopConfig(
             icp_type=self.icp_type, differentiable=bool(self.diff), max_iterations=int(self.max_iterations),
             tolerance=float(self.tolerance), trim_dist=trim_dist, loss_name=loss_name,

@@ -74,6 +74,7 @@ _SIGNATURES = {
     "dicp_query_keys": ([i32, vp, vp, i32, i32, vp, vp], ctypes.c_int),
     "dicp_loop_init": ([i32, vp, vp, ctypes.c_double, i32, i32, i32, vp, vp, vp, vp], ctypes.c_int),
     "dicp_loop_init_centered": ([i32, vp, vp, ctypes.c_double, i32, i32, i32, vp, vp, vp, vp, vp, vp], ctypes.c_int),
+    "dicp_search_pose": ([i32, vp, vp, i32, vp, vp], ctypes.c_int),
     "dicp_loop_finish": ([i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp], ctypes.c_int),
     "dicp_accumulate_bwd_window": ([i32, ctypes.POINTER(WeightParams), vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp], ctypes.c_int),
     "dicp_window_reduce": ([i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, i32, vp], ctypes.c_int),

@@ -347,7 +347,7 @@ def loss_weight(err2d, name, diff, metric, tanh_k):
 
 
 # --------------------------------------------------------------- the ICP loop
-def prebuild_search(source, target, knn_variant, want_rows):
+def prebuild_search(source, target, knn_variant, want_rows, T_init=None):
     """Enqueue the per-call search structure of the sweep path (target sort + index build, ~0.15 ms of kernels) NOW, so that
     it runs under the host work the caller still has to do before the loop starts (a call that begins on an idle GPU is
     host-bound until its first long kernel).  Returns (target, SweepIndex) for LoopConfig.prebuilt, or None when the loop
@@ -359,7 +359,16 @@ def prebuild_search(source, target, knn_variant, want_rows):
     if kind != _lib.KNN_SWEEP or not target.is_cuda or not target.is_contiguous() or target.dtype not in _DT:
         return None
     with torch.cuda.device(target.device):
-        return (target, SweepIndex(target, sorted_rows=bool(want_rows), center=cloud_center(target)))
+        sweep = SweepIndex(target, sorted_rows=bool(want_rows), center=cloud_center(target))
+        # ... and the first query order, from T_init alone (the loop's own pose_0 does not exist yet): with it the queue holds
+        # ~0.2 ms of work while the host builds the loop state
+        first = None
+        if (T_init is not None and T_init.is_cuda and T_init.is_contiguous() and T_init.dtype == target.dtype and source.is_contiguous()
+                and tuple(T_init.shape) == (N, 4, 4) and not FUSE_ACCUMULATE and not SPOS_ORDER):
+            pose_s = torch.empty((N, 12), dtype=target.dtype, device=target.device)
+            _lib.check(_lib.load().dicp_search_pose(_DT[target.dtype], _p(T_init), _p(sweep.center), N, _p(pose_s), _stream()), "dicp_search_pose")
+            first = (source, T_init, sweep.query_order(source, pose_s))
+        return (target, sweep, first)
 
 
 @dataclass
@@ -549,7 +558,12 @@ class ICPLoop(torch.autograd.Function):
                 if sweep is not None and (qorder is None or k0 in cfg.sweep_resort):
                     # queries re-ordered by x under the current pose (reproducibly when the forward sums in that order)
                     prev = spos_slabs[(k0 - 1) // kc][(k0 - 1) % kc] if (owned and k0 > 0 and SPOS_ORDER) else None
-                    qorder = sweep.query_order(src, poses_c[k0], reproducible=bool(FUSE_ACCUMULATE), spos_prev=prev)
+                    first = cfg.prebuilt[2] if (k0 == 0 and sweep is not None and cfg.prebuilt is not None and cfg.prebuilt[1] is sweep) else None
+                    if (first is not None and first[0].data_ptr() == src.data_ptr() and first[0].shape == src.shape
+                            and first[1].data_ptr() == T_init.data_ptr() and T_init.is_contiguous()):
+                        qorder = first[2]                    # ordered under T_init by the caller (prebuild_search)
+                    else:
+                        qorder = sweep.query_order(src, poses_c[k0], reproducible=bool(FUSE_ACCUMULATE), spos_prev=prev)
                     qorders.append(qorder)
                 seg_q.append(len(qorders) - 1)
                 base = j * kc                                         # virtual bases: slab pointer minus its first iteration

@@ -549,6 +549,18 @@ __global__ __launch_bounds__(BLOCK) void loop_init_kernel(const T* __restrict__ 
     }
 }
 
+// [C | r - centre] straight from T_init (N,4,4): the search pose of iteration 0, for a caller that wants the first query order in
+// the queue before the loop state exists (same values as loop_init_kernel writes)
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void search_pose_kernel(const T* __restrict__ T_init, const T* __restrict__ center, int N, T* __restrict__ out) {
+    const int e = blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= N * 12) return;
+    const int cloud = e / 12, k = e - cloud * 12;
+    const T* M = T_init + (size_t)cloud * 16;
+    const T v = k < 9 ? M[(k / 3) * 4 + k % 3] : M[(k - 9) * 4 + 3];
+    out[e] = (k >= 9 && center) ? v - center[(size_t)cloud * 3 + k - 9] : v;
+}
+
 // what follows the loop (ICP.py:267-281): stats of the clouds that never converged, and T from the last pose
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void loop_finish_kernel(const T* __restrict__ pose_K, const T* __restrict__ alive_K, const T* __restrict__ n_start,
@@ -2623,6 +2635,17 @@ int dicp_loop_init_centered(int dtype, const void* T_init, const void* w0, doubl
     begin_launch();
     if (dtype == DICP_F32) loop_init_kernel<float><<<N, BLOCK, 0, st>>>((const float*)T_init, (const float*)w0, (float)thresh, rows, n, (float*)pose0, (float*)alive0, (float*)n_start, (const float*)center, (float*)pose_search0);
     else                   loop_init_kernel<double><<<N, BLOCK, 0, st>>>((const double*)T_init, (const double*)w0, thresh, rows, n, (double*)pose0, (double*)alive0, (double*)n_start, (const double*)center, (double*)pose_search0);
+    return launch_status();
+}
+
+int dicp_search_pose(int dtype, const void* T_init, const void* center, int N, void* pose_search, void* stream) {
+    if (!T_init || !pose_search) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0) return DICP_ERR_SHAPE;
+    begin_launch();
+    const unsigned g = (unsigned)((N * 12 + BLOCK - 1) / BLOCK);
+    if (dtype == DICP_F32) search_pose_kernel<float><<<g, BLOCK, 0, (hipStream_t)stream>>>((const float*)T_init, (const float*)center, N, (float*)pose_search);
+    else                   search_pose_kernel<double><<<g, BLOCK, 0, (hipStream_t)stream>>>((const double*)T_init, (const double*)center, N, (double*)pose_search);
     return launch_status();
 }
 

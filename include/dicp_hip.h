@@ -275,6 +275,9 @@ int dicp_loop_init(int dtype, const void* T_init, const void* w0, double thresh,
 /* ... and the search pose of iteration 0, pose_search0 (N,12) = [C_0 | r_0 - center] (both optional) */
 int dicp_loop_init_centered(int dtype, const void* T_init, const void* w0, double thresh, int rows, int N, int n,
                             void* pose0, void* alive0, void* n_start, const void* center, void* pose_search0, void* stream);
+/* pose_search (N,12) = [C_0 | r_0 - center] from T_init (N,4,4) alone: the same values, for a caller that orders the first queries
+ * before the loop state exists (center optional) */
+int dicp_search_pose(int dtype, const void* T_init, const void* center, int N, void* pose_search, void* stream);
 int dicp_loop_finish(int dtype, const void* pose_K, const void* alive_K, const void* n_start, const void* n_matched, int K, int N,
                      void* iterations, void* matched_ratio, void* T_out, void* stream);
 

@@ -103,6 +103,7 @@ def test_new_entry_points_reject_bad_arguments(lib):
     assert lib.dicp_sweep_build_centered(0, one, 4, None, one, one, 1, 1, 64, 1024, one, one, one, one, None, None) == 2
     assert lib.dicp_loop_init_centered(0, one, one, 0.01, 2, 1, 1, one, one, one, None, None, None) == 2
     assert lib.dicp_loop_init_centered(0, None, one, 0.01, 1, 1, 1, one, one, one, one, one, None) == 1
+    assert lib.dicp_search_pose(0, None, None, 1, one, None) == 1 and lib.dicp_search_pose(0, one, None, 0, one, None) == 2
     assert lib.dicp_accumulate_bwd_window(0, ctypes.byref(P), one, one, 6, None, one, None, one, one, None, one, one, 1, 1, 64,
                                           one, None, None, None, one, 0, None) == 1
     assert lib.dicp_accumulate_bwd_window(0, ctypes.byref(P), one, one, 6, one, one, None, one, one, None, one, one, 1, 1, 63,

@@ -704,6 +704,27 @@ def test_cloud_center_is_the_quantised_centroid_and_zero_keeps_the_bits():
     assert torch.equal(sw.keys[:, :777], rows[:, :, 0] - cc[:, None, 0])
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_search_pose_from_T_init(dtype):
+    """dicp_search_pose: [C | r - centre] of T_init, the values dicp_loop_init_centered writes as pose_search_0."""
+    g = torch.Generator().manual_seed(2)
+    N = 7
+    T = torch.rand((N, 4, 4), generator=g, dtype=torch.float64).to(dtype).to(DEV)
+    ctr = (torch.rand((N, 3), generator=g, dtype=torch.float64) * 1000).to(dtype).to(DEV)
+    lib = _lib.load()
+    out = torch.empty((N, 12), dtype=dtype, device=DEV)
+    _lib.check(lib.dicp_search_pose(_ops._DT[dtype], _ops._p(T), _ops._p(ctr), N, _ops._p(out), _ops._stream()), "dicp_search_pose")
+    want = torch.cat((T[:, :3, :3].reshape(N, 9), T[:, :3, 3] - ctr), dim=1)
+    assert torch.equal(out, want)
+    w0 = torch.ones((N, 5), dtype=dtype, device=DEV)
+    pose0, alive, nst, ps0 = (torch.empty(sh, dtype=dtype, device=DEV) for sh in ((N, 12), (N,), (N,), (N, 12)))
+    _lib.check(lib.dicp_loop_init_centered(_ops._DT[dtype], _ops._p(T), _ops._p(w0), 0.01, 1, N, 5, _ops._p(pose0), _ops._p(alive), _ops._p(nst),
+                                           _ops._p(ctr), _ops._p(ps0), _ops._stream()), "dicp_loop_init_centered")
+    assert torch.equal(ps0, out) and torch.equal(pose0[:, :9], out[:, :9]) and torch.equal(pose0[:, 9:], T[:, :3, 3])
+    _lib.check(lib.dicp_search_pose(_ops._DT[dtype], _ops._p(T), None, N, _ops._p(out), _ops._stream()), "dicp_search_pose")
+    assert torch.equal(out, pose0)
+
+
 @pytest.mark.parametrize("offset", [0.0, 1000.0, 25000.0])
 @pytest.mark.parametrize("icp_type,n", [("pt2pl", 3000), ("pt2pt", 200)])
 def test_icp_far_from_the_origin_prunes_and_matches_brute_force(offset, icp_type, n):

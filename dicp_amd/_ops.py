@@ -359,7 +359,7 @@ def prebuild_search(source, target, knn_variant, want_rows, T_init=None):
     if kind != _lib.KNN_SWEEP or not target.is_cuda or not target.is_contiguous() or target.dtype not in _DT:
         return None
     with torch.cuda.device(target.device):
-        sweep = SweepIndex(target, sorted_rows=bool(want_rows), center=cloud_center(target))
+        sweep = SweepIndex(target, sorted_rows=bool(want_rows), center=None if FUSE_ACCUMULATE else cloud_center(target))
         # ... and the first query order, from T_init alone (the loop's own pose_0 does not exist yet): with it the queue holds
         # ~0.2 ms of work while the host builds the loop state
         first = None
@@ -498,14 +498,15 @@ class ICPLoop(torch.autograd.Function):
                         and (pre[1].tgt_s is not None or not owned)):
                     sweep = pre[1]                           # started by the caller, under its host work
                 else:
-                    sweep = SweepIndex(tgt, sorted_rows=owned, center=cloud_center(tgt))
+                    sweep = SweepIndex(tgt, sorted_rows=owned, center=None if FUSE_ACCUMULATE else cloud_center(tgt))
             # the searches run in coordinates centred on the target cloud (dicp_cloud_center): packed rows y - c, pose [C | r - c]
+            # (the fused search + accumulate form scores and accumulates with ONE pose: it keeps the uncentred search)
             center = sweep.center if sweep is not None else cloud_center(tgt)
             tgt4 = sweep.tgs4 if sweep is not None else pack_target(tgt, center)
             m_pad = tgt4.shape[1]
             nblk = lib.dicp_loop_partial_blocks(code, n)
             poses = torch.empty((Kmax + 1, N, 12), dtype=dt, device=dev)
-            poses_c = torch.empty((Kmax + 1, N, 12), dtype=dt, device=dev)     # [C | r - center]: what the searches read
+            poses_c = torch.empty((Kmax + 1, N, 12), dtype=dt, device=dev) if center is not None else None   # [C | r - center]: what the searches read
             alive = torch.empty((Kmax + 1, N), dtype=dt, device=dev)
             areg = torch.empty((Kmax, N, 36), dtype=torch.float64, device=dev) if need_grad else None
             n_start = torch.empty((N,), dtype=dt, device=dev)
@@ -563,7 +564,7 @@ class ICPLoop(torch.autograd.Function):
                             and first[1].data_ptr() == T_init.data_ptr() and T_init.is_contiguous()):
                         qorder = first[2]                    # ordered under T_init by the caller (prebuild_search)
                     else:
-                        qorder = sweep.query_order(src, poses_c[k0], reproducible=bool(FUSE_ACCUMULATE), spos_prev=prev)
+                        qorder = sweep.query_order(src, (poses_c if poses_c is not None else poses)[k0], reproducible=bool(FUSE_ACCUMULATE), spos_prev=prev)
                     qorders.append(qorder)
                 seg_q.append(len(qorders) - 1)
                 base = j * kc                                         # virtual bases: slab pointer minus its first iteration

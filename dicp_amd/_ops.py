@@ -58,11 +58,11 @@ def accumulate_blocks(n):
     return _lib.load().dicp_accumulate_blocks(int(n))
 
 
-CENTER_QUANTUM = float(os.environ.get("DICP_CENTER_QUANTUM", "16"))    # metres; clouds whose centroid is within half of it of the origin keep c = 0
+CENTER_QUANTUM = float(os.environ.get("DICP_CENTER_QUANTUM", "16"))    # metres; clouds whose median point is within half of it of the origin keep c = 0
 
 
 def cloud_center(tgt, quantum=None):
-    """(N,m,c) -> (N,3): the centre of the search coordinates (dicp_cloud_center): the target centroid rounded to a multiple of
+    """(N,m,c) -> (N,3): the centre of the search coordinates (dicp_cloud_center): the coordinate-wise median of (a sample of) the target, rounded to a multiple of
     `quantum`, so that clouds near the origin get exactly 0 and with it the bits of an uncentred search."""
     require_device(tgt, "cloud_center")
     N, m, c = tgt.shape

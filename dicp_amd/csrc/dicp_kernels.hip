@@ -114,40 +114,64 @@ __device__ __forceinline__ void query_point(const T* C, const T* r, const T* p, 
 // with 0.5|x|^2: in a map frame a kilometre from the origin nothing is pruned any more (profiles/r01_offset_clouds.txt).  So the
 // search runs in coordinates centred on the target cloud: packed rows hold y - c, and the search kernels are handed the pose
 // [C | r - c] (a second, search-only pose buffer).  Every search form reads only (pose, packed rows), so none of them changes and
-// they all stay index-for-index identical.  c = the target centroid rounded to a multiple of `quantum`: clouds near the origin get
+// they all stay index-for-index identical.  c = the target's median point rounded to a multiple of `quantum`: clouds near the origin get
 // c = 0 and with it exactly the bits they had without centring.
-constexpr int CC_SAMPLE = 4096;      // rows averaged per cloud
-constexpr int CC_THREADS = 1024;     // one block per cloud: wide, and several rows in flight per thread (the kernel is pure load latency)
+constexpr int CC_THREADS = 1024;     // one block per cloud
+constexpr int CC_SAMPLE = CC_THREADS;// rows looked at per cloud: one per thread, its three keys stay in registers
+__device__ __forceinline__ unsigned sortable_bits(float x);
+// The centre only sizes a margin (it decides no result), but it has to sit INSIDE the cloud: a mean would be dragged away by
+// far rows -- the reference pads ragged targets with rows at max(source) * 1000 (ICP.py:460), scans carry stray returns.  So it is
+// the coordinate-wise MEDIAN of a stride sample of at most CC_SAMPLE rows (rows 0, step, 2 step, ...), found by a radix select
+// (most significant byte first, the three axes side by side) over the order-preserving bit pattern of the float values (float
+// is plenty: the centre is rounded to `quantum` anyway).
 template <typename T>
 __global__ __launch_bounds__(CC_THREADS) void cloud_center_kernel(const T* __restrict__ tgt, int c, int m, double quantum, T* __restrict__ center) {
-    __shared__ double part[CC_THREADS / WAVE][3];
-    const int cloud = blockIdx.x, tid = threadIdx.x;
+    __shared__ int hist[3][256];
+    __shared__ unsigned sel_prefix[3];
+    __shared__ int sel_want[3];
+    const int cloud = blockIdx.x, tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
     const T* __restrict__ rows = tgt + (size_t)cloud * m * c;
-    double sx = 0.0, sy = 0.0, sz = 0.0;
-    // any point near the cloud serves as a centre (it sizes a margin, it decides no result): a stride sample of at most
-    // CC_SAMPLE rows -- rows 0, step, 2 step, ... -- is averaged, not all m
     const int step = (m + CC_SAMPLE - 1) / CC_SAMPLE, ms = (m + step - 1) / step;
-    constexpr int U = 4;
-    for (int j0 = tid; j0 < ms; j0 += CC_THREADS * U) {
-        T x[U], y[U], z[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = j0 + u * CC_THREADS;
-            const bool on = j < ms;
-            const T* r = rows + (size_t)(on ? j : 0) * step * c;
-            x[u] = on ? r[0] : T(0); y[u] = on ? r[1] : T(0); z[u] = on ? r[2] : T(0);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) { sx += (double)x[u]; sy += (double)y[u]; sz += (double)z[u]; }
+    const bool on = tid < ms;
+    unsigned key[3] = {0u, 0u, 0u};
+    if (on) {
+        const T* r = rows + (size_t)tid * step * c;
+        key[0] = sortable_bits((float)r[0]); key[1] = sortable_bits((float)r[1]); key[2] = sortable_bits((float)r[2]);
     }
+    if (tid < 3) { sel_prefix[tid] = 0u; sel_want[tid] = (ms - 1) / 2; }    // lower median
+    unsigned mask = 0u;
+    for (int pass = 3; pass >= 0; --pass) {
+        for (int d = tid; d < 3 * 256; d += CC_THREADS) (&hist[0][0])[d] = 0;
+        __syncthreads();
+        if (on) {
 #pragma unroll
-    for (int off = WAVE / 2; off > 0; off >>= 1) { sx += __shfl_down(sx, off); sy += __shfl_down(sy, off); sz += __shfl_down(sz, off); }
-    if ((tid & (WAVE - 1)) == 0) { part[tid >> 6][0] = sx; part[tid >> 6][1] = sy; part[tid >> 6][2] = sz; }
-    __syncthreads();
+            for (int a = 0; a < 3; ++a)
+                if ((key[a] & mask) == sel_prefix[a]) atomicAdd(&hist[a][(key[a] >> (8 * pass)) & 255u], 1);
+        }
+        __syncthreads();
+        if (wave < 3) {                                                     // wave a selects axis a's byte: 4 bins per lane
+            const int a = wave, want = sel_want[a];
+            const int h0 = hist[a][4 * lane], h1 = hist[a][4 * lane + 1], h2 = hist[a][4 * lane + 2], h3 = hist[a][4 * lane + 3];
+            int incl = h0 + h1 + h2 + h3;
+            const int own = incl;
+#pragma unroll
+            for (int off = 1; off < WAVE; off <<= 1) { const int o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+            const unsigned long long over = __ballot(incl > want);         // first lane whose running count passes `want`
+            const int L = over ? __ffsll((long long)over) - 1 : WAVE - 1;
+            if (lane == L) {
+                int w = want - (incl - own), d = 0;
+                if (w >= h0) { w -= h0; d = 1; if (w >= h1) { w -= h1; d = 2; if (w >= h2) { w -= h2; d = 3; } } }
+                sel_want[a] = w;
+                sel_prefix[a] |= (unsigned)(4 * lane + d) << (8 * pass);
+            }
+        }
+        mask |= 0xffu << (8 * pass);
+        __syncthreads();
+    }
     if (tid < 3) {
-        double v = 0.0;
-        for (int w = 0; w < CC_THREADS / WAVE; ++w) v += part[w][tid];
-        v /= (double)((m + (m + CC_SAMPLE - 1) / CC_SAMPLE - 1) / ((m + CC_SAMPLE - 1) / CC_SAMPLE));
+        unsigned u = sel_prefix[tid];
+        u ^= (u >> 31) ? 0x80000000u : 0xffffffffu;                         // inverse of sortable_bits
+        double v = (double)__uint_as_float(u);
         v = quantum > 0.0 ? rint(v / quantum) * quantum : v;
         center[(size_t)cloud * 3 + tid] = (v == v && fabs(v) < 1e30) ? (T)v : T(0);        // non-finite input: no centring
     }

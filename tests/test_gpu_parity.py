@@ -671,24 +671,27 @@ def test_icp_with_sweep_knn_matches_reference(golden, name, icp_type, diff, wind
     assert int(icp.knn_stats["knn_pairs"].sum().item()) > 0
 
 
-def test_cloud_center_is_the_quantised_centroid_and_zero_keeps_the_bits():
-    """dicp_cloud_center: centroid rounded to multiples of the quantum (0 near the origin); the *_centered producers with a zero
-    centre write exactly what the uncentred entry points write."""
+def test_cloud_center_is_the_quantised_median_and_zero_keeps_the_bits():
+    """dicp_cloud_center: coordinate-wise (lower) median of a stride sample of the target rows, rounded to multiples of the quantum
+    (0 near the origin), unmoved by far pad rows; the *_centered producers with a zero centre write exactly what the uncentred
+    entry points write."""
     g = torch.Generator().manual_seed(3)
     tgt = torch.rand((5, 777, 6), generator=g) * 20 - 10
     tgt[1, :, :3] += torch.tensor([1003.0, -37.0, 7.9])
     tgt[2, :, :3] += torch.tensor([-8.1, 24.3, 100000.0])
+    tgt[3, 500:, :] = 10000.0                                # a third of the rows are the reference's far pads (ICP.py:460)
     td = tgt.to(DEV)
-    c = _ops.cloud_center(td, quantum=16.0).cpu()
-    mean = tgt[:, :, :3].double().mean(1)                    # (777 rows: all of them are in the <= 4096-row sample)
-    assert torch.equal(c.double(), torch.round(mean / 16.0) * 16.0), (c, mean)
-    assert torch.equal(c[0], torch.zeros(3))
+    med = tgt[:, :, :3].float().sort(dim=1).values[:, (777 - 1) // 2]            # lower median per coordinate (777 rows: all sampled)
     exact = _ops.cloud_center(td, quantum=0.0).cpu()
-    np.testing.assert_allclose(exact.double().numpy(), mean.numpy(), rtol=1e-6, atol=1e-6)
+    assert torch.equal(exact, med), (exact, med)
+    c = _ops.cloud_center(td, quantum=16.0).cpu()
+    assert torch.equal(c.double(), torch.round(med.double() / 16.0) * 16.0), (c, med)
+    assert torch.equal(c[0], torch.zeros(3)) and torch.equal(c[3], torch.zeros(3))
     big = (torch.rand((2, 10000, 3), generator=g) * 20 - 10 + torch.tensor([500.0, 0.0, -300.0]))
-    step = (10000 + 4095) // 4096
-    np.testing.assert_allclose(_ops.cloud_center(big.to(DEV), quantum=0.0).cpu().double().numpy(), big[:, ::step].double().mean(1).numpy(),
-                               rtol=1e-6, atol=1e-6)         # larger clouds: the centroid of rows 0, step, 2 step, ...
+    step = (10000 + 1023) // 1024
+    sample = big[:, ::step]
+    assert torch.equal(_ops.cloud_center(big.to(DEV), quantum=0.0).cpu(), sample.sort(dim=1).values[:, (sample.shape[1] - 1) // 2])
+    assert torch.equal(_ops.cloud_center(big.double().to(DEV), quantum=0.0).cpu().float(), sample.sort(dim=1).values[:, (sample.shape[1] - 1) // 2])
     zero = torch.zeros((5, 3), device=DEV)
     assert torch.equal(_ops.pack_target(td), _ops.pack_target(td, zero))
     a, b = _ops.SweepIndex(td, sorted_rows=True), _ops.SweepIndex(td, sorted_rows=True, center=zero)

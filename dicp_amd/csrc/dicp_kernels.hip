@@ -132,13 +132,28 @@ __global__ __launch_bounds__(CC_THREADS) void cloud_center_kernel(const T* __res
     const int cloud = blockIdx.x, tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
     const T* __restrict__ rows = tgt + (size_t)cloud * m * c;
     const int step = (m + CC_SAMPLE - 1) / CC_SAMPLE, ms = (m + step - 1) / step;
-    const bool on = tid < ms;
+    // rows identical to the LAST row do not vote: the reference's pad rows are copies of one far point at the end of the cloud
+    // (ICP.py:460,472-477) and may well be the majority of a short cloud in a ragged batch
+    __shared__ int nact;
+    if (tid == 0) nact = 0;
+    __syncthreads();
+    const T* last = rows + (size_t)(m - 1) * c;
+    bool on = tid < ms;
     unsigned key[3] = {0u, 0u, 0u};
+    bool same = false;
     if (on) {
         const T* r = rows + (size_t)tid * step * c;
+        same = r[0] == last[0] && r[1] == last[1] && r[2] == last[2];
         key[0] = sortable_bits((float)r[0]); key[1] = sortable_bits((float)r[1]); key[2] = sortable_bits((float)r[2]);
     }
-    if (tid < 3) { sel_prefix[tid] = 0u; sel_want[tid] = (ms - 1) / 2; }    // lower median
+    {
+        const unsigned long long votes = __ballot(on && !same);
+        if (lane == 0 && votes) atomicAdd(&nact, __popcll(votes));
+    }
+    __syncthreads();
+    const int voters = nact > 0 ? nact : ms;                               // (every row the same point: they all vote)
+    on = on && (nact > 0 ? !same : true);
+    if (tid < 3) { sel_prefix[tid] = 0u; sel_want[tid] = (voters - 1) / 2; }    // lower median
     unsigned mask = 0u;
     for (int pass = 3; pass >= 0; --pass) {
         for (int d = tid; d < 3 * 256; d += CC_THREADS) (&hist[0][0])[d] = 0;

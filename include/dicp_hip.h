@@ -62,8 +62,9 @@ int dicp_pack_target(int dtype, const void* tgt, int N, int m, int c, void* tgt4
 
 /* Centred search coordinates.  The searches score in the expanded form 0.5|y|^2 - x.y (the reference's own: nn.py:32), whose rounding
  * error grows with 0.5|x|^2 -- and with it the prune margin of dicp_knn_sweep: a cloud a kilometre from the origin is searched almost
- * exhaustively.  dicp_cloud_center writes, per cloud, the coordinate-wise median of a stride sample of at most 1024 target rows (the centre only sizes
- * a margin, but it must sit inside the cloud: far pad rows -- ICP.py:460 -- would drag a mean away), rounded to a multiple of `quantum`
+ * exhaustively.  dicp_cloud_center writes, per cloud, the coordinate-wise median of a stride sample of at most 1024 target rows, copies of the cloud's last
+ * row not voting (the centre only sizes a margin, but it must sit inside the cloud: the reference's far pad rows -- ICP.py:460,472-477,
+ * copies of one point at the end -- can be most of a short cloud), rounded to a multiple of `quantum`
  * (0: not rounded; float precision) into
  * center (N,3) T; the *_centered entry points below pack rows as y - center, and the caller hands the searches the pose
  * [C | r - center] (dicp_loop_buffers.poses_search; dicp_loop_init_centered / the step kernels write it).  Every search form reads only

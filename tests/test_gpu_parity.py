@@ -679,14 +679,20 @@ def test_cloud_center_is_the_quantised_median_and_zero_keeps_the_bits():
     tgt = torch.rand((5, 777, 6), generator=g) * 20 - 10
     tgt[1, :, :3] += torch.tensor([1003.0, -37.0, 7.9])
     tgt[2, :, :3] += torch.tensor([-8.1, 24.3, 100000.0])
-    tgt[3, 500:, :] = 10000.0                                # a third of the rows are the reference's far pads (ICP.py:460)
+    tgt[3, 500:, :] = 10000.0                                # a third of the rows are the reference's far pads (ICP.py:460) ...
+    tgt[4, 200:, :] = 10000.0                                # ... or three quarters of them: copies of the last row do not vote
     td = tgt.to(DEV)
-    med = tgt[:, :, :3].float().sort(dim=1).values[:, (777 - 1) // 2]            # lower median per coordinate (777 rows: all sampled)
+    med = tgt[:, :776, :3].float().sort(dim=1).values[:, (776 - 1) // 2]         # lower median per coordinate (all 777 rows sampled; the last
+                                                                                 # row is a copy of itself: it never votes)
+    med[3] = tgt[3, :500, :3].float().sort(dim=0).values[(500 - 1) // 2]
+    med[4] = tgt[4, :200, :3].float().sort(dim=0).values[(200 - 1) // 2]
     exact = _ops.cloud_center(td, quantum=0.0).cpu()
     assert torch.equal(exact, med), (exact, med)
     c = _ops.cloud_center(td, quantum=16.0).cpu()
     assert torch.equal(c.double(), torch.round(med.double() / 16.0) * 16.0), (c, med)
-    assert torch.equal(c[0], torch.zeros(3)) and torch.equal(c[3], torch.zeros(3))
+    assert torch.equal(c[0], torch.zeros(3)) and torch.equal(c[3], torch.zeros(3)) and torch.equal(c[4], torch.zeros(3))
+    same = torch.full((1, 50, 3), 7.25)
+    assert torch.equal(_ops.cloud_center(same.to(DEV), quantum=0.0).cpu(), same[:, 0])                   # all rows one point: they all vote
     big = (torch.rand((2, 10000, 3), generator=g) * 20 - 10 + torch.tensor([500.0, 0.0, -300.0]))
     step = (10000 + 1023) // 1024
     sample = big[:, ::step]

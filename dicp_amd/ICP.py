@@ -64,7 +64,7 @@ class ICP:
         target : (m,3|6) | (N,m,3|6) | list of (m_i,3|6);  pt2pl needs the normals in 3:6
         T_init : (4,4) | (N,4,4) | list of (4,4)
         weight : None | (n) | (N,n) | list of (n_i)|None
-        trim_dist : None or a distance; loss_fn : None or {"name": "huber"|"cauchy", "metric": x}
+        trim_dist : None or a distance; loss_fn : None or {"name": "huber"|"cauchy"|"trim", "metric": x}
         dim : 3, or 2 to optimise rotation about z and translation in x,y only
         returns {"pc" (N,n,3), "T" (N,4,4), "costs" (N,K,1), "deltas" (N,K,6,1),
                  "weights" (N,K,n*r,1), "stats": {"converged","iterations","matched_ratio"}}
@@ -88,9 +88,7 @@ class ICP:
             source = source * keep_s
             target = target * keep_t
 
-        loss_name = loss_fn['name'] if loss_fn is not None else None
-        if loss_name == 'trim':
-            raise ValueError("dicp_amd: 'trim' is selected with trim_dist, not loss_fn")
+        loss_name = loss_fn['name'] if loss_fn is not None else None     # 'trim' is a valid loss too (loss.py:15-16)
         # the target sort / index build of the sweep path goes to the GPU before the rest of this function's host work
         prebuilt = None
         if not (self.nn.differentiable and self.nn.use_gumbel):
@@ -143,10 +141,13 @@ class ICP:
         returns (N,n,3), (N,4,4).  The step is the correct Kabsch solution C = U diag(1,1,det U det V) V^T,
         r = mu_t - C mu_s (the reference multiplies by V instead of V^T, ICP.py:566-570, which is only right
         for planar scenes; on those -- e.g. the bundled tests/data -- both reach the same pose).
-        Differences kept honest: ``T_init`` seeds the first correspondence search (the reference folds it into
-        the product without moving the points, ICP.py:545-547,578); ``trim_dist`` gates matches farther than
-        that (the reference ignores it); ``huber_delta`` and ``dim`` are accepted and ignored, as there;
-        ``weight`` (build-specific) gives per-point weights.  Stops when sum |T p - nn|^2 < tolerance (ICP.py:585).
+        ``T_init`` is folded in exactly as the reference does (ICP.py:545-547,578): the points are not moved by it -- the
+        search starts from the raw source and the result is T_ts = T_total @ T_init with T_total the transform that was
+        found, the returned cloud is T_total applied to the source.  (``self.svd_seed_T_init = True``, build-specific,
+        instead uses ``T_init`` as the starting pose of the search and returns the pose found.)
+        Differences kept honest: ``trim_dist`` gates matches farther than that (the reference ignores it);
+        ``huber_delta`` and ``dim`` are accepted and ignored, as there; ``weight`` (build-specific) gives per-point
+        weights.  Stops when sum |T p - nn|^2 < tolerance (ICP.py:585).
         """
         single = not isinstance(source, list) and source is not None and source.dim() == 2
         s_b, t_b, T_b, w_pts = self._batch(source, target, T_init, weight)
@@ -155,11 +156,14 @@ class ICP:
         home = s_b.device
         dev = home if s_b.is_cuda else compute_device()
         s_b, t_b, T_b, w_pts = (t.to(dev) for t in (s_b, t_b, T_b, w_pts))
-        T, costs, iterations = KabschLoop.apply(s_b, t_b, T_b, w_pts, int(self.max_iterations), float(self.tolerance),
-                                                trim_dist, bool(self.const_iter), self.knn_variant)
+        seed = bool(getattr(self, "svd_seed_T_init", False))
+        T_start = T_b if seed else torch.eye(4, dtype=T_b.dtype, device=dev).expand(T_b.shape[0], 4, 4).contiguous()
+        T_found, costs, iterations = KabschLoop.apply(s_b, t_b, T_start, w_pts, int(self.max_iterations), float(self.tolerance),
+                                                      trim_dist, bool(self.const_iter), self.knn_variant)
         if self.verbose:                                                                 # ICP.py:588-589
             print("ICP converged in {} iterations".format(int(iterations.max().item()) - 1))
-        pc = transform_points(s_b, T)                                                    # ICP.py:581
+        pc = transform_points(s_b, T_found)                                              # ICP.py:581
+        T = T_found if seed else torch.matmul(T_found, T_b)                              # ICP.py:578
         self.svd_stats = {"costs": costs, "iterations": iterations}
         if home != dev:
             pc, T = pc.to(home), T.to(home)
@@ -174,6 +178,19 @@ class ICP:
         if self.icp_type == 'pt2pt':
             w = w.repeat_interleave(3, dim=1)
         return s, t, T, w
+
+    @staticmethod
+    def _tensor_weight(w, source_b):
+        """A caller-supplied weight TENSOR (the list form is cast item by item below).  The reference multiplies it into the
+        residuals with torch broadcasting (ICP.py:169): a shape that does not broadcast against (N,n) raises there, a
+        different float dtype is promoted.  The kernels read raw (N,n) buffers of the cloud dtype, so both are settled
+        here: the same error for a wrong shape, a cast (differentiable) for a different dtype."""
+        if not isinstance(w, torch.Tensor):
+            raise TypeError("weight must be a tensor for a tensor source (got %s)" % (type(w),))
+        if tuple(w.shape) != tuple(source_b.shape[:2]):
+            raise RuntimeError("The size of tensor weight %s must match the source points %s"
+                               % (tuple(w.shape), tuple(source_b.shape[:2])))
+        return w if w.dtype == source_b.dtype else w.to(source_b.dtype)
 
     def _batch(self, source, target, T_init, weight):
         """As batch_size_handling, with ONE weight per point (what the kernels consume)."""
@@ -224,10 +241,10 @@ class ICP:
             w = torch.nn.utils.rnn.pad_sequence(pri, batch_first=True).to(**opts)
         elif source.dim() == 2 and source.shape[1] in (3, 6):
             source_b = source[:, :3].unsqueeze(0)
-            w = torch.ones((1, source_b.shape[1]), **opts) if weight is None else weight.unsqueeze(0)
+            w = torch.ones((1, source_b.shape[1]), **opts) if weight is None else self._tensor_weight(weight.unsqueeze(0), source_b)
         elif source.dim() == 3 and source.shape[2] in (3, 6):
             source_b = source[:, :, :3]
-            w = torch.ones(source_b.shape[:2], **opts) if weight is None else weight
+            w = torch.ones(source_b.shape[:2], **opts) if weight is None else self._tensor_weight(weight, source_b)
         else:
             raise ValueError("source must be (n x 3/6) or (N x n x 3/6) or list len(N) (n_N x 3/6)")
 

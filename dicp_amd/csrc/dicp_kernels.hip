@@ -2869,7 +2869,7 @@ int dicp_scatter_add_rows(int dtype, const void* gout, const int32_t* idx, int N
 static int check_params(const dicp_weight_params* p, int c) {
     if (!p) return DICP_ERR_NULL;
     if (p->mode != DICP_PT2PT && p->mode != DICP_PT2PL) return DICP_ERR_ENUM;
-    if (p->loss < DICP_LOSS_NONE || p->loss > DICP_LOSS_CAUCHY) return DICP_ERR_ENUM;
+    if (p->loss < DICP_LOSS_NONE || p->loss > DICP_LOSS_TRIM) return DICP_ERR_ENUM;
     if (p->mode == DICP_PT2PL ? (c != 6) : (c != 3 && c != 6)) return DICP_ERR_SHAPE;   // ICP.py:103
     return 0;
 }

@@ -24,7 +24,7 @@
 namespace dicp {
 
 enum Mode { MODE_PT2PT = 0, MODE_PT2PL = 1 };
-enum Loss { LOSS_NONE = 0, LOSS_HUBER = 1, LOSS_CAUCHY = 2 };
+enum Loss { LOSS_NONE = 0, LOSS_HUBER = 1, LOSS_CAUCHY = 2, LOSS_TRIM = 3 };   // trim as loss_fn: loss.py:15-16
 
 // Accumulator slots produced per cloud and iteration.
 //   [0,21)  upper triangle of the 6x6  A = sum u J^T J   (row-major, i<=j)
@@ -84,6 +84,7 @@ template <typename T> struct PointState {
     T en;        // norm the robust loss sees (|e| or d3)
     T tw, lw;    // trim and loss weights
     T th;        // tanh(...) of the soft trim gate
+    T lth;       // tanh(...) of the soft gate when loss_fn itself is "trim" (loss.py:15-16)
     T w, root, ws, u;   // w, sqrt(w+1e-10), root-1e-5, ws^2
 };
 
@@ -106,7 +107,7 @@ DICP_HD void point_weights(const WeightParams& P, const T* C, const T* r, const 
             s.tw = (s.d3 < T(P.trim_dist)) ? T(1) : T(0);
         }
     }
-    s.lw = T(1);
+    s.lw = T(1); s.lth = T(0);
     const T dl = T(P.loss_delta);
     if (P.loss == LOSS_HUBER) {
         if (P.differentiable) s.lw = (dl * dl) / (dl * dl + s.en * s.en);  // loss.py:30
@@ -114,6 +115,13 @@ DICP_HD void point_weights(const WeightParams& P, const T* C, const T* r, const 
     } else if (P.loss == LOSS_CAUCHY) {                                    // loss.py:41
         const T t = s.en / dl;
         s.lw = T(1) / (T(1) + t * t);
+    } else if (P.loss == LOSS_TRIM) {                                      // loss.py:43-58 on the loss residual (ICP.py:157-160)
+        if (P.differentiable) {
+            s.lth = m_tanh(T(P.tanh_k) * (dl - s.en) - T(3));
+            s.lw = T(0.5) * s.lth + T(0.5);
+        } else {
+            s.lw = (s.en < dl) ? T(1) : T(0);
+        }
     }
     s.w = w0 * s.tw * s.lw;                                                // ICP.py:169
     s.root = m_sqrt(s.w + T(1.0e-10));                                     // ICP.py:194
@@ -268,6 +276,8 @@ DICP_HD void point_backward(const WeightParams& P, const T* C, const T* r, const
         else                  dlw_den = hard_huber_slope(s.en, dl);
     } else if (P.loss == LOSS_CAUCHY) {
         dlw_den = -T(2) * s.en * s.lw * s.lw / (dl * dl);
+    } else if (P.loss == LOSS_TRIM && P.differentiable) {                  // the hard gate has no gradient
+        dlw_den = -T(0.5) * T(P.tanh_k) * (T(1) - s.lth * s.lth);
     }
     if (MODE == MODE_PT2PL) {
         // en = |e| ; torch's norm backward gives e/|e| (0 at e == 0)

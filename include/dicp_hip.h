@@ -41,7 +41,7 @@ typedef struct dicp_weight_params {
     int32_t mode;            /* DICP_PT2PT | DICP_PT2PL */
     int32_t trim_on;         /* trim_dist is not None and >= 0            ICP.py:153 */
     int32_t differentiable;  /* ICP(differentiable=...)                   ICP.py:38  */
-    int32_t loss;            /* DICP_LOSS_NONE | _HUBER | _CAUCHY         ICP.py:158 */
+    int32_t loss;            /* DICP_LOSS_NONE | _HUBER | _CAUCHY | _TRIM (loss.py:12-17)   ICP.py:158 */
     double trim_dist;
     double tanh_k;           /* config tanh_steepness                     ICP.py:119 */
     double loss_delta;       /* loss_fn["metric"]                                    */

@@ -241,6 +241,49 @@ def matrix3d():
     save("matrix3d", **arrs)
 
 
+def matrix3d_trimloss():
+    """loss_fn={"name": "trim", ...} is a valid call (ICP.py:157-160 -> loss.py:15-16,43-58: the trim gate applied to the
+    residual the robust loss sees, |e| for pt2pl and |e3| for pt2pt, on top of -- or instead of -- trim_dist).  Same clouds,
+    weights, T_init and cotangents as matrix3d (same seed), loss metric 1.2."""
+    rng = np.random.RandomState(77)
+    N, n, m, K = 3, 48, 60, 4
+    src_np, tgt_np = make_cloud(rng, N, n, m)
+    w_np = rng.uniform(0.2, 1.0, size=(N, n))
+    T0_np = np.stack([vec2tran(np.concatenate([rng.uniform(-0.05, 0.05, 3), rng.uniform(-0.02, 0.02, 3)])) for _ in range(N)])
+    gT = rng.normal(size=(N, 4, 4))
+    gpc = rng.normal(size=(N, n, 3))
+    metric = 1.2
+    arrs = dict(source=src_np, target=tgt_np, weight=w_np, T_init=T0_np, gT=gT, gpc=gpc, K=np.array(K), loss_metric=np.array(metric))
+    dtype = torch.float64
+    for icp_type in ("pt2pl", "pt2pt"):
+        for diff in (True, False):
+            for trim in (None, 1.5):
+                for dim in (3, 2):
+                    if dim == 2 and trim is None:
+                        continue
+                    key = "%s_%s_trim_%s_d%d" % (icp_type, "diff" if diff else "hard", "trim" if trim else "notrim", dim)
+                    src = torch.tensor(src_np, dtype=dtype, requires_grad=True)
+                    tg = tgt_np if icp_type == "pt2pl" else tgt_np[:, :, :3]
+                    tgt = torch.tensor(tg, dtype=dtype, requires_grad=True)
+                    w = torch.tensor(w_np, dtype=dtype, requires_grad=True)
+                    T0 = torch.tensor(T0_np, dtype=dtype, requires_grad=True)
+                    icp = RefICP(icp_type=icp_type, differentiable=diff, max_iterations=K, tolerance=1e-14)
+                    icp.const_iter = True
+                    r = icp.icp(src, tgt, T0, weight=w, trim_dist=trim, loss_fn={"name": "trim", "metric": metric}, dim=dim)
+                    obj = (r["T"] * torch.tensor(gT, dtype=dtype)).sum() + (r["pc"] * torch.tensor(gpc, dtype=dtype)).sum()
+                    obj.backward()
+                    for k, v in pack_result(r, key + "__").items():
+                        if k.endswith("weights") or k.endswith("pc"):
+                            continue
+                        arrs[k] = v
+                    arrs[key + "__w_last"] = npy(r["weights"][:, -1, :, 0])
+                    arrs[key + "__grad_source"] = npy(src.grad)
+                    arrs[key + "__grad_target"] = npy(tgt.grad)
+                    arrs[key + "__grad_weight"] = npy(w.grad)
+                    arrs[key + "__grad_T_init"] = npy(T0.grad)
+    save("matrix3d_trimloss", **arrs)
+
+
 # -------------------------------------------------------------------- nn / loss
 def nn_vectors():
     rng = np.random.RandomState(5)
@@ -304,6 +347,17 @@ def svd_planar():
     save("svd_planar", pc=npy(ps), T=npy(T), T_ts_true=np.linalg.inv(vec2tran([1.0, 1.0, 0, 0, 0, 0.1])))
 
 
+def svd_tinit():
+    """ICP.pt2pt_dICP_SVD with T_init != I (ICP.py:545-547,578): the points are NOT moved by T_init -- the search starts
+    from the raw source and the result is T_ts = (product of the updates) @ T_init, ps = (product of the updates) source."""
+    src = torch.tensor(SCAN[:, :3])
+    tgt = torch.tensor(MAP[:, :3])
+    T0 = torch.tensor(vec2tran([0.3, -0.2, 0, 0, 0, 0.05]))
+    icp = RefICP(icp_type="pt2pt", differentiable=False, max_iterations=100, tolerance=1e-20)
+    ps, T = icp.pt2pt_dICP_SVD(src, tgt, T0)
+    save("svd_tinit", pc=npy(ps), T=npy(T), T_init=npy(T0))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:                      # regenerate selected files only: make_golden.py svd_planar ...
         for fn in sys.argv[1:]:
@@ -322,6 +376,8 @@ if __name__ == "__main__":
     diff_vs_nondiff()
     padded_inputs()
     matrix3d()
+    matrix3d_trimloss()
     nn_vectors()
     loss_vectors()
     svd_planar()
+    svd_tinit()

@@ -85,17 +85,19 @@ def run_chain(hc, src, tgt, w0, T0, P, K, dim, gT, gpc):
     return T, saved, gs * mask_s, gt * mask_t, gw, gT0
 
 
-def test_matrix3d_forward_and_backward(hc, golden):
-    g = golden("matrix3d")
+@pytest.mark.parametrize("fixture", ["matrix3d", "matrix3d_trimloss"])
+def test_matrix3d_forward_and_backward(hc, golden, fixture):
+    g = golden(fixture)
     K = int(g["K"])
+    metric = float(g["loss_metric"]) if "loss_metric" in g else 0.3
     keys = sorted(k[:-len("__T")] for k in g if k.endswith("__T"))
     for key in keys:
         icp_type, mode, lname, trim, d = key.split("_")
         dim = int(d[1])
         P = WeightParams(mode=1 if icp_type == "pt2pl" else 0, trim_on=int(trim == "trim"),
                          differentiable=int(mode == "diff"),
-                         loss={"none": 0, "huber": 1, "cauchy": 2}[lname],
-                         trim_dist=1.5, tanh_k=5.0, loss_delta=0.3, match_thresh=0.0)
+                         loss={"none": 0, "huber": 1, "cauchy": 2, "trim": 3}[lname],
+                         trim_dist=1.5, tanh_k=5.0, loss_delta=metric, match_thresh=0.0)
         tgt_all = g["target"] if icp_type == "pt2pl" else np.ascontiguousarray(g["target"][:, :, :3])
         for b in range(g["source"].shape[0]):
             T, saved, gs, gt, gw, gT0 = run_chain(hc, g["source"][b], tgt_all[b], np.ascontiguousarray(g["weight"][b]),

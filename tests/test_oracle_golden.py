@@ -94,11 +94,14 @@ def matrix_keys(g):
     return sorted(k[:-len("__T")] for k in g if k.endswith("__T"))
 
 
-def test_matrix3d(golden):
-    g = golden("matrix3d")
+@pytest.mark.parametrize("fixture,count", [("matrix3d", 28), ("matrix3d_trimloss", 12)])
+def test_matrix3d(golden, fixture, count):
+    """matrix3d_trimloss: loss_fn={"name": "trim"} (ICP.py:157-160 -> loss.py:15-16), a valid reference call."""
+    g = golden(fixture)
     K = int(g["K"])
+    metric = float(g["loss_metric"]) if "loss_metric" in g else 0.3
     keys = matrix_keys(g)
-    assert len(keys) == 28
+    assert len(keys) == count
     for key in keys:
         icp_type, mode, lname, trim, d = key.split("_")
         src = t(g["source"], grad=True)
@@ -108,7 +111,7 @@ def test_matrix3d(golden):
         w_in = w if icp_type == "pt2pl" else w.repeat_interleave(3, dim=1)
         res = O.icp_batched(src, tgt, T0, w_in, icp_type=icp_type, differentiable=(mode == "diff"),
                             max_iterations=K, tolerance=1e-14, trim_dist=(1.5 if trim == "trim" else None),
-                            loss_fn=None if lname == "none" else {"name": lname, "metric": 0.3},
+                            loss_fn=None if lname == "none" else {"name": lname, "metric": metric},
                             dim=int(d[1]), const_iter=True)
         check_result(res, g, key + "__")
         np.testing.assert_allclose(res["weights"][:, -1, :, 0].numpy(), g[key + "__w_last"], **T64)

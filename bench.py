@@ -5,19 +5,32 @@
 
 Workload = BASELINE.json configs[2] ("C3"): per GPU B=256 synthetic scan pairs, n=m=16384,
 point-to-plane + Huber(1.0) + soft trim(5.0), differentiable, dim=3, float32, T_init=I.
-One "step" = one ICP iteration over the whole batch, forward AND backward: the timed region is
+One "step" = one ICP iteration over the whole batch, forward AND backward: a timed call is
 ONE differentiable icp() call of K constant iterations, backward of T.sum() w.r.t. source and
-target, and (N>1) the RCCL all-gather of the poses.  Inputs are resident in HBM when timing starts.
+target, and (N>1) the RCCL all-gather of the poses, between barrier + device syncs.  Inputs are
+resident in HBM when timing starts.  `value` is the MEDIAN of --reps (>= 5) such calls made
+back to back after a steady-state warm-up ("warm-up 2 calls, then median of >= 5").
+
+Beside `value` the same run reports, each as the median of its own timed calls:
+  value_bruteforce  the same K-iteration call with the brute-force kNN kernel in the loop (all n*m
+                    pairs: the data-independent floor; `value` runs the exact slab-pruned search,
+                    which returns the same indices but whose cost depends on the data and the pose)
+  value_tolerance   a tolerance-mode call (tolerance 1e-4, up to 50 iterations, const_iter off):
+                    cloud-iterations actually executed per second, early iterations included
 
 For N>1 launch with torch.distributed.run (one rank per GPU, weak scaling: 256 clouds per rank).
 Rank 0 prints ONE JSON line.  `roofline` is the kNN kernel (the dominant one, FP32-compute-bound:
-8*n*m flops per cloud-iteration against the 157.3 TF f32 peak) timed with HIP events on the
-launch stream; `roofline_streaming` is the HBM-bound backward accumulate kernel.  `cpu_baseline`
-is the CPU oracle (the reference's op sequence) timed on this host for a bounded sample.
+8 flop per scored pair against the 157.3 TF f32 peak) timed with HIP events on the launch stream;
+`roofline_accumulate` / `roofline_streaming` are the HBM-bound forward / backward accumulate
+kernels on their ALGORITHMIC bytes (48n / 88n per cloud).  `cpu_baseline` is the
+CPU oracle (the reference's op sequence) timed on this host for a bounded sample.  The run FAILS
+(exit 1, value null) if a result is not finite or the pose disagrees with the oracle by > 1e-4.
 """
 import argparse
+import gc
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -31,20 +44,23 @@ from dicp_amd import dist as ddist                      # noqa: E402
 from dicp_amd.ICP import ICP                            # noqa: E402
 from dicp_amd.synthetic import make_pairs               # noqa: E402
 
-STEADY_CALLS, STEADY_MAX = 3, 40   # untimed K-iteration calls before the timed one: at least / at most
+STEADY_CALLS, STEADY_MAX = 3, 40   # untimed K-iteration calls before the timed ones: at least / at most
 F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32 vector == f32-input MFMA peak
 HBM_PEAK_GBS = 8000.0        # HBM3E spec
 LOSS = {"name": "huber", "metric": 1.0}
 TRIM = 5.0
+POSE_BAR = 1e-4              # north-star parity bar for poses
+EV_PER_ITER = 6              # dicp_loop_buffers.events: kNN, accumulate (forward), accumulate_bwd -- a start/stop pair each
 
 
 class EventLog:
-    """HIP events around the kNN launch (forward) and the accumulate_bwd launch (backward) of every iteration.
+    """HIP events around the kNN, accumulate (forward) and accumulate_bwd (backward) launch of every iteration.
     The loop runs inside libdicp_hip.so (dicp_icp_forward / _backward), so the library records them: it is handed
     the raw hipEvent_t handles of these torch events (same HIP runtime) -- on the stream the kernels run on.  The
-    sweep and windowed-backward launches carry their pair on the dispatch itself (hipExtLaunchKernel start / stop
-    events: the kernel's own begin / end timestamps, no barrier packets in the timed queue); the brute-force and
-    atomic forms are bracketed by hipEventRecord."""
+    sweep, accumulate and windowed-backward launches carry their pair on the dispatch itself (hipExtLaunchKernel
+    start / stop events: the kernel's own begin / end timestamps, no barrier packets in the timed queue); the
+    brute-force and atomic forms are bracketed by hipEventRecord."""
+    OFF = {"knn": 0, "accumulate": 2, "accumulate_bwd": 4}
 
     def __init__(self):
         self.K, self.ev, self.arr = 0, None, None
@@ -52,26 +68,41 @@ class EventLog:
     def handles(self, K):
         import ctypes
         if self.K != K:
-            self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(4 * K)]
+            self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(EV_PER_ITER * K)]
             for e in self.ev:
                 e.record()                       # materialises the underlying hipEvent_t
-            self.arr = (ctypes.c_void_p * (4 * K))(*[e.cuda_event for e in self.ev])
+            self.arr = (ctypes.c_void_p * (EV_PER_ITER * K))(*[e.cuda_event for e in self.ev])
             self.K = K
         return ctypes.cast(self.arr, ctypes.c_void_p)
 
     def all_ms(self, name):
-        off = 0 if name == "knn" else 2
-        return [self.ev[4 * k + off].elapsed_time(self.ev[4 * k + off + 1]) for k in range(self.K)]
+        off = self.OFF[name]
+        out = []
+        for k in range(self.K):
+            try:
+                out.append(self.ev[EV_PER_ITER * k + off].elapsed_time(self.ev[EV_PER_ITER * k + off + 1]))
+            except Exception:
+                return []
+        return out
 
-    def mean_ms(self, name):
-        ts = self.all_ms(name)
-        return sum(ts) / len(ts) if ts else None
+
+def median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2])
+
+
+def git_head():
+    try:
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        return None
 
 
 def pmc_traffic(kernel_prefix, B, n):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_hbm_traffic.json, made by
-    scripts/pmc_summary.py from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command).
-    PMC counters cannot be read from inside the process, so this is null when no matching profile exists."""
+    """HBM bytes per launch from the COMMITTED rocprofv3 PMC passes (profiles/*_pmc_hbm_traffic*.json, made by
+    scripts/pmc_summary.py from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command).  PMC counters
+    cannot be read from inside the process: this number is NOT measured by the run that prints it, and the line says so
+    (file and the commit the profile was taken at).  None when no matching profile exists."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic*.json")), reverse=True):
         try:
@@ -83,7 +114,8 @@ def pmc_traffic(kernel_prefix, B, n):
         hits = [k for name, k in d["kernels"].items() if name.startswith(kernel_prefix) and k.get("launches")]
         if hits:        # several launch configurations of one kernel (template arguments): launch-weighted mean
             tot = sum(k["launches"] for k in hits)
-            return sum(k["hbm_bytes"] * k["launches"] for k in hits) / tot, os.path.basename(f)
+            src = "from committed profile %s@%s (not measured by this run)" % (os.path.basename(f), d.get("commit", "unknown"))
+            return sum(k["hbm_bytes"] * k["launches"] for k in hits) / tot, src
     return None, None
 
 
@@ -94,7 +126,7 @@ def run_call(icp, src, tgt, T0, world):
     out = icp.icp(s, t, T0, trim_dist=TRIM, loss_fn=LOSS, dim=3)
     out["T"].sum().backward()
     # every rank holds the same number of clouds: the shard sizes are known, no size exchange (and no host sync) before the gather
-    T_all = ddist.gather_poses(out["T"], total=src.shape[0] * abs(world), force=True) if world != 1 else out["T"].detach()
+    T_all = ddist.gather_poses(out["T"].detach(), total=src.shape[0] * abs(world), force=True) if world != 1 else out["T"].detach()
     return out, T_all, s.grad, t.grad
 
 
@@ -120,7 +152,7 @@ def cpu_baseline(n, m, budget_s=25.0):
         ref["T"].sum().backward()
         times.append(time.time() - t0)
         T_ref = ref["T"].detach()
-    best = sorted(times)[len(times) // 2]
+    best = median(times)
     return {"value": Bc * K / best, "unit": "cloud-iterations/s", "cores": cores, "kind": "port",
             "sample": "%d clouds x %d iterations fwd+bwd, n=m=%d, float32, median of %d runs (%.2f s each)"
                       % (Bc, K, n, len(times), best)}, T_ref
@@ -129,13 +161,15 @@ def cpu_baseline(n, m, budget_s=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=10, help="K: ICP iterations per timed call (SURVEY 8d: 10)")
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reps", type=int, default=5, help="timed K-iteration calls; `value` is their median (>= 5)")
     ap.add_argument("--batch", type=int, default=256, help="clouds per GPU")
     ap.add_argument("--points", type=int, default=16384, help="points per cloud (source and target)")
     ap.add_argument("--knn", choices=["auto", "sweep", "valu", "mfma"], default="auto",
                     help="auto/sweep: exact slab-pruned kNN (same indices as brute force); valu/mfma: brute-force kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip value_bruteforce / value_tolerance")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -154,53 +188,21 @@ def main():
     # even with one rank: how the N>1 path is smoke-tested on a 1-GPU box
     force_dist = os.environ.get("DICP_BENCH_FORCE_DIST", "0") == "1" and "RANK" in os.environ
     use_dist = world > 1 or force_dist
+    ranks_seen, rccl = 1, None
     if use_dist:
         torch.distributed.init_process_group("nccl", device_id=dev)     # RCCL
+        ranks_seen = torch.distributed.get_world_size()
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            rccl = None
 
     B, n, m, K, W = args.batch, args.points, args.points, args.steps, args.warmup
+    reps = max(5, args.reps)
     src, tgt = make_pairs(B, n, m, seed=3, dtype=torch.float32, first=rank * B)
     src, tgt = src.to(dev), tgt.to(dev)
     T0 = torch.eye(4, device=dev).repeat(B, 1, 1)
-
     cw = world if not (force_dist and world == 1) else -1
-    icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=max(W, 1), tolerance=1e-12)
-    icp.const_iter = True
-    icp.knn_variant = {"auto": 0, "sweep": 3, "valu": 1, "mfma": 2}[args.knn]
-    brute = args.knn in ("valu", "mfma")      # (auto also runs brute force when the clouds are small: settled after the timed call)
-    if W > 0:
-        run_call(icp, src, tgt, T0, cw)                                  # W untimed warm-up steps
-    icp.max_iterations = K
-    # still untimed: calls at the timed call's own shapes, so that the caching allocator already owns the K-sized
-    # history / saved-index buffers (the first use of a new size is a synchronous hipMalloc) and the chip is in its
-    # steady state -- back-to-back calls get faster for a while (6.8, 6.15, 6.1, 5.95, 5.9 ms: scripts/call_repeat_diag.py);
-    # the number reported is what a training loop that calls icp() every step sees
-    log = EventLog()
-    log.handles(K)                          # create the HIP events now: not part of the timed workload
-    icp._timing_events = None if os.environ.get("DICP_BENCH_NO_EVENTS") == "1" else log      # (experiment switch: what do the events cost?)
-    # a generational GC pass over this process's heap takes tens of ms (10 steps take 7 ms): whether one lands inside
-    # the timed call depends on the allocation count so far, i.e. on things as irrelevant as argv -> collect now and
-    # pause the collector.  The collection goes BEFORE the steady-state calls: the first call after one is ~0.8 ms
-    # slower (it frees the previous calls' graphs and the caching allocator re-splits its blocks).
-    import gc
-    gc.collect()
-    gc.disable()
-    steady_calls, recent = 0, []
-    while steady_calls < STEADY_MAX:        # the events ride along: their first use costs the host too
-        torch.cuda.synchronize()
-        t_w = time.perf_counter()
-        run_call(icp, src, tgt, T0, cw)
-        torch.cuda.synchronize()
-        recent = (recent + [time.perf_counter() - t_w])[-3:]
-        steady_calls += 1
-        # steady = the last three calls within 3 % of each other (a fresh box needs more calls than a warm one: clocks,
-        # first-touch of code objects and of the allocator's pools); every rank makes the same number of calls
-        done = steady_calls >= STEADY_CALLS and max(recent) <= 1.03 * min(recent)
-        if use_dist:
-            flag = torch.tensor([1 if done else 0], device=dev)
-            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
-            done = bool(flag.item())
-        if done:
-            break
 
     def fence():
         torch.cuda.synchronize()
@@ -208,30 +210,98 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    fence()
-    t0 = time.perf_counter()
-    out, T_all, gs, gt = run_call(icp, src, tgt, T0, cw)                 # exactly K steps
-    t_host = time.perf_counter() - t0
-    fence()
-    elapsed = time.perf_counter() - t0
-    if os.environ.get("DICP_BENCH_DIAG") == "1":
-        sys.stderr.write("timed call: host-return %.2f ms, done %.2f ms\n" % (t_host * 1e3, elapsed * 1e3))
-        for _ in range(3):
-            fence(); a = time.perf_counter(); run_call(icp, src, tgt, T0, cw); b = time.perf_counter(); fence()
-            sys.stderr.write("  again: host-return %.2f ms, done %.2f ms\n" % ((b - a) * 1e3, (time.perf_counter() - a) * 1e3))
-    gc.enable()
-    if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    def all_max(x):
+        if not use_dist:
+            return x
+        tmax = torch.tensor([x], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        return float(tmax.item())
 
-    knn_ms = log.mean_ms("knn")
-    bwd_ms = log.mean_ms("accumulate_bwd")
+    def steady(icp_obj, least=STEADY_CALLS, most=STEADY_MAX):
+        """Untimed calls at the timed call's own shapes until three in a row agree to 3 %: the caching allocator then owns
+        the K-sized buffers (the first use of a new size is a synchronous hipMalloc) and the chip is in its steady state
+        (back-to-back calls get faster for a while on a cold box: scripts/call_repeat_diag.py).  Same count on every rank."""
+        calls, recent = 0, []
+        while calls < most:
+            torch.cuda.synchronize()
+            t_w = time.perf_counter()
+            run_call(icp_obj, src, tgt, T0, cw)
+            torch.cuda.synchronize()
+            recent = (recent + [time.perf_counter() - t_w])[-3:]
+            calls += 1
+            done = calls >= least and max(recent) <= 1.03 * min(recent)
+            if use_dist:
+                flag = torch.tensor([1 if done else 0], device=dev)
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+                done = bool(flag.item())
+            if done:
+                break
+        return calls
+
+    def timed(icp_obj, count):
+        """`count` calls, each bracketed by barrier + device sync on both sides; per call the MAX over ranks."""
+        times, last = [], None
+        for _ in range(count):
+            fence()
+            t0 = time.perf_counter()
+            last = run_call(icp_obj, src, tgt, T0, cw)
+            fence()
+            times.append(all_max(time.perf_counter() - t0))
+        return times, last
+
+    icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=max(W, 1), tolerance=1e-12)
+    icp.const_iter = True
+    icp.knn_variant = {"auto": 0, "sweep": 3, "valu": 1, "mfma": 2}[args.knn]
+    brute = args.knn in ("valu", "mfma")      # (auto also runs brute force when the clouds are small: settled after the timed calls)
+    if W > 0:
+        run_call(icp, src, tgt, T0, cw)                                  # W untimed warm-up steps
+    icp.max_iterations = K
+    log = EventLog()
+    log.handles(K)                          # create the HIP events now: not part of the timed workload
+    icp._timing_events = None if os.environ.get("DICP_BENCH_NO_EVENTS") == "1" else log      # (experiment switch: what do the events cost?)
+    # a generational GC pass over this process's heap takes tens of ms (10 steps take 5 ms): whether one lands inside a
+    # timed call depends on the allocation count so far, i.e. on things as irrelevant as argv -> collect now and pause
+    # the collector.  The collection goes BEFORE the steady-state calls: the first call after one is ~0.8 ms slower
+    # (it frees the previous calls' graphs and the caching allocator re-splits its blocks).
+    gc.collect()
+    gc.disable()
+    steady_calls = steady(icp)
+    times, (out, T_all, gs, gt) = timed(icp, reps)                       # reps x exactly K steps
+    elapsed = median(times)
+    knn_all, acc_all, bwd_all = log.all_ms("knn"), log.all_ms("accumulate"), log.all_ms("accumulate_bwd")   # of the LAST timed call
     sane = bool(torch.isfinite(out["T"]).all() and torch.isfinite(gs).all() and torch.isfinite(gt).all())
-
-    # one extra, untimed launch of the brute-force kNN kernel with HIP events: its roofline is reported
-    # beside the running kernel's even when the (faster, exact) sweep kernel is the one in the loop
     from dicp_amd import _ops, _lib as L
+    from dicp_amd._ops import auto_knn_kind
+    # knn=auto takes the brute-force kernel for small clouds (no sorted-sweep statistics then)
+    if args.knn == "auto" and auto_knn_kind(B, n, m) != L.KNN_SWEEP:
+        brute = True
+    # pairs scored per kNN launch of the LAST timed call (each call has its own counters)
+    pairs_scored = None if brute else float(icp.knn_stats["knn_pairs"].sum().item()) / K
+
+    # ---- the brute-force floor and the tolerance-mode call, in the same run (median of their own timed calls)
+    extra = {}
+    if not args.no_extra_legs:
+        if not brute:
+            bf = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
+            bf.const_iter = True
+            bf.knn_variant = L.KNN_VALU
+            steady(bf, least=2, most=4)
+            bt, _ = timed(bf, 3)
+            extra["value_bruteforce"] = world * B * K / median(bt)
+            extra["bruteforce_note"] = "same call with the brute-force kNN kernel (all n*m pairs) in the loop: median of 3 calls, %.3f ms per step" % (median(bt) * 1e3 / K)
+        tol = ICP(icp_type="pt2pl", differentiable=True, max_iterations=50, tolerance=1e-4)
+        tol.const_iter = False
+        tol.knn_variant = icp.knn_variant
+        steady(tol, least=3, most=8)
+        tt, (tout, _, _, _) = timed(tol, reps)
+        k_exec = int(tout["deltas"].shape[1])
+        extra["value_tolerance"] = world * B * k_exec / median(tt)
+        extra["tolerance_note"] = ("tolerance 1e-4, max 50 iterations, const_iter off: %d iterations executed, %.3f ms per call, "
+                                   "median of %d calls" % (k_exec, median(tt) * 1e3, reps))
+    gc.enable()
+
+    # three extra, untimed launches of the brute-force kNN kernel with HIP events: its roofline is reported
+    # beside the running kernel's even when the (faster, exact) sweep kernel is the one in the loop
     tgt4 = _ops.pack_target(tgt)
     pose_id = torch.cat((torch.eye(3, device=dev).reshape(9), torch.zeros(3, device=dev))).repeat(B, 1).contiguous()
     idx_tmp = torch.empty((B, n), dtype=torch.int32, device=dev)
@@ -244,71 +314,93 @@ def main():
         torch.cuda.synchronize()
         bf.append(a.elapsed_time(b))
     bf_ms = sorted(bf)[1]
-    # knn=auto takes the brute-force kernel for small clouds (no sorted-sweep statistics then)
-    from dicp_amd._ops import auto_knn_kind
-    if args.knn == "auto" and auto_knn_kind(B, n, m) != L.KNN_SWEEP:
-        brute = True
-    pairs_scored = None if brute else float(icp.knn_stats["knn_pairs"].sum().item()) / K      # per launch
 
+    rc = 0
     if rank == 0:
+        def mean(v):
+            return sum(v) / len(v) if v else None
+        knn_ms, acc_ms, bwd_ms = mean(knn_all), mean(acc_all), mean(bwd_all)
         flops_bf = 8.0 * n * m * B                                       # brute force, per launch
-        flops = flops_bf if brute else 8.0 * pairs_scored                # pairs the kernel actually scored
-        knn_tf = flops / (knn_ms * 1e-3) / 1e12
+        flops = flops_bf if (brute or pairs_scored is None) else 8.0 * pairs_scored   # pairs the kernel actually scored
+        knn_tf = flops / (knn_ms * 1e-3) / 1e12 if knn_ms else None
+        acc_bytes = 48.0 * n * B                                         # per forward accumulate launch
         bwd_bytes = 88.0 * n * B                                         # per backward launch
         knn_traffic, knn_src = pmc_traffic("knn_valu" if brute else "knn_sweep", B, n)
         bwd_kernel = "accumulate_bwd_kernel" if brute else "accumulate_bwd_window_kernel"
         bwd_traffic, bwd_src = pmc_traffic(bwd_kernel, B, n)
+        acc_traffic, acc_src = pmc_traffic("accumulate_kernel", B, n)
         bf_traffic, bf_src = pmc_traffic("knn_valu", B, n)
         line = {
             "metric": "ICP cloud-iterations/sec (fwd+bwd), B=%dx%d-pt clouds per GPU" % (B, n),
             "value": world * B * K / elapsed,
             "unit": "cloud-iterations/s",
             "n_gpus": world, "steps": K, "warmup": W,
+            "timed_calls": reps, "call_ms": [round(v * 1e3, 4) for v in times],
+            "value_note": "median of %d timed %d-iteration calls (each: barrier + sync, icp() + backward(), barrier + sync; max over ranks)" % (reps, K),
             "warmup_note": "W-iteration call, then %d untimed K-iteration calls (until three in a row agree to 3 %%: allocator + steady state at the timed shapes)" % steady_calls,
             "ms_per_step": elapsed * 1e3 / K,
             "batch_iterations_per_s": K / elapsed,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "ranks_seen": ranks_seen, "rccl_version": rccl, "head": git_head(),
             "config": {"workload": "BASELINE configs[2]: B=%d/GPU synthetic %d-pt clouds, point-to-plane + huber(1.0) + "
-                                   "trim(5.0), differentiable, dim=3, %d const iterations fwd + backward of T.sum() "
+                                   "trim(5.0), differentiable, dim=3, K=%d const iterations fwd + backward of T.sum() "
                                    "w.r.t. source and target" % (B, n, K),
-                       "clouds_per_gpu": B, "points": n, "icp_type": "pt2pl", "knn": args.knn,
+                       "K": K, "clouds_per_gpu": B, "points": n, "icp_type": "pt2pl", "knn": args.knn,
                        "parallelism": "batch-sharded x%d, one pose all-gather per call" % world},
             "roofline": {"kernel": "knn (%s)" % ("brute force, " + args.knn if brute else "exact sorted sweep: same indices as brute force"),
-                         "bound": "mfma", "achieved": knn_tf, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": knn_tf / F32_PEAK_TFLOPS,
-                         "traffic": knn_traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, " + str(knn_src) + ")",
+                         "bound": "mfma", "executes_on": "valu f32 fma (same 157.3 TF peak as the f32 MFMA; the two share the ALUs)",
+                         "achieved": knn_tf, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": knn_tf / F32_PEAK_TFLOPS if knn_tf else None,
+                         "traffic": knn_traffic, "traffic_source": knn_src, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC)",
                          "algorithmic_hbm_bytes": (16.0 * n + 16.0 * m) * B, "avg_launch_ms": knn_ms,
                          "flops_per_launch": flops,
-                         "launch_ms_by_iteration": [round(v, 4) for v in log.all_ms("knn")],
-                         "pairs_scored_fraction": None if brute else pairs_scored / (float(n) * m * B),
-                         "dense_equivalent_tflops": flops_bf / (knn_ms * 1e-3) / 1e12,
-                         "note": "8 flop per scored (query,target) pair vs the f32 MFMA(=VALU) peak; the kernel is FP32-compute-bound, "
+                         "launch_ms_by_iteration": [round(v, 4) for v in knn_all],
+                         "pairs_scored_fraction": None if (brute or pairs_scored is None) else pairs_scored / (float(n) * m * B),
+                         "dense_equivalent_tflops": flops_bf / (knn_ms * 1e-3) / 1e12 if knn_ms else None,
+                         "note": "8 flop per SCORED (query,target) pair vs the f32 peak; the kernel is FP32-compute-bound, "
                                  "its algorithmic HBM traffic is <1% of what HBM could move in its run time"},
             "roofline_bruteforce_knn": {"kernel": "knn_%s_kernel (all n*m pairs)" % ("mfma" if args.knn == "mfma" else "valu"), "bound": "mfma",
                                         "achieved": flops_bf / (bf_ms * 1e-3) / 1e12, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                        "frac": flops_bf / (bf_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS, "traffic": bf_traffic,
+                                        "frac": flops_bf / (bf_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS, "traffic": bf_traffic, "traffic_source": bf_src,
                                         "avg_launch_ms": bf_ms, "measured": "3 extra launches outside the timed region, HIP events"},
-            "roofline_streaming": {"kernel": bwd_kernel + (" (row atomics)" if brute else " (sorted space: LDS windows, per-block slabs, no float atomics)"),
-                                   "bound": "hbm", "achieved": bwd_bytes / (bwd_ms * 1e-3) / 1e9,
-                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bwd_bytes / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "roofline_accumulate": {"kernel": "accumulate (forward: residuals, weights, Jacobian, normal-equation sums)", "bound": "hbm",
+                                    "achieved": acc_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": acc_bytes / (acc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if acc_ms else None,
+                                    "traffic": acc_traffic, "traffic_source": acc_src, "avg_launch_ms": acc_ms,
+                                    "algorithmic_bytes_per_launch": acc_bytes,
+                                    "launch_ms_by_iteration": [round(v, 4) for v in acc_all]},
+            "roofline_streaming": {"kernel": bwd_kernel + (" (row atomics)" if brute else " (sorted space: LDS windows, no float atomics on the common path)"),
+                                   "bound": "hbm", "achieved": bwd_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_ms else None,
+                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bwd_bytes / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if bwd_ms else None,
                                    "traffic": bwd_traffic, "traffic_source": bwd_src, "avg_launch_ms": bwd_ms,
                                    "algorithmic_bytes_per_launch": bwd_bytes,
-                                   "launch_ms_by_iteration": [round(v, 4) for v in log.all_ms("accumulate_bwd")]},
+                                   "launch_ms_by_iteration": [round(v, 4) for v in bwd_all]},
             "finite": sane,
         }
+        line.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             base, T_ref = cpu_baseline(n, m)
             line["cpu_baseline"] = base
-            # correctness gate: the same 2 clouds x 3 iterations on the GPU vs the oracle
+            # correctness gate: the same 4 clouds x 3 iterations on the GPU vs the oracle
             chk = ICP(icp_type="pt2pl", differentiable=True, max_iterations=3, tolerance=1e-12)
             chk.const_iter = True
             chk.knn_variant = icp.knn_variant
             o = chk.icp(src[:T_ref.shape[0]], tgt[:T_ref.shape[0]], T0[:T_ref.shape[0]], trim_dist=TRIM, loss_fn=LOSS, dim=3)
-            line["check"] = {"pose_max_abs_diff_vs_oracle": float((o["T"].cpu() - T_ref).abs().max())}
+            diff = float((o["T"].cpu() - T_ref).abs().max())
+            line["check"] = {"pose_max_abs_diff_vs_oracle": diff, "bar": POSE_BAR}
             line["speedup_vs_cpu"] = line["value"] / base["value"]
+            if not diff <= POSE_BAR:
+                sane = False
+        if not sane:        # a wrong-result kernel must not emit a headline number
+            line["invalid_value"] = line["value"]
+            line["value"] = None
+            line["error"] = "results not finite or pose differs from the oracle by more than %g" % POSE_BAR
+            rc = 1
         os.write(_REAL_STDOUT, (json.dumps(line) + "\n").encode())
     if use_dist:
         torch.distributed.destroy_process_group()
+    return rc
 
 
 if __name__ == "__main__":
@@ -317,4 +409,4 @@ if __name__ == "__main__":
     sys.stdout.flush()
     _REAL_STDOUT = os.dup(1)
     os.dup2(2, 1)
-    main()
+    sys.exit(main())

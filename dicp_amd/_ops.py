@@ -138,7 +138,8 @@ class SweepIndex:
                 _lib.check(lib.dicp_sweep_sort_centered(_DT[dt], _p(tgt), c, _p(center), N, m, m_pad, _p(keys), _p(self.tperm), self.NBKT,
                                                         _p(self.bucket), _p(self.brange), _stream()), "dicp_sweep_sort")
         else:
-            key = torch.full((N, m_pad), torch.finfo(dt).max, dtype=dt, device=dev)   # pad slots sort last
+            key = torch.full((N, m_pad), float("nan"), dtype=dt, device=dev)   # pad slots sort last: NaN sorts above +inf, and the stable
+                                                                               # order keeps real rows (even NaN ones) ahead of the pads
             key[:, :m] = tgt[:, :, 0] if center is None else tgt[:, :, 0] - center[:, 0:1]
             keys, order = torch.sort(key, dim=1, stable=True)
         self.keys = keys                                         # sorted x keys (N,m_pad): the rank search of query_order reads them

@@ -299,9 +299,9 @@ __global__ __launch_bounds__(RS_THREADS) void sort_keys_kernel(const float* __re
     for (int e = 0; e < RS_PER; ++e) {                      // striped: position = wave * 1024 + e * 64 + lane
         const int pos = wave * (WAVE * RS_PER) + e * WAVE + lane;
         unsigned u = 0xffffffffu;                           // beyond m_pad: sentinel, sorts after everything
-        if (pos < m_pad) {
-            u = sortable_bits(pos < m ? (center ? rows[(size_t)pos * c] - center[(size_t)cloud * 3] : rows[(size_t)pos * c]) : 3.402823466e+38f);
-        }
+        // pad slots keep the largest key there is: with the stable order they follow EVERY real row, also one whose x is
+        // +inf or NaN (which sort above +max) -- sorted positions [0, m) are exactly the real rows, whatever they hold
+        if (pos < m) u = sortable_bits(center ? rows[(size_t)pos * c] - center[(size_t)cloud * 3] : rows[(size_t)pos * c]);
         key[e] = u;
         idx[e] = (unsigned short)pos;
     }
@@ -2886,7 +2886,9 @@ int dicp_accumulate(int dtype, const dicp_weight_params* prm, const void* src, c
     const WeightParams P = to_params(prm);
     const int bpc = dicp_accumulate_blocks(n);
     const unsigned g = grid_for(N, bpc);
-#define DICP_ACC(T, M) accumulate_kernel<T, M><<<g, BLOCK, 0, st>>>(P, (const T*)src, (const T*)tgt, c, idx, (const T*)pose, \
+    hipEvent_t ev0, ev1;
+    take_launch_events(ev0, ev1);                                       // (null unless a timed loop set them for this launch)
+#define DICP_ACC(T, M) hipExtLaunchKernelGGL((accumulate_kernel<T, M>), dim3(g), dim3(BLOCK), 0, st, ev0, ev1, 0, P, (const T*)src, (const T*)tgt, c, idx, (const T*)pose, \
         (const T*)w_init, (const T*)alive, N, n, m, bpc, (T*)partials, (T*)w_out, (long)w_stride)
     if (dtype == DICP_F32) { if (P.mode == MODE_PT2PL) DICP_ACC(float, MODE_PT2PL); else DICP_ACC(float, MODE_PT2PT); }
     else                   { if (P.mode == MODE_PT2PL) DICP_ACC(double, MODE_PT2PL); else DICP_ACC(double, MODE_PT2PT); }
@@ -3176,8 +3178,8 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
         char* w_k = (char*)B->w + (size_t)k * B->w_iter * es;       // cloud stride B->w_stride: (N,K,n) or (K,N,n) alike
         const char* alive_k = (const char*)B->alive + (size_t)k * N * es;
         if (B->events) {    // the sweep launch carries its two events itself; the brute-force forms are bracketed by records
-            if (kind == DICP_KNN_SWEEP) set_launch_events((hipEvent_t)B->events[4 * k + 0], (hipEvent_t)B->events[4 * k + 1]);
-            else if (hipEventRecord((hipEvent_t)B->events[4 * k + 0], st) != hipSuccess) return -(int)hipGetLastError();
+            if (kind == DICP_KNN_SWEEP) set_launch_events((hipEvent_t)B->events[6 * k + 0], (hipEvent_t)B->events[6 * k + 1]);
+            else if (hipEventRecord((hipEvent_t)B->events[6 * k + 0], st) != hipSuccess) return -(int)hipGetLastError();
         }
         int rc;
         int nblk_k = nblk;
@@ -3206,14 +3208,20 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
                                     idx_k, spos_k, B->pairs, cfg, stream);
                 set_launch_events(nullptr, nullptr);
                 if (rc) return rc;
+                if (B->events) set_launch_events((hipEvent_t)B->events[6 * k + 2], (hipEvent_t)B->events[6 * k + 3]);
                 rc = dicp_accumulate(dtype, prm, B->src, B->tgt, B->c, idx_k, pose_k, B->w_init, alive_k, N, n, m, B->partials, w_k, B->w_stride, stream);
+                set_launch_events(nullptr, nullptr);
                 if (rc) return rc;
             }
         } else {
             rc = dicp_knn(dtype, B->src, pose_s, B->tgt4, N, n, m, B->m_pad, idx_k, B->knn_variant & 0xffff, stream);
             if (rc) return rc;
-            if (B->events) { if (hipEventRecord((hipEvent_t)B->events[4 * k + 1], st) != hipSuccess) return -(int)hipGetLastError(); }
+            if (B->events) {
+                if (hipEventRecord((hipEvent_t)B->events[6 * k + 1], st) != hipSuccess) return -(int)hipGetLastError();
+                set_launch_events((hipEvent_t)B->events[6 * k + 2], (hipEvent_t)B->events[6 * k + 3]);
+            }
             rc = dicp_accumulate(dtype, prm, B->src, B->tgt, B->c, idx_k, pose_k, B->w_init, alive_k, N, n, m, B->partials, w_k, B->w_stride, stream);
+            set_launch_events(nullptr, nullptr);
             if (rc) return rc;
         }
         dicp_step_io io = make_step_io(*B, k, k0, N, n, prm->mode, dim, const_iter, tolerance, es, nblk_k);
@@ -3261,8 +3269,8 @@ int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_
                                gs, gb, gout, N, stream);
         if (rc) return rc;
         if (B->events) {
-            if (B->spos) set_launch_events((hipEvent_t)B->events[4 * k + 2], (hipEvent_t)B->events[4 * k + 3]);
-            else if (hipEventRecord((hipEvent_t)B->events[4 * k + 2], st) != hipSuccess) return -(int)hipGetLastError();
+            if (B->spos) set_launch_events((hipEvent_t)B->events[6 * k + 4], (hipEvent_t)B->events[6 * k + 5]);
+            else if (hipEventRecord((hipEvent_t)B->events[6 * k + 4], st) != hipSuccess) return -(int)hipGetLastError();
         }
         if (B->spos)    // windowed form: src / w_init / tgt are the SORTED copies, gsrc / gw accumulate in slot order, gtgt is the slab
             rc = dicp_accumulate_bwd_window(dtype, prm, B->src, B->tgt, B->c, B->spos + (size_t)k * N * n, B->spos_ref, B->qorder, pose_k, B->w_init,
@@ -3273,7 +3281,7 @@ int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_
                                      (const char*)B->alive + (size_t)k * N * es, gs, gb, N, n, m, gsrc, gtgt, gw, bwd_partials, stream);
         set_launch_events(nullptr, nullptr);
         if (rc) return rc;
-        if (B->events && !B->spos) { if (hipEventRecord((hipEvent_t)B->events[4 * k + 3], st) != hipSuccess) return -(int)hipGetLastError(); }
+        if (B->events && !B->spos) { if (hipEventRecord((hipEvent_t)B->events[6 * k + 5], st) != hipSuccess) return -(int)hipGetLastError(); }
         have_partials = 1;
         double* t = gin; gin = gout; gout = t;
     }

@@ -250,10 +250,10 @@ typedef struct dicp_loop_buffers {
     const void* w_prev0;     /* weights of iteration k0-1 (cloud stride w_stride too), or NULL when k0 == 0   ICP.py:224-226 */
     void* partials;          /* (N, dicp_loop_partial_blocks(dtype, n), DICP_NACC_PAD) scratch */
     int32_t* counters;       /* (K) zero-initialised: #clouds with |delta| >= tol at iteration k */
-    void** events;           /* optional 4*K hipEvent_t: [4k] before / [4k+1] after the kNN of iteration k (forward),
-                                [4k+2] before / [4k+3] after its accumulate_bwd (backward); NULL = none.  The sweep and the
-                                windowed-backward launches take their pair as the start / stop events of the dispatch
-                                (hipExtLaunchKernel), the other forms are bracketed by hipEventRecord */
+    void** events;           /* optional 6*K hipEvent_t: [6k] before / [6k+1] after the kNN of iteration k, [6k+2] / [6k+3] its
+                                accumulate (forward), [6k+4] / [6k+5] its accumulate_bwd (backward); NULL = none.  The sweep,
+                                accumulate and windowed-backward launches take their pair as the start / stop events of the
+                                dispatch (hipExtLaunchKernel), the other forms are bracketed by hipEventRecord */
     int32_t bwd_overwrite;   /* dicp_icp_backward, windowed form: 1 = gsrc / gw / the slab (gtgt) are uninitialised and this call's
                                 first launch (iteration k1-1) writes them instead of adding; 0 = they are accumulators */
     const void* center;      /* optional (N,3) T: centre of the search coordinates (dicp_cloud_center); tgt4 / the sweep index were then

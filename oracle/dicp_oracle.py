@@ -47,10 +47,20 @@ def handle_dimensions(x, y):
     return xu, yu
 
 
+NN_CHUNK = None     # rows of x per cdist call (None: all at once, as the reference does).  The (N,n,m) matrix of a 65536-point
+                    # cloud is 17 GB and autograd would keep one per iteration; the argmin carries no gradient (nn.py:35), so
+                    # taking it chunk by chunk under no_grad returns the same indices and the same graph for what follows.
+
+
 def nn_index(x, y):
     """Hard 1-NN index, nn.py:32-35 (== :83-86): cdist -> argmin (ties: lowest index)."""
-    d = torch.cdist(x, y[:, :, :3], p=2)
-    return torch.argmin(d, dim=2)
+    if NN_CHUNK is None:
+        d = torch.cdist(x, y[:, :, :3], p=2)
+        return torch.argmin(d, dim=2)
+    with torch.no_grad():
+        yy = y[:, :, :3].detach()
+        return torch.cat([torch.argmin(torch.cdist(x[:, s:s + NN_CHUNK].detach(), yy, p=2), dim=2)
+                          for s in range(0, x.shape[1], NN_CHUNK)], dim=1)
 
 
 def nn_hard(x, y):

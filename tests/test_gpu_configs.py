@@ -1,0 +1,175 @@
+"""The BASELINE.json configurations at their FULL sizes (`-m gpu`): what the headline numbers are quoted on must be
+what the parity suite runs.
+
+  configs[2]  B=256 x 16384-point clouds, point-to-plane + Huber, fwd+bwd            test_config3_full_batch_256
+  configs[3]  65536-point clouds: the path KNN_AUTO takes there (sorted sweep with more than 16384 targets: key sort
+              beyond the LDS sort, two-pass query order) against brute force, and a whole ICP call (KNN_AUTO and the
+              MFMA brute-force variant) against the oracle                            test_sweep_equals_brute_force_at_65536,
+                                                                                     test_config4_icp_at_65536_vs_oracle
+The oracle (CPU restatement of the reference) runs on a slice that finishes in seconds; full-size claims beyond the
+slice are size-independent properties (index equality between two exact searches, batch == per-item, finiteness).
+"""
+import numpy as np
+import pytest
+import torch
+
+from dicp_amd import _lib, _ops
+from dicp_amd.ICP import ICP
+from dicp_amd.synthetic import make_pairs
+from oracle import dicp_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+KW = dict(trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0}, dim=3)
+
+
+def npy(x):
+    return x.detach().cpu().numpy()
+
+
+def sampled_exact(x, y, rows):
+    xs = x[rows].double()
+    d = ((xs[:, None, :] - y[None, :, :3].double()) ** 2).sum(-1)
+    v, _ = torch.topk(d, 2, dim=1, largest=False)
+    return torch.argmin(d, dim=1), v[:, 0], v[:, 1]
+
+
+def oracle_slice(src, tgt, K, chunk=None):
+    """fwd+bwd of the oracle on CPU copies; returns (T, grad_source, grad_target)."""
+    s, t = src.detach().cpu().clone().requires_grad_(True), tgt.detach().cpu().clone().requires_grad_(True)
+    N, n = s.shape[:2]
+    O.NN_CHUNK = chunk
+    try:
+        ref = O.icp_batched(s, t, torch.eye(4, dtype=s.dtype).repeat(N, 1, 1), torch.ones(N, n, dtype=s.dtype), icp_type="pt2pl",
+                            differentiable=True, max_iterations=K, tolerance=1e-12, const_iter=True, tanh_steepness=5.0, **KW)
+        ref["T"].sum().backward()
+    finally:
+        O.NN_CHUNK = None
+    return ref["T"].detach(), s.grad, t.grad
+
+
+@pytest.mark.parametrize("dtype,N,n", [(torch.float32, 2, 65536), (torch.float64, 1, 20000)])
+def test_sweep_equals_brute_force_at_65536(dtype, N, n):
+    """More than 16384 targets: the sweep's index is built beyond the one-block LDS sort and the query order takes its
+    two-pass form -- every launch configuration must still return the brute-force kernel's indices, bit for bit, under
+    the identity and under a real pose, with and without the query order, and in centred coordinates."""
+    src, tgt = make_pairs(N, n, n, seed=17, dtype=dtype)
+    sd, td = src.to(DEV), tgt.to(DEV)
+    brute = _ops.knn(sd, None, _ops.pack_target(td), n, _lib.KNN_VALU)
+    sw = _ops.SweepIndex(td)
+    assert sw.tgs4.shape[1] >= n and sw.tperm.shape == (N, sw.tgs4.shape[1])
+    # the permutation is the stable ascending sort of the x keys (what torch.sort(stable=True) gives)
+    key = td[:, :, 0]
+    want_perm = torch.sort(key, dim=1, stable=True).indices.to(torch.int32)
+    assert torch.equal(sw.tperm[:, :n], want_perm)
+    cfgs = (0, 1, 2, 3, 4, 5, 6, 7, 8, 16, 17) if dtype == torch.float32 else (0, 1, 2, 3, 16, 17)
+    qo = sw.query_order(sd, None)
+    assert torch.equal(torch.sort(qo.long(), dim=1).values, torch.arange(n, device=DEV).repeat(N, 1))     # a permutation
+    for cfg in cfgs:
+        assert torch.equal(sw.knn(sd, None, qo, cfg=cfg), brute), cfg
+    assert torch.equal(sw.knn(sd, None, None), brute)                              # natural query order: still exact
+    qx = sw.query_order(sd, None, exact=True)                                      # fully sorted queries
+    assert torch.equal(sw.knn(sd, None, qx), brute)
+    # under a pose (the loop's form: fused transform), against the brute-force kernel under the same pose
+    ang = 0.04
+    pose = torch.tensor([np.cos(ang), -np.sin(ang), 0, np.sin(ang), np.cos(ang), 0, 0, 0, 1, 0.2, -0.1, 0.05], dtype=dtype, device=DEV).repeat(N, 1)
+    brute_p = _ops.knn(sd, pose, _ops.pack_target(td), n, _lib.KNN_VALU)
+    assert torch.equal(sw.knn(sd, pose, sw.query_order(sd, pose)), brute_p)
+    # centred search coordinates (what the ICP loop uses): packed rows y - c, pose [C | r - c]
+    ctr = _ops.cloud_center(td + torch.tensor([300.0, -200.0, 50.0, 0, 0, 0], dtype=dtype, device=DEV))
+    far_t = (td + torch.tensor([300.0, -200.0, 50.0, 0, 0, 0], dtype=dtype, device=DEV)).contiguous()
+    far_s = (sd + torch.tensor([300.0, -200.0, 50.0], dtype=dtype, device=DEV)).contiguous()
+    swc = _ops.SweepIndex(far_t, center=ctr)
+    ps = _ops.search_pose(None, ctr, N)
+    got_c = swc.knn(far_s, ps, swc.query_order(far_s, ps))
+    brute_c = _ops.knn(far_s, ps, _ops.pack_target(far_t, ctr), n, _lib.KNN_VALU)
+    assert torch.equal(got_c, brute_c)
+    # and both agree with an exact float64 search on sampled queries (ties within float32 resolution excepted)
+    rows = torch.randint(0, n, (200,), generator=torch.Generator().manual_seed(2)).to(DEV)
+    want, best, second = sampled_exact(sd[0], td[0], rows)
+    bad = brute[0][rows].long() != want
+    assert int(bad.sum()) <= 2 and bool(((second - best)[bad] < 1e-4).all())
+
+
+@pytest.mark.parametrize("variant", [_lib.KNN_AUTO, _lib.KNN_MFMA])
+def test_config4_icp_at_65536_vs_oracle(variant):
+    """configs[3] cloud size through the whole ICP call, forward and backward: KNN_AUTO (= the sorted sweep: key sort and
+    query order beyond their LDS forms, windowed backward) and the MFMA brute-force variant, 2 clouds x 3 iterations; the
+    oracle checks cloud 1 (pose <= 1e-4, gradients <= 1e-3 of their scale: the north-star bars)."""
+    N, n, K = 2, 65536, 3
+    src, tgt = make_pairs(N, n, n, seed=23, dtype=torch.float32)
+    sd, td = src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True)
+    icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
+    icp.const_iter = True
+    icp.knn_variant = variant
+    assert variant != _lib.KNN_AUTO or _ops.auto_knn_kind(N, n, n) == _lib.KNN_SWEEP
+    out = icp.icp(sd, td, torch.eye(4, device=DEV).repeat(N, 1, 1), **KW)
+    out["T"].sum().backward()
+    assert bool(torch.isfinite(out["T"]).all() and torch.isfinite(sd.grad).all() and torch.isfinite(td.grad).all())
+    T_ref, gs_ref, gt_ref = oracle_slice(src[1:2], tgt[1:2], K, chunk=4096)
+    np.testing.assert_allclose(npy(out["T"])[1], T_ref[0].numpy(), rtol=0, atol=1e-4)
+    for got, want, nm in ((sd.grad[1], gs_ref[0], "source"), (td.grad[1], gt_ref[0], "target")):
+        scale = max(1.0, float(want.abs().max()))
+        # a float32 argmin may pick the other of two (nearly) equidistant targets for a handful of the 65536 queries; such a
+        # row differs in BOTH clouds' gradients.  Rows are held to the bar; at most 0.1 % may differ by more.
+        err = (got.cpu() - want).abs().amax(dim=1)
+        assert float((err > 1e-3 * scale).float().mean()) < 1e-3, nm
+        assert float(err.median()) < 1e-5 * scale, nm
+    assert out["weights"].shape == (N, K, n, 1) and out["pc"].shape == (N, n, 3)
+    if variant == _lib.KNN_AUTO:        # the sweep pruned: far fewer pairs than n*m per launch
+        frac = float(icp.knn_stats["knn_pairs"].sum().item()) / (float(N) * n * n * K)
+        assert frac < 0.2, frac
+
+
+def test_config3_full_batch_256(monkeypatch):
+    """configs[2] at its FULL batch (B=256 x 16384 points, pt2pl + Huber + trim, forward and backward): every cloud of
+    the batch is held, not just the first few -- clouds 128..131 and 252..255 against per-item calls (batch == per-item:
+    the XCD block mapping and every per-cloud stride beyond the lower half), clouds 200..203 against the oracle, and the
+    whole batch again with the histories cut into several slabs (HIST_CHUNK_BYTES) and with the brute-force kNN."""
+    B, n, K = 256, 16384, 4
+    src, tgt = make_pairs(B, n, n, seed=3, dtype=torch.float32)
+    sd, td = src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True)
+    T0 = torch.eye(4, device=DEV).repeat(B, 1, 1)
+    icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
+    icp.const_iter = True
+    out = icp.icp(sd, td, T0, **KW)
+    out["T"].sum().backward()
+    assert bool(torch.isfinite(out["T"]).all() and torch.isfinite(sd.grad).all() and torch.isfinite(td.grad).all())
+    assert out["weights"].shape == (B, K, n, 1)
+    T_full, gs_full, gt_full = out["T"].detach().clone(), sd.grad.clone(), td.grad.clone()
+    # (a) upper half of the batch == per-item calls
+    for lo in (128, 252):
+        s1 = src[lo:lo + 4].to(DEV).requires_grad_(True)
+        t1 = tgt[lo:lo + 4].to(DEV).requires_grad_(True)
+        one = icp.icp(s1, t1, T0[:4], **KW)
+        one["T"].sum().backward()
+        np.testing.assert_allclose(npy(one["T"]), npy(T_full[lo:lo + 4]), rtol=0, atol=2e-6)
+        np.testing.assert_allclose(npy(s1.grad), npy(gs_full[lo:lo + 4]), rtol=0, atol=2e-5)
+        np.testing.assert_allclose(npy(t1.grad), npy(gt_full[lo:lo + 4]), rtol=0, atol=2e-5)
+    # (b) oracle on a slice of the upper half
+    T_ref, gs_ref, gt_ref = oracle_slice(src[200:204], tgt[200:204], K)
+    np.testing.assert_allclose(npy(T_full[200:204]), T_ref.numpy(), rtol=0, atol=1e-4)
+    for got, want in ((gs_full[200:204].cpu(), gs_ref), (gt_full[200:204].cpu(), gt_ref)):
+        scale = max(1.0, float(want.abs().max()))
+        err = (got - want).abs().amax(dim=2)
+        assert float((err > 1e-3 * scale).float().mean()) < 1e-3
+        assert float(err.median()) < 1e-5 * scale
+    # (c) histories cut into slabs of 2 iterations: same bits
+    monkeypatch.setattr(_ops, "HIST_CHUNK_BYTES", 2 * B * n * 4)
+    s2, t2 = src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True)
+    cut = icp.icp(s2, t2, T0, **KW)
+    cut["T"].sum().backward()
+    assert torch.equal(cut["T"], T_full)
+    np.testing.assert_allclose(npy(s2.grad), npy(gs_full), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(npy(t2.grad), npy(gt_full), rtol=0, atol=1e-6)
+    monkeypatch.undo()
+    # (d) brute-force kNN in the loop: identical forward (same indices, same sums), gradients to rounding
+    bf = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
+    bf.const_iter = True
+    bf.knn_variant = _lib.KNN_VALU
+    s3, t3 = src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True)
+    b = bf.icp(s3, t3, T0, **KW)
+    b["T"].sum().backward()
+    np.testing.assert_allclose(npy(b["T"]), npy(T_full), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(npy(s3.grad), npy(gs_full), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(npy(t3.grad), npy(gt_full), rtol=0, atol=2e-5)

@@ -1449,3 +1449,31 @@ def test_pose_grad_in_out_kernels(dtype):
         want[:, :3, 3] = tot[:, 9:]
         assert float((out.to(torch.float64) - want).abs().max()) <= (1e-6 if dtype == torch.float32 else 1e-14)
         assert float(out[:, 3].abs().max()) == 0.0
+
+
+def test_nonfinite_target_x_keeps_its_sorted_slot_in_the_windowed_backward():
+    """a target row whose x is +inf or NaN sorts above +max; pad slots must still come after it, so that its
+    sorted position is < m and dicp_window_reduce writes its gradient row (the buffer is torch.empty)."""
+    B, n = 3, 5000
+    src, tgt = make_pairs(B, n, n, seed=3)
+    tgt[2, 5, 0] = float("inf")
+    tgt[0, 9, 0] = float("nan")
+    junk = torch.full((B * n * 6 * 4,), 12345.0, device=DEV)      # what "uninitialised" would show next
+    del junk
+    T0 = torch.eye(4, device=DEV).repeat(B, 1, 1)
+    grads = {}
+    for knn in (_lib.KNN_VALU, _lib.KNN_SWEEP):
+        icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=4, tolerance=1e-12)
+        icp.const_iter = True
+        icp.knn_variant = knn
+        s, tg = src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True)
+        out = icp.icp(s, tg, T0, trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0})
+        out["T"].sum().backward()
+        grads[knn] = (out["T"].detach().cpu(), tg.grad.detach().cpu())
+        assert bool(torch.isfinite(out["T"][1]).all() and torch.isfinite(tg.grad[1]).all())
+        assert not bool((tg.grad == 12345.0).any())
+        for b, j in ((2, 5), (0, 9)):                                # never matched (or NaN): no stale memory either way
+            row = tg.grad[b, j]
+            assert bool(((row == 0) | ~torch.isfinite(row)).all()), (knn, b, j, row)
+    np.testing.assert_allclose(grads[_lib.KNN_SWEEP][0][1].numpy(), grads[_lib.KNN_VALU][0][1].numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(grads[_lib.KNN_SWEEP][1][1].numpy(), grads[_lib.KNN_VALU][1][1].numpy(), rtol=0, atol=1e-5)

@@ -173,3 +173,24 @@ def test_knn_exact_helper():
     idx, best, second = O.knn_exact_f64(x, y)
     assert torch.equal(idx, O.nn_index(x, y))
     assert bool((second >= best).all())
+
+
+def test_chunked_argmin_is_the_same_oracle():
+    """O.NN_CHUNK (memory bound for 65536-point clouds): same indices, same results, same gradients."""
+    gen = torch.Generator().manual_seed(11)
+    src = torch.rand((2, 700, 3), generator=gen) * 4
+    tgt = torch.rand((2, 900, 6), generator=gen) * 4
+    kw = dict(icp_type="pt2pl", differentiable=True, max_iterations=3, tolerance=1e-12, trim_dist=5.0,
+              loss_fn={"name": "huber", "metric": 1.0}, const_iter=True)
+    outs = []
+    for chunk in (None, 128):
+        O.NN_CHUNK = chunk
+        try:
+            s, t_ = src.clone().requires_grad_(True), tgt.clone().requires_grad_(True)
+            r = O.icp_batched(s, t_, torch.eye(4).repeat(2, 1, 1), torch.ones(2, 700), **kw)
+            r["T"].sum().backward()
+            outs.append((r["T"].detach(), s.grad, t_.grad, O.nn_index(src, tgt)))
+        finally:
+            O.NN_CHUNK = None
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

@@ -12,7 +12,6 @@ reference; citations are inline.  Inputs may live on the CPU (the reference's te
 they are moved to the visible HIP device for the computation and the results are returned
 on the inputs' device.  Without a HIP device this class raises -- no CPU fallback exists.
 """
-import os
 import os.path as osp
 
 import torch
@@ -47,7 +46,8 @@ class ICP:
         # build-specific knob (not in the reference): which kNN kernel the loop uses
         self.knn_variant = _lib.KNN_AUTO      # _lib.KNN_VALU | KNN_MFMA (brute force) | KNN_SWEEP (exact, slab-pruned)
         self.knn_stats = {}                   # "knn_pairs": pairs scored by the last call's sweep kNN (device int64 shards: .sum())
-        self.bwd_window = os.environ.get("DICP_BWD_WINDOW", "1") == "1"   # sweep path: sorted-space backward (LDS window)
+        self.bwd_window = True                # sweep path: sorted-space backward (LDS windows); False: row atomics
+        self.small_loop = True                # small clouds: one block per cloud runs whole chunks of iterations
         # tolerance mode: iterations enqueued between two host checks of "all converged" (ICP.py:259).  None = auto:
         # every iteration for big batches (an iteration costs far more than a sync), every 4th for small ones
         # (converged clouds are frozen, so the extra iterations change nothing and the histories are trimmed)
@@ -104,7 +104,7 @@ class ICP:
             tanh_steepness=float(self.config['dICP']['parameters']['tanh_steepness']),   # ICP.py:119
             match_ratio_thresh=float(self.match_ratio_thresh),
             knn_variant=self.knn_variant, bwd_window=bool(self.bwd_window), stats_out=self.knn_stats,
-            sync_every=self.sync_every, timing_events=self._timing_events, prebuilt=prebuilt)
+            sync_every=self.sync_every, timing_events=self._timing_events, prebuilt=prebuilt, small_loop=bool(self.small_loop))
         if self.nn.differentiable and self.nn.use_gumbel:                                # nn.py:14-16 via ICP.py:140
             # soft correspondences carry gradient themselves: one autograd node per iteration instead of one per call
             T, deltas, weights, costs, converged, iterations, matched = icp_loop_gumbel(

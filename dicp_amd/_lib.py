@@ -19,7 +19,8 @@ PT2PT, PT2PL = 0, 1
 LOSS_NONE, LOSS_HUBER, LOSS_CAUCHY, LOSS_TRIM = 0, 1, 2, 3
 KNN_AUTO, KNN_VALU, KNN_MFMA, KNN_SWEEP = 0, 1, 2, 3
 NACC_PAD, NBWD_PAD, KAB_SAVE = 32, 16, 40
-SWEEP_SCAN, PAIR_SHARDS, SWEEP_SRC_SORTED = 16, 64, 0x100      # DICP_SWEEP_SCAN, DICP_PAIR_SHARDS, DICP_SWEEP_SRC_SORTED
+PAIR_SHARDS, SWEEP_SRC_SORTED = 64, 0x100      # DICP_PAIR_SHARDS, DICP_SWEEP_SRC_SORTED
+ABI_VERSION = 3
 _ERRORS = {1: "null pointer", 2: "bad shape/stride", 3: "unsupported dtype", 4: "bad enum value", 5: "misaligned buffer"}
 
 vp, i32, i64, f64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
@@ -66,10 +67,6 @@ _SIGNATURES = {
     "dicp_sweep_build": ([i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp], ctypes.c_int),
     "dicp_sweep_sort_centered": ([i32, vp, i32, vp, i32, i32, i32, vp, vp, i32, vp, vp, vp], ctypes.c_int),
     "dicp_sweep_build_centered": ([i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp], ctypes.c_int),
-    "dicp_sweep_partials": ([i32, i32, i32], ctypes.c_int),
-    "dicp_loop_partial_blocks": ([i32, i32], ctypes.c_int),
-    "dicp_knn_sweep_accumulate": ([i32, ctypes.POINTER(WeightParams), vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32,
-                                   vp, vp, vp, i32, vp, vp, i64, vp], ctypes.c_int),
     "dicp_query_order": ([i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, vp], ctypes.c_int),
     "dicp_query_keys": ([i32, vp, vp, i32, i32, vp, vp], ctypes.c_int),
     "dicp_loop_init": ([i32, vp, vp, ctypes.c_double, i32, i32, i32, vp, vp, vp, vp], ctypes.c_int),
@@ -147,7 +144,7 @@ def load():
                 fn = getattr(lib, name)
                 fn.argtypes = args
                 fn.restype = res
-            if lib.dicp_abi_version() != 2:
+            if lib.dicp_abi_version() != ABI_VERSION:
                 raise RuntimeError("dicp_amd: libdicp_hip.so ABI version mismatch; rebuild it")
             _lib = lib
     return _lib

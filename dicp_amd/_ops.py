@@ -5,7 +5,6 @@ arithmetic step of the ICP iteration runs in libdicp_hip.so.  All functions requ
 HIP-device tensors and raise otherwise -- there is no CPU compute path.
 """
 import ctypes
-import os
 from dataclasses import dataclass
 
 import torch
@@ -58,7 +57,7 @@ def accumulate_blocks(n):
     return _lib.load().dicp_accumulate_blocks(int(n))
 
 
-CENTER_QUANTUM = float(os.environ.get("DICP_CENTER_QUANTUM", "16"))    # metres; clouds whose median point is within half of it of the origin keep c = 0
+CENTER_QUANTUM = 16.0    # metres; clouds whose median point is within half of it of the origin keep c = 0
 
 
 def cloud_center(tgt, quantum=None):
@@ -113,8 +112,9 @@ class SweepIndex:
     an ICP call, so they are sorted by x once.  Index preparation uses torch.sort/searchsorted (plumbing)."""
     NBKT = 1024
 
-    def __init__(self, tgt, sorted_rows=False, center=None):
+    def __init__(self, tgt, sorted_rows=False, center=None, native_sort=True):
         """sorted_rows: also keep tgt_s (N,m_pad,c), the full rows in sorted order (the windowed backward reads them).
+        native_sort=False: the key sort through torch.sort even where dicp_sweep_sort applies (tests compare the two).
         center (N,3): the index is built on y - center (keys, table and packed rows; tgt_s keeps the rows as given) and the
         searches must then be given the pose [C | r - center]."""
         require_device(tgt, "SweepIndex")
@@ -129,7 +129,7 @@ class SweepIndex:
         self.tperm = torch.empty((N, m_pad), dtype=torch.int32, device=dev)
         self.bucket = torch.empty((N, self.NBKT + 1), dtype=torch.int32, device=dev)
         self.brange = torch.empty((N, 2), dtype=dt, device=dev)
-        native = dt == torch.float32 and m_pad <= 16384 and NATIVE_SORT
+        native = dt == torch.float32 and m_pad <= 16384 and native_sort
         if native:
             # the stable sort of the x keys in LDS (dicp_sweep_sort): same keys and permutation as torch.sort(stable=True),
             # and the bucket table while the keys are there
@@ -158,8 +158,8 @@ class SweepIndex:
     def query_order(self, src, pose, exact=False, w=None, copies=False, reproducible=False, spos_prev=None):
         """Query indices in (approximately) ascending transformed x: keeps a wave's queries neighbours.  Default: a
         counting sort by the rank bucket of each query's x among the sorted target keys (dicp_query_order; equal-width x
-        buckets for clouds beyond 16384 points or with RANK_ORDER off) -- or, given spos_prev (the matches of an earlier
-        iteration), by the rank of each query's previous match; exact=True: a full sort of the x keys.
+        buckets for clouds beyond 16384 points) -- or, given spos_prev (the matches of an earlier iteration), by the rank of
+        each query's previous match; exact=True: a full sort of the x keys.
         copies=True -> (qorder, src_s, w_s): also the source rows (and the weights w, if given) in that slot order."""
         N, n, _ = src.shape
         lib = _lib.load()
@@ -168,7 +168,7 @@ class SweepIndex:
                 qorder = torch.empty((N, n), dtype=torch.int32, device=src.device)
                 _lib.check(lib.dicp_query_order(_DT[src.dtype], _p(src), _p(pose), _p(self.brange), self.NBKT, N, n, _p(qorder),
                                                 None, None, None, int(reproducible), _p(spos_prev), self.tgs4.shape[1],
-                                                _p(self.keys) if RANK_ORDER else None, _p(self.bucket), self.m, _stream()),
+                                                _p(self.keys), _p(self.bucket), self.m, _stream()),
                            "dicp_query_order")
                 if copies:      # (the ordering kernel can write them itself, but one block per cloud gathers slowly: 115 vs 16 us)
                     return qorder, _gather_rows_raw(src, qorder), (_gather_rows_raw(w.unsqueeze(-1), qorder).squeeze(-1) if w is not None else None)
@@ -360,12 +360,12 @@ def prebuild_search(source, target, knn_variant, want_rows, T_init=None):
     if kind != _lib.KNN_SWEEP or not target.is_cuda or not target.is_contiguous() or target.dtype not in _DT:
         return None
     with torch.cuda.device(target.device):
-        sweep = SweepIndex(target, sorted_rows=bool(want_rows), center=None if FUSE_ACCUMULATE else cloud_center(target))
+        sweep = SweepIndex(target, sorted_rows=bool(want_rows), center=cloud_center(target))
         # ... and the first query order, from T_init alone (the loop's own pose_0 does not exist yet): with it the queue holds
         # ~0.2 ms of work while the host builds the loop state
         first = None
         if (T_init is not None and T_init.is_cuda and T_init.is_contiguous() and T_init.dtype == target.dtype and source.is_contiguous()
-                and tuple(T_init.shape) == (N, 4, 4) and not FUSE_ACCUMULATE and not SPOS_ORDER):
+                and tuple(T_init.shape) == (N, 4, 4)):
             pose_s = torch.empty((N, 12), dtype=target.dtype, device=target.device)
             _lib.check(_lib.load().dicp_search_pose(_DT[target.dtype], _p(T_init), _p(sweep.center), N, _p(pose_s), _stream()), "dicp_search_pose")
             first = (source, T_init, sweep.query_order(source, pose_s))
@@ -386,12 +386,13 @@ class LoopConfig:
     tanh_steepness: float
     match_ratio_thresh: float
     knn_variant: int = _lib.KNN_AUTO
-    sweep_resort: tuple = tuple(int(v) for v in os.environ.get("DICP_SWEEP_RESORT", "0,1,2,3").split(","))  # iterations at which the sweep kNN re-sorts its queries by x
+    sweep_resort: tuple = (0, 1, 2, 3)  # iterations at which the sweep kNN re-sorts its queries by x
     bwd_window: bool = True       # sweep path: backward in sorted space (LDS window + full-line atomic flush)
     stats_out: object = None      # optional dict: receives "knn_pairs" (pairs scored by the sweep kNN; int64 shards, sum them)
     sync_every: object = None     # tolerance mode: iterations between the host's all-converged checks (None = auto)
     timing_events: object = None  # optional object with .handles(K) -> ctypes array of 4*K hipEvent_t (bench.py)
     prebuilt: object = None       # (target, SweepIndex) started by the caller before its own host work (prebuild_search)
+    small_loop: bool = True       # small clouds: one block runs a cloud's whole chunk of iterations (icp_small_* kernels)
 
     def params(self):
         return _lib.WeightParams(
@@ -410,14 +411,7 @@ def _pose_from_T(T):
     return torch.cat((T[:, :3, :3].reshape(N, 9), T[:, :3, 3]), dim=1).contiguous()
 
 
-FUSE_ACCUMULATE = int(os.environ.get("DICP_FUSE_ACC", "0"))      # sweep path: accumulate in the search kernel's epilogue (measured slower: off)
-SMALL_LOOP = int(os.environ.get("DICP_SMALL_LOOP", "1"))       # small clouds: one block runs a cloud's whole chunk of iterations
-SPOS_ORDER = int(os.environ.get("DICP_SPOS_ORDER", "0"))       # re-order queries by the rank of their previous match instead of their x
-                                                              # (density-robust, but measured slower on the benchmark clouds: 0.62 vs 0.58 ms/step)
-RANK_ORDER = int(os.environ.get("DICP_RANK_ORDER", "1"))       # order queries by the rank of their x among the sorted targets (density-robust)
-NATIVE_SORT = int(os.environ.get("DICP_NATIVE_SORT", "1"))     # float32 clouds of up to 16384 targets: the key sort in LDS instead of torch.sort
 WINDOW_MIN_ITERS = 3            # fewer windowed iterations than this: all take the atomic backward (see ICPLoop.backward)
-WINDOW_FROM = int(os.environ.get("DICP_WINDOW_FROM", "0"))      # first windowed iteration (measured: even iteration 0 pays, 0.13 vs 0.28 ms)
 HIST_CHUNK_BYTES = 1 << 29      # per-iteration histories (indices, weights) are allocated in slabs of at most this size
 
 
@@ -499,13 +493,12 @@ class ICPLoop(torch.autograd.Function):
                         and (pre[1].tgt_s is not None or not owned)):
                     sweep = pre[1]                           # started by the caller, under its host work
                 else:
-                    sweep = SweepIndex(tgt, sorted_rows=owned, center=None if FUSE_ACCUMULATE else cloud_center(tgt))
+                    sweep = SweepIndex(tgt, sorted_rows=owned, center=cloud_center(tgt))
             # the searches run in coordinates centred on the target cloud (dicp_cloud_center): packed rows y - c, pose [C | r - c]
-            # (the fused search + accumulate form scores and accumulates with ONE pose: it keeps the uncentred search)
             center = sweep.center if sweep is not None else cloud_center(tgt)
             tgt4 = sweep.tgs4 if sweep is not None else pack_target(tgt, center)
             m_pad = tgt4.shape[1]
-            nblk = lib.dicp_loop_partial_blocks(code, n)
+            nblk = lib.dicp_accumulate_blocks(n)
             poses = torch.empty((Kmax + 1, N, 12), dtype=dt, device=dev)
             poses_c = torch.empty((Kmax + 1, N, 12), dtype=dt, device=dev) if center is not None else None   # [C | r - center]: what the searches read
             alive = torch.empty((Kmax + 1, N), dtype=dt, device=dev)
@@ -558,19 +551,18 @@ class ICPLoop(torch.autograd.Function):
                     if owned:
                         spos_slabs.append(torch.empty((kk, N, n), dtype=torch.int32, device=dev))
                 if sweep is not None and (qorder is None or k0 in cfg.sweep_resort):
-                    # queries re-ordered by x under the current pose (reproducibly when the forward sums in that order)
-                    prev = spos_slabs[(k0 - 1) // kc][(k0 - 1) % kc] if (owned and k0 > 0 and SPOS_ORDER) else None
+                    # queries re-ordered by x under the current pose
                     first = cfg.prebuilt[2] if (k0 == 0 and sweep is not None and cfg.prebuilt is not None and cfg.prebuilt[1] is sweep) else None
                     if (first is not None and first[0].data_ptr() == src.data_ptr() and first[0].shape == src.shape
                             and first[1].data_ptr() == T_init.data_ptr() and T_init.is_contiguous()):
                         qorder = first[2]                    # ordered under T_init by the caller (prebuild_search)
                     else:
-                        qorder = sweep.query_order(src, (poses_c if poses_c is not None else poses)[k0], reproducible=bool(FUSE_ACCUMULATE), spos_prev=prev)
+                        qorder = sweep.query_order(src, (poses_c if poses_c is not None else poses)[k0])
                     qorders.append(qorder)
                 seg_q.append(len(qorders) - 1)
                 base = j * kc                                         # virtual bases: slab pointer minus its first iteration
                 LB = _lib.LoopBuffers(
-                    src=_p(src), tgt=_p(tgt), w_init=_p(w0c), c=c, K=Kmax, knn_variant=kind | (cfg.knn_variant & 0xffff00) | (FUSE_ACCUMULATE << 24) | ((0 if SMALL_LOOP else 1) << 25), m_pad=m_pad,
+                    src=_p(src), tgt=_p(tgt), w_init=_p(w0c), c=c, K=Kmax, knn_variant=kind | (cfg.knn_variant & 0xff00) | ((0 if cfg.small_loop else 1) << 25), m_pad=m_pad,
                     tgt4=_p(tgt4), tperm=_p(sweep.tperm) if sweep else None, qorder=_p(qorder),
                     bucket=_p(sweep.bucket) if sweep else None, brange=_p(sweep.brange) if sweep else None,
                     nbkt=SweepIndex.NBKT, idx_per_iter=int(need_grad), pairs=_p(sweep.pair_shards) if sweep else None,
@@ -655,7 +647,7 @@ class ICPLoop(torch.autograd.Function):
             # matches are stored per query, so the forward may have searched those iterations in other orders.  Matches that
             # fall outside a window (early iterations, whose poses are still far) take the kernel's atomic side path.
             q_star = len(qorders) - 1
-            windowed = [owned and (q == q_star or a >= WINDOW_FROM) for (a, _, q) in segs]
+            windowed = [bool(owned)] * len(segs)        # (measured: even iteration 0, whose matches lie far from the final ones, pays: 0.13 vs 0.28 ms)
             if sum(b - a for (a, b, _), wf in zip(segs, windowed) if wf) < WINDOW_MIN_ITERS:
                 windowed = [False] * len(segs)
             only_windowed = all(windowed) and len(windowed) > 0
@@ -694,7 +686,7 @@ class ICPLoop(torch.autograd.Function):
                 base = j * kc
                 LB = _lib.LoopBuffers(
                     src=_p(src_s) if w_form else _p(src), tgt=_p(tgt_s) if w_form else _p(tgt),
-                    w_init=_p(w_s) if w_form else _p(w0c), c=c, K=Kmax, knn_variant=kind | ((0 if SMALL_LOOP else 1) << 25), m_pad=m_pad, idx_per_iter=1,
+                    w_init=_p(w_s) if w_form else _p(w0c), c=c, K=Kmax, knn_variant=kind | ((0 if cfg.small_loop else 1) << 25), m_pad=m_pad, idx_per_iter=1,
                     qorder=_p(qo) if w_form else None,
                     spos=ctypes.c_void_p(spos_slabs[j].data_ptr() - base * N * n * 4) if w_form else None,
                     spos_ref=_p(spos_ref) if w_form else None, gts_far=_p(gfar) if w_form else None,

@@ -5,11 +5,9 @@
 //   pack_kernel            target rows -> [x,y,z,0.5|y|^2] (once per ICP call)
 //   sweep_rows / sweep_buckets / query_order / query_keys / loop_init / loop_finish
 //                          per-call set-up of the sorted-sweep search and of the loop state (everything after torch.sort)
-//   knn_valu_kernel        fused transform + brute-force 1-NN, VALU FMA form, LDS-tiled targets (+ packed-FMA variant)
+//   knn_valu_kernel        fused transform + brute-force 1-NN, VALU FMA form, LDS-tiled targets
 //   knn_mfma_kernel        same contraction on the f32 matrix cores (v_mfma_f32_16x16x4_f32)
-//   knn_sweep_kernel       exact 1-NN with slab pruning over x-sorted targets (the ICP default for big clouds);
-//                          optionally goes on with the accumulate pass for its matches (FusedAcc)
-//   knn_scan_kernel        the same search as a per-lane scan (narrow slabs; selectable)
+//   knn_sweep_kernel       exact 1-NN with slab pruning over x-sorted targets
 //   gather / scatter / permute_add
 //                          row-indexed copies (nn.find_nn's gather and its backward; sorted copies and their undoing)
 //   accumulate_kernel      residual/weights/Jacobian/normal-equation sums, per-block partials
@@ -699,86 +697,6 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_valu_kernel(const T* __restri
     }
 }
 
-// Packed-math form of the same kernel (float only): the LDS tile holds target PAIRS as
-// {y0a,y0b,y1a,y1b},{y2a,y2b,ha,hb} so that one v_pk_fma_f32 scores two targets for one query.
-// Same IEEE fma per component, so scores are bit-identical to score<>() and the final resolve
-// (which re-reads the AoS rows from global memory) picks the same index.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-template <int Q, int TILE, int CH>
-__global__ __launch_bounds__(BLOCK) void knn_valu_pk_kernel(const float* __restrict__ src, const float* __restrict__ pose,
-                                                            const float4* __restrict__ tgt4, int32_t* __restrict__ idx,
-                                                            int N, int n, int m, int m_pad, int bpc) {
-    __shared__ float4 tile[TILE];
-    int cloud, blk;
-    if (!decode_block(bpc, N, cloud, blk)) return;
-    const int tid = threadIdx.x;
-    float C[9], r[3];
-    load_pose(pose, cloud, C, r);
-    float nx[Q][3], best[Q];
-    f32x2 nx2[Q][3];
-    int bchunk[Q];
-#pragma unroll
-    for (int qi = 0; qi < Q; ++qi) {
-        const int i = blk * (BLOCK * Q) + qi * BLOCK + tid;
-        float p[3] = {0.f, 0.f, 0.f};
-        if (i < n) {
-            const float* sp = src + ((size_t)cloud * n + i) * 3;
-            p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2];
-        }
-        query_point(C, r, p, nx[qi]);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) nx2[qi][k] = {nx[qi][k], nx[qi][k]};
-        best[qi] = inf_v<float>();
-        bchunk[qi] = 0;
-    }
-    const float4* __restrict__ tg = tgt4 + (size_t)cloud * m_pad;
-    for (int base = 0; base < m_pad; base += TILE) {
-        const int len = min(TILE, m_pad - base);            // multiple of 64
-        for (int t = tid; t < len / 2; t += BLOCK) {
-            const float4 a = tg[base + 2 * t], b = tg[base + 2 * t + 1];
-            tile[2 * t] = make_float4(a.x, b.x, a.y, b.y);
-            tile[2 * t + 1] = make_float4(a.z, b.z, a.w, b.w);
-        }
-        __syncthreads();
-        for (int j0 = 0; j0 < len; j0 += CH) {
-            float4 y[CH];
-#pragma unroll
-            for (int k = 0; k < CH; ++k) y[k] = tile[j0 + k];
-#pragma unroll
-            for (int qi = 0; qi < Q; ++qi) {
-                float c = best[qi];
-#pragma unroll
-                for (int k = 0; k < CH; k += 2) {
-                    const f32x2 y0 = {y[k].x, y[k].y}, y1 = {y[k].z, y[k].w};
-                    const f32x2 y2 = {y[k + 1].x, y[k + 1].y}, h = {y[k + 1].z, y[k + 1].w};
-                    const f32x2 s2 = __builtin_elementwise_fma(nx2[qi][0], y0, __builtin_elementwise_fma(nx2[qi][1], y1,
-                                     __builtin_elementwise_fma(nx2[qi][2], y2, h)));
-                    c = min_t(min_t(c, s2[0]), s2[1]);
-                }
-                bchunk[qi] = (c < best[qi]) ? base + j0 : bchunk[qi];
-                best[qi] = c;
-            }
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int qi = 0; qi < Q; ++qi) {
-        const int i = blk * (BLOCK * Q) + qi * BLOCK + tid;
-        if (i < n) {
-            const float4* cp = tg + bchunk[qi];
-            float bv = inf_v<float>();
-            int bj = bchunk[qi];
-#pragma unroll
-            for (int k = 0; k < CH; ++k) {
-                const float sc = score<float, float4>(nx[qi], cp[k]);
-                if (sc < bv) { bv = sc; bj = bchunk[qi] + k; }
-            }
-            idx[(size_t)cloud * n + i] = min(bj, m - 1);
-        }
-    }
-}
-
 // ------------------------------------------------------------------- kNN (MFMA)
 // The distance matrix IS a dense K=4 contraction: A = targets [y0,y1,y2,h] (16x4),
 // B = queries [-x0,-x1,-x2,1]^T (4x16), D = scores (16 targets x 16 queries) on
@@ -903,27 +821,14 @@ __device__ __forceinline__ void block_reduce_store(T* v, T* __restrict__ out, T*
 constexpr int SWEEP_CFG_BIG = 2;            // (Q, CH) = (2, 8)
 constexpr int SWEEP_MINW_Q2C8 = 5;
 
-// Optional fusion: with MODE >= 0 the search kernel goes on, for the matches it has just found, with what
-// accumulate_kernel does (residual, weights, Jacobian, normal-equation sums; ICP.py:143-201) -- the query, its pose and
-// the winner are in hand, so one pass over the points (and one launch) per iteration disappears.  The partials
-// then follow the search's waves: (N, units of this launch, NACC_PAD).
-constexpr int MODE_SEARCH_ONLY = -1;
-template <typename T> struct FusedAcc {
-    WeightParams P;
-    const T* tgt; int c;            // (N,m,c) target rows in ORIGINAL order
-    const T* w_init; const T* alive;
-    T* partials; T* w_out; long w_stride;
-    int units;                      // waves per cloud = partial rows per cloud
-};
-
-template <typename T, int Q, int CH, int MODE>
+template <typename T, int Q, int CH>
 __global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? SWEEP_MINW_Q2C8 : 1) void knn_sweep_kernel(const T* __restrict__ src, const T* __restrict__ pose,
                                                           const typename V4<T>::type* __restrict__ tgs4,
                                                           const int32_t* __restrict__ tperm, const int32_t* __restrict__ qorder,
                                                           const int32_t* __restrict__ bucket, const T* __restrict__ brange, int nbkt,
                                                           int32_t* __restrict__ idx, int32_t* __restrict__ spos,
                                                           unsigned long long* __restrict__ pairs,
-                                                          int N, int n, int m, int m_pad, int bpc, int src_sorted, FusedAcc<T> F) {
+                                                          int N, int n, int m, int m_pad, int bpc, int src_sorted) {
     using T4 = typename V4<T>::type;
     // each wave keeps the last NT tiles it scored in a ring: near the pose that is the whole visited range, and the
     // epilogue then re-scores the winning chunk out of LDS instead of gathering its rows (Q x CH 16-byte gathers per lane)
@@ -1111,192 +1016,6 @@ __global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? SWEE
     // sharded: one counter serialises ~12 ns per add, which at 65k waves would outlast the kernel itself
     if (pairs && lane == 0 && !idle_wave)
         atomicAdd(pairs + (blockIdx.x & (DICP_PAIR_SHARDS - 1)), (unsigned long long)(visR - visL) * WAVE * WAVE * Q);
-    if (MODE != MODE_SEARCH_ONLY) {
-        constexpr int M = MODE == MODE_SEARCH_ONLY ? MODE_PT2PT : MODE;
-        const T live = F.alive ? F.alive[cloud] : T(1);
-        T acc[NACC];
-#pragma unroll
-        for (int k = 0; k < NACC; ++k) acc[k] = T(0);
-        T p[Q][3], y[Q][3], nrm[Q][3], wv[Q];
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {                       // all gathers of the wave's Q queries in flight together
-            const size_t pt = (size_t)cloud * n + max(qi[q], 0);
-            const T* sp = src + (src_sorted ? (size_t)cloud * n + min(unit * (WAVE * Q) + q * WAVE + lane, n - 1) : pt) * 3;
-            p[q][0] = sp[0]; p[q][1] = sp[1]; p[q][2] = sp[2];
-            wv[q] = F.w_init[pt];
-            const T* yp = F.tgt + ((size_t)cloud * m + (qi[q] >= 0 ? mi[q] : 0)) * F.c;
-            y[q][0] = yp[0]; y[q][1] = yp[1]; y[q][2] = yp[2];
-            nrm[q][0] = nrm[q][1] = nrm[q][2] = T(0);
-            if (M == MODE_PT2PL) { nrm[q][0] = yp[3]; nrm[q][1] = yp[4]; nrm[q][2] = yp[5]; }
-        }
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            if (qi[q] < 0) continue;
-            PointState<T> st;
-            point_forward<T, M>(F.P, C, r, p[q], y[q], nrm[q], wv[q] * live, acc, st);
-            if (F.w_out) F.w_out[(size_t)cloud * F.w_stride + qi[q]] = st.w;
-        }
-        // one partial per WAVE (N, units, NACC_PAD): no block barrier, so a wave with a long sweep holds nobody up
-        T* out = F.partials + ((size_t)cloud * F.units + unit) * NACC_PAD;
-#pragma unroll
-        for (int k = 0; k < NACC; ++k) {
-            T v = acc[k];
-#pragma unroll
-            for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off);
-            if (lane == 0) out[k] = v;
-        }
-        if (lane == 0) { out[NACC] = T(0); out[NACC + 1] = T(0); }
-    }
-}
-
-// ------------------------------------------------------------------ kNN (scan)
-// The narrow-slab form of the same exact search, for iterations whose pose is already close: there a query's
-// neighbour is a few dozen sorted rows from its own x position, but the tile sweep above still scores every
-// query of a wave against the union of the wave's slabs (>= 256 rows at 192 queries per wave).  Here a wave owns 64
-// queries that are neighbours in x, stages ONE window of W sorted target rows around them in LDS, and each lane
-// scans outwards from ITS OWN lower bound, G rows per side per step, until its own slab bound
-// 0.5 (y.x - x.x)^2 - 0.5|x|^2 > best + margin closes each side -- the same bound, margin and score arithmetic as
-// the tile sweep, so the indices are identical.  The common step only tracks min3 of the G scores; the exact
-// per-candidate update (and the lowest-ORIGINAL-index rule on equal scores) runs when some lane's minimum moves.
-// Rows outside the staged window are read from global memory, so any data is handled; locality decides the speed.
-template <typename T, int W, int G>
-__global__ __launch_bounds__(BLOCK) void knn_scan_kernel(const T* __restrict__ src, const T* __restrict__ pose,
-                                                         const typename V4<T>::type* __restrict__ tgs4,
-                                                         const int32_t* __restrict__ tperm, const int32_t* __restrict__ qorder,
-                                                         const int32_t* __restrict__ bucket, const T* __restrict__ brange, int nbkt,
-                                                         int32_t* __restrict__ idx, int32_t* __restrict__ spos,
-                                                         unsigned long long* __restrict__ pairs,
-                                                         int N, int n, int m, int m_pad, int bpc) {
-    using T4 = typename V4<T>::type;
-    __shared__ T4 wins[BLOCK / WAVE][W];
-    int cloud, blk;
-    if (!decode_block(bpc, N, cloud, blk)) return;
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
-    const int unit = blk * (BLOCK / WAVE) + wave;           // 64 consecutive sorted queries
-    if (unit * WAVE >= n) return;                           // whole wave idle (no block-level sync below)
-    T C[9], r3[3];
-    load_pose(pose, cloud, C, r3);
-    const int slot = unit * WAVE + lane;
-    const bool live = slot < n;
-    int qi = -1;
-    T p[3] = {T(0), T(0), T(0)};
-    if (live) {
-        qi = qorder ? qorder[(size_t)cloud * n + slot] : slot;
-        const T* sp = src + ((size_t)cloud * n + qi) * 3;
-        p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2];
-    }
-    T nx[3];
-    query_point(C, r3, p, nx);
-    const T v[3] = {-nx[0], -nx[1], -nx[2]};
-    const T xq = v[0];
-    const T hx = T(0.5) * (v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-
-    // the wave's window starts a quarter of its length to the left of the smallest query x (coarse bucket table)
-    T xm = live ? xq : inf_v<T>();
-#pragma unroll
-    for (int off = WAVE / 2; off > 0; off >>= 1) { const T o = __shfl_xor(xm, off); xm = o < xm ? o : xm; }
-    const T xlo = brange[(size_t)cloud * 2], inv = brange[(size_t)cloud * 2 + 1];
-    T fb = (xm - xlo) * inv;
-    fb = fb > T(0) ? (fb > T(nbkt) ? T(nbkt) : fb) : T(0);      // NaN -> 0
-    const int start = bucket[(size_t)cloud * (nbkt + 1) + (int)fb];
-    const int w0 = max(min(start - W / 4, m_pad - W), 0);
-    const int wn = min(W, m_pad - w0);                       // staged rows: [w0, w0 + wn)
-    const T4* __restrict__ tg = tgs4 + (size_t)cloud * m_pad;
-    for (int k = lane; k < wn; k += WAVE) wins[wave][k] = tg[w0 + k];
-    __builtin_amdgcn_wave_barrier();
-
-    // per-lane lower bound of xq among the sorted x keys: in the window, else (rare) in the rest of the cloud
-    auto lower_bound = [&](auto key, int lo, int hi) {      // first j in [lo,hi) with key(j) >= xq
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (key(mid) < xq) lo = mid + 1; else hi = mid; }
-        return lo;
-    };
-    int c = w0 + lower_bound([&](int k) { return wins[wave][k].x; }, 0, wn);
-    if (live && c == w0 + wn && w0 + wn < m_pad) c = lower_bound([&](int j) { return tg[j].x; }, w0 + wn, m_pad);
-    else if (live && c == w0 && w0 > 0) c = lower_bound([&](int j) { return tg[j].x; }, 0, w0);
-
-    const int32_t* __restrict__ pm = tperm + (size_t)cloud * m_pad;
-    auto row = [&](int j) -> T4 {
-        j = min(max(j, 0), m_pad - 1);
-        const int k = j - w0;
-        const bool out = k < 0 || k >= wn;
-        T4 y = wins[wave][min(max(k, 0), wn - 1)];                 // always an LDS read (ds_read_b128), never a flat load
-        if (__any(out)) {                                   // wave-uniform branch: the global path costs nothing when unused
-            if (out) y = tg[j];
-        }
-        return y;
-    };
-    T best = inf_v<T>(), thr = inf_v<T>();
-    int bs = -1;
-    auto exact_update = [&](T sc, int j) {
-        j = min(max(j, 0), m_pad - 1);
-        if (sc < best) { best = sc; bs = j; }
-        else if (sc == best && sc < inf_v<T>() && pm[j] < pm[bs]) bs = j;       // lowest ORIGINAL index among equals
-    };
-    int r = c, l = c - 1;
-    bool aR = live && r < m_pad, aL = live && l >= 0;
-    // one group of G rows on one side: y[0] is the row nearest to the query in x, j0 its sorted index, dir = +-1
-    auto group = [&](const T4* y, int j0, int dir, T dx, bool& act) {
-        act = act && !(dx > T(0) && T(0.5) * dx * dx - hx > thr);
-        T sc[G];
-#pragma unroll
-        for (int g = 0; g < G; ++g) sc[g] = score<T, T4>(nx, y[g]);
-        T mg = sc[0];
-#pragma unroll
-        for (int g = 1; g < G; ++g) mg = min_t(mg, sc[g]);
-        const bool hit = act && mg <= best && mg < inf_v<T>();
-        if (__any(hit)) {               // some lane's minimum moves (or ties): exact per-candidate update
-            if (hit) {
-#pragma unroll
-                for (int g = 0; g < G; ++g) exact_update(sc[g], j0 + dir * g);
-                thr = best + SweepEps<T>::v * (T(1) + m_abs(best) + hx);
-            }
-        }
-    };
-    while (__any(aR || aL)) {
-        if (__any(aR)) {
-            const int k = r - w0;
-            const bool staged = k >= 0 && k + G <= wn;      // the whole group is in the LDS window (so also < m_pad)
-            T4 y[G];
-            if (!__any(aR && !staged)) {
-                const T4* b = &wins[wave][min(max(k, 0), wn - G)];
-#pragma unroll
-                for (int g = 0; g < G; ++g) y[g] = b[g];    // one address, immediate offsets
-            } else {
-#pragma unroll
-                for (int g = 0; g < G; ++g) y[g] = row(r + g);
-            }
-            group(y, r, 1, y[0].x - xq, aR);
-            r = aR ? r + G : r;
-            aR = aR && r < m_pad;
-        }
-        if (__any(aL)) {
-            const int k = l - (G - 1) - w0;
-            const bool staged = k >= 0 && k + G <= wn;
-            T4 y[G];
-            if (!__any(aL && !staged)) {
-                const T4* b = &wins[wave][min(max(k, 0), wn - G)];
-#pragma unroll
-                for (int g = 0; g < G; ++g) y[g] = b[G - 1 - g];
-            } else {
-#pragma unroll
-                for (int g = 0; g < G; ++g) y[g] = row(l - g);
-            }
-            group(y, l, -1, xq - y[0].x, aL);
-            l = aL ? l - G : l;
-            aL = aL && l >= 0;
-        }
-    }
-    if (live) {
-        const int bo = bs >= 0 ? pm[bs] : 0x7fffffff;
-        idx[(size_t)cloud * n + qi] = (bo == 0x7fffffff) ? 0 : min(max(bo, 0), m - 1);
-        if (spos) spos[(size_t)cloud * n + qi] = (bo == 0x7fffffff || bo >= m) ? -1 : bs;
-    }
-    if (pairs) {
-        int cnt = live ? (min(r, m_pad) - c) + (c - 1 - max(l, -1)) : 0;
-#pragma unroll
-        for (int off = WAVE / 2; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
-        if (lane == 0) atomicAdd(pairs + (blockIdx.x & (DICP_PAIR_SHARDS - 1)), (unsigned long long)cnt);
-    }
 }
 
 // ------------------------------------------------------------- gather / scatter
@@ -2511,20 +2230,8 @@ int knn_valu_launch(int cfg, const void* src, const void* pose, const void* tgt4
         case 1: knn_valu_go<T, 1, 8>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
         case 2: knn_valu_go<T, 2, 8>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
         case 3: knn_valu_go<T, 4, 8>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
-        case 4: knn_valu_go<T, 8, 8>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
         case 5: knn_valu_go<T, 4, 16>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
-        case 6: knn_valu_go<T, 8, 4>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
-        case 7: knn_valu_go<T, 8, 16>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
-        case 8: knn_valu_go<T, 4, 32>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
         case 11: knn_valu_go<T, 8, 16, (sizeof(T) == 4 ? 4 : 1)>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
-        case 9: case 10:
-            if (sizeof(T) != 4) return DICP_ERR_DTYPE;
-            {
-                const int Q = 4, bpc = (n + BLOCK * Q - 1) / (BLOCK * Q);
-                if (cfg == 9) knn_valu_pk_kernel<4, 2048, 16><<<grid_for(N, bpc), BLOCK, 0, st>>>((const float*)src, (const float*)pose, (const float4*)tgt4, idx, N, n, m, m_pad, bpc);
-                else          knn_valu_pk_kernel<4, 2048, 32><<<grid_for(N, bpc), BLOCK, 0, st>>>((const float*)src, (const float*)pose, (const float4*)tgt4, idx, N, n, m, m_pad, bpc);
-            }
-            break;
         default: return DICP_ERR_ENUM;
     }
     return launch_status();
@@ -2540,12 +2247,7 @@ int knn_mfma_launch(int cfg, const void* src, const void* pose, const void* tgt4
     if (cfg == 0) cfg = ((long)N * n >= 512L * 1024) ? 5 : 1;
     switch (cfg) {
         case 1: knn_mfma_go<2, 1>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
-        case 2: knn_mfma_go<4, 1>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
-        case 3: knn_mfma_go<8, 1>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
-        case 4: knn_mfma_go<4, 2>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
         case 5: knn_mfma_go<4, 4>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
-        case 6: knn_mfma_go<8, 4>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
-        case 7: knn_mfma_go<2, 4>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
         default: return DICP_ERR_ENUM;
     }
     return launch_status();
@@ -2741,84 +2443,33 @@ int dicp_knn(int dtype, const void* src, const void* pose, const void* tgt4, int
     return knn_valu_launch<double>(cfg, src, pose, tgt4, N, n, m, m_pad, idx, st);
 }
 
-// queries per lane of a tile-sweep launch configuration (0 = not a tile-sweep configuration)
-static int sweep_queries_per_lane(int dtype, int cfg) {
-    if (dtype == DICP_F32) {
-        switch (cfg) { case 1: case 4: return 1; case 2: case 5: return 2; case 3: case 6: return 4; case 7: case 8: return 3; default: return 0; }
-    }
-    switch (cfg) { case 1: case 4: return 1; case 2: case 5: case 7: case 8: return 2; case 3: case 6: return 4; default: return 0; }
-}
-static int sweep_auto_cfg(int N, int n) { return ((long)N * n >= 2L * BLOCK * 1024) ? SWEEP_CFG_BIG : 4; }   // 2 queries per lane / 8-row chunks, small problems 1 / 16
-
-int dicp_sweep_partials(int dtype, int n, int cfg) {      // waves per cloud of a tile-sweep configuration
-    const int Q = sweep_queries_per_lane(dtype, cfg);
-    if (Q <= 0 || n <= 0) return 0;
-    return (n + WAVE * Q - 1) / (WAVE * Q);
-}
-
-struct FusedHost { const dicp_weight_params* prm; const void* tgt; int c; const void* w_init; const void* alive; void* partials; void* w_out; int64_t w_stride; };
+// Tile-sweep launch configurations (queries per lane, rows per chunk): 0 = chosen from the problem size,
+// 1 = (1, 8), 2 = (2, 8) [the big-problem default], 4 = (1, 16) [float32: the small-problem default; float64: (1, 8)]
+static int sweep_queries_per_lane(int cfg) { return cfg == 2 ? 2 : ((cfg == 1 || cfg == 4) ? 1 : 0); }
+static int sweep_auto_cfg(int N, int n) { return ((long)N * n >= 2L * BLOCK * 1024) ? SWEEP_CFG_BIG : 4; }
 
 static int sweep_launch(int dtype, const void* src, const void* pose, const void* tgs4, const int32_t* tperm,
                         const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt,
-                        int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg,
-                        const FusedHost* fh, hipStream_t st) {
+                        int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg, hipStream_t st) {
     hipEvent_t ev0, ev1;
     take_launch_events(ev0, ev1);                                       // (null unless a timed loop set them for this launch)
     const int src_sorted = (cfg & DICP_SWEEP_SRC_SORTED) ? 1 : 0;      // src holds the rows in qorder's slot order
     cfg &= ~DICP_SWEEP_SRC_SORTED;
     if (src_sorted && !qorder) return DICP_ERR_NULL;
     if (cfg == 0) cfg = sweep_auto_cfg(N, n);
-    if (cfg >= DICP_SWEEP_SCAN && cfg <= DICP_SWEEP_SCAN + 3) {           // narrow-slab form: one query per lane, per-lane scan
-        if (fh || src_sorted) return DICP_ERR_ENUM;
-        const int bpc = (n + BLOCK - 1) / BLOCK;
-#define DICP_SCAN(T, W, G) hipExtLaunchKernelGGL((knn_scan_kernel<T, W, G>), dim3(grid_for(N, bpc)), dim3(BLOCK), 0, st, ev0, ev1, 0, \
-            (const T*)src, (const T*)pose, (const typename V4<T>::type*)tgs4, \
-            tperm, qorder, bucket, (const T*)brange, nbkt, idx, spos, pairs, N, n, m, m_pad, bpc)
-        if (dtype == DICP_F32) {
-            switch (cfg - DICP_SWEEP_SCAN) {
-                case 0: DICP_SCAN(float, 256, 8); break;  case 1: DICP_SCAN(float, 256, 4); break;
-                case 2: DICP_SCAN(float, 512, 8); break;  default: DICP_SCAN(float, 384, 8); break;
-            }
-        } else {
-            if ((cfg - DICP_SWEEP_SCAN) & 1) DICP_SCAN(double, 128, 4); else DICP_SCAN(double, 256, 4);
-        }
-#undef DICP_SCAN
-        return launch_status();
-    }
-    const int units = dicp_sweep_partials(dtype, n, cfg);
-    if (units <= 0) return DICP_ERR_ENUM;
+    const int Q = sweep_queries_per_lane(cfg);
+    if (Q <= 0) return DICP_ERR_ENUM;
+    const int units = (n + WAVE * Q - 1) / (WAVE * Q);                  // waves per cloud
     const int bpc = (units + BLOCK / WAVE - 1) / (BLOCK / WAVE);
-#define DICP_SWEEP_M(T, Q, CH, M, FA) hipExtLaunchKernelGGL((knn_sweep_kernel<T, Q, CH, M>), dim3(grid_for(N, bpc)), dim3(BLOCK), 0, st, ev0, ev1, 0, \
+#define DICP_SWEEP(T, Q, CH) hipExtLaunchKernelGGL((knn_sweep_kernel<T, Q, CH>), dim3(grid_for(N, bpc)), dim3(BLOCK), 0, st, ev0, ev1, 0, \
         (const T*)src, (const T*)pose, (const typename V4<T>::type*)tgs4, tperm, qorder, bucket, (const T*)brange, nbkt, idx, spos, pairs, \
-        N, n, m, m_pad, bpc, src_sorted, FA)
-#define DICP_SWEEP(T, Q, CH) do { FusedAcc<T> none{}; DICP_SWEEP_M(T, Q, CH, MODE_SEARCH_ONLY, none); } while (0)
-    // the fused form exists for the configurations the ICP loop uses
-#define DICP_SWEEP_F(T, Q, CH) do { if (!fh) { DICP_SWEEP(T, Q, CH); break; } \
-        FusedAcc<T> fa; fa.P = to_params(fh->prm); fa.tgt = (const T*)fh->tgt; fa.c = fh->c; fa.w_init = (const T*)fh->w_init; \
-        fa.alive = (const T*)fh->alive; fa.partials = (T*)fh->partials; fa.w_out = (T*)fh->w_out; fa.w_stride = (long)fh->w_stride; fa.units = units; \
-        if (fa.P.mode == MODE_PT2PL) DICP_SWEEP_M(T, Q, CH, MODE_PT2PL, fa); else DICP_SWEEP_M(T, Q, CH, MODE_PT2PT, fa); } while (0)
+        N, n, m, m_pad, bpc, src_sorted)
     if (dtype == DICP_F32) {
-        switch (cfg) {
-            case 2: DICP_SWEEP_F(float, 2, 8); break;   case 4: DICP_SWEEP_F(float, 1, 16); break;  case 8: DICP_SWEEP_F(float, 3, 16); break;
-            default:
-                if (fh) return DICP_ERR_ENUM;
-                switch (cfg) {
-                    case 1: DICP_SWEEP(float, 1, 8); break;   case 3: DICP_SWEEP(float, 4, 8); break;   case 5: DICP_SWEEP(float, 2, 16); break;
-                    case 6: DICP_SWEEP(float, 4, 16); break;  case 7: DICP_SWEEP(float, 3, 8); break;
-                    default: return DICP_ERR_ENUM;
-                }
-        }
+        if (cfg == 2) DICP_SWEEP(float, 2, 8); else if (cfg == 4) DICP_SWEEP(float, 1, 16); else DICP_SWEEP(float, 1, 8);
     } else {
-        switch (cfg) {
-            case 1: case 4: DICP_SWEEP_F(double, 1, 8); break;
-            case 2: case 5: case 7: case 8: DICP_SWEEP_F(double, 2, 8); break;
-            case 3: case 6: if (fh) return DICP_ERR_ENUM; DICP_SWEEP(double, 4, 8); break;
-            default: return DICP_ERR_ENUM;
-        }
+        if (cfg == 2) DICP_SWEEP(double, 2, 8); else DICP_SWEEP(double, 1, 8);
     }
-#undef DICP_SWEEP_F
 #undef DICP_SWEEP
-#undef DICP_SWEEP_M
     return launch_status();
 }
 
@@ -2830,7 +2481,7 @@ int dicp_knn_sweep(int dtype, const void* src, const void* pose, const void* tgs
     if (N <= 0 || n <= 0 || m <= 0 || nbkt <= 0 || m_pad != dicp_padded_targets(m)) return DICP_ERR_SHAPE;
     if ((uintptr_t)tgs4 % (dtype == DICP_F32 ? 16 : 32)) return DICP_ERR_ALIGN;
     begin_launch();
-    return sweep_launch(dtype, src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, N, n, m, m_pad, idx, spos, pairs, cfg, nullptr, (hipStream_t)stream);
+    return sweep_launch(dtype, src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, N, n, m, m_pad, idx, spos, pairs, cfg, (hipStream_t)stream);
 }
 
 int dicp_gather_rows(int dtype, const void* tgt, const int32_t* idx, int N, int n, int m, int c, void* out, void* stream) {
@@ -2894,27 +2545,6 @@ int dicp_accumulate(int dtype, const dicp_weight_params* prm, const void* src, c
     else                   { if (P.mode == MODE_PT2PL) DICP_ACC(double, MODE_PT2PL); else DICP_ACC(double, MODE_PT2PT); }
 #undef DICP_ACC
     return launch_status();
-}
-
-int dicp_knn_sweep_accumulate(int dtype, const dicp_weight_params* prm, const void* src, const void* pose, const void* tgs4,
-                              const int32_t* tperm, const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt,
-                              const void* tgt, int c, const void* w_init, const void* alive, int N, int n, int m, int m_pad,
-                              int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg,
-                              void* partials, void* w_out, int64_t w_stride, void* stream) {
-    if (const int e = check_params(prm, c)) return e;
-    if (!src || !tgs4 || !tperm || !bucket || !brange || !idx || !tgt || !w_init || !partials) return DICP_ERR_NULL;
-    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
-    if (N <= 0 || n <= 0 || m <= 0 || nbkt <= 0 || m_pad != dicp_padded_targets(m) || (w_out && w_stride < n)) return DICP_ERR_SHAPE;
-    if ((uintptr_t)tgs4 % (dtype == DICP_F32 ? 16 : 32)) return DICP_ERR_ALIGN;
-    begin_launch();
-    const FusedHost fh{prm, tgt, c, w_init, alive, partials, w_out, w_stride};
-    return sweep_launch(dtype, src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, N, n, m, m_pad, idx, spos, pairs, cfg, &fh, (hipStream_t)stream);
-}
-
-int dicp_loop_partial_blocks(int dtype, int n) {        // enough (N, blocks, DICP_NACC_PAD) partials for every launch of the loop
-    int b = dicp_accumulate_blocks(n);
-    for (int cfg = 1; cfg <= 8; ++cfg) { const int s = dicp_sweep_partials(dtype, n, cfg); b = s > b ? s : b; }
-    return b;
 }
 
 int dicp_step(int dtype, const dicp_step_io* io, int N, void* stream) {
@@ -3135,7 +2765,7 @@ static int permute_rows(int dtype, const void* in, const int32_t* perm, int N, i
 // search stays in the microseconds (SMALL_PAIRS pairs per iteration); anything bigger is better off spread over the chip.
 constexpr long SMALL_PAIRS = 128L * 1024;    // measured break-even against the multi-kernel path: ~512 x 512 (profiles/r01_small_clouds.txt)
 static bool small_loop_eligible(int dtype, int kind, int knn_variant, int n, int m_pad) {
-    if (kind == DICP_KNN_SWEEP || kind == DICP_KNN_MFMA || ((knn_variant >> 25) & 1) || ((knn_variant >> 8) & 0xff)) return false;
+    if (kind == DICP_KNN_SWEEP || kind == DICP_KNN_MFMA || ((knn_variant >> 25) & 1) || ((knn_variant >> 8) & 0xff)) return false;   // bit 25: switched off by the caller
     const size_t lds = (size_t)m_pad * (dtype == DICP_F32 ? 16 : 32);
     return lds <= 48 * 1024 && (long)n * m_pad <= SMALL_PAIRS;
 }
@@ -3182,37 +2812,21 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
             else if (hipEventRecord((hipEvent_t)B->events[6 * k + 0], st) != hipSuccess) return -(int)hipGetLastError();
         }
         int rc;
-        int nblk_k = nblk;
         if (kind == DICP_KNN_SWEEP) {
-            // bits 16..23 of knn_variant: first iteration that takes the narrow-slab (per-lane scan) form; 0 = never.
-            // bit 24: fuse accumulate into the search kernel's epilogue (tile-sweep configurations 2, 4, 8)
-            const int scan_from = (B->knn_variant >> 16) & 0xff;
-            const bool fuse = ((B->knn_variant >> 24) & 1) && !B->poses_search;   // (the fused form scores and accumulates with ONE pose)
+            // bits 8..15 of knn_variant optionally pin a tile-sweep launch configuration (0 = chosen from the problem size)
             int cfg = (B->knn_variant >> 8) & 0xff;
-            if (cfg == 0 && scan_from > 0 && k >= scan_from) cfg = DICP_SWEEP_SCAN;
-            if (cfg == 0) cfg = sweep_auto_cfg(N, n);
             int32_t* spos_k = B->spos ? B->spos + (size_t)k * N * n : nullptr;
             // src_s: the source rows in qorder's slot order (dicp_query_order wrote them): coalesced query loads
             const void* qsrc = B->src;
-            if (B->src_s && B->qorder && cfg < DICP_SWEEP_SCAN) { qsrc = B->src_s; cfg |= DICP_SWEEP_SRC_SORTED; }
-            const int cfg_plain = cfg & ~DICP_SWEEP_SRC_SORTED;
-            if (fuse && (cfg_plain == 2 || cfg_plain == 4 || cfg_plain == 8)) {
-                rc = dicp_knn_sweep_accumulate(dtype, prm, qsrc, pose_k, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt,
-                                               B->tgt, B->c, B->w_init, alive_k, N, n, m, B->m_pad, idx_k, spos_k, B->pairs, cfg,
-                                               B->partials, w_k, B->w_stride, stream);
-                nblk_k = dicp_sweep_partials(dtype, n, cfg_plain);
-                set_launch_events(nullptr, nullptr);
-                if (rc) return rc;
-            } else {
-                rc = dicp_knn_sweep(dtype, qsrc, pose_s, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, N, n, m, B->m_pad,
-                                    idx_k, spos_k, B->pairs, cfg, stream);
-                set_launch_events(nullptr, nullptr);
-                if (rc) return rc;
-                if (B->events) set_launch_events((hipEvent_t)B->events[6 * k + 2], (hipEvent_t)B->events[6 * k + 3]);
-                rc = dicp_accumulate(dtype, prm, B->src, B->tgt, B->c, idx_k, pose_k, B->w_init, alive_k, N, n, m, B->partials, w_k, B->w_stride, stream);
-                set_launch_events(nullptr, nullptr);
-                if (rc) return rc;
-            }
+            if (B->src_s && B->qorder) { qsrc = B->src_s; cfg |= DICP_SWEEP_SRC_SORTED; }
+            rc = dicp_knn_sweep(dtype, qsrc, pose_s, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, N, n, m, B->m_pad,
+                                idx_k, spos_k, B->pairs, cfg, stream);
+            set_launch_events(nullptr, nullptr);
+            if (rc) return rc;
+            if (B->events) set_launch_events((hipEvent_t)B->events[6 * k + 2], (hipEvent_t)B->events[6 * k + 3]);
+            rc = dicp_accumulate(dtype, prm, B->src, B->tgt, B->c, idx_k, pose_k, B->w_init, alive_k, N, n, m, B->partials, w_k, B->w_stride, stream);
+            set_launch_events(nullptr, nullptr);
+            if (rc) return rc;
         } else {
             rc = dicp_knn(dtype, B->src, pose_s, B->tgt4, N, n, m, B->m_pad, idx_k, B->knn_variant & 0xffff, stream);
             if (rc) return rc;
@@ -3224,7 +2838,7 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
             set_launch_events(nullptr, nullptr);
             if (rc) return rc;
         }
-        dicp_step_io io = make_step_io(*B, k, k0, N, n, prm->mode, dim, const_iter, tolerance, es, nblk_k);
+        dicp_step_io io = make_step_io(*B, k, k0, N, n, prm->mode, dim, const_iter, tolerance, es, nblk);
         rc = dicp_step(dtype, &io, N, stream);
         if (rc) return rc;
     }

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DICP_ABI_VERSION 2   /* 2: dicp_step_io / dicp_loop_buffers end with the centred-search fields */
+#define DICP_ABI_VERSION 3   /* 3: timing events are 6 per iteration; the scan / fused-accumulate search forms and their entry points are gone */
 
 enum { DICP_F32 = 0, DICP_F64 = 1 };
 enum { DICP_PT2PT = 0, DICP_PT2PL = 1 };                 /* ICP(icp_type=...)  ICP.py:15,101-105 */
@@ -110,7 +110,7 @@ int dicp_query_keys(int dtype, const void* src, const void* pose, int N, int n, 
  * query loads in dicp_knn_sweep (cfg | DICP_SWEEP_SRC_SORTED) and for dicp_accumulate_bwd_window (measured: one block
  * per cloud gathers slowly, 115 vs 16 us; dicp_gather_rows does it better).  reproducible != 0: buckets of up to 64
  * members are put in index order, so the permutation is the same on every run (needed only when sums are taken in
- * this order, i.e. by dicp_knn_sweep_accumulate).  spos_prev (N,n), optional: the queries' matches of an earlier iteration
+ * this order).  spos_prev (N,n), optional: the queries' matches of an earlier iteration
  * (dicp_knn_sweep's spos): the bucket is then the match's rank among the m_pad sorted targets instead of the query's x --
  * equal-population buckets, robust against uneven density along x (but one pose late).  keys_sorted (N,m_pad; the
  * sorted keys dicp_sweep_build was given) + bucket (from dicp_sweep_build; m real targets), optional: the bucket is the RANK of the query's x among the sorted target keys under the given pose (a
@@ -132,28 +132,12 @@ int dicp_query_order(int dtype, const void* src, const void* pose, const void* b
  *   what dicp_accumulate_bwd_window consumes.
  * pairs: optional DICP_PAIR_SHARDS device counters; their sum += number of (query,target) pairs actually scored
  *   (roofline accounting; sharded because adds to ONE address serialise at ~12 ns each).
- * cfg: 0 auto (tile sweep), 1..8 = fixed (queries per lane, chunk) tile-sweep configuration (tuning),
- *      DICP_SWEEP_SCAN (+1..3: other window / group sizes) = the narrow-slab form: per-lane scan from the query's own x position,
- *      same indices, far fewer pairs once the pose is close (iterations >= 1 of an ICP call). */
-#define DICP_SWEEP_SCAN 16
+ * cfg: 0 = launch configuration chosen from the problem size; 1, 2, 4 pin one (queries per lane, rows per chunk) = (1,8), (2,8), (1,16). */
 #define DICP_PAIR_SHARDS 64
 #define DICP_SWEEP_SRC_SORTED 0x100   /* OR into cfg: `src` holds the rows in qorder's slot order (dicp_query_order's src_s) */
 int dicp_knn_sweep(int dtype, const void* src, const void* pose, const void* tgs4, const int32_t* tperm,
                    const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt,
                    int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg, void* stream);
-
-/* dicp_knn_sweep that goes on, for the matches it has just found, with dicp_accumulate (declared below): one pass over
- * the points and one launch less per iteration.  Tile-sweep configurations cfg in {0 (auto), 2, 4, 8}; partials
- * (N, dicp_sweep_partials(dtype, n, cfg), DICP_NACC_PAD): one row per wave of the search (pass that count to dicp_step);
- * dicp_loop_partial_blocks(dtype, n) blocks are enough for any launch of the loop.  Sums are taken in the order of
- * `qorder`, which dicp_query_order makes reproducible. */
-int dicp_sweep_partials(int dtype, int n, int cfg);
-int dicp_loop_partial_blocks(int dtype, int n);
-int dicp_knn_sweep_accumulate(int dtype, const dicp_weight_params* prm, const void* src, const void* pose, const void* tgs4,
-                              const int32_t* tperm, const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt,
-                              const void* tgt, int c, const void* w_init, const void* alive, int N, int n, int m, int m_pad,
-                              int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg,
-                              void* partials, void* w_out, int64_t w_stride, void* stream);
 
 /* Gather whole target rows at idx (nn.py:37-38 / 89-90) and its backward, a scatter-add
  * into a zero-initialised (N,m,c) buffer (autograd's gather backward). */
@@ -217,7 +201,8 @@ typedef struct dicp_loop_buffers {
     const void* w_init;      /* (N,n) */
     int32_t c;
     int32_t K;               /* capacity of the histories (= max_iterations) */
-    int32_t knn_variant;     /* DICP_KNN_VALU | _MFMA (uses tgt4) or DICP_KNN_SWEEP (uses tgt4 = tgs4 + the arrays below) */
+    int32_t knn_variant;     /* DICP_KNN_VALU | _MFMA (uses tgt4) or DICP_KNN_SWEEP (uses tgt4 = tgs4 + the arrays below); bits 8..15: optional
+                                launch configuration (as dicp_knn / dicp_knn_sweep); bit 25: never take the one-block-per-cloud small path */
     int32_t m_pad;
     const void* tgt4;        /* dicp_pack_target output, or its x-sorted form for the sweep */
     const int32_t* tperm;    /* sweep only */
@@ -248,7 +233,7 @@ typedef struct dicp_loop_buffers {
                                 (N,K,n): w_iter = n, w_stride = K*n.  May be a per-slab virtual base: only [k0,k1) is touched */
     int64_t w_iter, w_stride;
     const void* w_prev0;     /* weights of iteration k0-1 (cloud stride w_stride too), or NULL when k0 == 0   ICP.py:224-226 */
-    void* partials;          /* (N, dicp_loop_partial_blocks(dtype, n), DICP_NACC_PAD) scratch */
+    void* partials;          /* (N, dicp_accumulate_blocks(n), DICP_NACC_PAD) scratch */
     int32_t* counters;       /* (K) zero-initialised: #clouds with |delta| >= tol at iteration k */
     void** events;           /* optional 6*K hipEvent_t: [6k] before / [6k+1] after the kNN of iteration k, [6k+2] / [6k+3] its
                                 accumulate (forward), [6k+4] / [6k+5] its accumulate_bwd (backward); NULL = none.  The sweep,

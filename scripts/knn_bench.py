@@ -12,10 +12,7 @@ if os.environ.get("NEAR") == "1":      # converged-pose queries: every query 0.0
     src = (tgt[:, torch.randperm(n, device="cuda"), :3] + 0.01 * torch.randn((B, n, 3), device="cuda")).contiguous()
 tgt4 = _ops.pack_target(tgt)
 idx = torch.empty((B, n), dtype=torch.int32, device="cuda")
-variants = {"valu_q4c8": 1 | (3 << 8), "valu_q8c8": 1 | (4 << 8), "valu_q4c16": 1 | (5 << 8), "valu_q8c16": 1 | (7 << 8),
-            "valu_q4c32": 1 | (8 << 8), "valu_q8c16w4": 1 | (11 << 8), "valu_pk_q4c16": 1 | (9 << 8), "valu_pk_q4c32": 1 | (10 << 8),
-            "mfma_nb4g1": 2 | (2 << 8), "mfma_nb8g1": 2 | (3 << 8), "mfma_nb4g2": 2 | (4 << 8), "mfma_nb4g4": 2 | (5 << 8),
-            "mfma_nb8g4": 2 | (6 << 8), "mfma_nb2g4": 2 | (7 << 8)}
+variants = {"valu_q4c16": 1 | (5 << 8), "valu_q8c16w4": 1 | (11 << 8), "mfma_nb2g1": 2 | (1 << 8), "mfma_nb4g4": 2 | (5 << 8)}
 sel = os.environ.get("VARIANTS")
 if sel:
     variants = {k: v for k, v in variants.items() if k in sel.split(",")}

@@ -75,8 +75,6 @@ def test_new_entry_points_reject_bad_arguments(lib):
     one, P = ctypes.c_void_p(64), _lib.WeightParams(mode=1, loss=0)
     assert [lib.dicp_window_blocks(0, n, 16384) for n in (0, 1, 16384)] == [0, 1, 16]
     assert lib.dicp_window_rows(0) == 1536 and lib.dicp_window_rows(1) == 768
-    assert lib.dicp_sweep_partials(0, 16384, 8) == 86 and lib.dicp_sweep_partials(0, 16384, 2) == 128 and lib.dicp_sweep_partials(0, 16384, 16) == 0
-    assert lib.dicp_loop_partial_blocks(0, 16384) == 256
     assert lib.dicp_sweep_build(0, None, 3, one, one, 1, 1, 64, 1024, one, one, one, one, None, None) == 1
     assert lib.dicp_sweep_build(0, one, 4, one, one, 1, 1, 64, 1024, one, one, one, one, None, None) == 2
     assert lib.dicp_sweep_build(0, one, 3, one, one, 1, 1, 64, 1024, ctypes.c_void_p(8), one, one, one, None, None) == 5
@@ -117,13 +115,12 @@ def test_new_entry_points_reject_bad_arguments(lib):
     assert lib.dicp_pose_grad_in(0, None, None, 1, None) == 1 and lib.dicp_pose_grad_in(7, None, one, 1, None) == 3
     assert lib.dicp_pose_grad_out(0, one, one, 0, one, 1, None) == 2 and lib.dicp_pose_grad_out(0, one, None, 0, None, 1, None) == 1
     assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, 1, 1, 1, 64, one, None, None, 99, None) == 4
-    assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, 1, 1, 1, 64, one, None, None, 8 | 0x100, None) == 1  # sorted rows need the order
-    assert lib.dicp_knn_sweep_accumulate(0, ctypes.byref(P), one, None, one, one, None, one, one, 1024, one, 6, one, None, 1, 1, 1, 64,
-                                         one, None, None, 16, one, None, 0, None) == 4      # no fused form of the scan kernel
+    assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, 1, 1, 1, 64, one, None, None, 16, None) == 4   # (the scan form is gone)
+    assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, 1, 1, 1, 64, one, None, None, 2 | 0x100, None) == 1  # sorted rows need the order
 
 
 def test_sizes_and_argument_checks(lib):
-    assert lib.dicp_abi_version() == 2
+    assert lib.dicp_abi_version() == _lib.ABI_VERSION == 3
     assert [lib.dicp_padded_targets(m) for m in (0, 1, 64, 65, 129)] == [0, 64, 64, 128, 192]
     assert [lib.dicp_accumulate_blocks(n) for n in (0, 1, 1024, 1025, 16384)] == [0, 1, 1, 2, 16]
     # rejected before any launch (no GPU touched): null pointers, bad dtype / shapes / enums

@@ -62,7 +62,7 @@ def test_sweep_equals_brute_force_at_65536(dtype, N, n):
     key = td[:, :, 0]
     want_perm = torch.sort(key, dim=1, stable=True).indices.to(torch.int32)
     assert torch.equal(sw.tperm[:, :n], want_perm)
-    cfgs = (0, 1, 2, 3, 4, 5, 6, 7, 8, 16, 17) if dtype == torch.float32 else (0, 1, 2, 3, 16, 17)
+    cfgs = (0, 1, 2, 4)
     qo = sw.query_order(sd, None)
     assert torch.equal(torch.sort(qo.long(), dim=1).values, torch.arange(n, device=DEV).repeat(N, 1))     # a permutation
     for cfg in cfgs:

@@ -88,8 +88,8 @@ def test_sweep_path_equals_brute_path(seed, kind):
 
 @pytest.mark.parametrize("seed", range(8))
 def test_every_knn_form_returns_the_same_indices(seed):
-    """All-pairs VALU (several launch configurations), packed-FMA, MFMA, tile sweep (every configuration, any query order)
-    and per-lane scan share one score arithmetic: under a random pose they must agree index for index, near-ties included."""
+    """All-pairs VALU (every launch configuration), MFMA and the tile sweep (every configuration, any query order) share one
+    score arithmetic: under a random pose they must agree index for index, near-ties included."""
     from dicp_amd import _ops
     rng = np.random.default_rng(50 + seed)
     N = int(rng.integers(1, 4))
@@ -106,11 +106,11 @@ def test_every_knn_form_returns_the_same_indices(seed):
     x, y = x.to(DEV).contiguous(), y.to(DEV).contiguous()
     tgt4 = _ops.pack_target(y)
     ref = _ops.knn(x, pose, tgt4, m, _lib.KNN_VALU)
-    for cfg in (1, 2, 5, 7, 11, 9):                         # VALU launch configurations, incl. the packed-FMA form (9)
+    for cfg in (1, 2, 3, 5, 11):                            # VALU launch configurations
         assert torch.equal(_ops.knn(x, pose, tgt4, m, _lib.KNN_VALU | (cfg << 8)), ref), ("valu", cfg)
     for cfg in (0, 1, 5):
         assert torch.equal(_ops.knn(x, pose, tgt4, m, _lib.KNN_MFMA | (cfg << 8)), ref), ("mfma", cfg)
     sw = _ops.SweepIndex(y)
-    for cfg in (1, 2, 3, 4, 5, 6, 7, 8, 16, 17, 18):
+    for cfg in (0, 1, 2, 4):
         for qo in (None, sw.query_order(x, pose), sw.query_order(x, pose, exact=True)):
             assert torch.equal(sw.knn(x, pose, qo, cfg=cfg), ref), ("sweep", cfg)

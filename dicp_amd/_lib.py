@@ -17,7 +17,8 @@ HEADERS = [os.path.join(_HERE, "csrc", "dicp_math.h"), os.path.join(_ROOT, "incl
 F32, F64 = 0, 1
 PT2PT, PT2PL = 0, 1
 LOSS_NONE, LOSS_HUBER, LOSS_CAUCHY, LOSS_TRIM = 0, 1, 2, 3
-KNN_AUTO, KNN_VALU, KNN_MFMA, KNN_SWEEP = 0, 1, 2, 3
+KNN_AUTO, KNN_VALU, KNN_MFMA, KNN_SWEEP, KNN_GRID = 0, 1, 2, 3, 4
+GRID_INFO = 16
 NACC_PAD, NBWD_PAD, KAB_SAVE = 32, 16, 40
 PAIR_SHARDS, SWEEP_SRC_SORTED = 64, 0x100      # DICP_PAIR_SHARDS, DICP_SWEEP_SRC_SORTED
 ABI_VERSION = 3
@@ -61,6 +62,10 @@ _SIGNATURES = {
     "dicp_pack_target_centered": ([i32, vp, i32, i32, i32, vp, vp, i32, vp], ctypes.c_int),
     "dicp_knn": ([i32, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp], ctypes.c_int),
     "dicp_knn_sweep": ([i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp], ctypes.c_int),
+    "dicp_grid_cells_max": ([i32], ctypes.c_int),
+    "dicp_grid_scratch_bytes": ([i32, i32], ctypes.c_size_t),
+    "dicp_grid_build": ([i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp], ctypes.c_int),
+    "dicp_knn_grid": ([i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp], ctypes.c_int),
     "dicp_window_blocks": ([i32, i32, i32], ctypes.c_int),
     "dicp_window_rows": ([i32], ctypes.c_int),
     "dicp_sweep_sort": ([i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp], ctypes.c_int),

@@ -193,6 +193,52 @@ class SweepIndex:
         return idx
 
 
+class GridIndex:
+    """Per-call search structure of the exact grid kNN (dicp_grid_build / dicp_knn_grid): targets do not move during an ICP
+    call, so they are binned into a uniform 3-D grid of cells once (about 4 per cell; stable order of the cell id).  A query
+    looks at its own cell and at a neighbouring one only if that cell's box is nearer than its best match so far: a few
+    dozen scored pairs per query whatever the pose, queries in the caller's order (no query ordering)."""
+
+    def __init__(self, tgt, sorted_rows=False, center=None, tgt_rows=None):
+        """sorted_rows: also keep tgt_s (N,m_pad,c), the full rows in cell order (the windowed backward reads them).
+        center (N,3): grid and packed rows are built on y - center; the searches must then be given [C | r - center].
+        tgt_rows (N) int32: leading rows of each cloud that take part (ragged batches)."""
+        require_device(tgt, "GridIndex")
+        tgt = tgt.contiguous()
+        N, m, c = tgt.shape
+        lib = _lib.load()
+        dev, dt = tgt.device, tgt.dtype
+        self.m, self.center = m, center
+        m_pad = lib.dicp_padded_targets(m)
+        self.ncell_max = lib.dicp_grid_cells_max(m)
+        self.tgs4 = torch.empty((N, m_pad, 4), dtype=dt, device=dev)
+        self.tperm = torch.empty((N, m_pad), dtype=torch.int32, device=dev)
+        self.cell_start = torch.empty((N, self.ncell_max + 1), dtype=torch.int32, device=dev)
+        self.ginfo = torch.empty((N, _lib.GRID_INFO), dtype=dt, device=dev)
+        self.tgt_s = torch.empty((N, m_pad, c), dtype=dt, device=dev) if sorted_rows else None
+        nbytes = int(lib.dicp_grid_scratch_bytes(N, m_pad))
+        scratch = torch.empty((nbytes,), dtype=torch.uint8, device=dev) if nbytes else None
+        with torch.cuda.device(dev):
+            _lib.check(lib.dicp_grid_build(_DT[dt], _p(tgt), c, _p(center), _p(tgt_rows), N, m, m_pad, self.ncell_max, _p(self.ginfo),
+                                           _p(self.tperm), _p(self.cell_start), _p(self.tgs4), _p(self.tgt_s), _p(scratch), nbytes, _stream()),
+                       "dicp_grid_build")
+        self.pair_shards = torch.zeros((_lib.PAIR_SHARDS,), dtype=torch.int64, device=dev)
+
+    @property
+    def pairs(self):
+        """(query,target) pairs scored so far (device scalar)."""
+        return self.pair_shards.sum()
+
+    def knn(self, src, pose, out=None, spos=None, src_rows=None):
+        N, n, _ = src.shape
+        idx = out if out is not None else torch.empty((N, n), dtype=torch.int32, device=src.device)
+        with torch.cuda.device(src.device):
+            _lib.check(_lib.load().dicp_knn_grid(_DT[src.dtype], _p(src), _p(pose), _p(self.tgs4), _p(self.tperm), _p(self.cell_start),
+                                                 self.ncell_max, _p(self.ginfo), _p(src_rows), N, n, self.m, self.tgs4.shape[1],
+                                                 _p(idx), _p(spos), _p(self.pair_shards), _stream()), "dicp_knn_grid")
+        return idx
+
+
 class _GatherRows(torch.autograd.Function):
     """nn.py:37-38: neighbours = y[idx]; backward = scatter-add into y.grad."""
 

@@ -1018,6 +1018,398 @@ __global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? SWEE
         atomicAdd(pairs + (blockIdx.x & (DICP_PAIR_SHARDS - 1)), (unsigned long long)(visR - visL) * WAVE * WAVE * Q);
 }
 
+// --------------------------------------------------------------- grid index / kNN (grid)
+// Exact 1-NN over a uniform 3-D grid of cells (the ICP default for big clouds).  The x-sorted sweep above prunes on ONE
+// coordinate: a wave scores every target of its queries' x slab -- 1.5 % of the pairs near the pose, 6 % before the first step,
+// 12 % on a dense blob, everything on a plane x = const.  A grid prunes on all three: a query looks at its own cell (a handful of
+// targets), and at a neighbouring cell only if that cell's box is nearer than the best match so far.
+//   per cloud, once per call (targets do not move):
+//     ginfo       grid geometry from robust sample quantiles of the (centred) target coordinates, ~GRID_PPC targets per cell
+//     tperm       targets in STABLE order of their cell id (cz, cy, cx: x fastest)    -- grid_sort_kernel (LSD radix, one block per cloud)
+//     cell_start  first sorted position of every cell (+ the end)
+//     tgs4/tgt_s  packed rows / full rows in that order                              -- sweep_rows_kernel, as for the sweep
+//   per iteration: knn_grid_kernel -- one query per lane, in the CALLER's order (no query ordering, coalesced index stores):
+//     rings of cells around the query's own, every (cy, cz) row of a ring is a run of consecutive sorted rows; a row / run is
+//     skipped when its box lies further than the best match so far, with the sweep's safety margin.  Same score(), same packed
+//     rows, same lowest-ORIGINAL-index rule on exact ties as every other search form => bit-identical indices.
+// Cells at the border of the grid are unbounded outwards (targets beyond the sampled quantiles are clamped into them), so
+// outliers cost pruning power in the border cells only, never correctness; a degenerate cloud (all targets in one cell)
+// degenerates to brute force.
+constexpr int GRID_PPC = 4;                 // targets per cell aimed at
+constexpr int GRID_MAX_CELLS = 32768;       // 15-bit cell ids; 0xffff = pad slot
+constexpr int GRID_INFO = DICP_GRID_INFO;   // T values per cloud: lo[3], inv[3], h[3], G[3], ncell, slack[3]
+constexpr int GS_THREADS = 1024, GS_PER = 16, GS_CHUNK = GS_THREADS * GS_PER;
+
+__host__ __device__ inline int grid_cells_max(int m) {
+    long c = (long)(m > 0 ? m : 1) / GRID_PPC + 8;
+    return (int)(c > GRID_MAX_CELLS ? GRID_MAX_CELLS : c);
+}
+
+template <typename T>
+__global__ __launch_bounds__(GS_THREADS) void grid_info_kernel(const T* __restrict__ tgt, int c, int m, const int32_t* __restrict__ tgt_rows,
+                                                               const T* __restrict__ center, int ncell_max, T* __restrict__ ginfo) {
+    __shared__ unsigned key[3][GS_THREADS];
+    __shared__ int nfin[3];
+    const int cloud = blockIdx.x, tid = threadIdx.x;
+    const int mc = tgt_rows ? min(max(tgt_rows[cloud], 1), m) : m;
+    const T* __restrict__ rows = tgt + (size_t)cloud * m * c;
+    const int step = (mc + GS_THREADS - 1) / GS_THREADS, ms = (mc + step - 1) / step;
+    if (tid < 3) nfin[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        unsigned u = 0xffffffffu;                               // unused / non-finite samples sort last
+        if (tid < ms) {
+            const float v = (float)(rows[(size_t)tid * step * c + a] - (center ? center[(size_t)cloud * 3 + a] : T(0)));
+            if (v == v && fabsf(v) < 3.0e38f) { u = sortable_bits(v); atomicAdd(&nfin[a], 1); }
+        }
+        key[a][tid] = u;
+    }
+    __syncthreads();
+    for (int k = 2; k <= GS_THREADS; k <<= 1)                   // bitonic sort of the three axes side by side
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int p = tid ^ j;
+            if (p > tid) {
+                const bool up = (tid & k) == 0;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const unsigned x = key[a][tid], y = key[a][p];
+                    if ((x > y) == up) { key[a][tid] = y; key[a][p] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    if (tid == 0) {
+        double lo[3], hi[3], e[3];
+        int flat = 0;
+        double vol = 1.0;
+        for (int a = 0; a < 3; ++a) {
+            const int nf = nfin[a];
+            auto val = [&](int i) { unsigned u = key[a][i]; u ^= (u >> 31) ? 0x80000000u : 0xffffffffu; return (double)__uint_as_float(u); };
+            if (nf <= 0) { lo[a] = hi[a] = 0.0; }
+            else {
+                const int q = nf / 64;                          // the 1/64 and 63/64 sample quantiles, widened by 1/16 of their span:
+                const double a0 = val(q), a1 = val(nf - 1 - q); // a uniform cloud is covered, a stray return does not stretch the grid
+                const double pad = (a1 - a0) / 16.0;
+                lo[a] = a0 - pad; hi[a] = a1 + pad;
+            }
+            e[a] = hi[a] - lo[a];
+            const double scale = fmax(fmax(fabs(lo[a]), fabs(hi[a])), 1e-30);
+            if (!(e[a] > 1e-9 * scale)) { e[a] = 0.0; ++flat; } else vol *= e[a];
+        }
+        int G[3] = {1, 1, 1};
+        const int d = 3 - flat;
+        double want = (double)mc / GRID_PPC;
+        want = want < 1.0 ? 1.0 : (want > (double)ncell_max ? (double)ncell_max : want);
+        if (d > 0) {
+            const double h = pow(vol / want, 1.0 / d);
+            for (int a = 0; a < 3; ++a)
+                if (e[a] > 0.0) { const double g = ceil(e[a] / h); G[a] = g < 1.0 ? 1 : (g > 1024.0 ? 1024 : (int)g); }
+            while ((long)G[0] * G[1] * G[2] > ncell_max) {      // (rounding up may overshoot: shrink the largest count)
+                int a = G[0] >= G[1] ? (G[0] >= G[2] ? 0 : 2) : (G[1] >= G[2] ? 1 : 2);
+                G[a] = G[a] > 1 ? G[a] - 1 : 1;
+            }
+        }
+        T* o = ginfo + (size_t)cloud * GRID_INFO;
+        for (int a = 0; a < 3; ++a) {
+            const double h = G[a] > 0 && e[a] > 0.0 ? e[a] / G[a] : 0.0;
+            o[a] = (T)lo[a];
+            o[3 + a] = (T)(h > 0.0 ? 1.0 / h : 0.0);
+            o[6 + a] = (T)h;
+            o[9 + a] = (T)G[a];
+            // a target's cell comes from floor((y - lo) * inv) in T arithmetic: its box is trusted up to this slack
+            o[13 + a] = (T)((sizeof(T) == 4 ? 2e-5 : 1e-12) * (fabs(lo[a]) + fabs(hi[a]) + e[a]));
+        }
+        o[12] = (T)((long)G[0] * G[1] * G[2]);
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ int grid_coord(T v, T lo, T inv, int G) {
+    const T f = (v - lo) * inv;
+    return (f > T(0)) ? (f < T(G) ? (int)f : G - 1) : 0;       // NaN and everything below lo -> 0, above hi -> G - 1
+}
+
+// Stable sort of a cloud's targets by cell id + the table of cell starts.  One block of 1024 threads per cloud, LSD radix,
+// two 8-bit digits.  A pass = digit histogram of all M slots, then the slots chunk by chunk (16384 at a time, in order): per
+// wave and round the ballot ranking of sort_keys_kernel, wave counts scanned per digit, scatter to base[digit] + offset.
+// BIG = false (M <= 16384): keys and indices live in LDS, one buffer, the chunk is in registers between its read and its
+// write.  BIG = true: global ping-pong buffers from the caller's scratch.
+template <typename T, bool BIG>
+__global__ __launch_bounds__(GS_THREADS) void grid_sort_kernel(const T* __restrict__ tgt, int c, int m, int m_pad, const int32_t* __restrict__ tgt_rows,
+                                                               const T* __restrict__ center, const T* __restrict__ ginfo, int cs_stride,
+                                                               int32_t* __restrict__ tperm, int32_t* __restrict__ cell_start,
+                                                               unsigned short* __restrict__ gkey /* BIG: (N,2,m_pad) */, int32_t* __restrict__ gidx /* BIG: (N,2,m_pad) */) {
+    constexpr int LN = BIG ? 1 : GS_CHUNK;
+    __shared__ unsigned short lkey[LN];
+    __shared__ unsigned short lidx[LN];
+    __shared__ int cnt[GS_THREADS / WAVE][256];
+    __shared__ int base[256], ctot[256];
+    const int cloud = blockIdx.x, tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
+    const int mc = tgt_rows ? min(max(tgt_rows[cloud], 0), m) : m;
+    const T* __restrict__ rows = tgt + (size_t)cloud * m * c;
+    const T* gi = ginfo + (size_t)cloud * GRID_INFO;
+    const T lo0 = gi[0], lo1 = gi[1], lo2 = gi[2], in0 = gi[3], in1 = gi[4], in2 = gi[5];
+    const int G0 = (int)gi[9], G1 = (int)gi[10], G2 = (int)gi[11], ncell = (int)gi[12];
+    T ctr[3] = {T(0), T(0), T(0)};
+    if (center) { ctr[0] = center[(size_t)cloud * 3]; ctr[1] = center[(size_t)cloud * 3 + 1]; ctr[2] = center[(size_t)cloud * 3 + 2]; }
+    unsigned short* kbuf[2];
+    int32_t* ibuf[2];
+    if (BIG) {
+        kbuf[0] = gkey + (size_t)cloud * 2 * m_pad; kbuf[1] = kbuf[0] + m_pad;
+        ibuf[0] = gidx + (size_t)cloud * 2 * m_pad; ibuf[1] = ibuf[0] + m_pad;
+    }
+    auto cell_of = [&](int j) -> unsigned {
+        if (j >= mc) return 0xffffu;                            // pad slots: after every real row
+        const T* y = rows + (size_t)j * c;
+        const int cx = grid_coord(y[0] - ctr[0], lo0, in0, G0), cy = grid_coord(y[1] - ctr[1], lo1, in1, G1), cz = grid_coord(y[2] - ctr[2], lo2, in2, G2);
+        return (unsigned)((cz * G1 + cy) * G0 + cx);
+    };
+    // pass-0 input: the computed ids in slot order
+    for (int j = tid; j < m_pad; j += GS_THREADS) {
+        const unsigned k = cell_of(j);
+        if (BIG) { kbuf[0][j] = (unsigned short)k; ibuf[0][j] = j; } else { lkey[j] = (unsigned short)k; lidx[j] = (unsigned short)j; }
+    }
+    __syncthreads();
+    for (int pass = 0; pass < 2; ++pass) {
+        const int shift = pass * 8;
+        const unsigned short* kin = BIG ? kbuf[pass & 1] : lkey;
+        unsigned short* kout = BIG ? kbuf[(pass & 1) ^ 1] : lkey;
+        const int32_t* iin_g = BIG ? ibuf[pass & 1] : nullptr;
+        int32_t* iout_g = BIG ? ibuf[(pass & 1) ^ 1] : nullptr;
+        if (tid < 256) base[tid] = 0;
+        __syncthreads();
+        for (int j = tid; j < m_pad; j += GS_THREADS) atomicAdd(&base[(kin[j] >> shift) & 0xff], 1);
+        __syncthreads();
+        if (tid < WAVE) {                                       // exclusive scan of the 256 digit totals (4 per lane)
+            int v[4], s = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[k] = base[lane * 4 + k]; s += v[k]; }
+            int inc = s;
+#pragma unroll
+            for (int off = 1; off < WAVE; off <<= 1) { const int o = __shfl_up(inc, off); if (lane >= off) inc += o; }
+            int run = inc - s;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { base[lane * 4 + k] = run; run += v[k]; }
+        }
+        __syncthreads();
+        for (int c0 = 0; c0 < m_pad; c0 += GS_CHUNK) {
+            unsigned key[GS_PER];
+            int idx[GS_PER], rank[GS_PER];
+            for (int d = lane; d < 256; d += WAVE) cnt[wave][d] = 0;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int e = 0; e < GS_PER; ++e) {                  // striped: position = c0 + wave * 1024 + e * 64 + lane
+                const int pos = c0 + wave * (WAVE * GS_PER) + e * WAVE + lane;
+                const bool on = pos < m_pad;
+                key[e] = on ? (unsigned)kin[pos] : 0u;
+                idx[e] = on ? (BIG ? iin_g[pos] : (int)lidx[pos]) : -1;
+                const unsigned d = on ? ((key[e] >> shift) & 0xffu) : 0x100u;       // 0x100: no slot here
+                unsigned long long same = __ballot(on);
+                if (!on) same = ~same;
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const unsigned long long bal = __ballot((d >> b) & 1u);
+                    same &= ((d >> b) & 1u) ? bal : ~bal;
+                }
+                const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(same >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)same, 0u));
+                const int bs = on ? cnt[wave][d & 0xff] : 0;    // every lane of a group reads before its first lane writes
+                __builtin_amdgcn_wave_barrier();
+                if (on && below == 0) cnt[wave][d] = bs + __popcll(same);
+                __builtin_amdgcn_wave_barrier();
+                rank[e] = bs + below;
+            }
+            __syncthreads();                                    // (all reads of this chunk are done: kout may alias kin)
+            if (tid < 256) {
+                int s = 0;
+                for (int w = 0; w < GS_THREADS / WAVE; ++w) { const int v = cnt[w][tid]; cnt[w][tid] = s; s += v; }
+                ctot[tid] = s;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < GS_PER; ++e) {
+                if (idx[e] < 0) continue;
+                const unsigned d = (key[e] >> shift) & 0xffu;
+                const int pos = base[d] + cnt[wave][d] + rank[e];
+                kout[pos] = (unsigned short)key[e];
+                if (BIG) iout_g[pos] = idx[e]; else lidx[pos] = (unsigned short)idx[e];
+            }
+            __syncthreads();
+            if (tid < 256) base[tid] += ctot[tid];
+            __syncthreads();
+        }
+    }
+    // two passes: the result is back in buffer 0
+    const unsigned short* ks = BIG ? kbuf[0] : lkey;
+    for (int s = tid; s < m_pad; s += GS_THREADS)           // slots past the cloud's real rows: m (no row)
+        tperm[(size_t)cloud * m_pad + s] = s < mc ? (BIG ? ibuf[0][s] : (int32_t)lidx[s]) : m;
+    int32_t* cs = cell_start + (size_t)cloud * cs_stride;
+    for (int s = tid; s <= m_pad; s += GS_THREADS) {            // cell_start[k] = first sorted slot whose id is >= k, for k = 0 .. ncell
+        const int cur = s < m_pad ? min((int)ks[s], ncell) : ncell;
+        const int prev = s > 0 ? min((int)ks[s - 1], ncell) : -1;
+        for (int k = prev + 1; k <= cur; ++k) cs[k] = s < mc ? s : mc;
+    }
+}
+
+// The search itself.  One query per lane, in the caller's order.  A lane's work is a chain of dependent memory round trips
+// (cell -> table -> rows -> bound -> next cell), and with 8 waves per SIMD in flight the kernel's time is simply
+// (waves / 8192) x (round trips per wave) x ~0.7 us -- so the kernel is organised to make few of them.  Per ring of cells:
+//   phase 1 (no memory): the (cz, cy) rows of the ring and their x runs whose boxes can still hold a nearer target are
+//            collected -- first cell, last cell + 1, the box's lower bound -- into a short per-lane list in LDS;
+//   phase 2: ALL table look-ups of the list in one round of loads, then the rows of each entry eight at a time.
+// The wave waits for memory once per list position and batch, not once per cell it ever enumerated (which lane passes where
+// differs from lane to lane).  Measured at the benchmark shape, near the pose (7 pairs per query): depth-first search (bound,
+// table, row, row, ..., next cell) 0.33 ms; lists + table in LDS, 2 waves per SIMD: 0.66 ms.
+constexpr int KG_THREADS = 256;
+#ifndef DICP_KG_RUNS
+#define DICP_KG_RUNS 6
+#endif
+#ifndef DICP_KG_ROWS
+#define DICP_KG_ROWS 8
+#endif
+#ifndef DICP_KG_MINW
+#define DICP_KG_MINW 1
+#endif
+constexpr int KG_RUNS = DICP_KG_RUNS;       // list entries per lane (a full list is worked off, then collection goes on)
+constexpr int KG_ROWS = DICP_KG_ROWS;       // rows in flight per lane
+
+template <typename T>
+__global__ __launch_bounds__(KG_THREADS, DICP_KG_MINW) void knn_grid_kernel(const T* __restrict__ src, const T* __restrict__ pose,
+                                                         const typename V4<T>::type* __restrict__ tgs4, const int32_t* __restrict__ tperm,
+                                                         const int32_t* __restrict__ cell_start, int cs_stride, const T* __restrict__ ginfo,
+                                                         const int32_t* __restrict__ src_rows, int32_t* __restrict__ idx, int32_t* __restrict__ spos,
+                                                         unsigned long long* __restrict__ pairs, int N, int n, int m, int m_pad, int bpc) {
+    using T4 = typename V4<T>::type;
+    __shared__ int run_a[KG_RUNS][KG_THREADS], run_b[KG_RUNS][KG_THREADS];
+    __shared__ float run_lb[KG_RUNS][KG_THREADS];
+    int cloud, blk;
+    if (!decode_block(bpc, N, cloud, blk)) return;
+    const int tid = threadIdx.x;
+    const int i = blk * KG_THREADS + tid;
+    const int nc = src_rows ? min(max(src_rows[cloud], 0), n) : n;
+    const bool live = i < nc;
+    const T* gi = ginfo + (size_t)cloud * GRID_INFO;
+    const T lo[3] = {gi[0], gi[1], gi[2]}, inv[3] = {gi[3], gi[4], gi[5]}, h[3] = {gi[6], gi[7], gi[8]};
+    const int G[3] = {(int)gi[9], (int)gi[10], (int)gi[11]};
+    const T slack[3] = {gi[13], gi[14], gi[15]};
+    const int32_t* __restrict__ cs = cell_start + (size_t)cloud * cs_stride;
+    T C[9], r[3];
+    load_pose(pose, cloud, C, r);
+    T p[3] = {T(0), T(0), T(0)};
+    if (live) { const T* sp = src + ((size_t)cloud * n + i) * 3; p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2]; }
+    T nx[3];
+    query_point(C, r, p, nx);                               // ICP.py:137
+    const T x[3] = {-nx[0], -nx[1], -nx[2]};
+    const T hx = T(0.5) * (x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    int cq[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) cq[a] = grid_coord(x[a], lo[a], inv[a], G[a]);
+    const T4* __restrict__ tg = tgs4 + (size_t)cloud * m_pad;
+    const int32_t* __restrict__ pm = tperm + (size_t)cloud * m_pad;
+    T best = inf_v<T>(), thr = inf_v<T>();                  // thr: half squared distance beyond which nothing can beat `best`
+    int bs = -1, bo = -1, scored = 0;
+    // outer faces of cell k along axis a, unbounded at the border of the grid, widened by the assignment slack
+    auto face_lo = [&](int a, int k) { return k <= 0 ? -inf_v<T>() : fma_t(T(k), h[a], lo[a]) - slack[a]; };
+    auto face_hi = [&](int a, int k) { return k >= G[a] - 1 ? inf_v<T>() : fma_t(T(k + 1), h[a], lo[a]) + slack[a]; };
+    auto gap = [&](int a, int k0, int k1) {                 // distance along axis a from the query to the cells k0..k1
+        const T d0 = face_lo(a, k0) - x[a], d1 = x[a] - face_hi(a, k1);
+        const T d = d0 > d1 ? d0 : d1;
+        return d > T(0) ? d : T(0);
+    };
+    int nrun = 0;
+    auto work_off = [&]() {                                 // phase 2 for this lane's list
+        {   // every table look-up of the list in ONE round of loads
+            int a[KG_RUNS], b[KG_RUNS];
+#pragma unroll
+            for (int j = 0; j < KG_RUNS; ++j) {
+                const bool on = j < nrun;
+                a[j] = cs[on ? run_a[j][tid] : 0];
+                b[j] = cs[on ? run_b[j][tid] : 0];
+            }
+#pragma unroll
+            for (int j = 0; j < KG_RUNS; ++j) { run_a[j][tid] = a[j]; run_b[j][tid] = b[j]; }
+        }
+        for (int j = 0; j < nrun; ++j) {
+            if ((T)run_lb[j][tid] > thr) continue;          // (the best match has moved since the entry was made)
+            const int s1 = run_b[j][tid];
+            for (int s = run_a[j][tid]; s < s1; s += KG_ROWS) {
+                T4 y[KG_ROWS];
+#pragma unroll
+                for (int k = 0; k < KG_ROWS; ++k) y[k] = tg[min(s + k, s1 - 1)];
+#pragma unroll
+                for (int k = 0; k < KG_ROWS; ++k) {
+                    const T sc = (s + k < s1) ? score<T, T4>(nx, y[k]) : inf_v<T>();
+                    if (sc < best) {
+                        best = sc; bs = s + k; bo = -1;
+                    } else if (sc == best && sc < inf_v<T>()) {      // exact tie: the lowest ORIGINAL index wins
+                        if (bo < 0) bo = pm[bs];
+                        const int o = pm[s + k];
+                        if (o < bo) { bo = o; bs = s + k; }
+                    }
+                }
+                scored += min(KG_ROWS, s1 - s);
+                thr = (best + hx) + SweepEps<T>::v * (T(1) + m_abs(best) + hx);
+            }
+        }
+        nrun = 0;
+    };
+    const int rmax = max(max(G[0], G[1]), G[2]);
+    for (int ring = 0; live && ring <= rmax; ++ring) {
+        const int z0 = max(cq[2] - ring, 0), z1 = min(cq[2] + ring, G[2] - 1);
+        for (int cz = z0; cz <= z1; ++cz) {
+            const T ez = gap(2, cz, cz);
+            const T hz = T(0.5) * ez * ez;
+            if (hz > thr) continue;
+            const bool zedge = cz == cq[2] - ring || cz == cq[2] + ring;
+            const int y0 = max(cq[1] - ring, 0), y1 = min(cq[1] + ring, G[1] - 1);
+            for (int cy = y0; cy <= y1; ++cy) {
+                const T ey = gap(1, cy, cy);
+                const T hy = fma_t(T(0.5) * ey, ey, hz);
+                if (hy > thr) continue;
+                const bool edge = zedge || cy == cq[1] - ring || cy == cq[1] + ring;
+                const int row = (cz * G[1] + cy) * G[0];
+                // on the shell's faces the whole x run of the ring, inside it only the two end cells
+                for (int part = 0; part < (edge ? 1 : 2); ++part) {
+                    int xa, xb;
+                    if (edge) { xa = max(cq[0] - ring, 0); xb = min(cq[0] + ring, G[0] - 1); }
+                    else { xa = xb = part == 0 ? cq[0] - ring : cq[0] + ring; if (xa < 0 || xa > G[0] - 1) continue; }
+                    const T ex = gap(0, xa, xb);
+                    const T lb = fma_t(T(0.5) * ex, ex, hy);
+                    if (lb > thr) continue;
+                    if (nrun == KG_RUNS) work_off();
+                    run_a[nrun][tid] = row + xa; run_b[nrun][tid] = row + xb + 1;
+                    run_lb[nrun][tid] = (float)lb * 0.999999f;      // (rounded down: the re-check must never be stricter)
+                    ++nrun;
+                }
+            }
+        }
+        work_off();
+        // everything inside the block of cells within `ring` of the query's has been scored or ruled out: done when the
+        // block covers the grid, or when its nearest outer face is further than the best match
+        bool covered = true;
+        T dout = inf_v<T>();
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            if (cq[a] - ring > 0) { covered = false; const T d = x[a] - fma_t(T(cq[a] - ring), h[a], lo[a]) - slack[a]; dout = d < dout ? d : dout; }
+            if (cq[a] + ring < G[a] - 1) { covered = false; const T d = fma_t(T(cq[a] + ring + 1), h[a], lo[a]) - x[a] - slack[a]; dout = d < dout ? d : dout; }
+        }
+        if (covered) break;
+        dout = dout > T(0) ? dout : T(0);
+        if (T(0.5) * dout * dout > thr) break;
+    }
+    if (live) {
+        if (bs >= 0 && bo < 0) bo = pm[bs];
+        const bool none = bs < 0 || bo < 0 || bo >= m;
+        idx[(size_t)cloud * n + i] = none ? 0 : bo;
+        if (spos) spos[(size_t)cloud * n + i] = none ? -1 : bs;
+    }
+    if (pairs) {
+#pragma unroll
+        for (int off = WAVE / 2; off > 0; off >>= 1) scored += __shfl_xor(scored, off);
+        if ((tid & (WAVE - 1)) == 0 && scored) atomicAdd(pairs + (blockIdx.x & (DICP_PAIR_SHARDS - 1)), (unsigned long long)scored);
+    }
+}
+
 // ------------------------------------------------------------- gather / scatter
 // Row-indexed copies.  One thread per ELEMENT (consecutive lanes walk a row, so reads of a row and writes of the
 // output are as coalesced as the data allows); all blocks of a cloud run on ONE XCD (decode_block): the rows they
@@ -2482,6 +2874,59 @@ int dicp_knn_sweep(int dtype, const void* src, const void* pose, const void* tgs
     if ((uintptr_t)tgs4 % (dtype == DICP_F32 ? 16 : 32)) return DICP_ERR_ALIGN;
     begin_launch();
     return sweep_launch(dtype, src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, N, n, m, m_pad, idx, spos, pairs, cfg, (hipStream_t)stream);
+}
+
+int dicp_grid_cells_max(int m) { return grid_cells_max(m); }
+
+size_t dicp_grid_scratch_bytes(int N, int m_pad) {
+    if (N <= 0 || m_pad <= GS_CHUNK) return 0;                 // up to 16384 slots the sort runs in LDS
+    return (size_t)N * 2 * m_pad * (sizeof(unsigned short) + sizeof(int32_t)) + 256;
+}
+
+int dicp_grid_build(int dtype, const void* tgt, int c, const void* center, const int32_t* tgt_rows, int N, int m, int m_pad, int ncell_max,
+                    void* ginfo, int32_t* tperm, int32_t* cell_start, void* tgs4, void* tgt_s, void* scratch, size_t scratch_bytes, void* stream) {
+    if (!tgt || !ginfo || !tperm || !cell_start || !tgs4) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0 || m <= 0 || (c != 3 && c != 6) || m_pad != dicp_padded_targets(m) || ncell_max < 1 || ncell_max > GRID_MAX_CELLS) return DICP_ERR_SHAPE;
+    if ((uintptr_t)tgs4 % (dtype == DICP_F32 ? 16 : 32)) return DICP_ERR_ALIGN;
+    const bool big = m_pad > GS_CHUNK;
+    if (big && (!scratch || scratch_bytes < dicp_grid_scratch_bytes(N, m_pad))) return DICP_ERR_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    begin_launch();
+    unsigned short* gkey = nullptr;
+    int32_t* gidx = nullptr;
+    if (big) {                                                  // indices first (4-byte aligned), then the 2-byte keys
+        gidx = (int32_t*)(((uintptr_t)scratch + 15) & ~(uintptr_t)15);
+        gkey = (unsigned short*)(gidx + (size_t)N * 2 * m_pad);
+    }
+    const int bpc = (m_pad + BLOCK * 4 - 1) / (BLOCK * 4);
+#define DICP_GRID(T) do { \
+        grid_info_kernel<T><<<N, GS_THREADS, 0, st>>>((const T*)tgt, c, m, tgt_rows, (const T*)center, ncell_max, (T*)ginfo); \
+        if (big) grid_sort_kernel<T, true><<<N, GS_THREADS, 0, st>>>((const T*)tgt, c, m, m_pad, tgt_rows, (const T*)center, (const T*)ginfo, ncell_max + 1, tperm, cell_start, gkey, gidx); \
+        else     grid_sort_kernel<T, false><<<N, GS_THREADS, 0, st>>>((const T*)tgt, c, m, m_pad, tgt_rows, (const T*)center, (const T*)ginfo, ncell_max + 1, tperm, cell_start, nullptr, nullptr); \
+        sweep_rows_kernel<T><<<grid_for(N, bpc), BLOCK, 0, st>>>((const T*)tgt, nullptr, N, m, c, m_pad, bpc, (typename V4<T>::type*)tgs4, tperm, (T*)tgt_s, (const T*)center); } while (0)
+    if (dtype == DICP_F32) DICP_GRID(float); else DICP_GRID(double);
+#undef DICP_GRID
+    return launch_status();
+}
+
+int dicp_knn_grid(int dtype, const void* src, const void* pose, const void* tgs4, const int32_t* tperm, const int32_t* cell_start, int ncell_max,
+                  const void* ginfo, const int32_t* src_rows, int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos,
+                  unsigned long long* pairs, void* stream) {
+    if (!src || !tgs4 || !tperm || !cell_start || !ginfo || !idx) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0 || n <= 0 || m <= 0 || m_pad != dicp_padded_targets(m) || ncell_max < 1 || ncell_max > GRID_MAX_CELLS) return DICP_ERR_SHAPE;
+    if ((uintptr_t)tgs4 % (dtype == DICP_F32 ? 16 : 32)) return DICP_ERR_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    begin_launch();
+    hipEvent_t ev0, ev1;
+    take_launch_events(ev0, ev1);                                       // (null unless a timed loop set them for this launch)
+    const int bpc = (n + KG_THREADS - 1) / KG_THREADS;
+#define DICP_KG(T) hipExtLaunchKernelGGL((knn_grid_kernel<T>), dim3(grid_for(N, bpc)), dim3(KG_THREADS), 0, st, ev0, ev1, 0, (const T*)src, (const T*)pose, \
+        (const typename V4<T>::type*)tgs4, tperm, cell_start, ncell_max + 1, (const T*)ginfo, src_rows, idx, spos, pairs, N, n, m, m_pad, bpc)
+    if (dtype == DICP_F32) DICP_KG(float); else DICP_KG(double);
+#undef DICP_KG
+    return launch_status();
 }
 
 int dicp_gather_rows(int dtype, const void* tgt, const int32_t* idx, int N, int n, int m, int c, void* out, void* stream) {

@@ -18,6 +18,7 @@
  */
 #ifndef DICP_HIP_H
 #define DICP_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -29,7 +30,7 @@ extern "C" {
 enum { DICP_F32 = 0, DICP_F64 = 1 };
 enum { DICP_PT2PT = 0, DICP_PT2PL = 1 };                 /* ICP(icp_type=...)  ICP.py:15,101-105 */
 enum { DICP_LOSS_NONE = 0, DICP_LOSS_HUBER = 1, DICP_LOSS_CAUCHY = 2, DICP_LOSS_TRIM = 3 };
-enum { DICP_KNN_AUTO = 0, DICP_KNN_VALU = 1, DICP_KNN_MFMA = 2, DICP_KNN_SWEEP = 3 /* via dicp_knn_sweep */ };
+enum { DICP_KNN_AUTO = 0, DICP_KNN_VALU = 1, DICP_KNN_MFMA = 2, DICP_KNN_SWEEP = 3 /* via dicp_knn_sweep */, DICP_KNN_GRID = 4 /* via dicp_knn_grid */ };
 enum { DICP_ERR_NULL = 1, DICP_ERR_SHAPE = 2, DICP_ERR_DTYPE = 3, DICP_ERR_ENUM = 4, DICP_ERR_ALIGN = 5 };
 
 /* Accumulator layout of one (cloud, block) partial: see dicp_amd/csrc/dicp_math.h */
@@ -138,6 +139,31 @@ int dicp_query_order(int dtype, const void* src, const void* pose, const void* b
 int dicp_knn_sweep(int dtype, const void* src, const void* pose, const void* tgs4, const int32_t* tperm,
                    const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt,
                    int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg, void* stream);
+
+/* Exact 1-NN over a uniform 3-D grid of cells: same result (and lowest-index tie rule) as dicp_knn, pruning on all three
+ * coordinates (nn.py:32-35 without the (N,n,m) matrix, and without scoring more than the few cells around a query).
+ * dicp_grid_build, ONCE per ICP call (targets do not move between iterations), from tgt (N,m,c) [and center (N,3): the grid
+ * and the packed rows are then in coordinates y - center, as for the *_centered entry points]:
+ *   ginfo (N,DICP_GRID_INFO) T   grid geometry per cloud: origin lo[3], cells per unit inv[3], cell size h[3], counts G[3] (as T),
+ *                                cell count, box slack[3]; from the 1/64 .. 63/64 sample quantiles of the coordinates, about 4
+ *                                targets per cell, at most ncell_max = dicp_grid_cells_max(m) cells;
+ *   tperm (N,m_pad)              original row of each sorted slot: STABLE order of the cell id (z, y, x: x fastest), m for slots
+ *                                past the cloud's rows;  cell_start (N,ncell_max+1): first sorted slot of every cell, then the end;
+ *   tgs4 (N,m_pad,4)             packed rows [x,y,z,0.5|y|^2] in that order (pads [max,0,0,+inf]);  tgt_s (N,m_pad,c), optional: the
+ *                                full rows in that order (what dicp_accumulate_bwd_window reads);
+ *   tgt_rows (N), optional       leading rows of each cloud that take part (ragged batches: ICP.py:460-477 pads the rest);
+ *   scratch                      dicp_grid_scratch_bytes(N, m_pad) bytes (0 up to 16384 slots: the sort then runs in LDS).
+ * dicp_knn_grid, per iteration: idx (N,n) original row of the nearest target, spos (N,n) optional: its sorted slot (-1: none),
+ *   queries in the caller's order (src_rows (N), optional: leading rows of each cloud that take part; the rest is not written);
+ *   pairs: optional DICP_PAIR_SHARDS counters, += pairs scored. */
+#define DICP_GRID_INFO 16
+int dicp_grid_cells_max(int m);
+size_t dicp_grid_scratch_bytes(int N, int m_pad);
+int dicp_grid_build(int dtype, const void* tgt, int c, const void* center, const int32_t* tgt_rows, int N, int m, int m_pad, int ncell_max,
+                    void* ginfo, int32_t* tperm, int32_t* cell_start, void* tgs4, void* tgt_s, void* scratch, size_t scratch_bytes, void* stream);
+int dicp_knn_grid(int dtype, const void* src, const void* pose, const void* tgs4, const int32_t* tperm, const int32_t* cell_start, int ncell_max,
+                  const void* ginfo, const int32_t* src_rows, int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos,
+                  unsigned long long* pairs, void* stream);
 
 /* Gather whole target rows at idx (nn.py:37-38 / 89-90) and its backward, a scatter-add
  * into a zero-initialised (N,m,c) buffer (autograd's gather backward). */

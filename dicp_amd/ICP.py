@@ -70,7 +70,7 @@ class ICP:
                  "weights" (N,K,n*r,1), "stats": {"converged","iterations","matched_ratio"}}
         """
         assert dim == 2 or dim == 3, "dim must be 2 or 3"                                # ICP.py:79
-        source, target, T_init, w_pts = self._batch(source, target, T_init, weight)      # ICP.py:85
+        source, target, T_init, w_pts, rows = self._batch(source, target, T_init, weight)   # ICP.py:85
         assert source.dtype == target.dtype == T_init.dtype                              # ICP.py:96
         if self.icp_type == 'pt2pl':
             assert target.shape[2] == 6                                                  # ICP.py:103
@@ -81,6 +81,7 @@ class ICP:
         home = source.device
         dev = home if source.is_cuda else compute_device()
         source, target, T_init, w_pts = (t.to(dev) for t in (source, target, T_init, w_pts))
+        src_rows, tgt_rows = self._device_rows(rows, dev)
 
         if dim == 2:                                                                     # ICP.py:107-116
             keep_s = torch.tensor([1.0, 1.0, 0.0], dtype=source.dtype, device=dev)
@@ -95,7 +96,7 @@ class ICP:
             target = target.contiguous()
             wants_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (source, target, T_init, w_pts))
             source = source.contiguous()
-            prebuilt = prebuild_search(source, target, self.knn_variant, wants_grad and bool(self.bwd_window), T_init)
+            prebuilt = prebuild_search(source, target, self.knn_variant, wants_grad and bool(self.bwd_window), T_init, src_rows, tgt_rows)
         cfg = LoopConfig(
             icp_type=self.icp_type, differentiable=bool(self.diff), max_iterations=int(self.max_iterations),
             tolerance=float(self.tolerance), trim_dist=trim_dist, loss_name=loss_name,
@@ -104,7 +105,8 @@ class ICP:
             tanh_steepness=float(self.config['dICP']['parameters']['tanh_steepness']),   # ICP.py:119
             match_ratio_thresh=float(self.match_ratio_thresh),
             knn_variant=self.knn_variant, bwd_window=bool(self.bwd_window), stats_out=self.knn_stats,
-            sync_every=self.sync_every, timing_events=self._timing_events, prebuilt=prebuilt, small_loop=bool(self.small_loop))
+            sync_every=self.sync_every, timing_events=self._timing_events, prebuilt=prebuilt, small_loop=bool(self.small_loop),
+            src_rows=src_rows, tgt_rows=tgt_rows)
         if self.nn.differentiable and self.nn.use_gumbel:                                # nn.py:14-16 via ICP.py:140
             # soft correspondences carry gradient themselves: one autograd node per iteration instead of one per call
             T, deltas, weights, costs, converged, iterations, matched = icp_loop_gumbel(
@@ -150,16 +152,17 @@ class ICP:
         weights.  Stops when sum |T p - nn|^2 < tolerance (ICP.py:585).
         """
         single = not isinstance(source, list) and source is not None and source.dim() == 2
-        s_b, t_b, T_b, w_pts = self._batch(source, target, T_init, weight)
+        s_b, t_b, T_b, w_pts, rows = self._batch(source, target, T_init, weight)
         t_b = t_b[:, :, :3]                                                              # ICP.py:548
         assert s_b.dtype == t_b.dtype == T_b.dtype
         home = s_b.device
         dev = home if s_b.is_cuda else compute_device()
         s_b, t_b, T_b, w_pts = (t.to(dev) for t in (s_b, t_b, T_b, w_pts))
+        src_rows, tgt_rows = self._device_rows(rows, dev)
         seed = bool(getattr(self, "svd_seed_T_init", False))
         T_start = T_b if seed else torch.eye(4, dtype=T_b.dtype, device=dev).expand(T_b.shape[0], 4, 4).contiguous()
         T_found, costs, iterations = KabschLoop.apply(s_b, t_b, T_start, w_pts, int(self.max_iterations), float(self.tolerance),
-                                                      trim_dist, bool(self.const_iter), self.knn_variant)
+                                                      trim_dist, bool(self.const_iter), self.knn_variant, src_rows, tgt_rows)
         if self.verbose:                                                                 # ICP.py:588-589
             print("ICP converged in {} iterations".format(int(iterations.max().item()) - 1))
         pc = transform_points(s_b, T_found)                                              # ICP.py:581
@@ -174,10 +177,27 @@ class ICP:
         """Normalise the accepted input forms to batched tensors (ICP.py:305-511):
         source (N,n_max,3) zero-padded, target (N,m_max,c) padded with max(source)*target_pad_val,
         T_init (N,4,4) or None, weights (N,n_max) -- repeated x3 along dim 1 for pt2pt (ICP.py:508-509)."""
-        s, t, T, w = self._batch(source, target, T_init, weight)
+        s, t, T, w, _ = self._batch(source, target, T_init, weight)
         if self.icp_type == 'pt2pt':
             w = w.repeat_interleave(3, dim=1)
         return s, t, T, w
+
+    @staticmethod
+    def _device_rows(rows, dev):
+        """Per-cloud row counts of a ragged batch as (N) int32 device tensors for the kernels (None: dense batch).
+        Source: the cloud's own length -- the rows behind it are the zero-weight pads of ICP.py:386-398, which contribute exactly
+        nothing.  Target: own length + 1 where pad rows follow: they are copies of ONE far point (ICP.py:460,472-477), and
+        one copy takes part exactly as all of them would (first of equals, like argmin)."""
+        if rows is None:
+            return None, None
+        src_len, tgt_len, n_max, m_max = rows
+        out = []
+        for lens, full, extra in ((src_len, n_max, 0), (tgt_len, m_max, 1)):
+            if lens is None or all(v == full for v in lens):
+                out.append(None)
+            else:
+                out.append(torch.tensor([min(v + extra, full) for v in lens], dtype=torch.int32).to(dev))
+        return out[0], out[1]
 
     @staticmethod
     def _tensor_weight(w, source_b):
@@ -193,7 +213,9 @@ class ICP:
         return w if w.dtype == source_b.dtype else w.to(source_b.dtype)
 
     def _batch(self, source, target, T_init, weight):
-        """As batch_size_handling, with ONE weight per point (what the kernels consume)."""
+        """As batch_size_handling, with ONE weight per point (what the kernels consume), and the clouds' own lengths:
+        -> (source_b, target_b, T_b, w, rows); rows = None, or (source lengths | None, target lengths | None, n_max, m_max)
+        when a list was padded."""
         if weight is not None:                                                           # ICP.py:321-326
             if isinstance(source, list):
                 assert len(source) == len(weight), "weight must be list of same length as source"
@@ -204,7 +226,7 @@ class ICP:
         if source is None or target is None or len(source) == 0 or len(target) == 0:
             f32 = dict(dtype=torch.float32, device="cpu")
             return (torch.zeros((1, 1, 3), **f32), torch.zeros((1, 1, 6), **f32),
-                    torch.eye(4, **f32).unsqueeze(0), torch.zeros((1, 1), **f32))
+                    torch.eye(4, **f32).unsqueeze(0), torch.zeros((1, 1), **f32), None)
 
         # dtype / device / column count come from the first non-empty target (ICP.py:347-358)
         dt, dev, cols = torch.float32, "cpu", None
@@ -220,6 +242,7 @@ class ICP:
                     break
         opts = dict(dtype=dt, device=dev)
 
+        src_len = tgt_len = None
         # ---- source and per-point prior weights (ICP.py:360-446)
         if isinstance(source, list):
             pts, pri = [], []
@@ -239,6 +262,7 @@ class ICP:
             # one padded copy for the whole list (the reference grows the batch item by item: O(N^2) copies)
             source_b = torch.nn.utils.rnn.pad_sequence(pts, batch_first=True).to(**opts)
             w = torch.nn.utils.rnn.pad_sequence(pri, batch_first=True).to(**opts)
+            src_len = [int(p_i.shape[0]) for p_i in pts]
         elif source.dim() == 2 and source.shape[1] in (3, 6):
             source_b = source[:, :3].unsqueeze(0)
             w = torch.ones((1, source_b.shape[1]), **opts) if weight is None else self._tensor_weight(weight.unsqueeze(0), source_b)
@@ -263,7 +287,8 @@ class ICP:
                 if i > 0 and (t_i.dim() != 2 or t_i.shape[1] != cols):
                     raise ValueError("target list must contain (m x 3/6) tensors. All tensors must have same number of columns")
                 rows.append(t_i)
-            lens = torch.tensor([r_i.shape[0] for r_i in rows], device=dev)
+            tgt_len = [int(r_i.shape[0]) for r_i in rows]
+            lens = torch.tensor(tgt_len, device=dev)
             target_b = torch.nn.utils.rnn.pad_sequence(rows, batch_first=True).to(**opts)
             real = (torch.arange(target_b.shape[1], device=dev)[None, :] < lens[:, None]).unsqueeze(-1)
             target_b = torch.where(real, target_b, pad * torch.ones((), **opts))
@@ -289,4 +314,5 @@ class ICP:
             T_b = T_init
         else:
             raise ValueError("T_init must be (4 x 4) or (N x 4 x 4) or list len(N) (4 x 4)")
-        return source_b, target_b, T_b, w
+        ragged = (src_len, tgt_len, int(source_b.shape[1]), int(target_b.shape[1])) if (src_len is not None or tgt_len is not None) else None
+        return source_b, target_b, T_b, w, ragged

@@ -17,8 +17,7 @@ HEADERS = [os.path.join(_HERE, "csrc", "dicp_math.h"), os.path.join(_ROOT, "incl
 F32, F64 = 0, 1
 PT2PT, PT2PL = 0, 1
 LOSS_NONE, LOSS_HUBER, LOSS_CAUCHY, LOSS_TRIM = 0, 1, 2, 3
-KNN_AUTO, KNN_VALU, KNN_MFMA, KNN_SWEEP, KNN_GRID = 0, 1, 2, 3, 4
-GRID_INFO = 16
+KNN_AUTO, KNN_VALU, KNN_MFMA, KNN_SWEEP = 0, 1, 2, 3
 NACC_PAD, NBWD_PAD, KAB_SAVE = 32, 16, 40
 PAIR_SHARDS, SWEEP_SRC_SORTED = 64, 0x100      # DICP_PAIR_SHARDS, DICP_SWEEP_SRC_SORTED
 ABI_VERSION = 3
@@ -50,54 +49,48 @@ class LoopBuffers(ctypes.Structure):
                 ("tgt4", vp), ("tperm", vp), ("qorder", vp), ("bucket", vp), ("brange", vp), ("nbkt", i32), ("idx_per_iter", i32),
                 ("pairs", vp), ("spos", vp), ("src_s", vp), ("spos_ref", vp), ("gts_far", vp), ("poses", vp), ("deltas", vp), ("costs", vp), ("areg", vp), ("alive", vp), ("converged", vp),
                 ("iterations", vp), ("matched_ratio", vp), ("n_start", vp), ("n_matched", vp), ("idx", vp), ("w", vp), ("w_iter", i64), ("w_stride", i64), ("w_prev0", vp),
-                ("partials", vp), ("counters", vp), ("events", vp), ("bwd_overwrite", i32), ("center", vp), ("poses_search", vp)]
+                ("partials", vp), ("counters", vp), ("events", vp), ("bwd_overwrite", i32), ("center", vp), ("poses_search", vp),
+                ("src_rows", vp), ("tgt_rows", vp)]
 
 
 _SIGNATURES = {
     "dicp_abi_version": ([], ctypes.c_int),
     "dicp_padded_targets": ([i32], ctypes.c_int),
     "dicp_accumulate_blocks": ([i32], ctypes.c_int),
-    "dicp_pack_target": ([i32, vp, i32, i32, i32, vp, i32, vp], ctypes.c_int),
-    "dicp_cloud_center": ([i32, vp, i32, i32, i32, f64, vp, vp], ctypes.c_int),
-    "dicp_pack_target_centered": ([i32, vp, i32, i32, i32, vp, vp, i32, vp], ctypes.c_int),
-    "dicp_knn": ([i32, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp], ctypes.c_int),
-    "dicp_knn_sweep": ([i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp], ctypes.c_int),
-    "dicp_grid_cells_max": ([i32], ctypes.c_int),
-    "dicp_grid_scratch_bytes": ([i32, i32], ctypes.c_size_t),
-    "dicp_grid_build": ([i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp], ctypes.c_int),
-    "dicp_knn_grid": ([i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp], ctypes.c_int),
+    "dicp_pack_target": ([i32, vp, i32, vp, vp, i32, i32, vp, i32, vp], ctypes.c_int),
+    "dicp_cloud_center": ([i32, vp, i32, vp, i32, i32, f64, vp, vp], ctypes.c_int),
+    "dicp_knn": ([i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp], ctypes.c_int),
+    "dicp_knn_sweep": ([i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp], ctypes.c_int),
     "dicp_window_blocks": ([i32, i32, i32], ctypes.c_int),
     "dicp_window_rows": ([i32], ctypes.c_int),
-    "dicp_sweep_sort": ([i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp], ctypes.c_int),
-    "dicp_sweep_build": ([i32, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp], ctypes.c_int),
-    "dicp_sweep_sort_centered": ([i32, vp, i32, vp, i32, i32, i32, vp, vp, i32, vp, vp, vp], ctypes.c_int),
-    "dicp_sweep_build_centered": ([i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp], ctypes.c_int),
-    "dicp_query_order": ([i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, vp], ctypes.c_int),
+    "dicp_sweep_sort_scratch_bytes": ([i32, i32, i32], ctypes.c_size_t),
+    "dicp_sweep_sort": ([i32, vp, i32, vp, vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, ctypes.c_size_t, vp], ctypes.c_int),
+    "dicp_sweep_build": ([i32, vp, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp], ctypes.c_int),
+    "dicp_query_order": ([i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, vp], ctypes.c_int),
     "dicp_query_keys": ([i32, vp, vp, i32, i32, vp, vp], ctypes.c_int),
-    "dicp_loop_init": ([i32, vp, vp, ctypes.c_double, i32, i32, i32, vp, vp, vp, vp], ctypes.c_int),
-    "dicp_loop_init_centered": ([i32, vp, vp, ctypes.c_double, i32, i32, i32, vp, vp, vp, vp, vp, vp], ctypes.c_int),
+    "dicp_loop_init": ([i32, vp, vp, ctypes.c_double, i32, i32, i32, vp, vp, vp, vp, vp, vp], ctypes.c_int),
     "dicp_search_pose": ([i32, vp, vp, i32, vp, vp], ctypes.c_int),
     "dicp_loop_finish": ([i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp], ctypes.c_int),
-    "dicp_accumulate_bwd_window": ([i32, ctypes.POINTER(WeightParams), vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp], ctypes.c_int),
-    "dicp_window_reduce": ([i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, i32, vp], ctypes.c_int),
+    "dicp_accumulate_bwd_window": ([i32, ctypes.POINTER(WeightParams), vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp], ctypes.c_int),
+    "dicp_window_reduce": ([i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, i32, vp], ctypes.c_int),
     "dicp_permute_add_rows": ([i32, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp], ctypes.c_int),
     "dicp_pose_grad_in": ([i32, vp, vp, i32, vp], ctypes.c_int),
     "dicp_pose_grad_out": ([i32, vp, vp, i32, vp, i32, vp], ctypes.c_int),
     "dicp_permute_rows": ([i32, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp], ctypes.c_int),
     "dicp_gather_rows": ([i32, vp, vp, i32, i32, i32, i32, vp, vp], ctypes.c_int),
     "dicp_scatter_add_rows": ([i32, vp, vp, i32, i32, i32, i32, vp, vp], ctypes.c_int),
-    "dicp_accumulate": ([i32, ctypes.POINTER(WeightParams), vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp, i64, vp], ctypes.c_int),
+    "dicp_accumulate": ([i32, ctypes.POINTER(WeightParams), vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, i64, vp], ctypes.c_int),
     "dicp_step": ([i32, ctypes.POINTER(StepIO), i32, vp], ctypes.c_int),
     "dicp_icp_forward": ([i32, ctypes.POINTER(WeightParams), ctypes.POINTER(LoopBuffers), i32, i32, i32, i32, i32, f64, i32, i32, vp], ctypes.c_int),
     "dicp_icp_backward": ([i32, ctypes.POINTER(WeightParams), ctypes.POINTER(LoopBuffers), i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp], ctypes.c_int),
     "dicp_step_bwd": ([i32, vp, vp, i32, i32, vp, vp, i64, vp, vp, vp, vp, i32, vp], ctypes.c_int),
-    "dicp_accumulate_bwd": ([i32, ctypes.POINTER(WeightParams), vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp], ctypes.c_int),
+    "dicp_accumulate_bwd": ([i32, ctypes.POINTER(WeightParams), vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp], ctypes.c_int),
     "dicp_gumbel_nn": ([i32, vp, vp, i32, vp, ctypes.c_uint32, f64, f64, i32, i32, i32, vp, vp, vp], ctypes.c_int),
     "dicp_gumbel_nn_bwd": ([i32, vp, vp, i32, vp, ctypes.c_uint32, f64, f64, vp, vp, vp, i32, i32, i32, vp, vp, vp], ctypes.c_int),
-    "dicp_kabsch_accumulate": ([i32, vp, vp, i32, vp, vp, vp, i32, f64, i32, i32, i32, vp, vp], ctypes.c_int),
+    "dicp_kabsch_accumulate": ([i32, vp, vp, i32, vp, vp, vp, i32, f64, vp, i32, i32, i32, vp, vp], ctypes.c_int),
     "dicp_kabsch_step": ([i32, vp, i32, vp, vp, vp, i32, vp], ctypes.c_int),
     "dicp_kabsch_step_bwd": ([i32, vp, vp, vp, i32, vp], ctypes.c_int),
-    "dicp_kabsch_bwd": ([i32, vp, vp, i32, vp, vp, vp, i32, f64, vp, i32, i32, i32, vp, vp, vp, vp], ctypes.c_int),
+    "dicp_kabsch_bwd": ([i32, vp, vp, i32, vp, vp, vp, i32, f64, vp, vp, i32, i32, i32, vp, vp, vp, vp], ctypes.c_int),
     "dicp_transform_points": ([i32, vp, vp, vp, i32, i32, vp], ctypes.c_int),
     "dicp_transform_points_bwd": ([i32, vp, vp, vp, vp, vp, i32, i32, vp], ctypes.c_int),
     "dicp_loss_weight": ([i32, i32, i32, f64, f64, vp, i64, i32, vp, vp], ctypes.c_int),

@@ -60,14 +60,15 @@ def accumulate_blocks(n):
 CENTER_QUANTUM = 16.0    # metres; clouds whose median point is within half of it of the origin keep c = 0
 
 
-def cloud_center(tgt, quantum=None):
+def cloud_center(tgt, quantum=None, tgt_rows=None):
     """(N,m,c) -> (N,3): the centre of the search coordinates (dicp_cloud_center): the coordinate-wise median of (a sample of) the target, rounded to a multiple of
-    `quantum`, so that clouds near the origin get exactly 0 and with it the bits of an uncentred search."""
+    `quantum`, so that clouds near the origin get exactly 0 and with it the bits of an uncentred search.
+    tgt_rows (N) int32, optional: rows of each cloud that take part (ragged batches)."""
     require_device(tgt, "cloud_center")
     N, m, c = tgt.shape
     out = torch.empty((N, 3), dtype=tgt.dtype, device=tgt.device)
     with torch.cuda.device(tgt.device):
-        _lib.check(_lib.load().dicp_cloud_center(_DT[tgt.dtype], _p(tgt), c, N, m, CENTER_QUANTUM if quantum is None else float(quantum),
+        _lib.check(_lib.load().dicp_cloud_center(_DT[tgt.dtype], _p(tgt), c, _p(tgt_rows), N, m, CENTER_QUANTUM if quantum is None else float(quantum),
                                                  _p(out), _stream()), "dicp_cloud_center")
     return out
 
@@ -84,44 +85,46 @@ def search_pose(pose, center, N=None):
     return out
 
 
-def pack_target(tgt, center=None):
+def pack_target(tgt, center=None, tgt_rows=None):
     """(N,m,c) -> (N,m_pad,4) rows [x,y,z,0.5|y|^2] of y (or of y - center: the caller then searches with [C | r - center])."""
     require_device(tgt, "pack_target")
+    tgt = tgt.contiguous()
     N, m, c = tgt.shape
     m_pad = padded_targets(m)
     out = torch.empty((N, m_pad, 4), dtype=tgt.dtype, device=tgt.device)
     with torch.cuda.device(tgt.device):
-        _lib.check(_lib.load().dicp_pack_target_centered(_DT[tgt.dtype], _p(tgt), N, m, c, _p(center), _p(out), m_pad, _stream()),
+        _lib.check(_lib.load().dicp_pack_target(_DT[tgt.dtype], _p(tgt), c, _p(center), _p(tgt_rows), N, m, _p(out), m_pad, _stream()),
                    "dicp_pack_target")
     return out
 
 
-def knn(src, pose, tgt4, m, variant=_lib.KNN_AUTO, out=None):
-    """Fused transform + brute-force 1-NN: (N,n,3), (N,12)|None, packed targets -> idx (N,n) int32."""
+def knn(src, pose, tgt4, m, variant=_lib.KNN_AUTO, out=None, src_rows=None, tgt_rows=None):
+    """Fused transform + brute-force 1-NN: (N,n,3), (N,12)|None, packed targets -> idx (N,n) int32.
+    src_rows / tgt_rows (N) int32, optional: rows of each cloud that take part (the idx of other rows is not written)."""
     require_device(src, "knn")
     N, n, _ = src.shape
     idx = out if out is not None else torch.empty((N, n), dtype=torch.int32, device=src.device)
     with torch.cuda.device(src.device):
-        _lib.check(_lib.load().dicp_knn(_DT[src.dtype], _p(src), _p(pose), _p(tgt4), N, n, m, tgt4.shape[1],
+        _lib.check(_lib.load().dicp_knn(_DT[src.dtype], _p(src), _p(pose), _p(tgt4), _p(src_rows), _p(tgt_rows), N, n, m, tgt4.shape[1],
                                         _p(idx), variant, _stream()), "dicp_knn")
     return idx
 
 
 class SweepIndex:
     """Per-call search structure of the exact sorted-sweep kNN (dicp_knn_sweep): targets do not move during
-    an ICP call, so they are sorted by x once.  Index preparation uses torch.sort/searchsorted (plumbing)."""
+    an ICP call, so they are sorted by x once (dicp_sweep_sort: native for every size and dtype)."""
     NBKT = 1024
 
-    def __init__(self, tgt, sorted_rows=False, center=None, native_sort=True):
+    def __init__(self, tgt, sorted_rows=False, center=None, tgt_rows=None):
         """sorted_rows: also keep tgt_s (N,m_pad,c), the full rows in sorted order (the windowed backward reads them).
-        native_sort=False: the key sort through torch.sort even where dicp_sweep_sort applies (tests compare the two).
         center (N,3): the index is built on y - center (keys, table and packed rows; tgt_s keeps the rows as given) and the
-        searches must then be given the pose [C | r - center]."""
+        searches must then be given the pose [C | r - center].
+        tgt_rows (N) int32: rows of each cloud that take part (ragged batches); the searches are given the same counts."""
         require_device(tgt, "SweepIndex")
         tgt = tgt.contiguous()
         N, m, c = tgt.shape
         self.m = m
-        self.center = center
+        self.center, self.tgt_rows = center, tgt_rows
         lib = _lib.load()
         dev, dt = tgt.device, tgt.dtype
         m_pad = lib.dicp_padded_targets(m)
@@ -129,25 +132,15 @@ class SweepIndex:
         self.tperm = torch.empty((N, m_pad), dtype=torch.int32, device=dev)
         self.bucket = torch.empty((N, self.NBKT + 1), dtype=torch.int32, device=dev)
         self.brange = torch.empty((N, 2), dtype=dt, device=dev)
-        native = dt == torch.float32 and m_pad <= 16384 and native_sort
-        if native:
-            # the stable sort of the x keys in LDS (dicp_sweep_sort): same keys and permutation as torch.sort(stable=True),
-            # and the bucket table while the keys are there
-            keys, order = torch.empty((N, m_pad), dtype=dt, device=dev), None
-            with torch.cuda.device(dev):
-                _lib.check(lib.dicp_sweep_sort_centered(_DT[dt], _p(tgt), c, _p(center), N, m, m_pad, _p(keys), _p(self.tperm), self.NBKT,
-                                                        _p(self.bucket), _p(self.brange), _stream()), "dicp_sweep_sort")
-        else:
-            key = torch.full((N, m_pad), float("nan"), dtype=dt, device=dev)   # pad slots sort last: NaN sorts above +inf, and the stable
-                                                                               # order keeps real rows (even NaN ones) ahead of the pads
-            key[:, :m] = tgt[:, :, 0] if center is None else tgt[:, :, 0] - center[:, 0:1]
-            keys, order = torch.sort(key, dim=1, stable=True)
-        self.keys = keys                                         # sorted x keys (N,m_pad): the rank search of query_order reads them
+        self.keys = torch.empty((N, m_pad), dtype=dt, device=dev)          # sorted x keys: the rank search of query_order reads them
         self.tgt_s = torch.empty((N, m_pad, c), dtype=dt, device=dev) if sorted_rows else None
+        nbytes = int(lib.dicp_sweep_sort_scratch_bytes(_DT[dt], N, m_pad))     # float64 keys / more than 16384 slots: chunked sort through scratch
+        scratch = torch.empty((nbytes,), dtype=torch.uint8, device=dev) if nbytes else None
         with torch.cuda.device(dev):
-            _lib.check(lib.dicp_sweep_build_centered(_DT[dt], _p(tgt), c, _p(center), _p(order), None if native else _p(keys), N, m, m_pad, self.NBKT,
-                                                     _p(self.tgs4), _p(self.tperm), _p(self.bucket), _p(self.brange), _p(self.tgt_s), _stream()),
-                       "dicp_sweep_build")
+            _lib.check(lib.dicp_sweep_sort(_DT[dt], _p(tgt), c, _p(center), _p(tgt_rows), N, m, m_pad, _p(self.keys), _p(self.tperm), self.NBKT,
+                                           _p(self.bucket), _p(self.brange), _p(scratch), nbytes, _stream()), "dicp_sweep_sort")
+            _lib.check(lib.dicp_sweep_build(_DT[dt], _p(tgt), c, _p(center), _p(tgt_rows), _p(self.tperm), N, m, m_pad,
+                                            _p(self.tgs4), _p(self.tgt_s), _stream()), "dicp_sweep_build")
         self.pair_shards = torch.zeros((_lib.PAIR_SHARDS,), dtype=torch.int64, device=dev)
 
     @property
@@ -155,7 +148,7 @@ class SweepIndex:
         """(query,target) pairs scored so far (device scalar)."""
         return self.pair_shards.sum()
 
-    def query_order(self, src, pose, exact=False, w=None, copies=False, reproducible=False, spos_prev=None):
+    def query_order(self, src, pose, exact=False, w=None, copies=False, reproducible=False, spos_prev=None, src_rows=None):
         """Query indices in (approximately) ascending transformed x: keeps a wave's queries neighbours.  Default: a
         counting sort by the rank bucket of each query's x among the sorted target keys (dicp_query_order; equal-width x
         buckets for clouds beyond 16384 points) -- or, given spos_prev (the matches of an earlier iteration), by the rank of
@@ -168,11 +161,12 @@ class SweepIndex:
                 qorder = torch.empty((N, n), dtype=torch.int32, device=src.device)
                 _lib.check(lib.dicp_query_order(_DT[src.dtype], _p(src), _p(pose), _p(self.brange), self.NBKT, N, n, _p(qorder),
                                                 None, None, None, int(reproducible), _p(spos_prev), self.tgs4.shape[1],
-                                                _p(self.keys), _p(self.bucket), self.m, _stream()),
+                                                _p(self.keys), _p(self.bucket), self.m, _p(src_rows), _p(self.tgt_rows), _stream()),
                            "dicp_query_order")
                 if copies:      # (the ordering kernel can write them itself, but one block per cloud gathers slowly: 115 vs 16 us)
                     return qorder, _gather_rows_raw(src, qorder), (_gather_rows_raw(w.unsqueeze(-1), qorder).squeeze(-1) if w is not None else None)
                 return qorder
+            assert src_rows is None, "exact query order: dense batches only (a test / tuning aid)"
             keys = torch.empty((N, n), dtype=src.dtype, device=src.device)
             _lib.check(lib.dicp_query_keys(_DT[src.dtype], _p(src), _p(pose), N, n, _p(keys), _stream()), "dicp_query_keys")
         qorder = torch.argsort(keys, dim=1).to(torch.int32)
@@ -180,62 +174,17 @@ class SweepIndex:
             return qorder, _gather_rows_raw(src, qorder), (_gather_rows_raw(w.unsqueeze(-1), qorder).squeeze(-1) if w is not None else None)
         return qorder
 
-    def knn(self, src, pose, qorder=None, out=None, cfg=0, spos=None, src_s=None):
-        """src_s: the rows of src in qorder's slot order (query_order(copies=True)) -> coalesced query loads."""
+    def knn(self, src, pose, qorder=None, out=None, cfg=0, spos=None, src_s=None, src_rows=None):
+        """src_s: the rows of src in qorder's slot order (query_order(copies=True)) -> coalesced query loads.
+        src_rows (N) int32: rows of each source cloud that take part (qorder, if any, made with the same counts)."""
         N, n, _ = src.shape
         idx = out if out is not None else torch.empty((N, n), dtype=torch.int32, device=src.device)
         if src_s is not None:
             src, cfg = src_s, cfg | _lib.SWEEP_SRC_SORTED
         with torch.cuda.device(src.device):
             _lib.check(_lib.load().dicp_knn_sweep(_DT[src.dtype], _p(src), _p(pose), _p(self.tgs4), _p(self.tperm), _p(qorder),
-                                                  _p(self.bucket), _p(self.brange), self.NBKT, N, n, self.m, self.tgs4.shape[1],
+                                                  _p(self.bucket), _p(self.brange), self.NBKT, _p(src_rows), _p(self.tgt_rows), N, n, self.m, self.tgs4.shape[1],
                                                   _p(idx), _p(spos), _p(self.pair_shards), cfg, _stream()), "dicp_knn_sweep")
-        return idx
-
-
-class GridIndex:
-    """Per-call search structure of the exact grid kNN (dicp_grid_build / dicp_knn_grid): targets do not move during an ICP
-    call, so they are binned into a uniform 3-D grid of cells once (about 4 per cell; stable order of the cell id).  A query
-    looks at its own cell and at a neighbouring one only if that cell's box is nearer than its best match so far: a few
-    dozen scored pairs per query whatever the pose, queries in the caller's order (no query ordering)."""
-
-    def __init__(self, tgt, sorted_rows=False, center=None, tgt_rows=None):
-        """sorted_rows: also keep tgt_s (N,m_pad,c), the full rows in cell order (the windowed backward reads them).
-        center (N,3): grid and packed rows are built on y - center; the searches must then be given [C | r - center].
-        tgt_rows (N) int32: leading rows of each cloud that take part (ragged batches)."""
-        require_device(tgt, "GridIndex")
-        tgt = tgt.contiguous()
-        N, m, c = tgt.shape
-        lib = _lib.load()
-        dev, dt = tgt.device, tgt.dtype
-        self.m, self.center = m, center
-        m_pad = lib.dicp_padded_targets(m)
-        self.ncell_max = lib.dicp_grid_cells_max(m)
-        self.tgs4 = torch.empty((N, m_pad, 4), dtype=dt, device=dev)
-        self.tperm = torch.empty((N, m_pad), dtype=torch.int32, device=dev)
-        self.cell_start = torch.empty((N, self.ncell_max + 1), dtype=torch.int32, device=dev)
-        self.ginfo = torch.empty((N, _lib.GRID_INFO), dtype=dt, device=dev)
-        self.tgt_s = torch.empty((N, m_pad, c), dtype=dt, device=dev) if sorted_rows else None
-        nbytes = int(lib.dicp_grid_scratch_bytes(N, m_pad))
-        scratch = torch.empty((nbytes,), dtype=torch.uint8, device=dev) if nbytes else None
-        with torch.cuda.device(dev):
-            _lib.check(lib.dicp_grid_build(_DT[dt], _p(tgt), c, _p(center), _p(tgt_rows), N, m, m_pad, self.ncell_max, _p(self.ginfo),
-                                           _p(self.tperm), _p(self.cell_start), _p(self.tgs4), _p(self.tgt_s), _p(scratch), nbytes, _stream()),
-                       "dicp_grid_build")
-        self.pair_shards = torch.zeros((_lib.PAIR_SHARDS,), dtype=torch.int64, device=dev)
-
-    @property
-    def pairs(self):
-        """(query,target) pairs scored so far (device scalar)."""
-        return self.pair_shards.sum()
-
-    def knn(self, src, pose, out=None, spos=None, src_rows=None):
-        N, n, _ = src.shape
-        idx = out if out is not None else torch.empty((N, n), dtype=torch.int32, device=src.device)
-        with torch.cuda.device(src.device):
-            _lib.check(_lib.load().dicp_knn_grid(_DT[src.dtype], _p(src), _p(pose), _p(self.tgs4), _p(self.tperm), _p(self.cell_start),
-                                                 self.ncell_max, _p(self.ginfo), _p(src_rows), N, n, self.m, self.tgs4.shape[1],
-                                                 _p(idx), _p(spos), _p(self.pair_shards), _stream()), "dicp_knn_grid")
         return idx
 
 
@@ -394,7 +343,7 @@ def loss_weight(err2d, name, diff, metric, tanh_k):
 
 
 # --------------------------------------------------------------- the ICP loop
-def prebuild_search(source, target, knn_variant, want_rows, T_init=None):
+def prebuild_search(source, target, knn_variant, want_rows, T_init=None, src_rows=None, tgt_rows=None):
     """Enqueue the per-call search structure of the sweep path (target sort + index build, ~0.15 ms of kernels) NOW, so that
     it runs under the host work the caller still has to do before the loop starts (a call that begins on an idle GPU is
     host-bound until its first long kernel).  Returns (target, SweepIndex) for LoopConfig.prebuilt, or None when the loop
@@ -406,7 +355,7 @@ def prebuild_search(source, target, knn_variant, want_rows, T_init=None):
     if kind != _lib.KNN_SWEEP or not target.is_cuda or not target.is_contiguous() or target.dtype not in _DT:
         return None
     with torch.cuda.device(target.device):
-        sweep = SweepIndex(target, sorted_rows=bool(want_rows), center=cloud_center(target))
+        sweep = SweepIndex(target, sorted_rows=bool(want_rows), center=cloud_center(target, tgt_rows=tgt_rows), tgt_rows=tgt_rows)
         # ... and the first query order, from T_init alone (the loop's own pose_0 does not exist yet): with it the queue holds
         # ~0.2 ms of work while the host builds the loop state
         first = None
@@ -414,7 +363,7 @@ def prebuild_search(source, target, knn_variant, want_rows, T_init=None):
                 and tuple(T_init.shape) == (N, 4, 4)):
             pose_s = torch.empty((N, 12), dtype=target.dtype, device=target.device)
             _lib.check(_lib.load().dicp_search_pose(_DT[target.dtype], _p(T_init), _p(sweep.center), N, _p(pose_s), _stream()), "dicp_search_pose")
-            first = (source, T_init, sweep.query_order(source, pose_s))
+            first = (source, T_init, sweep.query_order(source, pose_s, src_rows=src_rows))
         return (target, sweep, first)
 
 
@@ -439,6 +388,8 @@ class LoopConfig:
     timing_events: object = None  # optional object with .handles(K) -> ctypes array of 4*K hipEvent_t (bench.py)
     prebuilt: object = None       # (target, SweepIndex) started by the caller before its own host work (prebuild_search)
     small_loop: bool = True       # small clouds: one block runs a cloud's whole chunk of iterations (icp_small_* kernels)
+    src_rows: object = None       # ragged batches: (N) int32 device tensors, rows of each source / target cloud that take part
+    tgt_rows: object = None       # (ICP._batch: the clouds' own lengths; the kernels never touch a pad row)
 
     def params(self):
         return _lib.WeightParams(
@@ -536,13 +487,13 @@ class ICPLoop(torch.autograd.Function):
             if kind == _lib.KNN_SWEEP:
                 pre = cfg.prebuilt
                 if (pre is not None and pre[0].data_ptr() == tgt.data_ptr() and pre[0].shape == tgt.shape and pre[0].dtype == tgt.dtype
-                        and (pre[1].tgt_s is not None or not owned)):
+                        and (pre[1].tgt_s is not None or not owned) and pre[1].tgt_rows is cfg.tgt_rows):
                     sweep = pre[1]                           # started by the caller, under its host work
                 else:
-                    sweep = SweepIndex(tgt, sorted_rows=owned, center=cloud_center(tgt))
+                    sweep = SweepIndex(tgt, sorted_rows=owned, center=cloud_center(tgt, tgt_rows=cfg.tgt_rows), tgt_rows=cfg.tgt_rows)
             # the searches run in coordinates centred on the target cloud (dicp_cloud_center): packed rows y - c, pose [C | r - c]
-            center = sweep.center if sweep is not None else cloud_center(tgt)
-            tgt4 = sweep.tgs4 if sweep is not None else pack_target(tgt, center)
+            center = sweep.center if sweep is not None else cloud_center(tgt, tgt_rows=cfg.tgt_rows)
+            tgt4 = sweep.tgs4 if sweep is not None else pack_target(tgt, center, cfg.tgt_rows)
             m_pad = tgt4.shape[1]
             nblk = lib.dicp_accumulate_blocks(n)
             poses = torch.empty((Kmax + 1, N, 12), dtype=dt, device=dev)
@@ -562,8 +513,8 @@ class ICPLoop(torch.autograd.Function):
             counters = arena.take((Kmax,), torch.int32)
             deltas, costs, converged, iterations, matched, n_matched, counters = arena.finish()
             # pose_0, alive_0, n_start (ICP.py:124-129)
-            _lib.check(lib.dicp_loop_init_centered(code, _p(T_init.contiguous()), _p(w0c), float(cfg.match_ratio_thresh), rows, N, n,
-                                                   _p(poses), _p(alive), _p(n_start), _p(center), _p(poses_c), st), "dicp_loop_init")
+            _lib.check(lib.dicp_loop_init(code, _p(T_init.contiguous()), _p(w0c), float(cfg.match_ratio_thresh), rows, N, n,
+                                          _p(poses), _p(alive), _p(n_start), _p(center), _p(poses_c), st), "dicp_loop_init")
             idx_once = None if need_grad else torch.empty((N, n), dtype=torch.int32, device=dev)
 
             # histories in slabs of kc iterations: slab j covers iterations [j*kc, (j+1)*kc)
@@ -603,7 +554,7 @@ class ICPLoop(torch.autograd.Function):
                             and first[1].data_ptr() == T_init.data_ptr() and T_init.is_contiguous()):
                         qorder = first[2]                    # ordered under T_init by the caller (prebuild_search)
                     else:
-                        qorder = sweep.query_order(src, (poses_c if poses_c is not None else poses)[k0])
+                        qorder = sweep.query_order(src, (poses_c if poses_c is not None else poses)[k0], src_rows=cfg.src_rows)
                     qorders.append(qorder)
                 seg_q.append(len(qorders) - 1)
                 base = j * kc                                         # virtual bases: slab pointer minus its first iteration
@@ -618,7 +569,8 @@ class ICPLoop(torch.autograd.Function):
                     idx=ctypes.c_void_p(idx_slabs[j].data_ptr() - base * N * n * 4) if need_grad else _p(idx_once),
                     w=ctypes.c_void_p(w_slabs[j].data_ptr() - base * n * es), w_iter=n, w_stride=kc * n,
                     w_prev0=_p(w_slabs[(k0 - 1) // kc][:, (k0 - 1) % kc]) if k0 > 0 else None,
-                    partials=_p(partials), counters=_p(counters), events=events, center=_p(center), poses_search=_p(poses_c))
+                    partials=_p(partials), counters=_p(counters), events=events, center=_p(center), poses_search=_p(poses_c),
+                    src_rows=_p(cfg.src_rows), tgt_rows=_p(cfg.tgt_rows))
                 _lib.check(lib.dicp_icp_forward(code, ctypes.byref(P), ctypes.byref(LB), N, n, m, int(cfg.dim), int(cfg.const_iter),
                                                 float(cfg.tolerance), k0, k1, st), "dicp_icp_forward")
                 done_segs.append((k0, k1))
@@ -738,7 +690,7 @@ class ICPLoop(torch.autograd.Function):
                     spos_ref=_p(spos_ref) if w_form else None, gts_far=_p(gfar) if w_form else None,
                     poses=_p(poses), deltas=_p(deltas), areg=_p(areg), alive=_p(alive),
                     idx=ctypes.c_void_p(idx_slabs[j].data_ptr() - base * N * n * 4), events=events,
-                    bwd_overwrite=fresh if (w_form and k1 > k0) else 0)
+                    bwd_overwrite=fresh if (w_form and k1 > k0) else 0, src_rows=_p(cfg.src_rows), tgt_rows=_p(cfg.tgt_rows))
                 if w_form and k1 > k0:
                     fresh = 0
                 _lib.check(lib.dicp_icp_backward(code, ctypes.byref(P), ctypes.byref(LB), N, n, m, int(cfg.dim), _p(gpose), _p(gtmp), have,
@@ -753,7 +705,7 @@ class ICPLoop(torch.autograd.Function):
                 if want_w:
                     _lib.check(permute(code, _p(gw_s), _p(qo), N, n, n, n, 1, 1, _p(gw), n, 1, st), "dicp_permute_rows")
                 if want_tgt:
-                    _lib.check(lib.dicp_window_reduce(code, _p(slab), _p(spos_ref), _p(qo), _p(tperm), _p(gfar), N, n, m, m_pad, cv,
+                    _lib.check(lib.dicp_window_reduce(code, _p(slab), _p(spos_ref), _p(qo), _p(tperm), _p(gfar), _p(cfg.src_rows), N, n, m, m_pad, cv,
                                                       _p(gtgt), c, int(all_windowed), st), "dicp_window_reduce")
             gT0 = torch.empty((N, 4, 4), dtype=dt, device=dev)      # final gpose + the last launch's pose partials
             _lib.check(lib.dicp_pose_grad_out(code, _p(gpose), _p(bwdp[form]) if have else None, bwdp[form].shape[1] if have else 0,
@@ -772,7 +724,7 @@ class KabschLoop(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, source, target, T_init, w0, max_iterations, tolerance, trim_dist, const_iter, knn_variant):
+    def forward(ctx, source, target, T_init, w0, max_iterations, tolerance, trim_dist, const_iter, knn_variant, src_rows=None, tgt_rows=None):
         for t, nm in ((source, "source"), (target, "target"), (T_init, "T_init"), (w0, "weight")):
             require_device(t, "pt2pt_dICP_SVD(" + nm + ")")
         lib = _lib.load()
@@ -788,9 +740,9 @@ class KabschLoop(torch.autograd.Function):
             kind = knn_variant & 0xff
             if kind == _lib.KNN_AUTO:
                 kind = auto_knn_kind(N, n, m)
-            center = cloud_center(tgt)                          # centred search, as in ICPLoop
-            sweep = SweepIndex(tgt, center=center) if kind == _lib.KNN_SWEEP else None
-            tgt4 = sweep.tgs4 if sweep is not None else pack_target(tgt, center)
+            center = cloud_center(tgt, tgt_rows=tgt_rows)       # centred search, as in ICPLoop
+            sweep = SweepIndex(tgt, center=center, tgt_rows=tgt_rows) if kind == _lib.KNN_SWEEP else None
+            tgt4 = sweep.tgs4 if sweep is not None else pack_target(tgt, center, tgt_rows)
             nblk = lib.dicp_accumulate_blocks(n)
             pose = _pose_from_T(T_init)
             pose_prev = pose
@@ -805,12 +757,12 @@ class KabschLoop(torch.autograd.Function):
                 pose_s = search_pose(pose, center)
                 if sweep is not None:
                     if k < 2:
-                        qorder = sweep.query_order(src, pose_s)
-                    sweep.knn(src, pose_s, qorder, out=idx, cfg=(knn_variant >> 8) & 0xff)
+                        qorder = sweep.query_order(src, pose_s, src_rows=src_rows)
+                    sweep.knn(src, pose_s, qorder, out=idx, cfg=(knn_variant >> 8) & 0xff, src_rows=src_rows)
                 else:
-                    _lib.check(lib.dicp_knn(code, _p(src), _p(pose_s), _p(tgt4), N, n, m, tgt4.shape[1], _p(idx),
+                    _lib.check(lib.dicp_knn(code, _p(src), _p(pose_s), _p(tgt4), _p(src_rows), _p(tgt_rows), N, n, m, tgt4.shape[1], _p(idx),
                                             kind | (knn_variant & 0xff00), st), "dicp_knn")
-                _lib.check(lib.dicp_kabsch_accumulate(code, _p(src), _p(tgt), c, _p(idx), _p(pose), _p(w0c), trim_on, trim,
+                _lib.check(lib.dicp_kabsch_accumulate(code, _p(src), _p(tgt), c, _p(idx), _p(pose), _p(w0c), trim_on, trim, _p(src_rows),
                                                       N, n, m, _p(partials), st), "dicp_kabsch_accumulate")
                 pose_prev, pose = pose, torch.empty((N, 12), dtype=dt, device=dev)
                 cost_k = torch.empty((N,), dtype=dt, device=dev)
@@ -830,6 +782,7 @@ class KabschLoop(torch.autograd.Function):
             costs = costs[:, :K].contiguous()
         ctx.save_for_backward(src, tgt, w0c, idx, pose_prev, save)
         ctx.trim = (trim_on, trim)
+        ctx.src_rows = src_rows
         ctx.mark_non_differentiable(costs, iterations)
         return T, costs, iterations
 
@@ -851,9 +804,9 @@ class KabschLoop(torch.autograd.Function):
             gsrc = torch.zeros_like(src)
             gtgt = torch.zeros_like(tgt) if ctx.needs_input_grad[1] else None
             gw = torch.zeros_like(w0c)
-            _lib.check(lib.dicp_kabsch_bwd(code, _p(src), _p(tgt), c, _p(idx), _p(pose_prev), _p(w0c), trim_on, trim, _p(gacc),
+            _lib.check(lib.dicp_kabsch_bwd(code, _p(src), _p(tgt), c, _p(idx), _p(pose_prev), _p(w0c), trim_on, trim, _p(gacc), _p(ctx.src_rows),
                                            N, n, m, _p(gsrc), _p(gtgt), _p(gw), st), "dicp_kabsch_bwd")
-        return gsrc, gtgt, None, gw, None, None, None, None, None
+        return gsrc, gtgt, None, gw, None, None, None, None, None, None, None
 
 
 class _RowsIteration(torch.autograd.Function):
@@ -879,7 +832,7 @@ class _RowsIteration(torch.autograd.Function):
             partials = torch.empty((N, nblk, _lib.NACC_PAD), dtype=dt, device=dev)
             wk = torch.empty((N, n), dtype=dt, device=dev)
             alive_k = st["alive"].clone()
-            _lib.check(lib.dicp_accumulate(code, ctypes.byref(P), _p(src), _p(rows), c, None, _p(pose_in), _p(w0c), _p(st["alive"]),
+            _lib.check(lib.dicp_accumulate(code, ctypes.byref(P), _p(src), _p(rows), c, None, _p(pose_in), _p(w0c), _p(st["alive"]), None,
                                            N, n, n, _p(partials), _p(wk), n, stream), "dicp_accumulate")
             pose_out = torch.empty((N, 12), dtype=dt, device=dev)
             delta = torch.empty((N, 6), dtype=dt, device=dev)
@@ -922,7 +875,7 @@ class _RowsIteration(torch.autograd.Function):
             gw = torch.zeros_like(w0c)
             bwdp = torch.empty((N, nblk, _lib.NBWD_PAD), dtype=dt, device=dev)
             _lib.check(lib.dicp_accumulate_bwd(code, ctypes.byref(P), _p(src), _p(rows), c, None, _p(pose_in), _p(w0c), _p(alive_k),
-                                               _p(gs), _p(gb), N, n, n, _p(gsrc), _p(grows), _p(gw), _p(bwdp), stream), "dicp_accumulate_bwd")
+                                               _p(gs), _p(gb), None, N, n, n, _p(gsrc), _p(grows), _p(gw), _p(bwdp), stream), "dicp_accumulate_bwd")
             gpose = (gpass + bwdp.sum(dim=1)[:, :12].to(torch.float64)).to(dt)
         return gsrc, grows, gpose, gw, None, None, None
 

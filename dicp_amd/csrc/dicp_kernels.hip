@@ -68,6 +68,12 @@ __device__ __forceinline__ bool decode_block(int bpc, int N, int& cloud, int& bl
 }
 inline unsigned grid_for(int N, int bpc) { return 8u * (unsigned)((N + 7) / 8) * (unsigned)bpc; }
 
+// Ragged batches (ICP.py:305-511 pads every cloud to the longest): rows[cloud] = leading rows of the cloud that take part
+// (NULL: all `full` of them).  The kernels never read, score or accumulate a row beyond it.
+__device__ __forceinline__ int rows_of(const int32_t* __restrict__ rows, int cloud, int full) {
+    return rows ? min(max(rows[cloud], 0), full) : full;
+}
+
 template <typename T>
 __device__ __forceinline__ void load_pose(const T* __restrict__ pose, int cloud, T* C, T* r) {
     if (pose) {
@@ -118,40 +124,27 @@ constexpr int CC_THREADS = 1024;     // one block per cloud
 constexpr int CC_SAMPLE = CC_THREADS;// rows looked at per cloud: one per thread, its three keys stay in registers
 __device__ __forceinline__ unsigned sortable_bits(float x);
 // The centre only sizes a margin (it decides no result), but it has to sit INSIDE the cloud: a mean would be dragged away by
-// far rows -- the reference pads ragged targets with rows at max(source) * 1000 (ICP.py:460), scans carry stray returns.  So it is
-// the coordinate-wise MEDIAN of a stride sample of at most CC_SAMPLE rows (rows 0, step, 2 step, ...), found by a radix select
-// (most significant byte first, the three axes side by side) over the order-preserving bit pattern of the float values (float
-// is plenty: the centre is rounded to `quantum` anyway).
+// stray returns.  So it is the coordinate-wise MEDIAN of a stride sample of at most CC_SAMPLE of the cloud's rows (rows 0, step,
+// 2 step, ...; a ragged batch hands over the cloud's own length, so pad rows are not in it), found by a radix select (most
+// significant byte first, the three axes side by side) over the order-preserving bit pattern of the float values (float is
+// plenty: the centre is rounded to `quantum` anyway).
 template <typename T>
-__global__ __launch_bounds__(CC_THREADS) void cloud_center_kernel(const T* __restrict__ tgt, int c, int m, double quantum, T* __restrict__ center) {
+__global__ __launch_bounds__(CC_THREADS) void cloud_center_kernel(const T* __restrict__ tgt, int c, int m, const int32_t* __restrict__ tgt_rows,
+                                                                  double quantum, T* __restrict__ center) {
     __shared__ int hist[3][256];
     __shared__ unsigned sel_prefix[3];
     __shared__ int sel_want[3];
     const int cloud = blockIdx.x, tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
     const T* __restrict__ rows = tgt + (size_t)cloud * m * c;
-    const int step = (m + CC_SAMPLE - 1) / CC_SAMPLE, ms = (m + step - 1) / step;
-    // rows identical to the LAST row do not vote: the reference's pad rows are copies of one far point at the end of the cloud
-    // (ICP.py:460,472-477) and may well be the majority of a short cloud in a ragged batch
-    __shared__ int nact;
-    if (tid == 0) nact = 0;
-    __syncthreads();
-    const T* last = rows + (size_t)(m - 1) * c;
-    bool on = tid < ms;
+    const int mc = max(rows_of(tgt_rows, cloud, m), 1);
+    const int step = (mc + CC_SAMPLE - 1) / CC_SAMPLE, ms = (mc + step - 1) / step;
+    const bool on = tid < ms;
     unsigned key[3] = {0u, 0u, 0u};
-    bool same = false;
     if (on) {
         const T* r = rows + (size_t)tid * step * c;
-        same = r[0] == last[0] && r[1] == last[1] && r[2] == last[2];
         key[0] = sortable_bits((float)r[0]); key[1] = sortable_bits((float)r[1]); key[2] = sortable_bits((float)r[2]);
     }
-    {
-        const unsigned long long votes = __ballot(on && !same);
-        if (lane == 0 && votes) atomicAdd(&nact, __popcll(votes));
-    }
-    __syncthreads();
-    const int voters = nact > 0 ? nact : ms;                               // (every row the same point: they all vote)
-    on = on && (nact > 0 ? !same : true);
-    if (tid < 3) { sel_prefix[tid] = 0u; sel_want[tid] = (voters - 1) / 2; }    // lower median
+    if (tid < 3) { sel_prefix[tid] = 0u; sel_want[tid] = (ms - 1) / 2; }    // lower median
     unsigned mask = 0u;
     for (int pass = 3; pass >= 0; --pass) {
         for (int d = tid; d < 3 * 256; d += CC_THREADS) (&hist[0][0])[d] = 0;
@@ -193,41 +186,42 @@ __global__ __launch_bounds__(CC_THREADS) void cloud_center_kernel(const T* __res
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void pack_kernel(const T* __restrict__ tgt, int N, int m, int c,
                                                      typename V4<T>::type* __restrict__ out, int m_pad, int bpc,
-                                                     const T* __restrict__ center) {
+                                                     const T* __restrict__ center, const int32_t* __restrict__ tgt_rows) {
     int b, blk;                                             // all blocks of a cloud on one XCD (decode_block)
     if (!decode_block(bpc, N, b, blk)) return;
     const int j = blk * BLOCK + threadIdx.x;
     if (j >= m_pad) return;
     typename V4<T>::type v;
-    if (j < m) v = pack_row<T>(tgt + ((size_t)b * m + j) * c, center ? center + (size_t)b * 3 : nullptr);
+    if (j < rows_of(tgt_rows, b, m)) v = pack_row<T>(tgt + ((size_t)b * m + j) * c, center ? center + (size_t)b * 3 : nullptr);
     else { v.x = v.y = v.z = T(0); v.w = inf_v<T>(); }
     out[(size_t)b * m_pad + j] = v;
 }
 
 // ------------------------------------------------------------ sweep index / loop set-up
-// Everything of the sorted-sweep search structure that follows the sort itself (the sort is torch.sort: plumbing):
-// sorted packed rows, the permutation as int32, and the coarse bucket table of lower-bound positions.
+// What follows the key sort (dicp_sweep_sort) in the sorted-sweep search structure: the packed rows, and optionally the
+// full rows, in sorted order.
 template <typename T>
-__global__ __launch_bounds__(BLOCK) void sweep_rows_kernel(const T* __restrict__ tgt, const int64_t* __restrict__ order /* NULL: tperm holds it */, int N, int m, int c,
-                                                           int m_pad, int bpc, typename V4<T>::type* __restrict__ tgs4, int32_t* __restrict__ tperm,
+__global__ __launch_bounds__(BLOCK) void sweep_rows_kernel(const T* __restrict__ tgt, const int32_t* __restrict__ tgt_rows, int N, int m, int c,
+                                                           int m_pad, int bpc, typename V4<T>::type* __restrict__ tgs4, const int32_t* __restrict__ tperm,
                                                            T* __restrict__ tgt_s /* optional (N,m_pad,c): the full rows in sorted order */,
                                                            const T* __restrict__ center /* optional (N,3): tgs4 rows are y - centre; tgt_s stays as given */) {
     constexpr int U = 4;                                    // rows per thread in flight (index -> row is a dependent pair)
     int b, blk;
     if (!decode_block(bpc, N, b, blk)) return;
     const int s0 = blk * (BLOCK * U) + threadIdx.x;
+    const int mc = rows_of(tgt_rows, b, m);
     {
-        long j[U];
+        int j[U];
         T y[U][6];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const size_t at = (size_t)b * m_pad + min(s0 + u * BLOCK, m_pad - 1);
-            j[u] = order ? order[at] : (long)tperm[at];
+            j[u] = tperm[at];
         }
         const bool full = tgt_s && c == 6;                  // the normals are wanted too: read the whole row once
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const T* yp = tgt + ((size_t)b * m + (j[u] >= 0 && j[u] < m ? j[u] : 0)) * c;   // pad slots repeat row 0 (never matched)
+            const T* yp = tgt + ((size_t)b * m + (j[u] >= 0 && j[u] < mc ? j[u] : 0)) * c;   // pad slots repeat row 0 (never matched)
             y[u][0] = yp[0]; y[u][1] = yp[1]; y[u][2] = yp[2];
             if (full) { y[u][3] = yp[3]; y[u][4] = yp[4]; y[u][5] = yp[5]; }
         }
@@ -236,10 +230,9 @@ __global__ __launch_bounds__(BLOCK) void sweep_rows_kernel(const T* __restrict__
             const int sl = s0 + u * BLOCK;
             if (sl >= m_pad) continue;
             typename V4<T>::type v;
-            if (j[u] >= 0 && j[u] < m) v = pack_row<T>(y[u], center ? center + (size_t)b * 3 : nullptr);
+            if (j[u] >= 0 && j[u] < mc) v = pack_row<T>(y[u], center ? center + (size_t)b * 3 : nullptr);
             else { v.x = big_v<T>(); v.y = v.z = T(0); v.w = inf_v<T>(); }      // pads sort last and can never win
             tgs4[(size_t)b * m_pad + sl] = v;
-            tperm[(size_t)b * m_pad + sl] = (int32_t)j[u];
             if (tgt_s) {
                 T* o = tgt_s + ((size_t)b * m_pad + sl) * c;
                 o[0] = y[u][0]; o[1] = y[u][1]; o[2] = y[u][2];
@@ -250,9 +243,10 @@ __global__ __launch_bounds__(BLOCK) void sweep_rows_kernel(const T* __restrict__
 }
 
 template <typename T>
-__global__ __launch_bounds__(BLOCK) void sweep_buckets_kernel(const T* __restrict__ keys /* (N,m_pad) ascending */, int N, int m, int m_pad,
-                                                              int nbkt, int32_t* __restrict__ bucket, T* __restrict__ brange) {
+__global__ __launch_bounds__(BLOCK) void sweep_buckets_kernel(const T* __restrict__ keys /* (N,m_pad) ascending */, int N, int m_full, int m_pad,
+                                                              int nbkt, int32_t* __restrict__ bucket, T* __restrict__ brange, const int32_t* __restrict__ tgt_rows) {
     const int cloud = blockIdx.x;
+    const int m = max(rows_of(tgt_rows, cloud, m_full), 1);
     const T* __restrict__ xs = keys + (size_t)cloud * m_pad;
     const T xlo = xs[0], span = xs[m - 1] - xlo;
     for (int b = threadIdx.x; b <= nbkt; b += BLOCK) {
@@ -281,16 +275,17 @@ __device__ __forceinline__ unsigned sortable_bits(float x) {      // order-prese
     u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;
     return x != x ? 0xffffffffu : u;                               // NaN of either sign sorts last, as torch.sort has it
 }
-__global__ __launch_bounds__(RS_THREADS) void sort_keys_kernel(const float* __restrict__ tgt, int c, int N, int m, int m_pad,
+__global__ __launch_bounds__(RS_THREADS) void sort_keys_kernel(const float* __restrict__ tgt, int c, int N, int m_full, int m_pad,
                                                                float* __restrict__ keys_sorted, int32_t* __restrict__ tperm,
                                                                int nbkt, int32_t* __restrict__ bucket, float* __restrict__ brange,
-                                                               const float* __restrict__ center) {
+                                                               const float* __restrict__ center, const int32_t* __restrict__ tgt_rows) {
     __shared__ unsigned skey[RS_MAX];
     __shared__ unsigned short sidx[RS_MAX];
     __shared__ int cnt[RS_THREADS / WAVE][256];             // per wave, per digit: running count, then offset
     __shared__ int tot[256];
     const int cloud = blockIdx.x, tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
-    const float* __restrict__ rows = tgt + (size_t)cloud * m * c;
+    const float* __restrict__ rows = tgt + (size_t)cloud * m_full * c;
+    const int m = rows_of(tgt_rows, cloud, m_full);          // rows past the cloud's own length are pad slots too
     unsigned key[RS_PER];
     unsigned short idx[RS_PER];
 #pragma unroll
@@ -373,7 +368,7 @@ __global__ __launch_bounds__(RS_THREADS) void sort_keys_kernel(const float* __re
     // the sweep's bucket table (what sweep_buckets_kernel computes from global memory) while the sorted keys are in LDS
     if (bucket) {
         auto key_at = [&](int i) { unsigned u = skey[i]; u ^= (u >> 31) ? 0x80000000u : 0xffffffffu; return __uint_as_float(u); };
-        const float xlo = key_at(0), span = key_at(m - 1) - xlo;
+        const float xlo = key_at(0), span = key_at(max(m, 1) - 1) - xlo;
         for (int b = tid; b <= nbkt; b += RS_THREADS) {
             const unsigned edge = sortable_bits(fma_t(float(b), span / float(nbkt), xlo));
             int lo = 0, hi = m;
@@ -418,17 +413,33 @@ constexpr int QO_TABLE = 1024;      // ... and the coarse lower-bound table that
 // QO_STAGE: queries per cloud whose permutation is assembled in LDS (16384 -> 32 KiB, several clouds per CU; 65536 -> 128 KiB)
 template <typename T, int QO_STAGE>
 __global__ __launch_bounds__(QO_THREADS) void query_order_kernel(const T* __restrict__ src, const T* __restrict__ pose,
-                                                                 const T* __restrict__ brange, int nbkt_range, int N, int n,
+                                                                 const T* __restrict__ brange, int nbkt_range, int N, int n_full,
                                                                  int32_t* __restrict__ qorder, const T* __restrict__ w,
                                                                  T* __restrict__ src_s, T* __restrict__ w_s, int reproducible,
                                                                  const int32_t* __restrict__ spos_prev, int m_pad,
-                                                                 const T* __restrict__ skeys, int kstride, int mt, const int32_t* __restrict__ table) {
+                                                                 const T* __restrict__ skeys, int kstride, int mt_full, const int32_t* __restrict__ table,
+                                                                 const int32_t* __restrict__ src_rows, const int32_t* __restrict__ tgt_rows) {
     __shared__ int cnt[QO_BUCKETS];
     __shared__ int wsum[QO_THREADS / WAVE];
     __shared__ unsigned short stage[QO_STAGE];              // query ids (< 65536) by slot: the permutation is assembled here
     __shared__ float lkeys[QO_STAGE <= 16384 ? QO_KEYS : 1];
     __shared__ int ltab[QO_STAGE <= 16384 ? QO_TABLE + 1 : 1];
     const int cloud = blockIdx.x, tid = threadIdx.x;
+    // ragged batches: the cloud's own queries [0, n) are ordered; rows n .. n_full - 1 (pads) keep their slots, so that qorder
+    // stays a permutation of all n_full rows (the row copies and the un-permuting of the backward walk all of it)
+    const int n = rows_of(src_rows, cloud, n_full), mt = max(rows_of(tgt_rows, cloud, mt_full), 1);
+    src += (size_t)cloud * (n_full - n) * 3;                // (every access below is src + (cloud * n + i) * 3)
+    if (w) w += (size_t)cloud * (n_full - n);
+    if (spos_prev) spos_prev += (size_t)cloud * (n_full - n);
+    qorder += (size_t)cloud * (n_full - n);
+    if (src_s) src_s += (size_t)cloud * (n_full - n) * 3;
+    if (w_s) w_s += (size_t)cloud * (n_full - n);
+    for (int i = n + tid; i < n_full; i += QO_THREADS) {
+        qorder[(size_t)cloud * n + i] = i;
+        if (src_s) { const T* p = src + ((size_t)cloud * n + i) * 3; T* o = src_s + ((size_t)cloud * n + i) * 3; o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; }
+        if (w_s) w_s[(size_t)cloud * n + i] = w[(size_t)cloud * n + i];
+    }
+    if (n <= 0) return;
     for (int b = tid; b < QO_BUCKETS; b += QO_THREADS) cnt[b] = 0;
     T q[4] = {T(1), T(0), T(0), T(0)};
     if (pose) { const T* pp = pose + (size_t)cloud * 12; q[0] = pp[0]; q[1] = pp[1]; q[2] = pp[2]; q[3] = pp[9]; }
@@ -635,12 +646,17 @@ __device__ __forceinline__ T score(const T* nx, const T4& y) {
 template <typename T, int Q, int TILE, int CH, int MINW>
 __global__ __launch_bounds__(BLOCK, MINW) void knn_valu_kernel(const T* __restrict__ src, const T* __restrict__ pose,
                                                          const typename V4<T>::type* __restrict__ tgt4,
-                                                         int32_t* __restrict__ idx, int N, int n, int m, int m_pad, int bpc) {
+                                                         int32_t* __restrict__ idx, int N, int n_full, int m_full, int m_pad_full, int bpc,
+                                                         const int32_t* __restrict__ src_rows, const int32_t* __restrict__ tgt_rows) {
     using T4 = typename V4<T>::type;
     __shared__ T4 tile[TILE];
     int cloud, blk;
     if (!decode_block(bpc, N, cloud, blk)) return;
     const int tid = threadIdx.x;
+    // ragged batches: this cloud's own lengths (the packed rows past m are pad rows: they are not even read)
+    const int n = rows_of(src_rows, cloud, n_full), m = max(rows_of(tgt_rows, cloud, m_full), 1);
+    const int m_pad = min((m + KNN_PAD - 1) / KNN_PAD * KNN_PAD, m_pad_full);
+    if (blk * (BLOCK * Q) >= n) return;                     // (block-uniform)
     T C[9], r[3];
     load_pose(pose, cloud, C, r);
 
@@ -651,7 +667,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_valu_kernel(const T* __restri
         const int i = blk * (BLOCK * Q) + qi * BLOCK + tid;
         T p[3] = {T(0), T(0), T(0)};
         if (i < n) {
-            const T* sp = src + ((size_t)cloud * n + i) * 3;
+            const T* sp = src + ((size_t)cloud * n_full + i) * 3;
             p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2];
         }
         query_point(C, r, p, nx[qi]);                       // ICP.py:137
@@ -659,7 +675,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_valu_kernel(const T* __restri
         bchunk[qi] = 0;
     }
 
-    const T4* __restrict__ tg = tgt4 + (size_t)cloud * m_pad;
+    const T4* __restrict__ tg = tgt4 + (size_t)cloud * m_pad_full;
     for (int base = 0; base < m_pad; base += TILE) {
         const int len = min(TILE, m_pad - base);            // multiple of 16
         for (int t = tid; t < len; t += BLOCK) tile[t] = tg[base + t];
@@ -692,7 +708,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_valu_kernel(const T* __restri
                 const T s = score<T, T4>(nx[qi], cp[k]);
                 if (s < bv) { bv = s; bj = bchunk[qi] + k; }
             }
-            idx[(size_t)cloud * n + i] = min(bj, m - 1);
+            idx[(size_t)cloud * n_full + i] = min(bj, m - 1);
         }
     }
 }
@@ -708,12 +724,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int NB, int TILE, int G>
 __global__ __launch_bounds__(BLOCK) void knn_mfma_kernel(const float* __restrict__ src, const float* __restrict__ pose,
                                                          const float4* __restrict__ tgt4, int32_t* __restrict__ idx,
-                                                         int N, int n, int m, int m_pad, int bpc) {
+                                                         int N, int n_full, int m_full, int m_pad_full, int bpc,
+                                                         const int32_t* __restrict__ src_rows, const int32_t* __restrict__ tgt_rows) {
     constexpr int TS = TILE + 16;      // component stride: lanes 16..31 land 16 banks after lanes 0..15
     __shared__ float tl[4 * TS];
     int cloud, blk;
     if (!decode_block(bpc, N, cloud, blk)) return;
     const int tid = threadIdx.x;
+    const int n = rows_of(src_rows, cloud, n_full), m = max(rows_of(tgt_rows, cloud, m_full), 1);
+    const int m_pad = min((m + KNN_PAD - 1) / KNN_PAD * KNN_PAD, m_pad_full);
+    if (blk * (BLOCK / WAVE) * (16 * NB) >= n) return;     // (block-uniform)
     const int lane = tid & (WAVE - 1), wave = tid >> 6;
     const int ql = lane & 15, kq = lane >> 4;
     const int qwave = (blk * (BLOCK / WAVE) + wave) * (16 * NB);
@@ -727,7 +747,7 @@ __global__ __launch_bounds__(BLOCK) void knn_mfma_kernel(const float* __restrict
         const int i = qwave + nb * 16 + ql;
         float p[3] = {0.f, 0.f, 0.f};
         if (i < n) {
-            const float* sp = src + ((size_t)cloud * n + i) * 3;
+            const float* sp = src + ((size_t)cloud * n_full + i) * 3;
             p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2];
         }
         query_point(C, r, p, nx[nb]);
@@ -736,7 +756,7 @@ __global__ __launch_bounds__(BLOCK) void knn_mfma_kernel(const float* __restrict
         bt[nb] = 0;
     }
 
-    const float4* __restrict__ tg = tgt4 + (size_t)cloud * m_pad;
+    const float4* __restrict__ tg = tgt4 + (size_t)cloud * m_pad_full;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     for (int base = 0; base < m_pad; base += TILE) {
         const int len = min(TILE, m_pad - base);            // multiple of 16
@@ -790,7 +810,7 @@ __global__ __launch_bounds__(BLOCK) void knn_mfma_kernel(const float* __restrict
             const int oj = __shfl_xor(bj, off);
             if (ov < bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
         }
-        if (kq == 0 && i < n) idx[(size_t)cloud * n + i] = min(bj, m - 1);
+        if (kq == 0 && i < n) idx[(size_t)cloud * n_full + i] = min(bj, m - 1);
     }
 }
 
@@ -828,7 +848,8 @@ __global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? SWEE
                                                           const int32_t* __restrict__ bucket, const T* __restrict__ brange, int nbkt,
                                                           int32_t* __restrict__ idx, int32_t* __restrict__ spos,
                                                           unsigned long long* __restrict__ pairs,
-                                                          int N, int n, int m, int m_pad, int bpc, int src_sorted) {
+                                                          int N, int n_full, int m_full, int m_pad, int bpc, int src_sorted,
+                                                          const int32_t* __restrict__ src_rows, const int32_t* __restrict__ tgt_rows) {
     using T4 = typename V4<T>::type;
     // each wave keeps the last NT tiles it scored in a ring: near the pose that is the whole visited range, and the
     // epilogue then re-scores the winning chunk out of LDS instead of gathering its rows (Q x CH 16-byte gathers per lane)
@@ -838,6 +859,8 @@ __global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? SWEE
     if (!decode_block(bpc, N, cloud, blk)) return;
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
     const int unit = blk * (BLOCK / WAVE) + wave;           // 64*Q consecutive sorted queries
+    // ragged batches: this cloud's own lengths.  Its queries are the first n slots of qorder, its targets the first m sorted rows
+    const int n = rows_of(src_rows, cloud, n_full), m = max(rows_of(tgt_rows, cloud, m_full), 1);
     const bool idle_wave = unit * (WAVE * Q) >= n;
     if (idle_wave) return;                                  // whole wave idle (no block-level sync anywhere below)
     T C[9], r[3];
@@ -855,8 +878,8 @@ __global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? SWEE
         qi[q] = -1; mi[q] = 0;
         T p[3] = {T(0), T(0), T(0)};
         if (pos < n) {
-            qi[q] = qorder ? qorder[(size_t)cloud * n + pos] : pos;
-            const T* sp = src + ((size_t)cloud * n + (src_sorted ? pos : qi[q])) * 3;      // src_sorted: rows already in slot order
+            qi[q] = qorder ? qorder[(size_t)cloud * n_full + pos] : pos;
+            const T* sp = src + ((size_t)cloud * n_full + (src_sorted ? pos : qi[q])) * 3;      // src_sorted: rows already in slot order
             p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2];
         }
         query_point(C, r, p, nx[q]);
@@ -878,7 +901,7 @@ __global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? SWEE
     }
 
     const T4* __restrict__ tg = tgs4 + (size_t)cloud * m_pad;
-    const int ntiles = m_pad / WAVE;
+    const int ntiles = min((m + WAVE - 1) / WAVE, m_pad / WAVE);      // (the sorted rows past m are pad rows)
     // start under the wave's middle query: coarse bucket table of lower_bound positions (built once per call)
     const T xc = __shfl(xq[Q / 2], WAVE / 2);
     const T xlo = brange[(size_t)cloud * 2], inv = brange[(size_t)cloud * 2 + 1];
@@ -1009,177 +1032,69 @@ __global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? SWEE
         }
         if (bo < 0) bo = pm[bs];                            // (0x7fffffff: nothing finite was seen)
         mi[q] = (bo == 0x7fffffff) ? 0 : min(max(bo, 0), m - 1);
-        idx[(size_t)cloud * n + qi[q]] = mi[q];
+        idx[(size_t)cloud * n_full + qi[q]] = mi[q];
         // sorted position of the winner (indexed like idx, by the query): what the windowed backward consumes
-        if (spos) spos[(size_t)cloud * n + qi[q]] = (bo == 0x7fffffff || bo >= m) ? -1 : bs;
+        if (spos) spos[(size_t)cloud * n_full + qi[q]] = (bo == 0x7fffffff || bo >= m) ? -1 : bs;
     }
     // sharded: one counter serialises ~12 ns per add, which at 65k waves would outlast the kernel itself
     if (pairs && lane == 0 && !idle_wave)
         atomicAdd(pairs + (blockIdx.x & (DICP_PAIR_SHARDS - 1)), (unsigned long long)(visR - visL) * WAVE * WAVE * Q);
 }
 
-// --------------------------------------------------------------- grid index / kNN (grid)
-// Exact 1-NN over a uniform 3-D grid of cells (the ICP default for big clouds).  The x-sorted sweep above prunes on ONE
-// coordinate: a wave scores every target of its queries' x slab -- 1.5 % of the pairs near the pose, 6 % before the first step,
-// 12 % on a dense blob, everything on a plane x = const.  A grid prunes on all three: a query looks at its own cell (a handful of
-// targets), and at a neighbouring cell only if that cell's box is nearer than the best match so far.
-//   per cloud, once per call (targets do not move):
-//     ginfo       grid geometry from robust sample quantiles of the (centred) target coordinates, ~GRID_PPC targets per cell
-//     tperm       targets in STABLE order of their cell id (cz, cy, cx: x fastest)    -- grid_sort_kernel (LSD radix, one block per cloud)
-//     cell_start  first sorted position of every cell (+ the end)
-//     tgs4/tgt_s  packed rows / full rows in that order                              -- sweep_rows_kernel, as for the sweep
-//   per iteration: knn_grid_kernel -- one query per lane, in the CALLER's order (no query ordering, coalesced index stores):
-//     rings of cells around the query's own, every (cy, cz) row of a ring is a run of consecutive sorted rows; a row / run is
-//     skipped when its box lies further than the best match so far, with the sweep's safety margin.  Same score(), same packed
-//     rows, same lowest-ORIGINAL-index rule on exact ties as every other search form => bit-identical indices.
-// Cells at the border of the grid are unbounded outwards (targets beyond the sampled quantiles are clamped into them), so
-// outliers cost pruning power in the border cells only, never correctness; a degenerate cloud (all targets in one cell)
-// degenerates to brute force.
-constexpr int GRID_PPC = 4;                 // targets per cell aimed at
-constexpr int GRID_MAX_CELLS = 32768;       // 15-bit cell ids; 0xffff = pad slot
-constexpr int GRID_INFO = DICP_GRID_INFO;   // T values per cloud: lo[3], inv[3], h[3], G[3], ncell, slack[3]
+// ------------------------------------------------------------- key sort beyond the LDS sort
+// Stable sort of a cloud's target x keys for clouds sort_keys_kernel cannot take: float64 keys, or more than 16384 slots.
+// One block of 1024 threads per cloud, LSD radix over the order-preserving bit pattern of the key (4 or 8 digits of 8
+// bits), keys and indices in global ping-pong buffers from the caller's scratch.  A pass = digit histogram of all M slots,
+// then the slots chunk by chunk (16384 at a time, in order): per wave and round the ballot ranking of sort_keys_kernel,
+// wave counts scanned per digit, scatter to base[digit] + offset; the bases advance from chunk to chunk, so equal keys
+// keep their index order across chunks too.  (Written for the cell ids of the grid search experiment of round 2,
+// profiles/r02_grid_knn_experiment.txt; with it no torch.sort is left on the ICP path.)
 constexpr int GS_THREADS = 1024, GS_PER = 16, GS_CHUNK = GS_THREADS * GS_PER;
-
-__host__ __device__ inline int grid_cells_max(int m) {
-    long c = (long)(m > 0 ? m : 1) / GRID_PPC + 8;
-    return (int)(c > GRID_MAX_CELLS ? GRID_MAX_CELLS : c);
-}
+template <typename T> struct SortKey;
+template <> struct SortKey<float> {
+    using type = unsigned;
+    static __device__ __forceinline__ unsigned of(float x) { return sortable_bits(x); }
+    static __device__ __forceinline__ float back(unsigned u) { u ^= (u >> 31) ? 0x80000000u : 0xffffffffu; return __uint_as_float(u); }
+};
+template <> struct SortKey<double> {
+    using type = unsigned long long;
+    static __device__ __forceinline__ unsigned long long of(double x) {
+        unsigned long long u = (unsigned long long)__double_as_longlong(x + 0.0);      // -0 sorts as +0
+        u ^= (u >> 63) ? ~0ull : 0x8000000000000000ull;
+        return x != x ? ~0ull : u;                                                     // NaN of either sign sorts last
+    }
+    static __device__ __forceinline__ double back(unsigned long long u) { u ^= (u >> 63) ? 0x8000000000000000ull : ~0ull; return __longlong_as_double((long long)u); }
+};
 
 template <typename T>
-__global__ __launch_bounds__(GS_THREADS) void grid_info_kernel(const T* __restrict__ tgt, int c, int m, const int32_t* __restrict__ tgt_rows,
-                                                               const T* __restrict__ center, int ncell_max, T* __restrict__ ginfo) {
-    __shared__ unsigned key[3][GS_THREADS];
-    __shared__ int nfin[3];
-    const int cloud = blockIdx.x, tid = threadIdx.x;
-    const int mc = tgt_rows ? min(max(tgt_rows[cloud], 1), m) : m;
-    const T* __restrict__ rows = tgt + (size_t)cloud * m * c;
-    const int step = (mc + GS_THREADS - 1) / GS_THREADS, ms = (mc + step - 1) / step;
-    if (tid < 3) nfin[tid] = 0;
-    __syncthreads();
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        unsigned u = 0xffffffffu;                               // unused / non-finite samples sort last
-        if (tid < ms) {
-            const float v = (float)(rows[(size_t)tid * step * c + a] - (center ? center[(size_t)cloud * 3 + a] : T(0)));
-            if (v == v && fabsf(v) < 3.0e38f) { u = sortable_bits(v); atomicAdd(&nfin[a], 1); }
-        }
-        key[a][tid] = u;
-    }
-    __syncthreads();
-    for (int k = 2; k <= GS_THREADS; k <<= 1)                   // bitonic sort of the three axes side by side
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const int p = tid ^ j;
-            if (p > tid) {
-                const bool up = (tid & k) == 0;
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    const unsigned x = key[a][tid], y = key[a][p];
-                    if ((x > y) == up) { key[a][tid] = y; key[a][p] = x; }
-                }
-            }
-            __syncthreads();
-        }
-    if (tid == 0) {
-        double lo[3], hi[3], e[3];
-        int flat = 0;
-        double vol = 1.0;
-        for (int a = 0; a < 3; ++a) {
-            const int nf = nfin[a];
-            auto val = [&](int i) { unsigned u = key[a][i]; u ^= (u >> 31) ? 0x80000000u : 0xffffffffu; return (double)__uint_as_float(u); };
-            if (nf <= 0) { lo[a] = hi[a] = 0.0; }
-            else {
-                const int q = nf / 64;                          // the 1/64 and 63/64 sample quantiles, widened by 1/16 of their span:
-                const double a0 = val(q), a1 = val(nf - 1 - q); // a uniform cloud is covered, a stray return does not stretch the grid
-                const double pad = (a1 - a0) / 16.0;
-                lo[a] = a0 - pad; hi[a] = a1 + pad;
-            }
-            e[a] = hi[a] - lo[a];
-            const double scale = fmax(fmax(fabs(lo[a]), fabs(hi[a])), 1e-30);
-            if (!(e[a] > 1e-9 * scale)) { e[a] = 0.0; ++flat; } else vol *= e[a];
-        }
-        int G[3] = {1, 1, 1};
-        const int d = 3 - flat;
-        double want = (double)mc / GRID_PPC;
-        want = want < 1.0 ? 1.0 : (want > (double)ncell_max ? (double)ncell_max : want);
-        if (d > 0) {
-            const double h = pow(vol / want, 1.0 / d);
-            for (int a = 0; a < 3; ++a)
-                if (e[a] > 0.0) { const double g = ceil(e[a] / h); G[a] = g < 1.0 ? 1 : (g > 1024.0 ? 1024 : (int)g); }
-            while ((long)G[0] * G[1] * G[2] > ncell_max) {      // (rounding up may overshoot: shrink the largest count)
-                int a = G[0] >= G[1] ? (G[0] >= G[2] ? 0 : 2) : (G[1] >= G[2] ? 1 : 2);
-                G[a] = G[a] > 1 ? G[a] - 1 : 1;
-            }
-        }
-        T* o = ginfo + (size_t)cloud * GRID_INFO;
-        for (int a = 0; a < 3; ++a) {
-            const double h = G[a] > 0 && e[a] > 0.0 ? e[a] / G[a] : 0.0;
-            o[a] = (T)lo[a];
-            o[3 + a] = (T)(h > 0.0 ? 1.0 / h : 0.0);
-            o[6 + a] = (T)h;
-            o[9 + a] = (T)G[a];
-            // a target's cell comes from floor((y - lo) * inv) in T arithmetic: its box is trusted up to this slack
-            o[13 + a] = (T)((sizeof(T) == 4 ? 2e-5 : 1e-12) * (fabs(lo[a]) + fabs(hi[a]) + e[a]));
-        }
-        o[12] = (T)((long)G[0] * G[1] * G[2]);
-    }
-}
-
-template <typename T>
-__device__ __forceinline__ int grid_coord(T v, T lo, T inv, int G) {
-    const T f = (v - lo) * inv;
-    return (f > T(0)) ? (f < T(G) ? (int)f : G - 1) : 0;       // NaN and everything below lo -> 0, above hi -> G - 1
-}
-
-// Stable sort of a cloud's targets by cell id + the table of cell starts.  One block of 1024 threads per cloud, LSD radix,
-// two 8-bit digits.  A pass = digit histogram of all M slots, then the slots chunk by chunk (16384 at a time, in order): per
-// wave and round the ballot ranking of sort_keys_kernel, wave counts scanned per digit, scatter to base[digit] + offset.
-// BIG = false (M <= 16384): keys and indices live in LDS, one buffer, the chunk is in registers between its read and its
-// write.  BIG = true: global ping-pong buffers from the caller's scratch.
-template <typename T, bool BIG>
-__global__ __launch_bounds__(GS_THREADS) void grid_sort_kernel(const T* __restrict__ tgt, int c, int m, int m_pad, const int32_t* __restrict__ tgt_rows,
-                                                               const T* __restrict__ center, const T* __restrict__ ginfo, int cs_stride,
-                                                               int32_t* __restrict__ tperm, int32_t* __restrict__ cell_start,
-                                                               unsigned short* __restrict__ gkey /* BIG: (N,2,m_pad) */, int32_t* __restrict__ gidx /* BIG: (N,2,m_pad) */) {
-    constexpr int LN = BIG ? 1 : GS_CHUNK;
-    __shared__ unsigned short lkey[LN];
-    __shared__ unsigned short lidx[LN];
+__global__ __launch_bounds__(GS_THREADS) void sort_keys_big_kernel(const T* __restrict__ tgt, int c, int m_full, int m_pad, const T* __restrict__ center, const int32_t* __restrict__ tgt_rows,
+                                                                   T* __restrict__ keys_sorted, int32_t* __restrict__ tperm,
+                                                                   typename SortKey<T>::type* __restrict__ gkey /* (N,2,m_pad) */, int32_t* __restrict__ gidx /* (N,2,m_pad) */) {
+    using KT = typename SortKey<T>::type;
     __shared__ int cnt[GS_THREADS / WAVE][256];
     __shared__ int base[256], ctot[256];
     const int cloud = blockIdx.x, tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
-    const int mc = tgt_rows ? min(max(tgt_rows[cloud], 0), m) : m;
-    const T* __restrict__ rows = tgt + (size_t)cloud * m * c;
-    const T* gi = ginfo + (size_t)cloud * GRID_INFO;
-    const T lo0 = gi[0], lo1 = gi[1], lo2 = gi[2], in0 = gi[3], in1 = gi[4], in2 = gi[5];
-    const int G0 = (int)gi[9], G1 = (int)gi[10], G2 = (int)gi[11], ncell = (int)gi[12];
-    T ctr[3] = {T(0), T(0), T(0)};
-    if (center) { ctr[0] = center[(size_t)cloud * 3]; ctr[1] = center[(size_t)cloud * 3 + 1]; ctr[2] = center[(size_t)cloud * 3 + 2]; }
-    unsigned short* kbuf[2];
-    int32_t* ibuf[2];
-    if (BIG) {
-        kbuf[0] = gkey + (size_t)cloud * 2 * m_pad; kbuf[1] = kbuf[0] + m_pad;
-        ibuf[0] = gidx + (size_t)cloud * 2 * m_pad; ibuf[1] = ibuf[0] + m_pad;
-    }
-    auto cell_of = [&](int j) -> unsigned {
-        if (j >= mc) return 0xffffu;                            // pad slots: after every real row
-        const T* y = rows + (size_t)j * c;
-        const int cx = grid_coord(y[0] - ctr[0], lo0, in0, G0), cy = grid_coord(y[1] - ctr[1], lo1, in1, G1), cz = grid_coord(y[2] - ctr[2], lo2, in2, G2);
-        return (unsigned)((cz * G1 + cy) * G0 + cx);
-    };
-    // pass-0 input: the computed ids in slot order
+    const T* __restrict__ rows = tgt + (size_t)cloud * m_full * c;
+    const int m = rows_of(tgt_rows, cloud, m_full);
+    const T cx = center ? center[(size_t)cloud * 3] : T(0);
+    KT* kbuf[2] = {gkey + (size_t)cloud * 2 * m_pad, gkey + (size_t)cloud * 2 * m_pad + m_pad};
+    int32_t* ibuf[2] = {gidx + (size_t)cloud * 2 * m_pad, gidx + (size_t)cloud * 2 * m_pad + m_pad};
+    // pass-0 input: the keys in slot order; pad slots keep the largest key there is (after every real row, NaN rows included)
     for (int j = tid; j < m_pad; j += GS_THREADS) {
-        const unsigned k = cell_of(j);
-        if (BIG) { kbuf[0][j] = (unsigned short)k; ibuf[0][j] = j; } else { lkey[j] = (unsigned short)k; lidx[j] = (unsigned short)j; }
+        kbuf[0][j] = j < m ? SortKey<T>::of(center ? rows[(size_t)j * c] - cx : rows[(size_t)j * c]) : ~(KT)0;
+        ibuf[0][j] = j;
     }
     __syncthreads();
-    for (int pass = 0; pass < 2; ++pass) {
+    constexpr int PASSES = (int)sizeof(KT);
+    for (int pass = 0; pass < PASSES; ++pass) {
         const int shift = pass * 8;
-        const unsigned short* kin = BIG ? kbuf[pass & 1] : lkey;
-        unsigned short* kout = BIG ? kbuf[(pass & 1) ^ 1] : lkey;
-        const int32_t* iin_g = BIG ? ibuf[pass & 1] : nullptr;
-        int32_t* iout_g = BIG ? ibuf[(pass & 1) ^ 1] : nullptr;
+        const KT* kin = kbuf[pass & 1];
+        KT* kout = kbuf[(pass & 1) ^ 1];
+        const int32_t* iin = ibuf[pass & 1];
+        int32_t* iout = ibuf[(pass & 1) ^ 1];
         if (tid < 256) base[tid] = 0;
         __syncthreads();
-        for (int j = tid; j < m_pad; j += GS_THREADS) atomicAdd(&base[(kin[j] >> shift) & 0xff], 1);
+        for (int j = tid; j < m_pad; j += GS_THREADS) atomicAdd(&base[(unsigned)(kin[j] >> shift) & 0xffu], 1);
         __syncthreads();
         if (tid < WAVE) {                                       // exclusive scan of the 256 digit totals (4 per lane)
             int v[4], s = 0;
@@ -1194,7 +1109,7 @@ __global__ __launch_bounds__(GS_THREADS) void grid_sort_kernel(const T* __restri
         }
         __syncthreads();
         for (int c0 = 0; c0 < m_pad; c0 += GS_CHUNK) {
-            unsigned key[GS_PER];
+            KT key[GS_PER];
             int idx[GS_PER], rank[GS_PER];
             for (int d = lane; d < 256; d += WAVE) cnt[wave][d] = 0;
             __builtin_amdgcn_wave_barrier();
@@ -1202,9 +1117,9 @@ __global__ __launch_bounds__(GS_THREADS) void grid_sort_kernel(const T* __restri
             for (int e = 0; e < GS_PER; ++e) {                  // striped: position = c0 + wave * 1024 + e * 64 + lane
                 const int pos = c0 + wave * (WAVE * GS_PER) + e * WAVE + lane;
                 const bool on = pos < m_pad;
-                key[e] = on ? (unsigned)kin[pos] : 0u;
-                idx[e] = on ? (BIG ? iin_g[pos] : (int)lidx[pos]) : -1;
-                const unsigned d = on ? ((key[e] >> shift) & 0xffu) : 0x100u;       // 0x100: no slot here
+                key[e] = on ? kin[pos] : (KT)0;
+                idx[e] = on ? iin[pos] : -1;
+                const unsigned d = on ? ((unsigned)(key[e] >> shift) & 0xffu) : 0x100u;     // 0x100: no slot here
                 unsigned long long same = __ballot(on);
                 if (!on) same = ~same;
 #pragma unroll
@@ -1219,7 +1134,7 @@ __global__ __launch_bounds__(GS_THREADS) void grid_sort_kernel(const T* __restri
                 __builtin_amdgcn_wave_barrier();
                 rank[e] = bs + below;
             }
-            __syncthreads();                                    // (all reads of this chunk are done: kout may alias kin)
+            __syncthreads();
             if (tid < 256) {
                 int s = 0;
                 for (int w = 0; w < GS_THREADS / WAVE; ++w) { const int v = cnt[w][tid]; cnt[w][tid] = s; s += v; }
@@ -1229,184 +1144,20 @@ __global__ __launch_bounds__(GS_THREADS) void grid_sort_kernel(const T* __restri
 #pragma unroll
             for (int e = 0; e < GS_PER; ++e) {
                 if (idx[e] < 0) continue;
-                const unsigned d = (key[e] >> shift) & 0xffu;
+                const unsigned d = (unsigned)(key[e] >> shift) & 0xffu;
                 const int pos = base[d] + cnt[wave][d] + rank[e];
-                kout[pos] = (unsigned short)key[e];
-                if (BIG) iout_g[pos] = idx[e]; else lidx[pos] = (unsigned short)idx[e];
+                kout[pos] = key[e];
+                iout[pos] = idx[e];
             }
             __syncthreads();
             if (tid < 256) base[tid] += ctot[tid];
             __syncthreads();
         }
     }
-    // two passes: the result is back in buffer 0
-    const unsigned short* ks = BIG ? kbuf[0] : lkey;
-    for (int s = tid; s < m_pad; s += GS_THREADS)           // slots past the cloud's real rows: m (no row)
-        tperm[(size_t)cloud * m_pad + s] = s < mc ? (BIG ? ibuf[0][s] : (int32_t)lidx[s]) : m;
-    int32_t* cs = cell_start + (size_t)cloud * cs_stride;
-    for (int s = tid; s <= m_pad; s += GS_THREADS) {            // cell_start[k] = first sorted slot whose id is >= k, for k = 0 .. ncell
-        const int cur = s < m_pad ? min((int)ks[s], ncell) : ncell;
-        const int prev = s > 0 ? min((int)ks[s - 1], ncell) : -1;
-        for (int k = prev + 1; k <= cur; ++k) cs[k] = s < mc ? s : mc;
-    }
-}
-
-// The search itself.  One query per lane, in the caller's order.  A lane's work is a chain of dependent memory round trips
-// (cell -> table -> rows -> bound -> next cell), and with 8 waves per SIMD in flight the kernel's time is simply
-// (waves / 8192) x (round trips per wave) x ~0.7 us -- so the kernel is organised to make few of them.  Per ring of cells:
-//   phase 1 (no memory): the (cz, cy) rows of the ring and their x runs whose boxes can still hold a nearer target are
-//            collected -- first cell, last cell + 1, the box's lower bound -- into a short per-lane list in LDS;
-//   phase 2: ALL table look-ups of the list in one round of loads, then the rows of each entry eight at a time.
-// The wave waits for memory once per list position and batch, not once per cell it ever enumerated (which lane passes where
-// differs from lane to lane).  Measured at the benchmark shape, near the pose (7 pairs per query): depth-first search (bound,
-// table, row, row, ..., next cell) 0.33 ms; lists + table in LDS, 2 waves per SIMD: 0.66 ms.
-constexpr int KG_THREADS = 256;
-#ifndef DICP_KG_RUNS
-#define DICP_KG_RUNS 6
-#endif
-#ifndef DICP_KG_ROWS
-#define DICP_KG_ROWS 8
-#endif
-#ifndef DICP_KG_MINW
-#define DICP_KG_MINW 1
-#endif
-constexpr int KG_RUNS = DICP_KG_RUNS;       // list entries per lane (a full list is worked off, then collection goes on)
-constexpr int KG_ROWS = DICP_KG_ROWS;       // rows in flight per lane
-
-template <typename T>
-__global__ __launch_bounds__(KG_THREADS, DICP_KG_MINW) void knn_grid_kernel(const T* __restrict__ src, const T* __restrict__ pose,
-                                                         const typename V4<T>::type* __restrict__ tgs4, const int32_t* __restrict__ tperm,
-                                                         const int32_t* __restrict__ cell_start, int cs_stride, const T* __restrict__ ginfo,
-                                                         const int32_t* __restrict__ src_rows, int32_t* __restrict__ idx, int32_t* __restrict__ spos,
-                                                         unsigned long long* __restrict__ pairs, int N, int n, int m, int m_pad, int bpc) {
-    using T4 = typename V4<T>::type;
-    __shared__ int run_a[KG_RUNS][KG_THREADS], run_b[KG_RUNS][KG_THREADS];
-    __shared__ float run_lb[KG_RUNS][KG_THREADS];
-    int cloud, blk;
-    if (!decode_block(bpc, N, cloud, blk)) return;
-    const int tid = threadIdx.x;
-    const int i = blk * KG_THREADS + tid;
-    const int nc = src_rows ? min(max(src_rows[cloud], 0), n) : n;
-    const bool live = i < nc;
-    const T* gi = ginfo + (size_t)cloud * GRID_INFO;
-    const T lo[3] = {gi[0], gi[1], gi[2]}, inv[3] = {gi[3], gi[4], gi[5]}, h[3] = {gi[6], gi[7], gi[8]};
-    const int G[3] = {(int)gi[9], (int)gi[10], (int)gi[11]};
-    const T slack[3] = {gi[13], gi[14], gi[15]};
-    const int32_t* __restrict__ cs = cell_start + (size_t)cloud * cs_stride;
-    T C[9], r[3];
-    load_pose(pose, cloud, C, r);
-    T p[3] = {T(0), T(0), T(0)};
-    if (live) { const T* sp = src + ((size_t)cloud * n + i) * 3; p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2]; }
-    T nx[3];
-    query_point(C, r, p, nx);                               // ICP.py:137
-    const T x[3] = {-nx[0], -nx[1], -nx[2]};
-    const T hx = T(0.5) * (x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
-    int cq[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) cq[a] = grid_coord(x[a], lo[a], inv[a], G[a]);
-    const T4* __restrict__ tg = tgs4 + (size_t)cloud * m_pad;
-    const int32_t* __restrict__ pm = tperm + (size_t)cloud * m_pad;
-    T best = inf_v<T>(), thr = inf_v<T>();                  // thr: half squared distance beyond which nothing can beat `best`
-    int bs = -1, bo = -1, scored = 0;
-    // outer faces of cell k along axis a, unbounded at the border of the grid, widened by the assignment slack
-    auto face_lo = [&](int a, int k) { return k <= 0 ? -inf_v<T>() : fma_t(T(k), h[a], lo[a]) - slack[a]; };
-    auto face_hi = [&](int a, int k) { return k >= G[a] - 1 ? inf_v<T>() : fma_t(T(k + 1), h[a], lo[a]) + slack[a]; };
-    auto gap = [&](int a, int k0, int k1) {                 // distance along axis a from the query to the cells k0..k1
-        const T d0 = face_lo(a, k0) - x[a], d1 = x[a] - face_hi(a, k1);
-        const T d = d0 > d1 ? d0 : d1;
-        return d > T(0) ? d : T(0);
-    };
-    int nrun = 0;
-    auto work_off = [&]() {                                 // phase 2 for this lane's list
-        {   // every table look-up of the list in ONE round of loads
-            int a[KG_RUNS], b[KG_RUNS];
-#pragma unroll
-            for (int j = 0; j < KG_RUNS; ++j) {
-                const bool on = j < nrun;
-                a[j] = cs[on ? run_a[j][tid] : 0];
-                b[j] = cs[on ? run_b[j][tid] : 0];
-            }
-#pragma unroll
-            for (int j = 0; j < KG_RUNS; ++j) { run_a[j][tid] = a[j]; run_b[j][tid] = b[j]; }
-        }
-        for (int j = 0; j < nrun; ++j) {
-            if ((T)run_lb[j][tid] > thr) continue;          // (the best match has moved since the entry was made)
-            const int s1 = run_b[j][tid];
-            for (int s = run_a[j][tid]; s < s1; s += KG_ROWS) {
-                T4 y[KG_ROWS];
-#pragma unroll
-                for (int k = 0; k < KG_ROWS; ++k) y[k] = tg[min(s + k, s1 - 1)];
-#pragma unroll
-                for (int k = 0; k < KG_ROWS; ++k) {
-                    const T sc = (s + k < s1) ? score<T, T4>(nx, y[k]) : inf_v<T>();
-                    if (sc < best) {
-                        best = sc; bs = s + k; bo = -1;
-                    } else if (sc == best && sc < inf_v<T>()) {      // exact tie: the lowest ORIGINAL index wins
-                        if (bo < 0) bo = pm[bs];
-                        const int o = pm[s + k];
-                        if (o < bo) { bo = o; bs = s + k; }
-                    }
-                }
-                scored += min(KG_ROWS, s1 - s);
-                thr = (best + hx) + SweepEps<T>::v * (T(1) + m_abs(best) + hx);
-            }
-        }
-        nrun = 0;
-    };
-    const int rmax = max(max(G[0], G[1]), G[2]);
-    for (int ring = 0; live && ring <= rmax; ++ring) {
-        const int z0 = max(cq[2] - ring, 0), z1 = min(cq[2] + ring, G[2] - 1);
-        for (int cz = z0; cz <= z1; ++cz) {
-            const T ez = gap(2, cz, cz);
-            const T hz = T(0.5) * ez * ez;
-            if (hz > thr) continue;
-            const bool zedge = cz == cq[2] - ring || cz == cq[2] + ring;
-            const int y0 = max(cq[1] - ring, 0), y1 = min(cq[1] + ring, G[1] - 1);
-            for (int cy = y0; cy <= y1; ++cy) {
-                const T ey = gap(1, cy, cy);
-                const T hy = fma_t(T(0.5) * ey, ey, hz);
-                if (hy > thr) continue;
-                const bool edge = zedge || cy == cq[1] - ring || cy == cq[1] + ring;
-                const int row = (cz * G[1] + cy) * G[0];
-                // on the shell's faces the whole x run of the ring, inside it only the two end cells
-                for (int part = 0; part < (edge ? 1 : 2); ++part) {
-                    int xa, xb;
-                    if (edge) { xa = max(cq[0] - ring, 0); xb = min(cq[0] + ring, G[0] - 1); }
-                    else { xa = xb = part == 0 ? cq[0] - ring : cq[0] + ring; if (xa < 0 || xa > G[0] - 1) continue; }
-                    const T ex = gap(0, xa, xb);
-                    const T lb = fma_t(T(0.5) * ex, ex, hy);
-                    if (lb > thr) continue;
-                    if (nrun == KG_RUNS) work_off();
-                    run_a[nrun][tid] = row + xa; run_b[nrun][tid] = row + xb + 1;
-                    run_lb[nrun][tid] = (float)lb * 0.999999f;      // (rounded down: the re-check must never be stricter)
-                    ++nrun;
-                }
-            }
-        }
-        work_off();
-        // everything inside the block of cells within `ring` of the query's has been scored or ruled out: done when the
-        // block covers the grid, or when its nearest outer face is further than the best match
-        bool covered = true;
-        T dout = inf_v<T>();
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            if (cq[a] - ring > 0) { covered = false; const T d = x[a] - fma_t(T(cq[a] - ring), h[a], lo[a]) - slack[a]; dout = d < dout ? d : dout; }
-            if (cq[a] + ring < G[a] - 1) { covered = false; const T d = fma_t(T(cq[a] + ring + 1), h[a], lo[a]) - x[a] - slack[a]; dout = d < dout ? d : dout; }
-        }
-        if (covered) break;
-        dout = dout > T(0) ? dout : T(0);
-        if (T(0.5) * dout * dout > thr) break;
-    }
-    if (live) {
-        if (bs >= 0 && bo < 0) bo = pm[bs];
-        const bool none = bs < 0 || bo < 0 || bo >= m;
-        idx[(size_t)cloud * n + i] = none ? 0 : bo;
-        if (spos) spos[(size_t)cloud * n + i] = none ? -1 : bs;
-    }
-    if (pairs) {
-#pragma unroll
-        for (int off = WAVE / 2; off > 0; off >>= 1) scored += __shfl_xor(scored, off);
-        if ((tid & (WAVE - 1)) == 0 && scored) atomicAdd(pairs + (blockIdx.x & (DICP_PAIR_SHARDS - 1)), (unsigned long long)scored);
+    // an even number of passes: the result is back in buffer 0
+    for (int s = tid; s < m_pad; s += GS_THREADS) {
+        keys_sorted[(size_t)cloud * m_pad + s] = SortKey<T>::back(kbuf[0][s]);
+        tperm[(size_t)cloud * m_pad + s] = ibuf[0][s];
     }
 }
 
@@ -1512,7 +1263,7 @@ __global__ __launch_bounds__(BLOCK) void accumulate_kernel(WeightParams P, const
                                                            const int32_t* __restrict__ idx, const T* __restrict__ pose,
                                                            const T* __restrict__ w_init, const T* __restrict__ alive,
                                                            int N, int n, int m, int bpc, T* __restrict__ partials,
-                                                           T* __restrict__ w_out, long w_stride) {
+                                                           T* __restrict__ w_out, long w_stride, const int32_t* __restrict__ src_rows) {
     __shared__ T red[(BLOCK / WAVE) * NACC_PAD];
     int cloud, blk;
     if (!decode_block(bpc, N, cloud, blk)) return;
@@ -1522,7 +1273,10 @@ __global__ __launch_bounds__(BLOCK) void accumulate_kernel(WeightParams P, const
     T acc[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = T(0);
-    const int end = min(n, (blk + 1) * ACC_PTS);
+    const int nc = rows_of(src_rows, cloud, n);             // ragged batches: rows past the cloud's own carry weight 0 (ICP.py:386-398)
+    if (w_out)                                              // ... which is what the weight history reports for them
+        for (int i = max(blk * ACC_PTS, nc) + threadIdx.x; i < min(n, (blk + 1) * ACC_PTS); i += BLOCK) w_out[(size_t)cloud * w_stride + i] = T(0);
+    const int end = min(nc, (blk + 1) * ACC_PTS);
     for (int i = blk * ACC_PTS + threadIdx.x; i < end; i += BLOCK) {       // (2 or 4 points in flight per thread measured slower: 78 / 85 vs 72 us)
         const size_t pt = (size_t)cloud * n + i;
         const T* sp = src + pt * 3;
@@ -1654,9 +1408,11 @@ __global__ __launch_bounds__(BLOCK) void icp_small_forward_kernel(WeightParams P
     extern __shared__ __align__(32) unsigned char small_lds[];
     T4* tg = reinterpret_cast<T4*>(small_lds);
     __shared__ T red[(BLOCK / WAVE) * NACC_PAD];
-    const int cloud = blockIdx.x, tid = threadIdx.x, m_pad = B.m_pad, c = B.c;
+    const int cloud = blockIdx.x, tid = threadIdx.x, c = B.c;
+    const int nc = rows_of(B.src_rows, cloud, n), mc = max(rows_of(B.tgt_rows, cloud, m), 1);
+    const int m_pad = min((mc + KNN_PAD - 1) / KNN_PAD * KNN_PAD, B.m_pad);     // ragged batches: the cloud's own rows only
     {
-        const T4* __restrict__ g = (const T4*)B.tgt4 + (size_t)cloud * m_pad;
+        const T4* __restrict__ g = (const T4*)B.tgt4 + (size_t)cloud * B.m_pad;
         for (int j = tid; j < m_pad; j += BLOCK) tg[j] = g[j];
     }
     __syncthreads();
@@ -1674,7 +1430,8 @@ __global__ __launch_bounds__(BLOCK) void icp_small_forward_kernel(WeightParams P
         T acc[NACC];
 #pragma unroll
         for (int a = 0; a < NACC; ++a) acc[a] = T(0);
-        for (int i = tid; i < n; i += BLOCK) {
+        for (int i = nc + tid; i < n; i += BLOCK) w_k[i] = T(0);
+        for (int i = tid; i < nc; i += BLOCK) {
             const T p[3] = {src[i * 3], src[i * 3 + 1], src[i * 3 + 2]};
             T nx[3];
             query_point(C, rs, p, nx);
@@ -1688,7 +1445,7 @@ __global__ __launch_bounds__(BLOCK) void icp_small_forward_kernel(WeightParams P
                 if (s2 < best) { best = s2; bj = j + 2; }
                 if (s3 < best) { best = s3; bj = j + 3; }
             }
-            bj = min(bj, m - 1);
+            bj = min(bj, mc - 1);
             idx_k[i] = bj;
             const T* yp = tgt + (size_t)bj * c;
             const T y[3] = {yp[0], yp[1], yp[2]};
@@ -1721,7 +1478,7 @@ __global__ __launch_bounds__(BLOCK) void accumulate_bwd_kernel(WeightParams P, c
                                                                const T* __restrict__ gs, const T* __restrict__ gb,
                                                                int N, int n, int m, int bpc,
                                                                T* __restrict__ gsrc, T* __restrict__ gtgt, T* __restrict__ gw,
-                                                               T* __restrict__ bwd_partials) {
+                                                               T* __restrict__ bwd_partials, const int32_t* __restrict__ src_rows) {
     constexpr int CV = (MODE == MODE_PT2PL) ? 6 : 3;        // gradient columns per target row
     __shared__ T red[(BLOCK / WAVE) * NBWD_PAD];
     __shared__ T stage_v[(BLOCK / WAVE) * WAVE * CV];
@@ -1742,7 +1499,7 @@ __global__ __launch_bounds__(BLOCK) void accumulate_bwd_kernel(WeightParams P, c
     T* sv = stage_v + wave * (WAVE * CV);
     int* sj = stage_j + wave * WAVE;
     T* grow = gtgt ? gtgt + (size_t)cloud * m * c : nullptr;
-    const int end = min(n, (blk + 1) * ACC_PTS);
+    const int end = min(rows_of(src_rows, cloud, n), (blk + 1) * ACC_PTS);     // (rows past the cloud's own: weight 0, no gradient)
     for (int base = blk * ACC_PTS; base < end; base += BLOCK) {     // trip count is block-uniform
         const int i = base + tid;
         const bool on = i < end;
@@ -1811,8 +1568,8 @@ __host__ __device__ inline int window_slots(int WT, int n, int m_pad) {
 // first sorted row of block blk's window: centred on the reference neighbour of the block's middle slot
 // (robust against outliers at the ends), a multiple of 16 rows
 __device__ __forceinline__ int window_origin(const int32_t* __restrict__ sp_ref_c, const int32_t* __restrict__ qo_c,
-                                             int blk, int spb, int n, int m_pad, int WT) {
-    if (m_pad <= WT) return 0;
+                                             int blk, int spb, int n, int m_pad, int WT) {      // n: the cloud's own slots
+    if (m_pad <= WT || n <= 0) return 0;
     const int mid = min(blk * spb + spb / 2, n - 1);
     const int ctr = max(sp_ref_c[qo_c ? min(max(qo_c[mid], 0), n - 1) : mid], 0);
     return min(max(ctr - WT / 2, 0), m_pad - WT) & ~15;
@@ -1827,7 +1584,7 @@ __global__ __launch_bounds__(BLOCK) void accumulate_bwd_window_kernel(WeightPara
                                                                       int N, int n, int m_pad, int spb, int bpc,
                                                                       T* __restrict__ gsrc_s, T* __restrict__ slab /* (N,bpc,WT,CV) */,
                                                                       T* __restrict__ gts_far /* (N,m_pad,CV) */,
-                                                                      T* __restrict__ gw_s, T* __restrict__ bwd_partials) {
+                                                                      T* __restrict__ gw_s, T* __restrict__ bwd_partials, const int32_t* __restrict__ src_rows) {
     // overwrite: first launch into uninitialised accumulators -- gsrc_s / gw_s / the slab windows are written, not added to
     constexpr int CV = (MODE == MODE_PT2PL) ? 6 : 3;
     __shared__ T red[(BLOCK / WAVE) * NBWD_PAD];
@@ -1837,7 +1594,8 @@ __global__ __launch_bounds__(BLOCK) void accumulate_bwd_window_kernel(WeightPara
     int cloud, blk;
     if (!decode_block(bpc, N, cloud, blk)) return;
     const int tid = threadIdx.x;
-    const int s0 = blk * spb, s1 = min(n, s0 + spb);
+    const int nc = rows_of(src_rows, cloud, n);             // ragged batches: slots past the cloud's own carry weight 0: no work, zero gradient
+    const int s0 = blk * spb, s1 = min(nc, s0 + spb), s1_all = min(n, s0 + spb);
     const int32_t* __restrict__ sp_c = spos + (size_t)cloud * n;
     const int32_t* __restrict__ qo_c = qorder ? qorder + (size_t)cloud * n : nullptr;  // slot -> query (spos is indexed by query)
     constexpr int U = 4;                                    // slots per thread, all in flight: spb <= U * BLOCK = SPB
@@ -1852,10 +1610,10 @@ __global__ __launch_bounds__(BLOCK) void accumulate_bwd_window_kernel(WeightPara
         const int sq = on[u] ? s : s0;
         pos[u] = qo_c ? min(max(qo_c[sq], 0), n - 1) : sq;
     }
-    const int lo = window_origin(spos_ref + (size_t)cloud * n, qo_c, blk, spb, n, m_pad, WT);
+    const int lo = window_origin(spos_ref + (size_t)cloud * n, qo_c, blk, spb, nc, m_pad, WT);
     const int hi = min(lo + WT, m_pad);
 #pragma unroll
-    for (int u = 0; u < U; ++u) pos[u] = min(max(sp_c[pos[u]], 0), m_pad - 1);     // -1 (no neighbour: non-finite input) -> row 0
+    for (int u = 0; u < U; ++u) pos[u] = on[u] ? min(max(sp_c[pos[u]], 0), m_pad - 1) : 0;     // -1 (no neighbour: non-finite input) -> row 0
     if (slab)
         for (int k = tid; k < hi - lo; k += BLOCK) head[k] = -1;
     T C[9], r[3], Gs[36], Gb[6];
@@ -1896,7 +1654,14 @@ __global__ __launch_bounds__(BLOCK) void accumulate_bwd_window_kernel(WeightPara
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (!on[u]) continue;
+            if (!on[u]) {
+                if (overwrite && base + u * BLOCK + tid < s1_all) {      // a pad slot of a ragged batch: its accumulators start at zero
+                    const size_t pz = (size_t)cloud * n + base + u * BLOCK + tid;
+                    gsrc_s[pz * 3] = gsrc_s[pz * 3 + 1] = gsrc_s[pz * 3 + 2] = T(0);
+                    if (gw_s) gw_s[pz] = T(0);
+                }
+                continue;
+            }
             const size_t pt = (size_t)cloud * n + base + u * BLOCK + tid;
             T gp[3], gy[3], gn[3], gw0;
             point_backward<T, MODE>(P, C, r, p[u], y[u], nrm[u], wv[u] * live, Gs, Gb, gp, gy, gn, gw0, acc, acc + 9);
@@ -1948,7 +1713,7 @@ __global__ __launch_bounds__(BLOCK) void window_reduce_kernel(const T* __restric
                                                               const int32_t* __restrict__ qorder,
                                                               const int32_t* __restrict__ tperm, const T* __restrict__ gts_far,
                                                               int N, int n, int m, int m_pad, int cv, int spb, int bpc, int rpc,
-                                                              T* __restrict__ gtgt, int c, int overwrite) {
+                                                              T* __restrict__ gtgt, int c, int overwrite, const int32_t* __restrict__ src_rows) {
     constexpr int MAXB = 256;                               // window blocks per cloud handled per pass
     __shared__ int origin[MAXB];
     int cloud, rb;
@@ -1970,7 +1735,7 @@ __global__ __launch_bounds__(BLOCK) void window_reduce_kernel(const T* __restric
     for (int b0 = 0; b0 < bpc; b0 += MAXB) {
         __syncthreads();
         for (int b = tid; b < min(MAXB, bpc - b0); b += BLOCK)
-            origin[b] = window_origin(spos_ref + (size_t)cloud * n, qorder ? qorder + (size_t)cloud * n : nullptr, b0 + b, spb, n, m_pad, WT);
+            origin[b] = window_origin(spos_ref + (size_t)cloud * n, qorder ? qorder + (size_t)cloud * n : nullptr, b0 + b, spb, rows_of(src_rows, cloud, n), m_pad, WT);
         __syncthreads();
         const int nb = min(MAXB, bpc - b0);
         // the block loop is the OUTER one: all of a thread's elements have their (predicated) loads of WR_B window blocks in
@@ -2088,6 +1853,7 @@ __global__ __launch_bounds__(BLOCK) void icp_small_backward_kernel(WeightParams 
     __shared__ T red[(BLOCK / WAVE) * NBWD_PAD];
     __shared__ T part[NBWD_PAD];
     const int cloud = blockIdx.x, tid = threadIdx.x, c = B.c;
+    const int nc = rows_of(B.src_rows, cloud, n);           // ragged batches: rows past the cloud's own carry no gradient
     if (gtgt)
         for (int e = tid; e < m * CV; e += BLOCK) gt[e] = T(0);
     if (tid < 12) sgo[tid] = gpose_in[(size_t)cloud * 12 + tid];
@@ -2122,7 +1888,7 @@ __global__ __launch_bounds__(BLOCK) void icp_small_backward_kernel(WeightParams 
         T acc[NBWD];
 #pragma unroll
         for (int a = 0; a < NBWD; ++a) acc[a] = T(0);
-        for (int i = tid; i < n; i += BLOCK) {
+        for (int i = tid; i < nc; i += BLOCK) {
             const T p[3] = {src[i * 3], src[i * 3 + 1], src[i * 3 + 2]};
             const int j = min(max(idx_k[i], 0), m - 1);
             const T* yp = tgt + (size_t)j * c;
@@ -2337,7 +2103,7 @@ template <typename T>
 __global__ __launch_bounds__(BLOCK) void kabsch_accumulate_kernel(const T* __restrict__ src, const T* __restrict__ tgt, int c,
                                                                   const int32_t* __restrict__ idx, const T* __restrict__ pose,
                                                                   const T* __restrict__ w_init, int trim_on, T trim_dist,
-                                                                  int N, int n, int m, int bpc, T* __restrict__ partials) {
+                                                                  int N, int n, int m, int bpc, T* __restrict__ partials, const int32_t* __restrict__ src_rows) {
     __shared__ T red[(BLOCK / WAVE) * NACC_PAD];
     int cloud, blk;
     if (!decode_block(bpc, N, cloud, blk)) return;
@@ -2346,7 +2112,7 @@ __global__ __launch_bounds__(BLOCK) void kabsch_accumulate_kernel(const T* __res
     T acc[NKAB];
 #pragma unroll
     for (int k = 0; k < NKAB; ++k) acc[k] = T(0);
-    const int end = min(n, (blk + 1) * ACC_PTS);
+    const int end = min(rows_of(src_rows, cloud, n), (blk + 1) * ACC_PTS);
     for (int i = blk * ACC_PTS + threadIdx.x; i < end; i += BLOCK) {
         const size_t pt = (size_t)cloud * n + i;
         const T* sp = src + pt * 3;
@@ -2410,14 +2176,14 @@ __global__ __launch_bounds__(BLOCK) void kabsch_bwd_kernel(const T* __restrict__
                                                            const int32_t* __restrict__ idx, const T* __restrict__ pose,
                                                            const T* __restrict__ w_init, int trim_on, T trim_dist,
                                                            const T* __restrict__ gacc, int N, int n, int m, int bpc,
-                                                           T* __restrict__ gsrc, T* __restrict__ gtgt, T* __restrict__ gw) {
+                                                           T* __restrict__ gsrc, T* __restrict__ gtgt, T* __restrict__ gw, const int32_t* __restrict__ src_rows) {
     int cloud, blk;
     if (!decode_block(bpc, N, cloud, blk)) return;
     T C[9], r[3], g[16];
     load_pose(pose, cloud, C, r);
 #pragma unroll
     for (int k = 0; k < 16; ++k) g[k] = gacc[(size_t)cloud * 16 + k];
-    const int end = min(n, (blk + 1) * ACC_PTS);
+    const int end = min(rows_of(src_rows, cloud, n), (blk + 1) * ACC_PTS);
     for (int i = blk * ACC_PTS + threadIdx.x; i < end; i += BLOCK) {
         const size_t pt = (size_t)cloud * n + i;
         const T* sp = src + pt * 3;
@@ -2599,18 +2365,20 @@ inline WeightParams to_params(const dicp_weight_params* p) {
 inline bool bad_dtype(int d) { return d != DICP_F32 && d != DICP_F64; }
 inline unsigned blocks_for(size_t total) { return (unsigned)((total + BLOCK - 1) / BLOCK); }
 
+struct Rows { const int32_t* src; const int32_t* tgt; };     // optional per-cloud row counts of a ragged batch
+
 template <typename T, int Q, int CH, int MINW = 1>
-void knn_valu_go(const void* src, const void* pose, const void* tgt4, int N, int n, int m, int m_pad, int32_t* idx, hipStream_t st) {
+void knn_valu_go(const void* src, const void* pose, const void* tgt4, int N, int n, int m, int m_pad, int32_t* idx, Rows rw, hipStream_t st) {
     using T4 = typename V4<T>::type;
     constexpr int TILE = sizeof(T) == 4 ? 2048 : 1024;      // 32 KiB of LDS either way
     const int bpc = (n + BLOCK * Q - 1) / (BLOCK * Q);
-    knn_valu_kernel<T, Q, TILE, CH, MINW><<<grid_for(N, bpc), BLOCK, 0, st>>>((const T*)src, (const T*)pose, (const T4*)tgt4, idx, N, n, m, m_pad, bpc);
+    knn_valu_kernel<T, Q, TILE, CH, MINW><<<grid_for(N, bpc), BLOCK, 0, st>>>((const T*)src, (const T*)pose, (const T4*)tgt4, idx, N, n, m, m_pad, bpc, rw.src, rw.tgt);
 }
 
 // cfg 0 = pick by problem size: enough blocks to fill 256 CUs first, then register-block queries to
 // amortise the LDS broadcasts.  cfg 1.. = fixed (tuning / tests).
 template <typename T>
-int knn_valu_launch(int cfg, const void* src, const void* pose, const void* tgt4, int N, int n, int m, int m_pad, int32_t* idx, hipStream_t st) {
+int knn_valu_launch(int cfg, const void* src, const void* pose, const void* tgt4, int N, int n, int m, int m_pad, int32_t* idx, Rows rw, hipStream_t st) {
     const long q_total = (long)N * n;
     if (cfg == 0) {
         if (q_total >= 8L * BLOCK * 1024)      cfg = (sizeof(T) == 4) ? 11 : 3;    // Q=8, 16-target chunks (f32)
@@ -2619,27 +2387,27 @@ int knn_valu_launch(int cfg, const void* src, const void* pose, const void* tgt4
         else                                   cfg = 1;
     }
     switch (cfg) {
-        case 1: knn_valu_go<T, 1, 8>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
-        case 2: knn_valu_go<T, 2, 8>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
-        case 3: knn_valu_go<T, 4, 8>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
-        case 5: knn_valu_go<T, 4, 16>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
-        case 11: knn_valu_go<T, 8, 16, (sizeof(T) == 4 ? 4 : 1)>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
+        case 1: knn_valu_go<T, 1, 8>(src, pose, tgt4, N, n, m, m_pad, idx, rw, st); break;
+        case 2: knn_valu_go<T, 2, 8>(src, pose, tgt4, N, n, m, m_pad, idx, rw, st); break;
+        case 3: knn_valu_go<T, 4, 8>(src, pose, tgt4, N, n, m, m_pad, idx, rw, st); break;
+        case 5: knn_valu_go<T, 4, 16>(src, pose, tgt4, N, n, m, m_pad, idx, rw, st); break;
+        case 11: knn_valu_go<T, 8, 16, (sizeof(T) == 4 ? 4 : 1)>(src, pose, tgt4, N, n, m, m_pad, idx, rw, st); break;
         default: return DICP_ERR_ENUM;
     }
     return launch_status();
 }
 
 template <int NB, int G>
-void knn_mfma_go(const void* src, const void* pose, const void* tgt4, int N, int n, int m, int m_pad, int32_t* idx, hipStream_t st) {
+void knn_mfma_go(const void* src, const void* pose, const void* tgt4, int N, int n, int m, int m_pad, int32_t* idx, Rows rw, hipStream_t st) {
     const int bpc = (n + 64 * NB - 1) / (64 * NB);
-    knn_mfma_kernel<NB, 2048, G><<<grid_for(N, bpc), BLOCK, 0, st>>>((const float*)src, (const float*)pose, (const float4*)tgt4, idx, N, n, m, m_pad, bpc);
+    knn_mfma_kernel<NB, 2048, G><<<grid_for(N, bpc), BLOCK, 0, st>>>((const float*)src, (const float*)pose, (const float4*)tgt4, idx, N, n, m, m_pad, bpc, rw.src, rw.tgt);
 }
 
-int knn_mfma_launch(int cfg, const void* src, const void* pose, const void* tgt4, int N, int n, int m, int m_pad, int32_t* idx, hipStream_t st) {
+int knn_mfma_launch(int cfg, const void* src, const void* pose, const void* tgt4, int N, int n, int m, int m_pad, int32_t* idx, Rows rw, hipStream_t st) {
     if (cfg == 0) cfg = ((long)N * n >= 512L * 1024) ? 5 : 1;
     switch (cfg) {
-        case 1: knn_mfma_go<2, 1>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
-        case 5: knn_mfma_go<4, 4>(src, pose, tgt4, N, n, m, m_pad, idx, st); break;
+        case 1: knn_mfma_go<2, 1>(src, pose, tgt4, N, n, m, m_pad, idx, rw, st); break;
+        case 5: knn_mfma_go<4, 4>(src, pose, tgt4, N, n, m, m_pad, idx, rw, st); break;
         default: return DICP_ERR_ENUM;
     }
     return launch_status();
@@ -2654,21 +2422,17 @@ int dicp_abi_version(void) { return DICP_ABI_VERSION; }
 int dicp_padded_targets(int m) { return m <= 0 ? 0 : ((m + KNN_PAD - 1) / KNN_PAD) * KNN_PAD; }
 int dicp_accumulate_blocks(int n) { return n <= 0 ? 0 : (n + ACC_PTS - 1) / ACC_PTS; }
 
-int dicp_cloud_center(int dtype, const void* tgt, int c, int N, int m, double quantum, void* center, void* stream) {
+int dicp_cloud_center(int dtype, const void* tgt, int c, const int32_t* tgt_rows, int N, int m, double quantum, void* center, void* stream) {
     if (!tgt || !center) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || m <= 0 || (c != 3 && c != 6) || !(quantum >= 0.0)) return DICP_ERR_SHAPE;
     begin_launch();
-    if (dtype == DICP_F32) cloud_center_kernel<float><<<N, CC_THREADS, 0, (hipStream_t)stream>>>((const float*)tgt, c, m, quantum, (float*)center);
-    else                   cloud_center_kernel<double><<<N, CC_THREADS, 0, (hipStream_t)stream>>>((const double*)tgt, c, m, quantum, (double*)center);
+    if (dtype == DICP_F32) cloud_center_kernel<float><<<N, CC_THREADS, 0, (hipStream_t)stream>>>((const float*)tgt, c, m, tgt_rows, quantum, (float*)center);
+    else                   cloud_center_kernel<double><<<N, CC_THREADS, 0, (hipStream_t)stream>>>((const double*)tgt, c, m, tgt_rows, quantum, (double*)center);
     return launch_status();
 }
 
-int dicp_pack_target(int dtype, const void* tgt, int N, int m, int c, void* tgt4, int m_pad, void* stream) {
-    return dicp_pack_target_centered(dtype, tgt, N, m, c, nullptr, tgt4, m_pad, stream);
-}
-
-int dicp_pack_target_centered(int dtype, const void* tgt, int N, int m, int c, const void* center, void* tgt4, int m_pad, void* stream) {
+int dicp_pack_target(int dtype, const void* tgt, int c, const void* center, const int32_t* tgt_rows, int N, int m, void* tgt4, int m_pad, void* stream) {
     if (!tgt || !tgt4) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || m <= 0 || (c != 3 && c != 6) || m_pad != dicp_padded_targets(m)) return DICP_ERR_SHAPE;
@@ -2677,51 +2441,56 @@ int dicp_pack_target_centered(int dtype, const void* tgt, int N, int m, int c, c
     begin_launch();
     const int bpc = (int)blocks_for((size_t)m_pad);
     const unsigned g = grid_for(N, bpc);
-    if (dtype == DICP_F32) pack_kernel<float><<<g, BLOCK, 0, st>>>((const float*)tgt, N, m, c, (float4*)tgt4, m_pad, bpc, (const float*)center);
-    else                   pack_kernel<double><<<g, BLOCK, 0, st>>>((const double*)tgt, N, m, c, (double4*)tgt4, m_pad, bpc, (const double*)center);
+    if (dtype == DICP_F32) pack_kernel<float><<<g, BLOCK, 0, st>>>((const float*)tgt, N, m, c, (float4*)tgt4, m_pad, bpc, (const float*)center, tgt_rows);
+    else                   pack_kernel<double><<<g, BLOCK, 0, st>>>((const double*)tgt, N, m, c, (double4*)tgt4, m_pad, bpc, (const double*)center, tgt_rows);
     return launch_status();
 }
 
-int dicp_sweep_sort(int dtype, const void* tgt, int c, int N, int m, int m_pad, void* keys_sorted, int32_t* tperm,
-                    int nbkt, int32_t* bucket, void* brange, void* stream) {
-    return dicp_sweep_sort_centered(dtype, tgt, c, nullptr, N, m, m_pad, keys_sorted, tperm, nbkt, bucket, brange, stream);
+size_t dicp_sweep_sort_scratch_bytes(int dtype, int N, int m_pad) {
+    if (N <= 0 || m_pad <= 0 || (dtype == DICP_F32 && m_pad <= RS_MAX)) return 0;     // the one-block LDS sort needs none
+    return (size_t)N * 2 * m_pad * ((dtype == DICP_F32 ? 4 : 8) + sizeof(int32_t)) + 256;
 }
 
-int dicp_sweep_sort_centered(int dtype, const void* tgt, int c, const void* center, int N, int m, int m_pad, void* keys_sorted, int32_t* tperm,
-                             int nbkt, int32_t* bucket, void* brange, void* stream) {
+int dicp_sweep_sort(int dtype, const void* tgt, int c, const void* center, const int32_t* tgt_rows, int N, int m, int m_pad, void* keys_sorted,
+                    int32_t* tperm, int nbkt, int32_t* bucket, void* brange, void* scratch, size_t scratch_bytes, void* stream) {
     if (!tgt || !keys_sorted || !tperm || (bucket && !brange)) return DICP_ERR_NULL;
     if (bucket && nbkt <= 0) return DICP_ERR_SHAPE;
-    if (dtype != DICP_F32) return DICP_ERR_DTYPE;          // float keys; float64 clouds and more than 16384 targets: sort on the caller's side
-    if (N <= 0 || m <= 0 || (c != 3 && c != 6) || m_pad != dicp_padded_targets(m) || m_pad > RS_MAX) return DICP_ERR_SHAPE;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0 || m <= 0 || (c != 3 && c != 6) || m_pad != dicp_padded_targets(m)) return DICP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DICP_F32 && m_pad <= RS_MAX) {                 // in LDS, the bucket table while the sorted keys are there
+        begin_launch();
+        sort_keys_kernel<<<N, RS_THREADS, 0, st>>>((const float*)tgt, c, N, m, m_pad, (float*)keys_sorted, tperm, nbkt, bucket, (float*)brange, (const float*)center, tgt_rows);
+        return launch_status();
+    }
+    if (!scratch || scratch_bytes < dicp_sweep_sort_scratch_bytes(dtype, N, m_pad)) return DICP_ERR_NULL;
     begin_launch();
-    sort_keys_kernel<<<N, RS_THREADS, 0, (hipStream_t)stream>>>((const float*)tgt, c, N, m, m_pad, (float*)keys_sorted, tperm, nbkt, bucket, (float*)brange, (const float*)center);
+    void* kb = (void*)(((uintptr_t)scratch + 15) & ~(uintptr_t)15);       // keys first (8-byte aligned), then the indices
+    if (dtype == DICP_F32) {
+        int32_t* ib = (int32_t*)((unsigned*)kb + (size_t)N * 2 * m_pad);
+        sort_keys_big_kernel<float><<<N, GS_THREADS, 0, st>>>((const float*)tgt, c, m, m_pad, (const float*)center, tgt_rows, (float*)keys_sorted, tperm, (unsigned*)kb, ib);
+        if (bucket) sweep_buckets_kernel<float><<<N, BLOCK, 0, st>>>((const float*)keys_sorted, N, m, m_pad, nbkt, bucket, (float*)brange, tgt_rows);
+    } else {
+        int32_t* ib = (int32_t*)((unsigned long long*)kb + (size_t)N * 2 * m_pad);
+        sort_keys_big_kernel<double><<<N, GS_THREADS, 0, st>>>((const double*)tgt, c, m, m_pad, (const double*)center, tgt_rows, (double*)keys_sorted, tperm, (unsigned long long*)kb, ib);
+        if (bucket) sweep_buckets_kernel<double><<<N, BLOCK, 0, st>>>((const double*)keys_sorted, N, m, m_pad, nbkt, bucket, (double*)brange, tgt_rows);
+    }
     return launch_status();
 }
 
-int dicp_sweep_build(int dtype, const void* tgt, int c, const int64_t* order, const void* keys_sorted, int N, int m, int m_pad, int nbkt,
-                     void* tgs4, int32_t* tperm, int32_t* bucket, void* brange, void* tgt_s, void* stream) {
-    return dicp_sweep_build_centered(dtype, tgt, c, nullptr, order, keys_sorted, N, m, m_pad, nbkt, tgs4, tperm, bucket, brange, tgt_s, stream);
-}
-
-int dicp_sweep_build_centered(int dtype, const void* tgt, int c, const void* center, const int64_t* order, const void* keys_sorted, int N, int m,
-                              int m_pad, int nbkt, void* tgs4, int32_t* tperm, int32_t* bucket, void* brange, void* tgt_s, void* stream) {
-    // center != NULL: the packed rows tgs4 are y - centre and keys_sorted (if given) are the centred x keys; tgt_s stays as given
-    // order == NULL: tperm holds the permutation.  keys_sorted == NULL: bucket / brange are already filled (dicp_sweep_sort)
-    if (!tgt || !tgs4 || !tperm || !bucket || !brange) return DICP_ERR_NULL;
+int dicp_sweep_build(int dtype, const void* tgt, int c, const void* center, const int32_t* tgt_rows, const int32_t* tperm, int N, int m, int m_pad,
+                     void* tgs4, void* tgt_s, void* stream) {
+    // center != NULL: the packed rows tgs4 are y - centre; tgt_s stays as given
+    if (!tgt || !tgs4 || !tperm) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
-    if (N <= 0 || m <= 0 || (c != 3 && c != 6) || nbkt <= 0 || m_pad != dicp_padded_targets(m)) return DICP_ERR_SHAPE;
+    if (N <= 0 || m <= 0 || (c != 3 && c != 6) || m_pad != dicp_padded_targets(m)) return DICP_ERR_SHAPE;
     if ((uintptr_t)tgs4 % (dtype == DICP_F32 ? 16 : 32)) return DICP_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
     begin_launch();
     const int bpc = (m_pad + BLOCK * 4 - 1) / (BLOCK * 4);
     const unsigned g = grid_for(N, bpc);
-    if (dtype == DICP_F32) {
-        sweep_rows_kernel<float><<<g, BLOCK, 0, st>>>((const float*)tgt, order, N, m, c, m_pad, bpc, (float4*)tgs4, tperm, (float*)tgt_s, (const float*)center);
-        if (keys_sorted) sweep_buckets_kernel<float><<<N, BLOCK, 0, st>>>((const float*)keys_sorted, N, m, m_pad, nbkt, bucket, (float*)brange);
-    } else {
-        sweep_rows_kernel<double><<<g, BLOCK, 0, st>>>((const double*)tgt, order, N, m, c, m_pad, bpc, (double4*)tgs4, tperm, (double*)tgt_s, (const double*)center);
-        if (keys_sorted) sweep_buckets_kernel<double><<<N, BLOCK, 0, st>>>((const double*)keys_sorted, N, m, m_pad, nbkt, bucket, (double*)brange);
-    }
+    if (dtype == DICP_F32) sweep_rows_kernel<float><<<g, BLOCK, 0, st>>>((const float*)tgt, tgt_rows, N, m, c, m_pad, bpc, (float4*)tgs4, tperm, (float*)tgt_s, (const float*)center);
+    else                   sweep_rows_kernel<double><<<g, BLOCK, 0, st>>>((const double*)tgt, tgt_rows, N, m, c, m_pad, bpc, (double4*)tgs4, tperm, (double*)tgt_s, (const double*)center);
     return launch_status();
 }
 
@@ -2740,14 +2509,14 @@ int dicp_query_keys(int dtype, const void* src, const void* pose, int N, int n, 
 
 int dicp_query_order(int dtype, const void* src, const void* pose, const void* brange, int nbkt, int N, int n, int32_t* qorder,
                      const void* w, void* src_s, void* w_s, int reproducible, const int32_t* spos_prev, int m_pad,
-                     const void* skeys, const int32_t* bucket, int m, void* stream) {
+                     const void* skeys, const int32_t* bucket, int m, const int32_t* src_rows, const int32_t* tgt_rows, void* stream) {
     if (!src || !brange || !qorder || (w_s && !w)) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || n <= 0 || nbkt <= 0 || ((spos_prev || skeys) && m_pad <= 0) || (skeys && (m <= 0 || m > m_pad))) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     begin_launch();
 #define DICP_QO(T, S) query_order_kernel<T, S><<<N, QO_THREADS, 0, st>>>((const T*)src, (const T*)pose, (const T*)brange, nbkt, N, n, qorder, \
-        (const T*)w, (T*)src_s, (T*)w_s, reproducible, spos_prev, m_pad, (const T*)skeys, 1, m, bucket)
+        (const T*)w, (T*)src_s, (T*)w_s, reproducible, spos_prev, m_pad, (const T*)skeys, 1, m, bucket, src_rows, tgt_rows)
     if (dtype == DICP_F32) { if (n <= 16384) DICP_QO(float, 16384); else DICP_QO(float, 65536); }
     else                   { if (n <= 16384) DICP_QO(double, 16384); else DICP_QO(double, 65536); }
 #undef DICP_QO
@@ -2755,11 +2524,6 @@ int dicp_query_order(int dtype, const void* src, const void* pose, const void* b
 }
 
 int dicp_loop_init(int dtype, const void* T_init, const void* w0, double thresh, int rows, int N, int n,
-                   void* pose0, void* alive0, void* n_start, void* stream) {
-    return dicp_loop_init_centered(dtype, T_init, w0, thresh, rows, N, n, pose0, alive0, n_start, nullptr, nullptr, stream);
-}
-
-int dicp_loop_init_centered(int dtype, const void* T_init, const void* w0, double thresh, int rows, int N, int n,
                             void* pose0, void* alive0, void* n_start, const void* center, void* pose_search0, void* stream) {
     if (!T_init || !w0 || !pose0 || !alive0 || !n_start) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
@@ -2819,8 +2583,8 @@ int dicp_pose_grad_out(int dtype, const double* gpose, const void* bwd_partials,
     return launch_status();
 }
 
-int dicp_knn(int dtype, const void* src, const void* pose, const void* tgt4, int N, int n, int m, int m_pad,
-             int32_t* idx, int variant, void* stream) {
+int dicp_knn(int dtype, const void* src, const void* pose, const void* tgt4, const int32_t* src_rows, const int32_t* tgt_rows,
+             int N, int n, int m, int m_pad, int32_t* idx, int variant, void* stream) {
     if (!src || !tgt4 || !idx) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || n <= 0 || m <= 0 || m_pad != dicp_padded_targets(m)) return DICP_ERR_SHAPE;
@@ -2830,9 +2594,10 @@ int dicp_knn(int dtype, const void* src, const void* pose, const void* tgt4, int
     if ((uintptr_t)tgt4 % (dtype == DICP_F32 ? 16 : 32)) return DICP_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
     begin_launch();
-    if (kind == DICP_KNN_MFMA) return knn_mfma_launch(cfg, src, pose, tgt4, N, n, m, m_pad, idx, st);
-    if (dtype == DICP_F32) return knn_valu_launch<float>(cfg, src, pose, tgt4, N, n, m, m_pad, idx, st);
-    return knn_valu_launch<double>(cfg, src, pose, tgt4, N, n, m, m_pad, idx, st);
+    const Rows rw{src_rows, tgt_rows};
+    if (kind == DICP_KNN_MFMA) return knn_mfma_launch(cfg, src, pose, tgt4, N, n, m, m_pad, idx, rw, st);
+    if (dtype == DICP_F32) return knn_valu_launch<float>(cfg, src, pose, tgt4, N, n, m, m_pad, idx, rw, st);
+    return knn_valu_launch<double>(cfg, src, pose, tgt4, N, n, m, m_pad, idx, rw, st);
 }
 
 // Tile-sweep launch configurations (queries per lane, rows per chunk): 0 = chosen from the problem size,
@@ -2842,7 +2607,7 @@ static int sweep_auto_cfg(int N, int n) { return ((long)N * n >= 2L * BLOCK * 10
 
 static int sweep_launch(int dtype, const void* src, const void* pose, const void* tgs4, const int32_t* tperm,
                         const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt,
-                        int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg, hipStream_t st) {
+                        int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg, Rows rw, hipStream_t st) {
     hipEvent_t ev0, ev1;
     take_launch_events(ev0, ev1);                                       // (null unless a timed loop set them for this launch)
     const int src_sorted = (cfg & DICP_SWEEP_SRC_SORTED) ? 1 : 0;      // src holds the rows in qorder's slot order
@@ -2855,7 +2620,7 @@ static int sweep_launch(int dtype, const void* src, const void* pose, const void
     const int bpc = (units + BLOCK / WAVE - 1) / (BLOCK / WAVE);
 #define DICP_SWEEP(T, Q, CH) hipExtLaunchKernelGGL((knn_sweep_kernel<T, Q, CH>), dim3(grid_for(N, bpc)), dim3(BLOCK), 0, st, ev0, ev1, 0, \
         (const T*)src, (const T*)pose, (const typename V4<T>::type*)tgs4, tperm, qorder, bucket, (const T*)brange, nbkt, idx, spos, pairs, \
-        N, n, m, m_pad, bpc, src_sorted)
+        N, n, m, m_pad, bpc, src_sorted, rw.src, rw.tgt)
     if (dtype == DICP_F32) {
         if (cfg == 2) DICP_SWEEP(float, 2, 8); else if (cfg == 4) DICP_SWEEP(float, 1, 16); else DICP_SWEEP(float, 1, 8);
     } else {
@@ -2866,67 +2631,14 @@ static int sweep_launch(int dtype, const void* src, const void* pose, const void
 }
 
 int dicp_knn_sweep(int dtype, const void* src, const void* pose, const void* tgs4, const int32_t* tperm,
-                   const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt,
+                   const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt, const int32_t* src_rows, const int32_t* tgt_rows,
                    int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg, void* stream) {
     if (!src || !tgs4 || !tperm || !bucket || !brange || !idx) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || n <= 0 || m <= 0 || nbkt <= 0 || m_pad != dicp_padded_targets(m)) return DICP_ERR_SHAPE;
     if ((uintptr_t)tgs4 % (dtype == DICP_F32 ? 16 : 32)) return DICP_ERR_ALIGN;
     begin_launch();
-    return sweep_launch(dtype, src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, N, n, m, m_pad, idx, spos, pairs, cfg, (hipStream_t)stream);
-}
-
-int dicp_grid_cells_max(int m) { return grid_cells_max(m); }
-
-size_t dicp_grid_scratch_bytes(int N, int m_pad) {
-    if (N <= 0 || m_pad <= GS_CHUNK) return 0;                 // up to 16384 slots the sort runs in LDS
-    return (size_t)N * 2 * m_pad * (sizeof(unsigned short) + sizeof(int32_t)) + 256;
-}
-
-int dicp_grid_build(int dtype, const void* tgt, int c, const void* center, const int32_t* tgt_rows, int N, int m, int m_pad, int ncell_max,
-                    void* ginfo, int32_t* tperm, int32_t* cell_start, void* tgs4, void* tgt_s, void* scratch, size_t scratch_bytes, void* stream) {
-    if (!tgt || !ginfo || !tperm || !cell_start || !tgs4) return DICP_ERR_NULL;
-    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
-    if (N <= 0 || m <= 0 || (c != 3 && c != 6) || m_pad != dicp_padded_targets(m) || ncell_max < 1 || ncell_max > GRID_MAX_CELLS) return DICP_ERR_SHAPE;
-    if ((uintptr_t)tgs4 % (dtype == DICP_F32 ? 16 : 32)) return DICP_ERR_ALIGN;
-    const bool big = m_pad > GS_CHUNK;
-    if (big && (!scratch || scratch_bytes < dicp_grid_scratch_bytes(N, m_pad))) return DICP_ERR_NULL;
-    hipStream_t st = (hipStream_t)stream;
-    begin_launch();
-    unsigned short* gkey = nullptr;
-    int32_t* gidx = nullptr;
-    if (big) {                                                  // indices first (4-byte aligned), then the 2-byte keys
-        gidx = (int32_t*)(((uintptr_t)scratch + 15) & ~(uintptr_t)15);
-        gkey = (unsigned short*)(gidx + (size_t)N * 2 * m_pad);
-    }
-    const int bpc = (m_pad + BLOCK * 4 - 1) / (BLOCK * 4);
-#define DICP_GRID(T) do { \
-        grid_info_kernel<T><<<N, GS_THREADS, 0, st>>>((const T*)tgt, c, m, tgt_rows, (const T*)center, ncell_max, (T*)ginfo); \
-        if (big) grid_sort_kernel<T, true><<<N, GS_THREADS, 0, st>>>((const T*)tgt, c, m, m_pad, tgt_rows, (const T*)center, (const T*)ginfo, ncell_max + 1, tperm, cell_start, gkey, gidx); \
-        else     grid_sort_kernel<T, false><<<N, GS_THREADS, 0, st>>>((const T*)tgt, c, m, m_pad, tgt_rows, (const T*)center, (const T*)ginfo, ncell_max + 1, tperm, cell_start, nullptr, nullptr); \
-        sweep_rows_kernel<T><<<grid_for(N, bpc), BLOCK, 0, st>>>((const T*)tgt, nullptr, N, m, c, m_pad, bpc, (typename V4<T>::type*)tgs4, tperm, (T*)tgt_s, (const T*)center); } while (0)
-    if (dtype == DICP_F32) DICP_GRID(float); else DICP_GRID(double);
-#undef DICP_GRID
-    return launch_status();
-}
-
-int dicp_knn_grid(int dtype, const void* src, const void* pose, const void* tgs4, const int32_t* tperm, const int32_t* cell_start, int ncell_max,
-                  const void* ginfo, const int32_t* src_rows, int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos,
-                  unsigned long long* pairs, void* stream) {
-    if (!src || !tgs4 || !tperm || !cell_start || !ginfo || !idx) return DICP_ERR_NULL;
-    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
-    if (N <= 0 || n <= 0 || m <= 0 || m_pad != dicp_padded_targets(m) || ncell_max < 1 || ncell_max > GRID_MAX_CELLS) return DICP_ERR_SHAPE;
-    if ((uintptr_t)tgs4 % (dtype == DICP_F32 ? 16 : 32)) return DICP_ERR_ALIGN;
-    hipStream_t st = (hipStream_t)stream;
-    begin_launch();
-    hipEvent_t ev0, ev1;
-    take_launch_events(ev0, ev1);                                       // (null unless a timed loop set them for this launch)
-    const int bpc = (n + KG_THREADS - 1) / KG_THREADS;
-#define DICP_KG(T) hipExtLaunchKernelGGL((knn_grid_kernel<T>), dim3(grid_for(N, bpc)), dim3(KG_THREADS), 0, st, ev0, ev1, 0, (const T*)src, (const T*)pose, \
-        (const typename V4<T>::type*)tgs4, tperm, cell_start, ncell_max + 1, (const T*)ginfo, src_rows, idx, spos, pairs, N, n, m, m_pad, bpc)
-    if (dtype == DICP_F32) DICP_KG(float); else DICP_KG(double);
-#undef DICP_KG
-    return launch_status();
+    return sweep_launch(dtype, src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, N, n, m, m_pad, idx, spos, pairs, cfg, Rows{src_rows, tgt_rows}, (hipStream_t)stream);
 }
 
 int dicp_gather_rows(int dtype, const void* tgt, const int32_t* idx, int N, int n, int m, int c, void* out, void* stream) {
@@ -2971,7 +2683,7 @@ static int check_params(const dicp_weight_params* p, int c) {
 }
 
 int dicp_accumulate(int dtype, const dicp_weight_params* prm, const void* src, const void* tgt, int c,
-                    const int32_t* idx, const void* pose, const void* w_init, const void* alive,
+                    const int32_t* idx, const void* pose, const void* w_init, const void* alive, const int32_t* src_rows,
                     int N, int n, int m, void* partials, void* w_out, int64_t w_stride, void* stream) {
     if (const int e = check_params(prm, c)) return e;
     if (!src || !tgt || !w_init || !partials) return DICP_ERR_NULL;
@@ -2985,7 +2697,7 @@ int dicp_accumulate(int dtype, const dicp_weight_params* prm, const void* src, c
     hipEvent_t ev0, ev1;
     take_launch_events(ev0, ev1);                                       // (null unless a timed loop set them for this launch)
 #define DICP_ACC(T, M) hipExtLaunchKernelGGL((accumulate_kernel<T, M>), dim3(g), dim3(BLOCK), 0, st, ev0, ev1, 0, P, (const T*)src, (const T*)tgt, c, idx, (const T*)pose, \
-        (const T*)w_init, (const T*)alive, N, n, m, bpc, (T*)partials, (T*)w_out, (long)w_stride)
+        (const T*)w_init, (const T*)alive, N, n, m, bpc, (T*)partials, (T*)w_out, (long)w_stride, src_rows)
     if (dtype == DICP_F32) { if (P.mode == MODE_PT2PL) DICP_ACC(float, MODE_PT2PL); else DICP_ACC(float, MODE_PT2PT); }
     else                   { if (P.mode == MODE_PT2PL) DICP_ACC(double, MODE_PT2PL); else DICP_ACC(double, MODE_PT2PT); }
 #undef DICP_ACC
@@ -3024,7 +2736,7 @@ int dicp_step_bwd(int dtype, const double* gpose_in, const void* bwd_partials, i
 
 int dicp_accumulate_bwd(int dtype, const dicp_weight_params* prm, const void* src, const void* tgt, int c,
                         const int32_t* idx, const void* pose, const void* w_init, const void* alive,
-                        const void* gs, const void* gb, int N, int n, int m,
+                        const void* gs, const void* gb, const int32_t* src_rows, int N, int n, int m,
                         void* gsrc, void* gtgt, void* gw, void* bwd_partials, void* stream) {
     if (const int e = check_params(prm, c)) return e;
     if (!src || !tgt || !w_init || !gs || !gb || !gsrc || !bwd_partials) return DICP_ERR_NULL;
@@ -3036,7 +2748,7 @@ int dicp_accumulate_bwd(int dtype, const dicp_weight_params* prm, const void* sr
     const int bpc = dicp_accumulate_blocks(n);
     const unsigned g = grid_for(N, bpc);
 #define DICP_BWD(T, M) accumulate_bwd_kernel<T, M><<<g, BLOCK, 0, st>>>(P, (const T*)src, (const T*)tgt, c, idx, (const T*)pose, \
-        (const T*)w_init, (const T*)alive, (const T*)gs, (const T*)gb, N, n, m, bpc, (T*)gsrc, (T*)gtgt, (T*)gw, (T*)bwd_partials)
+        (const T*)w_init, (const T*)alive, (const T*)gs, (const T*)gb, N, n, m, bpc, (T*)gsrc, (T*)gtgt, (T*)gw, (T*)bwd_partials, src_rows)
     if (dtype == DICP_F32) { if (P.mode == MODE_PT2PL) DICP_BWD(float, MODE_PT2PL); else DICP_BWD(float, MODE_PT2PT); }
     else                   { if (P.mode == MODE_PT2PL) DICP_BWD(double, MODE_PT2PL); else DICP_BWD(double, MODE_PT2PT); }
 #undef DICP_BWD
@@ -3077,15 +2789,15 @@ int dicp_gumbel_nn_bwd(int dtype, const void* x, const void* y, int c, const voi
 }
 
 int dicp_kabsch_accumulate(int dtype, const void* src, const void* tgt, int c, const int32_t* idx, const void* pose,
-                           const void* w_init, int trim_on, double trim_dist, int N, int n, int m, void* partials, void* stream) {
+                           const void* w_init, int trim_on, double trim_dist, const int32_t* src_rows, int N, int n, int m, void* partials, void* stream) {
     if (!src || !tgt || !idx || !w_init || !partials) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || n <= 0 || m <= 0 || (c != 3 && c != 6)) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     begin_launch();
     const int bpc = dicp_accumulate_blocks(n);
-    if (dtype == DICP_F32) kabsch_accumulate_kernel<float><<<grid_for(N, bpc), BLOCK, 0, st>>>((const float*)src, (const float*)tgt, c, idx, (const float*)pose, (const float*)w_init, trim_on, (float)trim_dist, N, n, m, bpc, (float*)partials);
-    else                   kabsch_accumulate_kernel<double><<<grid_for(N, bpc), BLOCK, 0, st>>>((const double*)src, (const double*)tgt, c, idx, (const double*)pose, (const double*)w_init, trim_on, trim_dist, N, n, m, bpc, (double*)partials);
+    if (dtype == DICP_F32) kabsch_accumulate_kernel<float><<<grid_for(N, bpc), BLOCK, 0, st>>>((const float*)src, (const float*)tgt, c, idx, (const float*)pose, (const float*)w_init, trim_on, (float)trim_dist, N, n, m, bpc, (float*)partials, src_rows);
+    else                   kabsch_accumulate_kernel<double><<<grid_for(N, bpc), BLOCK, 0, st>>>((const double*)src, (const double*)tgt, c, idx, (const double*)pose, (const double*)w_init, trim_on, trim_dist, N, n, m, bpc, (double*)partials, src_rows);
     return launch_status();
 }
 
@@ -3112,15 +2824,15 @@ int dicp_kabsch_step_bwd(int dtype, const void* gpose, const double* save, void*
 }
 
 int dicp_kabsch_bwd(int dtype, const void* src, const void* tgt, int c, const int32_t* idx, const void* pose, const void* w_init,
-                    int trim_on, double trim_dist, const void* gacc, int N, int n, int m, void* gsrc, void* gtgt, void* gw, void* stream) {
+                    int trim_on, double trim_dist, const void* gacc, const int32_t* src_rows, int N, int n, int m, void* gsrc, void* gtgt, void* gw, void* stream) {
     if (!src || !tgt || !idx || !w_init || !gacc || !gsrc) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || n <= 0 || m <= 0 || (c != 3 && c != 6)) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     begin_launch();
     const int bpc = dicp_accumulate_blocks(n);
-    if (dtype == DICP_F32) kabsch_bwd_kernel<float><<<grid_for(N, bpc), BLOCK, 0, st>>>((const float*)src, (const float*)tgt, c, idx, (const float*)pose, (const float*)w_init, trim_on, (float)trim_dist, (const float*)gacc, N, n, m, bpc, (float*)gsrc, (float*)gtgt, (float*)gw);
-    else                   kabsch_bwd_kernel<double><<<grid_for(N, bpc), BLOCK, 0, st>>>((const double*)src, (const double*)tgt, c, idx, (const double*)pose, (const double*)w_init, trim_on, trim_dist, (const double*)gacc, N, n, m, bpc, (double*)gsrc, (double*)gtgt, (double*)gw);
+    if (dtype == DICP_F32) kabsch_bwd_kernel<float><<<grid_for(N, bpc), BLOCK, 0, st>>>((const float*)src, (const float*)tgt, c, idx, (const float*)pose, (const float*)w_init, trim_on, (float)trim_dist, (const float*)gacc, N, n, m, bpc, (float*)gsrc, (float*)gtgt, (float*)gw, src_rows);
+    else                   kabsch_bwd_kernel<double><<<grid_for(N, bpc), BLOCK, 0, st>>>((const double*)src, (const double*)tgt, c, idx, (const double*)pose, (const double*)w_init, trim_on, trim_dist, (const double*)gacc, N, n, m, bpc, (double*)gsrc, (double*)gtgt, (double*)gw, src_rows);
     return launch_status();
 }
 
@@ -3134,7 +2846,7 @@ int dicp_window_rows(int dtype) { return dtype == DICP_F32 ? WindowRows<float>::
 
 int dicp_accumulate_bwd_window(int dtype, const dicp_weight_params* prm, const void* src_s, const void* tgt_s, int c,
                                const int32_t* spos, const int32_t* spos_ref, const int32_t* qorder, const void* pose, const void* w_s,
-                               const void* alive, const void* gs, const void* gb, int N, int n, int m_pad, void* gsrc_s, void* slab,
+                               const void* alive, const void* gs, const void* gb, const int32_t* src_rows, int N, int n, int m_pad, void* gsrc_s, void* slab,
                                void* gts_far, void* gw_s, void* bwd_partials, int overwrite, void* stream) {
     if (const int e = check_params(prm, c)) return e;
     if (!src_s || !tgt_s || !spos || !spos_ref || !pose || !w_s || !gs || !gb || !gsrc_s || !bwd_partials || (slab && !gts_far))
@@ -3152,7 +2864,7 @@ int dicp_accumulate_bwd_window(int dtype, const dicp_weight_params* prm, const v
 #define DICP_WIN_O(T, M, OV) do { constexpr int WT = WindowRows<T>::v; const int spb = window_slots(WT, n, m_pad); \
         hipExtLaunchKernelGGL((accumulate_bwd_window_kernel<T, M, WT, OV>), dim3(g), dim3(BLOCK), 0, st, ev0, ev1, 0, P, (const T*)src_s, (const T*)tgt_s, c, spos, spos_ref, qorder, (const T*)pose, \
             (const T*)w_s, (const T*)alive, (const T*)gs, (const T*)gb, N, n, m_pad, spb, bpc, (T*)gsrc_s, (T*)slab, (T*)gts_far, (T*)gw_s, \
-            (T*)bwd_partials); } while (0)
+            (T*)bwd_partials, src_rows); } while (0)
     if (dtype == DICP_F32) { if (P.mode == MODE_PT2PL) DICP_WIN(float, MODE_PT2PL); else DICP_WIN(float, MODE_PT2PT); }
     else                   { if (P.mode == MODE_PT2PL) DICP_WIN(double, MODE_PT2PL); else DICP_WIN(double, MODE_PT2PT); }
 #undef DICP_WIN
@@ -3161,7 +2873,7 @@ int dicp_accumulate_bwd_window(int dtype, const dicp_weight_params* prm, const v
 }
 
 int dicp_window_reduce(int dtype, const void* slab, const int32_t* spos_ref, const int32_t* qorder, const int32_t* tperm, const void* gts_far,
-                       int N, int n, int m, int m_pad, int cv, void* gtgt, int c, int overwrite, void* stream) {
+                       const int32_t* src_rows, int N, int n, int m, int m_pad, int cv, void* gtgt, int c, int overwrite, void* stream) {
     if (!slab || !spos_ref || !tperm || !gtgt) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || n <= 0 || m <= 0 || m_pad != dicp_padded_targets(m) || (cv != 3 && cv != 6) || c < cv) return DICP_ERR_SHAPE;
@@ -3171,7 +2883,7 @@ int dicp_window_reduce(int dtype, const void* slab, const int32_t* spos_ref, con
     const int rpc = (m * cv + BLOCK * WR_U - 1) / (BLOCK * WR_U);
     const unsigned g = grid_for(N, rpc);
 #define DICP_RED(T, CVV) window_reduce_kernel<T, WindowRows<T>::v, CVV><<<g, BLOCK, 0, st>>>((const T*)slab, spos_ref, qorder, tperm, (const T*)gts_far, N, n, m, m_pad, cv, \
-        window_slots(WindowRows<T>::v, n, m_pad), bpc, rpc, (T*)gtgt, c, overwrite)
+        window_slots(WindowRows<T>::v, n, m_pad), bpc, rpc, (T*)gtgt, c, overwrite, src_rows)
     if (dtype == DICP_F32) { if (cv == 6) DICP_RED(float, 6); else DICP_RED(float, 3); }
     else                   { if (cv == 6) DICP_RED(double, 6); else DICP_RED(double, 3); }
 #undef DICP_RED
@@ -3264,22 +2976,22 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
             // src_s: the source rows in qorder's slot order (dicp_query_order wrote them): coalesced query loads
             const void* qsrc = B->src;
             if (B->src_s && B->qorder) { qsrc = B->src_s; cfg |= DICP_SWEEP_SRC_SORTED; }
-            rc = dicp_knn_sweep(dtype, qsrc, pose_s, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, N, n, m, B->m_pad,
+            rc = dicp_knn_sweep(dtype, qsrc, pose_s, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, B->src_rows, B->tgt_rows, N, n, m, B->m_pad,
                                 idx_k, spos_k, B->pairs, cfg, stream);
             set_launch_events(nullptr, nullptr);
             if (rc) return rc;
             if (B->events) set_launch_events((hipEvent_t)B->events[6 * k + 2], (hipEvent_t)B->events[6 * k + 3]);
-            rc = dicp_accumulate(dtype, prm, B->src, B->tgt, B->c, idx_k, pose_k, B->w_init, alive_k, N, n, m, B->partials, w_k, B->w_stride, stream);
+            rc = dicp_accumulate(dtype, prm, B->src, B->tgt, B->c, idx_k, pose_k, B->w_init, alive_k, B->src_rows, N, n, m, B->partials, w_k, B->w_stride, stream);
             set_launch_events(nullptr, nullptr);
             if (rc) return rc;
         } else {
-            rc = dicp_knn(dtype, B->src, pose_s, B->tgt4, N, n, m, B->m_pad, idx_k, B->knn_variant & 0xffff, stream);
+            rc = dicp_knn(dtype, B->src, pose_s, B->tgt4, B->src_rows, B->tgt_rows, N, n, m, B->m_pad, idx_k, B->knn_variant & 0xffff, stream);
             if (rc) return rc;
             if (B->events) {
                 if (hipEventRecord((hipEvent_t)B->events[6 * k + 1], st) != hipSuccess) return -(int)hipGetLastError();
                 set_launch_events((hipEvent_t)B->events[6 * k + 2], (hipEvent_t)B->events[6 * k + 3]);
             }
-            rc = dicp_accumulate(dtype, prm, B->src, B->tgt, B->c, idx_k, pose_k, B->w_init, alive_k, N, n, m, B->partials, w_k, B->w_stride, stream);
+            rc = dicp_accumulate(dtype, prm, B->src, B->tgt, B->c, idx_k, pose_k, B->w_init, alive_k, B->src_rows, N, n, m, B->partials, w_k, B->w_stride, stream);
             set_launch_events(nullptr, nullptr);
             if (rc) return rc;
         }
@@ -3333,11 +3045,11 @@ int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_
         }
         if (B->spos)    // windowed form: src / w_init / tgt are the SORTED copies, gsrc / gw accumulate in slot order, gtgt is the slab
             rc = dicp_accumulate_bwd_window(dtype, prm, B->src, B->tgt, B->c, B->spos + (size_t)k * N * n, B->spos_ref, B->qorder, pose_k, B->w_init,
-                                            (const char*)B->alive + (size_t)k * N * es, gs, gb, N, n, B->m_pad,
+                                            (const char*)B->alive + (size_t)k * N * es, gs, gb, B->src_rows, N, n, B->m_pad,
                                             gsrc, gtgt, B->gts_far, gw, bwd_partials, (B->bwd_overwrite && k == k1 - 1) ? 1 : 0, stream);
         else
             rc = dicp_accumulate_bwd(dtype, prm, B->src, B->tgt, B->c, B->idx + (size_t)k * N * n, pose_k, B->w_init,
-                                     (const char*)B->alive + (size_t)k * N * es, gs, gb, N, n, m, gsrc, gtgt, gw, bwd_partials, stream);
+                                     (const char*)B->alive + (size_t)k * N * es, gs, gb, B->src_rows, N, n, m, gsrc, gtgt, gw, bwd_partials, stream);
         set_launch_events(nullptr, nullptr);
         if (rc) return rc;
         if (B->events && !B->spos) { if (hipEventRecord((hipEvent_t)B->events[6 * k + 5], st) != hipSuccess) return -(int)hipGetLastError(); }

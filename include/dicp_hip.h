@@ -13,6 +13,11 @@
  *   - dtype: DICP_F32 or DICP_F64 selects the scalar type T of all `void*` tensors
  *     (the reference's tests run float64: tests/test_ICP.py:41-42);
  *   - tensors are dense row-major unless a stride argument says otherwise;
+ *   - ragged batches (the reference pads every cloud of a list to the longest, ICP.py:305-511): `src_rows` / `tgt_rows`
+ *     (N) int32, optional, are the leading rows of each cloud that take part.  NULL = all n / m of them.  No kernel reads,
+ *     scores or accumulates a row beyond them; outputs for such rows are what the reference's padding yields (weight 0,
+ *     zero gradient).  To reproduce the reference bit for bit pass tgt_rows = real rows + 1: its pad rows are copies of
+ *     ONE far point (ICP.py:460,472-477), and one copy takes part exactly like all of them;
  *   - return value: 0 = ok, DICP_ERR_* (>0) = rejected argument (nothing launched),
  *     <0 = -(hipError_t) from the launch.  Nothing throws across the boundary.
  */
@@ -25,12 +30,14 @@
 extern "C" {
 #endif
 
-#define DICP_ABI_VERSION 3   /* 3: timing events are 6 per iteration; the scan / fused-accumulate search forms and their entry points are gone */
+#define DICP_ABI_VERSION 3   /* 3: per-cloud row counts of ragged batches (src_rows / tgt_rows) on every entry point of the path; the centred and
+                                uncentred forms of an entry point are one (center may be NULL); the key sort is native for every size and dtype;
+                                timing events are 6 per iteration; the scan / packed / fused-accumulate search forms are gone */
 
 enum { DICP_F32 = 0, DICP_F64 = 1 };
 enum { DICP_PT2PT = 0, DICP_PT2PL = 1 };                 /* ICP(icp_type=...)  ICP.py:15,101-105 */
 enum { DICP_LOSS_NONE = 0, DICP_LOSS_HUBER = 1, DICP_LOSS_CAUCHY = 2, DICP_LOSS_TRIM = 3 };
-enum { DICP_KNN_AUTO = 0, DICP_KNN_VALU = 1, DICP_KNN_MFMA = 2, DICP_KNN_SWEEP = 3 /* via dicp_knn_sweep */, DICP_KNN_GRID = 4 /* via dicp_knn_grid */ };
+enum { DICP_KNN_AUTO = 0, DICP_KNN_VALU = 1, DICP_KNN_MFMA = 2, DICP_KNN_SWEEP = 3 /* via dicp_knn_sweep */ };
 enum { DICP_ERR_NULL = 1, DICP_ERR_SHAPE = 2, DICP_ERR_DTYPE = 3, DICP_ERR_ENUM = 4, DICP_ERR_ALIGN = 5 };
 
 /* Accumulator layout of one (cloud, block) partial: see dicp_amd/csrc/dicp_math.h */
@@ -56,52 +63,41 @@ int dicp_padded_targets(int m);
 /* Blocks per cloud used by dicp_accumulate / dicp_accumulate_bwd for n source points. */
 int dicp_accumulate_blocks(int n);
 
-/* Once per ICP call: tgt (N,m,c) -> tgt4 (N,m_pad,4) rows [x,y,z,0.5|y|^2], pad rows
- * [0,0,0,+inf].  The norms are the ||y||^2 column that torch.cdist's matmul path builds
- * on every call (nn.py:32 -> ATen _euclidean_dist).  c in {3,6}. */
-int dicp_pack_target(int dtype, const void* tgt, int N, int m, int c, void* tgt4, int m_pad, void* stream);
-
 /* Centred search coordinates.  The searches score in the expanded form 0.5|y|^2 - x.y (the reference's own: nn.py:32), whose rounding
  * error grows with 0.5|x|^2 -- and with it the prune margin of dicp_knn_sweep: a cloud a kilometre from the origin is searched almost
- * exhaustively.  dicp_cloud_center writes, per cloud, the coordinate-wise median of a stride sample of at most 1024 target rows, copies of the cloud's last
- * row not voting (the centre only sizes a margin, but it must sit inside the cloud: the reference's far pad rows -- ICP.py:460,472-477,
- * copies of one point at the end -- can be most of a short cloud), rounded to a multiple of `quantum`
- * (0: not rounded; float precision) into
- * center (N,3) T; the *_centered entry points below pack rows as y - center, and the caller hands the searches the pose
- * [C | r - center] (dicp_loop_buffers.poses_search; dicp_loop_init_centered / the step kernels write it).  Every search form reads only
- * (pose, packed rows): with the same centre they return the same indices as each other, and with center == 0 (clouds near the origin,
- * given a quantum) exactly the bits of the uncentred entry points.  center == NULL == the uncentred entry point. */
-int dicp_cloud_center(int dtype, const void* tgt, int c, int N, int m, double quantum, void* center, void* stream);
-int dicp_pack_target_centered(int dtype, const void* tgt, int N, int m, int c, const void* center, void* tgt4, int m_pad, void* stream);
+ * exhaustively.  dicp_cloud_center writes, per cloud, the coordinate-wise median of a stride sample of at most 1024 of its rows, rounded to
+ * a multiple of `quantum` (0: not rounded; float precision), into center (N,3) T; entry points given `center` pack rows as y - center, and the
+ * caller hands the searches the pose [C | r - center] (dicp_loop_buffers.poses_search; dicp_loop_init / the step kernels write it).  Every
+ * search form reads only (pose, packed rows): with the same centre they return the same indices as each other, and with center == 0 (clouds
+ * near the origin, given a quantum) exactly the bits of center == NULL. */
+int dicp_cloud_center(int dtype, const void* tgt, int c, const int32_t* tgt_rows, int N, int m, double quantum, void* center, void* stream);
+
+/* Once per ICP call: tgt (N,m,c) -> tgt4 (N,m_pad,4) rows [x,y,z,0.5|y|^2] (of y - center when center != NULL), pad rows
+ * [0,0,0,+inf].  The norms are the ||y||^2 column that torch.cdist's matmul path builds
+ * on every call (nn.py:32 -> ATen _euclidean_dist).  c in {3,6}. */
+int dicp_pack_target(int dtype, const void* tgt, int c, const void* center, const int32_t* tgt_rows, int N, int m, void* tgt4, int m_pad, void* stream);
 
 /* Fused transform + brute-force 1-NN: replaces ICP.py:137 (ps_t = C p + r) followed by
  * nn.find_nn's cdist -> argmin, nn.py:32-35 / 83-86.  Never materialises (N,n,m).
  *   src (N,n,3); pose (N,12) = [C row-major (9), r (3)] or NULL for identity;
  *   idx (N,n) int32, ties -> lowest index.  variant: DICP_KNN_* in the low byte (MFMA is f32 only);
  *   bits 8..15 optionally pin a launch configuration (0 = chosen from the problem size). */
-int dicp_knn(int dtype, const void* src, const void* pose, const void* tgt4, int N, int n, int m, int m_pad,
-             int32_t* idx, int variant, void* stream);
+int dicp_knn(int dtype, const void* src, const void* pose, const void* tgt4, const int32_t* src_rows, const int32_t* tgt_rows,
+             int N, int n, int m, int m_pad, int32_t* idx, int variant, void* stream);
 
-/* Set-up of the sorted-sweep search structure AFTER the sort (the sort itself is the caller's: any stable ascending
- * sort of the target x keys with the m_pad - m pad slots keyed +max so that they come last):
- *   order (N,m_pad) int64 = the sorting permutation, keys_sorted (N,m_pad) = the sorted keys
- *   -> tgs4 (N,m_pad,4) packed rows in sorted order (pads [max,0,0,+inf]), tperm (N,m_pad) = order as int32,
- *      bucket (N,nbkt+1) lower-bound positions of nbkt+1 equally spaced x edges, brange (N,2) = [x_min, nbkt/(x_max-x_min)],
- *      optional tgt_s (N,m_pad,c) = the full target rows in sorted order (what dicp_accumulate_bwd_window reads). */
-/* The sort itself, for float32 clouds of up to 16384 targets (m_pad <= 16384): keys_sorted (N,m_pad) and tperm (N,m_pad)
- * as a stable ascending sort of the target x keys gives them (an LDS radix sort, one block per cloud).  Then pass
- * order = NULL to dicp_sweep_build: it reads the permutation from tperm.  Given bucket (N,nbkt+1) and brange (N,2) it
- * also builds the bucket table while the sorted keys are in LDS; dicp_sweep_build is then told so with
- * keys_sorted = NULL and leaves the table alone. */
-int dicp_sweep_sort(int dtype, const void* tgt, int c, int N, int m, int m_pad, void* keys_sorted, int32_t* tperm,
-                    int nbkt, int32_t* bucket, void* brange, void* stream);
-int dicp_sweep_build(int dtype, const void* tgt, int c, const int64_t* order, const void* keys_sorted, int N, int m, int m_pad, int nbkt,
-                     void* tgs4, int32_t* tperm, int32_t* bucket, void* brange, void* tgt_s, void* stream);
-/* as above with packed rows / x keys taken relative to center (N,3) (NULL: as above); tgt_s keeps the rows as given */
-int dicp_sweep_sort_centered(int dtype, const void* tgt, int c, const void* center, int N, int m, int m_pad, void* keys_sorted, int32_t* tperm,
-                             int nbkt, int32_t* bucket, void* brange, void* stream);
-int dicp_sweep_build_centered(int dtype, const void* tgt, int c, const void* center, const int64_t* order, const void* keys_sorted, int N, int m,
-                              int m_pad, int nbkt, void* tgs4, int32_t* tperm, int32_t* bucket, void* brange, void* tgt_s, void* stream);
+/* Set-up of the sorted-sweep search structure, ONCE per ICP call (targets do not move between iterations).
+ * dicp_sweep_sort: keys_sorted (N,m_pad) T and tperm (N,m_pad) as a STABLE ascending sort of the target x keys (of y - center) gives them;
+ *   the m_pad - m pad slots (and, in a ragged batch, the slots past a cloud's own rows) keep the largest key: they follow every real row,
+ *   NaN rows included.  float32 clouds of up to 16384 slots: an LSD radix sort in LDS, one block per cloud; float64 keys or more slots: the
+ *   same sort chunk by chunk through `scratch` (dicp_sweep_sort_scratch_bytes(dtype, N, m_pad) bytes; 0 = none needed).  Given bucket
+ *   (N,nbkt+1) and brange (N,2) it also builds the search's coarse table: bucket[b] = #rows with x < xlo + b / inv, brange = [xlo, inv].
+ * dicp_sweep_build: from tperm, tgs4 (N,m_pad,4) = the packed rows in sorted order (pads [max,0,0,+inf]) and, optionally, tgt_s (N,m_pad,c) =
+ *   the full target rows in sorted order (what dicp_accumulate_bwd_window reads; row s = tgt[tperm[s]], as given: not centred). */
+size_t dicp_sweep_sort_scratch_bytes(int dtype, int N, int m_pad);
+int dicp_sweep_sort(int dtype, const void* tgt, int c, const void* center, const int32_t* tgt_rows, int N, int m, int m_pad, void* keys_sorted,
+                    int32_t* tperm, int nbkt, int32_t* bucket, void* brange, void* scratch, size_t scratch_bytes, void* stream);
+int dicp_sweep_build(int dtype, const void* tgt, int c, const void* center, const int32_t* tgt_rows, const int32_t* tperm, int N, int m, int m_pad,
+                     void* tgs4, void* tgt_s, void* stream);
 /* keys (N,n) = x coordinate of every source point under pose (NULL = identity): the sort key of the query order. */
 int dicp_query_keys(int dtype, const void* src, const void* pose, int N, int n, void* keys, void* stream);
 /* qorder (N,n) = the queries in ascending bucket of their x under pose (counting sort over equal-width buckets of the
@@ -117,10 +113,11 @@ int dicp_query_keys(int dtype, const void* src, const void* pose, int N, int n, 
  * sorted keys dicp_sweep_build was given) + bucket (from dicp_sweep_build; m real targets), optional: the bucket is the RANK of the query's x among the sorted target keys under the given pose (a
  * binary search in an LDS copy of the keys; clouds of up to 16384 queries and targets, bigger ones keep the x buckets):
  * equal-population buckets without the lag -- what the ICP loop uses (0.58 vs 1.50 ms/iteration on clouds with a dense
- * blob and one far outlier, profiles/r01_uneven_clouds.txt). */
+ * blob and one far outlier, profiles/r01_uneven_clouds.txt).  Ragged batches: a cloud's own queries fill the first src_rows[b] slots, the
+ * rows past them follow in index order, so qorder is always a permutation of all n rows. */
 int dicp_query_order(int dtype, const void* src, const void* pose, const void* brange, int nbkt, int N, int n, int32_t* qorder,
                      const void* w, void* src_s, void* w_s, int reproducible, const int32_t* spos_prev, int m_pad,
-                     const void* keys_sorted, const int32_t* bucket, int m, void* stream);
+                     const void* keys_sorted, const int32_t* bucket, int m, const int32_t* src_rows, const int32_t* tgt_rows, void* stream);
 
 /* Exact 1-NN with slab pruning: same result (and lowest-index tie rule) as dicp_knn, far fewer pairs.
  * The caller prepares, ONCE per ICP call (targets do not move between iterations):
@@ -137,33 +134,8 @@ int dicp_query_order(int dtype, const void* src, const void* pose, const void* b
 #define DICP_PAIR_SHARDS 64
 #define DICP_SWEEP_SRC_SORTED 0x100   /* OR into cfg: `src` holds the rows in qorder's slot order (dicp_query_order's src_s) */
 int dicp_knn_sweep(int dtype, const void* src, const void* pose, const void* tgs4, const int32_t* tperm,
-                   const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt,
+                   const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt, const int32_t* src_rows, const int32_t* tgt_rows,
                    int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg, void* stream);
-
-/* Exact 1-NN over a uniform 3-D grid of cells: same result (and lowest-index tie rule) as dicp_knn, pruning on all three
- * coordinates (nn.py:32-35 without the (N,n,m) matrix, and without scoring more than the few cells around a query).
- * dicp_grid_build, ONCE per ICP call (targets do not move between iterations), from tgt (N,m,c) [and center (N,3): the grid
- * and the packed rows are then in coordinates y - center, as for the *_centered entry points]:
- *   ginfo (N,DICP_GRID_INFO) T   grid geometry per cloud: origin lo[3], cells per unit inv[3], cell size h[3], counts G[3] (as T),
- *                                cell count, box slack[3]; from the 1/64 .. 63/64 sample quantiles of the coordinates, about 4
- *                                targets per cell, at most ncell_max = dicp_grid_cells_max(m) cells;
- *   tperm (N,m_pad)              original row of each sorted slot: STABLE order of the cell id (z, y, x: x fastest), m for slots
- *                                past the cloud's rows;  cell_start (N,ncell_max+1): first sorted slot of every cell, then the end;
- *   tgs4 (N,m_pad,4)             packed rows [x,y,z,0.5|y|^2] in that order (pads [max,0,0,+inf]);  tgt_s (N,m_pad,c), optional: the
- *                                full rows in that order (what dicp_accumulate_bwd_window reads);
- *   tgt_rows (N), optional       leading rows of each cloud that take part (ragged batches: ICP.py:460-477 pads the rest);
- *   scratch                      dicp_grid_scratch_bytes(N, m_pad) bytes (0 up to 16384 slots: the sort then runs in LDS).
- * dicp_knn_grid, per iteration: idx (N,n) original row of the nearest target, spos (N,n) optional: its sorted slot (-1: none),
- *   queries in the caller's order (src_rows (N), optional: leading rows of each cloud that take part; the rest is not written);
- *   pairs: optional DICP_PAIR_SHARDS counters, += pairs scored. */
-#define DICP_GRID_INFO 16
-int dicp_grid_cells_max(int m);
-size_t dicp_grid_scratch_bytes(int N, int m_pad);
-int dicp_grid_build(int dtype, const void* tgt, int c, const void* center, const int32_t* tgt_rows, int N, int m, int m_pad, int ncell_max,
-                    void* ginfo, int32_t* tperm, int32_t* cell_start, void* tgs4, void* tgt_s, void* scratch, size_t scratch_bytes, void* stream);
-int dicp_knn_grid(int dtype, const void* src, const void* pose, const void* tgs4, const int32_t* tperm, const int32_t* cell_start, int ncell_max,
-                  const void* ginfo, const int32_t* src_rows, int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos,
-                  unsigned long long* pairs, void* stream);
 
 /* Gather whole target rows at idx (nn.py:37-38 / 89-90) and its backward, a scatter-add
  * into a zero-initialised (N,m,c) buffer (autograd's gather backward). */
@@ -180,7 +152,7 @@ int dicp_scatter_add_rows(int dtype, const void* gout, const int32_t* idx, int N
  *   partials (N, nblk, DICP_NACC_PAD) with nblk = dicp_accumulate_blocks(n);
  *   w_out: cloud b's n weights are written at w_out + b*w_stride (elements); may be NULL. */
 int dicp_accumulate(int dtype, const dicp_weight_params* prm, const void* src, const void* tgt, int c,
-                    const int32_t* idx, const void* pose, const void* w_init, const void* alive,
+                    const int32_t* idx, const void* pose, const void* w_init, const void* alive, const int32_t* src_rows,
                     int N, int n, int m, void* partials, void* w_out, int64_t w_stride, void* stream);
 
 /* Per-cloud state advanced by dicp_step (one ICP iteration's tail, ICP.py:198-260). */
@@ -268,9 +240,12 @@ typedef struct dicp_loop_buffers {
     int32_t bwd_overwrite;   /* dicp_icp_backward, windowed form: 1 = gsrc / gw / the slab (gtgt) are uninitialised and this call's
                                 first launch (iteration k1-1) writes them instead of adding; 0 = they are accumulators */
     const void* center;      /* optional (N,3) T: centre of the search coordinates (dicp_cloud_center); tgt4 / the sweep index were then
-                                built by the *_centered entry points */
-    void* poses_search;      /* optional (K+1,N,12) T: [C | r - centre] per iteration, written by dicp_loop_init_centered (k = 0) and
+                                built with it */
+    void* poses_search;      /* optional (K+1,N,12) T: [C | r - centre] per iteration, written by dicp_loop_init (k = 0) and
                                 the step kernels; the searches read it instead of poses.  NULL: they read poses */
+    const int32_t* src_rows; /* optional (N): rows of each source cloud that take part (ragged batches); qorder, if any, from dicp_query_order
+                                with the same counts */
+    const int32_t* tgt_rows; /* optional (N): rows of each target cloud that take part; tgt4 / the sweep index built with the same counts */
 } dicp_loop_buffers;
 
 /* Head and tail of the backward loop.  dicp_pose_grad_in: gpose (N,12) double = [dL/dC row-major (9), dL/dr (3)] taken from the
@@ -284,10 +259,7 @@ int dicp_pose_grad_out(int dtype, const double* gpose, const void* bwd_partials,
  * n_start (N) = rows * #(w0 > thresh), rows = 3 for pt2pt, 1 for pt2pl.  And after the last executed iteration K
  * (ICP.py:267-281): iterations / matched_ratio of clouds that never converged, T_out (N,4,4) from pose_K. */
 int dicp_loop_init(int dtype, const void* T_init, const void* w0, double thresh, int rows, int N, int n,
-                   void* pose0, void* alive0, void* n_start, void* stream);
-/* ... and the search pose of iteration 0, pose_search0 (N,12) = [C_0 | r_0 - center] (both optional) */
-int dicp_loop_init_centered(int dtype, const void* T_init, const void* w0, double thresh, int rows, int N, int n,
-                            void* pose0, void* alive0, void* n_start, const void* center, void* pose_search0, void* stream);
+                   void* pose0, void* alive0, void* n_start, const void* center /* optional */, void* pose_search0 /* optional: [C_0 | r_0 - center] */, void* stream);
 /* pose_search (N,12) = [C_0 | r_0 - center] from T_init (N,4,4) alone: the same values, for a caller that orders the first queries
  * before the loop state exists (center optional) */
 int dicp_search_pose(int dtype, const void* T_init, const void* center, int N, void* pose_search, void* stream);
@@ -320,7 +292,7 @@ int dicp_step_bwd(int dtype, const double* gpose_in, const void* bwd_partials, i
  *   may be NULL if target needs no gradient), bwd_partials (N,nblk,DICP_NBWD_PAD) written. */
 int dicp_accumulate_bwd(int dtype, const dicp_weight_params* prm, const void* src, const void* tgt, int c,
                         const int32_t* idx, const void* pose, const void* w_init, const void* alive,
-                        const void* gs, const void* gb, int N, int n, int m,
+                        const void* gs, const void* gb, const int32_t* src_rows, int N, int n, int m,
                         void* gsrc, void* gtgt, void* gw, void* bwd_partials, void* stream);
 
 /* Windowed form of dicp_accumulate_bwd for the sorted-sweep path, entirely in SORTED space and without global
@@ -343,10 +315,10 @@ int dicp_window_blocks(int dtype, int n, int m_pad);
 int dicp_window_rows(int dtype);
 int dicp_accumulate_bwd_window(int dtype, const dicp_weight_params* prm, const void* src_s, const void* tgt_s, int c,
                                const int32_t* spos, const int32_t* spos_ref, const int32_t* qorder, const void* pose, const void* w_s,
-                               const void* alive, const void* gs, const void* gb, int N, int n, int m_pad, void* gsrc_s, void* slab,
+                               const void* alive, const void* gs, const void* gb, const int32_t* src_rows, int N, int n, int m_pad, void* gsrc_s, void* slab,
                                void* gts_far, void* gw_s, void* bwd_partials, int overwrite, void* stream);
 int dicp_window_reduce(int dtype, const void* slab, const int32_t* spos_ref, const int32_t* qorder, const int32_t* tperm, const void* gts_far,
-                       int N, int n, int m, int m_pad, int cv, void* gtgt, int c, int overwrite, void* stream);
+                       const int32_t* src_rows, int N, int n, int m, int m_pad, int cv, void* gtgt, int c, int overwrite, void* stream);
 
 /* out[b][perm[b][s]][k] += in[b][s][k] for s < cnt, k < cols.  in (N,in_rows,c_in), perm (N,perm_rows) injective per
  * cloud (plain read-modify-write), out (N,out_rows,c_out).  Undoes a sorted order. */
@@ -379,11 +351,11 @@ int dicp_gumbel_nn_bwd(int dtype, const void* x, const void* y, int c, const voi
  *   bwd:        gsrc (N,n,3) +=, gtgt (N,m,c) += (atomics, may be NULL), gw (N,n) += (may be NULL). */
 #define DICP_KAB_SAVE 40
 int dicp_kabsch_accumulate(int dtype, const void* src, const void* tgt, int c, const int32_t* idx, const void* pose,
-                           const void* w_init, int trim_on, double trim_dist, int N, int n, int m, void* partials, void* stream);
+                           const void* w_init, int trim_on, double trim_dist, const int32_t* src_rows, int N, int n, int m, void* partials, void* stream);
 int dicp_kabsch_step(int dtype, const void* partials, int nblk, void* pose_out, void* cost, double* save, int N, void* stream);
 int dicp_kabsch_step_bwd(int dtype, const void* gpose, const double* save, void* gacc, int N, void* stream);
 int dicp_kabsch_bwd(int dtype, const void* src, const void* tgt, int c, const int32_t* idx, const void* pose, const void* w_init,
-                    int trim_on, double trim_dist, const void* gacc, int N, int n, int m, void* gsrc, void* gtgt, void* gw, void* stream);
+                    int trim_on, double trim_dist, const void* gacc, const int32_t* src_rows, int N, int n, int m, void* gsrc, void* gtgt, void* gw, void* stream);
 
 /* The returned cloud pc = C p + r (ICP.py:274) and its adjoint: gsrc (N,n,3) = C^T gout (may be NULL);
  * partials (N, dicp_accumulate_blocks(n), DICP_NBWD_PAD) = per-block [sum gout p^T (9), sum gout (3)] for the pose. */

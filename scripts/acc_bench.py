@@ -28,7 +28,7 @@ part = torch.empty((B, nb, _lib.NACC_PAD), dtype=dt, device="cuda")
 
 
 def run(ix, w):
-    _lib.check(lib.dicp_accumulate(code, ctypes.byref(P), p(src), p(tgt), c, p(ix), p(pose), p(w0), None, B, n, n, p(part), p(w), n, st), "acc")
+    _lib.check(lib.dicp_accumulate(code, ctypes.byref(P), p(src), p(tgt), c, p(ix), p(pose), p(w0), None, None, B, n, n, p(part), p(w), n, st), "acc")
 
 
 cases = {"real idx + w": lambda: run(idx, wout), "real idx, no w": lambda: run(idx, None),

@@ -42,18 +42,18 @@ gfar = torch.zeros((B, m_pad, cv), dtype=dt, device="cuda")
 
 
 def atomic(want):
-    _lib.check(lib.dicp_accumulate_bwd(code, ctypes.byref(P), p(src), p(tgt), c, p(idx), p(pose), p(w0), None, p(gs), p(gb),
+    _lib.check(lib.dicp_accumulate_bwd(code, ctypes.byref(P), p(src), p(tgt), c, p(idx), p(pose), p(w0), None, p(gs), p(gb), None,
                                        B, n, n, p(gsrc), p(gtgt) if want else None, p(gw), p(part), st), "bwd")
 
 
 def window(want):
-    _lib.check(lib.dicp_accumulate_bwd_window(code, ctypes.byref(P), p(src_s), p(tgt_s), c, p(spos), p(spos), p(qo), p(pose), p(w_s), None, p(gs), p(gb),
+    _lib.check(lib.dicp_accumulate_bwd_window(code, ctypes.byref(P), p(src_s), p(tgt_s), c, p(spos), p(spos), p(qo), p(pose), p(w_s), None, p(gs), p(gb), None,
                                               B, n, m_pad, p(gsrc), p(slab) if want else None, p(gfar) if want else None, p(gw), p(part), 0, st),
                "bwd_window")
 
 
 def reduce_():
-    _lib.check(lib.dicp_window_reduce(code, p(slab), p(spos), p(qo), p(sw.tperm), p(gfar), B, n, n, m_pad, cv, p(gtgt), c, 0, st), "reduce")
+    _lib.check(lib.dicp_window_reduce(code, p(slab), p(spos), p(qo), p(sw.tperm), p(gfar), None, B, n, n, m_pad, cv, p(gtgt), c, 0, st), "reduce")
 
 
 def fresh():

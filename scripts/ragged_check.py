@@ -19,5 +19,19 @@ for _ in range(3): call()
 ts = []
 for _ in range(5):
     torch.cuda.synchronize(); t0 = time.perf_counter(); call(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
-frac = float(icp.knn_stats["knn_pairs"].sum()) / (float(B) * n * n * K)
-print("ragged lists B=%d (6000..16384 source points, targets 3000 shorter): %.3f ms/iteration, pairs scored %.2f %% of the padded n*m" % (B, sorted(ts)[2] * 1e3 / K, 100 * frac))
+pairs = float(icp.knn_stats["knn_pairs"].sum())
+real = float(sum(a * max(5000, a - 3000) for a in lens))
+print("ragged lists B=%d (6000..16384 source points, targets 3000 shorter): %.3f ms/iteration; pairs scored: %.2f %% of the padded n*m, %.2f %% of the real n_b*m_b"
+      % (B, sorted(ts)[2] * 1e3 / K, 100 * pairs / (float(B) * n * n * K), 100 * pairs / (real * K)))
+# the same clouds as one DENSE batch of the mean size, for the per-pair comparison
+nm = int(sum(lens) / B); mm = int(sum(max(5000, a - 3000) for a in lens) / B)
+Sd, Td = src[:, :nm].contiguous().cuda(), tgt[:, :mm].contiguous().cuda()
+T0d = torch.eye(4).cuda().repeat(B, 1, 1)
+def dense():
+    s, t = Sd.detach().requires_grad_(True), Td.detach().requires_grad_(True)
+    out = icp.icp(s, t, T0d, trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0}); out["T"].sum().backward(); return out
+for _ in range(3): dense()
+td = []
+for _ in range(5):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); dense(); torch.cuda.synchronize(); td.append(time.perf_counter() - t0)
+print("dense batch of the mean size (%d x %d): %.3f ms/iteration" % (nm, mm, sorted(td)[2] * 1e3 / K))

@@ -75,48 +75,50 @@ def test_new_entry_points_reject_bad_arguments(lib):
     one, P = ctypes.c_void_p(64), _lib.WeightParams(mode=1, loss=0)
     assert [lib.dicp_window_blocks(0, n, 16384) for n in (0, 1, 16384)] == [0, 1, 16]
     assert lib.dicp_window_rows(0) == 1536 and lib.dicp_window_rows(1) == 768
-    assert lib.dicp_sweep_build(0, None, 3, one, one, 1, 1, 64, 1024, one, one, one, one, None, None) == 1
-    assert lib.dicp_sweep_build(0, one, 4, one, one, 1, 1, 64, 1024, one, one, one, one, None, None) == 2
-    assert lib.dicp_sweep_build(0, one, 3, one, one, 1, 1, 64, 1024, ctypes.c_void_p(8), one, one, one, None, None) == 5
-    assert lib.dicp_sweep_sort(0, None, 3, 1, 1, 64, one, one, 0, None, None, None) == 1
-    assert lib.dicp_sweep_sort(1, one, 3, 1, 1, 64, one, one, 0, None, None, None) == 3                 # float keys only
-    assert lib.dicp_sweep_sort(0, one, 3, 1, 16385, 16448, one, one, 0, None, None, None) == 2          # beyond the LDS sort
-    assert lib.dicp_sweep_sort(0, one, 3, 1, 5, 128, one, one, 0, None, None, None) == 2                # not the padded size
-    assert lib.dicp_sweep_sort(0, one, 3, 1, 5, 64, one, one, 1024, one, None, None) == 1   # a table needs its range too
-    assert lib.dicp_query_order(0, one, None, None, 1024, 1, 1, one, None, None, None, 0, None, 0, None, None, 0, None) == 1
-    assert lib.dicp_query_order(9, one, None, one, 1024, 1, 1, one, None, None, None, 0, None, 0, None, None, 0, None) == 3
-    assert lib.dicp_query_order(0, one, None, one, 1024, 1, 1, one, None, None, None, 0, None, 0, one, one, 0, None) == 2      # keys without m
-    assert lib.dicp_loop_init(0, one, one, 0.01, 2, 1, 1, one, one, one, None) == 2
+    # dicp_sweep_build(dtype, tgt, c, center, tgt_rows, tperm, N, m, m_pad, tgs4, tgt_s, stream)
+    assert lib.dicp_sweep_build(0, None, 3, None, None, one, 1, 1, 64, one, None, None) == 1
+    assert lib.dicp_sweep_build(0, one, 4, None, None, one, 1, 1, 64, one, None, None) == 2
+    assert lib.dicp_sweep_build(0, one, 3, None, None, one, 1, 1, 64, ctypes.c_void_p(8), None, None) == 5
+    assert lib.dicp_sweep_build(0, one, 3, None, None, None, 1, 1, 64, one, None, None) == 1           # the permutation comes from dicp_sweep_sort
+    # dicp_sweep_sort(dtype, tgt, c, center, tgt_rows, N, m, m_pad, keys, tperm, nbkt, bucket, brange, scratch, bytes, stream)
+    assert lib.dicp_sweep_sort(0, None, 3, None, None, 1, 1, 64, one, one, 0, None, None, None, 0, None) == 1
+    assert lib.dicp_sweep_sort(9, one, 3, None, None, 1, 1, 64, one, one, 0, None, None, None, 0, None) == 3
+    assert lib.dicp_sweep_sort(0, one, 3, None, None, 1, 5, 128, one, one, 0, None, None, None, 0, None) == 2             # not the padded size
+    assert lib.dicp_sweep_sort(0, one, 3, None, None, 1, 5, 64, one, one, 1024, one, None, None, 0, None) == 1            # a table needs its range too
+    assert lib.dicp_sweep_sort(0, one, 3, None, None, 1, 16385, 16448, one, one, 0, None, None, None, 0, None) == 1       # beyond the LDS sort: scratch
+    assert lib.dicp_sweep_sort(1, one, 3, None, None, 1, 1, 64, one, one, 0, None, None, one, 8, None) == 1                # float64 keys: scratch too small
+    assert lib.dicp_sweep_sort_scratch_bytes(0, 4, 16384) == 0 and lib.dicp_sweep_sort_scratch_bytes(0, 4, 16448) >= 4 * 2 * 16448 * 8
+    assert lib.dicp_sweep_sort_scratch_bytes(1, 4, 64) >= 4 * 2 * 64 * 12
+    assert lib.dicp_query_order(0, one, None, None, 1024, 1, 1, one, None, None, None, 0, None, 0, None, None, 0, None, None, None) == 1
+    assert lib.dicp_query_order(9, one, None, one, 1024, 1, 1, one, None, None, None, 0, None, 0, None, None, 0, None, None, None) == 3
+    assert lib.dicp_query_order(0, one, None, one, 1024, 1, 1, one, None, None, None, 0, None, 0, one, one, 0, None, None, None) == 2      # keys without m
+    assert lib.dicp_loop_init(0, one, one, 0.01, 2, 1, 1, one, one, one, None, None, None) == 2
+    assert lib.dicp_loop_init(0, None, one, 0.01, 1, 1, 1, one, one, one, one, one, None) == 1
     assert lib.dicp_loop_finish(0, one, one, one, one, 1, 1, None, one, one, None) == 1
-    # centred search: the same checks as the uncentred entry points they extend (center itself is optional)
-    assert lib.dicp_cloud_center(0, None, 3, 1, 1, 16.0, one, None) == 1
-    assert lib.dicp_cloud_center(0, one, 3, 1, 1, 16.0, None, None) == 1
-    assert lib.dicp_cloud_center(0, one, 4, 1, 1, 16.0, one, None) == 2
-    assert lib.dicp_cloud_center(0, one, 3, 1, 1, -1.0, one, None) == 2
-    assert lib.dicp_cloud_center(5, one, 3, 1, 1, 16.0, one, None) == 3
-    assert lib.dicp_pack_target_centered(0, None, 1, 1, 3, None, None, 64, None) == 1
-    assert lib.dicp_pack_target_centered(0, one, 1, 1, 3, one, one, 63, None) == 2
-    assert lib.dicp_sweep_sort_centered(1, one, 3, one, 1, 1, 64, one, one, 0, None, None, None) == 3
-    assert lib.dicp_sweep_build_centered(0, None, 3, one, one, one, 1, 1, 64, 1024, one, one, one, one, None, None) == 1
-    assert lib.dicp_sweep_build_centered(0, one, 4, None, one, one, 1, 1, 64, 1024, one, one, one, one, None, None) == 2
-    assert lib.dicp_loop_init_centered(0, one, one, 0.01, 2, 1, 1, one, one, one, None, None, None) == 2
-    assert lib.dicp_loop_init_centered(0, None, one, 0.01, 1, 1, 1, one, one, one, one, one, None) == 1
+    # centred search (center itself is optional everywhere)
+    assert lib.dicp_cloud_center(0, None, 3, None, 1, 1, 16.0, one, None) == 1
+    assert lib.dicp_cloud_center(0, one, 3, None, 1, 1, 16.0, None, None) == 1
+    assert lib.dicp_cloud_center(0, one, 4, None, 1, 1, 16.0, one, None) == 2
+    assert lib.dicp_cloud_center(0, one, 3, None, 1, 1, -1.0, one, None) == 2
+    assert lib.dicp_cloud_center(5, one, 3, None, 1, 1, 16.0, one, None) == 3
     assert lib.dicp_search_pose(0, None, None, 1, one, None) == 1 and lib.dicp_search_pose(0, one, None, 0, one, None) == 2
-    assert lib.dicp_accumulate_bwd_window(0, ctypes.byref(P), one, one, 6, None, one, None, one, one, None, one, one, 1, 1, 64,
+    # dicp_accumulate_bwd_window(dtype, prm, src_s, tgt_s, c, spos, spos_ref, qorder, pose, w_s, alive, gs, gb, src_rows, N, n, m_pad, gsrc_s, slab, far, gw_s, partials, ow, stream)
+    assert lib.dicp_accumulate_bwd_window(0, ctypes.byref(P), one, one, 6, None, one, None, one, one, None, one, one, None, 1, 1, 64,
                                           one, None, None, None, one, 0, None) == 1
-    assert lib.dicp_accumulate_bwd_window(0, ctypes.byref(P), one, one, 6, one, one, None, one, one, None, one, one, 1, 1, 63,
+    assert lib.dicp_accumulate_bwd_window(0, ctypes.byref(P), one, one, 6, one, one, None, one, one, None, one, one, None, 1, 1, 63,
                                           one, None, None, None, one, 0, None) == 2
-    assert lib.dicp_accumulate_bwd_window(0, ctypes.byref(P), one, one, 6, one, one, None, one, one, None, one, one, 1, 1, 64,
+    assert lib.dicp_accumulate_bwd_window(0, ctypes.byref(P), one, one, 6, one, one, None, one, one, None, one, one, None, 1, 1, 64,
                                           one, one, None, None, one, 0, None) == 1      # a slab needs the side buffer too
-    assert lib.dicp_window_reduce(0, one, one, None, one, None, 1, 1, 1, 64, 5, one, 6, 0, None) == 2
-    assert lib.dicp_window_reduce(0, one, one, None, one, None, 1, 1, 1, 64, 6, one, 3, 0, None) == 2
+    assert lib.dicp_window_reduce(0, one, one, None, one, None, None, 1, 1, 1, 64, 5, one, 6, 0, None) == 2
+    assert lib.dicp_window_reduce(0, one, one, None, one, None, None, 1, 1, 1, 64, 6, one, 3, 0, None) == 2
     assert lib.dicp_permute_add_rows(0, one, one, 1, 2, 1, 2, 3, 3, one, 4, 3, None) == 2
     assert lib.dicp_permute_rows(0, one, one, 1, 2, 1, 2, 3, 3, one, 4, 3, None) == 2
     assert lib.dicp_pose_grad_in(0, None, None, 1, None) == 1 and lib.dicp_pose_grad_in(7, None, one, 1, None) == 3
     assert lib.dicp_pose_grad_out(0, one, one, 0, one, 1, None) == 2 and lib.dicp_pose_grad_out(0, one, None, 0, None, 1, None) == 1
-    assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, 1, 1, 1, 64, one, None, None, 99, None) == 4
-    assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, 1, 1, 1, 64, one, None, None, 16, None) == 4   # (the scan form is gone)
-    assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, 1, 1, 1, 64, one, None, None, 2 | 0x100, None) == 1  # sorted rows need the order
+    # dicp_knn_sweep(dtype, src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, src_rows, tgt_rows, N, n, m, m_pad, idx, spos, pairs, cfg, stream)
+    assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, None, None, 1, 1, 1, 64, one, None, None, 99, None) == 4
+    assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, None, None, 1, 1, 1, 64, one, None, None, 16, None) == 4   # (the scan form is gone)
+    assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, None, None, 1, 1, 1, 64, one, None, None, 2 | 0x100, None) == 1  # sorted rows need the order
 
 
 def test_sizes_and_argument_checks(lib):
@@ -125,17 +127,22 @@ def test_sizes_and_argument_checks(lib):
     assert [lib.dicp_accumulate_blocks(n) for n in (0, 1, 1024, 1025, 16384)] == [0, 1, 1, 2, 16]
     # rejected before any launch (no GPU touched): null pointers, bad dtype / shapes / enums
     one = ctypes.c_void_p(16)
-    assert lib.dicp_pack_target(0, None, 1, 1, 3, None, 64, None) == 1
-    assert lib.dicp_pack_target(7, one, 1, 1, 3, one, 64, None) == 3
-    assert lib.dicp_pack_target(0, one, 1, 1, 4, one, 64, None) == 2
-    assert lib.dicp_pack_target(0, one, 1, 1, 3, one, 63, None) == 2
-    assert lib.dicp_knn(0, one, None, one, 1, 1, 1, 64, one, 9, None) == 4
-    assert lib.dicp_knn(1, one, None, ctypes.c_void_p(32), 1, 1, 1, 64, one, _lib.KNN_MFMA, None) == 3
-    assert lib.dicp_knn(0, one, None, ctypes.c_void_p(8), 1, 1, 1, 64, one, 0, None) == 5
+    # dicp_pack_target(dtype, tgt, c, center, tgt_rows, N, m, tgt4, m_pad, stream)
+    assert lib.dicp_pack_target(0, None, 3, None, None, 1, 1, None, 64, None) == 1
+    assert lib.dicp_pack_target(7, one, 3, None, None, 1, 1, one, 64, None) == 3
+    assert lib.dicp_pack_target(0, one, 4, None, None, 1, 1, one, 64, None) == 2
+    assert lib.dicp_pack_target(0, one, 3, None, None, 1, 1, one, 63, None) == 2
+    # dicp_knn(dtype, src, pose, tgt4, src_rows, tgt_rows, N, n, m, m_pad, idx, variant, stream)
+    assert lib.dicp_knn(0, one, None, one, None, None, 1, 1, 1, 64, one, 9, None) == 4
+    assert lib.dicp_knn(1, one, None, ctypes.c_void_p(32), None, None, 1, 1, 1, 64, one, _lib.KNN_MFMA, None) == 3
+    assert lib.dicp_knn(0, one, None, ctypes.c_void_p(8), None, None, 1, 1, 1, 64, one, 0, None) == 5
     P = _lib.WeightParams(mode=1, loss=0)
-    assert lib.dicp_accumulate(0, ctypes.byref(P), one, one, 3, one, one, one, None, 1, 1, 1, one, None, 0, None) == 2   # pt2pl needs normals (ICP.py:103)
+    # dicp_accumulate(dtype, prm, src, tgt, c, idx, pose, w_init, alive, src_rows, N, n, m, partials, w_out, w_stride, stream)
+    assert lib.dicp_accumulate(0, ctypes.byref(P), one, one, 3, one, one, one, None, None, 1, 1, 1, one, None, 0, None) == 2   # pt2pl needs normals (ICP.py:103)
     P.loss = 9
-    assert lib.dicp_accumulate(0, ctypes.byref(P), one, one, 6, one, one, one, None, 1, 1, 1, one, None, 0, None) == 4
+    assert lib.dicp_accumulate(0, ctypes.byref(P), one, one, 6, one, one, one, None, None, 1, 1, 1, one, None, 0, None) == 4
+    P.loss = _lib.LOSS_TRIM                                                        # loss_fn "trim" is a loss like the others (loss.py:15-16)
+    assert lib.dicp_accumulate(0, ctypes.byref(P), one, one, 6, one, one, None, None, None, 1, 1, 1, one, None, 0, None) == 1   # (only the null weights are left to object to)
     assert lib.dicp_loss_weight(0, 0, 0, 1.0, 5.0, one, 4, 3, one, None) == 4      # unknown loss (loss.py:19)
     with pytest.raises(RuntimeError, match="rejected"):
         _lib.check(2, "x")

@@ -748,25 +748,26 @@ def test_icp_with_sweep_knn_matches_reference(golden, name, icp_type, diff, wind
 
 
 def test_cloud_center_is_the_quantised_median_and_zero_keeps_the_bits():
-    """dicp_cloud_center: coordinate-wise (lower) median of a stride sample of the target rows, rounded to multiples of the quantum
-    (0 near the origin), unmoved by far pad rows; the *_centered producers with a zero centre write exactly what the uncentred
-    entry points write."""
+    """dicp_cloud_center: coordinate-wise (lower) median of a stride sample of the cloud's rows, rounded to multiples of the quantum
+    (0 near the origin); a ragged batch hands over the clouds' own lengths, so the reference's far pad rows (ICP.py:460) are not in
+    the sample; with a zero centre every producer writes exactly what it writes without one."""
     g = torch.Generator().manual_seed(3)
     tgt = torch.rand((5, 777, 6), generator=g) * 20 - 10
     tgt[1, :, :3] += torch.tensor([1003.0, -37.0, 7.9])
     tgt[2, :, :3] += torch.tensor([-8.1, 24.3, 100000.0])
-    tgt[3, 500:, :] = 10000.0                                # a third of the rows are the reference's far pads (ICP.py:460) ...
-    tgt[4, 200:, :] = 10000.0                                # ... or three quarters of them: copies of the last row do not vote
+    tgt[3, 500:, :] = float("nan")                           # rows past the clouds' own lengths (never read) ...
+    tgt[4, 200:, :] = float("nan")
+    tr = torch.tensor([777, 777, 777, 500, 200], dtype=torch.int32, device=DEV)
     td = tgt.to(DEV)
-    med = tgt[:, :776, :3].float().sort(dim=1).values[:, (776 - 1) // 2]         # lower median per coordinate (all 777 rows sampled; the last
-                                                                                 # row is a copy of itself: it never votes)
+    med = tgt[:, :, :3].float().sort(dim=1).values[:, (777 - 1) // 2]            # lower median per coordinate (all 777 rows sampled)
     med[3] = tgt[3, :500, :3].float().sort(dim=0).values[(500 - 1) // 2]
     med[4] = tgt[4, :200, :3].float().sort(dim=0).values[(200 - 1) // 2]
-    exact = _ops.cloud_center(td, quantum=0.0).cpu()
+    exact = _ops.cloud_center(td, quantum=0.0, tgt_rows=tr).cpu()
     assert torch.equal(exact, med), (exact, med)
-    c = _ops.cloud_center(td, quantum=16.0).cpu()
+    c = _ops.cloud_center(td, quantum=16.0, tgt_rows=tr).cpu()
     assert torch.equal(c.double(), torch.round(med.double() / 16.0) * 16.0), (c, med)
     assert torch.equal(c[0], torch.zeros(3)) and torch.equal(c[3], torch.zeros(3)) and torch.equal(c[4], torch.zeros(3))
+    td = torch.nan_to_num(td, nan=10000.0)                   # (the index checks below run dense)
     same = torch.full((1, 50, 3), 7.25)
     assert torch.equal(_ops.cloud_center(same.to(DEV), quantum=0.0).cpu(), same[:, 0])                   # all rows one point: they all vote
     big = (torch.rand((2, 10000, 3), generator=g) * 20 - 10 + torch.tensor([500.0, 0.0, -300.0]))
@@ -806,7 +807,7 @@ def test_search_pose_from_T_init(dtype):
     assert torch.equal(out, want)
     w0 = torch.ones((N, 5), dtype=dtype, device=DEV)
     pose0, alive, nst, ps0 = (torch.empty(sh, dtype=dtype, device=DEV) for sh in ((N, 12), (N,), (N,), (N, 12)))
-    _lib.check(lib.dicp_loop_init_centered(_ops._DT[dtype], _ops._p(T), _ops._p(w0), 0.01, 1, N, 5, _ops._p(pose0), _ops._p(alive), _ops._p(nst),
+    _lib.check(lib.dicp_loop_init(_ops._DT[dtype], _ops._p(T), _ops._p(w0), 0.01, 1, N, 5, _ops._p(pose0), _ops._p(alive), _ops._p(nst),
                                            _ops._p(ctr), _ops._p(ps0), _ops._stream()), "dicp_loop_init_centered")
     assert torch.equal(ps0, out) and torch.equal(pose0[:, :9], out[:, :9]) and torch.equal(pose0[:, 9:], T[:, :3, 3])
     _lib.check(lib.dicp_search_pose(_ops._DT[dtype], _ops._p(T), None, N, _ops._p(out), _ops._stream()), "dicp_search_pose")
@@ -961,7 +962,7 @@ def test_windowed_backward_kernel_equals_atomic_kernel(dtype, mode, n, m, local)
     g1 = dict(gsrc=torch.zeros_like(src), gtgt=torch.zeros_like(tgt), gw=torch.zeros_like(w0),
               part=torch.zeros((N, nb, _lib.NBWD_PAD), dtype=dtype, device=DEV))
     _lib.check(lib.dicp_accumulate_bwd(code, ctypes.byref(P), _ops._p(src), _ops._p(tgt), c, _ops._p(idx), _ops._p(pose), _ops._p(w0),
-                                       _ops._p(alive), _ops._p(gs), _ops._p(gb), N, n, m, _ops._p(g1["gsrc"]), _ops._p(g1["gtgt"]),
+                                       _ops._p(alive), _ops._p(gs), _ops._p(gb), None, N, n, m, _ops._p(g1["gsrc"]), _ops._p(g1["gtgt"]),
                                        _ops._p(g1["gw"]), _ops._p(g1["part"]), st), "dicp_accumulate_bwd")
 
     src_s = _ops._gather_rows_raw(src, qorder)
@@ -979,14 +980,14 @@ def test_windowed_backward_kernel_equals_atomic_kernel(dtype, mode, n, m, local)
     spos_ref = spos_q if local else torch.randint(0, m, (N, n), generator=gen).to(torch.int32).to(DEV)
     for call in range(2):   # overwrite, then accumulate: two calls = twice the gradient
         _lib.check(lib.dicp_accumulate_bwd_window(code, ctypes.byref(P), _ops._p(src_s), _ops._p(tgt_s), c, _ops._p(spos_q), _ops._p(spos_ref),
-                                                  _ops._p(qorder), _ops._p(pose), _ops._p(w_s), _ops._p(alive), _ops._p(gs), _ops._p(gb), N, n, m_pad,
+                                                  _ops._p(qorder), _ops._p(pose), _ops._p(w_s), _ops._p(alive), _ops._p(gs), _ops._p(gb), None, N, n, m_pad,
                                                   _ops._p(gsrc_s), _ops._p(slab), _ops._p(gfar), _ops._p(gw_s), _ops._p(part), int(call == 0), st),
                    "dicp_accumulate_bwd_window")
     # un-permute: = into garbage (dicp_permute_rows) for the points, += into zeros (dicp_permute_add_rows) for the weights
     gsrc, gw, gtgt = torch.full_like(src, float("nan")), torch.zeros_like(w0), torch.zeros_like(tgt)
     _lib.check(lib.dicp_permute_rows(code, _ops._p(gsrc_s), _ops._p(qorder), N, n, n, n, 3, 3, _ops._p(gsrc), n, 3, st), "permute")
     _lib.check(lib.dicp_permute_add_rows(code, _ops._p(gw_s), _ops._p(qorder), N, n, n, n, 1, 1, _ops._p(gw), n, 1, st), "permute")
-    _lib.check(lib.dicp_window_reduce(code, _ops._p(slab), _ops._p(spos_ref), _ops._p(qorder), _ops._p(tperm), _ops._p(gfar), N, n, m, m_pad, cv,
+    _lib.check(lib.dicp_window_reduce(code, _ops._p(slab), _ops._p(spos_ref), _ops._p(qorder), _ops._p(tperm), _ops._p(gfar), None, N, n, m, m_pad, cv,
                                       _ops._p(gtgt), c, 0, st), "dicp_window_reduce")
     tol = 1e-11 if dtype == torch.float64 else 2e-4
     scale = lambda a: max(1.0, float(a.abs().max()))
@@ -1368,7 +1369,7 @@ def test_sweep_sort_is_the_stable_torch_sort(m, c):
     ref_keys, ref_order = torch.sort(key, dim=1, stable=True)
     keys = torch.empty((N, m_pad), device="cuda")
     perm = torch.empty((N, m_pad), dtype=torch.int32, device="cuda")
-    _lib.check(lib.dicp_sweep_sort(_lib.F32, _ops._p(tgt), c, N, m, m_pad, _ops._p(keys), _ops._p(perm), 0, None, None, _ops._stream()), "sort")
+    _lib.check(lib.dicp_sweep_sort(_lib.F32, _ops._p(tgt), c, None, None, N, m, m_pad, _ops._p(keys), _ops._p(perm), 0, None, None, None, 0, _ops._stream()), "sort")
     plain = [0, 1, 2, 4] if m >= 64 else list(range(N))                               # row 3 holds the special values
     assert torch.equal(perm.long()[plain], ref_order[plain])
     assert torch.equal(torch.nan_to_num(keys[plain], nan=7.0), torch.nan_to_num(ref_keys[plain], nan=7.0))
@@ -1385,13 +1386,50 @@ def test_sweep_sort_is_the_stable_torch_sort(m, c):
     if m >= 64:
         tgt[3, 30:32, 0] = 1.0                                                         # the index itself: finite clouds
         tgt[3, 11, 0], tgt[3, 20, 0] = 2.0, -2.0
-    a = _ops.SweepIndex(tgt)
-    b = _ops.SweepIndex(tgt, native_sort=False)
-    for name in ("keys", "tgs4", "tperm", "bucket", "brange"):
-        x, y = getattr(a, name), getattr(b, name)
-        if x.is_floating_point():                                                     # (pad keys are NaN: compare as values)
-            x, y = torch.nan_to_num(x, nan=7.0, posinf=8.0, neginf=-8.0), torch.nan_to_num(y, nan=7.0, posinf=8.0, neginf=-8.0)
-        assert torch.equal(x, y), name
+    # the index itself against one built from torch.sort's permutation
+    a = _ops.SweepIndex(tgt, sorted_rows=True)
+    key = torch.full((N, m_pad), float("nan"), device="cuda")
+    key[:, :m] = tgt[:, :, 0]
+    want = torch.sort(key, dim=1, stable=True).indices
+    assert torch.equal(a.tperm.long(), want)
+    rows = torch.gather(tgt, 1, want[:, :m].unsqueeze(-1).expand(-1, -1, c))
+    assert torch.equal(a.tgt_s[:, :m], rows) and torch.equal(a.tgs4[:, :m, :3], rows[:, :, :3])
+    assert bool((a.bucket[:, 0] == 0).all()) and bool((a.bucket[:, -1] <= m).all()) and bool((a.bucket[:, 1:] >= a.bucket[:, :-1]).all())
+
+
+@pytest.mark.parametrize("dtype,m", [(torch.float64, 300), (torch.float64, 16384), (torch.float32, 16385), (torch.float32, 40000), (torch.float64, 70001)])
+def test_chunked_key_sort_beyond_the_lds_sort(dtype, m):
+    """dicp_sweep_sort for float64 keys and for more than 16384 slots (chunked LSD radix through scratch): the stable
+    ascending order torch.sort(stable=True) gives, duplicates, -0 / +0, infinities and NaNs included; pads after everything."""
+    N, c = 3, 3
+    g = torch.Generator().manual_seed(m)
+    tgt = (torch.rand((N, m, c), generator=g, dtype=torch.float64) * 40 - 20).to(dtype)
+    tgt[1, :, 0] = torch.randint(-3, 4, (m,), generator=g).to(dtype)                  # many equal keys: stability decides
+    if m >= 64:
+        tgt[2, 5, 0], tgt[2, 9, 0], tgt[2, 11, 0], tgt[2, 20, 0] = 0.0, -0.0, float("inf"), float("-inf")
+        tgt[2, 30, 0], tgt[2, 31, 0] = float("nan"), -float("nan")
+    tgt = tgt.cuda()
+    sw = _ops.SweepIndex(tgt, sorted_rows=True)
+    m_pad = sw.tperm.shape[1]
+    key = torch.full((N, m_pad), float("nan"), dtype=dtype, device="cuda")
+    key[:, :m] = tgt[:, :, 0]
+    ref_keys, ref_order = torch.sort(key, dim=1, stable=True)
+    assert torch.equal(sw.tperm.long()[:2], ref_order[:2])
+    p64 = sw.tperm.long()
+    assert torch.equal(torch.sort(p64, dim=1).values, torch.arange(m_pad, device="cuda").expand(N, -1))
+    got = torch.gather(key, 1, p64)
+    assert torch.equal(torch.nan_to_num(sw.keys, nan=7.0), torch.nan_to_num(got, nan=7.0))
+    a_, b_ = sw.keys[:, :-1], sw.keys[:, 1:]
+    assert bool(((a_ <= b_) | torch.isnan(b_)).all()) and bool((~torch.isnan(a_) | torch.isnan(b_)).all())
+    tie = (a_ == b_) | (torch.isnan(a_) & torch.isnan(b_))
+    assert bool((p64[:, :-1] < p64[:, 1:])[tie].all())                                # ties keep their index order
+    assert bool((p64[:, :m] < m).all())                                               # sorted slots [0, m) are the real rows
+    # and the search built on it is exact
+    x = (torch.rand((N, 500, 3), generator=g, dtype=torch.float64) * 40 - 20).to(dtype).cuda()
+    clean = tgt.clone()
+    clean[2, :, 0] = torch.nan_to_num(clean[2, :, 0], nan=1.0, posinf=2.0, neginf=-2.0)
+    swc = _ops.SweepIndex(clean)
+    assert torch.equal(swc.knn(x, None, swc.query_order(x, None)), _ops.knn(x, None, _ops.pack_target(clean), m, _lib.KNN_VALU))
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])

@@ -1,0 +1,135 @@
+"""f-2: ragged batches without pad rows.  The reference pads every cloud of a list to the longest one
+(zero source rows of weight 0, target rows that are copies of one far point: ICP.py:305-511) and then computes on the pads;
+here the kernels are handed the clouds' own lengths (`src_rows` / `tgt_rows`) and never read, score or accumulate a row
+beyond them, while the API-visible tensors keep the reference's padded shapes.  `-m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+from dicp_amd import _lib, _ops
+from dicp_amd.ICP import ICP
+from dicp_amd.synthetic import make_pairs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def npy(x):
+    return x.detach().cpu().numpy()
+
+
+def rows(v):
+    return torch.tensor(v, dtype=torch.int32, device=DEV)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_search_kernels_with_row_counts_never_touch_a_pad(dtype):
+    """Every search form with per-cloud row counts == the dense call on the cropped cloud; pad rows hold NaN (any read of
+    one would poison the result) and the index slots of pad queries are left alone."""
+    N, n, m = 5, 3000, 3500
+    src, tgt = make_pairs(N, n, m, seed=31, dtype=dtype)
+    src, tgt = src.to(DEV), tgt.to(DEV)
+    ns, ms = [3000, 1, 777, 2048, 65], [3500, 900, 1, 64, 3000]
+    for b in range(N):
+        src[b, ns[b]:] = float("nan")
+        tgt[b, ms[b]:] = float("nan")
+    sr, tr = rows(ns), rows(ms)
+    ang = 0.03
+    pose = torch.tensor([np.cos(ang), -np.sin(ang), 0, np.sin(ang), np.cos(ang), 0, 0, 0, 1, 0.1, -0.2, 0.05], dtype=dtype, device=DEV).repeat(N, 1)
+    want = []
+    for b in range(N):
+        sb, tb = src[b:b + 1, :ns[b]].contiguous(), tgt[b:b + 1, :ms[b]].contiguous()
+        want.append(_ops.knn(sb, pose[b:b + 1], _ops.pack_target(tb), ms[b], _lib.KNN_VALU)[0])
+
+    def check(idx, what):
+        for b in range(N):
+            assert torch.equal(idx[b, :ns[b]], want[b]), (what, b)
+            assert bool((idx[b, ns[b]:] == -7).all()), (what, b, "pad queries must not be written")
+
+    tgt4 = _ops.pack_target(tgt, None, tr)
+    variants = [_lib.KNN_VALU | (c << 8) for c in (0, 1, 2, 3, 5, 11)] + ([_lib.KNN_MFMA, _lib.KNN_MFMA | (5 << 8)] if dtype == torch.float32 else [])
+    for v in variants:
+        idx = torch.full((N, n), -7, dtype=torch.int32, device=DEV)
+        check(_ops.knn(src, pose, tgt4, m, v, out=idx, src_rows=sr, tgt_rows=tr), ("brute", v))
+    sw = _ops.SweepIndex(tgt, sorted_rows=True, tgt_rows=tr)
+    for b in range(N):                                       # sorted slots [0, m_b) are exactly the cloud's own rows
+        assert bool((sw.tperm[b, :ms[b]] < ms[b]).all()) and not bool(torch.isnan(sw.tgs4[b, :ms[b]]).any())
+        assert not bool(torch.isnan(sw.tgt_s[b, :ms[b]]).any())
+    qo = sw.query_order(src, pose, src_rows=sr)
+    assert torch.equal(torch.sort(qo.long(), dim=1).values, torch.arange(n, device=DEV).repeat(N, 1))      # always a permutation
+    for b in range(N):
+        assert bool((qo[b, :ns[b]] < ns[b]).all()) and torch.equal(qo[b, ns[b]:].long(), torch.arange(ns[b], n, device=DEV))
+    for cfg in (0, 1, 2, 4):
+        for order in (qo, None):
+            idx = torch.full((N, n), -7, dtype=torch.int32, device=DEV)
+            spos = torch.full((N, n), -7, dtype=torch.int32, device=DEV)
+            check(sw.knn(src, pose, order, out=idx, cfg=cfg, spos=spos, src_rows=sr), ("sweep", cfg))
+            for b in range(N):
+                sp = spos[b, :ns[b]].long()
+                assert torch.equal(sw.tperm[b][sp], want[b]) and bool((spos[b, ns[b]:] == -7).all())
+    # the centre is taken from the cloud's own rows
+    ctr = _ops.cloud_center(tgt, quantum=0.0, tgt_rows=tr)
+    for b in range(N):
+        assert torch.equal(ctr[b], _ops.cloud_center(tgt[b:b + 1, :ms[b]].contiguous(), quantum=0.0)[0])
+
+
+@pytest.mark.parametrize("dtype,knn", [(torch.float64, _lib.KNN_SWEEP), (torch.float64, _lib.KNN_VALU), (torch.float32, _lib.KNN_SWEEP)])
+def test_ragged_icp_equals_per_item_calls(dtype, knn):
+    """A list of clouds of very different sizes through the whole call (sweep path with the windowed backward, and the
+    brute-force path): every result of the batch == the per-item call of that pair, gradients included; the pad rows of
+    the returned tensors are what the reference's padding yields (weight 0, pc of the zero point, zero gradient)."""
+    lens_s, lens_t = [2600, 900, 1500, 64], [2500, 1100, 2600, 300]
+    N, K = len(lens_s), 5
+    src, tgt = make_pairs(N, 2600, 2600, seed=41, dtype=dtype)
+    S = [src[b, :lens_s[b]].to(DEV).requires_grad_(True) for b in range(N)]
+    Tg = [tgt[b, :lens_t[b]].to(DEV).requires_grad_(True) for b in range(N)]
+    W = [(torch.rand(lens_s[b], generator=torch.Generator().manual_seed(b), dtype=torch.float64).to(dtype) * 0.5 + 0.5).to(DEV).requires_grad_(True) for b in range(N)]
+    T0 = [torch.eye(4, dtype=dtype, device=DEV) for _ in range(N)]
+    kw = dict(trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0}, dim=3)
+    icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
+    icp.const_iter = True
+    icp.knn_variant = knn
+    out = icp.icp(S, Tg, T0, weight=W, **kw)
+    # (the loss leaves the pad rows of pc out: they are the transformed zero point, which a per-item call does not have)
+    (out["T"].sum() + sum((out["pc"][b, :lens_s[b]] ** 2).sum() for b in range(N))).backward()
+    assert out["pc"].shape == (N, 2600, 3) and out["weights"].shape == (N, K, 2600, 1)
+    f64 = dtype == torch.float64
+    for b in range(N):
+        s1, t1, w1 = (x.detach().clone().requires_grad_(True) for x in (S[b], Tg[b], W[b]))
+        one = icp.icp(s1, t1, T0[b], weight=w1, **kw)
+        (one["T"].sum() + (one["pc"] ** 2).sum()).backward()
+        tol = 1e-10 if f64 else 2e-5
+        np.testing.assert_allclose(npy(out["T"])[b], npy(one["T"])[0], rtol=0, atol=tol)
+        np.testing.assert_allclose(npy(out["deltas"])[b], npy(one["deltas"])[0], rtol=0, atol=tol)
+        np.testing.assert_allclose(npy(out["costs"])[b], npy(one["costs"])[0], rtol=1e-6 if f64 else 1e-3, atol=tol)
+        np.testing.assert_allclose(npy(out["weights"])[b, :, :lens_s[b]], npy(one["weights"])[0], rtol=0, atol=10 * tol)
+        np.testing.assert_allclose(npy(out["pc"])[b, :lens_s[b]], npy(one["pc"])[0], rtol=0, atol=10 * tol)
+        gtol = 1e-8 if f64 else 2e-3
+        for got, want, nm in ((S[b].grad, s1.grad, "source"), (Tg[b].grad, t1.grad, "target"), (W[b].grad, w1.grad, "weight")):
+            scale = max(1.0, float(want.abs().max()))
+            np.testing.assert_allclose(npy(got), npy(want), rtol=0, atol=gtol * scale, err_msg="%s grad of cloud %d" % (nm, b))
+        # pads: weight 0 in every iteration, pc = the transformed zero point (ICP.py:274 on the zero rows)
+        assert float(out["weights"][b, :, lens_s[b]:].abs().max()) == 0.0 if lens_s[b] < 2600 else True
+        if lens_s[b] < 2600:
+            np.testing.assert_allclose(npy(out["pc"])[b, lens_s[b]:], np.broadcast_to(npy(out["T"])[b, :3, 3], (2600 - lens_s[b], 3)), rtol=0, atol=tol)
+        np.testing.assert_allclose(npy(out["stats"]["matched_ratio"])[b], npy(one["stats"]["matched_ratio"])[0], rtol=0, atol=1e-6)
+
+
+def test_ragged_batch_scores_only_real_pairs():
+    """Per real pair a ragged batch is searched no harder than a dense one: the pairs scored stay a small fraction of the
+    REAL n_b x m_b products (the padded products are 2.3x that here)."""
+    B, n, K = 16, 16384, 4
+    src, tgt = make_pairs(B, n, n, seed=3)
+    g = torch.Generator().manual_seed(0)
+    ls = torch.randint(5000, n + 1, (B,), generator=g).tolist()
+    lt = [max(4000, v - 3000) for v in ls]
+    S = [src[b, :ls[b]].to(DEV) for b in range(B)]
+    Tg = [tgt[b, :lt[b]].to(DEV) for b in range(B)]
+    icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
+    icp.const_iter = True
+    icp.knn_variant = _lib.KNN_SWEEP
+    out = icp.icp(S, Tg, [torch.eye(4, device=DEV)] * B, trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0})
+    assert bool(torch.isfinite(out["T"]).all())
+    real = float(sum(a * b for a, b in zip(ls, lt)))
+    frac = float(icp.knn_stats["knn_pairs"].sum().item()) / (real * K)
+    assert frac < 0.12, frac          # (dense benchmark clouds: ~4 % over the first four iterations; short clouds have wider tiles relative to m)

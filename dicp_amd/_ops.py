@@ -12,14 +12,16 @@ import torch
 from . import _lib
 
 _DT = {torch.float32: _lib.F32, torch.float64: _lib.F64}
-SWEEP_MIN_TARGETS = 2048     # KNN_AUTO inside ICP: below this the brute-force kernel is used
-SWEEP_MIN_PAIRS = 4e9        # ... and below this many (query,target) pairs per iteration: the per-call sorts of the
-                             # sweep cost ~0.6 ms, brute force scores ~1.4e13 pairs/s (profiles/r01_config_sweep.txt)
+SWEEP_MIN_TARGETS = 2048     # KNN_AUTO inside ICP: below this many targets per cloud the brute-force kernel is used
+SWEEP_MIN_QUERIES = 256
+SWEEP_MIN_PAIRS = 1e8        # ... and below this many (query,target) pairs per iteration.  Measured (profiles/r02_mid_size_paths.txt): with the
+                             # native key sort the sweep's per-call set-up is ~0.1 ms, and it already wins at 32 x 2048^2 and 8 x 4096^2
+                             # (0.090 vs 0.103 and 0.075 vs 0.121 ms per iteration, fwd+bwd); at 32 x 4096^2 (BASELINE configs[1]) 0.084 vs 0.175
 
 
 def auto_knn_kind(N, n, m):
-    """KNN_AUTO: exact slab-pruned search once the clouds are big enough to repay its per-call sorts."""
-    big = m >= SWEEP_MIN_TARGETS and n >= 64 and float(N) * n * m >= SWEEP_MIN_PAIRS
+    """KNN_AUTO: exact slab-pruned search once the clouds are big enough to repay its per-call sort."""
+    big = m >= SWEEP_MIN_TARGETS and n >= SWEEP_MIN_QUERIES and float(N) * n * m >= SWEEP_MIN_PAIRS
     return _lib.KNN_SWEEP if big else _lib.KNN_VALU
 _LOSS = {None: _lib.LOSS_NONE, "huber": _lib.LOSS_HUBER, "cauchy": _lib.LOSS_CAUCHY, "trim": _lib.LOSS_TRIM}
 

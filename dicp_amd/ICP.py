@@ -162,7 +162,7 @@ class ICP:
         seed = bool(getattr(self, "svd_seed_T_init", False))
         T_start = T_b if seed else torch.eye(4, dtype=T_b.dtype, device=dev).expand(T_b.shape[0], 4, 4).contiguous()
         T_found, costs, iterations = KabschLoop.apply(s_b, t_b, T_start, w_pts, int(self.max_iterations), float(self.tolerance),
-                                                      trim_dist, bool(self.const_iter), self.knn_variant, src_rows, tgt_rows)
+                                                      trim_dist, bool(self.const_iter), self.knn_variant, src_rows, tgt_rows, self.sync_every)
         if self.verbose:                                                                 # ICP.py:588-589
             print("ICP converged in {} iterations".format(int(iterations.max().item()) - 1))
         pc = transform_points(s_b, T_found)                                              # ICP.py:581

@@ -53,6 +53,14 @@ class LoopBuffers(ctypes.Structure):
                 ("src_rows", vp), ("tgt_rows", vp)]
 
 
+class KabschBuffers(ctypes.Structure):
+    """dicp_kabsch_buffers (include/dicp_hip.h)."""
+    _fields_ = [("src", vp), ("tgt", vp), ("w_init", vp), ("c", i32), ("K", i32), ("knn_variant", i32), ("m_pad", i32), ("tgt4", vp), ("tperm", vp),
+                ("qorder", vp), ("bucket", vp), ("brange", vp), ("nbkt", i32), ("pad0", i32), ("pairs", vp), ("center", vp), ("pose", vp),
+                ("pose_search", vp), ("pose_used", vp), ("idx", vp), ("partials", vp), ("save", vp), ("costs", vp), ("iterations", vp),
+                ("rows_live", vp), ("tgt_rows", vp), ("counters", vp)]
+
+
 _SIGNATURES = {
     "dicp_abi_version": ([], ctypes.c_int),
     "dicp_padded_targets": ([i32], ctypes.c_int),
@@ -90,6 +98,7 @@ _SIGNATURES = {
     "dicp_kabsch_accumulate": ([i32, vp, vp, i32, vp, vp, vp, i32, f64, vp, i32, i32, i32, vp, vp], ctypes.c_int),
     "dicp_kabsch_step": ([i32, vp, i32, vp, vp, vp, i32, vp], ctypes.c_int),
     "dicp_kabsch_step_bwd": ([i32, vp, vp, vp, i32, vp], ctypes.c_int),
+    "dicp_kabsch_forward": ([i32, ctypes.POINTER(KabschBuffers), i32, i32, i32, i32, f64, i32, f64, i32, i32, vp], ctypes.c_int),
     "dicp_kabsch_bwd": ([i32, vp, vp, i32, vp, vp, vp, i32, f64, vp, vp, i32, i32, i32, vp, vp, vp, vp], ctypes.c_int),
     "dicp_transform_points": ([i32, vp, vp, vp, i32, i32, vp], ctypes.c_int),
     "dicp_transform_points_bwd": ([i32, vp, vp, vp, vp, vp, i32, i32, vp], ctypes.c_int),

@@ -718,15 +718,18 @@ class ICPLoop(torch.autograd.Function):
 class KabschLoop(torch.autograd.Function):
     """Point-to-point ICP with the closed-form SVD step (reference: ICP.pt2pt_dICP_SVD, ICP.py:533-591), batched.
 
-    forward : K x { kNN -> dicp_kabsch_accumulate -> dicp_kabsch_step }.  Every iterate is the absolute optimum
-              T_k = argmin_T sum w |T p - y[idx_k]|^2, so the reference's composed updates telescope to the
-              last one and the gradient is ONE Kabsch adjoint through (source, target[idx_K], weight).
-    Inputs : source (N,n,3), target (N,m,3|6), T_init (N,4,4) [only seeds the first correspondence], w0 (N,n)
+    forward : dicp_kabsch_forward enqueues K x { kNN -> dicp_kabsch_accumulate -> step } back to back, one call per segment
+              (segments are cut where the host must act: a new query order of the sweep, or its all-converged check, which
+              reads a segment's counters one segment later, like ICPLoop).  Every iterate is the absolute optimum
+              T_k = argmin_T sum w |T p - y[idx_k]|^2, so the reference's composed updates telescope to the last one and
+              the gradient is ONE Kabsch adjoint through (source, target[idx_K], weight).  A cloud that meets the tolerance is
+              frozen on device at that pose (every pair stops where a call of its own would, ICP.py:585-586).
+    Inputs : source (N,n,3), target (N,m,3|6), T_init (N,4,4) [the starting pose of the search], w0 (N,n)
     Outputs: T (N,4,4) differentiable; costs (N,K), iterations (N) non-differentiable.
     """
 
     @staticmethod
-    def forward(ctx, source, target, T_init, w0, max_iterations, tolerance, trim_dist, const_iter, knn_variant, src_rows=None, tgt_rows=None):
+    def forward(ctx, source, target, T_init, w0, max_iterations, tolerance, trim_dist, const_iter, knn_variant, src_rows=None, tgt_rows=None, sync_every=None):
         for t, nm in ((source, "source"), (target, "target"), (T_init, "T_init"), (w0, "weight")):
             require_device(t, "pt2pt_dICP_SVD(" + nm + ")")
         lib = _lib.load()
@@ -737,6 +740,8 @@ class KabschLoop(torch.autograd.Function):
         src, tgt, w0c = source.contiguous(), target.contiguous(), w0.contiguous()
         trim_on = int(trim_dist is not None and trim_dist >= 0.0)
         trim = float(trim_dist) if trim_on else 0.0
+        Kmax = int(max_iterations)
+        assert Kmax >= 1, "max_iterations must be at least 1"
         with torch.cuda.device(dev):
             st = _stream()
             kind = knn_variant & 0xff
@@ -747,42 +752,54 @@ class KabschLoop(torch.autograd.Function):
             tgt4 = sweep.tgs4 if sweep is not None else pack_target(tgt, center, tgt_rows)
             nblk = lib.dicp_accumulate_blocks(n)
             pose = _pose_from_T(T_init)
-            pose_prev = pose
+            pose_s = search_pose(pose, center)
+            pose_used = torch.empty_like(pose)
             partials = torch.empty((N, nblk, _lib.NACC_PAD), dtype=dt, device=dev)
             save = torch.empty((N, _lib.KAB_SAVE), dtype=torch.float64, device=dev)
-            costs = torch.zeros((N, max_iterations), dtype=dt, device=dev)
-            iterations = torch.zeros((N,), dtype=dt, device=dev)
             idx = torch.empty((N, n), dtype=torch.int32, device=dev)
-            qorder = None
-            K = 0
-            for k in range(max_iterations):
-                pose_s = search_pose(pose, center)
-                if sweep is not None:
-                    if k < 2:
-                        qorder = sweep.query_order(src, pose_s, src_rows=src_rows)
-                    sweep.knn(src, pose_s, qorder, out=idx, cfg=(knn_variant >> 8) & 0xff, src_rows=src_rows)
-                else:
-                    _lib.check(lib.dicp_knn(code, _p(src), _p(pose_s), _p(tgt4), _p(src_rows), _p(tgt_rows), N, n, m, tgt4.shape[1], _p(idx),
-                                            kind | (knn_variant & 0xff00), st), "dicp_knn")
-                _lib.check(lib.dicp_kabsch_accumulate(code, _p(src), _p(tgt), c, _p(idx), _p(pose), _p(w0c), trim_on, trim, _p(src_rows),
-                                                      N, n, m, _p(partials), st), "dicp_kabsch_accumulate")
-                pose_prev, pose = pose, torch.empty((N, 12), dtype=dt, device=dev)
-                cost_k = torch.empty((N,), dtype=dt, device=dev)
-                _lib.check(lib.dicp_kabsch_step(code, _p(partials), nblk, _p(pose), _p(cost_k), _p(save), N, st), "dicp_kabsch_step")
-                costs[:, k] = cost_k
-                K = k + 1
-                if not const_iter:                                          # ICP.py:585-586
-                    done = cost_k < tolerance
-                    iterations = torch.where((iterations == 0) & done, torch.full_like(iterations, K), iterations)
-                    if bool(done.all()):
+            rows_live = src_rows.clone() if src_rows is not None else torch.full((N,), n, dtype=torch.int32, device=dev)
+            arena = _Arena(dev)
+            costs = arena.take((N, Kmax), dt)
+            iterations = arena.take((N,), dt)
+            counters = arena.take((Kmax,), torch.int32)
+            costs, iterations, counters = arena.finish()
+            cuts = [0, 1, 2] if sweep is not None else []
+            if not const_iter:
+                every = sync_every if sync_every is not None else (1 if float(N) * n * m >= SWEEP_MIN_PAIRS else 4)
+                cuts += list(range(0, Kmax, max(1, int(every))))
+            qorder, K = None, Kmax
+            pending, host_cnt = None, None
+            for (k0, k1) in _segments(Kmax, cuts):
+                if sweep is not None and k0 < 2:
+                    qorder = sweep.query_order(src, pose_s, src_rows=rows_live)
+                KB = _lib.KabschBuffers(
+                    src=_p(src), tgt=_p(tgt), w_init=_p(w0c), c=c, K=Kmax, knn_variant=kind | (knn_variant & 0xff00), m_pad=tgt4.shape[1],
+                    tgt4=_p(tgt4), tperm=_p(sweep.tperm) if sweep else None, qorder=_p(qorder), bucket=_p(sweep.bucket) if sweep else None,
+                    brange=_p(sweep.brange) if sweep else None, nbkt=SweepIndex.NBKT, pairs=_p(sweep.pair_shards) if sweep else None,
+                    center=_p(center), pose=_p(pose), pose_search=_p(pose_s), pose_used=_p(pose_used), idx=_p(idx), partials=_p(partials),
+                    save=_p(save), costs=_p(costs), iterations=_p(iterations), rows_live=_p(rows_live), tgt_rows=_p(tgt_rows), counters=_p(counters))
+                _lib.check(lib.dicp_kabsch_forward(code, ctypes.byref(KB), N, n, m, trim_on, trim, int(const_iter), float(tolerance), k0, k1, st),
+                           "dicp_kabsch_forward")
+                if not const_iter:      # ICP.py:585-586 for the batch: stop once every pair has stopped (frozen clouds make the overshoot a no-op)
+                    if pending is not None and _converged_at(pending) is not None:
+                        K = _converged_at(pending)
+                        pending = None
                         break
+                    if host_cnt is None:
+                        host_cnt = torch.empty((Kmax,), dtype=torch.int32, pin_memory=True)
+                    host_cnt[k0:k1].copy_(counters[k0:k1], non_blocking=True)
+                    seg_done = torch.cuda.Event()
+                    seg_done.record()
+                    pending = (k0, k1, host_cnt, seg_done)
+            if pending is not None and _converged_at(pending) is not None:
+                K = _converged_at(pending)
             iterations = torch.where(iterations == 0, torch.full_like(iterations, K), iterations)
             T = torch.zeros((N, 4, 4), dtype=dt, device=dev)
             T[:, :3, :3] = pose[:, :9].reshape(N, 3, 3)
             T[:, :3, 3] = pose[:, 9:]
             T[:, 3, 3] = 1.0
             costs = costs[:, :K].contiguous()
-        ctx.save_for_backward(src, tgt, w0c, idx, pose_prev, save)
+        ctx.save_for_backward(src, tgt, w0c, idx, pose_used, save)
         ctx.trim = (trim_on, trim)
         ctx.src_rows = src_rows
         ctx.mark_non_differentiable(costs, iterations)
@@ -808,7 +825,7 @@ class KabschLoop(torch.autograd.Function):
             gw = torch.zeros_like(w0c)
             _lib.check(lib.dicp_kabsch_bwd(code, _p(src), _p(tgt), c, _p(idx), _p(pose_prev), _p(w0c), trim_on, trim, _p(gacc), _p(ctx.src_rows),
                                            N, n, m, _p(gsrc), _p(gtgt), _p(gw), st), "dicp_kabsch_bwd")
-        return gsrc, gtgt, None, gw, None, None, None, None, None, None, None
+        return gsrc, gtgt, None, gw, None, None, None, None, None, None, None, None
 
 
 class _RowsIteration(torch.autograd.Function):
@@ -901,6 +918,7 @@ def icp_loop_gumbel(source, target, T_init, w0, cfg, eps, tau, inject_U=None):
     pose = _pose_from_T(T_init)
     deltas, costs, weights = [], [], []
     K = 0
+    pending, host_cnt, poses_hist = None, None, []
     for k in range(Kmax):
         C = pose[:, :9].reshape(N, 3, 3)
         ps_t = source @ C.transpose(1, 2) + pose[:, None, 9:]                      # ICP.py:137
@@ -911,9 +929,26 @@ def icp_loop_gumbel(source, target, T_init, w0, cfg, eps, tau, inject_U=None):
         deltas.append(delta)
         costs.append(cost)
         weights.append(wk)
+        poses_hist.append(pose)
         K = k + 1
-        if not cfg.const_iter and int(st["counters"][k].item()) == 0:              # ICP.py:259
-            break
+        if not cfg.const_iter:
+            # ICP.py:259 without draining the GPU every iteration: iteration k's counter travels to pinned memory while iteration
+            # k+1 is enqueued, and is read one iteration later.  Converged clouds are frozen (alive = 0), so the one iteration
+            # enqueued past the stopping point moves nothing; it is trimmed from the histories below.
+            if pending is not None and _converged_at(pending) is not None:
+                K = _converged_at(pending)
+                pending = None
+                break
+            if host_cnt is None:
+                host_cnt = torch.empty((Kmax,), dtype=torch.int32, pin_memory=True)
+            host_cnt[k:k + 1].copy_(st["counters"][k:k + 1], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            pending = (k, k + 1, host_cnt, ev)
+    if pending is not None and _converged_at(pending) is not None:
+        K = _converged_at(pending)
+    deltas, costs, weights = deltas[:K], costs[:K], weights[:K]
+    pose = poses_hist[K - 1]
     iterations = torch.where(st["iterations"] == 0, torch.full_like(st["iterations"], K), st["iterations"])
     start = (st["n_start"] * (st["alive"] != 0)).to(torch.int64)
     start[start == 0] = 1

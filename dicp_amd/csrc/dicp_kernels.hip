@@ -2158,6 +2158,52 @@ __global__ __launch_bounds__(WAVE) void kabsch_step_kernel(const T* __restrict__
     if (tid == 0 && cost) cost[cloud] = (T)scost;
 }
 
+// The step of the fused loop (dicp_kabsch_forward): as kabsch_step_kernel, plus the loop's bookkeeping on device.  A cloud whose
+// cost falls below the tolerance is FROZEN at that pose (rows_live = 0: the searches and sums of later iterations skip it, its
+// matches / pose / SVD of the last active iteration stay for the backward) -- every pair stops where a call of its own would
+// (ICP.py:585-586), and the iterations the host enqueues past that point before it notices are no-ops.
+template <typename T>
+__global__ __launch_bounds__(WAVE) void kabsch_loop_step_kernel(const T* __restrict__ partials, int nblk, T* __restrict__ pose, T* __restrict__ pose_search,
+                                                                T* __restrict__ pose_used, const T* __restrict__ center, T* __restrict__ costs, long cost_stride,
+                                                                int k, double* __restrict__ save, int32_t* __restrict__ rows_live, T* __restrict__ iterations,
+                                                                int const_iter, double tolerance, int32_t* __restrict__ counters) {
+    __shared__ double sacc[NACC_PAD], ssave[KAB_SAVE], sC[9], sr[3];
+    __shared__ double scost;
+    const int cloud = blockIdx.x, tid = threadIdx.x;
+    T* cst = costs + (size_t)cloud * cost_stride;
+    if (rows_live[cloud] <= 0) {                            // frozen (or empty): the history repeats its last entry
+        if (tid == 0) cst[k] = k > 0 ? cst[k - 1] : T(0);
+        return;
+    }
+    {
+        const int slot_i = tid & 31, part = tid >> 5;
+        const T* pp = partials + (size_t)cloud * nblk * NACC_PAD + slot_i;
+        double s = 0.0;
+        for (int b = part; b < nblk; b += 2) s += (double)pp[(size_t)b * NACC_PAD];
+        s += __shfl_down(s, 32);
+        if (tid < NACC_PAD) sacc[tid] = s;
+    }
+    __syncthreads();
+    if (tid == 0) scost = kabsch_forward(sacc, sC, sr, ssave);
+    __syncthreads();
+    T* ps = pose + (size_t)cloud * 12;
+    if (tid < 12) pose_used[(size_t)cloud * 12 + tid] = ps[tid];        // the pose the matches were found under (what the backward re-derives the gate from)
+    __syncthreads();
+    if (tid < 12) {
+        const T v = tid < 9 ? (T)sC[tid] : (T)sr[tid - 9];
+        ps[tid] = v;
+        if (pose_search) pose_search[(size_t)cloud * 12 + tid] = (tid >= 9 && center) ? v - center[(size_t)cloud * 3 + tid - 9] : v;
+    }
+    if (tid < KAB_SAVE) save[(size_t)cloud * KAB_SAVE + tid] = ssave[tid];
+    if (tid == 0) {
+        cst[k] = (T)scost;
+        if (!const_iter && (double)(T)scost < tolerance) {              // ICP.py:585-586
+            iterations[cloud] = (T)(k + 1);
+            rows_live[cloud] = 0;
+        } else if (counters) atomicAdd(counters + k, 1);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(WAVE) void kabsch_step_bwd_kernel(const T* __restrict__ gpose, const double* __restrict__ save,
                                                                T* __restrict__ gacc, int N) {
@@ -2810,6 +2856,43 @@ int dicp_kabsch_step(int dtype, const void* partials, int nblk, void* pose_out, 
     if (dtype == DICP_F32) kabsch_step_kernel<float><<<N, WAVE, 0, st>>>((const float*)partials, nblk, (float*)pose_out, (float*)cost, save, N);
     else                   kabsch_step_kernel<double><<<N, WAVE, 0, st>>>((const double*)partials, nblk, (double*)pose_out, (double*)cost, save, N);
     return launch_status();
+}
+
+// Iterations [k0, k1) of the SVD loop (ICP.py:549-586) enqueued back to back: K x { search -> 18 sums -> 3x3 SVD step }, no host work between.
+int dicp_kabsch_forward(int dtype, const dicp_kabsch_buffers* B, int N, int n, int m, int trim_on, double trim_dist, int const_iter, double tolerance,
+                        int k0, int k1, void* stream) {
+    if (!B || !B->src || !B->tgt || !B->w_init || !B->tgt4 || !B->pose || !B->pose_used || !B->idx || !B->partials || !B->save || !B->costs ||
+        !B->iterations || !B->rows_live || !B->counters) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (k0 < 0 || k1 > B->K || k0 > k1 || N <= 0 || n <= 0 || m <= 0 || (B->c != 3 && B->c != 6)) return DICP_ERR_SHAPE;
+    const int kind = B->knn_variant & 0xff;
+    if (kind == DICP_KNN_SWEEP && (!B->tperm || !B->bucket || !B->brange)) return DICP_ERR_NULL;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = dicp_accumulate_blocks(n);
+    const void* pose_s = B->pose_search ? B->pose_search : B->pose;
+    for (int k = k0; k < k1; ++k) {
+        int rc;
+        if (kind == DICP_KNN_SWEEP)
+            rc = dicp_knn_sweep(dtype, B->src, pose_s, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, B->rows_live, B->tgt_rows, N, n, m, B->m_pad,
+                                B->idx, nullptr, B->pairs, (B->knn_variant >> 8) & 0xff, stream);
+        else
+            rc = dicp_knn(dtype, B->src, pose_s, B->tgt4, B->rows_live, B->tgt_rows, N, n, m, B->m_pad, B->idx, B->knn_variant & 0xffff, stream);
+        if (rc) return rc;
+        rc = dicp_kabsch_accumulate(dtype, B->src, B->tgt, B->c, B->idx, B->pose, B->w_init, trim_on, trim_dist, B->rows_live, N, n, m, B->partials, stream);
+        if (rc) return rc;
+        begin_launch();
+        if (dtype == DICP_F32)
+            kabsch_loop_step_kernel<float><<<N, WAVE, 0, st>>>((const float*)B->partials, nblk, (float*)B->pose, (float*)B->pose_search, (float*)B->pose_used,
+                                                               (const float*)B->center, (float*)B->costs, (long)B->K, k, B->save, B->rows_live, (float*)B->iterations,
+                                                               const_iter, tolerance, B->counters);
+        else
+            kabsch_loop_step_kernel<double><<<N, WAVE, 0, st>>>((const double*)B->partials, nblk, (double*)B->pose, (double*)B->pose_search, (double*)B->pose_used,
+                                                                (const double*)B->center, (double*)B->costs, (long)B->K, k, B->save, B->rows_live, (double*)B->iterations,
+                                                                const_iter, tolerance, B->counters);
+        rc = launch_status();
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 int dicp_kabsch_step_bwd(int dtype, const void* gpose, const double* save, void* gacc, int N, void* stream) {

@@ -354,6 +354,43 @@ int dicp_kabsch_accumulate(int dtype, const void* src, const void* tgt, int c, c
                            const void* w_init, int trim_on, double trim_dist, const int32_t* src_rows, int N, int n, int m, void* partials, void* stream);
 int dicp_kabsch_step(int dtype, const void* partials, int nblk, void* pose_out, void* cost, double* save, int N, void* stream);
 int dicp_kabsch_step_bwd(int dtype, const void* gpose, const double* save, void* gacc, int N, void* stream);
+
+/* The whole SVD loop (ICP.py:549-586) behind one call per segment, like dicp_icp_forward: iterations [k0,k1) = K x { search -> dicp_kabsch_accumulate ->
+ * step } enqueued back to back, convergence on device.  A cloud whose cost sum w|T p - nn|^2 falls below `tolerance` (ICP.py:585; never under
+ * const_iter) is frozen at that pose: rows_live[b] becomes 0, so later searches and sums skip it, and its matches (idx), the pose they were found
+ * under (pose_used) and the SVD (save) of its last active iteration stay for dicp_kabsch_step_bwd / dicp_kabsch_bwd.  counters[k] = clouds still
+ * moving after iteration k: the caller reads them (asynchronously) to end the loop; iterations past that point are no-ops. */
+typedef struct dicp_kabsch_buffers {
+    const void* src;         /* (N,n,3) */
+    const void* tgt;         /* (N,m,c) */
+    const void* w_init;      /* (N,n) */
+    int32_t c;
+    int32_t K;               /* capacity of the cost history (= max_iterations) */
+    int32_t knn_variant;     /* as dicp_loop_buffers */
+    int32_t m_pad;
+    const void* tgt4;        /* packed rows (sorted for the sweep), built with `center` */
+    const int32_t* tperm;    /* sweep only */
+    const int32_t* qorder;   /* sweep only, may be NULL */
+    const int32_t* bucket;   /* sweep only */
+    const void* brange;      /* sweep only */
+    int32_t nbkt;
+    int32_t pad0;
+    unsigned long long* pairs;   /* sweep only, optional */
+    const void* center;      /* optional (N,3) */
+    void* pose;              /* (N,12) in/out: the current pose [C | r] */
+    void* pose_search;       /* optional (N,12) in/out: [C | r - center], what the searches read (NULL: they read pose) */
+    void* pose_used;         /* (N,12) out: the pose of each cloud's last active iteration BEFORE its step */
+    int32_t* idx;            /* (N,n) out: the matches of each cloud's last active iteration */
+    void* partials;          /* (N, dicp_accumulate_blocks(n), DICP_NACC_PAD) scratch */
+    double* save;            /* (N,DICP_KAB_SAVE) out */
+    void* costs;             /* (N,K) out */
+    void* iterations;        /* (N) zero-initialised: k+1 of the iteration a cloud converged at */
+    int32_t* rows_live;      /* (N) in/out: source rows of each cloud that take part (n, or the cloud's own length); 0 once frozen */
+    const int32_t* tgt_rows; /* optional (N) */
+    int32_t* counters;       /* (K) zero-initialised */
+} dicp_kabsch_buffers;
+int dicp_kabsch_forward(int dtype, const dicp_kabsch_buffers* buf, int N, int n, int m, int trim_on, double trim_dist, int const_iter, double tolerance,
+                        int k0, int k1, void* stream);
 int dicp_kabsch_bwd(int dtype, const void* src, const void* tgt, int c, const int32_t* idx, const void* pose, const void* w_init,
                     int trim_on, double trim_dist, const void* gacc, const int32_t* src_rows, int N, int n, int m, void* gsrc, void* gtgt, void* gw, void* stream);
 

@@ -1069,6 +1069,44 @@ def test_svd_icp_3d_batched_vs_numpy_kabsch(dtype):
     assert float((ps - tgt.to(dtype).to(DEV)[:, :, :3].mean()).abs().max()) < 50      # sane output
 
 
+@pytest.mark.parametrize("knn", [_lib.KNN_VALU, _lib.KNN_SWEEP])
+def test_svd_loop_freezes_each_pair_where_its_own_call_stops(knn):
+    """The fused SVD loop (dicp_kabsch_forward) with the tolerance check on device: every pair of a batch stops at the iteration a
+    call of its own stops at (ICP.py:585-586) -- same pose, same iteration count, same gradients -- however many iterations the
+    slowest pair of the batch needs and however rarely the host looks (sync_every); ragged lists included."""
+    N, n, m = 4, 900, 1100
+    src, tgt = make_pairs(N, n, m, seed=77, dtype=torch.float64, max_rot=0.06, max_trans=0.3, noise=0.0)
+    lens = [900, 500, 900, 120]
+    S = [src[b, :lens[b]].to(DEV).requires_grad_(True) for b in range(N)]
+    Tg = [tgt[b, :, :3].to(DEV).requires_grad_(True) for b in range(N)]
+    T0 = [torch.eye(4, dtype=torch.float64, device=DEV) for _ in range(N)]
+    outs = {}
+    for every in (1, 5):
+        icp = ICP(icp_type="pt2pt", max_iterations=40, tolerance=1e-18)
+        icp.knn_variant = knn
+        icp.sync_every = every
+        ps, T = icp.pt2pt_dICP_SVD([x.detach().clone().requires_grad_(True) for x in S], Tg, T0)
+        outs[every] = (T.detach().clone(), icp.svd_stats["iterations"].clone())
+    assert torch.equal(outs[1][0], outs[5][0]) and torch.equal(outs[1][1], outs[5][1])
+    icp = ICP(icp_type="pt2pt", max_iterations=40, tolerance=1e-18)
+    icp.knn_variant = knn
+    ps, T = icp.pt2pt_dICP_SVD(S, Tg, T0)
+    (T * torch.arange(16, dtype=torch.float64, device=DEV).reshape(4, 4)).sum().backward()
+    its = icp.svd_stats["iterations"]
+    assert float(its.min()) < 40, its                        # pairs stop on their own (each at its own iteration: compared per item below)
+    for b in range(N):
+        s1, t1 = S[b].detach().clone().requires_grad_(True), Tg[b].detach().clone().requires_grad_(True)
+        one = ICP(icp_type="pt2pt", max_iterations=40, tolerance=1e-18)
+        one.knn_variant = knn
+        p1, T1 = one.pt2pt_dICP_SVD(s1, t1, T0[b])
+        (T1 * torch.arange(16, dtype=torch.float64, device=DEV).reshape(4, 4)).sum().backward()
+        assert float(one.svd_stats["iterations"][0]) == float(its[b])
+        np.testing.assert_allclose(npy(T)[b], npy(T1), rtol=0, atol=1e-12)
+        np.testing.assert_allclose(npy(ps)[b, :lens[b]], npy(p1), rtol=0, atol=1e-11)
+        np.testing.assert_allclose(npy(S[b].grad), npy(s1.grad), rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(npy(Tg[b].grad), npy(t1.grad), rtol=1e-9, atol=1e-11)
+
+
 def test_svd_icp_gradients_vs_autograd():
     """Gradient of the final pose w.r.t. source, target and weight == torch autograd through one Kabsch solve
     on the final correspondences (the composed updates of the reference telescope to exactly that)."""

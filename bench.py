@@ -158,7 +158,11 @@ def cpu_baseline(n, m, budget_s=25.0):
                       % (Bc, K, n, len(times), best)}, T_ref
 
 
-def main():
+def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
+    """argv / make_icp / device / backend / emit: the launcher seam.  bench.py itself runs with the defaults (dicp_amd's ICP on
+    this rank's MI355X, RCCL, the JSON line to stdout); tests/test_bench_launcher.py drives the very same launcher path -- rank
+    environment, process group, weak-scaling seeds, barriers, max-over-ranks timing, pose all-gather, the JSON line -- on two gloo
+    CPU ranks with a stand-in `make_icp`, which is how the N > 1 path is covered without a multi-GPU box."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10, help="K: ICP iterations per timed call (SURVEY 8d: 10)")
@@ -170,7 +174,11 @@ def main():
                     help="auto/sweep: exact slab-pruned kNN (same indices as brute force); valu/mfma: brute-force kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip value_bruteforce / value_tolerance")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    on_gpu = device is None
+    sync = torch.cuda.synchronize if on_gpu else (lambda: None)
+    if make_icp is None:
+        make_icp = lambda **kw: ICP(**kw)                               # noqa: E731
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -178,10 +186,11 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
                          "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (args.gpus, args.gpus))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if on_gpu:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank) if on_gpu else device
     # synthetic inputs are generated on the CPU: keep N ranks from oversubscribing the host's cores
     torch.set_num_threads(max(1, min(16, (os.cpu_count() or 1) // max(1, world))))
     # DICP_BENCH_FORCE_DIST=1 runs the distributed code path (RCCL init, barrier, pose all-gather, max-reduce)
@@ -190,7 +199,10 @@ def main():
     use_dist = world > 1 or force_dist
     ranks_seen, rccl = 1, None
     if use_dist:
-        torch.distributed.init_process_group("nccl", device_id=dev)     # RCCL
+        if on_gpu:
+            torch.distributed.init_process_group(backend, device_id=dev)        # "nccl" = RCCL
+        else:
+            torch.distributed.init_process_group(backend)
         ranks_seen = torch.distributed.get_world_size()
         try:
             rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
@@ -205,10 +217,10 @@ def main():
     cw = world if not (force_dist and world == 1) else -1
 
     def fence():
-        torch.cuda.synchronize()
+        sync()
         if use_dist:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     def all_max(x):
         if not use_dist:
@@ -223,10 +235,10 @@ def main():
         (back-to-back calls get faster for a while on a cold box: scripts/call_repeat_diag.py).  Same count on every rank."""
         calls, recent = 0, []
         while calls < most:
-            torch.cuda.synchronize()
+            sync()
             t_w = time.perf_counter()
             run_call(icp_obj, src, tgt, T0, cw)
-            torch.cuda.synchronize()
+            sync()
             recent = (recent + [time.perf_counter() - t_w])[-3:]
             calls += 1
             done = calls >= least and max(recent) <= 1.03 * min(recent)
@@ -249,7 +261,7 @@ def main():
             times.append(all_max(time.perf_counter() - t0))
         return times, last
 
-    icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=max(W, 1), tolerance=1e-12)
+    icp = make_icp(icp_type="pt2pl", differentiable=True, max_iterations=max(W, 1), tolerance=1e-12)
     icp.const_iter = True
     icp.knn_variant = {"auto": 0, "sweep": 3, "valu": 1, "mfma": 2}[args.knn]
     brute = args.knn in ("valu", "mfma")      # (auto also runs brute force when the clouds are small: settled after the timed calls)
@@ -257,8 +269,9 @@ def main():
         run_call(icp, src, tgt, T0, cw)                                  # W untimed warm-up steps
     icp.max_iterations = K
     log = EventLog()
-    log.handles(K)                          # create the HIP events now: not part of the timed workload
-    icp._timing_events = None if os.environ.get("DICP_BENCH_NO_EVENTS") == "1" else log      # (experiment switch: what do the events cost?)
+    if on_gpu:
+        log.handles(K)                      # create the HIP events now: not part of the timed workload
+    icp._timing_events = None if (os.environ.get("DICP_BENCH_NO_EVENTS") == "1" or not on_gpu) else log      # (experiment switch: what do the events cost?)
     # a generational GC pass over this process's heap takes tens of ms (10 steps take 5 ms): whether one lands inside a
     # timed call depends on the allocation count so far, i.e. on things as irrelevant as argv -> collect now and pause
     # the collector.  The collection goes BEFORE the steady-state calls: the first call after one is ~0.8 ms slower
@@ -268,12 +281,12 @@ def main():
     steady_calls = steady(icp)
     times, (out, T_all, gs, gt) = timed(icp, reps)                       # reps x exactly K steps
     elapsed = median(times)
-    knn_all, acc_all, bwd_all = log.all_ms("knn"), log.all_ms("accumulate"), log.all_ms("accumulate_bwd")   # of the LAST timed call
+    knn_all, acc_all, bwd_all = ([], [], []) if not on_gpu else (log.all_ms("knn"), log.all_ms("accumulate"), log.all_ms("accumulate_bwd"))   # of the LAST timed call
     sane = bool(torch.isfinite(out["T"]).all() and torch.isfinite(gs).all() and torch.isfinite(gt).all())
     from dicp_amd import _ops, _lib as L
     from dicp_amd._ops import auto_knn_kind
     # knn=auto takes the brute-force kernel for small clouds (no sorted-sweep statistics then)
-    if args.knn == "auto" and auto_knn_kind(B, n, m) != L.KNN_SWEEP:
+    if (args.knn == "auto" and auto_knn_kind(B, n, m) != L.KNN_SWEEP) or not on_gpu:
         brute = True
     # pairs scored per kNN launch of the LAST timed call (each call has its own counters)
     pairs_scored = None if brute else float(icp.knn_stats["knn_pairs"].sum().item()) / K
@@ -282,14 +295,14 @@ def main():
     extra = {}
     if not args.no_extra_legs:
         if not brute:
-            bf = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
+            bf = make_icp(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
             bf.const_iter = True
             bf.knn_variant = L.KNN_VALU
             steady(bf, least=2, most=4)
             bt, _ = timed(bf, 3)
             extra["value_bruteforce"] = world * B * K / median(bt)
             extra["bruteforce_note"] = "same call with the brute-force kNN kernel (all n*m pairs) in the loop: median of 3 calls, %.3f ms per step" % (median(bt) * 1e3 / K)
-        tol = ICP(icp_type="pt2pl", differentiable=True, max_iterations=50, tolerance=1e-4)
+        tol = make_icp(icp_type="pt2pl", differentiable=True, max_iterations=50, tolerance=1e-4)
         tol.const_iter = False
         tol.knn_variant = icp.knn_variant
         steady(tol, least=3, most=8)
@@ -302,18 +315,20 @@ def main():
 
     # three extra, untimed launches of the brute-force kNN kernel with HIP events: its roofline is reported
     # beside the running kernel's even when the (faster, exact) sweep kernel is the one in the loop
-    tgt4 = _ops.pack_target(tgt)
-    pose_id = torch.cat((torch.eye(3, device=dev).reshape(9), torch.zeros(3, device=dev))).repeat(B, 1).contiguous()
-    idx_tmp = torch.empty((B, n), dtype=torch.int32, device=dev)
-    bf = []
-    for _ in range(3):
+    bf = [float("nan")] * 3
+    if on_gpu:
+        tgt4 = _ops.pack_target(tgt)
+        pose_id = torch.cat((torch.eye(3, device=dev).reshape(9), torch.zeros(3, device=dev))).repeat(B, 1).contiguous()
+        idx_tmp = torch.empty((B, n), dtype=torch.int32, device=dev)
+        bf = []
+    for _ in range(3 if on_gpu else 0):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         _ops.knn(src, pose_id, tgt4, m, L.KNN_MFMA if args.knn == "mfma" else L.KNN_VALU, out=idx_tmp)
         b.record()
         torch.cuda.synchronize()
         bf.append(a.elapsed_time(b))
-    bf_ms = sorted(bf)[1]
+    bf_ms = sorted(bf)[1] if on_gpu else None
 
     rc = 0
     if rank == 0:
@@ -361,8 +376,8 @@ def main():
                          "note": "8 flop per SCORED (query,target) pair vs the f32 peak; the kernel is FP32-compute-bound, "
                                  "its algorithmic HBM traffic is <1% of what HBM could move in its run time"},
             "roofline_bruteforce_knn": {"kernel": "knn_%s_kernel (all n*m pairs)" % ("mfma" if args.knn == "mfma" else "valu"), "bound": "mfma",
-                                        "achieved": flops_bf / (bf_ms * 1e-3) / 1e12, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                        "frac": flops_bf / (bf_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS, "traffic": bf_traffic, "traffic_source": bf_src,
+                                        "achieved": flops_bf / (bf_ms * 1e-3) / 1e12 if bf_ms else None, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                        "frac": flops_bf / (bf_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS if bf_ms else None, "traffic": bf_traffic, "traffic_source": bf_src,
                                         "avg_launch_ms": bf_ms, "measured": "3 extra launches outside the timed region, HIP events"},
             "roofline_accumulate": {"kernel": "accumulate (forward: residuals, weights, Jacobian, normal-equation sums)", "bound": "hbm",
                                     "achieved": acc_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -383,7 +398,7 @@ def main():
             base, T_ref = cpu_baseline(n, m)
             line["cpu_baseline"] = base
             # correctness gate: the same 4 clouds x 3 iterations on the GPU vs the oracle
-            chk = ICP(icp_type="pt2pl", differentiable=True, max_iterations=3, tolerance=1e-12)
+            chk = make_icp(icp_type="pt2pl", differentiable=True, max_iterations=3, tolerance=1e-12)
             chk.const_iter = True
             chk.knn_variant = icp.knn_variant
             o = chk.icp(src[:T_ref.shape[0]], tgt[:T_ref.shape[0]], T0[:T_ref.shape[0]], trim_dist=TRIM, loss_fn=LOSS, dim=3)
@@ -397,7 +412,7 @@ def main():
             line["value"] = None
             line["error"] = "results not finite or pose differs from the oracle by more than %g" % POSE_BAR
             rc = 1
-        os.write(_REAL_STDOUT, (json.dumps(line) + "\n").encode())
+        (emit or (lambda text: os.write(_REAL_STDOUT, text.encode())))(json.dumps(line) + "\n")
     if use_dist:
         torch.distributed.destroy_process_group()
     return rc

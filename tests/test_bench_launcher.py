@@ -1,0 +1,71 @@
+"""bench.py's N > 1 launcher path on two gloo CPU ranks (no GPU, no RCCL): rank environment, process group, weak-scaling
+cloud seeds (rank g draws clouds g*B ..), barriers, max-over-ranks timing, the pose all-gather and the ONE JSON line of rank 0.
+The compute is a stand-in handed in through bench.main's `make_icp` seam (the oracle: this is a test, bench.py itself never
+touches it outside its cpu_baseline leg); everything else is the code the driver launches with torch.distributed.run."""
+import hashlib
+import json
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+B, N_PTS, K = 2, 96, 2
+
+
+class OracleICP:
+    """Same call surface as dicp_amd.ICP.ICP for what bench.py uses; records which clouds it was handed."""
+
+    def __init__(self, log_dir, **kw):
+        self.kw, self.log_dir = kw, log_dir
+        self.max_iterations, self.const_iter, self.knn_variant, self._timing_events = kw["max_iterations"], True, 0, None
+        self.knn_stats = {}
+
+    def icp(self, source, target, T_init, trim_dist=None, loss_fn=None, dim=3):
+        from oracle import dicp_oracle as O
+        rank = int(os.environ["RANK"])
+        with open(os.path.join(self.log_dir, "clouds_%d.txt" % rank), "w") as f:
+            f.write(hashlib.sha256(source.detach().numpy().tobytes()).hexdigest())
+        return O.icp_batched(source, target, T_init, torch.ones(source.shape[:2], dtype=source.dtype), icp_type=self.kw["icp_type"],
+                             differentiable=True, max_iterations=int(self.max_iterations), tolerance=self.kw["tolerance"],
+                             trim_dist=trim_dist, loss_fn=loss_fn, dim=dim, const_iter=bool(self.const_iter), tanh_steepness=5.0)
+
+
+def worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    import bench
+    lines = []
+    rc = bench.main(["--gpus", str(world), "--steps", str(K), "--warmup", "1", "--batch", str(B), "--points", str(N_PTS), "--reps", "5",
+                     "--no-cpu-baseline", "--no-extra-legs"],
+                    make_icp=lambda **kw: OracleICP(out_dir, **kw), device=torch.device("cpu"), backend="gloo", emit=lines.append)
+    assert rc == 0
+    with open(os.path.join(out_dir, "line_%d.json" % rank), "w") as f:
+        f.write("".join(lines))
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_bench_two_rank_dry_run(tmp_path):
+    from dicp_amd.synthetic import make_pairs
+    world = 2
+    mp.spawn(worker, args=(world, free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert open(tmp_path / "line_1.json").read() == ""                  # only rank 0 prints
+    text = open(tmp_path / "line_0.json").read()
+    assert text.count("\n") == 1                                        # ONE line
+    line = json.loads(text)
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["steps"] == K and line["warmup"] == 1
+    assert line["scaling"] == "weak" and line["higher_is_better"] is True and line["unit"] == "cloud-iterations/s"
+    assert line["timed_calls"] == 5 and len(line["call_ms"]) == 5 and line["config"]["K"] == K
+    med = sorted(line["call_ms"])[2]
+    assert abs(line["value"] - world * B * K / (med * 1e-3)) <= 1e-4 * line["value"]        # whole-job aggregate over both ranks (call_ms is rounded to 0.1 us)
+    assert abs(line["ms_per_step"] - med / K) < 1e-4
+    assert "x2" in line["config"]["parallelism"] and line["finite"] is True
+    # weak scaling with global cloud seeds: rank g's clouds are clouds g*B .. (g+1)*B of the single-process batch
+    for g in range(world):
+        want, _ = make_pairs(B, N_PTS, N_PTS, seed=3, dtype=torch.float32, first=g * B)
+        assert open(tmp_path / ("clouds_%d.txt" % g)).read() == hashlib.sha256(want.numpy().tobytes()).hexdigest()

@@ -3,7 +3,7 @@ per-launch HBM traffic table bench.py quotes.  Units and corrections per MI355X_
 FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly half of a wide coalesced
 streaming read, so it is doubled; WRITE_SIZE is exact for 16-B streaming stores and float atomics.
 
-    python scripts/pmc_summary.py <fetch_dir> <write_dir> <out.json> [B n]
+    python scripts/pmc_summary.py <fetch_dir> <write_dir> <out.json> [B n [commit]]
 """
 import collections, csv, glob, json, sys
 
@@ -19,7 +19,8 @@ def load(d, counter):
 
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 out = {"units": "bytes per launch (mean over launches)", "fetch_correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-read under-count)",
-       "workload": {"B": int(sys.argv[4]) if len(sys.argv) > 4 else 256, "n": int(sys.argv[5]) if len(sys.argv) > 5 else 16384}, "kernels": {}}
+       "workload": {"B": int(sys.argv[4]) if len(sys.argv) > 4 else 256, "n": int(sys.argv[5]) if len(sys.argv) > 5 else 16384},
+       "commit": sys.argv[6] if len(sys.argv) > 6 else "unknown", "kernels": {}}
 for name in sorted(set(fetch) | set(write)):
     if "anonymous namespace" not in name:
         continue

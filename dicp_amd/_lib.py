@@ -50,7 +50,7 @@ class LoopBuffers(ctypes.Structure):
                 ("pairs", vp), ("spos", vp), ("src_s", vp), ("spos_ref", vp), ("gts_far", vp), ("poses", vp), ("deltas", vp), ("costs", vp), ("areg", vp), ("alive", vp), ("converged", vp),
                 ("iterations", vp), ("matched_ratio", vp), ("n_start", vp), ("n_matched", vp), ("idx", vp), ("w", vp), ("w_iter", i64), ("w_stride", i64), ("w_prev0", vp),
                 ("partials", vp), ("counters", vp), ("events", vp), ("bwd_overwrite", i32), ("center", vp), ("poses_search", vp),
-                ("src_rows", vp), ("tgt_rows", vp)]
+                ("src_rows", vp), ("tgt_rows", vp), ("tgt_sorted", vp), ("tgt_sorted_stride", i32)]
 
 
 class KabschBuffers(ctypes.Structure):
@@ -73,7 +73,7 @@ _SIGNATURES = {
     "dicp_window_rows": ([i32], ctypes.c_int),
     "dicp_sweep_sort_scratch_bytes": ([i32, i32, i32], ctypes.c_size_t),
     "dicp_sweep_sort": ([i32, vp, i32, vp, vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, ctypes.c_size_t, vp], ctypes.c_int),
-    "dicp_sweep_build": ([i32, vp, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp], ctypes.c_int),
+    "dicp_sweep_build": ([i32, vp, i32, vp, vp, vp, i32, i32, i32, vp, vp, i32, vp], ctypes.c_int),
     "dicp_query_order": ([i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, vp], ctypes.c_int),
     "dicp_query_keys": ([i32, vp, vp, i32, i32, vp, vp], ctypes.c_int),
     "dicp_loop_init": ([i32, vp, vp, ctypes.c_double, i32, i32, i32, vp, vp, vp, vp, vp, vp], ctypes.c_int),

@@ -118,7 +118,7 @@ class SweepIndex:
     NBKT = 1024
 
     def __init__(self, tgt, sorted_rows=False, center=None, tgt_rows=None):
-        """sorted_rows: also keep tgt_s (N,m_pad,c), the full rows in sorted order (the windowed backward reads them).
+        """sorted_rows: also keep tgt_s (N,m_pad,row_stride), the full rows in sorted order (the loop's accumulate and the windowed backward gather them).
         center (N,3): the index is built on y - center (keys, table and packed rows; tgt_s keeps the rows as given) and the
         searches must then be given the pose [C | r - center].
         tgt_rows (N) int32: rows of each cloud that take part (ragged batches); the searches are given the same counts."""
@@ -135,14 +135,16 @@ class SweepIndex:
         self.bucket = torch.empty((N, self.NBKT + 1), dtype=torch.int32, device=dev)
         self.brange = torch.empty((N, 2), dtype=dt, device=dev)
         self.keys = torch.empty((N, m_pad), dtype=dt, device=dev)          # sorted x keys: the rank search of query_order reads them
-        self.tgt_s = torch.empty((N, m_pad, c), dtype=dt, device=dev) if sorted_rows else None
+        # the full rows in sorted order, padded to 16 / 32 bytes (c = 3 / 6 float32; twice that in float64): one aligned sector per gathered row
+        self.row_stride = 8 if c == 6 else 4
+        self.tgt_s = torch.empty((N, m_pad, self.row_stride), dtype=dt, device=dev) if sorted_rows else None
         nbytes = int(lib.dicp_sweep_sort_scratch_bytes(_DT[dt], N, m_pad))     # float64 keys / more than 16384 slots: chunked sort through scratch
         scratch = torch.empty((nbytes,), dtype=torch.uint8, device=dev) if nbytes else None
         with torch.cuda.device(dev):
             _lib.check(lib.dicp_sweep_sort(_DT[dt], _p(tgt), c, _p(center), _p(tgt_rows), N, m, m_pad, _p(self.keys), _p(self.tperm), self.NBKT,
                                            _p(self.bucket), _p(self.brange), _p(scratch), nbytes, _stream()), "dicp_sweep_sort")
             _lib.check(lib.dicp_sweep_build(_DT[dt], _p(tgt), c, _p(center), _p(tgt_rows), _p(self.tperm), N, m, m_pad,
-                                            _p(self.tgs4), _p(self.tgt_s), _stream()), "dicp_sweep_build")
+                                            _p(self.tgs4), _p(self.tgt_s), self.row_stride, _stream()), "dicp_sweep_build")
         self.pair_shards = torch.zeros((_lib.PAIR_SHARDS,), dtype=torch.int64, device=dev)
 
     @property
@@ -357,7 +359,7 @@ def prebuild_search(source, target, knn_variant, want_rows, T_init=None, src_row
     if kind != _lib.KNN_SWEEP or not target.is_cuda or not target.is_contiguous() or target.dtype not in _DT:
         return None
     with torch.cuda.device(target.device):
-        sweep = SweepIndex(target, sorted_rows=bool(want_rows), center=cloud_center(target, tgt_rows=tgt_rows), tgt_rows=tgt_rows)
+        sweep = SweepIndex(target, sorted_rows=True, center=cloud_center(target, tgt_rows=tgt_rows), tgt_rows=tgt_rows)
         # ... and the first query order, from T_init alone (the loop's own pose_0 does not exist yet): with it the queue holds
         # ~0.2 ms of work while the host builds the loop state
         first = None
@@ -410,7 +412,6 @@ def _pose_from_T(T):
     return torch.cat((T[:, :3, :3].reshape(N, 9), T[:, :3, 3]), dim=1).contiguous()
 
 
-WINDOW_MIN_ITERS = 3            # fewer windowed iterations than this: all take the atomic backward (see ICPLoop.backward)
 HIST_CHUNK_BYTES = 1 << 29      # per-iteration histories (indices, weights) are allocated in slabs of at most this size
 
 
@@ -489,10 +490,10 @@ class ICPLoop(torch.autograd.Function):
             if kind == _lib.KNN_SWEEP:
                 pre = cfg.prebuilt
                 if (pre is not None and pre[0].data_ptr() == tgt.data_ptr() and pre[0].shape == tgt.shape and pre[0].dtype == tgt.dtype
-                        and (pre[1].tgt_s is not None or not owned) and pre[1].tgt_rows is cfg.tgt_rows):
+                        and pre[1].tgt_s is not None and pre[1].tgt_rows is cfg.tgt_rows):
                     sweep = pre[1]                           # started by the caller, under its host work
                 else:
-                    sweep = SweepIndex(tgt, sorted_rows=owned, center=cloud_center(tgt, tgt_rows=cfg.tgt_rows), tgt_rows=cfg.tgt_rows)
+                    sweep = SweepIndex(tgt, sorted_rows=True, center=cloud_center(tgt, tgt_rows=cfg.tgt_rows), tgt_rows=cfg.tgt_rows)
             # the searches run in coordinates centred on the target cloud (dicp_cloud_center): packed rows y - c, pose [C | r - c]
             center = sweep.center if sweep is not None else cloud_center(tgt, tgt_rows=cfg.tgt_rows)
             tgt4 = sweep.tgs4 if sweep is not None else pack_target(tgt, center, cfg.tgt_rows)
@@ -517,7 +518,12 @@ class ICPLoop(torch.autograd.Function):
             # pose_0, alive_0, n_start (ICP.py:124-129)
             _lib.check(lib.dicp_loop_init(code, _p(T_init.contiguous()), _p(w0c), float(cfg.match_ratio_thresh), rows, N, n,
                                           _p(poses), _p(alive), _p(n_start), _p(center), _p(poses_c), st), "dicp_loop_init")
-            idx_once = None if need_grad else torch.empty((N, n), dtype=torch.int32, device=dev)
+            # sweep path: the matches are kept as SORTED positions (spos) -- accumulate gathers the sorted, sector-aligned rows with them and
+            # the windowed backward consumes them; original indices (idx) are only kept for the brute-force searches and the atomic backward
+            keep_idx = sweep is None or (need_grad and not owned)
+            idx_once = torch.empty((N, n), dtype=torch.int32, device=dev) if (keep_idx and not need_grad) else None
+            keep_spos = sweep is not None and need_grad       # per-iteration sorted positions (the windowed backward reads them; same layout as idx)
+            spos_once = torch.empty((N, n), dtype=torch.int32, device=dev) if (sweep is not None and not need_grad) else None
 
             # histories in slabs of kc iterations: slab j covers iterations [j*kc, (j+1)*kc)
             per_iter = N * n * max(es, 4)
@@ -545,9 +551,9 @@ class ICPLoop(torch.autograd.Function):
                 if j == len(w_slabs):
                     kk = min(kc, Kmax - j * kc)
                     w_slabs.append(torch.empty((N, kc, n), dtype=dt, device=dev))     # (N,K,n) layout as returned; same cloud stride in every slab
-                    if need_grad:
+                    if need_grad and keep_idx:
                         idx_slabs.append(torch.empty((kk, N, n), dtype=torch.int32, device=dev))
-                    if owned:
+                    if keep_spos:
                         spos_slabs.append(torch.empty((kk, N, n), dtype=torch.int32, device=dev))
                 if sweep is not None and (qorder is None or k0 in cfg.sweep_resort):
                     # queries re-ordered by x under the current pose
@@ -565,10 +571,11 @@ class ICPLoop(torch.autograd.Function):
                     tgt4=_p(tgt4), tperm=_p(sweep.tperm) if sweep else None, qorder=_p(qorder),
                     bucket=_p(sweep.bucket) if sweep else None, brange=_p(sweep.brange) if sweep else None,
                     nbkt=SweepIndex.NBKT, idx_per_iter=int(need_grad), pairs=_p(sweep.pair_shards) if sweep else None,
-                    spos=ctypes.c_void_p(spos_slabs[j].data_ptr() - base * N * n * 4) if owned else None,
+                    spos=ctypes.c_void_p(spos_slabs[j].data_ptr() - base * N * n * 4) if keep_spos else _p(spos_once),
                     poses=_p(poses), deltas=_p(deltas), costs=_p(costs), areg=_p(areg), alive=_p(alive), converged=_p(converged),
                     iterations=_p(iterations), matched_ratio=_p(matched), n_start=_p(n_start), n_matched=_p(n_matched),
-                    idx=ctypes.c_void_p(idx_slabs[j].data_ptr() - base * N * n * 4) if need_grad else _p(idx_once),
+                    idx=(ctypes.c_void_p(idx_slabs[j].data_ptr() - base * N * n * 4) if need_grad else _p(idx_once)) if keep_idx else None,
+                    tgt_sorted=_p(sweep.tgt_s) if sweep is not None else None, tgt_sorted_stride=sweep.row_stride if sweep is not None else 0,
                     w=ctypes.c_void_p(w_slabs[j].data_ptr() - base * n * es), w_iter=n, w_stride=kc * n,
                     w_prev0=_p(w_slabs[(k0 - 1) // kc][:, (k0 - 1) % kc]) if k0 > 0 else None,
                     partials=_p(partials), counters=_p(counters), events=events, center=_p(center), poses_search=_p(poses_c),
@@ -647,9 +654,8 @@ class ICPLoop(torch.autograd.Function):
             # matches are stored per query, so the forward may have searched those iterations in other orders.  Matches that
             # fall outside a window (early iterations, whose poses are still far) take the kernel's atomic side path.
             q_star = len(qorders) - 1
-            windowed = [bool(owned)] * len(segs)        # (measured: even iteration 0, whose matches lie far from the final ones, pays: 0.13 vs 0.28 ms)
-            if sum(b - a for (a, b, _), wf in zip(segs, windowed) if wf) < WINDOW_MIN_ITERS:
-                windowed = [False] * len(segs)
+            windowed = [bool(owned)] * len(segs)        # (measured: even iteration 0, whose matches lie far from the final ones, pays: 0.13 vs 0.28 ms;
+                                                        #  a sweep call keeps sorted positions only, so it always takes the windowed form)
             only_windowed = all(windowed) and len(windowed) > 0
             all_windowed = only_windowed and c == cv
             if want_tgt:    # all windowed: dicp_window_reduce writes every element once, no zero fill needed
@@ -686,12 +692,12 @@ class ICPLoop(torch.autograd.Function):
                 base = j * kc
                 LB = _lib.LoopBuffers(
                     src=_p(src_s) if w_form else _p(src), tgt=_p(tgt_s) if w_form else _p(tgt),
-                    w_init=_p(w_s) if w_form else _p(w0c), c=c, K=Kmax, knn_variant=kind | ((0 if cfg.small_loop else 1) << 25), m_pad=m_pad, idx_per_iter=1,
+                    w_init=_p(w_s) if w_form else _p(w0c), c=tgt_s.shape[2] if w_form else c, K=Kmax, knn_variant=kind | ((0 if cfg.small_loop else 1) << 25), m_pad=m_pad, idx_per_iter=1,
                     qorder=_p(qo) if w_form else None,
                     spos=ctypes.c_void_p(spos_slabs[j].data_ptr() - base * N * n * 4) if w_form else None,
                     spos_ref=_p(spos_ref) if w_form else None, gts_far=_p(gfar) if w_form else None,
                     poses=_p(poses), deltas=_p(deltas), areg=_p(areg), alive=_p(alive),
-                    idx=ctypes.c_void_p(idx_slabs[j].data_ptr() - base * N * n * 4), events=events,
+                    idx=ctypes.c_void_p(idx_slabs[j].data_ptr() - base * N * n * 4) if idx_slabs else None, events=events,
                     bwd_overwrite=fresh if (w_form and k1 > k0) else 0, src_rows=_p(cfg.src_rows), tgt_rows=_p(cfg.tgt_rows))
                 if w_form and k1 > k0:
                     fresh = 0

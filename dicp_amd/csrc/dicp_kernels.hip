@@ -203,7 +203,7 @@ __global__ __launch_bounds__(BLOCK) void pack_kernel(const T* __restrict__ tgt, 
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void sweep_rows_kernel(const T* __restrict__ tgt, const int32_t* __restrict__ tgt_rows, int N, int m, int c,
                                                            int m_pad, int bpc, typename V4<T>::type* __restrict__ tgs4, const int32_t* __restrict__ tperm,
-                                                           T* __restrict__ tgt_s /* optional (N,m_pad,c): the full rows in sorted order */,
+                                                           T* __restrict__ tgt_s /* optional (N,m_pad,rs): the full rows in sorted order */, int rs /* elements per row of tgt_s, >= c */,
                                                            const T* __restrict__ center /* optional (N,3): tgs4 rows are y - centre; tgt_s stays as given */) {
     constexpr int U = 4;                                    // rows per thread in flight (index -> row is a dependent pair)
     int b, blk;
@@ -234,9 +234,10 @@ __global__ __launch_bounds__(BLOCK) void sweep_rows_kernel(const T* __restrict__
             else { v.x = big_v<T>(); v.y = v.z = T(0); v.w = inf_v<T>(); }      // pads sort last and can never win
             tgs4[(size_t)b * m_pad + sl] = v;
             if (tgt_s) {
-                T* o = tgt_s + ((size_t)b * m_pad + sl) * c;
+                T* o = tgt_s + ((size_t)b * m_pad + sl) * rs;
                 o[0] = y[u][0]; o[1] = y[u][1]; o[2] = y[u][2];
                 if (full) { o[3] = y[u][3]; o[4] = y[u][4]; o[5] = y[u][5]; }
+                for (int k = c; k < rs; ++k) o[k] = T(0);
             }
         }
     }
@@ -1030,9 +1031,10 @@ __global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? SWEE
             // >= 3 chunks share the minimum (duplicated targets): rare, re-scan what this wave visited
             for (int j = visL * WAVE; j < visR * WAVE; ++j) consider(j, tg[j]);
         }
-        if (bo < 0) bo = pm[bs];                            // (0x7fffffff: nothing finite was seen)
+        if (bo < 0) bo = idx ? pm[bs] : (bv < inf_v<T>() ? 0 : 0x7fffffff);   // (0x7fffffff: nothing finite was seen; without idx the
+                                                                                // original index is only looked up on exact ties)
         mi[q] = (bo == 0x7fffffff) ? 0 : min(max(bo, 0), m - 1);
-        idx[(size_t)cloud * n_full + qi[q]] = mi[q];
+        if (idx) idx[(size_t)cloud * n_full + qi[q]] = mi[q];
         // sorted position of the winner (indexed like idx, by the query): what the windowed backward consumes
         if (spos) spos[(size_t)cloud * n_full + qi[q]] = (bo == 0x7fffffff || bo >= m) ? -1 : bs;
     }
@@ -1259,7 +1261,7 @@ __device__ __forceinline__ void block_reduce_store(T* v, T* __restrict__ out, T*
 
 // -------------------------------------------------------------------- accumulate
 template <typename T, int MODE>
-__global__ __launch_bounds__(BLOCK) void accumulate_kernel(WeightParams P, const T* __restrict__ src, const T* __restrict__ tgt, int c,
+__global__ __launch_bounds__(BLOCK) void accumulate_kernel(WeightParams P, const T* __restrict__ src, const T* __restrict__ tgt, int c /* elements per row of tgt */,
                                                            const int32_t* __restrict__ idx, const T* __restrict__ pose,
                                                            const T* __restrict__ w_init, const T* __restrict__ alive,
                                                            int N, int n, int m, int bpc, T* __restrict__ partials,
@@ -2525,18 +2527,18 @@ int dicp_sweep_sort(int dtype, const void* tgt, int c, const void* center, const
 }
 
 int dicp_sweep_build(int dtype, const void* tgt, int c, const void* center, const int32_t* tgt_rows, const int32_t* tperm, int N, int m, int m_pad,
-                     void* tgs4, void* tgt_s, void* stream) {
+                     void* tgs4, void* tgt_s, int tgt_s_stride, void* stream) {
     // center != NULL: the packed rows tgs4 are y - centre; tgt_s stays as given
     if (!tgt || !tgs4 || !tperm) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
-    if (N <= 0 || m <= 0 || (c != 3 && c != 6) || m_pad != dicp_padded_targets(m)) return DICP_ERR_SHAPE;
+    if (N <= 0 || m <= 0 || (c != 3 && c != 6) || m_pad != dicp_padded_targets(m) || (tgt_s && tgt_s_stride < c)) return DICP_ERR_SHAPE;
     if ((uintptr_t)tgs4 % (dtype == DICP_F32 ? 16 : 32)) return DICP_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
     begin_launch();
     const int bpc = (m_pad + BLOCK * 4 - 1) / (BLOCK * 4);
     const unsigned g = grid_for(N, bpc);
-    if (dtype == DICP_F32) sweep_rows_kernel<float><<<g, BLOCK, 0, st>>>((const float*)tgt, tgt_rows, N, m, c, m_pad, bpc, (float4*)tgs4, tperm, (float*)tgt_s, (const float*)center);
-    else                   sweep_rows_kernel<double><<<g, BLOCK, 0, st>>>((const double*)tgt, tgt_rows, N, m, c, m_pad, bpc, (double4*)tgs4, tperm, (double*)tgt_s, (const double*)center);
+    if (dtype == DICP_F32) sweep_rows_kernel<float><<<g, BLOCK, 0, st>>>((const float*)tgt, tgt_rows, N, m, c, m_pad, bpc, (float4*)tgs4, tperm, (float*)tgt_s, tgt_s_stride, (const float*)center);
+    else                   sweep_rows_kernel<double><<<g, BLOCK, 0, st>>>((const double*)tgt, tgt_rows, N, m, c, m_pad, bpc, (double4*)tgs4, tperm, (double*)tgt_s, tgt_s_stride, (const double*)center);
     return launch_status();
 }
 
@@ -2679,7 +2681,7 @@ static int sweep_launch(int dtype, const void* src, const void* pose, const void
 int dicp_knn_sweep(int dtype, const void* src, const void* pose, const void* tgs4, const int32_t* tperm,
                    const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt, const int32_t* src_rows, const int32_t* tgt_rows,
                    int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg, void* stream) {
-    if (!src || !tgs4 || !tperm || !bucket || !brange || !idx) return DICP_ERR_NULL;
+    if (!src || !tgs4 || !tperm || !bucket || !brange || (!idx && !spos)) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || n <= 0 || m <= 0 || nbkt <= 0 || m_pad != dicp_padded_targets(m)) return DICP_ERR_SHAPE;
     if ((uintptr_t)tgs4 % (dtype == DICP_F32 ? 16 : 32)) return DICP_ERR_ALIGN;
@@ -2724,7 +2726,8 @@ static int check_params(const dicp_weight_params* p, int c) {
     if (!p) return DICP_ERR_NULL;
     if (p->mode != DICP_PT2PT && p->mode != DICP_PT2PL) return DICP_ERR_ENUM;
     if (p->loss < DICP_LOSS_NONE || p->loss > DICP_LOSS_TRIM) return DICP_ERR_ENUM;
-    if (p->mode == DICP_PT2PL ? (c != 6) : (c != 3 && c != 6)) return DICP_ERR_SHAPE;   // ICP.py:103
+    // c = elements per target row: 3 or 6 (normals in 3:6), or 4 / 8 for rows padded to 16 / 32 bytes (the sorted copies: one sector per gathered row)
+    if (p->mode == DICP_PT2PL ? (c != 6 && c != 8) : (c != 3 && c != 4 && c != 6 && c != 8)) return DICP_ERR_SHAPE;   // ICP.py:103
     return 0;
 }
 
@@ -3019,7 +3022,7 @@ static bool small_loop_eligible(int dtype, int kind, int knn_variant, int n, int
 int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_buffers* B, int N, int n, int m,
                      int dim, int const_iter, double tolerance, int k0, int k1, void* stream) {
     if (!prm || !B || !B->src || !B->tgt || !B->w_init || !B->poses || !B->deltas || !B->costs || !B->alive ||
-        !B->converged || !B->iterations || !B->matched_ratio || !B->n_start || !B->n_matched || !B->idx || !B->w ||
+        !B->converged || !B->iterations || !B->matched_ratio || !B->n_start || !B->n_matched || (!B->idx && !B->spos) || !B->w ||
         !B->partials || !B->counters) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (k0 < 0 || k1 > B->K || k0 > k1 || N <= 0 || n <= 0 || m <= 0 || B->w_stride < n || B->w_iter < n) return DICP_ERR_SHAPE;
@@ -3044,7 +3047,7 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
         const char* pose_k = (const char*)B->poses + (size_t)k * N * 12 * es;
         // the searches read [C | r - centre] when the caller keeps that second pose history (packed rows are then y - centre)
         const char* pose_s = B->poses_search ? (const char*)B->poses_search + (size_t)k * N * 12 * es : pose_k;
-        int32_t* idx_k = B->idx + (B->idx_per_iter ? (size_t)k * N * n : 0);
+        int32_t* idx_k = B->idx ? B->idx + (B->idx_per_iter ? (size_t)k * N * n : 0) : nullptr;
         char* w_k = (char*)B->w + (size_t)k * B->w_iter * es;       // cloud stride B->w_stride: (N,K,n) or (K,N,n) alike
         const char* alive_k = (const char*)B->alive + (size_t)k * N * es;
         if (B->events) {    // the sweep launch carries its two events itself; the brute-force forms are bracketed by records
@@ -3055,16 +3058,22 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
         if (kind == DICP_KNN_SWEEP) {
             // bits 8..15 of knn_variant optionally pin a tile-sweep launch configuration (0 = chosen from the problem size)
             int cfg = (B->knn_variant >> 8) & 0xff;
-            int32_t* spos_k = B->spos ? B->spos + (size_t)k * N * n : nullptr;
+            int32_t* spos_k = B->spos ? B->spos + (B->idx_per_iter ? (size_t)k * N * n : 0) : nullptr;
+            const bool sorted_rows = B->tgt_sorted && spos_k;      // accumulate gathers 32-byte aligned rows of the sorted copy at the sorted positions
+            if (!sorted_rows && !B->idx) return DICP_ERR_NULL;
             // src_s: the source rows in qorder's slot order (dicp_query_order wrote them): coalesced query loads
             const void* qsrc = B->src;
             if (B->src_s && B->qorder) { qsrc = B->src_s; cfg |= DICP_SWEEP_SRC_SORTED; }
             rc = dicp_knn_sweep(dtype, qsrc, pose_s, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, B->src_rows, B->tgt_rows, N, n, m, B->m_pad,
-                                idx_k, spos_k, B->pairs, cfg, stream);
+                                B->idx ? idx_k : nullptr, spos_k, B->pairs, cfg, stream);
             set_launch_events(nullptr, nullptr);
             if (rc) return rc;
             if (B->events) set_launch_events((hipEvent_t)B->events[6 * k + 2], (hipEvent_t)B->events[6 * k + 3]);
-            rc = dicp_accumulate(dtype, prm, B->src, B->tgt, B->c, idx_k, pose_k, B->w_init, alive_k, B->src_rows, N, n, m, B->partials, w_k, B->w_stride, stream);
+            if (sorted_rows)
+                rc = dicp_accumulate(dtype, prm, B->src, B->tgt_sorted, B->tgt_sorted_stride, spos_k, pose_k, B->w_init, alive_k, B->src_rows, N, n, B->m_pad,
+                                     B->partials, w_k, B->w_stride, stream);
+            else
+                rc = dicp_accumulate(dtype, prm, B->src, B->tgt, B->c, idx_k, pose_k, B->w_init, alive_k, B->src_rows, N, n, m, B->partials, w_k, B->w_stride, stream);
             set_launch_events(nullptr, nullptr);
             if (rc) return rc;
         } else {

@@ -91,13 +91,15 @@ int dicp_knn(int dtype, const void* src, const void* pose, const void* tgt4, con
  *   NaN rows included.  float32 clouds of up to 16384 slots: an LSD radix sort in LDS, one block per cloud; float64 keys or more slots: the
  *   same sort chunk by chunk through `scratch` (dicp_sweep_sort_scratch_bytes(dtype, N, m_pad) bytes; 0 = none needed).  Given bucket
  *   (N,nbkt+1) and brange (N,2) it also builds the search's coarse table: bucket[b] = #rows with x < xlo + b / inv, brange = [xlo, inv].
- * dicp_sweep_build: from tperm, tgs4 (N,m_pad,4) = the packed rows in sorted order (pads [max,0,0,+inf]) and, optionally, tgt_s (N,m_pad,c) =
- *   the full target rows in sorted order (what dicp_accumulate_bwd_window reads; row s = tgt[tperm[s]], as given: not centred). */
+ * dicp_sweep_build: from tperm, tgs4 (N,m_pad,4) = the packed rows in sorted order (pads [max,0,0,+inf]) and, optionally, tgt_s
+ *   (N,m_pad,tgt_s_stride) = the full target rows in sorted order (row s = tgt[tperm[s]], as given: not centred; tgt_s_stride >= c elements per
+ *   row, the rest zero: 8 for c = 6 / 4 for c = 3 makes every row ONE aligned 32- / 16-byte sector for the gathers of dicp_accumulate and
+ *   dicp_accumulate_bwd_window, which take such rows with c = the stride). */
 size_t dicp_sweep_sort_scratch_bytes(int dtype, int N, int m_pad);
 int dicp_sweep_sort(int dtype, const void* tgt, int c, const void* center, const int32_t* tgt_rows, int N, int m, int m_pad, void* keys_sorted,
                     int32_t* tperm, int nbkt, int32_t* bucket, void* brange, void* scratch, size_t scratch_bytes, void* stream);
 int dicp_sweep_build(int dtype, const void* tgt, int c, const void* center, const int32_t* tgt_rows, const int32_t* tperm, int N, int m, int m_pad,
-                     void* tgs4, void* tgt_s, void* stream);
+                     void* tgs4, void* tgt_s, int tgt_s_stride, void* stream);
 /* keys (N,n) = x coordinate of every source point under pose (NULL = identity): the sort key of the query order. */
 int dicp_query_keys(int dtype, const void* src, const void* pose, int N, int n, void* keys, void* stream);
 /* qorder (N,n) = the queries in ascending bucket of their x under pose (counting sort over equal-width buckets of the
@@ -127,7 +129,8 @@ int dicp_query_order(int dtype, const void* src, const void* pose, const void* b
  *   qorder (N,n)       optional: query indices in ascending x (under any recent pose) so that a wave's
  *                      queries are neighbours; NULL = natural order (still exact, less pruning).
  * spos (N,n), optional: spos[b][i] = SORTED position of the neighbour of query i (-1 if none; indexed like idx):
- *   what dicp_accumulate_bwd_window consumes.
+ *   what dicp_accumulate_bwd_window -- and dicp_accumulate on the sorted rows -- consume.  idx may be NULL when spos is given (the original
+ *   index then costs a look-up only on exact ties).
  * pairs: optional DICP_PAIR_SHARDS device counters; their sum += number of (query,target) pairs actually scored
  *   (roofline accounting; sharded because adds to ONE address serialise at ~12 ns each).
  * cfg: 0 = launch configuration chosen from the problem size; 1, 2, 4 pin one (queries per lane, rows per chunk) = (1,8), (2,8), (1,16). */
@@ -146,7 +149,8 @@ int dicp_scatter_add_rows(int dtype, const void* gout, const int32_t* idx, int N
  * (loss.py:21-58 via ICP.py:152-160), weight combine (ICP.py:162-169,194-196), Jacobian
  * rows (ICP.py:171-183) and the normal-equation sums A = J_w^T J_w, b = J_w^T e_w
  * (ICP.py:198-201) plus cost (ICP.py:229), sum(w) and #(w > thresh) (ICP.py:225,247).
- *   tgt (N,m,c) with c = 6 for pt2pl (normals in 3:6), 3 or 6 for pt2pt; idx == NULL (then m must equal n)
+ *   tgt (N,m,c) with c = 6 for pt2pl (normals in 3:6), 3 or 6 for pt2pt -- or 8 / 4: the same rows padded to 32 / 16 bytes (dicp_sweep_build's tgt_s,
+ *   gathered at the SORTED positions dicp_knn_sweep wrote: idx = spos, m = m_pad); idx == NULL (then m must equal n)
  *   means tgt already holds ONE ROW PER SOURCE POINT -- the soft neighbours of dicp_gumbel_nn;
  *   w_init (N,n); alive (N) multiplies w_init (the zeroing of ICP.py:256-257), may be NULL;
  *   partials (N, nblk, DICP_NACC_PAD) with nblk = dicp_accumulate_blocks(n);
@@ -208,7 +212,7 @@ typedef struct dicp_loop_buffers {
     const int32_t* bucket;   /* sweep only */
     const void* brange;      /* sweep only */
     int32_t nbkt;
-    int32_t idx_per_iter;    /* 1: idx is (K,N,n) and every iteration keeps its own (needed for backward); 0: (N,n) reused */
+    int32_t idx_per_iter;    /* 1: idx / spos are (K,N,n) and every iteration keeps its own (needed for backward); 0: (N,n) reused */
     unsigned long long* pairs;   /* sweep only, optional: DICP_PAIR_SHARDS counters */
     int32_t* spos;           /* sweep only, optional (K,N,n): per-iteration sorted match positions.  Non-NULL in dicp_icp_backward
                                 selects dicp_accumulate_bwd_window: src / w_init / tgt are then the SORTED copies it documents,
@@ -226,7 +230,7 @@ typedef struct dicp_loop_buffers {
     void* matched_ratio;     /* (N) zero-initialised */
     const void* n_start;     /* (N) */
     void* n_matched;         /* (N) */
-    int32_t* idx;            /* (K,N,n) or (N,n) */
+    int32_t* idx;            /* (K,N,n) or (N,n); optional on the sweep path when tgt_sorted and spos are given */
     void* w;                 /* weights of every iteration: iteration k, cloud b at w + k*w_iter + b*w_stride (elements);
                                 (N,K,n): w_iter = n, w_stride = K*n.  May be a per-slab virtual base: only [k0,k1) is touched */
     int64_t w_iter, w_stride;
@@ -246,6 +250,9 @@ typedef struct dicp_loop_buffers {
     const int32_t* src_rows; /* optional (N): rows of each source cloud that take part (ragged batches); qorder, if any, from dicp_query_order
                                 with the same counts */
     const int32_t* tgt_rows; /* optional (N): rows of each target cloud that take part; tgt4 / the sweep index built with the same counts */
+    const void* tgt_sorted;  /* sweep only, optional (N,m_pad,tgt_sorted_stride): dicp_sweep_build's tgt_s.  With it (and spos) the forward accumulate
+                                gathers the match rows from the sorted copy at spos -- one aligned sector per row -- and idx may be NULL */
+    int32_t tgt_sorted_stride;
 } dicp_loop_buffers;
 
 /* Head and tail of the backward loop.  dicp_pose_grad_in: gpose (N,12) double = [dL/dC row-major (9), dL/dr (3)] taken from the

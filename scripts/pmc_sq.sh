@@ -6,7 +6,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
            "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT" \
            "SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_SMEM SQ_LDS_IDX_ACTIVE SQ_IFETCH SQ_INSTS_BRANCH"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set -d $O/p$i -o p --output-format csv -- python3 $R/bench.py --no-cpu-baseline > $O/p$i.log 2>&1 || echo "pass $i failed"
+  rocprofv3 --kernel-trace --pmc $set -d $O/p$i -o p --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-extra-legs > $O/p$i.log 2>&1 || echo "pass $i failed"
 done
 python3 - "$O" <<'PY'
 import csv, glob, sys, collections

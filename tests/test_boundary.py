@@ -75,11 +75,12 @@ def test_new_entry_points_reject_bad_arguments(lib):
     one, P = ctypes.c_void_p(64), _lib.WeightParams(mode=1, loss=0)
     assert [lib.dicp_window_blocks(0, n, 16384) for n in (0, 1, 16384)] == [0, 1, 16]
     assert lib.dicp_window_rows(0) == 1536 and lib.dicp_window_rows(1) == 768
-    # dicp_sweep_build(dtype, tgt, c, center, tgt_rows, tperm, N, m, m_pad, tgs4, tgt_s, stream)
-    assert lib.dicp_sweep_build(0, None, 3, None, None, one, 1, 1, 64, one, None, None) == 1
-    assert lib.dicp_sweep_build(0, one, 4, None, None, one, 1, 1, 64, one, None, None) == 2
-    assert lib.dicp_sweep_build(0, one, 3, None, None, one, 1, 1, 64, ctypes.c_void_p(8), None, None) == 5
-    assert lib.dicp_sweep_build(0, one, 3, None, None, None, 1, 1, 64, one, None, None) == 1           # the permutation comes from dicp_sweep_sort
+    # dicp_sweep_build(dtype, tgt, c, center, tgt_rows, tperm, N, m, m_pad, tgs4, tgt_s, tgt_s_stride, stream)
+    assert lib.dicp_sweep_build(0, None, 3, None, None, one, 1, 1, 64, one, None, 0, None) == 1
+    assert lib.dicp_sweep_build(0, one, 4, None, None, one, 1, 1, 64, one, None, 0, None) == 2
+    assert lib.dicp_sweep_build(0, one, 3, None, None, one, 1, 1, 64, ctypes.c_void_p(8), None, 0, None) == 5
+    assert lib.dicp_sweep_build(0, one, 3, None, None, None, 1, 1, 64, one, None, 0, None) == 1           # the permutation comes from dicp_sweep_sort
+    assert lib.dicp_sweep_build(0, one, 6, None, None, one, 1, 1, 64, one, one, 4, None) == 2              # sorted rows narrower than the rows
     # dicp_sweep_sort(dtype, tgt, c, center, tgt_rows, N, m, m_pad, keys, tperm, nbkt, bucket, brange, scratch, bytes, stream)
     assert lib.dicp_sweep_sort(0, None, 3, None, None, 1, 1, 64, one, one, 0, None, None, None, 0, None) == 1
     assert lib.dicp_sweep_sort(9, one, 3, None, None, 1, 1, 64, one, one, 0, None, None, None, 0, None) == 3
@@ -117,6 +118,7 @@ def test_new_entry_points_reject_bad_arguments(lib):
     assert lib.dicp_pose_grad_out(0, one, one, 0, one, 1, None) == 2 and lib.dicp_pose_grad_out(0, one, None, 0, None, 1, None) == 1
     # dicp_knn_sweep(dtype, src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, src_rows, tgt_rows, N, n, m, m_pad, idx, spos, pairs, cfg, stream)
     assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, None, None, 1, 1, 1, 64, one, None, None, 99, None) == 4
+    assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, None, None, 1, 1, 1, 64, None, None, None, 0, None) == 1   # idx or spos
     assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, None, None, 1, 1, 1, 64, one, None, None, 16, None) == 4   # (the scan form is gone)
     assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, None, None, 1, 1, 1, 64, one, None, None, 2 | 0x100, None) == 1  # sorted rows need the order
 

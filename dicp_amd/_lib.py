@@ -40,7 +40,7 @@ class StepIO(ctypes.Structure):
                 ("cost", vp), ("cost_prev", vp), ("cost_stride", i64), ("areg", vp), ("alive", vp), ("alive_out", vp),
                 ("converged", vp), ("iterations", vp), ("matched_ratio", vp), ("n_start", vp),
                 ("n_matched", vp), ("w_cur", vp), ("w_prev", vp), ("w_stride", i64), ("n_not_converged", vp),
-                ("center", vp), ("pose_search_out", vp)]
+                ("center", vp), ("pose_search_out", vp), ("rmax", vp), ("dcum", vp), ("dcum_stride", i64)]
 
 
 class LoopBuffers(ctypes.Structure):
@@ -50,7 +50,8 @@ class LoopBuffers(ctypes.Structure):
                 ("pairs", vp), ("spos", vp), ("src_s", vp), ("spos_ref", vp), ("gts_far", vp), ("poses", vp), ("deltas", vp), ("costs", vp), ("areg", vp), ("alive", vp), ("converged", vp),
                 ("iterations", vp), ("matched_ratio", vp), ("n_start", vp), ("n_matched", vp), ("idx", vp), ("w", vp), ("w_iter", i64), ("w_stride", i64), ("w_prev0", vp),
                 ("partials", vp), ("counters", vp), ("events", vp), ("bwd_overwrite", i32), ("center", vp), ("poses_search", vp),
-                ("src_rows", vp), ("tgt_rows", vp), ("tgt_sorted", vp), ("tgt_sorted_stride", i32)]
+                ("src_rows", vp), ("tgt_rows", vp), ("cert_a", vp), ("cert_s", vp), ("unit_k", vp), ("dirty", vp), ("rmax", vp), ("dcum", vp),
+                ("cert_reset", i32), ("spos_prev0", vp), ("tgt_sorted", vp), ("tgt_sorted_stride", i32)]
 
 
 class KabschBuffers(ctypes.Structure):
@@ -76,7 +77,7 @@ _SIGNATURES = {
     "dicp_sweep_build": ([i32, vp, i32, vp, vp, vp, i32, i32, i32, vp, vp, i32, vp], ctypes.c_int),
     "dicp_query_order": ([i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, vp], ctypes.c_int),
     "dicp_query_keys": ([i32, vp, vp, i32, i32, vp, vp], ctypes.c_int),
-    "dicp_loop_init": ([i32, vp, vp, ctypes.c_double, i32, i32, i32, vp, vp, vp, vp, vp, vp], ctypes.c_int),
+    "dicp_loop_init": ([i32, vp, vp, ctypes.c_double, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp], ctypes.c_int),
     "dicp_search_pose": ([i32, vp, vp, i32, vp, vp], ctypes.c_int),
     "dicp_loop_finish": ([i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp], ctypes.c_int),
     "dicp_accumulate_bwd_window": ([i32, ctypes.POINTER(WeightParams), vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp], ctypes.c_int),

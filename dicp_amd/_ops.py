@@ -393,6 +393,8 @@ class LoopConfig:
     timing_events: object = None  # optional object with .handles(K) -> ctypes array of 4*K hipEvent_t (bench.py)
     prebuilt: object = None       # (target, SweepIndex) started by the caller before its own host work (prebuild_search)
     small_loop: bool = True       # small clouds: one block runs a cloud's whole chunk of iterations (icp_small_* kernels)
+    reuse_matches: bool = True    # sweep path: match certificates -- an iteration searches only the waves holding a query whose match is not proven
+                                  # unchanged since the wave's last search (exact; knn_sweep_kernel CERT)
     src_rows: object = None       # ragged batches: (N) int32 device tensors, rows of each source / target cloud that take part
     tgt_rows: object = None       # (ICP._batch: the clouds' own lengths; the kernels never touch a pad row)
 
@@ -517,8 +519,17 @@ class ICPLoop(torch.autograd.Function):
             counters = arena.take((Kmax,), torch.int32)
             deltas, costs, converged, iterations, matched, n_matched, counters = arena.finish()
             # pose_0, alive_0, n_start (ICP.py:124-129)
+            # match certificates (sweep path, the big-problem launch configuration): per-slot certificates, per-unit bookkeeping, per-cloud motion bounds
+            certs = None
+            if sweep is not None and cfg.reuse_matches and float(N) * n >= 2.0 * 256 * 1024 and not (cfg.knn_variant & 0xff00):
+                units = (n + 127) // 128
+                certs = dict(a=torch.empty((N, n), dtype=dt, device=dev), s=torch.empty((N, n), dtype=dt, device=dev),
+                             unit_k=torch.full((N, units), -1, dtype=torch.int32, device=dev), dirty=torch.empty((N, units), dtype=torch.int32, device=dev),
+                             rmax=torch.empty((N,), dtype=dt, device=dev), dcum=torch.empty((N, Kmax + 1), dtype=dt, device=dev))
             _lib.check(lib.dicp_loop_init(code, _p(T_init.contiguous()), _p(w0c), float(cfg.match_ratio_thresh), rows, N, n,
-                                          _p(poses), _p(alive), _p(n_start), _p(center), _p(poses_c), st), "dicp_loop_init")
+                                          _p(poses), _p(alive), _p(n_start), _p(center), _p(poses_c),
+                                          _p(src) if certs else None, _p(certs["rmax"]) if certs else None, _p(certs["dcum"]) if certs else None, Kmax + 1, st),
+                       "dicp_loop_init")
             # sweep path: the matches are kept as SORTED positions (spos) -- accumulate gathers the sorted, sector-aligned rows with them and
             # the windowed backward consumes them; original indices (idx) are only kept for the brute-force searches and the atomic backward
             keep_idx = sweep is None or (need_grad and not owned)
@@ -556,7 +567,9 @@ class ICPLoop(torch.autograd.Function):
                         idx_slabs.append(torch.empty((kk, N, n), dtype=torch.int32, device=dev))
                     if keep_spos:
                         spos_slabs.append(torch.empty((kk, N, n), dtype=torch.int32, device=dev))
+                new_order = False
                 if sweep is not None and (qorder is None or k0 in cfg.sweep_resort):
+                    new_order = True
                     # queries re-ordered by x under the current pose
                     first = cfg.prebuilt[2] if (k0 == 0 and sweep is not None and cfg.prebuilt is not None and cfg.prebuilt[1] is sweep) else None
                     if (first is not None and first[0].data_ptr() == src.data_ptr() and first[0].shape == src.shape
@@ -577,6 +590,10 @@ class ICPLoop(torch.autograd.Function):
                     iterations=_p(iterations), matched_ratio=_p(matched), n_start=_p(n_start), n_matched=_p(n_matched),
                     idx=(ctypes.c_void_p(idx_slabs[j].data_ptr() - base * N * n * 4) if need_grad else _p(idx_once)) if keep_idx else None,
                     tgt_sorted=_p(sweep.tgt_s) if sweep is not None else None, tgt_sorted_stride=sweep.row_stride if sweep is not None else 0,
+                    cert_a=_p(certs["a"]) if certs else None, cert_s=_p(certs["s"]) if certs else None, unit_k=_p(certs["unit_k"]) if certs else None,
+                    dirty=_p(certs["dirty"]) if certs else None, rmax=_p(certs["rmax"]) if certs else None, dcum=_p(certs["dcum"]) if certs else None,
+                    cert_reset=int(new_order),
+                    spos_prev0=_p(spos_slabs[(k0 - 1) // kc][(k0 - 1) % kc]) if (keep_spos and k0 > 0) else None,
                     w=ctypes.c_void_p(w_slabs[j].data_ptr() - base * n * es), w_iter=n, w_stride=kc * n,
                     w_prev0=_p(w_slabs[(k0 - 1) // kc][:, (k0 - 1) % kc]) if k0 > 0 else None,
                     partials=_p(partials), counters=_p(counters), events=events, center=_p(center), poses_search=_p(poses_c),

@@ -38,7 +38,8 @@ def test_struct_layouts_match_header(lib):
     # dicp_step_io: field order and padding as the C compiler lays it out
     expect = ["partials", "nblk", "iter", "dim", "const_iter", "tolerance", "rows_per_point", "n", "pose_in", "pose_out",
               "delta", "delta_stride", "cost", "cost_prev", "cost_stride", "areg", "alive", "alive_out", "converged", "iterations",
-              "matched_ratio", "n_start", "n_matched", "w_cur", "w_prev", "w_stride", "n_not_converged", "center", "pose_search_out"]
+              "matched_ratio", "n_start", "n_matched", "w_cur", "w_prev", "w_stride", "n_not_converged", "center", "pose_search_out",
+              "rmax", "dcum", "dcum_stride"]
     assert [f[0] for f in _lib.StepIO._fields_] == expect
     hdr = open(os.path.join(ROOT, "include", "dicp_hip.h")).read()
     body = hdr[hdr.index("typedef struct dicp_step_io {"):hdr.index("} dicp_step_io;")]
@@ -93,8 +94,9 @@ def test_new_entry_points_reject_bad_arguments(lib):
     assert lib.dicp_query_order(0, one, None, None, 1024, 1, 1, one, None, None, None, 0, None, 0, None, None, 0, None, None, None) == 1
     assert lib.dicp_query_order(9, one, None, one, 1024, 1, 1, one, None, None, None, 0, None, 0, None, None, 0, None, None, None) == 3
     assert lib.dicp_query_order(0, one, None, one, 1024, 1, 1, one, None, None, None, 0, None, 0, one, one, 0, None, None, None) == 2      # keys without m
-    assert lib.dicp_loop_init(0, one, one, 0.01, 2, 1, 1, one, one, one, None, None, None) == 2
-    assert lib.dicp_loop_init(0, None, one, 0.01, 1, 1, 1, one, one, one, one, one, None) == 1
+    assert lib.dicp_loop_init(0, one, one, 0.01, 2, 1, 1, one, one, one, None, None, None, None, None, 0, None) == 2
+    assert lib.dicp_loop_init(0, None, one, 0.01, 1, 1, 1, one, one, one, one, one, None, None, None, 0, None) == 1
+    assert lib.dicp_loop_init(0, one, one, 0.01, 1, 1, 1, one, one, one, None, None, None, one, None, 4, None) == 1     # rmax needs the points and dcum
     assert lib.dicp_loop_finish(0, one, one, one, one, 1, 1, None, one, one, None) == 1
     # centred search (center itself is optional everywhere)
     assert lib.dicp_cloud_center(0, None, 3, None, 1, 1, 16.0, one, None) == 1

@@ -173,3 +173,40 @@ def test_config3_full_batch_256(monkeypatch):
     np.testing.assert_allclose(npy(b["T"]), npy(T_full), rtol=0, atol=1e-6)
     np.testing.assert_allclose(npy(s3.grad), npy(gs_full), rtol=0, atol=2e-5)
     np.testing.assert_allclose(npy(t3.grad), npy(gt_full), rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("dtype,N,n,const_iter,ragged", [(torch.float32, 40, 16384, True, False), (torch.float32, 160, 4096, False, False),
+                                                         (torch.float64, 36, 16384, True, False), (torch.float32, 48, 16384, True, True)])
+def test_match_certificates_change_no_result(dtype, N, n, const_iter, ragged):
+    """Temporal coherence, exact: with certificates an iteration searches only the waves that hold a query whose match is
+    not PROVEN unchanged since the wave's last search.  Every result -- poses, per-iteration weights (i.e. every match of
+    every iteration), costs, gradients -- must be bit-identical to searching everything every iteration, while far fewer
+    pairs are scored; also under tolerance mode (segments of one iteration) and for ragged lists."""
+    K = 9
+    src, tgt = make_pairs(N, n, n, seed=5, dtype=dtype)
+    lens = [n - (977 * b) % (n // 3) for b in range(N)] if ragged else None
+    outs = {}
+    for reuse in (False, True):
+        icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12 if const_iter else 1e-4)
+        icp.const_iter = const_iter
+        icp.reuse_matches = reuse
+        if ragged:
+            S = [src[b, :lens[b]].to(DEV).requires_grad_(True) for b in range(N)]
+            Tg = [tgt[b, :lens[b] - 500].to(DEV).requires_grad_(True) for b in range(N)]
+            T0 = [torch.eye(4, dtype=dtype, device=DEV)] * N
+        else:
+            S, Tg = src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True)
+            T0 = torch.eye(4, dtype=dtype, device=DEV).repeat(N, 1, 1)
+        out = icp.icp(S, Tg, T0, **KW)
+        out["T"].sum().backward()
+        gs = torch.cat([x.grad.reshape(-1) for x in (S if ragged else [S])])
+        gt = torch.cat([x.grad.reshape(-1) for x in (Tg if ragged else [Tg])])
+        outs[reuse] = (out, gs, gt, float(icp.knn_stats["knn_pairs"].sum().item()))
+    a, b = outs[False], outs[True]
+    for key in ("T", "deltas", "weights", "costs", "pc"):
+        assert torch.equal(a[0][key], b[0][key]), key
+    assert torch.equal(a[0]["stats"]["iterations"], b[0]["stats"]["iterations"])
+    np.testing.assert_allclose(npy(b[1]), npy(a[1]), rtol=0, atol=1e-6 * max(1.0, float(a[1].abs().max())))       # (the backward's sums follow its own slot order)
+    np.testing.assert_allclose(npy(b[2]), npy(a[2]), rtol=0, atol=1e-6 * max(1.0, float(a[2].abs().max())))
+    if const_iter:
+        assert b[3] < 0.8 * a[3], (a[3], b[3])              # 9 iterations: the early ones dominate the pairs; the last five search (almost) nothing

@@ -808,7 +808,7 @@ def test_search_pose_from_T_init(dtype):
     w0 = torch.ones((N, 5), dtype=dtype, device=DEV)
     pose0, alive, nst, ps0 = (torch.empty(sh, dtype=dtype, device=DEV) for sh in ((N, 12), (N,), (N,), (N, 12)))
     _lib.check(lib.dicp_loop_init(_ops._DT[dtype], _ops._p(T), _ops._p(w0), 0.01, 1, N, 5, _ops._p(pose0), _ops._p(alive), _ops._p(nst),
-                                           _ops._p(ctr), _ops._p(ps0), _ops._stream()), "dicp_loop_init_centered")
+                                  _ops._p(ctr), _ops._p(ps0), None, None, None, 0, _ops._stream()), "dicp_loop_init")
     assert torch.equal(ps0, out) and torch.equal(pose0[:, :9], out[:, :9]) and torch.equal(pose0[:, 9:], T[:, :3, 3])
     _lib.check(lib.dicp_search_pose(_ops._DT[dtype], _ops._p(T), None, N, _ops._p(out), _ops._stream()), "dicp_search_pose")
     assert torch.equal(out, pose0)

@@ -50,7 +50,7 @@ class LoopBuffers(ctypes.Structure):
                 ("pairs", vp), ("spos", vp), ("src_s", vp), ("spos_ref", vp), ("gts_far", vp), ("poses", vp), ("deltas", vp), ("costs", vp), ("areg", vp), ("alive", vp), ("converged", vp),
                 ("iterations", vp), ("matched_ratio", vp), ("n_start", vp), ("n_matched", vp), ("idx", vp), ("w", vp), ("w_iter", i64), ("w_stride", i64), ("w_prev0", vp),
                 ("partials", vp), ("counters", vp), ("events", vp), ("bwd_overwrite", i32), ("center", vp), ("poses_search", vp),
-                ("src_rows", vp), ("tgt_rows", vp), ("cert_a", vp), ("cert_s", vp), ("unit_k", vp), ("dirty", vp), ("rmax", vp), ("dcum", vp),
+                ("src_rows", vp), ("tgt_rows", vp), ("cert_q", vp), ("cert_qu", vp), ("cert_count", vp), ("rmax", vp), ("dcum", vp),
                 ("cert_reset", i32), ("spos_prev0", vp), ("tgt_sorted", vp), ("tgt_sorted_stride", i32)]
 
 
@@ -115,14 +115,17 @@ _lock = threading.Lock()
 def build(force=False, verbose=False):
     """Compile the HIP sources for gfx950 into dicp_amd/libdicp_hip.so (hipcc cross-compiles
     without a GPU).  Rebuilds only when a source or header is newer than the library."""
-    deps = SOURCES + HEADERS
+    deps = SOURCES + HEADERS + [os.path.abspath(__file__)]       # (this file holds the compiler flags)
     if (not force and os.path.exists(LIB_PATH)
             and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(p) for p in deps)):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -amdgpu-mfma-vgpr-form: let the f32 MFMA of the kNN variant write VGPRs directly (no v_accvgpr_read per
     # result): 6.1 -> 5.5 ms on that kernel (profiles/r01_knn_variants_ab.txt); no effect on the other kernels
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form",
+    # -ffp-contract=on: a*b+c fuses where the SOURCE writes it in one expression, never across statements after inlining ("fast", the
+    # HIP default, did: the same point_forward then rounded differently in two instantiations of accumulate_kernel) -- results are a
+    # function of the source, not of the optimiser's context
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-ffp-contract=on", "-mllvm", "-amdgpu-mfma-vgpr-form",
            "-Wall", "-Wno-unused-function", "-I", os.path.join(_ROOT, "include"),
            "-o", LIB_PATH + ".tmp"] + SOURCES
     if verbose:

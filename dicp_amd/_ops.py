@@ -517,22 +517,29 @@ class ICPLoop(torch.autograd.Function):
             matched = arena.take((N,), dt)
             n_matched = arena.take((N,), dt)
             counters = arena.take((Kmax,), torch.int32)
-            deltas, costs, converged, iterations, matched, n_matched, counters = arena.finish()
+            # match certificates (sweep path, the big-problem launch configuration): per-slot certificates, per-unit bookkeeping, per-cloud motion
+            # bounds, the per-iteration list of units to search again
+            keep_idx = sweep is None or (need_grad and not owned)     # (original indices: the brute-force searches and the atomic backward)
+            want_certs = (sweep is not None and cfg.reuse_matches and float(N) * n >= 2.0 * 256 * 1024 and not (cfg.knn_variant & 0xff00) and not keep_idx
+                          and N * n < 2 ** 31)
+            arena.take((Kmax, 128) if want_certs else (0,), torch.int32)
+            deltas, costs, converged, iterations, matched, n_matched, counters, cert_count = arena.finish()
             # pose_0, alive_0, n_start (ICP.py:124-129)
-            # match certificates (sweep path, the big-problem launch configuration): per-slot certificates, per-unit bookkeeping, per-cloud motion bounds
             certs = None
-            if sweep is not None and cfg.reuse_matches and float(N) * n >= 2.0 * 256 * 1024 and not (cfg.knn_variant & 0xff00):
+            if want_certs:
                 units = (n + 127) // 128
-                certs = dict(a=torch.empty((N, n), dtype=dt, device=dev), s=torch.empty((N, n), dtype=dt, device=dev),
-                             unit_k=torch.full((N, units), -1, dtype=torch.int32, device=dev), dirty=torch.empty((N, units), dtype=torch.int32, device=dev),
-                             rmax=torch.empty((N,), dtype=dt, device=dev), dcum=torch.empty((N, Kmax + 1), dtype=dt, device=dev))
+                certs = dict(q=torch.empty((N, n), dtype=dt, device=dev), qu=torch.empty((N, units), dtype=dt, device=dev), count=cert_count,
+                             rmax=torch.empty((N,), dtype=dt, device=dev), dcum=torch.empty((N, 2 * (Kmax + 1)), dtype=dt, device=dev))
+                # the searches before the LAST re-ordering of the queries leave no certificate a later iteration could use (they are kept by
+                # slot of the order): those iterations run the plain search, which is ~25 % cheaper than the certifying one
+                resorts = [k for k in cfg.sweep_resort if 0 <= k < Kmax]
+                cert_from = max(resorts) if resorts else 0
             _lib.check(lib.dicp_loop_init(code, _p(T_init.contiguous()), _p(w0c), float(cfg.match_ratio_thresh), rows, N, n,
                                           _p(poses), _p(alive), _p(n_start), _p(center), _p(poses_c),
-                                          _p(src) if certs else None, _p(certs["rmax"]) if certs else None, _p(certs["dcum"]) if certs else None, Kmax + 1, st),
+                                          _p(src) if certs else None, _p(certs["rmax"]) if certs else None, _p(certs["dcum"]) if certs else None, 2 * (Kmax + 1), st),
                        "dicp_loop_init")
             # sweep path: the matches are kept as SORTED positions (spos) -- accumulate gathers the sorted, sector-aligned rows with them and
             # the windowed backward consumes them; original indices (idx) are only kept for the brute-force searches and the atomic backward
-            keep_idx = sweep is None or (need_grad and not owned)
             idx_once = torch.empty((N, n), dtype=torch.int32, device=dev) if (keep_idx and not need_grad) else None
             keep_spos = sweep is not None and need_grad       # per-iteration sorted positions (the windowed backward reads them; same layout as idx)
             spos_once = torch.empty((N, n), dtype=torch.int32, device=dev) if (sweep is not None and not need_grad) else None
@@ -568,6 +575,7 @@ class ICPLoop(torch.autograd.Function):
                     if keep_spos:
                         spos_slabs.append(torch.empty((kk, N, n), dtype=torch.int32, device=dev))
                 new_order = False
+                use_certs = certs is not None and k0 >= cert_from
                 if sweep is not None and (qorder is None or k0 in cfg.sweep_resort):
                     new_order = True
                     # queries re-ordered by x under the current pose
@@ -590,8 +598,9 @@ class ICPLoop(torch.autograd.Function):
                     iterations=_p(iterations), matched_ratio=_p(matched), n_start=_p(n_start), n_matched=_p(n_matched),
                     idx=(ctypes.c_void_p(idx_slabs[j].data_ptr() - base * N * n * 4) if need_grad else _p(idx_once)) if keep_idx else None,
                     tgt_sorted=_p(sweep.tgt_s) if sweep is not None else None, tgt_sorted_stride=sweep.row_stride if sweep is not None else 0,
-                    cert_a=_p(certs["a"]) if certs else None, cert_s=_p(certs["s"]) if certs else None, unit_k=_p(certs["unit_k"]) if certs else None,
-                    dirty=_p(certs["dirty"]) if certs else None, rmax=_p(certs["rmax"]) if certs else None, dcum=_p(certs["dcum"]) if certs else None,
+                    cert_q=_p(certs["q"]) if use_certs else None, cert_qu=_p(certs["qu"]) if use_certs else None,
+                    cert_count=_p(certs["count"]) if use_certs else None,
+                    rmax=_p(certs["rmax"]) if certs else None, dcum=_p(certs["dcum"]) if certs else None,
                     cert_reset=int(new_order),
                     spos_prev0=_p(spos_slabs[(k0 - 1) // kc][(k0 - 1) % kc]) if (keep_spos and k0 > 0) else None,
                     w=ctypes.c_void_p(w_slabs[j].data_ptr() - base * n * es), w_iter=n, w_stride=kc * n,
@@ -628,6 +637,9 @@ class ICPLoop(torch.autograd.Function):
                                             _p(iterations), _p(matched), _p(T), st), "dicp_loop_finish")
             if sweep is not None and cfg.stats_out is not None:
                 cfg.stats_out["knn_pairs"] = sweep.pair_shards    # device int64 shards: sum them after a sync
+                if certs is not None:             # (Kmax, 128) int32: [:, :64].sum(1) = units, [:, 64:].sum(1) = single queries searched again per iteration
+                    cfg.stats_out["searched_again"] = certs["count"]
+                    cfg.stats_out["budgets"] = certs["q"]         # (N,n) by query: the budgets as the last iteration left them
             weights = (w_slabs[0] if len(w_slabs) == 1 else torch.cat(w_slabs, dim=1))[:, :K]
             deltas_out = deltas[:, :K]
             costs_out = costs[:, :K]

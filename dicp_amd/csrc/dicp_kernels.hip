@@ -51,6 +51,10 @@ template <> struct V4<double> { using type = double4; };
 template <typename T> __device__ __forceinline__ T inf_v();
 template <> __device__ __forceinline__ float  inf_v<float>()  { return __builtin_huge_valf(); }
 template <> __device__ __forceinline__ double inf_v<double>() { return __builtin_huge_val(); }
+// (a little above) the machine epsilon: roundings of the match-certificate bookkeeping are covered with multiples of it
+template <typename T> struct CertUlp;
+template <> struct CertUlp<float>  { static constexpr float  v = 1.2e-7f; };
+template <> struct CertUlp<double> { static constexpr double v = 2.3e-16; };
 
 __device__ __forceinline__ float  fma_t(float a, float b, float c)    { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
@@ -592,8 +596,12 @@ __global__ __launch_bounds__(BLOCK) void loop_init_kernel(const T* __restrict__ 
         if (tid == 0) {
             T v = rm[0];
             for (int w = 1; w < BLOCK / WAVE; ++w) v = rm[w] > v ? rm[w] : v;
-            rmax[cloud] = (v == v) ? m_sqrt(v) : inf_v<T>();        // (NaN coordinates: nothing is ever certified)
+            const T rm0 = (v == v) ? m_sqrt(v) : inf_v<T>();
+            rmax[cloud] = rm0;
+            // (M_0, e_0): no motion yet; e_k = rounding of a transformed point C p + r under pose k
+            const T* Ti = T_init + (size_t)cloud * 16;
             dcum[(size_t)cloud * dstride] = T(0);
+            dcum[(size_t)cloud * dstride + 1] = T(16) * CertUlp<T>::v * (rm0 + m_sqrt(Ti[3] * Ti[3] + Ti[7] * Ti[7] + Ti[11] * Ti[11]) + T(1));
         }
     }
     int k = 0;
@@ -862,53 +870,78 @@ constexpr int SWEEP_MINW_Q2C8 = 5;
 
 // Match certificates (temporal coherence, exact).  Between two ICP iterations near the pose a query moves by ~1e-7 m while the
 // runner-up of its match is ~0.4 m further away: the argmin cannot have changed, and that can be PROVEN per query from what the
-// search already knows.  With CERT the sweep also tracks the second-smallest score it saw, stops a side only behind a wider
-// margin, and leaves per slot   A = H2 - H1 - 3E   and   S = d1 + d2,   where H1 = upper bound of the match's half squared
-// distance (score + 0.5|x|^2 + E), H2 = lower bound of every OTHER target's (the runner-up among the scored rows, minus E;
-// half the squared x-distance to the first unscored row on either side), E the rounding bound of a score (the prune margin's),
-// d = sqrt(2H).  After the query has moved by at most D, every other target is at least (d2 - D) away and the match at most
-// (d1 + D): the match's computed score stays strictly the smallest -- ties and the lowest-index rule cannot come into play --
-// while   A - D S > 0.   certify_kernel checks that per slot against the motion bound the step kernels accumulate per cloud and
-// marks the waves ("units") that hold an uncertified slot; the next search runs for those units only and the others keep their
-// matches.  Measured on the benchmark clouds: 97.8 % of the queries certified at iteration 3, 99.97 % from iteration 4 on.
+// search already knows.  A certifying search also tracks the second-smallest score it saw and stops a side only behind a wider
+// margin; from   H1 = upper bound of the match's half squared distance (score + 0.5|x|^2 + E),   H2 = lower bound of every OTHER
+// target's (the runner-up among the scored rows, minus E; half the squared x-distance to the first unscored row on either side),
+// E the rounding bound of a score (the prune margin's),  d = sqrt(2H),  it derives   A = H2 - H1 - 3E   and   S = d1 + d2.
+// After the query has moved by at most D, every other target is at least (d2 - D) away and the match at most (d1 + D): the match's
+// computed score stays strictly the smallest -- ties and the lowest-index rule cannot come into play -- while   A - D S > 0.
+// The step kernels keep, per cloud and iteration, M_k = a bound of how far any of its queries has moved since iteration 0
+// (sum of |dC|_F max|p| + |dr|) and e_k = the rounding of a transformed point; a search at iteration k0 leaves per query the BUDGET
+//     q = M_k0 + A / S - e_k0        (rounded down; -1: no certificate),
+// and at iteration k the match is proven unchanged while   M_k + e_k < q   -- no record of when the query was last searched.
+// The loop then runs, per iteration:  a guard launch (one wave per unit of the sweep: units with many spent budgets are searched
+// again as units), and the forward accumulate, which checks each point's budget where it reads the point's match and searches the
+// few spent ones on the spot (search_point).  Measured on the benchmark clouds: from the second certified iteration on, 0.18 % of
+// the queries are searched again per iteration (near-ties inside the rounding bound, far from the cloud's centre).
 template <typename T> struct SweepCert {
-    T* a; T* s;                     // (N,n) by SLOT of the current query order
-    const int32_t* dirty;           // (N,units) or NULL: units to search (NULL: all)
-    int32_t* unit_k;                // (N,units): iteration at which a unit was last searched
-    int units, k;
+    T* q;                           // (N,n) budgets by QUERY (like spos)
+    T* qu;                          // (N,units): per unit of the sweep, a lower bound of its certified queries' budgets (a filter, never a proof)
+    const T* dcum; int dstride;     // (N,dstride): (M_k, e_k) pairs per iteration
+    int k;                          // this iteration
+    int32_t* count;                 // (128) or NULL: [0,64) units searched again, [64,128) single queries, sharded by block
 };
 constexpr int CERT_MARGIN = 8;      // prune margin of a certifying search, in units of the plain one: the slab ends where H > H1 + 8E, so an
                                     // unscored row cannot be what denies the certificate (which needs H2 - H1 > 3E + D S)
+constexpr int CERT_SHARDS = 64;
+constexpr int CERT_SLOT_MAX = 16;   // a unit with more spent budgets than this is searched again as a unit (guard launch), the others' queries one by one
 
+template <typename T>
+__device__ __forceinline__ T cert_budget(T A, T S, const T* __restrict__ dk /* (M_k, e_k) */) {
+    if (!(A > T(0))) return T(-1);
+    if (!(S > T(0)) || !(A < inf_v<T>())) return inf_v<T>();    // no other target at all
+    return (A / S + dk[0]) * (T(1) - T(8) * CertUlp<T>::v) - dk[1] * (T(1) + T(8) * CertUlp<T>::v);
+}
+// what a budget is compared with at iteration k:  budget > cert_spent(...)  <=>  the match stands
+template <typename T>
+__device__ __forceinline__ T cert_spent(const T* __restrict__ dk) { return (dk[0] + dk[1]) * (T(1) + T(8) * CertUlp<T>::v); }
+
+// wave-wide minimum (all lanes get it)
+template <typename T> __device__ __forceinline__ T wave_min(T v) {
+#pragma unroll
+    for (int o = WAVE / 2; o > 0; o >>= 1) v = min_t(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+    for (int o = WAVE / 2; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+}
+
+// each wave keeps the last NT tiles it scored in a ring: near the pose that is the whole visited range, and the
+// epilogue then re-scores the winning chunk out of LDS instead of gathering its rows (Q x CH 16-byte gathers per lane)
+template <typename T> struct SweepRing { static constexpr int NT = sizeof(T) == 4 ? 6 : 3; };
+
+// The search of ONE unit (64*Q consecutive slots of a cloud's query order) by one wave; `ring`: the wave's NT tiles of LDS.
 template <typename T, int Q, int CH, bool CERT>
-__global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? SWEEP_MINW_Q2C8 : 1) void knn_sweep_kernel(const T* __restrict__ src, const T* __restrict__ pose,
-                                                          const typename V4<T>::type* __restrict__ tgs4,
-                                                          const int32_t* __restrict__ tperm, const int32_t* __restrict__ qorder,
-                                                          const int32_t* __restrict__ bucket, const T* __restrict__ brange, int nbkt,
-                                                          int32_t* __restrict__ idx, int32_t* __restrict__ spos,
-                                                          unsigned long long* __restrict__ pairs,
-                                                          int N, int n_full, int m_full, int m_pad, int bpc, int src_sorted,
-                                                          const int32_t* __restrict__ src_rows, const int32_t* __restrict__ tgt_rows, SweepCert<T> ct) {
+__device__ __forceinline__ void sweep_unit(const T* __restrict__ src, const T* __restrict__ pose,
+                                           const typename V4<T>::type* __restrict__ tgs4,
+                                           const int32_t* __restrict__ tperm, const int32_t* __restrict__ qorder,
+                                           const int32_t* __restrict__ bucket, const T* __restrict__ brange, int nbkt,
+                                           int32_t* __restrict__ idx, int32_t* __restrict__ spos,
+                                           unsigned long long* __restrict__ pairs,
+                                           int n_full, int m_full, int m_pad, int src_sorted,
+                                           const int32_t* __restrict__ src_rows, const int32_t* __restrict__ tgt_rows, const SweepCert<T>& ct,
+                                           const int cloud, const int unit, typename V4<T>::type* __restrict__ ring) {
     using T4 = typename V4<T>::type;
-    // each wave keeps the last NT tiles it scored in a ring: near the pose that is the whole visited range, and the
-    // epilogue then re-scores the winning chunk out of LDS instead of gathering its rows (Q x CH 16-byte gathers per lane)
-    constexpr int NT = sizeof(T) == 4 ? 6 : 3;
-    __shared__ T4 tiles[BLOCK / WAVE][NT * WAVE];
-    int cloud, blk;
-    if (!decode_block(bpc, N, cloud, blk)) return;
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
-    const int unit = blk * (BLOCK / WAVE) + wave;           // 64*Q consecutive sorted queries
+    constexpr int NT = SweepRing<T>::NT;
+    const int lane = threadIdx.x & (WAVE - 1);
     // ragged batches: this cloud's own lengths.  Its queries are the first n slots of qorder, its targets the first m sorted rows
     const int n = rows_of(src_rows, cloud, n_full), m = max(rows_of(tgt_rows, cloud, m_full), 1);
     const bool idle_wave = unit * (WAVE * Q) >= n;
     if (idle_wave) return;                                  // whole wave idle (no block-level sync anywhere below)
-    if (CERT) {
-        if (ct.dirty && !ct.dirty[(size_t)cloud * ct.units + unit]) return;      // every slot of this unit is certified: its matches stand
-        if (lane == 0) ct.unit_k[(size_t)cloud * ct.units + unit] = ct.k;
-    }
     T C[9], r[3];
     load_pose(pose, cloud, C, r);
-    T4* ring = tiles[wave];
 
     T nx[Q][3], xq[Q], hx[Q], best[Q];
     T sec[Q];                         // CERT: second-smallest chunk minimum seen
@@ -1044,6 +1077,7 @@ __global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? SWEE
     }
 
     const int32_t* __restrict__ pm = tperm + (size_t)cloud * m_pad;
+    T qmin = inf_v<T>();                                    // CERT: smallest budget this wave wrote
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         if (qi[q] < 0) continue;
@@ -1097,36 +1131,168 @@ __global__ __launch_bounds__(BLOCK, (Q == 2 && CH == 8 && sizeof(T) == 4) ? SWEE
                 if (H2 < inf_v<T>()) { A = (H2 - H1) - T(3) * E1; S = m_sqrt(T(2) * H1) + m_sqrt(T(2) * max_t(H2, T(0))); }
                 else                 { A = inf_v<T>(); S = T(0); }      // no other target at all
             }
-            const size_t sl = (size_t)cloud * n_full + unit * (WAVE * Q) + q * WAVE + lane;
-            ct.a[sl] = A; ct.s[sl] = S;
+            const T bq = cert_budget(A, S, ct.dcum + (size_t)cloud * ct.dstride + 2 * ct.k);
+            ct.q[(size_t)cloud * n_full + qi[q]] = bq;
+            if (bq > T(0)) qmin = min_t(qmin, bq);          // (uncertifiable queries are searched on their own every iteration: they do not hold the unit)
         }
+    }
+    if (CERT) {
+        qmin = wave_min(qmin);
+        if (lane == 0) ct.qu[(size_t)cloud * ((n_full + WAVE * Q - 1) / (WAVE * Q)) + unit] = qmin;
     }
     // sharded: one counter serialises ~12 ns per add, which at 65k waves would outlast the kernel itself
     if (pairs && lane == 0 && !idle_wave)
         atomicAdd(pairs + (blockIdx.x & (DICP_PAIR_SHARDS - 1)), (unsigned long long)(visR - visL) * WAVE * WAVE * Q);
 }
 
-// One wave per unit of the sweep (its 64*Q consecutive slots): the unit is dirty -- searched again at this iteration -- if the
-// certificate of any of its slots does not cover the motion D the cloud's queries may have made since the unit was last searched.
-template <typename T>
-__global__ __launch_bounds__(BLOCK) void certify_kernel(const T* __restrict__ cert_a, const T* __restrict__ cert_s, const T* __restrict__ dcum, int dstride, int k,
-                                                        const int32_t* __restrict__ unit_k, int32_t* __restrict__ dirty, const int32_t* __restrict__ src_rows,
-                                                        int N, int n_full, int units, int unit_slots, int bpc) {
+#define DICP_SWEEP_PARAMS const T* __restrict__ src, const T* __restrict__ pose, const typename V4<T>::type* __restrict__ tgs4, \
+        const int32_t* __restrict__ tperm, const int32_t* __restrict__ qorder, const int32_t* __restrict__ bucket, const T* __restrict__ brange, int nbkt, \
+        int32_t* __restrict__ idx, int32_t* __restrict__ spos, unsigned long long* __restrict__ pairs, \
+        int N, int n_full, int m_full, int m_pad, int bpc, int src_sorted, const int32_t* __restrict__ src_rows, const int32_t* __restrict__ tgt_rows, SweepCert<T> ct
+#define DICP_SWEEP_MINW ((Q == 2 && CH == 8 && sizeof(T) == 4) ? SWEEP_MINW_Q2C8 : 1)
+
+// Every unit of every cloud: block (cloud, blk) of the XCD-aware grid, one unit per wave.
+template <typename T, int Q, int CH, bool CERT>
+__global__ __launch_bounds__(BLOCK, DICP_SWEEP_MINW) void knn_sweep_kernel(DICP_SWEEP_PARAMS) {
+    __shared__ typename V4<T>::type tiles[BLOCK / WAVE][SweepRing<T>::NT * WAVE];
     int cloud, blk;
     if (!decode_block(bpc, N, cloud, blk)) return;
-    const int lane = threadIdx.x & (WAVE - 1), unit = blk * (BLOCK / WAVE) + (threadIdx.x >> 6);
-    const int n = rows_of(src_rows, cloud, n_full);
-    if (unit >= units || unit * unit_slots >= n) return;
-    const int kl = unit_k[(size_t)cloud * units + unit];
-    const T D = dcum[(size_t)cloud * dstride + k] - dcum[(size_t)cloud * dstride + min(max(kl, 0), k)];
-    bool bad = kl < 0;                                      // never searched
-    for (int s = unit * unit_slots + lane; s < min(n, (unit + 1) * unit_slots); s += WAVE) {
-        const T a = cert_a[(size_t)cloud * n_full + s], sd = cert_s[(size_t)cloud * n_full + s];
-        bad = bad || !(a - D * sd > T(0));                  // (NaN -> uncertified)
-    }
-    const bool any = __any(bad) != 0;
-    if (lane == 0) dirty[(size_t)cloud * units + unit] = any ? 1 : 0;
+    const int wave = threadIdx.x >> 6;
+    sweep_unit<T, Q, CH, CERT>(src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, idx, spos, pairs, n_full, m_full, m_pad, src_sorted, src_rows, tgt_rows, ct,
+                               cloud, blk * (BLOCK / WAVE) + wave, tiles[wave]);
 }
+
+// What the on-the-spot search of one query needs besides the query (certifying loop only).
+template <typename T> struct PointSearch {
+    const T* pose;                                  // (N,12) search pose of this iteration
+    const typename V4<T>::type* tgs4; const int32_t* tperm; const int32_t* bucket; const T* brange; int nbkt;
+    const int32_t* tgt_rows; int m_full, m_pad;
+    unsigned long long* pairs;
+    SweepCert<T> ct;                                // ct.dcum == NULL: no budget is checked (the iteration's search has just written them)
+    int32_t* spos;                                  // (N,n) this iteration's matches: read, and rewritten where a query is searched
+    int32_t* spos_next;                             // optional (N,n): the next iteration's, started as a copy of this one's
+};
+
+// The search of ONE query by one wave (all lanes carry the same arguments): the query's previous match, scored under the current
+// pose, bounds the best score from above, and with it the slab of sorted rows that can hold the new match -- the same bound the
+// sweep prunes with, so a row outside the slab can never beat the kept minimum.  The lanes score the slab's rows 64 at a time with
+// the score() every search form uses; equal scores resolve to the lowest ORIGINAL index: index for index the match of a full
+// search.  Returns the match's sorted position (-1: none) and leaves the query's new budget in `budget`.
+template <typename T>
+__device__ __forceinline__ int search_point(const PointSearch<T>& ps, const int cloud, const T* nx, const int prev, T& budget) {
+    using T4 = typename V4<T>::type;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int m = max(rows_of(ps.tgt_rows, cloud, ps.m_full), 1);
+    const T xq = -nx[0];
+    const T hx = T(0.5) * (nx[0] * nx[0] + nx[1] * nx[1] + nx[2] * nx[2]);
+    const T4* __restrict__ tg = ps.tgs4 + (size_t)cloud * ps.m_pad;
+    const int32_t* __restrict__ pm = ps.tperm + (size_t)cloud * ps.m_pad;
+    const T eps = SweepEps<T>::v;
+
+    // the slab: rows whose x alone does not put them beyond the previous match's score (+ the certifying margin)
+    const T ub = (prev >= 0 && prev < m) ? score<T, T4>(nx, tg[prev]) : inf_v<T>();
+    int r0 = 0, r1 = m;
+    T h_edge = inf_v<T>();                                      // lower bound of the half squared distance of every row outside the slab
+    const T inv = ps.brange[(size_t)cloud * 2 + 1];
+    if (ub < inf_v<T>() && inv > T(0)) {
+        const T thr = ub + T(CERT_MARGIN) * eps * (T(1) + m_abs(ub) + hx);
+        const T R = m_sqrt(max_t(T(2) * (thr + hx), T(0))) * (T(1) + T(4) * eps);      // 0.5 dx^2 - hx > thr  for every |dx| > R
+        const T xlo = ps.brange[(size_t)cloud * 2];
+        const int32_t* __restrict__ bk = ps.bucket + (size_t)cloud * (ps.nbkt + 1);
+        // bucket b of the table starts at the lower bound of xlo + b / inv (sweep_buckets_kernel); the index of a value and the
+        // table's edges are rounded differently by far less than one bucket, so one bucket more on either side is a superset
+        T fa = (xq - R - xlo) * inv - T(1), fb = (xq + R - xlo) * inv + T(2);
+        fa = fa < T(0) ? T(0) : (fa > T(ps.nbkt) ? T(ps.nbkt) : fa);
+        r0 = min(bk[(int)fa], m);
+        r1 = fb >= T(ps.nbkt) ? m : min(max(bk[(int)fb], r0), m);
+        if (r0 > 0 || r1 < m) h_edge = (thr + hx) * (T(1) - T(8) * eps);
+    }
+
+    T b1 = inf_v<T>(), b2 = inf_v<T>();                         // this lane's two smallest scores
+    int j1 = -1;
+    constexpr int U = 4;                                        // rows in flight per lane: a wide slab is a few round trips, not one per 64 rows
+    for (int j = r0 + lane; j < r1; j += U * WAVE) {
+        T4 y[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) y[u] = tg[min(j + u * WAVE, r1 - 1)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int jj = j + u * WAVE;
+            const T sc = jj < r1 ? score<T, T4>(nx, y[u]) : inf_v<T>();
+            if (sc < b1) { b2 = b1; b1 = sc; j1 = jj; }
+            else if (sc == b1 && sc < inf_v<T>()) { b2 = b1; if (pm[jj] < pm[j1]) j1 = jj; }
+            else if (sc < b2) b2 = sc;
+        }
+    }
+    const T bv = wave_min(b1);
+    int bs = -1;
+    budget = T(-1);
+    if (bv < inf_v<T>()) {                                      // (wave-uniform)
+        const bool cand = b1 == bv;
+        const unsigned long long cm = __ballot(cand);
+        int win;
+        if (__popcll(cm) == 1) win = __ffsll((long long)cm) - 1;
+        else {                                                  // equal scores in several lanes: lowest original index
+            const int o = cand ? pm[j1] : 0x7fffffff;
+            const int omin = wave_min(o);
+            win = __ffsll((long long)__ballot(cand && o == omin)) - 1;
+        }
+        bs = __shfl(j1, win);
+        const T s2 = wave_min(lane == win ? b2 : b1);
+        const T E1 = eps * (T(1) + m_abs(bv) + hx);
+        const T H1 = max_t((bv + hx) + E1, T(0));
+        T H2 = s2 < inf_v<T>() ? (s2 + hx) - eps * (T(1) + m_abs(s2) + hx) : inf_v<T>();
+        H2 = min_t(H2, h_edge);
+        T A = inf_v<T>(), S = T(0);
+        if (H2 < inf_v<T>()) { A = (H2 - H1) - T(3) * E1; S = m_sqrt(T(2) * H1) + m_sqrt(T(2) * max_t(H2, T(0))); }
+        budget = cert_budget(A, S, ps.ct.dcum + (size_t)cloud * ps.ct.dstride + 2 * ps.ct.k);
+    }
+    if (lane == 0) {
+        if (ps.pairs) atomicAdd(ps.pairs + (blockIdx.x & (DICP_PAIR_SHARDS - 1)), (unsigned long long)(r1 - r0));
+        if (ps.ct.count) atomicAdd(ps.ct.count + CERT_SHARDS + (blockIdx.x & (CERT_SHARDS - 1)), 1);
+    }
+    return bs;          // (sorted slots [0,m) hold the cloud's own rows: a row found is a real one)
+}
+
+// Guard of a certified iteration: one wave per unit of the sweep, as in knn_sweep_kernel.  A unit none of whose certified queries can
+// have spent its budget leaves at once; of the others, the ones with more than CERT_SLOT_MAX spent budgets are searched again as a
+// unit (cheaper per query than one by one, and what keeps a batch that suddenly moves far from falling back on single searches);
+// the rest is left to the accumulate that follows, which searches spent queries on the spot.
+template <typename T, int Q, int CH>
+__global__ __launch_bounds__(BLOCK, DICP_SWEEP_MINW) void knn_sweep_guard_kernel(DICP_SWEEP_PARAMS) {
+    __shared__ typename V4<T>::type tiles[BLOCK / WAVE][SweepRing<T>::NT * WAVE];
+    int cloud, blk;
+    if (!decode_block(bpc, N, cloud, blk)) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1);
+    const int unit = blk * (BLOCK / WAVE) + wave, units = (n_full + WAVE * Q - 1) / (WAVE * Q);
+    const int n = rows_of(src_rows, cloud, n_full);
+    if (unit * (WAVE * Q) >= n) return;
+    const T spent = cert_spent(ct.dcum + (size_t)cloud * ct.dstride + 2 * ct.k);
+    T* qu = ct.qu + (size_t)cloud * units + unit;
+    if (*qu > spent) return;
+    int bad = 0;
+    T qmin = inf_v<T>();
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int pos = unit * (WAVE * Q) + q * WAVE + lane;
+        if (pos < n) {
+            const T b = ct.q[(size_t)cloud * n_full + qorder[(size_t)cloud * n_full + pos]];
+            if (b > spent) qmin = min_t(qmin, b); else if (b > T(0)) ++bad;        // (b <= 0: never certifiable, searched on its own every iteration)
+        }
+    }
+    int nbad = 0;
+#pragma unroll
+    for (int q = 0; q <= Q; ++q) nbad += __popcll(__ballot(bad > q));
+    if (nbad > CERT_SLOT_MAX) {
+        if (lane == 0 && ct.count) atomicAdd(ct.count + (blockIdx.x & (CERT_SHARDS - 1)), 1);
+        sweep_unit<T, Q, CH, true>(src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, idx, spos, pairs, n_full, m_full, m_pad, src_sorted, src_rows, tgt_rows, ct,
+                                   cloud, unit, tiles[wave]);
+    } else {
+        qmin = wave_min(qmin);
+        if (lane == 0) *qu = qmin;
+    }
+}
+#undef DICP_SWEEP_PARAMS
 
 // ------------------------------------------------------------- key sort beyond the LDS sort
 // Stable sort of a cloud's target x keys for clouds sort_keys_kernel cannot take: float64 keys, or more than 16384 slots.
@@ -1345,30 +1511,71 @@ __device__ __forceinline__ void block_reduce_store(T* v, T* __restrict__ out, T*
 }
 
 // -------------------------------------------------------------------- accumulate
-template <typename T, int MODE>
-__global__ __launch_bounds__(BLOCK) void accumulate_kernel(WeightParams P, const T* __restrict__ src, const T* __restrict__ tgt, int c /* elements per row of tgt */,
+// CERT (certified iterations of the sweep loop; idx = this iteration's sorted positions): the point's budget is checked where its
+// match is read, a spent one is searched on the spot by the whole wave (search_point), and the matches are handed on to the next
+// iteration's buffer.
+template <typename T, int MODE, bool CERT = false>
+__global__ __launch_bounds__(BLOCK, (CERT && sizeof(T) == 4) ? 6 : 1) void accumulate_kernel(WeightParams P, const T* __restrict__ src, const T* __restrict__ tgt, int c /* elements per row of tgt */,
                                                            const int32_t* __restrict__ idx, const T* __restrict__ pose,
                                                            const T* __restrict__ w_init, const T* __restrict__ alive,
                                                            int N, int n, int m, int bpc, T* __restrict__ partials,
-                                                           T* __restrict__ w_out, long w_stride, const int32_t* __restrict__ src_rows) {
+                                                           T* __restrict__ w_out, long w_stride, const int32_t* __restrict__ src_rows, PointSearch<T> ps) {
     __shared__ T red[(BLOCK / WAVE) * NACC_PAD];
     int cloud, blk;
     if (!decode_block(bpc, N, cloud, blk)) return;
+    const int nc = rows_of(src_rows, cloud, n);             // ragged batches: rows past the cloud's own carry weight 0 (ICP.py:386-398)
+    const int end = min(nc, (blk + 1) * ACC_PTS);
+    if (CERT && ps.ct.dcum) {
+        // first the budgets of this block's points (before the sums' registers are live): spent ones are searched again, one query at a
+        // time by the whole wave; the thread that owns the point rewrites its match and budget and reads them back below
+        const int lane = threadIdx.x & (WAVE - 1);
+        const T spent = cert_spent(ps.ct.dcum + (size_t)cloud * ps.ct.dstride + 2 * ps.ct.k);
+        constexpr int ROUNDS = ACC_PTS / BLOCK;
+        T b[ROUNDS];
+#pragma unroll
+        for (int t = 0; t < ROUNDS; ++t) {
+            const int i = blk * ACC_PTS + t * BLOCK + threadIdx.x;
+            b[t] = i < end ? ps.ct.q[(size_t)cloud * n + i] : inf_v<T>();
+        }
+#pragma unroll 1
+        for (int t = 0; t < ROUNDS; ++t) {
+            const bool redo = !(b[t] > spent);                  // (NaN, -1: searched every iteration)
+            unsigned long long todo = __ballot(redo);
+            if (!todo) continue;                                // (wave-uniform; the common case)
+            const size_t pt = (size_t)cloud * n + min(blk * ACC_PTS + t * BLOCK + (int)threadIdx.x, n - 1);
+            T p[3] = {T(0), T(0), T(0)}, nb = T(-1);
+            int j = -1;
+            if (redo) { const T* sp = src + pt * 3; p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2]; j = ps.spos[pt]; }
+            T Cs[9], rs[3];
+            load_pose(ps.pose, cloud, Cs, rs);
+            while (todo) {
+                const int L = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const T pq[3] = {__shfl(p[0], L), __shfl(p[1], L), __shfl(p[2], L)};
+                T nx[3], got;
+                query_point(Cs, rs, pq, nx);
+                const int found = search_point<T>(ps, cloud, nx, __shfl(j, L), got);
+                if (lane == L) { j = found; nb = got; }
+            }
+            if (redo) { ps.spos[pt] = j; ps.ct.q[pt] = nb; }
+        }
+    }
     T C[9], r[3];
     load_pose(pose, cloud, C, r);
     const T live = alive ? alive[cloud] : T(1);
     T acc[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = T(0);
-    const int nc = rows_of(src_rows, cloud, n);             // ragged batches: rows past the cloud's own carry weight 0 (ICP.py:386-398)
     if (w_out)                                              // ... which is what the weight history reports for them
         for (int i = max(blk * ACC_PTS, nc) + threadIdx.x; i < min(n, (blk + 1) * ACC_PTS); i += BLOCK) w_out[(size_t)cloud * w_stride + i] = T(0);
-    const int end = min(nc, (blk + 1) * ACC_PTS);
+    const int32_t* __restrict__ ix = CERT ? ps.spos : idx;
     for (int i = blk * ACC_PTS + threadIdx.x; i < end; i += BLOCK) {       // (2 or 4 points in flight per thread measured slower: 78 / 85 vs 72 us)
         const size_t pt = (size_t)cloud * n + i;
         const T* sp = src + pt * 3;
         const T p[3] = {sp[0], sp[1], sp[2]};
-        const int j = idx ? min(max(idx[pt], 0), m - 1) : i;     // idx == NULL: tgt holds one row per source point
+        const int jm = ix ? ix[pt] : i;                     // ix == NULL: tgt holds one row per source point
+        if (CERT && ps.spos_next) ps.spos_next[pt] = jm;
+        const int j = min(max(jm, 0), m - 1);
         const T* yp = tgt + ((size_t)cloud * m + j) * c;
         const T y[3] = {yp[0], yp[1], yp[2]};
         T nrm[3] = {T(0), T(0), T(0)};
@@ -1401,7 +1608,7 @@ __host__ __device__ inline dicp_step_io make_step_io(const dicp_loop_buffers& B,
     io.w_cur = (char*)B.w + (size_t)k * B.w_iter * es;
     io.w_prev = k > k0 ? (const char*)B.w + (size_t)(k - 1) * B.w_iter * es : (const char*)B.w_prev0; io.w_stride = B.w_stride;
     io.n_not_converged = B.counters + k;
-    io.rmax = B.rmax; io.dcum = B.dcum; io.dcum_stride = B.K + 1;
+    io.rmax = B.rmax; io.dcum = B.dcum; io.dcum_stride = 2 * (B.K + 1);
     return io;
 }
 
@@ -1437,17 +1644,17 @@ __device__ __forceinline__ void step_body(const dicp_step_io& io, int cloud, int
             for (int j = 0; j < 3; ++j)
                 pout[i * 3 + j] = (T)(R[0 * 3 + i] * C[0 * 3 + j] + R[1 * 3 + i] * C[1 * 3 + j] + R[2 * 3 + i] * C[2 * 3 + j]);
         for (int k = 0; k < 3; ++k) pout[9 + k] = (T)(spose[9 + k] - d6[3 + k]);
-        if (io.dcum) {      // how far a query of this cloud can have moved between the two poses: |dC|_F max|p| + |dr|, rounded up, plus the
-                            // rounding of the two transformed points themselves
+        if (io.dcum) {      // match certificates: (M, e) of the new pose.  M += how far a query of this cloud can have moved between the two
+                            // poses, |dC|_F max|p| + |dr|, rounded up; e = the rounding of a point transformed with the new pose
             double dC = 0.0, dr = 0.0, rn = 0.0;
             for (int k = 0; k < 9; ++k) { const double d = (double)pout[k] - spose[k]; dC += d * d; }
             for (int k = 0; k < 3; ++k) { const double d = (double)pout[9 + k] - spose[9 + k]; dr += d * d; rn += (double)pout[9 + k] * (double)pout[9 + k]; }
             const double rm = (double)((const T*)io.rmax)[cloud];
             const double ulp = sizeof(T) == 4 ? 1.2e-7 : 2.3e-16;
-            const double step = (sqrt(dC) * rm + sqrt(dr)) * 1.0001 + 16.0 * ulp * (rm + sqrt(rn) + 1.0);
-            T* dc = (T*)io.dcum + (size_t)cloud * io.dcum_stride;
-            const T nxt = (T)((double)dc[io.iter] + step);
-            dc[io.iter + 1] = nxt + m_abs(nxt) * (T)(4.0 * ulp);           // (rounded up)
+            T* dc = (T*)io.dcum + (size_t)cloud * io.dcum_stride + 2 * io.iter;
+            const T nxt = (T)((double)dc[0] + (sqrt(dC) * rm + sqrt(dr)) * 1.0001);
+            dc[2] = nxt + m_abs(nxt) * (T)(4.0 * ulp);                    // (rounded up)
+            dc[3] = (T)(16.0 * ulp * (rm + sqrt(rn) + 1.0) * 1.0001);
         }
         if (io.pose_search_out) {                                         // what the next search reads: [C | r - centre]
             T* ps = (T*)io.pose_search_out + (size_t)cloud * 12;
@@ -2513,6 +2720,13 @@ inline unsigned blocks_for(size_t total) { return (unsigned)((total + BLOCK - 1)
 
 struct Rows { const int32_t* src; const int32_t* tgt; };     // optional per-cloud row counts of a ragged batch
 
+struct CertAcc {              // what the accumulate of a certified iteration needs for its on-the-spot searches (PointSearch, untyped)
+    const void* pose_search; const void* tgs4; const int32_t* tperm; const int32_t* bucket; const void* brange; int nbkt;
+    const int32_t* tgt_rows; int m_full, m_pad; unsigned long long* pairs;
+    void* q; void* qu; const void* dcum; int dstride, k; int32_t* count;
+    int32_t* spos; int32_t* spos_next;
+};
+
 template <typename T, int Q, int CH, int MINW = 1>
 void knn_valu_go(const void* src, const void* pose, const void* tgt4, int N, int n, int m, int m_pad, int32_t* idx, Rows rw, hipStream_t st) {
     using T4 = typename V4<T>::type;
@@ -2567,7 +2781,6 @@ extern "C" {
 int dicp_abi_version(void) { return DICP_ABI_VERSION; }
 int dicp_padded_targets(int m) { return m <= 0 ? 0 : ((m + KNN_PAD - 1) / KNN_PAD) * KNN_PAD; }
 int dicp_accumulate_blocks(int n) { return n <= 0 ? 0 : (n + ACC_PTS - 1) / ACC_PTS; }
-
 int dicp_cloud_center(int dtype, const void* tgt, int c, const int32_t* tgt_rows, int N, int m, double quantum, void* center, void* stream) {
     if (!tgt || !center) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
@@ -2674,7 +2887,7 @@ int dicp_loop_init(int dtype, const void* T_init, const void* w0, double thresh,
                    const void* src, void* rmax, void* dcum, int dcum_stride, void* stream) {
     if (!T_init || !w0 || !pose0 || !alive0 || !n_start || (rmax && (!src || !dcum))) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
-    if (N <= 0 || n <= 0 || (rows != 1 && rows != 3) || (rmax && dcum_stride < 1)) return DICP_ERR_SHAPE;
+    if (N <= 0 || n <= 0 || (rows != 1 && rows != 3) || (rmax && dcum_stride < 2)) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     begin_launch();
     if (dtype == DICP_F32) loop_init_kernel<float><<<N, BLOCK, 0, st>>>((const float*)T_init, (const float*)w0, (float)thresh, rows, n, (float*)pose0, (float*)alive0, (float*)n_start, (const float*)center, (float*)pose_search0, (const float*)src, (float*)rmax, (float*)dcum, dcum_stride);
@@ -2752,10 +2965,14 @@ int dicp_knn(int dtype, const void* src, const void* pose, const void* tgt4, con
 static int sweep_queries_per_lane(int cfg) { return cfg == 2 ? 2 : ((cfg == 1 || cfg == 4) ? 1 : 0); }
 static int sweep_auto_cfg(int N, int n) { return ((long)N * n >= 2L * BLOCK * 1024) ? SWEEP_CFG_BIG : 4; }
 
+struct CertArgs {             // certifying search: budgets (NULL q: plain search), motion bounds; guard: the launch of a certified iteration
+    void* q; void* qu; const void* dcum; int dstride; int k; int32_t* count; bool guard;
+};
+
 static int sweep_launch(int dtype, const void* src, const void* pose, const void* tgs4, const int32_t* tperm,
                         const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt,
                         int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg, Rows rw, hipStream_t st,
-                        void* cert_a = nullptr, void* cert_s = nullptr, const int32_t* dirty = nullptr, int32_t* unit_k = nullptr, int k_iter = 0) {
+                        CertArgs ca = CertArgs{}) {
     hipEvent_t ev0, ev1;
     take_launch_events(ev0, ev1);                                       // (null unless a timed loop set them for this launch)
     const int src_sorted = (cfg & DICP_SWEEP_SRC_SORTED) ? 1 : 0;      // src holds the rows in qorder's slot order
@@ -2766,14 +2983,20 @@ static int sweep_launch(int dtype, const void* src, const void* pose, const void
     if (Q <= 0) return DICP_ERR_ENUM;
     const int units = (n + WAVE * Q - 1) / (WAVE * Q);                  // waves per cloud
     const int bpc = (units + BLOCK / WAVE - 1) / (BLOCK / WAVE);
-#define DICP_SWEEP_C(T, Q, CH, CERT, CT) hipExtLaunchKernelGGL((knn_sweep_kernel<T, Q, CH, CERT>), dim3(grid_for(N, bpc)), dim3(BLOCK), 0, st, ev0, ev1, 0, \
-        (const T*)src, (const T*)pose, (const typename V4<T>::type*)tgs4, tperm, qorder, bucket, (const T*)brange, nbkt, idx, spos, pairs, \
-        N, n, m, m_pad, bpc, src_sorted, rw.src, rw.tgt, CT)
+#define DICP_SWEEP_ARGS(T) (const T*)src, (const T*)pose, (const typename V4<T>::type*)tgs4, tperm, qorder, bucket, (const T*)brange, nbkt, idx, spos, pairs, \
+        N, n, m, m_pad, bpc, src_sorted, rw.src, rw.tgt
+#define DICP_SWEEP_C(T, Q, CH, CERT, CT) hipExtLaunchKernelGGL((knn_sweep_kernel<T, Q, CH, CERT>), dim3(grid_for(N, bpc)), dim3(BLOCK), 0, st, ev0, ev1, 0, DICP_SWEEP_ARGS(T), CT)
+#define DICP_SWEEP_L(T, CT) hipExtLaunchKernelGGL((knn_sweep_guard_kernel<T, 2, 8>), dim3(grid_for(N, bpc)), dim3(BLOCK), 0, st, ev0, ev1, 0, DICP_SWEEP_ARGS(T), CT)
 #define DICP_SWEEP(T, Q, CH) do { SweepCert<T> none{}; DICP_SWEEP_C(T, Q, CH, false, none); } while (0)
-    if (cert_a) {           // certifying search (the configuration the loop uses for big problems: 2 queries per lane, 8-row chunks)
-        if (cfg != 2 || !cert_s || !unit_k || !spos) return DICP_ERR_ENUM;
-        if (dtype == DICP_F32) { SweepCert<float> c{(float*)cert_a, (float*)cert_s, dirty, unit_k, units, k_iter}; DICP_SWEEP_C(float, 2, 8, true, c); }
-        else                   { SweepCert<double> c{(double*)cert_a, (double*)cert_s, dirty, unit_k, units, k_iter}; DICP_SWEEP_C(double, 2, 8, true, c); }
+    if (ca.q) {             // certifying search (the configuration the loop uses for big problems: 2 queries per lane, 8-row chunks)
+        if (cfg != 2 || !ca.qu || !ca.dcum || !spos || !qorder) return DICP_ERR_ENUM;
+        if (dtype == DICP_F32) {
+            SweepCert<float> c{(float*)ca.q, (float*)ca.qu, (const float*)ca.dcum, ca.dstride, ca.k, ca.count};
+            if (ca.guard) DICP_SWEEP_L(float, c); else DICP_SWEEP_C(float, 2, 8, true, c);
+        } else {
+            SweepCert<double> c{(double*)ca.q, (double*)ca.qu, (const double*)ca.dcum, ca.dstride, ca.k, ca.count};
+            if (ca.guard) DICP_SWEEP_L(double, c); else DICP_SWEEP_C(double, 2, 8, true, c);
+        }
         return launch_status();
     }
     if (dtype == DICP_F32) {
@@ -2783,6 +3006,8 @@ static int sweep_launch(int dtype, const void* src, const void* pose, const void
     }
 #undef DICP_SWEEP
 #undef DICP_SWEEP_C
+#undef DICP_SWEEP_L
+#undef DICP_SWEEP_ARGS
     return launch_status();
 }
 
@@ -2839,13 +3064,14 @@ static int check_params(const dicp_weight_params* p, int c) {
     return 0;
 }
 
-int dicp_accumulate(int dtype, const dicp_weight_params* prm, const void* src, const void* tgt, int c,
-                    const int32_t* idx, const void* pose, const void* w_init, const void* alive, const int32_t* src_rows,
-                    int N, int n, int m, void* partials, void* w_out, int64_t w_stride, void* stream) {
+// (ca: the certified iterations of the sweep loop -- idx is then ca->spos)
+static int accumulate_go(int dtype, const dicp_weight_params* prm, const void* src, const void* tgt, int c,
+                         const int32_t* idx, const void* pose, const void* w_init, const void* alive, const int32_t* src_rows,
+                         int N, int n, int m, void* partials, void* w_out, int64_t w_stride, void* stream, const CertAcc* ca) {
     if (const int e = check_params(prm, c)) return e;
     if (!src || !tgt || !w_init || !partials) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
-    if (N <= 0 || n <= 0 || m <= 0 || (w_out && w_stride < n) || (!idx && m != n)) return DICP_ERR_SHAPE;
+    if (N <= 0 || n <= 0 || m <= 0 || (w_out && w_stride < n) || (!idx && !ca && m != n)) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     begin_launch();
     const WeightParams P = to_params(prm);
@@ -2853,12 +3079,26 @@ int dicp_accumulate(int dtype, const dicp_weight_params* prm, const void* src, c
     const unsigned g = grid_for(N, bpc);
     hipEvent_t ev0, ev1;
     take_launch_events(ev0, ev1);                                       // (null unless a timed loop set them for this launch)
-#define DICP_ACC(T, M) hipExtLaunchKernelGGL((accumulate_kernel<T, M>), dim3(g), dim3(BLOCK), 0, st, ev0, ev1, 0, P, (const T*)src, (const T*)tgt, c, idx, (const T*)pose, \
-        (const T*)w_init, (const T*)alive, N, n, m, bpc, (T*)partials, (T*)w_out, (long)w_stride, src_rows)
-    if (dtype == DICP_F32) { if (P.mode == MODE_PT2PL) DICP_ACC(float, MODE_PT2PL); else DICP_ACC(float, MODE_PT2PT); }
-    else                   { if (P.mode == MODE_PT2PL) DICP_ACC(double, MODE_PT2PL); else DICP_ACC(double, MODE_PT2PT); }
+#define DICP_ACC(T, M, CERT, PS) hipExtLaunchKernelGGL((accumulate_kernel<T, M, CERT>), dim3(g), dim3(BLOCK), 0, st, ev0, ev1, 0, P, (const T*)src, (const T*)tgt, c, idx, (const T*)pose, \
+        (const T*)w_init, (const T*)alive, N, n, m, bpc, (T*)partials, (T*)w_out, (long)w_stride, src_rows, PS)
+#define DICP_ACC_T(T) do { \
+        PointSearch<T> ps{}; \
+        if (ca) { \
+            ps.pose = (const T*)ca->pose_search; ps.tgs4 = (const typename V4<T>::type*)ca->tgs4; ps.tperm = ca->tperm; ps.bucket = ca->bucket; ps.brange = (const T*)ca->brange; \
+            ps.nbkt = ca->nbkt; ps.tgt_rows = ca->tgt_rows; ps.m_full = ca->m_full; ps.m_pad = ca->m_pad; ps.pairs = ca->pairs; \
+            ps.ct = SweepCert<T>{(T*)ca->q, (T*)ca->qu, (const T*)ca->dcum, ca->dstride, ca->k, ca->count}; ps.spos = ca->spos; ps.spos_next = ca->spos_next; \
+            if (P.mode == MODE_PT2PL) DICP_ACC(T, MODE_PT2PL, true, ps); else DICP_ACC(T, MODE_PT2PT, true, ps); \
+        } else { if (P.mode == MODE_PT2PL) DICP_ACC(T, MODE_PT2PL, false, ps); else DICP_ACC(T, MODE_PT2PT, false, ps); } } while (0)
+    if (dtype == DICP_F32) DICP_ACC_T(float); else DICP_ACC_T(double);
+#undef DICP_ACC_T
 #undef DICP_ACC
     return launch_status();
+}
+
+int dicp_accumulate(int dtype, const dicp_weight_params* prm, const void* src, const void* tgt, int c,
+                    const int32_t* idx, const void* pose, const void* w_init, const void* alive, const int32_t* src_rows,
+                    int N, int n, int m, void* partials, void* w_out, int64_t w_stride, void* stream) {
+    return accumulate_go(dtype, prm, src, tgt, c, idx, pose, w_init, alive, src_rows, N, n, m, partials, w_out, w_stride, stream, nullptr);
 }
 
 int dicp_step(int dtype, const dicp_step_io* io, int N, void* stream) {
@@ -3174,35 +3414,32 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
             if (B->src_s && B->qorder) { qsrc = B->src_s; cfg |= DICP_SWEEP_SRC_SORTED; }
             // match certificates: only the units holding a query whose match is not proven unchanged are searched again
             const int cfg_plain = (cfg & ~DICP_SWEEP_SRC_SORTED) ? (cfg & ~DICP_SWEEP_SRC_SORTED) : sweep_auto_cfg(N, n);
-            const bool cert = B->cert_a && B->cert_s && B->unit_k && B->dirty && B->rmax && B->dcum && spos_k && B->qorder && cfg_plain == 2;
+            const bool cert = B->cert_q && B->cert_qu && B->rmax && B->dcum && spos_k && sorted_rows && !B->idx && B->qorder && cfg_plain == 2;
+            const bool fresh = k == 0 || (k == k0 && B->cert_reset);           // a new query order: every query is searched, every budget written
+            int32_t* count_k = B->cert_count ? B->cert_count + (size_t)k * 2 * CERT_SHARDS : nullptr;
             if (cert) {
-                const int units = (n + 2 * WAVE - 1) / (2 * WAVE);
-                const bool fresh = k == 0 || (k == k0 && B->cert_reset);       // a new query order: the certificates (kept by slot) do not apply
-                if (!fresh) {
-                    if (B->idx_per_iter) {      // this iteration's matches start as the previous iteration's
-                        const int32_t* prev = k > k0 ? B->spos + (size_t)(k - 1) * N * n : B->spos_prev0;
-                        if (!prev) return DICP_ERR_NULL;
-                        if (hipMemcpyAsync(spos_k, prev, (size_t)N * n * sizeof(int32_t), hipMemcpyDeviceToDevice, st) != hipSuccess) return -(int)hipGetLastError();
-                    }
-                    const int cb = (units + BLOCK / WAVE - 1) / (BLOCK / WAVE);
-                    begin_launch();
-                    if (dtype == DICP_F32) certify_kernel<float><<<grid_for(N, cb), BLOCK, 0, st>>>((const float*)B->cert_a, (const float*)B->cert_s, (const float*)B->dcum, B->K + 1, k,
-                                                                                                    B->unit_k, B->dirty, B->src_rows, N, n, units, 2 * WAVE, cb);
-                    else                   certify_kernel<double><<<grid_for(N, cb), BLOCK, 0, st>>>((const double*)B->cert_a, (const double*)B->cert_s, (const double*)B->dcum, B->K + 1, k,
-                                                                                                     B->unit_k, B->dirty, B->src_rows, N, n, units, 2 * WAVE, cb);
-                    rc = launch_status();
-                    if (rc) return rc;
+                if (!fresh && k == k0 && B->idx_per_iter) {     // this call's first matches start as the previous call's last (later ones: handed on by accumulate)
+                    if (!B->spos_prev0) return DICP_ERR_NULL;
+                    if (hipMemcpyAsync(spos_k, B->spos_prev0, (size_t)N * n * sizeof(int32_t), hipMemcpyDeviceToDevice, st) != hipSuccess) return -(int)hipGetLastError();
                 }
                 begin_launch();
-                rc = sweep_launch(dtype, qsrc, pose_s, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, N, n, m, B->m_pad, B->idx ? idx_k : nullptr, spos_k,
-                                  B->pairs, cfg, Rows{B->src_rows, B->tgt_rows}, st, B->cert_a, B->cert_s, fresh ? nullptr : B->dirty, B->unit_k, k);
+                rc = sweep_launch(dtype, qsrc, pose_s, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, N, n, m, B->m_pad, nullptr, spos_k,
+                                  B->pairs, cfg, Rows{B->src_rows, B->tgt_rows}, st, CertArgs{B->cert_q, B->cert_qu, B->dcum, 2 * (B->K + 1), k, count_k, !fresh});
             } else
             rc = dicp_knn_sweep(dtype, qsrc, pose_s, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, B->src_rows, B->tgt_rows, N, n, m, B->m_pad,
                                 B->idx ? idx_k : nullptr, spos_k, B->pairs, cfg, stream);
             set_launch_events(nullptr, nullptr);
             if (rc) return rc;
             if (B->events) set_launch_events((hipEvent_t)B->events[6 * k + 2], (hipEvent_t)B->events[6 * k + 3]);
-            if (sorted_rows)
+            if (cert) {
+                // the accumulate of a certified iteration checks every point's budget and searches the spent ones on the spot; its matches
+                // are the start of the next iteration's (within this call)
+                const CertAcc ca{pose_s, B->tgt4, B->tperm, B->bucket, B->brange, B->nbkt, B->tgt_rows, m, B->m_pad, B->pairs,
+                                 B->cert_q, B->cert_qu, fresh ? nullptr : B->dcum, 2 * (B->K + 1), k, count_k,
+                                 spos_k, (B->idx_per_iter && k + 1 < k1) ? spos_k + (size_t)N * n : nullptr};
+                rc = accumulate_go(dtype, prm, B->src, B->tgt_sorted, B->tgt_sorted_stride, spos_k, pose_k, B->w_init, alive_k, B->src_rows, N, n, B->m_pad,
+                                   B->partials, w_k, B->w_stride, stream, &ca);
+            } else if (sorted_rows)
                 rc = dicp_accumulate(dtype, prm, B->src, B->tgt_sorted, B->tgt_sorted_stride, spos_k, pose_k, B->w_init, alive_k, B->src_rows, N, n, B->m_pad,
                                      B->partials, w_k, B->w_stride, stream);
             else

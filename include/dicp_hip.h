@@ -191,8 +191,9 @@ typedef struct dicp_step_io {
     const void* center;      /* optional (N,3) T: the search's centre (dicp_cloud_center) */
     void* pose_search_out;   /* optional (N,12) T: [C' | r' - centre], what the NEXT search reads (NULL: not kept) */
     const void* rmax;        /* optional (N) T: largest |p| of each source cloud (dicp_loop_init) */
-    void* dcum;              /* optional T: cloud b's cumulative motion bounds at dcum + b*dcum_stride: [iter+1] = [iter] + how far any query of
-                                the cloud can have moved between pose_in and pose_out (match certificates, dicp_loop_buffers.cert_a) */
+    void* dcum;              /* optional T: cloud b's (motion bound, point rounding) pairs at dcum + b*dcum_stride: [2(iter+1)] = [2 iter] + how far any
+                                query of the cloud can have moved between pose_in and pose_out, [2(iter+1)+1] = the rounding of a point transformed
+                                with pose_out (match certificates, dicp_loop_buffers.cert_q) */
     int64_t dcum_stride;
 } dicp_step_io;
 
@@ -254,15 +255,16 @@ typedef struct dicp_loop_buffers {
     const int32_t* src_rows; /* optional (N): rows of each source cloud that take part (ragged batches); qorder, if any, from dicp_query_order
                                 with the same counts */
     const int32_t* tgt_rows; /* optional (N): rows of each target cloud that take part; tgt4 / the sweep index built with the same counts */
-    void* cert_a;            /* sweep only, optional (N,n) T, by slot of qorder: match certificates (with cert_s).  With them an iteration searches only
-                                the units (waves of the sweep) that hold a query whose match is not PROVEN unchanged since the unit's last search
-                                (exact: same indices as a full search; see knn_sweep_kernel); needs spos, qorder, rmax, dcum, unit_k, dirty */
-    void* cert_s;            /* (N,n) T */
-    int32_t* unit_k;         /* (N, ceil(n/128)) initialised to -1: iteration of each unit's last search */
-    int32_t* dirty;          /* (N, ceil(n/128)) scratch */
+    void* cert_q;            /* sweep only, optional (N,n) T, by query: match certificates ("budgets": see knn_sweep_kernel).  With them the first iteration
+                                of a query order searches every query and writes its budget; a later one searches only the queries whose match is
+                                not PROVEN unchanged -- whole units in a guard launch where many are, the others inside dicp_accumulate's launch
+                                (exact: same indices as a full search).  Needs spos (and no idx), tgt_sorted, qorder, cert_qu, rmax, dcum */
+    void* cert_qu;           /* (N, ceil(n/128)) T scratch */
+    int32_t* cert_count;     /* optional (K,128) zeros: per iteration, units searched again [0,64) and single queries [64,128), sharded by block */
     void* rmax;              /* (N) T from dicp_loop_init */
-    void* dcum;              /* (N,K+1) T */
-    int32_t cert_reset;      /* 1: qorder is new in this call's first iteration: certificates (kept by slot) do not carry over into it */
+    void* dcum;              /* (N, 2(K+1)) T: per iteration (motion bound since iteration 0, rounding of a transformed point); dicp_loop_init
+                                writes iteration 0's, the step kernels the rest */
+    int32_t cert_reset;      /* 1: qorder is new in this call's first iteration: that iteration searches every query */
     const int32_t* spos_prev0; /* per-iteration spos: the matches of iteration k0-1 (NULL when k0 == 0 or spos is one reused buffer) */
     const void* tgt_sorted;  /* sweep only, optional (N,m_pad,tgt_sorted_stride): dicp_sweep_build's tgt_s.  With it (and spos) the forward accumulate
                                 gathers the match rows from the sorted copy at spos -- one aligned sector per row -- and idx may be NULL */
@@ -282,7 +284,7 @@ int dicp_pose_grad_out(int dtype, const double* gpose, const void* bwd_partials,
 int dicp_loop_init(int dtype, const void* T_init, const void* w0, double thresh, int rows, int N, int n,
                    void* pose0, void* alive0, void* n_start, const void* center /* optional */, void* pose_search0 /* optional: [C_0 | r_0 - center] */,
                    const void* src, void* rmax, void* dcum, int dcum_stride /* optional (match certificates): rmax (N) = largest |p| of each cloud of
-                   src (N,n,3), dcum (N,dcum_stride): [0] = 0 */, void* stream);
+                   src (N,n,3), dcum (N,dcum_stride >= 2): [0] = 0, [1] = the rounding of a point transformed with pose0 */, void* stream);
 /* pose_search (N,12) = [C_0 | r_0 - center] from T_init (N,4,4) alone: the same values, for a caller that orders the first queries
  * before the loop state exists (center optional) */
 int dicp_search_pose(int dtype, const void* T_init, const void* center, int N, void* pose_search, void* stream);

@@ -601,7 +601,9 @@ __global__ __launch_bounds__(BLOCK) void loop_init_kernel(const T* __restrict__ 
             // (M_0, e_0): no motion yet; e_k = rounding of a transformed point C p + r under pose k
             const T* Ti = T_init + (size_t)cloud * 16;
             dcum[(size_t)cloud * dstride] = T(0);
-            dcum[(size_t)cloud * dstride + 1] = T(16) * CertUlp<T>::v * (rm0 + m_sqrt(Ti[3] * Ti[3] + Ti[7] * Ti[7] + Ti[11] * Ti[11]) + T(1));
+            const T* ct = center ? center + (size_t)cloud * 3 : nullptr;
+            const T cn = ct ? m_sqrt(ct[0] * ct[0] + ct[1] * ct[1] + ct[2] * ct[2]) : T(0);     // (the search subtracts the centre from r)
+            dcum[(size_t)cloud * dstride + 1] = T(16) * CertUlp<T>::v * (rm0 + m_sqrt(Ti[3] * Ti[3] + Ti[7] * Ti[7] + Ti[11] * Ti[11]) + cn + T(1));
         }
     }
     int k = 0;
@@ -902,6 +904,8 @@ __device__ __forceinline__ T cert_budget(T A, T S, const T* __restrict__ dk /* (
     if (!(S > T(0)) || !(A < inf_v<T>())) return inf_v<T>();    // no other target at all
     return (A / S + dk[0]) * (T(1) - T(8) * CertUlp<T>::v) - dk[1] * (T(1) + T(8) * CertUlp<T>::v);
 }
+// "no certificate, searched at iteration k": never above cert_spent(), and told apart from a budget that was spent before this iteration
+template <typename T> __device__ __forceinline__ T cert_mark(int k) { return T(-(k + 2)); }
 // what a budget is compared with at iteration k:  budget > cert_spent(...)  <=>  the match stands
 template <typename T>
 __device__ __forceinline__ T cert_spent(const T* __restrict__ dk) { return (dk[0] + dk[1]) * (T(1) + T(8) * CertUlp<T>::v); }
@@ -1077,7 +1081,8 @@ __device__ __forceinline__ void sweep_unit(const T* __restrict__ src, const T* _
     }
 
     const int32_t* __restrict__ pm = tperm + (size_t)cloud * m_pad;
-    T qmin = inf_v<T>();                                    // CERT: smallest budget this wave wrote
+    T qmin = inf_v<T>();                                    // CERT: smallest budget this wave wrote,
+    int nunc = 0;                                           // ... and how many of this lane's queries got none
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         if (qi[q] < 0) continue;
@@ -1132,13 +1137,19 @@ __device__ __forceinline__ void sweep_unit(const T* __restrict__ src, const T* _
                 else                 { A = inf_v<T>(); S = T(0); }      // no other target at all
             }
             const T bq = cert_budget(A, S, ct.dcum + (size_t)cloud * ct.dstride + 2 * ct.k);
-            ct.q[(size_t)cloud * n_full + qi[q]] = bq;
-            if (bq > T(0)) qmin = min_t(qmin, bq);          // (uncertifiable queries are searched on their own every iteration: they do not hold the unit)
-        }
+            // no certificate: -(k + 2) says "searched at iteration k" -- spent for every later iteration, not searched twice in this one
+            ct.q[(size_t)cloud * n_full + qi[q]] = bq > T(0) ? bq : cert_mark<T>(ct.k);
+            if (bq > T(0)) qmin = min_t(qmin, bq); else ++nunc;
+        } else if (ct.q) ct.q[(size_t)cloud * n_full + qi[q]] = cert_mark<T>(ct.k);      // plain search of a unit inside a certified loop
     }
     if (CERT) {
+        // the unit's filter value: its smallest budget -- or 0 ("look at me every iteration") when more queries than the accumulate
+        // should search one by one have no certificate at all
         qmin = wave_min(qmin);
-        if (lane == 0) ct.qu[(size_t)cloud * ((n_full + WAVE * Q - 1) / (WAVE * Q)) + unit] = qmin;
+        int tot = 0;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) tot += __popcll(__ballot(nunc > q));
+        if (lane == 0) ct.qu[(size_t)cloud * ((n_full + WAVE * Q - 1) / (WAVE * Q)) + unit] = tot > CERT_SLOT_MAX ? T(0) : qmin;
     }
     // sharded: one counter serialises ~12 ns per add, which at 65k waves would outlast the kernel itself
     if (pairs && lane == 0 && !idle_wave)
@@ -1267,30 +1278,46 @@ __global__ __launch_bounds__(BLOCK, DICP_SWEEP_MINW) void knn_sweep_guard_kernel
     const int unit = blk * (BLOCK / WAVE) + wave, units = (n_full + WAVE * Q - 1) / (WAVE * Q);
     const int n = rows_of(src_rows, cloud, n_full);
     if (unit * (WAVE * Q) >= n) return;
-    const T spent = cert_spent(ct.dcum + (size_t)cloud * ct.dstride + 2 * ct.k);
+    const T* dk = ct.dcum + (size_t)cloud * ct.dstride + 2 * ct.k;
+    const T spent = cert_spent(dk);
+    const T step = ct.k > 0 ? dk[0] - dk[-2] : inf_v<T>();     // how far the cloud's queries can have moved in the last step
     T* qu = ct.qu + (size_t)cloud * units + unit;
-    if (*qu > spent) return;
-    int bad = 0;
-    T qmin = inf_v<T>();
+    const T v = *qu;
+    bool plain;
+    if (v < T(0)) plain = step > -v;                            // plain mode (below): certify again once the steps are at most -v
+    else {
+        if (v > spent) return;
+        int bad = 0, live = 0;
+        T qmin = inf_v<T>();
 #pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        const int pos = unit * (WAVE * Q) + q * WAVE + lane;
-        if (pos < n) {
-            const T b = ct.q[(size_t)cloud * n_full + qorder[(size_t)cloud * n_full + pos]];
-            if (b > spent) qmin = min_t(qmin, b); else if (b > T(0)) ++bad;        // (b <= 0: never certifiable, searched on its own every iteration)
+        for (int q = 0; q < Q; ++q) {
+            const int pos = unit * (WAVE * Q) + q * WAVE + lane;
+            if (pos < n) {
+                const T b = ct.q[(size_t)cloud * n_full + qorder[(size_t)cloud * n_full + pos]];
+                ++live;
+                if (b > spent) qmin = min_t(qmin, b); else ++bad;
+            }
         }
-    }
-    int nbad = 0;
+        int nbad = 0, nlive = 0;
 #pragma unroll
-    for (int q = 0; q <= Q; ++q) nbad += __popcll(__ballot(bad > q));
-    if (nbad > CERT_SLOT_MAX) {
-        if (lane == 0 && ct.count) atomicAdd(ct.count + (blockIdx.x & (CERT_SHARDS - 1)), 1);
-        sweep_unit<T, Q, CH, true>(src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, idx, spos, pairs, n_full, m_full, m_pad, src_sorted, src_rows, tgt_rows, ct,
-                                   cloud, unit, tiles[wave]);
-    } else {
-        qmin = wave_min(qmin);
-        if (lane == 0) *qu = qmin;
+        for (int q = 0; q < Q; ++q) { nbad += __popcll(__ballot(bad > q)); nlive += __popcll(__ballot(live > q)); }
+        if (nbad <= CERT_SLOT_MAX) {                            // the few spent ones are left to the accumulate
+            qmin = wave_min(qmin);
+            if (lane == 0) *qu = qmin;
+            return;
+        }
+        // three quarters of the last search's budgets did not survive one step, and the steps are not shrinking fast (less than halved
+        // since the one before): certifying this unit is wasted work while the cloud moves like this.  It is searched plainly (cheaper,
+        // no budgets) until the steps have halved.
+        const T step_before = ct.k > 1 ? dk[-2] - dk[-4] : inf_v<T>();
+        plain = 4 * nbad >= 3 * nlive && step > T(0) && step < inf_v<T>() && T(2) * step > step_before;
+        if (plain && lane == 0) *qu = -T(0.5) * step;
     }
+    if (lane == 0 && ct.count) atomicAdd(ct.count + (blockIdx.x & (CERT_SHARDS - 1)), 1);
+    if (plain) sweep_unit<T, Q, CH, false>(src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, idx, spos, pairs, n_full, m_full, m_pad, src_sorted, src_rows, tgt_rows, ct,
+                                           cloud, unit, tiles[wave]);
+    else       sweep_unit<T, Q, CH, true>(src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, idx, spos, pairs, n_full, m_full, m_pad, src_sorted, src_rows, tgt_rows, ct,
+                                          cloud, unit, tiles[wave]);
 }
 #undef DICP_SWEEP_PARAMS
 
@@ -1515,7 +1542,7 @@ __device__ __forceinline__ void block_reduce_store(T* v, T* __restrict__ out, T*
 // match is read, a spent one is searched on the spot by the whole wave (search_point), and the matches are handed on to the next
 // iteration's buffer.
 template <typename T, int MODE, bool CERT = false>
-__global__ __launch_bounds__(BLOCK, (CERT && sizeof(T) == 4) ? 6 : 1) void accumulate_kernel(WeightParams P, const T* __restrict__ src, const T* __restrict__ tgt, int c /* elements per row of tgt */,
+__global__ __launch_bounds__(BLOCK, (CERT && sizeof(T) == 4) ? 5 : 1) void accumulate_kernel(WeightParams P, const T* __restrict__ src, const T* __restrict__ tgt, int c /* elements per row of tgt */,
                                                            const int32_t* __restrict__ idx, const T* __restrict__ pose,
                                                            const T* __restrict__ w_init, const T* __restrict__ alive,
                                                            int N, int n, int m, int bpc, T* __restrict__ partials,
@@ -1539,7 +1566,7 @@ __global__ __launch_bounds__(BLOCK, (CERT && sizeof(T) == 4) ? 6 : 1) void accum
         }
 #pragma unroll 1
         for (int t = 0; t < ROUNDS; ++t) {
-            const bool redo = !(b[t] > spent);                  // (NaN, -1: searched every iteration)
+            const bool redo = !(b[t] > spent) && b[t] != cert_mark<T>(ps.ct.k);     // (spent, never certifiable, NaN -- unless this iteration's guard launch just searched it)
             unsigned long long todo = __ballot(redo);
             if (!todo) continue;                                // (wave-uniform; the common case)
             const size_t pt = (size_t)cloud * n + min(blk * ACC_PTS + t * BLOCK + (int)threadIdx.x, n - 1);
@@ -1654,7 +1681,9 @@ __device__ __forceinline__ void step_body(const dicp_step_io& io, int cloud, int
             T* dc = (T*)io.dcum + (size_t)cloud * io.dcum_stride + 2 * io.iter;
             const T nxt = (T)((double)dc[0] + (sqrt(dC) * rm + sqrt(dr)) * 1.0001);
             dc[2] = nxt + m_abs(nxt) * (T)(4.0 * ulp);                    // (rounded up)
-            dc[3] = (T)(16.0 * ulp * (rm + sqrt(rn) + 1.0) * 1.0001);
+            double cn = 0.0;                                              // (the search subtracts the centre from r)
+            if (io.center) { const T* ct = (const T*)io.center + (size_t)cloud * 3; cn = sqrt((double)ct[0] * ct[0] + (double)ct[1] * ct[1] + (double)ct[2] * ct[2]); }
+            dc[3] = (T)(16.0 * ulp * (rm + sqrt(rn) + cn + 1.0) * 1.0001);
         }
         if (io.pose_search_out) {                                         // what the next search reads: [C | r - centre]
             T* ps = (T*)io.pose_search_out + (size_t)cloud * 12;

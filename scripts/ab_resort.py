@@ -3,7 +3,7 @@ import os, sys, time, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 from dicp_amd.ICP import ICP
 from dicp_amd.synthetic import make_pairs
-B, n = 256, 16384
+B, n = 64, 16384
 src, tgt = make_pairs(B, n, n, seed=3)
 src, tgt = src.cuda(), tgt.cuda()
 T0 = torch.eye(4, device="cuda").repeat(B, 1, 1)
@@ -19,4 +19,4 @@ def bench(resort, K):
     return sorted(ts)[4] * 1e3
 for rnd in range(2):
     for K in (10, 20):
-        print("K=%d " % K + "  ".join("%s: %.3f ms" % (r, bench(r, K)) for r in ((0, 1, 2, 3), (0, 1, 2, 4), (0, 1, 2, 3, 5), (0, 1, 2, 3, 6), (0, 1, 2, 4, 8), (0, 1, 2, 3, 4))), flush=True)
+        print("K=%d " % K + "  ".join("%s: %.3f ms" % (r, bench(r, K)) for r in ((0, 1, 2, 3), (0, 1, 2), (0, 1), (0, 2), (0, 1, 2, 3, 4))), flush=True)

@@ -4,8 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dicp_amd.ICP import ICP
 from dicp_amd.synthetic import make_pairs
-B, n, K = 64, 16384, int(sys.argv[1]) if len(sys.argv) > 1 else 10
-src, tgt = make_pairs(B, n, n, seed=0)
+B, n, K = int(sys.argv[2]) if len(sys.argv) > 2 else 64, 16384, int(sys.argv[1]) if len(sys.argv) > 1 else 10
+src, tgt = make_pairs(B, n, n, seed=3)
 src, tgt = src.cuda(), tgt.cuda()
 icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12); icp.const_iter = True
 out = icp.icp(src.requires_grad_(True), tgt, torch.eye(4).cuda().repeat(B, 1, 1), trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0})

@@ -210,3 +210,59 @@ def test_match_certificates_change_no_result(dtype, N, n, const_iter, ragged):
     np.testing.assert_allclose(npy(b[2]), npy(a[2]), rtol=0, atol=1e-6 * max(1.0, float(a[2].abs().max())))
     if const_iter:
         assert b[3] < 0.8 * a[3], (a[3], b[3])              # 9 iterations: the early ones dominate the pairs; the last five search (almost) nothing
+
+
+def _cert_case(case, dtype):
+    """Inputs that stress the certificate machinery: (source, target, K)."""
+    N, n = 36, 16384                    # (N * n above the size from which the loop keeps certificates)
+    if case == "near_duplicates":
+        # every target twice, the copy 0.1 mm away: each query has two candidates whose distances differ by less than the rounding bound
+        # of a float32 score -- never certifiable, so every certified iteration searches (almost) every query again
+        src, tgt = make_pairs(N, n, n // 2, seed=24, dtype=torch.float64)
+        g = torch.Generator().manual_seed(11)
+        twin = tgt.clone()
+        twin[:, :, :3] += 1e-4 * torch.randn((N, n // 2, 3), generator=g, dtype=torch.float64)
+        return src.to(dtype), torch.cat([tgt, twin], dim=1).to(dtype), 8
+    if case == "slow_convergence":      # far from the pose: big steps for many iterations, budgets are spent again and again
+        src, tgt = make_pairs(N, n, n, seed=21, dtype=dtype, max_rot=0.35, max_trans=2.0)
+        return src, tgt, 12
+    if case == "far_from_origin":       # map-frame coordinates: the rounding of a transformed point is centimetres in float32
+        src, tgt = make_pairs(N, n, n, seed=22, dtype=torch.float64)
+        off = torch.tensor([2000.0, -1500.0, 300.0], dtype=torch.float64)
+        src = src + off
+        tgt[:, :, :3] += off
+        return src.to(dtype), tgt.to(dtype), 9
+    if case == "duplicated_targets":    # every target row twice: exact ties, decided by the lowest original index in every search form
+        src, tgt = make_pairs(N, n, n // 2, seed=23, dtype=dtype)
+        return src, torch.cat([tgt, tgt], dim=1), 9
+    raise AssertionError(case)
+
+
+@pytest.mark.parametrize("case,dtype", [("near_duplicates", torch.float32), ("slow_convergence", torch.float32), ("far_from_origin", torch.float32),
+                                        ("duplicated_targets", torch.float32), ("near_duplicates", torch.float64), ("far_from_origin", torch.float64)])
+def test_match_certificates_hold_on_hard_inputs(case, dtype):
+    """The certificates are proofs, not heuristics: on inputs built to break them (near-ties everywhere, exact ties, poses that keep
+    moving, coordinates whose float32 rounding is centimetres) the certified loop still returns, bit for bit, what searching
+    every query in every iteration returns."""
+    src, tgt, K = _cert_case(case, dtype)
+    N = src.shape[0]
+    outs = {}
+    for reuse in (False, True):
+        icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
+        icp.const_iter = True
+        icp.reuse_matches = reuse
+        icp.knn_variant = _lib.KNN_SWEEP
+        S, Tg = src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True)
+        out = icp.icp(S, Tg, torch.eye(4, dtype=dtype, device=DEV).repeat(N, 1, 1), **KW)
+        out["T"].sum().backward()
+        outs[reuse] = (out, S.grad, Tg.grad, icp.knn_stats)
+    a, b = outs[False], outs[True]
+    assert "searched_again" in b[3] and "searched_again" not in a[3]
+    for key in ("T", "deltas", "weights", "costs", "pc"):
+        assert torch.equal(a[0][key], b[0][key]), (case, key)
+    # (the backward adds in its own order, and its far-match atomics in no fixed order: sums of ~1e4 terms of the size of the coordinates)
+    gtol = (3e-5 if case == "far_from_origin" else 2e-6) if dtype == torch.float32 else 1e-12
+    for ga, gb in ((a[1], b[1]), (a[2], b[2])):
+        np.testing.assert_allclose(npy(gb), npy(ga), rtol=0, atol=gtol * max(1.0, float(ga.abs().max())))
+    cnt = b[3]["searched_again"]
+    assert int(cnt.sum()) > 0, "no query was ever searched again: the case does not exercise the certified iterations"

@@ -290,6 +290,14 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
         brute = True
     # pairs scored per kNN launch of the LAST timed call (each call has its own counters)
     pairs_scored = None if brute else float(icp.knn_stats["knn_pairs"].sum().item()) / K
+    again = icp.knn_stats.get("searched_again") if not brute else None     # (K,128) int32: units [0,64) / single queries [64,128) searched again
+    certified = None
+    if again is not None:
+        certified = {"units_searched_again": [int(v) for v in again[:K, :64].sum(1).tolist()], "queries_searched_again": [int(v) for v in again[:K, 64:].sum(1).tolist()],
+                     "units": B * ((n + 127) // 128), "queries": B * n,
+                     "note": "match certificates: from the last re-ordering of the queries on (0, 0 = every query searched) a launch searches only the "
+                             "units, and the accumulate only the single queries, whose match is not PROVEN unchanged; results identical to searching "
+                             "everything (tests/test_gpu_configs.py)"}
 
     # ---- the brute-force floor and the tolerance-mode call, in the same run (median of their own timed calls)
     extra = {}
@@ -373,8 +381,10 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
                          "launch_ms_by_iteration": [round(v, 4) for v in knn_all],
                          "pairs_scored_fraction": None if (brute or pairs_scored is None) else pairs_scored / (float(n) * m * B),
                          "dense_equivalent_tflops": flops_bf / (knn_ms * 1e-3) / 1e12 if knn_ms else None,
-                         "note": "8 flop per SCORED (query,target) pair vs the f32 peak; the kernel is FP32-compute-bound, "
-                                 "its algorithmic HBM traffic is <1% of what HBM could move in its run time"},
+                         "certified_iterations": certified,
+                         "note": "8 flop per SCORED (query,target) pair vs the f32 peak, over ALL K search launches of a call (the certified iterations' "
+                                 "guard launches included; the rows their single-query searches score inside the accumulate launch are in the pair count, "
+                                 "<0.2 % of it); the kernel is FP32-compute-bound, its algorithmic HBM traffic is <1% of what HBM could move in its run time"},
             "roofline_bruteforce_knn": {"kernel": "knn_%s_kernel (all n*m pairs)" % ("mfma" if args.knn == "mfma" else "valu"), "bound": "mfma",
                                         "achieved": flops_bf / (bf_ms * 1e-3) / 1e12 if bf_ms else None, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                         "frac": flops_bf / (bf_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS if bf_ms else None, "traffic": bf_traffic, "traffic_source": bf_src,

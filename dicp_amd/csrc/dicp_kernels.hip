@@ -899,10 +899,13 @@ constexpr int CERT_SHARDS = 64;
 constexpr int CERT_SLOT_MAX = 16;   // a unit with more spent budgets than this is searched again as a unit (guard launch), the others' queries one by one
 
 template <typename T>
-__device__ __forceinline__ T cert_budget(T A, T S, const T* __restrict__ dk /* (M_k, e_k) */) {
+__device__ __forceinline__ T cert_budget(T A, T S, T H1, T hx, const T* __restrict__ dk /* (M_k, e_k) */) {
     if (!(A > T(0))) return T(-1);
-    if (!(S > T(0)) || !(A < inf_v<T>())) return inf_v<T>();    // no other target at all
-    return (A / S + dk[0]) * (T(1) - T(8) * CertUlp<T>::v) - dk[1] * (T(1) + T(8) * CertUlp<T>::v);
+    // how far the query may move: A / S, and never further than a fifth of max(d1, |x|, 1) -- the margin 3E in A covers the rounding of
+    // the scores AFTER the move only while 0.5 |x|^2 and the match's distance have not grown past 1.8x (or stay below the constant in E)
+    const T cap = T(0.2) * max_t(max_t(m_sqrt(T(2) * H1), m_sqrt(T(2) * hx)), T(1));
+    const T slack = (S > T(0) && A < inf_v<T>()) ? min_t(A / S, cap) : cap;
+    return (slack + dk[0]) * (T(1) - T(8) * CertUlp<T>::v) - dk[1] * (T(1) + T(8) * CertUlp<T>::v);
 }
 // "no certificate, searched at iteration k": never above cert_spent(), and told apart from a budget that was spent before this iteration
 template <typename T> __device__ __forceinline__ T cert_mark(int k) { return T(-(k + 2)); }
@@ -1124,11 +1127,12 @@ __device__ __forceinline__ void sweep_unit(const T* __restrict__ src, const T* _
         // sorted position of the winner (indexed like idx, by the query): what the windowed backward consumes
         if (spos) spos[(size_t)cloud * n_full + qi[q]] = (bo == 0x7fffffff || bo >= m) ? -1 : bs;
         if (CERT) {
-            T A = T(-1), S = T(0);
+            T A = T(-1), S = T(0), H1c = T(0);
             if (bo != 0x7fffffff && ob[q] != best[q]) {     // (three or more tied chunks: no certificate)
                 const T eps = SweepEps<T>::v;
                 const T E1 = eps * (T(1) + m_abs(bv) + hx[q]);
                 const T H1 = max_t((bv + hx[q]) + E1, T(0));
+                H1c = H1;
                 const T s2 = min_t(sec[q], rv);             // runner-up among the scored rows: other chunks, and the winner's own
                 T H2 = s2 < inf_v<T>() ? (s2 + hx[q]) - eps * (T(1) + m_abs(s2) + hx[q]) : inf_v<T>();
                 if (cutR) { const T dx = edgeR - xq[q]; H2 = min_t(H2, dx > T(0) ? T(0.5) * dx * dx * (T(1) - T(8) * eps) : T(0)); }
@@ -1136,7 +1140,7 @@ __device__ __forceinline__ void sweep_unit(const T* __restrict__ src, const T* _
                 if (H2 < inf_v<T>()) { A = (H2 - H1) - T(3) * E1; S = m_sqrt(T(2) * H1) + m_sqrt(T(2) * max_t(H2, T(0))); }
                 else                 { A = inf_v<T>(); S = T(0); }      // no other target at all
             }
-            const T bq = cert_budget(A, S, ct.dcum + (size_t)cloud * ct.dstride + 2 * ct.k);
+            const T bq = cert_budget(A, S, H1c, hx[q], ct.dcum + (size_t)cloud * ct.dstride + 2 * ct.k);
             // no certificate: -(k + 2) says "searched at iteration k" -- spent for every later iteration, not searched twice in this one
             ct.q[(size_t)cloud * n_full + qi[q]] = bq > T(0) ? bq : cert_mark<T>(ct.k);
             if (bq > T(0)) qmin = min_t(qmin, bq); else ++nunc;
@@ -1256,7 +1260,7 @@ __device__ __forceinline__ int search_point(const PointSearch<T>& ps, const int 
         H2 = min_t(H2, h_edge);
         T A = inf_v<T>(), S = T(0);
         if (H2 < inf_v<T>()) { A = (H2 - H1) - T(3) * E1; S = m_sqrt(T(2) * H1) + m_sqrt(T(2) * max_t(H2, T(0))); }
-        budget = cert_budget(A, S, ps.ct.dcum + (size_t)cloud * ps.ct.dstride + 2 * ps.ct.k);
+        budget = cert_budget(A, S, H1, hx, ps.ct.dcum + (size_t)cloud * ps.ct.dstride + 2 * ps.ct.k);
     }
     if (lane == 0) {
         if (ps.pairs) atomicAdd(ps.pairs + (blockIdx.x & (DICP_PAIR_SHARDS - 1)), (unsigned long long)(r1 - r0));

@@ -25,7 +25,7 @@ def short(n):
 
 
 # the timed call = everything after the last big idle gap that precedes the last 10 kNN launches
-knn = [i for i, r in enumerate(rows) if "knn_sweep_kernel" in r["Kernel_Name"] or "knn_valu_kernel" in r["Kernel_Name"] or "knn_scan" in r["Kernel_Name"]]
+knn = [i for i, r in enumerate(rows) if "knn_sweep" in r["Kernel_Name"] or "knn_valu_kernel" in r["Kernel_Name"] or "knn_scan" in r["Kernel_Name"]]
 first = knn[-13] if len(knn) >= 13 else knn[0]      # 10 timed launches + 3 brute-force launches of the roofline leg after them
 # the call starts a few dozen small set-up kernels before its first kNN launch: walk back until the idle gap that
 # separates it from the previous (untimed, synchronised) call

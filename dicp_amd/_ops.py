@@ -517,23 +517,23 @@ class ICPLoop(torch.autograd.Function):
             matched = arena.take((N,), dt)
             n_matched = arena.take((N,), dt)
             counters = arena.take((Kmax,), torch.int32)
-            # match certificates (sweep path, the big-problem launch configuration): per-slot certificates, per-unit bookkeeping, per-cloud motion
-            # bounds, the per-iteration list of units to search again
+            # match certificates (sweep path): a motion budget per query, a filter value per unit of the sweep, per-cloud motion bounds, and
+            # what each iteration searched again.  The searches before the LAST re-ordering of the queries run plain (a certifying search costs
+            # a quarter more, and its budgets would not survive the steps of the first iterations).
             keep_idx = sweep is None or (need_grad and not owned)     # (original indices: the brute-force searches and the atomic backward)
-            want_certs = (sweep is not None and cfg.reuse_matches and float(N) * n >= 2.0 * 256 * 1024 and not (cfg.knn_variant & 0xff00) and not keep_idx
-                          and N * n < 2 ** 31)
+            # (the one certifying search costs a quarter more than a plain one: it takes three certified iterations to be worth it)
+            resorts = [k for k in cfg.sweep_resort if 0 <= k < Kmax]
+            cert_from = max(resorts) if resorts else 0
+            want_certs = (sweep is not None and cfg.reuse_matches and not (cfg.knn_variant & 0xff00) and not keep_idx
+                          and Kmax - 1 - cert_from >= 3)
             arena.take((Kmax, 128) if want_certs else (0,), torch.int32)
             deltas, costs, converged, iterations, matched, n_matched, counters, cert_count = arena.finish()
             # pose_0, alive_0, n_start (ICP.py:124-129)
             certs = None
             if want_certs:
-                units = (n + 127) // 128
+                units = (n + 63) // 64          # (units of the sweep's one-query-per-lane forms; the two-query form uses half of them)
                 certs = dict(q=torch.empty((N, n), dtype=dt, device=dev), qu=torch.empty((N, units), dtype=dt, device=dev), count=cert_count,
                              rmax=torch.empty((N,), dtype=dt, device=dev), dcum=torch.empty((N, 2 * (Kmax + 1)), dtype=dt, device=dev))
-                # the searches before the LAST re-ordering of the queries leave no certificate a later iteration could use (they are kept by
-                # slot of the order): those iterations run the plain search, which is ~25 % cheaper than the certifying one
-                resorts = [k for k in cfg.sweep_resort if 0 <= k < Kmax]
-                cert_from = max(resorts) if resorts else 0
             _lib.check(lib.dicp_loop_init(code, _p(T_init.contiguous()), _p(w0c), float(cfg.match_ratio_thresh), rows, N, n,
                                           _p(poses), _p(alive), _p(n_start), _p(center), _p(poses_c),
                                           _p(src) if certs else None, _p(certs["rmax"]) if certs else None, _p(certs["dcum"]) if certs else None, 2 * (Kmax + 1), st),

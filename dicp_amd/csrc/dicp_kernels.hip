@@ -3019,16 +3019,17 @@ static int sweep_launch(int dtype, const void* src, const void* pose, const void
 #define DICP_SWEEP_ARGS(T) (const T*)src, (const T*)pose, (const typename V4<T>::type*)tgs4, tperm, qorder, bucket, (const T*)brange, nbkt, idx, spos, pairs, \
         N, n, m, m_pad, bpc, src_sorted, rw.src, rw.tgt
 #define DICP_SWEEP_C(T, Q, CH, CERT, CT) hipExtLaunchKernelGGL((knn_sweep_kernel<T, Q, CH, CERT>), dim3(grid_for(N, bpc)), dim3(BLOCK), 0, st, ev0, ev1, 0, DICP_SWEEP_ARGS(T), CT)
-#define DICP_SWEEP_L(T, CT) hipExtLaunchKernelGGL((knn_sweep_guard_kernel<T, 2, 8>), dim3(grid_for(N, bpc)), dim3(BLOCK), 0, st, ev0, ev1, 0, DICP_SWEEP_ARGS(T), CT)
+#define DICP_SWEEP_L(T, Q, CH, CT) hipExtLaunchKernelGGL((knn_sweep_guard_kernel<T, Q, CH>), dim3(grid_for(N, bpc)), dim3(BLOCK), 0, st, ev0, ev1, 0, DICP_SWEEP_ARGS(T), CT)
+#define DICP_SWEEP_CG(T, Q, CH, CT) do { if (ca.guard) DICP_SWEEP_L(T, Q, CH, CT); else DICP_SWEEP_C(T, Q, CH, true, CT); } while (0)
 #define DICP_SWEEP(T, Q, CH) do { SweepCert<T> none{}; DICP_SWEEP_C(T, Q, CH, false, none); } while (0)
-    if (ca.q) {             // certifying search (the configuration the loop uses for big problems: 2 queries per lane, 8-row chunks)
-        if (cfg != 2 || !ca.qu || !ca.dcum || !spos || !qorder) return DICP_ERR_ENUM;
+    if (ca.q) {             // certifying search, or the guard launch of a certified iteration
+        if (!ca.qu || !ca.dcum || !spos || !qorder) return DICP_ERR_ENUM;
         if (dtype == DICP_F32) {
             SweepCert<float> c{(float*)ca.q, (float*)ca.qu, (const float*)ca.dcum, ca.dstride, ca.k, ca.count};
-            if (ca.guard) DICP_SWEEP_L(float, c); else DICP_SWEEP_C(float, 2, 8, true, c);
+            if (cfg == 2) DICP_SWEEP_CG(float, 2, 8, c); else if (cfg == 4) DICP_SWEEP_CG(float, 1, 16, c); else DICP_SWEEP_CG(float, 1, 8, c);
         } else {
             SweepCert<double> c{(double*)ca.q, (double*)ca.qu, (const double*)ca.dcum, ca.dstride, ca.k, ca.count};
-            if (ca.guard) DICP_SWEEP_L(double, c); else DICP_SWEEP_C(double, 2, 8, true, c);
+            if (cfg == 2) DICP_SWEEP_CG(double, 2, 8, c); else DICP_SWEEP_CG(double, 1, 8, c);
         }
         return launch_status();
     }
@@ -3040,6 +3041,7 @@ static int sweep_launch(int dtype, const void* src, const void* pose, const void
 #undef DICP_SWEEP
 #undef DICP_SWEEP_C
 #undef DICP_SWEEP_L
+#undef DICP_SWEEP_CG
 #undef DICP_SWEEP_ARGS
     return launch_status();
 }
@@ -3447,7 +3449,7 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
             if (B->src_s && B->qorder) { qsrc = B->src_s; cfg |= DICP_SWEEP_SRC_SORTED; }
             // match certificates: only the units holding a query whose match is not proven unchanged are searched again
             const int cfg_plain = (cfg & ~DICP_SWEEP_SRC_SORTED) ? (cfg & ~DICP_SWEEP_SRC_SORTED) : sweep_auto_cfg(N, n);
-            const bool cert = B->cert_q && B->cert_qu && B->rmax && B->dcum && spos_k && sorted_rows && !B->idx && B->qorder && cfg_plain == 2;
+            const bool cert = B->cert_q && B->cert_qu && B->rmax && B->dcum && spos_k && sorted_rows && !B->idx && B->qorder && sweep_queries_per_lane(cfg_plain) > 0;
             const bool fresh = k == 0 || (k == k0 && B->cert_reset);           // a new query order: every query is searched, every budget written
             int32_t* count_k = B->cert_count ? B->cert_count + (size_t)k * 2 * CERT_SHARDS : nullptr;
             if (cert) {

@@ -259,7 +259,7 @@ typedef struct dicp_loop_buffers {
                                 of a query order searches every query and writes its budget; a later one searches only the queries whose match is
                                 not PROVEN unchanged -- whole units in a guard launch where many are, the others inside dicp_accumulate's launch
                                 (exact: same indices as a full search).  Needs spos (and no idx), tgt_sorted, qorder, cert_qu, rmax, dcum */
-    void* cert_qu;           /* (N, ceil(n/128)) T scratch */
+    void* cert_qu;           /* (N, ceil(n/64)) T scratch */
     int32_t* cert_count;     /* optional (K,128) zeros: per iteration, units searched again [0,64) and single queries [64,128), sharded by block */
     void* rmax;              /* (N) T from dicp_loop_init */
     void* dcum;              /* (N, 2(K+1)) T: per iteration (motion bound since iteration 0, rounding of a transformed point); dicp_loop_init

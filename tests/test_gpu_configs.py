@@ -176,7 +176,9 @@ def test_config3_full_batch_256(monkeypatch):
 
 
 @pytest.mark.parametrize("dtype,N,n,const_iter,ragged", [(torch.float32, 40, 16384, True, False), (torch.float32, 160, 4096, False, False),
-                                                         (torch.float64, 36, 16384, True, False), (torch.float32, 48, 16384, True, True)])
+                                                         (torch.float64, 36, 16384, True, False), (torch.float32, 48, 16384, True, True),
+                                                         (torch.float32, 32, 4096, True, False), (torch.float64, 24, 4096, True, False),   # one query per lane
+                                                         (torch.float32, 32, 4096, False, True)])
 def test_match_certificates_change_no_result(dtype, N, n, const_iter, ragged):
     """Temporal coherence, exact: with certificates an iteration searches only the waves that hold a query whose match is
     not PROVEN unchanged since the wave's last search.  Every result -- poses, per-iteration weights (i.e. every match of

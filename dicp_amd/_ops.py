@@ -393,6 +393,7 @@ class LoopConfig:
     timing_events: object = None  # optional object with .handles(K) -> ctypes array of 4*K hipEvent_t (bench.py)
     prebuilt: object = None       # (target, SweepIndex) started by the caller before its own host work (prebuild_search)
     small_loop: bool = True       # small clouds: one block runs a cloud's whole chunk of iterations (icp_small_* kernels)
+    cert_from: object = None      # iteration of the certifying search (None: the last re-ordering of the queries)
     reuse_matches: bool = True    # sweep path: match certificates -- an iteration searches only the waves holding a query whose match is not proven
                                   # unchanged since the wave's last search (exact; knn_sweep_kernel CERT)
     src_rows: object = None       # ragged batches: (N) int32 device tensors, rows of each source / target cloud that take part
@@ -523,7 +524,7 @@ class ICPLoop(torch.autograd.Function):
             keep_idx = sweep is None or (need_grad and not owned)     # (original indices: the brute-force searches and the atomic backward)
             # (the one certifying search costs a quarter more than a plain one: it takes three certified iterations to be worth it)
             resorts = [k for k in cfg.sweep_resort if 0 <= k < Kmax]
-            cert_from = max(resorts) if resorts else 0
+            cert_from = (max(resorts) if resorts else 0) if cfg.cert_from is None else max(0, int(cfg.cert_from))     # iteration of the certifying search
             want_certs = (sweep is not None and cfg.reuse_matches and not (cfg.knn_variant & 0xff00) and not keep_idx
                           and Kmax - 1 - cert_from >= 3)
             arena.take((Kmax, 128) if want_certs else (0,), torch.int32)
@@ -550,7 +551,7 @@ class ICPLoop(torch.autograd.Function):
             w_slabs, idx_slabs, spos_slabs = [], [], []
             cuts = list(range(0, Kmax, kc))
             if sweep is not None:
-                cuts += list(cfg.sweep_resort)
+                cuts += list(cfg.sweep_resort) + ([cert_from] if certs is not None else [])
             if not cfg.const_iter:
                 every = cfg.sync_every
                 if every is None:
@@ -601,7 +602,7 @@ class ICPLoop(torch.autograd.Function):
                     cert_q=_p(certs["q"]) if use_certs else None, cert_qu=_p(certs["qu"]) if use_certs else None,
                     cert_count=_p(certs["count"]) if use_certs else None,
                     rmax=_p(certs["rmax"]) if certs else None, dcum=_p(certs["dcum"]) if certs else None,
-                    cert_reset=int(new_order),
+                    cert_reset=int(k0 == cert_from),
                     spos_prev0=_p(spos_slabs[(k0 - 1) // kc][(k0 - 1) % kc]) if (keep_spos and k0 > 0) else None,
                     w=ctypes.c_void_p(w_slabs[j].data_ptr() - base * n * es), w_iter=n, w_stride=kc * n,
                     w_prev0=_p(w_slabs[(k0 - 1) // kc][:, (k0 - 1) % kc]) if k0 > 0 else None,

@@ -3,12 +3,12 @@ import os, sys, time, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 from dicp_amd.ICP import ICP
 from dicp_amd.synthetic import make_pairs
-B, n = 64, 16384
+B, n = 256, 16384
 src, tgt = make_pairs(B, n, n, seed=3)
 src, tgt = src.cuda(), tgt.cuda()
 T0 = torch.eye(4, device="cuda").repeat(B, 1, 1)
-def bench(resort, K):
-    icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12); icp.const_iter = True; icp.sweep_resort = resort
+def bench(resort, K, cert_from=None):
+    icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12); icp.const_iter = True; icp.sweep_resort = resort; icp.cert_from = cert_from
     def call():
         s, t = src.detach().requires_grad_(True), tgt.detach().requires_grad_(True)
         icp.icp(s, t, T0, trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0})["T"].sum().backward()
@@ -19,4 +19,4 @@ def bench(resort, K):
     return sorted(ts)[4] * 1e3
 for rnd in range(2):
     for K in (10, 20):
-        print("K=%d " % K + "  ".join("%s: %.3f ms" % (r, bench(r, K)) for r in ((0, 1, 2, 3), (0, 1, 2), (0, 1), (0, 2), (0, 1, 2, 3, 4))), flush=True)
+        print("K=%d " % K + "  ".join("%s/%s: %.3f ms" % (r, c, bench(r, K, c)) for r, c in (((0, 1, 2, 3), None), ((0, 1, 2), 3), ((0, 1, 2), 2), ((0, 1), 3), ((0, 1, 2, 3), 4), ((0, 1, 2, 4), 4))), flush=True)

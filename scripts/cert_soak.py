@@ -41,7 +41,6 @@ for c in range(cases):
             T0 = [torch.eye(4, dtype=dtype).cuda()] * N
         else:
             S, T, T0 = src.cuda().requires_grad_(True), tgt.cuda().requires_grad_(True), torch.eye(4, dtype=dtype).cuda().repeat(N, 1, 1)
-        out = icp.icp(S, T, T0, trim_dist=rng.choice([5.0, 5.0, 1.0]) if reuse is False else trim, loss_fn=loss) if False else None
         trim = 5.0
         out = icp.icp(S, T, T0, trim_dist=trim, loss_fn=loss)
         out["T"].sum().backward()
@@ -50,7 +49,7 @@ for c in range(cases):
     a, b = outs
     ok = all(torch.equal(a[0][k], b[0][k]) for k in ("T", "deltas", "weights", "costs", "pc")) and torch.equal(a[0]["stats"]["iterations"], b[0]["stats"]["iterations"])
     gtol = (1e-4 if dtype == torch.float32 else 1e-10) * max(1.0, float(a[1].abs().max()))
-    gok = bool(((a[1] - b[1]).abs() <= gtol).all())
+    gok = bool((((a[1] - b[1]).abs() <= gtol) | (torch.isnan(a[1]) & torch.isnan(b[1]))).all())      # (hard huber weights at a zero residual: NaN in the reference too)
     cnt = b[2].get("searched_again")
     used = "no certificates" if cnt is None else "units %d, queries %d searched again" % (int(cnt[:, :64].sum()), int(cnt[:, 64:].sum()))
     print("case %2d %s N=%d n=%d m=%d %s K=%d %s%s%s: %s, gradients %s (%s)" % (c, str(dtype)[6:], N, n, m, typ, K, "const" if const_iter else "tol", " ragged" if ragged else "",

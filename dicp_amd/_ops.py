@@ -534,7 +534,7 @@ class ICPLoop(torch.autograd.Function):
             if want_certs:
                 units = (n + 63) // 64          # (units of the sweep's one-query-per-lane forms; the two-query form uses half of them)
                 certs = dict(q=torch.empty((N, n), dtype=dt, device=dev), qu=torch.empty((N, units), dtype=dt, device=dev), count=cert_count,
-                             rmax=torch.empty((N,), dtype=dt, device=dev), dcum=torch.empty((N, 2 * (Kmax + 1)), dtype=dt, device=dev))
+                             rmax=torch.empty((N, 4), dtype=dt, device=dev), dcum=torch.empty((N, 2 * (Kmax + 1)), dtype=dt, device=dev))
             _lib.check(lib.dicp_loop_init(code, _p(T_init.contiguous()), _p(w0c), float(cfg.match_ratio_thresh), rows, N, n,
                                           _p(poses), _p(alive), _p(n_start), _p(center), _p(poses_c),
                                           _p(src) if certs else None, _p(certs["rmax"]) if certs else None, _p(certs["dcum"]) if certs else None, 2 * (Kmax + 1), st),

@@ -584,26 +584,48 @@ __global__ __launch_bounds__(BLOCK) void loop_init_kernel(const T* __restrict__ 
                                                           const T* __restrict__ center, T* __restrict__ pose_search0,
                                                           const T* __restrict__ src, T* __restrict__ rmax, T* __restrict__ dcum, int dstride) {
     __shared__ int cnt[BLOCK / WAVE];
-    __shared__ T rm[BLOCK / WAVE];
+    __shared__ T box[(BLOCK / WAVE) * 6];
     const int cloud = blockIdx.x, tid = threadIdx.x;
-    if (rmax) {     // largest |p| of the cloud: with it the step kernels bound how far ANY query moves between two poses (match certificates)
-        T r2 = T(0);
-        for (int i = tid; i < n; i += BLOCK) { const T* p = src + ((size_t)cloud * n + i) * 3; const T v = p[0] * p[0] + p[1] * p[1] + p[2] * p[2]; r2 = v > r2 ? v : r2; }
+    if (rmax) {     // bounding box of the cloud -> (radius, midpoint): with them the step kernels bound how far ANY query moves between two
+                    // poses (match certificates): dC p + dr = dC (p - p0) + (dC p0 + dr), so a cloud far from the origin costs nothing
+        T lo[3] = {inf_v<T>(), inf_v<T>(), inf_v<T>()}, hi[3] = {-inf_v<T>(), -inf_v<T>(), -inf_v<T>()};
+        for (int i = tid; i < n; i += BLOCK) {
+            const T* p = src + ((size_t)cloud * n + i) * 3;
 #pragma unroll
-        for (int off = WAVE / 2; off > 0; off >>= 1) { const T o = __shfl_down(r2, off); r2 = o > r2 ? o : r2; }
-        if ((tid & (WAVE - 1)) == 0) rm[tid >> 6] = r2;
+            for (int k = 0; k < 3; ++k) { const T v = p[k]; lo[k] = v < lo[k] ? v : lo[k]; hi[k] = v > hi[k] ? v : hi[k]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+#pragma unroll
+            for (int off = WAVE / 2; off > 0; off >>= 1) {
+                const T a = __shfl_down(lo[k], off), c = __shfl_down(hi[k], off);
+                lo[k] = a < lo[k] ? a : lo[k]; hi[k] = c > hi[k] ? c : hi[k];
+            }
+        }
+        if ((tid & (WAVE - 1)) == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { box[(tid >> 6) * 6 + k] = lo[k]; box[(tid >> 6) * 6 + 3 + k] = hi[k]; }
+        }
         __syncthreads();
         if (tid == 0) {
-            T v = rm[0];
-            for (int w = 1; w < BLOCK / WAVE; ++w) v = rm[w] > v ? rm[w] : v;
-            const T rm0 = (v == v) ? m_sqrt(v) : inf_v<T>();
-            rmax[cloud] = rm0;
-            // (M_0, e_0): no motion yet; e_k = rounding of a transformed point C p + r under pose k
+            T d2 = T(0), p0[3], pn = T(0);
+            for (int k = 0; k < 3; ++k) {
+                T l = box[k], h = box[3 + k];
+                for (int w = 1; w < BLOCK / WAVE; ++w) { l = box[w * 6 + k] < l ? box[w * 6 + k] : l; h = box[w * 6 + 3 + k] > h ? box[w * 6 + 3 + k] : h; }
+                p0[k] = T(0.5) * (l + h);
+                d2 += (h - l) * (h - l);
+                pn += p0[k] * p0[k];
+            }
+            // (an empty or non-finite cloud: radius inf or NaN -> nothing is ever certified)
+            const T rad = T(0.5) * m_sqrt(d2) * (T(1) + T(8) * CertUlp<T>::v) + T(8) * CertUlp<T>::v * m_sqrt(pn);
+            T* ro = rmax + (size_t)cloud * 4;
+            ro[0] = rad; ro[1] = p0[0]; ro[2] = p0[1]; ro[3] = p0[2];
+            // (M_0, e_0): no motion yet; e_k = rounding of a transformed point C p + (r - centre) under pose k
             const T* Ti = T_init + (size_t)cloud * 16;
             dcum[(size_t)cloud * dstride] = T(0);
             const T* ct = center ? center + (size_t)cloud * 3 : nullptr;
-            const T cn = ct ? m_sqrt(ct[0] * ct[0] + ct[1] * ct[1] + ct[2] * ct[2]) : T(0);     // (the search subtracts the centre from r)
-            dcum[(size_t)cloud * dstride + 1] = T(16) * CertUlp<T>::v * (rm0 + m_sqrt(Ti[3] * Ti[3] + Ti[7] * Ti[7] + Ti[11] * Ti[11]) + cn + T(1));
+            const T cn = ct ? m_sqrt(ct[0] * ct[0] + ct[1] * ct[1] + ct[2] * ct[2]) : T(0);
+            dcum[(size_t)cloud * dstride + 1] = T(8) * CertUlp<T>::v * (m_sqrt(pn) + rad + m_sqrt(Ti[3] * Ti[3] + Ti[7] * Ti[7] + Ti[11] * Ti[11]) + cn + T(1));
         }
     }
     int k = 0;
@@ -1676,18 +1698,25 @@ __device__ __forceinline__ void step_body(const dicp_step_io& io, int cloud, int
                 pout[i * 3 + j] = (T)(R[0 * 3 + i] * C[0 * 3 + j] + R[1 * 3 + i] * C[1 * 3 + j] + R[2 * 3 + i] * C[2 * 3 + j]);
         for (int k = 0; k < 3; ++k) pout[9 + k] = (T)(spose[9 + k] - d6[3 + k]);
         if (io.dcum) {      // match certificates: (M, e) of the new pose.  M += how far a query of this cloud can have moved between the two
-                            // poses, |dC|_F max|p| + |dr|, rounded up; e = the rounding of a point transformed with the new pose
-            double dC = 0.0, dr = 0.0, rn = 0.0;
-            for (int k = 0; k < 9; ++k) { const double d = (double)pout[k] - spose[k]; dC += d * d; }
-            for (int k = 0; k < 3; ++k) { const double d = (double)pout[9 + k] - spose[9 + k]; dr += d * d; rn += (double)pout[9 + k] * (double)pout[9 + k]; }
-            const double rm = (double)((const T*)io.rmax)[cloud];
+                            // poses: dC p + dr = dC (p - p0) + (dC p0 + dr) <= |dC|_F radius + |dC p0 + dr|, rounded up (radius, p0: the cloud's
+                            // bounding box from dicp_loop_init); e = the rounding of a point transformed with the new pose
+            const T* box = (const T*)io.rmax + (size_t)cloud * 4;
+            const double rad = (double)box[0], p0[3] = {(double)box[1], (double)box[2], (double)box[3]};
+            double dC = 0.0, mv = 0.0, rn = 0.0;
+            for (int i = 0; i < 3; ++i) {
+                double m = (double)pout[9 + i] - spose[9 + i];
+                for (int j = 0; j < 3; ++j) { const double d = (double)pout[i * 3 + j] - spose[i * 3 + j]; dC += d * d; m += d * p0[j]; }
+                mv += m * m;
+                rn += (double)pout[9 + i] * (double)pout[9 + i];
+            }
             const double ulp = sizeof(T) == 4 ? 1.2e-7 : 2.3e-16;
             T* dc = (T*)io.dcum + (size_t)cloud * io.dcum_stride + 2 * io.iter;
-            const T nxt = (T)((double)dc[0] + (sqrt(dC) * rm + sqrt(dr)) * 1.0001);
+            const T nxt = (T)((double)dc[0] + (sqrt(dC) * rad + sqrt(mv)) * 1.0001);
             dc[2] = nxt + m_abs(nxt) * (T)(4.0 * ulp);                    // (rounded up)
             double cn = 0.0;                                              // (the search subtracts the centre from r)
             if (io.center) { const T* ct = (const T*)io.center + (size_t)cloud * 3; cn = sqrt((double)ct[0] * ct[0] + (double)ct[1] * ct[1] + (double)ct[2] * ct[2]); }
-            dc[3] = (T)(16.0 * ulp * (rm + sqrt(rn) + cn + 1.0) * 1.0001);
+            const double pn = sqrt(p0[0] * p0[0] + p0[1] * p0[1] + p0[2] * p0[2]);
+            dc[3] = (T)(8.0 * ulp * (pn + rad + sqrt(rn) + cn + 1.0) * 1.0001);
         }
         if (io.pose_search_out) {                                         // what the next search reads: [C | r - centre]
             T* ps = (T*)io.pose_search_out + (size_t)cloud * 12;

@@ -190,7 +190,7 @@ typedef struct dicp_step_io {
     int32_t* n_not_converged;/* device counter for this iteration, pre-zeroed: += 1 per cloud with |delta| >= tol */
     const void* center;      /* optional (N,3) T: the search's centre (dicp_cloud_center) */
     void* pose_search_out;   /* optional (N,12) T: [C' | r' - centre], what the NEXT search reads (NULL: not kept) */
-    const void* rmax;        /* optional (N) T: largest |p| of each source cloud (dicp_loop_init) */
+    const void* rmax;        /* optional (N,4) T: bounding radius and midpoint of each source cloud (dicp_loop_init) */
     void* dcum;              /* optional T: cloud b's (motion bound, point rounding) pairs at dcum + b*dcum_stride: [2(iter+1)] = [2 iter] + how far any
                                 query of the cloud can have moved between pose_in and pose_out, [2(iter+1)+1] = the rounding of a point transformed
                                 with pose_out (match certificates, dicp_loop_buffers.cert_q) */
@@ -261,7 +261,7 @@ typedef struct dicp_loop_buffers {
                                 (exact: same indices as a full search).  Needs spos (and no idx), tgt_sorted, qorder, cert_qu, rmax, dcum */
     void* cert_qu;           /* (N, ceil(n/64)) T scratch */
     int32_t* cert_count;     /* optional (K,128) zeros: per iteration, units searched again [0,64) and single queries [64,128), sharded by block */
-    void* rmax;              /* (N) T from dicp_loop_init */
+    void* rmax;              /* (N,4) T from dicp_loop_init: bounding radius and midpoint of each source cloud */
     void* dcum;              /* (N, 2(K+1)) T: per iteration (motion bound since iteration 0, rounding of a transformed point); dicp_loop_init
                                 writes iteration 0's, the step kernels the rest */
     int32_t cert_reset;      /* 1: qorder is new in this call's first iteration: that iteration searches every query */
@@ -283,7 +283,7 @@ int dicp_pose_grad_out(int dtype, const double* gpose, const void* bwd_partials,
  * (ICP.py:267-281): iterations / matched_ratio of clouds that never converged, T_out (N,4,4) from pose_K. */
 int dicp_loop_init(int dtype, const void* T_init, const void* w0, double thresh, int rows, int N, int n,
                    void* pose0, void* alive0, void* n_start, const void* center /* optional */, void* pose_search0 /* optional: [C_0 | r_0 - center] */,
-                   const void* src, void* rmax, void* dcum, int dcum_stride /* optional (match certificates): rmax (N) = largest |p| of each cloud of
+                   const void* src, void* rmax, void* dcum, int dcum_stride /* optional (match certificates): rmax (N,4) = bounding radius and midpoint of each cloud of
                    src (N,n,3), dcum (N,dcum_stride >= 2): [0] = 0, [1] = the rounding of a point transformed with pose0 */, void* stream);
 /* pose_search (N,12) = [C_0 | r_0 - center] from T_init (N,4,4) alone: the same values, for a caller that orders the first queries
  * before the loop state exists (center optional) */

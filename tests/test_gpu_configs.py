@@ -268,3 +268,35 @@ def test_match_certificates_hold_on_hard_inputs(case, dtype):
         np.testing.assert_allclose(npy(gb), npy(ga), rtol=0, atol=gtol * max(1.0, float(ga.abs().max())))
     cnt = b[3]["searched_again"]
     assert int(cnt.sum()) > 0, "no query was ever searched again: the case does not exercise the certified iterations"
+
+
+@pytest.mark.parametrize("icp_type,dim,loss,diff,dtype", [("pt2pt", 3, None, True, torch.float32), ("pt2pl", 2, {"name": "cauchy", "metric": 0.5}, True, torch.float32),
+                                                          ("pt2pt", 2, {"name": "huber", "metric": 0.3}, False, torch.float64), ("pt2pl", 3, {"name": "trim", "metric": 0.8}, True, torch.float32)])
+def test_match_certificates_other_modes(icp_type, dim, loss, diff, dtype):
+    """The certified loop in the other modes of the call (point-to-point, planar, the other losses, hard weights, a weight tensor and a
+    T_init that take gradients): identical to searching everything, gradients of every input included."""
+    N, n, K = 10, 4096, 9
+    src, tgt = make_pairs(N, n, n, seed=31, dtype=dtype)
+    if icp_type == "pt2pt":
+        tgt = tgt[:, :, :3].contiguous()
+    g = torch.Generator().manual_seed(3)
+    w0 = (0.5 + 0.5 * torch.rand((N, n), generator=g, dtype=torch.float64)).to(dtype)
+    T0 = torch.eye(4, dtype=dtype).repeat(N, 1, 1)
+    T0[:, :3, 3] = 0.02 * torch.randn((N, 3), generator=g, dtype=torch.float64).to(dtype)
+    outs = {}
+    for reuse in (False, True):
+        icp = ICP(icp_type=icp_type, differentiable=diff, max_iterations=K, tolerance=1e-12)
+        icp.const_iter = True
+        icp.reuse_matches = reuse
+        icp.knn_variant = _lib.KNN_SWEEP
+        S, Tg, W, Ti = (x.to(DEV).requires_grad_(True) for x in (src, tgt, w0, T0))
+        out = icp.icp(S, Tg, Ti, weight=W, trim_dist=5.0, loss_fn=loss, dim=dim)
+        (out["T"].sum() + (out["pc"] ** 2).sum() * 1e-3).backward()
+        outs[reuse] = (out, [S.grad, Tg.grad, W.grad, Ti.grad], icp.knn_stats)
+    a, b = outs[False], outs[True]
+    assert "searched_again" in b[2]
+    for key in ("T", "deltas", "weights", "costs", "pc"):
+        assert torch.equal(a[0][key], b[0][key]), key
+    for ga, gb in zip(a[1], b[1]):
+        tol = (2e-5 if dtype == torch.float32 else 1e-11) * max(1.0, float(ga.abs().max()))
+        assert bool((((ga - gb).abs() <= tol) | (torch.isnan(ga) & torch.isnan(gb))).all())

@@ -250,10 +250,12 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
                 break
         return calls
 
-    def timed(icp_obj, count):
+    def timed(icp_obj, count, events=None):
         """`count` calls, each bracketed by barrier + device sync on both sides; per call the MAX over ranks."""
         times, last = [], None
-        for _ in range(count):
+        for i in range(count):
+            if events is not None:          # the kernel timings of the roofline legs: HIP events on the dispatches of the LAST timed call only
+                icp_obj._timing_events = events if i == count - 1 else None
             fence()
             t0 = time.perf_counter()
             last = run_call(icp_obj, src, tgt, T0, cw)
@@ -271,7 +273,10 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
     log = EventLog()
     if on_gpu:
         log.handles(K)                      # create the HIP events now: not part of the timed workload
-    icp._timing_events = None if (os.environ.get("DICP_BENCH_NO_EVENTS") == "1" or not on_gpu) else log      # (experiment switch: what do the events cost?)
+    # An event pair carried on a dispatch costs the queue ~4 us of idle time before the next dependent launch (6 % of a call at this shape:
+    # profiles/r02_timed_call_timeline*.txt): the events ride on the last timed call only, `value` is the median of all of them.
+    use_events = on_gpu and os.environ.get("DICP_BENCH_NO_EVENTS") != "1"
+    icp._timing_events = None
     # a generational GC pass over this process's heap takes tens of ms (10 steps take 5 ms): whether one lands inside a
     # timed call depends on the allocation count so far, i.e. on things as irrelevant as argv -> collect now and pause
     # the collector.  The collection goes BEFORE the steady-state calls: the first call after one is ~0.8 ms slower
@@ -279,7 +284,7 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
     gc.collect()
     gc.disable()
     steady_calls = steady(icp)
-    times, (out, T_all, gs, gt) = timed(icp, reps)                       # reps x exactly K steps
+    times, (out, T_all, gs, gt) = timed(icp, reps, log if use_events else None)      # reps x exactly K steps
     elapsed = median(times)
     knn_all, acc_all, bwd_all = ([], [], []) if not on_gpu else (log.all_ms("knn"), log.all_ms("accumulate"), log.all_ms("accumulate_bwd"))   # of the LAST timed call
     sane = bool(torch.isfinite(out["T"]).all() and torch.isfinite(gs).all() and torch.isfinite(gt).all())
@@ -359,7 +364,8 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
             "unit": "cloud-iterations/s",
             "n_gpus": world, "steps": K, "warmup": W,
             "timed_calls": reps, "call_ms": [round(v * 1e3, 4) for v in times],
-            "value_note": "median of %d timed %d-iteration calls (each: barrier + sync, icp() + backward(), barrier + sync; max over ranks)" % (reps, K),
+            "value_note": "median of %d timed %d-iteration calls (each: barrier + sync, icp() + backward(), barrier + sync; max over ranks); the last of them "
+                          "carries the HIP events of the roofline legs on its dispatches (~6 %% slower for it: an event pair costs the queue ~4 us)" % (reps, K),
             "warmup_note": "W-iteration call, then %d untimed K-iteration calls (until three in a row agree to 3 %%: allocator + steady state at the timed shapes)" % steady_calls,
             "ms_per_step": elapsed * 1e3 / K,
             "batch_iterations_per_s": K / elapsed,

@@ -1670,16 +1670,33 @@ __host__ __device__ inline dicp_step_io make_step_io(const dicp_loop_buffers& B,
 // barriers): the body of step_kernel, and of the small-cloud kernel that keeps a cloud in one block for a whole chunk.
 template <typename T, int NT>
 __device__ __forceinline__ void step_body(const dicp_step_io& io, int cloud, int tid) {
-    __shared__ double sacc[NACC_PAD], sA[36], sAreg[36], spose[12], sout[24];
+    __shared__ double sacc[NACC_PAD], sA[36], sAreg[36], spose[12], sout[24], smisc[16];
     __shared__ int s_copy;
     if (tid < WAVE) {   // reduce the per-block partials: lane = (part, slot); fixed summation order -> bit-reproducible
         const int slot_i = tid & 31, part = tid >> 5;
         const T* pp = (const T*)io.partials + (size_t)cloud * io.nblk * NACC_PAD + slot_i;
         double s = 0.0;
-        for (int b = part; b < io.nblk; b += 2) s += (double)pp[(size_t)b * NACC_PAD];
+        // (the kernel is a chain of latencies: all of a lane's loads are issued before the first add -- the order of the adds is unchanged)
+        constexpr int UB = 8;
+        for (int b0 = part; b0 < io.nblk; b0 += 2 * UB) {
+            T v[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) v[u] = (b0 + 2 * u < io.nblk) ? pp[(size_t)(b0 + 2 * u) * NACC_PAD] : T(0);
+#pragma unroll
+            for (int u = 0; u < UB; ++u) if (b0 + 2 * u < io.nblk) s += (double)v[u];
+        }
         s += __shfl_down(s, 32);
         if (tid < NACC_PAD) sacc[tid] = s;
         if (tid < 12) spose[tid] = (double)((const T*)io.pose_in)[(size_t)cloud * 12 + tid];
+        // the scalars the serial part below needs, fetched by idle lanes while the partials arrive
+        if (tid == 40) smisc[0] = (double)((const T*)io.alive)[cloud];
+        if (tid == 41) smisc[1] = io.cost_prev ? (double)((const T*)io.cost_prev)[(size_t)cloud * io.cost_stride] : 0.0;
+        if (tid >= 42 && tid < 46) smisc[2 + (tid - 42)] = io.dcum ? (double)((const T*)io.rmax)[(size_t)cloud * 4 + (tid - 42)] : 0.0;
+        if (tid >= 46 && tid < 49) smisc[6 + (tid - 46)] = io.center ? (double)((const T*)io.center)[(size_t)cloud * 3 + (tid - 46)] : 0.0;
+        if (tid == 49) smisc[9] = io.dcum ? (double)((const T*)io.dcum)[(size_t)cloud * io.dcum_stride + 2 * io.iter] : 0.0;
+        if (tid == 50) smisc[10] = (double)((const T*)io.n_start)[cloud];
+        if (tid == 51) smisc[11] = (double)((const T*)io.iterations)[cloud];
+        if (tid == 52) smisc[12] = (double)((const T*)io.matched_ratio)[cloud];
     }
     __syncthreads();
     if (tid == 0) {
@@ -1694,55 +1711,54 @@ __device__ __forceinline__ void step_body(const dicp_step_io& io, int cloud, int
         so3_exp(d6, R);                                                   // ICP.py:210
         T* pout = (T*)io.pose_out + (size_t)cloud * 12;
         const double* C = spose;
+        T pn[12];                                                         // the new pose, kept in registers for what follows
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 3; ++j)
-                pout[i * 3 + j] = (T)(R[0 * 3 + i] * C[0 * 3 + j] + R[1 * 3 + i] * C[1 * 3 + j] + R[2 * 3 + i] * C[2 * 3 + j]);
-        for (int k = 0; k < 3; ++k) pout[9 + k] = (T)(spose[9 + k] - d6[3 + k]);
+                pn[i * 3 + j] = (T)(R[0 * 3 + i] * C[0 * 3 + j] + R[1 * 3 + i] * C[1 * 3 + j] + R[2 * 3 + i] * C[2 * 3 + j]);
+        for (int k = 0; k < 3; ++k) pn[9 + k] = (T)(spose[9 + k] - d6[3 + k]);
+        for (int k = 0; k < 12; ++k) pout[k] = pn[k];
         if (io.dcum) {      // match certificates: (M, e) of the new pose.  M += how far a query of this cloud can have moved between the two
                             // poses: dC p + dr = dC (p - p0) + (dC p0 + dr) <= |dC|_F radius + |dC p0 + dr|, rounded up (radius, p0: the cloud's
                             // bounding box from dicp_loop_init); e = the rounding of a point transformed with the new pose
-            const T* box = (const T*)io.rmax + (size_t)cloud * 4;
-            const double rad = (double)box[0], p0[3] = {(double)box[1], (double)box[2], (double)box[3]};
-            double dC = 0.0, mv = 0.0, rn = 0.0;
+            const double rad = smisc[2], p0[3] = {smisc[3], smisc[4], smisc[5]};
+            double dC = 0.0, mv = 0.0, rn2 = 0.0;
             for (int i = 0; i < 3; ++i) {
-                double m = (double)pout[9 + i] - spose[9 + i];
-                for (int j = 0; j < 3; ++j) { const double d = (double)pout[i * 3 + j] - spose[i * 3 + j]; dC += d * d; m += d * p0[j]; }
+                double m = (double)pn[9 + i] - spose[9 + i];
+                for (int j = 0; j < 3; ++j) { const double d = (double)pn[i * 3 + j] - spose[i * 3 + j]; dC += d * d; m += d * p0[j]; }
                 mv += m * m;
-                rn += (double)pout[9 + i] * (double)pout[9 + i];
+                rn2 += (double)pn[9 + i] * (double)pn[9 + i];
             }
             const double ulp = sizeof(T) == 4 ? 1.2e-7 : 2.3e-16;
             T* dc = (T*)io.dcum + (size_t)cloud * io.dcum_stride + 2 * io.iter;
-            const T nxt = (T)((double)dc[0] + (sqrt(dC) * rad + sqrt(mv)) * 1.0001);
+            const T nxt = (T)((double)(T)smisc[9] + (sqrt(dC) * rad + sqrt(mv)) * 1.0001);
             dc[2] = nxt + m_abs(nxt) * (T)(4.0 * ulp);                    // (rounded up)
-            double cn = 0.0;                                              // (the search subtracts the centre from r)
-            if (io.center) { const T* ct = (const T*)io.center + (size_t)cloud * 3; cn = sqrt((double)ct[0] * ct[0] + (double)ct[1] * ct[1] + (double)ct[2] * ct[2]); }
-            const double pn = sqrt(p0[0] * p0[0] + p0[1] * p0[1] + p0[2] * p0[2]);
-            dc[3] = (T)(8.0 * ulp * (pn + rad + sqrt(rn) + cn + 1.0) * 1.0001);
+            const double cn = io.center ? sqrt(smisc[6] * smisc[6] + smisc[7] * smisc[7] + smisc[8] * smisc[8]) : 0.0;      // (the search subtracts the centre from r)
+            const double pnm = sqrt(p0[0] * p0[0] + p0[1] * p0[1] + p0[2] * p0[2]);
+            dc[3] = (T)(8.0 * ulp * (pnm + rad + sqrt(rn2) + cn + 1.0) * 1.0001);
         }
         if (io.pose_search_out) {                                         // what the next search reads: [C | r - centre]
             T* ps = (T*)io.pose_search_out + (size_t)cloud * 12;
-            const T* ctr = io.center ? (const T*)io.center + (size_t)cloud * 3 : nullptr;
-            for (int k = 0; k < 9; ++k) ps[k] = pout[k];
-            for (int k = 0; k < 3; ++k) ps[9 + k] = ctr ? pout[9 + k] - ctr[k] : pout[9 + k];
+            for (int k = 0; k < 9; ++k) ps[k] = pn[k];
+            for (int k = 0; k < 3; ++k) ps[9 + k] = io.center ? pn[9 + k] - (T)smisc[6 + k] : pn[9 + k];
         }
 
         T cost = (T)sacc[ACC_COST];                                       // ICP.py:229-232
-        if (io.cost_prev && cost == T(0)) cost = ((const T*)io.cost_prev)[(size_t)cloud * io.cost_stride];
+        if (io.cost_prev && cost == T(0)) cost = (T)smisc[1];
         ((T*)io.cost)[(size_t)cloud * io.cost_stride] = cost;
 
         const double nmatch = sacc[ACC_NMATCH];
         if (io.n_matched) ((T*)io.n_matched)[cloud] = (T)nmatch;
-        const T alive_in = ((const T*)io.alive)[cloud];
+        const T alive_in = (T)smisc[0];
         T alive_next = alive_in;
         const bool hit = (double)(T)sqrt(nrm2) < io.tolerance;            // ICP.py:237-239
         if (hit) io.converged[cloud] = 1;
         else if (io.n_not_converged) atomicAdd(io.n_not_converged, 1);
         if (hit && !io.const_iter) {                                      // ICP.py:240-257
             T* it = (T*)io.iterations + cloud;
-            if (*it == T(0)) *it = (T)(io.iter + 1);
+            if ((T)smisc[11] == T(0)) *it = (T)(io.iter + 1);
             T* mr = (T*)io.matched_ratio + cloud;
-            if (*mr == T(0)) {
-                float start = (alive_in != T(0)) ? (float)((const T*)io.n_start)[cloud] : 0.f;
+            if ((T)smisc[12] == T(0)) {
+                float start = (alive_in != T(0)) ? (float)(T)smisc[10] : 0.f;
                 if (start == 0.f) start = 1.f;
                 *mr = (T)((float)nmatch / start);       // int64/int64 -> float32 in the reference
             }
@@ -2189,7 +2205,14 @@ __global__ __launch_bounds__(WAVE) void step_bwd_kernel(const double* __restrict
         double s = 0.0;
         if (bwd_partials && slot_i < NBWD) {
             const T* pp = bwd_partials + (size_t)cloud * nblk * NBWD_PAD + slot_i;
-            for (int b = part; b < nblk; b += 4) s += (double)pp[(size_t)b * NBWD_PAD];
+            constexpr int UB = 4;                           // (all of a lane's loads in flight before the first add; same order of adds)
+            for (int b0 = part; b0 < nblk; b0 += 4 * UB) {
+                T v[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) v[u] = (b0 + 4 * u < nblk) ? pp[(size_t)(b0 + 4 * u) * NBWD_PAD] : T(0);
+#pragma unroll
+                for (int u = 0; u < UB; ++u) if (b0 + 4 * u < nblk) s += (double)v[u];
+            }
         }
         s += __shfl_down(s, 32);
         s += __shfl_down(s, 16);
@@ -2199,7 +2222,24 @@ __global__ __launch_bounds__(WAVE) void step_bwd_kernel(const double* __restrict
         if (tid < 36) sAreg[tid] = areg_k[(size_t)cloud * 36 + tid];
     }
     __syncthreads();
-    if (tid == 0) step_backward(sg, sg + 9, dim, sC, sd, sAreg, sGs, sGb, sgo, sgo + 9);
+    if (tid == 0) {     // (operands in registers: the adjoint reads each of them many times, and an LDS read is ~64 cycles of a one-lane chain)
+        double g[12], C[9], d[6], A[36], Gs[36], Gb[6], go[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) g[k] = sg[k];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) C[k] = sC[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d[k] = sd[k];
+#pragma unroll
+        for (int k = 0; k < 36; ++k) A[k] = sAreg[k];
+        step_backward(g, g + 9, dim, C, d, A, Gs, Gb, go, go + 9);
+#pragma unroll
+        for (int k = 0; k < 36; ++k) sGs[k] = Gs[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sGb[k] = Gb[k];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) sgo[k] = go[k];
+    }
     __syncthreads();
     if (tid < 36) gs[(size_t)cloud * 36 + tid] = (T)sGs[tid];
     if (tid < 6) gb[(size_t)cloud * 6 + tid] = (T)sGb[tid];

@@ -73,6 +73,9 @@ class ICP:
                  "weights" (N,K,n*r,1), "stats": {"converged","iterations","matched_ratio"}}
         """
         assert dim == 2 or dim == 3, "dim must be 2 or 3"                                # ICP.py:79
+        # weight=None on tensor inputs: the weights are all 1 -- the loop is told so (w0 = None) instead of reading a tensor of ones
+        unit_w = (weight is None and isinstance(source, torch.Tensor) and isinstance(target, torch.Tensor) and len(source) > 0 and len(target) > 0
+                  and not self.source_zeroes_are_pad)
         source, target, T_init, w_pts, rows = self._batch(source, target, T_init, weight)   # ICP.py:85
         assert source.dtype == target.dtype == T_init.dtype                              # ICP.py:96
         if self.icp_type == 'pt2pl':
@@ -115,7 +118,7 @@ class ICP:
             T, deltas, weights, costs, converged, iterations, matched = icp_loop_gumbel(
                 source, target, T_init, w_pts, cfg, self.nn.eps, self.nn.tau, inject_U=getattr(self.nn, "_inject_U", None))
         else:
-            T, deltas, weights, costs, converged, iterations, matched = ICPLoop.apply(source, target, T_init, w_pts, cfg)
+            T, deltas, weights, costs, converged, iterations, matched = ICPLoop.apply(source, target, T_init, None if unit_w else w_pts, cfg)
 
         if self.verbose:                                                                 # ICP.py:262-264
             print("ICP converged in {} iterations".format(deltas.shape[1]))

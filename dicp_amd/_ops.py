@@ -469,14 +469,15 @@ class ICPLoop(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, source, target, T_init, w0, cfg):
-        for t, nm in ((source, "source"), (target, "target"), (T_init, "T_init"), (w0, "weight")):
+        for t, nm in ((source, "source"), (target, "target"), (T_init, "T_init")) + (((w0, "weight"),) if w0 is not None else ()):
             require_device(t, "ICP(" + nm + ")")
         lib = _lib.load()
         dev, dt = source.device, source.dtype
         code, es = _DT[dt], source.element_size()
         N, n, _ = source.shape
         m, c = target.shape[1], target.shape[2]
-        src, tgt, w0c = source.contiguous(), target.contiguous(), w0.contiguous()
+        # w0 None = unit weights (weight=None on a tensor input): the kernels take w_init == NULL and read 4 bytes per point less
+        src, tgt, w0c = source.contiguous(), target.contiguous(), (w0.contiguous() if w0 is not None else None)
         P = cfg.params()
         rows = 3 if cfg.icp_type == "pt2pt" else 1
         Kmax = int(cfg.max_iterations)
@@ -673,7 +674,7 @@ class ICPLoop(torch.autograd.Function):
             gpose = torch.empty((N, 12), dtype=torch.float64, device=dev)
             gtmp = torch.empty_like(gpose)
             _lib.check(lib.dicp_pose_grad_in(code, _p(gT.contiguous()) if gT is not None else None, _p(gpose), N, st), "dicp_pose_grad_in")
-            want_tgt, want_w = ctx.needs_input_grad[1], ctx.needs_input_grad[3]
+            want_tgt, want_w = ctx.needs_input_grad[1], ctx.needs_input_grad[3] and w0c is not None
             cv = 6 if cfg.icp_type == "pt2pl" else 3
             all_windowed = None         # set below: every iteration takes the windowed form -> dicp_window_reduce writes gtgt
             gtgt = None
@@ -698,7 +699,7 @@ class ICPLoop(torch.autograd.Function):
             if any(windowed):
                 qo = qorders[q_star]
                 src_s = _gather_rows_raw(src, qo)
-                w_s = _gather_rows_raw(w0c.unsqueeze(-1), qo).squeeze(-1)
+                w_s = _gather_rows_raw(w0c.unsqueeze(-1), qo).squeeze(-1) if w0c is not None else None
                 # slot-order accumulators and slabs: the first windowed launch writes them (bwd_overwrite), no zero fill
                 gsrc_s = torch.empty_like(src)
                 gw_s = torch.empty_like(w0c) if want_w else None

@@ -629,7 +629,8 @@ __global__ __launch_bounds__(BLOCK) void loop_init_kernel(const T* __restrict__ 
         }
     }
     int k = 0;
-    for (int i = tid; i < n; i += BLOCK) k += w0[(size_t)cloud * n + i] > thresh ? 1 : 0;
+    if (w0) { for (int i = tid; i < n; i += BLOCK) k += w0[(size_t)cloud * n + i] > thresh ? 1 : 0; }
+    else if (tid == 0) k = T(1) > thresh ? n : 0;            // w0 == NULL: unit weights
 #pragma unroll
     for (int off = WAVE / 2; off > 0; off >>= 1) k += __shfl_down(k, off);
     if ((tid & (WAVE - 1)) == 0) cnt[tid >> 6] = k;
@@ -1635,7 +1636,7 @@ __global__ __launch_bounds__(BLOCK, (CERT && sizeof(T) == 4) ? 5 : 1) void accum
         T nrm[3] = {T(0), T(0), T(0)};
         if (MODE == MODE_PT2PL) { nrm[0] = yp[3]; nrm[1] = yp[4]; nrm[2] = yp[5]; }
         PointState<T> s;
-        point_forward<T, MODE>(P, C, r, p, y, nrm, w_init[pt] * live, acc, s);
+        point_forward<T, MODE>(P, C, r, p, y, nrm, (w_init ? w_init[pt] : T(1)) * live, acc, s);
         if (w_out) w_out[(size_t)cloud * w_stride + i] = s.w;
     }
     block_reduce_store<T, NACC, NACC_PAD>(acc, partials + ((size_t)cloud * bpc + blk) * NACC_PAD, red);
@@ -1804,7 +1805,7 @@ __global__ __launch_bounds__(BLOCK) void icp_small_forward_kernel(WeightParams P
     __syncthreads();
     const T* __restrict__ src = (const T*)B.src + (size_t)cloud * n * 3;
     const T* __restrict__ tgt = (const T*)B.tgt + (size_t)cloud * m * c;
-    const T* __restrict__ w_init = (const T*)B.w_init + (size_t)cloud * n;
+    const T* __restrict__ w_init = B.w_init ? (const T*)B.w_init + (size_t)cloud * n : nullptr;
     for (int k = k0; k < k1; ++k) {
         T C[9], r[3];
         load_pose((const T*)B.poses + (size_t)k * N * 12, cloud, C, r);
@@ -1838,7 +1839,7 @@ __global__ __launch_bounds__(BLOCK) void icp_small_forward_kernel(WeightParams P
             T nrm[3] = {T(0), T(0), T(0)};
             if (MODE == MODE_PT2PL) { nrm[0] = yp[3]; nrm[1] = yp[4]; nrm[2] = yp[5]; }
             PointState<T> st;
-            point_forward<T, MODE>(P, C, r, p, y, nrm, w_init[i] * live, acc, st);
+            point_forward<T, MODE>(P, C, r, p, y, nrm, (w_init ? w_init[i] : T(1)) * live, acc, st);
             w_k[i] = st.w;
         }
         block_reduce_store<T, NACC, NACC_PAD>(acc, (T*)B.partials + (size_t)cloud * NACC_PAD, red);
@@ -1901,7 +1902,7 @@ __global__ __launch_bounds__(BLOCK) void accumulate_bwd_kernel(WeightParams P, c
             T nrm[3] = {T(0), T(0), T(0)};
             if (MODE == MODE_PT2PL) { nrm[0] = yp[3]; nrm[1] = yp[4]; nrm[2] = yp[5]; }
             T gp[3], gw0;
-            point_backward<T, MODE>(P, C, r, p, y, nrm, w_init[pt] * live, Gs, Gb, gp, gy, gn, gw0, acc, acc + 9);
+            point_backward<T, MODE>(P, C, r, p, y, nrm, (w_init ? w_init[pt] : T(1)) * live, Gs, Gb, gp, gy, gn, gw0, acc, acc + 9);
             T* gsp = gsrc + pt * 3;
             gsp[0] += gp[0]; gsp[1] += gp[1]; gsp[2] += gp[2];
             if (gw) gw[pt] += gw0 * live;
@@ -2023,7 +2024,7 @@ __global__ __launch_bounds__(BLOCK) void accumulate_bwd_window_kernel(WeightPara
             const size_t pt = (size_t)cloud * n + (on[u] ? s : s0);
             const T* spp = src_s + pt * 3;
             p[u][0] = spp[0]; p[u][1] = spp[1]; p[u][2] = spp[2];
-            wv[u] = w_s[pt];
+            wv[u] = w_s ? w_s[pt] : T(1);
             const T* gsp = gsrc_s + pt * 3;
             g0[u][0] = g0[u][1] = g0[u][2] = gwv[u] = T(0);
             if (!overwrite) {
@@ -2276,7 +2277,7 @@ __global__ __launch_bounds__(BLOCK) void icp_small_backward_kernel(WeightParams 
     }
     const T* __restrict__ src = (const T*)B.src + (size_t)cloud * n * 3;
     const T* __restrict__ tgt = (const T*)B.tgt + (size_t)cloud * m * c;
-    const T* __restrict__ w_init = (const T*)B.w_init + (size_t)cloud * n;
+    const T* __restrict__ w_init = B.w_init ? (const T*)B.w_init + (size_t)cloud * n : nullptr;
     __syncthreads();
     for (int k = k1 - 1; k >= k0; --k) {
         const T* pose_k = (const T*)B.poses + (size_t)k * N * 12;
@@ -2306,7 +2307,7 @@ __global__ __launch_bounds__(BLOCK) void icp_small_backward_kernel(WeightParams 
             T nrm[3] = {T(0), T(0), T(0)};
             if (MODE == MODE_PT2PL) { nrm[0] = yp[3]; nrm[1] = yp[4]; nrm[2] = yp[5]; }
             T gp[3], gy[3], gn[3], gw0;
-            point_backward<T, MODE>(P, C, r, p, y, nrm, w_init[i] * live, Gs, Gb, gp, gy, gn, gw0, acc, acc + 9);
+            point_backward<T, MODE>(P, C, r, p, y, nrm, (w_init ? w_init[i] : T(1)) * live, Gs, Gb, gp, gy, gn, gw0, acc, acc + 9);
             T* gsp = gsrc + ((size_t)cloud * n + i) * 3;
             gsp[0] += gp[0]; gsp[1] += gp[1]; gsp[2] += gp[2];
             if (gw) gw[(size_t)cloud * n + i] += gw0 * live;
@@ -2988,7 +2989,7 @@ int dicp_query_order(int dtype, const void* src, const void* pose, const void* b
 int dicp_loop_init(int dtype, const void* T_init, const void* w0, double thresh, int rows, int N, int n,
                    void* pose0, void* alive0, void* n_start, const void* center, void* pose_search0,
                    const void* src, void* rmax, void* dcum, int dcum_stride, void* stream) {
-    if (!T_init || !w0 || !pose0 || !alive0 || !n_start || (rmax && (!src || !dcum))) return DICP_ERR_NULL;
+    if (!T_init || !pose0 || !alive0 || !n_start || (rmax && (!src || !dcum))) return DICP_ERR_NULL;       // (w0 == NULL: unit weights)
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || n <= 0 || (rows != 1 && rows != 3) || (rmax && dcum_stride < 2)) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
@@ -3174,7 +3175,7 @@ static int accumulate_go(int dtype, const dicp_weight_params* prm, const void* s
                          const int32_t* idx, const void* pose, const void* w_init, const void* alive, const int32_t* src_rows,
                          int N, int n, int m, void* partials, void* w_out, int64_t w_stride, void* stream, const CertAcc* ca) {
     if (const int e = check_params(prm, c)) return e;
-    if (!src || !tgt || !w_init || !partials) return DICP_ERR_NULL;
+    if (!src || !tgt || !partials) return DICP_ERR_NULL;       // (w_init == NULL: unit weights)
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || n <= 0 || m <= 0 || (w_out && w_stride < n) || (!idx && !ca && m != n)) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
@@ -3241,7 +3242,7 @@ int dicp_accumulate_bwd(int dtype, const dicp_weight_params* prm, const void* sr
                         const void* gs, const void* gb, const int32_t* src_rows, int N, int n, int m,
                         void* gsrc, void* gtgt, void* gw, void* bwd_partials, void* stream) {
     if (const int e = check_params(prm, c)) return e;
-    if (!src || !tgt || !w_init || !gs || !gb || !gsrc || !bwd_partials) return DICP_ERR_NULL;
+    if (!src || !tgt || !gs || !gb || !gsrc || !bwd_partials || (gw && !w_init)) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || n <= 0 || m <= 0 || (!idx && m != n)) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
@@ -3388,7 +3389,7 @@ int dicp_accumulate_bwd_window(int dtype, const dicp_weight_params* prm, const v
                                const void* alive, const void* gs, const void* gb, const int32_t* src_rows, int N, int n, int m_pad, void* gsrc_s, void* slab,
                                void* gts_far, void* gw_s, void* bwd_partials, int overwrite, void* stream) {
     if (const int e = check_params(prm, c)) return e;
-    if (!src_s || !tgt_s || !spos || !spos_ref || !pose || !w_s || !gs || !gb || !gsrc_s || !bwd_partials || (slab && !gts_far))
+    if (!src_s || !tgt_s || !spos || !spos_ref || !pose || (gw_s && !w_s) || !gs || !gb || !gsrc_s || !bwd_partials || (slab && !gts_far))
         return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || n <= 0 || m_pad <= 0 || m_pad % KNN_PAD) return DICP_ERR_SHAPE;
@@ -3474,7 +3475,7 @@ static bool small_loop_eligible(int dtype, int kind, int knn_variant, int n, int
 // [k0,k1) chunks and reads counters[] between them (converged clouds are frozen, extra iterations are no-ops).
 int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_buffers* B, int N, int n, int m,
                      int dim, int const_iter, double tolerance, int k0, int k1, void* stream) {
-    if (!prm || !B || !B->src || !B->tgt || !B->w_init || !B->poses || !B->deltas || !B->costs || !B->alive ||
+    if (!prm || !B || !B->src || !B->tgt || !B->poses || !B->deltas || !B->costs || !B->alive ||
         !B->converged || !B->iterations || !B->matched_ratio || !B->n_start || !B->n_matched || (!B->idx && !B->spos) || !B->w ||
         !B->partials || !B->counters) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
@@ -3575,7 +3576,7 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
 int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_buffers* B, int N, int n, int m, int dim,
                       double* gpose, double* gpose_tmp, int have_partials, void* gs, void* gb, void* gsrc, void* gtgt, void* gw,
                       void* bwd_partials, int k0, int k1, void* stream) {
-    if (!prm || !B || !B->src || !B->tgt || !B->w_init || !B->poses || !B->deltas || !B->areg || !B->alive || (!B->idx && !B->spos) ||
+    if (!prm || !B || !B->src || !B->tgt || !B->poses || !B->deltas || !B->areg || !B->alive || (!B->idx && !B->spos) || (gw && !B->w_init) ||
         !gpose || !gpose_tmp || !gs || !gb || !gsrc || !bwd_partials) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (k0 < 0 || k1 > B->K || k0 > k1 || !B->idx_per_iter || (B->spos && (B->m_pad <= 0 || !B->spos_ref))) return DICP_ERR_SHAPE;

@@ -152,7 +152,7 @@ int dicp_scatter_add_rows(int dtype, const void* gout, const int32_t* idx, int N
  *   tgt (N,m,c) with c = 6 for pt2pl (normals in 3:6), 3 or 6 for pt2pt -- or 8 / 4: the same rows padded to 32 / 16 bytes (dicp_sweep_build's tgt_s,
  *   gathered at the SORTED positions dicp_knn_sweep wrote: idx = spos, m = m_pad); idx == NULL (then m must equal n)
  *   means tgt already holds ONE ROW PER SOURCE POINT -- the soft neighbours of dicp_gumbel_nn;
- *   w_init (N,n); alive (N) multiplies w_init (the zeroing of ICP.py:256-257), may be NULL;
+ *   w_init (N,n), NULL = unit weights (the reference's weight=None); alive (N) multiplies w_init (the zeroing of ICP.py:256-257), may be NULL;
  *   partials (N, nblk, DICP_NACC_PAD) with nblk = dicp_accumulate_blocks(n);
  *   w_out: cloud b's n weights are written at w_out + b*w_stride (elements); may be NULL. */
 int dicp_accumulate(int dtype, const dicp_weight_params* prm, const void* src, const void* tgt, int c,
@@ -205,7 +205,7 @@ int dicp_step(int dtype, const dicp_step_io* io, int N, void* stream);
 typedef struct dicp_loop_buffers {
     const void* src;         /* (N,n,3) */
     const void* tgt;         /* (N,m,c) */
-    const void* w_init;      /* (N,n) */
+    const void* w_init;      /* (N,n); NULL = unit weights (the reference's weight=None: 4 bytes per point and launch less to read) */
     int32_t c;
     int32_t K;               /* capacity of the histories (= max_iterations) */
     int32_t knn_variant;     /* DICP_KNN_VALU | _MFMA (uses tgt4) or DICP_KNN_SWEEP (uses tgt4 = tgs4 + the arrays below); bits 8..15: optional

@@ -146,7 +146,7 @@ def test_sizes_and_argument_checks(lib):
     P.loss = 9
     assert lib.dicp_accumulate(0, ctypes.byref(P), one, one, 6, one, one, one, None, None, 1, 1, 1, one, None, 0, None) == 4
     P.loss = _lib.LOSS_TRIM                                                        # loss_fn "trim" is a loss like the others (loss.py:15-16)
-    assert lib.dicp_accumulate(0, ctypes.byref(P), one, one, 6, one, one, None, None, None, 1, 1, 1, one, None, 0, None) == 1   # (only the null weights are left to object to)
+    assert lib.dicp_accumulate(0, ctypes.byref(P), one, one, 6, one, one, one, None, None, 1, 1, 1, None, None, 0, None) == 1   # (only the null partials are left to object to; null weights = unit weights)
     assert lib.dicp_loss_weight(0, 0, 0, 1.0, 5.0, one, 4, 3, one, None) == 4      # unknown loss (loss.py:19)
     with pytest.raises(RuntimeError, match="rejected"):
         _lib.check(2, "x")

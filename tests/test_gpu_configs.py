@@ -300,3 +300,26 @@ def test_match_certificates_other_modes(icp_type, dim, loss, diff, dtype):
     for ga, gb in zip(a[1], b[1]):
         tol = (2e-5 if dtype == torch.float32 else 1e-11) * max(1.0, float(ga.abs().max()))
         assert bool((((ga - gb).abs() <= tol) | (torch.isnan(ga) & torch.isnan(gb))).all())
+
+
+@pytest.mark.parametrize("N,n,icp_type", [(12, 4096, "pt2pl"), (3, 300, "pt2pt"), (40, 16384, "pt2pl")])
+def test_unit_weights_are_the_tensor_of_ones(N, n, icp_type):
+    """weight=None reaches the kernels as w_init == NULL (unit weights, nothing read): every output and gradient equals the call with an
+    explicit tensor of ones -- sweep path with certificates, small-cloud kernels and the brute-force path alike."""
+    src, tgt = make_pairs(N, n, n, seed=17)
+    if icp_type == "pt2pt":
+        tgt = tgt[:, :, :3].contiguous()
+    outs = []
+    for w in (None, torch.ones((N, n))):
+        icp = ICP(icp_type=icp_type, differentiable=True, max_iterations=8, tolerance=1e-12)
+        icp.const_iter = True
+        S, Tg = src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True)
+        out = icp.icp(S, Tg, torch.eye(4, device=DEV).repeat(N, 1, 1), weight=None if w is None else w.to(DEV), **KW)
+        out["T"].sum().backward()
+        outs.append((out, S.grad, Tg.grad))
+    a, b = outs
+    for key in ("T", "deltas", "weights", "costs", "pc"):
+        assert torch.equal(a[0][key], b[0][key]), key
+    assert torch.equal(a[0]["stats"]["matched_ratio"], b[0]["stats"]["matched_ratio"])
+    for ga, gb in ((a[1], b[1]), (a[2], b[2])):
+        np.testing.assert_allclose(npy(ga), npy(gb), rtol=0, atol=2e-6 * max(1.0, float(gb.abs().max())))

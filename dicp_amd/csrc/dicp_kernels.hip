@@ -578,18 +578,19 @@ __global__ __launch_bounds__(QO_THREADS) void query_order_kernel(const T* __rest
 }
 
 // first-iteration state of the loop: pose_0 from T_init, alive_0 = 1, n_start = rows * #(w0 > thresh)  (ICP.py:124-129)
+constexpr int LI_THREADS = 1024;     // one block per cloud: its two passes over the cloud (weights, bounding box) are chains of loads
 template <typename T>
-__global__ __launch_bounds__(BLOCK) void loop_init_kernel(const T* __restrict__ T_init, const T* __restrict__ w0, T thresh, int rows, int n,
+__global__ __launch_bounds__(LI_THREADS) void loop_init_kernel(const T* __restrict__ T_init, const T* __restrict__ w0, T thresh, int rows, int n,
                                                           T* __restrict__ pose0, T* __restrict__ alive0, T* __restrict__ n_start,
                                                           const T* __restrict__ center, T* __restrict__ pose_search0,
                                                           const T* __restrict__ src, T* __restrict__ rmax, T* __restrict__ dcum, int dstride) {
-    __shared__ int cnt[BLOCK / WAVE];
-    __shared__ T box[(BLOCK / WAVE) * 6];
+    __shared__ int cnt[LI_THREADS / WAVE];
+    __shared__ T box[(LI_THREADS / WAVE) * 6];
     const int cloud = blockIdx.x, tid = threadIdx.x;
     if (rmax) {     // bounding box of the cloud -> (radius, midpoint): with them the step kernels bound how far ANY query moves between two
                     // poses (match certificates): dC p + dr = dC (p - p0) + (dC p0 + dr), so a cloud far from the origin costs nothing
         T lo[3] = {inf_v<T>(), inf_v<T>(), inf_v<T>()}, hi[3] = {-inf_v<T>(), -inf_v<T>(), -inf_v<T>()};
-        for (int i = tid; i < n; i += BLOCK) {
+        for (int i = tid; i < n; i += LI_THREADS) {
             const T* p = src + ((size_t)cloud * n + i) * 3;
 #pragma unroll
             for (int k = 0; k < 3; ++k) { const T v = p[k]; lo[k] = v < lo[k] ? v : lo[k]; hi[k] = v > hi[k] ? v : hi[k]; }
@@ -611,7 +612,7 @@ __global__ __launch_bounds__(BLOCK) void loop_init_kernel(const T* __restrict__ 
             T d2 = T(0), p0[3], pn = T(0);
             for (int k = 0; k < 3; ++k) {
                 T l = box[k], h = box[3 + k];
-                for (int w = 1; w < BLOCK / WAVE; ++w) { l = box[w * 6 + k] < l ? box[w * 6 + k] : l; h = box[w * 6 + 3 + k] > h ? box[w * 6 + 3 + k] : h; }
+                for (int w = 1; w < LI_THREADS / WAVE; ++w) { l = box[w * 6 + k] < l ? box[w * 6 + k] : l; h = box[w * 6 + 3 + k] > h ? box[w * 6 + 3 + k] : h; }
                 p0[k] = T(0.5) * (l + h);
                 d2 += (h - l) * (h - l);
                 pn += p0[k] * p0[k];
@@ -629,7 +630,7 @@ __global__ __launch_bounds__(BLOCK) void loop_init_kernel(const T* __restrict__ 
         }
     }
     int k = 0;
-    if (w0) { for (int i = tid; i < n; i += BLOCK) k += w0[(size_t)cloud * n + i] > thresh ? 1 : 0; }
+    if (w0) { for (int i = tid; i < n; i += LI_THREADS) k += w0[(size_t)cloud * n + i] > thresh ? 1 : 0; }
     else if (tid == 0) k = T(1) > thresh ? n : 0;            // w0 == NULL: unit weights
 #pragma unroll
     for (int off = WAVE / 2; off > 0; off >>= 1) k += __shfl_down(k, off);
@@ -637,7 +638,7 @@ __global__ __launch_bounds__(BLOCK) void loop_init_kernel(const T* __restrict__ 
     __syncthreads();
     if (tid == 0) {
         int tot = 0;
-        for (int w = 0; w < BLOCK / WAVE; ++w) tot += cnt[w];
+        for (int w = 0; w < LI_THREADS / WAVE; ++w) tot += cnt[w];
         n_start[cloud] = (T)((long)tot * rows);
         alive0[cloud] = T(1);
     }
@@ -2994,8 +2995,8 @@ int dicp_loop_init(int dtype, const void* T_init, const void* w0, double thresh,
     if (N <= 0 || n <= 0 || (rows != 1 && rows != 3) || (rmax && dcum_stride < 2)) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     begin_launch();
-    if (dtype == DICP_F32) loop_init_kernel<float><<<N, BLOCK, 0, st>>>((const float*)T_init, (const float*)w0, (float)thresh, rows, n, (float*)pose0, (float*)alive0, (float*)n_start, (const float*)center, (float*)pose_search0, (const float*)src, (float*)rmax, (float*)dcum, dcum_stride);
-    else                   loop_init_kernel<double><<<N, BLOCK, 0, st>>>((const double*)T_init, (const double*)w0, thresh, rows, n, (double*)pose0, (double*)alive0, (double*)n_start, (const double*)center, (double*)pose_search0, (const double*)src, (double*)rmax, (double*)dcum, dcum_stride);
+    if (dtype == DICP_F32) loop_init_kernel<float><<<N, LI_THREADS, 0, st>>>((const float*)T_init, (const float*)w0, (float)thresh, rows, n, (float*)pose0, (float*)alive0, (float*)n_start, (const float*)center, (float*)pose_search0, (const float*)src, (float*)rmax, (float*)dcum, dcum_stride);
+    else                   loop_init_kernel<double><<<N, LI_THREADS, 0, st>>>((const double*)T_init, (const double*)w0, thresh, rows, n, (double*)pose0, (double*)alive0, (double*)n_start, (const double*)center, (double*)pose_search0, (const double*)src, (double*)rmax, (double*)dcum, dcum_stride);
     return launch_status();
 }
 

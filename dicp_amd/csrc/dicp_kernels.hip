@@ -926,11 +926,30 @@ constexpr int CERT_SLOT_MAX = 16;   // a unit with more spent budgets than this 
 template <typename T>
 __device__ __forceinline__ T cert_budget(T A, T S, T H1, T hx, const T* __restrict__ dk /* (M_k, e_k) */) {
     if (!(A > T(0))) return T(-1);
-    // how far the query may move: A / S, and never further than a fifth of max(d1, |x|, 1) -- the margin 3E in A covers the rounding of
-    // the scores AFTER the move only while 0.5 |x|^2 and the match's distance have not grown past 1.8x (or stay below the constant in E)
-    const T cap = T(0.2) * max_t(max_t(m_sqrt(T(2) * H1), m_sqrt(T(2) * hx)), T(1));
+    // how far the query may move: A / S, and never further than a fifth of max(d1, |x|) -- the last term of A covers the rounding of the
+    // scores AFTER the move only while 0.5 |x|^2 and the match's half squared distance have not grown past 1.8x, which this cap guarantees
+    // (15 (t + .2)^2 + 21 (1.2)^2 <= 1.8 (15 t^2 + 21) and 15 (1.2)^2 + 21 (t + .2)^2 <= 1.8 (15 + 21 t^2) for every t in [0, 1])
+    const T cap = T(0.2) * max_t(m_sqrt(T(2) * H1), m_sqrt(T(2) * hx));
     const T slack = (S > T(0) && A < inf_v<T>()) ? min_t(A / S, cap) : cap;
     return (slack + dk[0]) * (T(1) - T(8) * CertUlp<T>::v) - dk[1] * (T(1) + T(8) * CertUlp<T>::v);
+}
+// The budget of a query from what its search knows: bv = the match's score, s2 = the smallest score of any other SCORED row (inf: none),
+// h_unscored = a lower bound of the half squared distance of every row that was not scored (inf: all were), hx = 0.5 |x|^2.
+// Rounding model (u = unit roundoff; three fmas on a stored 0.5|y|^2, |y| <= |x| + d):  |score - (D - h)| <= 15u D + 21u h;  with the
+// rounding of hx and of the sum,  |(score + hx) - D| <= 16u D + 24u h.  Taken x1.5 for H1 (above D1) and H2 (below D2); the two scores
+// compared AFTER the move err by 2 (15u D' + 21u h') (1 + 16u) with D', h' <= 1.8x (the cap in cert_budget): 54u D1 + 76u h, taken x1.2.
+template <typename T>
+__device__ __forceinline__ T cert_from_scores(T bv, T s2, T hx, T h_unscored, const T* __restrict__ dk, T& H1_out) {
+    const T u = T(0.5) * CertUlp<T>::v;
+    const T H1r = max_t(bv + hx, T(0));
+    const T H1 = H1r + (T(24) * u * H1r + T(36) * u * hx);
+    H1_out = H1;
+    T H2 = inf_v<T>();
+    if (s2 < inf_v<T>()) { const T H2r = s2 + hx; H2 = H2r - (T(24) * u * m_abs(H2r) + T(36) * u * hx); }
+    H2 = min_t(H2, h_unscored);
+    T A = inf_v<T>(), S = T(0);                                  // (no other target at all: only the cap limits the budget)
+    if (H2 < inf_v<T>()) { A = (H2 - H1) - (T(65) * u * H1 + T(91) * u * hx); S = m_sqrt(T(2) * H1) + m_sqrt(T(2) * max_t(H2, T(0))); }
+    return cert_budget(A, S, H1, hx, dk);
 }
 // "no certificate, searched at iteration k": never above cert_spent(), and told apart from a budget that was spent before this iteration
 template <typename T> __device__ __forceinline__ T cert_mark(int k) { return T(-(k + 2)); }
@@ -1152,20 +1171,16 @@ __device__ __forceinline__ void sweep_unit(const T* __restrict__ src, const T* _
         // sorted position of the winner (indexed like idx, by the query): what the windowed backward consumes
         if (spos) spos[(size_t)cloud * n_full + qi[q]] = (bo == 0x7fffffff || bo >= m) ? -1 : bs;
         if (CERT) {
-            T A = T(-1), S = T(0), H1c = T(0);
+            T bq = T(-1);
             if (bo != 0x7fffffff && ob[q] != best[q]) {     // (three or more tied chunks: no certificate)
                 const T eps = SweepEps<T>::v;
-                const T E1 = eps * (T(1) + m_abs(bv) + hx[q]);
-                const T H1 = max_t((bv + hx[q]) + E1, T(0));
-                H1c = H1;
                 const T s2 = min_t(sec[q], rv);             // runner-up among the scored rows: other chunks, and the winner's own
-                T H2 = s2 < inf_v<T>() ? (s2 + hx[q]) - eps * (T(1) + m_abs(s2) + hx[q]) : inf_v<T>();
-                if (cutR) { const T dx = edgeR - xq[q]; H2 = min_t(H2, dx > T(0) ? T(0.5) * dx * dx * (T(1) - T(8) * eps) : T(0)); }
-                if (cutL) { const T dx = xq[q] - edgeL; H2 = min_t(H2, dx > T(0) ? T(0.5) * dx * dx * (T(1) - T(8) * eps) : T(0)); }
-                if (H2 < inf_v<T>()) { A = (H2 - H1) - T(3) * E1; S = m_sqrt(T(2) * H1) + m_sqrt(T(2) * max_t(H2, T(0))); }
-                else                 { A = inf_v<T>(); S = T(0); }      // no other target at all
+                T hu = inf_v<T>();                          // rows beyond a side that the bound ended: at least 0.5 dx^2 away
+                if (cutR) { const T dx = edgeR - xq[q]; hu = min_t(hu, dx > T(0) ? T(0.5) * dx * dx * (T(1) - T(8) * eps) : T(0)); }
+                if (cutL) { const T dx = xq[q] - edgeL; hu = min_t(hu, dx > T(0) ? T(0.5) * dx * dx * (T(1) - T(8) * eps) : T(0)); }
+                T H1c;
+                bq = cert_from_scores(bv, s2, hx[q], hu, ct.dcum + (size_t)cloud * ct.dstride + 2 * ct.k, H1c);
             }
-            const T bq = cert_budget(A, S, H1c, hx[q], ct.dcum + (size_t)cloud * ct.dstride + 2 * ct.k);
             // no certificate: -(k + 2) says "searched at iteration k" -- spent for every later iteration, not searched twice in this one
             ct.q[(size_t)cloud * n_full + qi[q]] = bq > T(0) ? bq : cert_mark<T>(ct.k);
             if (bq > T(0)) qmin = min_t(qmin, bq); else ++nunc;
@@ -1279,13 +1294,8 @@ __device__ __forceinline__ int search_point(const PointSearch<T>& ps, const int 
         }
         bs = __shfl(j1, win);
         const T s2 = wave_min(lane == win ? b2 : b1);
-        const T E1 = eps * (T(1) + m_abs(bv) + hx);
-        const T H1 = max_t((bv + hx) + E1, T(0));
-        T H2 = s2 < inf_v<T>() ? (s2 + hx) - eps * (T(1) + m_abs(s2) + hx) : inf_v<T>();
-        H2 = min_t(H2, h_edge);
-        T A = inf_v<T>(), S = T(0);
-        if (H2 < inf_v<T>()) { A = (H2 - H1) - T(3) * E1; S = m_sqrt(T(2) * H1) + m_sqrt(T(2) * max_t(H2, T(0))); }
-        budget = cert_budget(A, S, H1, hx, ps.ct.dcum + (size_t)cloud * ps.ct.dstride + 2 * ps.ct.k);
+        T H1c;
+        budget = cert_from_scores(bv, s2, hx, h_edge, ps.ct.dcum + (size_t)cloud * ps.ct.dstride + 2 * ps.ct.k, H1c);
     }
     if (lane == 0) {
         if (ps.pairs) atomicAdd(ps.pairs + (blockIdx.x & (DICP_PAIR_SHARDS - 1)), (unsigned long long)(r1 - r0));

@@ -233,12 +233,12 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
         """Untimed calls at the timed call's own shapes until three in a row agree to 3 %: the caching allocator then owns
         the K-sized buffers (the first use of a new size is a synchronous hipMalloc) and the chip is in its steady state
         (back-to-back calls get faster for a while on a cold box: scripts/call_repeat_diag.py).  Same count on every rank."""
-        calls, recent = 0, []
+        calls, recent, held = 0, [], None
         while calls < most:
             sync()
             t_w = time.perf_counter()
-            run_call(icp_obj, src, tgt, T0, cw)
-            sync()
+            held = run_call(icp_obj, src, tgt, T0, cw)      # (the previous call's results stay alive during the next one, as in timed(): the
+            sync()                                           #  allocator then owns room for two result sets before the first timed call)
             recent = (recent + [time.perf_counter() - t_w])[-3:]
             calls += 1
             done = calls >= least and max(recent) <= 1.03 * min(recent)

@@ -75,8 +75,8 @@ class ICP:
         assert dim == 2 or dim == 3, "dim must be 2 or 3"                                # ICP.py:79
         # weight=None on tensor inputs: the weights are all 1 -- the loop is told so (w0 = None) instead of reading a tensor of ones
         unit_w = (weight is None and isinstance(source, torch.Tensor) and isinstance(target, torch.Tensor) and len(source) > 0 and len(target) > 0
-                  and not self.source_zeroes_are_pad)
-        source, target, T_init, w_pts, rows = self._batch(source, target, T_init, weight)   # ICP.py:85
+                  and not self.source_zeroes_are_pad and not (self.nn.differentiable and self.nn.use_gumbel))
+        source, target, T_init, w_pts, rows = self._batch(source, target, T_init, weight, unit_weights=unit_w)   # ICP.py:85
         assert source.dtype == target.dtype == T_init.dtype                              # ICP.py:96
         if self.icp_type == 'pt2pl':
             assert target.shape[2] == 6                                                  # ICP.py:103
@@ -86,7 +86,8 @@ class ICP:
             raise ValueError("Invalid loss name: {}".format(loss_fn['name']))            # loss.py:19
         home = source.device
         dev = home if source.is_cuda else compute_device()
-        source, target, T_init, w_pts = (t.to(dev) for t in (source, target, T_init, w_pts))
+        source, target, T_init = (t.to(dev) for t in (source, target, T_init))
+        w_pts = w_pts.to(dev) if w_pts is not None else None
         src_rows, tgt_rows = self._device_rows(rows, dev)
 
         if dim == 2:                                                                     # ICP.py:107-116
@@ -100,7 +101,7 @@ class ICP:
         prebuilt = None
         if not (self.nn.differentiable and self.nn.use_gumbel):
             target = target.contiguous()
-            wants_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (source, target, T_init, w_pts))
+            wants_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (source, target, T_init, w_pts) if t is not None)
             source = source.contiguous()
             prebuilt = prebuild_search(source, target, self.knn_variant, wants_grad and bool(self.bwd_window), T_init, src_rows, tgt_rows)
         cfg = LoopConfig(
@@ -118,7 +119,7 @@ class ICP:
             T, deltas, weights, costs, converged, iterations, matched = icp_loop_gumbel(
                 source, target, T_init, w_pts, cfg, self.nn.eps, self.nn.tau, inject_U=getattr(self.nn, "_inject_U", None))
         else:
-            T, deltas, weights, costs, converged, iterations, matched = ICPLoop.apply(source, target, T_init, None if unit_w else w_pts, cfg)
+            T, deltas, weights, costs, converged, iterations, matched = ICPLoop.apply(source, target, T_init, w_pts, cfg)
 
         if self.verbose:                                                                 # ICP.py:262-264
             print("ICP converged in {} iterations".format(deltas.shape[1]))
@@ -218,10 +219,10 @@ class ICP:
                                % (tuple(w.shape), tuple(source_b.shape[:2])))
         return w if w.dtype == source_b.dtype else w.to(source_b.dtype)
 
-    def _batch(self, source, target, T_init, weight):
+    def _batch(self, source, target, T_init, weight, unit_weights=False):
         """As batch_size_handling, with ONE weight per point (what the kernels consume), and the clouds' own lengths:
         -> (source_b, target_b, T_b, w, rows); rows = None, or (source lengths | None, target lengths | None, n_max, m_max)
-        when a list was padded."""
+        when a list was padded.  unit_weights (tensor inputs, weight None): w is not built (None) -- the caller knows it is all ones."""
         if weight is not None:                                                           # ICP.py:321-326
             if isinstance(source, list):
                 assert len(source) == len(weight), "weight must be list of same length as source"
@@ -271,10 +272,10 @@ class ICP:
             src_len = [int(p_i.shape[0]) for p_i in pts]
         elif source.dim() == 2 and source.shape[1] in (3, 6):
             source_b = source[:, :3].unsqueeze(0)
-            w = torch.ones((1, source_b.shape[1]), **opts) if weight is None else self._tensor_weight(weight.unsqueeze(0), source_b)
+            w = (None if unit_weights else torch.ones((1, source_b.shape[1]), **opts)) if weight is None else self._tensor_weight(weight.unsqueeze(0), source_b)
         elif source.dim() == 3 and source.shape[2] in (3, 6):
             source_b = source[:, :, :3]
-            w = torch.ones(source_b.shape[:2], **opts) if weight is None else self._tensor_weight(weight, source_b)
+            w = (None if unit_weights else torch.ones(source_b.shape[:2], **opts)) if weight is None else self._tensor_weight(weight, source_b)
         else:
             raise ValueError("source must be (n x 3/6) or (N x n x 3/6) or list len(N) (n_N x 3/6)")
 

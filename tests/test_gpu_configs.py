@@ -323,3 +323,32 @@ def test_unit_weights_are_the_tensor_of_ones(N, n, icp_type):
     assert torch.equal(a[0]["stats"]["matched_ratio"], b[0]["stats"]["matched_ratio"])
     for ga, gb in ((a[1], b[1]), (a[2], b[2])):
         np.testing.assert_allclose(npy(ga), npy(gb), rtol=0, atol=2e-6 * max(1.0, float(gb.abs().max())))
+
+
+def test_match_certificates_across_history_slabs(monkeypatch):
+    """The per-iteration histories are cut into slabs (HIST_CHUNK_BYTES); the matches of a certified iteration start as the previous
+    iteration's, also when that one sits in another slab: with slabs of 2 and of 3 iterations the certified loop returns the bits of the
+    uncut, everything-searched call."""
+    N, n, K = 40, 16384, 9
+    src, tgt = make_pairs(N, n, n, seed=9)
+    T0 = torch.eye(4, device=DEV).repeat(N, 1, 1)
+
+    def run(reuse):
+        icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
+        icp.const_iter = True
+        icp.reuse_matches = reuse
+        S, Tg = src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True)
+        out = icp.icp(S, Tg, T0, **KW)
+        out["T"].sum().backward()
+        return out, S.grad, Tg.grad, icp.knn_stats
+
+    ref = run(False)
+    for per_slab in (2, 3):
+        monkeypatch.setattr(_ops, "HIST_CHUNK_BYTES", per_slab * N * n * 4)
+        got = run(True)
+        monkeypatch.undo()
+        assert "searched_again" in got[3]
+        for key in ("T", "deltas", "weights", "costs", "pc"):
+            assert torch.equal(ref[0][key], got[0][key]), (per_slab, key)
+        for ga, gb in ((ref[1], got[1]), (ref[2], got[2])):
+            np.testing.assert_allclose(npy(gb), npy(ga), rtol=0, atol=2e-6 * max(1.0, float(ga.abs().max())))

@@ -42,7 +42,15 @@ def compute_device():
     return torch.device("cuda", torch.cuda.current_device())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """The current HIP stream of the current device as a handle (torch.cuda.current_stream() builds a Stream object: ~10 us per call, and
+    a call of the loop asks a dozen times)."""
+    if _raw_stream is not None and _raw_device is not None:
+        return ctypes.c_void_p(_raw_stream(_raw_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -567,6 +575,7 @@ class ICPLoop(torch.autograd.Function):
             segs = _segments(Kmax, cuts)
             done_segs = []
             pending, host_cnt = None, None   # tolerance mode: the segment whose convergence counters are still in flight
+            LB, LBref, Pref = None, None, ctypes.byref(P)
             for (k0, k1) in segs:
                 j = k0 // kc
                 if j == len(w_slabs):
@@ -590,26 +599,29 @@ class ICPLoop(torch.autograd.Function):
                     qorders.append(qorder)
                 seg_q.append(len(qorders) - 1)
                 base = j * kc                                         # virtual bases: slab pointer minus its first iteration
-                LB = _lib.LoopBuffers(
-                    src=_p(src), tgt=_p(tgt), w_init=_p(w0c), c=c, K=Kmax, knn_variant=kind | (cfg.knn_variant & 0xff00) | ((0 if cfg.small_loop else 1) << 25), m_pad=m_pad,
-                    tgt4=_p(tgt4), tperm=_p(sweep.tperm) if sweep else None, qorder=_p(qorder),
-                    bucket=_p(sweep.bucket) if sweep else None, brange=_p(sweep.brange) if sweep else None,
-                    nbkt=SweepIndex.NBKT, idx_per_iter=int(need_grad), pairs=_p(sweep.pair_shards) if sweep else None,
-                    spos=ctypes.c_void_p(spos_slabs[j].data_ptr() - base * N * n * 4) if keep_spos else _p(spos_once),
-                    poses=_p(poses), deltas=_p(deltas), costs=_p(costs), areg=_p(areg), alive=_p(alive), converged=_p(converged),
-                    iterations=_p(iterations), matched_ratio=_p(matched), n_start=_p(n_start), n_matched=_p(n_matched),
-                    idx=(ctypes.c_void_p(idx_slabs[j].data_ptr() - base * N * n * 4) if need_grad else _p(idx_once)) if keep_idx else None,
-                    tgt_sorted=_p(sweep.tgt_s) if sweep is not None else None, tgt_sorted_stride=sweep.row_stride if sweep is not None else 0,
-                    cert_q=_p(certs["q"]) if use_certs else None, cert_qu=_p(certs["qu"]) if use_certs else None,
-                    cert_count=_p(certs["count"]) if use_certs else None,
-                    rmax=_p(certs["rmax"]) if certs else None, dcum=_p(certs["dcum"]) if certs else None,
-                    cert_reset=int(k0 == cert_from),
-                    spos_prev0=_p(spos_slabs[(k0 - 1) // kc][(k0 - 1) % kc]) if (keep_spos and k0 > 0) else None,
-                    w=ctypes.c_void_p(w_slabs[j].data_ptr() - base * n * es), w_iter=n, w_stride=kc * n,
-                    w_prev0=_p(w_slabs[(k0 - 1) // kc][:, (k0 - 1) % kc]) if k0 > 0 else None,
-                    partials=_p(partials), counters=_p(counters), events=events, center=_p(center), poses_search=_p(poses_c),
-                    src_rows=_p(cfg.src_rows), tgt_rows=_p(cfg.tgt_rows))
-                _lib.check(lib.dicp_icp_forward(code, ctypes.byref(P), ctypes.byref(LB), N, n, m, int(cfg.dim), int(cfg.const_iter),
+                if LB is None:      # the fields that do not change from segment to segment (building the struct is ~20 us of host time)
+                    LB = _lib.LoopBuffers(
+                        src=_p(src), tgt=_p(tgt), w_init=_p(w0c), c=c, K=Kmax, knn_variant=kind | (cfg.knn_variant & 0xff00) | ((0 if cfg.small_loop else 1) << 25), m_pad=m_pad,
+                        tgt4=_p(tgt4), tperm=_p(sweep.tperm) if sweep else None,
+                        bucket=_p(sweep.bucket) if sweep else None, brange=_p(sweep.brange) if sweep else None,
+                        nbkt=SweepIndex.NBKT, idx_per_iter=int(need_grad), pairs=_p(sweep.pair_shards) if sweep else None,
+                        poses=_p(poses), deltas=_p(deltas), costs=_p(costs), areg=_p(areg), alive=_p(alive), converged=_p(converged),
+                        iterations=_p(iterations), matched_ratio=_p(matched), n_start=_p(n_start), n_matched=_p(n_matched),
+                        tgt_sorted=_p(sweep.tgt_s) if sweep is not None else None, tgt_sorted_stride=sweep.row_stride if sweep is not None else 0,
+                        rmax=_p(certs["rmax"]) if certs else None, dcum=_p(certs["dcum"]) if certs else None,
+                        w_iter=n, w_stride=kc * n,
+                        partials=_p(partials), counters=_p(counters), events=events, center=_p(center), poses_search=_p(poses_c),
+                        src_rows=_p(cfg.src_rows), tgt_rows=_p(cfg.tgt_rows))
+                    LBref = ctypes.byref(LB)
+                LB.qorder = _p(qorder)
+                LB.spos = ctypes.c_void_p(spos_slabs[j].data_ptr() - base * N * n * 4) if keep_spos else _p(spos_once)
+                LB.idx = (ctypes.c_void_p(idx_slabs[j].data_ptr() - base * N * n * 4) if need_grad else _p(idx_once)) if keep_idx else None
+                LB.cert_q, LB.cert_qu, LB.cert_count = (_p(certs["q"]), _p(certs["qu"]), _p(certs["count"])) if use_certs else (None, None, None)
+                LB.cert_reset = int(k0 == cert_from)
+                LB.spos_prev0 = _p(spos_slabs[(k0 - 1) // kc][(k0 - 1) % kc]) if (keep_spos and k0 > 0) else None
+                LB.w = ctypes.c_void_p(w_slabs[j].data_ptr() - base * n * es)
+                LB.w_prev0 = _p(w_slabs[(k0 - 1) // kc][:, (k0 - 1) % kc]) if k0 > 0 else None
+                _lib.check(lib.dicp_icp_forward(code, Pref, LBref, N, n, m, int(cfg.dim), int(cfg.const_iter),
                                                 float(cfg.tolerance), k0, k1, st), "dicp_icp_forward")
                 done_segs.append((k0, k1))
                 if not cfg.const_iter:
@@ -715,7 +727,15 @@ class ICPLoop(torch.autograd.Function):
             ev = cfg.timing_events
             events = ev.handles(Kmax) if ev is not None else None
             have, form, fresh = 0, None, 1
+            # neighbouring segments of one form inside one history slab run as ONE library call (the forward cut them where the host had to
+            # act -- a new query order, a convergence check -- and none of that concerns the reverse sweep)
+            runs = []
             for (k0, k1, q), w_form in zip(reversed(segs), reversed(windowed)):
+                if runs and runs[-1][3] == w_form and runs[-1][0] == k1 and (k0 // kc) == ((runs[-1][1] - 1) // kc) and k1 > k0:
+                    runs[-1] = (k0, runs[-1][1], q, w_form)
+                else:
+                    runs.append((k0, k1, q, w_form))
+            for (k0, k1, q, w_form) in runs:
                 if have and w_form != form:     # the partials of the other form have another block count: fold them in here
                     gpose += bwdp[form].sum(dim=1)[:, :12].to(torch.float64)
                     have = 0

@@ -21,7 +21,7 @@ if len(sys.argv) > 1:
     pr = cProfile.Profile(); pr.enable()
     for _ in range(20): call()
     pr.disable(); torch.cuda.synchronize()
-    st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(28)
+    st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(16); st.sort_stats("cumulative").print_stats(30)
     t0 = time.perf_counter()
     for _ in range(50): call()
     t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()

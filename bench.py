@@ -124,9 +124,12 @@ def run_call(icp, src, tgt, T0, world):
     s = src.detach().requires_grad_(True)
     t = tgt.detach().requires_grad_(True)
     out = icp.icp(s, t, T0, trim_dist=TRIM, loss_fn=LOSS, dim=3)
+    # every rank holds the same number of clouds: the shard sizes are known, no size exchange (and no host sync) before the gather.  The
+    # poses are final once the forward is queued: the all-gather goes out on the communicator's stream NOW and runs under the backward
+    T_all, work = (ddist.gather_poses_async(out["T"].detach(), total=src.shape[0] * abs(world), force=True) if world != 1 else (out["T"].detach(), None))
     out["T"].sum().backward()
-    # every rank holds the same number of clouds: the shard sizes are known, no size exchange (and no host sync) before the gather
-    T_all = ddist.gather_poses(out["T"].detach(), total=src.shape[0] * abs(world), force=True) if world != 1 else out["T"].detach()
+    if work is not None:
+        work.wait()
     return out, T_all, s.grad, t.grad
 
 

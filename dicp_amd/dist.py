@@ -106,6 +106,26 @@ def gather_poses(T_local, total=None, group=None, force=False, grad_mode="slice"
     return _GatherPoses.apply(T_local, counts, group, grad_mode)
 
 
+def gather_poses_async(T_local, total=None, group=None, force=False, counts=None):
+    """The same all-gather for a caller that does not differentiate through it and has other work to queue first (the backward of a
+    shard-local loss): -> (T_all, work) with the collective in flight on the communicator's stream; work.wait() orders the current
+    stream behind it (work is None when nothing was communicated).  Equal shards only (`total` or `counts`)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
+        return T_local, None
+    world = dist.get_world_size(group)
+    if counts is None:
+        if total is None:
+            raise ValueError("gather_poses_async needs the shard sizes (total or counts): it does not exchange them")
+        counts = [shard_bounds(total, g, world)[1] - shard_bounds(total, g, world)[0] for g in range(world)]
+    counts = [int(c) for c in counts]
+    if min(counts) != max(counts) or T_local.shape[0] != counts[dist.get_rank(group)]:
+        raise ValueError("gather_poses_async: equal shards only, and this rank must hold its own (%s, this rank holds %d)" % (counts, T_local.shape[0]))
+    x = T_local.detach().contiguous()
+    recv = torch.empty((world * counts[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    work = dist.all_gather_into_tensor(recv, x, group=group, async_op=True)
+    return recv, work
+
+
 def icp_sharded(icp_fn, source, target, T_init, total=None, group=None, counts=None, grad_mode="slice", **kwargs):
     """Run `icp_fn(source, target, T_init, **kwargs)` on this rank's shard (the caller passes the shard, e.g. via
     shard()) and add "T_all": the poses of the whole batch on every rank.  An EMPTY shard (more ranks than clouds) is

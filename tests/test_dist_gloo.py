@@ -132,3 +132,32 @@ def test_balanced_bounds():
         assert max(loads) <= sum(costs) / world + max(costs)
     assert ddist.balanced_bounds([5, 5], 4)[-1][1] == 2          # more ranks than clouds: empty shards are legal
     assert ddist.shard(list(range(6)), rank=1, world=2, bounds=[(0, 4), (4, 6)]) == [4, 5]
+
+
+def async_worker(rank, world, port, total, out_dir):
+    """gather_poses_async: the collective is issued, other work is queued, wait() -> the same poses as the blocking gather."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(100 + rank)
+        lo, hi = ddist.shard_bounds(total, rank, world)
+        T_local = torch.rand((hi - lo, 4, 4), generator=g, dtype=torch.float64)
+        T_all, work = ddist.gather_poses_async(T_local, total=total)
+        other = (T_local * 2.0).sum()                    # (what a caller queues while the collective is in flight)
+        assert work is not None
+        work.wait()
+        ref = ddist.gather_poses(T_local, total=total)
+        assert torch.equal(T_all, ref) and float(other) == float((T_local * 2.0).sum())
+        with pytest.raises(ValueError):
+            ddist.gather_poses_async(T_local)            # no sizes given: it does not exchange them
+        np.save(os.path.join(out_dir, "async_%d.npy" % rank), T_all.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_async_pose_gather(tmp_path):
+    world, total = 2, 6
+    mp.spawn(async_worker, args=(world, free_port(), total, str(tmp_path)), nprocs=world, join=True)
+    a, b = (np.load(str(tmp_path / ("async_%d.npy" % r))) for r in range(world))
+    np.testing.assert_array_equal(a, b)
+    assert a.shape == (total, 4, 4)

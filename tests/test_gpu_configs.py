@@ -352,3 +352,23 @@ def test_match_certificates_across_history_slabs(monkeypatch):
             assert torch.equal(ref[0][key], got[0][key]), (per_slab, key)
         for ga, gb in ((ref[1], got[1]), (ref[2], got[2])):
             np.testing.assert_allclose(npy(gb), npy(ga), rtol=0, atol=2e-6 * max(1.0, float(ga.abs().max())))
+
+
+def test_certified_loop_against_the_oracle():
+    """The loop the benchmark runs (sweep + match certificates + unit weights, 8 iterations, forward and backward) against the CPU
+    oracle on two clouds of a 36-cloud batch: poses within 1e-4, gradients within the float32 bar (north star)."""
+    N, n, K = 36, 16384, 8
+    src, tgt = make_pairs(N, n, n, seed=13)
+    icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
+    icp.const_iter = True
+    S, Tg = src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True)
+    out = icp.icp(S, Tg, torch.eye(4, device=DEV).repeat(N, 1, 1), **KW)
+    out["T"].sum().backward()
+    assert "searched_again" in icp.knn_stats and int(icp.knn_stats["searched_again"].sum()) > 0
+    T_ref, gs_ref, gt_ref = oracle_slice(src[20:22], tgt[20:22], K)
+    np.testing.assert_allclose(npy(out["T"][20:22]), T_ref.numpy(), rtol=0, atol=1e-4)
+    for got, want in ((S.grad[20:22].cpu(), gs_ref), (Tg.grad[20:22].cpu(), gt_ref)):
+        scale = max(1.0, float(want.abs().max()))
+        err = (got - want).abs().amax(dim=2)
+        assert float((err > 1e-3 * scale).float().mean()) < 1e-3
+        assert float(err.median()) < 1e-5 * scale

@@ -76,7 +76,9 @@ class ICP:
         # weight=None on tensor inputs: the weights are all 1 -- the loop is told so (w0 = None) instead of reading a tensor of ones
         unit_w = (weight is None and isinstance(source, torch.Tensor) and isinstance(target, torch.Tensor) and len(source) > 0 and len(target) > 0
                   and not self.source_zeroes_are_pad and not (self.nn.differentiable and self.nn.use_gumbel))
+        self._weight_per_cloud = False
         source, target, T_init, w_pts, rows = self._batch(source, target, T_init, weight, unit_weights=unit_w)   # ICP.py:85
+        per_cloud_w = self._weight_per_cloud and source.shape[1] > 1
         assert source.dtype == target.dtype == T_init.dtype                              # ICP.py:96
         if self.icp_type == 'pt2pl':
             assert target.shape[2] == 6                                                  # ICP.py:103
@@ -121,6 +123,13 @@ class ICP:
         else:
             T, deltas, weights, costs, converged, iterations, matched = ICPLoop.apply(source, target, T_init, w_pts, cfg)
 
+        if per_cloud_w:
+            # an (N,1) weight stays (N,1) in the reference, so its "matches at the start" (ICP.py:248,269: sum over dim 1 of
+            # w_init > thresh) counts ONE per cloud where the kernels, handed the expanded (N,n) tensor, count n: same
+            # numerator, the reference's denominator (the kernels' ratio is float32(int / int): the integer is recovered exactly)
+            n_pts = float(source.shape[1])
+            on = (w_pts[:, 0] > self.match_ratio_thresh) & (matched > 0)
+            matched = torch.where(on, torch.round(matched * n_pts), matched)
         if self.verbose:                                                                 # ICP.py:262-264
             print("ICP converged in {} iterations".format(deltas.shape[1]))
             print("Final del_T_ts: {}".format(torch.linalg.norm(deltas[:, -1])))
@@ -206,18 +215,24 @@ class ICP:
                 out.append(torch.tensor([min(v + extra, full) for v in lens], dtype=torch.int32).to(dev))
         return out[0], out[1]
 
-    @staticmethod
-    def _tensor_weight(w, source_b):
+    def _tensor_weight(self, w, source_b):
         """A caller-supplied weight TENSOR (the list form is cast item by item below).  The reference multiplies it into the
         residuals with torch broadcasting (ICP.py:169): a shape that does not broadcast against (N,n) raises there, a
         different float dtype is promoted.  The kernels read raw (N,n) buffers of the cloud dtype, so both are settled
         here: the same error for a wrong shape, a cast (differentiable) for a different dtype."""
         if not isinstance(w, torch.Tensor):
             raise TypeError("weight must be a tensor for a tensor source (got %s)" % (type(w),))
-        if tuple(w.shape) != tuple(source_b.shape[:2]):
-            raise RuntimeError("The size of tensor weight %s must match the source points %s"
-                               % (tuple(w.shape), tuple(source_b.shape[:2])))
-        return w if w.dtype == source_b.dtype else w.to(source_b.dtype)
+        want = tuple(source_b.shape[:2])
+        if tuple(w.shape) != want:
+            # ICP.py:169 multiplies with broadcasting: after the row-count assert (ICP.py:326) the one other shape that
+            # multiplies against the (N,n) trim / loss weights is one weight per cloud, (N,1) -- and only for pt2pl (pt2pt
+            # repeats the weight x3 along dim 1 first, ICP.py:508-509, and (N,3) no longer broadcasts against (N,3n))
+            if w.dim() == 2 and w.shape[0] == want[0] and w.shape[1] == 1 and (self.icp_type == 'pt2pl' or want[1] == 1):
+                self._weight_per_cloud = True
+                w = w.expand(want)
+            else:
+                raise RuntimeError("The size of tensor weight %s must match the source points %s" % (tuple(w.shape), want))
+        return (w if w.dtype == source_b.dtype else w.to(source_b.dtype)).contiguous()
 
     def _batch(self, source, target, T_init, weight, unit_weights=False):
         """As batch_size_handling, with ONE weight per point (what the kernels consume), and the clouds' own lengths:

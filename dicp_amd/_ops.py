@@ -491,6 +491,9 @@ class ICPLoop(torch.autograd.Function):
         Kmax = int(cfg.max_iterations)
         assert Kmax >= 1, "max_iterations must be at least 1"
         need_grad = any(ctx.needs_input_grad[:4])
+        if cfg.stats_out is not None:       # the statistics describe THIS call (an earlier call's certificate counters must not outlive it)
+            for key in ("knn_pairs", "searched_again", "budgets"):
+                cfg.stats_out.pop(key, None)
         ctx.set_materialize_grads(False)    # no zero tensors for the six non-differentiable outputs (168 MB for the weights)
 
         with torch.cuda.device(dev):

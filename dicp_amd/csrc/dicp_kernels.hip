@@ -617,7 +617,8 @@ __global__ __launch_bounds__(LI_THREADS) void loop_init_kernel(const T* __restri
                 d2 += (h - l) * (h - l);
                 pn += p0[k] * p0[k];
             }
-            // (an empty or non-finite cloud: radius inf or NaN -> nothing is ever certified)
+            // (a cloud with an infinite coordinate: radius inf -> nothing is ever certified.  NaN points are skipped by the min / max
+            //  comparisons above, so the box covers the finite points only; a NaN query scores NaN against every target and never gets a budget)
             const T rad = T(0.5) * m_sqrt(d2) * (T(1) + T(8) * CertUlp<T>::v) + T(8) * CertUlp<T>::v * m_sqrt(pn);
             T* ro = rmax + (size_t)cloud * 4;
             ro[0] = rad; ro[1] = p0[0]; ro[2] = p0[1]; ro[3] = p0[2];
@@ -1260,6 +1261,20 @@ __device__ __forceinline__ int search_point(const PointSearch<T>& ps, const int 
         fa = fa < T(0) ? T(0) : (fa > T(ps.nbkt) ? T(ps.nbkt) : fa);
         r0 = min(bk[(int)fa], m);
         r1 = fb >= T(ps.nbkt) ? m : min(max(bk[(int)fb], r0), m);
+        // an equal-width table bucket can hold thousands of rows (an uneven cloud; a ragged batch's one far pad row stretches the table's
+        // span a thousandfold, so every real row sits in a bucket or two): finish both bounds by bisection on the sorted keys, as
+        // sweep_unit does for its start.  Rows left of xq - R and right of xq + R cannot beat the kept minimum (thr), so any r0 at or
+        // below the first row with x >= xq - R and any r1 at or above the first row with x > xq + R keep the search exact.
+        // (wave-uniform; on even clouds the slab is already a few tiles and the loops do not run)
+        if (r1 - r0 > 4 * WAVE) {
+            const T xa = xq - R, xb = xq + R;
+            int lo = r0, hi = r1;
+            while (hi - lo > WAVE) { const int mid = (lo + hi) >> 1; if (tg[mid].x < xa) lo = mid + 1; else hi = mid; }
+            r0 = max(lo - 1, r0);                               // (one row of slack: the keys were rounded when they were packed)
+            lo = r0; hi = r1;
+            while (hi - lo > WAVE) { const int mid = (lo + hi) >> 1; if (tg[mid].x <= xb) lo = mid + 1; else hi = mid; }
+            r1 = min(hi + 1, r1);
+        }
         if (r0 > 0 || r1 < m) h_edge = (thr + hx) * (T(1) - T(8) * eps);
     }
 
@@ -3525,7 +3540,7 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
             int cfg = (B->knn_variant >> 8) & 0xff;
             int32_t* spos_k = B->spos ? B->spos + (B->idx_per_iter ? (size_t)k * N * n : 0) : nullptr;
             const bool sorted_rows = B->tgt_sorted && spos_k;      // accumulate gathers 32-byte aligned rows of the sorted copy at the sorted positions
-            if (!sorted_rows && !B->idx) return DICP_ERR_NULL;
+            if (!sorted_rows && !B->idx) { set_launch_events(nullptr, nullptr); return DICP_ERR_NULL; }
             // src_s: the source rows in qorder's slot order (dicp_query_order wrote them): coalesced query loads
             const void* qsrc = B->src;
             if (B->src_s && B->qorder) { qsrc = B->src_s; cfg |= DICP_SWEEP_SRC_SORTED; }
@@ -3536,8 +3551,11 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
             int32_t* count_k = B->cert_count ? B->cert_count + (size_t)k * 2 * CERT_SHARDS : nullptr;
             if (cert) {
                 if (!fresh && k == k0 && B->idx_per_iter) {     // this call's first matches start as the previous call's last (later ones: handed on by accumulate)
-                    if (!B->spos_prev0) return DICP_ERR_NULL;
-                    if (hipMemcpyAsync(spos_k, B->spos_prev0, (size_t)N * n * sizeof(int32_t), hipMemcpyDeviceToDevice, st) != hipSuccess) return -(int)hipGetLastError();
+                    if (!B->spos_prev0) { set_launch_events(nullptr, nullptr); return DICP_ERR_NULL; }
+                    if (hipMemcpyAsync(spos_k, B->spos_prev0, (size_t)N * n * sizeof(int32_t), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+                        set_launch_events(nullptr, nullptr);        // (thread-local: the next launch on this thread must not carry them)
+                        return -(int)hipGetLastError();
+                    }
                 }
                 begin_launch();
                 rc = sweep_launch(dtype, qsrc, pose_s, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, N, n, m, B->m_pad, nullptr, spos_k,

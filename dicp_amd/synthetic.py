@@ -38,3 +38,53 @@ def make_pairs(N, n, m, seed=0, dtype=torch.float32, noise=0.01, max_rot=0.05, m
     if device is not None:
         src, tgt = src.to(device), tgt.to(device)
     return src, tgt
+
+
+def make_scene_pairs(N, n, m, seed=0, dtype=torch.float32, noise=0.01, max_rot=0.05, max_trans=0.3, device=None, first=0,
+                     half=10.0, height=3.0, clutter=0.10):
+    """LiDAR-like structured scenes in make_pairs' format: a ground plane (40 % of the target points), four walls (12.5 % each:
+    two of them perpendicular to x, i.e. all their points share ONE x -- the sorted sweep's documented worst case, two
+    perpendicular to y) and `clutter` of the points uniform in the volume.  Normals are the surfaces' own (ground +z, walls
+    pointing inwards; random for the clutter).  Points carry N(0, noise^2) sensor noise off their surface; the source is n
+    target rows + noise moved by a small SE(3), as in make_pairs."""
+    src = torch.empty((N, n, 3), dtype=torch.float64)
+    tgt = torch.empty((N, m, 6), dtype=torch.float64)
+    n_cl = int(round(clutter * m))
+    n_wall = (m - n_cl) * 5 // 36            # 4 walls: 5/9 of the surface points in all, the ground 4/9
+    n_gr = m - n_cl - 4 * n_wall
+    for b in range(N):
+        g = torch.Generator().manual_seed(100000 * seed + 7777 + first + b)
+        u = lambda k: torch.rand((k,), generator=g, dtype=torch.float64)                  # noqa: E731
+        pts, nrm = [], []
+        pts.append(torch.stack(((u(n_gr) - 0.5) * 2 * half, (u(n_gr) - 0.5) * 2 * half, torch.zeros(n_gr, dtype=torch.float64)), dim=1))
+        nrm.append(torch.tensor([0.0, 0.0, 1.0], dtype=torch.float64).repeat(n_gr, 1))
+        for axis, side in ((0, -1.0), (0, 1.0), (1, -1.0), (1, 1.0)):
+            w = torch.empty((n_wall, 3), dtype=torch.float64)
+            w[:, axis] = side * half
+            w[:, 1 - axis] = (u(n_wall) - 0.5) * 2 * half
+            w[:, 2] = u(n_wall) * height
+            nv = torch.zeros(3, dtype=torch.float64)
+            nv[axis] = -side
+            pts.append(w)
+            nrm.append(nv.repeat(n_wall, 1))
+        c = torch.stack(((u(n_cl) - 0.5) * 2 * half, (u(n_cl) - 0.5) * 2 * half, u(n_cl) * height), dim=1)
+        cn = torch.randn((n_cl, 3), generator=g, dtype=torch.float64)
+        pts.append(c)
+        nrm.append(cn / cn.norm(dim=1, keepdim=True))
+        P, Nv = torch.cat(pts, dim=0), torch.cat(nrm, dim=0)
+        P = P + noise * torch.randn((m, 3), generator=g, dtype=torch.float64) * Nv      # off-surface sensor noise
+        order = torch.randperm(m, generator=g)                                            # (rows in no particular order, like a scan's returns)
+        P, Nv = P[order], Nv[order]
+        pick = torch.randint(0, m, (n,), generator=g)
+        s_t = P[pick] + noise * torch.randn((n, 3), generator=g, dtype=torch.float64)
+        ax = torch.randn(3, generator=g, dtype=torch.float64)
+        ang = float(torch.rand(1, generator=g, dtype=torch.float64)) * max_rot
+        trans = (torch.rand(3, generator=g, dtype=torch.float64) - 0.5) * 2.0 * max_trans
+        C = _rot(ax, ang)
+        src[b] = (s_t - trans) @ C
+        tgt[b, :, :3] = P
+        tgt[b, :, 3:] = Nv
+    src, tgt = src.to(dtype), tgt.to(dtype)
+    if device is not None:
+        src, tgt = src.to(device), tgt.to(device)
+    return src, tgt

@@ -65,6 +65,8 @@ def test_bench_two_rank_dry_run(tmp_path):
     assert abs(line["value"] - world * B * K / (med * 1e-3)) <= 1e-4 * line["value"]        # whole-job aggregate over both ranks (call_ms is rounded to 0.1 us)
     assert abs(line["ms_per_step"] - med / K) < 1e-4
     assert "x2" in line["config"]["parallelism"] and line["finite"] is True
+    assert len(line["call_ms_by_rank"]) == world and max(line["call_ms_by_rank"]) <= med + 1e-3     # every rank's own time of the median call
+    assert line["pose_allgather_ms"] is not None and line["pose_allgather_ms"] > 0.0            # the collective, timed alone
     # weak scaling with global cloud seeds: rank g's clouds are clouds g*B .. (g+1)*B of the single-process batch
     for g in range(world):
         want, _ = make_pairs(B, N_PTS, N_PTS, seed=3, dtype=torch.float32, first=g * B)

@@ -372,3 +372,81 @@ def test_certified_loop_against_the_oracle():
         err = (got - want).abs().amax(dim=2)
         assert float((err > 1e-3 * scale).float().mean()) < 1e-3
         assert float(err.median()) < 1e-5 * scale
+
+
+def test_timed_loop_at_its_own_size():
+    """What bench.py times, checked at ITS size: B=256 x 16384 points, K=12 constant iterations (sweep + match certificates
+    from iteration 3 on + unit weights, forward and backward).  (i) the certified loop == the same call with every query
+    searched in every iteration (reuse_matches=False; nn.py:32-35 searches everything): poses, deltas, per-iteration
+    weights, costs, transformed clouds bit for bit, gradients to rounding; (ii) certificates really were engaged and did
+    search something again; (iii) clouds 130 and 251 against the CPU oracle run for the same 12 iterations: pose <= 1e-4,
+    gradients <= 1e-3 of their scale (north star; rows whose float32 argmin flipped: < 0.1 %)."""
+    B, n, K = 256, 16384, 12
+    src, tgt = make_pairs(B, n, n, seed=3, dtype=torch.float32)
+    T0 = torch.eye(4, device=DEV).repeat(B, 1, 1)
+    runs = {}
+    for reuse in (False, True):
+        icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
+        icp.const_iter = True
+        icp.reuse_matches = reuse
+        S, Tg = src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True)
+        out = icp.icp(S, Tg, T0, **KW)
+        out["T"].sum().backward()
+        runs[reuse] = (out, S.grad, Tg.grad, dict(icp.knn_stats))
+    plain, cert = runs[False], runs[True]
+    assert "searched_again" not in plain[3] and "searched_again" in cert[3]
+    again = cert[3]["searched_again"]
+    assert again.shape[0] == K and int(again[:, :64].sum()) > 0 and int(again[:, 64:].sum()) > 0
+    assert int(again[:3].sum()) == 0                        # iterations before the certifying search run plain
+    for key in ("T", "deltas", "weights", "costs", "pc"):
+        assert torch.equal(plain[0][key], cert[0][key]), key
+    for ga, gb in ((plain[1], cert[1]), (plain[2], cert[2])):
+        assert bool(torch.isfinite(gb).all())
+        np.testing.assert_allclose(npy(gb), npy(ga), rtol=0, atol=2e-6 * max(1.0, float(ga.abs().max())))
+    assert cert[3]["knn_pairs"].sum().item() < 0.7 * plain[3]["knn_pairs"].sum().item()
+    for b in (130, 251):
+        T_ref, gs_ref, gt_ref = oracle_slice(src[b:b + 1], tgt[b:b + 1], K)
+        np.testing.assert_allclose(npy(cert[0]["T"][b]), T_ref[0].numpy(), rtol=0, atol=1e-4)
+        for got, want in ((cert[1][b].cpu(), gs_ref[0]), (cert[2][b].cpu(), gt_ref[0])):
+            scale = max(1.0, float(want.abs().max()))
+            err = (got - want).abs().amax(dim=1)
+            assert float((err > 1e-3 * scale).float().mean()) < 1e-3, b
+            assert float(err.median()) < 1e-5 * scale, b
+
+
+def test_config4_full_batch_256_by_65536():
+    """configs[3] at its FULL batch (B=256 x 65536 points; the MFMA variant at this size is timed by scripts/config3_full.py,
+    91 ms per iteration): size-independent properties.  Everything finite; clouds 0 / 128 / 255 of the batch == per-item
+    calls (pose and gradients: every per-cloud stride, the XCD block mapping and the chunked key sort beyond a single
+    cloud); on those clouds the sweep's indices == the brute-force kernel's, index for index."""
+    B, n, K = 256, 65536, 3
+    src, tgt = make_pairs(B, n, n, seed=3, dtype=torch.float32)
+    sd, td = src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True)
+    T0 = torch.eye(4, device=DEV).repeat(B, 1, 1)
+    icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
+    icp.const_iter = True
+    assert _ops.auto_knn_kind(B, n, n) == _lib.KNN_SWEEP
+    out = icp.icp(sd, td, T0, **KW)
+    out["T"].sum().backward()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out["T"]).all() and torch.isfinite(sd.grad).all() and torch.isfinite(td.grad).all())
+    assert bool(torch.isfinite(out["weights"]).all() and torch.isfinite(out["costs"]).all())
+    assert out["weights"].shape == (B, K, n, 1)
+    frac = float(icp.knn_stats["knn_pairs"].sum().item()) / (float(B) * n * n * K)
+    assert frac < 0.2, frac
+    T_full, gs_full, gt_full = out["T"].detach(), sd.grad, td.grad
+    sw = _ops.SweepIndex(td.detach())
+    for b in (0, 128, 255):
+        s1 = src[b:b + 1].to(DEV).requires_grad_(True)
+        t1 = tgt[b:b + 1].to(DEV).requires_grad_(True)
+        one = icp.icp(s1, t1, T0[:1], **KW)
+        one["T"].sum().backward()
+        np.testing.assert_allclose(npy(one["T"]), npy(T_full[b:b + 1]), rtol=0, atol=2e-6)
+        np.testing.assert_allclose(npy(s1.grad), npy(gs_full[b:b + 1]), rtol=0, atol=5e-5 * max(1.0, float(gs_full[b].abs().max())))
+        np.testing.assert_allclose(npy(t1.grad), npy(gt_full[b:b + 1]), rtol=0, atol=5e-5 * max(1.0, float(gt_full[b].abs().max())))
+    # index equality on the three clouds: the batch-wide sweep index against the brute-force kernel on single clouds
+    pose = torch.cat((out["T"].detach()[:, :3, :3].reshape(B, 9), out["T"].detach()[:, :3, 3]), dim=1).contiguous()
+    got = sw.knn(sd.detach(), pose, sw.query_order(sd.detach(), pose))
+    for b in (0, 128, 255):
+        want = _ops.knn(sd.detach()[b:b + 1].contiguous(), pose[b:b + 1].contiguous(), _ops.pack_target(td.detach()[b:b + 1].contiguous()), n, _lib.KNN_VALU)
+        assert torch.equal(got[b:b + 1], want), b

@@ -404,6 +404,8 @@ class LoopConfig:
     cert_from: object = None      # iteration of the certifying search (None: the last re-ordering of the queries)
     reuse_matches: bool = True    # sweep path: match certificates -- an iteration searches only the waves holding a query whose match is not proven
                                   # unchanged since the wave's last search (exact; knn_sweep_kernel CERT)
+    bwd_run: bool = True          # windowed backward: the iterations from bwd_run_from on as ONE launch per group of co-resident clouds (dicp_icp_backward_run)
+    bwd_run_from: object = None   # first iteration of that run (None: the iteration after the last re-ordering of the queries)
     src_rows: object = None       # ragged batches: (N) int32 device tensors, rows of each source / target cloud that take part
     tgt_rows: object = None       # (ICP._batch: the clouds' own lengths; the kernels never touch a pad row)
 
@@ -424,6 +426,7 @@ def _pose_from_T(T):
     return torch.cat((T[:, :3, :3].reshape(N, 9), T[:, :3, 3]), dim=1).contiguous()
 
 
+RUN_DEBUG = False               # scripts/run_phases.py: per-block timestamps of the in-launch runs
 HIST_CHUNK_BYTES = 1 << 29      # per-iteration histories (indices, weights) are allocated in slabs of at most this size
 
 
@@ -492,7 +495,7 @@ class ICPLoop(torch.autograd.Function):
         assert Kmax >= 1, "max_iterations must be at least 1"
         need_grad = any(ctx.needs_input_grad[:4])
         if cfg.stats_out is not None:       # the statistics describe THIS call (an earlier call's certificate counters must not outlive it)
-            for key in ("knn_pairs", "searched_again", "budgets"):
+            for key in ("knn_pairs", "searched_again", "budgets", "bwd_run"):
                 cfg.stats_out.pop(key, None)
         ctx.set_materialize_grads(False)    # no zero tensors for the six non-differentiable outputs (168 MB for the weights)
 
@@ -738,6 +741,38 @@ class ICPLoop(torch.autograd.Function):
                     runs[-1] = (k0, runs[-1][1], q, w_form)
                 else:
                     runs.append((k0, k1, q, w_form))
+            # The run of iterations whose matches hardly change any more (from the iteration after the last query re-ordering on) goes first, as
+            # ONE launch per group of co-resident clouds: points, match rows and accumulating gradients stay on chip over the whole run
+            # (dicp_icp_backward_run; float32, windowed form, inside one history slab).
+            if runs and runs[0][3] and cfg.bwd_run and dt == torch.float32:
+                resorts = [k for k in cfg.sweep_resort if 0 <= k < K]
+                run_lo = (max(resorts) + 1 if resorts else 1) if cfg.bwd_run_from is None else max(0, int(cfg.bwd_run_from))
+                run_lo = max(run_lo, ((K - 1) // kc) * kc)
+                windowed_from = min((a for (a, b, q, wf) in runs if wf and b > a), default=K)
+                run_lo = max(run_lo, windowed_from)
+                if K - run_lo >= 2:
+                    j = (K - 1) // kc
+                    nbytes = int(lib.dicp_run_scratch_bytes(code, N, n, m_pad))
+                    if RUN_DEBUG:       # diagnostics (scripts/run_phases.py): room for per-block, per-iteration timestamps behind the scratch
+                        nblk_run = lib.dicp_window_blocks(code, n, m_pad)
+                        nbytes_all = nbytes + N * nblk_run * (K - run_lo) * 32 + 256
+                        scratch = torch.zeros((nbytes_all,), dtype=torch.uint8, device=dev)
+                        if cfg.stats_out is not None:
+                            cfg.stats_out["bwd_run_debug"] = scratch[nbytes:nbytes + N * nblk_run * (K - run_lo) * 32].view(torch.int64).view(N, nblk_run, K - run_lo, 4)
+                        nbytes = nbytes_all
+                    else:
+                        scratch = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+                    LB = _lib.LoopBuffers(
+                        src=_p(src_s), tgt=_p(tgt_s), w_init=_p(w_s), c=tgt_s.shape[2], K=Kmax, knn_variant=kind, m_pad=m_pad, idx_per_iter=1, qorder=_p(qo),
+                        spos=ctypes.c_void_p(spos_slabs[j].data_ptr() - j * kc * N * n * 4), spos_ref=_p(spos_ref), gts_far=_p(gfar),
+                        poses=_p(poses), deltas=_p(deltas), areg=_p(areg), alive=_p(alive), events=events, src_rows=_p(cfg.src_rows), tgt_rows=_p(cfg.tgt_rows))
+                    _lib.check(lib.dicp_icp_backward_run(code, ctypes.byref(P), ctypes.byref(LB), N, n, m, int(cfg.dim), _p(gpose), _p(gtmp),
+                                                         _p(gsrc_s), _p(slab), _p(gw_s), _p(scratch), nbytes, run_lo, K, st), "dicp_icp_backward_run")
+                    gpose, gtmp = gtmp, gpose           # complete cotangent of pose_run_lo: the next chunk starts without partials
+                    fresh = 0
+                    if cfg.stats_out is not None:
+                        cfg.stats_out["bwd_run"] = (run_lo, K)
+                    runs = [(a, min(b, run_lo), q, wf) for (a, b, q, wf) in runs if a < run_lo]
             for (k0, k1, q, w_form) in runs:
                 if have and w_form != form:     # the partials of the other form have another block count: fold them in here
                     gpose += bwdp[form].sum(dim=1)[:, :12].to(torch.float64)

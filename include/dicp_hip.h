@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define DICP_ABI_VERSION 3   /* 3: per-cloud row counts of ragged batches (src_rows / tgt_rows) on every entry point of the path; the centred and
+#define DICP_ABI_VERSION 4   /* 4: dicp_icp_backward_run / dicp_run_scratch_bytes (a run of backward iterations in one launch).
+                                3: per-cloud row counts of ragged batches (src_rows / tgt_rows) on every entry point of the path; the centred and
                                 uncentred forms of an entry point are one (center may be NULL); the key sort is native for every size and dtype;
                                 timing events are 6 per iteration; the scan / packed / fused-accumulate search forms are gone */
 
@@ -302,6 +303,20 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
 int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_buffers* buf, int N, int n, int m, int dim,
                       double* gpose, double* gpose_tmp, int have_partials, void* gs, void* gb, void* gsrc, void* gtgt, void* gw,
                       void* bwd_partials, int k0, int k1, void* stream);
+/* A RUN of iterations [k0,k1) of the windowed reverse sweep in one launch per group of co-resident clouds (float32; the reverse of
+ * ICP.py:132-260 for iterations whose matches (nn.py:32-35) hardly change any more): every block keeps its slots' points, match rows and
+ * the gradients it accumulates for them on chip over the whole run, the per-cloud chain accumulate_bwd(k) -> step_bwd(k-1) runs inside the
+ * launch.  `buf` as dicp_icp_backward's windowed form (src / w_init / tgt = the sorted copies, spos = virtual base of the
+ * match history, spos_ref, qorder, gts_far zero-initialised); [k0,k1) must lie in one history slab.  gpose_in (N,12) double: cotangent of
+ * pose_k1; gpose_out: cotangent of pose_k0 COMPLETE (continue with dicp_icp_backward(..., have_partials = 0, ...)).  gsrc / gtgt (the slab) /
+ * gw are WRITTEN, not added to: the run is the first writer of a backward call (later launches add with bwd_overwrite = 0).
+ * scratch: dicp_run_scratch_bytes() bytes, 256-byte aligned.  A wait that cannot complete (never observed; every spin is bounded) leaves NaN in
+ * that cloud's gpose_out instead of hanging. */
+size_t dicp_run_scratch_bytes(int dtype, int N, int n, int m_pad);
+int dicp_icp_backward_run(int dtype, const dicp_weight_params* prm, const dicp_loop_buffers* buf, int N, int n, int m, int dim,
+                          const double* gpose_in, double* gpose_out, void* gsrc, void* gtgt, void* gw,
+                          void* scratch, size_t scratch_bytes, int k0, int k1, void* stream);
+
 
 /* Backward of dicp_step for iteration k.  gpose_in (N,12) double = cotangent of pose_out
  * that flowed through later iterations; bwd_partials (N,nblk,DICP_NBWD_PAD) T = the

@@ -51,7 +51,8 @@ class LoopBuffers(ctypes.Structure):
                 ("iterations", vp), ("matched_ratio", vp), ("n_start", vp), ("n_matched", vp), ("idx", vp), ("w", vp), ("w_iter", i64), ("w_stride", i64), ("w_prev0", vp),
                 ("partials", vp), ("counters", vp), ("events", vp), ("bwd_overwrite", i32), ("center", vp), ("poses_search", vp),
                 ("src_rows", vp), ("tgt_rows", vp), ("cert_q", vp), ("cert_qu", vp), ("cert_count", vp), ("rmax", vp), ("dcum", vp),
-                ("cert_reset", i32), ("spos_prev0", vp), ("tgt_sorted", vp), ("tgt_sorted_stride", i32)]
+                ("cert_reset", i32), ("spos_prev0", vp), ("tgt_sorted", vp), ("tgt_sorted_stride", i32),
+                ("bwd_skip", vp), ("bwd_mref", vp), ("bwd_live", vp), ("bwd_skip_eps", f64)]
 
 
 class KabschBuffers(ctypes.Structure):
@@ -92,8 +93,6 @@ _SIGNATURES = {
     "dicp_step": ([i32, ctypes.POINTER(StepIO), i32, vp], ctypes.c_int),
     "dicp_icp_forward": ([i32, ctypes.POINTER(WeightParams), ctypes.POINTER(LoopBuffers), i32, i32, i32, i32, i32, f64, i32, i32, vp], ctypes.c_int),
     "dicp_icp_backward": ([i32, ctypes.POINTER(WeightParams), ctypes.POINTER(LoopBuffers), i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp], ctypes.c_int),
-    "dicp_run_scratch_bytes": ([i32, i32, i32, i32], ctypes.c_size_t),
-    "dicp_icp_backward_run": ([i32, ctypes.POINTER(WeightParams), ctypes.POINTER(LoopBuffers), i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, i32, i32, vp], ctypes.c_int),
     "dicp_step_bwd": ([i32, vp, vp, i32, i32, vp, vp, i64, vp, vp, vp, vp, i32, vp], ctypes.c_int),
     "dicp_accumulate_bwd": ([i32, ctypes.POINTER(WeightParams), vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp], ctypes.c_int),
     "dicp_gumbel_nn": ([i32, vp, vp, i32, vp, ctypes.c_uint32, f64, f64, i32, i32, i32, vp, vp, vp], ctypes.c_int),

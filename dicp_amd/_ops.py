@@ -404,8 +404,8 @@ class LoopConfig:
     cert_from: object = None      # iteration of the certifying search (None: the last re-ordering of the queries)
     reuse_matches: bool = True    # sweep path: match certificates -- an iteration searches only the waves holding a query whose match is not proven
                                   # unchanged since the wave's last search (exact; knn_sweep_kernel CERT)
-    bwd_run: bool = True          # windowed backward: the iterations from bwd_run_from on as ONE launch per group of co-resident clouds (dicp_icp_backward_run)
-    bwd_run_from: object = None   # first iteration of that run (None: the iteration after the last re-ordering of the queries)
+    bwd_skip_eps: object = None   # backward: an iteration whose normal-equation cotangent is below this fraction of the largest of the cloud's later
+                                  # iterations adds nothing above rounding and is skipped for that cloud (None: 2^-22 for float32, 2^-40 for float64; 0: off)
     src_rows: object = None       # ragged batches: (N) int32 device tensors, rows of each source / target cloud that take part
     tgt_rows: object = None       # (ICP._batch: the clouds' own lengths; the kernels never touch a pad row)
 
@@ -426,7 +426,6 @@ def _pose_from_T(T):
     return torch.cat((T[:, :3, :3].reshape(N, 9), T[:, :3, 3]), dim=1).contiguous()
 
 
-RUN_DEBUG = False               # scripts/run_phases.py: per-block timestamps of the in-launch runs
 HIST_CHUNK_BYTES = 1 << 29      # per-iteration histories (indices, weights) are allocated in slabs of at most this size
 
 
@@ -495,7 +494,7 @@ class ICPLoop(torch.autograd.Function):
         assert Kmax >= 1, "max_iterations must be at least 1"
         need_grad = any(ctx.needs_input_grad[:4])
         if cfg.stats_out is not None:       # the statistics describe THIS call (an earlier call's certificate counters must not outlive it)
-            for key in ("knn_pairs", "searched_again", "budgets", "bwd_run"):
+            for key in ("knn_pairs", "searched_again", "budgets", "bwd_live"):
                 cfg.stats_out.pop(key, None)
         ctx.set_materialize_grads(False)    # no zero tensors for the six non-differentiable outputs (168 MB for the weights)
 
@@ -732,6 +731,22 @@ class ICPLoop(torch.autograd.Function):
                     True: bwd_flat[:N * nblk_w * _lib.NBWD_PAD].view(N, nblk_w, _lib.NBWD_PAD)}
             ev = cfg.timing_events
             events = ev.handles(Kmax) if ev is not None else None
+            # truncated reverse sweep (dicp_hip.h, dicp_loop_buffers.bwd_skip): a cloud's sweep ends at the iteration from which on nothing reaches the
+            # result's own rounding; the iterations before it do no per-point work.  Not with hard Huber weights: their reference gradient is NaN at an exactly zero residual whatever the cotangent.
+            eps = cfg.bwd_skip_eps
+            if eps is None:
+                eps = 2.0 ** -22 if dt == torch.float32 else 2.0 ** -40
+            if cfg.loss_name == "huber" and not cfg.differentiable:
+                eps = 0.0
+            skip = None
+            if eps > 0.0:
+                sk_arena = _Arena(dev)
+                sk_arena.take((N,), torch.float64)
+                sk_arena.take((N,), torch.int32)
+                sk_arena.take((Kmax,), torch.int32)
+                skip = sk_arena.finish()            # mref, decisions, live counters
+                if cfg.stats_out is not None:
+                    cfg.stats_out["bwd_live"] = skip[2]     # (Kmax) int32: clouds that did per-point work in iteration k of the backward
             have, form, fresh = 0, None, 1
             # neighbouring segments of one form inside one history slab run as ONE library call (the forward cut them where the host had to
             # act -- a new query order, a convergence check -- and none of that concerns the reverse sweep)
@@ -741,38 +756,6 @@ class ICPLoop(torch.autograd.Function):
                     runs[-1] = (k0, runs[-1][1], q, w_form)
                 else:
                     runs.append((k0, k1, q, w_form))
-            # The run of iterations whose matches hardly change any more (from the iteration after the last query re-ordering on) goes first, as
-            # ONE launch per group of co-resident clouds: points, match rows and accumulating gradients stay on chip over the whole run
-            # (dicp_icp_backward_run; float32, windowed form, inside one history slab).
-            if runs and runs[0][3] and cfg.bwd_run and dt == torch.float32:
-                resorts = [k for k in cfg.sweep_resort if 0 <= k < K]
-                run_lo = (max(resorts) + 1 if resorts else 1) if cfg.bwd_run_from is None else max(0, int(cfg.bwd_run_from))
-                run_lo = max(run_lo, ((K - 1) // kc) * kc)
-                windowed_from = min((a for (a, b, q, wf) in runs if wf and b > a), default=K)
-                run_lo = max(run_lo, windowed_from)
-                if K - run_lo >= 2:
-                    j = (K - 1) // kc
-                    nbytes = int(lib.dicp_run_scratch_bytes(code, N, n, m_pad))
-                    if RUN_DEBUG:       # diagnostics (scripts/run_phases.py): room for per-block, per-iteration timestamps behind the scratch
-                        nblk_run = lib.dicp_window_blocks(code, n, m_pad)
-                        nbytes_all = nbytes + N * nblk_run * (K - run_lo) * 32 + 256
-                        scratch = torch.zeros((nbytes_all,), dtype=torch.uint8, device=dev)
-                        if cfg.stats_out is not None:
-                            cfg.stats_out["bwd_run_debug"] = scratch[nbytes:nbytes + N * nblk_run * (K - run_lo) * 32].view(torch.int64).view(N, nblk_run, K - run_lo, 4)
-                        nbytes = nbytes_all
-                    else:
-                        scratch = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
-                    LB = _lib.LoopBuffers(
-                        src=_p(src_s), tgt=_p(tgt_s), w_init=_p(w_s), c=tgt_s.shape[2], K=Kmax, knn_variant=kind, m_pad=m_pad, idx_per_iter=1, qorder=_p(qo),
-                        spos=ctypes.c_void_p(spos_slabs[j].data_ptr() - j * kc * N * n * 4), spos_ref=_p(spos_ref), gts_far=_p(gfar),
-                        poses=_p(poses), deltas=_p(deltas), areg=_p(areg), alive=_p(alive), events=events, src_rows=_p(cfg.src_rows), tgt_rows=_p(cfg.tgt_rows))
-                    _lib.check(lib.dicp_icp_backward_run(code, ctypes.byref(P), ctypes.byref(LB), N, n, m, int(cfg.dim), _p(gpose), _p(gtmp),
-                                                         _p(gsrc_s), _p(slab), _p(gw_s), _p(scratch), nbytes, run_lo, K, st), "dicp_icp_backward_run")
-                    gpose, gtmp = gtmp, gpose           # complete cotangent of pose_run_lo: the next chunk starts without partials
-                    fresh = 0
-                    if cfg.stats_out is not None:
-                        cfg.stats_out["bwd_run"] = (run_lo, K)
-                    runs = [(a, min(b, run_lo), q, wf) for (a, b, q, wf) in runs if a < run_lo]
             for (k0, k1, q, w_form) in runs:
                 if have and w_form != form:     # the partials of the other form have another block count: fold them in here
                     gpose += bwdp[form].sum(dim=1)[:, :12].to(torch.float64)
@@ -788,7 +771,9 @@ class ICPLoop(torch.autograd.Function):
                     spos_ref=_p(spos_ref) if w_form else None, gts_far=_p(gfar) if w_form else None,
                     poses=_p(poses), deltas=_p(deltas), areg=_p(areg), alive=_p(alive),
                     idx=ctypes.c_void_p(idx_slabs[j].data_ptr() - base * N * n * 4) if idx_slabs else None, events=events,
-                    bwd_overwrite=fresh if (w_form and k1 > k0) else 0, src_rows=_p(cfg.src_rows), tgt_rows=_p(cfg.tgt_rows))
+                    bwd_overwrite=fresh if (w_form and k1 > k0) else 0, src_rows=_p(cfg.src_rows), tgt_rows=_p(cfg.tgt_rows),
+                    bwd_skip=_p(skip[1]) if skip else None, bwd_mref=_p(skip[0]) if skip else None, bwd_live=_p(skip[2]) if skip else None,
+                    bwd_skip_eps=float(eps))
                 if w_form and k1 > k0:
                     fresh = 0
                 _lib.check(lib.dicp_icp_backward(code, ctypes.byref(P), ctypes.byref(LB), N, n, m, int(cfg.dim), _p(gpose), _p(gtmp), have,

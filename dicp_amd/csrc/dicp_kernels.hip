@@ -1891,13 +1891,18 @@ __global__ __launch_bounds__(BLOCK) void accumulate_bwd_kernel(WeightParams P, c
                                                                const T* __restrict__ gs, const T* __restrict__ gb,
                                                                int N, int n, int m, int bpc,
                                                                T* __restrict__ gsrc, T* __restrict__ gtgt, T* __restrict__ gw,
-                                                               T* __restrict__ bwd_partials, const int32_t* __restrict__ src_rows) {
+                                                               T* __restrict__ bwd_partials, const int32_t* __restrict__ src_rows,
+                                                               const int32_t* __restrict__ skip /* optional (N): step_bwd found this iteration's cotangent negligible */) {
     constexpr int CV = (MODE == MODE_PT2PL) ? 6 : 3;        // gradient columns per target row
     __shared__ T red[(BLOCK / WAVE) * NBWD_PAD];
     __shared__ T stage_v[(BLOCK / WAVE) * WAVE * CV];
     __shared__ int stage_j[BLOCK];
     int cloud, blk;
     if (!decode_block(bpc, N, cloud, blk)) return;
+    if (skip && skip[cloud]) {                              // nothing this cloud would add is above rounding: zero sums for the next step_bwd, done
+        if (threadIdx.x < NBWD_PAD) bwd_partials[((size_t)cloud * bpc + blk) * NBWD_PAD + threadIdx.x] = T(0);
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
     T C[9], r[3], Gs[36], Gb[6];
     load_pose(pose, cloud, C, r);
@@ -1997,7 +2002,8 @@ __global__ __launch_bounds__(BLOCK) void accumulate_bwd_window_kernel(WeightPara
                                                                       int N, int n, int m_pad, int spb, int bpc,
                                                                       T* __restrict__ gsrc_s, T* __restrict__ slab /* (N,bpc,WT,CV) */,
                                                                       T* __restrict__ gts_far /* (N,m_pad,CV) */,
-                                                                      T* __restrict__ gw_s, T* __restrict__ bwd_partials, const int32_t* __restrict__ src_rows) {
+                                                                      T* __restrict__ gw_s, T* __restrict__ bwd_partials, const int32_t* __restrict__ src_rows,
+                                                                      const int32_t* __restrict__ skip /* optional (N), see accumulate_bwd_kernel */) {
     // overwrite: first launch into uninitialised accumulators -- gsrc_s / gw_s / the slab windows are written, not added to
     constexpr int CV = (MODE == MODE_PT2PL) ? 6 : 3;
     __shared__ T red[(BLOCK / WAVE) * NBWD_PAD];
@@ -2006,6 +2012,10 @@ __global__ __launch_bounds__(BLOCK) void accumulate_bwd_window_kernel(WeightPara
     __shared__ int head[WT], next[SPB];                     // per window row: list of the slots that matched it
     int cloud, blk;
     if (!decode_block(bpc, N, cloud, blk)) return;
+    if (!overwrite && skip && skip[cloud]) {                // (the first launch initialises the accumulators: it always runs)
+        if (threadIdx.x < NBWD_PAD) bwd_partials[((size_t)cloud * bpc + blk) * NBWD_PAD + threadIdx.x] = T(0);
+        return;
+    }
     const int tid = threadIdx.x;
     const int nc = rows_of(src_rows, cloud, n);             // ragged batches: slots past the cloud's own carry weight 0: no work, zero gradient
     const int s0 = blk * spb, s1 = min(nc, s0 + spb), s1_all = min(n, s0 + spb);
@@ -2218,418 +2228,114 @@ __global__ __launch_bounds__(BLOCK) void permute_add_rows_kernel(const T* __rest
     }
 }
 
-// ------------------------------------------------------- a RUN of backward iterations in one launch
-// Over a run of iterations near the pose a query's match does not change (from the certifying search on: provably), yet the
-// per-iteration launches above re-read every point, its match row and its gradient accumulators each time (114 bytes per
-// point and iteration at the memory side against 84 algorithmic).  Here a block KEEPS its slots -- point, match row, and the
-// gradients it is accumulating for them -- on chip over all iterations [k0, k1) of the run, in the windowed form's sorted
-// space: registers for the point / row / source gradient, LDS for the target-row gradients (which then leave through the
-// same per-row lists and slab as one windowed launch).  Per iteration a block only reads its slots' matches (4 bytes per
-// slot: a changed one reloads its row and sends what it had accumulated for the old row to the out-of-window side buffer)
-// and publishes 12 pose-cotangent sums; the chain  accumulate_bwd(k) -> step_bwd(k-1)  runs inside the launch:
-//   every block of a cloud stores its sums (write-through, sc1), waits for them (vmcnt) and adds 1 to the cloud's counter with
-//   an agent-scope returning atomic; the block whose add came last reads the cloud's records (sc1 loads), takes the cloud's
-//   step_bwd on its first wave and publishes (G_A + G_A^T, g_b) and the pass-through cotangent behind an sc1 sequence number,
-//   which the other blocks poll (one lane, sc1 loads, s_sleep, BOUNDED: a run that cannot finish poisons the cloud's pose
-//   cotangent with NaN and sets `err` instead of hanging).  The form is the first row of the sc1 hand-off table of
-//   MI355X_MICROARCH.md ("Workgroup dispatch, XCD placement & inter-workgroup visibility"); all blocks of a launch must be
-//   resident together (the entry point sizes its launches by the occupancy query), which is what makes the waits safe.
-constexpr int RUN_SPIN_MAX = 1 << 21;      // polls (each >= one L2 round trip + s_sleep): seconds, against microseconds of expected wait
-constexpr int RUN_LINE = 32;               // ints per cloud between two counters / flags: 128-byte lines of their own
-
-template <typename T> __device__ __forceinline__ T ld_sc1(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <typename T> __device__ __forceinline__ void st_sc1(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// value of lane k (a compile-time constant) as a wave-uniform scalar
-__device__ __forceinline__ float lane_value(float v, int k) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k)); }
-__device__ __forceinline__ double lane_value(double v, int k) {
-    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, k), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), k);
-    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
-
-// step_backward (dicp_math.h) by ONE WAVE with every operand in LDS.  Inside a run kernel the stepping wave still holds its slots'
-// state in registers, and the serial form -- seven small matrices as per-lane arrays, ~230 VGPRs -- would live in scratch memory.
-// Here the 3x3 products and the elimination are spread over lanes ((i,j) -> one lane) and every intermediate is an LDS word; each
-// element goes through the same operations in the same order as in step_backward_fixed / solve_fixed, so the values are the same.
-struct StepBwdLds {
-    double g[12], C[9], d[6], A[36];            // in: cotangent of the new pose (gCn 9, grn 3), pose_k's C, delta_k, the regularised matrix
-    double R[9], abc[3], gR[9], Mm[9], M[36], rhs[6], x[6];
-    double Gs[36], Gb[6], go[12];               // out: G_A + G_A^T, g_b, cotangent of pose_k (pass-through part)
-    int ok;
-};
-// In-place D x D solve (leading dimension D) with partial pivoting, as solve_fixed: rows swapped lane-parallel, elimination by lane (i, c),
-// back substitution by every lane redundantly (uniform LDS reads broadcast).  All 64 lanes of the wave call it.
-template <int D>
-__device__ __forceinline__ bool wave_solve(double* M, double* rhs, double* x, int lane) {
-#pragma unroll 1
-    for (int k = 0; k < D; ++k) {
-        int piv = k;
-        double best = fabs(M[k * D + k]);
-        for (int i = k + 1; i < D; ++i) { const double v = fabs(M[i * D + k]); if (v > best) { best = v; piv = i; } }
-        if (best == 0.0) return false;
-        __builtin_amdgcn_wave_barrier();
-        if (piv != k) {                                     // (wave-uniform)
-            if (lane >= k && lane < D) { const double a = M[k * D + lane], b = M[piv * D + lane]; M[k * D + lane] = b; M[piv * D + lane] = a; }
-            if (lane == D) { const double a = rhs[k], b = rhs[piv]; rhs[k] = b; rhs[piv] = a; }
-        }
-        __builtin_amdgcn_wave_barrier();
-        const double inv = 1.0 / M[k * D + k];
-        const int i = lane >> 3, c = lane & 7;              // lane (i, c): row i > k, column c in (k, D]; c == D is the right-hand side
-        double f = 0.0, mk = 0.0, mi = 0.0;
-        const bool act = i > k && i < D && c > k && c <= D;
-        if (act) { f = M[i * D + k] * inv; mk = c < D ? M[k * D + c] : rhs[k]; mi = c < D ? M[i * D + c] : rhs[i]; }
-        __builtin_amdgcn_wave_barrier();
-        if (act) { mi -= f * mk; if (c < D) M[i * D + c] = mi; else rhs[i] = mi; }
-        __builtin_amdgcn_wave_barrier();
-    }
-#pragma unroll 1
-    for (int i = D - 1; i >= 0; --i) {
-        double v = rhs[i];
-        for (int c = i + 1; c < D; ++c) v -= M[i * D + c] * x[c];
-        v = v / M[i * D + i];
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) x[i] = v;
-        __builtin_amdgcn_wave_barrier();
-    }
-    return true;
-}
-template <int D>
-__device__ __forceinline__ void step_backward_wave_fixed(StepBwdLds& L, int lane) {
-    constexpr int OFF = (D == 3) ? 2 : 0;
-    const double* gCn = L.g; const double* grn = L.g + 9;
-    if (lane == 0) {
-        double R[9], a, b, c;
-        so3_exp(L.d, R);
-        so3_coeffs(L.d, a, b, c);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) L.R[i] = R[i];
-        L.abc[0] = a; L.abc[1] = b; L.abc[2] = c;
-    }
-    if (lane < 36) { L.Gs[lane] = 0.0; }
-    if (lane < 6) { L.Gb[lane] = 0.0; }
-    __builtin_amdgcn_wave_barrier();
-    if (lane < 9) {                                         // C_new = R^T C  ->  gC = R gCn ,  gR = C gCn^T
-        const int i = lane / 3, j = lane - 3 * i;
-        L.go[lane] = L.R[i * 3 + 0] * gCn[0 * 3 + j] + L.R[i * 3 + 1] * gCn[1 * 3 + j] + L.R[i * 3 + 2] * gCn[2 * 3 + j];
-        L.gR[lane] = L.C[i * 3 + 0] * gCn[j * 3 + 0] + L.C[i * 3 + 1] * gCn[j * 3 + 1] + L.C[i * 3 + 2] * gCn[j * 3 + 2];
-    } else if (lane < 12) L.go[lane] = grn[lane - 9];
-    __builtin_amdgcn_wave_barrier();
-    if (lane < 9) {                                         // M = gR R^T
-        const int i = lane / 3, j = lane - 3 * i;
-        L.Mm[lane] = L.gR[i * 3 + 0] * L.R[j * 3 + 0] + L.gR[i * 3 + 1] * L.R[j * 3 + 1] + L.gR[i * 3 + 2] * L.R[j * 3 + 2];
-    }
-    if (lane >= 16 && lane < 16 + D * D) {                  // the matrix that was inverted, compact
-        const int e = lane - 16, i = e / D, j = e - D * i;
-        L.M[e] = L.A[i * 6 + j];
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) {                                        // dR = (J_l dphi)^ R  ->  gphi = J_l^T vee(M - M^T); d(r - delta_r) -> -grn
-        const double v[3] = {L.Mm[7] - L.Mm[5], L.Mm[2] - L.Mm[6], L.Mm[3] - L.Mm[1]};
-        const double a = L.abc[0], b = L.abc[1], c = L.abc[2];
-        const double phi[3] = {L.d[0], L.d[1], L.d[2]};
-        const double pv = phi[0] * v[0] + phi[1] * v[1] + phi[2] * v[2];
-        double pxv[3];
-        cross3(phi, v, pxv);
-        double gd[6];
-        for (int i = 0; i < 3; ++i) gd[i] = a * v[i] + c * phi[i] * pv - b * pxv[i];
-        for (int i = 0; i < 3; ++i) gd[3 + i] = -grn[i];
-#pragma unroll
-        for (int i = 0; i < D; ++i) L.rhs[i] = gd[i + OFF];
-    }
-    __builtin_amdgcn_wave_barrier();
-    const bool ok = wave_solve<D>(L.M, L.rhs, L.x, lane);
-    __builtin_amdgcn_wave_barrier();
-    if (ok) {                                               // delta = -Areg^{-1} b  ->  g = Areg^{-1} gdelta ; gb = -g ; G_A + G_A^T = -(g delta^T + delta g^T)
-        if (lane < D * D) {
-            const int i = lane / D, j = lane - D * i;
-            L.Gs[(i + OFF) * 6 + (j + OFF)] = -(L.x[i] * L.d[j + OFF] + L.d[i + OFF] * L.x[j]);
-        }
-        if (lane >= 48 && lane < 48 + D) L.Gb[lane - 48 + OFF] = -L.x[lane - 48];
-    }
-    __builtin_amdgcn_wave_barrier();
-}
-__device__ __forceinline__ void step_backward_wave(StepBwdLds& L, int dim, int lane) {
-    if (dim == 2) step_backward_wave_fixed<3>(L, lane); else step_backward_wave_fixed<6>(L, lane);
-}
-
-template <typename T> struct RunBwdArgs {
-    const T* src_s; const T* tgt_s; int c;              // slot-order source rows, sorted target rows (c elements per row)
-    const int32_t* spos;                                 // virtual base of the (K,N,n) match history: iteration k at spos + k*N*n, by QUERY
-    const int32_t* spos_ref; const int32_t* qorder;      // window placement / slot -> query, as accumulate_bwd_window_kernel
-    const T* poses; const T* deltas; long delta_stride; const double* areg; const T* alive; const T* w_s;
-    const double* gpose_in; double* gpose_out;           // (N,12): cotangent of pose_k1 in, of pose_k0 out (complete: the last sums folded in)
-    T* gsrc_s; T* slab; T* gts_far; T* gw_s;             // written (not added to): the run is the first writer of a backward call
-    T* rec; T* gsb; double* gpass;                       // (N,bpc,NBWD_PAD) block records, (N,64) step results, (N,16) pass-through cotangents
-    int32_t* count; int32_t* flag; int32_t* err;         // (N,RUN_LINE) zero-initialised counters / sequence numbers; err[0] != 0: a wait timed out
-    const int32_t* src_rows;
-    unsigned long long* dbg;                             // optional (N,bpc,k1-k0,4) timestamps (s_memrealtime, 10 ns): loop top / matches known / sums ready / arrived
-    int N, n, m_pad, spb, bpc, cloud0, ncl, dim, k0, k1;
-};
-
-// one lane polls the cloud's sequence number; returns false on a timeout (or when another block has given up)
-__device__ __forceinline__ bool run_wait(const int32_t* flag, int want, int32_t* err) {
-    int spins = 0;
-    while (ld_sc1(flag) < want) {
-        __builtin_amdgcn_s_sleep(1);
-        ++spins;
-        if ((spins & 255) == 0 && ld_sc1(err) != 0) return false;
-        if (spins > RUN_SPIN_MAX) { atomicOr(err, 1); return false; }
-    }
-    return true;
-}
-
-template <typename T, int MODE, int WT, bool HAS_W>
-__global__ __launch_bounds__(BLOCK, 4) void icp_run_backward_kernel(WeightParams P, RunBwdArgs<T> A) {
-    constexpr int CV = (MODE == MODE_PT2PL) ? 6 : 3;
-    constexpr int SPB = 4 * BLOCK, U = 4;
-    __shared__ T red[(BLOCK / WAVE) * NBWD_PAD];
-    __shared__ T contrib[CV * SPB];                         // [column][slot of the block]: what the slot has accumulated for its match row
-    __shared__ int head[WT], next[SPB];
-    __shared__ StepBwdLds L;
-    __shared__ int s_role, s_ok;
-    int cl, blk;
-    if (!decode_block(A.bpc, A.ncl, cl, blk)) return;
-    const int cloud = A.cloud0 + cl;
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
-    const int N = A.N, n = A.n, m_pad = A.m_pad, c = A.c;
-    const int nc = rows_of(A.src_rows, cloud, n);
-    const int s0 = blk * A.spb, s1 = min(nc, s0 + A.spb), s1_all = min(n, s0 + A.spb);
-    const int32_t* __restrict__ qo_c = A.qorder ? A.qorder + (size_t)cloud * n : nullptr;
-    int32_t* cnt = A.count + (size_t)cloud * RUN_LINE;
-    int32_t* flg = A.flag + (size_t)cloud * RUN_LINE;
-    T* gsb = A.gsb + (size_t)cloud * 64;
-    double* gps = A.gpass + (size_t)cloud * 16;
-    T* rec_c = A.rec + (size_t)cloud * A.bpc * NBWD_PAD;
-
-    // ---- the block's slots: point, query, match (of the run's last iteration), match row; zeroed accumulators
-    // (HAS_W: a weight tensor was given; without one the weights are the implicit ones, nothing is kept for them and no weight gradient exists)
-    constexpr int UW = HAS_W ? U : 1;
-    bool on[U];
-    int pos[U], posn[U];
-    T p[U][3], row[U][CV], wv[UW], gp[U][3], gwv[UW];
-#pragma unroll
-    for (int u = 0; u < U; ++u) on[u] = s0 + u * BLOCK + tid < s1;
-    // the matches of iteration k for this thread's slots (slot -> query -> match; the query index is re-read where it is needed: it is a
-    // coalesced, cache-resident load, and four registers matter more here than its latency, which the prefetch below hides)
-    auto matches_of = [&](int k, int* out) {
-        const int32_t* __restrict__ sp_c = A.spos + (size_t)k * N * n + (size_t)cloud * n;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int sq = min(on[u] ? s0 + u * BLOCK + tid : s0, n - 1);
-            const int q = qo_c ? min(max(qo_c[sq], 0), n - 1) : sq;
-            out[u] = on[u] ? min(max(sp_c[q], 0), m_pad - 1) : 0;
-        }
-    };
-    const int lo = window_origin(A.spos_ref + (size_t)cloud * n, qo_c, blk, A.spb, nc, m_pad, WT);
-    const int hi = min(lo + WT, m_pad);
-    matches_of(A.k1 - 1, posn);
-#pragma unroll
-    for (int u = 0; u < UW; ++u) { wv[u] = T(1); gwv[u] = T(0); }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const size_t pt = (size_t)cloud * n + min(s0 + u * BLOCK + tid, n - 1);
-        const T* spp = A.src_s + pt * 3;
-        p[u][0] = spp[0]; p[u][1] = spp[1]; p[u][2] = spp[2];
-        if (HAS_W) wv[u] = A.w_s[pt];
-        gp[u][0] = gp[u][1] = gp[u][2] = T(0);
-        pos[u] = -1;                                        // (no row loaded yet: the first iteration's "changed match" path loads it)
-#pragma unroll
-        for (int k = 0; k < CV; ++k) { row[u][k] = T(0); contrib[k * SPB + u * BLOCK + tid] = T(0); }
-    }
-    T* gfar = A.gts_far ? A.gts_far + (size_t)cloud * m_pad * CV : nullptr;
-    int role = (blk == 0) ? 1 : 0;                          // who takes the cloud's step next: block 0 first, then whoever arrived last
-    int seq = 0;
-    for (int k = A.k1 - 1; k >= A.k0; --k) {
-        ++seq;
-        const bool first = (k == A.k1 - 1);
-        unsigned long long* dbg = A.dbg ? A.dbg + (((size_t)cloud * A.bpc + blk) * (A.k1 - A.k0) + (seq - 1)) * 4 : nullptr;
-        if (dbg && tid == 0) dbg[0] = __builtin_amdgcn_s_memrealtime();
-        // ---- step_bwd(k) by the first wave of ONE block: cotangent of pose_{k+1} (pass-through + the cloud's sums) -> (G_A + G_A^T, g_b)_k
-        if (role && wave == 0) {
-            const int slot_i = lane & 15, part = lane >> 4;
-            double s = 0.0;
-            if (!first && slot_i < NBWD) {
-                constexpr int UB = 4;
-                for (int b0 = part; b0 < A.bpc; b0 += 4 * UB) {
-                    T v[UB];
-#pragma unroll
-                    for (int u = 0; u < UB; ++u) v[u] = (b0 + 4 * u < A.bpc) ? ld_sc1(rec_c + (size_t)(b0 + 4 * u) * NBWD_PAD + slot_i) : T(0);
-#pragma unroll
-                    for (int u = 0; u < UB; ++u) if (b0 + 4 * u < A.bpc) s += (double)v[u];
-                }
-            }
-            s += __shfl_down(s, 32);
-            s += __shfl_down(s, 16);
-            if (lane < NBWD) L.g[lane] = s + (first ? A.gpose_in[(size_t)cloud * 12 + lane] : ld_sc1(gps + lane));
-            if (lane < 9) L.C[lane] = (double)A.poses[((size_t)k * N + cloud) * 12 + lane];
-            if (lane < 6) L.d[lane] = (double)A.deltas[(size_t)cloud * A.delta_stride + (size_t)k * 6 + lane];
-            if (lane < 36) L.A[lane] = A.areg[((size_t)k * N + cloud) * 36 + lane];
-            __builtin_amdgcn_wave_barrier();
-            step_backward_wave(L, A.dim, lane);
-            if (lane < 36) st_sc1(gsb + lane, (T)L.Gs[lane]);
-            if (lane < 6) st_sc1(gsb + 36 + lane, (T)L.Gb[lane]);
-            if (lane < 12) st_sc1(gps + lane, L.go[lane]);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) st_sc1(flg, seq);
-        }
-        // ---- everybody: wait for (Gs, Gb)_k, then take them (and pose_k, alive_k) as wave-uniform scalars
-        if (wave == 0) {
-            int ok = 1;
-            if (lane == 0) ok = run_wait(flg, seq, A.err) ? 1 : 0;
-            if (lane == 0) s_ok = ok;
-        }
-        __syncthreads();
-        if (!s_ok) {                                        // a wait timed out: poison this cloud's result, leave together
-            if (tid < 12) A.gpose_out[(size_t)cloud * 12 + tid] = __builtin_nan("");
-            return;
-        }
-        if (dbg && tid == 0) dbg[1] = __builtin_amdgcn_s_memrealtime();
-        T Gs[36], Gb[6], C[9], r[3], live;
-        {
-            T v = T(0);
-            if (lane < 42) v = ld_sc1(gsb + lane);
-            else if (lane < 54) v = A.poses[((size_t)k * N + cloud) * 12 + (lane - 42)];
-            else if (lane == 54) v = A.alive ? A.alive[(size_t)k * N + cloud] : T(1);
-#pragma unroll
-            for (int i = 0; i < 36; ++i) Gs[i] = lane_value(v, i);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) Gb[i] = lane_value(v, 36 + i);
-#pragma unroll
-            for (int i = 0; i < 9; ++i) C[i] = lane_value(v, 42 + i);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) r[i] = lane_value(v, 51 + i);
-            live = lane_value(v, 54);
-        }
-        // this iteration's matches arrived with the previous one's work; the next iteration's are requested now
-        int pk[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) pk[u] = posn[u];
-        if (k > A.k0) matches_of(k - 1, posn);
-        T acc[NBWD];
-#pragma unroll
-        for (int i = 0; i < NBWD; ++i) acc[i] = T(0);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (!on[u]) continue;
-            const int sl = u * BLOCK + tid;
-            if (pk[u] != pos[u]) {                          // the match changed (always so in the run's first iteration): hand over, reload the row
-                if (pos[u] >= 0 && gfar) {
-                    T* gr = gfar + (size_t)pos[u] * CV;
-#pragma unroll
-                    for (int i = 0; i < CV; ++i) { unsafeAtomicAdd(&gr[i], contrib[i * SPB + sl]); contrib[i * SPB + sl] = T(0); }
-                }
-                pos[u] = pk[u];
-                const T* yp = A.tgt_s + ((size_t)cloud * m_pad + pos[u]) * c;
-#pragma unroll
-                for (int i = 0; i < CV; ++i) row[u][i] = yp[i];
-            }
-            T nrm[3] = {T(0), T(0), T(0)};
-            if constexpr (MODE == MODE_PT2PL) { nrm[0] = row[u][3]; nrm[1] = row[u][4]; nrm[2] = row[u][5]; }
-            T g3[3], gy[3], gn[3], gw0;
-            point_backward<T, MODE>(P, C, r, p[u], row[u], nrm, (HAS_W ? wv[u] : T(1)) * live, Gs, Gb, g3, gy, gn, gw0, acc, acc + 9);
-            gp[u][0] += g3[0]; gp[u][1] += g3[1]; gp[u][2] += g3[2];
-            if (HAS_W) gwv[u] += gw0 * live;
-            contrib[0 * SPB + sl] += gy[0]; contrib[1 * SPB + sl] += gy[1]; contrib[2 * SPB + sl] += gy[2];
-            if constexpr (MODE == MODE_PT2PL) { contrib[3 * SPB + sl] += gn[0]; contrib[4 * SPB + sl] += gn[1]; contrib[5 * SPB + sl] += gn[2]; }
-            __builtin_amdgcn_sched_barrier(0);              // one slot's adjoint at a time: interleaving four of them costs more registers than the kernel has
-        }
-        if (dbg && tid == 0) dbg[2] = __builtin_amdgcn_s_memrealtime();
-        // ---- the block's 12 sums: reduced like the other kernels', published write-through; arrive; the last block to arrive steps next
-        {
-            T a32[32];
-#pragma unroll
-            for (int i = 0; i < 32; ++i) a32[i] = i < NBWD ? acc[i] : T(0);
-            halve_step<T, 16>(a32, lane);
-            halve_step<T, 8>(a32, lane);
-            halve_step<T, 4>(a32, lane);
-            halve_step<T, 2>(a32, lane);
-            halve_step<T, 1>(a32, lane);
-            const T x = a32[0] + __shfl_xor(a32[0], 1);
-            const int slot = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
-            if (!(lane & 1) && slot < NBWD) red[wave * NBWD_PAD + slot] = x;
-        }
-        __syncthreads();
-        if (wave == 0) {
-            if (lane < NBWD_PAD) {
-                T s = T(0);
-                if (lane < NBWD) {
-#pragma unroll
-                    for (int w = 0; w < BLOCK / WAVE; ++w) s += red[w * NBWD_PAD + lane];
-                }
-                st_sc1(rec_c + (size_t)blk * NBWD_PAD + lane, s);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) {
-                const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_role = (old == A.bpc * seq - 1) ? 1 : 0;
-            }
-        }
-        __syncthreads();
-        role = s_role;
-        if (dbg && tid == 0) dbg[3] = __builtin_amdgcn_s_memrealtime();
-    }
-    // ---- the run's end: the last block to arrive folds the final sums into the cotangent of pose_k0
-    if (role && wave == 0) {
-        const int slot_i = lane & 15, part = lane >> 4;
-        double s = 0.0;
-        if (slot_i < NBWD)
-            for (int b0 = part; b0 < A.bpc; b0 += 4) s += (double)ld_sc1(rec_c + (size_t)b0 * NBWD_PAD + slot_i);
-        s += __shfl_down(s, 32);
-        s += __shfl_down(s, 16);
-        if (lane < NBWD) A.gpose_out[(size_t)cloud * 12 + lane] = s + ld_sc1(gps + lane);
-    }
-    // ---- the accumulated gradients leave: source / weight rows in slot order, target rows through the block's window (per-row lists,
-    //      slab written once) -- or, outside the window, to the side buffer
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int s = s0 + u * BLOCK + tid;
-        if (s >= s1_all) continue;
-        const size_t pt = (size_t)cloud * n + s;
-        T* gsp = A.gsrc_s + pt * 3;
-        if (on[u]) { gsp[0] = gp[u][0]; gsp[1] = gp[u][1]; gsp[2] = gp[u][2]; if (HAS_W && A.gw_s) A.gw_s[pt] = gwv[u]; }
-        else { gsp[0] = gsp[1] = gsp[2] = T(0); if (A.gw_s) A.gw_s[pt] = T(0); }     // a pad slot of a ragged batch
-    }
-    if (A.slab) {
-        for (int i = tid; i < hi - lo; i += BLOCK) head[i] = -1;
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (!on[u] || pos[u] < 0) continue;
-            const int sl = u * BLOCK + tid;
-            if (pos[u] >= lo && pos[u] < hi) next[sl] = atomicExch(&head[pos[u] - lo], sl);
-            else {
-                T* gr = gfar + (size_t)pos[u] * CV;
-#pragma unroll
-                for (int i = 0; i < CV; ++i) unsafeAtomicAdd(&gr[i], contrib[i * SPB + sl]);
-            }
-        }
-        __syncthreads();
-        T* out = A.slab + ((size_t)cloud * A.bpc + blk) * (WT * CV);
-        for (int rr = tid; rr < hi - lo; rr += BLOCK) {
-            int h = head[rr];
-            T sum[CV];
-#pragma unroll
-            for (int i = 0; i < CV; ++i) sum[i] = T(0);
-            for (int guard = 0; h >= 0 && guard < SPB; ++guard) {
-#pragma unroll
-                for (int i = 0; i < CV; ++i) sum[i] += contrib[i * SPB + h];
-                h = next[h];
-            }
-#pragma unroll
-            for (int i = 0; i < CV; ++i) out[rr * CV + i] = sum[i];
-        }
-    }
-}
-
 // ---------------------------------------------------------------------- step bwd
+// Truncated reverse sweep.  Going backwards through the iterations, what iteration k adds to every gradient is LINEAR in the cotangent
+// (G_A + G_A^T, g_b)_k of its normal equations, with coefficients (the per-point Jacobians, residuals, weights) of the same size in every
+// iteration.  A Gauss-Newton step near its fixed point is a strong contraction -- the new pose hardly depends on the old one -- so the chain
+// of pose cotangents shrinks by ~2e-4 per iteration (oracle, float64, random clouds and planar scenes: the gradient through the last
+// 1 / 2 / 3 / 4 iterations only differs from the full one by 2e-4 / 4e-8 / 1e-11 / 2e-15 of its size, profiles/r03_cotangent_decay.txt):
+// all but the last few iterations of a call add less than the rounding error of the sums they are added to.  step_bwd measures it on device,
+// per cloud, in the data's own units (A = the iteration's normal matrix, sum u j_a^2 on its diagonal; s_a = sqrt(A_aa)):
+//     m_k = max( max_ab |G_ab| s_a s_b , max_a |g_a| s_a )                    what iteration k itself adds
+//     w_k = max_a |g_a| s_a  x  max_{k' < k, b} |delta_k',b| s_b              the most any EARLIER iteration could add: G_A = -(g delta^T + delta g^T)
+//                                                                             multiplies the chain by that iteration's step, which is 1e6 times
+//                                                                             larger at the start of a call than at its end, and the chain itself
+//                                                                             cannot grow by more than O(1) per iteration (x16 allowed below)
+// and ends the cloud's reverse sweep at iteration k -- this and every earlier iteration do no per-point work; of the pose cotangent only the
+// part that does not go through the normal equations travels on (pose_pass_through) -- when  16 max(m_k, w_k) <= eps x (the largest m of
+// the cloud's later iterations).  eps is a few units of the result
+// type's roundoff (2^-22 for float32, 2^-40 for float64 from the host side): what is dropped is below the resolution of the sums it would be
+// added to.  The sweep cannot be resumed after a skipped iteration (the partial sums a skipped iteration would have produced are what makes
+// the chain shrink), hence "ends".  Iterations at which the cloud was already frozen (alive = 0) are skipped without ending anything: their
+// weights are zero and every term of the adjoint is exactly zero.  A NaN measure never ends a sweep.  Hard Huber weights are excluded by the
+// caller (their reference gradient is NaN at an exactly zero residual whatever the cotangent).
+template <typename T> struct SkipArgs {
+    int32_t* skip;           // (N) zero-initialised per backward pass: 0 = take part, 1 = frozen at this iteration, 2 = the cloud's sweep has ended (sticky).
+                             // Written by step_bwd, read by the accumulate_bwd launch that follows (NULL: feature off)
+    double* mref;            // (N) zero-initialised per backward pass: the largest m so far
+    const T* alive_k;        // (N) or NULL
+    int32_t* live_k;         // optional counter: clouds that take part in this iteration
+    double eps;
+    int k;                   // this iteration (delta_k - 6 j = the step of iteration k - j)
+};
+template <typename T>
+__device__ __forceinline__ int skip_decision(const double* Gs, const double* Gb, const double* Areg, const double* dmax /* [6]: max |delta| of the earlier iterations */,
+                                             int dim, int cloud, const SkipArgs<T>& sk) {
+    const int D = dim == 2 ? 3 : 6, OFF = dim == 2 ? 2 : 0;   // (Areg is compact, leading dimension 6; Gs / Gb / delta sit at their slots)
+    const bool live = !sk.alive_k || sk.alive_k[cloud] != T(0);
+    if (!live) return 1;
+    double sa[6], m = 0.0, gmax = 0.0, amp = 0.0;
+    bool nan = false;
+    for (int i = 0; i < D; ++i) sa[i] = sqrt(fabs(Areg[i * 6 + i]));
+    for (int i = 0; i < D; ++i) {
+        const double vb = fabs(Gb[i + OFF]) * sa[i], va = dmax[i + OFF] * sa[i];
+        nan = nan || !(vb == vb) || !(va == va);
+        gmax = vb > gmax ? vb : gmax;
+        amp = va > amp ? va : amp;
+        for (int j = 0; j < D; ++j) {
+            const double v = fabs(Gs[(i + OFF) * 6 + (j + OFF)]) * sa[i] * sa[j];
+            nan = nan || !(v == v);
+            m = v > m ? v : m;
+        }
+    }
+    m = gmax > m ? gmax : m;
+    const double ref = sk.mref[cloud], worst = gmax * amp > m ? gmax * amp : m;
+    if (!nan && 16.0 * worst <= sk.eps * ref) return 2;
+    if (!nan && m > ref) sk.mref[cloud] = m;
+    if (sk.live_k) atomicAdd(sk.live_k, 1);
+    return 0;
+}
+
+// What is left of step_backward for a cloud whose sweep has ended: the part of the pose cotangent that does not go through the normal
+// equations, C_new = exp(delta^)^T C -> gC = R gCn, gr = grn.  It must go on: a loss may depend on the 3x3 block of T in directions that are
+// no rotation at all (T.sum() does), and those pass through every iteration unchanged down to the gradient of T_init.
+DICP_HD void pose_pass_through(const double* gCn, const double* grn, const double* delta6, double* gC, double* gr) {
+    double R[9];
+    so3_exp(delta6, R);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            gC[i * 3 + j] = R[i * 3 + 0] * gCn[0 * 3 + j] + R[i * 3 + 1] * gCn[1 * 3 + j] + R[i * 3 + 2] * gCn[2 * 3 + j];
+    for (int i = 0; i < 3; ++i) gr[i] = grn[i];
+}
+
 template <typename T>
 __global__ __launch_bounds__(WAVE) void step_bwd_kernel(const double* __restrict__ gpose_in, const T* __restrict__ bwd_partials,
                                                         int nblk, int dim, const T* __restrict__ pose_k,
                                                         const T* __restrict__ delta_k, long delta_stride,
                                                         const double* __restrict__ areg_k, T* __restrict__ gs,
-                                                        T* __restrict__ gb, double* __restrict__ gpose_out, int N) {
-    __shared__ double sg[NBWD_PAD], sC[9], sd[6], sAreg[36], sGs[36], sGb[6], sgo[12];
+                                                        T* __restrict__ gb, double* __restrict__ gpose_out, int N, SkipArgs<T> sk) {
+    __shared__ double sg[NBWD_PAD], sC[9], sd[6], sAreg[36], sGs[36], sGb[6], sgo[12], sdmax[6];
     const int cloud = blockIdx.x, tid = threadIdx.x;
+    if (sk.skip && sk.skip[cloud] == 2) {                   // this cloud's reverse sweep has ended (skip_decision): only the pass-through part goes on
+        if (tid == 0) {                                     // (the accumulate_bwd blocks of an ended cloud publish zero sums: nothing to add to gpose_in)
+            double g[12], d[6], go[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) g[k] = gpose_in[(size_t)cloud * 12 + k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) d[k] = (double)delta_k[(size_t)cloud * delta_stride + k];
+            pose_pass_through(g, g + 9, d, go, go + 9);
+#pragma unroll
+            for (int k = 0; k < 12; ++k) gpose_out[(size_t)cloud * 12 + k] = go[k];
+        }
+        return;
+    }
+    if (sk.skip) {                                          // the largest step of the EARLIER iterations, per component (lanes over iterations)
+        double dm[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int j = 1 + tid; j <= sk.k; j += WAVE) {
+            const T* dp = delta_k + (size_t)cloud * delta_stride - (size_t)j * 6;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { const double v = fabs((double)dp[i]); dm[i] = v > dm[i] ? v : dm[i]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+#pragma unroll
+            for (int off = WAVE / 2; off > 0; off >>= 1) { const double o = __shfl_down(dm[i], off); dm[i] = o > dm[i] ? o : dm[i]; }
+        }
+        if (tid == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) sdmax[i] = dm[i];
+        }
+    }
     {
         const int slot_i = tid & 15, part = tid >> 4;       // 4 partial sums per slot
         double s = 0.0;
@@ -2663,6 +2369,13 @@ __global__ __launch_bounds__(WAVE) void step_bwd_kernel(const double* __restrict
 #pragma unroll
         for (int k = 0; k < 36; ++k) A[k] = sAreg[k];
         step_backward(g, g + 9, dim, C, d, A, Gs, Gb, go, go + 9);
+        if (sk.skip) {
+            double dmx[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) dmx[k] = sdmax[k];
+            const int verdict = skip_decision(Gs, Gb, A, dmx, dim, cloud, sk);
+            sk.skip[cloud] = verdict;       // (verdict 2: go is already what passes through; Gs / Gb are written but no block will read them)
+        }
 #pragma unroll
         for (int k = 0; k < 36; ++k) sGs[k] = Gs[k];
 #pragma unroll
@@ -2692,8 +2405,10 @@ __global__ __launch_bounds__(BLOCK) void icp_small_backward_kernel(WeightParams 
     __shared__ double sg[NBWD_PAD], sC[9], sd[6], sAreg[36], sGs[36], sGb[6], sgo[12], spart[NBWD_PAD];
     __shared__ T red[(BLOCK / WAVE) * NBWD_PAD];
     __shared__ T part[NBWD_PAD];
+    __shared__ int s_skip;
     const int cloud = blockIdx.x, tid = threadIdx.x, c = B.c;
     const int nc = rows_of(B.src_rows, cloud, n);           // ragged batches: rows past the cloud's own carry no gradient
+    bool ended = B.bwd_skip && B.bwd_skip[cloud] == 2;      // (this cloud's reverse sweep ended in an earlier chunk)
     if (gtgt)
         for (int e = tid; e < m * CV; e += BLOCK) gt[e] = T(0);
     if (tid < 12) sgo[tid] = gpose_in[(size_t)cloud * 12 + tid];
@@ -2715,8 +2430,30 @@ __global__ __launch_bounds__(BLOCK) void icp_small_backward_kernel(WeightParams 
         if (tid < 6) sd[tid] = (double)((const T*)B.deltas)[(size_t)cloud * B.K * 6 + (size_t)k * 6 + tid];
         if (tid < 36) sAreg[tid] = B.areg[((size_t)k * N + cloud) * 36 + tid];
         __syncthreads();
-        if (tid == 0) step_backward(sg, sg + 9, dim, sC, sd, sAreg, sGs, sGb, sgo, sgo + 9);
+        if (ended) {                                        // the sweep has ended: only the pass-through part of the pose cotangent goes on
+            if (tid == 0) pose_pass_through(sg, sg + 9, sd, sgo, sgo + 9);
+            __syncthreads();
+            continue;
+        }
+        if (tid == 0) {
+            step_backward(sg, sg + 9, dim, sC, sd, sAreg, sGs, sGb, sgo, sgo + 9);
+            s_skip = 0;
+            if (B.bwd_skip) {
+                const SkipArgs<T> sk{B.bwd_skip, B.bwd_mref, (const T*)B.alive + (size_t)k * N, B.bwd_live ? B.bwd_live + k : nullptr, B.bwd_skip_eps, k};
+                double dmx[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+                for (int j = 0; j < k; ++j)
+                    for (int i = 0; i < 6; ++i) { const double v = fabs((double)((const T*)B.deltas)[(size_t)cloud * B.K * 6 + (size_t)j * 6 + i]); dmx[i] = v > dmx[i] ? v : dmx[i]; }
+                s_skip = skip_decision(sGs, sGb, sAreg, dmx, dim, cloud, sk);
+                B.bwd_skip[cloud] = s_skip;
+            }
+        }
         __syncthreads();
+        if (s_skip) {       // 2: the cloud's reverse sweep ends here (see skip_decision) -- 1: frozen at this iteration, every term is exactly zero
+            if (tid < NBWD_PAD) { spart[tid] = 0.0; part[tid] = T(0); }
+            __syncthreads();
+            if (s_skip == 2) { ended = true; }
+            continue;
+        }
         T C[9], r[3], Gs[36], Gb[6];
         load_pose(pose_k, cloud, C, r);
 #pragma unroll
@@ -3306,15 +3043,6 @@ int knn_mfma_launch(int cfg, const void* src, const void* pose, const void* tgt4
     return launch_status();
 }
 
-inline size_t run_align(size_t v) { return (v + 255) / 256 * 256; }
-// how many blocks of a run kernel one launch may hold: every block must be resident for the per-cloud waits to be safe
-template <typename K>
-int run_resident_blocks(K kernel, int cap_per_cu) {
-    int dev = 0, cus = 0, occ = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, BLOCK, 0) != hipSuccess) return 0;
-    return cus * std::max(0, std::min(occ, cap_per_cu));
-}
 }  // namespace
 
 // ======================================================================== C ABI
@@ -3658,27 +3386,45 @@ int dicp_step(int dtype, const dicp_step_io* io, int N, void* stream) {
     return launch_status();
 }
 
-int dicp_step_bwd(int dtype, const double* gpose_in, const void* bwd_partials, int nblk, int dim,
-                  const void* pose_k, const void* delta_k, int64_t delta_stride, const double* areg_k,
-                  void* gs, void* gb, double* gpose_out, int N, void* stream) {
-    if (!gpose_in || !pose_k || !delta_k || !areg_k || !gs || !gb || !gpose_out) return DICP_ERR_NULL;
+struct SkipHost { int32_t* skip; double* mref; const void* alive_k; int32_t* live_k; double eps; int k; };     // SkipArgs, untyped (all NULL / 0: off)
+static int step_bwd_go(int dtype, const double* gpose_in, const void* bwd_partials, int nblk, int dim,
+                       const void* pose_k, const void* delta_k, int64_t delta_stride, const double* areg_k,
+                       void* gs, void* gb, double* gpose_out, int N, void* stream, const SkipHost& sh) {
+    if (!gpose_in || !pose_k || !delta_k || !areg_k || !gs || !gb || !gpose_out || (sh.skip && !sh.mref)) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || (dim != 2 && dim != 3) || delta_stride < 6 || (bwd_partials && nblk <= 0)) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     begin_launch();
     if (dtype == DICP_F32)
         step_bwd_kernel<float><<<N, WAVE, 0, st>>>(gpose_in, (const float*)bwd_partials, nblk, dim, (const float*)pose_k,
-                                                  (const float*)delta_k, (long)delta_stride, areg_k, (float*)gs, (float*)gb, gpose_out, N);
+                                                  (const float*)delta_k, (long)delta_stride, areg_k, (float*)gs, (float*)gb, gpose_out, N,
+                                                  SkipArgs<float>{sh.skip, sh.mref, (const float*)sh.alive_k, sh.live_k, sh.eps, sh.k});
     else
         step_bwd_kernel<double><<<N, WAVE, 0, st>>>(gpose_in, (const double*)bwd_partials, nblk, dim, (const double*)pose_k,
-                                                   (const double*)delta_k, (long)delta_stride, areg_k, (double*)gs, (double*)gb, gpose_out, N);
+                                                   (const double*)delta_k, (long)delta_stride, areg_k, (double*)gs, (double*)gb, gpose_out, N,
+                                                   SkipArgs<double>{sh.skip, sh.mref, (const double*)sh.alive_k, sh.live_k, sh.eps, sh.k});
     return launch_status();
 }
+int dicp_step_bwd(int dtype, const double* gpose_in, const void* bwd_partials, int nblk, int dim,
+                  const void* pose_k, const void* delta_k, int64_t delta_stride, const double* areg_k,
+                  void* gs, void* gb, double* gpose_out, int N, void* stream) {
+    return step_bwd_go(dtype, gpose_in, bwd_partials, nblk, dim, pose_k, delta_k, delta_stride, areg_k, gs, gb, gpose_out, N, stream, SkipHost{});
+}
 
+static int accumulate_bwd_go(int dtype, const dicp_weight_params* prm, const void* src, const void* tgt, int c,
+                             const int32_t* idx, const void* pose, const void* w_init, const void* alive,
+                             const void* gs, const void* gb, const int32_t* src_rows, int N, int n, int m,
+                             void* gsrc, void* gtgt, void* gw, void* bwd_partials, void* stream, const int32_t* skip);
 int dicp_accumulate_bwd(int dtype, const dicp_weight_params* prm, const void* src, const void* tgt, int c,
                         const int32_t* idx, const void* pose, const void* w_init, const void* alive,
                         const void* gs, const void* gb, const int32_t* src_rows, int N, int n, int m,
                         void* gsrc, void* gtgt, void* gw, void* bwd_partials, void* stream) {
+    return accumulate_bwd_go(dtype, prm, src, tgt, c, idx, pose, w_init, alive, gs, gb, src_rows, N, n, m, gsrc, gtgt, gw, bwd_partials, stream, nullptr);
+}
+static int accumulate_bwd_go(int dtype, const dicp_weight_params* prm, const void* src, const void* tgt, int c,
+                             const int32_t* idx, const void* pose, const void* w_init, const void* alive,
+                             const void* gs, const void* gb, const int32_t* src_rows, int N, int n, int m,
+                             void* gsrc, void* gtgt, void* gw, void* bwd_partials, void* stream, const int32_t* skip) {
     if (const int e = check_params(prm, c)) return e;
     if (!src || !tgt || !gs || !gb || !gsrc || !bwd_partials || (gw && !w_init)) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
@@ -3689,7 +3435,7 @@ int dicp_accumulate_bwd(int dtype, const dicp_weight_params* prm, const void* sr
     const int bpc = dicp_accumulate_blocks(n);
     const unsigned g = grid_for(N, bpc);
 #define DICP_BWD(T, M) accumulate_bwd_kernel<T, M><<<g, BLOCK, 0, st>>>(P, (const T*)src, (const T*)tgt, c, idx, (const T*)pose, \
-        (const T*)w_init, (const T*)alive, (const T*)gs, (const T*)gb, N, n, m, bpc, (T*)gsrc, (T*)gtgt, (T*)gw, (T*)bwd_partials, src_rows)
+        (const T*)w_init, (const T*)alive, (const T*)gs, (const T*)gb, N, n, m, bpc, (T*)gsrc, (T*)gtgt, (T*)gw, (T*)bwd_partials, src_rows, skip)
     if (dtype == DICP_F32) { if (P.mode == MODE_PT2PL) DICP_BWD(float, MODE_PT2PL); else DICP_BWD(float, MODE_PT2PT); }
     else                   { if (P.mode == MODE_PT2PL) DICP_BWD(double, MODE_PT2PL); else DICP_BWD(double, MODE_PT2PT); }
 #undef DICP_BWD
@@ -3822,10 +3568,21 @@ int dicp_window_blocks(int dtype, int n, int m_pad) {
 
 int dicp_window_rows(int dtype) { return dtype == DICP_F32 ? WindowRows<float>::v : WindowRows<double>::v; }
 
+static int accumulate_bwd_window_go(int dtype, const dicp_weight_params* prm, const void* src_s, const void* tgt_s, int c,
+                                    const int32_t* spos, const int32_t* spos_ref, const int32_t* qorder, const void* pose, const void* w_s,
+                                    const void* alive, const void* gs, const void* gb, const int32_t* src_rows, int N, int n, int m_pad, void* gsrc_s, void* slab,
+                                    void* gts_far, void* gw_s, void* bwd_partials, int overwrite, void* stream, const int32_t* skip);
 int dicp_accumulate_bwd_window(int dtype, const dicp_weight_params* prm, const void* src_s, const void* tgt_s, int c,
                                const int32_t* spos, const int32_t* spos_ref, const int32_t* qorder, const void* pose, const void* w_s,
                                const void* alive, const void* gs, const void* gb, const int32_t* src_rows, int N, int n, int m_pad, void* gsrc_s, void* slab,
                                void* gts_far, void* gw_s, void* bwd_partials, int overwrite, void* stream) {
+    return accumulate_bwd_window_go(dtype, prm, src_s, tgt_s, c, spos, spos_ref, qorder, pose, w_s, alive, gs, gb, src_rows, N, n, m_pad, gsrc_s, slab, gts_far, gw_s,
+                                    bwd_partials, overwrite, stream, nullptr);
+}
+static int accumulate_bwd_window_go(int dtype, const dicp_weight_params* prm, const void* src_s, const void* tgt_s, int c,
+                                    const int32_t* spos, const int32_t* spos_ref, const int32_t* qorder, const void* pose, const void* w_s,
+                                    const void* alive, const void* gs, const void* gb, const int32_t* src_rows, int N, int n, int m_pad, void* gsrc_s, void* slab,
+                                    void* gts_far, void* gw_s, void* bwd_partials, int overwrite, void* stream, const int32_t* skip) {
     if (const int e = check_params(prm, c)) return e;
     if (!src_s || !tgt_s || !spos || !spos_ref || !pose || (gw_s && !w_s) || !gs || !gb || !gsrc_s || !bwd_partials || (slab && !gts_far))
         return DICP_ERR_NULL;
@@ -3842,7 +3599,7 @@ int dicp_accumulate_bwd_window(int dtype, const dicp_weight_params* prm, const v
 #define DICP_WIN_O(T, M, OV) do { constexpr int WT = WindowRows<T>::v; const int spb = window_slots(WT, n, m_pad); \
         hipExtLaunchKernelGGL((accumulate_bwd_window_kernel<T, M, WT, OV>), dim3(g), dim3(BLOCK), 0, st, ev0, ev1, 0, P, (const T*)src_s, (const T*)tgt_s, c, spos, spos_ref, qorder, (const T*)pose, \
             (const T*)w_s, (const T*)alive, (const T*)gs, (const T*)gb, N, n, m_pad, spb, bpc, (T*)gsrc_s, (T*)slab, (T*)gts_far, (T*)gw_s, \
-            (T*)bwd_partials, src_rows); } while (0)
+            (T*)bwd_partials, src_rows, skip); } while (0)
     if (dtype == DICP_F32) { if (P.mode == MODE_PT2PL) DICP_WIN(float, MODE_PT2PL); else DICP_WIN(float, MODE_PT2PT); }
     else                   { if (P.mode == MODE_PT2PL) DICP_WIN(double, MODE_PT2PL); else DICP_WIN(double, MODE_PT2PT); }
 #undef DICP_WIN
@@ -4021,6 +3778,7 @@ int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_
         !gpose || !gpose_tmp || !gs || !gb || !gsrc || !bwd_partials) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (k0 < 0 || k1 > B->K || k0 > k1 || !B->idx_per_iter || (B->spos && (B->m_pad <= 0 || !B->spos_ref))) return DICP_ERR_SHAPE;
+    if (B->bwd_skip && (!B->bwd_mref || !(B->bwd_skip_eps >= 0.0))) return DICP_ERR_NULL;
     const size_t es = dtype == DICP_F32 ? 4 : 8;
     hipStream_t st = (hipStream_t)stream;
     const int nblk = B->spos ? dicp_window_blocks(dtype, n, B->m_pad) : dicp_accumulate_blocks(n);
@@ -4044,21 +3802,23 @@ int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_
     double* gout = gpose_tmp;
     for (int k = k1 - 1; k >= k0; --k) {
         const char* pose_k = (const char*)B->poses + (size_t)k * N * 12 * es;
-        int rc = dicp_step_bwd(dtype, gin, have_partials ? bwd_partials : nullptr, nblk, dim, pose_k,
-                               (const char*)B->deltas + (size_t)k * 6 * es, (int64_t)B->K * 6, B->areg + (size_t)k * N * 36,
-                               gs, gb, gout, N, stream);
+        const char* alive_k = (const char*)B->alive + (size_t)k * N * es;
+        const SkipHost sh{B->bwd_skip, B->bwd_mref, alive_k, B->bwd_live ? B->bwd_live + k : nullptr, B->bwd_skip_eps, k};
+        int rc = step_bwd_go(dtype, gin, have_partials ? bwd_partials : nullptr, nblk, dim, pose_k,
+                             (const char*)B->deltas + (size_t)k * 6 * es, (int64_t)B->K * 6, B->areg + (size_t)k * N * 36,
+                             gs, gb, gout, N, stream, B->bwd_skip ? sh : SkipHost{});
         if (rc) return rc;
         if (B->events) {
             if (B->spos) set_launch_events((hipEvent_t)B->events[6 * k + 4], (hipEvent_t)B->events[6 * k + 5]);
             else if (hipEventRecord((hipEvent_t)B->events[6 * k + 4], st) != hipSuccess) return -(int)hipGetLastError();
         }
         if (B->spos)    // windowed form: src / w_init / tgt are the SORTED copies, gsrc / gw accumulate in slot order, gtgt is the slab
-            rc = dicp_accumulate_bwd_window(dtype, prm, B->src, B->tgt, B->c, B->spos + (size_t)k * N * n, B->spos_ref, B->qorder, pose_k, B->w_init,
-                                            (const char*)B->alive + (size_t)k * N * es, gs, gb, B->src_rows, N, n, B->m_pad,
-                                            gsrc, gtgt, B->gts_far, gw, bwd_partials, (B->bwd_overwrite && k == k1 - 1) ? 1 : 0, stream);
+            rc = accumulate_bwd_window_go(dtype, prm, B->src, B->tgt, B->c, B->spos + (size_t)k * N * n, B->spos_ref, B->qorder, pose_k, B->w_init,
+                                          alive_k, gs, gb, B->src_rows, N, n, B->m_pad,
+                                          gsrc, gtgt, B->gts_far, gw, bwd_partials, (B->bwd_overwrite && k == k1 - 1) ? 1 : 0, stream, B->bwd_skip);
         else
-            rc = dicp_accumulate_bwd(dtype, prm, B->src, B->tgt, B->c, B->idx + (size_t)k * N * n, pose_k, B->w_init,
-                                     (const char*)B->alive + (size_t)k * N * es, gs, gb, B->src_rows, N, n, m, gsrc, gtgt, gw, bwd_partials, stream);
+            rc = accumulate_bwd_go(dtype, prm, B->src, B->tgt, B->c, B->idx + (size_t)k * N * n, pose_k, B->w_init,
+                                   alive_k, gs, gb, B->src_rows, N, n, m, gsrc, gtgt, gw, bwd_partials, stream, B->bwd_skip);
         set_launch_events(nullptr, nullptr);
         if (rc) return rc;
         if (B->events && !B->spos) { if (hipEventRecord((hipEvent_t)B->events[6 * k + 5], st) != hipSuccess) return -(int)hipGetLastError(); }
@@ -4067,67 +3827,6 @@ int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_
     }
     // the two buffers alternate: after an odd number of iterations the result sits in gpose_tmp (no copy: the caller
     // swaps its two pointers, see dicp_hip.h)
-    return 0;
-}
-
-// ---- a run of backward iterations [k0, k1) of the windowed form in ONE launch per group of co-resident clouds (icp_run_backward_kernel).
-// Scratch (caller-allocated, dicp_run_scratch_bytes): | count (N,32) i32 | flag (N,32) i32 | err (32) i32 | gpass (N,16) f64 | gsb (N,64) T | rec (N,bpc,16) T |
-size_t dicp_run_scratch_bytes(int dtype, int N, int n, int m_pad) {
-    if (bad_dtype(dtype) || N <= 0 || n <= 0) return 0;
-    const size_t es = dtype == DICP_F32 ? 4 : 8;
-    const size_t bpc = (size_t)std::max(dicp_window_blocks(dtype, n, m_pad), dicp_accumulate_blocks(n));
-    return run_align((size_t)N * RUN_LINE * 4) * 2 + 256 + run_align((size_t)N * 16 * 8) + run_align((size_t)N * 64 * es) + run_align((size_t)N * bpc * 32 * es);
-}
-int dicp_icp_backward_run(int dtype, const dicp_weight_params* prm, const dicp_loop_buffers* B, int N, int n, int m, int dim,
-                          const double* gpose_in, double* gpose_out, void* gsrc, void* gtgt, void* gw,
-                          void* scratch, size_t scratch_bytes, int k0, int k1, void* stream) {
-    if (!prm || !B || !B->src || !B->tgt || !B->poses || !B->deltas || !B->areg || !B->alive || !B->spos || !B->spos_ref || (gw && !B->w_init) ||
-        !gpose_in || !gpose_out || !gsrc || !scratch || (gtgt && !B->gts_far)) return DICP_ERR_NULL;
-    if (dtype != DICP_F32) return DICP_ERR_DTYPE;                    // (the run keeps its slots in registers: float32 only; float64 takes the per-iteration launches)
-    if (k0 < 0 || k1 > B->K || k0 >= k1 || N <= 0 || n <= 0 || m <= 0 || B->m_pad <= 0 || B->m_pad % KNN_PAD || (dim != 2 && dim != 3)) return DICP_ERR_SHAPE;
-    if (scratch_bytes < dicp_run_scratch_bytes(dtype, N, n, B->m_pad) || ((uintptr_t)scratch & 255)) return DICP_ERR_SHAPE;
-    if (const int e = check_params(prm, B->c)) return e;
-    hipStream_t st = (hipStream_t)stream;
-    begin_launch();
-    const WeightParams P = to_params(prm);
-    const int bpc = dicp_window_blocks(dtype, n, B->m_pad);
-    constexpr int WT = WindowRows<float>::v;
-    const bool has_w = B->w_init != nullptr;
-#define DICP_RUNB(M, W) icp_run_backward_kernel<float, M, WT, W>
-    const int resident = P.mode == MODE_PT2PL ? (has_w ? run_resident_blocks(DICP_RUNB(MODE_PT2PL, true), 4) : run_resident_blocks(DICP_RUNB(MODE_PT2PL, false), 4))
-                                              : (has_w ? run_resident_blocks(DICP_RUNB(MODE_PT2PT, true), 4) : run_resident_blocks(DICP_RUNB(MODE_PT2PT, false), 4));
-    int per_launch = (resident / bpc) / 8 * 8;                       // whole clouds, in groups of 8 (the XCD block mapping)
-    if (per_launch < 8) { if (resident < bpc) return DICP_ERR_SHAPE; per_launch = resident / bpc; }     // (a cloud's blocks must fit on the chip together)
-    char* sc = (char*)scratch;
-    const size_t es = 4, line = run_align((size_t)N * RUN_LINE * 4);
-    int32_t* count = (int32_t*)sc; int32_t* flag = (int32_t*)(sc + line); int32_t* err = (int32_t*)(sc + 2 * line);
-    double* gpass = (double*)(sc + 2 * line + 256);
-    float* gsb = (float*)((char*)gpass + run_align((size_t)N * 16 * 8));
-    float* rec = (float*)((char*)gsb + run_align((size_t)N * 64 * es));
-    if (hipMemsetAsync(sc, 0, 2 * line + 256, st) != hipSuccess) return -(int)hipGetLastError();
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (B->events) { ev0 = (hipEvent_t)B->events[6 * (k1 - 1) + 4]; ev1 = (hipEvent_t)B->events[6 * (k1 - 1) + 5]; }   // the run's pair: the slot of its first (highest) iteration
-    RunBwdArgs<float> A;
-    A.src_s = (const float*)B->src; A.tgt_s = (const float*)B->tgt; A.c = B->c; A.spos = B->spos; A.spos_ref = B->spos_ref; A.qorder = B->qorder;
-    A.poses = (const float*)B->poses; A.deltas = (const float*)B->deltas; A.delta_stride = (long)B->K * 6; A.areg = B->areg; A.alive = (const float*)B->alive;
-    A.w_s = (const float*)B->w_init; A.gpose_in = gpose_in; A.gpose_out = gpose_out; A.gsrc_s = (float*)gsrc; A.slab = (float*)gtgt;
-    A.gts_far = (float*)B->gts_far; A.gw_s = (float*)gw; A.rec = rec; A.gsb = gsb; A.gpass = gpass; A.count = count; A.flag = flag; A.err = err;
-    {   // (diagnostics: a caller that hands over room for them behind the scratch gets per-block, per-iteration timestamps)
-        const size_t need = dicp_run_scratch_bytes(dtype, N, n, B->m_pad), dbg_bytes = (size_t)N * bpc * (k1 - k0) * 4 * 8;
-        A.dbg = scratch_bytes >= need + dbg_bytes + 256 ? (unsigned long long*)(sc + need) : nullptr;
-    }
-    A.src_rows = B->src_rows; A.N = N; A.n = n; A.m_pad = B->m_pad; A.spb = window_slots(WT, n, B->m_pad); A.bpc = bpc; A.dim = dim; A.k0 = k0; A.k1 = k1;
-    for (int c0 = 0; c0 < N; c0 += per_launch) {
-        A.cloud0 = c0; A.ncl = std::min(per_launch, N - c0);
-        const unsigned g = grid_for(A.ncl, bpc);
-        hipEvent_t a = c0 == 0 ? ev0 : nullptr, b = c0 + per_launch >= N ? ev1 : nullptr;
-        if (P.mode == MODE_PT2PL) { if (has_w) hipExtLaunchKernelGGL((DICP_RUNB(MODE_PT2PL, true)), dim3(g), dim3(BLOCK), 0, st, a, b, 0, P, A);
-                                    else       hipExtLaunchKernelGGL((DICP_RUNB(MODE_PT2PL, false)), dim3(g), dim3(BLOCK), 0, st, a, b, 0, P, A); }
-        else                      { if (has_w) hipExtLaunchKernelGGL((DICP_RUNB(MODE_PT2PT, true)), dim3(g), dim3(BLOCK), 0, st, a, b, 0, P, A);
-                                    else       hipExtLaunchKernelGGL((DICP_RUNB(MODE_PT2PT, false)), dim3(g), dim3(BLOCK), 0, st, a, b, 0, P, A); }
-        if (const int e = launch_status()) return e;
-    }
-#undef DICP_RUNB
     return 0;
 }
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DICP_ABI_VERSION 4   /* 4: dicp_icp_backward_run / dicp_run_scratch_bytes (a run of backward iterations in one launch).
+#define DICP_ABI_VERSION 4   /* 4: dicp_loop_buffers.bwd_skip / bwd_mref / bwd_live / bwd_skip_eps (truncated reverse sweep of dicp_icp_backward).
                                 3: per-cloud row counts of ragged batches (src_rows / tgt_rows) on every entry point of the path; the centred and
                                 uncentred forms of an entry point are one (center may be NULL); the key sort is native for every size and dtype;
                                 timing events are 6 per iteration; the scan / packed / fused-accumulate search forms are gone */
@@ -270,6 +270,20 @@ typedef struct dicp_loop_buffers {
     const void* tgt_sorted;  /* sweep only, optional (N,m_pad,tgt_sorted_stride): dicp_sweep_build's tgt_s.  With it (and spos) the forward accumulate
                                 gathers the match rows from the sorted copy at spos -- one aligned sector per row -- and idx may be NULL */
     int32_t tgt_sorted_stride;
+    /* dicp_icp_backward, optional: truncated reverse sweep.  Going backwards, iteration k adds to every gradient something LINEAR in the
+       cotangent (G_A + G_A^T, g_b)_k of its normal equations, and the chain of pose cotangents shrinks by orders of magnitude per iteration near
+       the pose (a Gauss-Newton step near its fixed point is a strong contraction).  step_bwd measures, per cloud and in the data's own units,
+       what iteration k adds (m_k = max |G_ab| s_a s_b, |g_a| s_a with s_a = sqrt(A_aa)) and the most any earlier iteration could add
+       (|g_a| s_a times the largest recorded step |delta_k',b| s_b of the iterations before k), and ENDS the cloud's sweep at iteration k -- this
+       and all earlier iterations do no per-point work; of the pose cotangent only the part that does not go through the normal equations
+       (C_new = exp(delta^)^T C: gC = R gCn, gr = grn) travels on to the gradient of T_init -- when 16x the larger of the two is
+       below bwd_skip_eps times the largest m of the cloud's later iterations.  The host side passes a few units of the result type's roundoff
+       (2^-22 for float32, 2^-40 for float64): what is dropped is below the resolution of the sums it would be added to.  Iterations at which a
+       cloud was frozen (alive = 0) are skipped too (every term is exactly zero).  bwd_skip NULL = off: every iteration runs, like autograd. */
+    int32_t* bwd_skip;       /* (N) zero-initialised once per backward pass (all chunks of it share it): 0 take part / 1 frozen at this iteration / 2 sweep ended */
+    double* bwd_mref;        /* (N) zero-initialised once per backward pass */
+    int32_t* bwd_live;       /* optional (K) zeros: clouds that took part in iteration k */
+    double bwd_skip_eps;
 } dicp_loop_buffers;
 
 /* Head and tail of the backward loop.  dicp_pose_grad_in: gpose (N,12) double = [dL/dC row-major (9), dL/dr (3)] taken from the
@@ -303,20 +317,6 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
 int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_buffers* buf, int N, int n, int m, int dim,
                       double* gpose, double* gpose_tmp, int have_partials, void* gs, void* gb, void* gsrc, void* gtgt, void* gw,
                       void* bwd_partials, int k0, int k1, void* stream);
-/* A RUN of iterations [k0,k1) of the windowed reverse sweep in one launch per group of co-resident clouds (float32; the reverse of
- * ICP.py:132-260 for iterations whose matches (nn.py:32-35) hardly change any more): every block keeps its slots' points, match rows and
- * the gradients it accumulates for them on chip over the whole run, the per-cloud chain accumulate_bwd(k) -> step_bwd(k-1) runs inside the
- * launch.  `buf` as dicp_icp_backward's windowed form (src / w_init / tgt = the sorted copies, spos = virtual base of the
- * match history, spos_ref, qorder, gts_far zero-initialised); [k0,k1) must lie in one history slab.  gpose_in (N,12) double: cotangent of
- * pose_k1; gpose_out: cotangent of pose_k0 COMPLETE (continue with dicp_icp_backward(..., have_partials = 0, ...)).  gsrc / gtgt (the slab) /
- * gw are WRITTEN, not added to: the run is the first writer of a backward call (later launches add with bwd_overwrite = 0).
- * scratch: dicp_run_scratch_bytes() bytes, 256-byte aligned.  A wait that cannot complete (never observed; every spin is bounded) leaves NaN in
- * that cloud's gpose_out instead of hanging. */
-size_t dicp_run_scratch_bytes(int dtype, int N, int n, int m_pad);
-int dicp_icp_backward_run(int dtype, const dicp_weight_params* prm, const dicp_loop_buffers* buf, int N, int n, int m, int dim,
-                          const double* gpose_in, double* gpose_out, void* gsrc, void* gtgt, void* gw,
-                          void* scratch, size_t scratch_bytes, int k0, int k1, void* stream);
-
 
 /* Backward of dicp_step for iteration k.  gpose_in (N,12) double = cotangent of pose_out
  * that flowed through later iterations; bwd_partials (N,nblk,DICP_NBWD_PAD) T = the

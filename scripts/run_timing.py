@@ -1,4 +1,5 @@
-"""Per-call timing of the headline call with / without the in-launch runs.  usage: python scripts/run_timing.py [K ...]"""
+"""Per-call timing of the headline call: forward / backward, with the backward's negligible-cotangent skip on and off.
+usage: python scripts/run_timing.py [K ...]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,7 +10,7 @@ Ks = [int(a) for a in sys.argv[1:]] or [10, 20]
 src, tgt = make_pairs(B, n, n, seed=3); src, tgt = src.cuda(), tgt.cuda()
 T0 = torch.eye(4, device="cuda").repeat(B, 1, 1)
 for K in Ks:
-    for name, kw in (("per-iteration launches", dict(bwd_run=False)), ("backward run", dict(bwd_run=True)), ("backward run from 2", dict(bwd_run=True, bwd_run_from=2))):
+    for name, kw in (("full reverse sweep", dict(bwd_skip_eps=0.0)), ("negligible-cotangent skip", dict(bwd_skip_eps=None))):
         icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12); icp.const_iter = True
         for k, v in kw.items(): setattr(icp, k, v)
         def call():
@@ -21,4 +22,6 @@ for K in Ks:
         for _ in range(7):
             torch.cuda.synchronize(); t0 = time.perf_counter(); t1, g = call(); t2 = time.perf_counter(); fw.append(t1 - t0); bw.append(t2 - t1)
         fw.sort(); bw.sort()
-        print("K=%2d %-24s forward %.3f ms  backward %.3f ms  total %.3f ms  (%.0f cloud-it/s)  finite %s  run %s" % (K, name, fw[3] * 1e3, bw[3] * 1e3, (fw[3] + bw[3]) * 1e3, B * K / (fw[3] + bw[3]), bool(torch.isfinite(g).all()), icp.knn_stats.get("bwd_run")), flush=True)
+        live = icp.knn_stats.get("bwd_live")
+        print("K=%2d %-26s forward %.3f ms  backward %.3f ms  total %.3f ms  (%.0f cloud-it/s)  finite %s  clouds at work per backward iteration %s" % (
+            K, name, fw[3] * 1e3, bw[3] * 1e3, (fw[3] + bw[3]) * 1e3, B * K / (fw[3] + bw[3]), bool(torch.isfinite(g).all()), None if live is None else live[:K].tolist()), flush=True)

@@ -367,6 +367,9 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
         return pairs, cert
 
     pairs_scored, certified = sweep_stats(icp, K)
+    # the backward's truncated reverse sweep: clouds at work per iteration of the last timed call (None: feature off / not this path)
+    bwd_live = icp.knn_stats.get("bwd_live") if on_gpu else None
+    bwd_live = [int(v) for v in bwd_live[:K].tolist()] if bwd_live is not None else None
 
     # ---- the other legs, in the same run (each the median of its own timed calls)
     extra = {}
@@ -458,7 +461,11 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
         def mean(v):
             return sum(v) / len(v) if v else None
         unit_w = True                                                    # run_call passes weight=None: the kernels read no weights (w_init == NULL)
-        knn_ms, acc_ms, bwd_ms = mean(ev_ms["knn"]), mean(ev_ms["accumulate"]), mean(ev_ms["accumulate_bwd"])
+        knn_ms, acc_ms = mean(ev_ms["knn"]), mean(ev_ms["accumulate"])
+        # accumulate_bwd: the launches in which every cloud was at work (the truncated reverse sweep leaves the earlier iterations' launches
+        # (next to) empty: their blocks read one flag and leave -- those are in the share of the call, not in the kernel's roofline)
+        full = [v for k, v in enumerate(ev_ms["accumulate_bwd"]) if bwd_live is None or bwd_live[k] == B]
+        bwd_ms = mean(full) if full else mean(ev_ms["accumulate_bwd"])
         flops_bf = 8.0 * n * m * B                                       # brute force, per launch
         flops = flops_bf if (brute or pairs_scored is None) else 8.0 * pairs_scored   # pairs the kernel actually scored
         knn_tf = flops / (knn_ms * 1e-3) / 1e12 if knn_ms else None
@@ -497,7 +504,14 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bwd_bytes / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if bwd_ms else None,
                                "traffic": bwd_traffic, "traffic_source": bwd_src, "avg_launch_ms": bwd_ms,
                                "algorithmic_bytes_per_launch": bwd_bytes, "algorithmic_bytes_per_point": bwd_bytes / (n * B),
-                               "launch_ms_by_iteration": [round(v, 4) for v in ev_ms["accumulate_bwd"]]},
+                               "launch_ms_by_iteration": [round(v, 4) for v in ev_ms["accumulate_bwd"]],
+                               "clouds_at_work_by_iteration": bwd_live,
+                               "avg_launch_ms_note": "mean over the launches in which all %d clouds were at work" % B if bwd_live is not None else None,
+                               "truncated_reverse_sweep": None if bwd_live is None else
+                               "a cloud's reverse sweep ends at the iteration from which on nothing -- that iteration's own contribution and the most any earlier one "
+                               "could add given the recorded steps -- reaches 2^-22 of the cloud's largest contribution (below float32 rounding of the sums; the chain of "
+                               "pose cotangents contracts by ~2e-4 per iteration near the pose: profiles/r03_cotangent_decay.txt); earlier iterations do no per-point "
+                               "work.  Gradients equal the full sweep's to rounding: tests/test_gpu_skip.py, and every parity test runs with it on"},
         }
         for nm in legs:
             legs[nm]["share_of_timed_call"] = round(share[nm], 4)

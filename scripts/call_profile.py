@@ -1,0 +1,26 @@
+"""A few headline-shaped calls (fwd + bwd) for a profiler run.  usage: python3 scripts/call_profile.py [scene|random] [K] [calls] [B]
+e.g.  rocprofv3 --kernel-trace --stats -d /tmp/prof -o s --output-format csv -- python3 scripts/call_profile.py scene 10 4"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dicp_amd.ICP import ICP
+from dicp_amd.synthetic import make_pairs, make_scene_pairs
+kind = sys.argv[1] if len(sys.argv) > 1 else "scene"
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+calls = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+B = int(sys.argv[4]) if len(sys.argv) > 4 else 256
+n = 16384
+src, tgt = (make_scene_pairs if kind == "scene" else make_pairs)(B, n, n, seed=3)
+src, tgt = src.cuda(), tgt.cuda()
+T0 = torch.eye(4, device="cuda").repeat(B, 1, 1)
+icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12); icp.const_iter = True
+for _ in range(calls):
+    s, t = src.detach().requires_grad_(True), tgt.detach().requires_grad_(True)
+    out = icp.icp(s, t, T0, trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0})
+    out["T"].sum().backward()
+    torch.cuda.synchronize()
+pairs = float(icp.knn_stats["knn_pairs"].sum().item()) / K / (float(B) * n * n)
+again = icp.knn_stats.get("searched_again")
+print("%s K=%d B=%d: pairs scored %.2f %% of n*m per launch; units / queries searched again per iteration: %s / %s; backward live: %s" % (
+    kind, K, B, 100 * pairs, None if again is None else again[:K, :64].sum(1).tolist(), None if again is None else again[:K, 64:].sum(1).tolist(),
+    icp.knn_stats["bwd_live"][:K].tolist() if "bwd_live" in icp.knn_stats else None))

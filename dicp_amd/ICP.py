@@ -51,6 +51,7 @@ class ICP:
         self.sweep_resort = (0, 1, 2, 3)      # iterations at which the sweep re-orders its queries by x under the current pose
         self.cert_from = None                 # iteration of the certifying search (None: the last re-ordering of the queries)
         self.reuse_matches = True             # sweep path: search only where a match is not PROVEN unchanged since the last search (exact)
+        self.cert_backoff = True              # ... switched off per cloud, on device, where proving costs more than searching (same results)
         # backward: an iteration whose normal-equation cotangent has decayed below this fraction of the cloud's largest adds nothing above
         # rounding and does no per-point work for that cloud (None: 2^-22 float32 / 2^-40 float64; 0: every iteration, like autograd)
         self.bwd_skip_eps = None
@@ -119,7 +120,7 @@ class ICP:
             knn_variant=self.knn_variant, bwd_window=bool(self.bwd_window), stats_out=self.knn_stats,
             sync_every=self.sync_every, timing_events=self._timing_events, prebuilt=prebuilt, small_loop=bool(self.small_loop),
             src_rows=src_rows, tgt_rows=tgt_rows, sweep_resort=tuple(int(v) for v in self.sweep_resort), reuse_matches=bool(self.reuse_matches), cert_from=self.cert_from,
-            bwd_skip_eps=self.bwd_skip_eps)
+            bwd_skip_eps=self.bwd_skip_eps, cert_backoff=bool(self.cert_backoff))
         if self.nn.differentiable and self.nn.use_gumbel:                                # nn.py:14-16 via ICP.py:140
             # soft correspondences carry gradient themselves: one autograd node per iteration instead of one per call
             T, deltas, weights, costs, converged, iterations, matched = icp_loop_gumbel(

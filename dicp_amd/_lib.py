@@ -40,7 +40,7 @@ class StepIO(ctypes.Structure):
                 ("cost", vp), ("cost_prev", vp), ("cost_stride", i64), ("areg", vp), ("alive", vp), ("alive_out", vp),
                 ("converged", vp), ("iterations", vp), ("matched_ratio", vp), ("n_start", vp),
                 ("n_matched", vp), ("w_cur", vp), ("w_prev", vp), ("w_stride", i64), ("n_not_converged", vp),
-                ("center", vp), ("pose_search_out", vp), ("rmax", vp), ("dcum", vp), ("dcum_stride", i64)]
+                ("center", vp), ("pose_search_out", vp), ("rmax", vp), ("dcum", vp), ("dcum_stride", i64), ("cert_cloud", vp)]
 
 
 class LoopBuffers(ctypes.Structure):
@@ -51,7 +51,7 @@ class LoopBuffers(ctypes.Structure):
                 ("iterations", vp), ("matched_ratio", vp), ("n_start", vp), ("n_matched", vp), ("idx", vp), ("w", vp), ("w_iter", i64), ("w_stride", i64), ("w_prev0", vp),
                 ("partials", vp), ("counters", vp), ("events", vp), ("bwd_overwrite", i32), ("center", vp), ("poses_search", vp),
                 ("src_rows", vp), ("tgt_rows", vp), ("cert_q", vp), ("cert_qu", vp), ("cert_count", vp), ("rmax", vp), ("dcum", vp),
-                ("cert_reset", i32), ("spos_prev0", vp), ("tgt_sorted", vp), ("tgt_sorted_stride", i32),
+                ("cert_reset", i32), ("cert_cloud", vp), ("spos_prev0", vp), ("tgt_sorted", vp), ("tgt_sorted_stride", i32),
                 ("bwd_skip", vp), ("bwd_mref", vp), ("bwd_live", vp), ("bwd_skip_eps", f64)]
 
 

@@ -402,6 +402,7 @@ class LoopConfig:
     prebuilt: object = None       # (target, SweepIndex) started by the caller before its own host work (prebuild_search)
     small_loop: bool = True       # small clouds: one block runs a cloud's whole chunk of iterations (icp_small_* kernels)
     cert_from: object = None      # iteration of the certifying search (None: the last re-ordering of the queries)
+    cert_backoff: bool = True     # match certificates are switched off per cloud, on device, when a certified iteration costs more than 60 % of a full search
     reuse_matches: bool = True    # sweep path: match certificates -- an iteration searches only the waves holding a query whose match is not proven
                                   # unchanged since the wave's last search (exact; knn_sweep_kernel CERT)
     bwd_skip_eps: object = None   # backward: an iteration whose normal-equation cotangent is below this fraction of the largest of the cloud's later
@@ -494,7 +495,7 @@ class ICPLoop(torch.autograd.Function):
         assert Kmax >= 1, "max_iterations must be at least 1"
         need_grad = any(ctx.needs_input_grad[:4])
         if cfg.stats_out is not None:       # the statistics describe THIS call (an earlier call's certificate counters must not outlive it)
-            for key in ("knn_pairs", "searched_again", "budgets", "bwd_live"):
+            for key in ("knn_pairs", "searched_again", "budgets", "bwd_live", "certs_off"):
                 cfg.stats_out.pop(key, None)
         ctx.set_materialize_grads(False)    # no zero tensors for the six non-differentiable outputs (168 MB for the weights)
 
@@ -542,7 +543,8 @@ class ICPLoop(torch.autograd.Function):
             want_certs = (sweep is not None and cfg.reuse_matches and not (cfg.knn_variant & 0xff00) and not keep_idx
                           and Kmax - 1 - cert_from >= 3)
             arena.take((Kmax, 128) if want_certs else (0,), torch.int32)
-            deltas, costs, converged, iterations, matched, n_matched, counters, cert_count = arena.finish()
+            arena.take((N, 4) if want_certs else (0,), torch.int32)
+            deltas, costs, converged, iterations, matched, n_matched, counters, cert_count, cert_cloud = arena.finish()
             # pose_0, alive_0, n_start (ICP.py:124-129)
             certs = None
             if want_certs:
@@ -622,6 +624,7 @@ class ICPLoop(torch.autograd.Function):
                 LB.spos = ctypes.c_void_p(spos_slabs[j].data_ptr() - base * N * n * 4) if keep_spos else _p(spos_once)
                 LB.idx = (ctypes.c_void_p(idx_slabs[j].data_ptr() - base * N * n * 4) if need_grad else _p(idx_once)) if keep_idx else None
                 LB.cert_q, LB.cert_qu, LB.cert_count = (_p(certs["q"]), _p(certs["qu"]), _p(certs["count"])) if use_certs else (None, None, None)
+                LB.cert_cloud = _p(cert_cloud) if (use_certs and cfg.cert_backoff) else None
                 LB.cert_reset = int(k0 == cert_from)
                 LB.spos_prev0 = _p(spos_slabs[(k0 - 1) // kc][(k0 - 1) % kc]) if (keep_spos and k0 > 0) else None
                 LB.w = ctypes.c_void_p(w_slabs[j].data_ptr() - base * n * es)
@@ -659,6 +662,7 @@ class ICPLoop(torch.autograd.Function):
                 if certs is not None:             # (Kmax, 128) int32: [:, :64].sum(1) = units, [:, 64:].sum(1) = single queries searched again per iteration
                     cfg.stats_out["searched_again"] = certs["count"]
                     cfg.stats_out["budgets"] = certs["q"]         # (N,n) by query: the budgets as the last iteration left them
+                    cfg.stats_out["certs_off"] = (cert_cloud[:, 2] > 0).to(torch.int32)  # (N) int32: 1 = the cloud's certificates were switched off during the call (they cost more than searching everything)
             weights = (w_slabs[0] if len(w_slabs) == 1 else torch.cat(w_slabs, dim=1))[:, :K]
             deltas_out = deltas[:, :K]
             costs_out = costs[:, :K]

@@ -917,6 +917,9 @@ template <typename T> struct SweepCert {
     const T* dcum; int dstride;     // (N,dstride): (M_k, e_k) pairs per iteration
     int k;                          // this iteration
     int32_t* count;                 // (128) or NULL: [0,64) units searched again, [64,128) single queries, sharded by block
+    int32_t* cloud;                 // (N,4) or NULL, per cloud: [0] units / [1] single queries searched again in this iteration, [2] != 0: the cloud's
+                                    // certificates are switched off for the rest of the call (step kernel: they cost more than searching everything),
+                                    // [3] its units (written by the guard: "a certified iteration ran")
 };
 constexpr int CERT_MARGIN = 6;      // prune margin of a certifying search, in units of the plain one: the slab ends where H > H1 + 6E, so an
                                     // unscored row alone still leaves A = 2E (the certificate needs H2 - H1 > 4E + D S); 8: the search 4 % slower,
@@ -1195,6 +1198,12 @@ __device__ __forceinline__ void sweep_unit(const T* __restrict__ src, const T* _
 #pragma unroll
         for (int q = 0; q < Q; ++q) tot += __popcll(__ballot(nunc > q));
         if (lane == 0) ct.qu[(size_t)cloud * ((n_full + WAVE * Q - 1) / (WAVE * Q)) + unit] = tot > CERT_SLOT_MAX ? T(0) : qmin;
+        // per cloud, for the step kernel's "are certificates worth it here?": queries that got no certificate will be searched one by one in
+        // every later iteration (near-ties inside the rounding bound of a score: dense surfaces far from the centre, duplicated targets)
+        if (ct.cloud && lane == 0) {
+            if (tot) atomicAdd(ct.cloud + (size_t)cloud * 4 + 1, tot);
+            if (unit == 0) ct.cloud[(size_t)cloud * 4 + 3] = (n_full + WAVE * Q - 1) / (WAVE * Q);
+        }
     }
     // sharded: one counter serialises ~12 ns per add, which at 65k waves would outlast the kernel itself
     if (pairs && lane == 0 && !idle_wave)
@@ -1315,6 +1324,7 @@ __device__ __forceinline__ int search_point(const PointSearch<T>& ps, const int 
     if (lane == 0) {
         if (ps.pairs) atomicAdd(ps.pairs + (blockIdx.x & (DICP_PAIR_SHARDS - 1)), (unsigned long long)(r1 - r0));
         if (ps.ct.count) atomicAdd(ps.ct.count + CERT_SHARDS + (blockIdx.x & (CERT_SHARDS - 1)), 1);
+        if (ps.ct.cloud) atomicAdd(ps.ct.cloud + (size_t)cloud * 4 + 1, 1);
     }
     return bs;          // (sorted slots [0,m) hold the cloud's own rows: a row found is a real one)
 }
@@ -1337,8 +1347,10 @@ __global__ __launch_bounds__(BLOCK, DICP_SWEEP_MINW) void knn_sweep_guard_kernel
     const T step = ct.k > 0 ? dk[0] - dk[-2] : inf_v<T>();     // how far the cloud's queries can have moved in the last step
     T* qu = ct.qu + (size_t)cloud * units + unit;
     const T v = *qu;
+    if (ct.cloud && unit == 0 && lane == 0) ct.cloud[(size_t)cloud * 4 + 3] = units;
     bool plain;
-    if (v < T(0)) plain = step > -v;                            // plain mode (below): certify again once the steps are at most -v
+    if (ct.cloud && ct.cloud[(size_t)cloud * 4 + 2] > 0) plain = true;     // this cloud's certificates are off (step kernel): every unit, plainly
+    else if (v < T(0)) plain = step > -v;                       // plain mode (below): certify again once the steps are at most -v
     else {
         if (v > spent) return;
         int bad = 0, live = 0;
@@ -1368,6 +1380,7 @@ __global__ __launch_bounds__(BLOCK, DICP_SWEEP_MINW) void knn_sweep_guard_kernel
         if (plain && lane == 0) *qu = -T(0.5) * step;
     }
     if (lane == 0 && ct.count) atomicAdd(ct.count + (blockIdx.x & (CERT_SHARDS - 1)), 1);
+    if (lane == 0 && ct.cloud) atomicAdd(ct.cloud + (size_t)cloud * 4, 1);
     if (plain) sweep_unit<T, Q, CH, false>(src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, idx, spos, pairs, n_full, m_full, m_pad, src_sorted, src_rows, tgt_rows, ct,
                                            cloud, unit, tiles[wave]);
     else       sweep_unit<T, Q, CH, true>(src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, idx, spos, pairs, n_full, m_full, m_pad, src_sorted, src_rows, tgt_rows, ct,
@@ -1606,7 +1619,7 @@ __global__ __launch_bounds__(BLOCK, (CERT && sizeof(T) == 4) ? 5 : 1) void accum
     if (!decode_block(bpc, N, cloud, blk)) return;
     const int nc = rows_of(src_rows, cloud, n);             // ragged batches: rows past the cloud's own carry weight 0 (ICP.py:386-398)
     const int end = min(nc, (blk + 1) * ACC_PTS);
-    if (CERT && ps.ct.dcum) {
+    if (CERT && ps.ct.dcum && !(ps.ct.cloud && ps.ct.cloud[(size_t)cloud * 4 + 2] > 0)) {      // (certificates off for this cloud: the guard launch has just searched every unit)
         // first the budgets of this block's points (before the sums' registers are live): spent ones are searched again, one query at a
         // time by the whole wave; the thread that owns the point rewrites its match and budget and reads them back below
         const int lane = threadIdx.x & (WAVE - 1);
@@ -1690,6 +1703,7 @@ __host__ __device__ inline dicp_step_io make_step_io(const dicp_loop_buffers& B,
     io.w_prev = k > k0 ? (const char*)B.w + (size_t)(k - 1) * B.w_iter * es : (const char*)B.w_prev0; io.w_stride = B.w_stride;
     io.n_not_converged = B.counters + k;
     io.rmax = B.rmax; io.dcum = B.dcum; io.dcum_stride = 2 * (B.K + 1);
+    io.cert_cloud = B.cert_cloud;
     return io;
 }
 
@@ -1793,6 +1807,27 @@ __device__ __forceinline__ void step_body(const dicp_step_io& io, int cloud, int
         }
         ((T*)io.alive_out)[cloud] = alive_next;
         s_copy = (io.w_cur && io.w_prev && sacc[ACC_SUMW] == 0.0) ? 1 : 0;   // ICP.py:224-226
+        if (io.cert_cloud) {
+            // Match certificates must never cost more than searching everything.  What this iteration searched again for this cloud --
+            // whole units (a certifying search of a unit costs ~1.3 plain ones) and single queries (one wave per query: ~0.2 of a unit's
+            // search each, measured at the benchmark shape and on planar scenes, profiles/r03_scene_kernel_stats_before.txt) -- against the
+            // cloud's units: from 60 % of a full search on, the cloud's certificates are switched off for the rest of the call (the guard
+            // launch then searches every unit plainly, the accumulate checks nothing).  Results do not depend on it: both are exact.
+            // Two kinds of evidence: queries that got NO certificate in a search of every unit (cc[0] == 0: structural -- they will be searched
+            // one by one in every iteration from now on) switch the cloud off at once; a guarded iteration that searched much again only if
+            // the one before it did too (cc[2] == -1: one strike) -- a cloud that is still moving when the certificates start needs one
+            // expensive iteration and is cheap ever after.
+            int32_t* cc = io.cert_cloud + (size_t)cloud * 4;
+            const int units = cc[3];
+            if (units > 0) {
+                if (cc[2] <= 0) {
+                    const bool costly = 1.3 * cc[0] + 0.2 * cc[1] > 0.6 * units;
+                    const bool structural = cc[0] == 0;
+                    cc[2] = !costly ? 0 : ((structural || cc[2] < 0) ? 1 : -1);
+                }
+                cc[0] = 0; cc[1] = 0; cc[3] = 0;
+            }
+        }
     }
     __syncthreads();
     if (io.areg && tid < 36) io.areg[(size_t)cloud * 36 + tid] = sAreg[tid];
@@ -2994,7 +3029,7 @@ struct CertAcc {              // what the accumulate of a certified iteration ne
     const void* pose_search; const void* tgs4; const int32_t* tperm; const int32_t* bucket; const void* brange; int nbkt;
     const int32_t* tgt_rows; int m_full, m_pad; unsigned long long* pairs;
     void* q; void* qu; const void* dcum; int dstride, k; int32_t* count;
-    int32_t* spos; int32_t* spos_next;
+    int32_t* spos; int32_t* spos_next; int32_t* cloud;
 };
 
 template <typename T, int Q, int CH, int MINW = 1>
@@ -3236,7 +3271,7 @@ static int sweep_queries_per_lane(int cfg) { return cfg == 2 ? 2 : ((cfg == 1 ||
 static int sweep_auto_cfg(int N, int n) { return ((long)N * n >= 2L * BLOCK * 1024) ? SWEEP_CFG_BIG : 4; }
 
 struct CertArgs {             // certifying search: budgets (NULL q: plain search), motion bounds; guard: the launch of a certified iteration
-    void* q; void* qu; const void* dcum; int dstride; int k; int32_t* count; bool guard;
+    void* q; void* qu; const void* dcum; int dstride; int k; int32_t* count; bool guard; int32_t* cloud;
 };
 
 static int sweep_launch(int dtype, const void* src, const void* pose, const void* tgs4, const int32_t* tperm,
@@ -3262,10 +3297,10 @@ static int sweep_launch(int dtype, const void* src, const void* pose, const void
     if (ca.q) {             // certifying search, or the guard launch of a certified iteration
         if (!ca.qu || !ca.dcum || !spos || !qorder) return DICP_ERR_ENUM;
         if (dtype == DICP_F32) {
-            SweepCert<float> c{(float*)ca.q, (float*)ca.qu, (const float*)ca.dcum, ca.dstride, ca.k, ca.count};
+            SweepCert<float> c{(float*)ca.q, (float*)ca.qu, (const float*)ca.dcum, ca.dstride, ca.k, ca.count, ca.cloud};
             if (cfg == 2) DICP_SWEEP_CG(float, 2, 8, c); else if (cfg == 4) DICP_SWEEP_CG(float, 1, 16, c); else DICP_SWEEP_CG(float, 1, 8, c);
         } else {
-            SweepCert<double> c{(double*)ca.q, (double*)ca.qu, (const double*)ca.dcum, ca.dstride, ca.k, ca.count};
+            SweepCert<double> c{(double*)ca.q, (double*)ca.qu, (const double*)ca.dcum, ca.dstride, ca.k, ca.count, ca.cloud};
             if (cfg == 2) DICP_SWEEP_CG(double, 2, 8, c); else DICP_SWEEP_CG(double, 1, 8, c);
         }
         return launch_status();
@@ -3358,7 +3393,7 @@ static int accumulate_go(int dtype, const dicp_weight_params* prm, const void* s
         if (ca) { \
             ps.pose = (const T*)ca->pose_search; ps.tgs4 = (const typename V4<T>::type*)ca->tgs4; ps.tperm = ca->tperm; ps.bucket = ca->bucket; ps.brange = (const T*)ca->brange; \
             ps.nbkt = ca->nbkt; ps.tgt_rows = ca->tgt_rows; ps.m_full = ca->m_full; ps.m_pad = ca->m_pad; ps.pairs = ca->pairs; \
-            ps.ct = SweepCert<T>{(T*)ca->q, (T*)ca->qu, (const T*)ca->dcum, ca->dstride, ca->k, ca->count}; ps.spos = ca->spos; ps.spos_next = ca->spos_next; \
+            ps.ct = SweepCert<T>{(T*)ca->q, (T*)ca->qu, (const T*)ca->dcum, ca->dstride, ca->k, ca->count, ca->cloud}; ps.spos = ca->spos; ps.spos_next = ca->spos_next; \
             if (P.mode == MODE_PT2PL) DICP_ACC(T, MODE_PT2PL, true, ps); else DICP_ACC(T, MODE_PT2PT, true, ps); \
         } else { if (P.mode == MODE_PT2PL) DICP_ACC(T, MODE_PT2PL, false, ps); else DICP_ACC(T, MODE_PT2PT, false, ps); } } while (0)
     if (dtype == DICP_F32) DICP_ACC_T(float); else DICP_ACC_T(double);
@@ -3728,7 +3763,7 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
                 }
                 begin_launch();
                 rc = sweep_launch(dtype, qsrc, pose_s, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, N, n, m, B->m_pad, nullptr, spos_k,
-                                  B->pairs, cfg, Rows{B->src_rows, B->tgt_rows}, st, CertArgs{B->cert_q, B->cert_qu, B->dcum, 2 * (B->K + 1), k, count_k, !fresh});
+                                  B->pairs, cfg, Rows{B->src_rows, B->tgt_rows}, st, CertArgs{B->cert_q, B->cert_qu, B->dcum, 2 * (B->K + 1), k, count_k, !fresh, B->cert_cloud});
             } else
             rc = dicp_knn_sweep(dtype, qsrc, pose_s, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, B->src_rows, B->tgt_rows, N, n, m, B->m_pad,
                                 B->idx ? idx_k : nullptr, spos_k, B->pairs, cfg, stream);
@@ -3740,7 +3775,7 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
                 // are the start of the next iteration's (within this call)
                 const CertAcc ca{pose_s, B->tgt4, B->tperm, B->bucket, B->brange, B->nbkt, B->tgt_rows, m, B->m_pad, B->pairs,
                                  B->cert_q, B->cert_qu, fresh ? nullptr : B->dcum, 2 * (B->K + 1), k, count_k,
-                                 spos_k, (B->idx_per_iter && k + 1 < k1) ? spos_k + (size_t)N * n : nullptr};
+                                 spos_k, (B->idx_per_iter && k + 1 < k1) ? spos_k + (size_t)N * n : nullptr, B->cert_cloud};
                 rc = accumulate_go(dtype, prm, B->src, B->tgt_sorted, B->tgt_sorted_stride, spos_k, pose_k, B->w_init, alive_k, B->src_rows, N, n, B->m_pad,
                                    B->partials, w_k, B->w_stride, stream, &ca);
             } else if (sorted_rows)

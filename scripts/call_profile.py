@@ -14,11 +14,14 @@ src, tgt = (make_scene_pairs if kind == "scene" else make_pairs)(B, n, n, seed=3
 src, tgt = src.cuda(), tgt.cuda()
 T0 = torch.eye(4, device="cuda").repeat(B, 1, 1)
 icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12); icp.const_iter = True
+icp.reuse_matches = os.environ.get("DICP_REUSE", "1") == "1"          # (DICP_REUSE=0: search everything in every iteration)
+icp.cert_backoff = os.environ.get("DICP_BACKOFF", "1") == "1"
 for _ in range(calls):
     s, t = src.detach().requires_grad_(True), tgt.detach().requires_grad_(True)
     out = icp.icp(s, t, T0, trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0})
     out["T"].sum().backward()
     torch.cuda.synchronize()
+print("certificates %s, per-cloud switch %s; off for %s clouds" % (icp.reuse_matches, icp.cert_backoff, int(icp.knn_stats["certs_off"].sum()) if "certs_off" in icp.knn_stats else None))
 pairs = float(icp.knn_stats["knn_pairs"].sum().item()) / K / (float(B) * n * n)
 again = icp.knn_stats.get("searched_again")
 print("%s K=%d B=%d: pairs scored %.2f %% of n*m per launch; units / queries searched again per iteration: %s / %s; backward live: %s" % (

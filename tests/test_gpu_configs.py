@@ -450,3 +450,41 @@ def test_config4_full_batch_256_by_65536():
     for b in (0, 128, 255):
         want = _ops.knn(sd.detach()[b:b + 1].contiguous(), pose[b:b + 1].contiguous(), _ops.pack_target(td.detach()[b:b + 1].contiguous()), n, _lib.KNN_VALU)
         assert torch.equal(got[b:b + 1], want), b
+
+
+@pytest.mark.parametrize("kind", ["scene", "near_duplicates", "random"])
+def test_certificates_switch_themselves_off_where_they_cost_more(kind):
+    """Proving a match unchanged must never cost more than searching it again.  Per cloud, on device, the step kernel weighs what a certified
+    iteration searched again against a full search and switches the cloud's certificates off for the rest of the call when they do not pay
+    (planar scenes: 8 % of the queries sit within float32's rounding of a second candidate on the dense surfaces; near-duplicated targets: all
+    of them).  Either way every search is exact: results are bit for bit those of searching everything, with and without the switch."""
+    from dicp_amd.synthetic import make_scene_pairs
+    N, n, K = 24, 16384, 9
+    if kind == "scene":
+        src, tgt = make_scene_pairs(N, n, n, seed=7)
+    elif kind == "near_duplicates":
+        src, tgt, K = _cert_case("near_duplicates", torch.float32)
+        N = src.shape[0]
+    else:
+        src, tgt = make_pairs(N, n, n, seed=7)
+    outs = {}
+    for name, reuse, backoff in (("plain", False, True), ("certs", True, False), ("switch", True, True)):
+        icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
+        icp.const_iter, icp.reuse_matches, icp.cert_backoff, icp.knn_variant = True, reuse, backoff, _lib.KNN_SWEEP
+        S, Tg = src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True)
+        out = icp.icp(S, Tg, torch.eye(4, device=DEV).repeat(N, 1, 1), **KW)
+        out["T"].sum().backward()
+        outs[name] = (out, S.grad, Tg.grad, dict(icp.knn_stats))
+    for other in ("certs", "switch"):
+        for key in ("T", "deltas", "weights", "costs", "pc"):
+            assert torch.equal(outs["plain"][0][key], outs[other][0][key]), (other, key)
+        for i in (1, 2):
+            np.testing.assert_allclose(npy(outs[other][i]), npy(outs["plain"][i]), rtol=0, atol=2e-6 * max(1.0, float(outs["plain"][i].abs().max())))
+    off = outs["switch"][3]["certs_off"].cpu()
+    assert int(outs["certs"][3]["certs_off"].sum()) == 0
+    if kind == "random":
+        assert int(off.sum()) == 0, off.tolist()                        # certificates pay on these clouds: they stay on
+    else:
+        assert int(off.sum()) == N, off.tolist()                        # ... and are off everywhere here, from the certifying search on
+        again = outs["switch"][3]["searched_again"]
+        assert int(again[5:, 64:].sum()) == 0                           # no single-query searches any more

@@ -40,7 +40,7 @@ class StepIO(ctypes.Structure):
                 ("cost", vp), ("cost_prev", vp), ("cost_stride", i64), ("areg", vp), ("alive", vp), ("alive_out", vp),
                 ("converged", vp), ("iterations", vp), ("matched_ratio", vp), ("n_start", vp),
                 ("n_matched", vp), ("w_cur", vp), ("w_prev", vp), ("w_stride", i64), ("n_not_converged", vp),
-                ("center", vp), ("pose_search_out", vp), ("rmax", vp), ("dcum", vp), ("dcum_stride", i64), ("cert_cloud", vp)]
+                ("frame", vp), ("pose_search_out", vp), ("rmax", vp), ("dcum", vp), ("dcum_stride", i64), ("cert_cloud", vp)]
 
 
 class LoopBuffers(ctypes.Structure):
@@ -49,7 +49,7 @@ class LoopBuffers(ctypes.Structure):
                 ("tgt4", vp), ("tperm", vp), ("qorder", vp), ("bucket", vp), ("brange", vp), ("nbkt", i32), ("idx_per_iter", i32),
                 ("pairs", vp), ("spos", vp), ("src_s", vp), ("spos_ref", vp), ("gts_far", vp), ("poses", vp), ("deltas", vp), ("costs", vp), ("areg", vp), ("alive", vp), ("converged", vp),
                 ("iterations", vp), ("matched_ratio", vp), ("n_start", vp), ("n_matched", vp), ("idx", vp), ("w", vp), ("w_iter", i64), ("w_stride", i64), ("w_prev0", vp),
-                ("partials", vp), ("counters", vp), ("events", vp), ("bwd_overwrite", i32), ("center", vp), ("poses_search", vp),
+                ("partials", vp), ("counters", vp), ("events", vp), ("bwd_overwrite", i32), ("frame", vp), ("poses_search", vp),
                 ("src_rows", vp), ("tgt_rows", vp), ("cert_q", vp), ("cert_qu", vp), ("cert_count", vp), ("rmax", vp), ("dcum", vp),
                 ("cert_reset", i32), ("cert_cloud", vp), ("spos_prev0", vp), ("tgt_sorted", vp), ("tgt_sorted_stride", i32),
                 ("bwd_skip", vp), ("bwd_mref", vp), ("bwd_live", vp), ("bwd_skip_eps", f64)]
@@ -58,7 +58,7 @@ class LoopBuffers(ctypes.Structure):
 class KabschBuffers(ctypes.Structure):
     """dicp_kabsch_buffers (include/dicp_hip.h)."""
     _fields_ = [("src", vp), ("tgt", vp), ("w_init", vp), ("c", i32), ("K", i32), ("knn_variant", i32), ("m_pad", i32), ("tgt4", vp), ("tperm", vp),
-                ("qorder", vp), ("bucket", vp), ("brange", vp), ("nbkt", i32), ("pad0", i32), ("pairs", vp), ("center", vp), ("pose", vp),
+                ("qorder", vp), ("bucket", vp), ("brange", vp), ("nbkt", i32), ("pad0", i32), ("pairs", vp), ("frame", vp), ("pose", vp),
                 ("pose_search", vp), ("pose_used", vp), ("idx", vp), ("partials", vp), ("save", vp), ("costs", vp), ("iterations", vp),
                 ("rows_live", vp), ("tgt_rows", vp), ("counters", vp)]
 
@@ -68,7 +68,7 @@ _SIGNATURES = {
     "dicp_padded_targets": ([i32], ctypes.c_int),
     "dicp_accumulate_blocks": ([i32], ctypes.c_int),
     "dicp_pack_target": ([i32, vp, i32, vp, vp, i32, i32, vp, i32, vp], ctypes.c_int),
-    "dicp_cloud_center": ([i32, vp, i32, vp, i32, i32, f64, vp, vp], ctypes.c_int),
+    "dicp_search_frame": ([i32, vp, i32, vp, i32, i32, f64, i32, vp, vp], ctypes.c_int),
     "dicp_knn": ([i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp], ctypes.c_int),
     "dicp_knn_sweep": ([i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp], ctypes.c_int),
     "dicp_window_blocks": ([i32, i32, i32], ctypes.c_int),

@@ -68,42 +68,52 @@ def accumulate_blocks(n):
 
 
 CENTER_QUANTUM = 16.0    # metres; clouds whose median point is within half of it of the origin keep c = 0
+FRAME_DIRECTIONS = True  # the search frame also picks the sort direction (False: the x axis, always)
 
 
-def cloud_center(tgt, quantum=None, tgt_rows=None):
-    """(N,m,c) -> (N,3): the centre of the search coordinates (dicp_cloud_center): the coordinate-wise median of (a sample of) the target, rounded to a multiple of
-    `quantum`, so that clouds near the origin get exactly 0 and with it the bits of an uncentred search.
+def search_frame(tgt, quantum=None, tgt_rows=None, directions=None):
+    """(N,m,c) -> (N,12): the search frame x' = Q x + t of every cloud (dicp_search_frame), [Q row-major | t] with t = -Q c:
+    c = the coordinate-wise median of (a sample of) the target, rounded to a multiple of `quantum`, so that clouds near the origin get exactly 0;
+    Q = the rotation whose first row is the direction the sorted sweep prunes along -- the identity unless one of five other candidates spreads
+    the cloud's points clearly better (planar scenes: a wall perpendicular to x sits in every slab that touches it).
     tgt_rows (N) int32, optional: rows of each cloud that take part (ragged batches)."""
-    require_device(tgt, "cloud_center")
+    require_device(tgt, "search_frame")
     N, m, c = tgt.shape
-    out = torch.empty((N, 3), dtype=tgt.dtype, device=tgt.device)
+    out = torch.empty((N, 12), dtype=tgt.dtype, device=tgt.device)
     with torch.cuda.device(tgt.device):
-        _lib.check(_lib.load().dicp_cloud_center(_DT[tgt.dtype], _p(tgt), c, _p(tgt_rows), N, m, CENTER_QUANTUM if quantum is None else float(quantum),
-                                                 _p(out), _stream()), "dicp_cloud_center")
+        _lib.check(_lib.load().dicp_search_frame(_DT[tgt.dtype], _p(tgt), c, _p(tgt_rows), N, m, CENTER_QUANTUM if quantum is None else float(quantum),
+                                                 int(FRAME_DIRECTIONS if directions is None else directions), _p(out), _stream()), "dicp_search_frame")
     return out
 
 
-def search_pose(pose, center, N=None):
-    """[C | r - center] (N,12): the pose a search is handed when its packed rows / index were built on y - center (pose None = identity)."""
+def search_pose(pose, frame, N=None):
+    """[Q C | Q r + t] (N,12): the pose a search is handed when its packed rows / index were built in `frame` (pose None = identity: the frame itself).
+    (torch arithmetic: a test / nn.find_nn helper -- the loop's search poses are written by the kernels.)"""
     if pose is None:
-        pose = torch.zeros((N if N is not None else center.shape[0], 12), dtype=center.dtype, device=center.device)
+        if frame is not None:
+            return frame.clone()
+        pose = torch.zeros((N, 12))
         pose[:, 0] = pose[:, 4] = pose[:, 8] = 1.0
-    if center is None:
         return pose
-    out = pose.clone()
-    out[:, 9:] = pose[:, 9:] - center
+    if frame is None:
+        return pose
+    n = pose.shape[0]
+    Q, t = frame[:, :9].reshape(n, 3, 3), frame[:, 9:]
+    out = torch.empty_like(pose)
+    out[:, :9] = torch.matmul(Q, pose[:, :9].reshape(n, 3, 3)).reshape(n, 9)
+    out[:, 9:] = torch.matmul(Q, pose[:, 9:, None]).squeeze(-1) + t
     return out
 
 
-def pack_target(tgt, center=None, tgt_rows=None):
-    """(N,m,c) -> (N,m_pad,4) rows [x,y,z,0.5|y|^2] of y (or of y - center: the caller then searches with [C | r - center])."""
+def pack_target(tgt, frame=None, tgt_rows=None):
+    """(N,m,c) -> (N,m_pad,4) rows [x,y,z,0.5|y|^2] of y (or of Q y + t: the caller then searches with [Q C | Q r + t])."""
     require_device(tgt, "pack_target")
     tgt = tgt.contiguous()
     N, m, c = tgt.shape
     m_pad = padded_targets(m)
     out = torch.empty((N, m_pad, 4), dtype=tgt.dtype, device=tgt.device)
     with torch.cuda.device(tgt.device):
-        _lib.check(_lib.load().dicp_pack_target(_DT[tgt.dtype], _p(tgt), c, _p(center), _p(tgt_rows), N, m, _p(out), m_pad, _stream()),
+        _lib.check(_lib.load().dicp_pack_target(_DT[tgt.dtype], _p(tgt), c, _p(frame), _p(tgt_rows), N, m, _p(out), m_pad, _stream()),
                    "dicp_pack_target")
     return out
 
@@ -125,16 +135,16 @@ class SweepIndex:
     an ICP call, so they are sorted by x once (dicp_sweep_sort: native for every size and dtype)."""
     NBKT = 1024
 
-    def __init__(self, tgt, sorted_rows=False, center=None, tgt_rows=None):
+    def __init__(self, tgt, sorted_rows=False, frame=None, tgt_rows=None):
         """sorted_rows: also keep tgt_s (N,m_pad,row_stride), the full rows in sorted order (the loop's accumulate and the windowed backward gather them).
-        center (N,3): the index is built on y - center (keys, table and packed rows; tgt_s keeps the rows as given) and the
-        searches must then be given the pose [C | r - center].
+        frame (N,12): the index is built on Q y + t (keys, table and packed rows; tgt_s keeps the rows as given) and the
+        searches must then be given the pose [Q C | Q r + t].
         tgt_rows (N) int32: rows of each cloud that take part (ragged batches); the searches are given the same counts."""
         require_device(tgt, "SweepIndex")
         tgt = tgt.contiguous()
         N, m, c = tgt.shape
         self.m = m
-        self.center, self.tgt_rows = center, tgt_rows
+        self.frame, self.tgt_rows = frame, tgt_rows
         lib = _lib.load()
         dev, dt = tgt.device, tgt.dtype
         m_pad = lib.dicp_padded_targets(m)
@@ -150,9 +160,9 @@ class SweepIndex:
         nbytes = int(lib.dicp_sweep_sort_scratch_bytes(_DT[dt], N, m_pad))     # float64 keys / more than 16384 slots: chunked sort through scratch
         scratch = torch.empty((nbytes,), dtype=torch.uint8, device=dev) if nbytes else None
         with torch.cuda.device(dev):
-            _lib.check(lib.dicp_sweep_sort(_DT[dt], _p(tgt), c, _p(center), _p(tgt_rows), N, m, m_pad, _p(self.keys), _p(self.tperm), self.NBKT,
+            _lib.check(lib.dicp_sweep_sort(_DT[dt], _p(tgt), c, _p(frame), _p(tgt_rows), N, m, m_pad, _p(self.keys), _p(self.tperm), self.NBKT,
                                            _p(self.bucket), _p(self.brange), _p(scratch), nbytes, _stream()), "dicp_sweep_sort")
-            _lib.check(lib.dicp_sweep_build(_DT[dt], _p(tgt), c, _p(center), _p(tgt_rows), _p(self.tperm), N, m, m_pad,
+            _lib.check(lib.dicp_sweep_build(_DT[dt], _p(tgt), c, _p(frame), _p(tgt_rows), _p(self.tperm), N, m, m_pad,
                                             _p(self.tgs4), _p(self.tgt_s), self.row_stride, _stream()), "dicp_sweep_build")
         self.pair_shards = torch.zeros((_lib.PAIR_SHARDS,), dtype=torch.int64, device=dev)
 
@@ -368,14 +378,14 @@ def prebuild_search(source, target, knn_variant, want_rows, T_init=None, src_row
     if kind != _lib.KNN_SWEEP or not target.is_cuda or not target.is_contiguous() or target.dtype not in _DT:
         return None
     with torch.cuda.device(target.device):
-        sweep = SweepIndex(target, sorted_rows=True, center=cloud_center(target, tgt_rows=tgt_rows), tgt_rows=tgt_rows)
+        sweep = SweepIndex(target, sorted_rows=True, frame=search_frame(target, tgt_rows=tgt_rows), tgt_rows=tgt_rows)
         # ... and the first query order, from T_init alone (the loop's own pose_0 does not exist yet): with it the queue holds
         # ~0.2 ms of work while the host builds the loop state
         first = None
         if (T_init is not None and T_init.is_cuda and T_init.is_contiguous() and T_init.dtype == target.dtype and source.is_contiguous()
                 and tuple(T_init.shape) == (N, 4, 4)):
             pose_s = torch.empty((N, 12), dtype=target.dtype, device=target.device)
-            _lib.check(_lib.load().dicp_search_pose(_DT[target.dtype], _p(T_init), _p(sweep.center), N, _p(pose_s), _stream()), "dicp_search_pose")
+            _lib.check(_lib.load().dicp_search_pose(_DT[target.dtype], _p(T_init), _p(sweep.frame), N, _p(pose_s), _stream()), "dicp_search_pose")
             first = (source, T_init, sweep.query_order(source, pose_s, src_rows=src_rows))
         return (target, sweep, first)
 
@@ -512,14 +522,14 @@ class ICPLoop(torch.autograd.Function):
                         and pre[1].tgt_s is not None and pre[1].tgt_rows is cfg.tgt_rows):
                     sweep = pre[1]                           # started by the caller, under its host work
                 else:
-                    sweep = SweepIndex(tgt, sorted_rows=True, center=cloud_center(tgt, tgt_rows=cfg.tgt_rows), tgt_rows=cfg.tgt_rows)
-            # the searches run in coordinates centred on the target cloud (dicp_cloud_center): packed rows y - c, pose [C | r - c]
-            center = sweep.center if sweep is not None else cloud_center(tgt, tgt_rows=cfg.tgt_rows)
+                    sweep = SweepIndex(tgt, sorted_rows=True, frame=search_frame(tgt, tgt_rows=cfg.tgt_rows), tgt_rows=cfg.tgt_rows)
+            # the searches run in the target cloud's search frame (dicp_search_frame): packed rows Q y + t, pose [Q C | Q r + t]
+            center = sweep.frame if sweep is not None else search_frame(tgt, tgt_rows=cfg.tgt_rows)
             tgt4 = sweep.tgs4 if sweep is not None else pack_target(tgt, center, cfg.tgt_rows)
             m_pad = tgt4.shape[1]
             nblk = lib.dicp_accumulate_blocks(n)
             poses = torch.empty((Kmax + 1, N, 12), dtype=dt, device=dev)
-            poses_c = torch.empty((Kmax + 1, N, 12), dtype=dt, device=dev) if center is not None else None   # [C | r - center]: what the searches read
+            poses_c = torch.empty((Kmax + 1, N, 12), dtype=dt, device=dev) if center is not None else None   # [Q C | Q r + t]: what the searches read
             alive = torch.empty((Kmax + 1, N), dtype=dt, device=dev)
             areg = torch.empty((Kmax, N, 36), dtype=torch.float64, device=dev) if need_grad else None
             n_start = torch.empty((N,), dtype=dt, device=dev)
@@ -617,7 +627,7 @@ class ICPLoop(torch.autograd.Function):
                         tgt_sorted=_p(sweep.tgt_s) if sweep is not None else None, tgt_sorted_stride=sweep.row_stride if sweep is not None else 0,
                         rmax=_p(certs["rmax"]) if certs else None, dcum=_p(certs["dcum"]) if certs else None,
                         w_iter=n, w_stride=kc * n,
-                        partials=_p(partials), counters=_p(counters), events=events, center=_p(center), poses_search=_p(poses_c),
+                        partials=_p(partials), counters=_p(counters), events=events, frame=_p(center), poses_search=_p(poses_c),
                         src_rows=_p(cfg.src_rows), tgt_rows=_p(cfg.tgt_rows))
                     LBref = ctypes.byref(LB)
                 LB.qorder = _p(qorder)
@@ -832,8 +842,8 @@ class KabschLoop(torch.autograd.Function):
             kind = knn_variant & 0xff
             if kind == _lib.KNN_AUTO:
                 kind = auto_knn_kind(N, n, m)
-            center = cloud_center(tgt, tgt_rows=tgt_rows)       # centred search, as in ICPLoop
-            sweep = SweepIndex(tgt, center=center, tgt_rows=tgt_rows) if kind == _lib.KNN_SWEEP else None
+            center = search_frame(tgt, tgt_rows=tgt_rows)       # the search frame, as in ICPLoop
+            sweep = SweepIndex(tgt, frame=center, tgt_rows=tgt_rows) if kind == _lib.KNN_SWEEP else None
             tgt4 = sweep.tgs4 if sweep is not None else pack_target(tgt, center, tgt_rows)
             nblk = lib.dicp_accumulate_blocks(n)
             pose = _pose_from_T(T_init)
@@ -861,7 +871,7 @@ class KabschLoop(torch.autograd.Function):
                     src=_p(src), tgt=_p(tgt), w_init=_p(w0c), c=c, K=Kmax, knn_variant=kind | (knn_variant & 0xff00), m_pad=tgt4.shape[1],
                     tgt4=_p(tgt4), tperm=_p(sweep.tperm) if sweep else None, qorder=_p(qorder), bucket=_p(sweep.bucket) if sweep else None,
                     brange=_p(sweep.brange) if sweep else None, nbkt=SweepIndex.NBKT, pairs=_p(sweep.pair_shards) if sweep else None,
-                    center=_p(center), pose=_p(pose), pose_search=_p(pose_s), pose_used=_p(pose_used), idx=_p(idx), partials=_p(partials),
+                    frame=_p(center), pose=_p(pose), pose_search=_p(pose_s), pose_used=_p(pose_used), idx=_p(idx), partials=_p(partials),
                     save=_p(save), costs=_p(costs), iterations=_p(iterations), rows_live=_p(rows_live), tgt_rows=_p(tgt_rows), counters=_p(counters))
                 _lib.check(lib.dicp_kabsch_forward(code, ctypes.byref(KB), N, n, m, trim_on, trim, int(const_iter), float(tolerance), k0, k1, st),
                            "dicp_kabsch_forward")

@@ -101,11 +101,38 @@ template <> __device__ __forceinline__ double big_v<double>() { return 1.7976931
 
 // one expression for 0.5|y|^2 wherever a target row is packed, so every kNN form sees bit-identical scores
 // ctr (optional): the search runs in coordinates centred on the target cloud, rows are packed as y - ctr (section "centre" below)
+// The SEARCH FRAME of a cloud (dicp_search_frame): x' = Q x + t, Q orthonormal (rows: the sort direction first), t = -Q c with c the
+// cloud's centre.  F = [Q row-major (9) | t (3)].  Every search form reads only (search pose, packed rows), and both come from the two
+// functions below, so a frame changes none of them and they all stay index-for-index identical.  An axis-aligned identity Q is applied as
+// the plain subtraction it is: the same bits as the centred search had before frames existed, also for rows with non-finite coordinates
+// (0 * inf in the general form would spread a NaN over the row).
 template <typename T>
-__device__ __forceinline__ typename V4<T>::type pack_row(const T* __restrict__ y, const T* __restrict__ ctr = nullptr) {
+__device__ __forceinline__ bool frame_is_translation(const T* __restrict__ F) {
+    return F[0] == T(1) && F[4] == T(1) && F[8] == T(1) && F[1] == T(0) && F[2] == T(0) && F[3] == T(0) && F[5] == T(0) && F[6] == T(0) && F[7] == T(0);
+}
+template <typename T>
+__device__ __forceinline__ void frame_apply(const T* __restrict__ F, const T* y, T* out) {      // out = Q y + t
+    if (!F) { out[0] = y[0]; out[1] = y[1]; out[2] = y[2]; return; }
+    if (frame_is_translation(F)) { out[0] = y[0] + F[9]; out[1] = y[1] + F[10]; out[2] = y[2] + F[11]; return; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[k] = fma_t(F[3 * k], y[0], fma_t(F[3 * k + 1], y[1], fma_t(F[3 * k + 2], y[2], F[9 + k])));
+}
+// the pose a search is handed: [Q C | Q r + t] (entry e of its 12)
+template <typename T>
+__device__ __forceinline__ T frame_pose_entry(const T* __restrict__ F, const T* pose /* [C row-major | r] */, int e) {
+    if (!F) return pose[e];
+    if (frame_is_translation(F)) return e < 9 ? pose[e] : pose[e] + F[e];
+    if (e < 9) { const int i = e / 3, j = e - 3 * i; return fma_t(F[3 * i], pose[j], fma_t(F[3 * i + 1], pose[3 + j], F[3 * i + 2] * pose[6 + j])); }
+    const int i = e - 9;
+    return fma_t(F[3 * i], pose[9], fma_t(F[3 * i + 1], pose[10], fma_t(F[3 * i + 2], pose[11], F[9 + i])));
+}
+
+template <typename T>
+__device__ __forceinline__ typename V4<T>::type pack_row(const T* __restrict__ y, const T* __restrict__ frame = nullptr) {
     typename V4<T>::type v;
-    v.x = y[0]; v.y = y[1]; v.z = y[2];
-    if (ctr) { v.x -= ctr[0]; v.y -= ctr[1]; v.z -= ctr[2]; }
+    T q[3];
+    frame_apply(frame, y, q);
+    v.x = q[0]; v.y = q[1]; v.z = q[2];
     v.w = T(0.5) * fma_t(v.z, v.z, fma_t(v.y, v.y, v.x * v.x));     // explicit fmas: no per-kernel contraction choices
     return v;
 }
@@ -119,15 +146,24 @@ __device__ __forceinline__ void query_point(const T* C, const T* r, const T* p, 
         nx[k] = -fma_t(C[3 * k], p[0], fma_t(C[3 * k + 1], p[1], fma_t(C[3 * k + 2], p[2], r[k])));
 }
 
-// ------------------------------------------------------------------------ centre
+// ------------------------------------------------------------------------ search frame
 // The search scores in the expanded form 0.5|y|^2 - x.y, whose rounding error -- and with it the sweep's prune margin -- grows
 // with 0.5|x|^2: in a map frame a kilometre from the origin nothing is pruned any more (profiles/r01_offset_clouds.txt).  So the
-// search runs in coordinates centred on the target cloud: packed rows hold y - c, and the search kernels are handed the pose
-// [C | r - c] (a second, search-only pose buffer).  Every search form reads only (pose, packed rows), so none of them changes and
-// they all stay index-for-index identical.  c = the target's median point rounded to a multiple of `quantum`: clouds near the origin get
-// c = 0 and with it exactly the bits they had without centring.
+// search runs in coordinates centred on the target cloud.  And the sorted sweep prunes along ONE direction: a wall perpendicular
+// to it puts all of its points into every slab that touches it (planar scenes: 4.9 % of the pairs scored per launch against 1.4 %
+// on volumetric clouds, profiles/r03_scene_kernel_stats_before.txt).  So the direction is chosen per cloud as well.  Both are one
+// affine map, the cloud's SEARCH FRAME x' = Q x + t (frame_apply): packed rows hold Q y + t, the search kernels are handed the
+// pose [Q C | Q r + t] (a second, search-only pose buffer).  Every search form reads only (pose, packed rows), so none of them
+// changes and they all stay index-for-index identical.
+//   c = the target's median point rounded to a multiple of `quantum`: clouds near the origin get c = 0;
+//   Q = the candidate rotation (sort direction = its first row) whose keys spread the cloud's points best: the sum over a
+//       256-bin histogram of the projected sample of count^2 -- proportional to the pairs a slab search scores -- is smallest;
+//       candidates: the three axes (pure permutations of the coordinates) and three oblique directions no axis-aligned plane
+//       is perpendicular to.  The identity keeps the job unless another candidate is 20 % better: volumetric clouds and clouds
+//       near the origin get Q = I, t = 0 and with it exactly the bits they had without a frame.
 constexpr int CC_THREADS = 1024;     // one block per cloud
 constexpr int CC_SAMPLE = CC_THREADS;// rows looked at per cloud: one per thread, its three keys stay in registers
+constexpr int SF_DIRS = 6;
 __device__ __forceinline__ unsigned sortable_bits(float x);
 // The centre only sizes a margin (it decides no result), but it has to sit INSIDE the cloud: a mean would be dragged away by
 // stray returns.  So it is the coordinate-wise MEDIAN of a stride sample of at most CC_SAMPLE of the cloud's rows (rows 0, step,
@@ -135,20 +171,31 @@ __device__ __forceinline__ unsigned sortable_bits(float x);
 // significant byte first, the three axes side by side) over the order-preserving bit pattern of the float values (float is
 // plenty: the centre is rounded to `quantum` anyway).
 template <typename T>
-__global__ __launch_bounds__(CC_THREADS) void cloud_center_kernel(const T* __restrict__ tgt, int c, int m, const int32_t* __restrict__ tgt_rows,
-                                                                  double quantum, T* __restrict__ center) {
+__global__ __launch_bounds__(CC_THREADS) void search_frame_kernel(const T* __restrict__ tgt, int c, int m, const int32_t* __restrict__ tgt_rows,
+                                                                  double quantum, int directions, T* __restrict__ frame) {
+    // rotations with det +1; row 0 = the sort direction.  0: identity, 1 / 2: y / z first (cyclic permutations), 3..5: oblique
+    const double QS[SF_DIRS][9] = {
+        {1, 0, 0, 0, 1, 0, 0, 0, 1}, {0, 1, 0, 0, 0, 1, 1, 0, 0}, {0, 0, 1, 1, 0, 0, 0, 1, 0},
+        {0.6, 0.64, 0.48, 0.72953720414008516, -0.68394112888132985, 0, 0.32829174186303833, 0.35017785798724088, -0.87726848797845247},
+        {0.6, -0.64, 0.48, -0.72953720414008516, -0.68394112888132985, 0, 0.32829174186303833, -0.35017785798724088, -0.87726848797845247},
+        {0.48, 0.6, -0.64, 0, -0.72953720414008516, -0.68394112888132985, -0.87726848797845247, 0.32829174186303833, -0.35017785798724088}};
     __shared__ int hist[3][256];
     __shared__ unsigned sel_prefix[3];
     __shared__ int sel_want[3];
+    __shared__ int dhist[SF_DIRS][256];
+    __shared__ float s_ctr[3], s_ext[CC_THREADS / WAVE];
+    __shared__ int s_cost[SF_DIRS];
     const int cloud = blockIdx.x, tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
     const T* __restrict__ rows = tgt + (size_t)cloud * m * c;
     const int mc = max(rows_of(tgt_rows, cloud, m), 1);
     const int step = (mc + CC_SAMPLE - 1) / CC_SAMPLE, ms = (mc + step - 1) / step;
     const bool on = tid < ms;
     unsigned key[3] = {0u, 0u, 0u};
+    float pt[3] = {0.f, 0.f, 0.f};
     if (on) {
         const T* r = rows + (size_t)tid * step * c;
-        key[0] = sortable_bits((float)r[0]); key[1] = sortable_bits((float)r[1]); key[2] = sortable_bits((float)r[2]);
+        pt[0] = (float)r[0]; pt[1] = (float)r[1]; pt[2] = (float)r[2];
+        key[0] = sortable_bits(pt[0]); key[1] = sortable_bits(pt[1]); key[2] = sortable_bits(pt[2]);
     }
     if (tid < 3) { sel_prefix[tid] = 0u; sel_want[tid] = (ms - 1) / 2; }    // lower median
     unsigned mask = 0u;
@@ -185,20 +232,67 @@ __global__ __launch_bounds__(CC_THREADS) void cloud_center_kernel(const T* __res
         u ^= (u >> 31) ? 0x80000000u : 0xffffffffu;                         // inverse of sortable_bits
         double v = (double)__uint_as_float(u);
         v = quantum > 0.0 ? rint(v / quantum) * quantum : v;
-        center[(size_t)cloud * 3 + tid] = (v == v && fabs(v) < 1e30) ? (T)v : T(0);        // non-finite input: no centring
+        s_ctr[tid] = (v == v && fabs(v) < 1e30) ? (float)(T)v : 0.f;        // non-finite input: no centring
+    }
+    for (int d = tid; d < SF_DIRS * 256; d += CC_THREADS) (&dhist[0][0])[d] = 0;
+    __syncthreads();
+    // ---- the sort direction: histograms of the sample's keys along every candidate, one bin width for all of them
+    const float dx = pt[0] - s_ctr[0], dy = pt[1] - s_ctr[1], dz = pt[2] - s_ctr[2];
+    const bool fin = on && fabsf(dx) < 1e30f && fabsf(dy) < 1e30f && fabsf(dz) < 1e30f;
+    float ext = fin ? fmaxf(fabsf(dx), fmaxf(fabsf(dy), fabsf(dz))) : 0.f;
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) ext = fmaxf(ext, __shfl_xor(ext, off));
+    if (lane == 0) s_ext[wave] = ext;
+    __syncthreads();
+    float R2 = 0.f;
+    for (int w = 0; w < CC_THREADS / WAVE; ++w) R2 = fmaxf(R2, s_ext[w]);
+    R2 *= 1.7321f;                                                          // |d . (p - c)| <= sqrt(3) max |p - c|_inf
+    int best = 0;
+    if (directions && R2 > 0.f) {
+        if (fin) {
+            const float scale = 128.f / R2;
+#pragma unroll
+            for (int j = 0; j < SF_DIRS; ++j) {
+                const float k = (float)QS[j][0] * dx + (float)QS[j][1] * dy + (float)QS[j][2] * dz;
+                const int bin = min(max((int)((k + R2) * scale), 0), 255);
+                atomicAdd(&dhist[j][bin], 1);
+            }
+        }
+        __syncthreads();
+        if (wave < SF_DIRS) {
+            int cst = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int h = dhist[wave][4 * lane + q]; cst += h * h; }
+#pragma unroll
+            for (int off = WAVE / 2; off > 0; off >>= 1) cst += __shfl_xor(cst, off);
+            if (lane == 0) s_cost[wave] = cst;
+        }
+        __syncthreads();
+        for (int j = 1; j < SF_DIRS; ++j) if (s_cost[j] < s_cost[best]) best = j;
+        if (!(5 * (long long)s_cost[best] < 4 * (long long)s_cost[0])) best = 0;    // the identity keeps the job unless another is 20 % better
+    }
+    if (tid < 12) {
+        T* F = frame + (size_t)cloud * 12;
+        if (tid < 9) F[tid] = (T)QS[best][tid];
+        else {          // t = -Q c, in T arithmetic (for Q = I: exactly -c)
+            const int i = tid - 9;
+            const T cx = (T)s_ctr[0], cy = (T)s_ctr[1], cz = (T)s_ctr[2];
+            F[tid] = best == 0 ? -(i == 0 ? cx : (i == 1 ? cy : cz))
+                               : -fma_t((T)QS[best][3 * i], cx, fma_t((T)QS[best][3 * i + 1], cy, (T)QS[best][3 * i + 2] * cz));
+        }
     }
 }
 
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void pack_kernel(const T* __restrict__ tgt, int N, int m, int c,
                                                      typename V4<T>::type* __restrict__ out, int m_pad, int bpc,
-                                                     const T* __restrict__ center, const int32_t* __restrict__ tgt_rows) {
+                                                     const T* __restrict__ frame, const int32_t* __restrict__ tgt_rows) {
     int b, blk;                                             // all blocks of a cloud on one XCD (decode_block)
     if (!decode_block(bpc, N, b, blk)) return;
     const int j = blk * BLOCK + threadIdx.x;
     if (j >= m_pad) return;
     typename V4<T>::type v;
-    if (j < rows_of(tgt_rows, b, m)) v = pack_row<T>(tgt + ((size_t)b * m + j) * c, center ? center + (size_t)b * 3 : nullptr);
+    if (j < rows_of(tgt_rows, b, m)) v = pack_row<T>(tgt + ((size_t)b * m + j) * c, frame ? frame + (size_t)b * 12 : nullptr);
     else { v.x = v.y = v.z = T(0); v.w = inf_v<T>(); }
     out[(size_t)b * m_pad + j] = v;
 }
@@ -210,7 +304,7 @@ template <typename T>
 __global__ __launch_bounds__(BLOCK) void sweep_rows_kernel(const T* __restrict__ tgt, const int32_t* __restrict__ tgt_rows, int N, int m, int c,
                                                            int m_pad, int bpc, typename V4<T>::type* __restrict__ tgs4, const int32_t* __restrict__ tperm,
                                                            T* __restrict__ tgt_s /* optional (N,m_pad,rs): the full rows in sorted order */, int rs /* elements per row of tgt_s, >= c */,
-                                                           const T* __restrict__ center /* optional (N,3): tgs4 rows are y - centre; tgt_s stays as given */) {
+                                                           const T* __restrict__ frame /* optional (N,12): tgs4 rows are Q y + t; tgt_s stays as given */) {
     constexpr int U = 4;                                    // rows per thread in flight (index -> row is a dependent pair)
     int b, blk;
     if (!decode_block(bpc, N, b, blk)) return;
@@ -236,7 +330,7 @@ __global__ __launch_bounds__(BLOCK) void sweep_rows_kernel(const T* __restrict__
             const int sl = s0 + u * BLOCK;
             if (sl >= m_pad) continue;
             typename V4<T>::type v;
-            if (j[u] >= 0 && j[u] < mc) v = pack_row<T>(y[u], center ? center + (size_t)b * 3 : nullptr);
+            if (j[u] >= 0 && j[u] < mc) v = pack_row<T>(y[u], frame ? frame + (size_t)b * 12 : nullptr);
             else { v.x = big_v<T>(); v.y = v.z = T(0); v.w = inf_v<T>(); }      // pads sort last and can never win
             tgs4[(size_t)b * m_pad + sl] = v;
             if (tgt_s) {
@@ -285,7 +379,7 @@ __device__ __forceinline__ unsigned sortable_bits(float x) {      // order-prese
 __global__ __launch_bounds__(RS_THREADS) void sort_keys_kernel(const float* __restrict__ tgt, int c, int N, int m_full, int m_pad,
                                                                float* __restrict__ keys_sorted, int32_t* __restrict__ tperm,
                                                                int nbkt, int32_t* __restrict__ bucket, float* __restrict__ brange,
-                                                               const float* __restrict__ center, const int32_t* __restrict__ tgt_rows) {
+                                                               const float* __restrict__ frame, const int32_t* __restrict__ tgt_rows) {
     __shared__ unsigned skey[RS_MAX];
     __shared__ unsigned short sidx[RS_MAX];
     __shared__ int cnt[RS_THREADS / WAVE][256];             // per wave, per digit: running count, then offset
@@ -301,7 +395,7 @@ __global__ __launch_bounds__(RS_THREADS) void sort_keys_kernel(const float* __re
         unsigned u = 0xffffffffu;                           // beyond m_pad: sentinel, sorts after everything
         // pad slots keep the largest key there is: with the stable order they follow EVERY real row, also one whose x is
         // +inf or NaN (which sort above +max) -- sorted positions [0, m) are exactly the real rows, whatever they hold
-        if (pos < m) u = sortable_bits(center ? rows[(size_t)pos * c] - center[(size_t)cloud * 3] : rows[(size_t)pos * c]);
+        if (pos < m) { float q[3]; frame_apply<float>(frame ? frame + (size_t)cloud * 12 : nullptr, rows + (size_t)pos * c, q); u = sortable_bits(q[0]); }   // (the packed rows' x)
         key[e] = u;
         idx[e] = (unsigned short)pos;
     }
@@ -582,7 +676,7 @@ constexpr int LI_THREADS = 1024;     // one block per cloud: its two passes over
 template <typename T>
 __global__ __launch_bounds__(LI_THREADS) void loop_init_kernel(const T* __restrict__ T_init, const T* __restrict__ w0, T thresh, int rows, int n,
                                                           T* __restrict__ pose0, T* __restrict__ alive0, T* __restrict__ n_start,
-                                                          const T* __restrict__ center, T* __restrict__ pose_search0,
+                                                          const T* __restrict__ frame, T* __restrict__ pose_search0,
                                                           const T* __restrict__ src, T* __restrict__ rmax, T* __restrict__ dcum, int dstride) {
     __shared__ int cnt[LI_THREADS / WAVE];
     __shared__ T box[(LI_THREADS / WAVE) * 6];
@@ -625,7 +719,7 @@ __global__ __launch_bounds__(LI_THREADS) void loop_init_kernel(const T* __restri
             // (M_0, e_0): no motion yet; e_k = rounding of a transformed point C p + (r - centre) under pose k
             const T* Ti = T_init + (size_t)cloud * 16;
             dcum[(size_t)cloud * dstride] = T(0);
-            const T* ct = center ? center + (size_t)cloud * 3 : nullptr;
+            const T* ct = frame ? frame + (size_t)cloud * 12 + 9 : nullptr;        // (|t| = |centre|: Q is orthonormal)
             const T cn = ct ? m_sqrt(ct[0] * ct[0] + ct[1] * ct[1] + ct[2] * ct[2]) : T(0);
             dcum[(size_t)cloud * dstride + 1] = T(8) * CertUlp<T>::v * (m_sqrt(pn) + rad + m_sqrt(Ti[3] * Ti[3] + Ti[7] * Ti[7] + Ti[11] * Ti[11]) + cn + T(1));
         }
@@ -647,23 +741,25 @@ __global__ __launch_bounds__(LI_THREADS) void loop_init_kernel(const T* __restri
         const T* M = T_init + (size_t)cloud * 16;
         const T v = tid < 9 ? M[(tid / 3) * 4 + tid % 3] : M[(tid - 9) * 4 + 3];
         pose0[(size_t)cloud * 12 + tid] = v;
-        if (pose_search0) pose_search0[(size_t)cloud * 12 + tid] = (tid >= 9 && center) ? v - center[(size_t)cloud * 3 + tid - 9] : v;
+        if (pose_search0) {
+            const T ps[12] = {M[0], M[1], M[2], M[4], M[5], M[6], M[8], M[9], M[10], M[3], M[7], M[11]};
+            pose_search0[(size_t)cloud * 12 + tid] = frame_pose_entry<T>(frame ? frame + (size_t)cloud * 12 : nullptr, ps, tid);
+        }
     }
 }
 
 // [C | r - centre] straight from T_init (N,4,4): the search pose of iteration 0, for a caller that wants the first query order in
 // the queue before the loop state exists (same values as loop_init_kernel writes)
 template <typename T>
-__global__ __launch_bounds__(BLOCK) void search_pose_kernel(const T* __restrict__ T_init, const T* __restrict__ center, int N, T* __restrict__ out) {
+__global__ __launch_bounds__(BLOCK) void search_pose_kernel(const T* __restrict__ T_init, const T* __restrict__ frame, int N, T* __restrict__ out) {
     const int e = blockIdx.x * BLOCK + threadIdx.x;
     if (e >= N * 12) return;
     const int cloud = e / 12, k = e - cloud * 12;
     const T* M = T_init + (size_t)cloud * 16;
-    const T v = k < 9 ? M[(k / 3) * 4 + k % 3] : M[(k - 9) * 4 + 3];
-    out[e] = (k >= 9 && center) ? v - center[(size_t)cloud * 3 + k - 9] : v;
+    const T ps[12] = {M[0], M[1], M[2], M[4], M[5], M[6], M[8], M[9], M[10], M[3], M[7], M[11]};
+    out[e] = frame_pose_entry<T>(frame ? frame + (size_t)cloud * 12 : nullptr, ps, k);
 }
 
-// what follows the loop (ICP.py:267-281): stats of the clouds that never converged, and T from the last pose
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void loop_finish_kernel(const T* __restrict__ pose_K, const T* __restrict__ alive_K, const T* __restrict__ n_start,
                                                             const T* __restrict__ n_matched, int K, int N, T* __restrict__ iterations,
@@ -1414,7 +1510,7 @@ template <> struct SortKey<double> {
 };
 
 template <typename T>
-__global__ __launch_bounds__(GS_THREADS) void sort_keys_big_kernel(const T* __restrict__ tgt, int c, int m_full, int m_pad, const T* __restrict__ center, const int32_t* __restrict__ tgt_rows,
+__global__ __launch_bounds__(GS_THREADS) void sort_keys_big_kernel(const T* __restrict__ tgt, int c, int m_full, int m_pad, const T* __restrict__ frame, const int32_t* __restrict__ tgt_rows,
                                                                    T* __restrict__ keys_sorted, int32_t* __restrict__ tperm,
                                                                    typename SortKey<T>::type* __restrict__ gkey /* (N,2,m_pad) */, int32_t* __restrict__ gidx /* (N,2,m_pad) */) {
     using KT = typename SortKey<T>::type;
@@ -1423,12 +1519,14 @@ __global__ __launch_bounds__(GS_THREADS) void sort_keys_big_kernel(const T* __re
     const int cloud = blockIdx.x, tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
     const T* __restrict__ rows = tgt + (size_t)cloud * m_full * c;
     const int m = rows_of(tgt_rows, cloud, m_full);
-    const T cx = center ? center[(size_t)cloud * 3] : T(0);
+    const T* __restrict__ Fc = frame ? frame + (size_t)cloud * 12 : nullptr;
     KT* kbuf[2] = {gkey + (size_t)cloud * 2 * m_pad, gkey + (size_t)cloud * 2 * m_pad + m_pad};
     int32_t* ibuf[2] = {gidx + (size_t)cloud * 2 * m_pad, gidx + (size_t)cloud * 2 * m_pad + m_pad};
     // pass-0 input: the keys in slot order; pad slots keep the largest key there is (after every real row, NaN rows included)
     for (int j = tid; j < m_pad; j += GS_THREADS) {
-        kbuf[0][j] = j < m ? SortKey<T>::of(center ? rows[(size_t)j * c] - cx : rows[(size_t)j * c]) : ~(KT)0;
+        T q[3] = {T(0), T(0), T(0)};
+        if (j < m) frame_apply<T>(Fc, rows + (size_t)j * c, q);
+        kbuf[0][j] = j < m ? SortKey<T>::of(q[0]) : ~(KT)0;
         ibuf[0][j] = j;
     }
     __syncthreads();
@@ -1691,7 +1789,7 @@ __host__ __device__ inline dicp_step_io make_step_io(const dicp_loop_buffers& B,
     io.partials = B.partials; io.nblk = nblk; io.iter = k; io.dim = dim; io.const_iter = const_iter; io.tolerance = tolerance;
     io.rows_per_point = mode == DICP_PT2PT ? 3 : 1; io.n = n;
     io.pose_in = (const char*)B.poses + (size_t)k * N * 12 * es; io.pose_out = (char*)B.poses + (size_t)(k + 1) * N * 12 * es;
-    io.center = B.center; io.pose_search_out = B.poses_search ? (char*)B.poses_search + (size_t)(k + 1) * N * 12 * es : nullptr;
+    io.frame = B.frame; io.pose_search_out = B.poses_search ? (char*)B.poses_search + (size_t)(k + 1) * N * 12 * es : nullptr;
     io.delta = (char*)B.deltas + (size_t)k * 6 * es; io.delta_stride = (int64_t)B.K * 6;
     io.cost = (char*)B.costs + (size_t)k * es; io.cost_prev = k > 0 ? (const char*)B.costs + (size_t)(k - 1) * es : nullptr;
     io.cost_stride = B.K;
@@ -1733,7 +1831,7 @@ __device__ __forceinline__ void step_body(const dicp_step_io& io, int cloud, int
         if (tid == 40) smisc[0] = (double)((const T*)io.alive)[cloud];
         if (tid == 41) smisc[1] = io.cost_prev ? (double)((const T*)io.cost_prev)[(size_t)cloud * io.cost_stride] : 0.0;
         if (tid >= 42 && tid < 46) smisc[2 + (tid - 42)] = io.dcum ? (double)((const T*)io.rmax)[(size_t)cloud * 4 + (tid - 42)] : 0.0;
-        if (tid >= 46 && tid < 49) smisc[6 + (tid - 46)] = io.center ? (double)((const T*)io.center)[(size_t)cloud * 3 + (tid - 46)] : 0.0;
+        if (tid >= 46 && tid < 49) smisc[6 + (tid - 46)] = io.frame ? (double)((const T*)io.frame)[(size_t)cloud * 12 + 9 + (tid - 46)] : 0.0;   // t of the search frame
         if (tid == 49) smisc[9] = io.dcum ? (double)((const T*)io.dcum)[(size_t)cloud * io.dcum_stride + 2 * io.iter] : 0.0;
         if (tid == 50) smisc[10] = (double)((const T*)io.n_start)[cloud];
         if (tid == 51) smisc[11] = (double)((const T*)io.iterations)[cloud];
@@ -1773,14 +1871,14 @@ __device__ __forceinline__ void step_body(const dicp_step_io& io, int cloud, int
             T* dc = (T*)io.dcum + (size_t)cloud * io.dcum_stride + 2 * io.iter;
             const T nxt = (T)((double)(T)smisc[9] + (sqrt(dC) * rad + sqrt(mv)) * 1.0001);
             dc[2] = nxt + m_abs(nxt) * (T)(4.0 * ulp);                    // (rounded up)
-            const double cn = io.center ? sqrt(smisc[6] * smisc[6] + smisc[7] * smisc[7] + smisc[8] * smisc[8]) : 0.0;      // (the search subtracts the centre from r)
+            const double cn = io.frame ? sqrt(smisc[6] * smisc[6] + smisc[7] * smisc[7] + smisc[8] * smisc[8]) : 0.0;      // (the search frame adds t, |t| = |centre|, to r)
             const double pnm = sqrt(p0[0] * p0[0] + p0[1] * p0[1] + p0[2] * p0[2]);
             dc[3] = (T)(8.0 * ulp * (pnm + rad + sqrt(rn2) + cn + 1.0) * 1.0001);
         }
-        if (io.pose_search_out) {                                         // what the next search reads: [C | r - centre]
+        if (io.pose_search_out) {                                         // what the next search reads: [Q C | Q r + t] (the cloud's search frame)
             T* ps = (T*)io.pose_search_out + (size_t)cloud * 12;
-            for (int k = 0; k < 9; ++k) ps[k] = pn[k];
-            for (int k = 0; k < 3; ++k) ps[9 + k] = io.center ? pn[9 + k] - (T)smisc[6 + k] : pn[9 + k];
+            const T* F = io.frame ? (const T*)io.frame + (size_t)cloud * 12 : nullptr;
+            for (int k = 0; k < 12; ++k) ps[k] = frame_pose_entry<T>(F, pn, k);
         }
 
         T cost = (T)sacc[ACC_COST];                                       // ICP.py:229-232
@@ -1870,8 +1968,15 @@ __global__ __launch_bounds__(BLOCK) void icp_small_forward_kernel(WeightParams P
     for (int k = k0; k < k1; ++k) {
         T C[9], r[3];
         load_pose((const T*)B.poses + (size_t)k * N * 12, cloud, C, r);
-        T rs[3] = {r[0], r[1], r[2]};                       // the search's translation: r - centre (packed rows are y - centre)
-        if (B.center) { const T* ctr = (const T*)B.center + (size_t)cloud * 3; rs[0] -= ctr[0]; rs[1] -= ctr[1]; rs[2] -= ctr[2]; }
+        T Cs[9], rs[3];                                     // the search's pose: [Q C | Q r + t] (packed rows are Q y + t)
+        {
+            const T pw[12] = {C[0], C[1], C[2], C[3], C[4], C[5], C[6], C[7], C[8], r[0], r[1], r[2]};
+            const T* F = B.frame ? (const T*)B.frame + (size_t)cloud * 12 : nullptr;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) Cs[e] = frame_pose_entry<T>(F, pw, e);
+#pragma unroll
+            for (int e = 0; e < 3; ++e) rs[e] = frame_pose_entry<T>(F, pw, 9 + e);
+        }
         const T live = ((const T*)B.alive)[(size_t)k * N + cloud];
         int32_t* __restrict__ idx_k = B.idx + (B.idx_per_iter ? (size_t)k * N * n : 0) + (size_t)cloud * n;
         T* __restrict__ w_k = (T*)B.w + (size_t)k * B.w_iter + (size_t)cloud * B.w_stride;
@@ -1882,7 +1987,7 @@ __global__ __launch_bounds__(BLOCK) void icp_small_forward_kernel(WeightParams P
         for (int i = tid; i < nc; i += BLOCK) {
             const T p[3] = {src[i * 3], src[i * 3 + 1], src[i * 3 + 2]};
             T nx[3];
-            query_point(C, rs, p, nx);
+            query_point(Cs, rs, p, nx);
             T best = inf_v<T>();
             int bj = 0;
             for (int j = 0; j < m_pad; j += 4) {            // m_pad is a multiple of 64; ascending, strict <: lowest index on ties
@@ -2776,7 +2881,7 @@ __global__ __launch_bounds__(WAVE) void kabsch_step_kernel(const T* __restrict__
 // (ICP.py:585-586), and the iterations the host enqueues past that point before it notices are no-ops.
 template <typename T>
 __global__ __launch_bounds__(WAVE) void kabsch_loop_step_kernel(const T* __restrict__ partials, int nblk, T* __restrict__ pose, T* __restrict__ pose_search,
-                                                                T* __restrict__ pose_used, const T* __restrict__ center, T* __restrict__ costs, long cost_stride,
+                                                                T* __restrict__ pose_used, const T* __restrict__ frame, T* __restrict__ costs, long cost_stride,
                                                                 int k, double* __restrict__ save, int32_t* __restrict__ rows_live, T* __restrict__ iterations,
                                                                 int const_iter, double tolerance, int32_t* __restrict__ counters) {
     __shared__ double sacc[NACC_PAD], ssave[KAB_SAVE], sC[9], sr[3];
@@ -2804,7 +2909,12 @@ __global__ __launch_bounds__(WAVE) void kabsch_loop_step_kernel(const T* __restr
     if (tid < 12) {
         const T v = tid < 9 ? (T)sC[tid] : (T)sr[tid - 9];
         ps[tid] = v;
-        if (pose_search) pose_search[(size_t)cloud * 12 + tid] = (tid >= 9 && center) ? v - center[(size_t)cloud * 3 + tid - 9] : v;
+        if (pose_search) {
+            T pw[12];
+#pragma unroll
+            for (int e = 0; e < 12; ++e) pw[e] = e < 9 ? (T)sC[e] : (T)sr[e - 9];
+            pose_search[(size_t)cloud * 12 + tid] = frame_pose_entry<T>(frame ? frame + (size_t)cloud * 12 : nullptr, pw, tid);
+        }
     }
     if (tid < KAB_SAVE) save[(size_t)cloud * KAB_SAVE + tid] = ssave[tid];
     if (tid == 0) {
@@ -3086,17 +3196,17 @@ extern "C" {
 int dicp_abi_version(void) { return DICP_ABI_VERSION; }
 int dicp_padded_targets(int m) { return m <= 0 ? 0 : ((m + KNN_PAD - 1) / KNN_PAD) * KNN_PAD; }
 int dicp_accumulate_blocks(int n) { return n <= 0 ? 0 : (n + ACC_PTS - 1) / ACC_PTS; }
-int dicp_cloud_center(int dtype, const void* tgt, int c, const int32_t* tgt_rows, int N, int m, double quantum, void* center, void* stream) {
-    if (!tgt || !center) return DICP_ERR_NULL;
+int dicp_search_frame(int dtype, const void* tgt, int c, const int32_t* tgt_rows, int N, int m, double quantum, int directions, void* frame, void* stream) {
+    if (!tgt || !frame) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
-    if (N <= 0 || m <= 0 || (c != 3 && c != 6) || !(quantum >= 0.0)) return DICP_ERR_SHAPE;
+    if (N <= 0 || m <= 0 || c < 3 || !(quantum >= 0.0)) return DICP_ERR_SHAPE;
     begin_launch();
-    if (dtype == DICP_F32) cloud_center_kernel<float><<<N, CC_THREADS, 0, (hipStream_t)stream>>>((const float*)tgt, c, m, tgt_rows, quantum, (float*)center);
-    else                   cloud_center_kernel<double><<<N, CC_THREADS, 0, (hipStream_t)stream>>>((const double*)tgt, c, m, tgt_rows, quantum, (double*)center);
+    if (dtype == DICP_F32) search_frame_kernel<float><<<N, CC_THREADS, 0, (hipStream_t)stream>>>((const float*)tgt, c, m, tgt_rows, quantum, directions, (float*)frame);
+    else                   search_frame_kernel<double><<<N, CC_THREADS, 0, (hipStream_t)stream>>>((const double*)tgt, c, m, tgt_rows, quantum, directions, (double*)frame);
     return launch_status();
 }
 
-int dicp_pack_target(int dtype, const void* tgt, int c, const void* center, const int32_t* tgt_rows, int N, int m, void* tgt4, int m_pad, void* stream) {
+int dicp_pack_target(int dtype, const void* tgt, int c, const void* frame, const int32_t* tgt_rows, int N, int m, void* tgt4, int m_pad, void* stream) {
     if (!tgt || !tgt4) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || m <= 0 || (c != 3 && c != 6) || m_pad != dicp_padded_targets(m)) return DICP_ERR_SHAPE;
@@ -3105,8 +3215,8 @@ int dicp_pack_target(int dtype, const void* tgt, int c, const void* center, cons
     begin_launch();
     const int bpc = (int)blocks_for((size_t)m_pad);
     const unsigned g = grid_for(N, bpc);
-    if (dtype == DICP_F32) pack_kernel<float><<<g, BLOCK, 0, st>>>((const float*)tgt, N, m, c, (float4*)tgt4, m_pad, bpc, (const float*)center, tgt_rows);
-    else                   pack_kernel<double><<<g, BLOCK, 0, st>>>((const double*)tgt, N, m, c, (double4*)tgt4, m_pad, bpc, (const double*)center, tgt_rows);
+    if (dtype == DICP_F32) pack_kernel<float><<<g, BLOCK, 0, st>>>((const float*)tgt, N, m, c, (float4*)tgt4, m_pad, bpc, (const float*)frame, tgt_rows);
+    else                   pack_kernel<double><<<g, BLOCK, 0, st>>>((const double*)tgt, N, m, c, (double4*)tgt4, m_pad, bpc, (const double*)frame, tgt_rows);
     return launch_status();
 }
 
@@ -3115,7 +3225,7 @@ size_t dicp_sweep_sort_scratch_bytes(int dtype, int N, int m_pad) {
     return (size_t)N * 2 * m_pad * ((dtype == DICP_F32 ? 4 : 8) + sizeof(int32_t)) + 256;
 }
 
-int dicp_sweep_sort(int dtype, const void* tgt, int c, const void* center, const int32_t* tgt_rows, int N, int m, int m_pad, void* keys_sorted,
+int dicp_sweep_sort(int dtype, const void* tgt, int c, const void* frame, const int32_t* tgt_rows, int N, int m, int m_pad, void* keys_sorted,
                     int32_t* tperm, int nbkt, int32_t* bucket, void* brange, void* scratch, size_t scratch_bytes, void* stream) {
     if (!tgt || !keys_sorted || !tperm || (bucket && !brange)) return DICP_ERR_NULL;
     if (bucket && nbkt <= 0) return DICP_ERR_SHAPE;
@@ -3124,7 +3234,7 @@ int dicp_sweep_sort(int dtype, const void* tgt, int c, const void* center, const
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DICP_F32 && m_pad <= RS_MAX) {                 // in LDS, the bucket table while the sorted keys are there
         begin_launch();
-        sort_keys_kernel<<<N, RS_THREADS, 0, st>>>((const float*)tgt, c, N, m, m_pad, (float*)keys_sorted, tperm, nbkt, bucket, (float*)brange, (const float*)center, tgt_rows);
+        sort_keys_kernel<<<N, RS_THREADS, 0, st>>>((const float*)tgt, c, N, m, m_pad, (float*)keys_sorted, tperm, nbkt, bucket, (float*)brange, (const float*)frame, tgt_rows);
         return launch_status();
     }
     if (!scratch || scratch_bytes < dicp_sweep_sort_scratch_bytes(dtype, N, m_pad)) return DICP_ERR_NULL;
@@ -3132,19 +3242,19 @@ int dicp_sweep_sort(int dtype, const void* tgt, int c, const void* center, const
     void* kb = (void*)(((uintptr_t)scratch + 15) & ~(uintptr_t)15);       // keys first (8-byte aligned), then the indices
     if (dtype == DICP_F32) {
         int32_t* ib = (int32_t*)((unsigned*)kb + (size_t)N * 2 * m_pad);
-        sort_keys_big_kernel<float><<<N, GS_THREADS, 0, st>>>((const float*)tgt, c, m, m_pad, (const float*)center, tgt_rows, (float*)keys_sorted, tperm, (unsigned*)kb, ib);
+        sort_keys_big_kernel<float><<<N, GS_THREADS, 0, st>>>((const float*)tgt, c, m, m_pad, (const float*)frame, tgt_rows, (float*)keys_sorted, tperm, (unsigned*)kb, ib);
         if (bucket) sweep_buckets_kernel<float><<<N, BLOCK, 0, st>>>((const float*)keys_sorted, N, m, m_pad, nbkt, bucket, (float*)brange, tgt_rows);
     } else {
         int32_t* ib = (int32_t*)((unsigned long long*)kb + (size_t)N * 2 * m_pad);
-        sort_keys_big_kernel<double><<<N, GS_THREADS, 0, st>>>((const double*)tgt, c, m, m_pad, (const double*)center, tgt_rows, (double*)keys_sorted, tperm, (unsigned long long*)kb, ib);
+        sort_keys_big_kernel<double><<<N, GS_THREADS, 0, st>>>((const double*)tgt, c, m, m_pad, (const double*)frame, tgt_rows, (double*)keys_sorted, tperm, (unsigned long long*)kb, ib);
         if (bucket) sweep_buckets_kernel<double><<<N, BLOCK, 0, st>>>((const double*)keys_sorted, N, m, m_pad, nbkt, bucket, (double*)brange, tgt_rows);
     }
     return launch_status();
 }
 
-int dicp_sweep_build(int dtype, const void* tgt, int c, const void* center, const int32_t* tgt_rows, const int32_t* tperm, int N, int m, int m_pad,
+int dicp_sweep_build(int dtype, const void* tgt, int c, const void* frame, const int32_t* tgt_rows, const int32_t* tperm, int N, int m, int m_pad,
                      void* tgs4, void* tgt_s, int tgt_s_stride, void* stream) {
-    // center != NULL: the packed rows tgs4 are y - centre; tgt_s stays as given
+    // frame != NULL: the packed rows tgs4 are y - centre; tgt_s stays as given
     if (!tgt || !tgs4 || !tperm) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || m <= 0 || (c != 3 && c != 6) || m_pad != dicp_padded_targets(m) || (tgt_s && tgt_s_stride < c)) return DICP_ERR_SHAPE;
@@ -3153,8 +3263,8 @@ int dicp_sweep_build(int dtype, const void* tgt, int c, const void* center, cons
     begin_launch();
     const int bpc = (m_pad + BLOCK * 4 - 1) / (BLOCK * 4);
     const unsigned g = grid_for(N, bpc);
-    if (dtype == DICP_F32) sweep_rows_kernel<float><<<g, BLOCK, 0, st>>>((const float*)tgt, tgt_rows, N, m, c, m_pad, bpc, (float4*)tgs4, tperm, (float*)tgt_s, tgt_s_stride, (const float*)center);
-    else                   sweep_rows_kernel<double><<<g, BLOCK, 0, st>>>((const double*)tgt, tgt_rows, N, m, c, m_pad, bpc, (double4*)tgs4, tperm, (double*)tgt_s, tgt_s_stride, (const double*)center);
+    if (dtype == DICP_F32) sweep_rows_kernel<float><<<g, BLOCK, 0, st>>>((const float*)tgt, tgt_rows, N, m, c, m_pad, bpc, (float4*)tgs4, tperm, (float*)tgt_s, tgt_s_stride, (const float*)frame);
+    else                   sweep_rows_kernel<double><<<g, BLOCK, 0, st>>>((const double*)tgt, tgt_rows, N, m, c, m_pad, bpc, (double4*)tgs4, tperm, (double*)tgt_s, tgt_s_stride, (const double*)frame);
     return launch_status();
 }
 
@@ -3188,26 +3298,26 @@ int dicp_query_order(int dtype, const void* src, const void* pose, const void* b
 }
 
 int dicp_loop_init(int dtype, const void* T_init, const void* w0, double thresh, int rows, int N, int n,
-                   void* pose0, void* alive0, void* n_start, const void* center, void* pose_search0,
+                   void* pose0, void* alive0, void* n_start, const void* frame, void* pose_search0,
                    const void* src, void* rmax, void* dcum, int dcum_stride, void* stream) {
     if (!T_init || !pose0 || !alive0 || !n_start || (rmax && (!src || !dcum))) return DICP_ERR_NULL;       // (w0 == NULL: unit weights)
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || n <= 0 || (rows != 1 && rows != 3) || (rmax && dcum_stride < 2)) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     begin_launch();
-    if (dtype == DICP_F32) loop_init_kernel<float><<<N, LI_THREADS, 0, st>>>((const float*)T_init, (const float*)w0, (float)thresh, rows, n, (float*)pose0, (float*)alive0, (float*)n_start, (const float*)center, (float*)pose_search0, (const float*)src, (float*)rmax, (float*)dcum, dcum_stride);
-    else                   loop_init_kernel<double><<<N, LI_THREADS, 0, st>>>((const double*)T_init, (const double*)w0, thresh, rows, n, (double*)pose0, (double*)alive0, (double*)n_start, (const double*)center, (double*)pose_search0, (const double*)src, (double*)rmax, (double*)dcum, dcum_stride);
+    if (dtype == DICP_F32) loop_init_kernel<float><<<N, LI_THREADS, 0, st>>>((const float*)T_init, (const float*)w0, (float)thresh, rows, n, (float*)pose0, (float*)alive0, (float*)n_start, (const float*)frame, (float*)pose_search0, (const float*)src, (float*)rmax, (float*)dcum, dcum_stride);
+    else                   loop_init_kernel<double><<<N, LI_THREADS, 0, st>>>((const double*)T_init, (const double*)w0, thresh, rows, n, (double*)pose0, (double*)alive0, (double*)n_start, (const double*)frame, (double*)pose_search0, (const double*)src, (double*)rmax, (double*)dcum, dcum_stride);
     return launch_status();
 }
 
-int dicp_search_pose(int dtype, const void* T_init, const void* center, int N, void* pose_search, void* stream) {
+int dicp_search_pose(int dtype, const void* T_init, const void* frame, int N, void* pose_search, void* stream) {
     if (!T_init || !pose_search) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0) return DICP_ERR_SHAPE;
     begin_launch();
     const unsigned g = (unsigned)((N * 12 + BLOCK - 1) / BLOCK);
-    if (dtype == DICP_F32) search_pose_kernel<float><<<g, BLOCK, 0, (hipStream_t)stream>>>((const float*)T_init, (const float*)center, N, (float*)pose_search);
-    else                   search_pose_kernel<double><<<g, BLOCK, 0, (hipStream_t)stream>>>((const double*)T_init, (const double*)center, N, (double*)pose_search);
+    if (dtype == DICP_F32) search_pose_kernel<float><<<g, BLOCK, 0, (hipStream_t)stream>>>((const float*)T_init, (const float*)frame, N, (float*)pose_search);
+    else                   search_pose_kernel<double><<<g, BLOCK, 0, (hipStream_t)stream>>>((const double*)T_init, (const double*)frame, N, (double*)pose_search);
     return launch_status();
 }
 
@@ -3559,11 +3669,11 @@ int dicp_kabsch_forward(int dtype, const dicp_kabsch_buffers* B, int N, int n, i
         begin_launch();
         if (dtype == DICP_F32)
             kabsch_loop_step_kernel<float><<<N, WAVE, 0, st>>>((const float*)B->partials, nblk, (float*)B->pose, (float*)B->pose_search, (float*)B->pose_used,
-                                                               (const float*)B->center, (float*)B->costs, (long)B->K, k, B->save, B->rows_live, (float*)B->iterations,
+                                                               (const float*)B->frame, (float*)B->costs, (long)B->K, k, B->save, B->rows_live, (float*)B->iterations,
                                                                const_iter, tolerance, B->counters);
         else
             kabsch_loop_step_kernel<double><<<N, WAVE, 0, st>>>((const double*)B->partials, nblk, (double*)B->pose, (double*)B->pose_search, (double*)B->pose_used,
-                                                                (const double*)B->center, (double*)B->costs, (long)B->K, k, B->save, B->rows_live, (double*)B->iterations,
+                                                                (const double*)B->frame, (double*)B->costs, (long)B->K, k, B->save, B->rows_live, (double*)B->iterations,
                                                                 const_iter, tolerance, B->counters);
         rc = launch_status();
         if (rc) return rc;

@@ -48,12 +48,12 @@ class nn:
             raise TypeError("x and y must share a dtype, got %s and %s" % (x.dtype, y.dtype))
         xd, yd = x.detach().contiguous(), y.detach().contiguous()
         if (self.knn_variant & 0xff) == _lib.KNN_SWEEP:
-            center = _ops.cloud_center(yd)                      # centred search (see _ops.ICPLoop): rows y - c, pose [I | -c]
-            pose_s = _ops.search_pose(None, center)
-            sw = _ops.SweepIndex(yd, center=center)
+            frame = _ops.search_frame(yd)                       # the cloud's search frame (see _ops.ICPLoop): rows Q y + t, pose [Q | t]
+            pose_s = _ops.search_pose(None, frame)
+            sw = _ops.SweepIndex(yd, frame=frame)
             return sw.knn(xd, pose_s, sw.query_order(xd, pose_s), cfg=(self.knn_variant >> 8) & 0xff)
-        center = _ops.cloud_center(yd)
-        return _ops.knn(xd, _ops.search_pose(None, center), _ops.pack_target(yd, center), y.shape[1], self.knn_variant)
+        frame = _ops.search_frame(yd)
+        return _ops.knn(xd, _ops.search_pose(None, frame), _ops.pack_target(yd, frame), y.shape[1], self.knn_variant)
 
     def _hard(self, x, y):
         return _ops.gather_rows(y, self._index(x, y))

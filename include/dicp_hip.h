@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define DICP_ABI_VERSION 4   /* 4: dicp_loop_buffers.bwd_skip / bwd_mref / bwd_live / bwd_skip_eps (truncated reverse sweep of dicp_icp_backward).
+#define DICP_ABI_VERSION 4   /* 4: dicp_loop_buffers.bwd_skip / bwd_mref / bwd_live / bwd_skip_eps (truncated reverse sweep of dicp_icp_backward); cert_cloud (per-cloud switch of the
+                                match certificates); dicp_cloud_center -> dicp_search_frame: centre AND sort direction as one affine map per cloud, (N,12).
                                 3: per-cloud row counts of ragged batches (src_rows / tgt_rows) on every entry point of the path; the centred and
                                 uncentred forms of an entry point are one (center may be NULL); the key sort is native for every size and dtype;
                                 timing events are 6 per iteration; the scan / packed / fused-accumulate search forms are gone */
@@ -64,19 +65,24 @@ int dicp_padded_targets(int m);
 /* Blocks per cloud used by dicp_accumulate / dicp_accumulate_bwd for n source points. */
 int dicp_accumulate_blocks(int n);
 
-/* Centred search coordinates.  The searches score in the expanded form 0.5|y|^2 - x.y (the reference's own: nn.py:32), whose rounding
- * error grows with 0.5|x|^2 -- and with it the prune margin of dicp_knn_sweep: a cloud a kilometre from the origin is searched almost
- * exhaustively.  dicp_cloud_center writes, per cloud, the coordinate-wise median of a stride sample of at most 1024 of its rows, rounded to
- * a multiple of `quantum` (0: not rounded; float precision), into center (N,3) T; entry points given `center` pack rows as y - center, and the
- * caller hands the searches the pose [C | r - center] (dicp_loop_buffers.poses_search; dicp_loop_init / the step kernels write it).  Every
- * search form reads only (pose, packed rows): with the same centre they return the same indices as each other, and with center == 0 (clouds
- * near the origin, given a quantum) exactly the bits of center == NULL. */
-int dicp_cloud_center(int dtype, const void* tgt, int c, const int32_t* tgt_rows, int N, int m, double quantum, void* center, void* stream);
+/* The search frame.  The searches score in the expanded form 0.5|y|^2 - x.y (the reference's own: nn.py:32), whose rounding error grows
+ * with 0.5|x|^2 -- and with it the prune margin of dicp_knn_sweep: a cloud a kilometre from the origin is searched almost exhaustively.
+ * And the sorted sweep prunes along ONE direction: a wall perpendicular to it sits in every slab that touches it.  Both are met by one
+ * affine map per cloud, x' = Q x + t:  frame (N,12) T = [Q row-major (9) | t (3)], Q a rotation whose first row is the sort direction,
+ * t = -Q c.  dicp_search_frame writes it: c = the coordinate-wise median of a stride sample of at most 1024 of the cloud's rows, rounded to a
+ * multiple of `quantum` (0: not rounded; float precision); Q = (directions != 0) the candidate -- identity, the two other axis orders, three
+ * oblique directions -- whose projected keys spread the sample best (smallest sum of squared counts of a 256-bin histogram: proportional to
+ * the pairs a slab search scores), the identity unless another candidate is 20 % better; directions == 0: Q = I.
+ * Entry points given `frame` pack rows as Q y + t, and the caller hands the searches the pose [Q C | Q r + t] (dicp_loop_buffers.poses_search;
+ * dicp_loop_init / the step kernels write it).  Every search form reads only (pose, packed rows): with the same frame they return the same
+ * indices as each other; Q = I is applied as the plain subtraction it is, and with t == 0 too (clouds near the origin, given a quantum) the
+ * results are exactly those of frame == NULL. */
+int dicp_search_frame(int dtype, const void* tgt, int c, const int32_t* tgt_rows, int N, int m, double quantum, int directions, void* frame, void* stream);
 
-/* Once per ICP call: tgt (N,m,c) -> tgt4 (N,m_pad,4) rows [x,y,z,0.5|y|^2] (of y - center when center != NULL), pad rows
+/* Once per ICP call: tgt (N,m,c) -> tgt4 (N,m_pad,4) rows [x,y,z,0.5|y|^2] (of Q y + t when frame != NULL), pad rows
  * [0,0,0,+inf].  The norms are the ||y||^2 column that torch.cdist's matmul path builds
  * on every call (nn.py:32 -> ATen _euclidean_dist).  c in {3,6}. */
-int dicp_pack_target(int dtype, const void* tgt, int c, const void* center, const int32_t* tgt_rows, int N, int m, void* tgt4, int m_pad, void* stream);
+int dicp_pack_target(int dtype, const void* tgt, int c, const void* frame, const int32_t* tgt_rows, int N, int m, void* tgt4, int m_pad, void* stream);
 
 /* Fused transform + brute-force 1-NN: replaces ICP.py:137 (ps_t = C p + r) followed by
  * nn.find_nn's cdist -> argmin, nn.py:32-35 / 83-86.  Never materialises (N,n,m).
@@ -87,19 +93,19 @@ int dicp_knn(int dtype, const void* src, const void* pose, const void* tgt4, con
              int N, int n, int m, int m_pad, int32_t* idx, int variant, void* stream);
 
 /* Set-up of the sorted-sweep search structure, ONCE per ICP call (targets do not move between iterations).
- * dicp_sweep_sort: keys_sorted (N,m_pad) T and tperm (N,m_pad) as a STABLE ascending sort of the target x keys (of y - center) gives them;
+ * dicp_sweep_sort: keys_sorted (N,m_pad) T and tperm (N,m_pad) as a STABLE ascending sort of the target x keys (first coordinate of Q y + t) gives them;
  *   the m_pad - m pad slots (and, in a ragged batch, the slots past a cloud's own rows) keep the largest key: they follow every real row,
  *   NaN rows included.  float32 clouds of up to 16384 slots: an LSD radix sort in LDS, one block per cloud; float64 keys or more slots: the
  *   same sort chunk by chunk through `scratch` (dicp_sweep_sort_scratch_bytes(dtype, N, m_pad) bytes; 0 = none needed).  Given bucket
  *   (N,nbkt+1) and brange (N,2) it also builds the search's coarse table: bucket[b] = #rows with x < xlo + b / inv, brange = [xlo, inv].
  * dicp_sweep_build: from tperm, tgs4 (N,m_pad,4) = the packed rows in sorted order (pads [max,0,0,+inf]) and, optionally, tgt_s
- *   (N,m_pad,tgt_s_stride) = the full target rows in sorted order (row s = tgt[tperm[s]], as given: not centred; tgt_s_stride >= c elements per
+ *   (N,m_pad,tgt_s_stride) = the full target rows in sorted order (row s = tgt[tperm[s]], as given: not in the search frame; tgt_s_stride >= c elements per
  *   row, the rest zero: 8 for c = 6 / 4 for c = 3 makes every row ONE aligned 32- / 16-byte sector for the gathers of dicp_accumulate and
  *   dicp_accumulate_bwd_window, which take such rows with c = the stride). */
 size_t dicp_sweep_sort_scratch_bytes(int dtype, int N, int m_pad);
-int dicp_sweep_sort(int dtype, const void* tgt, int c, const void* center, const int32_t* tgt_rows, int N, int m, int m_pad, void* keys_sorted,
+int dicp_sweep_sort(int dtype, const void* tgt, int c, const void* frame, const int32_t* tgt_rows, int N, int m, int m_pad, void* keys_sorted,
                     int32_t* tperm, int nbkt, int32_t* bucket, void* brange, void* scratch, size_t scratch_bytes, void* stream);
-int dicp_sweep_build(int dtype, const void* tgt, int c, const void* center, const int32_t* tgt_rows, const int32_t* tperm, int N, int m, int m_pad,
+int dicp_sweep_build(int dtype, const void* tgt, int c, const void* frame, const int32_t* tgt_rows, const int32_t* tperm, int N, int m, int m_pad,
                      void* tgs4, void* tgt_s, int tgt_s_stride, void* stream);
 /* keys (N,n) = x coordinate of every source point under pose (NULL = identity): the sort key of the query order. */
 int dicp_query_keys(int dtype, const void* src, const void* pose, int N, int n, void* keys, void* stream);
@@ -189,8 +195,8 @@ typedef struct dicp_step_io {
     const void* w_prev;      /* previous iteration's, or NULL              ICP.py:224-226 */
     int64_t w_stride;
     int32_t* n_not_converged;/* device counter for this iteration, pre-zeroed: += 1 per cloud with |delta| >= tol */
-    const void* center;      /* optional (N,3) T: the search's centre (dicp_cloud_center) */
-    void* pose_search_out;   /* optional (N,12) T: [C' | r' - centre], what the NEXT search reads (NULL: not kept) */
+    const void* frame;       /* optional (N,12) T: the search frame (dicp_search_frame) */
+    void* pose_search_out;   /* optional (N,12) T: [Q C' | Q r' + t], what the NEXT search reads (NULL: not kept) */
     const void* rmax;        /* optional (N,4) T: bounding radius and midpoint of each source cloud (dicp_loop_init) */
     void* dcum;              /* optional T: cloud b's (motion bound, point rounding) pairs at dcum + b*dcum_stride: [2(iter+1)] = [2 iter] + how far any
                                 query of the cloud can have moved between pose_in and pose_out, [2(iter+1)+1] = the rounding of a point transformed
@@ -251,9 +257,9 @@ typedef struct dicp_loop_buffers {
                                 dispatch (hipExtLaunchKernel), the other forms are bracketed by hipEventRecord */
     int32_t bwd_overwrite;   /* dicp_icp_backward, windowed form: 1 = gsrc / gw / the slab (gtgt) are uninitialised and this call's
                                 first launch (iteration k1-1) writes them instead of adding; 0 = they are accumulators */
-    const void* center;      /* optional (N,3) T: centre of the search coordinates (dicp_cloud_center); tgt4 / the sweep index were then
+    const void* frame;       /* optional (N,12) T: the search frame (dicp_search_frame); tgt4 / the sweep index were then
                                 built with it */
-    void* poses_search;      /* optional (K+1,N,12) T: [C | r - centre] per iteration, written by dicp_loop_init (k = 0) and
+    void* poses_search;      /* optional (K+1,N,12) T: [Q C | Q r + t] per iteration, written by dicp_loop_init (k = 0) and
                                 the step kernels; the searches read it instead of poses.  NULL: they read poses */
     const int32_t* src_rows; /* optional (N): rows of each source cloud that take part (ragged batches); qorder, if any, from dicp_query_order
                                 with the same counts */
@@ -303,12 +309,12 @@ int dicp_pose_grad_out(int dtype, const double* gpose, const void* bwd_partials,
  * n_start (N) = rows * #(w0 > thresh), rows = 3 for pt2pt, 1 for pt2pl.  And after the last executed iteration K
  * (ICP.py:267-281): iterations / matched_ratio of clouds that never converged, T_out (N,4,4) from pose_K. */
 int dicp_loop_init(int dtype, const void* T_init, const void* w0, double thresh, int rows, int N, int n,
-                   void* pose0, void* alive0, void* n_start, const void* center /* optional */, void* pose_search0 /* optional: [C_0 | r_0 - center] */,
+                   void* pose0, void* alive0, void* n_start, const void* frame /* optional */, void* pose_search0 /* optional: [Q C_0 | Q r_0 + t] */,
                    const void* src, void* rmax, void* dcum, int dcum_stride /* optional (match certificates): rmax (N,4) = bounding radius and midpoint of each cloud of
                    src (N,n,3), dcum (N,dcum_stride >= 2): [0] = 0, [1] = the rounding of a point transformed with pose0 */, void* stream);
-/* pose_search (N,12) = [C_0 | r_0 - center] from T_init (N,4,4) alone: the same values, for a caller that orders the first queries
- * before the loop state exists (center optional) */
-int dicp_search_pose(int dtype, const void* T_init, const void* center, int N, void* pose_search, void* stream);
+/* pose_search (N,12) = [Q C_0 | Q r_0 + t] from T_init (N,4,4) alone: the same values, for a caller that orders the first queries
+ * before the loop state exists (frame optional) */
+int dicp_search_pose(int dtype, const void* T_init, const void* frame, int N, void* pose_search, void* stream);
 int dicp_loop_finish(int dtype, const void* pose_K, const void* alive_K, const void* n_start, const void* n_matched, int K, int N,
                      void* iterations, void* matched_ratio, void* T_out, void* stream);
 
@@ -414,7 +420,7 @@ typedef struct dicp_kabsch_buffers {
     int32_t K;               /* capacity of the cost history (= max_iterations) */
     int32_t knn_variant;     /* as dicp_loop_buffers */
     int32_t m_pad;
-    const void* tgt4;        /* packed rows (sorted for the sweep), built with `center` */
+    const void* tgt4;        /* packed rows (sorted for the sweep), built with `frame` */
     const int32_t* tperm;    /* sweep only */
     const int32_t* qorder;   /* sweep only, may be NULL */
     const int32_t* bucket;   /* sweep only */
@@ -422,9 +428,9 @@ typedef struct dicp_kabsch_buffers {
     int32_t nbkt;
     int32_t pad0;
     unsigned long long* pairs;   /* sweep only, optional */
-    const void* center;      /* optional (N,3) */
+    const void* frame;       /* optional (N,12): the search frame */
     void* pose;              /* (N,12) in/out: the current pose [C | r] */
-    void* pose_search;       /* optional (N,12) in/out: [C | r - center], what the searches read (NULL: they read pose) */
+    void* pose_search;       /* optional (N,12) in/out: [Q C | Q r + t], what the searches read (NULL: they read pose) */
     void* pose_used;         /* (N,12) out: the pose of each cloud's last active iteration BEFORE its step */
     int32_t* idx;            /* (N,n) out: the matches of each cloud's last active iteration */
     void* partials;          /* (N, dicp_accumulate_blocks(n), DICP_NACC_PAD) scratch */

@@ -38,7 +38,7 @@ sorts = [i for i in range(lo, first) if "sort_keys_kernel" in rows[i]["Kernel_Na
 if sorts:
     lo = sorts[-1]
     steps = 0
-    while (lo > 0 and steps < 3 and ("Fill" in rows[lo - 1]["Kernel_Name"] or "cloud_center" in rows[lo - 1]["Kernel_Name"])
+    while (lo > 0 and steps < 3 and ("Fill" in rows[lo - 1]["Kernel_Name"] or "search_frame" in rows[lo - 1]["Kernel_Name"])
            and int(rows[lo]["Start_Timestamp"]) - int(rows[lo - 1]["End_Timestamp"]) < 90_000):
         lo -= 1; steps += 1
 # ... and ends at the first idle gap after its backward (the host synchronises there; later legs of bench.py follow)

@@ -38,7 +38,7 @@ def test_struct_layouts_match_header(lib):
     # dicp_step_io: field order and padding as the C compiler lays it out
     expect = ["partials", "nblk", "iter", "dim", "const_iter", "tolerance", "rows_per_point", "n", "pose_in", "pose_out",
               "delta", "delta_stride", "cost", "cost_prev", "cost_stride", "areg", "alive", "alive_out", "converged", "iterations",
-              "matched_ratio", "n_start", "n_matched", "w_cur", "w_prev", "w_stride", "n_not_converged", "center", "pose_search_out",
+              "matched_ratio", "n_start", "n_matched", "w_cur", "w_prev", "w_stride", "n_not_converged", "frame", "pose_search_out",
               "rmax", "dcum", "dcum_stride", "cert_cloud"]
     assert [f[0] for f in _lib.StepIO._fields_] == expect
     hdr = open(os.path.join(ROOT, "include", "dicp_hip.h")).read()
@@ -99,11 +99,11 @@ def test_new_entry_points_reject_bad_arguments(lib):
     assert lib.dicp_loop_init(0, one, one, 0.01, 1, 1, 1, one, one, one, None, None, None, one, None, 4, None) == 1     # rmax needs the points and dcum
     assert lib.dicp_loop_finish(0, one, one, one, one, 1, 1, None, one, one, None) == 1
     # centred search (center itself is optional everywhere)
-    assert lib.dicp_cloud_center(0, None, 3, None, 1, 1, 16.0, one, None) == 1
-    assert lib.dicp_cloud_center(0, one, 3, None, 1, 1, 16.0, None, None) == 1
-    assert lib.dicp_cloud_center(0, one, 4, None, 1, 1, 16.0, one, None) == 2
-    assert lib.dicp_cloud_center(0, one, 3, None, 1, 1, -1.0, one, None) == 2
-    assert lib.dicp_cloud_center(5, one, 3, None, 1, 1, 16.0, one, None) == 3
+    assert lib.dicp_search_frame(0, None, 3, None, 1, 1, 16.0, 1, one, None) == 1
+    assert lib.dicp_search_frame(0, one, 3, None, 1, 1, 16.0, 1, None, None) == 1
+    assert lib.dicp_search_frame(0, one, 2, None, 1, 1, 16.0, 1, one, None) == 2
+    assert lib.dicp_search_frame(0, one, 3, None, 1, 1, -1.0, 1, one, None) == 2
+    assert lib.dicp_search_frame(5, one, 3, None, 1, 1, 16.0, 1, one, None) == 3
     assert lib.dicp_search_pose(0, None, None, 1, one, None) == 1 and lib.dicp_search_pose(0, one, None, 0, one, None) == 2
     # dicp_accumulate_bwd_window(dtype, prm, src_s, tgt_s, c, spos, spos_ref, qorder, pose, w_s, alive, gs, gb, src_rows, N, n, m_pad, gsrc_s, slab, far, gw_s, partials, ow, stream)
     assert lib.dicp_accumulate_bwd_window(0, ctypes.byref(P), one, one, 6, None, one, None, one, one, None, one, one, None, 1, 1, 64,

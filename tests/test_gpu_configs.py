@@ -76,10 +76,10 @@ def test_sweep_equals_brute_force_at_65536(dtype, N, n):
     brute_p = _ops.knn(sd, pose, _ops.pack_target(td), n, _lib.KNN_VALU)
     assert torch.equal(sw.knn(sd, pose, sw.query_order(sd, pose)), brute_p)
     # centred search coordinates (what the ICP loop uses): packed rows y - c, pose [C | r - c]
-    ctr = _ops.cloud_center(td + torch.tensor([300.0, -200.0, 50.0, 0, 0, 0], dtype=dtype, device=DEV))
+    ctr = _ops.search_frame(td + torch.tensor([300.0, -200.0, 50.0, 0, 0, 0], dtype=dtype, device=DEV))
     far_t = (td + torch.tensor([300.0, -200.0, 50.0, 0, 0, 0], dtype=dtype, device=DEV)).contiguous()
     far_s = (sd + torch.tensor([300.0, -200.0, 50.0], dtype=dtype, device=DEV)).contiguous()
-    swc = _ops.SweepIndex(far_t, center=ctr)
+    swc = _ops.SweepIndex(far_t, frame=ctr)
     ps = _ops.search_pose(None, ctr, N)
     got_c = swc.knn(far_s, ps, swc.query_order(far_s, ps))
     brute_c = _ops.knn(far_s, ps, _ops.pack_target(far_t, ctr), n, _lib.KNN_VALU)

@@ -747,10 +747,10 @@ def test_icp_with_sweep_knn_matches_reference(golden, name, icp_type, diff, wind
     assert int(icp.knn_stats["knn_pairs"].sum().item()) > 0
 
 
-def test_cloud_center_is_the_quantised_median_and_zero_keeps_the_bits():
-    """dicp_cloud_center: coordinate-wise (lower) median of a stride sample of the cloud's rows, rounded to multiples of the quantum
-    (0 near the origin); a ragged batch hands over the clouds' own lengths, so the reference's far pad rows (ICP.py:460) are not in
-    the sample; with a zero centre every producer writes exactly what it writes without one."""
+def test_search_frame_centre_is_the_quantised_median_and_zero_keeps_the_bits():
+    """dicp_search_frame, the centre part (directions off: Q = I, t = -c): coordinate-wise (lower) median of a stride sample of the cloud's
+    rows, rounded to multiples of the quantum (0 near the origin); a ragged batch hands over the clouds' own lengths, so the reference's far
+    pad rows (ICP.py:460) are not in the sample; with a zero frame every producer writes exactly what it writes without one."""
     g = torch.Generator().manual_seed(3)
     tgt = torch.rand((5, 777, 6), generator=g) * 20 - 10
     tgt[1, :, :3] += torch.tensor([1003.0, -37.0, 7.9])
@@ -762,30 +762,37 @@ def test_cloud_center_is_the_quantised_median_and_zero_keeps_the_bits():
     med = tgt[:, :, :3].float().sort(dim=1).values[:, (777 - 1) // 2]            # lower median per coordinate (all 777 rows sampled)
     med[3] = tgt[3, :500, :3].float().sort(dim=0).values[(500 - 1) // 2]
     med[4] = tgt[4, :200, :3].float().sort(dim=0).values[(200 - 1) // 2]
-    exact = _ops.cloud_center(td, quantum=0.0, tgt_rows=tr).cpu()
+    eye = torch.eye(3).reshape(9)
+
+    def centre(t, **kw):
+        F = _ops.search_frame(t, directions=False, **kw).cpu()
+        assert torch.equal(F[:, :9].float(), eye.repeat(F.shape[0], 1))
+        return -F[:, 9:]
+    exact = centre(td, quantum=0.0, tgt_rows=tr)
     assert torch.equal(exact, med), (exact, med)
-    c = _ops.cloud_center(td, quantum=16.0, tgt_rows=tr).cpu()
+    c = centre(td, quantum=16.0, tgt_rows=tr)
     assert torch.equal(c.double(), torch.round(med.double() / 16.0) * 16.0), (c, med)
     assert torch.equal(c[0], torch.zeros(3)) and torch.equal(c[3], torch.zeros(3)) and torch.equal(c[4], torch.zeros(3))
     td = torch.nan_to_num(td, nan=10000.0)                   # (the index checks below run dense)
     same = torch.full((1, 50, 3), 7.25)
-    assert torch.equal(_ops.cloud_center(same.to(DEV), quantum=0.0).cpu(), same[:, 0])                   # all rows one point: they all vote
+    assert torch.equal(centre(same.to(DEV), quantum=0.0), same[:, 0])                   # all rows one point: they all vote
     big = (torch.rand((2, 10000, 3), generator=g) * 20 - 10 + torch.tensor([500.0, 0.0, -300.0]))
     step = (10000 + 1023) // 1024
     sample = big[:, ::step]
-    assert torch.equal(_ops.cloud_center(big.to(DEV), quantum=0.0).cpu(), sample.sort(dim=1).values[:, (sample.shape[1] - 1) // 2])
-    assert torch.equal(_ops.cloud_center(big.double().to(DEV), quantum=0.0).cpu().float(), sample.sort(dim=1).values[:, (sample.shape[1] - 1) // 2])
-    zero = torch.zeros((5, 3), device=DEV)
+    assert torch.equal(centre(big.to(DEV), quantum=0.0), sample.sort(dim=1).values[:, (sample.shape[1] - 1) // 2])
+    assert torch.equal(centre(big.double().to(DEV), quantum=0.0).float(), sample.sort(dim=1).values[:, (sample.shape[1] - 1) // 2])
+    zero = torch.cat((eye, torch.zeros(3))).repeat(5, 1).to(DEV)
     assert torch.equal(_ops.pack_target(td), _ops.pack_target(td, zero))
-    a, b = _ops.SweepIndex(td, sorted_rows=True), _ops.SweepIndex(td, sorted_rows=True, center=zero)
+    a, b = _ops.SweepIndex(td, sorted_rows=True), _ops.SweepIndex(td, sorted_rows=True, frame=zero)
     for name in ("tgs4", "tperm", "bucket", "brange", "keys", "tgt_s"):
         x, y = getattr(a, name), getattr(b, name)
         if name == "keys":                                                            # pad keys are NaN
             x, y = torch.nan_to_num(x, nan=7.0), torch.nan_to_num(y, nan=7.0)
         assert torch.equal(x, y), name
     # a real centre: rows and keys are the shifted ones, the full rows for the backward stay as given
-    cc = _ops.cloud_center(td)
-    sw = _ops.SweepIndex(td, sorted_rows=True, center=cc)
+    F = _ops.search_frame(td, directions=False)
+    cc = -F[:, 9:]
+    sw = _ops.SweepIndex(td, sorted_rows=True, frame=F)
     perm = sw.tperm[:, :777].long()
     rows = torch.gather(td, 1, perm.unsqueeze(-1).expand(-1, -1, 6))
     assert torch.equal(sw.tgt_s[:, :777, :6], rows)
@@ -793,25 +800,74 @@ def test_cloud_center_is_the_quantised_median_and_zero_keeps_the_bits():
     assert torch.equal(sw.keys[:, :777], rows[:, :, 0] - cc[:, None, 0])
 
 
+def test_search_frame_picks_a_direction_no_wall_is_perpendicular_to():
+    """dicp_search_frame, the direction part: volumetric clouds keep the identity (and with it every bit of the plain x sort); a planar scene
+    with walls perpendicular to x (and to y) gets one of the oblique rotations; a slab of a cloud that is thin in x but long in z gets z first.
+    Whatever the frame, Q is a rotation, and the sweep on it returns the brute-force kernel's indices in the same frame, index for index."""
+    from dicp_amd.synthetic import make_scene_pairs
+    vol_s, vol_t = make_pairs(3, 3000, 4096, seed=5)
+    sc_s, sc_t = make_scene_pairs(3, 3000, 4096, seed=5)
+    g = torch.Generator().manual_seed(1)
+    slab = torch.rand((3, 4096, 6), generator=g)
+    slab[:, :, 0] *= 0.5
+    slab[:, :, 1] *= 2.0
+    slab[:, :, 2] *= 30.0
+    for name, tgt, src, want in (("volume", vol_t, vol_s, "identity"), ("scene", sc_t, sc_s, "oblique"), ("slab", slab, slab[:, :3000, :3].contiguous() + 0.01, "z")):
+        td, sd = tgt.to(DEV), src.to(DEV)
+        F = _ops.search_frame(td)
+        Q = F[:, :9].reshape(3, 3, 3).double().cpu()
+        assert float((Q @ Q.transpose(1, 2) - torch.eye(3, dtype=torch.float64)).abs().max()) < 1e-6 and bool((torch.linalg.det(Q) > 0.999).all()), name
+        first = Q[:, 0]
+        if want == "identity":
+            assert torch.equal(Q, torch.eye(3, dtype=torch.float64).repeat(3, 1, 1)), (name, Q)
+        elif want == "z":
+            assert torch.equal(first, torch.tensor([0.0, 0.0, 1.0], dtype=torch.float64).repeat(3, 1)), (name, first)
+        else:
+            assert bool((first.abs().min(dim=1).values > 0.4).all()), (name, first)
+        sw = _ops.SweepIndex(td, frame=F)
+        pose = _ops.search_pose(None, F)
+        brute = _ops.knn(sd, pose, _ops.pack_target(td, F), td.shape[1], _lib.KNN_VALU)
+        assert torch.equal(sw.knn(sd, pose, sw.query_order(sd, pose)), brute), name
+        # ... and they are the true neighbours (float64, original coordinates), up to float32 near-ties
+        d = torch.cdist(sd[0].double(), td[0, :, :3].double())
+        v, ix = torch.topk(d, 2, dim=1, largest=False)
+        bad = brute[0].long() != ix[:, 0]
+        assert float(bad.float().mean()) < 0.02 and bool(((v[:, 1] ** 2 - v[:, 0] ** 2)[bad] < 1e-3).all()), name
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_search_pose_from_T_init(dtype):
-    """dicp_search_pose: [C | r - centre] of T_init, the values dicp_loop_init_centered writes as pose_search_0."""
+    """dicp_search_pose: [Q C | Q r + t] of T_init, the values dicp_loop_init writes as pose_search_0 -- for a pure translation frame
+    (Q = I: [C | r - centre], exactly) and for a rotated one (the kernels' fma chains against float64)."""
     g = torch.Generator().manual_seed(2)
     N = 7
     T = torch.rand((N, 4, 4), generator=g, dtype=torch.float64).to(dtype).to(DEV)
     ctr = (torch.rand((N, 3), generator=g, dtype=torch.float64) * 1000).to(dtype).to(DEV)
+    eye = torch.eye(3, dtype=dtype, device=DEV).reshape(1, 9).repeat(N, 1)
+    frame = torch.cat((eye, -ctr), dim=1).contiguous()
     lib = _lib.load()
     out = torch.empty((N, 12), dtype=dtype, device=DEV)
-    _lib.check(lib.dicp_search_pose(_ops._DT[dtype], _ops._p(T), _ops._p(ctr), N, _ops._p(out), _ops._stream()), "dicp_search_pose")
+    _lib.check(lib.dicp_search_pose(_ops._DT[dtype], _ops._p(T), _ops._p(frame), N, _ops._p(out), _ops._stream()), "dicp_search_pose")
     want = torch.cat((T[:, :3, :3].reshape(N, 9), T[:, :3, 3] - ctr), dim=1)
     assert torch.equal(out, want)
     w0 = torch.ones((N, 5), dtype=dtype, device=DEV)
     pose0, alive, nst, ps0 = (torch.empty(sh, dtype=dtype, device=DEV) for sh in ((N, 12), (N,), (N,), (N, 12)))
     _lib.check(lib.dicp_loop_init(_ops._DT[dtype], _ops._p(T), _ops._p(w0), 0.01, 1, N, 5, _ops._p(pose0), _ops._p(alive), _ops._p(nst),
-                                  _ops._p(ctr), _ops._p(ps0), None, None, None, 0, _ops._stream()), "dicp_loop_init")
+                                  _ops._p(frame), _ops._p(ps0), None, None, None, 0, _ops._stream()), "dicp_loop_init")
     assert torch.equal(ps0, out) and torch.equal(pose0[:, :9], out[:, :9]) and torch.equal(pose0[:, 9:], T[:, :3, 3])
     _lib.check(lib.dicp_search_pose(_ops._DT[dtype], _ops._p(T), None, N, _ops._p(out), _ops._stream()), "dicp_search_pose")
     assert torch.equal(out, pose0)
+    # a rotated frame
+    Q = torch.linalg.qr(torch.rand((N, 3, 3), generator=g, dtype=torch.float64)).Q
+    t = torch.rand((N, 3), generator=g, dtype=torch.float64) * 10
+    fr = torch.cat((Q.reshape(N, 9), t), dim=1).to(dtype).to(DEV).contiguous()
+    _lib.check(lib.dicp_search_pose(_ops._DT[dtype], _ops._p(T), _ops._p(fr), N, _ops._p(out), _ops._stream()), "dicp_search_pose")
+    _lib.check(lib.dicp_loop_init(_ops._DT[dtype], _ops._p(T), _ops._p(w0), 0.01, 1, N, 5, _ops._p(pose0), _ops._p(alive), _ops._p(nst),
+                                  _ops._p(fr), _ops._p(ps0), None, None, None, 0, _ops._stream()), "dicp_loop_init")
+    assert torch.equal(ps0, out)
+    Qd, td, Td = fr[:, :9].reshape(N, 3, 3).double(), fr[:, 9:].double(), T.double()
+    want = torch.cat(((Qd @ Td[:, :3, :3]).reshape(N, 9), (Qd @ Td[:, :3, 3:]).squeeze(-1) + td), dim=1)
+    np.testing.assert_allclose(npy(out), npy(want), rtol=0, atol=1e-5 if dtype == torch.float32 else 1e-13)
 
 
 @pytest.mark.parametrize("offset", [0.0, 1000.0, 25000.0])

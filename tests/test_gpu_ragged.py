@@ -68,9 +68,9 @@ def test_search_kernels_with_row_counts_never_touch_a_pad(dtype):
                 sp = spos[b, :ns[b]].long()
                 assert torch.equal(sw.tperm[b][sp], want[b]) and bool((spos[b, ns[b]:] == -7).all())
     # the centre is taken from the cloud's own rows
-    ctr = _ops.cloud_center(tgt, quantum=0.0, tgt_rows=tr)
+    ctr = _ops.search_frame(tgt, quantum=0.0, tgt_rows=tr)
     for b in range(N):
-        assert torch.equal(ctr[b], _ops.cloud_center(tgt[b:b + 1, :ms[b]].contiguous(), quantum=0.0)[0])
+        assert torch.equal(ctr[b], _ops.search_frame(tgt[b:b + 1, :ms[b]].contiguous(), quantum=0.0)[0])
 
 
 @pytest.mark.parametrize("dtype,knn", [(torch.float64, _lib.KNN_SWEEP), (torch.float64, _lib.KNN_VALU), (torch.float32, _lib.KNN_SWEEP)])

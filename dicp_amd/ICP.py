@@ -125,8 +125,9 @@ class ICP:
             # soft correspondences carry gradient themselves: one autograd node per iteration instead of one per call
             T, deltas, weights, costs, converged, iterations, matched = icp_loop_gumbel(
                 source, target, T_init, w_pts, cfg, self.nn.eps, self.nn.tau, inject_U=getattr(self.nn, "_inject_U", None))
+            pc = transform_points(source, T)                                             # ICP.py:274, with the graph running through T
         else:
-            T, deltas, weights, costs, converged, iterations, matched = ICPLoop.apply(source, target, T_init, w_pts, cfg)
+            T, pc, deltas, weights, costs, converged, iterations, matched = ICPLoop.apply(source, target, T_init, w_pts, cfg)
 
         if per_cloud_w:
             # an (N,1) weight stays (N,1) in the reference, so its "matches at the start" (ICP.py:248,269: sum over dim 1 of
@@ -139,8 +140,6 @@ class ICP:
             print("ICP converged in {} iterations".format(deltas.shape[1]))
             print("Final del_T_ts: {}".format(torch.linalg.norm(deltas[:, -1])))
 
-        # ICP.py:274: transformed source, with the graph running through T
-        pc = transform_points(source, T)
         if self.icp_type == 'pt2pt':                                                     # ICP.py:164-165
             weights = weights.repeat_interleave(3, dim=2)
         results = {                                                                      # ICP.py:283-303

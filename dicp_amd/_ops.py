@@ -58,6 +58,25 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+class _NoSwitch:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
+def _on(device):
+    """`with _on(dev):` = torch.cuda.device(dev), without the two device switches (~5 us) when dev already is the current device -- a call of the
+    loop enters nine such blocks, and a mid-size call is host-bound (scripts/host_breakdown.py)."""
+    if _raw_device is not None and device.index is not None and _raw_device() == device.index:
+        return _NO_SWITCH
+    return torch.cuda.device(device)
+
+
 # ------------------------------------------------------------------ thin kernels
 def padded_targets(m):
     return _lib.load().dicp_padded_targets(int(m))
@@ -80,7 +99,7 @@ def search_frame(tgt, quantum=None, tgt_rows=None, directions=None):
     require_device(tgt, "search_frame")
     N, m, c = tgt.shape
     out = torch.empty((N, 12), dtype=tgt.dtype, device=tgt.device)
-    with torch.cuda.device(tgt.device):
+    with _on(tgt.device):
         _lib.check(_lib.load().dicp_search_frame(_DT[tgt.dtype], _p(tgt), c, _p(tgt_rows), N, m, CENTER_QUANTUM if quantum is None else float(quantum),
                                                  int(FRAME_DIRECTIONS if directions is None else directions), _p(out), _stream()), "dicp_search_frame")
     return out
@@ -112,7 +131,7 @@ def pack_target(tgt, frame=None, tgt_rows=None):
     N, m, c = tgt.shape
     m_pad = padded_targets(m)
     out = torch.empty((N, m_pad, 4), dtype=tgt.dtype, device=tgt.device)
-    with torch.cuda.device(tgt.device):
+    with _on(tgt.device):
         _lib.check(_lib.load().dicp_pack_target(_DT[tgt.dtype], _p(tgt), c, _p(frame), _p(tgt_rows), N, m, _p(out), m_pad, _stream()),
                    "dicp_pack_target")
     return out
@@ -124,7 +143,7 @@ def knn(src, pose, tgt4, m, variant=_lib.KNN_AUTO, out=None, src_rows=None, tgt_
     require_device(src, "knn")
     N, n, _ = src.shape
     idx = out if out is not None else torch.empty((N, n), dtype=torch.int32, device=src.device)
-    with torch.cuda.device(src.device):
+    with _on(src.device):
         _lib.check(_lib.load().dicp_knn(_DT[src.dtype], _p(src), _p(pose), _p(tgt4), _p(src_rows), _p(tgt_rows), N, n, m, tgt4.shape[1],
                                         _p(idx), variant, _stream()), "dicp_knn")
     return idx
@@ -159,7 +178,7 @@ class SweepIndex:
         self.tgt_s = torch.empty((N, m_pad, self.row_stride), dtype=dt, device=dev) if sorted_rows else None
         nbytes = int(lib.dicp_sweep_sort_scratch_bytes(_DT[dt], N, m_pad))     # float64 keys / more than 16384 slots: chunked sort through scratch
         scratch = torch.empty((nbytes,), dtype=torch.uint8, device=dev) if nbytes else None
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(lib.dicp_sweep_sort(_DT[dt], _p(tgt), c, _p(frame), _p(tgt_rows), N, m, m_pad, _p(self.keys), _p(self.tperm), self.NBKT,
                                            _p(self.bucket), _p(self.brange), _p(scratch), nbytes, _stream()), "dicp_sweep_sort")
             _lib.check(lib.dicp_sweep_build(_DT[dt], _p(tgt), c, _p(frame), _p(tgt_rows), _p(self.tperm), N, m, m_pad,
@@ -179,7 +198,7 @@ class SweepIndex:
         copies=True -> (qorder, src_s, w_s): also the source rows (and the weights w, if given) in that slot order."""
         N, n, _ = src.shape
         lib = _lib.load()
-        with torch.cuda.device(src.device):
+        with _on(src.device):
             if not exact:
                 qorder = torch.empty((N, n), dtype=torch.int32, device=src.device)
                 _lib.check(lib.dicp_query_order(_DT[src.dtype], _p(src), _p(pose), _p(self.brange), self.NBKT, N, n, _p(qorder),
@@ -204,7 +223,7 @@ class SweepIndex:
         idx = out if out is not None else torch.empty((N, n), dtype=torch.int32, device=src.device)
         if src_s is not None:
             src, cfg = src_s, cfg | _lib.SWEEP_SRC_SORTED
-        with torch.cuda.device(src.device):
+        with _on(src.device):
             _lib.check(_lib.load().dicp_knn_sweep(_DT[src.dtype], _p(src), _p(pose), _p(self.tgs4), _p(self.tperm), _p(qorder),
                                                   _p(self.bucket), _p(self.brange), self.NBKT, _p(src_rows), _p(self.tgt_rows), N, n, self.m, self.tgs4.shape[1],
                                                   _p(idx), _p(spos), _p(self.pair_shards), cfg, _stream()), "dicp_knn_sweep")
@@ -219,7 +238,7 @@ class _GatherRows(torch.autograd.Function):
         N, m, c = y.shape
         n = idx.shape[1]
         out = torch.empty((N, n, c), dtype=y.dtype, device=y.device)
-        with torch.cuda.device(y.device):
+        with _on(y.device):
             _lib.check(_lib.load().dicp_gather_rows(_DT[y.dtype], _p(y), _p(idx), N, n, m, c, _p(out), _stream()), "dicp_gather_rows")
         ctx.save_for_backward(idx)
         ctx.shape = (N, m, c)
@@ -231,7 +250,7 @@ class _GatherRows(torch.autograd.Function):
         N, m, c = ctx.shape
         gout = gout.contiguous()
         gy = torch.zeros((N, m, c), dtype=gout.dtype, device=gout.device)
-        with torch.cuda.device(gout.device):
+        with _on(gout.device):
             _lib.check(_lib.load().dicp_scatter_add_rows(_DT[gout.dtype], _p(gout), _p(idx), N, idx.shape[1], m, c, _p(gy), _stream()),
                        "dicp_scatter_add_rows")
         return gy, None
@@ -247,7 +266,7 @@ def _gather_rows_raw(y, idx):
     N, m, c = y.shape
     k = idx.shape[1]
     out = torch.empty((N, k, c), dtype=y.dtype, device=y.device)
-    with torch.cuda.device(y.device):
+    with _on(y.device):
         _lib.check(_lib.load().dicp_gather_rows(_DT[y.dtype], _p(y), _p(idx), N, k, m, c, _p(out), _stream()), "dicp_gather_rows")
     return out
 
@@ -261,7 +280,7 @@ class _GumbelNN(torch.autograd.Function):
         m, c = y.shape[1], y.shape[2]
         out = torch.empty((N, n, c), dtype=x.dtype, device=x.device)
         lse = torch.empty((N, n), dtype=x.dtype, device=x.device)
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _lib.check(_lib.load().dicp_gumbel_nn(_DT[x.dtype], _p(x), _p(y), c, _p(U), seed, float(eps), float(tau), N, n, m,
                                                   _p(out), _p(lse), _stream()), "dicp_gumbel_nn")
         ctx.save_for_backward(x, y, out, lse, *([U] if U is not None else []))
@@ -279,7 +298,7 @@ class _GumbelNN(torch.autograd.Function):
         gy = torch.empty_like(y) if ctx.needs_input_grad[1] else None
         if gx is None and gy is None:
             return None, None, None, None, None, None
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _lib.check(_lib.load().dicp_gumbel_nn_bwd(_DT[x.dtype], _p(x), _p(y), c, _p(U), seed, eps, tau, _p(out), _p(lse),
                                                       _p(gout.contiguous()), N, n, m, _p(gx), _p(gy), _stream()), "dicp_gumbel_nn_bwd")
         return gx, gy, None, None, None, None
@@ -306,7 +325,7 @@ class _TransformPoints(torch.autograd.Function):
         src = source.contiguous()
         pose = _pose_from_T(T)
         out = torch.empty_like(src)
-        with torch.cuda.device(src.device):
+        with _on(src.device):
             _lib.check(_lib.load().dicp_transform_points(_DT[src.dtype], _p(src), _p(pose), _p(out), N, n, _stream()), "dicp_transform_points")
         ctx.save_for_backward(src, pose)
         return out
@@ -318,7 +337,7 @@ class _TransformPoints(torch.autograd.Function):
         lib = _lib.load()
         gsrc = torch.empty_like(src) if ctx.needs_input_grad[0] else None
         partials = torch.empty((N, lib.dicp_accumulate_blocks(n), _lib.NBWD_PAD), dtype=src.dtype, device=src.device)
-        with torch.cuda.device(src.device):
+        with _on(src.device):
             _lib.check(lib.dicp_transform_points_bwd(_DT[src.dtype], _p(src), _p(pose), _p(gout.contiguous()), _p(gsrc), _p(partials),
                                                      N, n, _stream()), "dicp_transform_points_bwd")
         gT = None
@@ -340,7 +359,7 @@ class _LossWeight(torch.autograd.Function):
     def forward(ctx, err2d, loss, diff, metric, tanh_k):
         rows, r = err2d.shape
         w = torch.empty((rows,), dtype=err2d.dtype, device=err2d.device)
-        with torch.cuda.device(err2d.device):
+        with _on(err2d.device):
             _lib.check(_lib.load().dicp_loss_weight(_DT[err2d.dtype], loss, int(diff), float(metric), float(tanh_k),
                                                     _p(err2d), rows, r, _p(w), _stream()), "dicp_loss_weight")
         ctx.save_for_backward(err2d)
@@ -354,7 +373,7 @@ class _LossWeight(torch.autograd.Function):
         rows, r = err2d.shape
         gerr = torch.empty_like(err2d)
         gw = gw.contiguous()
-        with torch.cuda.device(err2d.device):
+        with _on(err2d.device):
             _lib.check(_lib.load().dicp_loss_weight_bwd(_DT[err2d.dtype], loss, diff, metric, tanh_k, _p(err2d), _p(gw),
                                                         rows, r, _p(gerr), _stream()), "dicp_loss_weight_bwd")
         return gerr, None, None, None, None
@@ -377,7 +396,7 @@ def prebuild_search(source, target, knn_variant, want_rows, T_init=None, src_row
         kind = auto_knn_kind(N, n, target.shape[1])
     if kind != _lib.KNN_SWEEP or not target.is_cuda or not target.is_contiguous() or target.dtype not in _DT:
         return None
-    with torch.cuda.device(target.device):
+    with _on(target.device):
         sweep = SweepIndex(target, sorted_rows=True, frame=search_frame(target, tgt_rows=tgt_rows), tgt_rows=tgt_rows)
         # ... and the first query order, from T_init alone (the loop's own pose_0 does not exist yet): with it the queue holds
         # ~0.2 ms of work while the host builds the loop state
@@ -484,7 +503,7 @@ class ICPLoop(torch.autograd.Function):
     backward: dicp_icp_backward, K x { step_bwd -> accumulate_bwd } in reverse, recomputing per-point quantities
               from the saved (index, pose) histories instead of keeping autograd's intermediates.
     Inputs : source (N,n,3), target (N,m,c), T_init (N,4,4), w0 (N,n)  [one weight per POINT]
-    Outputs: T (N,4,4) differentiable; deltas (N,K,6), weights (N,K,n), costs (N,K),
+    Outputs: T (N,4,4) and pc (N,n,3) = the source under T (ICP.py:274), differentiable; deltas (N,K,6), weights (N,K,n), costs (N,K),
              converged (N) bool, iterations (N), matched_ratio (N)  (non-differentiable).
     """
 
@@ -509,7 +528,7 @@ class ICPLoop(torch.autograd.Function):
                 cfg.stats_out.pop(key, None)
         ctx.set_materialize_grads(False)    # no zero tensors for the six non-differentiable outputs (168 MB for the weights)
 
-        with torch.cuda.device(dev):
+        with _on(dev):
             st = _stream()
             kind = cfg.knn_variant & 0xff
             if kind == _lib.KNN_AUTO:
@@ -676,6 +695,9 @@ class ICPLoop(torch.autograd.Function):
             weights = (w_slabs[0] if len(w_slabs) == 1 else torch.cat(w_slabs, dim=1))[:, :K]
             deltas_out = deltas[:, :K]
             costs_out = costs[:, :K]
+            # ICP.py:274: the transformed source, in this node too (one launch; its own autograd node cost a mid-size call 35 us of host time)
+            pc = torch.empty_like(src)
+            _lib.check(lib.dicp_transform_points(code, _p(src), _p(poses[K]), _p(pc), N, n, st), "dicp_transform_points")
 
         if need_grad:
             saved = [src, tgt, w0c, poses, deltas, areg, alive] + idx_slabs + spos_slabs + qorders + ([sweep.tperm, sweep.tgt_s] if owned else [])
@@ -685,10 +707,10 @@ class ICPLoop(torch.autograd.Function):
                           [(a, min(b, K), q) for (a, b), q in zip(done_segs, seg_q) if a < K])
         conv = converged.bool()
         ctx.mark_non_differentiable(deltas_out, weights, costs_out, conv, iterations, matched)
-        return T, deltas_out, weights, costs_out, conv, iterations, matched
+        return T, pc, deltas_out, weights, costs_out, conv, iterations, matched
 
     @staticmethod
-    def backward(ctx, gT, *_unused):
+    def backward(ctx, gT, gpc, *_unused):
         src, tgt, w0c, poses, deltas, areg, alive, *rest = ctx.saved_tensors
         cfg, K, P, Kmax = ctx.cfg, ctx.K, ctx.P, ctx.Kmax
         n_idx, n_spos, n_q, kc, owned, m_pad, kind, segs = ctx.layout
@@ -700,8 +722,18 @@ class ICPLoop(torch.autograd.Function):
         code, es = _DT[dt], src.element_size()
         N, n, _ = src.shape
         m, c = tgt.shape[1], tgt.shape[2]
-        with torch.cuda.device(dev):
+        with _on(dev):
             st = _stream()
+            gsrc_pc = None
+            if gpc is not None:         # pc = C_K p + r_K: its cotangent reaches the source directly and the pose through T
+                gsrc_pc = torch.empty_like(src)
+                pcp = torch.empty((N, lib.dicp_accumulate_blocks(n), _lib.NBWD_PAD), dtype=dt, device=dev)
+                _lib.check(lib.dicp_transform_points_bwd(code, _p(src), _p(poses[K]), _p(gpc.contiguous()), _p(gsrc_pc), _p(pcp), N, n, st), "dicp_transform_points_bwd")
+                gsum = pcp.sum(dim=1)
+                gT_pc = torch.zeros((N, 4, 4), dtype=dt, device=dev)
+                gT_pc[:, :3, :3] = gsum[:, :9].reshape(N, 3, 3)
+                gT_pc[:, :3, 3] = gsum[:, 9:12]
+                gT = gT_pc if gT is None else gT + gT_pc
             gpose = torch.empty((N, 12), dtype=torch.float64, device=dev)
             gtmp = torch.empty_like(gpose)
             _lib.check(lib.dicp_pose_grad_in(code, _p(gT.contiguous()) if gT is not None else None, _p(gpose), N, st), "dicp_pose_grad_in")
@@ -807,6 +839,8 @@ class ICPLoop(torch.autograd.Function):
             gT0 = torch.empty((N, 4, 4), dtype=dt, device=dev)      # final gpose + the last launch's pose partials
             _lib.check(lib.dicp_pose_grad_out(code, _p(gpose), _p(bwdp[form]) if have else None, bwdp[form].shape[1] if have else 0,
                                               _p(gT0), N, st), "dicp_pose_grad_out")
+            if gsrc_pc is not None:
+                gsrc += gsrc_pc
         return gsrc, gtgt, gT0, gw, None
 
 
@@ -837,7 +871,7 @@ class KabschLoop(torch.autograd.Function):
         trim = float(trim_dist) if trim_on else 0.0
         Kmax = int(max_iterations)
         assert Kmax >= 1, "max_iterations must be at least 1"
-        with torch.cuda.device(dev):
+        with _on(dev):
             st = _stream()
             kind = knn_variant & 0xff
             if kind == _lib.KNN_AUTO:
@@ -909,7 +943,7 @@ class KabschLoop(torch.autograd.Function):
         code = _DT[dt]
         N, n, _ = src.shape
         m, c = tgt.shape[1], tgt.shape[2]
-        with torch.cuda.device(dev):
+        with _on(dev):
             st = _stream()
             gT = gT.contiguous()
             gpose = torch.cat((gT[:, :3, :3].reshape(N, 9), gT[:, :3, 3]), dim=1).contiguous()
@@ -941,7 +975,7 @@ class _RowsIteration(torch.autograd.Function):
         src, rows, pose_in, w0c = source.contiguous(), nbr.contiguous(), pose.contiguous(), w0.contiguous()
         P = cfg.params()
         nblk = lib.dicp_accumulate_blocks(n)
-        with torch.cuda.device(dev):
+        with _on(dev):
             stream = _stream()
             partials = torch.empty((N, nblk, _lib.NACC_PAD), dtype=dt, device=dev)
             wk = torch.empty((N, n), dtype=dt, device=dev)
@@ -976,7 +1010,7 @@ class _RowsIteration(torch.autograd.Function):
         N, n, _ = src.shape
         c = rows.shape[2]
         nblk = lib.dicp_accumulate_blocks(n)
-        with torch.cuda.device(dev):
+        with _on(dev):
             stream = _stream()
             gin = gpose_out.to(torch.float64).contiguous()
             gs = torch.empty((N, 36), dtype=dt, device=dev)

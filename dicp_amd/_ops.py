@@ -316,14 +316,24 @@ def gumbel_nn(x, y, eps, tau, U=None, seed=None):
     return _GumbelNN.apply(x.contiguous(), y.contiguous(), U, seed & 0xFFFFFFFF, eps, tau)
 
 
+def _pose_sums_to_gT(partials, N, dt, dev, st):
+    """(N,nblk,NBWD_PAD) per-block sums of [q-bar p^T | s-bar] -> gT (N,4,4): the library's own fixed-order reduction (dicp_pose_grad_out)."""
+    lib = _lib.load()
+    zero = torch.zeros((N, 12), dtype=torch.float64, device=dev)
+    gT = torch.empty((N, 4, 4), dtype=dt, device=dev)
+    _lib.check(lib.dicp_pose_grad_out(_DT[dt], _p(zero), _p(partials), partials.shape[1], _p(gT), N, st), "dicp_pose_grad_out")
+    return gT
+
+
 class _TransformPoints(torch.autograd.Function):
-    """pc = C p + r for every point (ICP.py:274), differentiable w.r.t. the points and the pose T (N,4,4)."""
+    """pc = C p + r for every point (ICP.py:137,274), differentiable w.r.t. the points and the pose: T (N,4,4), or (N,12) [C row-major | r]."""
 
     @staticmethod
     def forward(ctx, source, T):
         N, n, _ = source.shape
         src = source.contiguous()
-        pose = _pose_from_T(T)
+        ctx.as_pose = T.dim() == 2
+        pose = T.contiguous() if ctx.as_pose else _pose_from_T(T)
         out = torch.empty_like(src)
         with _on(src.device):
             _lib.check(_lib.load().dicp_transform_points(_DT[src.dtype], _p(src), _p(pose), _p(out), N, n, _stream()), "dicp_transform_points")
@@ -337,15 +347,15 @@ class _TransformPoints(torch.autograd.Function):
         lib = _lib.load()
         gsrc = torch.empty_like(src) if ctx.needs_input_grad[0] else None
         partials = torch.empty((N, lib.dicp_accumulate_blocks(n), _lib.NBWD_PAD), dtype=src.dtype, device=src.device)
-        with _on(src.device):
-            _lib.check(lib.dicp_transform_points_bwd(_DT[src.dtype], _p(src), _p(pose), _p(gout.contiguous()), _p(gsrc), _p(partials),
-                                                     N, n, _stream()), "dicp_transform_points_bwd")
         gT = None
-        if ctx.needs_input_grad[1]:
-            g = partials.sum(dim=1)
-            gT = torch.zeros((N, 4, 4), dtype=src.dtype, device=src.device)
-            gT[:, :3, :3] = g[:, :9].reshape(N, 3, 3)
-            gT[:, :3, 3] = g[:, 9:12]
+        with _on(src.device):
+            st = _stream()
+            _lib.check(lib.dicp_transform_points_bwd(_DT[src.dtype], _p(src), _p(pose), _p(gout.contiguous()), _p(gsrc), _p(partials),
+                                                     N, n, st), "dicp_transform_points_bwd")
+            if ctx.needs_input_grad[1]:
+                gT = _pose_sums_to_gT(partials, N, src.dtype, src.device, st)
+                if ctx.as_pose:
+                    gT = _pose_from_T(gT)
         return gsrc, gT
 
 
@@ -729,10 +739,7 @@ class ICPLoop(torch.autograd.Function):
                 gsrc_pc = torch.empty_like(src)
                 pcp = torch.empty((N, lib.dicp_accumulate_blocks(n), _lib.NBWD_PAD), dtype=dt, device=dev)
                 _lib.check(lib.dicp_transform_points_bwd(code, _p(src), _p(poses[K]), _p(gpc.contiguous()), _p(gsrc_pc), _p(pcp), N, n, st), "dicp_transform_points_bwd")
-                gsum = pcp.sum(dim=1)
-                gT_pc = torch.zeros((N, 4, 4), dtype=dt, device=dev)
-                gT_pc[:, :3, :3] = gsum[:, :9].reshape(N, 3, 3)
-                gT_pc[:, :3, 3] = gsum[:, 9:12]
+                gT_pc = _pose_sums_to_gT(pcp, N, dt, dev, st)
                 gT = gT_pc if gT is None else gT + gT_pc
             gpose = torch.empty((N, 12), dtype=torch.float64, device=dev)
             gtmp = torch.empty_like(gpose)
@@ -1049,8 +1056,7 @@ def icp_loop_gumbel(source, target, T_init, w0, cfg, eps, tau, inject_U=None):
     K = 0
     pending, host_cnt, poses_hist = None, None, []
     for k in range(Kmax):
-        C = pose[:, :9].reshape(N, 3, 3)
-        ps_t = source @ C.transpose(1, 2) + pose[:, None, 9:]                      # ICP.py:137
+        ps_t = _TransformPoints.apply(source, pose)                                # ICP.py:137 (dicp_transform_points; the pose carries gradient)
         U = inject_U[k] if inject_U is not None else None
         nbr = gumbel_nn(ps_t, target, eps, tau, U=U)                               # ICP.py:140 -> nn.py:43-70
         pose, delta, cost, wk = _RowsIteration.apply(source, nbr, pose, w0, st, cfg, k)

@@ -582,7 +582,7 @@ class ICPLoop(torch.autograd.Function):
             want_certs = (sweep is not None and cfg.reuse_matches and not (cfg.knn_variant & 0xff00) and not keep_idx
                           and Kmax - 1 - cert_from >= 3)
             arena.take((Kmax, 128) if want_certs else (0,), torch.int32)
-            arena.take((N, 4) if want_certs else (0,), torch.int32)
+            arena.take((N, 8) if want_certs else (0,), torch.int32)
             deltas, costs, converged, iterations, matched, n_matched, counters, cert_count, cert_cloud = arena.finish()
             # pose_0, alive_0, n_start (ICP.py:124-129)
             certs = None

@@ -1013,14 +1013,17 @@ template <typename T> struct SweepCert {
     const T* dcum; int dstride;     // (N,dstride): (M_k, e_k) pairs per iteration
     int k;                          // this iteration
     int32_t* count;                 // (128) or NULL: [0,64) units searched again, [64,128) single queries, sharded by block
-    int32_t* cloud;                 // (N,4) or NULL, per cloud: [0] units / [1] single queries searched again in this iteration, [2] != 0: the cloud's
-                                    // certificates are switched off for the rest of the call (step kernel: they cost more than searching everything),
-                                    // [3] its units (written by the guard: "a certified iteration ran")
+    int32_t* cloud;                 // (N,CERT_CLOUD) or NULL, per cloud: [0] units / [1] single queries searched again in this iteration; [2] the
+                                    // state the step kernel keeps: 0 on, -1 on with one strike, k > 0 off for k more iterations (CERT_OFF_FOR_GOOD:
+                                    // for the rest of the call), CERT_RECERTIFY: this iteration's guard searches every unit with certifying
+                                    // sweeps; [3] its units (written by the searches: "a certified iteration ran"); [4] the last back-off length
 };
 constexpr int CERT_MARGIN = 6;      // prune margin of a certifying search, in units of the plain one: the slab ends where H > H1 + 6E, so an
                                     // unscored row alone still leaves A = 2E (the certificate needs H2 - H1 > 4E + D S); 8: the search 4 % slower,
                                     // 8 % fewer single searches in the iteration after it -- a wash (A/B on one box)
 constexpr int CERT_SHARDS = 64;
+constexpr int CERT_CLOUD = 8;       // ints per cloud of the per-cloud certificate state (SweepCert::cloud)
+constexpr int CERT_OFF_FOR_GOOD = 1 << 20, CERT_RECERTIFY = -2;
 constexpr int CERT_SLOT_MAX = 16;   // a unit with more spent budgets than this is searched again as a unit (guard launch), the others' queries one by one
 
 template <typename T>
@@ -1297,8 +1300,8 @@ __device__ __forceinline__ void sweep_unit(const T* __restrict__ src, const T* _
         // per cloud, for the step kernel's "are certificates worth it here?": queries that got no certificate will be searched one by one in
         // every later iteration (near-ties inside the rounding bound of a score: dense surfaces far from the centre, duplicated targets)
         if (ct.cloud && lane == 0) {
-            if (tot) atomicAdd(ct.cloud + (size_t)cloud * 4 + 1, tot);
-            if (unit == 0) ct.cloud[(size_t)cloud * 4 + 3] = (n_full + WAVE * Q - 1) / (WAVE * Q);
+            if (tot) atomicAdd(ct.cloud + (size_t)cloud * CERT_CLOUD + 1, tot);
+            if (unit == 0) ct.cloud[(size_t)cloud * CERT_CLOUD + 3] = (n_full + WAVE * Q - 1) / (WAVE * Q);
         }
     }
     // sharded: one counter serialises ~12 ns per add, which at 65k waves would outlast the kernel itself
@@ -1420,7 +1423,7 @@ __device__ __forceinline__ int search_point(const PointSearch<T>& ps, const int 
     if (lane == 0) {
         if (ps.pairs) atomicAdd(ps.pairs + (blockIdx.x & (DICP_PAIR_SHARDS - 1)), (unsigned long long)(r1 - r0));
         if (ps.ct.count) atomicAdd(ps.ct.count + CERT_SHARDS + (blockIdx.x & (CERT_SHARDS - 1)), 1);
-        if (ps.ct.cloud) atomicAdd(ps.ct.cloud + (size_t)cloud * 4 + 1, 1);
+        if (ps.ct.cloud) atomicAdd(ps.ct.cloud + (size_t)cloud * CERT_CLOUD + 1, 1);
     }
     return bs;          // (sorted slots [0,m) hold the cloud's own rows: a row found is a real one)
 }
@@ -1443,9 +1446,11 @@ __global__ __launch_bounds__(BLOCK, DICP_SWEEP_MINW) void knn_sweep_guard_kernel
     const T step = ct.k > 0 ? dk[0] - dk[-2] : inf_v<T>();     // how far the cloud's queries can have moved in the last step
     T* qu = ct.qu + (size_t)cloud * units + unit;
     const T v = *qu;
-    if (ct.cloud && unit == 0 && lane == 0) ct.cloud[(size_t)cloud * 4 + 3] = units;
+    if (ct.cloud && unit == 0 && lane == 0) ct.cloud[(size_t)cloud * CERT_CLOUD + 3] = units;
     bool plain;
-    if (ct.cloud && ct.cloud[(size_t)cloud * 4 + 2] > 0) plain = true;     // this cloud's certificates are off (step kernel): every unit, plainly
+    const int cstate = ct.cloud ? ct.cloud[(size_t)cloud * CERT_CLOUD + 2] : 0;
+    if (cstate > 0) plain = true;                               // this cloud's certificates are off (step kernel): every unit, plainly
+    else if (cstate == CERT_RECERTIFY) plain = false;           // ... and this is the iteration that tries them again: every unit, certifying
     else if (v < T(0)) plain = step > -v;                       // plain mode (below): certify again once the steps are at most -v
     else {
         if (v > spent) return;
@@ -1476,7 +1481,7 @@ __global__ __launch_bounds__(BLOCK, DICP_SWEEP_MINW) void knn_sweep_guard_kernel
         if (plain && lane == 0) *qu = -T(0.5) * step;
     }
     if (lane == 0 && ct.count) atomicAdd(ct.count + (blockIdx.x & (CERT_SHARDS - 1)), 1);
-    if (lane == 0 && ct.cloud) atomicAdd(ct.cloud + (size_t)cloud * 4, 1);
+    if (lane == 0 && ct.cloud) atomicAdd(ct.cloud + (size_t)cloud * CERT_CLOUD, 1);
     if (plain) sweep_unit<T, Q, CH, false>(src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, idx, spos, pairs, n_full, m_full, m_pad, src_sorted, src_rows, tgt_rows, ct,
                                            cloud, unit, tiles[wave]);
     else       sweep_unit<T, Q, CH, true>(src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, idx, spos, pairs, n_full, m_full, m_pad, src_sorted, src_rows, tgt_rows, ct,
@@ -1717,7 +1722,7 @@ __global__ __launch_bounds__(BLOCK, (CERT && sizeof(T) == 4) ? 5 : 1) void accum
     if (!decode_block(bpc, N, cloud, blk)) return;
     const int nc = rows_of(src_rows, cloud, n);             // ragged batches: rows past the cloud's own carry weight 0 (ICP.py:386-398)
     const int end = min(nc, (blk + 1) * ACC_PTS);
-    if (CERT && ps.ct.dcum && !(ps.ct.cloud && ps.ct.cloud[(size_t)cloud * 4 + 2] > 0)) {      // (certificates off for this cloud: the guard launch has just searched every unit)
+    if (CERT && ps.ct.dcum && !(ps.ct.cloud && ps.ct.cloud[(size_t)cloud * CERT_CLOUD + 2] > 0)) {      // (certificates off for this cloud: the guard launch has just searched every unit)
         // first the budgets of this block's points (before the sums' registers are live): spent ones are searched again, one query at a
         // time by the whole wave; the thread that owns the point rewrites its match and budget and reads them back below
         const int lane = threadIdx.x & (WAVE - 1);
@@ -1911,18 +1916,25 @@ __device__ __forceinline__ void step_body(const dicp_step_io& io, int cloud, int
             // search each, measured at the benchmark shape and on planar scenes, profiles/r03_scene_kernel_stats_before.txt) -- against the
             // cloud's units: from 60 % of a full search on, the cloud's certificates are switched off for the rest of the call (the guard
             // launch then searches every unit plainly, the accumulate checks nothing).  Results do not depend on it: both are exact.
-            // Two kinds of evidence: queries that got NO certificate in a search of every unit (cc[0] == 0: structural -- they will be searched
-            // one by one in every iteration from now on) switch the cloud off at once; a guarded iteration that searched much again only if
-            // the one before it did too (cc[2] == -1: one strike) -- a cloud that is still moving when the certificates start needs one
-            // expensive iteration and is cheap ever after.
-            int32_t* cc = io.cert_cloud + (size_t)cloud * 4;
+            // Two kinds of evidence.  Queries that got NO certificate in a search of every unit (no unit was searched AGAIN: cc[0] == 0) are
+            // structural -- near-ties inside the rounding bound of a score, searched one by one in every iteration from now on: the cloud is
+            // switched off for good.  A guarded iteration that searched much again counts as a strike; on the second in a row the cloud
+            // is switched off for a while -- 2 iterations, doubling up to 16 -- and then certified afresh (CERT_RECERTIFY: one guard launch
+            // of certifying sweeps): a cloud that is still moving when the certificates start must get them back once it has settled.
+            int32_t* cc = io.cert_cloud + (size_t)cloud * CERT_CLOUD;
             const int units = cc[3];
             if (units > 0) {
-                if (cc[2] <= 0) {
-                    const bool costly = 1.3 * cc[0] + 0.2 * cc[1] > 0.6 * units;
-                    const bool structural = cc[0] == 0;
-                    cc[2] = !costly ? 0 : ((structural || cc[2] < 0) ? 1 : -1);
-                }
+                const int state = cc[2];
+                const bool costly = 1.3 * cc[0] + 0.2 * cc[1] > 0.6 * units;
+                int next = state;
+                if (state >= CERT_OFF_FOR_GOOD) next = state;
+                else if (state > 0) next = state > 1 ? state - 1 : CERT_RECERTIFY;
+                else if (state == CERT_RECERTIFY) next = (0.2 * cc[1] > 0.6 * units) ? CERT_OFF_FOR_GOOD : 0;
+                else if (!costly) next = 0;
+                else if (cc[0] == 0) next = CERT_OFF_FOR_GOOD;
+                else if (state == -1) { const int d = cc[4] > 0 ? min(2 * cc[4], 16) : 2; cc[4] = d; next = d; }
+                else next = -1;
+                cc[2] = next;
                 cc[0] = 0; cc[1] = 0; cc[3] = 0;
             }
         }

@@ -202,7 +202,7 @@ typedef struct dicp_step_io {
                                 query of the cloud can have moved between pose_in and pose_out, [2(iter+1)+1] = the rounding of a point transformed
                                 with pose_out (match certificates, dicp_loop_buffers.cert_q) */
     int64_t dcum_stride;
-    int32_t* cert_cloud;     /* optional (N,4): per-cloud counters of the match certificates (dicp_loop_buffers.cert_cloud); the step decides
+    int32_t* cert_cloud;     /* optional (N,8): per-cloud counters of the match certificates (dicp_loop_buffers.cert_cloud); the step decides
                                 from them whether the cloud's certificates stay on */
 } dicp_step_io;
 
@@ -274,10 +274,11 @@ typedef struct dicp_loop_buffers {
     void* dcum;              /* (N, 2(K+1)) T: per iteration (motion bound since iteration 0, rounding of a transformed point); dicp_loop_init
                                 writes iteration 0's, the step kernels the rest */
     int32_t cert_reset;      /* 1: qorder is new in this call's first iteration: that iteration searches every query */
-    int32_t* cert_cloud;     /* optional (N,4) zeros, per cloud: units / single queries searched again in the current iteration, a sticky flag
-                                "certificates off" that the step kernel sets when a certified iteration cost more than 60 % of a full search
-                                (every unit of the cloud is then searched plainly, nothing is checked: results are the same either way), and the
-                                cloud's unit count */
+    int32_t* cert_cloud;     /* optional (N,8) zeros, per cloud: units / single queries searched again in the current iteration, and the state the
+                                step kernel keeps from them: certificates that cost more than 60 % of a full search are switched off -- for good where
+                                the evidence is structural (queries without any certificate after a search of every unit), for 2, 4, .. 16 iterations
+                                and then certified afresh where a guarded iteration was costly twice in a row (a cloud that is still moving).
+                                While off, every unit of the cloud is searched plainly and nothing is checked: results are the same either way */
     const int32_t* spos_prev0; /* per-iteration spos: the matches of iteration k0-1 (NULL when k0 == 0 or spos is one reused buffer) */
     const void* tgt_sorted;  /* sweep only, optional (N,m_pad,tgt_sorted_stride): dicp_sweep_build's tgt_s.  With it (and spos) the forward accumulate
                                 gathers the match rows from the sorted copy at spos -- one aligned sector per row -- and idx may be NULL */

@@ -1815,6 +1815,8 @@ __host__ __device__ inline dicp_step_io make_step_io(const dicp_loop_buffers& B,
 template <typename T, int NT>
 __device__ __forceinline__ void step_body(const dicp_step_io& io, int cloud, int tid) {
     __shared__ double sacc[NACC_PAD], sA[36], sAreg[36], spose[12], sout[24], smisc[16];
+    __shared__ T sframe[12];
+    __shared__ int scc[5];
     __shared__ int s_copy;
     if (tid < WAVE) {   // reduce the per-block partials: lane = (part, slot); fixed summation order -> bit-reproducible
         const int slot_i = tid & 31, part = tid >> 5;
@@ -1841,6 +1843,8 @@ __device__ __forceinline__ void step_body(const dicp_step_io& io, int cloud, int
         if (tid == 50) smisc[10] = (double)((const T*)io.n_start)[cloud];
         if (tid == 51) smisc[11] = (double)((const T*)io.iterations)[cloud];
         if (tid == 52) smisc[12] = (double)((const T*)io.matched_ratio)[cloud];
+        if (tid >= 12 && tid < 24 && io.frame) sframe[tid - 12] = ((const T*)io.frame)[(size_t)cloud * 12 + (tid - 12)];
+        if (tid >= 24 && tid < 29 && io.cert_cloud) scc[tid - 24] = io.cert_cloud[(size_t)cloud * CERT_CLOUD + (tid - 24)];
     }
     __syncthreads();
     if (tid == 0) {
@@ -1882,8 +1886,9 @@ __device__ __forceinline__ void step_body(const dicp_step_io& io, int cloud, int
         }
         if (io.pose_search_out) {                                         // what the next search reads: [Q C | Q r + t] (the cloud's search frame)
             T* ps = (T*)io.pose_search_out + (size_t)cloud * 12;
-            const T* F = io.frame ? (const T*)io.frame + (size_t)cloud * 12 : nullptr;
-            for (int k = 0; k < 12; ++k) ps[k] = frame_pose_entry<T>(F, pn, k);
+            T Fr[12];                                                     // (fetched with the partials: this lane's chain waits for no load)
+            for (int k = 0; k < 12; ++k) Fr[k] = io.frame ? sframe[k] : T(0);
+            for (int k = 0; k < 12; ++k) ps[k] = frame_pose_entry<T>(io.frame ? Fr : nullptr, pn, k);
         }
 
         T cost = (T)sacc[ACC_COST];                                       // ICP.py:229-232
@@ -1922,17 +1927,16 @@ __device__ __forceinline__ void step_body(const dicp_step_io& io, int cloud, int
             // is switched off for a while -- 2 iterations, doubling up to 16 -- and then certified afresh (CERT_RECERTIFY: one guard launch
             // of certifying sweeps): a cloud that is still moving when the certificates start must get them back once it has settled.
             int32_t* cc = io.cert_cloud + (size_t)cloud * CERT_CLOUD;
-            const int units = cc[3];
+            const int c_units = scc[0], c_single = scc[1], state = scc[2], units = scc[3], c_back = scc[4];     // (read in the prologue)
             if (units > 0) {
-                const int state = cc[2];
-                const bool costly = 1.3 * cc[0] + 0.2 * cc[1] > 0.6 * units;
+                const bool costly = 1.3 * c_units + 0.2 * c_single > 0.6 * units;
                 int next = state;
                 if (state >= CERT_OFF_FOR_GOOD) next = state;
                 else if (state > 0) next = state > 1 ? state - 1 : CERT_RECERTIFY;
-                else if (state == CERT_RECERTIFY) next = (0.2 * cc[1] > 0.6 * units) ? CERT_OFF_FOR_GOOD : 0;
+                else if (state == CERT_RECERTIFY) next = (0.2 * c_single > 0.6 * units) ? CERT_OFF_FOR_GOOD : 0;
                 else if (!costly) next = 0;
-                else if (cc[0] == 0) next = CERT_OFF_FOR_GOOD;
-                else if (state == -1) { const int d = cc[4] > 0 ? min(2 * cc[4], 16) : 2; cc[4] = d; next = d; }
+                else if (c_units == 0) next = CERT_OFF_FOR_GOOD;
+                else if (state == -1) { const int d = c_back > 0 ? min(2 * c_back, 16) : 2; cc[4] = d; next = d; }
                 else next = -1;
                 cc[2] = next;
                 cc[0] = 0; cc[1] = 0; cc[3] = 0;
@@ -2412,9 +2416,8 @@ template <typename T> struct SkipArgs {
 };
 template <typename T>
 __device__ __forceinline__ int skip_decision(const double* Gs, const double* Gb, const double* Areg, const double* dmax /* [6]: max |delta| of the earlier iterations */,
-                                             int dim, int cloud, const SkipArgs<T>& sk) {
+                                             int dim, int cloud, const SkipArgs<T>& sk, bool live /* alive_k != 0 */, double ref /* mref[cloud] */) {
     const int D = dim == 2 ? 3 : 6, OFF = dim == 2 ? 2 : 0;   // (Areg is compact, leading dimension 6; Gs / Gb / delta sit at their slots)
-    const bool live = !sk.alive_k || sk.alive_k[cloud] != T(0);
     if (!live) return 1;
     double sa[6], m = 0.0, gmax = 0.0, amp = 0.0;
     bool nan = false;
@@ -2431,7 +2434,7 @@ __device__ __forceinline__ int skip_decision(const double* Gs, const double* Gb,
         }
     }
     m = gmax > m ? gmax : m;
-    const double ref = sk.mref[cloud], worst = gmax * amp > m ? gmax * amp : m;
+    const double worst = gmax * amp > m ? gmax * amp : m;
     if (!nan && 16.0 * worst <= sk.eps * ref) return 2;
     if (!nan && m > ref) sk.mref[cloud] = m;
     if (sk.live_k) atomicAdd(sk.live_k, 1);
@@ -2456,21 +2459,9 @@ __global__ __launch_bounds__(WAVE) void step_bwd_kernel(const double* __restrict
                                                         const T* __restrict__ delta_k, long delta_stride,
                                                         const double* __restrict__ areg_k, T* __restrict__ gs,
                                                         T* __restrict__ gb, double* __restrict__ gpose_out, int N, SkipArgs<T> sk) {
-    __shared__ double sg[NBWD_PAD], sC[9], sd[6], sAreg[36], sGs[36], sGb[6], sgo[12], sdmax[6];
+    __shared__ double sg[NBWD_PAD], sC[9], sd[6], sAreg[36], sGs[36], sGb[6], sgo[12], sdmax[6], smref;
+    __shared__ int salive, sended;
     const int cloud = blockIdx.x, tid = threadIdx.x;
-    if (sk.skip && sk.skip[cloud] == 2) {                   // this cloud's reverse sweep has ended (skip_decision): only the pass-through part goes on
-        if (tid == 0) {                                     // (the accumulate_bwd blocks of an ended cloud publish zero sums: nothing to add to gpose_in)
-            double g[12], d[6], go[12];
-#pragma unroll
-            for (int k = 0; k < 12; ++k) g[k] = gpose_in[(size_t)cloud * 12 + k];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) d[k] = (double)delta_k[(size_t)cloud * delta_stride + k];
-            pose_pass_through(g, g + 9, d, go, go + 9);
-#pragma unroll
-            for (int k = 0; k < 12; ++k) gpose_out[(size_t)cloud * 12 + k] = go[k];
-        }
-        return;
-    }
     if (sk.skip) {                                          // the largest step of the EARLIER iterations, per component (lanes over iterations)
         double dm[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         for (int j = 1 + tid; j <= sk.k; j += WAVE) {
@@ -2508,8 +2499,24 @@ __global__ __launch_bounds__(WAVE) void step_bwd_kernel(const double* __restrict
         if (tid < 9) sC[tid] = (double)pose_k[(size_t)cloud * 12 + tid];
         if (tid < 6) sd[tid] = (double)delta_k[(size_t)cloud * delta_stride + tid];
         if (tid < 36) sAreg[tid] = areg_k[(size_t)cloud * 36 + tid];
+        if (tid == 40 && sk.skip) smref = sk.mref[cloud];
+        if (tid == 41 && sk.skip) salive = (!sk.alive_k || sk.alive_k[cloud] != T(0)) ? 1 : 0;
+        if (tid == 42) sended = (sk.skip && sk.skip[cloud] == 2) ? 1 : 0;
     }
     __syncthreads();
+    if (sended) {                                           // this cloud's reverse sweep has ended (skip_decision): only the pass-through part goes on
+        if (tid == 0) {                                     // (the accumulate_bwd blocks of an ended cloud published zero sums: sg is the incoming cotangent)
+            double g[12], d[6], go[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) g[k] = sg[k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) d[k] = sd[k];
+            pose_pass_through(g, g + 9, d, go, go + 9);
+#pragma unroll
+            for (int k = 0; k < 12; ++k) gpose_out[(size_t)cloud * 12 + k] = go[k];
+        }
+        return;
+    }
     if (tid == 0) {     // (operands in registers: the adjoint reads each of them many times, and an LDS read is ~64 cycles of a one-lane chain)
         double g[12], C[9], d[6], A[36], Gs[36], Gb[6], go[12];
 #pragma unroll
@@ -2525,7 +2532,7 @@ __global__ __launch_bounds__(WAVE) void step_bwd_kernel(const double* __restrict
             double dmx[6];
 #pragma unroll
             for (int k = 0; k < 6; ++k) dmx[k] = sdmax[k];
-            const int verdict = skip_decision(Gs, Gb, A, dmx, dim, cloud, sk);
+            const int verdict = skip_decision(Gs, Gb, A, dmx, dim, cloud, sk, salive != 0, smref);
             sk.skip[cloud] = verdict;       // (verdict 2: go is already what passes through; Gs / Gb are written but no block will read them)
         }
 #pragma unroll
@@ -2595,7 +2602,7 @@ __global__ __launch_bounds__(BLOCK) void icp_small_backward_kernel(WeightParams 
                 double dmx[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
                 for (int j = 0; j < k; ++j)
                     for (int i = 0; i < 6; ++i) { const double v = fabs((double)((const T*)B.deltas)[(size_t)cloud * B.K * 6 + (size_t)j * 6 + i]); dmx[i] = v > dmx[i] ? v : dmx[i]; }
-                s_skip = skip_decision(sGs, sGb, sAreg, dmx, dim, cloud, sk);
+                s_skip = skip_decision(sGs, sGb, sAreg, dmx, dim, cloud, sk, sk.alive_k[cloud] != T(0), B.bwd_mref[cloud]);
                 B.bwd_skip[cloud] = s_skip;
             }
         }

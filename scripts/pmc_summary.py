@@ -29,5 +29,12 @@ for name in sorted(set(fetch) | set(write)):
     w = sum(write.get(name, [0])) / max(1, len(write.get(name, [])))
     out["kernels"][short] = {"launches": len(fetch.get(name, [])), "FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w,
                              "read_bytes_corrected": f * 1024 * 2, "write_bytes": w * 1024, "hbm_bytes": f * 1024 * 2 + w * 1024}
+    # launches in which every cloud was at work (the backward's truncated reverse sweep leaves most accumulate_bwd launches (next to) empty:
+    # their blocks read one flag and leave): those whose read traffic is at least half the largest launch's
+    fl, wl = fetch.get(name, []), write.get(name, [])
+    if fl and len(fl) == len(wl):
+        keep = [i for i, v in enumerate(fl) if v >= 0.5 * max(fl)]
+        ff, wf = sum(fl[i] for i in keep) / len(keep), sum(wl[i] for i in keep) / len(keep)
+        out["kernels"][short].update({"full_launches": len(keep), "hbm_bytes_full_launches": ff * 1024 * 2 + wf * 1024})
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -55,6 +55,15 @@ class LoopBuffers(ctypes.Structure):
                 ("bwd_skip", vp), ("bwd_mref", vp), ("bwd_live", vp), ("bwd_skip_eps", f64)]
 
 
+MAX_SEGMENTS = 16
+
+
+class SegmentPlan(ctypes.Structure):
+    """dicp_segment_plan (include/dicp_hip.h)."""
+    _fields_ = [("nseg", i32), ("k0", i32 * MAX_SEGMENTS), ("k1", i32 * MAX_SEGMENTS), ("new_order", i32 * MAX_SEGMENTS),
+                ("cert_from", i32), ("pad0", i32), ("order", vp * MAX_SEGMENTS), ("keys", vp), ("cert_q", vp), ("cert_qu", vp), ("cert_count", vp), ("cert_cloud", vp)]
+
+
 class KabschBuffers(ctypes.Structure):
     """dicp_kabsch_buffers (include/dicp_hip.h)."""
     _fields_ = [("src", vp), ("tgt", vp), ("w_init", vp), ("c", i32), ("K", i32), ("knn_variant", i32), ("m_pad", i32), ("tgt4", vp), ("tperm", vp),
@@ -92,6 +101,7 @@ _SIGNATURES = {
     "dicp_accumulate": ([i32, ctypes.POINTER(WeightParams), vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, i64, vp], ctypes.c_int),
     "dicp_step": ([i32, ctypes.POINTER(StepIO), i32, vp], ctypes.c_int),
     "dicp_icp_forward": ([i32, ctypes.POINTER(WeightParams), ctypes.POINTER(LoopBuffers), i32, i32, i32, i32, i32, f64, i32, i32, vp], ctypes.c_int),
+    "dicp_icp_forward_plan": ([i32, ctypes.POINTER(WeightParams), ctypes.POINTER(LoopBuffers), ctypes.POINTER(SegmentPlan), i32, i32, i32, i32, i32, f64, vp], ctypes.c_int),
     "dicp_icp_backward": ([i32, ctypes.POINTER(WeightParams), ctypes.POINTER(LoopBuffers), i32, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp], ctypes.c_int),
     "dicp_step_bwd": ([i32, vp, vp, i32, i32, vp, vp, i64, vp, vp, vp, vp, i32, vp], ctypes.c_int),
     "dicp_accumulate_bwd": ([i32, ctypes.POINTER(WeightParams), vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp], ctypes.c_int),

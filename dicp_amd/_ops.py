@@ -441,6 +441,7 @@ class LoopConfig:
     prebuilt: object = None       # (target, SweepIndex) started by the caller before its own host work (prebuild_search)
     small_loop: bool = True       # small clouds: one block runs a cloud's whole chunk of iterations (icp_small_* kernels)
     cert_from: object = None      # iteration of the certifying search (None: the last re-ordering of the queries)
+    plan_call: bool = True        # constant-iteration sweep calls: all segments behind one library call (dicp_icp_forward_plan)
     cert_backoff: bool = True     # match certificates are switched off per cloud, on device, when a certified iteration costs more than 60 % of a full search
     reuse_matches: bool = True    # sweep path: match certificates -- an iteration searches only the waves holding a query whose match is not proven
                                   # unchanged since the wave's last search (exact; knn_sweep_kernel CERT)
@@ -622,6 +623,53 @@ class ICPLoop(torch.autograd.Function):
             done_segs = []
             pending, host_cnt = None, None   # tolerance mode: the segment whose convergence counters are still in flight
             LB, LBref, Pref = None, None, ctypes.byref(P)
+            # constant-iteration calls of the sweep path with all histories in one slab: every segment and the query re-orderings between them
+            # behind ONE library call (dicp_icp_forward_plan) -- per segment the host spent ~40 us, which a mid-size call does not have
+            if cfg.const_iter and sweep is not None and kc >= Kmax and len(segs) <= _lib.MAX_SEGMENTS and cfg.plan_call:
+                w_slabs.append(torch.empty((N, kc, n), dtype=dt, device=dev))
+                if need_grad and keep_idx:
+                    idx_slabs.append(torch.empty((Kmax, N, n), dtype=torch.int32, device=dev))
+                if keep_spos:
+                    spos_slabs.append(torch.empty((Kmax, N, n), dtype=torch.int32, device=dev))
+                first = cfg.prebuilt[2] if (cfg.prebuilt is not None and cfg.prebuilt[1] is sweep) else None
+                have_first = (first is not None and first[0].data_ptr() == src.data_ptr() and first[0].shape == src.shape
+                              and first[1].data_ptr() == T_init.data_ptr() and T_init.is_contiguous())
+                SP = _lib.SegmentPlan(nseg=len(segs), cert_from=cert_from if certs is not None else -1, keys=_p(sweep.keys),
+                                      cert_q=_p(certs["q"]) if certs else None, cert_qu=_p(certs["qu"]) if certs else None,
+                                      cert_count=_p(certs["count"]) if certs else None, cert_cloud=_p(cert_cloud) if (certs and cfg.cert_backoff) else None)
+                n_new = sum(1 for (k0, _) in segs if (k0 == 0 or k0 in cfg.sweep_resort)) - (1 if have_first else 0)
+                fresh_orders = torch.empty((max(n_new, 1), N, n), dtype=torch.int32, device=dev)
+                used = 0
+                for si, (k0, k1) in enumerate(segs):
+                    SP.k0[si], SP.k1[si] = k0, k1
+                    if k0 == 0 or k0 in cfg.sweep_resort:
+                        if k0 == 0 and have_first:
+                            qorder, SP.new_order[si] = first[2], 0
+                        else:
+                            qorder, SP.new_order[si] = fresh_orders[used], 1
+                            used += 1
+                        qorders.append(qorder)
+                    else:
+                        SP.new_order[si] = 0
+                    SP.order[si] = qorder.data_ptr()
+                    seg_q.append(len(qorders) - 1)
+                    done_segs.append((k0, k1))
+                LB = _lib.LoopBuffers(
+                    src=_p(src), tgt=_p(tgt), w_init=_p(w0c), c=c, K=Kmax, knn_variant=kind | (cfg.knn_variant & 0xff00) | ((0 if cfg.small_loop else 1) << 25), m_pad=m_pad,
+                    tgt4=_p(tgt4), tperm=_p(sweep.tperm), bucket=_p(sweep.bucket), brange=_p(sweep.brange),
+                    nbkt=SweepIndex.NBKT, idx_per_iter=int(need_grad), pairs=_p(sweep.pair_shards),
+                    poses=_p(poses), deltas=_p(deltas), costs=_p(costs), areg=_p(areg), alive=_p(alive), converged=_p(converged),
+                    iterations=_p(iterations), matched_ratio=_p(matched), n_start=_p(n_start), n_matched=_p(n_matched),
+                    tgt_sorted=_p(sweep.tgt_s), tgt_sorted_stride=sweep.row_stride,
+                    rmax=_p(certs["rmax"]) if certs else None, dcum=_p(certs["dcum"]) if certs else None,
+                    w_iter=n, w_stride=kc * n, w=_p(w_slabs[0]),
+                    spos=_p(spos_slabs[0]) if keep_spos else _p(spos_once),
+                    idx=(_p(idx_slabs[0]) if need_grad else _p(idx_once)) if keep_idx else None,
+                    partials=_p(partials), counters=_p(counters), events=events, frame=_p(center), poses_search=_p(poses_c),
+                    src_rows=_p(cfg.src_rows), tgt_rows=_p(cfg.tgt_rows))
+                _lib.check(lib.dicp_icp_forward_plan(code, Pref, ctypes.byref(LB), ctypes.byref(SP), N, n, m, int(cfg.dim), 1, float(cfg.tolerance), st),
+                           "dicp_icp_forward_plan")
+                segs = []
             for (k0, k1) in segs:
                 j = k0 // kc
                 if j == len(w_slabs):

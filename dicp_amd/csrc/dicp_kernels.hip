@@ -3932,6 +3932,41 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
     return 0;
 }
 
+// The constant-iteration loop of the sweep path in ONE call: the segments dicp_icp_forward would be called for one by one -- cut where the
+// queries are re-ordered and where the certificates start -- with the query re-orderings between them (dicp_query_order under the segment's
+// first search pose).  What the host did per segment (four library calls and their glue for a 10-iteration call) is a tenth of a
+// millisecond of a mid-size call that has half a millisecond of kernels (scripts/host_breakdown.py).  All histories in ONE slab: buf->spos /
+// buf->idx / buf->w are their real bases.  Tolerance mode, where the host looks at the convergence counters between segments, keeps calling
+// dicp_icp_forward itself.
+int dicp_icp_forward_plan(int dtype, const dicp_weight_params* prm, const dicp_loop_buffers* buf, const dicp_segment_plan* S, int N, int n, int m,
+                          int dim, int const_iter, double tolerance, void* stream) {
+    if (!prm || !buf || !S) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (S->nseg <= 0 || S->nseg > DICP_MAX_SEGMENTS) return DICP_ERR_SHAPE;
+    const size_t es = dtype == DICP_F32 ? 4 : 8;
+    dicp_loop_buffers B = *buf;
+    for (int s = 0; s < S->nseg; ++s) {
+        const int k0 = S->k0[s], k1 = S->k1[s];
+        if (k0 < 0 || k1 > B.K || k0 >= k1 || (s > 0 && k0 != S->k1[s - 1])) return DICP_ERR_SHAPE;
+        int32_t* qo = S->order[s];
+        if (qo && S->new_order[s]) {
+            if (!S->keys) return DICP_ERR_NULL;
+            const char* pose_s = (const char*)(B.poses_search ? B.poses_search : B.poses) + (size_t)k0 * N * 12 * es;
+            if (const int rc = dicp_query_order(dtype, B.src, pose_s, B.brange, B.nbkt, N, n, qo, nullptr, nullptr, nullptr, 0, nullptr, B.m_pad,
+                                                S->keys, B.bucket, m, B.src_rows, B.tgt_rows, stream)) return rc;
+        }
+        B.qorder = qo;
+        const bool certs = S->cert_from >= 0 && k0 >= S->cert_from;
+        B.cert_q = certs ? S->cert_q : nullptr; B.cert_qu = certs ? S->cert_qu : nullptr; B.cert_count = certs ? S->cert_count : nullptr;
+        B.cert_cloud = certs ? S->cert_cloud : nullptr;
+        B.cert_reset = (S->cert_from >= 0 && k0 == S->cert_from) ? 1 : 0;
+        B.spos_prev0 = (B.spos && B.idx_per_iter && k0 > 0) ? B.spos + (size_t)(k0 - 1) * N * n : nullptr;
+        B.w_prev0 = k0 > 0 ? (const char*)B.w + (size_t)(k0 - 1) * B.w_iter * es : nullptr;
+        if (const int rc = dicp_icp_forward(dtype, prm, &B, N, n, m, dim, const_iter, tolerance, k0, k1, stream)) return rc;
+    }
+    return 0;
+}
+
 // Reverse sweep for iterations k1-1 .. k0: K x { step_bwd -> accumulate_bwd }.  gpose (N,12) double holds the
 // cotangent of pose_{k1} on entry; the cotangent of pose_{k0} (without the last accumulate_bwd partials, which stay in
 // bwd_partials for the caller or the next chunk) is left in gpose when k1-k0 is even and in gpose_tmp when it is odd.

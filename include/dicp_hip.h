@@ -322,6 +322,25 @@ int dicp_loop_finish(int dtype, const void* pose_K, const void* alive_K, const v
 /* Iterations [k0,k1) of the loop (ICP.py:131-260), enqueued back to back: no host work between iterations. */
 int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_buffers* buf, int N, int n, int m,
                      int dim, int const_iter, double tolerance, int k0, int k1, void* stream);
+/* The constant-iteration loop of the sweep path in ONE call: the segments [k0[s], k1[s]) dicp_icp_forward would be called for one after the
+ * other (cut where the queries are re-ordered and where the match certificates start), the query re-orderings between them included
+ * (new_order[s] != 0: dicp_query_order under the segment's first search pose into order[s]).  buf as for dicp_icp_forward with
+ * every history in one slab (spos / idx / w are their real bases); qorder, cert_q / cert_qu / cert_count / cert_cloud, cert_reset, spos_prev0
+ * and w_prev0 of `buf` are ignored: the call derives them per segment (certificates from iteration cert_from on; cert_from < 0: none).
+ * The reference's per-iteration host check (ICP.py:259) needs the host between segments: tolerance mode keeps calling dicp_icp_forward. */
+#define DICP_MAX_SEGMENTS 16
+typedef struct dicp_segment_plan {
+    int32_t nseg;
+    int32_t k0[DICP_MAX_SEGMENTS], k1[DICP_MAX_SEGMENTS];
+    int32_t new_order[DICP_MAX_SEGMENTS];    /* 1: order[s] is computed at the segment's start */
+    int32_t cert_from;
+    int32_t pad0;
+    int32_t* order[DICP_MAX_SEGMENTS];       /* (N,n) each: the query order the segment searches in (several segments may share one), NULL: none */
+    const void* keys;        /* (N,m_pad) sorted target x keys (dicp_sweep_sort): the rank search of dicp_query_order */
+    void* cert_q; void* cert_qu; int32_t* cert_count; int32_t* cert_cloud;
+} dicp_segment_plan;
+int dicp_icp_forward_plan(int dtype, const dicp_weight_params* prm, const dicp_loop_buffers* buf, const dicp_segment_plan* plan, int N, int n, int m,
+                          int dim, int const_iter, double tolerance, void* stream);
 /* Reverse sweep over iterations k1-1..k0.  gpose/gpose_tmp (N,12) double: gpose holds the cotangent of pose_k1 on entry;
  * the two alternate, so the cotangent of pose_k0 is left in gpose when k1-k0 is even and in gpose_tmp when it is odd
  * (no copy: swap the two pointers for the next chunk); gs (N,36), gb (N,6) scratch T;

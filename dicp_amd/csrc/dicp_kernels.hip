@@ -2528,13 +2528,6 @@ __global__ __launch_bounds__(WAVE) void step_bwd_kernel(const double* __restrict
 #pragma unroll
         for (int k = 0; k < 36; ++k) A[k] = sAreg[k];
         step_backward(g, g + 9, dim, C, d, A, Gs, Gb, go, go + 9);
-        if (sk.skip) {
-            double dmx[6];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) dmx[k] = sdmax[k];
-            const int verdict = skip_decision(Gs, Gb, A, dmx, dim, cloud, sk, salive != 0, smref);
-            sk.skip[cloud] = verdict;       // (verdict 2: go is already what passes through; Gs / Gb are written but no block will read them)
-        }
 #pragma unroll
         for (int k = 0; k < 36; ++k) sGs[k] = Gs[k];
 #pragma unroll
@@ -2543,6 +2536,39 @@ __global__ __launch_bounds__(WAVE) void step_bwd_kernel(const double* __restrict
         for (int k = 0; k < 12; ++k) sgo[k] = go[k];
     }
     __syncthreads();
+    if (sk.skip) {
+        // the measures of skip_decision, by the lanes (one entry of G_A / g_b each) from the LDS copies: inside the one-lane section above
+        // they cost it its registers (592 bytes of scratch in a serial chain: the kernel went from 8 to 30 us)
+        const int D = dim == 2 ? 3 : 6, OFF = dim == 2 ? 2 : 0;
+        double v = 0.0, vb = 0.0, va = 0.0;
+        if (tid < 36) {
+            const int i = tid / 6, j = tid - 6 * i;
+            if (i < D && j < D) v = fabs(sGs[(i + OFF) * 6 + (j + OFF)]) * sqrt(fabs(sAreg[i * 6 + i])) * sqrt(fabs(sAreg[j * 6 + j]));
+        } else if (tid < 42) {
+            const int i = tid - 36;
+            if (i < D) { const double sa = sqrt(fabs(sAreg[i * 6 + i])); vb = fabs(sGb[i + OFF]) * sa; va = sdmax[i + OFF] * sa; }
+        }
+        const bool nan = __any(!(v == v) || !(vb == vb) || !(va == va)) != 0;
+        double m = v > vb ? v : vb, gmax = vb, amp = va;
+#pragma unroll
+        for (int off = WAVE / 2; off > 0; off >>= 1) {
+            const double a = __shfl_xor(m, off), b = __shfl_xor(gmax, off), c = __shfl_xor(amp, off);
+            m = a > m ? a : m; gmax = b > gmax ? b : gmax; amp = c > amp ? c : amp;
+        }
+        if (tid == 0) {
+            int verdict = 0;
+            if (!salive) verdict = 1;
+            else {
+                const double worst = gmax * amp > m ? gmax * amp : m;
+                if (!nan && 16.0 * worst <= sk.eps * smref) verdict = 2;
+                else {
+                    if (!nan && m > smref) sk.mref[cloud] = m;
+                    if (sk.live_k) atomicAdd(sk.live_k, 1);
+                }
+            }
+            sk.skip[cloud] = verdict;       // (verdict 2: sgo is already what passes through; gs / gb are written but no block will read them)
+        }
+    }
     if (tid < 36) gs[(size_t)cloud * 36 + tid] = (T)sGs[tid];
     if (tid < 6) gb[(size_t)cloud * 6 + tid] = (T)sGb[tid];
     if (tid < 12) gpose_out[(size_t)cloud * 12 + tid] = sgo[tid];

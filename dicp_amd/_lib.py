@@ -85,6 +85,7 @@ _SIGNATURES = {
     "dicp_sweep_sort_scratch_bytes": ([i32, i32, i32], ctypes.c_size_t),
     "dicp_sweep_sort": ([i32, vp, i32, vp, vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, ctypes.c_size_t, vp], ctypes.c_int),
     "dicp_sweep_build": ([i32, vp, i32, vp, vp, vp, i32, i32, i32, vp, vp, i32, vp], ctypes.c_int),
+    "dicp_sweep_setup": ([i32, vp, i32, vp, i32, i32, i32, f64, i32, vp, vp, vp, i32, vp, vp, vp, ctypes.c_size_t, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp], ctypes.c_int),
     "dicp_query_order": ([i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, vp], ctypes.c_int),
     "dicp_query_keys": ([i32, vp, vp, i32, i32, vp, vp], ctypes.c_int),
     "dicp_loop_init": ([i32, vp, vp, ctypes.c_double, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp], ctypes.c_int),

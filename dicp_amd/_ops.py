@@ -154,11 +154,13 @@ class SweepIndex:
     an ICP call, so they are sorted by x once (dicp_sweep_sort: native for every size and dtype)."""
     NBKT = 1024
 
-    def __init__(self, tgt, sorted_rows=False, frame=None, tgt_rows=None):
+    def __init__(self, tgt, sorted_rows=False, frame=None, tgt_rows=None, first_order=None):
         """sorted_rows: also keep tgt_s (N,m_pad,row_stride), the full rows in sorted order (the loop's accumulate and the windowed backward gather them).
         frame (N,12): the index is built on Q y + t (keys, table and packed rows; tgt_s keeps the rows as given) and the
         searches must then be given the pose [Q C | Q r + t].
-        tgt_rows (N) int32: rows of each cloud that take part (ragged batches); the searches are given the same counts."""
+        tgt_rows (N) int32: rows of each cloud that take part (ragged batches); the searches are given the same counts.
+        first_order = (source, T_init, src_rows): the frame is chosen here and everything -- frame, sort, rows, the search pose of iteration 0 and the
+        first query order (self.first = (source, T_init, qorder)) -- goes out in ONE library call (dicp_sweep_setup)."""
         require_device(tgt, "SweepIndex")
         tgt = tgt.contiguous()
         N, m, c = tgt.shape
@@ -178,12 +180,24 @@ class SweepIndex:
         self.tgt_s = torch.empty((N, m_pad, self.row_stride), dtype=dt, device=dev) if sorted_rows else None
         nbytes = int(lib.dicp_sweep_sort_scratch_bytes(_DT[dt], N, m_pad))     # float64 keys / more than 16384 slots: chunked sort through scratch
         scratch = torch.empty((nbytes,), dtype=torch.uint8, device=dev) if nbytes else None
+        self.first = None
+        self.pair_shards = torch.zeros((_lib.PAIR_SHARDS,), dtype=torch.int64, device=dev)
+        if first_order is not None:
+            source, T_init, src_rows = first_order
+            self.frame = torch.empty((N, 12), dtype=dt, device=dev)
+            pose_s = torch.empty((N, 12), dtype=dt, device=dev)
+            qorder = torch.empty((N, source.shape[1]), dtype=torch.int32, device=dev)
+            with _on(dev):
+                _lib.check(lib.dicp_sweep_setup(_DT[dt], _p(tgt), c, _p(tgt_rows), N, m, m_pad, CENTER_QUANTUM, int(FRAME_DIRECTIONS), _p(self.frame), _p(self.keys), _p(self.tperm),
+                                                self.NBKT, _p(self.bucket), _p(self.brange), _p(scratch), nbytes, _p(self.tgs4), _p(self.tgt_s), self.row_stride,
+                                                _p(source), _p(src_rows), source.shape[1], _p(T_init), _p(pose_s), _p(qorder), _stream()), "dicp_sweep_setup")
+            self.first = (source, T_init, qorder)
+            return
         with _on(dev):
             _lib.check(lib.dicp_sweep_sort(_DT[dt], _p(tgt), c, _p(frame), _p(tgt_rows), N, m, m_pad, _p(self.keys), _p(self.tperm), self.NBKT,
                                            _p(self.bucket), _p(self.brange), _p(scratch), nbytes, _stream()), "dicp_sweep_sort")
             _lib.check(lib.dicp_sweep_build(_DT[dt], _p(tgt), c, _p(frame), _p(tgt_rows), _p(self.tperm), N, m, m_pad,
                                             _p(self.tgs4), _p(self.tgt_s), self.row_stride, _stream()), "dicp_sweep_build")
-        self.pair_shards = torch.zeros((_lib.PAIR_SHARDS,), dtype=torch.int64, device=dev)
 
     @property
     def pairs(self):
@@ -407,16 +421,14 @@ def prebuild_search(source, target, knn_variant, want_rows, T_init=None, src_row
     if kind != _lib.KNN_SWEEP or not target.is_cuda or not target.is_contiguous() or target.dtype not in _DT:
         return None
     with _on(target.device):
-        sweep = SweepIndex(target, sorted_rows=True, frame=search_frame(target, tgt_rows=tgt_rows), tgt_rows=tgt_rows)
-        # ... and the first query order, from T_init alone (the loop's own pose_0 does not exist yet): with it the queue holds
-        # ~0.2 ms of work while the host builds the loop state
-        first = None
+        # ... with the first query order, from T_init alone (the loop's own pose_0 does not exist yet): the queue then holds ~0.2 ms of work while
+        # the host builds the loop state.  Frame, sort, rows, search pose and that order are ONE library call.
         if (T_init is not None and T_init.is_cuda and T_init.is_contiguous() and T_init.dtype == target.dtype and source.is_contiguous()
-                and tuple(T_init.shape) == (N, 4, 4)):
-            pose_s = torch.empty((N, 12), dtype=target.dtype, device=target.device)
-            _lib.check(_lib.load().dicp_search_pose(_DT[target.dtype], _p(T_init), _p(sweep.frame), N, _p(pose_s), _stream()), "dicp_search_pose")
-            first = (source, T_init, sweep.query_order(source, pose_s, src_rows=src_rows))
-        return (target, sweep, first)
+                and source.dtype == target.dtype and tuple(T_init.shape) == (N, 4, 4)):
+            sweep = SweepIndex(target, sorted_rows=True, tgt_rows=tgt_rows, first_order=(source, T_init, src_rows))
+            return (target, sweep, sweep.first)
+        sweep = SweepIndex(target, sorted_rows=True, frame=search_frame(target, tgt_rows=tgt_rows), tgt_rows=tgt_rows)
+        return (target, sweep, None)
 
 
 @dataclass

@@ -3313,6 +3313,26 @@ int dicp_sweep_build(int dtype, const void* tgt, int c, const void* frame, const
     return launch_status();
 }
 
+// The whole per-call set-up of the sweep path behind one call: search frame -> key sort -> sorted rows -> (given T_init and the queries)
+// the search pose of iteration 0 and the first query order.  Five launches the host used to make one by one, with their glue, while the
+// GPU sat idle at the start of a call (profiles/r03_timed_call_timeline.txt: 73 us before the first search).
+int dicp_sweep_setup(int dtype, const void* tgt, int c, const int32_t* tgt_rows, int N, int m, int m_pad, double quantum, int directions,
+                     void* frame, void* keys_sorted, int32_t* tperm, int nbkt, int32_t* bucket, void* brange, void* scratch, size_t scratch_bytes,
+                     void* tgs4, void* tgt_s, int tgt_s_stride,
+                     const void* src, const int32_t* src_rows, int n, const void* T_init, void* pose_search0, int32_t* qorder0, void* stream) {
+    if (!frame) return DICP_ERR_NULL;
+    int rc = dicp_search_frame(dtype, tgt, c, tgt_rows, N, m, quantum, directions, frame, stream);
+    if (!rc) rc = dicp_sweep_sort(dtype, tgt, c, frame, tgt_rows, N, m, m_pad, keys_sorted, tperm, nbkt, bucket, brange, scratch, scratch_bytes, stream);
+    if (!rc) rc = dicp_sweep_build(dtype, tgt, c, frame, tgt_rows, tperm, N, m, m_pad, tgs4, tgt_s, tgt_s_stride, stream);
+    if (!rc && T_init && pose_search0 && qorder0) {
+        if (!src || n <= 0) return DICP_ERR_NULL;
+        rc = dicp_search_pose(dtype, T_init, frame, N, pose_search0, stream);
+        if (!rc) rc = dicp_query_order(dtype, src, pose_search0, brange, nbkt, N, n, qorder0, nullptr, nullptr, nullptr, 0, nullptr, m_pad, keys_sorted, bucket, m,
+                                       src_rows, tgt_rows, stream);
+    }
+    return rc;
+}
+
 int dicp_query_keys(int dtype, const void* src, const void* pose, int N, int n, void* keys, void* stream) {
     if (!src || !keys) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;

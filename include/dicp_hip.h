@@ -107,6 +107,14 @@ int dicp_sweep_sort(int dtype, const void* tgt, int c, const void* frame, const 
                     int32_t* tperm, int nbkt, int32_t* bucket, void* brange, void* scratch, size_t scratch_bytes, void* stream);
 int dicp_sweep_build(int dtype, const void* tgt, int c, const void* frame, const int32_t* tgt_rows, const int32_t* tperm, int N, int m, int m_pad,
                      void* tgs4, void* tgt_s, int tgt_s_stride, void* stream);
+/* The whole per-call set-up of the sweep path in one call: dicp_search_frame -> dicp_sweep_sort -> dicp_sweep_build and, given T_init
+ * (N,4,4), the queries src (N,n,3) and two outputs, dicp_search_pose (pose_search0 (N,12)) -> dicp_query_order (qorder0 (N,n): the query
+ * order of iteration 0).  Arguments as those entry points'. */
+int dicp_sweep_setup(int dtype, const void* tgt, int c, const int32_t* tgt_rows, int N, int m, int m_pad, double quantum, int directions,
+                     void* frame, void* keys_sorted, int32_t* tperm, int nbkt, int32_t* bucket, void* brange, void* scratch, size_t scratch_bytes,
+                     void* tgs4, void* tgt_s, int tgt_s_stride,
+                     const void* src, const int32_t* src_rows, int n, const void* T_init, void* pose_search0, int32_t* qorder0, void* stream);
+
 /* keys (N,n) = x coordinate of every source point under pose (NULL = identity): the sort key of the query order. */
 int dicp_query_keys(int dtype, const void* src, const void* pose, int N, int n, void* keys, void* stream);
 /* qorder (N,n) = the queries in ascending bucket of their x under pose (counting sort over equal-width buckets of the

@@ -52,10 +52,11 @@ class ICP:
         self.cert_from = None                 # iteration of the certifying search (None: the last re-ordering of the queries)
         self.reuse_matches = True             # sweep path: search only where a match is not PROVEN unchanged since the last search (exact)
         self.cert_backoff = True              # ... switched off per cloud, on device, where proving costs more than searching (same results)
+        self.plan_call = True                 # constant-iteration calls: every segment of the loop behind one library call (dicp_icp_forward_plan)
         # backward: an iteration whose normal-equation cotangent has decayed below this fraction of the cloud's largest adds nothing above
         # rounding and does no per-point work for that cloud (None: 2^-22 float32 / 2^-40 float64; 0: every iteration, like autograd)
-        self.plan_call = True                 # constant-iteration calls: every segment of the loop behind one library call (dicp_icp_forward_plan)
         self.bwd_skip_eps = None
+        self.bwd_tail = True                  # ... and its ended iterations run as one launch, placed by where the previous call's sweeps ended
         # tolerance mode: iterations enqueued between two host checks of "all converged" (ICP.py:259).  None = auto:
         # every iteration for big batches (an iteration costs far more than a sync), every 4th for small ones
         # (converged clouds are frozen, so the extra iterations change nothing and the histories are trimmed)
@@ -121,7 +122,7 @@ class ICP:
             knn_variant=self.knn_variant, bwd_window=bool(self.bwd_window), stats_out=self.knn_stats,
             sync_every=self.sync_every, timing_events=self._timing_events, prebuilt=prebuilt, small_loop=bool(self.small_loop),
             src_rows=src_rows, tgt_rows=tgt_rows, sweep_resort=tuple(int(v) for v in self.sweep_resort), reuse_matches=bool(self.reuse_matches), cert_from=self.cert_from,
-            bwd_skip_eps=self.bwd_skip_eps, cert_backoff=bool(self.cert_backoff), plan_call=bool(self.plan_call))
+            bwd_skip_eps=self.bwd_skip_eps, cert_backoff=bool(self.cert_backoff), plan_call=bool(self.plan_call), bwd_tail=bool(self.bwd_tail))
         if self.nn.differentiable and self.nn.use_gumbel:                                # nn.py:14-16 via ICP.py:140
             # soft correspondences carry gradient themselves: one autograd node per iteration instead of one per call
             T, deltas, weights, costs, converged, iterations, matched = icp_loop_gumbel(

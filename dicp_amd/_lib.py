@@ -20,7 +20,7 @@ LOSS_NONE, LOSS_HUBER, LOSS_CAUCHY, LOSS_TRIM = 0, 1, 2, 3
 KNN_AUTO, KNN_VALU, KNN_MFMA, KNN_SWEEP = 0, 1, 2, 3
 NACC_PAD, NBWD_PAD, KAB_SAVE = 32, 16, 40
 PAIR_SHARDS, SWEEP_SRC_SORTED = 64, 0x100      # DICP_PAIR_SHARDS, DICP_SWEEP_SRC_SORTED
-ABI_VERSION = 4
+ABI_VERSION = 5
 _ERRORS = {1: "null pointer", 2: "bad shape/stride", 3: "unsupported dtype", 4: "bad enum value", 5: "misaligned buffer"}
 
 vp, i32, i64, f64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
@@ -52,7 +52,7 @@ class LoopBuffers(ctypes.Structure):
                 ("partials", vp), ("counters", vp), ("events", vp), ("bwd_overwrite", i32), ("frame", vp), ("poses_search", vp),
                 ("src_rows", vp), ("tgt_rows", vp), ("cert_q", vp), ("cert_qu", vp), ("cert_count", vp), ("rmax", vp), ("dcum", vp),
                 ("cert_reset", i32), ("cert_cloud", vp), ("spos_prev0", vp), ("tgt_sorted", vp), ("tgt_sorted_stride", i32),
-                ("bwd_skip", vp), ("bwd_mref", vp), ("bwd_live", vp), ("bwd_skip_eps", f64)]
+                ("bwd_skip", vp), ("bwd_mref", vp), ("bwd_live", vp), ("bwd_skip_eps", f64), ("bwd_tail_from", i32), ("bwd_tail_partials", vp), ("bwd_tail_arrive", vp)]
 
 
 MAX_SEGMENTS = 16

@@ -453,6 +453,7 @@ class LoopConfig:
     prebuilt: object = None       # (target, SweepIndex) started by the caller before its own host work (prebuild_search)
     small_loop: bool = True       # small clouds: one block runs a cloud's whole chunk of iterations (icp_small_* kernels)
     cert_from: object = None      # iteration of the certifying search (None: the last re-ordering of the queries)
+    bwd_tail: bool = True         # truncated reverse sweep: the iterations before the ones the previous call still worked at run as ONE launch (dicp_loop_buffers.bwd_tail_from)
     plan_call: bool = True        # constant-iteration sweep calls: all segments behind one library call (dicp_icp_forward_plan)
     cert_backoff: bool = True     # match certificates are switched off per cloud, on device, when a certified iteration costs more than 60 % of a full search
     reuse_matches: bool = True    # sweep path: match certificates -- an iteration searches only the waves holding a query whose match is not proven
@@ -857,9 +858,20 @@ class ICPLoop(torch.autograd.Function):
                 sk_arena.take((N,), torch.float64)
                 sk_arena.take((N,), torch.int32)
                 sk_arena.take((Kmax,), torch.int32)
-                skip = sk_arena.finish()            # mref, decisions, live counters
+                sk_arena.take((N + 1,), torch.int32)
+                skip = sk_arena.finish()            # mref, decisions, live counters, the one-launch tail's per-cloud counters (+ its error word)
                 if cfg.stats_out is not None:
                     cfg.stats_out["bwd_live"] = skip[2]     # (Kmax) int32: clouds that did per-point work in iteration k of the backward
+            # The ended iterations as ONE launch (dicp_loop_buffers.bwd_tail_from).  Where a sweep ends is decided on the device, while the host
+            # enqueues; what the host can know is where the PREVIOUS call of this shape ended (its live counters, copied to pinned memory behind
+            # that call's launches): the iterations at which fewer than an eighth of its clouds were still at work go to the one launch, which
+            # sweeps a cloud that is at work after all with one block -- slower for that cloud, exact either way.
+            tail_from, hint = 0, None
+            if skip is not None and only_windowed and cfg.bwd_tail and cfg.stats_out is not None:
+                hint = cfg.stats_out.get("_bwd_hint")
+                if hint is not None and hint[2] == (N, n, K) and hint[1].query():
+                    live = hint[0][:K].tolist()
+                    tail_from = max(0, next((k for k in range(K) if live[k] * 8 >= N), K) - 1)      # (most sweeps have ended BEFORE the one launch starts)
             have, form, fresh = 0, None, 1
             # neighbouring segments of one form inside one history slab run as ONE library call (the forward cut them where the host had to
             # act -- a new query order, a convergence check -- and none of that concerns the reverse sweep)
@@ -869,6 +881,14 @@ class ICPLoop(torch.autograd.Function):
                     runs[-1] = (k0, runs[-1][1], q, w_form)
                 else:
                     runs.append((k0, k1, q, w_form))
+            # (the one launch runs down to iteration 0: it belongs to the last run, and starts no higher than that run does)
+            tail_from = min(tail_from, runs[-1][1]) if (runs and runs[-1][0] == 0 and runs[-1][3]) else 0
+            tail_part = torch.empty((N, nblk_w, _lib.NBWD_PAD), dtype=dt, device=dev) if tail_from > 0 else None
+            if cfg.stats_out is not None:
+                cfg.stats_out["bwd_tail_from"] = int(tail_from)
+                if tail_from > 0:
+                    cfg.stats_out["bwd_tail_error"] = skip[3][N:]       # (1) int32: nonzero = a wait of the tail launch ran out (never observed)
+            folded = False
             for (k0, k1, q, w_form) in runs:
                 if have and w_form != form:     # the partials of the other form have another block count: fold them in here
                     gpose += bwdp[form].sum(dim=1)[:, :12].to(torch.float64)
@@ -886,15 +906,26 @@ class ICPLoop(torch.autograd.Function):
                     idx=ctypes.c_void_p(idx_slabs[j].data_ptr() - base * N * n * 4) if idx_slabs else None, events=events,
                     bwd_overwrite=fresh if (w_form and k1 > k0) else 0, src_rows=_p(cfg.src_rows), tgt_rows=_p(cfg.tgt_rows),
                     bwd_skip=_p(skip[1]) if skip else None, bwd_mref=_p(skip[0]) if skip else None, bwd_live=_p(skip[2]) if skip else None,
-                    bwd_skip_eps=float(eps))
+                    bwd_skip_eps=float(eps), bwd_tail_from=int(tail_from) if (w_form and k0 == 0) else 0,
+                    bwd_tail_partials=_p(tail_part), bwd_tail_arrive=_p(skip[3]) if skip else None)
+                fresh_was = bool(w_form and k1 > k0 and fresh)
                 if w_form and k1 > k0:
                     fresh = 0
                 _lib.check(lib.dicp_icp_backward(code, ctypes.byref(P), ctypes.byref(LB), N, n, m, int(cfg.dim), _p(gpose), _p(gtmp), have,
                                                  _p(gs), _p(gb), _p(gsrc_s) if w_form else _p(gsrc), _p(slab) if w_form else _p(gtgt),
                                                  _p(gw_s) if w_form else _p(gw), _p(bwdp[form]), k0, k1, st), "dicp_icp_backward")
                 have = 1
+                if w_form and k0 == 0 and tail_from > 0:
+                    kt = min(tail_from, k1) - (1 if (fresh_was and tail_from >= k1) else 0)     # (dicp_icp_backward: the first windowed iteration is never the tail's)
+                    folded = kt > 0         # the tail launch left the cotangent of pose_0 with the last pose sums already in it
                 if (k1 - k0) % 2:           # the library alternates the two buffers: odd chunk -> the result is in the other one
                     gpose, gtmp = gtmp, gpose
+            if skip is not None and only_windowed and cfg.bwd_tail and cfg.stats_out is not None:
+                host = hint[0] if (hint is not None and hint[0].numel() >= Kmax) else torch.empty((Kmax,), dtype=torch.int32).pin_memory()
+                host[:Kmax].copy_(skip[2], non_blocking=True)
+                done = torch.cuda.Event()
+                done.record()
+                cfg.stats_out["_bwd_hint"] = (host, done, (N, n, K))
             if any(windowed):               # slot s is source point qo[s]; slabs + out-of-window rows -> original target order
                 permute = lib.dicp_permute_rows if only_windowed else lib.dicp_permute_add_rows
                 _lib.check(permute(code, _p(gsrc_s), _p(qo), N, n, n, n, 3, 3, _p(gsrc), n, 3, st), "dicp_permute_rows")
@@ -904,6 +935,8 @@ class ICPLoop(torch.autograd.Function):
                     _lib.check(lib.dicp_window_reduce(code, _p(slab), _p(spos_ref), _p(qo), _p(tperm), _p(gfar), _p(cfg.src_rows), N, n, m, m_pad, cv,
                                                       _p(gtgt), c, int(all_windowed), st), "dicp_window_reduce")
             gT0 = torch.empty((N, 4, 4), dtype=dt, device=dev)      # final gpose + the last launch's pose partials
+            if folded:
+                have = 0
             _lib.check(lib.dicp_pose_grad_out(code, _p(gpose), _p(bwdp[form]) if have else None, bwdp[form].shape[1] if have else 0,
                                               _p(gT0), N, st), "dicp_pose_grad_out")
             if gsrc_pc is not None:

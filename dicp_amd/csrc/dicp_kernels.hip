@@ -982,7 +982,7 @@ template <typename T> struct SweepEps;
 template <> struct SweepEps<float>  { static constexpr float  v = 3e-6f; };
 template <> struct SweepEps<double> { static constexpr double v = 1e-10; };
 
-template <typename T, int NV, int PAD>
+template <typename T, int NV, int PAD, int NT = BLOCK>
 __device__ __forceinline__ void block_reduce_store(T* v, T* __restrict__ out, T* lds);
 
 // Launch configuration of the tile sweep, measured at the benchmark shape (profiles/r01_sweep_configs_ab.txt): 2 queries per
@@ -1681,8 +1681,8 @@ __device__ __forceinline__ void halve_step(T* v, int lane) {      // v[0..2H) ->
         v[k] = keep + __shfl_xor(give, 2 * H);
     }
 }
-template <typename T, int NV, int PAD>
-__device__ __forceinline__ void block_reduce_store(T* v, T* __restrict__ out, T* lds /* [BLOCK/WAVE][PAD] */) {
+template <typename T, int NV, int PAD, int NT>
+__device__ __forceinline__ void block_reduce_store(T* v, T* __restrict__ out, T* lds /* [NT/WAVE][PAD] */) {
     static_assert(NV <= 32 && PAD >= NV, "reduce-scatter over 32 slots");
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
     T a[32];
@@ -1701,7 +1701,7 @@ __device__ __forceinline__ void block_reduce_store(T* v, T* __restrict__ out, T*
         T s = T(0);
         if (tid < NV) {
 #pragma unroll
-            for (int w = 0; w < BLOCK / WAVE; ++w) s += lds[w * PAD + tid];
+            for (int w = 0; w < NT / WAVE; ++w) s += lds[w * PAD + tid];
         }
         out[tid] = s;
     }
@@ -2149,29 +2149,23 @@ __device__ __forceinline__ int window_origin(const int32_t* __restrict__ sp_ref_
     return min(max(ctr - WT / 2, 0), m_pad - WT) & ~15;
 }
 
+// One block's share of one iteration (the body of accumulate_bwd_window_kernel, and of the tail launch that runs a cloud's remaining iterations):
+// gs / gb = THIS cloud's cotangents of the normal equations, part_out = this block's row of the pose partial sums.
 template <typename T, int MODE, int WT, bool overwrite>
-__global__ __launch_bounds__(BLOCK) void accumulate_bwd_window_kernel(WeightParams P, const T* __restrict__ src_s, const T* __restrict__ tgt_s, int c,
-                                                                      const int32_t* __restrict__ spos, const int32_t* __restrict__ spos_ref,
-                                                                      const int32_t* __restrict__ qorder,
-                                                                      const T* __restrict__ pose, const T* __restrict__ w_s, const T* __restrict__ alive,
-                                                                      const T* __restrict__ gs, const T* __restrict__ gb,
-                                                                      int N, int n, int m_pad, int spb, int bpc,
-                                                                      T* __restrict__ gsrc_s, T* __restrict__ slab /* (N,bpc,WT,CV) */,
-                                                                      T* __restrict__ gts_far /* (N,m_pad,CV) */,
-                                                                      T* __restrict__ gw_s, T* __restrict__ bwd_partials, const int32_t* __restrict__ src_rows,
-                                                                      const int32_t* __restrict__ skip /* optional (N), see accumulate_bwd_kernel */) {
+__device__ __forceinline__ void window_body(const WeightParams& P, const T* __restrict__ src_s, const T* __restrict__ tgt_s, int c,
+                                            const int32_t* __restrict__ spos, const int32_t* __restrict__ spos_ref,
+                                            const int32_t* __restrict__ qorder,
+                                            const T* __restrict__ pose, const T* __restrict__ w_s, const T* __restrict__ alive,
+                                            const T* gs, const T* gb, int n, int m_pad, int spb, int bpc,
+                                            T* __restrict__ gsrc_s, T* __restrict__ slab /* (N,bpc,WT,CV) */,
+                                            T* __restrict__ gts_far /* (N,m_pad,CV) */,
+                                            T* __restrict__ gw_s, T* part_out, const int32_t* __restrict__ src_rows, int cloud, int blk) {
     // overwrite: first launch into uninitialised accumulators -- gsrc_s / gw_s / the slab windows are written, not added to
     constexpr int CV = (MODE == MODE_PT2PL) ? 6 : 3;
     __shared__ T red[(BLOCK / WAVE) * NBWD_PAD];
     constexpr int SPB = 4 * BLOCK;                          // window_slots() never exceeds this
     __shared__ T contrib[SPB * CV];                         // target-row contribution of each of the block's slots
     __shared__ int head[WT], next[SPB];                     // per window row: list of the slots that matched it
-    int cloud, blk;
-    if (!decode_block(bpc, N, cloud, blk)) return;
-    if (!overwrite && skip && skip[cloud]) {                // (the first launch initialises the accumulators: it always runs)
-        if (threadIdx.x < NBWD_PAD) bwd_partials[((size_t)cloud * bpc + blk) * NBWD_PAD + threadIdx.x] = T(0);
-        return;
-    }
     const int tid = threadIdx.x;
     const int nc = rows_of(src_rows, cloud, n);             // ragged batches: slots past the cloud's own carry weight 0: no work, zero gradient
     const int s0 = blk * spb, s1 = min(nc, s0 + spb), s1_all = min(n, s0 + spb);
@@ -2198,9 +2192,9 @@ __global__ __launch_bounds__(BLOCK) void accumulate_bwd_window_kernel(WeightPara
     T C[9], r[3], Gs[36], Gb[6];
     load_pose(pose, cloud, C, r);
 #pragma unroll
-    for (int k = 0; k < 36; ++k) Gs[k] = gs[(size_t)cloud * 36 + k];
+    for (int k = 0; k < 36; ++k) Gs[k] = gs[k];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) Gb[k] = gb[(size_t)cloud * 6 + k];
+    for (int k = 0; k < 6; ++k) Gb[k] = gb[k];
     const T live = alive ? alive[cloud] : T(1);
     T acc[NBWD];
 #pragma unroll
@@ -2280,7 +2274,29 @@ __global__ __launch_bounds__(BLOCK) void accumulate_bwd_window_kernel(WeightPara
             for (int k = 0; k < CV; ++k) out[rr * CV + k] = overwrite ? sum[k] : out[rr * CV + k] + sum[k];
         }
     }
-    block_reduce_store<T, NBWD, NBWD_PAD>(acc, bwd_partials + ((size_t)cloud * bpc + blk) * NBWD_PAD, red);
+    block_reduce_store<T, NBWD, NBWD_PAD>(acc, part_out, red);
+}
+
+template <typename T, int MODE, int WT, bool overwrite>
+__global__ __launch_bounds__(BLOCK) void accumulate_bwd_window_kernel(WeightParams P, const T* __restrict__ src_s, const T* __restrict__ tgt_s, int c,
+                                                                      const int32_t* __restrict__ spos, const int32_t* __restrict__ spos_ref,
+                                                                      const int32_t* __restrict__ qorder,
+                                                                      const T* __restrict__ pose, const T* __restrict__ w_s, const T* __restrict__ alive,
+                                                                      const T* __restrict__ gs, const T* __restrict__ gb,
+                                                                      int N, int n, int m_pad, int spb, int bpc,
+                                                                      T* __restrict__ gsrc_s, T* __restrict__ slab /* (N,bpc,WT,CV) */,
+                                                                      T* __restrict__ gts_far /* (N,m_pad,CV) */,
+                                                                      T* __restrict__ gw_s, T* __restrict__ bwd_partials, const int32_t* __restrict__ src_rows,
+                                                                      const int32_t* __restrict__ skip /* optional (N), see accumulate_bwd_kernel */) {
+    int cloud, blk;
+    if (!decode_block(bpc, N, cloud, blk)) return;
+    T* part_out = bwd_partials + ((size_t)cloud * bpc + blk) * NBWD_PAD;
+    if (!overwrite && skip && skip[cloud]) {                // (the first launch initialises the accumulators: it always runs)
+        if (threadIdx.x < NBWD_PAD) part_out[threadIdx.x] = T(0);
+        return;
+    }
+    window_body<T, MODE, WT, overwrite>(P, src_s, tgt_s, c, spos, spos_ref, qorder, pose, w_s, alive, gs + (size_t)cloud * 36, gb + (size_t)cloud * 6,
+                                        n, m_pad, spb, bpc, gsrc_s, slab, gts_far, gw_s, part_out, src_rows, cloud, blk);
 }
 
 // gtgt[b][tperm[s]][col] += gts_far[b][s][col] + sum over the blocks whose window covers sorted row s of their
@@ -2587,48 +2603,90 @@ __global__ __launch_bounds__(BLOCK) void icp_small_backward_kernel(WeightParams 
     constexpr int CV = (MODE == MODE_PT2PL) ? 6 : 3;
     extern __shared__ __align__(16) unsigned char small_bwd_lds[];
     T* gt = reinterpret_cast<T*>(small_bwd_lds);            // (m, CV) target-gradient rows of this cloud
-    __shared__ double sg[NBWD_PAD], sC[9], sd[6], sAreg[36], sGs[36], sGb[6], sgo[12], spart[NBWD_PAD];
-    __shared__ T red[(BLOCK / WAVE) * NBWD_PAD];
+    __shared__ double sg[NBWD_PAD], sC[9], sd[6], sAreg[36], sGs[36], sGb[6], sgo[12], spart[NBWD_PAD], sdmax[6], sR[WAVE * 9];
+    constexpr int NT = BLOCK;
+    __shared__ T red[(NT / WAVE) * NBWD_PAD];
     __shared__ T part[NBWD_PAD];
     __shared__ int s_skip;
     const int cloud = blockIdx.x, tid = threadIdx.x, c = B.c;
     const int nc = rows_of(B.src_rows, cloud, n);           // ragged batches: rows past the cloud's own carry no gradient
     bool ended = B.bwd_skip && B.bwd_skip[cloud] == 2;      // (this cloud's reverse sweep ended in an earlier chunk)
     if (gtgt)
-        for (int e = tid; e < m * CV; e += BLOCK) gt[e] = T(0);
+        for (int e = tid; e < m * CV; e += NT) gt[e] = T(0);
     if (tid < 12) sgo[tid] = gpose_in[(size_t)cloud * 12 + tid];
-    if (tid < NBWD_PAD) {
+    if (tid >= WAVE && tid < WAVE + NBWD_PAD) {             // (second wave: 16 lanes, one slot each, loads of all blocks in flight together when they are few)
+        const int slot = tid - WAVE;
         double s = 0.0;
-        if (have_partials && tid < NBWD)
-            for (int b = 0; b < nblk; ++b) s += (double)bwd_partials[((size_t)cloud * nblk + b) * NBWD_PAD + tid];
-        spart[tid] = s;
-        part[tid] = T(0);
+        if (have_partials && slot < NBWD)
+            for (int b = 0; b < nblk; ++b) s += (double)bwd_partials[((size_t)cloud * nblk + b) * NBWD_PAD + slot];
+        spart[slot] = s;
+        part[slot] = T(0);
     }
     const T* __restrict__ src = (const T*)B.src + (size_t)cloud * n * 3;
     const T* __restrict__ tgt = (const T*)B.tgt + (size_t)cloud * m * c;
     const T* __restrict__ w_init = B.w_init ? (const T*)B.w_init + (size_t)cloud * n : nullptr;
+    const T* __restrict__ dlt = (const T*)B.deltas + (size_t)cloud * B.K * 6;
     __syncthreads();
     for (int k = k1 - 1; k >= k0; --k) {
+        if (ended) {
+            // The sweep has ended: only the pass-through part of the pose cotangent goes on (pose_pass_through), through ALL the
+            // remaining iterations at once: gC <- R_k gC with R_k = exp(delta_k^), the rotations by the lanes, the chain by one.
+            if (tid < 12) sgo[tid] += spart[tid];           // (the sums of the last launch / iteration before the end: zero for an ended cloud, added for form's sake)
+            __syncthreads();
+            for (int kb = k; kb >= k0; kb -= WAVE) {
+                const int cnt = min(WAVE, kb - k0 + 1);
+                if (tid < cnt) {
+                    const T* dp = dlt + (size_t)(kb - tid) * 6;
+                    const double d[6] = {(double)dp[0], (double)dp[1], (double)dp[2], (double)dp[3], (double)dp[4], (double)dp[5]};
+                    double R[9];
+                    so3_exp(d, R);
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) sR[tid * 9 + e] = R[e];
+                }
+                __syncthreads();
+                if (tid < 3) {                              // column tid of gC: the three columns are independent chains
+                    double v0 = sgo[0 * 3 + tid], v1 = sgo[1 * 3 + tid], v2 = sgo[2 * 3 + tid];
+                    for (int t = 0; t < cnt; ++t) {
+                        const double* R = sR + t * 9;
+                        const double a = R[0] * v0 + R[1] * v1 + R[2] * v2, b = R[3] * v0 + R[4] * v1 + R[5] * v2, cc = R[6] * v0 + R[7] * v1 + R[8] * v2;
+                        v0 = a; v1 = b; v2 = cc;
+                    }
+                    sgo[0 * 3 + tid] = v0; sgo[1 * 3 + tid] = v1; sgo[2 * 3 + tid] = v2;
+                }
+                __syncthreads();
+            }
+            if (tid < NBWD_PAD) { spart[tid] = 0.0; part[tid] = T(0); }
+            __syncthreads();
+            break;
+        }
         const T* pose_k = (const T*)B.poses + (size_t)k * N * 12;
         if (tid < NBWD) sg[tid] = spart[tid] + sgo[tid];
         if (tid < 9) sC[tid] = (double)pose_k[(size_t)cloud * 12 + tid];
-        if (tid < 6) sd[tid] = (double)((const T*)B.deltas)[(size_t)cloud * B.K * 6 + (size_t)k * 6 + tid];
+        if (tid < 6) sd[tid] = (double)dlt[(size_t)k * 6 + tid];
         if (tid < 36) sAreg[tid] = B.areg[((size_t)k * N + cloud) * 36 + tid];
-        __syncthreads();
-        if (ended) {                                        // the sweep has ended: only the pass-through part of the pose cotangent goes on
-            if (tid == 0) pose_pass_through(sg, sg + 9, sd, sgo, sgo + 9);
-            __syncthreads();
-            continue;
+        if (B.bwd_skip && tid >= WAVE && tid < 2 * WAVE) {  // the largest step of the EARLIER iterations, per component (second wave: lanes over iterations)
+            double dm[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            for (int j = tid - WAVE; j < k; j += WAVE) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) { const double v = fabs((double)dlt[(size_t)j * 6 + i]); dm[i] = v > dm[i] ? v : dm[i]; }
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+#pragma unroll
+                for (int off = WAVE / 2; off > 0; off >>= 1) { const double o = __shfl_down(dm[i], off); dm[i] = o > dm[i] ? o : dm[i]; }
+            }
+            if (tid == WAVE) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) sdmax[i] = dm[i];
+            }
         }
+        __syncthreads();
         if (tid == 0) {
             step_backward(sg, sg + 9, dim, sC, sd, sAreg, sGs, sGb, sgo, sgo + 9);
             s_skip = 0;
             if (B.bwd_skip) {
                 const SkipArgs<T> sk{B.bwd_skip, B.bwd_mref, (const T*)B.alive + (size_t)k * N, B.bwd_live ? B.bwd_live + k : nullptr, B.bwd_skip_eps, k};
-                double dmx[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-                for (int j = 0; j < k; ++j)
-                    for (int i = 0; i < 6; ++i) { const double v = fabs((double)((const T*)B.deltas)[(size_t)cloud * B.K * 6 + (size_t)j * 6 + i]); dmx[i] = v > dmx[i] ? v : dmx[i]; }
-                s_skip = skip_decision(sGs, sGb, sAreg, dmx, dim, cloud, sk, sk.alive_k[cloud] != T(0), B.bwd_mref[cloud]);
+                s_skip = skip_decision(sGs, sGb, sAreg, sdmax, dim, cloud, sk, sk.alive_k[cloud] != T(0), B.bwd_mref[cloud]);
                 B.bwd_skip[cloud] = s_skip;
             }
         }
@@ -2650,7 +2708,7 @@ __global__ __launch_bounds__(BLOCK) void icp_small_backward_kernel(WeightParams 
         T acc[NBWD];
 #pragma unroll
         for (int a = 0; a < NBWD; ++a) acc[a] = T(0);
-        for (int i = tid; i < nc; i += BLOCK) {
+        for (int i = tid; i < nc; i += NT) {
             const T p[3] = {src[i * 3], src[i * 3 + 1], src[i * 3 + 2]};
             const int j = min(max(idx_k[i], 0), m - 1);
             const T* yp = tgt + (size_t)j * c;
@@ -2668,20 +2726,234 @@ __global__ __launch_bounds__(BLOCK) void icp_small_backward_kernel(WeightParams 
                 if (MODE == MODE_PT2PL) { atomicAdd(&row[3], gn[0]); atomicAdd(&row[4], gn[1]); atomicAdd(&row[5], gn[2]); }
             }
         }
-        block_reduce_store<T, NBWD, NBWD_PAD>(acc, part, red);
+        block_reduce_store<T, NBWD, NBWD_PAD, NT>(acc, part, red);
         __syncthreads();
         if (tid < NBWD_PAD) spart[tid] = (double)part[tid];
         __syncthreads();
     }
     if (tid < 12) gpose_out[(size_t)cloud * 12 + tid] = sgo[tid];
     // the last accumulate_bwd's sums stay in bwd_partials (block 0 of nblk; the others are zero) for the caller / next chunk
-    for (int e = tid; e < nblk * NBWD_PAD; e += BLOCK)
+    for (int e = tid; e < nblk * NBWD_PAD; e += NT)
         bwd_partials[(size_t)cloud * nblk * NBWD_PAD + e] = e < NBWD_PAD ? part[e] : T(0);
     if (gtgt)
-        for (int e = tid; e < m * CV; e += BLOCK) {
+        for (int e = tid; e < m * CV; e += NT) {
             const int j = e / CV, col = e - j * CV;
             gtgt[((size_t)cloud * m + j) * c + col] += gt[e];
         }
+}
+
+// The TAIL of the windowed reverse sweep of big clouds (dicp_loop_buffers.bwd_tail_from): the iterations k1-1 .. 0 in ONE launch.
+// With the truncated sweep the iterations before the last few are, for almost every cloud, nothing but the pass-through of the pose
+// cotangent -- yet a pair of dependent launches each (21 us of dispatch per iteration at the benchmark shape: a third of a K = 20
+// backward).  Here, on accumulate_bwd_window's grid: block 0 of an ended cloud multiplies the cotangent through all its remaining
+// iterations (the rotations exp(delta_k^) by the lanes, one product chain), its other blocks leave at once.  A cloud that is still at
+// work (a straggler, or a cloud whose sweep ends in these iterations) is swept by ITS blocks together, iteration by iteration: every
+// block runs the cloud's step_bwd itself -- same inputs, same instructions, same verdicts in all of them, so nothing has to be handed
+// from one block to the others -- then its own share of accumulate_bwd_window (window_body), publishes its pose sums and waits until
+// all of the cloud's blocks have published theirs (one counter per cloud; sums double-buffered by generation, so a block that is ahead
+// never overwrites what a block behind still reads).  Blocks wait only for blocks of their own cloud, whose indices are all inside one
+// group of 8 bpc consecutive blocks (decode_block): dispatch is in index order, so the lowest unfinished group is always resident as a
+// whole and makes progress -- and every wait is bounded anyway (on running out it raises the error word and goes on: wrong sums, no hang).
+// On exit gpose_out holds the cotangent of pose_0 INCLUDING the last pose sums (dicp_pose_grad_out is then called without partials).
+// A word handed from one block to another inside a launch: agent-scope atomic accesses (sc1: coherent across the XCDs' L2s)
+__device__ __forceinline__ void coherent_store(float* p, float v)   { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void coherent_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float  coherent_load(const float* p)  { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double coherent_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <typename T, int MODE, int WT>
+__global__ __launch_bounds__(BLOCK) void bwd_tail_kernel(WeightParams P, dicp_loop_buffers B, int N, int n, int dim, int spb, int bpc,
+                                                         const double* __restrict__ gpose_in, double* __restrict__ gpose_out, int have_partials,
+                                                         T* __restrict__ gsrc_s, T* __restrict__ slab, T* __restrict__ gw_s,
+                                                         T* part0 /* bwd_partials: the sums on entry, then the even generations */, T* part1 /* the odd generations */,
+                                                         int32_t* arrive /* (N + 1) zeros: blocks that have published, per cloud; [N] = error word */, int k1) {
+    __shared__ double sg[NBWD_PAD], sC[9], sd[6], sAreg[36], sGs[36], sGb[6], sgo[12], sdmax[6], sR[WAVE * 9], smref;
+    __shared__ T sGsT[36], sGbT[6], spub[NBWD_PAD];
+    __shared__ int s_verdict, s_alive;
+    int cloud, blk;
+    if (!decode_block(bpc, N, cloud, blk)) return;
+    const int tid = threadIdx.x;
+    bool ended = B.bwd_skip[cloud] == 2;                    // (decided by an earlier launch: the same for all of the cloud's blocks)
+    if (ended && blk != 0) return;
+    if (tid < 12) sgo[tid] = gpose_in[(size_t)cloud * 12 + tid];
+    if (tid == 32) smref = B.bwd_mref[cloud];
+    const T* __restrict__ dlt = (const T*)B.deltas + (size_t)cloud * B.K * 6;
+    const T* cur = have_partials ? part0 : nullptr;         // the cloud's bpc rows of pose sums still to be added to the cotangent (NULL: zeros)
+    int gen = 0;
+    __syncthreads();
+    // sg[0..12) = the cotangent + the sums of the last accumulate_bwd, in step_bwd_kernel's order (every thread calls; ends with a barrier)
+    auto fold = [&](const T* rows) {
+        if (tid < WAVE) {
+            const int slot_i = tid & 15, part = tid >> 4;
+            double s = 0.0;
+            if (rows && slot_i < NBWD) {
+                const T* pp = rows + (size_t)cloud * bpc * NBWD_PAD + slot_i;
+                constexpr int UB = 4;
+                for (int b0 = part; b0 < bpc; b0 += 4 * UB) {
+                    T v[UB];
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) v[u] = (b0 + 4 * u < bpc) ? coherent_load(pp + (size_t)(b0 + 4 * u) * NBWD_PAD) : T(0);
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) if (b0 + 4 * u < bpc) s += (double)v[u];
+                }
+            }
+            s += __shfl_down(s, 32);
+            s += __shfl_down(s, 16);
+            if (tid < NBWD) sg[tid] = s + sgo[tid];
+        }
+        __syncthreads();
+    };
+    for (int k = k1 - 1; k >= 0; --k) {
+        if (ended) {        // (block 0 only) the pass-through part of the pose cotangent through ALL the remaining iterations: gC <- exp(delta_k^) gC
+            fold(cur);
+            cur = nullptr;
+            if (tid < 12) sgo[tid] = sg[tid];
+            __syncthreads();
+            for (int kb = k; kb >= 0; kb -= WAVE) {
+                const int cnt = min(WAVE, kb + 1);
+                if (tid < cnt) {
+                    const T* dp = dlt + (size_t)(kb - tid) * 6;
+                    const double d[6] = {(double)dp[0], (double)dp[1], (double)dp[2], (double)dp[3], (double)dp[4], (double)dp[5]};
+                    double R[9];
+                    so3_exp(d, R);
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) sR[tid * 9 + e] = R[e];
+                }
+                __syncthreads();
+                if (tid < 3) {                              // column tid of gC: three independent chains
+                    double v0 = sgo[0 * 3 + tid], v1 = sgo[1 * 3 + tid], v2 = sgo[2 * 3 + tid];
+                    for (int t = 0; t < cnt; ++t) {
+                        const double* R = sR + t * 9;
+                        const double a = R[0] * v0 + R[1] * v1 + R[2] * v2, b = R[3] * v0 + R[4] * v1 + R[5] * v2, cc = R[6] * v0 + R[7] * v1 + R[8] * v2;
+                        v0 = a; v1 = b; v2 = cc;
+                    }
+                    sgo[0 * 3 + tid] = v0; sgo[1 * 3 + tid] = v1; sgo[2 * 3 + tid] = v2;
+                }
+                __syncthreads();
+            }
+            break;
+        }
+        // ---- step_bwd of iteration k: by every block of the cloud alike
+        const T* pose_k = (const T*)B.poses + (size_t)k * N * 12;
+        const T* alive_k = (const T*)B.alive + (size_t)k * N;
+        if (tid >= WAVE && tid < 2 * WAVE) {                // (second wave, under the first one's loads) the largest step of the EARLIER iterations, per component
+            double dm[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            for (int j = tid - WAVE; j < k; j += WAVE) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) { const double v = fabs((double)dlt[(size_t)j * 6 + i]); dm[i] = v > dm[i] ? v : dm[i]; }
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+#pragma unroll
+                for (int off = WAVE / 2; off > 0; off >>= 1) { const double o = __shfl_down(dm[i], off); dm[i] = o > dm[i] ? o : dm[i]; }
+            }
+            if (tid == WAVE) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) sdmax[i] = dm[i];
+            }
+        }
+        if (tid >= 2 * WAVE && tid < 2 * WAVE + 9) sC[tid - 2 * WAVE] = (double)pose_k[(size_t)cloud * 12 + (tid - 2 * WAVE)];
+        if (tid >= 2 * WAVE + 16 && tid < 2 * WAVE + 22) sd[tid - 2 * WAVE - 16] = (double)dlt[(size_t)k * 6 + (tid - 2 * WAVE - 16)];
+        if (tid >= 3 * WAVE && tid < 3 * WAVE + 36) sAreg[tid - 3 * WAVE] = B.areg[((size_t)k * N + cloud) * 36 + (tid - 3 * WAVE)];
+        if (tid == 3 * WAVE + 40) s_alive = alive_k[cloud] != T(0) ? 1 : 0;
+        fold(cur);
+        cur = nullptr;
+        if (tid == 0) {     // (operands in registers, as in step_bwd_kernel)
+            double g[12], C[9], d[6], A[36], Gs[36], Gb[6], go[12];
+#pragma unroll
+            for (int e = 0; e < 12; ++e) g[e] = sg[e];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) C[e] = sC[e];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) d[e] = sd[e];
+#pragma unroll
+            for (int e = 0; e < 36; ++e) A[e] = sAreg[e];
+            step_backward(g, g + 9, dim, C, d, A, Gs, Gb, go, go + 9);
+#pragma unroll
+            for (int e = 0; e < 36; ++e) sGs[e] = Gs[e];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) sGb[e] = Gb[e];
+#pragma unroll
+            for (int e = 0; e < 12; ++e) sgo[e] = go[e];
+        }
+        __syncthreads();
+        if (tid < WAVE) {   // the measures of skip_decision by the lanes, as in step_bwd_kernel
+            const int D = dim == 2 ? 3 : 6, OFF = dim == 2 ? 2 : 0;
+            double v = 0.0, vb = 0.0, va = 0.0;
+            if (tid < 36) {
+                const int i = tid / 6, j = tid - 6 * i;
+                if (i < D && j < D) v = fabs(sGs[(i + OFF) * 6 + (j + OFF)]) * sqrt(fabs(sAreg[i * 6 + i])) * sqrt(fabs(sAreg[j * 6 + j]));
+            } else if (tid < 42) {
+                const int i = tid - 36;
+                if (i < D) { const double sa = sqrt(fabs(sAreg[i * 6 + i])); vb = fabs(sGb[i + OFF]) * sa; va = sdmax[i + OFF] * sa; }
+            }
+            const bool nan = __any(!(v == v) || !(vb == vb) || !(va == va)) != 0;
+            double mm = v > vb ? v : vb, gmax = vb, amp = va;
+#pragma unroll
+            for (int off = WAVE / 2; off > 0; off >>= 1) {
+                const double a = __shfl_xor(mm, off), b = __shfl_xor(gmax, off), cc = __shfl_xor(amp, off);
+                mm = a > mm ? a : mm; gmax = b > gmax ? b : gmax; amp = cc > amp ? cc : amp;
+            }
+            if (tid == 0) {
+                int verdict = 0;
+                if (!s_alive) verdict = 1;
+                else {
+                    const double worst = gmax * amp > mm ? gmax * amp : mm;
+                    if (!nan && 16.0 * worst <= B.bwd_skip_eps * smref) verdict = 2;
+                    else {
+                        if (!nan && mm > smref) { smref = mm; if (blk == 0) B.bwd_mref[cloud] = mm; }
+                        if (blk == 0 && B.bwd_live) atomicAdd(B.bwd_live + k, 1);
+                    }
+                }
+                if (blk == 0) B.bwd_skip[cloud] = verdict;  // (nobody reads it again in this launch: the cloud's blocks all hold the same verdict)
+                s_verdict = verdict;
+            }
+            if (tid < 36) sGsT[tid] = (T)sGs[tid];          // rounded to T like the gs / gb buffers of the per-iteration launches
+            if (tid < 6) sGbT[tid] = (T)sGb[tid];
+        }
+        __syncthreads();
+        const int verdict = s_verdict;
+        if (verdict == 2) {                                 // the cloud's sweep ends here: what is left is block 0's product chain
+            if (blk != 0) return;
+            ended = true;
+            continue;
+        }
+        if (verdict == 1) continue;                         // frozen at this iteration: every term is exactly zero, and so are its sums
+        // ---- this block's share of accumulate_bwd of iteration k
+        ++gen;
+        T* out = (gen & 1) ? part1 : part0;
+        window_body<T, MODE, WT, false>(P, (const T*)B.src, (const T*)B.tgt, B.c, B.spos + (size_t)k * N * n, B.spos_ref, B.qorder, pose_k, (const T*)B.w_init, alive_k,
+                                        sGsT, sGbT, n, B.m_pad, spb, bpc, gsrc_s, slab, (T*)B.gts_far, gw_s, spub, B.src_rows, cloud, blk);
+        // ---- publish the pose sums; wait until all of the cloud's blocks have published theirs.  The hand-off is a handful of words: they are
+        // written and read as agent-scope atomics (coherent where they live; a release / acquire FENCE at agent scope writes back and
+        // invalidates the whole L2 -- tens of microseconds under this kernel's gradient traffic), each store complete (the workgroup-scope
+        // release: s_waitcnt) before the block is counted.
+        __syncthreads();
+        if (tid < NBWD_PAD) {
+            coherent_store(out + ((size_t)cloud * bpc + blk) * NBWD_PAD + tid, spub[tid]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        }
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(arrive + cloud, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!(k == 0 && blk != 0)) {                    // (after the last iteration only block 0 still needs the sums)
+                const int want = gen * bpc;
+                int spins = 0;
+                while (__hip_atomic_load(arrive + cloud, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                    if (++spins > (1 << 20)) { atomicExch(arrive + N, 1); break; }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        if (k == 0 && blk != 0) return;
+        __syncthreads();
+        cur = out;
+    }
+    if (blk == 0) {
+        fold(cur);
+        if (tid < 12) gpose_out[(size_t)cloud * 12 + tid] = sg[tid];
+    }
 }
 
 // ------------------------------------------------------------- Gumbel-softmax soft kNN
@@ -4045,7 +4317,15 @@ int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_
     }
     double* gin = gpose;
     double* gout = gpose_tmp;
-    for (int k = k1 - 1; k >= k0; --k) {
+    // windowed form with the truncated sweep: the iterations below bwd_tail_from are ONE launch (bwd_tail_kernel)
+    int kt = k0;
+    if (B->spos && B->bwd_skip && B->bwd_tail_from > k0) {
+        if (k0 != 0) return DICP_ERR_SHAPE;                 // (the launch runs down to iteration 0 and folds the last pose sums into the cotangent)
+        if (!B->bwd_tail_partials || !B->bwd_tail_arrive) return DICP_ERR_NULL;
+        kt = B->bwd_tail_from < k1 ? B->bwd_tail_from : k1;
+        if (B->bwd_overwrite && kt >= k1) kt = k1 - 1;      // (the first windowed launch initialises the accumulators: it always runs)
+    }
+    for (int k = k1 - 1; k >= kt; --k) {
         const char* pose_k = (const char*)B->poses + (size_t)k * N * 12 * es;
         const char* alive_k = (const char*)B->alive + (size_t)k * N * es;
         const SkipHost sh{B->bwd_skip, B->bwd_mref, alive_k, B->bwd_live ? B->bwd_live + k : nullptr, B->bwd_skip_eps, k};
@@ -4069,6 +4349,20 @@ int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_
         if (B->events && !B->spos) { if (hipEventRecord((hipEvent_t)B->events[6 * k + 5], st) != hipSuccess) return -(int)hipGetLastError(); }
         have_partials = 1;
         double* t = gin; gin = gout; gout = t;
+    }
+    if (kt > k0) {
+        if (const int e = check_params(prm, B->c)) return e;
+        begin_launch();
+        const WeightParams P = to_params(prm);
+        double* dst = ((k1 - k0) & 1) ? gpose_tmp : gpose;            // where the alternating buffers would have left it
+        const unsigned g = grid_for(N, nblk);
+#define DICP_TAILB(T, M) do { constexpr int WT = WindowRows<T>::v; \
+        bwd_tail_kernel<T, M, WT><<<g, BLOCK, 0, st>>>(P, *B, N, n, dim, window_slots(WT, n, B->m_pad), nblk, gin, dst, have_partials, \
+            (T*)gsrc, (T*)gtgt, (T*)gw, (T*)bwd_partials, (T*)B->bwd_tail_partials, B->bwd_tail_arrive, kt); } while (0)
+        if (dtype == DICP_F32) { if (P.mode == MODE_PT2PL) DICP_TAILB(float, MODE_PT2PL); else DICP_TAILB(float, MODE_PT2PT); }
+        else                   { if (P.mode == MODE_PT2PL) DICP_TAILB(double, MODE_PT2PL); else DICP_TAILB(double, MODE_PT2PT); }
+#undef DICP_TAILB
+        return launch_status();
     }
     // the two buffers alternate: after an odd number of iterations the result sits in gpose_tmp (no copy: the caller
     // swaps its two pointers, see dicp_hip.h)

@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define DICP_ABI_VERSION 4   /* 4: dicp_loop_buffers.bwd_skip / bwd_mref / bwd_live / bwd_skip_eps (truncated reverse sweep of dicp_icp_backward); cert_cloud (per-cloud switch of the
+#define DICP_ABI_VERSION 5   /* 5: dicp_loop_buffers.bwd_tail_from (the ended iterations of the truncated reverse sweep as one launch).
+                                4: dicp_loop_buffers.bwd_skip / bwd_mref / bwd_live / bwd_skip_eps (truncated reverse sweep of dicp_icp_backward); cert_cloud (per-cloud switch of the
                                 match certificates); dicp_cloud_center -> dicp_search_frame: centre AND sort direction as one affine map per cloud, (N,12).
                                 3: per-cloud row counts of ragged batches (src_rows / tgt_rows) on every entry point of the path; the centred and
                                 uncentred forms of an entry point are one (center may be NULL); the key sort is native for every size and dtype;
@@ -305,6 +306,17 @@ typedef struct dicp_loop_buffers {
     double* bwd_mref;        /* (N) zero-initialised once per backward pass */
     int32_t* bwd_live;       /* optional (K) zeros: clouds that took part in iteration k */
     double bwd_skip_eps;
+    int32_t bwd_tail_from;   /* windowed form with bwd_skip: the iterations k < bwd_tail_from run as ONE launch (0: every iteration is its own pair of
+                                launches).  Before the last few iterations almost every cloud's sweep has ended, and a pair of dependent launches per
+                                iteration is pure dispatch time.  On accumulate_bwd_window's grid, that launch multiplies an ended cloud's pose cotangent
+                                through all its remaining iterations; a cloud that is still at work is swept by its own blocks together, iteration by
+                                iteration (each block runs the cloud's step_bwd itself, then its share of accumulate_bwd_window, and waits on a per-cloud
+                                counter for the others' pose sums): the same arithmetic as the per-iteration launches.  The call must then run down to
+                                k0 = 0, and the cotangent it leaves INCLUDES the last pose sums (dicp_pose_grad_out without partials).  The first
+                                iteration of a backward pass (bwd_overwrite) always takes the per-iteration launches.  The caller picks the iteration
+                                from where the previous call's sweeps ended. */
+    void* bwd_tail_partials; /* (N, dicp_window_blocks, DICP_NBWD_PAD): the second buffer of pose sums of that launch */
+    int32_t* bwd_tail_arrive;/* (N + 1) zeros per backward pass: its per-cloud counters; [N] is raised if a wait ran out (never observed; results are then wrong) */
 } dicp_loop_buffers;
 
 /* Head and tail of the backward loop.  dicp_pose_grad_in: gpose (N,12) double = [dL/dC row-major (9), dL/dr (3)] taken from the

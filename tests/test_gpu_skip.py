@@ -165,3 +165,64 @@ def test_skip_at_the_benchmark_size():
     full, skip = both(src, tgt, K, loss_of=lambda out: out["T"].sum())
     live = same_gradients(full, skip, 2e-6)
     assert ended_early(live, K, B, 4, stragglers=0.01) >= 2
+
+
+def _tail_call(icp, src, tgt, weight=None):
+    S, Tg = src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True)
+    Ti = torch.eye(4, dtype=src.dtype).repeat(src.shape[0], 1, 1).to(DEV).requires_grad_(True)
+    W = weight.to(DEV).requires_grad_(True) if weight is not None else None
+    out = icp.icp(S, Tg, Ti, weight=W, **KW)
+    out["T"].sum().backward()
+    torch.cuda.synchronize()
+    return [S.grad, Tg.grad, Ti.grad] + ([W.grad] if W is not None else [])
+
+
+@pytest.mark.parametrize("dtype,N,n,K,icp_type,weights", [(torch.float32, 24, 16384, 12, "pt2pl", False), (torch.float64, 10, 8192, 14, "pt2pl", True),
+                                                          (torch.float32, 33, 4096, 10, "pt2pt", True)])
+def test_tail_launch_changes_no_gradient(dtype, N, n, K, icp_type, weights):
+    """dicp_loop_buffers.bwd_tail_from: from the second call of a shape on, the iterations the previous call's sweeps had ended at are one launch.
+    (i) placed by the previous call, it holds only ended clouds: the gradients equal those of the per-iteration launches (the pass-through of the
+    pose cotangent to T_init.grad included); (ii) placed too late on purpose -- every iteration but the last in the one launch, all clouds still at
+    work in it -- each cloud is swept by one block, in another order of summation: the same gradients to rounding."""
+    src, tgt = make_pairs(N, n, n, seed=67, dtype=dtype)
+    if icp_type == "pt2pt":
+        tgt = tgt[:, :, :3].contiguous()
+    w = (0.5 + torch.rand((N, n), dtype=dtype, generator=torch.Generator().manual_seed(5))) if weights else None
+
+    def make(tail):
+        icp = ICP(icp_type=icp_type, differentiable=True, max_iterations=K, tolerance=1e-12)
+        icp.const_iter, icp.bwd_tail = True, tail
+        return icp
+    ref_icp = make(False)
+    ref = _tail_call(ref_icp, src, tgt, w)
+    assert "_bwd_hint" not in ref_icp.knn_stats
+    icp = make(True)
+    first = _tail_call(icp, src, tgt, w)                    # no earlier call: every iteration is its own pair of launches
+    assert icp.knn_stats["bwd_tail_from"] == 0
+    tiny = 1e-6 if dtype == torch.float32 else 1e-13
+    for a, b in zip(ref, first):                            # (the same launches; float atomics on the out-of-window rows: not bit for bit)
+        assert float((a - b).abs().max()) <= tiny * float(a.abs().max())
+    live_ref = ref_icp.knn_stats["bwd_live"][:K].tolist()
+    second = _tail_call(icp, src, tgt, w)
+    t_from = icp.knn_stats["bwd_tail_from"]
+    assert 0 < t_from < K and t_from == next(k for k in range(K) if live_ref[k] * 8 >= N) - 1, (t_from, live_ref)
+    live = icp.knn_stats["bwd_live"][:K].tolist()
+    assert live == live_ref, (live, live_ref)               # the one launch decides like the per-iteration ones
+    for i, (a, b) in enumerate(zip(ref, second)):
+        scale = float(a.abs().max())
+        assert float((a - b).abs().max()) <= tiny * scale, (i, float((a - b).abs().max()) / scale)
+    # (ii) a hint that is wrong: "only the last iteration was at work"
+    host, done, key = icp.knn_stats["_bwd_hint"]
+    done.synchronize()
+    host.zero_()
+    host[K - 1] = N
+    third = _tail_call(icp, src, tgt, w)
+    assert icp.knn_stats["bwd_tail_from"] == K - 2
+    assert icp.knn_stats["bwd_live"][:K].tolist() == live_ref
+    assert int(icp.knn_stats["bwd_tail_error"].item()) == 0
+    rnd = 1e-5 if dtype == torch.float32 else 1e-12         # (the same arithmetic in the same order; float atomics on the out-of-window rows)
+    for i, (a, b) in enumerate(zip(ref, third)):
+        scale = float(a.abs().max())
+        assert float((a - b).abs().max()) <= rnd * scale, (i, float((a - b).abs().max()) / scale)
+    fourth = _tail_call(icp, src, tgt, w)                   # ... and the hint has corrected itself
+    assert icp.knn_stats["bwd_tail_from"] == t_from

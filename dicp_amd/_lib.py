@@ -40,7 +40,7 @@ class StepIO(ctypes.Structure):
                 ("cost", vp), ("cost_prev", vp), ("cost_stride", i64), ("areg", vp), ("alive", vp), ("alive_out", vp),
                 ("converged", vp), ("iterations", vp), ("matched_ratio", vp), ("n_start", vp),
                 ("n_matched", vp), ("w_cur", vp), ("w_prev", vp), ("w_stride", i64), ("n_not_converged", vp),
-                ("frame", vp), ("pose_search_out", vp), ("rmax", vp), ("dcum", vp), ("dcum_stride", i64), ("cert_cloud", vp)]
+                ("frame", vp), ("pose_search_out", vp), ("rmax", vp), ("dcum", vp), ("dcum_stride", i64), ("cert_cloud", vp), ("w_copied", i32)]
 
 
 class LoopBuffers(ctypes.Structure):

@@ -1716,7 +1716,8 @@ __global__ __launch_bounds__(BLOCK, (CERT && sizeof(T) == 4) ? 5 : 1) void accum
                                                            const int32_t* __restrict__ idx, const T* __restrict__ pose,
                                                            const T* __restrict__ w_init, const T* __restrict__ alive,
                                                            int N, int n, int m, int bpc, T* __restrict__ partials,
-                                                           T* __restrict__ w_out, long w_stride, const int32_t* __restrict__ src_rows, PointSearch<T> ps) {
+                                                           T* __restrict__ w_out, long w_stride, const int32_t* __restrict__ src_rows, PointSearch<T> ps,
+                                                           const T* __restrict__ w_prev /* optional: a frozen cloud (alive = 0) keeps its previous weights, ICP.py:224-226 */) {
     __shared__ T red[(BLOCK / WAVE) * NACC_PAD];
     int cloud, blk;
     if (!decode_block(bpc, N, cloud, blk)) return;
@@ -1779,7 +1780,9 @@ __global__ __launch_bounds__(BLOCK, (CERT && sizeof(T) == 4) ? 5 : 1) void accum
         if (MODE == MODE_PT2PL) { nrm[0] = yp[3]; nrm[1] = yp[4]; nrm[2] = yp[5]; }
         PointState<T> s;
         point_forward<T, MODE>(P, C, r, p, y, nrm, (w_init ? w_init[pt] : T(1)) * live, acc, s);
-        if (w_out) w_out[(size_t)cloud * w_stride + i] = s.w;
+        // (a frozen cloud: all its weights are zero, and the reference then keeps the previous iteration's -- written here, by 1024 threads per
+        //  block instead of the step kernel's one wave per cloud: 97 us of every tolerance-mode iteration at the benchmark shape)
+        if (w_out) w_out[(size_t)cloud * w_stride + i] = (w_prev && live == T(0)) ? w_prev[(size_t)cloud * w_stride + i] : s.w;
     }
     block_reduce_store<T, NACC, NACC_PAD>(acc, partials + ((size_t)cloud * bpc + blk) * NACC_PAD, red);
 }
@@ -1807,6 +1810,7 @@ __host__ __device__ inline dicp_step_io make_step_io(const dicp_loop_buffers& B,
     io.n_not_converged = B.counters + k;
     io.rmax = B.rmax; io.dcum = B.dcum; io.dcum_stride = 2 * (B.K + 1);
     io.cert_cloud = B.cert_cloud;
+    io.w_copied = 0;
     return io;
 }
 
@@ -1914,7 +1918,7 @@ __device__ __forceinline__ void step_body(const dicp_step_io& io, int cloud, int
             alive_next = T(0);
         }
         ((T*)io.alive_out)[cloud] = alive_next;
-        s_copy = (io.w_cur && io.w_prev && sacc[ACC_SUMW] == 0.0) ? 1 : 0;   // ICP.py:224-226
+        s_copy = (io.w_cur && io.w_prev && sacc[ACC_SUMW] == 0.0 && !(io.w_copied && alive_in == T(0))) ? 1 : 0;   // ICP.py:224-226
         if (io.cert_cloud) {
             // Match certificates must never cost more than searching everything.  What this iteration searched again for this cloud --
             // whole units (a certifying search of a unit costs ~1.3 plain ones) and single queries (one wave per query: ~0.2 of a unit's
@@ -3821,7 +3825,7 @@ static int check_params(const dicp_weight_params* p, int c) {
 // (ca: the certified iterations of the sweep loop -- idx is then ca->spos)
 static int accumulate_go(int dtype, const dicp_weight_params* prm, const void* src, const void* tgt, int c,
                          const int32_t* idx, const void* pose, const void* w_init, const void* alive, const int32_t* src_rows,
-                         int N, int n, int m, void* partials, void* w_out, int64_t w_stride, void* stream, const CertAcc* ca) {
+                         int N, int n, int m, void* partials, void* w_out, int64_t w_stride, void* stream, const CertAcc* ca, const void* w_prev = nullptr) {
     if (const int e = check_params(prm, c)) return e;
     if (!src || !tgt || !partials) return DICP_ERR_NULL;       // (w_init == NULL: unit weights)
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
@@ -3834,7 +3838,7 @@ static int accumulate_go(int dtype, const dicp_weight_params* prm, const void* s
     hipEvent_t ev0, ev1;
     take_launch_events(ev0, ev1);                                       // (null unless a timed loop set them for this launch)
 #define DICP_ACC(T, M, CERT, PS) hipExtLaunchKernelGGL((accumulate_kernel<T, M, CERT>), dim3(g), dim3(BLOCK), 0, st, ev0, ev1, 0, P, (const T*)src, (const T*)tgt, c, idx, (const T*)pose, \
-        (const T*)w_init, (const T*)alive, N, n, m, bpc, (T*)partials, (T*)w_out, (long)w_stride, src_rows, PS)
+        (const T*)w_init, (const T*)alive, N, n, m, bpc, (T*)partials, (T*)w_out, (long)w_stride, src_rows, PS, (const T*)w_prev)
 #define DICP_ACC_T(T) do { \
         PointSearch<T> ps{}; \
         if (ca) { \
@@ -4180,6 +4184,7 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
         const char* pose_s = B->poses_search ? (const char*)B->poses_search + (size_t)k * N * 12 * es : pose_k;
         int32_t* idx_k = B->idx ? B->idx + (B->idx_per_iter ? (size_t)k * N * n : 0) : nullptr;
         char* w_k = (char*)B->w + (size_t)k * B->w_iter * es;       // cloud stride B->w_stride: (N,K,n) or (K,N,n) alike
+        const char* w_prev_k = k > k0 ? (const char*)B->w + (size_t)(k - 1) * B->w_iter * es : (const char*)B->w_prev0;     // (as make_step_io)
         const char* alive_k = (const char*)B->alive + (size_t)k * N * es;
         if (B->events) {    // the sweep launch carries its two events itself; the brute-force forms are bracketed by records
             if (kind == DICP_KNN_SWEEP) set_launch_events((hipEvent_t)B->events[6 * k + 0], (hipEvent_t)B->events[6 * k + 1]);
@@ -4224,12 +4229,12 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
                                  B->cert_q, B->cert_qu, fresh ? nullptr : B->dcum, 2 * (B->K + 1), k, count_k,
                                  spos_k, (B->idx_per_iter && k + 1 < k1) ? spos_k + (size_t)N * n : nullptr, B->cert_cloud};
                 rc = accumulate_go(dtype, prm, B->src, B->tgt_sorted, B->tgt_sorted_stride, spos_k, pose_k, B->w_init, alive_k, B->src_rows, N, n, B->m_pad,
-                                   B->partials, w_k, B->w_stride, stream, &ca);
+                                   B->partials, w_k, B->w_stride, stream, &ca, w_prev_k);
             } else if (sorted_rows)
-                rc = dicp_accumulate(dtype, prm, B->src, B->tgt_sorted, B->tgt_sorted_stride, spos_k, pose_k, B->w_init, alive_k, B->src_rows, N, n, B->m_pad,
-                                     B->partials, w_k, B->w_stride, stream);
+                rc = accumulate_go(dtype, prm, B->src, B->tgt_sorted, B->tgt_sorted_stride, spos_k, pose_k, B->w_init, alive_k, B->src_rows, N, n, B->m_pad,
+                                   B->partials, w_k, B->w_stride, stream, nullptr, w_prev_k);
             else
-                rc = dicp_accumulate(dtype, prm, B->src, B->tgt, B->c, idx_k, pose_k, B->w_init, alive_k, B->src_rows, N, n, m, B->partials, w_k, B->w_stride, stream);
+                rc = accumulate_go(dtype, prm, B->src, B->tgt, B->c, idx_k, pose_k, B->w_init, alive_k, B->src_rows, N, n, m, B->partials, w_k, B->w_stride, stream, nullptr, w_prev_k);
             set_launch_events(nullptr, nullptr);
             if (rc) return rc;
         } else {
@@ -4239,11 +4244,12 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
                 if (hipEventRecord((hipEvent_t)B->events[6 * k + 1], st) != hipSuccess) return -(int)hipGetLastError();
                 set_launch_events((hipEvent_t)B->events[6 * k + 2], (hipEvent_t)B->events[6 * k + 3]);
             }
-            rc = dicp_accumulate(dtype, prm, B->src, B->tgt, B->c, idx_k, pose_k, B->w_init, alive_k, B->src_rows, N, n, m, B->partials, w_k, B->w_stride, stream);
+            rc = accumulate_go(dtype, prm, B->src, B->tgt, B->c, idx_k, pose_k, B->w_init, alive_k, B->src_rows, N, n, m, B->partials, w_k, B->w_stride, stream, nullptr, w_prev_k);
             set_launch_events(nullptr, nullptr);
             if (rc) return rc;
         }
         dicp_step_io io = make_step_io(*B, k, k0, N, n, prm->mode, dim, const_iter, tolerance, es, nblk);
+        io.w_copied = w_prev_k ? 1 : 0;
         rc = dicp_step(dtype, &io, N, stream);
         if (rc) return rc;
     }

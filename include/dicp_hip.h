@@ -213,6 +213,8 @@ typedef struct dicp_step_io {
     int64_t dcum_stride;
     int32_t* cert_cloud;     /* optional (N,8): per-cloud counters of the match certificates (dicp_loop_buffers.cert_cloud); the step decides
                                 from them whether the cloud's certificates stay on */
+    int32_t w_copied;        /* 1: the accumulate launch of this iteration already wrote w_prev into w_cur for the clouds that are frozen (alive = 0;
+                                dicp_icp_forward does): the step then has nothing to copy for them (ICP.py:224-226) */
 } dicp_step_io;
 
 /* Reduce the partials, solve the 6x6 (3x3 for dim 2) system (ICP.py:200-201), update the

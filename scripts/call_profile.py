@@ -13,7 +13,8 @@ n = 16384
 src, tgt = (make_scene_pairs if kind == "scene" else make_pairs)(B, n, n, seed=3)
 src, tgt = src.cuda(), tgt.cuda()
 T0 = torch.eye(4, device="cuda").repeat(B, 1, 1)
-icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12); icp.const_iter = True
+TOL = os.environ.get("DICP_TOL")            # DICP_TOL=1e-4: a tolerance-mode call (up to K iterations, const_iter off)
+icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=float(TOL) if TOL else 1e-12); icp.const_iter = TOL is None
 icp.reuse_matches = os.environ.get("DICP_REUSE", "1") == "1"          # (DICP_REUSE=0: search everything in every iteration)
 icp.cert_backoff = os.environ.get("DICP_BACKOFF", "1") == "1"
 for _ in range(calls):
@@ -22,6 +23,7 @@ for _ in range(calls):
     out["T"].sum().backward()
     torch.cuda.synchronize()
 print("certificates %s, per-cloud switch %s; off for %s clouds" % (icp.reuse_matches, icp.cert_backoff, int(icp.knn_stats["certs_off"].sum()) if "certs_off" in icp.knn_stats else None))
+K = int(out["deltas"].shape[1])
 pairs = float(icp.knn_stats["knn_pairs"].sum().item()) / K / (float(B) * n * n)
 again = icp.knn_stats.get("searched_again")
 print("%s K=%d B=%d: pairs scored %.2f %% of n*m per launch; units / queries searched again per iteration: %s / %s; backward live: %s" % (

@@ -18,7 +18,7 @@ import torch
 import yaml
 
 from . import _lib
-from ._ops import ICPLoop, KabschLoop, LoopConfig, compute_device, icp_loop_gumbel, prebuild_search, transform_points
+from ._ops import ICPLoop, KabschLoop, LoopConfig, compute_device, prebuild_search, transform_points
 from .nn import nn
 
 
@@ -122,14 +122,10 @@ class ICP:
             knn_variant=self.knn_variant, bwd_window=bool(self.bwd_window), stats_out=self.knn_stats,
             sync_every=self.sync_every, timing_events=self._timing_events, prebuilt=prebuilt, small_loop=bool(self.small_loop),
             src_rows=src_rows, tgt_rows=tgt_rows, sweep_resort=tuple(int(v) for v in self.sweep_resort), reuse_matches=bool(self.reuse_matches), cert_from=self.cert_from,
-            bwd_skip_eps=self.bwd_skip_eps, cert_backoff=bool(self.cert_backoff), plan_call=bool(self.plan_call), bwd_tail=bool(self.bwd_tail))
-        if self.nn.differentiable and self.nn.use_gumbel:                                # nn.py:14-16 via ICP.py:140
-            # soft correspondences carry gradient themselves: one autograd node per iteration instead of one per call
-            T, deltas, weights, costs, converged, iterations, matched = icp_loop_gumbel(
-                source, target, T_init, w_pts, cfg, self.nn.eps, self.nn.tau, inject_U=getattr(self.nn, "_inject_U", None))
-            pc = transform_points(source, T)                                             # ICP.py:274, with the graph running through T
-        else:
-            T, pc, deltas, weights, costs, converged, iterations, matched = ICPLoop.apply(source, target, T_init, w_pts, cfg)
+            bwd_skip_eps=self.bwd_skip_eps, cert_backoff=bool(self.cert_backoff), plan_call=bool(self.plan_call), bwd_tail=bool(self.bwd_tail),
+            # nn.py:14-16 via ICP.py:140: soft correspondences -- the same library loop with dicp_gumbel_nn in place of the search, the same one node
+            gumbel=(self.nn.eps, self.nn.tau, getattr(self.nn, "_inject_U", None)) if (self.nn.differentiable and self.nn.use_gumbel) else None)
+        T, pc, deltas, weights, costs, converged, iterations, matched = ICPLoop.apply(source.contiguous(), target.contiguous(), T_init, w_pts, cfg)
 
         if per_cloud_w:
             # an (N,1) weight stays (N,1) in the reference, so its "matches at the start" (ICP.py:248,269: sum over dim 1 of

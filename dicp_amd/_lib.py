@@ -17,7 +17,7 @@ HEADERS = [os.path.join(_HERE, "csrc", "dicp_math.h"), os.path.join(_ROOT, "incl
 F32, F64 = 0, 1
 PT2PT, PT2PL = 0, 1
 LOSS_NONE, LOSS_HUBER, LOSS_CAUCHY, LOSS_TRIM = 0, 1, 2, 3
-KNN_AUTO, KNN_VALU, KNN_MFMA, KNN_SWEEP = 0, 1, 2, 3
+KNN_AUTO, KNN_VALU, KNN_MFMA, KNN_SWEEP, KNN_GUMBEL = 0, 1, 2, 3, 4
 NACC_PAD, NBWD_PAD, KAB_SAVE = 32, 16, 40
 PAIR_SHARDS, SWEEP_SRC_SORTED = 64, 0x100      # DICP_PAIR_SHARDS, DICP_SWEEP_SRC_SORTED
 ABI_VERSION = 5
@@ -52,7 +52,12 @@ class LoopBuffers(ctypes.Structure):
                 ("partials", vp), ("counters", vp), ("events", vp), ("bwd_overwrite", i32), ("frame", vp), ("poses_search", vp),
                 ("src_rows", vp), ("tgt_rows", vp), ("cert_q", vp), ("cert_qu", vp), ("cert_count", vp), ("rmax", vp), ("dcum", vp),
                 ("cert_reset", i32), ("cert_cloud", vp), ("spos_prev0", vp), ("tgt_sorted", vp), ("tgt_sorted_stride", i32),
-                ("bwd_skip", vp), ("bwd_mref", vp), ("bwd_live", vp), ("bwd_skip_eps", f64), ("bwd_tail_from", i32), ("bwd_tail_partials", vp), ("bwd_tail_arrive", vp)]
+                ("bwd_skip", vp), ("bwd_mref", vp), ("bwd_live", vp), ("bwd_skip_eps", f64), ("bwd_tail_from", i32), ("bwd_tail_partials", vp), ("bwd_tail_arrive", vp), ("gumbel", vp)]
+
+
+class GumbelLoop(ctypes.Structure):
+    """dicp_gumbel_loop (include/dicp_hip.h)."""
+    _fields_ = [("U", vp), ("seeds", vp), ("eps", f64), ("tau", f64), ("ps_t", vp), ("nbr", vp), ("lse", vp), ("g_nbr", vp), ("g_ps", vp)]
 
 
 MAX_SEGMENTS = 16

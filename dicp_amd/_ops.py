@@ -453,6 +453,7 @@ class LoopConfig:
     prebuilt: object = None       # (target, SweepIndex) started by the caller before its own host work (prebuild_search)
     small_loop: bool = True       # small clouds: one block runs a cloud's whole chunk of iterations (icp_small_* kernels)
     cert_from: object = None      # iteration of the certifying search (None: the last re-ordering of the queries)
+    gumbel: object = None         # (eps, tau, inject_U or None): the Gumbel-softmax correspondence (nn.py:43-70) instead of the nearest neighbour
     bwd_tail: bool = True         # truncated reverse sweep: the iterations before the ones the previous call still worked at run as ONE launch (dicp_loop_buffers.bwd_tail_from)
     plan_call: bool = True        # constant-iteration sweep calls: all segments behind one library call (dicp_icp_forward_plan)
     cert_backoff: bool = True     # match certificates are switched off per cloud, on device, when a certified iteration costs more than 60 % of a full search
@@ -555,7 +556,9 @@ class ICPLoop(torch.autograd.Function):
         with _on(dev):
             st = _stream()
             kind = cfg.knn_variant & 0xff
-            if kind == _lib.KNN_AUTO:
+            if cfg.gumbel is not None:
+                kind = _lib.KNN_GUMBEL
+            elif kind == _lib.KNN_AUTO:
                 kind = auto_knn_kind(N, n, m)
             owned = kind == _lib.KNN_SWEEP and need_grad and cfg.bwd_window
             sweep = None
@@ -567,9 +570,10 @@ class ICPLoop(torch.autograd.Function):
                 else:
                     sweep = SweepIndex(tgt, sorted_rows=True, frame=search_frame(tgt, tgt_rows=cfg.tgt_rows), tgt_rows=cfg.tgt_rows)
             # the searches run in the target cloud's search frame (dicp_search_frame): packed rows Q y + t, pose [Q C | Q r + t]
-            center = sweep.frame if sweep is not None else search_frame(tgt, tgt_rows=cfg.tgt_rows)
-            tgt4 = sweep.tgs4 if sweep is not None else pack_target(tgt, center, cfg.tgt_rows)
-            m_pad = tgt4.shape[1]
+            soft = kind == _lib.KNN_GUMBEL        # soft correspondences: no search structure at all
+            center = sweep.frame if sweep is not None else (None if soft else search_frame(tgt, tgt_rows=cfg.tgt_rows))
+            tgt4 = sweep.tgs4 if sweep is not None else (None if soft else pack_target(tgt, center, cfg.tgt_rows))
+            m_pad = tgt4.shape[1] if tgt4 is not None else 0
             nblk = lib.dicp_accumulate_blocks(n)
             poses = torch.empty((Kmax + 1, N, 12), dtype=dt, device=dev)
             poses_c = torch.empty((Kmax + 1, N, 12), dtype=dt, device=dev) if center is not None else None   # [Q C | Q r + t]: what the searches read
@@ -589,7 +593,7 @@ class ICPLoop(torch.autograd.Function):
             # match certificates (sweep path): a motion budget per query, a filter value per unit of the sweep, per-cloud motion bounds, and
             # what each iteration searched again.  The searches before the LAST re-ordering of the queries run plain (a certifying search costs
             # a quarter more, and its budgets would not survive the steps of the first iterations).
-            keep_idx = sweep is None or (need_grad and not owned)     # (original indices: the brute-force searches and the atomic backward)
+            keep_idx = (sweep is None or (need_grad and not owned)) and not soft     # (original indices: the brute-force searches and the atomic backward)
             # (the one certifying search costs a quarter more than a plain one: it takes three certified iterations to be worth it)
             resorts = [k for k in cfg.sweep_resort if 0 <= k < Kmax]
             cert_from = (max(resorts) if resorts else 0) if cfg.cert_from is None else max(0, int(cfg.cert_from))     # iteration of the certifying search
@@ -629,6 +633,20 @@ class ICPLoop(torch.autograd.Function):
             ev = cfg.timing_events
             events = ev.handles(Kmax) if ev is not None else None
 
+            gum = None
+            if soft:    # Gumbel-softmax correspondences: the neighbour ROWS of every iteration and their log-sum-exp are the history the reverse sweep reads
+                g_eps, g_tau, inject_U = cfg.gumbel
+                nbr_hist = torch.empty((Kmax, N, n, c), dtype=dt, device=dev)
+                lse_hist = torch.empty((Kmax, N, n), dtype=dt, device=dev)
+                ps_t = torch.empty((N, n, 3), dtype=dt, device=dev)
+                U_list = [u.to(device=dev, dtype=dt).contiguous() for u in inject_U[:Kmax]] if inject_U is not None else None
+                assert U_list is None or len(U_list) >= Kmax, "one injected noise tensor per iteration"
+                U_arr = (ctypes.c_void_p * Kmax)(*[u.data_ptr() for u in U_list]) if U_list is not None else None
+                # in-kernel noise: one seed per iteration from torch's CPU generator (torch.manual_seed makes a call reproducible)
+                seed_list = [int(v) & 0xFFFFFFFF for v in torch.randint(0, 2 ** 31 - 1, (Kmax,)).tolist()] if U_list is None else [0] * Kmax
+                seeds = (ctypes.c_uint32 * Kmax)(*seed_list)
+                gum = _lib.GumbelLoop(U=ctypes.cast(U_arr, ctypes.c_void_p) if U_arr is not None else None, seeds=ctypes.cast(seeds, ctypes.c_void_p),
+                                      eps=float(g_eps), tau=float(g_tau), ps_t=_p(ps_t), nbr=_p(nbr_hist), lse=_p(lse_hist))
             qorders, seg_q = [], []          # distinct query orders of the sweep and which one each segment used
             qorder = None
             K = Kmax
@@ -719,6 +737,8 @@ class ICPLoop(torch.autograd.Function):
                         w_iter=n, w_stride=kc * n,
                         partials=_p(partials), counters=_p(counters), events=events, frame=_p(center), poses_search=_p(poses_c),
                         src_rows=_p(cfg.src_rows), tgt_rows=_p(cfg.tgt_rows))
+                    if gum is not None:
+                        LB.gumbel = ctypes.cast(ctypes.pointer(gum), ctypes.c_void_p)
                     LBref = ctypes.byref(LB)
                 LB.qorder = _p(qorder)
                 LB.spos = ctypes.c_void_p(spos_slabs[j].data_ptr() - base * N * n * 4) if keep_spos else _p(spos_once)
@@ -772,8 +792,11 @@ class ICPLoop(torch.autograd.Function):
 
         if need_grad:
             saved = [src, tgt, w0c, poses, deltas, areg, alive] + idx_slabs + spos_slabs + qorders + ([sweep.tperm, sweep.tgt_s] if owned else [])
+            if soft:
+                saved += [nbr_hist, lse_hist] + (U_list if U_list is not None else [])
             ctx.save_for_backward(*saved)
             ctx.cfg, ctx.K, ctx.P, ctx.Kmax = cfg, K, P, Kmax
+            ctx.soft = (float(g_eps), float(g_tau), seed_list, len(U_list) if U_list is not None else 0) if soft else None
             ctx.layout = (len(idx_slabs), len(spos_slabs), len(qorders), kc, owned, m_pad, kind,
                           [(a, min(b, K), q) for (a, b), q in zip(done_segs, seg_q) if a < K])
         conv = converged.bool()
@@ -788,6 +811,9 @@ class ICPLoop(torch.autograd.Function):
         idx_slabs, spos_slabs = rest[:n_idx], rest[n_idx:n_idx + n_spos]
         qorders = rest[n_idx + n_spos:n_idx + n_spos + n_q]
         tperm, tgt_s = (rest[-2], rest[-1]) if owned else (None, None)
+        soft = getattr(ctx, "soft", None)
+        if soft is not None:    # Gumbel-softmax correspondences: neighbour rows and log-sum-exp of every iteration (+ the injected noise)
+            nbr_hist, lse_hist, *U_list = rest[n_idx + n_spos + n_q:]
         lib = _lib.load()
         dev, dt = src.device, src.dtype
         code, es = _DT[dt], src.element_size()
@@ -850,7 +876,7 @@ class ICPLoop(torch.autograd.Function):
             eps = cfg.bwd_skip_eps
             if eps is None:
                 eps = 2.0 ** -22 if dt == torch.float32 else 2.0 ** -40
-            if cfg.loss_name == "huber" and not cfg.differentiable:
+            if (cfg.loss_name == "huber" and not cfg.differentiable) or soft is not None:    # (soft correspondences carry gradient themselves: nothing contracts the chain)
                 eps = 0.0
             skip = None
             if eps > 0.0:
@@ -872,6 +898,15 @@ class ICPLoop(torch.autograd.Function):
                 if hint is not None and hint[2] == (N, n, K) and hint[1].query():
                     live = hint[0][:K].tolist()
                     tail_from = max(0, next((k for k in range(K) if live[k] * 8 >= N), K) - 1)      # (most sweeps have ended BEFORE the one launch starts)
+            gum = None
+            if soft is not None:
+                g_eps, g_tau, seed_list, n_u = soft
+                U_arr = (ctypes.c_void_p * Kmax)(*[u.data_ptr() for u in U_list[:Kmax]]) if n_u else None
+                seeds = (ctypes.c_uint32 * Kmax)(*seed_list)
+                ps_t, g_ps = torch.empty((N, n, 3), dtype=dt, device=dev), torch.empty((N, n, 3), dtype=dt, device=dev)
+                g_nbr = torch.empty((N, n, c), dtype=dt, device=dev)
+                gum = _lib.GumbelLoop(U=ctypes.cast(U_arr, ctypes.c_void_p) if U_arr is not None else None, seeds=ctypes.cast(seeds, ctypes.c_void_p),
+                                      eps=g_eps, tau=g_tau, ps_t=_p(ps_t), nbr=_p(nbr_hist), lse=_p(lse_hist), g_nbr=_p(g_nbr), g_ps=_p(g_ps))
             have, form, fresh = 0, None, 1
             # neighbouring segments of one form inside one history slab run as ONE library call (the forward cut them where the host had to
             # act -- a new query order, a convergence check -- and none of that concerns the reverse sweep)
@@ -907,7 +942,8 @@ class ICPLoop(torch.autograd.Function):
                     bwd_overwrite=fresh if (w_form and k1 > k0) else 0, src_rows=_p(cfg.src_rows), tgt_rows=_p(cfg.tgt_rows),
                     bwd_skip=_p(skip[1]) if skip else None, bwd_mref=_p(skip[0]) if skip else None, bwd_live=_p(skip[2]) if skip else None,
                     bwd_skip_eps=float(eps), bwd_tail_from=int(tail_from) if (w_form and k0 == 0) else 0,
-                    bwd_tail_partials=_p(tail_part), bwd_tail_arrive=_p(skip[3]) if skip else None)
+                    bwd_tail_partials=_p(tail_part), bwd_tail_arrive=_p(skip[3]) if skip else None,
+                    gumbel=ctypes.cast(ctypes.pointer(gum), ctypes.c_void_p) if gum is not None else None)
                 fresh_was = bool(w_form and k1 > k0 and fresh)
                 if w_form and k1 > k0:
                     fresh = 0
@@ -1057,133 +1093,3 @@ class KabschLoop(torch.autograd.Function):
         return gsrc, gtgt, None, gw, None, None, None, None, None, None, None, None
 
 
-class _RowsIteration(torch.autograd.Function):
-    """One ICP iteration on explicit per-point neighbour rows (the soft correspondences of the Gumbel path):
-    dicp_accumulate (idx = NULL) -> dicp_step, with dicp_step_bwd -> dicp_accumulate_bwd as its backward.
-    Unlike ICPLoop this is ONE node per iteration, because the neighbours themselves carry gradient
-    (to the transformed source and to the target) through the soft-kNN node upstream.
-    Inputs : source (N,n,3), nbr (N,n,c), pose (N,12), w0 (N,n); `st` = per-call bookkeeping tensors.
-    Outputs: pose_next (N,12) [differentiable]; delta (N,6), cost (N), w (N,n) [not differentiable]."""
-
-    @staticmethod
-    def forward(ctx, source, nbr, pose, w0, st, cfg, k):
-        lib = _lib.load()
-        dev, dt = source.device, source.dtype
-        code = _DT[dt]
-        N, n, _ = source.shape
-        c = nbr.shape[2]
-        src, rows, pose_in, w0c = source.contiguous(), nbr.contiguous(), pose.contiguous(), w0.contiguous()
-        P = cfg.params()
-        nblk = lib.dicp_accumulate_blocks(n)
-        with _on(dev):
-            stream = _stream()
-            partials = torch.empty((N, nblk, _lib.NACC_PAD), dtype=dt, device=dev)
-            wk = torch.empty((N, n), dtype=dt, device=dev)
-            alive_k = st["alive"].clone()
-            _lib.check(lib.dicp_accumulate(code, ctypes.byref(P), _p(src), _p(rows), c, None, _p(pose_in), _p(w0c), _p(st["alive"]), None,
-                                           N, n, n, _p(partials), _p(wk), n, stream), "dicp_accumulate")
-            pose_out = torch.empty((N, 12), dtype=dt, device=dev)
-            delta = torch.empty((N, 6), dtype=dt, device=dev)
-            cost = torch.empty((N,), dtype=dt, device=dev)
-            areg = torch.empty((N, 36), dtype=torch.float64, device=dev)
-            io = _lib.StepIO(
-                partials=_p(partials), nblk=nblk, iter=k, dim=int(cfg.dim), const_iter=int(cfg.const_iter),
-                tolerance=float(cfg.tolerance), rows_per_point=3 if cfg.icp_type == "pt2pt" else 1, n=n,
-                pose_in=_p(pose_in), pose_out=_p(pose_out), delta=_p(delta), delta_stride=6,
-                cost=_p(cost), cost_prev=_p(st["cost_prev"]), cost_stride=1, areg=_p(areg), alive=_p(st["alive"]), alive_out=_p(st["alive"]),
-                converged=_p(st["converged"]), iterations=_p(st["iterations"]), matched_ratio=_p(st["matched"]),
-                n_start=_p(st["n_start"]), n_matched=_p(st["n_matched"]), w_cur=_p(wk), w_prev=_p(st["w_prev"]), w_stride=n,
-                n_not_converged=ctypes.c_void_p(st["counters"].data_ptr() + 4 * k))
-            _lib.check(lib.dicp_step(code, ctypes.byref(io), N, stream), "dicp_step")
-        ctx.save_for_backward(src, rows, pose_in, w0c, alive_k, delta, areg)
-        ctx.cfg, ctx.P = cfg, P
-        ctx.mark_non_differentiable(delta, cost, wk)
-        return pose_out, delta, cost, wk
-
-    @staticmethod
-    def backward(ctx, gpose_out, *_unused):
-        src, rows, pose_in, w0c, alive_k, delta, areg = ctx.saved_tensors
-        cfg, P = ctx.cfg, ctx.P
-        lib = _lib.load()
-        dev, dt = src.device, src.dtype
-        code = _DT[dt]
-        N, n, _ = src.shape
-        c = rows.shape[2]
-        nblk = lib.dicp_accumulate_blocks(n)
-        with _on(dev):
-            stream = _stream()
-            gin = gpose_out.to(torch.float64).contiguous()
-            gs = torch.empty((N, 36), dtype=dt, device=dev)
-            gb = torch.empty((N, 6), dtype=dt, device=dev)
-            gpass = torch.empty((N, 12), dtype=torch.float64, device=dev)
-            _lib.check(lib.dicp_step_bwd(code, _p(gin), None, nblk, int(cfg.dim), _p(pose_in), _p(delta), 6, _p(areg),
-                                         _p(gs), _p(gb), _p(gpass), N, stream), "dicp_step_bwd")
-            gsrc = torch.zeros_like(src)
-            grows = torch.zeros_like(rows)
-            gw = torch.zeros_like(w0c)
-            bwdp = torch.empty((N, nblk, _lib.NBWD_PAD), dtype=dt, device=dev)
-            _lib.check(lib.dicp_accumulate_bwd(code, ctypes.byref(P), _p(src), _p(rows), c, None, _p(pose_in), _p(w0c), _p(alive_k),
-                                               _p(gs), _p(gb), None, N, n, n, _p(gsrc), _p(grows), _p(gw), _p(bwdp), stream), "dicp_accumulate_bwd")
-            gpose = (gpass + bwdp.sum(dim=1)[:, :12].to(torch.float64)).to(dt)
-        return gsrc, grows, gpose, gw, None, None, None
-
-
-def icp_loop_gumbel(source, target, T_init, w0, cfg, eps, tau, inject_U=None):
-    """ICP.dICP's loop (ICP.py:131-260) with the Gumbel-softmax correspondence (config functionality.gumbel):
-    per iteration  ps_t = C p + r  ->  dicp_gumbel_nn  ->  _RowsIteration.  Returns the same tuple as ICPLoop."""
-    for t, nm in ((source, "source"), (target, "target"), (T_init, "T_init"), (w0, "weight")):
-        require_device(t, "ICP(" + nm + ")")
-    dev, dt = source.device, source.dtype
-    N, n, _ = source.shape
-    rows = 3 if cfg.icp_type == "pt2pt" else 1
-    Kmax = int(cfg.max_iterations)
-    st = {
-        "alive": torch.ones((N,), dtype=dt, device=dev), "converged": torch.zeros((N,), dtype=torch.uint8, device=dev),
-        "iterations": torch.zeros((N,), dtype=dt, device=dev), "matched": torch.zeros((N,), dtype=dt, device=dev),
-        "n_matched": torch.zeros((N,), dtype=dt, device=dev),
-        "n_start": (torch.sum(w0.detach() > cfg.match_ratio_thresh, dim=1) * rows).to(dt),
-        "counters": torch.zeros((Kmax,), dtype=torch.int32, device=dev), "cost_prev": None, "w_prev": None,
-    }
-    pose = _pose_from_T(T_init)
-    deltas, costs, weights = [], [], []
-    K = 0
-    pending, host_cnt, poses_hist = None, None, []
-    for k in range(Kmax):
-        ps_t = _TransformPoints.apply(source, pose)                                # ICP.py:137 (dicp_transform_points; the pose carries gradient)
-        U = inject_U[k] if inject_U is not None else None
-        nbr = gumbel_nn(ps_t, target, eps, tau, U=U)                               # ICP.py:140 -> nn.py:43-70
-        pose, delta, cost, wk = _RowsIteration.apply(source, nbr, pose, w0, st, cfg, k)
-        st["cost_prev"], st["w_prev"] = cost, wk
-        deltas.append(delta)
-        costs.append(cost)
-        weights.append(wk)
-        poses_hist.append(pose)
-        K = k + 1
-        if not cfg.const_iter:
-            # ICP.py:259 without draining the GPU every iteration: iteration k's counter travels to pinned memory while iteration
-            # k+1 is enqueued, and is read one iteration later.  Converged clouds are frozen (alive = 0), so the one iteration
-            # enqueued past the stopping point moves nothing; it is trimmed from the histories below.
-            if pending is not None and _converged_at(pending) is not None:
-                K = _converged_at(pending)
-                pending = None
-                break
-            if host_cnt is None:
-                host_cnt = torch.empty((Kmax,), dtype=torch.int32, pin_memory=True)
-            host_cnt[k:k + 1].copy_(st["counters"][k:k + 1], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            pending = (k, k + 1, host_cnt, ev)
-    if pending is not None and _converged_at(pending) is not None:
-        K = _converged_at(pending)
-    deltas, costs, weights = deltas[:K], costs[:K], weights[:K]
-    pose = poses_hist[K - 1]
-    iterations = torch.where(st["iterations"] == 0, torch.full_like(st["iterations"], K), st["iterations"])
-    start = (st["n_start"] * (st["alive"] != 0)).to(torch.int64)
-    start[start == 0] = 1
-    ratio = st["n_matched"].to(torch.int64) / start
-    matched = torch.where(st["matched"] == 0, ratio.to(dt), st["matched"])
-    T = torch.zeros((N, 4, 4), dtype=dt, device=dev)
-    T[:, 3, 3] = 1.0
-    T = T + torch.nn.functional.pad(torch.cat((pose[:, :9].reshape(N, 3, 3), pose[:, 9:, None]), dim=2), (0, 0, 0, 1))
-    return (T, torch.stack(deltas, dim=1), torch.stack(weights, dim=1), torch.stack(costs, dim=1),
-            st["converged"].bool(), iterations, matched)

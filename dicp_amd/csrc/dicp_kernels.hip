@@ -3273,7 +3273,7 @@ template <typename T, int C>
 __global__ __launch_bounds__(BLOCK) void gumbel_bwd_t_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ U,
                                                              unsigned seed, T eps, T inv_tau, const T* __restrict__ out,
                                                              const T* __restrict__ lse, const T* __restrict__ gout, T* __restrict__ gy,
-                                                             int N, int n, int m, int bpc) {
+                                                             int N, int n, int m, int bpc, int add /* 1: gy += (a loop's iterations add up) */) {
     constexpr int R = C + 5;
     __shared__ T tq[GUM_TILE * R];
     int cloud, blk;
@@ -3314,7 +3314,7 @@ __global__ __launch_bounds__(BLOCK) void gumbel_bwd_t_kernel(const T* __restrict
     }
     if (on) {
 #pragma unroll
-        for (int k = 0; k < C; ++k) gy[tj * C + k] = g[k];
+        for (int k = 0; k < C; ++k) gy[tj * C + k] = add ? gy[tj * C + k] + g[k] : g[k];
     }
 }
 
@@ -3510,8 +3510,10 @@ __global__ __launch_bounds__(BLOCK) void transform_kernel(const T* __restrict__ 
 
 template <typename T>
 __global__ __launch_bounds__(BLOCK) void transform_bwd_kernel(const T* __restrict__ src, const T* __restrict__ pose, const T* __restrict__ gout,
-                                                              T* __restrict__ gsrc, T* __restrict__ partials, int N, int n, int bpc) {
+                                                              T* __restrict__ gsrc, T* __restrict__ partials, int N, int n, int bpc,
+                                                              int add /* 1: gsrc and partials are added to */) {
     __shared__ T red[(BLOCK / WAVE) * NBWD_PAD];
+    __shared__ T sums[NBWD_PAD];
     int cloud, blk;
     if (!decode_block(bpc, N, cloud, blk)) return;
     T C[9], r[3];
@@ -3525,9 +3527,10 @@ __global__ __launch_bounds__(BLOCK) void transform_bwd_kernel(const T* __restric
         const T p[3] = {src[pt], src[pt + 1], src[pt + 2]};
         const T g[3] = {gout[pt], gout[pt + 1], gout[pt + 2]};
         if (gsrc) {
-            gsrc[pt]     = C[0] * g[0] + C[3] * g[1] + C[6] * g[2];
-            gsrc[pt + 1] = C[1] * g[0] + C[4] * g[1] + C[7] * g[2];
-            gsrc[pt + 2] = C[2] * g[0] + C[5] * g[1] + C[8] * g[2];
+            const T v0 = C[0] * g[0] + C[3] * g[1] + C[6] * g[2], v1 = C[1] * g[0] + C[4] * g[1] + C[7] * g[2], v2 = C[2] * g[0] + C[5] * g[1] + C[8] * g[2];
+            gsrc[pt]     = add ? gsrc[pt] + v0 : v0;
+            gsrc[pt + 1] = add ? gsrc[pt + 1] + v1 : v1;
+            gsrc[pt + 2] = add ? gsrc[pt + 2] + v2 : v2;
         }
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -3536,7 +3539,11 @@ __global__ __launch_bounds__(BLOCK) void transform_bwd_kernel(const T* __restric
             acc[9 + a] += g[a];
         }
     }
-    block_reduce_store<T, NBWD, NBWD_PAD>(acc, partials + ((size_t)cloud * bpc + blk) * NBWD_PAD, red);
+    T* out = partials + ((size_t)cloud * bpc + blk) * NBWD_PAD;
+    if (!add) { block_reduce_store<T, NBWD, NBWD_PAD>(acc, out, red); return; }
+    block_reduce_store<T, NBWD, NBWD_PAD>(acc, sums, red);
+    __syncthreads();
+    if (threadIdx.x < NBWD_PAD) out[threadIdx.x] += sums[threadIdx.x];
 }
 
 // ------------------------------------------------------------------ loss weights
@@ -4143,8 +4150,14 @@ int dicp_gumbel_nn(int dtype, const void* x, const void* y, int c, const void* U
     return launch_status();
 }
 
+static int gumbel_nn_bwd_go(int dtype, const void* x, const void* y, int c, const void* U, uint32_t seed, double eps, double tau,
+                            const void* out, const void* lse, const void* gout, int N, int n, int m, void* gx, void* gy, int add_gy, void* stream);
 int dicp_gumbel_nn_bwd(int dtype, const void* x, const void* y, int c, const void* U, uint32_t seed, double eps, double tau,
                        const void* out, const void* lse, const void* gout, int N, int n, int m, void* gx, void* gy, void* stream) {
+    return gumbel_nn_bwd_go(dtype, x, y, c, U, seed, eps, tau, out, lse, gout, N, n, m, gx, gy, 0, stream);
+}
+static int gumbel_nn_bwd_go(int dtype, const void* x, const void* y, int c, const void* U, uint32_t seed, double eps, double tau,
+                            const void* out, const void* lse, const void* gout, int N, int n, int m, void* gx, void* gy, int add_gy, void* stream) {
     if (!x || !y || !out || !lse || !gout || (!gx && !gy)) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || n <= 0 || m <= 0 || (c != 3 && c != 6) || !(tau > 0.0)) return DICP_ERR_SHAPE;
@@ -4153,7 +4166,7 @@ int dicp_gumbel_nn_bwd(int dtype, const void* x, const void* y, int c, const voi
     const int bq = (n + BLOCK - 1) / BLOCK, bt = (m + BLOCK - 1) / BLOCK;
 #define DICP_GB(T, C) do { \
         if (gx) gumbel_bwd_q_kernel<T, C><<<grid_for(N, bq), BLOCK, 0, st>>>((const T*)x, (const T*)y, (const T*)U, seed, (T)eps, (T)(1.0 / tau), (const T*)out, (const T*)lse, (const T*)gout, (T*)gx, N, n, m, bq); \
-        if (gy) gumbel_bwd_t_kernel<T, C><<<grid_for(N, bt), BLOCK, 0, st>>>((const T*)x, (const T*)y, (const T*)U, seed, (T)eps, (T)(1.0 / tau), (const T*)out, (const T*)lse, (const T*)gout, (T*)gy, N, n, m, bt); } while (0)
+        if (gy) gumbel_bwd_t_kernel<T, C><<<grid_for(N, bt), BLOCK, 0, st>>>((const T*)x, (const T*)y, (const T*)U, seed, (T)eps, (T)(1.0 / tau), (const T*)out, (const T*)lse, (const T*)gout, (T*)gy, N, n, m, bt, add_gy); } while (0)
     if (dtype == DICP_F32) { if (c == 6) DICP_GB(float, 6); else DICP_GB(float, 3); }
     else                   { if (c == 6) DICP_GB(double, 6); else DICP_GB(double, 3); }
 #undef DICP_GB
@@ -4347,6 +4360,7 @@ static bool small_loop_eligible(int dtype, int kind, int knn_variant, int n, int
     return lds <= 48 * 1024 && (long)n * m_pad <= SMALL_PAIRS;
 }
 
+static int transform_points_bwd_go(int dtype, const void* src, const void* pose, const void* gout, void* gsrc, void* partials, int N, int n, int add, void* stream);
 // ------------------------------------------------------------------ whole-loop entry points
 // The iteration loop of ICP.dICP (ICP.py:131-260) behind ONE call: K x { kNN -> accumulate -> step } are
 // enqueued back to back on the stream with every piece of per-iteration state in caller-allocated buffers
@@ -4356,16 +4370,18 @@ static bool small_loop_eligible(int dtype, int kind, int knn_variant, int n, int
 int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_buffers* B, int N, int n, int m,
                      int dim, int const_iter, double tolerance, int k0, int k1, void* stream) {
     if (!prm || !B || !B->src || !B->tgt || !B->poses || !B->deltas || !B->costs || !B->alive ||
-        !B->converged || !B->iterations || !B->matched_ratio || !B->n_start || !B->n_matched || (!B->idx && !B->spos) || !B->w ||
+        !B->converged || !B->iterations || !B->matched_ratio || !B->n_start || !B->n_matched || !B->w ||
         !B->partials || !B->counters) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (k0 < 0 || k1 > B->K || k0 > k1 || N <= 0 || n <= 0 || m <= 0 || B->w_stride < n || B->w_iter < n) return DICP_ERR_SHAPE;
     const size_t es = dtype == DICP_F32 ? 4 : 8;
     const int kind = B->knn_variant & 0xff;
-    if (kind == DICP_KNN_SWEEP ? (!B->tperm || !B->bucket || !B->brange) : !B->tgt4) return DICP_ERR_NULL;
+    const dicp_gumbel_loop* G = kind == DICP_KNN_GUMBEL ? B->gumbel : nullptr;
+    if (kind == DICP_KNN_GUMBEL) { if (!G || !G->ps_t || !G->nbr || !G->lse || (!G->U && !G->seeds)) return DICP_ERR_NULL; }
+    else if ((!B->idx && !B->spos) || (kind == DICP_KNN_SWEEP ? (!B->tperm || !B->bucket || !B->brange) : !B->tgt4)) return DICP_ERR_NULL;
     hipStream_t st = (hipStream_t)stream;
     const int nblk = dicp_accumulate_blocks(n);
-    if (small_loop_eligible(dtype, kind, B->knn_variant, n, B->m_pad) && k1 > k0) {
+    if (!G && small_loop_eligible(dtype, kind, B->knn_variant, n, B->m_pad) && k1 > k0) {
         // small clouds: the whole chunk is ONE launch, one block per cloud (bit 25 of knn_variant switches this off)
         if (const int e = check_params(prm, B->c)) return e;
         begin_launch();
@@ -4436,6 +4452,21 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
                 rc = accumulate_go(dtype, prm, B->src, B->tgt, B->c, idx_k, pose_k, B->w_init, alive_k, B->src_rows, N, n, m, B->partials, w_k, B->w_stride, stream, nullptr, w_prev_k);
             set_launch_events(nullptr, nullptr);
             if (rc) return rc;
+        } else if (G) {
+            // soft correspondences (nn.py:43-70 inside ICP.py:137-140): the neighbours are ROWS of their own, one per source point, kept per
+            // iteration for the reverse sweep together with the log-sum-exp that lets it rebuild the probabilities
+            char* nbr_k = (char*)G->nbr + (size_t)k * N * n * B->c * es;
+            char* lse_k = (char*)G->lse + (size_t)k * N * n * es;
+            rc = dicp_transform_points(dtype, B->src, pose_k, G->ps_t, N, n, stream);
+            if (!rc) rc = dicp_gumbel_nn(dtype, G->ps_t, B->tgt, B->c, G->U ? G->U[k] : nullptr, G->seeds ? G->seeds[k] : 0u, G->eps, G->tau, N, n, m, nbr_k, lse_k, stream);
+            if (rc) return rc;
+            if (B->events) {
+                if (hipEventRecord((hipEvent_t)B->events[6 * k + 1], st) != hipSuccess) return -(int)hipGetLastError();
+                set_launch_events((hipEvent_t)B->events[6 * k + 2], (hipEvent_t)B->events[6 * k + 3]);
+            }
+            rc = accumulate_go(dtype, prm, B->src, nbr_k, B->c, nullptr, pose_k, B->w_init, alive_k, nullptr, N, n, n, B->partials, w_k, B->w_stride, stream, nullptr, w_prev_k);
+            set_launch_events(nullptr, nullptr);
+            if (rc) return rc;
         } else {
             rc = dicp_knn(dtype, B->src, pose_s, B->tgt4, B->src_rows, B->tgt_rows, N, n, m, B->m_pad, idx_k, B->knn_variant & 0xffff, stream);
             if (rc) return rc;
@@ -4496,8 +4527,10 @@ int dicp_icp_forward_plan(int dtype, const dicp_weight_params* prm, const dicp_l
 int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_buffers* B, int N, int n, int m, int dim,
                       double* gpose, double* gpose_tmp, int have_partials, void* gs, void* gb, void* gsrc, void* gtgt, void* gw,
                       void* bwd_partials, int k0, int k1, void* stream) {
-    if (!prm || !B || !B->src || !B->tgt || !B->poses || !B->deltas || !B->areg || !B->alive || (!B->idx && !B->spos) || (gw && !B->w_init) ||
+    const dicp_gumbel_loop* G = (B && (B->knn_variant & 0xff) == DICP_KNN_GUMBEL) ? B->gumbel : nullptr;
+    if (!prm || !B || !B->src || !B->tgt || !B->poses || !B->deltas || !B->areg || !B->alive || (!G && !B->idx && !B->spos) || (gw && !B->w_init) ||
         !gpose || !gpose_tmp || !gs || !gb || !gsrc || !bwd_partials) return DICP_ERR_NULL;
+    if ((B->knn_variant & 0xff) == DICP_KNN_GUMBEL && (!G || !G->ps_t || !G->nbr || !G->lse || !G->g_nbr || !G->g_ps || (!G->U && !G->seeds))) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (k0 < 0 || k1 > B->K || k0 > k1 || !B->idx_per_iter || (B->spos && (B->m_pad <= 0 || !B->spos_ref))) return DICP_ERR_SHAPE;
     if (B->bwd_skip && (!B->bwd_mref || !(B->bwd_skip_eps >= 0.0))) return DICP_ERR_NULL;
@@ -4506,7 +4539,7 @@ int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_
     const int nblk = B->spos ? dicp_window_blocks(dtype, n, B->m_pad) : dicp_accumulate_blocks(n);
     {   // small clouds (atomic form only): the whole chunk is ONE launch, one block per cloud
         const size_t lds = (size_t)m * (prm->mode == DICP_PT2PL ? 6 : 3) * es;
-        if (!B->spos && k1 > k0 && B->m_pad > 0 && lds <= 40 * 1024 &&
+        if (!G && !B->spos && k1 > k0 && B->m_pad > 0 && lds <= 40 * 1024 &&
             small_loop_eligible(dtype, B->knn_variant & 0xff, B->knn_variant, n, B->m_pad)) {
             if (const int e = check_params(prm, B->c)) return e;
             begin_launch();
@@ -4542,7 +4575,19 @@ int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_
             if (B->spos) set_launch_events((hipEvent_t)B->events[6 * k + 4], (hipEvent_t)B->events[6 * k + 5]);
             else if (hipEventRecord((hipEvent_t)B->events[6 * k + 4], st) != hipSuccess) return -(int)hipGetLastError();
         }
-        if (B->spos)    // windowed form: src / w_init / tgt are the SORTED copies, gsrc / gw accumulate in slot order, gtgt is the slab
+        if (G) {
+            // soft correspondences: the neighbour rows carry gradient themselves -- accumulate_bwd leaves it in g_nbr, the soft kNN's
+            // adjoint takes it on to the transformed source (g_ps) and to the target (added up over the iterations), and the transform's
+            // adjoint to the source and to the pose (its sums join accumulate_bwd's in bwd_partials)
+            const char* nbr_k = (const char*)G->nbr + (size_t)k * N * n * B->c * es;
+            const char* lse_k = (const char*)G->lse + (size_t)k * N * n * es;
+            if (hipMemsetAsync(G->g_nbr, 0, (size_t)N * n * B->c * es, st) != hipSuccess) return -(int)hipGetLastError();
+            rc = accumulate_bwd_go(dtype, prm, B->src, nbr_k, B->c, nullptr, pose_k, B->w_init, alive_k, gs, gb, nullptr, N, n, n, gsrc, G->g_nbr, gw, bwd_partials, stream, B->bwd_skip);
+            if (!rc) rc = dicp_transform_points(dtype, B->src, pose_k, G->ps_t, N, n, stream);
+            if (!rc) rc = gumbel_nn_bwd_go(dtype, G->ps_t, B->tgt, B->c, G->U ? G->U[k] : nullptr, G->seeds ? G->seeds[k] : 0u, G->eps, G->tau, nbr_k, lse_k, G->g_nbr,
+                                           N, n, m, G->g_ps, gtgt, 1, stream);
+            if (!rc) rc = transform_points_bwd_go(dtype, B->src, pose_k, G->g_ps, gsrc, bwd_partials, N, n, 1, stream);
+        } else if (B->spos)    // windowed form: src / w_init / tgt are the SORTED copies, gsrc / gw accumulate in slot order, gtgt is the slab
             rc = accumulate_bwd_window_go(dtype, prm, B->src, B->tgt, B->c, B->spos + (size_t)k * N * n, B->spos_ref, B->qorder, pose_k, B->w_init,
                                           alive_k, gs, gb, B->src_rows, N, n, B->m_pad,
                                           gsrc, gtgt, B->gts_far, gw, bwd_partials, (B->bwd_overwrite && k == k1 - 1) ? 1 : 0, stream, B->bwd_skip);
@@ -4588,14 +4633,17 @@ int dicp_transform_points(int dtype, const void* src, const void* pose, void* ou
 
 int dicp_transform_points_bwd(int dtype, const void* src, const void* pose, const void* gout, void* gsrc, void* partials,
                               int N, int n, void* stream) {
+    return transform_points_bwd_go(dtype, src, pose, gout, gsrc, partials, N, n, 0, stream);
+}
+static int transform_points_bwd_go(int dtype, const void* src, const void* pose, const void* gout, void* gsrc, void* partials, int N, int n, int add, void* stream) {
     if (!src || !pose || !gout || !partials) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || n <= 0) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     begin_launch();
     const int bpc = dicp_accumulate_blocks(n);
-    if (dtype == DICP_F32) transform_bwd_kernel<float><<<grid_for(N, bpc), BLOCK, 0, st>>>((const float*)src, (const float*)pose, (const float*)gout, (float*)gsrc, (float*)partials, N, n, bpc);
-    else                   transform_bwd_kernel<double><<<grid_for(N, bpc), BLOCK, 0, st>>>((const double*)src, (const double*)pose, (const double*)gout, (double*)gsrc, (double*)partials, N, n, bpc);
+    if (dtype == DICP_F32) transform_bwd_kernel<float><<<grid_for(N, bpc), BLOCK, 0, st>>>((const float*)src, (const float*)pose, (const float*)gout, (float*)gsrc, (float*)partials, N, n, bpc, add);
+    else                   transform_bwd_kernel<double><<<grid_for(N, bpc), BLOCK, 0, st>>>((const double*)src, (const double*)pose, (const double*)gout, (double*)gsrc, (double*)partials, N, n, bpc, add);
     return launch_status();
 }
 

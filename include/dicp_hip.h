@@ -40,7 +40,8 @@ extern "C" {
 enum { DICP_F32 = 0, DICP_F64 = 1 };
 enum { DICP_PT2PT = 0, DICP_PT2PL = 1 };                 /* ICP(icp_type=...)  ICP.py:15,101-105 */
 enum { DICP_LOSS_NONE = 0, DICP_LOSS_HUBER = 1, DICP_LOSS_CAUCHY = 2, DICP_LOSS_TRIM = 3 };
-enum { DICP_KNN_AUTO = 0, DICP_KNN_VALU = 1, DICP_KNN_MFMA = 2, DICP_KNN_SWEEP = 3 /* via dicp_knn_sweep */ };
+enum { DICP_KNN_AUTO = 0, DICP_KNN_VALU = 1, DICP_KNN_MFMA = 2, DICP_KNN_SWEEP = 3 /* via dicp_knn_sweep */,
+       DICP_KNN_GUMBEL = 4 /* dicp_icp_forward / _backward only: soft correspondences, dicp_loop_buffers.gumbel */ };
 enum { DICP_ERR_NULL = 1, DICP_ERR_SHAPE = 2, DICP_ERR_DTYPE = 3, DICP_ERR_ENUM = 4, DICP_ERR_ALIGN = 5 };
 
 /* Accumulator layout of one (cloud, block) partial: see dicp_amd/csrc/dicp_math.h */
@@ -222,6 +223,21 @@ typedef struct dicp_step_io {
 int dicp_step(int dtype, const dicp_step_io* io, int N, void* stream);
 
 /* Caller-allocated state of one whole ICP call, indexed by iteration k = 0..K-1 (T = dtype's scalar). */
+/* The Gumbel-softmax correspondence (nn.py:43-70, config functionality.gumbel) inside the ICP loop: iteration k is
+   dicp_transform_points -> dicp_gumbel_nn -> dicp_accumulate on the soft neighbour rows -> dicp_step, and in reverse
+   dicp_step_bwd -> dicp_accumulate_bwd (gradient of the rows) -> dicp_gumbel_nn_bwd (to the transformed source and the target) ->
+   dicp_transform_points_bwd (to the source and the pose).  U and seeds are HOST arrays (read while the call enqueues). */
+typedef struct dicp_gumbel_loop {
+    const void* const* U;    /* optional (K) device pointers, each (N,n,m): the uniform noise of iteration k; NULL: in-kernel noise from seeds[k] */
+    const uint32_t* seeds;   /* (K), used when U is NULL */
+    double eps, tau;
+    void* ps_t;              /* (N,n,3) scratch: the transformed source of the iteration at hand */
+    void* nbr;               /* (K,N,n,c) the soft neighbour rows of every iteration (the reverse sweep reads them) */
+    void* lse;               /* (K,N,n) their log-sum-exp */
+    void* g_nbr;             /* dicp_icp_backward: (N,n,c) scratch */
+    void* g_ps;              /* dicp_icp_backward: (N,n,3) scratch */
+} dicp_gumbel_loop;
+
 typedef struct dicp_loop_buffers {
     const void* src;         /* (N,n,3) */
     const void* tgt;         /* (N,m,c) */
@@ -319,6 +335,8 @@ typedef struct dicp_loop_buffers {
                                 from where the previous call's sweeps ended. */
     void* bwd_tail_partials; /* (N, dicp_window_blocks, DICP_NBWD_PAD): the second buffer of pose sums of that launch */
     int32_t* bwd_tail_arrive;/* (N + 1) zeros per backward pass: its per-cloud counters; [N] is raised if a wait ran out (never observed; results are then wrong) */
+    const dicp_gumbel_loop* gumbel; /* knn_variant DICP_KNN_GUMBEL: the soft correspondences' buffers (idx / spos / tgt4 are then unused; gtgt of dicp_icp_backward
+                                is (N,m,c) zeros and is added to; no truncated sweep: the matches themselves carry gradient) */
 } dicp_loop_buffers;
 
 /* Head and tail of the backward loop.  dicp_pose_grad_in: gpose (N,12) double = [dL/dC row-major (9), dL/dr (3)] taken from the

@@ -1406,6 +1406,7 @@ def test_icp_with_gumbel_correspondence_vs_oracle(icp_type, monkeypatch):
     sd, td, wd = src.to(DEV).requires_grad_(True), tg.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
     T0d = torch.eye(4, dtype=torch.float64, device=DEV).repeat(N, 1, 1).requires_grad_(True)
     out = icp.icp(sd, td, T0d, weight=wd, **kw)
+    assert type(out["T"].grad_fn).__name__ == "ICPLoopBackward"      # the library loop (dicp_icp_forward with DICP_KNN_GUMBEL): one node per call
     (out["T"] * gT.to(DEV)).sum().backward()
     # noise is float32 in the reference (torch.rand default dtype) and float64 here: agreement to ~1e-6
     np.testing.assert_allclose(npy(out["T"]), npy(ref["T"]), rtol=0, atol=2e-6)

@@ -1343,7 +1343,7 @@ template <typename T> struct PointSearch {
 // the score() every search form uses; equal scores resolve to the lowest ORIGINAL index: index for index the match of a full
 // search.  Returns the match's sorted position (-1: none) and leaves the query's new budget in `budget`.
 template <typename T>
-__device__ __forceinline__ int search_point(const PointSearch<T>& ps, const int cloud, const T* nx, const int prev, T& budget) {
+__device__ __forceinline__ int search_point(const PointSearch<T>& ps, const int cloud, const T* nx, const int prev, T& budget, unsigned long long& rows_scored) {
     using T4 = typename V4<T>::type;
     const int lane = threadIdx.x & (WAVE - 1);
     const int m = max(rows_of(ps.tgt_rows, cloud, ps.m_full), 1);
@@ -1420,11 +1420,8 @@ __device__ __forceinline__ int search_point(const PointSearch<T>& ps, const int 
         T H1c;
         budget = cert_from_scores(bv, s2, hx, h_edge, ps.ct.dcum + (size_t)cloud * ps.ct.dstride + 2 * ps.ct.k, H1c);
     }
-    if (lane == 0) {
-        if (ps.pairs) atomicAdd(ps.pairs + (blockIdx.x & (DICP_PAIR_SHARDS - 1)), (unsigned long long)(r1 - r0));
-        if (ps.ct.count) atomicAdd(ps.ct.count + CERT_SHARDS + (blockIdx.x & (CERT_SHARDS - 1)), 1);
-        if (ps.ct.cloud) atomicAdd(ps.ct.cloud + (size_t)cloud * CERT_CLOUD + 1, 1);
-    }
+    rows_scored += (unsigned long long)(r1 - r0);             // (the caller counts the searches and adds everything to the statistics ONCE, at its end:
+                                                                //  a wave's loads return behind its earlier atomics, and a cloud's word is one address)
     return bs;          // (sorted slots [0,m) hold the cloud's own rows: a row found is a real one)
 }
 
@@ -1919,6 +1916,8 @@ __global__ __launch_bounds__(BLOCK, (CERT && sizeof(T) == 4) ? 5 : 1) void accum
     if (!decode_block(bpc, N, cloud, blk)) return;
     const int nc = rows_of(src_rows, cloud, n);             // ragged batches: rows past the cloud's own carry weight 0 (ICP.py:386-398)
     const int end = min(nc, (blk + 1) * ACC_PTS);
+    unsigned long long rows_scored = 0;                     // this wave's on-the-spot searches: rows scored, searches made (wave-uniform)
+    int singles = 0;
     if (CERT && ps.ct.dcum && !(ps.ct.cloud && ps.ct.cloud[(size_t)cloud * CERT_CLOUD + 2] > 0)) {      // (certificates off for this cloud: the guard launch has just searched every unit)
         // first the budgets of this block's points (before the sums' registers are live): spent ones are searched again, one query at a
         // time by the whole wave; the thread that owns the point rewrites its match and budget and reads them back below
@@ -1948,7 +1947,8 @@ __global__ __launch_bounds__(BLOCK, (CERT && sizeof(T) == 4) ? 5 : 1) void accum
                 const T pq[3] = {__shfl(p[0], L), __shfl(p[1], L), __shfl(p[2], L)};
                 T nx[3], got;
                 query_point(Cs, rs, pq, nx);
-                const int found = search_point<T>(ps, cloud, nx, __shfl(j, L), got);
+                const int found = search_point<T>(ps, cloud, nx, __shfl(j, L), got, rows_scored);
+                ++singles;
                 if (lane == L) { j = found; nb = got; }
             }
             if (redo) { ps.spos[pt] = j; ps.ct.q[pt] = nb; }
@@ -1981,6 +1981,11 @@ __global__ __launch_bounds__(BLOCK, (CERT && sizeof(T) == 4) ? 5 : 1) void accum
         if (w_out) w_out[(size_t)cloud * w_stride + i] = (w_prev && live == T(0)) ? w_prev[(size_t)cloud * w_stride + i] : s.w;
     }
     block_reduce_store<T, NACC, NACC_PAD>(acc, partials + ((size_t)cloud * bpc + blk) * NACC_PAD, red);
+    if (CERT && singles > 0 && (threadIdx.x & (WAVE - 1)) == 0) {      // the statistics of this wave's on-the-spot searches, after everything else
+        if (ps.pairs) atomicAdd(ps.pairs + (blockIdx.x & (DICP_PAIR_SHARDS - 1)), rows_scored);
+        if (ps.ct.count) atomicAdd(ps.ct.count + CERT_SHARDS + (blockIdx.x & (CERT_SHARDS - 1)), singles);
+        if (ps.ct.cloud) atomicAdd(ps.ct.cloud + (size_t)cloud * CERT_CLOUD + 1, singles);
+    }
 }
 
 // -------------------------------------------------------------------------- step
@@ -2117,8 +2122,8 @@ __device__ __forceinline__ void step_body(const dicp_step_io& io, int cloud, int
         s_copy = (io.w_cur && io.w_prev && sacc[ACC_SUMW] == 0.0 && !(io.w_copied && alive_in == T(0))) ? 1 : 0;   // ICP.py:224-226
         if (io.cert_cloud) {
             // Match certificates must never cost more than searching everything.  What this iteration searched again for this cloud --
-            // whole units (a certifying search of a unit costs ~1.3 plain ones) and single queries (one wave per query: ~0.2 of a unit's
-            // search each, measured at the benchmark shape and on planar scenes, profiles/r03_scene_kernel_stats_before.txt) -- against the
+            // whole units (a certifying search of a unit costs ~1.3 plain ones) and single queries (one wave per query: ~0.12 of a unit's
+            // search each, measured on planar scenes once the searches' statistics were counted per wave at the kernel's end, profiles/r03_scene_kernel_stats_tally.txt) -- against the
             // cloud's units: from 60 % of a full search on, the cloud's certificates are switched off for the rest of the call (the guard
             // launch then searches every unit plainly, the accumulate checks nothing).  Results do not depend on it: both are exact.
             // Two kinds of evidence.  Queries that got NO certificate in a search of every unit (no unit was searched AGAIN: cc[0] == 0) are
@@ -2129,11 +2134,11 @@ __device__ __forceinline__ void step_body(const dicp_step_io& io, int cloud, int
             int32_t* cc = io.cert_cloud + (size_t)cloud * CERT_CLOUD;
             const int c_units = scc[0], c_single = scc[1], state = scc[2], units = scc[3], c_back = scc[4];     // (read in the prologue)
             if (units > 0) {
-                const bool costly = 1.3 * c_units + 0.2 * c_single > 0.6 * units;
+                const bool costly = 1.3 * c_units + 0.12 * c_single > 0.6 * units;
                 int next = state;
                 if (state >= CERT_OFF_FOR_GOOD) next = state;
                 else if (state > 0) next = state > 1 ? state - 1 : CERT_RECERTIFY;
-                else if (state == CERT_RECERTIFY) next = (0.2 * c_single > 0.6 * units) ? CERT_OFF_FOR_GOOD : 0;
+                else if (state == CERT_RECERTIFY) next = (0.12 * c_single > 0.6 * units) ? CERT_OFF_FOR_GOOD : 0;
                 else if (!costly) next = 0;
                 else if (c_units == 0) next = CERT_OFF_FOR_GOOD;
                 else if (state == -1) { const int d = c_back > 0 ? min(2 * c_back, 16) : 2; cc[4] = d; next = d; }

@@ -893,7 +893,8 @@ class ICPLoop(torch.autograd.Function):
             # that call's launches): the iterations at which fewer than an eighth of its clouds were still at work go to the one launch, which
             # sweeps a cloud that is at work after all with one block -- slower for that cloud, exact either way.
             tail_from, hint = 0, None
-            if skip is not None and only_windowed and cfg.bwd_tail and cfg.stats_out is not None:
+            capturing = torch.cuda.is_current_stream_capturing()        # (a graph capture: no event queries, no host-side hint)
+            if skip is not None and only_windowed and cfg.bwd_tail and cfg.stats_out is not None and not capturing:
                 hint = cfg.stats_out.get("_bwd_hint")
                 if hint is not None and hint[2] == (N, n, K) and hint[1].query():
                     live = hint[0][:K].tolist()
@@ -956,7 +957,7 @@ class ICPLoop(torch.autograd.Function):
                     folded = kt > 0         # the tail launch left the cotangent of pose_0 with the last pose sums already in it
                 if (k1 - k0) % 2:           # the library alternates the two buffers: odd chunk -> the result is in the other one
                     gpose, gtmp = gtmp, gpose
-            if skip is not None and only_windowed and cfg.bwd_tail and cfg.stats_out is not None:
+            if skip is not None and only_windowed and cfg.bwd_tail and cfg.stats_out is not None and not capturing:
                 host = hint[0] if (hint is not None and hint[0].numel() >= Kmax) else torch.empty((Kmax,), dtype=torch.int32).pin_memory()
                 host[:Kmax].copy_(skip[2], non_blocking=True)
                 done = torch.cuda.Event()

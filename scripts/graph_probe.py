@@ -4,13 +4,16 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 import torch
 from dicp_amd.ICP import ICP
 from dicp_amd.synthetic import make_pairs
-B, n, K = 256, 16384, 10
+B, n, typ, K = (int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4])) if len(sys.argv) > 4 else (256, 16384, "pt2pl", 10)
 src, tgt = make_pairs(B, n, n, seed=3)
+if typ == "pt2pt":
+    tgt = tgt[:, :, :3].contiguous()
 src, tgt = src.cuda().requires_grad_(True), tgt.cuda().requires_grad_(True)
 T0 = torch.eye(4, device="cuda").repeat(B, 1, 1)
-icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
+icp = ICP(icp_type=typ, differentiable=True, max_iterations=K, tolerance=1e-12)
 icp.const_iter = True
-kw = dict(trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0})
+kw = dict(trim_dist=5.0) if typ == "pt2pt" else dict(trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0})
+print("B=%d n=%d %s K=%d" % (B, n, typ, K))
 
 
 def call():

@@ -491,3 +491,46 @@ def test_certificates_switch_themselves_off_where_they_cost_more(kind):
         assert int(off.sum()) == N, off.tolist()                        # ... and are off everywhere here, from the certifying search on
         again = outs["switch"][3]["searched_again"]
         assert int(again[5:, 64:].sum()) == 0                           # no single-query searches any more
+
+
+@pytest.mark.parametrize("B,n,icp_type", [(6, 2048, "pt2pl"), (2, 65, "pt2pt")])
+def test_graphed_call_is_the_eager_call(B, n, icp_type):
+    """dicp_amd.graphed.graphed_icp: the fixed-shape call captured once as hipGraphs (forward and backward) and replayed -- for training loops whose
+    calls are host-bound (configs[1], single pairs).  Same kernels in the same order: poses and gradients of a replay equal the eager call's, also
+    for inputs other than the ones captured with; tolerance mode is refused (its host checks cannot be captured)."""
+    from dicp_amd.graphed import graphed_icp
+    src, tgt = make_pairs(B, n, n, seed=31)
+    if icp_type == "pt2pt":
+        tgt = tgt[:, :, :3].contiguous()
+    src2, tgt2 = make_pairs(B, n, n, seed=32)
+    if icp_type == "pt2pt":
+        tgt2 = tgt2[:, :, :3].contiguous()
+    T0 = torch.eye(4, device=DEV).repeat(B, 1, 1)
+    kw = dict(trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0}) if icp_type == "pt2pl" else dict(trim_dist=5.0)
+    icp = ICP(icp_type=icp_type, differentiable=True, max_iterations=8, tolerance=1e-12)
+    with pytest.raises(ValueError):
+        graphed_icp(icp, src.to(DEV), tgt.to(DEV), T0, **kw)
+    icp.const_iter = True
+    g = graphed_icp(icp, src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True), T0, **kw)
+    for s_in, t_in in ((src, tgt), (src2, tgt2), (src, tgt)):
+        res = []
+        for fn in (lambda s, t: icp.icp(s, t, T0, **kw), lambda s, t: g(s, t, T0)):
+            s, t = s_in.to(DEV).requires_grad_(True), t_in.to(DEV).requires_grad_(True)
+            out = fn(s, t)
+            (out["T"].sum() + 1e-3 * (out["pc"] ** 2).sum()).backward()
+            res.append((out["T"].clone(), out["pc"].clone(), out["deltas"].clone(), s.grad.clone(), t.grad.clone()))
+        for a, b in zip(*res):
+            scale = max(1.0, float(a.abs().max()))
+            assert float((a - b).abs().max()) <= 2e-6 * scale       # (float atomics of the atomic-form backward: not bit for bit)
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][2], res[1][2])      # the forward is
+    # the whole step (call + loss + backward) as one graph
+    from dicp_amd.graphed import graphed_icp_step
+    st = graphed_icp_step(icp, lambda out: out["T"].sum() + 1e-3 * (out["pc"] ** 2).sum(), src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True), T0, **kw)
+    for s_in, t_in in ((src2, tgt2), (src, tgt)):
+        s, t = s_in.to(DEV).requires_grad_(True), t_in.to(DEV).requires_grad_(True)
+        out = icp.icp(s, t, T0, **kw)
+        (out["T"].sum() + 1e-3 * (out["pc"] ** 2).sum()).backward()
+        gout, grads = st(s_in.to(DEV), t_in.to(DEV), T0)
+        assert torch.equal(gout["T"], out["T"])
+        for a, b in ((s.grad, grads["source"]), (t.grad, grads["target"])):
+            assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max()))

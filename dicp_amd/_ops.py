@@ -893,10 +893,12 @@ class ICPLoop(torch.autograd.Function):
             # that call's launches): the iterations at which fewer than an eighth of its clouds were still at work go to the one launch, which
             # sweeps a cloud that is at work after all with one block -- slower for that cloud, exact either way.
             tail_from, hint = 0, None
-            capturing = torch.cuda.is_current_stream_capturing()        # (a graph capture: no event queries, no host-side hint)
-            if skip is not None and only_windowed and cfg.bwd_tail and cfg.stats_out is not None and not capturing:
+            # (inside a graph capture no event may be queried: the hint of the warm-up calls is read as it stands -- torch's capture entry points
+            #  synchronise first -- and none is recorded; a stale hint costs time, never correctness: a cloud at work in the tail is swept there)
+            capturing = torch.cuda.is_current_stream_capturing()
+            if skip is not None and only_windowed and cfg.bwd_tail and cfg.stats_out is not None:
                 hint = cfg.stats_out.get("_bwd_hint")
-                if hint is not None and hint[2] == (N, n, K) and hint[1].query():
+                if hint is not None and hint[2] == (N, n, K) and (capturing or hint[1].query()):
                     live = hint[0][:K].tolist()
                     tail_from = max(0, next((k for k in range(K) if live[k] * 8 >= N), K) - 1)      # (most sweeps have ended BEFORE the one launch starts)
             gum = None

@@ -7,12 +7,13 @@ the host does per call can be done ONCE.  `graphed_icp` captures `ICP.icp` (cons
 checks of "all converged", ICP.py:259, cannot be captured) and its backward with torch.cuda.make_graphed_callables; a call of the
 returned function copies its arguments into the graphs' static inputs and replays; `graphed_icp_step` captures the call, a fixed
 loss and the backward as ONE graph.  Measured (scripts/graphed_timing.py, profiles/r03_hipgraph_mid_size.txt), forward + backward:
-configs[1] 0.76 -> 0.64 (two graphs, loss outside) / 0.60 ms (one graph), one 65-point pair 0.45 -> 0.32 / 0.28 ms, the benchmark
+configs[1] 0.76 -> 0.64 (two graphs, loss outside) / 0.55 ms (one graph), one 65-point pair 0.45 -> 0.32 / 0.28 ms, the benchmark
 shape (GPU-bound) unchanged.  The forward results are those of the eager call bit for bit (the same kernels in the same order).
 
 The usual rules of graphed callables apply: shapes, dtypes, requires_grad flags and every keyword are fixed at capture; the
 outputs are STATIC tensors, overwritten by the next call (clone what must survive); the truncated reverse sweep's one-launch
-tail (placed from the previous call's live counters, a host decision) is not used inside a capture."""
+tail is placed once, from the warm-up calls' live counters, and stays there in every replay (a cloud that is still at work in it
+is swept there: exact either way)."""
 import contextlib
 import gc
 

@@ -52,6 +52,7 @@ class ICP:
         self.cert_from = None                 # iteration of the certifying search (None: the last re-ordering of the queries)
         self.reuse_matches = True             # sweep path: search only where a match is not PROVEN unchanged since the last search (exact)
         self.cert_backoff = True              # ... switched off per cloud, on device, where proving costs more than searching (same results)
+        self.first_search = True              # sweep path: iteration 0's search is enqueued with the index build, before the loop state is prepared
         self.plan_call = True                 # constant-iteration calls: every segment of the loop behind one library call (dicp_icp_forward_plan)
         # backward: an iteration whose normal-equation cotangent has decayed below this fraction of the cloud's largest adds nothing above
         # rounding and does no per-point work for that cloud (None: 2^-22 float32 / 2^-40 float64; 0: every iteration, like autograd)
@@ -111,7 +112,9 @@ class ICP:
             target = target.contiguous()
             wants_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (source, target, T_init, w_pts) if t is not None)
             source = source.contiguous()
-            prebuilt = prebuild_search(source, target, self.knn_variant, wants_grad and bool(self.bwd_window), T_init, src_rows, tgt_rows)
+            # (... and the first search right behind it, unless the loop will want original indices -- the atomic backward -- or carries timing events)
+            prebuilt = prebuild_search(source, target, self.knn_variant, wants_grad and bool(self.bwd_window), T_init, src_rows, tgt_rows,
+                                       first_search=bool(self.first_search) and self._timing_events is None and not (wants_grad and not self.bwd_window))
         cfg = LoopConfig(
             icp_type=self.icp_type, differentiable=bool(self.diff), max_iterations=int(self.max_iterations),
             tolerance=float(self.tolerance), trim_dist=trim_dist, loss_name=loss_name,

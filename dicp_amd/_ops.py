@@ -154,13 +154,15 @@ class SweepIndex:
     an ICP call, so they are sorted by x once (dicp_sweep_sort: native for every size and dtype)."""
     NBKT = 1024
 
-    def __init__(self, tgt, sorted_rows=False, frame=None, tgt_rows=None, first_order=None):
+    def __init__(self, tgt, sorted_rows=False, frame=None, tgt_rows=None, first_order=None, first_search=False):
         """sorted_rows: also keep tgt_s (N,m_pad,row_stride), the full rows in sorted order (the loop's accumulate and the windowed backward gather them).
         frame (N,12): the index is built on Q y + t (keys, table and packed rows; tgt_s keeps the rows as given) and the
         searches must then be given the pose [Q C | Q r + t].
         tgt_rows (N) int32: rows of each cloud that take part (ragged batches); the searches are given the same counts.
         first_order = (source, T_init, src_rows): the frame is chosen here and everything -- frame, sort, rows, the search pose of iteration 0 and the
-        first query order (self.first = (source, T_init, qorder)) -- goes out in ONE library call (dicp_sweep_setup)."""
+        first query order (self.first = (source, T_init, qorder, spos0)) -- goes out in ONE library call (dicp_sweep_setup).
+        first_search: iteration 0's search is enqueued right behind it (spos0 (N,n): its matches as sorted positions; None otherwise): 0.4 ms of
+        kernel at the benchmark shape under which the host prepares the loop (dicp_loop_buffers.first_search_done)."""
         require_device(tgt, "SweepIndex")
         tgt = tgt.contiguous()
         N, m, c = tgt.shape
@@ -191,7 +193,13 @@ class SweepIndex:
                 _lib.check(lib.dicp_sweep_setup(_DT[dt], _p(tgt), c, _p(tgt_rows), N, m, m_pad, CENTER_QUANTUM, int(FRAME_DIRECTIONS), _p(self.frame), _p(self.keys), _p(self.tperm),
                                                 self.NBKT, _p(self.bucket), _p(self.brange), _p(scratch), nbytes, _p(self.tgs4), _p(self.tgt_s), self.row_stride,
                                                 _p(source), _p(src_rows), source.shape[1], _p(T_init), _p(pose_s), _p(qorder), _stream()), "dicp_sweep_setup")
-            self.first = (source, T_init, qorder)
+            spos0 = None
+            if first_search:
+                spos0 = torch.empty((N, source.shape[1]), dtype=torch.int32, device=dev)
+                with _on(dev):
+                    _lib.check(lib.dicp_knn_sweep(_DT[dt], _p(source), _p(pose_s), _p(self.tgs4), _p(self.tperm), _p(qorder), _p(self.bucket), _p(self.brange), self.NBKT,
+                                                  _p(src_rows), _p(tgt_rows), N, source.shape[1], m, m_pad, None, _p(spos0), _p(self.pair_shards), 0, _stream()), "dicp_knn_sweep")
+            self.first = (source, T_init, qorder, spos0)
             return
         with _on(dev):
             _lib.check(lib.dicp_sweep_sort(_DT[dt], _p(tgt), c, _p(frame), _p(tgt_rows), N, m, m_pad, _p(self.keys), _p(self.tperm), self.NBKT,
@@ -409,7 +417,7 @@ def loss_weight(err2d, name, diff, metric, tanh_k):
 
 
 # --------------------------------------------------------------- the ICP loop
-def prebuild_search(source, target, knn_variant, want_rows, T_init=None, src_rows=None, tgt_rows=None):
+def prebuild_search(source, target, knn_variant, want_rows, T_init=None, src_rows=None, tgt_rows=None, first_search=False):
     """Enqueue the per-call search structure of the sweep path (target sort + index build, ~0.15 ms of kernels) NOW, so that
     it runs under the host work the caller still has to do before the loop starts (a call that begins on an idle GPU is
     host-bound until its first long kernel).  Returns (target, SweepIndex) for LoopConfig.prebuilt, or None when the loop
@@ -425,7 +433,8 @@ def prebuild_search(source, target, knn_variant, want_rows, T_init=None, src_row
         # the host builds the loop state.  Frame, sort, rows, search pose and that order are ONE library call.
         if (T_init is not None and T_init.is_cuda and T_init.is_contiguous() and T_init.dtype == target.dtype and source.is_contiguous()
                 and source.dtype == target.dtype and tuple(T_init.shape) == (N, 4, 4)):
-            sweep = SweepIndex(target, sorted_rows=True, tgt_rows=tgt_rows, first_order=(source, T_init, src_rows))
+            sweep = SweepIndex(target, sorted_rows=True, tgt_rows=tgt_rows, first_order=(source, T_init, src_rows),
+                               first_search=bool(first_search) and not (knn_variant & 0xff00))
             return (target, sweep, sweep.first)
         sweep = SweepIndex(target, sorted_rows=True, frame=search_frame(target, tgt_rows=tgt_rows), tgt_rows=tgt_rows)
         return (target, sweep, None)
@@ -654,6 +663,16 @@ class ICPLoop(torch.autograd.Function):
             done_segs = []
             pending, host_cnt = None, None   # tolerance mode: the segment whose convergence counters are still in flight
             LB, LBref, Pref = None, None, ctypes.byref(P)
+            # iteration 0's search may already be running: prebuild_search enqueued it behind the index build (under T_init's search pose and the
+            # first query order), so that the GPU has 0.4 ms of work while this function prepares the loop (dicp_loop_buffers.first_search_done)
+            first0 = cfg.prebuilt[2] if (sweep is not None and cfg.prebuilt is not None and cfg.prebuilt[1] is sweep) else None
+            first_spos = None
+            if (first0 is not None and len(first0) > 3 and first0[3] is not None and first0[0].data_ptr() == src.data_ptr() and first0[0].shape == src.shape
+                    and first0[1].data_ptr() == T_init.data_ptr() and T_init.is_contiguous() and not keep_idx and events is None
+                    and not (certs is not None and cert_from <= 0)):
+                first_spos = first0[3]
+                if not keep_spos:
+                    spos_once = first_spos
             # constant-iteration calls of the sweep path with all histories in one slab: every segment and the query re-orderings between them
             # behind ONE library call (dicp_icp_forward_plan) -- per segment the host spent ~40 us, which a mid-size call does not have
             if cfg.const_iter and sweep is not None and kc >= Kmax and len(segs) <= _lib.MAX_SEGMENTS and cfg.plan_call:
@@ -662,6 +681,8 @@ class ICPLoop(torch.autograd.Function):
                     idx_slabs.append(torch.empty((Kmax, N, n), dtype=torch.int32, device=dev))
                 if keep_spos:
                     spos_slabs.append(torch.empty((Kmax, N, n), dtype=torch.int32, device=dev))
+                    if first_spos is not None:
+                        spos_slabs[0][0].copy_(first_spos)
                 first = cfg.prebuilt[2] if (cfg.prebuilt is not None and cfg.prebuilt[1] is sweep) else None
                 have_first = (first is not None and first[0].data_ptr() == src.data_ptr() and first[0].shape == src.shape
                               and first[1].data_ptr() == T_init.data_ptr() and T_init.is_contiguous())
@@ -697,7 +718,7 @@ class ICPLoop(torch.autograd.Function):
                     spos=_p(spos_slabs[0]) if keep_spos else _p(spos_once),
                     idx=(_p(idx_slabs[0]) if need_grad else _p(idx_once)) if keep_idx else None,
                     partials=_p(partials), counters=_p(counters), events=events, frame=_p(center), poses_search=_p(poses_c),
-                    src_rows=_p(cfg.src_rows), tgt_rows=_p(cfg.tgt_rows))
+                    src_rows=_p(cfg.src_rows), tgt_rows=_p(cfg.tgt_rows), first_search_done=int(first_spos is not None))
                 _lib.check(lib.dicp_icp_forward_plan(code, Pref, ctypes.byref(LB), ctypes.byref(SP), N, n, m, int(cfg.dim), 1, float(cfg.tolerance), st),
                            "dicp_icp_forward_plan")
                 segs = []
@@ -710,6 +731,8 @@ class ICPLoop(torch.autograd.Function):
                         idx_slabs.append(torch.empty((kk, N, n), dtype=torch.int32, device=dev))
                     if keep_spos:
                         spos_slabs.append(torch.empty((kk, N, n), dtype=torch.int32, device=dev))
+                        if j == 0 and first_spos is not None:
+                            spos_slabs[0][0].copy_(first_spos)
                 new_order = False
                 use_certs = certs is not None and k0 >= cert_from
                 if sweep is not None and (qorder is None or k0 in cfg.sweep_resort):
@@ -741,6 +764,7 @@ class ICPLoop(torch.autograd.Function):
                         LB.gumbel = ctypes.cast(ctypes.pointer(gum), ctypes.c_void_p)
                     LBref = ctypes.byref(LB)
                 LB.qorder = _p(qorder)
+                LB.first_search_done = int(k0 == 0 and first_spos is not None)
                 LB.spos = ctypes.c_void_p(spos_slabs[j].data_ptr() - base * N * n * 4) if keep_spos else _p(spos_once)
                 LB.idx = (ctypes.c_void_p(idx_slabs[j].data_ptr() - base * N * n * 4) if need_grad else _p(idx_once)) if keep_idx else None
                 LB.cert_q, LB.cert_qu, LB.cert_count = (_p(certs["q"]), _p(certs["qu"]), _p(certs["count"])) if use_certs else (None, None, None)

@@ -4428,7 +4428,9 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
             const bool cert = B->cert_q && B->cert_qu && B->rmax && B->dcum && spos_k && sorted_rows && !B->idx && B->qorder && sweep_queries_per_lane(cfg_plain) > 0;
             const bool fresh = k == 0 || (k == k0 && B->cert_reset);           // a new query order: every query is searched, every budget written
             int32_t* count_k = B->cert_count ? B->cert_count + (size_t)k * 2 * CERT_SHARDS : nullptr;
-            if (cert) {
+            const bool searched = B->first_search_done && k == 0 && !cert && spos_k && !B->idx;    // the caller ran iteration 0's search itself, ahead of this call
+            if (searched) rc = 0;
+            else if (cert) {
                 if (!fresh && k == k0 && B->idx_per_iter) {     // this call's first matches start as the previous call's last (later ones: handed on by accumulate)
                     if (!B->spos_prev0) { set_launch_events(nullptr, nullptr); return DICP_ERR_NULL; }
                     if (hipMemcpyAsync(spos_k, B->spos_prev0, (size_t)N * n * sizeof(int32_t), hipMemcpyDeviceToDevice, st) != hipSuccess) {

@@ -337,6 +337,9 @@ typedef struct dicp_loop_buffers {
     int32_t* bwd_tail_arrive;/* (N + 1) zeros per backward pass: its per-cloud counters; [N] is raised if a wait ran out (never observed; results are then wrong) */
     const dicp_gumbel_loop* gumbel; /* knn_variant DICP_KNN_GUMBEL: the soft correspondences' buffers (idx / spos / tgt4 are then unused; gtgt of dicp_icp_backward
                                 is (N,m,c) zeros and is added to; no truncated sweep: the matches themselves carry gradient) */
+    int32_t first_search_done;  /* sweep path: 1 = the matches of iteration 0 are already in spos (the caller enqueued dicp_knn_sweep under pose_search[0] and
+                                   the first query order itself, right behind the index build, so that the search runs while the host is still
+                                   preparing the loop): dicp_icp_forward then starts iteration 0 at its accumulate */
 } dicp_loop_buffers;
 
 /* Head and tail of the backward loop.  dicp_pose_grad_in: gpose (N,12) double = [dL/dC row-major (9), dL/dr (3)] taken from the

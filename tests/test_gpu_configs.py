@@ -534,3 +534,26 @@ def test_graphed_call_is_the_eager_call(B, n, icp_type):
         assert torch.equal(gout["T"], out["T"])
         for a, b in ((s.grad, grads["source"]), (t.grad, grads["target"])):
             assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max()))
+
+
+@pytest.mark.parametrize("const_iter,grad", [(True, True), (False, True), (True, False)])
+def test_first_search_ahead_of_the_loop_changes_nothing(const_iter, grad):
+    """ICP.first_search: iteration 0's search is enqueued with the index build, before the loop's state exists (dicp_loop_buffers.first_search_done),
+    so that the GPU works while the host prepares the call.  Same search under the same pose and query order: every output bit for bit, with and
+    without it, in the one-call plan, the per-segment (tolerance) path and the no-gradient path."""
+    N, n = 12, 16384
+    src, tgt = make_pairs(N, n, n, seed=77)
+    res = []
+    for early in (True, False):
+        icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=9, tolerance=1e-12 if const_iter else 1e-4)
+        icp.const_iter, icp.first_search = const_iter, early
+        S, Tg = src.to(DEV).requires_grad_(grad), tgt.to(DEV).requires_grad_(grad)
+        out = icp.icp(S, Tg, torch.eye(4, device=DEV).repeat(N, 1, 1), **KW)
+        if grad:
+            out["T"].sum().backward()
+        res.append((out, S.grad, Tg.grad))
+    for key in ("T", "deltas", "weights", "costs", "pc"):
+        assert torch.equal(res[0][0][key], res[1][0][key]), key
+    if grad:
+        for i in (1, 2):
+            assert float((res[0][i] - res[1][i]).abs().max()) <= 2e-6 * max(1.0, float(res[1][i].abs().max()))

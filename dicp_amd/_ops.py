@@ -921,8 +921,10 @@ class ICPLoop(torch.autograd.Function):
             #  synchronise first -- and none is recorded; a stale hint costs time, never correctness: a cloud at work in the tail is swept there)
             capturing = torch.cuda.is_current_stream_capturing()
             if skip is not None and only_windowed and cfg.bwd_tail and cfg.stats_out is not None:
-                hint = cfg.stats_out.get("_bwd_hint")
-                if hint is not None and hint[2] == (N, n, K) and (capturing or hint[1].query()):
+                # (the newest hint that has ARRIVED: in a loop that never waits for the GPU the last call's own counters are still on their way)
+                hints = cfg.stats_out.setdefault("_bwd_hints", [])
+                hint = next((h for h in reversed(hints) if h[2] == (N, n, K) and (capturing or h[1].query())), None)
+                if hint is not None:
                     live = hint[0][:K].tolist()
                     tail_from = max(0, next((k for k in range(K) if live[k] * 8 >= N), K) - 1)      # (most sweeps have ended BEFORE the one launch starts)
             gum = None
@@ -984,11 +986,20 @@ class ICPLoop(torch.autograd.Function):
                 if (k1 - k0) % 2:           # the library alternates the two buffers: odd chunk -> the result is in the other one
                     gpose, gtmp = gtmp, gpose
             if skip is not None and only_windowed and cfg.bwd_tail and cfg.stats_out is not None and not capturing:
-                host = hint[0] if (hint is not None and hint[0].numel() >= Kmax) else torch.empty((Kmax,), dtype=torch.int32).pin_memory()
-                host[:Kmax].copy_(skip[2], non_blocking=True)
-                done = torch.cuda.Event()
-                done.record()
-                cfg.stats_out["_bwd_hint"] = (host, done, (N, n, K))
+                hints = cfg.stats_out.setdefault("_bwd_hints", [])
+                entry = None
+                if len(hints) >= 4:         # four pinned buffers in rotation: the oldest one is re-used once its copy has landed
+                    if hints[0][1].query() and hints[0][0].numel() >= Kmax:
+                        entry = hints.pop(0)
+                else:
+                    entry = [torch.empty((max(Kmax, 64),), dtype=torch.int32).pin_memory(), None, None]
+                if entry is not None:
+                    entry[0][:Kmax].copy_(skip[2], non_blocking=True)
+                    entry[1] = torch.cuda.Event()
+                    entry[1].record()
+                    entry[2] = (N, n, K)
+                    hints.append(entry)
+                    cfg.stats_out["_bwd_hint"] = entry      # (the newest one, for the tests)
             if any(windowed):               # slot s is source point qo[s]; slabs + out-of-window rows -> original target order
                 permute = lib.dicp_permute_rows if only_windowed else lib.dicp_permute_add_rows
                 _lib.check(permute(code, _p(gsrc_s), _p(qo), N, n, n, n, 3, 3, _p(gsrc), n, 3, st), "dicp_permute_rows")

@@ -1584,3 +1584,31 @@ def test_nonfinite_target_x_keeps_its_sorted_slot_in_the_windowed_backward():
             assert bool(((row == 0) | ~torch.isfinite(row)).all()), (knn, b, j, row)
     np.testing.assert_allclose(grads[_lib.KNN_SWEEP][0][1].numpy(), grads[_lib.KNN_VALU][0][1].numpy(), rtol=0, atol=1e-6)
     np.testing.assert_allclose(grads[_lib.KNN_SWEEP][1][1].numpy(), grads[_lib.KNN_VALU][1][1].numpy(), rtol=0, atol=1e-5)
+
+
+def test_icp_with_gumbel_in_tolerance_mode_and_without_injected_noise():
+    """The Gumbel loop inside the library (DICP_KNN_GUMBEL) beyond the injected-noise parity case: tolerance mode (segments, frozen clouds, trimmed
+    histories) and the in-kernel noise (seeded from torch's generator: same seed -> same call, and the backward regenerates what the forward drew)."""
+    N, n, m = 3, 200, 230
+    src, tgt = make_pairs(N, n, m, seed=52, dtype=torch.float64, max_rot=0.03, max_trans=0.1)
+    kw = dict(trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0}, dim=3)
+
+    def run(seed, const_iter):
+        torch.manual_seed(seed)
+        icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=12, tolerance=1e-14 if const_iter else 2e-2)
+        icp.const_iter = const_iter
+        icp.nn.use_gumbel, icp.nn.eps, icp.nn.tau = True, 1e-10, 0.05
+        s, t = src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True)
+        out = icp.icp(s, t, torch.eye(4, dtype=torch.float64, device=DEV).repeat(N, 1, 1), **kw)
+        out["T"].sum().backward()
+        return out, s.grad, t.grad
+
+    a, b, c = run(5, True), run(5, True), run(6, True)
+    assert torch.equal(a[0]["T"], b[0]["T"]) and torch.equal(a[1], b[1]) and float((a[2] - b[2]).abs().max()) <= 1e-12 * float(a[2].abs().max())
+    assert not torch.equal(a[0]["T"], c[0]["T"])                        # another seed, another draw
+    assert bool(torch.isfinite(a[1]).all()) and bool(torch.isfinite(a[2]).all()) and float(a[2].abs().max()) > 0
+    d = run(5, False)
+    K = d[0]["deltas"].shape[1]
+    assert 1 <= K <= 12 and d[0]["weights"].shape[1] == K and d[0]["costs"].shape[1] == K
+    assert bool(torch.isfinite(d[0]["T"]).all()) and bool(torch.isfinite(d[1]).all())
+    assert torch.equal(d[0]["deltas"][:, 0], a[0]["deltas"][:, 0])     # (same seed: the first iteration is the constant-iteration call's; later ones freeze cloud by cloud)

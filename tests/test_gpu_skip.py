@@ -195,7 +195,7 @@ def test_tail_launch_changes_no_gradient(dtype, N, n, K, icp_type, weights):
         return icp
     ref_icp = make(False)
     ref = _tail_call(ref_icp, src, tgt, w)
-    assert "_bwd_hint" not in ref_icp.knn_stats
+    assert "_bwd_hint" not in ref_icp.knn_stats and not ref_icp.knn_stats.get("_bwd_hints")
     icp = make(True)
     first = _tail_call(icp, src, tgt, w)                    # no earlier call: every iteration is its own pair of launches
     assert icp.knn_stats["bwd_tail_from"] == 0
@@ -226,3 +226,37 @@ def test_tail_launch_changes_no_gradient(dtype, N, n, K, icp_type, weights):
         assert float((a - b).abs().max()) <= rnd * scale, (i, float((a - b).abs().max()) / scale)
     fourth = _tail_call(icp, src, tgt, w)                   # ... and the hint has corrected itself
     assert icp.knn_stats["bwd_tail_from"] == t_from
+
+
+def test_tail_launch_on_ragged_lists_and_in_tolerance_mode():
+    """The one-launch tail with the clouds' own lengths (pad slots carry no work in window_body, inside the tail as outside it), and a tolerance-mode
+    call (several runs of the backward: the tail belongs to the run that reaches iteration 0): gradients equal the per-iteration launches'."""
+    N, n = 10, 12288
+    src, tgt = make_pairs(N, n, n, seed=71)
+    lens = [n - 517 * b for b in range(N)]
+    for mode in ("ragged", "tolerance"):
+        grads = {}
+        for tail in (False, True):
+            icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=12 if mode == "ragged" else 30, tolerance=1e-12 if mode == "ragged" else 1e-5)
+            icp.const_iter, icp.bwd_tail = mode == "ragged", tail
+            for rep in range(3):        # (the later calls have the earlier ones' hints; the third one's is made to place the tail high)
+                if tail and rep == 2:
+                    entry = icp.knn_stats["_bwd_hint"]
+                    entry[1].synchronize()
+                    K_run = entry[2][2]
+                    entry[0].zero_()
+                    entry[0][K_run - 1] = N
+                if mode == "ragged":
+                    S = [src[b, :lens[b]].to(DEV).requires_grad_(True) for b in range(N)]
+                    Tg = [tgt[b, :max(2048, lens[b] - 300)].to(DEV).requires_grad_(True) for b in range(N)]
+                    out = icp.icp(S, Tg, [torch.eye(4, device=DEV)] * N, **KW)
+                else:
+                    S, Tg = [src.to(DEV).requires_grad_(True)], [tgt.to(DEV).requires_grad_(True)]
+                    out = icp.icp(S[0], Tg[0], torch.eye(4, device=DEV).repeat(N, 1, 1), **KW)
+                out["T"].sum().backward()
+                torch.cuda.synchronize()
+            if tail:
+                assert icp.knn_stats["bwd_tail_from"] > 0 and int(icp.knn_stats["bwd_tail_error"].item()) == 0
+            grads[tail] = [torch.cat([x.grad.reshape(-1) for x in S]), torch.cat([x.grad.reshape(-1) for x in Tg])]
+        for a, b in zip(grads[False], grads[True]):
+            assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()), mode

@@ -465,6 +465,7 @@ class LoopConfig:
     gumbel: object = None         # (eps, tau, inject_U or None): the Gumbel-softmax correspondence (nn.py:43-70) instead of the nearest neighbour
     bwd_tail: bool = True         # truncated reverse sweep: the iterations before the ones the previous call still worked at run as ONE launch (dicp_loop_buffers.bwd_tail_from)
     plan_call: bool = True        # constant-iteration sweep calls: all segments behind one library call (dicp_icp_forward_plan)
+    cert_sets: bool = True        # a query whose match has a runner-up within the scores' rounding keeps a SET of 4 candidate rows, re-scored per iteration instead of searched
     cert_backoff: bool = True     # match certificates are switched off per cloud, on device, when a certified iteration costs more than 60 % of a full search
     reuse_matches: bool = True    # sweep path: match certificates -- an iteration searches only the waves holding a query whose match is not proven
                                   # unchanged since the wave's last search (exact; knn_sweep_kernel CERT)
@@ -616,6 +617,7 @@ class ICPLoop(torch.autograd.Function):
             if want_certs:
                 units = (n + 63) // 64          # (units of the sweep's one-query-per-lane forms; the two-query form uses half of them)
                 certs = dict(q=torch.empty((N, n), dtype=dt, device=dev), qu=torch.empty((N, units), dtype=dt, device=dev), count=cert_count,
+                             set=torch.empty((N * n * (es + 16),), dtype=torch.uint8, device=dev) if cfg.cert_sets else None,     # candidate sets: (N,n) budgets + (N,n,4) rows
                              rmax=torch.empty((N, 4), dtype=dt, device=dev), dcum=torch.empty((N, 2 * (Kmax + 1)), dtype=dt, device=dev))
             _lib.check(lib.dicp_loop_init(code, _p(T_init.contiguous()), _p(w0c), float(cfg.match_ratio_thresh), rows, N, n,
                                           _p(poses), _p(alive), _p(n_start), _p(center), _p(poses_c),
@@ -688,7 +690,8 @@ class ICPLoop(torch.autograd.Function):
                               and first[1].data_ptr() == T_init.data_ptr() and T_init.is_contiguous())
                 SP = _lib.SegmentPlan(nseg=len(segs), cert_from=cert_from if certs is not None else -1, keys=_p(sweep.keys),
                                       cert_q=_p(certs["q"]) if certs else None, cert_qu=_p(certs["qu"]) if certs else None,
-                                      cert_count=_p(certs["count"]) if certs else None, cert_cloud=_p(cert_cloud) if (certs and cfg.cert_backoff) else None)
+                                      cert_count=_p(certs["count"]) if certs else None, cert_cloud=_p(cert_cloud) if (certs and cfg.cert_backoff) else None,
+                                      cert_set=_p(certs["set"]) if certs else None)
                 n_new = sum(1 for (k0, _) in segs if (k0 == 0 or k0 in cfg.sweep_resort)) - (1 if have_first else 0)
                 fresh_orders = torch.empty((max(n_new, 1), N, n), dtype=torch.int32, device=dev)
                 used = 0
@@ -769,6 +772,7 @@ class ICPLoop(torch.autograd.Function):
                 LB.idx = (ctypes.c_void_p(idx_slabs[j].data_ptr() - base * N * n * 4) if need_grad else _p(idx_once)) if keep_idx else None
                 LB.cert_q, LB.cert_qu, LB.cert_count = (_p(certs["q"]), _p(certs["qu"]), _p(certs["count"])) if use_certs else (None, None, None)
                 LB.cert_cloud = _p(cert_cloud) if (use_certs and cfg.cert_backoff) else None
+                LB.cert_set = _p(certs["set"]) if use_certs else None
                 LB.cert_reset = int(k0 == cert_from)
                 LB.spos_prev0 = _p(spos_slabs[(k0 - 1) // kc][(k0 - 1) % kc]) if (keep_spos and k0 > 0) else None
                 LB.w = ctypes.c_void_p(w_slabs[j].data_ptr() - base * n * es)

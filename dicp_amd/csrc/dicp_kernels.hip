@@ -1013,11 +1013,15 @@ template <typename T> struct SweepCert {
     const T* dcum; int dstride;     // (N,dstride): (M_k, e_k) pairs per iteration
     int k;                          // this iteration
     int32_t* count;                 // (128) or NULL: [0,64) units searched again, [64,128) single queries, sharded by block
+    void* set;                      // optional candidate sets (see search_point): (N,n) T set budgets by query, then (N,n,4) int32 sorted positions
     int32_t* cloud;                 // (N,CERT_CLOUD) or NULL, per cloud: [0] units / [1] single queries searched again in this iteration; [2] the
                                     // state the step kernel keeps: 0 on, -1 on with one strike, k > 0 off for k more iterations (CERT_OFF_FOR_GOOD:
                                     // for the rest of the call), CERT_RECERTIFY: this iteration's guard searches every unit with certifying
                                     // sweeps; [3] its units (written by the searches: "a certified iteration ran"); [4] the last back-off length
 };
+constexpr int CERT_CANDS = 4;       // rows of a candidate set
+template <typename T> __device__ __forceinline__ T* set_budgets(void* set) { return (T*)set; }
+template <typename T> __device__ __forceinline__ int32_t* set_cands(void* set, int N, int n) { return (int32_t*)((char*)set + (size_t)N * n * sizeof(T)); }
 constexpr int CERT_MARGIN = 6;      // prune margin of a certifying search, in units of the plain one: the slab ends where H > H1 + 6E, so an
                                     // unscored row alone still leaves A = 2E (the certificate needs H2 - H1 > 4E + D S); 8: the search 4 % slower,
                                     // 8 % fewer single searches in the iteration after it -- a wash (A/B on one box)
@@ -1286,8 +1290,12 @@ __device__ __forceinline__ void sweep_unit(const T* __restrict__ src, const T* _
             }
             // no certificate: -(k + 2) says "searched at iteration k" -- spent for every later iteration, not searched twice in this one
             ct.q[(size_t)cloud * n_full + qi[q]] = bq > T(0) ? bq : cert_mark<T>(ct.k);
+            if (ct.set) set_budgets<T>(ct.set)[(size_t)cloud * n_full + qi[q]] = T(-1);      // (a new match: whatever candidate set the query had is void)
             if (bq > T(0)) qmin = min_t(qmin, bq); else ++nunc;
-        } else if (ct.q) ct.q[(size_t)cloud * n_full + qi[q]] = cert_mark<T>(ct.k);      // plain search of a unit inside a certified loop
+        } else if (ct.q) {
+            ct.q[(size_t)cloud * n_full + qi[q]] = cert_mark<T>(ct.k);                      // plain search of a unit inside a certified loop
+            if (ct.set) set_budgets<T>(ct.set)[(size_t)cloud * n_full + qi[q]] = T(-1);
+        }
     }
     if (CERT) {
         // the unit's filter value: its smallest budget -- or 0 ("look at me every iteration") when more queries than the accumulate
@@ -1300,8 +1308,9 @@ __device__ __forceinline__ void sweep_unit(const T* __restrict__ src, const T* _
         // per cloud, for the step kernel's "are certificates worth it here?": queries that got no certificate will be searched one by one in
         // every later iteration (near-ties inside the rounding bound of a score: dense surfaces far from the centre, duplicated targets)
         if (ct.cloud && lane == 0) {
-            if (tot) atomicAdd(ct.cloud + (size_t)cloud * CERT_CLOUD + 1, tot);
-            if (unit == 0) ct.cloud[(size_t)cloud * CERT_CLOUD + 3] = (n_full + WAVE * Q - 1) / (WAVE * Q);
+            if (tot && !ct.set) atomicAdd(ct.cloud + (size_t)cloud * CERT_CLOUD + 1, tot);      // (with candidate sets they are searched ONCE more, and counted then)
+            if (tot && ct.set) atomicAdd(ct.cloud + (size_t)cloud * CERT_CLOUD + 6, tot);       // ... but a cloud where MOST queries came back without one is not worth the sets
+            if (unit == 0) { ct.cloud[(size_t)cloud * CERT_CLOUD + 3] = (n_full + WAVE * Q - 1) / (WAVE * Q); ct.cloud[(size_t)cloud * CERT_CLOUD + 5] = ct.set ? 1 : 0; }
         }
     }
     // sharded: one counter serialises ~12 ns per add, which at 65k waves would outlast the kernel itself
@@ -1343,7 +1352,8 @@ template <typename T> struct PointSearch {
 // the score() every search form uses; equal scores resolve to the lowest ORIGINAL index: index for index the match of a full
 // search.  Returns the match's sorted position (-1: none) and leaves the query's new budget in `budget`.
 template <typename T>
-__device__ __forceinline__ int search_point(const PointSearch<T>& ps, const int cloud, const T* nx, const int prev, T& budget, unsigned long long& rows_scored) {
+__device__ __forceinline__ int search_point(const PointSearch<T>& ps, const int cloud, const T* nx, const int prev, T& budget, unsigned long long& rows_scored,
+                                            T& set_budget, int* cset /* [CERT_CANDS], wave-uniform */) {
     using T4 = typename V4<T>::type;
     const int lane = threadIdx.x & (WAVE - 1);
     const int m = max(rows_of(ps.tgt_rows, cloud, ps.m_full), 1);
@@ -1386,8 +1396,8 @@ __device__ __forceinline__ int search_point(const PointSearch<T>& ps, const int 
         if (r0 > 0 || r1 < m) h_edge = (thr + hx) * (T(1) - T(8) * eps);
     }
 
-    T b1 = inf_v<T>(), b2 = inf_v<T>();                         // this lane's two smallest scores
-    int j1 = -1;
+    T b1 = inf_v<T>(), b2 = inf_v<T>(), b3 = inf_v<T>();       // this lane's three smallest scores (the third: a bound only)
+    int j1 = -1, j2 = -1;
     constexpr int U = 4;                                        // rows in flight per lane: a wide slab is a few round trips, not one per 64 rows
     for (int j = r0 + lane; j < r1; j += U * WAVE) {
         T4 y[U];
@@ -1397,9 +1407,10 @@ __device__ __forceinline__ int search_point(const PointSearch<T>& ps, const int 
         for (int u = 0; u < U; ++u) {
             const int jj = j + u * WAVE;
             const T sc = jj < r1 ? score<T, T4>(nx, y[u]) : inf_v<T>();
-            if (sc < b1) { b2 = b1; b1 = sc; j1 = jj; }
-            else if (sc == b1 && sc < inf_v<T>()) { b2 = b1; if (pm[jj] < pm[j1]) j1 = jj; }
-            else if (sc < b2) b2 = sc;
+            if (sc < b1) { b3 = b2; b2 = b1; j2 = j1; b1 = sc; j1 = jj; }
+            else if (sc == b1 && sc < inf_v<T>()) { b3 = b2; b2 = b1; if (pm[jj] < pm[j1]) { j2 = j1; j1 = jj; } else j2 = jj; }
+            else if (sc < b2) { b3 = b2; b2 = sc; j2 = jj; }
+            else if (sc < b3) b3 = sc;
         }
     }
     const T bv = wave_min(b1);
@@ -1419,7 +1430,33 @@ __device__ __forceinline__ int search_point(const PointSearch<T>& ps, const int 
         const T s2 = wave_min(lane == win ? b2 : b1);
         T H1c;
         budget = cert_from_scores(bv, s2, hx, h_edge, ps.ct.dcum + (size_t)cloud * ps.ct.dstride + 2 * ps.ct.k, H1c);
-    }
+        // No certificate for the match alone (a runner-up inside the rounding allowance of the scores: dense surfaces, duplicated targets):
+        // a certificate for a SET.  The CERT_CANDS smallest scores' rows are kept; s_rest bounds every other row from below (what the lanes
+        // have left of their three smallest, and the slab's edge).  While the query has moved by less than the budget that (match, s_rest)
+        // give -- the same inequality as above with the runner-up replaced by the best row OUTSIDE the set -- the old match still scores
+        // strictly below every outside row, so the new match is the best of the set under the same score() and tie rule: CERT_CANDS rows
+        // to re-score per iteration instead of a search.
+        set_budget = T(-1);
+        if (ps.ct.set && !(budget > T(0))) {
+            cset[0] = bs;
+            T r1 = b1, r2 = b2;
+            int i1 = j1, i2 = j2;
+            if (lane == win) { r1 = b2; i1 = j2; r2 = inf_v<T>(); }      // (the winner's own entry is used up)
+#pragma unroll
+            for (int c = 1; c < CERT_CANDS; ++c) {
+                const T mn = wave_min(r1);
+                cset[c] = -1;
+                if (mn < inf_v<T>()) {                              // (wave-uniform)
+                    const int L0 = __ffsll((long long)__ballot(r1 == mn)) - 1;
+                    cset[c] = __shfl(i1, L0);
+                    if (lane == L0) { r1 = r2; i1 = i2; r2 = inf_v<T>(); }
+                }
+            }
+            const T s_rest = wave_min(min_t(r1, b3));
+            T H1s;
+            set_budget = cert_from_scores(bv, s_rest, hx, h_edge, ps.ct.dcum + (size_t)cloud * ps.ct.dstride + 2 * ps.ct.k, H1s);
+        }
+    } else set_budget = T(-1);
     rows_scored += (unsigned long long)(r1 - r0);             // (the caller counts the searches and adds everything to the statistics ONCE, at its end:
                                                                 //  a wave's loads return behind its earlier atomics, and a cloud's word is one address)
     return bs;          // (sorted slots [0,m) hold the cloud's own rows: a row found is a real one)
@@ -1443,7 +1480,7 @@ __global__ __launch_bounds__(BLOCK, DICP_SWEEP_MINW) void knn_sweep_guard_kernel
     const T step = ct.k > 0 ? dk[0] - dk[-2] : inf_v<T>();     // how far the cloud's queries can have moved in the last step
     T* qu = ct.qu + (size_t)cloud * units + unit;
     const T v = *qu;
-    if (ct.cloud && unit == 0 && lane == 0) ct.cloud[(size_t)cloud * CERT_CLOUD + 3] = units;
+    if (ct.cloud && unit == 0 && lane == 0) { ct.cloud[(size_t)cloud * CERT_CLOUD + 3] = units; ct.cloud[(size_t)cloud * CERT_CLOUD + 5] = ct.set ? 1 : 0; }
     bool plain;
     const int cstate = ct.cloud ? ct.cloud[(size_t)cloud * CERT_CLOUD + 2] : 0;
     if (cstate > 0) plain = true;                               // this cloud's certificates are off (step kernel): every unit, plainly
@@ -1457,9 +1494,17 @@ __global__ __launch_bounds__(BLOCK, DICP_SWEEP_MINW) void knn_sweep_guard_kernel
         for (int q = 0; q < Q; ++q) {
             const int pos = unit * (WAVE * Q) + q * WAVE + lane;
             if (pos < n) {
-                const T b = ct.q[(size_t)cloud * n_full + qorder[(size_t)cloud * n_full + pos]];
+                const size_t at = (size_t)cloud * n_full + qorder[(size_t)cloud * n_full + pos];
+                const T b = ct.q[at];
                 ++live;
-                if (b > spent) qmin = min_t(qmin, b); else ++bad;
+                if (b > spent) qmin = min_t(qmin, b);
+                else {                                          // no certificate of its own: a candidate set that still stands is as good (the accumulate re-scores it)
+                    // A budget that the poses' motion has spent counts against the unit, as ever.  A query that never had a certificate of its own
+                    // (b < 0: a mark) may have a candidate set: one that stands is as good as a budget; none tried yet (-1): the accumulate's
+                    // search of this query will try; "no set either" (-2) or a spent set count against the unit.
+                    const T sb = (ct.set && b < T(0)) ? set_budgets<T>(ct.set)[at] : T(-2);
+                    if (sb > spent) qmin = min_t(qmin, sb); else if (sb != T(-1)) ++bad;
+                }
             }
         }
         int nbad = 0, nlive = 0;
@@ -1917,7 +1962,7 @@ __global__ __launch_bounds__(BLOCK, (CERT && sizeof(T) == 4) ? 5 : 1) void accum
     const int nc = rows_of(src_rows, cloud, n);             // ragged batches: rows past the cloud's own carry weight 0 (ICP.py:386-398)
     const int end = min(nc, (blk + 1) * ACC_PTS);
     unsigned long long rows_scored = 0;                     // this wave's on-the-spot searches: rows scored, searches made (wave-uniform)
-    int singles = 0;
+    int singles = 0, rescored = 0;                          // ... and this LANE's candidate sets re-scored
     if (CERT && ps.ct.dcum && !(ps.ct.cloud && ps.ct.cloud[(size_t)cloud * CERT_CLOUD + 2] > 0)) {      // (certificates off for this cloud: the guard launch has just searched every unit)
         // first the budgets of this block's points (before the sums' registers are live): spent ones are searched again, one query at a
         // time by the whole wave; the thread that owns the point rewrites its match and budget and reads them back below
@@ -1930,28 +1975,74 @@ __global__ __launch_bounds__(BLOCK, (CERT && sizeof(T) == 4) ? 5 : 1) void accum
             const int i = blk * ACC_PTS + t * BLOCK + threadIdx.x;
             b[t] = i < end ? ps.ct.q[(size_t)cloud * n + i] : inf_v<T>();
         }
+        T* __restrict__ qs = ps.ct.set ? set_budgets<T>(ps.ct.set) : nullptr;           // candidate sets (search_point): budgets by query, then the rows
+        int32_t* __restrict__ cands = ps.ct.set ? set_cands<T>(ps.ct.set, N, n) : nullptr;
 #pragma unroll 1
         for (int t = 0; t < ROUNDS; ++t) {
-            const bool redo = !(b[t] > spent) && b[t] != cert_mark<T>(ps.ct.k);     // (spent, never certifiable, NaN -- unless this iteration's guard launch just searched it)
-            unsigned long long todo = __ballot(redo);
-            if (!todo) continue;                                // (wave-uniform; the common case)
+            const bool open = !(b[t] > spent);                  // spent, never certifiable, NaN
+            if (!__ballot(open)) continue;                      // (wave-uniform; the common case)
             const size_t pt = (size_t)cloud * n + min(blk * ACC_PTS + t * BLOCK + (int)threadIdx.x, n - 1);
-            T p[3] = {T(0), T(0), T(0)}, nb = T(-1);
-            int j = -1;
+            const T sb = (open && qs) ? qs[pt] : T(-1);
+            bool redo = open && b[t] != cert_mark<T>(ps.ct.k);      // (a query this iteration's guard launch has just searched is not searched twice)
+            if (!__ballot(redo)) continue;
+            T p[3] = {T(0), T(0), T(0)}, nb = T(-1), ns = T(-2);
+            int j = -1, nc[CERT_CANDS];
+#pragma unroll
+            for (int c = 0; c < CERT_CANDS; ++c) nc[c] = -1;
             if (redo) { const T* sp = src + pt * 3; p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2]; j = ps.spos[pt]; }
             T Cs[9], rs[3];
             load_pose(ps.pose, cloud, Cs, rs);
+            if (redo && sb > spent) {
+                // the candidate set stands: the new match is its best row (same score(), equal scores -> lowest original index)
+                using T4 = typename V4<T>::type;
+                T nx[3];
+                query_point(Cs, rs, p, nx);
+                const T4* __restrict__ tg = ps.tgs4 + (size_t)cloud * ps.m_pad;
+                const int32_t* __restrict__ pm = ps.tperm + (size_t)cloud * ps.m_pad;
+                const int32_t* cd = cands + pt * CERT_CANDS;
+                int cj[CERT_CANDS];
+                T4 row[CERT_CANDS];
+#pragma unroll
+                for (int c = 0; c < CERT_CANDS; ++c) cj[c] = cd[c];
+#pragma unroll
+                for (int c = 0; c < CERT_CANDS; ++c) row[c] = tg[max(cj[c], 0)];       // (all four gathers in flight together)
+                T best = inf_v<T>();
+                int bj = -1;
+#pragma unroll
+                for (int c = 0; c < CERT_CANDS; ++c) {
+                    const T sc = cj[c] >= 0 ? score<T, T4>(nx, row[c]) : inf_v<T>();
+                    if (sc < best) { best = sc; bj = cj[c]; }
+                    else if (sc == best && sc < inf_v<T>() && pm[cj[c]] < pm[bj]) bj = cj[c];
+                }
+                if (bj >= 0) { ps.spos[pt] = bj; redo = false; ++rescored; }       // (a set of finite rows always has a best one; otherwise: search)
+            }
+            unsigned long long todo = __ballot(redo);
             while (todo) {
                 const int L = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
                 const T pq[3] = {__shfl(p[0], L), __shfl(p[1], L), __shfl(p[2], L)};
-                T nx[3], got;
+                T nx[3], got, gs;
+                int gc[CERT_CANDS];
                 query_point(Cs, rs, pq, nx);
-                const int found = search_point<T>(ps, cloud, nx, __shfl(j, L), got, rows_scored);
+                const int found = search_point<T>(ps, cloud, nx, __shfl(j, L), got, rows_scored, gs, gc);
                 ++singles;
-                if (lane == L) { j = found; nb = got; }
+                if (lane == L) {
+                    j = found; nb = got; ns = gs > T(0) ? gs : T(-2);       // (-2: searched, no set either)
+#pragma unroll
+                    for (int c = 0; c < CERT_CANDS; ++c) nc[c] = gc[c];
+                }
             }
-            if (redo) { ps.spos[pt] = j; ps.ct.q[pt] = nb; }
+            if (redo) {
+                ps.spos[pt] = j;
+                ps.ct.q[pt] = nb;
+                if (qs) {
+                    qs[pt] = nb > T(0) ? T(-1) : ns;
+                    if (ns > T(0)) {
+#pragma unroll
+                        for (int c = 0; c < CERT_CANDS; ++c) cands[pt * CERT_CANDS + c] = nc[c];
+                    }
+                }
+            }
         }
     }
     T C[9], r[3];
@@ -1981,10 +2072,17 @@ __global__ __launch_bounds__(BLOCK, (CERT && sizeof(T) == 4) ? 5 : 1) void accum
         if (w_out) w_out[(size_t)cloud * w_stride + i] = (w_prev && live == T(0)) ? w_prev[(size_t)cloud * w_stride + i] : s.w;
     }
     block_reduce_store<T, NACC, NACC_PAD>(acc, partials + ((size_t)cloud * bpc + blk) * NACC_PAD, red);
-    if (CERT && singles > 0 && (threadIdx.x & (WAVE - 1)) == 0) {      // the statistics of this wave's on-the-spot searches, after everything else
-        if (ps.pairs) atomicAdd(ps.pairs + (blockIdx.x & (DICP_PAIR_SHARDS - 1)), rows_scored);
-        if (ps.ct.count) atomicAdd(ps.ct.count + CERT_SHARDS + (blockIdx.x & (CERT_SHARDS - 1)), singles);
-        if (ps.ct.cloud) atomicAdd(ps.ct.cloud + (size_t)cloud * CERT_CLOUD + 1, singles);
+    if (CERT) {             // the statistics of this wave's on-the-spot searches, after everything else
+        // a re-scored candidate set costs about a twelfth of a single-query search (4 gathered rows against a slab): counted as such for the switch
+        int resc = rescored;
+#pragma unroll
+        for (int o = WAVE / 2; o > 0; o >>= 1) resc += __shfl_xor(resc, o);
+        const int eq = singles + resc / 12;
+        if (eq > 0 && (threadIdx.x & (WAVE - 1)) == 0) {
+            if (ps.pairs && rows_scored) atomicAdd(ps.pairs + (blockIdx.x & (DICP_PAIR_SHARDS - 1)), rows_scored);
+            if (ps.ct.count && singles) atomicAdd(ps.ct.count + CERT_SHARDS + (blockIdx.x & (CERT_SHARDS - 1)), singles);
+            if (ps.ct.cloud) atomicAdd(ps.ct.cloud + (size_t)cloud * CERT_CLOUD + 1, eq);
+        }
     }
 }
 
@@ -2021,7 +2119,7 @@ template <typename T, int NT>
 __device__ __forceinline__ void step_body(const dicp_step_io& io, int cloud, int tid) {
     __shared__ double sacc[NACC_PAD], sA[36], sAreg[36], spose[12], sout[24], smisc[16];
     __shared__ T sframe[12];
-    __shared__ int scc[5];
+    __shared__ int scc[7];
     __shared__ int s_copy;
     if (tid < WAVE) {   // reduce the per-block partials: lane = (part, slot); fixed summation order -> bit-reproducible
         const int slot_i = tid & 31, part = tid >> 5;
@@ -2049,7 +2147,7 @@ __device__ __forceinline__ void step_body(const dicp_step_io& io, int cloud, int
         if (tid == 51) smisc[11] = (double)((const T*)io.iterations)[cloud];
         if (tid == 52) smisc[12] = (double)((const T*)io.matched_ratio)[cloud];
         if (tid >= 12 && tid < 24 && io.frame) sframe[tid - 12] = ((const T*)io.frame)[(size_t)cloud * 12 + (tid - 12)];
-        if (tid >= 24 && tid < 29 && io.cert_cloud) scc[tid - 24] = io.cert_cloud[(size_t)cloud * CERT_CLOUD + (tid - 24)];
+        if (tid >= 24 && tid < 31 && io.cert_cloud) scc[tid - 24] = io.cert_cloud[(size_t)cloud * CERT_CLOUD + (tid - 24)];
     }
     __syncthreads();
     if (tid == 0) {
@@ -2133,18 +2231,23 @@ __device__ __forceinline__ void step_body(const dicp_step_io& io, int cloud, int
             // of certifying sweeps): a cloud that is still moving when the certificates start must get them back once it has settled.
             int32_t* cc = io.cert_cloud + (size_t)cloud * CERT_CLOUD;
             const int c_units = scc[0], c_single = scc[1], state = scc[2], units = scc[3], c_back = scc[4];     // (read in the prologue)
+            const bool sets = scc[5] != 0;      // candidate sets are kept: a query without a certificate of its own is searched ONCE more (for its set), not in every iteration
             if (units > 0) {
                 const bool costly = 1.3 * c_units + 0.12 * c_single > 0.6 * units;
                 int next = state;
                 if (state >= CERT_OFF_FOR_GOOD) next = state;
                 else if (state > 0) next = state > 1 ? state - 1 : CERT_RECERTIFY;
-                else if (state == CERT_RECERTIFY) next = (0.12 * c_single > 0.6 * units) ? CERT_OFF_FOR_GOOD : 0;
+                else if (state == CERT_RECERTIFY) next = sets ? (costly ? -1 : 0) : ((0.12 * c_single > 0.6 * units) ? CERT_OFF_FOR_GOOD : 0);
+                // (sets: making them costs one single-query search per query without a certificate, re-scoring them a twelfth of that per iteration --
+                //  against one full search per iteration that only pays while such queries are the minority)
+                else if (sets && 2 * scc[6] > io.n) next = CERT_OFF_FOR_GOOD;
                 else if (!costly) next = 0;
-                else if (c_units == 0) next = CERT_OFF_FOR_GOOD;
+                else if (c_units == 0 && !sets) next = CERT_OFF_FOR_GOOD;
+                else if (state == -1 && sets && c_units == 0) next = CERT_OFF_FOR_GOOD;      // twice in a row costly by per-query work alone (no unit moved): structural
                 else if (state == -1) { const int d = c_back > 0 ? min(2 * c_back, 16) : 2; cc[4] = d; next = d; }
                 else next = -1;
                 cc[2] = next;
-                cc[0] = 0; cc[1] = 0; cc[3] = 0;
+                cc[0] = 0; cc[1] = 0; cc[3] = 0; cc[6] = 0;
             }
         }
     }
@@ -3668,7 +3771,7 @@ struct CertAcc {              // what the accumulate of a certified iteration ne
     const void* pose_search; const void* tgs4; const int32_t* tperm; const int32_t* bucket; const void* brange; int nbkt;
     const int32_t* tgt_rows; int m_full, m_pad; unsigned long long* pairs;
     void* q; void* qu; const void* dcum; int dstride, k; int32_t* count;
-    int32_t* spos; int32_t* spos_next; int32_t* cloud;
+    int32_t* spos; int32_t* spos_next; int32_t* cloud; void* set;
 };
 
 template <typename T, int Q, int CH, int MINW = 1>
@@ -3936,7 +4039,7 @@ static int sweep_queries_per_lane(int cfg) { return cfg == 2 ? 2 : ((cfg == 1 ||
 static int sweep_auto_cfg(int N, int n) { return ((long)N * n >= 2L * BLOCK * 1024) ? SWEEP_CFG_BIG : 4; }
 
 struct CertArgs {             // certifying search: budgets (NULL q: plain search), motion bounds; guard: the launch of a certified iteration
-    void* q; void* qu; const void* dcum; int dstride; int k; int32_t* count; bool guard; int32_t* cloud;
+    void* q; void* qu; const void* dcum; int dstride; int k; int32_t* count; bool guard; int32_t* cloud; void* set;
 };
 
 static int sweep_launch(int dtype, const void* src, const void* pose, const void* tgs4, const int32_t* tperm,
@@ -3962,10 +4065,10 @@ static int sweep_launch(int dtype, const void* src, const void* pose, const void
     if (ca.q) {             // certifying search, or the guard launch of a certified iteration
         if (!ca.qu || !ca.dcum || !spos || !qorder) return DICP_ERR_ENUM;
         if (dtype == DICP_F32) {
-            SweepCert<float> c{(float*)ca.q, (float*)ca.qu, (const float*)ca.dcum, ca.dstride, ca.k, ca.count, ca.cloud};
+            SweepCert<float> c{(float*)ca.q, (float*)ca.qu, (const float*)ca.dcum, ca.dstride, ca.k, ca.count, ca.set, ca.cloud};
             if (cfg == 2) DICP_SWEEP_CG(float, 2, 8, c); else if (cfg == 4) DICP_SWEEP_CG(float, 1, 16, c); else DICP_SWEEP_CG(float, 1, 8, c);
         } else {
-            SweepCert<double> c{(double*)ca.q, (double*)ca.qu, (const double*)ca.dcum, ca.dstride, ca.k, ca.count, ca.cloud};
+            SweepCert<double> c{(double*)ca.q, (double*)ca.qu, (const double*)ca.dcum, ca.dstride, ca.k, ca.count, ca.set, ca.cloud};
             if (cfg == 2) DICP_SWEEP_CG(double, 2, 8, c); else DICP_SWEEP_CG(double, 1, 8, c);
         }
         return launch_status();
@@ -4058,7 +4161,7 @@ static int accumulate_go(int dtype, const dicp_weight_params* prm, const void* s
         if (ca) { \
             ps.pose = (const T*)ca->pose_search; ps.tgs4 = (const typename V4<T>::type*)ca->tgs4; ps.tperm = ca->tperm; ps.bucket = ca->bucket; ps.brange = (const T*)ca->brange; \
             ps.nbkt = ca->nbkt; ps.tgt_rows = ca->tgt_rows; ps.m_full = ca->m_full; ps.m_pad = ca->m_pad; ps.pairs = ca->pairs; \
-            ps.ct = SweepCert<T>{(T*)ca->q, (T*)ca->qu, (const T*)ca->dcum, ca->dstride, ca->k, ca->count, ca->cloud}; ps.spos = ca->spos; ps.spos_next = ca->spos_next; \
+            ps.ct = SweepCert<T>{(T*)ca->q, (T*)ca->qu, (const T*)ca->dcum, ca->dstride, ca->k, ca->count, ca->set, ca->cloud}; ps.spos = ca->spos; ps.spos_next = ca->spos_next; \
             if (P.mode == MODE_PT2PL) DICP_ACC(T, MODE_PT2PL, true, ps); else DICP_ACC(T, MODE_PT2PT, true, ps); \
         } else { if (P.mode == MODE_PT2PL) DICP_ACC(T, MODE_PT2PL, false, ps); else DICP_ACC(T, MODE_PT2PT, false, ps); } } while (0)
     if (dtype == DICP_F32) DICP_ACC_T(float); else DICP_ACC_T(double);
@@ -4440,7 +4543,7 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
                 }
                 begin_launch();
                 rc = sweep_launch(dtype, qsrc, pose_s, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, N, n, m, B->m_pad, nullptr, spos_k,
-                                  B->pairs, cfg, Rows{B->src_rows, B->tgt_rows}, st, CertArgs{B->cert_q, B->cert_qu, B->dcum, 2 * (B->K + 1), k, count_k, !fresh, B->cert_cloud});
+                                  B->pairs, cfg, Rows{B->src_rows, B->tgt_rows}, st, CertArgs{B->cert_q, B->cert_qu, B->dcum, 2 * (B->K + 1), k, count_k, !fresh, B->cert_cloud, B->cert_set});
             } else
             rc = dicp_knn_sweep(dtype, qsrc, pose_s, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, B->src_rows, B->tgt_rows, N, n, m, B->m_pad,
                                 B->idx ? idx_k : nullptr, spos_k, B->pairs, cfg, stream);
@@ -4452,7 +4555,7 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
                 // are the start of the next iteration's (within this call)
                 const CertAcc ca{pose_s, B->tgt4, B->tperm, B->bucket, B->brange, B->nbkt, B->tgt_rows, m, B->m_pad, B->pairs,
                                  B->cert_q, B->cert_qu, fresh ? nullptr : B->dcum, 2 * (B->K + 1), k, count_k,
-                                 spos_k, (B->idx_per_iter && k + 1 < k1) ? spos_k + (size_t)N * n : nullptr, B->cert_cloud};
+                                 spos_k, (B->idx_per_iter && k + 1 < k1) ? spos_k + (size_t)N * n : nullptr, B->cert_cloud, B->cert_set};
                 rc = accumulate_go(dtype, prm, B->src, B->tgt_sorted, B->tgt_sorted_stride, spos_k, pose_k, B->w_init, alive_k, B->src_rows, N, n, B->m_pad,
                                    B->partials, w_k, B->w_stride, stream, &ca, w_prev_k);
             } else if (sorted_rows)
@@ -4523,6 +4626,7 @@ int dicp_icp_forward_plan(int dtype, const dicp_weight_params* prm, const dicp_l
         const bool certs = S->cert_from >= 0 && k0 >= S->cert_from;
         B.cert_q = certs ? S->cert_q : nullptr; B.cert_qu = certs ? S->cert_qu : nullptr; B.cert_count = certs ? S->cert_count : nullptr;
         B.cert_cloud = certs ? S->cert_cloud : nullptr;
+        B.cert_set = certs ? S->cert_set : nullptr;
         B.cert_reset = (S->cert_from >= 0 && k0 == S->cert_from) ? 1 : 0;
         B.spos_prev0 = (B.spos && B.idx_per_iter && k0 > 0) ? B.spos + (size_t)(k0 - 1) * N * n : nullptr;
         B.w_prev0 = k0 > 0 ? (const char*)B.w + (size_t)(k0 - 1) * B.w_iter * es : nullptr;

@@ -296,6 +296,10 @@ typedef struct dicp_loop_buffers {
                                 not PROVEN unchanged -- whole units in a guard launch where many are, the others inside dicp_accumulate's launch
                                 (exact: same indices as a full search).  Needs spos (and no idx), tgt_sorted, qorder, cert_qu, rmax, dcum */
     void* cert_qu;           /* (N, ceil(n/64)) T scratch */
+    void* cert_set;          /* optional, N*n*(sizeof(T) + 16) bytes of scratch: candidate sets -- a query whose match has a runner-up inside the rounding allowance
+                                of the scores (dense surfaces, duplicated targets) gets no certificate of its own; the search that finds this keeps the
+                                rows of its 4 smallest scores and a budget from the best row OUTSIDE that set, and while the budget stands the accumulate
+                                re-scores those 4 rows instead of searching (exact: the match stays strictly below every outside row) */
     int32_t* cert_count;     /* optional (K,128) zeros: per iteration, units searched again [0,64) and single queries [64,128), sharded by block */
     void* rmax;              /* (N,4) T from dicp_loop_init: bounding radius and midpoint of each source cloud */
     void* dcum;              /* (N, 2(K+1)) T: per iteration (motion bound since iteration 0, rounding of a transformed point); dicp_loop_init
@@ -380,7 +384,7 @@ typedef struct dicp_segment_plan {
     int32_t pad0;
     int32_t* order[DICP_MAX_SEGMENTS];       /* (N,n) each: the query order the segment searches in (several segments may share one), NULL: none */
     const void* keys;        /* (N,m_pad) sorted target x keys (dicp_sweep_sort): the rank search of dicp_query_order */
-    void* cert_q; void* cert_qu; int32_t* cert_count; int32_t* cert_cloud;
+    void* cert_q; void* cert_qu; int32_t* cert_count; int32_t* cert_cloud; void* cert_set;
 } dicp_segment_plan;
 int dicp_icp_forward_plan(int dtype, const dicp_weight_params* prm, const dicp_loop_buffers* buf, const dicp_segment_plan* plan, int N, int n, int m,
                           int dim, int const_iter, double tolerance, void* stream);

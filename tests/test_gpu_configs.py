@@ -452,8 +452,8 @@ def test_config4_full_batch_256_by_65536():
         assert torch.equal(got[b:b + 1], want), b
 
 
-@pytest.mark.parametrize("kind", ["scene", "near_duplicates", "random"])
-def test_certificates_switch_themselves_off_where_they_cost_more(kind):
+@pytest.mark.parametrize("kind,sets", [("scene", True), ("scene", False), ("near_duplicates", True), ("near_duplicates", False), ("random", True)])
+def test_certificates_switch_themselves_off_where_they_cost_more(kind, sets):
     """Proving a match unchanged must never cost more than searching it again.  Per cloud, on device, the step kernel weighs what a certified
     iteration searched again against a full search and switches the cloud's certificates off for the rest of the call when they do not pay
     (planar scenes: 8 % of the queries sit within float32's rounding of a second candidate on the dense surfaces; near-duplicated targets: all
@@ -470,7 +470,7 @@ def test_certificates_switch_themselves_off_where_they_cost_more(kind):
     outs = {}
     for name, reuse, backoff in (("plain", False, True), ("certs", True, False), ("switch", True, True)):
         icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
-        icp.const_iter, icp.reuse_matches, icp.cert_backoff, icp.knn_variant = True, reuse, backoff, _lib.KNN_SWEEP
+        icp.const_iter, icp.reuse_matches, icp.cert_backoff, icp.knn_variant, icp.cert_sets = True, reuse, backoff, _lib.KNN_SWEEP, sets
         S, Tg = src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True)
         out = icp.icp(S, Tg, torch.eye(4, device=DEV).repeat(N, 1, 1), **KW)
         out["T"].sum().backward()
@@ -484,8 +484,16 @@ def test_certificates_switch_themselves_off_where_they_cost_more(kind):
     assert int(outs["certs"][3]["certs_off"].sum()) == 0
     if kind == "random":
         assert int(off.sum()) == 0, off.tolist()                        # certificates pay on these clouds: they stay on
+    elif sets:
+        # candidate sets (ICP.cert_sets, the default): a query whose match has a runner-up inside the scores' rounding keeps its 4 best rows and a budget from
+        # the best row outside them -- re-scored per iteration, not searched: the certificates pay on these clouds too and (mostly) stay on
+        again = outs["switch"][3]["searched_again"]
+        singles = again[:, 64:].sum(1).tolist()
+        if kind == "scene":
+            assert int(off.sum()) <= N // 4, off.tolist()
+            assert max(singles[6:]) * 20 < max(singles), singles         # the single-query searches all but vanish once the sets exist
     elif kind == "scene":
-        # ... and are off for most of these (a cloud whose single-query searches stay under 60 % of a full search keeps them: break-even by the rule)
+        # without them: off for most of these (a cloud whose single-query searches stay under 60 % of a full search keeps them: break-even by the rule)
         assert int(off.sum()) >= N // 2, off.tolist()
     else:
         assert int(off.sum()) == N, off.tolist()                        # ... and are off everywhere here, from the certifying search on

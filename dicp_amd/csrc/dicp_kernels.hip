@@ -1982,7 +1982,7 @@ __global__ __launch_bounds__(BLOCK, (CERT && sizeof(T) == 4) ? 5 : 1) void accum
             const bool open = !(b[t] > spent);                  // spent, never certifiable, NaN
             if (!__ballot(open)) continue;                      // (wave-uniform; the common case)
             const size_t pt = (size_t)cloud * n + min(blk * ACC_PTS + t * BLOCK + (int)threadIdx.x, n - 1);
-            const T sb = (open && qs) ? qs[pt] : T(-1);
+            const T sb = (open && qs) ? qs[pt] : T(-1);      // (all rounds' set budgets in flight up front: measured, no gain -- the chain behind them is what costs)
             bool redo = open && b[t] != cert_mark<T>(ps.ct.k);      // (a query this iteration's guard launch has just searched is not searched twice)
             if (!__ballot(redo)) continue;
             T p[3] = {T(0), T(0), T(0)}, nb = T(-1), ns = T(-2);

@@ -1957,6 +1957,7 @@ __global__ __launch_bounds__(BLOCK, (CERT && sizeof(T) == 4) ? 5 : 1) void accum
                                                            T* __restrict__ w_out, long w_stride, const int32_t* __restrict__ src_rows, PointSearch<T> ps,
                                                            const T* __restrict__ w_prev /* optional: a frozen cloud (alive = 0) keeps its previous weights, ICP.py:224-226 */) {
     __shared__ T red[(BLOCK / WAVE) * NACC_PAD];
+    __shared__ short set_list[CERT ? BLOCK / WAVE : 1][CERT ? ACC_PTS / (BLOCK / WAVE) : 1];      // per wave: its points (offsets in the block's range) with a standing candidate set
     int cloud, blk;
     if (!decode_block(bpc, N, cloud, blk)) return;
     const int nc = rows_of(src_rows, cloud, n);             // ragged batches: rows past the cloud's own carry weight 0 (ICP.py:386-398)
@@ -1977,14 +1978,73 @@ __global__ __launch_bounds__(BLOCK, (CERT && sizeof(T) == 4) ? 5 : 1) void accum
         }
         T* __restrict__ qs = ps.ct.set ? set_budgets<T>(ps.ct.set) : nullptr;           // candidate sets (search_point): budgets by query, then the rows
         int32_t* __restrict__ cands = ps.ct.set ? set_cands<T>(ps.ct.set, N, n) : nullptr;
+        bool isset[ROUNDS];
+#pragma unroll
+        for (int t = 0; t < ROUNDS; ++t) isset[t] = false;
+        if (qs) {
+            // Standing candidate sets first, ALL rounds of the wave at once: the points with one (8 % of them on scanned surfaces, in every wave)
+            // are listed in LDS and re-scored by consecutive lanes -- one chain of dependent loads (set budget, rows, scores) per 64 such
+            // points instead of one per round of the block (planar scenes: 110 -> 98 us per launch; the plain accumulate: 58).
+            const int wv = threadIdx.x >> 6;
+            T sbv[ROUNDS];
+#pragma unroll
+            for (int t = 0; t < ROUNDS; ++t) {
+                const int i = blk * ACC_PTS + t * BLOCK + (int)threadIdx.x;
+                const bool open = i < end && !(b[t] > spent) && b[t] != cert_mark<T>(ps.ct.k);
+                sbv[t] = open ? qs[(size_t)cloud * n + i] : T(-1);
+            }
+            int total = 0;
+#pragma unroll
+            for (int t = 0; t < ROUNDS; ++t) {
+                isset[t] = sbv[t] > spent;
+                const unsigned long long mk = __ballot(isset[t]);
+                if (isset[t]) set_list[wv][total + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u))] = (short)(t * BLOCK + (int)threadIdx.x);
+                total += __popcll(mk);
+            }
+            if (total) {                                        // (wave-uniform)
+                __builtin_amdgcn_wave_barrier();
+                using T4 = typename V4<T>::type;
+                T Cs[9], rs[3];
+                load_pose(ps.pose, cloud, Cs, rs);
+                const T4* __restrict__ tg = ps.tgs4 + (size_t)cloud * ps.m_pad;
+                const int32_t* __restrict__ pm = ps.tperm + (size_t)cloud * ps.m_pad;
+                for (int s0 = 0; s0 < total; s0 += WAVE) {
+                    const int kk = s0 + lane;
+                    if (kk < total) {
+                        const size_t pt = (size_t)cloud * n + blk * ACC_PTS + set_list[wv][kk];
+                        const T* sp = src + pt * 3;
+                        const T p[3] = {sp[0], sp[1], sp[2]};
+                        const int32_t* cd = cands + pt * CERT_CANDS;
+                        int cj[CERT_CANDS];
+                        T4 row[CERT_CANDS];
+#pragma unroll
+                        for (int c = 0; c < CERT_CANDS; ++c) cj[c] = cd[c];
+#pragma unroll
+                        for (int c = 0; c < CERT_CANDS; ++c) row[c] = tg[max(cj[c], 0)];       // (all four gathers in flight together)
+                        T nx[3];
+                        query_point(Cs, rs, p, nx);
+                        // the new match is the set's best row (same score(), equal scores -> lowest original index; the set's first row is the old match: never empty)
+                        T best = inf_v<T>();
+                        int bj = max(cj[0], 0);
+#pragma unroll
+                        for (int c = 0; c < CERT_CANDS; ++c) {
+                            const T sc = cj[c] >= 0 ? score<T, T4>(nx, row[c]) : inf_v<T>();
+                            if (sc < best) { best = sc; bj = cj[c]; }
+                            else if (sc == best && sc < inf_v<T>() && pm[cj[c]] < pm[bj]) bj = cj[c];
+                        }
+                        ps.spos[pt] = bj;
+                        ++rescored;
+                    }
+                }
+                __threadfence_block();                          // (the matches are read back by the points' own lanes below)
+            }
+        }
 #pragma unroll 1
         for (int t = 0; t < ROUNDS; ++t) {
-            const bool open = !(b[t] > spent);                  // spent, never certifiable, NaN
-            if (!__ballot(open)) continue;                      // (wave-uniform; the common case)
+            const bool redo = !(b[t] > spent) && b[t] != cert_mark<T>(ps.ct.k) && !isset[t];     // spent, never certifiable, NaN -- unless this iteration's
+            unsigned long long todo = __ballot(redo);                                             // guard launch has just searched it, or its candidate set stands
+            if (!todo) continue;                                // (wave-uniform; the common case)
             const size_t pt = (size_t)cloud * n + min(blk * ACC_PTS + t * BLOCK + (int)threadIdx.x, n - 1);
-            const T sb = (open && qs) ? qs[pt] : T(-1);      // (all rounds' set budgets in flight up front: measured, no gain -- the chain behind them is what costs)
-            bool redo = open && b[t] != cert_mark<T>(ps.ct.k);      // (a query this iteration's guard launch has just searched is not searched twice)
-            if (!__ballot(redo)) continue;
             T p[3] = {T(0), T(0), T(0)}, nb = T(-1), ns = T(-2);
             int j = -1, nc[CERT_CANDS];
 #pragma unroll
@@ -1992,31 +2052,6 @@ __global__ __launch_bounds__(BLOCK, (CERT && sizeof(T) == 4) ? 5 : 1) void accum
             if (redo) { const T* sp = src + pt * 3; p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2]; j = ps.spos[pt]; }
             T Cs[9], rs[3];
             load_pose(ps.pose, cloud, Cs, rs);
-            if (redo && sb > spent) {
-                // the candidate set stands: the new match is its best row (same score(), equal scores -> lowest original index)
-                using T4 = typename V4<T>::type;
-                T nx[3];
-                query_point(Cs, rs, p, nx);
-                const T4* __restrict__ tg = ps.tgs4 + (size_t)cloud * ps.m_pad;
-                const int32_t* __restrict__ pm = ps.tperm + (size_t)cloud * ps.m_pad;
-                const int32_t* cd = cands + pt * CERT_CANDS;
-                int cj[CERT_CANDS];
-                T4 row[CERT_CANDS];
-#pragma unroll
-                for (int c = 0; c < CERT_CANDS; ++c) cj[c] = cd[c];
-#pragma unroll
-                for (int c = 0; c < CERT_CANDS; ++c) row[c] = tg[max(cj[c], 0)];       // (all four gathers in flight together)
-                T best = inf_v<T>();
-                int bj = -1;
-#pragma unroll
-                for (int c = 0; c < CERT_CANDS; ++c) {
-                    const T sc = cj[c] >= 0 ? score<T, T4>(nx, row[c]) : inf_v<T>();
-                    if (sc < best) { best = sc; bj = cj[c]; }
-                    else if (sc == best && sc < inf_v<T>() && pm[cj[c]] < pm[bj]) bj = cj[c];
-                }
-                if (bj >= 0) { ps.spos[pt] = bj; redo = false; ++rescored; }       // (a set of finite rows always has a best one; otherwise: search)
-            }
-            unsigned long long todo = __ballot(redo);
             while (todo) {
                 const int L = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;

@@ -11,6 +11,8 @@ from dicp_amd import _lib
 from dicp_amd.ICP import ICP
 from dicp_amd.synthetic import make_pairs
 
+DEV = "cuda"
+
 pytestmark = pytest.mark.gpu
 CASES = 24
 
@@ -79,3 +81,32 @@ def test_certified_loop_equals_searching_everything(c):
     same, gok, what = run_case(c)
     assert same, what
     assert gok, what
+
+
+@pytest.mark.parametrize("seed,N,n,K,icp_type,dtype", [(11, 12, 16384, 10, "pt2pl", torch.float32), (12, 7, 8192, 14, "pt2pt", torch.float32),
+                                                       (13, 5, 12000, 9, "pt2pl", torch.float64), (14, 20, 16384, 8, "pt2pl", torch.float32)])
+def test_candidate_sets_on_planar_scenes(seed, N, n, K, icp_type, dtype):
+    """Planar scenes are where matches have runner-ups within the scores' rounding (dense surfaces): with candidate sets (ICP.cert_sets) such queries are
+    re-scored among four certified rows instead of searched.  Poses, weights, costs and the transformed cloud bit for bit those of searching every query
+    in every iteration, gradients to rounding -- and the sets really are in use (single-query searches collapse after the iteration that makes them)."""
+    from dicp_amd.synthetic import make_scene_pairs
+    src, tgt = make_scene_pairs(N, n, n, seed=seed, dtype=dtype)
+    if icp_type == "pt2pt":
+        tgt = tgt[:, :, :3].contiguous()
+    kw = dict(trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0}, dim=3)
+    outs = []
+    for reuse in (False, True):
+        icp = ICP(icp_type=icp_type, differentiable=True, max_iterations=K, tolerance=1e-12)
+        icp.const_iter, icp.reuse_matches, icp.knn_variant = True, reuse, _lib.KNN_SWEEP
+        S, Tg = src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True)
+        out = icp.icp(S, Tg, torch.eye(4, dtype=dtype, device=DEV).repeat(N, 1, 1), **kw)
+        out["T"].sum().backward()
+        outs.append((out, S.grad, Tg.grad, dict(icp.knn_stats)))
+    for key in ("T", "deltas", "weights", "costs", "pc"):
+        assert torch.equal(outs[0][0][key], outs[1][0][key]), key
+    for i in (1, 2):
+        scale = max(1.0, float(outs[0][i].abs().max()))
+        assert float((outs[0][i] - outs[1][i]).abs().max()) <= (2e-6 if dtype == torch.float32 else 1e-12) * scale
+    singles = outs[1][3]["searched_again"][:K, 64:].sum(1).tolist()
+    if dtype == torch.float32:
+        assert max(singles) > 50 * N and singles[-1] * 10 < max(singles), singles       # made once, then re-scored

@@ -52,6 +52,7 @@ class ICP:
         self.cert_from = None                 # iteration of the certifying search (None: the last re-ordering of the queries)
         self.reuse_matches = True             # sweep path: search only where a match is not PROVEN unchanged since the last search (exact)
         self.cert_sets = True                 # ... and where a match has a runner-up within rounding, a set of 4 candidate rows is certified and re-scored (same results)
+        self.cert_hint = True                 # ... a shape whose clouds all switched them off for good is searched plainly in the next calls
         self.cert_backoff = True              # ... switched off per cloud, on device, where proving costs more than searching (same results)
         self.first_search = True              # sweep path: iteration 0's search is enqueued with the index build, before the loop state is prepared
         self.plan_call = True                 # constant-iteration calls: every segment of the loop behind one library call (dicp_icp_forward_plan)
@@ -126,7 +127,7 @@ class ICP:
             knn_variant=self.knn_variant, bwd_window=bool(self.bwd_window), stats_out=self.knn_stats,
             sync_every=self.sync_every, timing_events=self._timing_events, prebuilt=prebuilt, small_loop=bool(self.small_loop),
             src_rows=src_rows, tgt_rows=tgt_rows, sweep_resort=tuple(int(v) for v in self.sweep_resort), reuse_matches=bool(self.reuse_matches), cert_from=self.cert_from,
-            bwd_skip_eps=self.bwd_skip_eps, cert_backoff=bool(self.cert_backoff), cert_sets=bool(self.cert_sets), plan_call=bool(self.plan_call), bwd_tail=bool(self.bwd_tail),
+            bwd_skip_eps=self.bwd_skip_eps, cert_backoff=bool(self.cert_backoff), cert_sets=bool(self.cert_sets), cert_hint=bool(self.cert_hint), plan_call=bool(self.plan_call), bwd_tail=bool(self.bwd_tail),
             # nn.py:14-16 via ICP.py:140: soft correspondences -- the same library loop with dicp_gumbel_nn in place of the search, the same one node
             gumbel=(self.nn.eps, self.nn.tau, getattr(self.nn, "_inject_U", None)) if (self.nn.differentiable and self.nn.use_gumbel) else None)
         T, pc, deltas, weights, costs, converged, iterations, matched = ICPLoop.apply(source.contiguous(), target.contiguous(), T_init, w_pts, cfg)

@@ -61,6 +61,7 @@ class GumbelLoop(ctypes.Structure):
 
 
 MAX_SEGMENTS = 16
+CERT_OFF_FOR_GOOD = 1 << 20     # dicp_loop_buffers.cert_cloud[:, 2]: the cloud's certificates are off for the rest of the call
 
 
 class SegmentPlan(ctypes.Structure):

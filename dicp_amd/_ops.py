@@ -440,6 +440,9 @@ def prebuild_search(source, target, knn_variant, want_rows, T_init=None, src_row
         return (target, sweep, None)
 
 
+CERT_MIN_WORK = 2.0e6        # certified point-iterations (iterations after the certifying search x N x n) below which match certificates are not used
+
+
 @dataclass
 class LoopConfig:
     icp_type: str
@@ -465,6 +468,7 @@ class LoopConfig:
     gumbel: object = None         # (eps, tau, inject_U or None): the Gumbel-softmax correspondence (nn.py:43-70) instead of the nearest neighbour
     bwd_tail: bool = True         # truncated reverse sweep: the iterations before the ones the previous call still worked at run as ONE launch (dicp_loop_buffers.bwd_tail_from)
     plan_call: bool = True        # constant-iteration sweep calls: all segments behind one library call (dicp_icp_forward_plan)
+    cert_hint: bool = True        # a shape whose clouds ALL ended a call with their certificates switched off is searched plainly for the next 32 calls
     cert_sets: bool = True        # a query whose match has a runner-up within the scores' rounding keeps a SET of 4 candidate rows, re-scored per iteration instead of searched
     cert_backoff: bool = True     # match certificates are switched off per cloud, on device, when a certified iteration costs more than 60 % of a full search
     reuse_matches: bool = True    # sweep path: match certificates -- an iteration searches only the waves holding a query whose match is not proven
@@ -607,8 +611,30 @@ class ICPLoop(torch.autograd.Function):
             # (the one certifying search costs a quarter more than a plain one: it takes three certified iterations to be worth it)
             resorts = [k for k in cfg.sweep_resort if 0 <= k < Kmax]
             cert_from = (max(resorts) if resorts else 0) if cfg.cert_from is None else max(0, int(cfg.cert_from))     # iteration of the certifying search
+            # (... and the point-iterations they can save must outweigh what they cost the host in buffers and set-up: measured break-even, forward +
+            #  backward, at ~2 M certified point-iterations -- 32 x 4096 x 10 iterations loses 6 %, x 20 iterations wins 6 %; profiles/r03_certificates_mid_sizes.txt)
             want_certs = (sweep is not None and cfg.reuse_matches and not (cfg.knn_variant & 0xff00) and not keep_idx
-                          and Kmax - 1 - cert_from >= 3)
+                          and Kmax - 1 - cert_from >= 3 and float(Kmax - 1 - cert_from) * N * n >= CERT_MIN_WORK)
+            # Where EVERY cloud of the previous call of this shape ended with its certificates switched off (near-duplicated or duplicated targets: no
+            # match can be proven; poses that keep moving: no budget survives), the next calls do not try: they search plainly -- the same results, without the certifying search and the guard
+            # launches -- and after 32 calls they try again.  The previous call's switch states arrive through pinned memory, like the tail's hint.
+            cert_hint = None
+            if want_certs and cfg.cert_hint and cfg.cert_backoff and cfg.stats_out is not None and not torch.cuda.is_current_stream_capturing():
+                cert_hint = cfg.stats_out.setdefault("_cert_hint", {"key": None, "skip": 0, "host": None, "event": None, "calls": 0})
+                key_c = (N, n, m, Kmax, dt)
+                if cert_hint["key"] != key_c:
+                    cert_hint.update(key=key_c, skip=0, event=None, calls=0)
+                cert_hint["calls"] += 1
+                if cert_hint["host"] is None or cert_hint["host"].shape[0] < N:
+                    cert_hint["host"] = torch.empty((N, 8), dtype=torch.int32).pin_memory()
+                if cert_hint["skip"] > 0:
+                    cert_hint["skip"] -= 1
+                    want_certs = False
+                elif cert_hint["event"] is not None and cert_hint["event"].query():
+                    if bool((cert_hint["host"][:N, 2] > 0).all()):           # (off for good, or backed off at the call's end: clouds that keep moving)
+                        cert_hint["skip"] = 31
+                        want_certs = False
+                    cert_hint["event"] = None
             arena.take((Kmax, 128) if want_certs else (0,), torch.int32)
             arena.take((N, 8) if want_certs else (0,), torch.int32)
             deltas, costs, converged, iterations, matched, n_matched, counters, cert_count, cert_cloud = arena.finish()
@@ -811,6 +837,10 @@ class ICPLoop(torch.autograd.Function):
                     cfg.stats_out["searched_again"] = certs["count"]
                     cfg.stats_out["budgets"] = certs["q"]         # (N,n) by query: the budgets as the last iteration left them
                     cfg.stats_out["certs_off"] = (cert_cloud[:, 2] > 0).to(torch.int32)  # (N) int32: 1 = the cloud's certificates were switched off during the call (they cost more than searching everything)
+                    if cert_hint is not None and cert_hint["event"] is None and cert_hint["calls"] % 16 == 1:     # (every sixteenth certified call: it is host time)
+                        cert_hint["host"][:N].copy_(cert_cloud, non_blocking=True)
+                        cert_hint["event"] = torch.cuda.Event()
+                        cert_hint["event"].record()
             weights = (w_slabs[0] if len(w_slabs) == 1 else torch.cat(w_slabs, dim=1))[:, :K]
             deltas_out = deltas[:, :K]
             costs_out = costs[:, :K]

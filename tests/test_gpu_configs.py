@@ -565,3 +565,34 @@ def test_first_search_ahead_of_the_loop_changes_nothing(const_iter, grad):
     if grad:
         for i in (1, 2):
             assert float((res[0][i] - res[1][i]).abs().max()) <= 2e-6 * max(1.0, float(res[1][i].abs().max()))
+
+
+def test_certificates_are_used_where_they_pay(monkeypatch):
+    """Size policy of the match certificates (dicp_amd._ops.CERT_MIN_WORK): on by default where the certified point-iterations outweigh their host cost, off below
+    (configs[1]-sized calls at 10 iterations) -- results identical either way; and a shape whose clouds all switch them off (duplicated targets) is searched plainly
+    in later calls of the same ICP object, until it is tried again."""
+    from dicp_amd import _ops
+    monkeypatch.undo()                                                  # (the product's own threshold, not the suite's 0)
+    assert _ops.CERT_MIN_WORK == 2.0e6
+    res = {}
+    for N, n, K, expect in ((8, 4096, 10, False), (8, 4096, 80, True), (40, 16384, 10, True)):
+        src, tgt = make_pairs(N, n, n, seed=5)
+        icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
+        icp.const_iter = True
+        out = icp.icp(src.to(DEV), tgt.to(DEV), torch.eye(4, device=DEV).repeat(N, 1, 1), **KW)
+        assert ("searched_again" in icp.knn_stats) == expect, (N, n, K)
+        res[(N, n, K)] = out["T"]
+    # all clouds off -> the next calls of this object do not certify; results unchanged
+    src, tgt, K = _cert_case("duplicated_targets", torch.float32)
+    N = src.shape[0]
+    icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
+    icp.const_iter, icp.knn_variant = True, _lib.KNN_SWEEP
+    monkeypatch.setattr(_ops, "CERT_MIN_WORK", 0.0)
+    used, Ts = [], []
+    for call in range(6):
+        out = icp.icp(src.to(DEV), tgt.to(DEV), torch.eye(4, device=DEV).repeat(N, 1, 1), **KW)
+        torch.cuda.synchronize()
+        used.append("searched_again" in icp.knn_stats)
+        Ts.append(out["T"].clone())
+    assert used[0] and not used[-1], used                               # certified at first, then not
+    assert all(torch.equal(Ts[0], t) for t in Ts[1:])

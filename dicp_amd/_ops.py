@@ -624,7 +624,6 @@ class ICPLoop(torch.autograd.Function):
                 key_c = (N, n, m, Kmax, dt)
                 if cert_hint["key"] != key_c:
                     cert_hint.update(key=key_c, skip=0, event=None, calls=0)
-                cert_hint["calls"] += 1
                 if cert_hint["host"] is None or cert_hint["host"].shape[0] < N:
                     cert_hint["host"] = torch.empty((N, 8), dtype=torch.int32).pin_memory()
                 if cert_hint["skip"] > 0:
@@ -632,9 +631,11 @@ class ICPLoop(torch.autograd.Function):
                     want_certs = False
                 elif cert_hint["event"] is not None and cert_hint["event"].query():
                     if bool((cert_hint["host"][:N, 2] > 0).all()):           # (off for good, or backed off at the call's end: clouds that keep moving)
-                        cert_hint["skip"] = 31
+                        cert_hint.update(skip=31, calls=0)                   # (the first certified call after the pause reports again)
                         want_certs = False
                     cert_hint["event"] = None
+                if want_certs:
+                    cert_hint["calls"] += 1                                  # certified calls of this shape
             arena.take((Kmax, 128) if want_certs else (0,), torch.int32)
             arena.take((N, 8) if want_certs else (0,), torch.int32)
             deltas, costs, converged, iterations, matched, n_matched, counters, cert_count, cert_cloud = arena.finish()

@@ -630,7 +630,10 @@ class ICPLoop(torch.autograd.Function):
                     cert_hint["skip"] -= 1
                     want_certs = False
                 elif cert_hint["event"] is not None and cert_hint["event"].query():
-                    if bool((cert_hint["host"][:N, 2] > 0).all()):           # (off for good, or backed off at the call's end: clouds that keep moving)
+                    # every cloud off at the call's end (for good, or backed off: clouds that keep moving) -- or, in a batch so small that a launch is as
+                    # long as its slowest cloud (no more units than the GPU holds at once), ANY cloud whose certificates did not pay in two iterations
+                    hc = cert_hint["host"][:N]
+                    if bool((hc[:, 2] > 0).all()) or (N * ((n + 127) // 128) <= 8192 and bool((hc[:, 7] >= 2).any())):
                         cert_hint.update(skip=31, calls=0)                   # (the first certified call after the pause reports again)
                         want_certs = False
                     cert_hint["event"] = None

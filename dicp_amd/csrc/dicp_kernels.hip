@@ -2282,6 +2282,7 @@ __device__ __forceinline__ void step_body(const dicp_step_io& io, int cloud, int
                 else if (state == -1) { const int d = c_back > 0 ? min(2 * c_back, 16) : 2; cc[4] = d; next = d; }
                 else next = -1;
                 cc[2] = next;
+                if (costly || state > 0) cc[7] += 1;            // iterations of this call in which the cloud's certificates did not pay (the host's call-to-call hint reads it)
                 cc[0] = 0; cc[1] = 0; cc[3] = 0; cc[6] = 0;
             }
         }

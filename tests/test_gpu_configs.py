@@ -34,18 +34,47 @@ def sampled_exact(x, y, rows):
     return torch.argmin(d, dim=1), v[:, 0], v[:, 1]
 
 
-def oracle_slice(src, tgt, K, chunk=None):
-    """fwd+bwd of the oracle on CPU copies; returns (T, grad_source, grad_target)."""
+def oracle_slice(src, tgt, K, chunk=None, record=None):
+    """fwd+bwd of the oracle on CPU copies; returns (T, grad_source, grad_target).  record: dict for the oracle's per-iteration poses (C, r)."""
     s, t = src.detach().cpu().clone().requires_grad_(True), tgt.detach().cpu().clone().requires_grad_(True)
     N, n = s.shape[:2]
     O.NN_CHUNK = chunk
     try:
         ref = O.icp_batched(s, t, torch.eye(4, dtype=s.dtype).repeat(N, 1, 1), torch.ones(N, n, dtype=s.dtype), icp_type="pt2pl",
-                            differentiable=True, max_iterations=K, tolerance=1e-12, const_iter=True, tanh_steepness=5.0, **KW)
+                            differentiable=True, max_iterations=K, tolerance=1e-12, const_iter=True, tanh_steepness=5.0, record=record, **KW)
         ref["T"].sum().backward()
     finally:
         O.NN_CHUNK = None
     return ref["T"].detach(), s.grad, t.grad
+
+
+def rows_beyond_the_bar_are_argmin_flips(src, tgt, record, err_src, err_tgt, bar):
+    """The float32 gradient rows that miss the bar must be EXPLAINED, not just few: a float32 argmin may pick the other of two targets whose squared
+    distances differ by less than the rounding of the expanded-form score, 8 eps (|x|^2 + |y|^2) -- and only such a flip moves a row by more than the
+    bar.  Checked against exact float64 distances (on the GPU, in chunks) under the oracle's own pose of every iteration: a source row beyond the bar is
+    a query with such a runner-up in some iteration; a target row beyond the bar is the match or the runner-up of one."""
+    eps32 = 2.0 ** -23
+    N, n = src.shape[:2]
+    s64, t64 = src.to(DEV, torch.float64), tgt[:, :, :3].to(DEV, torch.float64)
+    tn = (t64 * t64).sum(2)
+    near_q = torch.zeros((N, n), dtype=torch.bool, device=DEV)
+    near_t = torch.zeros((N, tgt.shape[1]), dtype=torch.bool, device=DEV)
+    for C, r in zip(record["C"], record["r"]):
+        pt = (C.to(DEV, torch.float64) @ s64.transpose(1, 2) + r.to(DEV, torch.float64)).transpose(1, 2)
+        for b in range(N):
+            for i0 in range(0, n, 4096):
+                x = pt[b, i0:i0 + 4096]
+                d2 = torch.cdist(x, t64[b]) ** 2
+                v, j = torch.topk(d2, 2, dim=1, largest=False)
+                tie = (v[:, 1] - v[:, 0]) <= 8.0 * eps32 * ((x * x).sum(1) + tn[b][j[:, 0]])
+                near_q[b, i0:i0 + 4096] |= tie
+                near_t[b].index_fill_(0, j[tie].reshape(-1), True)
+    assert float(near_q.float().mean()) < 0.02, float(near_q.float().mean())           # (the explanation is a narrow one: a few queries in a thousand have such a runner-up)
+    bad_s, bad_t = (err_src > bar).to(DEV), (err_tgt > bar).to(DEV)
+    print("rows beyond the bar: %d source, %d target; queries with a runner-up within float32's rounding: %d of %d" % (int(bad_s.sum()), int(bad_t.sum()), int(near_q.sum()), near_q.numel()))
+    assert bool((near_q | ~bad_s).all()), "source rows beyond the bar without a near-tie: %d" % int((bad_s & ~near_q).sum())
+    assert bool((near_t | ~bad_t).all()), "target rows beyond the bar that no near-tie touches: %d" % int((bad_t & ~near_t).sum())
+    return int(bad_s.sum()), int(bad_t.sum()), int(near_q.sum())
 
 
 @pytest.mark.parametrize("dtype,N,n", [(torch.float32, 2, 65536), (torch.float64, 1, 20000)])
@@ -106,15 +135,20 @@ def test_config4_icp_at_65536_vs_oracle(variant):
     out = icp.icp(sd, td, torch.eye(4, device=DEV).repeat(N, 1, 1), **KW)
     out["T"].sum().backward()
     assert bool(torch.isfinite(out["T"]).all() and torch.isfinite(sd.grad).all() and torch.isfinite(td.grad).all())
-    T_ref, gs_ref, gt_ref = oracle_slice(src[1:2], tgt[1:2], K, chunk=4096)
+    rec = {}
+    T_ref, gs_ref, gt_ref = oracle_slice(src[1:2], tgt[1:2], K, chunk=4096, record=rec)
     np.testing.assert_allclose(npy(out["T"])[1], T_ref[0].numpy(), rtol=0, atol=1e-4)
+    errs = []
     for got, want, nm in ((sd.grad[1], gs_ref[0], "source"), (td.grad[1], gt_ref[0], "target")):
         scale = max(1.0, float(want.abs().max()))
         # a float32 argmin may pick the other of two (nearly) equidistant targets for a handful of the 65536 queries; such a
-        # row differs in BOTH clouds' gradients.  Rows are held to the bar; at most 0.1 % may differ by more.
+        # row differs in BOTH clouds' gradients.  Rows are held to the bar; at most 0.1 % may differ by more -- and each of those
+        # must be such a flip by the exact float64 distances (rows_beyond_the_bar_are_argmin_flips)
         err = (got.cpu() - want).abs().amax(dim=1)
         assert float((err > 1e-3 * scale).float().mean()) < 1e-3, nm
         assert float(err.median()) < 1e-5 * scale, nm
+        errs.append(err.unsqueeze(0) / scale)
+    rows_beyond_the_bar_are_argmin_flips(src[1:2], tgt[1:2], rec, errs[0], errs[1], 1e-3)
     assert out["weights"].shape == (N, K, n, 1) and out["pc"].shape == (N, n, 3)
     if variant == _lib.KNN_AUTO:        # the sweep pruned: far fewer pairs than n*m per launch
         frac = float(icp.knn_stats["knn_pairs"].sum().item()) / (float(N) * n * n * K)
@@ -147,13 +181,17 @@ def test_config3_full_batch_256(monkeypatch):
         np.testing.assert_allclose(npy(s1.grad), npy(gs_full[lo:lo + 4]), rtol=0, atol=2e-5)
         np.testing.assert_allclose(npy(t1.grad), npy(gt_full[lo:lo + 4]), rtol=0, atol=2e-5)
     # (b) oracle on a slice of the upper half
-    T_ref, gs_ref, gt_ref = oracle_slice(src[200:204], tgt[200:204], K)
+    rec = {}
+    T_ref, gs_ref, gt_ref = oracle_slice(src[200:204], tgt[200:204], K, record=rec)
     np.testing.assert_allclose(npy(T_full[200:204]), T_ref.numpy(), rtol=0, atol=1e-4)
+    errs = []
     for got, want in ((gs_full[200:204].cpu(), gs_ref), (gt_full[200:204].cpu(), gt_ref)):
         scale = max(1.0, float(want.abs().max()))
         err = (got - want).abs().amax(dim=2)
         assert float((err > 1e-3 * scale).float().mean()) < 1e-3
         assert float(err.median()) < 1e-5 * scale
+        errs.append(err / scale)
+    rows_beyond_the_bar_are_argmin_flips(src[200:204], tgt[200:204], rec, errs[0], errs[1], 1e-3)      # (the rows beyond the bar: float32 argmin flips, each one)
     # (c) histories cut into slabs of 2 iterations: same bits
     monkeypatch.setattr(_ops, "HIST_CHUNK_BYTES", 2 * B * n * 4)
     s2, t2 = src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True)

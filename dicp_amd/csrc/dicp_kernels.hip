@@ -1949,6 +1949,7 @@ __device__ __forceinline__ void block_reduce_store(T* v, T* __restrict__ out, T*
 // CERT (certified iterations of the sweep loop; idx = this iteration's sorted positions): the point's budget is checked where its
 // match is read, a spent one is searched on the spot by the whole wave (search_point), and the matches are handed on to the next
 // iteration's buffer.
+constexpr bool PAIR_ROWS = true;     // (plain launches, 7 waves per SIMD: 58 -> 49 us; certified ones, 5 waves because of their search code: 55 -> 55 -- and 6 or 7 waves spill: 115 / 130 us)
 template <typename T, int MODE, bool CERT = false>
 __global__ __launch_bounds__(BLOCK, (CERT && sizeof(T) == 4) ? 5 : 1) void accumulate_kernel(WeightParams P, const T* __restrict__ src, const T* __restrict__ tgt, int c /* elements per row of tgt */,
                                                            const int32_t* __restrict__ idx, const T* __restrict__ pose,
@@ -2089,17 +2090,35 @@ __global__ __launch_bounds__(BLOCK, (CERT && sizeof(T) == 4) ? 5 : 1) void accum
     if (w_out)                                              // ... which is what the weight history reports for them
         for (int i = max(blk * ACC_PTS, nc) + threadIdx.x; i < min(n, (blk + 1) * ACC_PTS); i += BLOCK) w_out[(size_t)cloud * w_stride + i] = T(0);
     const int32_t* __restrict__ ix = CERT ? ps.spos : idx;
-    for (int i = blk * ACC_PTS + threadIdx.x; i < end; i += BLOCK) {       // (2 or 4 points in flight per thread measured slower: 78 / 85 vs 72 us)
-        const size_t pt = (size_t)cloud * n + i;
+    for (int base = blk * ACC_PTS; base < end; base += BLOCK) {            // (2 or 4 points in flight per thread measured slower: 78 / 85 vs 72 us)
+        const int i = base + (int)threadIdx.x;
+        const bool on = i < end;
+        const size_t pt = (size_t)cloud * n + (on ? i : end - 1);
         const T* sp = src + pt * 3;
         const T p[3] = {sp[0], sp[1], sp[2]};
-        const int jm = ix ? ix[pt] : i;                     // ix == NULL: tgt holds one row per source point
-        if (CERT && ps.spos_next) ps.spos_next[pt] = jm;
+        const int jm = ix ? ix[pt] : (on ? i : end - 1);    // ix == NULL: tgt holds one row per source point
+        if (CERT && ps.spos_next && on) ps.spos_next[pt] = jm;
         const int j = min(max(jm, 0), m - 1);
-        const T* yp = tgt + ((size_t)cloud * m + j) * c;
-        const T y[3] = {yp[0], yp[1], yp[2]};
-        T nrm[3] = {T(0), T(0), T(0)};
-        if (MODE == MODE_PT2PL) { nrm[0] = yp[3]; nrm[1] = yp[4]; nrm[2] = yp[5]; }
+        T y[3], nrm[3] = {T(0), T(0), T(0)};
+        if (MODE == MODE_PT2PL && PAIR_ROWS) {
+            // The 24-byte row gather: two lanes share the two rows of their two points -- each loads its half (12 bytes) of both, so a wave
+            // instruction touches 32 rows instead of 64 (the gather is bound by the cache's look-ups per instruction, not by bytes), and the
+            // halves change hands inside the lane pair.
+            const int half = threadIdx.x & 1;
+            const int je = __shfl(j, (int)(threadIdx.x & (WAVE - 1)) & ~1), jo = __shfl(j, (int)(threadIdx.x & (WAVE - 1)) | 1);
+            const T* re = tgt + ((size_t)cloud * m + je) * c + 3 * half;
+            const T* ro = tgt + ((size_t)cloud * m + jo) * c + 3 * half;
+            const T e[3] = {re[0], re[1], re[2]}, o[3] = {ro[0], ro[1], ro[2]};
+            const T pe[3] = {__shfl_xor(e[0], 1), __shfl_xor(e[1], 1), __shfl_xor(e[2], 1)};
+            const T po[3] = {__shfl_xor(o[0], 1), __shfl_xor(o[1], 1), __shfl_xor(o[2], 1)};
+            if (half == 0) { y[0] = e[0]; y[1] = e[1]; y[2] = e[2]; nrm[0] = pe[0]; nrm[1] = pe[1]; nrm[2] = pe[2]; }
+            else           { y[0] = po[0]; y[1] = po[1]; y[2] = po[2]; nrm[0] = o[0]; nrm[1] = o[1]; nrm[2] = o[2]; }
+        } else {
+            const T* yp = tgt + ((size_t)cloud * m + j) * c;
+            y[0] = yp[0]; y[1] = yp[1]; y[2] = yp[2];
+            if (MODE == MODE_PT2PL) { nrm[0] = yp[3]; nrm[1] = yp[4]; nrm[2] = yp[5]; }
+        }
+        if (!on) continue;
         PointState<T> s;
         point_forward<T, MODE>(P, C, r, p, y, nrm, (w_init ? w_init[pt] : T(1)) * live, acc, s);
         // (a frozen cloud: all its weights are zero, and the reference then keeps the previous iteration's -- written here, by 1024 threads per

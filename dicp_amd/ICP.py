@@ -18,7 +18,7 @@ import torch
 import yaml
 
 from . import _lib
-from ._ops import ICPLoop, KabschLoop, LoopConfig, compute_device, prebuild_search, transform_points
+from ._ops import CallHints, ICPLoop, KabschLoop, LoopConfig, compute_device, prebuild_search, transform_points
 from .nn import nn
 
 
@@ -46,6 +46,7 @@ class ICP:
         # build-specific knob (not in the reference): which kNN kernel the loop uses
         self.knn_variant = _lib.KNN_AUTO      # _lib.KNN_VALU | KNN_MFMA (brute force) | KNN_SWEEP (exact, slab-pruned)
         self.knn_stats = {}                   # "knn_pairs": pairs scored by the last call's sweep kNN (device int64 shards: .sum())
+        self._hints = CallHints()             # private: what this object's earlier calls tell later ones about time (per device, stream and shape)
         self.bwd_window = True                # sweep path: sorted-space backward (LDS windows); False: row atomics
         self.small_loop = True                # small clouds: one block per cloud runs whole chunks of iterations
         self.sweep_resort = (0, 1, 2, 3)      # iterations at which the sweep re-orders its queries by x under the current pose
@@ -85,9 +86,9 @@ class ICP:
         # weight=None on tensor inputs: the weights are all 1 -- the loop is told so (w0 = None) instead of reading a tensor of ones
         unit_w = (weight is None and isinstance(source, torch.Tensor) and isinstance(target, torch.Tensor) and len(source) > 0 and len(target) > 0
                   and not self.source_zeroes_are_pad and not (self.nn.differentiable and self.nn.use_gumbel))
-        self._weight_per_cloud = False
-        source, target, T_init, w_pts, rows = self._batch(source, target, T_init, weight, unit_weights=unit_w)   # ICP.py:85
-        per_cloud_w = self._weight_per_cloud and source.shape[1] > 1
+        source, target, T_init, w_pts, rows, per_cloud_w = self._batch(source, target, T_init, weight, unit_weights=unit_w)   # ICP.py:85
+        # (with source_zeroes_are_pad the reference's (N,1) weight is multiplied into an (N,n) mask first, ICP.py:445-446: it is per point from there on)
+        per_cloud_w = per_cloud_w and source.shape[1] > 1 and not self.source_zeroes_are_pad
         assert source.dtype == target.dtype == T_init.dtype                              # ICP.py:96
         if self.icp_type == 'pt2pl':
             assert target.shape[2] == 6                                                  # ICP.py:103
@@ -124,7 +125,7 @@ class ICP:
             const_iter=bool(self.const_iter),
             tanh_steepness=float(self.config['dICP']['parameters']['tanh_steepness']),   # ICP.py:119
             match_ratio_thresh=float(self.match_ratio_thresh),
-            knn_variant=self.knn_variant, bwd_window=bool(self.bwd_window), stats_out=self.knn_stats,
+            knn_variant=self.knn_variant, bwd_window=bool(self.bwd_window), stats_out=self.knn_stats, hints=self._hints,
             sync_every=self.sync_every, timing_events=self._timing_events, prebuilt=prebuilt, small_loop=bool(self.small_loop),
             src_rows=src_rows, tgt_rows=tgt_rows, sweep_resort=tuple(int(v) for v in self.sweep_resort), reuse_matches=bool(self.reuse_matches), cert_from=self.cert_from,
             bwd_skip_eps=self.bwd_skip_eps, cert_backoff=bool(self.cert_backoff), cert_sets=bool(self.cert_sets), cert_hint=bool(self.cert_hint), plan_call=bool(self.plan_call), bwd_tail=bool(self.bwd_tail),
@@ -158,6 +159,11 @@ class ICP:
                        for k, v in results.items()}
         return results
 
+    def check_errors(self):
+        """Wait for the backward passes this object has enqueued so far and raise if one of them reported a failure of its own (today: a wait of the
+        one-launch tail that ran out, _ops.TailTimeout -- that pass's gradients are NaN).  Without this call the error is raised by the next backward pass."""
+        self._hints.check(wait=True)
+
     def pt2pt_dICP_SVD(self, source, target, T_init, trim_dist=None, huber_delta=None, dim=3, weight=None):
         """SVD-based point-to-point ICP (reference: ICP.py:533-591, "not yet integrated").
 
@@ -175,7 +181,7 @@ class ICP:
         weights.  Stops when sum |T p - nn|^2 < tolerance (ICP.py:585).
         """
         single = not isinstance(source, list) and source is not None and source.dim() == 2
-        s_b, t_b, T_b, w_pts, rows = self._batch(source, target, T_init, weight)
+        s_b, t_b, T_b, w_pts, rows, _ = self._batch(source, target, T_init, weight)
         t_b = t_b[:, :, :3]                                                              # ICP.py:548
         assert s_b.dtype == t_b.dtype == T_b.dtype
         home = s_b.device
@@ -200,7 +206,7 @@ class ICP:
         """Normalise the accepted input forms to batched tensors (ICP.py:305-511):
         source (N,n_max,3) zero-padded, target (N,m_max,c) padded with max(source)*target_pad_val,
         T_init (N,4,4) or None, weights (N,n_max) -- repeated x3 along dim 1 for pt2pt (ICP.py:508-509)."""
-        s, t, T, w, _ = self._batch(source, target, T_init, weight)
+        s, t, T, w, _, _ = self._batch(source, target, T_init, weight)
         if self.icp_type == 'pt2pt':
             w = w.repeat_interleave(3, dim=1)
         return s, t, T, w
@@ -226,25 +232,27 @@ class ICP:
         """A caller-supplied weight TENSOR (the list form is cast item by item below).  The reference multiplies it into the
         residuals with torch broadcasting (ICP.py:169): a shape that does not broadcast against (N,n) raises there, a
         different float dtype is promoted.  The kernels read raw (N,n) buffers of the cloud dtype, so both are settled
-        here: the same error for a wrong shape, a cast (differentiable) for a different dtype."""
+        here: the same error for a wrong shape, a cast (differentiable) for a different dtype.  -> (weight (N,n), one weight per CLOUD was given)"""
         if not isinstance(w, torch.Tensor):
             raise TypeError("weight must be a tensor for a tensor source (got %s)" % (type(w),))
         want = tuple(source_b.shape[:2])
+        per_cloud = False
         if tuple(w.shape) != want:
             # ICP.py:169 multiplies with broadcasting: after the row-count assert (ICP.py:326) the one other shape that
             # multiplies against the (N,n) trim / loss weights is one weight per cloud, (N,1) -- and only for pt2pl (pt2pt
             # repeats the weight x3 along dim 1 first, ICP.py:508-509, and (N,3) no longer broadcasts against (N,3n))
             if w.dim() == 2 and w.shape[0] == want[0] and w.shape[1] == 1 and (self.icp_type == 'pt2pl' or want[1] == 1):
-                self._weight_per_cloud = True
+                per_cloud = True
                 w = w.expand(want)
             else:
                 raise RuntimeError("The size of tensor weight %s must match the source points %s" % (tuple(w.shape), want))
-        return (w if w.dtype == source_b.dtype else w.to(source_b.dtype)).contiguous()
+        return (w if w.dtype == source_b.dtype else w.to(source_b.dtype)).contiguous(), per_cloud
 
     def _batch(self, source, target, T_init, weight, unit_weights=False):
         """As batch_size_handling, with ONE weight per point (what the kernels consume), and the clouds' own lengths:
-        -> (source_b, target_b, T_b, w, rows); rows = None, or (source lengths | None, target lengths | None, n_max, m_max)
-        when a list was padded.  unit_weights (tensor inputs, weight None): w is not built (None) -- the caller knows it is all ones."""
+        -> (source_b, target_b, T_b, w, rows, per_cloud); rows = None, or (source lengths | None, target lengths | None, n_max, m_max)
+        when a list was padded; per_cloud: the caller gave ONE weight per cloud, (N,1) (the statistics count it once per cloud, ICP.py:248).
+        unit_weights (tensor inputs, weight None): w is not built (None) -- the caller knows it is all ones."""
         if weight is not None:                                                           # ICP.py:321-326
             if isinstance(source, list):
                 assert len(source) == len(weight), "weight must be list of same length as source"
@@ -255,7 +263,7 @@ class ICP:
         if source is None or target is None or len(source) == 0 or len(target) == 0:
             f32 = dict(dtype=torch.float32, device="cpu")
             return (torch.zeros((1, 1, 3), **f32), torch.zeros((1, 1, 6), **f32),
-                    torch.eye(4, **f32).unsqueeze(0), torch.zeros((1, 1), **f32), None)
+                    torch.eye(4, **f32).unsqueeze(0), torch.zeros((1, 1), **f32), None, False)
 
         # dtype / device / column count come from the first non-empty target (ICP.py:347-358)
         dt, dev, cols = torch.float32, "cpu", None
@@ -272,6 +280,7 @@ class ICP:
         opts = dict(dtype=dt, device=dev)
 
         src_len = tgt_len = None
+        per_cloud = False
         # ---- source and per-point prior weights (ICP.py:360-446)
         if isinstance(source, list):
             pts, pri = [], []
@@ -294,10 +303,10 @@ class ICP:
             src_len = [int(p_i.shape[0]) for p_i in pts]
         elif source.dim() == 2 and source.shape[1] in (3, 6):
             source_b = source[:, :3].unsqueeze(0)
-            w = (None if unit_weights else torch.ones((1, source_b.shape[1]), **opts)) if weight is None else self._tensor_weight(weight.unsqueeze(0), source_b)
+            w, per_cloud = ((None if unit_weights else torch.ones((1, source_b.shape[1]), **opts)), False) if weight is None else self._tensor_weight(weight.unsqueeze(0), source_b)
         elif source.dim() == 3 and source.shape[2] in (3, 6):
             source_b = source[:, :, :3]
-            w = (None if unit_weights else torch.ones(source_b.shape[:2], **opts)) if weight is None else self._tensor_weight(weight, source_b)
+            w, per_cloud = ((None if unit_weights else torch.ones(source_b.shape[:2], **opts)), False) if weight is None else self._tensor_weight(weight, source_b)
         else:
             raise ValueError("source must be (n x 3/6) or (N x n x 3/6) or list len(N) (n_N x 3/6)")
 
@@ -344,4 +353,4 @@ class ICP:
         else:
             raise ValueError("T_init must be (4 x 4) or (N x 4 x 4) or list len(N) (4 x 4)")
         ragged = (src_len, tgt_len, int(source_b.shape[1]), int(target_b.shape[1])) if (src_len is not None or tgt_len is not None) else None
-        return source_b, target_b, T_b, w, ragged
+        return source_b, target_b, T_b, w, ragged, per_cloud

@@ -11,8 +11,8 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("DICP_HIP_LIB") or os.path.join(_HERE, "libdicp_hip.so")   # env override: A/B builds
-SOURCES = [os.path.join(_HERE, "csrc", "dicp_kernels.hip")]
-HEADERS = [os.path.join(_HERE, "csrc", "dicp_math.h"), os.path.join(_ROOT, "include", "dicp_hip.h")]
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("dicp_kernels.hip", "knn_f16.hip")]
+HEADERS = [os.path.join(_HERE, "csrc", f) for f in ("dicp_math.h", "dicp_common.h", "dicp_internal.h")] + [os.path.join(_ROOT, "include", "dicp_hip.h")]
 
 F32, F64 = 0, 1
 PT2PT, PT2PL = 0, 1
@@ -20,7 +20,7 @@ LOSS_NONE, LOSS_HUBER, LOSS_CAUCHY, LOSS_TRIM = 0, 1, 2, 3
 KNN_AUTO, KNN_VALU, KNN_MFMA, KNN_SWEEP, KNN_GUMBEL = 0, 1, 2, 3, 4
 NACC_PAD, NBWD_PAD, KAB_SAVE = 32, 16, 40
 PAIR_SHARDS, SWEEP_SRC_SORTED = 64, 0x100      # DICP_PAIR_SHARDS, DICP_SWEEP_SRC_SORTED
-ABI_VERSION = 5
+ABI_VERSION = 6
 _ERRORS = {1: "null pointer", 2: "bad shape/stride", 3: "unsupported dtype", 4: "bad enum value", 5: "misaligned buffer"}
 
 vp, i32, i64, f64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
@@ -52,7 +52,7 @@ class LoopBuffers(ctypes.Structure):
                 ("partials", vp), ("counters", vp), ("events", vp), ("bwd_overwrite", i32), ("frame", vp), ("poses_search", vp),
                 ("src_rows", vp), ("tgt_rows", vp), ("cert_q", vp), ("cert_qu", vp), ("cert_set", vp), ("cert_count", vp), ("rmax", vp), ("dcum", vp),
                 ("cert_reset", i32), ("cert_cloud", vp), ("spos_prev0", vp), ("tgt_sorted", vp), ("tgt_sorted_stride", i32),
-                ("bwd_skip", vp), ("bwd_mref", vp), ("bwd_live", vp), ("bwd_skip_eps", f64), ("bwd_tail_from", i32), ("bwd_tail_partials", vp), ("bwd_tail_arrive", vp), ("gumbel", vp), ("first_search_done", i32)]
+                ("bwd_skip", vp), ("bwd_mref", vp), ("bwd_live", vp), ("bwd_skip_eps", f64), ("bwd_tail_from", i32), ("bwd_tail_partials", vp), ("bwd_tail_arrive", vp), ("gumbel", vp), ("first_search_done", i32), ("tgt_f16", vp)]
 
 
 class GumbelLoop(ctypes.Structure):
@@ -75,7 +75,7 @@ class KabschBuffers(ctypes.Structure):
     _fields_ = [("src", vp), ("tgt", vp), ("w_init", vp), ("c", i32), ("K", i32), ("knn_variant", i32), ("m_pad", i32), ("tgt4", vp), ("tperm", vp),
                 ("qorder", vp), ("bucket", vp), ("brange", vp), ("nbkt", i32), ("pad0", i32), ("pairs", vp), ("frame", vp), ("pose", vp),
                 ("pose_search", vp), ("pose_used", vp), ("idx", vp), ("partials", vp), ("save", vp), ("costs", vp), ("iterations", vp),
-                ("rows_live", vp), ("tgt_rows", vp), ("counters", vp)]
+                ("rows_live", vp), ("tgt_rows", vp), ("counters", vp), ("tgt_f16", vp)]
 
 
 _SIGNATURES = {
@@ -84,10 +84,13 @@ _SIGNATURES = {
     "dicp_accumulate_blocks": ([i32], ctypes.c_int),
     "dicp_pack_target": ([i32, vp, i32, vp, vp, i32, i32, vp, i32, vp], ctypes.c_int),
     "dicp_search_frame": ([i32, vp, i32, vp, i32, i32, f64, i32, vp, vp], ctypes.c_int),
-    "dicp_knn": ([i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp], ctypes.c_int),
+    "dicp_knn_f16_bytes": ([i32, i32], ctypes.c_size_t),
+    "dicp_knn_f16_pack": ([vp, vp, i32, i32, i32, vp, vp], ctypes.c_int),
+    "dicp_knn": ([i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp, vp], ctypes.c_int),
     "dicp_knn_sweep": ([i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp], ctypes.c_int),
     "dicp_window_blocks": ([i32, i32, i32], ctypes.c_int),
     "dicp_window_rows": ([i32], ctypes.c_int),
+    "dicp_bwd_tail_max_blocks": ([i32], ctypes.c_int),
     "dicp_sweep_sort_scratch_bytes": ([i32, i32, i32], ctypes.c_size_t),
     "dicp_sweep_sort": ([i32, vp, i32, vp, vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, ctypes.c_size_t, vp], ctypes.c_int),
     "dicp_sweep_build": ([i32, vp, i32, vp, vp, vp, i32, i32, i32, vp, vp, i32, vp], ctypes.c_int),
@@ -130,22 +133,41 @@ _lib = None
 _lock = threading.Lock()
 
 
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=on", "-mllvm", "-amdgpu-mfma-vgpr-form", "-Wall", "-Wno-unused-function"]
+
+
 def build(force=False, verbose=False):
-    """Compile the HIP sources for gfx950 into dicp_amd/libdicp_hip.so (hipcc cross-compiles
-    without a GPU).  Rebuilds only when a source or header is newer than the library."""
-    deps = SOURCES + HEADERS + [os.path.abspath(__file__)]       # (this file holds the compiler flags)
-    if (not force and os.path.exists(LIB_PATH)
-            and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(p) for p in deps)):
-        return LIB_PATH
+    """Compile the HIP sources for gfx950 into dicp_amd/libdicp_hip.so (hipcc cross-compiles without a GPU): one object per translation
+    unit (in parallel; only those whose source or a header is newer), then one link."""
+    hdr_time = max(os.path.getmtime(p) for p in HEADERS + [os.path.abspath(__file__)])       # (this file holds the compiler flags)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    # -amdgpu-mfma-vgpr-form: let the f32 MFMA of the kNN variant write VGPRs directly (no v_accvgpr_read per
-    # result): 6.1 -> 5.5 ms on that kernel (profiles/r01_knn_variants_ab.txt); no effect on the other kernels
+    objdir = os.path.join(_HERE, "csrc", "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    # -amdgpu-mfma-vgpr-form: the matrix-core search variants read their results with vector instructions right away: let the MFMA write VGPRs
+    # directly (no v_accvgpr_read per result; profiles/r01_knn_variants_ab.txt); no effect on the other kernels
     # -ffp-contract=on: a*b+c fuses where the SOURCE writes it in one expression, never across statements after inlining ("fast", the
     # HIP default, did: the same point_forward then rounded differently in two instantiations of accumulate_kernel) -- results are a
     # function of the source, not of the optimiser's context
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-ffp-contract=on", "-mllvm", "-amdgpu-mfma-vgpr-form",
-           "-Wall", "-Wno-unused-function", "-I", os.path.join(_ROOT, "include"),
-           "-o", LIB_PATH + ".tmp"] + SOURCES
+    jobs = []
+    for src in SOURCES:
+        obj = os.path.join(objdir, os.path.splitext(os.path.basename(src))[0] + ".o")
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+            jobs.append((src, obj))
+    objs = [os.path.join(objdir, os.path.splitext(os.path.basename(src))[0] + ".o") for src in SOURCES]
+    if not jobs and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(o) for o in objs):
+        return LIB_PATH
+
+    def compile_one(job):
+        cmd = [hipcc] + FLAGS + ["-I", os.path.join(_ROOT, "include"), "-c", "-o", job[1] + ".tmp", job[0]]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        os.replace(job[1] + ".tmp", job[1])
+    if jobs:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(jobs), 4)) as pool:
+            list(pool.map(compile_one, jobs))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH + ".tmp"] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

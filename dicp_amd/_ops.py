@@ -137,15 +137,38 @@ def pack_target(tgt, frame=None, tgt_rows=None):
     return out
 
 
-def knn(src, pose, tgt4, m, variant=_lib.KNN_AUTO, out=None, src_rows=None, tgt_rows=None):
+def f16_image(tgt4, m, tgt_rows=None):
+    """The split-f16 image of packed target rows (N,m_pad,4) float32 for the matrix-core search (dicp_knn_f16_pack): a uint8 tensor."""
+    require_device(tgt4, "f16_image")
+    if tgt4.dtype != torch.float32:
+        raise TypeError("dicp_amd.f16_image: the matrix-core search is float32 only")
+    lib = _lib.load()
+    N, m_pad, _ = tgt4.shape
+    img = torch.empty((int(lib.dicp_knn_f16_bytes(N, m_pad)),), dtype=torch.uint8, device=tgt4.device)
+    with _on(tgt4.device):
+        _lib.check(lib.dicp_knn_f16_pack(_p(tgt4), _p(tgt_rows), N, int(m), m_pad, _p(img), _stream()), "dicp_knn_f16_pack")
+    return img
+
+
+def f16_counters(image, N):
+    """(queries sent through the second filter pass, queries scored against every row): what the matrix-core searches since the image was packed
+    could not settle from one pass (near-ties inside the filter's resolution; queries outside the f16 range).  Synchronises."""
+    meta = image[image.numel() - N * 320:].view(torch.int32).view(N, 80)
+    return int(meta[:, 6].sum().item()), int(meta[:, 7].sum().item())
+
+
+def knn(src, pose, tgt4, m, variant=_lib.KNN_AUTO, out=None, src_rows=None, tgt_rows=None, image=None):
     """Fused transform + brute-force 1-NN: (N,n,3), (N,12)|None, packed targets -> idx (N,n) int32.
-    src_rows / tgt_rows (N) int32, optional: rows of each cloud that take part (the idx of other rows is not written)."""
+    src_rows / tgt_rows (N) int32, optional: rows of each cloud that take part (the idx of other rows is not written).
+    KNN_MFMA reads the split-f16 image of tgt4 (f16_image; built here when not given)."""
     require_device(src, "knn")
     N, n, _ = src.shape
     idx = out if out is not None else torch.empty((N, n), dtype=torch.int32, device=src.device)
+    if (variant & 0xff) == _lib.KNN_MFMA and image is None and src.dtype == torch.float32:
+        image = f16_image(tgt4, m, tgt_rows)
     with _on(src.device):
         _lib.check(_lib.load().dicp_knn(_DT[src.dtype], _p(src), _p(pose), _p(tgt4), _p(src_rows), _p(tgt_rows), N, n, m, tgt4.shape[1],
-                                        _p(idx), variant, _stream()), "dicp_knn")
+                                        _p(idx), variant, _p(image), _stream()), "dicp_knn")
     return idx
 
 
@@ -440,6 +463,63 @@ def prebuild_search(source, target, knn_variant, want_rows, T_init=None, src_row
         return (target, sweep, None)
 
 
+class TailTimeout(RuntimeError):
+    """A wait inside the one-launch tail of an EARLIER backward pass ran out (dicp_hip.h, bwd_tail_arrive): that pass poisoned the gradients of the
+    clouds concerned with NaN.  Raised at the next backward pass of the same ICP object, or by ICP.check_errors()."""
+
+
+class CallHints:
+    """What the earlier calls of ONE ICP object tell its later ones -- about time only, never about results (a stale or missing hint costs time; every
+    search and every sweep is exact either way).  Private to the object (ICP._hints), one record per (device, stream, call shape):
+      tail : where the previous backward passes' reverse sweeps ended (their live counters, copied to pinned memory behind their launches; the
+             error word of the one-launch tail rides along and is checked when the record is read),
+      cert : whether the shape's match certificates paid in the previous call (the per-cloud switch states, every sixteenth certified call)."""
+    MAX_SHAPES = 16
+
+    def __init__(self):
+        self.tail, self.cert = {}, {}
+        self.newest_tail = None         # [pinned counters (Kmax + 1), event, (N, n, K), Kmax, looked at, serial]: the record of the last backward pass (tests)
+        self.serial = 0
+
+    @staticmethod
+    def _where(dev):
+        return (dev.index if dev.index is not None else torch.cuda.current_device(), int(torch.cuda.current_stream(dev).cuda_stream))
+
+    def _slot(self, table, key, make):
+        if key not in table:
+            while len(table) >= self.MAX_SHAPES:
+                table.pop(next(iter(table)))
+            table[key] = make()
+        return table[key]
+
+    def tail_records(self, dev, shape, any_stream=False):
+        """The records of this (device, stream, shape).  any_stream (inside a graph capture, which runs on a stream of its own): the list whose newest
+        record is the newest of the shape on this device -- the warm-up calls' --, to be read only."""
+        key = self._where(dev) + tuple(shape)
+        if any_stream and not self.tail.get(key):
+            same = [recs for k, recs in self.tail.items() if k[0] == key[0] and k[2:] == key[2:] and recs]
+            if same:
+                return max(same, key=lambda recs: recs[-1][5])
+        return self._slot(self.tail, key, list)
+
+    def cert_record(self, dev, shape):
+        return self._slot(self.cert, self._where(dev) + tuple(shape), lambda: {"skip": 0, "host": None, "event": None, "calls": 0})
+
+    def check(self, wait=False):
+        """Raise TailTimeout if a backward pass whose record has arrived (wait: of every pass so far) reported a wait that ran out."""
+        for recs in self.tail.values():
+            for rec in recs:
+                if rec[1] is None or rec[4]:
+                    continue
+                if wait:
+                    rec[1].synchronize()
+                if rec[1].query():
+                    rec[4] = True       # (looked at)
+                    if int(rec[0][rec[3]]) != 0:
+                        raise TailTimeout("dicp_amd: a wait of an earlier backward pass's one-launch tail ran out (the GPU was kept full by other work for "
+                                          "~0.5 s); the gradients of that pass were poisoned with NaN.  Re-run it, or set ICP.bwd_tail = False")
+
+
 CERT_MIN_WORK = 2.0e6        # certified point-iterations (iterations after the certifying search x N x n) below which match certificates are not used
 
 
@@ -460,6 +540,7 @@ class LoopConfig:
     sweep_resort: tuple = (0, 1, 2, 3)  # iterations at which the sweep kNN re-sorts its queries by x
     bwd_window: bool = True       # sweep path: backward in sorted space (LDS window + full-line atomic flush)
     stats_out: object = None      # optional dict: receives "knn_pairs" (pairs scored by the sweep kNN; int64 shards, sum them)
+    hints: object = None          # optional CallHints of the calling ICP object (what its earlier calls tell this one about time)
     sync_every: object = None     # tolerance mode: iterations between the host's all-converged checks (None = auto)
     timing_events: object = None  # optional object with .handles(K) -> ctypes array of 4*K hipEvent_t (bench.py)
     prebuilt: object = None       # (target, SweepIndex) started by the caller before its own host work (prebuild_search)
@@ -588,6 +669,7 @@ class ICPLoop(torch.autograd.Function):
             center = sweep.frame if sweep is not None else (None if soft else search_frame(tgt, tgt_rows=cfg.tgt_rows))
             tgt4 = sweep.tgs4 if sweep is not None else (None if soft else pack_target(tgt, center, cfg.tgt_rows))
             m_pad = tgt4.shape[1] if tgt4 is not None else 0
+            img16 = f16_image(tgt4, m, cfg.tgt_rows) if kind == _lib.KNN_MFMA else None      # the matrix-core search's image of the packed rows
             nblk = lib.dicp_accumulate_blocks(n)
             poses = torch.empty((Kmax + 1, N, 12), dtype=dt, device=dev)
             poses_c = torch.empty((Kmax + 1, N, 12), dtype=dt, device=dev) if center is not None else None   # [Q C | Q r + t]: what the searches read
@@ -619,11 +701,8 @@ class ICPLoop(torch.autograd.Function):
             # match can be proven; poses that keep moving: no budget survives), the next calls do not try: they search plainly -- the same results, without the certifying search and the guard
             # launches -- and after 32 calls they try again.  The previous call's switch states arrive through pinned memory, like the tail's hint.
             cert_hint = None
-            if want_certs and cfg.cert_hint and cfg.cert_backoff and cfg.stats_out is not None and not torch.cuda.is_current_stream_capturing():
-                cert_hint = cfg.stats_out.setdefault("_cert_hint", {"key": None, "skip": 0, "host": None, "event": None, "calls": 0})
-                key_c = (N, n, m, Kmax, dt)
-                if cert_hint["key"] != key_c:
-                    cert_hint.update(key=key_c, skip=0, event=None, calls=0)
+            if want_certs and cfg.cert_hint and cfg.cert_backoff and cfg.hints is not None and not torch.cuda.is_current_stream_capturing():
+                cert_hint = cfg.hints.cert_record(dev, (N, n, m, Kmax, dt))
                 if cert_hint["host"] is None or cert_hint["host"].shape[0] < N:
                     cert_hint["host"] = torch.empty((N, 8), dtype=torch.int32).pin_memory()
                 if cert_hint["skip"] > 0:
@@ -751,7 +830,7 @@ class ICPLoop(torch.autograd.Function):
                     spos=_p(spos_slabs[0]) if keep_spos else _p(spos_once),
                     idx=(_p(idx_slabs[0]) if need_grad else _p(idx_once)) if keep_idx else None,
                     partials=_p(partials), counters=_p(counters), events=events, frame=_p(center), poses_search=_p(poses_c),
-                    src_rows=_p(cfg.src_rows), tgt_rows=_p(cfg.tgt_rows), first_search_done=int(first_spos is not None))
+                    src_rows=_p(cfg.src_rows), tgt_rows=_p(cfg.tgt_rows), first_search_done=int(first_spos is not None), tgt_f16=_p(img16))
                 _lib.check(lib.dicp_icp_forward_plan(code, Pref, ctypes.byref(LB), ctypes.byref(SP), N, n, m, int(cfg.dim), 1, float(cfg.tolerance), st),
                            "dicp_icp_forward_plan")
                 segs = []
@@ -792,7 +871,7 @@ class ICPLoop(torch.autograd.Function):
                         rmax=_p(certs["rmax"]) if certs else None, dcum=_p(certs["dcum"]) if certs else None,
                         w_iter=n, w_stride=kc * n,
                         partials=_p(partials), counters=_p(counters), events=events, frame=_p(center), poses_search=_p(poses_c),
-                        src_rows=_p(cfg.src_rows), tgt_rows=_p(cfg.tgt_rows))
+                        src_rows=_p(cfg.src_rows), tgt_rows=_p(cfg.tgt_rows), tgt_f16=_p(img16))
                     if gum is not None:
                         LB.gumbel = ctypes.cast(ctypes.pointer(gum), ctypes.c_void_p)
                     LBref = ctypes.byref(LB)
@@ -945,11 +1024,11 @@ class ICPLoop(torch.autograd.Function):
                 sk_arena = _Arena(dev)
                 sk_arena.take((N,), torch.float64)
                 sk_arena.take((N,), torch.int32)
-                sk_arena.take((Kmax,), torch.int32)
+                sk_arena.take((Kmax + 1,), torch.int32)
                 sk_arena.take((N + 1,), torch.int32)
-                skip = sk_arena.finish()            # mref, decisions, live counters, the one-launch tail's per-cloud counters (+ its error word)
+                skip = sk_arena.finish()            # mref, decisions, live counters (+ the tail's error word), the one-launch tail's per-cloud counters (+ its error word)
                 if cfg.stats_out is not None:
-                    cfg.stats_out["bwd_live"] = skip[2]     # (Kmax) int32: clouds that did per-point work in iteration k of the backward
+                    cfg.stats_out["bwd_live"] = skip[2]     # (Kmax + 1) int32: clouds that did per-point work in iteration k of the backward; [Kmax]: a wait of the tail ran out
             # The ended iterations as ONE launch (dicp_loop_buffers.bwd_tail_from).  Where a sweep ends is decided on the device, while the host
             # enqueues; what the host can know is where the PREVIOUS call of this shape ended (its live counters, copied to pinned memory behind
             # that call's launches): the iterations at which fewer than an eighth of its clouds were still at work go to the one launch, which
@@ -958,11 +1037,15 @@ class ICPLoop(torch.autograd.Function):
             # (inside a graph capture no event may be queried: the hint of the warm-up calls is read as it stands -- torch's capture entry points
             #  synchronise first -- and none is recorded; a stale hint costs time, never correctness: a cloud at work in the tail is swept there)
             capturing = torch.cuda.is_current_stream_capturing()
-            if skip is not None and only_windowed and cfg.bwd_tail and cfg.stats_out is not None:
+            use_tail = skip is not None and only_windowed and cfg.bwd_tail and cfg.hints is not None
+            if use_tail:
+                if not capturing:
+                    cfg.hints.check()       # an earlier pass's tail ran out of patience: its gradients are NaN, and the caller hears about it here at the latest
                 # (the newest hint that has ARRIVED: in a loop that never waits for the GPU the last call's own counters are still on their way)
-                hints = cfg.stats_out.setdefault("_bwd_hints", [])
+                hints = cfg.hints.tail_records(dev, (N, n, m, Kmax, dt), any_stream=capturing)
                 hint = next((h for h in reversed(hints) if h[2] == (N, n, K) and (capturing or h[1].query())), None)
-                if hint is not None:
+                # the tail's blocks wait for each other: only where all of a cloud's blocks are resident at once (dicp_bwd_tail_max_blocks)
+                if hint is not None and nblk_w <= lib.dicp_bwd_tail_max_blocks(code):
                     live = hint[0][:K].tolist()
                     tail_from = max(0, next((k for k in range(K) if live[k] * 8 >= N), K) - 1)      # (most sweeps have ended BEFORE the one launch starts)
             gum = None
@@ -989,7 +1072,7 @@ class ICPLoop(torch.autograd.Function):
             if cfg.stats_out is not None:
                 cfg.stats_out["bwd_tail_from"] = int(tail_from)
                 if tail_from > 0:
-                    cfg.stats_out["bwd_tail_error"] = skip[3][N:]       # (1) int32: nonzero = a wait of the tail launch ran out (never observed)
+                    cfg.stats_out["bwd_tail_error"] = skip[3][N:]       # (1) int32: nonzero = a wait of the tail launch ran out (TailTimeout at the next pass)
             folded = False
             for (k0, k1, q, w_form) in runs:
                 if have and w_form != form:     # the partials of the other form have another block count: fold them in here
@@ -1023,21 +1106,22 @@ class ICPLoop(torch.autograd.Function):
                     folded = kt > 0         # the tail launch left the cotangent of pose_0 with the last pose sums already in it
                 if (k1 - k0) % 2:           # the library alternates the two buffers: odd chunk -> the result is in the other one
                     gpose, gtmp = gtmp, gpose
-            if skip is not None and only_windowed and cfg.bwd_tail and cfg.stats_out is not None and not capturing:
-                hints = cfg.stats_out.setdefault("_bwd_hints", [])
+            if use_tail and not capturing:
                 entry = None
-                if len(hints) >= 4:         # four pinned buffers in rotation: the oldest one is re-used once its copy has landed
-                    if hints[0][1].query() and hints[0][0].numel() >= Kmax:
+                if len(hints) >= 4:         # four pinned buffers in rotation: the oldest one is re-used once its copy has landed (and has been looked at)
+                    if hints[0][1].query() and hints[0][0].numel() >= Kmax + 1:
+                        cfg.hints.check()
                         entry = hints.pop(0)
                 else:
-                    entry = [torch.empty((max(Kmax, 64),), dtype=torch.int32).pin_memory(), None, None]
+                    entry = [torch.empty((max(Kmax + 1, 64),), dtype=torch.int32).pin_memory(), None, None, Kmax, False, 0]
                 if entry is not None:
-                    entry[0][:Kmax].copy_(skip[2], non_blocking=True)
+                    entry[0][:Kmax + 1].copy_(skip[2], non_blocking=True)      # live counters + the tail's error word
                     entry[1] = torch.cuda.Event()
                     entry[1].record()
-                    entry[2] = (N, n, K)
+                    cfg.hints.serial += 1
+                    entry[2], entry[3], entry[4], entry[5] = (N, n, K), Kmax, False, cfg.hints.serial
                     hints.append(entry)
-                    cfg.stats_out["_bwd_hint"] = entry      # (the newest one, for the tests)
+                    cfg.hints.newest_tail = entry
             if any(windowed):               # slot s is source point qo[s]; slabs + out-of-window rows -> original target order
                 permute = lib.dicp_permute_rows if only_windowed else lib.dicp_permute_add_rows
                 _lib.check(permute(code, _p(gsrc_s), _p(qo), N, n, n, n, 3, 3, _p(gsrc), n, 3, st), "dicp_permute_rows")
@@ -1091,6 +1175,7 @@ class KabschLoop(torch.autograd.Function):
             center = search_frame(tgt, tgt_rows=tgt_rows)       # the search frame, as in ICPLoop
             sweep = SweepIndex(tgt, frame=center, tgt_rows=tgt_rows) if kind == _lib.KNN_SWEEP else None
             tgt4 = sweep.tgs4 if sweep is not None else pack_target(tgt, center, tgt_rows)
+            img16 = f16_image(tgt4, m, tgt_rows) if kind == _lib.KNN_MFMA else None
             nblk = lib.dicp_accumulate_blocks(n)
             pose = _pose_from_T(T_init)
             pose_s = search_pose(pose, center)
@@ -1118,7 +1203,7 @@ class KabschLoop(torch.autograd.Function):
                     tgt4=_p(tgt4), tperm=_p(sweep.tperm) if sweep else None, qorder=_p(qorder), bucket=_p(sweep.bucket) if sweep else None,
                     brange=_p(sweep.brange) if sweep else None, nbkt=SweepIndex.NBKT, pairs=_p(sweep.pair_shards) if sweep else None,
                     frame=_p(center), pose=_p(pose), pose_search=_p(pose_s), pose_used=_p(pose_used), idx=_p(idx), partials=_p(partials),
-                    save=_p(save), costs=_p(costs), iterations=_p(iterations), rows_live=_p(rows_live), tgt_rows=_p(tgt_rows), counters=_p(counters))
+                    save=_p(save), costs=_p(costs), iterations=_p(iterations), rows_live=_p(rows_live), tgt_rows=_p(tgt_rows), counters=_p(counters), tgt_f16=_p(img16))
                 _lib.check(lib.dicp_kabsch_forward(code, ctypes.byref(KB), N, n, m, trim_on, trim, int(const_iter), float(tolerance), k0, k1, st),
                            "dicp_kabsch_forward")
                 if not const_iter:      # ICP.py:585-586 for the batch: stop once every pair has stopped (frozen clouds make the overshoot a no-op)

@@ -6,7 +6,7 @@
 //   sweep_rows / sweep_buckets / query_order / query_keys / loop_init / loop_finish
 //                          per-call set-up of the sorted-sweep search and of the loop state (everything after torch.sort)
 //   knn_valu_kernel        fused transform + brute-force 1-NN, VALU FMA form, LDS-tiled targets
-//   knn_mfma_kernel        same contraction on the f32 matrix cores (v_mfma_f32_16x16x4_f32)
+//   (knn_f16.hip)          the same search on the matrix cores: split-f16 filter (v_mfma_f32_32x32x16_f16) + exact float32 refine
 //   knn_sweep_kernel       exact 1-NN with slab pruning over x-sorted targets
 //   gather / scatter / permute_add
 //                          row-indexed copies (nn.find_nn's gather and its backward; sorted copies and their undoing)
@@ -29,70 +29,10 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 
-#include "../../include/dicp_hip.h"
-#include "dicp_math.h"
-
-using namespace dicp;
+#include "dicp_common.h"
+#include "dicp_internal.h"
 
 namespace {
-
-constexpr int BLOCK = 256;
-constexpr int WAVE = 64;
-#ifndef DICP_ACC_PTS
-#define DICP_ACC_PTS 1024
-#endif
-constexpr int ACC_PTS = DICP_ACC_PTS;  // source points per accumulate block
-constexpr int KNN_PAD = 64;            // m_pad granularity: 4 MFMA tiles of 16 targets / largest VALU chunk
-
-template <typename T> struct V4;
-template <> struct V4<float>  { using type = float4; };
-template <> struct V4<double> { using type = double4; };
-
-template <typename T> __device__ __forceinline__ T inf_v();
-template <> __device__ __forceinline__ float  inf_v<float>()  { return __builtin_huge_valf(); }
-template <> __device__ __forceinline__ double inf_v<double>() { return __builtin_huge_val(); }
-// (a little above) the machine epsilon: roundings of the match-certificate bookkeeping are covered with multiples of it
-template <typename T> struct CertUlp;
-template <> struct CertUlp<float>  { static constexpr float  v = 1.2e-7f; };
-template <> struct CertUlp<double> { static constexpr double v = 2.3e-16; };
-
-__device__ __forceinline__ float  fma_t(float a, float b, float c)    { return __builtin_fmaf(a, b, c); }
-__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
-__device__ __forceinline__ float  min_t(float a, float b)   { return __builtin_fminf(a, b); }
-__device__ __forceinline__ double min_t(double a, double b) { return __builtin_fmin(a, b); }
-__device__ __forceinline__ float  max_t(float a, float b)   { return __builtin_fmaxf(a, b); }
-__device__ __forceinline__ double max_t(double a, double b) { return __builtin_fmax(a, b); }
-
-// Blocks b and b+8 share an XCD (round-robin dispatch; speed only, never correctness):
-// give every cloud's blocks the same b % 8.
-__device__ __forceinline__ bool decode_block(int bpc, int N, int& cloud, int& blk) {
-    const int b = blockIdx.x;
-    const int i = b >> 3;
-    cloud = (i / bpc) * 8 + (b & 7);
-    blk = i % bpc;
-    return cloud < N;
-}
-inline unsigned grid_for(int N, int bpc) { return 8u * (unsigned)((N + 7) / 8) * (unsigned)bpc; }
-
-// Ragged batches (ICP.py:305-511 pads every cloud to the longest): rows[cloud] = leading rows of the cloud that take part
-// (NULL: all `full` of them).  The kernels never read, score or accumulate a row beyond it.
-__device__ __forceinline__ int rows_of(const int32_t* __restrict__ rows, int cloud, int full) {
-    return rows ? min(max(rows[cloud], 0), full) : full;
-}
-
-template <typename T>
-__device__ __forceinline__ void load_pose(const T* __restrict__ pose, int cloud, T* C, T* r) {
-    if (pose) {
-        const T* p = pose + (size_t)cloud * 12;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) C[k] = p[k];
-        r[0] = p[9]; r[1] = p[10]; r[2] = p[11];
-    } else {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) C[k] = (k % 4 == 0) ? T(1) : T(0);
-        r[0] = r[1] = r[2] = T(0);
-    }
-}
 
 // ------------------------------------------------------------------------- pack
 template <typename T> __device__ __forceinline__ T big_v();
@@ -135,15 +75,6 @@ __device__ __forceinline__ typename V4<T>::type pack_row(const T* __restrict__ y
     v.x = q[0]; v.y = q[1]; v.z = q[2];
     v.w = T(0.5) * fma_t(v.z, v.z, fma_t(v.y, v.y, v.x * v.x));     // explicit fmas: no per-kernel contraction choices
     return v;
-}
-
-// -(C p + r), the query every kNN form scores with: ONE explicit fma chain, so that all forms (VALU, packed, MFMA,
-// sweep, scan) see bit-identical queries whatever the compiler would contract in their different surroundings
-template <typename T>
-__device__ __forceinline__ void query_point(const T* C, const T* r, const T* p, T* nx) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-        nx[k] = -fma_t(C[3 * k], p[0], fma_t(C[3 * k + 1], p[1], fma_t(C[3 * k + 2], p[2], r[k])));
 }
 
 // ------------------------------------------------------------------------ search frame
@@ -782,12 +713,6 @@ __global__ __launch_bounds__(BLOCK) void loop_finish_kernel(const T* __restrict_
 }
 
 // ------------------------------------------------------------------- kNN (VALU)
-// score(x, y) = 0.5|y|^2 - x.y  = 0.5(|x-y|^2 - |x|^2): same argmin as the distance.
-template <typename T, typename T4>
-__device__ __forceinline__ T score(const T* nx, const T4& y) {
-    return fma_t(nx[0], y.x, fma_t(nx[1], y.y, fma_t(nx[2], y.z, y.w)));
-}
-
 // Each lane owns Q queries and walks every target of its cloud; targets are staged once
 // per block through LDS and read back as wave-wide broadcasts.  Per chunk of 8 targets the
 // lane only tracks the running minimum VALUE (v_min3) and which chunk last improved it;
@@ -860,107 +785,6 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_valu_kernel(const T* __restri
             }
             idx[(size_t)cloud * n_full + i] = min(bj, m - 1);
         }
-    }
-}
-
-// ------------------------------------------------------------------- kNN (MFMA)
-// The distance matrix IS a dense K=4 contraction: A = targets [y0,y1,y2,h] (16x4),
-// B = queries [-x0,-x1,-x2,1]^T (4x16), D = scores (16 targets x 16 queries) on
-// v_mfma_f32_16x16x4_f32 (exact f32).  Lane l holds D[(l>>4)*4+r][l&15], r=0..3: four
-// targets of one query, so the running min stays lane-local; the four lanes that share a
-// query are combined once at the end.  The VALU only does 2 v_min3 + cmp + select per MFMA.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-template <int NB, int TILE, int G>
-__global__ __launch_bounds__(BLOCK) void knn_mfma_kernel(const float* __restrict__ src, const float* __restrict__ pose,
-                                                         const float4* __restrict__ tgt4, int32_t* __restrict__ idx,
-                                                         int N, int n_full, int m_full, int m_pad_full, int bpc,
-                                                         const int32_t* __restrict__ src_rows, const int32_t* __restrict__ tgt_rows) {
-    constexpr int TS = TILE + 16;      // component stride: lanes 16..31 land 16 banks after lanes 0..15
-    __shared__ float tl[4 * TS];
-    int cloud, blk;
-    if (!decode_block(bpc, N, cloud, blk)) return;
-    const int tid = threadIdx.x;
-    const int n = rows_of(src_rows, cloud, n_full), m = max(rows_of(tgt_rows, cloud, m_full), 1);
-    const int m_pad = min((m + KNN_PAD - 1) / KNN_PAD * KNN_PAD, m_pad_full);
-    if (blk * (BLOCK / WAVE) * (16 * NB) >= n) return;     // (block-uniform)
-    const int lane = tid & (WAVE - 1), wave = tid >> 6;
-    const int ql = lane & 15, kq = lane >> 4;
-    const int qwave = (blk * (BLOCK / WAVE) + wave) * (16 * NB);
-    float C[9], r[3];
-    load_pose(pose, cloud, C, r);
-
-    float nx[NB][3], bq[NB], best[NB];
-    int bt[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const int i = qwave + nb * 16 + ql;
-        float p[3] = {0.f, 0.f, 0.f};
-        if (i < n) {
-            const float* sp = src + ((size_t)cloud * n_full + i) * 3;
-            p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2];
-        }
-        query_point(C, r, p, nx[nb]);
-        bq[nb] = (kq == 0) ? nx[nb][0] : (kq == 1) ? nx[nb][1] : (kq == 2) ? nx[nb][2] : 1.0f;
-        best[nb] = inf_v<float>();
-        bt[nb] = 0;
-    }
-
-    const float4* __restrict__ tg = tgt4 + (size_t)cloud * m_pad_full;
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    for (int base = 0; base < m_pad; base += TILE) {
-        const int len = min(TILE, m_pad - base);            // multiple of 16
-        for (int t = tid; t < len; t += BLOCK) {
-            const float4 v = tg[base + t];
-            tl[t] = v.x; tl[TS + t] = v.y; tl[2 * TS + t] = v.z; tl[3 * TS + t] = v.w;
-        }
-        __syncthreads();
-        // G MFMA tiles (16 targets each) share one compare+select: the winning GROUP is recorded and
-        // re-scanned once at the end
-        for (int t0 = 0; t0 < len; t0 += 16 * G) {         // len is a multiple of 64 >= 16*G
-            float c[NB];
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) c[nb] = best[nb];
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const float a = tl[kq * TS + t0 + g * 16 + ql];      // A[target t0+16g+ql][k = kq]
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq[nb], zero, 0, 0, 0);
-                    c[nb] = min_t(min_t(c[nb], d[0]), d[1]);
-                    c[nb] = min_t(min_t(c[nb], d[2]), d[3]);
-                }
-            }
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                bt[nb] = (c[nb] < best[nb]) ? base + t0 : bt[nb];
-                best[nb] = c[nb];
-            }
-        }
-        __syncthreads();
-    }
-
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const int i = qwave + nb * 16 + ql;
-        float bv = inf_v<float>();
-        int bj = bt[nb];
-#pragma unroll
-        for (int g = 0; g < G; ++g) {                       // this lane's 4 targets in each tile of the winning group
-            const int j0 = bt[nb] + g * 16 + kq * 4;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float s = score<float, float4>(nx[nb], tg[j0 + k]);
-                if (s < bv) { bv = s; bj = j0 + k; }
-            }
-        }
-#pragma unroll
-        for (int off = 16; off < 64; off <<= 1) {           // the 4 lanes that share query ql
-            const float ov = __shfl_xor(bv, off);
-            const int oj = __shfl_xor(bj, off);
-            if (ov < bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
-        }
-        if (kq == 0 && i < n) idx[(size_t)cloud * n_full + i] = min(bj, m - 1);
     }
 }
 
@@ -3132,7 +2956,7 @@ __global__ __launch_bounds__(BLOCK) void bwd_tail_kernel(WeightParams P, dicp_lo
                                                          int32_t* arrive /* (N + 1) zeros: blocks that have published, per cloud; [N] = error word */, int k1) {
     __shared__ double sg[NBWD_PAD], sC[9], sd[6], sAreg[36], sGs[36], sGb[6], sgo[12], sdmax[6], sR[WAVE * 9], smref;
     __shared__ T sGsT[36], sGbT[6], spub[NBWD_PAD];
-    __shared__ int s_verdict, s_alive;
+    __shared__ int s_verdict, s_alive, s_timeout;
     int cloud, blk;
     if (!decode_block(bpc, N, cloud, blk)) return;
     const int tid = threadIdx.x;
@@ -3140,6 +2964,7 @@ __global__ __launch_bounds__(BLOCK) void bwd_tail_kernel(WeightParams P, dicp_lo
     if (ended && blk != 0) return;
     if (tid < 12) sgo[tid] = gpose_in[(size_t)cloud * 12 + tid];
     if (tid == 32) smref = B.bwd_mref[cloud];
+    if (tid == 33) s_timeout = 0;
     const T* __restrict__ dlt = (const T*)B.deltas + (size_t)cloud * B.K * 6;
     const T* cur = have_partials ? part0 : nullptr;         // the cloud's bpc rows of pose sums still to be added to the cotangent (NULL: zeros)
     int gen = 0;
@@ -3162,7 +2987,10 @@ __global__ __launch_bounds__(BLOCK) void bwd_tail_kernel(WeightParams P, dicp_lo
             }
             s += __shfl_down(s, 32);
             s += __shfl_down(s, 16);
-            if (tid < NBWD) sg[tid] = s + sgo[tid];
+            // a wait of this block ran out: the sums it would fold are not known to be complete.  Nothing plausible leaves this launch for the
+            // cloud any more -- every sum this block folds from here on is NaN (and with it its share of the gradients, the sums it publishes to the
+            // cloud's other blocks and the cloud's pose cotangent); the error words make the host raise (dicp_hip.h, bwd_tail_arrive)
+            if (tid < NBWD) sg[tid] = s_timeout ? __builtin_nan("") : s + sgo[tid];
         }
         __syncthreads();
     };
@@ -3294,20 +3122,27 @@ __global__ __launch_bounds__(BLOCK) void bwd_tail_kernel(WeightParams P, dicp_lo
         __syncthreads();
         if (tid < NBWD_PAD) {
             coherent_store(out + ((size_t)cloud * bpc + blk) * NBWD_PAD + tid, spub[tid]);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            // every store of the hand-off has left this wave before the block is counted (written as asm: the compiler's own wait after a
+            // fence can be dropped when it believes the wave's memory counter is already empty)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
         if (tid == 0) {
             __hip_atomic_fetch_add(arrive + cloud, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (!(k == 0 && blk != 0)) {                    // (after the last iteration only block 0 still needs the sums)
+            if (!(k == 0 && blk != 0) && !s_timeout) {      // (after the last iteration only block 0 still needs the sums; a block waits in vain at most once)
                 const int want = gen * bpc;
                 int spins = 0;
                 while (__hip_atomic_load(arrive + cloud, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-                    if (++spins > (1 << 20)) { atomicExch(arrive + N, 1); break; }
+                    if (++spins > (1 << 20)) {              // ~0.5 s: the cloud's other blocks are not running (dicp_bwd_tail_max_blocks keeps that from happening)
+                        atomicExch(arrive + N, 1);
+                        if (B.bwd_live) atomicExch(B.bwd_live + B.K, 1);
+                        s_timeout = 1;
+                        break;
+                    }
                     __builtin_amdgcn_s_sleep(8);
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            asm volatile("" ::: "memory");                  // (the sums are read with agent-scope loads after the barrier below: nothing to invalidate)
         }
         if (k == 0 && blk != 0) return;
         __syncthreads();
@@ -3796,10 +3631,6 @@ __global__ __launch_bounds__(BLOCK) void pose_grad_out_kernel(const double* __re
 }
 
 // ------------------------------------------------------------------- host helpers
-// hipGetLastError() is sticky per host thread and the HIP runtime is shared with PyTorch, which can
-// leave an unrelated error behind: every entry point clears it (begin_launch) before launching and
-// reads it back (launch_status) after, so the status returned is that of OUR launch only.
-inline void begin_launch() { (void)hipGetLastError(); }
 // Timing events of the loop entry points (dicp_loop_buffers.events): the search and the windowed-backward launches
 // carry their pair of events ON the dispatch (hipExtLaunchKernel: start / stop are taken from the kernel's own
 // completion signal), where two hipEventRecord calls would put a barrier packet -- about 6 us of idle queue -- on
@@ -3807,20 +3638,14 @@ inline void begin_launch() { (void)hipGetLastError(); }
 thread_local hipEvent_t tl_launch_start = nullptr, tl_launch_stop = nullptr;
 inline void set_launch_events(hipEvent_t a, hipEvent_t b) { tl_launch_start = a; tl_launch_stop = b; }
 inline void take_launch_events(hipEvent_t& a, hipEvent_t& b) { a = tl_launch_start; b = tl_launch_stop; tl_launch_start = tl_launch_stop = nullptr; }
-inline int launch_status() {
-    const hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : -(int)e;
-}
 inline WeightParams to_params(const dicp_weight_params* p) {
     WeightParams P;
     P.mode = p->mode; P.trim_on = p->trim_on; P.differentiable = p->differentiable; P.loss = p->loss;
     P.trim_dist = p->trim_dist; P.tanh_k = p->tanh_k; P.loss_delta = p->loss_delta; P.match_thresh = p->match_thresh;
     return P;
 }
-inline bool bad_dtype(int d) { return d != DICP_F32 && d != DICP_F64; }
 inline unsigned blocks_for(size_t total) { return (unsigned)((total + BLOCK - 1) / BLOCK); }
 
-struct Rows { const int32_t* src; const int32_t* tgt; };     // optional per-cloud row counts of a ragged batch
 
 struct CertAcc {              // what the accumulate of a certified iteration needs for its on-the-spot searches (PointSearch, untyped)
     const void* pose_search; const void* tgs4; const int32_t* tperm; const int32_t* bucket; const void* brange; int nbkt;
@@ -3854,22 +3679,6 @@ int knn_valu_launch(int cfg, const void* src, const void* pose, const void* tgt4
         case 3: knn_valu_go<T, 4, 8>(src, pose, tgt4, N, n, m, m_pad, idx, rw, st); break;
         case 5: knn_valu_go<T, 4, 16>(src, pose, tgt4, N, n, m, m_pad, idx, rw, st); break;
         case 11: knn_valu_go<T, 8, 16, (sizeof(T) == 4 ? 4 : 1)>(src, pose, tgt4, N, n, m, m_pad, idx, rw, st); break;
-        default: return DICP_ERR_ENUM;
-    }
-    return launch_status();
-}
-
-template <int NB, int G>
-void knn_mfma_go(const void* src, const void* pose, const void* tgt4, int N, int n, int m, int m_pad, int32_t* idx, Rows rw, hipStream_t st) {
-    const int bpc = (n + 64 * NB - 1) / (64 * NB);
-    knn_mfma_kernel<NB, 2048, G><<<grid_for(N, bpc), BLOCK, 0, st>>>((const float*)src, (const float*)pose, (const float4*)tgt4, idx, N, n, m, m_pad, bpc, rw.src, rw.tgt);
-}
-
-int knn_mfma_launch(int cfg, const void* src, const void* pose, const void* tgt4, int N, int n, int m, int m_pad, int32_t* idx, Rows rw, hipStream_t st) {
-    if (cfg == 0) cfg = ((long)N * n >= 512L * 1024) ? 5 : 1;
-    switch (cfg) {
-        case 1: knn_mfma_go<2, 1>(src, pose, tgt4, N, n, m, m_pad, idx, rw, st); break;
-        case 5: knn_mfma_go<4, 4>(src, pose, tgt4, N, n, m, m_pad, idx, rw, st); break;
         default: return DICP_ERR_ENUM;
     }
     return launch_status();
@@ -4071,8 +3880,13 @@ int dicp_pose_grad_out(int dtype, const double* gpose, const void* bwd_partials,
     return launch_status();
 }
 
+size_t dicp_knn_f16_bytes(int N, int m_pad) { return (N <= 0 || m_pad <= 0) ? 0 : dicp_tu::knn_f16_image_bytes(N, m_pad); }
+int dicp_knn_f16_pack(const void* tgt4, const int32_t* tgt_rows, int N, int m, int m_pad, void* image, void* stream) {
+    return dicp_tu::knn_f16_pack(tgt4, tgt_rows, N, m, m_pad, image, stream);
+}
+
 int dicp_knn(int dtype, const void* src, const void* pose, const void* tgt4, const int32_t* src_rows, const int32_t* tgt_rows,
-             int N, int n, int m, int m_pad, int32_t* idx, int variant, void* stream) {
+             int N, int n, int m, int m_pad, int32_t* idx, int variant, const void* f16_image, void* stream) {
     if (!src || !tgt4 || !idx) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || n <= 0 || m <= 0 || m_pad != dicp_padded_targets(m)) return DICP_ERR_SHAPE;
@@ -4083,7 +3897,10 @@ int dicp_knn(int dtype, const void* src, const void* pose, const void* tgt4, con
     hipStream_t st = (hipStream_t)stream;
     begin_launch();
     const Rows rw{src_rows, tgt_rows};
-    if (kind == DICP_KNN_MFMA) return knn_mfma_launch(cfg, src, pose, tgt4, N, n, m, m_pad, idx, rw, st);
+    if (kind == DICP_KNN_MFMA) {      // (the launch configuration bits are not used by this form)
+        if (!f16_image) return DICP_ERR_NULL;
+        return dicp_tu::knn_f16_brute(src, pose, tgt4, const_cast<void*>(f16_image), src_rows, tgt_rows, N, n, m, m_pad, idx, stream);
+    }
     if (dtype == DICP_F32) return knn_valu_launch<float>(cfg, src, pose, tgt4, N, n, m, m_pad, idx, rw, st);
     return knn_valu_launch<double>(cfg, src, pose, tgt4, N, n, m, m_pad, idx, rw, st);
 }
@@ -4381,7 +4198,7 @@ int dicp_kabsch_forward(int dtype, const dicp_kabsch_buffers* B, int N, int n, i
             rc = dicp_knn_sweep(dtype, B->src, pose_s, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, B->rows_live, B->tgt_rows, N, n, m, B->m_pad,
                                 B->idx, nullptr, B->pairs, (B->knn_variant >> 8) & 0xff, stream);
         else
-            rc = dicp_knn(dtype, B->src, pose_s, B->tgt4, B->rows_live, B->tgt_rows, N, n, m, B->m_pad, B->idx, B->knn_variant & 0xffff, stream);
+            rc = dicp_knn(dtype, B->src, pose_s, B->tgt4, B->rows_live, B->tgt_rows, N, n, m, B->m_pad, B->idx, B->knn_variant & 0xffff, B->tgt_f16, stream);
         if (rc) return rc;
         rc = dicp_kabsch_accumulate(dtype, B->src, B->tgt, B->c, B->idx, B->pose, B->w_init, trim_on, trim_dist, B->rows_live, N, n, m, B->partials, stream);
         if (rc) return rc;
@@ -4431,6 +4248,34 @@ int dicp_window_blocks(int dtype, int n, int m_pad) {
 }
 
 int dicp_window_rows(int dtype) { return dtype == DICP_F32 ? WindowRows<float>::v : WindowRows<double>::v; }
+
+// The one-launch tail of the reverse sweep (bwd_tail_kernel) lets the blocks of a cloud wait for each other inside an ordinary launch.  That is
+// only safe while ALL of a cloud's blocks can be resident at once: blocks are dispatched in index order and a cloud's blocks share an XCD
+// (decode_block), so a cloud with more blocks than an XCD holds would leave its first ones waiting for blocks that can never start.  The most
+// blocks per cloud the tail may be used with: HALF of what one XCD holds of that kernel (the occupancy query for the instantiation with the
+// larger register footprint, x the XCD's compute units) -- the other half is room for a second such launch on another stream, or for an
+// occupancy answer that is one block per unit too high.  0: never (query failed).  dicp_icp_backward refuses a tail beyond it.
+int dicp_bwd_tail_max_blocks(int dtype) {
+    static int cap[2] = {-1, -1};
+    if (bad_dtype(dtype)) return 0;
+    if (cap[dtype] >= 0) return cap[dtype];
+    int dev = 0, cus = 0, a = 0, b = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e == hipSuccess) {
+        if (dtype == DICP_F32) {
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bwd_tail_kernel<float, MODE_PT2PL, WindowRows<float>::v>, BLOCK, 0);
+            if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, bwd_tail_kernel<float, MODE_PT2PT, WindowRows<float>::v>, BLOCK, 0);
+        } else {
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bwd_tail_kernel<double, MODE_PT2PL, WindowRows<double>::v>, BLOCK, 0);
+            if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, bwd_tail_kernel<double, MODE_PT2PT, WindowRows<double>::v>, BLOCK, 0);
+        }
+    }
+    if (e != hipSuccess) { (void)hipGetLastError(); return 0; }           // (not cached: no device yet)
+    const int per_cu = a < b ? a : b, xcds = 8;
+    cap[dtype] = (per_cu > 0 && cus >= xcds) ? (per_cu * (cus / xcds)) / 2 : 0;
+    return cap[dtype];
+}
 
 static int accumulate_bwd_window_go(int dtype, const dicp_weight_params* prm, const void* src_s, const void* tgt_s, int c,
                                     const int32_t* spos, const int32_t* spos_ref, const int32_t* qorder, const void* pose, const void* w_s,
@@ -4636,7 +4481,7 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
             set_launch_events(nullptr, nullptr);
             if (rc) return rc;
         } else {
-            rc = dicp_knn(dtype, B->src, pose_s, B->tgt4, B->src_rows, B->tgt_rows, N, n, m, B->m_pad, idx_k, B->knn_variant & 0xffff, stream);
+            rc = dicp_knn(dtype, B->src, pose_s, B->tgt4, B->src_rows, B->tgt_rows, N, n, m, B->m_pad, idx_k, B->knn_variant & 0xffff, B->tgt_f16, stream);
             if (rc) return rc;
             if (B->events) {
                 if (hipEventRecord((hipEvent_t)B->events[6 * k + 1], st) != hipSuccess) return -(int)hipGetLastError();
@@ -4729,6 +4574,7 @@ int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_
     if (B->spos && B->bwd_skip && B->bwd_tail_from > k0) {
         if (k0 != 0) return DICP_ERR_SHAPE;                 // (the launch runs down to iteration 0 and folds the last pose sums into the cotangent)
         if (!B->bwd_tail_partials || !B->bwd_tail_arrive) return DICP_ERR_NULL;
+        if (nblk > dicp_bwd_tail_max_blocks(dtype)) return DICP_ERR_SHAPE;      // (its blocks wait for each other: they must all be resident)
         kt = B->bwd_tail_from < k1 ? B->bwd_tail_from : k1;
         if (B->bwd_overwrite && kt >= k1) kt = k1 - 1;      // (the first windowed launch initialises the accumulators: it always runs)
     }

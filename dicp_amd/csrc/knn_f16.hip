@@ -1,0 +1,484 @@
+// The search on the matrix cores (round 4): split-f16 FILTER on v_mfma_f32_32x32x16_f16 + exact float32 REFINE.
+//
+// The reference's hot line is the K = 5 contraction inside torch.cdist (/root/reference/dICP/nn.py:32): score(x, y) = 0.5|y|^2 - x.y.
+// gfx950's f32 MFMA runs at the vector rate (round 1: it never paid); its f16 MFMA is 16x faster and accumulates in f32.  So:
+//   FILTER  x and y are split into two f16 terms each (x = xh + xl to 2^-22, after a per-cloud power-of-two scale s that puts the
+//           cloud's extent at 2^10..2^11), and ONE 32x32x16 MFMA scores 32 targets x 32 queries with the K = 16 slots
+//               A (target):  yh0 yh1 yh2 | yl0 yl1 yl2 | yh0 yh1 yh2 | yl0 yl1 yl2 | H0 H1 H2 | 0        H = three-term split of h s^2 / P
+//               B (query):   xh0 xh1 xh2 | xh0 xh1 xh2 | xl0 xl1 xl2 | xl0 xl1 xl2 | P  P  P  | 0        x = -(C p + r) s,  P = 2^13
+//           = s^2 (x.y + h) up to the error bound E below.  Lane l of the result holds 16 targets of ONE query (column l & 31), so the
+//           running minimum is lane-local: per chunk of F16_CHT MFMAs a lane reduces its 16 F16_CHT scores (v_min3), and keeps the two
+//           smallest chunk minima b1 <= b2 and the chunk of b1 (v_med3, compare, select, min).
+//   REFINE  |filter - score()| <= E for every pair (E per query, below), so the true winner j* -- the argmin of the float32 score() every
+//           other search form computes, lowest index among equals -- lies in the chunk of b1 unless another chunk's minimum is within
+//           2E of it:  b2 - b1 > 2E  =>  re-score that one chunk (16 F16_CHT rows) with score() itself, ascending, strict <: bit-identical
+//           to knn_valu_kernel.  Otherwise (a near-tie inside the filter's resolution, a query outside the f16 range, nothing finite)
+//           the wave scores every row of the cloud for that query exactly, 64 rows at a time.
+// The bound (u = 2^-24; T = sum_i |x_i y_i| + h <= |x| |y| + 0.5 |y|^2, unscaled):
+//     |score() - (h - x.y)|          <= 3.01 u T                  three fmas on the stored h
+//     split:  |x^ y^ - x y|          <= 2 (4u) |x_i y_i| + phi (|x|_1 + |y|_1),  phi = 2^-24 / s  (f16 denormals are honoured: measured,
+//                                                                 scripts/ubench/mfma_f16_ubench.hip; the term covers their rounding)
+//     h split (three terms)          <= u h + hphi,               hphi = 3 * 2^-12 / s^2
+//     MFMA accumulation              <= 20 u T                    measured 4.97 u T at worst over 4e5 dot products of wide range and
+//                                                                 heavy cancellation (same ubench); 4x that is assumed
+//   E = 32 u T + phi (|x|_1 + sqrt3 |y|) + hphi, with |y| <= |x| + sqrt(2 D) and D the candidate's half squared distance, itself bounded
+//   from the filter's own minimum (D <= b1 / s^2 + 0.5|x|^2, taken with 2^-9 relative slack, which the code checks E against).
+// Rows the f16 range cannot hold next to the rest of the cloud (the reference's pad rows at max(source) * 1000, ICP.py:460: a cloud with up
+// to 64 rows beyond 16x the rest's extent) are left out of the image and scored exactly for every query at the end ("far rows").
+#include <stdlib.h>
+#include <type_traits>
+
+#include "dicp_common.h"
+#include "dicp_internal.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int F16_META = dicp_tu::KNN_F16_META;
+constexpr int F16_STAGE = dicp_tu::KNN_F16_STAGE_ROWS / 32;   // A tiles (32 rows, 1 KiB) per LDS stage
+constexpr int F16_G = 4;                // B tiles (32 queries each) per wave: 128 queries, like a unit of the sweep
+constexpr int F16_CHT = 4;              // A tiles per chunk of the lane-local bookkeeping
+constexpr int F16_FAR_MAX = 64;
+enum { FM_S = 0, FM_INV_S2 = 1, FM_PHI = 2, FM_NFAR = 3, FM_HPHI = 4, FM_FAR_ABOVE = 5, FM_AGAIN = 6 /* queries sent through pass 2, added up */,
+       FM_SCAN = 7 /* queries scored against every row */, FM_FAR0 = 8 };
+constexpr float F16_P = 8192.f;
+constexpr float F16_U = 5.9604644775390625e-8f;     // 2^-24
+constexpr float F16_CREL = 32.f;
+
+// row (inside its 32-row tile) held by MFMA row rho of the A operand: half h of the RESULT's lanes then owns rows 16h .. 16h + 15, in
+// register order (result register i of lane half h is MFMA row (i & 3) + 8 (i >> 2) + 4 h)
+__device__ __forceinline__ int f16_row_of(int rho) { return ((rho >> 2) & 1) * 16 + (rho >> 3) * 4 + (rho & 3); }
+
+__device__ __forceinline__ float block_max(float v, float* red) {
+#pragma unroll
+    for (int o = WAVE / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    __syncthreads();
+    if ((threadIdx.x & (WAVE - 1)) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int w = 1; w < BLOCK / WAVE; ++w) r = fmaxf(r, red[w]);
+    return r;
+}
+
+// per cloud: the scale and the far rows.  One block per cloud.
+__global__ __launch_bounds__(BLOCK) void knn_f16_scale_kernel(const float4* __restrict__ rows4, const int32_t* __restrict__ tgt_rows, int m_full, int m_pad,
+                                                              float* __restrict__ meta_all) {
+    __shared__ float red[BLOCK / WAVE];
+    __shared__ int s_cnt;
+    const int cloud = blockIdx.x, tid = threadIdx.x;
+    const int m = min(max(rows_of(tgt_rows, cloud, m_full), 1), m_pad);
+    const float4* __restrict__ tg = rows4 + (size_t)cloud * m_pad;
+    float* mt = meta_all + (size_t)cloud * F16_META;
+    int32_t* mi = (int32_t*)mt;
+    auto row_max = [&](int r) {
+        const float4 v = tg[r];
+        return (v.w < __builtin_huge_valf()) ? fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fabsf(v.z)) : -1.f;     // (0.5|y|^2 finite => the row is)
+    };
+    // a row that repeats the row before it bit for bit can never be the answer (lowest index among equal scores): the reference's pad rows --
+    // copies of ONE far point, ICP.py:460,472-477 -- count as one far row
+    auto repeats = [&](int r) {
+        if (r == 0) return false;
+        const float4 v = tg[r], p = tg[r - 1];
+        return __float_as_uint(v.x) == __float_as_uint(p.x) && __float_as_uint(v.y) == __float_as_uint(p.y) && __float_as_uint(v.z) == __float_as_uint(p.z) &&
+               __float_as_uint(v.w) == __float_as_uint(p.w);
+    };
+    float mx = 0.f;
+    for (int r = tid; r < m; r += BLOCK) mx = fmaxf(mx, row_max(r));
+    const float Minf = block_max(mx, red);
+    // the extent WITHOUT the rows beyond Minf / 16, and how many those are
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    const float cut = Minf * 0.0625f;
+    float m2 = 0.f;
+    int above = 0;
+    for (int r = tid; r < m; r += BLOCK) { const float v = row_max(r); if (v > cut) above += repeats(r) ? 0 : 1; else m2 = fmaxf(m2, v); }
+    if (above) atomicAdd(&s_cnt, above);
+    const float M2 = block_max(m2, red);
+    const int cnt = s_cnt;
+    __syncthreads();
+    const bool use_far = cnt > 0 && cnt <= F16_FAR_MAX && M2 > 0.f && cnt * 64 <= m;
+    const float M = use_far ? M2 : Minf;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    if (use_far)
+        for (int r = tid; r < m; r += BLOCK)
+            if (row_max(r) > cut && !repeats(r)) { const int slot = atomicAdd(&s_cnt, 1); if (slot < F16_FAR_MAX) mi[FM_FAR0 + slot] = r; }
+    __syncthreads();
+    if (tid == 0) {
+        int ex = 0;
+        float s = 1.f;
+        if (M > 0.f && M < __builtin_huge_valf()) {
+            (void)frexpf(M, &ex);                                   // M = f 2^ex, f in [0.5, 1): M 2^(11 - ex) in [2^10, 2^11): queries up to 32x
+            const int e = min(max(11 - ex, -60), 60);               // the cloud's extent away still fit the f16 range
+            s = ldexpf(1.f, e);
+        }
+        mt[FM_S] = s;
+        mt[FM_INV_S2] = (1.f / s) * (1.f / s);
+        mt[FM_PHI] = F16_U / s;
+        mi[FM_NFAR] = use_far ? min(s_cnt, F16_FAR_MAX) : 0;
+        mt[FM_HPHI] = 3.f * 0.000244140625f * ((1.f / s) * (1.f / s));      // 3 * 2^-12 / s^2
+        mt[FM_FAR_ABOVE] = use_far ? cut : __builtin_huge_valf();
+        mi[FM_AGAIN] = mi[FM_SCAN] = 0;
+    }
+}
+
+// the image: one thread per (row, k half) -> 16 bytes, written in MFMA operand order (a wave's load of a tile is one contiguous KiB)
+__global__ __launch_bounds__(BLOCK) void knn_f16_image_kernel(const float4* __restrict__ rows4, const int32_t* __restrict__ tgt_rows, int m_full, int m_pad, int m_img,
+                                                              const float* __restrict__ meta_all, uint4* __restrict__ image, int tiles_per_cloud, int N) {
+    const int cloud = blockIdx.y;
+    const int tile = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6), lane = threadIdx.x & (WAVE - 1);
+    if (tile >= tiles_per_cloud) return;
+    const int m = min(max(rows_of(tgt_rows, cloud, m_full), 1), m_pad);
+    const float* mt = meta_all + (size_t)cloud * F16_META;
+    const float s = mt[FM_S], far_above = mt[FM_FAR_ABOVE];
+    const int r = tile * 32 + f16_row_of(lane & 31), kh = lane >> 5;
+    _Float16 yh[3] = {0, 0, 0}, yl[3] = {0, 0, 0}, H[3] = {(_Float16)__builtin_huge_valf(), 0, 0};
+    if (r < m) {
+        const float4 v = rows4[(size_t)cloud * m_pad + r];
+        const float big = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fabsf(v.z));
+        if (v.w < __builtin_huge_valf() && !(big > far_above)) {
+            const float c[3] = {v.x * s, v.y * s, v.z * s};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { yh[k] = (_Float16)c[k]; yl[k] = (_Float16)(c[k] - (float)yh[k]); }
+            const float hs = v.w * (s * s * (1.f / F16_P));
+            H[0] = (_Float16)hs;
+            const float r1 = hs - (float)H[0];
+            H[1] = (_Float16)r1;
+            H[2] = (_Float16)(r1 - (float)H[1]);
+        }
+    }
+    half8 a;
+    if (kh == 0) { a[0] = yh[0]; a[1] = yh[1]; a[2] = yh[2]; a[3] = yl[0]; a[4] = yl[1]; a[5] = yl[2]; a[6] = yh[0]; a[7] = yh[1]; }
+    else         { a[0] = yh[2]; a[1] = yl[0]; a[2] = yl[1]; a[3] = yl[2]; a[4] = H[0];  a[5] = H[1];  a[6] = H[2];  a[7] = (_Float16)0.f; }
+    uint4 out;
+    __builtin_memcpy(&out, &a, 16);
+    image[((size_t)cloud * tiles_per_cloud + tile) * 64 + lane] = out;
+}
+
+// the query's B fragment: lane half 0 holds k = 0..7, half 1 k = 8..15
+__device__ __forceinline__ half8 f16_query_fragment(const float* nx, float s, int kh) {
+    _Float16 xh[3], xl[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const float c = nx[k] * s; xh[k] = (_Float16)c; xl[k] = (_Float16)(c - (float)xh[k]); }
+    half8 b;
+    const _Float16 P = (_Float16)F16_P;
+    if (kh == 0) { b[0] = xh[0]; b[1] = xh[1]; b[2] = xh[2]; b[3] = xh[0]; b[4] = xh[1]; b[5] = xh[2]; b[6] = xl[0]; b[7] = xl[1]; }
+    else         { b[0] = xl[2]; b[1] = xl[0]; b[2] = xl[1]; b[3] = xl[2]; b[4] = P;     b[5] = P;     b[6] = P;     b[7] = (_Float16)0.f; }
+    return b;
+}
+
+// 2E in the filter's own (scaled) units for a query whose smallest filter value is b1 (scaled); < 0: no bound (exact scan)
+__device__ __forceinline__ float f16_margin(const float* nx, float b1, const float* __restrict__ mt) {
+    const float s = mt[FM_S], inv_s2 = mt[FM_INV_S2];
+    const float x1 = fabsf(nx[0]) + fabsf(nx[1]) + fabsf(nx[2]);
+    const float hx = 0.5f * (nx[0] * nx[0] + nx[1] * nx[1] + nx[2] * nx[2]);
+    const float b1u = b1 * inv_s2;
+    const float D0 = fmaxf(b1u + hx, 0.f);
+    const float slack = 0.001953125f * (D0 + hx);                   // 2^-9 (D0 + hx)
+    const float Dup = D0 + slack;
+    const float X2 = sqrtf(2.f * hx) * 1.000001f;
+    const float Y = X2 + sqrtf(2.f * Dup) * 1.000001f;
+    const float Tup = X2 * Y + 0.5f * Y * Y;
+    const float E = (F16_CREL * F16_U * Tup + mt[FM_PHI] * (x1 + 1.7321f * Y) + mt[FM_HPHI]) * 1.01f;
+    if (!(4.f * E <= slack) || !(E < __builtin_huge_valf())) return -1.f;      // (also NaN / inf: a query outside the f16 range)
+    return 2.f * E * (s * s) * 1.0001f;
+}
+
+__device__ __forceinline__ float f16_chunk_min(const f32x16& d, float cm) {
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) cm = __builtin_fminf(__builtin_fminf(cm, d[i]), d[i + 1]);
+    return cm;
+}
+
+// The lane-local bookkeeping per chunk: the three smallest chunk minima b1 <= b2 <= b3 and the chunks of the first two.
+struct F16Track {
+    float b1, b2, b3;
+    int id1, id2;
+    __device__ __forceinline__ void init() { b1 = b2 = b3 = __builtin_huge_valf(); id1 = id2 = 0; }
+    // (written as instructions: the compiler turned the nested selects into divergent branches, which also kept it from interleaving the
+    //  MFMAs with the minima of the previous results)
+    __device__ __forceinline__ void add(float cm, int chunk /* in a vector register */) {
+        asm("v_cmp_lt_f32 vcc, %5, %1\n\t"            // cm < b2
+            "v_cndmask_b32 %4, %4, %6, vcc\n\t"       //   id2 = chunk
+            "v_cmp_lt_f32 vcc, %5, %0\n\t"            // cm < b1
+            "v_cndmask_b32 %4, %4, %3, vcc\n\t"       //   id2 = id1
+            "v_cndmask_b32 %3, %3, %6, vcc\n\t"       //   id1 = chunk
+            "v_med3_f32 %2, %1, %5, %2\n\t"           // b3 = cm clamped into [b2, b3]: the third smallest of the four
+            "v_med3_f32 %1, %0, %5, %1\n\t"           // b2 likewise
+            "v_min_f32 %0, %0, %5"
+            : "+v"(b1), "+v"(b2), "+v"(b3), "+v"(id1), "+v"(id2) : "v"(cm), "v"(chunk) : "vcc");
+    }
+};
+
+// stage st of the cloud's image -> registers (issued early), registers -> LDS (after the stage in LDS has been used)
+#define DICP_F16_FETCH(st_)  _Pragma("unroll") for (int k_ = 0; k_ < F16_STAGE * 64 / BLOCK; ++k_) pre[k_] = img[(size_t)(st_) * (F16_STAGE * 64) + tid + k_ * BLOCK];
+#define DICP_F16_COMMIT(buf_) _Pragma("unroll") for (int k_ = 0; k_ < F16_STAGE * 64 / BLOCK; ++k_) lds[buf_][tid + k_ * BLOCK] = pre[k_];
+
+// every n x m pair.  Block = 4 waves x 128 queries; the cloud's image streams through LDS in stages of 512 rows, double-buffered.
+//   pass 1   the filter over all tiles (four B tiles per wave), lane-local bookkeeping per chunk of F16_CHT tiles;
+//   refine   b2 - b1 > 2E: the winner's chunk is re-scored exactly; b3 - b1 > 2E: the two candidate chunks are;
+//   pass 2   queries with three or more chunks inside 2E (dense surfaces: a fifth of the queries of a planar scene have a second candidate
+//            there, a few per cent a third): the block streams the image once more, each wave with ONE B tile made of up to 32 such queries,
+//            and every lane re-scores exactly the 16-row pieces whose filter minimum is within 2E of the query's b1 -- a quarter of pass 1's
+//            matrix work per round of 32 queries per wave, whatever the number of candidates;
+//   scan     queries the filter has no bound for (outside the f16 range, nothing finite): the wave scores every row, 64 at a time.
+template <int MINW>
+__global__ __launch_bounds__(BLOCK, MINW) void knn_f16_kernel(const float* __restrict__ src, const float* __restrict__ pose, const float4* __restrict__ tgt4,
+                                                              const uint4* __restrict__ image, float* __restrict__ meta_all, int32_t* __restrict__ idx,
+                                                              int N, int n_full, int m_full, int m_pad_full, int tiles_per_cloud, int bpc,
+                                                              const int32_t* __restrict__ src_rows, const int32_t* __restrict__ tgt_rows) {
+    __shared__ uint4 lds[2][F16_STAGE * 64];
+    __shared__ float4 qlist[BLOCK / WAVE][32];          // pass 2: (query, threshold) of the wave's B tile
+    __shared__ int qslot[BLOCK / WAVE][32];             // ... and where its result goes: (g << 8) | column
+    __shared__ int s_rounds;
+    int cloud, blk;
+    if (!decode_block(bpc, N, cloud, blk)) return;
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
+    const int n = rows_of(src_rows, cloud, n_full), m = min(max(rows_of(tgt_rows, cloud, m_full), 1), m_pad_full);
+    if (blk * (BLOCK / WAVE) * (32 * F16_G) >= n) return;           // (block-uniform)
+    const int col = lane & 31, kh = lane >> 5;
+    const int qwave = (blk * (BLOCK / WAVE) + wave) * (32 * F16_G);
+    float* __restrict__ mt = meta_all + (size_t)cloud * F16_META;
+    const float s = mt[FM_S];
+    float C[9], r[3];
+    load_pose(pose, cloud, C, r);
+    if (tid == 0) s_rounds = 0;
+
+    float nx[F16_G][3];
+    F16Track tr[F16_G];
+    half8 b[F16_G];
+#pragma unroll
+    for (int g = 0; g < F16_G; ++g) {
+        const int i = qwave + g * 32 + col;
+        float p[3] = {0.f, 0.f, 0.f};
+        if (i < n) {
+            const float* sp = src + ((size_t)cloud * n_full + i) * 3;
+            p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2];
+        }
+        query_point(C, r, p, nx[g]);                                // ICP.py:137
+        b[g] = f16_query_fragment(nx[g], s, kh);
+        tr[g].init();
+    }
+
+    const uint4* __restrict__ img = image + (size_t)cloud * tiles_per_cloud * 64;
+    const int nst = (m + 32 * F16_STAGE - 1) / (32 * F16_STAGE);      // stages that hold a real row
+    f32x16 zero;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) zero[i] = 0.f;
+    uint4 pre[F16_STAGE * 64 / BLOCK];
+    DICP_F16_FETCH(0)
+    DICP_F16_COMMIT(0)
+    __syncthreads();
+    // ---- pass 1
+    for (int st = 0; st < nst; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < nst) { DICP_F16_FETCH(st + 1) }
+#pragma unroll 1
+        for (int t = 0; t < F16_STAGE; t += F16_CHT) {
+            half8 a[F16_CHT];
+#pragma unroll
+            for (int c = 0; c < F16_CHT; ++c) { const uint4 v = lds[cur][(t + c) * 64 + lane]; __builtin_memcpy(&a[c], &v, 16); }
+            int chunk = st * (F16_STAGE / F16_CHT) + t / F16_CHT;
+            asm("v_mov_b32 %0, %1" : "=v"(chunk) : "s"(chunk));       // (a vector register: v_cndmask's second source)
+#pragma unroll
+            for (int g = 0; g < F16_G; ++g) {
+                float cm = __builtin_huge_valf();
+#pragma unroll
+                for (int c = 0; c < F16_CHT; ++c)
+                    cm = f16_chunk_min(__builtin_amdgcn_mfma_f32_32x32x16_f16(a[c], b[g], zero, 0, 0, 0), cm);
+                tr[g].add(cm, chunk);
+            }
+        }
+        if (st + 1 < nst) { DICP_F16_COMMIT(cur ^ 1) }
+        __syncthreads();
+    }
+
+    // ---- refine
+    const float4* __restrict__ tg = tgt4 + (size_t)cloud * m_pad_full;
+    const int nfar = ((const int32_t*)mt)[FM_NFAR];
+    float bv[F16_G], thr[F16_G];
+    int bj[F16_G];
+    int n_scan = 0, n_again = 0, my_unsure = 0;          // (my_unsure: bit g = this query goes to pass 2)
+    auto rescore = [&](const float* q, int r0, int cnt, float& v, int& j) {      // rows r0 .. r0 + cnt - 1, ascending
+#pragma unroll 4
+        for (int k = 0; k < cnt; ++k) {
+            const int rr = r0 + k;
+            if (rr < m) {
+                const float sc = score<float, float4>(q, tg[rr]);
+                if (sc < v || (sc == v && rr < j)) { v = sc; j = rr; }
+            }
+        }
+    };
+#pragma unroll
+    for (int g = 0; g < F16_G; ++g) {
+        const int i = qwave + g * 32 + col;
+        // the query's two lanes (the two halves of every tile) merge their bookkeeping: the three smallest of the six values, the chunks
+        // (and lane halves) of the first two
+        const F16Track me = tr[g];
+        F16Track ot;
+        ot.b1 = __shfl_xor(me.b1, 32); ot.b2 = __shfl_xor(me.b2, 32); ot.b3 = __shfl_xor(me.b3, 32);
+        ot.id1 = __shfl_xor(me.id1, 32); ot.id2 = __shfl_xor(me.id2, 32);
+        // (lo, hi): lo holds the smaller b1 (lane half 0 on equal values: any consistent choice -- equal values are a near-tie anyway)
+        const bool me_lo = me.b1 < ot.b1 || (me.b1 == ot.b1 && kh == 0);
+        const F16Track lo = me_lo ? me : ot, hi = me_lo ? ot : me;
+        const int lo_h = me_lo ? kh : (kh ^ 1), hi_h = lo_h ^ 1;
+        const float B1 = lo.b1;
+        const bool second_lo = lo.b2 < hi.b1;                       // the second smallest: lo's second or hi's first
+        const float B2 = second_lo ? lo.b2 : hi.b1;
+        const int c1 = lo.id1, h1 = lo_h, c2 = second_lo ? lo.id2 : hi.id1, h2 = second_lo ? lo_h : hi_h;
+        const float B3 = second_lo ? __builtin_fminf(lo.b3, hi.b1) : __builtin_fminf(lo.b2, hi.b2);
+        const float margin = f16_margin(nx[g], B1, mt);
+        const bool bounded = (B1 < __builtin_huge_valf()) && margin >= 0.f;
+        const int ncand = !bounded ? 0 : (B2 - B1 > margin ? 1 : (B3 - B1 > margin ? 2 : 3));
+        bv[g] = __builtin_huge_valf();
+        bj[g] = 0;
+        thr[g] = B1 + margin;
+        if (ncand == 1) {           // the winner's 16 F16_CHT rows by the query's two lanes (tiles 0..1 / 2..3 of the chunk)
+            for (int c = kh * (F16_CHT / 2); c < (kh + 1) * (F16_CHT / 2); ++c) rescore(nx[g], (c1 * F16_CHT + c) * 32 + h1 * 16, 16, bv[g], bj[g]);
+        } else if (ncand == 2) {    // one candidate chunk per lane
+            const int cc = kh ? c2 : c1, hh = kh ? h2 : h1;
+            for (int c = 0; c < F16_CHT; ++c) rescore(nx[g], (cc * F16_CHT + c) * 32 + hh * 16, 16, bv[g], bj[g]);
+        }
+        if (ncand == 1 || ncand == 2) {
+            const float ov = __shfl_xor(bv[g], 32);
+            const int oj = __shfl_xor(bj[g], 32);
+            if (ov < bv[g] || (ov == bv[g] && oj < bj[g])) { bv[g] = ov; bj[g] = oj; }
+        }
+        if (ncand == 3 && i < n) my_unsure |= 1 << g;
+        // queries the filter has no bound for: the wave scores every row for them, one query at a time (lane half 0 asks)
+        unsigned long long need = __ballot(ncand == 0 && kh == 0 && i < n);
+        while (need) {
+            const int L = __builtin_ctzll(need);
+            need &= need - 1;
+            const float q[3] = {__shfl(nx[g][0], L), __shfl(nx[g][1], L), __shfl(nx[g][2], L)};
+            float v = __builtin_huge_valf();
+            int j = 0x7fffffff;
+            for (int rr = lane; rr < m; rr += WAVE) {
+                const float sc = score<float, float4>(q, tg[rr]);
+                if (sc < v) { v = sc; j = rr; }
+            }
+#pragma unroll
+            for (int o = WAVE / 2; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(v, o);
+                const int oj = __shfl_xor(j, o);
+                if (ov < v || (ov == v && oj < j)) { v = ov; j = oj; }
+            }
+            if (col == (L & 31)) { bv[g] = v; bj[g] = (j == 0x7fffffff) ? 0 : j; }
+            ++n_scan;
+        }
+    }
+
+    // ---- pass 2: rounds of up to 32 queries per wave
+    int cnt = 0, base[F16_G];        // this wave's pass-2 queries: base[g] = how many precede B tile g's
+#pragma unroll
+    for (int g = 0; g < F16_G; ++g) { base[g] = cnt; cnt += __popcll(__ballot(((my_unsure >> g) & 1) && kh == 0)); }
+    n_again = cnt;
+    if (lane == 0 && cnt) atomicMax(&s_rounds, (cnt + 31) / 32);
+    __syncthreads();
+    const int rounds = s_rounds;
+    for (int rd = 0; rd < rounds; ++rd) {
+        // the wave's B tile of this round: its pass-2 queries number 32 rd .. 32 rd + 31
+#pragma unroll
+        for (int g = 0; g < F16_G; ++g) {
+            const bool mineg = ((my_unsure >> g) & 1) && kh == 0;
+            const unsigned long long mask = __ballot(mineg);
+            const int rank = base[g] + __popcll(mask & ((1ull << lane) - 1)) - 32 * rd;
+            if (mineg && rank >= 0 && rank < 32) {
+                qlist[wave][rank] = make_float4(nx[g][0], nx[g][1], nx[g][2], thr[g]);
+                qslot[wave][rank] = (g << 8) | col;
+            }
+        }
+        const int have = min(max(cnt - 32 * rd, 0), 32);
+        __builtin_amdgcn_wave_barrier();
+        float q[3] = {0.f, 0.f, 0.f}, tau = -__builtin_huge_valf();
+        if (col < have) { const float4 e = qlist[wave][col]; q[0] = e.x; q[1] = e.y; q[2] = e.z; tau = e.w; }
+        const half8 b2 = f16_query_fragment(q, s, kh);
+        float v2 = __builtin_huge_valf();
+        int j2 = 0;
+        DICP_F16_FETCH(0)
+        DICP_F16_COMMIT(0)
+        __syncthreads();
+        for (int st = 0; st < nst; ++st) {
+            const int cur = st & 1;
+            if (st + 1 < nst) { DICP_F16_FETCH(st + 1) }
+            if (have) {
+#pragma unroll 2
+                for (int t = 0; t < F16_STAGE; ++t) {
+                    half8 a;
+                    { const uint4 v = lds[cur][t * 64 + lane]; __builtin_memcpy(&a, &v, 16); }
+                    const float cm = f16_chunk_min(__builtin_amdgcn_mfma_f32_32x32x16_f16(a, b2, zero, 0, 0, 0), __builtin_huge_valf());
+                    if (cm <= tau) rescore(q, (st * F16_STAGE + t) * 32 + kh * 16, 16, v2, j2);       // (rare: this lane's 16 rows of the tile, exactly)
+                }
+            }
+            if (st + 1 < nst) { DICP_F16_COMMIT(cur ^ 1) }
+            __syncthreads();
+        }
+        {   // the query's two lanes merge; the result goes back to the lanes that own the query
+            const float ov = __shfl_xor(v2, 32);
+            const int oj = __shfl_xor(j2, 32);
+            if (ov < v2 || (ov == v2 && oj < j2)) { v2 = ov; j2 = oj; }
+        }
+        for (int e = 0; e < have; ++e) {
+            const int slot = qslot[wave][e];                         // (wave-uniform)
+            const float rv = __shfl(v2, e);
+            const int rj = __shfl(j2, e);
+#pragma unroll
+            for (int g = 0; g < F16_G; ++g)
+                if ((slot >> 8) == g && col == (slot & 0xff)) { bv[g] = rv; bj[g] = rj; }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- far rows (left out of the image) are scored exactly for every query; results
+#pragma unroll
+    for (int g = 0; g < F16_G; ++g) {
+        const int i = qwave + g * 32 + col;
+        for (int f = 0; f < nfar; ++f) {
+            const int rr = ((const int32_t*)mt)[FM_FAR0 + f];
+            if (rr < m) {
+                const float sc = score<float, float4>(nx[g], tg[rr]);
+                if (sc < bv[g] || (sc == bv[g] && rr < bj[g])) { bv[g] = sc; bj[g] = rr; }
+            }
+        }
+        if (kh == 0 && i < n) idx[(size_t)cloud * n_full + i] = min(bj[g], m - 1);
+    }
+    if (lane == 0 && n_again) atomicAdd((int*)mt + FM_AGAIN, n_again);
+    if (lane == 0 && n_scan) atomicAdd((int*)mt + FM_SCAN, n_scan);
+}
+#undef DICP_F16_FETCH
+#undef DICP_F16_COMMIT
+
+}  // namespace
+
+namespace dicp_tu {
+
+int knn_f16_pack(const void* rows4, const int32_t* tgt_rows, int N, int m_full, int m_pad, void* image, void* stream) {
+    if (!rows4 || !image) return DICP_ERR_NULL;
+    if (N <= 0 || m_full <= 0 || m_pad < m_full || (m_pad % 32)) return DICP_ERR_SHAPE;
+    if (((uintptr_t)rows4 % 16) || ((uintptr_t)image % 16)) return DICP_ERR_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    const int m_img = knn_f16_image_rows(m_pad), tiles = m_img / 32;
+    float* meta = (float*)((char*)image + (size_t)N * m_img * 32);
+    begin_launch();
+    knn_f16_scale_kernel<<<N, BLOCK, 0, st>>>((const float4*)rows4, tgt_rows, m_full, m_pad, meta);
+    knn_f16_image_kernel<<<dim3((tiles + BLOCK / WAVE - 1) / (BLOCK / WAVE), N), BLOCK, 0, st>>>((const float4*)rows4, tgt_rows, m_full, m_pad, m_img, meta, (uint4*)image, tiles, N);
+    return launch_status();
+}
+
+int knn_f16_brute(const void* src, const void* pose, const void* tgt4, void* image, const int32_t* src_rows, const int32_t* tgt_rows,
+                  int N, int n, int m, int m_pad, int32_t* idx, void* stream) {
+    if (!src || !tgt4 || !image || !idx) return DICP_ERR_NULL;
+    if (N <= 0 || n <= 0 || m <= 0 || m_pad < m) return DICP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int m_img = knn_f16_image_rows(m_pad), tiles = m_img / 32;
+    float* meta = (float*)((char*)image + (size_t)N * m_img * 32);        // (its two counters are added to)
+    const int bpc = (n + (BLOCK / WAVE) * 32 * F16_G - 1) / ((BLOCK / WAVE) * 32 * F16_G);
+    begin_launch();
+    knn_f16_kernel<4><<<grid_for(N, bpc), BLOCK, 0, st>>>((const float*)src, (const float*)pose, (const float4*)tgt4, (const uint4*)image, meta, idx,
+                                                         N, n, m, m_pad, tiles, bpc, src_rows, tgt_rows);
+    return launch_status();
+}
+
+}  // namespace dicp_tu

@@ -11,7 +11,8 @@ configs[1] 0.76 -> 0.64 (two graphs, loss outside) / 0.55 ms (one graph), one 65
 shape (GPU-bound) unchanged.  The forward results are those of the eager call bit for bit (the same kernels in the same order).
 
 The usual rules of graphed callables apply: shapes, dtypes, requires_grad flags and every keyword are fixed at capture; the
-outputs are STATIC tensors, overwritten by the next call (clone what must survive); the truncated reverse sweep's one-launch
+outputs are STATIC tensors, overwritten by the next call (clone what must survive); Gumbel-softmax correspondences with in-kernel noise are
+refused (their per-iteration seeds are drawn on the host and would be frozen into the graph); the truncated reverse sweep's one-launch
 tail is placed once, from the warm-up calls' live counters, and stays there in every replay (a cloud that is still at work in it
 is swept there: exact either way)."""
 import contextlib
@@ -38,14 +39,23 @@ def _no_gc():
 OUTPUTS = ("T", "pc", "deltas", "weights", "costs")
 
 
+def _capturable(icp, what):
+    if not icp.const_iter:
+        raise ValueError("%s needs ICP.const_iter = True: tolerance mode reads convergence counters on the host between iterations" % what)
+    # Gumbel-softmax correspondences draw one noise seed per iteration on the HOST (torch's CPU generator) and hand them to the kernels by value:
+    # a capture would freeze them, and every replay would draw the identical noise.  Injected noise tensors (nn._inject_U) are read in place.
+    if icp.nn.differentiable and icp.nn.use_gumbel and getattr(icp.nn, "_inject_U", None) is None:
+        raise ValueError("%s: the Gumbel-softmax correspondence draws its noise seeds on the host at every call; a captured graph would replay ONE "
+                         "draw for ever.  Call ICP.icp eagerly, or inject the noise tensors (nn._inject_U)" % what)
+
+
 def graphed_icp(icp: ICP, source, target, T_init, weight=None, num_warmup_iters=3, **icp_kwargs):
     """Capture ``icp.icp(source, target, T_init, weight=weight, **icp_kwargs)`` for tensors of these shapes / dtypes / requires_grad flags.
 
     Returns ``call(source, target, T_init[, weight]) -> dict`` with the keys T (N,4,4), pc (N,n,3) [differentiable],
     deltas, weights, costs [as ICP.icp returns them] -- static tensors.  ``source`` / ``target`` must be dense batches (N,n,3) /
     (N,m,3|6) on the GPU (lists are ragged: their shapes change from call to call)."""
-    if not icp.const_iter:
-        raise ValueError("graphed_icp needs ICP.const_iter = True: tolerance mode reads convergence counters on the host between iterations")
+    _capturable(icp, "graphed_icp")
     for t, nm in ((source, "source"), (target, "target"), (T_init, "T_init")) + (((weight, "weight"),) if weight is not None else ()):
         if not (torch.is_tensor(t) and t.is_cuda):
             raise ValueError("graphed_icp(%s): a CUDA tensor of the call's shape is needed for the capture" % nm)
@@ -69,8 +79,7 @@ def graphed_icp_step(icp: ICP, loss_of, source, target, T_init, weight=None, num
 
     Returns ``step(source, target, T_init[, weight]) -> (out, grads)``: ``out`` as `graphed_icp`, ``grads`` a dict of the gradients of the
     arguments that required grad at capture ("source", "target", "T_init", "weight") -- all static tensors, overwritten by the next step."""
-    if not icp.const_iter:
-        raise ValueError("graphed_icp_step needs ICP.const_iter = True: tolerance mode reads convergence counters on the host between iterations")
+    _capturable(icp, "graphed_icp_step")
     names = ("source", "target", "T_init") + (("weight",) if weight is not None else ())
     given = (source, target, T_init) + ((weight,) if weight is not None else ())
     for t, nm in zip(given, names):

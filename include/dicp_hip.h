@@ -30,7 +30,9 @@
 extern "C" {
 #endif
 
-#define DICP_ABI_VERSION 5   /* 5: dicp_loop_buffers.bwd_tail_from (the ended iterations of the truncated reverse sweep as one launch).
+#define DICP_ABI_VERSION 6   /* 6: dicp_bwd_tail_max_blocks (the one-launch tail only where a cloud's blocks are all resident; a wait that runs out poisons the
+                                cloud's gradients with NaN and raises bwd_live[K] next to bwd_tail_arrive[N]); bwd_live is (K + 1).
+                                5: dicp_loop_buffers.bwd_tail_from (the ended iterations of the truncated reverse sweep as one launch).
                                 4: dicp_loop_buffers.bwd_skip / bwd_mref / bwd_live / bwd_skip_eps (truncated reverse sweep of dicp_icp_backward); cert_cloud (per-cloud switch of the
                                 match certificates); dicp_cloud_center -> dicp_search_frame: centre AND sort direction as one affine map per cloud, (N,12).
                                 3: per-cloud row counts of ragged batches (src_rows / tgt_rows) on every entry point of the path; the centred and
@@ -86,13 +88,21 @@ int dicp_search_frame(int dtype, const void* tgt, int c, const int32_t* tgt_rows
  * on every call (nn.py:32 -> ATen _euclidean_dist).  c in {3,6}. */
 int dicp_pack_target(int dtype, const void* tgt, int c, const void* frame, const int32_t* tgt_rows, int N, int m, void* tgt4, int m_pad, void* stream);
 
+/* The matrix-core form of the brute-force search (DICP_KNN_MFMA, float32): a split-f16 FILTER on v_mfma_f32_32x32x16_f16 and an exact float32
+ * REFINE with the score every other form computes -- index for index the result of DICP_KNN_VALU (csrc/knn_f16.hip has the error bound).
+ * It reads, next to tgt4, an IMAGE of the packed rows in MFMA operand order: dicp_knn_f16_bytes(N, m_pad) bytes (16-byte aligned), built once
+ * per call by dicp_knn_f16_pack from tgt4 (N,m_pad,4) float32 with the SAME tgt_rows the search is given.  Replaces the K = 5 bmm inside
+ * torch.cdist, nn.py:32. */
+size_t dicp_knn_f16_bytes(int N, int m_pad);
+int dicp_knn_f16_pack(const void* tgt4, const int32_t* tgt_rows, int N, int m, int m_pad, void* image, void* stream);
+
 /* Fused transform + brute-force 1-NN: replaces ICP.py:137 (ps_t = C p + r) followed by
  * nn.find_nn's cdist -> argmin, nn.py:32-35 / 83-86.  Never materialises (N,n,m).
  *   src (N,n,3); pose (N,12) = [C row-major (9), r (3)] or NULL for identity;
- *   idx (N,n) int32, ties -> lowest index.  variant: DICP_KNN_* in the low byte (MFMA is f32 only);
- *   bits 8..15 optionally pin a launch configuration (0 = chosen from the problem size). */
+ *   idx (N,n) int32, ties -> lowest index.  variant: DICP_KNN_* in the low byte (MFMA is f32 only and needs f16_image, NULL otherwise);
+ *   bits 8..15 optionally pin a launch configuration of the VALU form (0 = chosen from the problem size). */
 int dicp_knn(int dtype, const void* src, const void* pose, const void* tgt4, const int32_t* src_rows, const int32_t* tgt_rows,
-             int N, int n, int m, int m_pad, int32_t* idx, int variant, void* stream);
+             int N, int n, int m, int m_pad, int32_t* idx, int variant, const void* f16_image, void* stream);
 
 /* Set-up of the sorted-sweep search structure, ONCE per ICP call (targets do not move between iterations).
  * dicp_sweep_sort: keys_sorted (N,m_pad) T and tperm (N,m_pad) as a STABLE ascending sort of the target x keys (first coordinate of Q y + t) gives them;
@@ -326,7 +336,7 @@ typedef struct dicp_loop_buffers {
        cloud was frozen (alive = 0) are skipped too (every term is exactly zero).  bwd_skip NULL = off: every iteration runs, like autograd. */
     int32_t* bwd_skip;       /* (N) zero-initialised once per backward pass (all chunks of it share it): 0 take part / 1 frozen at this iteration / 2 sweep ended */
     double* bwd_mref;        /* (N) zero-initialised once per backward pass */
-    int32_t* bwd_live;       /* optional (K) zeros: clouds that took part in iteration k */
+    int32_t* bwd_live;       /* optional (K + 1) zeros: clouds that took part in iteration k; [K]: raised with bwd_tail_arrive[N] (so that one copy brings the host both) */
     double bwd_skip_eps;
     int32_t bwd_tail_from;   /* windowed form with bwd_skip: the iterations k < bwd_tail_from run as ONE launch (0: every iteration is its own pair of
                                 launches).  Before the last few iterations almost every cloud's sweep has ended, and a pair of dependent launches per
@@ -338,12 +348,21 @@ typedef struct dicp_loop_buffers {
                                 iteration of a backward pass (bwd_overwrite) always takes the per-iteration launches.  The caller picks the iteration
                                 from where the previous call's sweeps ended. */
     void* bwd_tail_partials; /* (N, dicp_window_blocks, DICP_NBWD_PAD): the second buffer of pose sums of that launch */
-    int32_t* bwd_tail_arrive;/* (N + 1) zeros per backward pass: its per-cloud counters; [N] is raised if a wait ran out (never observed; results are then wrong) */
+    int32_t* bwd_tail_arrive;/* (N + 1) zeros per backward pass: its per-cloud counters; [N] is raised if a wait ran out.  That cannot happen while a cloud's
+                                blocks are all resident, which dicp_bwd_tail_max_blocks guarantees for a launch that has the GPU to itself (or shares it with one
+                                more of its kind); a GPU kept full by other work for longer than the wait's bound (~0.5 s) can still make one run out.  The
+                                block then stops waiting for good and folds NaN from there on: the cloud's pose cotangent and (part of) its point gradients
+                                come out NaN, never as plausible wrong numbers, and the caller must treat the error word as a failed call.
+                                Hand-off between the blocks (hardware assumption, gfx950): the pose sums are written and read with agent-scope atomic
+                                accesses (sc1: served by the memory side, coherent across the XCDs' L2s) and counted with an agent-scope atomic add after
+                                the storing wave's s_waitcnt vmcnt(0) -- MI355X_MICROARCH's measured hand-off form, not the C++ memory model's release /
+                                acquire pair (an agent-scope fence writes back / invalidates the XCD's whole L2: 70 us per iteration against 26) */
     const dicp_gumbel_loop* gumbel; /* knn_variant DICP_KNN_GUMBEL: the soft correspondences' buffers (idx / spos / tgt4 are then unused; gtgt of dicp_icp_backward
                                 is (N,m,c) zeros and is added to; no truncated sweep: the matches themselves carry gradient) */
     int32_t first_search_done;  /* sweep path: 1 = the matches of iteration 0 are already in spos (the caller enqueued dicp_knn_sweep under pose_search[0] and
                                    the first query order itself, right behind the index build, so that the search runs while the host is still
                                    preparing the loop): dicp_icp_forward then starts iteration 0 at its accumulate */
+    const void* tgt_f16;     /* knn_variant DICP_KNN_MFMA: the split-f16 image of tgt4 (dicp_knn_f16_pack, with the same tgt_rows) */
 } dicp_loop_buffers;
 
 /* Head and tail of the backward loop.  dicp_pose_grad_in: gpose (N,12) double = [dL/dC row-major (9), dL/dr (3)] taken from the
@@ -432,6 +451,10 @@ int dicp_accumulate_bwd(int dtype, const dicp_weight_params* prm, const void* sr
  * zero fill (it writes every slot and every window row instead of adding to them); gts_far is always added to. */
 int dicp_window_blocks(int dtype, int n, int m_pad);
 int dicp_window_rows(int dtype);
+/* the most dicp_window_blocks(...) per cloud with which dicp_loop_buffers.bwd_tail_from may be used on the current device (0: never): its launch lets a
+ * cloud's blocks wait for each other, so they must all be resident -- half of what one XCD holds of that kernel.  dicp_icp_backward returns
+ * DICP_ERR_SHAPE for a tail beyond it. */
+int dicp_bwd_tail_max_blocks(int dtype);
 int dicp_accumulate_bwd_window(int dtype, const dicp_weight_params* prm, const void* src_s, const void* tgt_s, int c,
                                const int32_t* spos, const int32_t* spos_ref, const int32_t* qorder, const void* pose, const void* w_s,
                                const void* alive, const void* gs, const void* gb, const int32_t* src_rows, int N, int n, int m_pad, void* gsrc_s, void* slab,
@@ -507,6 +530,7 @@ typedef struct dicp_kabsch_buffers {
     int32_t* rows_live;      /* (N) in/out: source rows of each cloud that take part (n, or the cloud's own length); 0 once frozen */
     const int32_t* tgt_rows; /* optional (N) */
     int32_t* counters;       /* (K) zero-initialised */
+    const void* tgt_f16;     /* knn_variant DICP_KNN_MFMA: the split-f16 image of tgt4 (dicp_knn_f16_pack) */
 } dicp_kabsch_buffers;
 int dicp_kabsch_forward(int dtype, const dicp_kabsch_buffers* buf, int N, int n, int m, int trim_on, double trim_dist, int const_iter, double tolerance,
                         int k0, int k1, void* stream);

@@ -126,7 +126,7 @@ def test_new_entry_points_reject_bad_arguments(lib):
 
 
 def test_sizes_and_argument_checks(lib):
-    assert lib.dicp_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.dicp_abi_version() == _lib.ABI_VERSION == 6
     assert [lib.dicp_padded_targets(m) for m in (0, 1, 64, 65, 129)] == [0, 64, 64, 128, 192]
     assert [lib.dicp_accumulate_blocks(n) for n in (0, 1, 1024, 1025, 16384)] == [0, 1, 1, 2, 16]
     # rejected before any launch (no GPU touched): null pointers, bad dtype / shapes / enums
@@ -136,10 +136,16 @@ def test_sizes_and_argument_checks(lib):
     assert lib.dicp_pack_target(7, one, 3, None, None, 1, 1, one, 64, None) == 3
     assert lib.dicp_pack_target(0, one, 4, None, None, 1, 1, one, 64, None) == 2
     assert lib.dicp_pack_target(0, one, 3, None, None, 1, 1, one, 63, None) == 2
-    # dicp_knn(dtype, src, pose, tgt4, src_rows, tgt_rows, N, n, m, m_pad, idx, variant, stream)
-    assert lib.dicp_knn(0, one, None, one, None, None, 1, 1, 1, 64, one, 9, None) == 4
-    assert lib.dicp_knn(1, one, None, ctypes.c_void_p(32), None, None, 1, 1, 1, 64, one, _lib.KNN_MFMA, None) == 3
-    assert lib.dicp_knn(0, one, None, ctypes.c_void_p(8), None, None, 1, 1, 1, 64, one, 0, None) == 5
+    # dicp_knn(dtype, src, pose, tgt4, src_rows, tgt_rows, N, n, m, m_pad, idx, variant, f16_image, stream)
+    assert lib.dicp_knn(0, one, None, one, None, None, 1, 1, 1, 64, one, 9, None, None) == 4
+    assert lib.dicp_knn(1, one, None, ctypes.c_void_p(32), None, None, 1, 1, 1, 64, one, _lib.KNN_MFMA, one, None) == 3
+    assert lib.dicp_knn(0, one, None, ctypes.c_void_p(8), None, None, 1, 1, 1, 64, one, 0, None, None) == 5
+    assert lib.dicp_knn(0, one, None, one, None, None, 1, 1, 1, 64, one, _lib.KNN_MFMA, None, None) == 1       # the matrix-core form needs its image
+    # dicp_knn_f16_bytes(N, m_pad) / dicp_knn_f16_pack(tgt4, tgt_rows, N, m, m_pad, image, stream): 32 bytes per row, rows rounded up to 512, + 320 bytes per cloud
+    assert lib.dicp_knn_f16_bytes(2, 64) == 2 * (512 * 32 + 320) and lib.dicp_knn_f16_bytes(1, 16384) == 16384 * 32 + 320 and lib.dicp_knn_f16_bytes(0, 64) == 0
+    assert lib.dicp_knn_f16_pack(None, None, 1, 1, 64, one, None) == 1
+    assert lib.dicp_knn_f16_pack(one, None, 1, 65, 64, one, None) == 2
+    assert lib.dicp_knn_f16_pack(ctypes.c_void_p(8), None, 1, 1, 64, one, None) == 5
     P = _lib.WeightParams(mode=1, loss=0)
     # dicp_accumulate(dtype, prm, src, tgt, c, idx, pose, w_init, alive, src_rows, N, n, m, partials, w_out, w_stride, stream)
     assert lib.dicp_accumulate(0, ctypes.byref(P), one, one, 3, one, one, one, None, None, 1, 1, 1, one, None, 0, None) == 2   # pt2pl needs normals (ICP.py:103)

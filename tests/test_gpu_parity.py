@@ -241,6 +241,26 @@ def test_diff_vs_nondiff_and_padding(golden, scan_map):
     check_result(padded, gp, "padded_")
 
 
+def test_per_cloud_weight_with_zero_rows_as_pads(scan_map):
+    """ICP.py:445-446: with source_zeroes_are_pad an (N,1) weight is multiplied into the (N,n) mask of non-zero rows and is a per-POINT weight from
+    there on (ICP.py:248,269 then count points, not clouds) -- the call must report what the same call with that (N,n) weight reports."""
+    scan, mp = scan_map
+    pts = np.vstack((scan[:40, :3], np.zeros((9, 3))))
+    S = torch.stack([t(pts), t(pts)])
+    Tg = torch.stack([t(mp[:50]), t(mp[:50])])
+    T0 = torch.stack([torch.eye(4, dtype=torch.float64, device=DEV)] * 2)
+    w1 = torch.tensor([[1.0], [0.7]], dtype=torch.float64, device=DEV)
+    outs = []
+    for w in (w1, w1.expand(2, 49) * (S.norm(dim=2) != 0)):
+        icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=12, tolerance=1e-12)
+        icp.source_zeroes_are_pad = True
+        outs.append(icp.icp(S, Tg, T0, weight=w.contiguous(), trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0}, dim=2))
+    for key in ("converged", "iterations", "matched_ratio"):
+        assert torch.equal(outs[0]["stats"][key], outs[1]["stats"][key]), key
+    assert torch.equal(outs[0]["T"], outs[1]["T"])
+    assert bool((outs[0]["stats"]["matched_ratio"] <= 1.0).all())
+
+
 # ------------------------------------------------ 3-D matrix with all four gradients
 def matrix_keys(g):
     return sorted(k[:-len("__T")] for k in g if k.endswith("__T"))

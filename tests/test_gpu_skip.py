@@ -195,7 +195,7 @@ def test_tail_launch_changes_no_gradient(dtype, N, n, K, icp_type, weights):
         return icp
     ref_icp = make(False)
     ref = _tail_call(ref_icp, src, tgt, w)
-    assert "_bwd_hint" not in ref_icp.knn_stats and not ref_icp.knn_stats.get("_bwd_hints")
+    assert ref_icp._hints.newest_tail is None and not ref_icp._hints.tail
     icp = make(True)
     first = _tail_call(icp, src, tgt, w)                    # no earlier call: every iteration is its own pair of launches
     assert icp.knn_stats["bwd_tail_from"] == 0
@@ -212,7 +212,7 @@ def test_tail_launch_changes_no_gradient(dtype, N, n, K, icp_type, weights):
         scale = float(a.abs().max())
         assert float((a - b).abs().max()) <= tiny * scale, (i, float((a - b).abs().max()) / scale)
     # (ii) a hint that is wrong: "only the last iteration was at work"
-    host, done, key = icp.knn_stats["_bwd_hint"]
+    host, done = icp._hints.newest_tail[:2]
     done.synchronize()
     host.zero_()
     host[K - 1] = N
@@ -241,7 +241,7 @@ def test_tail_launch_on_ragged_lists_and_in_tolerance_mode():
             icp.const_iter, icp.bwd_tail = mode == "ragged", tail
             for rep in range(3):        # (the later calls have the earlier ones' hints; the third one's is made to place the tail high)
                 if tail and rep == 2:
-                    entry = icp.knn_stats["_bwd_hint"]
+                    entry = icp._hints.newest_tail
                     entry[1].synchronize()
                     K_run = entry[2][2]
                     entry[0].zero_()
@@ -260,3 +260,113 @@ def test_tail_launch_on_ragged_lists_and_in_tolerance_mode():
             grads[tail] = [torch.cat([x.grad.reshape(-1) for x in S]), torch.cat([x.grad.reshape(-1) for x in Tg])]
         for a, b in zip(grads[False], grads[True]):
             assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()), mode
+
+
+def test_tail_launch_only_where_a_clouds_blocks_are_all_resident():
+    """The one-launch tail lets a cloud's blocks wait for each other, which is only safe while they are all resident (dispatch is in index order and
+    a cloud's blocks share an XCD): beyond dicp_bwd_tail_max_blocks blocks per cloud -- half of what an XCD holds of that kernel -- the host does not
+    place it, whatever the hint says (float64 clouds of 32768 points have 43 blocks, an XCD holds 32), and the library refuses it."""
+    import ctypes
+    lib = _lib.load()
+    cap32, cap64 = lib.dicp_bwd_tail_max_blocks(_lib.F32), lib.dicp_bwd_tail_max_blocks(_lib.F64)
+    assert 16 <= cap32 <= 128 and 8 <= cap64 <= cap32, (cap32, cap64)
+    N, n, K = 9, 32768, 8
+    assert lib.dicp_window_blocks(_lib.F64, n, n) > cap64
+    src, tgt = make_pairs(N, n, n, seed=91, dtype=torch.float64)
+    icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
+    icp.const_iter = True
+    first = _tail_call(icp, src, tgt)
+    host, done = icp._hints.newest_tail[:2]
+    done.synchronize()
+    host.zero_()
+    host[K - 1] = N                                         # "only the last iteration was at work": asks for the tail at its highest
+    second = _tail_call(icp, src, tgt)
+    assert icp.knn_stats["bwd_tail_from"] == 0              # ... and does not get it
+    for a, b in zip(first, second):
+        assert float((a - b).abs().max()) <= 1e-12 * float(a.abs().max())
+    icp.check_errors()
+    # the same shape in float32 (32 blocks <= the cap) does take it, stragglers and all
+    if lib.dicp_window_blocks(_lib.F32, n, n) <= cap32:
+        icp32 = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
+        icp32.const_iter = True
+        a32 = _tail_call(icp32, src.float(), tgt.float())
+        host, done = icp32._hints.newest_tail[:2]
+        done.synchronize()
+        host.zero_()
+        host[K - 1] = N
+        b32 = _tail_call(icp32, src.float(), tgt.float())
+        assert icp32.knn_stats["bwd_tail_from"] == K - 2 and int(icp32.knn_stats["bwd_tail_error"].item()) == 0
+        for a, b in zip(a32, b32):
+            assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
+        icp32.check_errors()
+
+
+def test_a_wait_that_ran_out_is_raised_not_returned():
+    """The error word of the tail launch travels with the live counters; a record that reports one makes the NEXT backward pass (and
+    ICP.check_errors) raise _ops.TailTimeout.  (The wait itself cannot be made to run out on a healthy GPU: the word is raised by hand.)"""
+    from dicp_amd._ops import TailTimeout
+    N, n, K = 12, 8192, 8
+    src, tgt = make_pairs(N, n, n, seed=93)
+    icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
+    icp.const_iter = True
+    _tail_call(icp, src, tgt)
+    _tail_call(icp, src, tgt)
+    icp.check_errors()                                      # nothing to report
+    rec = icp._hints.newest_tail
+    rec[1].synchronize()
+    rec[0][rec[3]] = 1                                      # what bwd_tail_kernel raises next to bwd_tail_arrive[N]
+    rec[4] = False
+    with pytest.raises(TailTimeout):
+        _tail_call(icp, src, tgt)
+    rec[4] = False
+    with pytest.raises(TailTimeout):
+        icp.check_errors()
+    rec[0][rec[3]] = 0
+    rec[4] = False
+    _tail_call(icp, src, tgt)
+
+
+def test_two_backward_passes_on_two_streams_beside_a_busy_gpu():
+    """Two ICP objects run forward + backward (tails placed, with stragglers: hints wrong on purpose) concurrently on two streams while a third
+    stream keeps the GPU full of other work: same gradients as alone, no wait ran out."""
+    N, n, K = 24, 16384, 10
+    pairs = [make_pairs(N, n, n, seed=97 + i) for i in range(2)]
+    icps, alone = [], []
+    for src, tgt in pairs:
+        icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
+        icp.const_iter = True
+        _tail_call(icp, src, tgt)
+        alone.append(_tail_call(icp, src, tgt))
+        icps.append(icp)
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    busy_in = torch.randn((4096, 4096), device=DEV)
+    results = [None, None]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        with torch.cuda.stream(streams[2]):                 # the third kernel(s): a chain of GEMMs that fills every CU for the duration
+            acc = busy_in
+            for _ in range(12):
+                acc = torch.tanh(acc @ busy_in * 1e-3)
+        for i, (src, tgt) in enumerate(pairs):
+            with torch.cuda.stream(streams[i]):
+                # per stream the hints start afresh (they are kept per device, stream and shape): two calls, the second with a wrong hint
+                for call in range(2):
+                    S, Tg = src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True)
+                    Ti = torch.eye(4).repeat(N, 1, 1).to(DEV).requires_grad_(True)
+                    out = icps[i].icp(S, Tg, Ti, **KW)
+                    out["T"].sum().backward()
+                    if call == 0:
+                        streams[i].synchronize()
+                        rec = icps[i]._hints.newest_tail
+                        rec[1].synchronize()
+                        rec[0].zero_()
+                        rec[0][K - 1] = N
+                results[i] = [S.grad, Tg.grad, Ti.grad]
+        torch.cuda.synchronize()
+        for i in range(2):
+            assert icps[i].knn_stats["bwd_tail_from"] == K - 2 and int(icps[i].knn_stats["bwd_tail_error"].item()) == 0
+            icps[i].check_errors()
+            for a, b in zip(alone[i], results[i]):
+                assert bool(torch.isfinite(b).all())
+                assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
+    del acc

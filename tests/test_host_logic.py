@@ -140,3 +140,22 @@ def test_no_cpu_fallback(scan_map):
         loss("huber").get_weight(torch.rand(4, 3))
     with pytest.raises(ValueError):
         loss("tukey").get_weight(torch.rand(4, 3))
+
+
+def test_graph_capture_refuses_host_drawn_gumbel_noise():
+    """the Gumbel-softmax correspondence draws its per-iteration noise seeds on the host (ICPLoop.forward) and hands them to the kernels by
+    value; a captured graph would replay one draw for ever.  graphed_icp / graphed_icp_step refuse it before anything touches a device."""
+    import pytest
+    from dicp_amd.ICP import ICP
+    from dicp_amd.graphed import graphed_icp, graphed_icp_step
+    icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=3, tolerance=1e-12)
+    icp.const_iter = True
+    icp.nn.use_gumbel = True
+    x = torch.zeros((1, 8, 3))
+    with pytest.raises(ValueError, match="Gumbel"):
+        graphed_icp(icp, x, torch.zeros((1, 8, 6)), torch.eye(4).unsqueeze(0))
+    with pytest.raises(ValueError, match="Gumbel"):
+        graphed_icp_step(icp, lambda out: out["T"].sum(), x, torch.zeros((1, 8, 6)), torch.eye(4).unsqueeze(0))
+    icp.const_iter = False
+    with pytest.raises(ValueError, match="const_iter"):
+        graphed_icp(icp, x, torch.zeros((1, 8, 6)), torch.eye(4).unsqueeze(0))

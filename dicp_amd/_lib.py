@@ -87,7 +87,7 @@ _SIGNATURES = {
     "dicp_knn_f16_bytes": ([i32, i32], ctypes.c_size_t),
     "dicp_knn_f16_pack": ([vp, vp, i32, i32, i32, vp, vp], ctypes.c_int),
     "dicp_knn": ([i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp, vp], ctypes.c_int),
-    "dicp_knn_sweep": ([i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp], ctypes.c_int),
+    "dicp_knn_sweep": ([i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp], ctypes.c_int),
     "dicp_window_blocks": ([i32, i32, i32], ctypes.c_int),
     "dicp_window_rows": ([i32], ctypes.c_int),
     "dicp_bwd_tail_max_blocks": ([i32], ctypes.c_int),

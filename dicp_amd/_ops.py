@@ -14,6 +14,10 @@ from . import _lib
 _DT = {torch.float32: _lib.F32, torch.float64: _lib.F64}
 SWEEP_MIN_TARGETS = 2048     # KNN_AUTO inside ICP: below this many targets per cloud the brute-force kernel is used
 SWEEP_MIN_QUERIES = 256
+F16_SWEEP = True             # float32 sweep path: the plain searches of big clouds score on the matrix cores (split-f16 filter + exact refine; same indices)
+F16_SWEEP_MIN_QUERIES = 2 * 256 * 1024      # ... from the size at which the sweep works in units of 128 queries (sweep_auto_cfg)
+F16_SWEEP_MIN_TARGETS = 32768               # ... and from 32768 targets per cloud on: measured (profiles/r04_knn_f16_sweep.txt) 1.27x at 32768, 1.4-1.5x at 65536,
+                                            # 0.92x at 16384 -- a wave's slab there is 16 tiles, 128 MFMAs, and the per-wave refine costs as much as the scoring
 SWEEP_MIN_PAIRS = 1e8        # ... and below this many (query,target) pairs per iteration.  Measured (profiles/r02_mid_size_paths.txt): with the
                              # native key sort the sweep's per-call set-up is ~0.1 ms, and it already wins at 32 x 2048^2 and 8 x 4096^2
                              # (0.090 vs 0.103 and 0.075 vs 0.121 ms per iteration, fwd+bwd); at 32 x 4096^2 (BASELINE configs[1]) 0.084 vs 0.175
@@ -150,10 +154,11 @@ def f16_image(tgt4, m, tgt_rows=None):
     return img
 
 
-def f16_counters(image, N):
+def f16_counters(image, N, m_pad):
     """(queries sent through the second filter pass, queries scored against every row): what the matrix-core searches since the image was packed
     could not settle from one pass (near-ties inside the filter's resolution; queries outside the f16 range).  Synchronises."""
-    meta = image[image.numel() - N * 320:].view(torch.int32).view(N, 80)
+    m_img = (int(m_pad) + 511) // 512 * 512
+    meta = image[N * m_img * 32:N * m_img * 32 + N * 320].view(torch.int32).view(N, 80)
     return int(meta[:, 6].sum().item()), int(meta[:, 7].sum().item())
 
 
@@ -207,6 +212,11 @@ class SweepIndex:
         scratch = torch.empty((nbytes,), dtype=torch.uint8, device=dev) if nbytes else None
         self.first = None
         self.pair_shards = torch.zeros((_lib.PAIR_SHARDS,), dtype=torch.int64, device=dev)
+        # float32: the image of the sorted rows for the matrix-core scoring of the plain searches (dicp_knn_sweep's f16_image; big problems only:
+        # the form works in units of 128 queries)
+        self.img16 = None
+        want_img = (bool(F16_SWEEP) and dt == torch.float32 and first_order is not None and float(N) * first_order[0].shape[1] >= F16_SWEEP_MIN_QUERIES
+                    and m >= F16_SWEEP_MIN_TARGETS)
         if first_order is not None:
             source, T_init, src_rows = first_order
             self.frame = torch.empty((N, 12), dtype=dt, device=dev)
@@ -216,12 +226,14 @@ class SweepIndex:
                 _lib.check(lib.dicp_sweep_setup(_DT[dt], _p(tgt), c, _p(tgt_rows), N, m, m_pad, CENTER_QUANTUM, int(FRAME_DIRECTIONS), _p(self.frame), _p(self.keys), _p(self.tperm),
                                                 self.NBKT, _p(self.bucket), _p(self.brange), _p(scratch), nbytes, _p(self.tgs4), _p(self.tgt_s), self.row_stride,
                                                 _p(source), _p(src_rows), source.shape[1], _p(T_init), _p(pose_s), _p(qorder), _stream()), "dicp_sweep_setup")
+            if want_img:
+                self.img16 = f16_image(self.tgs4, m, tgt_rows)
             spos0 = None
             if first_search:
                 spos0 = torch.empty((N, source.shape[1]), dtype=torch.int32, device=dev)
                 with _on(dev):
                     _lib.check(lib.dicp_knn_sweep(_DT[dt], _p(source), _p(pose_s), _p(self.tgs4), _p(self.tperm), _p(qorder), _p(self.bucket), _p(self.brange), self.NBKT,
-                                                  _p(src_rows), _p(tgt_rows), N, source.shape[1], m, m_pad, None, _p(spos0), _p(self.pair_shards), 0, _stream()), "dicp_knn_sweep")
+                                                  _p(src_rows), _p(tgt_rows), N, source.shape[1], m, m_pad, None, _p(spos0), _p(self.pair_shards), 0, _p(self.img16), _stream()), "dicp_knn_sweep")
             self.first = (source, T_init, qorder, spos0)
             return
         with _on(dev):
@@ -261,9 +273,16 @@ class SweepIndex:
             return qorder, _gather_rows_raw(src, qorder), (_gather_rows_raw(w.unsqueeze(-1), qorder).squeeze(-1) if w is not None else None)
         return qorder
 
-    def knn(self, src, pose, qorder=None, out=None, cfg=0, spos=None, src_s=None, src_rows=None):
+    def make_image(self):
+        """The split-f16 image of the sorted rows (float32): searches given it score on the matrix cores."""
+        if self.img16 is None:
+            self.img16 = f16_image(self.tgs4, self.m, self.tgt_rows)
+        return self.img16
+
+    def knn(self, src, pose, qorder=None, out=None, cfg=0, spos=None, src_s=None, src_rows=None, mfma=False):
         """src_s: the rows of src in qorder's slot order (query_order(copies=True)) -> coalesced query loads.
-        src_rows (N) int32: rows of each source cloud that take part (qorder, if any, made with the same counts)."""
+        src_rows (N) int32: rows of each source cloud that take part (qorder, if any, made with the same counts).
+        mfma: score on the matrix cores (float32, the (2,8) configuration's units: cfg 0 on big problems, or 2)."""
         N, n, _ = src.shape
         idx = out if out is not None else torch.empty((N, n), dtype=torch.int32, device=src.device)
         if src_s is not None:
@@ -271,7 +290,7 @@ class SweepIndex:
         with _on(src.device):
             _lib.check(_lib.load().dicp_knn_sweep(_DT[src.dtype], _p(src), _p(pose), _p(self.tgs4), _p(self.tperm), _p(qorder),
                                                   _p(self.bucket), _p(self.brange), self.NBKT, _p(src_rows), _p(self.tgt_rows), N, n, self.m, self.tgs4.shape[1],
-                                                  _p(idx), _p(spos), _p(self.pair_shards), cfg, _stream()), "dicp_knn_sweep")
+                                                  _p(idx), _p(spos), _p(self.pair_shards), cfg, _p(self.make_image()) if mfma else None, _stream()), "dicp_knn_sweep")
         return idx
 
 
@@ -669,7 +688,8 @@ class ICPLoop(torch.autograd.Function):
             center = sweep.frame if sweep is not None else (None if soft else search_frame(tgt, tgt_rows=cfg.tgt_rows))
             tgt4 = sweep.tgs4 if sweep is not None else (None if soft else pack_target(tgt, center, cfg.tgt_rows))
             m_pad = tgt4.shape[1] if tgt4 is not None else 0
-            img16 = f16_image(tgt4, m, cfg.tgt_rows) if kind == _lib.KNN_MFMA else None      # the matrix-core search's image of the packed rows
+            # the matrix-core searches' image of the packed rows (the sweep path: of the sorted rows, made with the index)
+            img16 = f16_image(tgt4, m, cfg.tgt_rows) if kind == _lib.KNN_MFMA else (sweep.img16 if sweep is not None else None)
             nblk = lib.dicp_accumulate_blocks(n)
             poses = torch.empty((Kmax + 1, N, 12), dtype=dt, device=dev)
             poses_c = torch.empty((Kmax + 1, N, 12), dtype=dt, device=dev) if center is not None else None   # [Q C | Q r + t]: what the searches read

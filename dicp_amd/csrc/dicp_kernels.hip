@@ -3917,13 +3917,17 @@ struct CertArgs {             // certifying search: budgets (NULL q: plain searc
 static int sweep_launch(int dtype, const void* src, const void* pose, const void* tgs4, const int32_t* tperm,
                         const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt,
                         int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg, Rows rw, hipStream_t st,
-                        CertArgs ca = CertArgs{}) {
+                        CertArgs ca = CertArgs{}, const void* f16_image = nullptr) {
     hipEvent_t ev0, ev1;
     take_launch_events(ev0, ev1);                                       // (null unless a timed loop set them for this launch)
     const int src_sorted = (cfg & DICP_SWEEP_SRC_SORTED) ? 1 : 0;      // src holds the rows in qorder's slot order
     cfg &= ~DICP_SWEEP_SRC_SORTED;
     if (src_sorted && !qorder) return DICP_ERR_NULL;
     if (cfg == 0) cfg = sweep_auto_cfg(N, n);
+    // plain float32 searches in units of 128 queries, given the image of the sorted rows: the scoring runs on the matrix cores (knn_f16.hip)
+    if (f16_image && dtype == DICP_F32 && !ca.q && cfg == SWEEP_CFG_BIG)
+        return dicp_tu::knn_f16_sweep(src, pose, tgs4, const_cast<void*>(f16_image), tperm, qorder, bucket, brange, nbkt, rw.src, rw.tgt, N, n, m, m_pad, idx, spos,
+                                      pairs, src_sorted, ev0, ev1, st);
     const int Q = sweep_queries_per_lane(cfg);
     if (Q <= 0) return DICP_ERR_ENUM;
     const int units = (n + WAVE * Q - 1) / (WAVE * Q);                  // waves per cloud
@@ -3960,13 +3964,14 @@ static int sweep_launch(int dtype, const void* src, const void* pose, const void
 
 int dicp_knn_sweep(int dtype, const void* src, const void* pose, const void* tgs4, const int32_t* tperm,
                    const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt, const int32_t* src_rows, const int32_t* tgt_rows,
-                   int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg, void* stream) {
+                   int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg, const void* f16_image, void* stream) {
     if (!src || !tgs4 || !tperm || !bucket || !brange || (!idx && !spos)) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || n <= 0 || m <= 0 || nbkt <= 0 || m_pad != dicp_padded_targets(m)) return DICP_ERR_SHAPE;
     if ((uintptr_t)tgs4 % (dtype == DICP_F32 ? 16 : 32)) return DICP_ERR_ALIGN;
     begin_launch();
-    return sweep_launch(dtype, src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, N, n, m, m_pad, idx, spos, pairs, cfg, Rows{src_rows, tgt_rows}, (hipStream_t)stream);
+    return sweep_launch(dtype, src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, N, n, m, m_pad, idx, spos, pairs, cfg, Rows{src_rows, tgt_rows}, (hipStream_t)stream,
+                        CertArgs{}, f16_image);
 }
 
 int dicp_gather_rows(int dtype, const void* tgt, const int32_t* idx, int N, int n, int m, int c, void* out, void* stream) {
@@ -4196,7 +4201,7 @@ int dicp_kabsch_forward(int dtype, const dicp_kabsch_buffers* B, int N, int n, i
         int rc;
         if (kind == DICP_KNN_SWEEP)
             rc = dicp_knn_sweep(dtype, B->src, pose_s, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, B->rows_live, B->tgt_rows, N, n, m, B->m_pad,
-                                B->idx, nullptr, B->pairs, (B->knn_variant >> 8) & 0xff, stream);
+                                B->idx, nullptr, B->pairs, (B->knn_variant >> 8) & 0xff, B->tgt_f16, stream);
         else
             rc = dicp_knn(dtype, B->src, pose_s, B->tgt4, B->rows_live, B->tgt_rows, N, n, m, B->m_pad, B->idx, B->knn_variant & 0xffff, B->tgt_f16, stream);
         if (rc) return rc;
@@ -4446,7 +4451,7 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
                                   B->pairs, cfg, Rows{B->src_rows, B->tgt_rows}, st, CertArgs{B->cert_q, B->cert_qu, B->dcum, 2 * (B->K + 1), k, count_k, !fresh, B->cert_cloud, B->cert_set});
             } else
             rc = dicp_knn_sweep(dtype, qsrc, pose_s, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, B->src_rows, B->tgt_rows, N, n, m, B->m_pad,
-                                B->idx ? idx_k : nullptr, spos_k, B->pairs, cfg, stream);
+                                B->idx ? idx_k : nullptr, spos_k, B->pairs, cfg, B->tgt_f16, stream);
             set_launch_events(nullptr, nullptr);
             if (rc) return rc;
             if (B->events) set_launch_events((hipEvent_t)B->events[6 * k + 2], (hipEvent_t)B->events[6 * k + 3]);

@@ -41,6 +41,7 @@ constexpr int F16_STAGE = dicp_tu::KNN_F16_STAGE_ROWS / 32;   // A tiles (32 row
 constexpr int F16_G = 4;                // B tiles (32 queries each) per wave: 128 queries, like a unit of the sweep
 constexpr int F16_CHT = 4;              // A tiles per chunk of the lane-local bookkeeping
 constexpr int F16_FAR_MAX = 64;
+constexpr int F16_NTC = 8;              // sweep form: 64-row tiles whose float32 rows a wave keeps in LDS for its refine
 enum { FM_S = 0, FM_INV_S2 = 1, FM_PHI = 2, FM_NFAR = 3, FM_HPHI = 4, FM_FAR_ABOVE = 5, FM_AGAIN = 6 /* queries sent through pass 2, added up */,
        FM_SCAN = 7 /* queries scored against every row */, FM_FAR0 = 8 };
 constexpr float F16_P = 8192.f;
@@ -126,7 +127,8 @@ __global__ __launch_bounds__(BLOCK) void knn_f16_scale_kernel(const float4* __re
 
 // the image: one thread per (row, k half) -> 16 bytes, written in MFMA operand order (a wave's load of a tile is one contiguous KiB)
 __global__ __launch_bounds__(BLOCK) void knn_f16_image_kernel(const float4* __restrict__ rows4, const int32_t* __restrict__ tgt_rows, int m_full, int m_pad, int m_img,
-                                                              const float* __restrict__ meta_all, uint4* __restrict__ image, int tiles_per_cloud, int N) {
+                                                              const float* __restrict__ meta_all, uint4* __restrict__ image, int tiles_per_cloud, int N,
+                                                              float* __restrict__ edges /* (N, tiles_per_cloud / 2, 2) */) {
     const int cloud = blockIdx.y;
     const int tile = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6), lane = threadIdx.x & (WAVE - 1);
     if (tile >= tiles_per_cloud) return;
@@ -134,6 +136,9 @@ __global__ __launch_bounds__(BLOCK) void knn_f16_image_kernel(const float4* __re
     const float* mt = meta_all + (size_t)cloud * F16_META;
     const float s = mt[FM_S], far_above = mt[FM_FAR_ABOVE];
     const int r = tile * 32 + f16_row_of(lane & 31), kh = lane >> 5;
+    // x of the first / last row of the 64-row tile (as the packed rows hold it: pad rows of a sorted batch carry the largest key)
+    if (kh == 0 && r < m_pad && (r & 63) == 0) edges[((size_t)cloud * (tiles_per_cloud / 2) + (r >> 6)) * 2] = rows4[(size_t)cloud * m_pad + r].x;
+    if (kh == 0 && r < m_pad && (r & 63) == 63) edges[((size_t)cloud * (tiles_per_cloud / 2) + (r >> 6)) * 2 + 1] = rows4[(size_t)cloud * m_pad + r].x;
     _Float16 yh[3] = {0, 0, 0}, yl[3] = {0, 0, 0}, H[3] = {(_Float16)__builtin_huge_valf(), 0, 0};
     if (r < m) {
         const float4 v = rows4[(size_t)cloud * m_pad + r];
@@ -157,17 +162,29 @@ __global__ __launch_bounds__(BLOCK) void knn_f16_image_kernel(const float4* __re
     image[((size_t)cloud * tiles_per_cloud + tile) * 64 + lane] = out;
 }
 
-// the query's B fragment: lane half 0 holds k = 0..7, half 1 k = 8..15
-__device__ __forceinline__ half8 f16_query_fragment(const float* nx, float s, int kh) {
+// the query's B fragment: lane half 0 holds k = 0..7, half 1 k = 8..15.  ok = false: the scaled query does not fit the f16 range (further than
+// ~30x the cloud's extent from its centre, or not finite): its fragment is all zeros (finite filter values that mean nothing) and the caller
+// must take the exact scan for it
+__device__ __forceinline__ half8 f16_query_fragment(const float* nx, float s, int kh, bool& ok) {
     _Float16 xh[3], xl[3];
+    ok = true;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { const float c = nx[k] * s; xh[k] = (_Float16)c; xl[k] = (_Float16)(c - (float)xh[k]); }
+    for (int k = 0; k < 3; ++k) {
+        float c = nx[k] * s;
+        if (!(fabsf(c) <= 60000.f)) { ok = false; c = 0.f; }
+        xh[k] = (_Float16)c; xl[k] = (_Float16)(c - (float)xh[k]);
+    }
+    if (!ok) { xh[0] = xh[1] = xh[2] = xl[0] = xl[1] = xl[2] = (_Float16)0.f; }
     half8 b;
     const _Float16 P = (_Float16)F16_P;
     if (kh == 0) { b[0] = xh[0]; b[1] = xh[1]; b[2] = xh[2]; b[3] = xh[0]; b[4] = xh[1]; b[5] = xh[2]; b[6] = xl[0]; b[7] = xl[1]; }
     else         { b[0] = xl[2]; b[1] = xl[0]; b[2] = xl[1]; b[3] = xl[2]; b[4] = P;     b[5] = P;     b[6] = P;     b[7] = (_Float16)0.f; }
     return b;
 }
+
+// an upper bound of sqrt(v), v >= 0: the hardware's v_sqrt_f32 (1 ulp) with room to spare (the correctly rounded sqrtf is a dozen instructions, and
+// the bounds that use it are taken a per cent above what is needed anyway); tiny arguments get an absolute 1e-18
+__device__ __forceinline__ float f16_sqrt_up(float v) { return __builtin_amdgcn_sqrtf(v) * 1.00001f + 1e-18f; }
 
 // 2E in the filter's own (scaled) units for a query whose smallest filter value is b1 (scaled); < 0: no bound (exact scan)
 __device__ __forceinline__ float f16_margin(const float* nx, float b1, const float* __restrict__ mt) {
@@ -178,13 +195,17 @@ __device__ __forceinline__ float f16_margin(const float* nx, float b1, const flo
     const float D0 = fmaxf(b1u + hx, 0.f);
     const float slack = 0.001953125f * (D0 + hx);                   // 2^-9 (D0 + hx)
     const float Dup = D0 + slack;
-    const float X2 = sqrtf(2.f * hx) * 1.000001f;
-    const float Y = X2 + sqrtf(2.f * Dup) * 1.000001f;
+    const float X2 = f16_sqrt_up(2.f * hx);
+    const float Y = X2 + f16_sqrt_up(2.f * Dup);
     const float Tup = X2 * Y + 0.5f * Y * Y;
     const float E = (F16_CREL * F16_U * Tup + mt[FM_PHI] * (x1 + 1.7321f * Y) + mt[FM_HPHI]) * 1.01f;
     if (!(4.f * E <= slack) || !(E < __builtin_huge_valf())) return -1.f;      // (also NaN / inf: a query outside the f16 range)
     return 2.f * E * (s * s) * 1.0001f;
 }
+
+// v_min / v_max on values that are never signalling NaNs (the compiler's fminf / fmaxf canonicalise both inputs first: two more instructions each)
+__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 __device__ __forceinline__ float f16_chunk_min(const f32x16& d, float cm) {
 #pragma unroll
@@ -249,6 +270,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_f16_kernel(const float* __res
     float nx[F16_G][3];
     F16Track tr[F16_G];
     half8 b[F16_G];
+    int q_ok = 0;                                                   // bit g: the query fits the filter's range
 #pragma unroll
     for (int g = 0; g < F16_G; ++g) {
         const int i = qwave + g * 32 + col;
@@ -258,7 +280,9 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_f16_kernel(const float* __res
             p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2];
         }
         query_point(C, r, p, nx[g]);                                // ICP.py:137
-        b[g] = f16_query_fragment(nx[g], s, kh);
+        bool ok;
+        b[g] = f16_query_fragment(nx[g], s, kh, ok);
+        q_ok |= ok ? (1 << g) : 0;
         tr[g].init();
     }
 
@@ -330,7 +354,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_f16_kernel(const float* __res
         const int c1 = lo.id1, h1 = lo_h, c2 = second_lo ? lo.id2 : hi.id1, h2 = second_lo ? lo_h : hi_h;
         const float B3 = second_lo ? __builtin_fminf(lo.b3, hi.b1) : __builtin_fminf(lo.b2, hi.b2);
         const float margin = f16_margin(nx[g], B1, mt);
-        const bool bounded = (B1 < __builtin_huge_valf()) && margin >= 0.f;
+        const bool bounded = ((q_ok >> g) & 1) && (B1 < __builtin_huge_valf()) && (B1 > -__builtin_huge_valf()) && margin >= 0.f;
         const int ncand = !bounded ? 0 : (B2 - B1 > margin ? 1 : (B3 - B1 > margin ? 2 : 3));
         bv[g] = __builtin_huge_valf();
         bj[g] = 0;
@@ -394,7 +418,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_f16_kernel(const float* __res
         __builtin_amdgcn_wave_barrier();
         float q[3] = {0.f, 0.f, 0.f}, tau = -__builtin_huge_valf();
         if (col < have) { const float4 e = qlist[wave][col]; q[0] = e.x; q[1] = e.y; q[2] = e.z; tau = e.w; }
-        const half8 b2 = f16_query_fragment(q, s, kh);
+        bool ok2;
+        const half8 b2 = f16_query_fragment(q, s, kh, ok2);          // (pass-2 queries are bounded ones: they fit)
         float v2 = __builtin_huge_valf();
         int j2 = 0;
         DICP_F16_FETCH(0)
@@ -450,6 +475,393 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_f16_kernel(const float* __res
 #undef DICP_F16_FETCH
 #undef DICP_F16_COMMIT
 
+// ------------------------------------------------------------------ the same filter inside the exact sorted sweep
+// knn_sweep_kernel's search (dicp_kernels.hip: targets sorted by x once per call, a wave owns 128 queries that are neighbours in x and sweeps
+// 64-row tiles outwards from the tile under them, a side ending where x-distance alone exceeds every query's best) with the SCORING on the
+// matrix cores: per 64-row tile two A tiles straight from the image (global memory, no LDS) x the wave's four B tiles = 8 MFMAs, lane-local
+// bookkeeping per (tile, lane half).  The refine is the brute-force kernel's (one candidate piece / two / a second filter pass over the visited
+// tiles / the exact scan), with the sweep's tie rule: the lowest ORIGINAL index among equal scores.  Plain searches only (no certificates).
+// A side ends when  0.5 dx^2 > kappa1 (b1 / s^2 + 0.5|x|^2) + kappa0  for every query of the wave, dx its x-distance to the side's last scored
+// row: the right side is what a skipped row's computed score would have to beat, with the filter's error E(D) <= alpha |x|^2 + beta D + gamma
+// (linear in the candidate's half squared distance D; E as in the header, sqrt(2D) <= 0.5 + D) and the rounding model of knn_sweep_kernel's
+// margin (computed score of a row >= D (1 - 15u) - 0.5|x|^2 (1 + 21u)) solved for D:  beta = 2^-17 + 2 phi, kappa1 = 1 + 2.02 beta (never, when
+// beta >= 1/4), kappa0 = 1.01 kappa1 (2^-15 0.5|x|^2 + phi (|x|_1 + 1.7321 |x| + 0.87) + hphi).
+struct SweepBest {                   // exact (score, sorted position, original index or -1 = not looked up yet)
+    float v; int s, o;
+};
+__device__ __forceinline__ void sweep_consider(SweepBest& b, const float* q, const float4& row, int j, const int32_t* __restrict__ pm) {
+    const float sc = score<float, float4>(q, row);
+    if (sc < b.v) { b.v = sc; b.s = j; b.o = -1; }
+    else if (sc == b.v && sc < __builtin_huge_valf()) {
+        if (b.o < 0) b.o = pm[b.s];
+        const int o = pm[j];
+        if (o < b.o) { b.o = o; b.s = j; }
+    }
+}
+__device__ __forceinline__ void sweep_merge(SweepBest& b, float ov, int os, int oo, const int32_t* __restrict__ pm) {
+    if (ov < b.v) { b.v = ov; b.s = os; b.o = oo; }
+    else if (ov == b.v && ov < __builtin_huge_valf() && os != b.s) {
+        if (b.o < 0) b.o = pm[b.s];
+        if (oo < 0) oo = pm[os];
+        if (oo < b.o) { b.o = oo; b.s = os; }
+    }
+}
+
+template <int MINW>
+__global__ __launch_bounds__(BLOCK, MINW) void knn_f16_sweep_kernel(const float* __restrict__ src, const float* __restrict__ pose, const float4* __restrict__ tgs4,
+                                                                    const uint4* __restrict__ image, float* __restrict__ meta_all,
+                                                                    const int32_t* __restrict__ tperm, const int32_t* __restrict__ qorder,
+                                                                    const int32_t* __restrict__ bucket, const float* __restrict__ brange, int nbkt,
+                                                                    int32_t* __restrict__ idx, int32_t* __restrict__ spos, unsigned long long* __restrict__ pairs,
+                                                                    int N, int n_full, int m_full, int m_pad, int tiles_per_cloud, int bpc, int src_sorted,
+                                                                    const int32_t* __restrict__ src_rows, const int32_t* __restrict__ tgt_rows,
+                                                                    const float* __restrict__ edges_all) {
+    __shared__ float4 qlist[BLOCK / WAVE][32];
+    __shared__ int qslot[BLOCK / WAVE][32];
+    // the float32 rows of the F16_NTC tiles around the wave's first one (copied by LDS-DMA beside the scoring): where the winners are -- a
+    // match is at most its own distance away in x -- so the refine reads its rows from LDS instead of gathering 512 bytes per query from L2
+    // (2 GB per launch at the benchmark shape: that gather was half of the kernel)
+    __shared__ float4 rowcache[BLOCK / WAVE][F16_NTC * WAVE];
+    int cloud, blk;
+    if (!decode_block(bpc, N, cloud, blk)) return;
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
+    const int unit = blk * (BLOCK / WAVE) + wave;
+    const int n = rows_of(src_rows, cloud, n_full), m = min(max(rows_of(tgt_rows, cloud, m_full), 1), m_pad);
+    if (unit * (32 * F16_G) >= n) return;                           // whole wave idle (no block-level synchronisation anywhere below)
+    const int col = lane & 31, kh = lane >> 5;
+    float* __restrict__ mt = meta_all + (size_t)cloud * F16_META;
+    const float s = mt[FM_S], inv_s2 = mt[FM_INV_S2], phi = mt[FM_PHI], hphi = mt[FM_HPHI];
+    float C[9], r[3];
+    load_pose(pose, cloud, C, r);
+
+    float nx[F16_G][3], xq[F16_G], k0[F16_G];
+    int qi[F16_G], q_ok = 0;
+    F16Track tr[F16_G];
+    half8 b[F16_G];
+    const float beta = 7.62939453125e-6f + 2.f * phi;               // 2^-17 + 2 phi
+    const float kappa1 = beta < 0.25f ? 1.f + 2.02f * beta : __builtin_huge_valf();
+    const float kA = inv_s2 * kappa1;
+#pragma unroll
+    for (int g = 0; g < F16_G; ++g) {
+        const int pos = unit * (32 * F16_G) + g * 32 + col;
+        qi[g] = -1;
+        float p[3] = {0.f, 0.f, 0.f};
+        if (pos < n) {
+            qi[g] = qorder ? qorder[(size_t)cloud * n_full + pos] : pos;
+            const float* sp = src + ((size_t)cloud * n_full + (src_sorted ? pos : qi[g])) * 3;
+            p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2];
+        }
+        query_point(C, r, p, nx[g]);
+    }
+    {   // idle slots of a partial last wave take a real query's values (lane 0 of B tile 0 always holds one): they never hold the sweep open
+        const float a0 = __shfl(nx[0][0], 0), a1 = __shfl(nx[0][1], 0), a2 = __shfl(nx[0][2], 0);
+#pragma unroll
+        for (int g = 0; g < F16_G; ++g)
+            if (qi[g] < 0) { nx[g][0] = a0; nx[g][1] = a1; nx[g][2] = a2; }
+    }
+    float xmax = -__builtin_huge_valf(), xmin = __builtin_huge_valf();
+#pragma unroll
+    for (int g = 0; g < F16_G; ++g) {
+        xq[g] = -nx[g][0];
+        const float hx = 0.5f * (nx[g][0] * nx[g][0] + nx[g][1] * nx[g][1] + nx[g][2] * nx[g][2]);
+        const float x1 = fabsf(nx[g][0]) + fabsf(nx[g][1]) + fabsf(nx[g][2]);
+        k0[g] = hx * kappa1 + 1.01f * kappa1 * (3.0517578125e-5f * hx + phi * (x1 + 1.7321f * f16_sqrt_up(2.f * hx) + 0.87f) + hphi);     // kappa1 hx + kappa0
+        xmax = fmaxf(xmax, xq[g]); xmin = fminf(xmin, xq[g]);
+        bool ok;
+        b[g] = f16_query_fragment(nx[g], s, kh, ok);
+        q_ok |= ok ? (1 << g) : 0;
+        if (!ok || !(k0[g] < __builtin_huge_valf())) k0[g] = __builtin_huge_valf();      // never ends a side: such a wave visits every tile, and the query is scanned exactly
+        tr[g].init();
+    }
+
+    const float4* __restrict__ tg = tgs4 + (size_t)cloud * m_pad;
+    const uint4* __restrict__ img = image + (size_t)cloud * tiles_per_cloud * 64;      // 64-row tile t = A tiles 2t, 2t + 1 = 128 uint4
+    const int ntiles = min((m + WAVE - 1) / WAVE, m_pad / WAVE);
+    const float xc = __shfl(xq[F16_G / 2], 0);                      // the wave's middle query
+    const float xlo = brange[(size_t)cloud * 2], inv = brange[(size_t)cloud * 2 + 1];
+    float fb = (xc - xlo) * inv;
+    fb = fb < 0.f ? 0.f : (fb > (float)nbkt ? (float)nbkt : fb);
+    int start = bucket[(size_t)cloud * (nbkt + 1) + (int)fb];
+    {
+        int hi = bucket[(size_t)cloud * (nbkt + 1) + min((int)fb + 1, nbkt)];
+        while (hi - start > WAVE) {
+            const int mid = (start + hi) >> 1;
+            if (tg[mid].x < xc) start = mid + 1; else hi = mid;
+        }
+    }
+    // (wave-uniform from here on, and told so: the tile counters then live in scalar registers, the loop is scalar control flow and the tiles' edge
+    //  values come through the scalar cache -- as vector loads they queued behind the prefetched tiles and every slab test waited for those)
+    start = __builtin_amdgcn_readfirstlane(start);
+    int tR = min(max(start / WAVE, 0), ntiles - 1), tL = tR - 1;
+    int visR = tR, visL = tR;
+    float edgeR = -__builtin_huge_valf(), edgeL = __builtin_huge_valf();
+    typedef const __attribute__((address_space(4))) float* cfloat_p;
+    const cfloat_p edges = (cfloat_p)(uintptr_t)(edges_all + (size_t)cloud * (tiles_per_cloud / 2) * 2);
+    uint4 preR0 = img[(size_t)tR * 128 + lane], preR1 = img[(size_t)tR * 128 + 64 + lane];
+    uint4 preL0 = img[(size_t)max(tL, 0) * 128 + lane], preL1 = img[(size_t)max(tL, 0) * 128 + 64 + lane];
+    f32x16 zero;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) zero[i] = 0.f;
+
+    const int tc0 = tR - F16_NTC / 2;                               // the row cache holds tiles [tc0, tc0 + F16_NTC)
+    auto process = [&](const uint4& u0, const uint4& u1, int t) {
+        half8 a0, a1;
+        __builtin_memcpy(&a0, &u0, 16); __builtin_memcpy(&a1, &u1, 16);
+        if (t - tc0 >= 0 && t - tc0 < F16_NTC)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tg + (size_t)t * WAVE + lane),
+                                             (__attribute__((address_space(3))) void*)&rowcache[wave][(t - tc0) * WAVE], 16, 0, 0);
+        int chunk;
+        asm("v_mov_b32 %0, %1" : "=v"(chunk) : "s"(t));
+#pragma unroll
+        for (int g = 0; g < F16_G; ++g) {
+            float cm = f16_chunk_min(__builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b[g], zero, 0, 0, 0), __builtin_huge_valf());
+            cm = f16_chunk_min(__builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b[g], zero, 0, 0, 0), cm);
+            tr[g].add(cm, chunk);
+        }
+    };
+    auto prunable = [&](float edge, bool right) {
+        // (a query's best so far is the smaller of its two lanes' -- each lane sees half of every tile's rows)
+        float dreq = -__builtin_huge_valf();
+#pragma unroll
+        for (int g = 0; g < F16_G; ++g) dreq = vmax(dreq, fmaf(vmin(tr[g].b1, __shfl_xor(tr[g].b1, 32)), kA, k0[g]));
+        const float dx = right ? edge - xmax : xmin - edge;
+        return __all(dx > 0.f && 0.5f * dx * dx > dreq) != 0;       // (inf thresholds: never)
+    };
+    while (tR < ntiles || tL >= 0) {
+        if (tR < ntiles) {
+            if (prunable(edgeR, true)) tR = ntiles;
+            else {
+                const uint4 c0 = preR0, c1 = preR1;
+                if (tR + 1 < ntiles) { preR0 = img[(size_t)(tR + 1) * 128 + lane]; preR1 = img[(size_t)(tR + 1) * 128 + 64 + lane]; }
+                edgeR = edges[2 * tR + 1];
+                process(c0, c1, tR);
+                visR = ++tR;
+            }
+        }
+        if (tL >= 0) {
+            if (prunable(edgeL, false)) tL = -1;
+            else {
+                const uint4 c0 = preL0, c1 = preL1;
+                if (tL >= 1) { preL0 = img[(size_t)(tL - 1) * 128 + lane]; preL1 = img[(size_t)(tL - 1) * 128 + 64 + lane]; }
+                edgeL = edges[2 * tL];
+                process(c0, c1, tL);
+                visL = tL--;
+            }
+        }
+    }
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // (the row cache's copies have landed)
+    __builtin_amdgcn_wave_barrier();
+    auto row_at = [&](int rr) {                                     // a visited row: from the cache when its tile is in it
+        const int sl = (rr >> 6) - tc0;
+        return (sl >= 0 && sl < F16_NTC) ? rowcache[wave][sl * WAVE + (rr & 63)] : tg[rr];
+    };
+    // ---- refine.  A piece = the 2 x 16 rows of one (tile, lane half): rows 64 t + 32 a + 16 h + i, a = 0, 1
+    const int32_t* __restrict__ pm = tperm + (size_t)cloud * m_pad;
+    const int nfar = ((const int32_t*)mt)[FM_NFAR];
+    SweepBest best[F16_G];
+    float thr[F16_G];
+    int n_scan = 0, my_unsure = 0, my_scan = 0;
+    int run0[F16_G], run1[F16_G], ncands[F16_G];        // this lane's rows to re-score per query: up to two runs of 16 (-1: none)
+#pragma unroll
+    for (int g = 0; g < F16_G; ++g) {
+        const F16Track me = tr[g];
+        F16Track ot;
+        ot.b1 = __shfl_xor(me.b1, 32); ot.b2 = __shfl_xor(me.b2, 32); ot.b3 = __shfl_xor(me.b3, 32);
+        ot.id1 = __shfl_xor(me.id1, 32); ot.id2 = __shfl_xor(me.id2, 32);
+        const bool me_lo = me.b1 < ot.b1 || (me.b1 == ot.b1 && kh == 0);
+        const F16Track lo = me_lo ? me : ot, hi = me_lo ? ot : me;
+        const int lo_h = me_lo ? kh : (kh ^ 1), hi_h = lo_h ^ 1;
+        const float B1 = lo.b1;
+        const bool second_lo = lo.b2 < hi.b1;
+        const float B2 = second_lo ? lo.b2 : hi.b1;
+        const int c1 = lo.id1, h1 = lo_h, c2 = second_lo ? lo.id2 : hi.id1, h2 = second_lo ? lo_h : hi_h;
+        const float B3 = second_lo ? __builtin_fminf(lo.b3, hi.b1) : __builtin_fminf(lo.b2, hi.b2);
+        const float margin = f16_margin(nx[g], B1, mt);
+        const bool bounded = ((q_ok >> g) & 1) && (B1 < __builtin_huge_valf()) && (B1 > -__builtin_huge_valf()) && margin >= 0.f;
+        const int ncand = !bounded ? 0 : (B2 - B1 > margin ? 1 : (B3 - B1 > margin ? 2 : 3));
+        ncands[g] = ncand;
+        best[g].v = __builtin_huge_valf(); best[g].s = 0; best[g].o = 0x7fffffff;
+        thr[g] = B1 + margin;
+        run0[g] = run1[g] = -1;
+        if (ncand == 1) run0[g] = c1 * 64 + 32 * kh + 16 * h1;                            // the winner's piece, half each
+        else if (ncand == 2) { const int cc = kh ? c2 : c1, hh = kh ? h2 : h1; run0[g] = cc * 64 + 16 * hh; run1[g] = run0[g] + 32; }
+    }
+    // the rows of all four queries are fetched four at a time each (16 loads in flight per lane instead of a chain of dependent gathers), from the
+    // wave's LDS cache where their tile is in it.  Strict < in ascending sorted position; an EQUAL score only raises a flag
+    int ties = 0;
+#pragma unroll 1
+    for (int rn = 0; rn < 2; ++rn) {
+        if (rn == 1 && !__any(run1[0] >= 0 || run1[1] >= 0 || run1[2] >= 0 || run1[3] >= 0)) break;
+#pragma unroll 1
+        for (int kb = 0; kb < 16; kb += 4) {
+            float4 rw[F16_G][4];
+#pragma unroll
+            for (int g = 0; g < F16_G; ++g) {
+                const int r0 = rn ? run1[g] : run0[g];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) rw[g][k] = row_at(min(max(r0, 0) + kb + k, m_pad - 1));
+            }
+#pragma unroll
+            for (int g = 0; g < F16_G; ++g) {
+                const int r0 = rn ? run1[g] : run0[g];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int rr = r0 + kb + k;
+                    float sc = score<float, float4>(nx[g], rw[g][k]);
+                    sc = (r0 >= 0 && rr < m) ? sc : __builtin_huge_valf();
+                    ties |= (sc == best[g].v && sc < __builtin_huge_valf()) ? (1 << g) : 0;
+                    const bool lt = sc < best[g].v;
+                    best[g].v = lt ? sc : best[g].v;
+                    best[g].s = lt ? rr : best[g].s;
+                }
+            }
+        }
+    }
+    // The rare paths below run over the four B tiles in a LOOP (one copy of the code, the tile's values picked with selects): unrolled four times they
+    // made the kernel 40 KB of instructions that every wave streamed through once -- the instruction fetches cost more than the scoring.
+    auto pick = [&](const auto* a, int g) { auto r = a[0]; if (g == 1) r = a[1]; if (g == 2) r = a[2]; if (g == 3) r = a[3]; return r; };
+    auto put_best = [&](int g, bool mine, const SweepBest& w) {
+#pragma unroll
+        for (int i = 0; i < F16_G; ++i) if (g == i && mine) best[i] = w;
+    };
+    // exact ties inside a lane's rows (duplicated targets): those rows again, with the rule -- the lowest ORIGINAL index among equal scores
+    if (__any(ties != 0)) {
+#pragma unroll 1
+        for (int g = 0; g < F16_G; ++g) {
+            const bool mine = (ties >> g) & 1;
+            if (!__any(mine)) continue;
+            float qq[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { const float c[4] = {nx[0][k], nx[1][k], nx[2][k], nx[3][k]}; qq[k] = pick(c, g); }
+            SweepBest w;
+            w.v = __builtin_huge_valf(); w.s = 0; w.o = 0x7fffffff;
+#pragma unroll 1
+            for (int rn = 0; rn < 2; ++rn) {
+                const int r0 = mine ? (rn ? pick(run1, g) : pick(run0, g)) : -1;
+#pragma unroll 1
+                for (int k = 0; k < 16; ++k)
+                    if (r0 >= 0 && r0 + k < m) sweep_consider(w, qq, row_at(r0 + k), r0 + k, pm);
+            }
+            put_best(g, mine, w);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < F16_G; ++g) {
+        const int ncand = ncands[g];
+        if (!((ties >> g) & 1) && best[g].v < __builtin_huge_valf()) best[g].o = -1;      // (original index not looked up yet)
+        if (ncand == 1 || ncand == 2) sweep_merge(best[g], __shfl_xor(best[g].v, 32), __shfl_xor(best[g].s, 32), __shfl_xor(best[g].o, 32), pm);
+        if (ncand == 3 && qi[g] >= 0) my_unsure |= 1 << g;
+        if (ncand == 0 && qi[g] >= 0 && kh == 0) my_scan |= 1 << g;
+    }
+    // queries the filter has no bound for: every visited row, 64 at a time (such a wave never pruned: it visited every tile)
+    if (__any(my_scan != 0)) {
+#pragma unroll 1
+        for (int g = 0; g < F16_G; ++g) {
+            unsigned long long need = __ballot((my_scan >> g) & 1);
+            float qq[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { const float c[4] = {nx[0][k], nx[1][k], nx[2][k], nx[3][k]}; qq[k] = pick(c, g); }
+            while (need) {
+                const int L = __builtin_ctzll(need);
+                need &= need - 1;
+                const float q[3] = {__shfl(qq[0], L), __shfl(qq[1], L), __shfl(qq[2], L)};
+                SweepBest w;
+                w.v = __builtin_huge_valf(); w.s = 0; w.o = 0x7fffffff;
+#pragma unroll 1
+                for (int rr = visL * WAVE + lane; rr < min(visR * WAVE, m); rr += WAVE) sweep_consider(w, q, tg[rr], rr, pm);
+#pragma unroll 1
+                for (int o = WAVE / 2; o > 0; o >>= 1) sweep_merge(w, __shfl_xor(w.v, o), __shfl_xor(w.s, o), __shfl_xor(w.o, o), pm);
+                put_best(g, col == (L & 31), w);
+                ++n_scan;
+            }
+        }
+    }
+
+    // ---- second filter pass over the visited tiles for the queries with three or more candidate pieces: one B tile of up to 32 of them per round
+    int cnt = 0;
+    if (__any(my_unsure != 0)) {
+        int base[F16_G];
+#pragma unroll
+        for (int g = 0; g < F16_G; ++g) { base[g] = cnt; cnt += __popcll(__ballot(((my_unsure >> g) & 1) && kh == 0)); }
+#pragma unroll 1
+        for (int rd = 0; rd * 32 < cnt; ++rd) {
+#pragma unroll 1
+            for (int g = 0; g < F16_G; ++g) {
+                const bool mineg = ((my_unsure >> g) & 1) && kh == 0;
+                const unsigned long long mask = __ballot(mineg);
+                const int rank = pick(base, g) + __popcll(mask & ((1ull << lane) - 1)) - 32 * rd;
+                if (mineg && rank >= 0 && rank < 32) {
+                    float qq[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { const float c[4] = {nx[0][k], nx[1][k], nx[2][k], nx[3][k]}; qq[k] = pick(c, g); }
+                    qlist[wave][rank] = make_float4(qq[0], qq[1], qq[2], pick(thr, g));
+                    qslot[wave][rank] = (g << 8) | col;
+                }
+            }
+            const int have = min(cnt - 32 * rd, 32);
+            __builtin_amdgcn_wave_barrier();
+            float q[3] = {0.f, 0.f, 0.f}, tau = -__builtin_huge_valf();
+            if (col < have) { const float4 e = qlist[wave][col]; q[0] = e.x; q[1] = e.y; q[2] = e.z; tau = e.w; }
+            bool ok2;
+            const half8 b2 = f16_query_fragment(q, s, kh, ok2);
+            SweepBest w;
+            w.v = __builtin_huge_valf(); w.s = 0; w.o = 0x7fffffff;
+#pragma unroll 1
+            for (int t = visL * 2; t < visR * 2; ++t) {             // A tiles of the visited range
+                half8 a;
+                { const uint4 v = img[(size_t)t * 64 + lane]; __builtin_memcpy(&a, &v, 16); }
+                const float cm = f16_chunk_min(__builtin_amdgcn_mfma_f32_32x32x16_f16(a, b2, zero, 0, 0, 0), __builtin_huge_valf());
+                if (cm <= tau) {
+#pragma unroll 1
+                    for (int k = 0; k < 16; ++k) { const int rr = t * 32 + 16 * kh + k; if (rr < m) sweep_consider(w, q, tg[rr], rr, pm); }
+                }
+            }
+            sweep_merge(w, __shfl_xor(w.v, 32), __shfl_xor(w.s, 32), __shfl_xor(w.o, 32), pm);
+#pragma unroll 1
+            for (int e = 0; e < have; ++e) {
+                const int slot = qslot[wave][e];
+                SweepBest r;
+                r.v = __shfl(w.v, e); r.s = __shfl(w.s, e); r.o = __shfl(w.o, e);
+                put_best(slot >> 8, col == (slot & 0xff), r);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+
+    // ---- far rows (left out of the image), then the results as knn_sweep_kernel writes them
+    if (nfar > 0) {
+#pragma unroll 1
+        for (int g = 0; g < F16_G; ++g) {
+            float qq[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { const float c[4] = {nx[0][k], nx[1][k], nx[2][k], nx[3][k]}; qq[k] = pick(c, g); }
+            SweepBest w = pick(best, g);
+#pragma unroll 1
+            for (int f = 0; f < nfar; ++f) {
+                const int rr = ((const int32_t*)mt)[FM_FAR0 + f];
+                if (rr < m) sweep_consider(w, qq, tg[rr], rr, pm);
+            }
+            put_best(g, true, w);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < F16_G; ++g) {
+        if (qi[g] < 0 || kh != 0) continue;
+        const bool found = best[g].v < __builtin_huge_valf();
+        int bo = best[g].o;
+        if (found && bo < 0) bo = pm[best[g].s];
+        if (!found) bo = 0x7fffffff;
+        if (idx) idx[(size_t)cloud * n_full + qi[g]] = (bo == 0x7fffffff) ? 0 : min(max(bo, 0), m - 1);
+        if (spos) spos[(size_t)cloud * n_full + qi[g]] = (bo == 0x7fffffff || bo >= m) ? -1 : best[g].s;
+    }
+    if (lane == 0) {
+        if (cnt) atomicAdd((int*)mt + FM_AGAIN, cnt);
+        if (n_scan) atomicAdd((int*)mt + FM_SCAN, n_scan);
+        if (pairs) atomicAdd(pairs + (blockIdx.x & (DICP_PAIR_SHARDS - 1)), (unsigned long long)(visR - visL) * WAVE * (32 * F16_G));
+    }
+}
+
 }  // namespace
 
 namespace dicp_tu {
@@ -460,10 +872,11 @@ int knn_f16_pack(const void* rows4, const int32_t* tgt_rows, int N, int m_full, 
     if (((uintptr_t)rows4 % 16) || ((uintptr_t)image % 16)) return DICP_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
     const int m_img = knn_f16_image_rows(m_pad), tiles = m_img / 32;
-    float* meta = (float*)((char*)image + (size_t)N * m_img * 32);
+    float* meta = (float*)((char*)image + knn_f16_meta_offset(N, m_pad));
+    float* edges = (float*)((char*)image + knn_f16_edges_offset(N, m_pad));
     begin_launch();
     knn_f16_scale_kernel<<<N, BLOCK, 0, st>>>((const float4*)rows4, tgt_rows, m_full, m_pad, meta);
-    knn_f16_image_kernel<<<dim3((tiles + BLOCK / WAVE - 1) / (BLOCK / WAVE), N), BLOCK, 0, st>>>((const float4*)rows4, tgt_rows, m_full, m_pad, m_img, meta, (uint4*)image, tiles, N);
+    knn_f16_image_kernel<<<dim3((tiles + BLOCK / WAVE - 1) / (BLOCK / WAVE), N), BLOCK, 0, st>>>((const float4*)rows4, tgt_rows, m_full, m_pad, m_img, meta, (uint4*)image, tiles, N, edges);
     return launch_status();
 }
 
@@ -473,11 +886,28 @@ int knn_f16_brute(const void* src, const void* pose, const void* tgt4, void* ima
     if (N <= 0 || n <= 0 || m <= 0 || m_pad < m) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int m_img = knn_f16_image_rows(m_pad), tiles = m_img / 32;
-    float* meta = (float*)((char*)image + (size_t)N * m_img * 32);        // (its two counters are added to)
+    float* meta = (float*)((char*)image + knn_f16_meta_offset(N, m_pad));        // (its two counters are added to)
     const int bpc = (n + (BLOCK / WAVE) * 32 * F16_G - 1) / ((BLOCK / WAVE) * 32 * F16_G);
     begin_launch();
     knn_f16_kernel<4><<<grid_for(N, bpc), BLOCK, 0, st>>>((const float*)src, (const float*)pose, (const float4*)tgt4, (const uint4*)image, meta, idx,
                                                          N, n, m, m_pad, tiles, bpc, src_rows, tgt_rows);
+    return launch_status();
+}
+
+int knn_f16_sweep(const void* src, const void* pose, const void* tgs4, void* image, const int32_t* tperm, const int32_t* qorder, const int32_t* bucket,
+                  const void* brange, int nbkt, const int32_t* src_rows, const int32_t* tgt_rows, int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos,
+                  unsigned long long* pairs, int src_sorted, void* ev0, void* ev1, void* stream) {
+    if (!src || !tgs4 || !image || !tperm || !bucket || !brange || (!idx && !spos)) return DICP_ERR_NULL;
+    if (N <= 0 || n <= 0 || m <= 0 || m_pad < m || (m_pad % WAVE)) return DICP_ERR_SHAPE;
+    const int m_img = knn_f16_image_rows(m_pad), tiles = m_img / 32;
+    float* meta = (float*)((char*)image + knn_f16_meta_offset(N, m_pad));
+    const float* edges = (const float*)((const char*)image + knn_f16_edges_offset(N, m_pad));
+    const int units = (n + 32 * F16_G - 1) / (32 * F16_G);
+    const int bpc = (units + BLOCK / WAVE - 1) / (BLOCK / WAVE);
+    begin_launch();
+    hipExtLaunchKernelGGL((knn_f16_sweep_kernel<4>), dim3(grid_for(N, bpc)), dim3(BLOCK), 0, (hipStream_t)stream, (hipEvent_t)ev0, (hipEvent_t)ev1, 0,
+                          (const float*)src, (const float*)pose, (const float4*)tgs4, (const uint4*)image, meta, tperm, qorder, bucket, (const float*)brange, nbkt,
+                          idx, spos, pairs, N, n, m, m_pad, tiles, bpc, src_sorted, src_rows, tgt_rows, edges);
     return launch_status();
 }
 

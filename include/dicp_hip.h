@@ -160,12 +160,15 @@ int dicp_query_order(int dtype, const void* src, const void* pose, const void* b
  *   index then costs a look-up only on exact ties).
  * pairs: optional DICP_PAIR_SHARDS device counters; their sum += number of (query,target) pairs actually scored
  *   (roofline accounting; sharded because adds to ONE address serialise at ~12 ns each).
- * cfg: 0 = launch configuration chosen from the problem size; 1, 2, 4 pin one (queries per lane, rows per chunk) = (1,8), (2,8), (1,16). */
+ * cfg: 0 = launch configuration chosen from the problem size; 1, 2, 4 pin one (queries per lane, rows per chunk) = (1,8), (2,8), (1,16).
+ * f16_image: optional (float32): the image dicp_knn_f16_pack made of tgs4 (the SORTED packed rows, same tgt_rows).  The scoring of the (2,8)
+ *   configuration's units -- 128 queries per wave, what big problems get -- then runs on the matrix cores (split-f16 filter + exact float32
+ *   refine, csrc/knn_f16.hip): the same idx / spos, index for index. */
 #define DICP_PAIR_SHARDS 64
 #define DICP_SWEEP_SRC_SORTED 0x100   /* OR into cfg: `src` holds the rows in qorder's slot order (dicp_query_order's src_s) */
 int dicp_knn_sweep(int dtype, const void* src, const void* pose, const void* tgs4, const int32_t* tperm,
                    const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt, const int32_t* src_rows, const int32_t* tgt_rows,
-                   int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg, void* stream);
+                   int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg, const void* f16_image, void* stream);
 
 /* Gather whole target rows at idx (nn.py:37-38 / 89-90) and its backward, a scatter-add
  * into a zero-initialised (N,m,c) buffer (autograd's gather backward). */
@@ -362,7 +365,8 @@ typedef struct dicp_loop_buffers {
     int32_t first_search_done;  /* sweep path: 1 = the matches of iteration 0 are already in spos (the caller enqueued dicp_knn_sweep under pose_search[0] and
                                    the first query order itself, right behind the index build, so that the search runs while the host is still
                                    preparing the loop): dicp_icp_forward then starts iteration 0 at its accumulate */
-    const void* tgt_f16;     /* knn_variant DICP_KNN_MFMA: the split-f16 image of tgt4 (dicp_knn_f16_pack, with the same tgt_rows) */
+    const void* tgt_f16;     /* optional, float32: the split-f16 image of tgt4 (dicp_knn_f16_pack, with the same tgt_rows).  DICP_KNN_MFMA needs it; on the
+                                sweep path (tgt4 = the sorted rows) the plain searches of big problems score on the matrix cores when it is given */
 } dicp_loop_buffers;
 
 /* Head and tail of the backward loop.  dicp_pose_grad_in: gpose (N,12) double = [dL/dC row-major (9), dL/dr (3)] taken from the

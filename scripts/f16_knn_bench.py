@@ -31,5 +31,5 @@ for form in forms:
     print("%-5s B=%d n=m=%d: median %.3f ms  min %.3f ms   %.1f Tpairs/s  (8nm flop: %.0f TF)" % (form, B, n, ts[len(ts) // 2], ts[0], pairs / ts[len(ts) // 2] / 1e9, 8 * pairs / ts[len(ts) // 2] / 1e9))
 if len(res) == 2:
     print("mismatches:", int((res["valu"] != res["mfma"]).sum()))
-again, scan = _ops.f16_counters(img, B)
+again, scan = _ops.f16_counters(img, B, tgt4.shape[1])
 print("second filter pass: %.4f %% of the queries per launch; exact scans: %.4f %%" % (100.0 * again / (B * n) / max(1, (reps + 1) * forms.count("mfma")), 100.0 * scan / (B * n) / max(1, (reps + 1) * forms.count("mfma"))))

@@ -118,11 +118,11 @@ def test_new_entry_points_reject_bad_arguments(lib):
     assert lib.dicp_permute_rows(0, one, one, 1, 2, 1, 2, 3, 3, one, 4, 3, None) == 2
     assert lib.dicp_pose_grad_in(0, None, None, 1, None) == 1 and lib.dicp_pose_grad_in(7, None, one, 1, None) == 3
     assert lib.dicp_pose_grad_out(0, one, one, 0, one, 1, None) == 2 and lib.dicp_pose_grad_out(0, one, None, 0, None, 1, None) == 1
-    # dicp_knn_sweep(dtype, src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, src_rows, tgt_rows, N, n, m, m_pad, idx, spos, pairs, cfg, stream)
-    assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, None, None, 1, 1, 1, 64, one, None, None, 99, None) == 4
-    assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, None, None, 1, 1, 1, 64, None, None, None, 0, None) == 1   # idx or spos
-    assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, None, None, 1, 1, 1, 64, one, None, None, 16, None) == 4   # (the scan form is gone)
-    assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, None, None, 1, 1, 1, 64, one, None, None, 2 | 0x100, None) == 1  # sorted rows need the order
+    # dicp_knn_sweep(dtype, src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, src_rows, tgt_rows, N, n, m, m_pad, idx, spos, pairs, cfg, f16_image, stream)
+    assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, None, None, 1, 1, 1, 64, one, None, None, 99, None, None) == 4
+    assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, None, None, 1, 1, 1, 64, None, None, None, 0, None, None) == 1   # idx or spos
+    assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, None, None, 1, 1, 1, 64, one, None, None, 16, None, None) == 4   # (the scan form is gone)
+    assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, None, None, 1, 1, 1, 64, one, None, None, 2 | 0x100, None, None) == 1  # sorted rows need the order
 
 
 def test_sizes_and_argument_checks(lib):
@@ -141,8 +141,8 @@ def test_sizes_and_argument_checks(lib):
     assert lib.dicp_knn(1, one, None, ctypes.c_void_p(32), None, None, 1, 1, 1, 64, one, _lib.KNN_MFMA, one, None) == 3
     assert lib.dicp_knn(0, one, None, ctypes.c_void_p(8), None, None, 1, 1, 1, 64, one, 0, None, None) == 5
     assert lib.dicp_knn(0, one, None, one, None, None, 1, 1, 1, 64, one, _lib.KNN_MFMA, None, None) == 1       # the matrix-core form needs its image
-    # dicp_knn_f16_bytes(N, m_pad) / dicp_knn_f16_pack(tgt4, tgt_rows, N, m, m_pad, image, stream): 32 bytes per row, rows rounded up to 512, + 320 bytes per cloud
-    assert lib.dicp_knn_f16_bytes(2, 64) == 2 * (512 * 32 + 320) and lib.dicp_knn_f16_bytes(1, 16384) == 16384 * 32 + 320 and lib.dicp_knn_f16_bytes(0, 64) == 0
+    # dicp_knn_f16_bytes(N, m_pad) / dicp_knn_f16_pack(tgt4, tgt_rows, N, m, m_pad, image, stream): 32 bytes per row, rows rounded up to 512, + 320 bytes per cloud + 8 per 64 rows
+    assert lib.dicp_knn_f16_bytes(2, 64) == 2 * (512 * 32 + 320 + 64) and lib.dicp_knn_f16_bytes(1, 16384) == 16384 * 32 + 320 + 2048 and lib.dicp_knn_f16_bytes(0, 64) == 0
     assert lib.dicp_knn_f16_pack(None, None, 1, 1, 64, one, None) == 1
     assert lib.dicp_knn_f16_pack(one, None, 1, 65, 64, one, None) == 2
     assert lib.dicp_knn_f16_pack(ctypes.c_void_p(8), None, 1, 1, 64, one, None) == 5

@@ -1,0 +1,125 @@
+"""The matrix-core search (`-m gpu`; csrc/knn_f16.hip: split-f16 filter on v_mfma_f32_32x32x16_f16 + exact float32 refine) replaces the K = 5 bmm
+inside torch.cdist (/root/reference/dICP/nn.py:32-35) for float32 clouds.  Its contract is the brute-force VALU kernel's result INDEX FOR INDEX --
+torch.argmin's lowest-index rule included -- on every input: the filter only decides which rows are re-scored exactly.  Checked here on the inputs
+that stress the filter's error bound and its fall-backs (near-ties inside the bound, exact ties, far rows, queries outside the f16 range,
+non-finite rows, ragged batches), for the all-pairs form (dicp_knn, DICP_KNN_MFMA) and inside the exact sorted sweep (dicp_knn_sweep with f16_image)."""
+import pytest
+import torch
+
+from dicp_amd import _lib, _ops
+from dicp_amd.ICP import ICP
+from dicp_amd.synthetic import make_pairs, make_scene_pairs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def cases():
+    src, tgt = make_pairs(6, 8192, 8192, seed=11)
+    tgt = tgt[:, :, :3].contiguous()
+    out = [("random", src, tgt, None, None)]
+    s2, t2 = make_scene_pairs(6, 8192, 8192, seed=3)
+    out.append(("planar scenes", s2, t2[:, :, :3].contiguous(), None, None))
+    off = torch.tensor([2500.0, -1200.0, 300.0])
+    out.append(("2.8 km from the origin", src + off, tgt + off, None, None))
+    dup = tgt.clone(); dup[:, 1::2] = dup[:, 0::2]
+    out.append(("every target twice", src, dup, None, None))
+    trip = tgt.clone(); k = trip[:, 1::3].shape[1]; trip[:, 1::3] = trip[:, 0::3][:, :k]; k2 = trip[:, 2::3].shape[1]; trip[:, 2::3] = trip[:, 0::3][:, :k2]
+    out.append(("every target three times", src, trip, None, None))
+    near = tgt.clone(); near[:, 1::2] = near[:, 0::2] + 1e-4
+    out.append(("every target twice, 0.1 mm apart", src, near, None, None))
+    padded = tgt.clone(); padded[:, -300:] = float(src.max()) * 1000.0
+    out.append(("reference pad rows in the target", src, padded, None, None))
+    out.append(("the same with tgt_rows", src, padded, None, torch.full((6,), 8192 - 299, dtype=torch.int32)))
+    outl = tgt.clone(); outl[:, 5] = 1e6; outl[:, 77] = -3e5
+    out.append(("two far outliers", src, outl, None, None))
+    plane = tgt.clone(); plane[:, :, 0] = 1.25
+    out.append(("all targets on one x plane", src, plane, None, None))
+    out.append(("cloud 2 cm across", src * 1e-3, tgt * 1e-3, None, None))
+    qfar = src.clone(); qfar[:, ::7] *= 40.0
+    out.append(("queries far outside the cloud", qfar, tgt, None, None))
+    nanr = tgt.clone(); nanr[:, 100:110] = float("nan"); nanr[:, 200, 0] = float("inf")
+    out.append(("non-finite target rows", src, nanr, None, None))
+    out.append(("ragged sources", src, tgt, torch.tensor([8192, 100, 5000, 1, 8000, 129], dtype=torch.int32), None))
+    s3, t3 = make_pairs(5, 777, 3001, seed=7)
+    out.append(("odd sizes", s3, t3[:, :, :3].contiguous(), None, None))
+    return out
+
+
+CASES = cases()
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_matrix_core_brute_force_equals_valu(case):
+    _, src, tgt, src_rows, tgt_rows = case
+    src, tgt = src.to(DEV).contiguous(), tgt.to(DEV).contiguous()
+    src_rows = src_rows.to(DEV) if src_rows is not None else None
+    tgt_rows = tgt_rows.to(DEV) if tgt_rows is not None else None
+    N, n, _ = src.shape
+    m = tgt.shape[1]
+    frame = _ops.search_frame(tgt, tgt_rows=tgt_rows)
+    tgt4 = _ops.pack_target(tgt, frame, tgt_rows)
+    ps = _ops.search_pose(None, frame, N)
+    ref = _ops.knn(src, ps, tgt4, m, _lib.KNN_VALU, src_rows=src_rows, tgt_rows=tgt_rows)
+    got = _ops.knn(src, ps, tgt4, m, _lib.KNN_MFMA, src_rows=src_rows, tgt_rows=tgt_rows)
+    if src_rows is not None:
+        mask = torch.arange(n, device=DEV)[None, :] < src_rows[:, None]
+        assert torch.equal(ref[mask], got[mask])
+    else:
+        assert torch.equal(ref, got)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_matrix_core_sweep_equals_valu_sweep(case):
+    _, src, tgt, src_rows, tgt_rows = case
+    src, tgt = src.to(DEV).contiguous(), tgt.to(DEV).contiguous()
+    src_rows = src_rows.to(DEV) if src_rows is not None else None
+    tgt_rows = tgt_rows.to(DEV) if tgt_rows is not None else None
+    N, n, _ = src.shape
+    frame = _ops.search_frame(tgt, tgt_rows=tgt_rows)
+    sw = _ops.SweepIndex(tgt, frame=frame, tgt_rows=tgt_rows)
+    ps = _ops.search_pose(None, frame, N)
+    qo = sw.query_order(src, ps, src_rows=src_rows)
+    res = {}
+    for mf in (False, True):
+        idx = torch.full((N, n), -7, dtype=torch.int32, device=DEV)
+        spos = torch.full((N, n), -7, dtype=torch.int32, device=DEV)
+        sw.knn(src, ps, qo, out=idx, cfg=2, spos=spos, src_rows=src_rows, mfma=mf)
+        res[mf] = (idx, spos)
+    assert torch.equal(res[False][0], res[True][0]) and torch.equal(res[False][1], res[True][1])
+
+
+def test_the_filter_settles_almost_every_query_in_one_pass():
+    """On volumetric clouds the second filter pass takes well under 1 % of the queries and the exact scan none; on planar scenes (a fifth of the
+    queries have a second candidate inside the filter's resolution) the second pass stays a few per cent."""
+    for maker, limit in ((make_pairs, 0.002), (make_scene_pairs, 0.05)):
+        src, tgt = maker(8, 16384, 16384, seed=5)
+        src, tgt = src.to(DEV), tgt[:, :, :3].contiguous().to(DEV)
+        frame = _ops.search_frame(tgt)
+        tgt4 = _ops.pack_target(tgt, frame)
+        img = _ops.f16_image(tgt4, 16384)
+        _ops.knn(src, _ops.search_pose(None, frame, 8), tgt4, 16384, _lib.KNN_MFMA, image=img)
+        again, scan = _ops.f16_counters(img, 8, tgt4.shape[1])
+        assert scan == 0 and again <= limit * 8 * 16384, (maker.__name__, again, scan)
+
+
+def test_icp_call_with_the_matrix_core_sweep_is_the_same_call(monkeypatch):
+    """The ICP loop on clouds big enough for the matrix-core sweep (>= 32768 targets; forced on a small batch here): poses, histories and gradients
+    are those of the VALU sweep (the searches return the same indices, everything after them is the same code)."""
+    N, n = 2, 32768
+    src, tgt = make_pairs(N, n, n, seed=21)
+    kw = dict(trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0}, dim=3)
+    outs = {}
+    for on in (False, True):
+        monkeypatch.setattr(_ops, "F16_SWEEP", on)
+        monkeypatch.setattr(_ops, "F16_SWEEP_MIN_QUERIES", 0)
+        icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=5, tolerance=1e-12)
+        icp.const_iter, icp.knn_variant = True, _lib.KNN_SWEEP | (2 << 8)
+        s, t = src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True)
+        out = icp.icp(s, t, torch.eye(4, device=DEV).repeat(N, 1, 1), **kw)
+        out["T"].sum().backward()
+        outs[on] = (out["T"].detach(), out["deltas"], out["weights"], s.grad, t.grad)
+    for a, b in zip(outs[False][:3], outs[True][:3]):
+        assert torch.equal(a, b)
+    for a, b in zip(outs[False][3:], outs[True][3:]):       # (the windowed backward adds its out-of-window rows with float atomics: not bit for bit)
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())

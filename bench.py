@@ -21,6 +21,14 @@ Beside `value` the same run reports, each as the median of its own timed calls:
                     cloud-iterations actually executed per second, early iterations included
   value_structured  the same K-iteration call on LiDAR-like scenes (ground plane + four walls, two of them
                     perpendicular to the sweep's sort axis, + 10 % clutter: dicp_amd/synthetic.make_scene_pairs)
+  value_c2          BASELINE configs[1] (one GPU only): B=32 x 4096 points, point-to-point, K=10 fwd+bwd -- the Gauss-Newton loop
+                    (`gn`) and the closed-form SVD step (`svd`: ICP.pt2pt_dICP_SVD), cloud-iterations/s and ms per call
+  value_c4          BASELINE configs[3] on a 64-cloud slice (one GPU only): 65536-point clouds, pt2pl + Huber, K=5 fwd+bwd, with the exact
+                    sweep (its plain searches score on the matrix cores from 32768 targets on) and with the matrix-core brute force in the loop
+  ms_by_iteration_class   search + accumulate time of the event-carrying call by kind of iteration: full search (before the
+                    certificates start), certifying search, certified (guard launch + accumulate with its on-the-spot searches)
+`value_bruteforce` runs the matrix-core brute force (split-f16 filter on v_mfma_f32_32x32x16_f16 + exact float32 refine: the same indices);
+`value_bruteforce_valu` is the same call with the float32 FMA kernel of rounds 1-3.
 
 For N>1 launch with torch.distributed.run (one rank per GPU, weak scaling: 256 clouds per rank).
 Rank 0 prints ONE JSON line.  Kernel times come from HIP events carried on the dispatches of the last
@@ -53,6 +61,7 @@ from dicp_amd.synthetic import make_pairs, make_scene_pairs   # noqa: E402
 
 STEADY_CALLS, STEADY_MAX = 3, 40   # untimed K-iteration calls before the timed ones: at least / at most
 F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32 vector == f32-input MFMA peak
+F16_MFMA_PEAK_TFLOPS = 2500.0   # ... dense f16 / bf16 MFMA peak
 HBM_PEAK_GBS = 8000.0        # HBM3E spec
 LOSS = {"name": "huber", "metric": 1.0}
 TRIM = 5.0
@@ -171,6 +180,68 @@ def cpu_baseline(n, m, budget_s=25.0):
                       % (Bc, K, n, len(times), best)}
 
 
+def other_configs(make_icp, dev, sync):
+    """BASELINE configs[1] and a slice of configs[3] on this GPU: median of 5 (3) eager calls each, forward + backward, steady state first."""
+    from dicp_amd import _lib as L
+    out = {}
+
+    def time_calls(fn, count, warm=3):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(count):
+            sync()
+            t0 = time.perf_counter()
+            fn()
+            sync()
+            ts.append(time.perf_counter() - t0)
+        return median(ts)
+
+    # configs[1]: B = 32 x 4096, point-to-point, K = 10
+    Bc, nc, Kc = 32, 4096, 10
+    s2, t2 = make_pairs(Bc, nc, nc, seed=2, dtype=torch.float32)
+    s2, t2 = s2.to(dev), t2[:, :, :3].contiguous().to(dev)
+    T2 = torch.eye(4, device=dev).repeat(Bc, 1, 1)
+    gn = make_icp(icp_type="pt2pt", differentiable=True, max_iterations=Kc, tolerance=1e-12)
+    gn.const_iter = True
+
+    def gn_call():
+        s, t = s2.detach().requires_grad_(True), t2.detach().requires_grad_(True)
+        gn.icp(s, t, T2, trim_dist=TRIM, loss_fn=LOSS, dim=3)["T"].sum().backward()
+
+    def svd_call():
+        s, t = s2.detach().requires_grad_(True), t2.detach().requires_grad_(True)
+        gn.pt2pt_dICP_SVD(s, t, T2, trim_dist=TRIM)[1].sum().backward()
+    t_gn, t_svd = time_calls(gn_call, 5), time_calls(svd_call, 5)
+    out["value_c2"] = {"workload": "BASELINE configs[1]: B=32 x 4096-pt clouds, point-to-point, K=10 fwd+bwd, eager calls",
+                       "gn": {"cloud_iterations_per_s": Bc * Kc / t_gn, "ms_per_call": t_gn * 1e3},
+                       "svd": {"cloud_iterations_per_s": Bc * Kc / t_svd, "ms_per_call": t_svd * 1e3, "note": "ICP.pt2pt_dICP_SVD: closed-form 3x3 SVD step (batched, weighted)"}}
+    del s2, t2, gn
+    # configs[3], a 64-cloud slice: 65536-point clouds, pt2pl + Huber, K = 5
+    Bc, nc, Kc = 64, 65536, 5
+    s4, t4 = make_pairs(Bc, nc, nc, seed=4, dtype=torch.float32)
+    s4, t4 = s4.to(dev), t4.to(dev)
+    T4 = torch.eye(4, device=dev).repeat(Bc, 1, 1)
+    legs = {}
+    for name, kv in (("sweep", L.KNN_AUTO), ("mfma_bruteforce", L.KNN_MFMA)):
+        obj = make_icp(icp_type="pt2pl", differentiable=True, max_iterations=Kc, tolerance=1e-12)
+        obj.const_iter, obj.knn_variant = True, kv
+
+        def call():
+            s, t = s4.detach().requires_grad_(True), t4.detach().requires_grad_(True)
+            obj.icp(s, t, T4, trim_dist=TRIM, loss_fn=LOSS, dim=3)["T"].sum().backward()
+        tc = time_calls(call, 3, warm=2)
+        legs[name] = {"cloud_iterations_per_s": Bc * Kc / tc, "ms_per_call": tc * 1e3, "ms_per_iteration": tc * 1e3 / Kc}
+        if name == "sweep" and "knn_pairs" in obj.knn_stats:
+            legs[name]["pairs_scored_fraction"] = float(obj.knn_stats["knn_pairs"].sum().item()) / Kc / (float(Bc) * nc * nc)
+        del obj
+    legs["workload"] = "BASELINE configs[3] on a 64-cloud slice: 65536-pt clouds, point-to-plane + huber(1.0) + trim(5.0), K=5 fwd+bwd"
+    legs["note"] = ("sweep: the exact sorted sweep, its plain searches scoring on the matrix cores (from 32768 targets per cloud on); mfma_bruteforce: all n*m pairs on "
+                    "v_mfma_f32_32x32x16_f16 (split-f16 filter + exact float32 refine); matrix-pipe counters of both at HEAD: profiles/r04_knn_c4_65536_pmc.txt")
+    out["value_c4"] = legs
+    return out
+
+
 def oracle_gate(src, tgt, K, out_T, g_src, g_tgt):
     """The TIMED call's own results on its first clouds against the oracle run for the same K iterations (fwd+bwd):
     -> (dict for the line, ok).  Pose bar 1e-4; gradients: median row error <= 1e-5 and at most 0.1 % of the rows beyond 1e-3
@@ -229,6 +300,8 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
     if on_gpu:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+        if torch.cuda.device_count() < max(1, args.gpus) or local_rank >= torch.cuda.device_count():
+            raise SystemExit("bench.py --gpus %d: this node shows %d device(s) (local rank %d)" % (args.gpus, torch.cuda.device_count(), local_rank))
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank) if on_gpu else device
     # synthetic inputs are generated on the CPU: keep N ranks from oversubscribing the host's cores
@@ -250,6 +323,13 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
             rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
         except Exception:
             rccl = None
+        # one rank per device: two ranks on one GPU would time half a GPU each and report it as two
+        mine = torch.tensor([local_rank if on_gpu else rank], dtype=torch.int64, device=dev if on_gpu else device)
+        every = [torch.empty_like(mine) for _ in range(ranks_seen)]
+        torch.distributed.all_gather(every, mine)
+        seen_devices = sorted(int(v.item()) for v in every)
+        if len(set(seen_devices)) != ranks_seen:
+            raise SystemExit("bench.py --gpus %d: the ranks map to devices %s -- one rank per device is required" % (args.gpus, seen_devices))
 
     B, n, m, K, W = args.batch, args.points, args.points, args.steps, args.warmup
     reps = max(5, args.reps)
@@ -385,12 +465,14 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
             extra["k10_note"] = "the same call at K = 10 (SURVEY.md 8d): %.3f ms per step, median of %d calls" % (median(kt) * 1e3 / 10, reps)
             del k10
         if not brute:
-            bf = new_icp(K, knn=L.KNN_VALU)
-            steady(bf, data, least=2, most=4)
-            bt, _, _ = timed(bf, data, 3)
-            extra["value_bruteforce"] = world * B * K / median(bt)
-            extra["bruteforce_note"] = "same call with the brute-force kNN kernel (all n*m pairs) in the loop: median of 3 calls, %.3f ms per step" % (median(bt) * 1e3 / K)
-            del bf
+            for key, kv, what in (("value_bruteforce", L.KNN_MFMA, "the matrix-core brute force (split-f16 filter on v_mfma_f32_32x32x16_f16 + exact float32 refine)"),
+                                  ("value_bruteforce_valu", L.KNN_VALU, "the float32 FMA brute-force kernel")):
+                bf = new_icp(K, knn=kv)
+                steady(bf, data, least=2, most=4)
+                bt, _, _ = timed(bf, data, 3)
+                extra[key] = world * B * K / median(bt)
+                extra[key.replace("value_", "") + "_note"] = "same call with %s (all n*m pairs, same indices) in the loop: median of 3 calls, %.3f ms per step" % (what, median(bt) * 1e3 / K)
+                del bf
         tol = new_icp(50, tol=1e-4, const_iter=False)
         steady(tol, data, least=3, most=8)
         tt, (tout, _, _, _), _ = timed(tol, data, reps)
@@ -416,6 +498,8 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
             extra["structured_pairs_scored_fraction"] = sp / (float(n) * m * B)
         sane = sane and bool(torch.isfinite(sout["T"]).all() and torch.isfinite(sgs).all() and torch.isfinite(sgt).all())
         del sc, sout, sgs, sgt, scene, s2, t2
+        if on_gpu and world == 1:
+            extra.update(other_configs(make_icp, dev, sync))
     gc.enable()
 
     # the pose all-gather on its own (N > 1): the collective bench.py overlaps with the backward, timed alone between fences
@@ -440,14 +524,20 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
         pose_id = torch.cat((torch.eye(3, device=dev).reshape(9), torch.zeros(3, device=dev))).repeat(B, 1).contiguous()
         idx_tmp = torch.empty((B, n), dtype=torch.int32, device=dev)
         bf = []
+    bfm = []
+    if on_gpu:
+        img16 = _ops.f16_image(tgt4, m)
     for _ in range(3 if on_gpu else 0):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        _ops.knn(src, pose_id, tgt4, m, L.KNN_MFMA if args.knn == "mfma" else L.KNN_VALU, out=idx_tmp)
-        b.record()
-        torch.cuda.synchronize()
-        bf.append(a.elapsed_time(b))
+        for kv, dst in ((L.KNN_VALU, bf), (L.KNN_MFMA, bfm)):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            _ops.knn(src, pose_id, tgt4, m, kv, out=idx_tmp, image=img16)
+            b.record()
+            torch.cuda.synchronize()
+            dst.append(a.elapsed_time(b))
     bf_ms = sorted(bf)[1] if on_gpu else None
+    bfm_ms = sorted(bfm)[1] if on_gpu else None
+    f16_again = (_ops.f16_counters(img16, B, tgt4.shape[1])[0] / 3.0 / (B * n)) if on_gpu else None
 
     # ---- the gate, on every rank: finite everywhere; rank 0 also holds its timed call against the oracle
     gate, base = None, None
@@ -545,12 +635,34 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
                        "parallelism": "batch-sharded x%d, one pose all-gather per call" % world},
             "roofline": dict(legs[top], dominant="largest share of the event-carrying timed call (%.3f ms): %s"
                              % (last_ms, ", ".join("%s %.0f %%" % (nm, 100 * share[nm]) for nm in sorted(share, key=lambda q: -share[q])))),
-            "roofline_bruteforce_knn": {"kernel": "knn_%s_kernel (all n*m pairs)" % ("mfma" if args.knn == "mfma" else "valu"), "bound": "valu",
+            "roofline_bruteforce_knn": {"kernel": "knn_valu_kernel (all n*m pairs, float32 FMA)", "bound": "valu",
                                         "achieved": flops_bf / (bf_ms * 1e-3) / 1e12 if bf_ms else None, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                         "frac": flops_bf / (bf_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS if bf_ms else None, "traffic": bf_traffic, "traffic_source": bf_src,
                                         "avg_launch_ms": bf_ms, "measured": "3 extra launches outside the timed region, HIP events"},
+            "roofline_bruteforce_knn_mfma": {
+                "kernel": "knn_f16_kernel (all n*m pairs: split-f16 filter on v_mfma_f32_32x32x16_f16 + exact float32 refine; the same indices)", "bound": "mfma",
+                "achieved": 4.0 * flops_bf / (bfm_ms * 1e-3) / 1e12 if bfm_ms else None, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": 4.0 * flops_bf / (bfm_ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS if bfm_ms else None,
+                "achieved_note": "EXECUTED f16 flops: one 32x32x16 MFMA (32768 flop) per 1024 pairs = 32 flop per pair, four times SURVEY 8d's algorithmic 8",
+                "algorithmic_tflops": flops_bf / (bfm_ms * 1e-3) / 1e12 if bfm_ms else None,
+                "algorithmic_frac_of_f32_peak": flops_bf / (bfm_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS if bfm_ms else None,
+                "speedup_vs_valu_kernel": bf_ms / bfm_ms if (bf_ms and bfm_ms) else None,
+                "avg_launch_ms": bfm_ms, "second_filter_pass_fraction_of_queries": f16_again,
+                "bound_note": "the launch is bound by the VECTOR work beside the matrix pipe -- 8 v_min3 per MFMA for the lane-local minima + 2 of bookkeeping, and vector "
+                              "and matrix instructions of one SIMD do not overlap here (scripts/ubench/mfma_valu_overlap.hip: 28 + 2.2 V cycles per MFMA with V vector "
+                              "instructions) -- and by the clock the chip holds under it (1.77 GHz); matrix-pipe busy 37 % of the kernel (SQ_VALU_MFMA_BUSY_CYCLES, "
+                              "profiles/r04_knn_f16_c3_pmc.txt)",
+                "measured": "3 extra launches outside the timed region, HIP events"},
             "finite": sane,
         }
+        if ev_ms["knn"] and ev_ms["accumulate"] and not brute:
+            cf = max(k for k in getattr(icp, "sweep_resort", (0, 1, 2, 3)) if k < K) if certified is not None else K
+            classes = {"full_search": list(range(0, min(cf, K))), "certifying_search": [cf] if cf < K else [], "certified": list(range(cf + 1, K))}
+            line["ms_by_iteration_class"] = {
+                nm: {"iterations": ks, "search_ms_mean": round(sum(ev_ms["knn"][k] for k in ks) / len(ks), 4),
+                     "accumulate_ms_mean": round(sum(ev_ms["accumulate"][k] for k in ks) / len(ks), 4)} for nm, ks in classes.items() if ks}
+            line["ms_by_iteration_class"]["note"] = ("HIP events of the last timed call; certified: the search launch is the guard (one wave per unit, re-searches units with many "
+                                                     "spent budgets), the accumulate also searches the single queries whose budget is spent")
         for nm, key in (("knn", "roofline_knn"), ("accumulate", "roofline_accumulate"), ("accumulate_bwd", "roofline_streaming")):
             if nm != top:
                 line[key] = legs[nm]

@@ -33,13 +33,29 @@ class OracleICP:
 
 def worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
-    torch.set_num_threads(2)
+    torch.set_num_threads(2 if world <= 2 else 1)
     import bench
+    from dicp_amd import dist as ddist
+    gathers, real = [], ddist.gather_poses_async
+
+    def counted(*a, **kw):              # the data path's one collective: counted per call of bench.run_call
+        gathers.append(1)
+        return real(*a, **kw)
+    ddist.gather_poses_async = counted
+    calls, run = [], bench.run_call
+
+    def counted_call(*a, **kw):
+        before = len(gathers)
+        res = run(*a, **kw)
+        calls.append(len(gathers) - before)
+        return res
+    bench.run_call = counted_call
     lines = []
     rc = bench.main(["--gpus", str(world), "--steps", str(K), "--warmup", "1", "--batch", str(B), "--points", str(N_PTS), "--reps", "5",
                      "--no-cpu-baseline", "--no-extra-legs"],
                     make_icp=lambda **kw: OracleICP(out_dir, **kw), device=torch.device("cpu"), backend="gloo", emit=lines.append)
     assert rc == 0
+    assert calls and set(calls) == {1}, calls                       # ONE pose all-gather per icp() + backward(), nothing else on the data path
     with open(os.path.join(out_dir, "line_%d.json" % rank), "w") as f:
         f.write("".join(lines))
 
@@ -71,3 +87,39 @@ def test_bench_two_rank_dry_run(tmp_path):
     for g in range(world):
         want, _ = make_pairs(B, N_PTS, N_PTS, seed=3, dtype=torch.float32, first=g * B)
         assert open(tmp_path / ("clouds_%d.txt" % g)).read() == hashlib.sha256(want.numpy().tobytes()).hexdigest()
+
+
+def test_bench_eight_rank_dry_run(tmp_path):
+    """BASELINE configs[4]'s launch shape -- 8 ranks of one node -- on gloo: the line says 8 ranks were seen, every rank drew its own clouds
+    (first = rank * B), `value` is the whole job's, and each timed call made exactly one all-gather (asserted inside the workers)."""
+    from dicp_amd.synthetic import make_pairs
+    world = 8
+    mp.spawn(worker, args=(world, free_port(), str(tmp_path)), nprocs=world, join=True)
+    line = json.loads(open(tmp_path / "line_0.json").read())
+    assert all(open(tmp_path / ("line_%d.json" % r)).read() == "" for r in range(1, world))
+    assert line["n_gpus"] == 8 and line["ranks_seen"] == 8 and "x8" in line["config"]["parallelism"] and line["scaling"] == "weak"
+    med = sorted(line["call_ms"])[2]
+    assert abs(line["value"] - world * B * K / (med * 1e-3)) <= 1e-4 * line["value"]
+    assert len(line["call_ms_by_rank"]) == world
+    seen = set()
+    for g in range(world):
+        want, _ = make_pairs(B, N_PTS, N_PTS, seed=3, dtype=torch.float32, first=g * B)
+        digest = open(tmp_path / ("clouds_%d.txt" % g)).read()
+        assert digest == hashlib.sha256(want.numpy().tobytes()).hexdigest()
+        seen.add(digest)
+    assert len(seen) == world                                           # eight different shards
+
+
+def test_bench_refuses_a_rank_count_the_node_does_not_have(monkeypatch):
+    """--gpus N on a node with fewer devices, or a process group of another size, stops before anything is timed."""
+    import pytest
+    import bench
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "0")
+    with pytest.raises(SystemExit, match="launch with"):
+        bench.main(["--gpus", "8"], device=torch.device("cpu"))
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(SystemExit, match="this node shows 1 device"):
+        bench.main(["--gpus", "2"], device=None)

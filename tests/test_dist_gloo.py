@@ -87,7 +87,8 @@ def test_shard_bounds():
     assert ddist.gather_poses(torch.eye(4).repeat(3, 1, 1)).shape == (3, 4, 4)    # no process group: identity
 
 
-@pytest.mark.parametrize("total,world,sizes", [(5, 2, [3, 2]), (4, 2, [2, 2]), (5, 3, [2, 2, 1]), (2, 3, [1, 1, 0])])
+@pytest.mark.parametrize("total,world,sizes", [(5, 2, [3, 2]), (4, 2, [2, 2]), (5, 3, [2, 2, 1]), (2, 3, [1, 1, 0]),
+                                               (11, 8, [2, 2, 2, 1, 1, 1, 1, 1])])      # BASELINE configs[4]'s rank count, unequal shards
 def test_gloo_ranks_match_single_process(tmp_path, total, world, sizes):
     mp.spawn(worker, args=(world, free_port(), total, str(tmp_path)), nprocs=world, join=True)
     src, tgt = make_pairs(total, 96, 128, seed=4, dtype=torch.float64)
@@ -96,7 +97,7 @@ def test_gloo_ranks_match_single_process(tmp_path, total, world, sizes):
     assert [int(np.load(tmp_path / ("n_local_%d.npy" % r))) for r in range(world)] == sizes
     for r in range(1, world):                            # every rank holds the whole batch's poses, in cloud order
         np.testing.assert_array_equal(a, np.load(tmp_path / ("T_all_%d.npy" % r)))
-    np.testing.assert_allclose(a, ref, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(a, ref, rtol=0, atol=1e-11)       # (the oracle's batched CPU kernels round differently at other batch sizes: 2e-12)
 
 
 @pytest.mark.parametrize("total,world,grad_mode", [(5, 2, "slice"), (2, 3, "slice"), (4, 2, "reduce_scatter")])

@@ -43,28 +43,30 @@ class ICP:
         self.diff = differentiable
         # ICP.py:40-44
         self.nn = nn(self.diff, use_gumbel=fun['gumbel'], eps=fun['gumbel_eps'], tau=fun['gumbel_tau'])
-        # build-specific knob (not in the reference): which kNN kernel the loop uses
-        self.knn_variant = _lib.KNN_AUTO      # _lib.KNN_VALU | KNN_MFMA (brute force) | KNN_SWEEP (exact, slab-pruned)
-        self.knn_stats = {}                   # "knn_pairs": pairs scored by the last call's sweep kNN (device int64 shards: .sum())
-        self._hints = CallHints()             # private: what this object's earlier calls tell later ones about time (per device, stream and shape)
-        self.bwd_window = True                # sweep path: sorted-space backward (LDS windows); False: row atomics
-        self.small_loop = True                # small clouds: one block per cloud runs whole chunks of iterations
-        self.sweep_resort = (0, 1, 2, 3)      # iterations at which the sweep re-orders its queries by x under the current pose
-        self.cert_from = None                 # iteration of the certifying search (None: the last re-ordering of the queries)
-        self.reuse_matches = True             # sweep path: search only where a match is not PROVEN unchanged since the last search (exact)
-        self.cert_sets = True                 # ... and where a match has a runner-up within rounding, a set of 4 candidate rows is certified and re-scored (same results)
-        self.cert_hint = True                 # ... a shape whose clouds all switched them off for good is searched plainly in the next calls
-        self.cert_backoff = True              # ... switched off per cloud, on device, where proving costs more than searching (same results)
-        self.first_search = True              # sweep path: iteration 0's search is enqueued with the index build, before the loop state is prepared
-        self.plan_call = True                 # constant-iteration calls: every segment of the loop behind one library call (dicp_icp_forward_plan)
+        # Build-specific attributes (not in the reference).  Every one leaves the RESULTS as they are; they choose among exact forms.
+        self.knn_variant = _lib.KNN_AUTO      # which search the loop uses: _lib.KNN_AUTO | KNN_VALU | KNN_MFMA (brute force) | KNN_SWEEP (exact, slab-pruned)
+        self.knn_stats = {}                   # OUTPUT: statistics of the last call ("knn_pairs": pairs scored by its sweep searches, device int64 shards: .sum(); ...)
+        self.reuse_matches = True             # sweep path: match certificates -- search only where a match is not PROVEN unchanged since the last search
+        self.bwd_window = True                # sweep path: backward in sorted space (LDS windows); False: row atomics
         # backward: an iteration whose normal-equation cotangent has decayed below this fraction of the cloud's largest adds nothing above
         # rounding and does no per-point work for that cloud (None: 2^-22 float32 / 2^-40 float64; 0: every iteration, like autograd)
         self.bwd_skip_eps = None
-        self.bwd_tail = True                  # ... and its ended iterations run as one launch, placed by where the previous call's sweeps ended
         # tolerance mode: iterations enqueued between two host checks of "all converged" (ICP.py:259).  None = auto:
         # every iteration for big batches (an iteration costs far more than a sync), every 4th for small ones
         # (converged clouds are frozen, so the extra iterations change nothing and the histories are trimmed)
         self.sync_every = None
+        # Private switches of single mechanisms, all on: what the tests flip to hold each mechanism to the path without it (and what the
+        # measurements in DESIGN.md A/B'd).  Not part of the call surface.
+        self._tuning = dict(
+            small_loop=True,                  # small clouds: one block per cloud runs whole chunks of iterations
+            sweep_resort=(0, 1, 2, 3),        # iterations at which the sweep re-orders its queries by x under the current pose
+            cert_from=None,                   # iteration of the certifying search (None: the last re-ordering of the queries)
+            cert_sets=True,                   # a match with a runner-up within rounding keeps a set of 4 candidate rows, re-scored per iteration
+            cert_hint=True,                   # a shape whose clouds all switched their certificates off is searched plainly in the next calls
+            cert_backoff=True,                # certificates are switched off per cloud, on device, where proving costs more than searching
+            first_search=True,                # iteration 0's search is enqueued with the index build, before the loop state is prepared
+            plan_call=True,                   # constant-iteration calls: every segment of the loop behind one library call (dicp_icp_forward_plan)
+            bwd_tail=True)                    # the ended iterations of the truncated reverse sweep run as one launch
         self._timing_events = None
 
     def icp(self, source, target, T_init, weight=None, trim_dist=None, loss_fn=None, dim=3):
@@ -117,7 +119,7 @@ class ICP:
             source = source.contiguous()
             # (... and the first search right behind it, unless the loop will want original indices -- the atomic backward -- or carries timing events)
             prebuilt = prebuild_search(source, target, self.knn_variant, wants_grad and bool(self.bwd_window), T_init, src_rows, tgt_rows,
-                                       first_search=bool(self.first_search) and self._timing_events is None and not (wants_grad and not self.bwd_window))
+                                       first_search=bool(self._tuning["first_search"]) and self._timing_events is None and not (wants_grad and not self.bwd_window))
         cfg = LoopConfig(
             icp_type=self.icp_type, differentiable=bool(self.diff), max_iterations=int(self.max_iterations),
             tolerance=float(self.tolerance), trim_dist=trim_dist, loss_name=loss_name,
@@ -126,9 +128,10 @@ class ICP:
             tanh_steepness=float(self.config['dICP']['parameters']['tanh_steepness']),   # ICP.py:119
             match_ratio_thresh=float(self.match_ratio_thresh),
             knn_variant=self.knn_variant, bwd_window=bool(self.bwd_window), stats_out=self.knn_stats, hints=self._hints,
-            sync_every=self.sync_every, timing_events=self._timing_events, prebuilt=prebuilt, small_loop=bool(self.small_loop),
-            src_rows=src_rows, tgt_rows=tgt_rows, sweep_resort=tuple(int(v) for v in self.sweep_resort), reuse_matches=bool(self.reuse_matches), cert_from=self.cert_from,
-            bwd_skip_eps=self.bwd_skip_eps, cert_backoff=bool(self.cert_backoff), cert_sets=bool(self.cert_sets), cert_hint=bool(self.cert_hint), plan_call=bool(self.plan_call), bwd_tail=bool(self.bwd_tail),
+            sync_every=self.sync_every, timing_events=self._timing_events, prebuilt=prebuilt, small_loop=bool(self._tuning["small_loop"]),
+            src_rows=src_rows, tgt_rows=tgt_rows, sweep_resort=tuple(int(v) for v in self._tuning["sweep_resort"]), reuse_matches=bool(self.reuse_matches), cert_from=self._tuning["cert_from"],
+            bwd_skip_eps=self.bwd_skip_eps, cert_backoff=bool(self._tuning["cert_backoff"]), cert_sets=bool(self._tuning["cert_sets"]), cert_hint=bool(self._tuning["cert_hint"]),
+            plan_call=bool(self._tuning["plan_call"]), bwd_tail=bool(self._tuning["bwd_tail"]),
             # nn.py:14-16 via ICP.py:140: soft correspondences -- the same library loop with dicp_gumbel_nn in place of the search, the same one node
             gumbel=(self.nn.eps, self.nn.tau, getattr(self.nn, "_inject_U", None)) if (self.nn.differentiable and self.nn.use_gumbel) else None)
         T, pc, deltas, weights, costs, converged, iterations, matched = ICPLoop.apply(source.contiguous(), target.contiguous(), T_init, w_pts, cfg)

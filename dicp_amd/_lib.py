@@ -12,7 +12,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("DICP_HIP_LIB") or os.path.join(_HERE, "libdicp_hip.so")   # env override: A/B builds
 SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("dicp_kernels.hip", "knn_f16.hip")]
-HEADERS = [os.path.join(_HERE, "csrc", f) for f in ("dicp_math.h", "dicp_common.h", "dicp_internal.h")] + [os.path.join(_ROOT, "include", "dicp_hip.h")]
+HEADERS = ([os.path.join(_HERE, "csrc", f) for f in ("dicp_math.h", "dicp_common.h", "dicp_internal.h")]
+           + [os.path.join(_HERE, "csrc", "kernels_%s.h" % f) for f in ("setup", "search", "setup_sort", "rows", "accumulate", "backward", "soft_svd", "host")]
+           + [os.path.join(_ROOT, "include", "dicp_hip.h")])
 
 F32, F64 = 0, 1
 PT2PT, PT2PL = 0, 1

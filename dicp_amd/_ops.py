@@ -536,7 +536,7 @@ class CallHints:
                     rec[4] = True       # (looked at)
                     if int(rec[0][rec[3]]) != 0:
                         raise TailTimeout("dicp_amd: a wait of an earlier backward pass's one-launch tail ran out (the GPU was kept full by other work for "
-                                          "~0.5 s); the gradients of that pass were poisoned with NaN.  Re-run it, or set ICP.bwd_tail = False")
+                                          "~0.5 s); the gradients of that pass were poisoned with NaN.  Re-run it, or set ICP._tuning['bwd_tail'] = False")
 
 
 CERT_MIN_WORK = 2.0e6        # certified point-iterations (iterations after the certifying search x N x n) below which match certificates are not used

@@ -1,4 +1,4 @@
-"""A/B on one box: query re-order schedule of the sweep (ICP.sweep_resort), whole call fwd+bwd at the headline shape."""
+"""A/B on one box: query re-order schedule of the sweep (ICP._tuning["sweep_resort"]), whole call fwd+bwd at the headline shape."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dicp_amd.ICP import ICP
@@ -8,7 +8,7 @@ src, tgt = make_pairs(B, n, n, seed=3)
 src, tgt = src.cuda(), tgt.cuda()
 T0 = torch.eye(4, device="cuda").repeat(B, 1, 1)
 def bench(resort, K, cert_from=None):
-    icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12); icp.const_iter = True; icp.sweep_resort = resort; icp.cert_from = cert_from
+    icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12); icp.const_iter = True; icp._tuning["sweep_resort"] = resort; icp._tuning["cert_from"] = cert_from
     def call():
         s, t = src.detach().requires_grad_(True), tgt.detach().requires_grad_(True)
         icp.icp(s, t, T0, trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0})["T"].sum().backward()

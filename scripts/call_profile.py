@@ -16,13 +16,13 @@ T0 = torch.eye(4, device="cuda").repeat(B, 1, 1)
 TOL = os.environ.get("DICP_TOL")            # DICP_TOL=1e-4: a tolerance-mode call (up to K iterations, const_iter off)
 icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=float(TOL) if TOL else 1e-12); icp.const_iter = TOL is None
 icp.reuse_matches = os.environ.get("DICP_REUSE", "1") == "1"          # (DICP_REUSE=0: search everything in every iteration)
-icp.cert_backoff = os.environ.get("DICP_BACKOFF", "1") == "1"
+icp._tuning["cert_backoff"] = os.environ.get("DICP_BACKOFF", "1") == "1"
 for _ in range(calls):
     s, t = src.detach().requires_grad_(True), tgt.detach().requires_grad_(True)
     out = icp.icp(s, t, T0, trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0})
     out["T"].sum().backward()
     torch.cuda.synchronize()
-print("certificates %s, per-cloud switch %s; off for %s clouds" % (icp.reuse_matches, icp.cert_backoff, int(icp.knn_stats["certs_off"].sum()) if "certs_off" in icp.knn_stats else None))
+print("certificates %s, per-cloud switch %s; off for %s clouds" % (icp.reuse_matches, icp._tuning["cert_backoff"], int(icp.knn_stats["certs_off"].sum()) if "certs_off" in icp.knn_stats else None))
 K = int(out["deltas"].shape[1])
 pairs = float(icp.knn_stats["knn_pairs"].sum().item()) / K / (float(B) * n * n)
 again = icp.knn_stats.get("searched_again")

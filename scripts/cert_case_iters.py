@@ -9,7 +9,7 @@ import test_gpu_configs as TG
 src, tgt, K = TG._cert_case(sys.argv[1], torch.float32)
 N, n = src.shape[0], src.shape[1]
 icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12); icp.const_iter = True
-icp.knn_variant, icp.cert_hint = _lib.KNN_SWEEP, False
+icp.knn_variant, icp._tuning["cert_hint"] = _lib.KNN_SWEEP, False
 out = icp.icp(src.cuda(), tgt.cuda(), torch.eye(4).cuda().repeat(N, 1, 1), **TG.KW); torch.cuda.synchronize()
 a = icp.knn_stats["searched_again"]
 print(sys.argv[1], "N", N, "n", n, "K", K, "units per cloud", (n + 127) // 128)

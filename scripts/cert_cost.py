@@ -10,7 +10,7 @@ import test_gpu_configs as TG
 def fwd_ms(src, tgt, K, reuse, backoff):
     N = src.shape[0]
     icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12); icp.const_iter = True
-    icp.knn_variant, icp.reuse_matches, icp.cert_backoff = _lib.KNN_SWEEP, reuse, backoff
+    icp.knn_variant, icp.reuse_matches, icp._tuning["cert_backoff"] = _lib.KNN_SWEEP, reuse, backoff
     s, t, T0 = src.cuda(), tgt.cuda(), torch.eye(4).cuda().repeat(N, 1, 1)
     ts = []
     for _ in range(8):

@@ -8,7 +8,7 @@ def bench(B, n, typ, K, resort, reps=15):
     src, tgt = make_pairs(B, n, n, seed=3)
     src, tgt = src.cuda(), (tgt[:, :, :3].contiguous() if typ == "pt2pt" else tgt).cuda()
     T0 = torch.eye(4, device="cuda").repeat(B, 1, 1)
-    icp = ICP(icp_type=typ, differentiable=True, max_iterations=K, tolerance=1e-12); icp.const_iter = True; icp.sweep_resort = resort
+    icp = ICP(icp_type=typ, differentiable=True, max_iterations=K, tolerance=1e-12); icp.const_iter = True; icp._tuning["sweep_resort"] = resort
     kw = dict(trim_dist=5.0) if typ == "pt2pt" else dict(trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0})
     def call():
         s, t = src.detach().requires_grad_(True), tgt.detach().requires_grad_(True)

@@ -86,7 +86,7 @@ def test_certified_loop_equals_searching_everything(c):
 @pytest.mark.parametrize("seed,N,n,K,icp_type,dtype", [(11, 12, 16384, 10, "pt2pl", torch.float32), (12, 7, 8192, 14, "pt2pt", torch.float32),
                                                        (13, 5, 12000, 9, "pt2pl", torch.float64), (14, 20, 16384, 8, "pt2pl", torch.float32)])
 def test_candidate_sets_on_planar_scenes(seed, N, n, K, icp_type, dtype):
-    """Planar scenes are where matches have runner-ups within the scores' rounding (dense surfaces): with candidate sets (ICP.cert_sets) such queries are
+    """Planar scenes are where matches have runner-ups within the scores' rounding (dense surfaces): with candidate sets (ICP._tuning["cert_sets"]) such queries are
     re-scored among four certified rows instead of searched.  Poses, weights, costs and the transformed cloud bit for bit those of searching every query
     in every iteration, gradients to rounding -- and the sets really are in use (single-query searches collapse after the iteration that makes them)."""
     from dicp_amd.synthetic import make_scene_pairs

@@ -508,7 +508,8 @@ def test_certificates_switch_themselves_off_where_they_cost_more(kind, sets):
     outs = {}
     for name, reuse, backoff in (("plain", False, True), ("certs", True, False), ("switch", True, True)):
         icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
-        icp.const_iter, icp.reuse_matches, icp.cert_backoff, icp.knn_variant, icp.cert_sets = True, reuse, backoff, _lib.KNN_SWEEP, sets
+        icp.const_iter, icp.reuse_matches, icp.knn_variant = True, reuse, _lib.KNN_SWEEP
+        icp._tuning.update(cert_backoff=backoff, cert_sets=sets)
         S, Tg = src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True)
         out = icp.icp(S, Tg, torch.eye(4, device=DEV).repeat(N, 1, 1), **KW)
         out["T"].sum().backward()
@@ -523,7 +524,7 @@ def test_certificates_switch_themselves_off_where_they_cost_more(kind, sets):
     if kind == "random":
         assert int(off.sum()) == 0, off.tolist()                        # certificates pay on these clouds: they stay on
     elif sets:
-        # candidate sets (ICP.cert_sets, the default): a query whose match has a runner-up inside the scores' rounding keeps its 4 best rows and a budget from
+        # candidate sets (ICP._tuning["cert_sets"], the default): a query whose match has a runner-up inside the scores' rounding keeps its 4 best rows and a budget from
         # the best row outside them -- re-scored per iteration, not searched: the certificates pay on these clouds too and (mostly) stay on
         again = outs["switch"][3]["searched_again"]
         singles = again[:, 64:].sum(1).tolist()
@@ -584,7 +585,7 @@ def test_graphed_call_is_the_eager_call(B, n, icp_type):
 
 @pytest.mark.parametrize("const_iter,grad", [(True, True), (False, True), (True, False)])
 def test_first_search_ahead_of_the_loop_changes_nothing(const_iter, grad):
-    """ICP.first_search: iteration 0's search is enqueued with the index build, before the loop's state exists (dicp_loop_buffers.first_search_done),
+    """ICP._tuning["first_search"]: iteration 0's search is enqueued with the index build, before the loop's state exists (dicp_loop_buffers.first_search_done),
     so that the GPU works while the host prepares the call.  Same search under the same pose and query order: every output bit for bit, with and
     without it, in the one-call plan, the per-segment (tolerance) path and the no-gradient path."""
     N, n = 12, 16384
@@ -592,7 +593,7 @@ def test_first_search_ahead_of_the_loop_changes_nothing(const_iter, grad):
     res = []
     for early in (True, False):
         icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=9, tolerance=1e-12 if const_iter else 1e-4)
-        icp.const_iter, icp.first_search = const_iter, early
+        icp.const_iter, icp._tuning["first_search"] = const_iter, early
         S, Tg = src.to(DEV).requires_grad_(grad), tgt.to(DEV).requires_grad_(grad)
         out = icp.icp(S, Tg, torch.eye(4, device=DEV).repeat(N, 1, 1), **KW)
         if grad:

@@ -974,7 +974,7 @@ def test_small_cloud_kernels_equal_multi_kernel_loop(dtype, icp_type, N, n, m, c
         icp = ICP(icp_type=icp_type, differentiable=True, max_iterations=9, tolerance=1e-12 if const_iter else (1e-7 if dtype == torch.float64 else 1e-4))
         icp.const_iter = const_iter
         icp.sync_every = 2
-        icp.small_loop = small
+        icp._tuning["small_loop"] = small
         out = icp.icp(sd, td if icp_type == "pt2pl" else td[:, :, :3], T0, weight=wd, trim_dist=4.0, loss_fn={"name": "huber", "metric": 0.7})
         (out["T"][:, :3].sum() + out["pc"].mean()).backward()
         outs.append((out, sd.grad, td.grad, wd.grad, T0.grad))

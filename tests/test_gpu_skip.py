@@ -191,7 +191,7 @@ def test_tail_launch_changes_no_gradient(dtype, N, n, K, icp_type, weights):
 
     def make(tail):
         icp = ICP(icp_type=icp_type, differentiable=True, max_iterations=K, tolerance=1e-12)
-        icp.const_iter, icp.bwd_tail = True, tail
+        icp.const_iter, icp._tuning["bwd_tail"] = True, tail
         return icp
     ref_icp = make(False)
     ref = _tail_call(ref_icp, src, tgt, w)
@@ -238,7 +238,7 @@ def test_tail_launch_on_ragged_lists_and_in_tolerance_mode():
         grads = {}
         for tail in (False, True):
             icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=12 if mode == "ragged" else 30, tolerance=1e-12 if mode == "ragged" else 1e-5)
-            icp.const_iter, icp.bwd_tail = mode == "ragged", tail
+            icp.const_iter, icp._tuning["bwd_tail"] = mode == "ragged", tail
             for rep in range(3):        # (the later calls have the earlier ones' hints; the third one's is made to place the tail high)
                 if tail and rep == 2:
                     entry = icp._hints.newest_tail

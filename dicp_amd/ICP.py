@@ -67,6 +67,7 @@ class ICP:
             first_search=True,                # iteration 0's search is enqueued with the index build, before the loop state is prepared
             plan_call=True,                   # constant-iteration calls: every segment of the loop behind one library call (dicp_icp_forward_plan)
             bwd_tail=True)                    # the ended iterations of the truncated reverse sweep run as one launch
+        self._hints = CallHints()             # private: what this object's earlier calls tell later ones about time (per device, stream and shape)
         self._timing_events = None
 
     def icp(self, source, target, T_init, weight=None, trim_dist=None, loss_fn=None, dim=3):

@@ -187,8 +187,7 @@ __device__ __forceinline__ half8 f16_query_fragment(const float* nx, float s, in
 __device__ __forceinline__ float f16_sqrt_up(float v) { return __builtin_amdgcn_sqrtf(v) * 1.00001f + 1e-18f; }
 
 // 2E in the filter's own (scaled) units for a query whose smallest filter value is b1 (scaled); < 0: no bound (exact scan)
-__device__ __forceinline__ float f16_margin(const float* nx, float b1, const float* __restrict__ mt) {
-    const float s = mt[FM_S], inv_s2 = mt[FM_INV_S2];
+__device__ __forceinline__ float f16_margin(const float* nx, float b1, float s, float inv_s2, float phi, float hphi) {
     const float x1 = fabsf(nx[0]) + fabsf(nx[1]) + fabsf(nx[2]);
     const float hx = 0.5f * (nx[0] * nx[0] + nx[1] * nx[1] + nx[2] * nx[2]);
     const float b1u = b1 * inv_s2;
@@ -198,9 +197,12 @@ __device__ __forceinline__ float f16_margin(const float* nx, float b1, const flo
     const float X2 = f16_sqrt_up(2.f * hx);
     const float Y = X2 + f16_sqrt_up(2.f * Dup);
     const float Tup = X2 * Y + 0.5f * Y * Y;
-    const float E = (F16_CREL * F16_U * Tup + mt[FM_PHI] * (x1 + 1.7321f * Y) + mt[FM_HPHI]) * 1.01f;
+    const float E = (F16_CREL * F16_U * Tup + phi * (x1 + 1.7321f * Y) + hphi) * 1.01f;
     if (!(4.f * E <= slack) || !(E < __builtin_huge_valf())) return -1.f;      // (also NaN / inf: a query outside the f16 range)
     return 2.f * E * (s * s) * 1.0001f;
+}
+__device__ __forceinline__ float f16_margin(const float* nx, float b1, const float* __restrict__ mt) {
+    return f16_margin(nx, b1, mt[FM_S], mt[FM_INV_S2], mt[FM_PHI], mt[FM_HPHI]);
 }
 
 // v_min / v_max on values that are never signalling NaNs (the compiler's fminf / fmaxf canonicalise both inputs first: two more instructions each)
@@ -657,12 +659,14 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_f16_sweep_kernel(const float*
         return (sl >= 0 && sl < F16_NTC) ? rowcache[wave][sl * WAVE + (rr & 63)] : tg[rr];
     };
     // ---- refine.  A piece = the 2 x 16 rows of one (tile, lane half): rows 64 t + 32 a + 16 h + i, a = 0, 1
+    // Written for latency: a wave passes here once, with three others per SIMD at best to hide behind -- so no scratch memory (register arrays
+    // are only ever indexed by constants), the cloud's constants in scalar registers, and the rows of a query fetched eight at a time.
     const int32_t* __restrict__ pm = tperm + (size_t)cloud * m_pad;
     const int nfar = ((const int32_t*)mt)[FM_NFAR];
     SweepBest best[F16_G];
     float thr[F16_G];
-    int n_scan = 0, my_unsure = 0, my_scan = 0;
-    int run0[F16_G], run1[F16_G], ncands[F16_G];        // this lane's rows to re-score per query: up to two runs of 16 (-1: none)
+    int run0[F16_G], run1[F16_G];       // this lane's rows to re-score per query: up to two runs of 16 (-1: none)
+    int n_scan = 0, my_unsure = 0, my_scan = 0, ties = 0;       // (ties: bit g = this query's rows are taken again by the careful loop below)
 #pragma unroll
     for (int g = 0; g < F16_G; ++g) {
         const F16Track me = tr[g];
@@ -677,43 +681,42 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_f16_sweep_kernel(const float*
         const float B2 = second_lo ? lo.b2 : hi.b1;
         const int c1 = lo.id1, h1 = lo_h, c2 = second_lo ? lo.id2 : hi.id1, h2 = second_lo ? lo_h : hi_h;
         const float B3 = second_lo ? __builtin_fminf(lo.b3, hi.b1) : __builtin_fminf(lo.b2, hi.b2);
-        const float margin = f16_margin(nx[g], B1, mt);
+        const float margin = f16_margin(nx[g], B1, s, inv_s2, phi, hphi);
         const bool bounded = ((q_ok >> g) & 1) && (B1 < __builtin_huge_valf()) && (B1 > -__builtin_huge_valf()) && margin >= 0.f;
         const int ncand = !bounded ? 0 : (B2 - B1 > margin ? 1 : (B3 - B1 > margin ? 2 : 3));
-        ncands[g] = ncand;
         best[g].v = __builtin_huge_valf(); best[g].s = 0; best[g].o = 0x7fffffff;
         thr[g] = B1 + margin;
         run0[g] = run1[g] = -1;
         if (ncand == 1) run0[g] = c1 * 64 + 32 * kh + 16 * h1;                            // the winner's piece, half each
         else if (ncand == 2) { const int cc = kh ? c2 : c1, hh = kh ? h2 : h1; run0[g] = cc * 64 + 16 * hh; run1[g] = run0[g] + 32; }
+        if (ncand == 3 && qi[g] >= 0) my_unsure |= 1 << g;
+        if (ncand == 0 && qi[g] >= 0 && kh == 0) my_scan |= 1 << g;
     }
-    // the rows of all four queries are fetched four at a time each (16 loads in flight per lane instead of a chain of dependent gathers), from the
-    // wave's LDS cache where their tile is in it.  Strict < in ascending sorted position; an EQUAL score only raises a flag
-    int ties = 0;
-#pragma unroll 1
-    for (int rn = 0; rn < 2; ++rn) {
-        if (rn == 1 && !__any(run1[0] >= 0 || run1[1] >= 0 || run1[2] >= 0 || run1[3] >= 0)) break;
-#pragma unroll 1
-        for (int kb = 0; kb < 16; kb += 4) {
-            float4 rw[F16_G][4];
+    // the rows, out of the wave's LDS cache (a run outside it is flagged for the careful loop).  Strict < in ascending sorted position; an
+    // EQUAL score only raises the flag: ties go by the lowest ORIGINAL index, which the careful loop looks up
 #pragma unroll
-            for (int g = 0; g < F16_G; ++g) {
-                const int r0 = rn ? run1[g] : run0[g];
+    for (int g = 0; g < F16_G; ++g) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) rw[g][k] = row_at(min(max(r0, 0) + kb + k, m_pad - 1));
-            }
+        for (int rn = 0; rn < 2; ++rn) {
+            const int r0 = rn ? run1[g] : run0[g];
+            if (rn == 1 && !__any(r0 >= 0)) continue;               // (second runs: near-ties only)
+            const int sl = (max(r0, 0) >> 6) - tc0;
+            const bool cached = sl >= 0 && sl < F16_NTC;
+            if (r0 >= 0 && !cached) ties |= 1 << g;
+            const float4* __restrict__ rp = &rowcache[wave][min(max(sl, 0), F16_NTC - 1) * WAVE + (max(r0, 0) & 63)];
 #pragma unroll
-            for (int g = 0; g < F16_G; ++g) {
-                const int r0 = rn ? run1[g] : run0[g];
+            for (int kb = 0; kb < 16; kb += 8) {
+                float4 rw[8];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int rr = r0 + kb + k;
-                    float sc = score<float, float4>(nx[g], rw[g][k]);
-                    sc = (r0 >= 0 && rr < m) ? sc : __builtin_huge_valf();
+                for (int k = 0; k < 8; ++k) rw[k] = rp[kb + k];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float sc = score<float, float4>(nx[g], rw[k]);
+                    sc = (r0 >= 0 && cached && r0 + kb + k < m) ? sc : __builtin_huge_valf();
                     ties |= (sc == best[g].v && sc < __builtin_huge_valf()) ? (1 << g) : 0;
                     const bool lt = sc < best[g].v;
                     best[g].v = lt ? sc : best[g].v;
-                    best[g].s = lt ? rr : best[g].s;
+                    best[g].s = lt ? r0 + kb + k : best[g].s;
                 }
             }
         }
@@ -748,11 +751,9 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_f16_sweep_kernel(const float*
     }
 #pragma unroll
     for (int g = 0; g < F16_G; ++g) {
-        const int ncand = ncands[g];
         if (!((ties >> g) & 1) && best[g].v < __builtin_huge_valf()) best[g].o = -1;      // (original index not looked up yet)
-        if (ncand == 1 || ncand == 2) sweep_merge(best[g], __shfl_xor(best[g].v, 32), __shfl_xor(best[g].s, 32), __shfl_xor(best[g].o, 32), pm);
-        if (ncand == 3 && qi[g] >= 0) my_unsure |= 1 << g;
-        if (ncand == 0 && qi[g] >= 0 && kh == 0) my_scan |= 1 << g;
+        // (one or two candidate pieces: the query's two lanes hold a part each.  Lanes of a pair took the same branch: their tracks were merged)
+        if (__any(run0[g] >= 0)) sweep_merge(best[g], __shfl_xor(best[g].v, 32), __shfl_xor(best[g].s, 32), __shfl_xor(best[g].o, 32), pm);
     }
     // queries the filter has no bound for: every visited row, 64 at a time (such a wave never pruned: it visited every tile)
     if (__any(my_scan != 0)) {

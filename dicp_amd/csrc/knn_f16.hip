@@ -205,6 +205,15 @@ __device__ __forceinline__ float f16_margin(const float* nx, float b1, const flo
     return f16_margin(nx, b1, mt[FM_S], mt[FM_INV_S2], mt[FM_PHI], mt[FM_HPHI]);
 }
 
+// the value the lane 32 away holds (a query's two lanes are l and l ^ 32): v_permlane32_swap exchanges the upper half of one register with the lower
+// half of another inside the vector unit -- the generic shuffle goes through the LDS crossbar (ds_bpermute), a hundred cycles of latency each time
+__device__ __forceinline__ unsigned swap32(unsigned v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);      // r[0] = {lower, lower}, r[1] = {upper, upper} of v
+    return (threadIdx.x & 32) ? r[0] : r[1];
+}
+__device__ __forceinline__ float swap32(float v) { return __uint_as_float(swap32(__float_as_uint(v))); }
+__device__ __forceinline__ int swap32(int v) { return (int)swap32((unsigned)v); }
+
 // v_min / v_max on values that are never signalling NaNs (the compiler's fminf / fmaxf canonicalise both inputs first: two more instructions each)
 __device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
@@ -344,8 +353,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_f16_kernel(const float* __res
         // (and lane halves) of the first two
         const F16Track me = tr[g];
         F16Track ot;
-        ot.b1 = __shfl_xor(me.b1, 32); ot.b2 = __shfl_xor(me.b2, 32); ot.b3 = __shfl_xor(me.b3, 32);
-        ot.id1 = __shfl_xor(me.id1, 32); ot.id2 = __shfl_xor(me.id2, 32);
+        ot.b1 = swap32(me.b1); ot.b2 = swap32(me.b2); ot.b3 = swap32(me.b3);
+        ot.id1 = swap32(me.id1); ot.id2 = swap32(me.id2);
         // (lo, hi): lo holds the smaller b1 (lane half 0 on equal values: any consistent choice -- equal values are a near-tie anyway)
         const bool me_lo = me.b1 < ot.b1 || (me.b1 == ot.b1 && kh == 0);
         const F16Track lo = me_lo ? me : ot, hi = me_lo ? ot : me;
@@ -368,8 +377,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_f16_kernel(const float* __res
             for (int c = 0; c < F16_CHT; ++c) rescore(nx[g], (cc * F16_CHT + c) * 32 + hh * 16, 16, bv[g], bj[g]);
         }
         if (ncand == 1 || ncand == 2) {
-            const float ov = __shfl_xor(bv[g], 32);
-            const int oj = __shfl_xor(bj[g], 32);
+            const float ov = swap32(bv[g]);
+            const int oj = swap32(bj[g]);
             if (ov < bv[g] || (ov == bv[g] && oj < bj[g])) { bv[g] = ov; bj[g] = oj; }
         }
         if (ncand == 3 && i < n) my_unsure |= 1 << g;
@@ -443,8 +452,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_f16_kernel(const float* __res
             __syncthreads();
         }
         {   // the query's two lanes merge; the result goes back to the lanes that own the query
-            const float ov = __shfl_xor(v2, 32);
-            const int oj = __shfl_xor(j2, 32);
+            const float ov = swap32(v2);
+            const int oj = swap32(j2);
             if (ov < v2 || (ov == v2 && oj < j2)) { v2 = ov; j2 = oj; }
         }
         for (int e = 0; e < have; ++e) {
@@ -625,7 +634,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_f16_sweep_kernel(const float*
         // (a query's best so far is the smaller of its two lanes' -- each lane sees half of every tile's rows)
         float dreq = -__builtin_huge_valf();
 #pragma unroll
-        for (int g = 0; g < F16_G; ++g) dreq = vmax(dreq, fmaf(vmin(tr[g].b1, __shfl_xor(tr[g].b1, 32)), kA, k0[g]));
+        for (int g = 0; g < F16_G; ++g) dreq = vmax(dreq, fmaf(vmin(tr[g].b1, swap32(tr[g].b1)), kA, k0[g]));
         const float dx = right ? edge - xmax : xmin - edge;
         return __all(dx > 0.f && 0.5f * dx * dx > dreq) != 0;       // (inf thresholds: never)
     };
@@ -671,8 +680,8 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_f16_sweep_kernel(const float*
     for (int g = 0; g < F16_G; ++g) {
         const F16Track me = tr[g];
         F16Track ot;
-        ot.b1 = __shfl_xor(me.b1, 32); ot.b2 = __shfl_xor(me.b2, 32); ot.b3 = __shfl_xor(me.b3, 32);
-        ot.id1 = __shfl_xor(me.id1, 32); ot.id2 = __shfl_xor(me.id2, 32);
+        ot.b1 = swap32(me.b1); ot.b2 = swap32(me.b2); ot.b3 = swap32(me.b3);
+        ot.id1 = swap32(me.id1); ot.id2 = swap32(me.id2);
         const bool me_lo = me.b1 < ot.b1 || (me.b1 == ot.b1 && kh == 0);
         const F16Track lo = me_lo ? me : ot, hi = me_lo ? ot : me;
         const int lo_h = me_lo ? kh : (kh ^ 1), hi_h = lo_h ^ 1;
@@ -692,33 +701,48 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_f16_sweep_kernel(const float*
         if (ncand == 3 && qi[g] >= 0) my_unsure |= 1 << g;
         if (ncand == 0 && qi[g] >= 0 && kh == 0) my_scan |= 1 << g;
     }
-    // the rows, out of the wave's LDS cache (a run outside it is flagged for the careful loop).  Strict < in ascending sorted position; an
-    // EQUAL score only raises the flag: ties go by the lowest ORIGINAL index, which the careful loop looks up
+    // the rows, out of the wave's LDS cache (a run outside it is flagged for the careful loop).  Per run of 16 rows: the scores (independent), their
+    // minimum as a tree, the first and the last row that has it -- a serial compare-and-select chain over the rows was three times the instructions,
+    // and a wave's instruction count is what this part of the kernel costs.  Rows past the cloud's own are pad rows (score +inf) by construction.
+    // Two rows with the minimum (duplicated targets) only raise the flag: ties go by the lowest ORIGINAL index, which the careful loop looks up.
 #pragma unroll
     for (int g = 0; g < F16_G; ++g) {
 #pragma unroll
         for (int rn = 0; rn < 2; ++rn) {
             const int r0 = rn ? run1[g] : run0[g];
-            if (rn == 1 && !__any(r0 >= 0)) continue;               // (second runs: near-ties only)
+            if (!__any(r0 >= 0)) continue;                          // (second runs: near-ties only)
             const int sl = (max(r0, 0) >> 6) - tc0;
             const bool cached = sl >= 0 && sl < F16_NTC;
-            if (r0 >= 0 && !cached) ties |= 1 << g;
+            const bool far_run = r0 >= 0 && !cached;                // (a lane whose run is not in the cache gathers it from the sorted rows themselves)
             const float4* __restrict__ rp = &rowcache[wave][min(max(sl, 0), F16_NTC - 1) * WAVE + (max(r0, 0) & 63)];
+            float sc[16];
 #pragma unroll
             for (int kb = 0; kb < 16; kb += 8) {
                 float4 rw[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) rw[k] = rp[kb + k];
+                if (__any(far_run)) {
+                    if (far_run) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    float sc = score<float, float4>(nx[g], rw[k]);
-                    sc = (r0 >= 0 && cached && r0 + kb + k < m) ? sc : __builtin_huge_valf();
-                    ties |= (sc == best[g].v && sc < __builtin_huge_valf()) ? (1 << g) : 0;
-                    const bool lt = sc < best[g].v;
-                    best[g].v = lt ? sc : best[g].v;
-                    best[g].s = lt ? r0 + kb + k : best[g].s;
+                        for (int k = 0; k < 8; ++k) rw[k] = tg[r0 + kb + k];        // (r0 + 15 < m_pad: a run lies inside its tile)
+                    }
                 }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sc[kb + k] = score<float, float4>(nx[g], rw[k]);
             }
+            float mn = __builtin_fminf(sc[0], sc[1]);
+#pragma unroll
+            for (int k = 2; k < 16; k += 2) mn = __builtin_fminf(__builtin_fminf(mn, sc[k]), sc[k + 1]);
+            int first = 15, last = 0;
+#pragma unroll
+            for (int k = 14; k >= 0; --k) first = (sc[k] == mn) ? k : first;
+#pragma unroll
+            for (int k = 1; k < 16; ++k) last = (sc[k] == mn) ? k : last;
+            const bool use = r0 >= 0 && mn < __builtin_huge_valf();
+            if (use && (first != last || mn == best[g].v)) ties |= 1 << g;
+            const bool lt = use && mn < best[g].v;
+            best[g].v = lt ? mn : best[g].v;
+            best[g].s = lt ? r0 + first : best[g].s;
         }
     }
     // The rare paths below run over the four B tiles in a LOOP (one copy of the code, the tile's values picked with selects): unrolled four times they
@@ -753,7 +777,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_f16_sweep_kernel(const float*
     for (int g = 0; g < F16_G; ++g) {
         if (!((ties >> g) & 1) && best[g].v < __builtin_huge_valf()) best[g].o = -1;      // (original index not looked up yet)
         // (one or two candidate pieces: the query's two lanes hold a part each.  Lanes of a pair took the same branch: their tracks were merged)
-        if (__any(run0[g] >= 0)) sweep_merge(best[g], __shfl_xor(best[g].v, 32), __shfl_xor(best[g].s, 32), __shfl_xor(best[g].o, 32), pm);
+        if (__any(run0[g] >= 0)) sweep_merge(best[g], swap32(best[g].v), swap32(best[g].s), swap32(best[g].o), pm);
     }
     // queries the filter has no bound for: every visited row, 64 at a time (such a wave never pruned: it visited every tile)
     if (__any(my_scan != 0)) {
@@ -818,7 +842,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_f16_sweep_kernel(const float*
                     for (int k = 0; k < 16; ++k) { const int rr = t * 32 + 16 * kh + k; if (rr < m) sweep_consider(w, q, tg[rr], rr, pm); }
                 }
             }
-            sweep_merge(w, __shfl_xor(w.v, 32), __shfl_xor(w.s, 32), __shfl_xor(w.o, 32), pm);
+            sweep_merge(w, swap32(w.v), swap32(w.s), swap32(w.o), pm);
 #pragma unroll 1
             for (int e = 0; e < have; ++e) {
                 const int slot = qslot[wave][e];

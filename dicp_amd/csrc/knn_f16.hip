@@ -52,6 +52,7 @@ constexpr float F16_CREL = 32.f;
 // register order (result register i of lane half h is MFMA row (i & 3) + 8 (i >> 2) + 4 h)
 __device__ __forceinline__ int f16_row_of(int rho) { return ((rho >> 2) & 1) * 16 + (rho >> 3) * 4 + (rho & 3); }
 
+constexpr int F16_SCALE_THREADS = 1024;      // one block per cloud: three passes over its rows, 16 rows per thread and pass at 16384
 __device__ __forceinline__ float block_max(float v, float* red) {
 #pragma unroll
     for (int o = WAVE / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
@@ -59,14 +60,14 @@ __device__ __forceinline__ float block_max(float v, float* red) {
     if ((threadIdx.x & (WAVE - 1)) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
     float r = red[0];
-    for (int w = 1; w < BLOCK / WAVE; ++w) r = fmaxf(r, red[w]);
+    for (int w = 1; w < F16_SCALE_THREADS / WAVE; ++w) r = fmaxf(r, red[w]);
     return r;
 }
 
 // per cloud: the scale and the far rows.  One block per cloud.
-__global__ __launch_bounds__(BLOCK) void knn_f16_scale_kernel(const float4* __restrict__ rows4, const int32_t* __restrict__ tgt_rows, int m_full, int m_pad,
+__global__ __launch_bounds__(F16_SCALE_THREADS) void knn_f16_scale_kernel(const float4* __restrict__ rows4, const int32_t* __restrict__ tgt_rows, int m_full, int m_pad,
                                                               float* __restrict__ meta_all) {
-    __shared__ float red[BLOCK / WAVE];
+    __shared__ float red[F16_SCALE_THREADS / WAVE];
     __shared__ int s_cnt;
     const int cloud = blockIdx.x, tid = threadIdx.x;
     const int m = min(max(rows_of(tgt_rows, cloud, m_full), 1), m_pad);
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(BLOCK) void knn_f16_scale_kernel(const float4* __re
                __float_as_uint(v.w) == __float_as_uint(p.w);
     };
     float mx = 0.f;
-    for (int r = tid; r < m; r += BLOCK) mx = fmaxf(mx, row_max(r));
+    for (int r = tid; r < m; r += F16_SCALE_THREADS) mx = fmaxf(mx, row_max(r));
     const float Minf = block_max(mx, red);
     // the extent WITHOUT the rows beyond Minf / 16, and how many those are
     if (tid == 0) s_cnt = 0;
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(BLOCK) void knn_f16_scale_kernel(const float4* __re
     const float cut = Minf * 0.0625f;
     float m2 = 0.f;
     int above = 0;
-    for (int r = tid; r < m; r += BLOCK) { const float v = row_max(r); if (v > cut) above += repeats(r) ? 0 : 1; else m2 = fmaxf(m2, v); }
+    for (int r = tid; r < m; r += F16_SCALE_THREADS) { const float v = row_max(r); if (v > cut) above += repeats(r) ? 0 : 1; else m2 = fmaxf(m2, v); }
     if (above) atomicAdd(&s_cnt, above);
     const float M2 = block_max(m2, red);
     const int cnt = s_cnt;
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(BLOCK) void knn_f16_scale_kernel(const float4* __re
     if (tid == 0) s_cnt = 0;
     __syncthreads();
     if (use_far)
-        for (int r = tid; r < m; r += BLOCK)
+        for (int r = tid; r < m; r += F16_SCALE_THREADS)
             if (row_max(r) > cut && !repeats(r)) { const int slot = atomicAdd(&s_cnt, 1); if (slot < F16_FAR_MAX) mi[FM_FAR0 + slot] = r; }
     __syncthreads();
     if (tid == 0) {
@@ -900,7 +901,7 @@ int knn_f16_pack(const void* rows4, const int32_t* tgt_rows, int N, int m_full, 
     float* meta = (float*)((char*)image + knn_f16_meta_offset(N, m_pad));
     float* edges = (float*)((char*)image + knn_f16_edges_offset(N, m_pad));
     begin_launch();
-    knn_f16_scale_kernel<<<N, BLOCK, 0, st>>>((const float4*)rows4, tgt_rows, m_full, m_pad, meta);
+    knn_f16_scale_kernel<<<N, F16_SCALE_THREADS, 0, st>>>((const float4*)rows4, tgt_rows, m_full, m_pad, meta);
     knn_f16_image_kernel<<<dim3((tiles + BLOCK / WAVE - 1) / (BLOCK / WAVE), N), BLOCK, 0, st>>>((const float4*)rows4, tgt_rows, m_full, m_pad, m_img, meta, (uint4*)image, tiles, N, edges);
     return launch_status();
 }

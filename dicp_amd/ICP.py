@@ -17,7 +17,7 @@ import os.path as osp
 import torch
 import yaml
 
-from . import _lib
+from . import _call, _lib
 from ._ops import CallHints, ICPLoop, KabschLoop, LoopConfig, compute_device, prebuild_search, transform_points
 from .nn import nn
 
@@ -66,7 +66,8 @@ class ICP:
             cert_backoff=True,                # certificates are switched off per cloud, on device, where proving costs more than searching
             first_search=True,                # iteration 0's search is enqueued with the index build, before the loop state is prepared
             plan_call=True,                   # constant-iteration calls: every segment of the loop behind one library call (dicp_icp_forward_plan)
-            bwd_tail=True)                    # the ended iterations of the truncated reverse sweep run as one launch
+            bwd_tail=True,                    # the ended iterations of the truncated reverse sweep run as one launch
+            one_call=True)                    # calls that need none of the loop's host decisions: one library call per direction (dicp_call_*)
         self._hints = CallHints()             # private: what this object's earlier calls tell later ones about time (per device, stream and shape)
         self._timing_events = None
 
@@ -113,14 +114,12 @@ class ICP:
 
         loss_name = loss_fn['name'] if loss_fn is not None else None     # 'trim' is a valid loss too (loss.py:15-16)
         # the target sort / index build of the sweep path goes to the GPU before the rest of this function's host work
-        prebuilt = None
-        if not (self.nn.differentiable and self.nn.use_gumbel):
+        soft = bool(self.nn.differentiable and self.nn.use_gumbel)
+        if not soft:
             target = target.contiguous()
-            wants_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (source, target, T_init, w_pts) if t is not None)
             source = source.contiguous()
-            # (... and the first search right behind it, unless the loop will want original indices -- the atomic backward -- or carries timing events)
-            prebuilt = prebuild_search(source, target, self.knn_variant, wants_grad and bool(self.bwd_window), T_init, src_rows, tgt_rows,
-                                       first_search=bool(self._tuning["first_search"]) and self._timing_events is None and not (wants_grad and not self.bwd_window))
+        wants_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (source, target, T_init, w_pts) if t is not None)
+        first_search = bool(self._tuning["first_search"]) and self._timing_events is None and not (wants_grad and not self.bwd_window)
         cfg = LoopConfig(
             icp_type=self.icp_type, differentiable=bool(self.diff), max_iterations=int(self.max_iterations),
             tolerance=float(self.tolerance), trim_dist=trim_dist, loss_name=loss_name,
@@ -129,13 +128,22 @@ class ICP:
             tanh_steepness=float(self.config['dICP']['parameters']['tanh_steepness']),   # ICP.py:119
             match_ratio_thresh=float(self.match_ratio_thresh),
             knn_variant=self.knn_variant, bwd_window=bool(self.bwd_window), stats_out=self.knn_stats, hints=self._hints,
-            sync_every=self.sync_every, timing_events=self._timing_events, prebuilt=prebuilt, small_loop=bool(self._tuning["small_loop"]),
+            sync_every=self.sync_every, timing_events=self._timing_events, small_loop=bool(self._tuning["small_loop"]),
             src_rows=src_rows, tgt_rows=tgt_rows, sweep_resort=tuple(int(v) for v in self._tuning["sweep_resort"]), reuse_matches=bool(self.reuse_matches), cert_from=self._tuning["cert_from"],
             bwd_skip_eps=self.bwd_skip_eps, cert_backoff=bool(self._tuning["cert_backoff"]), cert_sets=bool(self._tuning["cert_sets"]), cert_hint=bool(self._tuning["cert_hint"]),
-            plan_call=bool(self._tuning["plan_call"]), bwd_tail=bool(self._tuning["bwd_tail"]),
+            plan_call=bool(self._tuning["plan_call"]), bwd_tail=bool(self._tuning["bwd_tail"]), first_search=first_search,
             # nn.py:14-16 via ICP.py:140: soft correspondences -- the same library loop with dicp_gumbel_nn in place of the search, the same one node
-            gumbel=(self.nn.eps, self.nn.tau, getattr(self.nn, "_inject_U", None)) if (self.nn.differentiable and self.nn.use_gumbel) else None)
-        T, pc, deltas, weights, costs, converged, iterations, matched = ICPLoop.apply(source.contiguous(), target.contiguous(), T_init, w_pts, cfg)
+            gumbel=(self.nn.eps, self.nn.tau, getattr(self.nn, "_inject_U", None)) if soft else None)
+        T_c = T_init.contiguous()
+        if self._tuning["one_call"] and _call.eligible(cfg, source, target, T_c, w_pts, wants_grad):
+            # a call that needs none of the loop's host decisions: one library call per direction on one allocation (dicp_call_forward / _backward)
+            T, pc, deltas, weights, costs, converged, iterations, matched = _call.CallLoop.apply(source, target, T_c, w_pts, cfg)
+        else:
+            # the target sort / index build of the sweep path goes to the GPU before the rest of the host work
+            # (... and the first search right behind it, unless the loop will want original indices -- the atomic backward -- or carries timing events)
+            if not soft:
+                cfg.prebuilt = prebuild_search(source, target, self.knn_variant, wants_grad and bool(self.bwd_window), T_init, src_rows, tgt_rows, first_search=first_search)
+            T, pc, deltas, weights, costs, converged, iterations, matched = ICPLoop.apply(source.contiguous(), target.contiguous(), T_init, w_pts, cfg)
 
         if per_cloud_w:
             # an (N,1) weight stays (N,1) in the reference, so its "matches at the start" (ICP.py:248,269: sum over dim 1 of

@@ -1,0 +1,196 @@
+"""One eager ICP call behind ONE library call per direction (include/dicp_hip.h, dicp_call_*).
+
+A mid-size call of the sweep path -- 32 clouds x 4096 points x 10 iterations is 0.55 ms of kernels -- spent more time than that in the interpreter,
+which prepared ~30 buffers and ~12 library calls per direction (dicp_amd/_ops.py, ICPLoop).  For the calls that need none of ICPLoop's host decisions
+(dense batch, constant iteration count, sorted sweep, no match certificates, every history in one slab) the same sequence of launches is made by
+dicp_call_forward / dicp_call_backward on ONE allocation each; this module allocates, hands out the results as views and keeps autograd's books.
+Every other call takes ICPLoop.  The two give the same results bit for bit (tests/test_gpu_call.py).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from . import _ops
+from ._ops import _DT, _on, _p, _stream
+
+MAX_POINTS = 1 << 20        # source points of a batch up to which a call is taken here: beyond, the kernels outlast the host anyway, and ICPLoop
+                            # frees the search structure at the end of the call where this path's one allocation lives as long as any result does
+_PLANS = {}      # (dtype, shape, ...) -> (Call prototype values, CallLayout): dicp_call_plan asked once per shape
+
+
+def eligible(cfg, source, target, T_init, w0, need_grad):
+    """True when ICPLoop would run this call as: sweep search, one dicp_icp_forward_plan, no certificates, windowed backward -- and nothing else."""
+    if cfg.gumbel is not None or not cfg.const_iter or cfg.timing_events is not None or cfg.src_rows is not None or cfg.tgt_rows is not None:
+        return False
+    if not cfg.plan_call or (cfg.knn_variant & 0xff00) or (need_grad and not cfg.bwd_window):
+        return False
+    dt = source.dtype
+    if dt not in _DT or not (source.is_cuda and target.is_cuda and T_init.is_cuda) or target.dtype != dt or T_init.dtype != dt:
+        return False
+    if not (source.is_contiguous() and target.is_contiguous() and T_init.is_contiguous()) or (w0 is not None and not (w0.is_cuda and w0.is_contiguous() and w0.dtype == dt)):
+        return False
+    N, n, _ = source.shape
+    m, c = target.shape[1], target.shape[2]
+    if N * n > MAX_POINTS or N * m > 4 * MAX_POINTS:
+        return False
+    if tuple(T_init.shape) != (N, 4, 4) or c != (6 if cfg.icp_type == "pt2pl" else 3):
+        return False
+    kind = cfg.knn_variant & 0xff
+    if kind == _lib.KNN_AUTO:
+        kind = _ops.auto_knn_kind(N, n, m)
+    if kind != _lib.KNN_SWEEP:
+        return False
+    Kmax = int(cfg.max_iterations)
+    resorts = [k for k in cfg.sweep_resort if 0 <= k < Kmax]
+    if len([k for k in resorts if k > 0]) >= _lib.MAX_SEGMENTS:
+        return False
+    cert_from = (max(resorts) if resorts else 0) if cfg.cert_from is None else max(0, int(cfg.cert_from))
+    if cfg.reuse_matches and Kmax - 1 - cert_from >= 3 and float(Kmax - 1 - cert_from) * N * n >= _ops.CERT_MIN_WORK:
+        return False                # match certificates pay from there on: ICPLoop's business
+    if _ops.F16_SWEEP and dt == torch.float32 and float(N) * n >= _ops.F16_SWEEP_MIN_QUERIES and m >= _ops.F16_SWEEP_MIN_TARGETS:
+        return False                # the matrix-core scoring of big problems
+    if _ops.HIST_CHUNK_BYTES // max(1, N * n * max(source.element_size(), 4)) < Kmax:
+        return False                # histories in several slabs
+    return not torch.cuda.is_current_stream_capturing()
+
+
+def _plan(code, N, n, m, c, K, dim, need_grad, resort, flags):
+    key = (code, N, n, m, c, K, dim, need_grad, resort, flags)
+    got = _PLANS.get(key)
+    if got is None:
+        call = _lib.Call(N=N, n=n, m=m, c=c, K=K, dim=dim, need_grad=need_grad, n_resort=len(resort), flags=flags)
+        for i, k in enumerate(resort):
+            call.resort[i] = k
+        lay = _lib.CallLayout()
+        _lib.check(_lib.load().dicp_call_plan(code, ctypes.byref(call), ctypes.byref(lay)), "dicp_call_plan")
+        if len(_PLANS) > 256:
+            _PLANS.clear()
+        got = _PLANS[key] = lay
+    return got
+
+
+class CallLoop(torch.autograd.Function):
+    """ICPLoop's contract (same inputs, same eight outputs, same gradients) for the calls `eligible` admits."""
+
+    @staticmethod
+    def forward(ctx, source, target, T_init, w0, cfg):
+        lib = _lib.load()
+        dev, dt = source.device, source.dtype
+        code, es = _DT[dt], source.element_size()
+        N, n, _ = source.shape
+        m, c = target.shape[1], target.shape[2]
+        K = int(cfg.max_iterations)
+        need_grad = int(any(ctx.needs_input_grad[:4]))
+        stats = cfg.stats_out
+        if stats is not None:
+            for key in ("knn_pairs", "searched_again", "budgets", "bwd_live", "certs_off"):
+                stats.pop(key, None)
+        ctx.set_materialize_grads(False)
+        resort = tuple(sorted(set(k for k in cfg.sweep_resort if 0 < k < K)))
+        flags = (_lib.CALL_FIRST_SEARCH if cfg.first_search else 0) | (0 if cfg.small_loop else _lib.CALL_NO_SMALL_LOOP)
+        L = _plan(code, N, n, m, c, K, int(cfg.dim), need_grad, resort, flags)
+        P = cfg.params()
+        with _on(dev):
+            ws = torch.empty((L.total // es,), dtype=dt, device=dev)
+            # (the two differentiable results are tensors of their own: autograd refuses the backward pass of a view whose base has been edited, and
+            #  the other results -- views of the workspace -- are the caller's to edit)
+            T = torch.empty((N, 4, 4), dtype=dt, device=dev)
+            pc = torch.empty((N, n, 3), dtype=dt, device=dev)
+            call = _lib.Call(T_out=T.data_ptr(), pc_out=pc.data_ptr(), src=source.data_ptr(), tgt=target.data_ptr(), T_init=T_init.data_ptr(), w0=w0.data_ptr() if w0 is not None else None,
+                             N=N, n=n, m=m, c=c, K=K, dim=int(cfg.dim), need_grad=need_grad, n_resort=len(resort), flags=flags,
+                             directions=int(_ops.FRAME_DIRECTIONS), quantum=_ops.CENTER_QUANTUM, tolerance=float(cfg.tolerance), workspace=ws.data_ptr())
+            for i, k in enumerate(resort):
+                call.resort[i] = k
+            _lib.check(lib.dicp_call_forward(code, ctypes.byref(P), ctypes.byref(call), _stream()), "dicp_call_forward")
+        view = ws.as_strided
+        deltas = view((N, K, 6), (6 * K, 6, 1), L.deltas // es)
+        weights = view((N, K, n), (K * n, n, 1), L.weights // es)
+        costs = view((N, K), (K, 1), L.costs // es)
+        iterations = view((N,), (1,), L.iterations // es)
+        matched = view((N,), (1,), L.matched_ratio // es)
+        conv = ws[L.converged // es:L.converged // es + (N + es - 1) // es].view(torch.uint8)[:N].bool()
+        if stats is not None:
+            stats["knn_pairs"] = ws[L.pairs // es:L.pairs // es + _lib.PAIR_SHARDS * 8 // es].view(torch.int64)
+        if need_grad:
+            # (the workspace is kept as it is -- the reverse sweep reads poses, steps, matches and the sorted rows out of it -- not through
+            #  save_for_backward: the non-differentiable results are views of it, and a caller who edits the weights in place must not be refused
+            #  its backward pass.  Of those results the reverse sweep reads `deltas` only.)
+            ctx.save_for_backward(source, target, w0)
+            ctx.ws, ctx.call, ctx.cfg, ctx.P, ctx.L = ws, call, cfg, P, L
+        ctx.mark_non_differentiable(deltas, weights, costs, conv, iterations, matched)
+        return T, pc, deltas, weights, costs, conv, iterations, matched
+
+    @staticmethod
+    def backward(ctx, gT, gpc, *_unused):
+        src, tgt, w0 = ctx.saved_tensors
+        cfg, P, call, FL = ctx.cfg, ctx.P, ctx.call, ctx.L
+        lib = _lib.load()
+        dev, dt = src.device, src.dtype
+        code, es = _DT[dt], src.element_size()
+        N, n, _ = src.shape
+        m = tgt.shape[1]
+        K = call.K
+        stats = cfg.stats_out
+        want_tgt, want_w = bool(ctx.needs_input_grad[1]), bool(ctx.needs_input_grad[3] and w0 is not None)
+        with _on(dev):
+            st = _stream()
+            gsrc_pc = None
+            if gpc is not None:         # pc = C_K p + r_K: its cotangent reaches the source directly and the pose through T
+                gsrc_pc = torch.empty_like(src)
+                pcp = torch.empty((N, FL.nblk, _lib.NBWD_PAD), dtype=dt, device=dev)
+                pose_K = ctx.ws.as_strided((N, 12), (12, 1), FL.poses // es + K * N * 12)
+                _lib.check(lib.dicp_transform_points_bwd(code, _p(src), _p(pose_K), _p(gpc.contiguous()), _p(gsrc_pc), _p(pcp), N, n, st), "dicp_transform_points_bwd")
+                gT_pc = _ops._pose_sums_to_gT(pcp, N, dt, dev, st)
+                gT = gT_pc if gT is None else gT + gT_pc
+            L = _lib.CallBackwardLayout()
+            _lib.check(lib.dicp_call_backward_plan(code, ctypes.byref(P), ctypes.byref(call), int(want_tgt), int(want_w), ctypes.byref(L)), "dicp_call_backward_plan")
+            eps = cfg.bwd_skip_eps
+            if eps is None:
+                eps = 2.0 ** -22 if dt == torch.float32 else 2.0 ** -40
+            if cfg.loss_name == "huber" and not cfg.differentiable:
+                eps = 0.0
+            ws = torch.empty((L.total // es,), dtype=dt, device=dev)
+            live = ws[L.live // es:L.live // es + (K + 1 + (es // 4) - 1) * 4 // es].view(torch.int32)[:K + 1]
+            if stats is not None and eps > 0.0:
+                stats["bwd_live"] = live
+            # where the sweeps of the previous call of this shape ended decides which iterations go to the one launch (ICPLoop.backward)
+            tail_from, hints, entry = 0, None, None
+            use_tail = eps > 0.0 and cfg.bwd_tail and cfg.hints is not None
+            if use_tail:
+                cfg.hints.check()
+                hints = cfg.hints.tail_records(dev, (N, n, m, K, dt))
+                hint = next((h for h in reversed(hints) if h[2] == (N, n, K) and h[1].query()), None)
+                if hint is not None and L.nblk_w <= lib.dicp_bwd_tail_max_blocks(code):
+                    counts = hint[0][:K].tolist()
+                    tail_from = min(K, max(0, next((k for k in range(K) if counts[k] * 8 >= N), K) - 1))
+                if len(hints) >= 4:         # four pinned buffers in rotation
+                    if hints[0][1].query() and hints[0][0].numel() >= K + 1:
+                        cfg.hints.check()
+                        entry = hints.pop(0)
+                else:
+                    entry = [torch.empty((max(K + 1, 64),), dtype=torch.int32).pin_memory(), None, None, K, False, 0]
+            if stats is not None:
+                stats["bwd_tail_from"] = int(tail_from)
+                if tail_from > 0:
+                    a0 = L.arrive // es
+                    stats["bwd_tail_error"] = ws[a0:a0 + (N + 1 + (es // 4) - 1) * 4 // es].view(torch.int32)[N:N + 1]
+            gsrc = torch.empty_like(src)
+            gtgt = torch.empty_like(tgt) if want_tgt else None
+            gw = torch.empty_like(w0) if want_w else None
+            gT0 = torch.empty((N, 4, 4), dtype=dt, device=dev)
+            gTc = gT.contiguous() if gT is not None else None
+            G = _lib.CallGrads(gT=gTc.data_ptr() if gTc is not None else None, gsrc=gsrc.data_ptr(), gtgt=gtgt.data_ptr() if want_tgt else None,
+                               gT0=gT0.data_ptr(), gw=gw.data_ptr() if want_w else None, workspace=ws.data_ptr(), skip_eps=float(eps), tail_from=int(tail_from),
+                               live_host=entry[0].data_ptr() if entry is not None else None)
+            _lib.check(lib.dicp_call_backward(code, ctypes.byref(P), ctypes.byref(call), ctypes.byref(G), st), "dicp_call_backward")
+            if entry is not None:
+                entry[1] = torch.cuda.Event()
+                entry[1].record()
+                cfg.hints.serial += 1
+                entry[2], entry[3], entry[4], entry[5] = (N, n, K), K, False, cfg.hints.serial
+                hints.append(entry)
+                cfg.hints.newest_tail = entry
+            if gsrc_pc is not None:
+                gsrc += gsrc_pc
+        return gsrc, gtgt, gT0, gw, None

@@ -11,7 +11,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("DICP_HIP_LIB") or os.path.join(_HERE, "libdicp_hip.so")   # env override: A/B builds
-SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("dicp_kernels.hip", "knn_f16.hip")]
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("dicp_kernels.hip", "knn_f16.hip", "dicp_call.hip")]
 HEADERS = ([os.path.join(_HERE, "csrc", f) for f in ("dicp_math.h", "dicp_common.h", "dicp_internal.h")]
            + [os.path.join(_HERE, "csrc", "kernels_%s.h" % f) for f in ("setup", "search", "setup_sort", "rows", "accumulate", "backward", "soft_svd", "host")]
            + [os.path.join(_ROOT, "include", "dicp_hip.h")])
@@ -22,7 +22,7 @@ LOSS_NONE, LOSS_HUBER, LOSS_CAUCHY, LOSS_TRIM = 0, 1, 2, 3
 KNN_AUTO, KNN_VALU, KNN_MFMA, KNN_SWEEP, KNN_GUMBEL = 0, 1, 2, 3, 4
 NACC_PAD, NBWD_PAD, KAB_SAVE = 32, 16, 40
 PAIR_SHARDS, SWEEP_SRC_SORTED = 64, 0x100      # DICP_PAIR_SHARDS, DICP_SWEEP_SRC_SORTED
-ABI_VERSION = 6
+ABI_VERSION = 7
 _ERRORS = {1: "null pointer", 2: "bad shape/stride", 3: "unsupported dtype", 4: "bad enum value", 5: "misaligned buffer"}
 
 vp, i32, i64, f64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
@@ -70,6 +70,37 @@ class SegmentPlan(ctypes.Structure):
     """dicp_segment_plan (include/dicp_hip.h)."""
     _fields_ = [("nseg", i32), ("k0", i32 * MAX_SEGMENTS), ("k1", i32 * MAX_SEGMENTS), ("new_order", i32 * MAX_SEGMENTS),
                 ("cert_from", i32), ("pad0", i32), ("order", vp * MAX_SEGMENTS), ("keys", vp), ("cert_q", vp), ("cert_qu", vp), ("cert_count", vp), ("cert_cloud", vp), ("cert_set", vp)]
+
+
+class Call(ctypes.Structure):
+    """dicp_call (include/dicp_hip.h)."""
+    _fields_ = [("src", vp), ("tgt", vp), ("T_init", vp), ("w0", vp), ("N", i32), ("n", i32), ("m", i32), ("c", i32), ("K", i32), ("dim", i32), ("need_grad", i32),
+                ("n_resort", i32), ("resort", i32 * MAX_SEGMENTS), ("flags", i32), ("directions", i32), ("quantum", f64), ("tolerance", f64), ("workspace", vp), ("T_out", vp), ("pc_out", vp)]
+
+
+_sz = ctypes.c_size_t
+
+
+class CallLayout(ctypes.Structure):
+    """dicp_call_layout (include/dicp_hip.h)."""
+    _fields_ = ([(k, _sz) for k in ("total", "zeroed", "T", "pc", "deltas", "weights", "costs", "converged", "iterations", "matched_ratio", "pairs", "n_matched", "counters",
+                                    "poses", "poses_search", "alive", "areg", "n_start", "partials", "tgs4", "tperm", "bucket", "brange", "keys", "tgt_sorted", "scratch",
+                                    "scratch_bytes", "frame", "pose_s", "orders", "spos")]
+                + [("n_orders", i32), ("m_pad", i32), ("nblk", i32), ("pad0", i32)])
+
+
+class CallGrads(ctypes.Structure):
+    """dicp_call_grads (include/dicp_hip.h)."""
+    _fields_ = [("gT", vp), ("gsrc", vp), ("gtgt", vp), ("gT0", vp), ("gw", vp), ("workspace", vp), ("skip_eps", f64), ("tail_from", i32), ("pad0", i32), ("live_host", vp)]
+
+
+class CallBackwardLayout(ctypes.Structure):
+    """dicp_call_backward_layout (include/dicp_hip.h)."""
+    _fields_ = ([(k, _sz) for k in ("total", "zeroed", "live", "arrive", "mref", "decisions", "far", "gpose", "gtmp", "src_s", "w_s", "gsrc_s", "gw_s", "slab", "gs", "gb",
+                                    "partials", "tail_partials")] + [("nblk_w", i32), ("pad0", i32)])
+
+
+CALL_FIRST_SEARCH, CALL_NO_SMALL_LOOP, CALL_NBKT = 1, 2, 1024
 
 
 class KabschBuffers(ctypes.Structure):
@@ -128,6 +159,10 @@ _SIGNATURES = {
     "dicp_transform_points_bwd": ([i32, vp, vp, vp, vp, vp, i32, i32, vp], ctypes.c_int),
     "dicp_loss_weight": ([i32, i32, i32, f64, f64, vp, i64, i32, vp, vp], ctypes.c_int),
     "dicp_loss_weight_bwd": ([i32, i32, i32, f64, f64, vp, vp, i64, i32, vp, vp], ctypes.c_int),
+    "dicp_call_plan": ([i32, ctypes.POINTER(Call), ctypes.POINTER(CallLayout)], ctypes.c_int),
+    "dicp_call_forward": ([i32, ctypes.POINTER(WeightParams), ctypes.POINTER(Call), vp], ctypes.c_int),
+    "dicp_call_backward_plan": ([i32, ctypes.POINTER(WeightParams), ctypes.POINTER(Call), i32, i32, ctypes.POINTER(CallBackwardLayout)], ctypes.c_int),
+    "dicp_call_backward": ([i32, ctypes.POINTER(WeightParams), ctypes.POINTER(Call), ctypes.POINTER(CallGrads), vp], ctypes.c_int),
 }
 EXPORTS = tuple(_SIGNATURES)
 

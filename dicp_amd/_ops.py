@@ -568,6 +568,7 @@ class LoopConfig:
     gumbel: object = None         # (eps, tau, inject_U or None): the Gumbel-softmax correspondence (nn.py:43-70) instead of the nearest neighbour
     bwd_tail: bool = True         # truncated reverse sweep: the iterations before the ones the previous call still worked at run as ONE launch (dicp_loop_buffers.bwd_tail_from)
     plan_call: bool = True        # constant-iteration sweep calls: all segments behind one library call (dicp_icp_forward_plan)
+    first_search: bool = True     # sweep path: iteration 0's search is enqueued right behind the index build
     cert_hint: bool = True        # a shape whose clouds ALL ended a call with their certificates switched off is searched plainly for the next 32 calls
     cert_sets: bool = True        # a query whose match has a runner-up within the scores' rounding keeps a SET of 4 candidate rows, re-scored per iteration instead of searched
     cert_backoff: bool = True     # match certificates are switched off per cloud, on device, when a certified iteration costs more than 60 % of a full search

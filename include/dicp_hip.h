@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define DICP_ABI_VERSION 6   /* 6: dicp_bwd_tail_max_blocks (the one-launch tail only where a cloud's blocks are all resident; a wait that runs out poisons the
+#define DICP_ABI_VERSION 7   /* 7: dicp_call_* (one eager call of the sweep path behind one host call per direction).
+                                6: dicp_bwd_tail_max_blocks (the one-launch tail only where a cloud's blocks are all resident; a wait that runs out poisons the
                                 cloud's gradients with NaN and raises bwd_live[K] next to bwd_tail_arrive[N]); bwd_live is (K + 1).
                                 5: dicp_loop_buffers.bwd_tail_from (the ended iterations of the truncated reverse sweep as one launch).
                                 4: dicp_loop_buffers.bwd_skip / bwd_mref / bwd_live / bwd_skip_eps (truncated reverse sweep of dicp_icp_backward); cert_cloud (per-cloud switch of the
@@ -553,6 +554,66 @@ int dicp_loss_weight(int dtype, int loss, int differentiable, double metric, dou
                      const void* err, int64_t rows, int r, void* w, void* stream);
 int dicp_loss_weight_bwd(int dtype, int loss, int differentiable, double metric, double tanh_k,
                          const void* err, const void* gw, int64_t rows, int r, void* gerr, void* stream);
+
+/* ---- One eager ICP call behind ONE host call per direction (ICP.py:49-303 for a dense batch on the sorted-sweep path, constant iteration count, no match
+ * certificates: the mid-size calls -- 32 clouds x 4096 points x 10 iterations is 0.55 ms of kernels -- whose time was the host's, preparing ~30 buffers
+ * and ~12 library calls from the interpreter).  The caller makes ONE allocation per direction; dicp_call_plan / dicp_call_backward_plan say how big and
+ * where the results lie in it; dicp_call_forward runs dicp_sweep_setup -> dicp_knn_sweep (iteration 0) -> dicp_loop_init -> dicp_icp_forward_plan ->
+ * dicp_loop_finish -> dicp_transform_points on it, dicp_call_backward runs dicp_pose_grad_in -> dicp_gather_rows -> dicp_icp_backward (windowed form,
+ * truncated sweep, one-launch tail) -> dicp_permute_rows -> dicp_window_reduce -> dicp_pose_grad_out.  Same kernels, same arguments, same results bit for
+ * bit as the per-buffer sequence (dicp_amd/_ops.py ICPLoop), which stays the path of every other kind of call. */
+#define DICP_CALL_NBKT 1024
+enum { DICP_CALL_FIRST_SEARCH = 1 /* iteration 0's search right behind the index build */, DICP_CALL_NO_SMALL_LOOP = 2 /* knn_variant bit 25 */ };
+typedef struct dicp_call {
+    const void* src;         /* (N,n,3) */
+    const void* tgt;         /* (N,m,c) */
+    const void* T_init;      /* (N,4,4) */
+    const void* w0;          /* (N,n) or NULL = unit weights */
+    int32_t N, n, m, c;
+    int32_t K;               /* iterations: every one of them runs (the reference's const_iter) */
+    int32_t dim;             /* 3, or 2 (ICP.py:107-116) */
+    int32_t need_grad;       /* 1: keep what dicp_call_backward reads (per-iteration matches, the regularised normal matrices) */
+    int32_t n_resort;        /* iterations in (0, K), ascending, before which the sweep re-orders its queries under the current pose (at most DICP_MAX_SEGMENTS - 1) */
+    int32_t resort[DICP_MAX_SEGMENTS];
+    int32_t flags;           /* DICP_CALL_* */
+    int32_t directions;      /* dicp_search_frame's */
+    double quantum;          /* dicp_search_frame's */
+    double tolerance;        /* ICP.py:237: a cloud whose step falls below it is frozen */
+    void* workspace;         /* dicp_call_layout.total bytes, 256-byte aligned; dicp_call_backward reads what dicp_call_forward left in it */
+    void* T_out;             /* optional (N,4,4) / (N,n,3): the two differentiable results go here instead of into the workspace (a binding whose autograd */
+    void* pc_out;            /* must not see them as views of one buffer that also holds results a caller may edit) */
+} dicp_call;
+typedef struct dicp_call_layout {       /* byte offsets into dicp_call.workspace */
+    size_t total, zeroed;    /* its size; the first `zeroed` bytes are cleared by dicp_call_forward itself */
+    size_t T, pc, deltas, weights, costs, converged, iterations, matched_ratio;   /* results: (N,4,4) T, (N,n,3) T, (N,K,6) T, (N,K,n) T, (N,K) T, (N) uint8, (N) T, (N) T */
+    size_t pairs;            /* DICP_PAIR_SHARDS uint64: pairs scored by the searches */
+    size_t n_matched, counters, poses, poses_search, alive, areg, n_start, partials, tgs4, tperm, bucket, brange, keys, tgt_sorted, scratch, scratch_bytes,
+           frame, pose_s, orders, spos;      /* loop state and search structure (as dicp_loop_buffers names them) */
+    int32_t n_orders, m_pad, nblk, pad0;
+} dicp_call_layout;
+int dicp_call_plan(int dtype, const dicp_call* call, dicp_call_layout* layout);
+int dicp_call_forward(int dtype, const dicp_weight_params* prm, const dicp_call* call, void* stream);
+
+typedef struct dicp_call_grads {
+    const void* gT;          /* (N,4,4) cotangent of T, or NULL = zeros (the cotangent of pc reaches the pose through dicp_transform_points_bwd: the caller adds it to gT) */
+    void* gsrc;              /* (N,n,3) written */
+    void* gtgt;              /* (N,m,c) written, or NULL: not wanted (c = 6 for pt2pl, 3 for pt2pt: the rows ARE the gradient's rows) */
+    void* gT0;               /* (N,4,4) written: the gradient w.r.t. T_init */
+    void* gw;                /* (N,n) written, or NULL */
+    void* workspace;         /* dicp_call_backward_layout.total bytes, 256-byte aligned */
+    double skip_eps;         /* dicp_loop_buffers.bwd_skip_eps; 0: every iteration runs */
+    int32_t tail_from;       /* dicp_loop_buffers.bwd_tail_from (0: none; the caller checks dicp_bwd_tail_max_blocks against nblk_w) */
+    int32_t pad0;
+    int32_t* live_host;      /* optional PINNED host memory, (K + 1) int32: receives bwd_live (+ the tail's error word) behind the pass's launches */
+} dicp_call_grads;
+typedef struct dicp_call_backward_layout {
+    size_t total, zeroed;
+    size_t live, arrive;     /* (K + 1) / (N + 1) int32: dicp_loop_buffers.bwd_live / bwd_tail_arrive of the pass */
+    size_t mref, decisions, far, gpose, gtmp, src_s, w_s, gsrc_s, gw_s, slab, gs, gb, partials, tail_partials;
+    int32_t nblk_w, pad0;    /* dicp_window_blocks of the shape */
+} dicp_call_backward_layout;
+int dicp_call_backward_plan(int dtype, const dicp_weight_params* prm, const dicp_call* call, int want_tgt, int want_w, dicp_call_backward_layout* layout);
+int dicp_call_backward(int dtype, const dicp_weight_params* prm, const dicp_call* call, const dicp_call_grads* grads, void* stream);
 
 #ifdef __cplusplus
 }

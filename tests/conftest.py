@@ -42,12 +42,14 @@ def scan_map():
 # (plain searches below the threshold), so that what a user gets at those sizes is held to the same bars;
 # tests/test_gpu_configs.py::test_certificates_are_used_where_they_pay checks the policy itself.
 BOTH_POLICIES = ("test_gpu_parity", "test_reference_suite")
+SHIPPED_ONLY = ("test_gpu_call",)       # (the one-call path is part of the shipped policy: it takes the calls below the threshold)
 
 
 def pytest_generate_tests(metafunc):
     if "cert_policy" in metafunc.fixturenames:
-        both = metafunc.module.__name__.rsplit(".", 1)[-1] in BOTH_POLICIES
-        metafunc.parametrize("cert_policy", ["certs-at-every-size", "shipped-policy"] if both else ["certs-at-every-size"])
+        module = metafunc.module.__name__.rsplit(".", 1)[-1]
+        metafunc.parametrize("cert_policy", ["shipped-policy"] if module in SHIPPED_ONLY else
+                             (["certs-at-every-size", "shipped-policy"] if module in BOTH_POLICIES else ["certs-at-every-size"]))
 
 
 @pytest.fixture(autouse=True)

@@ -123,10 +123,32 @@ def test_new_entry_points_reject_bad_arguments(lib):
     assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, None, None, 1, 1, 1, 64, None, None, None, 0, None, None) == 1   # idx or spos
     assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, None, None, 1, 1, 1, 64, one, None, None, 16, None, None) == 4   # (the scan form is gone)
     assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, None, None, 1, 1, 1, 64, one, None, None, 2 | 0x100, None, None) == 1  # sorted rows need the order
+    # dicp_call_*: plans are pure host arithmetic; a bad shape, a bad dtype, a missing buffer are refused before anything is touched
+    call = _lib.Call(N=2, n=300, m=200, c=3, K=5, dim=3, need_grad=1, n_resort=2)
+    call.resort[0], call.resort[1] = 1, 2
+    lay = _lib.CallLayout()
+    assert lib.dicp_call_plan(0, ctypes.byref(call), ctypes.byref(lay)) == 0
+    assert lay.m_pad == 256 and lay.n_orders == 3 and lay.zeroed > 0 and lay.total > lay.spos >= lay.orders + 3 * 2 * 300 * 4
+    offs = sorted(getattr(lay, k) for k in ("deltas", "costs", "converged", "iterations", "matched_ratio", "n_matched", "counters", "pairs"))
+    assert offs[0] == 0 and offs[-1] < lay.zeroed <= lay.T and all(o % 256 == 0 for o in offs)       # the zeroed state leads, everything 256-byte aligned
+    lay64 = _lib.CallLayout()
+    assert lib.dicp_call_plan(1, ctypes.byref(call), ctypes.byref(lay64)) == 0 and lay64.total > lay.total
+    assert lib.dicp_call_plan(3, ctypes.byref(call), ctypes.byref(lay)) == 3 and lib.dicp_call_plan(0, None, ctypes.byref(lay)) == 1
+    call.resort[1] = 1
+    assert lib.dicp_call_plan(0, ctypes.byref(call), ctypes.byref(lay)) == 2             # not ascending
+    call.resort[1] = 5
+    assert lib.dicp_call_plan(0, ctypes.byref(call), ctypes.byref(lay)) == 2             # not inside (0, K)
+    call.resort[1] = 2
+    assert lib.dicp_call_forward(0, ctypes.byref(P), ctypes.byref(call), None) == 1      # no buffers
+    blay = _lib.CallBackwardLayout()
+    assert lib.dicp_call_backward_plan(0, ctypes.byref(P), ctypes.byref(call), 1, 0, ctypes.byref(blay)) == 0
+    assert blay.far > 0 and blay.slab > 0 and blay.gw_s == 0 and blay.w_s == 0 and blay.live < blay.zeroed <= blay.gpose and blay.nblk_w == lib.dicp_window_blocks(0, 300, 256)
+    G = _lib.CallGrads()
+    assert lib.dicp_call_backward(0, ctypes.byref(P), ctypes.byref(call), ctypes.byref(G), None) == 1
 
 
 def test_sizes_and_argument_checks(lib):
-    assert lib.dicp_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.dicp_abi_version() == _lib.ABI_VERSION == 7
     assert [lib.dicp_padded_targets(m) for m in (0, 1, 64, 65, 129)] == [0, 64, 64, 128, 192]
     assert [lib.dicp_accumulate_blocks(n) for n in (0, 1, 1024, 1025, 16384)] == [0, 1, 1, 2, 16]
     # rejected before any launch (no GPU touched): null pointers, bad dtype / shapes / enums

@@ -246,8 +246,11 @@ struct F16Track {
 };
 
 // stage st of the cloud's image -> registers (issued early), registers -> LDS (after the stage in LDS has been used)
-#define DICP_F16_FETCH(st_)  _Pragma("unroll") for (int k_ = 0; k_ < F16_STAGE * 64 / BLOCK; ++k_) pre[k_] = img[(size_t)(st_) * (F16_STAGE * 64) + tid + k_ * BLOCK];
-#define DICP_F16_COMMIT(buf_) _Pragma("unroll") for (int k_ = 0; k_ < F16_STAGE * 64 / BLOCK; ++k_) lds[buf_][tid + k_ * BLOCK] = pre[k_];
+// (four named registers, not an array: the array form was left in scratch memory -- 64 bytes per lane written and read back per stage, 2 GB of HBM writes per
+//  launch at 256 x 16384 x 16384, and an s_waitcnt right behind the loads it was meant to hide; profiles/r04_pmc_hbm_traffic.json at 8ee49b5 shows it)
+static_assert(F16_STAGE * 64 / BLOCK == 4, "DICP_F16_FETCH / _COMMIT move four 16-byte pieces per thread");
+#define DICP_F16_FETCH(st_)  { const uint4* f_ = img + (size_t)(st_) * (F16_STAGE * 64) + tid; pre0 = f_[0]; pre1 = f_[BLOCK]; pre2 = f_[2 * BLOCK]; pre3 = f_[3 * BLOCK]; }
+#define DICP_F16_COMMIT(buf_) { uint4* c_ = &lds[buf_][tid]; c_[0] = pre0; c_[BLOCK] = pre1; c_[2 * BLOCK] = pre2; c_[3 * BLOCK] = pre3; }
 
 // every n x m pair.  Block = 4 waves x 128 queries; the cloud's image streams through LDS in stages of 512 rows, double-buffered.
 //   pass 1   the filter over all tiles (four B tiles per wave), lane-local bookkeeping per chunk of F16_CHT tiles;
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_f16_kernel(const float* __res
     f32x16 zero;
 #pragma unroll
     for (int i = 0; i < 16; ++i) zero[i] = 0.f;
-    uint4 pre[F16_STAGE * 64 / BLOCK];
+    uint4 pre0, pre1, pre2, pre3;
     DICP_F16_FETCH(0)
     DICP_F16_COMMIT(0)
     __syncthreads();

@@ -162,3 +162,36 @@ def test_results_outlive_the_call_and_an_edited_result_does_not_block_the_backwa
     for k in ("T", "pc", "costs", "deltas"):
         assert torch.equal(out[k], keep[k]), k
     del filler
+
+
+def test_the_c_abi_alone():
+    """INTEGRATION.md's stub: dicp_call_plan + dicp_call_forward bound with ctypes and nothing else of the package's host side -- the poses and steps
+    ICP.icp returns for the same call, bit for bit."""
+    import ctypes
+    lib = _lib.load()
+    N, n, m, K = 3, 2048, 2304, 5
+    src, tgt = make_pairs(N, n, m, seed=21, dtype=torch.float32)
+    S, Tg, Ti = src.to(DEV), tgt.to(DEV), torch.eye(4).repeat(N, 1, 1).to(DEV)
+    call = _lib.Call(src=S.data_ptr(), tgt=Tg.data_ptr(), T_init=Ti.data_ptr(), w0=None, N=N, n=n, m=m, c=6, K=K, dim=3, need_grad=0, n_resort=3, flags=_lib.CALL_FIRST_SEARCH,
+                     directions=int(_ops.FRAME_DIRECTIONS), quantum=_ops.CENTER_QUANTUM, tolerance=1e-12)
+    for i in range(3):
+        call.resort[i] = i + 1
+    lay = _lib.CallLayout()
+    assert lib.dicp_call_plan(_lib.F32, ctypes.byref(call), ctypes.byref(lay)) == 0
+    ws = torch.empty(lay.total // 4, dtype=torch.float32, device=DEV)
+    call.workspace = ws.data_ptr()
+    icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
+    icp.const_iter, icp.knn_variant = True, _lib.KNN_SWEEP
+    P = _lib.WeightParams(mode=_lib.PT2PL, trim_on=1, differentiable=1, loss=_lib.LOSS_HUBER, trim_dist=5.0, tanh_k=float(icp.config['dICP']['parameters']['tanh_steepness']),
+                          loss_delta=1.0, match_thresh=float(icp.match_ratio_thresh))
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.dicp_call_forward(_lib.F32, ctypes.byref(P), ctypes.byref(call), st) == 0
+    torch.cuda.synchronize()
+    T = ws[lay.T // 4: lay.T // 4 + 16 * N].view(N, 4, 4)
+    deltas = ws[lay.deltas // 4: lay.deltas // 4 + 6 * K * N].view(N, K, 6)
+    with torch.no_grad():
+        out = icp.icp(S, Tg, Ti, trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0}, dim=3)
+    assert torch.equal(T, out["T"]) and torch.equal(deltas, out["deltas"][..., 0])
+    # a misaligned workspace is refused before anything is launched
+    call.workspace = ws.data_ptr() + 16
+    assert lib.dicp_call_forward(_lib.F32, ctypes.byref(P), ctypes.byref(call), st) == 5

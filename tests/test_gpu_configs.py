@@ -6,6 +6,7 @@ what the parity suite runs.
               beyond the LDS sort, two-pass query order) against brute force, and a whole ICP call (KNN_AUTO and the
               MFMA brute-force variant) against the oracle                            test_sweep_equals_brute_force_at_65536,
                                                                                      test_config4_icp_at_65536_vs_oracle
+  configs[4]  2048 clouds of 16384 points over 8 ranks: every rank's 256-cloud call == the one 2048-cloud call     test_config5_2048_clouds_as_eight_shards
 The oracle (CPU restatement of the reference) runs on a slice that finishes in seconds; full-size claims beyond the
 slice are size-independent properties (index equality between two exact searches, batch == per-item, finiteness).
 """
@@ -635,3 +636,48 @@ def test_certificates_are_used_where_they_pay(monkeypatch):
         Ts.append(out["T"].clone())
     assert used[0] and not used[-1], used                               # certified at first, then not
     assert all(torch.equal(Ts[0], t) for t in Ts[1:])
+
+
+def test_config5_2048_clouds_as_eight_shards():
+    """BASELINE configs[4]: 2048 clouds of 16384 points over 8 ranks (this box has one GPU: the ranks' shards run one after the other).
+    The path shards with no data-path collective, so the claim is a property of the kernels: every rank's call on ITS 256 clouds
+    (dist.shard_bounds, as bench.py --gpus 8 cuts the batch) gives what the one 2048-cloud call gives for those clouds -- poses, statistics and
+    both gradients; whole-batch strides, the XCD block mapping at 8x the blocks, certificates engaged in either."""
+    from dicp_amd import dist as ddist
+    world, per, n, K = 8, 256, 16384, 8
+    base_s, base_t = make_pairs(per, n, n, seed=3, dtype=torch.float32, first=7 * per)          # (rank 7's clouds as bench.py draws them)
+    base_s, base_t = base_s.to(DEV), base_t.to(DEV)
+    # seven more shards of distinct clouds, made on the device (2048 clouds from the generator take a minute of host time): points re-ordered and shifted
+    shards_s, shards_t = [], []
+    for g in range(world):
+        shift = torch.tensor([0.37 * g, -0.21 * g, 0.11 * g], device=DEV)
+        shards_s.append(torch.roll(base_s, shifts=131 * g, dims=1) + shift)
+        t = torch.roll(base_t, shifts=977 * g, dims=1).clone()
+        t[:, :, :3] += shift
+        shards_t.append(t)
+    src_all, tgt_all = torch.cat(shards_s), torch.cat(shards_t)
+    del shards_s, shards_t
+    B = world * per
+    T0 = torch.eye(4, device=DEV).repeat(B, 1, 1)
+    icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
+    icp.const_iter = True
+    sa, ta = src_all.clone().requires_grad_(True), tgt_all.clone().requires_grad_(True)
+    whole = icp.icp(sa, ta, T0, **KW)
+    whole["T"].sum().backward()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(whole["T"]).all() and torch.isfinite(sa.grad).all() and torch.isfinite(ta.grad).all())
+    seen = 0
+    for g in range(world):
+        lo, hi = ddist.shard_bounds(B, g, world)
+        assert hi - lo == per
+        s, t = src_all[lo:hi].clone().requires_grad_(True), tgt_all[lo:hi].clone().requires_grad_(True)
+        part = icp.icp(s, t, T0[lo:hi], **KW)
+        part["T"].sum().backward()
+        np.testing.assert_allclose(npy(part["T"]), npy(whole["T"][lo:hi]), rtol=0, atol=2e-6)
+        for key in ("converged", "iterations", "matched_ratio"):
+            assert torch.equal(part["stats"][key], whole["stats"][key][lo:hi]), key
+        for got, want in ((s.grad, sa.grad[lo:hi]), (t.grad, ta.grad[lo:hi])):
+            scale = max(1.0, float(want.abs().max()))
+            assert float((got - want).abs().max()) <= 5e-5 * scale
+        seen += hi - lo
+    assert seen == B

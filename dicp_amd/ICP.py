@@ -70,6 +70,7 @@ class ICP:
             one_call=True)                    # calls that need none of the loop's host decisions: one library call per direction (dicp_call_*)
         self._hints = CallHints()             # private: what this object's earlier calls tell later ones about time (per device, stream and shape)
         self._timing_events = None
+        self._eye = {}                        # private: identity start poses of pt2pt_dICP_SVD by (batch size, dtype, device)
 
     def icp(self, source, target, T_init, weight=None, trim_dist=None, loss_fn=None, dim=3):
         return self.dICP(source, target, T_init, weight, trim_dist, loss_fn, dim)      # ICP.py:46-47
@@ -201,12 +202,24 @@ class ICP:
         s_b, t_b, T_b, w_pts = (t.to(dev) for t in (s_b, t_b, T_b, w_pts))
         src_rows, tgt_rows = self._device_rows(rows, dev)
         seed = bool(getattr(self, "svd_seed_T_init", False))
-        T_start = T_b if seed else torch.eye(4, dtype=T_b.dtype, device=dev).expand(T_b.shape[0], 4, 4).contiguous()
-        T_found, costs, iterations = KabschLoop.apply(s_b, t_b, T_start, w_pts, int(self.max_iterations), float(self.tolerance),
-                                                      trim_dist, bool(self.const_iter), self.knn_variant, src_rows, tgt_rows, self.sync_every)
+        if seed:
+            T_start = T_b
+        else:       # (the identity start is read, never written: one tensor per batch size serves every call)
+            key = (int(T_b.shape[0]), T_b.dtype, dev)
+            T_start = self._eye.get(key)
+            if T_start is None:
+                if len(self._eye) > 16:
+                    self._eye.clear()
+                T_start = self._eye[key] = torch.eye(4, dtype=T_b.dtype, device=dev).expand(T_b.shape[0], 4, 4).contiguous()
+        if self._tuning["one_call"] and _call.kabsch_eligible(s_b, t_b, T_start, w_pts, bool(self.const_iter), self.knn_variant, src_rows, tgt_rows):
+            # the whole loop, the pose and the transformed cloud (ICP.py:581) from one library call per direction (dicp_kabsch_call_*)
+            T_found, pc, costs, iterations = _call.KabschCall.apply(s_b, t_b, T_start, w_pts, int(self.max_iterations), trim_dist)
+        else:
+            T_found, costs, iterations = KabschLoop.apply(s_b, t_b, T_start, w_pts, int(self.max_iterations), float(self.tolerance),
+                                                          trim_dist, bool(self.const_iter), self.knn_variant, src_rows, tgt_rows, self.sync_every)
+            pc = transform_points(s_b, T_found)                                          # ICP.py:581
         if self.verbose:                                                                 # ICP.py:588-589
             print("ICP converged in {} iterations".format(int(iterations.max().item()) - 1))
-        pc = transform_points(s_b, T_found)                                              # ICP.py:581
         T = T_found if seed else torch.matmul(T_found, T_b)                              # ICP.py:578
         self.svd_stats = {"costs": costs, "iterations": iterations}
         if home != dev:

@@ -194,3 +194,93 @@ class CallLoop(torch.autograd.Function):
             if gsrc_pc is not None:
                 gsrc += gsrc_pc
         return gsrc, gtgt, gT0, gw, None
+
+
+# ------------------------------------------------------------------ ICP.pt2pt_dICP_SVD (ICP.py:533-591), the same way
+def kabsch_eligible(source, target, T_start, w0, const_iter, knn_variant, src_rows, tgt_rows):
+    """True when KabschLoop would run this call as: sweep search, three segments, no host decision in between."""
+    if not const_iter or src_rows is not None or tgt_rows is not None or (knn_variant & 0xff00):
+        return False
+    dt = source.dtype
+    if dt not in _DT or not (source.is_cuda and target.is_cuda and T_start.is_cuda and w0.is_cuda) or target.dtype != dt or T_start.dtype != dt or w0.dtype != dt:
+        return False
+    N, n, _ = source.shape
+    m = target.shape[1]
+    if N * n > MAX_POINTS or N * m > 4 * MAX_POINTS or tuple(T_start.shape) != (N, 4, 4) or tuple(w0.shape) != (N, n):
+        return False
+    kind = knn_variant & 0xff
+    if kind == _lib.KNN_AUTO:
+        kind = _ops.auto_knn_kind(N, n, m)
+    return kind == _lib.KNN_SWEEP and not torch.cuda.is_current_stream_capturing()
+
+
+_KPLANS = {}
+
+
+class KabschCall(torch.autograd.Function):
+    """KabschLoop + the transformed cloud (ICP.py:581) as one node on one allocation: dicp_kabsch_call_forward / _backward.
+    Inputs : source (N,n,3), target (N,m,c), T_start (N,4,4), w0 (N,n), K, trim_dist
+    Outputs: T_found (N,4,4), pc (N,n,3) differentiable; costs (N,K), iterations (N)."""
+
+    @staticmethod
+    def forward(ctx, source, target, T_start, w0, K, trim_dist):
+        lib = _lib.load()
+        dev, dt = source.device, source.dtype
+        code, es = _DT[dt], source.element_size()
+        src, tgt, Ts, w0c = source.contiguous(), target.contiguous(), T_start.contiguous(), w0.contiguous()
+        N, n, _ = src.shape
+        m, c = tgt.shape[1], tgt.shape[2]
+        K = int(K)
+        trim_on = int(trim_dist is not None and trim_dist >= 0.0)
+        key = (code, N, n, m, c, K)
+        L = _KPLANS.get(key)
+        if L is None:
+            L = _lib.KabschCallLayout()
+            _lib.check(lib.dicp_kabsch_call_plan(code, ctypes.byref(_lib.KabschCall(N=N, n=n, m=m, c=c, K=K)), ctypes.byref(L)), "dicp_kabsch_call_plan")
+            if len(_KPLANS) > 256:
+                _KPLANS.clear()
+            _KPLANS[key] = L
+        ctx.set_materialize_grads(False)
+        with _on(dev):
+            ws = torch.empty((L.total // es,), dtype=dt, device=dev)
+            T = torch.empty((N, 4, 4), dtype=dt, device=dev)
+            pc = torch.empty((N, n, 3), dtype=dt, device=dev)
+            call = _lib.KabschCall(src=src.data_ptr(), tgt=tgt.data_ptr(), T_start=Ts.data_ptr(), w0=w0c.data_ptr(), N=N, n=n, m=m, c=c, K=K, trim_on=trim_on,
+                                   directions=int(_ops.FRAME_DIRECTIONS), trim_dist=float(trim_dist) if trim_on else 0.0, quantum=_ops.CENTER_QUANTUM, tolerance=0.0,
+                                   workspace=ws.data_ptr(), T_out=T.data_ptr(), pc_out=pc.data_ptr())
+            _lib.check(lib.dicp_kabsch_call_forward(code, ctypes.byref(call), _stream()), "dicp_kabsch_call_forward")
+        costs = ws.as_strided((N, K), (K, 1), L.costs // es)
+        iterations = ws.as_strided((N,), (1,), L.iterations // es)
+        ctx.save_for_backward(src, tgt, w0c)
+        ctx.ws, ctx.call, ctx.L = ws, call, L
+        ctx.mark_non_differentiable(costs, iterations)
+        return T, pc, costs, iterations
+
+    @staticmethod
+    def backward(ctx, gT, gpc, *_unused):
+        src, tgt, w0c = ctx.saved_tensors
+        call, L = ctx.call, ctx.L
+        lib = _lib.load()
+        dev, dt = src.device, src.dtype
+        code, es = _DT[dt], src.element_size()
+        N, n, _ = src.shape
+        with _on(dev):
+            st = _stream()
+            gsrc_pc = None
+            if gpc is not None:         # pc = C p + r under the pose found: to the source directly, to the pose through T
+                gsrc_pc = torch.empty_like(src)
+                pcp = torch.empty((N, L.nblk, _lib.NBWD_PAD), dtype=dt, device=dev)
+                pose = ctx.ws.as_strided((N, 12), (12, 1), L.pose // es)
+                _lib.check(lib.dicp_transform_points_bwd(code, _p(src), _p(pose), _p(gpc.contiguous()), _p(gsrc_pc), _p(pcp), N, n, st), "dicp_transform_points_bwd")
+                gT_pc = _ops._pose_sums_to_gT(pcp, N, dt, dev, st)
+                gT = gT_pc if gT is None else gT + gT_pc
+            gTc = gT.contiguous() if gT is not None else None
+            gsrc = torch.empty_like(src)
+            gtgt = torch.empty_like(tgt) if ctx.needs_input_grad[1] else None
+            gw = torch.empty_like(w0c) if ctx.needs_input_grad[3] else None
+            G = _lib.KabschCallGrads(gT=gTc.data_ptr() if gTc is not None else None, gsrc=gsrc.data_ptr(), gtgt=gtgt.data_ptr() if gtgt is not None else None,
+                                     gw=gw.data_ptr() if gw is not None else None)
+            _lib.check(lib.dicp_kabsch_call_backward(code, ctypes.byref(call), ctypes.byref(G), st), "dicp_kabsch_call_backward")
+            if gsrc_pc is not None:
+                gsrc += gsrc_pc
+        return gsrc, gtgt, None, gw, None, None

@@ -100,6 +100,23 @@ class CallBackwardLayout(ctypes.Structure):
                                     "partials", "tail_partials")] + [("nblk_w", i32), ("pad0", i32)])
 
 
+class KabschCall(ctypes.Structure):
+    """dicp_kabsch_call (include/dicp_hip.h)."""
+    _fields_ = [("src", vp), ("tgt", vp), ("T_start", vp), ("w0", vp), ("N", i32), ("n", i32), ("m", i32), ("c", i32), ("K", i32), ("trim_on", i32), ("directions", i32), ("pad0", i32),
+                ("trim_dist", f64), ("quantum", f64), ("tolerance", f64), ("workspace", vp), ("T_out", vp), ("pc_out", vp)]
+
+
+class KabschCallLayout(ctypes.Structure):
+    """dicp_kabsch_call_layout (include/dicp_hip.h)."""
+    _fields_ = ([(k, _sz) for k in ("total", "zeroed", "costs", "iterations", "pairs", "counters", "frame", "keys", "tperm", "bucket", "brange", "tgs4", "scratch", "scratch_bytes",
+                                    "pose", "pose_search", "pose_used", "partials", "save", "idx", "rows_live", "orders", "gpose", "gacc")] + [("m_pad", i32), ("nblk", i32)])
+
+
+class KabschCallGrads(ctypes.Structure):
+    """dicp_kabsch_call_grads (include/dicp_hip.h)."""
+    _fields_ = [("gT", vp), ("gsrc", vp), ("gtgt", vp), ("gw", vp)]
+
+
 CALL_FIRST_SEARCH, CALL_NO_SMALL_LOOP, CALL_NBKT = 1, 2, 1024
 
 
@@ -163,6 +180,9 @@ _SIGNATURES = {
     "dicp_call_forward": ([i32, ctypes.POINTER(WeightParams), ctypes.POINTER(Call), vp], ctypes.c_int),
     "dicp_call_backward_plan": ([i32, ctypes.POINTER(WeightParams), ctypes.POINTER(Call), i32, i32, ctypes.POINTER(CallBackwardLayout)], ctypes.c_int),
     "dicp_call_backward": ([i32, ctypes.POINTER(WeightParams), ctypes.POINTER(Call), ctypes.POINTER(CallGrads), vp], ctypes.c_int),
+    "dicp_kabsch_call_plan": ([i32, ctypes.POINTER(KabschCall), ctypes.POINTER(KabschCallLayout)], ctypes.c_int),
+    "dicp_kabsch_call_forward": ([i32, ctypes.POINTER(KabschCall), vp], ctypes.c_int),
+    "dicp_kabsch_call_backward": ([i32, ctypes.POINTER(KabschCall), ctypes.POINTER(KabschCallGrads), vp], ctypes.c_int),
 }
 EXPORTS = tuple(_SIGNATURES)
 

@@ -34,6 +34,37 @@ inline bool call_ok(int dtype, const dicp_call* c) {
 
 inline char* at(const dicp_call* c, size_t off) { return (char*)c->workspace + off; }
 
+// ---- the SVD loop's one-call form: three per-cloud trifles that were torch arithmetic on the host side
+template <typename T>
+__global__ void kabsch_prep_kernel(int32_t* __restrict__ rows_live, int N, int n) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < N) rows_live[b] = n;                                 // every source row takes part (a cloud's count drops to 0 when it is frozen)
+}
+// T (N,4,4) from the pose [C | r]; a cloud that never met the tolerance reports all K iterations (ICP.py:585-589)
+template <typename T>
+__global__ void kabsch_finish_kernel(const T* __restrict__ pose, T* __restrict__ iterations, T* __restrict__ T_out, int N, int K) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * 16) return;
+    const int b = i >> 4, e = i & 15, row = e >> 2, col = e & 3;
+    T v = row == 3 ? (col == 3 ? T(1) : T(0)) : (col == 3 ? pose[b * 12 + 9 + row] : pose[b * 12 + row * 3 + col]);
+    T_out[i] = v;
+    if (e == 0 && iterations[b] == T(0)) iterations[b] = T(K);
+}
+// the cotangent of the pose [C | r] out of the cotangent of T (NULL: zeros)
+template <typename T>
+__global__ void kabsch_gpose_kernel(const T* __restrict__ gT, T* __restrict__ gpose, int N) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * 12) return;
+    const int b = i / 12, e = i % 12;
+    gpose[i] = gT ? (e < 9 ? gT[b * 16 + (e / 3) * 4 + e % 3] : gT[b * 16 + (e - 9) * 4 + 3]) : T(0);
+}
+
+inline bool kabsch_call_ok(int dtype, const dicp_kabsch_call* c) {
+    return (dtype == DICP_F32 || dtype == DICP_F64) && c->N >= 1 && c->n >= 1 && c->m >= 1 && c->K >= 1 && (c->c == 3 || c->c == 6);
+}
+inline char* kat(const dicp_kabsch_call* c, size_t off) { return (char*)c->workspace + off; }
+inline int last_launch() { const hipError_t e = hipGetLastError(); return e == hipSuccess ? 0 : -(int)e; }
+
 }  // namespace
 
 extern "C" {
@@ -239,6 +270,110 @@ int dicp_call_backward(int dtype, const dicp_weight_params* prm, const dicp_call
                                         g->gtgt, c->c, 1, stream))
             return rc;
     return dicp_pose_grad_out(dtype, gpose, folded ? nullptr : W + L.partials, folded ? 0 : L.nblk_w, g->gT0, c->N, stream);
+}
+
+// ---- ICP.pt2pt_dICP_SVD (ICP.py:533-591) for a dense batch on the sweep path with a constant iteration count, one call per direction
+int dicp_kabsch_call_plan(int dtype, const dicp_kabsch_call* c, dicp_kabsch_call_layout* L) {
+    if (!c || !L) return DICP_ERR_NULL;
+    if (!kabsch_call_ok(dtype, c)) return dtype != DICP_F32 && dtype != DICP_F64 ? DICP_ERR_DTYPE : DICP_ERR_SHAPE;
+    const size_t es = esize(dtype), N = c->N, n = c->n, K = c->K;
+    memset(L, 0, sizeof(*L));
+    L->m_pad = dicp_padded_targets(c->m);
+    L->nblk = dicp_accumulate_blocks(c->n);
+    const size_t m_pad = L->m_pad;
+    Carver w;
+    L->costs = w.take(N * K * es);
+    L->iterations = w.take(N * es);
+    L->counters = w.take(K * 4);
+    L->pairs = w.take(DICP_PAIR_SHARDS * 8);
+    L->zeroed = w.off;
+    L->frame = w.take(N * 12 * es);
+    L->keys = w.take(N * m_pad * es);
+    L->tperm = w.take(N * m_pad * 4);
+    L->bucket = w.take(N * (DICP_CALL_NBKT + 1) * 4);
+    L->brange = w.take(N * 2 * es);
+    L->tgs4 = w.take(N * m_pad * 4 * es);
+    L->scratch_bytes = dicp_sweep_sort_scratch_bytes(dtype, c->N, L->m_pad);
+    L->scratch = L->scratch_bytes ? w.take(L->scratch_bytes) : 0;
+    L->pose = w.take(N * 12 * es);
+    L->pose_search = w.take(N * 12 * es);
+    L->pose_used = w.take(N * 12 * es);
+    L->partials = w.take(N * L->nblk * DICP_NACC_PAD * es);
+    L->save = w.take(N * DICP_KAB_SAVE * 8);
+    L->idx = w.take(N * n * 4);
+    L->rows_live = w.take(N * 4);
+    L->orders = w.take(2 * N * n * 4);
+    L->gpose = w.take(N * 12 * es);
+    L->gacc = w.take(N * 16 * es);
+    L->total = w.off;
+    return 0;
+}
+
+int dicp_kabsch_call_forward(int dtype, const dicp_kabsch_call* c, void* stream) {
+    if (!c || !c->src || !c->tgt || !c->T_start || !c->w0 || !c->workspace || !c->T_out) return DICP_ERR_NULL;
+    dicp_kabsch_call_layout L;
+    if (int rc = dicp_kabsch_call_plan(dtype, c, &L)) return rc;
+    if (((uintptr_t)c->workspace & 255) != 0) return DICP_ERR_ALIGN;
+    const size_t N = c->N, n = c->n;
+    const int K = c->K;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipError_t e = hipMemsetAsync(c->workspace, 0, L.zeroed, st)) return -(int)e;
+    int32_t* order0 = (int32_t*)kat(c, L.orders);
+    int32_t* order1 = order0 + N * n;
+    // frame, sort, packed rows (the Kabsch sums gather the rows as given: no sorted copy), search pose of the start, first query order
+    if (int rc = dicp_sweep_setup(dtype, c->tgt, c->c, nullptr, c->N, c->m, L.m_pad, c->quantum, c->directions, kat(c, L.frame), kat(c, L.keys), (int32_t*)kat(c, L.tperm),
+                                  DICP_CALL_NBKT, (int32_t*)kat(c, L.bucket), kat(c, L.brange), L.scratch_bytes ? kat(c, L.scratch) : nullptr, L.scratch_bytes,
+                                  kat(c, L.tgs4), nullptr, c->c, c->src, nullptr, c->n, c->T_start, kat(c, L.pose_search), order0, stream))
+        return rc;
+    if (int rc = dicp_search_pose(dtype, c->T_start, nullptr, c->N, kat(c, L.pose), stream)) return rc;          // [C | r] itself
+    (void)hipGetLastError();
+    if (dtype == DICP_F32) kabsch_prep_kernel<float><<<(c->N + 255) / 256, 256, 0, st>>>((int32_t*)kat(c, L.rows_live), c->N, c->n);
+    else                   kabsch_prep_kernel<double><<<(c->N + 255) / 256, 256, 0, st>>>((int32_t*)kat(c, L.rows_live), c->N, c->n);
+    if (int rc = last_launch()) return rc;
+    dicp_kabsch_buffers B;
+    memset(&B, 0, sizeof(B));
+    B.src = c->src; B.tgt = c->tgt; B.w_init = c->w0; B.c = c->c; B.K = K; B.knn_variant = DICP_KNN_SWEEP; B.m_pad = L.m_pad;
+    B.tgt4 = kat(c, L.tgs4); B.tperm = (int32_t*)kat(c, L.tperm); B.bucket = (int32_t*)kat(c, L.bucket); B.brange = kat(c, L.brange); B.nbkt = DICP_CALL_NBKT;
+    B.pairs = (unsigned long long*)kat(c, L.pairs); B.frame = kat(c, L.frame); B.pose = kat(c, L.pose); B.pose_search = kat(c, L.pose_search);
+    B.pose_used = kat(c, L.pose_used); B.idx = (int32_t*)kat(c, L.idx); B.partials = kat(c, L.partials); B.save = (double*)kat(c, L.save);
+    B.costs = kat(c, L.costs); B.iterations = kat(c, L.iterations); B.rows_live = (int32_t*)kat(c, L.rows_live); B.counters = (int32_t*)kat(c, L.counters);
+    // segments [0,1) [1,2) [2,K): the queries are re-ordered under the pose before iteration 1 (the poses move most in the first step)
+    const int cuts[4] = {0, K > 1 ? 1 : K, K > 2 ? 2 : K, K};
+    for (int s = 0; s < 3; ++s) {
+        const int k0 = cuts[s], k1 = cuts[s + 1];
+        if (k1 <= k0) continue;
+        if (k0 == 1)
+            if (int rc = dicp_query_order(dtype, c->src, kat(c, L.pose_search), kat(c, L.brange), DICP_CALL_NBKT, c->N, c->n, order1, nullptr, nullptr, nullptr, 0, nullptr,
+                                          L.m_pad, kat(c, L.keys), (int32_t*)kat(c, L.bucket), c->m, (int32_t*)kat(c, L.rows_live), nullptr, stream))
+                return rc;
+        B.qorder = k0 == 0 ? order0 : order1;
+        if (int rc = dicp_kabsch_forward(dtype, &B, c->N, c->n, c->m, c->trim_on, c->trim_dist, 1, c->tolerance, k0, k1, stream)) return rc;
+    }
+    (void)hipGetLastError();
+    if (dtype == DICP_F32) kabsch_finish_kernel<float><<<(c->N * 16 + 255) / 256, 256, 0, st>>>((const float*)kat(c, L.pose), (float*)kat(c, L.iterations), (float*)c->T_out, c->N, K);
+    else                   kabsch_finish_kernel<double><<<(c->N * 16 + 255) / 256, 256, 0, st>>>((const double*)kat(c, L.pose), (double*)kat(c, L.iterations), (double*)c->T_out, c->N, K);
+    if (int rc = last_launch()) return rc;
+    if (c->pc_out) return dicp_transform_points(dtype, c->src, kat(c, L.pose), c->pc_out, c->N, c->n, stream);     // ICP.py:581
+    return 0;
+}
+
+int dicp_kabsch_call_backward(int dtype, const dicp_kabsch_call* c, const dicp_kabsch_call_grads* g, void* stream) {
+    if (!c || !g || !c->workspace || !c->src || !c->tgt || !c->w0 || !g->gsrc) return DICP_ERR_NULL;
+    dicp_kabsch_call_layout L;
+    if (int rc = dicp_kabsch_call_plan(dtype, c, &L)) return rc;
+    const size_t es = esize(dtype), N = c->N, n = c->n;
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipGetLastError();
+    if (dtype == DICP_F32) kabsch_gpose_kernel<float><<<(c->N * 12 + 255) / 256, 256, 0, st>>>((const float*)g->gT, (float*)kat(c, L.gpose), c->N);
+    else                   kabsch_gpose_kernel<double><<<(c->N * 12 + 255) / 256, 256, 0, st>>>((const double*)g->gT, (double*)kat(c, L.gpose), c->N);
+    if (int rc = last_launch()) return rc;
+    if (int rc = dicp_kabsch_step_bwd(dtype, kat(c, L.gpose), (const double*)kat(c, L.save), kat(c, L.gacc), c->N, stream)) return rc;
+    // dicp_kabsch_bwd adds: the three gradients start at zero
+    if (hipError_t e = hipMemsetAsync(g->gsrc, 0, N * n * 3 * es, st)) return -(int)e;
+    if (g->gtgt) if (hipError_t e = hipMemsetAsync(g->gtgt, 0, N * (size_t)c->m * c->c * es, st)) return -(int)e;
+    if (g->gw) if (hipError_t e = hipMemsetAsync(g->gw, 0, N * n * es, st)) return -(int)e;
+    return dicp_kabsch_bwd(dtype, c->src, c->tgt, c->c, (const int32_t*)kat(c, L.idx), kat(c, L.pose_used), c->w0, c->trim_on, c->trim_dist, kat(c, L.gacc), nullptr,
+                           c->N, c->n, c->m, g->gsrc, g->gtgt, g->gw, stream);
 }
 
 }  // extern "C"

@@ -511,47 +511,69 @@ constexpr int KAB_S0 = 0, KAB_SP = 1, KAB_SY = 4, KAB_M = 7, KAB_PP = 16, KAB_YY
 constexpr int KAB_SAVE = 40;      // doubles kept per cloud for the backward pass
 
 // One-sided Jacobi SVD of a 3x3 (row-major): A = U diag(S) V^T, S descending, U and V orthogonal.
+// A pair of columns counts as orthogonal at 1e-15 of the product of their norms: a few units of double rounding.  (Up to round 3 the bound was 1e-17 --
+// below the rounding of the inner product itself, so it was never met and EVERY call ran all 30 sweeps of three rotations, each with three square roots
+// and two divisions in double: 45 of the step kernel's 48 us.  Jacobi converges quadratically; 4-6 sweeps reach 1e-15.)
+// Every index below is a compile-time constant (the pairs and the column sort are written out): with loops over (p, q) and an index array for the
+// sort the nine + nine entries lived in scratch memory and one lane's 3x3 SVD took 45 us of the SVD loop's step kernel (profiles/r04_svd_step.txt).
+#define DICP_SVD3_ROTATE(p, q)                                                                                              \
+    {                                                                                                                       \
+        double a = 0, b = 0, g = 0;                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i) { a += G[i * 3 + p] * G[i * 3 + p]; b += G[i * 3 + q] * G[i * 3 + q]; g += G[i * 3 + p] * G[i * 3 + q]; } \
+        if (!(fabs(g) <= 1e-300 || fabs(g) <= 1e-15 * sqrt(a * b))) {                                                       \
+            off += fabs(g);                                                                                                 \
+            const double zeta = (b - a) / (2.0 * g);                                                                        \
+            const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));                             \
+            const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;                                                           \
+            _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                                 \
+                const double gp = G[i * 3 + p], gq = G[i * 3 + q];                                                          \
+                G[i * 3 + p] = c * gp - sn * gq; G[i * 3 + q] = sn * gp + c * gq;                                           \
+                const double vp = V[i * 3 + p], vq = V[i * 3 + q];                                                          \
+                V[i * 3 + p] = c * vp - sn * vq; V[i * 3 + q] = sn * vp + c * vq;                                           \
+            }                                                                                                               \
+        }                                                                                                                   \
+    }
+// columns a and b of G and V change places when column b's norm is the larger one (strictly: the order of equal values stays)
+#define DICP_SVD3_ORDER(a, b)                                                                                               \
+    if (nrm[b] > nrm[a]) {                                                                                                  \
+        const double tn = nrm[a]; nrm[a] = nrm[b]; nrm[b] = tn;                                                             \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                                     \
+            const double tg = G[i * 3 + a]; G[i * 3 + a] = G[i * 3 + b]; G[i * 3 + b] = tg;                                 \
+            const double tv = V[i * 3 + a]; V[i * 3 + a] = V[i * 3 + b]; V[i * 3 + b] = tv;                                 \
+        }                                                                                                                   \
+    }
 DICP_HD void svd3(const double* A, double* U, double* S, double* V) {
     double G[9];
+#pragma unroll
     for (int i = 0; i < 9; ++i) { G[i] = A[i]; V[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+#pragma unroll 1
     for (int sweep = 0; sweep < 30; ++sweep) {
         double off = 0.0;
-        for (int p = 0; p < 2; ++p)
-            for (int q = p + 1; q < 3; ++q) {
-                double a = 0, b = 0, g = 0;
-                for (int i = 0; i < 3; ++i) { a += G[i * 3 + p] * G[i * 3 + p]; b += G[i * 3 + q] * G[i * 3 + q]; g += G[i * 3 + p] * G[i * 3 + q]; }
-                if (fabs(g) <= 1e-300 || fabs(g) <= 1e-17 * sqrt(a * b)) continue;
-                off += fabs(g);
-                const double zeta = (b - a) / (2.0 * g);
-                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
-                for (int i = 0; i < 3; ++i) {
-                    const double gp = G[i * 3 + p], gq = G[i * 3 + q];
-                    G[i * 3 + p] = c * gp - sn * gq; G[i * 3 + q] = sn * gp + c * gq;
-                    const double vp = V[i * 3 + p], vq = V[i * 3 + q];
-                    V[i * 3 + p] = c * vp - sn * vq; V[i * 3 + q] = sn * vp + c * vq;
-                }
-            }
+        DICP_SVD3_ROTATE(0, 1)
+        DICP_SVD3_ROTATE(0, 2)
+        DICP_SVD3_ROTATE(1, 2)
         if (off == 0.0) break;
     }
     double nrm[3];
+#pragma unroll
     for (int j = 0; j < 3; ++j) nrm[j] = sqrt(G[j] * G[j] + G[3 + j] * G[3 + j] + G[6 + j] * G[6 + j]);
-    int ord[3] = {0, 1, 2};                                            // sort columns by singular value, descending
-    for (int a = 0; a < 2; ++a) for (int b = a + 1; b < 3; ++b) if (nrm[ord[b]] > nrm[ord[a]]) { const int t = ord[a]; ord[a] = ord[b]; ord[b] = t; }
-    double Vs[9];
+    DICP_SVD3_ORDER(0, 1)                                              // sort columns by singular value, descending
+    DICP_SVD3_ORDER(0, 2)
+    DICP_SVD3_ORDER(1, 2)
+#pragma unroll
     for (int j = 0; j < 3; ++j) {
-        S[j] = nrm[ord[j]];
-        for (int i = 0; i < 3; ++i) { Vs[i * 3 + j] = V[i * 3 + ord[j]]; U[i * 3 + j] = (S[j] > 0) ? G[i * 3 + ord[j]] / S[j] : 0.0; }
+        S[j] = nrm[j];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) U[i * 3 + j] = (S[j] > 0) ? G[i * 3 + j] / S[j] : 0.0;
     }
-    for (int i = 0; i < 9; ++i) V[i] = Vs[i];
     // rank-deficient input (planar / collinear clouds): complete U to an orthonormal basis
     const double tiny = 1e-14 * (S[0] > 0 ? S[0] : 1.0);
     if (S[0] <= 0) { for (int i = 0; i < 9; ++i) U[i] = (i % 4 == 0) ? 1.0 : 0.0; return; }
     if (S[1] <= tiny) {
         const double u0[3] = {U[0], U[3], U[6]};
         int k = (fabs(u0[0]) <= fabs(u0[1]) && fabs(u0[0]) <= fabs(u0[2])) ? 0 : (fabs(u0[1]) <= fabs(u0[2]) ? 1 : 2);
-        double e[3] = {0, 0, 0}; e[k] = 1.0;
-        const double d = u0[k];
+        const double e[3] = {k == 0 ? 1.0 : 0.0, k == 1 ? 1.0 : 0.0, k == 2 ? 1.0 : 0.0};
+        const double d = k == 0 ? u0[0] : (k == 1 ? u0[1] : u0[2]);
         double v[3] = {e[0] - d * u0[0], e[1] - d * u0[1], e[2] - d * u0[2]};
         const double n = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
         U[1] = v[0] / n; U[4] = v[1] / n; U[7] = v[2] / n;

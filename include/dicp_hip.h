@@ -615,6 +615,42 @@ typedef struct dicp_call_backward_layout {
 int dicp_call_backward_plan(int dtype, const dicp_weight_params* prm, const dicp_call* call, int want_tgt, int want_w, dicp_call_backward_layout* layout);
 int dicp_call_backward(int dtype, const dicp_weight_params* prm, const dicp_call* call, const dicp_call_grads* grads, void* stream);
 
+/* The same for ICP.pt2pt_dICP_SVD (ICP.py:533-591; BASELINE configs[1]'s "HIP kNN + 3x3 SVD"): a dense batch on the sweep path, every one of K iterations run.
+ * dicp_kabsch_call_forward: dicp_sweep_setup -> dicp_search_pose -> 3 x { dicp_query_order (before iteration 1) -> dicp_kabsch_forward } -> T -> dicp_transform_points;
+ * dicp_kabsch_call_backward: the cotangent of the found pose -> dicp_kabsch_step_bwd -> dicp_kabsch_bwd (gradients written, not added). */
+typedef struct dicp_kabsch_call {
+    const void* src;         /* (N,n,3) */
+    const void* tgt;         /* (N,m,c) */
+    const void* T_start;     /* (N,4,4): the starting pose of the search */
+    const void* w0;          /* (N,n) */
+    int32_t N, n, m, c;
+    int32_t K;
+    int32_t trim_on;         /* matches farther than trim_dist are gated out */
+    int32_t directions;      /* dicp_search_frame's */
+    int32_t pad0;
+    double trim_dist;
+    double quantum;          /* dicp_search_frame's */
+    double tolerance;        /* unused while every iteration runs; kept for the segment calls */
+    void* workspace;         /* dicp_kabsch_call_layout.total bytes, 256-byte aligned */
+    void* T_out;             /* (N,4,4): the pose found */
+    void* pc_out;            /* optional (N,n,3): the source under it (ICP.py:581) */
+} dicp_kabsch_call;
+typedef struct dicp_kabsch_call_layout {
+    size_t total, zeroed;
+    size_t costs, iterations;    /* results: (N,K) T, (N) T */
+    size_t pairs, counters, frame, keys, tperm, bucket, brange, tgs4, scratch, scratch_bytes, pose, pose_search, pose_used, partials, save, idx, rows_live, orders, gpose, gacc;
+    int32_t m_pad, nblk;
+} dicp_kabsch_call_layout;
+typedef struct dicp_kabsch_call_grads {
+    const void* gT;          /* (N,4,4) cotangent of the pose found, or NULL = zeros */
+    void* gsrc;              /* (N,n,3) written */
+    void* gtgt;              /* (N,m,c) written, or NULL */
+    void* gw;                /* (N,n) written, or NULL */
+} dicp_kabsch_call_grads;
+int dicp_kabsch_call_plan(int dtype, const dicp_kabsch_call* call, dicp_kabsch_call_layout* layout);
+int dicp_kabsch_call_forward(int dtype, const dicp_kabsch_call* call, void* stream);
+int dicp_kabsch_call_backward(int dtype, const dicp_kabsch_call* call, const dicp_kabsch_call_grads* grads, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2,6 +2,9 @@
 import sys
 import time
 
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from dicp_amd.ICP import ICP

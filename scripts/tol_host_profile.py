@@ -4,6 +4,9 @@ import cProfile
 import pstats
 import sys
 
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from dicp_amd.ICP import ICP

@@ -145,6 +145,17 @@ def test_new_entry_points_reject_bad_arguments(lib):
     assert blay.far > 0 and blay.slab > 0 and blay.gw_s == 0 and blay.w_s == 0 and blay.live < blay.zeroed <= blay.gpose and blay.nblk_w == lib.dicp_window_blocks(0, 300, 256)
     G = _lib.CallGrads()
     assert lib.dicp_call_backward(0, ctypes.byref(P), ctypes.byref(call), ctypes.byref(G), None) == 1
+    # dicp_kabsch_call_*: the same contract
+    kc = _lib.KabschCall(N=2, n=300, m=200, c=3, K=5)
+    kl = _lib.KabschCallLayout()
+    assert lib.dicp_kabsch_call_plan(0, ctypes.byref(kc), ctypes.byref(kl)) == 0
+    assert kl.m_pad == 256 and 0 == kl.costs < kl.iterations < kl.zeroed <= kl.frame and kl.total > kl.gacc > kl.gpose > kl.orders
+    kc.c = 4
+    assert lib.dicp_kabsch_call_plan(0, ctypes.byref(kc), ctypes.byref(kl)) == 2
+    kc.c = 3
+    assert lib.dicp_kabsch_call_plan(2, ctypes.byref(kc), ctypes.byref(kl)) == 3
+    assert lib.dicp_kabsch_call_forward(0, ctypes.byref(kc), None) == 1
+    assert lib.dicp_kabsch_call_backward(0, ctypes.byref(kc), ctypes.byref(_lib.KabschCallGrads()), None) == 1
 
 
 def test_sizes_and_argument_checks(lib):

@@ -195,3 +195,53 @@ def test_the_c_abi_alone():
     # a misaligned workspace is refused before anything is launched
     call.workspace = ws.data_ptr() + 16
     assert lib.dicp_call_forward(_lib.F32, ctypes.byref(P), ctypes.byref(call), st) == 5
+
+
+@pytest.mark.parametrize("dtype,K,weights,seed_T", [(torch.float32, 10, False, False), (torch.float64, 4, True, False), (torch.float32, 1, False, True), (torch.float32, 2, True, False)])
+def test_svd_step_one_call_equals_the_per_buffer_loop(dtype, K, weights, seed_T):
+    """ICP.pt2pt_dICP_SVD (ICP.py:533-591) through dicp_kabsch_call_* against KabschLoop + transform_points: pose, cloud, costs, iterations and the gradients
+    w.r.t. source, target and weight.  (The two differ in ONE rounding: the first search pose is a kernel's here and torch matmuls there; with the frame
+    at the origin -- these clouds -- both are exact copies of the start pose.)"""
+    N, n, m = 5, 3000, 2800
+    src, tgt = make_pairs(N, n, m, seed=31, dtype=dtype)
+    w = ((torch.rand((N, n), generator=torch.Generator().manual_seed(9), dtype=torch.float64) > 0.05).to(dtype) * 0.8) if weights else None
+    T0 = torch.eye(4, dtype=dtype).repeat(N, 1, 1)
+    T0[:, :3, 3] = torch.tensor([0.04, 0.01, -0.03], dtype=dtype)
+    res = []
+    for one in (True, False):
+        icp = ICP(icp_type="pt2pt", differentiable=True, max_iterations=K, tolerance=1e-12)
+        icp.const_iter, icp.knn_variant, icp.svd_seed_T_init = True, _lib.KNN_SWEEP, seed_T
+        icp._tuning["one_call"] = one
+        taken = []
+        real = _call.KabschCall.apply
+        _call.KabschCall.apply = staticmethod(lambda *a: (taken.append(1), real(*a))[1])
+        try:
+            S, Tg = src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True)
+            W = w.to(DEV).requires_grad_(True) if w is not None else None
+            pc, T = icp.pt2pt_dICP_SVD(S, Tg, T0.to(DEV), trim_dist=3.0, weight=W)
+            (T.sum() + 1e-3 * (pc ** 2).sum()).backward()
+            torch.cuda.synchronize()
+        finally:
+            _call.KabschCall.apply = real
+        assert len(taken) == (1 if one else 0)
+        res.append((pc.detach(), T.detach(), icp.svd_stats["costs"].clone(), icp.svd_stats["iterations"].clone(), S.grad, Tg.grad, W.grad if W is not None else None))
+    a, b = res
+    assert a[0].shape == b[0].shape == (N, n, 3) and a[2].shape == b[2].shape == (N, K)
+    tol = 2e-6 if dtype == torch.float32 else 1e-13
+    for i in (0, 1, 2):
+        assert float((a[i] - b[i]).abs().max()) <= tol * max(1.0, float(b[i].abs().max())), i
+    assert torch.equal(a[3], b[3])
+    for i in (4, 5, 6):
+        assert (a[i] is None) == (b[i] is None)
+        if a[i] is not None:
+            assert float((a[i] - b[i]).abs().max()) <= (2e-5 if dtype == torch.float32 else 1e-12) * max(1e-30, float(b[i].abs().max())), i
+
+
+def test_svd_step_which_calls_take_it():
+    src, tgt = make_pairs(2, 1024, 1024, seed=4, dtype=torch.float32)
+    S, Tg, Ti, W = src.to(DEV), tgt[:, :, :3].contiguous().to(DEV), torch.eye(4).repeat(2, 1, 1).to(DEV), torch.ones((2, 1024), device=DEV)
+    assert _call.kabsch_eligible(S, Tg, Ti, W, True, _lib.KNN_SWEEP, None, None)
+    assert not _call.kabsch_eligible(S, Tg, Ti, W, False, _lib.KNN_SWEEP, None, None)                  # tolerance mode: the host reads the counters between segments
+    assert not _call.kabsch_eligible(S, Tg, Ti, W, True, _lib.KNN_AUTO, None, None)                    # 2 x 1024 x 1024: brute force
+    assert not _call.kabsch_eligible(S, Tg, Ti, W, True, _lib.KNN_SWEEP, torch.tensor([1024, 1000], dtype=torch.int32, device=DEV), None)
+    assert not _call.kabsch_eligible(S, Tg, Ti.double(), W, True, _lib.KNN_SWEEP, None, None)

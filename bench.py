@@ -656,7 +656,7 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
             "finite": sane,
         }
         if ev_ms["knn"] and ev_ms["accumulate"] and not brute:
-            cf = max(k for k in getattr(icp, "_tuning", {}).get("sweep_resort", (0, 1, 2, 3)) if k < K) if certified is not None else K
+            cf = max(k for k in (getattr(icp, "_tuning", {}).get("sweep_resort") or (0, 1, 2, 3)) if k < K) if certified is not None else K
             classes = {"full_search": list(range(0, min(cf, K))), "certifying_search": [cf] if cf < K else [], "certified": list(range(cf + 1, K))}
             line["ms_by_iteration_class"] = {
                 nm: {"iterations": ks, "search_ms_mean": round(sum(ev_ms["knn"][k] for k in ks) / len(ks), 4),

@@ -18,7 +18,7 @@ import torch
 import yaml
 
 from . import _call, _lib
-from ._ops import CallHints, ICPLoop, KabschLoop, LoopConfig, compute_device, prebuild_search, transform_points
+from ._ops import CallHints, ICPLoop, KabschLoop, LoopConfig, compute_device, prebuild_search, resort_schedule, transform_points
 from .nn import nn
 
 
@@ -59,7 +59,7 @@ class ICP:
         # measurements in DESIGN.md A/B'd).  Not part of the call surface.
         self._tuning = dict(
             small_loop=True,                  # small clouds: one block per cloud runs whole chunks of iterations
-            sweep_resort=(0, 1, 2, 3),        # iterations at which the sweep re-orders its queries by x under the current pose
+            sweep_resort=None,                # iterations at which the sweep re-orders its queries by x under the current pose (None: (0,1,2,3); small calls (0,1))
             cert_from=None,                   # iteration of the certifying search (None: the last re-ordering of the queries)
             cert_sets=True,                   # a match with a runner-up within rounding keeps a set of 4 candidate rows, re-scored per iteration
             cert_hint=True,                   # a shape whose clouds all switched their certificates off is searched plainly in the next calls
@@ -130,7 +130,7 @@ class ICP:
             match_ratio_thresh=float(self.match_ratio_thresh),
             knn_variant=self.knn_variant, bwd_window=bool(self.bwd_window), stats_out=self.knn_stats, hints=self._hints,
             sync_every=self.sync_every, timing_events=self._timing_events, small_loop=bool(self._tuning["small_loop"]),
-            src_rows=src_rows, tgt_rows=tgt_rows, sweep_resort=tuple(int(v) for v in self._tuning["sweep_resort"]), reuse_matches=bool(self.reuse_matches), cert_from=self._tuning["cert_from"],
+            src_rows=src_rows, tgt_rows=tgt_rows, sweep_resort=resort_schedule(self._tuning["sweep_resort"], source.shape[0], source.shape[1], int(self.max_iterations), bool(self.reuse_matches), self._tuning["cert_from"]), reuse_matches=bool(self.reuse_matches), cert_from=self._tuning["cert_from"],
             bwd_skip_eps=self.bwd_skip_eps, cert_backoff=bool(self._tuning["cert_backoff"]), cert_sets=bool(self._tuning["cert_sets"]), cert_hint=bool(self._tuning["cert_hint"]),
             plan_call=bool(self._tuning["plan_call"]), bwd_tail=bool(self._tuning["bwd_tail"]), first_search=first_search,
             # nn.py:14-16 via ICP.py:140: soft correspondences -- the same library loop with dicp_gumbel_nn in place of the search, the same one node

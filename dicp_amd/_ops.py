@@ -540,6 +540,21 @@ class CallHints:
 
 
 CERT_MIN_WORK = 2.0e6        # certified point-iterations (iterations after the certifying search x N x n) below which match certificates are not used
+RESORT_SMALL_POINTS = 262144  # source points of a batch below which a call without certificates re-orders its queries before iterations 0 and 1 only: a re-ordering is
+                              # ~23 us of latency whatever the size, and what it saves the next searches shrinks with the batch (profiles/r04_mid_size_resort.txt:
+                              # 32 x 4096: 0.561 -> 0.514 ms per call; 64 x 8192: the full schedule stays best, 0.714 against 0.815)
+
+
+def resort_schedule(resort, N, n, Kmax, reuse_matches, cert_from):
+    """The iterations before which the sweep re-orders its queries: `resort` as given, or (None) by the size of the call."""
+    if resort is not None:
+        return tuple(int(v) for v in resort)
+    full = (0, 1, 2, 3)
+    cf = max([k for k in full if k < Kmax] or [0]) if cert_from is None else max(0, int(cert_from))
+    certs = reuse_matches and Kmax - 1 - cf >= 3 and float(Kmax - 1 - cf) * N * n >= CERT_MIN_WORK
+    return (0, 1) if (not certs and N * n < RESORT_SMALL_POINTS) else full
+
+
 
 
 @dataclass

@@ -143,54 +143,12 @@ class CallLoop(torch.autograd.Function):
                 _lib.check(lib.dicp_transform_points_bwd(code, _p(src), _p(pose_K), _p(gpc.contiguous()), _p(gsrc_pc), _p(pcp), N, n, st), "dicp_transform_points_bwd")
                 gT_pc = _ops._pose_sums_to_gT(pcp, N, dt, dev, st)
                 gT = gT_pc if gT is None else gT + gT_pc
-            L = _lib.CallBackwardLayout()
-            _lib.check(lib.dicp_call_backward_plan(code, ctypes.byref(P), ctypes.byref(call), int(want_tgt), int(want_w), ctypes.byref(L)), "dicp_call_backward_plan")
-            eps = cfg.bwd_skip_eps
-            if eps is None:
-                eps = 2.0 ** -22 if dt == torch.float32 else 2.0 ** -40
-            if cfg.loss_name == "huber" and not cfg.differentiable:
-                eps = 0.0
-            ws = torch.empty((L.total // es,), dtype=dt, device=dev)
-            live = ws[L.live // es:L.live // es + (K + 1 + (es // 4) - 1) * 4 // es].view(torch.int32)[:K + 1]
-            if stats is not None and eps > 0.0:
-                stats["bwd_live"] = live
-            # where the sweeps of the previous call of this shape ended decides which iterations go to the one launch (ICPLoop.backward)
-            tail_from, hints, entry = 0, None, None
-            use_tail = eps > 0.0 and cfg.bwd_tail and cfg.hints is not None
-            if use_tail:
-                cfg.hints.check()
-                hints = cfg.hints.tail_records(dev, (N, n, m, K, dt))
-                hint = next((h for h in reversed(hints) if h[2] == (N, n, K) and h[1].query()), None)
-                if hint is not None and L.nblk_w <= lib.dicp_bwd_tail_max_blocks(code):
-                    counts = hint[0][:K].tolist()
-                    tail_from = min(K, max(0, next((k for k in range(K) if counts[k] * 8 >= N), K) - 1))
-                if len(hints) >= 4:         # four pinned buffers in rotation
-                    if hints[0][1].query() and hints[0][0].numel() >= K + 1:
-                        cfg.hints.check()
-                        entry = hints.pop(0)
-                else:
-                    entry = [torch.empty((max(K + 1, 64),), dtype=torch.int32).pin_memory(), None, None, K, False, 0]
-            if stats is not None:
-                stats["bwd_tail_from"] = int(tail_from)
-                if tail_from > 0:
-                    a0 = L.arrive // es
-                    stats["bwd_tail_error"] = ws[a0:a0 + (N + 1 + (es // 4) - 1) * 4 // es].view(torch.int32)[N:N + 1]
-            gsrc = torch.empty_like(src)
-            gtgt = torch.empty_like(tgt) if want_tgt else None
-            gw = torch.empty_like(w0) if want_w else None
-            gT0 = torch.empty((N, 4, 4), dtype=dt, device=dev)
-            gTc = gT.contiguous() if gT is not None else None
-            G = _lib.CallGrads(gT=gTc.data_ptr() if gTc is not None else None, gsrc=gsrc.data_ptr(), gtgt=gtgt.data_ptr() if want_tgt else None,
-                               gT0=gT0.data_ptr(), gw=gw.data_ptr() if want_w else None, workspace=ws.data_ptr(), skip_eps=float(eps), tail_from=int(tail_from),
-                               live_host=entry[0].data_ptr() if entry is not None else None)
-            _lib.check(lib.dicp_call_backward(code, ctypes.byref(P), ctypes.byref(call), ctypes.byref(G), st), "dicp_call_backward")
-            if entry is not None:
-                entry[1] = torch.cuda.Event()
-                entry[1].record()
-                cfg.hints.serial += 1
-                entry[2], entry[3], entry[4], entry[5] = (N, n, K), K, False, cfg.hints.serial
-                hints.append(entry)
-                cfg.hints.newest_tail = entry
+            base = ctx.ws.data_ptr()
+            F = _lib.LoopBackwardIn(src=src.data_ptr(), tgt_sorted=base + FL.tgt_sorted, w0=w0.data_ptr() if w0 is not None else None, tperm=base + FL.tperm,
+                                    qorder=base + FL.orders + (FL.n_orders - 1) * N * n * 4, spos=base + FL.spos, poses=base + FL.poses, deltas=base + FL.deltas,
+                                    areg=base + FL.areg, alive=base + FL.alive, N=N, n=n, m=m, c=call.c, K=K, K_cap=K, m_pad=FL.m_pad, dim=call.dim,
+                                    knn_variant=_lib.KNN_SWEEP | ((1 << 25) if (call.flags & _lib.CALL_NO_SMALL_LOOP) else 0))
+            gsrc, gtgt, gT0, gw = _ops.backward_once(lib, code, P, F, cfg, src, tgt, w0, gT, want_tgt, want_w)
             if gsrc_pc is not None:
                 gsrc += gsrc_pc
         return gsrc, gtgt, gT0, gw, None

@@ -100,6 +100,12 @@ class CallBackwardLayout(ctypes.Structure):
                                     "partials", "tail_partials")] + [("nblk_w", i32), ("pad0", i32)])
 
 
+class LoopBackwardIn(ctypes.Structure):
+    """dicp_loop_backward_in (include/dicp_hip.h)."""
+    _fields_ = ([(k, vp) for k in ("src", "tgt_sorted", "w0", "tperm", "qorder", "spos", "poses", "deltas", "areg", "alive", "src_rows", "tgt_rows")]
+                + [(k, i32) for k in ("N", "n", "m", "c", "K", "K_cap", "m_pad", "dim", "knn_variant", "pad0")])
+
+
 class KabschCall(ctypes.Structure):
     """dicp_kabsch_call (include/dicp_hip.h)."""
     _fields_ = [("src", vp), ("tgt", vp), ("T_start", vp), ("w0", vp), ("N", i32), ("n", i32), ("m", i32), ("c", i32), ("K", i32), ("trim_on", i32), ("directions", i32), ("pad0", i32),
@@ -180,6 +186,8 @@ _SIGNATURES = {
     "dicp_call_forward": ([i32, ctypes.POINTER(WeightParams), ctypes.POINTER(Call), vp], ctypes.c_int),
     "dicp_call_backward_plan": ([i32, ctypes.POINTER(WeightParams), ctypes.POINTER(Call), i32, i32, ctypes.POINTER(CallBackwardLayout)], ctypes.c_int),
     "dicp_call_backward": ([i32, ctypes.POINTER(WeightParams), ctypes.POINTER(Call), ctypes.POINTER(CallGrads), vp], ctypes.c_int),
+    "dicp_loop_backward_plan": ([i32, ctypes.POINTER(WeightParams), ctypes.POINTER(LoopBackwardIn), i32, i32, ctypes.POINTER(CallBackwardLayout)], ctypes.c_int),
+    "dicp_loop_backward": ([i32, ctypes.POINTER(WeightParams), ctypes.POINTER(LoopBackwardIn), ctypes.POINTER(CallGrads), vp], ctypes.c_int),
     "dicp_kabsch_call_plan": ([i32, ctypes.POINTER(KabschCall), ctypes.POINTER(KabschCallLayout)], ctypes.c_int),
     "dicp_kabsch_call_forward": ([i32, ctypes.POINTER(KabschCall), vp], ctypes.c_int),
     "dicp_kabsch_call_backward": ([i32, ctypes.POINTER(KabschCall), ctypes.POINTER(KabschCallGrads), vp], ctypes.c_int),

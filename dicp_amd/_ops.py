@@ -647,6 +647,67 @@ def _converged_at(pending):
     return k0 + int(zero[0, 0]) + 1 if zero.numel() else None
 
 
+def backward_once(lib, code, P, F, cfg, src, tgt, w0c, gT, want_tgt, want_w):
+    """The reverse sweep of a sweep-path call whose iterations all take the windowed form inside one history slab, from ONE library call (dicp_loop_backward):
+    F = _lib.LoopBackwardIn naming the forward's buffers.  Allocates the pass's workspace and results, places the one-launch tail by the hints of the previous
+    calls of this shape and records this call's (ICPLoop.backward documents both).  -> (gsrc, gtgt, gT0, gw)"""
+    dev, dt = src.device, src.dtype
+    es = src.element_size()
+    N, n, m, K, Kcap = F.N, F.n, F.m, F.K, F.K_cap
+    stats = cfg.stats_out
+    st = _stream()
+    L = _lib.CallBackwardLayout()
+    _lib.check(lib.dicp_loop_backward_plan(code, ctypes.byref(P), ctypes.byref(F), int(want_tgt), int(want_w), ctypes.byref(L)), "dicp_loop_backward_plan")
+    eps = cfg.bwd_skip_eps
+    if eps is None:
+        eps = 2.0 ** -22 if dt == torch.float32 else 2.0 ** -40
+    if cfg.loss_name == "huber" and not cfg.differentiable:       # (their reference gradient is NaN at an exactly zero residual whatever the cotangent)
+        eps = 0.0
+    ws = torch.empty((L.total // es,), dtype=dt, device=dev)
+    if stats is not None and eps > 0.0:
+        stats["bwd_live"] = ws[L.live // es:L.live // es + (Kcap + 1 + (es // 4) - 1) * 4 // es].view(torch.int32)[:Kcap + 1]
+    tail_from, hints, entry = 0, None, None
+    capturing = torch.cuda.is_current_stream_capturing()
+    use_tail = eps > 0.0 and cfg.bwd_tail and cfg.hints is not None
+    if use_tail:
+        if not capturing:
+            cfg.hints.check()
+        hints = cfg.hints.tail_records(dev, (N, n, m, Kcap, dt), any_stream=capturing)
+        hint = next((h for h in reversed(hints) if h[2] == (N, n, K) and (capturing or h[1].query())), None)
+        if hint is not None and L.nblk_w <= lib.dicp_bwd_tail_max_blocks(code):
+            counts = hint[0][:K].tolist()
+            tail_from = min(K, max(0, next((k for k in range(K) if counts[k] * 8 >= N), K) - 1))
+        if not capturing:
+            if len(hints) >= 4:         # four pinned buffers in rotation: the oldest one is re-used once its copy has landed (and has been looked at)
+                if hints[0][1].query() and hints[0][0].numel() >= Kcap + 1:
+                    cfg.hints.check()
+                    entry = hints.pop(0)
+            else:
+                entry = [torch.empty((max(Kcap + 1, 64),), dtype=torch.int32).pin_memory(), None, None, Kcap, False, 0]
+    if stats is not None:
+        stats["bwd_tail_from"] = int(tail_from)
+        if tail_from > 0:
+            a0 = L.arrive // es
+            stats["bwd_tail_error"] = ws[a0:a0 + (N + 1 + (es // 4) - 1) * 4 // es].view(torch.int32)[N:N + 1]
+    gsrc = torch.empty_like(src)
+    gtgt = torch.empty_like(tgt) if want_tgt else None
+    gw = torch.empty_like(w0c) if want_w else None
+    gT0 = torch.empty((N, 4, 4), dtype=dt, device=dev)
+    gTc = gT.contiguous() if gT is not None else None
+    G = _lib.CallGrads(gT=gTc.data_ptr() if gTc is not None else None, gsrc=gsrc.data_ptr(), gtgt=gtgt.data_ptr() if want_tgt else None,
+                       gT0=gT0.data_ptr(), gw=gw.data_ptr() if want_w else None, workspace=ws.data_ptr(), skip_eps=float(eps), tail_from=int(tail_from),
+                       live_host=entry[0].data_ptr() if entry is not None else None)
+    _lib.check(lib.dicp_loop_backward(code, ctypes.byref(P), ctypes.byref(F), ctypes.byref(G), st), "dicp_loop_backward")
+    if entry is not None:
+        entry[1] = torch.cuda.Event()
+        entry[1].record()
+        cfg.hints.serial += 1
+        entry[2], entry[3], entry[4], entry[5] = (N, n, K), Kcap, False, cfg.hints.serial
+        hints.append(entry)
+        cfg.hints.newest_tail = entry
+    return gsrc, gtgt, gT0, gw
+
+
 class ICPLoop(torch.autograd.Function):
     """The whole iteration loop of ICP.dICP (ICP.py:131-260) as ONE autograd node.
 
@@ -1005,11 +1066,23 @@ class ICPLoop(torch.autograd.Function):
                 _lib.check(lib.dicp_transform_points_bwd(code, _p(src), _p(poses[K]), _p(gpc.contiguous()), _p(gsrc_pc), _p(pcp), N, n, st), "dicp_transform_points_bwd")
                 gT_pc = _pose_sums_to_gT(pcp, N, dt, dev, st)
                 gT = gT_pc if gT is None else gT + gT_pc
+            want_tgt, want_w = ctx.needs_input_grad[1], ctx.needs_input_grad[3] and w0c is not None
+            cv = 6 if cfg.icp_type == "pt2pl" else 3
+            if owned and soft is None and cfg.timing_events is None and n_spos == 1 and n_idx == 0 and c == cv and segs and K >= 1:
+                # every iteration takes the windowed form inside one slab: the whole pass is one library call (dicp_loop_backward) on one allocation.
+                # (Tolerance mode feels it most: there the host cannot run ahead of the GPU, and what it does before the pass's first launch is exposed.)
+                F = _lib.LoopBackwardIn(src=src.data_ptr(), tgt_sorted=tgt_s.data_ptr(), w0=w0c.data_ptr() if w0c is not None else None, tperm=tperm.data_ptr(),
+                                        qorder=qorders[-1].data_ptr(), spos=spos_slabs[0].data_ptr(), poses=poses.data_ptr(), deltas=deltas.data_ptr(), areg=areg.data_ptr(),
+                                        alive=alive.data_ptr(), src_rows=cfg.src_rows.data_ptr() if cfg.src_rows is not None else None,
+                                        tgt_rows=cfg.tgt_rows.data_ptr() if cfg.tgt_rows is not None else None, N=N, n=n, m=m, c=tgt_s.shape[2], K=K, K_cap=Kmax, m_pad=m_pad,
+                                        dim=int(cfg.dim), knn_variant=kind | ((0 if cfg.small_loop else 1) << 25))
+                gsrc, gtgt, gT0, gw = backward_once(lib, code, P, F, cfg, src, tgt, w0c, gT, bool(want_tgt), bool(want_w))
+                if gsrc_pc is not None:
+                    gsrc += gsrc_pc
+                return gsrc, gtgt, gT0, gw, None
             gpose = torch.empty((N, 12), dtype=torch.float64, device=dev)
             gtmp = torch.empty_like(gpose)
             _lib.check(lib.dicp_pose_grad_in(code, _p(gT.contiguous()) if gT is not None else None, _p(gpose), N, st), "dicp_pose_grad_in")
-            want_tgt, want_w = ctx.needs_input_grad[1], ctx.needs_input_grad[3] and w0c is not None
-            cv = 6 if cfg.icp_type == "pt2pl" else 3
             all_windowed = None         # set below: every iteration takes the windowed form -> dicp_window_reduce writes gtgt
             gtgt = None
             # Two forms of accumulate_bwd.  Atomic form (dicp_accumulate_bwd): original order, no set-up.  Windowed form

@@ -178,14 +178,13 @@ int dicp_call_forward(int dtype, const dicp_weight_params* prm, const dicp_call*
     return dicp_transform_points(dtype, c->src, pose_K, c->pc_out ? c->pc_out : at(c, L.pc), c->N, c->n, stream);
 }
 
-int dicp_call_backward_plan(int dtype, const dicp_weight_params* prm, const dicp_call* c, int want_tgt, int want_w, dicp_call_backward_layout* L) {
-    if (!prm || !c || !L) return DICP_ERR_NULL;
-    if (!call_ok(dtype, c)) return dtype != DICP_F32 && dtype != DICP_F64 ? DICP_ERR_DTYPE : DICP_ERR_SHAPE;
-    const size_t es = esize(dtype), N = c->N, n = c->n, K = c->K;
-    const int m_pad = dicp_padded_targets(c->m), cv = prm->mode == DICP_PT2PL ? 6 : 3;
+// the reverse sweep of ONE windowed run over iterations [0, K) -- dicp_call_backward's and dicp_loop_backward's common body
+static int backward_layout(int dtype, const dicp_weight_params* prm, int N_, int n_, int m_, int Kcap_, bool has_w0, int want_tgt, int want_w, dicp_call_backward_layout* L) {
+    const size_t es = esize(dtype), N = N_, n = n_, K = Kcap_;
+    const int m_pad = dicp_padded_targets(m_), cv = prm->mode == DICP_PT2PL ? 6 : 3;
     memset(L, 0, sizeof(*L));
-    L->nblk_w = dicp_window_blocks(dtype, c->n, m_pad);
-    const size_t nblk = (size_t)(L->nblk_w > dicp_accumulate_blocks(c->n) ? L->nblk_w : dicp_accumulate_blocks(c->n));
+    L->nblk_w = dicp_window_blocks(dtype, n_, m_pad);
+    const size_t nblk = (size_t)(L->nblk_w > dicp_accumulate_blocks(n_) ? L->nblk_w : dicp_accumulate_blocks(n_));
     Carver w;
     // zero-initialised: the truncated sweep's state, and the rows matched outside every window
     L->mref = w.take(N * 8);
@@ -197,7 +196,7 @@ int dicp_call_backward_plan(int dtype, const dicp_weight_params* prm, const dicp
     L->gpose = w.take(N * 12 * 8);
     L->gtmp = w.take(N * 12 * 8);
     L->src_s = w.take(N * n * 3 * es);
-    L->w_s = c->w0 ? w.take(N * n * es) : 0;
+    L->w_s = has_w0 ? w.take(N * n * es) : 0;
     L->gsrc_s = w.take(N * n * 3 * es);
     L->gw_s = want_w ? w.take(N * n * es) : 0;
     L->slab = want_tgt ? w.take(N * (size_t)L->nblk_w * dicp_window_rows(dtype) * cv * es) : 0;
@@ -209,20 +208,16 @@ int dicp_call_backward_plan(int dtype, const dicp_weight_params* prm, const dicp
     return 0;
 }
 
-int dicp_call_backward(int dtype, const dicp_weight_params* prm, const dicp_call* c, const dicp_call_grads* g, void* stream) {
-    if (!prm || !c || !g || !c->workspace || !g->workspace || !g->gsrc || !g->gT0 || !c->src || !c->tgt) return DICP_ERR_NULL;
-    if (!c->need_grad) return DICP_ERR_ENUM;
+static int backward_once(int dtype, const dicp_weight_params* prm, const dicp_loop_backward_in* f, const dicp_call_grads* g, void* stream) {
     const int want_tgt = g->gtgt != nullptr, want_w = g->gw != nullptr;
-    if (want_w && !c->w0) return DICP_ERR_NULL;
-    dicp_call_layout F;
-    dicp_call_backward_layout L;
-    if (int rc = dicp_call_plan(dtype, c, &F)) return rc;
-    if (int rc = dicp_call_backward_plan(dtype, prm, c, want_tgt, want_w, &L)) return rc;
+    if (want_w && !f->w0) return DICP_ERR_NULL;
     const int cv = prm->mode == DICP_PT2PL ? 6 : 3;
-    if (c->c != cv) return DICP_ERR_SHAPE;           // (every element of gtgt is written once by dicp_window_reduce: the row is the gradient's row)
-    if ((((uintptr_t)c->workspace | (uintptr_t)g->workspace) & 255) != 0) return DICP_ERR_ALIGN;
-    const size_t N = c->N, n = c->n;
-    const int K = c->K;
+    if (f->c != cv) return DICP_ERR_SHAPE;           // (every element of gtgt is written once by dicp_window_reduce: the row is the gradient's row)
+    if (((uintptr_t)g->workspace & 255) != 0) return DICP_ERR_ALIGN;
+    dicp_call_backward_layout L;
+    backward_layout(dtype, prm, f->N, f->n, f->m, f->K_cap, f->w0 != nullptr, want_tgt, want_w, &L);
+    const size_t N = f->N, n = f->n;
+    const int K = f->K;
     const bool skip = g->skip_eps > 0.0;
     int tail_from = skip ? g->tail_from : 0;
     if (tail_from < 0) return DICP_ERR_SHAPE;
@@ -232,20 +227,20 @@ int dicp_call_backward(int dtype, const dicp_weight_params* prm, const dicp_call
     if (hipError_t e = hipMemsetAsync(W, 0, L.zeroed, st)) return -(int)e;
     double* gpose = (double*)(W + L.gpose);
     double* gtmp = (double*)(W + L.gtmp);
-    if (int rc = dicp_pose_grad_in(dtype, g->gT, gpose, c->N, stream)) return rc;
+    if (int rc = dicp_pose_grad_in(dtype, g->gT, gpose, f->N, stream)) return rc;
     // ONE slot order serves every iteration: the last query order of the forward
-    const int32_t* qo = (const int32_t*)at(c, F.orders) + (size_t)(F.n_orders - 1) * N * n;
-    if (int rc = dicp_gather_rows(dtype, c->src, qo, c->N, c->n, c->n, 3, W + L.src_s, stream)) return rc;
-    if (c->w0)
-        if (int rc = dicp_gather_rows(dtype, c->w0, qo, c->N, c->n, c->n, 1, W + L.w_s, stream)) return rc;
-    int32_t* spos = (int32_t*)at(c, F.spos);
-    const int32_t* spos_ref = spos + (size_t)(K - 1) * N * n;      // windows placed by the last iteration's matches
+    const int32_t* qo = f->qorder;
+    if (int rc = dicp_gather_rows(dtype, f->src, qo, f->N, f->n, f->n, 3, W + L.src_s, stream)) return rc;
+    if (f->w0)
+        if (int rc = dicp_gather_rows(dtype, f->w0, qo, f->N, f->n, f->n, 1, W + L.w_s, stream)) return rc;
+    const int32_t* spos_ref = f->spos + (size_t)(K - 1) * N * n;      // windows placed by the last iteration's matches
     dicp_loop_buffers B;
     memset(&B, 0, sizeof(B));
-    B.src = W + L.src_s; B.tgt = at(c, F.tgt_sorted); B.w_init = c->w0 ? W + L.w_s : nullptr; B.c = c->c; B.K = K;
-    B.knn_variant = DICP_KNN_SWEEP | ((c->flags & DICP_CALL_NO_SMALL_LOOP) ? (1 << 25) : 0);
-    B.m_pad = F.m_pad; B.idx_per_iter = 1; B.qorder = qo; B.spos = spos; B.spos_ref = spos_ref; B.gts_far = want_tgt ? W + L.far : nullptr;
-    B.poses = at(c, F.poses); B.deltas = at(c, F.deltas); B.areg = (double*)at(c, F.areg); B.alive = at(c, F.alive);
+    B.src = W + L.src_s; B.tgt = f->tgt_sorted; B.w_init = f->w0 ? W + L.w_s : nullptr; B.c = f->c; B.K = f->K_cap;
+    B.knn_variant = f->knn_variant;
+    B.m_pad = f->m_pad; B.idx_per_iter = 1; B.qorder = qo; B.spos = (int32_t*)f->spos; B.spos_ref = spos_ref; B.gts_far = want_tgt ? W + L.far : nullptr;
+    B.poses = (void*)f->poses; B.deltas = (void*)f->deltas; B.areg = (double*)f->areg; B.alive = (void*)f->alive;
+    B.src_rows = f->src_rows; B.tgt_rows = f->tgt_rows;
     B.bwd_overwrite = 1;
     if (skip) {
         B.bwd_skip = (int32_t*)(W + L.decisions); B.bwd_mref = (double*)(W + L.mref); B.bwd_live = (int32_t*)(W + L.live);
@@ -254,22 +249,60 @@ int dicp_call_backward(int dtype, const dicp_weight_params* prm, const dicp_call
     B.bwd_skip_eps = g->skip_eps;
     B.bwd_tail_from = tail_from;
     B.bwd_tail_partials = tail_from > 0 ? W + L.tail_partials : nullptr;
-    if (int rc = dicp_icp_backward(dtype, prm, &B, c->N, c->n, c->m, c->dim, gpose, gtmp, 0, W + L.gs, W + L.gb, W + L.gsrc_s, want_tgt ? W + L.slab : nullptr,
+    if (int rc = dicp_icp_backward(dtype, prm, &B, f->N, f->n, f->m, f->dim, gpose, gtmp, 0, W + L.gs, W + L.gb, W + L.gsrc_s, want_tgt ? W + L.slab : nullptr,
                                    want_w ? W + L.gw_s : nullptr, W + L.partials, 0, K, stream))
         return rc;
     // the tail launch leaves the cotangent of pose_0 with the last pose sums already in it (the first iteration of the pass is never the tail's)
     const bool folded = tail_from > 0 && (tail_from - (tail_from >= K ? 1 : 0)) > 0;
     if (K % 2) { double* t = gpose; gpose = gtmp; gtmp = t; }
     if (skip && g->live_host)        // where the sweeps ended, for the next call's tail (and the tail's error word)
-        if (hipError_t e = hipMemcpyAsync(g->live_host, W + L.live, (size_t)(K + 1) * 4, hipMemcpyDeviceToHost, st)) return -(int)e;
-    if (int rc = dicp_permute_rows(dtype, W + L.gsrc_s, qo, c->N, c->n, c->n, c->n, 3, 3, g->gsrc, c->n, 3, stream)) return rc;
+        if (hipError_t e = hipMemcpyAsync(g->live_host, W + L.live, (size_t)(f->K_cap + 1) * 4, hipMemcpyDeviceToHost, st)) return -(int)e;
+    if (int rc = dicp_permute_rows(dtype, W + L.gsrc_s, qo, f->N, f->n, f->n, f->n, 3, 3, g->gsrc, f->n, 3, stream)) return rc;
     if (want_w)
-        if (int rc = dicp_permute_rows(dtype, W + L.gw_s, qo, c->N, c->n, c->n, c->n, 1, 1, g->gw, c->n, 1, stream)) return rc;
+        if (int rc = dicp_permute_rows(dtype, W + L.gw_s, qo, f->N, f->n, f->n, f->n, 1, 1, g->gw, f->n, 1, stream)) return rc;
     if (want_tgt)
-        if (int rc = dicp_window_reduce(dtype, W + L.slab, spos_ref, qo, (const int32_t*)at(c, F.tperm), W + L.far, nullptr, c->N, c->n, c->m, F.m_pad, cv,
-                                        g->gtgt, c->c, 1, stream))
+        if (int rc = dicp_window_reduce(dtype, W + L.slab, spos_ref, qo, f->tperm, W + L.far, f->src_rows, f->N, f->n, f->m, f->m_pad, cv,
+                                        g->gtgt, f->c, 1, stream))
             return rc;
-    return dicp_pose_grad_out(dtype, gpose, folded ? nullptr : W + L.partials, folded ? 0 : L.nblk_w, g->gT0, c->N, stream);
+    return dicp_pose_grad_out(dtype, gpose, folded ? nullptr : W + L.partials, folded ? 0 : L.nblk_w, g->gT0, f->N, stream);
+}
+
+int dicp_call_backward_plan(int dtype, const dicp_weight_params* prm, const dicp_call* c, int want_tgt, int want_w, dicp_call_backward_layout* L) {
+    if (!prm || !c || !L) return DICP_ERR_NULL;
+    if (!call_ok(dtype, c)) return dtype != DICP_F32 && dtype != DICP_F64 ? DICP_ERR_DTYPE : DICP_ERR_SHAPE;
+    return backward_layout(dtype, prm, c->N, c->n, c->m, c->K, c->w0 != nullptr, want_tgt, want_w, L);
+}
+
+int dicp_call_backward(int dtype, const dicp_weight_params* prm, const dicp_call* c, const dicp_call_grads* g, void* stream) {
+    if (!prm || !c || !g || !c->workspace || !g->workspace || !g->gsrc || !g->gT0 || !c->src || !c->tgt) return DICP_ERR_NULL;
+    if (!c->need_grad) return DICP_ERR_ENUM;
+    dicp_call_layout F;
+    if (int rc = dicp_call_plan(dtype, c, &F)) return rc;
+    if (((uintptr_t)c->workspace & 255) != 0) return DICP_ERR_ALIGN;
+    dicp_loop_backward_in f;
+    memset(&f, 0, sizeof(f));
+    f.src = c->src; f.tgt_sorted = at(c, F.tgt_sorted); f.w0 = c->w0; f.tperm = (const int32_t*)at(c, F.tperm);
+    f.qorder = (const int32_t*)at(c, F.orders) + (size_t)(F.n_orders - 1) * c->N * c->n;
+    f.spos = (const int32_t*)at(c, F.spos); f.poses = at(c, F.poses); f.deltas = at(c, F.deltas); f.areg = (const double*)at(c, F.areg); f.alive = at(c, F.alive);
+    f.N = c->N; f.n = c->n; f.m = c->m; f.c = c->c; f.K = c->K; f.K_cap = c->K; f.m_pad = F.m_pad; f.dim = c->dim;
+    f.knn_variant = DICP_KNN_SWEEP | ((c->flags & DICP_CALL_NO_SMALL_LOOP) ? (1 << 25) : 0);
+    return backward_once(dtype, prm, &f, g, stream);
+}
+
+// the same reverse sweep for a forward that was run buffer by buffer (dicp_icp_forward / _plan with every history in one slab): the caller names the buffers
+int dicp_loop_backward_plan(int dtype, const dicp_weight_params* prm, const dicp_loop_backward_in* f, int want_tgt, int want_w, dicp_call_backward_layout* L) {
+    if (!prm || !f || !L) return DICP_ERR_NULL;
+    if (dtype != DICP_F32 && dtype != DICP_F64) return DICP_ERR_DTYPE;
+    if (f->N < 1 || f->n < 1 || f->m < 1 || f->K < 1 || f->K_cap < f->K) return DICP_ERR_SHAPE;
+    return backward_layout(dtype, prm, f->N, f->n, f->m, f->K_cap, f->w0 != nullptr, want_tgt, want_w, L);
+}
+
+int dicp_loop_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_backward_in* f, const dicp_call_grads* g, void* stream) {
+    if (!prm || !f || !g || !g->workspace || !g->gsrc || !g->gT0) return DICP_ERR_NULL;
+    if (!f->src || !f->tgt_sorted || !f->tperm || !f->qorder || !f->spos || !f->poses || !f->deltas || !f->areg || !f->alive) return DICP_ERR_NULL;
+    if (dtype != DICP_F32 && dtype != DICP_F64) return DICP_ERR_DTYPE;
+    if (f->N < 1 || f->n < 1 || f->m < 1 || f->K < 1 || f->K_cap < f->K || f->m_pad != dicp_padded_targets(f->m) || (f->dim != 2 && f->dim != 3)) return DICP_ERR_SHAPE;
+    return backward_once(dtype, prm, f, g, stream);
 }
 
 // ---- ICP.pt2pt_dICP_SVD (ICP.py:533-591) for a dense batch on the sweep path with a constant iteration count, one call per direction

@@ -614,6 +614,28 @@ typedef struct dicp_call_backward_layout {
 } dicp_call_backward_layout;
 int dicp_call_backward_plan(int dtype, const dicp_weight_params* prm, const dicp_call* call, int want_tgt, int want_w, dicp_call_backward_layout* layout);
 int dicp_call_backward(int dtype, const dicp_weight_params* prm, const dicp_call* call, const dicp_call_grads* grads, void* stream);
+/* The same reverse sweep behind one call for a forward that was run buffer by buffer (dicp_icp_forward / dicp_icp_forward_plan on the sweep path, every history in
+ * one slab): the caller names the forward's buffers.  K iterations were executed (tolerance mode: fewer than the histories' capacity K_cap, which is what their
+ * strides and the live counters' length follow). */
+typedef struct dicp_loop_backward_in {
+    const void* src;         /* (N,n,3) */
+    const void* tgt_sorted;  /* (N,m_pad,c): dicp_sweep_build's tgt_s */
+    const void* w0;          /* (N,n) or NULL */
+    const int32_t* tperm;    /* (N,m_pad) */
+    const int32_t* qorder;   /* (N,n): the slot order of the pass (the forward's last query order) */
+    const int32_t* spos;     /* (K_cap,N,n): sorted match positions per iteration, by query */
+    const void* poses;       /* (K_cap+1,N,12) */
+    const void* deltas;      /* (N,K_cap,6) */
+    const double* areg;      /* (K_cap,N,36) */
+    const void* alive;       /* (K_cap+1,N) */
+    const int32_t* src_rows; /* optional (N) */
+    const int32_t* tgt_rows; /* optional (N) */
+    int32_t N, n, m, c, K, K_cap, m_pad, dim;
+    int32_t knn_variant;     /* as dicp_loop_buffers */
+    int32_t pad0;
+} dicp_loop_backward_in;
+int dicp_loop_backward_plan(int dtype, const dicp_weight_params* prm, const dicp_loop_backward_in* fwd, int want_tgt, int want_w, dicp_call_backward_layout* layout);
+int dicp_loop_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_backward_in* fwd, const dicp_call_grads* grads, void* stream);
 
 /* The same for ICP.pt2pt_dICP_SVD (ICP.py:533-591; BASELINE configs[1]'s "HIP kNN + 3x3 SVD"): a dense batch on the sweep path, every one of K iterations run.
  * dicp_kabsch_call_forward: dicp_sweep_setup -> dicp_search_pose -> 3 x { dicp_query_order (before iteration 1) -> dicp_kabsch_forward } -> T -> dicp_transform_points;

@@ -145,6 +145,13 @@ def test_new_entry_points_reject_bad_arguments(lib):
     assert blay.far > 0 and blay.slab > 0 and blay.gw_s == 0 and blay.w_s == 0 and blay.live < blay.zeroed <= blay.gpose and blay.nblk_w == lib.dicp_window_blocks(0, 300, 256)
     G = _lib.CallGrads()
     assert lib.dicp_call_backward(0, ctypes.byref(P), ctypes.byref(call), ctypes.byref(G), None) == 1
+    # dicp_loop_backward: the reverse sweep of a buffer-by-buffer forward from one call; the same layout as dicp_call_backward's for the same shape
+    F = _lib.LoopBackwardIn(N=2, n=300, m=200, c=3, K=4, K_cap=5, m_pad=256, dim=3, knn_variant=3)
+    bl2 = _lib.CallBackwardLayout()
+    assert lib.dicp_loop_backward_plan(0, ctypes.byref(P), ctypes.byref(F), 1, 0, ctypes.byref(bl2)) == 0 and bl2.total == blay.total and bl2.live == blay.live
+    assert lib.dicp_loop_backward(0, ctypes.byref(P), ctypes.byref(F), ctypes.byref(G), None) == 1        # no buffers named
+    F.K = 6
+    assert lib.dicp_loop_backward_plan(0, ctypes.byref(P), ctypes.byref(F), 1, 0, ctypes.byref(bl2)) == 2     # more iterations than the histories hold
     # dicp_kabsch_call_*: the same contract
     kc = _lib.KabschCall(N=2, n=300, m=200, c=3, K=5)
     kl = _lib.KabschCallLayout()

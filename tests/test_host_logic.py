@@ -159,3 +159,16 @@ def test_graph_capture_refuses_host_drawn_gumbel_noise():
     icp.const_iter = False
     with pytest.raises(ValueError, match="const_iter"):
         graphed_icp(icp, x, torch.zeros((1, 8, 6)), torch.eye(4).unsqueeze(0))
+
+
+def test_resort_schedule_by_size(monkeypatch):
+    """dicp_amd._ops.resort_schedule: an explicit schedule is taken as given; by default small calls without certificates re-order before iterations 0 and 1 only."""
+    from dicp_amd import _ops
+    monkeypatch.setattr(_ops, "CERT_MIN_WORK", 2.0e6)          # (the shipped threshold: tests/conftest.py runs this module with certificates at every size)
+    assert _ops.resort_schedule((0, 2), 256, 16384, 10, True, None) == (0, 2)
+    assert _ops.resort_schedule(None, 256, 16384, 10, True, None) == (0, 1, 2, 3)            # the headline shape: certificates pay, full schedule
+    assert _ops.resort_schedule(None, 32, 4096, 10, True, None) == (0, 1)                     # configs[1]: 131072 points, no certificates at this size
+    assert _ops.resort_schedule(None, 64, 8192, 10, True, None) == (0, 1, 2, 3)               # 524288 points: the full schedule stays best (profiles/r04_mid_size_resort.txt)
+    assert _ops.resort_schedule(None, 32, 4096, 100, True, None) == (0, 1, 2, 3)              # a long call: 96 certified iterations x 131072 points pay for certificates
+    assert _ops.resort_schedule(None, 32, 4096, 100, False, None) == (0, 1)                   # ... unless they are switched off
+    assert _ops.resort_schedule(None, 1, 65, 2, True, None) == (0, 1)

@@ -407,9 +407,9 @@ DICP_HD bool solve_fixed(double (&M)[D * D], double (&rhs)[D], double (&x)[D]) {
     return true;
 }
 
+// the solve alone: delta6 (zeros outside the optimised slots) and the matrix that was inverted
 template <int D>
-DICP_HD void step_forward_fixed(const double* A6, const double* b6, const double* C, const double* r,
-                                double* delta6, double* Cn, double* rn, double* Areg) {
+DICP_HD void step_solve_fixed(const double* A6, const double* b6, double* delta6, double* Areg) {
     constexpr int OFF = (D == 3) ? 2 : 0;              // dim == 2 optimises slots 2,3,4 (ICP.py:186-189)
     double M[D * D], rhs[D], x[D];
 #pragma unroll
@@ -429,18 +429,23 @@ DICP_HD void step_forward_fixed(const double* A6, const double* b6, const double
 #pragma unroll
         for (int i = 0; i < D; ++i) delta6[i + OFF] = -x[i];         // ICP.py:201
     }
+}
+
+DICP_HD void step_solve(const double* A6, const double* b6, int dim, double* delta6, double* Areg) {
+    if (dim == 2) step_solve_fixed<3>(A6, b6, delta6, Areg);
+    else          step_solve_fixed<6>(A6, b6, delta6, Areg);
+}
+
+// solve + the new pose from the UNROUNDED step (the kernels round delta to the cloud type first, like the reference, and apply it themselves: step_body)
+DICP_HD void step_forward(const double* A6, const double* b6, int dim, const double* C, const double* r,
+                          double* delta6, double* Cn, double* rn, double* Areg) {
+    step_solve(A6, b6, dim, delta6, Areg);
     double R[9];
     so3_exp(delta6, R);                                              // ICP.py:210
     for (int i = 0; i < 3; ++i)                                      // C <- R^T C   ICP.py:214
         for (int j = 0; j < 3; ++j)
             Cn[i * 3 + j] = R[0 * 3 + i] * C[0 * 3 + j] + R[1 * 3 + i] * C[1 * 3 + j] + R[2 * 3 + i] * C[2 * 3 + j];
     for (int i = 0; i < 3; ++i) rn[i] = r[i] - delta6[3 + i];        // ICP.py:216
-}
-
-DICP_HD void step_forward(const double* A6, const double* b6, int dim, const double* C, const double* r,
-                          double* delta6, double* Cn, double* rn, double* Areg) {
-    if (dim == 2) step_forward_fixed<3>(A6, b6, C, r, delta6, Cn, rn, Areg);
-    else          step_forward_fixed<6>(A6, b6, C, r, delta6, Cn, rn, Areg);
 }
 
 // Backward step.  In: gCn, grn (cotangents of the new pose), saved C, delta6, Areg.

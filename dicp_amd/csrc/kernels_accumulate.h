@@ -303,10 +303,10 @@ __device__ __forceinline__ void step_body(const dicp_step_io& io, int cloud, int
     }
     __syncthreads();
     if (tid == 0) {
-        double* d6 = sout; double* Cn = sout + 6; double* rn = sout + 15;
+        double* d6 = sout;
         unpack_sym6(sacc + ACC_A, sA);
-        // solve with the pose untouched first so delta can be rounded to T like the reference's
-        step_forward(sA, sacc + ACC_B, io.dim, spose, spose + 9, d6, Cn, rn, sAreg);
+        // the solve alone first: delta is rounded to T like the reference's before it moves the pose
+        step_solve(sA, sacc + ACC_B, io.dim, d6, sAreg);
         T* dout = (T*)io.delta + (size_t)cloud * io.delta_stride;
         double nrm2 = 0.0;
         for (int k = 0; k < 6; ++k) { const T v = (T)d6[k]; dout[k] = v; d6[k] = (double)v; nrm2 += d6[k] * d6[k]; }

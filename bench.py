@@ -570,6 +570,7 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
         bwd_traffic, bwd_src = pmc_traffic(bwd_kernel, B, n)
         acc_traffic, acc_src = pmc_traffic("accumulate_kernel", B, n)
         bf_traffic, bf_src = pmc_traffic("knn_valu", B, n)
+        bfm_traffic, bfm_src = pmc_traffic("knn_f16_kernel", B, n)
         last_ms = times[-1] * 1e3                                        # the call that carried the events
         share = {nm: (sum(v) / last_ms if v else 0.0) for nm, v in ev_ms.items()}
         legs = {
@@ -648,10 +649,11 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
                 "algorithmic_frac_of_f32_peak": flops_bf / (bfm_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS if bfm_ms else None,
                 "speedup_vs_valu_kernel": bf_ms / bfm_ms if (bf_ms and bfm_ms) else None,
                 "avg_launch_ms": bfm_ms, "second_filter_pass_fraction_of_queries": f16_again,
-                "bound_note": "the launch is bound by the VECTOR work beside the matrix pipe -- 8 v_min3 per MFMA for the lane-local minima + 2 of bookkeeping, and vector "
+                "traffic": bfm_traffic, "traffic_source": bfm_src, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC)",
+                "bound_note": "the launch is bound by the VECTOR work beside the matrix pipe -- 8 v_min3 per MFMA for the lane-local minima + 3-4 of bookkeeping, and vector "
                               "and matrix instructions of one SIMD do not overlap here (scripts/ubench/mfma_valu_overlap.hip: 28 + 2.2 V cycles per MFMA with V vector "
-                              "instructions) -- and by the clock the chip holds under it (1.77 GHz); matrix-pipe busy 37 % of the kernel (SQ_VALU_MFMA_BUSY_CYCLES, "
-                              "profiles/r04_knn_f16_c3_pmc.txt)",
+                              "instructions) -- and by the clock the chip holds under it (1.7 GHz); matrix-pipe busy 48 % of the kernel here, 56 % at 256 x 65536 "
+                              "(SQ_VALU_MFMA_BUSY_CYCLES, profiles/r04_knn_f16_c3_pmc.txt, profiles/r04_knn_c4_65536_pmc.txt)",
                 "measured": "3 extra launches outside the timed region, HIP events"},
             "finite": sane,
         }

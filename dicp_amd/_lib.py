@@ -21,7 +21,7 @@ PT2PT, PT2PL = 0, 1
 LOSS_NONE, LOSS_HUBER, LOSS_CAUCHY, LOSS_TRIM = 0, 1, 2, 3
 KNN_AUTO, KNN_VALU, KNN_MFMA, KNN_SWEEP, KNN_GUMBEL = 0, 1, 2, 3, 4
 NACC_PAD, NBWD_PAD, KAB_SAVE = 32, 16, 40
-PAIR_SHARDS, SWEEP_SRC_SORTED = 64, 0x100      # DICP_PAIR_SHARDS, DICP_SWEEP_SRC_SORTED
+PAIR_SHARDS = 64      # DICP_PAIR_SHARDS
 ABI_VERSION = 7
 _ERRORS = {1: "null pointer", 2: "bad shape/stride", 3: "unsupported dtype", 4: "bad enum value", 5: "misaligned buffer"}
 
@@ -49,7 +49,7 @@ class LoopBuffers(ctypes.Structure):
     """dicp_loop_buffers (include/dicp_hip.h)."""
     _fields_ = [("src", vp), ("tgt", vp), ("w_init", vp), ("c", i32), ("K", i32), ("knn_variant", i32), ("m_pad", i32),
                 ("tgt4", vp), ("tperm", vp), ("qorder", vp), ("bucket", vp), ("brange", vp), ("nbkt", i32), ("idx_per_iter", i32),
-                ("pairs", vp), ("spos", vp), ("src_s", vp), ("spos_ref", vp), ("gts_far", vp), ("poses", vp), ("deltas", vp), ("costs", vp), ("areg", vp), ("alive", vp), ("converged", vp),
+                ("pairs", vp), ("spos", vp), ("spos_ref", vp), ("gts_far", vp), ("poses", vp), ("deltas", vp), ("costs", vp), ("areg", vp), ("alive", vp), ("converged", vp),
                 ("iterations", vp), ("matched_ratio", vp), ("n_start", vp), ("n_matched", vp), ("idx", vp), ("w", vp), ("w_iter", i64), ("w_stride", i64), ("w_prev0", vp),
                 ("partials", vp), ("counters", vp), ("events", vp), ("bwd_overwrite", i32), ("frame", vp), ("poses_search", vp),
                 ("src_rows", vp), ("tgt_rows", vp), ("cert_q", vp), ("cert_qu", vp), ("cert_set", vp), ("cert_count", vp), ("rmax", vp), ("dcum", vp),

@@ -279,14 +279,11 @@ class SweepIndex:
             self.img16 = f16_image(self.tgs4, self.m, self.tgt_rows)
         return self.img16
 
-    def knn(self, src, pose, qorder=None, out=None, cfg=0, spos=None, src_s=None, src_rows=None, mfma=False):
-        """src_s: the rows of src in qorder's slot order (query_order(copies=True)) -> coalesced query loads.
-        src_rows (N) int32: rows of each source cloud that take part (qorder, if any, made with the same counts).
+    def knn(self, src, pose, qorder=None, out=None, cfg=0, spos=None, src_rows=None, mfma=False):
+        """src_rows (N) int32: rows of each source cloud that take part (qorder, if any, made with the same counts).
         mfma: score on the matrix cores (float32, the (2,8) configuration's units: cfg 0 on big problems, or 2)."""
         N, n, _ = src.shape
         idx = out if out is not None else torch.empty((N, n), dtype=torch.int32, device=src.device)
-        if src_s is not None:
-            src, cfg = src_s, cfg | _lib.SWEEP_SRC_SORTED
         with _on(src.device):
             _lib.check(_lib.load().dicp_knn_sweep(_DT[src.dtype], _p(src), _p(pose), _p(self.tgs4), _p(self.tperm), _p(qorder),
                                                   _p(self.bucket), _p(self.brange), self.NBKT, _p(src_rows), _p(self.tgt_rows), N, n, self.m, self.tgs4.shape[1],

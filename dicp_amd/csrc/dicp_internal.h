@@ -26,6 +26,6 @@ int knn_f16_brute(const void* src, const void* pose, const void* tgt4, void* ima
 // rows tgs4; ev0 / ev1: optional hipEvent_t carried on the dispatch
 int knn_f16_sweep(const void* src, const void* pose, const void* tgs4, void* image, const int32_t* tperm, const int32_t* qorder, const int32_t* bucket,
                   const void* brange, int nbkt, const int32_t* src_rows, const int32_t* tgt_rows, int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos,
-                  unsigned long long* pairs, int src_sorted, void* ev0, void* ev1, void* stream);
+                  unsigned long long* pairs, void* ev0, void* ev1, void* stream);
 
 }  // namespace dicp_tu

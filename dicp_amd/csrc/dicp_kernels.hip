@@ -279,20 +279,17 @@ static int sweep_launch(int dtype, const void* src, const void* pose, const void
                         CertArgs ca = CertArgs{}, const void* f16_image = nullptr) {
     hipEvent_t ev0, ev1;
     take_launch_events(ev0, ev1);                                       // (null unless a timed loop set them for this launch)
-    const int src_sorted = (cfg & DICP_SWEEP_SRC_SORTED) ? 1 : 0;      // src holds the rows in qorder's slot order
-    cfg &= ~DICP_SWEEP_SRC_SORTED;
-    if (src_sorted && !qorder) return DICP_ERR_NULL;
     if (cfg == 0) cfg = sweep_auto_cfg(N, n);
     // plain float32 searches in units of 128 queries, given the image of the sorted rows: the scoring runs on the matrix cores (knn_f16.hip)
     if (f16_image && dtype == DICP_F32 && !ca.q && cfg == SWEEP_CFG_BIG)
         return dicp_tu::knn_f16_sweep(src, pose, tgs4, const_cast<void*>(f16_image), tperm, qorder, bucket, brange, nbkt, rw.src, rw.tgt, N, n, m, m_pad, idx, spos,
-                                      pairs, src_sorted, ev0, ev1, st);
+                                      pairs, ev0, ev1, st);
     const int Q = sweep_queries_per_lane(cfg);
     if (Q <= 0) return DICP_ERR_ENUM;
     const int units = (n + WAVE * Q - 1) / (WAVE * Q);                  // waves per cloud
     const int bpc = (units + BLOCK / WAVE - 1) / (BLOCK / WAVE);
 #define DICP_SWEEP_ARGS(T) (const T*)src, (const T*)pose, (const typename V4<T>::type*)tgs4, tperm, qorder, bucket, (const T*)brange, nbkt, idx, spos, pairs, \
-        N, n, m, m_pad, bpc, src_sorted, rw.src, rw.tgt
+        N, n, m, m_pad, bpc, rw.src, rw.tgt
 #define DICP_SWEEP_C(T, Q, CH, CERT, CT) hipExtLaunchKernelGGL((knn_sweep_kernel<T, Q, CH, CERT>), dim3(grid_for(N, bpc)), dim3(BLOCK), 0, st, ev0, ev1, 0, DICP_SWEEP_ARGS(T), CT)
 #define DICP_SWEEP_L(T, Q, CH, CT) hipExtLaunchKernelGGL((knn_sweep_guard_kernel<T, Q, CH>), dim3(grid_for(N, bpc)), dim3(BLOCK), 0, st, ev0, ev1, 0, DICP_SWEEP_ARGS(T), CT)
 #define DICP_SWEEP_CG(T, Q, CH, CT) do { if (ca.guard) DICP_SWEEP_L(T, Q, CH, CT); else DICP_SWEEP_C(T, Q, CH, true, CT); } while (0)
@@ -787,11 +784,8 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
             int32_t* spos_k = B->spos ? B->spos + (B->idx_per_iter ? (size_t)k * N * n : 0) : nullptr;
             const bool sorted_rows = B->tgt_sorted && spos_k;      // accumulate gathers 32-byte aligned rows of the sorted copy at the sorted positions
             if (!sorted_rows && !B->idx) { set_launch_events(nullptr, nullptr); return DICP_ERR_NULL; }
-            // src_s: the source rows in qorder's slot order (dicp_query_order wrote them): coalesced query loads
-            const void* qsrc = B->src;
-            if (B->src_s && B->qorder) { qsrc = B->src_s; cfg |= DICP_SWEEP_SRC_SORTED; }
             // match certificates: only the units holding a query whose match is not proven unchanged are searched again
-            const int cfg_plain = (cfg & ~DICP_SWEEP_SRC_SORTED) ? (cfg & ~DICP_SWEEP_SRC_SORTED) : sweep_auto_cfg(N, n);
+            const int cfg_plain = cfg ? cfg : sweep_auto_cfg(N, n);
             const bool cert = B->cert_q && B->cert_qu && B->rmax && B->dcum && spos_k && sorted_rows && !B->idx && B->qorder && sweep_queries_per_lane(cfg_plain) > 0;
             const bool fresh = k == 0 || (k == k0 && B->cert_reset);           // a new query order: every query is searched, every budget written
             int32_t* count_k = B->cert_count ? B->cert_count + (size_t)k * 2 * CERT_SHARDS : nullptr;
@@ -806,10 +800,10 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
                     }
                 }
                 begin_launch();
-                rc = sweep_launch(dtype, qsrc, pose_s, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, N, n, m, B->m_pad, nullptr, spos_k,
+                rc = sweep_launch(dtype, B->src, pose_s, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, N, n, m, B->m_pad, nullptr, spos_k,
                                   B->pairs, cfg, Rows{B->src_rows, B->tgt_rows}, st, CertArgs{B->cert_q, B->cert_qu, B->dcum, 2 * (B->K + 1), k, count_k, !fresh, B->cert_cloud, B->cert_set});
             } else
-            rc = dicp_knn_sweep(dtype, qsrc, pose_s, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, B->src_rows, B->tgt_rows, N, n, m, B->m_pad,
+            rc = dicp_knn_sweep(dtype, B->src, pose_s, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, B->src_rows, B->tgt_rows, N, n, m, B->m_pad,
                                 B->idx ? idx_k : nullptr, spos_k, B->pairs, cfg, B->tgt_f16, stream);
             set_launch_events(nullptr, nullptr);
             if (rc) return rc;

@@ -200,7 +200,7 @@ __device__ __forceinline__ void sweep_unit(const T* __restrict__ src, const T* _
                                            const int32_t* __restrict__ bucket, const T* __restrict__ brange, int nbkt,
                                            int32_t* __restrict__ idx, int32_t* __restrict__ spos,
                                            unsigned long long* __restrict__ pairs,
-                                           int n_full, int m_full, int m_pad, int src_sorted,
+                                           int n_full, int m_full, int m_pad,
                                            const int32_t* __restrict__ src_rows, const int32_t* __restrict__ tgt_rows, const SweepCert<T>& ct,
                                            const int cloud, const int unit, typename V4<T>::type* __restrict__ ring) {
     using T4 = typename V4<T>::type;
@@ -226,7 +226,7 @@ __device__ __forceinline__ void sweep_unit(const T* __restrict__ src, const T* _
         T p[3] = {T(0), T(0), T(0)};
         if (pos < n) {
             qi[q] = qorder ? qorder[(size_t)cloud * n_full + pos] : pos;
-            const T* sp = src + ((size_t)cloud * n_full + (src_sorted ? pos : qi[q])) * 3;      // src_sorted: rows already in slot order
+            const T* sp = src + ((size_t)cloud * n_full + qi[q]) * 3;
             p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2];
         }
         query_point(C, r, p, nx[q]);
@@ -433,7 +433,7 @@ __device__ __forceinline__ void sweep_unit(const T* __restrict__ src, const T* _
 #define DICP_SWEEP_PARAMS const T* __restrict__ src, const T* __restrict__ pose, const typename V4<T>::type* __restrict__ tgs4, \
         const int32_t* __restrict__ tperm, const int32_t* __restrict__ qorder, const int32_t* __restrict__ bucket, const T* __restrict__ brange, int nbkt, \
         int32_t* __restrict__ idx, int32_t* __restrict__ spos, unsigned long long* __restrict__ pairs, \
-        int N, int n_full, int m_full, int m_pad, int bpc, int src_sorted, const int32_t* __restrict__ src_rows, const int32_t* __restrict__ tgt_rows, SweepCert<T> ct
+        int N, int n_full, int m_full, int m_pad, int bpc, const int32_t* __restrict__ src_rows, const int32_t* __restrict__ tgt_rows, SweepCert<T> ct
 #define DICP_SWEEP_MINW ((Q == 2 && CH == 8 && sizeof(T) == 4) ? SWEEP_MINW_Q2C8 : 1)
 
 // Every unit of every cloud: block (cloud, blk) of the XCD-aware grid, one unit per wave.
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(BLOCK, DICP_SWEEP_MINW) void knn_sweep_kernel(DICP_
     int cloud, blk;
     if (!decode_block(bpc, N, cloud, blk)) return;
     const int wave = threadIdx.x >> 6;
-    sweep_unit<T, Q, CH, CERT>(src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, idx, spos, pairs, n_full, m_full, m_pad, src_sorted, src_rows, tgt_rows, ct,
+    sweep_unit<T, Q, CH, CERT>(src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, idx, spos, pairs, n_full, m_full, m_pad, src_rows, tgt_rows, ct,
                                cloud, blk * (BLOCK / WAVE) + wave, tiles[wave]);
 }
 
@@ -634,9 +634,9 @@ __global__ __launch_bounds__(BLOCK, DICP_SWEEP_MINW) void knn_sweep_guard_kernel
         plain = 4 * nbad >= 3 * nlive && step > T(0) && step < inf_v<T>() && T(2) * step > step_before;
         if (plain && lane == 0) *qu = -T(0.5) * step;
     }
-    if (plain) sweep_unit<T, Q, CH, false>(src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, idx, spos, pairs, n_full, m_full, m_pad, src_sorted, src_rows, tgt_rows, ct,
+    if (plain) sweep_unit<T, Q, CH, false>(src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, idx, spos, pairs, n_full, m_full, m_pad, src_rows, tgt_rows, ct,
                                            cloud, unit, tiles[wave]);
-    else       sweep_unit<T, Q, CH, true>(src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, idx, spos, pairs, n_full, m_full, m_pad, src_sorted, src_rows, tgt_rows, ct,
+    else       sweep_unit<T, Q, CH, true>(src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, idx, spos, pairs, n_full, m_full, m_pad, src_rows, tgt_rows, ct,
                                           cloud, unit, tiles[wave]);
     // the counters LAST: vector memory operations return in order, so a unit that counted itself first waited for its add -- one of up to
     // 128 to the same word when a whole cloud is searched again -- before its first load came back (a cloud with its certificates off:

@@ -528,7 +528,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_f16_sweep_kernel(const float*
                                                                     const int32_t* __restrict__ tperm, const int32_t* __restrict__ qorder,
                                                                     const int32_t* __restrict__ bucket, const float* __restrict__ brange, int nbkt,
                                                                     int32_t* __restrict__ idx, int32_t* __restrict__ spos, unsigned long long* __restrict__ pairs,
-                                                                    int N, int n_full, int m_full, int m_pad, int tiles_per_cloud, int bpc, int src_sorted,
+                                                                    int N, int n_full, int m_full, int m_pad, int tiles_per_cloud, int bpc,
                                                                     const int32_t* __restrict__ src_rows, const int32_t* __restrict__ tgt_rows,
                                                                     const float* __restrict__ edges_all) {
     __shared__ float4 qlist[BLOCK / WAVE][32];
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_f16_sweep_kernel(const float*
         float p[3] = {0.f, 0.f, 0.f};
         if (pos < n) {
             qi[g] = qorder ? qorder[(size_t)cloud * n_full + pos] : pos;
-            const float* sp = src + ((size_t)cloud * n_full + (src_sorted ? pos : qi[g])) * 3;
+            const float* sp = src + ((size_t)cloud * n_full + qi[g]) * 3;
             p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2];
         }
         query_point(C, r, p, nx[g]);
@@ -925,7 +925,7 @@ int knn_f16_brute(const void* src, const void* pose, const void* tgt4, void* ima
 
 int knn_f16_sweep(const void* src, const void* pose, const void* tgs4, void* image, const int32_t* tperm, const int32_t* qorder, const int32_t* bucket,
                   const void* brange, int nbkt, const int32_t* src_rows, const int32_t* tgt_rows, int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos,
-                  unsigned long long* pairs, int src_sorted, void* ev0, void* ev1, void* stream) {
+                  unsigned long long* pairs, void* ev0, void* ev1, void* stream) {
     if (!src || !tgs4 || !image || !tperm || !bucket || !brange || (!idx && !spos)) return DICP_ERR_NULL;
     if (N <= 0 || n <= 0 || m <= 0 || m_pad < m || (m_pad % WAVE)) return DICP_ERR_SHAPE;
     const int m_img = knn_f16_image_rows(m_pad), tiles = m_img / 32;
@@ -936,7 +936,7 @@ int knn_f16_sweep(const void* src, const void* pose, const void* tgs4, void* ima
     begin_launch();
     hipExtLaunchKernelGGL((knn_f16_sweep_kernel<4>), dim3(grid_for(N, bpc)), dim3(BLOCK), 0, (hipStream_t)stream, (hipEvent_t)ev0, (hipEvent_t)ev1, 0,
                           (const float*)src, (const float*)pose, (const float4*)tgs4, (const uint4*)image, meta, tperm, qorder, bucket, (const float*)brange, nbkt,
-                          idx, spos, pairs, N, n, m, m_pad, tiles, bpc, src_sorted, src_rows, tgt_rows, edges);
+                          idx, spos, pairs, N, n, m, m_pad, tiles, bpc, src_rows, tgt_rows, edges);
     return launch_status();
 }
 

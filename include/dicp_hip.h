@@ -134,7 +134,7 @@ int dicp_query_keys(int dtype, const void* src, const void* pose, int N, int n, 
  * target's x range [brange from dicp_sweep_build, nbkt its bucket count]; arbitrary order inside a bucket).  A cheap
  * replacement for an exact sort of dicp_query_keys: the sweep is exact for ANY query order, the order is speed only.
  * Optional: src_s (N,n,3) / w_s (N,n) = the source rows / the per-point weights w (N,n) in that slot order, for coalesced
- * query loads in dicp_knn_sweep (cfg | DICP_SWEEP_SRC_SORTED) and for dicp_accumulate_bwd_window (measured: one block
+ * loads of dicp_accumulate_bwd_window (measured: one block
  * per cloud gathers slowly, 115 vs 16 us; dicp_gather_rows does it better).  reproducible != 0: buckets of up to 64
  * members are put in index order, so the permutation is the same on every run (needed only when sums are taken in
  * this order).  spos_prev (N,n), optional: the queries' matches of an earlier iteration
@@ -166,7 +166,6 @@ int dicp_query_order(int dtype, const void* src, const void* pose, const void* b
  *   configuration's units -- 128 queries per wave, what big problems get -- then runs on the matrix cores (split-f16 filter + exact float32
  *   refine, csrc/knn_f16.hip): the same idx / spos, index for index. */
 #define DICP_PAIR_SHARDS 64
-#define DICP_SWEEP_SRC_SORTED 0x100   /* OR into cfg: `src` holds the rows in qorder's slot order (dicp_query_order's src_s) */
 int dicp_knn_sweep(int dtype, const void* src, const void* pose, const void* tgs4, const int32_t* tperm,
                    const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt, const int32_t* src_rows, const int32_t* tgt_rows,
                    int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg, const void* f16_image, void* stream);
@@ -272,7 +271,6 @@ typedef struct dicp_loop_buffers {
     int32_t* spos;           /* sweep only, optional (K,N,n): per-iteration sorted match positions.  Non-NULL in dicp_icp_backward
                                 selects dicp_accumulate_bwd_window: src / w_init / tgt are then the SORTED copies it documents,
                                 gsrc / gw accumulate in slot order, gtgt is the slab, bwd_partials has dicp_window_blocks blocks */
-    const void* src_s;       /* forward, sweep: optional source rows in qorder's slot order (dicp_query_order) */
     const int32_t* spos_ref; /* backward, windowed form: (N,n) reference matches that place the windows; qorder = its slot order */
     void* gts_far;           /* backward, windowed form: (N,m_pad,CV) atomically accumulated out-of-window rows */
     void* poses;             /* (K+1,N,12): poses[0] = initial pose, poses[k+1] written by iteration k */

@@ -122,7 +122,7 @@ def test_new_entry_points_reject_bad_arguments(lib):
     assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, None, None, 1, 1, 1, 64, one, None, None, 99, None, None) == 4
     assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, None, None, 1, 1, 1, 64, None, None, None, 0, None, None) == 1   # idx or spos
     assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, None, None, 1, 1, 1, 64, one, None, None, 16, None, None) == 4   # (the scan form is gone)
-    assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, None, None, 1, 1, 1, 64, one, None, None, 2 | 0x100, None, None) == 1  # sorted rows need the order
+    assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, None, None, 1, 1, 1, 64, one, None, None, 2 | 0x100, None, None) == 4  # (the slot-ordered source copy is gone too)
     # dicp_call_*: plans are pure host arithmetic; a bad shape, a bad dtype, a missing buffer are refused before anything is touched
     call = _lib.Call(N=2, n=300, m=200, c=3, K=5, dim=3, need_grad=1, n_resort=2)
     call.resort[0], call.resort[1] = 1, 2

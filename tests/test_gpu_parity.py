@@ -583,9 +583,6 @@ def test_tolerance_stop_equals_const_iter(golden):
 # ----------------------------------------------------------- exact sorted-sweep kNN (dicp_knn_sweep)
 def sweep_knn(x, y, pose=None, sort_queries=True, cfg=0):
     sw = _ops.SweepIndex(y)
-    if sort_queries == "copies":        # queries read from the slot-ordered copy dicp_query_order makes
-        qo, x_s, _ = sw.query_order(x, pose, copies=True)
-        return sw.knn(x, pose, qo, cfg=cfg, src_s=x_s), sw
     return sw.knn(x, pose, sw.query_order(x, pose) if sort_queries else None, cfg=cfg), sw
 
 
@@ -597,7 +594,7 @@ def test_sweep_knn_equals_brute_force(dtype, N, n, m):
     y = (torch.rand((N, m, 6), generator=g, dtype=torch.float64) * 10 - 5).to(dtype).to(DEV)
     brute = _ops.knn(x, None, _ops.pack_target(y), m, _lib.KNN_VALU)
     for cfg in (0, 1, 2, 4):                                      # every launch configuration of the tile sweep
-        for sort_q in (True, False, "copies"):
+        for sort_q in (True, False):
             got, sw = sweep_knn(x, y, sort_queries=sort_q, cfg=cfg)
             assert torch.equal(got, brute), (cfg, sort_q)        # same scores, same tie rule: bit-identical indices
     if dtype == torch.float64:

@@ -245,3 +245,29 @@ def test_svd_step_which_calls_take_it():
     assert not _call.kabsch_eligible(S, Tg, Ti, W, True, _lib.KNN_AUTO, None, None)                    # 2 x 1024 x 1024: brute force
     assert not _call.kabsch_eligible(S, Tg, Ti, W, True, _lib.KNN_SWEEP, torch.tensor([1024, 1000], dtype=torch.int32, device=DEV), None)
     assert not _call.kabsch_eligible(S, Tg, Ti.double(), W, True, _lib.KNN_SWEEP, None, None)
+
+
+@pytest.mark.parametrize("icp_type", ["pt2pl", "pt2pt"])
+def test_one_call_against_the_oracle(icp_type):
+    """The one-call path held to the CPU restatement of the reference directly (float64: poses, steps, weights 1e-10; gradients 1e-9 of their size)."""
+    from oracle import dicp_oracle as O
+    N, n, m, K = 3, 2500, 2600, 5
+    src, tgt = make_pairs(N, n, m, seed=41, dtype=torch.float64)
+    if icp_type == "pt2pt":
+        tgt = tgt[:, :, :3].contiguous()
+    kw = dict(trim_dist=5.0, loss_fn={"name": "cauchy", "metric": 0.7}, dim=3)
+    T0 = torch.eye(4, dtype=torch.float64).repeat(N, 1, 1)
+    counts = []
+    outs, gs, _ = run(True, src, tgt, K, icp_type, kw, None, None, torch.float64, counts=counts)
+    assert counts == [2]
+    s_c, t_c = src.clone().requires_grad_(True), tgt.clone().requires_grad_(True)
+    ref = O.icp_batched(s_c, t_c, T0, torch.ones(N, n * (3 if icp_type == "pt2pt" else 1), dtype=torch.float64), icp_type=icp_type, differentiable=True, max_iterations=K,
+                        tolerance=1e-12, const_iter=True, tanh_steepness=5.0, **kw)
+    ref["T"].sum().backward()
+    out = outs[1]
+    assert float((out["T"].detach().cpu() - ref["T"].detach()).abs().max()) < 1e-10
+    assert float((out["deltas"].detach().cpu() - ref["deltas"].detach()).abs().max()) < 1e-10
+    assert float((out["weights"].detach().cpu() - ref["weights"].detach()).abs().max()) < 1e-9
+    assert float((out["pc"].detach().cpu() - ref["pc"].detach()).abs().max()) < 1e-9
+    for got, want in ((gs[1][0].cpu(), s_c.grad), (gs[1][1].cpu(), t_c.grad)):
+        assert float((got - want).abs().max()) <= 1e-9 * max(1.0, float(want.abs().max()))

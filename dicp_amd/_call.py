@@ -46,7 +46,7 @@ def eligible(cfg, source, target, T_init, w0, need_grad):
     if len([k for k in resorts if k > 0]) >= _lib.MAX_SEGMENTS:
         return False
     cert_from = (max(resorts) if resorts else 0) if cfg.cert_from is None else max(0, int(cfg.cert_from))
-    if cfg.reuse_matches and Kmax - 1 - cert_from >= 3 and float(Kmax - 1 - cert_from) * N * n >= _ops.CERT_MIN_WORK:
+    if _ops.certificates_pay(cfg.reuse_matches, Kmax, cert_from, N, n):
         return False                # match certificates pay from there on: ICPLoop's business
     if _ops.F16_SWEEP and dt == torch.float32 and float(N) * n >= _ops.F16_SWEEP_MIN_QUERIES and m >= _ops.F16_SWEEP_MIN_TARGETS:
         return False                # the matrix-core scoring of big problems

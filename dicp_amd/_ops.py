@@ -542,14 +542,20 @@ RESORT_SMALL_POINTS = 262144  # source points of a batch below which a call with
                               # 32 x 4096: 0.561 -> 0.514 ms per call; 64 x 8192: the full schedule stays best, 0.714 against 0.815)
 
 
+def certificates_pay(reuse_matches, Kmax, cert_from, N, n):
+    """The size policy of the match certificates: at least three certified iterations, and enough certified point-iterations to outweigh what they cost the host
+    in buffers and set-up (CERT_MIN_WORK).  One definition for the loop, the one-call path's admission and the re-order schedule."""
+    left = Kmax - 1 - cert_from
+    return bool(reuse_matches) and left >= 3 and float(left) * N * n >= CERT_MIN_WORK
+
+
 def resort_schedule(resort, N, n, Kmax, reuse_matches, cert_from):
     """The iterations before which the sweep re-orders its queries: `resort` as given, or (None) by the size of the call."""
     if resort is not None:
         return tuple(int(v) for v in resort)
     full = (0, 1, 2, 3)
     cf = max([k for k in full if k < Kmax] or [0]) if cert_from is None else max(0, int(cert_from))
-    certs = reuse_matches and Kmax - 1 - cf >= 3 and float(Kmax - 1 - cf) * N * n >= CERT_MIN_WORK
-    return (0, 1) if (not certs and N * n < RESORT_SMALL_POINTS) else full
+    return (0, 1) if (not certificates_pay(reuse_matches, Kmax, cf, N, n) and N * n < RESORT_SMALL_POINTS) else full
 
 
 
@@ -789,8 +795,7 @@ class ICPLoop(torch.autograd.Function):
             cert_from = (max(resorts) if resorts else 0) if cfg.cert_from is None else max(0, int(cfg.cert_from))     # iteration of the certifying search
             # (... and the point-iterations they can save must outweigh what they cost the host in buffers and set-up: measured break-even, forward +
             #  backward, at ~2 M certified point-iterations -- 32 x 4096 x 10 iterations loses 6 %, x 20 iterations wins 6 %; profiles/r03_certificates_mid_sizes.txt)
-            want_certs = (sweep is not None and cfg.reuse_matches and not (cfg.knn_variant & 0xff00) and not keep_idx
-                          and Kmax - 1 - cert_from >= 3 and float(Kmax - 1 - cert_from) * N * n >= CERT_MIN_WORK)
+            want_certs = sweep is not None and not (cfg.knn_variant & 0xff00) and not keep_idx and certificates_pay(cfg.reuse_matches, Kmax, cert_from, N, n)
             # Where EVERY cloud of the previous call of this shape ended with its certificates switched off (near-duplicated or duplicated targets: no
             # match can be proven; poses that keep moving: no budget survives), the next calls do not try: they search plainly -- the same results, without the certifying search and the guard
             # launches -- and after 32 calls they try again.  The previous call's switch states arrive through pinned memory, like the tail's hint.

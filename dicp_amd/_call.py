@@ -5,6 +5,10 @@ which prepared ~30 buffers and ~12 library calls per direction (dicp_amd/_ops.py
 (dense batch, constant iteration count, sorted sweep, no match certificates, every history in one slab) the same sequence of launches is made by
 dicp_call_forward / dicp_call_backward on ONE allocation each; this module allocates, hands out the results as views and keeps autograd's books.
 Every other call takes ICPLoop.  The two give the same results bit for bit (tests/test_gpu_call.py).
+
+Lifetime of the one allocation: it lives as long as any result that is a view of it (deltas, weights, costs, iterations, matched_ratio), as the autograd
+node (the reverse sweep reads it), and -- through the small views `ICP.knn_stats` holds (pairs scored, live counters) -- until the object's next call replaces
+them.  MAX_POINTS bounds it to a few hundred MB.
 """
 import ctypes
 

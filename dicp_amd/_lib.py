@@ -22,7 +22,7 @@ LOSS_NONE, LOSS_HUBER, LOSS_CAUCHY, LOSS_TRIM = 0, 1, 2, 3
 KNN_AUTO, KNN_VALU, KNN_MFMA, KNN_SWEEP, KNN_GUMBEL = 0, 1, 2, 3, 4
 NACC_PAD, NBWD_PAD, KAB_SAVE = 32, 16, 40
 PAIR_SHARDS = 64      # DICP_PAIR_SHARDS
-ABI_VERSION = 7
+ABI_VERSION = 8
 _ERRORS = {1: "null pointer", 2: "bad shape/stride", 3: "unsupported dtype", 4: "bad enum value", 5: "misaligned buffer"}
 
 vp, i32, i64, f64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
@@ -42,7 +42,8 @@ class StepIO(ctypes.Structure):
                 ("cost", vp), ("cost_prev", vp), ("cost_stride", i64), ("areg", vp), ("alive", vp), ("alive_out", vp),
                 ("converged", vp), ("iterations", vp), ("matched_ratio", vp), ("n_start", vp),
                 ("n_matched", vp), ("w_cur", vp), ("w_prev", vp), ("w_stride", i64), ("n_not_converged", vp),
-                ("frame", vp), ("pose_search_out", vp), ("rmax", vp), ("dcum", vp), ("dcum_stride", i64), ("cert_cloud", vp), ("w_copied", i32)]
+                ("frame", vp), ("pose_search_out", vp), ("rmax", vp), ("dcum", vp), ("dcum_stride", i64), ("cert_cloud", vp),
+                ("cert_qu", vp), ("cert_units", i32), ("glist_cap", i32), ("glist", vp), ("gcount", vp), ("w_copied", i32)]
 
 
 class LoopBuffers(ctypes.Structure):
@@ -53,7 +54,8 @@ class LoopBuffers(ctypes.Structure):
                 ("iterations", vp), ("matched_ratio", vp), ("n_start", vp), ("n_matched", vp), ("idx", vp), ("w", vp), ("w_iter", i64), ("w_stride", i64), ("w_prev0", vp),
                 ("partials", vp), ("counters", vp), ("events", vp), ("bwd_overwrite", i32), ("frame", vp), ("poses_search", vp),
                 ("src_rows", vp), ("tgt_rows", vp), ("cert_q", vp), ("cert_qu", vp), ("cert_set", vp), ("cert_count", vp), ("rmax", vp), ("dcum", vp),
-                ("cert_reset", i32), ("cert_cloud", vp), ("spos_prev0", vp), ("tgt_sorted", vp), ("tgt_sorted_stride", i32),
+                ("cert_reset", i32), ("cert_cloud", vp), ("spos_prev_chunk", vp), ("spos_floor", i32), ("spos_of", vp), ("spos_of_from", i32),
+                ("cert_nbr", vp), ("cert_gdirty", vp), ("cert_pend", vp), ("cert_glist", vp), ("cert_gcount", vp), ("cert_cm", vp), ("tgt_sorted", vp), ("tgt_sorted_stride", i32),
                 ("bwd_skip", vp), ("bwd_mref", vp), ("bwd_live", vp), ("bwd_skip_eps", f64), ("bwd_tail_from", i32), ("bwd_tail_partials", vp), ("bwd_tail_arrive", vp), ("gumbel", vp), ("first_search_done", i32), ("tgt_f16", vp)]
 
 
@@ -69,7 +71,8 @@ CERT_OFF_FOR_GOOD = 1 << 20     # dicp_loop_buffers.cert_cloud[:, 2]: the cloud'
 class SegmentPlan(ctypes.Structure):
     """dicp_segment_plan (include/dicp_hip.h)."""
     _fields_ = [("nseg", i32), ("k0", i32 * MAX_SEGMENTS), ("k1", i32 * MAX_SEGMENTS), ("new_order", i32 * MAX_SEGMENTS),
-                ("cert_from", i32), ("pad0", i32), ("order", vp * MAX_SEGMENTS), ("keys", vp), ("cert_q", vp), ("cert_qu", vp), ("cert_count", vp), ("cert_cloud", vp), ("cert_set", vp)]
+                ("cert_from", i32), ("pad0", i32), ("order", vp * MAX_SEGMENTS), ("keys", vp), ("cert_q", vp), ("cert_qu", vp), ("cert_count", vp), ("cert_cloud", vp), ("cert_set", vp),
+                ("cert_nbr", vp), ("cert_gdirty", vp), ("cert_pend", vp), ("cert_cm", vp), ("cert_glist", vp), ("cert_gcount", vp)]
 
 
 class Call(ctypes.Structure):
@@ -97,13 +100,13 @@ class CallGrads(ctypes.Structure):
 class CallBackwardLayout(ctypes.Structure):
     """dicp_call_backward_layout (include/dicp_hip.h)."""
     _fields_ = ([(k, _sz) for k in ("total", "zeroed", "live", "arrive", "mref", "decisions", "far", "gpose", "gtmp", "src_s", "w_s", "gsrc_s", "gw_s", "slab", "gs", "gb",
-                                    "partials", "tail_partials")] + [("nblk_w", i32), ("pad0", i32)])
+                                    "partials", "tail_partials", "spos_ref")] + [("nblk_w", i32), ("pad0", i32)])
 
 
 class LoopBackwardIn(ctypes.Structure):
     """dicp_loop_backward_in (include/dicp_hip.h)."""
-    _fields_ = ([(k, vp) for k in ("src", "tgt_sorted", "w0", "tperm", "qorder", "spos", "poses", "deltas", "areg", "alive", "src_rows", "tgt_rows")]
-                + [(k, i32) for k in ("N", "n", "m", "c", "K", "K_cap", "m_pad", "dim", "knn_variant", "pad0")])
+    _fields_ = ([(k, vp) for k in ("src", "tgt_sorted", "w0", "tperm", "qorder", "spos", "poses", "deltas", "areg", "alive", "src_rows", "tgt_rows", "spos_of")]
+                + [(k, i32) for k in ("N", "n", "m", "c", "K", "K_cap", "m_pad", "dim", "knn_variant", "spos_of_from")])
 
 
 class KabschCall(ctypes.Structure):
@@ -157,6 +160,7 @@ _SIGNATURES = {
     "dicp_search_pose": ([i32, vp, vp, i32, vp, vp], ctypes.c_int),
     "dicp_loop_finish": ([i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp], ctypes.c_int),
     "dicp_accumulate_bwd_window": ([i32, ctypes.POINTER(WeightParams), vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp], ctypes.c_int),
+    "dicp_resolve_matches": ([vp, vp, i32, vp, i32, i32, vp, vp], ctypes.c_int),
     "dicp_window_reduce": ([i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, i32, vp], ctypes.c_int),
     "dicp_permute_add_rows": ([i32, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp], ctypes.c_int),
     "dicp_pose_grad_in": ([i32, vp, vp, i32, vp], ctypes.c_int),

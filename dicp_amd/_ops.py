@@ -819,12 +819,19 @@ class ICPLoop(torch.autograd.Function):
                     cert_hint["calls"] += 1                                  # certified calls of this shape
             arena.take((Kmax, 128) if want_certs else (0,), torch.int32)
             arena.take((N, 8) if want_certs else (0,), torch.int32)
-            deltas, costs, converged, iterations, matched, n_matched, counters, cert_count, cert_cloud = arena.finish()
+            arena.take((N, n) if want_certs else (0,), torch.int32)     # (row cache: matches a guard launch leaves for the accumulate of its iteration; zero = none)
+            arena.take((Kmax + 1, 8) if want_certs else (0,), torch.int32)     # (lengths of the guard launches' work lists, per iteration)
+            deltas, costs, converged, iterations, matched, n_matched, counters, cert_count, cert_cloud, cert_pend, cert_gcount = arena.finish()
             # pose_0, alive_0, n_start (ICP.py:124-129)
             certs = None
             if want_certs:
                 units = (n + 63) // 64          # (units of the sweep's one-query-per-lane forms; the two-query form uses half of them)
+                # (row cache of the certified iterations: the matched row of every query, a filter per 64 queries, and -- with gradients -- where each such
+                #  group's matches lie in the history, which those iterations keep by reference: dicp_loop_buffers.spos_of)
                 certs = dict(q=torch.empty((N, n), dtype=dt, device=dev), qu=torch.empty((N, units), dtype=dt, device=dev), count=cert_count,
+                             nbr=torch.empty((N, n, 6 if cfg.icp_type == "pt2pl" else 3), dtype=dt, device=dev), gdirty=torch.empty((N, units), dtype=torch.int32, device=dev),
+                             cm=torch.empty((N, n), dtype=torch.int32, device=dev), glist=torch.empty((8, N * units), dtype=torch.int32, device=dev), gcount=cert_gcount,
+                             pend=cert_pend, of=torch.empty((Kmax + 1, N, units), dtype=torch.int32, device=dev) if need_grad else None,
                              set=torch.empty((N * n * (es + 16),), dtype=torch.uint8, device=dev) if cfg.cert_sets else None,     # candidate sets: (N,n) budgets + (N,n,4) rows
                              rmax=torch.empty((N, 4), dtype=dt, device=dev), dcum=torch.empty((N, 2 * (Kmax + 1)), dtype=dt, device=dev))
             _lib.check(lib.dicp_loop_init(code, _p(T_init.contiguous()), _p(w0c), float(cfg.match_ratio_thresh), rows, N, n,
@@ -899,7 +906,10 @@ class ICPLoop(torch.autograd.Function):
                 SP = _lib.SegmentPlan(nseg=len(segs), cert_from=cert_from if certs is not None else -1, keys=_p(sweep.keys),
                                       cert_q=_p(certs["q"]) if certs else None, cert_qu=_p(certs["qu"]) if certs else None,
                                       cert_count=_p(certs["count"]) if certs else None, cert_cloud=_p(cert_cloud) if (certs and cfg.cert_backoff) else None,
-                                      cert_set=_p(certs["set"]) if certs else None)
+                                      cert_set=_p(certs["set"]) if certs else None, cert_nbr=_p(certs["nbr"]) if certs else None,
+                                      cert_gdirty=_p(certs["gdirty"]) if certs else None, cert_pend=_p(certs["pend"]) if certs else None,
+                                      cert_cm=_p(certs["cm"]) if certs else None, cert_glist=_p(certs["glist"]) if certs else None,
+                                      cert_gcount=_p(certs["gcount"]) if certs else None)
                 n_new = sum(1 for (k0, _) in segs if (k0 == 0 or k0 in cfg.sweep_resort)) - (1 if have_first else 0)
                 fresh_orders = torch.empty((max(n_new, 1), N, n), dtype=torch.int32, device=dev)
                 used = 0
@@ -929,7 +939,8 @@ class ICPLoop(torch.autograd.Function):
                     spos=_p(spos_slabs[0]) if keep_spos else _p(spos_once),
                     idx=(_p(idx_slabs[0]) if need_grad else _p(idx_once)) if keep_idx else None,
                     partials=_p(partials), counters=_p(counters), events=events, frame=_p(center), poses_search=_p(poses_c),
-                    src_rows=_p(cfg.src_rows), tgt_rows=_p(cfg.tgt_rows), first_search_done=int(first_spos is not None), tgt_f16=_p(img16))
+                    src_rows=_p(cfg.src_rows), tgt_rows=_p(cfg.tgt_rows), first_search_done=int(first_spos is not None), tgt_f16=_p(img16),
+                    spos_of=_p(certs["of"]) if certs else None)
                 _lib.check(lib.dicp_icp_forward_plan(code, Pref, ctypes.byref(LB), ctypes.byref(SP), N, n, m, int(cfg.dim), 1, float(cfg.tolerance), st),
                            "dicp_icp_forward_plan")
                 segs = []
@@ -981,8 +992,13 @@ class ICPLoop(torch.autograd.Function):
                 LB.cert_q, LB.cert_qu, LB.cert_count = (_p(certs["q"]), _p(certs["qu"]), _p(certs["count"])) if use_certs else (None, None, None)
                 LB.cert_cloud = _p(cert_cloud) if (use_certs and cfg.cert_backoff) else None
                 LB.cert_set = _p(certs["set"]) if use_certs else None
+                LB.cert_nbr, LB.cert_gdirty, LB.cert_pend, LB.cert_cm = (_p(certs["nbr"]), _p(certs["gdirty"]), _p(certs["pend"]), _p(certs["cm"])) if use_certs else (None, None, None, None)
+                LB.cert_glist, LB.cert_gcount = (_p(certs["glist"]), _p(certs["gcount"])) if use_certs else (None, None)
+                LB.spos_of = _p(certs["of"]) if use_certs else None
                 LB.cert_reset = int(k0 == cert_from)
-                LB.spos_prev0 = _p(spos_slabs[(k0 - 1) // kc][(k0 - 1) % kc]) if (keep_spos and k0 > 0) else None
+                # (history in several slabs: a certified iteration finds the matches of the slab before its own through spos_prev_chunk)
+                LB.spos_floor = base
+                LB.spos_prev_chunk = ctypes.c_void_p(spos_slabs[j - 1].data_ptr() - (j - 1) * kc * N * n * 4) if (keep_spos and j > 0) else None
                 LB.w = ctypes.c_void_p(w_slabs[j].data_ptr() - base * n * es)
                 LB.w_prev0 = _p(w_slabs[(k0 - 1) // kc][:, (k0 - 1) % kc]) if k0 > 0 else None
                 _lib.check(lib.dicp_icp_forward(code, Pref, LBref, N, n, m, int(cfg.dim), int(cfg.const_iter),
@@ -1031,7 +1047,8 @@ class ICPLoop(torch.autograd.Function):
             _lib.check(lib.dicp_transform_points(code, _p(src), _p(poses[K]), _p(pc), N, n, st), "dicp_transform_points")
 
         if need_grad:
-            saved = [src, tgt, w0c, poses, deltas, areg, alive] + idx_slabs + spos_slabs + qorders + ([sweep.tperm, sweep.tgt_s] if owned else [])
+            spos_of = certs["of"] if (certs is not None and keep_spos) else None
+            saved = [src, tgt, w0c, poses, deltas, areg, alive] + idx_slabs + spos_slabs + qorders + ([sweep.tperm, sweep.tgt_s] if owned else []) + ([spos_of] if spos_of is not None else [])
             if soft:
                 saved += [nbr_hist, lse_hist] + (U_list if U_list is not None else [])
             ctx.save_for_backward(*saved)
@@ -1039,6 +1056,7 @@ class ICPLoop(torch.autograd.Function):
             ctx.soft = (float(g_eps), float(g_tau), seed_list, len(U_list) if U_list is not None else 0) if soft else None
             ctx.layout = (len(idx_slabs), len(spos_slabs), len(qorders), kc, owned, m_pad, kind,
                           [(a, min(b, K), q) for (a, b), q in zip(done_segs, seg_q) if a < K])
+            ctx.of_from = cert_from if spos_of is not None else None
         conv = converged.bool()
         ctx.mark_non_differentiable(deltas_out, weights, costs_out, conv, iterations, matched)
         return T, pc, deltas_out, weights, costs_out, conv, iterations, matched
@@ -1050,6 +1068,10 @@ class ICPLoop(torch.autograd.Function):
         n_idx, n_spos, n_q, kc, owned, m_pad, kind, segs = ctx.layout
         idx_slabs, spos_slabs = rest[:n_idx], rest[n_idx:n_idx + n_spos]
         qorders = rest[n_idx + n_spos:n_idx + n_spos + n_q]
+        of_from = getattr(ctx, "of_from", None)
+        spos_of = None
+        if of_from is not None:         # (the certified iterations' match history is kept by reference: dicp_loop_buffers.spos_of)
+            spos_of, rest = rest[-1], rest[:-1]
         tperm, tgt_s = (rest[-2], rest[-1]) if owned else (None, None)
         soft = getattr(ctx, "soft", None)
         if soft is not None:    # Gumbel-softmax correspondences: neighbour rows and log-sum-exp of every iteration (+ the injected noise)
@@ -1077,7 +1099,8 @@ class ICPLoop(torch.autograd.Function):
                                         qorder=qorders[-1].data_ptr(), spos=spos_slabs[0].data_ptr(), poses=poses.data_ptr(), deltas=deltas.data_ptr(), areg=areg.data_ptr(),
                                         alive=alive.data_ptr(), src_rows=cfg.src_rows.data_ptr() if cfg.src_rows is not None else None,
                                         tgt_rows=cfg.tgt_rows.data_ptr() if cfg.tgt_rows is not None else None, N=N, n=n, m=m, c=tgt_s.shape[2], K=K, K_cap=Kmax, m_pad=m_pad,
-                                        dim=int(cfg.dim), knn_variant=kind | ((0 if cfg.small_loop else 1) << 25))
+                                        dim=int(cfg.dim), knn_variant=kind | ((0 if cfg.small_loop else 1) << 25),
+                                        spos_of=spos_of.data_ptr() if spos_of is not None else None, spos_of_from=int(of_from) if of_from is not None else 0)
                 gsrc, gtgt, gT0, gw = backward_once(lib, code, P, F, cfg, src, tgt, w0c, gT, bool(want_tgt), bool(want_w))
                 if gsrc_pc is not None:
                     gsrc += gsrc_pc
@@ -1114,6 +1137,11 @@ class ICPLoop(torch.autograd.Function):
                 gw_s = torch.empty_like(w0c) if want_w else None
                 k_ref = max(b for (_, b, _), wf in zip(segs, windowed) if wf) - 1      # windows placed by the last iteration's matches
                 spos_ref = spos_slabs[k_ref // kc][k_ref % kc]
+                if spos_of is not None and k_ref >= of_from:    # (kept by reference: a plain array of them)
+                    spos_ref = torch.empty((N, n), dtype=torch.int32, device=dev)
+                    jr = k_ref // kc
+                    _lib.check(lib.dicp_resolve_matches(ctypes.c_void_p(spos_slabs[jr].data_ptr() - jr * kc * N * n * 4), _p(spos_of), k_ref, _p(cfg.src_rows), N, n, _p(spos_ref), st),
+                               "dicp_resolve_matches")
                 slab = torch.empty((N, nblk_w, lib.dicp_window_rows(code), cv), dtype=dt, device=dev) if want_tgt else None
                 gfar = torch.zeros((N, m_pad, cv), dtype=dt, device=dev) if want_tgt else None
             gs = torch.empty((N, 36), dtype=dt, device=dev)
@@ -1198,6 +1226,7 @@ class ICPLoop(torch.autograd.Function):
                     qorder=_p(qo) if w_form else None,
                     spos=ctypes.c_void_p(spos_slabs[j].data_ptr() - base * N * n * 4) if w_form else None,
                     spos_ref=_p(spos_ref) if w_form else None, gts_far=_p(gfar) if w_form else None,
+                    spos_of=_p(spos_of) if (w_form and spos_of is not None) else None, spos_of_from=int(of_from) if of_from is not None else 0,
                     poses=_p(poses), deltas=_p(deltas), areg=_p(areg), alive=_p(alive),
                     idx=ctypes.c_void_p(idx_slabs[j].data_ptr() - base * N * n * 4) if idx_slabs else None, events=events,
                     bwd_overwrite=fresh if (w_form and k1 > k0) else 0, src_rows=_p(cfg.src_rows), tgt_rows=_p(cfg.tgt_rows),

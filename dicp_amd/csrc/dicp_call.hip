@@ -204,6 +204,7 @@ static int backward_layout(int dtype, const dicp_weight_params* prm, int N_, int
     L->gb = w.take(N * 6 * es);
     L->partials = w.take(N * nblk * DICP_NBWD_PAD * es);
     L->tail_partials = w.take(N * (size_t)L->nblk_w * DICP_NBWD_PAD * es);
+    L->spos_ref = w.take(N * n * 4);
     L->total = w.off;
     return 0;
 }
@@ -233,12 +234,18 @@ static int backward_once(int dtype, const dicp_weight_params* prm, const dicp_lo
     if (int rc = dicp_gather_rows(dtype, f->src, qo, f->N, f->n, f->n, 3, W + L.src_s, stream)) return rc;
     if (f->w0)
         if (int rc = dicp_gather_rows(dtype, f->w0, qo, f->N, f->n, f->n, 1, W + L.w_s, stream)) return rc;
-    const int32_t* spos_ref = f->spos + (size_t)(K - 1) * N * n;      // windows placed by the last iteration's matches
+    // windows placed by the last iteration's matches (a plain array of them: the history may be kept by reference)
+    const int32_t* spos_ref = f->spos + (size_t)(K - 1) * N * n;
+    if (f->spos_of && K - 1 >= f->spos_of_from) {
+        if (int rc = dicp_resolve_matches(f->spos, f->spos_of, K - 1, f->src_rows, f->N, f->n, (int32_t*)(W + L.spos_ref), stream)) return rc;
+        spos_ref = (const int32_t*)(W + L.spos_ref);
+    }
     dicp_loop_buffers B;
     memset(&B, 0, sizeof(B));
     B.src = W + L.src_s; B.tgt = f->tgt_sorted; B.w_init = f->w0 ? W + L.w_s : nullptr; B.c = f->c; B.K = f->K_cap;
     B.knn_variant = f->knn_variant;
     B.m_pad = f->m_pad; B.idx_per_iter = 1; B.qorder = qo; B.spos = (int32_t*)f->spos; B.spos_ref = spos_ref; B.gts_far = want_tgt ? W + L.far : nullptr;
+    B.spos_of = (int32_t*)f->spos_of; B.spos_of_from = f->spos_of_from;
     B.poses = (void*)f->poses; B.deltas = (void*)f->deltas; B.areg = (double*)f->areg; B.alive = (void*)f->alive;
     B.src_rows = f->src_rows; B.tgt_rows = f->tgt_rows;
     B.bwd_overwrite = 1;

@@ -271,6 +271,8 @@ static int sweep_auto_cfg(int N, int n) { return ((long)N * n >= 2L * BLOCK * 10
 
 struct CertArgs {             // certifying search: budgets (NULL q: plain search), motion bounds; guard: the launch of a certified iteration
     void* q; void* qu; const void* dcum; int dstride; int k; int32_t* count; bool guard; int32_t* cloud; void* set;
+    int32_t* cm; int32_t* pend; int32_t* gdirty;     // the searches' own copy of the matches (by slot); guard launches: where a CHANGED match is left (SweepCert::pend)
+    const int32_t* glist; const int32_t* gcount; int glist_cap;     // guard launches: the work lists the previous step made
 };
 
 static int sweep_launch(int dtype, const void* src, const void* pose, const void* tgs4, const int32_t* tperm,
@@ -291,16 +293,18 @@ static int sweep_launch(int dtype, const void* src, const void* pose, const void
 #define DICP_SWEEP_ARGS(T) (const T*)src, (const T*)pose, (const typename V4<T>::type*)tgs4, tperm, qorder, bucket, (const T*)brange, nbkt, idx, spos, pairs, \
         N, n, m, m_pad, bpc, rw.src, rw.tgt
 #define DICP_SWEEP_C(T, Q, CH, CERT, CT) hipExtLaunchKernelGGL((knn_sweep_kernel<T, Q, CH, CERT>), dim3(grid_for(N, bpc)), dim3(BLOCK), 0, st, ev0, ev1, 0, DICP_SWEEP_ARGS(T), CT)
-#define DICP_SWEEP_L(T, Q, CH, CT) hipExtLaunchKernelGGL((knn_sweep_guard_kernel<T, Q, CH>), dim3(grid_for(N, bpc)), dim3(BLOCK), 0, st, ev0, ev1, 0, DICP_SWEEP_ARGS(T), CT)
+#define DICP_SWEEP_L(T, Q, CH, CT) do { /* the guard: a grid the GPU holds at once (5 blocks per unit), or as many blocks as there are units */ \
+        const long want = ((long)N * units + BLOCK / WAVE - 1) / (BLOCK / WAVE); const unsigned g8 = (unsigned)((want < 1280 ? want : 1280) + 7) / 8 * 8; \
+        hipExtLaunchKernelGGL((knn_sweep_guard_kernel<T, Q, CH>), dim3(g8), dim3(BLOCK), 0, st, ev0, ev1, 0, DICP_SWEEP_ARGS(T), CT, ca.glist, ca.gcount, ca.glist_cap); } while (0)
 #define DICP_SWEEP_CG(T, Q, CH, CT) do { if (ca.guard) DICP_SWEEP_L(T, Q, CH, CT); else DICP_SWEEP_C(T, Q, CH, true, CT); } while (0)
 #define DICP_SWEEP(T, Q, CH) do { SweepCert<T> none{}; DICP_SWEEP_C(T, Q, CH, false, none); } while (0)
     if (ca.q) {             // certifying search, or the guard launch of a certified iteration
-        if (!ca.qu || !ca.dcum || !spos || !qorder) return DICP_ERR_ENUM;
+        if (!ca.qu || !ca.dcum || !spos || !qorder || (ca.guard && (!ca.glist || !ca.gcount))) return DICP_ERR_ENUM;
         if (dtype == DICP_F32) {
-            SweepCert<float> c{(float*)ca.q, (float*)ca.qu, (const float*)ca.dcum, ca.dstride, ca.k, ca.count, ca.set, ca.cloud};
+            SweepCert<float> c{(float*)ca.q, (float*)ca.qu, (const float*)ca.dcum, ca.dstride, ca.k, ca.count, ca.set, ca.cloud, ca.cm, ca.guard ? ca.pend : nullptr, ca.gdirty, (n + WAVE - 1) / WAVE};
             if (cfg == 2) DICP_SWEEP_CG(float, 2, 8, c); else if (cfg == 4) DICP_SWEEP_CG(float, 1, 16, c); else DICP_SWEEP_CG(float, 1, 8, c);
         } else {
-            SweepCert<double> c{(double*)ca.q, (double*)ca.qu, (const double*)ca.dcum, ca.dstride, ca.k, ca.count, ca.set, ca.cloud};
+            SweepCert<double> c{(double*)ca.q, (double*)ca.qu, (const double*)ca.dcum, ca.dstride, ca.k, ca.count, ca.set, ca.cloud, ca.cm, ca.guard ? ca.pend : nullptr, ca.gdirty, (n + WAVE - 1) / WAVE};
             if (cfg == 2) DICP_SWEEP_CG(double, 2, 8, c); else DICP_SWEEP_CG(double, 1, 8, c);
         }
         return launch_status();
@@ -390,11 +394,10 @@ static int accumulate_go(int dtype, const dicp_weight_params* prm, const void* s
 #define DICP_ACC(T, M, CERT, PS) hipExtLaunchKernelGGL((accumulate_kernel<T, M, CERT>), dim3(g), dim3(BLOCK), 0, st, ev0, ev1, 0, P, (const T*)src, (const T*)tgt, c, idx, (const T*)pose, \
         (const T*)w_init, (const T*)alive, N, n, m, bpc, (T*)partials, (T*)w_out, (long)w_stride, src_rows, PS, (const T*)w_prev)
 #define DICP_ACC_T(T) do { \
-        PointSearch<T> ps{}; \
+        AccCert<T> ps{}; \
         if (ca) { \
-            ps.pose = (const T*)ca->pose_search; ps.tgs4 = (const typename V4<T>::type*)ca->tgs4; ps.tperm = ca->tperm; ps.bucket = ca->bucket; ps.brange = (const T*)ca->brange; \
-            ps.nbkt = ca->nbkt; ps.tgt_rows = ca->tgt_rows; ps.m_full = ca->m_full; ps.m_pad = ca->m_pad; ps.pairs = ca->pairs; \
-            ps.ct = SweepCert<T>{(T*)ca->q, (T*)ca->qu, (const T*)ca->dcum, ca->dstride, ca->k, ca->count, ca->set, ca->cloud}; ps.spos = ca->spos; ps.spos_next = ca->spos_next; \
+            ps.spos = ca->spos; ps.hist = ca->hist; ps.hist_prev = ca->hist_prev; ps.of = ca->of; ps.k_floor = ca->k_floor; ps.N = N; ps.nwr = (n + WAVE - 1) / WAVE; ps.k = ca->k; \
+            ps.nbr = (T*)ca->nbr; ps.gdirty = ca->gdirty; ps.pend = ca->pend; ps.cloud = ca->cloud; ps.fresh = ca->fresh; ps.units = ca->units; ps.sets = ca->sets; \
             if (P.mode == MODE_PT2PL) DICP_ACC(T, MODE_PT2PL, true, ps); else DICP_ACC(T, MODE_PT2PT, true, ps); \
         } else { if (P.mode == MODE_PT2PL) DICP_ACC(T, MODE_PT2PL, false, ps); else DICP_ACC(T, MODE_PT2PT, false, ps); } } while (0)
     if (dtype == DICP_F32) DICP_ACC_T(float); else DICP_ACC_T(double);
@@ -602,6 +605,16 @@ int dicp_kabsch_bwd(int dtype, const void* src, const void* tgt, int c, const in
     return launch_status();
 }
 
+int dicp_resolve_matches(const int32_t* spos, const int32_t* spos_of, int k, const int32_t* src_rows, int N, int n, int32_t* out, void* stream) {
+    if (!spos || !out) return DICP_ERR_NULL;
+    if (N <= 0 || n <= 0 || k < 0) return DICP_ERR_SHAPE;
+    begin_launch();
+    const int bpc = (int)blocks_for((size_t)n);
+    const MatchHist h = spos_of ? MatchHist{spos, spos_of, k, N, n, (n + WAVE - 1) / WAVE} : plain_matches(spos + (size_t)k * N * n, N, n);
+    resolve_matches_kernel<<<grid_for(N, bpc), BLOCK, 0, (hipStream_t)stream>>>(h, bpc, src_rows, out);
+    return launch_status();
+}
+
 int dicp_window_blocks(int dtype, int n, int m_pad) {
     if (n <= 0 || m_pad <= 0) return 0;
     const int spb = window_slots(dtype == DICP_F32 ? WindowRows<float>::v : WindowRows<double>::v, n, m_pad);
@@ -639,22 +652,23 @@ int dicp_bwd_tail_max_blocks(int dtype) {
 }
 
 static int accumulate_bwd_window_go(int dtype, const dicp_weight_params* prm, const void* src_s, const void* tgt_s, int c,
-                                    const int32_t* spos, const int32_t* spos_ref, const int32_t* qorder, const void* pose, const void* w_s,
+                                    const MatchHist spos, const int32_t* spos_ref, const int32_t* qorder, const void* pose, const void* w_s,
                                     const void* alive, const void* gs, const void* gb, const int32_t* src_rows, int N, int n, int m_pad, void* gsrc_s, void* slab,
                                     void* gts_far, void* gw_s, void* bwd_partials, int overwrite, void* stream, const int32_t* skip);
 int dicp_accumulate_bwd_window(int dtype, const dicp_weight_params* prm, const void* src_s, const void* tgt_s, int c,
                                const int32_t* spos, const int32_t* spos_ref, const int32_t* qorder, const void* pose, const void* w_s,
                                const void* alive, const void* gs, const void* gb, const int32_t* src_rows, int N, int n, int m_pad, void* gsrc_s, void* slab,
                                void* gts_far, void* gw_s, void* bwd_partials, int overwrite, void* stream) {
-    return accumulate_bwd_window_go(dtype, prm, src_s, tgt_s, c, spos, spos_ref, qorder, pose, w_s, alive, gs, gb, src_rows, N, n, m_pad, gsrc_s, slab, gts_far, gw_s,
+    if (!spos) return DICP_ERR_NULL;
+    return accumulate_bwd_window_go(dtype, prm, src_s, tgt_s, c, plain_matches(spos, N, n), spos_ref, qorder, pose, w_s, alive, gs, gb, src_rows, N, n, m_pad, gsrc_s, slab, gts_far, gw_s,
                                     bwd_partials, overwrite, stream, nullptr);
 }
 static int accumulate_bwd_window_go(int dtype, const dicp_weight_params* prm, const void* src_s, const void* tgt_s, int c,
-                                    const int32_t* spos, const int32_t* spos_ref, const int32_t* qorder, const void* pose, const void* w_s,
+                                    const MatchHist spos, const int32_t* spos_ref, const int32_t* qorder, const void* pose, const void* w_s,
                                     const void* alive, const void* gs, const void* gb, const int32_t* src_rows, int N, int n, int m_pad, void* gsrc_s, void* slab,
                                     void* gts_far, void* gw_s, void* bwd_partials, int overwrite, void* stream, const int32_t* skip) {
     if (const int e = check_params(prm, c)) return e;
-    if (!src_s || !tgt_s || !spos || !spos_ref || !pose || (gw_s && !w_s) || !gs || !gb || !gsrc_s || !bwd_partials || (slab && !gts_far))
+    if (!src_s || !tgt_s || !spos.base || !spos_ref || !pose || (gw_s && !w_s) || !gs || !gb || !gsrc_s || !bwd_partials || (slab && !gts_far))
         return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || n <= 0 || m_pad <= 0 || m_pad % KNN_PAD) return DICP_ERR_SHAPE;
@@ -787,21 +801,21 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
             // match certificates: only the units holding a query whose match is not proven unchanged are searched again
             const int cfg_plain = cfg ? cfg : sweep_auto_cfg(N, n);
             const bool cert = B->cert_q && B->cert_qu && B->rmax && B->dcum && spos_k && sorted_rows && !B->idx && B->qorder && sweep_queries_per_lane(cfg_plain) > 0;
+            // (the certified iterations keep a row cache and their match history by reference: accumulate_kernel)
+            if (cert && (!B->cert_nbr || !B->cert_gdirty || !B->cert_pend || !B->cert_cm || !B->cert_glist || !B->cert_gcount || (B->idx_per_iter && !B->spos_of))) { set_launch_events(nullptr, nullptr); return DICP_ERR_NULL; }
+            const int cert_units = cert ? (n + WAVE * sweep_queries_per_lane(cfg_plain) - 1) / (WAVE * sweep_queries_per_lane(cfg_plain)) : 0;
+            const int glist_cap = N * ((n + WAVE - 1) / WAVE);
             const bool fresh = k == 0 || (k == k0 && B->cert_reset);           // a new query order: every query is searched, every budget written
             int32_t* count_k = B->cert_count ? B->cert_count + (size_t)k * 2 * CERT_SHARDS : nullptr;
             const bool searched = B->first_search_done && k == 0 && !cert && spos_k && !B->idx;    // the caller ran iteration 0's search itself, ahead of this call
             if (searched) rc = 0;
             else if (cert) {
-                if (!fresh && k == k0 && B->idx_per_iter) {     // this call's first matches start as the previous call's last (later ones: handed on by accumulate)
-                    if (!B->spos_prev0) { set_launch_events(nullptr, nullptr); return DICP_ERR_NULL; }
-                    if (hipMemcpyAsync(spos_k, B->spos_prev0, (size_t)N * n * sizeof(int32_t), hipMemcpyDeviceToDevice, st) != hipSuccess) {
-                        set_launch_events(nullptr, nullptr);        // (thread-local: the next launch on this thread must not carry them)
-                        return -(int)hipGetLastError();
-                    }
-                }
+                // (nothing is copied from iteration to iteration, or from call to call: where a group of queries finds its matches is a word of spos_of)
                 begin_launch();
                 rc = sweep_launch(dtype, B->src, pose_s, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, N, n, m, B->m_pad, nullptr, spos_k,
-                                  B->pairs, cfg, Rows{B->src_rows, B->tgt_rows}, st, CertArgs{B->cert_q, B->cert_qu, B->dcum, 2 * (B->K + 1), k, count_k, !fresh, B->cert_cloud, B->cert_set});
+                                  B->pairs, cfg, Rows{B->src_rows, B->tgt_rows}, st, CertArgs{B->cert_q, B->cert_qu, B->dcum, 2 * (B->K + 1), k, count_k, !fresh, B->cert_cloud, B->cert_set,
+                                                                                              B->cert_cm, B->cert_pend, B->cert_gdirty,
+                                                                                              B->cert_glist, B->cert_gcount ? B->cert_gcount + (size_t)k * 8 : nullptr, glist_cap});
             } else
             rc = dicp_knn_sweep(dtype, B->src, pose_s, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, B->src_rows, B->tgt_rows, N, n, m, B->m_pad,
                                 B->idx ? idx_k : nullptr, spos_k, B->pairs, cfg, B->tgt_f16, stream);
@@ -811,9 +825,8 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
             if (cert) {
                 // the accumulate of a certified iteration checks every point's budget and searches the spent ones on the spot; its matches
                 // are the start of the next iteration's (within this call)
-                const CertAcc ca{pose_s, B->tgt4, B->tperm, B->bucket, B->brange, B->nbkt, B->tgt_rows, m, B->m_pad, B->pairs,
-                                 B->cert_q, B->cert_qu, fresh ? nullptr : B->dcum, 2 * (B->K + 1), k, count_k,
-                                 spos_k, (B->idx_per_iter && k + 1 < k1) ? spos_k + (size_t)N * n : nullptr, B->cert_cloud, B->cert_set};
+                const CertAcc ca{spos_k, B->spos, B->spos_prev_chunk, B->idx_per_iter ? B->spos_of : nullptr, B->spos_floor, k,
+                                 B->cert_nbr, B->cert_gdirty, B->cert_pend, B->cert_cloud, fresh ? 1 : 0, cert_units, B->cert_set ? 1 : 0};
                 rc = accumulate_go(dtype, prm, B->src, B->tgt_sorted, B->tgt_sorted_stride, spos_k, pose_k, B->w_init, alive_k, B->src_rows, N, n, B->m_pad,
                                    B->partials, w_k, B->w_stride, stream, &ca, w_prev_k);
             } else if (sorted_rows)
@@ -851,6 +864,15 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
         }
         dicp_step_io io = make_step_io(*B, k, k0, N, n, prm->mode, dim, const_iter, tolerance, es, nblk);
         io.w_copied = w_prev_k ? 1 : 0;
+        if (kind == DICP_KNN_SWEEP && B->cert_q && B->cert_qu && B->cert_glist && B->cert_gcount && B->rmax && B->dcum && k + 1 < B->K) {
+            // a certified iteration's step also makes the next guard launch its work list (dicp_step_io.glist)
+            const int cfgp = ((B->knn_variant >> 8) & 0xff) ? ((B->knn_variant >> 8) & 0xff) : sweep_auto_cfg(N, n);
+            const int Qp = sweep_queries_per_lane(cfgp);
+            if (Qp > 0) {
+                io.cert_qu = B->cert_qu; io.cert_units = (n + WAVE * Qp - 1) / (WAVE * Qp); io.glist_cap = N * ((n + WAVE - 1) / WAVE);
+                io.glist = B->cert_glist; io.gcount = B->cert_gcount + (size_t)(k + 1) * 8;
+            }
+        }
         rc = dicp_step(dtype, &io, N, stream);
         if (rc) return rc;
     }
@@ -885,8 +907,9 @@ int dicp_icp_forward_plan(int dtype, const dicp_weight_params* prm, const dicp_l
         B.cert_q = certs ? S->cert_q : nullptr; B.cert_qu = certs ? S->cert_qu : nullptr; B.cert_count = certs ? S->cert_count : nullptr;
         B.cert_cloud = certs ? S->cert_cloud : nullptr;
         B.cert_set = certs ? S->cert_set : nullptr;
+        B.cert_nbr = certs ? S->cert_nbr : nullptr; B.cert_gdirty = certs ? S->cert_gdirty : nullptr; B.cert_pend = certs ? S->cert_pend : nullptr; B.cert_cm = certs ? S->cert_cm : nullptr; B.cert_glist = certs ? S->cert_glist : nullptr; B.cert_gcount = certs ? S->cert_gcount : nullptr;
         B.cert_reset = (S->cert_from >= 0 && k0 == S->cert_from) ? 1 : 0;
-        B.spos_prev0 = (B.spos && B.idx_per_iter && k0 > 0) ? B.spos + (size_t)(k0 - 1) * N * n : nullptr;
+        B.spos_prev_chunk = nullptr; B.spos_floor = 0;
         B.w_prev0 = k0 > 0 ? (const char*)B.w + (size_t)(k0 - 1) * B.w_iter * es : nullptr;
         if (const int rc = dicp_icp_forward(dtype, prm, &B, N, n, m, dim, const_iter, tolerance, k0, k1, stream)) return rc;
     }
@@ -961,7 +984,9 @@ int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_
                                            N, n, m, G->g_ps, gtgt, 1, stream);
             if (!rc) rc = transform_points_bwd_go(dtype, B->src, pose_k, G->g_ps, gsrc, bwd_partials, N, n, 1, stream);
         } else if (B->spos)    // windowed form: src / w_init / tgt are the SORTED copies, gsrc / gw accumulate in slot order, gtgt is the slab
-            rc = accumulate_bwd_window_go(dtype, prm, B->src, B->tgt, B->c, B->spos + (size_t)k * N * n, B->spos_ref, B->qorder, pose_k, B->w_init,
+            rc = accumulate_bwd_window_go(dtype, prm, B->src, B->tgt, B->c,
+                                          (B->spos_of && k >= B->spos_of_from) ? MatchHist{B->spos, B->spos_of, k, N, n, (n + WAVE - 1) / WAVE} : plain_matches(B->spos + (size_t)k * N * n, N, n),
+                                          B->spos_ref, B->qorder, pose_k, B->w_init,
                                           alive_k, gs, gb, B->src_rows, N, n, B->m_pad,
                                           gsrc, gtgt, B->gts_far, gw, bwd_partials, (B->bwd_overwrite && k == k1 - 1) ? 1 : 0, stream, B->bwd_skip);
         else

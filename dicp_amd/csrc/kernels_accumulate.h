@@ -44,139 +44,118 @@ __device__ __forceinline__ void block_reduce_store(T* v, T* __restrict__ out, T*
 }
 
 // -------------------------------------------------------------------- accumulate
-// CERT (certified iterations of the sweep loop; idx = this iteration's sorted positions): the point's budget is checked where its
-// match is read, a spent one is searched on the spot by the whole wave (search_point), and the matches are handed on to the next
-// iteration's buffer.
-constexpr bool PAIR_ROWS = true;     // (plain launches, 7 waves per SIMD: 58 -> 49 us; certified ones, 5 waves because of their search code: 55 -> 55 -- and 6 or 7 waves spill: 115 / 130 us)
+// CERT (certified iterations of the sweep loop): the ROW CACHE form.  Near the pose a query's match does not change for many iterations (that is
+// what the certificates prove), so gathering its 24-byte target row again in every iteration -- 39 bytes at the memory side, from a random place of
+// the cloud's sorted rows -- and reading its budget and its match only to hand the match on to the next iteration's history slab was most of what such
+// a launch moved (63 bytes per point where section 8d counts 44).  Here every query keeps its matched ROW next to it (nbr, by query: a stream), the
+// match history is kept by reference (AccCert::of), and the certificates are the guard launch's business alone (knn_sweep_guard_kernel): a match it
+// CHANGED waits in pend, its group of 64 queries is marked in gdirty.  A launch reads, per group, one mark and one history word; a marked group first
+// takes its pending matches over (the group's matches into this iteration's slab, the new rows into the cache); then every point streams its
+// coordinates and its cached row and writes its weight: 40 bytes per point.  The launch behind a search of EVERY query of a cloud (the certifying
+// search: fresh; a cloud whose certificates are off or tried again) is all gather: it reads the iteration's own slab and fills the cache.
+// The kernel carries no search code any more, and with it went 30 registers: occupancy, not bytes, is what these launches were short of (a chain of
+// memory latencies: 48 us whether the rows were gathered or streamed at 5 waves per SIMD; profiles/r05_accumulate_occupancy.txt).
+constexpr bool PAIR_ROWS = true;     // (plain launches, 7 waves per SIMD: 58 -> 49 us: two lanes share the two 24-byte rows of their two points)
+template <typename T, int NB> __device__ __forceinline__ void load_cached_row(const T* __restrict__ p, T* v) {
+    if constexpr (NB == 6 && sizeof(T) == 4) {
+        const float2* q = reinterpret_cast<const float2*>(p);      // (rows are 24 bytes: 8-byte aligned)
+        const float2 a = q[0], b = q[1], c = q[2];
+        v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y;
+    } else {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) v[k] = p[k];
+    }
+}
+template <typename T, int NB> __device__ __forceinline__ void store_cached_row(T* __restrict__ p, const T* v) {
+    if constexpr (NB == 6 && sizeof(T) == 4) {
+        float2* q = reinterpret_cast<float2*>(p);
+        q[0] = make_float2(v[0], v[1]); q[1] = make_float2(v[2], v[3]); q[2] = make_float2(v[4], v[5]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) p[k] = v[k];
+    }
+}
+
+#ifndef DICP_ACC_CERT_WAVES
+#define DICP_ACC_CERT_WAVES 7
+#endif
+#ifndef DICP_ACC_PRELOAD
+#define DICP_ACC_PRELOAD 2
+#endif
 template <typename T, int MODE, bool CERT = false>
-__global__ __launch_bounds__(BLOCK, (CERT && sizeof(T) == 4) ? 5 : 1) void accumulate_kernel(WeightParams P, const T* __restrict__ src, const T* __restrict__ tgt, int c /* elements per row of tgt */,
+__global__ __launch_bounds__(BLOCK, (CERT && sizeof(T) == 4) ? DICP_ACC_CERT_WAVES : 1) void accumulate_kernel(WeightParams P, const T* __restrict__ src, const T* __restrict__ tgt, int c /* elements per row of tgt */,
                                                            const int32_t* __restrict__ idx, const T* __restrict__ pose,
                                                            const T* __restrict__ w_init, const T* __restrict__ alive,
                                                            int N, int n, int m, int bpc, T* __restrict__ partials,
-                                                           T* __restrict__ w_out, long w_stride, const int32_t* __restrict__ src_rows, PointSearch<T> ps,
+                                                           T* __restrict__ w_out, long w_stride, const int32_t* __restrict__ src_rows, AccCert<T> ps,
                                                            const T* __restrict__ w_prev /* optional: a frozen cloud (alive = 0) keeps its previous weights, ICP.py:224-226 */) {
+    constexpr int NB = MODE == MODE_PT2PL ? 6 : 3;          // elements of a cached row
+    constexpr int ROUNDS = ACC_PTS / BLOCK;
     __shared__ T red[(BLOCK / WAVE) * NACC_PAD];
-    __shared__ short set_list[CERT ? BLOCK / WAVE : 1][CERT ? ACC_PTS / (BLOCK / WAVE) : 1];      // per wave: its points (offsets in the block's range) with a standing candidate set
     int cloud, blk;
     if (!decode_block(bpc, N, cloud, blk)) return;
     const int nc = rows_of(src_rows, cloud, n);             // ragged batches: rows past the cloud's own carry weight 0 (ICP.py:386-398)
     const int end = min(nc, (blk + 1) * ACC_PTS);
-    unsigned long long rows_scored = 0;                     // this wave's on-the-spot searches: rows scored, searches made (wave-uniform)
-    int singles = 0, rescored = 0;                          // ... and this LANE's candidate sets re-scored
-    if (CERT && ps.ct.dcum && !(ps.ct.cloud && ps.ct.cloud[(size_t)cloud * CERT_CLOUD + 2] > 0)) {      // (certificates off for this cloud: the guard launch has just searched every unit)
-        // first the budgets of this block's points (before the sums' registers are live): spent ones are searched again, one query at a
-        // time by the whole wave; the thread that owns the point rewrites its match and budget and reads them back below
-        const int lane = threadIdx.x & (WAVE - 1);
-        const T spent = cert_spent(ps.ct.dcum + (size_t)cloud * ps.ct.dstride + 2 * ps.ct.k);
-        constexpr int ROUNDS = ACC_PTS / BLOCK;
-        T b[ROUNDS];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // CERT: how this block's cloud is served (block-uniform).  cached: the matches are where the last iteration left them, but for what the guard
+    // launch changed; otherwise the search of this iteration has just written every match of the cloud into the iteration's own slab (certifying
+    // search, certificates off, certificates tried again): everything is gathered and cached.  What a wave needs to know about its (up to) four
+    // groups is fetched at once, up front: the launch is a chain of memory latencies, not of bytes.
+    bool cached = false;
+    size_t of_k = 0;                                        // this cloud's row of `of` at iteration k
+    unsigned live_mask = 0, todo_mask = 0;                  // per round of the wave: its group exists / has something to take over first (wave-uniform)
+    int gslab[ROUNDS];                                      // the iteration whose slab holds the group's matches (wave-uniform)
+#pragma unroll
+    for (int t = 0; t < ROUNDS; ++t) gslab[t] = 0;
+    if (CERT) {
+        of_k = ((size_t)ps.k * ps.N + cloud) * ps.nwr;
+        const int cstate = ps.cloud ? ps.cloud[(size_t)cloud * CERT_CLOUD + 2] : 0;
+        int dirty[ROUNDS];
+#pragma unroll
+        for (int t = 0; t < ROUNDS; ++t) {                  // (read whatever the cloud's state turns out to be: one latency instead of two; the words exist)
+            const int g0 = blk * ACC_PTS + t * BLOCK + wave * WAVE;
+            const bool have = g0 < end;
+            dirty[t] = (have && !ps.fresh) ? ps.gdirty[(size_t)cloud * ps.nwr + (g0 >> 6)] : 0;
+            gslab[t] = (have && !ps.fresh && ps.of) ? ps.of[of_k + (g0 >> 6)] : ps.k;
+            live_mask |= have ? (1u << t) : 0u;
+        }
+        cached = !ps.fresh && !(cstate > 0) && cstate != CERT_RECERTIFY;
+        if (ps.cloud && !ps.fresh && blk == 0 && threadIdx.x == 0) { ps.cloud[(size_t)cloud * CERT_CLOUD + 3] = ps.units; ps.cloud[(size_t)cloud * CERT_CLOUD + 5] = ps.sets; }
+        if (cached) {
+#pragma unroll
+            for (int t = 0; t < ROUNDS; ++t)                // a marked group; a group whose slab belongs to the previous history chunk (copied into this iteration's)
+                if (((live_mask >> t) & 1u) && (dirty[t] != 0 || (ps.of && gslab[t] < ps.k_floor))) todo_mask |= 1u << t;
+        }
+    }
+    if (CERT && cached && todo_mask) {
 #pragma unroll
         for (int t = 0; t < ROUNDS; ++t) {
-            const int i = blk * ACC_PTS + t * BLOCK + threadIdx.x;
-            b[t] = i < end ? ps.ct.q[(size_t)cloud * n + i] : inf_v<T>();
-        }
-        T* __restrict__ qs = ps.ct.set ? set_budgets<T>(ps.ct.set) : nullptr;           // candidate sets (search_point): budgets by query, then the rows
-        int32_t* __restrict__ cands = ps.ct.set ? set_cands<T>(ps.ct.set, N, n) : nullptr;
-        bool isset[ROUNDS];
-#pragma unroll
-        for (int t = 0; t < ROUNDS; ++t) isset[t] = false;
-        if (qs) {
-            // Standing candidate sets first, ALL rounds of the wave at once: the points with one (8 % of them on scanned surfaces, in every wave)
-            // are listed in LDS and re-scored by consecutive lanes -- one chain of dependent loads (set budget, rows, scores) per 64 such
-            // points instead of one per round of the block (planar scenes: 110 -> 98 us per launch; the plain accumulate: 58).
-            const int wv = threadIdx.x >> 6;
-            T sbv[ROUNDS];
-#pragma unroll
-            for (int t = 0; t < ROUNDS; ++t) {
-                const int i = blk * ACC_PTS + t * BLOCK + (int)threadIdx.x;
-                const bool open = i < end && !(b[t] > spent) && b[t] != cert_mark<T>(ps.ct.k);
-                sbv[t] = open ? qs[(size_t)cloud * n + i] : T(-1);
+            if (!((todo_mask >> t) & 1u)) continue;         // (wave-uniform)
+            const int i = blk * ACC_PTS + t * BLOCK + (int)threadIdx.x;
+            const int grp = (i - lane) >> 6;
+            const int s = gslab[t];
+            // the group's matches into this iteration's slab (a marked group: some of them change; and references never reach behind the history chunk)
+            if (ps.of && s != ps.k) {
+                const int32_t* from = (s < ps.k_floor ? ps.hist_prev : ps.hist) + ((size_t)s * ps.N + cloud) * n;
+                if (i < end) ps.spos[(size_t)cloud * n + i] = from[i];
+                if (lane == 0) ps.of[of_k + grp] = ps.k;
+                gslab[t] = ps.k;
             }
-            int total = 0;
+            if (i < end) {
+                const size_t pt = (size_t)cloud * n + i;
+                const int pd = ps.pend[pt];
+                if (pd != 0) {                              // the match the guard launch left: into the history, its row into the cache
+                    ps.spos[pt] = pd - 2;
+                    ps.pend[pt] = 0;
+                    const T* yp = tgt + ((size_t)cloud * m + min(max(pd - 2, 0), m - 1)) * c;
+                    T row[NB];
 #pragma unroll
-            for (int t = 0; t < ROUNDS; ++t) {
-                isset[t] = sbv[t] > spent;
-                const unsigned long long mk = __ballot(isset[t]);
-                if (isset[t]) set_list[wv][total + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u))] = (short)(t * BLOCK + (int)threadIdx.x);
-                total += __popcll(mk);
-            }
-            if (total) {                                        // (wave-uniform)
-                __builtin_amdgcn_wave_barrier();
-                using T4 = typename V4<T>::type;
-                T Cs[9], rs[3];
-                load_pose(ps.pose, cloud, Cs, rs);
-                const T4* __restrict__ tg = ps.tgs4 + (size_t)cloud * ps.m_pad;
-                const int32_t* __restrict__ pm = ps.tperm + (size_t)cloud * ps.m_pad;
-                for (int s0 = 0; s0 < total; s0 += WAVE) {
-                    const int kk = s0 + lane;
-                    if (kk < total) {
-                        const size_t pt = (size_t)cloud * n + blk * ACC_PTS + set_list[wv][kk];
-                        const T* sp = src + pt * 3;
-                        const T p[3] = {sp[0], sp[1], sp[2]};
-                        const int32_t* cd = cands + pt * CERT_CANDS;
-                        int cj[CERT_CANDS];
-                        T4 row[CERT_CANDS];
-#pragma unroll
-                        for (int c = 0; c < CERT_CANDS; ++c) cj[c] = cd[c];
-#pragma unroll
-                        for (int c = 0; c < CERT_CANDS; ++c) row[c] = tg[max(cj[c], 0)];       // (all four gathers in flight together)
-                        T nx[3];
-                        query_point(Cs, rs, p, nx);
-                        // the new match is the set's best row (same score(), equal scores -> lowest original index; the set's first row is the old match: never empty)
-                        T best = inf_v<T>();
-                        int bj = max(cj[0], 0);
-#pragma unroll
-                        for (int c = 0; c < CERT_CANDS; ++c) {
-                            const T sc = cj[c] >= 0 ? score<T, T4>(nx, row[c]) : inf_v<T>();
-                            if (sc < best) { best = sc; bj = cj[c]; }
-                            else if (sc == best && sc < inf_v<T>() && pm[cj[c]] < pm[bj]) bj = cj[c];
-                        }
-                        ps.spos[pt] = bj;
-                        ++rescored;
-                    }
-                }
-                __threadfence_block();                          // (the matches are read back by the points' own lanes below)
-            }
-        }
-#pragma unroll 1
-        for (int t = 0; t < ROUNDS; ++t) {
-            const bool redo = !(b[t] > spent) && b[t] != cert_mark<T>(ps.ct.k) && !isset[t];     // spent, never certifiable, NaN -- unless this iteration's
-            unsigned long long todo = __ballot(redo);                                             // guard launch has just searched it, or its candidate set stands
-            if (!todo) continue;                                // (wave-uniform; the common case)
-            const size_t pt = (size_t)cloud * n + min(blk * ACC_PTS + t * BLOCK + (int)threadIdx.x, n - 1);
-            T p[3] = {T(0), T(0), T(0)}, nb = T(-1), ns = T(-2);
-            int j = -1, nc[CERT_CANDS];
-#pragma unroll
-            for (int c = 0; c < CERT_CANDS; ++c) nc[c] = -1;
-            if (redo) { const T* sp = src + pt * 3; p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2]; j = ps.spos[pt]; }
-            T Cs[9], rs[3];
-            load_pose(ps.pose, cloud, Cs, rs);
-            while (todo) {
-                const int L = __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                const T pq[3] = {__shfl(p[0], L), __shfl(p[1], L), __shfl(p[2], L)};
-                T nx[3], got, gs;
-                int gc[CERT_CANDS];
-                query_point(Cs, rs, pq, nx);
-                const int found = search_point<T>(ps, cloud, nx, __shfl(j, L), got, rows_scored, gs, gc);
-                ++singles;
-                if (lane == L) {
-                    j = found; nb = got; ns = gs > T(0) ? gs : T(-2);       // (-2: searched, no set either)
-#pragma unroll
-                    for (int c = 0; c < CERT_CANDS; ++c) nc[c] = gc[c];
+                    for (int e = 0; e < NB; ++e) row[e] = yp[e];
+                    store_cached_row<T, NB>(ps.nbr + pt * NB, row);
                 }
             }
-            if (redo) {
-                ps.spos[pt] = j;
-                ps.ct.q[pt] = nb;
-                if (qs) {
-                    qs[pt] = nb > T(0) ? T(-1) : ns;
-                    if (ns > T(0)) {
-#pragma unroll
-                        for (int c = 0; c < CERT_CANDS; ++c) cands[pt * CERT_CANDS + c] = nc[c];
-                    }
-                }
-            }
+            if (lane == 0) ps.gdirty[(size_t)cloud * ps.nwr + grp] = 0;
         }
     }
     T C[9], r[3];
@@ -188,54 +167,87 @@ __global__ __launch_bounds__(BLOCK, (CERT && sizeof(T) == 4) ? 5 : 1) void accum
     if (w_out)                                              // ... which is what the weight history reports for them
         for (int i = max(blk * ACC_PTS, nc) + threadIdx.x; i < min(n, (blk + 1) * ACC_PTS); i += BLOCK) w_out[(size_t)cloud * w_stride + i] = T(0);
     const int32_t* __restrict__ ix = CERT ? ps.spos : idx;
-    for (int base = blk * ACC_PTS; base < end; base += BLOCK) {            // (2 or 4 points in flight per thread measured slower: 78 / 85 vs 72 us)
-        const int i = base + (int)threadIdx.x;
-        const bool on = i < end;
-        const size_t pt = (size_t)cloud * n + (on ? i : end - 1);
-        const T* sp = src + pt * 3;
-        const T p[3] = {sp[0], sp[1], sp[2]};
-        const int jm = ix ? ix[pt] : (on ? i : end - 1);    // ix == NULL: tgt holds one row per source point
-        if (CERT && ps.spos_next && on) ps.spos_next[pt] = jm;
-        const int j = min(max(jm, 0), m - 1);
-        T y[3], nrm[3] = {T(0), T(0), T(0)};
-        if (MODE == MODE_PT2PL && PAIR_ROWS) {
-            // The 24-byte row gather: two lanes share the two rows of their two points -- each loads its half (12 bytes) of both, so a wave
-            // instruction touches 32 rows instead of 64 (the gather is bound by the cache's look-ups per instruction, not by bytes), and the
-            // halves change hands inside the lane pair.
-            const int half = threadIdx.x & 1;
-            const int je = __shfl(j, (int)(threadIdx.x & (WAVE - 1)) & ~1), jo = __shfl(j, (int)(threadIdx.x & (WAVE - 1)) | 1);
-            const T* re = tgt + ((size_t)cloud * m + je) * c + 3 * half;
-            const T* ro = tgt + ((size_t)cloud * m + jo) * c + 3 * half;
-            const T e[3] = {re[0], re[1], re[2]}, o[3] = {ro[0], ro[1], ro[2]};
-            const T pe[3] = {__shfl_xor(e[0], 1), __shfl_xor(e[1], 1), __shfl_xor(e[2], 1)};
-            const T po[3] = {__shfl_xor(o[0], 1), __shfl_xor(o[1], 1), __shfl_xor(o[2], 1)};
-            if (half == 0) { y[0] = e[0]; y[1] = e[1]; y[2] = e[2]; nrm[0] = pe[0]; nrm[1] = pe[1]; nrm[2] = pe[2]; }
-            else           { y[0] = po[0]; y[1] = po[1]; y[2] = po[2]; nrm[0] = o[0]; nrm[1] = o[1]; nrm[2] = o[2]; }
-        } else {
-            const T* yp = tgt + ((size_t)cloud * m + j) * c;
-            y[0] = yp[0]; y[1] = yp[1]; y[2] = yp[2];
-            if (MODE == MODE_PT2PL) { nrm[0] = yp[3]; nrm[1] = yp[4]; nrm[2] = yp[5]; }
-        }
-        if (!on) continue;
+    // one point from its row: the sums, the weight
+    auto point = [&](const T* p, const T* y, const T* nrm, size_t pt, int i) {
         PointState<T> s;
         point_forward<T, MODE>(P, C, r, p, y, nrm, (w_init ? w_init[pt] : T(1)) * live, acc, s);
         // (a frozen cloud: all its weights are zero, and the reference then keeps the previous iteration's -- written here, by 1024 threads per
         //  block instead of the step kernel's one wave per cloud: 97 us of every tolerance-mode iteration at the benchmark shape)
         if (w_out) w_out[(size_t)cloud * w_stride + i] = (w_prev && live == T(0)) ? w_prev[(size_t)cloud * w_stride + i] : s.w;
-    }
-    block_reduce_store<T, NACC, NACC_PAD>(acc, partials + ((size_t)cloud * bpc + blk) * NACC_PAD, red);
-    if (CERT) {             // the statistics of this wave's on-the-spot searches, after everything else
-        // a re-scored candidate set costs about a twelfth of a single-query search (4 gathered rows against a slab): counted as such for the switch
-        int resc = rescored;
+    };
+    if (CERT && cached) {
+        // Every thread sums its rounds in the order 0, 1, 2, 3, like a launch that gathers everything: the sums are bit for bit the same.  All
+        // loads of all rounds go out before the first sum -- unconditionally, so that nothing but arithmetic lies between them (a round past the
+        // block's end re-reads the last point's; branches between the rounds made the compiler wait for each round's loads before issuing the next)
+        constexpr int PRE = DICP_ACC_PRELOAD < ROUNDS ? DICP_ACC_PRELOAD : ROUNDS;      // rounds whose loads are in flight together
 #pragma unroll
-        for (int o = WAVE / 2; o > 0; o >>= 1) resc += __shfl_xor(resc, o);
-        const int eq = singles + resc / 12;
-        if (eq > 0 && (threadIdx.x & (WAVE - 1)) == 0) {
-            if (ps.pairs && rows_scored) atomicAdd(ps.pairs + (blockIdx.x & (DICP_PAIR_SHARDS - 1)), rows_scored);
-            if (ps.ct.count && singles) atomicAdd(ps.ct.count + CERT_SHARDS + (blockIdx.x & (CERT_SHARDS - 1)), singles);
-            if (ps.ct.cloud) atomicAdd(ps.ct.cloud + (size_t)cloud * CERT_CLOUD + 1, eq);
+        for (int t0 = 0; t0 < ROUNDS; t0 += PRE) {
+            T pp[PRE][3], rw[PRE][NB];
+#pragma unroll
+            for (int u = 0; u < PRE; ++u) {
+                const int i = blk * ACC_PTS + (t0 + u) * BLOCK + (int)threadIdx.x;
+                const size_t pt = (size_t)cloud * n + min(i, end - 1);
+                const T* sp = src + pt * 3;
+                pp[u][0] = sp[0]; pp[u][1] = sp[1]; pp[u][2] = sp[2];
+                load_cached_row<T, NB>(ps.nbr + pt * NB, rw[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < PRE; ++u) {
+                const int t = t0 + u;
+                const int i = blk * ACC_PTS + t * BLOCK + (int)threadIdx.x;
+                if (ps.of && lane == 0 && ((live_mask >> t) & 1u))      // the next iteration finds the group's matches where this one did
+                    ps.of[of_k + (size_t)ps.N * ps.nwr + ((i - lane) >> 6)] = gslab[t];      // (`of` has K + 1 rows)
+                if (i < end) {
+                    const T nrm[3] = {MODE == MODE_PT2PL ? rw[u][NB - 3] : T(0), MODE == MODE_PT2PL ? rw[u][NB - 2] : T(0), MODE == MODE_PT2PL ? rw[u][NB - 1] : T(0)};
+                    point(pp[u], rw[u], nrm, (size_t)cloud * n + i, i);
+                }
+            }
+        }
+    } else {
+        for (int base = blk * ACC_PTS; base < end; base += BLOCK) {        // (2 or 4 points in flight per thread measured slower: 78 / 85 vs 72 us)
+            const int i = base + (int)threadIdx.x;
+            const bool on = i < end;
+            const size_t pt = (size_t)cloud * n + (on ? i : end - 1);
+            const T* sp = src + pt * 3;
+            const T p[3] = {sp[0], sp[1], sp[2]};
+            T y[3], nrm[3] = {T(0), T(0), T(0)};
+            const int jm = ix ? ix[pt] : (on ? i : end - 1);    // ix == NULL: tgt holds one row per source point
+            const int j = min(max(jm, 0), m - 1);
+            if (MODE == MODE_PT2PL && PAIR_ROWS) {
+                // The 24-byte row gather: two lanes share the two rows of their two points -- each loads its half (12 bytes) of both, so a wave
+                // instruction touches 32 rows instead of 64 (the gather is bound by the cache's look-ups per instruction, not by bytes), and the
+                // halves change hands inside the lane pair.
+                const int half = threadIdx.x & 1;
+                const int je = __shfl(j, lane & ~1), jo = __shfl(j, lane | 1);
+                const T* re = tgt + ((size_t)cloud * m + je) * c + 3 * half;
+                const T* ro = tgt + ((size_t)cloud * m + jo) * c + 3 * half;
+                const T e[3] = {re[0], re[1], re[2]}, o[3] = {ro[0], ro[1], ro[2]};
+                const T pe[3] = {__shfl_xor(e[0], 1), __shfl_xor(e[1], 1), __shfl_xor(e[2], 1)};
+                const T po[3] = {__shfl_xor(o[0], 1), __shfl_xor(o[1], 1), __shfl_xor(o[2], 1)};
+                if (half == 0) { y[0] = e[0]; y[1] = e[1]; y[2] = e[2]; nrm[0] = pe[0]; nrm[1] = pe[1]; nrm[2] = pe[2]; }
+                else           { y[0] = po[0]; y[1] = po[1]; y[2] = po[2]; nrm[0] = o[0]; nrm[1] = o[1]; nrm[2] = o[2]; }
+            } else {
+                const T* yp = tgt + ((size_t)cloud * m + j) * c;
+                y[0] = yp[0]; y[1] = yp[1]; y[2] = yp[2];
+                if (MODE == MODE_PT2PL) { nrm[0] = yp[3]; nrm[1] = yp[4]; nrm[2] = yp[5]; }
+            }
+            if (CERT && (i - lane) < end) {                 // the group's rows into the cache; its matches lie in this iteration's slab
+                if (on) {
+                    T row[NB];
+                    row[0] = y[0]; row[1] = y[1]; row[2] = y[2];
+                    if (MODE == MODE_PT2PL) { row[3] = nrm[0]; row[4] = nrm[1]; row[5] = nrm[2]; }
+                    store_cached_row<T, NB>(ps.nbr + pt * NB, row);
+                }
+                if (lane == 0) {
+                    const int grp = (i - lane) >> 6;
+                    ps.gdirty[(size_t)cloud * ps.nwr + grp] = 0;
+                    if (ps.of) { ps.of[of_k + grp] = ps.k; ps.of[of_k + (size_t)ps.N * ps.nwr + grp] = ps.k; }
+                }
+            }
+            if (on) point(p, y, nrm, pt, i);
         }
     }
+    block_reduce_store<T, NACC, NACC_PAD>(acc, partials + ((size_t)cloud * bpc + blk) * NACC_PAD, red);
 }
 
 // -------------------------------------------------------------------------- step
@@ -261,6 +273,7 @@ __host__ __device__ inline dicp_step_io make_step_io(const dicp_loop_buffers& B,
     io.n_not_converged = B.counters + k;
     io.rmax = B.rmax; io.dcum = B.dcum; io.dcum_stride = 2 * (B.K + 1);
     io.cert_cloud = B.cert_cloud;
+    io.cert_qu = nullptr; io.cert_units = 0; io.glist_cap = 0; io.glist = nullptr; io.gcount = nullptr;      // (dicp_icp_forward fills them in for a certified iteration)
     io.w_copied = 0;
     return io;
 }
@@ -272,7 +285,8 @@ __device__ __forceinline__ void step_body(const dicp_step_io& io, int cloud, int
     __shared__ double sacc[NACC_PAD], sA[36], sAreg[36], spose[12], sout[24], smisc[16];
     __shared__ T sframe[12];
     __shared__ int scc[7];
-    __shared__ int s_copy;
+    __shared__ int s_copy, s_next_state;
+    __shared__ T s_dnext[2];
     if (tid < WAVE) {   // reduce the per-block partials: lane = (part, slot); fixed summation order -> bit-reproducible
         const int slot_i = tid & 31, part = tid >> 5;
         const T* pp = (const T*)io.partials + (size_t)cloud * io.nblk * NACC_PAD + slot_i;
@@ -335,9 +349,11 @@ __device__ __forceinline__ void step_body(const dicp_step_io& io, int cloud, int
             T* dc = (T*)io.dcum + (size_t)cloud * io.dcum_stride + 2 * io.iter;
             const T nxt = (T)((double)(T)smisc[9] + (sqrt(dC) * rad + sqrt(mv)) * 1.0001);
             dc[2] = nxt + m_abs(nxt) * (T)(4.0 * ulp);                    // (rounded up)
+            s_dnext[0] = dc[2];
             const double cn = io.frame ? sqrt(smisc[6] * smisc[6] + smisc[7] * smisc[7] + smisc[8] * smisc[8]) : 0.0;      // (the search frame adds t, |t| = |centre|, to r)
             const double pnm = sqrt(p0[0] * p0[0] + p0[1] * p0[1] + p0[2] * p0[2]);
             dc[3] = (T)(8.0 * ulp * (pnm + rad + sqrt(rn2) + cn + 1.0) * 1.0001);
+            s_dnext[1] = dc[3];
         }
         if (io.pose_search_out) {                                         // what the next search reads: [Q C | Q r + t] (the cloud's search frame)
             T* ps = (T*)io.pose_search_out + (size_t)cloud * 12;
@@ -370,6 +386,7 @@ __device__ __forceinline__ void step_body(const dicp_step_io& io, int cloud, int
         }
         ((T*)io.alive_out)[cloud] = alive_next;
         s_copy = (io.w_cur && io.w_prev && sacc[ACC_SUMW] == 0.0 && !(io.w_copied && alive_in == T(0))) ? 1 : 0;   // ICP.py:224-226
+        s_next_state = io.cert_cloud ? scc[2] : 0;
         if (io.cert_cloud) {
             // Match certificates must never cost more than searching everything.  What this iteration searched again for this cloud --
             // whole units (a certifying search of a unit costs ~1.3 plain ones) and single queries (one wave per query: ~0.12 of a unit's
@@ -399,12 +416,35 @@ __device__ __forceinline__ void step_body(const dicp_step_io& io, int cloud, int
                 else if (state == -1) { const int d = c_back > 0 ? min(2 * c_back, 16) : 2; cc[4] = d; next = d; }
                 else next = -1;
                 cc[2] = next;
+                s_next_state = next;
                 if (costly || state > 0) cc[7] += 1;            // iterations of this call in which the cloud's certificates did not pay (the host's call-to-call hint reads it)
                 cc[0] = 0; cc[1] = 0; cc[3] = 0; cc[6] = 0;
             }
         }
     }
     __syncthreads();
+    if (io.cert_qu && io.glist && tid < WAVE) {
+        // the next iteration's guard launch: which of this cloud's units it has to look at (knn_sweep_guard_kernel decides again, from the same
+        // numbers: the list only has to hold every unit it would not leave at once)
+        const T spent = cert_spent<T>(s_dnext);
+        const int st = s_next_state;
+        const bool certs_on = st <= 0 && st != CERT_RECERTIFY;
+        const T* qu = (const T*)io.cert_qu + (size_t)cloud * io.cert_units;
+        int32_t* list = io.glist + (size_t)(cloud & 7) * io.glist_cap;
+        for (int u0 = 0; u0 < io.cert_units; u0 += WAVE) {
+            const int u = u0 + tid;
+            bool work = false;
+            if (u < io.cert_units) { const T v = qu[u]; work = !(certs_on && v >= T(0) && v > spent); }
+            const unsigned long long mk = __ballot(work);
+            if (mk) {                                               // (wave-uniform)
+                int base = 0;
+                if (tid == 0) base = atomicAdd(io.gcount + (cloud & 7), __popcll(mk));
+                base = __shfl(base, 0);
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+                if (work && base + rank < io.glist_cap) list[base + rank] = cloud * io.cert_units + u;
+            }
+        }
+    }
     if (io.areg && tid < 36) io.areg[(size_t)cloud * 36 + tid] = sAreg[tid];
     if (s_copy) {
         T* wc = (T*)io.w_cur + (size_t)cloud * io.w_stride;

@@ -105,6 +105,16 @@ __host__ __device__ inline int window_slots(int WT, int n, int m_pad) {
     return (int)(s < BLOCK ? BLOCK : (s > 4 * BLOCK ? 4 * BLOCK : s));        // <= SPB of the kernel
 }
 
+// Where the matches of one iteration are found: a plain (N,n) array (of == NULL: base itself), or the history kept by reference
+// (dicp_loop_buffers.spos_of): the matches of queries [64g, 64g+64) of cloud b at iteration k lie in the slab of iteration of[(k N + b) nwr + g].
+struct MatchHist { const int32_t* base; const int32_t* of; int k, N, n, nwr; };
+__device__ __forceinline__ int match_at(const MatchHist& h, int cloud, int q) {
+    if (!h.of) return h.base[(size_t)cloud * h.n + q];
+    const int s = h.of[((size_t)h.k * h.N + cloud) * h.nwr + (q >> 6)];
+    return h.base[((size_t)s * h.N + cloud) * h.n + q];
+}
+__host__ __device__ inline MatchHist plain_matches(const int32_t* spos, int N, int n) { return MatchHist{spos, nullptr, 0, N, n, (n + WAVE - 1) / WAVE}; }
+
 // first sorted row of block blk's window: centred on the reference neighbour of the block's middle slot
 // (robust against outliers at the ends), a multiple of 16 rows
 __device__ __forceinline__ int window_origin(const int32_t* __restrict__ sp_ref_c, const int32_t* __restrict__ qo_c,
@@ -119,7 +129,7 @@ __device__ __forceinline__ int window_origin(const int32_t* __restrict__ sp_ref_
 // gs / gb = THIS cloud's cotangents of the normal equations, part_out = this block's row of the pose partial sums.
 template <typename T, int MODE, int WT, bool overwrite>
 __device__ __forceinline__ void window_body(const WeightParams& P, const T* __restrict__ src_s, const T* __restrict__ tgt_s, int c,
-                                            const int32_t* __restrict__ spos, const int32_t* __restrict__ spos_ref,
+                                            const MatchHist spos, const int32_t* __restrict__ spos_ref,
                                             const int32_t* __restrict__ qorder,
                                             const T* __restrict__ pose, const T* __restrict__ w_s, const T* __restrict__ alive,
                                             const T* gs, const T* gb, int n, int m_pad, int spb, int bpc,
@@ -135,7 +145,6 @@ __device__ __forceinline__ void window_body(const WeightParams& P, const T* __re
     const int tid = threadIdx.x;
     const int nc = rows_of(src_rows, cloud, n);             // ragged batches: slots past the cloud's own carry weight 0: no work, zero gradient
     const int s0 = blk * spb, s1 = min(nc, s0 + spb), s1_all = min(n, s0 + spb);
-    const int32_t* __restrict__ sp_c = spos + (size_t)cloud * n;
     const int32_t* __restrict__ qo_c = qorder ? qorder + (size_t)cloud * n : nullptr;  // slot -> query (spos is indexed by query)
     constexpr int U = 4;                                    // slots per thread, all in flight: spb <= U * BLOCK = SPB
     // the two dependent index chains (slot -> query -> match, and the same for the window origin) start first and
@@ -152,7 +161,7 @@ __device__ __forceinline__ void window_body(const WeightParams& P, const T* __re
     const int lo = window_origin(spos_ref + (size_t)cloud * n, qo_c, blk, spb, nc, m_pad, WT);
     const int hi = min(lo + WT, m_pad);
 #pragma unroll
-    for (int u = 0; u < U; ++u) pos[u] = on[u] ? min(max(sp_c[pos[u]], 0), m_pad - 1) : 0;     // -1 (no neighbour: non-finite input) -> row 0
+    for (int u = 0; u < U; ++u) pos[u] = on[u] ? min(max(match_at(spos, cloud, pos[u]), 0), m_pad - 1) : 0;     // -1 (no neighbour: non-finite input) -> row 0
     if (slab)
         for (int k = tid; k < hi - lo; k += BLOCK) head[k] = -1;
     T C[9], r[3], Gs[36], Gb[6];
@@ -245,7 +254,7 @@ __device__ __forceinline__ void window_body(const WeightParams& P, const T* __re
 
 template <typename T, int MODE, int WT, bool overwrite>
 __global__ __launch_bounds__(BLOCK) void accumulate_bwd_window_kernel(WeightParams P, const T* __restrict__ src_s, const T* __restrict__ tgt_s, int c,
-                                                                      const int32_t* __restrict__ spos, const int32_t* __restrict__ spos_ref,
+                                                                      const MatchHist spos, const int32_t* __restrict__ spos_ref,
                                                                       const int32_t* __restrict__ qorder,
                                                                       const T* __restrict__ pose, const T* __restrict__ w_s, const T* __restrict__ alive,
                                                                       const T* __restrict__ gs, const T* __restrict__ gb,
@@ -364,6 +373,16 @@ __global__ __launch_bounds__(BLOCK) void permute_add_rows_kernel(const T* __rest
         for (int u = 0; u < ROWS_U; ++u)
             if (ok[u]) out[((size_t)b * out_rows + j[u]) * c_out + k[u]] = o[u] + v[u];
     }
+}
+
+// out[b][q] = the match of query q of cloud b at the iteration h stands for: a plain (N,n) array out of the history kept by reference (the window
+// origins of the backward pass and dicp_window_reduce read the reference iteration's matches at a few places per block)
+__global__ __launch_bounds__(BLOCK) void resolve_matches_kernel(const MatchHist h, int bpc, const int32_t* __restrict__ src_rows, int32_t* __restrict__ out) {
+    int cloud, blk;
+    if (!decode_block(bpc, h.N, cloud, blk)) return;
+    const int q = blk * BLOCK + threadIdx.x;
+    // (ragged batches: the rows past a cloud's own have no match, and the groups past them no word in `of`)
+    if (q < h.n) out[(size_t)cloud * h.n + q] = q < rows_of(src_rows, cloud, h.n) ? match_at(h, cloud, q) : -1;
 }
 
 // ---------------------------------------------------------------------- step bwd
@@ -892,7 +911,8 @@ __global__ __launch_bounds__(BLOCK) void bwd_tail_kernel(WeightParams P, dicp_lo
         // ---- this block's share of accumulate_bwd of iteration k
         ++gen;
         T* out = (gen & 1) ? part1 : part0;
-        window_body<T, MODE, WT, false>(P, (const T*)B.src, (const T*)B.tgt, B.c, B.spos + (size_t)k * N * n, B.spos_ref, B.qorder, pose_k, (const T*)B.w_init, alive_k,
+        const MatchHist mh = (B.spos_of && k >= B.spos_of_from) ? MatchHist{B.spos, B.spos_of, k, N, n, (n + WAVE - 1) / WAVE} : plain_matches(B.spos + (size_t)k * N * n, N, n);
+        window_body<T, MODE, WT, false>(P, (const T*)B.src, (const T*)B.tgt, B.c, mh, B.spos_ref, B.qorder, pose_k, (const T*)B.w_init, alive_k,
                                         sGsT, sGbT, n, B.m_pad, spb, bpc, gsrc_s, slab, (T*)B.gts_far, gw_s, spub, B.src_rows, cloud, blk);
         // ---- publish the pose sums; wait until all of the cloud's blocks have published theirs.  The hand-off is a handful of words: they are
         // written and read as agent-scope atomics (coherent where they live; a release / acquire FENCE at agent scope writes back and

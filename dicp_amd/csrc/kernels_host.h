@@ -17,11 +17,9 @@ inline WeightParams to_params(const dicp_weight_params* p) {
 inline unsigned blocks_for(size_t total) { return (unsigned)((total + BLOCK - 1) / BLOCK); }
 
 
-struct CertAcc {              // what the accumulate of a certified iteration needs for its on-the-spot searches (PointSearch, untyped)
-    const void* pose_search; const void* tgs4; const int32_t* tperm; const int32_t* bucket; const void* brange; int nbkt;
-    const int32_t* tgt_rows; int m_full, m_pad; unsigned long long* pairs;
-    void* q; void* qu; const void* dcum; int dstride, k; int32_t* count;
-    int32_t* spos; int32_t* spos_next; int32_t* cloud; void* set;
+struct CertAcc {              // what the accumulate of a certified iteration needs (AccCert, untyped)
+    int32_t* spos; const int32_t* hist; const int32_t* hist_prev; int32_t* of; int k_floor, k;
+    void* nbr; int32_t* gdirty; int32_t* pend; int32_t* cloud; int fresh, units, sets;
 };
 
 template <typename T, int Q, int CH, int MINW = 1>

@@ -120,16 +120,23 @@ constexpr int SWEEP_MINW_Q2C8 = 5;
 // few spent ones on the spot (search_point).  Measured on the benchmark clouds: from the second certified iteration on, 0.18 % of
 // the queries are searched again per iteration (near-ties inside the rounding bound, far from the cloud's centre).
 template <typename T> struct SweepCert {
-    T* q;                           // (N,n) budgets by QUERY (like spos)
-    T* qu;                          // (N,units): per unit of the sweep, a lower bound of its certified queries' budgets (a filter, never a proof)
+    T* q;                           // (N,n) budgets by SLOT (position in the query order of the certified iterations): only the searches read them
+    T* qu;                          // (N,units): per unit of the sweep, the smallest budget if every query of the unit has one that stood when it was last
+                                    // looked at, else 0 ("look at this unit": a query searched one by one, a candidate set to re-score) -- a filter, never a proof
     const T* dcum; int dstride;     // (N,dstride): (M_k, e_k) pairs per iteration
     int k;                          // this iteration
     int32_t* count;                 // (128) or NULL: [0,64) units searched again, [64,128) single queries, sharded by block
-    void* set;                      // optional candidate sets (see search_point): (N,n) T set budgets by query, then (N,n,4) int32 sorted positions
+    void* set;                      // optional candidate sets (see search_point): (N,n) T set budgets by slot, then (N,n,4) int32 sorted positions
     int32_t* cloud;                 // (N,CERT_CLOUD) or NULL, per cloud: [0] units / [1] single queries searched again in this iteration; [2] the
                                     // state the step kernel keeps: 0 on, -1 on with one strike, k > 0 off for k more iterations (CERT_OFF_FOR_GOOD:
                                     // for the rest of the call), CERT_RECERTIFY: this iteration's guard searches every unit with certifying
                                     // sweeps; [3] its units (written by the searches: "a certified iteration ran"); [4] the last back-off length
+    int32_t* cm;                    // (N,n) by slot: the query's current match (sorted position, -1 none), kept by the searches: a search that finds the
+                                    // same match again changes nothing anywhere else
+    int32_t* pend;                  // (N,n) zeros, by QUERY: a match that a guard launch CHANGED is left here (match + 2) for the accumulate of the same
+                                    // iteration, which owns the history's slabs and the cached rows (accumulate_kernel) ...
+    int32_t* gdirty;                // (N,nwr) by group of 64 queries: ... and is told so here (1: some pend of the group is set)
+    int nwr;
 };
 constexpr int CERT_CANDS = 4;       // rows of a candidate set
 template <typename T> __device__ __forceinline__ T* set_budgets(void* set) { return (T*)set; }
@@ -202,7 +209,7 @@ __device__ __forceinline__ void sweep_unit(const T* __restrict__ src, const T* _
                                            unsigned long long* __restrict__ pairs,
                                            int n_full, int m_full, int m_pad,
                                            const int32_t* __restrict__ src_rows, const int32_t* __restrict__ tgt_rows, const SweepCert<T>& ct,
-                                           const int cloud, const int unit, typename V4<T>::type* __restrict__ ring) {
+                                           const int cloud, const int unit, typename V4<T>::type* __restrict__ ring, const bool to_pend = false) {
     using T4 = typename V4<T>::type;
     constexpr int NT = SweepRing<T>::NT;
     const int lane = threadIdx.x & (WAVE - 1);
@@ -387,8 +394,17 @@ __device__ __forceinline__ void sweep_unit(const T* __restrict__ src, const T* _
                                                                                 // original index is only looked up on exact ties)
         mi[q] = (bo == 0x7fffffff) ? 0 : min(max(bo, 0), m - 1);
         if (idx) idx[(size_t)cloud * n_full + qi[q]] = mi[q];
-        // sorted position of the winner (indexed like idx, by the query): what the windowed backward consumes
-        if (spos) spos[(size_t)cloud * n_full + qi[q]] = (bo == 0x7fffffff || bo >= m) ? -1 : bs;
+        // sorted position of the winner (indexed like idx, by the query): what the windowed backward consumes.  Inside a certified iteration
+        // (to_pend) a match that CHANGED is left for the accumulate that follows, which owns the history's slabs and the cached rows
+        const int val = (bo == 0x7fffffff || bo >= m) ? -1 : bs;
+        const size_t at = (size_t)cloud * n_full + unit * (WAVE * Q) + q * WAVE + lane;       // the query's slot: the certificates' own arrays go by it
+        if (to_pend) {
+            if (ct.cm[at] != val) {
+                ct.pend[(size_t)cloud * n_full + qi[q]] = val + 2;
+                ct.gdirty[(size_t)cloud * ct.nwr + (qi[q] >> 6)] = 1;
+            }
+        } else if (spos) spos[(size_t)cloud * n_full + qi[q]] = val;
+        if (ct.cm) ct.cm[at] = val;
         if (CERT) {
             T bq = T(-1);
             if (bo != 0x7fffffff && ob[q] != best[q]) {     // (three or more tied chunks: no certificate)
@@ -400,23 +416,23 @@ __device__ __forceinline__ void sweep_unit(const T* __restrict__ src, const T* _
                 T H1c;
                 bq = cert_from_scores(bv, s2, hx[q], hu, ct.dcum + (size_t)cloud * ct.dstride + 2 * ct.k, H1c);
             }
-            // no certificate: -(k + 2) says "searched at iteration k" -- spent for every later iteration, not searched twice in this one
-            ct.q[(size_t)cloud * n_full + qi[q]] = bq > T(0) ? bq : cert_mark<T>(ct.k);
-            if (ct.set) set_budgets<T>(ct.set)[(size_t)cloud * n_full + qi[q]] = T(-1);      // (a new match: whatever candidate set the query had is void)
+            // no certificate: -(k + 2) says "searched at iteration k" -- spent for every later iteration
+            ct.q[at] = bq > T(0) ? bq : cert_mark<T>(ct.k);
+            if (ct.set) set_budgets<T>(ct.set)[at] = T(-1);      // (a new search: whatever candidate set the query had is void)
             if (bq > T(0)) qmin = min_t(qmin, bq); else ++nunc;
         } else if (ct.q) {
-            ct.q[(size_t)cloud * n_full + qi[q]] = cert_mark<T>(ct.k);                      // plain search of a unit inside a certified loop
-            if (ct.set) set_budgets<T>(ct.set)[(size_t)cloud * n_full + qi[q]] = T(-1);
+            ct.q[at] = cert_mark<T>(ct.k);                      // plain search of a unit inside a certified loop
+            if (ct.set) set_budgets<T>(ct.set)[at] = T(-1);
         }
     }
     if (CERT) {
-        // the unit's filter value: its smallest budget -- or 0 ("look at me every iteration") when more queries than the accumulate
-        // should search one by one have no certificate at all
+        // the unit's filter value: its smallest budget -- or 0 ("look at me every iteration") when a query has no certificate at all: the
+        // guard launch of the next iteration then searches it on its own (and tries a candidate set for it)
         qmin = wave_min(qmin);
         int tot = 0;
 #pragma unroll
         for (int q = 0; q < Q; ++q) tot += __popcll(__ballot(nunc > q));
-        if (lane == 0) ct.qu[(size_t)cloud * ((n_full + WAVE * Q - 1) / (WAVE * Q)) + unit] = tot > CERT_SLOT_MAX ? T(0) : qmin;
+        if (lane == 0) ct.qu[(size_t)cloud * ((n_full + WAVE * Q - 1) / (WAVE * Q)) + unit] = tot > 0 ? T(0) : qmin;
         // per cloud, for the step kernel's "are certificates worth it here?": queries that got no certificate will be searched one by one in
         // every later iteration (near-ties inside the rounding bound of a score: dense surfaces far from the centre, duplicated targets)
         if (ct.cloud && lane == 0) {
@@ -447,15 +463,28 @@ __global__ __launch_bounds__(BLOCK, DICP_SWEEP_MINW) void knn_sweep_kernel(DICP_
                                cloud, blk * (BLOCK / WAVE) + wave, tiles[wave]);
 }
 
-// What the on-the-spot search of one query needs besides the query (certifying loop only).
-template <typename T> struct PointSearch {
-    const T* pose;                                  // (N,12) search pose of this iteration
+// What the search of one query needs besides the query (guard launches of the certified loop).
+template <typename T> struct SearchCtx {
     const typename V4<T>::type* tgs4; const int32_t* tperm; const int32_t* bucket; const T* brange; int nbkt;
     const int32_t* tgt_rows; int m_full, m_pad;
-    unsigned long long* pairs;
-    SweepCert<T> ct;                                // ct.dcum == NULL: no budget is checked (the iteration's search has just written them)
-    int32_t* spos;                                  // (N,n) this iteration's matches: read, and rewritten where a query is searched
-    int32_t* spos_next;                             // optional (N,n): the next iteration's, started as a copy of this one's
+    SweepCert<T> ct;
+};
+
+// What the accumulate of a certified iteration needs (accumulate_kernel CERT: the row cache and the match history kept by reference).
+template <typename T> struct AccCert {
+    int32_t* spos;                                  // (N,n) this iteration's slab of the match history (or the one reused buffer)
+    // The match history is kept BY REFERENCE: of[(k N + cloud) nwr + g] = the iteration whose slab holds the matches of queries [64 g, 64 g + 64) at
+    // iteration k.  A certified iteration that changes no match of such a group writes nothing but that word; one that does copies the group into its own
+    // slab first.  hist = the virtual base of the slabs of this history chunk (iteration s at hist + s N n), hist_prev that of the chunk before it
+    // (references never reach further back: the first iteration of a chunk copies every group), k_floor the chunk's first iteration.
+    const int32_t* hist; const int32_t* hist_prev; int32_t* of; int k_floor, N, nwr, k;
+    T* nbr;                                         // (N,n,NB) row cache: the matched target row of every query (NB = 6 pt2pl / 3 pt2pt elements), rewritten with the match
+    int32_t* gdirty;                                // (N,nwr): 1 = the guard launch of this iteration changed a match of the group (SweepCert::pend)
+    int32_t* pend;                                  // (N,n): those matches (match + 2; 0: none)
+    int32_t* cloud;                                 // optional (N,CERT_CLOUD): the per-cloud switch's state in [2] (SweepCert::cloud); [3] / [5] are written here ("a certified
+                                                    // iteration ran": the cloud's units, whether candidate sets are kept) -- the guard launch has no block per cloud
+    int fresh;                                      // the search of this iteration has just written EVERY match into `spos` (the certifying search): everything is gathered and cached
+    int units, sets;
 };
 
 // The search of ONE query by one wave (all lanes carry the same arguments): the query's previous match, scored under the current
@@ -464,7 +493,7 @@ template <typename T> struct PointSearch {
 // the score() every search form uses; equal scores resolve to the lowest ORIGINAL index: index for index the match of a full
 // search.  Returns the match's sorted position (-1: none) and leaves the query's new budget in `budget`.
 template <typename T>
-__device__ __forceinline__ int search_point(const PointSearch<T>& ps, const int cloud, const T* nx, const int prev, T& budget, unsigned long long& rows_scored,
+__device__ __forceinline__ int search_point(const SearchCtx<T>& ps, const int cloud, const T* nx, const int prev, T& budget, unsigned long long& rows_scored,
                                             T& set_budget, int* cset /* [CERT_CANDS], wave-uniform */) {
     using T4 = typename V4<T>::type;
     const int lane = threadIdx.x & (WAVE - 1);
@@ -574,74 +603,224 @@ __device__ __forceinline__ int search_point(const PointSearch<T>& ps, const int 
     return bs;          // (sorted slots [0,m) hold the cloud's own rows: a row found is a real one)
 }
 
-// Guard of a certified iteration: one wave per unit of the sweep, as in knn_sweep_kernel.  A unit none of whose certified queries can
-// have spent its budget leaves at once; of the others, the ones with more than CERT_SLOT_MAX spent budgets are searched again as a
-// unit (cheaper per query than one by one, and what keeps a batch that suddenly moves far from falling back on single searches);
-// the rest is left to the accumulate that follows, which searches spent queries on the spot.
+// Guard of a certified iteration: one wave per unit of the sweep, as in knn_sweep_kernel.  It owns the certificates: a unit whose filter value
+// stands (every query has a budget, and the smallest of them is not spent) leaves after one load.  Of the others, a unit with more than
+// CERT_SLOT_MAX spent budgets is searched again as a unit (cheaper per query than one by one, and what keeps a batch that suddenly moves far
+// from falling back on single searches).  The rest is dealt with here, query by query (until round 5 inside the accumulate that follows, whose
+// registers -- and with them the occupancy of every launch that had nothing to search -- that code decided): a standing candidate set is
+// re-scored by the query's own lane (four gathered rows), a query without budget or set is searched by the whole wave (search_point).  Whatever
+// match CHANGES is left in pend for the accumulate, its group of 64 queries marked in gdirty; the certificates' own state (budgets, sets,
+// current matches) goes by slot, so a unit's share of it is one coalesced piece.
 template <typename T, int Q, int CH>
-__global__ __launch_bounds__(BLOCK, DICP_SWEEP_MINW) void knn_sweep_guard_kernel(DICP_SWEEP_PARAMS) {
-    __shared__ typename V4<T>::type tiles[BLOCK / WAVE][SweepRing<T>::NT * WAVE];
-    int cloud, blk;
-    if (!decode_block(bpc, N, cloud, blk)) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1);
-    const int unit = blk * (BLOCK / WAVE) + wave, units = (n_full + WAVE * Q - 1) / (WAVE * Q);
+__device__ __forceinline__ void guard_unit(DICP_SWEEP_PARAMS, const int cloud, const int unit, typename V4<T>::type* __restrict__ ring) {
+    using T4 = typename V4<T>::type;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int units = (n_full + WAVE * Q - 1) / (WAVE * Q);
     const int n = rows_of(src_rows, cloud, n_full);
-    if (unit * (WAVE * Q) >= n) return;
+    if (unit * (WAVE * Q) >= n) return;                        // (a unit past the cloud's own rows)
     const T* dk = ct.dcum + (size_t)cloud * ct.dstride + 2 * ct.k;
     const T spent = cert_spent(dk);
     const T step = ct.k > 0 ? dk[0] - dk[-2] : inf_v<T>();     // how far the cloud's queries can have moved in the last step
     T* qu = ct.qu + (size_t)cloud * units + unit;
     const T v = *qu;
-    if (ct.cloud && unit == 0 && lane == 0) { ct.cloud[(size_t)cloud * CERT_CLOUD + 3] = units; ct.cloud[(size_t)cloud * CERT_CLOUD + 5] = ct.set ? 1 : 0; }
-    bool plain;
+    bool plain = false, research = true;
     const int cstate = ct.cloud ? ct.cloud[(size_t)cloud * CERT_CLOUD + 2] : 0;
+    // what the unit's queries need: 0 nothing (the budget stands) / 1 the candidate set re-scored / 2 a search of their own
+    int need[Q], cmv[Q], qiv[Q], cjv[Q][CERT_CANDS];
+    T bud[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        need[q] = 0; bud[q] = inf_v<T>(); cmv[q] = -1; qiv[q] = 0;
+#pragma unroll
+        for (int c = 0; c < CERT_CANDS; ++c) cjv[q][c] = -1;
+    }
+    T* __restrict__ qs = ct.set ? set_budgets<T>(ct.set) : nullptr;
+    int32_t* __restrict__ cands = ct.set ? set_cands<T>(ct.set, N, n_full) : nullptr;
     if (cstate > 0) plain = true;                               // this cloud's certificates are off (step kernel): every unit, plainly
     else if (cstate == CERT_RECERTIFY) plain = false;           // ... and this is the iteration that tries them again: every unit, certifying
     else if (v < T(0)) plain = step > -v;                       // plain mode (below): certify again once the steps are at most -v
     else {
         if (v > spent) return;
         int bad = 0, live = 0;
-        T qmin = inf_v<T>();
+        // every piece of the unit's state goes by slot: all of it at once, whatever the budgets turn out to say (a unit that is looked at mostly has
+        // a candidate set to re-score: budget -> set budget -> candidates -> rows was a chain of dependent loads, the launch's whole time near the pose)
+        T bq[Q], sq[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int pos = unit * (WAVE * Q) + q * WAVE + lane;
+            const size_t at = (size_t)cloud * n_full + min(pos, n - 1);
+            bq[q] = ct.q[at];
+            sq[q] = qs ? qs[at] : T(-2);
+            cmv[q] = ct.cm[at];
+            qiv[q] = qorder ? qorder[at] : min(pos, n - 1);
+#pragma unroll
+            for (int c = 0; c < CERT_CANDS; ++c) cjv[q][c] = cands ? cands[at * CERT_CANDS + c] : -1;
+        }
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             const int pos = unit * (WAVE * Q) + q * WAVE + lane;
             if (pos < n) {
-                const size_t at = (size_t)cloud * n_full + qorder[(size_t)cloud * n_full + pos];
-                const T b = ct.q[at];
+                const T b = bq[q];
+                bud[q] = b;
                 ++live;
-                if (b > spent) qmin = min_t(qmin, b);
-                else {                                          // no certificate of its own: a candidate set that still stands is as good (the accumulate re-scores it)
+                if (!(b > spent)) {                             // no certificate of its own: a candidate set that still stands is as good (re-scored below)
                     // A budget that the poses' motion has spent counts against the unit, as ever.  A query that never had a certificate of its own
-                    // (b < 0: a mark) may have a candidate set: one that stands is as good as a budget; none tried yet (-1): the accumulate's
-                    // search of this query will try; "no set either" (-2) or a spent set count against the unit.
-                    const T sb = (ct.set && b < T(0)) ? set_budgets<T>(ct.set)[at] : T(-2);
-                    if (sb > spent) qmin = min_t(qmin, sb); else if (sb != T(-1)) ++bad;
+                    // (b < 0: a mark) may have a candidate set: one that stands is as good as a budget; none tried yet (-1): its search below
+                    // will try; "no set either" (-2) or a spent set count against the unit.
+                    const T sb = (qs && b < T(0)) ? sq[q] : T(-2);
+                    if (sb > spent) need[q] = 1;
+                    else { need[q] = 2; if (sb != T(-1)) ++bad; }
                 }
             }
         }
         int nbad = 0, nlive = 0;
 #pragma unroll
         for (int q = 0; q < Q; ++q) { nbad += __popcll(__ballot(bad > q)); nlive += __popcll(__ballot(live > q)); }
-        if (nbad <= CERT_SLOT_MAX) {                            // the few spent ones are left to the accumulate
-            qmin = wave_min(qmin);
-            if (lane == 0) *qu = qmin;
-            return;
+        research = nbad > CERT_SLOT_MAX;
+        if (research) {
+            // three quarters of the last search's budgets did not survive one step, and the steps are not shrinking fast (less than halved
+            // since the one before): certifying this unit is wasted work while the cloud moves like this.  It is searched plainly (cheaper,
+            // no budgets) until the steps have halved.
+            const T step_before = ct.k > 1 ? dk[-2] - dk[-4] : inf_v<T>();
+            plain = 4 * nbad >= 3 * nlive && step > T(0) && step < inf_v<T>() && T(2) * step > step_before;
+            if (plain && lane == 0) *qu = -T(0.5) * step;
         }
-        // three quarters of the last search's budgets did not survive one step, and the steps are not shrinking fast (less than halved
-        // since the one before): certifying this unit is wasted work while the cloud moves like this.  It is searched plainly (cheaper,
-        // no budgets) until the steps have halved.
-        const T step_before = ct.k > 1 ? dk[-2] - dk[-4] : inf_v<T>();
-        plain = 4 * nbad >= 3 * nlive && step > T(0) && step < inf_v<T>() && T(2) * step > step_before;
-        if (plain && lane == 0) *qu = -T(0.5) * step;
     }
-    if (plain) sweep_unit<T, Q, CH, false>(src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, idx, spos, pairs, n_full, m_full, m_pad, src_rows, tgt_rows, ct,
-                                           cloud, unit, tiles[wave]);
-    else       sweep_unit<T, Q, CH, true>(src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, idx, spos, pairs, n_full, m_full, m_pad, src_rows, tgt_rows, ct,
-                                          cloud, unit, tiles[wave]);
-    // the counters LAST: vector memory operations return in order, so a unit that counted itself first waited for its add -- one of up to
-    // 128 to the same word when a whole cloud is searched again -- before its first load came back (a cloud with its certificates off:
-    // 53 us per launch instead of the plain kernel's 31)
-    if (lane == 0 && ct.count) atomicAdd(ct.count + (blockIdx.x & (CERT_SHARDS - 1)), 1);
-    if (lane == 0 && ct.cloud) atomicAdd(ct.cloud + (size_t)cloud * CERT_CLOUD, 1);
+    if (research) {
+        // a unit searched again leaves the matches it CHANGED for the accumulate (pend) -- unless the whole cloud is searched (certificates off, or
+        // tried again): that accumulate then reads the iteration's own slab for the cloud, as after the certifying search
+        const bool to_pend = ct.pend && !(cstate > 0 || cstate == CERT_RECERTIFY);
+        if (plain) sweep_unit<T, Q, CH, false>(src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, idx, spos, pairs, n_full, m_full, m_pad, src_rows, tgt_rows, ct,
+                                               cloud, unit, ring, to_pend);
+        else       sweep_unit<T, Q, CH, true>(src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, idx, spos, pairs, n_full, m_full, m_pad, src_rows, tgt_rows, ct,
+                                              cloud, unit, ring, to_pend);
+        // the counters LAST: vector memory operations return in order, so a unit that counted itself first waited for its add -- one of up to
+        // 128 to the same word when a whole cloud is searched again -- before its first load came back (a cloud with its certificates off:
+        // 53 us per launch instead of the plain kernel's 31)
+        if (lane == 0 && ct.count) atomicAdd(ct.count + (blockIdx.x & (CERT_SHARDS - 1)), 1);
+        if (lane == 0 && ct.cloud) atomicAdd(ct.cloud + (size_t)cloud * CERT_CLOUD, 1);
+        return;
+    }
+    // ---- the unit's open queries, one by one
+    const SearchCtx<T> sc{tgs4, tperm, bucket, brange, nbkt, tgt_rows, m_full, m_pad, ct};
+    const T4* __restrict__ tg = tgs4 + (size_t)cloud * m_pad;
+    const int32_t* __restrict__ pm = tperm + (size_t)cloud * m_pad;
+    T C[9], r[3];
+    load_pose(pose, cloud, C, r);
+    unsigned long long rows_scored = 0;
+    int singles = 0, rescored = 0;
+    T qmin = inf_v<T>();
+    bool open = false;                                          // this lane keeps a query that must be looked at again in the next iteration
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int pos = unit * (WAVE * Q) + q * WAVE + lane;
+        const size_t at = (size_t)cloud * n_full + min(pos, n - 1);
+        const int qi = qiv[q], cur = cmv[q];
+        T nx[3] = {T(0), T(0), T(0)};
+        int cj[CERT_CANDS];
+        T4 row[CERT_CANDS];
+#pragma unroll
+        for (int c = 0; c < CERT_CANDS; ++c) { cj[c] = cjv[q][c]; row[c] = T4{}; }
+        if (need[q]) {                                          // (the query and, for a set, its four rows: the second and last round of loads)
+            const T* sp = src + ((size_t)cloud * n_full + qi) * 3;
+            const T p[3] = {sp[0], sp[1], sp[2]};
+            if (need[q] == 1) {
+#pragma unroll
+                for (int c = 0; c < CERT_CANDS; ++c) row[c] = tg[max(cj[c], 0)];
+            }
+            query_point(C, r, p, nx);
+        }
+        int found = cur;
+        if (need[q] == 1) {
+            // the new match is the set's best row (same score(), equal scores -> lowest original index; the set's first row is the old match: never empty)
+            T best = inf_v<T>();
+            int bj = max(cj[0], 0);
+#pragma unroll
+            for (int c = 0; c < CERT_CANDS; ++c) {
+                const T scv = cj[c] >= 0 ? score<T, T4>(nx, row[c]) : inf_v<T>();
+                if (scv < best) { best = scv; bj = cj[c]; }
+                else if (scv == best && scv < inf_v<T>() && pm[cj[c]] < pm[bj]) bj = cj[c];
+            }
+            found = bj;
+            ++rescored;
+            open = true;                                        // (a set is re-scored in every iteration)
+        }
+        // spent, never certifiable, NaN: searched by the whole wave, one query at a time
+        unsigned long long todo = __ballot(need[q] == 2);
+        T nb = T(-1), ns = T(-2);
+        int nc[CERT_CANDS];
+#pragma unroll
+        for (int c = 0; c < CERT_CANDS; ++c) nc[c] = -1;
+        while (todo) {                                          // (wave-uniform)
+            const int L = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const T nq[3] = {__shfl(nx[0], L), __shfl(nx[1], L), __shfl(nx[2], L)};
+            T got, gs;
+            int gc[CERT_CANDS];
+            const int fnd = search_point<T>(sc, cloud, nq, __shfl(cur, L), got, rows_scored, gs, gc);
+            ++singles;
+            if (lane == L) {
+                found = fnd; nb = got; ns = gs > T(0) ? gs : T(-2);       // (-2: searched, no set either)
+#pragma unroll
+                for (int c = 0; c < CERT_CANDS; ++c) nc[c] = gc[c];
+            }
+        }
+        if (need[q] == 2) {
+            ct.q[at] = nb;
+            if (qs) {
+                qs[at] = nb > T(0) ? T(-1) : ns;
+                if (ns > T(0)) {
+#pragma unroll
+                    for (int c = 0; c < CERT_CANDS; ++c) cands[at * CERT_CANDS + c] = nc[c];
+                }
+            }
+            bud[q] = nb;
+            if (!(nb > spent)) open = true;
+        }
+        if (need[q] && found != cur) {                          // a match that changed: for the accumulate of this iteration
+            ct.cm[at] = found;
+            if (ct.pend) {
+                ct.pend[(size_t)cloud * n_full + qi] = found + 2;
+                ct.gdirty[(size_t)cloud * ct.nwr + (qi >> 6)] = 1;
+            } else if (spos) spos[(size_t)cloud * n_full + qi] = found;
+        }
+        if (pos < n && bud[q] > spent) qmin = min_t(qmin, bud[q]);
+    }
+    // the unit's filter afresh: its smallest budget, or 0 while a query of it has to be looked at in every iteration
+    qmin = wave_min(qmin);
+    const bool any_open = __any(open) != 0;
+    if (lane == 0) *qu = any_open ? T(0) : qmin;
+    // the statistics last (a wave's loads return behind its earlier atomics); a re-scored candidate set costs about a twelfth of a single-query
+    // search (4 gathered rows against a slab): counted as such for the per-cloud switch
+    int resc = rescored;
+#pragma unroll
+    for (int o = WAVE / 2; o > 0; o >>= 1) resc += __shfl_xor(resc, o);
+    const int eq = singles + resc / 12;
+    if (eq > 0 && lane == 0) {
+        if (pairs && rows_scored) atomicAdd(pairs + (blockIdx.x & (DICP_PAIR_SHARDS - 1)), rows_scored);
+        if (ct.count && singles) atomicAdd(ct.count + CERT_SHARDS + (blockIdx.x & (CERT_SHARDS - 1)), singles);
+        if (ct.cloud) atomicAdd(ct.cloud + (size_t)cloud * CERT_CLOUD + 1, eq);
+    }
+}
+
+// The guard launch: a small grid of waves working through the lists the previous iteration's step kernel made (dicp_step_io.glist: the units that
+// have anything to do, one list per XCD so that a cloud's units are searched on the XCD whose L2 holds its rows).  Near the pose the lists are
+// (next to) empty and the launch is one load per wave.
+template <typename T, int Q, int CH>
+__global__ __launch_bounds__(BLOCK, DICP_SWEEP_MINW) void knn_sweep_guard_kernel(DICP_SWEEP_PARAMS, const int32_t* __restrict__ glist, const int32_t* __restrict__ gcount, int glist_cap) {
+    __shared__ typename V4<T>::type tiles[BLOCK / WAVE][SweepRing<T>::NT * WAVE];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int xcd = blockIdx.x & 7;
+    const int units = (n_full + WAVE * Q - 1) / (WAVE * Q);
+    const int count = min(gcount[xcd], glist_cap);
+    const int32_t* __restrict__ list = glist + (size_t)xcd * glist_cap;
+    const int stride = (int)(gridDim.x >> 3) * (BLOCK / WAVE);
+    for (int e = (int)(blockIdx.x >> 3) * (BLOCK / WAVE) + wave; e < count; e += stride) {      // (wave-uniform)
+        const int entry = list[e];
+        const int cloud = entry / units, unit = entry - cloud * units;
+        if (cloud >= N) continue;
+        guard_unit<T, Q, CH>(src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, idx, spos, pairs, N, n_full, m_full, m_pad, bpc, src_rows, tgt_rows, ct,
+                             cloud, unit, tiles[wave]);
+    }
 }
 #undef DICP_SWEEP_PARAMS

@@ -30,7 +30,9 @@
 extern "C" {
 #endif
 
-#define DICP_ABI_VERSION 7   /* 7: dicp_call_* (one eager call of the sweep path behind one host call per direction).
+#define DICP_ABI_VERSION 8   /* 8: certified iterations keep a row cache and their match history by reference (dicp_loop_buffers.spos_of / cert_nbr / cert_gdirty /
+                                cert_pend / cert_cm, spos_prev_chunk + spos_floor instead of spos_prev0; dicp_resolve_matches).
+                                7: dicp_call_* (one eager call of the sweep path behind one host call per direction).
                                 6: dicp_bwd_tail_max_blocks (the one-launch tail only where a cloud's blocks are all resident; a wait that runs out poisons the
                                 cloud's gradients with NaN and raises bwd_live[K] next to bwd_tail_arrive[N]); bwd_live is (K + 1).
                                 5: dicp_loop_buffers.bwd_tail_from (the ended iterations of the truncated reverse sweep as one launch).
@@ -227,6 +229,15 @@ typedef struct dicp_step_io {
     int64_t dcum_stride;
     int32_t* cert_cloud;     /* optional (N,8): per-cloud counters of the match certificates (dicp_loop_buffers.cert_cloud); the step decides
                                 from them whether the cloud's certificates stay on */
+    /* Match certificates, optional: the step also makes the NEXT iteration's guard launch its work list -- the units whose filter value (cert_qu) does not stand
+       under the motion bound it has just written, or all units of a cloud whose certificates are off / tried again.  A guard launch with one wave per unit
+       spent 12 us finding out that it had nothing to do (the footprint of the search code it carries: 4096 blocks in 3.2 rounds); with the list it is a
+       small grid that reads one counter. */
+    const void* cert_qu;     /* (N, cert_units) T */
+    int32_t cert_units;      /* units per cloud of the sweep's launch configuration */
+    int32_t glist_cap;       /* entries per list */
+    int32_t* glist;          /* (8, glist_cap) int32: entry = cloud * cert_units + unit, list = cloud & 7 (the XCD the cloud's blocks run on) */
+    int32_t* gcount;         /* (8) zeros: entries in each list of the next iteration */
     int32_t w_copied;        /* 1: the accumulate launch of this iteration already wrote w_prev into w_cur for the clouds that are frozen (alive = 0;
                                 dicp_icp_forward does): the step then has nothing to copy for them (ICP.py:224-226) */
 } dicp_step_io;
@@ -322,7 +333,24 @@ typedef struct dicp_loop_buffers {
                                 the evidence is structural (queries without any certificate after a search of every unit), for 2, 4, .. 16 iterations
                                 and then certified afresh where a guarded iteration was costly twice in a row (a cloud that is still moving).
                                 While off, every unit of the cloud is searched plainly and nothing is checked: results are the same either way */
-    const int32_t* spos_prev0; /* per-iteration spos: the matches of iteration k0-1 (NULL when k0 == 0 or spos is one reused buffer) */
+    const int32_t* spos_prev_chunk; /* certified iterations, histories in several slabs: the virtual base of the slabs BEFORE the one `spos` addresses
+                                (iteration s < spos_floor at spos_prev_chunk + s*N*n), NULL when spos_floor == 0 */
+    int32_t spos_floor;      /* first iteration of the history slab `spos` addresses (0: one slab) */
+    /* Certified iterations keep the match history BY REFERENCE and the matched rows in a cache (accumulate_kernel, csrc/kernels_accumulate.h).
+       Near the pose almost no match changes from one iteration to the next: copying every match into the next iteration's slab, reading every
+       budget and gathering every 24-byte row again was 19 of the 63 bytes per point such a launch moved (section 8d counts 44). */
+    int32_t* spos_of;        /* (K+1, N, ceil(n/64)) int32, needed with cert_q when idx_per_iter: spos_of[k][b][g] = the iteration whose slab of `spos` holds
+                                the matches of queries [64g, 64g+64) of cloud b at iteration k >= spos_of_from.  Written by the certified iterations' accumulate
+                                (rows k and k+1); dicp_icp_backward reads the matches through it */
+    int32_t spos_of_from;    /* dicp_icp_backward: iterations below it have complete slabs of their own (the searches before the certificates start); the
+                                forward ignores it */
+    void* cert_nbr;          /* (N, n, 6 | 3) T scratch (pt2pl | pt2pt): the matched target row of every query, rewritten where a match changes */
+    int32_t* cert_gdirty;    /* (N, ceil(n/64)) int32 scratch: 1 = the guard launch of the iteration changed a match among these 64 consecutive queries */
+    int32_t* cert_pend;      /* (N, n) int32 ZEROS, by query: a match the guard launch CHANGED, left for the accumulate of the same iteration (match + 2) */
+    int32_t* cert_glist;     /* (8, N * ceil(n/64)) int32 scratch: the guard launches' work lists (dicp_step_io.glist), rewritten by every step */
+    int32_t* cert_gcount;    /* (K + 1, 8) int32 ZEROS: their lengths, per iteration */
+    int32_t* cert_cm;        /* (N, n) int32 scratch, by slot of the query order: the searches' own copy of the current matches.  The certificates' state
+                                (cert_q, cert_set, cert_cm) goes by SLOT: the guard launch, which alone reads it, takes a unit's share as one coalesced piece */
     const void* tgt_sorted;  /* sweep only, optional (N,m_pad,tgt_sorted_stride): dicp_sweep_build's tgt_s.  With it (and spos) the forward accumulate
                                 gathers the match rows from the sorted copy at spos -- one aligned sector per row -- and idx may be NULL */
     int32_t tgt_sorted_stride;
@@ -394,7 +422,7 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
 /* The constant-iteration loop of the sweep path in ONE call: the segments [k0[s], k1[s]) dicp_icp_forward would be called for one after the
  * other (cut where the queries are re-ordered and where the match certificates start), the query re-orderings between them included
  * (new_order[s] != 0: dicp_query_order under the segment's first search pose into order[s]).  buf as for dicp_icp_forward with
- * every history in one slab (spos / idx / w are their real bases); qorder, cert_q / cert_qu / cert_count / cert_cloud, cert_reset, spos_prev0
+ * every history in one slab (spos / idx / w are their real bases); qorder, cert_q / cert_qu / cert_count / cert_cloud / cert_nbr / cert_gdirty / cert_pend / cert_cm, cert_reset, spos_prev_chunk / spos_floor
  * and w_prev0 of `buf` are ignored: the call derives them per segment (certificates from iteration cert_from on; cert_from < 0: none).
  * The reference's per-iteration host check (ICP.py:259) needs the host between segments: tolerance mode keeps calling dicp_icp_forward. */
 #define DICP_MAX_SEGMENTS 16
@@ -407,6 +435,7 @@ typedef struct dicp_segment_plan {
     int32_t* order[DICP_MAX_SEGMENTS];       /* (N,n) each: the query order the segment searches in (several segments may share one), NULL: none */
     const void* keys;        /* (N,m_pad) sorted target x keys (dicp_sweep_sort): the rank search of dicp_query_order */
     void* cert_q; void* cert_qu; int32_t* cert_count; int32_t* cert_cloud; void* cert_set;
+    void* cert_nbr; int32_t* cert_gdirty; int32_t* cert_pend; int32_t* cert_cm; int32_t* cert_glist; int32_t* cert_gcount;     /* as dicp_loop_buffers' (its spos_of is taken from `buf`) */
 } dicp_segment_plan;
 int dicp_icp_forward_plan(int dtype, const dicp_weight_params* prm, const dicp_loop_buffers* buf, const dicp_segment_plan* plan, int N, int n, int m,
                           int dim, int const_iter, double tolerance, void* stream);
@@ -418,6 +447,11 @@ int dicp_icp_forward_plan(int dtype, const dicp_weight_params* prm, const dicp_l
 int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_buffers* buf, int N, int n, int m, int dim,
                       double* gpose, double* gpose_tmp, int have_partials, void* gs, void* gb, void* gsrc, void* gtgt, void* gw,
                       void* bwd_partials, int k0, int k1, void* stream);
+/* out (N,n) = the matches of iteration k out of the history `spos` (virtual base: iteration s at spos + s*N*n) kept by reference through spos_of
+ * (dicp_loop_buffers.spos_of; NULL: iteration k's own slab, a plain copy): what places the windows of the backward pass (spos_ref). */
+int dicp_resolve_matches(const int32_t* spos, const int32_t* spos_of, int k, const int32_t* src_rows /* optional (N): -1 for the rows past a cloud's own */,
+                         int N, int n, int32_t* out, void* stream);
+
 
 /* Backward of dicp_step for iteration k.  gpose_in (N,12) double = cotangent of pose_out
  * that flowed through later iterations; bwd_partials (N,nblk,DICP_NBWD_PAD) T = the
@@ -608,6 +642,7 @@ typedef struct dicp_call_backward_layout {
     size_t total, zeroed;
     size_t live, arrive;     /* (K + 1) / (N + 1) int32: dicp_loop_buffers.bwd_live / bwd_tail_arrive of the pass */
     size_t mref, decisions, far, gpose, gtmp, src_s, w_s, gsrc_s, gw_s, slab, gs, gb, partials, tail_partials;
+    size_t spos_ref;         /* (N,n) int32: the matches of the last executed iteration as a plain array (dicp_resolve_matches: they place the windows) */
     int32_t nblk_w, pad0;    /* dicp_window_blocks of the shape */
 } dicp_call_backward_layout;
 int dicp_call_backward_plan(int dtype, const dicp_weight_params* prm, const dicp_call* call, int want_tgt, int want_w, dicp_call_backward_layout* layout);
@@ -628,9 +663,10 @@ typedef struct dicp_loop_backward_in {
     const void* alive;       /* (K_cap+1,N) */
     const int32_t* src_rows; /* optional (N) */
     const int32_t* tgt_rows; /* optional (N) */
+    const int32_t* spos_of;  /* optional (K_cap+1,N,ceil(n/64)): the history is kept by reference from iteration spos_of_from on (dicp_loop_buffers.spos_of) */
     int32_t N, n, m, c, K, K_cap, m_pad, dim;
     int32_t knn_variant;     /* as dicp_loop_buffers */
-    int32_t pad0;
+    int32_t spos_of_from;
 } dicp_loop_backward_in;
 int dicp_loop_backward_plan(int dtype, const dicp_weight_params* prm, const dicp_loop_backward_in* fwd, int want_tgt, int want_w, dicp_call_backward_layout* layout);
 int dicp_loop_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_backward_in* fwd, const dicp_call_grads* grads, void* stream);

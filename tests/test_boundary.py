@@ -39,7 +39,7 @@ def test_struct_layouts_match_header(lib):
     expect = ["partials", "nblk", "iter", "dim", "const_iter", "tolerance", "rows_per_point", "n", "pose_in", "pose_out",
               "delta", "delta_stride", "cost", "cost_prev", "cost_stride", "areg", "alive", "alive_out", "converged", "iterations",
               "matched_ratio", "n_start", "n_matched", "w_cur", "w_prev", "w_stride", "n_not_converged", "frame", "pose_search_out",
-              "rmax", "dcum", "dcum_stride", "cert_cloud", "w_copied"]
+              "rmax", "dcum", "dcum_stride", "cert_cloud", "cert_qu", "cert_units", "glist_cap", "glist", "gcount", "w_copied"]
     assert [f[0] for f in _lib.StepIO._fields_] == expect
     hdr = open(os.path.join(ROOT, "include", "dicp_hip.h")).read()
     body = hdr[hdr.index("typedef struct dicp_step_io {"):hdr.index("} dicp_step_io;")]
@@ -166,7 +166,7 @@ def test_new_entry_points_reject_bad_arguments(lib):
 
 
 def test_sizes_and_argument_checks(lib):
-    assert lib.dicp_abi_version() == _lib.ABI_VERSION == 7
+    assert lib.dicp_abi_version() == _lib.ABI_VERSION == 8
     assert [lib.dicp_padded_targets(m) for m in (0, 1, 64, 65, 129)] == [0, 64, 64, 128, 192]
     assert [lib.dicp_accumulate_blocks(n) for n in (0, 1, 1024, 1025, 16384)] == [0, 1, 1, 2, 16]
     # rejected before any launch (no GPU touched): null pointers, bad dtype / shapes / enums

@@ -57,7 +57,7 @@ if ROOT not in sys.path:
 
 from dicp_amd import dist as ddist                      # noqa: E402
 from dicp_amd.ICP import ICP                            # noqa: E402
-from dicp_amd.synthetic import make_pairs, make_scene_pairs   # noqa: E402
+from dicp_amd.synthetic import make_pairs, make_scene_pairs, make_independent_pairs   # noqa: E402
 
 STEADY_CALLS, STEADY_MAX = 3, 40   # untimed K-iteration calls before the timed ones: at least / at most
 F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: f32 vector == f32-input MFMA peak
@@ -498,6 +498,63 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
             extra["structured_pairs_scored_fraction"] = sp / (float(n) * m * B)
         sane = sane and bool(torch.isfinite(sout["T"]).all() and torch.isfinite(sgs).all() and torch.isfinite(sgt).all())
         del sc, sout, sgs, sgt, scene, s2, t2
+        # Inputs that are NOT the certificates' best case: source and target sampled independently from the same surfaces (no shared
+        # point), 30 % of either cloud outside the other's footprint, 10 % clutter, start poses up to 0.2 rad / 1 m -- dense batches (the kernels'
+        # own behaviour) and the same clouds as ragged lists (the reference's list inputs, tests/test_ICP_inputs.py:36-103: the host's list handling is in the call)
+        def indep_leg(K_, const_iter, ragged, count):
+            S, Tg = make_independent_pairs(B, n, m, seed=3, dtype=torch.float32, first=rank * B, ragged=ragged)
+            if ragged:
+                S, Tg = [x.to(dev) for x in S], [x.to(dev) for x in Tg]
+                T0i = [torch.eye(4, device=dev)] * B
+            else:
+                S, Tg, T0i = S.to(dev), Tg.to(dev), T0
+            obj = new_icp(K_, tol=1e-12 if const_iter else 1e-4, const_iter=const_iter)
+
+            def call():
+                if ragged:
+                    s_ = [x.detach().requires_grad_(True) for x in S]
+                    t_ = [x.detach().requires_grad_(True) for x in Tg]
+                else:
+                    s_, t_ = S.detach().requires_grad_(True), Tg.detach().requires_grad_(True)
+                o = obj.icp(s_, t_, T0i, trim_dist=TRIM, loss_fn=LOSS, dim=3)
+                o["T"].sum().backward()
+                return o, s_, t_
+            for _ in range(3):
+                held = call()
+            tms = []
+            for _ in range(count):
+                fence()
+                t0_ = time.perf_counter()
+                held = call()
+                fence()
+                tms.append(all_max(time.perf_counter() - t0_))
+            o, s_, t_ = held
+            k_exec = int(o["deltas"].shape[1])
+            grads = [x.grad for x in (s_ + t_)] if ragged else [s_.grad, t_.grad]
+            fin = bool(torch.isfinite(o["T"]).all()) and all(bool(torch.isfinite(g_).all()) for g_ in grads)
+            real_pairs = float(sum(a.shape[0] * b.shape[0] for a, b in zip(S, Tg))) if ragged else float(B) * n * m
+            st = obj.knn_stats
+            rec = {"cloud_it_per_s": world * B * k_exec / median(tms), "iterations_executed": k_exec, "ms_per_call": median(tms) * 1e3, "finite": fin,
+                   "converged_clouds": int(o["stats"]["converged"].sum().item()) if "converged" in o["stats"] else None}
+            if "knn_pairs" in st:
+                rec["pairs_scored_fraction"] = float(st["knn_pairs"].sum().item()) / k_exec / real_pairs
+            if "searched_again" in st:
+                ag = st["searched_again"]
+                rec["units_searched_again_by_iteration"] = [int(v) for v in ag[:k_exec, :64].sum(1).tolist()]
+                rec["single_queries_searched_by_iteration"] = [int(v) for v in ag[:k_exec, 64:].sum(1).tolist()]
+                rec["certs_off_clouds"] = int(st["certs_off"].sum().item()) if "certs_off" in st else None
+            return rec, fin
+        indep = {}
+        for name, K_, ci, rg in (("k10", 10, True, False), ("tolerance", 50, False, False), ("k10_ragged_lists", 10, True, True), ("tolerance_ragged_lists", 50, False, True)):
+            indep[name], fin_ = indep_leg(K_, ci, rg, 5)
+            sane = sane and fin_
+        extra["value_independent"] = indep["k10"]["cloud_it_per_s"]
+        extra["independent"] = indep
+        extra["independent_note"] = ("dicp_amd.synthetic.make_independent_pairs: source and target sampled INDEPENDENTLY from the same surfaces (corridor with partitions and pillars), "
+                                     "footprints 6 m apart (30 %% of either cloud without counterpart), 10 %% clutter each, start poses up to 0.2 rad / 1 m; k10 = 10 constant "
+                                     "iterations (compare value_k10 = %.0f on make_pairs, whose source IS target rows), tolerance = 1e-4 / max 50 / const_iter off; "
+                                     "*_ragged_lists: the same clouds with lengths in [0.75, 1] x %d handed over as Python lists (the host's list handling is inside the call)"
+                                     % (extra.get("value_k10", float("nan")), n))
         if on_gpu and world == 1:
             extra.update(other_configs(make_icp, dev, sync))
     gc.enable()

@@ -43,7 +43,7 @@ class StepIO(ctypes.Structure):
                 ("converged", vp), ("iterations", vp), ("matched_ratio", vp), ("n_start", vp),
                 ("n_matched", vp), ("w_cur", vp), ("w_prev", vp), ("w_stride", i64), ("n_not_converged", vp),
                 ("frame", vp), ("pose_search_out", vp), ("rmax", vp), ("dcum", vp), ("dcum_stride", i64), ("cert_cloud", vp),
-                ("cert_qu", vp), ("cert_units", i32), ("glist_cap", i32), ("glist", vp), ("gcount", vp), ("w_copied", i32)]
+                ("cert_qu", vp), ("cert_units", i32), ("glist_cap", i32), ("glist", vp), ("gcount", vp), ("cert_scount", vp), ("w_copied", i32)]
 
 
 class LoopBuffers(ctypes.Structure):
@@ -55,8 +55,8 @@ class LoopBuffers(ctypes.Structure):
                 ("partials", vp), ("counters", vp), ("events", vp), ("bwd_overwrite", i32), ("frame", vp), ("poses_search", vp),
                 ("src_rows", vp), ("tgt_rows", vp), ("cert_q", vp), ("cert_qu", vp), ("cert_set", vp), ("cert_count", vp), ("rmax", vp), ("dcum", vp),
                 ("cert_reset", i32), ("cert_cloud", vp), ("spos_prev_chunk", vp), ("spos_floor", i32), ("spos_of", vp), ("spos_of_from", i32),
-                ("cert_nbr", vp), ("cert_gdirty", vp), ("cert_pend", vp), ("cert_glist", vp), ("cert_gcount", vp), ("cert_cm", vp), ("tgt_sorted", vp), ("tgt_sorted_stride", i32),
-                ("bwd_skip", vp), ("bwd_mref", vp), ("bwd_live", vp), ("bwd_skip_eps", f64), ("bwd_tail_from", i32), ("bwd_tail_partials", vp), ("bwd_tail_arrive", vp), ("gumbel", vp), ("first_search_done", i32), ("tgt_f16", vp)]
+                ("cert_nbr", vp), ("cert_gdirty", vp), ("cert_pend", vp), ("cert_glist", vp), ("cert_gcount", vp), ("cert_slist", vp), ("cert_scount", vp), ("cert_cm", vp), ("tgt_sorted", vp), ("tgt_sorted_stride", i32),
+                ("bwd_skip", vp), ("bwd_mref", vp), ("bwd_live", vp), ("bwd_skip_eps", f64), ("bwd_tail_from", i32), ("bwd_tail_partials", vp), ("bwd_tail_arrive", vp), ("gumbel", vp), ("first_search_done", i32), ("tgt_f16", vp), ("sweep_form", vp), ("sweep_form_default", i32)]
 
 
 class GumbelLoop(ctypes.Structure):
@@ -72,7 +72,7 @@ class SegmentPlan(ctypes.Structure):
     """dicp_segment_plan (include/dicp_hip.h)."""
     _fields_ = [("nseg", i32), ("k0", i32 * MAX_SEGMENTS), ("k1", i32 * MAX_SEGMENTS), ("new_order", i32 * MAX_SEGMENTS),
                 ("cert_from", i32), ("pad0", i32), ("order", vp * MAX_SEGMENTS), ("keys", vp), ("cert_q", vp), ("cert_qu", vp), ("cert_count", vp), ("cert_cloud", vp), ("cert_set", vp),
-                ("cert_nbr", vp), ("cert_gdirty", vp), ("cert_pend", vp), ("cert_cm", vp), ("cert_glist", vp), ("cert_gcount", vp)]
+                ("cert_nbr", vp), ("cert_gdirty", vp), ("cert_pend", vp), ("cert_cm", vp), ("cert_glist", vp), ("cert_gcount", vp), ("cert_slist", vp), ("cert_scount", vp)]
 
 
 class Call(ctypes.Structure):
@@ -146,7 +146,7 @@ _SIGNATURES = {
     "dicp_knn_f16_bytes": ([i32, i32], ctypes.c_size_t),
     "dicp_knn_f16_pack": ([vp, vp, i32, i32, i32, vp, vp], ctypes.c_int),
     "dicp_knn": ([i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp, vp], ctypes.c_int),
-    "dicp_knn_sweep": ([i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp], ctypes.c_int),
+    "dicp_knn_sweep": ([i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp], ctypes.c_int),
     "dicp_window_blocks": ([i32, i32, i32], ctypes.c_int),
     "dicp_window_rows": ([i32], ctypes.c_int),
     "dicp_bwd_tail_max_blocks": ([i32], ctypes.c_int),

@@ -16,8 +16,13 @@ SWEEP_MIN_TARGETS = 2048     # KNN_AUTO inside ICP: below this many targets per 
 SWEEP_MIN_QUERIES = 256
 F16_SWEEP = True             # float32 sweep path: the plain searches of big clouds score on the matrix cores (split-f16 filter + exact refine; same indices)
 F16_SWEEP_MIN_QUERIES = 2 * 256 * 1024      # ... from the size at which the sweep works in units of 128 queries (sweep_auto_cfg)
-F16_SWEEP_MIN_TARGETS = 32768               # ... and from 32768 targets per cloud on: measured (profiles/r04_knn_f16_sweep.txt) 1.27x at 32768, 1.4-1.5x at 65536,
-                                            # 0.92x at 16384 -- a wave's slab there is 16 tiles, 128 MFMAs, and the per-wave refine costs as much as the scoring
+F16_SWEEP_MIN_TARGETS = 32768               # ... and, for a cloud whose slabs have not been measured yet, from 32768 targets on: measured (profiles/r04_knn_f16_sweep.txt) 1.27x at
+                                            # 32768, 1.4-1.5x at 65536, 0.92x at 16384 -- a wave's slab there is 16 tiles, 128 MFMAs, and the per-wave refine costs as much as the
+                                            # scoring.  Round 5: every plain search of the loop tallies its slabs' tiles per cloud, and the next one scores a cloud on the matrix
+                                            # cores if they were long (dicp_loop_buffers.sweep_form) -- clouds of 16384 points that start a metre off, or a third of which has no
+                                            # counterpart in the target, score 30 % of the pairs: 28.2 -> 19.0 ms per 10-iteration call (profiles/r05_independent_forms.txt)
+F16_SWEEP_ADAPTIVE = True                   # (False: the form is chosen by the size alone, as in round 4)
+FORM_TILES = 20                             # (kernels_search.h: tiles per unit of 128 queries from which on a cloud's plain searches score on the matrix cores)
 SWEEP_MIN_PAIRS = 1e8        # ... and below this many (query,target) pairs per iteration.  Measured (profiles/r02_mid_size_paths.txt): with the
                              # native key sort the sweep's per-call set-up is ~0.1 ms, and it already wins at 32 x 2048^2 and 8 x 4096^2
                              # (0.090 vs 0.103 and 0.075 vs 0.121 ms per iteration, fwd+bwd); at 32 x 4096^2 (BASELINE configs[1]) 0.084 vs 0.175
@@ -217,6 +222,8 @@ class SweepIndex:
         self.img16 = None
         want_img = (bool(F16_SWEEP) and dt == torch.float32 and first_order is not None and float(N) * first_order[0].shape[1] >= F16_SWEEP_MIN_QUERIES
                     and m >= F16_SWEEP_MIN_TARGETS)
+        self.form_default = int(m >= F16_SWEEP_MIN_TARGETS)      # the scoring form of a cloud whose slabs have not been measured yet
+        self.form0 = None                                        # (N) int32: the first search's tally of tiles per cloud
         if first_order is not None:
             source, T_init, src_rows = first_order
             self.frame = torch.empty((N, 12), dtype=dt, device=dev)
@@ -231,9 +238,12 @@ class SweepIndex:
             spos0 = None
             if first_search:
                 spos0 = torch.empty((N, source.shape[1]), dtype=torch.int32, device=dev)
+                if F16_SWEEP_ADAPTIVE and dt == torch.float32 and float(N) * source.shape[1] >= F16_SWEEP_MIN_QUERIES and bool(F16_SWEEP):
+                    self.form0 = torch.zeros((N,), dtype=torch.int32, device=dev)     # (that search's tally of its slabs' tiles per cloud: dicp_loop_buffers.sweep_form)
                 with _on(dev):
                     _lib.check(lib.dicp_knn_sweep(_DT[dt], _p(source), _p(pose_s), _p(self.tgs4), _p(self.tperm), _p(qorder), _p(self.bucket), _p(self.brange), self.NBKT,
-                                                  _p(src_rows), _p(tgt_rows), N, source.shape[1], m, m_pad, None, _p(spos0), _p(self.pair_shards), 0, _p(self.img16), _stream()), "dicp_knn_sweep")
+                                                  _p(src_rows), _p(tgt_rows), N, source.shape[1], m, m_pad, None, _p(spos0), _p(self.pair_shards), 0,
+                                                  _p(self.img16) if (self.form_default or not F16_SWEEP_ADAPTIVE) else None, None, _p(self.form0), self.form_default, _stream()), "dicp_knn_sweep")
             self.first = (source, T_init, qorder, spos0)
             return
         with _on(dev):
@@ -287,7 +297,7 @@ class SweepIndex:
         with _on(src.device):
             _lib.check(_lib.load().dicp_knn_sweep(_DT[src.dtype], _p(src), _p(pose), _p(self.tgs4), _p(self.tperm), _p(qorder),
                                                   _p(self.bucket), _p(self.brange), self.NBKT, _p(src_rows), _p(self.tgt_rows), N, n, self.m, self.tgs4.shape[1],
-                                                  _p(idx), _p(spos), _p(self.pair_shards), cfg, _p(self.make_image()) if mfma else None, _stream()), "dicp_knn_sweep")
+                                                  _p(idx), _p(spos), _p(self.pair_shards), cfg, _p(self.make_image()) if mfma else None, None, None, 1, _stream()), "dicp_knn_sweep")
         return idx
 
 
@@ -493,7 +503,7 @@ class CallHints:
     MAX_SHAPES = 16
 
     def __init__(self):
-        self.tail, self.cert = {}, {}
+        self.tail, self.cert, self.form = {}, {}, {}
         self.newest_tail = None         # [pinned counters (Kmax + 1), event, (N, n, K), Kmax, looked at, serial]: the record of the last backward pass (tests)
         self.serial = 0
 
@@ -517,6 +527,10 @@ class CallHints:
             if same:
                 return max(same, key=lambda recs: recs[-1][5])
         return self._slot(self.tail, key, list)
+
+    def form_record(self, dev, shape):
+        """form : whether the previous call's plain searches had long slabs in any cloud (then this call's score such clouds on the matrix cores)."""
+        return self._slot(self.form, self._where(dev) + tuple(shape), lambda: {"long": False, "host": None, "event": None, "calls": 0})
 
     def cert_record(self, dev, shape):
         return self._slot(self.cert, self._where(dev) + tuple(shape), lambda: {"skip": 0, "host": None, "event": None, "calls": 0})
@@ -770,6 +784,21 @@ class ICPLoop(torch.autograd.Function):
             m_pad = tgt4.shape[1] if tgt4 is not None else 0
             # the matrix-core searches' image of the packed rows (the sweep path: of the sorted rows, made with the index)
             img16 = f16_image(tgt4, m, cfg.tgt_rows) if kind == _lib.KNN_MFMA else (sweep.img16 if sweep is not None else None)
+            # The per-cloud choice of the scoring form (dicp_loop_buffers.sweep_form).  Every plain search tallies its slabs' tiles per cloud; what the tallies of
+            # the PREVIOUS call of this shape said (a hint, like the tail's and the certificates': it arrives through pinned memory, costs time at worst) decides
+            # whether this call builds the matrix-core image for clouds too small to get one by size: where some cloud's slabs were long, the plain searches
+            # launch both forms and each takes its clouds (start poses a metre off, a third of the source without counterpart: 28.2 -> 19.0 ms per call,
+            # profiles/r05_independent_forms.txt); where none was, nothing is built and nothing more is launched.
+            tally = (sweep is not None and F16_SWEEP and F16_SWEEP_ADAPTIVE and dt == torch.float32 and float(N) * n >= F16_SWEEP_MIN_QUERIES
+                     and not (cfg.knn_variant & 0xff00))
+            form_hint = None
+            if tally and cfg.hints is not None and not torch.cuda.is_current_stream_capturing():
+                form_hint = cfg.hints.form_record(dev, (N, n, m, dt))
+                if form_hint["event"] is not None and form_hint["event"].query():
+                    form_hint["long"] = bool(int(form_hint["host"][0]) > 0)
+                    form_hint["event"] = None
+                if img16 is None and form_hint["long"]:
+                    img16 = sweep.make_image()
             nblk = lib.dicp_accumulate_blocks(n)
             poses = torch.empty((Kmax + 1, N, 12), dtype=dt, device=dev)
             poses_c = torch.empty((Kmax + 1, N, 12), dtype=dt, device=dev) if center is not None else None   # [Q C | Q r + t]: what the searches read
@@ -811,7 +840,9 @@ class ICPLoop(torch.autograd.Function):
                     # every cloud off at the call's end (for good, or backed off: clouds that keep moving) -- or, in a batch so small that a launch is as
                     # long as its slowest cloud (no more units than the GPU holds at once), ANY cloud whose certificates did not pay in two iterations
                     hc = cert_hint["host"][:N]
-                    if bool((hc[:, 2] > 0).all()) or (N * ((n + 127) // 128) <= 8192 and bool((hc[:, 7] >= 2).any())):
+                    # (round 5: or most of them -- partially overlapping clouds that start a metre off: 247 of 256 ended a call switched off, and the call cost
+                    #  34.6 ms with certificates against 28.2 without, profiles/r05_independent_forms.txt)
+                    if float((hc[:, 2] > 0).float().mean()) >= 0.5 or (N * ((n + 127) // 128) <= 8192 and bool((hc[:, 7] >= 2).any())):
                         cert_hint.update(skip=31, calls=0)                   # (the first certified call after the pause reports again)
                         want_certs = False
                     cert_hint["event"] = None
@@ -821,7 +852,11 @@ class ICPLoop(torch.autograd.Function):
             arena.take((N, 8) if want_certs else (0,), torch.int32)
             arena.take((N, n) if want_certs else (0,), torch.int32)     # (row cache: matches a guard launch leaves for the accumulate of its iteration; zero = none)
             arena.take((Kmax + 1, 8) if want_certs else (0,), torch.int32)     # (lengths of the guard launches' work lists, per iteration)
-            deltas, costs, converged, iterations, matched, n_matched, counters, cert_count, cert_cloud, cert_pend, cert_gcount = arena.finish()
+            # per-cloud tallies of the plain searches' slab lengths: the scoring form of the next plain search (dicp_loop_buffers.sweep_form)
+            adaptive = bool(tally) and kind == _lib.KNN_SWEEP
+            arena.take((Kmax, N) if adaptive else (0,), torch.int32)
+            arena.take((N,) if (want_certs and cfg.cert_sets) else (0,), torch.int32)     # (lengths of the clouds' candidate-set lists)
+            deltas, costs, converged, iterations, matched, n_matched, counters, cert_count, cert_cloud, cert_pend, cert_gcount, sweep_form, cert_scount = arena.finish()
             # pose_0, alive_0, n_start (ICP.py:124-129)
             certs = None
             if want_certs:
@@ -831,6 +866,7 @@ class ICPLoop(torch.autograd.Function):
                 certs = dict(q=torch.empty((N, n), dtype=dt, device=dev), qu=torch.empty((N, units), dtype=dt, device=dev), count=cert_count,
                              nbr=torch.empty((N, n, 6 if cfg.icp_type == "pt2pl" else 3), dtype=dt, device=dev), gdirty=torch.empty((N, units), dtype=torch.int32, device=dev),
                              cm=torch.empty((N, n), dtype=torch.int32, device=dev), glist=torch.empty((8, N * units), dtype=torch.int32, device=dev), gcount=cert_gcount,
+                             slist=torch.empty((N, n), dtype=torch.int32, device=dev) if cfg.cert_sets else None, scount=cert_scount if cfg.cert_sets else None,
                              pend=cert_pend, of=torch.empty((Kmax + 1, N, units), dtype=torch.int32, device=dev) if need_grad else None,
                              set=torch.empty((N * n * (es + 16),), dtype=torch.uint8, device=dev) if cfg.cert_sets else None,     # candidate sets: (N,n) budgets + (N,n,4) rows
                              rmax=torch.empty((N, 4), dtype=dt, device=dev), dcum=torch.empty((N, 2 * (Kmax + 1)), dtype=dt, device=dev))
@@ -888,6 +924,8 @@ class ICPLoop(torch.autograd.Function):
                     and first0[1].data_ptr() == T_init.data_ptr() and T_init.is_contiguous() and not keep_idx and events is None
                     and not (certs is not None and cert_from <= 0)):
                 first_spos = first0[3]
+                if adaptive and sweep.form0 is not None:
+                    sweep_form[0].copy_(sweep.form0)        # (that search's tally of its slabs: the scoring form of iteration 1's)
                 if not keep_spos:
                     spos_once = first_spos
             # constant-iteration calls of the sweep path with all histories in one slab: every segment and the query re-orderings between them
@@ -909,7 +947,8 @@ class ICPLoop(torch.autograd.Function):
                                       cert_set=_p(certs["set"]) if certs else None, cert_nbr=_p(certs["nbr"]) if certs else None,
                                       cert_gdirty=_p(certs["gdirty"]) if certs else None, cert_pend=_p(certs["pend"]) if certs else None,
                                       cert_cm=_p(certs["cm"]) if certs else None, cert_glist=_p(certs["glist"]) if certs else None,
-                                      cert_gcount=_p(certs["gcount"]) if certs else None)
+                                      cert_gcount=_p(certs["gcount"]) if certs else None, cert_slist=_p(certs["slist"]) if certs else None,
+                                      cert_scount=_p(certs["scount"]) if certs else None)
                 n_new = sum(1 for (k0, _) in segs if (k0 == 0 or k0 in cfg.sweep_resort)) - (1 if have_first else 0)
                 fresh_orders = torch.empty((max(n_new, 1), N, n), dtype=torch.int32, device=dev)
                 used = 0
@@ -940,7 +979,7 @@ class ICPLoop(torch.autograd.Function):
                     idx=(_p(idx_slabs[0]) if need_grad else _p(idx_once)) if keep_idx else None,
                     partials=_p(partials), counters=_p(counters), events=events, frame=_p(center), poses_search=_p(poses_c),
                     src_rows=_p(cfg.src_rows), tgt_rows=_p(cfg.tgt_rows), first_search_done=int(first_spos is not None), tgt_f16=_p(img16),
-                    spos_of=_p(certs["of"]) if certs else None)
+                    spos_of=_p(certs["of"]) if certs else None, sweep_form=_p(sweep_form) if adaptive else None, sweep_form_default=sweep.form_default)
                 _lib.check(lib.dicp_icp_forward_plan(code, Pref, ctypes.byref(LB), ctypes.byref(SP), N, n, m, int(cfg.dim), 1, float(cfg.tolerance), st),
                            "dicp_icp_forward_plan")
                 segs = []
@@ -981,7 +1020,8 @@ class ICPLoop(torch.autograd.Function):
                         rmax=_p(certs["rmax"]) if certs else None, dcum=_p(certs["dcum"]) if certs else None,
                         w_iter=n, w_stride=kc * n,
                         partials=_p(partials), counters=_p(counters), events=events, frame=_p(center), poses_search=_p(poses_c),
-                        src_rows=_p(cfg.src_rows), tgt_rows=_p(cfg.tgt_rows), tgt_f16=_p(img16))
+                        src_rows=_p(cfg.src_rows), tgt_rows=_p(cfg.tgt_rows), tgt_f16=_p(img16),
+                        sweep_form=_p(sweep_form) if adaptive else None, sweep_form_default=sweep.form_default if sweep is not None else 0)
                     if gum is not None:
                         LB.gumbel = ctypes.cast(ctypes.pointer(gum), ctypes.c_void_p)
                     LBref = ctypes.byref(LB)
@@ -994,6 +1034,7 @@ class ICPLoop(torch.autograd.Function):
                 LB.cert_set = _p(certs["set"]) if use_certs else None
                 LB.cert_nbr, LB.cert_gdirty, LB.cert_pend, LB.cert_cm = (_p(certs["nbr"]), _p(certs["gdirty"]), _p(certs["pend"]), _p(certs["cm"])) if use_certs else (None, None, None, None)
                 LB.cert_glist, LB.cert_gcount = (_p(certs["glist"]), _p(certs["gcount"])) if use_certs else (None, None)
+                LB.cert_slist, LB.cert_scount = (_p(certs["slist"]), _p(certs["scount"])) if use_certs else (None, None)
                 LB.spos_of = _p(certs["of"]) if use_certs else None
                 LB.cert_reset = int(k0 == cert_from)
                 # (history in several slabs: a certified iteration finds the matches of the slab before its own through spos_prev_chunk)
@@ -1039,6 +1080,16 @@ class ICPLoop(torch.autograd.Function):
                         cert_hint["host"][:N].copy_(cert_cloud, non_blocking=True)
                         cert_hint["event"] = torch.cuda.Event()
                         cert_hint["event"].record()
+            if adaptive and form_hint is not None and form_hint["event"] is None and (form_hint["calls"] < 2 or form_hint["calls"] % 16 == 0):
+                # (the first two calls of a shape and every sixteenth after: it is host time) clouds with long slabs in any plain search of this call
+                if form_hint["host"] is None:
+                    form_hint["host"] = torch.empty((1,), dtype=torch.int32).pin_memory()
+                units128 = ((cfg.src_rows if cfg.src_rows is not None else n) + 127) // 128
+                form_hint["host"].copy_(((sweep_form > FORM_TILES * units128).any(dim=0)).sum(dtype=torch.int32).reshape(1), non_blocking=True)
+                form_hint["event"] = torch.cuda.Event()
+                form_hint["event"].record()
+            if form_hint is not None:
+                form_hint["calls"] += 1
             weights = (w_slabs[0] if len(w_slabs) == 1 else torch.cat(w_slabs, dim=1))[:, :K]
             deltas_out = deltas[:, :K]
             costs_out = costs[:, :K]

@@ -133,7 +133,7 @@ int dicp_call_forward(int dtype, const dicp_weight_params* prm, const dicp_call*
     const bool first_search = (c->flags & DICP_CALL_FIRST_SEARCH) != 0;
     if (first_search)
         if (int rc = dicp_knn_sweep(dtype, c->src, at(c, L.pose_s), at(c, L.tgs4), (int32_t*)at(c, L.tperm), order0, (int32_t*)at(c, L.bucket), at(c, L.brange),
-                                    DICP_CALL_NBKT, nullptr, nullptr, c->N, c->n, c->m, L.m_pad, nullptr, spos, (unsigned long long*)at(c, L.pairs), 0, nullptr, stream))
+                                    DICP_CALL_NBKT, nullptr, nullptr, c->N, c->n, c->m, L.m_pad, nullptr, spos, (unsigned long long*)at(c, L.pairs), 0, nullptr, nullptr, nullptr, 0, stream))
             return rc;
     if (int rc = dicp_loop_init(dtype, c->T_init, c->w0, prm->match_thresh, prm->mode == DICP_PT2PT ? 3 : 1, c->N, c->n, at(c, L.poses), at(c, L.alive),
                                 at(c, L.n_start), at(c, L.frame), at(c, L.poses_search), nullptr, nullptr, nullptr, 2 * (K + 1), stream))

@@ -272,20 +272,28 @@ static int sweep_auto_cfg(int N, int n) { return ((long)N * n >= 2L * BLOCK * 10
 struct CertArgs {             // certifying search: budgets (NULL q: plain search), motion bounds; guard: the launch of a certified iteration
     void* q; void* qu; const void* dcum; int dstride; int k; int32_t* count; bool guard; int32_t* cloud; void* set;
     int32_t* cm; int32_t* pend; int32_t* gdirty;     // the searches' own copy of the matches (by slot); guard launches: where a CHANGED match is left (SweepCert::pend)
+    int32_t* slist; int32_t* scount;                 // the clouds' candidate-set lists (SweepCert::slist)
     const int32_t* glist; const int32_t* gcount; int glist_cap;     // guard launches: the work lists the previous step made
 };
 
+struct FormArgs { const int32_t* in; int32_t* out; int dflt; };       // per-cloud slab tallies of the loop's plain searches (dicp_loop_buffers.sweep_form)
 static int sweep_launch(int dtype, const void* src, const void* pose, const void* tgs4, const int32_t* tperm,
                         const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt,
                         int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg, Rows rw, hipStream_t st,
-                        CertArgs ca = CertArgs{}, const void* f16_image = nullptr) {
+                        CertArgs ca = CertArgs{}, const void* f16_image = nullptr, FormArgs fa = FormArgs{nullptr, nullptr, 0}) {
     hipEvent_t ev0, ev1;
     take_launch_events(ev0, ev1);                                       // (null unless a timed loop set them for this launch)
     if (cfg == 0) cfg = sweep_auto_cfg(N, n);
-    // plain float32 searches in units of 128 queries, given the image of the sorted rows: the scoring runs on the matrix cores (knn_f16.hip)
-    if (f16_image && dtype == DICP_F32 && !ca.q && cfg == SWEEP_CFG_BIG)
+    // plain float32 searches in units of 128 queries, given the image of the sorted rows: the scoring runs on the matrix cores (knn_f16.hip) -- for every
+    // cloud, or (given the previous plain search's tally) for the clouds whose slabs were long, the others staying with the vector form: two launches, each
+    // of which leaves the other's clouds at once
+    const bool f16_ok = f16_image && dtype == DICP_F32 && !ca.q && cfg == SWEEP_CFG_BIG;
+    const bool hybrid = f16_ok && fa.in;
+    if (f16_ok && !hybrid)
         return dicp_tu::knn_f16_sweep(src, pose, tgs4, const_cast<void*>(f16_image), tperm, qorder, bucket, brange, nbkt, rw.src, rw.tgt, N, n, m, m_pad, idx, spos,
-                                      pairs, ev0, ev1, st);
+                                      pairs, nullptr, fa.out, FORM_TILES, 1, ev0, ev1, st);
+    hipEvent_t ev_stop = ev1;
+    if (hybrid) ev1 = nullptr;                                          // (the pair brackets both launches)
     const int Q = sweep_queries_per_lane(cfg);
     if (Q <= 0) return DICP_ERR_ENUM;
     const int units = (n + WAVE * Q - 1) / (WAVE * Q);                  // waves per cloud
@@ -297,14 +305,14 @@ static int sweep_launch(int dtype, const void* src, const void* pose, const void
         const long want = ((long)N * units + BLOCK / WAVE - 1) / (BLOCK / WAVE); const unsigned g8 = (unsigned)((want < 1280 ? want : 1280) + 7) / 8 * 8; \
         hipExtLaunchKernelGGL((knn_sweep_guard_kernel<T, Q, CH>), dim3(g8), dim3(BLOCK), 0, st, ev0, ev1, 0, DICP_SWEEP_ARGS(T), CT, ca.glist, ca.gcount, ca.glist_cap); } while (0)
 #define DICP_SWEEP_CG(T, Q, CH, CT) do { if (ca.guard) DICP_SWEEP_L(T, Q, CH, CT); else DICP_SWEEP_C(T, Q, CH, true, CT); } while (0)
-#define DICP_SWEEP(T, Q, CH) do { SweepCert<T> none{}; DICP_SWEEP_C(T, Q, CH, false, none); } while (0)
+#define DICP_SWEEP(T, Q, CH) do { SweepCert<T> none{}; none.form_in = hybrid ? fa.in : nullptr; none.form_out = fa.out; none.form_mine = 0; none.form_default = fa.dflt; DICP_SWEEP_C(T, Q, CH, false, none); } while (0)
     if (ca.q) {             // certifying search, or the guard launch of a certified iteration
         if (!ca.qu || !ca.dcum || !spos || !qorder || (ca.guard && (!ca.glist || !ca.gcount))) return DICP_ERR_ENUM;
         if (dtype == DICP_F32) {
-            SweepCert<float> c{(float*)ca.q, (float*)ca.qu, (const float*)ca.dcum, ca.dstride, ca.k, ca.count, ca.set, ca.cloud, ca.cm, ca.guard ? ca.pend : nullptr, ca.gdirty, (n + WAVE - 1) / WAVE};
+            SweepCert<float> c{(float*)ca.q, (float*)ca.qu, (const float*)ca.dcum, ca.dstride, ca.k, ca.count, ca.set, ca.cloud, ca.cm, ca.guard ? ca.pend : nullptr, ca.gdirty, (n + WAVE - 1) / WAVE, ca.slist, ca.scount};
             if (cfg == 2) DICP_SWEEP_CG(float, 2, 8, c); else if (cfg == 4) DICP_SWEEP_CG(float, 1, 16, c); else DICP_SWEEP_CG(float, 1, 8, c);
         } else {
-            SweepCert<double> c{(double*)ca.q, (double*)ca.qu, (const double*)ca.dcum, ca.dstride, ca.k, ca.count, ca.set, ca.cloud, ca.cm, ca.guard ? ca.pend : nullptr, ca.gdirty, (n + WAVE - 1) / WAVE};
+            SweepCert<double> c{(double*)ca.q, (double*)ca.qu, (const double*)ca.dcum, ca.dstride, ca.k, ca.count, ca.set, ca.cloud, ca.cm, ca.guard ? ca.pend : nullptr, ca.gdirty, (n + WAVE - 1) / WAVE, ca.slist, ca.scount};
             if (cfg == 2) DICP_SWEEP_CG(double, 2, 8, c); else DICP_SWEEP_CG(double, 1, 8, c);
         }
         return launch_status();
@@ -313,6 +321,11 @@ static int sweep_launch(int dtype, const void* src, const void* pose, const void
         if (cfg == 2) DICP_SWEEP(float, 2, 8); else if (cfg == 4) DICP_SWEEP(float, 1, 16); else DICP_SWEEP(float, 1, 8);
     } else {
         if (cfg == 2) DICP_SWEEP(double, 2, 8); else DICP_SWEEP(double, 1, 8);
+    }
+    if (hybrid) {
+        if (const int rc = launch_status()) return rc;
+        return dicp_tu::knn_f16_sweep(src, pose, tgs4, const_cast<void*>(f16_image), tperm, qorder, bucket, brange, nbkt, rw.src, rw.tgt, N, n, m, m_pad, idx, spos,
+                                      pairs, fa.in, fa.out, FORM_TILES, fa.dflt, nullptr, ev_stop, st);
     }
 #undef DICP_SWEEP
 #undef DICP_SWEEP_C
@@ -324,14 +337,15 @@ static int sweep_launch(int dtype, const void* src, const void* pose, const void
 
 int dicp_knn_sweep(int dtype, const void* src, const void* pose, const void* tgs4, const int32_t* tperm,
                    const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt, const int32_t* src_rows, const int32_t* tgt_rows,
-                   int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg, const void* f16_image, void* stream) {
+                   int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg, const void* f16_image,
+                   const int32_t* form_in, int32_t* form_out, int form_default, void* stream) {
     if (!src || !tgs4 || !tperm || !bucket || !brange || (!idx && !spos)) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || n <= 0 || m <= 0 || nbkt <= 0 || m_pad != dicp_padded_targets(m)) return DICP_ERR_SHAPE;
     if ((uintptr_t)tgs4 % (dtype == DICP_F32 ? 16 : 32)) return DICP_ERR_ALIGN;
     begin_launch();
     return sweep_launch(dtype, src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, N, n, m, m_pad, idx, spos, pairs, cfg, Rows{src_rows, tgt_rows}, (hipStream_t)stream,
-                        CertArgs{}, f16_image);
+                        CertArgs{}, f16_image, FormArgs{form_in, form_out, form_default});
 }
 
 int dicp_gather_rows(int dtype, const void* tgt, const int32_t* idx, int N, int n, int m, int c, void* out, void* stream) {
@@ -397,7 +411,7 @@ static int accumulate_go(int dtype, const dicp_weight_params* prm, const void* s
         AccCert<T> ps{}; \
         if (ca) { \
             ps.spos = ca->spos; ps.hist = ca->hist; ps.hist_prev = ca->hist_prev; ps.of = ca->of; ps.k_floor = ca->k_floor; ps.N = N; ps.nwr = (n + WAVE - 1) / WAVE; ps.k = ca->k; \
-            ps.nbr = (T*)ca->nbr; ps.gdirty = ca->gdirty; ps.pend = ca->pend; ps.cloud = ca->cloud; ps.fresh = ca->fresh; ps.units = ca->units; ps.sets = ca->sets; \
+            ps.nbr = (T*)ca->nbr; ps.gdirty = ca->gdirty; ps.pend = ca->pend; ps.cloud = ca->cloud; ps.fresh = ca->fresh; ps.units = ca->units; ps.sets = ca->sets; ps.scount = ca->scount; \
             if (P.mode == MODE_PT2PL) DICP_ACC(T, MODE_PT2PL, true, ps); else DICP_ACC(T, MODE_PT2PT, true, ps); \
         } else { if (P.mode == MODE_PT2PL) DICP_ACC(T, MODE_PT2PL, false, ps); else DICP_ACC(T, MODE_PT2PT, false, ps); } } while (0)
     if (dtype == DICP_F32) DICP_ACC_T(float); else DICP_ACC_T(double);
@@ -560,7 +574,7 @@ int dicp_kabsch_forward(int dtype, const dicp_kabsch_buffers* B, int N, int n, i
         int rc;
         if (kind == DICP_KNN_SWEEP)
             rc = dicp_knn_sweep(dtype, B->src, pose_s, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, B->rows_live, B->tgt_rows, N, n, m, B->m_pad,
-                                B->idx, nullptr, B->pairs, (B->knn_variant >> 8) & 0xff, B->tgt_f16, stream);
+                                B->idx, nullptr, B->pairs, (B->knn_variant >> 8) & 0xff, B->tgt_f16, nullptr, nullptr, 0, stream);
         else
             rc = dicp_knn(dtype, B->src, pose_s, B->tgt4, B->rows_live, B->tgt_rows, N, n, m, B->m_pad, B->idx, B->knn_variant & 0xffff, B->tgt_f16, stream);
         if (rc) return rc;
@@ -802,7 +816,7 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
             const int cfg_plain = cfg ? cfg : sweep_auto_cfg(N, n);
             const bool cert = B->cert_q && B->cert_qu && B->rmax && B->dcum && spos_k && sorted_rows && !B->idx && B->qorder && sweep_queries_per_lane(cfg_plain) > 0;
             // (the certified iterations keep a row cache and their match history by reference: accumulate_kernel)
-            if (cert && (!B->cert_nbr || !B->cert_gdirty || !B->cert_pend || !B->cert_cm || !B->cert_glist || !B->cert_gcount || (B->idx_per_iter && !B->spos_of))) { set_launch_events(nullptr, nullptr); return DICP_ERR_NULL; }
+            if (cert && (!B->cert_nbr || !B->cert_gdirty || !B->cert_pend || !B->cert_cm || !B->cert_glist || !B->cert_gcount || (B->cert_set && (!B->cert_slist || !B->cert_scount)) || (B->idx_per_iter && !B->spos_of))) { set_launch_events(nullptr, nullptr); return DICP_ERR_NULL; }
             const int cert_units = cert ? (n + WAVE * sweep_queries_per_lane(cfg_plain) - 1) / (WAVE * sweep_queries_per_lane(cfg_plain)) : 0;
             const int glist_cap = N * ((n + WAVE - 1) / WAVE);
             const bool fresh = k == 0 || (k == k0 && B->cert_reset);           // a new query order: every query is searched, every budget written
@@ -814,11 +828,20 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
                 begin_launch();
                 rc = sweep_launch(dtype, B->src, pose_s, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, N, n, m, B->m_pad, nullptr, spos_k,
                                   B->pairs, cfg, Rows{B->src_rows, B->tgt_rows}, st, CertArgs{B->cert_q, B->cert_qu, B->dcum, 2 * (B->K + 1), k, count_k, !fresh, B->cert_cloud, B->cert_set,
-                                                                                              B->cert_cm, B->cert_pend, B->cert_gdirty,
+                                                                                              B->cert_cm, B->cert_pend, B->cert_gdirty, B->cert_set ? B->cert_slist : nullptr, B->cert_set ? B->cert_scount : nullptr,
                                                                                               B->cert_glist, B->cert_gcount ? B->cert_gcount + (size_t)k * 8 : nullptr, glist_cap});
             } else
-            rc = dicp_knn_sweep(dtype, B->src, pose_s, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, B->src_rows, B->tgt_rows, N, n, m, B->m_pad,
-                                B->idx ? idx_k : nullptr, spos_k, B->pairs, cfg, B->tgt_f16, stream);
+            {
+                // plain search.  Scoring form per cloud (sweep_form): the matrix-core form pays where a wave's slab is long -- big clouds, and clouds of any size
+                // whose queries are far from their matches (start poses a metre off; parts of the source without counterpart in the target) -- and loses where
+                // it is a few tiles.  Each plain search tallies its slabs' tiles per cloud; the next one launches both forms, each taking its clouds.
+                const int32_t* form_in = (B->sweep_form && B->tgt_f16 && k > 0) ? B->sweep_form + (size_t)(k - 1) * N : nullptr;     // (all zeros behind a certified iteration: no tally)
+                int32_t* form_out = B->sweep_form ? B->sweep_form + (size_t)k * N : nullptr;
+                const void* img = (form_in || B->sweep_form_default || !B->sweep_form) ? B->tgt_f16 : nullptr;
+                begin_launch();
+                rc = sweep_launch(dtype, B->src, pose_s, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, N, n, m, B->m_pad, B->idx ? idx_k : nullptr, spos_k, B->pairs, cfg,
+                                  Rows{B->src_rows, B->tgt_rows}, st, CertArgs{}, img, FormArgs{form_in, form_out, B->sweep_form_default});
+            }
             set_launch_events(nullptr, nullptr);
             if (rc) return rc;
             if (B->events) set_launch_events((hipEvent_t)B->events[6 * k + 2], (hipEvent_t)B->events[6 * k + 3]);
@@ -826,7 +849,7 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
                 // the accumulate of a certified iteration checks every point's budget and searches the spent ones on the spot; its matches
                 // are the start of the next iteration's (within this call)
                 const CertAcc ca{spos_k, B->spos, B->spos_prev_chunk, B->idx_per_iter ? B->spos_of : nullptr, B->spos_floor, k,
-                                 B->cert_nbr, B->cert_gdirty, B->cert_pend, B->cert_cloud, fresh ? 1 : 0, cert_units, B->cert_set ? 1 : 0};
+                                 B->cert_nbr, B->cert_gdirty, B->cert_pend, B->cert_cloud, fresh ? 1 : 0, cert_units, B->cert_set ? 1 : 0, B->cert_scount};
                 rc = accumulate_go(dtype, prm, B->src, B->tgt_sorted, B->tgt_sorted_stride, spos_k, pose_k, B->w_init, alive_k, B->src_rows, N, n, B->m_pad,
                                    B->partials, w_k, B->w_stride, stream, &ca, w_prev_k);
             } else if (sorted_rows)
@@ -871,6 +894,7 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
             if (Qp > 0) {
                 io.cert_qu = B->cert_qu; io.cert_units = (n + WAVE * Qp - 1) / (WAVE * Qp); io.glist_cap = N * ((n + WAVE - 1) / WAVE);
                 io.glist = B->cert_glist; io.gcount = B->cert_gcount + (size_t)(k + 1) * 8;
+                io.cert_scount = B->cert_set ? B->cert_scount : nullptr;
             }
         }
         rc = dicp_step(dtype, &io, N, stream);
@@ -907,7 +931,7 @@ int dicp_icp_forward_plan(int dtype, const dicp_weight_params* prm, const dicp_l
         B.cert_q = certs ? S->cert_q : nullptr; B.cert_qu = certs ? S->cert_qu : nullptr; B.cert_count = certs ? S->cert_count : nullptr;
         B.cert_cloud = certs ? S->cert_cloud : nullptr;
         B.cert_set = certs ? S->cert_set : nullptr;
-        B.cert_nbr = certs ? S->cert_nbr : nullptr; B.cert_gdirty = certs ? S->cert_gdirty : nullptr; B.cert_pend = certs ? S->cert_pend : nullptr; B.cert_cm = certs ? S->cert_cm : nullptr; B.cert_glist = certs ? S->cert_glist : nullptr; B.cert_gcount = certs ? S->cert_gcount : nullptr;
+        B.cert_nbr = certs ? S->cert_nbr : nullptr; B.cert_gdirty = certs ? S->cert_gdirty : nullptr; B.cert_pend = certs ? S->cert_pend : nullptr; B.cert_cm = certs ? S->cert_cm : nullptr; B.cert_glist = certs ? S->cert_glist : nullptr; B.cert_gcount = certs ? S->cert_gcount : nullptr; B.cert_slist = certs ? S->cert_slist : nullptr; B.cert_scount = certs ? S->cert_scount : nullptr;
         B.cert_reset = (S->cert_from >= 0 && k0 == S->cert_from) ? 1 : 0;
         B.spos_prev_chunk = nullptr; B.spos_floor = 0;
         B.w_prev0 = k0 > 0 ? (const char*)B.w + (size_t)(k0 - 1) * B.w_iter * es : nullptr;

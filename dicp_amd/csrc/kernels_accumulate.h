@@ -122,6 +122,7 @@ __global__ __launch_bounds__(BLOCK, (CERT && sizeof(T) == 4) ? DICP_ACC_CERT_WAV
         }
         cached = !ps.fresh && !(cstate > 0) && cstate != CERT_RECERTIFY;
         if (ps.cloud && !ps.fresh && blk == 0 && threadIdx.x == 0) { ps.cloud[(size_t)cloud * CERT_CLOUD + 3] = ps.units; ps.cloud[(size_t)cloud * CERT_CLOUD + 5] = ps.sets; }
+        if (ps.fresh && ps.scount && blk == 0 && threadIdx.x == 0) ps.scount[cloud] = 0;       // (a new query order: the slots the set lists name are gone)
         if (cached) {
 #pragma unroll
             for (int t = 0; t < ROUNDS; ++t)                // a marked group; a group whose slab belongs to the previous history chunk (copied into this iteration's)
@@ -273,7 +274,7 @@ __host__ __device__ inline dicp_step_io make_step_io(const dicp_loop_buffers& B,
     io.n_not_converged = B.counters + k;
     io.rmax = B.rmax; io.dcum = B.dcum; io.dcum_stride = 2 * (B.K + 1);
     io.cert_cloud = B.cert_cloud;
-    io.cert_qu = nullptr; io.cert_units = 0; io.glist_cap = 0; io.glist = nullptr; io.gcount = nullptr;      // (dicp_icp_forward fills them in for a certified iteration)
+    io.cert_qu = nullptr; io.cert_units = 0; io.glist_cap = 0; io.glist = nullptr; io.gcount = nullptr; io.cert_scount = nullptr;      // (dicp_icp_forward fills them in for a certified iteration)
     io.w_copied = 0;
     return io;
 }
@@ -442,6 +443,21 @@ __device__ __forceinline__ void step_body(const dicp_step_io& io, int cloud, int
                 base = __shfl(base, 0);
                 const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
                 if (work && base + rank < io.glist_cap) list[base + rank] = cloud * io.cert_units + u;
+            }
+        }
+        // ... and the cloud's standing candidate sets, 64 to an entry (guard_sets); a cloud that is searched as a whole has none left afterwards
+        if (io.cert_scount) {
+            if (!certs_on) { if (tid == 0) io.cert_scount[cloud] = 0; }
+            else {
+                const int nwr = (io.n + WAVE - 1) / WAVE;
+                const int nch = (min(io.cert_scount[cloud], io.n) + WAVE - 1) / WAVE;
+                if (nch > 0) {
+                    int base = 0;
+                    if (tid == 0) base = atomicAdd(io.gcount + (cloud & 7), nch);
+                    base = __shfl(base, 0);
+                    for (int c = tid; c < nch; c += WAVE)
+                        if (base + c < io.glist_cap) list[base + c] = -1 - (cloud * nwr + c);
+                }
             }
         }
     }

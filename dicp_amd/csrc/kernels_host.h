@@ -19,7 +19,7 @@ inline unsigned blocks_for(size_t total) { return (unsigned)((total + BLOCK - 1)
 
 struct CertAcc {              // what the accumulate of a certified iteration needs (AccCert, untyped)
     int32_t* spos; const int32_t* hist; const int32_t* hist_prev; int32_t* of; int k_floor, k;
-    void* nbr; int32_t* gdirty; int32_t* pend; int32_t* cloud; int fresh, units, sets;
+    void* nbr; int32_t* gdirty; int32_t* pend; int32_t* cloud; int fresh, units, sets; int32_t* scount;
 };
 
 template <typename T, int Q, int CH, int MINW = 1>

@@ -137,7 +137,21 @@ template <typename T> struct SweepCert {
                                     // iteration, which owns the history's slabs and the cached rows (accumulate_kernel) ...
     int32_t* gdirty;                // (N,nwr) by group of 64 queries: ... and is told so here (1: some pend of the group is set)
     int nwr;
+    int32_t* slist; int32_t* scount;    // (N,n) / (N) zeros: per cloud, the slots that were given a candidate set (appended by the search that made it; entries whose set
+                                    // no longer stands are skipped, the list is emptied when the whole cloud is searched again).  The guard launch re-scores the
+                                    // standing sets 64 to a wave from this list: a unit whose only open queries have sets is not looked at for them
+    // Plain searches of the loop, scoring form per cloud (dicp_loop_buffers.sweep_form): form_out[cloud] += the 64-row tiles this unit's slab had; a launch given
+    // form_in (the previous plain search's tally) leaves a cloud alone unless its slabs were long (form_mine = 1: the matrix-core form) / short (0: this one)
+    const int32_t* form_in; int32_t* form_out; int form_mine, form_default;     // (form_default: the form of a cloud without a tally -- 0 in form_in: no plain search before)
 };
+constexpr int FORM_TILES = 20;      // tiles per unit from which on a cloud's plain searches score on the matrix cores: a wave's fixed cost there (prologue, margins, the exact
+                                    // refine of the winners' rows) is ~16 tiles' worth of VALU scoring (profiles/r04_knn_f16_sweep.txt: 0.92x at 16 tiles, 1.27x at 32)
+__device__ __forceinline__ bool form_is_mine(const int32_t* __restrict__ form_in, int form_mine, int form_default, int cloud, int queries) {
+    if (!form_in) return true;
+    const int units = (queries + 2 * WAVE - 1) / (2 * WAVE), tally = form_in[cloud];     // (units of 128 queries: the matrix-core form's)
+    const bool lng = tally > 0 ? tally > FORM_TILES * units : form_default != 0;
+    return lng == (form_mine != 0);
+}
 constexpr int CERT_CANDS = 4;       // rows of a candidate set
 template <typename T> __device__ __forceinline__ T* set_budgets(void* set) { return (T*)set; }
 template <typename T> __device__ __forceinline__ int32_t* set_cands(void* set, int N, int n) { return (int32_t*)((char*)set + (size_t)N * n * sizeof(T)); }
@@ -444,6 +458,7 @@ __device__ __forceinline__ void sweep_unit(const T* __restrict__ src, const T* _
     // sharded: one counter serialises ~12 ns per add, which at 65k waves would outlast the kernel itself
     if (pairs && lane == 0 && !idle_wave)
         atomicAdd(pairs + (blockIdx.x & (DICP_PAIR_SHARDS - 1)), (unsigned long long)(visR - visL) * WAVE * WAVE * Q);
+    if (ct.form_out && lane == 0 && (Q > 1 || !(unit & 1))) atomicAdd(ct.form_out + cloud, visR - visL);      // (per 128 queries: the one-query-per-lane forms tally every other unit)
 }
 
 #define DICP_SWEEP_PARAMS const T* __restrict__ src, const T* __restrict__ pose, const typename V4<T>::type* __restrict__ tgs4, \
@@ -458,6 +473,7 @@ __global__ __launch_bounds__(BLOCK, DICP_SWEEP_MINW) void knn_sweep_kernel(DICP_
     __shared__ typename V4<T>::type tiles[BLOCK / WAVE][SweepRing<T>::NT * WAVE];
     int cloud, blk;
     if (!decode_block(bpc, N, cloud, blk)) return;
+    if (!CERT && !form_is_mine(ct.form_in, ct.form_mine, ct.form_default, cloud, rows_of(src_rows, cloud, n_full))) return;      // (this cloud's slabs were long: the matrix-core launch has it)
     const int wave = threadIdx.x >> 6;
     sweep_unit<T, Q, CH, CERT>(src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, idx, spos, pairs, n_full, m_full, m_pad, src_rows, tgt_rows, ct,
                                cloud, blk * (BLOCK / WAVE) + wave, tiles[wave]);
@@ -485,6 +501,7 @@ template <typename T> struct AccCert {
                                                     // iteration ran": the cloud's units, whether candidate sets are kept) -- the guard launch has no block per cloud
     int fresh;                                      // the search of this iteration has just written EVERY match into `spos` (the certifying search): everything is gathered and cached
     int units, sets;
+    int32_t* scount;                                // (N) lengths of the candidate-set lists (SweepCert::scount): emptied behind a certifying search of everything
 };
 
 // The search of ONE query by one wave (all lanes carry the same arguments): the query's previous match, scored under the current
@@ -613,7 +630,6 @@ __device__ __forceinline__ int search_point(const SearchCtx<T>& ps, const int cl
 // current matches) goes by slot, so a unit's share of it is one coalesced piece.
 template <typename T, int Q, int CH>
 __device__ __forceinline__ void guard_unit(DICP_SWEEP_PARAMS, const int cloud, const int unit, typename V4<T>::type* __restrict__ ring) {
-    using T4 = typename V4<T>::type;
     const int lane = threadIdx.x & (WAVE - 1);
     const int units = (n_full + WAVE * Q - 1) / (WAVE * Q);
     const int n = rows_of(src_rows, cloud, n_full);
@@ -626,14 +642,10 @@ __device__ __forceinline__ void guard_unit(DICP_SWEEP_PARAMS, const int cloud, c
     bool plain = false, research = true;
     const int cstate = ct.cloud ? ct.cloud[(size_t)cloud * CERT_CLOUD + 2] : 0;
     // what the unit's queries need: 0 nothing (the budget stands) / 1 the candidate set re-scored / 2 a search of their own
-    int need[Q], cmv[Q], qiv[Q], cjv[Q][CERT_CANDS];
+    int need[Q], cmv[Q], qiv[Q];
     T bud[Q];
 #pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        need[q] = 0; bud[q] = inf_v<T>(); cmv[q] = -1; qiv[q] = 0;
-#pragma unroll
-        for (int c = 0; c < CERT_CANDS; ++c) cjv[q][c] = -1;
-    }
+    for (int q = 0; q < Q; ++q) { need[q] = 0; bud[q] = inf_v<T>(); cmv[q] = -1; qiv[q] = 0; }
     T* __restrict__ qs = ct.set ? set_budgets<T>(ct.set) : nullptr;
     int32_t* __restrict__ cands = ct.set ? set_cands<T>(ct.set, N, n_full) : nullptr;
     if (cstate > 0) plain = true;                               // this cloud's certificates are off (step kernel): every unit, plainly
@@ -653,8 +665,6 @@ __device__ __forceinline__ void guard_unit(DICP_SWEEP_PARAMS, const int cloud, c
             sq[q] = qs ? qs[at] : T(-2);
             cmv[q] = ct.cm[at];
             qiv[q] = qorder ? qorder[at] : min(pos, n - 1);
-#pragma unroll
-            for (int c = 0; c < CERT_CANDS; ++c) cjv[q][c] = cands ? cands[at * CERT_CANDS + c] : -1;
         }
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
@@ -668,7 +678,7 @@ __device__ __forceinline__ void guard_unit(DICP_SWEEP_PARAMS, const int cloud, c
                     // (b < 0: a mark) may have a candidate set: one that stands is as good as a budget; none tried yet (-1): its search below
                     // will try; "no set either" (-2) or a spent set count against the unit.
                     const T sb = (qs && b < T(0)) ? sq[q] : T(-2);
-                    if (sb > spent) need[q] = 1;
+                    if (sb > spent) bud[q] = sb;                // (a standing set: re-scored from the cloud's list, guard_sets; as good as a budget here)
                     else { need[q] = 2; if (sb != T(-1)) ++bad; }
                 }
             }
@@ -703,48 +713,24 @@ __device__ __forceinline__ void guard_unit(DICP_SWEEP_PARAMS, const int cloud, c
     }
     // ---- the unit's open queries, one by one
     const SearchCtx<T> sc{tgs4, tperm, bucket, brange, nbkt, tgt_rows, m_full, m_pad, ct};
-    const T4* __restrict__ tg = tgs4 + (size_t)cloud * m_pad;
-    const int32_t* __restrict__ pm = tperm + (size_t)cloud * m_pad;
     T C[9], r[3];
     load_pose(pose, cloud, C, r);
     unsigned long long rows_scored = 0;
-    int singles = 0, rescored = 0;
+    int singles = 0;
     T qmin = inf_v<T>();
-    bool open = false;                                          // this lane keeps a query that must be looked at again in the next iteration
+    bool open = false;                                          // this lane keeps a query that must be searched again in the next iteration
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         const int pos = unit * (WAVE * Q) + q * WAVE + lane;
         const size_t at = (size_t)cloud * n_full + min(pos, n - 1);
         const int qi = qiv[q], cur = cmv[q];
         T nx[3] = {T(0), T(0), T(0)};
-        int cj[CERT_CANDS];
-        T4 row[CERT_CANDS];
-#pragma unroll
-        for (int c = 0; c < CERT_CANDS; ++c) { cj[c] = cjv[q][c]; row[c] = T4{}; }
-        if (need[q]) {                                          // (the query and, for a set, its four rows: the second and last round of loads)
+        if (need[q]) {
             const T* sp = src + ((size_t)cloud * n_full + qi) * 3;
             const T p[3] = {sp[0], sp[1], sp[2]};
-            if (need[q] == 1) {
-#pragma unroll
-                for (int c = 0; c < CERT_CANDS; ++c) row[c] = tg[max(cj[c], 0)];
-            }
             query_point(C, r, p, nx);
         }
         int found = cur;
-        if (need[q] == 1) {
-            // the new match is the set's best row (same score(), equal scores -> lowest original index; the set's first row is the old match: never empty)
-            T best = inf_v<T>();
-            int bj = max(cj[0], 0);
-#pragma unroll
-            for (int c = 0; c < CERT_CANDS; ++c) {
-                const T scv = cj[c] >= 0 ? score<T, T4>(nx, row[c]) : inf_v<T>();
-                if (scv < best) { best = scv; bj = cj[c]; }
-                else if (scv == best && scv < inf_v<T>() && pm[cj[c]] < pm[bj]) bj = cj[c];
-            }
-            found = bj;
-            ++rescored;
-            open = true;                                        // (a set is re-scored in every iteration)
-        }
         // spent, never certifiable, NaN: searched by the whole wave, one query at a time
         unsigned long long todo = __ballot(need[q] == 2);
         T nb = T(-1), ns = T(-2);
@@ -768,14 +754,19 @@ __device__ __forceinline__ void guard_unit(DICP_SWEEP_PARAMS, const int cloud, c
         if (need[q] == 2) {
             ct.q[at] = nb;
             if (qs) {
+                if (!(nb > T(0)) && ns > T(0)) {                    // a candidate set: onto the cloud's list (full: no set, the query is searched in every iteration)
+                    const int e = atomicAdd(ct.scount + cloud, 1);
+                    if (e < n_full) ct.slist[(size_t)cloud * n_full + e] = (int)(at - (size_t)cloud * n_full);
+                    else ns = T(-2);
+                }
                 qs[at] = nb > T(0) ? T(-1) : ns;
                 if (ns > T(0)) {
 #pragma unroll
                     for (int c = 0; c < CERT_CANDS; ++c) cands[at * CERT_CANDS + c] = nc[c];
                 }
             }
-            bud[q] = nb;
-            if (!(nb > spent)) open = true;
+            bud[q] = nb > spent ? nb : (ns > spent ? ns : nb);
+            if (!(bud[q] > spent)) open = true;
         }
         if (need[q] && found != cur) {                          // a match that changed: for the accumulate of this iteration
             ct.cm[at] = found;
@@ -790,17 +781,64 @@ __device__ __forceinline__ void guard_unit(DICP_SWEEP_PARAMS, const int cloud, c
     qmin = wave_min(qmin);
     const bool any_open = __any(open) != 0;
     if (lane == 0) *qu = any_open ? T(0) : qmin;
-    // the statistics last (a wave's loads return behind its earlier atomics); a re-scored candidate set costs about a twelfth of a single-query
-    // search (4 gathered rows against a slab): counted as such for the per-cloud switch
-    int resc = rescored;
-#pragma unroll
-    for (int o = WAVE / 2; o > 0; o >>= 1) resc += __shfl_xor(resc, o);
-    const int eq = singles + resc / 12;
+    // the statistics last (a wave's loads return behind its earlier atomics)
+    const int eq = singles;
     if (eq > 0 && lane == 0) {
         if (pairs && rows_scored) atomicAdd(pairs + (blockIdx.x & (DICP_PAIR_SHARDS - 1)), rows_scored);
         if (ct.count && singles) atomicAdd(ct.count + CERT_SHARDS + (blockIdx.x & (CERT_SHARDS - 1)), singles);
         if (ct.cloud) atomicAdd(ct.cloud + (size_t)cloud * CERT_CLOUD + 1, eq);
     }
+}
+
+// The standing candidate sets of one cloud, 64 to a wave (entries [64 chunk, 64 chunk + 64) of the cloud's list): the new match of each is the set's best
+// row under this iteration's pose -- same score(), equal scores -> lowest original index; the set's first row is the old match: never empty.  Four gathered
+// rows per query instead of a search; a re-scored set counts a twelfth of a single-query search for the per-cloud switch.
+template <typename T>
+__device__ __forceinline__ void guard_sets(const T* __restrict__ src, const T* __restrict__ pose, const typename V4<T>::type* __restrict__ tgs4,
+                                           const int32_t* __restrict__ tperm, const int32_t* __restrict__ qorder, int32_t* __restrict__ spos,
+                                           int N, int n_full, int m_pad, const SweepCert<T>& ct, const int cloud, const int chunk) {
+    using T4 = typename V4<T>::type;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int cnt = min(ct.scount[cloud], n_full), e = chunk * WAVE + lane;
+    const bool have = e < cnt;
+    const size_t at = (size_t)cloud * n_full + (have ? min(max(ct.slist[(size_t)cloud * n_full + e], 0), n_full - 1) : 0);
+    const T spent = cert_spent(ct.dcum + (size_t)cloud * ct.dstride + 2 * ct.k);
+    const T b = ct.q[at], sb = set_budgets<T>(ct.set)[at];
+    const bool on = have && !(b > spent) && b < T(0) && sb > spent;        // (the set still stands, and the query has no budget of its own)
+    int rescored = 0;
+    if (on) {
+        const int32_t* cd = set_cands<T>(ct.set, N, n_full) + at * CERT_CANDS;
+        const int cur = ct.cm[at], qi = qorder ? qorder[at] : (int)(at - (size_t)cloud * n_full);
+        int cj[CERT_CANDS];
+#pragma unroll
+        for (int c = 0; c < CERT_CANDS; ++c) cj[c] = cd[c];
+        const T4* __restrict__ tg = tgs4 + (size_t)cloud * m_pad;
+        const int32_t* __restrict__ pm = tperm + (size_t)cloud * m_pad;
+        T4 row[CERT_CANDS];
+#pragma unroll
+        for (int c = 0; c < CERT_CANDS; ++c) row[c] = tg[max(cj[c], 0)];       // (all four gathers in flight together)
+        const T* sp = src + ((size_t)cloud * n_full + qi) * 3;
+        const T p[3] = {sp[0], sp[1], sp[2]};
+        T C[9], r[3], nx[3];
+        load_pose(pose, cloud, C, r);
+        query_point(C, r, p, nx);
+        T best = inf_v<T>();
+        int bj = max(cj[0], 0);
+#pragma unroll
+        for (int c = 0; c < CERT_CANDS; ++c) {
+            const T scv = cj[c] >= 0 ? score<T, T4>(nx, row[c]) : inf_v<T>();
+            if (scv < best) { best = scv; bj = cj[c]; }
+            else if (scv == best && scv < inf_v<T>() && pm[cj[c]] < pm[bj]) bj = cj[c];
+        }
+        if (bj != cur) {                                            // a match that changed: for the accumulate of this iteration
+            ct.cm[at] = bj;
+            if (ct.pend) { ct.pend[(size_t)cloud * n_full + qi] = bj + 2; ct.gdirty[(size_t)cloud * ct.nwr + (qi >> 6)] = 1; }
+            else if (spos) spos[(size_t)cloud * n_full + qi] = bj;
+        }
+        rescored = 1;
+    }
+    const int resc = __popcll(__ballot(rescored != 0));
+    if (lane == 0 && ct.cloud && resc >= 12) atomicAdd(ct.cloud + (size_t)cloud * CERT_CLOUD + 1, resc / 12);
 }
 
 // The guard launch: a small grid of waves working through the lists the previous iteration's step kernel made (dicp_step_io.glist: the units that
@@ -817,6 +855,11 @@ __global__ __launch_bounds__(BLOCK, DICP_SWEEP_MINW) void knn_sweep_guard_kernel
     const int stride = (int)(gridDim.x >> 3) * (BLOCK / WAVE);
     for (int e = (int)(blockIdx.x >> 3) * (BLOCK / WAVE) + wave; e < count; e += stride) {      // (wave-uniform)
         const int entry = list[e];
+        if (entry < 0) {                                            // 64 of a cloud's candidate sets: -1 - (cloud nwr + chunk)
+            const int id = -1 - entry, cloud = id / ct.nwr;
+            if (cloud < N && ct.set && ct.slist) guard_sets<T>(src, pose, tgs4, tperm, qorder, spos, N, n_full, m_pad, ct, cloud, id - cloud * ct.nwr);
+            continue;
+        }
         const int cloud = entry / units, unit = entry - cloud * units;
         if (cloud >= N) continue;
         guard_unit<T, Q, CH>(src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, idx, spos, pairs, N, n_full, m_full, m_pad, bpc, src_rows, tgt_rows, ct,

@@ -65,6 +65,17 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 }
 
 // per cloud: the scale and the far rows.  One block per cloud.
+// Which clouds a launch concerns (the loop's per-cloud choice of the scoring form, dicp_loop_buffers.sweep_form): those whose last plain search tallied more than
+// `tiles` 64-row tiles per unit of 128 queries (no tally: if dflt).
+struct FormPick {
+    const int32_t* tally; const int32_t* src_rows; int n_full, tiles, dflt;
+};
+__device__ __forceinline__ bool form_long(const FormPick& f, int cloud) {
+    if (!f.tally) return true;
+    const int t = f.tally[cloud], units = (rows_of(f.src_rows, cloud, f.n_full) + 32 * F16_G - 1) / (32 * F16_G);
+    return t > 0 ? t > f.tiles * units : f.dflt != 0;
+}
+
 __global__ __launch_bounds__(F16_SCALE_THREADS) void knn_f16_scale_kernel(const float4* __restrict__ rows4, const int32_t* __restrict__ tgt_rows, int m_full, int m_pad,
                                                               float* __restrict__ meta_all) {
     __shared__ float red[F16_SCALE_THREADS / WAVE];
@@ -522,23 +533,20 @@ __device__ __forceinline__ void sweep_merge(SweepBest& b, float ov, int os, int 
     }
 }
 
-template <int MINW>
-__global__ __launch_bounds__(BLOCK, MINW) void knn_f16_sweep_kernel(const float* __restrict__ src, const float* __restrict__ pose, const float4* __restrict__ tgs4,
+__device__ __forceinline__ void f16_sweep_unit(const float* __restrict__ src, const float* __restrict__ pose, const float4* __restrict__ tgs4,
                                                                     const uint4* __restrict__ image, float* __restrict__ meta_all,
                                                                     const int32_t* __restrict__ tperm, const int32_t* __restrict__ qorder,
                                                                     const int32_t* __restrict__ bucket, const float* __restrict__ brange, int nbkt,
                                                                     int32_t* __restrict__ idx, int32_t* __restrict__ spos, unsigned long long* __restrict__ pairs,
                                                                     int N, int n_full, int m_full, int m_pad, int tiles_per_cloud, int bpc,
                                                                     const int32_t* __restrict__ src_rows, const int32_t* __restrict__ tgt_rows,
-                                                                    const float* __restrict__ edges_all) {
+                                                                    const float* __restrict__ edges_all, int32_t* __restrict__ form_out, const int cloud, const int blk) {
     __shared__ float4 qlist[BLOCK / WAVE][32];
     __shared__ int qslot[BLOCK / WAVE][32];
     // the float32 rows of the F16_NTC tiles around the wave's first one (copied by LDS-DMA beside the scoring): where the winners are -- a
     // match is at most its own distance away in x -- so the refine reads its rows from LDS instead of gathering 512 bytes per query from L2
     // (2 GB per launch at the benchmark shape: that gather was half of the kernel)
     __shared__ float4 rowcache[BLOCK / WAVE][F16_NTC * WAVE];
-    int cloud, blk;
-    if (!decode_block(bpc, N, cloud, blk)) return;
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
     const int unit = blk * (BLOCK / WAVE) + wave;
     const int n = rows_of(src_rows, cloud, n_full), m = min(max(rows_of(tgt_rows, cloud, m_full), 1), m_pad);
@@ -676,7 +684,10 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_f16_sweep_kernel(const float*
     // are only ever indexed by constants), the cloud's constants in scalar registers, and the rows of a query fetched eight at a time.
     const int32_t* __restrict__ pm = tperm + (size_t)cloud * m_pad;
     const int nfar = ((const int32_t*)mt)[FM_NFAR];
-    SweepBest best[F16_G];
+    // (the best row per query as three plain register arrays, indexed by constants only: as an array of structs picked from inside the rare loops below
+    //  it lived in scratch memory -- 128 bytes per lane, 6.9 M scratch writes per launch, a reload behind every update; profiles/r04_knn_c4_65536_pmc.txt)
+    float bV[F16_G];
+    int bS[F16_G], bO[F16_G];
     float thr[F16_G];
     int run0[F16_G], run1[F16_G];       // this lane's rows to re-score per query: up to two runs of 16 (-1: none)
     int n_scan = 0, my_unsure = 0, my_scan = 0, ties = 0;       // (ties: bit g = this query's rows are taken again by the careful loop below)
@@ -697,7 +708,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_f16_sweep_kernel(const float*
         const float margin = f16_margin(nx[g], B1, s, inv_s2, phi, hphi);
         const bool bounded = ((q_ok >> g) & 1) && (B1 < __builtin_huge_valf()) && (B1 > -__builtin_huge_valf()) && margin >= 0.f;
         const int ncand = !bounded ? 0 : (B2 - B1 > margin ? 1 : (B3 - B1 > margin ? 2 : 3));
-        best[g].v = __builtin_huge_valf(); best[g].s = 0; best[g].o = 0x7fffffff;
+        bV[g] = __builtin_huge_valf(); bS[g] = 0; bO[g] = 0x7fffffff;
         thr[g] = B1 + margin;
         run0[g] = run1[g] = -1;
         if (ncand == 1) run0[g] = c1 * 64 + 32 * kh + 16 * h1;                            // the winner's piece, half each
@@ -743,18 +754,22 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_f16_sweep_kernel(const float*
 #pragma unroll
             for (int k = 1; k < 16; ++k) last = (sc[k] == mn) ? k : last;
             const bool use = r0 >= 0 && mn < __builtin_huge_valf();
-            if (use && (first != last || mn == best[g].v)) ties |= 1 << g;
-            const bool lt = use && mn < best[g].v;
-            best[g].v = lt ? mn : best[g].v;
-            best[g].s = lt ? r0 + first : best[g].s;
+            if (use && (first != last || mn == bV[g])) ties |= 1 << g;
+            const bool lt = use && mn < bV[g];
+            bV[g] = lt ? mn : bV[g];
+            bS[g] = lt ? r0 + first : bS[g];
         }
     }
     // The rare paths below run over the four B tiles in a LOOP (one copy of the code, the tile's values picked with selects): unrolled four times they
     // made the kernel 40 KB of instructions that every wave streamed through once -- the instruction fetches cost more than the scoring.
-    auto pick = [&](const auto* a, int g) { auto r = a[0]; if (g == 1) r = a[1]; if (g == 2) r = a[2]; if (g == 3) r = a[3]; return r; };
+    static_assert(F16_G == 4, "pick4 below picks one of four");
+#define DICP_PICK4(a, g) ((g) == 0 ? (a)[0] : ((g) == 1 ? (a)[1] : ((g) == 2 ? (a)[2] : (a)[3])))      /* selects over constant indices: the arrays stay in registers */
     auto put_best = [&](int g, bool mine, const SweepBest& w) {
 #pragma unroll
-        for (int i = 0; i < F16_G; ++i) if (g == i && mine) best[i] = w;
+        for (int i = 0; i < F16_G; ++i) {
+            const bool on = g == i && mine;
+            bV[i] = on ? w.v : bV[i]; bS[i] = on ? w.s : bS[i]; bO[i] = on ? w.o : bO[i];
+        }
     };
     // exact ties inside a lane's rows (duplicated targets): those rows again, with the rule -- the lowest ORIGINAL index among equal scores
     if (__any(ties != 0)) {
@@ -764,12 +779,12 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_f16_sweep_kernel(const float*
             if (!__any(mine)) continue;
             float qq[3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { const float c[4] = {nx[0][k], nx[1][k], nx[2][k], nx[3][k]}; qq[k] = pick(c, g); }
+            for (int k = 0; k < 3; ++k) qq[k] = g == 0 ? nx[0][k] : (g == 1 ? nx[1][k] : (g == 2 ? nx[2][k] : nx[3][k]));
             SweepBest w;
             w.v = __builtin_huge_valf(); w.s = 0; w.o = 0x7fffffff;
 #pragma unroll 1
             for (int rn = 0; rn < 2; ++rn) {
-                const int r0 = mine ? (rn ? pick(run1, g) : pick(run0, g)) : -1;
+                const int r0 = mine ? (rn ? DICP_PICK4(run1, g) : DICP_PICK4(run0, g)) : -1;
 #pragma unroll 1
                 for (int k = 0; k < 16; ++k)
                     if (r0 >= 0 && r0 + k < m) sweep_consider(w, qq, row_at(r0 + k), r0 + k, pm);
@@ -779,9 +794,14 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_f16_sweep_kernel(const float*
     }
 #pragma unroll
     for (int g = 0; g < F16_G; ++g) {
-        if (!((ties >> g) & 1) && best[g].v < __builtin_huge_valf()) best[g].o = -1;      // (original index not looked up yet)
+        if (!((ties >> g) & 1) && bV[g] < __builtin_huge_valf()) bO[g] = -1;      // (original index not looked up yet)
         // (one or two candidate pieces: the query's two lanes hold a part each.  Lanes of a pair took the same branch: their tracks were merged)
-        if (__any(run0[g] >= 0)) sweep_merge(best[g], swap32(best[g].v), swap32(best[g].s), swap32(best[g].o), pm);
+        if (__any(run0[g] >= 0)) {
+            SweepBest t;
+            t.v = bV[g]; t.s = bS[g]; t.o = bO[g];
+            sweep_merge(t, swap32(bV[g]), swap32(bS[g]), swap32(bO[g]), pm);
+            bV[g] = t.v; bS[g] = t.s; bO[g] = t.o;
+        }
     }
     // queries the filter has no bound for: every visited row, 64 at a time (such a wave never pruned: it visited every tile)
     if (__any(my_scan != 0)) {
@@ -790,7 +810,7 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_f16_sweep_kernel(const float*
             unsigned long long need = __ballot((my_scan >> g) & 1);
             float qq[3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { const float c[4] = {nx[0][k], nx[1][k], nx[2][k], nx[3][k]}; qq[k] = pick(c, g); }
+            for (int k = 0; k < 3; ++k) qq[k] = g == 0 ? nx[0][k] : (g == 1 ? nx[1][k] : (g == 2 ? nx[2][k] : nx[3][k]));
             while (need) {
                 const int L = __builtin_ctzll(need);
                 need &= need - 1;
@@ -819,12 +839,12 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_f16_sweep_kernel(const float*
             for (int g = 0; g < F16_G; ++g) {
                 const bool mineg = ((my_unsure >> g) & 1) && kh == 0;
                 const unsigned long long mask = __ballot(mineg);
-                const int rank = pick(base, g) + __popcll(mask & ((1ull << lane) - 1)) - 32 * rd;
+                const int rank = DICP_PICK4(base, g) + __popcll(mask & ((1ull << lane) - 1)) - 32 * rd;
                 if (mineg && rank >= 0 && rank < 32) {
                     float qq[3];
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) { const float c[4] = {nx[0][k], nx[1][k], nx[2][k], nx[3][k]}; qq[k] = pick(c, g); }
-                    qlist[wave][rank] = make_float4(qq[0], qq[1], qq[2], pick(thr, g));
+                    for (int k = 0; k < 3; ++k) qq[k] = g == 0 ? nx[0][k] : (g == 1 ? nx[1][k] : (g == 2 ? nx[2][k] : nx[3][k]));
+                    qlist[wave][rank] = make_float4(qq[0], qq[1], qq[2], DICP_PICK4(thr, g));
                     qslot[wave][rank] = (g << 8) | col;
                 }
             }
@@ -864,8 +884,9 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_f16_sweep_kernel(const float*
         for (int g = 0; g < F16_G; ++g) {
             float qq[3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { const float c[4] = {nx[0][k], nx[1][k], nx[2][k], nx[3][k]}; qq[k] = pick(c, g); }
-            SweepBest w = pick(best, g);
+            for (int k = 0; k < 3; ++k) qq[k] = g == 0 ? nx[0][k] : (g == 1 ? nx[1][k] : (g == 2 ? nx[2][k] : nx[3][k]));
+            SweepBest w;
+            w.v = DICP_PICK4(bV, g); w.s = DICP_PICK4(bS, g); w.o = DICP_PICK4(bO, g);
 #pragma unroll 1
             for (int f = 0; f < nfar; ++f) {
                 const int rr = ((const int32_t*)mt)[FM_FAR0 + f];
@@ -877,18 +898,38 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_f16_sweep_kernel(const float*
 #pragma unroll
     for (int g = 0; g < F16_G; ++g) {
         if (qi[g] < 0 || kh != 0) continue;
-        const bool found = best[g].v < __builtin_huge_valf();
-        int bo = best[g].o;
-        if (found && bo < 0) bo = pm[best[g].s];
+        const bool found = bV[g] < __builtin_huge_valf();
+        int bo = bO[g];
+        if (found && bo < 0) bo = pm[bS[g]];
         if (!found) bo = 0x7fffffff;
         if (idx) idx[(size_t)cloud * n_full + qi[g]] = (bo == 0x7fffffff) ? 0 : min(max(bo, 0), m - 1);
-        if (spos) spos[(size_t)cloud * n_full + qi[g]] = (bo == 0x7fffffff || bo >= m) ? -1 : best[g].s;
+        if (spos) spos[(size_t)cloud * n_full + qi[g]] = (bo == 0x7fffffff || bo >= m) ? -1 : bS[g];
     }
     if (lane == 0) {
         if (cnt) atomicAdd((int*)mt + FM_AGAIN, cnt);
         if (n_scan) atomicAdd((int*)mt + FM_SCAN, n_scan);
         if (pairs) atomicAdd(pairs + (blockIdx.x & (DICP_PAIR_SHARDS - 1)), (unsigned long long)(visR - visL) * WAVE * (32 * F16_G));
+        if (form_out) atomicAdd(form_out + cloud, visR - visL);
     }
+}
+#undef DICP_PICK4
+
+// The launch: one block per 4 units of every cloud; given the clouds' tallies (the loop's per-cloud choice of the form) the blocks of a cloud whose slabs were
+// short leave at once -- the vector form's launch has it.
+template <int MINW>
+__global__ __launch_bounds__(BLOCK, MINW) void knn_f16_sweep_kernel(const float* __restrict__ src, const float* __restrict__ pose, const float4* __restrict__ tgs4,
+                                                                    const uint4* __restrict__ image, float* __restrict__ meta_all,
+                                                                    const int32_t* __restrict__ tperm, const int32_t* __restrict__ qorder,
+                                                                    const int32_t* __restrict__ bucket, const float* __restrict__ brange, int nbkt,
+                                                                    int32_t* __restrict__ idx, int32_t* __restrict__ spos, unsigned long long* __restrict__ pairs,
+                                                                    int N, int n_full, int m_full, int m_pad, int tiles_per_cloud, int bpc,
+                                                                    const int32_t* __restrict__ src_rows, const int32_t* __restrict__ tgt_rows,
+                                                                    const float* __restrict__ edges_all, FormPick pick, int32_t* __restrict__ form_out) {
+    int cloud, blk;
+    if (!decode_block(bpc, N, cloud, blk)) return;
+    if (!form_long(pick, cloud)) return;
+    f16_sweep_unit(src, pose, tgs4, image, meta_all, tperm, qorder, bucket, brange, nbkt, idx, spos, pairs, N, n_full, m_full, m_pad, tiles_per_cloud, bpc,
+                   src_rows, tgt_rows, edges_all, form_out, cloud, blk);
 }
 
 }  // namespace
@@ -925,7 +966,7 @@ int knn_f16_brute(const void* src, const void* pose, const void* tgt4, void* ima
 
 int knn_f16_sweep(const void* src, const void* pose, const void* tgs4, void* image, const int32_t* tperm, const int32_t* qorder, const int32_t* bucket,
                   const void* brange, int nbkt, const int32_t* src_rows, const int32_t* tgt_rows, int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos,
-                  unsigned long long* pairs, void* ev0, void* ev1, void* stream) {
+                  unsigned long long* pairs, const int32_t* form_in, int32_t* form_out, int form_tiles, int form_default, void* ev0, void* ev1, void* stream) {
     if (!src || !tgs4 || !image || !tperm || !bucket || !brange || (!idx && !spos)) return DICP_ERR_NULL;
     if (N <= 0 || n <= 0 || m <= 0 || m_pad < m || (m_pad % WAVE)) return DICP_ERR_SHAPE;
     const int m_img = knn_f16_image_rows(m_pad), tiles = m_img / 32;
@@ -933,10 +974,11 @@ int knn_f16_sweep(const void* src, const void* pose, const void* tgs4, void* ima
     const float* edges = (const float*)((const char*)image + knn_f16_edges_offset(N, m_pad));
     const int units = (n + 32 * F16_G - 1) / (32 * F16_G);
     const int bpc = (units + BLOCK / WAVE - 1) / (BLOCK / WAVE);
+    const FormPick pick{form_in, src_rows, n, form_tiles, form_default};
     begin_launch();
     hipExtLaunchKernelGGL((knn_f16_sweep_kernel<4>), dim3(grid_for(N, bpc)), dim3(BLOCK), 0, (hipStream_t)stream, (hipEvent_t)ev0, (hipEvent_t)ev1, 0,
                           (const float*)src, (const float*)pose, (const float4*)tgs4, (const uint4*)image, meta, tperm, qorder, bucket, (const float*)brange, nbkt,
-                          idx, spos, pairs, N, n, m, m_pad, tiles, bpc, src_rows, tgt_rows, edges);
+                          idx, spos, pairs, N, n, m, m_pad, tiles, bpc, src_rows, tgt_rows, edges, pick, form_out);
     return launch_status();
 }
 

@@ -88,3 +88,75 @@ def make_scene_pairs(N, n, m, seed=0, dtype=torch.float32, noise=0.01, max_rot=0
     if device is not None:
         src, tgt = src.to(device), tgt.to(device)
     return src, tgt
+
+
+def make_independent_pairs(N, n, m, seed=0, dtype=torch.float32, noise=0.01, max_rot=0.2, max_trans=1.0, device=None, first=0,
+                           shift=6.0, clutter=0.10, ragged=True):
+    """Scan pairs that share NO point: source and target are sampled independently from the same surfaces (a 26 m corridor: ground, two
+    long walls, four partition walls across it, six pillars), each inside its own 20 m footprint -- the two footprints are `shift` metres
+    apart along the corridor, so 30 % of either cloud has nothing to match in the other --, each with its own sensor noise and its own
+    `clutter` share of points in the free volume (no counterpart at all).  The source is moved by up to max_rot radians about a seeded
+    axis and max_trans metres per axis: the inputs of the reference's own timing test (tests/test_ICP_inputs.py:36-103: ragged, partially
+    overlapping clouds with outliers), at the benchmark's size.  Where make_pairs' source IS target rows (match 0.017 m away, runner-up
+    0.4 m: the match certificates' best case), a match here is a neighbouring sample of the same surface (0.05-0.1 m away) with runners-up
+    at the same distance.
+    ragged: the clouds' lengths vary in [0.75, 1] of n / m -> (list of (n_b,3), list of (m_b,6)); otherwise dense (N,n,3), (N,m,6)."""
+    half, height, x0, x1 = 10.0, 3.0, -10.0, 16.0
+
+    def sample(g, count, lo, hi):
+        """`count` points on the scene's surfaces inside the footprint x in [lo, hi], with normals."""
+        u = lambda k: torch.rand((k,), generator=g, dtype=torch.float64)                  # noqa: E731
+        n_cl = int(round(clutter * count))
+        # areas: ground 20 x (hi - lo); long walls 2 x (hi - lo) x height; partitions (10 x height each) and pillars inside the footprint
+        parts = [x for x in (-7.0, 1.0, 9.0, 13.0) if lo <= x <= hi]
+        pillars = [(px, py) for (px, py) in ((-5.0, -4.0), (-1.0, 5.0), (4.0, -6.0), (7.0, 3.0), (11.0, -2.0), (14.5, 6.0)) if lo <= px <= hi]
+        areas = [2 * half * (hi - lo), 2 * (hi - lo) * height] + [half * height] * len(parts) + [2 * math.pi * 0.4 * height] * len(pillars)
+        tot = sum(areas)
+        counts = [int((count - n_cl) * a / tot) for a in areas]
+        counts[0] += (count - n_cl) - sum(counts)
+        pts, nrm = [], []
+        k = counts[0]                                                                       # ground
+        pts.append(torch.stack((lo + u(k) * (hi - lo), (u(k) - 0.5) * 2 * half, torch.zeros(k, dtype=torch.float64)), dim=1))
+        nrm.append(torch.tensor([0.0, 0.0, 1.0], dtype=torch.float64).repeat(k, 1))
+        k = counts[1]                                                                       # the two long walls (y = -half / +half)
+        side = torch.where(u(k) < 0.5, -1.0, 1.0).to(torch.float64)
+        pts.append(torch.stack((lo + u(k) * (hi - lo), side * half, u(k) * height), dim=1))
+        nrm.append(torch.stack((torch.zeros(k, dtype=torch.float64), -side, torch.zeros(k, dtype=torch.float64)), dim=1))
+        for j, xw in enumerate(parts):                                                      # partitions across the corridor, alternately from either long wall
+            k = counts[2 + j]
+            sgn = -1.0 if (int(xw) % 2 == 0) else 1.0
+            pts.append(torch.stack((torch.full((k,), xw, dtype=torch.float64), sgn * u(k) * half, u(k) * height), dim=1))
+            nrm.append(torch.tensor([1.0, 0.0, 0.0], dtype=torch.float64).repeat(k, 1))
+        for j, (px, py) in enumerate(pillars):
+            k = counts[2 + len(parts) + j]
+            a = u(k) * 2 * math.pi
+            pts.append(torch.stack((px + 0.4 * torch.cos(a), py + 0.4 * torch.sin(a), u(k) * height), dim=1))
+            nrm.append(torch.stack((torch.cos(a), torch.sin(a), torch.zeros(k, dtype=torch.float64)), dim=1))
+        c = torch.stack((lo + u(n_cl) * (hi - lo), (u(n_cl) - 0.5) * 2 * half, u(n_cl) * height), dim=1)
+        cn = torch.randn((n_cl, 3), generator=g, dtype=torch.float64)
+        pts.append(c)
+        nrm.append(cn / cn.norm(dim=1, keepdim=True))
+        P, Nv = torch.cat(pts, dim=0), torch.cat(nrm, dim=0)
+        P = P + noise * torch.randn((P.shape[0], 3), generator=g, dtype=torch.float64)    # sensor noise
+        order = torch.randperm(P.shape[0], generator=g)
+        return P[order], Nv[order]
+
+    S, Tg = [], []
+    for b in range(N):
+        g = torch.Generator().manual_seed(100000 * seed + 424242 + first + b)
+        nb = n - int(float(torch.rand(1, generator=g)) * 0.25 * n) if ragged else n
+        mb = m - int(float(torch.rand(1, generator=g)) * 0.25 * m) if ragged else m
+        Pt, Nt = sample(g, mb, x0, x0 + 2 * half)
+        Ps, _ = sample(g, nb, x0 + shift, min(x0 + shift + 2 * half, x1))
+        ax = torch.randn(3, generator=g, dtype=torch.float64)
+        ang = float(torch.rand(1, generator=g, dtype=torch.float64)) * max_rot
+        trans = (torch.rand(3, generator=g, dtype=torch.float64) - 0.5) * 2.0 * max_trans
+        C = _rot(ax, ang)
+        ctr = torch.tensor([x0 + half + 0.5 * shift, 0.0, 0.5 * height], dtype=torch.float64)      # rotate about the scene's middle: a lever arm of metres, not tens
+        S.append((((Ps - ctr) - trans) @ C + ctr).to(dtype))
+        Tg.append(torch.cat((Pt, Nt), dim=1).to(dtype))
+    if device is not None:
+        S, Tg = [s.to(device) for s in S], [t.to(device) for t in Tg]
+    if ragged:
+        return S, Tg
+    return torch.stack(S), torch.stack(Tg)

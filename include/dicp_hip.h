@@ -166,11 +166,16 @@ int dicp_query_order(int dtype, const void* src, const void* pose, const void* b
  * cfg: 0 = launch configuration chosen from the problem size; 1, 2, 4 pin one (queries per lane, rows per chunk) = (1,8), (2,8), (1,16).
  * f16_image: optional (float32): the image dicp_knn_f16_pack made of tgs4 (the SORTED packed rows, same tgt_rows).  The scoring of the (2,8)
  *   configuration's units -- 128 queries per wave, what big problems get -- then runs on the matrix cores (split-f16 filter + exact float32
- *   refine, csrc/knn_f16.hip): the same idx / spos, index for index. */
+ *   refine, csrc/knn_f16.hip): the same idx / spos, index for index.
+ * form_in / form_out (N) int32, optional; form_default: the scoring form per CLOUD.  The matrix-core form pays where a wave's slab is long -- big clouds, or clouds of
+ *   any size whose queries lie far from their matches -- and loses where it is a few tiles.  Every unit adds the 64-row tiles its slab had to form_out[cloud].
+ *   Given f16_image AND form_in (such a tally of an earlier search of the same clouds), both forms are launched and each takes its clouds: the matrix cores those
+ *   with more than 20 tiles per unit in form_in (a cloud whose tally is 0: if form_default != 0), the vector form the others.  Same idx / spos either way. */
 #define DICP_PAIR_SHARDS 64
 int dicp_knn_sweep(int dtype, const void* src, const void* pose, const void* tgs4, const int32_t* tperm,
                    const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt, const int32_t* src_rows, const int32_t* tgt_rows,
-                   int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg, const void* f16_image, void* stream);
+                   int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg, const void* f16_image,
+                   const int32_t* form_in, int32_t* form_out, int form_default, void* stream);
 
 /* Gather whole target rows at idx (nn.py:37-38 / 89-90) and its backward, a scatter-add
  * into a zero-initialised (N,m,c) buffer (autograd's gather backward). */
@@ -238,6 +243,7 @@ typedef struct dicp_step_io {
     int32_t glist_cap;       /* entries per list */
     int32_t* glist;          /* (8, glist_cap) int32: entry = cloud * cert_units + unit, list = cloud & 7 (the XCD the cloud's blocks run on) */
     int32_t* gcount;         /* (8) zeros: entries in each list of the next iteration */
+    int32_t* cert_scount;    /* optional (N): lengths of the clouds' candidate-set lists (dicp_loop_buffers.cert_scount): 64 sets make one more entry, -1 - (cloud * ceil(n/64) + chunk) */
     int32_t w_copied;        /* 1: the accumulate launch of this iteration already wrote w_prev into w_cur for the clouds that are frozen (alive = 0;
                                 dicp_icp_forward does): the step then has nothing to copy for them (ICP.py:224-226) */
 } dicp_step_io;
@@ -349,6 +355,9 @@ typedef struct dicp_loop_buffers {
     int32_t* cert_pend;      /* (N, n) int32 ZEROS, by query: a match the guard launch CHANGED, left for the accumulate of the same iteration (match + 2) */
     int32_t* cert_glist;     /* (8, N * ceil(n/64)) int32 scratch: the guard launches' work lists (dicp_step_io.glist), rewritten by every step */
     int32_t* cert_gcount;    /* (K + 1, 8) int32 ZEROS: their lengths, per iteration */
+    int32_t* cert_slist;     /* with cert_set, (N, n) int32 scratch: per cloud, the slots that were given a candidate set -- the guard launch re-scores the standing
+                                ones 64 to a wave from it */
+    int32_t* cert_scount;    /* (N) int32 ZEROS: its lengths */
     int32_t* cert_cm;        /* (N, n) int32 scratch, by slot of the query order: the searches' own copy of the current matches.  The certificates' state
                                 (cert_q, cert_set, cert_cm) goes by SLOT: the guard launch, which alone reads it, takes a unit's share as one coalesced piece */
     const void* tgt_sorted;  /* sweep only, optional (N,m_pad,tgt_sorted_stride): dicp_sweep_build's tgt_s.  With it (and spos) the forward accumulate
@@ -394,6 +403,10 @@ typedef struct dicp_loop_buffers {
                                    preparing the loop): dicp_icp_forward then starts iteration 0 at its accumulate */
     const void* tgt_f16;     /* optional, float32: the split-f16 image of tgt4 (dicp_knn_f16_pack, with the same tgt_rows).  DICP_KNN_MFMA needs it; on the
                                 sweep path (tgt4 = the sorted rows) the plain searches of big problems score on the matrix cores when it is given */
+    int32_t* sweep_form;     /* sweep path, optional (K, N) int32 ZEROS: the plain search of iteration k tallies its slabs' tiles per cloud in row k and, given tgt_f16,
+                                takes the scoring form of every cloud from row k-1 (dicp_knn_sweep's form_in / form_out; a row of zeros: no plain search then).
+                                Without tgt_f16 the tallies are only kept (a caller may decide from them whether the next call of the shape gets the image) */
+    int32_t sweep_form_default;  /* the form of a cloud without a tally: 0 vector, 1 matrix cores */
 } dicp_loop_buffers;
 
 /* Head and tail of the backward loop.  dicp_pose_grad_in: gpose (N,12) double = [dL/dC row-major (9), dL/dr (3)] taken from the
@@ -435,7 +448,7 @@ typedef struct dicp_segment_plan {
     int32_t* order[DICP_MAX_SEGMENTS];       /* (N,n) each: the query order the segment searches in (several segments may share one), NULL: none */
     const void* keys;        /* (N,m_pad) sorted target x keys (dicp_sweep_sort): the rank search of dicp_query_order */
     void* cert_q; void* cert_qu; int32_t* cert_count; int32_t* cert_cloud; void* cert_set;
-    void* cert_nbr; int32_t* cert_gdirty; int32_t* cert_pend; int32_t* cert_cm; int32_t* cert_glist; int32_t* cert_gcount;     /* as dicp_loop_buffers' (its spos_of is taken from `buf`) */
+    void* cert_nbr; int32_t* cert_gdirty; int32_t* cert_pend; int32_t* cert_cm; int32_t* cert_glist; int32_t* cert_gcount; int32_t* cert_slist; int32_t* cert_scount;     /* as dicp_loop_buffers' (its spos_of is taken from `buf`) */
 } dicp_segment_plan;
 int dicp_icp_forward_plan(int dtype, const dicp_weight_params* prm, const dicp_loop_buffers* buf, const dicp_segment_plan* plan, int N, int n, int m,
                           int dim, int const_iter, double tolerance, void* stream);

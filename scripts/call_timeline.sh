@@ -4,12 +4,12 @@ rocprofv3 --kernel-trace -d $O/t -o t --output-format csv -- python3 $R/scripts/
 python3 - $O/t/t_kernel_trace.csv > $O/timeline.txt <<'PY'
 import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
-# the last call: after the last gap > 200 us
-start = 0
-for i in range(1, len(rows)):
-    if int(rows[i]["Start_Timestamp"]) - int(rows[i - 1]["End_Timestamp"]) > 200000: start = i
+# the last call: from the last search_frame_kernel (the first kernel of a sweep-path call) to the last pose_grad_out_kernel (the backward's last)
+start = max([i for i, r in enumerate(rows) if "search_frame_kernel" in r["Kernel_Name"]] or [0])
+ends = [i for i, r in enumerate(rows) if "pose_grad_out_kernel" in r["Kernel_Name"] and i > start]
+stop = (max(ends) + 1) if ends else len(rows)
 t0 = int(rows[start]["Start_Timestamp"]); prev = None
-for r in rows[start:]:
+for r in rows[start:stop]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:70]
     print("%9.1f us  dur %8.1f  gap %6.1f  %s" % ((s - t0) / 1e3, (e - s) / 1e3, 0.0 if prev is None else (s - prev) / 1e3, name))

@@ -39,7 +39,7 @@ def test_struct_layouts_match_header(lib):
     expect = ["partials", "nblk", "iter", "dim", "const_iter", "tolerance", "rows_per_point", "n", "pose_in", "pose_out",
               "delta", "delta_stride", "cost", "cost_prev", "cost_stride", "areg", "alive", "alive_out", "converged", "iterations",
               "matched_ratio", "n_start", "n_matched", "w_cur", "w_prev", "w_stride", "n_not_converged", "frame", "pose_search_out",
-              "rmax", "dcum", "dcum_stride", "cert_cloud", "cert_qu", "cert_units", "glist_cap", "glist", "gcount", "w_copied"]
+              "rmax", "dcum", "dcum_stride", "cert_cloud", "cert_qu", "cert_units", "glist_cap", "glist", "gcount", "cert_scount", "w_copied"]
     assert [f[0] for f in _lib.StepIO._fields_] == expect
     hdr = open(os.path.join(ROOT, "include", "dicp_hip.h")).read()
     body = hdr[hdr.index("typedef struct dicp_step_io {"):hdr.index("} dicp_step_io;")]
@@ -118,11 +118,11 @@ def test_new_entry_points_reject_bad_arguments(lib):
     assert lib.dicp_permute_rows(0, one, one, 1, 2, 1, 2, 3, 3, one, 4, 3, None) == 2
     assert lib.dicp_pose_grad_in(0, None, None, 1, None) == 1 and lib.dicp_pose_grad_in(7, None, one, 1, None) == 3
     assert lib.dicp_pose_grad_out(0, one, one, 0, one, 1, None) == 2 and lib.dicp_pose_grad_out(0, one, None, 0, None, 1, None) == 1
-    # dicp_knn_sweep(dtype, src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, src_rows, tgt_rows, N, n, m, m_pad, idx, spos, pairs, cfg, f16_image, stream)
-    assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, None, None, 1, 1, 1, 64, one, None, None, 99, None, None) == 4
-    assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, None, None, 1, 1, 1, 64, None, None, None, 0, None, None) == 1   # idx or spos
-    assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, None, None, 1, 1, 1, 64, one, None, None, 16, None, None) == 4   # (the scan form is gone)
-    assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, None, None, 1, 1, 1, 64, one, None, None, 2 | 0x100, None, None) == 4  # (the slot-ordered source copy is gone too)
+    # dicp_knn_sweep(dtype, src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, src_rows, tgt_rows, N, n, m, m_pad, idx, spos, pairs, cfg, f16_image, form_in, form_out, form_default, stream)
+    assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, None, None, 1, 1, 1, 64, one, None, None, 99, None, None, None, 0, None) == 4
+    assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, None, None, 1, 1, 1, 64, None, None, None, 0, None, None, None, 0, None) == 1   # idx or spos
+    assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, None, None, 1, 1, 1, 64, one, None, None, 16, None, None, None, 0, None) == 4   # (the scan form is gone)
+    assert lib.dicp_knn_sweep(0, one, None, one, one, None, one, one, 1024, None, None, 1, 1, 1, 64, one, None, None, 2 | 0x100, None, None, None, 0, None) == 4  # (the slot-ordered source copy is gone too)
     # dicp_call_*: plans are pure host arithmetic; a bad shape, a bad dtype, a missing buffer are refused before anything is touched
     call = _lib.Call(N=2, n=300, m=200, c=3, K=5, dim=3, need_grad=1, n_resort=2)
     call.resort[0], call.resort[1] = 1, 2

@@ -55,6 +55,10 @@ class ICP:
         # every iteration for big batches (an iteration costs far more than a sync), every 4th for small ones
         # (converged clouds are frozen, so the extra iterations change nothing and the histories are trimmed)
         self.sync_every = None
+        # True: a backward pass that used the one-launch tail of the truncated reverse sweep waits for itself and raises _ops.TailTimeout IN that pass if a
+        # wait inside the launch ran out (a GPU kept full by other work for half a second) -- before the NaN gradients it would otherwise return reach an
+        # optimizer.  False (default): no synchronisation; the failure is raised by the next backward pass of this object, or by check_errors().
+        self.strict_errors = False
         # Private switches of single mechanisms, all on: what the tests flip to hold each mechanism to the path without it (and what the
         # measurements in DESIGN.md A/B'd).  Not part of the call surface.
         self._tuning = dict(
@@ -132,7 +136,7 @@ class ICP:
             sync_every=self.sync_every, timing_events=self._timing_events, small_loop=bool(self._tuning["small_loop"]),
             src_rows=src_rows, tgt_rows=tgt_rows, sweep_resort=resort_schedule(self._tuning["sweep_resort"], source.shape[0], source.shape[1], int(self.max_iterations), bool(self.reuse_matches), self._tuning["cert_from"]), reuse_matches=bool(self.reuse_matches), cert_from=self._tuning["cert_from"],
             bwd_skip_eps=self.bwd_skip_eps, cert_backoff=bool(self._tuning["cert_backoff"]), cert_sets=bool(self._tuning["cert_sets"]), cert_hint=bool(self._tuning["cert_hint"]),
-            plan_call=bool(self._tuning["plan_call"]), bwd_tail=bool(self._tuning["bwd_tail"]), first_search=first_search,
+            plan_call=bool(self._tuning["plan_call"]), bwd_tail=bool(self._tuning["bwd_tail"]), first_search=first_search, strict_errors=bool(self.strict_errors),
             # nn.py:14-16 via ICP.py:140: soft correspondences -- the same library loop with dicp_gumbel_nn in place of the search, the same one node
             gumbel=(self.nn.eps, self.nn.tau, getattr(self.nn, "_inject_U", None)) if soft else None)
         T_c = T_init.contiguous()
@@ -174,7 +178,8 @@ class ICP:
 
     def check_errors(self):
         """Wait for the backward passes this object has enqueued so far and raise if one of them reported a failure of its own (today: a wait of the
-        one-launch tail that ran out, _ops.TailTimeout -- that pass's gradients are NaN).  Without this call the error is raised by the next backward pass."""
+        one-launch tail that ran out, _ops.TailTimeout -- that pass's gradients are NaN).  Without this call the error is raised by the next backward pass
+        -- or, with `strict_errors = True`, by the failing pass itself.  Call it before `optimizer.step()` when neither is acceptable."""
         self._hints.check(wait=True)
 
     def pt2pt_dICP_SVD(self, source, target, T_init, trim_dist=None, huber_delta=None, dim=3, weight=None):

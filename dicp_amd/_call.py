@@ -6,9 +6,10 @@ which prepared ~30 buffers and ~12 library calls per direction (dicp_amd/_ops.py
 dicp_call_forward / dicp_call_backward on ONE allocation each; this module allocates, hands out the results as views and keeps autograd's books.
 Every other call takes ICPLoop.  The two give the same results bit for bit (tests/test_gpu_call.py).
 
-Lifetime of the one allocation: it lives as long as any result that is a view of it (deltas, weights, costs, iterations, matched_ratio), as the autograd
-node (the reverse sweep reads it), and -- through the small views `ICP.knn_stats` holds (pairs scored, live counters) -- until the object's next call replaces
-them.  MAX_POINTS bounds it to a few hundred MB.
+Lifetimes: the workspace (search structure, match history, pose histories, sort scratch: 18 MB at 32 x 4096, up to a few hundred MB at MAX_POINTS) lives as
+long as the autograd node does -- the reverse sweep reads it -- and no longer: the non-differentiable results (deltas, weights, costs, iterations, matched_ratio,
+converged) are views of a SECOND, small allocation of their own (dicp_call.results), so a training loop that keeps the costs of every step keeps nothing else.
+`deltas`, the one result the reverse sweep reads, goes through save_for_backward: an in-place edit of it is refused by autograd's version check, as with ICPLoop.
 """
 import ctypes
 
@@ -97,37 +98,39 @@ class CallLoop(torch.autograd.Function):
         P = cfg.params()
         with _on(dev):
             ws = torch.empty((L.total // es,), dtype=dt, device=dev)
-            # (the two differentiable results are tensors of their own: autograd refuses the backward pass of a view whose base has been edited, and
-            #  the other results -- views of the workspace -- are the caller's to edit)
+            rs = torch.empty((L.results_total // es,), dtype=dt, device=dev)       # (the non-differentiable results: an allocation of their own, see the module's docstring)
+            # (the two differentiable results are tensors of their own: autograd refuses the backward pass of a view whose base has been edited)
             T = torch.empty((N, 4, 4), dtype=dt, device=dev)
             pc = torch.empty((N, n, 3), dtype=dt, device=dev)
-            call = _lib.Call(T_out=T.data_ptr(), pc_out=pc.data_ptr(), src=source.data_ptr(), tgt=target.data_ptr(), T_init=T_init.data_ptr(), w0=w0.data_ptr() if w0 is not None else None,
+            call = _lib.Call(T_out=T.data_ptr(), pc_out=pc.data_ptr(), results=rs.data_ptr(), src=source.data_ptr(), tgt=target.data_ptr(), T_init=T_init.data_ptr(), w0=w0.data_ptr() if w0 is not None else None,
                              N=N, n=n, m=m, c=c, K=K, dim=int(cfg.dim), need_grad=need_grad, n_resort=len(resort), flags=flags,
                              directions=int(_ops.FRAME_DIRECTIONS), quantum=_ops.CENTER_QUANTUM, tolerance=float(cfg.tolerance), workspace=ws.data_ptr())
             for i, k in enumerate(resort):
                 call.resort[i] = k
             _lib.check(lib.dicp_call_forward(code, ctypes.byref(P), ctypes.byref(call), _stream()), "dicp_call_forward")
-        view = ws.as_strided
-        deltas = view((N, K, 6), (6 * K, 6, 1), L.deltas // es)
-        weights = view((N, K, n), (K * n, n, 1), L.weights // es)
-        costs = view((N, K), (K, 1), L.costs // es)
-        iterations = view((N,), (1,), L.iterations // es)
-        matched = view((N,), (1,), L.matched_ratio // es)
-        conv = ws[L.converged // es:L.converged // es + (N + es - 1) // es].view(torch.uint8)[:N].bool()
+        # each result a tensor on its own slice of `rs` with a version counter of its OWN (.data): editing the weights in place must not look like an edit of
+        # the steps, which the reverse sweep reads and autograd therefore watches
+        def piece(off, count, shape):
+            return rs.narrow(0, off // es, count).view(shape).data
+        deltas = piece(L.deltas, N * K * 6, (N, K, 6))
+        weights = piece(L.weights, N * K * n, (N, K, n))
+        costs = piece(L.costs, N * K, (N, K))
+        iterations = piece(L.iterations, N, (N,))
+        matched = piece(L.matched_ratio, N, (N,))
+        conv = rs[L.converged // es:L.converged // es + (N + es - 1) // es].view(torch.uint8)[:N].bool()
         if stats is not None:
-            stats["knn_pairs"] = ws[L.pairs // es:L.pairs // es + _lib.PAIR_SHARDS * 8 // es].view(torch.int64)
+            stats["knn_pairs"] = ws[L.pairs // es:L.pairs // es + _lib.PAIR_SHARDS * 8 // es].view(torch.int64).clone()    # (a copy: the statistics must not keep the workspace alive)
         if need_grad:
-            # (the workspace is kept as it is -- the reverse sweep reads poses, steps, matches and the sorted rows out of it -- not through
-            #  save_for_backward: the non-differentiable results are views of it, and a caller who edits the weights in place must not be refused
-            #  its backward pass.  Of those results the reverse sweep reads `deltas` only.)
-            ctx.save_for_backward(source, target, w0)
+            # (the workspace -- poses, matches, sorted rows: what the reverse sweep reads -- is the node's own; of the caller-visible results it reads
+            #  `deltas`, which therefore goes through save_for_backward: autograd's version check refuses the pass if the caller edited it in place)
+            ctx.save_for_backward(source, target, w0, deltas)
             ctx.ws, ctx.call, ctx.cfg, ctx.P, ctx.L = ws, call, cfg, P, L
         ctx.mark_non_differentiable(deltas, weights, costs, conv, iterations, matched)
         return T, pc, deltas, weights, costs, conv, iterations, matched
 
     @staticmethod
     def backward(ctx, gT, gpc, *_unused):
-        src, tgt, w0 = ctx.saved_tensors
+        src, tgt, w0, deltas = ctx.saved_tensors
         cfg, P, call, FL = ctx.cfg, ctx.P, ctx.call, ctx.L
         lib = _lib.load()
         dev, dt = src.device, src.dtype
@@ -149,7 +152,7 @@ class CallLoop(torch.autograd.Function):
                 gT = gT_pc if gT is None else gT + gT_pc
             base = ctx.ws.data_ptr()
             F = _lib.LoopBackwardIn(src=src.data_ptr(), tgt_sorted=base + FL.tgt_sorted, w0=w0.data_ptr() if w0 is not None else None, tperm=base + FL.tperm,
-                                    qorder=base + FL.orders + (FL.n_orders - 1) * N * n * 4, spos=base + FL.spos, poses=base + FL.poses, deltas=base + FL.deltas,
+                                    qorder=base + FL.orders + (FL.n_orders - 1) * N * n * 4, spos=base + FL.spos, poses=base + FL.poses, deltas=deltas.data_ptr(),
                                     areg=base + FL.areg, alive=base + FL.alive, N=N, n=n, m=m, c=call.c, K=K, K_cap=K, m_pad=FL.m_pad, dim=call.dim,
                                     knn_variant=_lib.KNN_SWEEP | ((1 << 25) if (call.flags & _lib.CALL_NO_SMALL_LOOP) else 0))
             gsrc, gtgt, gT0, gw = _ops.backward_once(lib, code, P, F, cfg, src, tgt, w0, gT, want_tgt, want_w)
@@ -211,8 +214,9 @@ class KabschCall(torch.autograd.Function):
                                    directions=int(_ops.FRAME_DIRECTIONS), trim_dist=float(trim_dist) if trim_on else 0.0, quantum=_ops.CENTER_QUANTUM, tolerance=0.0,
                                    workspace=ws.data_ptr(), T_out=T.data_ptr(), pc_out=pc.data_ptr())
             _lib.check(lib.dicp_kabsch_call_forward(code, ctypes.byref(call), _stream()), "dicp_kabsch_call_forward")
-        costs = ws.as_strided((N, K), (K, 1), L.costs // es)
-        iterations = ws.as_strided((N,), (1,), L.iterations // es)
+        # (copies: these two small results must not keep the workspace -- the search structure and the sort scratch -- alive in a caller's log)
+        costs = ws.as_strided((N, K), (K, 1), L.costs // es).clone()
+        iterations = ws.as_strided((N,), (1,), L.iterations // es).clone()
         ctx.save_for_backward(src, tgt, w0c)
         ctx.ws, ctx.call, ctx.L = ws, call, L
         ctx.mark_non_differentiable(costs, iterations)

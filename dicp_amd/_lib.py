@@ -78,7 +78,7 @@ class SegmentPlan(ctypes.Structure):
 class Call(ctypes.Structure):
     """dicp_call (include/dicp_hip.h)."""
     _fields_ = [("src", vp), ("tgt", vp), ("T_init", vp), ("w0", vp), ("N", i32), ("n", i32), ("m", i32), ("c", i32), ("K", i32), ("dim", i32), ("need_grad", i32),
-                ("n_resort", i32), ("resort", i32 * MAX_SEGMENTS), ("flags", i32), ("directions", i32), ("quantum", f64), ("tolerance", f64), ("workspace", vp), ("T_out", vp), ("pc_out", vp)]
+                ("n_resort", i32), ("resort", i32 * MAX_SEGMENTS), ("flags", i32), ("directions", i32), ("quantum", f64), ("tolerance", f64), ("workspace", vp), ("results", vp), ("T_out", vp), ("pc_out", vp)]
 
 
 _sz = ctypes.c_size_t
@@ -86,7 +86,7 @@ _sz = ctypes.c_size_t
 
 class CallLayout(ctypes.Structure):
     """dicp_call_layout (include/dicp_hip.h)."""
-    _fields_ = ([(k, _sz) for k in ("total", "zeroed", "T", "pc", "deltas", "weights", "costs", "converged", "iterations", "matched_ratio", "pairs", "n_matched", "counters",
+    _fields_ = ([(k, _sz) for k in ("total", "zeroed", "results_total", "results_zeroed", "T", "pc", "deltas", "weights", "costs", "converged", "iterations", "matched_ratio", "pairs", "n_matched", "counters",
                                     "poses", "poses_search", "alive", "areg", "n_start", "partials", "tgs4", "tperm", "bucket", "brange", "keys", "tgt_sorted", "scratch",
                                     "scratch_bytes", "frame", "pose_s", "orders", "spos")]
                 + [("n_orders", i32), ("m_pad", i32), ("nblk", i32), ("pad0", i32)])

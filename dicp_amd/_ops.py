@@ -490,8 +490,16 @@ def prebuild_search(source, target, knn_variant, want_rows, T_init=None, src_row
 
 
 class TailTimeout(RuntimeError):
-    """A wait inside the one-launch tail of an EARLIER backward pass ran out (dicp_hip.h, bwd_tail_arrive): that pass poisoned the gradients of the
-    clouds concerned with NaN.  Raised at the next backward pass of the same ICP object, or by ICP.check_errors()."""
+    """A wait inside the one-launch tail of a backward pass ran out (dicp_hip.h, bwd_tail_arrive): that pass poisoned the gradients of the clouds
+    concerned with NaN.  Raised by the pass itself when ICP.strict_errors is set (it then waits for its own kernels), else at the next backward pass of the
+    same ICP object, or by ICP.check_errors()."""
+
+
+def _strict_tail_check(cfg, word):
+    """ICP.strict_errors: wait for the pass and look at its tail's error word (a (1,) int32 device tensor) now."""
+    if cfg.strict_errors and word is not None and not torch.cuda.is_current_stream_capturing() and int(word.item()) != 0:
+        raise TailTimeout("dicp_amd: a wait of this backward pass's one-launch tail ran out (the GPU was kept full by other work for ~0.5 s); its gradients "
+                          "are NaN and were not returned.  Re-run the step, or set ICP._tuning['bwd_tail'] = False")
 
 
 class CallHints:
@@ -599,6 +607,7 @@ class LoopConfig:
     cert_from: object = None      # iteration of the certifying search (None: the last re-ordering of the queries)
     gumbel: object = None         # (eps, tau, inject_U or None): the Gumbel-softmax correspondence (nn.py:43-70) instead of the nearest neighbour
     bwd_tail: bool = True         # truncated reverse sweep: the iterations before the ones the previous call still worked at run as ONE launch (dicp_loop_buffers.bwd_tail_from)
+    strict_errors: bool = False   # a pass that used that launch waits for itself and raises TailTimeout if a wait inside it ran out (ICP.strict_errors)
     plan_call: bool = True        # constant-iteration sweep calls: all segments behind one library call (dicp_icp_forward_plan)
     first_search: bool = True     # sweep path: iteration 0's search is enqueued right behind the index build
     cert_hint: bool = True        # a shape whose clouds ALL ended a call with their certificates switched off is searched plainly for the next 32 calls
@@ -701,11 +710,14 @@ def backward_once(lib, code, P, F, cfg, src, tgt, w0c, gT, want_tgt, want_w):
                     entry = hints.pop(0)
             else:
                 entry = [torch.empty((max(Kcap + 1, 64),), dtype=torch.int32).pin_memory(), None, None, Kcap, False, 0]
+    tail_word = None
+    if tail_from > 0:
+        a0 = L.arrive // es
+        tail_word = ws[a0:a0 + (N + 1 + (es // 4) - 1) * 4 // es].view(torch.int32)[N:N + 1]
     if stats is not None:
         stats["bwd_tail_from"] = int(tail_from)
         if tail_from > 0:
-            a0 = L.arrive // es
-            stats["bwd_tail_error"] = ws[a0:a0 + (N + 1 + (es // 4) - 1) * 4 // es].view(torch.int32)[N:N + 1]
+            stats["bwd_tail_error"] = tail_word
     gsrc = torch.empty_like(src)
     gtgt = torch.empty_like(tgt) if want_tgt else None
     gw = torch.empty_like(w0c) if want_w else None
@@ -722,6 +734,7 @@ def backward_once(lib, code, P, F, cfg, src, tgt, w0c, gT, want_tgt, want_w):
         entry[2], entry[3], entry[4], entry[5] = (N, n, K), Kcap, False, cfg.hints.serial
         hints.append(entry)
         cfg.hints.newest_tail = entry
+    _strict_tail_check(cfg, tail_word)
     return gsrc, gtgt, gT0, gw
 
 
@@ -1328,6 +1341,8 @@ class ICPLoop(torch.autograd.Function):
                                               _p(gT0), N, st), "dicp_pose_grad_out")
             if gsrc_pc is not None:
                 gsrc += gsrc_pc
+            if tail_from > 0:
+                _strict_tail_check(cfg, skip[3][N:])
         return gsrc, gtgt, gT0, gw, None
 
 

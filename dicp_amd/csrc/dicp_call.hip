@@ -33,6 +33,7 @@ inline bool call_ok(int dtype, const dicp_call* c) {
 }
 
 inline char* at(const dicp_call* c, size_t off) { return (char*)c->workspace + off; }
+inline char* res(const dicp_call* c, size_t off) { return (char*)c->results + off; }
 
 // ---- the SVD loop's one-call form: three per-cloud trifles that were torch arithmetic on the host side
 template <typename T>
@@ -78,20 +79,24 @@ int dicp_call_plan(int dtype, const dicp_call* c, dicp_call_layout* L) {
     L->nblk = dicp_accumulate_blocks(c->n);
     L->n_orders = 1 + c->n_resort;
     const size_t m_pad = L->m_pad;
+    // the non-differentiable results: an allocation of their own (dicp_call.results), the zero-initialised ones first
+    Carver rs;
+    L->deltas = rs.take(N * K * 6 * es);
+    L->costs = rs.take(N * K * es);
+    L->converged = rs.take(N);
+    L->iterations = rs.take(N * es);
+    L->matched_ratio = rs.take(N * es);
+    L->results_zeroed = rs.off;
+    L->weights = rs.take(N * K * n * es);
+    L->results_total = rs.off;
     Carver w;
     // zero-initialised loop state first: one fill
-    L->deltas = w.take(N * K * 6 * es);
-    L->costs = w.take(N * K * es);
-    L->converged = w.take(N);
-    L->iterations = w.take(N * es);
-    L->matched_ratio = w.take(N * es);
     L->n_matched = w.take(N * es);
     L->counters = w.take(K * 4);
     L->pairs = w.take(DICP_PAIR_SHARDS * 8);
     L->zeroed = w.off;
     L->T = w.take(N * 16 * es);
     L->pc = w.take(N * n * 3 * es);
-    L->weights = w.take(N * K * n * es);
     L->poses = w.take((K + 1) * N * 12 * es);
     L->poses_search = w.take((K + 1) * N * 12 * es);
     L->alive = w.take((K + 1) * N * es);
@@ -115,14 +120,15 @@ int dicp_call_plan(int dtype, const dicp_call* c, dicp_call_layout* L) {
 }
 
 int dicp_call_forward(int dtype, const dicp_weight_params* prm, const dicp_call* c, void* stream) {
-    if (!prm || !c || !c->src || !c->tgt || !c->T_init || !c->workspace) return DICP_ERR_NULL;
+    if (!prm || !c || !c->src || !c->tgt || !c->T_init || !c->workspace || !c->results) return DICP_ERR_NULL;
     dicp_call_layout L;
     if (int rc = dicp_call_plan(dtype, c, &L)) return rc;
-    if (((uintptr_t)c->workspace & 255) != 0) return DICP_ERR_ALIGN;
+    if (((uintptr_t)c->workspace & 255) != 0 || ((uintptr_t)c->results & 255) != 0) return DICP_ERR_ALIGN;
     const size_t es = esize(dtype), N = c->N, n = c->n;
     const int K = c->K;
     hipStream_t st = (hipStream_t)stream;
     if (hipError_t e = hipMemsetAsync(c->workspace, 0, L.zeroed, st)) return -(int)e;
+    if (hipError_t e = hipMemsetAsync(c->results, 0, L.results_zeroed, st)) return -(int)e;
     int32_t* order0 = (int32_t*)at(c, L.orders);
     int32_t* spos = (int32_t*)at(c, L.spos);
     // frame, sort, rows, the search pose of iteration 0 and the first query order; iteration 0's search right behind them
@@ -161,19 +167,19 @@ int dicp_call_forward(int dtype, const dicp_weight_params* prm, const dicp_call*
     B.m_pad = L.m_pad;
     B.tgt4 = at(c, L.tgs4); B.tperm = (int32_t*)at(c, L.tperm); B.bucket = (int32_t*)at(c, L.bucket); B.brange = at(c, L.brange);
     B.nbkt = DICP_CALL_NBKT; B.idx_per_iter = c->need_grad ? 1 : 0; B.pairs = (unsigned long long*)at(c, L.pairs);
-    B.poses = at(c, L.poses); B.deltas = at(c, L.deltas); B.costs = at(c, L.costs); B.areg = c->need_grad ? (double*)at(c, L.areg) : nullptr;
-    B.alive = at(c, L.alive); B.converged = (uint8_t*)at(c, L.converged); B.iterations = at(c, L.iterations); B.matched_ratio = at(c, L.matched_ratio);
+    B.poses = at(c, L.poses); B.deltas = res(c, L.deltas); B.costs = res(c, L.costs); B.areg = c->need_grad ? (double*)at(c, L.areg) : nullptr;
+    B.alive = at(c, L.alive); B.converged = (uint8_t*)res(c, L.converged); B.iterations = res(c, L.iterations); B.matched_ratio = res(c, L.matched_ratio);
     B.n_start = at(c, L.n_start); B.n_matched = at(c, L.n_matched);
     B.tgt_sorted = at(c, L.tgt_sorted); B.tgt_sorted_stride = c->c;
-    B.w_iter = c->n; B.w_stride = (int64_t)K * c->n; B.w = at(c, L.weights);
+    B.w_iter = c->n; B.w_stride = (int64_t)K * c->n; B.w = res(c, L.weights);
     B.spos = spos;
     B.partials = at(c, L.partials); B.counters = (int32_t*)at(c, L.counters);
     B.frame = at(c, L.frame); B.poses_search = at(c, L.poses_search);
     B.first_search_done = first_search ? 1 : 0;
     if (int rc = dicp_icp_forward_plan(dtype, prm, &B, &SP, c->N, c->n, c->m, c->dim, 1, c->tolerance, stream)) return rc;
     char* pose_K = at(c, L.poses) + (size_t)K * N * 12 * es;
-    if (int rc = dicp_loop_finish(dtype, pose_K, at(c, L.alive) + (size_t)K * N * es, at(c, L.n_start), at(c, L.n_matched), K, c->N, at(c, L.iterations),
-                                  at(c, L.matched_ratio), c->T_out ? c->T_out : at(c, L.T), stream))
+    if (int rc = dicp_loop_finish(dtype, pose_K, at(c, L.alive) + (size_t)K * N * es, at(c, L.n_start), at(c, L.n_matched), K, c->N, res(c, L.iterations),
+                                  res(c, L.matched_ratio), c->T_out ? c->T_out : at(c, L.T), stream))
         return rc;
     return dicp_transform_points(dtype, c->src, pose_K, c->pc_out ? c->pc_out : at(c, L.pc), c->N, c->n, stream);
 }
@@ -281,7 +287,7 @@ int dicp_call_backward_plan(int dtype, const dicp_weight_params* prm, const dicp
 }
 
 int dicp_call_backward(int dtype, const dicp_weight_params* prm, const dicp_call* c, const dicp_call_grads* g, void* stream) {
-    if (!prm || !c || !g || !c->workspace || !g->workspace || !g->gsrc || !g->gT0 || !c->src || !c->tgt) return DICP_ERR_NULL;
+    if (!prm || !c || !g || !c->workspace || !c->results || !g->workspace || !g->gsrc || !g->gT0 || !c->src || !c->tgt) return DICP_ERR_NULL;
     if (!c->need_grad) return DICP_ERR_ENUM;
     dicp_call_layout F;
     if (int rc = dicp_call_plan(dtype, c, &F)) return rc;
@@ -290,7 +296,7 @@ int dicp_call_backward(int dtype, const dicp_weight_params* prm, const dicp_call
     memset(&f, 0, sizeof(f));
     f.src = c->src; f.tgt_sorted = at(c, F.tgt_sorted); f.w0 = c->w0; f.tperm = (const int32_t*)at(c, F.tperm);
     f.qorder = (const int32_t*)at(c, F.orders) + (size_t)(F.n_orders - 1) * c->N * c->n;
-    f.spos = (const int32_t*)at(c, F.spos); f.poses = at(c, F.poses); f.deltas = at(c, F.deltas); f.areg = (const double*)at(c, F.areg); f.alive = at(c, F.alive);
+    f.spos = (const int32_t*)at(c, F.spos); f.poses = at(c, F.poses); f.deltas = res(c, F.deltas); f.areg = (const double*)at(c, F.areg); f.alive = at(c, F.alive);
     f.N = c->N; f.n = c->n; f.m = c->m; f.c = c->c; f.K = c->K; f.K_cap = c->K; f.m_pad = F.m_pad; f.dim = c->dim;
     f.knn_variant = DICP_KNN_SWEEP | ((c->flags & DICP_CALL_NO_SMALL_LOOP) ? (1 << 25) : 0);
     return backward_once(dtype, prm, &f, g, stream);

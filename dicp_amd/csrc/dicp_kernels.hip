@@ -644,12 +644,15 @@ int dicp_window_rows(int dtype) { return dtype == DICP_F32 ? WindowRows<float>::
 // larger register footprint, x the XCD's compute units) -- the other half is room for a second such launch on another stream, or for an
 // occupancy answer that is one block per unit too high.  0: never (query failed).  dicp_icp_backward refuses a tail beyond it.
 int dicp_bwd_tail_max_blocks(int dtype) {
-    static int cap[2] = {-1, -1};
+    constexpr int MAXDEV = 64;
+    static int cap[MAXDEV][2];                               // per DEVICE of the process (0: not asked yet; the answer + 1 otherwise)
     if (bad_dtype(dtype)) return 0;
-    if (cap[dtype] >= 0) return cap[dtype];
-    int dev = 0, cus = 0, a = 0, b = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (dev >= 0 && dev < MAXDEV && cap[dev][dtype] > 0) return cap[dev][dtype] - 1;
+    int cus = 0, xcds = 0, a = 0, b = 0;
+    hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&xcds, hipDeviceAttributeNumberOfXccs, dev);       // (the device's own count: 8 on MI355X)
     if (e == hipSuccess) {
         if (dtype == DICP_F32) {
             e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, bwd_tail_kernel<float, MODE_PT2PL, WindowRows<float>::v>, BLOCK, 0);
@@ -660,9 +663,12 @@ int dicp_bwd_tail_max_blocks(int dtype) {
         }
     }
     if (e != hipSuccess) { (void)hipGetLastError(); return 0; }           // (not cached: no device yet)
-    const int per_cu = a < b ? a : b, xcds = 8;
-    cap[dtype] = (per_cu > 0 && cus >= xcds) ? (per_cu * (cus / xcds)) / 2 : 0;
-    return cap[dtype];
+    // (decode_block deals a cloud's blocks to ONE of 8 residue classes of the block index -- one XCD on an 8-XCD part; with another count the classes spread
+    //  over the XCDs and the bound is the whole device's share of one class, which is smaller or equal: still safe)
+    const int per_cu = a < b ? a : b;
+    const int ans = (per_cu > 0 && xcds > 0 && cus >= xcds) ? (per_cu * (cus / (xcds > 8 ? xcds : 8))) / 2 : 0;
+    if (dev >= 0 && dev < MAXDEV) cap[dev][dtype] = ans + 1;
+    return ans;
 }
 
 static int accumulate_bwd_window_go(int dtype, const dicp_weight_params* prm, const void* src_s, const void* tgt_s, int c,

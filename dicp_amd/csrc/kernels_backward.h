@@ -738,9 +738,15 @@ __global__ __launch_bounds__(BLOCK) void icp_small_backward_kernel(WeightParams 
 // all of the cloud's blocks have published theirs (one counter per cloud; sums double-buffered by generation, so a block that is ahead
 // never overwrites what a block behind still reads).  Blocks wait only for blocks of their own cloud, whose indices are all inside one
 // group of 8 bpc consecutive blocks (decode_block): dispatch is in index order, so the lowest unfinished group is always resident as a
-// whole and makes progress -- and every wait is bounded anyway (on running out it raises the error word and goes on: wrong sums, no hang).
+// whole and makes progress (dicp_bwd_tail_max_blocks refuses grids where it could not be) -- and every wait is bounded anyway: a block whose
+// wait runs out raises the error words and folds NaN from there on, so the cloud's gradients come out NaN, never as plausible wrong numbers.
 // On exit gpose_out holds the cotangent of pose_0 INCLUDING the last pose sums (dicp_pose_grad_out is then called without partials).
-// A word handed from one block to another inside a launch: agent-scope atomic accesses (sc1: coherent across the XCDs' L2s)
+// The hand-off of the pose sums (round 5: the C++ memory model's own form): the publishing block's stores, a workgroup barrier, then ONE lane's
+// agent-scope RELEASE fence + relaxed agent-scope add to the cloud's counter; the waiting lane polls the counter with relaxed agent-scope loads,
+// then an agent-scope ACQUIRE fence, then the workgroup barrier behind which the block reads the sums.  (Rounds 3-4 used sc1 accesses counted
+// behind s_waitcnt alone -- MI355X_MICROARCH's measured hand-off -- because the fences write back / invalidate the XCD's L2 under this kernel's
+// gradient traffic; they are paid by the clouds that are still at work inside this launch only, which are few: profiles/r05_tail_handoff.txt.)
+// The words themselves stay agent-scope atomic accesses (sc1: served at the memory side, never from a stale L1 line).
 __device__ __forceinline__ void coherent_store(float* p, float v)   { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void coherent_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float  coherent_load(const float* p)  { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -927,6 +933,10 @@ __global__ __launch_bounds__(BLOCK) void bwd_tail_kernel(WeightParams P, dicp_lo
         }
         __syncthreads();
         if (tid == 0) {
+            // release: everything this block stored before the barrier above is visible at agent scope before its arrival is.  (The wait is written as asm:
+            // the compiler may drop its own behind the write-back when it believes the wave's memory counter empty -- MI355X_MICROARCH, compiler hazard.)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_fetch_add(arrive + cloud, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (!(k == 0 && blk != 0) && !s_timeout) {      // (after the last iteration only block 0 still needs the sums; a block waits in vain at most once)
                 const int want = gen * bpc;
@@ -940,8 +950,10 @@ __global__ __launch_bounds__(BLOCK) void bwd_tail_kernel(WeightParams P, dicp_lo
                     }
                     __builtin_amdgcn_s_sleep(8);
                 }
+                // acquire: what the other blocks released before the arrivals just seen is visible to this block behind the barrier below
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            asm volatile("" ::: "memory");                  // (the sums are read with agent-scope loads after the barrier below: nothing to invalidate)
         }
         if (k == 0 && blk != 0) return;
         __syncthreads();

@@ -39,6 +39,16 @@ def _no_gc():
 OUTPUTS = ("T", "pc", "deltas", "weights", "costs")
 
 
+def _check_tail_word(icp):
+    """A replay cannot report a wait of the backward's one-launch tail that ran out the way an eager call does (no host code runs between the kernels): the
+    error word of the captured pass is a static tensor of the graph -- ``call.check_errors()`` / ``step.check_errors()`` wait for the replays made so far and
+    raise _ops.TailTimeout if the last one raised it (its gradients are NaN).  Call it before the optimizer's step."""
+    from ._ops import TailTimeout
+    word = icp.knn_stats.get("bwd_tail_error")
+    if word is not None and int(word.item()) != 0:
+        raise TailTimeout("dicp_amd: a wait of the captured backward pass's one-launch tail ran out in the last replay; its gradients are NaN")
+
+
 def _capturable(icp, what):
     if not icp.const_iter:
         raise ValueError("%s needs ICP.const_iter = True: tolerance mode reads convergence counters on the host between iterations" % what)
@@ -70,6 +80,7 @@ def graphed_icp(icp: ICP, source, target, T_init, weight=None, num_warmup_iters=
 
     def call(s, t, T0, *w):
         return dict(zip(OUTPUTS, graphed(s, t, T0, *w)))
+    call.check_errors = lambda: _check_tail_word(icp)
     return call
 
 
@@ -113,4 +124,5 @@ def graphed_icp_step(icp: ICP, loss_of, source, target, T_init, weight=None, num
                 dst.detach().copy_(src.detach())
         graph.replay()
         return outs, grads
+    step.check_errors = lambda: _check_tail_word(icp)
     return step

@@ -625,12 +625,18 @@ typedef struct dicp_call {
     double quantum;          /* dicp_search_frame's */
     double tolerance;        /* ICP.py:237: a cloud whose step falls below it is frozen */
     void* workspace;         /* dicp_call_layout.total bytes, 256-byte aligned; dicp_call_backward reads what dicp_call_forward left in it */
+    void* results;           /* dicp_call_layout.results_total bytes, 256-byte aligned: the non-differentiable results (deltas, costs, converged, iterations,
+                                matched_ratio, weights), in an allocation of their OWN -- a caller that keeps one of them (a per-step log of the costs) must not
+                                keep the search structure, the match history and the sort scratch alive with it, and one that edits them must not be able to
+                                touch what the reverse sweep reads (it reads `deltas`: the binding keeps that tensor's version) */
     void* T_out;             /* optional (N,4,4) / (N,n,3): the two differentiable results go here instead of into the workspace (a binding whose autograd */
     void* pc_out;            /* must not see them as views of one buffer that also holds results a caller may edit) */
 } dicp_call;
-typedef struct dicp_call_layout {       /* byte offsets into dicp_call.workspace */
-    size_t total, zeroed;    /* its size; the first `zeroed` bytes are cleared by dicp_call_forward itself */
-    size_t T, pc, deltas, weights, costs, converged, iterations, matched_ratio;   /* results: (N,4,4) T, (N,n,3) T, (N,K,6) T, (N,K,n) T, (N,K) T, (N) uint8, (N) T, (N) T */
+typedef struct dicp_call_layout {       /* byte offsets into dicp_call.workspace -- and, for the six results named below, into dicp_call.results */
+    size_t total, zeroed;    /* the workspace's size; its first `zeroed` bytes are cleared by dicp_call_forward itself */
+    size_t results_total, results_zeroed;   /* the same for dicp_call.results */
+    size_t T, pc;            /* (N,4,4) T, (N,n,3) T in the workspace (unused when T_out / pc_out are given) */
+    size_t deltas, weights, costs, converged, iterations, matched_ratio;   /* in dicp_call.results: (N,K,6) T, (N,K,n) T, (N,K) T, (N) uint8, (N) T, (N) T */
     size_t pairs;            /* DICP_PAIR_SHARDS uint64: pairs scored by the searches */
     size_t n_matched, counters, poses, poses_search, alive, areg, n_start, partials, tgs4, tperm, bucket, brange, keys, tgt_sorted, scratch, scratch_bytes,
            frame, pose_s, orders, spos;      /* loop state and search structure (as dicp_loop_buffers names them) */

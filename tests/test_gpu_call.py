@@ -146,6 +146,36 @@ def test_which_calls_take_it():
     assert res["T"].shape == (2, 4, 4) and bool(torch.isfinite(res["T"]).all())
 
 
+def test_kept_results_keep_only_themselves_and_an_edited_step_history_is_refused():
+    """the non-differentiable results are views of a small allocation of their own -- a log of the costs of every training step must not keep
+    the call's workspace (search structure, match history, sort scratch) alive; and `deltas`, which the reverse sweep reads, is saved through autograd:
+    an in-place edit of it is refused instead of silently giving wrong gradients."""
+    src, tgt = make_pairs(8, 4096, 4096, seed=8, dtype=torch.float32)
+    icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=6, tolerance=1e-12)
+    icp.const_iter, icp.knn_variant = True, _lib.KNN_SWEEP
+    Tg, Ti = tgt.to(DEV), torch.eye(4).repeat(8, 1, 1).to(DEV)
+    log = []
+    torch.cuda.synchronize()
+    base = None
+    for step in range(6):
+        S = src.to(DEV).requires_grad_(True)
+        out = icp.icp(S, Tg, Ti, trim_dist=5.0, loss_fn=None, dim=3)
+        out["T"].sum().backward()
+        log.append(out["costs"])                        # what a training loop keeps per step
+        log.append(out["stats"]["iterations"])
+        del out, S
+        torch.cuda.synchronize()
+        if step == 1:
+            base = torch.cuda.memory_allocated()
+    grown = torch.cuda.memory_allocated() - base
+    assert grown < 4 * (1 << 20), grown                 # four more steps' logs: kilobytes, not four workspaces of ~5 MB (+ 0.8 MB of weights each)
+    S = src.to(DEV).requires_grad_(True)
+    out = icp.icp(S, Tg, Ti, trim_dist=5.0, loss_fn=None, dim=3)
+    out["deltas"].mul_(2.0)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        out["T"].sum().backward()
+
+
 def test_results_outlive_the_call_and_an_edited_result_does_not_block_the_backward():
     src, tgt = make_pairs(2, 2048, 2048, seed=8, dtype=torch.float32)
     icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=4, tolerance=1e-12)
@@ -179,7 +209,8 @@ def test_the_c_abi_alone():
     lay = _lib.CallLayout()
     assert lib.dicp_call_plan(_lib.F32, ctypes.byref(call), ctypes.byref(lay)) == 0
     ws = torch.empty(lay.total // 4, dtype=torch.float32, device=DEV)
-    call.workspace = ws.data_ptr()
+    rs = torch.empty(lay.results_total // 4, dtype=torch.float32, device=DEV)
+    call.workspace, call.results = ws.data_ptr(), rs.data_ptr()
     icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
     icp.const_iter, icp.knn_variant = True, _lib.KNN_SWEEP
     P = _lib.WeightParams(mode=_lib.PT2PL, trim_on=1, differentiable=1, loss=_lib.LOSS_HUBER, trim_dist=5.0, tanh_k=float(icp.config['dICP']['parameters']['tanh_steepness']),
@@ -188,7 +219,7 @@ def test_the_c_abi_alone():
     assert lib.dicp_call_forward(_lib.F32, ctypes.byref(P), ctypes.byref(call), st) == 0
     torch.cuda.synchronize()
     T = ws[lay.T // 4: lay.T // 4 + 16 * N].view(N, 4, 4)
-    deltas = ws[lay.deltas // 4: lay.deltas // 4 + 6 * K * N].view(N, K, 6)
+    deltas = rs[lay.deltas // 4: lay.deltas // 4 + 6 * K * N].view(N, K, 6)
     with torch.no_grad():
         out = icp.icp(S, Tg, Ti, trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0}, dim=3)
     assert torch.equal(T, out["T"]) and torch.equal(deltas, out["deltas"][..., 0])

@@ -326,6 +326,38 @@ def test_a_wait_that_ran_out_is_raised_not_returned():
     _tail_call(icp, src, tgt)
 
 
+def test_strict_errors_raise_in_the_failing_pass(monkeypatch):
+    """ICP.strict_errors: the pass that used the tail waits for itself and raises before it returns a gradient (the error word is raised by hand: the
+    library's memset of the pass's workspace is followed by a fill of that word, on the same stream, before the pass's kernels)."""
+    from dicp_amd import _ops
+    from dicp_amd._ops import TailTimeout
+    N, n, K = 12, 8192, 8
+    src, tgt = make_pairs(N, n, n, seed=93)
+    icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
+    icp.const_iter, icp.strict_errors = True, True
+    _tail_call(icp, src, tgt)
+    _tail_call(icp, src, tgt)                               # (strict and healthy: nothing raised)
+    assert icp.knn_stats["bwd_tail_from"] > 0
+    real = _ops._strict_tail_check
+    seen = []
+
+    def raised(cfg, word):
+        if word is not None:
+            word.fill_(1)                                   # what bwd_tail_kernel does when a wait runs out
+            seen.append(1)
+        return real(cfg, word)
+    monkeypatch.setattr(_ops, "_strict_tail_check", raised)
+    S = src.to(DEV).requires_grad_(True)
+    Tg = tgt.to(DEV).requires_grad_(True)
+    out = icp.icp(S, Tg, torch.eye(4, device=DEV).repeat(N, 1, 1), trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0})
+    with pytest.raises(TailTimeout):
+        out["T"].sum().backward()
+    assert seen and S.grad is None and Tg.grad is None      # no gradient was handed to the caller
+    icp.strict_errors = False
+    monkeypatch.setattr(_ops, "_strict_tail_check", real)
+    _tail_call(icp, src, tgt)
+
+
 def test_two_backward_passes_on_two_streams_beside_a_busy_gpu():
     """Two ICP objects run forward + backward (tails placed, with stragglers: hints wrong on purpose) concurrently on two streams while a third
     stream keeps the GPU full of other work: same gradients as alone, no wait ran out."""

@@ -22,7 +22,7 @@ F16_SWEEP_MIN_TARGETS = 32768               # ... and, for a cloud whose slabs h
                                             # cores if they were long (dicp_loop_buffers.sweep_form) -- clouds of 16384 points that start a metre off, or a third of which has no
                                             # counterpart in the target, score 30 % of the pairs: 28.2 -> 19.0 ms per 10-iteration call (profiles/r05_independent_forms.txt)
 F16_SWEEP_ADAPTIVE = True                   # (False: the form is chosen by the size alone, as in round 4)
-FORM_TILES = 20                             # (kernels_search.h: tiles per unit of 128 queries from which on a cloud's plain searches score on the matrix cores)
+FORM_TILES = 32                             # (kernels_search.h: tiles per unit of 128 queries from which on a cloud's plain searches score on the matrix cores)
 SWEEP_MIN_PAIRS = 1e8        # ... and below this many (query,target) pairs per iteration.  Measured (profiles/r02_mid_size_paths.txt): with the
                              # native key sort the sweep's per-call set-up is ~0.1 ms, and it already wins at 32 x 2048^2 and 8 x 4096^2
                              # (0.090 vs 0.103 and 0.075 vs 0.121 ms per iteration, fwd+bwd); at 32 x 4096^2 (BASELINE configs[1]) 0.084 vs 0.175
@@ -575,9 +575,14 @@ def resort_schedule(resort, N, n, Kmax, reuse_matches, cert_from):
     """The iterations before which the sweep re-orders its queries: `resort` as given, or (None) by the size of the call."""
     if resort is not None:
         return tuple(int(v) for v in resort)
-    full = (0, 1, 2, 3)
+    full, small = (0, 1, 2, 3), (0, 1)
     cf = max([k for k in full if k < Kmax] or [0]) if cert_from is None else max(0, int(cert_from))
-    return (0, 1) if (not certificates_pay(reuse_matches, Kmax, cf, N, n) and N * n < RESORT_SMALL_POINTS) else full
+    if certificates_pay(reuse_matches, Kmax, cf, N, n) or N * n >= RESORT_SMALL_POINTS:
+        return full
+    # the short schedule was measured for calls WITHOUT certificates: it is only taken where they do not pay under it either (the loop derives the
+    # certifying search's iteration from the schedule it is handed -- with (0, 1) that is iteration 1, two certified iterations more than under `full`)
+    cf_small = max([k for k in small if k < Kmax] or [0]) if cert_from is None else cf
+    return full if certificates_pay(reuse_matches, Kmax, cf_small, N, n) else small
 
 
 
@@ -808,7 +813,7 @@ class ICPLoop(torch.autograd.Function):
             if tally and cfg.hints is not None and not torch.cuda.is_current_stream_capturing():
                 form_hint = cfg.hints.form_record(dev, (N, n, m, dt))
                 if form_hint["event"] is not None and form_hint["event"].query():
-                    form_hint["long"] = bool(int(form_hint["host"][0]) > 0)
+                    form_hint["long"] = bool(4 * int(form_hint["host"][0]) >= N)     # (a quarter of the clouds: the image and the second launch cost every call 0.1 ms)
                     form_hint["event"] = None
                 if img16 is None and form_hint["long"]:
                     img16 = sweep.make_image()

@@ -144,8 +144,9 @@ template <typename T> struct SweepCert {
     // form_in (the previous plain search's tally) leaves a cloud alone unless its slabs were long (form_mine = 1: the matrix-core form) / short (0: this one)
     const int32_t* form_in; int32_t* form_out; int form_mine, form_default;     // (form_default: the form of a cloud without a tally -- 0 in form_in: no plain search before)
 };
-constexpr int FORM_TILES = 20;      // tiles per unit from which on a cloud's plain searches score on the matrix cores: a wave's fixed cost there (prologue, margins, the exact
-                                    // refine of the winners' rows) is ~16 tiles' worth of VALU scoring (profiles/r04_knn_f16_sweep.txt: 0.92x at 16 tiles, 1.27x at 32)
+constexpr int FORM_TILES = 32;      // tiles per unit from which on a cloud's plain searches score on the matrix cores: a wave's fixed cost there (prologue, margins, the exact
+                                    // refine of the winners' rows) is ~16 tiles' worth of VALU scoring (profiles/r04_knn_f16_sweep.txt: 0.92x at 16 tiles, 1.27x at 32;
+                                    // at 20 the benchmark's own first search -- 15-25 tiles per unit -- sent a few clouds there for nothing)
 __device__ __forceinline__ bool form_is_mine(const int32_t* __restrict__ form_in, int form_mine, int form_default, int cloud, int queries) {
     if (!form_in) return true;
     const int units = (queries + 2 * WAVE - 1) / (2 * WAVE), tally = form_in[cloud];     // (units of 128 queries: the matrix-core form's)
@@ -214,7 +215,9 @@ __device__ __forceinline__ int wave_min(int v) {
 template <typename T> struct SweepRing { static constexpr int NT = sizeof(T) == 4 ? 6 : 3; };
 
 // The search of ONE unit (64*Q consecutive slots of a cloud's query order) by one wave; `ring`: the wave's NT tiles of LDS.
-template <typename T, int Q, int CH, bool CERT>
+// STATE: the search runs inside the certified loop and keeps its state (budgets or marks, the searches' copy of the matches, pending matches); the plain
+// kernel outside it is compiled without (its registers are the headline's: at 96 it spilled 40 bytes with that code merely present)
+template <typename T, int Q, int CH, bool CERT, bool STATE = true>
 __device__ __forceinline__ void sweep_unit(const T* __restrict__ src, const T* __restrict__ pose,
                                            const typename V4<T>::type* __restrict__ tgs4,
                                            const int32_t* __restrict__ tperm, const int32_t* __restrict__ qorder,
@@ -412,13 +415,13 @@ __device__ __forceinline__ void sweep_unit(const T* __restrict__ src, const T* _
         // (to_pend) a match that CHANGED is left for the accumulate that follows, which owns the history's slabs and the cached rows
         const int val = (bo == 0x7fffffff || bo >= m) ? -1 : bs;
         const size_t at = (size_t)cloud * n_full + unit * (WAVE * Q) + q * WAVE + lane;       // the query's slot: the certificates' own arrays go by it
-        if (to_pend) {
+        if (STATE && to_pend) {
             if (ct.cm[at] != val) {
                 ct.pend[(size_t)cloud * n_full + qi[q]] = val + 2;
                 ct.gdirty[(size_t)cloud * ct.nwr + (qi[q] >> 6)] = 1;
             }
         } else if (spos) spos[(size_t)cloud * n_full + qi[q]] = val;
-        if (ct.cm) ct.cm[at] = val;
+        if (STATE && ct.cm) ct.cm[at] = val;
         if (CERT) {
             T bq = T(-1);
             if (bo != 0x7fffffff && ob[q] != best[q]) {     // (three or more tied chunks: no certificate)
@@ -434,7 +437,7 @@ __device__ __forceinline__ void sweep_unit(const T* __restrict__ src, const T* _
             ct.q[at] = bq > T(0) ? bq : cert_mark<T>(ct.k);
             if (ct.set) set_budgets<T>(ct.set)[at] = T(-1);      // (a new search: whatever candidate set the query had is void)
             if (bq > T(0)) qmin = min_t(qmin, bq); else ++nunc;
-        } else if (ct.q) {
+        } else if (STATE && ct.q) {
             ct.q[at] = cert_mark<T>(ct.k);                      // plain search of a unit inside a certified loop
             if (ct.set) set_budgets<T>(ct.set)[at] = T(-1);
         }
@@ -468,15 +471,21 @@ __device__ __forceinline__ void sweep_unit(const T* __restrict__ src, const T* _
 #define DICP_SWEEP_MINW ((Q == 2 && CH == 8 && sizeof(T) == 4) ? SWEEP_MINW_Q2C8 : 1)
 
 // Every unit of every cloud: block (cloud, blk) of the XCD-aware grid, one unit per wave.
+// The certifying search and the guard launch carry more state than the plain search (the runner-up, the budgets; both forms of the unit search, the
+// single-query search): at the plain kernel's 5 waves per SIMD they kept 64 / 132 bytes per lane in scratch memory; at 4 they keep none
+// (profiles/r05_kernel_resources.txt).
+#ifndef DICP_CERT_MINW
+#define DICP_CERT_MINW 4
+#endif
 template <typename T, int Q, int CH, bool CERT>
-__global__ __launch_bounds__(BLOCK, DICP_SWEEP_MINW) void knn_sweep_kernel(DICP_SWEEP_PARAMS) {
+__global__ __launch_bounds__(BLOCK, (CERT && DICP_SWEEP_MINW > DICP_CERT_MINW) ? DICP_CERT_MINW : DICP_SWEEP_MINW) void knn_sweep_kernel(DICP_SWEEP_PARAMS) {
     __shared__ typename V4<T>::type tiles[BLOCK / WAVE][SweepRing<T>::NT * WAVE];
     int cloud, blk;
     if (!decode_block(bpc, N, cloud, blk)) return;
     if (!CERT && !form_is_mine(ct.form_in, ct.form_mine, ct.form_default, cloud, rows_of(src_rows, cloud, n_full))) return;      // (this cloud's slabs were long: the matrix-core launch has it)
-    const int wave = threadIdx.x >> 6;
-    sweep_unit<T, Q, CH, CERT>(src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, idx, spos, pairs, n_full, m_full, m_pad, src_rows, tgt_rows, ct,
-                               cloud, blk * (BLOCK / WAVE) + wave, tiles[wave]);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // (wave-uniform, and told so: the unit's number then lives in a scalar register)
+    sweep_unit<T, Q, CH, CERT, CERT>(src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, idx, spos, pairs, n_full, m_full, m_pad, src_rows, tgt_rows, ct,
+                                     cloud, blk * (BLOCK / WAVE) + wave, tiles[wave]);
 }
 
 // What the search of one query needs besides the query (guard launches of the certified loop).
@@ -845,7 +854,7 @@ __device__ __forceinline__ void guard_sets(const T* __restrict__ src, const T* _
 // have anything to do, one list per XCD so that a cloud's units are searched on the XCD whose L2 holds its rows).  Near the pose the lists are
 // (next to) empty and the launch is one load per wave.
 template <typename T, int Q, int CH>
-__global__ __launch_bounds__(BLOCK, DICP_SWEEP_MINW) void knn_sweep_guard_kernel(DICP_SWEEP_PARAMS, const int32_t* __restrict__ glist, const int32_t* __restrict__ gcount, int glist_cap) {
+__global__ __launch_bounds__(BLOCK, (DICP_SWEEP_MINW > DICP_CERT_MINW ? DICP_CERT_MINW : DICP_SWEEP_MINW)) void knn_sweep_guard_kernel(DICP_SWEEP_PARAMS, const int32_t* __restrict__ glist, const int32_t* __restrict__ gcount, int glist_cap) {
     __shared__ typename V4<T>::type tiles[BLOCK / WAVE][SweepRing<T>::NT * WAVE];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int xcd = blockIdx.x & 7;

@@ -172,3 +172,7 @@ def test_resort_schedule_by_size(monkeypatch):
     assert _ops.resort_schedule(None, 32, 4096, 100, True, None) == (0, 1, 2, 3)              # a long call: 96 certified iterations x 131072 points pay for certificates
     assert _ops.resort_schedule(None, 32, 4096, 100, False, None) == (0, 1)                   # ... unless they are switched off
     assert _ops.resort_schedule(None, 1, 65, 2, True, None) == (0, 1)
+    # a size where certificates do not pay under the full schedule (certifying search at iteration 3) but would under the short one (at 1) keeps the
+    # full schedule: the short one was measured for calls without certificates only, and the loop derives the certificates from the schedule it is handed
+    assert not _ops.certificates_pay(True, 13, 3, 49, 4096) and _ops.certificates_pay(True, 13, 1, 49, 4096)
+    assert _ops.resort_schedule(None, 49, 4096, 13, True, None) == (0, 1, 2, 3)

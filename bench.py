@@ -115,6 +115,18 @@ def git_head():
         return None
 
 
+def kernel_sources_sha16():
+    """A hash of the library's sources (csrc + the header): what a committed PMC profile is stamped with (scripts/pmc_summary.py), so that a traffic figure
+    taken from it can say whether the kernels have changed since (the GPU box has no .git to ask)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "dicp_amd", "csrc", "*.h*")) + [os.path.join(ROOT, "include", "dicp_hip.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel_prefix, B, n):
     """HBM bytes per launch from the COMMITTED rocprofv3 PMC passes (profiles/*_pmc_hbm_traffic*.json, made by
     scripts/pmc_summary.py from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command).  PMC counters
@@ -131,7 +143,9 @@ def pmc_traffic(kernel_prefix, B, n):
         hits = [k for name, k in d["kernels"].items() if name.startswith(kernel_prefix) and k.get("launches")]
         if hits:        # several launch configurations of one kernel (template arguments): launch-weighted mean
             tot = sum(k["launches"] for k in hits)
-            src = "from committed profile %s@%s (not measured by this run)" % (os.path.basename(f), d.get("commit", "unknown"))
+            stale = d.get("kernel_sources_sha16") != kernel_sources_sha16()
+            src = "from committed profile %s@%s (not measured by this run)%s" % (os.path.basename(f), d.get("commit", "unknown"),
+                  "; STALE: the kernel sources have changed since that profile was taken" if stale else "; kernel sources unchanged since")
             if kernel_prefix.startswith("accumulate_bwd") and all("hbm_bytes_full_launches" in k for k in hits):      # (launches with every cloud at work)
                 tot = sum(k["full_launches"] for k in hits)
                 return sum(k["hbm_bytes_full_launches"] * k["full_launches"] for k in hits) / tot, src
@@ -235,9 +249,57 @@ def other_configs(make_icp, dev, sync):
         if name == "sweep" and "knn_pairs" in obj.knn_stats:
             legs[name]["pairs_scored_fraction"] = float(obj.knn_stats["knn_pairs"].sum().item()) / Kc / (float(Bc) * nc * nc)
         del obj
+    del s4, t4, T4
+    # configs[3] at its FULL batch: 256 x 65536, the default search (sorted sweep, matrix-core scoring from 32768 targets on)
+    Bf = 256
+    parts = [make_pairs(64, nc, nc, seed=4, dtype=torch.float32, first=64 * i) for i in range(Bf // 64)]
+    sf, tf = torch.cat([p_[0] for p_ in parts]).to(dev), torch.cat([p_[1] for p_ in parts]).to(dev)
+    del parts
+    Tf = torch.eye(4, device=dev).repeat(Bf, 1, 1)
+    full = make_icp(icp_type="pt2pl", differentiable=True, max_iterations=Kc, tolerance=1e-12)
+    full.const_iter = True
+
+    def full_call():
+        s, t = sf.detach().requires_grad_(True), tf.detach().requires_grad_(True)
+        o = full.icp(s, t, Tf, trim_dist=TRIM, loss_fn=LOSS, dim=3)
+        o["T"].sum().backward()
+        return o, s, t
+    tfull = time_calls(full_call, 3, warm=2)
+    o, s_, t_ = full_call()
+    out["value_c4_full"] = {"workload": "BASELINE configs[3] at its full batch: B=256 x 65536-pt clouds, point-to-plane + huber(1.0) + trim(5.0), K=5 fwd+bwd, default search",
+                            "cloud_iterations_per_s": Bf * Kc / tfull, "ms_per_call": tfull * 1e3, "ms_per_iteration": tfull * 1e3 / Kc,
+                            "pairs_scored_fraction": float(full.knn_stats["knn_pairs"].sum().item()) / Kc / (float(Bf) * nc * nc) if "knn_pairs" in full.knn_stats else None,
+                            "finite": bool(torch.isfinite(o["T"]).all() and torch.isfinite(s_.grad).all() and torch.isfinite(t_.grad).all()),
+                            "peak_memory_GB": torch.cuda.max_memory_allocated() / 1e9}
+    del sf, tf, Tf, full, o, s_, t_
+    # configs[0]: the reference's own test pair (tests/test_ICP.py:35-117: 65 points, float64, point-to-plane, dim 2) -- latency of one call, forward + backward
+    try:
+        import numpy as np
+        from dicp_amd.graphed import graphed_icp_step
+        scan = torch.from_numpy(np.load(os.path.join(ROOT, "tests", "golden", "points_scan.npy"))).to(torch.float64)
+        mp = torch.from_numpy(np.load(os.path.join(ROOT, "tests", "golden", "points_map.npy"))).to(torch.float64)
+        s1, t1 = scan.to(dev), mp.to(dev)
+        T1 = torch.eye(4, dtype=torch.float64, device=dev)
+        one = make_icp(icp_type="pt2pl", differentiable=True, max_iterations=6, tolerance=1e-12)     # (6: where the reference's own tolerance stops this pair)
+        one.const_iter = True
+        kw1 = dict(trim_dist=5.0, loss_fn={"name": "huber", "metric": 10.0}, dim=2)
+
+        def one_call():
+            s, t = s1.detach().requires_grad_(True), t1.detach().requires_grad_(True)
+            one.icp(s, t, T1, **kw1)["T"].sum().backward()
+        t_eager = time_calls(one_call, 20, warm=5)
+        sg, tg = s1.detach().unsqueeze(0).requires_grad_(True), t1.detach().unsqueeze(0).requires_grad_(True)
+        step = graphed_icp_step(one, lambda o_: o_["T"].sum(), sg, tg, T1.unsqueeze(0), **kw1)
+        t_graph = time_calls(lambda: step(sg, tg, T1.unsqueeze(0)), 20, warm=5)
+        out["value_c1"] = {"workload": "BASELINE configs[0]: the reference's tests/data pair (%d source / %d target points), float64, point-to-plane + huber(10) + trim(5), dim 2, "
+                                       "6 iterations, forward + backward of T.sum(), one pair per call" % (s1.shape[0], t1.shape[0]),
+                           "eager_ms_per_call": t_eager * 1e3, "graphed_ms_per_call": t_graph * 1e3,
+                           "note": "latency, not throughput: one block per cloud runs the whole loop (icp_small_* kernels); graphed = dicp_amd.graphed.graphed_icp_step (call + loss + backward as one hipGraph)"}
+    except Exception as e:      # (the fixtures travel with tests/; a missing file must not cost the run its line)
+        out["value_c1"] = {"error": repr(e)}
     legs["workload"] = "BASELINE configs[3] on a 64-cloud slice: 65536-pt clouds, point-to-plane + huber(1.0) + trim(5.0), K=5 fwd+bwd"
     legs["note"] = ("sweep: the exact sorted sweep, its plain searches scoring on the matrix cores (from 32768 targets per cloud on); mfma_bruteforce: all n*m pairs on "
-                    "v_mfma_f32_32x32x16_f16 (split-f16 filter + exact float32 refine); matrix-pipe counters of both at HEAD: profiles/r04_knn_c4_65536_pmc.txt")
+                    "v_mfma_f32_32x32x16_f16 (split-f16 filter + exact float32 refine); matrix-pipe counters: profiles/r05_knn_c4_65536_pmc.txt")
     out["value_c4"] = legs
     return out
 
@@ -690,7 +752,15 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
                                    "trim(5.0), differentiable, dim=3, K=%d const iterations fwd + backward of T.sum() "
                                    "w.r.t. source and target" % (B, n, K),
                        "K": K, "clouds_per_gpu": B, "points": n, "icp_type": "pt2pl", "knn": args.knn,
-                       "parallelism": "batch-sharded x%d, one pose all-gather per call" % world},
+                       "parallelism": "batch-sharded x%d, one pose all-gather per call" % world,
+                       # (`value` grows with K -- the clouds converge in ~6 iterations, every further one is a certified iteration that costs a
+                       #  sixth of an early one; the same run's other figures belong next to it wherever it is quoted)
+                       "k_note": ("value is cloud-iterations/s at K = %d constant iterations, of which ~%d run after the clouds have converged; the same run at SURVEY 8d's "
+                                  "K = 10: value_k10 = %s; in the reference's default tolerance mode (const_iter off, 6 iterations executed): value_tolerance = %s; on "
+                                  "independently sampled, partially overlapping clouds with metre-sized start poses (K = 10): value_independent = %s"
+                                  % (K, max(0, K - 6), ("%.0f" % extra["value_k10"]) if "value_k10" in extra else ("%.0f" % (world * B * K / elapsed) if K == 10 else "not run"),
+                                     ("%.0f" % extra["value_tolerance"]) if "value_tolerance" in extra else "not run",
+                                     ("%.0f" % extra["value_independent"]) if "value_independent" in extra else "not run"))},
             "roofline": dict(legs[top], dominant="largest share of the event-carrying timed call (%.3f ms): %s"
                              % (last_ms, ", ".join("%s %.0f %%" % (nm, 100 * share[nm]) for nm in sorted(share, key=lambda q: -share[q])))),
             "roofline_bruteforce_knn": {"kernel": "knn_valu_kernel (all n*m pairs, float32 FMA)", "bound": "valu",
@@ -720,8 +790,9 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
             line["ms_by_iteration_class"] = {
                 nm: {"iterations": ks, "search_ms_mean": round(sum(ev_ms["knn"][k] for k in ks) / len(ks), 4),
                      "accumulate_ms_mean": round(sum(ev_ms["accumulate"][k] for k in ks) / len(ks), 4)} for nm, ks in classes.items() if ks}
-            line["ms_by_iteration_class"]["note"] = ("HIP events of the last timed call; certified: the search launch is the guard (one wave per unit, re-searches units with many "
-                                                     "spent budgets), the accumulate also searches the single queries whose budget is spent")
+            line["ms_by_iteration_class"]["note"] = ("HIP events of the last timed call; certified: the search launch is the guard (it works through the list of units the "
+                                                     "previous step made: re-searches units with many spent budgets, single queries, re-scores candidate sets), the "
+                                                     "accumulate streams each query's cached match row")
         for nm, key in (("knn", "roofline_knn"), ("accumulate", "roofline_accumulate"), ("accumulate_bwd", "roofline_streaming")):
             if nm != top:
                 line[key] = legs[nm]

@@ -277,7 +277,6 @@ __global__ __launch_bounds__(BLOCK) void accumulate_bwd_window_kernel(WeightPara
 // gtgt[b][tperm[s]][col] += gts_far[b][s][col] + sum over the blocks whose window covers sorted row s of their
 // slab rows: the once-per-call end of the windowed backward (also undoes the sorted target order).
 constexpr int WR_U = 4;      // gradient elements per thread
-constexpr int WR_B = 8;      // window blocks per round of loads (16: 160 us instead of 118 -- registers)
 template <typename T, int WT, int CV>
 __global__ __launch_bounds__(BLOCK) void window_reduce_kernel(const T* __restrict__ slab, const int32_t* __restrict__ spos_ref,
                                                               const int32_t* __restrict__ qorder,
@@ -308,26 +307,37 @@ __global__ __launch_bounds__(BLOCK) void window_reduce_kernel(const T* __restric
             origin[b] = window_origin(spos_ref + (size_t)cloud * n, qorder ? qorder + (size_t)cloud * n : nullptr, b0 + b, spb, rows_of(src_rows, cloud, n), m_pad, WT);
         __syncthreads();
         const int nb = min(MAXB, bpc - b0);
-        // the block loop is the OUTER one: all of a thread's elements have their (predicated) loads of WR_B window blocks in
-        // flight together -- the kernel is bound by how many dependent rounds of loads a thread makes, not by bytes
-        for (int bb = 0; bb < nb; bb += WR_B) {
-            T v[WR_U][WR_B];
+        // Which windows cover a row is arithmetic on the origins in LDS; only those are loaded (two or three of the cloud's blocks, in ascending block order: the
+        // order of the sums is what it was).  Round 5: the kernel used to issue a predicated load per (element, block) -- 64 load instructions per thread for ~9
+        // real loads, 117 us per call; it is bound by instructions, not bytes.
+        for (int bb = 0; bb < nb; bb += 32) {
+            unsigned cover[WR_U];
 #pragma unroll
-            for (int u = 0; u < WR_U; ++u) {
-                const int e = min(e0 + u * BLOCK + tid, m * cv - 1);
-                const int s = e / CV;
+            for (int u = 0; u < WR_U; ++u) cover[u] = 0u;
+            const int nbb = min(32, nb - bb);
+            for (int k = 0; k < nbb; ++k) {
+                const int lo = origin[bb + k];
 #pragma unroll
-                for (int k = 0; k < WR_B; ++k) {
-                    const int b = min(bb + k, nb - 1);
-                    const int lo = origin[b];
-                    const bool cov = bb + k < nb && s >= lo && s < lo + WT;
-                    v[u][k] = cov ? slab[((size_t)cloud * bpc + b0 + b) * (WT * CV) + (size_t)(e - lo * CV)] : T(0);
+                for (int u = 0; u < WR_U; ++u) {
+                    const int sr = min(e0 + u * BLOCK + tid, m * cv - 1) / CV;
+                    cover[u] |= (sr >= lo && sr < lo + WT) ? (1u << k) : 0u;
                 }
             }
+            while (__any((cover[0] | cover[1] | cover[2] | cover[3]) != 0u)) {       // (rounds of one load per element, all of a thread's in flight together)
+                T v[WR_U];
 #pragma unroll
-            for (int u = 0; u < WR_U; ++u)
+                for (int u = 0; u < WR_U; ++u) {
+                    v[u] = T(0);
+                    if (cover[u]) {
+                        const int k = __ffs((int)cover[u]) - 1;
+                        cover[u] &= cover[u] - 1;
+                        const int e = min(e0 + u * BLOCK + tid, m * cv - 1);
+                        v[u] = slab[((size_t)cloud * bpc + b0 + bb + k) * (WT * CV) + (size_t)(e - origin[bb + k] * CV)];
+                    }
+                }
 #pragma unroll
-                for (int k = 0; k < WR_B; ++k) acc[u] += v[u][k];
+                for (int u = 0; u < WR_U; ++u) acc[u] += v[u];
+            }
         }
     }
 #pragma unroll

@@ -17,10 +17,14 @@ def load(d, counter):
     return agg
 
 
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_sources_sha16      # (what bench.py compares: a traffic figure quoted from this profile says whether the kernels have changed since)
+
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 out = {"units": "bytes per launch (mean over launches)", "fetch_correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-read under-count)",
        "workload": {"B": int(sys.argv[4]) if len(sys.argv) > 4 else 256, "n": int(sys.argv[5]) if len(sys.argv) > 5 else 16384},
-       "commit": sys.argv[6] if len(sys.argv) > 6 else "unknown", "kernels": {}}
+       "commit": sys.argv[6] if len(sys.argv) > 6 else "unknown", "kernel_sources_sha16": kernel_sources_sha16(), "kernels": {}}
 for name in sorted(set(fetch) | set(write)):
     if "anonymous namespace" not in name:
         continue

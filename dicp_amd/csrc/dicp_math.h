@@ -46,11 +46,36 @@ struct WeightParams {
     double match_thresh;
 };
 
+// A parameter of the call in the kernel's scalar type.  On the device a float comes back in a SCALAR register: the parameters are doubles, a conversion is a
+// vector instruction, and its wave-uniform result would otherwise sit in a vector register for as long as a loop around the point functions runs.
+template <typename T> DICP_HD T wp_val(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (sizeof(T) == 4) return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)v)));
+#endif
+    return (T)v;
+}
+
 DICP_HD int tri(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }   // i <= j
 
+// float32 on the device: the hardware's own one-instruction forms (v_sqrt_f32, v_rcp_f32, v_exp_f32: 1 ulp each), not the correctly rounded expansions --
+// a division is 10 vector instructions that way, tanhf ~40, sqrtf ~12, and the per-point functions below are instruction-bound: of the 430 vector instructions
+// the windowed backward spent per point, ~100 were these (profiles/r05_point_math.txt).  A weight or a gradient moves by parts in 1e7; north_star's float32
+// bar is 1e-4 / 1e-3, and every form of every kernel shares these functions, so results that are compared bit for bit (searches, certified iterations) still are.
+// float64, and the host build of this header (tests/hostcheck), keep the correctly rounded forms.
+#if defined(__HIP_DEVICE_COMPILE__)
+DICP_HD float  m_sqrt(float x)  { return __builtin_amdgcn_sqrtf(x); }
+DICP_HD float  m_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+DICP_HD float  m_tanh(float x)  {                       // 1 - 2 / (e^2x + 1): +-1 at the ends (e -> inf, 0), absolute error ~1e-7
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+}
+#else
 DICP_HD float  m_sqrt(float x)  { return sqrtf(x); }
-DICP_HD double m_sqrt(double x) { return sqrt(x); }
+DICP_HD float  m_div(float a, float b) { return a / b; }
 DICP_HD float  m_tanh(float x)  { return tanhf(x); }
+#endif
+DICP_HD double m_sqrt(double x) { return sqrt(x); }
+DICP_HD double m_div(double a, double b) { return a / b; }
 DICP_HD double m_tanh(double x) { return tanh(x); }
 DICP_HD float  m_abs(float x)   { return fabsf(x); }
 DICP_HD double m_abs(double x)  { return fabs(x); }
@@ -59,8 +84,8 @@ DICP_HD double m_abs(double x)  { return fabs(x); }
 // BOTH where() branches and masks afterwards, so at en == 0 the reference's gradient is 0 * (-inf) = NaN;
 // that (tested-as-is) behaviour is kept rather than silently repaired.
 template <typename T> DICP_HD T hard_huber_slope(T en, T delta) {
-    if (en > delta) return -delta / (en * en);
-    return (en == T(0)) ? (T(0) * (-delta / (en * en))) : T(0);
+    if (en > delta) return m_div(-delta, en * en);
+    return (en == T(0)) ? (T(0) * m_div(-delta, en * en)) : T(0);
 }
 
 template <typename T> DICP_HD void cross3(const T* a, const T* b, T* o) {
@@ -101,23 +126,23 @@ DICP_HD void point_weights(const WeightParams& P, const T* C, const T* r, const 
     s.tw = T(1); s.th = T(0);
     if (P.trim_on) {
         if (P.differentiable) {                                            // loss.py:54
-            s.th = m_tanh(T(P.tanh_k) * (T(P.trim_dist) - s.d3) - T(3));
+            s.th = m_tanh(wp_val<T>(P.tanh_k) * (wp_val<T>(P.trim_dist) - s.d3) - T(3));
             s.tw = T(0.5) * s.th + T(0.5);
         } else {                                                           // loss.py:58
-            s.tw = (s.d3 < T(P.trim_dist)) ? T(1) : T(0);
+            s.tw = (s.d3 < wp_val<T>(P.trim_dist)) ? T(1) : T(0);
         }
     }
     s.lw = T(1); s.lth = T(0);
-    const T dl = T(P.loss_delta);
+    const T dl = wp_val<T>(P.loss_delta);
     if (P.loss == LOSS_HUBER) {
-        if (P.differentiable) s.lw = (dl * dl) / (dl * dl + s.en * s.en);  // loss.py:30
-        else                  s.lw = (s.en > dl) ? dl / s.en : T(1);       // loss.py:32
+        if (P.differentiable) s.lw = m_div(dl * dl, dl * dl + s.en * s.en);  // loss.py:30
+        else                  s.lw = (s.en > dl) ? m_div(dl, s.en) : T(1);   // loss.py:32
     } else if (P.loss == LOSS_CAUCHY) {                                    // loss.py:41
-        const T t = s.en / dl;
-        s.lw = T(1) / (T(1) + t * t);
+        const T t = m_div(s.en, dl);
+        s.lw = m_div(T(1), T(1) + t * t);
     } else if (P.loss == LOSS_TRIM) {                                      // loss.py:43-58 on the loss residual (ICP.py:157-160)
         if (P.differentiable) {
-            s.lth = m_tanh(T(P.tanh_k) * (dl - s.en) - T(3));
+            s.lth = m_tanh(wp_val<T>(P.tanh_k) * (dl - s.en) - T(3));
             s.lw = T(0.5) * s.lth + T(0.5);
         } else {
             s.lw = (s.en < dl) ? T(1) : T(0);
@@ -183,7 +208,7 @@ DICP_HD void point_forward(const WeightParams& P, const T* C, const T* r, const 
     }
     const T rows = (MODE == MODE_PT2PT) ? T(3) : T(1);
     acc[ACC_SUMW] += rows * s.w;
-    if (s.w > T(P.match_thresh)) acc[ACC_NMATCH] += rows;
+    if (s.w > wp_val<T>(P.match_thresh)) acc[ACC_NMATCH] += rows;
 }
 
 // Backward for one point.  Gs = G_A + G_A^T (6x6 row-major, symmetric), gb = dL/db.
@@ -264,20 +289,20 @@ DICP_HD void point_backward(const WeightParams& P, const T* C, const T* r, const
         e3bar[0] = u * Jgb[0]; e3bar[1] = u * Jgb[1]; e3bar[2] = u * Jgb[2];
     }
     // u = (sqrt(w+1e-10) - 1e-5)^2
-    const T wbar = ubar * s.ws / s.root;
+    const T wbar = m_div(ubar * s.ws, s.root);
     gw0 = wbar * s.tw * s.lw;
     const T twbar = wbar * w0 * s.lw;
     const T lwbar = wbar * w0 * s.tw;
     // robust loss -> error
-    const T dl = T(P.loss_delta);
+    const T dl = wp_val<T>(P.loss_delta);
     T dlw_den = T(0);     // d lw / d en
     if (P.loss == LOSS_HUBER) {
-        if (P.differentiable) dlw_den = -T(2) * s.en * s.lw * s.lw / (dl * dl);
+        if (P.differentiable) dlw_den = m_div(-T(2) * s.en * s.lw * s.lw, dl * dl);
         else                  dlw_den = hard_huber_slope(s.en, dl);
     } else if (P.loss == LOSS_CAUCHY) {
-        dlw_den = -T(2) * s.en * s.lw * s.lw / (dl * dl);
+        dlw_den = m_div(-T(2) * s.en * s.lw * s.lw, dl * dl);
     } else if (P.loss == LOSS_TRIM && P.differentiable) {                  // the hard gate has no gradient
-        dlw_den = -T(0.5) * T(P.tanh_k) * (T(1) - s.lth * s.lth);
+        dlw_den = -T(0.5) * wp_val<T>(P.tanh_k) * (T(1) - s.lth * s.lth);
     }
     if (MODE == MODE_PT2PL) {
         // en = |e| ; torch's norm backward gives e/|e| (0 at e == 0)
@@ -285,12 +310,12 @@ DICP_HD void point_backward(const WeightParams& P, const T* C, const T* r, const
         ebar_s += lwbar * dlw_den * sgn;
     } else {
         // torch's vector-norm backward is e3/|e3|, and 0 at e3 == 0 (a NaN slope still propagates)
-        const T f = (s.d3 > T(0)) ? lwbar * dlw_den / s.d3 : lwbar * dlw_den * T(0);
+        const T f = (s.d3 > T(0)) ? m_div(lwbar * dlw_den, s.d3) : lwbar * dlw_den * T(0);
         e3bar[0] += f * s.e3[0]; e3bar[1] += f * s.e3[1]; e3bar[2] += f * s.e3[2];
     }
     // soft trim gate -> e3 (hard gate has no gradient)
     if (P.trim_on && P.differentiable && s.d3 > T(0)) {
-        const T f = twbar * (-T(0.5) * T(P.tanh_k) * (T(1) - s.th * s.th)) / s.d3;
+        const T f = m_div(twbar * (-T(0.5) * wp_val<T>(P.tanh_k) * (T(1) - s.th * s.th)), s.d3);
         e3bar[0] += f * s.e3[0]; e3bar[1] += f * s.e3[1]; e3bar[2] += f * s.e3[2];
     }
     if (MODE == MODE_PT2PL) {

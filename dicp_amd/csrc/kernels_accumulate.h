@@ -21,6 +21,31 @@ template <typename T, int NV, int PAD, int NT>
 __device__ __forceinline__ void block_reduce_store(T* v, T* __restrict__ out, T* lds /* [NT/WAVE][PAD] */) {
     static_assert(NV <= 32 && PAD >= NV, "reduce-scatter over 32 slots");
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
+    if constexpr (NV <= 16) {
+        // 16 slots (the backward's 12 pose sums): four halving steps over lane bits 4..1, then the two lane bits that are left (0 and 5) as plain
+        // exchanges of the one value a lane still carries: 17 exchanges instead of 32
+        T a[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a[k] = k < NV ? v[k] : T(0);
+        halve_step<T, 8>(a, lane);
+        halve_step<T, 4>(a, lane);
+        halve_step<T, 2>(a, lane);
+        halve_step<T, 1>(a, lane);
+        T x = a[0] + __shfl_xor(a[0], 1);
+        x += __shfl_xor(x, 32);
+        const int slot = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+        if (!(lane & 33) && slot < NV) lds[wave * PAD + slot] = x;
+        __syncthreads();
+        if (tid < PAD) {
+            T s = T(0);
+            if (tid < NV) {
+#pragma unroll
+                for (int w = 0; w < NT / WAVE; ++w) s += lds[w * PAD + tid];
+            }
+            out[tid] = s;
+        }
+        return;
+    }
     T a[32];
 #pragma unroll
     for (int k = 0; k < 32; ++k) a[k] = k < NV ? v[k] : T(0);

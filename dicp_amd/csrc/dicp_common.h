@@ -16,7 +16,7 @@ namespace {
 constexpr int BLOCK = 256;
 constexpr int WAVE = 64;
 #ifndef DICP_ACC_PTS
-#define DICP_ACC_PTS 1024
+#define DICP_ACC_PTS 512
 #endif
 constexpr int ACC_PTS = DICP_ACC_PTS;  // source points per accumulate block
 constexpr int KNN_PAD = 64;            // m_pad granularity: 4 MFMA tiles of 16 targets / largest VALU chunk

@@ -630,8 +630,8 @@ __device__ __forceinline__ void f16_sweep_unit(const float* __restrict__ src, co
     auto process = [&](const uint4& u0, const uint4& u1, int t) {
         half8 a0, a1;
         __builtin_memcpy(&a0, &u0, 16); __builtin_memcpy(&a1, &u1, 16);
-        if (t - tc0 >= 0 && t - tc0 < F16_NTC)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tg + (size_t)t * WAVE + lane),
+        if (t - tc0 >= 0 && t - tc0 < F16_NTC)      // (slot `lane` of the tile's 64 takes the row whose swizzled place it is: cache_slot)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tg + (size_t)t * WAVE + (lane & 48) + ((lane & 15) ^ (((t - tc0) * 4 + (lane >> 4)) & 15))),
                                              (__attribute__((address_space(3))) void*)&rowcache[wave][(t - tc0) * WAVE], 16, 0, 0);
         int chunk;
         asm("v_mov_b32 %0, %1" : "=v"(chunk) : "s"(t));
@@ -675,9 +675,14 @@ __device__ __forceinline__ void f16_sweep_unit(const float* __restrict__ src, co
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // (the row cache's copies have landed)
     __builtin_amdgcn_wave_barrier();
+    // Where a cached row lies.  The refine reads RUNS of 16 rows, every lane its own run, all lanes row k of their run at the same time: laid out in row
+    // order those reads fall on the same four LDS banks for every run (a run is 256 bytes = all 64 banks) and were served one run at a time -- bank
+    // conflicts on 81 % of the LDS cycles of this kernel (profiles/r04_knn_c4_65536_pmc.txt).  Row i of run R (of the 4 F16_NTC runs of the cache) is kept
+    // in place i ^ (R & 15) of its run instead: lanes on different runs now read different banks (runs R and R + 16 still share theirs).
+    auto cache_slot = [&](int sl, int in_tile) { const int R = sl * 4 + (in_tile >> 4); return R * 16 + ((in_tile & 15) ^ (R & 15)); };
     auto row_at = [&](int rr) {                                     // a visited row: from the cache when its tile is in it
         const int sl = (rr >> 6) - tc0;
-        return (sl >= 0 && sl < F16_NTC) ? rowcache[wave][sl * WAVE + (rr & 63)] : tg[rr];
+        return (sl >= 0 && sl < F16_NTC) ? rowcache[wave][cache_slot(sl, rr & 63)] : tg[rr];
     };
     // ---- refine.  A piece = the 2 x 16 rows of one (tile, lane half): rows 64 t + 32 a + 16 h + i, a = 0, 1
     // Written for latency: a wave passes here once, with three others per SIMD at best to hide behind -- so no scratch memory (register arrays
@@ -729,13 +734,14 @@ __device__ __forceinline__ void f16_sweep_unit(const float* __restrict__ src, co
             const int sl = (max(r0, 0) >> 6) - tc0;
             const bool cached = sl >= 0 && sl < F16_NTC;
             const bool far_run = r0 >= 0 && !cached;                // (a lane whose run is not in the cache gathers it from the sorted rows themselves)
-            const float4* __restrict__ rp = &rowcache[wave][min(max(sl, 0), F16_NTC - 1) * WAVE + (max(r0, 0) & 63)];
+            const int run = min(max(sl, 0), F16_NTC - 1) * 4 + ((max(r0, 0) & 63) >> 4), rx = run & 15;      // (r0 is a multiple of 16)
+            const float4* __restrict__ rp = &rowcache[wave][run * 16];
             float sc[16];
 #pragma unroll
             for (int kb = 0; kb < 16; kb += 8) {
                 float4 rw[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) rw[k] = rp[kb + k];
+                for (int k = 0; k < 8; ++k) rw[k] = rp[(kb + k) ^ rx];
                 if (__any(far_run)) {
                     if (far_run) {
 #pragma unroll

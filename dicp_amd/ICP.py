@@ -59,6 +59,14 @@ class ICP:
         # wait inside the launch ran out (a GPU kept full by other work for half a second) -- before the NaN gradients it would otherwise return reach an
         # optimizer.  False (default): no synchronisation; the failure is raised by the next backward pass of this object, or by check_errors().
         self.strict_errors = False
+        # True: gradients are the same bits on every run.  By default a target row's contributions are summed in the order the GPU's waves reach it (and the
+        # few whose match lies outside its block's window with float atomics), and the slot order of the backward comes from a counting sort that is not
+        # reproducible inside a bucket: two runs of one call differ by parts in 1e4 of the largest gradient (float32, profiles/r04_soak.txt), within the
+        # 1e-3 bar but unlike the reference, which is deterministic.  With the switch the call takes the exact sweep search and the windowed backward
+        # (whatever knn_variant says), the backward's slot order is a stable sort, every window row is summed in slot order and the out-of-window rows are
+        # added by a fixed-order launch instead of atomics; the one-launch tail and the one-call path are not used.  The forward's results do not depend
+        # on it.  Cost: DESIGN.md section 4 (about +0.5 ms per backward pass at 256 x 16384).  Not available with Gumbel correspondences.
+        self.deterministic = False
         # Private switches of single mechanisms, all on: what the tests flip to hold each mechanism to the path without it (and what the
         # measurements in DESIGN.md A/B'd).  Not part of the call surface.
         self._tuning = dict(
@@ -129,6 +137,9 @@ class ICP:
             source = source.contiguous()
         wants_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (source, target, T_init, w_pts) if t is not None)
         first_search = bool(self._tuning["first_search"]) and self._timing_events is None and not (wants_grad and not self.bwd_window)
+        deterministic = bool(self.deterministic) and wants_grad
+        if deterministic and soft:
+            raise NotImplementedError("ICP.deterministic: not with Gumbel-softmax correspondences (their adjoint adds to the target with float atomics)")
         cfg = LoopConfig(
             icp_type=self.icp_type, differentiable=bool(self.diff), max_iterations=int(self.max_iterations),
             tolerance=float(self.tolerance), trim_dist=trim_dist, loss_name=loss_name,
@@ -136,22 +147,23 @@ class ICP:
             const_iter=bool(self.const_iter),
             tanh_steepness=float(self.config['dICP']['parameters']['tanh_steepness']),   # ICP.py:119
             match_ratio_thresh=float(self.match_ratio_thresh),
-            knn_variant=self.knn_variant, bwd_window=bool(self.bwd_window), stats_out=self.knn_stats, hints=self._hints,
-            sync_every=self.sync_every, timing_events=self._timing_events, small_loop=bool(self._tuning["small_loop"]),
+            knn_variant=(_lib.KNN_SWEEP | (self.knn_variant & 0xff00)) if deterministic else self.knn_variant, bwd_window=True if deterministic else bool(self.bwd_window),
+            deterministic=deterministic, stats_out=self.knn_stats, hints=self._hints,
+            sync_every=self.sync_every, timing_events=self._timing_events, small_loop=False if deterministic else bool(self._tuning["small_loop"]),
             src_rows=src_rows, tgt_rows=tgt_rows, sweep_resort=resort_schedule(self._tuning["sweep_resort"], source.shape[0], source.shape[1], int(self.max_iterations), bool(self.reuse_matches), self._tuning["cert_from"]), reuse_matches=bool(self.reuse_matches), cert_from=self._tuning["cert_from"],
             bwd_skip_eps=self.bwd_skip_eps, cert_backoff=bool(self._tuning["cert_backoff"]), cert_sets=bool(self._tuning["cert_sets"]), cert_hint=bool(self._tuning["cert_hint"]),
             plan_call=bool(self._tuning["plan_call"]), bwd_tail=bool(self._tuning["bwd_tail"]), first_search=first_search, strict_errors=bool(self.strict_errors),
             # nn.py:14-16 via ICP.py:140: soft correspondences -- the same library loop with dicp_gumbel_nn in place of the search, the same one node
             gumbel=(self.nn.eps, self.nn.tau, getattr(self.nn, "_inject_U", None)) if soft else None)
         T_c = T_init.contiguous()
-        if self._tuning["one_call"] and _call.eligible(cfg, source, target, T_c, w_pts, wants_grad):
+        if self._tuning["one_call"] and not deterministic and _call.eligible(cfg, source, target, T_c, w_pts, wants_grad):
             # a call that needs none of the loop's host decisions: one library call per direction on one allocation (dicp_call_forward / _backward)
             T, pc, deltas, weights, costs, converged, iterations, matched = _call.CallLoop.apply(source, target, T_c, w_pts, cfg)
         else:
             # the target sort / index build of the sweep path goes to the GPU before the rest of the host work
             # (... and the first search right behind it, unless the loop will want original indices -- the atomic backward -- or carries timing events)
             if not soft:
-                cfg.prebuilt = prebuild_search(source, target, self.knn_variant, wants_grad and bool(self.bwd_window), T_init, src_rows, tgt_rows, first_search=first_search)
+                cfg.prebuilt = prebuild_search(source, target, cfg.knn_variant, wants_grad and bool(cfg.bwd_window), T_init, src_rows, tgt_rows, first_search=first_search)
             T, pc, deltas, weights, costs, converged, iterations, matched = ICPLoop.apply(source.contiguous(), target.contiguous(), T_init, w_pts, cfg)
 
         if per_cloud_w:

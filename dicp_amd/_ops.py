@@ -611,6 +611,7 @@ class LoopConfig:
     small_loop: bool = True       # small clouds: one block runs a cloud's whole chunk of iterations (icp_small_* kernels)
     cert_from: object = None      # iteration of the certifying search (None: the last re-ordering of the queries)
     gumbel: object = None         # (eps, tau, inject_U or None): the Gumbel-softmax correspondence (nn.py:43-70) instead of the nearest neighbour
+    deterministic: bool = False   # backward: the same bits on every run (slot order from a stable sort, window rows summed in slot order, out-of-window rows without float atomics)
     bwd_tail: bool = True         # truncated reverse sweep: the iterations before the ones the previous call still worked at run as ONE launch (dicp_loop_buffers.bwd_tail_from)
     strict_errors: bool = False   # a pass that used that launch waits for itself and raises TailTimeout if a wait inside it ran out (ICP.strict_errors)
     plan_call: bool = True        # constant-iteration sweep calls: all segments behind one library call (dicp_icp_forward_plan)
@@ -1161,7 +1162,7 @@ class ICPLoop(torch.autograd.Function):
                 gT = gT_pc if gT is None else gT + gT_pc
             want_tgt, want_w = ctx.needs_input_grad[1], ctx.needs_input_grad[3] and w0c is not None
             cv = 6 if cfg.icp_type == "pt2pl" else 3
-            if owned and soft is None and cfg.timing_events is None and n_spos == 1 and n_idx == 0 and c == cv and segs and K >= 1:
+            if owned and soft is None and cfg.timing_events is None and n_spos == 1 and n_idx == 0 and c == cv and segs and K >= 1 and not cfg.deterministic:
                 # every iteration takes the windowed form inside one slab: the whole pass is one library call (dicp_loop_backward) on one allocation.
                 # (Tolerance mode feels it most: there the host cannot run ahead of the GPU, and what it does before the pass's first launch is exposed.)
                 F = _lib.LoopBackwardIn(src=src.data_ptr(), tgt_sorted=tgt_s.data_ptr(), w0=w0c.data_ptr() if w0c is not None else None, tperm=tperm.data_ptr(),
@@ -1197,13 +1198,10 @@ class ICPLoop(torch.autograd.Function):
             gsrc = torch.empty_like(src) if only_windowed else torch.zeros_like(src)
             gw = (torch.empty_like(w0c) if only_windowed else torch.zeros_like(w0c)) if want_w else None
             nblk_a, nblk_w = lib.dicp_accumulate_blocks(n), lib.dicp_window_blocks(code, n, m_pad)
+            det_row = det_val = None
+            if cfg.deterministic and not only_windowed:
+                raise NotImplementedError("ICP.deterministic covers the sweep search with the windowed backward (knn_variant KNN_SWEEP, bwd_window): this call took another form")
             if any(windowed):
-                qo = qorders[q_star]
-                src_s = _gather_rows_raw(src, qo)
-                w_s = _gather_rows_raw(w0c.unsqueeze(-1), qo).squeeze(-1) if w0c is not None else None
-                # slot-order accumulators and slabs: the first windowed launch writes them (bwd_overwrite), no zero fill
-                gsrc_s = torch.empty_like(src)
-                gw_s = torch.empty_like(w0c) if want_w else None
                 k_ref = max(b for (_, b, _), wf in zip(segs, windowed) if wf) - 1      # windows placed by the last iteration's matches
                 spos_ref = spos_slabs[k_ref // kc][k_ref % kc]
                 if spos_of is not None and k_ref >= of_from:    # (kept by reference: a plain array of them)
@@ -1211,6 +1209,23 @@ class ICPLoop(torch.autograd.Function):
                     jr = k_ref // kc
                     _lib.check(lib.dicp_resolve_matches(ctypes.c_void_p(spos_slabs[jr].data_ptr() - jr * kc * N * n * 4), _p(spos_of), k_ref, _p(cfg.src_rows), N, n, _p(spos_ref), st),
                                "dicp_resolve_matches")
+                qo = qorders[q_star]
+                if cfg.deterministic:
+                    # The forward's query order comes from a counting sort whose order inside a bucket is the arrival order of LDS adds: fine for a search
+                    # (exact for any order), but the backward takes its sums by slot.  Any permutation serves as slot order: here a STABLE sort of the
+                    # queries by their reference match (the best locality the windows can have; a cloud's pad rows last, in index order).
+                    key = spos_ref.to(torch.int64)
+                    if cfg.src_rows is not None:
+                        key = torch.where(torch.arange(n, device=dev)[None, :] < cfg.src_rows[:, None].to(torch.int64), key, torch.full_like(key, 2 ** 40))
+                    qo = torch.argsort(key, dim=1, stable=True).to(torch.int32)
+                    if want_tgt:
+                        det_row = torch.empty((N, n), dtype=torch.int32, device=dev)
+                        det_val = torch.empty((N, n, cv), dtype=dt, device=dev)
+                src_s = _gather_rows_raw(src, qo)
+                w_s = _gather_rows_raw(w0c.unsqueeze(-1), qo).squeeze(-1) if w0c is not None else None
+                # slot-order accumulators and slabs: the first windowed launch writes them (bwd_overwrite), no zero fill
+                gsrc_s = torch.empty_like(src)
+                gw_s = torch.empty_like(w0c) if want_w else None
                 slab = torch.empty((N, nblk_w, lib.dicp_window_rows(code), cv), dtype=dt, device=dev) if want_tgt else None
                 gfar = torch.zeros((N, m_pad, cv), dtype=dt, device=dev) if want_tgt else None
             gs = torch.empty((N, 36), dtype=dt, device=dev)
@@ -1245,7 +1260,7 @@ class ICPLoop(torch.autograd.Function):
             # (inside a graph capture no event may be queried: the hint of the warm-up calls is read as it stands -- torch's capture entry points
             #  synchronise first -- and none is recorded; a stale hint costs time, never correctness: a cloud at work in the tail is swept there)
             capturing = torch.cuda.is_current_stream_capturing()
-            use_tail = skip is not None and only_windowed and cfg.bwd_tail and cfg.hints is not None
+            use_tail = skip is not None and only_windowed and cfg.bwd_tail and cfg.hints is not None and not cfg.deterministic
             if use_tail:
                 if not capturing:
                     cfg.hints.check()       # an earlier pass's tail ran out of patience: its gradients are NaN, and the caller hears about it here at the latest
@@ -1302,7 +1317,8 @@ class ICPLoop(torch.autograd.Function):
                     bwd_skip=_p(skip[1]) if skip else None, bwd_mref=_p(skip[0]) if skip else None, bwd_live=_p(skip[2]) if skip else None,
                     bwd_skip_eps=float(eps), bwd_tail_from=int(tail_from) if (w_form and k0 == 0) else 0,
                     bwd_tail_partials=_p(tail_part), bwd_tail_arrive=_p(skip[3]) if skip else None,
-                    gumbel=ctypes.cast(ctypes.pointer(gum), ctypes.c_void_p) if gum is not None else None)
+                    gumbel=ctypes.cast(ctypes.pointer(gum), ctypes.c_void_p) if gum is not None else None,
+                    det_far_row=_p(det_row) if w_form else None, det_far_val=_p(det_val) if w_form else None)
                 fresh_was = bool(w_form and k1 > k0 and fresh)
                 if w_form and k1 > k0:
                     fresh = 0

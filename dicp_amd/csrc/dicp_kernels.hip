@@ -674,7 +674,7 @@ int dicp_bwd_tail_max_blocks(int dtype) {
 static int accumulate_bwd_window_go(int dtype, const dicp_weight_params* prm, const void* src_s, const void* tgt_s, int c,
                                     const MatchHist spos, const int32_t* spos_ref, const int32_t* qorder, const void* pose, const void* w_s,
                                     const void* alive, const void* gs, const void* gb, const int32_t* src_rows, int N, int n, int m_pad, void* gsrc_s, void* slab,
-                                    void* gts_far, void* gw_s, void* bwd_partials, int overwrite, void* stream, const int32_t* skip);
+                                    void* gts_far, void* gw_s, void* bwd_partials, int overwrite, void* stream, const int32_t* skip, int32_t* det_row = nullptr, void* det_val = nullptr);
 int dicp_accumulate_bwd_window(int dtype, const dicp_weight_params* prm, const void* src_s, const void* tgt_s, int c,
                                const int32_t* spos, const int32_t* spos_ref, const int32_t* qorder, const void* pose, const void* w_s,
                                const void* alive, const void* gs, const void* gb, const int32_t* src_rows, int N, int n, int m_pad, void* gsrc_s, void* slab,
@@ -686,8 +686,9 @@ int dicp_accumulate_bwd_window(int dtype, const dicp_weight_params* prm, const v
 static int accumulate_bwd_window_go(int dtype, const dicp_weight_params* prm, const void* src_s, const void* tgt_s, int c,
                                     const MatchHist spos, const int32_t* spos_ref, const int32_t* qorder, const void* pose, const void* w_s,
                                     const void* alive, const void* gs, const void* gb, const int32_t* src_rows, int N, int n, int m_pad, void* gsrc_s, void* slab,
-                                    void* gts_far, void* gw_s, void* bwd_partials, int overwrite, void* stream, const int32_t* skip) {
+                                    void* gts_far, void* gw_s, void* bwd_partials, int overwrite, void* stream, const int32_t* skip, int32_t* det_row, void* det_val) {
     if (const int e = check_params(prm, c)) return e;
+    if ((det_row != nullptr) != (det_val != nullptr)) return DICP_ERR_NULL;
     if (!src_s || !tgt_s || !spos.base || !spos_ref || !pose || (gw_s && !w_s) || !gs || !gb || !gsrc_s || !bwd_partials || (slab && !gts_far))
         return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
@@ -703,7 +704,8 @@ static int accumulate_bwd_window_go(int dtype, const dicp_weight_params* prm, co
 #define DICP_WIN_O(T, M, OV) do { constexpr int WT = WindowRows<T>::v; const int spb = window_slots(WT, n, m_pad); \
         hipExtLaunchKernelGGL((accumulate_bwd_window_kernel<T, M, WT, OV>), dim3(g), dim3(BLOCK), 0, st, ev0, ev1, 0, P, (const T*)src_s, (const T*)tgt_s, c, spos, spos_ref, qorder, (const T*)pose, \
             (const T*)w_s, (const T*)alive, (const T*)gs, (const T*)gb, N, n, m_pad, spb, bpc, (T*)gsrc_s, (T*)slab, (T*)gts_far, (T*)gw_s, \
-            (T*)bwd_partials, src_rows, skip); } while (0)
+            (T*)bwd_partials, src_rows, skip, det_row, (T*)det_val); \
+        if (det_row && slab) far_apply_kernel<T, (M == MODE_PT2PL ? 6 : 3)><<<N, WAVE, 0, st>>>(det_row, (const T*)det_val, (T*)gts_far, n, m_pad, src_rows, OV ? nullptr : skip); } while (0)
     if (dtype == DICP_F32) { if (P.mode == MODE_PT2PL) DICP_WIN(float, MODE_PT2PL); else DICP_WIN(float, MODE_PT2PT); }
     else                   { if (P.mode == MODE_PT2PL) DICP_WIN(double, MODE_PT2PL); else DICP_WIN(double, MODE_PT2PT); }
 #undef DICP_WIN
@@ -983,6 +985,7 @@ int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_
     // windowed form with the truncated sweep: the iterations below bwd_tail_from are ONE launch (bwd_tail_kernel)
     int kt = k0;
     if (B->spos && B->bwd_skip && B->bwd_tail_from > k0) {
+        if (B->det_far_row) return DICP_ERR_SHAPE;          // (deterministic target gradients: per-iteration launches only)
         if (k0 != 0) return DICP_ERR_SHAPE;                 // (the launch runs down to iteration 0 and folds the last pose sums into the cotangent)
         if (!B->bwd_tail_partials || !B->bwd_tail_arrive) return DICP_ERR_NULL;
         if (nblk > dicp_bwd_tail_max_blocks(dtype)) return DICP_ERR_SHAPE;      // (its blocks wait for each other: they must all be resident)
@@ -1018,7 +1021,7 @@ int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_
                                           (B->spos_of && k >= B->spos_of_from) ? MatchHist{B->spos, B->spos_of, k, N, n, (n + WAVE - 1) / WAVE} : plain_matches(B->spos + (size_t)k * N * n, N, n),
                                           B->spos_ref, B->qorder, pose_k, B->w_init,
                                           alive_k, gs, gb, B->src_rows, N, n, B->m_pad,
-                                          gsrc, gtgt, B->gts_far, gw, bwd_partials, (B->bwd_overwrite && k == k1 - 1) ? 1 : 0, stream, B->bwd_skip);
+                                          gsrc, gtgt, B->gts_far, gw, bwd_partials, (B->bwd_overwrite && k == k1 - 1) ? 1 : 0, stream, B->bwd_skip, B->det_far_row, B->det_far_val);
         else
             rc = accumulate_bwd_go(dtype, prm, B->src, B->tgt, B->c, B->idx + (size_t)k * N * n, pose_k, B->w_init,
                                    alive_k, gs, gb, B->src_rows, N, n, m, gsrc, gtgt, gw, bwd_partials, stream, B->bwd_skip);

@@ -135,7 +135,9 @@ __device__ __forceinline__ void window_body(const WeightParams& P, const T* __re
                                             const T* gs, const T* gb, int n, int m_pad, int spb, int bpc,
                                             T* __restrict__ gsrc_s, T* __restrict__ slab /* (N,bpc,WT,CV) */,
                                             T* __restrict__ gts_far /* (N,m_pad,CV) */,
-                                            T* __restrict__ gw_s, T* part_out, const int32_t* __restrict__ src_rows, int cloud, int blk) {
+                                            T* __restrict__ gw_s, T* part_out, const int32_t* __restrict__ src_rows, int cloud, int blk,
+                                            int32_t* __restrict__ det_row = nullptr /* (N,n), with det_val (N,n,CV): deterministic target gradients (dicp_loop_buffers.det_far_row) */,
+                                            T* __restrict__ det_val = nullptr) {
     // overwrite: first launch into uninitialised accumulators -- gsrc_s / gw_s / the slab windows are written, not added to
     constexpr int CV = (MODE == MODE_PT2PL) ? 6 : 3;
     __shared__ T red[(BLOCK / WAVE) * NBWD_PAD];
@@ -203,10 +205,13 @@ __device__ __forceinline__ void window_body(const WeightParams& P, const T* __re
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (!on[u]) {
-                if (overwrite && base + u * BLOCK + tid < s1_all) {      // a pad slot of a ragged batch: its accumulators start at zero
+                if (base + u * BLOCK + tid < s1_all) {
                     const size_t pz = (size_t)cloud * n + base + u * BLOCK + tid;
-                    gsrc_s[pz * 3] = gsrc_s[pz * 3 + 1] = gsrc_s[pz * 3 + 2] = T(0);
-                    if (gw_s) gw_s[pz] = T(0);
+                    if (overwrite) {                        // a pad slot of a ragged batch: its accumulators start at zero
+                        gsrc_s[pz * 3] = gsrc_s[pz * 3 + 1] = gsrc_s[pz * 3 + 2] = T(0);
+                        if (gw_s) gw_s[pz] = T(0);
+                    }
+                    if (det_row && slab) det_row[pz] = -1;
                 }
                 continue;
             }
@@ -223,6 +228,12 @@ __device__ __forceinline__ void window_body(const WeightParams& P, const T* __re
                     row[0] = gy[0]; row[1] = gy[1]; row[2] = gy[2];
                     if (MODE == MODE_PT2PL) { row[3] = gn[0]; row[4] = gn[1]; row[5] = gn[2]; }
                     next[sl] = atomicExch(&head[pos[u] - lo], sl);
+                    if (det_row) det_row[pt] = -1;
+                } else if (det_row) {                       // deterministic: left by its slot for far_apply_kernel, which adds a cloud's in slot order
+                    det_row[pt] = pos[u];
+                    T* dv = det_val + pt * CV;
+                    dv[0] = gy[0]; dv[1] = gy[1]; dv[2] = gy[2];
+                    if (MODE == MODE_PT2PL) { dv[3] = gn[0]; dv[4] = gn[1]; dv[5] = gn[2]; }
                 } else {
                     T* row = gfar + (size_t)pos[u] * CV;
                     unsafeAtomicAdd(&row[0], gy[0]); unsafeAtomicAdd(&row[1], gy[1]); unsafeAtomicAdd(&row[2], gy[2]);
@@ -240,10 +251,24 @@ __device__ __forceinline__ void window_body(const WeightParams& P, const T* __re
             T sum[CV];
 #pragma unroll
             for (int k = 0; k < CV; ++k) sum[k] = T(0);
-            for (int guard = 0; h >= 0 && guard < SPB; ++guard) {       // every slot is on at most one list
+            if (det_row) {
+                // deterministic: the list is in the order the block's waves reached the row; its slots are summed in ASCENDING order instead
+                // (lists are one to three slots long: a selection pass per slot)
+                int last = -1;
+                for (int guard = 0; guard < SPB; ++guard) {
+                    int best = 0x7fffffff;
+                    for (int h2 = h, g2 = 0; h2 >= 0 && g2 < SPB; ++g2) { if (h2 > last && h2 < best) best = h2; h2 = next[h2]; }
+                    if (best == 0x7fffffff) break;
 #pragma unroll
-                for (int k = 0; k < CV; ++k) sum[k] += contrib[h * CV + k];
-                h = next[h];
+                    for (int k = 0; k < CV; ++k) sum[k] += contrib[best * CV + k];
+                    last = best;
+                }
+            } else {
+                for (int guard = 0; h >= 0 && guard < SPB; ++guard) {       // every slot is on at most one list
+#pragma unroll
+                    for (int k = 0; k < CV; ++k) sum[k] += contrib[h * CV + k];
+                    h = next[h];
+                }
             }
 #pragma unroll
             for (int k = 0; k < CV; ++k) out[rr * CV + k] = overwrite ? sum[k] : out[rr * CV + k] + sum[k];
@@ -262,7 +287,8 @@ __global__ __launch_bounds__(BLOCK) void accumulate_bwd_window_kernel(WeightPara
                                                                       T* __restrict__ gsrc_s, T* __restrict__ slab /* (N,bpc,WT,CV) */,
                                                                       T* __restrict__ gts_far /* (N,m_pad,CV) */,
                                                                       T* __restrict__ gw_s, T* __restrict__ bwd_partials, const int32_t* __restrict__ src_rows,
-                                                                      const int32_t* __restrict__ skip /* optional (N), see accumulate_bwd_kernel */) {
+                                                                      const int32_t* __restrict__ skip /* optional (N), see accumulate_bwd_kernel */,
+                                                                      int32_t* __restrict__ det_row, T* __restrict__ det_val) {
     int cloud, blk;
     if (!decode_block(bpc, N, cloud, blk)) return;
     T* part_out = bwd_partials + ((size_t)cloud * bpc + blk) * NBWD_PAD;
@@ -271,7 +297,35 @@ __global__ __launch_bounds__(BLOCK) void accumulate_bwd_window_kernel(WeightPara
         return;
     }
     window_body<T, MODE, WT, overwrite>(P, src_s, tgt_s, c, spos, spos_ref, qorder, pose, w_s, alive, gs + (size_t)cloud * 36, gb + (size_t)cloud * 6,
-                                        n, m_pad, spb, bpc, gsrc_s, slab, gts_far, gw_s, part_out, src_rows, cloud, blk);
+                                        n, m_pad, spb, bpc, gsrc_s, slab, gts_far, gw_s, part_out, src_rows, cloud, blk, det_row, det_val);
+}
+
+// Deterministic mode: the out-of-window contributions of one iteration, left by slot (det_row >= 0: the sorted target row, det_val: its CV values), into
+// gts_far.  One wave per cloud walks the slots in order; an entry is added by the lane that owns its row (row mod 64), so two entries of one row are added by
+// the same lane, the lower slot first, and entries of different rows in parallel.  ~1 % of the slots are such entries at the benchmark shape.
+template <typename T, int CV>
+__global__ __launch_bounds__(WAVE) void far_apply_kernel(const int32_t* __restrict__ det_row, const T* __restrict__ det_val, T* __restrict__ gts_far, int n, int m_pad,
+                                                        const int32_t* __restrict__ src_rows, const int32_t* __restrict__ skip) {
+    const int cloud = blockIdx.x, lane = threadIdx.x;
+    if (skip && skip[cloud]) return;                        // (the window launch did not run for this cloud: its records are an earlier iteration's)
+    const int nc = rows_of(src_rows, cloud, n);
+    T* gfar = gts_far + (size_t)cloud * m_pad * CV;
+    for (int s0 = 0; s0 < nc; s0 += WAVE) {
+        const int s = s0 + lane;
+        const int r = s < nc ? det_row[(size_t)cloud * n + s] : -1;
+        unsigned long long mk = __ballot(r >= 0);
+        while (mk) {
+            const int b = __builtin_ctzll(mk);
+            mk &= mk - 1;
+            const int row = __shfl(r, b);
+            if ((row & (WAVE - 1)) == lane && row < m_pad) {
+                const T* v = det_val + ((size_t)cloud * n + s0 + b) * CV;
+                T* o = gfar + (size_t)row * CV;
+#pragma unroll
+                for (int k = 0; k < CV; ++k) o[k] += v[k];
+            }
+        }
+    }
 }
 
 // gtgt[b][tperm[s]][col] += gts_far[b][s][col] + sum over the blocks whose window covers sorted row s of their

@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define DICP_ABI_VERSION 8   /* 8: certified iterations keep a row cache and their match history by reference (dicp_loop_buffers.spos_of / cert_nbr / cert_gdirty /
+#define DICP_ABI_VERSION 9   /* 9: dicp_loop_buffers.det_far_row / det_far_val (deterministic target gradients of the windowed backward).
+                                8: certified iterations keep a row cache and their match history by reference (dicp_loop_buffers.spos_of / cert_nbr / cert_gdirty /
                                 cert_pend / cert_cm, spos_prev_chunk + spos_floor instead of spos_prev0; dicp_resolve_matches).
                                 7: dicp_call_* (one eager call of the sweep path behind one host call per direction).
                                 6: dicp_bwd_tail_max_blocks (the one-launch tail only where a cloud's blocks are all resident; a wait that runs out poisons the
@@ -407,6 +408,12 @@ typedef struct dicp_loop_buffers {
                                 takes the scoring form of every cloud from row k-1 (dicp_knn_sweep's form_in / form_out; a row of zeros: no plain search then).
                                 Without tgt_f16 the tallies are only kept (a caller may decide from them whether the next call of the shape gets the image) */
     int32_t sweep_form_default;  /* the form of a cloud without a tally: 0 vector, 1 matrix cores */
+    int32_t* det_far_row;    /* dicp_icp_backward, windowed form, optional (N,n) int32 + det_far_val (N,n,cv): DETERMINISTIC target gradients.  Without them the
+                                contributions to a target row are summed in the order the block's waves happened to reach it, and those whose match lies outside the
+                                block's window are added with float atomics: two runs differ in the last bits.  With them every window row sums its slots in
+                                ascending slot order, and an out-of-window contribution is left here by its slot (row, values) and added by one launch per
+                                iteration that walks a cloud's slots in order (one lane per target row): the same bits on every run, given the same slot order. */
+    void* det_far_val;
 } dicp_loop_buffers;
 
 /* Head and tail of the backward loop.  dicp_pose_grad_in: gpose (N,12) double = [dL/dC row-major (9), dL/dr (3)] taken from the

@@ -1,0 +1,109 @@
+"""ICP.deterministic (`-m gpu`): the same gradient bits on every run.  The reference's backward is autograd over deterministic CPU ops
+(/root/reference/dICP/ICP.py:132-260 differentiated by torch); the default GPU path sums a target row's contributions in the order the waves
+reach it and adds the out-of-window ones with float atomics -- equal to rounding, not bit for bit (profiles/r04_soak.txt: 2.6e-4 of the largest
+gradient between two runs of one call).  With the switch: bit-identical runs, the same results as the default path to rounding, and the oracle's."""
+import numpy as np
+import pytest
+import torch
+
+from dicp_amd import _lib
+from dicp_amd.ICP import ICP
+from dicp_amd.synthetic import make_pairs, make_independent_pairs
+from oracle import dicp_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+KW = dict(trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0}, dim=3)
+
+
+def run(src, tgt, K, deterministic, icp_type="pt2pl", weight=None, lists=None, kw=KW, const_iter=True, tol=1e-12):
+    icp = ICP(icp_type=icp_type, differentiable=True, max_iterations=K, tolerance=tol)
+    icp.const_iter, icp.deterministic = const_iter, deterministic
+    if lists is not None:           # (src, tgt: lists of clouds of their own lengths)
+        N, dtype = len(src), src[0].dtype
+        S = [x.to(DEV).requires_grad_(True) for x in src]
+        Tg = [x.to(DEV).requires_grad_(True) for x in tgt]
+        Ti, W = [torch.eye(4, dtype=dtype, device=DEV)] * N, None
+    else:
+        N, dtype = src.shape[0], src.dtype
+        if icp_type == "pt2pt":
+            tgt = tgt[:, :, :3]
+        S, Tg = src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True)
+        Ti = torch.eye(4, dtype=dtype).repeat(N, 1, 1).to(DEV).requires_grad_(True)
+        W = weight.to(DEV).requires_grad_(True) if weight is not None else None
+    out = icp.icp(S, Tg, Ti, weight=W, **kw)
+    (out["T"][:, :3].sum() + 0.1 * out["pc"].sum()).backward()
+    torch.cuda.synchronize()
+    leaves = (S if lists is not None else [S]) + (Tg if lists is not None else [Tg]) + ([] if lists is not None else [Ti]) + ([W] if W is not None else [])
+    return out, [x.grad.detach().clone() for x in leaves]
+
+
+def identical(a, b):
+    return all(torch.equal(x, y) or bool((torch.isnan(x) == torch.isnan(y)).all() and torch.equal(torch.nan_to_num(x), torch.nan_to_num(y))) for x, y in zip(a, b))
+
+
+def close(a, b, rtol):
+    for x, y in zip(a, b):
+        scale = max(1.0, float(x.abs().max()))
+        assert float((x - y).abs().max()) <= rtol * scale, float((x - y).abs().max()) / scale
+
+
+@pytest.mark.parametrize("offset", [0.0, 600.0])
+def test_two_runs_are_bit_identical_float32(offset):
+    """The soak's case: float32, clouds far from the origin (out-of-window rows and long lists are common there)."""
+    src, tgt = make_pairs(24, 16384, 16384, seed=31, dtype=torch.float32)
+    src, tgt = src.clone(), tgt.clone()
+    src[:, :, :3] += offset
+    tgt[:, :, :3] += offset
+    o1, g1 = run(src, tgt, 8, True)
+    o2, g2 = run(src, tgt, 8, True)
+    assert identical(g1, g2)
+    assert torch.equal(o1["T"], o2["T"])
+    od, gd = run(src, tgt, 8, False)
+    assert torch.equal(o1["T"], od["T"])                  # the forward does not depend on the switch
+    close(g1, gd, 1e-3)
+
+
+def test_hard_inputs_ragged_lists_bit_identical():
+    """Independently sampled, partially overlapping clouds with metre-sized start poses, as ragged lists (test_ICP_inputs.py:36-103's shape of input)."""
+    src, tgt = make_independent_pairs(6, 6000, 6000, seed=5, dtype=torch.float32)      # ragged: lists
+    assert len({x.shape[0] for x in src}) > 1
+    _, g1 = run(src, tgt, 6, True, lists=True)
+    _, g2 = run(src, tgt, 6, True, lists=True)
+    assert identical(g1, g2)
+    _, gd = run(src, tgt, 6, False, lists=True)
+    close(g1, gd, 2e-3)
+
+
+@pytest.mark.parametrize("icp_type", ["pt2pl", "pt2pt"])
+def test_float64_weights_against_default_and_oracle(icp_type):
+    src, tgt = make_pairs(3, 2048, 2300, seed=17, dtype=torch.float64)
+    w = torch.rand(3, 2048, dtype=torch.float64) * 0.5 + 0.5
+    o1, g1 = run(src, tgt, 5, True, icp_type=icp_type, weight=w)
+    o2, g2 = run(src, tgt, 5, True, icp_type=icp_type, weight=w)
+    assert identical(g1, g2)
+    _, gd = run(src, tgt, 5, False, icp_type=icp_type, weight=w)
+    close(g1, gd, 1e-10)
+    s_c, t_c = src.clone().requires_grad_(True), (tgt if icp_type == "pt2pl" else tgt[:, :, :3]).clone().requires_grad_(True)
+    T_c, w_c = torch.eye(4, dtype=torch.float64).repeat(3, 1, 1).requires_grad_(True), w.clone().requires_grad_(True)
+    ref = O.icp_batched(s_c, t_c, T_c, w_c if icp_type == "pt2pl" else w_c.repeat_interleave(3, dim=1), icp_type=icp_type, differentiable=True, max_iterations=5, tolerance=1e-12, const_iter=True, tanh_steepness=5.0, **KW)
+    (ref["T"][:, :3].sum() + 0.1 * ref["pc"].sum()).backward()
+    np.testing.assert_allclose(o1["T"].detach().cpu().numpy(), ref["T"].detach().numpy(), atol=1e-10)
+    for g, r in zip(g1, (s_c.grad, t_c.grad, T_c.grad, w_c.grad)):
+        np.testing.assert_allclose(g.cpu().numpy(), r.numpy(), atol=1e-8 * max(1.0, float(r.abs().max())))
+
+
+def test_tolerance_mode_bit_identical():
+    src, tgt = make_pairs(8, 8192, 8192, seed=3, dtype=torch.float32)
+    o1, g1 = run(src, tgt, 30, True, const_iter=False, tol=1e-4)
+    o2, g2 = run(src, tgt, 30, True, const_iter=False, tol=1e-4)
+    assert o1["deltas"].shape == o2["deltas"].shape and identical(g1, g2)
+
+
+def test_not_with_gumbel():
+    icp = ICP(icp_type="pt2pt", differentiable=True, max_iterations=2, tolerance=1e-12)
+    icp.nn.use_gumbel = True
+    icp.deterministic = True
+    src, tgt = make_pairs(1, 256, 256, seed=1, dtype=torch.float64)
+    with pytest.raises(NotImplementedError):
+        icp.icp(src.to(DEV).requires_grad_(True), tgt[:, :, :3].to(DEV), torch.eye(4, dtype=torch.float64, device=DEV).unsqueeze(0))

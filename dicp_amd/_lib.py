@@ -145,6 +145,7 @@ _SIGNATURES = {
     "dicp_search_frame": ([i32, vp, i32, vp, i32, i32, f64, i32, vp, vp], ctypes.c_int),
     "dicp_knn_f16_bytes": ([i32, i32], ctypes.c_size_t),
     "dicp_knn_f16_pack": ([vp, vp, i32, i32, i32, vp, vp], ctypes.c_int),
+    "dicp_knn_f16_probe": ([vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp], ctypes.c_int),
     "dicp_knn": ([i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp, vp], ctypes.c_int),
     "dicp_knn_sweep": ([i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp], ctypes.c_int),
     "dicp_window_blocks": ([i32, i32, i32], ctypes.c_int),

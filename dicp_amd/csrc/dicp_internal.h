@@ -19,6 +19,8 @@ inline size_t knn_f16_edges_offset(int N, int m_pad) { return knn_f16_meta_offse
 int knn_f16_pack(const void* rows4, const int32_t* tgt_rows, int N, int m_full, int m_pad, void* image, void* stream);
 // all n x m pairs of every cloud; idx (N,n) as dicp_knn writes it.  Words 6 / 7 of a cloud's meta record count the queries that needed the second
 // filter pass / the exact scan of every row (added up over the launches since the pack)
+int knn_f16_probe(const void* src, const void* pose, const void* tgt4, const void* image, const int32_t* src_rows, const int32_t* tgt_rows,
+                  int N, int n, int m, int m_pad, float* out, void* stream);
 int knn_f16_brute(const void* src, const void* pose, const void* tgt4, void* image, const int32_t* src_rows, const int32_t* tgt_rows,
                   int N, int n, int m, int m_pad, int32_t* idx, void* stream);
 

@@ -239,6 +239,10 @@ int dicp_pose_grad_out(int dtype, const double* gpose, const void* bwd_partials,
     return launch_status();
 }
 
+int dicp_knn_f16_probe(const void* src, const void* pose, const void* tgt4, const void* f16_image, const int32_t* src_rows, const int32_t* tgt_rows,
+                       int N, int n, int m, int m_pad, float* out, void* stream) {
+    return dicp_tu::knn_f16_probe(src, pose, tgt4, f16_image, src_rows, tgt_rows, N, n, m, m_pad, out, stream);
+}
 size_t dicp_knn_f16_bytes(int N, int m_pad) { return (N <= 0 || m_pad <= 0) ? 0 : dicp_tu::knn_f16_image_bytes(N, m_pad); }
 int dicp_knn_f16_pack(const void* tgt4, const int32_t* tgt_rows, int N, int m, int m_pad, void* image, void* stream) {
     return dicp_tu::knn_f16_pack(tgt4, tgt_rows, N, m, m_pad, image, stream);

@@ -20,7 +20,12 @@
 //                                                                 scripts/ubench/mfma_f16_ubench.hip; the term covers their rounding)
 //     h split (three terms)          <= u h + hphi,               hphi = 3 * 2^-12 / s^2
 //     MFMA accumulation              <= 20 u T                    measured 4.97 u T at worst over 4e5 dot products of wide range and
-//                                                                 heavy cancellation (same ubench); 4x that is assumed
+//                                                                 heavy cancellation (same ubench); 4x that is assumed -- and the WHOLE bound was then
+//                                                                 searched for its worst case: knn_f16_probe_kernel below scores every pair of adversarial
+//                                                                 clouds (queries on targets km from the origin, f16-denormal low terms, extents at the
+//                                                                 scale's boundaries, rows at 16x the extent, queries at the edge of the f16 range,
+//                                                                 cancelling products) as the searches do: max |filter - score()| / E = 0.34 over 5.6e9
+//                                                                 pairs (profiles/r05_knn_f16_bound_search.txt; tests/test_gpu_f16.py holds <= 0.5)
 //   E = 32 u T + phi (|x|_1 + sqrt3 |y|) + hphi, with |y| <= |x| + sqrt(2 D) and D the candidate's half squared distance, itself bounded
 //   from the filter's own minimum (D <= b1 / s^2 + 0.5|x|^2, taken with 2^-9 relative slack, which the code checks E against).
 // Rows the f16 range cannot hold next to the rest of the cloud (the reference's pad rows at max(source) * 1000, ICP.py:460: a cloud with up
@@ -938,9 +943,94 @@ __global__ __launch_bounds__(BLOCK, MINW) void knn_f16_sweep_kernel(const float*
                    src_rows, tgt_rows, edges_all, form_out, cloud, blk);
 }
 
+// ------------------------------------------------------------------ the filter's error bound, held to account (a test aid: dicp_knn_f16_probe)
+// For EVERY (query, image row) pair of a cloud: the filter value exactly as the searches compute it (the same image tile, the same query fragment, one
+// v_mfma_f32_32x32x16_f16 into a zero accumulator) against score() -- the float32 value every other search form compares -- and against the bound E of this
+// file's header evaluated for THAT pair (T = sum |x_i y_i| + h).  Per cloud: the largest |filter / s^2 - score()| / E, that error, its E, and the pairs
+// checked.  The searches rely on ratio <= 1; the header's MFMA term assumes 4x the worst accumulation error that was measured, so a healthy margin is < 0.5.
+// One wave = 32 queries against all tiles of the cloud.
+__global__ __launch_bounds__(BLOCK) void knn_f16_probe_kernel(const float* __restrict__ src, const float* __restrict__ pose, const float4* __restrict__ tgt4,
+                                                               const uint4* __restrict__ image, const float* __restrict__ meta_all, int N, int n_full, int m_full,
+                                                               int m_pad, int tiles_per_cloud, int bpc, const int32_t* __restrict__ src_rows,
+                                                               const int32_t* __restrict__ tgt_rows, float* __restrict__ out /* (N,4) */) {
+    int cloud, blk;
+    if (!decode_block(bpc, N, cloud, blk)) return;
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6, col = lane & 31, kh = lane >> 5;
+    const int n = rows_of(src_rows, cloud, n_full), m = min(max(rows_of(tgt_rows, cloud, m_full), 1), m_pad);
+    const int q = (blk * (BLOCK / WAVE) + wave) * 32 + col;
+    if ((blk * (BLOCK / WAVE) + wave) * 32 >= n) return;
+    const float* mt = meta_all + (size_t)cloud * F16_META;
+    const float s = mt[FM_S], inv_s2 = mt[FM_INV_S2], phi = mt[FM_PHI], hphi = mt[FM_HPHI];
+    float C[9], r[3];
+    load_pose(pose, cloud, C, r);
+    float p[3] = {0.f, 0.f, 0.f}, nx[3];
+    if (q < n) { const float* sp = src + ((size_t)cloud * n_full + q) * 3; p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2]; }
+    query_point(C, r, p, nx);
+    bool ok;
+    const half8 b = f16_query_fragment(nx, s, kh, ok);
+    ok = ok && q < n;
+    const float x1 = fabsf(nx[0]) + fabsf(nx[1]) + fabsf(nx[2]);
+    const float4* __restrict__ tg = tgt4 + (size_t)cloud * m_pad;
+    const uint4* __restrict__ img = image + (size_t)cloud * tiles_per_cloud * 64;
+    f32x16 zero;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) zero[i] = 0.f;
+    double best = 0.0, best_err = 0.0, best_E = 0.0;
+    unsigned long long cnt = 0;
+    const int ntiles = min((m + 31) / 32, tiles_per_cloud);
+    for (int t = 0; t < ntiles; ++t) {
+        half8 a;
+        { const uint4 v = img[(size_t)t * 64 + lane]; __builtin_memcpy(&a, &v, 16); }
+        const f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, zero, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = t * 32 + 16 * kh + i;
+            const float f = d[i];
+            if (!ok || row >= m || !(f < __builtin_huge_valf()) || !(f > -__builtin_huge_valf())) continue;      // (rows left out of the image carry +inf)
+            const float4 y = tg[row];
+            const float sc = score<float, float4>(nx, y);
+            const double err = fabs((double)f * (double)inv_s2 - (double)sc);
+            const double T = fabs((double)nx[0] * y.x) + fabs((double)nx[1] * y.y) + fabs((double)nx[2] * y.z) + (double)y.w;
+            const double ynorm = sqrt(2.0 * (double)y.w);
+            const double E = (double)F16_CREL * (double)F16_U * T + (double)phi * ((double)x1 + 1.7321 * ynorm) + (double)hphi;
+            const double ratio = err / E;
+            ++cnt;
+            if (ratio > best) { best = ratio; best_err = err; best_E = E; }
+        }
+    }
+#pragma unroll 1
+    for (int o = WAVE / 2; o > 0; o >>= 1) {
+        const double ob = __shfl_xor(best, o), oe = __shfl_xor(best_err, o), oE = __shfl_xor(best_E, o);
+        cnt += __shfl_xor(cnt, o);
+        if (ob > best) { best = ob; best_err = oe; best_E = oE; }
+    }
+    if (lane == 0) {
+        // (non-negative floats order like their bit patterns: the maximum as an integer atomic; the error and its bound of the wave that raised it last)
+        const float bf = (float)best;
+        const int old = atomicMax((int*)out + (size_t)cloud * 4, __float_as_int(bf));
+        if (__float_as_int(bf) > old) { out[(size_t)cloud * 4 + 1] = (float)best_err; out[(size_t)cloud * 4 + 2] = (float)best_E; }
+        atomicAdd(out + (size_t)cloud * 4 + 3, (float)cnt);
+    }
+}
+
 }  // namespace
 
 namespace dicp_tu {
+
+int knn_f16_probe(const void* src, const void* pose, const void* tgt4, const void* image, const int32_t* src_rows, const int32_t* tgt_rows,
+                  int N, int n, int m, int m_pad, float* out, void* stream) {
+    if (!src || !tgt4 || !image || !out) return DICP_ERR_NULL;
+    if (N <= 0 || n <= 0 || m <= 0 || m_pad < m) return DICP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int m_img = knn_f16_image_rows(m_pad), tiles = m_img / 32;
+    const float* meta = (const float*)((const char*)image + knn_f16_meta_offset(N, m_pad));
+    const int bpc = (n + (BLOCK / WAVE) * 32 - 1) / ((BLOCK / WAVE) * 32);
+    begin_launch();
+    if (hipMemsetAsync(out, 0, (size_t)N * 4 * sizeof(float), st) != hipSuccess) return -(int)hipGetLastError();
+    knn_f16_probe_kernel<<<grid_for(N, bpc), BLOCK, 0, st>>>((const float*)src, (const float*)pose, (const float4*)tgt4, (const uint4*)image, meta, N, n, m, m_pad, tiles, bpc,
+                                                             src_rows, tgt_rows, out);
+    return launch_status();
+}
 
 int knn_f16_pack(const void* rows4, const int32_t* tgt_rows, int N, int m_full, int m_pad, void* image, void* stream) {
     if (!rows4 || !image) return DICP_ERR_NULL;

@@ -99,6 +99,12 @@ int dicp_pack_target(int dtype, const void* tgt, int c, const void* frame, const
  * torch.cdist, nn.py:32. */
 size_t dicp_knn_f16_bytes(int N, int m_pad);
 int dicp_knn_f16_pack(const void* tgt4, const int32_t* tgt_rows, int N, int m, int m_pad, void* image, void* stream);
+/* A TEST AID, not on the path of nn.py:32: the matrix-core filter's error bound held to account.  For every (query, image row) pair of every cloud the
+ * filter value exactly as DICP_KNN_MFMA / the matrix-core sweep compute it, against the float32 score of the other search forms and the bound E of
+ * csrc/knn_f16.hip evaluated for that pair.  out (N,4) float32: [max over pairs of |filter - score| / E, that error, its E, pairs checked].  The searches
+ * are index-identical to DICP_KNN_VALU while the first stays <= 1 (tests/test_gpu_f16.py searches for its maximum on adversarial clouds). */
+int dicp_knn_f16_probe(const void* src, const void* pose, const void* tgt4, const void* f16_image, const int32_t* src_rows, const int32_t* tgt_rows,
+                       int N, int n, int m, int m_pad, float* out, void* stream);
 
 /* Fused transform + brute-force 1-NN: replaces ICP.py:137 (ps_t = C p + r) followed by
  * nn.find_nn's cdist -> argmin, nn.py:32-35 / 83-86.  Never materialises (N,n,m).

@@ -123,3 +123,22 @@ def test_icp_call_with_the_matrix_core_sweep_is_the_same_call(monkeypatch):
         assert torch.equal(a, b)
     for a, b in zip(outs[False][3:], outs[True][3:]):       # (the windowed backward adds its out-of-window rows with float atomics: not bit for bit)
         assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
+
+
+def test_the_filter_error_bound_on_adversarial_clouds():
+    """The bound E of csrc/knn_f16.hip (whose MFMA-accumulation term was ASSUMED at 4x a measured worst case) against a search for its worst case: every
+    (query, image row) pair of clouds built to stress each of its terms -- queries sitting on targets far from the origin, f16-denormal low terms, extents at the
+    scale's power-of-two boundaries, rows at exactly 16x the extent, queries at the edge of the f16 range, cancelling dot products -- scored exactly as the
+    searches score them (dicp_knn_f16_probe).  The searches' index-identity with the brute-force VALU kernel (nn.py:32-35's argmin) rests on ratio <= 1."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("f16_bound_search", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "f16_bound_search.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    worst, pairs = 0.0, 0.0
+    for name, s, t in mod.adversarial_cases(seed=0):
+        r = mod.probe(s, t)
+        assert float(r[:, 3].sum()) > 0.5 * s.shape[0] * s.shape[1] * t.shape[1] * (0.3 if "28x" in name else 0.9), name      # (the pairs really were checked)
+        worst, pairs = max(worst, float(r[:, 0].max())), pairs + float(r[:, 3].sum())
+        assert float(r[:, 0].max()) <= 0.5, (name, r)
+    assert pairs >= 1e8

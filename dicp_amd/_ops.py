@@ -210,7 +210,7 @@ class SweepIndex:
         self.brange = torch.empty((N, 2), dtype=dt, device=dev)
         self.keys = torch.empty((N, m_pad), dtype=dt, device=dev)          # sorted x keys: the rank search of query_order reads them
         # the full rows in sorted order.  Their stride is an argument of dicp_sweep_build (padding a row to one aligned 32-byte sector, stride 8, was
-        # measured: 2 % SLOWER end to end -- the copy grows by a third and leaves the cache sooner), so rows stay packed
+        # measured: 2 % SLOWER end to end -- the copy grows by a third and leaves the cache sooner, docs/HISTORY.md section 5), so rows stay packed
         self.row_stride = c
         self.tgt_s = torch.empty((N, m_pad, self.row_stride), dtype=dt, device=dev) if sorted_rows else None
         nbytes = int(lib.dicp_sweep_sort_scratch_bytes(_DT[dt], N, m_pad))     # float64 keys / more than 16384 slots: chunked sort through scratch

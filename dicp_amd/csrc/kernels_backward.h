@@ -816,8 +816,9 @@ __device__ __forceinline__ void coherent_store(double* p, double v) { __hip_atom
 __device__ __forceinline__ float  coherent_load(const float* p)  { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double coherent_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// (float32: compiled for two waves per SIMD -- left to itself the pt2pl form took 257 registers, one block per CU, and with it half the residency cap of dicp_bwd_tail_max_blocks)
 template <typename T, int MODE, int WT>
-__global__ __launch_bounds__(BLOCK) void bwd_tail_kernel(WeightParams P, dicp_loop_buffers B, int N, int n, int dim, int spb, int bpc,
+__global__ __launch_bounds__(BLOCK, sizeof(T) == 4 ? 2 : 1) void bwd_tail_kernel(WeightParams P, dicp_loop_buffers B, int N, int n, int dim, int spb, int bpc,
                                                          const double* __restrict__ gpose_in, double* __restrict__ gpose_out, int have_partials,
                                                          T* __restrict__ gsrc_s, T* __restrict__ slab, T* __restrict__ gw_s,
                                                          T* part0 /* bwd_partials: the sums on entry, then the even generations */, T* part1 /* the odd generations */,

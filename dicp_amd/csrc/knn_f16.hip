@@ -551,7 +551,7 @@ __device__ __forceinline__ void f16_sweep_unit(const float* __restrict__ src, co
     // the float32 rows of the F16_NTC tiles around the wave's first one (copied by LDS-DMA beside the scoring): where the winners are -- a
     // match is at most its own distance away in x -- so the refine reads its rows from LDS instead of gathering 512 bytes per query from L2
     // (2 GB per launch at the benchmark shape: that gather was half of the kernel)
-    __shared__ float4 rowcache[BLOCK / WAVE][F16_NTC * WAVE];
+    __shared__ __align__(256) float4 rowcache[BLOCK / WAVE][F16_NTC * WAVE];      // (256-byte aligned: a run's swizzled places are its base XOR a 4-bit field, below)
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
     const int unit = blk * (BLOCK / WAVE) + wave;
     const int n = rows_of(src_rows, cloud, n_full), m = min(max(rows_of(tgt_rows, cloud, m_full), 1), m_pad);
@@ -739,14 +739,17 @@ __device__ __forceinline__ void f16_sweep_unit(const float* __restrict__ src, co
             const int sl = (max(r0, 0) >> 6) - tc0;
             const bool cached = sl >= 0 && sl < F16_NTC;
             const bool far_run = r0 >= 0 && !cached;                // (a lane whose run is not in the cache gathers it from the sorted rows themselves)
-            const int run = min(max(sl, 0), F16_NTC - 1) * 4 + ((max(r0, 0) & 63) >> 4), rx = run & 15;      // (r0 is a multiple of 16)
-            const float4* __restrict__ rp = &rowcache[wave][run * 16];
+            const int run = min(max(sl, 0), F16_NTC - 1) * 4 + ((max(r0, 0) & 63) >> 4);      // (r0 is a multiple of 16)
+            // LDS byte address of the run's place 0, XOR its swizzle: place i ^ (run & 15) of a 256-byte-aligned run is ONE v_xor with an inline constant away
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            typedef const __attribute__((address_space(3))) f32x4* lds_row_p;
+            const unsigned pre = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)&rowcache[wave][run * 16] ^ ((unsigned)(run & 15) << 4);
             float sc[16];
 #pragma unroll
             for (int kb = 0; kb < 16; kb += 8) {
                 float4 rw[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) rw[k] = rp[(kb + k) ^ rx];
+                for (int k = 0; k < 8; ++k) { const f32x4 v = *(lds_row_p)(uintptr_t)(pre ^ ((unsigned)(kb + k) << 4)); rw[k] = make_float4(v[0], v[1], v[2], v[3]); }
                 if (__any(far_run)) {
                     if (far_run) {
 #pragma unroll

@@ -79,7 +79,7 @@ __device__ __forceinline__ void block_reduce_store(T* v, T* __restrict__ out, T*
 // coordinates and its cached row and writes its weight: 40 bytes per point.  The launch behind a search of EVERY query of a cloud (the certifying
 // search: fresh; a cloud whose certificates are off or tried again) is all gather: it reads the iteration's own slab and fills the cache.
 // The kernel carries no search code any more, and with it went 30 registers: occupancy, not bytes, is what these launches were short of (a chain of
-// memory latencies; 94 -> 69 registers, 5 -> 7 waves per SIMD, 57 -> 31.5 us per certified launch: profiles/r05_accumulate_occupancy.txt).
+// memory latencies; 94 -> 69 registers, 5 -> 7 waves per SIMD, 54 -> 31.5 us per certified launch: profiles/r05_accumulate_occupancy.txt).
 constexpr bool PAIR_ROWS = true;     // (plain launches, 7 waves per SIMD: 58 -> 49 us: two lanes share the two 24-byte rows of their two points)
 template <typename T, int NB> __device__ __forceinline__ void load_cached_row(const T* __restrict__ p, T* v) {
     if constexpr (NB == 6 && sizeof(T) == 4) {

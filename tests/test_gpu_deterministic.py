@@ -107,3 +107,24 @@ def test_not_with_gumbel():
     src, tgt = make_pairs(1, 256, 256, seed=1, dtype=torch.float64)
     with pytest.raises(NotImplementedError):
         icp.icp(src.to(DEV).requires_grad_(True), tgt[:, :, :3].to(DEV), torch.eye(4, dtype=torch.float64, device=DEV).unsqueeze(0))
+
+
+def test_the_reference_pair_takes_the_deterministic_path_too():
+    """tests/data's 65-point pair (test_ICP.py:35-117: float64, point-to-plane, dim 2): forced onto the sweep search + windowed backward, same results as the default
+    (small-cloud) path to rounding, bit-identical between runs."""
+    import os
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    scan = torch.from_numpy(np.load(os.path.join(g, "points_scan.npy"))).to(torch.float64)
+    mp = torch.from_numpy(np.load(os.path.join(g, "points_map.npy"))).to(torch.float64)
+    kw = dict(trim_dist=5.0, loss_fn={"name": "huber", "metric": 10.0}, dim=2)
+    outs = []
+    for det in (True, True, False):
+        icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=6, tolerance=1e-12)
+        icp.const_iter, icp.deterministic = True, det
+        s, t = scan.to(DEV).requires_grad_(True), mp.to(DEV).requires_grad_(True)
+        o = icp.icp(s, t, torch.eye(4, dtype=torch.float64, device=DEV), **kw)
+        o["T"].sum().backward()
+        outs.append((o["T"].detach().clone(), s.grad.clone(), t.grad.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+    for a, b in zip(outs[0], outs[2]):
+        assert float((a - b).abs().max()) <= 1e-10 * max(1.0, float(b.abs().max()))

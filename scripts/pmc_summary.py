@@ -36,9 +36,18 @@ for name in sorted(set(fetch) | set(write)):
     # launches in which every cloud was at work (the backward's truncated reverse sweep leaves most accumulate_bwd launches (next to) empty:
     # their blocks read one flag and leave): those whose read traffic is at least half the largest launch's
     fl, wl = fetch.get(name, []), write.get(name, [])
-    if fl and len(fl) == len(wl):
-        keep = [i for i, v in enumerate(fl) if v >= 0.5 * max(fl)]
-        ff, wf = sum(fl[i] for i in keep) / len(keep), sum(wl[i] for i in keep) / len(keep)
-        out["kernels"][short].update({"full_launches": len(keep), "hbm_bytes_full_launches": ff * 1024 * 2 + wf * 1024})
+    # (the two passes are separate runs of the command, whose warm-up repeats until its calls agree: they need not have the same number of launches,
+    #  so each pass picks its own full launches)
+    #  so a kernel with (next to) empty launches -- by its reads -- takes the full ones of each pass by that pass's own figures)
+    if fl and wl:
+        kf = [v for v in fl if v >= 0.5 * max(fl)]
+        if len(kf) == len(fl):
+            kw = wl                                         # every launch did its work: the mean over all of them
+        elif len(fl) == len(wl):
+            kw = [wl[i] for i, v in enumerate(fl) if v >= 0.5 * max(fl)]
+        else:
+            kw = [v for v in wl if v >= 0.5 * max(wl)] if max(wl) > 0 else wl
+        ff, wf = sum(kf) / len(kf), sum(kw) / len(kw)
+        out["kernels"][short].update({"full_launches": len(kf), "hbm_bytes_full_launches": ff * 1024 * 2 + wf * 1024})
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -318,7 +318,7 @@ __device__ __forceinline__ void step_body(const dicp_step_io& io, int cloud, int
         const T* pp = (const T*)io.partials + (size_t)cloud * io.nblk * NACC_PAD + slot_i;
         double s = 0.0;
         // (the kernel is a chain of latencies: all of a lane's loads are issued before the first add -- the order of the adds is unchanged)
-        constexpr int UB = 16;     // (32 partial rows per cloud at 16384 points -- blocks of 512 -- are ONE round of loads per lane)
+        constexpr int UB = 8;
         for (int b0 = part; b0 < io.nblk; b0 += 2 * UB) {
             T v[UB];
 #pragma unroll

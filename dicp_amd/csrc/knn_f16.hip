@@ -569,29 +569,24 @@ __device__ __forceinline__ void f16_sweep_unit(const float* __restrict__ src, co
     const float beta = 7.62939453125e-6f + 2.f * phi;               // 2^-17 + 2 phi
     const float kappa1 = beta < 0.25f ? 1.f + 2.02f * beta : __builtin_huge_valf();
     const float kA = inv_s2 * kappa1;
-    // the lane's four queries (index, transformed point).  Called twice: before the tile loop, which needs only what is derived from them (fragments, bounds),
-    // and again behind it for the refine -- the same values from the same memory, 16 registers the loop does not have (kept across it they pushed three other
-    // values into scratch memory)
-    auto fetch_queries = [&](const float* __restrict__ srcp, const int32_t* __restrict__ qop) {
 #pragma unroll
-        for (int g = 0; g < F16_G; ++g) {
-            const int pos = unit * (32 * F16_G) + g * 32 + col;
-            qi[g] = -1;
-            float p[3] = {0.f, 0.f, 0.f};
-            if (pos < n) {
-                qi[g] = qop ? qop[(size_t)cloud * n_full + pos] : pos;
-                const float* sp = srcp + ((size_t)cloud * n_full + qi[g]) * 3;
-                p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2];
-            }
-            query_point(C, r, p, nx[g]);
+    for (int g = 0; g < F16_G; ++g) {
+        const int pos = unit * (32 * F16_G) + g * 32 + col;
+        qi[g] = -1;
+        float p[3] = {0.f, 0.f, 0.f};
+        if (pos < n) {
+            qi[g] = qorder ? qorder[(size_t)cloud * n_full + pos] : pos;
+            const float* sp = src + ((size_t)cloud * n_full + qi[g]) * 3;
+            p[0] = sp[0]; p[1] = sp[1]; p[2] = sp[2];
         }
-        // idle slots of a partial last wave take a real query's values (lane 0 of B tile 0 always holds one): they never hold the sweep open
+        query_point(C, r, p, nx[g]);
+    }
+    {   // idle slots of a partial last wave take a real query's values (lane 0 of B tile 0 always holds one): they never hold the sweep open
         const float a0 = __shfl(nx[0][0], 0), a1 = __shfl(nx[0][1], 0), a2 = __shfl(nx[0][2], 0);
 #pragma unroll
         for (int g = 0; g < F16_G; ++g)
             if (qi[g] < 0) { nx[g][0] = a0; nx[g][1] = a1; nx[g][2] = a2; }
-    };
-    fetch_queries(src, qorder);
+    }
     float xmax = -__builtin_huge_valf(), xmin = __builtin_huge_valf();
 #pragma unroll
     for (int g = 0; g < F16_G; ++g) {
@@ -683,12 +678,6 @@ __device__ __forceinline__ void f16_sweep_unit(const float* __restrict__ src, co
         }
     }
 
-    {   // (the pointers are made opaque: the compiler must load again, not keep the first call's values alive across the loop)
-        const float* src2 = src;
-        const int32_t* qo2 = qorder;
-        asm volatile("" : "+s"(src2), "+s"(qo2));
-        fetch_queries(src2, qo2);
-    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // (the row cache's copies have landed)
     __builtin_amdgcn_wave_barrier();
     // Where a cached row lies.  The refine reads RUNS of 16 rows, every lane its own run, all lanes row k of their run at the same time: laid out in row

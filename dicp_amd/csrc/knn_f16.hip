@@ -563,7 +563,8 @@ __device__ __forceinline__ void f16_sweep_unit(const float* __restrict__ src, co
     load_pose(pose, cloud, C, r);
 
     float nx[F16_G][3], xq[F16_G], k0[F16_G];
-    int qi[F16_G], q_ok = 0;
+    int qi[F16_G], q_ok = 0;          // (the compiler parks three values -- 16 bytes per lane -- in scratch memory across the tile loop: stored once, loaded once.  Fetching the
+                                      //  queries again behind the loop instead frees the registers -- ScratchSize 0 -- and runs 2.5-6 % SLOWER on one box: profiles/r05_kernel_resources.txt)
     F16Track tr[F16_G];
     half8 b[F16_G];
     const float beta = 7.62939453125e-6f + 2.f * phi;               // 2^-17 + 2 phi

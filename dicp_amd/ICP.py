@@ -18,7 +18,7 @@ import torch
 import yaml
 
 from . import _call, _lib
-from ._ops import CallHints, ICPLoop, KabschLoop, LoopConfig, compute_device, prebuild_search, resort_schedule, transform_points
+from ._ops import CallHints, F16_SWEEP_MIN_TARGETS, ICPLoop, KabschLoop, LoopConfig, compute_device, form_tally_wanted, prebuild_search, resort_schedule, transform_points
 from .nn import nn
 
 
@@ -164,7 +164,9 @@ class ICP:
             # the target sort / index build of the sweep path goes to the GPU before the rest of the host work
             # (... and the first search right behind it, unless the loop will want original indices -- the atomic backward -- or carries timing events)
             if not soft:
-                cfg.prebuilt = prebuild_search(source, target, cfg.knn_variant, wants_grad and bool(cfg.bwd_window), T_init, src_rows, tgt_rows, first_search=first_search)
+                rec = self._hints.form_record(dev, (source.shape[0], source.shape[1], target.shape[1], source.dtype)) if source.is_cuda else None
+                cfg.prebuilt = prebuild_search(source, target, cfg.knn_variant, wants_grad and bool(cfg.bwd_window), T_init, src_rows, tgt_rows, first_search=first_search,
+                                               tally=form_tally_wanted(rec, target.shape[1] >= F16_SWEEP_MIN_TARGETS))
             T, pc, deltas, weights, costs, converged, iterations, matched = ICPLoop.apply(source.contiguous(), target.contiguous(), T_init, w_pts, cfg)
 
         if per_cloud_w:

@@ -4,6 +4,7 @@ PyTorch-ROCm is plumbing here (device memory, streams, the autograd graph); ever
 arithmetic step of the ICP iteration runs in libdicp_hip.so.  All functions require
 HIP-device tensors and raise otherwise -- there is no CPU compute path.
 """
+import os
 import ctypes
 from dataclasses import dataclass
 
@@ -21,7 +22,7 @@ F16_SWEEP_MIN_TARGETS = 32768               # ... and, for a cloud whose slabs h
                                             # scoring.  Round 5: every plain search of the loop tallies its slabs' tiles per cloud, and the next one scores a cloud on the matrix
                                             # cores if they were long (dicp_loop_buffers.sweep_form) -- clouds of 16384 points that start a metre off, or a third of which has no
                                             # counterpart in the target, score 30 % of the pairs: 28.2 -> 19.0 ms per 10-iteration call (profiles/r05_independent_forms.txt)
-F16_SWEEP_ADAPTIVE = True                   # (False: the form is chosen by the size alone, as in round 4)
+F16_SWEEP_ADAPTIVE = os.environ.get("DICP_F16_ADAPTIVE", "1") != "0"   # (the environment switch: scripts/ab_adaptive.sh)                 # (False: the form is chosen by the size alone, as in round 4)
 FORM_TILES = 32                             # (kernels_search.h: tiles per unit of 128 queries from which on a cloud's plain searches score on the matrix cores)
 SWEEP_MIN_PAIRS = 1e8        # ... and below this many (query,target) pairs per iteration.  Measured (profiles/r02_mid_size_paths.txt): with the
                              # native key sort the sweep's per-call set-up is ~0.1 ms, and it already wins at 32 x 2048^2 and 8 x 4096^2
@@ -187,7 +188,7 @@ class SweepIndex:
     an ICP call, so they are sorted by x once (dicp_sweep_sort: native for every size and dtype)."""
     NBKT = 1024
 
-    def __init__(self, tgt, sorted_rows=False, frame=None, tgt_rows=None, first_order=None, first_search=False):
+    def __init__(self, tgt, sorted_rows=False, frame=None, tgt_rows=None, first_order=None, first_search=False, tally=True):
         """sorted_rows: also keep tgt_s (N,m_pad,row_stride), the full rows in sorted order (the loop's accumulate and the windowed backward gather them).
         frame (N,12): the index is built on Q y + t (keys, table and packed rows; tgt_s keeps the rows as given) and the
         searches must then be given the pose [Q C | Q r + t].
@@ -238,7 +239,7 @@ class SweepIndex:
             spos0 = None
             if first_search:
                 spos0 = torch.empty((N, source.shape[1]), dtype=torch.int32, device=dev)
-                if F16_SWEEP_ADAPTIVE and dt == torch.float32 and float(N) * source.shape[1] >= F16_SWEEP_MIN_QUERIES and bool(F16_SWEEP):
+                if tally and F16_SWEEP_ADAPTIVE and dt == torch.float32 and float(N) * source.shape[1] >= F16_SWEEP_MIN_QUERIES and bool(F16_SWEEP):
                     self.form0 = torch.zeros((N,), dtype=torch.int32, device=dev)     # (that search's tally of its slabs' tiles per cloud: dicp_loop_buffers.sweep_form)
                 with _on(dev):
                     _lib.check(lib.dicp_knn_sweep(_DT[dt], _p(source), _p(pose_s), _p(self.tgs4), _p(self.tperm), _p(qorder), _p(self.bucket), _p(self.brange), self.NBKT,
@@ -466,7 +467,15 @@ def loss_weight(err2d, name, diff, metric, tanh_k):
 
 
 # --------------------------------------------------------------- the ICP loop
-def prebuild_search(source, target, knn_variant, want_rows, T_init=None, src_rows=None, tgt_rows=None, first_search=False):
+def form_tally_wanted(rec, have_image):
+    """Whether a call's plain searches should tally their slabs' tiles per cloud (dicp_loop_buffers.sweep_form): when the matrix-core image exists -- the searches then
+    choose each cloud's scoring form by the tallies -- or when this call REPORTS (the first two calls of a shape and every sixteenth: CallHints.form_record).  The
+    tally is an atomic add per unit of the sweep onto one word per cloud: 0.03 ms of the search near the pose, 1.6 % of the benchmark's call (round 5, A/B on one box),
+    for a statistic that is read once in sixteen calls."""
+    return bool(have_image) or (rec is not None and (rec["long"] or (rec["event"] is None and (rec["calls"] < 2 or rec["calls"] % 16 == 0))))
+
+
+def prebuild_search(source, target, knn_variant, want_rows, T_init=None, src_rows=None, tgt_rows=None, first_search=False, tally=True):
     """Enqueue the per-call search structure of the sweep path (target sort + index build, ~0.15 ms of kernels) NOW, so that
     it runs under the host work the caller still has to do before the loop starts (a call that begins on an idle GPU is
     host-bound until its first long kernel).  Returns (target, SweepIndex) for LoopConfig.prebuilt, or None when the loop
@@ -483,7 +492,7 @@ def prebuild_search(source, target, knn_variant, want_rows, T_init=None, src_row
         if (T_init is not None and T_init.is_cuda and T_init.is_contiguous() and T_init.dtype == target.dtype and source.is_contiguous()
                 and source.dtype == target.dtype and tuple(T_init.shape) == (N, 4, 4)):
             sweep = SweepIndex(target, sorted_rows=True, tgt_rows=tgt_rows, first_order=(source, T_init, src_rows),
-                               first_search=bool(first_search) and not (knn_variant & 0xff00))
+                               first_search=bool(first_search) and not (knn_variant & 0xff00), tally=tally)
             return (target, sweep, sweep.first)
         sweep = SweepIndex(target, sorted_rows=True, frame=search_frame(target, tgt_rows=tgt_rows), tgt_rows=tgt_rows)
         return (target, sweep, None)
@@ -818,6 +827,8 @@ class ICPLoop(torch.autograd.Function):
                     form_hint["event"] = None
                 if img16 is None and form_hint["long"]:
                     img16 = sweep.make_image()
+            if tally and not form_tally_wanted(form_hint, img16 is not None):
+                tally = False           # (no image in this call and nobody reads its tallies afterwards: the searches do not take them)
             nblk = lib.dicp_accumulate_blocks(n)
             poses = torch.empty((Kmax + 1, N, 12), dtype=dt, device=dev)
             poses_c = torch.empty((Kmax + 1, N, 12), dtype=dt, device=dev) if center is not None else None   # [Q C | Q r + t]: what the searches read

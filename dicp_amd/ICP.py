@@ -166,7 +166,7 @@ class ICP:
             if not soft:
                 rec = self._hints.form_record(dev, (source.shape[0], source.shape[1], target.shape[1], source.dtype)) if source.is_cuda else None
                 cfg.prebuilt = prebuild_search(source, target, cfg.knn_variant, wants_grad and bool(cfg.bwd_window), T_init, src_rows, tgt_rows, first_search=first_search,
-                                               tally=form_tally_wanted(rec, target.shape[1] >= F16_SWEEP_MIN_TARGETS))
+                                               tally=target.shape[1] < F16_SWEEP_MIN_TARGETS and form_tally_wanted(rec, False))
             T, pc, deltas, weights, costs, converged, iterations, matched = ICPLoop.apply(source.contiguous(), target.contiguous(), T_init, w_pts, cfg)
 
         if per_cloud_w:

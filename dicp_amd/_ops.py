@@ -817,8 +817,10 @@ class ICPLoop(torch.autograd.Function):
             # whether this call builds the matrix-core image for clouds too small to get one by size: where some cloud's slabs were long, the plain searches
             # launch both forms and each takes its clouds (start poses a metre off, a third of the source without counterpart: 28.2 -> 19.0 ms per call,
             # profiles/r05_independent_forms.txt); where none was, nothing is built and nothing more is launched.
+            # (clouds that get the image by their size score on the matrix cores in every plain search, as in round 4: there the per-cloud choice -- it sends a
+            #  cloud whose slabs have become short back to the vector form -- cost 8-10 % of a 64 x 65536 call, profiles/r05_form_tally.txt)
             tally = (sweep is not None and F16_SWEEP and F16_SWEEP_ADAPTIVE and dt == torch.float32 and float(N) * n >= F16_SWEEP_MIN_QUERIES
-                     and not (cfg.knn_variant & 0xff00))
+                     and not (cfg.knn_variant & 0xff00) and not sweep.form_default)
             form_hint = None
             if tally and cfg.hints is not None and not torch.cuda.is_current_stream_capturing():
                 form_hint = cfg.hints.form_record(dev, (N, n, m, dt))

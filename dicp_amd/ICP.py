@@ -18,7 +18,7 @@ import torch
 import yaml
 
 from . import _call, _lib
-from ._ops import CallHints, F16_SWEEP_MIN_TARGETS, ICPLoop, KabschLoop, LoopConfig, compute_device, form_tally_wanted, prebuild_search, resort_schedule, transform_points
+from ._ops import CallHints, F16_SWEEP_MIN_TARGETS, ICPLoop, KabschLoop, LoopConfig, compute_device, form_tally_wanted, pack_list, packable, prebuild_search, resort_schedule, transform_points
 from .nn import nn
 
 
@@ -331,7 +331,13 @@ class ICP:
         src_len = tgt_len = None
         per_cloud = False
         # ---- source and per-point prior weights (ICP.py:360-446)
-        if isinstance(source, list):
+        if (isinstance(source, list) and (weight is None or all(w_i is None for w_i in weight)) and packable(source, (3, 6))
+                and source[0].dtype == dt and source[0].device == torch.device(dev)):
+            # device tensors of the batch's dtype, no empty cloud, no weights: the whole list in one launch (and its gradients in one) instead of one op per cloud
+            src_len = [int(s_i.shape[0]) for s_i in source]
+            source_b = pack_list(source, 3)
+            w = (torch.arange(source_b.shape[1], device=dev)[None, :] < torch.tensor(src_len, device=dev)[:, None]).to(dt)
+        elif isinstance(source, list):
             pts, pri = [], []
             for i, s_i in enumerate(source):
                 if len(s_i) == 0:                                   # empty cloud: one zero point, zero weight
@@ -363,7 +369,11 @@ class ICP:
             w = w * (torch.linalg.norm(source_b, dim=2) != 0.0).to(dt)
 
         # ---- target, padded with a value no source point can be nearest to (ICP.py:448-491)
-        if isinstance(target, list):
+        if isinstance(target, list) and packable(target, (cols,)) and target[0].dtype == dt and target[0].device == source_b.device:
+            pad = (torch.max(source_b.detach()) * self.target_pad_val).to(dt)            # ICP.py:460 (a device scalar: no host round trip)
+            tgt_len = [int(t_i.shape[0]) for t_i in target]
+            target_b = pack_list(target, cols, pad)
+        elif isinstance(target, list):
             pad = torch.max(source_b) * self.target_pad_val                              # ICP.py:460
             rows, dead = [], []
             for i, t_i in enumerate(target):

@@ -343,6 +343,60 @@ def _gather_rows_raw(y, idx):
     return out
 
 
+class _PackList(torch.autograd.Function):
+    """A list of clouds (len_i, c_i) -> ONE padded batch (N, n_max, cols) of their first `cols` columns, one launch (dicp_pack_list); the reverse is one launch too
+    (dicp_unpack_list into ONE flat buffer: the clouds' gradients are views of it).  What ICP.py:305-511 does with one op per cloud: at 256 clouds ~800 launches
+    going in and ~2300 coming back through autograd, 20 ms of host and GPU time per call (profiles/r05_ragged_lists.txt)."""
+
+    @staticmethod
+    def forward(ctx, cols, pad, *clouds):
+        lib = _lib.load()
+        N, dev, dt = len(clouds), clouds[0].device, clouds[0].dtype
+        lens = [int(t.shape[0]) for t in clouds]
+        n_max = max(lens)
+        # pointers, lengths and row strides travel as one small tensor (pageable host memory: the copy is synchronous for the host, 6 KB)
+        meta = torch.tensor([t.data_ptr() for t in clouds] + lens + [int(t.stride(0)) for t in clouds], dtype=torch.int64).to(dev)
+        lens_d, strides_d = meta[N:2 * N].to(torch.int32), meta[2 * N:].to(torch.int32)
+        out = torch.empty((N, n_max, cols), dtype=dt, device=dev)
+        with _on(dev):
+            _lib.check(lib.dicp_pack_list(_DT[dt], _p(meta), _p(lens_d), _p(strides_d), N, n_max, int(cols), _p(out), _p(pad), _stream()), "dicp_pack_list")
+        ctx.geom = (cols, n_max, lens, [int(t.shape[1]) for t in clouds], dt, dev)
+        ctx.lens_d = lens_d
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        cols, n_max, lens, widths, dt, dev = ctx.geom
+        lib = _lib.load()
+        N, es = len(lens), torch.empty((), dtype=dt).element_size()
+        sizes = [l * c for l, c in zip(lens, widths)]
+        offs = [0]
+        for sz in sizes:
+            offs.append(offs[-1] + sz)
+        flat = torch.empty((offs[-1],), dtype=dt, device=dev)
+        meta = torch.tensor([flat.data_ptr() + o * es for o in offs[:-1]] + widths, dtype=torch.int64).to(dev)
+        strides_d = meta[N:].to(torch.int32)
+        g = gout.contiguous()
+        with _on(dev):
+            _lib.check(lib.dicp_unpack_list(_DT[dt], _p(g), _p(meta), _p(ctx.lens_d), _p(strides_d), N, n_max, int(cols), max(widths), _stream()), "dicp_unpack_list")
+        grads = tuple(flat[offs[i]:offs[i + 1]].view(lens[i], widths[i]) if ctx.needs_input_grad[2 + i] else None for i in range(N))
+        return (None, None) + grads
+
+
+def packable(clouds, widths):
+    """A list that dicp_pack_list can take as it stands: non-empty 2-D device tensors of one dtype and device with unit column stride and one of the given widths."""
+    first = clouds[0]
+    if not isinstance(first, torch.Tensor) or not first.is_cuda or first.dtype not in _DT:
+        return False
+    return all(isinstance(t, torch.Tensor) and t.is_cuda and t.dim() == 2 and t.shape[0] > 0 and t.shape[1] in widths and t.dtype == first.dtype
+               and t.device == first.device and t.stride(1) == 1 for t in clouds)
+
+
+def pack_list(clouds, cols, pad=None):
+    """(N, n_max, cols): the clouds' first `cols` columns, rows past a cloud's own filled with the device scalar `pad` (None: zero).  Differentiable w.r.t. the clouds."""
+    return _PackList.apply(int(cols), pad, *clouds)
+
+
 class _GumbelNN(torch.autograd.Function):
     """nn.__diff_nn_gumbel (nn.py:43-70) through dicp_gumbel_nn / dicp_gumbel_nn_bwd."""
 

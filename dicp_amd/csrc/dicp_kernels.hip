@@ -369,6 +369,28 @@ int dicp_gather_rows(int dtype, const void* tgt, const int32_t* idx, int N, int 
     return launch_status();
 }
 
+int dicp_pack_list(int dtype, const void* const* ptrs, const int32_t* lens, const int32_t* strides, int N, int n_max, int cols, void* out, const void* pad, void* stream) {
+    if (!ptrs || !lens || !strides || !out) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0 || n_max <= 0 || cols <= 0) return DICP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    begin_launch();
+    const int bpc = (int)blocks_for((size_t)n_max * cols);
+    if (dtype == DICP_F32) pack_list_kernel<float><<<grid_for(N, bpc), BLOCK, 0, st>>>((const float* const*)ptrs, lens, strides, N, n_max, cols, bpc, (float*)out, (const float*)pad);
+    else                   pack_list_kernel<double><<<grid_for(N, bpc), BLOCK, 0, st>>>((const double* const*)ptrs, lens, strides, N, n_max, cols, bpc, (double*)out, (const double*)pad);
+    return launch_status();
+}
+int dicp_unpack_list(int dtype, const void* gout, void* const* ptrs, const int32_t* lens, const int32_t* strides, int N, int n_max, int cols, int stride_max, void* stream) {
+    if (!gout || !ptrs || !lens || !strides) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0 || n_max <= 0 || cols <= 0 || stride_max < cols) return DICP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    begin_launch();
+    const int bpc = (int)blocks_for((size_t)n_max * stride_max);
+    if (dtype == DICP_F32) unpack_list_kernel<float><<<grid_for(N, bpc), BLOCK, 0, st>>>((const float*)gout, (float* const*)ptrs, lens, strides, N, n_max, cols, bpc);
+    else                   unpack_list_kernel<double><<<grid_for(N, bpc), BLOCK, 0, st>>>((const double*)gout, (double* const*)ptrs, lens, strides, N, n_max, cols, bpc);
+    return launch_status();
+}
 int dicp_scatter_add_rows(int dtype, const void* gout, const int32_t* idx, int N, int n, int m, int c, void* gtgt, void* stream) {
     if (!gout || !idx || !gtgt) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;

@@ -52,3 +52,32 @@ __global__ __launch_bounds__(BLOCK) void scatter_add_kernel(const T* __restrict_
         unsafeAtomicAdd(&gtgt[((size_t)b * m + j) * c + k], gout[(size_t)b * n * c + e]);
     }
 }
+
+// ------------------------------------------------------------- lists of clouds <-> one padded batch
+// ICP.py:305-511 (batch_size_handling) pads a LIST of clouds to the longest, one torch op per cloud: 256 clouds are ~800 copy / fill launches going in and -- autograd
+// through them -- ~2300 coming back: 20 ms of a 40 ms call on the hard benchmark clouds (profiles/r05_ragged_lists.txt).  Here the list is a table of pointers:
+// pack: out[b][i][k] = rows_b[i][k] for i < lens[b] (k < cols of the row's first `cols`), else *pad (NULL: zero); unpack (the adjoint): grads_b[i][k] = gout[b][i][k]
+// for k < cols, zero in the row's further columns.  One thread per element of the padded batch.
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void pack_list_kernel(const T* const* __restrict__ ptrs, const int32_t* __restrict__ lens, const int32_t* __restrict__ strides,
+                                                          int N, int n_max, int cols, int bpc, T* __restrict__ out, const T* __restrict__ pad) {
+    int b, blk;
+    if (!decode_block(bpc, N, b, blk)) return;
+    const unsigned e = (unsigned)blk * BLOCK + threadIdx.x;
+    if (e >= (unsigned)n_max * (unsigned)cols) return;
+    const int i = (int)(e / (unsigned)cols), k = (int)(e - (unsigned)i * cols);
+    T v = pad ? *pad : T(0);
+    if (i < lens[b]) v = ptrs[b][(size_t)i * strides[b] + k];
+    out[(size_t)b * n_max * cols + e] = v;
+}
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void unpack_list_kernel(const T* __restrict__ gout, T* const* __restrict__ ptrs, const int32_t* __restrict__ lens,
+                                                            const int32_t* __restrict__ strides, int N, int n_max, int cols, int bpc) {
+    int b, blk;
+    if (!decode_block(bpc, N, b, blk)) return;
+    const int stride = strides[b];                          // (elements per row of the cloud's gradient: its own column count)
+    const unsigned e = (unsigned)blk * BLOCK + threadIdx.x;
+    if (e >= (unsigned)n_max * (unsigned)stride) return;
+    const int i = (int)(e / (unsigned)stride), k = (int)(e - (unsigned)i * stride);
+    if (i < lens[b]) ptrs[b][(size_t)i * stride + k] = k < cols ? gout[((size_t)b * n_max + i) * cols + k] : T(0);
+}

@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define DICP_ABI_VERSION 9   /* 9: dicp_loop_buffers.det_far_row / det_far_val (deterministic target gradients of the windowed backward).
+#define DICP_ABI_VERSION 10  /* 10: dicp_pack_list / dicp_unpack_list (lists of clouds to one padded batch and back, one launch each).
+                                9: dicp_loop_buffers.det_far_row / det_far_val (deterministic target gradients of the windowed backward).
                                 8: certified iterations keep a row cache and their match history by reference (dicp_loop_buffers.spos_of / cert_nbr / cert_gdirty /
                                 cert_pend / cert_cm, spos_prev_chunk + spos_floor instead of spos_prev0; dicp_resolve_matches).
                                 7: dicp_call_* (one eager call of the sweep path behind one host call per direction).
@@ -187,6 +188,13 @@ int dicp_knn_sweep(int dtype, const void* src, const void* pose, const void* tgs
 /* Gather whole target rows at idx (nn.py:37-38 / 89-90) and its backward, a scatter-add
  * into a zero-initialised (N,m,c) buffer (autograd's gather backward). */
 int dicp_gather_rows(int dtype, const void* tgt, const int32_t* idx, int N, int n, int m, int c, void* out, void* stream);
+/* Lists of clouds <-> one padded batch (ICP.py:305-511, batch_size_handling: the reference pads a list to its longest cloud with one op per cloud).
+ * dicp_pack_list: out (N,n_max,cols)[b][i][k] = rows_b[i * strides[b] + k] for i < lens[b], else *pad (a DEVICE scalar; NULL: zero).  ptrs (N) device array of the
+ * clouds' base pointers (dtype elements), lens / strides (N) int32 device arrays: rows and elements per row of each cloud (strides[b] >= cols: only the first
+ * `cols` columns of a row are taken).  dicp_unpack_list, its adjoint: the cloud's gradient rows_b (lens[b], strides[b]) contiguous = gout[b][i][k] in the first
+ * `cols` columns and zero beyond them; stride_max = max strides[b] sizes the launch.  One launch each whatever N. */
+int dicp_pack_list(int dtype, const void* const* ptrs, const int32_t* lens, const int32_t* strides, int N, int n_max, int cols, void* out, const void* pad, void* stream);
+int dicp_unpack_list(int dtype, const void* gout, void* const* ptrs, const int32_t* lens, const int32_t* strides, int N, int n_max, int cols, int stride_max, void* stream);
 int dicp_scatter_add_rows(int dtype, const void* gout, const int32_t* idx, int N, int n, int m, int c, void* gtgt, void* stream);
 
 /* One pass over the source points: residuals (ICP.py:143-149), trim and robust weights

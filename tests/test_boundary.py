@@ -169,7 +169,7 @@ def test_new_entry_points_reject_bad_arguments(lib):
 
 
 def test_sizes_and_argument_checks(lib):
-    assert lib.dicp_abi_version() == _lib.ABI_VERSION == 9
+    assert lib.dicp_abi_version() == _lib.ABI_VERSION == 10
     assert [lib.dicp_padded_targets(m) for m in (0, 1, 64, 65, 129)] == [0, 64, 64, 128, 192]
     assert [lib.dicp_accumulate_blocks(n) for n in (0, 1, 512, 513, 16384)] == [0, 1, 1, 2, 32]
     # rejected before any launch (no GPU touched): null pointers, bad dtype / shapes / enums

@@ -133,3 +133,29 @@ def test_ragged_batch_scores_only_real_pairs():
     real = float(sum(a * b for a, b in zip(ls, lt)))
     frac = float(icp.knn_stats["knn_pairs"].sum().item()) / (real * K)
     assert frac < 0.12, frac          # (dense benchmark clouds: ~4 % over the first four iterations; short clouds have wider tiles relative to m)
+
+
+def test_lists_are_packed_by_one_launch_like_pad_sequence():
+    """ICP.py:305-511 pads a list of clouds with one op per cloud; device lists go through dicp_pack_list / dicp_unpack_list (one launch each way): the same padded
+    batch as torch's pad_sequence + the reference's pad value, bit for bit, and the same gradients back to every cloud of the list."""
+    import torch
+    from dicp_amd import _ops
+    g = torch.Generator().manual_seed(5)
+    for dt in (torch.float32, torch.float64):
+        clouds = [torch.randn((int(torch.randint(1, 700, (1,), generator=g)), 6), generator=g, dtype=dt).cuda().requires_grad_(True) for _ in range(37)]
+        pad = torch.tensor(1234.5, dtype=dt, device="cuda")
+        for cols in (3, 6):
+            out = _ops.pack_list(clouds, cols, pad)
+            ref = torch.nn.utils.rnn.pad_sequence([c[:, :cols] for c in clouds], batch_first=True)
+            lens = torch.tensor([c.shape[0] for c in clouds], device="cuda")
+            ref = torch.where((torch.arange(ref.shape[1], device="cuda")[None, :] < lens[:, None]).unsqueeze(-1), ref, pad)
+            assert torch.equal(out, ref)
+            wgt = torch.randn(out.shape, generator=g, dtype=dt).cuda()
+            ga = torch.autograd.grad((out * wgt).sum(), clouds)
+            gb = torch.autograd.grad((ref * wgt).sum(), clouds)
+            assert all(torch.equal(a, b) for a, b in zip(ga, gb))
+        assert torch.equal(_ops.pack_list(clouds, 3), torch.nn.utils.rnn.pad_sequence([c[:, :3] for c in clouds], batch_first=True))
+    # a strided view (the first three columns of six-column clouds, every other row) is taken as it stands or refused, never misread
+    views = [c.detach()[::2] for c in clouds]
+    assert _ops.packable(views, (6,)) and torch.equal(_ops.pack_list(views, 6), torch.nn.utils.rnn.pad_sequence(views, batch_first=True))
+    assert not _ops.packable([c.detach().t() for c in clouds], (6,)) and not _ops.packable([c.detach().cpu() for c in clouds], (6,))

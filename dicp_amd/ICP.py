@@ -65,7 +65,7 @@ class ICP:
         # 1e-3 bar but unlike the reference, which is deterministic.  With the switch the call takes the exact sweep search and the windowed backward
         # (whatever knn_variant says), the backward's slot order is a stable sort, every window row is summed in slot order and the out-of-window rows are
         # added by a fixed-order launch instead of atomics; the one-launch tail and the one-call path are not used.  The forward's results do not depend
-        # on it.  Cost: +0.87 ms per 10-iteration call at 256 x 16384 (profiles/r05_deterministic_cost.txt).  Not available with Gumbel correspondences; pt2pt_dICP_SVD and the
+        # on it.  Cost: +0.7 ms per 10-iteration call at 256 x 16384, 2.4x the backward on clouds that do not converge (profiles/r05_deterministic_cost.txt).  Not available with Gumbel correspondences; pt2pt_dICP_SVD and the
         # standalone nn / loss operators are not covered (their target gradients are row atomics).
         self.deterministic = False
         # Private switches of single mechanisms, all on: what the tests flip to hold each mechanism to the path without it (and what the

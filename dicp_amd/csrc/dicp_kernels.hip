@@ -731,7 +731,7 @@ static int accumulate_bwd_window_go(int dtype, const dicp_weight_params* prm, co
         hipExtLaunchKernelGGL((accumulate_bwd_window_kernel<T, M, WT, OV>), dim3(g), dim3(BLOCK), 0, st, ev0, ev1, 0, P, (const T*)src_s, (const T*)tgt_s, c, spos, spos_ref, qorder, (const T*)pose, \
             (const T*)w_s, (const T*)alive, (const T*)gs, (const T*)gb, N, n, m_pad, spb, bpc, (T*)gsrc_s, (T*)slab, (T*)gts_far, (T*)gw_s, \
             (T*)bwd_partials, src_rows, skip, det_row, (T*)det_val); \
-        if (det_row && slab) far_apply_kernel<T, (M == MODE_PT2PL ? 6 : 3)><<<N, WAVE, 0, st>>>(det_row, (const T*)det_val, (T*)gts_far, n, m_pad, src_rows, OV ? nullptr : skip); } while (0)
+        if (det_row && slab) far_apply_kernel<T, (M == MODE_PT2PL ? 6 : 3)><<<N * FAR_RANGES, BLOCK, 0, st>>>(det_row, (const T*)det_val, (T*)gts_far, n, m_pad, src_rows, OV ? nullptr : skip); } while (0)
     if (dtype == DICP_F32) { if (P.mode == MODE_PT2PL) DICP_WIN(float, MODE_PT2PL); else DICP_WIN(float, MODE_PT2PT); }
     else                   { if (P.mode == MODE_PT2PL) DICP_WIN(double, MODE_PT2PL); else DICP_WIN(double, MODE_PT2PT); }
 #undef DICP_WIN

@@ -252,16 +252,31 @@ __device__ __forceinline__ void window_body(const WeightParams& P, const T* __re
 #pragma unroll
             for (int k = 0; k < CV; ++k) sum[k] = T(0);
             if (det_row) {
-                // deterministic: the list is in the order the block's waves reached the row; its slots are summed in ASCENDING order instead
-                // (lists are one to three slots long: a selection pass per slot)
-                int last = -1;
-                for (int guard = 0; guard < SPB; ++guard) {
-                    int best = 0x7fffffff;
-                    for (int h2 = h, g2 = 0; h2 >= 0 && g2 < SPB; ++g2) { if (h2 > last && h2 < best) best = h2; h2 = next[h2]; }
-                    if (best == 0x7fffffff) break;
+                // deterministic: the list is in the order the block's waves reached the row; its slots are summed in ASCENDING order instead (lists are one to
+                // three slots long on clouds that converge: a selection pass per slot).  A LONG list -- many queries of one neighbourhood matched to one row: the
+                // part of a cloud that has no counterpart in the target, all of it matched to the target's rim -- would cost its length squared: its slots are
+                // handed to far_apply_kernel instead (left by slot like an out-of-window contribution), which adds them in slot order whatever their number.
+                constexpr int DET_LIST_MAX = 24;
+                int len = 0;
+                for (int h2 = h; h2 >= 0 && len <= DET_LIST_MAX; ++len) h2 = next[h2];
+                if (len > DET_LIST_MAX) {
+                    for (int h2 = h, g2 = 0; h2 >= 0 && g2 < SPB; ++g2) {
+                        const size_t pt = (size_t)cloud * n + s0 + h2;
+                        det_row[pt] = lo + rr;
 #pragma unroll
-                    for (int k = 0; k < CV; ++k) sum[k] += contrib[best * CV + k];
-                    last = best;
+                        for (int k = 0; k < CV; ++k) det_val[pt * CV + k] = contrib[h2 * CV + k];
+                        h2 = next[h2];
+                    }
+                } else {
+                    int last = -1;
+                    for (int guard = 0; guard < SPB; ++guard) {
+                        int best = 0x7fffffff;
+                        for (int h2 = h, g2 = 0; h2 >= 0 && g2 < SPB; ++g2) { if (h2 > last && h2 < best) best = h2; h2 = next[h2]; }
+                        if (best == 0x7fffffff) break;
+#pragma unroll
+                        for (int k = 0; k < CV; ++k) sum[k] += contrib[best * CV + k];
+                        last = best;
+                    }
                 }
             } else {
                 for (int guard = 0; h >= 0 && guard < SPB; ++guard) {       // every slot is on at most one list
@@ -300,29 +315,41 @@ __global__ __launch_bounds__(BLOCK) void accumulate_bwd_window_kernel(WeightPara
                                         n, m_pad, spb, bpc, gsrc_s, slab, gts_far, gw_s, part_out, src_rows, cloud, blk, det_row, det_val);
 }
 
-// Deterministic mode: the out-of-window contributions of one iteration, left by slot (det_row >= 0: the sorted target row, det_val: its CV values), into
-// gts_far.  One wave per cloud walks the slots in order; an entry is added by the lane that owns its row (row mod 64), so two entries of one row are added by
-// the same lane, the lower slot first, and entries of different rows in parallel.  ~1 % of the slots are such entries at the benchmark shape.
+// Deterministic mode: the contributions of one iteration that were left by slot (det_row >= 0: the sorted target row, det_val: its CV values: matches outside their
+// block's window, and the slots of window rows with long lists), into gts_far.  A block per (cloud, eighth of its target rows); the cloud's slots pass through LDS
+// 256 at a time, in order, and every thread adds the entries of the rows it owns (row mod 256) as it meets them: two entries of one row are added by one thread,
+// the lower slot first, whatever their number (a wave per cloud that walked the entries one by one took 16 ms per launch where half of the slots were such
+// entries; this form 0.1 ms, profiles/r05_deterministic_cost.txt).
+constexpr int FAR_RANGES = 8;
 template <typename T, int CV>
-__global__ __launch_bounds__(WAVE) void far_apply_kernel(const int32_t* __restrict__ det_row, const T* __restrict__ det_val, T* __restrict__ gts_far, int n, int m_pad,
-                                                        const int32_t* __restrict__ src_rows, const int32_t* __restrict__ skip) {
-    const int cloud = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(BLOCK) void far_apply_kernel(const int32_t* __restrict__ det_row, const T* __restrict__ det_val, T* __restrict__ gts_far, int n, int m_pad,
+                                                          const int32_t* __restrict__ src_rows, const int32_t* __restrict__ skip) {
+    __shared__ int rows_l[BLOCK];
+    const int cloud = blockIdx.x / FAR_RANGES, rg = blockIdx.x % FAR_RANGES, tid = threadIdx.x;
     if (skip && skip[cloud]) return;                        // (the window launch did not run for this cloud: its records are an earlier iteration's)
     const int nc = rows_of(src_rows, cloud, n);
+    const int per = ((m_pad + FAR_RANGES - 1) / FAR_RANGES + BLOCK - 1) / BLOCK * BLOCK;
+    const int lo = rg * per, hi = min(lo + per, m_pad);
     T* gfar = gts_far + (size_t)cloud * m_pad * CV;
-    for (int s0 = 0; s0 < nc; s0 += WAVE) {
-        const int s = s0 + lane;
+    for (int s0 = 0; s0 < nc; s0 += BLOCK) {                // (block-uniform trip count)
+        const int s = s0 + tid;
         const int r = s < nc ? det_row[(size_t)cloud * n + s] : -1;
-        unsigned long long mk = __ballot(r >= 0);
-        while (mk) {
-            const int b = __builtin_ctzll(mk);
-            mk &= mk - 1;
-            const int row = __shfl(r, b);
-            if ((row & (WAVE - 1)) == lane && row < m_pad) {
-                const T* v = det_val + ((size_t)cloud * n + s0 + b) * CV;
-                T* o = gfar + (size_t)row * CV;
+        const bool mine = r >= lo && r < hi;
+        __syncthreads();                                    // (the previous chunk has been read by everybody)
+        rows_l[tid] = mine ? r : -1;
+        if (!__syncthreads_or(mine ? 1 : 0)) continue;
+        for (int j0 = 0; j0 < BLOCK; j0 += 8) {             // (eight entries per round of LDS reads: one at a time the loop was a chain of LDS latencies)
+            int rj[8];
 #pragma unroll
-                for (int k = 0; k < CV; ++k) o[k] += v[k];
+            for (int u = 0; u < 8; ++u) rj[u] = rows_l[j0 + u];          // (the same words for every thread: broadcasts)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (rj[u] >= 0 && ((rj[u] - lo) & (BLOCK - 1)) == tid) {
+                    const T* v = det_val + ((size_t)cloud * n + s0 + j0 + u) * CV;
+                    T* o = gfar + (size_t)rj[u] * CV;
+#pragma unroll
+                    for (int k = 0; k < CV; ++k) o[k] += v[k];
+                }
             }
         }
     }

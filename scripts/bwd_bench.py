@@ -10,7 +10,11 @@ from dicp_amd.synthetic import make_pairs
 B = int(os.environ.get("B", 256)); n = int(os.environ.get("NPTS", 16384)); rounds = int(os.environ.get("ROUNDS", 7))
 mode = os.environ.get("MODE", "pt2pl")
 lib = _lib.load()
-src, tgt = make_pairs(B, n, n, seed=3)
+if os.environ.get("HARD") == "1":       # independently sampled, partially overlapping clouds a metre off (dicp_amd.synthetic.make_independent_pairs)
+    from dicp_amd.synthetic import make_independent_pairs
+    src, tgt = make_independent_pairs(B, n, n, seed=3, dtype=torch.float32, ragged=False)
+else:
+    src, tgt = make_pairs(B, n, n, seed=3)
 src, tgt = src.cuda(), tgt.cuda()
 if mode == "pt2pt":
     tgt = tgt[:, :, :3].contiguous()

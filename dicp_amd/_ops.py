@@ -742,6 +742,18 @@ def _converged_at(pending):
     return k0 + int(zero[0, 0]) + 1 if zero.numel() else None
 
 
+def order_by_matches(src, spos_ref, m, m_pad, src_rows, tgt_rows):
+    """(N,n) int32 slot order for the windowed backward: the queries by the sorted position of their reference match (dicp_query_order with spos_prev: equal-population
+    buckets of the target's sorted rows; a cloud's pad rows last)."""
+    N, n, _ = src.shape
+    qo = torch.empty((N, n), dtype=torch.int32, device=src.device)
+    unused = torch.ones((N, 2), dtype=src.dtype, device=src.device)      # (the x range of the targets: not read when the buckets come from the matches)
+    with _on(src.device):
+        _lib.check(_lib.load().dicp_query_order(_DT[src.dtype], _p(src), None, _p(unused), SweepIndex.NBKT, N, n, _p(qo), None, None, None, 0, _p(spos_ref), int(m_pad),
+                                                None, None, int(m), _p(src_rows), _p(tgt_rows), _stream()), "dicp_query_order")
+    return qo
+
+
 def backward_once(lib, code, P, F, cfg, src, tgt, w0c, gT, want_tgt, want_w):
     """The reverse sweep of a sweep-path call whose iterations all take the windowed form inside one history slab, from ONE library call (dicp_loop_backward):
     F = _lib.LoopBackwardIn naming the forward's buffers.  Allocates the pass's workspace and results, places the one-launch tail by the hints of the previous
@@ -915,6 +927,7 @@ class ICPLoop(torch.autograd.Function):
             # match can be proven; poses that keep moving: no budget survives), the next calls do not try: they search plainly -- the same results, without the certifying search and the guard
             # launches -- and after 32 calls they try again.  The previous call's switch states arrive through pinned memory, like the tail's hint.
             cert_hint = None
+            clouds_moving = False       # the hint says: most clouds of this shape were still moving when their certificates were tried (they switched them off)
             if want_certs and cfg.cert_hint and cfg.cert_backoff and cfg.hints is not None and not torch.cuda.is_current_stream_capturing():
                 cert_hint = cfg.hints.cert_record(dev, (N, n, m, Kmax, dt))
                 if cert_hint["host"] is None or cert_hint["host"].shape[0] < N:
@@ -922,15 +935,18 @@ class ICPLoop(torch.autograd.Function):
                 if cert_hint["skip"] > 0:
                     cert_hint["skip"] -= 1
                     want_certs = False
+                    clouds_moving = bool(cert_hint.get("moving", False))
                 elif cert_hint["event"] is not None and cert_hint["event"].query():
                     # every cloud off at the call's end (for good, or backed off: clouds that keep moving) -- or, in a batch so small that a launch is as
                     # long as its slowest cloud (no more units than the GPU holds at once), ANY cloud whose certificates did not pay in two iterations
                     hc = cert_hint["host"][:N]
                     # (round 5: or most of them -- partially overlapping clouds that start a metre off: 247 of 256 ended a call switched off, and the call cost
                     #  34.6 ms with certificates against 28.2 without, profiles/r05_independent_forms.txt)
-                    if float((hc[:, 2] > 0).float().mean()) >= 0.5 or (N * ((n + 127) // 128) <= 8192 and bool((hc[:, 7] >= 2).any())):
-                        cert_hint.update(skip=31, calls=0)                   # (the first certified call after the pause reports again)
+                    most_off = float((hc[:, 2] > 0).float().mean()) >= 0.5
+                    if most_off or (N * ((n + 127) // 128) <= 8192 and bool((hc[:, 7] >= 2).any())):
+                        cert_hint.update(skip=31, calls=0, moving=most_off)  # (the first certified call after the pause reports again)
                         want_certs = False
+                        clouds_moving = most_off
                     cert_hint["event"] = None
                 if want_certs:
                     cert_hint["calls"] += 1                                  # certified calls of this shape
@@ -1194,6 +1210,10 @@ class ICPLoop(torch.autograd.Function):
             ctx.layout = (len(idx_slabs), len(spos_slabs), len(qorders), kc, owned, m_pad, kind,
                           [(a, min(b, K), q) for (a, b), q in zip(done_segs, seg_q) if a < K])
             ctx.of_from = cert_from if spos_of is not None else None
+            # Clouds that do not converge: the forward's last query order (iteration 3's) is stale by the last iteration -- a block's slots no longer match a
+            # window of neighbouring target rows, and most contributions take the float atomics (0.43 instead of 0.15 ms per launch on independently sampled
+            # clouds, profiles/r05_ragged_lists.txt).  The backward then orders its slots by the reference matches themselves (one counting-sort launch).
+            ctx.bwd_reorder = bool(clouds_moving) and sweep is not None
         conv = converged.bool()
         ctx.mark_non_differentiable(deltas_out, weights, costs_out, conv, iterations, matched)
         return T, pc, deltas_out, weights, costs_out, conv, iterations, matched
@@ -1232,8 +1252,15 @@ class ICPLoop(torch.autograd.Function):
             if owned and soft is None and cfg.timing_events is None and n_spos == 1 and n_idx == 0 and c == cv and segs and K >= 1 and not cfg.deterministic:
                 # every iteration takes the windowed form inside one slab: the whole pass is one library call (dicp_loop_backward) on one allocation.
                 # (Tolerance mode feels it most: there the host cannot run ahead of the GPU, and what it does before the pass's first launch is exposed.)
+                qo_b = qorders[-1]
+                if getattr(ctx, "bwd_reorder", False):
+                    ref = spos_slabs[0][K - 1]
+                    if spos_of is not None and K - 1 >= of_from:
+                        ref = torch.empty((N, n), dtype=torch.int32, device=dev)
+                        _lib.check(lib.dicp_resolve_matches(_p(spos_slabs[0]), _p(spos_of), K - 1, _p(cfg.src_rows), N, n, _p(ref), st), "dicp_resolve_matches")
+                    qo_b = order_by_matches(src, ref, m, m_pad, cfg.src_rows, cfg.tgt_rows)
                 F = _lib.LoopBackwardIn(src=src.data_ptr(), tgt_sorted=tgt_s.data_ptr(), w0=w0c.data_ptr() if w0c is not None else None, tperm=tperm.data_ptr(),
-                                        qorder=qorders[-1].data_ptr(), spos=spos_slabs[0].data_ptr(), poses=poses.data_ptr(), deltas=deltas.data_ptr(), areg=areg.data_ptr(),
+                                        qorder=qo_b.data_ptr(), spos=spos_slabs[0].data_ptr(), poses=poses.data_ptr(), deltas=deltas.data_ptr(), areg=areg.data_ptr(),
                                         alive=alive.data_ptr(), src_rows=cfg.src_rows.data_ptr() if cfg.src_rows is not None else None,
                                         tgt_rows=cfg.tgt_rows.data_ptr() if cfg.tgt_rows is not None else None, N=N, n=n, m=m, c=tgt_s.shape[2], K=K, K_cap=Kmax, m_pad=m_pad,
                                         dim=int(cfg.dim), knn_variant=kind | ((0 if cfg.small_loop else 1) << 25),
@@ -1277,6 +1304,8 @@ class ICPLoop(torch.autograd.Function):
                     _lib.check(lib.dicp_resolve_matches(ctypes.c_void_p(spos_slabs[jr].data_ptr() - jr * kc * N * n * 4), _p(spos_of), k_ref, _p(cfg.src_rows), N, n, _p(spos_ref), st),
                                "dicp_resolve_matches")
                 qo = qorders[q_star]
+                if getattr(ctx, "bwd_reorder", False) and not cfg.deterministic:
+                    qo = order_by_matches(src, spos_ref, m, m_pad, cfg.src_rows, cfg.tgt_rows)
                 if cfg.deterministic:
                     # The forward's query order comes from a counting sort whose order inside a bucket is the arrival order of LDS adds: fine for a search
                     # (exact for any order), but the backward takes its sums by slot.  Any permutation serves as slot order: here a STABLE sort of the

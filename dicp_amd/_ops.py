@@ -950,6 +950,8 @@ class ICPLoop(torch.autograd.Function):
                     cert_hint["event"] = None
                 if want_certs:
                     cert_hint["calls"] += 1                                  # certified calls of this shape
+            # (... or, in a call without certificates, the form hint: a quarter of the clouds of this shape had long slabs in a plain search of the previous call)
+            clouds_moving = bool(clouds_moving or (not want_certs and form_hint is not None and form_hint["long"]))
             arena.take((Kmax, 128) if want_certs else (0,), torch.int32)
             arena.take((N, 8) if want_certs else (0,), torch.int32)
             arena.take((N, n) if want_certs else (0,), torch.int32)     # (row cache: matches a guard launch leaves for the accumulate of its iteration; zero = none)
@@ -1253,6 +1255,8 @@ class ICPLoop(torch.autograd.Function):
                 # every iteration takes the windowed form inside one slab: the whole pass is one library call (dicp_loop_backward) on one allocation.
                 # (Tolerance mode feels it most: there the host cannot run ahead of the GPU, and what it does before the pass's first launch is exposed.)
                 qo_b = qorders[-1]
+                if cfg.stats_out is not None:
+                    cfg.stats_out["bwd_reordered"] = bool(getattr(ctx, "bwd_reorder", False))     # (the backward's slots were ordered by the reference matches: the clouds keep moving)
                 if getattr(ctx, "bwd_reorder", False):
                     ref = spos_slabs[0][K - 1]
                     if spos_of is not None and K - 1 >= of_from:
@@ -1304,6 +1308,8 @@ class ICPLoop(torch.autograd.Function):
                     _lib.check(lib.dicp_resolve_matches(ctypes.c_void_p(spos_slabs[jr].data_ptr() - jr * kc * N * n * 4), _p(spos_of), k_ref, _p(cfg.src_rows), N, n, _p(spos_ref), st),
                                "dicp_resolve_matches")
                 qo = qorders[q_star]
+                if cfg.stats_out is not None:
+                    cfg.stats_out["bwd_reordered"] = bool(getattr(ctx, "bwd_reorder", False)) and not cfg.deterministic
                 if getattr(ctx, "bwd_reorder", False) and not cfg.deterministic:
                     qo = order_by_matches(src, spos_ref, m, m_pad, cfg.src_rows, cfg.tgt_rows)
                 if cfg.deterministic:

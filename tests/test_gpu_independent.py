@@ -91,3 +91,26 @@ def test_against_the_oracle(dtype):
             assert float(err.max()) <= grad_bar * scale, float(err.max())
         else:       # (a float32 argmin may pick the other of two equidistant neighbours of a surface sample: at most 0.2 % of the rows, as at the benchmark's sizes)
             assert float((err > grad_bar * scale).double().mean()) <= 2e-3, (float(err.max()), float((err > grad_bar * scale).double().mean()))
+
+
+def test_later_calls_of_a_moving_shape_take_the_hints_and_give_the_same_gradients():
+    """The first call of a shape tries the match certificates; where most clouds switch them off (they keep moving: this generator) the hint makes the next calls run
+    without them and order the backward's slots by the reference matches (ICPLoop: ctx.bwd_reorder).  Exact searches and the same sums in another order: the same
+    poses bit for bit, the same gradients to rounding."""
+    S, T = make_independent_pairs(64, 8192, 8192, seed=11, dtype=torch.float32, ragged=False)
+    S, T = S.to(DEV), T.to(DEV)
+    T0 = torch.eye(4, device=DEV).repeat(64, 1, 1)
+    icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=8, tolerance=1e-12)
+    icp.const_iter = True
+    outs = []
+    for call in range(4):
+        s, t = S.detach().requires_grad_(True), T.detach().requires_grad_(True)
+        o = icp.icp(s, t, T0, trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0}, dim=3)
+        o["T"].sum().backward()
+        torch.cuda.synchronize()
+        outs.append((o["T"].detach().clone(), s.grad.clone(), t.grad.clone(), bool(icp.knn_stats.get("bwd_reordered", False)), "certs_off" in icp.knn_stats))
+    assert outs[0][4] and not outs[0][3]                    # the first call: certificates tried, the forward's own slot order
+    assert outs[-1][3] and not outs[-1][4], [o[3:] for o in outs]      # later calls: no certificates, slots ordered by the matches
+    assert torch.equal(outs[0][0], outs[-1][0])
+    for a, b in zip(outs[0][1:3], outs[-1][1:3]):
+        assert float((a - b).abs().max()) <= 1e-3 * max(1.0, float(a.abs().max()))

@@ -18,7 +18,7 @@ import torch
 import yaml
 
 from . import _call, _lib
-from ._ops import CallHints, F16_SWEEP_MIN_TARGETS, ICPLoop, KabschLoop, LoopConfig, compute_device, form_tally_wanted, pack_list, packable, prebuild_search, resort_schedule, transform_points
+from ._ops import CallHints, F16_SWEEP_MIN_TARGETS, F16_SWEEP_STATIC_TARGETS, ICPLoop, KabschLoop, LoopConfig, compute_device, form_tally_wanted, pack_list, packable, prebuild_search, resort_schedule, transform_points
 from .nn import nn
 
 
@@ -166,7 +166,7 @@ class ICP:
             if not soft:
                 rec = self._hints.form_record(dev, (source.shape[0], source.shape[1], target.shape[1], source.dtype)) if source.is_cuda else None
                 cfg.prebuilt = prebuild_search(source, target, cfg.knn_variant, wants_grad and bool(cfg.bwd_window), T_init, src_rows, tgt_rows, first_search=first_search,
-                                               tally=target.shape[1] < F16_SWEEP_MIN_TARGETS and form_tally_wanted(rec, False))
+                                               tally=target.shape[1] < F16_SWEEP_STATIC_TARGETS and form_tally_wanted(rec, target.shape[1] >= F16_SWEEP_MIN_TARGETS))
             T, pc, deltas, weights, costs, converged, iterations, matched = ICPLoop.apply(source.contiguous(), target.contiguous(), T_init, w_pts, cfg)
 
         if per_cloud_w:

@@ -56,7 +56,7 @@ class LoopBuffers(ctypes.Structure):
                 ("src_rows", vp), ("tgt_rows", vp), ("cert_q", vp), ("cert_qu", vp), ("cert_set", vp), ("cert_count", vp), ("rmax", vp), ("dcum", vp),
                 ("cert_reset", i32), ("cert_cloud", vp), ("spos_prev_chunk", vp), ("spos_floor", i32), ("spos_of", vp), ("spos_of_from", i32),
                 ("cert_nbr", vp), ("cert_gdirty", vp), ("cert_pend", vp), ("cert_glist", vp), ("cert_gcount", vp), ("cert_slist", vp), ("cert_scount", vp), ("cert_cm", vp), ("tgt_sorted", vp), ("tgt_sorted_stride", i32),
-                ("bwd_skip", vp), ("bwd_mref", vp), ("bwd_live", vp), ("bwd_skip_eps", f64), ("bwd_tail_from", i32), ("bwd_tail_partials", vp), ("bwd_tail_arrive", vp), ("gumbel", vp), ("first_search_done", i32), ("tgt_f16", vp), ("sweep_form", vp), ("sweep_form_default", i32), ("det_far_row", vp), ("det_far_val", vp)]
+                ("bwd_skip", vp), ("bwd_mref", vp), ("bwd_live", vp), ("bwd_skip_eps", f64), ("bwd_tail_from", i32), ("bwd_tail_partials", vp), ("bwd_tail_arrive", vp), ("gumbel", vp), ("first_search_done", i32), ("tgt_f16", vp), ("sweep_form", vp), ("sweep_form_default", i32), ("sweep_form_plan", vp), ("det_far_row", vp), ("det_far_val", vp)]
 
 
 class GumbelLoop(ctypes.Structure):
@@ -142,7 +142,7 @@ _SIGNATURES = {
     "dicp_padded_targets": ([i32], ctypes.c_int),
     "dicp_accumulate_blocks": ([i32], ctypes.c_int),
     "dicp_pack_target": ([i32, vp, i32, vp, vp, i32, i32, vp, i32, vp], ctypes.c_int),
-    "dicp_search_frame": ([i32, vp, i32, vp, i32, i32, f64, i32, vp, vp], ctypes.c_int),
+    "dicp_search_frame": ([i32, vp, i32, vp, i32, i32, f64, i32, vp, vp, i32, vp, vp, vp], ctypes.c_int),
     "dicp_knn_f16_bytes": ([i32, i32], ctypes.c_size_t),
     "dicp_knn_f16_pack": ([vp, vp, i32, i32, i32, vp, vp], ctypes.c_int),
     "dicp_knn_f16_probe": ([vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp], ctypes.c_int),

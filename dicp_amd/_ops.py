@@ -17,13 +17,18 @@ SWEEP_MIN_TARGETS = 2048     # KNN_AUTO inside ICP: below this many targets per 
 SWEEP_MIN_QUERIES = 256
 F16_SWEEP = True             # float32 sweep path: the plain searches of big clouds score on the matrix cores (split-f16 filter + exact refine; same indices)
 F16_SWEEP_MIN_QUERIES = 2 * 256 * 1024      # ... from the size at which the sweep works in units of 128 queries (sweep_auto_cfg)
-F16_SWEEP_MIN_TARGETS = 32768               # ... and, for a cloud whose slabs have not been measured yet, from 32768 targets on: measured (profiles/r04_knn_f16_sweep.txt) 1.27x at
-                                            # 32768, 1.4-1.5x at 65536, 0.92x at 16384 -- a wave's slab there is 16 tiles, 128 MFMAs, and the per-wave refine costs as much as the
-                                            # scoring.  Round 5: every plain search of the loop tallies its slabs' tiles per cloud, and the next one scores a cloud on the matrix
-                                            # cores if they were long (dicp_loop_buffers.sweep_form) -- clouds of 16384 points that start a metre off, or a third of which has no
-                                            # counterpart in the target, score 30 % of the pairs: 28.2 -> 19.0 ms per 10-iteration call (profiles/r05_independent_forms.txt)
+F16_SWEEP_MIN_TARGETS = 16384               # ... and, for a cloud whose slabs have not been measured yet, from 16384 targets on.  Round 6 (profiles/r06_f16_sweep_crossover.txt, the
+                                            # sweep form as round 5 left it): at 256 x 16384 the matrix cores win from ~7 tiles per unit of 128 queries on -- 1.38x under the start
+                                            # pose (15 tiles), 1.23x after one iteration (10), level after two (5.5), 0.85x after three (4); round 4 had measured 0.92x at 16 tiles,
+                                            # and the threshold stood at 32768 targets / 32 tiles until this round.  Smaller clouds: per cloud by the previous plain search's tally of
+                                            # slab lengths (dicp_loop_buffers.sweep_form; FORM_TILES) -- clouds that start metres off, or a third of which has no counterpart
+FORM_PLAN_ITERS = 6                         # iterations whose tallies a reporting call hands to the next calls' plan (dicp_loop_buffers.sweep_form_plan); later ones follow the last
+FORM_TILES_MOVING = 32                      # tiles per unit in a call's LAST plain search from which on its clouds count as still moving (the backward then orders its slots by the matches)
+F16_SWEEP_STATIC_TARGETS = 32768            # from here on every plain search of every cloud scores on the matrix cores (the per-cloud choice cost 8-10 % of a 64 x 65536 call,
+                                            # profiles/r05_form_tally.txt); between the two thresholds iteration 0's search does and the later ones go by the tallies -- planar
+                                            # scenes close their slabs to 5 tiles in one iteration and are then faster in the vector form (0.200 against 0.240 ms per search)
 F16_SWEEP_ADAPTIVE = os.environ.get("DICP_F16_ADAPTIVE", "1") != "0"   # (the environment switch: scripts/ab_adaptive.sh)                 # (False: the form is chosen by the size alone, as in round 4)
-FORM_TILES = 32                             # (kernels_search.h: tiles per unit of 128 queries from which on a cloud's plain searches score on the matrix cores)
+FORM_TILES = 12                             # (kernels_search.h: tiles per unit of 128 queries from which on a cloud's plain searches score on the matrix cores)
 SWEEP_MIN_PAIRS = 1e8        # ... and below this many (query,target) pairs per iteration.  Measured (profiles/r02_mid_size_paths.txt): with the
                              # native key sort the sweep's per-call set-up is ~0.1 ms, and it already wins at 32 x 2048^2 and 8 x 4096^2
                              # (0.090 vs 0.103 and 0.075 vs 0.121 ms per iteration, fwd+bwd); at 32 x 4096^2 (BASELINE configs[1]) 0.084 vs 0.175
@@ -100,18 +105,24 @@ CENTER_QUANTUM = 16.0    # metres; clouds whose median point is within half of i
 FRAME_DIRECTIONS = True  # the search frame also picks the sort direction (False: the x axis, always)
 
 
-def search_frame(tgt, quantum=None, tgt_rows=None, directions=None):
+def search_frame(tgt, quantum=None, tgt_rows=None, directions=None, src=None, T_init=None, src_rows=None):
     """(N,m,c) -> (N,12): the search frame x' = Q x + t of every cloud (dicp_search_frame), [Q row-major | t] with t = -Q c:
     c = the coordinate-wise median of (a sample of) the target, rounded to a multiple of `quantum`, so that clouds near the origin get exactly 0;
     Q = the rotation whose first row is the direction the sorted sweep prunes along -- the identity unless one of five other candidates spreads
     the cloud's points clearly better (planar scenes: a wall perpendicular to x sits in every slab that touches it).
-    tgt_rows (N) int32, optional: rows of each cloud that take part (ragged batches)."""
+    tgt_rows (N) int32, optional: rows of each cloud that take part (ragged batches).
+    src (N,n,3) + T_init (N,4,4), optional: the queries the searches will run for -- the direction is then chosen by the rows THEIR slabs hold."""
     require_device(tgt, "search_frame")
     N, m, c = tgt.shape
     out = torch.empty((N, 12), dtype=tgt.dtype, device=tgt.device)
+    with_q = src is not None and T_init is not None
+    if with_q:
+        src, T_init = src.contiguous(), T_init.contiguous()
     with _on(tgt.device):
         _lib.check(_lib.load().dicp_search_frame(_DT[tgt.dtype], _p(tgt), c, _p(tgt_rows), N, m, CENTER_QUANTUM if quantum is None else float(quantum),
-                                                 int(FRAME_DIRECTIONS if directions is None else directions), _p(out), _stream()), "dicp_search_frame")
+                                                 int(FRAME_DIRECTIONS if directions is None else directions),
+                                                 _p(src) if with_q else None, _p(src_rows) if with_q else None, int(src.shape[1]) if with_q else 0,
+                                                 _p(T_init) if with_q else None, _p(out), _stream()), "dicp_search_frame")
     return out
 
 
@@ -522,11 +533,14 @@ def loss_weight(err2d, name, diff, metric, tanh_k):
 
 # --------------------------------------------------------------- the ICP loop
 def form_tally_wanted(rec, have_image):
-    """Whether a call's plain searches should tally their slabs' tiles per cloud (dicp_loop_buffers.sweep_form): when the matrix-core image exists -- the searches then
-    choose each cloud's scoring form by the tallies -- or when this call REPORTS (the first two calls of a shape and every sixteenth: CallHints.form_record).  The
-    tally is an atomic add per unit of the sweep onto one word per cloud: 0.03 ms of the search near the pose, 1.6 % of the benchmark's call (round 5, A/B on one box),
-    for a statistic that is read once in sixteen calls."""
-    return bool(have_image) or (rec is not None and (rec["long"] or (rec["event"] is None and (rec["calls"] < 2 or rec["calls"] % 16 == 0))))
+    """Whether a call's plain searches should tally their slabs' tiles per cloud (dicp_loop_buffers.sweep_form): when this call REPORTS (the first two calls of a shape
+    and every sixteenth: CallHints.form_record), or when its searches choose each cloud's scoring form by the tallies -- the matrix-core image exists (or the record
+    says the shape's slabs are long: it will) and no earlier report has given the shape a plan yet.  The tally is an atomic add per unit of the sweep onto one word
+    per cloud: 0.03 ms of the search near the pose, 1.6 % of the benchmark's call (round 5, A/B on one box)."""
+    if rec is None:
+        return bool(have_image)
+    reporting = rec["event"] is None and (rec["calls"] < 2 or rec["calls"] % 16 == 0)
+    return bool(reporting or ((have_image or rec["long"]) and not rec.get("plan")))
 
 
 def prebuild_search(source, target, knn_variant, want_rows, T_init=None, src_rows=None, tgt_rows=None, first_search=False, tally=True):
@@ -870,7 +884,9 @@ class ICPLoop(torch.autograd.Function):
                         and pre[1].tgt_s is not None and pre[1].tgt_rows is cfg.tgt_rows):
                     sweep = pre[1]                           # started by the caller, under its host work
                 else:
-                    sweep = SweepIndex(tgt, sorted_rows=True, frame=search_frame(tgt, tgt_rows=cfg.tgt_rows), tgt_rows=cfg.tgt_rows)
+                    with_q = T_init.dtype == dt and tuple(T_init.shape) == (N, 4, 4)
+                    sweep = SweepIndex(tgt, sorted_rows=True, tgt_rows=cfg.tgt_rows,
+                                       frame=search_frame(tgt, tgt_rows=cfg.tgt_rows, src=src if with_q else None, T_init=T_init if with_q else None, src_rows=cfg.src_rows))
             # the searches run in the target cloud's search frame (dicp_search_frame): packed rows Q y + t, pose [Q C | Q r + t]
             soft = kind == _lib.KNN_GUMBEL        # soft correspondences: no search structure at all
             center = sweep.frame if sweep is not None else (None if soft else search_frame(tgt, tgt_rows=cfg.tgt_rows))
@@ -886,17 +902,27 @@ class ICPLoop(torch.autograd.Function):
             # (clouds that get the image by their size score on the matrix cores in every plain search, as in round 4: there the per-cloud choice -- it sends a
             #  cloud whose slabs have become short back to the vector form -- cost 8-10 % of a 64 x 65536 call, profiles/r05_form_tally.txt)
             tally = (sweep is not None and F16_SWEEP and F16_SWEEP_ADAPTIVE and dt == torch.float32 and float(N) * n >= F16_SWEEP_MIN_QUERIES
-                     and not (cfg.knn_variant & 0xff00) and not sweep.form_default)
+                     and not (cfg.knn_variant & 0xff00) and m < F16_SWEEP_STATIC_TARGETS)
             form_hint = None
             if tally and cfg.hints is not None and not torch.cuda.is_current_stream_capturing():
                 form_hint = cfg.hints.form_record(dev, (N, n, m, dt))
                 if form_hint["event"] is not None and form_hint["event"].query():
-                    form_hint["long"] = bool(4 * int(form_hint["host"][0]) >= N)     # (a quarter of the clouds: the image and the second launch cost every call 0.1 ms)
+                    rep = form_hint["host"].tolist()
+                    form_hint["long"] = bool(4 * rep[0] >= N)       # (a quarter of the clouds: the image costs every call 0.03 ms)
+                    form_hint["moving"] = bool(4 * rep[1] >= N)     # ... still had long slabs in the call's LAST plain search: they keep moving
+                    # the plan of the next calls: iteration k + 1 scores on the matrix cores if most clouds' slabs were long in iteration k's plain search
+                    # (-1: no plain search then -- a certified iteration -- : the loop decides as it does without a plan)
+                    form_hint["plan"] = [0] + [0 if c < 0 else (2 if 2 * c >= N else 1) for c in rep[2:2 + FORM_PLAN_ITERS]]
                     form_hint["event"] = None
                 if img16 is None and form_hint["long"]:
                     img16 = sweep.make_image()
+            form_plan = None
+            if tally and img16 is not None and form_hint is not None and form_hint.get("plan"):
+                # one form per iteration for the whole batch, from an earlier call's tallies (iterations beyond the report: as the last reported one)
+                pl = form_hint["plan"]
+                form_plan = (ctypes.c_int32 * Kmax)(*[(pl[k] if k < len(pl) else pl[-1]) for k in range(Kmax)])
             if tally and not form_tally_wanted(form_hint, img16 is not None):
-                tally = False           # (no image in this call and nobody reads its tallies afterwards: the searches do not take them)
+                tally = False           # (nobody reads this call's tallies: no per-cloud choice inside it, no report after it -- the searches do not take them)
             nblk = lib.dicp_accumulate_blocks(n)
             poses = torch.empty((Kmax + 1, N, 12), dtype=dt, device=dev)
             poses_c = torch.empty((Kmax + 1, N, 12), dtype=dt, device=dev) if center is not None else None   # [Q C | Q r + t]: what the searches read
@@ -951,7 +977,7 @@ class ICPLoop(torch.autograd.Function):
                 if want_certs:
                     cert_hint["calls"] += 1                                  # certified calls of this shape
             # (... or, in a call without certificates, the form hint: a quarter of the clouds of this shape had long slabs in a plain search of the previous call)
-            clouds_moving = bool(clouds_moving or (not want_certs and form_hint is not None and form_hint["long"]))
+            clouds_moving = bool(clouds_moving or (not want_certs and form_hint is not None and form_hint.get("moving", False)))
             arena.take((Kmax, 128) if want_certs else (0,), torch.int32)
             arena.take((N, 8) if want_certs else (0,), torch.int32)
             arena.take((N, n) if want_certs else (0,), torch.int32)     # (row cache: matches a guard launch leaves for the accumulate of its iteration; zero = none)
@@ -969,7 +995,7 @@ class ICPLoop(torch.autograd.Function):
                 #  group's matches lie in the history, which those iterations keep by reference: dicp_loop_buffers.spos_of)
                 certs = dict(q=torch.empty((N, n), dtype=dt, device=dev), qu=torch.empty((N, units), dtype=dt, device=dev), count=cert_count,
                              nbr=torch.empty((N, n, 6 if cfg.icp_type == "pt2pl" else 3), dtype=dt, device=dev), gdirty=torch.empty((N, units), dtype=torch.int32, device=dev),
-                             cm=torch.empty((N, n), dtype=torch.int32, device=dev), glist=torch.empty((8, N * units), dtype=torch.int32, device=dev), gcount=cert_gcount,
+                             cm=torch.empty((N, n), dtype=torch.int32, device=dev), glist=torch.empty((8, max(N, 2) * units), dtype=torch.int32, device=dev), gcount=cert_gcount,
                              slist=torch.empty((N, n), dtype=torch.int32, device=dev) if cfg.cert_sets else None, scount=cert_scount if cfg.cert_sets else None,
                              pend=cert_pend, of=torch.empty((Kmax + 1, N, units), dtype=torch.int32, device=dev) if need_grad else None,
                              set=torch.empty((N * n * (es + 16),), dtype=torch.uint8, device=dev) if cfg.cert_sets else None,     # candidate sets: (N,n) budgets + (N,n,4) rows
@@ -1083,7 +1109,8 @@ class ICPLoop(torch.autograd.Function):
                     idx=(_p(idx_slabs[0]) if need_grad else _p(idx_once)) if keep_idx else None,
                     partials=_p(partials), counters=_p(counters), events=events, frame=_p(center), poses_search=_p(poses_c),
                     src_rows=_p(cfg.src_rows), tgt_rows=_p(cfg.tgt_rows), first_search_done=int(first_spos is not None), tgt_f16=_p(img16),
-                    spos_of=_p(certs["of"]) if certs else None, sweep_form=_p(sweep_form) if adaptive else None, sweep_form_default=sweep.form_default)
+                    spos_of=_p(certs["of"]) if certs else None, sweep_form=_p(sweep_form) if adaptive else None, sweep_form_default=sweep.form_default,
+                    sweep_form_plan=ctypes.cast(form_plan, ctypes.c_void_p) if form_plan is not None else None)
                 _lib.check(lib.dicp_icp_forward_plan(code, Pref, ctypes.byref(LB), ctypes.byref(SP), N, n, m, int(cfg.dim), 1, float(cfg.tolerance), st),
                            "dicp_icp_forward_plan")
                 segs = []
@@ -1125,7 +1152,8 @@ class ICPLoop(torch.autograd.Function):
                         w_iter=n, w_stride=kc * n,
                         partials=_p(partials), counters=_p(counters), events=events, frame=_p(center), poses_search=_p(poses_c),
                         src_rows=_p(cfg.src_rows), tgt_rows=_p(cfg.tgt_rows), tgt_f16=_p(img16),
-                        sweep_form=_p(sweep_form) if adaptive else None, sweep_form_default=sweep.form_default if sweep is not None else 0)
+                        sweep_form=_p(sweep_form) if adaptive else None, sweep_form_default=sweep.form_default if sweep is not None else 0,
+                        sweep_form_plan=ctypes.cast(form_plan, ctypes.c_void_p) if form_plan is not None else None)
                     if gum is not None:
                         LB.gumbel = ctypes.cast(ctypes.pointer(gum), ctypes.c_void_p)
                     LBref = ctypes.byref(LB)
@@ -1187,9 +1215,17 @@ class ICPLoop(torch.autograd.Function):
             if adaptive and form_hint is not None and form_hint["event"] is None and (form_hint["calls"] < 2 or form_hint["calls"] % 16 == 0):
                 # (the first two calls of a shape and every sixteenth after: it is host time) clouds with long slabs in any plain search of this call
                 if form_hint["host"] is None:
-                    form_hint["host"] = torch.empty((1,), dtype=torch.int32).pin_memory()
+                    form_hint["host"] = torch.empty((2 + FORM_PLAN_ITERS,), dtype=torch.int32).pin_memory()
                 units128 = ((cfg.src_rows if cfg.src_rows is not None else n) + 127) // 128
-                form_hint["host"].copy_(((sweep_form > FORM_TILES * units128).any(dim=0)).sum(dtype=torch.int32).reshape(1), non_blocking=True)
+                tallied = sweep_form[:K]
+                searched = (tallied > 0).any(dim=1)                                    # iterations with a plain search
+                last = torch.where(searched, torch.arange(1, tallied.shape[0] + 1, device=dev), 0).argmax()     # the last of them
+                long_k = (tallied > FORM_TILES * units128).sum(dim=1, dtype=torch.int32)                        # clouds with long slabs, per iteration
+                per_k = torch.full((FORM_PLAN_ITERS,), -1, dtype=torch.int32, device=dev)
+                kk = min(K, FORM_PLAN_ITERS)
+                per_k[:kk] = torch.where(searched[:kk], long_k[:kk], torch.full_like(long_k[:kk], -1))
+                form_hint["host"].copy_(torch.cat((torch.stack(((tallied > FORM_TILES * units128).any(dim=0).sum(dtype=torch.int32),
+                                                                (tallied[last] > FORM_TILES_MOVING * units128).sum(dtype=torch.int32))), per_k)), non_blocking=True)
                 form_hint["event"] = torch.cuda.Event()
                 form_hint["event"].record()
             if form_hint is not None:

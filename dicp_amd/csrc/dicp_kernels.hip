@@ -51,13 +51,15 @@ extern "C" {
 int dicp_abi_version(void) { return DICP_ABI_VERSION; }
 int dicp_padded_targets(int m) { return m <= 0 ? 0 : ((m + KNN_PAD - 1) / KNN_PAD) * KNN_PAD; }
 int dicp_accumulate_blocks(int n) { return n <= 0 ? 0 : (n + ACC_PTS - 1) / ACC_PTS; }
-int dicp_search_frame(int dtype, const void* tgt, int c, const int32_t* tgt_rows, int N, int m, double quantum, int directions, void* frame, void* stream) {
+int dicp_search_frame(int dtype, const void* tgt, int c, const int32_t* tgt_rows, int N, int m, double quantum, int directions,
+                      const void* src, const int32_t* src_rows, int n, const void* T_init, void* frame, void* stream) {
     if (!tgt || !frame) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
-    if (N <= 0 || m <= 0 || c < 3 || !(quantum >= 0.0)) return DICP_ERR_SHAPE;
+    if (N <= 0 || m <= 0 || c < 3 || !(quantum >= 0.0) || (src && T_init && n <= 0)) return DICP_ERR_SHAPE;
+    if (!src || !T_init) { src = nullptr; T_init = nullptr; }          // (the queries count only with their pose)
     begin_launch();
-    if (dtype == DICP_F32) search_frame_kernel<float><<<N, CC_THREADS, 0, (hipStream_t)stream>>>((const float*)tgt, c, m, tgt_rows, quantum, directions, (float*)frame);
-    else                   search_frame_kernel<double><<<N, CC_THREADS, 0, (hipStream_t)stream>>>((const double*)tgt, c, m, tgt_rows, quantum, directions, (double*)frame);
+    if (dtype == DICP_F32) search_frame_kernel<float><<<N, CC_THREADS, 0, (hipStream_t)stream>>>((const float*)tgt, c, m, tgt_rows, quantum, directions, (float*)frame, (const float*)src, n, src_rows, (const float*)T_init);
+    else                   search_frame_kernel<double><<<N, CC_THREADS, 0, (hipStream_t)stream>>>((const double*)tgt, c, m, tgt_rows, quantum, directions, (double*)frame, (const double*)src, n, src_rows, (const double*)T_init);
     return launch_status();
 }
 
@@ -137,7 +139,7 @@ int dicp_sweep_setup(int dtype, const void* tgt, int c, const int32_t* tgt_rows,
                      void* tgs4, void* tgt_s, int tgt_s_stride,
                      const void* src, const int32_t* src_rows, int n, const void* T_init, void* pose_search0, int32_t* qorder0, void* stream) {
     if (!frame) return DICP_ERR_NULL;
-    int rc = dicp_search_frame(dtype, tgt, c, tgt_rows, N, m, quantum, directions, frame, stream);
+    int rc = dicp_search_frame(dtype, tgt, c, tgt_rows, N, m, quantum, directions, src, src_rows, n, T_init, frame, stream);
     if (!rc) rc = dicp_sweep_sort(dtype, tgt, c, frame, tgt_rows, N, m, m_pad, keys_sorted, tperm, nbkt, bucket, brange, scratch, scratch_bytes, stream);
     if (!rc) rc = dicp_sweep_build(dtype, tgt, c, frame, tgt_rows, tperm, N, m, m_pad, tgs4, tgt_s, tgt_s_stride, stream);
     if (!rc && T_init && pose_search0 && qorder0) {
@@ -272,6 +274,11 @@ int dicp_knn(int dtype, const void* src, const void* pose, const void* tgt4, con
 // 1 = (1, 8), 2 = (2, 8) [the big-problem default], 4 = (1, 16) [float32: the small-problem default; float64: (1, 8)]
 static int sweep_queries_per_lane(int cfg) { return cfg == 2 ? 2 : ((cfg == 1 || cfg == 4) ? 1 : 0); }
 static int sweep_auto_cfg(int N, int n) { return ((long)N * n >= 2L * BLOCK * 1024) ? SWEEP_CFG_BIG : 4; }
+
+// entries per guard work list (one list per XCD, clouds dealt by cloud & 7): a cloud appends at most one entry per unit of the sweep and one per 64 of its
+// candidate sets, 2 ceil(n/64) in all; N ceil(n/64) holds that for every N >= 2, a single cloud needs twice its own (round 5's advice: entries past the
+// capacity were dropped silently, and with them those sets' re-scoring)
+static int guard_list_cap(int N, int n) { return (N > 2 ? N : 2) * ((n + WAVE - 1) / WAVE); }
 
 struct CertArgs {             // certifying search: budgets (NULL q: plain search), motion bounds; guard: the launch of a certified iteration
     void* q; void* qu; const void* dcum; int dstride; int k; int32_t* count; bool guard; int32_t* cloud; void* set;
@@ -852,7 +859,7 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
             // (the certified iterations keep a row cache and their match history by reference: accumulate_kernel)
             if (cert && (!B->cert_nbr || !B->cert_gdirty || !B->cert_pend || !B->cert_cm || !B->cert_glist || !B->cert_gcount || (B->cert_set && (!B->cert_slist || !B->cert_scount)) || (B->idx_per_iter && !B->spos_of))) { set_launch_events(nullptr, nullptr); return DICP_ERR_NULL; }
             const int cert_units = cert ? (n + WAVE * sweep_queries_per_lane(cfg_plain) - 1) / (WAVE * sweep_queries_per_lane(cfg_plain)) : 0;
-            const int glist_cap = N * ((n + WAVE - 1) / WAVE);
+            const int glist_cap = guard_list_cap(N, n);
             const bool fresh = k == 0 || (k == k0 && B->cert_reset);           // a new query order: every query is searched, every budget written
             int32_t* count_k = B->cert_count ? B->cert_count + (size_t)k * 2 * CERT_SHARDS : nullptr;
             const bool searched = B->first_search_done && k == 0 && !cert && spos_k && !B->idx;    // the caller ran iteration 0's search itself, ahead of this call
@@ -866,12 +873,16 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
                                                                                               B->cert_glist, B->cert_gcount ? B->cert_gcount + (size_t)k * 8 : nullptr, glist_cap});
             } else
             {
-                // plain search.  Scoring form per cloud (sweep_form): the matrix-core form pays where a wave's slab is long -- big clouds, and clouds of any size
-                // whose queries are far from their matches (start poses a metre off; parts of the source without counterpart in the target) -- and loses where
-                // it is a few tiles.  Each plain search tallies its slabs' tiles per cloud; the next one launches both forms, each taking its clouds.
-                const int32_t* form_in = (B->sweep_form && B->tgt_f16 && k > 0) ? B->sweep_form + (size_t)(k - 1) * N : nullptr;     // (all zeros behind a certified iteration: no tally)
+                // plain search.  The matrix-core form pays where a wave's slab is long -- big clouds, and clouds of any size whose queries are far from their
+                // matches (the first iterations; start poses a metre off; parts of the source without counterpart in the target) -- and loses where it is a few
+                // tiles.  Which form iteration k takes: the caller's plan (sweep_form_plan[k]: 1 vector, 2 matrix cores -- what the tallies of an EARLIER call
+                // of the shape said about this iteration: one launch), else per cloud from the previous plain search's tally (both forms are launched, each takes
+                // its clouds: 0.02-0.03 ms per search at 256 x 16384 for the launch that finds nothing to do), else the default.  Every plain search tallies its
+                // slabs' tiles per cloud when given sweep_form.
+                const int planned = (B->sweep_form_plan && B->tgt_f16) ? B->sweep_form_plan[k] : 0;
+                const int32_t* form_in = (!planned && B->sweep_form && B->tgt_f16 && k > 0) ? B->sweep_form + (size_t)(k - 1) * N : nullptr;     // (all zeros behind a certified iteration: no tally)
                 int32_t* form_out = B->sweep_form ? B->sweep_form + (size_t)k * N : nullptr;
-                const void* img = (form_in || B->sweep_form_default || !B->sweep_form) ? B->tgt_f16 : nullptr;
+                const void* img = planned ? (planned == 2 ? B->tgt_f16 : nullptr) : ((form_in || B->sweep_form_default || !B->sweep_form) ? B->tgt_f16 : nullptr);
                 begin_launch();
                 rc = sweep_launch(dtype, B->src, pose_s, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, N, n, m, B->m_pad, B->idx ? idx_k : nullptr, spos_k, B->pairs, cfg,
                                   Rows{B->src_rows, B->tgt_rows}, st, CertArgs{}, img, FormArgs{form_in, form_out, B->sweep_form_default});
@@ -926,7 +937,7 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
             const int cfgp = ((B->knn_variant >> 8) & 0xff) ? ((B->knn_variant >> 8) & 0xff) : sweep_auto_cfg(N, n);
             const int Qp = sweep_queries_per_lane(cfgp);
             if (Qp > 0) {
-                io.cert_qu = B->cert_qu; io.cert_units = (n + WAVE * Qp - 1) / (WAVE * Qp); io.glist_cap = N * ((n + WAVE - 1) / WAVE);
+                io.cert_qu = B->cert_qu; io.cert_units = (n + WAVE * Qp - 1) / (WAVE * Qp); io.glist_cap = guard_list_cap(N, n);
                 io.glist = B->cert_glist; io.gcount = B->cert_gcount + (size_t)(k + 1) * 8;
                 io.cert_scount = B->cert_set ? B->cert_scount : nullptr;
             }

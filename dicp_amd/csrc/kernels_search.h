@@ -144,9 +144,10 @@ template <typename T> struct SweepCert {
     // form_in (the previous plain search's tally) leaves a cloud alone unless its slabs were long (form_mine = 1: the matrix-core form) / short (0: this one)
     const int32_t* form_in; int32_t* form_out; int form_mine, form_default;     // (form_default: the form of a cloud without a tally -- 0 in form_in: no plain search before)
 };
-constexpr int FORM_TILES = 32;      // tiles per unit from which on a cloud's plain searches score on the matrix cores: a wave's fixed cost there (prologue, margins, the exact
-                                    // refine of the winners' rows) is ~16 tiles' worth of VALU scoring (profiles/r04_knn_f16_sweep.txt: 0.92x at 16 tiles, 1.27x at 32;
-                                    // at 20 the benchmark's own first search -- 15-25 tiles per unit -- sent a few clouds there for nothing)
+constexpr int FORM_TILES = 12;      // tiles per unit (in the PREVIOUS plain search) from which on a cloud's plain searches score on the matrix cores: a wave's fixed cost there
+                                    // (prologue, margins, the exact refine of the winners' rows) is ~6 tiles' worth of VALU scoring (profiles/r06_f16_sweep_crossover.txt: 1.23x at
+                                    // 10 tiles, level at 5.5, 0.85x at 4), and slabs halve from one early iteration to the next; round 4's form lost up to 16 tiles and the
+                                    // threshold stood at 32 until round 6
 __device__ __forceinline__ bool form_is_mine(const int32_t* __restrict__ form_in, int form_mine, int form_default, int cloud, int queries) {
     if (!form_in) return true;
     const int units = (queries + 2 * WAVE - 1) / (2 * WAVE), tally = form_in[cloud];     // (units of 128 queries: the matrix-core form's)

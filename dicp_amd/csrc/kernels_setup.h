@@ -67,9 +67,17 @@ __device__ __forceinline__ unsigned sortable_bits(float x);
 // 2 step, ...; a ragged batch hands over the cloud's own length, so pad rows are not in it), found by a radix select (most
 // significant byte first, the three axes side by side) over the order-preserving bit pattern of the float values (float is
 // plenty: the centre is rounded to `quantum` anyway).
+// Round 6: given the QUERIES too (src under T_init: dicp_sweep_setup has them) the cost of a direction is what it stands for, the rows a slab
+// search scores: for a sample of the queries, the sample targets whose key lies within the query's own reach of its key -- the reach being
+// the distance to its nearest SAMPLE target (an upper bound of its nearest target's).  The target-only cost above is the special case "every
+// query sits on a target": scan pairs that overlap only partly are not that case -- the queries outside the target's footprint reach metres
+// far, and along a direction oblique to the footprint's edge their slabs hold a third of the cloud (profiles/r06_search_direction.txt: a
+// corridor scanned from two places 6 m apart, 33 % of all pairs scored per search with the target-only choice, 9 % along the corridor).
+constexpr int SF_QUERIES = CC_THREADS / 4;     // sample queries per cloud: four threads each share the scan of the sample targets
 template <typename T>
 __global__ __launch_bounds__(CC_THREADS) void search_frame_kernel(const T* __restrict__ tgt, int c, int m, const int32_t* __restrict__ tgt_rows,
-                                                                  double quantum, int directions, T* __restrict__ frame) {
+                                                                  double quantum, int directions, T* __restrict__ frame,
+                                                                  const T* __restrict__ src, int n, const int32_t* __restrict__ src_rows, const T* __restrict__ T_init) {
     // rotations with det +1; row 0 = the sort direction.  0: identity, 1 / 2: y / z first (cyclic permutations), 3..5: oblique
     const double QS[SF_DIRS][9] = {
         {1, 0, 0, 0, 1, 0, 0, 0, 1}, {0, 1, 0, 0, 0, 1, 1, 0, 0}, {0, 0, 1, 1, 0, 0, 0, 1, 0},
@@ -80,8 +88,10 @@ __global__ __launch_bounds__(CC_THREADS) void search_frame_kernel(const T* __res
     __shared__ unsigned sel_prefix[3];
     __shared__ int sel_want[3];
     __shared__ int dhist[SF_DIRS][256];
-    __shared__ float s_ctr[3], s_ext[CC_THREADS / WAVE];
+    __shared__ float s_ctr[3], s_ext[CC_THREADS / WAVE], s_cnt[CC_THREADS / WAVE];
     __shared__ int s_cost[SF_DIRS];
+    __shared__ float s_t[3][CC_SAMPLE];          // the sample targets, centred (query-aware cost)
+    __shared__ int s_cum[SF_DIRS][256 + 1];      // exclusive prefix sums of dhist
     const int cloud = blockIdx.x, tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
     const T* __restrict__ rows = tgt + (size_t)cloud * m * c;
     const int mc = max(rows_of(tgt_rows, cloud, m), 1);
@@ -136,7 +146,20 @@ __global__ __launch_bounds__(CC_THREADS) void search_frame_kernel(const T* __res
     // ---- the sort direction: histograms of the sample's keys along every candidate, one bin width for all of them
     const float dx = pt[0] - s_ctr[0], dy = pt[1] - s_ctr[1], dz = pt[2] - s_ctr[2];
     const bool fin = on && fabsf(dx) < 1e30f && fabsf(dy) < 1e30f && fabsf(dz) < 1e30f;
-    float ext = fin ? fmaxf(fabsf(dx), fmaxf(fabsf(dy), fabsf(dz))) : 0.f;
+    // the histograms' span: the sample's extent about the centre -- of the points within 32x the MEAN deviation (round 6: one stray return, or
+    // the far pad row a ragged batch's cloud carries (max(source) * 1000: a thousand times the cloud), stretched the span until every real
+    // point shared a bin or two and all directions cost the same; such points now land in the edge bins)
+    const float dev = fin ? fmaxf(fabsf(dx), fmaxf(fabsf(dy), fabsf(dz))) : 0.f;
+    float dsum = dev, dcnt = fin ? 1.f : 0.f;
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) { dsum += __shfl_xor(dsum, off); dcnt += __shfl_xor(dcnt, off); }
+    if (lane == 0) { s_ext[wave] = dsum; s_cnt[wave] = dcnt; }
+    __syncthreads();
+    float mean_dev = 0.f, cnt_all = 0.f;
+    for (int w = 0; w < CC_THREADS / WAVE; ++w) { mean_dev += s_ext[w]; cnt_all += s_cnt[w]; }
+    mean_dev = cnt_all > 0.f ? mean_dev / cnt_all : 0.f;
+    __syncthreads();
+    float ext = (fin && dev <= 32.f * mean_dev) ? dev : 0.f;
 #pragma unroll
     for (int off = WAVE / 2; off > 0; off >>= 1) ext = fmaxf(ext, __shfl_xor(ext, off));
     if (lane == 0) s_ext[wave] = ext;
@@ -155,16 +178,60 @@ __global__ __launch_bounds__(CC_THREADS) void search_frame_kernel(const T* __res
                 atomicAdd(&dhist[j][bin], 1);
             }
         }
+        const bool with_queries = src != nullptr && T_init != nullptr && n > 0;
+        if (with_queries) { s_t[0][tid] = fin ? dx : 1e18f; s_t[1][tid] = fin ? dy : 1e18f; s_t[2][tid] = fin ? dz : 1e18f; }
         __syncthreads();
         if (wave < SF_DIRS) {
-            int cst = 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { const int h = dhist[wave][4 * lane + q]; cst += h * h; }
+            const int h0 = dhist[wave][4 * lane], h1 = dhist[wave][4 * lane + 1], h2 = dhist[wave][4 * lane + 2], h3 = dhist[wave][4 * lane + 3];
+            int cst = h0 * h0 + h1 * h1 + h2 * h2 + h3 * h3;
 #pragma unroll
             for (int off = WAVE / 2; off > 0; off >>= 1) cst += __shfl_xor(cst, off);
-            if (lane == 0) s_cost[wave] = cst;
+            if (lane == 0) s_cost[wave] = with_queries ? 0 : cst;
+            if (with_queries) {
+                int incl = h0 + h1 + h2 + h3;
+                const int own = incl;
+#pragma unroll
+                for (int off = 1; off < WAVE; off <<= 1) { const int o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+                const int ex = incl - own;
+                s_cum[wave][4 * lane] = ex; s_cum[wave][4 * lane + 1] = ex + h0; s_cum[wave][4 * lane + 2] = ex + h0 + h1; s_cum[wave][4 * lane + 3] = ex + h0 + h1 + h2;
+                if (lane == WAVE - 1) s_cum[wave][256] = incl;
+            }
         }
         __syncthreads();
+        if (with_queries) {
+            // sample query tid / 4 under T_init, centred like the targets; its four threads share the sample targets
+            const int nc = rows_of(src_rows, cloud, n);
+            const int qstep = max((nc + SF_QUERIES - 1) / SF_QUERIES, 1), nq = (nc + qstep - 1) / qstep;
+            const int qid = tid >> 2, part = tid & 3;
+            bool qon = qid < nq;
+            float qx = 0.f, qy = 0.f, qz = 0.f;
+            if (qon) {
+                const T* p = src + ((size_t)cloud * n + (size_t)qid * qstep) * 3;
+                const T* M = T_init + (size_t)cloud * 16;
+                const float p0 = (float)p[0], p1 = (float)p[1], p2 = (float)p[2];
+                qx = (float)M[0] * p0 + (float)M[1] * p1 + (float)M[2] * p2 + (float)M[3] - s_ctr[0];
+                qy = (float)M[4] * p0 + (float)M[5] * p1 + (float)M[6] * p2 + (float)M[7] - s_ctr[1];
+                qz = (float)M[8] * p0 + (float)M[9] * p1 + (float)M[10] * p2 + (float)M[11] - s_ctr[2];
+                qon = fabsf(qx) < 1e18f && fabsf(qy) < 1e18f && fabsf(qz) < 1e18f;
+            }
+            float d2 = 3e38f;
+            if (qon)
+                for (int t = part; t < ms; t += 4) {
+                    const float ex = s_t[0][t] - qx, ey = s_t[1][t] - qy, ez = s_t[2][t] - qz;
+                    d2 = fminf(d2, ex * ex + ey * ey + ez * ez);
+                }
+            d2 = fminf(d2, __shfl_xor(d2, 1));
+            d2 = fminf(d2, __shfl_xor(d2, 2));
+            if (qon && d2 < 1e30f) {
+                const float d = sqrtf(d2), scale = 128.f / R2;
+                for (int j = part; j < SF_DIRS; j += 4) {
+                    const float k = (float)QS[j][0] * qx + (float)QS[j][1] * qy + (float)QS[j][2] * qz;
+                    const int lo = min(max((int)((k - d + R2) * scale), 0), 255), hi = min(max((int)((k + d + R2) * scale), 0), 255);
+                    atomicAdd(&s_cost[j], s_cum[j][hi + 1] - s_cum[j][lo]);
+                }
+            }
+            __syncthreads();
+        }
         for (int j = 1; j < SF_DIRS; ++j) if (s_cost[j] < s_cost[best]) best = j;
         if (!(5 * (long long)s_cost[best] < 4 * (long long)s_cost[0])) best = 0;    // the identity keeps the job unless another is 20 % better
     }
@@ -408,6 +475,13 @@ constexpr int QO_THREADS = 1024;
 constexpr int QO_BUCKETS = 2048;
 constexpr int QO_KEYS = 16384;      // sorted target keys kept in LDS for the rank search (64 KiB)
 constexpr int QO_TABLE = 1024;      // ... and the coarse lower-bound table that brackets it
+// Queries OUTSIDE the targets' x range (round 6).  Scan pairs that overlap only partly put a third of the source there; ordered by rank (or by buckets
+// over the targets' range) they all shared the end bucket, in arrival order -- units of the sweep whose queries lay metres apart in x, each dragging the
+// slab of the farthest (the matrix-core sweep, whose slab test is per lane, scored twice the pairs of the per-query test: profiles/r06_search_direction.txt).
+// QO_SIDE ordering buckets on either side now hold them by x, one bucket per 1/QO_SIDE of the targets' span (clamped at one span away).
+constexpr int QO_SIDE = 256;
+constexpr int QO_MID = QO_BUCKETS - 2 * QO_SIDE;
+__device__ __forceinline__ int qo_side_bucket(float dist_scaled) { return (int)fminf(fmaxf(dist_scaled, 0.f), (float)(QO_SIDE - 1)); }
 // QO_STAGE: queries per cloud whose permutation is assembled in LDS (16384 -> 32 KiB, several clouds per CU; 65536 -> 128 KiB)
 template <typename T, int QO_STAGE>
 __global__ __launch_bounds__(QO_THREADS) void query_order_kernel(const T* __restrict__ src, const T* __restrict__ pose,
@@ -443,7 +517,7 @@ __global__ __launch_bounds__(QO_THREADS) void query_order_kernel(const T* __rest
     if (pose) { const T* pp = pose + (size_t)cloud * 12; q[0] = pp[0]; q[1] = pp[1]; q[2] = pp[2]; q[3] = pp[9]; }
     const T xlo = brange[(size_t)cloud * 2];
     const T tscale = brange[(size_t)cloud * 2 + 1];                                       // table buckets per unit x
-    const T scale = tscale * (T(QO_BUCKETS) / T(nbkt_range));                             // ordering buckets per unit x
+    const T scale = tscale * (T(QO_MID) / T(nbkt_range));                                 // ordering buckets per unit x (the middle ones: inside the targets' range)
     // rank ordering: the cloud's sorted target x keys, as floats, in LDS (QO_KEYS of them: bigger clouds fall back to x buckets)
     const bool ranked = QO_STAGE <= 16384 && skeys && table && !spos_prev && mt <= QO_KEYS && nbkt_range <= QO_TABLE;
     if (ranked) {
@@ -451,6 +525,8 @@ __global__ __launch_bounds__(QO_THREADS) void query_order_kernel(const T* __rest
         for (int j = tid; j < mt; j += QO_THREADS) lkeys[j] = (float)keys[(size_t)j * kstride];
         for (int j = tid; j <= nbkt_range; j += QO_THREADS) ltab[j] = table[(size_t)cloud * (nbkt_range + 1) + j];
     }
+    const float span_w = tscale > T(0) ? (float)(T(nbkt_range) / tscale) : 0.f;          // the targets' x range as the bucket table has it
+    const float side_w = span_w > 0.f ? (float)QO_SIDE / span_w : 0.f;                    // side buckets per unit x
     auto bucket_of = [&](int i) {
         if (spos_prev) {        // bucket = rank of the query's previous match among the sorted targets: equal-POPULATION buckets,
                                 // whatever the density of the cloud along x (an outlier cannot coarsen them)
@@ -459,11 +535,23 @@ __global__ __launch_bounds__(QO_THREADS) void query_order_kernel(const T* __rest
         }
         const T* p = src + ((size_t)cloud * n + i) * 3;
         const T x = fma_t(q[0], p[0], fma_t(q[1], p[1], fma_t(q[2], p[2], q[3])));
-        T f = (x - xlo) * scale;
-        f = f > T(0) ? (f < T(QO_BUCKETS - 1) ? f : T(QO_BUCKETS - 1)) : T(0);             // NaN and out-of-range -> end buckets
-        return (int)f;
+        const float d = (float)(x - xlo);
+        if (d < 0.f) return QO_SIDE - 1 - qo_side_bucket(-d * side_w);                    // left of every target, by x
+        if (d > span_w) return QO_SIDE + QO_MID + qo_side_bucket((d - span_w) * side_w);  // right of every target
+        const float f = d * (float)scale;
+        return QO_SIDE + (f > 0.f ? (f < (float)(QO_MID - 1) ? (int)f : QO_MID - 1) : 0); // (NaN -> the first middle bucket)
     };
     __syncthreads();
+    // ranked: the ends of the targets' x range, leaving out ONE key per end that lies further from the rest than the rest is wide (a ragged batch's far
+    // pad row: it would make "inside the range" of everything to its left)
+    float rk_lo = 0.f, rk_hi = 0.f, rk_side = 0.f;
+    if (ranked) {
+        int jl = 0, jh = mt - 1;
+        if (mt >= 3 && lkeys[mt - 1] - lkeys[mt - 2] > lkeys[mt - 2] - lkeys[0]) jh = mt - 2;
+        if (mt >= 3 && lkeys[1] - lkeys[0] > lkeys[jh] - lkeys[1]) jl = 1;
+        rk_lo = lkeys[jl]; rk_hi = lkeys[jh];
+        rk_side = rk_hi > rk_lo ? (float)QO_SIDE / (rk_hi - rk_lo) : 0.f;
+    }
     // one returning LDS add per query gives its bucket AND its rank inside the bucket; both stay in registers while
     // the counters are turned into offsets (LDS atomics are the cost of this kernel: ~137 cycles per wave-instruction)
     constexpr int PER = 16;                                 // register-resident up to PER * QO_THREADS queries per cloud
@@ -486,7 +574,9 @@ __global__ __launch_bounds__(QO_THREADS) void query_order_kernel(const T* __rest
                 int lo = ltab[tb], hi = ltab[min(tb + 1, nbkt_range)];
                 if (!(lo <= hi) || (lo > 0 && !(lkeys[lo - 1] < x)) || (hi < mt && lkeys[hi] < x)) { lo = 0; hi = mt; }  // rounding at an edge
                 while (lo < hi) { const int mid = (lo + hi) >> 1; if (lkeys[mid] < x) lo = mid + 1; else hi = mid; }
-                bb = (int)(((long)lo * (QO_BUCKETS - 1)) / max(mt, 1));
+                if (x < rk_lo) bb = QO_SIDE - 1 - qo_side_bucket((rk_lo - x) * rk_side);
+                else if (x > rk_hi) bb = QO_SIDE + QO_MID + qo_side_bucket((x - rk_hi) * rk_side);
+                else bb = QO_SIDE + (int)(((long)lo * (QO_MID - 1)) / max(mt, 1));
                 rr = atomicAdd(&cnt[bb], 1);
             }
 #pragma unroll

@@ -47,6 +47,7 @@ constexpr int F16_G = 4;                // B tiles (32 queries each) per wave: 1
 constexpr int F16_CHT = 4;              // A tiles per chunk of the lane-local bookkeeping
 constexpr int F16_FAR_MAX = 64;
 constexpr int F16_NTC = 8;              // sweep form: 64-row tiles whose float32 rows a wave keeps in LDS for its refine
+constexpr int F16_SCAN_MAX = 6;         // sweep form: up to this many queries of a wave with three or more candidate pieces are scanned exactly instead of filtered again
 enum { FM_S = 0, FM_INV_S2 = 1, FM_PHI = 2, FM_NFAR = 3, FM_HPHI = 4, FM_FAR_ABOVE = 5, FM_AGAIN = 6 /* queries sent through pass 2, added up */,
        FM_SCAN = 7 /* queries scored against every row */, FM_FAR0 = 8 };
 constexpr float F16_P = 8192.f;
@@ -727,6 +728,16 @@ __device__ __forceinline__ void f16_sweep_unit(const float* __restrict__ src, co
         if (ncand == 3 && qi[g] >= 0) my_unsure |= 1 << g;
         if (ncand == 0 && qi[g] >= 0 && kh == 0) my_scan |= 1 << g;
     }
+    // A few queries of the wave with three or more candidate pieces (dense surfaces: a runner-up chunk within the filter's resolution): their visited rows are
+    // scored exactly, 64 at a time, by the whole wave -- the second filter pass below walks the visited tiles one dependent load at a time for up to 32 such
+    // queries at once, ~40 us of a wave's time even for ONE (round 6, planar scenes: 0.3 % of the queries took it and the launch was 0.17 ms longer for them:
+    // profiles/r06_f16_sweep_crossover.txt); it is kept for waves with many.
+    {
+        int tot = 0;
+#pragma unroll
+        for (int g = 0; g < F16_G; ++g) tot += __popcll(__ballot(((my_unsure >> g) & 1) && kh == 0));
+        if (tot <= F16_SCAN_MAX) { if (kh == 0) my_scan |= my_unsure; my_unsure = 0; }
+    }
     // the rows, out of the wave's LDS cache (a run outside it is flagged for the careful loop).  Per run of 16 rows: the scores (independent), their
     // minimum as a tree, the first and the last row that has it -- a serial compare-and-select chain over the rows was three times the instructions,
     // and a wave's instruction count is what this part of the kernel costs.  Rows past the cloud's own are pad rows (score +inf) by construction.
@@ -832,8 +843,18 @@ __device__ __forceinline__ void f16_sweep_unit(const float* __restrict__ src, co
                 const float q[3] = {__shfl(qq[0], L), __shfl(qq[1], L), __shfl(qq[2], L)};
                 SweepBest w;
                 w.v = __builtin_huge_valf(); w.s = 0; w.o = 0x7fffffff;
+                {   // (four rows in flight per lane: one row per round trip made this a chain of dependent loads)
+                    const int r_end = min(visR * WAVE, m);
+                    int rr = visL * WAVE + lane;
 #pragma unroll 1
-                for (int rr = visL * WAVE + lane; rr < min(visR * WAVE, m); rr += WAVE) sweep_consider(w, q, tg[rr], rr, pm);
+                    for (; rr + 3 * WAVE < r_end; rr += 4 * WAVE) {
+                        const float4 y0 = tg[rr], y1 = tg[rr + WAVE], y2 = tg[rr + 2 * WAVE], y3 = tg[rr + 3 * WAVE];
+                        sweep_consider(w, q, y0, rr, pm); sweep_consider(w, q, y1, rr + WAVE, pm);
+                        sweep_consider(w, q, y2, rr + 2 * WAVE, pm); sweep_consider(w, q, y3, rr + 3 * WAVE, pm);
+                    }
+#pragma unroll 1
+                    for (; rr < r_end; rr += WAVE) sweep_consider(w, q, tg[rr], rr, pm);
+                }
 #pragma unroll 1
                 for (int o = WAVE / 2; o > 0; o >>= 1) sweep_merge(w, __shfl_xor(w.v, o), __shfl_xor(w.s, o), __shfl_xor(w.o, o), pm);
                 put_best(g, col == (L & 31), w);

@@ -82,11 +82,17 @@ int dicp_accumulate_blocks(int n);
  * multiple of `quantum` (0: not rounded; float precision); Q = (directions != 0) the candidate -- identity, the two other axis orders, three
  * oblique directions -- whose projected keys spread the sample best (smallest sum of squared counts of a 256-bin histogram: proportional to
  * the pairs a slab search scores), the identity unless another candidate is 20 % better; directions == 0: Q = I.
+ * Given the queries as well (src (N,n,3) with T_init (N,4,4) row-major, optional src_rows; both NULL: the target-only choice) the cost of a
+ * candidate is the rows the slabs of a sample of 256 queries hold along it, a query's reach being the distance to its nearest sample target:
+ * scan pairs that overlap only partly reach metres far outside the common footprint, and a direction oblique to its edge then puts a third of
+ * the target into those slabs.  Points beyond 32x the sample's mean deviation from the centre (a ragged cloud's far pad row) do not stretch
+ * the histograms' span.
  * Entry points given `frame` pack rows as Q y + t, and the caller hands the searches the pose [Q C | Q r + t] (dicp_loop_buffers.poses_search;
  * dicp_loop_init / the step kernels write it).  Every search form reads only (pose, packed rows): with the same frame they return the same
  * indices as each other; Q = I is applied as the plain subtraction it is, and with t == 0 too (clouds near the origin, given a quantum) the
  * results are exactly those of frame == NULL. */
-int dicp_search_frame(int dtype, const void* tgt, int c, const int32_t* tgt_rows, int N, int m, double quantum, int directions, void* frame, void* stream);
+int dicp_search_frame(int dtype, const void* tgt, int c, const int32_t* tgt_rows, int N, int m, double quantum, int directions,
+                      const void* src, const int32_t* src_rows, int n, const void* T_init, void* frame, void* stream);
 
 /* Once per ICP call: tgt (N,m,c) -> tgt4 (N,m_pad,4) rows [x,y,z,0.5|y|^2] (of Q y + t when frame != NULL), pad rows
  * [0,0,0,+inf].  The norms are the ||y||^2 column that torch.cdist's matmul path builds
@@ -368,7 +374,7 @@ typedef struct dicp_loop_buffers {
     void* cert_nbr;          /* (N, n, 6 | 3) T scratch (pt2pl | pt2pt): the matched target row of every query, rewritten where a match changes */
     int32_t* cert_gdirty;    /* (N, ceil(n/64)) int32 scratch: 1 = the guard launch of the iteration changed a match among these 64 consecutive queries */
     int32_t* cert_pend;      /* (N, n) int32 ZEROS, by query: a match the guard launch CHANGED, left for the accumulate of the same iteration (match + 2) */
-    int32_t* cert_glist;     /* (8, N * ceil(n/64)) int32 scratch: the guard launches' work lists (dicp_step_io.glist), rewritten by every step */
+    int32_t* cert_glist;     /* (8, max(N, 2) * ceil(n/64)) int32 scratch: the guard launches' work lists (dicp_step_io.glist), rewritten by every step */
     int32_t* cert_gcount;    /* (K + 1, 8) int32 ZEROS: their lengths, per iteration */
     int32_t* cert_slist;     /* with cert_set, (N, n) int32 scratch: per cloud, the slots that were given a candidate set -- the guard launch re-scores the standing
                                 ones 64 to a wave from it */
@@ -422,6 +428,9 @@ typedef struct dicp_loop_buffers {
                                 takes the scoring form of every cloud from row k-1 (dicp_knn_sweep's form_in / form_out; a row of zeros: no plain search then).
                                 Without tgt_f16 the tallies are only kept (a caller may decide from them whether the next call of the shape gets the image) */
     int32_t sweep_form_default;  /* the form of a cloud without a tally: 0 vector, 1 matrix cores */
+    const int32_t* sweep_form_plan;  /* optional HOST array (K) int32, read during the call: the form of iteration k's plain search for EVERY cloud -- 1 vector, 2 matrix
+                                cores (needs tgt_f16), 0 as above (by the tallies / the default).  A caller that has seen an earlier call's tallies of the same shape
+                                plans with them: one launch per search instead of the two of the per-cloud choice */
     int32_t* det_far_row;    /* dicp_icp_backward, windowed form, optional (N,n) int32 + det_far_val (N,n,cv): DETERMINISTIC target gradients.  Without them the
                                 contributions to a target row are summed in the order the block's waves happened to reach it, and those whose match lies outside the
                                 block's window are added with float atomics: two runs differ in the last bits.  With them every window row sums its slots in

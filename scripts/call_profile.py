@@ -1,16 +1,16 @@
-"""A few headline-shaped calls (fwd + bwd) for a profiler run.  usage: python3 scripts/call_profile.py [scene|random] [K] [calls] [B]
+"""A few headline-shaped calls (fwd + bwd) for a profiler run.  usage: python3 scripts/call_profile.py [scene|random|indep] [K] [calls] [B]
 e.g.  rocprofv3 --kernel-trace --stats -d /tmp/prof -o s --output-format csv -- python3 scripts/call_profile.py scene 10 4"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dicp_amd.ICP import ICP
-from dicp_amd.synthetic import make_pairs, make_scene_pairs
+from dicp_amd.synthetic import make_pairs, make_scene_pairs, make_independent_pairs
 kind = sys.argv[1] if len(sys.argv) > 1 else "scene"
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 calls = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 B = int(sys.argv[4]) if len(sys.argv) > 4 else 256
 n = 16384
-src, tgt = (make_scene_pairs if kind == "scene" else make_pairs)(B, n, n, seed=3)
+src, tgt = (make_independent_pairs(B, n, n, seed=3, ragged=False) if kind == "indep" else (make_scene_pairs if kind == "scene" else make_pairs)(B, n, n, seed=3))
 src, tgt = src.cuda(), tgt.cuda()
 T0 = torch.eye(4, device="cuda").repeat(B, 1, 1)
 TOL = os.environ.get("DICP_TOL")            # DICP_TOL=1e-4: a tolerance-mode call (up to K iterations, const_iter off)

@@ -99,11 +99,12 @@ def test_new_entry_points_reject_bad_arguments(lib):
     assert lib.dicp_loop_init(0, one, one, 0.01, 1, 1, 1, one, one, one, None, None, None, one, None, 4, None) == 1     # rmax needs the points and dcum
     assert lib.dicp_loop_finish(0, one, one, one, one, 1, 1, None, one, one, None) == 1
     # centred search (center itself is optional everywhere)
-    assert lib.dicp_search_frame(0, None, 3, None, 1, 1, 16.0, 1, one, None) == 1
-    assert lib.dicp_search_frame(0, one, 3, None, 1, 1, 16.0, 1, None, None) == 1
-    assert lib.dicp_search_frame(0, one, 2, None, 1, 1, 16.0, 1, one, None) == 2
-    assert lib.dicp_search_frame(0, one, 3, None, 1, 1, -1.0, 1, one, None) == 2
-    assert lib.dicp_search_frame(5, one, 3, None, 1, 1, 16.0, 1, one, None) == 3
+    assert lib.dicp_search_frame(0, None, 3, None, 1, 1, 16.0, 1, None, None, 0, None, one, None) == 1
+    assert lib.dicp_search_frame(0, one, 3, None, 1, 1, 16.0, 1, None, None, 0, None, None, None) == 1
+    assert lib.dicp_search_frame(0, one, 2, None, 1, 1, 16.0, 1, None, None, 0, None, one, None) == 2
+    assert lib.dicp_search_frame(0, one, 3, None, 1, 1, -1.0, 1, None, None, 0, None, one, None) == 2
+    assert lib.dicp_search_frame(0, one, 3, None, 1, 1, 16.0, 1, one, None, 0, one, one, None) == 2      # queries without their count
+    assert lib.dicp_search_frame(5, one, 3, None, 1, 1, 16.0, 1, None, None, 0, None, one, None) == 3
     assert lib.dicp_search_pose(0, None, None, 1, one, None) == 1 and lib.dicp_search_pose(0, one, None, 0, one, None) == 2
     # dicp_accumulate_bwd_window(dtype, prm, src_s, tgt_s, c, spos, spos_ref, qorder, pose, w_s, alive, gs, gb, src_rows, N, n, m_pad, gsrc_s, slab, far, gw_s, partials, ow, stream)
     assert lib.dicp_accumulate_bwd_window(0, ctypes.byref(P), one, one, 6, None, one, None, one, one, None, one, one, None, 1, 1, 64,

@@ -110,3 +110,29 @@ def test_candidate_sets_on_planar_scenes(seed, N, n, K, icp_type, dtype):
     singles = outs[1][3]["searched_again"][:K, 64:].sum(1).tolist()
     if dtype == torch.float32:
         assert max(singles) > 50 * N and singles[-1] * 10 < max(singles), singles       # made once, then re-scored
+
+
+@pytest.mark.parametrize("n,K", [(65536, 50), (16384, 130)])
+def test_single_cloud_with_duplicated_targets_fills_its_guard_list(n, K):
+    """One cloud (N = 1: the guard launches' work lists are sized per batch, and a single cloud can append an entry per unit of the sweep AND one per 64 of its
+    candidate sets -- round 5's advice: twice the old capacity, the overflow was dropped silently).  Every target twice (each match has an exact runner-up: no
+    certificate, a candidate set) and a planar scene (dense surfaces), a start pose that keeps it moving: the certified loop must still equal searching
+    everything, bit for bit."""
+    from dicp_amd.synthetic import make_scene_pairs
+    src, tgt = make_scene_pairs(1, n, n // 2, seed=21, dtype=torch.float32, max_rot=0.1, max_trans=0.5)
+    tgt = torch.cat((tgt, tgt), dim=1)[:, torch.randperm(n, generator=torch.Generator().manual_seed(3))].contiguous()
+    kw = dict(trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0}, dim=3)
+    outs = []
+    for reuse in (False, True):
+        icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
+        icp.const_iter, icp.reuse_matches, icp.knn_variant = True, reuse, _lib.KNN_SWEEP
+        S, Tg = src.to(DEV).requires_grad_(True), tgt.to(DEV).requires_grad_(True)
+        out = icp.icp(S, Tg, torch.eye(4, device=DEV).repeat(1, 1, 1), **kw)
+        out["T"].sum().backward()
+        outs.append((out, S.grad, Tg.grad, dict(icp.knn_stats)))
+    assert "searched_again" in outs[1][3] and "searched_again" not in outs[0][3]      # (certificates were in use)
+    for key in ("T", "deltas", "weights", "costs", "pc"):
+        assert torch.equal(outs[0][0][key], outs[1][0][key]), key
+    for i in (1, 2):
+        scale = max(1.0, float(outs[0][i].abs().max()))
+        assert float((outs[0][i] - outs[1][i]).abs().max()) <= 2e-5 * scale

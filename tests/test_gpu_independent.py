@@ -94,23 +94,37 @@ def test_against_the_oracle(dtype):
 
 
 def test_later_calls_of_a_moving_shape_take_the_hints_and_give_the_same_gradients():
-    """The first call of a shape tries the match certificates; where most clouds switch them off (they keep moving: this generator) the hint makes the next calls run
-    without them and order the backward's slots by the reference matches (ICPLoop: ctx.bwd_reorder).  Exact searches and the same sums in another order: the same
-    poses bit for bit, the same gradients to rounding."""
-    S, T = make_independent_pairs(64, 8192, 8192, seed=11, dtype=torch.float32, ragged=False)
+    """What the earlier calls of an object tell the later ones (CallHints) decides about time only.  Three objects on the same inputs: a fresh one (no hint:
+    match certificates tried, the forward's own slot order in the backward), the same object three calls later (whatever its hints have become), and one whose
+    hint says "the clouds of this shape keep moving" (no certificates, the backward's slots ordered by the reference matches: ctx.bwd_reorder) -- which policy a
+    shape ends up with depends on the data (round 6: with the sort direction chosen for the queries these clouds keep their certificates), so the third is
+    set by hand.  Exact searches and the same sums in another order: the same poses bit for bit, the same gradients to rounding."""
+    N, n, K = 64, 8192, 8
+    S, T = make_independent_pairs(N, n, n, seed=11, dtype=torch.float32, ragged=False)
     S, T = S.to(DEV), T.to(DEV)
-    T0 = torch.eye(4, device=DEV).repeat(64, 1, 1)
-    icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=8, tolerance=1e-12)
-    icp.const_iter = True
-    outs = []
-    for call in range(4):
+    T0 = torch.eye(4, device=DEV).repeat(N, 1, 1)
+
+    def call(icp):
         s, t = S.detach().requires_grad_(True), T.detach().requires_grad_(True)
         o = icp.icp(s, t, T0, trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0}, dim=3)
         o["T"].sum().backward()
         torch.cuda.synchronize()
-        outs.append((o["T"].detach().clone(), s.grad.clone(), t.grad.clone(), bool(icp.knn_stats.get("bwd_reordered", False)), "certs_off" in icp.knn_stats))
-    assert outs[0][4] and not outs[0][3]                    # the first call: certificates tried, the forward's own slot order
-    assert outs[-1][3] and not outs[-1][4], [o[3:] for o in outs]      # later calls: no certificates, slots ordered by the matches
-    assert torch.equal(outs[0][0], outs[-1][0])
-    for a, b in zip(outs[0][1:3], outs[-1][1:3]):
-        assert float((a - b).abs().max()) <= 1e-3 * max(1.0, float(a.abs().max()))
+        return o["T"].detach().clone(), s.grad.clone(), t.grad.clone(), bool(icp.knn_stats.get("bwd_reordered", False)), "certs_off" in icp.knn_stats
+
+    def new():
+        icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
+        icp.const_iter = True
+        return icp
+    a = new()
+    first = call(a)
+    assert first[4] and not first[3]                        # the first call: certificates tried, the forward's own slot order
+    for _ in range(3):
+        later = call(a)
+    b = new()
+    b._hints.cert_record(S.device, (N, n, n, K, torch.float32)).update(skip=31, moving=True)
+    moving = call(b)
+    assert moving[3] and not moving[4]                      # no certificates, slots ordered by the matches
+    for other in (later, moving):
+        assert torch.equal(first[0], other[0])
+        for x, y in zip(first[1:3], other[1:3]):            # (the same per-row sums in another order: float32 rounding of the largest gradient)
+            assert float((x - y).abs().max()) <= 2e-5 * max(1.0, float(x.abs().max())), float((x - y).abs().max()) / max(1.0, float(x.abs().max()))

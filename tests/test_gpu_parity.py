@@ -601,15 +601,25 @@ def test_sweep_knn_equals_brute_force(dtype, N, n, m):
         assert torch.equal(brute.cpu().long(), O.nn_index(x.cpu(), y.cpu()))
 
 
+QO_SIDE, QO_MID = 256, 2048 - 2 * 256        # kernels_setup.h: ordering buckets for the queries outside the targets' x range (either side), and inside it
+
+
 def rank_buckets_ascend(sw, keys, qo):
-    """The query order is a counting sort by RANK bucket: rank = lower bound of the query's x among the sorted target keys,
-    bucket = rank * 2047 // m.  Along the order the buckets must never decrease."""
+    """The query order is a counting sort by bucket: inside the targets' x range the RANK bucket (rank = lower bound of the query's x among the
+    sorted target keys, bucket = QO_SIDE + rank * (QO_MID - 1) // m), outside it QO_SIDE equal-width x buckets per side (one per 1/QO_SIDE of the
+    targets' span, clamped a span away: round 6 -- the queries a partly overlapping scan has outside the other's footprint stay neighbours in x).
+    Along the order the buckets must never decrease."""
     m = sw.m
     xs = sw.tgs4[:, :m, 0].contiguous()
     ks = torch.gather(keys, 1, qo.long())
-    ks = torch.nan_to_num(ks, nan=float(xs.min()) - 1.0)                    # NaN keys are parked in the first bucket
+    lo, hi = xs[:, :1], xs[:, m - 1:m]
+    ks = torch.nan_to_num(ks, nan=0.0, posinf=3e38, neginf=-3e38)
+    ks = torch.where(torch.isnan(torch.gather(keys, 1, qo.long())), lo.expand_as(ks), ks)      # NaN keys are parked in the first middle bucket
     rank = torch.searchsorted(xs, ks.contiguous())
-    b = (rank * 2047) // max(m, 1)
+    side = QO_SIDE / (hi - lo).clamp_min(1e-30)
+    b = QO_SIDE + (rank * (QO_MID - 1)) // max(m, 1)
+    b = torch.where(ks < lo, QO_SIDE - 1 - ((lo - ks) * side).clamp(0, QO_SIDE - 1).long(), b)
+    b = torch.where(ks > hi, QO_SIDE + QO_MID + ((ks - hi) * side).clamp(0, QO_SIDE - 1).long(), b)
     # the kernel finds the rank through a float bucket table: allow one bucket of slack for its rounding at the edges
     return bool(((torch.cummax(b, dim=1).values - b) <= 1).all())
 
@@ -626,8 +636,8 @@ def test_query_order_beyond_the_lds_path():
     assert torch.equal(torch.sort(qo.long(), dim=1).values, torch.arange(n, device=DEV).repeat(N, 1))
     # (clouds of more than 16384 queries are ordered by equal-WIDTH x buckets of the targets' range, not by rank)
     lo, hi = y[:, :, 0].min(dim=1).values[:, None], y[:, :, 0].max(dim=1).values[:, None]
-    ks = torch.gather(x[:, :, 0], 1, qo.long()).clamp(lo, hi)          # queries outside the targets' x range sit in the end buckets
-    width = float(((hi - lo) / 2048.0).max())
+    ks = torch.gather(x[:, :, 0], 1, qo.long()).clamp(lo, hi)          # (queries outside the targets' x range: side buckets, by x as well)
+    width = float(((hi - lo) / QO_MID).max())
     assert float((torch.cummax(ks, dim=1).values - ks).max()) <= 1.05 * width + 1e-4
     assert torch.equal(sw.knn(x, None, qo), _ops.knn(x, None, _ops.pack_target(y), m, _lib.KNN_VALU))
 

@@ -449,7 +449,7 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
         times, by_rank, last = [], [], None
         for i in range(count):
             if events is not None:          # the kernel timings of the roofline legs: HIP events on the dispatches of the LAST timed call only
-                icp_obj._timing_events = events if i == count - 1 else None
+                icp_obj._tuning["timing_events"] = events if i == count - 1 else None
             fence()
             t0 = time.perf_counter()
             last = run_call(icp_obj, data[0], data[1], T0, cw)
@@ -477,7 +477,7 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
     # An event pair carried on a dispatch costs the queue ~4 us of idle time before the next dependent launch (6 % of a call at this shape:
     # profiles/r02_timed_call_timeline*.txt): the events ride on the last timed call only, `value` is the median of all of them.
     use_events = on_gpu and os.environ.get("DICP_BENCH_NO_EVENTS") != "1"
-    icp._timing_events = None
+    icp._tuning["timing_events"] = None
     # a generational GC pass over this process's heap takes tens of ms (10 steps take 5 ms): whether one lands inside a
     # timed call depends on the allocation count so far, i.e. on things as irrelevant as argv -> collect now and pause
     # the collector.  The collection goes BEFORE the steady-state calls: the first call after one is ~0.8 ms slower
@@ -526,6 +526,26 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
             extra["value_k10"] = world * B * 10 / median(kt)
             extra["k10_note"] = "the same call at K = 10 (SURVEY.md 8d): %.3f ms per step, median of %d calls" % (median(kt) * 1e3 / 10, reps)
             del k10
+        # A training loop presents NEW clouds of the same shape every step, and what an ICP object carries from call to call (CallHints: tail placement,
+        # certificate pauses, the scoring forms' plan) was learned on other data.  The K = 10 call of ONE object rotating over four different batches
+        # (every timed call's hints come from another batch); results do not depend on hints (tests/test_gpu_hints.py), time may.
+        fresh = [data] + [tuple(x.to(dev) for x in make_pairs(B, n, m, seed=101 + i, dtype=torch.float32, first=rank * B)) for i in range(3)]
+        fr = new_icp(10)
+        for d_ in fresh + fresh:
+            run_call(fr, d_[0], d_[1], T0, cw)
+        ft = []
+        for i in range(2 * len(fresh)):
+            d_ = fresh[i % len(fresh)]
+            fence()
+            t0_ = time.perf_counter()
+            run_call(fr, d_[0], d_[1], T0, cw)
+            fence()
+            ft.append(all_max(time.perf_counter() - t0_))
+        extra["value_fresh_inputs"] = world * B * 10 / median(ft)
+        extra["fresh_inputs_note"] = ("K = 10, one ICP object, %d timed calls rotating over %d different make_pairs batches of the benchmark's shape (seeds 3, 101-103): every "
+                                      "call-to-call hint was recorded on another batch; %.3f ms per call (min %.3f, max %.3f); compare value_k10, whose calls replay one batch"
+                                      % (len(ft), len(fresh), median(ft) * 1e3, min(ft) * 1e3, max(ft) * 1e3))
+        del fr, fresh
         if not brute:
             for key, kv, what in (("value_bruteforce", L.KNN_MFMA, "the matrix-core brute force (split-f16 filter on v_mfma_f32_32x32x16_f16 + exact float32 refine)"),
                                   ("value_bruteforce_valu", L.KNN_VALU, "the float32 FMA brute-force kernel")):

@@ -18,7 +18,8 @@ import torch
 import yaml
 
 from . import _call, _lib
-from ._ops import CallHints, F16_SWEEP_MIN_TARGETS, F16_SWEEP_STATIC_TARGETS, ICPLoop, KabschLoop, LoopConfig, compute_device, form_tally_wanted, pack_list, packable, prebuild_search, resort_schedule, transform_points
+from ._ops import F16_SWEEP_MIN_TARGETS, F16_SWEEP_STATIC_TARGETS, KabschLoop, compute_device, pack_list, packable, prebuild_search, transform_points
+from ._loop import CallHints, ICPLoop, LoopConfig, form_tally_wanted, resort_schedule
 from .nn import nn
 
 
@@ -55,7 +56,7 @@ class ICP:
         # every iteration for big batches (an iteration costs far more than a sync), every 4th for small ones
         # (converged clouds are frozen, so the extra iterations change nothing and the histories are trimmed)
         self.sync_every = None
-        # True: a backward pass that used the one-launch tail of the truncated reverse sweep waits for itself and raises _ops.TailTimeout IN that pass if a
+        # True: a backward pass that used the one-launch tail of the truncated reverse sweep waits for itself and raises _loop.TailTimeout IN that pass if a
         # wait inside the launch ran out (a GPU kept full by other work for half a second) -- before the NaN gradients it would otherwise return reach an
         # optimizer.  False (default): no synchronisation; the failure is raised by the next backward pass of this object, or by check_errors().
         self.strict_errors = False
@@ -80,9 +81,9 @@ class ICP:
             first_search=True,                # iteration 0's search is enqueued with the index build, before the loop state is prepared
             plan_call=True,                   # constant-iteration calls: every segment of the loop behind one library call (dicp_icp_forward_plan)
             bwd_tail=True,                    # the ended iterations of the truncated reverse sweep run as one launch
-            one_call=True)                    # calls that need none of the loop's host decisions: one library call per direction (dicp_call_*)
+            one_call=True,                    # calls that need none of the loop's host decisions: one library call per direction (dicp_call_*)
+            timing_events=None)               # measurement only: an object with .handles(K) -> 6 K HIP events the loop's launches carry (bench.py's EventLog)
         self._hints = CallHints()             # private: what this object's earlier calls tell later ones about time (per device, stream and shape)
-        self._timing_events = None
         self._eye = {}                        # private: identity start poses of pt2pt_dICP_SVD by (batch size, dtype, device)
 
     def icp(self, source, target, T_init, weight=None, trim_dist=None, loss_fn=None, dim=3):
@@ -137,7 +138,7 @@ class ICP:
             target = target.contiguous()
             source = source.contiguous()
         wants_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (source, target, T_init, w_pts) if t is not None)
-        first_search = bool(self._tuning["first_search"]) and self._timing_events is None and not (wants_grad and not self.bwd_window)
+        first_search = bool(self._tuning["first_search"]) and self._tuning["timing_events"] is None and not (wants_grad and not self.bwd_window)
         deterministic = bool(self.deterministic) and wants_grad
         if deterministic and soft:
             raise NotImplementedError("ICP.deterministic: not with Gumbel-softmax correspondences (their adjoint adds to the target with float atomics)")
@@ -150,7 +151,7 @@ class ICP:
             match_ratio_thresh=float(self.match_ratio_thresh),
             knn_variant=(_lib.KNN_SWEEP | (self.knn_variant & 0xff00)) if deterministic else self.knn_variant, bwd_window=True if deterministic else bool(self.bwd_window),
             deterministic=deterministic, stats_out=self.knn_stats, hints=self._hints,
-            sync_every=self.sync_every, timing_events=self._timing_events, small_loop=False if deterministic else bool(self._tuning["small_loop"]),
+            sync_every=self.sync_every, timing_events=self._tuning["timing_events"], small_loop=False if deterministic else bool(self._tuning["small_loop"]),
             src_rows=src_rows, tgt_rows=tgt_rows, sweep_resort=resort_schedule(self._tuning["sweep_resort"], source.shape[0], source.shape[1], int(self.max_iterations), bool(self.reuse_matches), self._tuning["cert_from"]), reuse_matches=bool(self.reuse_matches), cert_from=self._tuning["cert_from"],
             bwd_skip_eps=self.bwd_skip_eps, cert_backoff=bool(self._tuning["cert_backoff"]), cert_sets=bool(self._tuning["cert_sets"]), cert_hint=bool(self._tuning["cert_hint"]),
             plan_call=bool(self._tuning["plan_call"]), bwd_tail=bool(self._tuning["bwd_tail"]), first_search=first_search, strict_errors=bool(self.strict_errors),
@@ -197,7 +198,7 @@ class ICP:
 
     def check_errors(self):
         """Wait for the backward passes this object has enqueued so far and raise if one of them reported a failure of its own (today: a wait of the
-        one-launch tail that ran out, _ops.TailTimeout -- that pass's gradients are NaN).  Without this call the error is raised by the next backward pass
+        one-launch tail that ran out, _loop.TailTimeout -- that pass's gradients are NaN).  Without this call the error is raised by the next backward pass
         -- or, with `strict_errors = True`, by the failing pass itself.  Call it before `optimizer.step()` when neither is acceptable."""
         self._hints.check(wait=True)
 

@@ -16,6 +16,7 @@ import ctypes
 import torch
 
 from . import _lib
+from . import _loop
 from . import _ops
 from ._ops import _DT, _on, _p, _stream
 
@@ -51,7 +52,7 @@ def eligible(cfg, source, target, T_init, w0, need_grad):
     if len([k for k in resorts if k > 0]) >= _lib.MAX_SEGMENTS:
         return False
     cert_from = (max(resorts) if resorts else 0) if cfg.cert_from is None else max(0, int(cfg.cert_from))
-    if _ops.certificates_pay(cfg.reuse_matches, Kmax, cert_from, N, n):
+    if _loop.certificates_pay(cfg.reuse_matches, Kmax, cert_from, N, n):
         return False                # match certificates pay from there on: ICPLoop's business
     if _ops.F16_SWEEP and dt == torch.float32 and float(N) * n >= _ops.F16_SWEEP_MIN_QUERIES and m >= _ops.F16_SWEEP_MIN_TARGETS:
         return False                # the matrix-core scoring of big problems
@@ -155,7 +156,7 @@ class CallLoop(torch.autograd.Function):
                                     qorder=base + FL.orders + (FL.n_orders - 1) * N * n * 4, spos=base + FL.spos, poses=base + FL.poses, deltas=deltas.data_ptr(),
                                     areg=base + FL.areg, alive=base + FL.alive, N=N, n=n, m=m, c=call.c, K=K, K_cap=K, m_pad=FL.m_pad, dim=call.dim,
                                     knn_variant=_lib.KNN_SWEEP | ((1 << 25) if (call.flags & _lib.CALL_NO_SMALL_LOOP) else 0))
-            gsrc, gtgt, gT0, gw = _ops.backward_once(lib, code, P, F, cfg, src, tgt, w0, gT, want_tgt, want_w)
+            gsrc, gtgt, gT0, gw = _loop.backward_once(lib, code, P, F, cfg, src, tgt, w0, gT, want_tgt, want_w)
             if gsrc_pc is not None:
                 gsrc += gsrc_pc
         return gsrc, gtgt, gT0, gw, None

@@ -22,7 +22,7 @@ LOSS_NONE, LOSS_HUBER, LOSS_CAUCHY, LOSS_TRIM = 0, 1, 2, 3
 KNN_AUTO, KNN_VALU, KNN_MFMA, KNN_SWEEP, KNN_GUMBEL = 0, 1, 2, 3, 4
 NACC_PAD, NBWD_PAD, KAB_SAVE = 32, 16, 40
 PAIR_SHARDS = 64      # DICP_PAIR_SHARDS
-ABI_VERSION = 10
+ABI_VERSION = 11
 _ERRORS = {1: "null pointer", 2: "bad shape/stride", 3: "unsupported dtype", 4: "bad enum value", 5: "misaligned buffer"}
 
 vp, i32, i64, f64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
@@ -156,6 +156,7 @@ _SIGNATURES = {
     "dicp_sweep_build": ([i32, vp, i32, vp, vp, vp, i32, i32, i32, vp, vp, i32, vp], ctypes.c_int),
     "dicp_sweep_setup": ([i32, vp, i32, vp, i32, i32, i32, f64, i32, vp, vp, vp, i32, vp, vp, vp, ctypes.c_size_t, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp], ctypes.c_int),
     "dicp_query_order": ([i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, vp], ctypes.c_int),
+    "dicp_query_reorder": ([i32, vp, vp, vp, vp, vp, i32, i32, i32, vp, i32, vp, vp, i32, vp, vp, vp], ctypes.c_int),
     "dicp_query_keys": ([i32, vp, vp, i32, i32, vp, vp], ctypes.c_int),
     "dicp_loop_init": ([i32, vp, vp, ctypes.c_double, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp], ctypes.c_int),
     "dicp_search_pose": ([i32, vp, vp, i32, vp, vp], ctypes.c_int),

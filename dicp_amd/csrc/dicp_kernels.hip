@@ -164,16 +164,29 @@ int dicp_query_keys(int dtype, const void* src, const void* pose, int N, int n, 
     return launch_status();
 }
 
+static int query_order_go(int dtype, const void* src, const void* pose, const void* brange, int nbkt, int N, int n, int32_t* qorder,
+                          const void* w, void* src_s, void* w_s, int reproducible, const int32_t* spos_prev, int m_pad,
+                          const void* skeys, const int32_t* bucket, int m, const int32_t* src_rows, const int32_t* tgt_rows, const void* pose_prev, const int32_t* order_prev, void* stream);
 int dicp_query_order(int dtype, const void* src, const void* pose, const void* brange, int nbkt, int N, int n, int32_t* qorder,
                      const void* w, void* src_s, void* w_s, int reproducible, const int32_t* spos_prev, int m_pad,
                      const void* skeys, const int32_t* bucket, int m, const int32_t* src_rows, const int32_t* tgt_rows, void* stream) {
+    return query_order_go(dtype, src, pose, brange, nbkt, N, n, qorder, w, src_s, w_s, reproducible, spos_prev, m_pad, skeys, bucket, m, src_rows, tgt_rows, nullptr, nullptr, stream);
+}
+int dicp_query_reorder(int dtype, const void* src, const void* pose, const void* pose_prev, const int32_t* order_prev, const void* brange, int nbkt, int N, int n,
+                       int32_t* qorder, int m_pad, const void* skeys, const int32_t* bucket, int m, const int32_t* src_rows, const int32_t* tgt_rows, void* stream) {
+    if (!pose || !pose_prev || !order_prev || order_prev == qorder) return DICP_ERR_NULL;
+    return query_order_go(dtype, src, pose, brange, nbkt, N, n, qorder, nullptr, nullptr, nullptr, 0, nullptr, m_pad, skeys, bucket, m, src_rows, tgt_rows, pose_prev, order_prev, stream);
+}
+static int query_order_go(int dtype, const void* src, const void* pose, const void* brange, int nbkt, int N, int n, int32_t* qorder,
+                          const void* w, void* src_s, void* w_s, int reproducible, const int32_t* spos_prev, int m_pad,
+                          const void* skeys, const int32_t* bucket, int m, const int32_t* src_rows, const int32_t* tgt_rows, const void* pose_prev, const int32_t* order_prev, void* stream) {
     if (!src || !brange || !qorder || (w_s && !w)) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (N <= 0 || n <= 0 || nbkt <= 0 || ((spos_prev || skeys) && m_pad <= 0) || (skeys && (m <= 0 || m > m_pad))) return DICP_ERR_SHAPE;
     hipStream_t st = (hipStream_t)stream;
     begin_launch();
 #define DICP_QO(T, S) query_order_kernel<T, S><<<N, QO_THREADS, 0, st>>>((const T*)src, (const T*)pose, (const T*)brange, nbkt, N, n, qorder, \
-        (const T*)w, (T*)src_s, (T*)w_s, reproducible, spos_prev, m_pad, (const T*)skeys, 1, m, bucket, src_rows, tgt_rows)
+        (const T*)w, (T*)src_s, (T*)w_s, reproducible, spos_prev, m_pad, (const T*)skeys, 1, m, bucket, src_rows, tgt_rows, (const T*)pose_prev, order_prev)
     if (dtype == DICP_F32) { if (n <= 16384) DICP_QO(float, 16384); else DICP_QO(float, 65536); }
     else                   { if (n <= 16384) DICP_QO(double, 16384); else DICP_QO(double, 65536); }
 #undef DICP_QO
@@ -961,16 +974,21 @@ int dicp_icp_forward_plan(int dtype, const dicp_weight_params* prm, const dicp_l
     if (S->nseg <= 0 || S->nseg > DICP_MAX_SEGMENTS) return DICP_ERR_SHAPE;
     const size_t es = dtype == DICP_F32 ? 4 : 8;
     dicp_loop_buffers B = *buf;
+    const int32_t* order_before = nullptr;      // the order in use before this segment's, and the iteration it was made (or kept) at
+    int k_before = 0;
     for (int s = 0; s < S->nseg; ++s) {
         const int k0 = S->k0[s], k1 = S->k1[s];
         if (k0 < 0 || k1 > B.K || k0 >= k1 || (s > 0 && k0 != S->k1[s - 1])) return DICP_ERR_SHAPE;
         int32_t* qo = S->order[s];
         if (qo && S->new_order[s]) {
             if (!S->keys) return DICP_ERR_NULL;
-            const char* pose_s = (const char*)(B.poses_search ? B.poses_search : B.poses) + (size_t)k0 * N * 12 * es;
-            if (const int rc = dicp_query_order(dtype, B.src, pose_s, B.brange, B.nbkt, N, n, qo, nullptr, nullptr, nullptr, 0, nullptr, B.m_pad,
-                                                S->keys, B.bucket, m, B.src_rows, B.tgt_rows, stream)) return rc;
+            const char* poses_s = (const char*)(B.poses_search ? B.poses_search : B.poses);
+            // (a re-ordering: a cloud that has hardly moved since the order before keeps it, dicp_query_reorder)
+            if (const int rc = query_order_go(dtype, B.src, poses_s + (size_t)k0 * N * 12 * es, B.brange, B.nbkt, N, n, qo, nullptr, nullptr, nullptr, 0, nullptr, B.m_pad,
+                                              S->keys, B.bucket, m, B.src_rows, B.tgt_rows, (order_before && order_before != qo) ? poses_s + (size_t)k_before * N * 12 * es : nullptr,
+                                              order_before != qo ? order_before : nullptr, stream)) return rc;
         }
+        if (qo && qo != order_before) { order_before = qo; k_before = k0; }
         B.qorder = qo;
         const bool certs = S->cert_from >= 0 && k0 >= S->cert_from;
         B.cert_q = certs ? S->cert_q : nullptr; B.cert_qu = certs ? S->cert_qu : nullptr; B.cert_count = certs ? S->cert_count : nullptr;

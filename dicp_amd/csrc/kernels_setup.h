@@ -90,7 +90,7 @@ __global__ __launch_bounds__(CC_THREADS) void search_frame_kernel(const T* __res
     __shared__ int dhist[SF_DIRS][256];
     __shared__ float s_ctr[3], s_ext[CC_THREADS / WAVE], s_cnt[CC_THREADS / WAVE];
     __shared__ int s_cost[SF_DIRS];
-    __shared__ float s_t[3][CC_SAMPLE];          // the sample targets, centred (query-aware cost)
+    __shared__ float4 s_t[CC_SAMPLE];            // the sample targets, centred (query-aware cost)
     __shared__ int s_cum[SF_DIRS][256 + 1];      // exclusive prefix sums of dhist
     const int cloud = blockIdx.x, tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
     const T* __restrict__ rows = tgt + (size_t)cloud * m * c;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(CC_THREADS) void search_frame_kernel(const T* __res
             }
         }
         const bool with_queries = src != nullptr && T_init != nullptr && n > 0;
-        if (with_queries) { s_t[0][tid] = fin ? dx : 1e18f; s_t[1][tid] = fin ? dy : 1e18f; s_t[2][tid] = fin ? dz : 1e18f; }
+        if (with_queries) s_t[tid] = fin ? make_float4(dx, dy, dz, 0.f) : make_float4(1e18f, 1e18f, 1e18f, 0.f);
         __syncthreads();
         if (wave < SF_DIRS) {
             const int h0 = dhist[wave][4 * lane], h1 = dhist[wave][4 * lane + 1], h2 = dhist[wave][4 * lane + 2], h3 = dhist[wave][4 * lane + 3];
@@ -215,16 +215,26 @@ __global__ __launch_bounds__(CC_THREADS) void search_frame_kernel(const T* __res
                 qon = fabsf(qx) < 1e18f && fabsf(qy) < 1e18f && fabsf(qz) < 1e18f;
             }
             float d2 = 3e38f;
-            if (qon)
-                for (int t = part; t < ms; t += 4) {
-                    const float ex = s_t[0][t] - qx, ey = s_t[1][t] - qy, ez = s_t[2][t] - qz;
-                    d2 = fminf(d2, ex * ex + ey * ey + ez * ez);
+            if (qon) {      // (four targets per round, one 16-byte LDS read each: every sample slot past ms holds the far filler or is never reached)
+                float da = 3e38f, db = 3e38f, dc = 3e38f, dd = 3e38f;
+                int t = part;
+                for (; t + 12 < ms; t += 16) {
+                    const float4 a = s_t[t], b = s_t[t + 4], c4 = s_t[t + 8], e4 = s_t[t + 12];
+                    da = fminf(da, (a.x - qx) * (a.x - qx) + (a.y - qy) * (a.y - qy) + (a.z - qz) * (a.z - qz));
+                    db = fminf(db, (b.x - qx) * (b.x - qx) + (b.y - qy) * (b.y - qy) + (b.z - qz) * (b.z - qz));
+                    dc = fminf(dc, (c4.x - qx) * (c4.x - qx) + (c4.y - qy) * (c4.y - qy) + (c4.z - qz) * (c4.z - qz));
+                    dd = fminf(dd, (e4.x - qx) * (e4.x - qx) + (e4.y - qy) * (e4.y - qy) + (e4.z - qz) * (e4.z - qz));
                 }
+                for (; t < ms; t += 4) { const float4 a = s_t[t]; da = fminf(da, (a.x - qx) * (a.x - qx) + (a.y - qy) * (a.y - qy) + (a.z - qz) * (a.z - qz)); }
+                d2 = fminf(fminf(da, db), fminf(dc, dd));
+            }
             d2 = fminf(d2, __shfl_xor(d2, 1));
             d2 = fminf(d2, __shfl_xor(d2, 2));
             if (qon && d2 < 1e30f) {
                 const float d = sqrtf(d2), scale = 128.f / R2;
-                for (int j = part; j < SF_DIRS; j += 4) {
+#pragma unroll
+                for (int j = 0; j < SF_DIRS; ++j) {             // (constant indices: the candidates' table stays in registers / literals)
+                    if ((j & 3) != part) continue;
                     const float k = (float)QS[j][0] * qx + (float)QS[j][1] * qy + (float)QS[j][2] * qz;
                     const int lo = min(max((int)((k - d + R2) * scale), 0), 255), hi = min(max((int)((k + d + R2) * scale), 0), 255);
                     atomicAdd(&s_cost[j], s_cum[j][hi + 1] - s_cum[j][lo]);
@@ -490,8 +500,10 @@ __global__ __launch_bounds__(QO_THREADS) void query_order_kernel(const T* __rest
                                                                  T* __restrict__ src_s, T* __restrict__ w_s, int reproducible,
                                                                  const int32_t* __restrict__ spos_prev, int m_pad,
                                                                  const T* __restrict__ skeys, int kstride, int mt_full, const int32_t* __restrict__ table,
-                                                                 const int32_t* __restrict__ src_rows, const int32_t* __restrict__ tgt_rows) {
+                                                                 const int32_t* __restrict__ src_rows, const int32_t* __restrict__ tgt_rows,
+                                                                 const T* __restrict__ pose_prev = nullptr, const int32_t* __restrict__ order_prev = nullptr) {
     __shared__ int cnt[QO_BUCKETS];
+    __shared__ int s_same;
     __shared__ int wsum[QO_THREADS / WAVE];
     __shared__ unsigned short stage[QO_STAGE];              // query ids (< 65536) by slot: the permutation is assembled here
     __shared__ float lkeys[QO_STAGE <= 16384 ? QO_KEYS : 1];
@@ -512,6 +524,31 @@ __global__ __launch_bounds__(QO_THREADS) void query_order_kernel(const T* __rest
         if (w_s) w_s[(size_t)cloud * n + i] = w[(size_t)cloud * n + i];
     }
     if (n <= 0) return;
+    // A RE-ordering (dicp_query_reorder: given the order made under an earlier pose of the same call): a cloud whose points have moved by less than a tenth
+    // of the x extent of a unit of the sweep since then keeps that order -- a copy instead of the counting sort (round 6: the re-orderings before iterations
+    // 2 and 3 were 37 us each at the benchmark shape for clouds that had moved by a millimetre).  The bound: |dC|_F R + |dr| with R the radius of the targets'
+    // x range about the frame's origin (the order only keeps a wave's queries neighbours: a stale one costs pairs, never results).
+    if (pose && pose_prev && order_prev && !src_s && !w_s) {
+        if (tid == 0) {
+            const T* a = pose + (size_t)cloud * 12;
+            const T* b = pose_prev + (size_t)cloud * 12;
+            float dc = 0.f, dr = 0.f;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) { const float d = (float)(a[e] - b[e]); dc += d * d; }
+#pragma unroll
+            for (int e = 9; e < 12; ++e) { const float d = (float)(a[e] - b[e]); dr += d * d; }
+            const float x0 = (float)brange[(size_t)cloud * 2], ts = (float)brange[(size_t)cloud * 2 + 1];
+            const float span = ts > 0.f ? (float)nbkt_range / ts : 0.f;
+            const float moved = sqrtf(dc) * 1.7321f * fmaxf(fabsf(x0), fabsf(x0 + span)) + sqrtf(dr);
+            s_same = (moved * (float)n < 0.1f * span * (float)(2 * WAVE)) ? 1 : 0;        // (NaN: re-order)
+        }
+        __syncthreads();
+        if (s_same) {
+            const int32_t* op = order_prev + (size_t)cloud * (n_full - n);
+            for (int i = tid; i < n; i += QO_THREADS) qorder[(size_t)cloud * n + i] = op[(size_t)cloud * n + i];
+            return;
+        }
+    }
     for (int b = tid; b < QO_BUCKETS; b += QO_THREADS) cnt[b] = 0;
     T q[4] = {T(1), T(0), T(0), T(0)};
     if (pose) { const T* pp = pose + (size_t)cloud * 12; q[0] = pp[0]; q[1] = pp[1]; q[2] = pp[2]; q[3] = pp[9]; }

@@ -42,8 +42,8 @@ OUTPUTS = ("T", "pc", "deltas", "weights", "costs")
 def _check_tail_word(icp):
     """A replay cannot report a wait of the backward's one-launch tail that ran out the way an eager call does (no host code runs between the kernels): the
     error word of the captured pass is a static tensor of the graph -- ``call.check_errors()`` / ``step.check_errors()`` wait for the replays made so far and
-    raise _ops.TailTimeout if the last one raised it (its gradients are NaN).  Call it before the optimizer's step."""
-    from ._ops import TailTimeout
+    raise _loop.TailTimeout if the last one raised it (its gradients are NaN).  Call it before the optimizer's step."""
+    from ._loop import TailTimeout
     word = icp.knn_stats.get("bwd_tail_error")
     if word is not None and int(word.item()) != 0:
         raise TailTimeout("dicp_amd: a wait of the captured backward pass's one-launch tail ran out in the last replay; its gradients are NaN")

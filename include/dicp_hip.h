@@ -30,7 +30,9 @@
 extern "C" {
 #endif
 
-#define DICP_ABI_VERSION 10  /* 10: dicp_pack_list / dicp_unpack_list (lists of clouds to one padded batch and back, one launch each).
+#define DICP_ABI_VERSION 11  /* 11: dicp_search_frame takes the queries (src under T_init): the sort direction is chosen for THEIR slabs; dicp_query_reorder (a re-ordering
+                                keeps the order of a cloud that hardly moved); dicp_loop_buffers.sweep_form_plan (one scoring form per iteration from an earlier call's tallies).
+                                10: dicp_pack_list / dicp_unpack_list (lists of clouds to one padded batch and back, one launch each).
                                 9: dicp_loop_buffers.det_far_row / det_far_val (deterministic target gradients of the windowed backward).
                                 8: certified iterations keep a row cache and their match history by reference (dicp_loop_buffers.spos_of / cert_nbr / cert_gdirty /
                                 cert_pend / cert_cm, spos_prev_chunk + spos_floor instead of spos_prev0; dicp_resolve_matches).
@@ -164,6 +166,12 @@ int dicp_query_keys(int dtype, const void* src, const void* pose, int N, int n, 
 int dicp_query_order(int dtype, const void* src, const void* pose, const void* brange, int nbkt, int N, int n, int32_t* qorder,
                      const void* w, void* src_s, void* w_s, int reproducible, const int32_t* spos_prev, int m_pad,
                      const void* keys_sorted, const int32_t* bucket, int m, const int32_t* src_rows, const int32_t* tgt_rows, void* stream);
+/* A RE-ordering inside one call: as dicp_query_order (no copies, no previous matches), given the order that was made under an earlier pose of the same call.
+ * A cloud whose points have moved by less than a tenth of the x extent of a unit of the sweep between the two poses (|dC|_F R + |dr|, R the radius of the
+ * targets' x range) keeps that order -- qorder gets a copy of order_prev -- instead of being sorted again; order_prev != qorder.  The order only keeps a wave's
+ * queries neighbours in x: which clouds were sorted again changes pairs scored, never results.  dicp_icp_forward_plan re-orders this way. */
+int dicp_query_reorder(int dtype, const void* src, const void* pose, const void* pose_prev, const int32_t* order_prev, const void* brange, int nbkt, int N, int n,
+                       int32_t* qorder, int m_pad, const void* skeys, const int32_t* bucket, int m, const int32_t* src_rows, const int32_t* tgt_rows, void* stream);
 
 /* Exact 1-NN with slab pruning: same result (and lowest-index tie rule) as dicp_knn, far fewer pairs.
  * The caller prepares, ONCE per ICP call (targets do not move between iterations):

@@ -3,7 +3,7 @@
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from dicp_amd import _lib, _ops
+from dicp_amd import _lib, _loop, _ops
 from dicp_amd.synthetic import make_pairs
 
 B = int(os.environ.get("B", 256)); n = int(os.environ.get("NPTS", 16384)); rounds = int(os.environ.get("ROUNDS", 9))
@@ -20,7 +20,7 @@ sw.knn(src, pose, qo, out=idx)
 ident = torch.arange(n, dtype=torch.int32, device="cuda").repeat(B, 1).contiguous()
 w0 = torch.ones((B, n), dtype=dt, device="cuda")
 wout = torch.empty((B, n), dtype=dt, device="cuda")
-P = _ops.LoopConfig(icp_type="pt2pl", differentiable=True, max_iterations=1, tolerance=0.0, trim_dist=5.0, loss_name="huber",
+P = _loop.LoopConfig(icp_type="pt2pl", differentiable=True, max_iterations=1, tolerance=0.0, trim_dist=5.0, loss_name="huber",
                     loss_metric=1.0, dim=3, const_iter=True, tanh_steepness=10.0, match_ratio_thresh=0.01).params()
 p, st = _ops._p, _ops._stream()
 nb = lib.dicp_accumulate_blocks(n)

@@ -4,7 +4,7 @@ under the identity pose): dicp_accumulate_bwd (row atomics, original order) vs d
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from dicp_amd import _lib, _ops
+from dicp_amd import _lib, _loop, _ops
 from dicp_amd.synthetic import make_pairs
 
 B = int(os.environ.get("B", 256)); n = int(os.environ.get("NPTS", 16384)); rounds = int(os.environ.get("ROUNDS", 7))
@@ -31,7 +31,7 @@ sw.knn(src, pose, qo, out=idx, spos=spos)
 w0 = torch.ones((B, n), dtype=dt, device="cuda")
 gs = torch.randn((B, 36), dtype=dt, device="cuda")
 gb = torch.randn((B, 6), dtype=dt, device="cuda")
-P = _ops.LoopConfig(icp_type=mode, differentiable=True, max_iterations=1, tolerance=0.0, trim_dist=5.0, loss_name="huber",
+P = _loop.LoopConfig(icp_type=mode, differentiable=True, max_iterations=1, tolerance=0.0, trim_dist=5.0, loss_name="huber",
                     loss_metric=1.0, dim=3, const_iter=True, tanh_steepness=10.0, match_ratio_thresh=0.01).params()
 p, st = _ops._p, _ops._stream()
 src_s = _ops._gather_rows_raw(src, qo)

@@ -21,7 +21,7 @@ gc.collect(); gc.disable()
 if os.environ.get("EVENTS") == "1":
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
-    log = bench.EventLog(); log.handles(K); icp._timing_events = log
+    log = bench.EventLog(); log.handles(K); icp._tuning["timing_events"] = log
 for rep in range(6):
     torch.cuda.synchronize(); t0 = time.perf_counter(); o = call(); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
     print("call %d: host-return %.2f ms, done %.2f ms" % (rep, (t1 - t0) * 1e3, (t2 - t0) * 1e3), flush=True)

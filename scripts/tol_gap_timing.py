@@ -3,7 +3,7 @@ usage (MI355X): PYTHONPATH=. python scripts/tol_gap_timing.py"""
 import os, sys, time, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from dicp_amd import _ops
+from dicp_amd import _loop, _ops
 from dicp_amd.ICP import ICP
 from dicp_amd.synthetic import make_pairs
 
@@ -15,7 +15,7 @@ kw = dict(trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0}, dim=3)
 icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=50, tolerance=1e-4)
 icp.const_iter = False
 marks = {}
-orig_conv, orig_bwd = _ops._converged_at, _ops.backward_once
+orig_conv, orig_bwd = _loop._converged_at, _loop.backward_once
 
 
 def conv(p):
@@ -32,7 +32,7 @@ def bwd(*a, **k):
     return r
 
 
-_ops._converged_at, _ops.backward_once = conv, bwd
+_loop._converged_at, _loop.backward_once = conv, bwd
 rows = []
 for it in range(40):
     marks.clear()

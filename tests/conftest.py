@@ -36,7 +36,7 @@ def scan_map():
             np.load(os.path.join(GOLDEN, "points_map.npy")))
 
 
-# The product uses match certificates only from ~2 M certified point-iterations on (dicp_amd._ops.CERT_MIN_WORK: below that they cost the host more
+# The product uses match certificates only from ~2 M certified point-iterations on (dicp_amd._loop.CERT_MIN_WORK: below that they cost the host more
 # than they save the GPU).  Most GPU tests are about what the certified loop COMPUTES and run it at every size (threshold 0), as before the policy
 # existed.  The parity and gradient tests against the reference's vectors -- and the reference's own nine tests -- also run with the SHIPPED policy
 # (plain searches below the threshold), so that what a user gets at those sizes is held to the same bars;
@@ -55,5 +55,5 @@ def pytest_generate_tests(metafunc):
 @pytest.fixture(autouse=True)
 def _certificate_policy(monkeypatch, cert_policy):
     if cert_policy == "certs-at-every-size":
-        from dicp_amd import _ops
-        monkeypatch.setattr(_ops, "CERT_MIN_WORK", 0.0)
+        from dicp_amd import _loop
+        monkeypatch.setattr(_loop, "CERT_MIN_WORK", 0.0)

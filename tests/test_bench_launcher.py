@@ -18,7 +18,7 @@ class OracleICP:
 
     def __init__(self, log_dir, **kw):
         self.kw, self.log_dir = kw, log_dir
-        self.max_iterations, self.const_iter, self.knn_variant, self._timing_events = kw["max_iterations"], True, 0, None
+        self.max_iterations, self.const_iter, self.knn_variant, self._tuning = kw["max_iterations"], True, 0, {"timing_events": None}
         self.knn_stats = {}
 
     def icp(self, source, target, T_init, trim_dist=None, loss_fn=None, dim=3):

@@ -94,6 +94,10 @@ def test_new_entry_points_reject_bad_arguments(lib):
     assert lib.dicp_query_order(0, one, None, None, 1024, 1, 1, one, None, None, None, 0, None, 0, None, None, 0, None, None, None) == 1
     assert lib.dicp_query_order(9, one, None, one, 1024, 1, 1, one, None, None, None, 0, None, 0, None, None, 0, None, None, None) == 3
     assert lib.dicp_query_order(0, one, None, one, 1024, 1, 1, one, None, None, None, 0, None, 0, one, one, 0, None, None, None) == 2      # keys without m
+    # dicp_query_reorder(dtype, src, pose, pose_prev, order_prev, brange, nbkt, N, n, qorder, m_pad, skeys, bucket, m, src_rows, tgt_rows, stream): both poses and the order before
+    assert lib.dicp_query_reorder(0, one, None, one, one, one, 1024, 1, 1, one, 0, None, None, 0, None, None, None) == 1
+    assert lib.dicp_query_reorder(0, one, one, one, None, one, 1024, 1, 1, one, 0, None, None, 0, None, None, None) == 1
+    assert lib.dicp_query_reorder(0, one, one, one, one, one, 1024, 1, 1, one, 0, None, None, 0, None, None, None) == 1       # (in place: order_prev == qorder)
     assert lib.dicp_loop_init(0, one, one, 0.01, 2, 1, 1, one, one, one, None, None, None, None, None, 0, None) == 2
     assert lib.dicp_loop_init(0, None, one, 0.01, 1, 1, 1, one, one, one, one, one, None, None, None, 0, None) == 1
     assert lib.dicp_loop_init(0, one, one, 0.01, 1, 1, 1, one, one, one, None, None, None, one, None, 4, None) == 1     # rmax needs the points and dcum
@@ -170,7 +174,7 @@ def test_new_entry_points_reject_bad_arguments(lib):
 
 
 def test_sizes_and_argument_checks(lib):
-    assert lib.dicp_abi_version() == _lib.ABI_VERSION == 10
+    assert lib.dicp_abi_version() == _lib.ABI_VERSION == 11
     assert [lib.dicp_padded_targets(m) for m in (0, 1, 64, 65, 129)] == [0, 64, 64, 128, 192]
     assert [lib.dicp_accumulate_blocks(n) for n in (0, 1, 512, 513, 16384)] == [0, 1, 1, 2, 32]
     # rejected before any launch (no GPU touched): null pointers, bad dtype / shapes / enums

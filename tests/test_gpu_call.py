@@ -6,7 +6,7 @@ float atomics: two passes of EITHER path differ by that much).  And: which calls
 import pytest
 import torch
 
-from dicp_amd import _call, _lib, _ops
+from dicp_amd import _call, _lib, _loop, _ops
 from dicp_amd.ICP import ICP
 from dicp_amd.synthetic import make_pairs, make_scene_pairs
 
@@ -114,7 +114,7 @@ def test_which_calls_take_it():
     S, Tg, Ti = src.to(DEV), tgt.to(DEV), torch.eye(4).repeat(2, 1, 1).to(DEV)
 
     def cfg_of(icp):
-        return _ops.LoopConfig(icp_type="pt2pl", differentiable=True, max_iterations=int(icp.max_iterations), tolerance=1e-12, trim_dist=5.0, loss_name=None,
+        return _loop.LoopConfig(icp_type="pt2pl", differentiable=True, max_iterations=int(icp.max_iterations), tolerance=1e-12, trim_dist=5.0, loss_name=None,
                                loss_metric=1.0, dim=3, const_iter=bool(icp.const_iter), tanh_steepness=5.0, match_ratio_thresh=0.5, knn_variant=icp.knn_variant,
                                reuse_matches=bool(icp.reuse_matches))
     icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=5, tolerance=1e-12)

@@ -608,12 +608,12 @@ def test_first_search_ahead_of_the_loop_changes_nothing(const_iter, grad):
 
 
 def test_certificates_are_used_where_they_pay(monkeypatch):
-    """Size policy of the match certificates (dicp_amd._ops.CERT_MIN_WORK): on by default where the certified point-iterations outweigh their host cost, off below
+    """Size policy of the match certificates (dicp_amd._loop.CERT_MIN_WORK): on by default where the certified point-iterations outweigh their host cost, off below
     (configs[1]-sized calls at 10 iterations) -- results identical either way; and a shape whose clouds all switch them off (duplicated targets) is searched plainly
     in later calls of the same ICP object, until it is tried again."""
-    from dicp_amd import _ops
+    from dicp_amd import _loop
     monkeypatch.undo()                                                  # (the product's own threshold, not the suite's 0)
-    assert _ops.CERT_MIN_WORK == 2.0e6
+    assert _loop.CERT_MIN_WORK == 2.0e6
     res = {}
     for N, n, K, expect in ((8, 4096, 10, False), (8, 4096, 80, True), (40, 16384, 10, True)):
         src, tgt = make_pairs(N, n, n, seed=5)
@@ -627,7 +627,7 @@ def test_certificates_are_used_where_they_pay(monkeypatch):
     N = src.shape[0]
     icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
     icp.const_iter, icp.knn_variant = True, _lib.KNN_SWEEP
-    monkeypatch.setattr(_ops, "CERT_MIN_WORK", 0.0)
+    monkeypatch.setattr(_loop, "CERT_MIN_WORK", 0.0)
     used, Ts = [], []
     for call in range(6):
         out = icp.icp(src.to(DEV), tgt.to(DEV), torch.eye(4, device=DEV).repeat(N, 1, 1), **KW)

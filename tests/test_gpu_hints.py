@@ -1,0 +1,47 @@
+"""What an ICP object carries from call to call (CallHints: where the reverse sweep's one-launch tail starts, certificate pauses, the scoring forms' plan, the
+"clouds keep moving" flag) is about TIME only (`-m gpu`).  A training loop hands such an object NEW clouds of the same shape every step, so every hint it acts on was
+recorded on other data: here one object is called in rotation with batches of five different kinds, and every call is held to a hint-free object's call on the same
+batch -- the forward's results bit for bit, the gradients to the rounding of sums taken in another order.  bench.py's `value_fresh_inputs` times the same rotation."""
+import pytest
+import torch
+
+from dicp_amd.ICP import ICP
+from dicp_amd.synthetic import make_pairs, make_scene_pairs, make_independent_pairs
+
+DEV = "cuda"
+pytestmark = pytest.mark.gpu
+KW = dict(trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0}, dim=3)
+
+
+def call(icp, S, T, T0):
+    s, t = S.detach().requires_grad_(True), T.detach().requires_grad_(True)
+    o = icp.icp(s, t, T0, **KW)
+    o["T"].sum().backward()
+    torch.cuda.synchronize()
+    return o, s.grad, t.grad
+
+
+@pytest.mark.parametrize("const_iter,K", [(True, 10), (False, 40)])
+def test_rotating_batches_equal_hint_free_objects(const_iter, K):
+    N, n = 64, 16384            # (big enough for every hint to be in play: match certificates, the matrix-core plan from 16384 targets on, the one-launch tail)
+    batches = [make_pairs(N, n, n, seed=s) for s in (1, 2)] + [make_pairs(N, n, n, seed=3, max_rot=0.2, max_trans=1.0), make_scene_pairs(N, n, n, seed=4),
+                                                               make_independent_pairs(N, n, n, seed=5, ragged=False)]
+    batches = [(s.to(DEV), t.to(DEV)) for s, t in batches]
+    T0 = torch.eye(4, device=DEV).repeat(N, 1, 1)
+
+    def new():
+        icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12 if const_iter else 1e-4)
+        icp.const_iter = const_iter
+        return icp
+    want = [call(new(), S, T, T0) for S, T in batches]                         # hint-free: a new object per batch
+    worn = new()
+    for rnd in range(4):                                                        # the same object, 20 calls: every hint it uses comes from another batch
+        for i, (S, T) in enumerate(batches):
+            got = call(worn, S, T, T0)
+            for key in ("T", "deltas", "weights", "costs", "pc"):
+                assert torch.equal(got[0][key], want[i][0][key]), (rnd, i, key)
+            for key in ("iterations", "converged", "matched_ratio"):
+                assert torch.equal(got[0]["stats"][key], want[i][0]["stats"][key]), (rnd, i, key)
+            for g, w in ((got[1], want[i][1]), (got[2], want[i][2])):
+                scale = max(1.0, float(w.abs().max()))
+                assert float((g - w).abs().max()) <= 2e-5 * scale, (rnd, i, float((g - w).abs().max()) / scale)

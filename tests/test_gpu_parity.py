@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from dicp_amd import _lib, _ops
+from dicp_amd import _lib, _loop, _ops
 from dicp_amd.ICP import ICP
 from dicp_amd.loss import loss
 from dicp_amd.nn import nn
@@ -678,6 +678,32 @@ def test_query_order_is_a_permutation_in_bucket_order(dtype):
     assert torch.equal(sw.query_order(xin, None, reproducible=True), sw.query_order(xin, None, reproducible=True))
 
 
+def test_query_reorder_keeps_the_order_of_clouds_that_hardly_moved():
+    """dicp_query_reorder: given the order made under an earlier pose of the call, a cloud whose points have moved by less than a tenth of a unit's x
+    extent keeps it (a copy); a cloud that moved further is sorted again (a permutation in bucket order under the NEW pose)."""
+    g = torch.Generator().manual_seed(17)
+    N, n, m = 4, 8192, 8192
+    x = (torch.rand((N, n, 3), generator=g) * 20 - 10).to(DEV)
+    y = (torch.rand((N, m, 3), generator=g) * 20 - 10).to(DEV)
+    sw = _ops.SweepIndex(y)
+    eye = torch.tensor([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0], dtype=torch.float32).repeat(N, 1).to(DEV)
+    first = sw.query_order(x, eye)
+    moved = eye.clone()
+    moved[0, 9] += 1e-4                                      # 0.1 mm: far below a tenth of 20 m * 128 / 8192 = 0.31 m
+    moved[1, 9] += 0.5                                       # half a metre
+    moved[2, 0], moved[2, 1], moved[2, 3], moved[2, 4] = float(np.cos(0.2)), float(-np.sin(0.2)), float(np.sin(0.2)), float(np.cos(0.2))      # 0.2 rad about z
+    again = sw.query_order(x, moved, pose_prev=eye, order_prev=first)
+    assert again.data_ptr() != first.data_ptr()
+    for b in range(N):
+        assert torch.equal(torch.sort(again[b].long()).values, torch.arange(n, device=DEV)), b
+    assert torch.equal(again[0], first[0]) and torch.equal(again[3], first[3])            # kept
+    assert not torch.equal(again[1], first[1]) and not torch.equal(again[2], first[2])    # sorted again ...
+    key = (x * moved[:, None, 0:3]).sum(dim=2) + moved[:, None, 9]
+    assert rank_buckets_ascend(sw, key.contiguous(), again)                               # ... under the new pose (the kept ones moved by less than a bucket)
+    got = sw.knn(x, moved, again)
+    assert torch.equal(got, _ops.knn(x, moved, _ops.pack_target(y), m, _lib.KNN_VALU))
+
+
 def test_sweep_knn_ties_duplicates_and_pads():
     """Duplicated targets (exact score ties across chunks and tiles) resolve to the lowest ORIGINAL index,
     like torch.argmin; pad rows never win; a fused pose is honoured."""
@@ -1033,7 +1059,7 @@ def test_windowed_backward_kernel_equals_atomic_kernel(dtype, mode, n, m, local)
     alive = torch.tensor([1.0, 1.0, 0.0], dtype=dtype, device=DEV)
     gs = torch.randn((N, 36), generator=gen, dtype=dtype).to(DEV)
     gb = torch.randn((N, 6), generator=gen, dtype=dtype).to(DEV)
-    P = _ops.LoopConfig(icp_type=mode, differentiable=True, max_iterations=1, tolerance=0.0, trim_dist=2.0, loss_name="huber", loss_metric=1.0,
+    P = _loop.LoopConfig(icp_type=mode, differentiable=True, max_iterations=1, tolerance=0.0, trim_dist=2.0, loss_name="huber", loss_metric=1.0,
                         dim=3, const_iter=True, tanh_steepness=10.0, match_ratio_thresh=0.01).params()
     st = _ops._stream()
 

@@ -303,8 +303,8 @@ def test_tail_launch_only_where_a_clouds_blocks_are_all_resident():
 
 def test_a_wait_that_ran_out_is_raised_not_returned():
     """The error word of the tail launch travels with the live counters; a record that reports one makes the NEXT backward pass (and
-    ICP.check_errors) raise _ops.TailTimeout.  (The wait itself cannot be made to run out on a healthy GPU: the word is raised by hand.)"""
-    from dicp_amd._ops import TailTimeout
+    ICP.check_errors) raise _loop.TailTimeout.  (The wait itself cannot be made to run out on a healthy GPU: the word is raised by hand.)"""
+    from dicp_amd._loop import TailTimeout
     N, n, K = 12, 8192, 8
     src, tgt = make_pairs(N, n, n, seed=93)
     icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
@@ -329,8 +329,8 @@ def test_a_wait_that_ran_out_is_raised_not_returned():
 def test_strict_errors_raise_in_the_failing_pass(monkeypatch):
     """ICP.strict_errors: the pass that used the tail waits for itself and raises before it returns a gradient (the error word is raised by hand: the
     library's memset of the pass's workspace is followed by a fill of that word, on the same stream, before the pass's kernels)."""
-    from dicp_amd import _ops
-    from dicp_amd._ops import TailTimeout
+    from dicp_amd import _loop
+    from dicp_amd._loop import TailTimeout
     N, n, K = 12, 8192, 8
     src, tgt = make_pairs(N, n, n, seed=93)
     icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
@@ -338,7 +338,7 @@ def test_strict_errors_raise_in_the_failing_pass(monkeypatch):
     _tail_call(icp, src, tgt)
     _tail_call(icp, src, tgt)                               # (strict and healthy: nothing raised)
     assert icp.knn_stats["bwd_tail_from"] > 0
-    real = _ops._strict_tail_check
+    real = _loop._strict_tail_check
     seen = []
 
     def raised(cfg, word):
@@ -346,7 +346,7 @@ def test_strict_errors_raise_in_the_failing_pass(monkeypatch):
             word.fill_(1)                                   # what bwd_tail_kernel does when a wait runs out
             seen.append(1)
         return real(cfg, word)
-    monkeypatch.setattr(_ops, "_strict_tail_check", raised)
+    monkeypatch.setattr(_loop, "_strict_tail_check", raised)
     S = src.to(DEV).requires_grad_(True)
     Tg = tgt.to(DEV).requires_grad_(True)
     out = icp.icp(S, Tg, torch.eye(4, device=DEV).repeat(N, 1, 1), trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0})
@@ -354,7 +354,7 @@ def test_strict_errors_raise_in_the_failing_pass(monkeypatch):
         out["T"].sum().backward()
     assert seen and S.grad is None and Tg.grad is None      # no gradient was handed to the caller
     icp.strict_errors = False
-    monkeypatch.setattr(_ops, "_strict_tail_check", real)
+    monkeypatch.setattr(_loop, "_strict_tail_check", real)
     _tail_call(icp, src, tgt)
 
 

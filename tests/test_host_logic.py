@@ -162,17 +162,17 @@ def test_graph_capture_refuses_host_drawn_gumbel_noise():
 
 
 def test_resort_schedule_by_size(monkeypatch):
-    """dicp_amd._ops.resort_schedule: an explicit schedule is taken as given; by default small calls without certificates re-order before iterations 0 and 1 only."""
-    from dicp_amd import _ops
-    monkeypatch.setattr(_ops, "CERT_MIN_WORK", 2.0e6)          # (the shipped threshold: tests/conftest.py runs this module with certificates at every size)
-    assert _ops.resort_schedule((0, 2), 256, 16384, 10, True, None) == (0, 2)
-    assert _ops.resort_schedule(None, 256, 16384, 10, True, None) == (0, 1, 2, 3)            # the headline shape: certificates pay, full schedule
-    assert _ops.resort_schedule(None, 32, 4096, 10, True, None) == (0, 1)                     # configs[1]: 131072 points, no certificates at this size
-    assert _ops.resort_schedule(None, 64, 8192, 10, True, None) == (0, 1, 2, 3)               # 524288 points: the full schedule stays best (profiles/r04_mid_size_resort.txt)
-    assert _ops.resort_schedule(None, 32, 4096, 100, True, None) == (0, 1, 2, 3)              # a long call: 96 certified iterations x 131072 points pay for certificates
-    assert _ops.resort_schedule(None, 32, 4096, 100, False, None) == (0, 1)                   # ... unless they are switched off
-    assert _ops.resort_schedule(None, 1, 65, 2, True, None) == (0, 1)
+    """dicp_amd._loop.resort_schedule: an explicit schedule is taken as given; by default small calls without certificates re-order before iterations 0 and 1 only."""
+    from dicp_amd import _loop
+    monkeypatch.setattr(_loop, "CERT_MIN_WORK", 2.0e6)          # (the shipped threshold: tests/conftest.py runs this module with certificates at every size)
+    assert _loop.resort_schedule((0, 2), 256, 16384, 10, True, None) == (0, 2)
+    assert _loop.resort_schedule(None, 256, 16384, 10, True, None) == (0, 1, 2, 3)            # the headline shape: certificates pay, full schedule
+    assert _loop.resort_schedule(None, 32, 4096, 10, True, None) == (0, 1)                     # configs[1]: 131072 points, no certificates at this size
+    assert _loop.resort_schedule(None, 64, 8192, 10, True, None) == (0, 1, 2, 3)               # 524288 points: the full schedule stays best (profiles/r04_mid_size_resort.txt)
+    assert _loop.resort_schedule(None, 32, 4096, 100, True, None) == (0, 1, 2, 3)              # a long call: 96 certified iterations x 131072 points pay for certificates
+    assert _loop.resort_schedule(None, 32, 4096, 100, False, None) == (0, 1)                   # ... unless they are switched off
+    assert _loop.resort_schedule(None, 1, 65, 2, True, None) == (0, 1)
     # ADVICE r4: a size where certificates do not pay under the full schedule (certifying search at iteration 3) but would under the short one (at 1) keeps the
     # full schedule: the short one was measured for calls without certificates only, and the loop derives the certificates from the schedule it is handed
-    assert not _ops.certificates_pay(True, 13, 3, 49, 4096) and _ops.certificates_pay(True, 13, 1, 49, 4096)
-    assert _ops.resort_schedule(None, 49, 4096, 13, True, None) == (0, 1, 2, 3)
+    assert not _loop.certificates_pay(True, 13, 3, 49, 4096) and _loop.certificates_pay(True, 13, 1, 49, 4096)
+    assert _loop.resort_schedule(None, 49, 4096, 13, True, None) == (0, 1, 2, 3)

@@ -712,9 +712,26 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
         bfm_traffic, bfm_src = pmc_traffic("knn_f16_kernel", B, n)
         last_ms = times[-1] * 1e3                                        # the call that carried the events
         share = {nm: (sum(v) / last_ms if v else 0.0) for nm, v in ev_ms.items()}
+        # which scoring form each iteration's search took: the plan the object's earlier calls of this shape left (dicp_loop_buffers.sweep_form_plan; 0 = the default
+        # by size, the matrix cores from 16384 targets on), the certifying search and the guard launches are vector code
+        forms = None
+        if on_gpu and not brute and certified is not None:
+            try:
+                rec = icp._hints.form_record(torch.device("cuda", torch.cuda.current_device()), (B, n, m, torch.float32))
+                plan = rec.get("plan") or [0]
+                cf_ = max(k for k in (icp._tuning.get("sweep_resort") or (0, 1, 2, 3)) if k < K)
+                f16_default = m >= _ops.F16_SWEEP_MIN_TARGETS
+                forms = [("matrix cores" if ((plan[min(k, len(plan) - 1)] == 2) or (plan[min(k, len(plan) - 1)] == 0 and f16_default)) else "vector") if k < cf_
+                         else ("vector, certifying" if k == cf_ else "guard (vector)") for k in range(K)]
+            except Exception:       # (a diagnostic: never the reason a line is lost)
+                forms = None
         legs = {
             "knn": {"kernel": "knn (%s)" % ("brute force, " + args.knn if brute else "exact sorted sweep: same indices as brute force"),
-                    "bound": "valu", "executes_on": "valu f32 fma (same 157.3 TF peak as the f32 MFMA; the two share the ALUs)",
+                    "bound": "valu", "executes_on": ("valu f32 fma (same 157.3 TF peak as the f32 MFMA; the two share the ALUs)" if forms is None else
+                                                      "per iteration as forms_by_iteration says: the plain searches of long slabs score on the matrix cores (knn_f16_sweep_kernel: "
+                                                      "split-f16 filter on v_mfma_f32_32x32x16_f16, 32 executed f16 flop per pair, + exact float32 refine), the others on the "
+                                                      "float32 vector ALUs; `achieved` counts SURVEY 8d's 8 flop per scored pair for either form against the float32 peak"),
+                    "forms_by_iteration": forms,
                     "achieved": knn_tf, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": knn_tf / F32_PEAK_TFLOPS if knn_tf else None,
                     "traffic": knn_traffic, "traffic_source": knn_src, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC)",

@@ -649,15 +649,27 @@ __device__ __forceinline__ void f16_sweep_unit(const float* __restrict__ src, co
             tr[g].add(cm, chunk);
         }
     };
-    auto prunable = [&](float edge, bool right) {
+    // what a skipped row would have to beat, per lane: the largest of its four queries' bounds.  Taken ONCE per round of the loop below (a right and a left
+    // tile): the left side's test then uses bounds that the right tile of the same round may just have lowered -- a stale bound is only larger, so a side
+    // ends at most one tile later than it could, and the 20 vector instructions of the second evaluation per round are gone (round 6: the loop is bound by
+    // its vector instructions, 20 per MFMA; profiles/r06_knn_f16_sweep.txt)
+    float dreq = __builtin_huge_valf();
+    auto bound = [&]() {
         // (a query's best so far is the smaller of its two lanes' -- each lane sees half of every tile's rows)
-        float dreq = -__builtin_huge_valf();
+        float d = -__builtin_huge_valf();
 #pragma unroll
-        for (int g = 0; g < F16_G; ++g) dreq = vmax(dreq, fmaf(vmin(tr[g].b1, swap32(tr[g].b1)), kA, k0[g]));
+        for (int g = 0; g < F16_G; ++g) d = vmax(d, fmaf(vmin(tr[g].b1, swap32(tr[g].b1)), kA, k0[g]));
+        return d;
+    };
+    auto prunable = [&](float edge, bool right) {
         const float dx = right ? edge - xmax : xmin - edge;
         return __all(dx > 0.f && 0.5f * dx * dx > dreq) != 0;       // (inf thresholds: never)
     };
+#if defined(DICP_F16_ABLATE) && DICP_F16_ABLATE == 1      // (timing builds only, scripts/f16_ablate.sh: the prologue alone)
+    if (spos && lane == 0) spos[(size_t)cloud * n_full + unit] = (int)(xq[0] + k0[1]) + tR; return;
+#endif
     while (tR < ntiles || tL >= 0) {
+        dreq = bound();
         if (tR < ntiles) {
             if (prunable(edgeR, true)) tR = ntiles;
             else {
@@ -682,6 +694,9 @@ __device__ __forceinline__ void f16_sweep_unit(const float* __restrict__ src, co
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // (the row cache's copies have landed)
     __builtin_amdgcn_wave_barrier();
+#if defined(DICP_F16_ABLATE) && DICP_F16_ABLATE == 2      // (timing builds only: prologue + the sweep)
+    if (spos && kh == 0) { for (int g = 0; g < F16_G; ++g) if (qi[g] >= 0) spos[(size_t)cloud * n_full + qi[g]] = tr[g].id1 + (int)tr[g].b2 + (int)tr[g].b3 + tr[g].id2 + visR - visL; } return;
+#endif
     // Where a cached row lies.  The refine reads RUNS of 16 rows, every lane its own run, all lanes row k of their run at the same time: laid out in row
     // order those reads fall on the same four LDS banks for every run (a run is 256 bytes = all 64 banks) and were served one run at a time -- bank
     // conflicts on 81 % of the LDS cycles of this kernel (profiles/r04_knn_c4_65536_pmc.txt).  Row i of run R (of the 4 F16_NTC runs of the cache) is kept
@@ -786,6 +801,9 @@ __device__ __forceinline__ void f16_sweep_unit(const float* __restrict__ src, co
             bS[g] = lt ? r0 + first : bS[g];
         }
     }
+#if defined(DICP_F16_ABLATE) && DICP_F16_ABLATE == 3      // (timing builds only: everything up to and including the winners' rows)
+    if (spos && kh == 0) { for (int g = 0; g < F16_G; ++g) if (qi[g] >= 0) spos[(size_t)cloud * n_full + qi[g]] = bS[g] + ties; } return;
+#endif
     // The rare paths below run over the four B tiles in a LOOP (one copy of the code, the tile's values picked with selects): unrolled four times they
     // made the kernel 40 KB of instructions that every wave streamed through once -- the instruction fetches cost more than the scoring.
     static_assert(F16_G == 4, "pick4 below picks one of four");

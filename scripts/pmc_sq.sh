@@ -14,8 +14,8 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1] + "/p*/**/*_counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "knn_sweep_kernel" in k or "accumulate_kernel" in k or "accumulate_bwd_window" in k:
-            short = k.split("::")[1].split("(")[0]
+        if "knn_sweep_kernel" in k or "knn_f16_sweep_kernel" in k or "accumulate_kernel" in k or "accumulate_bwd_window" in k:
+            short = k.split("::")[1].split("(")[0] if "::" in k else k.split("(")[0][-60:]
             agg[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(sys.argv[1] + "/summary.txt", "w") as out:
     for k in sorted(agg):

@@ -143,7 +143,8 @@ __device__ __forceinline__ void window_body(const WeightParams& P, const T* __re
     __shared__ T red[(BLOCK / WAVE) * NBWD_PAD];
     constexpr int SPB = 4 * BLOCK;                          // window_slots() never exceeds this
     __shared__ T contrib[SPB * CV];                         // target-row contribution of each of the block's slots
-    __shared__ int head[WT], next[SPB];                     // per window row: list of the slots that matched it
+    __shared__ int head[WT], next[SPB];                     // per window row: list of the slots that matched it (a slot whose match lies OUTSIDE the window keeps the row there)
+    __shared__ int far_list[SPB], far_n;                    // ... and the slots with such matches
     const int tid = threadIdx.x;
     const int nc = rows_of(src_rows, cloud, n);             // ragged batches: slots past the cloud's own carry weight 0: no work, zero gradient
     const int s0 = blk * spb, s1 = min(nc, s0 + spb), s1_all = min(n, s0 + spb);
@@ -166,6 +167,7 @@ __device__ __forceinline__ void window_body(const WeightParams& P, const T* __re
     for (int u = 0; u < U; ++u) pos[u] = on[u] ? min(max(match_at(spos, cloud, pos[u]), 0), m_pad - 1) : 0;     // -1 (no neighbour: non-finite input) -> row 0
     if (slab)
         for (int k = tid; k < hi - lo; k += BLOCK) head[k] = -1;
+    if (tid == 0) far_n = 0;
     T C[9], r[3], Gs[36], Gb[6];
     load_pose(pose, cloud, C, r);
 #pragma unroll
@@ -235,14 +237,28 @@ __device__ __forceinline__ void window_body(const WeightParams& P, const T* __re
                     dv[0] = gy[0]; dv[1] = gy[1]; dv[2] = gy[2];
                     if (MODE == MODE_PT2PL) { dv[3] = gn[0]; dv[4] = gn[1]; dv[5] = gn[2]; }
                 } else {
-                    T* row = gfar + (size_t)pos[u] * CV;
-                    unsafeAtomicAdd(&row[0], gy[0]); unsafeAtomicAdd(&row[1], gy[1]); unsafeAtomicAdd(&row[2], gy[2]);
-                    if (MODE == MODE_PT2PL) { unsafeAtomicAdd(&row[3], gn[0]); unsafeAtomicAdd(&row[4], gn[1]); unsafeAtomicAdd(&row[5], gn[2]); }
+                    // outside the window: float atomics into gts_far -- issued below with a row's CV floats in CV consecutive lanes.  One lane adding its own
+                    // row's CV floats makes every wave instruction touch 64 rows, 64 memory-side requests (MI355X_MICROARCH.md, global float atomics); on
+                    // clouds that keep moving MOST contributions of the early iterations come this way (a launch took 0.38 ms there, more than the
+                    // all-atomic kernel's 0.28: profiles/r06_backward_far_rows.txt)
+                    const int sl = base - s0 + u * BLOCK + tid;
+                    T* row = contrib + sl * CV;
+                    row[0] = gy[0]; row[1] = gy[1]; row[2] = gy[2];
+                    if (MODE == MODE_PT2PL) { row[3] = gn[0]; row[4] = gn[1]; row[5] = gn[2]; }
+                    next[sl] = pos[u];
+                    far_list[atomicAdd(&far_n, 1)] = sl;
                 }
             }
         }
     }
     __syncthreads();
+    if (slab && gfar) {     // the out-of-window contributions: element e of the flattened [far slot][column] list per lane
+        const int ne = far_n * CV;
+        for (int e = tid; e < ne; e += BLOCK) {
+            const int f = e / CV, col = e - f * CV, sl = far_list[f];
+            unsafeAtomicAdd(gfar + (size_t)next[sl] * CV + col, contrib[sl * CV + col]);
+        }
+    }
     if (slab) {     // one thread per window row; this block is the only writer of its slab rows
         T* out = slab + ((size_t)cloud * bpc + blk) * (WT * CV);
         for (int rr = tid; rr < hi - lo; rr += BLOCK) {

@@ -163,6 +163,8 @@ _SIGNATURES = {
     "dicp_loop_finish": ([i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp], ctypes.c_int),
     "dicp_accumulate_bwd_window": ([i32, ctypes.POINTER(WeightParams), vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp], ctypes.c_int),
     "dicp_resolve_matches": ([vp, vp, i32, vp, i32, i32, vp, vp], ctypes.c_int),
+    "dicp_match_order_scratch_bytes": ([i32, i32, i32], ctypes.c_size_t),
+    "dicp_match_order": ([i32, vp, vp, i32, i32, vp, ctypes.c_size_t, vp, vp], ctypes.c_int),
     "dicp_window_reduce": ([i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, i32, vp], ctypes.c_int),
     "dicp_permute_add_rows": ([i32, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp], ctypes.c_int),
     "dicp_pose_grad_in": ([i32, vp, vp, i32, vp], ctypes.c_int),

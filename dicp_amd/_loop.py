@@ -790,10 +790,10 @@ def _bwd_windowed_setup(B):
         # The forward's query order comes from a counting sort whose order inside a bucket is the arrival order of LDS adds: fine for a search
         # (exact for any order), but the backward takes its sums by slot.  Any permutation serves as slot order: here a STABLE sort of the
         # queries by their reference match (the best locality the windows can have; a cloud's pad rows last, in index order).
-        key = spos_ref.to(torch.int64)
-        if cfg.src_rows is not None:
-            key = torch.where(torch.arange(n, device=dev)[None, :] < cfg.src_rows[:, None].to(torch.int64), key, torch.full_like(key, 2 ** 40))
-        qo = torch.argsort(key, dim=1, stable=True).to(torch.int32)
+        qo = torch.empty((N, n), dtype=torch.int32, device=dev)
+        nbytes = int(lib.dicp_match_order_scratch_bytes(B.code, N, n))
+        scratch = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        _lib.check(lib.dicp_match_order(B.code, _p(spos_ref), _p(cfg.src_rows), N, n, _p(scratch), nbytes, _p(qo), B.st), "dicp_match_order")
         if B.want_tgt:
             B.det_row = torch.empty((N, n), dtype=torch.int32, device=dev)
             B.det_val = torch.empty((N, n, B.cv), dtype=dt, device=dev)

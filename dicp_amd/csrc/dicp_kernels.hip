@@ -675,6 +675,46 @@ int dicp_resolve_matches(const int32_t* spos, const int32_t* spos_of, int k, con
     return launch_status();
 }
 
+// The slot order of ICP.deterministic's backward: the queries in a STABLE order of their reference matches (dicp_sweep_sort's radix sort on the match
+// positions as keys) -- the same permutation on every run, windows as local as they can be.  (Round 5 took it from torch.argsort: the one torch operator on
+// the product's per-call path.)
+static size_t match_order_parts(int dtype, int N, int n, size_t* keys3, size_t* keys_sorted, size_t* tperm, size_t* sort_scratch) {
+    const size_t es = dtype == DICP_F32 ? 4 : 8, m_pad = (size_t)dicp_padded_targets(n);
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t off = 0;
+    *keys3 = off; off = up(off + (size_t)N * n * 3 * es);
+    *keys_sorted = off; off = up(off + (size_t)N * m_pad * es);
+    *tperm = off; off = up(off + (size_t)N * m_pad * 4);
+    *sort_scratch = off; off = up(off + dicp_sweep_sort_scratch_bytes(dtype, N, (int)m_pad));
+    return off;
+}
+size_t dicp_match_order_scratch_bytes(int dtype, int N, int n) {
+    if (bad_dtype(dtype) || N <= 0 || n <= 0) return 0;
+    size_t a, b, c, d;
+    return match_order_parts(dtype, N, n, &a, &b, &c, &d);
+}
+int dicp_match_order(int dtype, const int32_t* spos_ref, const int32_t* src_rows, int N, int n, void* scratch, size_t scratch_bytes, int32_t* qorder, void* stream) {
+    if (!spos_ref || !scratch || !qorder) return DICP_ERR_NULL;
+    if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
+    if (N <= 0 || n <= 0) return DICP_ERR_SHAPE;
+    if ((uintptr_t)scratch & 255) return DICP_ERR_ALIGN;
+    size_t k3, ks, tp, sc;
+    if (scratch_bytes < match_order_parts(dtype, N, n, &k3, &ks, &tp, &sc)) return DICP_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    char* W = (char*)scratch;
+    const int m_pad = dicp_padded_targets(n);
+    begin_launch();
+    const int bpc = (int)blocks_for((size_t)n);
+    if (dtype == DICP_F32) match_keys_kernel<float><<<grid_for(N, bpc), BLOCK, 0, st>>>(spos_ref, src_rows, N, n, bpc, (float*)(W + k3));
+    else                   match_keys_kernel<double><<<grid_for(N, bpc), BLOCK, 0, st>>>(spos_ref, src_rows, N, n, bpc, (double*)(W + k3));
+    if (const int rc = launch_status()) return rc;
+    const size_t sort_bytes = dicp_sweep_sort_scratch_bytes(dtype, N, m_pad);
+    if (const int rc = dicp_sweep_sort(dtype, W + k3, 3, nullptr, nullptr, N, n, m_pad, W + ks, (int32_t*)(W + tp), 0, nullptr, nullptr, sort_bytes ? W + sc : nullptr, sort_bytes, stream)) return rc;
+    // the first n entries of each cloud's sorted order (the slots past n are the sort's own pads, last): a strided device copy
+    if (hipError_t e = hipMemcpy2DAsync(qorder, (size_t)n * 4, W + tp, (size_t)m_pad * 4, (size_t)n * 4, (size_t)N, hipMemcpyDeviceToDevice, st)) return -(int)e;
+    return 0;
+}
+
 int dicp_window_blocks(int dtype, int n, int m_pad) {
     if (n <= 0 || m_pad <= 0) return 0;
     const int spb = window_slots(dtype == DICP_F32 ? WindowRows<float>::v : WindowRows<double>::v, n, m_pad);

@@ -492,6 +492,20 @@ __global__ __launch_bounds__(BLOCK) void resolve_matches_kernel(const MatchHist 
     if (q < h.n) out[(size_t)cloud * h.n + q] = q < rows_of(src_rows, cloud, h.n) ? match_at(h, cloud, q) : -1;
 }
 
+// keys[b][q][0] = the sorted position of query q's match as a float (a cloud's pad rows and queries without a match: the largest finite value, so that a
+// stable sort leaves them last in index order): the keys dicp_match_order sorts.  Match positions are below 2^24: exact in float32.
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void match_keys_kernel(const int32_t* __restrict__ spos_ref, const int32_t* __restrict__ src_rows, int N, int n, int bpc, T* __restrict__ keys3) {
+    int cloud, blk;
+    if (!decode_block(bpc, N, cloud, blk)) return;
+    const int q = blk * BLOCK + threadIdx.x;
+    if (q >= n) return;
+    const int v = q < rows_of(src_rows, cloud, n) ? spos_ref[(size_t)cloud * n + q] : -1;
+    T* o = keys3 + ((size_t)cloud * n + q) * 3;
+    o[0] = v >= 0 ? (T)v : big_v<T>();
+    o[1] = o[2] = T(0);
+}
+
 // ---------------------------------------------------------------------- step bwd
 // Truncated reverse sweep.  Going backwards through the iterations, what iteration k adds to every gradient is LINEAR in the cotangent
 // (G_A + G_A^T, g_b)_k of its normal equations, with coefficients (the per-point Jacobians, residuals, weights) of the same size in every

@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define DICP_ABI_VERSION 11  /* 11: dicp_search_frame takes the queries (src under T_init): the sort direction is chosen for THEIR slabs; dicp_query_reorder (a re-ordering
-                                keeps the order of a cloud that hardly moved); dicp_loop_buffers.sweep_form_plan (one scoring form per iteration from an earlier call's tallies).
+                                keeps the order of a cloud that hardly moved); dicp_loop_buffers.sweep_form_plan (one scoring form per iteration from an earlier call's tallies); dicp_match_order (the deterministic backward's slot order, natively).
                                 10: dicp_pack_list / dicp_unpack_list (lists of clouds to one padded batch and back, one launch each).
                                 9: dicp_loop_buffers.det_far_row / det_far_val (deterministic target gradients of the windowed backward).
                                 8: certified iterations keep a row cache and their match history by reference (dicp_loop_buffers.spos_of / cert_nbr / cert_gdirty /
@@ -502,6 +502,11 @@ int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_
  * (dicp_loop_buffers.spos_of; NULL: iteration k's own slab, a plain copy): what places the windows of the backward pass (spos_ref). */
 int dicp_resolve_matches(const int32_t* spos, const int32_t* spos_of, int k, const int32_t* src_rows /* optional (N): -1 for the rows past a cloud's own */,
                          int N, int n, int32_t* out, void* stream);
+/* The slot order of a DETERMINISTIC windowed backward (dicp_loop_buffers.det_far_row): qorder (N,n) = the queries in a stable order of their reference matches
+ * spos_ref (N,n) (sorted positions; -1 and a cloud's rows past src_rows: last, in index order) -- the same permutation on every run.  dicp_sweep_sort's stable
+ * radix sort on the positions as keys; scratch: dicp_match_order_scratch_bytes(dtype, N, n) bytes, 256-byte aligned. */
+size_t dicp_match_order_scratch_bytes(int dtype, int N, int n);
+int dicp_match_order(int dtype, const int32_t* spos_ref, const int32_t* src_rows, int N, int n, void* scratch, size_t scratch_bytes, int32_t* qorder, void* stream);
 
 
 /* Backward of dicp_step for iteration k.  gpose_in (N,12) double = cotangent of pose_out

@@ -94,6 +94,8 @@ def test_new_entry_points_reject_bad_arguments(lib):
     assert lib.dicp_query_order(0, one, None, None, 1024, 1, 1, one, None, None, None, 0, None, 0, None, None, 0, None, None, None) == 1
     assert lib.dicp_query_order(9, one, None, one, 1024, 1, 1, one, None, None, None, 0, None, 0, None, None, 0, None, None, None) == 3
     assert lib.dicp_query_order(0, one, None, one, 1024, 1, 1, one, None, None, None, 0, None, 0, one, one, 0, None, None, None) == 2      # keys without m
+    assert lib.dicp_match_order(0, None, None, 1, 1, one, 1 << 20, one, None) == 1 and lib.dicp_match_order(0, one, None, 1, 1, one, 0, one, None) in (2, 5)      # (no matches; scratch too small or misaligned)
+    assert lib.dicp_match_order_scratch_bytes(0, 0, 16) == 0 and lib.dicp_match_order_scratch_bytes(0, 2, 100) >= 2 * 100 * 12 + 2 * 128 * 8
     # dicp_query_reorder(dtype, src, pose, pose_prev, order_prev, brange, nbkt, N, n, qorder, m_pad, skeys, bucket, m, src_rows, tgt_rows, stream): both poses and the order before
     assert lib.dicp_query_reorder(0, one, None, one, one, one, 1024, 1, 1, one, 0, None, None, 0, None, None, None) == 1
     assert lib.dicp_query_reorder(0, one, one, one, None, one, 1024, 1, 1, one, 0, None, None, 0, None, None, None) == 1

@@ -128,3 +128,31 @@ def test_the_reference_pair_takes_the_deterministic_path_too():
     assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
     for a, b in zip(outs[0], outs[2]):
         assert float((a - b).abs().max()) <= 1e-10 * max(1.0, float(b.abs().max()))
+
+
+@pytest.mark.parametrize("dtype,N,n", [(torch.float32, 3, 5000), (torch.float32, 2, 16384), (torch.float32, 2, 20011), (torch.float64, 3, 3001)])
+def test_match_order_is_the_stable_sort_of_the_matches(dtype, N, n):
+    """dicp_match_order (the deterministic backward's slot order, round 6: the library's own stable radix sort in place of torch.argsort): the queries in
+    ascending order of their reference match, equal matches in index order, queries without a match and a cloud's rows past its own last."""
+    import ctypes
+    g = torch.Generator().manual_seed(n)
+    spos = torch.randint(0, n // 3, (N, n), generator=g, dtype=torch.int32)          # (many queries share a match: stability is visible)
+    spos[:, ::97] = -1
+    rows = torch.tensor([n - 7 * b - 1 for b in range(N)], dtype=torch.int32)
+    lib = _lib.load()
+    code = _lib.F32 if dtype == torch.float32 else _lib.F64
+    for src_rows in (None, rows.to(DEV)):
+        sd = spos.to(DEV)
+        qo = torch.full((N, n), -5, dtype=torch.int32, device=DEV)
+        nbytes = int(lib.dicp_match_order_scratch_bytes(code, N, n))
+        scratch = torch.empty((nbytes,), dtype=torch.uint8, device=DEV)
+        rc = lib.dicp_match_order(code, ctypes.c_void_p(sd.data_ptr()), ctypes.c_void_p(src_rows.data_ptr()) if src_rows is not None else None, N, n,
+                                  ctypes.c_void_p(scratch.data_ptr()), nbytes, ctypes.c_void_p(qo.data_ptr()), None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        key = spos.to(torch.int64)
+        key[key < 0] = 2 ** 40
+        if src_rows is not None:
+            key = torch.where(torch.arange(n)[None, :] < rows[:, None].to(torch.int64), key, torch.full_like(key, 2 ** 40))
+        want = torch.argsort(key, dim=1, stable=True).to(torch.int32)
+        assert torch.equal(qo.cpu(), want), (dtype, N, n, src_rows is not None)

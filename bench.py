@@ -167,6 +167,16 @@ def run_call(icp, src, tgt, T0, world):
     return out, T_all, s.grad, t.grad
 
 
+_T_START = time.perf_counter()
+
+
+def progress(msg):
+    """One line per leg on stderr (stdout carries the JSON line only): a long run shows where it is -- and, should a leg fail, which one."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        sys.stderr.write("[bench %6.1f s] %s\n" % (time.perf_counter() - _T_START, msg))
+        sys.stderr.flush()
+
+
 def cpu_baseline(n, m, budget_s=25.0):
     """The oracle (reference op sequence: cdist -> argmin -> gather -> ... -> linalg.inv -> matrix_exp)
     on this host's cores, fwd+bwd, on a bounded sample: chunks of 4 clouds x 3 iterations
@@ -517,9 +527,11 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
     bwd_live = [int(v) for v in bwd_live[:K].tolist()] if bwd_live is not None else None
 
     # ---- the other legs, in the same run (each the median of its own timed calls)
+    progress("timed calls done (K = %d): %.3f ms per call" % (K, elapsed * 1e3))
     extra = {}
     if not args.no_extra_legs:
         if K != 10:
+            progress("leg: value_k10")
             k10 = new_icp(10)
             steady(k10, data, least=3, most=8)
             kt, _, _ = timed(k10, data, reps)
@@ -529,6 +541,7 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
         # A training loop presents NEW clouds of the same shape every step, and what an ICP object carries from call to call (CallHints: tail placement,
         # certificate pauses, the scoring forms' plan) was learned on other data.  The K = 10 call of ONE object rotating over four different batches
         # (every timed call's hints come from another batch); results do not depend on hints (tests/test_gpu_hints.py), time may.
+        progress("leg: value_fresh_inputs")
         fresh = [data] + [tuple(x.to(dev) for x in make_pairs(B, n, m, seed=101 + i, dtype=torch.float32, first=rank * B)) for i in range(3)]
         fr = new_icp(10)
         for d_ in fresh + fresh:
@@ -547,6 +560,7 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
                                       % (len(ft), len(fresh), median(ft) * 1e3, min(ft) * 1e3, max(ft) * 1e3))
         del fr, fresh
         if not brute:
+            progress("leg: value_bruteforce (matrix cores, VALU)")
             for key, kv, what in (("value_bruteforce", L.KNN_MFMA, "the matrix-core brute force (split-f16 filter on v_mfma_f32_32x32x16_f16 + exact float32 refine)"),
                                   ("value_bruteforce_valu", L.KNN_VALU, "the float32 FMA brute-force kernel")):
                 bf = new_icp(K, knn=kv)
@@ -555,6 +569,7 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
                 extra[key] = world * B * K / median(bt)
                 extra[key.replace("value_", "") + "_note"] = "same call with %s (all n*m pairs, same indices) in the loop: median of 3 calls, %.3f ms per step" % (what, median(bt) * 1e3 / K)
                 del bf
+        progress("leg: value_tolerance")
         tol = new_icp(50, tol=1e-4, const_iter=False)
         steady(tol, data, least=3, most=8)
         tt, (tout, _, _, _), _ = timed(tol, data, reps)
@@ -564,6 +579,7 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
                                    "median of %d calls" % (k_exec, median(tt) * 1e3, reps))
         del tol, tout
         # LiDAR-like scenes: planar structure, two walls perpendicular to the sweep's sort axis
+        progress("leg: value_structured")
         s2, t2 = make_scene_pairs(B, n, m, seed=3, dtype=torch.float32, first=rank * B)
         scene = (s2.to(dev), t2.to(dev))
         sc = new_icp(K)
@@ -628,6 +644,7 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
             return rec, fin
         indep = {}
         for name, K_, ci, rg in (("k10", 10, True, False), ("tolerance", 50, False, False), ("k10_ragged_lists", 10, True, True), ("tolerance_ragged_lists", 50, False, True)):
+            progress("leg: value_independent / %s" % name)
             indep[name], fin_ = indep_leg(K_, ci, rg, 5)
             sane = sane and fin_
         extra["value_independent"] = indep["k10"]["cloud_it_per_s"]
@@ -638,10 +655,12 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
                                      "*_ragged_lists: the same clouds with lengths in [0.75, 1] x %d handed over as Python lists (the host's list handling is inside the call)"
                                      % (extra.get("value_k10", float("nan")), n))
         if on_gpu and world == 1:
+            progress("legs: configs[1], configs[3] slice and full batch, configs[0]")
             extra.update(other_configs(make_icp, dev, sync))
     gc.enable()
 
     # the pose all-gather on its own (N > 1): the collective bench.py overlaps with the backward, timed alone between fences
+    progress("extra legs done")
     gather_ms = None
     if use_dist:
         gtimes = []
@@ -681,6 +700,7 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
     # ---- the gate, on every rank: finite everywhere; rank 0 also holds its timed call against the oracle
     gate, base = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        progress("cpu baseline (bounded sample) and oracle gate")
         base = cpu_baseline(n, m)
         gate, ok = oracle_gate(src[:2], tgt[:2], K, out["T"][:2], gs[:2], gt[:2])
         sane = sane and ok

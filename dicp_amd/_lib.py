@@ -43,7 +43,7 @@ class StepIO(ctypes.Structure):
                 ("converged", vp), ("iterations", vp), ("matched_ratio", vp), ("n_start", vp),
                 ("n_matched", vp), ("w_cur", vp), ("w_prev", vp), ("w_stride", i64), ("n_not_converged", vp),
                 ("frame", vp), ("pose_search_out", vp), ("rmax", vp), ("dcum", vp), ("dcum_stride", i64), ("cert_cloud", vp),
-                ("cert_qu", vp), ("cert_units", i32), ("glist_cap", i32), ("glist", vp), ("gcount", vp), ("cert_scount", vp), ("w_copied", i32)]
+                ("cert_qu", vp), ("cert_units", i32), ("glist_cap", i32), ("glist", vp), ("gcount", vp), ("cert_scount", vp), ("cert_slist", vp), ("w_copied", i32)]
 
 
 class LoopBuffers(ctypes.Structure):

@@ -94,7 +94,10 @@ class CallHints:
                     rec[4] = True       # (looked at)
                     if int(rec[0][rec[3]]) != 0:
                         raise TailTimeout("dicp_amd: a wait of an earlier backward pass's one-launch tail ran out (the GPU was kept full by other work for "
-                                          "~0.5 s); the gradients of that pass were poisoned with NaN.  Re-run it, or set ICP._tuning['bwd_tail'] = False")
+                                          "~0.5 s); the gradients of that pass were poisoned with NaN.  Re-run it, or set ICP._tuning['bwd_tail'] = False"
+                                          "  [report word 0x%08x: arrivals seen %d, block %d, generation %d; live clouds by iteration %s]"
+                                          % (int(rec[0][rec[3]]) & 0xffffffff, (int(rec[0][rec[3]]) >> 16) & 0xfff, (int(rec[0][rec[3]]) >> 8) & 0xff,
+                                             int(rec[0][rec[3]]) & 0xff, rec[0][:rec[3]].tolist()))
 
 
 CERT_MIN_WORK = 2.0e6        # certified point-iterations (iterations after the certifying search x N x n) below which match certificates are not used

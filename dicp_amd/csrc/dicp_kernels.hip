@@ -992,7 +992,7 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
             if (Qp > 0) {
                 io.cert_qu = B->cert_qu; io.cert_units = (n + WAVE * Qp - 1) / (WAVE * Qp); io.glist_cap = guard_list_cap(N, n);
                 io.glist = B->cert_glist; io.gcount = B->cert_gcount + (size_t)(k + 1) * 8;
-                io.cert_scount = B->cert_set ? B->cert_scount : nullptr;
+                io.cert_scount = B->cert_set ? B->cert_scount : nullptr; io.cert_slist = B->cert_set ? B->cert_slist : nullptr;
             }
         }
         rc = dicp_step(dtype, &io, N, stream);
@@ -1131,6 +1131,16 @@ int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_
         begin_launch();
         const WeightParams P = to_params(prm);
         double* dst = ((k1 - k0) & 1) ? gpose_tmp : gpose;            // where the alternating buffers would have left it
+        if (gin == dst) {
+            // (an even number of iterations left for the launch: it would read the cotangent from the buffer it writes the result to.  Block 0 of a cloud whose
+            //  sweep ends at its first iteration here is through its product chain in microseconds and writes the cloud's result -- and a block of the same
+            //  cloud that is dispatched after that (the grid is larger than what is resident at once) would start from the RESULT as its cotangent, reach
+            //  another verdict than its siblings and wait for them in vain: the TailTimeout seen every few hundred calls on planar scenes in rounds 5 and 6.
+            //  The launch reads from the other buffer instead: 12 doubles per cloud to copy.)
+            double* other = gin == gpose ? gpose_tmp : gpose;
+            if (hipMemcpyAsync(other, gin, (size_t)N * 12 * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) return -(int)hipGetLastError();
+            gin = other;
+        }
         const unsigned g = grid_for(N, nblk);
 #define DICP_TAILB(T, M) do { constexpr int WT = WindowRows<T>::v; \
         bwd_tail_kernel<T, M, WT><<<g, BLOCK, 0, st>>>(P, *B, N, n, dim, window_slots(WT, n, B->m_pad), nblk, gin, dst, have_partials, \

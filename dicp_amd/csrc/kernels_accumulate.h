@@ -299,7 +299,7 @@ __host__ __device__ inline dicp_step_io make_step_io(const dicp_loop_buffers& B,
     io.n_not_converged = B.counters + k;
     io.rmax = B.rmax; io.dcum = B.dcum; io.dcum_stride = 2 * (B.K + 1);
     io.cert_cloud = B.cert_cloud;
-    io.cert_qu = nullptr; io.cert_units = 0; io.glist_cap = 0; io.glist = nullptr; io.gcount = nullptr; io.cert_scount = nullptr;      // (dicp_icp_forward fills them in for a certified iteration)
+    io.cert_qu = nullptr; io.cert_units = 0; io.glist_cap = 0; io.glist = nullptr; io.gcount = nullptr; io.cert_scount = nullptr; io.cert_slist = nullptr;      // (dicp_icp_forward fills them in for a certified iteration)
     io.w_copied = 0;
     return io;
 }
@@ -475,7 +475,17 @@ __device__ __forceinline__ void step_body(const dicp_step_io& io, int cloud, int
             if (!certs_on) { if (tid == 0) io.cert_scount[cloud] = 0; }
             else {
                 const int nwr = (io.n + WAVE - 1) / WAVE;
-                const int nch = (min(io.cert_scount[cloud], io.n) + WAVE - 1) / WAVE;
+                const int have = min(io.cert_scount[cloud], io.n);
+                const int nch = (have + WAVE - 1) / WAVE;
+                // The list is handed over in WHOLE chunks: the tail of the last one is filled with -1 (no slot) and the length moved up to it.  The guard launch
+                // that re-scores these chunks also APPENDS to the list (a query that gets a new set): an append inside a chunk another of its waves is reading
+                // showed that wave an entry whose slot, set budget and candidate rows were not written yet -- whatever the memory held, and a row gather from
+                // there (round 6: a memory fault once in a few hundred calls on planar scenes, as soon as the buffers stopped being the previous call's own).
+                if (io.cert_slist && nch > 0) {
+                    const int upto = min(nch * WAVE, io.n);
+                    for (int e = have + tid; e < upto; e += WAVE) io.cert_slist[(size_t)cloud * io.n + e] = -1;
+                    if (tid == 0 && upto > have) io.cert_scount[cloud] = upto;
+                }
                 if (nch > 0) {
                     int base = 0;
                     if (tid == 0) base = atomicAdd(io.gcount + (cloud & 7), nch);

@@ -236,7 +236,15 @@ __device__ __forceinline__ void window_body(const WeightParams& P, const T* __re
                     T* dv = det_val + pt * CV;
                     dv[0] = gy[0]; dv[1] = gy[1]; dv[2] = gy[2];
                     if (MODE == MODE_PT2PL) { dv[3] = gn[0]; dv[4] = gn[1]; dv[5] = gn[2]; }
-                } else {
+                }
+#ifdef DICP_FAR_DIRECT      // (A/B builds, scripts/build_variant.sh: round 5's form -- every lane adds its own row's floats)
+                else {
+                    T* row = gfar + (size_t)pos[u] * CV;
+                    unsafeAtomicAdd(&row[0], gy[0]); unsafeAtomicAdd(&row[1], gy[1]); unsafeAtomicAdd(&row[2], gy[2]);
+                    if (MODE == MODE_PT2PL) { unsafeAtomicAdd(&row[3], gn[0]); unsafeAtomicAdd(&row[4], gn[1]); unsafeAtomicAdd(&row[5], gn[2]); }
+                }
+#else
+                else {
                     // outside the window: float atomics into gts_far -- issued below with a row's CV floats in CV consecutive lanes.  One lane adding its own
                     // row's CV floats makes every wave instruction touch 64 rows, 64 memory-side requests (MI355X_MICROARCH.md, global float atomics); on
                     // clouds that keep moving MOST contributions of the early iterations come this way (a launch took 0.38 ms there, more than the
@@ -248,6 +256,7 @@ __device__ __forceinline__ void window_body(const WeightParams& P, const T* __re
                     next[sl] = pos[u];
                     far_list[atomicAdd(&far_n, 1)] = sl;
                 }
+#endif
             }
         }
     }
@@ -1018,7 +1027,11 @@ __global__ __launch_bounds__(BLOCK, sizeof(T) == 4 ? 2 : 1) void bwd_tail_kernel
                     const double worst = gmax * amp > mm ? gmax * amp : mm;
                     if (!nan && 16.0 * worst <= B.bwd_skip_eps * smref) verdict = 2;
                     else {
-                        if (!nan && mm > smref) { smref = mm; if (blk == 0) B.bwd_mref[cloud] = mm; }
+                        // (kept in the block until the launch ends: a sibling block that STARTS after block 0 has been here -- dispatch is in index order, not
+                        //  simultaneous -- would read the raised value where block 0 compared with the old one, could reach another verdict for this very
+                        //  iteration and leave, and the cloud's other blocks would wait for it until their patience ran out: the TailTimeout seen once in a
+                        //  thousand calls on planar scenes, rounds 5 and 6)
+                        if (!nan && mm > smref) smref = mm;
                         if (blk == 0 && B.bwd_live) atomicAdd(B.bwd_live + k, 1);
                     }
                 }
@@ -1065,8 +1078,9 @@ __global__ __launch_bounds__(BLOCK, sizeof(T) == 4 ? 2 : 1) void bwd_tail_kernel
                 int spins = 0;
                 while (__hip_atomic_load(arrive + cloud, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
                     if (++spins > (1 << 20)) {              // ~0.5 s: the cloud's other blocks are not running (dicp_bwd_tail_max_blocks keeps that from happening)
-                        atomicExch(arrive + N, 1);
-                        if (B.bwd_live) atomicExch(B.bwd_live + B.K, 1);
+                        // (nonzero = a wait ran out; the words say whose, for the report: cloud and iteration | arrivals seen, block, generation)
+                        atomicExch(arrive + N, 0x40000000 | ((cloud & 0xffff) << 8) | (k & 0xff));
+                        if (B.bwd_live) atomicExch(B.bwd_live + B.K, 0x40000000 | ((__hip_atomic_load(arrive + cloud, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xfff) << 16) | ((blk & 0xff) << 8) | (gen & 0xff));
                         s_timeout = 1;
                         break;
                     }
@@ -1084,5 +1098,6 @@ __global__ __launch_bounds__(BLOCK, sizeof(T) == 4 ? 2 : 1) void bwd_tail_kernel
     if (blk == 0) {
         fold(cur);
         if (tid < 12) gpose_out[(size_t)cloud * 12 + tid] = sg[tid];
+        if (tid == 0) B.bwd_mref[cloud] = smref;            // (the largest contribution measure so far, for a later chunk's launches)
     }
 }

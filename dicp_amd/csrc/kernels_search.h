@@ -809,9 +809,12 @@ __device__ __forceinline__ void guard_sets(const T* __restrict__ src, const T* _
                                            int N, int n_full, int m_pad, const SweepCert<T>& ct, const int cloud, const int chunk) {
     using T4 = typename V4<T>::type;
     const int lane = threadIdx.x & (WAVE - 1);
+    // (entries of this chunk were all written before this launch: the step kernel hands the list over in whole chunks, their tails filled with -1, and this
+    //  launch's own appends go behind them)
     const int cnt = min(ct.scount[cloud], n_full), e = chunk * WAVE + lane;
-    const bool have = e < cnt;
-    const size_t at = (size_t)cloud * n_full + (have ? min(max(ct.slist[(size_t)cloud * n_full + e], 0), n_full - 1) : 0);
+    const int slot = e < cnt ? ct.slist[(size_t)cloud * n_full + e] : -1;
+    const bool have = slot >= 0 && slot < n_full;
+    const size_t at = (size_t)cloud * n_full + (have ? slot : 0);
     const T spent = cert_spent(ct.dcum + (size_t)cloud * ct.dstride + 2 * ct.k);
     const T b = ct.q[at], sb = set_budgets<T>(ct.set)[at];
     const bool on = have && !(b > spent) && b < T(0) && sb > spent;        // (the set still stands, and the query has no budget of its own)

@@ -47,7 +47,10 @@ constexpr int F16_G = 4;                // B tiles (32 queries each) per wave: 1
 constexpr int F16_CHT = 4;              // A tiles per chunk of the lane-local bookkeeping
 constexpr int F16_FAR_MAX = 64;
 constexpr int F16_NTC = 8;              // sweep form: 64-row tiles whose float32 rows a wave keeps in LDS for its refine
-constexpr int F16_SCAN_MAX = 6;         // sweep form: up to this many queries of a wave with three or more candidate pieces are scanned exactly instead of filtered again
+#ifndef DICP_F16_SCAN_MAX
+#define DICP_F16_SCAN_MAX 6
+#endif
+constexpr int F16_SCAN_MAX = DICP_F16_SCAN_MAX;         // sweep form: up to this many queries of a wave with three or more candidate pieces are scanned exactly instead of filtered again
 enum { FM_S = 0, FM_INV_S2 = 1, FM_PHI = 2, FM_NFAR = 3, FM_HPHI = 4, FM_FAR_ABOVE = 5, FM_AGAIN = 6 /* queries sent through pass 2, added up */,
        FM_SCAN = 7 /* queries scored against every row */, FM_FAR0 = 8 };
 constexpr float F16_P = 8192.f;

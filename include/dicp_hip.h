@@ -273,6 +273,8 @@ typedef struct dicp_step_io {
     int32_t* glist;          /* (8, glist_cap) int32: entry = cloud * cert_units + unit, list = cloud & 7 (the XCD the cloud's blocks run on) */
     int32_t* gcount;         /* (8) zeros: entries in each list of the next iteration */
     int32_t* cert_scount;    /* optional (N): lengths of the clouds' candidate-set lists (dicp_loop_buffers.cert_scount): 64 sets make one more entry, -1 - (cloud * ceil(n/64) + chunk) */
+    int32_t* cert_slist;     /* with cert_scount, (N, n): the lists themselves -- the step fills the tail of a list's last chunk of 64 with -1 and moves the length up to it, so that the
+                                next guard launch's appends never land inside a chunk that launch is re-scoring */
     int32_t w_copied;        /* 1: the accumulate launch of this iteration already wrote w_prev into w_cur for the clouds that are frozen (alive = 0;
                                 dicp_icp_forward does): the step then has nothing to copy for them (ICP.py:224-226) */
 } dicp_step_io;
@@ -421,6 +423,8 @@ typedef struct dicp_loop_buffers {
                                 more of its kind); a GPU kept full by other work for longer than the wait's bound (~0.5 s) can still make one run out.  The
                                 block then stops waiting for good and folds NaN from there on: the cloud's pose cotangent and (part of) its point gradients
                                 come out NaN, never as plausible wrong numbers, and the caller must treat the error word as a failed call.
+                                (Nonzero = failed.  The words also say whose wait it was, for the report: [N] = 0x40000000 | cloud << 8 | iteration;
+                                bwd_live[K] = 0x40000000 | arrivals seen << 16 | block << 8 | generation.)
                                 Hand-off between the blocks (hardware assumption, gfx950): the pose sums are written and read with agent-scope atomic
                                 accesses (sc1: served by the memory side, coherent across the XCDs' L2s) and counted with an agent-scope atomic add after
                                 the storing wave's s_waitcnt vmcnt(0) -- MI355X_MICROARCH's measured hand-off form, not the C++ memory model's release /

@@ -39,7 +39,7 @@ def test_struct_layouts_match_header(lib):
     expect = ["partials", "nblk", "iter", "dim", "const_iter", "tolerance", "rows_per_point", "n", "pose_in", "pose_out",
               "delta", "delta_stride", "cost", "cost_prev", "cost_stride", "areg", "alive", "alive_out", "converged", "iterations",
               "matched_ratio", "n_start", "n_matched", "w_cur", "w_prev", "w_stride", "n_not_converged", "frame", "pose_search_out",
-              "rmax", "dcum", "dcum_stride", "cert_cloud", "cert_qu", "cert_units", "glist_cap", "glist", "gcount", "cert_scount", "w_copied"]
+              "rmax", "dcum", "dcum_stride", "cert_cloud", "cert_qu", "cert_units", "glist_cap", "glist", "gcount", "cert_scount", "cert_slist", "w_copied"]
     assert [f[0] for f in _lib.StepIO._fields_] == expect
     hdr = open(os.path.join(ROOT, "include", "dicp_hip.h")).read()
     body = hdr[hdr.index("typedef struct dicp_step_io {"):hdr.index("} dicp_step_io;")]

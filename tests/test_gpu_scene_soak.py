@@ -1,0 +1,39 @@
+"""Back-to-back calls on planar scenes at the benchmark shape (`-m gpu`): the workload on which the reverse sweep's one-launch tail has clouds
+still at work inside it, and the match certificates' guard has candidate sets to re-check -- the two places where a block depends on what
+another block of the same launch wrote.  Round 6 found a race in each (profiles/r06_scene_soak.txt), each once in a few hundred calls, neither
+on the random clouds of the other tests: a few hundred calls here, every one of them finite and none raising TailTimeout, and the same
+gradients from the first call and the last.  scripts/scene_soak.py runs the same loop for thousands of calls."""
+import pytest
+import torch
+
+from dicp_amd.ICP import ICP
+from dicp_amd.synthetic import make_scene_pairs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("tail", [True, False])
+def test_scene_calls_back_to_back(tail):
+    B, n, K, calls = 256, 16384, 20, 400
+    S, T = make_scene_pairs(B, n, n, seed=3)
+    S, T = S.cuda(), T.cuda()
+    T0 = torch.eye(4, device="cuda").repeat(B, 1, 1)
+    icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
+    icp.const_iter = True
+    icp._tuning["bwd_tail"] = tail
+    first = None
+    for i in range(calls):
+        s, t = S.detach().requires_grad_(True), T.detach().requires_grad_(True)
+        out = icp.icp(s, t, T0, trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0})      # (raises TailTimeout of an earlier pass)
+        out["T"].sum().backward()
+        if i == 0 or i % 50 == 49 or i == calls - 1:
+            torch.cuda.synchronize()
+            assert bool(torch.isfinite(out["T"]).all()) and bool(torch.isfinite(s.grad).all()) and bool(torch.isfinite(t.grad).all()), "call %d" % i
+            if first is None:
+                first = (out["T"].clone(), s.grad.clone(), t.grad.clone())
+    torch.cuda.synchronize()
+    icp.icp(S, T, T0, trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0})                # (looks at the last passes' error words)
+    assert torch.equal(out["T"], first[0])
+    # (float atomics on the out-of-window rows: the order of the adds differs from call to call)
+    for a, b in ((s.grad, first[1]), (t.grad, first[2])):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())

@@ -1,3 +1,5 @@
 set -x
 export TMPDIR=/tmp
-timeout -k 10 1100 python -m pytest tests -m gpu -x -q > gpurun_out/gputest.log 2>&1; echo "pytest rc=$?"; tail -5 gpurun_out/gputest.log
+timeout -k 10 500 python bench.py --steps 20 --warmup 3 > gpurun_out/bench_k20.json 2> gpurun_out/bench_k20.err; echo "k20 rc=$?"
+timeout -k 10 400 python bench.py > gpurun_out/bench_k10.json 2> gpurun_out/bench_k10.err; echo "k10 rc=$?"
+bash scripts/profile_bench.sh prof_final e38ad2c

@@ -732,7 +732,7 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
         bfm_traffic, bfm_src = pmc_traffic("knn_f16_kernel", B, n)
         last_ms = times[-1] * 1e3                                        # the call that carried the events
         share = {nm: (sum(v) / last_ms if v else 0.0) for nm, v in ev_ms.items()}
-        # which scoring form each iteration's search took: the plan the object's earlier calls of this shape left (dicp_loop_buffers.sweep_form_plan; 0 = the default
+        # which scoring form each iteration's search took: the plan the object's earlier calls of this shape left (dicp_loop_buffers.search.form_plan; 0 = the default
         # by size, the matrix cores from 16384 targets on), the certifying search and the guard launches are vector code
         forms = None
         if on_gpu and not brute and certified is not None:

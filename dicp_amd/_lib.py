@@ -46,17 +46,50 @@ class StepIO(ctypes.Structure):
                 ("cert_qu", vp), ("cert_units", i32), ("glist_cap", i32), ("glist", vp), ("gcount", vp), ("cert_scount", vp), ("cert_slist", vp), ("w_copied", i32)]
 
 
+class SearchBuffers(ctypes.Structure):
+    """dicp_search_buffers (include/dicp_hip.h)."""
+    _fields_ = [("knn_variant", i32), ("m_pad", i32), ("tgt4", vp), ("tperm", vp), ("qorder", vp), ("bucket", vp), ("brange", vp), ("nbkt", i32), ("pairs", vp), ("frame", vp), ("poses", vp),
+                ("tgt_sorted", vp), ("tgt_sorted_stride", i32), ("gumbel", vp), ("first_done", i32), ("tgt_f16", vp), ("form", vp), ("form_default", i32), ("form_plan", vp)]
+
+
+class CertBuffers(ctypes.Structure):
+    """dicp_cert_buffers (include/dicp_hip.h)."""
+    _fields_ = [("q", vp), ("qu", vp), ("set", vp), ("count", vp), ("rmax", vp), ("dcum", vp), ("reset", i32), ("cloud", vp), ("nbr", vp), ("gdirty", vp), ("pend", vp), ("glist", vp),
+                ("gcount", vp), ("slist", vp), ("scount", vp), ("cm", vp)]
+
+
+class HistoryBuffers(ctypes.Structure):
+    """dicp_history_buffers (include/dicp_hip.h)."""
+    _fields_ = [("per_iter", i32), ("spos", vp), ("poses", vp), ("deltas", vp), ("costs", vp), ("areg", vp), ("alive", vp), ("idx", vp), ("w", vp), ("w_iter", i64), ("w_stride", i64),
+                ("w_prev0", vp), ("spos_prev_chunk", vp), ("spos_floor", i32), ("spos_of", vp), ("spos_of_from", i32)]
+
+
+class BwdBuffers(ctypes.Structure):
+    """dicp_bwd_buffers (include/dicp_hip.h)."""
+    _fields_ = [("spos_ref", vp), ("gts_far", vp), ("overwrite", i32), ("skip", vp), ("mref", vp), ("live", vp), ("skip_eps", f64), ("tail_from", i32), ("tail_partials", vp),
+                ("tail_arrive", vp), ("det_far_row", vp), ("det_far_val", vp)]
+
+
 class LoopBuffers(ctypes.Structure):
-    """dicp_loop_buffers (include/dicp_hip.h)."""
-    _fields_ = [("src", vp), ("tgt", vp), ("w_init", vp), ("c", i32), ("K", i32), ("knn_variant", i32), ("m_pad", i32),
-                ("tgt4", vp), ("tperm", vp), ("qorder", vp), ("bucket", vp), ("brange", vp), ("nbkt", i32), ("idx_per_iter", i32),
-                ("pairs", vp), ("spos", vp), ("spos_ref", vp), ("gts_far", vp), ("poses", vp), ("deltas", vp), ("costs", vp), ("areg", vp), ("alive", vp), ("converged", vp),
-                ("iterations", vp), ("matched_ratio", vp), ("n_start", vp), ("n_matched", vp), ("idx", vp), ("w", vp), ("w_iter", i64), ("w_stride", i64), ("w_prev0", vp),
-                ("partials", vp), ("counters", vp), ("events", vp), ("bwd_overwrite", i32), ("frame", vp), ("poses_search", vp),
-                ("src_rows", vp), ("tgt_rows", vp), ("cert_q", vp), ("cert_qu", vp), ("cert_set", vp), ("cert_count", vp), ("rmax", vp), ("dcum", vp),
-                ("cert_reset", i32), ("cert_cloud", vp), ("spos_prev_chunk", vp), ("spos_floor", i32), ("spos_of", vp), ("spos_of_from", i32),
-                ("cert_nbr", vp), ("cert_gdirty", vp), ("cert_pend", vp), ("cert_glist", vp), ("cert_gcount", vp), ("cert_slist", vp), ("cert_scount", vp), ("cert_cm", vp), ("tgt_sorted", vp), ("tgt_sorted_stride", i32),
-                ("bwd_skip", vp), ("bwd_mref", vp), ("bwd_live", vp), ("bwd_skip_eps", f64), ("bwd_tail_from", i32), ("bwd_tail_partials", vp), ("bwd_tail_arrive", vp), ("gumbel", vp), ("first_search_done", i32), ("tgt_f16", vp), ("sweep_form", vp), ("sweep_form_default", i32), ("sweep_form_plan", vp), ("det_far_row", vp), ("det_far_val", vp)]
+    """dicp_loop_buffers (include/dicp_hip.h): one versioned struct, the buffers of the search / the certificates / the histories / the backward in sub-structs."""
+    _fields_ = [("abi", i32), ("src", vp), ("tgt", vp), ("w_init", vp), ("c", i32), ("K", i32), ("converged", vp), ("iterations", vp), ("matched_ratio", vp), ("n_start", vp), ("n_matched", vp),
+                ("partials", vp), ("counters", vp), ("events", vp), ("src_rows", vp), ("tgt_rows", vp),
+                ("search", SearchBuffers), ("cert", CertBuffers), ("hist", HistoryBuffers), ("bwd", BwdBuffers)]
+
+    def __init__(self, **kw):
+        """Keywords: the top-level fields by name, the sub-structs' as search_<field> / cert_<field> / hist_<field> / bwd_<field>."""
+        super().__init__(abi=ABI_VERSION)
+        subs = (self, self.search, self.cert, self.hist, self.bwd)
+        where = LoopBuffers._KW
+        for k, v in kw.items():
+            if v is not None:           # (a fresh struct is all zeros)
+                i, f = where[k]
+                setattr(subs[i], f, v)
+
+
+LoopBuffers._KW = dict([(f[0], (0, f[0])) for f in LoopBuffers._fields_[:-4]] +
+                       [(g + "_" + f[0], (i + 1, f[0])) for i, (g, cls) in enumerate((("search", SearchBuffers), ("cert", CertBuffers), ("hist", HistoryBuffers), ("bwd", BwdBuffers)))
+                        for f in cls._fields_])
 
 
 class GumbelLoop(ctypes.Structure):
@@ -65,7 +98,7 @@ class GumbelLoop(ctypes.Structure):
 
 
 MAX_SEGMENTS = 16
-CERT_OFF_FOR_GOOD = 1 << 20     # dicp_loop_buffers.cert_cloud[:, 2]: the cloud's certificates are off for the rest of the call
+CERT_OFF_FOR_GOOD = 1 << 20     # dicp_loop_buffers.cert.cloud[:, 2]: the cloud's certificates are off for the rest of the call
 
 
 class SegmentPlan(ctypes.Structure):

@@ -17,7 +17,7 @@ from ._ops import (_DT, _LOSS, SweepIndex, _Arena, _converged_at, _gather_rows_r
 
 
 def form_tally_wanted(rec, have_image):
-    """Whether a call's plain searches should tally their slabs' tiles per cloud (dicp_loop_buffers.sweep_form): when this call REPORTS (the first two calls of a shape
+    """Whether a call's plain searches should tally their slabs' tiles per cloud (dicp_loop_buffers.search.form): when this call REPORTS (the first two calls of a shape
     and every sixteenth: CallHints.form_record), or when its searches choose each cloud's scoring form by the tallies -- the matrix-core image exists (or the record
     says the shape's slabs are long: it will) and no earlier report has given the shape a plan yet.  The tally is an atomic add per unit of the sweep onto one word
     per cloud: 0.03 ms of the search near the pose, 1.6 % of the benchmark's call (round 5, A/B on one box)."""
@@ -154,7 +154,7 @@ class LoopConfig:
     cert_from: object = None      # iteration of the certifying search (None: the last re-ordering of the queries)
     gumbel: object = None         # (eps, tau, inject_U or None): the Gumbel-softmax correspondence (nn.py:43-70) instead of the nearest neighbour
     deterministic: bool = False   # backward: the same bits on every run (slot order from a stable sort, window rows summed in slot order, out-of-window rows without float atomics)
-    bwd_tail: bool = True         # truncated reverse sweep: the iterations before the ones the previous call still worked at run as ONE launch (dicp_loop_buffers.bwd_tail_from)
+    bwd_tail: bool = True         # truncated reverse sweep: the iterations before the ones the previous call still worked at run as ONE launch (dicp_loop_buffers.bwd.tail_from)
     strict_errors: bool = False   # a pass that used that launch waits for itself and raises TailTimeout if a wait inside it ran out (ICP.strict_errors)
     plan_call: bool = True        # constant-iteration sweep calls: all segments behind one library call (dicp_icp_forward_plan)
     first_search: bool = True     # sweep path: iteration 0's search is enqueued right behind the index build
@@ -309,7 +309,7 @@ def _fwd_search_setup(S):
     S.m_pad = S.tgt4.shape[1] if S.tgt4 is not None else 0
     # the matrix-core searches' image of the packed rows (the sweep path: of the sorted rows, made with the index)
     img16 = f16_image(S.tgt4, m, cfg.tgt_rows) if kind == _lib.KNN_MFMA else (sweep.img16 if sweep is not None else None)
-    # The scoring form of the plain searches (dicp_loop_buffers.sweep_form / sweep_form_plan).  Every plain search of a REPORTING call tallies its slabs' tiles per
+    # The scoring form of the plain searches (dicp_loop_buffers.search.form / search.form_plan).  Every plain search of a REPORTING call tallies its slabs' tiles per
     # cloud; what the tallies of an earlier call of this shape said (a hint, like the tail's and the certificates': it arrives through pinned memory, costs time
     # at worst) decides whether this call builds the matrix-core image for clouds too small to get one by size (some cloud's slabs were long: start poses a metre
     # off, a third of the source without counterpart) and which form each iteration's search takes for the whole batch; until a report has arrived the searches
@@ -410,7 +410,7 @@ def _fwd_loop_state(S):
     arena.take((N, 8) if want_certs else (0,), torch.int32)
     arena.take((N, n) if want_certs else (0,), torch.int32)     # (row cache: matches a guard launch leaves for the accumulate of its iteration; zero = none)
     arena.take((Kmax + 1, 8) if want_certs else (0,), torch.int32)     # (lengths of the guard launches' work lists, per iteration)
-    # per-cloud tallies of the plain searches' slab lengths (dicp_loop_buffers.sweep_form)
+    # per-cloud tallies of the plain searches' slab lengths (dicp_loop_buffers.search.form)
     arena.take((Kmax, N) if S.adaptive else (0,), torch.int32)
     arena.take((N,) if (want_certs and cfg.cert_sets) else (0,), torch.int32)     # (lengths of the clouds' candidate-set lists)
     (S.deltas, S.costs, S.converged, S.iterations, S.matched, S.n_matched, S.counters, cert_count, S.cert_cloud, cert_pend, cert_gcount, S.sweep_form,
@@ -419,7 +419,7 @@ def _fwd_loop_state(S):
     if want_certs:
         units = (n + 63) // 64          # (units of the sweep's one-query-per-lane forms; the two-query form uses half of them)
         # (row cache of the certified iterations: the matched row of every query, a filter per 64 queries, and -- with gradients -- where each such
-        #  group's matches lie in the history, which those iterations keep by reference: dicp_loop_buffers.spos_of)
+        #  group's matches lie in the history, which those iterations keep by reference: dicp_loop_buffers.hist.spos_of)
         S.certs = dict(q=torch.empty((N, n), dtype=dt, device=dev), qu=torch.empty((N, units), dtype=dt, device=dev), count=cert_count,
                        nbr=torch.empty((N, n, 6 if cfg.icp_type == "pt2pl" else 3), dtype=dt, device=dev), gdirty=torch.empty((N, units), dtype=torch.int32, device=dev),
                        cm=torch.empty((N, n), dtype=torch.int32, device=dev), glist=torch.empty((8, max(N, 2) * units), dtype=torch.int32, device=dev), gcount=cert_gcount,
@@ -469,7 +469,7 @@ def _fwd_loop_state(S):
                                 eps=float(g_eps), tau=float(g_tau), ps_t=_p(S.ps_t), nbr=_p(S.nbr_hist), lse=_p(S.lse_hist))
         S.g_eps, S.g_tau = float(g_eps), float(g_tau)
     # iteration 0's search may already be running: prebuild_search enqueued it behind the index build (under T_init's search pose and the
-    # first query order), so that the GPU has 0.4 ms of work while this function prepares the loop (dicp_loop_buffers.first_search_done)
+    # first query order), so that the GPU has 0.4 ms of work while this function prepares the loop (dicp_loop_buffers.search.first_done)
     S.first = cfg.prebuilt[2] if (sweep is not None and cfg.prebuilt is not None and cfg.prebuilt[1] is sweep) else None
     S.have_first = (S.first is not None and S.first[0].data_ptr() == S.src.data_ptr() and S.first[0].shape == S.src.shape
                     and S.first[1].data_ptr() == S.T_init.data_ptr() and S.T_init.is_contiguous())
@@ -488,27 +488,27 @@ def _fwd_loop_buffers(S, plan_call):
     """dicp_loop_buffers with the fields that do not change from segment to segment (building the struct is ~20 us of host time)."""
     cfg, sweep, certs = S.cfg, S.sweep, S.certs
     LB = _lib.LoopBuffers(
-        src=_p(S.src), tgt=_p(S.tgt), w_init=_p(S.w0c), c=S.c, K=S.Kmax, knn_variant=S.kind | (cfg.knn_variant & 0xff00) | ((0 if cfg.small_loop else 1) << 25), m_pad=S.m_pad,
-        tgt4=_p(S.tgt4), tperm=_p(sweep.tperm) if sweep else None,
-        bucket=_p(sweep.bucket) if sweep else None, brange=_p(sweep.brange) if sweep else None,
-        nbkt=SweepIndex.NBKT, idx_per_iter=int(S.need_grad), pairs=_p(sweep.pair_shards) if sweep else None,
-        poses=_p(S.poses), deltas=_p(S.deltas), costs=_p(S.costs), areg=_p(S.areg), alive=_p(S.alive), converged=_p(S.converged),
+        src=_p(S.src), tgt=_p(S.tgt), w_init=_p(S.w0c), c=S.c, K=S.Kmax, search_knn_variant=S.kind | (cfg.knn_variant & 0xff00) | ((0 if cfg.small_loop else 1) << 25), search_m_pad=S.m_pad,
+        search_tgt4=_p(S.tgt4), search_tperm=_p(sweep.tperm) if sweep else None,
+        search_bucket=_p(sweep.bucket) if sweep else None, search_brange=_p(sweep.brange) if sweep else None,
+        search_nbkt=SweepIndex.NBKT, hist_per_iter=int(S.need_grad), search_pairs=_p(sweep.pair_shards) if sweep else None,
+        hist_poses=_p(S.poses), hist_deltas=_p(S.deltas), hist_costs=_p(S.costs), hist_areg=_p(S.areg), hist_alive=_p(S.alive), converged=_p(S.converged),
         iterations=_p(S.iterations), matched_ratio=_p(S.matched), n_start=_p(S.n_start), n_matched=_p(S.n_matched),
-        tgt_sorted=_p(sweep.tgt_s) if sweep is not None else None, tgt_sorted_stride=sweep.row_stride if sweep is not None else 0,
-        rmax=_p(certs["rmax"]) if certs else None, dcum=_p(certs["dcum"]) if certs else None,
-        w_iter=S.n, w_stride=S.kc * S.n,
-        partials=_p(S.partials), counters=_p(S.counters), events=S.events, frame=_p(S.center), poses_search=_p(S.poses_c),
-        src_rows=_p(cfg.src_rows), tgt_rows=_p(cfg.tgt_rows), tgt_f16=_p(S.img16),
-        sweep_form=_p(S.sweep_form) if S.adaptive else None, sweep_form_default=sweep.form_default if sweep is not None else 0,
-        sweep_form_plan=ctypes.cast(S.form_plan, ctypes.c_void_p) if S.form_plan is not None else None)
+        search_tgt_sorted=_p(sweep.tgt_s) if sweep is not None else None, search_tgt_sorted_stride=sweep.row_stride if sweep is not None else 0,
+        cert_rmax=_p(certs["rmax"]) if certs else None, cert_dcum=_p(certs["dcum"]) if certs else None,
+        hist_w_iter=S.n, hist_w_stride=S.kc * S.n,
+        partials=_p(S.partials), counters=_p(S.counters), events=S.events, search_frame=_p(S.center), search_poses=_p(S.poses_c),
+        src_rows=_p(cfg.src_rows), tgt_rows=_p(cfg.tgt_rows), search_tgt_f16=_p(S.img16),
+        search_form=_p(S.sweep_form) if S.adaptive else None, search_form_default=sweep.form_default if sweep is not None else 0,
+        search_form_plan=ctypes.cast(S.form_plan, ctypes.c_void_p) if S.form_plan is not None else None)
     if plan_call:       # (one slab of every history: the plan call's segments all write into it)
-        LB.w = _p(S.w_slabs[0])
-        LB.spos = _p(S.spos_slabs[0]) if S.keep_spos else _p(S.spos_once)
-        LB.idx = (_p(S.idx_slabs[0]) if S.need_grad else _p(S.idx_once)) if S.keep_idx else None
-        LB.first_search_done = int(S.first_spos is not None)
-        LB.spos_of = _p(certs["of"]) if certs else None
+        LB.hist.w = _p(S.w_slabs[0])
+        LB.hist.spos = _p(S.spos_slabs[0]) if S.keep_spos else _p(S.spos_once)
+        LB.hist.idx = (_p(S.idx_slabs[0]) if S.need_grad else _p(S.idx_once)) if S.keep_idx else None
+        LB.search.first_done = int(S.first_spos is not None)
+        LB.hist.spos_of = _p(certs["of"]) if certs else None
     if S.gum is not None:
-        LB.gumbel = ctypes.cast(ctypes.pointer(S.gum), ctypes.c_void_p)
+        LB.search.gumbel = ctypes.cast(ctypes.pointer(S.gum), ctypes.c_void_p)
     return LB
 
 
@@ -585,23 +585,23 @@ def _fwd_enqueue_segments(S):
         if LB is None:
             LB = _fwd_loop_buffers(S, False)
             LBref = ctypes.byref(LB)
-        LB.qorder = _p(qorder)
-        LB.first_search_done = int(k0 == 0 and S.first_spos is not None)
-        LB.spos = ctypes.c_void_p(S.spos_slabs[j].data_ptr() - base * N * n * 4) if S.keep_spos else _p(S.spos_once)
-        LB.idx = (ctypes.c_void_p(S.idx_slabs[j].data_ptr() - base * N * n * 4) if S.need_grad else _p(S.idx_once)) if S.keep_idx else None
-        LB.cert_q, LB.cert_qu, LB.cert_count = (_p(certs["q"]), _p(certs["qu"]), _p(certs["count"])) if use_certs else (None, None, None)
-        LB.cert_cloud = _p(S.cert_cloud) if (use_certs and cfg.cert_backoff) else None
-        LB.cert_set = _p(certs["set"]) if use_certs else None
-        LB.cert_nbr, LB.cert_gdirty, LB.cert_pend, LB.cert_cm = (_p(certs["nbr"]), _p(certs["gdirty"]), _p(certs["pend"]), _p(certs["cm"])) if use_certs else (None, None, None, None)
-        LB.cert_glist, LB.cert_gcount = (_p(certs["glist"]), _p(certs["gcount"])) if use_certs else (None, None)
-        LB.cert_slist, LB.cert_scount = (_p(certs["slist"]), _p(certs["scount"])) if use_certs else (None, None)
-        LB.spos_of = _p(certs["of"]) if use_certs else None
-        LB.cert_reset = int(k0 == S.cert_from)
+        LB.search.qorder = _p(qorder)
+        LB.search.first_done = int(k0 == 0 and S.first_spos is not None)
+        LB.hist.spos = ctypes.c_void_p(S.spos_slabs[j].data_ptr() - base * N * n * 4) if S.keep_spos else _p(S.spos_once)
+        LB.hist.idx = (ctypes.c_void_p(S.idx_slabs[j].data_ptr() - base * N * n * 4) if S.need_grad else _p(S.idx_once)) if S.keep_idx else None
+        LB.cert.q, LB.cert.qu, LB.cert.count = (_p(certs["q"]), _p(certs["qu"]), _p(certs["count"])) if use_certs else (None, None, None)
+        LB.cert.cloud = _p(S.cert_cloud) if (use_certs and cfg.cert_backoff) else None
+        LB.cert.set = _p(certs["set"]) if use_certs else None
+        LB.cert.nbr, LB.cert.gdirty, LB.cert.pend, LB.cert.cm = (_p(certs["nbr"]), _p(certs["gdirty"]), _p(certs["pend"]), _p(certs["cm"])) if use_certs else (None, None, None, None)
+        LB.cert.glist, LB.cert.gcount = (_p(certs["glist"]), _p(certs["gcount"])) if use_certs else (None, None)
+        LB.cert.slist, LB.cert.scount = (_p(certs["slist"]), _p(certs["scount"])) if use_certs else (None, None)
+        LB.hist.spos_of = _p(certs["of"]) if use_certs else None
+        LB.cert.reset = int(k0 == S.cert_from)
         # (history in several slabs: a certified iteration finds the matches of the slab before its own through spos_prev_chunk)
-        LB.spos_floor = base
-        LB.spos_prev_chunk = ctypes.c_void_p(S.spos_slabs[j - 1].data_ptr() - (j - 1) * kc * N * n * 4) if (S.keep_spos and j > 0) else None
-        LB.w = ctypes.c_void_p(S.w_slabs[j].data_ptr() - base * n * S.es)
-        LB.w_prev0 = _p(S.w_slabs[(k0 - 1) // kc][:, (k0 - 1) % kc]) if k0 > 0 else None
+        LB.hist.spos_floor = base
+        LB.hist.spos_prev_chunk = ctypes.c_void_p(S.spos_slabs[j - 1].data_ptr() - (j - 1) * kc * N * n * 4) if (S.keep_spos and j > 0) else None
+        LB.hist.w = ctypes.c_void_p(S.w_slabs[j].data_ptr() - base * n * S.es)
+        LB.hist.w_prev0 = _p(S.w_slabs[(k0 - 1) // kc][:, (k0 - 1) % kc]) if k0 > 0 else None
         _lib.check(lib.dicp_icp_forward(S.code, ctypes.byref(S.P), LBref, N, n, S.m, int(cfg.dim), int(cfg.const_iter),
                                         float(cfg.tolerance), k0, k1, S.st), "dicp_icp_forward")
         S.done_segs.append((k0, k1))
@@ -700,7 +700,7 @@ def _bwd_begin(ctx, gT, gpc):
     B.qorders = rest[n_idx + n_spos:n_idx + n_spos + n_q]
     B.of_from = getattr(ctx, "of_from", None)
     B.spos_of = None
-    if B.of_from is not None:         # (the certified iterations' match history is kept by reference: dicp_loop_buffers.spos_of)
+    if B.of_from is not None:         # (the certified iterations' match history is kept by reference: dicp_loop_buffers.hist.spos_of)
         B.spos_of, rest = rest[-1], rest[:-1]
     B.tperm, B.tgt_s = (rest[-2], rest[-1]) if B.owned else (None, None)
     B.soft = getattr(ctx, "soft", None)
@@ -811,7 +811,7 @@ def _bwd_windowed_setup(B):
 
 
 def _bwd_truncation_and_tail(B):
-    """The truncated reverse sweep's state (dicp_loop_buffers.bwd_skip) and where the one-launch tail starts (from the previous calls' live counters)."""
+    """The truncated reverse sweep's state (dicp_loop_buffers.bwd.skip) and where the one-launch tail starts (from the previous calls' live counters)."""
     cfg, lib, N, n, K, Kmax, dt, dev = B.cfg, B.lib, B.N, B.n, B.K, B.Kmax, B.dt, B.dev
     # a cloud's sweep ends at the iteration from which on nothing reaches the result's own rounding; the iterations before it do no per-point work.
     # Not with hard Huber weights: their reference gradient is NaN at an exactly zero residual whatever the cotangent.
@@ -830,7 +830,7 @@ def _bwd_truncation_and_tail(B):
         B.skip = sk_arena.finish()          # mref, decisions, live counters (+ the tail's error word), the one-launch tail's per-cloud counters (+ its error word)
         if cfg.stats_out is not None:
             cfg.stats_out["bwd_live"] = B.skip[2]     # (Kmax + 1) int32: clouds that did per-point work in iteration k of the backward; [Kmax]: a wait of the tail ran out
-    # The ended iterations as ONE launch (dicp_loop_buffers.bwd_tail_from).  Where a sweep ends is decided on the device, while the host
+    # The ended iterations as ONE launch (dicp_loop_buffers.bwd.tail_from).  Where a sweep ends is decided on the device, while the host
     # enqueues; what the host can know is where the PREVIOUS call of this shape ended (its live counters, copied to pinned memory behind
     # that call's launches): the iterations at which fewer than an eighth of its clouds were still at work go to the one launch, which
     # sweeps a cloud that is at work after all with its blocks in step -- slower for that cloud (3x per iteration: profiles/r06_backward_forms.txt), exact either way.
@@ -894,19 +894,19 @@ def _bwd_runs(B, gpose, gtmp):
         base = j * kc
         LB = _lib.LoopBuffers(
             src=_p(B.src_s) if w_form else _p(B.src), tgt=_p(B.tgt_s) if w_form else _p(B.tgt),
-            w_init=_p(B.w_s) if w_form else _p(B.w0c), c=B.tgt_s.shape[2] if w_form else B.c, K=Kmax, knn_variant=B.kind | ((0 if cfg.small_loop else 1) << 25), m_pad=B.m_pad, idx_per_iter=1,
-            qorder=_p(B.qo) if w_form else None,
-            spos=ctypes.c_void_p(B.spos_slabs[j].data_ptr() - base * N * n * 4) if w_form else None,
-            spos_ref=_p(B.spos_ref) if w_form else None, gts_far=_p(B.gfar) if w_form else None,
-            spos_of=_p(B.spos_of) if (w_form and B.spos_of is not None) else None, spos_of_from=int(B.of_from) if B.of_from is not None else 0,
-            poses=_p(B.poses), deltas=_p(B.deltas), areg=_p(B.areg), alive=_p(B.alive),
-            idx=ctypes.c_void_p(B.idx_slabs[j].data_ptr() - base * N * n * 4) if B.idx_slabs else None, events=events,
+            w_init=_p(B.w_s) if w_form else _p(B.w0c), c=B.tgt_s.shape[2] if w_form else B.c, K=Kmax, search_knn_variant=B.kind | ((0 if cfg.small_loop else 1) << 25), search_m_pad=B.m_pad, hist_per_iter=1,
+            search_qorder=_p(B.qo) if w_form else None,
+            hist_spos=ctypes.c_void_p(B.spos_slabs[j].data_ptr() - base * N * n * 4) if w_form else None,
+            bwd_spos_ref=_p(B.spos_ref) if w_form else None, bwd_gts_far=_p(B.gfar) if w_form else None,
+            hist_spos_of=_p(B.spos_of) if (w_form and B.spos_of is not None) else None, hist_spos_of_from=int(B.of_from) if B.of_from is not None else 0,
+            hist_poses=_p(B.poses), hist_deltas=_p(B.deltas), hist_areg=_p(B.areg), hist_alive=_p(B.alive),
+            hist_idx=ctypes.c_void_p(B.idx_slabs[j].data_ptr() - base * N * n * 4) if B.idx_slabs else None, events=events,
             bwd_overwrite=fresh if (w_form and k1 > k0) else 0, src_rows=_p(cfg.src_rows), tgt_rows=_p(cfg.tgt_rows),
             bwd_skip=_p(skip[1]) if skip else None, bwd_mref=_p(skip[0]) if skip else None, bwd_live=_p(skip[2]) if skip else None,
             bwd_skip_eps=float(B.eps), bwd_tail_from=int(tail_from) if (w_form and k0 == 0) else 0,
             bwd_tail_partials=_p(tail_part), bwd_tail_arrive=_p(skip[3]) if skip else None,
-            gumbel=ctypes.cast(ctypes.pointer(gum), ctypes.c_void_p) if gum is not None else None,
-            det_far_row=_p(B.det_row) if w_form else None, det_far_val=_p(B.det_val) if w_form else None)
+            search_gumbel=ctypes.cast(ctypes.pointer(gum), ctypes.c_void_p) if gum is not None else None,
+            bwd_det_far_row=_p(B.det_row) if w_form else None, bwd_det_far_val=_p(B.det_val) if w_form else None)
         fresh_was = bool(w_form and k1 > k0 and fresh)
         if w_form and k1 > k0:
             fresh = 0

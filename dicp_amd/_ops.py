@@ -20,8 +20,8 @@ F16_SWEEP_MIN_TARGETS = 16384               # ... and, for a cloud whose slabs h
                                             # sweep form as round 5 left it): at 256 x 16384 the matrix cores win from ~7 tiles per unit of 128 queries on -- 1.38x under the start
                                             # pose (15 tiles), 1.23x after one iteration (10), level after two (5.5), 0.85x after three (4); round 4 had measured 0.92x at 16 tiles,
                                             # and the threshold stood at 32768 targets / 32 tiles until this round.  Smaller clouds: per cloud by the previous plain search's tally of
-                                            # slab lengths (dicp_loop_buffers.sweep_form; FORM_TILES) -- clouds that start metres off, or a third of which has no counterpart
-FORM_PLAN_ITERS = 6                         # iterations whose tallies a reporting call hands to the next calls' plan (dicp_loop_buffers.sweep_form_plan); later ones follow the last
+                                            # slab lengths (dicp_loop_buffers.search.form; FORM_TILES) -- clouds that start metres off, or a third of which has no counterpart
+FORM_PLAN_ITERS = 6                         # iterations whose tallies a reporting call hands to the next calls' plan (dicp_loop_buffers.search.form_plan); later ones follow the last
 FORM_TILES_MOVING = 32                      # tiles per unit in a call's LAST plain search from which on its clouds count as still moving (the backward then orders its slots by the matches)
 F16_SWEEP_STATIC_TARGETS = 32768            # from here on every plain search of every cloud scores on the matrix cores (the per-cloud choice cost 8-10 % of a 64 x 65536 call,
                                             # profiles/r05_form_tally.txt); between the two thresholds iteration 0's search does and the later ones go by the tallies -- planar
@@ -206,7 +206,7 @@ class SweepIndex:
         first_order = (source, T_init, src_rows): the frame is chosen here and everything -- frame, sort, rows, the search pose of iteration 0 and the
         first query order (self.first = (source, T_init, qorder, spos0)) -- goes out in ONE library call (dicp_sweep_setup).
         first_search: iteration 0's search is enqueued right behind it (spos0 (N,n): its matches as sorted positions; None otherwise): 0.4 ms of
-        kernel at the benchmark shape under which the host prepares the loop (dicp_loop_buffers.first_search_done)."""
+        kernel at the benchmark shape under which the host prepares the loop (dicp_loop_buffers.search.first_done)."""
         require_device(tgt, "SweepIndex")
         tgt = tgt.contiguous()
         N, m, c = tgt.shape
@@ -250,7 +250,7 @@ class SweepIndex:
             if first_search:
                 spos0 = torch.empty((N, source.shape[1]), dtype=torch.int32, device=dev)
                 if tally and F16_SWEEP_ADAPTIVE and dt == torch.float32 and float(N) * source.shape[1] >= F16_SWEEP_MIN_QUERIES and bool(F16_SWEEP):
-                    self.form0 = torch.zeros((N,), dtype=torch.int32, device=dev)     # (that search's tally of its slabs' tiles per cloud: dicp_loop_buffers.sweep_form)
+                    self.form0 = torch.zeros((N,), dtype=torch.int32, device=dev)     # (that search's tally of its slabs' tiles per cloud: dicp_loop_buffers.search.form)
                 with _on(dev):
                     _lib.check(lib.dicp_knn_sweep(_DT[dt], _p(source), _p(pose_s), _p(self.tgs4), _p(self.tperm), _p(qorder), _p(self.bucket), _p(self.brange), self.NBKT,
                                                   _p(src_rows), _p(tgt_rows), N, source.shape[1], m, m_pad, None, _p(spos0), _p(self.pair_shards), 0,

@@ -162,20 +162,21 @@ int dicp_call_forward(int dtype, const dicp_weight_params* prm, const dicp_call*
     }
     dicp_loop_buffers B;
     memset(&B, 0, sizeof(B));
+    B.abi = DICP_ABI_VERSION;
     B.src = c->src; B.tgt = c->tgt; B.w_init = c->w0; B.c = c->c; B.K = K;
-    B.knn_variant = DICP_KNN_SWEEP | ((c->flags & DICP_CALL_NO_SMALL_LOOP) ? (1 << 25) : 0);
-    B.m_pad = L.m_pad;
-    B.tgt4 = at(c, L.tgs4); B.tperm = (int32_t*)at(c, L.tperm); B.bucket = (int32_t*)at(c, L.bucket); B.brange = at(c, L.brange);
-    B.nbkt = DICP_CALL_NBKT; B.idx_per_iter = c->need_grad ? 1 : 0; B.pairs = (unsigned long long*)at(c, L.pairs);
-    B.poses = at(c, L.poses); B.deltas = res(c, L.deltas); B.costs = res(c, L.costs); B.areg = c->need_grad ? (double*)at(c, L.areg) : nullptr;
-    B.alive = at(c, L.alive); B.converged = (uint8_t*)res(c, L.converged); B.iterations = res(c, L.iterations); B.matched_ratio = res(c, L.matched_ratio);
+    B.search.knn_variant = DICP_KNN_SWEEP | ((c->flags & DICP_CALL_NO_SMALL_LOOP) ? (1 << 25) : 0);
+    B.search.m_pad = L.m_pad;
+    B.search.tgt4 = at(c, L.tgs4); B.search.tperm = (int32_t*)at(c, L.tperm); B.search.bucket = (int32_t*)at(c, L.bucket); B.search.brange = at(c, L.brange);
+    B.search.nbkt = DICP_CALL_NBKT; B.hist.per_iter = c->need_grad ? 1 : 0; B.search.pairs = (unsigned long long*)at(c, L.pairs);
+    B.hist.poses = at(c, L.poses); B.hist.deltas = res(c, L.deltas); B.hist.costs = res(c, L.costs); B.hist.areg = c->need_grad ? (double*)at(c, L.areg) : nullptr;
+    B.hist.alive = at(c, L.alive); B.converged = (uint8_t*)res(c, L.converged); B.iterations = res(c, L.iterations); B.matched_ratio = res(c, L.matched_ratio);
     B.n_start = at(c, L.n_start); B.n_matched = at(c, L.n_matched);
-    B.tgt_sorted = at(c, L.tgt_sorted); B.tgt_sorted_stride = c->c;
-    B.w_iter = c->n; B.w_stride = (int64_t)K * c->n; B.w = res(c, L.weights);
-    B.spos = spos;
+    B.search.tgt_sorted = at(c, L.tgt_sorted); B.search.tgt_sorted_stride = c->c;
+    B.hist.w_iter = c->n; B.hist.w_stride = (int64_t)K * c->n; B.hist.w = res(c, L.weights);
+    B.hist.spos = spos;
     B.partials = at(c, L.partials); B.counters = (int32_t*)at(c, L.counters);
-    B.frame = at(c, L.frame); B.poses_search = at(c, L.poses_search);
-    B.first_search_done = first_search ? 1 : 0;
+    B.search.frame = at(c, L.frame); B.search.poses = at(c, L.poses_search);
+    B.search.first_done = first_search ? 1 : 0;
     if (int rc = dicp_icp_forward_plan(dtype, prm, &B, &SP, c->N, c->n, c->m, c->dim, 1, c->tolerance, stream)) return rc;
     char* pose_K = at(c, L.poses) + (size_t)K * N * 12 * es;
     if (int rc = dicp_loop_finish(dtype, pose_K, at(c, L.alive) + (size_t)K * N * es, at(c, L.n_start), at(c, L.n_matched), K, c->N, res(c, L.iterations),
@@ -248,20 +249,21 @@ static int backward_once(int dtype, const dicp_weight_params* prm, const dicp_lo
     }
     dicp_loop_buffers B;
     memset(&B, 0, sizeof(B));
+    B.abi = DICP_ABI_VERSION;
     B.src = W + L.src_s; B.tgt = f->tgt_sorted; B.w_init = f->w0 ? W + L.w_s : nullptr; B.c = f->c; B.K = f->K_cap;
-    B.knn_variant = f->knn_variant;
-    B.m_pad = f->m_pad; B.idx_per_iter = 1; B.qorder = qo; B.spos = (int32_t*)f->spos; B.spos_ref = spos_ref; B.gts_far = want_tgt ? W + L.far : nullptr;
-    B.spos_of = (int32_t*)f->spos_of; B.spos_of_from = f->spos_of_from;
-    B.poses = (void*)f->poses; B.deltas = (void*)f->deltas; B.areg = (double*)f->areg; B.alive = (void*)f->alive;
+    B.search.knn_variant = f->knn_variant;
+    B.search.m_pad = f->m_pad; B.hist.per_iter = 1; B.search.qorder = qo; B.hist.spos = (int32_t*)f->spos; B.bwd.spos_ref = spos_ref; B.bwd.gts_far = want_tgt ? W + L.far : nullptr;
+    B.hist.spos_of = (int32_t*)f->spos_of; B.hist.spos_of_from = f->spos_of_from;
+    B.hist.poses = (void*)f->poses; B.hist.deltas = (void*)f->deltas; B.hist.areg = (double*)f->areg; B.hist.alive = (void*)f->alive;
     B.src_rows = f->src_rows; B.tgt_rows = f->tgt_rows;
-    B.bwd_overwrite = 1;
+    B.bwd.overwrite = 1;
     if (skip) {
-        B.bwd_skip = (int32_t*)(W + L.decisions); B.bwd_mref = (double*)(W + L.mref); B.bwd_live = (int32_t*)(W + L.live);
-        B.bwd_tail_arrive = (int32_t*)(W + L.arrive);
+        B.bwd.skip = (int32_t*)(W + L.decisions); B.bwd.mref = (double*)(W + L.mref); B.bwd.live = (int32_t*)(W + L.live);
+        B.bwd.tail_arrive = (int32_t*)(W + L.arrive);
     }
-    B.bwd_skip_eps = g->skip_eps;
-    B.bwd_tail_from = tail_from;
-    B.bwd_tail_partials = tail_from > 0 ? W + L.tail_partials : nullptr;
+    B.bwd.skip_eps = g->skip_eps;
+    B.bwd.tail_from = tail_from;
+    B.bwd.tail_partials = tail_from > 0 ? W + L.tail_partials : nullptr;
     if (int rc = dicp_icp_backward(dtype, prm, &B, f->N, f->n, f->m, f->dim, gpose, gtmp, 0, W + L.gs, W + L.gb, W + L.gsrc_s, want_tgt ? W + L.slab : nullptr,
                                    want_w ? W + L.gw_s : nullptr, W + L.partials, 0, K, stream))
         return rc;

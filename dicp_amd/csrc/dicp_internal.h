@@ -27,7 +27,7 @@ int knn_f16_brute(const void* src, const void* pose, const void* tgt4, void* ima
 // the exact sorted sweep (dicp_knn_sweep's plain search, units of 128 queries) with the scoring on the matrix cores; image = the image of the SORTED packed
 // rows tgs4; ev0 / ev1: optional hipEvent_t carried on the dispatch.  form_in / form_out / form_tiles / form_default: optional (N) tallies of 64-row tiles per
 // cloud -- given form_in the launch takes only the clouds with more than form_tiles tiles per unit in it (a cloud without a tally: if form_default); form_out is
-// added to (dicp_loop_buffers.sweep_form)
+// added to (dicp_loop_buffers.search.form)
 int knn_f16_sweep(const void* src, const void* pose, const void* tgs4, void* image, const int32_t* tperm, const int32_t* qorder, const int32_t* bucket,
                   const void* brange, int nbkt, const int32_t* src_rows, const int32_t* tgt_rows, int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos,
                   unsigned long long* pairs, const int32_t* form_in, int32_t* form_out, int form_tiles, int form_default, void* ev0, void* ev1, void* stream);

@@ -300,7 +300,7 @@ struct CertArgs {             // certifying search: budgets (NULL q: plain searc
     const int32_t* glist; const int32_t* gcount; int glist_cap;     // guard launches: the work lists the previous step made
 };
 
-struct FormArgs { const int32_t* in; int32_t* out; int dflt; };       // per-cloud slab tallies of the loop's plain searches (dicp_loop_buffers.sweep_form)
+struct FormArgs { const int32_t* in; int32_t* out; int dflt; };       // per-cloud slab tallies of the loop's plain searches (dicp_loop_buffers.search.form)
 static int sweep_launch(int dtype, const void* src, const void* pose, const void* tgs4, const int32_t* tperm,
                         const int32_t* qorder, const int32_t* bucket, const void* brange, int nbkt,
                         int N, int n, int m, int m_pad, int32_t* idx, int32_t* spos, unsigned long long* pairs, int cfg, Rows rw, hipStream_t st,
@@ -863,24 +863,25 @@ static int transform_points_bwd_go(int dtype, const void* src, const void* pose,
 // [k0,k1) chunks and reads counters[] between them (converged clouds are frozen, extra iterations are no-ops).
 int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_buffers* B, int N, int n, int m,
                      int dim, int const_iter, double tolerance, int k0, int k1, void* stream) {
-    if (!prm || !B || !B->src || !B->tgt || !B->poses || !B->deltas || !B->costs || !B->alive ||
-        !B->converged || !B->iterations || !B->matched_ratio || !B->n_start || !B->n_matched || !B->w ||
+    if (!prm || !B || !B->src || !B->tgt || !B->hist.poses || !B->hist.deltas || !B->hist.costs || !B->hist.alive ||
+        !B->converged || !B->iterations || !B->matched_ratio || !B->n_start || !B->n_matched || !B->hist.w ||
         !B->partials || !B->counters) return DICP_ERR_NULL;
+    if (B->abi != DICP_ABI_VERSION) return DICP_ERR_ABI;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
-    if (k0 < 0 || k1 > B->K || k0 > k1 || N <= 0 || n <= 0 || m <= 0 || B->w_stride < n || B->w_iter < n) return DICP_ERR_SHAPE;
+    if (k0 < 0 || k1 > B->K || k0 > k1 || N <= 0 || n <= 0 || m <= 0 || B->hist.w_stride < n || B->hist.w_iter < n) return DICP_ERR_SHAPE;
     const size_t es = dtype == DICP_F32 ? 4 : 8;
-    const int kind = B->knn_variant & 0xff;
-    const dicp_gumbel_loop* G = kind == DICP_KNN_GUMBEL ? B->gumbel : nullptr;
+    const int kind = B->search.knn_variant & 0xff;
+    const dicp_gumbel_loop* G = kind == DICP_KNN_GUMBEL ? B->search.gumbel : nullptr;
     if (kind == DICP_KNN_GUMBEL) { if (!G || !G->ps_t || !G->nbr || !G->lse || (!G->U && !G->seeds)) return DICP_ERR_NULL; }
-    else if ((!B->idx && !B->spos) || (kind == DICP_KNN_SWEEP ? (!B->tperm || !B->bucket || !B->brange) : !B->tgt4)) return DICP_ERR_NULL;
+    else if ((!B->hist.idx && !B->hist.spos) || (kind == DICP_KNN_SWEEP ? (!B->search.tperm || !B->search.bucket || !B->search.brange) : !B->search.tgt4)) return DICP_ERR_NULL;
     hipStream_t st = (hipStream_t)stream;
     const int nblk = dicp_accumulate_blocks(n);
-    if (!G && small_loop_eligible(dtype, kind, B->knn_variant, n, B->m_pad) && k1 > k0) {
+    if (!G && small_loop_eligible(dtype, kind, B->search.knn_variant, n, B->search.m_pad) && k1 > k0) {
         // small clouds: the whole chunk is ONE launch, one block per cloud (bit 25 of knn_variant switches this off)
         if (const int e = check_params(prm, B->c)) return e;
         begin_launch();
         const WeightParams P = to_params(prm);
-        const size_t lds = (size_t)B->m_pad * (dtype == DICP_F32 ? sizeof(float4) : sizeof(double4));
+        const size_t lds = (size_t)B->search.m_pad * (dtype == DICP_F32 ? sizeof(float4) : sizeof(double4));
 #define DICP_SMALL(T, M) icp_small_forward_kernel<T, M><<<N, BLOCK, lds, st>>>(P, *B, N, n, m, dim, const_iter, tolerance, k0, k1)
         if (dtype == DICP_F32) { if (P.mode == MODE_PT2PL) DICP_SMALL(float, MODE_PT2PL); else DICP_SMALL(float, MODE_PT2PT); }
         else                   { if (P.mode == MODE_PT2PL) DICP_SMALL(double, MODE_PT2PL); else DICP_SMALL(double, MODE_PT2PT); }
@@ -888,13 +889,13 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
         return launch_status();
     }
     for (int k = k0; k < k1; ++k) {
-        const char* pose_k = (const char*)B->poses + (size_t)k * N * 12 * es;
+        const char* pose_k = (const char*)B->hist.poses + (size_t)k * N * 12 * es;
         // the searches read [C | r - centre] when the caller keeps that second pose history (packed rows are then y - centre)
-        const char* pose_s = B->poses_search ? (const char*)B->poses_search + (size_t)k * N * 12 * es : pose_k;
-        int32_t* idx_k = B->idx ? B->idx + (B->idx_per_iter ? (size_t)k * N * n : 0) : nullptr;
-        char* w_k = (char*)B->w + (size_t)k * B->w_iter * es;       // cloud stride B->w_stride: (N,K,n) or (K,N,n) alike
-        const char* w_prev_k = k > k0 ? (const char*)B->w + (size_t)(k - 1) * B->w_iter * es : (const char*)B->w_prev0;     // (as make_step_io)
-        const char* alive_k = (const char*)B->alive + (size_t)k * N * es;
+        const char* pose_s = B->search.poses ? (const char*)B->search.poses + (size_t)k * N * 12 * es : pose_k;
+        int32_t* idx_k = B->hist.idx ? B->hist.idx + (B->hist.per_iter ? (size_t)k * N * n : 0) : nullptr;
+        char* w_k = (char*)B->hist.w + (size_t)k * B->hist.w_iter * es;       // cloud stride B->hist.w_stride: (N,K,n) or (K,N,n) alike
+        const char* w_prev_k = k > k0 ? (const char*)B->hist.w + (size_t)(k - 1) * B->hist.w_iter * es : (const char*)B->hist.w_prev0;     // (as make_step_io)
+        const char* alive_k = (const char*)B->hist.alive + (size_t)k * N * es;
         if (B->events) {    // the sweep launch carries its two events itself; the brute-force forms are bracketed by records
             if (kind == DICP_KNN_SWEEP) set_launch_events((hipEvent_t)B->events[6 * k + 0], (hipEvent_t)B->events[6 * k + 1]);
             else if (hipEventRecord((hipEvent_t)B->events[6 * k + 0], st) != hipSuccess) return -(int)hipGetLastError();
@@ -902,28 +903,28 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
         int rc;
         if (kind == DICP_KNN_SWEEP) {
             // bits 8..15 of knn_variant optionally pin a tile-sweep launch configuration (0 = chosen from the problem size)
-            int cfg = (B->knn_variant >> 8) & 0xff;
-            int32_t* spos_k = B->spos ? B->spos + (B->idx_per_iter ? (size_t)k * N * n : 0) : nullptr;
-            const bool sorted_rows = B->tgt_sorted && spos_k;      // accumulate gathers 32-byte aligned rows of the sorted copy at the sorted positions
-            if (!sorted_rows && !B->idx) { set_launch_events(nullptr, nullptr); return DICP_ERR_NULL; }
+            int cfg = (B->search.knn_variant >> 8) & 0xff;
+            int32_t* spos_k = B->hist.spos ? B->hist.spos + (B->hist.per_iter ? (size_t)k * N * n : 0) : nullptr;
+            const bool sorted_rows = B->search.tgt_sorted && spos_k;      // accumulate gathers 32-byte aligned rows of the sorted copy at the sorted positions
+            if (!sorted_rows && !B->hist.idx) { set_launch_events(nullptr, nullptr); return DICP_ERR_NULL; }
             // match certificates: only the units holding a query whose match is not proven unchanged are searched again
             const int cfg_plain = cfg ? cfg : sweep_auto_cfg(N, n);
-            const bool cert = B->cert_q && B->cert_qu && B->rmax && B->dcum && spos_k && sorted_rows && !B->idx && B->qorder && sweep_queries_per_lane(cfg_plain) > 0;
+            const bool cert = B->cert.q && B->cert.qu && B->cert.rmax && B->cert.dcum && spos_k && sorted_rows && !B->hist.idx && B->search.qorder && sweep_queries_per_lane(cfg_plain) > 0;
             // (the certified iterations keep a row cache and their match history by reference: accumulate_kernel)
-            if (cert && (!B->cert_nbr || !B->cert_gdirty || !B->cert_pend || !B->cert_cm || !B->cert_glist || !B->cert_gcount || (B->cert_set && (!B->cert_slist || !B->cert_scount)) || (B->idx_per_iter && !B->spos_of))) { set_launch_events(nullptr, nullptr); return DICP_ERR_NULL; }
+            if (cert && (!B->cert.nbr || !B->cert.gdirty || !B->cert.pend || !B->cert.cm || !B->cert.glist || !B->cert.gcount || (B->cert.set && (!B->cert.slist || !B->cert.scount)) || (B->hist.per_iter && !B->hist.spos_of))) { set_launch_events(nullptr, nullptr); return DICP_ERR_NULL; }
             const int cert_units = cert ? (n + WAVE * sweep_queries_per_lane(cfg_plain) - 1) / (WAVE * sweep_queries_per_lane(cfg_plain)) : 0;
             const int glist_cap = guard_list_cap(N, n);
-            const bool fresh = k == 0 || (k == k0 && B->cert_reset);           // a new query order: every query is searched, every budget written
-            int32_t* count_k = B->cert_count ? B->cert_count + (size_t)k * 2 * CERT_SHARDS : nullptr;
-            const bool searched = B->first_search_done && k == 0 && !cert && spos_k && !B->idx;    // the caller ran iteration 0's search itself, ahead of this call
+            const bool fresh = k == 0 || (k == k0 && B->cert.reset);           // a new query order: every query is searched, every budget written
+            int32_t* count_k = B->cert.count ? B->cert.count + (size_t)k * 2 * CERT_SHARDS : nullptr;
+            const bool searched = B->search.first_done && k == 0 && !cert && spos_k && !B->hist.idx;    // the caller ran iteration 0's search itself, ahead of this call
             if (searched) rc = 0;
             else if (cert) {
                 // (nothing is copied from iteration to iteration, or from call to call: where a group of queries finds its matches is a word of spos_of)
                 begin_launch();
-                rc = sweep_launch(dtype, B->src, pose_s, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, N, n, m, B->m_pad, nullptr, spos_k,
-                                  B->pairs, cfg, Rows{B->src_rows, B->tgt_rows}, st, CertArgs{B->cert_q, B->cert_qu, B->dcum, 2 * (B->K + 1), k, count_k, !fresh, B->cert_cloud, B->cert_set,
-                                                                                              B->cert_cm, B->cert_pend, B->cert_gdirty, B->cert_set ? B->cert_slist : nullptr, B->cert_set ? B->cert_scount : nullptr,
-                                                                                              B->cert_glist, B->cert_gcount ? B->cert_gcount + (size_t)k * 8 : nullptr, glist_cap});
+                rc = sweep_launch(dtype, B->src, pose_s, B->search.tgt4, B->search.tperm, B->search.qorder, B->search.bucket, B->search.brange, B->search.nbkt, N, n, m, B->search.m_pad, nullptr, spos_k,
+                                  B->search.pairs, cfg, Rows{B->src_rows, B->tgt_rows}, st, CertArgs{B->cert.q, B->cert.qu, B->cert.dcum, 2 * (B->K + 1), k, count_k, !fresh, B->cert.cloud, B->cert.set,
+                                                                                              B->cert.cm, B->cert.pend, B->cert.gdirty, B->cert.set ? B->cert.slist : nullptr, B->cert.set ? B->cert.scount : nullptr,
+                                                                                              B->cert.glist, B->cert.gcount ? B->cert.gcount + (size_t)k * 8 : nullptr, glist_cap});
             } else
             {
                 // plain search.  The matrix-core form pays where a wave's slab is long -- big clouds, and clouds of any size whose queries are far from their
@@ -932,13 +933,13 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
                 // of the shape said about this iteration: one launch), else per cloud from the previous plain search's tally (both forms are launched, each takes
                 // its clouds: 0.02-0.03 ms per search at 256 x 16384 for the launch that finds nothing to do), else the default.  Every plain search tallies its
                 // slabs' tiles per cloud when given sweep_form.
-                const int planned = (B->sweep_form_plan && B->tgt_f16) ? B->sweep_form_plan[k] : 0;
-                const int32_t* form_in = (!planned && B->sweep_form && B->tgt_f16 && k > 0) ? B->sweep_form + (size_t)(k - 1) * N : nullptr;     // (all zeros behind a certified iteration: no tally)
-                int32_t* form_out = B->sweep_form ? B->sweep_form + (size_t)k * N : nullptr;
-                const void* img = planned ? (planned == 2 ? B->tgt_f16 : nullptr) : ((form_in || B->sweep_form_default || !B->sweep_form) ? B->tgt_f16 : nullptr);
+                const int planned = (B->search.form_plan && B->search.tgt_f16) ? B->search.form_plan[k] : 0;
+                const int32_t* form_in = (!planned && B->search.form && B->search.tgt_f16 && k > 0) ? B->search.form + (size_t)(k - 1) * N : nullptr;     // (all zeros behind a certified iteration: no tally)
+                int32_t* form_out = B->search.form ? B->search.form + (size_t)k * N : nullptr;
+                const void* img = planned ? (planned == 2 ? B->search.tgt_f16 : nullptr) : ((form_in || B->search.form_default || !B->search.form) ? B->search.tgt_f16 : nullptr);
                 begin_launch();
-                rc = sweep_launch(dtype, B->src, pose_s, B->tgt4, B->tperm, B->qorder, B->bucket, B->brange, B->nbkt, N, n, m, B->m_pad, B->idx ? idx_k : nullptr, spos_k, B->pairs, cfg,
-                                  Rows{B->src_rows, B->tgt_rows}, st, CertArgs{}, img, FormArgs{form_in, form_out, B->sweep_form_default});
+                rc = sweep_launch(dtype, B->src, pose_s, B->search.tgt4, B->search.tperm, B->search.qorder, B->search.bucket, B->search.brange, B->search.nbkt, N, n, m, B->search.m_pad, B->hist.idx ? idx_k : nullptr, spos_k, B->search.pairs, cfg,
+                                  Rows{B->src_rows, B->tgt_rows}, st, CertArgs{}, img, FormArgs{form_in, form_out, B->search.form_default});
             }
             set_launch_events(nullptr, nullptr);
             if (rc) return rc;
@@ -946,15 +947,15 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
             if (cert) {
                 // the accumulate of a certified iteration checks every point's budget and searches the spent ones on the spot; its matches
                 // are the start of the next iteration's (within this call)
-                const CertAcc ca{spos_k, B->spos, B->spos_prev_chunk, B->idx_per_iter ? B->spos_of : nullptr, B->spos_floor, k,
-                                 B->cert_nbr, B->cert_gdirty, B->cert_pend, B->cert_cloud, fresh ? 1 : 0, cert_units, B->cert_set ? 1 : 0, B->cert_scount};
-                rc = accumulate_go(dtype, prm, B->src, B->tgt_sorted, B->tgt_sorted_stride, spos_k, pose_k, B->w_init, alive_k, B->src_rows, N, n, B->m_pad,
-                                   B->partials, w_k, B->w_stride, stream, &ca, w_prev_k);
+                const CertAcc ca{spos_k, B->hist.spos, B->hist.spos_prev_chunk, B->hist.per_iter ? B->hist.spos_of : nullptr, B->hist.spos_floor, k,
+                                 B->cert.nbr, B->cert.gdirty, B->cert.pend, B->cert.cloud, fresh ? 1 : 0, cert_units, B->cert.set ? 1 : 0, B->cert.scount};
+                rc = accumulate_go(dtype, prm, B->src, B->search.tgt_sorted, B->search.tgt_sorted_stride, spos_k, pose_k, B->w_init, alive_k, B->src_rows, N, n, B->search.m_pad,
+                                   B->partials, w_k, B->hist.w_stride, stream, &ca, w_prev_k);
             } else if (sorted_rows)
-                rc = accumulate_go(dtype, prm, B->src, B->tgt_sorted, B->tgt_sorted_stride, spos_k, pose_k, B->w_init, alive_k, B->src_rows, N, n, B->m_pad,
-                                   B->partials, w_k, B->w_stride, stream, nullptr, w_prev_k);
+                rc = accumulate_go(dtype, prm, B->src, B->search.tgt_sorted, B->search.tgt_sorted_stride, spos_k, pose_k, B->w_init, alive_k, B->src_rows, N, n, B->search.m_pad,
+                                   B->partials, w_k, B->hist.w_stride, stream, nullptr, w_prev_k);
             else
-                rc = accumulate_go(dtype, prm, B->src, B->tgt, B->c, idx_k, pose_k, B->w_init, alive_k, B->src_rows, N, n, m, B->partials, w_k, B->w_stride, stream, nullptr, w_prev_k);
+                rc = accumulate_go(dtype, prm, B->src, B->tgt, B->c, idx_k, pose_k, B->w_init, alive_k, B->src_rows, N, n, m, B->partials, w_k, B->hist.w_stride, stream, nullptr, w_prev_k);
             set_launch_events(nullptr, nullptr);
             if (rc) return rc;
         } else if (G) {
@@ -969,30 +970,30 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
                 if (hipEventRecord((hipEvent_t)B->events[6 * k + 1], st) != hipSuccess) return -(int)hipGetLastError();
                 set_launch_events((hipEvent_t)B->events[6 * k + 2], (hipEvent_t)B->events[6 * k + 3]);
             }
-            rc = accumulate_go(dtype, prm, B->src, nbr_k, B->c, nullptr, pose_k, B->w_init, alive_k, nullptr, N, n, n, B->partials, w_k, B->w_stride, stream, nullptr, w_prev_k);
+            rc = accumulate_go(dtype, prm, B->src, nbr_k, B->c, nullptr, pose_k, B->w_init, alive_k, nullptr, N, n, n, B->partials, w_k, B->hist.w_stride, stream, nullptr, w_prev_k);
             set_launch_events(nullptr, nullptr);
             if (rc) return rc;
         } else {
-            rc = dicp_knn(dtype, B->src, pose_s, B->tgt4, B->src_rows, B->tgt_rows, N, n, m, B->m_pad, idx_k, B->knn_variant & 0xffff, B->tgt_f16, stream);
+            rc = dicp_knn(dtype, B->src, pose_s, B->search.tgt4, B->src_rows, B->tgt_rows, N, n, m, B->search.m_pad, idx_k, B->search.knn_variant & 0xffff, B->search.tgt_f16, stream);
             if (rc) return rc;
             if (B->events) {
                 if (hipEventRecord((hipEvent_t)B->events[6 * k + 1], st) != hipSuccess) return -(int)hipGetLastError();
                 set_launch_events((hipEvent_t)B->events[6 * k + 2], (hipEvent_t)B->events[6 * k + 3]);
             }
-            rc = accumulate_go(dtype, prm, B->src, B->tgt, B->c, idx_k, pose_k, B->w_init, alive_k, B->src_rows, N, n, m, B->partials, w_k, B->w_stride, stream, nullptr, w_prev_k);
+            rc = accumulate_go(dtype, prm, B->src, B->tgt, B->c, idx_k, pose_k, B->w_init, alive_k, B->src_rows, N, n, m, B->partials, w_k, B->hist.w_stride, stream, nullptr, w_prev_k);
             set_launch_events(nullptr, nullptr);
             if (rc) return rc;
         }
         dicp_step_io io = make_step_io(*B, k, k0, N, n, prm->mode, dim, const_iter, tolerance, es, nblk);
         io.w_copied = w_prev_k ? 1 : 0;
-        if (kind == DICP_KNN_SWEEP && B->cert_q && B->cert_qu && B->cert_glist && B->cert_gcount && B->rmax && B->dcum && k + 1 < B->K) {
+        if (kind == DICP_KNN_SWEEP && B->cert.q && B->cert.qu && B->cert.glist && B->cert.gcount && B->cert.rmax && B->cert.dcum && k + 1 < B->K) {
             // a certified iteration's step also makes the next guard launch its work list (dicp_step_io.glist)
-            const int cfgp = ((B->knn_variant >> 8) & 0xff) ? ((B->knn_variant >> 8) & 0xff) : sweep_auto_cfg(N, n);
+            const int cfgp = ((B->search.knn_variant >> 8) & 0xff) ? ((B->search.knn_variant >> 8) & 0xff) : sweep_auto_cfg(N, n);
             const int Qp = sweep_queries_per_lane(cfgp);
             if (Qp > 0) {
-                io.cert_qu = B->cert_qu; io.cert_units = (n + WAVE * Qp - 1) / (WAVE * Qp); io.glist_cap = guard_list_cap(N, n);
-                io.glist = B->cert_glist; io.gcount = B->cert_gcount + (size_t)(k + 1) * 8;
-                io.cert_scount = B->cert_set ? B->cert_scount : nullptr; io.cert_slist = B->cert_set ? B->cert_slist : nullptr;
+                io.cert_qu = B->cert.qu; io.cert_units = (n + WAVE * Qp - 1) / (WAVE * Qp); io.glist_cap = guard_list_cap(N, n);
+                io.glist = B->cert.glist; io.gcount = B->cert.gcount + (size_t)(k + 1) * 8;
+                io.cert_scount = B->cert.set ? B->cert.scount : nullptr; io.cert_slist = B->cert.set ? B->cert.slist : nullptr;
             }
         }
         rc = dicp_step(dtype, &io, N, stream);
@@ -1010,6 +1011,7 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
 int dicp_icp_forward_plan(int dtype, const dicp_weight_params* prm, const dicp_loop_buffers* buf, const dicp_segment_plan* S, int N, int n, int m,
                           int dim, int const_iter, double tolerance, void* stream) {
     if (!prm || !buf || !S) return DICP_ERR_NULL;
+    if (buf->abi != DICP_ABI_VERSION) return DICP_ERR_ABI;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
     if (S->nseg <= 0 || S->nseg > DICP_MAX_SEGMENTS) return DICP_ERR_SHAPE;
     const size_t es = dtype == DICP_F32 ? 4 : 8;
@@ -1022,22 +1024,22 @@ int dicp_icp_forward_plan(int dtype, const dicp_weight_params* prm, const dicp_l
         int32_t* qo = S->order[s];
         if (qo && S->new_order[s]) {
             if (!S->keys) return DICP_ERR_NULL;
-            const char* poses_s = (const char*)(B.poses_search ? B.poses_search : B.poses);
+            const char* poses_s = (const char*)(B.search.poses ? B.search.poses : B.hist.poses);
             // (a re-ordering: a cloud that has hardly moved since the order before keeps it, dicp_query_reorder)
-            if (const int rc = query_order_go(dtype, B.src, poses_s + (size_t)k0 * N * 12 * es, B.brange, B.nbkt, N, n, qo, nullptr, nullptr, nullptr, 0, nullptr, B.m_pad,
-                                              S->keys, B.bucket, m, B.src_rows, B.tgt_rows, (order_before && order_before != qo) ? poses_s + (size_t)k_before * N * 12 * es : nullptr,
+            if (const int rc = query_order_go(dtype, B.src, poses_s + (size_t)k0 * N * 12 * es, B.search.brange, B.search.nbkt, N, n, qo, nullptr, nullptr, nullptr, 0, nullptr, B.search.m_pad,
+                                              S->keys, B.search.bucket, m, B.src_rows, B.tgt_rows, (order_before && order_before != qo) ? poses_s + (size_t)k_before * N * 12 * es : nullptr,
                                               order_before != qo ? order_before : nullptr, stream)) return rc;
         }
         if (qo && qo != order_before) { order_before = qo; k_before = k0; }
-        B.qorder = qo;
+        B.search.qorder = qo;
         const bool certs = S->cert_from >= 0 && k0 >= S->cert_from;
-        B.cert_q = certs ? S->cert_q : nullptr; B.cert_qu = certs ? S->cert_qu : nullptr; B.cert_count = certs ? S->cert_count : nullptr;
-        B.cert_cloud = certs ? S->cert_cloud : nullptr;
-        B.cert_set = certs ? S->cert_set : nullptr;
-        B.cert_nbr = certs ? S->cert_nbr : nullptr; B.cert_gdirty = certs ? S->cert_gdirty : nullptr; B.cert_pend = certs ? S->cert_pend : nullptr; B.cert_cm = certs ? S->cert_cm : nullptr; B.cert_glist = certs ? S->cert_glist : nullptr; B.cert_gcount = certs ? S->cert_gcount : nullptr; B.cert_slist = certs ? S->cert_slist : nullptr; B.cert_scount = certs ? S->cert_scount : nullptr;
-        B.cert_reset = (S->cert_from >= 0 && k0 == S->cert_from) ? 1 : 0;
-        B.spos_prev_chunk = nullptr; B.spos_floor = 0;
-        B.w_prev0 = k0 > 0 ? (const char*)B.w + (size_t)(k0 - 1) * B.w_iter * es : nullptr;
+        B.cert.q = certs ? S->cert_q : nullptr; B.cert.qu = certs ? S->cert_qu : nullptr; B.cert.count = certs ? S->cert_count : nullptr;
+        B.cert.cloud = certs ? S->cert_cloud : nullptr;
+        B.cert.set = certs ? S->cert_set : nullptr;
+        B.cert.nbr = certs ? S->cert_nbr : nullptr; B.cert.gdirty = certs ? S->cert_gdirty : nullptr; B.cert.pend = certs ? S->cert_pend : nullptr; B.cert.cm = certs ? S->cert_cm : nullptr; B.cert.glist = certs ? S->cert_glist : nullptr; B.cert.gcount = certs ? S->cert_gcount : nullptr; B.cert.slist = certs ? S->cert_slist : nullptr; B.cert.scount = certs ? S->cert_scount : nullptr;
+        B.cert.reset = (S->cert_from >= 0 && k0 == S->cert_from) ? 1 : 0;
+        B.hist.spos_prev_chunk = nullptr; B.hist.spos_floor = 0;
+        B.hist.w_prev0 = k0 > 0 ? (const char*)B.hist.w + (size_t)(k0 - 1) * B.hist.w_iter * es : nullptr;
         if (const int rc = dicp_icp_forward(dtype, prm, &B, N, n, m, dim, const_iter, tolerance, k0, k1, stream)) return rc;
     }
     return 0;
@@ -1049,20 +1051,21 @@ int dicp_icp_forward_plan(int dtype, const dicp_weight_params* prm, const dicp_l
 int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_buffers* B, int N, int n, int m, int dim,
                       double* gpose, double* gpose_tmp, int have_partials, void* gs, void* gb, void* gsrc, void* gtgt, void* gw,
                       void* bwd_partials, int k0, int k1, void* stream) {
-    const dicp_gumbel_loop* G = (B && (B->knn_variant & 0xff) == DICP_KNN_GUMBEL) ? B->gumbel : nullptr;
-    if (!prm || !B || !B->src || !B->tgt || !B->poses || !B->deltas || !B->areg || !B->alive || (!G && !B->idx && !B->spos) || (gw && !B->w_init) ||
+    const dicp_gumbel_loop* G = (B && (B->search.knn_variant & 0xff) == DICP_KNN_GUMBEL) ? B->search.gumbel : nullptr;
+    if (!prm || !B || !B->src || !B->tgt || !B->hist.poses || !B->hist.deltas || !B->hist.areg || !B->hist.alive || (!G && !B->hist.idx && !B->hist.spos) || (gw && !B->w_init) ||
         !gpose || !gpose_tmp || !gs || !gb || !gsrc || !bwd_partials) return DICP_ERR_NULL;
-    if ((B->knn_variant & 0xff) == DICP_KNN_GUMBEL && (!G || !G->ps_t || !G->nbr || !G->lse || !G->g_nbr || !G->g_ps || (!G->U && !G->seeds))) return DICP_ERR_NULL;
+    if (B->abi != DICP_ABI_VERSION) return DICP_ERR_ABI;
+    if ((B->search.knn_variant & 0xff) == DICP_KNN_GUMBEL && (!G || !G->ps_t || !G->nbr || !G->lse || !G->g_nbr || !G->g_ps || (!G->U && !G->seeds))) return DICP_ERR_NULL;
     if (bad_dtype(dtype)) return DICP_ERR_DTYPE;
-    if (k0 < 0 || k1 > B->K || k0 > k1 || !B->idx_per_iter || (B->spos && (B->m_pad <= 0 || !B->spos_ref))) return DICP_ERR_SHAPE;
-    if (B->bwd_skip && (!B->bwd_mref || !(B->bwd_skip_eps >= 0.0))) return DICP_ERR_NULL;
+    if (k0 < 0 || k1 > B->K || k0 > k1 || !B->hist.per_iter || (B->hist.spos && (B->search.m_pad <= 0 || !B->bwd.spos_ref))) return DICP_ERR_SHAPE;
+    if (B->bwd.skip && (!B->bwd.mref || !(B->bwd.skip_eps >= 0.0))) return DICP_ERR_NULL;
     const size_t es = dtype == DICP_F32 ? 4 : 8;
     hipStream_t st = (hipStream_t)stream;
-    const int nblk = B->spos ? dicp_window_blocks(dtype, n, B->m_pad) : dicp_accumulate_blocks(n);
+    const int nblk = B->hist.spos ? dicp_window_blocks(dtype, n, B->search.m_pad) : dicp_accumulate_blocks(n);
     {   // small clouds (atomic form only): the whole chunk is ONE launch, one block per cloud
         const size_t lds = (size_t)m * (prm->mode == DICP_PT2PL ? 6 : 3) * es;
-        if (!G && !B->spos && k1 > k0 && B->m_pad > 0 && lds <= 40 * 1024 &&
-            small_loop_eligible(dtype, B->knn_variant & 0xff, B->knn_variant, n, B->m_pad)) {
+        if (!G && !B->hist.spos && k1 > k0 && B->search.m_pad > 0 && lds <= 40 * 1024 &&
+            small_loop_eligible(dtype, B->search.knn_variant & 0xff, B->search.knn_variant, n, B->search.m_pad)) {
             if (const int e = check_params(prm, B->c)) return e;
             begin_launch();
             const WeightParams P = to_params(prm);
@@ -1079,24 +1082,24 @@ int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_
     double* gout = gpose_tmp;
     // windowed form with the truncated sweep: the iterations below bwd_tail_from are ONE launch (bwd_tail_kernel)
     int kt = k0;
-    if (B->spos && B->bwd_skip && B->bwd_tail_from > k0) {
-        if (B->det_far_row) return DICP_ERR_SHAPE;          // (deterministic target gradients: per-iteration launches only)
+    if (B->hist.spos && B->bwd.skip && B->bwd.tail_from > k0) {
+        if (B->bwd.det_far_row) return DICP_ERR_SHAPE;          // (deterministic target gradients: per-iteration launches only)
         if (k0 != 0) return DICP_ERR_SHAPE;                 // (the launch runs down to iteration 0 and folds the last pose sums into the cotangent)
-        if (!B->bwd_tail_partials || !B->bwd_tail_arrive) return DICP_ERR_NULL;
+        if (!B->bwd.tail_partials || !B->bwd.tail_arrive) return DICP_ERR_NULL;
         if (nblk > dicp_bwd_tail_max_blocks(dtype)) return DICP_ERR_SHAPE;      // (its blocks wait for each other: they must all be resident)
-        kt = B->bwd_tail_from < k1 ? B->bwd_tail_from : k1;
-        if (B->bwd_overwrite && kt >= k1) kt = k1 - 1;      // (the first windowed launch initialises the accumulators: it always runs)
+        kt = B->bwd.tail_from < k1 ? B->bwd.tail_from : k1;
+        if (B->bwd.overwrite && kt >= k1) kt = k1 - 1;      // (the first windowed launch initialises the accumulators: it always runs)
     }
     for (int k = k1 - 1; k >= kt; --k) {
-        const char* pose_k = (const char*)B->poses + (size_t)k * N * 12 * es;
-        const char* alive_k = (const char*)B->alive + (size_t)k * N * es;
-        const SkipHost sh{B->bwd_skip, B->bwd_mref, alive_k, B->bwd_live ? B->bwd_live + k : nullptr, B->bwd_skip_eps, k};
+        const char* pose_k = (const char*)B->hist.poses + (size_t)k * N * 12 * es;
+        const char* alive_k = (const char*)B->hist.alive + (size_t)k * N * es;
+        const SkipHost sh{B->bwd.skip, B->bwd.mref, alive_k, B->bwd.live ? B->bwd.live + k : nullptr, B->bwd.skip_eps, k};
         int rc = step_bwd_go(dtype, gin, have_partials ? bwd_partials : nullptr, nblk, dim, pose_k,
-                             (const char*)B->deltas + (size_t)k * 6 * es, (int64_t)B->K * 6, B->areg + (size_t)k * N * 36,
-                             gs, gb, gout, N, stream, B->bwd_skip ? sh : SkipHost{});
+                             (const char*)B->hist.deltas + (size_t)k * 6 * es, (int64_t)B->K * 6, B->hist.areg + (size_t)k * N * 36,
+                             gs, gb, gout, N, stream, B->bwd.skip ? sh : SkipHost{});
         if (rc) return rc;
         if (B->events) {
-            if (B->spos) set_launch_events((hipEvent_t)B->events[6 * k + 4], (hipEvent_t)B->events[6 * k + 5]);
+            if (B->hist.spos) set_launch_events((hipEvent_t)B->events[6 * k + 4], (hipEvent_t)B->events[6 * k + 5]);
             else if (hipEventRecord((hipEvent_t)B->events[6 * k + 4], st) != hipSuccess) return -(int)hipGetLastError();
         }
         if (G) {
@@ -1106,23 +1109,23 @@ int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_
             const char* nbr_k = (const char*)G->nbr + (size_t)k * N * n * B->c * es;
             const char* lse_k = (const char*)G->lse + (size_t)k * N * n * es;
             if (hipMemsetAsync(G->g_nbr, 0, (size_t)N * n * B->c * es, st) != hipSuccess) return -(int)hipGetLastError();
-            rc = accumulate_bwd_go(dtype, prm, B->src, nbr_k, B->c, nullptr, pose_k, B->w_init, alive_k, gs, gb, nullptr, N, n, n, gsrc, G->g_nbr, gw, bwd_partials, stream, B->bwd_skip);
+            rc = accumulate_bwd_go(dtype, prm, B->src, nbr_k, B->c, nullptr, pose_k, B->w_init, alive_k, gs, gb, nullptr, N, n, n, gsrc, G->g_nbr, gw, bwd_partials, stream, B->bwd.skip);
             if (!rc) rc = dicp_transform_points(dtype, B->src, pose_k, G->ps_t, N, n, stream);
             if (!rc) rc = gumbel_nn_bwd_go(dtype, G->ps_t, B->tgt, B->c, G->U ? G->U[k] : nullptr, G->seeds ? G->seeds[k] : 0u, G->eps, G->tau, nbr_k, lse_k, G->g_nbr,
                                            N, n, m, G->g_ps, gtgt, 1, stream);
             if (!rc) rc = transform_points_bwd_go(dtype, B->src, pose_k, G->g_ps, gsrc, bwd_partials, N, n, 1, stream);
-        } else if (B->spos)    // windowed form: src / w_init / tgt are the SORTED copies, gsrc / gw accumulate in slot order, gtgt is the slab
+        } else if (B->hist.spos)    // windowed form: src / w_init / tgt are the SORTED copies, gsrc / gw accumulate in slot order, gtgt is the slab
             rc = accumulate_bwd_window_go(dtype, prm, B->src, B->tgt, B->c,
-                                          (B->spos_of && k >= B->spos_of_from) ? MatchHist{B->spos, B->spos_of, k, N, n, (n + WAVE - 1) / WAVE} : plain_matches(B->spos + (size_t)k * N * n, N, n),
-                                          B->spos_ref, B->qorder, pose_k, B->w_init,
-                                          alive_k, gs, gb, B->src_rows, N, n, B->m_pad,
-                                          gsrc, gtgt, B->gts_far, gw, bwd_partials, (B->bwd_overwrite && k == k1 - 1) ? 1 : 0, stream, B->bwd_skip, B->det_far_row, B->det_far_val);
+                                          (B->hist.spos_of && k >= B->hist.spos_of_from) ? MatchHist{B->hist.spos, B->hist.spos_of, k, N, n, (n + WAVE - 1) / WAVE} : plain_matches(B->hist.spos + (size_t)k * N * n, N, n),
+                                          B->bwd.spos_ref, B->search.qorder, pose_k, B->w_init,
+                                          alive_k, gs, gb, B->src_rows, N, n, B->search.m_pad,
+                                          gsrc, gtgt, B->bwd.gts_far, gw, bwd_partials, (B->bwd.overwrite && k == k1 - 1) ? 1 : 0, stream, B->bwd.skip, B->bwd.det_far_row, B->bwd.det_far_val);
         else
-            rc = accumulate_bwd_go(dtype, prm, B->src, B->tgt, B->c, B->idx + (size_t)k * N * n, pose_k, B->w_init,
-                                   alive_k, gs, gb, B->src_rows, N, n, m, gsrc, gtgt, gw, bwd_partials, stream, B->bwd_skip);
+            rc = accumulate_bwd_go(dtype, prm, B->src, B->tgt, B->c, B->hist.idx + (size_t)k * N * n, pose_k, B->w_init,
+                                   alive_k, gs, gb, B->src_rows, N, n, m, gsrc, gtgt, gw, bwd_partials, stream, B->bwd.skip);
         set_launch_events(nullptr, nullptr);
         if (rc) return rc;
-        if (B->events && !B->spos) { if (hipEventRecord((hipEvent_t)B->events[6 * k + 5], st) != hipSuccess) return -(int)hipGetLastError(); }
+        if (B->events && !B->hist.spos) { if (hipEventRecord((hipEvent_t)B->events[6 * k + 5], st) != hipSuccess) return -(int)hipGetLastError(); }
         have_partials = 1;
         double* t = gin; gin = gout; gout = t;
     }
@@ -1143,8 +1146,8 @@ int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_
         }
         const unsigned g = grid_for(N, nblk);
 #define DICP_TAILB(T, M) do { constexpr int WT = WindowRows<T>::v; \
-        bwd_tail_kernel<T, M, WT><<<g, BLOCK, 0, st>>>(P, *B, N, n, dim, window_slots(WT, n, B->m_pad), nblk, gin, dst, have_partials, \
-            (T*)gsrc, (T*)gtgt, (T*)gw, (T*)bwd_partials, (T*)B->bwd_tail_partials, B->bwd_tail_arrive, kt); } while (0)
+        bwd_tail_kernel<T, M, WT><<<g, BLOCK, 0, st>>>(P, *B, N, n, dim, window_slots(WT, n, B->search.m_pad), nblk, gin, dst, have_partials, \
+            (T*)gsrc, (T*)gtgt, (T*)gw, (T*)bwd_partials, (T*)B->bwd.tail_partials, B->bwd.tail_arrive, kt); } while (0)
         if (dtype == DICP_F32) { if (P.mode == MODE_PT2PL) DICP_TAILB(float, MODE_PT2PL); else DICP_TAILB(float, MODE_PT2PT); }
         else                   { if (P.mode == MODE_PT2PL) DICP_TAILB(double, MODE_PT2PL); else DICP_TAILB(double, MODE_PT2PT); }
 #undef DICP_TAILB

@@ -285,20 +285,20 @@ __host__ __device__ inline dicp_step_io make_step_io(const dicp_loop_buffers& B,
     dicp_step_io io;
     io.partials = B.partials; io.nblk = nblk; io.iter = k; io.dim = dim; io.const_iter = const_iter; io.tolerance = tolerance;
     io.rows_per_point = mode == DICP_PT2PT ? 3 : 1; io.n = n;
-    io.pose_in = (const char*)B.poses + (size_t)k * N * 12 * es; io.pose_out = (char*)B.poses + (size_t)(k + 1) * N * 12 * es;
-    io.frame = B.frame; io.pose_search_out = B.poses_search ? (char*)B.poses_search + (size_t)(k + 1) * N * 12 * es : nullptr;
-    io.delta = (char*)B.deltas + (size_t)k * 6 * es; io.delta_stride = (int64_t)B.K * 6;
-    io.cost = (char*)B.costs + (size_t)k * es; io.cost_prev = k > 0 ? (const char*)B.costs + (size_t)(k - 1) * es : nullptr;
+    io.pose_in = (const char*)B.hist.poses + (size_t)k * N * 12 * es; io.pose_out = (char*)B.hist.poses + (size_t)(k + 1) * N * 12 * es;
+    io.frame = B.search.frame; io.pose_search_out = B.search.poses ? (char*)B.search.poses + (size_t)(k + 1) * N * 12 * es : nullptr;
+    io.delta = (char*)B.hist.deltas + (size_t)k * 6 * es; io.delta_stride = (int64_t)B.K * 6;
+    io.cost = (char*)B.hist.costs + (size_t)k * es; io.cost_prev = k > 0 ? (const char*)B.hist.costs + (size_t)(k - 1) * es : nullptr;
     io.cost_stride = B.K;
-    io.areg = B.areg ? B.areg + (size_t)k * N * 36 : nullptr;
-    io.alive = (const char*)B.alive + (size_t)k * N * es; io.alive_out = (char*)B.alive + (size_t)(k + 1) * N * es;
+    io.areg = B.hist.areg ? B.hist.areg + (size_t)k * N * 36 : nullptr;
+    io.alive = (const char*)B.hist.alive + (size_t)k * N * es; io.alive_out = (char*)B.hist.alive + (size_t)(k + 1) * N * es;
     io.converged = B.converged; io.iterations = B.iterations; io.matched_ratio = B.matched_ratio;
     io.n_start = B.n_start; io.n_matched = B.n_matched;
-    io.w_cur = (char*)B.w + (size_t)k * B.w_iter * es;
-    io.w_prev = k > k0 ? (const char*)B.w + (size_t)(k - 1) * B.w_iter * es : (const char*)B.w_prev0; io.w_stride = B.w_stride;
+    io.w_cur = (char*)B.hist.w + (size_t)k * B.hist.w_iter * es;
+    io.w_prev = k > k0 ? (const char*)B.hist.w + (size_t)(k - 1) * B.hist.w_iter * es : (const char*)B.hist.w_prev0; io.w_stride = B.hist.w_stride;
     io.n_not_converged = B.counters + k;
-    io.rmax = B.rmax; io.dcum = B.dcum; io.dcum_stride = 2 * (B.K + 1);
-    io.cert_cloud = B.cert_cloud;
+    io.rmax = B.cert.rmax; io.dcum = B.cert.dcum; io.dcum_stride = 2 * (B.K + 1);
+    io.cert_cloud = B.cert.cloud;
     io.cert_qu = nullptr; io.cert_units = 0; io.glist_cap = 0; io.glist = nullptr; io.gcount = nullptr; io.cert_scount = nullptr; io.cert_slist = nullptr;      // (dicp_icp_forward fills them in for a certified iteration)
     io.w_copied = 0;
     return io;
@@ -524,9 +524,9 @@ __global__ __launch_bounds__(BLOCK) void icp_small_forward_kernel(WeightParams P
     __shared__ T red[(BLOCK / WAVE) * NACC_PAD];
     const int cloud = blockIdx.x, tid = threadIdx.x, c = B.c;
     const int nc = rows_of(B.src_rows, cloud, n), mc = max(rows_of(B.tgt_rows, cloud, m), 1);
-    const int m_pad = min((mc + KNN_PAD - 1) / KNN_PAD * KNN_PAD, B.m_pad);     // ragged batches: the cloud's own rows only
+    const int m_pad = min((mc + KNN_PAD - 1) / KNN_PAD * KNN_PAD, B.search.m_pad);     // ragged batches: the cloud's own rows only
     {
-        const T4* __restrict__ g = (const T4*)B.tgt4 + (size_t)cloud * B.m_pad;
+        const T4* __restrict__ g = (const T4*)B.search.tgt4 + (size_t)cloud * B.search.m_pad;
         for (int j = tid; j < m_pad; j += BLOCK) tg[j] = g[j];
     }
     __syncthreads();
@@ -535,19 +535,19 @@ __global__ __launch_bounds__(BLOCK) void icp_small_forward_kernel(WeightParams P
     const T* __restrict__ w_init = B.w_init ? (const T*)B.w_init + (size_t)cloud * n : nullptr;
     for (int k = k0; k < k1; ++k) {
         T C[9], r[3];
-        load_pose((const T*)B.poses + (size_t)k * N * 12, cloud, C, r);
+        load_pose((const T*)B.hist.poses + (size_t)k * N * 12, cloud, C, r);
         T Cs[9], rs[3];                                     // the search's pose: [Q C | Q r + t] (packed rows are Q y + t)
         {
             const T pw[12] = {C[0], C[1], C[2], C[3], C[4], C[5], C[6], C[7], C[8], r[0], r[1], r[2]};
-            const T* F = B.frame ? (const T*)B.frame + (size_t)cloud * 12 : nullptr;
+            const T* F = B.search.frame ? (const T*)B.search.frame + (size_t)cloud * 12 : nullptr;
 #pragma unroll
             for (int e = 0; e < 9; ++e) Cs[e] = frame_pose_entry<T>(F, pw, e);
 #pragma unroll
             for (int e = 0; e < 3; ++e) rs[e] = frame_pose_entry<T>(F, pw, 9 + e);
         }
-        const T live = ((const T*)B.alive)[(size_t)k * N + cloud];
-        int32_t* __restrict__ idx_k = B.idx + (B.idx_per_iter ? (size_t)k * N * n : 0) + (size_t)cloud * n;
-        T* __restrict__ w_k = (T*)B.w + (size_t)k * B.w_iter + (size_t)cloud * B.w_stride;
+        const T live = ((const T*)B.hist.alive)[(size_t)k * N + cloud];
+        int32_t* __restrict__ idx_k = B.hist.idx + (B.hist.per_iter ? (size_t)k * N * n : 0) + (size_t)cloud * n;
+        T* __restrict__ w_k = (T*)B.hist.w + (size_t)k * B.hist.w_iter + (size_t)cloud * B.hist.w_stride;
         T acc[NACC];
 #pragma unroll
         for (int a = 0; a < NACC; ++a) acc[a] = T(0);

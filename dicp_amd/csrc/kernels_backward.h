@@ -106,7 +106,7 @@ __host__ __device__ inline int window_slots(int WT, int n, int m_pad) {
 }
 
 // Where the matches of one iteration are found: a plain (N,n) array (of == NULL: base itself), or the history kept by reference
-// (dicp_loop_buffers.spos_of): the matches of queries [64g, 64g+64) of cloud b at iteration k lie in the slab of iteration of[(k N + b) nwr + g].
+// (dicp_loop_buffers.hist.spos_of): the matches of queries [64g, 64g+64) of cloud b at iteration k lie in the slab of iteration of[(k N + b) nwr + g].
 struct MatchHist { const int32_t* base; const int32_t* of; int k, N, n, nwr; };
 __device__ __forceinline__ int match_at(const MatchHist& h, int cloud, int q) {
     if (!h.of) return h.base[(size_t)cloud * h.n + q];
@@ -136,7 +136,7 @@ __device__ __forceinline__ void window_body(const WeightParams& P, const T* __re
                                             T* __restrict__ gsrc_s, T* __restrict__ slab /* (N,bpc,WT,CV) */,
                                             T* __restrict__ gts_far /* (N,m_pad,CV) */,
                                             T* __restrict__ gw_s, T* part_out, const int32_t* __restrict__ src_rows, int cloud, int blk,
-                                            int32_t* __restrict__ det_row = nullptr /* (N,n), with det_val (N,n,CV): deterministic target gradients (dicp_loop_buffers.det_far_row) */,
+                                            int32_t* __restrict__ det_row = nullptr /* (N,n), with det_val (N,n,CV): deterministic target gradients (dicp_loop_buffers.bwd.det_far_row) */,
                                             T* __restrict__ det_val = nullptr) {
     // overwrite: first launch into uninitialised accumulators -- gsrc_s / gw_s / the slab windows are written, not added to
     constexpr int CV = (MODE == MODE_PT2PL) ? 6 : 3;
@@ -725,7 +725,7 @@ __global__ __launch_bounds__(BLOCK) void icp_small_backward_kernel(WeightParams 
     __shared__ int s_skip;
     const int cloud = blockIdx.x, tid = threadIdx.x, c = B.c;
     const int nc = rows_of(B.src_rows, cloud, n);           // ragged batches: rows past the cloud's own carry no gradient
-    bool ended = B.bwd_skip && B.bwd_skip[cloud] == 2;      // (this cloud's reverse sweep ended in an earlier chunk)
+    bool ended = B.bwd.skip && B.bwd.skip[cloud] == 2;      // (this cloud's reverse sweep ended in an earlier chunk)
     if (gtgt)
         for (int e = tid; e < m * CV; e += NT) gt[e] = T(0);
     if (tid < 12) sgo[tid] = gpose_in[(size_t)cloud * 12 + tid];
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(BLOCK) void icp_small_backward_kernel(WeightParams 
     const T* __restrict__ src = (const T*)B.src + (size_t)cloud * n * 3;
     const T* __restrict__ tgt = (const T*)B.tgt + (size_t)cloud * m * c;
     const T* __restrict__ w_init = B.w_init ? (const T*)B.w_init + (size_t)cloud * n : nullptr;
-    const T* __restrict__ dlt = (const T*)B.deltas + (size_t)cloud * B.K * 6;
+    const T* __restrict__ dlt = (const T*)B.hist.deltas + (size_t)cloud * B.K * 6;
     __syncthreads();
     for (int k = k1 - 1; k >= k0; --k) {
         if (ended) {
@@ -774,12 +774,12 @@ __global__ __launch_bounds__(BLOCK) void icp_small_backward_kernel(WeightParams 
             __syncthreads();
             break;
         }
-        const T* pose_k = (const T*)B.poses + (size_t)k * N * 12;
+        const T* pose_k = (const T*)B.hist.poses + (size_t)k * N * 12;
         if (tid < NBWD) sg[tid] = spart[tid] + sgo[tid];
         if (tid < 9) sC[tid] = (double)pose_k[(size_t)cloud * 12 + tid];
         if (tid < 6) sd[tid] = (double)dlt[(size_t)k * 6 + tid];
-        if (tid < 36) sAreg[tid] = B.areg[((size_t)k * N + cloud) * 36 + tid];
-        if (B.bwd_skip && tid >= WAVE && tid < 2 * WAVE) {  // the largest step of the EARLIER iterations, per component (second wave: lanes over iterations)
+        if (tid < 36) sAreg[tid] = B.hist.areg[((size_t)k * N + cloud) * 36 + tid];
+        if (B.bwd.skip && tid >= WAVE && tid < 2 * WAVE) {  // the largest step of the EARLIER iterations, per component (second wave: lanes over iterations)
             double dm[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
             for (int j = tid - WAVE; j < k; j += WAVE) {
 #pragma unroll
@@ -799,10 +799,10 @@ __global__ __launch_bounds__(BLOCK) void icp_small_backward_kernel(WeightParams 
         if (tid == 0) {
             step_backward(sg, sg + 9, dim, sC, sd, sAreg, sGs, sGb, sgo, sgo + 9);
             s_skip = 0;
-            if (B.bwd_skip) {
-                const SkipArgs<T> sk{B.bwd_skip, B.bwd_mref, (const T*)B.alive + (size_t)k * N, B.bwd_live ? B.bwd_live + k : nullptr, B.bwd_skip_eps, k};
-                s_skip = skip_decision(sGs, sGb, sAreg, sdmax, dim, cloud, sk, sk.alive_k[cloud] != T(0), B.bwd_mref[cloud]);
-                B.bwd_skip[cloud] = s_skip;
+            if (B.bwd.skip) {
+                const SkipArgs<T> sk{B.bwd.skip, B.bwd.mref, (const T*)B.hist.alive + (size_t)k * N, B.bwd.live ? B.bwd.live + k : nullptr, B.bwd.skip_eps, k};
+                s_skip = skip_decision(sGs, sGb, sAreg, sdmax, dim, cloud, sk, sk.alive_k[cloud] != T(0), B.bwd.mref[cloud]);
+                B.bwd.skip[cloud] = s_skip;
             }
         }
         __syncthreads();
@@ -818,8 +818,8 @@ __global__ __launch_bounds__(BLOCK) void icp_small_backward_kernel(WeightParams 
         for (int a = 0; a < 36; ++a) Gs[a] = (T)sGs[a];     // rounded to T like the gs / gb buffers of the multi-kernel path
 #pragma unroll
         for (int a = 0; a < 6; ++a) Gb[a] = (T)sGb[a];
-        const T live = ((const T*)B.alive)[(size_t)k * N + cloud];
-        const int32_t* __restrict__ idx_k = B.idx + (size_t)k * N * n + (size_t)cloud * n;
+        const T live = ((const T*)B.hist.alive)[(size_t)k * N + cloud];
+        const int32_t* __restrict__ idx_k = B.hist.idx + (size_t)k * N * n + (size_t)cloud * n;
         T acc[NBWD];
 #pragma unroll
         for (int a = 0; a < NBWD; ++a) acc[a] = T(0);
@@ -857,7 +857,7 @@ __global__ __launch_bounds__(BLOCK) void icp_small_backward_kernel(WeightParams 
         }
 }
 
-// The TAIL of the windowed reverse sweep of big clouds (dicp_loop_buffers.bwd_tail_from): the iterations k1-1 .. 0 in ONE launch.
+// The TAIL of the windowed reverse sweep of big clouds (dicp_loop_buffers.bwd.tail_from): the iterations k1-1 .. 0 in ONE launch.
 // With the truncated sweep the iterations before the last few are, for almost every cloud, nothing but the pass-through of the pose
 // cotangent -- yet a pair of dependent launches each (21 us of dispatch per iteration at the benchmark shape: a third of a K = 20
 // backward).  Here, on accumulate_bwd_window's grid: block 0 of an ended cloud multiplies the cotangent through all its remaining
@@ -895,12 +895,12 @@ __global__ __launch_bounds__(BLOCK, sizeof(T) == 4 ? 2 : 1) void bwd_tail_kernel
     int cloud, blk;
     if (!decode_block(bpc, N, cloud, blk)) return;
     const int tid = threadIdx.x;
-    bool ended = B.bwd_skip[cloud] == 2;                    // (decided by an earlier launch: the same for all of the cloud's blocks)
+    bool ended = B.bwd.skip[cloud] == 2;                    // (decided by an earlier launch: the same for all of the cloud's blocks)
     if (ended && blk != 0) return;
     if (tid < 12) sgo[tid] = gpose_in[(size_t)cloud * 12 + tid];
-    if (tid == 32) smref = B.bwd_mref[cloud];
+    if (tid == 32) smref = B.bwd.mref[cloud];
     if (tid == 33) s_timeout = 0;
-    const T* __restrict__ dlt = (const T*)B.deltas + (size_t)cloud * B.K * 6;
+    const T* __restrict__ dlt = (const T*)B.hist.deltas + (size_t)cloud * B.K * 6;
     const T* cur = have_partials ? part0 : nullptr;         // the cloud's bpc rows of pose sums still to be added to the cotangent (NULL: zeros)
     int gen = 0;
     __syncthreads();
@@ -960,8 +960,8 @@ __global__ __launch_bounds__(BLOCK, sizeof(T) == 4 ? 2 : 1) void bwd_tail_kernel
             break;
         }
         // ---- step_bwd of iteration k: by every block of the cloud alike
-        const T* pose_k = (const T*)B.poses + (size_t)k * N * 12;
-        const T* alive_k = (const T*)B.alive + (size_t)k * N;
+        const T* pose_k = (const T*)B.hist.poses + (size_t)k * N * 12;
+        const T* alive_k = (const T*)B.hist.alive + (size_t)k * N;
         if (tid >= WAVE && tid < 2 * WAVE) {                // (second wave, under the first one's loads) the largest step of the EARLIER iterations, per component
             double dm[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
             for (int j = tid - WAVE; j < k; j += WAVE) {
@@ -980,7 +980,7 @@ __global__ __launch_bounds__(BLOCK, sizeof(T) == 4 ? 2 : 1) void bwd_tail_kernel
         }
         if (tid >= 2 * WAVE && tid < 2 * WAVE + 9) sC[tid - 2 * WAVE] = (double)pose_k[(size_t)cloud * 12 + (tid - 2 * WAVE)];
         if (tid >= 2 * WAVE + 16 && tid < 2 * WAVE + 22) sd[tid - 2 * WAVE - 16] = (double)dlt[(size_t)k * 6 + (tid - 2 * WAVE - 16)];
-        if (tid >= 3 * WAVE && tid < 3 * WAVE + 36) sAreg[tid - 3 * WAVE] = B.areg[((size_t)k * N + cloud) * 36 + (tid - 3 * WAVE)];
+        if (tid >= 3 * WAVE && tid < 3 * WAVE + 36) sAreg[tid - 3 * WAVE] = B.hist.areg[((size_t)k * N + cloud) * 36 + (tid - 3 * WAVE)];
         if (tid == 3 * WAVE + 40) s_alive = alive_k[cloud] != T(0) ? 1 : 0;
         fold(cur);
         cur = nullptr;
@@ -1025,17 +1025,17 @@ __global__ __launch_bounds__(BLOCK, sizeof(T) == 4 ? 2 : 1) void bwd_tail_kernel
                 if (!s_alive) verdict = 1;
                 else {
                     const double worst = gmax * amp > mm ? gmax * amp : mm;
-                    if (!nan && 16.0 * worst <= B.bwd_skip_eps * smref) verdict = 2;
+                    if (!nan && 16.0 * worst <= B.bwd.skip_eps * smref) verdict = 2;
                     else {
                         // (kept in the block until the launch ends: a sibling block that STARTS after block 0 has been here -- dispatch is in index order, not
                         //  simultaneous -- would read the raised value where block 0 compared with the old one, could reach another verdict for this very
                         //  iteration and leave, and the cloud's other blocks would wait for it until their patience ran out: the TailTimeout seen once in a
                         //  thousand calls on planar scenes, rounds 5 and 6)
                         if (!nan && mm > smref) smref = mm;
-                        if (blk == 0 && B.bwd_live) atomicAdd(B.bwd_live + k, 1);
+                        if (blk == 0 && B.bwd.live) atomicAdd(B.bwd.live + k, 1);
                     }
                 }
-                if (blk == 0) B.bwd_skip[cloud] = verdict;  // (nobody reads it again in this launch: the cloud's blocks all hold the same verdict)
+                if (blk == 0) B.bwd.skip[cloud] = verdict;  // (nobody reads it again in this launch: the cloud's blocks all hold the same verdict)
                 s_verdict = verdict;
             }
             if (tid < 36) sGsT[tid] = (T)sGs[tid];          // rounded to T like the gs / gb buffers of the per-iteration launches
@@ -1052,9 +1052,9 @@ __global__ __launch_bounds__(BLOCK, sizeof(T) == 4 ? 2 : 1) void bwd_tail_kernel
         // ---- this block's share of accumulate_bwd of iteration k
         ++gen;
         T* out = (gen & 1) ? part1 : part0;
-        const MatchHist mh = (B.spos_of && k >= B.spos_of_from) ? MatchHist{B.spos, B.spos_of, k, N, n, (n + WAVE - 1) / WAVE} : plain_matches(B.spos + (size_t)k * N * n, N, n);
-        window_body<T, MODE, WT, false>(P, (const T*)B.src, (const T*)B.tgt, B.c, mh, B.spos_ref, B.qorder, pose_k, (const T*)B.w_init, alive_k,
-                                        sGsT, sGbT, n, B.m_pad, spb, bpc, gsrc_s, slab, (T*)B.gts_far, gw_s, spub, B.src_rows, cloud, blk);
+        const MatchHist mh = (B.hist.spos_of && k >= B.hist.spos_of_from) ? MatchHist{B.hist.spos, B.hist.spos_of, k, N, n, (n + WAVE - 1) / WAVE} : plain_matches(B.hist.spos + (size_t)k * N * n, N, n);
+        window_body<T, MODE, WT, false>(P, (const T*)B.src, (const T*)B.tgt, B.c, mh, B.bwd.spos_ref, B.search.qorder, pose_k, (const T*)B.w_init, alive_k,
+                                        sGsT, sGbT, n, B.search.m_pad, spb, bpc, gsrc_s, slab, (T*)B.bwd.gts_far, gw_s, spub, B.src_rows, cloud, blk);
         // ---- publish the pose sums; wait until all of the cloud's blocks have published theirs.  The hand-off is a handful of words: they are
         // written and read as agent-scope atomics (coherent where they live; a release / acquire FENCE at agent scope writes back and
         // invalidates the whole L2 -- tens of microseconds under this kernel's gradient traffic), each store complete (the workgroup-scope
@@ -1080,7 +1080,7 @@ __global__ __launch_bounds__(BLOCK, sizeof(T) == 4 ? 2 : 1) void bwd_tail_kernel
                     if (++spins > (1 << 20)) {              // ~0.5 s: the cloud's other blocks are not running (dicp_bwd_tail_max_blocks keeps that from happening)
                         // (nonzero = a wait ran out; the words say whose, for the report: cloud and iteration | arrivals seen, block, generation)
                         atomicExch(arrive + N, 0x40000000 | ((cloud & 0xffff) << 8) | (k & 0xff));
-                        if (B.bwd_live) atomicExch(B.bwd_live + B.K, 0x40000000 | ((__hip_atomic_load(arrive + cloud, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xfff) << 16) | ((blk & 0xff) << 8) | (gen & 0xff));
+                        if (B.bwd.live) atomicExch(B.bwd.live + B.K, 0x40000000 | ((__hip_atomic_load(arrive + cloud, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xfff) << 16) | ((blk & 0xff) << 8) | (gen & 0xff));
                         s_timeout = 1;
                         break;
                     }
@@ -1098,6 +1098,6 @@ __global__ __launch_bounds__(BLOCK, sizeof(T) == 4 ? 2 : 1) void bwd_tail_kernel
     if (blk == 0) {
         fold(cur);
         if (tid < 12) gpose_out[(size_t)cloud * 12 + tid] = sg[tid];
-        if (tid == 0) B.bwd_mref[cloud] = smref;            // (the largest contribution measure so far, for a later chunk's launches)
+        if (tid == 0) B.bwd.mref[cloud] = smref;            // (the largest contribution measure so far, for a later chunk's launches)
     }
 }

@@ -140,7 +140,7 @@ template <typename T> struct SweepCert {
     int32_t* slist; int32_t* scount;    // (N,n) / (N) zeros: per cloud, the slots that were given a candidate set (appended by the search that made it; entries whose set
                                     // no longer stands are skipped, the list is emptied when the whole cloud is searched again).  The guard launch re-scores the
                                     // standing sets 64 to a wave from this list: a unit whose only open queries have sets is not looked at for them
-    // Plain searches of the loop, scoring form per cloud (dicp_loop_buffers.sweep_form): form_out[cloud] += the 64-row tiles this unit's slab had; a launch given
+    // Plain searches of the loop, scoring form per cloud (dicp_loop_buffers.search.form): form_out[cloud] += the 64-row tiles this unit's slab had; a launch given
     // form_in (the previous plain search's tally) leaves a cloud alone unless its slabs were long (form_mine = 1: the matrix-core form) / short (0: this one)
     const int32_t* form_in; int32_t* form_out; int form_mine, form_default;     // (form_default: the form of a cloud without a tally -- 0 in form_in: no plain search before)
 };

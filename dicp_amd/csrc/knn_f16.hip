@@ -74,7 +74,7 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 }
 
 // per cloud: the scale and the far rows.  One block per cloud.
-// Which clouds a launch concerns (the loop's per-cloud choice of the scoring form, dicp_loop_buffers.sweep_form): those whose last plain search tallied more than
+// Which clouds a launch concerns (the loop's per-cloud choice of the scoring form, dicp_loop_buffers.search.form): those whose last plain search tallied more than
 // `tiles` 64-row tiles per unit of 128 queries (no tally: if dflt).
 struct FormPick {
     const int32_t* tally; const int32_t* src_rows; int n_full, tiles, dflt;

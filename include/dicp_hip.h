@@ -31,16 +31,18 @@ extern "C" {
 #endif
 
 #define DICP_ABI_VERSION 11  /* 11: dicp_search_frame takes the queries (src under T_init): the sort direction is chosen for THEIR slabs; dicp_query_reorder (a re-ordering
-                                keeps the order of a cloud that hardly moved); dicp_loop_buffers.sweep_form_plan (one scoring form per iteration from an earlier call's tallies); dicp_match_order (the deterministic backward's slot order, natively).
+                                keeps the order of a cloud that hardly moved); dicp_loop_buffers.search.form_plan (one scoring form per iteration from an earlier call's tallies); dicp_match_order (the deterministic backward's slot order, natively);
+                                dicp_loop_buffers is ONE VERSIONED struct: `abi` first (the entry points return DICP_ERR_ABI for another layout), its ~80 fields in four sub-structs
+                                (search / cert / hist / bwd); dicp_step_io.cert_slist.
                                 10: dicp_pack_list / dicp_unpack_list (lists of clouds to one padded batch and back, one launch each).
-                                9: dicp_loop_buffers.det_far_row / det_far_val (deterministic target gradients of the windowed backward).
-                                8: certified iterations keep a row cache and their match history by reference (dicp_loop_buffers.spos_of / cert_nbr / cert_gdirty /
+                                9: dicp_loop_buffers.bwd.det_far_row / det_far_val (deterministic target gradients of the windowed backward).
+                                8: certified iterations keep a row cache and their match history by reference (dicp_loop_buffers.hist.spos_of / cert_nbr / cert_gdirty /
                                 cert_pend / cert_cm, spos_prev_chunk + spos_floor instead of spos_prev0; dicp_resolve_matches).
                                 7: dicp_call_* (one eager call of the sweep path behind one host call per direction).
                                 6: dicp_bwd_tail_max_blocks (the one-launch tail only where a cloud's blocks are all resident; a wait that runs out poisons the
                                 cloud's gradients with NaN and raises bwd_live[K] next to bwd_tail_arrive[N]); bwd_live is (K + 1).
-                                5: dicp_loop_buffers.bwd_tail_from (the ended iterations of the truncated reverse sweep as one launch).
-                                4: dicp_loop_buffers.bwd_skip / bwd_mref / bwd_live / bwd_skip_eps (truncated reverse sweep of dicp_icp_backward); cert_cloud (per-cloud switch of the
+                                5: dicp_loop_buffers.bwd.tail_from (the ended iterations of the truncated reverse sweep as one launch).
+                                4: dicp_loop_buffers.bwd.skip / bwd_mref / bwd_live / bwd_skip_eps (truncated reverse sweep of dicp_icp_backward); cert_cloud (per-cloud switch of the
                                 match certificates); dicp_cloud_center -> dicp_search_frame: centre AND sort direction as one affine map per cloud, (N,12).
                                 3: per-cloud row counts of ragged batches (src_rows / tgt_rows) on every entry point of the path; the centred and
                                 uncentred forms of an entry point are one (center may be NULL); the key sort is native for every size and dtype;
@@ -50,8 +52,8 @@ enum { DICP_F32 = 0, DICP_F64 = 1 };
 enum { DICP_PT2PT = 0, DICP_PT2PL = 1 };                 /* ICP(icp_type=...)  ICP.py:15,101-105 */
 enum { DICP_LOSS_NONE = 0, DICP_LOSS_HUBER = 1, DICP_LOSS_CAUCHY = 2, DICP_LOSS_TRIM = 3 };
 enum { DICP_KNN_AUTO = 0, DICP_KNN_VALU = 1, DICP_KNN_MFMA = 2, DICP_KNN_SWEEP = 3 /* via dicp_knn_sweep */,
-       DICP_KNN_GUMBEL = 4 /* dicp_icp_forward / _backward only: soft correspondences, dicp_loop_buffers.gumbel */ };
-enum { DICP_ERR_NULL = 1, DICP_ERR_SHAPE = 2, DICP_ERR_DTYPE = 3, DICP_ERR_ENUM = 4, DICP_ERR_ALIGN = 5 };
+       DICP_KNN_GUMBEL = 4 /* dicp_icp_forward / _backward only: soft correspondences, dicp_loop_buffers.search.gumbel */ };
+enum { DICP_ERR_NULL = 1, DICP_ERR_SHAPE = 2, DICP_ERR_DTYPE = 3, DICP_ERR_ENUM = 4, DICP_ERR_ALIGN = 5, DICP_ERR_ABI = 6 /* dicp_loop_buffers.abi is not this library's */ };
 
 /* Accumulator layout of one (cloud, block) partial: see dicp_amd/csrc/dicp_math.h */
 #define DICP_NACC_PAD 32   /* 21 A-upper, 6 b, cost, sum w, #matched, 2 pad */
@@ -89,7 +91,7 @@ int dicp_accumulate_blocks(int n);
  * scan pairs that overlap only partly reach metres far outside the common footprint, and a direction oblique to its edge then puts a third of
  * the target into those slabs.  Points beyond 32x the sample's mean deviation from the centre (a ragged cloud's far pad row) do not stretch
  * the histograms' span.
- * Entry points given `frame` pack rows as Q y + t, and the caller hands the searches the pose [Q C | Q r + t] (dicp_loop_buffers.poses_search;
+ * Entry points given `frame` pack rows as Q y + t, and the caller hands the searches the pose [Q C | Q r + t] (dicp_loop_buffers.search.poses;
  * dicp_loop_init / the step kernels write it).  Every search form reads only (pose, packed rows): with the same frame they return the same
  * indices as each other; Q = I is applied as the plain subtraction it is, and with t == 0 too (clouds near the origin, given a quantum) the
  * results are exactly those of frame == NULL. */
@@ -259,9 +261,9 @@ typedef struct dicp_step_io {
     const void* rmax;        /* optional (N,4) T: bounding radius and midpoint of each source cloud (dicp_loop_init) */
     void* dcum;              /* optional T: cloud b's (motion bound, point rounding) pairs at dcum + b*dcum_stride: [2(iter+1)] = [2 iter] + how far any
                                 query of the cloud can have moved between pose_in and pose_out, [2(iter+1)+1] = the rounding of a point transformed
-                                with pose_out (match certificates, dicp_loop_buffers.cert_q) */
+                                with pose_out (match certificates, dicp_loop_buffers.cert.q) */
     int64_t dcum_stride;
-    int32_t* cert_cloud;     /* optional (N,8): per-cloud counters of the match certificates (dicp_loop_buffers.cert_cloud); the step decides
+    int32_t* cert_cloud;     /* optional (N,8): per-cloud counters of the match certificates (dicp_loop_buffers.cert.cloud); the step decides
                                 from them whether the cloud's certificates stay on */
     /* Match certificates, optional: the step also makes the NEXT iteration's guard launch its work list -- the units whose filter value (cert_qu) does not stand
        under the motion bound it has just written, or all units of a cloud whose certificates are off / tried again.  A guard launch with one wave per unit
@@ -272,7 +274,7 @@ typedef struct dicp_step_io {
     int32_t glist_cap;       /* entries per list */
     int32_t* glist;          /* (8, glist_cap) int32: entry = cloud * cert_units + unit, list = cloud & 7 (the XCD the cloud's blocks run on) */
     int32_t* gcount;         /* (8) zeros: entries in each list of the next iteration */
-    int32_t* cert_scount;    /* optional (N): lengths of the clouds' candidate-set lists (dicp_loop_buffers.cert_scount): 64 sets make one more entry, -1 - (cloud * ceil(n/64) + chunk) */
+    int32_t* cert_scount;    /* optional (N): lengths of the clouds' candidate-set lists (dicp_loop_buffers.cert.scount): 64 sets make one more entry, -1 - (cloud * ceil(n/64) + chunk) */
     int32_t* cert_slist;     /* with cert_scount, (N, n): the lists themselves -- the step fills the tail of a list's last chunk of 64 with -1 and moves the length up to it, so that the
                                 next guard launch's appends never land inside a chunk that launch is re-scoring */
     int32_t w_copied;        /* 1: the accumulate launch of this iteration already wrote w_prev into w_cur for the clouds that are frozen (alive = 0;
@@ -299,12 +301,8 @@ typedef struct dicp_gumbel_loop {
     void* g_ps;              /* dicp_icp_backward: (N,n,3) scratch */
 } dicp_gumbel_loop;
 
-typedef struct dicp_loop_buffers {
-    const void* src;         /* (N,n,3) */
-    const void* tgt;         /* (N,m,c) */
-    const void* w_init;      /* (N,n); NULL = unit weights (the reference's weight=None: 4 bytes per point and launch less to read) */
-    int32_t c;
-    int32_t K;               /* capacity of the histories (= max_iterations) */
+/* dicp_loop_buffers.search -- the nearest-neighbour search of the loop: the packed / sorted target, the sweep's index and query order, the search frame, the scoring form */
+typedef struct dicp_search_buffers {
     int32_t knn_variant;     /* DICP_KNN_VALU | _MFMA (uses tgt4) or DICP_KNN_SWEEP (uses tgt4 = tgs4 + the arrays below); bits 8..15: optional
                                 launch configuration (as dicp_knn / dicp_knn_sweep); bit 25: never take the one-block-per-cloud small path */
     int32_t m_pad;
@@ -314,86 +312,98 @@ typedef struct dicp_loop_buffers {
     const int32_t* bucket;   /* sweep only */
     const void* brange;      /* sweep only */
     int32_t nbkt;
-    int32_t idx_per_iter;    /* 1: idx / spos are (K,N,n) and every iteration keeps its own (needed for backward); 0: (N,n) reused */
-    unsigned long long* pairs;   /* sweep only, optional: DICP_PAIR_SHARDS counters */
+    unsigned long long* pairs; /* sweep only, optional: DICP_PAIR_SHARDS counters */
+    const void* frame;       /* optional (N,12) T: the search frame (dicp_search_frame); tgt4 / the sweep index were then
+                                built with it */
+    void* poses;             /* optional (K+1,N,12) T: [Q C | Q r + t] per iteration, written by dicp_loop_init (k = 0) and
+                                the step kernels; the searches read it instead of poses.  NULL: they read poses */
+    const void* tgt_sorted;  /* sweep only, optional (N,m_pad,tgt_sorted_stride): dicp_sweep_build's tgt_s.  With it (and spos) the forward accumulate
+                                gathers the match rows from the sorted copy at spos -- one aligned sector per row -- and idx may be NULL */
+    int32_t tgt_sorted_stride;
+    const dicp_gumbel_loop* gumbel; /* knn_variant DICP_KNN_GUMBEL: the soft correspondences' buffers (idx / spos / tgt4 are then unused; gtgt of dicp_icp_backward
+                                is (N,m,c) zeros and is added to; no truncated sweep: the matches themselves carry gradient) */
+    int32_t first_done;      /* sweep path: 1 = the matches of iteration 0 are already in spos (the caller enqueued dicp_knn_sweep under pose_search[0] and
+                                   the first query order itself, right behind the index build, so that the search runs while the host is still
+                                   preparing the loop): dicp_icp_forward then starts iteration 0 at its accumulate */
+    const void* tgt_f16;     /* optional, float32: the split-f16 image of tgt4 (dicp_knn_f16_pack, with the same tgt_rows).  DICP_KNN_MFMA needs it; on the
+                                sweep path (tgt4 = the sorted rows) the plain searches of big problems score on the matrix cores when it is given */
+    int32_t* form;           /* sweep path, optional (K, N) int32 ZEROS: the plain search of iteration k tallies its slabs' tiles per cloud in row k and, given tgt_f16,
+                                takes the scoring form of every cloud from row k-1 (dicp_knn_sweep's form_in / form_out; a row of zeros: no plain search then).
+                                Without tgt_f16 the tallies are only kept (a caller may decide from them whether the next call of the shape gets the image) */
+    int32_t form_default;    /* the form of a cloud without a tally: 0 vector, 1 matrix cores */
+    const int32_t* form_plan; /* optional HOST array (K) int32, read during the call: the form of iteration k's plain search for EVERY cloud -- 1 vector, 2 matrix
+                                cores (needs tgt_f16), 0 as above (by the tallies / the default).  A caller that has seen an earlier call's tallies of the same shape
+                                plans with them: one launch per search instead of the two of the per-cloud choice */
+} dicp_search_buffers;
+
+/* dicp_loop_buffers.cert -- match certificates (sweep path, optional: q == NULL = off): which queries' matches are PROVEN unchanged, so that an iteration searches only the others */
+typedef struct dicp_cert_buffers {
+    void* q;                 /* sweep only, optional (N,n) T, by query: match certificates ("budgets": see knn_sweep_kernel).  With them the first iteration
+                                of a query order searches every query and writes its budget; a later one searches only the queries whose match is
+                                not PROVEN unchanged -- whole units in a guard launch where many are, the others inside dicp_accumulate's launch
+                                (exact: same indices as a full search).  Needs spos (and no idx), tgt_sorted, qorder, cert.qu, rmax, dcum */
+    void* qu;                /* (N, ceil(n/64)) T scratch */
+    void* set;               /* optional, N*n*(sizeof(T) + 16) bytes of scratch: candidate sets -- a query whose match has a runner-up inside the rounding allowance
+                                of the scores (dense surfaces, duplicated targets) gets no certificate of its own; the search that finds this keeps the
+                                rows of its 4 smallest scores and a budget from the best row OUTSIDE that set, and while the budget stands the accumulate
+                                re-scores those 4 rows instead of searching (exact: the match stays strictly below every outside row) */
+    int32_t* count;          /* optional (K,128) zeros: per iteration, units searched again [0,64) and single queries [64,128), sharded by block */
+    void* rmax;              /* (N,4) T from dicp_loop_init: bounding radius and midpoint of each source cloud */
+    void* dcum;              /* (N, 2(K+1)) T: per iteration (motion bound since iteration 0, rounding of a transformed point); dicp_loop_init
+                                writes iteration 0's, the step kernels the rest */
+    int32_t reset;           /* 1: qorder is new in this call's first iteration: that iteration searches every query */
+    int32_t* cloud;          /* optional (N,8) zeros, per cloud: units / single queries searched again in the current iteration, and the state the
+                                step kernel keeps from them: certificates that cost more than 60 % of a full search are switched off -- for good where
+                                the evidence is structural (queries without any certificate after a search of every unit), for 2, 4, .. 16 iterations
+                                and then certified afresh where a guarded iteration was costly twice in a row (a cloud that is still moving).
+                                While off, every unit of the cloud is searched plainly and nothing is checked: results are the same either way */
+    void* nbr;               /* (N, n, 6 | 3) T scratch (pt2pl | pt2pt): the matched target row of every query, rewritten where a match changes */
+    int32_t* gdirty;         /* (N, ceil(n/64)) int32 scratch: 1 = the guard launch of the iteration changed a match among these 64 consecutive queries */
+    int32_t* pend;           /* (N, n) int32 ZEROS, by query: a match the guard launch CHANGED, left for the accumulate of the same iteration (match + 2) */
+    int32_t* glist;          /* (8, max(N, 2) * ceil(n/64)) int32 scratch: the guard launches' work lists (dicp_step_io.glist), rewritten by every step */
+    int32_t* gcount;         /* (K + 1, 8) int32 ZEROS: their lengths, per iteration */
+    int32_t* slist;          /* with cert.set, (N, n) int32 scratch: per cloud, the slots that were given a candidate set -- the guard launch re-scores the standing
+                                ones 64 to a wave from it */
+    int32_t* scount;         /* (N) int32 ZEROS: its lengths */
+    int32_t* cm;             /* (N, n) int32 scratch, by slot of the query order: the searches' own copy of the current matches.  The certificates' state
+                                (cert.q, cert.set, cert.cm) goes by SLOT: the guard launch, which alone reads it, takes a unit's share as one coalesced piece */
+} dicp_cert_buffers;
+
+/* dicp_loop_buffers.hist -- what every iteration leaves for the result and for the reverse sweep: poses, steps, costs, matches, weights */
+typedef struct dicp_history_buffers {
+    int32_t per_iter;        /* 1: idx / spos are (K,N,n) and every iteration keeps its own (needed for backward); 0: (N,n) reused */
     int32_t* spos;           /* sweep only, optional (K,N,n): per-iteration sorted match positions.  Non-NULL in dicp_icp_backward
                                 selects dicp_accumulate_bwd_window: src / w_init / tgt are then the SORTED copies it documents,
                                 gsrc / gw accumulate in slot order, gtgt is the slab, bwd_partials has dicp_window_blocks blocks */
-    const int32_t* spos_ref; /* backward, windowed form: (N,n) reference matches that place the windows; qorder = its slot order */
-    void* gts_far;           /* backward, windowed form: (N,m_pad,CV) atomically accumulated out-of-window rows */
     void* poses;             /* (K+1,N,12): poses[0] = initial pose, poses[k+1] written by iteration k */
     void* deltas;            /* (N,K,6) */
     void* costs;             /* (N,K) */
     double* areg;            /* (K,N,36) or NULL when no backward is needed */
     void* alive;             /* (K+1,N): alive[0] = 1, alive[k+1] written by iteration k */
-    uint8_t* converged;      /* (N) zero-initialised */
-    void* iterations;        /* (N) zero-initialised */
-    void* matched_ratio;     /* (N) zero-initialised */
-    const void* n_start;     /* (N) */
-    void* n_matched;         /* (N) */
     int32_t* idx;            /* (K,N,n) or (N,n); optional on the sweep path when tgt_sorted and spos are given */
     void* w;                 /* weights of every iteration: iteration k, cloud b at w + k*w_iter + b*w_stride (elements);
                                 (N,K,n): w_iter = n, w_stride = K*n.  May be a per-slab virtual base: only [k0,k1) is touched */
     int64_t w_iter, w_stride;
     const void* w_prev0;     /* weights of iteration k0-1 (cloud stride w_stride too), or NULL when k0 == 0   ICP.py:224-226 */
-    void* partials;          /* (N, dicp_accumulate_blocks(n), DICP_NACC_PAD) scratch */
-    int32_t* counters;       /* (K) zero-initialised: #clouds with |delta| >= tol at iteration k */
-    void** events;           /* optional 6*K hipEvent_t: [6k] before / [6k+1] after the kNN of iteration k, [6k+2] / [6k+3] its
-                                accumulate (forward), [6k+4] / [6k+5] its accumulate_bwd (backward); NULL = none.  The sweep,
-                                accumulate and windowed-backward launches take their pair as the start / stop events of the
-                                dispatch (hipExtLaunchKernel), the other forms are bracketed by hipEventRecord */
-    int32_t bwd_overwrite;   /* dicp_icp_backward, windowed form: 1 = gsrc / gw / the slab (gtgt) are uninitialised and this call's
-                                first launch (iteration k1-1) writes them instead of adding; 0 = they are accumulators */
-    const void* frame;       /* optional (N,12) T: the search frame (dicp_search_frame); tgt4 / the sweep index were then
-                                built with it */
-    void* poses_search;      /* optional (K+1,N,12) T: [Q C | Q r + t] per iteration, written by dicp_loop_init (k = 0) and
-                                the step kernels; the searches read it instead of poses.  NULL: they read poses */
-    const int32_t* src_rows; /* optional (N): rows of each source cloud that take part (ragged batches); qorder, if any, from dicp_query_order
-                                with the same counts */
-    const int32_t* tgt_rows; /* optional (N): rows of each target cloud that take part; tgt4 / the sweep index built with the same counts */
-    void* cert_q;            /* sweep only, optional (N,n) T, by query: match certificates ("budgets": see knn_sweep_kernel).  With them the first iteration
-                                of a query order searches every query and writes its budget; a later one searches only the queries whose match is
-                                not PROVEN unchanged -- whole units in a guard launch where many are, the others inside dicp_accumulate's launch
-                                (exact: same indices as a full search).  Needs spos (and no idx), tgt_sorted, qorder, cert_qu, rmax, dcum */
-    void* cert_qu;           /* (N, ceil(n/64)) T scratch */
-    void* cert_set;          /* optional, N*n*(sizeof(T) + 16) bytes of scratch: candidate sets -- a query whose match has a runner-up inside the rounding allowance
-                                of the scores (dense surfaces, duplicated targets) gets no certificate of its own; the search that finds this keeps the
-                                rows of its 4 smallest scores and a budget from the best row OUTSIDE that set, and while the budget stands the accumulate
-                                re-scores those 4 rows instead of searching (exact: the match stays strictly below every outside row) */
-    int32_t* cert_count;     /* optional (K,128) zeros: per iteration, units searched again [0,64) and single queries [64,128), sharded by block */
-    void* rmax;              /* (N,4) T from dicp_loop_init: bounding radius and midpoint of each source cloud */
-    void* dcum;              /* (N, 2(K+1)) T: per iteration (motion bound since iteration 0, rounding of a transformed point); dicp_loop_init
-                                writes iteration 0's, the step kernels the rest */
-    int32_t cert_reset;      /* 1: qorder is new in this call's first iteration: that iteration searches every query */
-    int32_t* cert_cloud;     /* optional (N,8) zeros, per cloud: units / single queries searched again in the current iteration, and the state the
-                                step kernel keeps from them: certificates that cost more than 60 % of a full search are switched off -- for good where
-                                the evidence is structural (queries without any certificate after a search of every unit), for 2, 4, .. 16 iterations
-                                and then certified afresh where a guarded iteration was costly twice in a row (a cloud that is still moving).
-                                While off, every unit of the cloud is searched plainly and nothing is checked: results are the same either way */
     const int32_t* spos_prev_chunk; /* certified iterations, histories in several slabs: the virtual base of the slabs BEFORE the one `spos` addresses
                                 (iteration s < spos_floor at spos_prev_chunk + s*N*n), NULL when spos_floor == 0 */
     int32_t spos_floor;      /* first iteration of the history slab `spos` addresses (0: one slab) */
     /* Certified iterations keep the match history BY REFERENCE and the matched rows in a cache (accumulate_kernel, csrc/kernels_accumulate.h).
        Near the pose almost no match changes from one iteration to the next: copying every match into the next iteration's slab, reading every
        budget and gathering every 24-byte row again was 19 of the 63 bytes per point such a launch moved (section 8d counts 44). */
-    int32_t* spos_of;        /* (K+1, N, ceil(n/64)) int32, needed with cert_q when idx_per_iter: spos_of[k][b][g] = the iteration whose slab of `spos` holds
+    int32_t* spos_of;        /* (K+1, N, ceil(n/64)) int32, needed with cert.q when hist.per_iter: spos_of[k][b][g] = the iteration whose slab of `spos` holds
                                 the matches of queries [64g, 64g+64) of cloud b at iteration k >= spos_of_from.  Written by the certified iterations' accumulate
                                 (rows k and k+1); dicp_icp_backward reads the matches through it */
     int32_t spos_of_from;    /* dicp_icp_backward: iterations below it have complete slabs of their own (the searches before the certificates start); the
                                 forward ignores it */
-    void* cert_nbr;          /* (N, n, 6 | 3) T scratch (pt2pl | pt2pt): the matched target row of every query, rewritten where a match changes */
-    int32_t* cert_gdirty;    /* (N, ceil(n/64)) int32 scratch: 1 = the guard launch of the iteration changed a match among these 64 consecutive queries */
-    int32_t* cert_pend;      /* (N, n) int32 ZEROS, by query: a match the guard launch CHANGED, left for the accumulate of the same iteration (match + 2) */
-    int32_t* cert_glist;     /* (8, max(N, 2) * ceil(n/64)) int32 scratch: the guard launches' work lists (dicp_step_io.glist), rewritten by every step */
-    int32_t* cert_gcount;    /* (K + 1, 8) int32 ZEROS: their lengths, per iteration */
-    int32_t* cert_slist;     /* with cert_set, (N, n) int32 scratch: per cloud, the slots that were given a candidate set -- the guard launch re-scores the standing
-                                ones 64 to a wave from it */
-    int32_t* cert_scount;    /* (N) int32 ZEROS: its lengths */
-    int32_t* cert_cm;        /* (N, n) int32 scratch, by slot of the query order: the searches' own copy of the current matches.  The certificates' state
-                                (cert_q, cert_set, cert_cm) goes by SLOT: the guard launch, which alone reads it, takes a unit's share as one coalesced piece */
-    const void* tgt_sorted;  /* sweep only, optional (N,m_pad,tgt_sorted_stride): dicp_sweep_build's tgt_s.  With it (and spos) the forward accumulate
-                                gathers the match rows from the sorted copy at spos -- one aligned sector per row -- and idx may be NULL */
-    int32_t tgt_sorted_stride;
+} dicp_history_buffers;
+
+/* dicp_loop_buffers.bwd -- dicp_icp_backward only: the windowed form's placement and side buffer, the truncated reverse sweep, its one-launch tail, deterministic target gradients */
+typedef struct dicp_bwd_buffers {
+    const int32_t* spos_ref; /* backward, windowed form: (N,n) reference matches that place the windows; qorder = its slot order */
+    void* gts_far;           /* backward, windowed form: (N,m_pad,CV) atomically accumulated out-of-window rows */
+    int32_t overwrite;       /* dicp_icp_backward, windowed form: 1 = gsrc / gw / the slab (gtgt) are uninitialised and this call's
+                                first launch (iteration k1-1) writes them instead of adding; 0 = they are accumulators */
     /* dicp_icp_backward, optional: truncated reverse sweep.  Going backwards, iteration k adds to every gradient something LINEAR in the
        cotangent (G_A + G_A^T, g_b)_k of its normal equations, and the chain of pose cotangents shrinks by orders of magnitude per iteration near
        the pose (a Gauss-Newton step near its fixed point is a strong contraction).  step_bwd measures, per cloud and in the data's own units,
@@ -401,54 +411,69 @@ typedef struct dicp_loop_buffers {
        (|g_a| s_a times the largest recorded step |delta_k',b| s_b of the iterations before k), and ENDS the cloud's sweep at iteration k -- this
        and all earlier iterations do no per-point work; of the pose cotangent only the part that does not go through the normal equations
        (C_new = exp(delta^)^T C: gC = R gCn, gr = grn) travels on to the gradient of T_init -- when 16x the larger of the two is
-       below bwd_skip_eps times the largest m of the cloud's later iterations.  The host side passes a few units of the result type's roundoff
+       below bwd.skip_eps times the largest m of the cloud's later iterations.  The host side passes a few units of the result type's roundoff
        (2^-22 for float32, 2^-40 for float64): what is dropped is below the resolution of the sums it would be added to.  Iterations at which a
-       cloud was frozen (alive = 0) are skipped too (every term is exactly zero).  bwd_skip NULL = off: every iteration runs, like autograd. */
-    int32_t* bwd_skip;       /* (N) zero-initialised once per backward pass (all chunks of it share it): 0 take part / 1 frozen at this iteration / 2 sweep ended */
-    double* bwd_mref;        /* (N) zero-initialised once per backward pass */
-    int32_t* bwd_live;       /* optional (K + 1) zeros: clouds that took part in iteration k; [K]: raised with bwd_tail_arrive[N] (so that one copy brings the host both) */
-    double bwd_skip_eps;
-    int32_t bwd_tail_from;   /* windowed form with bwd_skip: the iterations k < bwd_tail_from run as ONE launch (0: every iteration is its own pair of
+       cloud was frozen (alive = 0) are skipped too (every term is exactly zero).  bwd.skip NULL = off: every iteration runs, like autograd. */
+    int32_t* skip;           /* (N) zero-initialised once per backward pass (all chunks of it share it): 0 take part / 1 frozen at this iteration / 2 sweep ended */
+    double* mref;            /* (N) zero-initialised once per backward pass */
+    int32_t* live;           /* optional (K + 1) zeros: clouds that took part in iteration k; [K]: raised with bwd.tail_arrive[N] (so that one copy brings the host both) */
+    double skip_eps;
+    int32_t tail_from;       /* windowed form with bwd.skip: the iterations k < bwd.tail_from run as ONE launch (0: every iteration is its own pair of
                                 launches).  Before the last few iterations almost every cloud's sweep has ended, and a pair of dependent launches per
                                 iteration is pure dispatch time.  On accumulate_bwd_window's grid, that launch multiplies an ended cloud's pose cotangent
                                 through all its remaining iterations; a cloud that is still at work is swept by its own blocks together, iteration by
                                 iteration (each block runs the cloud's step_bwd itself, then its share of accumulate_bwd_window, and waits on a per-cloud
                                 counter for the others' pose sums): the same arithmetic as the per-iteration launches.  The call must then run down to
                                 k0 = 0, and the cotangent it leaves INCLUDES the last pose sums (dicp_pose_grad_out without partials).  The first
-                                iteration of a backward pass (bwd_overwrite) always takes the per-iteration launches.  The caller picks the iteration
+                                iteration of a backward pass (bwd.overwrite) always takes the per-iteration launches.  The caller picks the iteration
                                 from where the previous call's sweeps ended. */
-    void* bwd_tail_partials; /* (N, dicp_window_blocks, DICP_NBWD_PAD): the second buffer of pose sums of that launch */
-    int32_t* bwd_tail_arrive;/* (N + 1) zeros per backward pass: its per-cloud counters; [N] is raised if a wait ran out.  That cannot happen while a cloud's
+    void* tail_partials;     /* (N, dicp_window_blocks, DICP_NBWD_PAD): the second buffer of pose sums of that launch */
+    int32_t* tail_arrive;    /* (N + 1) zeros per backward pass: its per-cloud counters; [N] is raised if a wait ran out.  That cannot happen while a cloud's
                                 blocks are all resident, which dicp_bwd_tail_max_blocks guarantees for a launch that has the GPU to itself (or shares it with one
                                 more of its kind); a GPU kept full by other work for longer than the wait's bound (~0.5 s) can still make one run out.  The
                                 block then stops waiting for good and folds NaN from there on: the cloud's pose cotangent and (part of) its point gradients
                                 come out NaN, never as plausible wrong numbers, and the caller must treat the error word as a failed call.
                                 (Nonzero = failed.  The words also say whose wait it was, for the report: [N] = 0x40000000 | cloud << 8 | iteration;
-                                bwd_live[K] = 0x40000000 | arrivals seen << 16 | block << 8 | generation.)
+                                bwd.live[K] = 0x40000000 | arrivals seen << 16 | block << 8 | generation.)
                                 Hand-off between the blocks (hardware assumption, gfx950): the pose sums are written and read with agent-scope atomic
                                 accesses (sc1: served by the memory side, coherent across the XCDs' L2s) and counted with an agent-scope atomic add after
                                 the storing wave's s_waitcnt vmcnt(0) -- MI355X_MICROARCH's measured hand-off form, not the C++ memory model's release /
                                 acquire pair (an agent-scope fence writes back / invalidates the XCD's whole L2: 70 us per iteration against 26) */
-    const dicp_gumbel_loop* gumbel; /* knn_variant DICP_KNN_GUMBEL: the soft correspondences' buffers (idx / spos / tgt4 are then unused; gtgt of dicp_icp_backward
-                                is (N,m,c) zeros and is added to; no truncated sweep: the matches themselves carry gradient) */
-    int32_t first_search_done;  /* sweep path: 1 = the matches of iteration 0 are already in spos (the caller enqueued dicp_knn_sweep under pose_search[0] and
-                                   the first query order itself, right behind the index build, so that the search runs while the host is still
-                                   preparing the loop): dicp_icp_forward then starts iteration 0 at its accumulate */
-    const void* tgt_f16;     /* optional, float32: the split-f16 image of tgt4 (dicp_knn_f16_pack, with the same tgt_rows).  DICP_KNN_MFMA needs it; on the
-                                sweep path (tgt4 = the sorted rows) the plain searches of big problems score on the matrix cores when it is given */
-    int32_t* sweep_form;     /* sweep path, optional (K, N) int32 ZEROS: the plain search of iteration k tallies its slabs' tiles per cloud in row k and, given tgt_f16,
-                                takes the scoring form of every cloud from row k-1 (dicp_knn_sweep's form_in / form_out; a row of zeros: no plain search then).
-                                Without tgt_f16 the tallies are only kept (a caller may decide from them whether the next call of the shape gets the image) */
-    int32_t sweep_form_default;  /* the form of a cloud without a tally: 0 vector, 1 matrix cores */
-    const int32_t* sweep_form_plan;  /* optional HOST array (K) int32, read during the call: the form of iteration k's plain search for EVERY cloud -- 1 vector, 2 matrix
-                                cores (needs tgt_f16), 0 as above (by the tallies / the default).  A caller that has seen an earlier call's tallies of the same shape
-                                plans with them: one launch per search instead of the two of the per-cloud choice */
-    int32_t* det_far_row;    /* dicp_icp_backward, windowed form, optional (N,n) int32 + det_far_val (N,n,cv): DETERMINISTIC target gradients.  Without them the
+    int32_t* det_far_row;    /* dicp_icp_backward, windowed form, optional (N,n) int32 + bwd.det_far_val (N,n,cv): DETERMINISTIC target gradients.  Without them the
                                 contributions to a target row are summed in the order the block's waves happened to reach it, and those whose match lies outside the
                                 block's window are added with float atomics: two runs differ in the last bits.  With them every window row sums its slots in
                                 ascending slot order, and an out-of-window contribution is left here by its slot (row, values) and added by one launch per
                                 iteration that walks a cloud's slots in order (one lane per target row): the same bits on every run, given the same slot order. */
     void* det_far_val;
+} dicp_bwd_buffers;
+
+/* The buffers of the loop entry points (dicp_icp_forward / _forward_plan / dicp_icp_backward), one versioned struct: `abi` must be DICP_ABI_VERSION (the entry
+ * points return DICP_ERR_ABI otherwise: a caller built against another layout would hand the library a pose history where it expects an index history). */
+typedef struct dicp_loop_buffers {
+    int32_t abi;             /* DICP_ABI_VERSION of the header the caller was built against */
+    const void* src;         /* (N,n,3) */
+    const void* tgt;         /* (N,m,c) */
+    const void* w_init;      /* (N,n); NULL = unit weights (the reference's weight=None: 4 bytes per point and launch less to read) */
+    int32_t c;
+    int32_t K;               /* capacity of the histories (= max_iterations) */
+    uint8_t* converged;      /* (N) zero-initialised */
+    void* iterations;        /* (N) zero-initialised */
+    void* matched_ratio;     /* (N) zero-initialised */
+    const void* n_start;     /* (N) */
+    void* n_matched;         /* (N) */
+    void* partials;          /* (N, dicp_accumulate_blocks(n), DICP_NACC_PAD) scratch */
+    int32_t* counters;       /* (K) zero-initialised: #clouds with |delta| >= tol at iteration k */
+    void** events;           /* optional 6*K hipEvent_t: [6k] before / [6k+1] after the kNN of iteration k, [6k+2] / [6k+3] its
+                                accumulate (forward), [6k+4] / [6k+5] its accumulate_bwd (backward); NULL = none.  The sweep,
+                                accumulate and windowed-backward launches take their pair as the start / stop events of the
+                                dispatch (hipExtLaunchKernel), the other forms are bracketed by hipEventRecord */
+    const int32_t* src_rows; /* optional (N): rows of each source cloud that take part (ragged batches); qorder, if any, from dicp_query_order
+                                with the same counts */
+    const int32_t* tgt_rows; /* optional (N): rows of each target cloud that take part; tgt4 / the sweep index built with the same counts */
+    dicp_search_buffers search;
+    dicp_cert_buffers cert;
+    dicp_history_buffers hist;
+    dicp_bwd_buffers bwd;
 } dicp_loop_buffers;
 
 /* Head and tail of the backward loop.  dicp_pose_grad_in: gpose (N,12) double = [dL/dC row-major (9), dL/dr (3)] taken from the
@@ -503,10 +528,10 @@ int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_
                       double* gpose, double* gpose_tmp, int have_partials, void* gs, void* gb, void* gsrc, void* gtgt, void* gw,
                       void* bwd_partials, int k0, int k1, void* stream);
 /* out (N,n) = the matches of iteration k out of the history `spos` (virtual base: iteration s at spos + s*N*n) kept by reference through spos_of
- * (dicp_loop_buffers.spos_of; NULL: iteration k's own slab, a plain copy): what places the windows of the backward pass (spos_ref). */
+ * (dicp_loop_buffers.hist.spos_of; NULL: iteration k's own slab, a plain copy): what places the windows of the backward pass (spos_ref). */
 int dicp_resolve_matches(const int32_t* spos, const int32_t* spos_of, int k, const int32_t* src_rows /* optional (N): -1 for the rows past a cloud's own */,
                          int N, int n, int32_t* out, void* stream);
-/* The slot order of a DETERMINISTIC windowed backward (dicp_loop_buffers.det_far_row): qorder (N,n) = the queries in a stable order of their reference matches
+/* The slot order of a DETERMINISTIC windowed backward (dicp_loop_buffers.bwd.det_far_row): qorder (N,n) = the queries in a stable order of their reference matches
  * spos_ref (N,n) (sorted positions; -1 and a cloud's rows past src_rows: last, in index order) -- the same permutation on every run.  dicp_sweep_sort's stable
  * radix sort on the positions as keys; scratch: dicp_match_order_scratch_bytes(dtype, N, n) bytes, 256-byte aligned. */
 size_t dicp_match_order_scratch_bytes(int dtype, int N, int n);
@@ -548,7 +573,7 @@ int dicp_accumulate_bwd(int dtype, const dicp_weight_params* prm, const void* sr
  * zero fill (it writes every slot and every window row instead of adding to them); gts_far is always added to. */
 int dicp_window_blocks(int dtype, int n, int m_pad);
 int dicp_window_rows(int dtype);
-/* the most dicp_window_blocks(...) per cloud with which dicp_loop_buffers.bwd_tail_from may be used on the current device (0: never): its launch lets a
+/* the most dicp_window_blocks(...) per cloud with which dicp_loop_buffers.bwd.tail_from may be used on the current device (0: never): its launch lets a
  * cloud's blocks wait for each other, so they must all be resident -- half of what one XCD holds of that kernel.  dicp_icp_backward returns
  * DICP_ERR_SHAPE for a tail beyond it. */
 int dicp_bwd_tail_max_blocks(int dtype);
@@ -699,14 +724,14 @@ typedef struct dicp_call_grads {
     void* gT0;               /* (N,4,4) written: the gradient w.r.t. T_init */
     void* gw;                /* (N,n) written, or NULL */
     void* workspace;         /* dicp_call_backward_layout.total bytes, 256-byte aligned */
-    double skip_eps;         /* dicp_loop_buffers.bwd_skip_eps; 0: every iteration runs */
-    int32_t tail_from;       /* dicp_loop_buffers.bwd_tail_from (0: none; the caller checks dicp_bwd_tail_max_blocks against nblk_w) */
+    double skip_eps;         /* dicp_loop_buffers.bwd.skip_eps; 0: every iteration runs */
+    int32_t tail_from;       /* dicp_loop_buffers.bwd.tail_from (0: none; the caller checks dicp_bwd_tail_max_blocks against nblk_w) */
     int32_t pad0;
     int32_t* live_host;      /* optional PINNED host memory, (K + 1) int32: receives bwd_live (+ the tail's error word) behind the pass's launches */
 } dicp_call_grads;
 typedef struct dicp_call_backward_layout {
     size_t total, zeroed;
-    size_t live, arrive;     /* (K + 1) / (N + 1) int32: dicp_loop_buffers.bwd_live / bwd_tail_arrive of the pass */
+    size_t live, arrive;     /* (K + 1) / (N + 1) int32: dicp_loop_buffers.bwd.live / bwd_tail_arrive of the pass */
     size_t mref, decisions, far, gpose, gtmp, src_s, w_s, gsrc_s, gw_s, slab, gs, gb, partials, tail_partials;
     size_t spos_ref;         /* (N,n) int32: the matches of the last executed iteration as a plain array (dicp_resolve_matches: they place the windows) */
     int32_t nblk_w, pad0;    /* dicp_window_blocks of the shape */
@@ -729,7 +754,7 @@ typedef struct dicp_loop_backward_in {
     const void* alive;       /* (K_cap+1,N) */
     const int32_t* src_rows; /* optional (N) */
     const int32_t* tgt_rows; /* optional (N) */
-    const int32_t* spos_of;  /* optional (K_cap+1,N,ceil(n/64)): the history is kept by reference from iteration spos_of_from on (dicp_loop_buffers.spos_of) */
+    const int32_t* spos_of;  /* optional (K_cap+1,N,ceil(n/64)): the history is kept by reference from iteration spos_of_from on (dicp_loop_buffers.hist.spos_of) */
     int32_t N, n, m, c, K, K_cap, m_pad, dim;
     int32_t knn_variant;     /* as dicp_loop_buffers */
     int32_t spos_of_from;

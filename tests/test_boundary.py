@@ -48,27 +48,38 @@ def test_struct_layouts_match_header(lib):
     assert fields == expect
 
 
-def test_loop_buffers_layout_matches_header(lib):
-    """dicp_loop_buffers: the ctypes mirror lists the header's fields in the header's order (a mismatch would hand the
-    library a pose history where it expects an index history)."""
-    hdr = open(os.path.join(ROOT, "include", "dicp_hip.h")).read()
-    body = hdr[hdr.index("typedef struct dicp_loop_buffers {"):hdr.index("} dicp_loop_buffers;")]
+def _header_fields(hdr, name):
+    """The declared field names of `typedef struct <name> { ... } <name>;`, in order ("int64_t w_iter, w_stride" declares two)."""
+    body = hdr[hdr.index("typedef struct %s {" % name):hdr.index("} %s;" % name)]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     fields = []
     for decl in body.split("{", 1)[1].split(";"):
         decl = decl.strip()
-        if not decl:
-            continue
-        names = decl.replace("*", " ").split()
-        # "int64_t w_iter, w_stride" declares two fields
-        first = names[-1] if "," not in decl else None
-        if first is None:
-            head, *more = [x.strip() for x in decl.split(",")]
-            fields.append(head.replace("*", " ").split()[-1])
-            fields.extend(x.replace("*", " ").split()[-1] for x in more)
-        else:
-            fields.append(first)
-    assert [f[0] for f in _lib.LoopBuffers._fields_] == fields
+        if decl:
+            fields.extend(x.replace("*", " ").split()[-1] for x in decl.split(","))
+    return fields
+
+
+def test_loop_buffers_layout_matches_header(lib):
+    """dicp_loop_buffers and its four sub-structs: the ctypes mirrors list the header's fields in the header's order (a mismatch would hand the
+    library a pose history where it expects an index history), the struct carries the ABI version first, and the entry points refuse another one."""
+    hdr = open(os.path.join(ROOT, "include", "dicp_hip.h")).read()
+    for name, cls in (("dicp_search_buffers", _lib.SearchBuffers), ("dicp_cert_buffers", _lib.CertBuffers), ("dicp_history_buffers", _lib.HistoryBuffers),
+                      ("dicp_bwd_buffers", _lib.BwdBuffers), ("dicp_loop_buffers", _lib.LoopBuffers)):
+        assert [f[0] for f in cls._fields_] == _header_fields(hdr, name), name
+    assert _lib.LoopBuffers._fields_[0][0] == "abi" and _lib.LoopBuffers().abi == _lib.ABI_VERSION
+    assert [f[0] for f in _lib.LoopBuffers._fields_[-4:]] == ["search", "cert", "hist", "bwd"]
+    # keyword construction reaches the sub-structs
+    LB = _lib.LoopBuffers(c=6, search_m_pad=64, cert_reset=1, hist_w_iter=7, bwd_tail_from=3)
+    assert (LB.c, LB.search.m_pad, LB.cert.reset, LB.hist.w_iter, LB.bwd.tail_from) == (6, 64, 1, 7, 3)
+    # another layout's struct is refused before anything is read from it (DICP_ERR_ABI = 6)
+    one, P = ctypes.c_void_p(64), _lib.WeightParams(mode=1, loss=0)
+    LB = _lib.LoopBuffers(src=one, tgt=one, converged=one, iterations=one, matched_ratio=one, n_start=one, n_matched=one, partials=one, counters=one, K=4,
+                          hist_poses=one, hist_deltas=one, hist_costs=one, hist_alive=one, hist_areg=one, hist_w=one, hist_idx=one, hist_w_iter=1, hist_w_stride=4)
+    LB.abi = _lib.ABI_VERSION - 1
+    assert lib.dicp_icp_forward(0, ctypes.byref(P), ctypes.byref(LB), 1, 1, 1, 3, 1, 1e-4, 0, 1, None) == 6
+    assert lib.dicp_icp_forward_plan(0, ctypes.byref(P), ctypes.byref(LB), ctypes.byref(_lib.SegmentPlan(nseg=1)), 1, 1, 1, 3, 1, 1e-4, None) == 6
+    assert lib.dicp_icp_backward(0, ctypes.byref(P), ctypes.byref(LB), 1, 1, 1, 3, one, one, 0, one, one, one, one, None, one, 0, 1, None) == 6
 
 
 def test_new_entry_points_reject_bad_arguments(lib):

@@ -586,7 +586,7 @@ def test_graphed_call_is_the_eager_call(B, n, icp_type):
 
 @pytest.mark.parametrize("const_iter,grad", [(True, True), (False, True), (True, False)])
 def test_first_search_ahead_of_the_loop_changes_nothing(const_iter, grad):
-    """ICP._tuning["first_search"]: iteration 0's search is enqueued with the index build, before the loop's state exists (dicp_loop_buffers.first_search_done),
+    """ICP._tuning["first_search"]: iteration 0's search is enqueued with the index build, before the loop's state exists (dicp_loop_buffers.search.first_done),
     so that the GPU works while the host prepares the call.  Same search under the same pose and query order: every output bit for bit, with and
     without it, in the one-call plan, the per-segment (tolerance) path and the no-gradient path."""
     N, n = 12, 16384

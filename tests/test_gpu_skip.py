@@ -1,4 +1,4 @@
-"""Truncated reverse sweep of the backward pass (`-m gpu`; include/dicp_hip.h, dicp_loop_buffers.bwd_skip).  Going backwards through the
+"""Truncated reverse sweep of the backward pass (`-m gpu`; include/dicp_hip.h, dicp_loop_buffers.bwd.skip).  Going backwards through the
 iterations (the reverse of ICP.py:132-260, which the reference leaves to autograd), the chain of pose cotangents shrinks by orders of
 magnitude per iteration near the pose; a cloud's sweep ends at the iteration from which on nothing -- this iteration's own contribution and
 the most any earlier one could add, given the steps that were recorded -- reaches 2^-22 (float32) / 2^-40 (float64) of the cloud's largest
@@ -180,7 +180,7 @@ def _tail_call(icp, src, tgt, weight=None):
 @pytest.mark.parametrize("dtype,N,n,K,icp_type,weights", [(torch.float32, 24, 16384, 12, "pt2pl", False), (torch.float64, 10, 8192, 14, "pt2pl", True),
                                                           (torch.float32, 33, 4096, 10, "pt2pt", True)])
 def test_tail_launch_changes_no_gradient(dtype, N, n, K, icp_type, weights):
-    """dicp_loop_buffers.bwd_tail_from: from the second call of a shape on, the iterations the previous call's sweeps had ended at are one launch.
+    """dicp_loop_buffers.bwd.tail_from: from the second call of a shape on, the iterations the previous call's sweeps had ended at are one launch.
     (i) placed by the previous call, it holds only ended clouds: the gradients equal those of the per-iteration launches (the pass-through of the
     pose cotangent to T_init.grad included); (ii) placed too late on purpose -- every iteration but the last in the one launch, all clouds still at
     work in it -- each cloud is swept by one block, in another order of summation: the same gradients to rounding."""

@@ -309,7 +309,7 @@ def other_configs(make_icp, dev, sync):
         out["value_c1"] = {"error": repr(e)}
     legs["workload"] = "BASELINE configs[3] on a 64-cloud slice: 65536-pt clouds, point-to-plane + huber(1.0) + trim(5.0), K=5 fwd+bwd"
     legs["note"] = ("sweep: the exact sorted sweep, its plain searches scoring on the matrix cores (from 32768 targets per cloud on); mfma_bruteforce: all n*m pairs on "
-                    "v_mfma_f32_32x32x16_f16 (split-f16 filter + exact float32 refine); matrix-pipe counters: profiles/r05_knn_c4_65536_pmc.txt")
+                    "v_mfma_f32_32x32x16_f16 (split-f16 filter + exact float32 refine); matrix-pipe counters: profiles/r06_knn_c4_65536_pmc.txt")
     out["value_c4"] = legs
     return out
 

@@ -73,7 +73,7 @@ class BwdBuffers(ctypes.Structure):
 class LoopBuffers(ctypes.Structure):
     """dicp_loop_buffers (include/dicp_hip.h): one versioned struct, the buffers of the search / the certificates / the histories / the backward in sub-structs."""
     _fields_ = [("abi", i32), ("src", vp), ("tgt", vp), ("w_init", vp), ("c", i32), ("K", i32), ("converged", vp), ("iterations", vp), ("matched_ratio", vp), ("n_start", vp), ("n_matched", vp),
-                ("partials", vp), ("counters", vp), ("events", vp), ("src_rows", vp), ("tgt_rows", vp),
+                ("partials", vp), ("counters", vp), ("counters_host", vp), ("counters_tag", i32), ("events", vp), ("src_rows", vp), ("tgt_rows", vp),
                 ("search", SearchBuffers), ("cert", CertBuffers), ("hist", HistoryBuffers), ("bwd", BwdBuffers)]
 
     def __init__(self, **kw):

@@ -5,6 +5,7 @@ into stages -- ICPLoop.forward = search set-up -> certificate policy -> loop sta
 one library call (backward_once) where every iteration takes the windowed form, else set-up -> runs -> finish.
 """
 import ctypes
+import time
 from dataclasses import dataclass
 from types import SimpleNamespace
 
@@ -12,7 +13,7 @@ import torch
 
 from . import _lib
 from . import _ops           # (its tunables are read through the module at call time: tests and scripts set them there)
-from ._ops import (_DT, _LOSS, SweepIndex, _Arena, _converged_at, _gather_rows_raw, _on, _p, _pose_sums_to_gT, _segments, _stream, auto_knn_kind, f16_image,
+from ._ops import (_DT, _LOSS, SweepIndex, _Arena, _gather_rows_raw, _on, _p, _pose_sums_to_gT, _segments, _stream, auto_knn_kind, f16_image,
                    pack_target, require_device, search_frame)
 
 
@@ -559,13 +560,54 @@ def _fwd_enqueue_plan(S):
                "dicp_icp_forward_plan")
 
 
+_TOL_WORDS = {}      # (device, stream) -> [pinned int32 words, their numpy view, serial of the last call]
+
+
+def _tolerance_words(dev, Kmax):
+    """Tolerance mode's mapped host words (dicp_loop_buffers.counters_host) for a call on this device and stream: every word -1, and the call's tag.  Calls on one
+    stream follow each other, so they share the words; a late segment of the PREVIOUS call that is still running writes words with the previous tag, in stream
+    order before any of this call's, and is ignored."""
+    key = CallHints._where(dev)
+    rec = _TOL_WORDS.get(key)
+    if rec is None or rec[0].numel() < Kmax:
+        if len(_TOL_WORDS) >= 64:
+            _TOL_WORDS.pop(next(iter(_TOL_WORDS)))
+        t = torch.empty((max(64, Kmax),), dtype=torch.int32).pin_memory()
+        rec = _TOL_WORDS[key] = [t, t.numpy(), rec[2] if rec else 0]
+    rec[2] = (rec[2] + 1) % 0x7ff                     # (0x7ff itself is what -1 carries in the tag bits)
+    rec[1][:Kmax] = -1
+    return rec, rec[2] << 20
+
+
+def _words_converged_at(pending, view, tag):
+    """pending = (k0, k1): K = 1 + the first iteration of [k0, k1) after which no cloud was still moving (ICP.py:240,259), or None.  Waits for that segment's
+    words only (they arrive behind its last step; the next segment is already enqueued)."""
+    k0, k1 = pending
+    t_end = None
+    while True:
+        vals = view[k0:k1]
+        if bool(((vals >= 0) & ((vals & 0x7ff00000) == tag)).all()):
+            break
+        if t_end is None:
+            t_end = time.monotonic() + 10.0
+        elif time.monotonic() > t_end:
+            torch.cuda.synchronize()
+            vals = view[k0:k1]
+            if not bool(((vals >= 0) & ((vals & 0x7ff00000) == tag)).all()):
+                raise RuntimeError("dicp_amd: the convergence counters of iterations [%d, %d) never reached the host" % (k0, k1))
+            break
+    zero = (vals & 0xfffff) == 0
+    return k0 + int(zero.argmax()) + 1 if bool(zero.any()) else None
+
+
 def _fwd_enqueue_segments(S):
     """One dicp_icp_forward per segment: the host acts between them -- a new history slab, a re-ordering of the sweep's queries, or (tolerance mode) the
     reference's all-converged check, ICP.py:259."""
     cfg, certs, lib, N, n, kc, sweep = S.cfg, S.certs, S.lib, S.N, S.n, S.kc, S.sweep
     LB = LBref = None
     qorder, order_k = None, 0        # (order_k: the iteration whose search pose `qorder` was made -- or kept -- under)
-    pending, host_cnt = None, None   # tolerance mode: the segment whose convergence counters are still in flight
+    pending = None                   # tolerance mode: the segment whose convergence counters are still in flight
+    words, tag = (None, 0) if cfg.const_iter else _tolerance_words(S.dev, S.Kmax)
     for (k0, k1) in S.segs:
         j = k0 // kc
         if j == len(S.w_slabs):
@@ -585,6 +627,8 @@ def _fwd_enqueue_segments(S):
         if LB is None:
             LB = _fwd_loop_buffers(S, False)
             LBref = ctypes.byref(LB)
+            if words is not None:
+                LB.counters_host, LB.counters_tag = words[0].data_ptr(), tag
         LB.search.qorder = _p(qorder)
         LB.search.first_done = int(k0 == 0 and S.first_spos is not None)
         LB.hist.spos = ctypes.c_void_p(S.spos_slabs[j].data_ptr() - base * N * n * 4) if S.keep_spos else _p(S.spos_once)
@@ -607,22 +651,21 @@ def _fwd_enqueue_segments(S):
         S.done_segs.append((k0, k1))
         if not cfg.const_iter:
             # ICP.py:259: stop at the first iteration whose steps are ALL below tolerance.  The reference synchronises
-            # every iteration for this; here the counters of a segment travel to pinned host memory asynchronously
-            # and are read one segment LATER, while the next segment is already running: no drained GPU, no launch
-            # bubble.  The price is at most one segment of frozen no-op iterations past K (every cloud has converged,
+            # every iteration for this; here the segment's last launch stores its counters to mapped host words (dicp_loop_buffers.counters_host:
+            # no copy engine in the stream) and they are read one segment LATER, while the next segment is already running: no drained GPU, no
+            # launch bubble.  The price is at most one segment of frozen no-op iterations past K (every cloud has converged,
             # so nothing moves), trimmed below exactly like the ones a sync_every > 1 leaves.
-            if pending is not None and _converged_at(pending) is not None:
-                S.K = _converged_at(pending)
-                pending = None
-                break
-            if host_cnt is None:
-                host_cnt = torch.empty((S.Kmax,), dtype=torch.int32, pin_memory=True)
-            host_cnt[k0:k1].copy_(S.counters[k0:k1], non_blocking=True)
-            seg_done = torch.cuda.Event()
-            seg_done.record()
-            pending = (k0, k1, host_cnt, seg_done)
-    if pending is not None and _converged_at(pending) is not None:          # the last segment that ran
-        S.K = _converged_at(pending)
+            if pending is not None:
+                K_at = _words_converged_at(pending, words[1], tag)
+                if K_at is not None:
+                    S.K = K_at
+                    pending = None
+                    break
+            pending = (k0, k1)
+    if pending is not None:          # the last segment that ran
+        K_at = _words_converged_at(pending, words[1], tag)
+        if K_at is not None:
+            S.K = K_at
 
 
 def _fwd_finish(S):

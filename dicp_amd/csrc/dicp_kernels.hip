@@ -861,6 +861,14 @@ static int transform_points_bwd_go(int dtype, const void* src, const void* pose,
 // (pose / alive / index / weight histories indexed by iteration), so the host does no per-iteration work.
 // The reference's per-iteration host check `all(converged)` (ICP.py:259) is the caller's business: it runs
 // [k0,k1) chunks and reads counters[] between them (converged clouds are frozen, extra iterations are no-ops).
+// tolerance mode: the segment's convergence counters to the host's mapped words (dicp_loop_buffers.counters_host), behind the segment's last step
+static int report_counters(const dicp_loop_buffers* B, int const_iter, int k0, int k1, void* stream) {
+    if (const_iter || !B->counters_host || k1 <= k0) return 0;
+    begin_launch();
+    counters_report_kernel<<<1, WAVE, 0, (hipStream_t)stream>>>(B->counters, B->counters_host, k0, k1 - k0, B->counters_tag);
+    return launch_status();
+}
+
 int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_buffers* B, int N, int n, int m,
                      int dim, int const_iter, double tolerance, int k0, int k1, void* stream) {
     if (!prm || !B || !B->src || !B->tgt || !B->hist.poses || !B->hist.deltas || !B->hist.costs || !B->hist.alive ||
@@ -886,7 +894,8 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
         if (dtype == DICP_F32) { if (P.mode == MODE_PT2PL) DICP_SMALL(float, MODE_PT2PL); else DICP_SMALL(float, MODE_PT2PT); }
         else                   { if (P.mode == MODE_PT2PL) DICP_SMALL(double, MODE_PT2PL); else DICP_SMALL(double, MODE_PT2PT); }
 #undef DICP_SMALL
-        return launch_status();
+        if (const int e = launch_status()) return e;
+        return report_counters(B, const_iter, k0, k1, stream);
     }
     for (int k = k0; k < k1; ++k) {
         const char* pose_k = (const char*)B->hist.poses + (size_t)k * N * 12 * es;
@@ -999,7 +1008,7 @@ int dicp_icp_forward(int dtype, const dicp_weight_params* prm, const dicp_loop_b
         rc = dicp_step(dtype, &io, N, stream);
         if (rc) return rc;
     }
-    return 0;
+    return report_counters(B, const_iter, k0, k1, stream);
 }
 
 // The constant-iteration loop of the sweep path in ONE call: the segments dicp_icp_forward would be called for one by one -- cut where the

@@ -509,6 +509,14 @@ __global__ __launch_bounds__(WAVE) void step_kernel(dicp_step_io io, int N) {
     step_body<T, WAVE>(io, blockIdx.x, threadIdx.x);
 }
 
+// The convergence counters of iterations [k0, k0 + cnt) to the host's mapped words (dicp_loop_buffers.counters_host): system-scope stores, tagged with the call
+__global__ __launch_bounds__(WAVE) void counters_report_kernel(const int32_t* __restrict__ counters, int32_t* __restrict__ host, int k0, int cnt, int tag) {
+    for (int k = threadIdx.x; k < cnt; k += WAVE) {
+        const int v = __hip_atomic_load(counters + k0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(host + k0 + k, (tag & 0x7ff00000) | (v < 0xfffff ? v : 0xfffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // ------------------------------------------------------------ whole loop, small clouds
 // Clouds of a few hundred points (the reference's own 65-point test pair; batches of many small scans) are pure
 // launch latency on the multi-kernel path: 3 dependent launches per iteration, each a few microseconds of work.

@@ -597,13 +597,21 @@ __global__ __launch_bounds__(QO_THREADS) void query_order_kernel(const T* __rest
     if (small && ranked) {
         // rank of every query's x among the sorted target keys, from the LDS copy of the keys: a full binary search per
         // query (14 LDS reads; from global memory the same chain of dependent loads took 144 us per launch)
-#pragma unroll 1
+        // (every query's coordinates are loaded before the first search, and the rounds below are unrolled so that their LDS chains overlap: 43 -> 38 us per
+        //  launch at the benchmark shape, round 6.  What is left is the LDS adds: ~137 cycles per wave-instruction on 2048 random counters)
+        float xq[PER];
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const int i = min(e * QO_THREADS + tid, n - 1);
+            const T* p = src + ((size_t)cloud * n + i) * 3;
+            xq[e] = (float)fma_t(q[0], p[0], fma_t(q[1], p[1], fma_t(q[2], p[2], q[3])));
+        }
+#pragma unroll
         for (int e = 0; e < PER; ++e) {
             const int i = e * QO_THREADS + tid;
             int bb = -1, rr = 0;
             if (i < n) {
-                const T* p = src + ((size_t)cloud * n + i) * 3;
-                const float x = (float)fma_t(q[0], p[0], fma_t(q[1], p[1], fma_t(q[2], p[2], q[3])));
+                const float x = xq[e];
                 // the coarse table (also in LDS) brackets the lower bound: ~4 steps on an even cloud instead of 14
                 float f = (x - (float)xlo) * (float)tscale;
                 f = f > 0.f ? (f < (float)nbkt_range ? f : (float)nbkt_range) : 0.f;
@@ -616,8 +624,7 @@ __global__ __launch_bounds__(QO_THREADS) void query_order_kernel(const T* __rest
                 else bb = QO_SIDE + (int)(((long)lo * (QO_MID - 1)) / max(mt, 1));
                 rr = atomicAdd(&cnt[bb], 1);
             }
-#pragma unroll
-            for (int k = 0; k < PER; ++k) if (k == e) { bk[k] = bb; rk[k] = rr; }
+            bk[e] = bb; rk[e] = rr;
         }
     } else if (small) {
 #pragma unroll

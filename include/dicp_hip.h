@@ -463,6 +463,11 @@ typedef struct dicp_loop_buffers {
     void* n_matched;         /* (N) */
     void* partials;          /* (N, dicp_accumulate_blocks(n), DICP_NACC_PAD) scratch */
     int32_t* counters;       /* (K) zero-initialised: #clouds with |delta| >= tol at iteration k */
+    int32_t* counters_host;  /* optional (K) int32 in PINNED (device-mapped) host memory: a dicp_icp_forward call that is not const_iter ends with one small launch
+                                that stores counters_tag | min(counters[k], 0xfffff) to counters_host[k] for its iterations [k0,k1) -- the host's all-converged check
+                                (ICP.py:259) reads the words one segment later, without a copy engine in the stream (a hipMemcpyAsync per segment cost a blit and its
+                                completion signal: 10 us of every iteration of the reference's default mode).  The caller fills the words with -1 before the call */
+    int32_t counters_tag;    /* bits 20..30: which call the words belong to (a late segment of the object's PREVIOUS call may still be writing when the host prepares the next) */
     void** events;           /* optional 6*K hipEvent_t: [6k] before / [6k+1] after the kNN of iteration k, [6k+2] / [6k+3] its
                                 accumulate (forward), [6k+4] / [6k+5] its accumulate_bwd (backward); NULL = none.  The sweep,
                                 accumulate and windowed-backward launches take their pair as the start / stop events of the

@@ -11,6 +11,8 @@ if os.environ.get("AB") == "2":
     VARIANTS = [("default (0,1,2,3)", {}), ("(0,1,2) cert 3", {"sweep_resort": (0, 1, 2), "cert_from": 3}), ("(0,1,3)", {"sweep_resort": (0, 1, 3)}), ("(0,2,3)", {"sweep_resort": (0, 2, 3)}),
                 ("(0,1) cert 3", {"sweep_resort": (0, 1), "cert_from": 3})]
 MODES = [("K=10", 10, None), ("K=20", 20, None), ("tolerance", 50, 1e-4)]
+if os.environ.get("ONLY_TOL") == "1":
+    MODES = MODES[2:]
 
 
 def bench(src, tgt, K, tol, tune):

@@ -237,8 +237,7 @@ def backward_once(lib, code, P, F, cfg, src, tgt, w0c, gT, want_tgt, want_w):
         tail_word = ws[a0:a0 + (N + 1 + (es // 4) - 1) * 4 // es].view(torch.int32)[N:N + 1]
     if stats is not None:
         stats["bwd_tail_from"] = int(tail_from)
-        if tail_from > 0:
-            stats["bwd_tail_error"] = tail_word
+        stats["bwd_tail_error"] = tail_word         # (None: this pass had no one-launch tail -- an earlier pass's word must not stand for it)
     gsrc = torch.empty_like(src)
     gtgt = torch.empty_like(tgt) if want_tgt else None
     gw = torch.empty_like(w0c) if want_w else None
@@ -292,6 +291,10 @@ def _fwd_search_setup(S):
         kind = auto_knn_kind(N, n, m)
     S.kind = kind
     S.owned = kind == _lib.KNN_SWEEP and S.need_grad and cfg.bwd_window
+    if cfg.deterministic and S.need_grad and not S.owned:
+        # (said here, before anything is enqueued -- not by loss.backward() after the whole forward has run)
+        raise NotImplementedError("ICP.deterministic covers the sweep search with the windowed backward (knn_variant KNN_SWEEP, bwd_window): this call "
+                                  "would take another form")
     sweep = None
     if kind == _lib.KNN_SWEEP:
         pre = cfg.prebuilt
@@ -815,7 +818,7 @@ def _bwd_windowed_setup(B):
     B.gw = (torch.empty_like(B.w0c) if B.only_windowed else torch.zeros_like(B.w0c)) if B.want_w else None
     B.nblk_a, B.nblk_w = lib.dicp_accumulate_blocks(n), lib.dicp_window_blocks(B.code, n, B.m_pad)
     B.det_row = B.det_val = B.qo = B.spos_ref = B.src_s = B.w_s = B.gsrc_s = B.gw_s = B.slab = B.gfar = None
-    if cfg.deterministic and not B.only_windowed:
+    if cfg.deterministic and not B.only_windowed and len(B.segs) > 0:      # (the forward refuses such a call; no executed iteration: zero gradients, nothing to order)
         raise NotImplementedError("ICP.deterministic covers the sweep search with the windowed backward (knn_variant KNN_SWEEP, bwd_window): this call took another form")
     if not any(B.windowed):
         return
@@ -925,8 +928,8 @@ def _bwd_runs(B, gpose, gtmp):
     tail_part = torch.empty((N, B.nblk_w, _lib.NBWD_PAD), dtype=dt, device=dev) if tail_from > 0 else None
     if cfg.stats_out is not None:
         cfg.stats_out["bwd_tail_from"] = int(tail_from)
-        if tail_from > 0:
-            cfg.stats_out["bwd_tail_error"] = skip[3][N:]       # (1) int32: nonzero = a wait of the tail launch ran out (TailTimeout at the next pass)
+        # (1) int32: nonzero = a wait of the tail launch ran out (TailTimeout at the next pass); None: this pass had no one-launch tail
+        cfg.stats_out["bwd_tail_error"] = skip[3][N:] if tail_from > 0 else None
     have, form, fresh, folded = 0, None, 1, False
     for (k0, k1, q, w_form) in runs:
         if have and w_form != form:     # the partials of the other form have another block count: fold them in here

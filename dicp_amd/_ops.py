@@ -368,6 +368,10 @@ class _PackList(torch.autograd.Function):
     def forward(ctx, cols, pad, *clouds):
         lib = _lib.load()
         N, dev, dt = len(clouds), clouds[0].device, clouds[0].dtype
+        # (the launch reads the clouds through RAW pointers: whatever would make it read foreign memory is refused here, whoever the caller is)
+        for t in clouds:
+            if not (t.is_cuda and t.device == dev and t.dtype == dt and t.dim() == 2 and t.shape[1] >= cols and (t.shape[0] <= 1 or t.stride(1) == 1) and t.stride(0) >= t.shape[1]):
+                raise ValueError("pack_list: every cloud must be a 2-D %s tensor on %s with unit column stride and at least %d columns" % (dt, dev, cols))
         lens = [int(t.shape[0]) for t in clouds]
         n_max = max(lens)
         # pointers, lengths and row strides travel as one small tensor (pageable host memory: the copy is synchronous for the host, 6 KB)

@@ -62,6 +62,10 @@ DICP_HD int tri(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }   
 // the windowed backward spent per point, ~100 were these (profiles/r05_point_math.txt).  A weight or a gradient moves by parts in 1e7; north_star's float32
 // bar is 1e-4 / 1e-3, and every form of every kernel shares these functions, so results that are compared bit for bit (searches, certified iterations) still are.
 // float64, and the host build of this header (tests/hostcheck), keep the correctly rounded forms.
+// Edges of the one-instruction forms (they differ from IEEE division beyond the last ulp): v_rcp_f32 flushes denormals -- m_div(a, b) is +-inf for |b| < 2^-126
+// and 0 for |b| > 2^126 -- and a * rcp(a) is not exactly 1: a Huber / Cauchy weight at a residual of exactly the metric comes out 0.99999994.  The quotients here
+// are metric / residual, 1 / (1 + (e/c)^2) and trim / loss ratios of coordinates in metres: neither range occurs; 0 / 0 and x / 0 stay NaN / inf as in the
+// reference (the hard Huber slope's NaN at a zero residual is kept: tests/test_gpu_parity.py).
 #if defined(__HIP_DEVICE_COMPILE__)
 DICP_HD float  m_sqrt(float x)  { return __builtin_amdgcn_sqrtf(x); }
 DICP_HD float  m_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }

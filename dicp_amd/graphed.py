@@ -39,12 +39,13 @@ def _no_gc():
 OUTPUTS = ("T", "pc", "deltas", "weights", "costs")
 
 
-def _check_tail_word(icp):
+def _check_tail_word(word):
     """A replay cannot report a wait of the backward's one-launch tail that ran out the way an eager call does (no host code runs between the kernels): the
     error word of the captured pass is a static tensor of the graph -- ``call.check_errors()`` / ``step.check_errors()`` wait for the replays made so far and
-    raise _loop.TailTimeout if the last one raised it (its gradients are NaN).  Call it before the optimizer's step."""
+    raise _loop.TailTimeout if the last one raised it (its gradients are NaN).  Call it before the optimizer's step.
+    `word` is the CAPTURED pass's own (taken from the object's statistics right after the capture: a later eager call of the same object replaces the entry
+    there); None: the captured pass has no one-launch tail, nothing to report."""
     from ._loop import TailTimeout
-    word = icp.knn_stats.get("bwd_tail_error")
     if word is not None and int(word.item()) != 0:
         raise TailTimeout("dicp_amd: a wait of the captured backward pass's one-launch tail ran out in the last replay; its gradients are NaN")
 
@@ -78,9 +79,11 @@ def graphed_icp(icp: ICP, source, target, T_init, weight=None, num_warmup_iters=
     with _no_gc():
         graphed = torch.cuda.make_graphed_callables(fn, sample, num_warmup_iters=num_warmup_iters)
 
+    word = icp.knn_stats.get("bwd_tail_error")      # (the last pass that ran was the capture's backward, if the inputs carry gradients at all)
+
     def call(s, t, T0, *w):
         return dict(zip(OUTPUTS, graphed(s, t, T0, *w)))
-    call.check_errors = lambda: _check_tail_word(icp)
+    call.check_errors = lambda: _check_tail_word(word)
     return call
 
 
@@ -117,6 +120,7 @@ def graphed_icp_step(icp: ICP, loss_of, source, target, T_init, weight=None, num
             out = run()
     outs = {k: out[k] for k in OUTPUTS}
     grads = {nm: x.grad for nm, x in zip(names, static) if x.requires_grad}
+    word = icp.knn_stats.get("bwd_tail_error")      # the captured pass's own error word (a static tensor of the graph), or None
 
     def step(*args):
         for dst, src in zip(static, args):
@@ -124,5 +128,5 @@ def graphed_icp_step(icp: ICP, loss_of, source, target, T_init, weight=None, num
                 dst.detach().copy_(src.detach())
         graph.replay()
         return outs, grads
-    step.check_errors = lambda: _check_tail_word(icp)
+    step.check_errors = lambda: _check_tail_word(word)
     return step

@@ -109,6 +109,31 @@ def test_not_with_gumbel():
         icp.icp(src.to(DEV).requires_grad_(True), tgt[:, :, :3].to(DEV), torch.eye(4, dtype=torch.float64, device=DEV).unsqueeze(0))
 
 
+def test_unsupported_forms_are_refused_by_the_call_not_by_backward():
+    """A caller who set ICP.deterministic hears about a form it does not cover from icp() itself -- before anything is enqueued, not from loss.backward() after
+    the whole forward has run."""
+    src, tgt = make_pairs(2, 4096, 4096, seed=2, dtype=torch.float32)
+    icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=3, tolerance=1e-12)
+    icp.const_iter, icp.deterministic = True, True
+    T0 = torch.eye(4, device=DEV).repeat(2, 1, 1)
+    import dicp_amd._loop as loop
+    cfg_seen = {}
+    real = loop.ICPLoop.apply
+
+    def no_window(*a):       # (the public switches route a deterministic call to the supported form: take the window away behind them)
+        cfg = [x for x in a if isinstance(x, loop.LoopConfig)][0]
+        cfg.bwd_window = False
+        cfg_seen["cfg"] = cfg
+        return real(*a)
+    loop.ICPLoop.apply = no_window
+    try:
+        with pytest.raises(NotImplementedError):
+            icp.icp(src.to(DEV).requires_grad_(True), tgt.to(DEV), T0, trim_dist=5.0)
+    finally:
+        loop.ICPLoop.apply = real
+    assert cfg_seen["cfg"].deterministic
+
+
 def test_the_reference_pair_takes_the_deterministic_path_too():
     """tests/data's 65-point pair (test_ICP.py:35-117: float64, point-to-plane, dim 2): forced onto the sweep search + windowed backward, same results as the default
     (small-cloud) path to rounding, bit-identical between runs."""

@@ -158,4 +158,9 @@ def test_lists_are_packed_by_one_launch_like_pad_sequence():
     # a strided view (the first three columns of six-column clouds, every other row) is taken as it stands or refused, never misread
     views = [c.detach()[::2] for c in clouds]
     assert _ops.packable(views, (6,)) and torch.equal(_ops.pack_list(views, 6), torch.nn.utils.rnn.pad_sequence(views, batch_first=True))
+    # the launch reads the clouds through raw pointers: a cloud of another dtype, too few columns or a strided column is refused by pack_list itself
+    base = torch.randn((10, 6), generator=g, dtype=torch.float32).cuda()
+    for bad in ([base, base.double()], [base[:, :2]], [base.t().contiguous().t()], [base, base.cpu()], [base.reshape(2, 5, 6)]):
+        with pytest.raises(ValueError):
+            _ops.pack_list(bad, 3)
     assert not _ops.packable([c.detach().t() for c in clouds], (6,)) and not _ops.packable([c.detach().cpu() for c in clouds], (6,))

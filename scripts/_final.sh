@@ -1,3 +1,4 @@
 export TMPDIR=/tmp
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/gputest.log 2>&1; echo "pytest rc=$?"; tail -2 gpurun_out/gputest.log
-timeout -k 10 300 python scripts/soak_modes.py 1000 > gpurun_out/soak_modes.txt 2>&1; echo "soak rc=$?"; tail -3 gpurun_out/soak_modes.txt
+timeout -k 10 500 python bench.py --steps 20 --warmup 3 > gpurun_out/bench_k20.json 2> gpurun_out/bench_k20.err; echo "k20 rc=$?"
+timeout -k 10 400 python bench.py > gpurun_out/bench_k10.json 2> gpurun_out/bench_k10.err; echo "k10 rc=$?"
+python scripts/headline_host_time.py 20 30 | tail -1

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("DICP_HIP_LIB") or os.path.join(_HERE, "libdicp_hip.so")   # env override: A/B builds
 SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("dicp_kernels.hip", "knn_f16.hip", "dicp_call.hip")]
-HEADERS = ([os.path.join(_HERE, "csrc", f) for f in ("dicp_math.h", "dicp_common.h", "dicp_internal.h")]
+HEADERS = ([os.path.join(_HERE, "csrc", f) for f in ("dicp_math.h", "dicp_common.h", "dicp_internal.h", "dicp_fill.h")]
            + [os.path.join(_HERE, "csrc", "kernels_%s.h" % f) for f in ("setup", "search", "setup_sort", "rows", "accumulate", "backward", "soft_svd", "host")]
            + [os.path.join(_ROOT, "include", "dicp_hip.h")])
 
@@ -172,6 +172,8 @@ class KabschBuffers(ctypes.Structure):
 
 _SIGNATURES = {
     "dicp_abi_version": ([], ctypes.c_int),
+    "dicp_copy": ([vp, vp, ctypes.c_size_t, vp], ctypes.c_int),
+    "dicp_zero": ([vp, ctypes.c_size_t, vp], ctypes.c_int),
     "dicp_padded_targets": ([i32], ctypes.c_int),
     "dicp_accumulate_blocks": ([i32], ctypes.c_int),
     "dicp_pack_target": ([i32, vp, i32, vp, vp, i32, i32, vp, i32, vp], ctypes.c_int),

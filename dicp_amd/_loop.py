@@ -525,7 +525,9 @@ def _fwd_new_slab(S, j):
     if S.keep_spos:
         S.spos_slabs.append(torch.empty((kk, S.N, S.n), dtype=torch.int32, device=S.dev))
         if j == 0 and S.first_spos is not None:
-            S.spos_slabs[0][0].copy_(S.first_spos)
+            # (a kernel of the library, not torch's copy_: a contiguous device-to-device copy_ is a runtime memcpy, and under a hipGraph capture the runtime's
+            #  memset / memcpy nodes are not reliably ordered against the kernel nodes around them: csrc/dicp_fill.h)
+            _lib.check(S.lib.dicp_copy(_p(S.spos_slabs[0][0]), _p(S.first_spos), S.first_spos.numel() * 4, S.st), "dicp_copy")
 
 
 def _fwd_enqueue_plan(S):

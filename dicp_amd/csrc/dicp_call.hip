@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 #include "dicp_hip.h"
+#include "dicp_fill.h"
 
 namespace {
 
@@ -31,6 +32,8 @@ inline bool call_ok(int dtype, const dicp_call* c) {
     }
     return true;
 }
+
+inline int zero_fill(void* p, size_t bytes, hipStream_t st) { return dicp_fill::zero(p, bytes, st); }      // (a kernel, not hipMemsetAsync: dicp_fill.h)
 
 inline char* at(const dicp_call* c, size_t off) { return (char*)c->workspace + off; }
 inline char* res(const dicp_call* c, size_t off) { return (char*)c->results + off; }
@@ -127,8 +130,8 @@ int dicp_call_forward(int dtype, const dicp_weight_params* prm, const dicp_call*
     const size_t es = esize(dtype), N = c->N, n = c->n;
     const int K = c->K;
     hipStream_t st = (hipStream_t)stream;
-    if (hipError_t e = hipMemsetAsync(c->workspace, 0, L.zeroed, st)) return -(int)e;
-    if (hipError_t e = hipMemsetAsync(c->results, 0, L.results_zeroed, st)) return -(int)e;
+    if (int rc = zero_fill(c->workspace, L.zeroed, st)) return rc;
+    if (int rc = zero_fill(c->results, L.results_zeroed, st)) return rc;
     int32_t* order0 = (int32_t*)at(c, L.orders);
     int32_t* spos = (int32_t*)at(c, L.spos);
     // frame, sort, rows, the search pose of iteration 0 and the first query order; iteration 0's search right behind them
@@ -232,7 +235,7 @@ static int backward_once(int dtype, const dicp_weight_params* prm, const dicp_lo
     if (tail_from > K) tail_from = K;
     hipStream_t st = (hipStream_t)stream;
     char* W = (char*)g->workspace;
-    if (hipError_t e = hipMemsetAsync(W, 0, L.zeroed, st)) return -(int)e;
+    if (int rc = zero_fill(W, L.zeroed, st)) return rc;
     double* gpose = (double*)(W + L.gpose);
     double* gtmp = (double*)(W + L.gtmp);
     if (int rc = dicp_pose_grad_in(dtype, g->gT, gpose, f->N, stream)) return rc;
@@ -365,7 +368,7 @@ int dicp_kabsch_call_forward(int dtype, const dicp_kabsch_call* c, void* stream)
     const size_t N = c->N, n = c->n;
     const int K = c->K;
     hipStream_t st = (hipStream_t)stream;
-    if (hipError_t e = hipMemsetAsync(c->workspace, 0, L.zeroed, st)) return -(int)e;
+    if (int rc = zero_fill(c->workspace, L.zeroed, st)) return rc;
     int32_t* order0 = (int32_t*)kat(c, L.orders);
     int32_t* order1 = order0 + N * n;
     // frame, sort, packed rows (the Kabsch sums gather the rows as given: no sorted copy), search pose of the start, first query order
@@ -417,9 +420,9 @@ int dicp_kabsch_call_backward(int dtype, const dicp_kabsch_call* c, const dicp_k
     if (int rc = last_launch()) return rc;
     if (int rc = dicp_kabsch_step_bwd(dtype, kat(c, L.gpose), (const double*)kat(c, L.save), kat(c, L.gacc), c->N, stream)) return rc;
     // dicp_kabsch_bwd adds: the three gradients start at zero
-    if (hipError_t e = hipMemsetAsync(g->gsrc, 0, N * n * 3 * es, st)) return -(int)e;
-    if (g->gtgt) if (hipError_t e = hipMemsetAsync(g->gtgt, 0, N * (size_t)c->m * c->c * es, st)) return -(int)e;
-    if (g->gw) if (hipError_t e = hipMemsetAsync(g->gw, 0, N * n * es, st)) return -(int)e;
+    if (int rc = zero_fill(g->gsrc, N * n * 3 * es, st)) return rc;
+    if (g->gtgt) if (int rc = zero_fill(g->gtgt, N * (size_t)c->m * c->c * es, st)) return rc;
+    if (g->gw) if (int rc = zero_fill(g->gw, N * n * es, st)) return rc;
     return dicp_kabsch_bwd(dtype, c->src, c->tgt, c->c, (const int32_t*)kat(c, L.idx), kat(c, L.pose_used), c->w0, c->trim_on, c->trim_dist, kat(c, L.gacc), nullptr,
                            c->N, c->n, c->m, g->gsrc, g->gtgt, g->gw, stream);
 }

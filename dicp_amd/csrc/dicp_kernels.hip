@@ -31,6 +31,7 @@
 
 #include "dicp_common.h"
 #include "dicp_internal.h"
+#include "dicp_fill.h"
 
 namespace {
 
@@ -49,6 +50,16 @@ namespace {
 extern "C" {
 
 int dicp_abi_version(void) { return DICP_ABI_VERSION; }
+int dicp_copy(void* dst, const void* src, size_t bytes, void* stream) {
+    if (!dst || !src) return DICP_ERR_NULL;
+    if ((((uintptr_t)dst | (uintptr_t)src | bytes) & 3) != 0) return DICP_ERR_ALIGN;
+    return dicp_fill::copy(dst, src, bytes, (hipStream_t)stream);
+}
+int dicp_zero(void* dst, size_t bytes, void* stream) {
+    if (!dst) return DICP_ERR_NULL;
+    if ((((uintptr_t)dst | bytes) & 3) != 0) return DICP_ERR_ALIGN;
+    return dicp_fill::zero(dst, bytes, (hipStream_t)stream);
+}
 int dicp_padded_targets(int m) { return m <= 0 ? 0 : ((m + KNN_PAD - 1) / KNN_PAD) * KNN_PAD; }
 int dicp_accumulate_blocks(int n) { return n <= 0 ? 0 : (n + ACC_PTS - 1) / ACC_PTS; }
 int dicp_search_frame(int dtype, const void* tgt, int c, const int32_t* tgt_rows, int N, int m, double quantum, int directions,
@@ -711,7 +722,7 @@ int dicp_match_order(int dtype, const int32_t* spos_ref, const int32_t* src_rows
     const size_t sort_bytes = dicp_sweep_sort_scratch_bytes(dtype, N, m_pad);
     if (const int rc = dicp_sweep_sort(dtype, W + k3, 3, nullptr, nullptr, N, n, m_pad, W + ks, (int32_t*)(W + tp), 0, nullptr, nullptr, sort_bytes ? W + sc : nullptr, sort_bytes, stream)) return rc;
     // the first n entries of each cloud's sorted order (the slots past n are the sort's own pads, last): a strided device copy
-    if (hipError_t e = hipMemcpy2DAsync(qorder, (size_t)n * 4, W + tp, (size_t)m_pad * 4, (size_t)n * 4, (size_t)N, hipMemcpyDeviceToDevice, st)) return -(int)e;
+    if (const int e = dicp_fill::copy_rows(qorder, (size_t)n * 4, W + tp, (size_t)m_pad * 4, (size_t)n * 4, (size_t)N, st)) return e;
     return 0;
 }
 
@@ -1117,7 +1128,7 @@ int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_
             // adjoint to the source and to the pose (its sums join accumulate_bwd's in bwd_partials)
             const char* nbr_k = (const char*)G->nbr + (size_t)k * N * n * B->c * es;
             const char* lse_k = (const char*)G->lse + (size_t)k * N * n * es;
-            if (hipMemsetAsync(G->g_nbr, 0, (size_t)N * n * B->c * es, st) != hipSuccess) return -(int)hipGetLastError();
+            if (const int e = dicp_fill::zero(G->g_nbr, (size_t)N * n * B->c * es, st)) return e;
             rc = accumulate_bwd_go(dtype, prm, B->src, nbr_k, B->c, nullptr, pose_k, B->w_init, alive_k, gs, gb, nullptr, N, n, n, gsrc, G->g_nbr, gw, bwd_partials, stream, B->bwd.skip);
             if (!rc) rc = dicp_transform_points(dtype, B->src, pose_k, G->ps_t, N, n, stream);
             if (!rc) rc = gumbel_nn_bwd_go(dtype, G->ps_t, B->tgt, B->c, G->U ? G->U[k] : nullptr, G->seeds ? G->seeds[k] : 0u, G->eps, G->tau, nbr_k, lse_k, G->g_nbr,
@@ -1150,7 +1161,7 @@ int dicp_icp_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_
             //  another verdict than its siblings and wait for them in vain: the TailTimeout seen every few hundred calls on planar scenes in rounds 5 and 6.
             //  The launch reads from the other buffer instead: 12 doubles per cloud to copy.)
             double* other = gin == gpose ? gpose_tmp : gpose;
-            if (hipMemcpyAsync(other, gin, (size_t)N * 12 * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) return -(int)hipGetLastError();
+            if (const int e = dicp_fill::copy(other, gin, (size_t)N * 12 * sizeof(double), st)) return e;
             gin = other;
         }
         const unsigned g = grid_for(N, nblk);

@@ -35,6 +35,7 @@
 
 #include "dicp_common.h"
 #include "dicp_internal.h"
+#include "dicp_fill.h"
 
 namespace {
 
@@ -1072,7 +1073,7 @@ int knn_f16_probe(const void* src, const void* pose, const void* tgt4, const voi
     const float* meta = (const float*)((const char*)image + knn_f16_meta_offset(N, m_pad));
     const int bpc = (n + (BLOCK / WAVE) * 32 - 1) / ((BLOCK / WAVE) * 32);
     begin_launch();
-    if (hipMemsetAsync(out, 0, (size_t)N * 4 * sizeof(float), st) != hipSuccess) return -(int)hipGetLastError();
+    if (const int e = dicp_fill::zero(out, (size_t)N * 4 * sizeof(float), st)) return e;
     knn_f16_probe_kernel<<<grid_for(N, bpc), BLOCK, 0, st>>>((const float*)src, (const float*)pose, (const float4*)tgt4, (const uint4*)image, meta, N, n, m, m_pad, tiles, bpc,
                                                              src_rows, tgt_rows, out);
     return launch_status();

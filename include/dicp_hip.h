@@ -72,6 +72,11 @@ typedef struct dicp_weight_params {
 } dicp_weight_params;
 
 int dicp_abi_version(void);
+/* Plain device-to-device copy / zero fill of `bytes` (multiples of 4, 4-byte aligned) as KERNELS of this library, for callers whose calls may be captured into a
+ * hipGraph: the runtime's memset node (hipMemsetAsync under capture) is not ordered against the kernel nodes around it when a replay starts on an idle GPU
+ * (round 6, csrc/dicp_fill.h); every fill and copy inside the library goes the same way. */
+int dicp_copy(void* dst, const void* src, size_t bytes, void* stream);
+int dicp_zero(void* dst, size_t bytes, void* stream);
 
 /* Rows of target points padded for the kNN kernels: returns m rounded up to 64. */
 int dicp_padded_targets(int m);

@@ -134,6 +134,8 @@ def test_new_entry_points_reject_bad_arguments(lib):
     assert lib.dicp_window_reduce(0, one, one, None, one, None, None, 1, 1, 1, 64, 6, one, 3, 0, None) == 2
     assert lib.dicp_permute_add_rows(0, one, one, 1, 2, 1, 2, 3, 3, one, 4, 3, None) == 2
     assert lib.dicp_permute_rows(0, one, one, 1, 2, 1, 2, 3, 3, one, 4, 3, None) == 2
+    assert lib.dicp_copy(None, one, 16, None) == 1 and lib.dicp_copy(one, one, 6, None) == 5 and lib.dicp_zero(None, 16, None) == 1 and lib.dicp_zero(ctypes.c_void_p(66), 16, None) == 5
+    assert lib.dicp_copy(one, one, 0, None) == 0 and lib.dicp_zero(one, 0, None) == 0                                    # (nothing to do: nothing launched)
     assert lib.dicp_pose_grad_in(0, None, None, 1, None) == 1 and lib.dicp_pose_grad_in(7, None, one, 1, None) == 3
     assert lib.dicp_pose_grad_out(0, one, one, 0, one, 1, None) == 2 and lib.dicp_pose_grad_out(0, one, None, 0, None, 1, None) == 1
     # dicp_knn_sweep(dtype, src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, src_rows, tgt_rows, N, n, m, m_pad, idx, spos, pairs, cfg, f16_image, form_in, form_out, form_default, stream)

@@ -584,6 +584,52 @@ def test_graphed_call_is_the_eager_call(B, n, icp_type):
             assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max()))
 
 
+@pytest.mark.parametrize("B,n,K", [(32, 8192, 10), (8, 16384, 6)])
+def test_captured_step_after_a_synchronisation(B, n, K):
+    """A captured step (dicp_amd.graphed.graphed_icp_step) at sizes that take the sweep search and the windowed backward, replayed after the GPU has gone idle
+    and after eager work of the caller: the same gradients as the eager call every time.  Round 6: replays that followed a synchronisation returned garbage
+    target gradients (1e7 x their size) while replays back to back were right -- the zero fill of the backward's workspace was a hipMemsetAsync, and the
+    runtime's memset node is not ordered against the kernel nodes around it when a replay starts on an idle GPU; fills and copies are kernels of the library now
+    (csrc/dicp_fill.h).  The two-graph form (graphed_icp) is held to the same."""
+    from dicp_amd.graphed import graphed_icp, graphed_icp_step
+    src, tgt = make_pairs(B, n, n, seed=41)
+    src, tgt = src.to(DEV), tgt.to(DEV)
+    T0 = torch.eye(4, device=DEV).repeat(B, 1, 1)
+    kw = dict(trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0})
+    icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
+    icp.const_iter = True
+    a, b = src.clone().requires_grad_(True), tgt.clone().requires_grad_(True)
+    for _ in range(3):
+        a.grad = b.grad = None
+        out_e = icp.icp(a, b, T0, **kw)
+        out_e["T"].sum().backward()
+    assert "bwd_tail_from" in icp.knn_stats                     # (the truncated, windowed reverse sweep ran)
+    gs_e, gt_e, T_e = a.grad.clone(), b.grad.clone(), out_e["T"].detach().clone()
+    s, t = src.clone().requires_grad_(True), tgt.clone().requires_grad_(True)
+    step = graphed_icp_step(icp, lambda o: o["T"].sum(), s, t, T0, num_warmup_iters=3, **kw)
+
+    def check(out, gs, gt, what):
+        assert torch.equal(out["T"], T_e), what
+        for g, e in ((gs, gs_e), (gt, gt_e)):
+            assert float((g - e).abs().max()) <= 2e-5 * float(e.abs().max()), what
+    for i in range(6):
+        out, grads = step(s, t, T0)
+        if i % 2:                                                   # every other replay starts on an idle GPU, behind eager work of the caller's
+            torch.cuda.synchronize()
+            junk = (grads["target"] - gt_e).abs().max() + torch.full((1 << 20,), 3.0, device=DEV).sum()
+            torch.cuda.synchronize()
+            check(out, grads["source"], grads["target"], "captured step, replay %d" % i)
+            del junk
+    step.check_errors()
+    g2 = graphed_icp(icp, src.clone().requires_grad_(True), tgt.clone().requires_grad_(True), T0, **kw)
+    for i in range(4):
+        s2, t2 = src.clone().requires_grad_(True), tgt.clone().requires_grad_(True)
+        o2 = g2(s2, t2, T0)
+        o2["T"].sum().backward()
+        torch.cuda.synchronize()
+        check(o2, s2.grad, t2.grad, "two graphs, replay %d" % i)
+
+
 @pytest.mark.parametrize("const_iter,grad", [(True, True), (False, True), (True, False)])
 def test_first_search_ahead_of_the_loop_changes_nothing(const_iter, grad):
     """ICP._tuning["first_search"]: iteration 0's search is enqueued with the index build, before the loop's state exists (dicp_loop_buffers.search.first_done),

@@ -1665,3 +1665,21 @@ def test_icp_with_gumbel_in_tolerance_mode_and_without_injected_noise():
     assert 1 <= K <= 12 and d[0]["weights"].shape[1] == K and d[0]["costs"].shape[1] == K
     assert bool(torch.isfinite(d[0]["T"]).all()) and bool(torch.isfinite(d[1]).all())
     assert torch.equal(d[0]["deltas"][:, 0], a[0]["deltas"][:, 0])     # (same seed: the first iteration is the constant-iteration call's; later ones freeze cloud by cloud)
+
+
+@pytest.mark.gpu
+def test_library_copy_and_zero_fill():
+    """dicp_copy / dicp_zero (csrc/dicp_fill.h: the library's own fills and copies, kernels instead of the runtime's memset / memcpy): every size class, unaligned
+    ends, and nothing outside the range touched."""
+    import ctypes
+    from dicp_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(9)
+    for words in (1, 3, 4, 63, 64, 1000, 4096, 1 << 20, (1 << 22) + 5):
+        src = torch.randint(-2 ** 31, 2 ** 31 - 1, (words + 8,), generator=g, dtype=torch.int64).to(torch.int32).cuda()
+        for off in (0, 1, 3):          # 16-byte aligned or only 4-byte aligned
+            dst = torch.full((words + 8,), 77, dtype=torch.int32, device="cuda")
+            _lib.check(lib.dicp_copy(ctypes.c_void_p(dst.data_ptr() + 4 * (off + 1)), ctypes.c_void_p(src.data_ptr() + 4 * off), words * 4, None), "dicp_copy")
+            assert torch.equal(dst[off + 1:off + 1 + words], src[off:off + words]) and bool((dst[:off + 1] == 77).all()) and bool((dst[off + 1 + words:] == 77).all())
+            _lib.check(lib.dicp_zero(ctypes.c_void_p(dst.data_ptr() + 4 * (off + 1)), words * 4, None), "dicp_zero")
+            assert bool((dst[off + 1:off + 1 + words] == 0).all()) and bool((dst[:off + 1] == 77).all()) and bool((dst[off + 1 + words:] == 77).all())

@@ -481,7 +481,7 @@ def _fwd_loop_state(S):
     if (S.have_first and len(S.first) > 3 and S.first[3] is not None and not S.keep_idx and S.events is None and not (certs is not None and S.cert_from <= 0)):
         S.first_spos = S.first[3]
         if S.adaptive and sweep.form0 is not None:
-            S.sweep_form[0].copy_(sweep.form0)        # (that search's tally of its slabs: the scoring form of iteration 1's)
+            _lib.check(S.lib.dicp_copy(_p(S.sweep_form[0]), _p(sweep.form0), N * 4, S.st), "dicp_copy")      # (that search's tally of its slabs: the scoring form of iteration 1's)
         if not S.keep_spos:
             S.spos_once = S.first_spos
     S.qorders, S.seg_q, S.done_segs = [], [], []          # distinct query orders of the sweep, which one each segment used, the segments that ran
@@ -688,11 +688,14 @@ def _fwd_finish(S):
             cfg.stats_out["budgets"] = certs["q"]         # (N,n) by query: the budgets as the last iteration left them
             cfg.stats_out["certs_off"] = (S.cert_cloud[:, 2] > 0).to(torch.int32)  # (N) int32: 1 = the cloud's certificates were switched off during the call (they cost more than searching everything)
     cert_hint, form_hint = S.cert_hint, S.form_hint
-    if certs is not None and sweep is not None and cfg.stats_out is not None and cert_hint is not None and cert_hint["event"] is None and cert_hint["calls"] % 16 == 1:
+    # (reports to later calls are copies to pinned memory behind an event: not from inside a graph capture, whose replays nobody would read them from)
+    if (certs is not None and sweep is not None and cfg.stats_out is not None and cert_hint is not None and cert_hint["event"] is None and cert_hint["calls"] % 16 == 1
+            and not torch.cuda.is_current_stream_capturing()):
         cert_hint["host"][:N].copy_(S.cert_cloud, non_blocking=True)        # (every sixteenth certified call: it is host time)
         cert_hint["event"] = torch.cuda.Event()
         cert_hint["event"].record()
-    if S.adaptive and form_hint is not None and form_hint["event"] is None and (form_hint["calls"] < 2 or form_hint["calls"] % 16 == 0):
+    if (S.adaptive and form_hint is not None and form_hint["event"] is None and (form_hint["calls"] < 2 or form_hint["calls"] % 16 == 0)
+            and not torch.cuda.is_current_stream_capturing()):
         # (the first two calls of a shape and every sixteenth after: it is host time) clouds with long slabs in any plain search of this call, in its
         # last one, and per iteration (the next calls' plan)
         if form_hint["host"] is None:

@@ -559,6 +559,29 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
                                       "call-to-call hint was recorded on another batch; %.3f ms per call (min %.3f, max %.3f); compare value_k10, whose calls replay one batch"
                                       % (len(ft), len(fresh), median(ft) * 1e3, min(ft) * 1e3, max(ft) * 1e3))
         del fr, fresh
+        if world == 1:
+            # The timed call as ONE captured hipGraph (dicp_amd.graphed.graphed_icp_step: call + loss + backward): what the headline shape does when the host is
+            # the slow side -- an eager call is ~1 ms of host work against 2.7-3.3 ms of kernels (profiles/r06_host_time.txt), a replay is one launch.
+            progress("leg: value_graphed")
+            from dicp_amd.graphed import graphed_icp_step
+            gi = new_icp(K)
+            gs_, gt_ = data[0].detach().requires_grad_(True), data[1].detach().requires_grad_(True)
+            gstep = graphed_icp_step(gi, lambda o_: o_["T"].sum(), gs_, gt_, T0, num_warmup_iters=4, trim_dist=TRIM, loss_fn=LOSS, dim=3)
+            for _ in range(3):
+                gout, ggr = gstep(gs_, gt_, T0)
+            gtimes = []
+            for _ in range(reps):
+                fence()
+                t0_ = time.perf_counter()
+                gout, ggr = gstep(gs_, gt_, T0)
+                fence()
+                gtimes.append(time.perf_counter() - t0_)
+            gstep.check_errors()
+            extra["value_graphed"] = B * K / median(gtimes)
+            extra["graphed_note"] = ("the timed call (K = %d, fwd + loss + bwd) captured once and replayed: %.3f ms per replay, every replay behind a synchronisation; results equal "
+                                     "the eager call's (tests/test_gpu_configs.py::test_captured_step_after_a_synchronisation); finite: %s"
+                                     % (K, median(gtimes) * 1e3, bool(torch.isfinite(gout["T"]).all() and torch.isfinite(ggr["source"]).all() and torch.isfinite(ggr["target"]).all())))
+            del gi, gstep, gout, ggr, gs_, gt_
         if not brute:
             progress("leg: value_bruteforce (matrix cores, VALU)")
             for key, kv, what in (("value_bruteforce", L.KNN_MFMA, "the matrix-core brute force (split-f16 filter on v_mfma_f32_32x32x16_f16 + exact float32 refine)"),

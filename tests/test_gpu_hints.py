@@ -45,3 +45,42 @@ def test_rotating_batches_equal_hint_free_objects(const_iter, K):
             for g, w in ((got[1], want[i][1]), (got[2], want[i][2])):
                 scale = max(1.0, float(w.abs().max()))
                 assert float((g - w).abs().max()) <= 2e-5 * scale, (rnd, i, float((g - w).abs().max()) / scale)
+
+
+@pytest.mark.parametrize("tol", [None, 1e-4])
+def test_calls_interleaved_with_their_backward_passes(tol):
+    """Two calls of ONE object before either backward pass, the passes in either order, and a third call between them: every call's buffers, certificates and
+    hint records are its own -- poses bit for bit and gradients to rounding as when each call is followed by its own backward."""
+    from dicp_amd.synthetic import make_scene_pairs
+    B, n, K = 32, 16384, 10 if tol is None else 50
+    d1 = [x.cuda() for x in make_pairs(B, n, n, seed=5)]
+    d2 = [x.cuda() for x in make_scene_pairs(B, n, n, seed=6)]
+    T0 = torch.eye(4, device="cuda").repeat(B, 1, 1)
+    kw = dict(trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0})
+    icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=tol if tol else 1e-12)
+    icp.const_iter = tol is None
+    ref = []
+    for d in (d1, d2):
+        for _ in range(2):
+            s, t = d[0].clone().requires_grad_(True), d[1].clone().requires_grad_(True)
+            o = icp.icp(s, t, T0, **kw)
+            o["T"].sum().backward()
+        ref.append((o["T"].detach().clone(), s.grad.clone(), t.grad.clone()))
+    for rnd in range(3):
+        s1, t1 = d1[0].clone().requires_grad_(True), d1[1].clone().requires_grad_(True)
+        s2, t2 = d2[0].clone().requires_grad_(True), d2[1].clone().requires_grad_(True)
+        o1 = icp.icp(s1, t1, T0, **kw)
+        o2 = icp.icp(s2, t2, T0, **kw)
+        if rnd == 0:
+            (o1["T"].sum() + o2["T"].sum()).backward()
+        elif rnd == 1:
+            o2["T"].sum().backward()
+            o1["T"].sum().backward()
+        else:
+            o1["T"].sum().backward()
+            icp.icp(s1.detach(), t1.detach(), T0, **kw)
+            o2["T"].sum().backward()
+        torch.cuda.synchronize()
+        assert torch.equal(o1["T"], ref[0][0]) and torch.equal(o2["T"], ref[1][0]), rnd
+        for g, e in ((s1.grad, ref[0][1]), (t1.grad, ref[0][2]), (s2.grad, ref[1][1]), (t2.grad, ref[1][2])):
+            assert float((g - e).abs().max()) <= 3e-5 * float(e.abs().max()), rnd

@@ -623,12 +623,22 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
         # point), 30 % of either cloud outside the other's footprint, 10 % clutter, start poses up to 0.2 rad / 1 m -- dense batches (the kernels'
         # own behaviour) and the same clouds as ragged lists (the reference's list inputs, tests/test_ICP_inputs.py:36-103: the host's list handling is in the call)
         def indep_leg(K_, const_iter, ragged, count):
-            S, Tg = make_independent_pairs(B, n, m, seed=3, dtype=torch.float32, first=rank * B, ragged=ragged)
-            if ragged:
+            S, Tg = make_independent_pairs(B, n, m, seed=3, dtype=torch.float32, first=rank * B, ragged=bool(ragged))
+            rows_kw = {}
+            if ragged == "rows":        # the ragged clouds as ONE padded batch with per-cloud row counts (ICP.icp's source_rows / target_rows)
+                real = float(sum(a.shape[0] * b.shape[0] for a, b in zip(S, Tg)))
+                rows_kw = dict(source_rows=torch.tensor([x.shape[0] for x in S], dtype=torch.int32, device=dev),
+                               target_rows=torch.tensor([x.shape[0] for x in Tg], dtype=torch.int32, device=dev))
+                S = torch.nn.utils.rnn.pad_sequence(S, batch_first=True).to(dev)
+                Tg = torch.nn.utils.rnn.pad_sequence(Tg, batch_first=True).to(dev)
+                T0i, ragged = T0, False
+            elif ragged:
                 S, Tg = [x.to(dev) for x in S], [x.to(dev) for x in Tg]
                 T0i = [torch.eye(4, device=dev)] * B
+                real = float(sum(a.shape[0] * b.shape[0] for a, b in zip(S, Tg)))
             else:
                 S, Tg, T0i = S.to(dev), Tg.to(dev), T0
+                real = float(B) * n * m
             obj = new_icp(K_, tol=1e-12 if const_iter else 1e-4, const_iter=const_iter)
 
             def call():
@@ -637,7 +647,7 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
                     t_ = [x.detach().requires_grad_(True) for x in Tg]
                 else:
                     s_, t_ = S.detach().requires_grad_(True), Tg.detach().requires_grad_(True)
-                o = obj.icp(s_, t_, T0i, trim_dist=TRIM, loss_fn=LOSS, dim=3)
+                o = obj.icp(s_, t_, T0i, trim_dist=TRIM, loss_fn=LOSS, dim=3, **rows_kw)
                 o["T"].sum().backward()
                 return o, s_, t_
             for _ in range(3):
@@ -653,7 +663,7 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
             k_exec = int(o["deltas"].shape[1])
             grads = [x.grad for x in (s_ + t_)] if ragged else [s_.grad, t_.grad]
             fin = bool(torch.isfinite(o["T"]).all()) and all(bool(torch.isfinite(g_).all()) for g_ in grads)
-            real_pairs = float(sum(a.shape[0] * b.shape[0] for a, b in zip(S, Tg))) if ragged else float(B) * n * m
+            real_pairs = real
             st = obj.knn_stats
             rec = {"cloud_it_per_s": world * B * k_exec / median(tms), "iterations_executed": k_exec, "ms_per_call": median(tms) * 1e3, "finite": fin,
                    "converged_clouds": int(o["stats"]["converged"].sum().item()) if "converged" in o["stats"] else None}
@@ -666,7 +676,8 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
                 rec["certs_off_clouds"] = int(st["certs_off"].sum().item()) if "certs_off" in st else None
             return rec, fin
         indep = {}
-        for name, K_, ci, rg in (("k10", 10, True, False), ("tolerance", 50, False, False), ("k10_ragged_lists", 10, True, True), ("tolerance_ragged_lists", 50, False, True)):
+        for name, K_, ci, rg in (("k10", 10, True, False), ("tolerance", 50, False, False), ("k10_ragged_lists", 10, True, True), ("tolerance_ragged_lists", 50, False, True),
+                                 ("k10_ragged_rows", 10, True, "rows")):
             progress("leg: value_independent / %s" % name)
             indep[name], fin_ = indep_leg(K_, ci, rg, 5)
             sane = sane and fin_
@@ -675,7 +686,8 @@ def main(argv=None, make_icp=None, device=None, backend="nccl", emit=None):
         extra["independent_note"] = ("dicp_amd.synthetic.make_independent_pairs: source and target sampled INDEPENDENTLY from the same surfaces (corridor with partitions and pillars), "
                                      "footprints 6 m apart (30 %% of either cloud without counterpart), 10 %% clutter each, start poses up to 0.2 rad / 1 m; k10 = 10 constant "
                                      "iterations (compare value_k10 = %.0f on make_pairs, whose source IS target rows), tolerance = 1e-4 / max 50 / const_iter off; "
-                                     "*_ragged_lists: the same clouds with lengths in [0.75, 1] x %d handed over as Python lists (the host's list handling is inside the call)"
+                                     "*_ragged_lists: the same clouds with lengths in [0.75, 1] x %d handed over as Python lists (the host's list handling is inside the call); k10_ragged_rows: "
+                                     "those ragged clouds as ONE padded batch with per-cloud row counts (ICP.icp(source_rows=, target_rows=)): no lists, no 512 autograd leaves"
                                      % (extra.get("value_k10", float("nan")), n))
         if on_gpu and world == 1:
             progress("legs: configs[1], configs[3] slice and full batch, configs[0]")

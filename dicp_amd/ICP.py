@@ -86,10 +86,10 @@ class ICP:
         self._hints = CallHints()             # private: what this object's earlier calls tell later ones about time (per device, stream and shape)
         self._eye = {}                        # private: identity start poses of pt2pt_dICP_SVD by (batch size, dtype, device)
 
-    def icp(self, source, target, T_init, weight=None, trim_dist=None, loss_fn=None, dim=3):
-        return self.dICP(source, target, T_init, weight, trim_dist, loss_fn, dim)      # ICP.py:46-47
+    def icp(self, source, target, T_init, weight=None, trim_dist=None, loss_fn=None, dim=3, source_rows=None, target_rows=None):
+        return self.dICP(source, target, T_init, weight, trim_dist, loss_fn, dim, source_rows, target_rows)      # ICP.py:46-47
 
-    def dICP(self, source, target, T_init, weight=None, trim_dist=None, loss_fn=None, dim=3):
+    def dICP(self, source, target, T_init, weight=None, trim_dist=None, loss_fn=None, dim=3, source_rows=None, target_rows=None):
         """Point-to-point / point-to-plane ICP on a batch of scan pairs (ICP.py:49-303).
 
         source : (n,3|6) | (N,n,3|6) | list of (n_i,3|6);  only xyz is used
@@ -98,6 +98,9 @@ class ICP:
         weight : None | (n) | (N,n) | list of (n_i)|None
         trim_dist : None or a distance; loss_fn : None or {"name": "huber"|"cauchy"|"trim", "metric": x}
         dim : 3, or 2 to optimise rotation about z and translation in x,y only
+        source_rows, target_rows (build-specific, optional): (N) row counts of a PADDED batch (N,n,3|6) / (N,m,3|6) -- ragged clouds without Python lists: rows
+                 past a cloud's count take no part (whatever they hold), as if the clouds had been given as a list of their own lengths.  A list of 256
+                 clouds is 512 leaf tensors to autograd, ~8 ms of host time per call; the padded batch is one
         returns {"pc" (N,n,3), "T" (N,4,4), "costs" (N,K,1), "deltas" (N,K,6,1),
                  "weights" (N,K,n*r,1), "stats": {"converged","iterations","matched_ratio"}}
         """
@@ -120,6 +123,13 @@ class ICP:
         source, target, T_init = (t.to(dev) for t in (source, target, T_init))
         w_pts = w_pts.to(dev) if w_pts is not None else None
         src_rows, tgt_rows = self._device_rows(rows, dev)
+        if source_rows is not None or target_rows is not None:
+            if rows is not None:
+                raise ValueError("source_rows / target_rows describe a padded batch: not together with lists of clouds")
+            src_rows, tgt_rows = self._given_rows(source_rows, source, "source_rows"), self._given_rows(target_rows, target, "target_rows")
+            if src_rows is not None:      # the rows past a cloud's own carry weight zero, like the pads of a list (ICP.py:386-398)
+                live = (torch.arange(source.shape[1], device=dev)[None, :] < src_rows[:, None]).to(source.dtype)
+                w_pts = live if w_pts is None else w_pts * live
 
         if dim == 2:                                                                     # ICP.py:107-116
             # (the masks are made once per dtype and device: a host-to-device copy per call cannot be captured into a hipGraph -- the reference's own
@@ -277,6 +287,20 @@ class ICP:
             else:
                 out.append(torch.tensor([min(v + extra, full) for v in lens], dtype=torch.int32).to(dev))
         return out[0], out[1]
+
+    @staticmethod
+    def _given_rows(rows, batch, name):
+        """Caller-given row counts of a padded batch -> (N) int32 on the batch's device, or None (every row takes part)."""
+        if rows is None:
+            return None
+        r = torch.as_tensor(rows).to(device=batch.device, dtype=torch.int32).reshape(-1).contiguous()
+        if r.numel() != batch.shape[0]:
+            raise ValueError("%s: one count per cloud (%d), got %d" % (name, batch.shape[0], r.numel()))
+        if not isinstance(rows, torch.Tensor) or not rows.is_cuda:          # (host values: checked here; device counts are the caller's word)
+            host = torch.as_tensor(rows).reshape(-1)
+            if int(host.min()) < 1 or int(host.max()) > batch.shape[1]:
+                raise ValueError("%s: counts must lie in [1, %d]" % (name, batch.shape[1]))
+        return r
 
     def _tensor_weight(self, w, source_b):
         """A caller-supplied weight TENSOR (the list form is cast item by item below).  The reference multiplies it into the

@@ -164,3 +164,55 @@ def test_lists_are_packed_by_one_launch_like_pad_sequence():
         with pytest.raises(ValueError):
             _ops.pack_list(bad, 3)
     assert not _ops.packable([c.detach().t() for c in clouds], (6,)) and not _ops.packable([c.detach().cpu() for c in clouds], (6,))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("icp_type,const_iter", [("pt2pl", True), ("pt2pt", False)])
+def test_padded_batch_with_row_counts_equals_the_list_call(icp_type, const_iter):
+    """ICP.icp(..., source_rows=, target_rows=) (build-specific): ragged clouds as ONE padded batch with per-cloud row counts -- the same poses, per-iteration
+    outputs and gradients (on the clouds' own rows; zero on the pads) as the list call the reference's API offers for them (ICP.py:305-511), to rounding: the
+    sums are grouped by another query order (the list's target keeps one far pad row).  Whatever the pad rows hold."""
+    N, n, m, K = 12, 6000, 7000, 8
+    src, tgt = make_pairs(N, n, m, seed=23, dtype=torch.float32)
+    if icp_type == "pt2pt":
+        tgt = tgt[:, :, :3].contiguous()
+    g = torch.Generator().manual_seed(4)
+    ls = [int(v) for v in torch.randint(n // 2, n + 1, (N,), generator=g)]
+    lt = [int(v) for v in torch.randint(m // 2, m + 1, (N,), generator=g)]
+    ls[0], lt[1] = n, m
+    kw = dict(trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0})
+
+    def new():
+        icp = ICP(icp_type=icp_type, differentiable=True, max_iterations=K, tolerance=1e-12 if const_iter else 1e-5)
+        icp.const_iter = const_iter
+        return icp
+    S = [src[b, :ls[b]].cuda().requires_grad_(True) for b in range(N)]
+    T = [tgt[b, :lt[b]].cuda().requires_grad_(True) for b in range(N)]
+    out_l = new().icp(S, T, [torch.eye(4, device="cuda")] * N, **kw)
+    mask = (torch.arange(n, device="cuda")[None, :] < torch.tensor(ls, device="cuda")[:, None])        # (the loss looks at the clouds' own rows of pc only)
+    (out_l["T"][:, :3].sum() + 1e-3 * ((out_l["pc"] * mask.unsqueeze(-1)) ** 2).sum()).backward()
+    # the padded batch: garbage behind every cloud's own rows
+    sp, tp = src.clone(), tgt.clone()
+    for b in range(N):
+        sp[b, ls[b]:] = 1e3 * torch.randn((n - ls[b], 3), generator=g)
+        tp[b, lt[b]:] = float("nan")
+    sp, tp = sp.cuda().requires_grad_(True), tp.cuda().requires_grad_(True)
+    for rows_as in ("list", "device"):
+        sp.grad = tp.grad = None
+        sr = ls if rows_as == "list" else torch.tensor(ls, dtype=torch.int32, device="cuda")
+        tr = lt if rows_as == "list" else torch.tensor(lt, dtype=torch.int64, device="cuda")
+        out_p = new().icp(sp, tp, torch.eye(4, device="cuda").repeat(N, 1, 1), source_rows=sr, target_rows=tr, **kw)
+        (out_p["T"][:, :3].sum() + 1e-3 * ((out_p["pc"] * mask.unsqueeze(-1)) ** 2).sum()).backward()
+        assert out_p["deltas"].shape == out_l["deltas"].shape
+        assert float((out_p["T"] - out_l["T"]).abs().max()) <= 2e-5
+        assert float((out_p["deltas"] - out_l["deltas"]).abs().max()) <= 2e-5
+        for b in range(N):
+            for got, want in ((sp.grad[b, :ls[b]], S[b].grad), (tp.grad[b, :lt[b]], T[b].grad)):
+                assert float((got - want).abs().max()) <= 2e-4 * max(1e-6, float(want.abs().max())), (b, rows_as)
+            assert bool((sp.grad[b, ls[b]:] == 0).all()) and bool((torch.nan_to_num(tp.grad[b, lt[b]:]) == 0).all())
+    with pytest.raises(ValueError):
+        new().icp(sp, tp, torch.eye(4, device="cuda").repeat(N, 1, 1), source_rows=ls[:-1], **kw)
+    with pytest.raises(ValueError):
+        new().icp(sp, tp, torch.eye(4, device="cuda").repeat(N, 1, 1), source_rows=[0] + ls[1:], **kw)
+    with pytest.raises(ValueError):
+        new().icp(S, T, [torch.eye(4, device="cuda")] * N, source_rows=ls, **kw)

@@ -242,3 +242,20 @@ def test_product_never_imports_oracle():
         if not f.endswith(".py"):
             continue
         assert "oracle" not in open(os.path.join(ROOT, "dICP", f)).read()
+
+
+def test_public_header_is_plain_c(tmp_path):
+    """include/dicp_hip.h is the drop-in boundary: a C99 (and C++) translation unit that names the versioned struct and its sub-structs compiles against it alone --
+    no HIP, no torch types in the signatures."""
+    import shutil
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "dicp_hip.h"\n'
+                   "int main(void) { dicp_loop_buffers b; b.abi = DICP_ABI_VERSION; b.search.m_pad = 1; b.cert.q = 0; b.hist.w_iter = 2; b.bwd.tail_from = 3;\n"
+                   "                 dicp_step_io io; io.cert_slist = 0; (void)io; return (int)sizeof(b) & 0; }\n")
+    inc = os.path.join(ROOT, "include")
+    for cc, args in (("gcc", ["-std=c99", "-pedantic"]), ("g++", ["-std=c++17", "-x", "c++"])):
+        if shutil.which(cc) is None:
+            pytest.skip(cc + " not installed")
+        r = subprocess.run([cc, "-Wall", "-Wextra", "-Werror", "-I", inc, "-fsyntax-only"] + args + [str(src)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr

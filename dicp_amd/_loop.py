@@ -575,10 +575,10 @@ def _tolerance_words(dev, Kmax):
     key = CallHints._where(dev)
     rec = _TOL_WORDS.get(key)
     if rec is None or rec[0].numel() < Kmax:
-        if len(_TOL_WORDS) >= 64:
-            _TOL_WORDS.pop(next(iter(_TOL_WORDS)))
         t = torch.empty((max(64, Kmax),), dtype=torch.int32).pin_memory()
-        rec = _TOL_WORDS[key] = [t, t.numpy(), rec[2] if rec else 0]
+        # (the words a longer call outgrows are kept, not freed: a late segment of the previous call may still store to them, and the pinned allocator knows
+        #  nothing of stores made by kernels -- it would hand the memory to the next pin_memory() at once)
+        rec = _TOL_WORDS[key] = [t, t.numpy(), rec[2] if rec else 0, (rec[3] + [rec[0]]) if rec else []]
     rec[2] = (rec[2] + 1) % 0x7ff                     # (0x7ff itself is what -1 carries in the tag bits)
     rec[1][:Kmax] = -1
     return rec, rec[2] << 20

@@ -84,3 +84,30 @@ def test_calls_interleaved_with_their_backward_passes(tol):
         assert torch.equal(o1["T"], ref[0][0]) and torch.equal(o2["T"], ref[1][0]), rnd
         for g, e in ((s1.grad, ref[0][1]), (t1.grad, ref[0][2]), (s2.grad, ref[1][1]), (t2.grad, ref[1][2])):
             assert float((g - e).abs().max()) <= 3e-5 * float(e.abs().max()), rnd
+
+
+def test_tolerance_mode_reads_the_counters_from_mapped_words():
+    """The reference's all-converged check (ICP.py:259) without a copy in the stream: the last launch of every segment stores the segment's counters -- clouds
+    still moving per iteration -- to mapped host words tagged with the call (dicp_loop_buffers.counters_host / counters_tag).  After a call the words of its
+    executed iterations carry the call's tag, the last executed iteration's count is zero and every earlier one's is not; the next call's tag differs."""
+    import dicp_amd._loop as L
+    N, n = 16, 8192
+    src, tgt = make_pairs(N, n, n, seed=12)
+    src, tgt = src.cuda(), tgt.cuda()
+    T0 = torch.eye(4, device="cuda").repeat(N, 1, 1)
+    icp = ICP(icp_type="pt2pl", differentiable=False, max_iterations=40, tolerance=1e-4)
+    icp.const_iter = False
+    tags = []
+    for _ in range(3):
+        out = icp.icp(src, tgt, T0, trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0})
+        torch.cuda.synchronize()
+        K = int(out["deltas"].shape[1])
+        rec = L._TOL_WORDS[L.CallHints._where(src.device)]
+        words = rec[1][:K].copy()
+        tag = rec[2] << 20
+        assert 1 < K < 40 and bool(((words & 0x7ff00000) == tag).all()) and bool((words >= 0).all())
+        counts = words & 0xfffff
+        assert int(counts[K - 1]) == 0 and bool((counts[:K - 1] > 0).all()) and int(counts[0]) == N
+        assert bool((out["stats"]["iterations"] <= K).all())
+        tags.append(tag)
+    assert len(set(tags)) == 3

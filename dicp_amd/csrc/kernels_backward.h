@@ -407,22 +407,37 @@ __global__ __launch_bounds__(BLOCK) void window_reduce_kernel(const T* __restric
         dst[u] = tperm[(size_t)cloud * m_pad + s];
         if (gts_far) acc[u] = gts_far[((size_t)cloud * m_pad + s) * cv + (e - s * CV)];
     }
+    static_assert(MAXB == BLOCK, "one window block per thread in the relevance pass below");
+    __shared__ int rlist[MAXB], wcnt[BLOCK / WAVE];
+    // the sorted rows this block's elements lie in
+    const int r_lo = e0 / CV, r_hi = min(e0 + BLOCK * WR_U - 1, m * cv - 1) / CV;
     for (int b0 = 0; b0 < bpc; b0 += MAXB) {
         __syncthreads();
-        for (int b = tid; b < min(MAXB, bpc - b0); b += BLOCK)
-            origin[b] = window_origin(spos_ref + (size_t)cloud * n, qorder ? qorder + (size_t)cloud * n : nullptr, b0 + b, spb, rows_of(src_rows, cloud, n), m_pad, WT);
-        __syncthreads();
         const int nb = min(MAXB, bpc - b0);
-        // Which windows cover a row is arithmetic on the origins in LDS; only those are loaded (two or three of the cloud's blocks, in ascending block order: the
-        // order of the sums is what it was).  Round 5: the kernel used to issue a predicated load per (element, block) -- 64 load instructions per thread for ~9
-        // real loads, 117 us per call; it is bound by instructions, not bytes.
-        for (int bb = 0; bb < nb; bb += 32) {
+        int org = 0;
+        if (tid < nb)
+            origin[tid] = org = window_origin(spos_ref + (size_t)cloud * n, qorder ? qorder + (size_t)cloud * n : nullptr, b0 + tid, spb, rows_of(src_rows, cloud, n), m_pad, WT);
+        // Which windows cover a row is arithmetic on the origins; only those are loaded (two or three of the cloud's blocks, in ascending block order: the order of
+        // the sums is what it was).  Round 5: the kernel used to issue a predicated load per (element, block) -- 64 load instructions per thread for ~9 real loads,
+        // 117 us per call; it is bound by instructions, not bytes.  Round 6: the blocks whose window reaches this block's ~170 rows at all are listed first (one
+        // thread per window block, ballots: the list stays in ascending block order) and every element is held against THAT list -- three blocks, not all of the
+        // cloud's: at configs[3]'s size (64 window blocks per cloud) the launch took 866 us for 1.2 GB.
+        const bool rel = tid < nb && org <= r_hi && org + WT > r_lo;
+        const unsigned long long rmask = __ballot(rel);
+        if ((tid & (WAVE - 1)) == 0) wcnt[tid >> 6] = __popcll(rmask);
+        __syncthreads();
+        int base = 0, nrel = 0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / WAVE; ++w) { if (w < (tid >> 6)) base += wcnt[w]; nrel += wcnt[w]; }
+        if (rel) rlist[base + __popcll(rmask & ((1ull << (tid & (WAVE - 1))) - 1ull))] = tid;
+        __syncthreads();
+        for (int bb = 0; bb < nrel; bb += 32) {
             unsigned cover[WR_U];
 #pragma unroll
             for (int u = 0; u < WR_U; ++u) cover[u] = 0u;
-            const int nbb = min(32, nb - bb);
+            const int nbb = min(32, nrel - bb);
             for (int k = 0; k < nbb; ++k) {
-                const int lo = origin[bb + k];
+                const int lo = origin[rlist[bb + k]];
 #pragma unroll
                 for (int u = 0; u < WR_U; ++u) {
                     const int sr = min(e0 + u * BLOCK + tid, m * cv - 1) / CV;
@@ -438,7 +453,8 @@ __global__ __launch_bounds__(BLOCK) void window_reduce_kernel(const T* __restric
                         const int k = __ffs((int)cover[u]) - 1;
                         cover[u] &= cover[u] - 1;
                         const int e = min(e0 + u * BLOCK + tid, m * cv - 1);
-                        v[u] = slab[((size_t)cloud * bpc + b0 + bb + k) * (WT * CV) + (size_t)(e - origin[bb + k] * CV)];
+                        const int b = rlist[bb + k];
+                        v[u] = slab[((size_t)cloud * bpc + b0 + b) * (WT * CV) + (size_t)(e - origin[b] * CV)];
                     }
                 }
 #pragma unroll

@@ -121,6 +121,9 @@ def test_sweep_equals_brute_force_at_65536(dtype, N, n):
     assert int(bad.sum()) <= 2 and bool(((second - best)[bad] < 1e-4).all())
 
 
+_ORACLE_ONCE = {}
+
+
 @pytest.mark.parametrize("variant", [_lib.KNN_AUTO, _lib.KNN_MFMA])
 def test_config4_icp_at_65536_vs_oracle(variant):
     """configs[3] cloud size through the whole ICP call, forward and backward: KNN_AUTO (= the sorted sweep: key sort and
@@ -136,8 +139,10 @@ def test_config4_icp_at_65536_vs_oracle(variant):
     out = icp.icp(sd, td, torch.eye(4, device=DEV).repeat(N, 1, 1), **KW)
     out["T"].sum().backward()
     assert bool(torch.isfinite(out["T"]).all() and torch.isfinite(sd.grad).all() and torch.isfinite(td.grad).all())
-    rec = {}
-    T_ref, gs_ref, gt_ref = oracle_slice(src[1:2], tgt[1:2], K, chunk=4096, record=rec)
+    if "c4" not in _ORACLE_ONCE:        # (the same cloud for both variants: 30 s of host time at this size, once)
+        rec = {}
+        _ORACLE_ONCE["c4"] = oracle_slice(src[1:2], tgt[1:2], K, chunk=4096, record=rec) + (rec,)
+    T_ref, gs_ref, gt_ref, rec = _ORACLE_ONCE["c4"]
     np.testing.assert_allclose(npy(out["T"])[1], T_ref[0].numpy(), rtol=0, atol=1e-4)
     errs = []
     for got, want, nm in ((sd.grad[1], gs_ref[0], "source"), (td.grad[1], gt_ref[0], "target")):

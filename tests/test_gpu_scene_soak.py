@@ -10,13 +10,15 @@ from dicp_amd.ICP import ICP
 from dicp_amd.synthetic import make_scene_pairs
 
 pytestmark = pytest.mark.gpu
+_SCENES = {}
 
 
 @pytest.mark.parametrize("tail", [True, False])
 def test_scene_calls_back_to_back(tail):
     B, n, K, calls = 256, 16384, 20, 300
-    S, T = make_scene_pairs(B, n, n, seed=3)
-    S, T = S.cuda(), T.cuda()
+    if "d" not in _SCENES:      # (generated on the host: ten seconds at this size, once for both forms)
+        _SCENES["d"] = tuple(x.cuda() for x in make_scene_pairs(B, n, n, seed=3))
+    S, T = _SCENES["d"]
     T0 = torch.eye(4, device="cuda").repeat(B, 1, 1)
     icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=K, tolerance=1e-12)
     icp.const_iter = True

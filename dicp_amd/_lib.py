@@ -139,7 +139,8 @@ class CallBackwardLayout(ctypes.Structure):
 class LoopBackwardIn(ctypes.Structure):
     """dicp_loop_backward_in (include/dicp_hip.h)."""
     _fields_ = ([(k, vp) for k in ("src", "tgt_sorted", "w0", "tperm", "qorder", "spos", "poses", "deltas", "areg", "alive", "src_rows", "tgt_rows", "spos_of")]
-                + [(k, i32) for k in ("N", "n", "m", "c", "K", "K_cap", "m_pad", "dim", "knn_variant", "spos_of_from")])
+                + [(k, i32) for k in ("N", "n", "m", "c", "K", "K_cap", "m_pad", "dim", "knn_variant", "spos_of_from")]
+                + [(k, vp) for k in ("src_s", "w_s", "spos_ref")])
 
 
 class KabschCall(ctypes.Structure):
@@ -233,6 +234,7 @@ _SIGNATURES = {
     "dicp_call_backward": ([i32, ctypes.POINTER(WeightParams), ctypes.POINTER(Call), ctypes.POINTER(CallGrads), vp], ctypes.c_int),
     "dicp_loop_backward_plan": ([i32, ctypes.POINTER(WeightParams), ctypes.POINTER(LoopBackwardIn), i32, i32, ctypes.POINTER(CallBackwardLayout)], ctypes.c_int),
     "dicp_loop_backward": ([i32, ctypes.POINTER(WeightParams), ctypes.POINTER(LoopBackwardIn), ctypes.POINTER(CallGrads), vp], ctypes.c_int),
+    "dicp_loop_backward_prepare": ([i32, ctypes.POINTER(LoopBackwardIn), vp, vp, vp, vp], ctypes.c_int),
     "dicp_kabsch_call_plan": ([i32, ctypes.POINTER(KabschCall), ctypes.POINTER(KabschCallLayout)], ctypes.c_int),
     "dicp_kabsch_call_forward": ([i32, ctypes.POINTER(KabschCall), vp], ctypes.c_int),
     "dicp_kabsch_call_backward": ([i32, ctypes.POINTER(KabschCall), ctypes.POINTER(KabschCallGrads), vp], ctypes.c_int),

@@ -739,6 +739,45 @@ def _fwd_save(ctx, S):
     # window of neighbouring target rows, and most contributions take the float atomics (0.43 instead of 0.15 ms per launch on independently sampled
     # clouds, profiles/r05_ragged_lists.txt).  The backward then orders its slots by the reference matches themselves (one counting-sort launch).
     ctx.bwd_reorder = bool(S.clouds_moving) and sweep is not None
+    _fwd_prepare_backward(ctx, S, spos_of)
+
+
+def _one_call_backward(cfg, owned, soft, n_spos_slabs, n_idx_slabs, c, cv, segs, K):
+    """Whether the pass is ONE library call (dicp_loop_backward): every iteration takes the windowed form inside one history slab."""
+    return bool(owned and soft is None and cfg.timing_events is None and n_spos_slabs == 1 and n_idx_slabs == 0 and c == cv and segs and K >= 1 and not cfg.deterministic)
+
+
+def _loop_backward_in(cfg, src, tgt_s, w0c, tperm, qorder, spos, poses, deltas, areg, alive, m, K, Kmax, m_pad, kind, spos_of, of_from):
+    N, n, _ = src.shape
+    return _lib.LoopBackwardIn(src=src.data_ptr(), tgt_sorted=tgt_s.data_ptr(), w0=w0c.data_ptr() if w0c is not None else None, tperm=tperm.data_ptr(),
+                               qorder=qorder.data_ptr(), spos=spos.data_ptr(), poses=poses.data_ptr(), deltas=deltas.data_ptr(), areg=areg.data_ptr(),
+                               alive=alive.data_ptr(), src_rows=cfg.src_rows.data_ptr() if cfg.src_rows is not None else None,
+                               tgt_rows=cfg.tgt_rows.data_ptr() if cfg.tgt_rows is not None else None, N=N, n=n, m=m, c=tgt_s.shape[2], K=K, K_cap=Kmax, m_pad=m_pad,
+                               dim=int(cfg.dim), knn_variant=kind | ((0 if cfg.small_loop else 1) << 25),
+                               spos_of=spos_of.data_ptr() if spos_of is not None else None, spos_of_from=int(of_from) if of_from is not None else 0)
+
+
+def _fwd_prepare_backward(ctx, S, spos_of):
+    """Tolerance mode: the part of the reverse sweep that needs no cotangent -- the source and its weights in slot order, the reference matches out of the history
+    kept by reference -- goes to the GPU NOW, behind the forward (dicp_loop_backward_prepare).  The host has just waited for the iteration count; until the
+    backward's first launch it returns from the call, the loss is taken and autograd starts its thread, ~0.2 ms in which the GPU has nothing else to do
+    (profiles/r06_tolerance_gap.txt): 58 us of the pass at 256 x 16384 move into that gap.  Constant-iteration calls gain nothing from it (their GPU is never idle
+    there) and would pay for it when no backward follows: they do not."""
+    cfg, sweep = S.cfg, S.sweep
+    ctx.pre = None
+    cv = 6 if cfg.icp_type == "pt2pl" else 3
+    if (cfg.const_iter or not S.need_grad or ctx.bwd_reorder or torch.cuda.is_current_stream_capturing()
+            or not _one_call_backward(cfg, S.owned, ctx.soft, len(S.spos_slabs), len(S.idx_slabs), S.c, cv, ctx.layout[7], S.K)):
+        return
+    N, n, K = S.N, S.n, S.K
+    F = _loop_backward_in(cfg, S.src, sweep.tgt_s, S.w0c, sweep.tperm, S.qorders[-1], S.spos_slabs[0], S.poses, S.deltas, S.areg, S.alive, S.m, K, S.Kmax, S.m_pad, S.kind,
+                          spos_of, ctx.of_from)
+    by_ref = spos_of is not None and K - 1 >= ctx.of_from
+    src_s = torch.empty_like(S.src)
+    w_s = torch.empty_like(S.w0c) if S.w0c is not None else None
+    ref = torch.empty((N, n), dtype=torch.int32, device=S.dev) if by_ref else None
+    _lib.check(S.lib.dicp_loop_backward_prepare(S.code, ctypes.byref(F), _p(src_s), _p(w_s), _p(ref), S.st), "dicp_loop_backward_prepare")
+    ctx.pre = (src_s, w_s, ref, S.qorders[-1].data_ptr())
 
 
 # ------------------------------------------------------------------ ICPLoop.backward, stage by stage (one namespace B, as the forward's S)
@@ -758,6 +797,7 @@ def _bwd_begin(ctx, gT, gpc):
     if B.soft is not None:    # Gumbel-softmax correspondences: neighbour rows and log-sum-exp of every iteration (+ the injected noise)
         B.nbr_hist, B.lse_hist, *B.U_list = rest[n_idx + n_spos + n_q:]
     B.bwd_reorder = bool(getattr(ctx, "bwd_reorder", False))
+    B.pre = getattr(ctx, "pre", None)
     B.lib = _lib.load()
     B.dev, B.dt = src.device, src.dtype
     B.code, B.es = _DT[B.dt], src.element_size()
@@ -792,12 +832,9 @@ def _bwd_one_call(B, gT):
             ref = torch.empty((N, n), dtype=torch.int32, device=B.dev)
             _lib.check(B.lib.dicp_resolve_matches(_p(B.spos_slabs[0]), _p(B.spos_of), K - 1, _p(cfg.src_rows), N, n, _p(ref), B.st), "dicp_resolve_matches")
         qo_b = order_by_matches(B.src, ref, B.m, B.m_pad, cfg.src_rows, cfg.tgt_rows)
-    F = _lib.LoopBackwardIn(src=B.src.data_ptr(), tgt_sorted=B.tgt_s.data_ptr(), w0=B.w0c.data_ptr() if B.w0c is not None else None, tperm=B.tperm.data_ptr(),
-                            qorder=qo_b.data_ptr(), spos=B.spos_slabs[0].data_ptr(), poses=B.poses.data_ptr(), deltas=B.deltas.data_ptr(), areg=B.areg.data_ptr(),
-                            alive=B.alive.data_ptr(), src_rows=cfg.src_rows.data_ptr() if cfg.src_rows is not None else None,
-                            tgt_rows=cfg.tgt_rows.data_ptr() if cfg.tgt_rows is not None else None, N=N, n=n, m=B.m, c=B.tgt_s.shape[2], K=K, K_cap=B.Kmax, m_pad=B.m_pad,
-                            dim=int(cfg.dim), knn_variant=B.kind | ((0 if cfg.small_loop else 1) << 25),
-                            spos_of=B.spos_of.data_ptr() if B.spos_of is not None else None, spos_of_from=int(B.of_from) if B.of_from is not None else 0)
+    F = _loop_backward_in(cfg, B.src, B.tgt_s, B.w0c, B.tperm, qo_b, B.spos_slabs[0], B.poses, B.deltas, B.areg, B.alive, B.m, K, B.Kmax, B.m_pad, B.kind, B.spos_of, B.of_from)
+    if B.pre is not None and B.pre[3] == qo_b.data_ptr():        # (made behind the forward, in this slot order: dicp_loop_backward_prepare)
+        F.src_s, F.w_s, F.spos_ref = _p(B.pre[0]), _p(B.pre[1]), _p(B.pre[2])
     return backward_once(B.lib, B.code, B.P, F, cfg, B.src, B.tgt, B.w0c, gT, B.want_tgt, B.want_w)
 
 
@@ -1050,8 +1087,7 @@ class ICPLoop(torch.autograd.Function):
         with _on(B.dev):
             B.st = _stream()
             gT = _bwd_pc_cotangent(B, gT, gpc)
-            if (B.owned and B.soft is None and cfg.timing_events is None and len(B.spos_slabs) == 1 and len(B.idx_slabs) == 0 and B.c == B.cv and B.segs and B.K >= 1
-                    and not cfg.deterministic):
+            if _one_call_backward(cfg, B.owned, B.soft, len(B.spos_slabs), len(B.idx_slabs), B.c, B.cv, B.segs, B.K):
                 gsrc, gtgt, gT0, gw = _bwd_one_call(B, gT)
                 if B.gsrc_pc is not None:
                     gsrc += B.gsrc_pc

@@ -219,6 +219,16 @@ static int backward_layout(int dtype, const dicp_weight_params* prm, int N_, int
     return 0;
 }
 
+// the part of the pass that needs no cotangent: the slot-order copies, and the reference matches out of a history kept by reference
+static int prepare_pass(int dtype, const dicp_loop_backward_in* f, void* src_s, void* w_s, int32_t* spos_ref, void* stream) {
+    if (int rc = dicp_gather_rows(dtype, f->src, f->qorder, f->N, f->n, f->n, 3, src_s, stream)) return rc;
+    if (f->w0)
+        if (int rc = dicp_gather_rows(dtype, f->w0, f->qorder, f->N, f->n, f->n, 1, w_s, stream)) return rc;
+    if (spos_ref)
+        if (int rc = dicp_resolve_matches(f->spos, f->spos_of, f->K - 1, f->src_rows, f->N, f->n, spos_ref, stream)) return rc;
+    return 0;
+}
+
 static int backward_once(int dtype, const dicp_weight_params* prm, const dicp_loop_backward_in* f, const dicp_call_grads* g, void* stream) {
     const int want_tgt = g->gtgt != nullptr, want_w = g->gw != nullptr;
     if (want_w && !f->w0) return DICP_ERR_NULL;
@@ -241,19 +251,23 @@ static int backward_once(int dtype, const dicp_weight_params* prm, const dicp_lo
     if (int rc = dicp_pose_grad_in(dtype, g->gT, gpose, f->N, stream)) return rc;
     // ONE slot order serves every iteration: the last query order of the forward
     const int32_t* qo = f->qorder;
-    if (int rc = dicp_gather_rows(dtype, f->src, qo, f->N, f->n, f->n, 3, W + L.src_s, stream)) return rc;
-    if (f->w0)
-        if (int rc = dicp_gather_rows(dtype, f->w0, qo, f->N, f->n, f->n, 1, W + L.w_s, stream)) return rc;
+    const bool prepared = f->src_s != nullptr;                       // (dicp_loop_backward_prepare ran behind the forward)
+    if (prepared && f->w0 && !f->w_s) return DICP_ERR_NULL;
+    const char* src_s = prepared ? (const char*)f->src_s : W + L.src_s;
+    const char* w_s = f->w0 ? (prepared ? (const char*)f->w_s : W + L.w_s) : nullptr;
     // windows placed by the last iteration's matches (a plain array of them: the history may be kept by reference)
     const int32_t* spos_ref = f->spos + (size_t)(K - 1) * N * n;
-    if (f->spos_of && K - 1 >= f->spos_of_from) {
-        if (int rc = dicp_resolve_matches(f->spos, f->spos_of, K - 1, f->src_rows, f->N, f->n, (int32_t*)(W + L.spos_ref), stream)) return rc;
-        spos_ref = (const int32_t*)(W + L.spos_ref);
+    const bool by_reference = f->spos_of && K - 1 >= f->spos_of_from;
+    if (prepared) {
+        if (by_reference) { if (!f->spos_ref) return DICP_ERR_NULL; spos_ref = f->spos_ref; }
+    } else {
+        if (int rc = prepare_pass(dtype, f, W + L.src_s, f->w0 ? W + L.w_s : nullptr, by_reference ? (int32_t*)(W + L.spos_ref) : nullptr, stream)) return rc;
+        if (by_reference) spos_ref = (const int32_t*)(W + L.spos_ref);
     }
     dicp_loop_buffers B;
     memset(&B, 0, sizeof(B));
     B.abi = DICP_ABI_VERSION;
-    B.src = W + L.src_s; B.tgt = f->tgt_sorted; B.w_init = f->w0 ? W + L.w_s : nullptr; B.c = f->c; B.K = f->K_cap;
+    B.src = src_s; B.tgt = f->tgt_sorted; B.w_init = w_s; B.c = f->c; B.K = f->K_cap;
     B.search.knn_variant = f->knn_variant;
     B.search.m_pad = f->m_pad; B.hist.per_iter = 1; B.search.qorder = qo; B.hist.spos = (int32_t*)f->spos; B.bwd.spos_ref = spos_ref; B.bwd.gts_far = want_tgt ? W + L.far : nullptr;
     B.hist.spos_of = (int32_t*)f->spos_of; B.hist.spos_of_from = f->spos_of_from;
@@ -313,6 +327,15 @@ int dicp_loop_backward_plan(int dtype, const dicp_weight_params* prm, const dicp
     if (dtype != DICP_F32 && dtype != DICP_F64) return DICP_ERR_DTYPE;
     if (f->N < 1 || f->n < 1 || f->m < 1 || f->K < 1 || f->K_cap < f->K) return DICP_ERR_SHAPE;
     return backward_layout(dtype, prm, f->N, f->n, f->m, f->K_cap, f->w0 != nullptr, want_tgt, want_w, L);
+}
+
+int dicp_loop_backward_prepare(int dtype, const dicp_loop_backward_in* f, void* src_s_out, void* w_s_out, int32_t* spos_ref_out, void* stream) {
+    if (!f || !f->src || !f->qorder || !f->spos || !src_s_out || (f->w0 && !w_s_out)) return DICP_ERR_NULL;
+    if (dtype != DICP_F32 && dtype != DICP_F64) return DICP_ERR_DTYPE;
+    if (f->N < 1 || f->n < 1 || f->K < 1 || f->K_cap < f->K) return DICP_ERR_SHAPE;
+    const bool by_reference = f->spos_of && f->K - 1 >= f->spos_of_from;
+    if (by_reference && !spos_ref_out) return DICP_ERR_NULL;
+    return prepare_pass(dtype, f, src_s_out, w_s_out, by_reference ? spos_ref_out : nullptr, stream);
 }
 
 int dicp_loop_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_backward_in* f, const dicp_call_grads* g, void* stream) {

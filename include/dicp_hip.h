@@ -768,7 +768,16 @@ typedef struct dicp_loop_backward_in {
     int32_t N, n, m, c, K, K_cap, m_pad, dim;
     int32_t knn_variant;     /* as dicp_loop_buffers */
     int32_t spos_of_from;
+    /* optional, all or none: what dicp_loop_backward_prepare made ahead of the pass -- the part of it that needs no cotangent */
+    const void* src_s;       /* (N,n,3): src in the slot order `qorder` */
+    const void* w_s;         /* (N,n): w0 in that order (NULL with w0 == NULL) */
+    const int32_t* spos_ref; /* (N,n): the matches of iteration K - 1 as a plain array (NULL when that iteration's slab is its own: the pass reads it in place) */
 } dicp_loop_backward_in;
+/* The set-up of dicp_loop_backward that depends on the forward alone -- slot-order copies of the source and its weights, the reference matches resolved out of a
+ * history kept by reference -- into caller buffers, to be named in `fwd` (src_s / w_s / spos_ref) for the pass.  A caller whose GPU would idle between the forward
+ * and the backward (the reference's default mode: the host waits for the iteration count, returns, the loss is taken, autograd starts its thread: ~0.2 ms)
+ * enqueues it behind the forward; 58 us of the pass at 256 x 16384.  spos_ref_out may be NULL (and fwd->spos_ref then stays NULL) when K - 1 < spos_of_from. */
+int dicp_loop_backward_prepare(int dtype, const dicp_loop_backward_in* fwd, void* src_s_out, void* w_s_out, int32_t* spos_ref_out, void* stream);
 int dicp_loop_backward_plan(int dtype, const dicp_weight_params* prm, const dicp_loop_backward_in* fwd, int want_tgt, int want_w, dicp_call_backward_layout* layout);
 int dicp_loop_backward(int dtype, const dicp_weight_params* prm, const dicp_loop_backward_in* fwd, const dicp_call_grads* grads, void* stream);
 

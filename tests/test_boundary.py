@@ -136,6 +136,16 @@ def test_new_entry_points_reject_bad_arguments(lib):
     assert lib.dicp_permute_rows(0, one, one, 1, 2, 1, 2, 3, 3, one, 4, 3, None) == 2
     assert lib.dicp_copy(None, one, 16, None) == 1 and lib.dicp_copy(one, one, 6, None) == 5 and lib.dicp_zero(None, 16, None) == 1 and lib.dicp_zero(ctypes.c_void_p(66), 16, None) == 5
     assert lib.dicp_copy(one, one, 0, None) == 0 and lib.dicp_zero(one, 0, None) == 0                                    # (nothing to do: nothing launched)
+    # dicp_loop_backward_prepare(dtype, fwd, src_s_out, w_s_out, spos_ref_out, stream): the forward's buffers it reads, its own outputs
+    F = _lib.LoopBackwardIn(src=one, qorder=one, spos=one, N=1, n=1, m=1, c=6, K=2, K_cap=2, m_pad=64, dim=3)
+    assert lib.dicp_loop_backward_prepare(0, ctypes.byref(F), None, None, None, None) == 1
+    assert lib.dicp_loop_backward_prepare(9, ctypes.byref(F), one, None, None, None) == 3
+    F.w0 = one
+    assert lib.dicp_loop_backward_prepare(0, ctypes.byref(F), one, None, None, None) == 1           # weights need their copy too
+    F.w0, F.spos_of, F.spos_of_from = None, one, 0
+    assert lib.dicp_loop_backward_prepare(0, ctypes.byref(F), one, None, None, None) == 1           # a history by reference needs the resolved matches
+    F.K = 3
+    assert lib.dicp_loop_backward_prepare(0, ctypes.byref(F), one, None, one, None) == 2            # K beyond the histories
     assert lib.dicp_pose_grad_in(0, None, None, 1, None) == 1 and lib.dicp_pose_grad_in(7, None, one, 1, None) == 3
     assert lib.dicp_pose_grad_out(0, one, one, 0, one, 1, None) == 2 and lib.dicp_pose_grad_out(0, one, None, 0, None, 1, None) == 1
     # dicp_knn_sweep(dtype, src, pose, tgs4, tperm, qorder, bucket, brange, nbkt, src_rows, tgt_rows, N, n, m, m_pad, idx, spos, pairs, cfg, f16_image, form_in, form_out, form_default, stream)

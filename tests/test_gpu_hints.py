@@ -111,3 +111,34 @@ def test_tolerance_mode_reads_the_counters_from_mapped_words():
         assert bool((out["stats"]["iterations"] <= K).all())
         tags.append(tag)
     assert len(set(tags)) == 3
+
+
+def test_backward_prepared_behind_a_tolerance_mode_forward(monkeypatch):
+    """Tolerance mode enqueues the cotangent-free part of the reverse sweep behind the forward (dicp_loop_backward_prepare: the GPU idles there while the host
+    returns and autograd starts): the pass that finds it made gives the gradients of the pass that makes it itself; with and without point weights."""
+    import dicp_amd._loop as L
+    N, n = 24, 16384
+    src, tgt = make_pairs(N, n, n, seed=14)
+    src, tgt = src.cuda(), tgt.cuda()
+    T0 = torch.eye(4, device="cuda").repeat(N, 1, 1)
+    wgt = (torch.rand((N, n), generator=torch.Generator().manual_seed(2)) * 0.5 + 0.5).cuda()
+    for weight in (None, wgt):
+        res = []
+        for prepared in (True, False):
+            if not prepared:
+                monkeypatch.setattr(L, "_fwd_prepare_backward", lambda ctx, S, spos_of: setattr(ctx, "pre", None))
+            icp = ICP(icp_type="pt2pl", differentiable=True, max_iterations=40, tolerance=1e-4)
+            icp.const_iter = False
+            seen = []
+            real = L.backward_once
+            monkeypatch.setattr(L, "backward_once", lambda lib, code, P, F, *a, **k: (seen.append(bool(F.src_s)), real(lib, code, P, F, *a, **k))[1])
+            s, t = src.clone().requires_grad_(True), tgt.clone().requires_grad_(True)
+            w = weight.clone().requires_grad_(True) if weight is not None else None
+            out = icp.icp(s, t, T0, weight=w, trim_dist=5.0, loss_fn={"name": "huber", "metric": 1.0})
+            out["T"].sum().backward()
+            monkeypatch.undo()
+            assert seen == [prepared]
+            res.append((out["T"].detach(), s.grad, t.grad) + ((w.grad,) if w is not None else ()))
+        assert torch.equal(res[0][0], res[1][0])
+        for a, b in zip(res[0][1:], res[1][1:]):
+            assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())

@@ -296,19 +296,23 @@ def _fwd_search_setup(S):
         raise NotImplementedError("ICP.deterministic covers the sweep search with the windowed backward (knn_variant KNN_SWEEP, bwd_window): this call "
                                   "would take another form")
     sweep = None
+    # (every search variant of a call scores in the SAME frame -- the one chosen for the queries' slabs, whether or not this variant sweeps: identical coordinates,
+    #  identical scores, identical matches, near-ties included.  Round 6's extended fuzz had the brute-force path, in the target-only frame, take the other of two
+    #  targets 6e-8 .. 2e-6 apart in squared distance in 5 of 552 cases.)
+    with_q = S.T_init.dtype == dt and tuple(S.T_init.shape) == (N, 4, 4)
     if kind == _lib.KNN_SWEEP:
         pre = cfg.prebuilt
         if (pre is not None and pre[0].data_ptr() == S.tgt.data_ptr() and pre[0].shape == S.tgt.shape and pre[0].dtype == S.tgt.dtype
                 and pre[1].tgt_s is not None and pre[1].tgt_rows is cfg.tgt_rows):
             sweep = pre[1]                           # started by the caller, under its host work
         else:
-            with_q = S.T_init.dtype == dt and tuple(S.T_init.shape) == (N, 4, 4)
             sweep = SweepIndex(S.tgt, sorted_rows=True, tgt_rows=cfg.tgt_rows,
                                frame=search_frame(S.tgt, tgt_rows=cfg.tgt_rows, src=S.src if with_q else None, T_init=S.T_init if with_q else None, src_rows=cfg.src_rows))
     S.sweep = sweep
     # the searches run in the target cloud's search frame (dicp_search_frame): packed rows Q y + t, pose [Q C | Q r + t]
     S.soft = kind == _lib.KNN_GUMBEL        # soft correspondences: no search structure at all
-    S.center = sweep.frame if sweep is not None else (None if S.soft else search_frame(S.tgt, tgt_rows=cfg.tgt_rows))
+    S.center = sweep.frame if sweep is not None else (None if S.soft else search_frame(S.tgt, tgt_rows=cfg.tgt_rows, src=S.src if with_q else None,
+                                                                                   T_init=S.T_init if with_q else None, src_rows=cfg.src_rows))
     S.tgt4 = sweep.tgs4 if sweep is not None else (None if S.soft else pack_target(S.tgt, S.center, cfg.tgt_rows))
     S.m_pad = S.tgt4.shape[1] if S.tgt4 is not None else 0
     # the matrix-core searches' image of the packed rows (the sweep path: of the sorted rows, made with the index)

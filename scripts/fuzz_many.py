@@ -1,7 +1,7 @@
-"""The differential fuzz of tests/test_gpu_fuzz.py over ten times its seeds.  Round 6 (552 + 52 cases): 5 "plane" cases fail its bars (seeds 37, 61, 64, 112, 145) -- in
-each ONE query has two targets whose squared distances differ by 6e-8 .. 2e-6, inside the float32 rounding of a score in the brute-force path's uncentred
-coordinates (|y|^2 / 2 ~ 16); the sweep, which scores in the centred search frame, returns the float64-nearest of the two, the brute-force path the other one
-(6e-6 further away), and one flipped match of 300 moves the step by 7e-4.  Either is a nearest neighbour to rounding; the committed seeds hold no such pair."""
+"""The differential fuzz of tests/test_gpu_fuzz.py over ten times its seeds (552 + 52 cases).  Round 6: 5 "plane" cases used to fail its bars (seeds 37, 61, 64,
+112, 145) -- in each ONE query has two targets whose squared distances differ by 6e-8 .. 2e-6, inside the float32 rounding of a score, and the brute-force path,
+scoring in the target-only search frame, took the other one than the sweep in the frame chosen for the queries' slabs (either is a nearest neighbour to rounding;
+one flipped match of 300 moves the step by 7e-4).  Every variant of a call scores in the same frame now: 0 failures."""
 import sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "tests"))

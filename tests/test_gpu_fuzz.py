@@ -33,6 +33,9 @@ def cloud_pair(rng, N, n, m, dtype, kind):
 
 
 CASES = [(seed, kind) for seed in range(12) for kind in ("plain", "plane", "dups", "far")]
+# (round 6, scripts/fuzz_many.py: in each of these ONE query has two targets within float32 rounding of each other in squared distance; the two paths took
+#  different ones while they scored in different search frames)
+CASES += [(37, "plane"), (61, "plane"), (64, "plane"), (112, "plane"), (145, "plane")]
 
 
 @pytest.mark.parametrize("seed,kind", CASES)
